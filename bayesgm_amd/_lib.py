@@ -1,0 +1,93 @@
+"""ctypes binding of libbgm_hip.so (C ABI: include/bgm_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or a call
+fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbgm_hip.so")
+
+BGM_MAX_LAYERS = 8
+NET_G, NET_F, NET_H, NET_E = 0, 1, 2, 3
+EFFECT_NONE, EFFECT_ADRF, EFFECT_ITE = 0, 1, 2
+
+
+class CausalConfig(C.Structure):
+    _fields_ = [
+        ("v_dim", C.c_int32), ("z_dims", C.c_int32 * 4), ("binary_treatment", C.c_int32),
+        ("n_hidden_g", C.c_int32), ("g_units", C.c_int32 * BGM_MAX_LAYERS),
+        ("n_hidden_f", C.c_int32), ("f_units", C.c_int32 * BGM_MAX_LAYERS),
+        ("n_hidden_h", C.c_int32), ("h_units", C.c_int32 * BGM_MAX_LAYERS),
+        ("n_hidden_e", C.c_int32), ("e_units", C.c_int32 * BGM_MAX_LAYERS),
+        ("sigma_v", C.c_float), ("sigma_x", C.c_float), ("sigma_y", C.c_float),
+    ]
+
+
+class MhArgs(C.Structure):
+    _fields_ = [
+        ("x_dev", C.c_void_p), ("y_dev", C.c_void_p), ("v_dev", C.c_void_p),
+        ("n", C.c_int64), ("row_base", C.c_int64),
+        ("state_dev", C.c_void_p), ("logp_dev", C.c_void_p),
+        ("init", C.c_int32), ("it_begin", C.c_int32), ("n_iters", C.c_int32), ("burn_in", C.c_int32),
+        ("q_sd", C.c_float), ("seed", C.c_uint64),
+        ("acc_count_dev", C.c_void_p), ("draws_dev", C.c_void_p),
+        ("n_keep", C.c_int32), ("effect", C.c_int32), ("sample_y", C.c_int32),
+        ("x_values_dev", C.c_void_p), ("n_doses", C.c_int32),
+        ("adrf_partial_dev", C.c_void_p), ("ite_dev", C.c_void_p),
+    ]
+
+
+class MhInfo(C.Structure):
+    _fields_ = [("rows_per_wave", C.c_int32), ("waves_per_block", C.c_int32), ("grid_blocks", C.c_int32),
+                ("mfma_per_transition_per_wave", C.c_int32), ("lds_bytes", C.c_int32),
+                ("flop_per_row_transition", C.c_double)]
+
+
+# every symbol include/bgm_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "bgm_last_error": (C.c_char_p, []),
+    "bgm_version": (C.c_char_p, []),
+    "bgm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "bgm_destroy": (C.c_int, [C.c_void_p]),
+    "bgm_causal_configure": (C.c_int, [C.c_void_p, C.POINTER(CausalConfig)]),
+    "bgm_causal_set_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "bgm_causal_logpost": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int64, C.c_void_p, C.c_void_p]),
+    "bgm_causal_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "bgm_causal_mh_slots": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]),
+    "bgm_causal_mh_run": (C.c_int, [C.c_void_p, C.POINTER(MhArgs), C.c_void_p]),
+    "bgm_adrf_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double,
+                                  C.c_void_p, C.c_void_p]),
+    "bgm_row_mean_quantiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_double,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bgm_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "bgm_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int]),
+    "bgm_causal_mh_info": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(MhInfo)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libbgm_hip.so (raises RuntimeError when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "bayesgm_amd: %s not found -- build the HIP extension first "
+            "(python -m bayesgm_amd.csrc.build); there is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().bgm_last_error()
+        raise RuntimeError("bgm_hip %s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))

@@ -1,0 +1,63 @@
+"""Build libbgm_hip.so for gfx950 with hipcc (in-tree, next to the package).
+
+    python -m bayesgm_amd.csrc.build [--force] [-D NAME=VALUE ...]
+
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels to the
+GPU box with the source snapshot.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+OUT = os.path.join(PKG, "libbgm_hip.so")
+SOURCES = ["causal_api.hip", "aux_kernels.hip"]
+HEADERS = ["bgm_device.h", "causal_kernels.h", "bgm_host.h", os.path.join("..", "..", "include", "bgm_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+         "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def _newer(src, dst):
+    return (not os.path.exists(dst)) or os.path.getmtime(src) > os.path.getmtime(dst)
+
+
+def build(force=False, defines=(), verbose=True):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    objs = []
+    srcs = [os.path.join(HERE, s) for s in SOURCES]
+    deps = srcs + [os.path.join(HERE, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    if not force and os.path.exists(OUT) and all(not _newer(d, OUT) for d in deps):
+        return OUT
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+
+    def cc(src):
+        obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")
+        cmd = [hipcc] + FLAGS + ["-D" + d for d in defines] + ["-I", HERE, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(cc, srcs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    defs = []
+    argv = sys.argv[1:]
+    force = "--force" in argv
+    for i, a in enumerate(argv):
+        if a == "-D":
+            defs.append(argv[i + 1])
+        elif a.startswith("-D") and len(a) > 2:
+            defs.append(a[2:])
+    print(build(force=force, defines=defs))

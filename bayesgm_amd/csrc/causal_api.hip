@@ -1,0 +1,367 @@
+// causal_api.hip -- C-ABI entry points of the CausalBGM posterior-sampling path
+// (declared in include/bgm_hip.h) + host-side packing of the Keras-order weights
+// into the LDS fragment order of causal_kernels.h.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "bgm_host.h"
+
+static thread_local std::string g_err;
+void bgm_set_error(const std::string &msg) { g_err = msg; }
+
+extern "C" const char *bgm_last_error(void) { return g_err.c_str(); }
+extern "C" const char *bgm_version(void) { return "bayesgm_amd-hip 0.1 (gfx950)"; }
+
+extern "C" int bgm_create(bgm_handle **out, int device) {
+  if (!out) { bgm_set_error("bgm_create: out == NULL"); return BGM_E_INVALID; }
+  BGM_HIP_CHECK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  BGM_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+    bgm_set_error(std::string("bgm_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    return BGM_E_UNSUPPORTED;
+  }
+  bgm_handle *h = new bgm_handle();
+  h->device = device;
+  h->n_cus = prop.multiProcessorCount;
+  *out = h;
+  return BGM_OK;
+}
+
+extern "C" int bgm_destroy(bgm_handle *h) {
+  if (!h) return BGM_OK;
+  hipSetDevice(h->device);
+  if (h->blob_dev) hipFree(h->blob_dev);
+  if (h->eblob_dev) hipFree(h->eblob_dev);
+  for (auto &e : h->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+  delete h;
+  return BGM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// configuration
+// ---------------------------------------------------------------------------
+static bool units_are(const int32_t *u, int n, std::initializer_list<int> want) {
+  if (n != (int)want.size()) return false;
+  int i = 0;
+  for (int w : want) if (u[i++] != w) return false;
+  return true;
+}
+
+extern "C" int bgm_causal_configure(bgm_handle *h, const bgm_causal_config *cfg) {
+  if (!h || !cfg) { bgm_set_error("bgm_causal_configure: NULL argument"); return BGM_E_INVALID; }
+  const int q = cfg->z_dims[0] + cfg->z_dims[1] + cfg->z_dims[2] + cfg->z_dims[3];
+  const int p = cfg->v_dim;
+  if (p < 1 || q < 1 || cfg->z_dims[0] < 0 || cfg->z_dims[1] < 0 || cfg->z_dims[2] < 0 || cfg->z_dims[3] < 0) {
+    bgm_set_error("bgm_causal_configure: bad v_dim / z_dims"); return BGM_E_INVALID;
+  }
+  for (int n : {cfg->n_hidden_g, cfg->n_hidden_f, cfg->n_hidden_h, cfg->n_hidden_e})
+    if (n < 1 || n > BGM_MAX_LAYERS) { bgm_set_error("bgm_causal_configure: hidden layer count out of range"); return BGM_E_INVALID; }
+  // The fused kernels are specialised to the reference's default widths
+  // (g_units [64]*k, f_units = h_units = [64,32,8]; configs/*.yaml, cli/cli.py).
+  bool g_ok = true;
+  for (int i = 0; i < cfg->n_hidden_g; ++i) g_ok &= (cfg->g_units[i] == 64);
+  if (!g_ok || !units_are(cfg->f_units, cfg->n_hidden_f, {64, 32, 8}) ||
+      !units_are(cfg->h_units, cfg->n_hidden_h, {64, 32, 8})) {
+    bgm_set_error("bgm_causal_configure: only g_units=[64]*k, f_units=h_units=[64,32,8] are compiled");
+    return BGM_E_UNSUPPORTED;
+  }
+  if (q + 1 > 32) { bgm_set_error("bgm_causal_configure: sum(z_dims) > 31 not compiled"); return BGM_E_UNSUPPORTED; }
+  h->cfg = *cfg;
+  h->q = q;
+  h->p = p;
+  auto mk = [](HostNet &n, int in, const int32_t *units, int nh, int out) {
+    n.dims.clear();
+    n.dims.push_back(in);
+    for (int i = 0; i < nh; ++i) n.dims.push_back(units[i]);
+    n.dims.push_back(out);
+    n.theta.assign(n.count(), 0.0f);
+    n.set = false;
+  };
+  mk(h->nets[BGM_NET_G], q, cfg->g_units, cfg->n_hidden_g, p + 1);
+  mk(h->nets[BGM_NET_F], cfg->z_dims[0] + cfg->z_dims[1] + 1, cfg->f_units, cfg->n_hidden_f, 2);
+  mk(h->nets[BGM_NET_H], cfg->z_dims[0] + cfg->z_dims[2], cfg->h_units, cfg->n_hidden_h, 2);
+  mk(h->nets[BGM_NET_E], p, cfg->e_units, cfg->n_hidden_e, q);
+  h->configured = true;
+  h->blob_valid = false;
+  h->eblob_valid = false;
+  return BGM_OK;
+}
+
+extern "C" int bgm_causal_set_weights(bgm_handle *h, int net_id, const float *theta_host, int64_t count,
+                                      void *stream) {
+  (void)stream;
+  if (!h || !h->configured) { bgm_set_error("bgm_causal_set_weights: handle not configured"); return BGM_E_STATE; }
+  if (net_id < 0 || net_id > 3 || !theta_host) { bgm_set_error("bgm_causal_set_weights: bad net_id / NULL"); return BGM_E_INVALID; }
+  HostNet &n = h->nets[net_id];
+  if ((size_t)count != n.count()) {
+    bgm_set_error("bgm_causal_set_weights: expected " + std::to_string(n.count()) + " floats, got " + std::to_string(count));
+    return BGM_E_INVALID;
+  }
+  std::memcpy(n.theta.data(), theta_host, sizeof(float) * count);
+  n.set = true;
+  if (net_id == BGM_NET_E) h->eblob_valid = false; else h->blob_valid = false;
+  return BGM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// packing (layout documented in bgm_device.h)
+// ---------------------------------------------------------------------------
+int bgm_causal_build_blob(bgm_handle *h, hipStream_t stream) {
+  if (h->blob_valid) return BGM_OK;
+  for (int id : {BGM_NET_G, BGM_NET_F, BGM_NET_H})
+    if (!h->nets[id].set) { bgm_set_error("weights of g/f/h not all set"); return BGM_E_STATE; }
+  const int q = h->q, p = h->p;
+  const int z0 = h->cfg.z_dims[0], z1 = h->cfg.z_dims[1], z2 = h->cfg.z_dims[2];
+  const int q1 = q + 1;
+  const int KT1 = (q1 + 15) / 16;
+  const int KSL1 = (q1 - 16 * (KT1 - 1) + 3) / 4;
+  const int NTL = (p + 1 + 15) / 16;
+  h->KT1 = KT1; h->KSL1 = KSL1; h->NTL = NTL;
+  CausalMeta &m = h->meta;
+  std::memset(&m, 0, sizeof(m));
+  m.q = q; m.p = p; m.binary = h->cfg.binary_treatment ? 1 : 0;
+  auto s2 = [](float s) { return s > 0.0f ? s * s : -1.0f; };
+  m.sig2_v = s2(h->cfg.sigma_v); m.sig2_x = s2(h->cfg.sigma_x); m.sig2_y = s2(h->cfg.sigma_y);
+  m.n_gh = h->cfg.n_hidden_g - 1;
+  int off = 0;
+  auto take = [&](int n) { int o = off; off += (n + 3) / 4 * 4; return o; };
+  m.w1g = take(16 * KT1 * 64); m.w1f = take(16 * KT1 * 64); m.w1h = take(16 * KT1 * 64);
+  m.b1g = take(64); m.b1f = take(64); m.b1h = take(64);
+  m.wg = take(m.n_gh * 4096); m.bg = take(m.n_gh * 64);
+  // NTL_alloc: the kernel variant may be compiled for more tiles than needed
+  m.wgl = take(64 * 16 * NTL); m.bgl = take(16 * NTL);
+  m.wf2 = take(64 * 32); m.bf2 = take(32); m.wf3 = take(32 * 16); m.bf3 = take(16); m.wf4 = take(16 * 16); m.bf4 = take(16);
+  m.wh2 = take(64 * 32); m.bh2 = take(32); m.wh3 = take(32 * 16); m.bh3 = take(16); m.wh4 = take(16 * 16); m.bh4 = take(16);
+  m.wxf = take(64);
+  m.total = off;
+  if ((size_t)m.total * 4 > 160 * 1024) {
+    bgm_set_error("model does not fit the 160 KiB LDS-resident layout (" + std::to_string(m.total * 4) + " B); p <= 207 with default widths");
+    return BGM_E_UNSUPPORTED;
+  }
+  std::vector<float> blob(m.total, 0.0f);
+  const HostNet &G = h->nets[BGM_NET_G], &F = h->nets[BGM_NET_F], &H = h->nets[BGM_NET_H];
+  auto ident = [](int rho) { return rho; };
+  // first layers: shared extended input [z (q), x]
+  pack_layer(blob, m.w1g, G.W(0), q, 64, KT1, 4, [&](int rho) { int f = l1_feature(rho); return f < q ? f : -1; });
+  pack_layer(blob, m.w1f, F.W(0), z0 + z1 + 1, 64, KT1, 4, [&](int rho) {
+    int f = l1_feature(rho);
+    if (f < z0 + z1) return f;
+    if (f == q) return z0 + z1;  // treatment column
+    return -1;
+  });
+  pack_layer(blob, m.w1h, H.W(0), z0 + z2, 64, KT1, 4, [&](int rho) {
+    int f = l1_feature(rho);
+    if (f < z0) return f;
+    if (f >= z0 + z1 && f < z0 + z1 + z2) return z0 + (f - z0 - z1);
+    return -1;
+  });
+  pack_bias(blob, m.b1g, G.b(0), 64, 4); pack_bias(blob, m.b1f, F.b(0), 64, 4); pack_bias(blob, m.b1h, H.b(0), 64, 4);
+  for (int l = 0; l < m.n_gh; ++l) {
+    pack_layer(blob, m.wg + l * 4096, G.W(1 + l), 64, 64, 4, 4, ident);
+    pack_bias(blob, m.bg + l * 64, G.b(1 + l), 64, 4);
+  }
+  const int LG = (int)G.dims.size() - 2;  // index of last layer
+  pack_layer(blob, m.wgl, G.W(LG), 64, p + 1, 4, NTL, ident);
+  pack_bias(blob, m.bgl, G.b(LG), p + 1, NTL);
+  pack_layer(blob, m.wf2, F.W(1), 64, 32, 4, 2, ident); pack_bias(blob, m.bf2, F.b(1), 32, 2);
+  pack_layer(blob, m.wf3, F.W(2), 32, 8, 2, 1, ident); pack_bias(blob, m.bf3, F.b(2), 8, 1);
+  pack_layer(blob, m.wf4, F.W(3), 8, 2, 1, 1, ident); pack_bias(blob, m.bf4, F.b(3), 2, 1);
+  pack_layer(blob, m.wh2, H.W(1), 64, 32, 4, 2, ident); pack_bias(blob, m.bh2, H.b(1), 32, 2);
+  pack_layer(blob, m.wh3, H.W(2), 32, 8, 2, 1, ident); pack_bias(blob, m.bh3, H.b(2), 8, 1);
+  pack_layer(blob, m.wh4, H.W(3), 8, 2, 1, 1, ident); pack_bias(blob, m.bh4, H.b(3), 2, 1);
+  for (int o = 0; o < 64; ++o) blob[m.wxf + o] = F.W(0)[(size_t)(z0 + z1) * 64 + o];
+
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  if (h->blob_cap < blob.size()) {
+    if (h->blob_dev) BGM_HIP_CHECK(hipFree(h->blob_dev));
+    BGM_HIP_CHECK(hipMalloc(&h->blob_dev, blob.size() * sizeof(float)));
+    h->blob_cap = blob.size();
+  }
+  BGM_HIP_CHECK(hipMemcpyAsync(h->blob_dev, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+  BGM_HIP_CHECK(hipStreamSynchronize(stream));  // blob is a stack-local staging buffer
+  h->blob_valid = true;
+  return BGM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// kernel variants.  (KT1, KSL1, NTL): first-layer K tiling and number of
+// 16-wide output tiles of g's last layer.
+//   (1,3,13): z_dims [1,1,1,7], p = 200   (configs/Sim_Hirano_Imbens.yaml)
+//   (2,1, 7): z_dims [3,3,6,6], p = 100   (cli/cli.py defaults)
+//   (1,3, 2): z_dims [1,1,1,7], p <= 31   (small panels / tests)
+//   (2,1, 2): z_dims [3,3,6,6], p <= 31
+// ---------------------------------------------------------------------------
+#ifndef BGM_MH_R
+#define BGM_MH_R 1
+#endif
+#ifndef BGM_MH_WAVES
+#define BGM_MH_WAVES 8
+#endif
+static constexpr int MH_R = BGM_MH_R, MH_WAVES = BGM_MH_WAVES;
+
+#define BGM_CAUSAL_VARIANTS(X) X(1, 3, 13) X(2, 1, 7) X(1, 3, 2) X(2, 1, 2)
+
+template <class K>
+static int set_lds(K kernel, int bytes) {
+  BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  return BGM_OK;
+}
+
+static int mh_grid(const bgm_handle *h, int64_t n) {
+  const int64_t tiles = (n + 16 * MH_R - 1) / (16 * MH_R);
+  const int64_t blocks = (tiles + MH_WAVES - 1) / MH_WAVES;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(blocks, h->n_cus));
+}
+
+extern "C" int bgm_causal_mh_slots(bgm_handle *h, int64_t n, int32_t *n_slots) {
+  if (!h || !n_slots) { bgm_set_error("bgm_causal_mh_slots: NULL"); return BGM_E_INVALID; }
+  *n_slots = mh_grid(h, n) * MH_WAVES;
+  return BGM_OK;
+}
+
+extern "C" int bgm_causal_logpost(bgm_handle *h, const float *x, const float *y, const float *v, const float *z,
+                                  int64_t n, float *out, void *stream_) {
+  if (!h || !h->configured) { bgm_set_error("bgm_causal_logpost: handle not configured"); return BGM_E_STATE; }
+  if (n <= 0) return BGM_OK;
+  if (!x || !y || !v || !z || !out) { bgm_set_error("bgm_causal_logpost: NULL pointer"); return BGM_E_INVALID; }
+  hipStream_t stream = (hipStream_t)stream_;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  int rc = bgm_causal_build_blob(h, stream);
+  if (rc) return rc;
+  const int grid = mh_grid(h, n);
+  const int lds = h->meta.total * 4;
+#define X(KT1_, KSL1_, NTL_)                                                                   \
+  if (h->KT1 == KT1_ && h->KSL1 == KSL1_ && h->NTL == NTL_) {                                  \
+    auto k = causal_logpost_kernel<KT1_, KSL1_, NTL_, MH_R, MH_WAVES>;                         \
+    rc = set_lds(k, lds);                                                                      \
+    if (rc) return rc;                                                                         \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * MH_WAVES), lds, stream, h->blob_dev, h->meta,  \
+                       x, y, v, z, (long long)n, out);                                         \
+    BGM_HIP_CHECK(hipGetLastError());                                                          \
+    return BGM_OK;                                                                             \
+  }
+  BGM_CAUSAL_VARIANTS(X)
+#undef X
+  bgm_set_error("no compiled kernel variant for (KT1,KSL1,NTL)=(" + std::to_string(h->KT1) + "," +
+                std::to_string(h->KSL1) + "," + std::to_string(h->NTL) + ")");
+  return BGM_E_UNSUPPORTED;
+}
+
+template <int EFFECT>
+static int launch_mh(bgm_handle *h, const CausalMhKArgs &ka, int grid, int lds, hipStream_t stream) {
+  int rc;
+#define X(KT1_, KSL1_, NTL_)                                                                   \
+  if (h->KT1 == KT1_ && h->KSL1 == KSL1_ && h->NTL == NTL_) {                                  \
+    auto k = causal_mh_kernel<KT1_, KSL1_, NTL_, MH_R, MH_WAVES, EFFECT>;                      \
+    rc = set_lds(k, lds);                                                                      \
+    if (rc) return rc;                                                                         \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * MH_WAVES), lds, stream, ka);                   \
+    BGM_HIP_CHECK(hipGetLastError());                                                          \
+    return BGM_OK;                                                                             \
+  }
+  BGM_CAUSAL_VARIANTS(X)
+#undef X
+  bgm_set_error("no compiled MH kernel variant for (KT1,KSL1,NTL)=(" + std::to_string(h->KT1) + "," +
+                std::to_string(h->KSL1) + "," + std::to_string(h->NTL) + ")");
+  return BGM_E_UNSUPPORTED;
+}
+
+extern "C" int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *a, void *stream_) {
+  if (!h || !h->configured) { bgm_set_error("bgm_causal_mh_run: handle not configured"); return BGM_E_STATE; }
+  if (!a) { bgm_set_error("bgm_causal_mh_run: NULL args"); return BGM_E_INVALID; }
+  if (a->n <= 0 || a->n_iters <= 0) return BGM_OK;
+  if (!a->x_dev || !a->y_dev || !a->v_dev || !a->state_dev || !a->logp_dev) { bgm_set_error("bgm_causal_mh_run: NULL data pointer"); return BGM_E_INVALID; }
+  if (a->row_base + a->n > 0xFFFFFFFFll) { bgm_set_error("bgm_causal_mh_run: row index exceeds the 32-bit RNG counter"); return BGM_E_INVALID; }
+  if (a->effect == BGM_EFFECT_ADRF && (!a->x_values_dev || a->n_doses <= 0 || !a->adrf_partial_dev)) { bgm_set_error("bgm_causal_mh_run: ADRF effect needs x_values / adrf_partial"); return BGM_E_INVALID; }
+  if (a->effect == BGM_EFFECT_ITE && !a->ite_dev) { bgm_set_error("bgm_causal_mh_run: ITE effect needs ite_dev"); return BGM_E_INVALID; }
+  if (a->effect == BGM_EFFECT_ADRF && h->cfg.binary_treatment) { bgm_set_error("bgm_causal_mh_run: ADRF effect on a binary-treatment model"); return BGM_E_INVALID; }
+  const int it_end = a->it_begin + a->n_iters;
+  if ((a->effect != BGM_EFFECT_NONE || a->draws_dev) && it_end - a->burn_in > a->n_keep) { bgm_set_error("bgm_causal_mh_run: iterations beyond burn_in + n_keep"); return BGM_E_INVALID; }
+  hipStream_t stream = (hipStream_t)stream_;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  int rc = bgm_causal_build_blob(h, stream);
+  if (rc) return rc;
+  const int grid = mh_grid(h, a->n);
+  const int lds = h->meta.total * 4;
+
+  CausalMhKArgs ka{};
+  ka.blob = h->blob_dev; ka.x = a->x_dev; ka.y = a->y_dev; ka.v = a->v_dev;
+  ka.n = a->n; ka.row_base = a->row_base; ka.state = a->state_dev; ka.logp = a->logp_dev;
+  ka.burn_in = a->burn_in; ka.q_sd = a->q_sd;
+  ka.k0 = (unsigned)(a->seed & 0xFFFFFFFFull); ka.k1 = (unsigned)(a->seed >> 32);
+  ka.acc_count = a->acc_count_dev; ka.draws = a->draws_dev; ka.n_keep = a->n_keep;
+  ka.sample_y = a->sample_y; ka.n_doses = a->n_doses; ka.x_values = a->x_values_dev;
+  ka.adrf_partial = a->adrf_partial_dev; ka.ite = a->ite_dev; ka.m = h->meta;
+
+  // Split the segment at burn_in: the burn-in part runs the pure-transition kernel.
+  struct Seg { int begin, n, effect, init; };
+  Seg segs[2];
+  int nseg = 0;
+  const int split = std::min(std::max(a->burn_in, a->it_begin), it_end);
+  if (split > a->it_begin) segs[nseg++] = {a->it_begin, split - a->it_begin, BGM_EFFECT_NONE, a->init};
+  if (it_end > split) segs[nseg++] = {split, it_end - split, a->effect, (nseg == 0) ? a->init : 0};
+  for (int s = 0; s < nseg; ++s) {
+    ka.it_begin = segs[s].begin; ka.n_iters = segs[s].n; ka.init = segs[s].init;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->timing) {
+      BGM_HIP_CHECK(hipEventCreate(&e0)); BGM_HIP_CHECK(hipEventCreate(&e1));
+      BGM_HIP_CHECK(hipEventRecord(e0, stream));
+    }
+    if (segs[s].effect == BGM_EFFECT_ADRF) rc = launch_mh<1>(h, ka, grid, lds, stream);
+    else if (segs[s].effect == BGM_EFFECT_ITE) rc = launch_mh<2>(h, ka, grid, lds, stream);
+    else rc = launch_mh<0>(h, ka, grid, lds, stream);
+    if (rc) return rc;
+    if (h->timing) {
+      BGM_HIP_CHECK(hipEventRecord(e1, stream));
+      h->events.emplace_back(e0, e1);
+    }
+  }
+  return BGM_OK;
+}
+
+extern "C" int bgm_timing_enable(bgm_handle *h, int enable) {
+  if (!h) return BGM_E_INVALID;
+  h->timing = enable != 0;
+  return BGM_OK;
+}
+
+extern "C" int bgm_timing_read(bgm_handle *h, int64_t *n_launches, double *total_ms, int reset) {
+  if (!h) return BGM_E_INVALID;
+  for (auto &e : h->events) {
+    BGM_HIP_CHECK(hipEventSynchronize(e.second));
+    float ms = 0.0f;
+    BGM_HIP_CHECK(hipEventElapsedTime(&ms, e.first, e.second));
+    h->timed_ms += ms;
+    h->timed_launches += 1;
+    hipEventDestroy(e.first); hipEventDestroy(e.second);
+  }
+  h->events.clear();
+  if (n_launches) *n_launches = h->timed_launches;
+  if (total_ms) *total_ms = h->timed_ms;
+  if (reset) { h->timed_launches = 0; h->timed_ms = 0.0; }
+  return BGM_OK;
+}
+
+extern "C" int bgm_causal_mh_info(bgm_handle *h, int64_t n, bgm_mh_info *info) {
+  if (!h || !h->configured || !info) { bgm_set_error("bgm_causal_mh_info: bad argument"); return BGM_E_INVALID; }
+  const int q1 = h->q + 1;
+  const int KT1 = (q1 + 15) / 16, KSL1 = (q1 - 16 * (KT1 - 1) + 3) / 4, NTL = (h->p + 1 + 15) / 16;
+  const int ks1 = 4 * (KT1 - 1) + KSL1;
+  const int n_gh = h->cfg.n_hidden_g - 1;
+  info->rows_per_wave = 16 * MH_R;
+  info->waves_per_block = MH_WAVES;
+  info->grid_blocks = mh_grid(h, n);
+  // issued MFMAs per 16 rows, times R row groups
+  const int per16 = 3 * ks1 * 4 + n_gh * 64 + 16 * NTL + 2 * (32 + 8 + 4);
+  info->mfma_per_transition_per_wave = per16 * MH_R;
+  info->lds_bytes = h->blob_valid ? h->meta.total * 4 : 0;
+  double macs = 0.0;
+  for (int id : {BGM_NET_G, BGM_NET_F, BGM_NET_H}) {
+    const HostNet &nn = h->nets[id];
+    for (size_t l = 0; l + 1 < nn.dims.size(); ++l) macs += (double)nn.dims[l] * nn.dims[l + 1];
+  }
+  info->flop_per_row_transition = 2.0 * macs;
+  return BGM_OK;
+}

@@ -1,0 +1,484 @@
+// causal_kernels.h -- CausalBGM log-posterior / Metropolis-Hastings kernels (gfx950).
+//
+// replaces (reference file:line, all in src/bayesgm/models/causalbgm/base.py):
+//   get_log_posterior            :765-817   -> causal_logp<> (device), causal_logpost_kernel
+//   metropolis_hastings_sampler  :820-904   -> causal_mh_kernel (persistent over iterations)
+//   infer_from_latent_posterior  :671-763   -> fused into causal_mh_kernel (EFFECT != 0)
+//
+// One wave owns R groups of 16 chains for the whole segment of iterations: its V
+// rows (R x NTL x 4 VGPRs), x, y, the chain state and the cached log-posterior
+// stay in registers; the g/f/h weights (about 150 KB fp32 at p = 200) stay in
+// LDS, shared by the block's waves.  Per transition only the Philox counters
+// change; HBM is touched again only to emit retained draws / effects.
+#pragma once
+#include "bgm_device.h"
+
+struct CausalMeta {
+  int q, p, zq_f;       // zq_f unused placeholder (keeps struct 16B friendly)
+  int binary;
+  float sig2_v, sig2_x, sig2_y;  // fixed variances (sigma^2) if > 0
+  int n_gh;             // number of hidden->hidden 64x64 layers of g
+  // LDS blob offsets (floats)
+  int w1g, w1f, w1h, b1g, b1f, b1h;
+  int wg, bg;           // n_gh consecutive [64][64] / [64]
+  int wgl, bgl;         // last g layer [64][16*NTL] / [16*NTL]
+  int wf2, bf2, wf3, bf3, wf4, bf4;
+  int wh2, bh2, wh3, bh3, wh4, bh4;
+  int wxf;              // f L1 x-row, accumulator layout [64]
+  int total;            // blob floats
+};
+
+struct CausalMhKArgs {
+  const float *blob;    // packed weights (global)
+  const float *x, *y, *v;
+  long long n, row_base;
+  float *state, *logp;
+  int init, it_begin, n_iters, burn_in;
+  float q_sd;
+  unsigned k0, k1;
+  unsigned *acc_count;
+  float *draws;
+  int n_keep, sample_y, n_doses;
+  const float *x_values;
+  float *adrf_partial;
+  float *ite;
+  CausalMeta m;
+};
+
+// ---------------------------------------------------------------------------
+// log p(z | x, y, v) for R x 16 chains held by one wave.
+//   zin  : L1 input tiles, feature 16 t + 4 r + g  (z features, then x at index q, then 0)
+//   vreg : V rows, feature 16 t + 4 g + r, zero padded
+// Returns logp[rr] replicated over the four lane groups.
+// ---------------------------------------------------------------------------
+template <int T0, int KT, int NTL, int R>
+__device__ __forceinline__ void g_last_groups(const float *wl, const float *bl, int lane_off, int g,
+                                              int sig_r, const f32x4 (&in)[R][KT],
+                                              const f32x4 (&vreg)[R][NTL], float (&ssq)[R],
+                                              float (&sraw)[R]) {
+  if constexpr (T0 < NTL) {
+    constexpr int GS = group_size(NTL - T0);
+    f32x4 acc[R][NTL];  // only [T0, T0+GS) is touched; the rest is dead and never allocated
+#pragma unroll
+    for (int u = 0; u < GS; ++u) {
+      const f32x4 b = *reinterpret_cast<const f32x4 *>(bl + 16 * (T0 + u) + 4 * g);
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr) acc[rr][T0 + u] = b;
+    }
+    constexpr int K_ROWS = 16 * KT;
+    const float *base = wl + K_ROWS * 16 * T0 + lane_off * GS;
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        AFrag<GS> a;
+        a.load(base + (16 * t + r) * 16 * GS);
+#pragma unroll
+        for (int u = 0; u < GS; ++u)
+#pragma unroll
+          for (int rr = 0; rr < R; ++rr)
+            acc[rr][T0 + u] = BGM_MFMA(a.get(u), in[rr][t][r], acc[rr][T0 + u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < GS; ++u) {
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float d = vreg[rr][T0 + u][r] - acc[rr][T0 + u][r];
+          if (T0 + u == NTL - 1) {  // tile holding the variance column (feature p)
+            const bool is_sig = (r == sig_r);
+            sraw[rr] = is_sig ? acc[rr][T0 + u][r] : sraw[rr];
+            d = is_sig ? 0.0f : d;
+          }
+          ssq[rr] = fmaf(d, d, ssq[rr]);
+        }
+      }
+    }
+    g_last_groups<T0 + GS, KT, NTL, R>(wl, bl, lane_off, g, sig_r, in, vreg, ssq, sraw);
+  }
+}
+
+// f / h tail:  64 -> 32 -> 8 -> 2   (f_units = h_units = [64, 32, 8]); a1 is the
+// activated first hidden layer.  Returns raw outputs (mu, s) replicated over g.
+template <int R>
+__device__ __forceinline__ void fh_tail(const float *lds, int w2, int b2, int w3, int b3, int w4,
+                                        int b4, int lane_off, int g, int j,
+                                        const f32x4 (&a1)[R][4], float (&mu)[R], float (&sr)[R]) {
+  f32x4 a2[R][2];
+  dense<4, 4, 2, R>(lds + w2, lds + b2, lane_off, g, a1, a2);
+  lrelu_inplace<2, R>(a2);
+  f32x4 a3[R][1];
+  dense<2, 4, 1, R>(lds + w3, lds + b3, lane_off, g, a2, a3);
+  lrelu_inplace<1, R>(a3);
+  f32x4 a4[R][1];
+  dense<1, 4, 1, R>(lds + w4, lds + b4, lane_off, g, a3, a4);
+#pragma unroll
+  for (int rr = 0; rr < R; ++rr) {
+    mu[rr] = __shfl(a4[rr][0][0], j);  // output features 0,1 live in lane group g = 0
+    sr[rr] = __shfl(a4[rr][0][1], j);
+  }
+}
+
+template <int KT1, int KSL1, int NTL, int R>
+__device__ __forceinline__ void causal_logp(const float *lds, const CausalMeta &m, int lane_off, int g,
+                                            int j, const f32x4 (&zin)[R][KT1],
+                                            const f32x4 (&vreg)[R][NTL], const float (&xr)[R],
+                                            const float (&yr)[R], float (&logp)[R]) {
+  // ---- g : z -> (mu_v, s_v), Gaussian NLL over p covariates (base.py:779-801)
+  float ssq[R], sraw_v[R];
+  {
+    f32x4 h[R][4];
+    dense<KT1, KSL1, 4, R>(lds + m.w1g, lds + m.b1g, lane_off, g, zin, h);
+    lrelu_inplace<4, R>(h);
+    for (int l = 0; l < m.n_gh; ++l) {
+      BGM_NO_HOIST();
+      f32x4 h2[R][4];
+      dense<4, 4, 4, R>(lds + m.wg + l * 4096, lds + m.bg + l * 64, lane_off, g, h, h2);
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[rr][t][r] = lrelu(h2[rr][t][r]);
+    }
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) { ssq[rr] = 0.0f; sraw_v[rr] = 0.0f; }
+    const int pc = m.p - 16 * (NTL - 1);  // position of feature p inside the last tile
+    g_last_groups<0, 4, NTL, R>(lds + m.wgl, lds + m.bgl, lane_off, g, pc - 4 * g, h, vreg, ssq, sraw_v);
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) sraw_v[rr] = __shfl(sraw_v[rr], j + 16 * (pc >> 2));
+  }
+  // ---- f : (z0, z1, x) -> (mu_y, s_y)   (base.py:793-798)
+  float mu_y[R], sr_y[R];
+  {
+    f32x4 a1[R][4];
+    dense<KT1, KSL1, 4, R>(lds + m.w1f, lds + m.b1f, lane_off, g, zin, a1);
+    lrelu_inplace<4, R>(a1);
+    fh_tail<R>(lds, m.wf2, m.bf2, m.wf3, m.bf3, m.wf4, m.bf4, lane_off, g, j, a1, mu_y, sr_y);
+  }
+  // ---- h : (z0, z2) -> (mu_x | logit, s_x)   (base.py:786-791)
+  float mu_x[R], sr_x[R];
+  {
+    f32x4 a1[R][4];
+    dense<KT1, KSL1, 4, R>(lds + m.w1h, lds + m.b1h, lane_off, g, zin, a1);
+    lrelu_inplace<4, R>(a1);
+    fh_tail<R>(lds, m.wh2, m.bh2, m.wh3, m.bh3, m.wh4, m.bh4, lane_off, g, j, a1, mu_x, sr_x);
+  }
+  // ---- assemble -(loss_v + loss_x + loss_y + |z|^2/2)   (base.py:800-816)
+#pragma unroll
+  for (int rr = 0; rr < R; ++rr) {
+    float zsq = 0.0f;
+#pragma unroll
+    for (int t = 0; t < KT1; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float zz = zin[rr][t][r];
+        zsq = (16 * t + 4 * r + g < m.q) ? fmaf(zz, zz, zsq) : zsq;
+      }
+    const float s2v = (m.sig2_v > 0.0f) ? m.sig2_v : softplus_f(sraw_v[rr]) + BGM_EPS;
+    // per-lane partial of  ssq/(2 s2v) + |z|^2/2 ; reduce over g
+    const float part = sum_over_g(ssq[rr] / (2.0f * s2v) + 0.5f * zsq);
+    const float loss_v = part + 0.5f * (float)m.p * logf(s2v);
+    float loss_x;
+    if (m.binary) {
+      const float l = mu_x[rr];
+      loss_x = fmaxf(l, 0.0f) - l * xr[rr] + log1pf(__expf(-fabsf(l)));
+    } else {
+      const float s2x = (m.sig2_x > 0.0f) ? m.sig2_x : softplus_f(sr_x[rr]) + BGM_EPS;
+      const float dx = xr[rr] - mu_x[rr];
+      loss_x = dx * dx / (2.0f * s2x) + 0.5f * logf(s2x);
+    }
+    const float s2y = (m.sig2_y > 0.0f) ? m.sig2_y : softplus_f(sr_y[rr]) + BGM_EPS;
+    const float dy = yr[rr] - mu_y[rr];
+    const float loss_y = dy * dy / (2.0f * s2y) + 0.5f * logf(s2y);
+    logp[rr] = -(loss_v + loss_x + loss_y);
+  }
+}
+
+// ---- helpers to move rows between HBM and the register layouts ---------------
+template <int NTL, int R>
+__device__ __forceinline__ void load_v_rows(const float *v, long long n, int p, long long row0, int j,
+                                            int g, f32x4 (&vreg)[R][NTL]) {
+#pragma unroll
+  for (int rr = 0; rr < R; ++rr) {
+    long long row = row0 + 16 * rr + j;
+    row = row < n ? row : n - 1;
+    const float *vr = v + row * (long long)p;
+#pragma unroll
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 16 * t + 4 * g + r;
+        vreg[rr][t][r] = (c < p) ? vr[c] : 0.0f;
+      }
+  }
+}
+
+// z row (q floats) + x -> L1 input tiles (feature 16 t + 4 r + g)
+template <int KT1, int R>
+__device__ __forceinline__ void load_z_rows(const float *z, long long n, int q, long long row0, int j,
+                                            int g, const float (&xr)[R], f32x4 (&zin)[R][KT1]) {
+#pragma unroll
+  for (int rr = 0; rr < R; ++rr) {
+    long long row = row0 + 16 * rr + j;
+    row = row < n ? row : n - 1;
+    const float *zr = z + row * (long long)q;
+#pragma unroll
+    for (int t = 0; t < KT1; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = 16 * t + 4 * r + g;
+        zin[rr][t][r] = (f < q) ? zr[f] : (f == q ? xr[rr] : 0.0f);
+      }
+  }
+}
+
+template <int KT1, int R>
+__device__ __forceinline__ void store_z_rows(float *z, long long n, int q, long long row0, int j, int g,
+                                             const f32x4 (&zin)[R][KT1]) {
+#pragma unroll
+  for (int rr = 0; rr < R; ++rr) {
+    const long long row = row0 + 16 * rr + j;
+    if (row < n) {
+      float *zr = z + row * (long long)q;
+#pragma unroll
+      for (int t = 0; t < KT1; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 16 * t + 4 * r + g;
+          if (f < q) zr[f] = zin[rr][t][r];
+        }
+    }
+  }
+}
+
+__device__ __forceinline__ void lds_fill(float *lds, const float *blob, int total_floats) {
+  const f32x4 *src = reinterpret_cast<const f32x4 *>(blob);
+  f32x4 *dst = reinterpret_cast<f32x4 *>(lds);
+  for (int i = threadIdx.x; i < total_floats / 4; i += blockDim.x) dst[i] = src[i];
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// get_log_posterior for n rows (one evaluation)
+// ---------------------------------------------------------------------------
+template <int KT1, int KSL1, int NTL, int R, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void causal_logpost_kernel(const float *blob, CausalMeta m,
+                                                                    const float *x, const float *y,
+                                                                    const float *v, const float *z,
+                                                                    long long n, float *out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  lds_fill(lds, blob, m.total);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4, lane_off = 64 * g + j;
+  const long long n_tiles = (n + 16 * R - 1) / (16 * R);
+  for (long long tile = (long long)blockIdx.x * WAVES + wave; tile < n_tiles;
+       tile += (long long)gridDim.x * WAVES) {
+    BGM_NO_HOIST();
+    const long long row0 = tile * 16 * R;
+    float xr[R], yr[R], lp[R];
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+      long long row = row0 + 16 * rr + j;
+      row = row < n ? row : n - 1;
+      xr[rr] = x[row];
+      yr[rr] = y[row];
+    }
+    f32x4 vreg[R][NTL];
+    load_v_rows<NTL, R>(v, n, m.p, row0, j, g, vreg);
+    f32x4 zin[R][KT1];
+    load_z_rows<KT1, R>(z, n, m.q, row0, j, g, xr, zin);
+    causal_logp<KT1, KSL1, NTL, R>(lds, m, lane_off, g, j, zin, vreg, xr, yr, lp);
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+      const long long row = row0 + 16 * rr + j;
+      if (g == 0 && row < n) out[row] = lp[rr];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Persistent random-walk Metropolis-Hastings over a segment of iterations.
+// ---------------------------------------------------------------------------
+template <int KT1, int KSL1, int NTL, int R, int WAVES, int EFFECT>
+__global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const CausalMeta &m = a.m;
+  lds_fill(lds, a.blob, m.total);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4, lane_off = 64 * g + j;
+  const long long n = a.n;
+  const long long n_tiles = (n + 16 * R - 1) / (16 * R);
+  const long long slot = (long long)blockIdx.x * WAVES + wave;
+  const long long n_slots = (long long)gridDim.x * WAVES;
+
+  for (long long tile = slot; tile < n_tiles; tile += n_slots) {
+    const long long row0 = tile * 16 * R;
+    float xr[R], yr[R], lp[R];
+    unsigned rowid[R];
+    bool valid[R];
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+      long long row = row0 + 16 * rr + j;
+      valid[rr] = row < n;
+      row = row < n ? row : n - 1;
+      xr[rr] = a.x[row];
+      yr[rr] = a.y[row];
+      rowid[rr] = (unsigned)(a.row_base + row);
+    }
+    f32x4 vreg[R][NTL];
+    load_v_rows<NTL, R>(a.v, n, m.p, row0, j, g, vreg);
+    f32x4 zs[R][KT1];
+    if (a.init) {
+      // current_state ~ N(0,1)  (base.py:842), RNG spec tag 0
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+        for (int t = 0; t < KT1; ++t) {
+          const f32x4 e = box_muller4(philox4x32_10(rowid[rr], 0u, (unsigned)(g + 4 * t), TAG_INIT, a.k0, a.k1));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int f = 16 * t + 4 * r + g;
+            zs[rr][t][r] = (f < m.q) ? e[r] : (f == m.q ? xr[rr] : 0.0f);
+          }
+        }
+      causal_logp<KT1, KSL1, NTL, R>(lds, m, lane_off, g, j, zs, vreg, xr, yr, lp);
+    } else {
+      load_z_rows<KT1, R>(a.state, n, m.q, row0, j, g, xr, zs);
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr) {
+        long long row = row0 + 16 * rr + j;
+        row = row < n ? row : n - 1;
+        lp[rr] = a.logp[row];
+      }
+    }
+
+    for (int it = a.it_begin; it < a.it_begin + a.n_iters; ++it) {
+      BGM_NO_HOIST();
+      // ---- proposal  z' = z + q_sd * eps   (base.py:862)
+      f32x4 zp[R][KT1];
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+        for (int t = 0; t < KT1; ++t) {
+          const f32x4 e = box_muller4(philox4x32_10(rowid[rr], (unsigned)it, (unsigned)(g + 4 * t), TAG_PROP, a.k0, a.k1));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int f = 16 * t + 4 * r + g;
+            zp[rr][t][r] = (f < m.q) ? fmaf(a.q_sd, e[r], zs[rr][t][r]) : zs[rr][t][r];
+          }
+        }
+      float lpp[R];
+      causal_logp<KT1, KSL1, NTL, R>(lds, m, lane_off, g, j, zp, vreg, xr, yr, lpp);
+      // ---- accept / reject   (base.py:868-871)
+      unsigned long long accmask = 0ull;
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr) {
+        const float u = u01_open(philox4x32_10(rowid[rr], (unsigned)it, 0u, TAG_ACC, a.k0, a.k1).x);
+        const float ratio = __expf(fminf(lpp[rr] - lp[rr], 0.0f));
+        const bool acc = u < ratio;
+#pragma unroll
+        for (int t = 0; t < KT1; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) zs[rr][t][r] = acc ? zp[rr][t][r] : zs[rr][t][r];
+        lp[rr] = acc ? lpp[rr] : lp[rr];
+        accmask += __popcll(__ballot(acc && valid[rr] && g == 0));
+      }
+      if (a.acc_count != nullptr && lane == 0) atomicAdd(a.acc_count + it, (unsigned)accmask);
+
+      if (it >= a.burn_in) {
+        const long long d = it - a.burn_in;
+        if (a.draws != nullptr) {  // samples.append(current_state.copy())  (base.py:896)
+#pragma unroll
+          for (int rr = 0; rr < R; ++rr) {
+            const long long row = row0 + 16 * rr + j;
+            if (row < n) {
+              float *dr = a.draws + (d * n + row) * (long long)m.q;
+#pragma unroll
+              for (int t = 0; t < KT1; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const int f = 16 * t + 4 * r + g;
+                  if (f < m.q) dr[f] = zs[rr][t][r];
+                }
+            }
+          }
+        }
+        if constexpr (EFFECT != 0) {
+          BGM_NO_HOIST();
+          // ---- infer_from_latent_posterior (base.py:671-763), fused.
+          // f first layer: pre-activation at x = 0, then rank-1 update per dose.
+          f32x4 z0in[R][KT1];
+#pragma unroll
+          for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+            for (int t = 0; t < KT1; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                z0in[rr][t][r] = (16 * t + 4 * r + g == m.q) ? 0.0f : zs[rr][t][r];
+          f32x4 base[R][4];
+          dense<KT1, KSL1, 4, R>(lds + m.w1f, lds + m.b1f, lane_off, g, z0in, base);
+          f32x4 wx[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) wx[t] = *reinterpret_cast<const f32x4 *>(lds + m.wxf + 16 * t + 4 * g);
+          const int nd = (EFFECT == 2) ? 2 : a.n_doses;
+          float ite_acc[R];
+#pragma unroll
+          for (int rr = 0; rr < R; ++rr) ite_acc[rr] = 0.0f;
+          for (int kb = 0; kb < (nd + 3) / 4; ++kb) {
+            f32x4 nz[R];
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr)
+              nz[rr] = box_muller4(philox4x32_10(rowid[rr], (unsigned)it, (unsigned)kb, TAG_YNOISE, a.k0, a.k1));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int k = 4 * kb + e;
+              if (k < nd) {
+                BGM_NO_HOIST();
+                const float xk = (EFFECT == 2) ? (k == 0 ? 1.0f : 0.0f) : a.x_values[k];
+                f32x4 a1[R][4];
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+                  for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a1[rr][t][r] = lrelu(fmaf(wx[t][r], xk, base[rr][t][r]));
+                float mu[R], sr[R];
+                fh_tail<R>(lds, m.wf2, m.bf2, m.wf3, m.bf3, m.wf4, m.bf4, lane_off, g, j, a1, mu, sr);
+                float tot = 0.0f;
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) {
+                  const float s2 = (m.sig2_y > 0.0f) ? m.sig2_y : softplus_f(sr[rr]) + BGM_EPS;
+                  const float yk = a.sample_y ? fmaf(__builtin_sqrtf(s2), nz[rr][e], mu[rr]) : mu[rr];
+                  if (EFFECT == 2) ite_acc[rr] += (k == 0) ? yk : -yk;
+                  tot += valid[rr] ? yk : 0.0f;
+                }
+                if constexpr (EFFECT == 1) {
+                  tot = sum_over_j(tot);  // sum over the 16 rows of the lane group
+                  if (lane == 0)
+                    unsafeAtomicAdd(a.adrf_partial + (slot * nd + k) * (long long)a.n_keep + d, tot);
+                }
+              }
+            }
+          }
+          if constexpr (EFFECT == 2) {
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+              const long long row = row0 + 16 * rr + j;
+              if (g == 0 && row < n) a.ite[row * (long long)a.n_keep + d] = ite_acc[rr];
+            }
+          }
+        }
+      }
+    }
+    // ---- write the chain state back
+    store_z_rows<KT1, R>(a.state, n, m.q, row0, j, g, zs);
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+      const long long row = row0 + 16 * rr + j;
+      if (g == 0 && row < n) a.logp[row] = lp[rr];
+    }
+  }
+}

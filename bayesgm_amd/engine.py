@@ -1,0 +1,226 @@
+"""Thin Python driver over the C ABI (include/bgm_hip.h).
+
+PyTorch supplies device memory and the HIP stream only; all arithmetic of the
+hot path runs in libbgm_hip.so.  There is no CPU fallback: constructing an
+engine without a gfx950 GPU or without the built library raises.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+DEFAULT_G_UNITS = [64, 64, 64, 64, 64]
+DEFAULT_FH_UNITS = [64, 32, 8]
+
+
+def flatten_net(net):
+    """[(W [in,out], b [out]), ...] -> flat float32 in Keras order."""
+    return np.concatenate([np.concatenate([np.asarray(W, np.float32).ravel(), np.asarray(b, np.float32).ravel()])
+                           for W, b in net]).astype(np.float32)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _f32(t, device):
+    if isinstance(t, np.ndarray):
+        t = torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32))
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class CausalEngine(object):
+    """Device-side state of one CausalBGM model: packed weights + kernels."""
+
+    def __init__(self, v_dim, z_dims, binary_treatment=False, g_units=None, f_units=None, h_units=None,
+                 e_units=None, sigma_v=None, sigma_x=None, sigma_y=None, device=0):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("bayesgm_amd: no HIP device visible; the hot path has no CPU fallback")
+        self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
+        self.v_dim = int(v_dim)
+        self.z_dims = [int(z) for z in z_dims]
+        self.q = sum(self.z_dims)
+        self.binary = bool(binary_treatment)
+        cfg = _lib.CausalConfig()
+        cfg.v_dim = self.v_dim
+        for i in range(4):
+            cfg.z_dims[i] = self.z_dims[i]
+        cfg.binary_treatment = int(self.binary)
+        for name, units, default in (("g", g_units, DEFAULT_G_UNITS), ("f", f_units, DEFAULT_FH_UNITS),
+                                     ("h", h_units, DEFAULT_FH_UNITS), ("e", e_units, DEFAULT_G_UNITS)):
+            units = list(default if units is None else units)
+            if len(units) > _lib.BGM_MAX_LAYERS:
+                raise ValueError("%s_units: at most %d hidden layers" % (name, _lib.BGM_MAX_LAYERS))
+            setattr(cfg, "n_hidden_" + name, len(units))
+            arr = getattr(cfg, name + "_units")
+            for i, u in enumerate(units):
+                arr[i] = int(u)
+        cfg.sigma_v = float(sigma_v) if sigma_v is not None else -1.0
+        cfg.sigma_x = float(sigma_x) if sigma_x is not None else -1.0
+        cfg.sigma_y = float(sigma_y) if sigma_y is not None else -1.0
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        _lib.check(self.lib.bgm_create(C.byref(self.h), self.device.index), "bgm_create")
+        _lib.check(self.lib.bgm_causal_configure(self.h, C.byref(cfg)), "bgm_causal_configure")
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.bgm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # -- weights ---------------------------------------------------------
+    def set_weights(self, net_id, net):
+        theta = flatten_net(net) if not isinstance(net, np.ndarray) else np.ascontiguousarray(net, np.float32)
+        _lib.check(self.lib.bgm_causal_set_weights(self.h, net_id, theta.ctypes.data_as(C.c_void_p),
+                                                   theta.size, self._stream()), "bgm_causal_set_weights")
+
+    def set_model(self, g=None, f=None, h=None, e=None):
+        for nid, net in ((_lib.NET_G, g), (_lib.NET_F, f), (_lib.NET_H, h), (_lib.NET_E, e)):
+            if net is not None:
+                self.set_weights(nid, net)
+
+    # -- kernels ---------------------------------------------------------
+    def logpost(self, x, y, v, z):
+        """get_log_posterior (causalbgm/base.py:765-817) -> torch [n] on device."""
+        x, y, v, z = (_f32(t, self.device) for t in (x, y, v, z))
+        n = v.shape[0]
+        out = torch.empty(n, device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.bgm_causal_logpost(self.h, _ptr(x), _ptr(y), _ptr(v), _ptr(z), n, _ptr(out),
+                                               self._stream()), "bgm_causal_logpost")
+        return out
+
+    def encode(self, v):
+        v = _f32(v, self.device)
+        n = v.shape[0]
+        z = torch.empty((n, self.q), device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.bgm_causal_encode(self.h, _ptr(v), n, _ptr(z), self._stream()), "bgm_causal_encode")
+        return z
+
+    def mh_slots(self, n):
+        s = C.c_int32()
+        _lib.check(self.lib.bgm_causal_mh_slots(self.h, n, C.byref(s)), "bgm_causal_mh_slots")
+        return s.value
+
+    def mh_info(self, n):
+        info = _lib.MhInfo()
+        _lib.check(self.lib.bgm_causal_mh_info(self.h, n, C.byref(info)), "bgm_causal_mh_info")
+        return info
+
+    def mh_run(self, x, y, v, state, logp, it_begin, n_iters, burn_in, q_sd, seed, init=False, row_base=0,
+               acc_count=None, draws=None, n_keep=0, effect=_lib.EFFECT_NONE, sample_y=True, x_values=None,
+               adrf_partial=None, ite=None):
+        """One segment of metropolis_hastings_sampler (causalbgm/base.py:860-898) for all rows."""
+        a = _lib.MhArgs()
+        a.x_dev, a.y_dev, a.v_dev = x.data_ptr(), y.data_ptr(), v.data_ptr()
+        a.n = v.shape[0]
+        a.row_base = int(row_base)
+        a.state_dev, a.logp_dev = state.data_ptr(), logp.data_ptr()
+        a.init = int(bool(init))
+        a.it_begin, a.n_iters, a.burn_in = int(it_begin), int(n_iters), int(burn_in)
+        a.q_sd = float(q_sd)
+        a.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        a.acc_count_dev = acc_count.data_ptr() if acc_count is not None else None
+        a.draws_dev = draws.data_ptr() if draws is not None else None
+        a.n_keep = int(n_keep)
+        a.effect = int(effect)
+        a.sample_y = int(bool(sample_y))
+        a.x_values_dev = x_values.data_ptr() if x_values is not None else None
+        a.n_doses = int(x_values.numel()) if x_values is not None else 0
+        a.adrf_partial_dev = adrf_partial.data_ptr() if adrf_partial is not None else None
+        a.ite_dev = ite.data_ptr() if ite is not None else None
+        _lib.check(self.lib.bgm_causal_mh_run(self.h, C.byref(a), self._stream()), "bgm_causal_mh_run")
+
+    def adrf_reduce(self, partial, n_slots, n_doses, n_keep, n_total):
+        out = torch.empty((n_doses, n_keep), device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.bgm_adrf_reduce(self.h, _ptr(partial), n_slots, n_doses, n_keep, float(n_total),
+                                            _ptr(out), self._stream()), "bgm_adrf_reduce")
+        return out
+
+    def row_mean_quantiles(self, mat, q_lo, q_hi):
+        """mat [n_rows, m] on device -> (mean, lo, hi) each [n_rows]."""
+        mat = mat.contiguous()
+        n_rows, m = mat.shape
+        mean = torch.empty(n_rows, device=self.device, dtype=torch.float32)
+        lo = torch.empty_like(mean)
+        hi = torch.empty_like(mean)
+        _lib.check(self.lib.bgm_row_mean_quantiles(self.h, _ptr(mat), n_rows, m, float(q_lo), float(q_hi),
+                                                   _ptr(mean), _ptr(lo), _ptr(hi), self._stream()),
+                   "bgm_row_mean_quantiles")
+        return mean, lo, hi
+
+    def timing_enable(self, on=True):
+        _lib.check(self.lib.bgm_timing_enable(self.h, int(on)), "bgm_timing_enable")
+
+    def timing_read(self, reset=True):
+        n = C.c_int64()
+        ms = C.c_double()
+        _lib.check(self.lib.bgm_timing_read(self.h, C.byref(n), C.byref(ms), int(reset)), "bgm_timing_read")
+        return n.value, ms.value
+
+    # -- whole-sampler conveniences -------------------------------------------
+    def mh_sample(self, x, y, v, burn_in, n_keep, q_sd, seed, chunk=None, want_draws=False,
+                  effect=_lib.EFFECT_NONE, x_values=None, sample_y=True, row_base=0, adaptive=False,
+                  initial_q_sd=1.0, target=0.25, tol=0.05, adj_int=50, window=100):
+        """metropolis_hastings_sampler (+ fused infer_from_latent_posterior) over all rows.
+
+        Returns dict(state, logp, acc_count [burn_in+n_keep], draws | None, adrf [n_doses,n_keep] | None,
+        ite [n, n_keep] | None, q_sd)."""
+        dev = self.device
+        x, y, v = (_f32(t, dev) for t in (x, y, v))
+        x = x.reshape(-1)
+        y = y.reshape(-1)
+        n = v.shape[0]
+        total = burn_in + n_keep
+        state = torch.empty((n, self.q), device=dev, dtype=torch.float32)
+        logp = torch.empty(n, device=dev, dtype=torch.float32)
+        acc = torch.zeros(total, device=dev, dtype=torch.int32)
+        draws = torch.empty((n_keep, n, self.q), device=dev, dtype=torch.float32) if want_draws else None
+        xv = partial = ite = None
+        n_slots = self.mh_slots(n)
+        if effect == _lib.EFFECT_ADRF:
+            xv = _f32(np.atleast_1d(np.asarray(x_values, dtype=np.float32)), dev)
+            partial = torch.zeros((n_slots, xv.numel(), n_keep), device=dev, dtype=torch.float32)
+        elif effect == _lib.EFFECT_ITE:
+            ite = torch.empty((n, n_keep), device=dev, dtype=torch.float32)
+        if adaptive:
+            q_sd = initial_q_sd
+            chunk = adj_int  # q_sd may change every adj_int iterations during burn-in (base.py:880)
+        if chunk is None:
+            chunk = total
+        it = 0
+        while it < total:
+            # segment boundaries: the adaptive rule looks at the window *after* iteration it
+            # where it % adj_int == 0, i.e. q_sd changes between it and it+1.
+            if adaptive and it < burn_in:
+                nxt = min(((it // adj_int) + 1) * adj_int + 1, total) if it > 0 else min(adj_int + 1, total)
+            else:
+                nxt = min(it + (chunk if not adaptive else total), total)
+            self.mh_run(x, y, v, state, logp, it, nxt - it, burn_in, q_sd, seed, init=(it == 0),
+                        row_base=row_base, acc_count=acc, draws=draws, n_keep=n_keep, effect=effect,
+                        sample_y=sample_y, x_values=xv, adrf_partial=partial, ite=ite)
+            it = nxt
+            last = it - 1  # counter value of the iteration just finished
+            if adaptive and last < burn_in and last % adj_int == 0 and last > 0:
+                w0 = max(0, last + 1 - window)
+                rate = float(acc[w0:last + 1].sum().item()) / ((last + 1 - w0) * n)
+                if rate < target - tol:
+                    q_sd *= 0.9
+                elif rate > target + tol:
+                    q_sd *= 1.1
+        adrf = None
+        if effect == _lib.EFFECT_ADRF:
+            adrf = self.adrf_reduce(partial, n_slots, xv.numel(), n_keep, n)
+        return dict(state=state, logp=logp, acc_count=acc, draws=draws, adrf=adrf, ite=ite, q_sd=q_sd,
+                    adrf_partial=partial, n_slots=n_slots)

@@ -1,0 +1,158 @@
+/*
+ * bgm_hip.h -- C ABI of the MI355X (gfx950) hot-path library  libbgm_hip.so
+ *
+ * The reference (liuq-lab/bayesgm v1.0.2) is pure Python on TensorFlow: it has
+ * NO plugin / FFI interface.  Each entry point below therefore replaces one
+ * @tf.function (or the NumPy loop around it) of the reference; the citation
+ * after "replaces:" is the reference file:line whose arithmetic it computes.
+ * The reference-side binding a maintainer would add is a ctypes stub -- see
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C, no torch / C++ types in any signature;
+ *   - every `*_dev` pointer is a DEVICE pointer owned by the caller
+ *     (row-major float32 unless stated), every `*_host` pointer is host memory;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls
+ *     are asynchronous on that stream unless stated;
+ *   - return value: 0 = ok, negative = error (BGM_E_*), message via
+ *     bgm_last_error() (thread-local);
+ *   - a handle is bound to one device and is thread-compatible (one caller at a
+ *     time per handle).
+ */
+#ifndef BGM_HIP_H
+#define BGM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BGM_OK 0
+#define BGM_E_INVALID (-1)     /* bad argument / unsupported shape            */
+#define BGM_E_HIP (-2)         /* HIP runtime error                           */
+#define BGM_E_STATE (-3)       /* call order (weights not set, ...)           */
+#define BGM_E_UNSUPPORTED (-4) /* shape outside the compiled kernel variants  */
+
+#define BGM_MAX_LAYERS 8
+
+#define BGM_NET_G 0 /* z -> (mu_v[p], s_v)           causalbgm/base.py:65,74  */
+#define BGM_NET_F 1 /* (z0,z1,x) -> (mu_y, s_y)      causalbgm/base.py:69,78  */
+#define BGM_NET_H 2 /* (z0,z2) -> (mu_x|logit, s_x)  causalbgm/base.py:71,80  */
+#define BGM_NET_E 3 /* v -> z  (encoder)             causalbgm/base.py:67,76  */
+
+#define BGM_EFFECT_NONE 0
+#define BGM_EFFECT_ADRF 1 /* continuous treatment: dose-response sums          */
+#define BGM_EFFECT_ITE 2  /* binary treatment: individual treatment effects    */
+
+typedef struct bgm_handle bgm_handle;
+
+/* Shape of a CausalBGM model (the `params` dict of causalbgm/base.py:56-93). */
+typedef struct {
+  int32_t v_dim;            /* p                                              */
+  int32_t z_dims[4];        /* [z0, z1, z2, z3]; q = sum                      */
+  int32_t binary_treatment; /* 0 continuous (Gaussian x), 1 binary (BCE)      */
+  int32_t n_hidden_g, g_units[BGM_MAX_LAYERS];
+  int32_t n_hidden_f, f_units[BGM_MAX_LAYERS];
+  int32_t n_hidden_h, h_units[BGM_MAX_LAYERS];
+  int32_t n_hidden_e, e_units[BGM_MAX_LAYERS];
+  float sigma_v, sigma_x, sigma_y; /* params['sigma_*'] if > 0, else learned
+                                      variance head softplus(.)+1e-6           */
+} bgm_causal_config;
+
+const char *bgm_last_error(void);
+const char *bgm_version(void);
+
+/* Create / destroy a per-device handle.  Synchronous. */
+int bgm_create(bgm_handle **out, int device);
+int bgm_destroy(bgm_handle *h);
+
+/* Declare the model shape.  Synchronous.  replaces: CausalBGM.__init__ network
+ * construction, causalbgm/base.py:64-84. */
+int bgm_causal_configure(bgm_handle *h, const bgm_causal_config *cfg);
+
+/* Upload one network's parameters from HOST memory, flat float32 in Keras
+ * order: for each Dense layer  W [in x out] row-major, then b [out]
+ * (networks/base.py:17-26).  `count` = number of floats.  Synchronous on
+ * `stream`.  Packs the weights into the MFMA fragment order used by the
+ * kernels. */
+int bgm_causal_set_weights(bgm_handle *h, int net_id, const float *theta_host, int64_t count,
+                           void *stream);
+
+/* log p(z | x, y, v) up to a constant for n rows.
+ * replaces: CausalBGM.get_log_posterior, causalbgm/base.py:765-817.
+ * x,y [n], v [n x p], z [n x q] -> out [n]. */
+int bgm_causal_logpost(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev,
+                       const float *z_dev, int64_t n, float *out_dev, void *stream);
+
+/* Encoder forward  z = e(v)  for n rows (Z initialisation of fit and
+ * evaluate(data_z=None)).  replaces: self.e_net(data_v), causalbgm/base.py:479,538. */
+int bgm_causal_encode(bgm_handle *h, const float *v_dev, int64_t n, float *z_dev, void *stream);
+
+/* Arguments of one segment of the random-walk Metropolis-Hastings sampler.
+ * replaces: CausalBGM.metropolis_hastings_sampler loop body, causalbgm/base.py:860-898,
+ * fused with CausalBGM.infer_from_latent_posterior, :671-763, for retained draws. */
+typedef struct {
+  const float *x_dev, *y_dev, *v_dev; /* [n], [n], [n x p]                    */
+  int64_t n;                          /* rows (independent chains)            */
+  int64_t row_base;                   /* global index of row 0 (RNG counter)  */
+  float *state_dev;                   /* [n x q] chain state, in/out          */
+  float *logp_dev;                    /* [n] cached log posterior, in/out     */
+  int32_t init;                       /* 1: draw state ~ N(0,1) (base.py:842)
+                                         and compute logp before iterating    */
+  int32_t it_begin, n_iters;          /* iterations [it_begin, it_begin+n)    */
+  int32_t burn_in;                    /* draws are retained for it >= burn_in */
+  float q_sd;                         /* proposal std-dev (base.py:862)       */
+  uint64_t seed;                      /* Philox key                           */
+  uint32_t *acc_count_dev;            /* [>= it_begin+n_iters] accepted-chain
+                                         count per iteration (+=), or NULL    */
+  float *draws_dev;                   /* [n_keep x n x q] retained states
+                                         (base.py:896), or NULL               */
+  int32_t n_keep;                     /* leading dim of draws / effects       */
+  int32_t effect;                     /* BGM_EFFECT_*                         */
+  int32_t sample_y;                   /* base.py:703,752                      */
+  const float *x_values_dev;          /* [n_doses] (ADRF)                     */
+  int32_t n_doses;
+  float *adrf_partial_dev;            /* ADRF: [n_slots x n_doses x n_keep]
+                                         per-wave-slot sums over rows (+=);
+                                         n_slots from bgm_causal_mh_slots()   */
+  float *ite_dev;                     /* ITE: [n x n_keep] draws, row-major
+                                         per observation                      */
+} bgm_mh_args;
+
+/* Number of wave slots (leading dim of adrf_partial) the MH kernel uses for n rows. */
+int bgm_causal_mh_slots(bgm_handle *h, int64_t n, int32_t *n_slots);
+
+int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *args, void *stream);
+
+/* out[k][d] = sum_s partial[s][k][d] / n_total  (fixed order => deterministic).
+ * replaces: adrf_draw_sums / n_seen, causalbgm/base.py:660-663. */
+int bgm_adrf_reduce(bgm_handle *h, const float *partial_dev, int32_t n_slots, int32_t n_doses,
+                    int32_t n_keep, double n_total, float *out_dev, void *stream);
+
+/* Per-row mean and linear-interpolated quantiles over m contiguous values:
+ * in [n_rows x m] -> mean [n_rows], lo [n_rows], hi [n_rows].
+ * replaces: np.mean / np.quantile(..., axis) at causalbgm/base.py:640-642,664-666. */
+int bgm_row_mean_quantiles(bgm_handle *h, const float *in_dev, int64_t n_rows, int32_t m,
+                           double q_lo, double q_hi, float *mean_dev, float *lo_dev,
+                           float *hi_dev, void *stream);
+
+/* Kernel duration bookkeeping for bench.py: when enabled, bgm_causal_mh_run
+ * brackets its kernel with hipEvents on the launch stream and accumulates
+ * (launches, milliseconds).  Reading synchronises the events. */
+int bgm_timing_enable(bgm_handle *h, int enable);
+int bgm_timing_read(bgm_handle *h, int64_t *n_launches, double *total_ms, int reset);
+
+/* Static facts of the selected MH kernel variant (for roofline accounting). */
+typedef struct {
+  int32_t rows_per_wave, waves_per_block, grid_blocks;
+  int32_t mfma_per_transition_per_wave; /* issued 16x16x4 MFMAs                */
+  int32_t lds_bytes;
+  double flop_per_row_transition;       /* algorithmic 2*MACs(g+f+h)           */
+} bgm_mh_info;
+int bgm_causal_mh_info(bgm_handle *h, int64_t n, bgm_mh_info *info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BGM_HIP_H */

@@ -1,0 +1,39 @@
+"""The C-ABI library loads and exports every symbol include/bgm_hip.h declares
+(no compute calls: runs without a GPU)."""
+import os
+import re
+
+from bayesgm_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "bgm_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(bgm_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = _declared_symbols()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), "libbgm_hip.so does not export " + n
+        assert n in _lib.SYMBOLS, "ctypes binding misses " + n
+    assert sorted(_lib.SYMBOLS) == names
+
+
+def test_version_and_error_strings():
+    lib = _lib.load()
+    assert b"gfx950" in lib.bgm_version()
+    assert lib.bgm_last_error() is not None
+
+
+def test_struct_layouts_match_header():
+    import ctypes as C
+    # sizes implied by the header (int32/float fields, 8-byte pointers)
+    assert C.sizeof(_lib.CausalConfig) == 4 * (1 + 4 + 1 + 4 * (1 + 8) + 3)
+    a = _lib.MhArgs()
+    assert C.sizeof(a) % 8 == 0
+    assert _lib.MhArgs.n.offset == 24 and _lib.MhArgs.state_dev.offset == 40
