@@ -62,7 +62,7 @@ SYMBOLS = {
     "bgm_row_mean_quantiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_double,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bgm_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
-    "bgm_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int]),
+    "bgm_timing_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int]),
     "bgm_causal_mh_info": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(MhInfo)]),
 }
 
@@ -74,6 +74,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  Import torch FIRST so
+    # that libbgm_hip.so binds (by SONAME) to the runtime torch already loaded; loading ours first
+    # would bring /opt/rocm's copy into the process as a second, device-less HIP runtime.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             "bayesgm_amd: %s not found -- build the HIP extension first "

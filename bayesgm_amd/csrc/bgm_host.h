@@ -55,9 +55,10 @@ struct bgm_handle {
   bool eblob_valid = false;
   // timing
   bool timing = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-  long long timed_launches = 0;
-  double timed_ms = 0.0;
+  struct Ev { hipEvent_t a, b; int kind; };
+  std::vector<Ev> events;
+  long long timed_launches[3] = {0, 0, 0};
+  double timed_ms[3] = {0.0, 0.0, 0.0};
 };
 
 int bgm_causal_build_blob(bgm_handle *h, hipStream_t stream);

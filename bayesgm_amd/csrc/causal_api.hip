@@ -34,7 +34,7 @@ extern "C" int bgm_destroy(bgm_handle *h) {
   hipSetDevice(h->device);
   if (h->blob_dev) hipFree(h->blob_dev);
   if (h->eblob_dev) hipFree(h->eblob_dev);
-  for (auto &e : h->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+  for (auto &e : h->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   delete h;
   return BGM_OK;
 }
@@ -315,7 +315,7 @@ extern "C" int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *a, void *stre
     if (rc) return rc;
     if (h->timing) {
       BGM_HIP_CHECK(hipEventRecord(e1, stream));
-      h->events.emplace_back(e0, e1);
+      h->events.push_back({e0, e1, segs[s].effect});
     }
   }
   return BGM_OK;
@@ -327,20 +327,22 @@ extern "C" int bgm_timing_enable(bgm_handle *h, int enable) {
   return BGM_OK;
 }
 
-extern "C" int bgm_timing_read(bgm_handle *h, int64_t *n_launches, double *total_ms, int reset) {
-  if (!h) return BGM_E_INVALID;
+extern "C" int bgm_timing_read(bgm_handle *h, int kind, int64_t *n_launches, double *total_ms, int reset) {
+  if (!h || kind < -1 || kind > 2) { bgm_set_error("bgm_timing_read: bad argument"); return BGM_E_INVALID; }
   for (auto &e : h->events) {
-    BGM_HIP_CHECK(hipEventSynchronize(e.second));
+    BGM_HIP_CHECK(hipEventSynchronize(e.b));
     float ms = 0.0f;
-    BGM_HIP_CHECK(hipEventElapsedTime(&ms, e.first, e.second));
-    h->timed_ms += ms;
-    h->timed_launches += 1;
-    hipEventDestroy(e.first); hipEventDestroy(e.second);
+    BGM_HIP_CHECK(hipEventElapsedTime(&ms, e.a, e.b));
+    h->timed_ms[e.kind] += ms;
+    h->timed_launches[e.kind] += 1;
+    hipEventDestroy(e.a); hipEventDestroy(e.b);
   }
   h->events.clear();
-  if (n_launches) *n_launches = h->timed_launches;
-  if (total_ms) *total_ms = h->timed_ms;
-  if (reset) { h->timed_launches = 0; h->timed_ms = 0.0; }
+  long long n = 0; double ms = 0.0;
+  for (int k = 0; k < 3; ++k) if (kind < 0 || kind == k) { n += h->timed_launches[k]; ms += h->timed_ms[k]; }
+  if (n_launches) *n_launches = n;
+  if (total_ms) *total_ms = ms;
+  if (reset) for (int k = 0; k < 3; ++k) if (kind < 0 || kind == k) { h->timed_launches[k] = 0; h->timed_ms[k] = 0.0; }
   return BGM_OK;
 }
 

@@ -40,6 +40,8 @@ class CausalEngine(object):
         if not torch.cuda.is_available():
             raise RuntimeError("bayesgm_amd: no HIP device visible; the hot path has no CPU fallback")
         self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
+        torch.cuda.init()
+        torch.zeros(1, device=self.device)  # make sure the HIP context of this device exists
         self.v_dim = int(v_dim)
         self.z_dims = [int(z) for z in z_dims]
         self.q = sum(self.z_dims)
@@ -163,10 +165,12 @@ class CausalEngine(object):
     def timing_enable(self, on=True):
         _lib.check(self.lib.bgm_timing_enable(self.h, int(on)), "bgm_timing_enable")
 
-    def timing_read(self, reset=True):
+    def timing_read(self, kind=-1, reset=True):
+        """(launches, total ms) of the MH kernel launches of `kind` (EFFECT_*; -1 = all)."""
         n = C.c_int64()
         ms = C.c_double()
-        _lib.check(self.lib.bgm_timing_read(self.h, C.byref(n), C.byref(ms), int(reset)), "bgm_timing_read")
+        _lib.check(self.lib.bgm_timing_read(self.h, int(kind), C.byref(n), C.byref(ms), int(reset)),
+                   "bgm_timing_read")
         return n.value, ms.value
 
     # -- whole-sampler conveniences -------------------------------------------

@@ -1,0 +1,4 @@
+"""Drop-in mirror of ``bayesgm.models`` for the hot path."""
+from .causalbgm import CausalBGM
+
+__all__ = ["CausalBGM"]

@@ -1,0 +1,185 @@
+"""CausalBGM -- host-side mirror of the reference class (same constructor, method
+names, argument meaning, return values, error behaviour and output files), driving the
+gfx950 kernels of libbgm_hip.so.
+
+Mirrors /root/reference/src/bayesgm/models/causalbgm/base.py:
+    __init__ :56-128   get_config :130   fit :434   evaluate :535   predict :573
+    metropolis_hastings_sampler :820   infer_from_latent_posterior :672
+Deterministic networks (``use_bnn=False``) are implemented; ``use_bnn=True`` (SURVEY.md
+section 8f row N2) raises NotImplementedError rather than silently changing the model.
+"""
+import datetime
+import os
+
+import numpy as np
+import torch
+
+from .. import _lib, parallel
+from ..engine import CausalEngine
+from ..datasets import Gaussian_sampler
+from ..utils import save_data
+
+_DEFAULTS = dict(use_bnn=True, g_units=[64] * 5, e_units=[64] * 5, f_units=[64, 32, 8], h_units=[64, 32, 8],
+                 dz_units=[64, 32, 8], lr=0.0002, lr_theta=0.0001, lr_z=0.0001, g_d_freq=5, save_model=False,
+                 save_res=True, kl_weight=0.0001, use_z_rec=True)
+
+
+def _glorot(rs, fan_in, fan_out):
+    lim = np.sqrt(6.0 / (fan_in + fan_out))
+    return rs.uniform(-lim, lim, size=(fan_in, fan_out)).astype(np.float32)
+
+
+def _init_mlp(rs, dims):
+    """Keras Dense defaults: glorot-uniform kernel, zero bias (networks/base.py:17-26)."""
+    return [(_glorot(rs, dims[i], dims[i + 1]), np.zeros(dims[i + 1], np.float32)) for i in range(len(dims) - 1)]
+
+
+class CausalBGM(object):
+    def __init__(self, params, timestamp=None, random_seed=None, device=None):
+        self.params = params
+        self.timestamp = timestamp
+        p = dict(_DEFAULTS)
+        p.update(params)
+        self._p = p
+        if p["use_bnn"]:
+            raise NotImplementedError(
+                "bayesgm_amd: use_bnn=True (tfp DenseFlipout networks, networks/bnn.py) is not built yet; "
+                "set params['use_bnn']=False")
+        self._rs = np.random.RandomState(random_seed) if random_seed is not None else np.random.RandomState()
+        if random_seed is not None:
+            np.random.seed(random_seed)
+        self._seed_counter = 0
+        self._base_seed = int(random_seed) if random_seed is not None else int(np.random.randint(0, 2 ** 31 - 1))
+        z = list(p["z_dims"])
+        q = sum(z)
+        self.nets = {
+            "g": _init_mlp(self._rs, [q] + list(p["g_units"]) + [p["v_dim"] + 1]),
+            "e": _init_mlp(self._rs, [p["v_dim"]] + list(p["e_units"]) + [q]),
+            "f": _init_mlp(self._rs, [z[0] + z[1] + 1] + list(p["f_units"]) + [2]),
+            "h": _init_mlp(self._rs, [z[0] + z[2]] + list(p["h_units"]) + [2]),
+        }
+        self.z_sampler = Gaussian_sampler(mean=np.zeros(q), sd=1.0)
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", 0))
+        self.engine = CausalEngine(p["v_dim"], z, binary_treatment=p["binary_treatment"], g_units=p["g_units"],
+                                   f_units=p["f_units"], h_units=p["h_units"], e_units=p["e_units"],
+                                   sigma_v=params.get("sigma_v"), sigma_x=params.get("sigma_x"),
+                                   sigma_y=params.get("sigma_y"), device=device)
+        self._push_weights()
+        if self.timestamp is None:
+            self.timestamp = datetime.datetime.now().astimezone().strftime('%Y%m%d_%H%M%S')
+        self.checkpoint_path = "{}/checkpoints/{}/{}".format(params['output_dir'], params['dataset'], self.timestamp)
+        if p['save_model'] and not os.path.exists(self.checkpoint_path):
+            os.makedirs(self.checkpoint_path, exist_ok=True)
+        self.save_dir = "{}/results/{}/{}".format(params['output_dir'], params['dataset'], self.timestamp)
+        if p['save_res'] and not os.path.exists(self.save_dir):
+            os.makedirs(self.save_dir, exist_ok=True)
+        self.data_z = None
+        self.last_acceptance_rate = None
+
+    # ------------------------------------------------------------------ plumbing
+    def get_config(self):
+        return {"params": self.params}
+
+    def _push_weights(self, which=("g", "f", "h", "e")):
+        ids = {"g": _lib.NET_G, "f": _lib.NET_F, "h": _lib.NET_H, "e": _lib.NET_E}
+        for k in which:
+            self.engine.set_weights(ids[k], self.nets[k])
+
+    def set_weights(self, **nets):
+        """Install network parameters ([(W, b), ...] per net) -- the counterpart of restoring a checkpoint."""
+        for k, v in nets.items():
+            self.nets[k] = [(np.asarray(W, np.float32), np.asarray(b, np.float32)) for W, b in v]
+        self._push_weights(tuple(nets))
+
+    def _next_seed(self):
+        self._seed_counter += 1
+        return (self._base_seed * 1000003 + self._seed_counter) & 0x7FFFFFFFFFFFFFFF
+
+    def _dev(self, a):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.engine.device, dtype=torch.float32).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.engine.device)
+
+    # ------------------------------------------------------------------ predict
+    def predict(self, data, alpha=0.01, n_mcmc=3000, burn_in=5000, x_values=None, q_sd=1.0, sample_y=True,
+                bs=10000, verbose=1):
+        """Causal effects with posterior intervals from latent MCMC samples (base.py:573-668).
+
+        ``bs`` bounded the host memory of the reference; here all rows are sampled in one launch per
+        segment (row-blocked only if the ITE draw matrix would exceed device memory) and the result does
+        not depend on it.  Under torch.distributed the rows are sharded by rank and results gathered."""
+        assert 0 < alpha < 1, "The significance level 'alpha' must be greater than 0 and less than 1."
+        binary = bool(self._p['binary_treatment'])
+        if not binary and x_values is None:
+            raise ValueError("For continuous treatment, 'x_values' must not be None. Provide a list or a single treatment value.")
+        if x_values is not None:
+            x_values = np.array([x_values], dtype=float) if np.isscalar(x_values) else np.array(x_values, dtype=float)
+        data_x, data_y, data_v = data
+        n_test = len(data_x)
+        lo_r, hi_r = parallel.shard_range(n_test)
+        x = self._dev(data_x[lo_r:hi_r]).reshape(-1)
+        y = self._dev(data_y[lo_r:hi_r]).reshape(-1)
+        v = self._dev(data_v[lo_r:hi_r])
+        n_loc = hi_r - lo_r
+        adaptive = (q_sd is None) or (q_sd <= 0)
+        seed = self._next_seed()
+        if verbose:
+            print('MCMC Latent Variable Sampling ...')
+        eng = self.engine
+        total_it = burn_in + n_mcmc
+        acc_tail = 0.0
+        if binary:
+            # row blocks so that the [rows x n_mcmc] draw matrix stays below ~32 GiB
+            max_rows = max(16, int((32 << 30) // (4 * max(1, n_mcmc))))
+            means, los, his = [], [], []
+            for s in range(0, n_loc, max_rows):
+                e = min(s + max_rows, n_loc)
+                out = eng.mh_sample(x[s:e], y[s:e], v[s:e], burn_in, n_mcmc, q_sd, seed, effect=_lib.EFFECT_ITE,
+                                    sample_y=sample_y, row_base=lo_r + s, adaptive=adaptive)
+                mean, lo, hi = eng.row_mean_quantiles(out["ite"], alpha / 2, 1 - alpha / 2)
+                means.append(mean); los.append(lo); his.append(hi)
+                acc_tail += float(out["acc_count"][max(0, total_it - 100):].sum().item())
+            mean = parallel.all_gather_rows(torch.cat(means), n_test)
+            lo = parallel.all_gather_rows(torch.cat(los), n_test)
+            hi = parallel.all_gather_rows(torch.cat(his), n_test)
+            self._report_acceptance(acc_tail, min(100, total_it), n_test, verbose)
+            return mean.cpu().numpy(), torch.stack([lo, hi], dim=1).cpu().numpy()
+        out = eng.mh_sample(x, y, v, burn_in, n_mcmc, q_sd, seed, effect=_lib.EFFECT_ADRF, x_values=x_values,
+                            sample_y=sample_y, row_base=lo_r, adaptive=adaptive)
+        acc_tail = float(out["acc_count"][max(0, total_it - 100):].sum().item())
+        sums = out["adrf"].double() * float(n_loc)           # adrf_draw_sums (base.py:660)
+        parallel.all_reduce_sum_(sums)                        # C3: [n_doses x n_mcmc]
+        causal_effects = (sums / float(n_test)).float().contiguous()
+        adrf, lo, hi = eng.row_mean_quantiles(causal_effects, alpha / 2, 1 - alpha / 2)
+        self._report_acceptance(acc_tail, min(100, total_it), n_test, verbose)
+        return adrf.cpu().numpy(), torch.stack([lo, hi], dim=1).cpu().numpy()
+
+    def _report_acceptance(self, acc_tail, window, n_test, verbose):
+        t = torch.tensor([acc_tail], dtype=torch.float64, device=self.engine.device)
+        parallel.all_reduce_sum_(t)
+        self.last_acceptance_rate = float(t.item()) / (window * n_test)
+        if verbose:
+            print(f"Final MCMC Acceptance Rate: {self.last_acceptance_rate:.4f}")
+
+    def metropolis_hastings_sampler(self, data, initial_q_sd=1.0, q_sd=None, burn_in=5000, n_keep=3000,
+                                    target_acceptance_rate=0.25, tolerance=0.05, adjustment_interval=50,
+                                    adaptive_sd=None, window_size=100):
+        """Posterior samples of Z, shape (n_keep, n, q) (base.py:820-904)."""
+        data_x, data_y, data_v = data
+        if adaptive_sd is None:
+            adaptive_sd = (q_sd is None or q_sd <= 0)
+        out = self.engine.mh_sample(self._dev(data_x).reshape(-1), self._dev(data_y).reshape(-1), self._dev(data_v),
+                                    burn_in, n_keep, q_sd, self._next_seed(), want_draws=True, adaptive=adaptive_sd,
+                                    initial_q_sd=initial_q_sd, target=target_acceptance_rate, tol=tolerance,
+                                    adj_int=adjustment_interval, window=window_size)
+        tot = burn_in + n_keep
+        w = min(window_size, tot)
+        self.last_acceptance_rate = float(out["acc_count"][tot - w:].sum().item()) / (w * len(data_x))
+        print(f"Final MCMC Acceptance Rate: {self.last_acceptance_rate:.4f}")
+        return out["draws"].cpu().numpy()
+
+    def get_log_posterior(self, data_x, data_y, data_v, data_z, eps=1e-6):
+        """log p(z | x, y, v) + const, shape (n,) (base.py:765-817)."""
+        return self.engine.logpost(self._dev(data_x).reshape(-1), self._dev(data_y).reshape(-1), self._dev(data_v),
+                                   self._dev(data_z)).cpu().numpy()

@@ -1,0 +1,50 @@
+"""One-process-per-GPU helpers (torch.distributed; backend "nccl" is RCCL on ROCm).
+
+The hot path shards by observation: rows are split into
+contiguous per-rank ranges, MCMC chains never communicate, and the only
+exchanges are (C1) the network-gradient all-reduce in fit, (C3) the ADRF
+partial sums [n_doses x n_keep] once per predict and gathers of per-row results.
+"""
+import torch
+import torch.distributed as dist
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def rank():
+    return dist.get_rank() if is_dist() else 0
+
+
+def world_size():
+    return dist.get_world_size() if is_dist() else 1
+
+
+def shard_range(n, r=None, w=None):
+    """Contiguous row range [lo, hi) owned by rank r of w (sizes differ by at most 1)."""
+    r = rank() if r is None else r
+    w = world_size() if w is None else w
+    base, rem = divmod(n, w)
+    lo = r * base + min(r, rem)
+    return lo, lo + base + (1 if r < rem else 0)
+
+
+def all_reduce_sum_(t):
+    if is_dist():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def all_gather_rows(t, n_total):
+    """Concatenate per-rank row blocks (first dim) of possibly unequal length."""
+    if not is_dist():
+        return t
+    w = world_size()
+    sizes = [shard_range(n_total, r, w)[1] - shard_range(n_total, r, w)[0] for r in range(w)]
+    mx = max(sizes)
+    pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[:t.shape[0]] = t
+    outs = [torch.empty_like(pad) for _ in range(w)]
+    dist.all_gather(outs, pad)
+    return torch.cat([o[:s] for o, s in zip(outs, sizes)], dim=0)

@@ -1,0 +1,185 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the BGM / CausalBGM posterior-sampling hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): posterior samples/sec, whole job = MCMC transitions of per-observation
+latent chains per second, CausalBGM continuous treatment, Sim_Hirano_Imbens panel N=1e6 (per GPU,
+weak scaling), p=200, z_dims [1,1,1,7], burn_in=5000, n_mcmc=3000, q_sd=1, 20 doses on [0,3],
+sample_y=True (causalbgm/base.py:573 defaults).  One "step" = one CausalBGM.predict over the whole
+panel with the inputs already resident in HBM: burn_in + n_mcmc Metropolis-Hastings transitions of
+every row, the fused dose-response inference for the retained draws, the slot reduction, (N>1) the
+ADRF all-reduce, and the posterior mean / quantiles.
+
+The JSON line also carries
+  roofline     -- the dominant kernel (burn-in MH transition kernel, fp32 MFMA): algorithmic
+                  FLOP/launch (2*MACs(g+f+h) = 69,696 FLOP per row-transition) over
+                  its hipEvent-measured duration, against the 157.3 TF dense fp32-MFMA peak.
+  cpu_baseline -- the oracle's literal restatement of the reference loop (NumPy, host RNG, two
+                  log-posterior evaluations per iteration) timed on this box's host cores on a
+                  bounded sample (bs=10000 rows x a few iterations).
+Weights are glorot-uniform random (seed 0): throughput does not depend on their values.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def make_panel(n, p, seed, device):
+    """Hirano-Imbens panel, generated per rank on the host with the reference's generator
+    restatement (bayesgm_amd.datasets, pinned by tests/golden) and moved to HBM."""
+    import torch
+    from bayesgm_amd.datasets import Sim_Hirano_Imbens_sampler
+    x, y, v = Sim_Hirano_Imbens_sampler(N=n, v_dim=p, seed=seed).load_all()
+    return (torch.from_numpy(x).to(device), torch.from_numpy(y).to(device), torch.from_numpy(v).to(device))
+
+
+def cpu_baseline(params, p, z_dims, budget_s=20.0):
+    """Reference loop as written, on the host cores (kind = "port")."""
+    from oracle import causal as OC
+    from bayesgm_amd.datasets import Sim_Hirano_Imbens_sampler
+    try:
+        import threadpoolctl
+        cores = max(i["num_threads"] for i in threadpoolctl.threadpool_info()) if threadpoolctl.threadpool_info() else 1
+    except Exception:
+        cores = os.cpu_count() or 1
+    m = OC.init_model(0, z_dims, p)
+    bs = 10000
+    x, y, v = Sim_Hirano_Imbens_sampler(N=bs, v_dim=p, seed=1).load_all()
+    rng = np.random.RandomState(0)
+    OC.mh_reference_loop(m, (x, y, v), 1, 1.0, rng)  # warm BLAS
+    t0 = time.time()
+    OC.mh_reference_loop(m, (x, y, v), 3, 1.0, rng)
+    per_it = (time.time() - t0) / 3
+    n_it = int(max(5, min(400, budget_s / max(per_it, 1e-6))))
+    t0 = time.time()
+    OC.mh_reference_loop(m, (x, y, v), n_it, 1.0, rng)
+    dt = time.time() - t0
+    return {"value": bs * n_it / dt, "unit": "posterior samples/s (MH transitions/s)", "cores": int(cores),
+            "kind": "port",
+            "sample": f"oracle.causal.mh_reference_loop: bs={bs} rows x {n_it} iterations, p={p}, "
+                      f"2 log-posterior evals/iter + NumPy RNG as causalbgm/base.py:860-871; {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=float, default=1e6, help="rows per GPU")
+    ap.add_argument("--p", type=int, default=200)
+    ap.add_argument("--burn-in", type=int, default=5000)
+    ap.add_argument("--n-mcmc", type=int, default=3000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from bayesgm_amd.models import CausalBGM
+    from bayesgm_amd import parallel
+
+    n_loc, p = int(args.n), args.p
+    z_dims = [1, 1, 1, 7]
+    params = dict(dataset="Sim_Hirano_Imbens", output_dir=".", save_res=False, save_model=False,
+                  binary_treatment=False, use_bnn=False, z_dims=z_dims, v_dim=p, lr_theta=1e-4, lr_z=1e-4,
+                  g_units=[64] * 5, f_units=[64, 32, 8], h_units=[64, 32, 8], kl_weight=1e-4, lr=2e-4,
+                  g_d_freq=5, use_z_rec=True, e_units=[64] * 5, dz_units=[64, 32, 8])
+    model = CausalBGM(params, timestamp="bench", random_seed=0, device=local_rank)
+    eng = model.engine
+    x, y, v = make_panel(n_loc, p, seed=rank, device=device)  # each rank its own panel (weak scaling)
+    x_values = np.linspace(0, 3, 20)
+    n_total = n_loc * world
+
+    class Shard:  # predict() shards data[lo:hi] by rank; hand it this rank's rows for any slice
+        def __init__(self, t): self.t = t
+        def __len__(self): return n_total
+        def __getitem__(self, s): return self.t
+    data = (Shard(x), Shard(y), Shard(v))
+
+    def step():
+        return model.predict(data, alpha=0.01, n_mcmc=args.n_mcmc, burn_in=args.burn_in, x_values=x_values,
+                             q_sd=1.0, sample_y=True, verbose=0)
+
+    for _ in range(args.warmup):
+        step()
+    eng.timing_enable(True)
+    eng.timing_read(kind=-1, reset=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        adrf, interval = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    eng.timing_enable(False)
+
+    if rank == 0:
+        iters = args.burn_in + args.n_mcmc
+        value = n_total * iters * args.steps / elapsed
+        info = eng.mh_info(n_loc)
+        n_burn, ms_burn = eng.timing_read(kind=0, reset=False)
+        n_keep_l, ms_keep = eng.timing_read(kind=1, reset=False)
+        roof = None
+        if n_burn:
+            avg = ms_burn / n_burn
+            flop = info.flop_per_row_transition * n_loc * args.burn_in
+            ach = flop / (avg * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "causal_mh_kernel<EFFECT=0> (burn-in transitions)",
+                    "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                    "avg_launch_ms": avg, "launches": n_burn, "flop_per_launch": flop,
+                    "keep_phase_avg_launch_ms": (ms_keep / n_keep_l) if n_keep_l else None}
+        out = {
+            "metric": "posterior samples/sec (whole node), CausalBGM N=1e6 p=200",
+            "value": value, "unit": "MH transitions/s (rows x (burn_in+n_mcmc) / t_predict)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic (Sim_Hirano_Imbens generator, random-init glorot weights)",
+            "config": {"workload": f"CausalBGM.predict continuous treatment, N={n_loc} rows/GPU, p={p}, "
+                                   f"z_dims {z_dims}, burn_in={args.burn_in}, n_mcmc={args.n_mcmc}, q_sd=1.0, "
+                                   f"20 doses, sample_y=True",
+                       "rows_per_gpu": n_loc, "p": p, "parallelism": f"dp{world} (rows sharded, ADRF all-reduce)"},
+            "retained_draws_per_s": n_total * args.n_mcmc * args.steps / elapsed,
+            "acceptance_rate": model.last_acceptance_rate,
+            "adrf_head": [float(a) for a in adrf[:3]],
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(params, p, z_dims)
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

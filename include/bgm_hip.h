@@ -138,10 +138,12 @@ int bgm_row_mean_quantiles(bgm_handle *h, const float *in_dev, int64_t n_rows, i
                            float *hi_dev, void *stream);
 
 /* Kernel duration bookkeeping for bench.py: when enabled, bgm_causal_mh_run
- * brackets its kernel with hipEvents on the launch stream and accumulates
- * (launches, milliseconds).  Reading synchronises the events. */
+ * brackets each kernel launch with hipEvents on the launch stream and
+ * accumulates (launches, milliseconds) per kernel kind = BGM_EFFECT_* of the
+ * launch (BGM_EFFECT_NONE = the pure-transition kernel); kind -1 = all.
+ * Reading synchronises the pending events. */
 int bgm_timing_enable(bgm_handle *h, int enable);
-int bgm_timing_read(bgm_handle *h, int64_t *n_launches, double *total_ms, int reset);
+int bgm_timing_read(bgm_handle *h, int kind, int64_t *n_launches, double *total_ms, int reset);
 
 /* Static facts of the selected MH kernel variant (for roofline accounting). */
 typedef struct {

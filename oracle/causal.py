@@ -257,3 +257,25 @@ def evaluate(m, data, data_z=None, nb_intervals=200):
     dose = np.array([mlp_forward(m["f"], np.concatenate(
         [z0, z1, np.full((n, 1), xv, v.dtype)], -1))[:, 0].mean() for xv in xs], dtype=v.dtype)
     return dose, mse_x, mse_y, mse_v
+
+
+def mh_reference_loop(m, data, n_iter, q_sd=1.0, rng=None):
+    """The reference's MH loop AS WRITTEN (base.py:842-871), for CPU-baseline timing only:
+    host NumPy RNG (Mersenne Twister), fresh proposal each iteration, and TWO
+    get_log_posterior evaluations per iteration (:865 proposed, :866 current).
+    Returns (state, n_accepted)."""
+    x, y, v = data
+    rng = np.random if rng is None else rng
+    n = len(x)
+    q = int(sum(m["z_dims"]))
+    state = rng.normal(0, 1, size=(n, q)).astype('float32')
+    n_acc = 0
+    for _ in range(n_iter):
+        prop = state + rng.normal(0, q_sd, size=(n, q)).astype('float32')
+        lp_prop = log_posterior(m, x, y, v, prop)
+        lp_cur = log_posterior(m, x, y, v, state)
+        ratio = np.exp(np.minimum(lp_prop - lp_cur, 0))
+        idx = rng.rand(n) < ratio
+        state[idx] = prop[idx]
+        n_acc += int(idx.sum())
+    return state, n_acc
