@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbgm_hip.so")
+LIB_PATH = os.environ.get("BGM_HIP_LIB", os.path.join(_HERE, "libbgm_hip.so"))  # override: dev A/B builds only
 
 BGM_MAX_LAYERS = 8
 NET_G, NET_F, NET_H, NET_E = 0, 1, 2, 3

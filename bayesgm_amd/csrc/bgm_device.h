@@ -87,9 +87,22 @@ __device__ __forceinline__ f32x4 box_muller4(uint4 w) {
 }
 
 // ------------------------------------------------------------- math ----------
-__device__ __forceinline__ float lrelu(float x) { return fmaxf(x, BGM_LEAK * x); }
-__device__ __forceinline__ float softplus_f(float x) {  // tf.nn.softplus
-  return fmaxf(x, 0.0f) + log1pf(__expf(-fabsf(x)));
+// max(a,b) as v_med3_f32(a, b, +inf): a single VOP3 without the NaN-canonicalising extra v_max
+// that fmaxf() costs on MFMA outputs.  (An inline-asm v_max_f32 is NOT an option here: hipcc pads
+// no MFMA->VALU hazard wait states inside asm statements, so it would read stale accumulators.)
+__device__ __forceinline__ float vmax(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
+__device__ __forceinline__ float lrelu(float x) { return vmax(x, BGM_LEAK * x); }
+// natural log / exp on the hardware transcendental units (v_log_f32 = log2, v_exp_f32 = exp2;
+// ~1 ulp each), used where the argument is O(1) and the result enters a sum of O(1e2) terms.
+__device__ __forceinline__ float fast_log(float x) { return 0.6931471805599453f * __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(1.4426950408889634f * x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// tf.nn.softplus(x) = log(1 + exp(x)) = max(x,0) + log(1 + exp(-|x|)); for e = exp(-|x|) < 2^-12
+// log(1+e) = e - e^2/2 + O(e^3) is used so that tiny tails keep their relative accuracy.
+__device__ __forceinline__ float softplus_f(float x) {
+  const float e = fast_exp(-fabsf(x));
+  const float l = (e < 2.44140625e-4f) ? e * (1.0f - 0.5f * e) : fast_log(1.0f + e);
+  return vmax(x, 0.0f) + l;
 }
 
 // sum over the four lane groups g (lanes j, j+16, j+32, j+48); result in all.
@@ -98,12 +111,13 @@ __device__ __forceinline__ float sum_over_g(float x) {
   x += __shfl_xor(x, 32);
   return x;
 }
-// sum over the 16 rows j of a lane group (result in every lane of the group)
-__device__ __forceinline__ float sum_over_j(float x) {
-  x += __shfl_xor(x, 1);
-  x += __shfl_xor(x, 2);
-  x += __shfl_xor(x, 4);
-  x += __shfl_xor(x, 8);
+// sum over the 16 rows j of a lane group with DPP row shifts (no LDS traffic);
+// the total lands in lane j = 15 of each group.
+__device__ __forceinline__ float sum_over_j_to_lane15(float x) {
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xF, 0xF, true));  // row_shr:1
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xF, 0xF, true));  // row_shr:2
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xF, 0xF, true));  // row_shr:4
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xF, 0xF, true));  // row_shr:8
   return x;
 }
 
@@ -144,20 +158,21 @@ __device__ __forceinline__ void dense_groups(const float *wl, int lane_off, cons
   if constexpr (T0 < NT) {
     constexpr int GS = group_size(NT - T0);
     constexpr int K_ROWS = 16 * KT;
+    constexpr int NKS = 4 * (KT - 1) + KSL;  // K-steps of this layer
     const float *base = wl + K_ROWS * 16 * T0 + lane_off * GS;
+    // software pipeline: the A fragment of K-step s+1 is in flight while the MFMAs of step s issue
+    AFrag<GS> a_cur, a_nxt;
+    a_cur.load(base);
 #pragma unroll
-    for (int t = 0; t < KT; ++t) {
+    for (int s = 0; s < NKS; ++s) {
+      const int t = s >> 2, r = s & 3;
+      if (s + 1 < NKS) a_nxt.load(base + (16 * ((s + 1) >> 2) + ((s + 1) & 3)) * 16 * GS);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (t == KT - 1 && r >= KSL) continue;
-        AFrag<GS> a;
-        a.load(base + (16 * t + r) * 16 * GS);
+      for (int u = 0; u < GS; ++u) {
 #pragma unroll
-        for (int u = 0; u < GS; ++u) {
-#pragma unroll
-          for (int rr = 0; rr < R; ++rr) acc[rr][T0 + u] = BGM_MFMA(a.get(u), in[rr][t][r], acc[rr][T0 + u]);
-        }
+        for (int rr = 0; rr < R; ++rr) acc[rr][T0 + u] = BGM_MFMA(a_cur.get(u), in[rr][t][r], acc[rr][T0 + u]);
       }
+      a_cur = a_nxt;
     }
     dense_groups<T0 + GS, KT, KSL, NT, R>(wl, lane_off, in, acc);
   }

@@ -15,7 +15,7 @@ PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libbgm_hip.so")
 SOURCES = ["causal_api.hip", "aux_kernels.hip"]
 HEADERS = ["bgm_device.h", "causal_kernels.h", "bgm_host.h", os.path.join("..", "..", "include", "bgm_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+FLAGS = os.environ.get("BGM_EXTRA_FLAGS", "").split() + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wno-unused-value", "-Wno-unused-result"]
 
 
@@ -23,7 +23,8 @@ def _newer(src, dst):
     return (not os.path.exists(dst)) or os.path.getmtime(src) > os.path.getmtime(dst)
 
 
-def build(force=False, defines=(), verbose=True):
+def build(force=False, defines=(), verbose=True, out=None):
+    OUT = out or globals()["OUT"]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
@@ -35,7 +36,7 @@ def build(force=False, defines=(), verbose=True):
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
 
     def cc(src):
-        obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")
+        obj = os.path.join(HERE, "build", os.path.basename(OUT) + "." + os.path.basename(src) + ".o")
         cmd = [hipcc] + FLAGS + ["-D" + d for d in defines] + ["-I", HERE, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -55,9 +56,12 @@ if __name__ == "__main__":
     defs = []
     argv = sys.argv[1:]
     force = "--force" in argv
+    out = None
     for i, a in enumerate(argv):
         if a == "-D":
             defs.append(argv[i + 1])
         elif a.startswith("-D") and len(a) > 2:
             defs.append(a[2:])
-    print(build(force=force, defines=defs))
+        elif a == "-o":
+            out = os.path.abspath(argv[i + 1])
+    print(build(force=force or bool(defs), defines=defs, out=out))

@@ -66,19 +66,20 @@ __device__ __forceinline__ void g_last_groups(const float *wl, const float *bl, 
       for (int rr = 0; rr < R; ++rr) acc[rr][T0 + u] = b;
     }
     constexpr int K_ROWS = 16 * KT;
+    constexpr int NKS = 4 * KT;
     const float *base = wl + K_ROWS * 16 * T0 + lane_off * GS;
+    AFrag<GS> a_cur, a_nxt;
+    a_cur.load(base);
 #pragma unroll
-    for (int t = 0; t < KT; ++t) {
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int t = ks >> 2, r = ks & 3;
+      if (ks + 1 < NKS) a_nxt.load(base + (16 * ((ks + 1) >> 2) + ((ks + 1) & 3)) * 16 * GS);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        AFrag<GS> a;
-        a.load(base + (16 * t + r) * 16 * GS);
+      for (int u = 0; u < GS; ++u)
 #pragma unroll
-        for (int u = 0; u < GS; ++u)
-#pragma unroll
-          for (int rr = 0; rr < R; ++rr)
-            acc[rr][T0 + u] = BGM_MFMA(a.get(u), in[rr][t][r], acc[rr][T0 + u]);
-      }
+        for (int rr = 0; rr < R; ++rr)
+          acc[rr][T0 + u] = BGM_MFMA(a_cur.get(u), in[rr][t][r], acc[rr][T0 + u]);
+      a_cur = a_nxt;
     }
 #pragma unroll
     for (int u = 0; u < GS; ++u) {
@@ -101,10 +102,11 @@ __device__ __forceinline__ void g_last_groups(const float *wl, const float *bl, 
 }
 
 // f / h tail:  64 -> 32 -> 8 -> 2   (f_units = h_units = [64, 32, 8]); a1 is the
-// activated first hidden layer.  Returns raw outputs (mu, s) replicated over g.
+// activated first hidden layer.  Returns the raw outputs (mu, s) of every row group;
+// they are VALID IN LANE GROUP g = 0 ONLY (output features 0,1 live there).
 template <int R>
 __device__ __forceinline__ void fh_tail(const float *lds, int w2, int b2, int w3, int b3, int w4,
-                                        int b4, int lane_off, int g, int j,
+                                        int b4, int lane_off, int g,
                                         const f32x4 (&a1)[R][4], float (&mu)[R], float (&sr)[R]) {
   f32x4 a2[R][2];
   dense<4, 4, 2, R>(lds + w2, lds + b2, lane_off, g, a1, a2);
@@ -116,8 +118,8 @@ __device__ __forceinline__ void fh_tail(const float *lds, int w2, int b2, int w3
   dense<1, 4, 1, R>(lds + w4, lds + b4, lane_off, g, a3, a4);
 #pragma unroll
   for (int rr = 0; rr < R; ++rr) {
-    mu[rr] = __shfl(a4[rr][0][0], j);  // output features 0,1 live in lane group g = 0
-    sr[rr] = __shfl(a4[rr][0][1], j);
+    mu[rr] = a4[rr][0][0];
+    sr[rr] = a4[rr][0][1];
   }
 }
 
@@ -156,7 +158,7 @@ __device__ __forceinline__ void causal_logp(const float *lds, const CausalMeta &
     f32x4 a1[R][4];
     dense<KT1, KSL1, 4, R>(lds + m.w1f, lds + m.b1f, lane_off, g, zin, a1);
     lrelu_inplace<4, R>(a1);
-    fh_tail<R>(lds, m.wf2, m.bf2, m.wf3, m.bf3, m.wf4, m.bf4, lane_off, g, j, a1, mu_y, sr_y);
+    fh_tail<R>(lds, m.wf2, m.bf2, m.wf3, m.bf3, m.wf4, m.bf4, lane_off, g, a1, mu_y, sr_y);
   }
   // ---- h : (z0, z2) -> (mu_x | logit, s_x)   (base.py:786-791)
   float mu_x[R], sr_x[R];
@@ -164,9 +166,11 @@ __device__ __forceinline__ void causal_logp(const float *lds, const CausalMeta &
     f32x4 a1[R][4];
     dense<KT1, KSL1, 4, R>(lds + m.w1h, lds + m.b1h, lane_off, g, zin, a1);
     lrelu_inplace<4, R>(a1);
-    fh_tail<R>(lds, m.wh2, m.bh2, m.wh3, m.bh3, m.wh4, m.bh4, lane_off, g, j, a1, mu_x, sr_x);
+    fh_tail<R>(lds, m.wh2, m.bh2, m.wh3, m.bh3, m.wh4, m.bh4, lane_off, g, a1, mu_x, sr_x);
   }
   // ---- assemble -(loss_v + loss_x + loss_y + |z|^2/2)   (base.py:800-816)
+  // mu_x/sr_x/mu_y/sr_y are valid in lane group 0 only: their losses are evaluated there and
+  // folded into the per-lane partial that is summed over g, so one reduction serves all terms.
 #pragma unroll
   for (int rr = 0; rr < R; ++rr) {
     float zsq = 0.0f;
@@ -178,22 +182,22 @@ __device__ __forceinline__ void causal_logp(const float *lds, const CausalMeta &
         zsq = (16 * t + 4 * r + g < m.q) ? fmaf(zz, zz, zsq) : zsq;
       }
     const float s2v = (m.sig2_v > 0.0f) ? m.sig2_v : softplus_f(sraw_v[rr]) + BGM_EPS;
-    // per-lane partial of  ssq/(2 s2v) + |z|^2/2 ; reduce over g
-    const float part = sum_over_g(ssq[rr] / (2.0f * s2v) + 0.5f * zsq);
-    const float loss_v = part + 0.5f * (float)m.p * logf(s2v);
     float loss_x;
     if (m.binary) {
       const float l = mu_x[rr];
-      loss_x = fmaxf(l, 0.0f) - l * xr[rr] + log1pf(__expf(-fabsf(l)));
+      const float e = fast_exp(-fabsf(l));
+      loss_x = vmax(l, 0.0f) - l * xr[rr] + ((e < 2.44140625e-4f) ? e * (1.0f - 0.5f * e) : fast_log(1.0f + e));
     } else {
       const float s2x = (m.sig2_x > 0.0f) ? m.sig2_x : softplus_f(sr_x[rr]) + BGM_EPS;
       const float dx = xr[rr] - mu_x[rr];
-      loss_x = dx * dx / (2.0f * s2x) + 0.5f * logf(s2x);
+      loss_x = 0.5f * (dx * dx * fast_rcp(s2x) + fast_log(s2x));
     }
     const float s2y = (m.sig2_y > 0.0f) ? m.sig2_y : softplus_f(sr_y[rr]) + BGM_EPS;
     const float dy = yr[rr] - mu_y[rr];
-    const float loss_y = dy * dy / (2.0f * s2y) + 0.5f * logf(s2y);
-    logp[rr] = -(loss_v + loss_x + loss_y);
+    const float loss_y = 0.5f * (dy * dy * fast_rcp(s2y) + fast_log(s2y));
+    float part = 0.5f * (ssq[rr] * fast_rcp(s2v) + zsq);
+    part += (g == 0) ? (loss_x + loss_y) : 0.0f;
+    logp[rr] = -(sum_over_g(part) + 0.5f * (float)m.p * fast_log(s2v));
   }
 }
 
@@ -355,6 +359,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
       }
     }
 
+    uint4 uacc[R];
     for (int it = a.it_begin; it < a.it_begin + a.n_iters; ++it) {
       BGM_NO_HOIST();
       // ---- proposal  z' = z + q_sd * eps   (base.py:862)
@@ -372,12 +377,17 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
         }
       float lpp[R];
       causal_logp<KT1, KSL1, NTL, R>(lds, m, lane_off, g, j, zp, vreg, xr, yr, lpp);
-      // ---- accept / reject   (base.py:868-871)
+      // ---- accept / reject   (base.py:868-871).  u(it) = word (it & 3) of Philox(row, it >> 2, 0, TAG_ACC)
+      if ((it & 3) == 0 || it == a.it_begin) {
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) uacc[rr] = philox4x32_10(rowid[rr], (unsigned)it >> 2, 0u, TAG_ACC, a.k0, a.k1);
+      }
       unsigned long long accmask = 0ull;
 #pragma unroll
       for (int rr = 0; rr < R; ++rr) {
-        const float u = u01_open(philox4x32_10(rowid[rr], (unsigned)it, 0u, TAG_ACC, a.k0, a.k1).x);
-        const float ratio = __expf(fminf(lpp[rr] - lp[rr], 0.0f));
+        const unsigned w = (it & 2) ? ((it & 1) ? uacc[rr].w : uacc[rr].z) : ((it & 1) ? uacc[rr].y : uacc[rr].x);
+        const float u = u01_open(w);
+        const float ratio = fast_exp(fminf(lpp[rr] - lp[rr], 0.0f));
         const bool acc = u < ratio;
 #pragma unroll
         for (int t = 0; t < KT1; ++t)
@@ -424,50 +434,56 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
 #pragma unroll
           for (int t = 0; t < 4; ++t) wx[t] = *reinterpret_cast<const f32x4 *>(lds + m.wxf + 16 * t + 4 * g);
           const int nd = (EFFECT == 2) ? 2 : a.n_doses;
-          float ite_acc[R];
-#pragma unroll
-          for (int rr = 0; rr < R; ++rr) ite_acc[rr] = 0.0f;
+          constexpr int DB = (EFFECT == 2) ? 2 : 4;  // doses evaluated per pass (independent MFMA chains)
           for (int kb = 0; kb < (nd + 3) / 4; ++kb) {
+            BGM_NO_HOIST();
             f32x4 nz[R];
 #pragma unroll
             for (int rr = 0; rr < R; ++rr)
               nz[rr] = box_muller4(philox4x32_10(rowid[rr], (unsigned)it, (unsigned)kb, TAG_YNOISE, a.k0, a.k1));
+            float xk[DB];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < DB; ++e) {
               const int k = 4 * kb + e;
-              if (k < nd) {
-                BGM_NO_HOIST();
-                const float xk = (EFFECT == 2) ? (k == 0 ? 1.0f : 0.0f) : a.x_values[k];
-                f32x4 a1[R][4];
+              xk[e] = (EFFECT == 2) ? (e == 0 ? 1.0f : 0.0f) : a.x_values[k < nd ? k : nd - 1];
+            }
+            f32x4 a1[DB * R][4];
 #pragma unroll
-                for (int rr = 0; rr < R; ++rr)
+            for (int e = 0; e < DB; ++e)
 #pragma unroll
-                  for (int t = 0; t < 4; ++t)
+              for (int rr = 0; rr < R; ++rr)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) a1[rr][t][r] = lrelu(fmaf(wx[t][r], xk, base[rr][t][r]));
-                float mu[R], sr[R];
-                fh_tail<R>(lds, m.wf2, m.bf2, m.wf3, m.bf3, m.wf4, m.bf4, lane_off, g, j, a1, mu, sr);
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                  for (int r = 0; r < 4; ++r)
+                    a1[e * R + rr][t][r] = lrelu(fmaf(wx[t][r], xk[e], base[rr][t][r]));
+            float mu[DB * R], sr[DB * R];
+            fh_tail<DB * R>(lds, m.wf2, m.bf2, m.wf3, m.bf3, m.wf4, m.bf4, lane_off, g, a1, mu, sr);
+            float yk[DB][R];
+#pragma unroll
+            for (int e = 0; e < DB; ++e)
+#pragma unroll
+              for (int rr = 0; rr < R; ++rr) {
+                const float s2 = (m.sig2_y > 0.0f) ? m.sig2_y : softplus_f(sr[e * R + rr]) + BGM_EPS;
+                yk[e][rr] = a.sample_y ? fmaf(__builtin_sqrtf(s2), nz[rr][e], mu[e * R + rr]) : mu[e * R + rr];
+              }
+            if constexpr (EFFECT == 1) {
+#pragma unroll
+              for (int e = 0; e < DB; ++e) {
                 float tot = 0.0f;
 #pragma unroll
-                for (int rr = 0; rr < R; ++rr) {
-                  const float s2 = (m.sig2_y > 0.0f) ? m.sig2_y : softplus_f(sr[rr]) + BGM_EPS;
-                  const float yk = a.sample_y ? fmaf(__builtin_sqrtf(s2), nz[rr][e], mu[rr]) : mu[rr];
-                  if (EFFECT == 2) ite_acc[rr] += (k == 0) ? yk : -yk;
-                  tot += valid[rr] ? yk : 0.0f;
-                }
-                if constexpr (EFFECT == 1) {
-                  tot = sum_over_j(tot);  // sum over the 16 rows of the lane group
-                  if (lane == 0)
-                    unsafeAtomicAdd(a.adrf_partial + (slot * nd + k) * (long long)a.n_keep + d, tot);
-                }
+                for (int rr = 0; rr < R; ++rr) tot += valid[rr] ? yk[e][rr] : 0.0f;
+                tot = sum_over_j_to_lane15(tot);  // values are valid in lane group 0 -> lane 15
+                const int k = 4 * kb + e;
+                if (lane == 15 && k < nd)
+                  unsafeAtomicAdd(a.adrf_partial + (slot * nd + k) * (long long)a.n_keep + d, tot);
               }
-            }
-          }
-          if constexpr (EFFECT == 2) {
+            } else {
 #pragma unroll
-            for (int rr = 0; rr < R; ++rr) {
-              const long long row = row0 + 16 * rr + j;
-              if (g == 0 && row < n) a.ite[row * (long long)a.n_keep + d] = ite_acc[rr];
+              for (int rr = 0; rr < R; ++rr) {
+                const long long row = row0 + 16 * rr + j;
+                if (g == 0 && row < n) a.ite[row * (long long)a.n_keep + d] = yk[0][rr] - yk[1][rr];
+              }
             }
           }
         }

@@ -14,7 +14,8 @@ Counter layout  ctr = (row, iteration, call, purpose),  key = (seed_lo, seed_hi)
 purpose tags
   0  initial state      z0      ~ N(0,1)            (base.py:842)
   1  MH proposal noise  eps     ~ N(0,1)            (base.py:862)
-  2  MH accept uniform  u       ~ U(0,1)            (base.py:870)
+  2  MH accept uniform  u       ~ U(0,1)            (base.py:870); u(it) = word (it & 3)
+                                                    of the call with iteration field it >> 2
   3  outcome noise      eps_y   ~ N(0,1)            (base.py:704-706,753-755)
   4  HMC momentum, 5 HMC accept uniform, 6 posterior-predictive noise (BGM)
 
@@ -94,11 +95,12 @@ def normals(rows, iteration, n_feat, tag, seed):
 
 
 def uniforms(rows, iteration, tag, seed, call=0):
-    """[len(rows)] float32 uniforms in (0,1): word 0 of call `call`."""
+    """[len(rows)] float32 uniforms in (0,1) for `iteration`: word (iteration & 3) of
+    Philox(row, iteration >> 2, call, tag) -- one Philox call serves four iterations."""
     rows = np.asarray(rows, dtype=np.uint32)
     k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
-    x0, _, _, _ = philox4x32_10(rows, iteration, call, tag, k0, k1)
-    return u01_open(x0)
+    words = philox4x32_10(rows, int(iteration) >> 2, call, tag, k0, k1)
+    return u01_open(words[int(iteration) & 3])
 
 
 def normals_seq(rows, iteration, n_feat, tag, seed):
