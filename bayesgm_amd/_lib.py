@@ -64,6 +64,18 @@ SYMBOLS = {
     "bgm_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "bgm_timing_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int]),
     "bgm_causal_mh_info": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(MhInfo)]),
+    "bgm_causal_evaluate": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int64, C.c_void_p, C.c_int32,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bgm_causal_evaluate_slots": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]),
+    "bgm_causal_fit_begin": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "bgm_causal_fit_n_params": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "bgm_causal_fit_theta_grad": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int64, C.c_int32, C.c_int32,
+                                            C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bgm_causal_fit_theta_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
+    "bgm_causal_fit_z_step": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_int32, C.c_float,
+                                        C.c_int32, C.c_void_p, C.c_void_p]),
+    "bgm_causal_get_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "bgm_causal_fit_end": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

@@ -7,6 +7,7 @@
 
 #include "../../include/bgm_hip.h"
 #include "causal_kernels.h"
+#include "fit_types.h"
 
 void bgm_set_error(const std::string &msg);
 
@@ -53,6 +54,18 @@ struct bgm_handle {
   float *eblob_dev = nullptr;
   size_t eblob_cap = 0;
   bool eblob_valid = false;
+  // fit state (device)
+  bool fit_active = false;
+  long long fit_rows = 0;
+  int fit_bcap = 0, n_params = 0, n_slices_cap = 0, rows_per_slice = 0;
+  long long t_theta = 0, t_z = 0;
+  float *theta_dev = nullptr, *m1_dev = nullptr, *m2_dev = nullptr, *bblob_dev = nullptr, *ws_dev = nullptr,
+        *partial_dev = nullptr;
+  int *tables_dev = nullptr;  // fwd_dst | fwd_dst2 | bwd_dst | grad_src, n_params each
+  int *pos_dev = nullptr;
+  FitMeta fit_meta{};
+  FitWs fit_ws{};
+  DwArgs dw{};
   // timing
   bool timing = false;
   struct Ev { hipEvent_t a, b; int kind; };
@@ -62,6 +75,7 @@ struct bgm_handle {
 };
 
 int bgm_causal_build_blob(bgm_handle *h, hipStream_t stream);
+int causal_pack_forward(bgm_handle *h, const HostNet &G, const HostNet &F, const HostNet &H, std::vector<float> &blob);
 
 // ---- packing into MFMA fragment order (layout documented in bgm_device.h)
 // rowmap(rho) -> source input-feature row of W (or -1 for a zero row)

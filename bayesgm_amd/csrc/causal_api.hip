@@ -34,6 +34,7 @@ extern "C" int bgm_destroy(bgm_handle *h) {
   hipSetDevice(h->device);
   if (h->blob_dev) hipFree(h->blob_dev);
   if (h->eblob_dev) hipFree(h->eblob_dev);
+  bgm_causal_fit_end(h, nullptr);
   for (auto &e : h->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   delete h;
   return BGM_OK;
@@ -108,10 +109,10 @@ extern "C" int bgm_causal_set_weights(bgm_handle *h, int net_id, const float *th
 // ---------------------------------------------------------------------------
 // packing (layout documented in bgm_device.h)
 // ---------------------------------------------------------------------------
-int bgm_causal_build_blob(bgm_handle *h, hipStream_t stream) {
-  if (h->blob_valid) return BGM_OK;
-  for (int id : {BGM_NET_G, BGM_NET_F, BGM_NET_H})
-    if (!h->nets[id].set) { bgm_set_error("weights of g/f/h not all set"); return BGM_E_STATE; }
+// Lay out and fill the forward (LDS) blob from three HostNets (g, f, h).  Also used with
+// "iota" nets to derive the canonical-parameter -> blob-position tables of the fit path.
+int causal_pack_forward(bgm_handle *h, const HostNet &G, const HostNet &F, const HostNet &H,
+                        std::vector<float> &blob) {
   const int q = h->q, p = h->p;
   const int z0 = h->cfg.z_dims[0], z1 = h->cfg.z_dims[1], z2 = h->cfg.z_dims[2];
   const int q1 = q + 1;
@@ -130,7 +131,6 @@ int bgm_causal_build_blob(bgm_handle *h, hipStream_t stream) {
   m.w1g = take(16 * KT1 * 64); m.w1f = take(16 * KT1 * 64); m.w1h = take(16 * KT1 * 64);
   m.b1g = take(64); m.b1f = take(64); m.b1h = take(64);
   m.wg = take(m.n_gh * 4096); m.bg = take(m.n_gh * 64);
-  // NTL_alloc: the kernel variant may be compiled for more tiles than needed
   m.wgl = take(64 * 16 * NTL); m.bgl = take(16 * NTL);
   m.wf2 = take(64 * 32); m.bf2 = take(32); m.wf3 = take(32 * 16); m.bf3 = take(16); m.wf4 = take(16 * 16); m.bf4 = take(16);
   m.wh2 = take(64 * 32); m.bh2 = take(32); m.wh3 = take(32 * 16); m.bh3 = take(16); m.wh4 = take(16 * 16); m.bh4 = take(16);
@@ -140,10 +140,8 @@ int bgm_causal_build_blob(bgm_handle *h, hipStream_t stream) {
     bgm_set_error("model does not fit the 160 KiB LDS-resident layout (" + std::to_string(m.total * 4) + " B); p <= 207 with default widths");
     return BGM_E_UNSUPPORTED;
   }
-  std::vector<float> blob(m.total, 0.0f);
-  const HostNet &G = h->nets[BGM_NET_G], &F = h->nets[BGM_NET_F], &H = h->nets[BGM_NET_H];
+  blob.assign(m.total, 0.0f);
   auto ident = [](int rho) { return rho; };
-  // first layers: shared extended input [z (q), x]
   pack_layer(blob, m.w1g, G.W(0), q, 64, KT1, 4, [&](int rho) { int f = l1_feature(rho); return f < q ? f : -1; });
   pack_layer(blob, m.w1f, F.W(0), z0 + z1 + 1, 64, KT1, 4, [&](int rho) {
     int f = l1_feature(rho);
@@ -172,7 +170,16 @@ int bgm_causal_build_blob(bgm_handle *h, hipStream_t stream) {
   pack_layer(blob, m.wh3, H.W(2), 32, 8, 2, 1, ident); pack_bias(blob, m.bh3, H.b(2), 8, 1);
   pack_layer(blob, m.wh4, H.W(3), 8, 2, 1, 1, ident); pack_bias(blob, m.bh4, H.b(3), 2, 1);
   for (int o = 0; o < 64; ++o) blob[m.wxf + o] = F.W(0)[(size_t)(z0 + z1) * 64 + o];
+  return BGM_OK;
+}
 
+int bgm_causal_build_blob(bgm_handle *h, hipStream_t stream) {
+  if (h->blob_valid) return BGM_OK;
+  for (int id : {BGM_NET_G, BGM_NET_F, BGM_NET_H})
+    if (!h->nets[id].set) { bgm_set_error("weights of g/f/h not all set"); return BGM_E_STATE; }
+  std::vector<float> blob;
+  int rc = causal_pack_forward(h, h->nets[BGM_NET_G], h->nets[BGM_NET_F], h->nets[BGM_NET_H], blob);
+  if (rc) return rc;
   BGM_HIP_CHECK(hipSetDevice(h->device));
   if (h->blob_cap < blob.size()) {
     if (h->blob_dev) BGM_HIP_CHECK(hipFree(h->blob_dev));
@@ -318,6 +325,53 @@ extern "C" int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *a, void *stre
       h->events.push_back({e0, e1, segs[s].effect});
     }
   }
+  return BGM_OK;
+}
+
+template <int EFFECT>
+static int launch_eval(bgm_handle *h, const CausalEvalKArgs &ka, int grid, int lds, hipStream_t stream) {
+  int rc;
+#define X(KT1_, KSL1_, NTL_)                                                                   \
+  if (h->KT1 == KT1_ && h->KSL1 == KSL1_ && h->NTL == NTL_) {                                  \
+    auto k = causal_eval_kernel<KT1_, KSL1_, NTL_, MH_WAVES, EFFECT>;                          \
+    rc = set_lds(k, lds);                                                                      \
+    if (rc) return rc;                                                                         \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * MH_WAVES), lds, stream, ka);                   \
+    BGM_HIP_CHECK(hipGetLastError());                                                          \
+    return BGM_OK;                                                                             \
+  }
+  BGM_CAUSAL_VARIANTS(X)
+#undef X
+  bgm_set_error("no compiled evaluate kernel variant for this shape");
+  return BGM_E_UNSUPPORTED;
+}
+
+extern "C" int bgm_causal_evaluate(bgm_handle *h, const float *x, const float *y, const float *v, const float *z,
+                                   int64_t n, const float *x_values, int32_t n_doses, double *sums,
+                                   float *adrf_partial, float *ite, void *stream_) {
+  if (!h || !h->configured) { bgm_set_error("bgm_causal_evaluate: handle not configured"); return BGM_E_STATE; }
+  if (n <= 0) return BGM_OK;
+  if (!x || !y || !v || !z || !sums) { bgm_set_error("bgm_causal_evaluate: NULL pointer"); return BGM_E_INVALID; }
+  const bool binary = h->cfg.binary_treatment != 0;
+  if (binary && !ite) { bgm_set_error("bgm_causal_evaluate: ite_dev required for binary treatment"); return BGM_E_INVALID; }
+  if (!binary && (!x_values || n_doses <= 0 || !adrf_partial)) { bgm_set_error("bgm_causal_evaluate: x_values / adrf_partial required"); return BGM_E_INVALID; }
+  hipStream_t stream = (hipStream_t)stream_;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  int rc = bgm_causal_build_blob(h, stream);
+  if (rc) return rc;
+  CausalEvalKArgs ka{};
+  ka.blob = h->blob_dev; ka.x = x; ka.y = y; ka.v = v; ka.z = z; ka.n = n; ka.sums = sums;
+  ka.x_values = x_values; ka.n_doses = binary ? 2 : n_doses; ka.adrf_partial = adrf_partial; ka.ite = ite; ka.m = h->meta;
+  const int64_t tiles = (n + 15) / 16;
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((tiles + MH_WAVES - 1) / MH_WAVES, h->n_cus));
+  const int lds = h->meta.total * 4;
+  return binary ? launch_eval<2>(h, ka, grid, lds, stream) : launch_eval<1>(h, ka, grid, lds, stream);
+}
+
+extern "C" int bgm_causal_evaluate_slots(bgm_handle *h, int64_t n, int32_t *n_slots) {
+  if (!h || !n_slots) { bgm_set_error("bgm_causal_evaluate_slots: NULL"); return BGM_E_INVALID; }
+  const int64_t tiles = (n + 15) / 16;
+  *n_slots = (int)std::max<int64_t>(1, std::min<int64_t>((tiles + MH_WAVES - 1) / MH_WAVES, h->n_cus)) * MH_WAVES;
   return BGM_OK;
 }
 

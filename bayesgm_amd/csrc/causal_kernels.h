@@ -304,6 +304,86 @@ __global__ __launch_bounds__(64 * WAVES) void causal_logpost_kernel(const float 
 }
 
 // ---------------------------------------------------------------------------
+// infer_from_latent_posterior (base.py:671-763) for the R x 16 states held by one wave:
+// f first layer once at x = 0, doses as rank-1 updates, DB doses per pass.
+//   EFFECT 1: adrf_slot[k * n_keep + d] += sum over the wave's valid rows of y_k
+//   EFFECT 2: ite[row * n_keep + d] = y(x=1) - y(x=0)
+// ---------------------------------------------------------------------------
+template <int KT1, int KSL1, int R, int EFFECT>
+__device__ __forceinline__ void causal_effects(const float *lds, const CausalMeta &m, int lane_off, int g, int j,
+                                               int lane, const f32x4 (&zs)[R][KT1], const unsigned (&rowid)[R],
+                                               const bool (&valid)[R], long long row0, long long n, unsigned it,
+                                               long long d, int n_keep, int sample_y, int n_doses,
+                                               const float *x_values, float *adrf_slot, float *ite, unsigned k0,
+                                               unsigned k1) {
+  BGM_NO_HOIST();
+  f32x4 z0in[R][KT1];
+#pragma unroll
+  for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+    for (int t = 0; t < KT1; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) z0in[rr][t][r] = (16 * t + 4 * r + g == m.q) ? 0.0f : zs[rr][t][r];
+  f32x4 base[R][4];
+  dense<KT1, KSL1, 4, R>(lds + m.w1f, lds + m.b1f, lane_off, g, z0in, base);
+  f32x4 wx[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) wx[t] = *reinterpret_cast<const f32x4 *>(lds + m.wxf + 16 * t + 4 * g);
+  const int nd = (EFFECT == 2) ? 2 : n_doses;
+  constexpr int DB = (EFFECT == 2) ? 2 : 4;  // doses evaluated per pass (independent MFMA chains)
+  for (int kb = 0; kb < (nd + 3) / 4; ++kb) {
+    BGM_NO_HOIST();
+    f32x4 nz[R];
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr)
+      nz[rr] = sample_y ? box_muller4(philox4x32_10(rowid[rr], it, (unsigned)kb, TAG_YNOISE, k0, k1))
+                        : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float xk[DB];
+#pragma unroll
+    for (int e = 0; e < DB; ++e) {
+      const int k = 4 * kb + e;
+      xk[e] = (EFFECT == 2) ? (e == 0 ? 1.0f : 0.0f) : x_values[k < nd ? k : nd - 1];
+    }
+    f32x4 a1[DB * R][4];
+#pragma unroll
+    for (int e = 0; e < DB; ++e)
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a1[e * R + rr][t][r] = lrelu(fmaf(wx[t][r], xk[e], base[rr][t][r]));
+    float mu[DB * R], sr[DB * R];
+    fh_tail<DB * R>(lds, m.wf2, m.bf2, m.wf3, m.bf3, m.wf4, m.bf4, lane_off, g, a1, mu, sr);
+    float yk[DB][R];
+#pragma unroll
+    for (int e = 0; e < DB; ++e)
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr) {
+        const float s2 = (m.sig2_y > 0.0f) ? m.sig2_y : softplus_f(sr[e * R + rr]) + BGM_EPS;
+        yk[e][rr] = sample_y ? fmaf(__builtin_sqrtf(s2), nz[rr][e], mu[e * R + rr]) : mu[e * R + rr];
+      }
+    if constexpr (EFFECT == 1) {
+#pragma unroll
+      for (int e = 0; e < DB; ++e) {
+        float tot = 0.0f;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) tot += valid[rr] ? yk[e][rr] : 0.0f;
+        tot = sum_over_j_to_lane15(tot);  // values are valid in lane group 0 -> lane 15
+        const int k = 4 * kb + e;
+        if (lane == 15 && k < nd) unsafeAtomicAdd(adrf_slot + (long long)k * n_keep + d, tot);
+      }
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr) {
+        const long long row = row0 + 16 * rr + j;
+        if (g == 0 && row < n) ite[row * (long long)n_keep + d] = yk[0][rr] - yk[1][rr];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Persistent random-walk Metropolis-Hastings over a segment of iterations.
 // ---------------------------------------------------------------------------
 template <int KT1, int KSL1, int NTL, int R, int WAVES, int EFFECT>
@@ -417,75 +497,10 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
           }
         }
         if constexpr (EFFECT != 0) {
-          BGM_NO_HOIST();
-          // ---- infer_from_latent_posterior (base.py:671-763), fused.
-          // f first layer: pre-activation at x = 0, then rank-1 update per dose.
-          f32x4 z0in[R][KT1];
-#pragma unroll
-          for (int rr = 0; rr < R; ++rr)
-#pragma unroll
-            for (int t = 0; t < KT1; ++t)
-#pragma unroll
-              for (int r = 0; r < 4; ++r)
-                z0in[rr][t][r] = (16 * t + 4 * r + g == m.q) ? 0.0f : zs[rr][t][r];
-          f32x4 base[R][4];
-          dense<KT1, KSL1, 4, R>(lds + m.w1f, lds + m.b1f, lane_off, g, z0in, base);
-          f32x4 wx[4];
-#pragma unroll
-          for (int t = 0; t < 4; ++t) wx[t] = *reinterpret_cast<const f32x4 *>(lds + m.wxf + 16 * t + 4 * g);
-          const int nd = (EFFECT == 2) ? 2 : a.n_doses;
-          constexpr int DB = (EFFECT == 2) ? 2 : 4;  // doses evaluated per pass (independent MFMA chains)
-          for (int kb = 0; kb < (nd + 3) / 4; ++kb) {
-            BGM_NO_HOIST();
-            f32x4 nz[R];
-#pragma unroll
-            for (int rr = 0; rr < R; ++rr)
-              nz[rr] = box_muller4(philox4x32_10(rowid[rr], (unsigned)it, (unsigned)kb, TAG_YNOISE, a.k0, a.k1));
-            float xk[DB];
-#pragma unroll
-            for (int e = 0; e < DB; ++e) {
-              const int k = 4 * kb + e;
-              xk[e] = (EFFECT == 2) ? (e == 0 ? 1.0f : 0.0f) : a.x_values[k < nd ? k : nd - 1];
-            }
-            f32x4 a1[DB * R][4];
-#pragma unroll
-            for (int e = 0; e < DB; ++e)
-#pragma unroll
-              for (int rr = 0; rr < R; ++rr)
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                  for (int r = 0; r < 4; ++r)
-                    a1[e * R + rr][t][r] = lrelu(fmaf(wx[t][r], xk[e], base[rr][t][r]));
-            float mu[DB * R], sr[DB * R];
-            fh_tail<DB * R>(lds, m.wf2, m.bf2, m.wf3, m.bf3, m.wf4, m.bf4, lane_off, g, a1, mu, sr);
-            float yk[DB][R];
-#pragma unroll
-            for (int e = 0; e < DB; ++e)
-#pragma unroll
-              for (int rr = 0; rr < R; ++rr) {
-                const float s2 = (m.sig2_y > 0.0f) ? m.sig2_y : softplus_f(sr[e * R + rr]) + BGM_EPS;
-                yk[e][rr] = a.sample_y ? fmaf(__builtin_sqrtf(s2), nz[rr][e], mu[e * R + rr]) : mu[e * R + rr];
-              }
-            if constexpr (EFFECT == 1) {
-#pragma unroll
-              for (int e = 0; e < DB; ++e) {
-                float tot = 0.0f;
-#pragma unroll
-                for (int rr = 0; rr < R; ++rr) tot += valid[rr] ? yk[e][rr] : 0.0f;
-                tot = sum_over_j_to_lane15(tot);  // values are valid in lane group 0 -> lane 15
-                const int k = 4 * kb + e;
-                if (lane == 15 && k < nd)
-                  unsafeAtomicAdd(a.adrf_partial + (slot * nd + k) * (long long)a.n_keep + d, tot);
-              }
-            } else {
-#pragma unroll
-              for (int rr = 0; rr < R; ++rr) {
-                const long long row = row0 + 16 * rr + j;
-                if (g == 0 && row < n) a.ite[row * (long long)a.n_keep + d] = yk[0][rr] - yk[1][rr];
-              }
-            }
-          }
+          causal_effects<KT1, KSL1, R, EFFECT>(lds, m, lane_off, g, j, lane, zs, rowid, valid, row0, n, (unsigned)it, d,
+                                                a.n_keep, a.sample_y, a.n_doses, a.x_values,
+                                                a.adrf_partial + slot * (long long)((EFFECT == 2) ? 2 : a.n_doses) * a.n_keep,
+                                                a.ite, a.k0, a.k1);
         }
       }
     }
@@ -496,5 +511,98 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
       const long long row = row0 + 16 * rr + j;
       if (g == 0 && row < n) a.logp[row] = lp[rr];
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// evaluate (base.py:534-570): reconstruction errors of g, h, f at the given latent matrix and the
+// plug-in causal estimate (ITE per row, or the dose-response curve summed over rows).
+// sums[0..2] += sum |v - mu_v|^2, sum (x - x_pred)^2, sum (y - mu_y)^2   (x_pred = sigmoid(logit) if binary)
+// ---------------------------------------------------------------------------
+struct CausalEvalKArgs {
+  const float *blob, *x, *y, *v, *z;
+  long long n;
+  double *sums;
+  const float *x_values;
+  int n_doses;
+  float *adrf_partial;   // [n_slots][n_doses]
+  float *ite;            // [n]
+  CausalMeta m;
+};
+
+template <int KT1, int KSL1, int NTL, int WAVES, int EFFECT>
+__global__ __launch_bounds__(64 * WAVES) void causal_eval_kernel(CausalEvalKArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const CausalMeta &m = a.m;
+  lds_fill(lds, a.blob, m.total);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4, lane_off = 64 * g + j;
+  const long long n = a.n, n_tiles = (n + 15) / 16;
+  const long long slot = (long long)blockIdx.x * WAVES + wave;
+  double sv = 0.0, sx = 0.0, sy = 0.0;
+  for (long long tile = slot; tile < n_tiles; tile += (long long)gridDim.x * WAVES) {
+    BGM_NO_HOIST();
+    const long long row0 = tile * 16;
+    long long row = row0 + j;
+    bool valid[1] = {row < n};
+    row = row < n ? row : n - 1;
+    float xr[1] = {a.x[row]}, yr[1] = {a.y[row]};
+    unsigned rowid[1] = {0u};
+    f32x4 vreg[1][NTL];
+    load_v_rows<NTL, 1>(a.v, n, m.p, row0, j, g, vreg);
+    f32x4 zin[1][KT1];
+    load_z_rows<KT1, 1>(a.z, n, m.q, row0, j, g, xr, zin);
+    float ssq[1] = {0.0f}, sraw[1] = {0.0f};
+    {
+      f32x4 h[1][4];
+      dense<KT1, KSL1, 4, 1>(lds + m.w1g, lds + m.b1g, lane_off, g, zin, h);
+      lrelu_inplace<4, 1>(h);
+      for (int l = 0; l < m.n_gh; ++l) {
+        BGM_NO_HOIST();
+        f32x4 h2[1][4];
+        dense<4, 4, 4, 1>(lds + m.wg + l * 4096, lds + m.bg + l * 64, lane_off, g, h, h2);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[0][t][r] = lrelu(h2[0][t][r]);
+      }
+      const int pc = m.p - 16 * (NTL - 1);
+      g_last_groups<0, 4, NTL, 1>(lds + m.wgl, lds + m.bgl, lane_off, g, pc - 4 * g, h, vreg, ssq, sraw);
+    }
+    float mu_y[1], sr_y[1], mu_x[1], sr_x[1];
+    {
+      f32x4 a1[1][4];
+      dense<KT1, KSL1, 4, 1>(lds + m.w1f, lds + m.b1f, lane_off, g, zin, a1);
+      lrelu_inplace<4, 1>(a1);
+      fh_tail<1>(lds, m.wf2, m.bf2, m.wf3, m.bf3, m.wf4, m.bf4, lane_off, g, a1, mu_y, sr_y);
+    }
+    {
+      f32x4 a1[1][4];
+      dense<KT1, KSL1, 4, 1>(lds + m.w1h, lds + m.b1h, lane_off, g, zin, a1);
+      lrelu_inplace<4, 1>(a1);
+      fh_tail<1>(lds, m.wh2, m.bh2, m.wh3, m.bh3, m.wh4, m.bh4, lane_off, g, a1, mu_x, sr_x);
+    }
+    if (valid[0]) {
+      sv += (double)ssq[0];   // every lane group holds its own partial of |v - mu|^2
+      if (g == 0) {
+        const float xp = m.binary ? 1.0f / (1.0f + expf(-mu_x[0])) : mu_x[0];
+        sx += (double)((xr[0] - xp) * (xr[0] - xp));
+        sy += (double)((yr[0] - mu_y[0]) * (yr[0] - mu_y[0]));
+      }
+    }
+    if constexpr (EFFECT != 0)
+      causal_effects<KT1, KSL1, 1, EFFECT>(lds, m, lane_off, g, j, lane, zin, rowid, valid, row0, n, 0u, 0, 1, 0,
+                                           a.n_doses, a.x_values, a.adrf_partial + slot * (long long)a.n_doses,
+                                           a.ite, 0u, 0u);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    sv += __shfl_xor(sv, off);
+    sx += __shfl_xor(sx, off);
+    sy += __shfl_xor(sy, off);
+  }
+  if (lane == 0) {
+    atomicAdd(a.sums + 0, sv);
+    atomicAdd(a.sums + 1, sx);
+    atomicAdd(a.sums + 2, sy);
   }
 }

@@ -1,0 +1,378 @@
+// fit_api.hip -- C-ABI entry points of the CausalBGM iterative-update step functions.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+#include "bgm_host.h"
+#include "fit_kernels.h"
+
+static constexpr int FIT_WAVES = 8;
+static constexpr float ADAM_B1 = 0.9f, ADAM_B2 = 0.99f, ADAM_EPS = 1e-7f;  // causalbgm/base.py:90-93
+
+// Transposed ("backward") packing: a forward layer W [n_in x n_out] becomes the layer
+// Wt [rows = out features (KT_b tiles)] -> [cols = in features (NT_b tiles)];  colmap(c) gives the
+// canonical input row of W for packed output column c (or -1).
+template <class ColMap>
+static void pack_layer_t(std::vector<float> &blob, int off, const float *W, int n_in, int n_out, int KT_b,
+                         int NT_b, ColMap colmap) {
+  const int K_ROWS = 16 * KT_b;
+  for (int T0 = 0; T0 < NT_b;) {
+    const int GS = group_size(NT_b - T0);
+    float *base = blob.data() + off + K_ROWS * 16 * T0;
+    for (int rho = 0; rho < K_ROWS; ++rho)   // rho = output feature of the forward layer
+      for (int j = 0; j < 16; ++j)
+        for (int u = 0; u < GS; ++u) {
+          const int src = colmap(16 * (T0 + u) + j);
+          float val = 0.0f;
+          if (src >= 0 && src < n_in && rho < n_out) val = W[(size_t)src * n_out + rho];
+          base[(rho * 16 + j) * GS + u] = val;
+        }
+    T0 += GS;
+  }
+}
+
+static void fit_layout_backward(bgm_handle *h, FitMeta &bm) {
+  const int KT1 = h->KT1, NTL = h->NTL;
+  int off = 0;
+  auto take = [&](int n) { int o = off; off += (n + 3) / 4 * 4; return o; };
+  bm.w1g = take(64 * 16 * KT1); bm.w1f = take(64 * 16 * KT1); bm.w1h = take(64 * 16 * KT1);
+  bm.wg = take(h->meta.n_gh * 4096);
+  bm.wgl = take(16 * NTL * 64);
+  bm.wf2 = take(32 * 64); bm.wf3 = take(16 * 32); bm.wf4 = take(16 * 16);
+  bm.wh2 = take(32 * 64); bm.wh3 = take(16 * 32); bm.wh4 = take(16 * 16);
+  bm.total = off;
+}
+
+static void causal_pack_backward(bgm_handle *h, const HostNet &G, const HostNet &F, const HostNet &H,
+                                 const FitMeta &bm, std::vector<float> &blob) {
+  const int q = h->q, p = h->p, KT1 = h->KT1, NTL = h->NTL;
+  const int z0 = h->cfg.z_dims[0], z1 = h->cfg.z_dims[1], z2 = h->cfg.z_dims[2];
+  blob.assign(bm.total, 0.0f);
+  auto ident = [](int c) { return c; };
+  // first layers: packed output column c <-> extended input feature l1_feature(c)
+  pack_layer_t(blob, bm.w1g, G.W(0), q, 64, 4, KT1, [&](int c) { int f = l1_feature(c); return f < q ? f : -1; });
+  pack_layer_t(blob, bm.w1f, F.W(0), z0 + z1 + 1, 64, 4, KT1, [&](int c) {
+    int f = l1_feature(c);
+    if (f < z0 + z1) return f;
+    if (f == q) return z0 + z1;
+    return -1;
+  });
+  pack_layer_t(blob, bm.w1h, H.W(0), z0 + z2, 64, 4, KT1, [&](int c) {
+    int f = l1_feature(c);
+    if (f < z0) return f;
+    if (f >= z0 + z1 && f < z0 + z1 + z2) return z0 + (f - z0 - z1);
+    return -1;
+  });
+  for (int l = 0; l < h->meta.n_gh; ++l) pack_layer_t(blob, bm.wg + l * 4096, G.W(1 + l), 64, 64, 4, 4, ident);
+  const int LG = (int)G.dims.size() - 2;
+  pack_layer_t(blob, bm.wgl, G.W(LG), 64, p + 1, NTL, 4, ident);
+  pack_layer_t(blob, bm.wf2, F.W(1), 64, 32, 2, 4, ident);
+  pack_layer_t(blob, bm.wf3, F.W(2), 32, 8, 1, 2, ident);
+  pack_layer_t(blob, bm.wf4, F.W(3), 8, 2, 1, 1, ident);
+  pack_layer_t(blob, bm.wh2, H.W(1), 64, 32, 2, 4, ident);
+  pack_layer_t(blob, bm.wh3, H.W(2), 32, 8, 1, 2, ident);
+  pack_layer_t(blob, bm.wh4, H.W(3), 8, 2, 1, 1, ident);
+}
+
+static void fit_free(bgm_handle *h) {
+  for (void *p : {(void *)h->theta_dev, (void *)h->m1_dev, (void *)h->m2_dev, (void *)h->bblob_dev, (void *)h->ws_dev,
+                  (void *)h->partial_dev, (void *)h->tables_dev, (void *)h->pos_dev})
+    if (p) hipFree(p);
+  h->theta_dev = h->m1_dev = h->m2_dev = h->bblob_dev = h->ws_dev = h->partial_dev = nullptr;
+  h->tables_dev = h->pos_dev = nullptr;
+  h->fit_active = false;
+}
+
+static HostNet iota_net(const HostNet &n, int base) {
+  HostNet r;
+  r.dims = n.dims;
+  r.theta.resize(n.count());
+  for (size_t i = 0; i < r.theta.size(); ++i) r.theta[i] = (float)(base + (int)i + 1);  // exact below 2^24
+  r.set = true;
+  return r;
+}
+
+extern "C" int bgm_causal_fit_n_params(bgm_handle *h, int64_t *n_params) {
+  if (!h || !h->configured || !n_params) { bgm_set_error("bgm_causal_fit_n_params: bad argument"); return BGM_E_INVALID; }
+  *n_params = (int64_t)(h->nets[BGM_NET_G].count() + h->nets[BGM_NET_F].count() + h->nets[BGM_NET_H].count());
+  return BGM_OK;
+}
+
+extern "C" int bgm_causal_fit_begin(bgm_handle *h, int64_t n_rows, int32_t max_batch, void *stream_) {
+  if (!h || !h->configured) { bgm_set_error("bgm_causal_fit_begin: handle not configured"); return BGM_E_STATE; }
+  if (n_rows <= 0 || max_batch <= 0) { bgm_set_error("bgm_causal_fit_begin: n_rows / max_batch must be positive"); return BGM_E_INVALID; }
+  hipStream_t stream = (hipStream_t)stream_;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  int rc = bgm_causal_build_blob(h, stream);   // forward blob + meta from the host weights
+  if (rc) return rc;
+  fit_free(h);
+  const HostNet &G = h->nets[BGM_NET_G], &F = h->nets[BGM_NET_F], &H = h->nets[BGM_NET_H];
+  const int ng = (int)G.count(), nf = (int)F.count(), nh = (int)H.count();
+  const int np = ng + nf + nh;
+  if (np >= (1 << 24)) { bgm_set_error("bgm_causal_fit_begin: too many parameters"); return BGM_E_UNSUPPORTED; }
+  h->n_params = np;
+  const int KT1 = h->KT1, NTL = h->NTL, n_gh = h->meta.n_gh, q = h->q;
+  // ---- canonical theta on the device
+  std::vector<float> theta(np);
+  std::copy(G.theta.begin(), G.theta.end(), theta.begin());
+  std::copy(F.theta.begin(), F.theta.end(), theta.begin() + ng);
+  std::copy(H.theta.begin(), H.theta.end(), theta.begin() + ng + nf);
+  BGM_HIP_CHECK(hipMalloc(&h->theta_dev, sizeof(float) * np));
+  BGM_HIP_CHECK(hipMalloc(&h->m1_dev, sizeof(float) * np));
+  BGM_HIP_CHECK(hipMalloc(&h->m2_dev, sizeof(float) * np));
+  BGM_HIP_CHECK(hipMemcpy(h->theta_dev, theta.data(), sizeof(float) * np, hipMemcpyHostToDevice));
+  BGM_HIP_CHECK(hipMemset(h->m1_dev, 0, sizeof(float) * np));
+  BGM_HIP_CHECK(hipMemset(h->m2_dev, 0, sizeof(float) * np));
+  h->t_theta = 0; h->t_z = 0;
+  // ---- transposed blob
+  fit_layout_backward(h, h->fit_meta);
+  if ((size_t)h->fit_meta.total * 4 > 160 * 1024) { bgm_set_error("transposed weights do not fit in LDS"); return BGM_E_UNSUPPORTED; }
+  std::vector<float> bblob;
+  causal_pack_backward(h, G, F, H, h->fit_meta, bblob);
+  BGM_HIP_CHECK(hipMalloc(&h->bblob_dev, sizeof(float) * bblob.size()));
+  BGM_HIP_CHECK(hipMemcpy(h->bblob_dev, bblob.data(), sizeof(float) * bblob.size(), hipMemcpyHostToDevice));
+  // ---- parameter -> blob position tables, derived by packing iota nets through the same packers
+  HostNet Gi = iota_net(G, 0), Fi = iota_net(F, ng), Hi = iota_net(H, ng + nf);
+  std::vector<float> fidx, bidx;
+  CausalMeta keep = h->meta;
+  rc = causal_pack_forward(h, Gi, Fi, Hi, fidx);
+  h->meta = keep;
+  if (rc) return rc;
+  causal_pack_backward(h, Gi, Fi, Hi, h->fit_meta, bidx);
+  std::vector<int> tables(4 * (size_t)np, -1);
+  int *fwd_dst = tables.data(), *fwd_dst2 = fwd_dst + np, *bwd_dst = fwd_dst2 + np, *grad_src = bwd_dst + np;
+  for (size_t d = 0; d < fidx.size(); ++d) {
+    const int c = (int)fidx[d] - 1;
+    if (c < 0) continue;
+    if (fwd_dst[c] < 0) fwd_dst[c] = (int)d; else fwd_dst2[c] = (int)d;
+  }
+  for (size_t d = 0; d < bidx.size(); ++d) {
+    const int c = (int)bidx[d] - 1;
+    if (c >= 0) bwd_dst[c] = (int)d;
+  }
+  // ---- workspace layout for up to max_batch rows
+  const int B = (max_batch + 15) / 16 * 16;
+  h->fit_bcap = B;
+  FitWs &w = h->fit_ws;
+  std::memset(&w, 0, sizeof(w));
+  w.B = B;
+  long long off = 0;
+  auto wtake = [&](long long n) { long long o = off; off += (n + 3) / 4 * 4; return o; };
+  w.zin = wtake((long long)B * 16 * KT1);
+  w.ag = wtake((long long)(n_gh + 1) * B * 64);
+  w.outg = wtake((long long)B * 16 * NTL);
+  w.af1 = wtake((long long)B * 64); w.af2 = wtake((long long)B * 32); w.af3 = wtake((long long)B * 16); w.outf = wtake((long long)B * 16);
+  w.ah1 = wtake((long long)B * 64); w.ah2 = wtake((long long)B * 32); w.ah3 = wtake((long long)B * 16); w.outh = wtake((long long)B * 16);
+  w.dg = wtake((long long)(n_gh + 1) * B * 64);
+  w.dgl = wtake((long long)B * 16 * NTL);
+  w.df1 = wtake((long long)B * 64); w.df2 = wtake((long long)B * 32); w.df3 = wtake((long long)B * 16); w.df4 = wtake((long long)B * 16);
+  w.dh1 = wtake((long long)B * 64); w.dh2 = wtake((long long)B * 32); w.dh3 = wtake((long long)B * 16); w.dh4 = wtake((long long)B * 16);
+  w.dz = wtake((long long)B * q);
+  w.total = off;
+  BGM_HIP_CHECK(hipMalloc(&h->ws_dev, sizeof(float) * w.total));
+  BGM_HIP_CHECK(hipMemset(h->ws_dev, 0, sizeof(float) * w.total));
+  // ---- weight-gradient GEMM layers + gradient source table
+  DwArgs &dw = h->dw;
+  std::memset(&dw, 0, sizeof(dw));
+  int nl = 0, poff = 0;
+  auto add = [&](long long a_off, long long d_off, int K, int N) {
+    DwLayer &L = dw.layer[nl++];
+    L.a_off = a_off; L.d_off = d_off; L.K = K; L.N = N; L.out_off = poff;
+    poff += K * N + N;
+    return nl - 1;
+  };
+  const int z0 = h->cfg.z_dims[0], z1 = h->cfg.z_dims[1];
+  // maps canonical (layer, in, out) -> partial offset
+  auto fill = [&](const HostNet &net, int base, int layer, int li, auto in_map) {
+    const DwLayer &L = dw.layer[li];
+    const int n_in = net.dims[layer], n_out = net.dims[layer + 1];
+    const int wbase = base + (int)(net.W(layer) - net.theta.data());
+    for (int i = 0; i < n_in; ++i)
+      for (int o = 0; o < n_out; ++o) grad_src[wbase + i * n_out + o] = L.out_off + in_map(i) * L.N + o;
+    const int bbase = base + (int)(net.b(layer) - net.theta.data());
+    for (int o = 0; o < n_out; ++o) grad_src[bbase + o] = L.out_off + L.K * L.N + o;
+  };
+  auto idm = [](int i) { return i; };
+  {
+    int li = add(w.zin, w.dg, 16 * KT1, 64);
+    fill(G, 0, 0, li, idm);
+    for (int l = 1; l <= n_gh; ++l) {
+      li = add(w.ag + (long long)(l - 1) * B * 64, w.dg + (long long)l * B * 64, 64, 64);
+      fill(G, 0, l, li, idm);
+    }
+    li = add(w.ag + (long long)n_gh * B * 64, w.dgl, 64, 16 * NTL);
+    fill(G, 0, n_gh + 1, li, idm);
+    li = add(w.zin, w.df1, 16 * KT1, 64);
+    fill(F, ng, 0, li, [&](int i) { return i < z0 + z1 ? i : q; });
+    li = add(w.af1, w.df2, 64, 32); fill(F, ng, 1, li, idm);
+    li = add(w.af2, w.df3, 32, 16); fill(F, ng, 2, li, idm);
+    li = add(w.af3, w.df4, 16, 16); fill(F, ng, 3, li, idm);
+    li = add(w.zin, w.dh1, 16 * KT1, 64);
+    fill(H, ng + nf, 0, li, [&](int i) { return i < z0 ? i : z0 + z1 + (i - z0); });
+    li = add(w.ah1, w.dh2, 64, 32); fill(H, ng + nf, 1, li, idm);
+    li = add(w.ah2, w.dh3, 32, 16); fill(H, ng + nf, 2, li, idm);
+    li = add(w.ah3, w.dh4, 16, 16); fill(H, ng + nf, 3, li, idm);
+  }
+  if (nl > BGM_MAX_DW_LAYERS) { bgm_set_error("too many layers"); return BGM_E_UNSUPPORTED; }
+  dw.n_layers = nl;
+  dw.partial_stride = (poff + 3) / 4 * 4;
+  h->rows_per_slice = 256;
+  h->n_slices_cap = (B + h->rows_per_slice - 1) / h->rows_per_slice;
+  BGM_HIP_CHECK(hipMalloc(&h->partial_dev, sizeof(float) * dw.partial_stride * h->n_slices_cap));
+  BGM_HIP_CHECK(hipMalloc(&h->tables_dev, sizeof(int) * tables.size()));
+  BGM_HIP_CHECK(hipMemcpy(h->tables_dev, tables.data(), sizeof(int) * tables.size(), hipMemcpyHostToDevice));
+  h->fit_rows = n_rows;
+  BGM_HIP_CHECK(hipMalloc(&h->pos_dev, sizeof(int) * n_rows));
+  BGM_HIP_CHECK(hipMemset(h->pos_dev, 0xFF, sizeof(int) * n_rows));
+  BGM_HIP_CHECK(hipDeviceSynchronize());
+  h->fit_active = true;
+  return BGM_OK;
+}
+
+#define BGM_FIT_VARIANTS(X) X(1, 3, 13) X(2, 1, 7) X(1, 3, 2) X(2, 1, 2)
+
+static int fit_grid(const bgm_handle *h, int B) {
+  const int tiles = (B + 15) / 16;
+  return std::max(1, std::min((tiles + FIT_WAVES - 1) / FIT_WAVES, h->n_cus));
+}
+
+static int launch_fwd_bwd(bgm_handle *h, FitKArgs &ka, hipStream_t stream) {
+  const int grid = fit_grid(h, ka.B);
+#define X(KT1_, KSL1_, NTL_)                                                                           \
+  if (h->KT1 == KT1_ && h->KSL1 == KSL1_ && h->NTL == NTL_) {                                          \
+    auto kf = fit_fwd_kernel<KT1_, KSL1_, NTL_, FIT_WAVES>;                                            \
+    auto kb = fit_bwd_kernel<KT1_, KSL1_, NTL_, FIT_WAVES>;                                            \
+    const int lds_f = h->meta.total * 4, lds_b = h->fit_meta.total * 4;                                \
+    BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, lds_f)); \
+    BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b)); \
+    ka.blob = h->blob_dev;                                                                             \
+    hipLaunchKernelGGL(kf, dim3(grid), dim3(64 * FIT_WAVES), lds_f, stream, ka);                       \
+    BGM_HIP_CHECK(hipGetLastError());                                                                  \
+    ka.blob = h->bblob_dev;                                                                            \
+    ka.loss = nullptr;                                                                                 \
+    hipLaunchKernelGGL(kb, dim3(grid), dim3(64 * FIT_WAVES), lds_b, stream, ka);                       \
+    BGM_HIP_CHECK(hipGetLastError());                                                                  \
+    return BGM_OK;                                                                                     \
+  }
+  BGM_FIT_VARIANTS(X)
+#undef X
+  bgm_set_error("no compiled fit kernel variant for this shape");
+  return BGM_E_UNSUPPORTED;
+}
+
+static int fit_check(bgm_handle *h, const void *x, const void *y, const void *v, const void *z, int batch, int bg, const char *who) {
+  if (!h || !h->fit_active) { bgm_set_error(std::string(who) + ": call bgm_causal_fit_begin first"); return BGM_E_STATE; }
+  if (!x || !y || !v || !z) { bgm_set_error(std::string(who) + ": NULL data pointer"); return BGM_E_INVALID; }
+  if (batch <= 0 || batch > h->fit_bcap || bg < batch) { bgm_set_error(std::string(who) + ": batch out of range (max_batch of fit_begin)"); return BGM_E_INVALID; }
+  return BGM_OK;
+}
+
+extern "C" int bgm_causal_fit_theta_grad(bgm_handle *h, const float *x, const float *y, const float *v,
+                                         const float *data_z, const int32_t *idx, int64_t row_lo, int32_t batch,
+                                         int32_t batch_global, float *grad, double *loss, void *stream_) {
+  int rc = fit_check(h, x, y, v, data_z, batch, batch_global, "bgm_causal_fit_theta_grad");
+  if (rc) return rc;
+  if (!grad) { bgm_set_error("bgm_causal_fit_theta_grad: grad_dev is NULL"); return BGM_E_INVALID; }
+  hipStream_t stream = (hipStream_t)stream_;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  FitKArgs ka{};
+  ka.m = h->meta; ka.bm = h->fit_meta; ka.ws = h->fit_ws; ka.wsp = h->ws_dev;
+  ka.x = x; ka.y = y; ka.v = v; ka.data_z = data_z; ka.idx = idx; ka.row_lo = row_lo; ka.B = batch;
+  ka.inv_B = 1.0f / (float)batch_global; ka.z_mode = 0; ka.loss = loss;
+  rc = launch_fwd_bwd(h, ka, stream);
+  if (rc) return rc;
+  DwArgs dw = h->dw;
+  dw.ws = h->ws_dev; dw.partial = h->partial_dev; dw.B = batch; dw.rows_per_slice = h->rows_per_slice;
+  const int n_slices = (batch + h->rows_per_slice - 1) / h->rows_per_slice;
+  hipLaunchKernelGGL(fit_dw_kernel, dim3(n_slices, dw.n_layers), dim3(256), 0, stream, dw);
+  BGM_HIP_CHECK(hipGetLastError());
+  const int np = h->n_params;
+  hipLaunchKernelGGL(fit_grad_reduce_kernel, dim3((np + 255) / 256), dim3(256), 0, stream, h->partial_dev,
+                     dw.partial_stride, n_slices, h->tables_dev + 3 * (size_t)np, np, grad);
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+extern "C" int bgm_causal_fit_theta_apply(bgm_handle *h, const float *grad, float lr_theta, void *stream_) {
+  if (!h || !h->fit_active) { bgm_set_error("bgm_causal_fit_theta_apply: call bgm_causal_fit_begin first"); return BGM_E_STATE; }
+  if (!grad) { bgm_set_error("bgm_causal_fit_theta_apply: grad_dev is NULL"); return BGM_E_INVALID; }
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  h->t_theta += 1;
+  const double t = (double)h->t_theta;
+  const float lr_t = (float)((double)lr_theta * std::sqrt(1.0 - std::pow((double)ADAM_B2, t)) / (1.0 - std::pow((double)ADAM_B1, t)));
+  const int np = h->n_params;
+  const int *tb = h->tables_dev;
+  hipLaunchKernelGGL(fit_adam_theta_kernel, dim3((np + 255) / 256), dim3(256), 0, (hipStream_t)stream_, h->theta_dev,
+                     h->m1_dev, h->m2_dev, grad, np, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS, h->blob_dev, h->bblob_dev, tb,
+                     tb + np, tb + 2 * (size_t)np);
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+extern "C" int bgm_causal_fit_z_step(bgm_handle *h, const float *x, const float *y, const float *v, float *data_z,
+                                     float *zm, float *zv, const int32_t *idx, int64_t row_lo, int32_t batch,
+                                     int32_t batch_global, float lr_z, int32_t lazy, double *loss, void *stream_) {
+  int rc = fit_check(h, x, y, v, data_z, batch, batch_global, "bgm_causal_fit_z_step");
+  if (rc) return rc;
+  if (!zm || !zv) { bgm_set_error("bgm_causal_fit_z_step: NULL Adam slots"); return BGM_E_INVALID; }
+  if (!idx) { bgm_set_error("bgm_causal_fit_z_step: idx_dev is required"); return BGM_E_INVALID; }
+  hipStream_t stream = (hipStream_t)stream_;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  FitKArgs ka{};
+  ka.m = h->meta; ka.bm = h->fit_meta; ka.ws = h->fit_ws; ka.wsp = h->ws_dev;
+  ka.x = x; ka.y = y; ka.v = v; ka.data_z = data_z; ka.idx = idx; ka.row_lo = row_lo; ka.B = batch;
+  ka.inv_B = 1.0f / (float)batch_global; ka.z_mode = 1; ka.loss = loss;
+  rc = launch_fwd_bwd(h, ka, stream);
+  if (rc) return rc;
+  h->t_z += 1;
+  const double t = (double)h->t_z;
+  const float lr_t = (float)((double)lr_z * std::sqrt(1.0 - std::pow((double)ADAM_B2, t)) / (1.0 - std::pow((double)ADAM_B1, t)));
+  const int q = h->q;
+  const float *dz = h->ws_dev + h->fit_ws.dz;
+  if (lazy) {
+    const long long n = (long long)batch * q;
+    hipLaunchKernelGGL(fit_adam_z_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, data_z, zm, zv, dz,
+                       h->pos_dev, h->fit_rows, q, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS, 1, idx, batch);
+  } else {
+    hipLaunchKernelGGL(fit_set_pos_kernel, dim3((batch + 255) / 256), dim3(256), 0, stream, h->pos_dev, idx, batch, 1);
+    const long long n = h->fit_rows * q;
+    hipLaunchKernelGGL(fit_adam_z_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, data_z, zm, zv, dz,
+                       h->pos_dev, h->fit_rows, q, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS, 0, idx, batch);
+    hipLaunchKernelGGL(fit_set_pos_kernel, dim3((batch + 255) / 256), dim3(256), 0, stream, h->pos_dev, idx, batch, 0);
+  }
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+extern "C" int bgm_causal_get_weights(bgm_handle *h, int net_id, float *theta_host, int64_t count, void *stream_) {
+  if (!h || !h->configured) { bgm_set_error("bgm_causal_get_weights: handle not configured"); return BGM_E_STATE; }
+  if (net_id < 0 || net_id > 3 || !theta_host) { bgm_set_error("bgm_causal_get_weights: bad argument"); return BGM_E_INVALID; }
+  HostNet &n = h->nets[net_id];
+  if ((size_t)count != n.count()) { bgm_set_error("bgm_causal_get_weights: wrong count"); return BGM_E_INVALID; }
+  if (h->fit_active && net_id != BGM_NET_E) {
+    BGM_HIP_CHECK(hipSetDevice(h->device));
+    BGM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_));
+    size_t off = 0;
+    if (net_id == BGM_NET_F) off = h->nets[BGM_NET_G].count();
+    if (net_id == BGM_NET_H) off = h->nets[BGM_NET_G].count() + h->nets[BGM_NET_F].count();
+    BGM_HIP_CHECK(hipMemcpy(n.theta.data(), h->theta_dev + off, sizeof(float) * count, hipMemcpyDeviceToHost));
+  }
+  std::memcpy(theta_host, n.theta.data(), sizeof(float) * count);
+  return BGM_OK;
+}
+
+extern "C" int bgm_causal_fit_end(bgm_handle *h, void *stream_) {
+  if (!h) return BGM_E_INVALID;
+  if (!h->fit_active) return BGM_OK;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  BGM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_));
+  size_t off = 0;
+  for (int id : {BGM_NET_G, BGM_NET_F, BGM_NET_H}) {   // theta order g | f | h
+    HostNet &n = h->nets[id];
+    BGM_HIP_CHECK(hipMemcpy(n.theta.data(), h->theta_dev + off, sizeof(float) * n.count(), hipMemcpyDeviceToHost));
+    off += n.count();
+  }
+  fit_free(h);   // forward blob on the device is already current (blob_valid stays true)
+  return BGM_OK;
+}

@@ -162,6 +162,68 @@ class CausalEngine(object):
                    "bgm_row_mean_quantiles")
         return mean, lo, hi
 
+    # -- evaluate -----------------------------------------------------------------
+    def evaluate(self, x, y, v, z, x_values=None):
+        """CausalBGM.evaluate arithmetic (causalbgm/base.py:534-570) on device tensors.
+        Returns (sums[3] float64 tensor, causal): causal = ITE [n] (binary) or dose sums [n_doses]."""
+        n = v.shape[0]
+        sums = torch.zeros(4, device=self.device, dtype=torch.float64)
+        if self.binary:
+            ite = torch.empty(n, device=self.device, dtype=torch.float32)
+            _lib.check(self.lib.bgm_causal_evaluate(self.h, _ptr(x), _ptr(y), _ptr(v), _ptr(z), n, None, 0, _ptr(sums),
+                                                    None, _ptr(ite), self._stream()), "bgm_causal_evaluate")
+            return sums, ite
+        xv = _f32(np.atleast_1d(np.asarray(x_values, dtype=np.float32)), self.device)
+        ns = C.c_int32()
+        _lib.check(self.lib.bgm_causal_evaluate_slots(self.h, n, C.byref(ns)), "bgm_causal_evaluate_slots")
+        partial = torch.zeros((ns.value, xv.numel()), device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.bgm_causal_evaluate(self.h, _ptr(x), _ptr(y), _ptr(v), _ptr(z), n, _ptr(xv), xv.numel(),
+                                                _ptr(sums), _ptr(partial), None, self._stream()), "bgm_causal_evaluate")
+        dose_sums = self.adrf_reduce(partial, ns.value, xv.numel(), 1, 1.0).reshape(-1)
+        return sums, dose_sums
+
+    # -- fit step functions ------------------------------------------------------
+    def fit_begin(self, n_rows, max_batch):
+        _lib.check(self.lib.bgm_causal_fit_begin(self.h, int(n_rows), int(max_batch), self._stream()),
+                   "bgm_causal_fit_begin")
+        n = C.c_int64()
+        _lib.check(self.lib.bgm_causal_fit_n_params(self.h, C.byref(n)), "bgm_causal_fit_n_params")
+        self.n_params = n.value
+        return n.value
+
+    def fit_theta_grad(self, x, y, v, data_z, idx, batch_global, grad, loss=None, row_lo=0, batch=None):
+        b = int(idx.numel()) if idx is not None else int(batch)
+        _lib.check(self.lib.bgm_causal_fit_theta_grad(self.h, _ptr(x), _ptr(y), _ptr(v), _ptr(data_z), _ptr(idx),
+                                                      int(row_lo), b, int(batch_global), _ptr(grad), _ptr(loss),
+                                                      self._stream()), "bgm_causal_fit_theta_grad")
+
+    def fit_theta_apply(self, grad, lr_theta):
+        _lib.check(self.lib.bgm_causal_fit_theta_apply(self.h, _ptr(grad), float(lr_theta), self._stream()),
+                   "bgm_causal_fit_theta_apply")
+
+    def fit_z_step(self, x, y, v, data_z, zm, zv, idx, batch_global, lr_z, lazy=False, loss=None):
+        _lib.check(self.lib.bgm_causal_fit_z_step(self.h, _ptr(x), _ptr(y), _ptr(v), _ptr(data_z), _ptr(zm), _ptr(zv),
+                                                  _ptr(idx), 0, int(idx.numel()), int(batch_global), float(lr_z),
+                                                  int(bool(lazy)), _ptr(loss), self._stream()),
+                   "bgm_causal_fit_z_step")
+
+    def get_weights(self, net_id, dims):
+        """Device parameters of one net -> [(W, b), ...] (Keras order)."""
+        count = sum(dims[i] * dims[i + 1] + dims[i + 1] for i in range(len(dims) - 1))
+        buf = np.empty(count, np.float32)
+        _lib.check(self.lib.bgm_causal_get_weights(self.h, int(net_id), buf.ctypes.data_as(C.c_void_p), count,
+                                                   self._stream()), "bgm_causal_get_weights")
+        out, off = [], 0
+        for i in range(len(dims) - 1):
+            nw = dims[i] * dims[i + 1]
+            out.append((buf[off:off + nw].reshape(dims[i], dims[i + 1]).copy(),
+                        buf[off + nw:off + nw + dims[i + 1]].copy()))
+            off += nw + dims[i + 1]
+        return out
+
+    def fit_end(self):
+        _lib.check(self.lib.bgm_causal_fit_end(self.h, self._stream()), "bgm_causal_fit_end")
+
     def timing_enable(self, on=True):
         _lib.check(self.lib.bgm_timing_enable(self.h, int(on)), "bgm_timing_enable")
 

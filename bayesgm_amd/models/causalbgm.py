@@ -101,6 +101,159 @@ class CausalBGM(object):
             return a.to(device=self.engine.device, dtype=torch.float32).contiguous()
         return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.engine.device)
 
+    # ------------------------------------------------------------------ fit
+    def _net_dims(self, k):
+        return [self.nets[k][0][0].shape[0]] + [W.shape[1] for W, _ in self.nets[k]]
+
+    def _pull_weights(self, which=("g", "f", "h")):
+        ids = {"g": _lib.NET_G, "f": _lib.NET_F, "h": _lib.NET_H, "e": _lib.NET_E}
+        for k in which:
+            self.nets[k] = self.engine.get_weights(ids[k], self._net_dims(k))
+
+    def egm_init(self, data, egm_n_iter=30000, batch_size=32, egm_batches_per_eval=500, verbose=1):
+        """EGM warm start (base.py:380-431): SURVEY.md section 8(f) row N1 -- not built yet."""
+        raise NotImplementedError("bayesgm_amd: the EGM warm start (egm_init / use_egm_init=True) is not built yet; "
+                                  "call fit(..., use_egm_init=False)")
+
+    def fit(self, data, epochs=100, epochs_per_eval=5, batch_size=32, startoff=0, use_egm_init=True,
+            egm_n_iter=30000, egm_batches_per_eval=500, save_format='txt', verbose=1, z_adam="dense"):
+        """Iterative theta / Z updates (base.py:434-532).
+
+        ``batch_size`` is the GLOBAL minibatch; under torch.distributed every rank owns a contiguous row
+        shard, draws its share of each minibatch from its own rows, and the g/f/h gradients are
+        all-reduced (RCCL) before the Adam step, so all ranks hold identical networks.
+        ``z_adam``: "dense" = Keras sparse-gradient Adam semantics of the reference (moment decay and update
+        on ALL rows every step, base.py:301), "lazy" = batch rows only (build option, O(B) per step)."""
+        if use_egm_init:
+            self.egm_init(data, egm_n_iter=egm_n_iter, batch_size=batch_size,
+                          egm_batches_per_eval=egm_batches_per_eval, verbose=verbose)
+        data_x, data_y, data_v = data
+        n_total = len(data_x)
+        if self._p['save_res'] and parallel.rank() == 0:
+            with open('{}/params.txt'.format(self.save_dir), 'w') as f_params:
+                f_params.write(str(self.params))
+        if verbose:
+            print('Random initialization of latent variables Z...')
+        q = self.engine.q
+        data_z_init = np.random.normal(0, 1, size=(n_total, q)).astype('float32')   # base.py:482
+        lo_r, hi_r = parallel.shard_range(n_total)
+        n_loc = hi_r - lo_r
+        world = parallel.world_size()
+        dev = self.engine.device
+        x = self._dev(data_x[lo_r:hi_r]).reshape(-1)
+        y = self._dev(data_y[lo_r:hi_r]).reshape(-1)
+        v = self._dev(data_v[lo_r:hi_r])
+        self.data_z = self._dev(data_z_init[lo_r:hi_r])
+        zm = torch.zeros_like(self.data_z)
+        zv = torch.zeros_like(self.data_z)
+        b_loc = max(1, batch_size // world)
+        eng = self.engine
+        n_params = eng.fit_begin(n_loc, b_loc)
+        grad = torch.empty(n_params, device=dev, dtype=torch.float32)
+        loss = torch.zeros(8, device=dev, dtype=torch.float64)
+        lazy = (z_adam == "lazy")
+        best_loss = np.inf
+        if verbose:
+            print('Iterative Updating Starts ...')
+        try:
+            for epoch in range(epochs + 1):
+                # permutation of the LOCAL rows (np.random.choice(N, N, replace=False), base.py:489)
+                sample_idx = torch.from_numpy(np.random.choice(n_loc, n_loc, replace=False).astype(np.int32)).to(dev)
+                loss.zero_()
+                n_steps = 0
+                for i in range(0, n_loc, b_loc):
+                    idx = sample_idx[i:i + b_loc]
+                    bg = int(idx.numel()) * world
+                    eng.fit_theta_grad(x, y, v, self.data_z, idx, bg, grad, loss)
+                    parallel.all_reduce_sum_(grad)                       # C1: fused g|f|h gradient
+                    eng.fit_theta_apply(grad, self._p['lr_theta'])
+                    eng.fit_z_step(x, y, v, self.data_z, zm, zv, idx, bg, self._p['lr_z'], lazy, loss)
+                    n_steps += 1
+                if verbose:
+                    l = loss.cpu().numpy() / max(1, n_loc)
+                    print('Epoch [%d/%d]: loss_px_z [%.4f], loss_py_z [%.4f], loss_pv_z [%.4f], loss_postrior_z [%.4f]'
+                          % (epoch, epochs, l[2], l[4], l[0], l[6]))
+                if epoch % epochs_per_eval == 0:
+                    causal_pre, mse_x, mse_y, mse_v = self._evaluate_dev(x, y, v, self.data_z, n_total, lo_r)
+                    if verbose:
+                        print('Epoch [%d/%d]: MSE_x: %.4f, MSE_y: %.4f, MSE_v: %.4f\n' % (epoch, epochs, mse_x, mse_y, mse_v))
+                    if epoch >= startoff and mse_y < best_loss:
+                        best_loss = mse_y
+                        self.best_causal_pre = causal_pre
+                        self.best_epoch = epoch
+                        if self._p['save_model'] and parallel.rank() == 0:
+                            self._pull_weights()
+                            self.save_checkpoint(epoch)
+                    if self._p['save_res'] and parallel.rank() == 0:
+                        save_data('{}/causal_pre_at_{}.{}'.format(self.save_dir, epoch, save_format), causal_pre)
+        finally:
+            eng.fit_end()
+            self._pull_weights()
+
+    def save_checkpoint(self, epoch):
+        """The reference checkpoints with tf.train.CheckpointManager (base.py:112-128, 529); the build writes
+        the same information (network parameters) as an .npz at the same directory."""
+        path = os.path.join(self.checkpoint_path, "ckpt-%d.npz" % epoch)
+        flat = {}
+        for k, net in self.nets.items():
+            for i, (W, b) in enumerate(net):
+                flat["%s_W%d" % (k, i)] = W
+                flat["%s_b%d" % (k, i)] = b
+        np.savez(path, **flat)
+        print('Saving checkpoint for epoch {} at {}'.format(epoch, path))
+        return path
+
+    def load_checkpoint(self, path):
+        d = np.load(path)
+        for k in list(self.nets):
+            self.nets[k] = [(d["%s_W%d" % (k, i)], d["%s_b%d" % (k, i)]) for i in range(len(self.nets[k]))]
+        self._push_weights()
+
+    # ------------------------------------------------------------------ evaluate
+    @staticmethod
+    def _percentile_nearest(a, qpct):
+        """tfp.stats.percentile default interpolation='nearest' (base.py:558-559)."""
+        s = np.sort(np.asarray(a).ravel())
+        return s[int(np.round((len(s) - 1) * qpct / 100.0))]
+
+    def _evaluate_dev(self, x, y, v, z, n_total, lo_r, nb_intervals=200, x_full=None):
+        """evaluate on this rank's rows + reduction over ranks.  Returns numpy (causal_pre, mse_x, mse_y, mse_v)."""
+        eng = self.engine
+        n_loc = v.shape[0]
+        if self._p['binary_treatment']:
+            sums, ite = eng.evaluate(x, y, v, z)
+            parallel.all_reduce_sum_(sums)
+            ite = parallel.all_gather_rows(ite.reshape(-1, 1), n_total)
+            s = sums.cpu().numpy()
+            return (ite.cpu().numpy(), np.float32(s[1] / n_total), np.float32(s[2] / n_total),
+                    np.float32(s[0] / (n_total * self.engine.v_dim)))
+        # dose grid between the 5th / 95th percentile of ALL x (base.py:558-560)
+        xs_all = parallel.all_gather_rows(x.reshape(-1, 1), n_total).cpu().numpy() if x_full is None else x_full
+        x_min = self._percentile_nearest(xs_all, 5.0)
+        x_max = self._percentile_nearest(xs_all, 95.0)
+        x_values = np.linspace(x_min, x_max, nb_intervals).astype(np.float32)
+        sums, dose = eng.evaluate(x, y, v, z, x_values)
+        dose = dose.double()
+        parallel.all_reduce_sum_(sums)
+        parallel.all_reduce_sum_(dose)
+        s = sums.cpu().numpy()
+        return ((dose / n_total).float().cpu().numpy(), np.float32(s[1] / n_total), np.float32(s[2] / n_total),
+                np.float32(s[0] / (n_total * self.engine.v_dim)))
+
+    def evaluate(self, data, data_z=None, nb_intervals=200):
+        """(causal_pre, mse_x, mse_y, mse_v) (base.py:534-570); data_z=None -> e_net(data_v)."""
+        data_x, data_y, data_v = data
+        n_total = len(data_x)
+        lo_r, hi_r = parallel.shard_range(n_total)
+        x = self._dev(data_x[lo_r:hi_r]).reshape(-1)
+        y = self._dev(data_y[lo_r:hi_r]).reshape(-1)
+        v = self._dev(data_v[lo_r:hi_r])
+        if data_z is None:
+            z = self.engine.encode(v)
+        else:
+            z = self._dev(data_z[lo_r:hi_r]) if len(data_z) == n_total else self._dev(data_z)
+        return self._evaluate_dev(x, y, v, z, n_total, lo_r, nb_intervals)
+
     # ------------------------------------------------------------------ predict
     def predict(self, data, alpha=0.01, n_mcmc=3000, burn_in=5000, x_values=None, q_sd=1.0, sample_y=True,
                 bs=10000, verbose=1):

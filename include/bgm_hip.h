@@ -154,6 +154,68 @@ typedef struct {
 } bgm_mh_info;
 int bgm_causal_mh_info(bgm_handle *h, int64_t n, bgm_mh_info *info);
 
+/* evaluate at a given latent matrix z [n x q]: accumulates sums[0..2] += {sum |v - mu_v|^2,
+ * sum (x - x_pred)^2, sum (y - mu_y)^2} (divide by n*p, n, n for the MSEs) and the plug-in causal
+ * estimate: binary -> ite_dev[n] = f(z0,z1,1) - f(z0,z1,0); continuous -> adrf_partial_dev
+ * [n_slots x n_doses] += per-wave sums over rows of f(z0,z1,x_k) (reduce with bgm_adrf_reduce,
+ * n_keep = 1; n_slots from bgm_causal_evaluate_slots).
+ * replaces: CausalBGM.evaluate, causalbgm/base.py:534-570 (the dose grid / percentiles stay on the host). */
+int bgm_causal_evaluate(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev,
+                        const float *z_dev, int64_t n, const float *x_values_dev, int32_t n_doses,
+                        double *sums_dev, float *adrf_partial_dev, float *ite_dev, void *stream);
+int bgm_causal_evaluate_slots(bgm_handle *h, int64_t n, int32_t *n_slots);
+
+/* ------------------------------------------------------------------------------------------
+ * CausalBGM.fit step functions (iterative theta / Z updates).
+ * replaces: update_g_net :156-180, update_h_net :183-214, update_f_net :217-243,
+ *           update_latent_variable_sgd :246-302 of causalbgm/base.py, and the Keras Adam
+ *           optimizers created at :90-93 (beta_1 = 0.9, beta_2 = 0.99, epsilon = 1e-7).
+ * One minibatch of the loop :494-505 is
+ *     bgm_causal_fit_theta_grad  -> [caller: RCCL all-reduce(SUM) of grad_dev across ranks]
+ *     bgm_causal_fit_theta_apply -> bgm_causal_fit_z_step
+ * Losses are batch means over `batch_global` rows (the sum of the ranks' local batches), so the
+ * all-reduced gradient is the gradient of the global-batch mean.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Start a fit session: uploads the current g/f/h parameters to the device, zeroes the Adam slots
+ * and step counters, sizes the workspace for minibatches of up to max_batch LOCAL rows out of
+ * n_rows local rows.  Synchronous. */
+int bgm_causal_fit_begin(bgm_handle *h, int64_t n_rows, int32_t max_batch, void *stream);
+
+/* Number of trainable parameters of g, f, h (= length of grad_dev). */
+int bgm_causal_fit_n_params(bgm_handle *h, int64_t *n_params);
+
+/* Gradients of the three batch-mean losses w.r.t. theta_g | theta_f | theta_h (Keras order) for the
+ * local minibatch rows idx_dev[0..batch) (int32 row indices into x/y/v/data_z; NULL = rows
+ * row_lo .. row_lo+batch-1).  grad_dev [n_params] is overwritten.  loss_dev (double[8], may be NULL)
+ * is incremented by {sum loss_v, sum |v-mu|^2, sum loss_x, sum (x-mu_x)^2 | sum bce, sum loss_y,
+ * sum (y-mu_y)^2, unused, unused} over the local rows. */
+int bgm_causal_fit_theta_grad(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev,
+                              const float *data_z_dev, const int32_t *idx_dev, int64_t row_lo,
+                              int32_t batch, int32_t batch_global, float *grad_dev, double *loss_dev,
+                              void *stream);
+
+/* One Adam step on theta with the (all-reduced) gradient; refreshes the packed weights used by
+ * every other kernel of the handle. */
+int bgm_causal_fit_theta_apply(bgm_handle *h, const float *grad_dev, float lr_theta, void *stream);
+
+/* update_latent_variable_sgd for the local minibatch with the CURRENT networks: gradient of the
+ * batch-mean negative log joint w.r.t. the batch rows of data_z and one Adam step on the latent
+ * matrix.  zm/zv [n_rows x q] are the Adam slots.  lazy = 0 reproduces Keras' sparse-gradient Adam
+ * (moment decay and update applied to ALL n_rows rows every step), lazy = 1 touches the batch rows
+ * only.  loss_dev[6] += sum over local rows of the per-row negative log joint. */
+int bgm_causal_fit_z_step(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev,
+                          float *data_z_dev, float *zm_dev, float *zv_dev, const int32_t *idx_dev,
+                          int64_t row_lo, int32_t batch, int32_t batch_global, float lr_z, int32_t lazy,
+                          double *loss_dev, void *stream);
+
+/* Copy the device parameters of one network back to the host (Keras order) and make them the
+ * handle's host copy.  Synchronous. */
+int bgm_causal_get_weights(bgm_handle *h, int net_id, float *theta_host, int64_t count, void *stream);
+
+/* End the fit session (frees the workspace; the trained parameters stay installed). */
+int bgm_causal_fit_end(bgm_handle *h, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

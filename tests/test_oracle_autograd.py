@@ -1,0 +1,138 @@
+"""Independent second opinion on the oracle's hand-derived gradients and Adam: PyTorch-CPU autograd /
+torch.optim.Adam (float64).  This is how the "parity unpinned" oracle is kept honest."""
+import numpy as np
+import torch
+
+from oracle import causal as OC
+from oracle import fit as OF
+from oracle.nets import mlp_forward
+
+
+def _t(a):
+    return torch.tensor(np.asarray(a, np.float64), dtype=torch.float64)
+
+
+def _torch_net(net):
+    return [(_t(W).requires_grad_(), _t(b).requires_grad_()) for W, b in net]
+
+
+def _fwd(net, x):
+    h = x
+    for i, (W, b) in enumerate(net):
+        h = h @ W + b
+        if i < len(net) - 1:
+            h = torch.maximum(h, 0.2 * h)
+    return h
+
+
+def _sp(x):
+    return torch.nn.functional.softplus(x)
+
+
+def _losses(tm, m, z, x, y, v):
+    p = m["v_dim"]
+    z0d, z1d, z2d, _ = m["z_dims"]
+    go = _fwd(tm["g"], z)
+    s2v = _sp(go[:, -1]) + 1e-6
+    lv = (((v - go[:, :p]) ** 2).sum(1) / (2 * s2v) + p * torch.log(s2v) / 2).mean()
+    ho = _fwd(tm["h"], torch.cat([z[:, :z0d], z[:, z0d + z1d:z0d + z1d + z2d]], 1))
+    if m["binary_treatment"]:
+        lx = torch.nn.functional.binary_cross_entropy_with_logits(ho[:, :1], x)
+    else:
+        s2x = _sp(ho[:, -1]) + 1e-6
+        lx = (((x - ho[:, :1]) ** 2).sum(1) / (2 * s2x) + torch.log(s2x) / 2).mean()
+    fo = _fwd(tm["f"], torch.cat([z[:, :z0d + z1d], x], 1))
+    s2y = _sp(fo[:, -1]) + 1e-6
+    ly = (((y - fo[:, :1]) ** 2).sum(1) / (2 * s2y) + torch.log(s2y) / 2).mean()
+    return lv, lx, ly
+
+
+def _setup(binary, seed=0, n=24, p=17, z_dims=(2, 1, 3, 4)):
+    m = OC.cast_model(OC.init_model(seed, list(z_dims), p, binary_treatment=binary), np.float64)
+    rs = np.random.RandomState(seed + 1)
+    for k in ("g", "f", "h"):
+        m[k] = [(W, 0.1 * rs.randn(*b.shape)) for W, b in m[k]]
+    z = rs.randn(n, sum(z_dims))
+    v = rs.randn(n, p)
+    x = (rs.rand(n, 1) > 0.5).astype(np.float64) if binary else rs.exponential(size=(n, 1))
+    y = rs.randn(n, 1)
+    return m, z, x, y, v
+
+
+def test_theta_and_z_gradients_match_autograd():
+    for binary in (False, True):
+        m, z, x, y, v = _setup(binary)
+        tm = {k: _torch_net(m[k]) for k in ("g", "f", "h")}
+        tz = _t(z).requires_grad_()
+        lv, lx, ly = _losses(tm, m, tz, _t(x), _t(y), _t(v))
+        total = lv + lx + ly + ((tz ** 2).sum(1) / 2).mean()
+        total.backward()
+        l_v, _, gg, _ = OF.g_loss_and_grads(m, z, v)
+        l_x, _, gh, _ = OF.h_loss_and_grads(m, z, x)
+        l_y, _, gf, _ = OF.f_loss_and_grads(m, z, x, y)
+        assert np.allclose([l_v, l_x, l_y], [lv.item(), lx.item(), ly.item()], rtol=1e-12)
+        for key, grads in (("g", gg), ("h", gh), ("f", gf)):
+            for (dW, db), (W, b) in zip(grads, tm[key]):
+                assert np.allclose(dW, W.grad.numpy(), rtol=1e-9, atol=1e-12)
+                assert np.allclose(db, b.grad.numpy(), rtol=1e-9, atol=1e-12)
+        lz, dz = OF.z_loss_and_grad(m, z, x, y, v)
+        assert np.isclose(lz, total.item(), rtol=1e-12)
+        assert np.allclose(dz, tz.grad.numpy(), rtol=1e-9, atol=1e-12)
+
+
+def test_fixed_sigma_gradients():
+    m, z, x, y, v = _setup(False, seed=3)
+    m.update(sigma_v=0.7, sigma_x=1.2, sigma_y=0.9)
+    tz = _t(z).requires_grad_()
+    tm = {k: _torch_net(m[k]) for k in ("g", "f", "h")}
+    p = m["v_dim"]
+    go = _fwd(tm["g"], tz)
+    lv = (((_t(v) - go[:, :p]) ** 2).sum(1) / (2 * 0.49) + p * np.log(0.49) / 2).mean()
+    lv.backward()
+    l_v, _, gg, dz = OF.g_loss_and_grads(m, z, v)
+    assert np.isclose(l_v, lv.item())
+    assert np.allclose(dz, tz.grad.numpy(), rtol=1e-9, atol=1e-12)
+    assert np.allclose(gg[-1][0][:, -1], 0)  # variance column receives no gradient
+
+
+def test_adam_matches_torch_adam_with_keras_epsilon_form():
+    """Keras: var -= lr_t*m/(sqrt(v)+eps) with lr_t folding both bias corrections; torch.optim.Adam:
+    lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).  They agree when eps_torch = eps_keras/sqrt(1-b2^t);
+    check the oracle against the closed form over several steps instead."""
+    rs = np.random.RandomState(0)
+    p = rs.randn(5, 3)
+    ref = p.copy()
+    st = OF.AdamState([p])
+    m_ = np.zeros_like(p)
+    v_ = np.zeros_like(p)
+    for t in range(1, 8):
+        g = rs.randn(5, 3)
+        st.apply([p], [g], 1e-2)
+        m_ = 0.9 * m_ + 0.1 * g
+        v_ = 0.99 * v_ + 0.01 * g * g
+        ref -= 1e-2 * np.sqrt(1 - 0.99 ** t) / (1 - 0.9 ** t) * m_ / (np.sqrt(v_) + 1e-7)
+        assert np.allclose(p, ref, rtol=1e-13)
+
+
+def test_sparse_adam_dense_decay_moves_untouched_rows():
+    m, z, x, y, v = _setup(False, seed=5, n=12)
+    st = OF.FitState(m, z.copy(), 1e-3, 1e-2)
+    OF.fit_step(st, x, y, v, np.array([0, 1, 2, 3]))
+    z1 = st.data_z.copy()
+    OF.fit_step(st, x, y, v, np.array([4, 5, 6, 7]))
+    # rows 0..3 keep drifting by their decaying momentum under the reference's dense-decay semantics
+    assert np.all(np.abs(st.data_z[:4] - z1[:4]) > 0)
+    assert np.all(st.data_z[8:] == z[8:])  # never-touched rows: m = v = 0 -> no movement
+    st2 = OF.FitState(OC.cast_model(m, np.float64), z.copy(), 1e-3, 1e-2)
+    OF.fit_step(st2, x, y, v, np.array([0, 1, 2, 3]), lazy_z=True)
+    z2 = st2.data_z.copy()
+    OF.fit_step(st2, x, y, v, np.array([4, 5, 6, 7]), lazy_z=True)
+    assert np.all(st2.data_z[:4] == z2[:4])
+
+
+def test_fit_epochs_reduces_loss():
+    m, z, x, y, v = _setup(False, seed=7, n=64)
+    st = OF.FitState(m, z.copy(), 1e-3, 1e-3)
+    hist = OF.fit_epochs(st, (x, y, v), 20, 32, np.random.RandomState(0))
+    assert hist.shape == (21 * 2, 7)
+    assert hist[-4:, 4].mean() < hist[:4, 4].mean()  # loss_v decreases
