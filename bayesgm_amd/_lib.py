@@ -39,6 +39,21 @@ class MhArgs(C.Structure):
     ]
 
 
+class BgmConfig(C.Structure):
+    _fields_ = [("x_dim", C.c_int32), ("z_dim", C.c_int32), ("n_hidden_g", C.c_int32),
+                ("g_units", C.c_int32 * BGM_MAX_LAYERS)]
+
+
+class HmcArgs(C.Structure):
+    _fields_ = [
+        ("x_dev", C.c_void_p), ("n", C.c_int64), ("row_base", C.c_int64),
+        ("state_dev", C.c_void_p), ("logp_dev", C.c_void_p), ("grad_dev", C.c_void_p),
+        ("init", C.c_int32), ("it_begin", C.c_int32), ("n_iters", C.c_int32), ("burn_in", C.c_int32),
+        ("n_leapfrog", C.c_int32), ("step_dev", C.c_void_p), ("seed", C.c_uint64),
+        ("acc_prob_sum_dev", C.c_void_p), ("acc_count_dev", C.c_void_p), ("draws_dev", C.c_void_p),
+    ]
+
+
 class MhInfo(C.Structure):
     _fields_ = [("rows_per_wave", C.c_int32), ("waves_per_block", C.c_int32), ("grid_blocks", C.c_int32),
                 ("mfma_per_transition_per_wave", C.c_int32), ("lds_bytes", C.c_int32),
@@ -76,6 +91,14 @@ SYMBOLS = {
                                         C.c_int32, C.c_void_p, C.c_void_p]),
     "bgm_causal_get_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "bgm_causal_fit_end": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bgm_bgm_configure": (C.c_int, [C.c_void_p, C.POINTER(BgmConfig)]),
+    "bgm_bgm_set_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "bgm_bgm_logpost": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bgm_bgm_hmc_run": (C.c_int, [C.c_void_p, C.POINTER(HmcArgs), C.c_void_p]),
+    "bgm_bgm_hmc_adapt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_float, C.c_float,
+                                    C.c_void_p]),
+    "bgm_bgm_predict_draws": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                        C.c_uint64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,249 @@
+// bgm_api.hip -- C-ABI entry points of the BGM posterior path (include/bgm_hip.h, BGM section).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "bgm_host.h"
+#include "bgm_kernels.h"
+
+static constexpr int BGM_WAVES = 8;
+static constexpr float BN_EPS_F = 1e-3f;   // keras BatchNormalization default epsilon
+
+struct BgmState {
+  bgm_bgm_config cfg{};
+  bool configured = false, set = false;
+  std::vector<float> theta;
+  BgmMeta meta{};
+  int KTQ = 0, NTX = 0, NH = 0;
+  float *blob_dev = nullptr;
+  size_t blob_cap = 0;
+  bool blob_valid = false;
+};
+
+static BgmState *bst(bgm_handle *h) {
+  if (!h->bgm_state) h->bgm_state = new BgmState();
+  return static_cast<BgmState *>(h->bgm_state);
+}
+void bgm_bgm_free_state(bgm_handle *h) {
+  if (!h->bgm_state) return;
+  BgmState *s = static_cast<BgmState *>(h->bgm_state);
+  if (s->blob_dev) hipFree(s->blob_dev);
+  delete s;
+  h->bgm_state = nullptr;
+}
+
+static size_t bgm_count(const bgm_bgm_config &c) {
+  size_t n = 4 * (size_t)c.z_dim;
+  int in = c.z_dim;
+  for (int i = 0; i < c.n_hidden_g; ++i) { n += (size_t)in * c.g_units[i] + c.g_units[i]; in = c.g_units[i]; }
+  n += 2 * ((size_t)in * c.x_dim + c.x_dim);
+  return n;
+}
+
+extern "C" int bgm_bgm_configure(bgm_handle *h, const bgm_bgm_config *cfg) {
+  if (!h || !cfg) { bgm_set_error("bgm_bgm_configure: NULL argument"); return BGM_E_INVALID; }
+  if (cfg->x_dim < 1 || cfg->z_dim < 1 || cfg->n_hidden_g < 1 || cfg->n_hidden_g > BGM_MAX_LAYERS) {
+    bgm_set_error("bgm_bgm_configure: bad dimensions"); return BGM_E_INVALID;
+  }
+  for (int i = 0; i < cfg->n_hidden_g; ++i)
+    if (cfg->g_units[i] != 64) { bgm_set_error("bgm_bgm_configure: only g_units=[64]*k is compiled"); return BGM_E_UNSUPPORTED; }
+  if (cfg->z_dim > 16) { bgm_set_error("bgm_bgm_configure: z_dim > 16 not compiled"); return BGM_E_UNSUPPORTED; }
+  BgmState *s = bst(h);
+  s->cfg = *cfg;
+  s->configured = true; s->set = false; s->blob_valid = false;
+  s->theta.assign(bgm_count(*cfg), 0.0f);
+  return BGM_OK;
+}
+
+extern "C" int bgm_bgm_set_weights(bgm_handle *h, const float *theta, int64_t count, void *stream) {
+  (void)stream;
+  if (!h || !h->bgm_state || !bst(h)->configured) { bgm_set_error("bgm_bgm_set_weights: not configured"); return BGM_E_STATE; }
+  BgmState *s = bst(h);
+  if (!theta || (size_t)count != s->theta.size()) {
+    bgm_set_error("bgm_bgm_set_weights: expected " + std::to_string(s->theta.size()) + " floats"); return BGM_E_INVALID;
+  }
+  std::memcpy(s->theta.data(), theta, sizeof(float) * count);
+  s->set = true; s->blob_valid = false;
+  return BGM_OK;
+}
+
+// dual-access pack: [out tile][in slot (K_ROWS)][17]; slotmap(slot) -> source input row or -1
+template <class SlotMap>
+static void pack17(std::vector<float> &blob, int off, const std::vector<float> &W, int n_in, int n_out, int K_ROWS,
+                   int NT, SlotMap slotmap) {
+  for (int t = 0; t < NT; ++t)
+    for (int rho = 0; rho < K_ROWS; ++rho) {
+      const int src = slotmap(rho);
+      for (int j = 0; j < 16; ++j) {
+        const int o = 16 * t + j;
+        float v = 0.0f;
+        if (src >= 0 && src < n_in && o < n_out) v = W[(size_t)src * n_out + o];
+        blob[off + (t * K_ROWS + rho) * 17 + j] = v;
+      }
+    }
+}
+
+static int bgm_build_blob(bgm_handle *h, hipStream_t stream) {
+  BgmState *s = bst(h);
+  if (s->blob_valid) return BGM_OK;
+  if (!s->set) { bgm_set_error("BGM weights not set"); return BGM_E_STATE; }
+  const int q = s->cfg.z_dim, p = s->cfg.x_dim, NH = s->cfg.n_hidden_g;
+  const int KTQ = (q + 15) / 16, NTX = (p + 15) / 16;
+  s->KTQ = KTQ; s->NTX = NTX; s->NH = NH;
+  BgmMeta &m = s->meta;
+  std::memset(&m, 0, sizeof(m));
+  m.q = q; m.p = p; m.n_hh = NH - 1;
+  int off = 0;
+  auto take = [&](int n) { int o = off; off += (n + 3) / 4 * 4; return o; };
+  m.w1 = take(4 * 16 * KTQ * 17); m.b1 = take(64);
+  m.wh = take(m.n_hh * 4 * 64 * 17); m.bh = take(m.n_hh * 64);
+  m.whd = take(2 * NTX * 64 * 17); m.bhd = take(2 * 16 * NTX);
+  m.total = off;
+  if ((size_t)m.total * 4 > 160 * 1024) {
+    bgm_set_error("BGM generator does not fit the 160 KiB LDS-resident dual-access layout (" + std::to_string(m.total * 4) + " B)");
+    return BGM_E_UNSUPPORTED;
+  }
+  std::vector<float> blob(m.total, 0.0f);
+  const float *th = s->theta.data();
+  const float *gamma = th, *beta = th + q, *mmean = th + 2 * q, *mvar = th + 3 * q;
+  size_t o = 4 * (size_t)q;
+  // first Dense with the inference-mode BatchNorm folded in:  zn = z*scale + shift
+  std::vector<float> scale(q), shift(q);
+  for (int i = 0; i < q; ++i) { scale[i] = gamma[i] / std::sqrt(mvar[i] + BN_EPS_F); shift[i] = beta[i] - mmean[i] * scale[i]; }
+  std::vector<float> W1(th + o, th + o + (size_t)q * 64); o += (size_t)q * 64;
+  std::vector<float> b1(th + o, th + o + 64); o += 64;
+  for (int k = 0; k < 64; ++k) { double acc = b1[k]; for (int i = 0; i < q; ++i) acc += (double)shift[i] * W1[(size_t)i * 64 + k]; b1[k] = (float)acc; }
+  for (int i = 0; i < q; ++i) for (int k = 0; k < 64; ++k) W1[(size_t)i * 64 + k] *= scale[i];
+  pack17(blob, m.w1, W1, q, 64, 16 * KTQ, 4, [&](int slot) { int f = l1_feature(slot); return f < q ? f : -1; });
+  for (int k = 0; k < 64; ++k) blob[m.b1 + k] = b1[k];
+  auto ident = [](int r) { return r; };
+  for (int l = 0; l < m.n_hh; ++l) {
+    std::vector<float> W(th + o, th + o + 4096); o += 4096;
+    pack17(blob, m.wh + l * 4 * 64 * 17, W, 64, 64, 64, 4, ident);
+    for (int k = 0; k < 64; ++k) blob[m.bh + l * 64 + k] = th[o + k];
+    o += 64;
+  }
+  for (int head = 0; head < 2; ++head) {   // mean, var
+    std::vector<float> W(th + o, th + o + (size_t)64 * p); o += (size_t)64 * p;
+    pack17(blob, m.whd + head * NTX * 64 * 17, W, 64, p, 64, NTX, ident);
+    for (int k = 0; k < p; ++k) blob[m.bhd + head * 16 * NTX + k] = th[o + k];
+    o += p;
+  }
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  if (s->blob_cap < blob.size()) {
+    if (s->blob_dev) BGM_HIP_CHECK(hipFree(s->blob_dev));
+    BGM_HIP_CHECK(hipMalloc(&s->blob_dev, blob.size() * sizeof(float)));
+    s->blob_cap = blob.size();
+  }
+  BGM_HIP_CHECK(hipMemcpyAsync(s->blob_dev, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+  BGM_HIP_CHECK(hipStreamSynchronize(stream));
+  s->blob_valid = true;
+  return BGM_OK;
+}
+
+// (KTQ, NTX, NH) variants: z_dim <= 16; x_dim <= 32 / <= 112; 5 hidden layers (configs/*.yaml) or 3
+#define BGM_BGM_VARIANTS(X) X(1, 2, 5) X(1, 7, 5) X(1, 2, 3) X(1, 7, 3)
+
+static int bgm_grid(const bgm_handle *h, long long tiles) {
+  return (int)std::max<long long>(1, std::min<long long>((tiles + BGM_WAVES - 1) / BGM_WAVES, h->n_cus));
+}
+#define BGM_NO_VARIANT(s)                                                                               \
+  bgm_set_error("no compiled BGM kernel variant for (KTQ,NTX,NH)=(" + std::to_string((s)->KTQ) + "," +  \
+                std::to_string((s)->NTX) + "," + std::to_string((s)->NH) + ")");                        \
+  return BGM_E_UNSUPPORTED;
+
+extern "C" int bgm_bgm_logpost(bgm_handle *h, const float *z, const float *x, int64_t n, float *out, float *grad,
+                               void *stream_) {
+  if (!h || !h->bgm_state || !bst(h)->configured) { bgm_set_error("bgm_bgm_logpost: not configured"); return BGM_E_STATE; }
+  if (n <= 0) return BGM_OK;
+  if (!z || !x || !out) { bgm_set_error("bgm_bgm_logpost: NULL pointer"); return BGM_E_INVALID; }
+  hipStream_t stream = (hipStream_t)stream_;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  int rc = bgm_build_blob(h, stream);
+  if (rc) return rc;
+  BgmState *s = bst(h);
+  const int grid = bgm_grid(h, (n + 15) / 16), lds = s->meta.total * 4;
+#define X(KTQ_, NTX_, NH_)                                                                                          \
+  if (s->KTQ == KTQ_ && s->NTX == NTX_ && s->NH == NH_) {                                                           \
+    auto k = bgm_logpost_kernel<KTQ_, NTX_, NH_, BGM_WAVES>;                                                        \
+    BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * BGM_WAVES), lds, stream, s->blob_dev, s->meta, z, x, (long long)n, out, grad); \
+    BGM_HIP_CHECK(hipGetLastError());                                                                               \
+    return BGM_OK;                                                                                                  \
+  }
+  BGM_BGM_VARIANTS(X)
+#undef X
+  BGM_NO_VARIANT(s)
+}
+
+extern "C" int bgm_bgm_hmc_run(bgm_handle *h, const bgm_hmc_args *a, void *stream_) {
+  if (!h || !h->bgm_state || !bst(h)->configured) { bgm_set_error("bgm_bgm_hmc_run: not configured"); return BGM_E_STATE; }
+  if (!a) { bgm_set_error("bgm_bgm_hmc_run: NULL args"); return BGM_E_INVALID; }
+  if (a->n <= 0 || a->n_iters <= 0) return BGM_OK;
+  if (!a->x_dev || !a->state_dev || !a->logp_dev || !a->grad_dev || !a->step_dev) { bgm_set_error("bgm_bgm_hmc_run: NULL pointer"); return BGM_E_INVALID; }
+  if (a->n_leapfrog < 1) { bgm_set_error("bgm_bgm_hmc_run: num_leapfrog_steps must be >= 1"); return BGM_E_INVALID; }
+  if (a->row_base + a->n > 0xFFFFFFFFll) { bgm_set_error("bgm_bgm_hmc_run: row index exceeds the 32-bit RNG counter"); return BGM_E_INVALID; }
+  hipStream_t stream = (hipStream_t)stream_;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  int rc = bgm_build_blob(h, stream);
+  if (rc) return rc;
+  BgmState *s = bst(h);
+  BgmHmcKArgs ka{};
+  ka.blob = s->blob_dev; ka.x = a->x_dev; ka.n = a->n; ka.row_base = a->row_base;
+  ka.state = a->state_dev; ka.logp = a->logp_dev; ka.grad = a->grad_dev; ka.init = a->init;
+  ka.it_begin = a->it_begin; ka.n_iters = a->n_iters; ka.burn_in = a->burn_in; ka.n_leapfrog = a->n_leapfrog;
+  ka.step = a->step_dev; ka.k0 = (unsigned)(a->seed & 0xFFFFFFFFull); ka.k1 = (unsigned)(a->seed >> 32);
+  ka.acc_prob_sum = a->acc_prob_sum_dev; ka.acc_count = a->acc_count_dev; ka.draws = a->draws_dev; ka.m = s->meta;
+  const int grid = bgm_grid(h, (a->n + 15) / 16), lds = s->meta.total * 4;
+#define X(KTQ_, NTX_, NH_)                                                                                          \
+  if (s->KTQ == KTQ_ && s->NTX == NTX_ && s->NH == NH_) {                                                           \
+    auto k = bgm_hmc_kernel<KTQ_, NTX_, NH_, BGM_WAVES>;                                                            \
+    BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * BGM_WAVES), lds, stream, ka);                                       \
+    BGM_HIP_CHECK(hipGetLastError());                                                                               \
+    return BGM_OK;                                                                                                  \
+  }
+  BGM_BGM_VARIANTS(X)
+#undef X
+  BGM_NO_VARIANT(s)
+}
+
+extern "C" int bgm_bgm_hmc_adapt(bgm_handle *h, float *step, const double *acc_prob_sum, int32_t it, double n_chains,
+                                 float target, float rate, void *stream_) {
+  if (!h || !step || !acc_prob_sum || !(n_chains > 0)) { bgm_set_error("bgm_bgm_hmc_adapt: bad argument"); return BGM_E_INVALID; }
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(bgm_hmc_adapt_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, step, acc_prob_sum, it, n_chains, target, rate);
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+extern "C" int bgm_bgm_predict_draws(bgm_handle *h, const float *draws, int64_t n, int64_t row_base, int32_t n_draws,
+                                     int32_t burn_in, uint64_t seed, const int32_t *slot, int32_t k_slots, float *cells,
+                                     float *full, void *stream_) {
+  if (!h || !h->bgm_state || !bst(h)->configured) { bgm_set_error("bgm_bgm_predict_draws: not configured"); return BGM_E_STATE; }
+  if (n <= 0 || n_draws <= 0) return BGM_OK;
+  if (!draws || (!cells && !full) || (cells && (!slot || k_slots <= 0))) { bgm_set_error("bgm_bgm_predict_draws: bad pointers"); return BGM_E_INVALID; }
+  hipStream_t stream = (hipStream_t)stream_;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  int rc = bgm_build_blob(h, stream);
+  if (rc) return rc;
+  BgmState *s = bst(h);
+  BgmPredKArgs ka{};
+  ka.blob = s->blob_dev; ka.draws = draws; ka.n = n; ka.row_base = row_base; ka.n_draws = n_draws; ka.burn_in = burn_in;
+  ka.k_slots = k_slots; ka.slot = slot; ka.cells = cells; ka.full = full;
+  ka.k0 = (unsigned)(seed & 0xFFFFFFFFull); ka.k1 = (unsigned)(seed >> 32); ka.m = s->meta;
+  const long long work = ((n + 15) / 16) * (long long)n_draws;
+  const int grid = (int)std::max<long long>(1, std::min<long long>((work + BGM_WAVES - 1) / BGM_WAVES, (long long)h->n_cus));
+  const int lds = s->meta.total * 4;
+#define X(KTQ_, NTX_, NH_)                                                                                          \
+  if (s->KTQ == KTQ_ && s->NTX == NTX_ && s->NH == NH_) {                                                           \
+    auto k = bgm_predict_kernel<KTQ_, NTX_, NH_, BGM_WAVES>;                                                        \
+    BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * BGM_WAVES), lds, stream, ka);                                       \
+    BGM_HIP_CHECK(hipGetLastError());                                                                               \
+    return BGM_OK;                                                                                                  \
+  }
+  BGM_BGM_VARIANTS(X)
+#undef X
+  BGM_NO_VARIANT(s)
+}

@@ -31,6 +31,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // every weight read out of the iteration loops and spills it.  A compiler-only
 // memory clobber at the top of each iteration keeps the reads where they are used.
 #define BGM_NO_HOIST() asm volatile("" ::: "memory")
+// The same LICM also hoists every loop-invariant LDS *address* (lane offset + layer offset) out of the
+// iteration loops and keeps dozens of them live.  Laundering the lane indices through an empty asm at
+// the entry of a layer makes the addresses be formed where they are used.
+#define BGM_OPAQUE2(a, b) asm volatile("" : "+v"(a), "+v"(b))
 
 #define BGM_LEAK 0.2f
 #define BGM_EPS 1e-6f
@@ -204,4 +208,12 @@ __device__ __forceinline__ void lrelu_inplace(f32x4 (&a)[R][NT]) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) a[rr][t][r] = lrelu(a[rr][t][r]);
+}
+
+// copy a packed weight blob (global) into LDS, all threads of the block
+__device__ __forceinline__ void lds_fill(float *lds, const float *blob, int total_floats) {
+  const f32x4 *src = reinterpret_cast<const f32x4 *>(blob);
+  f32x4 *dst = reinterpret_cast<f32x4 *>(lds);
+  for (int i = threadIdx.x; i < total_floats / 4; i += blockDim.x) dst[i] = src[i];
+  __syncthreads();
 }

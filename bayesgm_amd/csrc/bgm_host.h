@@ -66,6 +66,7 @@ struct bgm_handle {
   FitMeta fit_meta{};
   FitWs fit_ws{};
   DwArgs dw{};
+  void *bgm_state = nullptr;  // BgmState (bgm_api.hip)
   // timing
   bool timing = false;
   struct Ev { hipEvent_t a, b; int kind; };
@@ -75,6 +76,7 @@ struct bgm_handle {
 };
 
 int bgm_causal_build_blob(bgm_handle *h, hipStream_t stream);
+void bgm_bgm_free_state(bgm_handle *h);
 int causal_pack_forward(bgm_handle *h, const HostNet &G, const HostNet &F, const HostNet &H, std::vector<float> &blob);
 
 // ---- packing into MFMA fragment order (layout documented in bgm_device.h)

@@ -1,0 +1,482 @@
+// bgm_kernels.h -- BGM posterior path on gfx950: masked log-posterior + gradient, HMC, predictive draws.
+//
+// replaces (src/bayesgm/models/bgm/base.py):
+//   get_log_posterior        :665-705  -> bgm_logp_grad<> (device), bgm_logpost_kernel
+//   tfp_mcmc_sampler         :709-830  -> bgm_hmc_kernel (+ bgm_hmc_adapt_kernel for SimpleStepSizeAdaptation)
+//   predict_on_posteriors    :511-525  -> bgm_predict_cells_kernel
+// g_net = BaseVariationalNet (networks/base.py:53-117) in inference mode: the input BatchNorm is an
+// affine map and is folded into the first Dense layer on the host.
+//
+// HMC alternates forward and backward passes, so both orientations of every weight matrix are
+// needed in the same kernel; two packed copies exceed the 160 KiB LDS.  A SINGLE copy is kept in a
+// dual-access layout  [out tile][in row][17]  (row stride 17 floats): the forward A fragment
+// (lanes = 16 consecutive outputs of one input row) and the backward A fragment (lanes = 16
+// consecutive input rows of one output column) are both <= 2-way bank conflicted ds_read_b32.
+// The first layer is stored slot-permuted (slot 16t+4g+r holds input feature 16t+4r+g) so that the
+// state z, the momentum and dlogp/dz all live in the layout the Philox spec fills with one call per
+// lane (feature 16t + 4r + g in register r of lane group g).
+#pragma once
+#include "bgm_device.h"
+
+struct BgmMeta {
+  int q, p, n_hh;        // latent dim, data dim, hidden->hidden layers of the trunk
+  int w1, b1;            // [4 tiles][16*KTQ][17], [64]
+  int wh, bh;            // n_hh x ([4][64][17]), n_hh x [64]
+  int whd, bhd;          // heads [2*NTX tiles][64][17] (mean tiles then var tiles), [2*16*NTX]
+  int total;
+};
+
+// forward: acc[to] += W^T in   (acc pre-initialised with the bias).  The A values of K-step s+1 are
+// loaded while the MFMAs of step s issue; a compiler memory fence per step stops hipcc from
+// clustering all 16*KT*NT independent ds_read_b32 ahead of the MFMAs (register blow-up).
+template <int KT, int NT>
+__device__ __forceinline__ void fwd17(const float *wl, int j, int g, const f32x4 (&in)[KT], f32x4 (&acc)[NT]) {
+  BGM_OPAQUE2(j, g);
+  constexpr int KR = 16 * KT;
+  float a_cur[NT], a_nxt[NT];
+  const float *base = wl + (4 * g) * 17 + j;
+#pragma unroll
+  for (int to = 0; to < NT; ++to) a_cur[to] = base[to * KR * 17];
+#pragma unroll
+  for (int s = 0; s < 4 * KT; ++s) {
+    const int t = s >> 2, r = s & 3;
+    if (s + 1 < 4 * KT) {
+      const float *row = base + (16 * ((s + 1) >> 2) + ((s + 1) & 3)) * 17;
+#pragma unroll
+      for (int to = 0; to < NT; ++to) a_nxt[to] = row[to * KR * 17];
+    }
+#pragma unroll
+    for (int to = 0; to < NT; ++to) acc[to] = BGM_MFMA(a_cur[to], in[t][r], acc[to]);
+    BGM_NO_HOIST();
+#pragma unroll
+    for (int to = 0; to < NT; ++to) a_cur[to] = a_nxt[to];
+  }
+}
+// backward to the input: out[ti] += W dpre ;  KT_IN input tiles, NT_K output (contraction) tiles
+template <int KT_IN, int NT_K>
+__device__ __forceinline__ void bwd17(const float *wl, int i, int g, const f32x4 (&dpre)[NT_K], f32x4 (&out)[KT_IN]) {
+  BGM_OPAQUE2(i, g);
+  constexpr int KR = 16 * KT_IN;
+  float a_cur[KT_IN], a_nxt[KT_IN];
+  const float *base = wl + i * 17 + 4 * g;
+#pragma unroll
+  for (int ti = 0; ti < KT_IN; ++ti) a_cur[ti] = base[16 * ti * 17];
+#pragma unroll
+  for (int s = 0; s < 4 * NT_K; ++s) {
+    const int t = s >> 2, r = s & 3;
+    if (s + 1 < 4 * NT_K) {
+      const float *col = base + ((s + 1) >> 2) * KR * 17 + ((s + 1) & 3);
+#pragma unroll
+      for (int ti = 0; ti < KT_IN; ++ti) a_nxt[ti] = col[16 * ti * 17];
+    }
+#pragma unroll
+    for (int ti = 0; ti < KT_IN; ++ti) out[ti] = BGM_MFMA(a_cur[ti], dpre[t][r], out[ti]);
+    BGM_NO_HOIST();
+#pragma unroll
+    for (int ti = 0; ti < KT_IN; ++ti) a_cur[ti] = a_nxt[ti];
+  }
+}
+template <int NT>
+__device__ __forceinline__ void bias17(const float *bl, int g, f32x4 (&acc)[NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = *reinterpret_cast<const f32x4 *>(bl + 16 * t + 4 * g);
+}
+
+// mean tile (at wl) and variance tile (at wl + NTX*64*17) of one 16-feature block: forward ...
+template <int NTX>
+__device__ __forceinline__ void heads_fwd17(const float *wl, int j, int g, const f32x4 (&h)[4], f32x4 (&ms)[2]) {
+  BGM_OPAQUE2(j, g);
+  const float *base = wl + (4 * g) * 17 + j;
+  float c0 = base[0], c1 = base[NTX * 64 * 17], n0 = 0.0f, n1 = 0.0f;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const int t = s >> 2, r = s & 3;
+    if (s + 1 < 16) {
+      const float *row = base + (16 * ((s + 1) >> 2) + ((s + 1) & 3)) * 17;
+      n0 = row[0];
+      n1 = row[NTX * 64 * 17];
+    }
+    ms[0] = BGM_MFMA(c0, h[t][r], ms[0]);
+    ms[1] = BGM_MFMA(c1, h[t][r], ms[1]);
+    BGM_NO_HOIST();
+    c0 = n0; c1 = n1;
+  }
+}
+// ... and backward: dh[ti] += Wmean dmu + Wvar ds
+template <int NTX>
+__device__ __forceinline__ void heads_bwd17(const float *wl, int i, int g, const f32x4 (&dms)[2], f32x4 (&dh)[4]) {
+  BGM_OPAQUE2(i, g);
+  const float *base = wl + i * 17 + 4 * g;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float am[4], av[4];
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) { am[ti] = base[16 * ti * 17 + r]; av[ti] = base[NTX * 64 * 17 + 16 * ti * 17 + r]; }
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+      dh[ti] = BGM_MFMA(am[ti], dms[0][r], dh[ti]);
+      dh[ti] = BGM_MFMA(av[ti], dms[1][r], dh[ti]);
+    }
+    BGM_NO_HOIST();
+  }
+}
+
+// log p(z | x_obs) and dlogp/dz for 16 chains held by one wave.
+//   z  : feature 16t + 4r + g in register r of tile t
+//   xr : data row, feature 16t + 4g + r, NaN = missing (ignored), zero padded beyond p
+// logp is replicated over the lane groups; grad has the layout of z.
+template <int KTQ, int NTX, int NH, bool WANT_GRAD>
+__device__ __forceinline__ void bgm_logp_grad(const float *lds, const BgmMeta &m, int j, int g,
+                                              const f32x4 (&z)[KTQ], const f32x4 (&xr)[NTX], float &logp,
+                                              f32x4 (&grad)[KTQ]) {
+  // trunk forward; only the SIGN of every activation is kept for the backward pass (bit 4t+r of sgn[l])
+  unsigned sgn[NH];
+  f32x4 h[4];
+  bias17<4>(lds + m.b1, g, h);
+  fwd17<KTQ, 4>(lds + m.w1, j, g, z, h);
+  sgn[0] = 0u;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      sgn[0] |= (h[t][r] > 0.0f) ? (1u << (4 * t + r)) : 0u;
+      h[t][r] = lrelu(h[t][r]);
+    }
+  asm volatile("" : "+v"(sgn[0]));   // materialise the mask now (else the activations stay live until backward)
+#pragma unroll
+  for (int l = 1; l < NH; ++l) {
+    BGM_NO_HOIST();
+    f32x4 h2[4];
+    bias17<4>(lds + m.bh + (l - 1) * 64, g, h2);
+    fwd17<4, 4>(lds + m.wh + (l - 1) * (4 * 64 * 17), j, g, h, h2);
+    sgn[l] = 0u;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sgn[l] |= (h2[t][r] > 0.0f) ? (1u << (4 * t + r)) : 0u;
+        h[t][r] = lrelu(h2[t][r]);
+      }
+    asm volatile("" : "+v"(sgn[l]));
+  }
+  // heads, one 16-feature tile at a time: mean tile tx and variance tile NTX + tx
+  float nll = 0.0f;
+  f32x4 dh[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) dh[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int tx = 0; tx < NTX; ++tx) {
+    BGM_NO_HOIST();
+    f32x4 ms[2];
+    ms[0] = *reinterpret_cast<const f32x4 *>(lds + m.bhd + 16 * tx + 4 * g);
+    ms[1] = *reinterpret_cast<const f32x4 *>(lds + m.bhd + 16 * (NTX + tx) + 4 * g);
+    heads_fwd17<NTX>(lds + m.whd + tx * (64 * 17), j, g, h, ms);
+    f32x4 dms[2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float xv = xr[tx][r];
+      const bool obs = (xv == xv) && (16 * tx + 4 * g + r < m.p);   // NaN = missing
+      const float s2 = softplus_f(ms[1][r]) + BGM_EPS;
+      const float inv = fast_rcp(s2);
+      const float d = obs ? xv - ms[0][r] : 0.0f;
+      nll += obs ? 0.5f * (d * d * inv + fast_log(s2)) : 0.0f;
+      if (WANT_GRAD) {
+        const float sg = fast_rcp(1.0f + fast_exp(-ms[1][r]));      // sigmoid(s) = d softplus / ds
+        dms[0][r] = d * inv;                                                        // dlogp/dmu
+        dms[1][r] = obs ? (0.5f * d * d * inv * inv - 0.5f * inv) * sg : 0.0f;     // dlogp/ds
+      }
+    }
+    if (WANT_GRAD) heads_bwd17<NTX>(lds + m.whd + tx * (64 * 17), j, g, dms, dh);
+  }
+  float zsq = 0.0f;
+#pragma unroll
+  for (int t = 0; t < KTQ; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zsq = fmaf(z[t][r], z[t][r], zsq);   // padded features are zero
+  logp = -sum_over_g(nll + 0.5f * zsq);
+  if (WANT_GRAD) {
+#pragma unroll
+    for (int l = NH - 1; l >= 0; --l) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh[t][r] *= ((sgn[l] >> (4 * t + r)) & 1u) ? 1.0f : BGM_LEAK;
+      if (l > 0) {
+        BGM_NO_HOIST();
+        f32x4 dn[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dn[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        bwd17<4, 4>(lds + m.wh + (l - 1) * (4 * 64 * 17), j, g, dh, dn);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dh[t] = dn[t];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < KTQ; ++t) grad[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    bwd17<KTQ, 4>(lds + m.w1, j, g, dh, grad);
+#pragma unroll
+    for (int t = 0; t < KTQ; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) grad[t][r] -= z[t][r];   // prior  -|z|^2/2
+  }
+}
+
+template <int NTX>
+__device__ __forceinline__ void bgm_load_x(const float *x, long long n, int p, long long row, int g, f32x4 (&xr)[NTX]) {
+  const float *p_ = x + row * (long long)p;
+#pragma unroll
+  for (int t = 0; t < NTX; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = 16 * t + 4 * g + r;
+      xr[t][r] = (c < p) ? p_[c] : 0.0f;
+    }
+}
+template <int KTQ>
+__device__ __forceinline__ void bgm_load_z(const float *z, int q, long long row, int g, f32x4 (&zr)[KTQ]) {
+#pragma unroll
+  for (int t = 0; t < KTQ; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = 16 * t + 4 * r + g;
+      zr[t][r] = (f < q) ? z[row * (long long)q + f] : 0.0f;
+    }
+}
+template <int KTQ>
+__device__ __forceinline__ void bgm_store_z(float *z, int q, long long row, int g, const f32x4 (&zr)[KTQ]) {
+#pragma unroll
+  for (int t = 0; t < KTQ; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = 16 * t + 4 * r + g;
+      if (f < q) z[row * (long long)q + f] = zr[t][r];
+    }
+}
+
+// get_log_posterior (+ optional gradient) for n rows
+template <int KTQ, int NTX, int NH, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void bgm_logpost_kernel(const float *blob, BgmMeta m, const float *z,
+                                                                 const float *x, long long n, float *out,
+                                                                 float *grad_out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  lds_fill(lds, blob, m.total);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  const long long n_tiles = (n + 15) / 16;
+  for (long long tile = (long long)blockIdx.x * WAVES + wave; tile < n_tiles; tile += (long long)gridDim.x * WAVES) {
+    BGM_NO_HOIST();
+    long long row = tile * 16 + j;
+    const bool ok = row < n;
+    row = ok ? row : n - 1;
+    f32x4 xr[NTX], zr[KTQ], gr[KTQ];
+    bgm_load_x<NTX>(x, n, m.p, row, g, xr);
+    bgm_load_z<KTQ>(z, m.q, row, g, zr);
+    float lp;
+    if (grad_out != nullptr) bgm_logp_grad<KTQ, NTX, NH, true>(lds, m, j, g, zr, xr, lp, gr);
+    else bgm_logp_grad<KTQ, NTX, NH, false>(lds, m, j, g, zr, xr, lp, gr);
+    if (ok) {
+      if (g == 0) out[row] = lp;
+      if (grad_out != nullptr) bgm_store_z<KTQ>(grad_out, m.q, row, g, gr);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Hamiltonian Monte Carlo, identity mass, n_leapfrog steps, one chain per row.
+// ---------------------------------------------------------------------------
+struct BgmHmcKArgs {
+  const float *blob;
+  const float *x;            // [n x p], NaN = missing
+  long long n, row_base;
+  float *state, *logp, *grad;   // chain state [n x q], cached logp [n] and dlogp/dz [n x q] (in/out)
+  int init, it_begin, n_iters, burn_in, n_leapfrog;
+  const float *step;         // device scalar: current step size
+  unsigned k0, k1;
+  double *acc_prob_sum;      // [it]  += sum over chains of exp(min(0, log_accept_ratio))
+  unsigned *acc_count;       // [it]  += accepted chains
+  float *draws;              // [n_keep x n x q] or NULL
+  BgmMeta m;
+};
+
+template <int KTQ, int NTX, int NH, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void bgm_hmc_kernel(BgmHmcKArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const BgmMeta &m = a.m;
+  lds_fill(lds, a.blob, m.total);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  const long long n = a.n, n_tiles = (n + 15) / 16;
+  const float eps = *a.step;
+  for (long long tile = (long long)blockIdx.x * WAVES + wave; tile < n_tiles; tile += (long long)gridDim.x * WAVES) {
+    long long row = tile * 16 + j;
+    const bool ok = row < n;
+    row = ok ? row : n - 1;
+    const unsigned rowid = (unsigned)(a.row_base + row);
+    f32x4 xr[NTX], z[KTQ], gr[KTQ];
+    bgm_load_x<NTX>(a.x, n, m.p, row, g, xr);
+    float lp;
+    if (a.init) {   // initial_state ~ N(0,1)  (bgm/base.py:778), RNG tag 0
+#pragma unroll
+      for (int t = 0; t < KTQ; ++t) {
+        const f32x4 e = box_muller4(philox4x32_10(rowid, 0u, (unsigned)(g + 4 * t), TAG_INIT, a.k0, a.k1));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[t][r] = (16 * t + 4 * r + g < m.q) ? e[r] : 0.0f;
+      }
+      bgm_logp_grad<KTQ, NTX, NH, true>(lds, m, j, g, z, xr, lp, gr);
+    } else {
+      bgm_load_z<KTQ>(a.state, m.q, row, g, z);
+      bgm_load_z<KTQ>(a.grad, m.q, row, g, gr);
+      lp = a.logp[row];
+    }
+    for (int it = a.it_begin; it < a.it_begin + a.n_iters; ++it) {
+      BGM_NO_HOIST();
+      f32x4 mom[KTQ], zc[KTQ], gc[KTQ];
+      float ke0 = 0.0f;
+#pragma unroll
+      for (int t = 0; t < KTQ; ++t) {
+        const f32x4 e = box_muller4(philox4x32_10(rowid, (unsigned)it, (unsigned)(g + 4 * t), TAG_MOM, a.k0, a.k1));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pm = (16 * t + 4 * r + g < m.q) ? e[r] : 0.0f;
+          ke0 = fmaf(pm, pm, ke0);
+          mom[t][r] = fmaf(0.5f * eps, gr[t][r], pm);   // first half kick
+          zc[t][r] = z[t][r];
+        }
+      }
+      ke0 = sum_over_g(ke0);
+      float lpc = lp;
+      for (int l = 0; l < a.n_leapfrog; ++l) {
+        BGM_NO_HOIST();
+#pragma unroll
+        for (int t = 0; t < KTQ; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) zc[t][r] = fmaf(eps, mom[t][r], zc[t][r]);
+        bgm_logp_grad<KTQ, NTX, NH, true>(lds, m, j, g, zc, xr, lpc, gc);
+        const float kick = (l < a.n_leapfrog - 1) ? eps : 0.5f * eps;
+#pragma unroll
+        for (int t = 0; t < KTQ; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mom[t][r] = fmaf(kick, gc[t][r], mom[t][r]);
+      }
+      float ke1 = 0.0f;
+#pragma unroll
+      for (int t = 0; t < KTQ; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ke1 = fmaf(mom[t][r], mom[t][r], ke1);
+      ke1 = sum_over_g(ke1);
+      float log_ratio = -((-lpc + 0.5f * ke1) - (-lp + 0.5f * ke0));
+      log_ratio = (log_ratio == log_ratio && fabsf(log_ratio) != INFINITY) ? log_ratio : -INFINITY;
+      const uint4 w4 = philox4x32_10(rowid, (unsigned)it >> 2, 0u, TAG_HACC, a.k0, a.k1);
+      const unsigned w_ = (it & 2) ? ((it & 1) ? w4.w : w4.z) : ((it & 1) ? w4.y : w4.x);
+      const float u = u01_open(w_);
+      const bool acc = logf(u) < log_ratio;
+#pragma unroll
+      for (int t = 0; t < KTQ; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          z[t][r] = acc ? zc[t][r] : z[t][r];
+          gr[t][r] = acc ? gc[t][r] : gr[t][r];
+        }
+      lp = acc ? lpc : lp;
+      // per-iteration statistics for SimpleStepSizeAdaptation and the acceptance report
+      {
+        float pa = (ok && g == 0) ? expf(fminf(log_ratio, 0.0f)) : 0.0f;
+        for (int off = 8; off > 0; off >>= 1) pa += __shfl_xor(pa, off);
+        const unsigned cnt = (unsigned)__popcll(__ballot(acc && ok && g == 0));
+        if (lane == 0) {
+          if (a.acc_prob_sum) atomicAdd(a.acc_prob_sum + it, (double)pa);
+          if (a.acc_count) atomicAdd(a.acc_count + it, cnt);
+        }
+      }
+      if (a.draws != nullptr && it >= a.burn_in && ok)
+        bgm_store_z<KTQ>(a.draws + (long long)(it - a.burn_in) * n * m.q, m.q, row, g, z);
+    }
+    if (ok) {
+      bgm_store_z<KTQ>(a.state, m.q, row, g, z);
+      bgm_store_z<KTQ>(a.grad, m.q, row, g, gr);
+      if (g == 0) a.logp[row] = lp;
+    }
+  }
+}
+
+// SimpleStepSizeAdaptation (target 0.75, rate 0.01 by default): one scalar step for all chains,
+// multiplied / divided by (1 + rate) according to the mean acceptance probability of iteration `it`
+// (mean of exp(min(0, log_accept_ratio)) == exp(reduce_logmeanexp)).
+__global__ void bgm_hmc_adapt_kernel(float *step, const double *acc_prob_sum, int it, double n_chains, float target,
+                                     float rate) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const double mean = acc_prob_sum[it] / n_chains;
+    *step = (mean > (double)target) ? *step * (1.0f + rate) : *step / (1.0f + rate);
+  }
+}
+
+// predict_on_posteriors (bgm/base.py:511-525): x ~ N(mu(z_d), sigma^2(z_d)) for every retained draw d.
+//   full  [n_draws x n x p]                      (return_samples=True), or NULL
+//   cells [(row * k_slots + slot) * n_draws + d]  for features with slot[row*p + c] >= 0, or NULL
+struct BgmPredKArgs {
+  const float *blob;
+  const float *draws;       // [n_draws x n x q]
+  long long n, row_base;
+  int n_draws, burn_in, k_slots;
+  const int *slot;          // [n x p] or NULL
+  float *cells, *full;
+  unsigned k0, k1;
+  BgmMeta m;
+};
+
+template <int KTQ, int NTX, int NH, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void bgm_predict_kernel(BgmPredKArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const BgmMeta &m = a.m;
+  lds_fill(lds, a.blob, m.total);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  const long long n = a.n, n_tiles = (n + 15) / 16;
+  const long long work = n_tiles * a.n_draws;
+  for (long long w = (long long)blockIdx.x * WAVES + wave; w < work; w += (long long)gridDim.x * WAVES) {
+    BGM_NO_HOIST();
+    const long long tile = w / a.n_draws;
+    const int d = (int)(w - tile * a.n_draws);
+    long long row = tile * 16 + j;
+    const bool ok = row < n;
+    row = ok ? row : n - 1;
+    const unsigned rowid = (unsigned)(a.row_base + row);
+    f32x4 z[KTQ];
+    bgm_load_z<KTQ>(a.draws + (long long)d * n * m.q, m.q, row, g, z);
+    f32x4 h[4], h2[4];
+    bias17<4>(lds + m.b1, g, h);
+    fwd17<KTQ, 4>(lds + m.w1, j, g, z, h);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[t][r] = lrelu(h[t][r]);
+    for (int l = 1; l < NH; ++l) {
+      BGM_NO_HOIST();
+      bias17<4>(lds + m.bh + (l - 1) * 64, g, h2);
+      fwd17<4, 4>(lds + m.wh + (l - 1) * (4 * 64 * 17), j, g, h, h2);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[t][r] = lrelu(h2[t][r]);
+    }
+#pragma unroll
+    for (int tx = 0; tx < NTX; ++tx) {
+      f32x4 ms[2];
+      ms[0] = *reinterpret_cast<const f32x4 *>(lds + m.bhd + 16 * tx + 4 * g);
+      ms[1] = *reinterpret_cast<const f32x4 *>(lds + m.bhd + 16 * (NTX + tx) + 4 * g);
+      heads_fwd17<NTX>(lds + m.whd + tx * (64 * 17), j, g, h, ms);
+      // reparameterize (networks/base.py:113-117): noise = Philox tag 6, call (16 tx + 4 g)/4, outputs r
+      const f32x4 e = box_muller4(philox4x32_10(rowid, (unsigned)(a.burn_in + d), (unsigned)(4 * tx + g), TAG_XNOISE, a.k0, a.k1));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 16 * tx + 4 * g + r;
+        if (ok && c < m.p) {
+          const float s2 = softplus_f(ms[1][r]) + BGM_EPS;
+          const float xp = fmaf(__builtin_sqrtf(s2), e[r], ms[0][r]);
+          if (a.full) a.full[((long long)d * n + row) * m.p + c] = xp;
+          if (a.cells) {
+            const int sl = a.slot[row * (long long)m.p + c];
+            if (sl >= 0) a.cells[(row * (long long)a.k_slots + sl) * a.n_draws + d] = xp;
+          }
+        }
+      }
+    }
+  }
+}

@@ -35,6 +35,7 @@ extern "C" int bgm_destroy(bgm_handle *h) {
   if (h->blob_dev) hipFree(h->blob_dev);
   if (h->eblob_dev) hipFree(h->eblob_dev);
   bgm_causal_fit_end(h, nullptr);
+  bgm_bgm_free_state(h);
   for (auto &e : h->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   delete h;
   return BGM_OK;

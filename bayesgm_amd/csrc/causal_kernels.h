@@ -258,12 +258,6 @@ __device__ __forceinline__ void store_z_rows(float *z, long long n, int q, long 
   }
 }
 
-__device__ __forceinline__ void lds_fill(float *lds, const float *blob, int total_floats) {
-  const f32x4 *src = reinterpret_cast<const f32x4 *>(blob);
-  f32x4 *dst = reinterpret_cast<f32x4 *>(lds);
-  for (int i = threadIdx.x; i < total_floats / 4; i += blockDim.x) dst[i] = src[i];
-  __syncthreads();
-}
 
 // ---------------------------------------------------------------------------
 // get_log_posterior for n rows (one evaluation)

@@ -290,3 +290,130 @@ class CausalEngine(object):
             adrf = self.adrf_reduce(partial, n_slots, xv.numel(), n_keep, n)
         return dict(state=state, logp=logp, acc_count=acc, draws=draws, adrf=adrf, ite=ite, q_sd=q_sd,
                     adrf_partial=partial, n_slots=n_slots)
+
+
+def flatten_varnet(g):
+    """oracle/reference BaseVariationalNet dict -> flat float32 in the order of bgm_bgm_set_weights."""
+    parts = [g["bn"]["gamma"], g["bn"]["beta"], g["bn"]["mean"], g["bn"]["var"]]
+    for W, b in g["trunk"]:
+        parts += [W, b]
+    parts += [g["mean"][0], g["mean"][1], g["var"][0], g["var"][1]]
+    return np.concatenate([np.asarray(a, np.float32).ravel() for a in parts]).astype(np.float32)
+
+
+class BgmEngine(object):
+    """Device-side state of one BGM generator (BaseVariationalNet, inference mode) + kernels."""
+
+    def __init__(self, x_dim, z_dim, g_units=None, device=0):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("bayesgm_amd: no HIP device visible; the hot path has no CPU fallback")
+        self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
+        torch.cuda.init()
+        torch.zeros(1, device=self.device)
+        self.p, self.q = int(x_dim), int(z_dim)
+        units = list(DEFAULT_G_UNITS if g_units is None else g_units)
+        cfg = _lib.BgmConfig()
+        cfg.x_dim, cfg.z_dim, cfg.n_hidden_g = self.p, self.q, len(units)
+        for i, u in enumerate(units):
+            cfg.g_units[i] = int(u)
+        self.h = C.c_void_p()
+        _lib.check(self.lib.bgm_create(C.byref(self.h), self.device.index), "bgm_create")
+        _lib.check(self.lib.bgm_bgm_configure(self.h, C.byref(cfg)), "bgm_bgm_configure")
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.bgm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_weights(self, g):
+        theta = flatten_varnet(g) if isinstance(g, dict) else np.ascontiguousarray(g, np.float32)
+        _lib.check(self.lib.bgm_bgm_set_weights(self.h, theta.ctypes.data_as(C.c_void_p), theta.size, self._stream()),
+                   "bgm_bgm_set_weights")
+
+    def logpost(self, z, x, want_grad=False):
+        """get_log_posterior (bgm/base.py:665-705); x carries NaN at missing cells."""
+        z, x = _f32(z, self.device), _f32(x, self.device)
+        n = x.shape[0]
+        out = torch.empty(n, device=self.device, dtype=torch.float32)
+        grad = torch.empty((n, self.q), device=self.device, dtype=torch.float32) if want_grad else None
+        _lib.check(self.lib.bgm_bgm_logpost(self.h, _ptr(z), _ptr(x), n, _ptr(out), _ptr(grad), self._stream()),
+                   "bgm_bgm_logpost")
+        return (out, grad) if want_grad else out
+
+    def hmc_run(self, x, state, logp, grad, step, it_begin, n_iters, burn_in, n_leapfrog, seed, init=False,
+                row_base=0, acc_prob=None, acc_count=None, draws=None):
+        a = _lib.HmcArgs()
+        a.x_dev = x.data_ptr(); a.n = x.shape[0]; a.row_base = int(row_base)
+        a.state_dev, a.logp_dev, a.grad_dev = state.data_ptr(), logp.data_ptr(), grad.data_ptr()
+        a.init = int(bool(init)); a.it_begin = int(it_begin); a.n_iters = int(n_iters); a.burn_in = int(burn_in)
+        a.n_leapfrog = int(n_leapfrog); a.step_dev = step.data_ptr(); a.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        a.acc_prob_sum_dev = acc_prob.data_ptr() if acc_prob is not None else None
+        a.acc_count_dev = acc_count.data_ptr() if acc_count is not None else None
+        a.draws_dev = draws.data_ptr() if draws is not None else None
+        _lib.check(self.lib.bgm_bgm_hmc_run(self.h, C.byref(a), self._stream()), "bgm_bgm_hmc_run")
+
+    def hmc_adapt(self, step, acc_prob, it, n_chains, target=0.75, rate=0.01):
+        _lib.check(self.lib.bgm_bgm_hmc_adapt(self.h, _ptr(step), _ptr(acc_prob), int(it), float(n_chains),
+                                              float(target), float(rate), self._stream()), "bgm_bgm_hmc_adapt")
+
+    def hmc_sample(self, x, n_mcmc, burn_in, step_size=0.01, n_leapfrog=10, seed=42, row_base=0, want_draws=True,
+                   n_chains_global=None, reduce_fn=None):
+        """tfp_mcmc_sampler (bgm/base.py:709-830): HMC + SimpleStepSizeAdaptation over int(0.8*burn_in)
+        steps, all rows one chain each.  `reduce_fn(tensor)` all-reduces the per-iteration acceptance
+        statistic across ranks (the step size is shared by ALL chains)."""
+        dev = self.device
+        x = _f32(x, dev)
+        n = x.shape[0]
+        total = burn_in + n_mcmc
+        state = torch.empty((n, self.q), device=dev)
+        logp = torch.empty(n, device=dev)
+        grad = torch.empty((n, self.q), device=dev)
+        step = torch.full((1,), float(step_size), device=dev, dtype=torch.float32)
+        acc_prob = torch.zeros(total, device=dev, dtype=torch.float64)
+        acc_count = torch.zeros(total, device=dev, dtype=torch.int32)
+        draws = torch.empty((n_mcmc, n, self.q), device=dev) if want_draws else None
+        n_adapt = int(burn_in * 0.8)
+        n_all = float(n_chains_global if n_chains_global is not None else n)
+        it = 0
+        while it < n_adapt:          # one launch per transition: the step size changes after each
+            self.hmc_run(x, state, logp, grad, step, it, 1, burn_in, n_leapfrog, seed, init=(it == 0),
+                         row_base=row_base, acc_prob=acc_prob, acc_count=acc_count, draws=draws)
+            if reduce_fn is not None:
+                reduce_fn(acc_prob[it:it + 1])
+            self.hmc_adapt(step, acc_prob, it, n_all)
+            it += 1
+        if it < total:
+            self.hmc_run(x, state, logp, grad, step, it, total - it, burn_in, n_leapfrog, seed, init=(it == 0),
+                         row_base=row_base, acc_prob=acc_prob, acc_count=acc_count, draws=draws)
+        return dict(state=state, logp=logp, grad=grad, step=step, acc_prob=acc_prob, acc_count=acc_count, draws=draws)
+
+    def predict_draws(self, draws, burn_in, seed, slot=None, k_slots=0, want_full=False, row_base=0):
+        """predict_on_posteriors (bgm/base.py:511-525) -> (cells [n*k_slots, n_draws] | None, full | None)."""
+        n_draws, n, _ = draws.shape
+        cells = torch.zeros((n * k_slots, n_draws), device=self.device) if slot is not None else None
+        full = torch.empty((n_draws, n, self.p), device=self.device) if want_full else None
+        _lib.check(self.lib.bgm_bgm_predict_draws(self.h, _ptr(draws), n, int(row_base), n_draws, int(burn_in),
+                                                  int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(slot), int(k_slots),
+                                                  _ptr(cells), _ptr(full), self._stream()), "bgm_bgm_predict_draws")
+        return cells, full
+
+    def row_mean_quantiles(self, mat, q_lo, q_hi):
+        mat = mat.contiguous()
+        n_rows, m = mat.shape
+        mean = torch.empty(n_rows, device=self.device, dtype=torch.float32)
+        lo = torch.empty_like(mean)
+        hi = torch.empty_like(mean)
+        _lib.check(self.lib.bgm_row_mean_quantiles(self.h, _ptr(mat), n_rows, m, float(q_lo), float(q_hi),
+                                                   _ptr(mean), _ptr(lo), _ptr(hi), self._stream()),
+                   "bgm_row_mean_quantiles")
+        return mean, lo, hi

@@ -216,6 +216,60 @@ int bgm_causal_get_weights(bgm_handle *h, int net_id, float *theta_host, int64_t
 /* End the fit session (frees the workspace; the trained parameters stay installed). */
 int bgm_causal_fit_end(bgm_handle *h, void *stream);
 
+/* ==========================================================================================
+ * BGM (bgm/base.py): posterior of Z given partially observed rows, HMC, predictive draws.
+ * g_net = BaseVariationalNet (networks/base.py:53-117) evaluated with training=False.
+ * ========================================================================================== */
+typedef struct {
+  int32_t x_dim, z_dim;
+  int32_t n_hidden_g, g_units[BGM_MAX_LAYERS];
+} bgm_bgm_config;
+
+int bgm_bgm_configure(bgm_handle *h, const bgm_bgm_config *cfg);
+
+/* Generator parameters from HOST memory, flat float32:
+ *   BatchNormalization gamma[q], beta[q], moving_mean[q], moving_variance[q]   (networks/base.py:76),
+ *   then per trunk Dense layer W [in x out], b [out], then mean_layer W, b, then var_layer W, b. */
+int bgm_bgm_set_weights(bgm_handle *h, const float *theta_host, int64_t count, void *stream);
+
+/* log p(z | x_obs) + const for n rows; x_dev [n x p] with NaN marking missing cells
+ * (the reference passes index lists + obs_mask: bgm/base.py:578-592, 689-700).  grad_dev
+ * [n x q] (dlogp/dz) may be NULL.  replaces: BGM.get_log_posterior, bgm/base.py:665-705. */
+int bgm_bgm_logpost(bgm_handle *h, const float *z_dev, const float *x_dev, int64_t n, float *out_dev,
+                    float *grad_dev, void *stream);
+
+/* One segment of HMC transitions for all rows.
+ * replaces: tfp.mcmc.HamiltonianMonteCarlo(step_size, num_leapfrog_steps).one_step driven by
+ * tfp.mcmc.sample_chain, bgm/base.py:798-821. */
+typedef struct {
+  const float *x_dev;          /* [n x p], NaN = missing                          */
+  int64_t n, row_base;
+  float *state_dev;            /* [n x q] in/out                                  */
+  float *logp_dev;             /* [n]     in/out (cached target log prob)         */
+  float *grad_dev;             /* [n x q] in/out (cached gradient)                */
+  int32_t init;                /* 1: state ~ N(0,1) (bgm/base.py:778)             */
+  int32_t it_begin, n_iters, burn_in, n_leapfrog;
+  const float *step_dev;       /* device scalar: step size                        */
+  uint64_t seed;
+  double *acc_prob_sum_dev;    /* [>= it_begin+n_iters] += sum_chains exp(min(0, log_accept_ratio)), or NULL */
+  uint32_t *acc_count_dev;     /* [>= it_begin+n_iters] += accepted chains, or NULL */
+  float *draws_dev;            /* [n_keep x n x q] states after burn_in, or NULL  */
+} bgm_hmc_args;
+int bgm_bgm_hmc_run(bgm_handle *h, const bgm_hmc_args *args, void *stream);
+
+/* tfp.mcmc.SimpleStepSizeAdaptation update after iteration `it`:  *step_dev *= (1+rate) if
+ * acc_prob_sum_dev[it] / n_chains > target else /= (1+rate).  (bgm/base.py:805-809: target 0.75;
+ * TFP default adaptation_rate 0.01.)  With several ranks, all-reduce acc_prob_sum_dev[it] first. */
+int bgm_bgm_hmc_adapt(bgm_handle *h, float *step_dev, const double *acc_prob_sum_dev, int32_t it,
+                      double n_chains, float target, float rate, void *stream);
+
+/* Posterior-predictive draws x ~ N(mu(z_d), sigma^2(z_d)) for draws_dev [n_draws x n x q]:
+ * full_dev [n_draws x n x p] (or NULL) and / or cells_dev [(row*k_slots + slot)*n_draws + d] for
+ * the cells with slot_dev[row*p + c] >= 0 (or NULL).  replaces: predict_on_posteriors, :511-525. */
+int bgm_bgm_predict_draws(bgm_handle *h, const float *draws_dev, int64_t n, int64_t row_base, int32_t n_draws,
+                          int32_t burn_in, uint64_t seed, const int32_t *slot_dev, int32_t k_slots,
+                          float *cells_dev, float *full_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,26 @@
+"""Fit-step throughput probe (dev tool): python scripts/probe_fit.py N B [lazy] [steps]"""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+from bayesgm_amd.engine import CausalEngine
+from oracle import causal as OC
+N = int(float(sys.argv[1])); B = int(float(sys.argv[2])); lazy = len(sys.argv) > 3 and sys.argv[3] == "lazy"
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 200
+z_dims, p = [1, 1, 1, 7], 200
+m = OC.init_model(0, z_dims, p)
+eng = CausalEngine(p, z_dims); eng.set_model(g=m["g"], f=m["f"], h=m["h"], e=m["e"])
+g = torch.Generator(device="cuda").manual_seed(0)
+v = torch.randn(N, p, device="cuda", generator=g); x = torch.rand(N, device="cuda", generator=g); y = torch.randn(N, device="cuda", generator=g)
+z = torch.randn(N, 10, device="cuda", generator=g); zm = torch.zeros_like(z); zv = torch.zeros_like(z)
+npar = eng.fit_begin(N, B); grad = torch.empty(npar, device="cuda")
+perm = torch.randperm(N, device="cuda", generator=g).to(torch.int32)
+def run(k):
+    for s in range(k):
+        i = (s * B) % max(1, N - B)
+        idx = perm[i:i + B]
+        eng.fit_theta_grad(x, y, v, z, idx, B, grad); eng.fit_theta_apply(grad, 1e-4)
+        eng.fit_z_step(x, y, v, z, zm, zv, idx, B, 1e-4, lazy=lazy)
+run(5); torch.cuda.synchronize(); t0 = time.time(); run(steps); torch.cuda.synchronize(); dt = time.time() - t0
+flop = 348480.0 * B * steps
+print(f"N={N} B={B} lazy={lazy}: {dt/steps*1e6:.1f} us/step, {B*steps/dt:.3e} obs/s, {flop/dt/1e12:.2f} TFLOP/s algorithmic")
+eng.fit_end()

@@ -136,3 +136,81 @@ def test_fit_epochs_reduces_loss():
     hist = OF.fit_epochs(st, (x, y, v), 20, 32, np.random.RandomState(0))
     assert hist.shape == (21 * 2, 7)
     assert hist[-4:, 4].mean() < hist[:4, 4].mean()  # loss_v decreases
+
+
+# ----------------------------------------------------------------------------- BGM
+def _bgm_setup(seed=0, n=20, p=13, q=5):
+    from oracle import bgm as OB
+    m = OB.cast_model(OB.init_model(seed, q, p, g_units=(16, 16, 16)), np.float64)
+    rs = np.random.RandomState(seed + 1)
+    g = m["g"]
+    g["bn"].update(gamma=1 + 0.1 * rs.randn(q), beta=0.1 * rs.randn(q), mean=0.2 * rs.randn(q), var=0.5 + rs.rand(q))
+    g["trunk"] = [(W, 0.1 * rs.randn(*b.shape)) for W, b in g["trunk"]]
+    z = rs.randn(n, q)
+    x = rs.randn(n, p)
+    mask = (rs.rand(n, p) > 0.3).astype(np.float64)
+    return OB, m, z, x, mask
+
+
+def _torch_varnet(g, z, training):
+    bn = g["bn"]
+    if training:
+        mu = z.mean(0)
+        var = z.var(0, unbiased=False)
+        zn = (z - mu) / torch.sqrt(var + 1e-3) * bn["gamma"] + bn["beta"]
+    else:
+        zn = (z - bn["mean"]) / torch.sqrt(bn["var"] + 1e-3) * bn["gamma"] + bn["beta"]
+    h = zn
+    for W, b in g["trunk"]:
+        h = h @ W + b
+        h = torch.maximum(h, 0.2 * h)
+    return h @ g["mean"][0] + g["mean"][1], torch.nn.functional.softplus(h @ g["var"][0] + g["var"][1]) + 1e-6
+
+
+def _tg(g, req):
+    f = (lambda a: _t(a).requires_grad_()) if req else _t
+    return {"bn": {k: f(v) if k in ("gamma", "beta") else _t(v) for k, v in g["bn"].items()},
+            "trunk": [(f(W), f(b)) for W, b in g["trunk"]], "mean": (f(g["mean"][0]), f(g["mean"][1])),
+            "var": (f(g["var"][0]), f(g["var"][1]))}
+
+
+def test_bgm_log_posterior_gradient_matches_autograd():
+    OB, m, z, x, mask = _bgm_setup()
+    tz = _t(z).requires_grad_()
+    mu, s2 = _torch_varnet(_tg(m["g"], False), tz, training=False)
+    lp = -((_t(mask) * ((_t(x) - mu) ** 2 / (2 * s2) + 0.5 * torch.log(s2))).sum(1) + (tz ** 2).sum(1) / 2)
+    lp.sum().backward()
+    lp_o, gr_o = OB.log_posterior_and_grad(m, z, x, mask)
+    assert np.allclose(lp_o, lp.detach().numpy(), rtol=1e-12)
+    assert np.allclose(gr_o, tz.grad.numpy(), rtol=1e-9, atol=1e-12)
+    assert np.allclose(OB.log_posterior(m, z, x, mask), lp_o, rtol=1e-12)
+
+
+def test_bgm_fit_gradients_with_batchnorm_match_autograd():
+    OB, m, z, x, _ = _bgm_setup(seed=3)
+    tg = _tg(m["g"], True)
+    tz = _t(z).requires_grad_()
+    mu, s2 = _torch_varnet(tg, tz, training=True)
+    loss = (((_t(x) - mu) ** 2) / (2 * s2) + 0.5 * torch.log(s2)).sum(1).mean()
+    loss.backward()
+    l, _, gr, dz, _ = OB.g_loss_and_grads(m, z, x)
+    assert np.isclose(l, loss.item(), rtol=1e-12)
+    assert np.allclose(dz, tz.grad.numpy(), rtol=1e-8, atol=1e-12)
+    assert np.allclose(gr["gamma"], tg["bn"]["gamma"].grad.numpy(), rtol=1e-8, atol=1e-12)
+    assert np.allclose(gr["beta"], tg["bn"]["beta"].grad.numpy(), rtol=1e-8, atol=1e-12)
+    for (dW, db), (W, b) in zip(gr["trunk"], tg["trunk"]):
+        assert np.allclose(dW, W.grad.numpy(), rtol=1e-8, atol=1e-12) and np.allclose(db, b.grad.numpy(), rtol=1e-8, atol=1e-12)
+    for k in ("mean", "var"):
+        assert np.allclose(gr[k][0], tg[k][0].grad.numpy(), rtol=1e-8, atol=1e-12)
+        assert np.allclose(gr[k][1], tg[k][1].grad.numpy(), rtol=1e-8, atol=1e-12)
+
+
+def test_bgm_hmc_samples_known_gaussian_posterior():
+    """Known-answer test of the HMC restatement: with all features masked out the posterior is the
+    N(0, I) prior; sample mean / variance must match and the step size must adapt upwards."""
+    OB, m, z, x, mask = _bgm_setup(seed=5, n=400, p=7, q=3)
+    out, info = OB.hmc_sampler(m, x, np.zeros_like(mask), n_mcmc=150, burn_in=100, step_size=0.05, n_leapfrog=5,
+                               seed=9, return_info=True)
+    flat = out.reshape(-1, 3)
+    assert np.abs(flat.mean(0)).max() < 0.05 and np.abs(flat.var(0) - 1).max() < 0.1
+    assert info["step"] > 0.05 and 0.5 < info["accept_rate"] <= 1.0
