@@ -98,7 +98,8 @@ SYMBOLS = {
     "bgm_bgm_hmc_adapt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_float, C.c_float,
                                     C.c_void_p]),
     "bgm_bgm_predict_draws": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
-                                        C.c_uint64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                        C.c_uint64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                        C.c_void_p]),
 }
 
 _lib = None

@@ -219,10 +219,10 @@ extern "C" int bgm_bgm_hmc_adapt(bgm_handle *h, float *step, const double *acc_p
 
 extern "C" int bgm_bgm_predict_draws(bgm_handle *h, const float *draws, int64_t n, int64_t row_base, int32_t n_draws,
                                      int32_t burn_in, uint64_t seed, const int32_t *slot, int32_t k_slots, float *cells,
-                                     float *full, void *stream_) {
+                                     float *full, float *var_full, int32_t add_noise, void *stream_) {
   if (!h || !h->bgm_state || !bst(h)->configured) { bgm_set_error("bgm_bgm_predict_draws: not configured"); return BGM_E_STATE; }
   if (n <= 0 || n_draws <= 0) return BGM_OK;
-  if (!draws || (!cells && !full) || (cells && (!slot || k_slots <= 0))) { bgm_set_error("bgm_bgm_predict_draws: bad pointers"); return BGM_E_INVALID; }
+  if (!draws || (!cells && !full && !var_full) || (cells && (!slot || k_slots <= 0))) { bgm_set_error("bgm_bgm_predict_draws: bad pointers"); return BGM_E_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
   int rc = bgm_build_blob(h, stream);
@@ -230,7 +230,7 @@ extern "C" int bgm_bgm_predict_draws(bgm_handle *h, const float *draws, int64_t 
   BgmState *s = bst(h);
   BgmPredKArgs ka{};
   ka.blob = s->blob_dev; ka.draws = draws; ka.n = n; ka.row_base = row_base; ka.n_draws = n_draws; ka.burn_in = burn_in;
-  ka.k_slots = k_slots; ka.slot = slot; ka.cells = cells; ka.full = full;
+  ka.k_slots = k_slots; ka.slot = slot; ka.cells = cells; ka.full = full; ka.var_full = var_full; ka.add_noise = add_noise;
   ka.k0 = (unsigned)(seed & 0xFFFFFFFFull); ka.k1 = (unsigned)(seed >> 32); ka.m = s->meta;
   const long long work = ((n + 15) / 16) * (long long)n_draws;
   const int grid = (int)std::max<long long>(1, std::min<long long>((work + BGM_WAVES - 1) / BGM_WAVES, (long long)h->n_cus));

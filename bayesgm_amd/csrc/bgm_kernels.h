@@ -417,7 +417,8 @@ struct BgmPredKArgs {
   long long n, row_base;
   int n_draws, burn_in, k_slots;
   const int *slot;          // [n x p] or NULL
-  float *cells, *full;
+  float *cells, *full, *var_full;   // var_full [n_draws x n x p]: sigma^2 of every cell, or NULL
+  int add_noise;                     // 0: x = mu (use_x_sd=False paths)
   unsigned k0, k1;
   BgmMeta m;
 };
@@ -469,8 +470,9 @@ __global__ __launch_bounds__(64 * WAVES) void bgm_predict_kernel(BgmPredKArgs a)
         const int c = 16 * tx + 4 * g + r;
         if (ok && c < m.p) {
           const float s2 = softplus_f(ms[1][r]) + BGM_EPS;
-          const float xp = fmaf(__builtin_sqrtf(s2), e[r], ms[0][r]);
+          const float xp = a.add_noise ? fmaf(__builtin_sqrtf(s2), e[r], ms[0][r]) : ms[0][r];
           if (a.full) a.full[((long long)d * n + row) * m.p + c] = xp;
+          if (a.var_full) a.var_full[((long long)d * n + row) * m.p + c] = s2;
           if (a.cells) {
             const int sl = a.slot[row * (long long)m.p + c];
             if (sl >= 0) a.cells[(row * (long long)a.k_slots + sl) * a.n_draws + d] = xp;

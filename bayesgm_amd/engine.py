@@ -397,15 +397,18 @@ class BgmEngine(object):
                          row_base=row_base, acc_prob=acc_prob, acc_count=acc_count, draws=draws)
         return dict(state=state, logp=logp, grad=grad, step=step, acc_prob=acc_prob, acc_count=acc_count, draws=draws)
 
-    def predict_draws(self, draws, burn_in, seed, slot=None, k_slots=0, want_full=False, row_base=0):
-        """predict_on_posteriors (bgm/base.py:511-525) -> (cells [n*k_slots, n_draws] | None, full | None)."""
+    def predict_draws(self, draws, burn_in, seed, slot=None, k_slots=0, want_full=False, row_base=0, want_var=False,
+                      add_noise=True):
+        """predict_on_posteriors (bgm/base.py:511-525) -> (cells [n*k_slots, n_draws] | None, full | None[, var])."""
         n_draws, n, _ = draws.shape
         cells = torch.zeros((n * k_slots, n_draws), device=self.device) if slot is not None else None
         full = torch.empty((n_draws, n, self.p), device=self.device) if want_full else None
+        var = torch.empty((n_draws, n, self.p), device=self.device) if want_var else None
         _lib.check(self.lib.bgm_bgm_predict_draws(self.h, _ptr(draws), n, int(row_base), n_draws, int(burn_in),
                                                   int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(slot), int(k_slots),
-                                                  _ptr(cells), _ptr(full), self._stream()), "bgm_bgm_predict_draws")
-        return cells, full
+                                                  _ptr(cells), _ptr(full), _ptr(var), int(bool(add_noise)),
+                                                  self._stream()), "bgm_bgm_predict_draws")
+        return (cells, full, var) if want_var else (cells, full)
 
     def row_mean_quantiles(self, mat, q_lo, q_hi):
         mat = mat.contiguous()

@@ -1,4 +1,5 @@
 """Drop-in mirror of ``bayesgm.models`` for the hot path."""
 from .causalbgm import CausalBGM
+from .bgm import BGM
 
-__all__ = ["CausalBGM"]
+__all__ = ["CausalBGM", "BGM"]

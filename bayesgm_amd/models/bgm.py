@@ -1,0 +1,242 @@
+"""BGM -- host-side mirror of the reference class, driving the gfx950 kernels of libbgm_hip.so.
+
+Mirrors /root/reference/src/bayesgm/models/bgm/base.py:
+    __init__ :59-121   get_config :123   fit :343   evaluate :445   generate :479
+    predict_on_posteriors :511   predict :527   get_log_posterior :666   tfp_mcmc_sampler :709
+Deterministic generator (``use_bnn=False``: BaseVariationalNet, networks/base.py:53-117) only;
+``use_bnn=True`` raises NotImplementedError.
+"""
+import datetime
+import os
+
+import numpy as np
+import torch
+
+from .. import parallel
+from ..engine import BgmEngine
+from ..datasets import Gaussian_sampler
+
+_DEFAULTS = dict(use_bnn=False, g_units=[64] * 5, e_units=[64] * 5, dz_units=[64, 32, 8], dx_units=[64, 32, 8],
+                 lr=0.001, lr_theta=0.005, lr_z=0.005, g_d_freq=1, save_model=False, save_res=True, kl_weight=5e-5,
+                 use_z_rec=True, alpha=0.0, gamma=0.0)
+
+
+def _glorot(rs, fan_in, fan_out):
+    lim = np.sqrt(6.0 / (fan_in + fan_out))
+    return rs.uniform(-lim, lim, size=(fan_in, fan_out)).astype(np.float32)
+
+
+class BGM(object):
+    def __init__(self, params, timestamp=None, random_seed=None, device=None):
+        self.params = params
+        self.timestamp = timestamp
+        p = dict(_DEFAULTS)
+        p.update(params)
+        self._p = p
+        if p["use_bnn"]:
+            raise NotImplementedError("bayesgm_amd: use_bnn=True (BayesianVariationalNet) is not built yet; "
+                                      "set params['use_bnn']=False")
+        if random_seed is not None:
+            np.random.seed(random_seed)
+        self._rs = np.random.RandomState(random_seed)
+        q, xd = int(p["z_dim"]), int(p["x_dim"])
+        dims = [q] + list(p["g_units"])
+        # BaseVariationalNet parameters: BatchNormalization(z) + Dense stack + mean/var heads, Keras defaults
+        self.g = {"bn": {"gamma": np.ones(q, np.float32), "beta": np.zeros(q, np.float32),
+                         "mean": np.zeros(q, np.float32), "var": np.ones(q, np.float32)},
+                  "trunk": [(_glorot(self._rs, dims[i], dims[i + 1]), np.zeros(dims[i + 1], np.float32))
+                            for i in range(len(dims) - 1)],
+                  "mean": (_glorot(self._rs, dims[-1], xd), np.zeros(xd, np.float32)),
+                  "var": (_glorot(self._rs, dims[-1], xd), np.zeros(xd, np.float32))}
+        self.z_sampler = Gaussian_sampler(mean=np.zeros(q), sd=1.0)
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", 0))
+        self.engine = BgmEngine(xd, q, g_units=p["g_units"], device=device)
+        self.engine.set_weights(self.g)
+        if self.timestamp is None:
+            self.timestamp = datetime.datetime.now().astimezone().strftime('%Y%m%d_%H%M%S')
+        self.checkpoint_path = "{}/checkpoints/{}/{}".format(params['output_dir'], params['dataset'], self.timestamp)
+        if p['save_model'] and not os.path.exists(self.checkpoint_path):
+            os.makedirs(self.checkpoint_path, exist_ok=True)
+        self.save_dir = "{}/results/{}/{}".format(params['output_dir'], params['dataset'], self.timestamp)
+        if p['save_res'] and not os.path.exists(self.save_dir):
+            os.makedirs(self.save_dir, exist_ok=True)
+        self.data_z = None
+        self.last_acceptance_rate = None
+
+    def get_config(self):
+        return {"params": self.params}
+
+    def set_weights(self, g):
+        """Install generator parameters (dict with 'bn', 'trunk', 'mean', 'var' as in oracle/nets.init_varnet)."""
+        self.g = g
+        self.engine.set_weights(g)
+
+    def _dev(self, a):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.engine.device, dtype=torch.float32).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.engine.device)
+
+    # ------------------------------------------------------------------ inference helpers
+    def get_log_posterior(self, data_z, data_x, ind_x1=None, obs_mask=None):
+        """log p(z | x_obs) + const (bgm/base.py:665-705).  Missing cells: NaN in data_x, or the reference's
+        (ind_x1 [n,K], obs_mask [n,K]) index form, which is converted to the NaN form."""
+        x = np.array(data_x, dtype=np.float32, copy=True)
+        if ind_x1 is not None:
+            ind = np.asarray(ind_x1)
+            if ind.ndim == 1:
+                ind = np.broadcast_to(ind[None, :], (x.shape[0], ind.shape[0]))
+            keep = np.zeros(x.shape, bool)
+            mk = np.ones(ind.shape, bool) if obs_mask is None else (np.asarray(obs_mask) > 0)
+            rows = np.repeat(np.arange(x.shape[0])[:, None], ind.shape[1], 1)
+            keep[rows[mk], ind[mk]] = True
+            x[~keep] = np.nan
+        return self.engine.logpost(self._dev(data_z), self._dev(x)).cpu().numpy()
+
+    def tfp_mcmc_sampler(self, data, ind_x1=None, n_mcmc=3000, burn_in=5000, step_size=0.01, num_leapfrog_steps=10,
+                         seed=42):
+        """Posterior samples of Z, shape (n_mcmc, n, z_dim) (bgm/base.py:709-830)."""
+        x = np.array(data, dtype=np.float32, copy=True)
+        if ind_x1 is not None:
+            keep = np.zeros(x.shape, bool)
+            if len(ind_x1) > 0 and isinstance(ind_x1[0], (list, tuple, np.ndarray)):
+                assert len(ind_x1) == x.shape[0], f"len(ind_x1)={len(ind_x1)} != n_samples={x.shape[0]}"
+                assert max(len(r) for r in ind_x1) > 0, "No observed features"
+                for i, r in enumerate(ind_x1):
+                    keep[i, list(r)] = True
+            else:
+                keep[:, list(ind_x1)] = True
+            x[~keep] = np.nan
+        out = self.engine.hmc_sample(self._dev(x), n_mcmc, burn_in, step_size, num_leapfrog_steps, seed)
+        self.last_acceptance_rate = float(out["acc_count"][burn_in:].sum().item()) / max(1, n_mcmc * x.shape[0])
+        print(f"TFP MCMC Acceptance Rate: {self.last_acceptance_rate:.4f}")
+        return out["draws"].cpu().numpy()
+
+    def predict_on_posteriors(self, data_posterior_z, seed=0):
+        """x ~ N(mu(z), sigma^2(z)) for every draw (bgm/base.py:511-525) -> (n_mcmc, n, x_dim)."""
+        _, full = self.engine.predict_draws(self._dev(data_posterior_z), 0, seed, want_full=True)
+        return full.cpu().numpy()
+
+    def generate(self, nb_samples=1000, use_x_sd=True):
+        """(data_x_gen, sigma_square_x) from z ~ N(0, I) (bgm/base.py:478-509)."""
+        z = np.random.normal(0, 1, size=(1, nb_samples, self.engine.q)).astype(np.float32)
+        return self._decode(z[0], use_x_sd)
+
+    def _decode(self, z, use_x_sd, seed=None):
+        """(x, sigma^2) for latent rows z with g_net(training=False) on the device (bgm/base.py:468-473,503-508)."""
+        seed = int(np.random.randint(0, 2 ** 31 - 1)) if seed is None else seed
+        zt = self._dev(z)[None]
+        _, full, var = self.engine.predict_draws(zt, 0, seed, want_full=True, want_var=True, add_noise=use_x_sd)
+        return full[0].cpu().numpy(), var[0].cpu().numpy()
+
+    def evaluate(self, data, data_z=None, use_x_sd=True):
+        """mse_x between data and its reconstruction (bgm/base.py:444-476)."""
+        if data_z is None:
+            raise NotImplementedError("bayesgm_amd: BGM.evaluate(data_z=None) needs the EGM encoder (SURVEY 8f N1); "
+                                      "pass data_z")
+        z = data_z.cpu().numpy() if isinstance(data_z, torch.Tensor) else np.asarray(data_z, np.float32)
+        x_pred, _ = self._decode(z, use_x_sd)
+        return np.float32(np.mean((np.asarray(data, np.float32) - x_pred) ** 2))
+
+    # ------------------------------------------------------------------ predict
+    def predict(self, data, alpha=0.05, return_samples=False, bs=100, n_mcmc=5000, burn_in=5000, step_size=0.01,
+                num_leapfrog_steps=10, seed=42, max_draw_bytes=8 << 30):
+        """Posterior-predictive imputation of the NaN cells (bgm/base.py:527-663).
+
+        HMC burn-in (with the shared step-size adaptation) runs over ALL rows at once as in the reference;
+        the sampling phase then runs in row blocks sized so that the latent draws and the predictive cells of
+        a block stay below ``max_draw_bytes`` (the reference materialises [n_mcmc, n, x_dim] on the host)."""
+        assert 0 < alpha < 1, "The significance level 'alpha' must be greater than 0 and less than 1."
+        data_np = data.cpu().numpy() if isinstance(data, torch.Tensor) else np.asarray(data, dtype=np.float32)
+        data_np = data_np.astype(np.float32)
+        n, p = data_np.shape
+        eng = self.engine
+        dev = eng.device
+        miss = np.isnan(data_np)
+        lo_r, hi_r = parallel.shard_range(n)
+        x = self._dev(data_np[lo_r:hi_r])
+        n_loc = hi_r - lo_r
+        q = eng.q
+        # ---- burn-in over all local rows, step size shared by all chains of all ranks
+        state = torch.empty((n_loc, q), device=dev)
+        logp = torch.empty(n_loc, device=dev)
+        grad = torch.empty((n_loc, q), device=dev)
+        step = torch.full((1,), float(step_size), device=dev)
+        total = burn_in + n_mcmc
+        acc_prob = torch.zeros(total, device=dev, dtype=torch.float64)
+        acc_count = torch.zeros(total, device=dev, dtype=torch.int32)
+        n_adapt = int(burn_in * 0.8)
+        for it in range(n_adapt):
+            eng.hmc_run(x, state, logp, grad, step, it, 1, burn_in, num_leapfrog_steps, seed, init=(it == 0),
+                        row_base=lo_r, acc_prob=acc_prob, acc_count=acc_count)
+            parallel.all_reduce_sum_(acc_prob[it:it + 1])
+            eng.hmc_adapt(step, acc_prob, it, n)
+        if burn_in > n_adapt:
+            eng.hmc_run(x, state, logp, grad, step, n_adapt, burn_in - n_adapt, burn_in, num_leapfrog_steps, seed,
+                        init=(n_adapt == 0), row_base=lo_r, acc_prob=acc_prob, acc_count=acc_count)
+        # ---- sampling + predictive draws per row block
+        miss_loc = miss[lo_r:hi_r]
+        k_slots = int(miss_loc.sum(axis=1).max()) if n_loc else 0
+        per_row = 4 * n_mcmc * (q + max(k_slots, 1) + (p if return_samples else 0))
+        rows_blk = max(16, int(max_draw_bytes // max(1, per_row)))
+        means = np.zeros((n_loc, max(k_slots, 1)), np.float32)
+        los = np.zeros_like(means)
+        his = np.zeros_like(means)
+        samples = []
+        slot_np = np.full((n_loc, p), -1, np.int32)
+        for i in range(n_loc):
+            c = np.where(miss_loc[i])[0]
+            slot_np[i, c] = np.arange(len(c), dtype=np.int32)
+        for s in range(0, n_loc, rows_blk):
+            e = min(s + rows_blk, n_loc)
+            draws = torch.empty((n_mcmc, e - s, q), device=dev)
+            eng.hmc_run(x[s:e], state[s:e], logp[s:e], grad[s:e], step, burn_in, n_mcmc, burn_in, num_leapfrog_steps,
+                        seed, init=(burn_in == 0), row_base=lo_r + s, acc_count=acc_count, draws=draws)
+            slot = torch.from_numpy(slot_np[s:e]).to(dev) if k_slots > 0 else None
+            cells = full = None
+            if k_slots > 0 or return_samples:
+                cells, full = eng.predict_draws(draws, burn_in, seed, slot=slot, k_slots=k_slots,
+                                                want_full=return_samples, row_base=lo_r + s)
+            if k_slots > 0:
+                mean, lo, hi = eng.row_mean_quantiles(cells, alpha / 2.0, 1.0 - alpha / 2.0)
+                means[s:e] = mean.reshape(e - s, k_slots).cpu().numpy()
+                los[s:e] = lo.reshape(e - s, k_slots).cpu().numpy()
+                his[s:e] = hi.reshape(e - s, k_slots).cpu().numpy()
+            if return_samples:
+                samples.append(full.cpu().numpy())
+        acc = acc_count[burn_in:].sum().double().reshape(1)
+        parallel.all_reduce_sum_(acc)
+        self.last_acceptance_rate = float(acc.item()) / max(1, n_mcmc * n)
+        print(f"TFP MCMC Acceptance Rate: {self.last_acceptance_rate:.4f}")
+        if parallel.is_dist():
+            means, los, his = (parallel.all_gather_rows(torch.from_numpy(a).to(dev), n).cpu().numpy()
+                               for a in (means, los, his))
+        # ---- assemble the reference's return values
+        same_pattern = bool(np.all(miss == miss[0]))
+        if same_pattern:
+            mi = np.where(miss[0])[0]
+            if mi.size == 0:
+                pred_interval = np.zeros((n, 0, 2), dtype=np.float32)
+            else:
+                pred_interval = np.stack([los[:, :mi.size], his[:, :mi.size]], axis=-1)
+        else:
+            pred_interval = []
+            for i in range(n):
+                k = int(miss[i].sum())
+                pred_interval.append(np.zeros((0, 2), np.float32) if k == 0 else np.stack([los[i, :k], his[i, :k]], -1))
+        if return_samples:
+            full = np.concatenate(samples, axis=1)
+            if parallel.is_dist():
+                full = parallel.all_gather_rows(torch.from_numpy(np.ascontiguousarray(full.transpose(1, 0, 2))).to(dev),
+                                                n).cpu().numpy().transpose(1, 0, 2)
+            return full, pred_interval
+        data_obs = np.nan_to_num(data_np, nan=0.0)
+        imputed = data_obs.copy()
+        rr, cc = np.where(miss)
+        if rr.size:
+            slot_full = np.full((n, p), -1, np.int64)
+            for i in range(n):
+                c = np.where(miss[i])[0]
+                slot_full[i, c] = np.arange(len(c))
+            imputed[rr, cc] = means[rr, slot_full[rr, cc]]
+        return imputed, pred_interval

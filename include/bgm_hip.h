@@ -265,10 +265,13 @@ int bgm_bgm_hmc_adapt(bgm_handle *h, float *step_dev, const double *acc_prob_sum
 
 /* Posterior-predictive draws x ~ N(mu(z_d), sigma^2(z_d)) for draws_dev [n_draws x n x q]:
  * full_dev [n_draws x n x p] (or NULL) and / or cells_dev [(row*k_slots + slot)*n_draws + d] for
- * the cells with slot_dev[row*p + c] >= 0 (or NULL).  replaces: predict_on_posteriors, :511-525. */
+ * the cells with slot_dev[row*p + c] >= 0 (or NULL); var_full_dev [n_draws x n x p] receives sigma^2
+ * (or NULL); add_noise = 0 returns the mean instead of a draw (use_x_sd=False in generate/evaluate,
+ * :470-473,505-508).  replaces: predict_on_posteriors, :511-525; g_net(z, training=False), :468,503. */
 int bgm_bgm_predict_draws(bgm_handle *h, const float *draws_dev, int64_t n, int64_t row_base, int32_t n_draws,
                           int32_t burn_in, uint64_t seed, const int32_t *slot_dev, int32_t k_slots,
-                          float *cells_dev, float *full_dev, void *stream);
+                          float *cells_dev, float *full_dev, float *var_full_dev, int32_t add_noise,
+                          void *stream);
 
 #ifdef __cplusplus
 }

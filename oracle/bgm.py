@@ -18,7 +18,7 @@ tag 5 accept uniform, tag 6 posterior-predictive noise (networks/base.py:113-117
 """
 import numpy as np
 from . import rng as R
-from .nets import (init_varnet, varnet_forward, varnet_bn_affine, softplus, sigmoid, lrelu, LEAK,
+from .nets import (init_varnet, varnet_forward, varnet_bn_affine, softplus, sigmoid, lrelu, LEAK,  # noqa: F401
                    BN_EPS, BN_MOMENTUM)
 
 EPS = 1e-6
