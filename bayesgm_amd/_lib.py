@@ -92,6 +92,15 @@ SYMBOLS = {
     "bgm_causal_get_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "bgm_causal_fit_end": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bgm_bgm_configure": (C.c_int, [C.c_void_p, C.POINTER(BgmConfig)]),
+    "bgm_bgm_fit_begin": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "bgm_bgm_fit_n_params": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "bgm_bgm_fit_theta_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]),
+    "bgm_bgm_fit_theta_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
+    "bgm_bgm_fit_z_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p,
+                                     C.c_void_p]),
+    "bgm_bgm_get_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "bgm_bgm_fit_end": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bgm_bgm_set_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "bgm_bgm_logpost": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bgm_bgm_hmc_run": (C.c_int, [C.c_void_p, C.POINTER(HmcArgs), C.c_void_p]),

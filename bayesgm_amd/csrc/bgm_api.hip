@@ -5,32 +5,20 @@
 
 #include "bgm_host.h"
 #include "bgm_kernels.h"
+#include "bgm_state.h"
 
 static constexpr int BGM_WAVES = 8;
 static constexpr float BN_EPS_F = 1e-3f;   // keras BatchNormalization default epsilon
 
-struct BgmState {
-  bgm_bgm_config cfg{};
-  bool configured = false, set = false;
-  std::vector<float> theta;
-  BgmMeta meta{};
-  int KTQ = 0, NTX = 0, NH = 0;
-  float *blob_dev = nullptr;
-  size_t blob_cap = 0;
-  bool blob_valid = false;
-};
-
-static BgmState *bst(bgm_handle *h) {
-  if (!h->bgm_state) h->bgm_state = new BgmState();
-  return static_cast<BgmState *>(h->bgm_state);
-}
 void bgm_bgm_free_state(bgm_handle *h) {
   if (!h->bgm_state) return;
   BgmState *s = static_cast<BgmState *>(h->bgm_state);
+  bgm_bgm_fit_free(h);
   if (s->blob_dev) hipFree(s->blob_dev);
   delete s;
   h->bgm_state = nullptr;
 }
+
 
 static size_t bgm_count(const bgm_bgm_config &c) {
   size_t n = 4 * (size_t)c.z_dim;
@@ -65,22 +53,6 @@ extern "C" int bgm_bgm_set_weights(bgm_handle *h, const float *theta, int64_t co
   std::memcpy(s->theta.data(), theta, sizeof(float) * count);
   s->set = true; s->blob_valid = false;
   return BGM_OK;
-}
-
-// dual-access pack: [out tile][in slot (K_ROWS)][17]; slotmap(slot) -> source input row or -1
-template <class SlotMap>
-static void pack17(std::vector<float> &blob, int off, const std::vector<float> &W, int n_in, int n_out, int K_ROWS,
-                   int NT, SlotMap slotmap) {
-  for (int t = 0; t < NT; ++t)
-    for (int rho = 0; rho < K_ROWS; ++rho) {
-      const int src = slotmap(rho);
-      for (int j = 0; j < 16; ++j) {
-        const int o = 16 * t + j;
-        float v = 0.0f;
-        if (src >= 0 && src < n_in && o < n_out) v = W[(size_t)src * n_out + o];
-        blob[off + (t * K_ROWS + rho) * 17 + j] = v;
-      }
-    }
 }
 
 static int bgm_build_blob(bgm_handle *h, hipStream_t stream) {

@@ -109,6 +109,10 @@ __device__ __forceinline__ float softplus_f(float x) {
   return vmax(x, 0.0f) + l;
 }
 
+// accurate (libm) forms, used where a value is reported or differentiated in the fit path
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float softplus_acc(float x) { return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x))); }
+
 // sum over the four lane groups g (lanes j, j+16, j+32, j+48); result in all.
 __device__ __forceinline__ float sum_over_g(float x) {
   x += __shfl_xor(x, 16);

@@ -1,0 +1,300 @@
+// bgm_fit_kernels.h -- BGM iterative-update step functions on gfx950.
+//
+// replaces (src/bayesgm/models/bgm/base.py):
+//   update_g_net :145-164, update_latent_variable_sgd :167-187 and the loop body :399-413,
+//   with g_net = BaseVariationalNet called with training=True (networks/base.py:98-111): the input
+//   BatchNormalization uses the minibatch statistics and updates its moving averages.
+// One dual-access weight blob (bgm_kernels.h) serves the forward and the backward kernel; layer
+// activations / pre-activation gradients round-trip through an HBM workspace read by the shared
+// weight-gradient GEMM (fit_dw_kernel).
+#pragma once
+#include "bgm_kernels.h"
+#include "fit_types.h"
+
+struct BgmFitWs {
+  int B;
+  long long zn;           // [B][16*KTQ]  normalised input (natural feature order)
+  long long zhat;         // [B][16*KTQ]  (z - mu_B) * inv_std
+  long long act;          // [NH][B][64]
+  long long omean, osraw; // [B][16*NTX] each
+  long long dact;         // [NH][B][64]  dpre of the trunk layers
+  long long dmean, dsraw; // [B][16*NTX]
+  long long dzn;          // [B][16*KTQ]
+  long long dz;           // [B][q]
+  long long total;
+};
+
+struct BgmFitKArgs {
+  const float *blob;      // training blob (dual-access, first layer NOT folded with BN)
+  BgmMeta m;
+  BgmFitWs ws;
+  float *wsp;
+  const float *x;         // [N x p] data
+  const float *data_z;    // [N x q]
+  const int *idx;         // [B]
+  int B;
+  float inv_B;
+  const float *bn;        // [4*KQ]: mu_B | inv_std | gamma | beta   (KQ = 16*KTQ, zero padded)
+  double *loss;           // [4]: sum loss_x, sum |x-mu|^2, -, -
+};
+
+// ---- batch-norm statistics of the batch latents (single block) + moving-average update
+static __global__ __launch_bounds__(256) void bgm_bn_stats_kernel(const float *data_z, const int *idx, int B, int q, int KQ,
+                                                          const float *theta /* gamma|beta|mmean|mvar */, float *bn,
+                                                          float *moving /* mmean|mvar in theta, updated */,
+                                                          int update_moving) {
+  __shared__ double s1[256], s2[256];
+  for (int f = 0; f < KQ; ++f) {
+    double a = 0.0, b2 = 0.0;
+    if (f < q)
+      for (int b = threadIdx.x; b < B; b += 256) {
+        const double v = data_z[(long long)idx[b] * q + f];
+        a += v; b2 += v * v;
+      }
+    s1[threadIdx.x] = a; s2[threadIdx.x] = b2;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+      if (threadIdx.x < st) { s1[threadIdx.x] += s1[threadIdx.x + st]; s2[threadIdx.x] += s2[threadIdx.x + st]; }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      if (f < q) {
+        const double mu = s1[0] / B, var = fmax(s2[0] / B - mu * mu, 0.0);   // biased variance, as Keras
+        bn[f] = (float)mu;
+        bn[KQ + f] = (float)(1.0 / sqrt(var + 1e-3));
+        bn[2 * KQ + f] = theta[f];
+        bn[3 * KQ + f] = theta[q + f];
+        if (update_moving) {   // moving = moving * 0.99 + batch * 0.01
+          moving[f] = moving[f] * 0.99f + (float)mu * 0.01f;
+          moving[q + f] = moving[q + f] * 0.99f + (float)var * 0.01f;
+        }
+      } else {
+        bn[f] = 0.0f; bn[KQ + f] = 0.0f; bn[2 * KQ + f] = 0.0f; bn[3 * KQ + f] = 0.0f;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void st_tiles(float *base, int width, long long brow, bool ok, int g, const f32x4 (&r)[NT]) {
+  if (ok) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4 *>(base + brow * width + 16 * t + 4 * g) = r[t];
+  }
+}
+template <int NT>
+__device__ __forceinline__ void ld_tiles(const float *base, int width, long long brow, int g, f32x4 (&r)[NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) r[t] = *reinterpret_cast<const f32x4 *>(base + brow * width + 16 * t + 4 * g);
+}
+
+template <int KTQ, int NTX, int NH, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void bgm_fit_fwd_kernel(BgmFitKArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const BgmMeta &m = a.m;
+  lds_fill(lds, a.blob, m.total);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  constexpr int KQ = 16 * KTQ;
+  const long long n_tiles = (a.B + 15) / 16;
+  float *ws = a.wsp;
+  double l0 = 0.0, l1 = 0.0;
+  for (long long tile = (long long)blockIdx.x * WAVES + wave; tile < n_tiles; tile += (long long)gridDim.x * WAVES) {
+    BGM_NO_HOIST();
+    long long b = tile * 16 + j;
+    const bool ok = b < a.B;
+    b = ok ? b : a.B - 1;
+    const long long row = a.idx[b];
+    f32x4 zn[KTQ];
+#pragma unroll
+    for (int t = 0; t < KTQ; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = 16 * t + 4 * r + g;
+        float zh = 0.0f, v = 0.0f;
+        if (f < m.q) {
+          zh = (a.data_z[row * (long long)m.q + f] - a.bn[f]) * a.bn[KQ + f];
+          v = fmaf(zh, a.bn[2 * KQ + f], a.bn[3 * KQ + f]);
+        }
+        zn[t][r] = v;
+        if (ok) { ws[a.ws.zn + b * KQ + f] = v; ws[a.ws.zhat + b * KQ + f] = zh; }
+      }
+    f32x4 h[4], h2[4];
+    bias17<4>(lds + m.b1, g, h);
+    fwd17<KTQ, 4>(lds + m.w1, j, g, zn, h);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[t][r] = lrelu(h[t][r]);
+    st_tiles<4>(ws + a.ws.act, 64, b, ok, g, h);
+    for (int l = 1; l < NH; ++l) {
+      BGM_NO_HOIST();
+      bias17<4>(lds + m.bh + (l - 1) * 64, g, h2);
+      fwd17<4, 4>(lds + m.wh + (l - 1) * (4 * 64 * 17), j, g, h, h2);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[t][r] = lrelu(h2[t][r]);
+      st_tiles<4>(ws + a.ws.act + (long long)l * a.ws.B * 64, 64, b, ok, g, h);
+    }
+    float nll = 0.0f, sse = 0.0f;
+    const float *xr = a.x + row * (long long)m.p;
+#pragma unroll
+    for (int tx = 0; tx < NTX; ++tx) {
+      BGM_NO_HOIST();
+      f32x4 ms[2];
+      ms[0] = *reinterpret_cast<const f32x4 *>(lds + m.bhd + 16 * tx + 4 * g);
+      ms[1] = *reinterpret_cast<const f32x4 *>(lds + m.bhd + 16 * (NTX + tx) + 4 * g);
+      heads_fwd17<NTX>(lds + m.whd + tx * (64 * 17), j, g, h, ms);
+      if (ok) {
+        *reinterpret_cast<f32x4 *>(ws + a.ws.omean + b * (16 * NTX) + 16 * tx + 4 * g) = ms[0];
+        *reinterpret_cast<f32x4 *>(ws + a.ws.osraw + b * (16 * NTX) + 16 * tx + 4 * g) = ms[1];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 16 * tx + 4 * g + r;
+        if (c < m.p) {
+          const float s2 = softplus_acc(ms[1][r]) + BGM_EPS;
+          const float d = xr[c] - ms[0][r];
+          nll += d * d / (2.0f * s2) + 0.5f * logf(s2);
+          sse += d * d;
+        }
+      }
+    }
+    nll = sum_over_g(nll);
+    sse = sum_over_g(sse);
+    if (ok && g == 0) { l0 += nll; l1 += sse; }
+  }
+  if (a.loss != nullptr) {
+    for (int off = 32; off > 0; off >>= 1) { l0 += __shfl_xor(l0, off); l1 += __shfl_xor(l1, off); }
+    if (lane == 0) { atomicAdd(a.loss + 0, l0); atomicAdd(a.loss + 1, l1); }
+  }
+}
+
+template <int KTQ, int NTX, int NH, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void bgm_fit_bwd_kernel(BgmFitKArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const BgmMeta &m = a.m;
+  lds_fill(lds, a.blob, m.total);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  constexpr int KQ = 16 * KTQ;
+  const long long n_tiles = (a.B + 15) / 16;
+  float *ws = a.wsp;
+  for (long long tile = (long long)blockIdx.x * WAVES + wave; tile < n_tiles; tile += (long long)gridDim.x * WAVES) {
+    BGM_NO_HOIST();
+    long long b = tile * 16 + j;
+    const bool ok = b < a.B;
+    b = ok ? b : a.B - 1;
+    const long long row = a.idx[b];
+    const float *xr = a.x + row * (long long)m.p;
+    f32x4 dh[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dh[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int tx = 0; tx < NTX; ++tx) {
+      BGM_NO_HOIST();
+      const f32x4 mu = *reinterpret_cast<const f32x4 *>(ws + a.ws.omean + b * (16 * NTX) + 16 * tx + 4 * g);
+      const f32x4 sr = *reinterpret_cast<const f32x4 *>(ws + a.ws.osraw + b * (16 * NTX) + 16 * tx + 4 * g);
+      f32x4 dms[2];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 16 * tx + 4 * g + r;
+        float dm = 0.0f, dsr = 0.0f;
+        if (c < m.p) {   // d/d(mean), d/d(s_raw) of the batch-mean loss  (bgm/base.py:151-153)
+          const float s2 = softplus_acc(sr[r]) + BGM_EPS;
+          const float d = xr[c] - mu[r];
+          dm = -d / s2 * a.inv_B;
+          dsr = (-d * d / (2.0f * s2 * s2) + 0.5f / s2) * sigmoid_f(sr[r]) * a.inv_B;
+        }
+        dms[0][r] = dm;
+        dms[1][r] = dsr;
+      }
+      if (ok) {
+        *reinterpret_cast<f32x4 *>(ws + a.ws.dmean + b * (16 * NTX) + 16 * tx + 4 * g) = dms[0];
+        *reinterpret_cast<f32x4 *>(ws + a.ws.dsraw + b * (16 * NTX) + 16 * tx + 4 * g) = dms[1];
+      }
+      heads_bwd17<NTX>(lds + m.whd + tx * (64 * 17), j, g, dms, dh);
+    }
+    for (int l = NH - 1; l >= 0; --l) {
+      BGM_NO_HOIST();
+      f32x4 act[4];
+      ld_tiles<4>(ws + a.ws.act + (long long)l * a.ws.B * 64, 64, b, g, act);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh[t][r] *= (act[t][r] > 0.0f) ? 1.0f : BGM_LEAK;
+      st_tiles<4>(ws + a.ws.dact + (long long)l * a.ws.B * 64, 64, b, ok, g, dh);
+      if (l > 0) {
+        f32x4 dn[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dn[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        bwd17<4, 4>(lds + m.wh + (l - 1) * (4 * 64 * 17), j, g, dh, dn);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dh[t] = dn[t];
+      }
+    }
+    f32x4 dzn[KTQ];
+#pragma unroll
+    for (int t = 0; t < KTQ; ++t) dzn[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    bwd17<KTQ, 4>(lds + m.w1, j, g, dh, dzn);
+    if (ok) {
+#pragma unroll
+      for (int t = 0; t < KTQ; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ws[a.ws.dzn + b * KQ + 16 * t + 4 * r + g] = dzn[t][r];
+    }
+  }
+}
+
+// ---- batch-norm backward (single block): dgamma, dbeta into grad[], dz (incl. the prior z/B) into ws.dz
+static __global__ __launch_bounds__(256) void bgm_bn_bwd_kernel(const float *wsp, BgmFitWs w, const float *bn, int B, int q,
+                                                        int KQ, float inv_B, const float *data_z, const int *idx,
+                                                        float *grad_gamma_beta /* [2q] or NULL */, float *dz_out,
+                                                        int add_prior) {
+  __shared__ double s1[256], s2[256];
+  __shared__ float m1s, m2s;
+  for (int f = 0; f < q; ++f) {
+    double a = 0.0, c = 0.0;   // sum dzn, sum dzn*zhat
+    for (int b = threadIdx.x; b < B; b += 256) {
+      const double d = wsp[w.dzn + (long long)b * KQ + f];
+      a += d; c += d * wsp[w.zhat + (long long)b * KQ + f];
+    }
+    s1[threadIdx.x] = a; s2[threadIdx.x] = c;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+      if (threadIdx.x < st) { s1[threadIdx.x] += s1[threadIdx.x + st]; s2[threadIdx.x] += s2[threadIdx.x + st]; }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      if (grad_gamma_beta) { grad_gamma_beta[f] = (float)s2[0]; grad_gamma_beta[q + f] = (float)s1[0]; }
+      m1s = (float)(s1[0] / B);   // mean over the batch of dzn
+      m2s = (float)(s2[0] / B);   // mean of dzn*zhat
+    }
+    __syncthreads();
+    if (dz_out) {
+      const float gam = bn[2 * KQ + f], inv = bn[KQ + f];
+      for (int b = threadIdx.x; b < B; b += 256) {
+        const float zh = wsp[w.zhat + (long long)b * KQ + f];
+        const float dzh_centered = gam * (wsp[w.dzn + (long long)b * KQ + f] - m1s - zh * m2s);
+        float v = inv * dzh_centered;
+        if (add_prior) v += data_z[(long long)idx[b] * q + f] * inv_B;   // d/dz of mean(|z|^2/2)
+        dz_out[(long long)b * q + f] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// update_latent_variable_sgd's optimizer step: `batch_z` is a FRESH tf.Variable every minibatch
+// (bgm/base.py:402), so the Adam slots start at zero while `iterations` keeps counting:
+//   m = (1-b1) g, v = (1-b2) g^2, z -= lr_t * m / (sqrt(v) + eps)
+static __global__ void bgm_fit_z_update_kernel(float *data_z, const float *dz, const int *idx, int B, int q, float lr_t,
+                                        float b1, float b2, float eps) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * q) return;
+  const long long b = i / q;
+  const int f = (int)(i - b * q);
+  const float g = dz[i];
+  const float m = (1.0f - b1) * g, v = (1.0f - b2) * g * g;
+  data_z[(long long)idx[b] * q + f] -= lr_t * m / (sqrtf(v) + eps);
+}

@@ -400,7 +400,7 @@ __global__ __launch_bounds__(64 * WAVES) void bgm_hmc_kernel(BgmHmcKArgs a) {
 // SimpleStepSizeAdaptation (target 0.75, rate 0.01 by default): one scalar step for all chains,
 // multiplied / divided by (1 + rate) according to the mean acceptance probability of iteration `it`
 // (mean of exp(min(0, log_accept_ratio)) == exp(reduce_logmeanexp)).
-__global__ void bgm_hmc_adapt_kernel(float *step, const double *acc_prob_sum, int it, double n_chains, float target,
+static __global__ void bgm_hmc_adapt_kernel(float *step, const double *acc_prob_sum, int it, double n_chains, float target,
                                      float rate) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const double mean = acc_prob_sum[it] / n_chains;

@@ -376,3 +376,275 @@ extern "C" int bgm_causal_fit_end(bgm_handle *h, void *stream_) {
   fit_free(h);   // forward blob on the device is already current (blob_valid stays true)
   return BGM_OK;
 }
+
+// ===========================================================================================
+// BGM.fit step functions (bgm/base.py:145-187, 399-413) -- see bgm_fit_kernels.h
+// ===========================================================================================
+#include "bgm_state.h"
+
+static constexpr int BGM_FIT_WAVES = 8;
+
+void bgm_bgm_fit_free(bgm_handle *h) {
+  if (!h->bgm_state) return;
+  BgmState *s = static_cast<BgmState *>(h->bgm_state);
+  for (void *p : {(void *)s->theta_dev, (void *)s->m1_dev, (void *)s->m2_dev, (void *)s->tblob_dev, (void *)s->ws_dev,
+                  (void *)s->partial_dev, (void *)s->bn_dev, (void *)s->tables_dev})
+    if (p) hipFree(p);
+  s->theta_dev = s->m1_dev = s->m2_dev = s->tblob_dev = s->ws_dev = s->partial_dev = s->bn_dev = nullptr;
+  s->tables_dev = nullptr;
+  s->fit_active = false;
+}
+
+// training blob: same layout as the inference blob but WITHOUT folding the BatchNorm into layer 1
+static void bgm_pack_training(const BgmState *s, const std::vector<float> &theta, std::vector<float> &blob) {
+  const BgmMeta &m = s->tmeta;
+  const int q = m.q, p = m.p, KTQ = s->KTQ, NTX = s->NTX;
+  blob.assign(m.total, 0.0f);
+  size_t o = 4 * (size_t)q;
+  std::vector<float> W1(theta.begin() + o, theta.begin() + o + (size_t)q * 64); o += (size_t)q * 64;
+  pack17(blob, m.w1, W1, q, 64, 16 * KTQ, 4, [&](int slot) { int f = l1_feature(slot); return f < q ? f : -1; });
+  for (int k = 0; k < 64; ++k) blob[m.b1 + k] = theta[o + k];
+  o += 64;
+  auto ident = [](int r) { return r; };
+  for (int l = 0; l < m.n_hh; ++l) {
+    std::vector<float> W(theta.begin() + o, theta.begin() + o + 4096); o += 4096;
+    pack17(blob, m.wh + l * 4 * 64 * 17, W, 64, 64, 64, 4, ident);
+    for (int k = 0; k < 64; ++k) blob[m.bh + l * 64 + k] = theta[o + k];
+    o += 64;
+  }
+  for (int head = 0; head < 2; ++head) {
+    std::vector<float> W(theta.begin() + o, theta.begin() + o + (size_t)64 * p); o += (size_t)64 * p;
+    pack17(blob, m.whd + head * NTX * 64 * 17, W, 64, p, 64, NTX, ident);
+    for (int k = 0; k < p; ++k) blob[m.bhd + head * 16 * NTX + k] = theta[o + k];
+    o += p;
+  }
+}
+
+extern "C" int bgm_bgm_fit_n_params(bgm_handle *h, int64_t *n) {
+  if (!h || !h->bgm_state || !bst(h)->configured || !n) { bgm_set_error("bgm_bgm_fit_n_params: bad argument"); return BGM_E_INVALID; }
+  *n = (int64_t)bst(h)->theta.size();
+  return BGM_OK;
+}
+
+extern "C" int bgm_bgm_fit_begin(bgm_handle *h, int64_t n_rows, int32_t max_batch, void *stream_) {
+  (void)stream_;
+  if (!h || !h->bgm_state || !bst(h)->configured || !bst(h)->set) { bgm_set_error("bgm_bgm_fit_begin: configure and set weights first"); return BGM_E_STATE; }
+  if (n_rows <= 0 || max_batch <= 0) { bgm_set_error("bgm_bgm_fit_begin: n_rows / max_batch must be positive"); return BGM_E_INVALID; }
+  BgmState *s = bst(h);
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  bgm_bgm_fit_free(h);
+  const int q = s->cfg.z_dim, p = s->cfg.x_dim, NH = s->cfg.n_hidden_g;
+  const int KTQ = (q + 15) / 16, NTX = (p + 15) / 16, KQ = 16 * KTQ;
+  s->KTQ = KTQ; s->NTX = NTX; s->NH = NH;
+  BgmMeta &m = s->tmeta;
+  std::memset(&m, 0, sizeof(m));
+  m.q = q; m.p = p; m.n_hh = NH - 1;
+  int off = 0;
+  auto take = [&](int n) { int o = off; off += (n + 3) / 4 * 4; return o; };
+  m.w1 = take(4 * KQ * 17); m.b1 = take(64);
+  m.wh = take(m.n_hh * 4 * 64 * 17); m.bh = take(m.n_hh * 64);
+  m.whd = take(2 * NTX * 64 * 17); m.bhd = take(2 * 16 * NTX);
+  m.total = off;
+  if ((size_t)m.total * 4 > 160 * 1024) { bgm_set_error("BGM generator does not fit the LDS-resident layout"); return BGM_E_UNSUPPORTED; }
+  const int np = (int)s->theta.size();
+  if (np >= (1 << 24)) { bgm_set_error("too many parameters"); return BGM_E_UNSUPPORTED; }
+  s->n_params = np;
+  BGM_HIP_CHECK(hipMalloc(&s->theta_dev, sizeof(float) * np));
+  BGM_HIP_CHECK(hipMalloc(&s->m1_dev, sizeof(float) * np));
+  BGM_HIP_CHECK(hipMalloc(&s->m2_dev, sizeof(float) * np));
+  BGM_HIP_CHECK(hipMemcpy(s->theta_dev, s->theta.data(), sizeof(float) * np, hipMemcpyHostToDevice));
+  BGM_HIP_CHECK(hipMemset(s->m1_dev, 0, sizeof(float) * np));
+  BGM_HIP_CHECK(hipMemset(s->m2_dev, 0, sizeof(float) * np));
+  s->t_theta = 0; s->t_z = 0;
+  std::vector<float> blob;
+  bgm_pack_training(s, s->theta, blob);
+  BGM_HIP_CHECK(hipMalloc(&s->tblob_dev, sizeof(float) * blob.size()));
+  BGM_HIP_CHECK(hipMemcpy(s->tblob_dev, blob.data(), sizeof(float) * blob.size(), hipMemcpyHostToDevice));
+  // canonical parameter -> training-blob position (pack an iota vector through the same packer)
+  std::vector<float> iota(np);
+  for (int i = 0; i < np; ++i) iota[i] = (float)(i + 1);
+  std::vector<float> bidx;
+  bgm_pack_training(s, iota, bidx);
+  std::vector<int> tables(4 * (size_t)np, -1);
+  int *dst = tables.data(), *grad_src = dst + 3 * (size_t)np;
+  for (size_t d = 0; d < bidx.size(); ++d) { const int c = (int)bidx[d] - 1; if (c >= 0) dst[c] = (int)d; }
+  // workspace
+  const int B = (max_batch + 15) / 16 * 16;
+  s->fit_bcap = B;
+  BgmFitWs &w = s->fit_ws;
+  std::memset(&w, 0, sizeof(w));
+  w.B = B;
+  long long woff = 0;
+  auto wtake = [&](long long n) { long long o = woff; woff += (n + 3) / 4 * 4; return o; };
+  w.zn = wtake((long long)B * KQ); w.zhat = wtake((long long)B * KQ);
+  w.act = wtake((long long)NH * B * 64);
+  w.omean = wtake((long long)B * 16 * NTX); w.osraw = wtake((long long)B * 16 * NTX);
+  w.dact = wtake((long long)NH * B * 64);
+  w.dmean = wtake((long long)B * 16 * NTX); w.dsraw = wtake((long long)B * 16 * NTX);
+  w.dzn = wtake((long long)B * KQ); w.dz = wtake((long long)B * q);
+  w.total = woff;
+  BGM_HIP_CHECK(hipMalloc(&s->ws_dev, sizeof(float) * w.total));
+  BGM_HIP_CHECK(hipMemset(s->ws_dev, 0, sizeof(float) * w.total));
+  BGM_HIP_CHECK(hipMalloc(&s->bn_dev, sizeof(float) * 4 * KQ));
+  // dW layers + gradient source table (theta order: gamma,beta,mmean,mvar | trunk W,b.. | mean W,b | var W,b)
+  DwArgs &dw = s->dw;
+  std::memset(&dw, 0, sizeof(dw));
+  int nl = 0, poff = 0;
+  size_t o = 4 * (size_t)q;
+  auto add = [&](long long a_off, long long d_off, int K, int N, int n_in, int n_out) {
+    DwLayer &L = dw.layer[nl++];
+    L.a_off = a_off; L.d_off = d_off; L.K = K; L.N = N; L.out_off = poff;
+    for (int i = 0; i < n_in; ++i) for (int k = 0; k < n_out; ++k) grad_src[o + (size_t)i * n_out + k] = poff + i * N + k;
+    o += (size_t)n_in * n_out;
+    for (int k = 0; k < n_out; ++k) grad_src[o + k] = poff + K * N + k;
+    o += n_out;
+    poff += K * N + N;
+  };
+  add(w.zn, w.dact, KQ, 64, q, 64);
+  for (int l = 1; l < NH; ++l) add(w.act + (long long)(l - 1) * B * 64, w.dact + (long long)l * B * 64, 64, 64, 64, 64);
+  add(w.act + (long long)(NH - 1) * B * 64, w.dmean, 64, 16 * NTX, 64, p);
+  add(w.act + (long long)(NH - 1) * B * 64, w.dsraw, 64, 16 * NTX, 64, p);
+  dw.n_layers = nl;
+  dw.partial_stride = (poff + 3) / 4 * 4;
+  s->n_slices_cap = (B + s->rows_per_slice - 1) / s->rows_per_slice;
+  BGM_HIP_CHECK(hipMalloc(&s->partial_dev, sizeof(float) * dw.partial_stride * s->n_slices_cap));
+  BGM_HIP_CHECK(hipMalloc(&s->tables_dev, sizeof(int) * tables.size()));
+  BGM_HIP_CHECK(hipMemcpy(s->tables_dev, tables.data(), sizeof(int) * tables.size(), hipMemcpyHostToDevice));
+  BGM_HIP_CHECK(hipDeviceSynchronize());
+  s->fit_active = true;
+  s->blob_valid = false;   // the inference blob must be rebuilt from the trained parameters
+  return BGM_OK;
+}
+
+#define BGM_BGM_FIT_VARIANTS(X) X(1, 2, 5) X(1, 7, 5) X(1, 2, 3) X(1, 7, 3)
+
+static int bgm_fit_fwd_bwd(bgm_handle *h, BgmState *s, const float *x, const float *data_z, const int32_t *idx, int batch,
+                           double *loss, int update_moving, hipStream_t stream) {
+  const int q = s->cfg.z_dim, KQ = 16 * s->KTQ;
+  hipLaunchKernelGGL(bgm_bn_stats_kernel, dim3(1), dim3(256), 0, stream, data_z, idx, batch, q, KQ, s->theta_dev, s->bn_dev,
+                     s->theta_dev + 2 * q, update_moving);
+  BGM_HIP_CHECK(hipGetLastError());
+  BgmFitKArgs ka{};
+  ka.blob = s->tblob_dev; ka.m = s->tmeta; ka.ws = s->fit_ws; ka.wsp = s->ws_dev; ka.x = x; ka.data_z = data_z;
+  ka.idx = idx; ka.B = batch; ka.inv_B = 1.0f / (float)batch; ka.bn = s->bn_dev; ka.loss = loss;
+  const int tiles = (batch + 15) / 16;
+  const int grid = std::max(1, std::min((tiles + BGM_FIT_WAVES - 1) / BGM_FIT_WAVES, h->n_cus));
+  const int lds = s->tmeta.total * 4;
+#define X(KTQ_, NTX_, NH_)                                                                                          \
+  if (s->KTQ == KTQ_ && s->NTX == NTX_ && s->NH == NH_) {                                                           \
+    auto kf = bgm_fit_fwd_kernel<KTQ_, NTX_, NH_, BGM_FIT_WAVES>;                                                   \
+    auto kb = bgm_fit_bwd_kernel<KTQ_, NTX_, NH_, BGM_FIT_WAVES>;                                                   \
+    BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+    BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+    hipLaunchKernelGGL(kf, dim3(grid), dim3(64 * BGM_FIT_WAVES), lds, stream, ka);                                  \
+    BGM_HIP_CHECK(hipGetLastError());                                                                               \
+    hipLaunchKernelGGL(kb, dim3(grid), dim3(64 * BGM_FIT_WAVES), lds, stream, ka);                                  \
+    BGM_HIP_CHECK(hipGetLastError());                                                                               \
+    return BGM_OK;                                                                                                  \
+  }
+  BGM_BGM_FIT_VARIANTS(X)
+#undef X
+  bgm_set_error("no compiled BGM fit kernel variant for this shape");
+  return BGM_E_UNSUPPORTED;
+}
+
+static int bgm_fit_check(bgm_handle *h, const void *x, const void *z, const void *idx, int batch, const char *who) {
+  if (!h || !h->bgm_state || !bst(h)->fit_active) { bgm_set_error(std::string(who) + ": call bgm_bgm_fit_begin first"); return BGM_E_STATE; }
+  if (!x || !z || !idx) { bgm_set_error(std::string(who) + ": NULL pointer"); return BGM_E_INVALID; }
+  if (batch <= 0 || batch > bst(h)->fit_bcap) { bgm_set_error(std::string(who) + ": batch out of range"); return BGM_E_INVALID; }
+  return BGM_OK;
+}
+
+extern "C" int bgm_bgm_fit_theta_grad(bgm_handle *h, const float *x, const float *data_z, const int32_t *idx,
+                                      int32_t batch, float *grad, double *loss, void *stream_) {
+  int rc = bgm_fit_check(h, x, data_z, idx, batch, "bgm_bgm_fit_theta_grad");
+  if (rc) return rc;
+  if (!grad) { bgm_set_error("bgm_bgm_fit_theta_grad: grad_dev is NULL"); return BGM_E_INVALID; }
+  BgmState *s = bst(h);
+  hipStream_t stream = (hipStream_t)stream_;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  rc = bgm_fit_fwd_bwd(h, s, x, data_z, idx, batch, loss, 1, stream);
+  if (rc) return rc;
+  DwArgs dw = s->dw;
+  dw.ws = s->ws_dev; dw.partial = s->partial_dev; dw.B = batch; dw.rows_per_slice = s->rows_per_slice;
+  const int n_slices = (batch + s->rows_per_slice - 1) / s->rows_per_slice;
+  hipLaunchKernelGGL(fit_dw_kernel, dim3(n_slices, dw.n_layers), dim3(256), 0, stream, dw);
+  BGM_HIP_CHECK(hipGetLastError());
+  const int np = s->n_params, q = s->cfg.z_dim;
+  hipLaunchKernelGGL(fit_grad_reduce_kernel, dim3((np + 255) / 256), dim3(256), 0, stream, s->partial_dev, dw.partial_stride,
+                     n_slices, s->tables_dev + 3 * (size_t)np, np, grad);
+  BGM_HIP_CHECK(hipGetLastError());
+  // d gamma, d beta of the input BatchNorm -> grad[0..2q)
+  hipLaunchKernelGGL(bgm_bn_bwd_kernel, dim3(1), dim3(256), 0, stream, s->ws_dev, s->fit_ws, s->bn_dev, batch, q, 16 * s->KTQ,
+                     1.0f / (float)batch, data_z, idx, grad, (float *)nullptr, 0);
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+extern "C" int bgm_bgm_fit_theta_apply(bgm_handle *h, const float *grad, float lr_theta, void *stream_) {
+  if (!h || !h->bgm_state || !bst(h)->fit_active) { bgm_set_error("bgm_bgm_fit_theta_apply: call bgm_bgm_fit_begin first"); return BGM_E_STATE; }
+  if (!grad) { bgm_set_error("bgm_bgm_fit_theta_apply: grad_dev is NULL"); return BGM_E_INVALID; }
+  BgmState *s = bst(h);
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  s->t_theta += 1;
+  const double t = (double)s->t_theta;
+  const float lr_t = (float)((double)lr_theta * std::sqrt(1.0 - std::pow((double)ADAM_B2, t)) / (1.0 - std::pow((double)ADAM_B1, t)));
+  const int np = s->n_params;
+  const int *tb = s->tables_dev;
+  // moving mean/var sit in theta but receive a zero gradient (m = v = 0 -> no Adam movement)
+  hipLaunchKernelGGL(fit_adam_theta_kernel, dim3((np + 255) / 256), dim3(256), 0, (hipStream_t)stream_, s->theta_dev, s->m1_dev,
+                     s->m2_dev, grad, np, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS, s->tblob_dev, s->tblob_dev, tb, tb + np, tb + 2 * (size_t)np);
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+extern "C" int bgm_bgm_fit_z_step(bgm_handle *h, const float *x, float *data_z, const int32_t *idx, int32_t batch,
+                                  float lr_z, double *loss, void *stream_) {
+  int rc = bgm_fit_check(h, x, data_z, idx, batch, "bgm_bgm_fit_z_step");
+  if (rc) return rc;
+  BgmState *s = bst(h);
+  hipStream_t stream = (hipStream_t)stream_;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  // g_net(data_z) is called with training=True again (bgm/base.py:172): batch statistics, moving stats updated
+  rc = bgm_fit_fwd_bwd(h, s, x, data_z, idx, batch, loss ? loss + 2 : nullptr, 1, stream);
+  if (rc) return rc;
+  const int q = s->cfg.z_dim;
+  float *dz = s->ws_dev + s->fit_ws.dz;
+  hipLaunchKernelGGL(bgm_bn_bwd_kernel, dim3(1), dim3(256), 0, stream, s->ws_dev, s->fit_ws, s->bn_dev, batch, q, 16 * s->KTQ,
+                     1.0f / (float)batch, data_z, idx, (float *)nullptr, dz, 1);
+  BGM_HIP_CHECK(hipGetLastError());
+  s->t_z += 1;
+  const double t = (double)s->t_z;
+  const float lr_t = (float)((double)lr_z * std::sqrt(1.0 - std::pow((double)ADAM_B2, t)) / (1.0 - std::pow((double)ADAM_B1, t)));
+  const long long n = (long long)batch * q;
+  hipLaunchKernelGGL(bgm_fit_z_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, data_z, dz, idx, batch, q,
+                     lr_t, ADAM_B1, ADAM_B2, ADAM_EPS);
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+extern "C" int bgm_bgm_get_weights(bgm_handle *h, float *theta_host, int64_t count, void *stream_) {
+  if (!h || !h->bgm_state || !bst(h)->configured) { bgm_set_error("bgm_bgm_get_weights: not configured"); return BGM_E_STATE; }
+  BgmState *s = bst(h);
+  if (!theta_host || (size_t)count != s->theta.size()) { bgm_set_error("bgm_bgm_get_weights: wrong count"); return BGM_E_INVALID; }
+  if (s->fit_active) {
+    BGM_HIP_CHECK(hipSetDevice(h->device));
+    BGM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_));
+    BGM_HIP_CHECK(hipMemcpy(s->theta.data(), s->theta_dev, sizeof(float) * count, hipMemcpyDeviceToHost));
+    s->blob_valid = false;
+  }
+  std::memcpy(theta_host, s->theta.data(), sizeof(float) * count);
+  return BGM_OK;
+}
+
+extern "C" int bgm_bgm_fit_end(bgm_handle *h, void *stream_) {
+  if (!h || !h->bgm_state) return BGM_E_INVALID;
+  BgmState *s = bst(h);
+  if (!s->fit_active) return BGM_OK;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  BGM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_));
+  BGM_HIP_CHECK(hipMemcpy(s->theta.data(), s->theta_dev, sizeof(float) * s->theta.size(), hipMemcpyDeviceToHost));
+  bgm_bgm_fit_free(h);
+  s->blob_valid = false;   // inference blob (BN folded with the new moving statistics) is rebuilt on next use
+  return BGM_OK;
+}

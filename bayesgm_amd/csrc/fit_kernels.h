@@ -196,8 +196,6 @@ __device__ __forceinline__ void dense_t(const float *wl, int lane_off, const f32
   dense_groups<0, KT, 4, NT, 1>(wl, lane_off, in, out);
 }
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
-__device__ __forceinline__ float softplus_acc(float x) { return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x))); }
 
 template <int KT1, int KSL1, int NTL, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void fit_bwd_kernel(FitKArgs a) {
@@ -401,7 +399,8 @@ __global__ void fit_grad_reduce_kernel(const float *partial, long long stride, i
   if (c >= n_params) return;
   const int s = src[c];
   float acc = 0.0f;
-  for (int k = 0; k < n_slices; ++k) acc += partial[(long long)k * stride + s];
+  if (s >= 0)
+    for (int k = 0; k < n_slices; ++k) acc += partial[(long long)k * stride + s];
   grad[c] = acc;
 }
 

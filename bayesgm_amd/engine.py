@@ -313,6 +313,7 @@ class BgmEngine(object):
         torch.zeros(1, device=self.device)
         self.p, self.q = int(x_dim), int(z_dim)
         units = list(DEFAULT_G_UNITS if g_units is None else g_units)
+        self.units = units
         cfg = _lib.BgmConfig()
         cfg.x_dim, cfg.z_dim, cfg.n_hidden_g = self.p, self.q, len(units)
         for i, u in enumerate(units):
@@ -420,3 +421,51 @@ class BgmEngine(object):
                                                    _ptr(mean), _ptr(lo), _ptr(hi), self._stream()),
                    "bgm_row_mean_quantiles")
         return mean, lo, hi
+
+    # -- fit step functions (bgm/base.py:145-187) ---------------------------------
+    def fit_begin(self, n_rows, max_batch):
+        _lib.check(self.lib.bgm_bgm_fit_begin(self.h, int(n_rows), int(max_batch), self._stream()), "bgm_bgm_fit_begin")
+        n = C.c_int64()
+        _lib.check(self.lib.bgm_bgm_fit_n_params(self.h, C.byref(n)), "bgm_bgm_fit_n_params")
+        self.n_params = n.value
+        return n.value
+
+    def fit_theta_grad(self, x, data_z, idx, grad, loss=None):
+        _lib.check(self.lib.bgm_bgm_fit_theta_grad(self.h, _ptr(x), _ptr(data_z), _ptr(idx), int(idx.numel()), _ptr(grad),
+                                                   _ptr(loss), self._stream()), "bgm_bgm_fit_theta_grad")
+
+    def fit_theta_apply(self, grad, lr_theta):
+        _lib.check(self.lib.bgm_bgm_fit_theta_apply(self.h, _ptr(grad), float(lr_theta), self._stream()),
+                   "bgm_bgm_fit_theta_apply")
+
+    def fit_z_step(self, x, data_z, idx, lr_z, loss=None):
+        _lib.check(self.lib.bgm_bgm_fit_z_step(self.h, _ptr(x), _ptr(data_z), _ptr(idx), int(idx.numel()), float(lr_z),
+                                               _ptr(loss), self._stream()), "bgm_bgm_fit_z_step")
+
+    def get_weights(self):
+        """Device parameters -> generator dict (bn / trunk / mean / var)."""
+        buf = np.empty(self.n_theta(), np.float32)
+        _lib.check(self.lib.bgm_bgm_get_weights(self.h, buf.ctypes.data_as(C.c_void_p), buf.size, self._stream()),
+                   "bgm_bgm_get_weights")
+        q, p = self.q, self.p
+        g = {"bn": {"gamma": buf[:q].copy(), "beta": buf[q:2 * q].copy(), "mean": buf[2 * q:3 * q].copy(),
+                    "var": buf[3 * q:4 * q].copy()}, "trunk": []}
+        o, d_in = 4 * q, q
+        for u in self.units:
+            g["trunk"].append((buf[o:o + d_in * u].reshape(d_in, u).copy(), buf[o + d_in * u:o + d_in * u + u].copy()))
+            o += d_in * u + u
+            d_in = u
+        for k in ("mean", "var"):
+            g[k] = (buf[o:o + d_in * p].reshape(d_in, p).copy(), buf[o + d_in * p:o + d_in * p + p].copy())
+            o += d_in * p + p
+        return g
+
+    def n_theta(self):
+        n, d_in = 4 * self.q, self.q
+        for u in self.units:
+            n += d_in * u + u
+            d_in = u
+        return n + 2 * (d_in * self.p + self.p)
+
+    def fit_end(self):
+        _lib.check(self.lib.bgm_bgm_fit_end(self.h, self._stream()), "bgm_bgm_fit_end")

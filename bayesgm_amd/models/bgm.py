@@ -77,6 +77,81 @@ class BGM(object):
             return a.to(device=self.engine.device, dtype=torch.float32).contiguous()
         return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.engine.device)
 
+    # ------------------------------------------------------------------ fit
+    def egm_init(self, data, egm_n_iter=10000, batch_size=32, egm_batches_per_eval=500, verbose=1):
+        """EGM warm start (bgm/base.py:294-340): SURVEY.md section 8(f) row N1 -- not built yet."""
+        raise NotImplementedError("bayesgm_amd: the EGM warm start (egm_init / use_egm_init=True) is not built yet; "
+                                  "call fit(..., use_egm_init=False)")
+
+    def fit(self, data, batch_size=32, epochs=100, epochs_per_eval=5, use_egm_init=True, egm_n_iter=20000,
+            egm_batches_per_eval=500, verbose=1):
+        """Iterative theta / Z updates (bgm/base.py:343-442).  The incomplete last minibatch of an epoch is
+        skipped (:399) and the batch latents take a fresh-slot Adam step (:402, see bgm_fit_kernels.h)."""
+        if parallel.is_dist():
+            raise NotImplementedError("bayesgm_amd: BGM.fit is single-GPU (BatchNorm batch statistics are not all-reduced)")
+        if use_egm_init:
+            self.egm_init(data, egm_n_iter=egm_n_iter, batch_size=batch_size,
+                          egm_batches_per_eval=egm_batches_per_eval, verbose=verbose)
+        data = np.asarray(data, dtype=np.float32)
+        n = len(data)
+        if self._p['save_res']:
+            with open('{}/params.txt'.format(self.save_dir), 'w') as f_params:
+                f_params.write(str(self.params))
+        if verbose:
+            print('Random initialization of latent variables Z...')
+        eng = self.engine
+        dev = eng.device
+        data_z_init = np.random.normal(0, 1, size=(n, eng.q)).astype('float32')     # :388
+        x = self._dev(data)
+        self.data_z = self._dev(data_z_init)
+        n_params = eng.fit_begin(n, batch_size)
+        grad = torch.empty(n_params, device=dev)
+        loss = torch.zeros(4, device=dev, dtype=torch.float64)
+        self.history_loss = []
+        if verbose:
+            print('Iterative Updating Starts ...')
+        try:
+            for epoch in range(epochs + 1):
+                sample_idx = torch.from_numpy(np.random.choice(n, n, replace=False).astype(np.int32)).to(dev)
+                loss.zero_()
+                n_used = 0
+                for i in range(0, n - batch_size + 1, batch_size):                  # skip the incomplete last batch
+                    idx = sample_idx[i:i + batch_size]
+                    eng.fit_theta_grad(x, self.data_z, idx, grad, loss)
+                    eng.fit_theta_apply(grad, self._p['lr_theta'])
+                    eng.fit_z_step(x, self.data_z, idx, self._p['lr_z'], loss)
+                    n_used += batch_size
+                if epoch % epochs_per_eval == 0:
+                    self.g = eng.get_weights()
+                    mse_x = self.evaluate(data, data_z=self.data_z)
+                    self.history_loss.append(mse_x)
+                    if verbose:
+                        l = loss.cpu().numpy() / max(1, n_used)
+                        print('Epoch [%d/%d]: loss_x [%.4f], loss_mse_x [%.4f], MSE_x: %.4f\n'
+                              % (epoch, epochs, l[0], l[1] / eng.p, mse_x))
+                    if self._p['save_model']:
+                        self.save_checkpoint(epoch)
+                    if self._p['save_res']:
+                        gen1, var1 = self.generate(nb_samples=5000)
+                        gen12, var12 = self.generate(nb_samples=5000, use_x_sd=False)
+                        np.savez('%s/data_gen_at_%d.npz' % (self.save_dir, epoch), gen1=gen1, gen12=gen12,
+                                 z=self.data_z.cpu().numpy(), var1=var1, var12=var12)
+        finally:
+            eng.fit_end()
+            self.g = eng.get_weights()
+
+    def save_checkpoint(self, epoch):
+        """Counterpart of g_net.save_weights(...) (bgm/base.py:431-434): generator parameters as .npz."""
+        path = os.path.join(self.checkpoint_path, "weights_at_%d_generator.npz" % epoch)
+        flat = {"bn_" + k: v for k, v in self.g["bn"].items()}
+        for i, (W, b) in enumerate(self.g["trunk"]):
+            flat["trunk_W%d" % i], flat["trunk_b%d" % i] = W, b
+        for k in ("mean", "var"):
+            flat[k + "_W"], flat[k + "_b"] = self.g[k]
+        np.savez(path, **flat)
+        print('Saving checkpoint for epoch {} at {}'.format(epoch, path))
+        return path
+
     # ------------------------------------------------------------------ inference helpers
     def get_log_posterior(self, data_z, data_x, ind_x1=None, obs_mask=None):
         """log p(z | x_obs) + const (bgm/base.py:665-705).  Missing cells: NaN in data_x, or the reference's

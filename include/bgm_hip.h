@@ -273,6 +273,25 @@ int bgm_bgm_predict_draws(bgm_handle *h, const float *draws_dev, int64_t n, int6
                           float *cells_dev, float *full_dev, float *var_full_dev, int32_t add_noise,
                           void *stream);
 
+/* BGM.fit step functions.  replaces: BGM.update_g_net (bgm/base.py:145-164),
+ * BGM.update_latent_variable_sgd (:167-187) and the loop body :399-413, with g_net called with
+ * training=True (BatchNormalization on z uses the minibatch statistics and updates its moving
+ * averages, networks/base.py:100).  Single GPU (the batch statistics are not all-reduced).
+ *   theta order = bgm_bgm_set_weights order; the moving statistics receive a zero gradient.
+ *   loss_dev (double[4], may be NULL): [0] += sum loss_x, [1] += sum |x-mu|^2 (theta phase),
+ *                                      [2] += sum loss_px_z, [3] += sum |x-mu|^2 (z phase). */
+int bgm_bgm_fit_begin(bgm_handle *h, int64_t n_rows, int32_t max_batch, void *stream);
+int bgm_bgm_fit_n_params(bgm_handle *h, int64_t *n_params);
+int bgm_bgm_fit_theta_grad(bgm_handle *h, const float *x_dev, const float *data_z_dev, const int32_t *idx_dev,
+                           int32_t batch, float *grad_dev, double *loss_dev, void *stream);
+int bgm_bgm_fit_theta_apply(bgm_handle *h, const float *grad_dev, float lr_theta, void *stream);
+/* Z step: the batch latents are a FRESH variable every minibatch in the reference (:402), i.e. Adam
+ * slots start at zero while the step counter keeps running; the updated rows are written back. */
+int bgm_bgm_fit_z_step(bgm_handle *h, const float *x_dev, float *data_z_dev, const int32_t *idx_dev,
+                       int32_t batch, float lr_z, double *loss_dev, void *stream);
+int bgm_bgm_get_weights(bgm_handle *h, float *theta_host, int64_t count, void *stream);
+int bgm_bgm_fit_end(bgm_handle *h, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

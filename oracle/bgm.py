@@ -250,3 +250,48 @@ def bn_update_stats(g, c):
     t = c["mu_b"].dtype.type
     g["bn"]["mean"] = g["bn"]["mean"] * t(BN_MOMENTUM) + c["mu_b"] * t(1 - BN_MOMENTUM)
     g["bn"]["var"] = g["bn"]["var"] * t(BN_MOMENTUM) + c["var_b"] * t(1 - BN_MOMENTUM)
+
+
+class BgmFitState(object):
+    """Optimizer state of BGM.fit (bgm/base.py:88-89, :390)."""
+
+    def __init__(self, m, data_z, lr_theta, lr_z):
+        from .fit import AdamState
+        self.m, self.data_z, self.lr_theta, self.lr_z = m, data_z, lr_theta, lr_z
+        self.opt = AdamState(self.params())
+        self.zt = 0
+
+    def params(self):
+        g = self.m["g"]
+        out = [g["bn"]["gamma"], g["bn"]["beta"]]
+        for W, b in g["trunk"]:
+            out += [W, b]
+        return out + [g["mean"][0], g["mean"][1], g["var"][0], g["var"][1]]
+
+
+def _flat_bgm_grads(gr):
+    out = [gr["gamma"], gr["beta"]]
+    for dW, db in gr["trunk"]:
+        out += [dW, db]
+    return out + [gr["mean"][0], gr["mean"][1], gr["var"][0], gr["var"][1]]
+
+
+def fit_step(st, data, idx):
+    """One minibatch of the loop body bgm/base.py:399-413.  Returns (loss_x, loss_mse_x, loss_postrior_z)."""
+    from .fit import adam_lr_t, B1, B2, ADAM_EPS
+    m = st.m
+    t = st.data_z.dtype.type
+    zb, xb = st.data_z[idx].copy(), data[idx]
+    loss_x, mse_x, gr, _, c = g_loss_and_grads(m, zb, xb)
+    bn_update_stats(m["g"], c)
+    st.opt.apply(st.params(), _flat_bgm_grads(gr), st.lr_theta)
+    lz, _, _, dz, c2 = g_loss_and_grads(m, zb, xb)          # training=True again, updated networks
+    bn_update_stats(m["g"], c2)
+    dz = dz + zb / t(len(idx))
+    loss_post = lz + ((zb ** 2).sum(axis=1) / 2).mean()
+    st.zt += 1
+    lr_t = t(adam_lr_t(st.lr_z, st.zt))
+    m_, v_ = t(1 - B1) * dz, t(1 - B2) * dz * dz             # fresh slots every minibatch (:402)
+    zb = zb - lr_t * m_ / (np.sqrt(v_) + t(ADAM_EPS))
+    st.data_z[idx] = zb
+    return loss_x, mse_x, loss_post

@@ -186,3 +186,76 @@ def test_bgm_class_predict_ragged_pattern_and_edge_cases(tmp_path):
     lp_idx = model.get_log_posterior(z, full, ind_x1=np.array([0, 5, 7]))
     mk = np.zeros_like(full); mk[:, [0, 5, 7]] = 1
     assert np.allclose(lp_idx, OB.log_posterior(m, z, full, mk), rtol=1e-5, atol=1e-3)
+
+
+def test_bgm_fit_steps_match_oracle(tmp_path):
+    """BGM fit step functions (training-mode BatchNorm, per-dimension variance head, fresh-slot Adam on Z)."""
+    import torch
+    p, q, n, B, lr = 20, 10, 96, 32, 2e-3
+    m = _model(61, q, p)
+    rs = np.random.RandomState(62)
+    x = rs.randn(n, p).astype(np.float32)
+    z = rs.randn(n, q).astype(np.float32)
+    eng = _engine(m)
+    xd, zd = torch.from_numpy(x).cuda(), torch.from_numpy(z.copy()).cuda()
+    npar = eng.fit_begin(n, B)
+    grad = torch.empty(npar, device="cuda")
+    loss = torch.zeros(4, device="cuda", dtype=torch.float64)
+    m64 = OB.cast_model(m, np.float64)
+    st = OB.BgmFitState(m64, z.astype(np.float64), lr, lr)
+    x64 = x.astype(np.float64)
+    # gradient parity on the first minibatch
+    idx_np = rs.choice(n, B, replace=False).astype(np.int32)
+    idx = torch.from_numpy(idx_np).cuda()
+    eng.fit_theta_grad(xd, zd, idx, grad, loss)
+    l_ref, mse_ref, gr, _, _ = OB.g_loss_and_grads(m64, st.data_z[idx_np], x64[idx_np])
+    ref = np.concatenate([a.ravel() for a in OB._flat_bgm_grads(gr)])
+    got = grad.cpu().numpy()
+    got_t = np.concatenate([got[:2 * q], got[4 * q:]])          # moving statistics carry no gradient
+    assert np.all(got[2 * q:4 * q] == 0)
+    assert np.abs(got_t - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-7, np.abs(got_t - ref).max()
+    assert np.isclose(loss.cpu().numpy()[0] / B, l_ref, rtol=2e-5)
+    # the gradient call already moved the BN moving statistics once; mirror that, then run full steps
+    eng.fit_end()
+    eng.set_weights(m["g"])
+    eng.fit_begin(n, B)
+    for step in range(3):
+        idx_np = rs.choice(n, B, replace=False).astype(np.int32)
+        idx = torch.from_numpy(idx_np).cuda()
+        eng.fit_theta_grad(xd, zd, idx, grad)
+        eng.fit_theta_apply(grad, lr)
+        eng.fit_z_step(xd, zd, idx, lr)
+        OB.fit_step(st, x64, idx_np)
+    assert np.abs(zd.cpu().numpy() - st.data_z).max() <= 5e-4
+    g_tr = eng.get_weights()
+    for k in ("gamma", "beta", "mean", "var"):
+        assert np.abs(g_tr["bn"][k] - m64["g"]["bn"][k]).max() <= 5e-4, k
+    for (W, b), (Wr, br) in zip(g_tr["trunk"], m64["g"]["trunk"]):
+        assert np.abs(W - Wr).max() <= 5e-4 and np.abs(b - br).max() <= 5e-4
+    for k in ("mean", "var"):
+        assert np.abs(g_tr[k][0] - m64["g"][k][0]).max() <= 5e-4
+    eng.fit_end()
+    # after fit_end the inference blob is rebuilt with the new moving statistics folded in
+    lp = eng.logpost(zd, xd).cpu().numpy()
+    ref_lp = OB.log_posterior(m64, st.data_z, x64)
+    assert np.abs(lp - ref_lp).max() <= 0.1
+
+
+def test_bgm_class_fit_reduces_reconstruction_error(tmp_path):
+    from bayesgm_amd.models import BGM
+    from bayesgm_amd.datasets import simulate_z_hetero
+    X, Y = simulate_z_hetero(n=2000, k=3, d=19, seed=42)
+    data = np.c_[X, Y].astype(np.float32)
+    params = _bgm_params(tmp_path, 20)
+    params.update(save_res=True, lr_theta=2e-3, lr_z=2e-3)
+    model = BGM(params, random_seed=3)
+    with pytest.raises(NotImplementedError):
+        model.fit(data, epochs=1)                     # EGM warm start not built: loud
+    model.fit(data, epochs=8, epochs_per_eval=4, use_egm_init=False, verbose=0)
+    assert len(model.history_loss) == 3 and model.history_loss[-1] < model.history_loss[0]
+    import os
+    assert os.path.exists(os.path.join(model.save_dir, "data_gen_at_4.npz"))
+    miss = data[:64].copy()
+    miss[:, -1] = np.nan
+    imp, interval = model.predict(miss, n_mcmc=30, burn_in=30)
+    assert imp.shape == (64, 20) and interval.shape == (64, 1, 2)

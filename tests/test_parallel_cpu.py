@@ -1,0 +1,111 @@
+"""World-size-2 gloo tests (CPU) of the N>1 host logic: row sharding, unequal-length gathers, and the two
+data-parallel identities the multi-GPU path relies on -- checked with the oracle as the compute:
+  (C1) sum over ranks of local theta-gradients taken with inv_B = 1/B_global  ==  gradient of the
+       global-batch mean loss (so one all-reduce(SUM) reproduces the single-process step);
+  (C3) predict: all-reduce(SUM) of n_loc-weighted ADRF draw means / n_total == single-process ADRF draws,
+       independent of the sharding because the Philox stream is keyed by the GLOBAL row index.
+The GPU kernels themselves cannot run here (no CPU fallback by design)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, fn, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(fn, world=2):
+    port = 29500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, fn, ret), nprocs=world, join=True)
+    return [ret[r] for r in range(world)]
+
+
+def _shard_fn(rank, world):
+    from bayesgm_amd import parallel
+    assert parallel.is_dist() and parallel.rank() == rank and parallel.world_size() == world
+    n = 11
+    lo, hi = parallel.shard_range(n)
+    full = torch.arange(n * 3, dtype=torch.float32).reshape(n, 3)
+    got = parallel.all_gather_rows(full[lo:hi].clone(), n)
+    t = torch.tensor([float(rank + 1)])
+    parallel.all_reduce_sum_(t)
+    return (lo, hi, bool(torch.equal(got, full)), float(t.item()))
+
+
+def test_shard_range_and_gather():
+    from bayesgm_amd import parallel
+    # single process behaviour
+    assert parallel.shard_range(10) == (0, 10) and parallel.world_size() == 1
+    cover = [parallel.shard_range(11, r, 4) for r in range(4)]
+    assert cover[0][0] == 0 and cover[-1][1] == 11 and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+    assert max(h - l for l, h in cover) - min(h - l for l, h in cover) <= 1
+    res = _run(_shard_fn)
+    assert res[0][:2] == (0, 6) and res[1][:2] == (6, 11)
+    assert all(r[2] for r in res) and all(r[3] == 3.0 for r in res)
+
+
+def _dp_grad_fn(rank, world):
+    from oracle import causal as OC, fit as OF
+    from bayesgm_amd import parallel
+    rs = np.random.RandomState(0)
+    m = OC.cast_model(OC.init_model(1, [1, 1, 1, 7], 20), np.float64)
+    n, B = 40, 16
+    z = rs.randn(n, 10); v = rs.randn(n, 20); x = rs.exponential(size=(n, 1)); y = rs.randn(n, 1)
+    idx = rs.choice(n, B, replace=False)
+    # single-process reference gradient on the global batch
+    _, _, gg, _ = OF.g_loss_and_grads(m, z[idx], v[idx])
+    ref = np.concatenate([np.concatenate([a.ravel(), b.ravel()]) for a, b in gg])
+    # this rank's half of the batch, batch-mean factor of the GLOBAL batch: scale local-mean grads by B_loc/B
+    loc = idx[rank::world]
+    _, _, gl, _ = OF.g_loss_and_grads(m, z[loc], v[loc])
+    mine = np.concatenate([np.concatenate([a.ravel(), b.ravel()]) for a, b in gl]) * (len(loc) / B)
+    t = torch.from_numpy(mine)
+    parallel.all_reduce_sum_(t)
+    return float(np.abs(t.numpy() - ref).max() / np.abs(ref).max())
+
+
+def test_dp_gradient_allreduce_equals_global_batch_gradient():
+    res = _run(_dp_grad_fn)
+    assert all(r < 1e-12 for r in res), res
+
+
+def _adrf_fn(rank, world):
+    from oracle import causal as OC
+    from bayesgm_amd import parallel
+    rs = np.random.RandomState(3)
+    m = OC.init_model(2, [1, 1, 1, 7], 20)
+    n = 37
+    v = rs.randn(n, 20).astype(np.float32); x = rs.exponential(size=(n, 1)).astype(np.float32)
+    y = rs.randn(n, 1).astype(np.float32)
+    xs = np.array([0.5, 1.5])
+    burn, keep, seed = 6, 5, 11
+    lo, hi = parallel.shard_range(n)
+    pz = OC.mh_sampler(m, (x[lo:hi], y[lo:hi], v[lo:hi]), burn, keep, 0.5, seed, row0=lo)
+    eff = OC.infer_from_latent_posterior(m, pz, xs, True, seed, row0=lo, burn_in=burn)      # means over local rows
+    sums = torch.from_numpy(eff.astype(np.float64) * (hi - lo))
+    parallel.all_reduce_sum_(sums)
+    got = (sums / n).numpy()
+    pz_all = OC.mh_sampler(m, (x, y, v), burn, keep, 0.5, seed)
+    ref = OC.infer_from_latent_posterior(m, pz_all, xs, True, seed, burn_in=burn)
+    return float(np.abs(got - ref).max())
+
+
+def test_sharded_adrf_equals_single_process():
+    res = _run(_adrf_fn)
+    assert all(r < 1e-5 for r in res), res
