@@ -35,7 +35,7 @@ class MhArgs(C.Structure):
         ("acc_count_dev", C.c_void_p), ("draws_dev", C.c_void_p),
         ("n_keep", C.c_int32), ("effect", C.c_int32), ("sample_y", C.c_int32),
         ("x_values_dev", C.c_void_p), ("n_doses", C.c_int32),
-        ("adrf_partial_dev", C.c_void_p), ("ite_dev", C.c_void_p),
+        ("adrf_partial_dev", C.c_void_p), ("ite_dev", C.c_void_p), ("clock_dev", C.c_void_p),
     ]
 
 
@@ -78,6 +78,7 @@ SYMBOLS = {
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bgm_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "bgm_timing_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int]),
+    "bgm_debug_clock_probe": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "bgm_causal_mh_info": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(MhInfo)]),
     "bgm_causal_evaluate": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int64, C.c_void_p, C.c_int32,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

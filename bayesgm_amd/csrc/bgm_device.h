@@ -168,7 +168,11 @@ __device__ __forceinline__ void dense_groups(const float *wl, int lane_off, cons
     constexpr int K_ROWS = 16 * KT;
     constexpr int NKS = 4 * (KT - 1) + KSL;  // K-steps of this layer
     const float *base = wl + K_ROWS * 16 * T0 + lane_off * GS;
-    // software pipeline: the A fragment of K-step s+1 is in flight while the MFMAs of step s issue
+    // software pipeline in SOURCE order: the A fragment of K-step s+1 is requested before the MFMAs of
+    // step s.  (hipcc sinks the load back to its first use; pinning the order with sched_barrier(0) or
+    // inline-asm ds_read + counted lgkmcnt gives the ideal stream but ~300 spilled VGPRs and 68 vs 113 TF --
+    // measured, see DESIGN.md -- so the load placement is left to the compiler and covered by the
+    // second wave of the SIMD.)
     AFrag<GS> a_cur, a_nxt;
     a_cur.load(base);
 #pragma unroll

@@ -66,6 +66,8 @@ struct bgm_handle {
   FitMeta fit_meta{};
   FitWs fit_ws{};
   DwArgs dw{};
+  unsigned *acc_scratch = nullptr;   // [n_slots x n_iters] per-launch acceptance counters
+  size_t acc_scratch_cap = 0;
   void *bgm_state = nullptr;  // BgmState (bgm_api.hip)
   // timing
   bool timing = false;

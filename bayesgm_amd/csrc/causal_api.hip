@@ -34,6 +34,7 @@ extern "C" int bgm_destroy(bgm_handle *h) {
   hipSetDevice(h->device);
   if (h->blob_dev) hipFree(h->blob_dev);
   if (h->eblob_dev) hipFree(h->eblob_dev);
+  if (h->acc_scratch) hipFree(h->acc_scratch);
   bgm_causal_fit_end(h, nullptr);
   bgm_bgm_free_state(h);
   for (auto &e : h->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -292,7 +293,7 @@ extern "C" int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *a, void *stre
   int rc = bgm_causal_build_blob(h, stream);
   if (rc) return rc;
   const int grid = mh_grid(h, a->n);
-  const int lds = h->meta.total * 4;
+  const int lds = h->meta.total * 4 + 64;   // + per-wave progress counters
 
   CausalMhKArgs ka{};
   ka.blob = h->blob_dev; ka.x = a->x_dev; ka.y = a->y_dev; ka.v = a->v_dev;
@@ -301,7 +302,7 @@ extern "C" int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *a, void *stre
   ka.k0 = (unsigned)(a->seed & 0xFFFFFFFFull); ka.k1 = (unsigned)(a->seed >> 32);
   ka.acc_count = a->acc_count_dev; ka.draws = a->draws_dev; ka.n_keep = a->n_keep;
   ka.sample_y = a->sample_y; ka.n_doses = a->n_doses; ka.x_values = a->x_values_dev;
-  ka.adrf_partial = a->adrf_partial_dev; ka.ite = a->ite_dev; ka.m = h->meta;
+  ka.adrf_partial = a->adrf_partial_dev; ka.ite = a->ite_dev; ka.clk = (unsigned long long *)a->clock_dev; ka.m = h->meta;
 
   // Split the segment at burn_in: the burn-in part runs the pure-transition kernel.
   struct Seg { int begin, n, effect, init; };
@@ -310,8 +311,19 @@ extern "C" int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *a, void *stre
   const int split = std::min(std::max(a->burn_in, a->it_begin), it_end);
   if (split > a->it_begin) segs[nseg++] = {a->it_begin, split - a->it_begin, BGM_EFFECT_NONE, a->init};
   if (it_end > split) segs[nseg++] = {split, it_end - split, a->effect, (nseg == 0) ? a->init : 0};
+  const int n_slots = grid * MH_WAVES;
   for (int s = 0; s < nseg; ++s) {
     ka.it_begin = segs[s].begin; ka.n_iters = segs[s].n; ka.init = segs[s].init;
+    if (a->acc_count_dev) {   // slot-private counters for this launch, reduced into acc_count_dev afterwards
+      const size_t need = (size_t)n_slots * segs[s].n;
+      if (h->acc_scratch_cap < need) {
+        if (h->acc_scratch) BGM_HIP_CHECK(hipFree(h->acc_scratch));
+        BGM_HIP_CHECK(hipMalloc(&h->acc_scratch, need * sizeof(unsigned)));
+        h->acc_scratch_cap = need;
+      }
+      BGM_HIP_CHECK(hipMemsetAsync(h->acc_scratch, 0, need * sizeof(unsigned), stream));
+      ka.acc_count = h->acc_scratch;
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->timing) {
       BGM_HIP_CHECK(hipEventCreate(&e0)); BGM_HIP_CHECK(hipEventCreate(&e1));
@@ -321,6 +333,11 @@ extern "C" int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *a, void *stre
     else if (segs[s].effect == BGM_EFFECT_ITE) rc = launch_mh<2>(h, ka, grid, lds, stream);
     else rc = launch_mh<0>(h, ka, grid, lds, stream);
     if (rc) return rc;
+    if (a->acc_count_dev) {
+      hipLaunchKernelGGL(acc_reduce_kernel, dim3((segs[s].n + 255) / 256), dim3(256), 0, stream, h->acc_scratch, n_slots,
+                         segs[s].n, a->acc_count_dev + segs[s].begin);
+      BGM_HIP_CHECK(hipGetLastError());
+    }
     if (h->timing) {
       BGM_HIP_CHECK(hipEventRecord(e1, stream));
       h->events.push_back({e0, e1, segs[s].effect});

@@ -42,6 +42,7 @@ struct CausalMhKArgs {
   const float *x_values;
   float *adrf_partial;
   float *ite;
+  unsigned long long *clk;
   CausalMeta m;
 };
 
@@ -391,6 +392,11 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
   const long long n_tiles = (n + 16 * R - 1) / (16 * R);
   const long long slot = (long long)blockIdx.x * WAVES + wave;
   const long long n_slots = (long long)gridDim.x * WAVES;
+  const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  volatile int *prog = reinterpret_cast<volatile int *>(lds + m.total);   // [WAVES] progress counters after the blob
+  if (lane == 0) prog[wave_u] = 0;
+  int tiles_done = 0;
 
   for (long long tile = slot; tile < n_tiles; tile += n_slots) {
     const long long row0 = tile * 16 * R;
@@ -436,6 +442,16 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
     uint4 uacc[R];
     for (int it = a.it_begin; it < a.it_begin + a.n_iters; ++it) {
       BGM_NO_HOIST();
+      // The two waves that share a SIMD (w, w+4) are arbitrated oldest-first: left alone the older one
+      // runs ahead, finishes ~30 % early and leaves the younger wave by itself on the SIMD at low MFMA
+      // utilisation (measured: waves 0-3 done at 45 ms, waves 4-7 at 63 ms).  Each wave publishes its
+      // progress in LDS and raises its priority only while it is behind its partner.
+      if constexpr (WAVES == 8) {
+        const int mine = tiles_done * a.n_iters + (it - a.it_begin);
+        if (lane == 0) prog[wave_u] = mine;
+        const int other = __builtin_amdgcn_readfirstlane(prog[wave_u ^ 4]);
+        if (mine < other) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+      }
       // ---- proposal  z' = z + q_sd * eps   (base.py:862)
       f32x4 zp[R][KT1];
 #pragma unroll
@@ -470,7 +486,9 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
         lp[rr] = acc ? lpp[rr] : lp[rr];
         accmask += __popcll(__ballot(acc && valid[rr] && g == 0));
       }
-      if (a.acc_count != nullptr && lane == 0) atomicAdd(a.acc_count + it, (unsigned)accmask);
+      // per-(wave slot, iteration) counter, slot-private: a shared per-iteration word would take ~1e8
+      // atomics/s on one address and saturate it (measured: -30 % kernel throughput)
+      if (a.acc_count != nullptr && lane == 0) a.acc_count[slot * (long long)a.n_iters + (it - a.it_begin)] += (unsigned)accmask;
 
       if (it >= a.burn_in) {
         const long long d = it - a.burn_in;
@@ -505,6 +523,14 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
       const long long row = row0 + 16 * rr + j;
       if (g == 0 && row < n) a.logp[row] = lp[rr];
     }
+    ++tiles_done;
+  }
+  if (lane == 0) prog[wave_u] = 0x7fffffff;   // finished: the partner never needs to catch up
+  if (a.clk != nullptr && lane == 0) {   // [n_slots][4]: cycles, 100 MHz ticks, start tick, XCC id
+    a.clk[4 * slot + 0] = __builtin_readcyclecounter() - clk_c0;
+    a.clk[4 * slot + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    a.clk[4 * slot + 2] = clk_r0;
+    a.clk[4 * slot + 3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));   // HW_REG_XCC_ID[3:0]
   }
 }
 
@@ -599,4 +625,13 @@ __global__ __launch_bounds__(64 * WAVES) void causal_eval_kernel(CausalEvalKArgs
     atomicAdd(a.sums + 1, sx);
     atomicAdd(a.sums + 2, sy);
   }
+}
+
+// acc[it_begin + i] += sum over wave slots of scratch[slot][i]
+static __global__ void acc_reduce_kernel(const unsigned *scratch, int n_slots, int n_iters, unsigned *acc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_iters) return;
+  unsigned s = 0;
+  for (int k = 0; k < n_slots; ++k) s += scratch[(long long)k * n_iters + i];
+  acc[i] += s;
 }

@@ -122,7 +122,7 @@ class CausalEngine(object):
 
     def mh_run(self, x, y, v, state, logp, it_begin, n_iters, burn_in, q_sd, seed, init=False, row_base=0,
                acc_count=None, draws=None, n_keep=0, effect=_lib.EFFECT_NONE, sample_y=True, x_values=None,
-               adrf_partial=None, ite=None):
+               adrf_partial=None, ite=None, clock=None):
         """One segment of metropolis_hastings_sampler (causalbgm/base.py:860-898) for all rows."""
         a = _lib.MhArgs()
         a.x_dev, a.y_dev, a.v_dev = x.data_ptr(), y.data_ptr(), v.data_ptr()
@@ -142,6 +142,7 @@ class CausalEngine(object):
         a.n_doses = int(x_values.numel()) if x_values is not None else 0
         a.adrf_partial_dev = adrf_partial.data_ptr() if adrf_partial is not None else None
         a.ite_dev = ite.data_ptr() if ite is not None else None
+        a.clock_dev = clock.data_ptr() if clock is not None else None
         _lib.check(self.lib.bgm_causal_mh_run(self.h, C.byref(a), self._stream()), "bgm_causal_mh_run")
 
     def adrf_reduce(self, partial, n_slots, n_doses, n_keep, n_total):
@@ -223,6 +224,12 @@ class CausalEngine(object):
 
     def fit_end(self):
         _lib.check(self.lib.bgm_causal_fit_end(self.h, self._stream()), "bgm_causal_fit_end")
+
+    def clock_probe(self, iters=200000):
+        """(shader MHz, fp32-MFMA TFLOP/s) sustained under a pure 16x16x4 fp32 MFMA load."""
+        mhz, tf = C.c_double(), C.c_double()
+        _lib.check(self.lib.bgm_debug_clock_probe(self.h, int(iters), C.byref(mhz), C.byref(tf)), "bgm_debug_clock_probe")
+        return mhz.value, tf.value
 
     def timing_enable(self, on=True):
         _lib.check(self.lib.bgm_timing_enable(self.h, int(on)), "bgm_timing_enable")

@@ -118,6 +118,9 @@ typedef struct {
                                          n_slots from bgm_causal_mh_slots()   */
   float *ite_dev;                     /* ITE: [n x n_keep] draws, row-major
                                          per observation                      */
+  uint64_t *clock_dev;                /* optional measurement aid: [n_slots][4] =
+                                         shader cycles, 100 MHz ticks, start
+                                         tick, XCC id of every wave; or NULL  */
 } bgm_mh_args;
 
 /* Number of wave slots (leading dim of adrf_partial) the MH kernel uses for n rows. */
@@ -291,6 +294,11 @@ int bgm_bgm_fit_z_step(bgm_handle *h, const float *x_dev, float *data_z_dev, con
                        int32_t batch, float lr_z, double *loss_dev, void *stream);
 int bgm_bgm_get_weights(bgm_handle *h, float *theta_host, int64_t count, void *stream);
 int bgm_bgm_fit_end(bgm_handle *h, void *stream);
+
+/* Measurement aid: effective shader clock (MHz) and fp32-MFMA rate (TFLOP/s) of this device under a
+ * back-to-back v_mfma_f32_16x16x4_f32 load on every CU (8 waves/CU, `iters` x 16 MFMAs per wave).
+ * Synchronous.  Used by bench.py to state the roofline at the clock the chip actually sustains. */
+int bgm_debug_clock_probe(bgm_handle *h, int32_t iters, double *shader_mhz, double *mfma_tflops);
 
 #ifdef __cplusplus
 }
