@@ -110,10 +110,55 @@ class CausalBGM(object):
         for k in which:
             self.nets[k] = self.engine.get_weights(ids[k], self._net_dims(k))
 
+    @staticmethod
+    def _choice_no_replace(n, k):
+        """np.random.choice(n, k, replace=False) (base.py:406,413).  NumPy's implementation permutes all n
+        indices per call (O(n)); for large panels draw k distinct indices by rejection instead (same law)."""
+        if n <= 200000 or k * 20 > n:
+            return np.random.choice(n, k, replace=False)
+        while True:
+            idx = np.random.randint(0, n, size=k)
+            if len(np.unique(idx)) == k:
+                return idx
+
     def egm_init(self, data, egm_n_iter=30000, batch_size=32, egm_batches_per_eval=500, verbose=1):
-        """EGM warm start (base.py:380-431): SURVEY.md section 8(f) row N1 -- not built yet."""
-        raise NotImplementedError("bayesgm_amd: the EGM warm start (egm_init / use_egm_init=True) is not built yet; "
-                                  "call fit(..., use_egm_init=False)")
+        """EGM warm start (base.py:380-431).  INTERIM: runs on the GPU through PyTorch autograd
+        (bayesgm_amd/egm.py), not yet as hand-written kernels; see that module's docstring."""
+        from ..egm import CausalEGM
+        data_x, data_y, data_v = data
+        n = len(data_x)
+        dev = self.engine.device
+        xd, yd, vd = self._dev(data_x).reshape(-1, 1), self._dev(data_y).reshape(-1, 1), self._dev(data_v)
+        egm = CausalEGM(self.nets, self._p, dev, self._rs, batch_size)
+        try:
+            egm.capture()
+        except Exception as e:   # graph capture is an optimisation only
+            if verbose:
+                print("EGM: HIP-graph capture unavailable (%s); running eagerly" % type(e).__name__)
+        if verbose:
+            print('EGM Initialization Starts ...')
+        g_d_freq = int(self._p['g_d_freq'])
+        for batch_iter in range(egm_n_iter + 1):
+            for _ in range(g_d_freq):
+                idx = torch.from_numpy(self._choice_no_replace(n, batch_size)).to(dev)
+                bz = torch.from_numpy(self.z_sampler.get_batch(batch_size)).to(dev)
+                egm.disc_step(bz, vd[idx], np.random.uniform(0.0, 1.0))
+            bz = torch.from_numpy(self.z_sampler.get_batch(batch_size)).to(dev)
+            idx = torch.from_numpy(self._choice_no_replace(n, batch_size)).to(dev)
+            egm.gen_step(bz, vd[idx], xd[idx], yd[idx])
+            if batch_iter % egm_batches_per_eval == 0:
+                self.set_weights(**egm.export())
+                if verbose:
+                    lg, ld = egm.out_g.cpu().numpy(), egm.out_d.cpu().numpy()
+                    print('EGM Initialization Iter [%d] : e_loss_adv [%.4f], l2_loss_v [%.4f], l2_loss_z [%.4f], '
+                          'l2_loss_x [%.4f], l2_loss_y [%.4f], g_e_loss [%.4f], dz_loss [%.4f], d_loss [%.4f]'
+                          % (batch_iter, lg[0], lg[1], lg[2], lg[3], lg[4], lg[5], ld[0], ld[1]))
+                causal_pre, mse_x, mse_y, mse_v = self.evaluate(data=data)
+                if self._p['save_res'] and parallel.rank() == 0:
+                    save_data('{}/causal_pre_egm_init_iter-{}.txt'.format(self.save_dir, batch_iter), causal_pre)
+        self.set_weights(**egm.export())
+        if verbose:
+            print('EGM Initialization Ends.')
 
     def fit(self, data, epochs=100, epochs_per_eval=5, batch_size=32, startoff=0, use_egm_init=True,
             egm_n_iter=30000, egm_batches_per_eval=500, save_format='txt', verbose=1, z_adam="dense"):
@@ -132,18 +177,23 @@ class CausalBGM(object):
         if self._p['save_res'] and parallel.rank() == 0:
             with open('{}/params.txt'.format(self.save_dir), 'w') as f_params:
                 f_params.write(str(self.params))
-        if verbose:
-            print('Random initialization of latent variables Z...')
         q = self.engine.q
-        data_z_init = np.random.normal(0, 1, size=(n_total, q)).astype('float32')   # base.py:482
         lo_r, hi_r = parallel.shard_range(n_total)
+        if use_egm_init:
+            if verbose:
+                print('Initialize latent variables Z with e(V)...')
+            data_z_init = None                                                          # base.py:479
+        else:
+            if verbose:
+                print('Random initialization of latent variables Z...')
+            data_z_init = np.random.normal(0, 1, size=(n_total, q)).astype('float32')   # base.py:482
         n_loc = hi_r - lo_r
         world = parallel.world_size()
         dev = self.engine.device
         x = self._dev(data_x[lo_r:hi_r]).reshape(-1)
         y = self._dev(data_y[lo_r:hi_r]).reshape(-1)
         v = self._dev(data_v[lo_r:hi_r])
-        self.data_z = self._dev(data_z_init[lo_r:hi_r])
+        self.data_z = self.engine.encode(v) if data_z_init is None else self._dev(data_z_init[lo_r:hi_r])
         zm = torch.zeros_like(self.data_z)
         zv = torch.zeros_like(self.data_z)
         b_loc = max(1, batch_size // world)

@@ -12,6 +12,7 @@ from bayesgm_amd.utils import get_ADRF
 N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20000
 epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+egm_iters = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 x, y, v = Sim_Hirano_Imbens_sampler(N=N, v_dim=200, seed=0).load_all()
 params = dict(dataset="Sim_Hirano_Imbens", output_dir="gpurun_out/e2e", save_res=False, save_model=False,
               binary_treatment=False, use_bnn=False, z_dims=[1, 1, 1, 7], v_dim=200, lr_theta=1e-4, lr_z=1e-4,
@@ -19,7 +20,8 @@ params = dict(dataset="Sim_Hirano_Imbens", output_dir="gpurun_out/e2e", save_res
               kl_weight=1e-4, lr=2e-4, g_d_freq=5, use_z_rec=True)
 model = CausalBGM(params, random_seed=123)
 t0 = time.time()
-model.fit((x, y, v), epochs=epochs, epochs_per_eval=max(1, epochs // 5), batch_size=batch, use_egm_init=False, verbose=1)
+model.fit((x, y, v), epochs=epochs, epochs_per_eval=max(1, epochs // 5), batch_size=batch, use_egm_init=egm_iters > 0,
+          egm_n_iter=egm_iters, egm_batches_per_eval=max(1, egm_iters // 6), verbose=1)
 t_fit = time.time() - t0
 xs = np.linspace(0, 3, 20)
 t0 = time.time()
@@ -40,7 +42,7 @@ out = model.engine.mh_sample(x[sub].ravel(), y[sub].ravel(), v[sub], 300, 100, 1
 ref_post = OC.mh_sampler(m, (x[sub], y[sub], v[sub]), 300, 100, 1.0, seed)
 ref_eff = OC.infer_from_latent_posterior(m, ref_post, xs, True, seed, burn_in=300)
 d_oracle = float(np.abs(out["adrf"].cpu().numpy().mean(axis=1) - ref_eff.mean(axis=1)).max())
-print(json.dumps(dict(N=N, epochs=epochs, batch=batch, fit_s=t_fit, fit_obs_per_s=N * (epochs + 1) / t_fit, predict_s=t_pred,
+print(json.dumps(dict(N=N, epochs=epochs, batch=batch, egm_iters=egm_iters, fit_s=t_fit, fit_obs_per_s=N * (epochs + 1) / t_fit, predict_s=t_pred,
                       predict_transitions_per_s=N * 8000 / t_pred, adrf_rmse=rmse, adrf_mape=mape, interval_coverage=cover,
                       acceptance=model.last_acceptance_rate, adrf_max_abs_diff_vs_oracle_256rows=d_oracle,
                       adrf=[float(a) for a in adrf], truth=[float(t) for t in truth])))

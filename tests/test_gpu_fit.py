@@ -150,7 +150,7 @@ def test_causalbgm_fit_predict_end_to_end(tmp_path):
                   lr=2e-4, g_d_freq=5, use_z_rec=True)
     model = CausalBGM(params, random_seed=1)
     with pytest.raises(NotImplementedError):
-        model.fit((x, y, v), epochs=1)                      # EGM warm start not built: loud, not silent
+        CausalBGM(dict(params, use_bnn=True))               # Bayesian nets not built: loud, not silent
     c0, mx0, my0, mv0 = model.evaluate((x, y, v))
     model.fit((x, y, v), epochs=6, epochs_per_eval=3, batch_size=32, use_egm_init=False, verbose=0)
     c1, mx1, my1, mv1 = model.evaluate((x, y, v), data_z=model.data_z.cpu().numpy())
@@ -167,3 +167,25 @@ def test_causalbgm_fit_predict_end_to_end(tmp_path):
         model.predict((x[:10], y[:10], v[:10]), n_mcmc=5, burn_in=5)   # continuous needs x_values
     with pytest.raises(AssertionError):
         model.predict((x[:10], y[:10], v[:10]), alpha=1.5, x_values=[1.0])
+
+
+def test_causalbgm_default_fit_with_egm_warm_start(tmp_path):
+    """fit() with its default use_egm_init=True: the (interim, torch-autograd) EGM warm start trains g,e,f,h,
+    Z is initialised as e(V) by the HIP encoder, and the iterative updates continue from there."""
+    from bayesgm_amd.models import CausalBGM
+    from bayesgm_amd.datasets import Sim_Hirano_Imbens_sampler
+    x, y, v = Sim_Hirano_Imbens_sampler(N=1500, v_dim=200, seed=1).load_all()
+    params = dict(dataset="t", output_dir=str(tmp_path), save_res=True, save_model=False, binary_treatment=False,
+                  use_bnn=False, z_dims=[1, 1, 1, 7], v_dim=200, lr_theta=1e-4, lr_z=1e-4, g_units=[64] * 5,
+                  f_units=[64, 32, 8], h_units=[64, 32, 8], e_units=[64] * 5, dz_units=[64, 32, 8], kl_weight=1e-4,
+                  lr=2e-4, g_d_freq=5, use_z_rec=True)
+    model = CausalBGM(params, random_seed=2)
+    _, _, my0, _ = model.evaluate((x, y, v))
+    model.fit((x, y, v), epochs=1, epochs_per_eval=1, egm_n_iter=400, egm_batches_per_eval=200, verbose=0)
+    _, _, my1, _ = model.evaluate((x, y, v), data_z=model.data_z.cpu().numpy())
+    assert my1 < my0
+    import os
+    assert os.path.exists(os.path.join(model.save_dir, "causal_pre_egm_init_iter-400.txt"))
+    # Z was initialised by the encoder: data_z stays close to e(V) after one epoch at lr_z = 1e-4
+    z_enc = model.engine.encode(model._dev(v)).cpu().numpy()
+    assert np.abs(model.data_z.cpu().numpy() - z_enc).mean() < 0.5
