@@ -153,8 +153,11 @@ struct AFrag<1> {
   __device__ __forceinline__ float get(int) const { return v; }
 };
 
+#ifndef BGM_MAX_GROUP
+#define BGM_MAX_GROUP 4
+#endif
 __host__ __device__ constexpr int group_size(int tiles_left) {
-  return tiles_left >= 4 ? 4 : (tiles_left >= 2 ? 2 : 1);
+  return (tiles_left >= 4 && BGM_MAX_GROUP >= 4) ? 4 : (tiles_left >= 2 ? 2 : 1);
 }
 
 // One tile group [T0, T0+GS) of a layer.  KT input tiles, the last of which

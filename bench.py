@@ -77,8 +77,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=float, default=1e6, help="rows per GPU")
-    ap.add_argument("--p", type=int, default=200)
+    ap.add_argument("--rows", "--n", dest="n", type=float, default=1e6, help="rows per GPU")
+    ap.add_argument("--covariates", "--p", dest="p", type=int, default=200)
     ap.add_argument("--burn-in", type=int, default=5000)
     ap.add_argument("--n-mcmc", type=int, default=3000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -91,11 +91,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # Dev aid (1-GPU box): BGM_BENCH_SINGLE_DEVICE=1 BGM_BENCH_BACKEND=gloo runs all ranks on cuda:0 over gloo so
+    # that the N>1 code path (sharding, ADRF all-reduce, max-over-ranks timing) can be exercised without N GPUs.
+    if os.environ.get("BGM_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("BGM_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     from bayesgm_amd.models import CausalBGM
     from bayesgm_amd import parallel
