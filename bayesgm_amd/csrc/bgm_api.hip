@@ -8,6 +8,9 @@
 #include "bgm_state.h"
 
 static constexpr int BGM_WAVES = 8;
+#ifndef BGM_WAVES_WIDE_HMC
+#define BGM_WAVES_WIDE_HMC 12   // 148 VGPRs -> 3 waves/SIMD; measured 89 vs 86 (8) vs 86 (16) TF at p=500
+#endif
 static constexpr float BN_EPS_F = 1e-3f;   // keras BatchNormalization default epsilon
 
 void bgm_bgm_free_state(bgm_handle *h) {
@@ -60,21 +63,16 @@ static int bgm_build_blob(bgm_handle *h, hipStream_t stream) {
   if (s->blob_valid) return BGM_OK;
   if (!s->set) { bgm_set_error("BGM weights not set"); return BGM_E_STATE; }
   const int q = s->cfg.z_dim, p = s->cfg.x_dim, NH = s->cfg.n_hidden_g;
-  const int KTQ = (q + 15) / 16, NTX = (p + 15) / 16;
-  s->KTQ = KTQ; s->NTX = NTX; s->NH = NH;
+  const int KTQ = (q + 15) / 16;
   BgmMeta &m = s->meta;
-  std::memset(&m, 0, sizeof(m));
-  m.q = q; m.p = p; m.n_hh = NH - 1;
-  int off = 0;
-  auto take = [&](int n) { int o = off; off += (n + 3) / 4 * 4; return o; };
-  m.w1 = take(4 * 16 * KTQ * 17); m.b1 = take(64);
-  m.wh = take(m.n_hh * 4 * 64 * 17); m.bh = take(m.n_hh * 64);
-  m.whd = take(2 * NTX * 64 * 17); m.bhd = take(2 * 16 * NTX);
-  m.total = off;
-  if ((size_t)m.total * 4 > 160 * 1024) {
-    bgm_set_error("BGM generator does not fit the 160 KiB LDS-resident dual-access layout (" + std::to_string(m.total * 4) + " B)");
+  int ntx_variant = 0;
+  const int lds_bytes = bgm_layout(q, p, NH, m, ntx_variant);
+  if (lds_bytes < 0) {
+    bgm_set_error("BGM generator: trunk + head biases + stage exceed the 160 KiB LDS (x_dim too large)");
     return BGM_E_UNSUPPORTED;
   }
+  s->KTQ = KTQ; s->NTX = ntx_variant; s->NH = NH; s->lds_bytes = lds_bytes;
+  const int NTX = m.ntx;
   std::vector<float> blob(m.total, 0.0f);
   const float *th = s->theta.data();
   const float *gamma = th, *beta = th + q, *mmean = th + 2 * q, *mvar = th + 3 * q;
@@ -97,7 +95,7 @@ static int bgm_build_blob(bgm_handle *h, hipStream_t stream) {
   }
   for (int head = 0; head < 2; ++head) {   // mean, var
     std::vector<float> W(th + o, th + o + (size_t)64 * p); o += (size_t)64 * p;
-    pack17(blob, m.whd + head * NTX * 64 * 17, W, 64, p, 64, NTX, ident);
+    pack17_heads(blob, m.whd, W.data(), p, NTX, head);
     for (int k = 0; k < p; ++k) blob[m.bhd + head * 16 * NTX + k] = th[o + k];
     o += p;
   }
@@ -113,8 +111,9 @@ static int bgm_build_blob(bgm_handle *h, hipStream_t stream) {
   return BGM_OK;
 }
 
-// (KTQ, NTX, NH) variants: z_dim <= 16; x_dim <= 32 / <= 112; 5 hidden layers (configs/*.yaml) or 3
-#define BGM_BGM_VARIANTS(X) X(1, 2, 5) X(1, 7, 5) X(1, 2, 3) X(1, 7, 3)
+// (KTQ, NTX, NH) variants: z_dim <= 16; x_dim in (16,32] / (96,112] LDS-resident, NTX = 0 = wide (any x_dim,
+// head weights streamed through an LDS stage); 5 hidden layers (configs/*.yaml) or 3
+#define BGM_BGM_VARIANTS(X) X(1, 2, 5) X(1, 7, 5) X(1, 0, 5) X(1, 2, 3) X(1, 7, 3) X(1, 0, 3)
 
 static int bgm_grid(const bgm_handle *h, long long tiles) {
   return (int)std::max<long long>(1, std::min<long long>((tiles + BGM_WAVES - 1) / BGM_WAVES, h->n_cus));
@@ -134,7 +133,7 @@ extern "C" int bgm_bgm_logpost(bgm_handle *h, const float *z, const float *x, in
   int rc = bgm_build_blob(h, stream);
   if (rc) return rc;
   BgmState *s = bst(h);
-  const int grid = bgm_grid(h, (n + 15) / 16), lds = s->meta.total * 4;
+  const int grid = bgm_grid(h, (n + 15) / 16), lds = s->lds_bytes;
 #define X(KTQ_, NTX_, NH_)                                                                                          \
   if (s->KTQ == KTQ_ && s->NTX == NTX_ && s->NH == NH_) {                                                           \
     auto k = bgm_logpost_kernel<KTQ_, NTX_, NH_, BGM_WAVES>;                                                        \
@@ -166,12 +165,15 @@ extern "C" int bgm_bgm_hmc_run(bgm_handle *h, const bgm_hmc_args *a, void *strea
   ka.it_begin = a->it_begin; ka.n_iters = a->n_iters; ka.burn_in = a->burn_in; ka.n_leapfrog = a->n_leapfrog;
   ka.step = a->step_dev; ka.k0 = (unsigned)(a->seed & 0xFFFFFFFFull); ka.k1 = (unsigned)(a->seed >> 32);
   ka.acc_prob_sum = a->acc_prob_sum_dev; ka.acc_count = a->acc_count_dev; ka.draws = a->draws_dev; ka.m = s->meta;
-  const int grid = bgm_grid(h, (a->n + 15) / 16), lds = s->meta.total * 4;
+  const int lds = s->lds_bytes;
+  const long long tiles = (a->n + 15) / 16;
 #define X(KTQ_, NTX_, NH_)                                                                                          \
   if (s->KTQ == KTQ_ && s->NTX == NTX_ && s->NH == NH_) {                                                           \
-    auto k = bgm_hmc_kernel<KTQ_, NTX_, NH_, BGM_WAVES>;                                                            \
+    constexpr int W = (NTX_ == 0) ? BGM_WAVES_WIDE_HMC : BGM_WAVES;                                                 \
+    const int grid = (int)std::max<long long>(1, std::min<long long>((tiles + W - 1) / W, h->n_cus));               \
+    auto k = bgm_hmc_kernel<KTQ_, NTX_, NH_, W>;                                                                    \
     BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
-    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * BGM_WAVES), lds, stream, ka);                                       \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * W), lds, stream, ka);                                               \
     BGM_HIP_CHECK(hipGetLastError());                                                                               \
     return BGM_OK;                                                                                                  \
   }
@@ -206,7 +208,7 @@ extern "C" int bgm_bgm_predict_draws(bgm_handle *h, const float *draws, int64_t 
   ka.k0 = (unsigned)(seed & 0xFFFFFFFFull); ka.k1 = (unsigned)(seed >> 32); ka.m = s->meta;
   const long long work = ((n + 15) / 16) * (long long)n_draws;
   const int grid = (int)std::max<long long>(1, std::min<long long>((work + BGM_WAVES - 1) / BGM_WAVES, (long long)h->n_cus));
-  const int lds = s->meta.total * 4;
+  const int lds = s->lds_bytes;
 #define X(KTQ_, NTX_, NH_)                                                                                          \
   if (s->KTQ == KTQ_ && s->NTX == NTX_ && s->NH == NH_) {                                                           \
     auto k = bgm_predict_kernel<KTQ_, NTX_, NH_, BGM_WAVES>;                                                        \

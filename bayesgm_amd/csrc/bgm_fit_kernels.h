@@ -93,17 +93,24 @@ template <int KTQ, int NTX, int NH, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void bgm_fit_fwd_kernel(BgmFitKArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const BgmMeta &m = a.m;
-  lds_fill(lds, a.blob, m.total);
+  lds_fill(lds, a.blob, m.lds_resident);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  BgmHeadStream hs;
+  if constexpr (NTX == 0) hs.begin(a.blob, m, lds);
   constexpr int KQ = 16 * KTQ;
-  const long long n_tiles = (a.B + 15) / 16;
+  const int XW = 16 * m.ntx;
+  const long long n_tiles = (a.B + 15) / 16, passes = bgm_block_passes(n_tiles, WAVES);
   float *ws = a.wsp;
   double l0 = 0.0, l1 = 0.0;
-  for (long long tile = (long long)blockIdx.x * WAVES + wave; tile < n_tiles; tile += (long long)gridDim.x * WAVES) {
+  for (long long ps = 0; ps < passes; ++ps) {
     BGM_NO_HOIST();
+    long long tile = (ps * gridDim.x + blockIdx.x) * WAVES + wave;
+    const bool tile_ok = tile < n_tiles;
+    if (NTX > 0 && !tile_ok) break;
+    tile = tile_ok ? tile : n_tiles - 1;
     long long b = tile * 16 + j;
-    const bool ok = b < a.B;
-    b = ok ? b : a.B - 1;
+    const bool ok = tile_ok && b < a.B;
+    b = b < a.B ? b : a.B - 1;
     const long long row = a.idx[b];
     f32x4 zn[KTQ];
 #pragma unroll
@@ -139,16 +146,14 @@ __global__ __launch_bounds__(64 * WAVES) void bgm_fit_fwd_kernel(BgmFitKArgs a) 
     }
     float nll = 0.0f, sse = 0.0f;
     const float *xr = a.x + row * (long long)m.p;
-#pragma unroll
-    for (int tx = 0; tx < NTX; ++tx) {
-      BGM_NO_HOIST();
+    auto head = [&](int tx, const float *wl) {
       f32x4 ms[2];
       ms[0] = *reinterpret_cast<const f32x4 *>(lds + m.bhd + 16 * tx + 4 * g);
-      ms[1] = *reinterpret_cast<const f32x4 *>(lds + m.bhd + 16 * (NTX + tx) + 4 * g);
-      heads_fwd17<NTX>(lds + m.whd + tx * (64 * 17), j, g, h, ms);
+      ms[1] = *reinterpret_cast<const f32x4 *>(lds + m.bhd + 16 * (m.ntx + tx) + 4 * g);
+      heads_fwd17(wl, j, g, h, ms);
       if (ok) {
-        *reinterpret_cast<f32x4 *>(ws + a.ws.omean + b * (16 * NTX) + 16 * tx + 4 * g) = ms[0];
-        *reinterpret_cast<f32x4 *>(ws + a.ws.osraw + b * (16 * NTX) + 16 * tx + 4 * g) = ms[1];
+        *reinterpret_cast<f32x4 *>(ws + a.ws.omean + b * XW + 16 * tx + 4 * g) = ms[0];
+        *reinterpret_cast<f32x4 *>(ws + a.ws.osraw + b * XW + 16 * tx + 4 * g) = ms[1];
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -159,6 +164,21 @@ __global__ __launch_bounds__(64 * WAVES) void bgm_fit_fwd_kernel(BgmFitKArgs a) 
           nll += d * d / (2.0f * s2) + 0.5f * logf(s2);
           sse += d * d;
         }
+      }
+    };
+    if constexpr (NTX > 0) {
+#pragma unroll
+      for (int tx = 0; tx < NTX; ++tx) {
+        BGM_NO_HOIST();
+        head(tx, lds + m.whd + tx * BGM_PAIR);
+      }
+    } else {
+#pragma unroll 1
+      for (int tx = 0; tx < m.ntx; ++tx) {
+        BGM_NO_HOIST();
+        hs.fetch(tx + 1 < m.ntx ? tx + 1 : 0);
+        head(tx, hs.tile());
+        hs.commit();
       }
     }
     nll = sum_over_g(nll);
@@ -175,26 +195,31 @@ template <int KTQ, int NTX, int NH, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void bgm_fit_bwd_kernel(BgmFitKArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const BgmMeta &m = a.m;
-  lds_fill(lds, a.blob, m.total);
+  lds_fill(lds, a.blob, m.lds_resident);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  BgmHeadStream hs;
+  if constexpr (NTX == 0) hs.begin(a.blob, m, lds);
   constexpr int KQ = 16 * KTQ;
-  const long long n_tiles = (a.B + 15) / 16;
+  const int XW = 16 * m.ntx;
+  const long long n_tiles = (a.B + 15) / 16, passes = bgm_block_passes(n_tiles, WAVES);
   float *ws = a.wsp;
-  for (long long tile = (long long)blockIdx.x * WAVES + wave; tile < n_tiles; tile += (long long)gridDim.x * WAVES) {
+  for (long long ps = 0; ps < passes; ++ps) {
     BGM_NO_HOIST();
+    long long tile = (ps * gridDim.x + blockIdx.x) * WAVES + wave;
+    const bool tile_ok = tile < n_tiles;
+    if (NTX > 0 && !tile_ok) break;
+    tile = tile_ok ? tile : n_tiles - 1;
     long long b = tile * 16 + j;
-    const bool ok = b < a.B;
-    b = ok ? b : a.B - 1;
+    const bool ok = tile_ok && b < a.B;
+    b = b < a.B ? b : a.B - 1;
     const long long row = a.idx[b];
     const float *xr = a.x + row * (long long)m.p;
     f32x4 dh[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) dh[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int tx = 0; tx < NTX; ++tx) {
-      BGM_NO_HOIST();
-      const f32x4 mu = *reinterpret_cast<const f32x4 *>(ws + a.ws.omean + b * (16 * NTX) + 16 * tx + 4 * g);
-      const f32x4 sr = *reinterpret_cast<const f32x4 *>(ws + a.ws.osraw + b * (16 * NTX) + 16 * tx + 4 * g);
+    auto head = [&](int tx, const float *wl) {
+      const f32x4 mu = *reinterpret_cast<const f32x4 *>(ws + a.ws.omean + b * XW + 16 * tx + 4 * g);
+      const f32x4 sr = *reinterpret_cast<const f32x4 *>(ws + a.ws.osraw + b * XW + 16 * tx + 4 * g);
       f32x4 dms[2];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -210,10 +235,25 @@ __global__ __launch_bounds__(64 * WAVES) void bgm_fit_bwd_kernel(BgmFitKArgs a) 
         dms[1][r] = dsr;
       }
       if (ok) {
-        *reinterpret_cast<f32x4 *>(ws + a.ws.dmean + b * (16 * NTX) + 16 * tx + 4 * g) = dms[0];
-        *reinterpret_cast<f32x4 *>(ws + a.ws.dsraw + b * (16 * NTX) + 16 * tx + 4 * g) = dms[1];
+        *reinterpret_cast<f32x4 *>(ws + a.ws.dmean + b * XW + 16 * tx + 4 * g) = dms[0];
+        *reinterpret_cast<f32x4 *>(ws + a.ws.dsraw + b * XW + 16 * tx + 4 * g) = dms[1];
       }
-      heads_bwd17<NTX>(lds + m.whd + tx * (64 * 17), j, g, dms, dh);
+      heads_bwd17(wl, j, g, dms, dh);
+    };
+    if constexpr (NTX > 0) {
+#pragma unroll
+      for (int tx = 0; tx < NTX; ++tx) {
+        BGM_NO_HOIST();
+        head(tx, lds + m.whd + tx * BGM_PAIR);
+      }
+    } else {
+#pragma unroll 1
+      for (int tx = 0; tx < m.ntx; ++tx) {
+        BGM_NO_HOIST();
+        hs.fetch(tx + 1 < m.ntx ? tx + 1 : 0);
+        head(tx, hs.tile());
+        hs.commit();
+      }
     }
     for (int l = NH - 1; l >= 0; --l) {
       BGM_NO_HOIST();

@@ -18,12 +18,50 @@
 #pragma once
 #include "bgm_device.h"
 
+// One head "tile pair": the mean tile and the variance tile of one 16-feature block, contiguous.
+#define BGM_PAIR (2 * 64 * 17)
+
 struct BgmMeta {
   int q, p, n_hh;        // latent dim, data dim, hidden->hidden layers of the trunk
+  int ntx;               // 16-feature blocks of the data dimension
   int w1, b1;            // [4 tiles][16*KTQ][17], [64]
   int wh, bh;            // n_hh x ([4][64][17]), n_hh x [64]
-  int whd, bhd;          // heads [2*NTX tiles][64][17] (mean tiles then var tiles), [2*16*NTX]
-  int total;
+  int bhd;               // head biases [2][16*ntx]  (mean then var)
+  int whd;               // head weights [ntx][BGM_PAIR]  (LAST: the wide kernels keep them out of LDS)
+  int total;             // floats in the blob
+  int lds_resident;      // floats copied into LDS at kernel start: total (resident heads) or whd (wide)
+  int stage;             // wide: LDS offset of the 2 x BGM_PAIR staging buffers
+};
+
+// Wide data rows (x_dim beyond the LDS-resident variants, e.g. BASELINE config C4, p = 500): the 2 x 64 x p
+// head weights stay in HBM/L2 and every block streams them through a double-buffered LDS stage, one
+// tile pair at a time, shared by all of its waves: the block walks the head tiles in lock step (one
+// barrier per tile), so a tile pair is fetched once per block and gradient evaluation instead of
+// once per wave.  The data row is re-read per tile (L2) instead of living in 4*ntx registers.
+struct BgmHeadStream {
+  const float *src;      // global: [ntx][BGM_PAIR]
+  float *buf;            // LDS:    [2][BGM_PAIR]
+  int cur, tid, nthreads;
+  f32x4 r0, r1;
+  __device__ __forceinline__ void fetch(int tx) {
+    const f32x4 *s = reinterpret_cast<const f32x4 *>(src + (long long)tx * BGM_PAIR);
+    if (tid < BGM_PAIR / 4) r0 = s[tid];
+    if (tid + nthreads < BGM_PAIR / 4) r1 = s[tid + nthreads];
+  }
+  __device__ __forceinline__ void commit() {   // publish the fetched pair, flip buffers (block-wide barrier)
+    f32x4 *d = reinterpret_cast<f32x4 *>(buf + (cur ^ 1) * BGM_PAIR);
+    if (tid < BGM_PAIR / 4) d[tid] = r0;
+    if (tid + nthreads < BGM_PAIR / 4) d[tid + nthreads] = r1;
+    __syncthreads();
+    cur ^= 1;
+  }
+  __device__ __forceinline__ const float *tile() const { return buf + cur * BGM_PAIR; }
+  __device__ __forceinline__ void begin(const float *blob, const BgmMeta &m, float *lds) {
+    src = blob + m.whd; buf = lds + m.stage; tid = threadIdx.x; nthreads = blockDim.x;
+    cur = 1;
+    fetch(0);
+    commit();            // tile 0 is current on entry to every gradient evaluation
+  }
 };
 
 // forward: acc[to] += W^T in   (acc pre-initialised with the bias).  The A values of K-step s+1 are
@@ -82,19 +120,18 @@ __device__ __forceinline__ void bias17(const float *bl, int g, f32x4 (&acc)[NT])
   for (int t = 0; t < NT; ++t) acc[t] = *reinterpret_cast<const f32x4 *>(bl + 16 * t + 4 * g);
 }
 
-// mean tile (at wl) and variance tile (at wl + NTX*64*17) of one 16-feature block: forward ...
-template <int NTX>
+// mean tile (at wl) and variance tile (at wl + 64*17) of one 16-feature block: forward ...
 __device__ __forceinline__ void heads_fwd17(const float *wl, int j, int g, const f32x4 (&h)[4], f32x4 (&ms)[2]) {
   BGM_OPAQUE2(j, g);
   const float *base = wl + (4 * g) * 17 + j;
-  float c0 = base[0], c1 = base[NTX * 64 * 17], n0 = 0.0f, n1 = 0.0f;
+  float c0 = base[0], c1 = base[64 * 17], n0 = 0.0f, n1 = 0.0f;
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
     const int t = s >> 2, r = s & 3;
     if (s + 1 < 16) {
       const float *row = base + (16 * ((s + 1) >> 2) + ((s + 1) & 3)) * 17;
       n0 = row[0];
-      n1 = row[NTX * 64 * 17];
+      n1 = row[64 * 17];
     }
     ms[0] = BGM_MFMA(c0, h[t][r], ms[0]);
     ms[1] = BGM_MFMA(c1, h[t][r], ms[1]);
@@ -103,7 +140,6 @@ __device__ __forceinline__ void heads_fwd17(const float *wl, int j, int g, const
   }
 }
 // ... and backward: dh[ti] += Wmean dmu + Wvar ds
-template <int NTX>
 __device__ __forceinline__ void heads_bwd17(const float *wl, int i, int g, const f32x4 (&dms)[2], f32x4 (&dh)[4]) {
   BGM_OPAQUE2(i, g);
   const float *base = wl + i * 17 + 4 * g;
@@ -111,7 +147,7 @@ __device__ __forceinline__ void heads_bwd17(const float *wl, int i, int g, const
   for (int r = 0; r < 4; ++r) {
     float am[4], av[4];
 #pragma unroll
-    for (int ti = 0; ti < 4; ++ti) { am[ti] = base[16 * ti * 17 + r]; av[ti] = base[NTX * 64 * 17 + 16 * ti * 17 + r]; }
+    for (int ti = 0; ti < 4; ++ti) { am[ti] = base[16 * ti * 17 + r]; av[ti] = base[64 * 17 + 16 * ti * 17 + r]; }
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti) {
       dh[ti] = BGM_MFMA(am[ti], dms[0][r], dh[ti]);
@@ -121,14 +157,47 @@ __device__ __forceinline__ void heads_bwd17(const float *wl, int i, int g, const
   }
 }
 
+// The data rows of the 16 chains of a wave: registers for the LDS-resident variants (NTX > 0), a
+// pointer to the (clamped) row for the wide variant (NTX == 0; the row is re-read per head tile).
+template <int NTX> struct BgmX { f32x4 r[NTX]; };
+template <> struct BgmX<0> { const float *row; };
+
+// one 16-feature head block: forward, masked NLL, (optionally) dlogp/d(mean, s_raw) and backward into dh
+template <bool WANT_GRAD>
+__device__ __forceinline__ void bgm_head_tile(const float *wl, const float *lds, const BgmMeta &m, int tx, int j, int g,
+                                              const f32x4 (&h)[4], const f32x4 &xv, float &nll, f32x4 (&dh)[4]) {
+  f32x4 ms[2];
+  ms[0] = *reinterpret_cast<const f32x4 *>(lds + m.bhd + 16 * tx + 4 * g);
+  ms[1] = *reinterpret_cast<const f32x4 *>(lds + m.bhd + 16 * (m.ntx + tx) + 4 * g);
+  heads_fwd17(wl, j, g, h, ms);
+  f32x4 dms[2];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float x_ = xv[r];
+    const bool obs = (x_ == x_) && (16 * tx + 4 * g + r < m.p);   // NaN = missing
+    const float s2 = softplus_f(ms[1][r]) + BGM_EPS;
+    const float inv = fast_rcp(s2);
+    const float d = obs ? x_ - ms[0][r] : 0.0f;
+    nll += obs ? 0.5f * (d * d * inv + fast_log(s2)) : 0.0f;
+    if (WANT_GRAD) {
+      const float sg = fast_rcp(1.0f + fast_exp(-ms[1][r]));      // sigmoid(s) = d softplus / ds
+      dms[0][r] = d * inv;                                                        // dlogp/dmu
+      dms[1][r] = obs ? (0.5f * d * d * inv * inv - 0.5f * inv) * sg : 0.0f;     // dlogp/ds
+    }
+  }
+  if (WANT_GRAD) heads_bwd17(wl, j, g, dms, dh);
+}
+
 // log p(z | x_obs) and dlogp/dz for 16 chains held by one wave.
 //   z  : feature 16t + 4r + g in register r of tile t
-//   xr : data row, feature 16t + 4g + r, NaN = missing (ignored), zero padded beyond p
+//   xs : data row, feature 16t + 4g + r, NaN = missing (ignored), zero padded beyond p
+//   hs : head-weight stream of the block (wide variant only; every wave of the block must call this
+//        function the same number of times)
 // logp is replicated over the lane groups; grad has the layout of z.
 template <int KTQ, int NTX, int NH, bool WANT_GRAD>
 __device__ __forceinline__ void bgm_logp_grad(const float *lds, const BgmMeta &m, int j, int g,
-                                              const f32x4 (&z)[KTQ], const f32x4 (&xr)[NTX], float &logp,
-                                              f32x4 (&grad)[KTQ]) {
+                                              const f32x4 (&z)[KTQ], const BgmX<NTX> &xs, BgmHeadStream &hs,
+                                              float &logp, f32x4 (&grad)[KTQ]) {
   // trunk forward; only the SIGN of every activation is kept for the backward pass (bit 4t+r of sgn[l])
   unsigned sgn[NH];
   f32x4 h[4];
@@ -159,34 +228,31 @@ __device__ __forceinline__ void bgm_logp_grad(const float *lds, const BgmMeta &m
       }
     asm volatile("" : "+v"(sgn[l]));
   }
-  // heads, one 16-feature tile at a time: mean tile tx and variance tile NTX + tx
+  // heads, one 16-feature block at a time
   float nll = 0.0f;
   f32x4 dh[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) dh[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  if constexpr (NTX > 0) {
 #pragma unroll
-  for (int tx = 0; tx < NTX; ++tx) {
-    BGM_NO_HOIST();
-    f32x4 ms[2];
-    ms[0] = *reinterpret_cast<const f32x4 *>(lds + m.bhd + 16 * tx + 4 * g);
-    ms[1] = *reinterpret_cast<const f32x4 *>(lds + m.bhd + 16 * (NTX + tx) + 4 * g);
-    heads_fwd17<NTX>(lds + m.whd + tx * (64 * 17), j, g, h, ms);
-    f32x4 dms[2];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float xv = xr[tx][r];
-      const bool obs = (xv == xv) && (16 * tx + 4 * g + r < m.p);   // NaN = missing
-      const float s2 = softplus_f(ms[1][r]) + BGM_EPS;
-      const float inv = fast_rcp(s2);
-      const float d = obs ? xv - ms[0][r] : 0.0f;
-      nll += obs ? 0.5f * (d * d * inv + fast_log(s2)) : 0.0f;
-      if (WANT_GRAD) {
-        const float sg = fast_rcp(1.0f + fast_exp(-ms[1][r]));      // sigmoid(s) = d softplus / ds
-        dms[0][r] = d * inv;                                                        // dlogp/dmu
-        dms[1][r] = obs ? (0.5f * d * d * inv * inv - 0.5f * inv) * sg : 0.0f;     // dlogp/ds
-      }
+    for (int tx = 0; tx < NTX; ++tx) {
+      BGM_NO_HOIST();
+      bgm_head_tile<WANT_GRAD>(lds + m.whd + tx * BGM_PAIR, lds, m, tx, j, g, h, xs.r[tx], nll, dh);
     }
-    if (WANT_GRAD) heads_bwd17<NTX>(lds + m.whd + tx * (64 * 17), j, g, dms, dh);
+  } else {
+#pragma unroll 1
+    for (int tx = 0; tx < m.ntx; ++tx) {
+      BGM_NO_HOIST();
+      hs.fetch(tx + 1 < m.ntx ? tx + 1 : 0);
+      f32x4 xv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 16 * tx + 4 * g + r;
+        xv[r] = (c < m.p) ? xs.row[c] : 0.0f;
+      }
+      bgm_head_tile<WANT_GRAD>(hs.tile(), lds, m, tx, j, g, h, xv, nll, dh);
+      hs.commit();
+    }
   }
   float zsq = 0.0f;
 #pragma unroll
@@ -222,15 +288,26 @@ __device__ __forceinline__ void bgm_logp_grad(const float *lds, const BgmMeta &m
 }
 
 template <int NTX>
-__device__ __forceinline__ void bgm_load_x(const float *x, long long n, int p, long long row, int g, f32x4 (&xr)[NTX]) {
+__device__ __forceinline__ void bgm_load_x(const float *x, long long n, int p, long long row, int g, BgmX<NTX> &xs) {
   const float *p_ = x + row * (long long)p;
+  if constexpr (NTX > 0) {
 #pragma unroll
-  for (int t = 0; t < NTX; ++t)
+    for (int t = 0; t < NTX; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int c = 16 * t + 4 * g + r;
-      xr[t][r] = (c < p) ? p_[c] : 0.0f;
-    }
+      for (int r = 0; r < 4; ++r) {
+        const int c = 16 * t + 4 * g + r;
+        xs.r[t][r] = (c < p) ? p_[c] : 0.0f;
+      }
+  } else {
+    xs.row = p_;
+  }
+}
+// Row tile of this wave in pass `it` of the block.  The wide variant (NTX == 0) needs every wave of a
+// block to make the same number of passes (block-wide barriers in the head loop): waves beyond the
+// last tile recompute the last row and store nothing.
+__device__ __forceinline__ long long bgm_block_passes(long long n_tiles, int waves) {
+  const long long per_pass = (long long)gridDim.x * waves;
+  return (n_tiles + per_pass - 1) / per_pass;
 }
 template <int KTQ>
 __device__ __forceinline__ void bgm_load_z(const float *z, int q, long long row, int g, f32x4 (&zr)[KTQ]) {
@@ -259,20 +336,27 @@ __global__ __launch_bounds__(64 * WAVES) void bgm_logpost_kernel(const float *bl
                                                                  const float *x, long long n, float *out,
                                                                  float *grad_out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  lds_fill(lds, blob, m.total);
+  lds_fill(lds, blob, m.lds_resident);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
-  const long long n_tiles = (n + 15) / 16;
-  for (long long tile = (long long)blockIdx.x * WAVES + wave; tile < n_tiles; tile += (long long)gridDim.x * WAVES) {
+  BgmHeadStream hs;
+  if constexpr (NTX == 0) hs.begin(blob, m, lds);
+  const long long n_tiles = (n + 15) / 16, passes = bgm_block_passes(n_tiles, WAVES);
+  for (long long ps = 0; ps < passes; ++ps) {
     BGM_NO_HOIST();
+    long long tile = (ps * gridDim.x + blockIdx.x) * WAVES + wave;
+    const bool tile_ok = tile < n_tiles;
+    if (NTX > 0 && !tile_ok) break;
+    tile = tile_ok ? tile : n_tiles - 1;
     long long row = tile * 16 + j;
-    const bool ok = row < n;
-    row = ok ? row : n - 1;
-    f32x4 xr[NTX], zr[KTQ], gr[KTQ];
+    const bool ok = tile_ok && row < n;
+    row = row < n ? row : n - 1;
+    BgmX<NTX> xr;
+    f32x4 zr[KTQ], gr[KTQ];
     bgm_load_x<NTX>(x, n, m.p, row, g, xr);
     bgm_load_z<KTQ>(z, m.q, row, g, zr);
     float lp;
-    if (grad_out != nullptr) bgm_logp_grad<KTQ, NTX, NH, true>(lds, m, j, g, zr, xr, lp, gr);
-    else bgm_logp_grad<KTQ, NTX, NH, false>(lds, m, j, g, zr, xr, lp, gr);
+    if (grad_out != nullptr) bgm_logp_grad<KTQ, NTX, NH, true>(lds, m, j, g, zr, xr, hs, lp, gr);
+    else bgm_logp_grad<KTQ, NTX, NH, false>(lds, m, j, g, zr, xr, hs, lp, gr);
     if (ok) {
       if (g == 0) out[row] = lp;
       if (grad_out != nullptr) bgm_store_z<KTQ>(grad_out, m.q, row, g, gr);
@@ -301,16 +385,23 @@ template <int KTQ, int NTX, int NH, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void bgm_hmc_kernel(BgmHmcKArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const BgmMeta &m = a.m;
-  lds_fill(lds, a.blob, m.total);
+  lds_fill(lds, a.blob, m.lds_resident);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
-  const long long n = a.n, n_tiles = (n + 15) / 16;
+  BgmHeadStream hs;
+  if constexpr (NTX == 0) hs.begin(a.blob, m, lds);
+  const long long n = a.n, n_tiles = (n + 15) / 16, passes = bgm_block_passes(n_tiles, WAVES);
   const float eps = *a.step;
-  for (long long tile = (long long)blockIdx.x * WAVES + wave; tile < n_tiles; tile += (long long)gridDim.x * WAVES) {
+  for (long long ps = 0; ps < passes; ++ps) {
+    long long tile = (ps * gridDim.x + blockIdx.x) * WAVES + wave;
+    const bool tile_ok = tile < n_tiles;
+    if (NTX > 0 && !tile_ok) break;
+    tile = tile_ok ? tile : n_tiles - 1;
     long long row = tile * 16 + j;
-    const bool ok = row < n;
-    row = ok ? row : n - 1;
+    const bool ok = tile_ok && row < n;
+    row = row < n ? row : n - 1;
     const unsigned rowid = (unsigned)(a.row_base + row);
-    f32x4 xr[NTX], z[KTQ], gr[KTQ];
+    BgmX<NTX> xr;
+    f32x4 z[KTQ], gr[KTQ];
     bgm_load_x<NTX>(a.x, n, m.p, row, g, xr);
     float lp;
     if (a.init) {   // initial_state ~ N(0,1)  (bgm/base.py:778), RNG tag 0
@@ -320,7 +411,7 @@ __global__ __launch_bounds__(64 * WAVES) void bgm_hmc_kernel(BgmHmcKArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) z[t][r] = (16 * t + 4 * r + g < m.q) ? e[r] : 0.0f;
       }
-      bgm_logp_grad<KTQ, NTX, NH, true>(lds, m, j, g, z, xr, lp, gr);
+      bgm_logp_grad<KTQ, NTX, NH, true>(lds, m, j, g, z, xr, hs, lp, gr);
     } else {
       bgm_load_z<KTQ>(a.state, m.q, row, g, z);
       bgm_load_z<KTQ>(a.grad, m.q, row, g, gr);
@@ -349,7 +440,7 @@ __global__ __launch_bounds__(64 * WAVES) void bgm_hmc_kernel(BgmHmcKArgs a) {
         for (int t = 0; t < KTQ; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) zc[t][r] = fmaf(eps, mom[t][r], zc[t][r]);
-        bgm_logp_grad<KTQ, NTX, NH, true>(lds, m, j, g, zc, xr, lpc, gc);
+        bgm_logp_grad<KTQ, NTX, NH, true>(lds, m, j, g, zc, xr, hs, lpc, gc);
         const float kick = (l < a.n_leapfrog - 1) ? eps : 0.5f * eps;
 #pragma unroll
         for (int t = 0; t < KTQ; ++t)
@@ -427,17 +518,23 @@ template <int KTQ, int NTX, int NH, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void bgm_predict_kernel(BgmPredKArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const BgmMeta &m = a.m;
-  lds_fill(lds, a.blob, m.total);
+  lds_fill(lds, a.blob, m.lds_resident);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  BgmHeadStream hs;
+  if constexpr (NTX == 0) hs.begin(a.blob, m, lds);
   const long long n = a.n, n_tiles = (n + 15) / 16;
-  const long long work = n_tiles * a.n_draws;
-  for (long long w = (long long)blockIdx.x * WAVES + wave; w < work; w += (long long)gridDim.x * WAVES) {
+  const long long work = n_tiles * a.n_draws, passes = bgm_block_passes(work, WAVES);
+  for (long long ps = 0; ps < passes; ++ps) {
     BGM_NO_HOIST();
+    long long w = (ps * gridDim.x + blockIdx.x) * WAVES + wave;
+    const bool w_ok = w < work;
+    if (NTX > 0 && !w_ok) break;
+    w = w_ok ? w : work - 1;
     const long long tile = w / a.n_draws;
     const int d = (int)(w - tile * a.n_draws);
     long long row = tile * 16 + j;
-    const bool ok = row < n;
-    row = ok ? row : n - 1;
+    const bool ok = w_ok && row < n;
+    row = row < n ? row : n - 1;
     const unsigned rowid = (unsigned)(a.row_base + row);
     f32x4 z[KTQ];
     bgm_load_z<KTQ>(a.draws + (long long)d * n * m.q, m.q, row, g, z);
@@ -457,12 +554,11 @@ __global__ __launch_bounds__(64 * WAVES) void bgm_predict_kernel(BgmPredKArgs a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[t][r] = lrelu(h2[t][r]);
     }
-#pragma unroll
-    for (int tx = 0; tx < NTX; ++tx) {
+    auto head = [&](int tx, const float *wl) {
       f32x4 ms[2];
       ms[0] = *reinterpret_cast<const f32x4 *>(lds + m.bhd + 16 * tx + 4 * g);
-      ms[1] = *reinterpret_cast<const f32x4 *>(lds + m.bhd + 16 * (NTX + tx) + 4 * g);
-      heads_fwd17<NTX>(lds + m.whd + tx * (64 * 17), j, g, h, ms);
+      ms[1] = *reinterpret_cast<const f32x4 *>(lds + m.bhd + 16 * (m.ntx + tx) + 4 * g);
+      heads_fwd17(wl, j, g, h, ms);
       // reparameterize (networks/base.py:113-117): noise = Philox tag 6, call (16 tx + 4 g)/4, outputs r
       const f32x4 e = box_muller4(philox4x32_10(rowid, (unsigned)(a.burn_in + d), (unsigned)(4 * tx + g), TAG_XNOISE, a.k0, a.k1));
 #pragma unroll
@@ -478,6 +574,18 @@ __global__ __launch_bounds__(64 * WAVES) void bgm_predict_kernel(BgmPredKArgs a)
             if (sl >= 0) a.cells[(row * (long long)a.k_slots + sl) * a.n_draws + d] = xp;
           }
         }
+      }
+    };
+    if constexpr (NTX > 0) {
+#pragma unroll
+      for (int tx = 0; tx < NTX; ++tx) head(tx, lds + m.whd + tx * BGM_PAIR);
+    } else {
+#pragma unroll 1
+      for (int tx = 0; tx < m.ntx; ++tx) {
+        BGM_NO_HOIST();
+        hs.fetch(tx + 1 < m.ntx ? tx + 1 : 0);
+        head(tx, hs.tile());
+        hs.commit();
       }
     }
   }

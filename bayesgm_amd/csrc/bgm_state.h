@@ -1,5 +1,6 @@
 // bgm_state.h -- host-side state of the BGM path shared by bgm_api.hip and fit_api.hip.
 #pragma once
+#include <cstdlib>
 #include <vector>
 
 #include "bgm_host.h"
@@ -11,7 +12,9 @@ struct BgmState {
   bool configured = false, set = false;
   std::vector<float> theta;
   BgmMeta meta{};
-  int KTQ = 0, NTX = 0, NH = 0;
+  int KTQ = 0, NTX = 0, NH = 0;   // NTX = 0: wide variant (head weights streamed, any x_dim)
+  int lds_bytes = 0;              // dynamic LDS of the posterior kernels
+  int fit_lds_bytes = 0;
   float *blob_dev = nullptr;
   size_t blob_cap = 0;
   bool blob_valid = false;
@@ -48,5 +51,40 @@ inline void pack17(std::vector<float> &blob, int off, const std::vector<float> &
     }
 }
 
+
+// head weights, pair-contiguous: [tx][head][64 in][17]
+inline void pack17_heads(std::vector<float> &blob, int off, const float *W, int p, int ntx, int head) {
+  for (int tx = 0; tx < ntx; ++tx)
+    for (int rho = 0; rho < 64; ++rho)
+      for (int j = 0; j < 16; ++j) {
+        const int o = 16 * tx + j;
+        blob[off + tx * BGM_PAIR + head * 64 * 17 + rho * 17 + j] = (o < p) ? W[(size_t)rho * p + o] : 0.0f;
+      }
+}
+
+// Blob layout shared by the inference and the training blob.  Chooses the LDS-resident variant when the
+// whole generator fits the 160 KiB LDS AND a kernel is compiled for ceil(p/16); otherwise the wide variant.
+// Returns the dynamic LDS bytes, or -1 if not even the trunk + stage fits.
+inline int bgm_layout(int q, int p, int NH, BgmMeta &m, int &ntx_variant) {
+  const int KTQ = (q + 15) / 16, NTX = (p + 15) / 16;
+  m = BgmMeta{};
+  m.q = q; m.p = p; m.n_hh = NH - 1; m.ntx = NTX;
+  int off = 0;
+  auto take = [&](int n) { int o = off; off += (n + 3) / 4 * 4; return o; };
+  m.w1 = take(4 * 16 * KTQ * 17); m.b1 = take(64);
+  m.wh = take(m.n_hh * 4 * 64 * 17); m.bh = take(m.n_hh * 64);
+  m.bhd = take(2 * 16 * NTX);
+  m.whd = take(NTX * BGM_PAIR);
+  m.total = off;
+  const char *force = std::getenv("BGM_FORCE_WIDE");   // test hook: run the wide variant on small shapes too
+  const bool resident = (size_t)m.total * 4 <= 160 * 1024 && (NTX == 2 || NTX == 7) && !(force && force[0] == '1');
+  if (resident) {
+    ntx_variant = NTX; m.lds_resident = m.total; m.stage = 0;
+    return m.total * 4;
+  }
+  ntx_variant = 0; m.lds_resident = m.whd; m.stage = m.whd;
+  const size_t bytes = ((size_t)m.whd + 2 * BGM_PAIR) * 4;
+  return bytes <= 160 * 1024 ? (int)bytes : -1;
+}
 
 void bgm_bgm_fit_free(bgm_handle *h);

@@ -398,7 +398,7 @@ void bgm_bgm_fit_free(bgm_handle *h) {
 // training blob: same layout as the inference blob but WITHOUT folding the BatchNorm into layer 1
 static void bgm_pack_training(const BgmState *s, const std::vector<float> &theta, std::vector<float> &blob) {
   const BgmMeta &m = s->tmeta;
-  const int q = m.q, p = m.p, KTQ = s->KTQ, NTX = s->NTX;
+  const int q = m.q, p = m.p, KTQ = s->KTQ, NTX = m.ntx;
   blob.assign(m.total, 0.0f);
   size_t o = 4 * (size_t)q;
   std::vector<float> W1(theta.begin() + o, theta.begin() + o + (size_t)q * 64); o += (size_t)q * 64;
@@ -414,7 +414,7 @@ static void bgm_pack_training(const BgmState *s, const std::vector<float> &theta
   }
   for (int head = 0; head < 2; ++head) {
     std::vector<float> W(theta.begin() + o, theta.begin() + o + (size_t)64 * p); o += (size_t)64 * p;
-    pack17(blob, m.whd + head * NTX * 64 * 17, W, 64, p, 64, NTX, ident);
+    pack17_heads(blob, m.whd, W.data(), p, NTX, head);
     for (int k = 0; k < p; ++k) blob[m.bhd + head * 16 * NTX + k] = theta[o + k];
     o += p;
   }
@@ -435,17 +435,11 @@ extern "C" int bgm_bgm_fit_begin(bgm_handle *h, int64_t n_rows, int32_t max_batc
   bgm_bgm_fit_free(h);
   const int q = s->cfg.z_dim, p = s->cfg.x_dim, NH = s->cfg.n_hidden_g;
   const int KTQ = (q + 15) / 16, NTX = (p + 15) / 16, KQ = 16 * KTQ;
-  s->KTQ = KTQ; s->NTX = NTX; s->NH = NH;
   BgmMeta &m = s->tmeta;
-  std::memset(&m, 0, sizeof(m));
-  m.q = q; m.p = p; m.n_hh = NH - 1;
-  int off = 0;
-  auto take = [&](int n) { int o = off; off += (n + 3) / 4 * 4; return o; };
-  m.w1 = take(4 * KQ * 17); m.b1 = take(64);
-  m.wh = take(m.n_hh * 4 * 64 * 17); m.bh = take(m.n_hh * 64);
-  m.whd = take(2 * NTX * 64 * 17); m.bhd = take(2 * 16 * NTX);
-  m.total = off;
-  if ((size_t)m.total * 4 > 160 * 1024) { bgm_set_error("BGM generator does not fit the LDS-resident layout"); return BGM_E_UNSUPPORTED; }
+  int ntx_variant = 0;
+  s->fit_lds_bytes = bgm_layout(q, p, NH, m, ntx_variant);
+  if (s->fit_lds_bytes < 0) { bgm_set_error("BGM generator does not fit the LDS layout (x_dim too large)"); return BGM_E_UNSUPPORTED; }
+  s->KTQ = KTQ; s->NTX = ntx_variant; s->NH = NH;
   const int np = (int)s->theta.size();
   if (np >= (1 << 24)) { bgm_set_error("too many parameters"); return BGM_E_UNSUPPORTED; }
   s->n_params = np;
@@ -516,7 +510,7 @@ extern "C" int bgm_bgm_fit_begin(bgm_handle *h, int64_t n_rows, int32_t max_batc
   return BGM_OK;
 }
 
-#define BGM_BGM_FIT_VARIANTS(X) X(1, 2, 5) X(1, 7, 5) X(1, 2, 3) X(1, 7, 3)
+#define BGM_BGM_FIT_VARIANTS(X) X(1, 2, 5) X(1, 7, 5) X(1, 0, 5) X(1, 2, 3) X(1, 7, 3) X(1, 0, 3)
 
 static int bgm_fit_fwd_bwd(bgm_handle *h, BgmState *s, const float *x, const float *data_z, const int32_t *idx, int batch,
                            double *loss, int update_moving, hipStream_t stream) {
@@ -529,7 +523,7 @@ static int bgm_fit_fwd_bwd(bgm_handle *h, BgmState *s, const float *x, const flo
   ka.idx = idx; ka.B = batch; ka.inv_B = 1.0f / (float)batch; ka.bn = s->bn_dev; ka.loss = loss;
   const int tiles = (batch + 15) / 16;
   const int grid = std::max(1, std::min((tiles + BGM_FIT_WAVES - 1) / BGM_FIT_WAVES, h->n_cus));
-  const int lds = s->tmeta.total * 4;
+  const int lds = s->fit_lds_bytes;
 #define X(KTQ_, NTX_, NH_)                                                                                          \
   if (s->KTQ == KTQ_ && s->NTX == NTX_ && s->NH == NH_) {                                                           \
     auto kf = bgm_fit_fwd_kernel<KTQ_, NTX_, NH_, BGM_FIT_WAVES>;                                                   \

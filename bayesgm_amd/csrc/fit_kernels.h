@@ -355,6 +355,7 @@ __global__ __launch_bounds__(256) void fit_dw_kernel(DwArgs a) {
   float *out = a.partial + (long long)blockIdx.x * a.partial_stride + L.out_off;
   const float *A = a.ws + L.a_off, *D = a.ws + L.d_off;
   constexpr int NT_MAX = 13;
+  for (int to0 = 0; to0 < NT; to0 += NT_MAX)   // output tiles in register-sized chunks (one chunk up to N = 208)
   for (int ti = wave; ti < KT; ti += 4) {
     f32x4 acc[NT_MAX];
 #pragma unroll
@@ -368,8 +369,8 @@ __global__ __launch_bounds__(256) void fit_dw_kernel(DwArgs a) {
       const float av = ok ? A[rr * L.K + 16 * ti + i] : 0.0f;
 #pragma unroll
       for (int to = 0; to < NT_MAX; ++to) {
-        if (to < NT) {
-          const float dv = ok ? D[rr * L.N + 16 * to + i] : 0.0f;
+        if (to0 + to < NT) {
+          const float dv = ok ? D[rr * L.N + 16 * (to0 + to) + i] : 0.0f;
           acc[to] = BGM_MFMA(av, dv, acc[to]);
           bsum[to] += dv;
         }
@@ -378,14 +379,14 @@ __global__ __launch_bounds__(256) void fit_dw_kernel(DwArgs a) {
     // D tile [in feature 16 ti + 4 kk + r][out feature 16 to + i]
 #pragma unroll
     for (int to = 0; to < NT_MAX; ++to) {
-      if (to < NT) {
+      if (to0 + to < NT) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[(long long)(16 * ti + 4 * kk + r) * L.N + 16 * to + i] = acc[to][r];
+        for (int r = 0; r < 4; ++r) out[(long long)(16 * ti + 4 * kk + r) * L.N + 16 * (to0 + to) + i] = acc[to][r];
         if (ti == 0) {   // bias gradient = column sums of dpre (wave 0 only: ti == wave for the first pass)
           float s = bsum[to];
           s += __shfl_xor(s, 16);
           s += __shfl_xor(s, 32);
-          if (kk == 0) out[(long long)L.K * L.N + 16 * to + i] = s;
+          if (kk == 0) out[(long long)L.K * L.N + 16 * (to0 + to) + i] = s;
         }
       }
     }

@@ -258,10 +258,8 @@ class BGM(object):
         los = np.zeros_like(means)
         his = np.zeros_like(means)
         samples = []
-        slot_np = np.full((n_loc, p), -1, np.int32)
-        for i in range(n_loc):
-            c = np.where(miss_loc[i])[0]
-            slot_np[i, c] = np.arange(len(c), dtype=np.int32)
+        slot_np = (np.cumsum(miss_loc, axis=1, dtype=np.int32) - 1).astype(np.int32)   # k-th missing cell of a row -> slot k
+        slot_np[~miss_loc] = -1
         for s in range(0, n_loc, rows_blk):
             e = min(s + rows_blk, n_loc)
             draws = torch.empty((n_mcmc, e - s, q), device=dev)
@@ -295,10 +293,10 @@ class BGM(object):
             else:
                 pred_interval = np.stack([los[:, :mi.size], his[:, :mi.size]], axis=-1)
         else:
-            pred_interval = []
-            for i in range(n):
-                k = int(miss[i].sum())
-                pred_interval.append(np.zeros((0, 2), np.float32) if k == 0 else np.stack([los[i, :k], his[i, :k]], -1))
+            k_row = miss.sum(axis=1)
+            used = np.arange(los.shape[1])[None, :] < k_row[:, None]
+            flat = np.stack([los[used], his[used]], axis=-1).astype(np.float32)          # row-major: row i's cells together
+            pred_interval = np.split(flat, np.cumsum(k_row)[:-1]) if n else []
         if return_samples:
             full = np.concatenate(samples, axis=1)
             if parallel.is_dist():
@@ -309,9 +307,6 @@ class BGM(object):
         imputed = data_obs.copy()
         rr, cc = np.where(miss)
         if rr.size:
-            slot_full = np.full((n, p), -1, np.int64)
-            for i in range(n):
-                c = np.where(miss[i])[0]
-                slot_full[i, c] = np.arange(len(c))
+            slot_full = np.cumsum(miss, axis=1) - 1
             imputed[rr, cc] = means[rr, slot_full[rr, cc]]
         return imputed, pred_interval

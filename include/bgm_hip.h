@@ -228,6 +228,10 @@ typedef struct {
   int32_t n_hidden_g, g_units[BGM_MAX_LAYERS];
 } bgm_bgm_config;
 
+/* Supported shapes: z_dim <= 16, g_units = [64]*3 or [64]*5, any x_dim whose head biases fit the LDS beside
+ * the trunk (x_dim <= ~2000).  x_dim in (16,32] and (96,112] run with the whole generator resident in LDS;
+ * every other width (e.g. config C4, x_dim = 500) streams the 2 x 64 x x_dim head weights through an LDS
+ * stage shared by the waves of a block. */
 int bgm_bgm_configure(bgm_handle *h, const bgm_bgm_config *cfg);
 
 /* Generator parameters from HOST memory, flat float32:

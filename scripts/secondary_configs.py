@@ -1,6 +1,9 @@
 """Throughput of the secondary BASELINE.json configurations on one MI355X (random-init weights).
 C1: CausalBGM binary treatment N=1e5 p=100 z_dims [3,3,6,6] (cli defaults): predict (MH + ITE + per-row quantiles)
-C0/BGM: BGM imputation, 10 % cells missing: N=2000 p=20 and N=1e5 p=100, HMC L=10."""
+C0/BGM: BGM imputation, 10 % cells missing: N=2000 p=20 and N=1e5 p=100, HMC L=10.
+C4 (one GPU's share of N=5e6 over 8 GPUs): BGM imputation N=625000 p=500, 1000 burn-in + 1000 retained draws.
+FLOP accounting: L=10 gradient evaluations (forward+backward = 4 MACs(g)) per transition are EXECUTED (the
+gradient at the current state is cached, as TFP does); SURVEY 8(d)'s figure of 44 MACs counts one more."""
 import json, sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -21,7 +24,10 @@ for rep in range(2):
     torch.cuda.synchronize(); dt = time.time() - t0
 out["C1_causal_binary_N1e5_p100"] = dict(predict_s=dt, transitions_per_s=N * 8000 / dt, acceptance=m.last_acceptance_rate,
                                          ate=float(ite.mean()), shapes=[list(ite.shape), list(interval.shape)])
-for (N, p, n_mcmc, burn) in [(2000, 20, 5000, 5000), (100000, 100, 1000, 1000)]:
+cases = [(2000, 20, 5000, 5000), (100000, 100, 1000, 1000)]
+if "--c4" in sys.argv:
+    cases.append((625000, 500, 1000, 1000))
+for (N, p, n_mcmc, burn) in cases:
     bp = dict(dataset="t", output_dir="gpurun_out/sec", save_res=False, save_model=False, use_bnn=False, z_dim=10, x_dim=p,
               lr_theta=5e-3, lr_z=5e-3, g_units=[64] * 5, e_units=[64] * 5, dz_units=[64, 32, 8], dx_units=[64, 32, 8],
               kl_weight=5e-5, lr=1e-3, g_d_freq=1, use_z_rec=True, alpha=0.0, gamma=0.0)
@@ -29,12 +35,12 @@ for (N, p, n_mcmc, burn) in [(2000, 20, 5000, 5000), (100000, 100, 1000, 1000)]:
     rs = np.random.RandomState(0)
     data = rs.randn(N, p).astype(np.float32)
     data[rs.rand(N, p) < 0.1] = np.nan
-    for rep in range(2):
+    for rep in range(1 if N > 200000 else 2):
         torch.cuda.synchronize(); t0 = time.time()
         imp, interval = bm.predict(data, n_mcmc=n_mcmc, burn_in=burn)
         torch.cuda.synchronize(); dt = time.time() - t0
     macs = 10 * 64 + 4 * 4096 + 2 * 64 * p
     out[f"BGM_impute_N{N}_p{p}"] = dict(predict_s=dt, hmc_transitions_per_s=N * (n_mcmc + burn) / dt,
-                                        tflops_algorithmic=N * (n_mcmc + burn) * 44 * macs / dt / 1e12,
+                                        tflops_executed=N * (n_mcmc + burn) * 40 * macs / dt / 1e12,
                                         acceptance=bm.last_acceptance_rate)
 print(json.dumps(out))
