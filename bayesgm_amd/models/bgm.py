@@ -215,13 +215,21 @@ class BGM(object):
 
     # ------------------------------------------------------------------ predict
     def predict(self, data, alpha=0.05, return_samples=False, bs=100, n_mcmc=5000, burn_in=5000, step_size=0.01,
-                num_leapfrog_steps=10, seed=42, max_draw_bytes=8 << 30):
+                num_leapfrog_steps=10, seed=42, max_draw_bytes=64 << 30):
         """Posterior-predictive imputation of the NaN cells (bgm/base.py:527-663).
 
         HMC burn-in (with the shared step-size adaptation) runs over ALL rows at once as in the reference;
         the sampling phase then runs in row blocks sized so that the latent draws and the predictive cells of
         a block stay below ``max_draw_bytes`` (the reference materialises [n_mcmc, n, x_dim] on the host)."""
         assert 0 < alpha < 1, "The significance level 'alpha' must be greater than 0 and less than 1."
+        import time as _time
+        _t = {"_last": _time.perf_counter()}
+
+        def _mark(name):   # wall-clock phase breakdown (diagnostics only; kept in self.last_predict_timing)
+            torch.cuda.synchronize(self.engine.device)
+            now = _time.perf_counter()
+            _t[name] = _t.get(name, 0.0) + now - _t["_last"]
+            _t["_last"] = now
         data_np = data.cpu().numpy() if isinstance(data, torch.Tensor) else np.asarray(data, dtype=np.float32)
         data_np = data_np.astype(np.float32)
         n, p = data_np.shape
@@ -241,6 +249,7 @@ class BGM(object):
         acc_prob = torch.zeros(total, device=dev, dtype=torch.float64)
         acc_count = torch.zeros(total, device=dev, dtype=torch.int32)
         n_adapt = int(burn_in * 0.8)
+        _mark("setup_h2d")
         for it in range(n_adapt):
             eng.hmc_run(x, state, logp, grad, step, it, 1, burn_in, num_leapfrog_steps, seed, init=(it == 0),
                         row_base=lo_r, acc_prob=acc_prob, acc_count=acc_count)
@@ -249,41 +258,53 @@ class BGM(object):
         if burn_in > n_adapt:
             eng.hmc_run(x, state, logp, grad, step, n_adapt, burn_in - n_adapt, burn_in, num_leapfrog_steps, seed,
                         init=(n_adapt == 0), row_base=lo_r, acc_prob=acc_prob, acc_count=acc_count)
-        # ---- sampling + predictive draws per row block
-        miss_loc = miss[lo_r:hi_r]
-        k_slots = int(miss_loc.sum(axis=1).max()) if n_loc else 0
+        _mark("burn_in")
+        # ---- sampling + predictive draws per row block (slot maps, moments and the imputation stay in HBM)
+        miss_dev = torch.isnan(x)
+        k_row_dev = miss_dev.sum(dim=1)
+        k_max = k_row_dev.max().reshape(1) if n_loc else torch.zeros(1, dtype=torch.int64, device=dev)
+        k_slots = int(parallel.all_reduce_max_(k_max).item())   # same slot width on every rank (rows are gathered later)
+        slot_dev = (torch.cumsum(miss_dev, dim=1, dtype=torch.int32) - 1).to(torch.int32)   # k-th missing cell -> slot k
+        slot_dev.masked_fill_(~miss_dev, -1)
         per_row = 4 * n_mcmc * (q + max(k_slots, 1) + (p if return_samples else 0))
         rows_blk = max(16, int(max_draw_bytes // max(1, per_row)))
-        means = np.zeros((n_loc, max(k_slots, 1)), np.float32)
-        los = np.zeros_like(means)
-        his = np.zeros_like(means)
+        quantum = 16 * 24 * torch.cuda.get_device_properties(dev).multi_processor_count   # whole launch waves (8 / 12 waves per CU)
+        if rows_blk > quantum:
+            rows_blk -= rows_blk % quantum
+        means = torch.zeros((n_loc, max(k_slots, 1)), device=dev)
+        los = torch.zeros_like(means)
+        his = torch.zeros_like(means)
         samples = []
-        slot_np = (np.cumsum(miss_loc, axis=1, dtype=np.int32) - 1).astype(np.int32)   # k-th missing cell of a row -> slot k
-        slot_np[~miss_loc] = -1
+        _mark("slots")
         for s in range(0, n_loc, rows_blk):
             e = min(s + rows_blk, n_loc)
             draws = torch.empty((n_mcmc, e - s, q), device=dev)
             eng.hmc_run(x[s:e], state[s:e], logp[s:e], grad[s:e], step, burn_in, n_mcmc, burn_in, num_leapfrog_steps,
                         seed, init=(burn_in == 0), row_base=lo_r + s, acc_count=acc_count, draws=draws)
-            slot = torch.from_numpy(slot_np[s:e]).to(dev) if k_slots > 0 else None
             cells = full = None
             if k_slots > 0 or return_samples:
-                cells, full = eng.predict_draws(draws, burn_in, seed, slot=slot, k_slots=k_slots,
-                                                want_full=return_samples, row_base=lo_r + s)
+                cells, full = eng.predict_draws(draws, burn_in, seed, slot=slot_dev[s:e] if k_slots > 0 else None,
+                                                k_slots=k_slots, want_full=return_samples, row_base=lo_r + s)
             if k_slots > 0:
                 mean, lo, hi = eng.row_mean_quantiles(cells, alpha / 2.0, 1.0 - alpha / 2.0)
-                means[s:e] = mean.reshape(e - s, k_slots).cpu().numpy()
-                los[s:e] = lo.reshape(e - s, k_slots).cpu().numpy()
-                his[s:e] = hi.reshape(e - s, k_slots).cpu().numpy()
+                means[s:e] = mean.reshape(e - s, k_slots)
+                los[s:e] = lo.reshape(e - s, k_slots)
+                his[s:e] = hi.reshape(e - s, k_slots)
             if return_samples:
                 samples.append(full.cpu().numpy())
+            del draws, cells, full
+        _mark("sample_predict_quantiles")
         acc = acc_count[burn_in:].sum().double().reshape(1)
         parallel.all_reduce_sum_(acc)
         self.last_acceptance_rate = float(acc.item()) / max(1, n_mcmc * n)
         print(f"TFP MCMC Acceptance Rate: {self.last_acceptance_rate:.4f}")
+        # imputation: observed cells as given, missing cells = posterior-predictive mean
+        imputed_dev = torch.where(miss_dev, means.gather(1, slot_dev.clamp(min=0).long()), torch.nan_to_num(x, nan=0.0)) \
+            if k_slots > 0 else x.clone()
         if parallel.is_dist():
-            means, los, his = (parallel.all_gather_rows(torch.from_numpy(a).to(dev), n).cpu().numpy()
-                               for a in (means, los, his))
+            means, los, his = (parallel.all_gather_rows(a_, n) for a_ in (means, los, his))
+            imputed_dev = parallel.all_gather_rows(imputed_dev, n)
+        los, his = los.cpu().numpy(), his.cpu().numpy()
         # ---- assemble the reference's return values
         same_pattern = bool(np.all(miss == miss[0]))
         if same_pattern:
@@ -297,16 +318,15 @@ class BGM(object):
             used = np.arange(los.shape[1])[None, :] < k_row[:, None]
             flat = np.stack([los[used], his[used]], axis=-1).astype(np.float32)          # row-major: row i's cells together
             pred_interval = np.split(flat, np.cumsum(k_row)[:-1]) if n else []
+        _mark("intervals")
+        self.last_predict_timing = {k: v for k, v in _t.items() if k != "_last"}
         if return_samples:
             full = np.concatenate(samples, axis=1)
             if parallel.is_dist():
                 full = parallel.all_gather_rows(torch.from_numpy(np.ascontiguousarray(full.transpose(1, 0, 2))).to(dev),
                                                 n).cpu().numpy().transpose(1, 0, 2)
             return full, pred_interval
-        data_obs = np.nan_to_num(data_np, nan=0.0)
-        imputed = data_obs.copy()
-        rr, cc = np.where(miss)
-        if rr.size:
-            slot_full = np.cumsum(miss, axis=1) - 1
-            imputed[rr, cc] = means[rr, slot_full[rr, cc]]
+        imputed = imputed_dev.cpu().numpy()
+        _mark("impute_assembly")
+        self.last_predict_timing = {k: v for k, v in _t.items() if k != "_last"}
         return imputed, pred_interval

@@ -36,6 +36,13 @@ def all_reduce_sum_(t):
     return t
 
 
+def all_reduce_max_(t):
+    """In-place MAX all-reduce (no-op when not distributed)."""
+    if is_dist():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t
+
+
 def all_gather_rows(t, n_total):
     """Concatenate per-rank row blocks (first dim) of possibly unequal length."""
     if not is_dist():
