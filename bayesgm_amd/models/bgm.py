@@ -3,7 +3,8 @@
 Mirrors /root/reference/src/bayesgm/models/bgm/base.py:
     __init__ :59-121   get_config :123   fit :343   evaluate :445   generate :479
     predict_on_posteriors :511   predict :527   get_log_posterior :666   tfp_mcmc_sampler :709
-Deterministic generator (``use_bnn=False``: BaseVariationalNet, networks/base.py:53-117) only;
+Deterministic generator (``use_bnn=False``: BaseVariationalNet, networks/base.py:53-117) only; the EGM warm
+start runs through the interim torch-autograd module (bayesgm_amd/egm.py);
 ``use_bnn=True`` raises NotImplementedError.
 """
 import datetime
@@ -62,6 +63,7 @@ class BGM(object):
         if p['save_res'] and not os.path.exists(self.save_dir):
             os.makedirs(self.save_dir, exist_ok=True)
         self.data_z = None
+        self._egm = None
         self.last_acceptance_rate = None
 
     def get_config(self):
@@ -79,9 +81,56 @@ class BGM(object):
 
     # ------------------------------------------------------------------ fit
     def egm_init(self, data, egm_n_iter=10000, batch_size=32, egm_batches_per_eval=500, verbose=1):
-        """EGM warm start (bgm/base.py:294-340): SURVEY.md section 8(f) row N1 -- not built yet."""
-        raise NotImplementedError("bayesgm_amd: the EGM warm start (egm_init / use_egm_init=True) is not built yet; "
-                                  "call fit(..., use_egm_init=False)")
+        """EGM warm start (bgm/base.py:292-340).  INTERIM: runs on the GPU through PyTorch autograd
+        (bayesgm_amd/egm.py), not yet as hand-written kernels; see that module's docstring.  The trained
+        generator is installed in the HIP engine; the encoder stays with the EGM object (`self._egm`) for
+        the Z initialisation e(X) and `evaluate(data_z=None)`."""
+        from ..egm import BgmEGM
+        from ..datasets import Base_sampler
+        data = np.asarray(data, dtype=np.float32)
+        dev = self.engine.device
+        self.data_sampler = Base_sampler(x=data, y=data, v=data, batch_size=batch_size, normalize=False)   # :294
+        xd = self._dev(data)
+        egm = BgmEGM(self.g, self._p, dev, self._rs, batch_size)
+        try:
+            egm.capture()
+        except Exception as e:   # graph capture is an optimisation only
+            if verbose:
+                print("EGM: HIP-graph capture unavailable (%s); running eagerly" % type(e).__name__)
+        self._egm = egm
+        print('EGM Initialization Starts ...')
+        g_d_freq = int(self._p['g_d_freq'])
+        for batch_iter in range(egm_n_iter + 1):
+            for _ in range(g_d_freq):
+                bx, _, _ = self.data_sampler.next_batch()
+                bz = self.z_sampler.get_batch(batch_size)
+                egm.disc_step(torch.from_numpy(bz).to(dev), torch.from_numpy(bx).to(dev),
+                              np.random.uniform(0.0, 1.0), np.random.uniform(0.0, 1.0))
+            bx, _, _ = self.data_sampler.next_batch()
+            bz = self.z_sampler.get_batch(batch_size)
+            egm.gen_step(torch.from_numpy(bz).to(dev), torch.from_numpy(bx).to(dev))
+            if batch_iter % egm_batches_per_eval == 0:
+                if verbose:
+                    lg, ld = egm.out_g.cpu().numpy(), egm.out_d.cpu().numpy()
+                    print('EGM Initialization Iter [%d] : g_loss_adv[%.4f], e_loss_adv [%.4f], l2_loss_z [%.4f], '
+                          'l2_loss_x [%.4f], sd^2_loss[%.4f], g_e_loss [%.4f], dz_loss [%.4f], dx_loss[%.4f], d_loss [%.4f]'
+                          % (batch_iter, lg[0], lg[1], lg[2], lg[3], lg[4], lg[5], ld[0], ld[1], ld[2]))
+                z_, x_rec, mse = egm.eval_pass(xd)          # moves the BatchNorm moving statistics (training=True call)
+                self.set_weights(egm.export_g())
+                print('MSE_x', mse)
+                if self._p['save_res']:
+                    gen1, var1 = self.generate(nb_samples=5000)
+                    gen12, var12 = self.generate(nb_samples=5000, use_x_sd=False)
+                    np.savez('%s/init_data_gen_at_%d.npz' % (self.save_dir, batch_iter), gen1=gen1, gen12=gen12,
+                             z=z_.cpu().numpy(), x_rec=x_rec.cpu().numpy(), var1=var1, var12=var12)
+                mse_x = self.evaluate(data=data, use_x_sd=True)
+                print('iter [%d/%d]: MSE_x: %.4f\n' % (batch_iter, egm_n_iter, mse_x))
+                mse_x = self.evaluate(data=data, use_x_sd=False)
+                print('iter [%d/%d]: MSE_x no x_sd: %.4f\n' % (batch_iter, egm_n_iter, mse_x))
+                if self._p['save_model']:
+                    self.save_checkpoint('egm_init_%d' % batch_iter)
+        self.set_weights(egm.export_g())
+        print('EGM Initialization Ends.')
 
     def fit(self, data, batch_size=32, epochs=100, epochs_per_eval=5, use_egm_init=True, egm_n_iter=20000,
             egm_batches_per_eval=500, verbose=1):
@@ -97,13 +146,16 @@ class BGM(object):
         if self._p['save_res']:
             with open('{}/params.txt'.format(self.save_dir), 'w') as f_params:
                 f_params.write(str(self.params))
-        if verbose:
-            print('Random initialization of latent variables Z...')
         eng = self.engine
         dev = eng.device
-        data_z_init = np.random.normal(0, 1, size=(n, eng.q)).astype('float32')     # :388
         x = self._dev(data)
-        self.data_z = self._dev(data_z_init)
+        if use_egm_init:
+            print('Initialize latent variables Z with e(V)...')
+            self.data_z = self._egm.encode(x).contiguous()                              # :384
+        else:
+            print('Random initialization of latent variables Z...')
+            data_z_init = np.random.normal(0, 1, size=(n, eng.q)).astype('float32')     # :388
+            self.data_z = self._dev(data_z_init)
         n_params = eng.fit_begin(n, batch_size)
         grad = torch.empty(n_params, device=dev)
         loss = torch.zeros(4, device=dev, dtype=torch.float64)
@@ -142,7 +194,7 @@ class BGM(object):
 
     def save_checkpoint(self, epoch):
         """Counterpart of g_net.save_weights(...) (bgm/base.py:431-434): generator parameters as .npz."""
-        path = os.path.join(self.checkpoint_path, "weights_at_%d_generator.npz" % epoch)
+        path = os.path.join(self.checkpoint_path, "weights_at_%s_generator.npz" % epoch)
         flat = {"bn_" + k: v for k, v in self.g["bn"].items()}
         for i, (W, b) in enumerate(self.g["trunk"]):
             flat["trunk_W%d" % i], flat["trunk_b%d" % i] = W, b
@@ -207,8 +259,9 @@ class BGM(object):
     def evaluate(self, data, data_z=None, use_x_sd=True):
         """mse_x between data and its reconstruction (bgm/base.py:444-476)."""
         if data_z is None:
-            raise NotImplementedError("bayesgm_amd: BGM.evaluate(data_z=None) needs the EGM encoder (SURVEY 8f N1); "
-                                      "pass data_z")
+            if getattr(self, "_egm", None) is None:
+                raise RuntimeError("BGM.evaluate(data_z=None) needs the encoder trained by egm_init(); pass data_z")
+            data_z = self._egm.encode(self._dev(data))
         z = data_z.cpu().numpy() if isinstance(data_z, torch.Tensor) else np.asarray(data_z, np.float32)
         x_pred, _ = self._decode(z, use_x_sd)
         return np.float32(np.mean((np.asarray(data, np.float32) - x_pred) ** 2))
