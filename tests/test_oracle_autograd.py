@@ -214,3 +214,93 @@ def test_bgm_hmc_samples_known_gaussian_posterior():
     flat = out.reshape(-1, 3)
     assert np.abs(flat.mean(0)).max() < 0.05 and np.abs(flat.var(0) - 1).max() < 0.1
     assert info["step"] > 0.05 and 0.5 < info["accept_rate"] <= 1.0
+
+
+# ---------------------------------------------------------------------------------------------
+# EGM warm start (oracle/egm.py): WGAN-GP double backward through batch-statistics BatchNorm
+# ---------------------------------------------------------------------------------------------
+def _egm_setup(rs, q=10, pdim=23):
+    from oracle import egm as OE
+    from oracle import nets as N
+    nets = {"g": N.init_mlp(rs, [q, 64, 64, pdim + 1], np.float64), "e": N.init_mlp(rs, [pdim, 64, 64, q], np.float64),
+            "f": N.init_mlp(rs, [3, 64, 32, 8, 2], np.float64), "h": N.init_mlp(rs, [2, 64, 32, 8, 2], np.float64)}
+    for k in nets:
+        nets[k] = [(W, 0.1 * rs.randn(*b.shape)) for W, b in nets[k]]
+    dz = OE.init_disc(rs, q, [64, 32, 8], np.float64)
+    dz["b"] = [0.1 * rs.randn(*b.shape) for b in dz["b"]]
+    dz["gamma"] = [1 + 0.2 * rs.randn(*b.shape) for b in dz["gamma"]]
+    dz["beta"] = [0.1 * rs.randn(*b.shape) for b in dz["beta"]]
+    return nets, dz
+
+
+def _tdisc(d, x):
+    h = x
+    L = len(d["gamma"])
+    for l in range(L):
+        h = h @ d["W"][l] + d["b"][l]
+        h = torch.tanh((h - h.mean(0)) / torch.sqrt(h.var(0, unbiased=False) + 1e-3) * d["gamma"][l] + d["beta"][l])
+    return h @ d["W"][L] + d["b"][L]
+
+
+def _max_err(ours, theirs):
+    scale = max(float(np.abs(b).max()) for b in theirs)
+    return max(float(np.abs(a - b).max()) for a, b in zip(ours, theirs)) / scale
+
+
+def test_egm_disc_step_double_backward_matches_autograd():
+    from oracle import egm as OE
+    rs = np.random.RandomState(0)
+    nets, dz = _egm_setup(rs)
+    B, q, pdim = 32, 10, 23
+    z, v = rs.randn(B, q), rs.randn(B, pdim)
+    eps = 0.37
+    tdz = {k: [_t(a).requires_grad_() for a in vv] for k, vv in dz.items()}
+    te = [(_t(W), _t(b)) for W, b in nets["e"]]
+    z_ = _fwd(te, _t(v))
+    zhat = (_t(z) * eps + z_ * (1 - eps)).requires_grad_(True)
+    dz_loss = -_tdisc(tdz, _t(z)).mean() + _tdisc(tdz, z_).mean()
+    (gz,) = torch.autograd.grad(_tdisc(tdz, zhat).sum(), zhat, create_graph=True)
+    gp = ((torch.sqrt((gz ** 2).sum(1)) - 1) ** 2).mean()
+    d_loss = dz_loss + 10 * gp
+    plist = tdz["W"] + tdz["b"] + tdz["gamma"] + tdz["beta"]
+    tg = [g.numpy() for g in torch.autograd.grad(d_loss, plist)]
+    l1, l2, gr = OE.disc_step_grads(nets, dz, z, v, eps)
+    assert abs(l1 - dz_loss.item()) < 1e-12 and abs(l2 - d_loss.item()) < 1e-12
+    assert _max_err(OE.disc_param_list(gr), tg) < 1e-12
+    # the penalty alone, on its own batch
+    zh = rs.randn(B, q)
+    tzh = _t(zh).requires_grad_(True)
+    (gz,) = torch.autograd.grad(_tdisc(tdz, tzh).sum(), tzh, create_graph=True)
+    gp = ((torch.sqrt((gz ** 2).sum(1)) - 1) ** 2).mean()
+    tg = [np.zeros(tuple(p_.shape)) if g is None else g.numpy() for g, p_ in zip(torch.autograd.grad(gp, plist, allow_unused=True), plist)]
+    gpo, gr = OE.gradient_penalty_and_grads(dz, zh)
+    assert abs(gpo - gp.item()) < 1e-12 and _max_err(OE.disc_param_list(gr), tg) < 1e-12
+
+
+def test_egm_gen_step_gradients_match_autograd():
+    from oracle import egm as OE
+    rs = np.random.RandomState(1)
+    nets, dz = _egm_setup(rs)
+    B, q, pdim = 32, 10, 23
+    z, v, x, y = rs.randn(B, q), rs.randn(B, pdim), rs.rand(B, 1), rs.randn(B, 1)
+    for binary in (False, True):
+        p = dict(v_dim=pdim, z_dims=[1, 1, 1, 7], binary_treatment=binary, use_z_rec=True, lr=2e-4)
+        xx = (x > 0.5).astype(np.float64) if binary else x
+        tn = {k: _torch_net(nets[k]) for k in nets}
+        tdz = {k: [_t(a) for a in vv] for k, vv in dz.items()}
+        tz, tv, tx, ty = _t(z), _t(v), _t(xx), _t(y)
+        g_z = _fwd(tn["g"], tz)
+        z_ = _fwd(tn["e"], tv)
+        z__ = _fwd(tn["e"], g_z[:, :pdim])
+        v__ = _fwd(tn["g"], z_)[:, :pdim]
+        fo = _fwd(tn["f"], torch.cat([z_[:, :1], z_[:, 1:2], tx], 1))
+        ho = _fwd(tn["h"], torch.cat([z_[:, :1], z_[:, 2:3]], 1))
+        sig = (g_z[:, -1] ** 2).mean() + (fo[:, -1] ** 2).mean() + (ho[:, -1] ** 2).mean()
+        l2x = torch.nn.functional.binary_cross_entropy_with_logits(ho[:, :1], tx) if binary else ((ho[:, :1] - tx) ** 2).mean()
+        loss = (-_tdisc(tdz, z_).mean() + ((tv - v__) ** 2).mean() + ((tz - z__) ** 2).mean() + l2x +
+                ((fo[:, :1] - ty) ** 2).mean() + 0.001 * sig)
+        pl = [a for k in ("g", "e", "f", "h") for Wb in tn[k] for a in Wb]
+        tg = [g.numpy() for g in torch.autograd.grad(loss, pl)]
+        losses, gr = OE.gen_step_grads(nets, dz, p, z, v, xx, y)
+        assert abs(losses[-1] - loss.item()) < 1e-12 and abs(losses[3] - l2x.item()) < 1e-12
+        assert _max_err(OE.gen_param_list(gr), tg) < 1e-12
