@@ -37,6 +37,7 @@ extern "C" int bgm_destroy(bgm_handle *h) {
   if (h->acc_scratch) hipFree(h->acc_scratch);
   bgm_causal_fit_end(h, nullptr);
   bgm_bgm_free_state(h);
+  bgm_egm_free_state(h);
   for (auto &e : h->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   delete h;
   return BGM_OK;

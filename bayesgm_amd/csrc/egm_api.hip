@@ -1,0 +1,203 @@
+// egm_api.hip -- C-ABI entry points of the CausalBGM EGM warm start (include/bgm_hip.h, EGM section).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "bgm_host.h"
+#include "egm_kernels.h"
+
+static constexpr float EGM_B1 = 0.9f, EGM_B2 = 0.99f, EGM_ADAM_EPS = 1e-7f;   // causalbgm/base.py:86-87, Keras epsilon
+
+struct EgmState {
+  bgm_egm_config cfg{};
+  EgmArgs base{};              // network descriptions + device pointers shared by both kernels
+  size_t n_gen = 0, n_dz = 0, ws_floats = 0;
+  int lds_bytes = 0;
+  long long t_g = 0, t_d = 0;  // Adam iteration counters of g_pre_optimizer / d_pre_optimizer
+  float *dev = nullptr;        // one allocation: theta_g|m_g|v_g|grad_g|theta_d|m_d|v_d|grad_d|ws
+};
+
+static EgmState *est(bgm_handle *h) { return static_cast<EgmState *>(h->egm_state); }
+
+void bgm_egm_free_state(bgm_handle *h) {
+  if (!h->egm_state) return;
+  EgmState *s = est(h);
+  if (s->dev) hipFree(s->dev);
+  delete s;
+  h->egm_state = nullptr;
+}
+
+static bool fill_mlp(const HostNet &n, EgmMlp &m, int off) {
+  const int L = (int)n.dims.size() - 1;
+  if (L < 1 || L > EGM_MAX_LAYERS) return false;
+  m.n_layers = L;
+  for (int i = 0; i <= L; ++i) m.dims[i] = n.dims[i];
+  m.off = off;
+  return true;
+}
+
+extern "C" int bgm_causal_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, const float *theta_dz_host, int64_t count,
+                                    void *stream_) {
+  (void)stream_;
+  if (!h || !h->configured) { bgm_set_error("bgm_causal_egm_begin: handle not configured"); return BGM_E_STATE; }
+  if (!cfg || !theta_dz_host) { bgm_set_error("bgm_causal_egm_begin: NULL argument"); return BGM_E_INVALID; }
+  for (int k = 0; k < 4; ++k)
+    if (!h->nets[k].set) { bgm_set_error("bgm_causal_egm_begin: install g, f, h and e with bgm_causal_set_weights first"); return BGM_E_STATE; }
+  if (cfg->batch_size < 2 || cfg->batch_size > 4096) { bgm_set_error("bgm_causal_egm_begin: batch_size must be in [2, 4096]"); return BGM_E_INVALID; }
+  if (cfg->n_hidden_dz < 1 || cfg->n_hidden_dz + 1 > EGM_MAX_LAYERS) { bgm_set_error("bgm_causal_egm_begin: bad dz_units"); return BGM_E_INVALID; }
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  bgm_egm_free_state(h);
+  EgmState *s = new EgmState();
+  h->egm_state = s;
+  s->cfg = *cfg;
+  EgmArgs &a = s->base;
+  const HostNet &G = h->nets[BGM_NET_G], &E = h->nets[BGM_NET_E], &F = h->nets[BGM_NET_F], &H = h->nets[BGM_NET_H];
+  int off = 0;
+  bool ok = fill_mlp(G, a.g, off); off += (int)G.count();
+  ok = ok && fill_mlp(E, a.e, off); off += (int)E.count();
+  ok = ok && fill_mlp(F, a.f, off); off += (int)F.count();
+  ok = ok && fill_mlp(H, a.h, off); off += (int)H.count();
+  if (!ok) { bgm_egm_free_state(h); bgm_set_error("bgm_causal_egm_begin: too many layers"); return BGM_E_UNSUPPORTED; }
+  s->n_gen = (size_t)off;
+  // discriminator layout: W0..WL | b0..bL | gamma0..gamma(L-1) | beta0..beta(L-1)
+  EgmDisc &d = a.dz;
+  const int L = cfg->n_hidden_dz;
+  d.n_hidden = L;
+  d.dims[0] = h->q;
+  for (int l = 0; l < L; ++l) d.dims[l + 1] = cfg->dz_units[l];
+  d.dims[L + 1] = 1;
+  int o = 0;
+  for (int l = 0; l <= L; ++l) { d.w[l] = o; o += d.dims[l] * d.dims[l + 1]; }
+  for (int l = 0; l <= L; ++l) { d.b[l] = o; o += d.dims[l + 1]; }
+  for (int l = 0; l < L; ++l) { d.gamma[l] = o; o += d.dims[l + 1]; }
+  for (int l = 0; l < L; ++l) { d.beta[l] = o; o += d.dims[l + 1]; }
+  d.n_params = o;
+  s->n_dz = (size_t)o;
+  if ((int64_t)o != count) {
+    bgm_egm_free_state(h);
+    bgm_set_error("bgm_causal_egm_begin: expected " + std::to_string(o) + " discriminator parameters, got " + std::to_string(count));
+    return BGM_E_INVALID;
+  }
+  // widest layer / largest staged matrix
+  int wmax = std::max(h->q, h->p + 1);
+  size_t stage = 0;
+  auto scan = [&](const int *dims, int n_layers) {
+    for (int l = 0; l < n_layers; ++l) {
+      wmax = std::max(wmax, std::max(dims[l], dims[l + 1]));
+      stage = std::max(stage, (size_t)dims[l] * (size_t)(dims[l + 1] | 1));
+    }
+  };
+  scan(a.g.dims, a.g.n_layers); scan(a.e.dims, a.e.n_layers); scan(a.f.dims, a.f.n_layers); scan(a.h.dims, a.h.n_layers);
+  scan(d.dims, L + 1);
+  s->lds_bytes = (int)((32 + stage) * sizeof(float));
+  if (s->lds_bytes > 160 * 1024) { bgm_egm_free_state(h); bgm_set_error("bgm_causal_egm_begin: a weight matrix exceeds the LDS stage"); return BGM_E_UNSUPPORTED; }
+  const int B = cfg->batch_size;
+  a.n_gen = (int)s->n_gen; a.B = B; a.q = h->q; a.p = h->p; a.wmax = wmax;
+  a.z0 = h->cfg.z_dims[0]; a.z1 = h->cfg.z_dims[1]; a.z2 = h->cfg.z_dims[2];
+  a.binary = h->cfg.binary_treatment; a.use_z_rec = cfg->use_z_rec;
+  // workspace bound: every buffer of either kernel is [B x width <= wmax]; count them generously
+  size_t acts = 0;
+  auto widths = [&](const int *dims, int n_layers) { size_t t = 0; for (int l = 0; l <= n_layers; ++l) t += dims[l] + 4; return t; };
+  acts += 2 * widths(a.g.dims, a.g.n_layers) + 2 * widths(a.e.dims, a.e.n_layers) + widths(a.f.dims, a.f.n_layers) +
+          widths(a.h.dims, a.h.n_layers) + 3 * 3 * widths(d.dims, L + 1) + 12 * widths(d.dims, L + 1);
+  s->ws_floats = (size_t)B * (acts + 16 * (size_t)wmax + 4 * (size_t)h->p + 64) + s->n_dz + 4096;
+  const size_t total = 4 * s->n_gen + 4 * s->n_dz + s->ws_floats + 64;
+  BGM_HIP_CHECK(hipMalloc(&s->dev, total * sizeof(float)));
+  BGM_HIP_CHECK(hipMemset(s->dev, 0, total * sizeof(float)));
+  float *p = s->dev;
+  auto take = [&](size_t n) { float *r = p; p += (n + 3) / 4 * 4; return r; };
+  a.theta_g = take(s->n_gen); a.m_g = take(s->n_gen); a.v_g = take(s->n_gen); a.grad_g = take(s->n_gen);
+  a.theta_d = take(s->n_dz); a.m_d = take(s->n_dz); a.v_d = take(s->n_dz); a.grad_d = take(s->n_dz);
+  a.ws = take(s->ws_floats);
+  std::vector<float> tg;
+  tg.reserve(s->n_gen);
+  for (const HostNet *n : {&G, &E, &F, &H}) tg.insert(tg.end(), n->theta.begin(), n->theta.end());
+  BGM_HIP_CHECK(hipMemcpy(a.theta_g, tg.data(), tg.size() * sizeof(float), hipMemcpyHostToDevice));
+  BGM_HIP_CHECK(hipMemcpy(a.theta_d, theta_dz_host, s->n_dz * sizeof(float), hipMemcpyHostToDevice));
+  return BGM_OK;
+}
+
+static EgmAdam egm_adam_coeffs(float lr, long long t) {
+  EgmAdam ad;
+  ad.b1 = EGM_B1; ad.b2 = EGM_B2; ad.eps = EGM_ADAM_EPS;
+  ad.lr_t = (float)((double)lr * std::sqrt(1.0 - std::pow((double)EGM_B2, (double)t)) / (1.0 - std::pow((double)EGM_B1, (double)t)));
+  return ad;
+}
+
+extern "C" int bgm_causal_egm_disc_step(bgm_handle *h, const float *z_dev, const int32_t *idx_dev, const float *v_dev, float eps,
+                                        int32_t apply, float *out_dev, void *stream_) {
+  if (!h || !h->egm_state) { bgm_set_error("bgm_causal_egm_disc_step: call bgm_causal_egm_begin first"); return BGM_E_STATE; }
+  if (!z_dev || !idx_dev || !v_dev) { bgm_set_error("bgm_causal_egm_disc_step: NULL pointer"); return BGM_E_INVALID; }
+  EgmState *s = est(h);
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  EgmArgs a = s->base;
+  a.z = z_dev; a.idx = idx_dev; a.v = v_dev; a.x = nullptr; a.y = nullptr; a.eps = eps; a.out = out_dev; a.apply = apply ? 1 : 0;
+  if (apply) s->t_d += 1;
+  a.adam = egm_adam_coeffs(s->cfg.lr, std::max<long long>(1, s->t_d));
+  auto k = egm_disc_step_kernel;
+  BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
+  hipLaunchKernelGGL(k, dim3(1), dim3(EGM_THREADS), s->lds_bytes, (hipStream_t)stream_, a);
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+extern "C" int bgm_causal_egm_gen_step(bgm_handle *h, const float *z_dev, const int32_t *idx_dev, const float *v_dev,
+                                       const float *x_dev, const float *y_dev, int32_t apply, float *out_dev, void *stream_) {
+  if (!h || !h->egm_state) { bgm_set_error("bgm_causal_egm_gen_step: call bgm_causal_egm_begin first"); return BGM_E_STATE; }
+  if (!z_dev || !idx_dev || !v_dev || !x_dev || !y_dev) { bgm_set_error("bgm_causal_egm_gen_step: NULL pointer"); return BGM_E_INVALID; }
+  EgmState *s = est(h);
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  EgmArgs a = s->base;
+  a.z = z_dev; a.idx = idx_dev; a.v = v_dev; a.x = x_dev; a.y = y_dev; a.eps = 0.0f; a.out = out_dev; a.apply = apply ? 1 : 0;
+  if (apply) s->t_g += 1;
+  a.adam = egm_adam_coeffs(s->cfg.lr, std::max<long long>(1, s->t_g));
+  auto k = egm_gen_step_kernel;
+  BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
+  hipLaunchKernelGGL(k, dim3(1), dim3(EGM_THREADS), s->lds_bytes, (hipStream_t)stream_, a);
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+extern "C" int bgm_causal_egm_read(bgm_handle *h, int32_t what, float *host, int64_t count, void *stream_) {
+  if (!h || !h->egm_state || !host) { bgm_set_error("bgm_causal_egm_read: no session / NULL"); return BGM_E_STATE; }
+  EgmState *s = est(h);
+  const float *src = nullptr;
+  size_t n = 0;
+  switch (what) {
+    case 0: src = s->base.theta_g; n = s->n_gen; break;
+    case 1: src = s->base.theta_d; n = s->n_dz; break;
+    case 2: src = s->base.grad_g; n = s->n_gen; break;
+    case 3: src = s->base.grad_d; n = s->n_dz; break;
+    default: bgm_set_error("bgm_causal_egm_read: what must be 0..3"); return BGM_E_INVALID;
+  }
+  if ((size_t)count != n) { bgm_set_error("bgm_causal_egm_read: expected " + std::to_string(n) + " floats"); return BGM_E_INVALID; }
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  BGM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_));
+  BGM_HIP_CHECK(hipMemcpy(host, src, n * sizeof(float), hipMemcpyDeviceToHost));
+  return BGM_OK;
+}
+
+extern "C" int bgm_causal_egm_sync(bgm_handle *h, void *stream_) {
+  if (!h || !h->egm_state) { bgm_set_error("bgm_causal_egm_sync: no session"); return BGM_E_STATE; }
+  EgmState *s = est(h);
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  BGM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_));
+  std::vector<float> tg(s->n_gen);
+  BGM_HIP_CHECK(hipMemcpy(tg.data(), s->base.theta_g, s->n_gen * sizeof(float), hipMemcpyDeviceToHost));
+  size_t off = 0;
+  for (int id : {BGM_NET_G, BGM_NET_E, BGM_NET_F, BGM_NET_H}) {
+    HostNet &n = h->nets[id];
+    std::memcpy(n.theta.data(), tg.data() + off, n.count() * sizeof(float));
+    off += n.count();
+  }
+  h->blob_valid = false; h->eblob_valid = false;
+  return BGM_OK;
+}
+
+extern "C" int bgm_causal_egm_end(bgm_handle *h, void *stream_) {
+  if (!h) return BGM_E_INVALID;
+  if (!h->egm_state) return BGM_OK;
+  int rc = bgm_causal_egm_sync(h, stream_);
+  bgm_egm_free_state(h);
+  return rc;
+}

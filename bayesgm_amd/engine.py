@@ -225,6 +225,48 @@ class CausalEngine(object):
     def fit_end(self):
         _lib.check(self.lib.bgm_causal_fit_end(self.h, self._stream()), "bgm_causal_fit_end")
 
+    # -- EGM warm start (causalbgm/base.py:305-431) -------------------------------
+    @staticmethod
+    def flatten_disc(dz):
+        """{'W','b','gamma','beta'} lists -> flat [W0..WL | b0..bL | gamma.. | beta..] (bgm_hip.h layout)."""
+        return np.concatenate([np.asarray(a, np.float32).ravel() for k in ("W", "b", "gamma", "beta") for a in dz[k]])
+
+    def egm_begin(self, batch_size, dz_units, lr, use_z_rec, dz):
+        """Start a warm-start session from the installed g, e, f, h and the discriminator `dz`."""
+        cfg = _lib.EgmConfig()
+        cfg.batch_size = int(batch_size)
+        cfg.n_hidden_dz = len(dz_units)
+        for i, u in enumerate(dz_units):
+            cfg.dz_units[i] = int(u)
+        cfg.lr = float(lr)
+        cfg.use_z_rec = int(bool(use_z_rec))
+        theta = self.flatten_disc(dz) if isinstance(dz, dict) else np.ascontiguousarray(dz, np.float32)
+        self._egm_counts = None
+        _lib.check(self.lib.bgm_causal_egm_begin(self.h, C.byref(cfg), theta.ctypes.data_as(C.c_void_p), theta.size,
+                                                 self._stream()), "bgm_causal_egm_begin")
+        self._egm_n_dz = theta.size
+
+    def egm_disc_step(self, z, idx, v, eps, apply=True, out=None):
+        _lib.check(self.lib.bgm_causal_egm_disc_step(self.h, _ptr(z), _ptr(idx), _ptr(v), float(eps), int(bool(apply)),
+                                                     _ptr(out), self._stream()), "bgm_causal_egm_disc_step")
+
+    def egm_gen_step(self, z, idx, v, x, y, apply=True, out=None):
+        _lib.check(self.lib.bgm_causal_egm_gen_step(self.h, _ptr(z), _ptr(idx), _ptr(v), _ptr(x), _ptr(y),
+                                                    int(bool(apply)), _ptr(out), self._stream()), "bgm_causal_egm_gen_step")
+
+    def egm_read(self, what, count):
+        """what: 0 generator-side parameters [g|e|f|h], 1 discriminator, 2 / 3 last gen / disc gradients."""
+        buf = np.empty(int(count), np.float32)
+        _lib.check(self.lib.bgm_causal_egm_read(self.h, int(what), buf.ctypes.data_as(C.c_void_p), buf.size, self._stream()),
+                   "bgm_causal_egm_read")
+        return buf
+
+    def egm_sync(self):
+        _lib.check(self.lib.bgm_causal_egm_sync(self.h, self._stream()), "bgm_causal_egm_sync")
+
+    def egm_end(self):
+        _lib.check(self.lib.bgm_causal_egm_end(self.h, self._stream()), "bgm_causal_egm_end")
+
     def clock_probe(self, iters=200000):
         """(shader MHz, fp32-MFMA TFLOP/s) sustained under a pure 16x16x4 fp32 MFMA load."""
         mhz, tf = C.c_double(), C.c_double()

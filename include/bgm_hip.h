@@ -219,6 +219,40 @@ int bgm_causal_get_weights(bgm_handle *h, int net_id, float *theta_host, int64_t
 /* End the fit session (frees the workspace; the trained parameters stay installed). */
 int bgm_causal_fit_end(bgm_handle *h, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * EGM warm start (causalbgm/base.py:305-431): alternating WGAN-GP steps on the latent
+ * discriminator dz_net (networks/base.py:338-385) and on g, e, f, h.  One call = one minibatch
+ * step = one kernel launch (forward, backward incl. the gradient-penalty double backward, Adam).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t batch_size;                            /* rows per step (egm_init batch_size)            */
+  int32_t n_hidden_dz, dz_units[BGM_MAX_LAYERS]; /* params['dz_units']                              */
+  float lr;                                      /* params['lr']: Adam(lr, 0.9, 0.99), base.py:86-87 */
+  int32_t use_z_rec;                             /* params['use_z_rec'], base.py:367                */
+} bgm_egm_config;
+
+/* Start a warm-start session from the networks currently installed with bgm_causal_set_weights (all four:
+ * g, e, f, h).  theta_dz_host: discriminator parameters [W0..WL | b0..bL | gamma0.. | beta0..] (W_l row-major
+ * [in x out], L = n_hidden_dz hidden layers + the scalar output layer). */
+int bgm_causal_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, const float *theta_dz_host, int64_t count,
+                         void *stream);
+/* replaces: train_disc_step, base.py:305-330.  z_dev [B x q] prior sample, idx_dev [B] panel rows,
+ * v_dev [N x p] panel, eps = interpolation coefficient (tf.random.uniform([])).  apply = 0 leaves the
+ * gradient in the session (bgm_causal_egm_read) without the Adam step.  out_dev: [dz_loss, d_loss] or NULL. */
+int bgm_causal_egm_disc_step(bgm_handle *h, const float *z_dev, const int32_t *idx_dev, const float *v_dev, float eps,
+                             int32_t apply, float *out_dev, void *stream);
+/* replaces: train_gen_step, base.py:332-377.  out_dev: [e_loss_adv, l2_loss_v, l2_loss_z, l2_loss_x, l2_loss_y,
+ * g_e_loss] or NULL. */
+int bgm_causal_egm_gen_step(bgm_handle *h, const float *z_dev, const int32_t *idx_dev, const float *v_dev,
+                            const float *x_dev, const float *y_dev, int32_t apply, float *out_dev, void *stream);
+/* Copy session state to the host: what = 0 generator-side parameters [g | e | f | h] (Keras order), 1 discriminator
+ * parameters, 2 / 3 the gradients of the last gen / disc step.  Synchronises the stream. */
+int bgm_causal_egm_read(bgm_handle *h, int32_t what, float *host, int64_t count, void *stream);
+/* Install the session's current g, e, f, h in the handle (as bgm_causal_set_weights would); the session continues. */
+int bgm_causal_egm_sync(bgm_handle *h, void *stream);
+/* bgm_causal_egm_sync + free the session. */
+int bgm_causal_egm_end(bgm_handle *h, void *stream);
+
 /* ==========================================================================================
  * BGM (bgm/base.py): posterior of Z given partially observed rows, HMC, predictive draws.
  * g_net = BaseVariationalNet (networks/base.py:53-117) evaluated with training=False.

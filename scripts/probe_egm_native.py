@@ -1,0 +1,36 @@
+"""Latency of the native EGM steps (one launch each):  python scripts/probe_egm_native.py [p] [iters]"""
+import sys, os, time, json
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from bayesgm_amd.engine import CausalEngine
+from oracle import nets as N, egm as OE   # parameter initialisers only
+
+p = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+z_dims = [1, 1, 1, 7]; q = 10; B = 32; n = 20000
+rs = np.random.RandomState(0)
+nets = {"g": N.init_mlp(rs, [q] + [64] * 5 + [p + 1]), "e": N.init_mlp(rs, [p] + [64] * 5 + [q]),
+        "f": N.init_mlp(rs, [3, 64, 32, 8, 2]), "h": N.init_mlp(rs, [2, 64, 32, 8, 2])}
+dz = OE.init_disc(rs, q, [64, 32, 8])
+eng = CausalEngine(p, z_dims)
+eng.set_model(g=nets["g"], f=nets["f"], h=nets["h"], e=nets["e"])
+eng.egm_begin(B, [64, 32, 8], 2e-4, True, dz)
+v = torch.randn(n, p, device="cuda"); x = torch.rand(n, device="cuda"); y = torch.randn(n, device="cuda")
+zs = torch.randn(iters * 6, B, q, device="cuda")
+idx = torch.randint(0, n, (iters * 6, B), device="cuda", dtype=torch.int32)
+def run(k):
+    for it in range(k):
+        for j in range(5):
+            eng.egm_disc_step(zs[it * 6 + j], idx[it * 6 + j], v, 0.5)
+        eng.egm_gen_step(zs[it * 6 + 5], idx[it * 6 + 5], v, x, y)
+run(10); torch.cuda.synchronize()
+t0 = time.perf_counter(); run(iters); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+t1 = time.perf_counter()
+for it in range(iters): eng.egm_disc_step(zs[it], idx[it], v, 0.5)
+torch.cuda.synchronize(); td = (time.perf_counter() - t1) / iters
+t1 = time.perf_counter()
+for it in range(iters): eng.egm_gen_step(zs[it], idx[it], v, x, y)
+torch.cuda.synchronize(); tg = (time.perf_counter() - t1) / iters
+print(json.dumps(dict(p=p, ms_per_iteration=1e3 * dt / iters, disc_step_us=1e6 * td, gen_step_us=1e6 * tg,
+                      est_30000_iters_s=30000 * dt / iters)))

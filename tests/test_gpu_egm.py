@@ -1,0 +1,125 @@
+"""GPU parity tests of the native EGM warm start (egm_kernels.h) vs the NumPy oracle (oracle/egm.py), whose
+gradients are themselves checked against PyTorch autograd in tests/test_oracle_autograd.py.
+
+Tolerances (fp32 kernels vs float64 oracle): losses 2e-5 relative; gradients 5e-5 of the largest gradient entry
+of the same step; after 5 alternating Adam steps the parameters agree to 2e-5 absolute (lr 2e-4)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import egm as OE      # noqa: E402
+from oracle import nets as N      # noqa: E402
+
+
+def _setup(binary, p=23, z_dims=(1, 1, 1, 7), B=32, n=200, seed=0):
+    import torch
+    from bayesgm_amd.engine import CausalEngine
+    from bayesgm_amd import _lib
+    rs = np.random.RandomState(seed)
+    q = sum(z_dims)
+    g_units, e_units, f_units, h_units, dz_units = [64] * 5, [64] * 5, [64, 32, 8], [64, 32, 8], [64, 32, 8]
+    nets = {"g": N.init_mlp(rs, [q] + g_units + [p + 1]), "e": N.init_mlp(rs, [p] + e_units + [q]),
+            "f": N.init_mlp(rs, [z_dims[0] + z_dims[1] + 1] + f_units + [2]),
+            "h": N.init_mlp(rs, [z_dims[0] + z_dims[2]] + h_units + [2])}
+    for k in nets:
+        nets[k] = [(W, (0.1 * rs.randn(*b.shape)).astype(np.float32)) for W, b in nets[k]]
+    dz = OE.init_disc(rs, q, dz_units)
+    dz["b"] = [(0.1 * rs.randn(*b.shape)).astype(np.float32) for b in dz["b"]]
+    dz["gamma"] = [(1 + 0.2 * rs.randn(*b.shape)).astype(np.float32) for b in dz["gamma"]]
+    dz["beta"] = [(0.1 * rs.randn(*b.shape)).astype(np.float32) for b in dz["beta"]]
+    eng = CausalEngine(p, list(z_dims), binary_treatment=binary, g_units=g_units, f_units=f_units, h_units=h_units,
+                       e_units=e_units)
+    eng.set_model(g=nets["g"], f=nets["f"], h=nets["h"], e=nets["e"])
+    v = rs.randn(n, p).astype(np.float32)
+    x = (rs.rand(n) > 0.5).astype(np.float32) if binary else rs.rand(n).astype(np.float32)
+    y = rs.randn(n).astype(np.float32)
+    params = dict(v_dim=p, z_dims=list(z_dims), binary_treatment=binary, use_z_rec=True, lr=2e-4)
+    dev = dict(v=torch.from_numpy(v).cuda(), x=torch.from_numpy(x).cuda(), y=torch.from_numpy(y).cuda())
+    return eng, nets, dz, params, (x, y, v), dev, rs, dz_units
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.mark.parametrize("case", [dict(binary=False, p=23, z_dims=(1, 1, 1, 7), B=32),
+                                  dict(binary=True, p=200, z_dims=(3, 3, 6, 6), B=32),
+                                  dict(binary=False, p=50, z_dims=(2, 1, 3, 4), B=17)])
+def test_egm_step_gradients_match_oracle(case):
+    import torch
+    B = case["B"]
+    eng, nets, dz, params, (x, y, v), dev, rs, dz_units = _setup(case["binary"], case["p"], case["z_dims"], B)
+    q = sum(case["z_dims"])
+    eng.egm_begin(B, dz_units, params["lr"], True, dz)
+    n_gen = sum(W.size + b.size for k in ("g", "e", "f", "h") for W, b in nets[k])
+    n_dz = CausalEngineFlat(dz).size
+    z = rs.randn(B, q).astype(np.float32)
+    idx = rs.choice(len(x), B, replace=False).astype(np.int32)
+    zd, idd = torch.from_numpy(z).cuda(), torch.from_numpy(idx).cuda()
+    nets64 = {k: N.cast_net(nets[k], np.float64) for k in nets}
+    dz64 = OE.cast_disc(dz, np.float64)
+    # ---- discriminator step
+    out_d = torch.zeros(2, device="cuda")
+    eng.egm_disc_step(zd, idd, dev["v"], 0.37, apply=False, out=out_d)
+    l1, l2, gr = OE.disc_step_grads(nets64, dz64, z.astype(np.float64), v[idx].astype(np.float64), 0.37)
+    ref = np.concatenate([a.ravel() for a in OE.disc_param_list(gr)])
+    got = eng.egm_read(3, n_dz)
+    od = out_d.cpu().numpy()
+    assert abs(od[0] - l1) <= 2e-5 * abs(l1) + 1e-6 and abs(od[1] - l2) <= 2e-5 * abs(l2) + 1e-5
+    assert _rel(got, ref) <= 5e-5, _rel(got, ref)
+    # ---- generator step
+    out_g = torch.zeros(6, device="cuda")
+    eng.egm_gen_step(zd, idd, dev["v"], dev["x"], dev["y"], apply=False, out=out_g)
+    losses, gr = OE.gen_step_grads(nets64, dz64, params, z.astype(np.float64), v[idx].astype(np.float64),
+                                   x[idx].astype(np.float64).reshape(-1, 1), y[idx].astype(np.float64).reshape(-1, 1))
+    ref = np.concatenate([a.ravel() for a in OE.gen_param_list(gr)])
+    got = eng.egm_read(2, n_gen)
+    assert np.all(np.abs(out_g.cpu().numpy() - losses) <= 2e-5 * np.abs(losses) + 1e-6), (out_g.cpu().numpy(), losses)
+    assert _rel(got, ref) <= 5e-5, _rel(got, ref)
+    # apply=False left the parameters alone
+    assert np.array_equal(eng.egm_read(1, n_dz), CausalEngineFlat(dz))
+    eng.egm_end()
+
+
+def CausalEngineFlat(dz):
+    from bayesgm_amd.engine import CausalEngine
+    return CausalEngine.flatten_disc(dz)
+
+
+def test_egm_alternating_adam_steps_track_oracle():
+    import torch
+    B = 32
+    eng, nets, dz, params, (x, y, v), dev, rs, dz_units = _setup(False, 23, (1, 1, 1, 7), B)
+    q = 10
+    eng.egm_begin(B, dz_units, params["lr"], True, dz)
+    st = OE.EgmState({k: N.cast_net(nets[k], np.float64) for k in nets}, OE.cast_disc(dz, np.float64), params)
+    for it in range(5):
+        for _ in range(2):
+            z = rs.randn(B, q).astype(np.float32)
+            idx = rs.choice(len(x), B, replace=False).astype(np.int32)
+            eps = float(rs.rand())
+            eng.egm_disc_step(torch.from_numpy(z).cuda(), torch.from_numpy(idx).cuda(), dev["v"], eps)
+            st.disc_step(z.astype(np.float64), v[idx].astype(np.float64), eps)
+        z = rs.randn(B, q).astype(np.float32)
+        idx = rs.choice(len(x), B, replace=False).astype(np.int32)
+        eng.egm_gen_step(torch.from_numpy(z).cuda(), torch.from_numpy(idx).cuda(), dev["v"], dev["x"], dev["y"])
+        st.gen_step(z.astype(np.float64), v[idx].astype(np.float64), x[idx].astype(np.float64).reshape(-1, 1),
+                    y[idx].astype(np.float64).reshape(-1, 1))
+    ref_g = np.concatenate([a.ravel() for a in OE.gen_param_list(st.nets)])
+    ref_d = np.concatenate([a.ravel() for a in OE.disc_param_list(st.dz)])
+    got_g, got_d = eng.egm_read(0, ref_g.size), eng.egm_read(1, ref_d.size)
+    # The biases of the discriminator's hidden layers sit in front of a BatchNorm: their exact gradient is zero, the
+    # fp32 gradient is rounding noise, and Adam's normalisation turns noise into steps of up to ~lr.  They do not
+    # influence the function; exclude them from the parameter comparison.
+    n_w = sum(a.size for a in st.dz["W"])
+    inert = np.zeros(ref_d.size, bool)
+    inert[n_w:n_w + sum(a.size for a in st.dz["b"][:-1])] = True
+    assert np.abs(got_g - ref_g).max() <= 2e-5 and np.abs(got_d - ref_d)[~inert].max() <= 2e-5
+    assert np.abs(got_d - ref_d)[inert].max() <= 12 * params["lr"]
+    # parameters actually moved (Adam's first steps are ~lr each)
+    assert np.abs(got_g - np.concatenate([a.ravel() for k in ("g", "e", "f", "h") for Wb in nets[k] for a in Wb])).max() > 5e-4
+    # end of session: the trained networks are installed in the handle
+    eng.egm_end()
+    g_tr = eng.get_weights(0, [q] + [64] * 5 + [24])
+    assert np.abs(g_tr[0][0] - st.nets["g"][0][0]).max() <= 2e-5
