@@ -1,18 +1,14 @@
-"""EGM warm start of CausalBGM and BGM -- INTERIM implementation.
+"""EGM warm start of BGM -- INTERIM implementation.
 
-Mirrors /root/reference/src/bayesgm/models/causalbgm/base.py:
-    train_disc_step :305-330   train_gen_step :332-377   egm_init :380-431
-/root/reference/src/bayesgm/models/bgm/base.py:
+Mirrors /root/reference/src/bayesgm/models/bgm/base.py:
     train_disc_step :190-244   train_gen_step :246-289   egm_init :292-340
 and the Discriminator of models/networks/base.py:338-385 (Dense -> BatchNorm(batch statistics) -> tanh).
 
-Unlike the hot path (fit step functions, MCMC, effects -- hand-written HIP behind the C ABI), this
-warm start runs on the GPU through PyTorch autograd: the WGAN-GP discriminator step differentiates a
-gradient norm through BatchNorm batch statistics (a double backward with cross-sample terms) and has
-not been hand-derived into kernels yet.  It is B=32 latency-bound work outside SURVEY section 8's
-a-e rows; the two steps are captured into HIP graphs so that an iteration costs two graph launches.
-The networks it trains are handed to the HIP engine afterwards (Z initialisation = e(V) runs in
-`causal_encode_kernel`).
+CausalBGM's warm start is native (csrc/egm_kernels.h behind bgm_causal_egm_*).  BGM's still runs on the GPU
+through PyTorch autograd: two discriminators (latent and data space, LSGAN targets 0.9 / 0.1, optional gradient
+penalty) against a generator that is itself batch-normalised in training mode.  It is B=32 latency-bound work
+outside SURVEY section 8's a-e rows; both steps are captured into HIP graphs so that an iteration costs two graph
+launches.  The generator it trains is handed to the HIP engine afterwards.
 """
 import numpy as np
 import torch
@@ -68,139 +64,6 @@ class _KerasAdam(object):
 def _glorot(rs, fan_in, fan_out):
     lim = np.sqrt(6.0 / (fan_in + fan_out))
     return rs.uniform(-lim, lim, size=(fan_in, fan_out)).astype(np.float32)
-
-
-class CausalEGM(object):
-    """State of the EGM warm start: torch views of g, e, f, h plus the latent discriminator dz."""
-
-    def __init__(self, nets, params, device, rs, batch_size=32, use_graphs=True):
-        self.p = params
-        self.dev = device
-        self.B = batch_size
-        t = lambda a: torch.tensor(np.asarray(a, np.float32), device=device)
-        self.nets = {k: [(t(W), t(b)) for W, b in nets[k]] for k in ("g", "e", "f", "h")}
-        q = sum(params["z_dims"])
-        dims = [q] + list(params["dz_units"]) + [1]
-        self.dz = {"W": [t(_glorot(rs, dims[i], dims[i + 1])) for i in range(len(dims) - 1)],
-                   "b": [torch.zeros(dims[i + 1], device=device) for i in range(len(dims) - 1)],
-                   "gamma": [torch.ones(dims[i + 1], device=device) for i in range(len(dims) - 2)],
-                   "beta": [torch.zeros(dims[i + 1], device=device) for i in range(len(dims) - 2)]}
-        self.gen_params = [a for k in ("g", "e", "f", "h") for Wb in self.nets[k] for a in Wb]
-        self.disc_params = self.dz["W"] + self.dz["b"] + self.dz["gamma"] + self.dz["beta"]
-        for a in self.gen_params + self.disc_params:
-            a.requires_grad_(True)
-        self.g_opt = _KerasAdam(self.gen_params, params["lr"])
-        self.d_opt = _KerasAdam(self.disc_params, params["lr"])
-        # static input buffers (graph capture)
-        pdim = params["v_dim"]
-        self.in_z = torch.zeros(batch_size, q, device=device)
-        self.in_v = torch.zeros(batch_size, pdim, device=device)
-        self.in_x = torch.zeros(batch_size, 1, device=device)
-        self.in_y = torch.zeros(batch_size, 1, device=device)
-        self.in_eps = torch.zeros((), device=device)
-        self.out_d = torch.zeros(2, device=device)
-        self.out_g = torch.zeros(6, device=device)
-        self._graph_d = self._graph_g = None
-        self.use_graphs = use_graphs
-
-    # ---- the two step functions ---------------------------------------------------------------
-    def _disc_step(self):
-        """train_disc_step, causalbgm/base.py:305-330."""
-        z, v, eps = self.in_z, self.in_v, self.in_eps
-        with torch.no_grad():
-            z_ = _mlp(self.nets["e"], v)
-        z_hat = (z * eps + z_ * (1 - eps)).requires_grad_(True)
-        d_hat = _disc(self.dz, z_hat)
-        d_ = _disc(self.dz, z_)
-        d = _disc(self.dz, z)
-        dz_loss = -d.mean() + d_.mean()
-        (grad_z,) = torch.autograd.grad(d_hat.sum(), z_hat, create_graph=True)
-        gp = ((torch.sqrt((grad_z ** 2).sum(dim=1)) - 1.0) ** 2).mean()
-        d_loss = dz_loss + 10 * gp
-        grads = torch.autograd.grad(d_loss, self.disc_params)
-        with torch.no_grad():
-            self.d_opt.step(grads)
-            self.out_d[0] = dz_loss
-            self.out_d[1] = d_loss
-
-    def _gen_step(self):
-        """train_gen_step, causalbgm/base.py:332-377."""
-        p = self.p
-        z, v, x, y = self.in_z, self.in_v, self.in_x, self.in_y
-        pdim = p["v_dim"]
-        z0d, z1d, z2d, _ = p["z_dims"]
-        g_z = _mlp(self.nets["g"], z)
-        v_ = g_z[:, :pdim]
-        sig_loss = (g_z[:, -1] ** 2).mean()
-        z_ = _mlp(self.nets["e"], v)
-        z0, z1, z2 = z_[:, :z0d], z_[:, z0d:z0d + z1d], z_[:, z0d + z1d:z0d + z1d + z2d]
-        z__ = _mlp(self.nets["e"], v_)
-        v__ = _mlp(self.nets["g"], z_)[:, :pdim]
-        d_ = _disc(self.dz, z_)
-        l2_v = ((v - v__) ** 2).mean()
-        l2_z = ((z - z__) ** 2).mean()
-        e_adv = -d_.mean()
-        f_out = _mlp(self.nets["f"], torch.cat([z0, z1, x], dim=1))
-        y_ = f_out[:, :1]
-        sig_loss = sig_loss + (f_out[:, -1] ** 2).mean()
-        h_out = _mlp(self.nets["h"], torch.cat([z0, z2], dim=1))
-        x_ = h_out[:, :1]
-        sig_loss = sig_loss + (h_out[:, -1] ** 2).mean()
-        if p["binary_treatment"]:
-            l2_x = torch.nn.functional.binary_cross_entropy_with_logits(x_, x)
-        else:
-            l2_x = ((x_ - x) ** 2).mean()
-        l2_y = ((y_ - y) ** 2).mean()
-        loss = e_adv + (l2_v + float(p["use_z_rec"]) * l2_z) + (l2_x + l2_y) + 0.001 * sig_loss
-        grads = torch.autograd.grad(loss, self.gen_params)
-        with torch.no_grad():
-            self.g_opt.step(grads)
-            self.out_g.copy_(torch.stack([e_adv, l2_v, l2_z, l2_x, l2_y, loss]).detach())
-
-    def capture(self):
-        """Capture both steps into HIP graphs (static B).  The standard recipe needs a few eager warm-up
-        iterations on a side stream; they are run on throw-away copies of the state."""
-        saved = [a.detach().clone() for a in self.gen_params + self.disc_params]
-        opt_saved = [[t_.clone() for t_ in o.m + o.v] + [o.t.clone()] for o in (self.g_opt, self.d_opt)]
-        s = torch.cuda.Stream(device=self.dev)
-        s.wait_stream(torch.cuda.current_stream(self.dev))
-        with torch.cuda.stream(s):
-            for _ in range(3):
-                self._disc_step()
-                self._gen_step()
-        torch.cuda.current_stream(self.dev).wait_stream(s)
-        gd, gg = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gd):
-            self._disc_step()
-        with torch.cuda.graph(gg):
-            self._gen_step()
-        with torch.no_grad():       # restore the pre-warm-up state (capture itself executes nothing)
-            for a, b in zip(self.gen_params + self.disc_params, saved):
-                a.copy_(b)
-            for o, sv in zip((self.g_opt, self.d_opt), opt_saved):
-                for t_, b in zip(o.m + o.v, sv[:-1]):
-                    t_.copy_(b)
-                o.t.copy_(sv[-1])
-        self._graph_d, self._graph_g = gd, gg
-
-    def disc_step(self, z, v, eps):
-        self.in_z.copy_(z); self.in_v.copy_(v); self.in_eps.fill_(float(eps))
-        if self._graph_d is not None:
-            self._graph_d.replay()
-        else:
-            self._disc_step()
-
-    def gen_step(self, z, v, x, y):
-        self.in_z.copy_(z); self.in_v.copy_(v); self.in_x.copy_(x); self.in_y.copy_(y)
-        if self._graph_g is not None:
-            self._graph_g.replay()
-        else:
-            self._gen_step()
-
-    def export(self):
-        """Trained g, e, f, h as host [(W, b), ...] lists (Keras order) for the HIP engine."""
-        return {k: [(W.detach().cpu().numpy().copy(), b.detach().cpu().numpy().copy()) for W, b in self.nets[k]]
-                for k in ("g", "e", "f", "h")}
 
 
 # =====================================================================================================

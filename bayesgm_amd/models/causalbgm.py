@@ -122,41 +122,69 @@ class CausalBGM(object):
                 return idx
 
     def egm_init(self, data, egm_n_iter=30000, batch_size=32, egm_batches_per_eval=500, verbose=1):
-        """EGM warm start (base.py:380-431).  INTERIM: runs on the GPU through PyTorch autograd
-        (bayesgm_amd/egm.py), not yet as hand-written kernels; see that module's docstring."""
-        from ..egm import CausalEGM
+        """EGM warm start (base.py:380-431): g_d_freq WGAN-GP steps on the latent discriminator dz_net, then one
+        step on g, e, f, h, per iteration.  Every step is one launch of the hand-written kernels of
+        csrc/egm_kernels.h (forward, backward incl. the gradient-penalty double backward through the
+        BatchNorm'd discriminator, Keras Adam).  The host draws the minibatch indices, the prior samples and the
+        interpolation coefficients in the reference's order, one evaluation period at a time."""
         data_x, data_y, data_v = data
         n = len(data_x)
-        dev = self.engine.device
-        xd, yd, vd = self._dev(data_x).reshape(-1, 1), self._dev(data_y).reshape(-1, 1), self._dev(data_v)
-        egm = CausalEGM(self.nets, self._p, dev, self._rs, batch_size)
-        try:
-            egm.capture()
-        except Exception as e:   # graph capture is an optimisation only
-            if verbose:
-                print("EGM: HIP-graph capture unavailable (%s); running eagerly" % type(e).__name__)
+        eng = self.engine
+        dev = eng.device
+        p_ = self._p
+        xd, yd, vd = self._dev(data_x).reshape(-1), self._dev(data_y).reshape(-1), self._dev(data_v)
+        q = sum(p_["z_dims"])
+        dims = [q] + list(p_["dz_units"]) + [1]
+        dz = {"W": [_glorot(self._rs, dims[i], dims[i + 1]) for i in range(len(dims) - 1)],       # networks/base.py:338-363
+              "b": [np.zeros(dims[i + 1], np.float32) for i in range(len(dims) - 1)],
+              "gamma": [np.ones(dims[i + 1], np.float32) for i in range(len(dims) - 2)],
+              "beta": [np.zeros(dims[i + 1], np.float32) for i in range(len(dims) - 2)]}
+        self._push_weights()
+        eng.egm_begin(batch_size, p_["dz_units"], p_["lr"], p_["use_z_rec"], dz)
+        out_d = torch.zeros(2, device=dev)
+        out_g = torch.zeros(6, device=dev)
         if verbose:
             print('EGM Initialization Starts ...')
-        g_d_freq = int(self._p['g_d_freq'])
-        for batch_iter in range(egm_n_iter + 1):
-            for _ in range(g_d_freq):
-                idx = torch.from_numpy(self._choice_no_replace(n, batch_size)).to(dev)
-                bz = torch.from_numpy(self.z_sampler.get_batch(batch_size)).to(dev)
-                egm.disc_step(bz, vd[idx], np.random.uniform(0.0, 1.0))
-            bz = torch.from_numpy(self.z_sampler.get_batch(batch_size)).to(dev)
-            idx = torch.from_numpy(self._choice_no_replace(n, batch_size)).to(dev)
-            egm.gen_step(bz, vd[idx], xd[idx], yd[idx])
-            if batch_iter % egm_batches_per_eval == 0:
-                self.set_weights(**egm.export())
-                if verbose:
-                    lg, ld = egm.out_g.cpu().numpy(), egm.out_d.cpu().numpy()
-                    print('EGM Initialization Iter [%d] : e_loss_adv [%.4f], l2_loss_v [%.4f], l2_loss_z [%.4f], '
-                          'l2_loss_x [%.4f], l2_loss_y [%.4f], g_e_loss [%.4f], dz_loss [%.4f], d_loss [%.4f]'
-                          % (batch_iter, lg[0], lg[1], lg[2], lg[3], lg[4], lg[5], ld[0], ld[1]))
-                causal_pre, mse_x, mse_y, mse_v = self.evaluate(data=data)
-                if self._p['save_res'] and parallel.rank() == 0:
-                    save_data('{}/causal_pre_egm_init_iter-{}.txt'.format(self.save_dir, batch_iter), causal_pre)
-        self.set_weights(**egm.export())
+        g_d_freq = int(p_['g_d_freq'])
+        steps = g_d_freq + 1
+        try:
+            batch_iter = 0
+            while batch_iter <= egm_n_iter:
+                # iterations up to and including the next evaluation point
+                stop = min(egm_n_iter, (batch_iter // egm_batches_per_eval + 1) * egm_batches_per_eval
+                           if batch_iter % egm_batches_per_eval else batch_iter)
+                n_it = stop - batch_iter + 1
+                idx_h = np.empty((n_it, steps, batch_size), np.int32)
+                z_h = np.empty((n_it, steps, batch_size, q), np.float32)
+                eps_h = np.empty((n_it, g_d_freq), np.float64)
+                for i in range(n_it):                       # host RNG consumed in the reference's order
+                    for j in range(g_d_freq):
+                        idx_h[i, j] = self._choice_no_replace(n, batch_size)
+                        z_h[i, j] = self.z_sampler.get_batch(batch_size)
+                        eps_h[i, j] = np.random.uniform(0.0, 1.0)
+                    z_h[i, g_d_freq] = self.z_sampler.get_batch(batch_size)
+                    idx_h[i, g_d_freq] = self._choice_no_replace(n, batch_size)
+                idx_d, z_d = torch.from_numpy(idx_h).to(dev), torch.from_numpy(z_h).to(dev)
+                for i in range(n_it):
+                    for j in range(g_d_freq):
+                        eng.egm_disc_step(z_d[i, j], idx_d[i, j], vd, eps_h[i, j], out=out_d)
+                    eng.egm_gen_step(z_d[i, g_d_freq], idx_d[i, g_d_freq], vd, xd, yd, out=out_g)
+                batch_iter = stop
+                if batch_iter % egm_batches_per_eval == 0:
+                    eng.egm_sync()
+                    self._pull_weights(("g", "f", "h", "e"))
+                    if verbose:
+                        lg, ld = out_g.cpu().numpy(), out_d.cpu().numpy()
+                        print('EGM Initialization Iter [%d] : e_loss_adv [%.4f], l2_loss_v [%.4f], l2_loss_z [%.4f], '
+                              'l2_loss_x [%.4f], l2_loss_y [%.4f], g_e_loss [%.4f], dz_loss [%.4f], d_loss [%.4f]'
+                              % (batch_iter, lg[0], lg[1], lg[2], lg[3], lg[4], lg[5], ld[0], ld[1]))
+                    causal_pre, mse_x, mse_y, mse_v = self.evaluate(data=data)
+                    if self._p['save_res'] and parallel.rank() == 0:
+                        save_data('{}/causal_pre_egm_init_iter-{}.txt'.format(self.save_dir, batch_iter), causal_pre)
+                batch_iter += 1
+        finally:
+            eng.egm_end()
+            self._pull_weights(("g", "f", "h", "e"))
         if verbose:
             print('EGM Initialization Ends.')
 

@@ -4,15 +4,22 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from bayesgm_amd.engine import CausalEngine
-from oracle import nets as N, egm as OE   # parameter initialisers only
+
+def _glorot(rs, a, b):
+    l = np.sqrt(6.0 / (a + b)); return rs.uniform(-l, l, (a, b)).astype(np.float32)
+def _mlp(rs, dims):
+    return [(_glorot(rs, dims[i], dims[i + 1]), np.zeros(dims[i + 1], np.float32)) for i in range(len(dims) - 1)]
+def _disc(rs, dims):
+    return {"W": [_glorot(rs, dims[i], dims[i + 1]) for i in range(len(dims) - 1)], "b": [np.zeros(d, np.float32) for d in dims[1:]],
+            "gamma": [np.ones(d, np.float32) for d in dims[1:-1]], "beta": [np.zeros(d, np.float32) for d in dims[1:-1]]}
 
 p = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 z_dims = [1, 1, 1, 7]; q = 10; B = 32; n = 20000
 rs = np.random.RandomState(0)
-nets = {"g": N.init_mlp(rs, [q] + [64] * 5 + [p + 1]), "e": N.init_mlp(rs, [p] + [64] * 5 + [q]),
-        "f": N.init_mlp(rs, [3, 64, 32, 8, 2]), "h": N.init_mlp(rs, [2, 64, 32, 8, 2])}
-dz = OE.init_disc(rs, q, [64, 32, 8])
+nets = {"g": _mlp(rs, [q] + [64] * 5 + [p + 1]), "e": _mlp(rs, [p] + [64] * 5 + [q]),
+        "f": _mlp(rs, [3, 64, 32, 8, 2]), "h": _mlp(rs, [2, 64, 32, 8, 2])}
+dz = _disc(rs, [q, 64, 32, 8, 1])
 eng = CausalEngine(p, z_dims)
 eng.set_model(g=nets["g"], f=nets["f"], h=nets["h"], e=nets["e"])
 eng.egm_begin(B, [64, 32, 8], 2e-4, True, dz)

@@ -170,7 +170,7 @@ def test_causalbgm_fit_predict_end_to_end(tmp_path):
 
 
 def test_causalbgm_default_fit_with_egm_warm_start(tmp_path):
-    """fit() with its default use_egm_init=True: the (interim, torch-autograd) EGM warm start trains g,e,f,h,
+    """fit() with its default use_egm_init=True: the native EGM warm start (egm_kernels.h) trains g,e,f,h,
     Z is initialised as e(V) by the HIP encoder, and the iterative updates continue from there."""
     from bayesgm_amd.models import CausalBGM
     from bayesgm_amd.datasets import Sim_Hirano_Imbens_sampler
