@@ -1,6 +1,7 @@
 // egm_api.hip -- C-ABI entry points of the CausalBGM EGM warm start (include/bgm_hip.h, EGM section).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "bgm_host.h"
@@ -89,9 +90,18 @@ extern "C" int bgm_causal_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, co
   };
   scan(a.g.dims, a.g.n_layers); scan(a.e.dims, a.e.n_layers); scan(a.f.dims, a.f.n_layers); scan(a.h.dims, a.h.n_layers);
   scan(d.dims, L + 1);
-  s->lds_bytes = (int)((32 + stage) * sizeof(float));
-  if (s->lds_bytes > 160 * 1024) { bgm_egm_free_state(h); bgm_set_error("bgm_causal_egm_begin: a weight matrix exceeds the LDS stage"); return BGM_E_UNSUPPORTED; }
+  (void)stage;
   const int B = cfg->batch_size;
+  int dmax = 0, dsum = 0, dall = 0;
+  for (int l = 0; l <= L; ++l) { dmax = std::max(dmax, d.dims[l]); dall += d.dims[l]; }
+  for (int l = 1; l <= L; ++l) dsum += d.dims[l];
+  a.dmax = dmax;
+  // discriminator working set of the disc step (egm_disc_step_kernel): cache A | max(cache B + da + du, GP scratch)
+  const size_t cache = ((size_t)(2 * B + 1) * dsum + B + 3) / 4 * 4;
+  const size_t gp = ((size_t)B * dall + (size_t)(5 * B + 1) * dsum + 3) / 4 * 4 + 3 * (size_t)B * dmax;
+  const size_t arena = cache + std::max(cache + 2 * (size_t)B * dmax, gp);
+  a.disc_lds = (64 + arena) * sizeof(float) <= 160 * 1024 ? 1 : 0;
+  s->lds_bytes = (int)((64 + (a.disc_lds ? arena : 0)) * sizeof(float));
   a.n_gen = (int)s->n_gen; a.B = B; a.q = h->q; a.p = h->p; a.wmax = wmax;
   a.z0 = h->cfg.z_dims[0]; a.z1 = h->cfg.z_dims[1]; a.z2 = h->cfg.z_dims[2];
   a.binary = h->cfg.binary_treatment; a.use_z_rec = cfg->use_z_rec;
@@ -100,7 +110,7 @@ extern "C" int bgm_causal_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, co
   auto widths = [&](const int *dims, int n_layers) { size_t t = 0; for (int l = 0; l <= n_layers; ++l) t += dims[l] + 4; return t; };
   acts += 2 * widths(a.g.dims, a.g.n_layers) + 2 * widths(a.e.dims, a.e.n_layers) + widths(a.f.dims, a.f.n_layers) +
           widths(a.h.dims, a.h.n_layers) + 3 * 3 * widths(d.dims, L + 1) + 12 * widths(d.dims, L + 1);
-  s->ws_floats = (size_t)B * (acts + 16 * (size_t)wmax + 4 * (size_t)h->p + 64) + s->n_dz + 4096;
+  s->ws_floats = (size_t)B * (acts + 16 * (size_t)wmax + 4 * (size_t)h->p + 64) + s->n_dz + arena + 4096;
   const size_t total = 4 * s->n_gen + 4 * s->n_dz + s->ws_floats + 64;
   BGM_HIP_CHECK(hipMalloc(&s->dev, total * sizeof(float)));
   BGM_HIP_CHECK(hipMemset(s->dev, 0, total * sizeof(float)));

@@ -8,15 +8,16 @@
 // These are B = 32 minibatch steps: ~10 MFLOP each, 180 000 of them per default fit.  The work is
 // latency, not throughput: one step = ONE launch of ONE 1024-thread workgroup that walks the whole
 // forward / backward / (double-backward) / Adam sequence with workgroup barriers between the tiny
-// dense ops; every weight matrix is staged through LDS once per use (odd row stride, so the forward
-// W[i][o] and the transposed W^T accesses are both conflict-free), activations live in an L2-resident
-// workspace.  No MFMA: at B = 32 the matrix pipe would idle on the barriers anyway.
+// dense ops.  Each dense op is a handful of 16x16 fp32-MFMA tiles dealt to the 16 waves, operands read
+// straight from the L1/L2-resident parameter arrays and activation workspace (see egm_gemm_tiles).
 // All gradient formulas are the hand-derived ones of oracle/egm.py (checked there against autograd);
 // the gradient penalty needs reverse mode through the backward pass of a batch-normalised network.
 #pragma once
 #include <hip/hip_runtime.h>
 
-#define EGM_THREADS 1024
+#include "bgm_device.h"
+
+#define EGM_THREADS 512
 #define EGM_MAX_LAYERS 8
 #define EGM_LEAK 0.2f
 #define EGM_BN_EPS 1e-3f
@@ -41,6 +42,7 @@ struct EgmArgs {
   float *theta_d, *m_d, *v_d, *grad_d;   // discriminator parameters
   int n_gen, B, q, p;
   int wmax;                              // widest layer of any network (scratch row width)
+  int dmax;                              // widest discriminator layer incl. its input
   int z0, z1, z2;                        // z_dims[0..2]
   int binary, use_z_rec;
   const float *z;                        // [B x q] prior sample of this step
@@ -51,71 +53,120 @@ struct EgmArgs {
   float *ws;                             // workspace
   float *out;                            // disc: [dz_loss, d_loss]   gen: [e_adv, l2_v, l2_z, l2_x, l2_y, total]
   int apply;                             // 1: Adam step; 0: leave the gradients in grad_* (parity tests)
+  int disc_lds;                          // 1: the discriminator working set of the step lives in LDS (it fits)
 };
 
 struct EgmCtx {
   int tid;
-  float *lds;      // weight stage
   float *red;      // [32] reduction scratch (LDS)
 };
 
-__device__ __forceinline__ int egm_ldw(int out) { return out | 1; }
+// ---------------------------------------------------------------------------------------------
+// Tiny GEMMs on the matrix pipe.  C[M x N] = A[M x K] B[K x N] with arbitrary element strides, one
+// 16x16 output tile per wave and round, K in steps of 4 on v_mfma_f32_16x16x4_f32 (exact fp32 fma
+// chain).  Lane (j = lane & 15, g = lane >> 4) feeds A(m0 + j, 4s + g) and B(4s + g, n0 + j) and
+// receives C(m0 + 4g + r, n0 + j) in accumulator register r.  Operands come straight from the
+// L1/L2-resident workspace and parameter arrays: two loads per 1024 multiply-adds.  (The first,
+// scalar version of these kernels issued two loads per multiply-add and was bound by the vector
+// memory pipe of its single CU: 1.2 ms per generator step.)
+// ---------------------------------------------------------------------------------------------
+struct EgmMat { const float *p; int s0, s1; };   // element (i, j) at p[i * s0 + j * s1]
 
-// stage W [in x out] (row-major, Keras) into LDS with an odd row stride
-__device__ __forceinline__ void egm_stage(const EgmCtx &c, const float *W, int in, int out) {
-  const int ld = egm_ldw(out);
-  for (int k = c.tid; k < in * out; k += EGM_THREADS) {
-    const int i = k / out, o = k - i * out;
-    c.lds[i * ld + o] = W[k];
+template <class Epi>
+__device__ __forceinline__ void egm_gemm_tiles(const EgmCtx &c, EgmMat A, EgmMat Bm, int M, int N, int K, int tile_begin,
+                                               int tile_stride, Epi epi) {
+  const int lane = c.tid & 63, j = lane & 15, g = lane >> 4;
+  const int tn_count = (N + 15) >> 4, tiles = ((M + 15) >> 4) * tn_count;
+  for (int t = tile_begin; t < tiles; t += tile_stride) {
+    const int m0 = (t / tn_count) << 4, n0 = (t % tn_count) << 4;
+    // Loads are unconditional (indices clamped into the matrix, contributions masked to zero).
+    const float am = (m0 + j < M) ? 1.0f : 0.0f, bn = (n0 + j < N) ? 1.0f : 0.0f;
+    const float *ap = A.p + (long long)min(m0 + j, M - 1) * A.s0, *bp = Bm.p + (long long)min(n0 + j, N - 1) * Bm.s1;
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    // K in chunks of 16 steps: all 32 operand loads of a chunk are in flight before its first MFMA.
+    for (int k0 = 0; k0 < K; k0 += 64) {
+      float av[16], bv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int k = k0 + 4 * u + g;
+        const int kc = min(k, K - 1);
+        av[u] = ap[kc * A.s1] * ((k < K) ? am : 0.0f);
+        bv[u] = bp[kc * Bm.s0];
+      }
+      BGM_NO_HOIST();
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc = BGM_MFMA(av[u], bv[u] * bn, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + 4 * g + r, n = n0 + j;
+      if (m < M && n < N) epi(m, n, acc[r]);
+    }
   }
-  __syncthreads();
 }
 
-// Y = X W + bias  (optionally LeakyReLU);  W staged
+// Y = X W + bias  (optionally LeakyReLU)
 __device__ __forceinline__ void egm_fwd(const EgmCtx &c, const float *X, int ldx, const float *W, const float *bias, float *Y,
                                         int ldy, int B, int in, int out, bool act) {
-  egm_stage(c, W, in, out);
-  const int ld = egm_ldw(out);
-  for (int k = c.tid; k < B * out; k += EGM_THREADS) {
-    const int b = k / out, o = k - b * out;
-    float acc = bias ? bias[o] : 0.0f;
-    const float *xr = X + (long long)b * ldx;
-    for (int i = 0; i < in; ++i) acc = fmaf(xr[i], c.lds[i * ld + o], acc);
-    if (act) acc = fmaxf(acc, EGM_LEAK * acc);
-    Y[(long long)b * ldy + o] = acc;
-  }
+  egm_gemm_tiles(c, EgmMat{X, ldx, 1}, EgmMat{W, out, 1}, B, out, in, c.tid >> 6, EGM_THREADS / 64,
+                 [&](int m, int n, float v) {
+                   v += bias ? bias[n] : 0.0f;
+                   if (act) v = fmaxf(v, EGM_LEAK * v);
+                   Y[(long long)m * ldy + n] = v;
+                 });
   __syncthreads();
 }
 // dX (+)= dY W^T
 __device__ __forceinline__ void egm_bwd_in(const EgmCtx &c, const float *dY, int ldy, const float *W, float *dX, int ldx, int B,
                                            int in, int out, bool accumulate) {
-  egm_stage(c, W, in, out);
-  const int ld = egm_ldw(out);
-  for (int k = c.tid; k < B * in; k += EGM_THREADS) {
-    const int b = k / in, i = k - b * in;
-    float acc = 0.0f;
-    const float *dr = dY + (long long)b * ldy;
-    for (int o = 0; o < out; ++o) acc = fmaf(dr[o], c.lds[i * ld + o], acc);
-    float *dst = dX + (long long)b * ldx + i;
-    *dst = accumulate ? *dst + acc : acc;
-  }
+  egm_gemm_tiles(c, EgmMat{dY, ldy, 1}, EgmMat{W, 1, out}, B, in, out, c.tid >> 6, EGM_THREADS / 64,
+                 [&](int m, int n, float v) {
+                   float *dst = dX + (long long)m * ldx + n;
+                   *dst = accumulate ? *dst + v : v;
+                 });
   __syncthreads();
+}
+__device__ __forceinline__ void egm_colsum(const EgmCtx &c, const float *dY, int ldy, float *gb, int B, int out, bool accumulate,
+                                           float s) {
+  for (int o = c.tid; o < out; o += EGM_THREADS) {
+    float acc = 0.0f;
+    for (int b = 0; b < B; ++b) acc += dY[(long long)b * ldy + o];
+    gb[o] = accumulate ? gb[o] + s * acc : s * acc;
+  }
 }
 // gW (+)= s * X^T dY ;  gb (+)= s * column sums of dY
 __device__ __forceinline__ void egm_bwd_w(const EgmCtx &c, const float *X, int ldx, const float *dY, int ldy, float *gW, float *gb,
                                           int B, int in, int out, bool accumulate, float s = 1.0f) {
-  for (int k = c.tid; k < in * out + out; k += EGM_THREADS) {
-    float acc = 0.0f;
-    if (k < in * out) {
-      const int i = k / out, o = k - i * out;
-      for (int b = 0; b < B; ++b) acc = fmaf(X[(long long)b * ldx + i], dY[(long long)b * ldy + o], acc);
-      gW[k] = accumulate ? gW[k] + s * acc : s * acc;
-    } else if (gb) {
-      const int o = k - in * out;
-      for (int b = 0; b < B; ++b) acc += dY[(long long)b * ldy + o];
-      gb[o] = accumulate ? gb[o] + s * acc : s * acc;
-    }
+  egm_gemm_tiles(c, EgmMat{X, 1, ldx}, EgmMat{dY, ldy, 1}, in, out, B, c.tid >> 6, EGM_THREADS / 64,
+                 [&](int m, int n, float v) {
+                   float *dst = gW + (long long)m * out + n;
+                   *dst = accumulate ? *dst + s * v : s * v;
+                 });
+  if (gb) egm_colsum(c, dY, ldy, gb, B, out, accumulate, s);
+  __syncthreads();
+}
+// One backward phase of a Dense layer: gW, gb (+)= X^T dY, sums of dY;  dX = (dY W^T) * lrelu'(X) when `mask`
+// (X is the LeakyReLU output of the layer below, so dX is that layer's PRE-activation gradient), all behind one
+// barrier: the weight-gradient tiles and the input-gradient tiles are dealt to the waves together.  dX may be NULL.
+__device__ __forceinline__ void egm_bwd_layer(const EgmCtx &c, const float *X, const float *dY, const float *W, float *gW, float *gb,
+                                              float *dX, int B, int in, int out, bool accumulate, bool mask) {
+  const int nw = EGM_THREADS / 64, wave = c.tid >> 6;
+  const int t_w = ((in + 15) >> 4) * ((out + 15) >> 4);
+  egm_gemm_tiles(c, EgmMat{X, 1, in}, EgmMat{dY, out, 1}, in, out, B, wave, nw,
+                 [&](int m, int n, float v) {
+                   float *dst = gW + (long long)m * out + n;
+                   *dst = accumulate ? *dst + v : v;
+                 });
+  if (dX) {
+    const int first = (wave - t_w % nw + nw) % nw;      // continue the round-robin deal after the last dW tile
+    egm_gemm_tiles(c, EgmMat{dY, out, 1}, EgmMat{W, 1, out}, B, in, out, first, nw,
+                   [&](int m, int n, float v) {
+                     const long long t = (long long)m * in + n;
+                     if (mask) v *= (X[t] > 0.0f) ? 1.0f : EGM_LEAK;
+                     dX[t] = v;
+                   });
   }
+  egm_colsum(c, dY, out, gb, B, out, accumulate, 1.0f);
   __syncthreads();
 }
 // workgroup sum (every thread gets the result)
@@ -132,7 +183,17 @@ __device__ __forceinline__ float egm_block_sum(const EgmCtx &c, float v) {
 // ---------------------------------------------------------------------------------------------
 // MLP forward (activations kept) / backward
 // ---------------------------------------------------------------------------------------------
-struct EgmMlpCache { float *act[EGM_MAX_LAYERS + 1]; };   // act[0] = input, act[L] = output; act[l] is [B x dims[l]]
+// Activation cache of one MLP call: layer l's output [B x dims[l]] (l >= 1) lives at base + B * (dims[1] + ... +
+// dims[l-1]); l = 0 is the caller's input.  Pointers are COMPUTED (scalar ALU on kernel-argument dims): arrays of
+// pointers indexed by a runtime layer number live in scratch memory and put a private-memory round trip at the
+// head of every phase.
+struct EgmMlpCache { float *in, *base; };
+__device__ __forceinline__ float *egm_act(const EgmMlp &n, const EgmMlpCache &a, int l, int B) {
+  if (l == 0) return a.in;
+  int o = 0;
+  for (int k = 1; k < l; ++k) o += n.dims[k];
+  return a.base + (long long)B * o;
+}
 
 __device__ __forceinline__ const float *egm_W(const float *theta, const EgmMlp &n, int l) {
   int o = n.off;
@@ -142,7 +203,7 @@ __device__ __forceinline__ const float *egm_W(const float *theta, const EgmMlp &
 __device__ __forceinline__ void egm_mlp_fwd(const EgmCtx &c, const float *theta, const EgmMlp &n, const EgmMlpCache &a, int B) {
   for (int l = 0; l < n.n_layers; ++l) {
     const float *W = egm_W(theta, n, l);
-    egm_fwd(c, a.act[l], n.dims[l], W, W + n.dims[l] * n.dims[l + 1], a.act[l + 1], n.dims[l + 1], B, n.dims[l], n.dims[l + 1],
+    egm_fwd(c, egm_act(n, a, l, B), n.dims[l], W, W + n.dims[l] * n.dims[l + 1], egm_act(n, a, l + 1, B), n.dims[l + 1], B, n.dims[l], n.dims[l + 1],
             l < n.n_layers - 1);
   }
 }
@@ -153,56 +214,63 @@ __device__ __forceinline__ void egm_mlp_bwd(const EgmCtx &c, const float *theta,
   float *cur = d, *nxt = tmp;
   for (int l = n.n_layers - 1; l >= 0; --l) {
     const int in = n.dims[l], out = n.dims[l + 1];
-    if (l < n.n_layers - 1) {   // through LeakyReLU: the sign of the activation is the sign of the pre-activation
-      for (int k = c.tid; k < B * out; k += EGM_THREADS) cur[k] *= (a.act[l + 1][k] > 0.0f) ? 1.0f : EGM_LEAK;
-      __syncthreads();
-    }
     const float *W = egm_W(theta, n, l);
     float *gW = grad + (W - theta);
-    egm_bwd_w(c, a.act[l], in, cur, out, gW, gW + in * out, B, in, out, accumulate);
-    if (l > 0) {
-      egm_bwd_in(c, cur, out, W, nxt, in, B, in, out, false);
-      float *t = cur; cur = nxt; nxt = t;
-    } else if (dx) {
-      egm_bwd_in(c, cur, out, W, dx, in, B, in, out, false);
-    }
+    // act[l] (l > 0) is a LeakyReLU output: its sign is the sign of the pre-activation
+    egm_bwd_layer(c, egm_act(n, a, l, B), cur, W, gW, gW + in * out, l > 0 ? nxt : dx, B, in, out, accumulate, l > 0);
+    float *t = cur; cur = nxt; nxt = t;
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Discriminator: forward with batch statistics, backward, gradient penalty (double backward)
 // ---------------------------------------------------------------------------------------------
-struct EgmDiscCache {
-  float *a[EGM_MAX_LAYERS + 1];     // a[0] = input [B x dims[0]], a[l] = tanh output of hidden layer l
-  float *uhat[EGM_MAX_LAYERS];      // [B x dims[l+1]]
-  float *sigma[EGM_MAX_LAYERS];     // [dims[l+1]]
-  float *out;                       // [B]
-};
+// Forward cache of one discriminator call; computed pointers as above.  Per hidden layer l the block
+// [a_{l+1} (B x w) | uhat_l (B x w) | sigma_l (w)], w = dims[l+1]; the scalar outputs [B] follow the last block.
+struct EgmDiscCache { float *in, *base; };
+__device__ __forceinline__ int egm_dk_off(const EgmDisc &d, int l, int B) {
+  int o = 0;
+  for (int k = 0; k < l; ++k) o += (2 * B + 1) * d.dims[k + 1];
+  return o;
+}
+__device__ __forceinline__ float *egm_dk_a(const EgmDisc &d, const EgmDiscCache &k, int l, int B) {   // a_l, l = 0..L
+  return l == 0 ? k.in : k.base + egm_dk_off(d, l - 1, B);
+}
+__device__ __forceinline__ float *egm_dk_uhat(const EgmDisc &d, const EgmDiscCache &k, int l, int B) {
+  return k.base + egm_dk_off(d, l, B) + B * d.dims[l + 1];
+}
+__device__ __forceinline__ float *egm_dk_sigma(const EgmDisc &d, const EgmDiscCache &k, int l, int B) {
+  return k.base + egm_dk_off(d, l, B) + 2 * B * d.dims[l + 1];
+}
+__device__ __forceinline__ float *egm_dk_out(const EgmDisc &d, const EgmDiscCache &k, int B) {
+  return k.base + egm_dk_off(d, d.n_hidden, B);
+}
 
 __device__ __forceinline__ void egm_disc_fwd(const EgmCtx &c, const float *th, const EgmDisc &d, const EgmDiscCache &k, int B) {
   const int L = d.n_hidden;
   for (int l = 0; l < L; ++l) {
     const int in = d.dims[l], out = d.dims[l + 1];
-    egm_fwd(c, k.a[l], in, th + d.w[l], th + d.b[l], k.uhat[l], out, B, in, out, false);   // u (normalised in place below)
+    float *uh_ = egm_dk_uhat(d, k, l, B), *sg_ = egm_dk_sigma(d, k, l, B), *ao_ = egm_dk_a(d, k, l + 1, B);
+    egm_fwd(c, egm_dk_a(d, k, l, B), in, th + d.w[l], th + d.b[l], uh_, out, B, in, out, false);   // u (normalised in place below)
     for (int o = c.tid; o < out; o += EGM_THREADS) {
       float mu = 0.0f;
-      for (int b = 0; b < B; ++b) mu += k.uhat[l][b * out + o];
+      for (int b = 0; b < B; ++b) mu += uh_[b * out + o];
       mu /= (float)B;
       float var = 0.0f;
-      for (int b = 0; b < B; ++b) { const float t = k.uhat[l][b * out + o] - mu; var = fmaf(t, t, var); }
+      for (int b = 0; b < B; ++b) { const float t = uh_[b * out + o] - mu; var = fmaf(t, t, var); }
       var /= (float)B;
       const float sg = sqrtf(var + EGM_BN_EPS);
-      k.sigma[l][o] = sg;
+      sg_[o] = sg;
       const float ga = th[d.gamma[l] + o], be = th[d.beta[l] + o];
       for (int b = 0; b < B; ++b) {
-        const float uh = (k.uhat[l][b * out + o] - mu) / sg;
-        k.uhat[l][b * out + o] = uh;
-        k.a[l + 1][b * out + o] = tanhf(fmaf(uh, ga, be));
+        const float uh = (uh_[b * out + o] - mu) / sg;
+        uh_[b * out + o] = uh;
+        ao_[b * out + o] = tanhf(fmaf(uh, ga, be));
       }
     }
     __syncthreads();
   }
-  egm_fwd(c, k.a[L], d.dims[L], th + d.w[L], th + d.b[L], k.out, 1, B, d.dims[L], 1, false);
+  egm_fwd(c, egm_dk_a(d, k, L, B), d.dims[L], th + d.w[L], th + d.b[L], egm_dk_out(d, k, B), 1, B, d.dims[L], 1, false);
 }
 
 // x - mean_b x - uhat * mean_b(x uhat), per feature column o (one thread per column)
@@ -213,20 +281,40 @@ __device__ __forceinline__ void egm_bn_proj_col(float *x, const float *uhat, int
   for (int b = 0; b < B; ++b) x[b * out + o] = (x[b * out + o] - m1 - uhat[b * out + o] * m2) * scale;
 }
 
-struct EgmDiscAdj {   // extra adjoints on forward nodes (gradient-penalty reverse pass); NULL pointers = none
-  float *a_bar[EGM_MAX_LAYERS], *uhat_bar[EGM_MAX_LAYERS], *sigma_bar[EGM_MAX_LAYERS];
-};
+// Scratch of the gradient-penalty pass (computed pointers).  First the adjoint-network activations da_l [B x dims[l]],
+// l = 0..L; then per hidden layer l the block [dy | dhat | du | a_bar | uhat_bar (B x w each) | sigma_bar (w)].
+struct EgmGpScr { float *base; };
+__device__ __forceinline__ float *egm_gp_da(const EgmDisc &d, const EgmGpScr &g, int l, int B) {
+  int o = 0;
+  for (int k = 0; k < l; ++k) o += d.dims[k];
+  return g.base + B * o;
+}
+__device__ __forceinline__ float *egm_gp_blk(const EgmDisc &d, const EgmGpScr &g, int l, int B, int which) {
+  int o = 0;
+  for (int k = 0; k <= d.n_hidden; ++k) o += B * d.dims[k];
+  for (int k = 0; k < l; ++k) o += (5 * B + 1) * d.dims[k + 1];
+  return g.base + o + which * B * d.dims[l + 1];
+}
+__device__ __forceinline__ int egm_gp_floats(const EgmDisc &d, int B) {
+  int o = 0;
+  for (int k = 0; k <= d.n_hidden; ++k) o += B * d.dims[k];
+  for (int k = 0; k < d.n_hidden; ++k) o += (5 * B + 1) * d.dims[k + 1];
+  return (o + 3) & ~3;
+}
+enum { GP_DY = 0, GP_DHAT = 1, GP_DU = 2, GP_ABAR = 3, GP_UBAR = 4, GP_SBAR = 5 };
 
 // Ordinary backward.  dout_val: dLoss/dout of every row (has_dout), grads accumulate (scaled by s) when `accumulate`.
+// adj (may be NULL): extra adjoints a_bar / uhat_bar / sigma_bar on the forward nodes (gradient-penalty reverse pass).
 // da / du: scratch [B x max width].  dx (may be NULL) receives dLoss/dinput [B x dims[0]].
 __device__ __forceinline__ void egm_disc_bwd(const EgmCtx &c, const float *th, float *gr, const EgmDisc &d, const EgmDiscCache &k,
-                                             bool has_dout, float dout_val, const EgmDiscAdj *adj, float *da, float *du, float *dx,
+                                             bool has_dout, float dout_val, const EgmGpScr *adj, float *da, float *du, float *dx,
                                              int B, bool accumulate, float s) {
   const int L = d.n_hidden, nL = d.dims[L];
+  const float *aL = egm_dk_a(d, k, L, B);
   if (has_dout) {
     for (int i = c.tid; i < nL + 1; i += EGM_THREADS) {
       float acc = 0.0f;
-      if (i < nL) { for (int b = 0; b < B; ++b) acc += k.a[L][b * nL + i]; acc *= dout_val; }
+      if (i < nL) { for (int b = 0; b < B; ++b) acc += aL[b * nL + i]; acc *= dout_val; }
       else acc = dout_val * (float)B;
       float *dst = gr + (i < nL ? d.w[L] + i : d.b[L]);
       *dst = accumulate ? *dst + s * acc : s * acc;
@@ -240,6 +328,10 @@ __device__ __forceinline__ void egm_disc_bwd(const EgmCtx &c, const float *th, f
   __syncthreads();
   for (int l = L - 1; l >= 0; --l) {
     const int in = d.dims[l], out = d.dims[l + 1];
+    const float *uh_ = egm_dk_uhat(d, k, l, B), *sg_ = egm_dk_sigma(d, k, l, B), *ao_ = egm_dk_a(d, k, l + 1, B);
+    const float *abar = adj ? egm_gp_blk(d, *adj, l, B, GP_ABAR) : nullptr;
+    const float *ubar = adj ? egm_gp_blk(d, *adj, l, B, GP_UBAR) : nullptr;
+    const float *sbar = adj ? egm_gp_blk(d, *adj, l, B, GP_SBAR) : nullptr;
     // dy = (da + a_bar) (1 - a^2);  dgamma, dbeta;  duhat = dy gamma + uhat_bar;  du = proj(duhat)/sigma + sigma_bar uhat / B
     for (int o = c.tid; o < out; o += EGM_THREADS) {
       float gg = 0.0f, gb = 0.0f;
@@ -247,115 +339,118 @@ __device__ __forceinline__ void egm_disc_bwd(const EgmCtx &c, const float *th, f
       for (int b = 0; b < B; ++b) {
         const int t = b * out + o;
         float dav = da[t];
-        if (adj && adj->a_bar[l]) dav += adj->a_bar[l][t];
-        const float av = k.a[l + 1][t];
+        if (abar) dav += abar[t];
+        const float av = ao_[t];
         const float dy = dav * (1.0f - av * av);
-        gg = fmaf(dy, k.uhat[l][t], gg);
+        gg = fmaf(dy, uh_[t], gg);
         gb += dy;
         float dh = dy * ga;
-        if (adj && adj->uhat_bar[l]) dh += adj->uhat_bar[l][t];
+        if (ubar) dh += ubar[t];
         du[t] = dh;
       }
       float *pg = gr + d.gamma[l] + o, *pb = gr + d.beta[l] + o;
       *pg = accumulate ? *pg + s * gg : s * gg;
       *pb = accumulate ? *pb + s * gb : s * gb;
-      egm_bn_proj_col(du, k.uhat[l], B, out, o, 1.0f / k.sigma[l][o]);
-      if (adj && adj->sigma_bar[l]) {
-        const float sb = adj->sigma_bar[l][o] / (float)B;
-        for (int b = 0; b < B; ++b) du[b * out + o] = fmaf(sb, k.uhat[l][b * out + o], du[b * out + o]);
+      egm_bn_proj_col(du, uh_, B, out, o, 1.0f / sg_[o]);
+      if (sbar) {
+        const float sb = sbar[o] / (float)B;
+        for (int b = 0; b < B; ++b) du[b * out + o] = fmaf(sb, uh_[b * out + o], du[b * out + o]);
       }
     }
     __syncthreads();
-    egm_bwd_w(c, k.a[l], in, du, out, gr + d.w[l], gr + d.b[l], B, in, out, accumulate, s);
+    const float *ai_ = egm_dk_a(d, k, l, B);
+    egm_bwd_w(c, ai_, in, du, out, gr + d.w[l], gr + d.b[l], B, in, out, accumulate, s);
     if (l > 0) egm_bwd_in(c, du, out, th + d.w[l], da, in, B, in, out, false);
     else if (dx) egm_bwd_in(c, du, out, th + d.w[l], dx, in, B, in, out, false);
   }
 }
 
 // Gradient penalty GP = mean_b (||g_b|| - 1)^2 on the batch whose forward cache is k; accumulates s * dGP/dtheta
-// into gr (which must already hold valid values) and returns GP.  Scratch: per hidden layer dy, dhat, du, da
-// ([B x width] each) inside `scr`, plus the adjoint buffers.
+// into gr (which must already hold valid values) and returns GP.
 __device__ __forceinline__ float egm_disc_gp(const EgmCtx &c, const float *th, float *gr, const EgmDisc &d, const EgmDiscCache &k,
                                              float *scr, int B, float s, int wmax) {
   const int L = d.n_hidden;
+  EgmGpScr G{scr};
+  float *rest = scr + egm_gp_floats(d, B);
+  float *bar_a = rest, *bar_b = rest + B * wmax, *tmp = rest + 2 * B * wmax;
   // ---- adjoint network: g = d(sum_b out_b)/d input
-  float *da_[EGM_MAX_LAYERS + 1], *dy_[EGM_MAX_LAYERS], *dhat_[EGM_MAX_LAYERS], *du_[EGM_MAX_LAYERS];
-  EgmDiscAdj adj;
-  int off = 0;
-  auto take = [&](int n) { float *p_ = scr + off; off += (n + 3) & ~3; return p_; };
-  for (int l = 0; l <= L; ++l) da_[l] = take(B * d.dims[l]);
-  for (int l = 0; l < L; ++l) {
-    const int w = B * d.dims[l + 1];
-    dy_[l] = take(w); dhat_[l] = take(w); du_[l] = take(w);
-    adj.a_bar[l] = take(w); adj.uhat_bar[l] = take(w); adj.sigma_bar[l] = take(d.dims[l + 1]);
-  }
-  float *bar_a = take(B * wmax), *bar_b = take(B * wmax), *tmp = take(B * wmax);
   const int nL = d.dims[L];
-  for (int t = c.tid; t < B * nL; t += EGM_THREADS) da_[L][t] = th[d.w[L] + (t % nL)];
+  {
+    float *daL = egm_gp_da(d, G, L, B);
+    for (int t = c.tid; t < B * nL; t += EGM_THREADS) daL[t] = th[d.w[L] + (t % nL)];
+  }
   __syncthreads();
   for (int l = L - 1; l >= 0; --l) {
     const int in = d.dims[l], out = d.dims[l + 1];
+    const float *uh_ = egm_dk_uhat(d, k, l, B), *sg_ = egm_dk_sigma(d, k, l, B), *ao_ = egm_dk_a(d, k, l + 1, B);
+    const float *da_up = egm_gp_da(d, G, l + 1, B);
+    float *dy_ = egm_gp_blk(d, G, l, B, GP_DY), *dhat_ = egm_gp_blk(d, G, l, B, GP_DHAT), *du_ = egm_gp_blk(d, G, l, B, GP_DU);
     for (int o = c.tid; o < out; o += EGM_THREADS) {
       const float ga = th[d.gamma[l] + o];
       for (int b = 0; b < B; ++b) {
         const int t = b * out + o;
-        const float av = k.a[l + 1][t];
-        const float dy = da_[l + 1][t] * (1.0f - av * av);
-        dy_[l][t] = dy;
-        dhat_[l][t] = dy * ga;
-        du_[l][t] = dy * ga;
+        const float av = ao_[t];
+        const float dy = da_up[t] * (1.0f - av * av);
+        dy_[t] = dy;
+        dhat_[t] = dy * ga;
+        du_[t] = dy * ga;
       }
-      egm_bn_proj_col(du_[l], k.uhat[l], B, out, o, 1.0f / k.sigma[l][o]);
+      egm_bn_proj_col(du_, uh_, B, out, o, 1.0f / sg_[o]);
     }
     __syncthreads();
-    egm_bwd_in(c, du_[l], out, th + d.w[l], da_[l], in, B, in, out, false);
+    egm_bwd_in(c, du_, out, th + d.w[l], egm_gp_da(d, G, l, B), in, B, in, out, false);
   }
-  // ---- penalty and its adjoint on g = da_[0]
+  // ---- penalty and its adjoint on g = da_0
   const int q = d.dims[0];
+  const float *g0 = egm_gp_da(d, G, 0, B);
   float part = 0.0f;
   for (int b = c.tid; b < B; b += EGM_THREADS) {
     float n2 = 0.0f;
-    for (int i = 0; i < q; ++i) n2 = fmaf(da_[0][b * q + i], da_[0][b * q + i], n2);
+    for (int i = 0; i < q; ++i) n2 = fmaf(g0[b * q + i], g0[b * q + i], n2);
     const float nrm = sqrtf(n2);
     part += (nrm - 1.0f) * (nrm - 1.0f);
     const float coef = 2.0f * (nrm - 1.0f) / nrm / (float)B;
-    for (int i = 0; i < q; ++i) bar_a[b * q + i] = coef * da_[0][b * q + i];
+    for (int i = 0; i < q; ++i) bar_a[b * q + i] = coef * g0[b * q + i];
   }
   const float gp = egm_block_sum(c, part) / (float)B;
   // ---- reverse through the adjoint network, bottom (l = 0) to top
   float *da_bar = bar_a, *du_bar = bar_b;
   for (int l = 0; l < L; ++l) {
     const int in = d.dims[l], out = d.dims[l + 1];
+    const float *uh_ = egm_dk_uhat(d, k, l, B), *sg_ = egm_dk_sigma(d, k, l, B), *ao_ = egm_dk_a(d, k, l + 1, B);
+    const float *da_up = egm_gp_da(d, G, l + 1, B);
+    const float *dy_ = egm_gp_blk(d, G, l, B, GP_DY), *dhat_ = egm_gp_blk(d, G, l, B, GP_DHAT), *du_ = egm_gp_blk(d, G, l, B, GP_DU);
+    float *abar = egm_gp_blk(d, G, l, B, GP_ABAR), *ubar = egm_gp_blk(d, G, l, B, GP_UBAR), *sbar = egm_gp_blk(d, G, l, B, GP_SBAR);
     // da_{l-1} = du W^T :  W_bar += da_bar^T du ;  du_bar = da_bar W
-    egm_bwd_w(c, da_bar, in, du_[l], out, gr + d.w[l], nullptr, B, in, out, true, s);
+    egm_bwd_w(c, da_bar, in, du_, out, gr + d.w[l], nullptr, B, in, out, true, s);
     egm_fwd(c, da_bar, in, th + d.w[l], nullptr, du_bar, out, B, in, out, false);
     // du = (dhat - m1 - uhat m2) / sigma
     for (int o = c.tid; o < out; o += EGM_THREADS) {
-      const float sg = k.sigma[l][o], ga = th[d.gamma[l] + o];
+      const float sg = sg_[o], ga = th[d.gamma[l] + o];
       float sb = 0.0f, m2 = 0.0f, tu = 0.0f;
       for (int b = 0; b < B; ++b) {
         const int t = b * out + o;
-        sb = fmaf(du_bar[t], du_[l][t], sb);
-        m2 = fmaf(dhat_[l][t], k.uhat[l][t], m2);
-        tu = fmaf(du_bar[t] / sg, k.uhat[l][t], tu);
+        sb = fmaf(du_bar[t], du_[t], sb);
+        m2 = fmaf(dhat_[t], uh_[t], m2);
+        tu = fmaf(du_bar[t] / sg, uh_[t], tu);
       }
-      adj.sigma_bar[l][o] = -sb / sg;
+      sbar[o] = -sb / sg;
       m2 /= (float)B; tu /= (float)B;
       for (int b = 0; b < B; ++b) {
         const int t = b * out + o;
         const float tt = du_bar[t] / sg;
-        adj.uhat_bar[l][t] = -(tt * m2 + dhat_[l][t] * tu);
+        ubar[t] = -(tt * m2 + dhat_[t] * tu);
         tmp[t] = tt;
       }
-      egm_bn_proj_col(tmp, k.uhat[l], B, out, o, 1.0f);          // dhat_bar
+      egm_bn_proj_col(tmp, uh_, B, out, o, 1.0f);          // dhat_bar
       float gg = 0.0f;
       for (int b = 0; b < B; ++b) {
         const int t = b * out + o;
-        gg = fmaf(tmp[t], dy_[l][t], gg);
+        gg = fmaf(tmp[t], dy_[t], gg);
         const float dyb = tmp[t] * ga;
-        const float av = k.a[l + 1][t];
-        adj.a_bar[l][t] = dyb * da_[l + 1][t] * (-2.0f * av);
-        tmp[t] = dyb * (1.0f - av * av);                          // da_bar of the layer above
+        const float av = ao_[t];
+        abar[t] = dyb * da_up[t] * (-2.0f * av);
+        tmp[t] = dyb * (1.0f - av * av);                    // da_bar of the layer above
       }
       gr[d.gamma[l] + o] += s * gg;
     }
@@ -371,7 +466,7 @@ __device__ __forceinline__ float egm_disc_gp(const EgmCtx &c, const float *th, f
   }
   __syncthreads();
   // ---- ... and on through the forward pass (scratch: bar_b, tmp)
-  egm_disc_bwd(c, th, gr, d, k, false, 0.0f, &adj, bar_b, tmp, nullptr, B, true, s);
+  egm_disc_bwd(c, th, gr, d, k, false, 0.0f, &G, bar_b, tmp, nullptr, B, true, s);
   return gp;
 }
 
@@ -387,19 +482,16 @@ __device__ __forceinline__ void egm_adam(const EgmCtx &c, float *theta, float *m
 
 // carve a discriminator cache out of the workspace
 __device__ __forceinline__ void egm_disc_cache(const EgmDisc &d, int B, float *&p, EgmDiscCache &k, float *input) {
-  auto take = [&](int n) { float *r = p; p += (n + 3) & ~3; return r; };
-  k.a[0] = input;
-  for (int l = 0; l < d.n_hidden; ++l) {
-    k.a[l + 1] = take(B * d.dims[l + 1]);
-    k.uhat[l] = take(B * d.dims[l + 1]);
-    k.sigma[l] = take(d.dims[l + 1]);
-  }
-  k.out = take(B);
+  k.in = input;
+  k.base = p;
+  p += (egm_dk_off(d, d.n_hidden, B) + B + 3) & ~3;
 }
 __device__ __forceinline__ void egm_mlp_cache(const EgmMlp &n, int B, float *&p, EgmMlpCache &a, float *input) {
   auto take = [&](int k) { float *r = p; p += (k + 3) & ~3; return r; };
-  a.act[0] = input;
-  for (int l = 0; l < n.n_layers; ++l) a.act[l + 1] = take(B * n.dims[l + 1]);
+  a.in = input;
+  int w = 0;
+  for (int l = 1; l <= n.n_layers; ++l) w += n.dims[l];
+  a.base = take(B * w);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -407,7 +499,7 @@ __device__ __forceinline__ void egm_mlp_cache(const EgmMlp &n, int B, float *&p,
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(EGM_THREADS) void egm_disc_step_kernel(EgmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float egm_lds[];
-  EgmCtx c{(int)threadIdx.x, egm_lds + 32, egm_lds};
+  EgmCtx c{(int)threadIdx.x, egm_lds};
   const int B = a.B, q = a.q, p = a.p;
   float *wp = a.ws;
   auto take = [&](int n) { float *r = wp; wp += (n + 3) & ~3; return r; };
@@ -417,24 +509,35 @@ __global__ __launch_bounds__(EGM_THREADS) void egm_disc_step_kernel(EgmArgs a) {
   EgmMlpCache ce;
   egm_mlp_cache(a.e, B, wp, ce, vb);
   egm_mlp_fwd(c, a.theta_g, a.e, ce, B);                      // z_ = e(v)   (encoder fixed in this step)
-  float *z_ = ce.act[a.e.n_layers];
+  float *z_ = egm_act(a.e, ce, a.e.n_layers, B);
   for (int k = c.tid; k < B * q; k += EGM_THREADS) zhat[k] = a.z[k] * a.eps + z_[k] * (1.0f - a.eps);
   __syncthreads();
+  // Discriminator working set: [cache A | cache B, da, du  (later overlaid by the gradient-penalty scratch)].
+  // In LDS when it fits (B = 32, dz_units [64, 32, 8]: 147 KB): its many small per-column passes are chains of
+  // dependent accesses and an LDS access costs ~1/15 of an L2 round trip.  Cache A holds D(z_) first and
+  // D(zhat) afterwards.
+  float *arena = a.disc_lds ? (egm_lds + 64) : wp;
+  float *ap_ = arena;
   EgmDiscCache kf, kr, kh;
-  egm_disc_cache(a.dz, B, wp, kf, z_);
-  egm_disc_cache(a.dz, B, wp, kr, const_cast<float *>(a.z));
-  egm_disc_cache(a.dz, B, wp, kh, zhat);
-  float *da = take(B * a.wmax), *du = take(B * a.wmax);
+  egm_disc_cache(a.dz, B, ap_, kf, z_);
+  float *overlay = ap_;
+  egm_disc_cache(a.dz, B, ap_, kr, const_cast<float *>(a.z));
+  float *da = ap_; ap_ += B * a.dmax;
+  float *du = ap_; ap_ += B * a.dmax;
   egm_disc_fwd(c, a.theta_d, a.dz, kf, B);
   egm_disc_fwd(c, a.theta_d, a.dz, kr, B);
-  egm_disc_fwd(c, a.theta_d, a.dz, kh, B);
   float sf = 0.0f, sr = 0.0f;
-  for (int b = c.tid; b < B; b += EGM_THREADS) { sf += kf.out[b]; sr += kr.out[b]; }
+  {
+    const float *of_ = egm_dk_out(a.dz, kf, B), *or_ = egm_dk_out(a.dz, kr, B);
+    for (int b = c.tid; b < B; b += EGM_THREADS) { sf += of_[b]; sr += or_[b]; }
+  }
   sf = egm_block_sum(c, sf); sr = egm_block_sum(c, sr);
   const float dz_loss = (-sr + sf) / (float)B;
   egm_disc_bwd(c, a.theta_d, a.grad_d, a.dz, kf, true, 1.0f / (float)B, nullptr, da, du, nullptr, B, false, 1.0f);
   egm_disc_bwd(c, a.theta_d, a.grad_d, a.dz, kr, true, -1.0f / (float)B, nullptr, da, du, nullptr, B, true, 1.0f);
-  const float gp = egm_disc_gp(c, a.theta_d, a.grad_d, a.dz, kh, wp, B, 10.0f, a.wmax);
+  kh.in = zhat; kh.base = kf.base;
+  egm_disc_fwd(c, a.theta_d, a.dz, kh, B);
+  const float gp = egm_disc_gp(c, a.theta_d, a.grad_d, a.dz, kh, overlay, B, 10.0f, a.dmax);
   __syncthreads();
   if (a.apply) egm_adam(c, a.theta_d, a.m_d, a.v_d, a.grad_d, a.dz.n_params, a.adam);
   if (c.tid == 0 && a.out) { a.out[0] = dz_loss; a.out[1] = dz_loss + 10.0f * gp; }
@@ -445,7 +548,7 @@ __global__ __launch_bounds__(EGM_THREADS) void egm_disc_step_kernel(EgmArgs a) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(EGM_THREADS) void egm_gen_step_kernel(EgmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float egm_lds[];
-  EgmCtx c{(int)threadIdx.x, egm_lds + 32, egm_lds};
+  EgmCtx c{(int)threadIdx.x, egm_lds};
   const int B = a.B, q = a.q, p = a.p, z0 = a.z0, z1 = a.z1, z2 = a.z2;
   const float invB = 1.0f / (float)B;
   float *wp = a.ws;
@@ -460,19 +563,19 @@ __global__ __launch_bounds__(EGM_THREADS) void egm_gen_step_kernel(EgmArgs a) {
   EgmMlpCache g1, e1, e2, g2, cf, ch;
   egm_mlp_cache(a.g, B, wp, g1, const_cast<float *>(a.z));
   egm_mlp_fwd(c, a.theta_g, a.g, g1, B);                       // g(z): v_ = [:, :p], sigma head [:, p]
-  float *gz = g1.act[Lg];
+  float *gz = egm_act(a.g, g1, Lg, B);
   egm_mlp_cache(a.e, B, wp, e1, vb);
   egm_mlp_fwd(c, a.theta_g, a.e, e1, B);                       // z_ = e(v)
-  float *z_ = e1.act[Le];
+  float *z_ = egm_act(a.e, e1, Le, B);
   float *v_ = take(B * p);                                     // contiguous copy of g(z)[:, :p]
   for (int k = c.tid; k < B * p; k += EGM_THREADS) { const int b = k / p; v_[k] = gz[b * wg + (k - b * p)]; }
   __syncthreads();
   egm_mlp_cache(a.e, B, wp, e2, v_);
   egm_mlp_fwd(c, a.theta_g, a.e, e2, B);                       // z__ = e(v_)
-  float *z__ = e2.act[Le];
+  float *z__ = egm_act(a.e, e2, Le, B);
   egm_mlp_cache(a.g, B, wp, g2, z_);
   egm_mlp_fwd(c, a.theta_g, a.g, g2, B);                       // g(z_): v__ = [:, :p]
-  float *gv = g2.act[Lg];
+  float *gv = egm_act(a.g, g2, Lg, B);
   EgmDiscCache kd;
   egm_disc_cache(a.dz, B, wp, kd, z_);
   egm_disc_fwd(c, a.theta_d, a.dz, kd, B);
@@ -490,11 +593,12 @@ __global__ __launch_bounds__(EGM_THREADS) void egm_gen_step_kernel(EgmArgs a) {
   egm_mlp_fwd(c, a.theta_g, a.f, cf, B);
   egm_mlp_cache(a.h, B, wp, ch, hin);
   egm_mlp_fwd(c, a.theta_g, a.h, ch, B);
-  float *fo = cf.act[Lf], *ho = ch.act[Lh];
+  float *fo = egm_act(a.f, cf, Lf, B), *ho = egm_act(a.h, ch, Lh, B);
   // ---- losses
   float l_v = 0.0f, l_z = 0.0f, l_x = 0.0f, l_y = 0.0f, s_g = 0.0f, s_f = 0.0f, s_h = 0.0f, adv = 0.0f;
   for (int k = c.tid; k < B * p; k += EGM_THREADS) { const int b = k / p; const float t = vb[k] - gv[b * wg + (k - b * p)]; l_v = fmaf(t, t, l_v); }
   for (int k = c.tid; k < B * q; k += EGM_THREADS) { const float t = a.z[k] - z__[k]; l_z = fmaf(t, t, l_z); }
+  const float *dout_ = egm_dk_out(a.dz, kd, B);
   for (int b = c.tid; b < B; b += EGM_THREADS) {
     const float xl = ho[b * oh], yl = fo[b * of];
     if (a.binary) l_x += fmaxf(xl, 0.0f) - xl * xb[b] + log1pf(expf(-fabsf(xl)));
@@ -503,7 +607,7 @@ __global__ __launch_bounds__(EGM_THREADS) void egm_gen_step_kernel(EgmArgs a) {
     s_g += gz[b * wg + p] * gz[b * wg + p];
     s_f += fo[b * of + of - 1] * fo[b * of + of - 1];
     s_h += ho[b * oh + oh - 1] * ho[b * oh + oh - 1];
-    adv -= kd.out[b];
+    adv -= dout_[b];
   }
   l_v = egm_block_sum(c, l_v) / (float)(B * p);
   l_z = egm_block_sum(c, l_z) / (float)(B * q);
