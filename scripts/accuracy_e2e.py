@@ -1,7 +1,7 @@
 """End-to-end accuracy: CausalBGM fit + predict on Sim_Hirano_Imbens (the reference tutorial's setting,
 docs/source/causalbgm/tutorial_py.ipynb: N=20000, p=200, 20 doses on [0,3]; reported ADRF RMSE 0.0188 / MAPE
-0.0103 with EGM warm start + 100 epochs, use_bnn=True).  Here: use_bnn=False, no EGM (not built yet).
-usage: python scripts/accuracy_e2e.py [N] [epochs] [batch]"""
+0.0103 with EGM warm start + 100 epochs, use_bnn=True).  Here: use_bnn=False.
+usage: python scripts/accuracy_e2e.py [N] [epochs] [batch] [egm_iters]"""
 import json, sys, time
 import numpy as np
 sys.path.insert(0, ".")
