@@ -157,13 +157,24 @@ def main():
         n_burn, ms_burn = eng.timing_read(kind=0, reset=False)
         n_keep_l, ms_keep = eng.timing_read(kind=1, reset=False)
         roof = None
+        # HBM traffic cannot be collected from inside this process: use the committed PMC pass of the same kernel on the
+        # same panel shape, if there is one (per-launch read traffic is independent of the iteration count, see the file)
+        traffic = traffic_src = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pm = json.load(f)
+            if pm["rows"] == n_loc and pm["p"] == p:
+                traffic, traffic_src = pm["hbm_read_bytes_per_launch"], "profiles/r01_pmc_traffic.json"
+        except (OSError, KeyError, ValueError):
+            pass
         if n_burn:
             avg = ms_burn / n_burn
             flop = info.flop_per_row_transition * n_loc * args.burn_in
             ach = flop / (avg * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "causal_mh_kernel<EFFECT=0> (burn-in transitions)",
                     "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                    "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "HBM read bytes per launch",
+                    "traffic_source": traffic_src, "algorithmic_bytes_per_launch": n_loc * (4 * p + 8),
                     "avg_launch_ms": avg, "launches": n_burn, "flop_per_launch": flop,
                     "keep_phase_avg_launch_ms": (ms_keep / n_keep_l) if n_keep_l else None}
         out = {
