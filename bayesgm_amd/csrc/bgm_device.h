@@ -156,9 +156,138 @@ struct AFrag<1> {
 #ifndef BGM_MAX_GROUP
 #define BGM_MAX_GROUP 4
 #endif
+#ifndef BGM_PREFETCH_ALL_MAX
+#define BGM_PREFETCH_ALL_MAX 32   // fragment registers a small layer may request up front (0 disables)
+#endif
 __host__ __device__ constexpr int group_size(int tiles_left) {
   return (tiles_left >= 4 && BGM_MAX_GROUP >= 4) ? 4 : (tiles_left >= 2 ? 2 : 1);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Hand-scheduled tile group: acc[0..3] += W[64 K-rows x 4 tiles] (packed group, GS = 4) * in.
+// hipcc sinks every LDS fragment load to its first use (ds_read; s_waitcnt lgkmcnt(0); 4 x MFMA), which
+// exposes the LDS latency once per K-step; pinning the order from C++ made the register allocator
+// spill.  Here the 16 K-steps are one asm block with its own three A-fragment buffers (fixed
+// v244-v255, declared clobbered): fragments are requested TWO steps ahead and waited for with
+// counted lgkmcnt, so a step's four MFMAs issue back to back.  The block drains every older LGKM
+// operation first (SMEM returns out of order, which would break counted waits) and ends with the
+// wait states the MFMA -> VALU read hazard needs (the compiler does not see the MFMAs).
+// `lds_addr` = LDS byte address of this lane's fragment of K-step 0.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dense_group4_k64_asm(unsigned lds_addr, const f32x4 (&in)[4], f32x4 &a0, f32x4 &a1, f32x4 &a2,
+                                                     f32x4 &a3) {
+  asm volatile(
+      "s_waitcnt lgkmcnt(0)\n"
+      "ds_read_b128 v[244:247], %20 offset:0\n"
+      "ds_read_b128 v[248:251], %20 offset:256\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v244, %4, %0\n"
+      "ds_read_b128 v[252:255], %20 offset:512\n"
+      "v_mfma_f32_16x16x4_f32 %1, v245, %4, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v246, %4, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v247, %4, %3\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v248, %5, %0\n"
+      "ds_read_b128 v[244:247], %20 offset:768\n"
+      "v_mfma_f32_16x16x4_f32 %1, v249, %5, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v250, %5, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v251, %5, %3\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v252, %6, %0\n"
+      "ds_read_b128 v[248:251], %20 offset:4096\n"
+      "v_mfma_f32_16x16x4_f32 %1, v253, %6, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v254, %6, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v255, %6, %3\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v244, %7, %0\n"
+      "ds_read_b128 v[252:255], %20 offset:4352\n"
+      "v_mfma_f32_16x16x4_f32 %1, v245, %7, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v246, %7, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v247, %7, %3\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v248, %8, %0\n"
+      "ds_read_b128 v[244:247], %20 offset:4608\n"
+      "v_mfma_f32_16x16x4_f32 %1, v249, %8, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v250, %8, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v251, %8, %3\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v252, %9, %0\n"
+      "ds_read_b128 v[248:251], %20 offset:4864\n"
+      "v_mfma_f32_16x16x4_f32 %1, v253, %9, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v254, %9, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v255, %9, %3\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v244, %10, %0\n"
+      "ds_read_b128 v[252:255], %20 offset:8192\n"
+      "v_mfma_f32_16x16x4_f32 %1, v245, %10, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v246, %10, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v247, %10, %3\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v248, %11, %0\n"
+      "ds_read_b128 v[244:247], %20 offset:8448\n"
+      "v_mfma_f32_16x16x4_f32 %1, v249, %11, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v250, %11, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v251, %11, %3\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v252, %12, %0\n"
+      "ds_read_b128 v[248:251], %20 offset:8704\n"
+      "v_mfma_f32_16x16x4_f32 %1, v253, %12, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v254, %12, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v255, %12, %3\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v244, %13, %0\n"
+      "ds_read_b128 v[252:255], %20 offset:8960\n"
+      "v_mfma_f32_16x16x4_f32 %1, v245, %13, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v246, %13, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v247, %13, %3\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v248, %14, %0\n"
+      "ds_read_b128 v[244:247], %20 offset:12288\n"
+      "v_mfma_f32_16x16x4_f32 %1, v249, %14, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v250, %14, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v251, %14, %3\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v252, %15, %0\n"
+      "ds_read_b128 v[248:251], %20 offset:12544\n"
+      "v_mfma_f32_16x16x4_f32 %1, v253, %15, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v254, %15, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v255, %15, %3\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v244, %16, %0\n"
+      "ds_read_b128 v[252:255], %20 offset:12800\n"
+      "v_mfma_f32_16x16x4_f32 %1, v245, %16, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v246, %16, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v247, %16, %3\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v248, %17, %0\n"
+      "ds_read_b128 v[244:247], %20 offset:13056\n"
+      "v_mfma_f32_16x16x4_f32 %1, v249, %17, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v250, %17, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v251, %17, %3\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v252, %18, %0\n"
+      "v_mfma_f32_16x16x4_f32 %1, v253, %18, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v254, %18, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v255, %18, %3\n"
+      "s_waitcnt lgkmcnt(0)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v244, %19, %0\n"
+      "v_mfma_f32_16x16x4_f32 %1, v245, %19, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v246, %19, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v247, %19, %3\n"
+      "s_nop 15\n"
+      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+      : "v"(in[0][0]), "v"(in[0][1]), "v"(in[0][2]), "v"(in[0][3]), "v"(in[1][0]), "v"(in[1][1]), "v"(in[1][2]), "v"(in[1][3]),
+        "v"(in[2][0]), "v"(in[2][1]), "v"(in[2][2]), "v"(in[2][3]), "v"(in[3][0]), "v"(in[3][1]), "v"(in[3][2]), "v"(in[3][3]),
+        "v"(lds_addr)
+      : "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
+}
+__device__ __forceinline__ unsigned lds_byte_addr(const float *p) {
+  // flat -> LDS address = low 32 bits of the flat address (the aperture base lives in the high half); avoids the
+  // null-checked addrspacecast, which hipcc 7.2 mis-selects in some inlining contexts ("Illegal instruction ...
+  // V_CMP_NE_U32 0, $src_shared_base")
+  return (unsigned)(unsigned long long)p;
+}
+
 
 // One tile group [T0, T0+GS) of a layer.  KT input tiles, the last of which
 // uses KSL (1..4) K-steps.  `wl` points at the layer's packed weights in LDS,
@@ -171,11 +300,30 @@ __device__ __forceinline__ void dense_groups(const float *wl, int lane_off, cons
     constexpr int K_ROWS = 16 * KT;
     constexpr int NKS = 4 * (KT - 1) + KSL;  // K-steps of this layer
     const float *base = wl + K_ROWS * 16 * T0 + lane_off * GS;
+#ifndef BGM_NO_ASM_DENSE
+    if constexpr (R == 1 && KT == 4 && KSL == 4 && GS == 4) {
+      dense_group4_k64_asm(lds_byte_addr(base), in[0], acc[0][T0], acc[0][T0 + 1], acc[0][T0 + 2], acc[0][T0 + 3]);
+      dense_groups<T0 + GS, KT, KSL, NT, R>(wl, lane_off, in, acc);
+      return;
+    }
+#endif
+    if constexpr (R == 1 && NKS * GS <= BGM_PREFETCH_ALL_MAX) {
+      // Small layer (f / h nets, first layers): one or two MFMAs per K-step cannot cover an LDS round trip, and
+      // hipcc sinks each fragment load to its first use, so the layer would pay one exposed LDS latency PER STEP
+      // (~110 cycles x 16 steps vs 32-64 cycles of MFMA).  Request every fragment of the group up front (the
+      // compiler fence keeps the loads above it) and let the counted waits drain them in order: one round trip.
+      AFrag<GS> a[NKS];
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) a[s].load(base + (16 * (s >> 2) + (s & 3)) * 16 * GS);
+      BGM_NO_HOIST();
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) {
+#pragma unroll
+        for (int u = 0; u < GS; ++u) acc[0][T0 + u] = BGM_MFMA(a[s].get(u), in[0][s >> 2][s & 3], acc[0][T0 + u]);
+      }
+    } else {
     // software pipeline in SOURCE order: the A fragment of K-step s+1 is requested before the MFMAs of
-    // step s.  (hipcc sinks the load back to its first use; pinning the order with sched_barrier(0) or
-    // inline-asm ds_read + counted lgkmcnt gives the ideal stream but ~300 spilled VGPRs and 68 vs 113 TF --
-    // measured, see DESIGN.md -- so the load placement is left to the compiler and covered by the
-    // second wave of the SIMD.)
+    // step s (hipcc sinks the load back to its first use; the second wave of the SIMD covers it).
     AFrag<GS> a_cur, a_nxt;
     a_cur.load(base);
 #pragma unroll
@@ -189,9 +337,11 @@ __device__ __forceinline__ void dense_groups(const float *wl, int lane_off, cons
       }
       a_cur = a_nxt;
     }
+    }
     dense_groups<T0 + GS, KT, KSL, NT, R>(wl, lane_off, in, acc);
   }
 }
+
 
 // acc = bias (feature 16 t + 4 g + r) for every row group
 template <int NT, int R>
@@ -209,6 +359,47 @@ __device__ __forceinline__ void dense(const float *wl, const float *bl, int lane
                                       const f32x4 (&in)[R][KT], f32x4 (&acc)[R][NT]) {
   bias_init<NT, R>(bl, g, acc);
   dense_groups<0, KT, KSL, NT, R>(wl, lane_off, in, acc);
+}
+
+// Two independent layers of the SAME shape (the f and h nets of CausalBGM) evaluated in lock step: K-step by K-step
+// the MFMAs of both are interleaved, so twice as many independent accumulators are in flight.  Alone, the narrow
+// f / h layers are chains of one or two dependent MFMAs per step; with a second wave streaming g-net MFMAs through
+// the same matrix pipe those chains measured 3x their solo time (17.1k vs 6.0k cycles per transition).
+// Single tile group per layer (NT in {4, 2, 1}); fragments are requested a chunk ahead (<= 32 registers).
+template <int KT, int KSL, int NT>
+__device__ __forceinline__ void dense_pair(const float *wlA, const float *blA, const float *wlB, const float *blB, int lane_off, int g,
+                                           const f32x4 (&inA)[1][KT], const f32x4 (&inB)[1][KT], f32x4 (&accA)[1][NT],
+                                           f32x4 (&accB)[1][NT]) {
+  static_assert(NT == 4 || NT == 2 || NT == 1, "dense_pair: one tile group per layer");
+  constexpr int GS = NT, NKS = 4 * (KT - 1) + KSL;
+  constexpr int CH = (NKS * GS <= 16) ? NKS : (16 / GS);
+  bias_init<NT, 1>(blA, g, accA);
+  bias_init<NT, 1>(blB, g, accB);
+  const float *baseA = wlA + lane_off * GS, *baseB = wlB + lane_off * GS;
+#pragma unroll
+  for (int c0 = 0; c0 < NKS; c0 += CH) {
+    AFrag<GS> fa[CH], fb[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int s = c0 + i;
+      if (s < NKS) {
+        fa[i].load(baseA + (16 * (s >> 2) + (s & 3)) * 16 * GS);
+        fb[i].load(baseB + (16 * (s >> 2) + (s & 3)) * 16 * GS);
+      }
+    }
+    BGM_NO_HOIST();
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int s = c0 + i;
+      if (s < NKS) {
+#pragma unroll
+        for (int u = 0; u < GS; ++u) {
+          accA[0][u] = BGM_MFMA(fa[i].get(u), inA[0][s >> 2][s & 3], accA[0][u]);
+          accB[0][u] = BGM_MFMA(fb[i].get(u), inB[0][s >> 2][s & 3], accB[0][u]);
+        }
+      }
+    }
+  }
 }
 
 template <int NT, int R>

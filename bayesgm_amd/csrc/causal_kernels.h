@@ -69,18 +69,38 @@ __device__ __forceinline__ void g_last_groups(const float *wl, const float *bl, 
     constexpr int K_ROWS = 16 * KT;
     constexpr int NKS = 4 * KT;
     const float *base = wl + K_ROWS * 16 * T0 + lane_off * GS;
-    AFrag<GS> a_cur, a_nxt;
-    a_cur.load(base);
+    bool done = false;
+#ifndef BGM_NO_ASM_DENSE
+    if constexpr (R == 1 && KT == 4 && GS == 4) {
+      dense_group4_k64_asm(lds_byte_addr(base), in[0], acc[0][T0], acc[0][T0 + 1], acc[0][T0 + 2], acc[0][T0 + 3]);
+      done = true;
+    }
+#endif
+    if constexpr (R == 1 && NKS * GS <= BGM_PREFETCH_ALL_MAX) {   // the single trailing tile: see dense_groups
+      AFrag<GS> af[NKS];
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-      const int t = ks >> 2, r = ks & 3;
-      if (ks + 1 < NKS) a_nxt.load(base + (16 * ((ks + 1) >> 2) + ((ks + 1) & 3)) * 16 * GS);
+      for (int ks = 0; ks < NKS; ++ks) af[ks].load(base + (16 * (ks >> 2) + (ks & 3)) * 16 * GS);
+      BGM_NO_HOIST();
 #pragma unroll
-      for (int u = 0; u < GS; ++u)
+      for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-        for (int rr = 0; rr < R; ++rr)
-          acc[rr][T0 + u] = BGM_MFMA(a_cur.get(u), in[rr][t][r], acc[rr][T0 + u]);
-      a_cur = a_nxt;
+        for (int u = 0; u < GS; ++u) acc[0][T0 + u] = BGM_MFMA(af[ks].get(u), in[0][ks >> 2][ks & 3], acc[0][T0 + u]);
+      done = true;
+    }
+    if (!done) {
+      AFrag<GS> a_cur, a_nxt;
+      a_cur.load(base);
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const int t = ks >> 2, r = ks & 3;
+        if (ks + 1 < NKS) a_nxt.load(base + (16 * ((ks + 1) >> 2) + ((ks + 1) & 3)) * 16 * GS);
+#pragma unroll
+        for (int u = 0; u < GS; ++u)
+#pragma unroll
+          for (int rr = 0; rr < R; ++rr)
+            acc[rr][T0 + u] = BGM_MFMA(a_cur.get(u), in[rr][t][r], acc[rr][T0 + u]);
+        a_cur = a_nxt;
+      }
     }
 #pragma unroll
     for (int u = 0; u < GS; ++u) {
@@ -124,17 +144,27 @@ __device__ __forceinline__ void fh_tail(const float *lds, int w2, int b2, int w3
   }
 }
 
+#ifdef BGM_PROF
+#define PMARK(i) do { const unsigned long long _t = __builtin_readcyclecounter(); tsec[i] += _t - tlast; tlast = _t; } while (0)
+#else
+#define PMARK(i)
+#endif
 template <int KT1, int KSL1, int NTL, int R>
 __device__ __forceinline__ void causal_logp(const float *lds, const CausalMeta &m, int lane_off, int g,
                                             int j, const f32x4 (&zin)[R][KT1],
                                             const f32x4 (&vreg)[R][NTL], const float (&xr)[R],
-                                            const float (&yr)[R], float (&logp)[R]) {
+                                            const float (&yr)[R], float (&logp)[R]
+#ifdef BGM_PROF
+                                            , unsigned long long (&tsec)[8], unsigned long long &tlast
+#endif
+                                            ) {
   // ---- g : z -> (mu_v, s_v), Gaussian NLL over p covariates (base.py:779-801)
   float ssq[R], sraw_v[R];
   {
     f32x4 h[R][4];
     dense<KT1, KSL1, 4, R>(lds + m.w1g, lds + m.b1g, lane_off, g, zin, h);
     lrelu_inplace<4, R>(h);
+    PMARK(1);
     for (int l = 0; l < m.n_gh; ++l) {
       BGM_NO_HOIST();
       f32x4 h2[R][4];
@@ -146,29 +176,46 @@ __device__ __forceinline__ void causal_logp(const float *lds, const CausalMeta &
 #pragma unroll
           for (int r = 0; r < 4; ++r) h[rr][t][r] = lrelu(h2[rr][t][r]);
     }
+    PMARK(2);
 #pragma unroll
     for (int rr = 0; rr < R; ++rr) { ssq[rr] = 0.0f; sraw_v[rr] = 0.0f; }
     const int pc = m.p - 16 * (NTL - 1);  // position of feature p inside the last tile
     g_last_groups<0, 4, NTL, R>(lds + m.wgl, lds + m.bgl, lane_off, g, pc - 4 * g, h, vreg, ssq, sraw_v);
 #pragma unroll
     for (int rr = 0; rr < R; ++rr) sraw_v[rr] = __shfl(sraw_v[rr], j + 16 * (pc >> 2));
+    PMARK(3);
   }
-  // ---- f : (z0, z1, x) -> (mu_y, s_y)   (base.py:793-798)
-  float mu_y[R], sr_y[R];
-  {
-    f32x4 a1[R][4];
-    dense<KT1, KSL1, 4, R>(lds + m.w1f, lds + m.b1f, lane_off, g, zin, a1);
-    lrelu_inplace<4, R>(a1);
-    fh_tail<R>(lds, m.wf2, m.bf2, m.wf3, m.bf3, m.wf4, m.bf4, lane_off, g, a1, mu_y, sr_y);
+  // ---- f : (z0, z1, x) -> (mu_y, s_y)   (base.py:793-798)  and  h : (z0, z2) -> (mu_x | logit, s_x)   (:786-791)
+  float mu_y[R], sr_y[R], mu_x[R], sr_x[R];
+  if constexpr (R == 1) {   // the two small nets in lock step (see dense_pair)
+    f32x4 f1[1][4], h1[1][4];
+    dense_pair<KT1, KSL1, 4>(lds + m.w1f, lds + m.b1f, lds + m.w1h, lds + m.b1h, lane_off, g, zin, zin, f1, h1);
+    lrelu_inplace<4, 1>(f1); lrelu_inplace<4, 1>(h1);
+    f32x4 f2[1][2], h2[1][2];
+    dense_pair<4, 4, 2>(lds + m.wf2, lds + m.bf2, lds + m.wh2, lds + m.bh2, lane_off, g, f1, h1, f2, h2);
+    lrelu_inplace<2, 1>(f2); lrelu_inplace<2, 1>(h2);
+    f32x4 f3[1][1], h3[1][1];
+    dense_pair<2, 4, 1>(lds + m.wf3, lds + m.bf3, lds + m.wh3, lds + m.bh3, lane_off, g, f2, h2, f3, h3);
+    lrelu_inplace<1, 1>(f3); lrelu_inplace<1, 1>(h3);
+    f32x4 f4[1][1], h4[1][1];
+    dense_pair<1, 4, 1>(lds + m.wf4, lds + m.bf4, lds + m.wh4, lds + m.bh4, lane_off, g, f3, h3, f4, h4);
+    mu_y[0] = f4[0][0][0]; sr_y[0] = f4[0][0][1];
+    mu_x[0] = h4[0][0][0]; sr_x[0] = h4[0][0][1];
+  } else {
+    {
+      f32x4 a1[R][4];
+      dense<KT1, KSL1, 4, R>(lds + m.w1f, lds + m.b1f, lane_off, g, zin, a1);
+      lrelu_inplace<4, R>(a1);
+      fh_tail<R>(lds, m.wf2, m.bf2, m.wf3, m.bf3, m.wf4, m.bf4, lane_off, g, a1, mu_y, sr_y);
+    }
+    {
+      f32x4 a1[R][4];
+      dense<KT1, KSL1, 4, R>(lds + m.w1h, lds + m.b1h, lane_off, g, zin, a1);
+      lrelu_inplace<4, R>(a1);
+      fh_tail<R>(lds, m.wh2, m.bh2, m.wh3, m.bh3, m.wh4, m.bh4, lane_off, g, a1, mu_x, sr_x);
+    }
   }
-  // ---- h : (z0, z2) -> (mu_x | logit, s_x)   (base.py:786-791)
-  float mu_x[R], sr_x[R];
-  {
-    f32x4 a1[R][4];
-    dense<KT1, KSL1, 4, R>(lds + m.w1h, lds + m.b1h, lane_off, g, zin, a1);
-    lrelu_inplace<4, R>(a1);
-    fh_tail<R>(lds, m.wh2, m.bh2, m.wh3, m.bh3, m.wh4, m.bh4, lane_off, g, a1, mu_x, sr_x);
-  }
+  PMARK(4);
   // ---- assemble -(loss_v + loss_x + loss_y + |z|^2/2)   (base.py:800-816)
   // mu_x/sr_x/mu_y/sr_y are valid in lane group 0 only: their losses are evaluated there and
   // folded into the per-lane partial that is summed over g, so one reduction serves all terms.
@@ -289,7 +336,12 @@ __global__ __launch_bounds__(64 * WAVES) void causal_logpost_kernel(const float 
     load_v_rows<NTL, R>(v, n, m.p, row0, j, g, vreg);
     f32x4 zin[R][KT1];
     load_z_rows<KT1, R>(z, n, m.q, row0, j, g, xr, zin);
+#ifdef BGM_PROF
+    unsigned long long tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+    causal_logp<KT1, KSL1, NTL, R>(lds, m, lane_off, g, j, zin, vreg, xr, yr, lp, tsec, tlast);
+#else
     causal_logp<KT1, KSL1, NTL, R>(lds, m, lane_off, g, j, zin, vreg, xr, yr, lp);
+#endif
 #pragma unroll
     for (int rr = 0; rr < R; ++rr) {
       const long long row = row0 + 16 * rr + j;
@@ -393,6 +445,9 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
   const long long slot = (long long)blockIdx.x * WAVES + wave;
   const long long n_slots = (long long)gridDim.x * WAVES;
   const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#ifdef BGM_PROF
+  unsigned long long tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+#endif
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   volatile int *prog = reinterpret_cast<volatile int *>(lds + m.total);   // [WAVES] progress counters after the blob
   if (lane == 0) prog[wave_u] = 0;
@@ -428,7 +483,12 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
             zs[rr][t][r] = (f < m.q) ? e[r] : (f == m.q ? xr[rr] : 0.0f);
           }
         }
+#ifdef BGM_PROF
+      { unsigned long long tsec0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast0 = 0;
+        causal_logp<KT1, KSL1, NTL, R>(lds, m, lane_off, g, j, zs, vreg, xr, yr, lp, tsec0, tlast0); }
+#else
       causal_logp<KT1, KSL1, NTL, R>(lds, m, lane_off, g, j, zs, vreg, xr, yr, lp);
+#endif
     } else {
       load_z_rows<KT1, R>(a.state, n, m.q, row0, j, g, xr, zs);
 #pragma unroll
@@ -440,12 +500,20 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
     }
 
     uint4 uacc[R];
+#ifdef BGM_PROF
+    tlast = __builtin_readcyclecounter();
+#endif
     for (int it = a.it_begin; it < a.it_begin + a.n_iters; ++it) {
       BGM_NO_HOIST();
+      PMARK(7);
       // The two waves that share a SIMD (w, w+4) are arbitrated oldest-first: left alone the older one
       // runs ahead, finishes ~30 % early and leaves the younger wave by itself on the SIMD at low MFMA
       // utilisation (measured: waves 0-3 done at 45 ms, waves 4-7 at 63 ms).  Each wave publishes its
       // progress in LDS and raises its priority only while it is behind its partner.
+      // The two waves that share a SIMD (w, w+4) are arbitrated oldest-first: left alone the older one runs
+      // ahead, finishes ~30 % early and leaves the younger wave by itself on the SIMD (measured: waves 0-3 done
+      // at 45 ms, waves 4-7 at 63 ms).  Each wave publishes its progress in LDS and raises its priority only
+      // while it is behind its partner.
       if constexpr (WAVES == 8) {
         const int mine = tiles_done * a.n_iters + (it - a.it_begin);
         if (lane == 0) prog[wave_u] = mine;
@@ -466,7 +534,13 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
           }
         }
       float lpp[R];
+      PMARK(0);
+#ifdef BGM_PROF
+      causal_logp<KT1, KSL1, NTL, R>(lds, m, lane_off, g, j, zp, vreg, xr, yr, lpp, tsec, tlast);
+#else
       causal_logp<KT1, KSL1, NTL, R>(lds, m, lane_off, g, j, zp, vreg, xr, yr, lpp);
+#endif
+      PMARK(5);
       // ---- accept / reject   (base.py:868-871).  u(it) = word (it & 3) of Philox(row, it >> 2, 0, TAG_ACC)
       if ((it & 3) == 0 || it == a.it_begin) {
 #pragma unroll
@@ -490,6 +564,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
       // atomics/s on one address and saturate it (measured: -30 % kernel throughput)
       if (a.acc_count != nullptr && lane == 0) a.acc_count[slot * (long long)a.n_iters + (it - a.it_begin)] += (unsigned)accmask;
 
+      PMARK(6);
       if (it >= a.burn_in) {
         const long long d = it - a.burn_in;
         if (a.draws != nullptr) {  // samples.append(current_state.copy())  (base.py:896)
@@ -526,6 +601,9 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
     ++tiles_done;
   }
   if (lane == 0) prog[wave_u] = 0x7fffffff;   // finished: the partner never needs to catch up
+#ifdef BGM_PROF
+  if (a.clk != nullptr && lane == 0 && slot == 0) for (int i = 0; i < 8; ++i) a.clk[4ll * gridDim.x * WAVES + i] = tsec[i];
+#endif
   if (a.clk != nullptr && lane == 0) {   // [n_slots][4]: cycles, 100 MHz ticks, start tick, XCC id
     a.clk[4 * slot + 0] = __builtin_readcyclecounter() - clk_c0;
     a.clk[4 * slot + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
