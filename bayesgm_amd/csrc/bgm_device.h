@@ -289,6 +289,529 @@ __device__ __forceinline__ unsigned lds_byte_addr(const float *p) {
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// The four hidden->hidden layers of the g net (64 x 64 each) as ONE hand-scheduled block.
+// Between two layers the compiler-scheduled path pays bias loads + the first A fragments + the MFMA drain + a
+// 32-instruction LeakyReLU, ~580 cycles per layer with the matrix pipe empty (measured).  Here the activation sets
+// live in fixed registers (P = v208-v223, Q = v224-v239) and alternate as B operands / accumulators; a layer's
+// accumulator tuples are loaded with the bias as soon as the previous layer has consumed them as inputs, the A
+// fragments stream two K-steps ahead ACROSS layer boundaries, and LeakyReLU is applied to one input element per
+// K-step, just in time.  Software-managed hazards: counted lgkmcnt per LDS load, s_nop between the last MFMA of a
+// layer and the first VALU read of its result.
+//   w_addr: LDS byte address of this lane's fragment of layer 0, K-step 0 (layers are 16 KiB apart);
+//   b_addr: LDS byte address of bias feature 4g of layer 0 (layers 256 B apart).
+//   p: in = activated input, out = RAW output of the 4th layer (caller applies LeakyReLU);  q: scratch set.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dense_hidden4_asm(unsigned w_addr, unsigned b_addr, f32x4 (&p)[4], f32x4 (&q)[4]) {
+  asm volatile(
+      "s_waitcnt lgkmcnt(0)\n"
+      "ds_read_b128 v[224:227], %9 offset:0\n"
+      "ds_read_b128 v[228:231], %9 offset:64\n"
+      "ds_read_b128 v[232:235], %9 offset:128\n"
+      "ds_read_b128 v[236:239], %9 offset:192\n"
+      "ds_read_b128 v[244:247], %8 offset:0\n"
+      "ds_read_b128 v[248:251], %8 offset:256\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v244, v208, v[224:227]\n"
+      "ds_read_b128 v[252:255], %8 offset:512\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v245, v208, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v246, v208, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v247, v208, v[236:239]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v248, v209, v[224:227]\n"
+      "ds_read_b128 v[244:247], %8 offset:768\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v249, v209, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v250, v209, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v251, v209, v[236:239]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v252, v210, v[224:227]\n"
+      "ds_read_b128 v[248:251], %8 offset:4096\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v253, v210, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v254, v210, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v255, v210, v[236:239]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v244, v211, v[224:227]\n"
+      "ds_read_b128 v[252:255], %8 offset:4352\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v245, v211, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v246, v211, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v247, v211, v[236:239]\n"
+      "ds_read_b128 v[208:211], %9 offset:256\n"
+      "s_waitcnt lgkmcnt(2)\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v248, v212, v[224:227]\n"
+      "ds_read_b128 v[244:247], %8 offset:4608\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v249, v212, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v250, v212, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v251, v212, v[236:239]\n"
+      "s_waitcnt lgkmcnt(2)\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v252, v213, v[224:227]\n"
+      "ds_read_b128 v[248:251], %8 offset:4864\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v253, v213, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v254, v213, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v255, v213, v[236:239]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v244, v214, v[224:227]\n"
+      "ds_read_b128 v[252:255], %8 offset:8192\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v245, v214, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v246, v214, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v247, v214, v[236:239]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v248, v215, v[224:227]\n"
+      "ds_read_b128 v[244:247], %8 offset:8448\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v249, v215, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v250, v215, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v251, v215, v[236:239]\n"
+      "ds_read_b128 v[212:215], %9 offset:320\n"
+      "s_waitcnt lgkmcnt(2)\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v252, v216, v[224:227]\n"
+      "ds_read_b128 v[248:251], %8 offset:8704\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v253, v216, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v254, v216, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v255, v216, v[236:239]\n"
+      "s_waitcnt lgkmcnt(2)\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v244, v217, v[224:227]\n"
+      "ds_read_b128 v[252:255], %8 offset:8960\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v245, v217, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v246, v217, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v247, v217, v[236:239]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v248, v218, v[224:227]\n"
+      "ds_read_b128 v[244:247], %8 offset:12288\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v249, v218, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v250, v218, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v251, v218, v[236:239]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v252, v219, v[224:227]\n"
+      "ds_read_b128 v[248:251], %8 offset:12544\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v253, v219, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v254, v219, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v255, v219, v[236:239]\n"
+      "ds_read_b128 v[216:219], %9 offset:384\n"
+      "s_waitcnt lgkmcnt(2)\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v244, v220, v[224:227]\n"
+      "ds_read_b128 v[252:255], %8 offset:12800\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v245, v220, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v246, v220, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v247, v220, v[236:239]\n"
+      "s_waitcnt lgkmcnt(2)\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v248, v221, v[224:227]\n"
+      "ds_read_b128 v[244:247], %8 offset:13056\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v249, v221, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v250, v221, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v251, v221, v[236:239]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v252, v222, v[224:227]\n"
+      "ds_read_b128 v[248:251], %8 offset:16384\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v253, v222, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v254, v222, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v255, v222, v[236:239]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v244, v223, v[224:227]\n"
+      "ds_read_b128 v[252:255], %8 offset:16640\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v245, v223, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v246, v223, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v247, v223, v[236:239]\n"
+      "ds_read_b128 v[220:223], %9 offset:448\n"
+      "s_nop 15\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v224\n"
+      "v_max_f32 v224, v224, v243\n"
+      "s_waitcnt lgkmcnt(2)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v225\n"
+      "v_max_f32 v225, v225, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v248, v224, v[208:211]\n"
+      "ds_read_b128 v[244:247], %8 offset:16896\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v249, v224, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v250, v224, v[216:219]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v251, v224, v[220:223]\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v226\n"
+      "v_max_f32 v226, v226, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v252, v225, v[208:211]\n"
+      "ds_read_b128 v[248:251], %8 offset:17152\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v253, v225, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v254, v225, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v255, v225, v[220:223]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v227\n"
+      "v_max_f32 v227, v227, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v244, v226, v[208:211]\n"
+      "ds_read_b128 v[252:255], %8 offset:20480\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v245, v226, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v246, v226, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v247, v226, v[220:223]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v228\n"
+      "v_max_f32 v228, v228, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v248, v227, v[208:211]\n"
+      "ds_read_b128 v[244:247], %8 offset:20736\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v249, v227, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v250, v227, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v251, v227, v[220:223]\n"
+      "ds_read_b128 v[224:227], %9 offset:512\n"
+      "s_waitcnt lgkmcnt(2)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v229\n"
+      "v_max_f32 v229, v229, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v252, v228, v[208:211]\n"
+      "ds_read_b128 v[248:251], %8 offset:20992\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v253, v228, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v254, v228, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v255, v228, v[220:223]\n"
+      "s_waitcnt lgkmcnt(2)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v230\n"
+      "v_max_f32 v230, v230, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v244, v229, v[208:211]\n"
+      "ds_read_b128 v[252:255], %8 offset:21248\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v245, v229, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v246, v229, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v247, v229, v[220:223]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v231\n"
+      "v_max_f32 v231, v231, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v248, v230, v[208:211]\n"
+      "ds_read_b128 v[244:247], %8 offset:24576\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v249, v230, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v250, v230, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v251, v230, v[220:223]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v232\n"
+      "v_max_f32 v232, v232, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v252, v231, v[208:211]\n"
+      "ds_read_b128 v[248:251], %8 offset:24832\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v253, v231, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v254, v231, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v255, v231, v[220:223]\n"
+      "ds_read_b128 v[228:231], %9 offset:576\n"
+      "s_waitcnt lgkmcnt(2)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v233\n"
+      "v_max_f32 v233, v233, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v244, v232, v[208:211]\n"
+      "ds_read_b128 v[252:255], %8 offset:25088\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v245, v232, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v246, v232, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v247, v232, v[220:223]\n"
+      "s_waitcnt lgkmcnt(2)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v234\n"
+      "v_max_f32 v234, v234, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v248, v233, v[208:211]\n"
+      "ds_read_b128 v[244:247], %8 offset:25344\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v249, v233, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v250, v233, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v251, v233, v[220:223]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v235\n"
+      "v_max_f32 v235, v235, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v252, v234, v[208:211]\n"
+      "ds_read_b128 v[248:251], %8 offset:28672\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v253, v234, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v254, v234, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v255, v234, v[220:223]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v236\n"
+      "v_max_f32 v236, v236, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v244, v235, v[208:211]\n"
+      "ds_read_b128 v[252:255], %8 offset:28928\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v245, v235, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v246, v235, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v247, v235, v[220:223]\n"
+      "ds_read_b128 v[232:235], %9 offset:640\n"
+      "s_waitcnt lgkmcnt(2)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v237\n"
+      "v_max_f32 v237, v237, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v248, v236, v[208:211]\n"
+      "ds_read_b128 v[244:247], %8 offset:29184\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v249, v236, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v250, v236, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v251, v236, v[220:223]\n"
+      "s_waitcnt lgkmcnt(2)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v238\n"
+      "v_max_f32 v238, v238, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v252, v237, v[208:211]\n"
+      "ds_read_b128 v[248:251], %8 offset:29440\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v253, v237, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v254, v237, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v255, v237, v[220:223]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v239\n"
+      "v_max_f32 v239, v239, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v244, v238, v[208:211]\n"
+      "ds_read_b128 v[252:255], %8 offset:32768\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v245, v238, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v246, v238, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v247, v238, v[220:223]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v248, v239, v[208:211]\n"
+      "ds_read_b128 v[244:247], %8 offset:33024\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v249, v239, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v250, v239, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v251, v239, v[220:223]\n"
+      "ds_read_b128 v[236:239], %9 offset:704\n"
+      "s_nop 15\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v208\n"
+      "v_max_f32 v208, v208, v243\n"
+      "s_waitcnt lgkmcnt(2)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v209\n"
+      "v_max_f32 v209, v209, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v252, v208, v[224:227]\n"
+      "ds_read_b128 v[248:251], %8 offset:33280\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v253, v208, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v254, v208, v[232:235]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v255, v208, v[236:239]\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v210\n"
+      "v_max_f32 v210, v210, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v244, v209, v[224:227]\n"
+      "ds_read_b128 v[252:255], %8 offset:33536\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v245, v209, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v246, v209, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v247, v209, v[236:239]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v211\n"
+      "v_max_f32 v211, v211, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v248, v210, v[224:227]\n"
+      "ds_read_b128 v[244:247], %8 offset:36864\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v249, v210, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v250, v210, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v251, v210, v[236:239]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v212\n"
+      "v_max_f32 v212, v212, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v252, v211, v[224:227]\n"
+      "ds_read_b128 v[248:251], %8 offset:37120\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v253, v211, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v254, v211, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v255, v211, v[236:239]\n"
+      "ds_read_b128 v[208:211], %9 offset:768\n"
+      "s_waitcnt lgkmcnt(2)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v213\n"
+      "v_max_f32 v213, v213, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v244, v212, v[224:227]\n"
+      "ds_read_b128 v[252:255], %8 offset:37376\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v245, v212, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v246, v212, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v247, v212, v[236:239]\n"
+      "s_waitcnt lgkmcnt(2)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v214\n"
+      "v_max_f32 v214, v214, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v248, v213, v[224:227]\n"
+      "ds_read_b128 v[244:247], %8 offset:37632\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v249, v213, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v250, v213, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v251, v213, v[236:239]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v215\n"
+      "v_max_f32 v215, v215, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v252, v214, v[224:227]\n"
+      "ds_read_b128 v[248:251], %8 offset:40960\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v253, v214, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v254, v214, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v255, v214, v[236:239]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v216\n"
+      "v_max_f32 v216, v216, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v244, v215, v[224:227]\n"
+      "ds_read_b128 v[252:255], %8 offset:41216\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v245, v215, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v246, v215, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v247, v215, v[236:239]\n"
+      "ds_read_b128 v[212:215], %9 offset:832\n"
+      "s_waitcnt lgkmcnt(2)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v217\n"
+      "v_max_f32 v217, v217, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v248, v216, v[224:227]\n"
+      "ds_read_b128 v[244:247], %8 offset:41472\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v249, v216, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v250, v216, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v251, v216, v[236:239]\n"
+      "s_waitcnt lgkmcnt(2)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v218\n"
+      "v_max_f32 v218, v218, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v252, v217, v[224:227]\n"
+      "ds_read_b128 v[248:251], %8 offset:41728\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v253, v217, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v254, v217, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v255, v217, v[236:239]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v219\n"
+      "v_max_f32 v219, v219, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v244, v218, v[224:227]\n"
+      "ds_read_b128 v[252:255], %8 offset:45056\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v245, v218, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v246, v218, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v247, v218, v[236:239]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v220\n"
+      "v_max_f32 v220, v220, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v248, v219, v[224:227]\n"
+      "ds_read_b128 v[244:247], %8 offset:45312\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v249, v219, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v250, v219, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v251, v219, v[236:239]\n"
+      "ds_read_b128 v[216:219], %9 offset:896\n"
+      "s_waitcnt lgkmcnt(2)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v221\n"
+      "v_max_f32 v221, v221, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v252, v220, v[224:227]\n"
+      "ds_read_b128 v[248:251], %8 offset:45568\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v253, v220, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v254, v220, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v255, v220, v[236:239]\n"
+      "s_waitcnt lgkmcnt(2)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v222\n"
+      "v_max_f32 v222, v222, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v244, v221, v[224:227]\n"
+      "ds_read_b128 v[252:255], %8 offset:45824\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v245, v221, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v246, v221, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v247, v221, v[236:239]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v223\n"
+      "v_max_f32 v223, v223, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v248, v222, v[224:227]\n"
+      "ds_read_b128 v[244:247], %8 offset:49152\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v249, v222, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v250, v222, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v251, v222, v[236:239]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 v[224:227], v252, v223, v[224:227]\n"
+      "ds_read_b128 v[248:251], %8 offset:49408\n"
+      "v_mfma_f32_16x16x4_f32 v[228:231], v253, v223, v[228:231]\n"
+      "v_mfma_f32_16x16x4_f32 v[232:235], v254, v223, v[232:235]\n"
+      "v_mfma_f32_16x16x4_f32 v[236:239], v255, v223, v[236:239]\n"
+      "ds_read_b128 v[220:223], %9 offset:960\n"
+      "s_nop 15\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v224\n"
+      "v_max_f32 v224, v224, v243\n"
+      "s_waitcnt lgkmcnt(2)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v225\n"
+      "v_max_f32 v225, v225, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v244, v224, v[208:211]\n"
+      "ds_read_b128 v[252:255], %8 offset:49664\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v245, v224, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v246, v224, v[216:219]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v247, v224, v[220:223]\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v226\n"
+      "v_max_f32 v226, v226, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v248, v225, v[208:211]\n"
+      "ds_read_b128 v[244:247], %8 offset:49920\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v249, v225, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v250, v225, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v251, v225, v[220:223]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v227\n"
+      "v_max_f32 v227, v227, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v252, v226, v[208:211]\n"
+      "ds_read_b128 v[248:251], %8 offset:53248\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v253, v226, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v254, v226, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v255, v226, v[220:223]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v228\n"
+      "v_max_f32 v228, v228, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v244, v227, v[208:211]\n"
+      "ds_read_b128 v[252:255], %8 offset:53504\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v245, v227, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v246, v227, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v247, v227, v[220:223]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v229\n"
+      "v_max_f32 v229, v229, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v248, v228, v[208:211]\n"
+      "ds_read_b128 v[244:247], %8 offset:53760\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v249, v228, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v250, v228, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v251, v228, v[220:223]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v230\n"
+      "v_max_f32 v230, v230, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v252, v229, v[208:211]\n"
+      "ds_read_b128 v[248:251], %8 offset:54016\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v253, v229, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v254, v229, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v255, v229, v[220:223]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v231\n"
+      "v_max_f32 v231, v231, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v244, v230, v[208:211]\n"
+      "ds_read_b128 v[252:255], %8 offset:57344\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v245, v230, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v246, v230, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v247, v230, v[220:223]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v232\n"
+      "v_max_f32 v232, v232, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v248, v231, v[208:211]\n"
+      "ds_read_b128 v[244:247], %8 offset:57600\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v249, v231, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v250, v231, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v251, v231, v[220:223]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v233\n"
+      "v_max_f32 v233, v233, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v252, v232, v[208:211]\n"
+      "ds_read_b128 v[248:251], %8 offset:57856\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v253, v232, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v254, v232, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v255, v232, v[220:223]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v234\n"
+      "v_max_f32 v234, v234, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v244, v233, v[208:211]\n"
+      "ds_read_b128 v[252:255], %8 offset:58112\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v245, v233, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v246, v233, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v247, v233, v[220:223]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v235\n"
+      "v_max_f32 v235, v235, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v248, v234, v[208:211]\n"
+      "ds_read_b128 v[244:247], %8 offset:61440\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v249, v234, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v250, v234, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v251, v234, v[220:223]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v236\n"
+      "v_max_f32 v236, v236, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v252, v235, v[208:211]\n"
+      "ds_read_b128 v[248:251], %8 offset:61696\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v253, v235, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v254, v235, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v255, v235, v[220:223]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v237\n"
+      "v_max_f32 v237, v237, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v244, v236, v[208:211]\n"
+      "ds_read_b128 v[252:255], %8 offset:61952\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v245, v236, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v246, v236, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v247, v236, v[220:223]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v238\n"
+      "v_max_f32 v238, v238, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v248, v237, v[208:211]\n"
+      "ds_read_b128 v[244:247], %8 offset:62208\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v249, v237, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v250, v237, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v251, v237, v[220:223]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mul_f32 v243, 0x3e4ccccd, v239\n"
+      "v_max_f32 v239, v239, v243\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v252, v238, v[208:211]\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v253, v238, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v254, v238, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v255, v238, v[220:223]\n"
+      "s_waitcnt lgkmcnt(0)\n"
+      "v_mfma_f32_16x16x4_f32 v[208:211], v244, v239, v[208:211]\n"
+      "v_mfma_f32_16x16x4_f32 v[212:215], v245, v239, v[212:215]\n"
+      "v_mfma_f32_16x16x4_f32 v[216:219], v246, v239, v[216:219]\n"
+      "v_mfma_f32_16x16x4_f32 v[220:223], v247, v239, v[220:223]\n"
+      "s_nop 15\n"
+      "s_waitcnt lgkmcnt(0)\n"
+      : "+{v[208:211]}"(p[0]), "+{v[212:215]}"(p[1]), "+{v[216:219]}"(p[2]), "+{v[220:223]}"(p[3]),
+        "=&{v[224:227]}"(q[0]), "=&{v[228:231]}"(q[1]), "=&{v[232:235]}"(q[2]), "=&{v[236:239]}"(q[3])
+      : "v"(w_addr), "v"(b_addr)
+      : "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
+}
+
 // One tile group [T0, T0+GS) of a layer.  KT input tiles, the last of which
 // uses KSL (1..4) K-steps.  `wl` points at the layer's packed weights in LDS,
 // `lane_off` = (64 g + j).

@@ -165,16 +165,29 @@ __device__ __forceinline__ void causal_logp(const float *lds, const CausalMeta &
     dense<KT1, KSL1, 4, R>(lds + m.w1g, lds + m.b1g, lane_off, g, zin, h);
     lrelu_inplace<4, R>(h);
     PMARK(1);
-    for (int l = 0; l < m.n_gh; ++l) {
-      BGM_NO_HOIST();
-      f32x4 h2[R][4];
-      dense<4, 4, 4, R>(lds + m.wg + l * 4096, lds + m.bg + l * 64, lane_off, g, h, h2);
+    bool hidden_done = false;
+#ifndef BGM_NO_ASM_HIDDEN4
+    if constexpr (R == 1) {
+      if (m.n_gh == 4) {   // g_units = [64]*5 (every shipped config): all four hidden layers as one scheduled block
+        f32x4 q[4];
+        dense_hidden4_asm(lds_byte_addr(lds + m.wg + lane_off * 4), lds_byte_addr(lds + m.bg + 4 * g), h[0], q);
+        lrelu_inplace<4, 1>(h);
+        hidden_done = true;
+      }
+    }
+#endif
+    if (!hidden_done) {
+      for (int l = 0; l < m.n_gh; ++l) {
+        BGM_NO_HOIST();
+        f32x4 h2[R][4];
+        dense<4, 4, 4, R>(lds + m.wg + l * 4096, lds + m.bg + l * 64, lane_off, g, h, h2);
 #pragma unroll
-      for (int rr = 0; rr < R; ++rr)
+        for (int rr = 0; rr < R; ++rr)
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+          for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) h[rr][t][r] = lrelu(h2[rr][t][r]);
+            for (int r = 0; r < 4; ++r) h[rr][t][r] = lrelu(h2[rr][t][r]);
+      }
     }
     PMARK(2);
 #pragma unroll

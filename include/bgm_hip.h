@@ -336,6 +336,9 @@ int bgm_bgm_fit_end(bgm_handle *h, void *stream);
 /* Measurement aid: effective shader clock (MHz) and fp32-MFMA rate (TFLOP/s) of this device under a
  * back-to-back v_mfma_f32_16x16x4_f32 load on every CU (8 waves/CU, `iters` x 16 MFMAs per wave).
  * Synchronous.  Used by bench.py to state the roofline at the clock the chip actually sustains. */
+/* Debug: throughput of the hand-scheduled 64x4-tile MFMA block alone (mode 1: fragments streamed from LDS; mode 0:
+ * register operands only) with `waves_per_cu` waves on every CU. */
+int bgm_debug_group_probe(bgm_handle *h, int32_t mode, int32_t waves_per_cu, int32_t iters, double *mfma_tflops);
 int bgm_debug_clock_probe(bgm_handle *h, int32_t iters, double *shader_mhz, double *mfma_tflops);
 
 #ifdef __cplusplus
