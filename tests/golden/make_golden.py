@@ -52,6 +52,33 @@ def main():
     adrf["adrf_range_Imbens"] = get_ADRF(x_min=0.5, x_max=2.5, nb_intervals=7, dataset="Imbens")
     np.savez_compressed(os.path.join(HERE, "adrf_truth.npz"), **adrf)
 
+    # ---- data_io: parse_file / parse_file_triplet on tiny input files kept beside the fixtures (utils/data_io.py:33-150)
+    from bayesgm.utils.data_io import parse_file, parse_file_triplet, save_data
+    io_dir = os.path.join(HERE, "io")
+    os.makedirs(io_dir, exist_ok=True)
+    rs = np.random.RandomState(11)
+    mat = np.round(rs.randn(12, 5) * np.array([1.0, 10.0, 0.1, 3.0, 1.0]) + np.array([0, 5, -2, 0, 1.0]), 4)
+    mat[:, 4] = 2.5                                        # a constant column (StandardScaler edge case)
+    np.savetxt(os.path.join(io_dir, "mat_tab.txt"), mat, fmt="%.4f", delimiter="\t")
+    with open(os.path.join(io_dir, "mat_comma.csv"), "w") as f:
+        f.write("x,y,v1,v2,v3\n")
+        for row in mat:
+            f.write(",".join("%.4f" % t for t in row) + "\n")
+    np.savez(os.path.join(io_dir, "mat_keys.npz"), other=mat[:3], x=mat)       # 'x' is preferred over the first key
+    np.savez(os.path.join(io_dir, "mat_first.npz"), foo=mat[:7], bar=mat)      # no known key: first key wins
+    np.savez(os.path.join(io_dir, "triplet.npz"), x=mat[:, :1], y=mat[:, 1:2], v=mat[:, 2:])
+    io = {}
+    for name, kw in [("mat_tab.txt", dict(sep="\t")), ("mat_comma.csv", dict(sep=",")), ("mat_keys.npz", {}), ("mat_first.npz", {})]:
+        for norm in (True, False):
+            io[f"parse_{name}_{int(norm)}"] = parse_file(os.path.join(io_dir, name), normalize=norm, **kw)
+    for name, kw in [("mat_tab.txt", dict(sep="\t")), ("mat_comma.csv", dict(sep=",")), ("triplet.npz", {})]:
+        for norm in (True, False):
+            x_, y_, v_ = parse_file_triplet(os.path.join(io_dir, name), normalize=norm, **kw)
+            io[f"triplet_{name}_{int(norm)}_x"], io[f"triplet_{name}_{int(norm)}_y"], io[f"triplet_{name}_{int(norm)}_v"] = x_, y_, v_
+    save_data(os.path.join(io_dir, "saved.txt"), mat[:4])
+    save_data(os.path.join(io_dir, "saved.csv"), mat[:4], delimiter=",")
+    np.savez_compressed(os.path.join(HERE, "data_io.npz"), **io)
+
     gs = Gaussian_sampler(mean=np.zeros(10), sd=1.0)
     np.random.seed(5)
     gb = gs.get_batch(32)
