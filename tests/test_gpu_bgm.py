@@ -326,3 +326,48 @@ def test_bgm_default_fit_with_egm_warm_start(tmp_path):
     assert os.path.exists(os.path.join(model.save_dir, "init_data_gen_at_150.npz"))
     mse_enc = model.evaluate(data, use_x_sd=False)            # encoder path of evaluate
     assert np.isfinite(mse_enc) and mse_enc < float(np.mean(data ** 2)) * 1.5
+
+
+def test_bgm_wide_panel_properties():
+    """BASELINE config C4's row width (p = 500, wide variant) on a 120 001-row panel, through size-independent
+    properties: determinism, invariance to row blocking (Philox keyed by the global row index), agreement of sampled
+    rows with the oracle chain, acceptance statistics consistent between the full run and its blocks."""
+    import torch
+    n, p, q, burn, keep, L = 120_001, 500, 10, 6, 3, 5
+    m = _model(81, q, p)
+    rs = np.random.RandomState(82)
+    x = rs.standard_normal((n, p)).astype(np.float32)
+    x[rs.rand(n, p) < 0.1] = np.nan
+    eng = _engine(m)
+    xd = torch.from_numpy(x).cuda()
+
+    def run(lo, hi):
+        n_ = hi - lo
+        state = torch.empty((n_, q), device="cuda"); logp = torch.empty(n_, device="cuda"); grad = torch.empty((n_, q), device="cuda")
+        step = torch.full((1,), 0.02, device="cuda")
+        acc = torch.zeros(burn + keep, device="cuda", dtype=torch.int32)
+        draws = torch.empty((keep, n_, q), device="cuda")
+        eng.hmc_run(xd[lo:hi], state, logp, grad, step, 0, burn + keep, burn, L, 9, init=True, row_base=lo, acc_count=acc, draws=draws)
+        return state, logp, acc, draws
+    s1, l1, a1, d1 = run(0, n)
+    s2, l2, a2, d2 = run(0, n)
+    assert torch.equal(s1, s2) and torch.equal(l1, l2) and torch.equal(a1, a2) and torch.equal(d1, d2)
+    lo, hi = 40_016, 40_016 + 33_333
+    s3, l3, a3, d3 = run(lo, hi)
+    assert torch.equal(s1[lo:hi], s3) and torch.equal(l1[lo:hi], l3) and torch.equal(d1[:, lo:hi], d3)
+    s4, l4, a4, d4 = run(0, lo)
+    s5, l5, a5, d5 = run(hi, n)
+    assert torch.equal(a1, a3 + a4 + a5)                           # per-iteration acceptance counts add up over blocks
+    idx = np.sort(rs.choice(n, 24, replace=False))
+    obs, clean = OB.obs_mask_of(x[idx])
+    ref = []
+    for k, i in enumerate(idx):                       # fixed step size (hmc_run does not adapt): oracle transitions directly
+        xk, mk = clean[k:k + 1], obs[k:k + 1].astype(np.float32)
+        z = OB.hmc_init_state(1, q, 9, int(i)).astype(np.float32)
+        lp, gr = OB.log_posterior_and_grad(m, z, xk, mk)
+        for it in range(burn + keep):
+            z, lp, gr, _, _ = OB.hmc_transition(m, z, xk, mk, 0.02, L, it, 9, int(i), lp, gr)
+        ref.append(z[0])
+    ref = np.stack(ref)
+    got = s1.cpu().numpy()[idx]
+    assert np.all(np.abs(got - ref) <= 2e-3, axis=1).mean() >= 0.9

@@ -189,3 +189,34 @@ def test_causalbgm_default_fit_with_egm_warm_start(tmp_path):
     # Z was initialised by the encoder: data_z stays close to e(V) after one epoch at lr_z = 1e-4
     z_enc = model.engine.encode(model._dev(v)).cpu().numpy()
     assert np.abs(model.data_z.cpu().numpy() - z_enc).mean() < 0.5
+
+
+def test_large_batch_gradient_is_the_sum_of_its_shards():
+    """Size-independent property at a throughput-sized minibatch (B = 65 536 rows of a 200 000-row panel, p = 200):
+    the theta gradient of a batch equals the sum of the gradients of its two halves when both are scaled by the
+    GLOBAL batch size -- the identity the data-parallel fit relies on (each rank computes its local rows with
+    1/B_global, one all-reduce adds them) -- and is reproducible bit for bit."""
+    import torch
+    n, p, B = 200_000, 200, 65_536
+    m = _model(17, [1, 1, 1, 7], p)
+    rs = np.random.RandomState(18)
+    v = rs.standard_normal((n, p)).astype(np.float32)
+    x = rs.exponential(size=n).astype(np.float32)
+    y = (x + rs.standard_normal(n)).astype(np.float32)
+    z = rs.standard_normal((n, 10)).astype(np.float32)
+    eng = _engine(m)
+    dev = eng.device
+    xd, yd, vd, zd = (torch.from_numpy(a).to(dev) for a in (x, y, v, z))
+    idx = torch.from_numpy(rs.choice(n, B, replace=False).astype(np.int32)).to(dev)
+    npar = eng.fit_begin(n, B)
+    g_all, g_again, g_a, g_b = (torch.empty(npar, device=dev) for _ in range(4))
+    eng.fit_theta_grad(xd, yd, vd, zd, idx, B, g_all)
+    eng.fit_theta_grad(xd, yd, vd, zd, idx, B, g_again)
+    assert torch.equal(g_all, g_again)                                   # deterministic reduction order
+    eng.fit_theta_grad(xd, yd, vd, zd, idx[:B // 2].contiguous(), B, g_a, batch=B // 2)
+    eng.fit_theta_grad(xd, yd, vd, zd, idx[B // 2:].contiguous(), B, g_b, batch=B // 2)
+    ref = g_all.double()
+    err = (g_a.double() + g_b.double() - ref).abs().max().item()
+    assert err <= 2e-5 * ref.abs().max().item(), err
+    assert torch.isfinite(g_all).all() and g_all.abs().max().item() > 0
+    eng.fit_end()
