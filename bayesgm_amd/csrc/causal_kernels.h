@@ -404,17 +404,81 @@ __device__ __forceinline__ void causal_effects(const float *lds, const CausalMet
       const int k = 4 * kb + e;
       xk[e] = (EFFECT == 2) ? (e == 0 ? 1.0f : 0.0f) : x_values[k < nd ? k : nd - 1];
     }
-    f32x4 a1[DB * R][4];
-#pragma unroll
-    for (int e = 0; e < DB; ++e)
-#pragma unroll
-      for (int rr = 0; rr < R; ++rr)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) a1[e * R + rr][t][r] = lrelu(fmaf(wx[t][r], xk[e], base[rr][t][r]));
     float mu[DB * R], sr[DB * R];
-    fh_tail<DB * R>(lds, m.wf2, m.bf2, m.wf3, m.bf3, m.wf4, m.bf4, lane_off, g, a1, mu, sr);
+#ifndef BGM_NO_JIT_EFFECTS
+    if constexpr (R == 1) {
+      // The dose-specific first-layer activations a1[e] = lrelu(base + wx * x_e) are never materialised: element
+      // (t, r) is the B operand of K-step 4t + r of the second layer, so it is computed right there, between the
+      // MFMAs of the same wave (the two waves of a SIMD share its VALU issue slots as well as its matrix pipe: a
+      // separate 768-instruction VALU block per 4 doses cost its full issue time, VALU placed inside the MFMA stream
+      // of the same wave is covered by it).  Same for the LeakyReLU feeding layers 3 and 4.
+      f32x4 a2[DB][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(lds + m.bf2 + 16 * u + 4 * g);
+#pragma unroll
+        for (int e = 0; e < DB; ++e) a2[e][u] = b;
+      }
+      const float *w2 = lds + m.wf2 + lane_off * 2;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int t = s >> 2, r = s & 3;
+        AFrag<2> af;
+        af.load(w2 + (16 * t + r) * 16 * 2);
+        float bop[DB];
+#pragma unroll
+        for (int e = 0; e < DB; ++e) bop[e] = lrelu(fmaf(wx[t][r], xk[e], base[0][t][r]));
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int e = 0; e < DB; ++e) a2[e][u] = BGM_MFMA(af.get(u), bop[e], a2[e][u]);
+        // (Forcing MFMA, VALU, VALU, MFMA ... with sched_group_barrier -- with or without software-pipelining the
+        // next step's operands and fragment -- produced the intended instruction stream and was 2-3 % SLOWER than
+        // leaving the placement to the compiler: measured 5.30-5.36 s vs 5.18 s for the keep phase.)
+      }
+      f32x4 a3[DB];
+      {
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(lds + m.bf3 + 4 * g);
+#pragma unroll
+        for (int e = 0; e < DB; ++e) a3[e] = b;
+      }
+      const float *w3 = lds + m.wf3 + lane_off;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int t = s >> 2, r = s & 3;
+        const float af = w3[(16 * t + r) * 16];
+#pragma unroll
+        for (int e = 0; e < DB; ++e) a3[e] = BGM_MFMA(af, lrelu(a2[e][t][r]), a3[e]);
+      }
+      f32x4 a4[DB];
+      {
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(lds + m.bf4 + 4 * g);
+#pragma unroll
+        for (int e = 0; e < DB; ++e) a4[e] = b;
+      }
+      const float *w4 = lds + m.wf4 + lane_off;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float af = w4[s * 16];
+#pragma unroll
+        for (int e = 0; e < DB; ++e) a4[e] = BGM_MFMA(af, lrelu(a3[e][s]), a4[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < DB; ++e) { mu[e] = a4[e][0]; sr[e] = a4[e][1]; }
+    } else
+#endif
+    {
+      f32x4 a1[DB * R][4];
+#pragma unroll
+      for (int e = 0; e < DB; ++e)
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a1[e * R + rr][t][r] = lrelu(fmaf(wx[t][r], xk[e], base[rr][t][r]));
+      fh_tail<DB * R>(lds, m.wf2, m.bf2, m.wf3, m.bf3, m.wf4, m.bf4, lane_off, g, a1, mu, sr);
+    }
     float yk[DB][R];
 #pragma unroll
     for (int e = 0; e < DB; ++e)
