@@ -288,3 +288,136 @@ class EgmState(object):
         losses, gr = gen_step_grads(self.nets, self.dz, self.p, z, v, x, y)
         self.g_opt.step(gen_param_list(gr))
         return losses
+
+
+# =============================================================================================
+# BGM's EGM warm start (bgm/base.py:190-340): generator = BaseVariationalNet called with training=True (input
+# BatchNorm on batch statistics, moving averages updated by every call), encoder e, LSGAN discriminators dz (latent)
+# and dx (data) with targets 0.9 / 0.1, optional gradient penalty `gamma`, Adam(lr, beta1 0.5, beta2 0.9).
+# =============================================================================================
+def g_backward(g, c, dmean, ds_raw, want_dz=True):
+    """Backward of BaseVariationalNet (training mode) given dLoss/dmean and dLoss/d(s_raw) [B x p].
+    c = cache of oracle.bgm.g_train_forward.  -> (grads dict like oracle.bgm.g_loss_and_grads, dz | None)."""
+    from .bgm import LEAK as _LEAK
+    h = c["acts"][-1]
+    grads = {"mean": (h.T @ dmean, dmean.sum(0)), "var": (h.T @ ds_raw, ds_raw.sum(0))}
+    dh = dmean @ g["mean"][0].T + ds_raw @ g["var"][0].T
+    tg = [None] * len(g["trunk"])
+    for i in reversed(range(len(g["trunk"]))):
+        dh = dh * np.where(c["pres"][i] > 0, 1.0, _LEAK).astype(dh.dtype)
+        tg[i] = (c["acts"][i].T @ dh, dh.sum(0))
+        dh = dh @ g["trunk"][i][0].T
+    grads["trunk"] = tg
+    grads["gamma"] = (dh * c["zhat"]).sum(0)
+    grads["beta"] = dh.sum(0)
+    dz = None
+    if want_dz:
+        dzhat = dh * g["bn"]["gamma"]
+        dz = c["inv"] * (dzhat - dzhat.mean(0) - c["zhat"] * (dzhat * c["zhat"]).mean(0))
+    return grads, dz
+
+
+def _add_g(a, b):
+    out = {"gamma": a["gamma"] + b["gamma"], "beta": a["beta"] + b["beta"],
+           "trunk": [(wa + wb, ba + bb) for (wa, ba), (wb, bb) in zip(a["trunk"], b["trunk"])]}
+    for k in ("mean", "var"):
+        out[k] = (a[k][0] + b[k][0], a[k][1] + b[k][1])
+    return out
+
+
+def bgm_gen_step_grads(g, e, dz, dx, z, x, n1, n2, alpha):
+    """train_gen_step (bgm/base.py:246-289).  n1, n2: the reparameterisation noise of the two generator calls.
+    -> (losses [g_adv, e_adv, l2_z, l2_x, reg, total], grads {'g': dict, 'e': [(dW, db)..]}, [cache1, cache2])"""
+    from .bgm import g_train_forward
+    B, q = z.shape
+    p = x.shape[1]
+    mu1, s21, c1 = g_train_forward(g, z)
+    x_ = n1 * np.sqrt(s21) + mu1
+    reg = (s21 ** 2).mean()
+    z_, ce1 = N.mlp_forward_cache(e, x)
+    z__, ce2 = N.mlp_forward_cache(e, x_)
+    mu2, s22, c2 = g_train_forward(g, z_)
+    x__ = n2 * np.sqrt(s22) + mu2
+    dxo, cdx = disc_forward(dx, x_)
+    dzo, cdz = disc_forward(dz, z_)
+    l2_x = ((x - x__) ** 2).mean()
+    l2_z = ((z - z__) ** 2).mean()
+    g_adv = ((0.9 - dxo) ** 2).mean()
+    e_adv = ((0.9 - dzo) ** 2).mean()
+    total = g_adv + e_adv + 10.0 * (l2_x + l2_z) + alpha * reg
+    # ---- backward
+    dx__ = 10.0 * (-2.0 / (B * p)) * (x - x__)
+    gg2, dz_ = g_backward(g, c2, dx__, dx__ * n2 * 0.5 / np.sqrt(s22) * N.sigmoid(c2["s_raw"]))
+    dz__ = 10.0 * (-2.0 / (B * q)) * (z - z__)
+    ge2, dx_ = N.mlp_backward(e, ce2, dz__)
+    _, dx_d = disc_backward(dx, cdx, -2.0 * (0.9 - dxo) / B)
+    dx_ = dx_ + dx_d
+    ds21 = dx_ * n1 * 0.5 / np.sqrt(s21) + alpha * 2.0 * s21 / (B * p)
+    gg1, _ = g_backward(g, c1, dx_, ds21 * N.sigmoid(c1["s_raw"]), want_dz=False)
+    _, dz_d = disc_backward(dz, cdz, -2.0 * (0.9 - dzo) / B)
+    ge1, _ = N.mlp_backward(e, ce1, dz_ + dz_d)
+    grads = {"g": _add_g(gg1, gg2), "e": [(wa + wb, ba + bb) for (wa, ba), (wb, bb) in zip(ge1, ge2)]}
+    return np.array([g_adv, e_adv, l2_z, l2_x, reg, total]), grads, [c1, c2]
+
+
+def bgm_disc_step_grads(g, e, dz, dx, z, x, n1, eps_z, eps_x, gamma):
+    """train_disc_step (bgm/base.py:190-244) -> ([dz_loss, dx_loss, d_loss], {'dz': grads, 'dx': grads}, [cache])."""
+    from .bgm import g_train_forward
+    B = z.shape[0]
+    z_ = N.mlp_forward(e, x)
+    mu, s2, c = g_train_forward(g, z)
+    x_ = n1 * np.sqrt(s2) + mu
+    gz, gx = zero_disc_grads(dz), zero_disc_grads(dx)
+    losses = []
+    for d, gr, real, fake in ((dz, gz, z, z_), (dx, gx, x, x_)):
+        o_r, c_r = disc_forward(d, real)
+        o_f, c_f = disc_forward(d, fake)
+        losses.append((((0.9 - o_r) ** 2).mean() + ((0.1 - o_f) ** 2).mean()) / 2.0)
+        disc_backward(d, c_r, -(0.9 - o_r) / B, gr)
+        disc_backward(d, c_f, -(0.1 - o_f) / B, gr)
+    d_loss = losses[0] + losses[1]
+    if gamma != 0.0:
+        gpz, _ = gradient_penalty_and_grads(dz, z * eps_z + z_ * (1.0 - eps_z), gz, scale=gamma)
+        gpx, _ = gradient_penalty_and_grads(dx, x * eps_x + x_ * (1.0 - eps_x), gx, scale=gamma)
+        d_loss = d_loss + gamma * (gpz + gpx)
+    return np.array([losses[0], losses[1], d_loss]), {"dz": gz, "dx": gx}, [c]
+
+
+def g_param_list(g):
+    out = [g["bn"]["gamma"], g["bn"]["beta"]]
+    for W, b in g["trunk"]:
+        out += [W, b]
+    return out + [g["mean"][0], g["mean"][1], g["var"][0], g["var"][1]]
+
+
+def g_grad_list(gr):
+    out = [gr["gamma"], gr["beta"]]
+    for dW, db in gr["trunk"]:
+        out += [dW, db]
+    return out + [gr["mean"][0], gr["mean"][1], gr["var"][0], gr["var"][1]]
+
+
+class BgmEgmState(object):
+    """g (variational, training-mode BN incl. moving statistics), e, dz, dx and the two Adam(lr, 0.5, 0.9) optimizers."""
+
+    def __init__(self, g, e, dz, dx, params):
+        self.g, self.e, self.dz, self.dx, self.p = g, e, dz, dx, params
+        self.g_opt = Adam(g_param_list(g) + [a for Wb in e for a in Wb], params["lr"], 0.5, 0.9)
+        self.d_opt = Adam(disc_param_list(dz) + disc_param_list(dx), params["lr"], 0.5, 0.9)
+
+    def _move(self, caches):
+        from .bgm import bn_update_stats
+        for c in caches:
+            bn_update_stats(self.g, c)
+
+    def disc_step(self, z, x, n1, eps_z, eps_x):
+        losses, gr, caches = bgm_disc_step_grads(self.g, self.e, self.dz, self.dx, z, x, n1, eps_z, eps_x, self.p["gamma"])
+        self._move(caches)
+        self.d_opt.step(disc_param_list(gr["dz"]) + disc_param_list(gr["dx"]))
+        return losses
+
+    def gen_step(self, z, x, n1, n2):
+        losses, gr, caches = bgm_gen_step_grads(self.g, self.e, self.dz, self.dx, z, x, n1, n2, self.p["alpha"])
+        self._move(caches)
+        self.g_opt.step(g_grad_list(gr["g"]) + [a for Wb in gr["e"] for a in Wb])
+        return losses

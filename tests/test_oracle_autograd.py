@@ -304,3 +304,80 @@ def test_egm_gen_step_gradients_match_autograd():
         losses, gr = OE.gen_step_grads(nets, dz, p, z, v, xx, y)
         assert abs(losses[-1] - loss.item()) < 1e-12 and abs(losses[3] - l2x.item()) < 1e-12
         assert _max_err(OE.gen_param_list(gr), tg) < 1e-12
+
+
+def _bgm_egm_setup(rs, q=6, p=19):
+    from oracle import egm as OE
+    from oracle import nets as N
+    g = N.init_varnet(rs, q, (64, 64, 64), p, np.float64)
+    g["bn"].update(gamma=1 + 0.1 * rs.randn(q), beta=0.1 * rs.randn(q), mean=0.2 * rs.randn(q), var=0.5 + rs.rand(q))
+    g["trunk"] = [(W, 0.1 * rs.randn(*b.shape)) for W, b in g["trunk"]]
+    g["mean"] = (g["mean"][0], 0.1 * rs.randn(p)); g["var"] = (g["var"][0], 0.1 * rs.randn(p))
+    e = [(W, 0.1 * rs.randn(*b.shape)) for W, b in N.init_mlp(rs, [p, 64, 64, q], np.float64)]
+    ds = []
+    for in_dim in (q, p):
+        d = OE.init_disc(rs, in_dim, [64, 32, 8], np.float64)
+        d["b"] = [0.1 * rs.randn(*b.shape) for b in d["b"]]
+        d["gamma"] = [1 + 0.2 * rs.randn(*b.shape) for b in d["gamma"]]
+        d["beta"] = [0.1 * rs.randn(*b.shape) for b in d["beta"]]
+        ds.append(d)
+    return g, e, ds[0], ds[1]
+
+
+def _tg_train(tg, z):
+    """BaseVariationalNet(training=True) in torch."""
+    h = (z - z.mean(0)) / torch.sqrt(z.var(0, unbiased=False) + 1e-3) * tg["gamma"] + tg["beta"]
+    for W, b in tg["trunk"]:
+        h = h @ W + b
+        h = torch.maximum(h, 0.2 * h)
+    return h @ tg["mean"][0] + tg["mean"][1], _sp(h @ tg["var"][0] + tg["var"][1]) + 1e-6
+
+
+def test_bgm_egm_steps_match_autograd():
+    from oracle import egm as OE
+    rs = np.random.RandomState(3)
+    q, p, B = 6, 19, 32
+    g, e, dz, dx = _bgm_egm_setup(rs, q, p)
+    z, x, n1, n2 = rs.randn(B, q), rs.randn(B, p), rs.randn(B, p), rs.randn(B, p)
+    r = lambda a: _t(a).requires_grad_()
+    tg = {"gamma": r(g["bn"]["gamma"]), "beta": r(g["bn"]["beta"]), "trunk": [(r(W), r(b)) for W, b in g["trunk"]],
+          "mean": (r(g["mean"][0]), r(g["mean"][1])), "var": (r(g["var"][0]), r(g["var"][1]))}
+    te = _torch_net(e)
+    tdz = {k: [r(a) for a in v] for k, v in dz.items()}
+    tdx = {k: [r(a) for a in v] for k, v in dx.items()}
+    tz, tx, tn1, tn2 = _t(z), _t(x), _t(n1), _t(n2)
+    # ---- generator step
+    alpha = 0.3
+    mu1, s21 = _tg_train(tg, tz)
+    x_ = tn1 * torch.sqrt(s21) + mu1
+    z_ = _fwd(te, tx)
+    z__ = _fwd(te, x_)
+    mu2, s22 = _tg_train(tg, z_)
+    x__ = tn2 * torch.sqrt(s22) + mu2
+    loss = (((0.9 - _tdisc(tdx, x_)) ** 2).mean() + ((0.9 - _tdisc(tdz, z_)) ** 2).mean() +
+            10 * (((tx - x__) ** 2).mean() + ((tz - z__) ** 2).mean()) + alpha * (s21 ** 2).mean())
+    gl = [tg["gamma"], tg["beta"]] + [a for Wb in tg["trunk"] for a in Wb] + list(tg["mean"]) + list(tg["var"])
+    el = [a for Wb in te for a in Wb]
+    ref = [t_.numpy() for t_ in torch.autograd.grad(loss, gl + el)]
+    losses, gr, _ = OE.bgm_gen_step_grads(g, e, dz, dx, z, x, n1, n2, alpha)
+    ours = OE.g_grad_list(gr["g"]) + [a for Wb in gr["e"] for a in Wb]
+    assert abs(losses[-1] - loss.item()) < 1e-12 and _max_err(ours, ref) < 1e-12
+    # ---- discriminator step (gamma > 0: gradient penalties on both discriminators)
+    gamma, ez, ex = 0.7, 0.31, 0.64
+    with torch.no_grad():
+        z_ = _fwd(te, tx)
+        mu, s2 = _tg_train(tg, tz)
+        x_ = tn1 * torch.sqrt(s2) + mu
+    zh = (tz * ez + z_ * (1 - ez)).requires_grad_(True)
+    xh = (tx * ex + x_ * (1 - ex)).requires_grad_(True)
+    dz_loss = (((0.9 - _tdisc(tdz, tz)) ** 2).mean() + ((0.1 - _tdisc(tdz, z_)) ** 2).mean()) / 2
+    dx_loss = (((0.9 - _tdisc(tdx, tx)) ** 2).mean() + ((0.1 - _tdisc(tdx, x_)) ** 2).mean()) / 2
+    (gz,) = torch.autograd.grad(_tdisc(tdz, zh).sum(), zh, create_graph=True)
+    (gx,) = torch.autograd.grad(_tdisc(tdx, xh).sum(), xh, create_graph=True)
+    d_loss = dz_loss + dx_loss + gamma * (((torch.sqrt((gz ** 2).sum(1)) - 1) ** 2).mean() + ((torch.sqrt((gx ** 2).sum(1)) - 1) ** 2).mean())
+    pl = tdz["W"] + tdz["b"] + tdz["gamma"] + tdz["beta"] + tdx["W"] + tdx["b"] + tdx["gamma"] + tdx["beta"]
+    ref = [t_.numpy() for t_ in torch.autograd.grad(d_loss, pl)]
+    losses, gr, _ = OE.bgm_disc_step_grads(g, e, dz, dx, z, x, n1, ez, ex, gamma)
+    ours = OE.disc_param_list(gr["dz"]) + OE.disc_param_list(gr["dx"])
+    assert abs(losses[2] - d_loss.item()) < 1e-12 and abs(losses[0] - dz_loss.item()) < 1e-12
+    assert _max_err(ours, ref) < 1e-11
