@@ -59,6 +59,14 @@ class EgmConfig(C.Structure):
                 ("lr", C.c_float), ("use_z_rec", C.c_int32)]
 
 
+class BgmEgmConfig(C.Structure):
+    _fields_ = [("batch_size", C.c_int32),
+                ("n_hidden_e", C.c_int32), ("e_units", C.c_int32 * BGM_MAX_LAYERS),
+                ("n_hidden_dz", C.c_int32), ("dz_units", C.c_int32 * BGM_MAX_LAYERS),
+                ("n_hidden_dx", C.c_int32), ("dx_units", C.c_int32 * BGM_MAX_LAYERS),
+                ("lr", C.c_float), ("gamma", C.c_float), ("alpha", C.c_float)]
+
+
 class MhInfo(C.Structure):
     _fields_ = [("rows_per_wave", C.c_int32), ("waves_per_block", C.c_int32), ("grid_blocks", C.c_int32),
                 ("mfma_per_transition_per_wave", C.c_int32), ("lds_bytes", C.c_int32),
@@ -115,6 +123,16 @@ SYMBOLS = {
     "bgm_bgm_predict_draws": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                         C.c_uint64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                         C.c_void_p]),
+    "bgm_bgm_egm_begin": (C.c_int, [C.c_void_p, C.POINTER(BgmEgmConfig), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                    C.c_int64, C.c_void_p]),
+    "bgm_bgm_egm_disc_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_void_p,
+                                        C.c_void_p]),
+    "bgm_bgm_egm_gen_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "bgm_bgm_egm_read": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "bgm_bgm_egm_write": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "bgm_bgm_egm_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "bgm_bgm_egm_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bgm_bgm_egm_end": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bgm_debug_group_probe": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     "bgm_causal_egm_begin": (C.c_int, [C.c_void_p, C.POINTER(EgmConfig), C.c_void_p, C.c_int64, C.c_void_p]),
     "bgm_causal_egm_disc_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_void_p,

@@ -70,6 +70,7 @@ struct bgm_handle {
   size_t acc_scratch_cap = 0;
   void *bgm_state = nullptr;  // BgmState (bgm_api.hip)
   void *egm_state = nullptr;  // EgmState (egm_api.hip)
+  void *bgm_egm_state = nullptr;  // BgmEgmState (bgm_egm_api.hip)
   // timing
   bool timing = false;
   struct Ev { hipEvent_t a, b; int kind; };
@@ -81,6 +82,7 @@ struct bgm_handle {
 int bgm_causal_build_blob(bgm_handle *h, hipStream_t stream);
 void bgm_bgm_free_state(bgm_handle *h);
 void bgm_egm_free_state(bgm_handle *h);
+void bgm_bgm_egm_free_state(bgm_handle *h);
 int causal_pack_forward(bgm_handle *h, const HostNet &G, const HostNet &F, const HostNet &H, std::vector<float> &blob);
 
 // ---- packing into MFMA fragment order (layout documented in bgm_device.h)

@@ -149,7 +149,8 @@ __device__ __forceinline__ void egm_bwd_w(const EgmCtx &c, const float *X, int l
 // (X is the LeakyReLU output of the layer below, so dX is that layer's PRE-activation gradient), all behind one
 // barrier: the weight-gradient tiles and the input-gradient tiles are dealt to the waves together.  dX may be NULL.
 __device__ __forceinline__ void egm_bwd_layer(const EgmCtx &c, const float *X, const float *dY, const float *W, float *gW, float *gb,
-                                              float *dX, int B, int in, int out, bool accumulate, bool mask) {
+                                              float *dX, int B, int in, int out, bool accumulate, bool mask,
+                                              const float *add = nullptr) {
   const int nw = EGM_THREADS / 64, wave = c.tid >> 6;
   const int t_w = ((in + 15) >> 4) * ((out + 15) >> 4);
   egm_gemm_tiles(c, EgmMat{X, 1, in}, EgmMat{dY, out, 1}, in, out, B, wave, nw,
@@ -162,6 +163,7 @@ __device__ __forceinline__ void egm_bwd_layer(const EgmCtx &c, const float *X, c
     egm_gemm_tiles(c, EgmMat{dY, out, 1}, EgmMat{W, 1, out}, B, in, out, first, nw,
                    [&](int m, int n, float v) {
                      const long long t = (long long)m * in + n;
+                     if (add) v += add[t];     // a second consumer of X (the variance head of a variational net)
                      if (mask) v *= (X[t] > 0.0f) ? 1.0f : EGM_LEAK;
                      dX[t] = v;
                    });
@@ -308,18 +310,18 @@ enum { GP_DY = 0, GP_DHAT = 1, GP_DU = 2, GP_ABAR = 3, GP_UBAR = 4, GP_SBAR = 5 
 // da / du: scratch [B x max width].  dx (may be NULL) receives dLoss/dinput [B x dims[0]].
 __device__ __forceinline__ void egm_disc_bwd(const EgmCtx &c, const float *th, float *gr, const EgmDisc &d, const EgmDiscCache &k,
                                              bool has_dout, float dout_val, const EgmGpScr *adj, float *da, float *du, float *dx,
-                                             int B, bool accumulate, float s) {
+                                             int B, bool accumulate, float s, const float *dout_vec = nullptr) {
   const int L = d.n_hidden, nL = d.dims[L];
   const float *aL = egm_dk_a(d, k, L, B);
-  if (has_dout) {
+  if (has_dout) {   // dLoss/dout_b = dout_vec[b] (LSGAN) or the same dout_val for every row (Wasserstein)
     for (int i = c.tid; i < nL + 1; i += EGM_THREADS) {
       float acc = 0.0f;
-      if (i < nL) { for (int b = 0; b < B; ++b) acc += aL[b * nL + i]; acc *= dout_val; }
-      else acc = dout_val * (float)B;
+      if (i < nL) { for (int b = 0; b < B; ++b) acc = fmaf(dout_vec ? dout_vec[b] : dout_val, aL[b * nL + i], acc); }
+      else { for (int b = 0; b < B; ++b) acc += dout_vec ? dout_vec[b] : dout_val; }
       float *dst = gr + (i < nL ? d.w[L] + i : d.b[L]);
       *dst = accumulate ? *dst + s * acc : s * acc;
     }
-    for (int t = c.tid; t < B * nL; t += EGM_THREADS) da[t] = dout_val * th[d.w[L] + (t % nL)];
+    for (int t = c.tid; t < B * nL; t += EGM_THREADS) da[t] = (dout_vec ? dout_vec[t / nL] : dout_val) * th[d.w[L] + (t % nL)];
   } else {
     for (int t = c.tid; t < B * nL; t += EGM_THREADS) da[t] = 0.0f;
     if (!accumulate)
@@ -497,7 +499,7 @@ __device__ __forceinline__ void egm_mlp_cache(const EgmMlp &n, int B, float *&p,
 // ---------------------------------------------------------------------------------------------
 // train_disc_step
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(EGM_THREADS) void egm_disc_step_kernel(EgmArgs a) {
+static __global__ __launch_bounds__(EGM_THREADS) void egm_disc_step_kernel(EgmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float egm_lds[];
   EgmCtx c{(int)threadIdx.x, egm_lds};
   const int B = a.B, q = a.q, p = a.p;
@@ -546,7 +548,7 @@ __global__ __launch_bounds__(EGM_THREADS) void egm_disc_step_kernel(EgmArgs a) {
 // ---------------------------------------------------------------------------------------------
 // train_gen_step
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(EGM_THREADS) void egm_gen_step_kernel(EgmArgs a) {
+static __global__ __launch_bounds__(EGM_THREADS) void egm_gen_step_kernel(EgmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float egm_lds[];
   EgmCtx c{(int)threadIdx.x, egm_lds};
   const int B = a.B, q = a.q, p = a.p, z0 = a.z0, z1 = a.z1, z2 = a.z2;

@@ -460,6 +460,57 @@ class BgmEngine(object):
                                                   self._stream()), "bgm_bgm_predict_draws")
         return (cells, full, var) if want_var else (cells, full)
 
+    # -- EGM warm start (bgm/base.py:190-340) ------------------------------------
+    def egm_begin(self, batch_size, e_units, dz_units, dx_units, lr, gamma, alpha, e_net, dz, dx):
+        """Session from the installed generator, the encoder `e_net` ([(W, b)..]) and the discriminators (dicts)."""
+        cfg = _lib.BgmEgmConfig()
+        cfg.batch_size = int(batch_size)
+        for name, units in (("e", e_units), ("dz", dz_units), ("dx", dx_units)):
+            setattr(cfg, "n_hidden_" + name, len(units))
+            arr = getattr(cfg, name + "_units")
+            for i, u in enumerate(units):
+                arr[i] = int(u)
+        cfg.lr, cfg.gamma, cfg.alpha = float(lr), float(gamma), float(alpha)
+        te = flatten_net(e_net)
+        tz, tx = CausalEngine.flatten_disc(dz), CausalEngine.flatten_disc(dx)
+        _lib.check(self.lib.bgm_bgm_egm_begin(self.h, C.byref(cfg), te.ctypes.data_as(C.c_void_p), te.size,
+                                              tz.ctypes.data_as(C.c_void_p), tz.size, tx.ctypes.data_as(C.c_void_p), tx.size,
+                                              self._stream()), "bgm_bgm_egm_begin")
+        self._egm_sizes = (self.n_theta(), te.size, tz.size, tx.size)
+
+    def egm_disc_step(self, z, x, noise, eps_z, eps_x, apply=True, out=None):
+        _lib.check(self.lib.bgm_bgm_egm_disc_step(self.h, _ptr(z), _ptr(x), _ptr(noise), float(eps_z), float(eps_x),
+                                                  int(bool(apply)), _ptr(out), self._stream()), "bgm_bgm_egm_disc_step")
+
+    def egm_gen_step(self, z, x, noise1, noise2, apply=True, out=None):
+        _lib.check(self.lib.bgm_bgm_egm_gen_step(self.h, _ptr(z), _ptr(x), _ptr(noise1), _ptr(noise2), int(bool(apply)),
+                                                 _ptr(out), self._stream()), "bgm_bgm_egm_gen_step")
+
+    def egm_read(self, what):
+        """0: generator side [g | e], 1: discriminators [dz | dx], 2 / 3: gradients of the last gen / disc step."""
+        n_g, n_e, n_dz, n_dx = self._egm_sizes
+        buf = np.empty((n_g + n_e) if what in (0, 2) else (n_dz + n_dx), np.float32)
+        _lib.check(self.lib.bgm_bgm_egm_read(self.h, int(what), buf.ctypes.data_as(C.c_void_p), buf.size, self._stream()),
+                   "bgm_bgm_egm_read")
+        return buf
+
+    def egm_write(self, what, buf):
+        buf = np.ascontiguousarray(buf, np.float32)
+        _lib.check(self.lib.bgm_bgm_egm_write(self.h, int(what), buf.ctypes.data_as(C.c_void_p), buf.size, self._stream()),
+                   "bgm_bgm_egm_write")
+
+    def egm_encode(self, x):
+        x = _f32(x, self.device)
+        z = torch.empty((x.shape[0], self.q), device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.bgm_bgm_egm_encode(self.h, _ptr(x), x.shape[0], _ptr(z), self._stream()), "bgm_bgm_egm_encode")
+        return z
+
+    def egm_sync(self):
+        _lib.check(self.lib.bgm_bgm_egm_sync(self.h, self._stream()), "bgm_bgm_egm_sync")
+
+    def egm_end(self):
+        _lib.check(self.lib.bgm_bgm_egm_end(self.h, self._stream()), "bgm_bgm_egm_end")
+
     def row_mean_quantiles(self, mat, q_lo, q_hi):
         mat = mat.contiguous()
         n_rows, m = mat.shape

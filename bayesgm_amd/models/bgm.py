@@ -4,7 +4,7 @@ Mirrors /root/reference/src/bayesgm/models/bgm/base.py:
     __init__ :59-121   get_config :123   fit :343   evaluate :445   generate :479
     predict_on_posteriors :511   predict :527   get_log_posterior :666   tfp_mcmc_sampler :709
 Deterministic generator (``use_bnn=False``: BaseVariationalNet, networks/base.py:53-117) only; the EGM warm
-start runs through the interim torch-autograd module (bayesgm_amd/egm.py);
+start runs on the kernels of csrc/bgm_egm_kernels.h;
 ``use_bnn=True`` raises NotImplementedError.
 """
 import datetime
@@ -63,7 +63,7 @@ class BGM(object):
         if p['save_res'] and not os.path.exists(self.save_dir):
             os.makedirs(self.save_dir, exist_ok=True)
         self.data_z = None
-        self._egm = None
+        self._egm_open = False
         self.last_acceptance_rate = None
 
     def get_config(self):
@@ -81,55 +81,99 @@ class BGM(object):
 
     # ------------------------------------------------------------------ fit
     def egm_init(self, data, egm_n_iter=10000, batch_size=32, egm_batches_per_eval=500, verbose=1):
-        """EGM warm start (bgm/base.py:292-340).  INTERIM: runs on the GPU through PyTorch autograd
-        (bayesgm_amd/egm.py), not yet as hand-written kernels; see that module's docstring.  The trained
-        generator is installed in the HIP engine; the encoder stays with the EGM object (`self._egm`) for
-        the Z initialisation e(X) and `evaluate(data_z=None)`."""
-        from ..egm import BgmEGM
+        """EGM warm start (bgm/base.py:292-340): g_d_freq LSGAN steps on the discriminators dz_net / dx_net, then one
+        step on the generator and the encoder, per iteration -- each step one launch of the kernels of
+        csrc/bgm_egm_kernels.h.  The host draws minibatches (Base_sampler), prior samples and interpolation
+        coefficients in the reference's order; the reparameterisation noise is drawn on the device.  The session stays
+        open afterwards: its encoder serves the Z initialisation e(X) and `evaluate(data_z=None)`."""
         from ..datasets import Base_sampler
         data = np.asarray(data, dtype=np.float32)
-        dev = self.engine.device
+        eng = self.engine
+        dev = eng.device
+        p_ = self._p
+        q, xd_ = eng.q, eng.p
         self.data_sampler = Base_sampler(x=data, y=data, v=data, batch_size=batch_size, normalize=False)   # :294
         xd = self._dev(data)
-        egm = BgmEGM(self.g, self._p, dev, self._rs, batch_size)
-        try:
-            egm.capture()
-        except Exception as e:   # graph capture is an optimisation only
-            if verbose:
-                print("EGM: HIP-graph capture unavailable (%s); running eagerly" % type(e).__name__)
-        self._egm = egm
+
+        def mlp(dims):
+            return [(_glorot(self._rs, dims[i], dims[i + 1]), np.zeros(dims[i + 1], np.float32)) for i in range(len(dims) - 1)]
+
+        def disc(in_dim, units):                                   # networks/base.py:338-363
+            dims = [in_dim] + list(units) + [1]
+            return {"W": [_glorot(self._rs, dims[i], dims[i + 1]) for i in range(len(dims) - 1)],
+                    "b": [np.zeros(dims[i + 1], np.float32) for i in range(len(dims) - 1)],
+                    "gamma": [np.ones(dims[i + 1], np.float32) for i in range(len(dims) - 2)],
+                    "beta": [np.zeros(dims[i + 1], np.float32) for i in range(len(dims) - 2)]}
+        if self._egm_open:
+            eng.egm_end()
+            self._egm_open = False
+        eng.set_weights(self.g)
+        eng.egm_begin(batch_size, p_["e_units"], p_["dz_units"], p_["dx_units"], p_["lr"], p_["gamma"], p_["alpha"],
+                      mlp([xd_] + list(p_["e_units"]) + [q]), disc(q, p_["dz_units"]), disc(xd_, p_["dx_units"]))
+        self._egm_open = True
+        out_d = torch.zeros(3, device=dev)
+        out_g = torch.zeros(6, device=dev)
         print('EGM Initialization Starts ...')
-        g_d_freq = int(self._p['g_d_freq'])
-        for batch_iter in range(egm_n_iter + 1):
-            for _ in range(g_d_freq):
-                bx, _, _ = self.data_sampler.next_batch()
-                bz = self.z_sampler.get_batch(batch_size)
-                egm.disc_step(torch.from_numpy(bz).to(dev), torch.from_numpy(bx).to(dev),
-                              np.random.uniform(0.0, 1.0), np.random.uniform(0.0, 1.0))
-            bx, _, _ = self.data_sampler.next_batch()
-            bz = self.z_sampler.get_batch(batch_size)
-            egm.gen_step(torch.from_numpy(bz).to(dev), torch.from_numpy(bx).to(dev))
+        g_d_freq = int(p_['g_d_freq'])
+        steps = g_d_freq + 1
+        batch_iter = 0
+        while batch_iter <= egm_n_iter:
+            stop = min(egm_n_iter, (batch_iter // egm_batches_per_eval + 1) * egm_batches_per_eval
+                       if batch_iter % egm_batches_per_eval else batch_iter)
+            n_it = stop - batch_iter + 1
+            x_h = np.empty((n_it, steps, batch_size, xd_), np.float32)
+            z_h = np.empty((n_it, steps, batch_size, q), np.float32)
+            eps_h = np.empty((n_it, g_d_freq, 2), np.float64)
+            for i in range(n_it):                       # host RNG / sampler consumed in the reference's order
+                for j in range(steps):
+                    x_h[i, j] = self.data_sampler.next_batch()[0]
+                    z_h[i, j] = self.z_sampler.get_batch(batch_size)
+                    if j < g_d_freq:
+                        eps_h[i, j] = np.random.uniform(0.0, 1.0, size=2)
+            x_d, z_d = torch.from_numpy(x_h).to(dev), torch.from_numpy(z_h).to(dev)
+            noise = torch.randn((n_it, steps + 1, batch_size, xd_), device=dev)
+            for i in range(n_it):
+                for j in range(g_d_freq):
+                    eng.egm_disc_step(z_d[i, j], x_d[i, j], noise[i, j], eps_h[i, j, 0], eps_h[i, j, 1], out=out_d)
+                eng.egm_gen_step(z_d[i, g_d_freq], x_d[i, g_d_freq], noise[i, g_d_freq], noise[i, g_d_freq + 1], out=out_g)
+            batch_iter = stop
             if batch_iter % egm_batches_per_eval == 0:
                 if verbose:
-                    lg, ld = egm.out_g.cpu().numpy(), egm.out_d.cpu().numpy()
+                    lg, ld = out_g.cpu().numpy(), out_d.cpu().numpy()
                     print('EGM Initialization Iter [%d] : g_loss_adv[%.4f], e_loss_adv [%.4f], l2_loss_z [%.4f], '
                           'l2_loss_x [%.4f], sd^2_loss[%.4f], g_e_loss [%.4f], dz_loss [%.4f], dx_loss[%.4f], d_loss [%.4f]'
                           % (batch_iter, lg[0], lg[1], lg[2], lg[3], lg[4], lg[5], ld[0], ld[1], ld[2]))
-                z_, x_rec, mse = egm.eval_pass(xd)          # moves the BatchNorm moving statistics (training=True call)
-                self.set_weights(egm.export_g())
-                print('MSE_x', mse)
+                # evaluation block (:312-317): g_net(e_net(data)) is called with its default training=True, i.e. with the
+                # batch statistics of e(data), and moves the BatchNorm moving averages once more
+                z_ = eng.egm_encode(xd)
+                mu_b, var_b = z_.mean(dim=0).cpu().numpy(), z_.var(dim=0, unbiased=False).cpu().numpy()
+                th = eng.egm_read(0)
+                eng.egm_sync()
+                g_batch = eng.get_weights()
+                g_batch["bn"]["mean"], g_batch["bn"]["var"] = mu_b.astype(np.float32), var_b.astype(np.float32)
+                th[2 * q:3 * q] = th[2 * q:3 * q] * np.float32(0.99) + mu_b * np.float32(0.01)
+                th[3 * q:4 * q] = th[3 * q:4 * q] * np.float32(0.99) + var_b * np.float32(0.01)
+                eng.egm_write(0, th)
+                # x_rec = mean head of the training-mode call = inference with the batch statistics installed
+                eng.set_weights(g_batch)
+                x_rec, _ = self._decode(z_, use_x_sd=False)
+                print('MSE_x', float(np.mean((data - x_rec) ** 2)))
+                eng.egm_sync()
+                self.g = eng.get_weights()
                 if self._p['save_res']:
                     gen1, var1 = self.generate(nb_samples=5000)
                     gen12, var12 = self.generate(nb_samples=5000, use_x_sd=False)
                     np.savez('%s/init_data_gen_at_%d.npz' % (self.save_dir, batch_iter), gen1=gen1, gen12=gen12,
-                             z=z_.cpu().numpy(), x_rec=x_rec.cpu().numpy(), var1=var1, var12=var12)
+                             z=z_.cpu().numpy(), x_rec=x_rec, var1=var1, var12=var12)
                 mse_x = self.evaluate(data=data, use_x_sd=True)
                 print('iter [%d/%d]: MSE_x: %.4f\n' % (batch_iter, egm_n_iter, mse_x))
                 mse_x = self.evaluate(data=data, use_x_sd=False)
                 print('iter [%d/%d]: MSE_x no x_sd: %.4f\n' % (batch_iter, egm_n_iter, mse_x))
                 if self._p['save_model']:
                     self.save_checkpoint('egm_init_%d' % batch_iter)
-        self.set_weights(egm.export_g())
+            batch_iter += 1
+        eng.egm_sync()
+        self.g = eng.get_weights()
         print('EGM Initialization Ends.')
 
     def fit(self, data, batch_size=32, epochs=100, epochs_per_eval=5, use_egm_init=True, egm_n_iter=20000,
@@ -151,7 +195,7 @@ class BGM(object):
         x = self._dev(data)
         if use_egm_init:
             print('Initialize latent variables Z with e(V)...')
-            self.data_z = self._egm.encode(x).contiguous()                              # :384
+            self.data_z = eng.egm_encode(x).contiguous()                                # :384
         else:
             print('Random initialization of latent variables Z...')
             data_z_init = np.random.normal(0, 1, size=(n, eng.q)).astype('float32')     # :388
@@ -251,7 +295,8 @@ class BGM(object):
 
     def _decode(self, z, use_x_sd, seed=None):
         """(x, sigma^2) for latent rows z with g_net(training=False) on the device (bgm/base.py:468-473,503-508)."""
-        seed = int(np.random.randint(0, 2 ** 31 - 1)) if seed is None else seed
+        if seed is None:      # the mean path needs no noise: leave NumPy's global stream alone
+            seed = int(np.random.randint(0, 2 ** 31 - 1)) if use_x_sd else 0
         zt = self._dev(z)[None]
         _, full, var = self.engine.predict_draws(zt, 0, seed, want_full=True, want_var=True, add_noise=use_x_sd)
         return full[0].cpu().numpy(), var[0].cpu().numpy()
@@ -259,9 +304,9 @@ class BGM(object):
     def evaluate(self, data, data_z=None, use_x_sd=True):
         """mse_x between data and its reconstruction (bgm/base.py:444-476)."""
         if data_z is None:
-            if getattr(self, "_egm", None) is None:
+            if not self._egm_open:
                 raise RuntimeError("BGM.evaluate(data_z=None) needs the encoder trained by egm_init(); pass data_z")
-            data_z = self._egm.encode(self._dev(data))
+            data_z = self.engine.egm_encode(self._dev(data))
         z = data_z.cpu().numpy() if isinstance(data_z, torch.Tensor) else np.asarray(data_z, np.float32)
         x_pred, _ = self._decode(z, use_x_sd)
         return np.float32(np.mean((np.asarray(data, np.float32) - x_pred) ** 2))

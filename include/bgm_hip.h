@@ -336,6 +336,45 @@ int bgm_bgm_fit_end(bgm_handle *h, void *stream);
 /* Measurement aid: effective shader clock (MHz) and fp32-MFMA rate (TFLOP/s) of this device under a
  * back-to-back v_mfma_f32_16x16x4_f32 load on every CU (8 waves/CU, `iters` x 16 MFMAs per wave).
  * Synchronous.  Used by bench.py to state the roofline at the clock the chip actually sustains. */
+/* ------------------------------------------------------------------------------------------
+ * EGM warm start of BGM (bgm/base.py:190-340): LSGAN discriminators dz_net (latent) and dx_net (data), generator
+ * g_net (BaseVariationalNet called with training=True: batch statistics, moving averages updated by every call)
+ * and encoder e_net; Adam(lr, beta1 0.5, beta2 0.9), base.py:82-85.  One call = one minibatch step = one launch.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t batch_size;
+  int32_t n_hidden_e, e_units[BGM_MAX_LAYERS];   /* params['e_units']                       */
+  int32_t n_hidden_dz, dz_units[BGM_MAX_LAYERS]; /* params['dz_units']                      */
+  int32_t n_hidden_dx, dx_units[BGM_MAX_LAYERS]; /* params['dx_units']                      */
+  float lr;                                      /* params['lr']                            */
+  float gamma;                                   /* gradient-penalty weight params['gamma'] */
+  float alpha;                                   /* variance regulariser params['alpha']    */
+} bgm_bgm_egm_config;
+
+/* Start a session from the generator installed with bgm_bgm_set_weights.  theta_e: encoder [W0,b0,...] (x_dim ->
+ * e_units -> z_dim); theta_dz / theta_dx: discriminators [W0..WL | b0..bL | gamma.. | beta..]. */
+int bgm_bgm_egm_begin(bgm_handle *h, const bgm_bgm_egm_config *cfg, const float *theta_e_host, int64_t count_e,
+                      const float *theta_dz_host, int64_t count_dz, const float *theta_dx_host, int64_t count_dx,
+                      void *stream);
+/* replaces: train_disc_step, bgm/base.py:190-244.  z_dev [B x z_dim] prior sample, x_dev [B x x_dim] data rows,
+ * noise_dev [B x x_dim] standard normals of the reparameterisation, eps_* the interpolation coefficients of the
+ * gradient penalties (used when gamma != 0).  out_dev: [dz_loss, dx_loss, d_loss] or NULL. */
+int bgm_bgm_egm_disc_step(bgm_handle *h, const float *z_dev, const float *x_dev, const float *noise_dev, float eps_z,
+                          float eps_x, int32_t apply, float *out_dev, void *stream);
+/* replaces: train_gen_step, bgm/base.py:246-289.  out_dev: [g_loss_adv, e_loss_adv, l2_loss_z, l2_loss_x, reg_loss,
+ * g_e_loss] or NULL. */
+int bgm_bgm_egm_gen_step(bgm_handle *h, const float *z_dev, const float *x_dev, const float *noise1_dev,
+                         const float *noise2_dev, int32_t apply, float *out_dev, void *stream);
+/* Session state <-> host: what = 0 generator side [g (bgm_bgm_set_weights order) | e], 1 discriminators [dz | dx],
+ * 2 / 3 gradients of the last gen / disc step (read only). */
+int bgm_bgm_egm_read(bgm_handle *h, int32_t what, float *host, int64_t count, void *stream);
+int bgm_bgm_egm_write(bgm_handle *h, int32_t what, const float *host, int64_t count, void *stream);
+/* z = e_net(x) for n rows with the session's encoder (Z initialisation bgm/base.py:384, evaluate :466). */
+int bgm_bgm_egm_encode(bgm_handle *h, const float *x_dev, int64_t n, float *z_dev, void *stream);
+/* Install the session's generator in the handle (as bgm_bgm_set_weights would); _end also frees the session. */
+int bgm_bgm_egm_sync(bgm_handle *h, void *stream);
+int bgm_bgm_egm_end(bgm_handle *h, void *stream);
+
 /* Debug: throughput of the hand-scheduled 64x4-tile MFMA block alone (mode 1: fragments streamed from LDS; mode 0:
  * register operands only) with `waves_per_cu` waves on every CU. */
 int bgm_debug_group_probe(bgm_handle *h, int32_t mode, int32_t waves_per_cu, int32_t iters, double *mfma_tflops);

@@ -123,3 +123,123 @@ def test_egm_alternating_adam_steps_track_oracle():
     eng.egm_end()
     g_tr = eng.get_weights(0, [q] + [64] * 5 + [24])
     assert np.abs(g_tr[0][0] - st.nets["g"][0][0]).max() <= 2e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# BGM EGM (bgm_egm_kernels.h) vs oracle.egm.bgm_*_step_grads
+# ---------------------------------------------------------------------------------------------
+def _bgm_setup(p, q=10, B=32, n=128, seed=0, gamma=0.0, alpha=0.0):
+    import torch
+    from bayesgm_amd.engine import BgmEngine
+    rs = np.random.RandomState(seed)
+    g = N.init_varnet(rs, q, (64,) * 5, p)
+    g["bn"].update(gamma=(1 + 0.1 * rs.randn(q)).astype(np.float32), beta=(0.1 * rs.randn(q)).astype(np.float32),
+                   mean=(0.2 * rs.randn(q)).astype(np.float32), var=(0.5 + rs.rand(q)).astype(np.float32))
+    g["trunk"] = [(W, (0.1 * rs.randn(*b.shape)).astype(np.float32)) for W, b in g["trunk"]]
+    g["mean"] = (g["mean"][0], (0.1 * rs.randn(p)).astype(np.float32))
+    g["var"] = (g["var"][0], (0.1 * rs.randn(p)).astype(np.float32))
+    e = [(W, (0.1 * rs.randn(*b.shape)).astype(np.float32)) for W, b in N.init_mlp(rs, [p] + [64] * 5 + [q])]
+    ds = []
+    for in_dim in (q, p):
+        d = OE.init_disc(rs, in_dim, [64, 32, 8])
+        d["b"] = [(0.1 * rs.randn(*b.shape)).astype(np.float32) for b in d["b"]]
+        d["gamma"] = [(1 + 0.2 * rs.randn(*b.shape)).astype(np.float32) for b in d["gamma"]]
+        d["beta"] = [(0.1 * rs.randn(*b.shape)).astype(np.float32) for b in d["beta"]]
+        ds.append(d)
+    eng = BgmEngine(p, q, g_units=[64] * 5)
+    eng.set_weights(g)
+    eng.egm_begin(B, [64] * 5, [64, 32, 8], [64, 32, 8], 1e-3, gamma, alpha, e, ds[0], ds[1])
+    x = rs.randn(n, p).astype(np.float32)
+    return eng, g, e, ds[0], ds[1], x, rs
+
+
+def _c64(g, e, dz, dx):
+    from oracle import bgm as OB
+    g64 = {"bn": {k: v.astype(np.float64) for k, v in g["bn"].items()}, "trunk": N.cast_net(g["trunk"], np.float64),
+           "mean": tuple(a.astype(np.float64) for a in g["mean"]), "var": tuple(a.astype(np.float64) for a in g["var"])}
+    return g64, N.cast_net(e, np.float64), OE.cast_disc(dz, np.float64), OE.cast_disc(dx, np.float64)
+
+
+def _g_flat(g):
+    from bayesgm_amd.engine import flatten_varnet
+    return flatten_varnet(g).astype(np.float64)
+
+
+@pytest.mark.parametrize("case", [dict(p=20, gamma=0.0, alpha=0.0, B=32), dict(p=100, gamma=0.7, alpha=0.3, B=32),
+                                  dict(p=37, gamma=1.0, alpha=0.0, B=19)])
+def test_bgm_egm_step_gradients_match_oracle(case):
+    import torch
+    p, B, q = case["p"], case["B"], 10
+    eng, g, e, dz, dx, x, rs = _bgm_setup(p, q, B, gamma=case["gamma"], alpha=case["alpha"])
+    g64, e64, dz64, dx64 = _c64(g, e, dz, dx)
+    z = rs.randn(B, q).astype(np.float32)
+    xb = x[rs.choice(len(x), B, replace=False)]
+    n1, n2 = rs.randn(B, p).astype(np.float32), rs.randn(B, p).astype(np.float32)
+    d = lambda a: torch.from_numpy(a).cuda()
+    # ---- discriminator step
+    out_d = torch.zeros(3, device="cuda")
+    eng.egm_disc_step(d(z), d(xb), d(n1), 0.31, 0.64, apply=False, out=out_d)
+    losses, gr, caches = OE.bgm_disc_step_grads(g64, e64, dz64, dx64, z.astype(np.float64), xb.astype(np.float64),
+                                                n1.astype(np.float64), 0.31, 0.64, case["gamma"])
+    ref = np.concatenate([a.ravel() for a in OE.disc_param_list(gr["dz"]) + OE.disc_param_list(gr["dx"])])
+    got = eng.egm_read(3)
+    assert np.all(np.abs(out_d.cpu().numpy() - losses) <= 3e-5 * np.abs(losses) + 1e-6), (out_d.cpu().numpy(), losses)
+    n_dz = OE.disc_param_list(gr["dz"]).__len__() and sum(a.size for a in OE.disc_param_list(gr["dz"]))
+    for lo, hi in ((0, n_dz), (n_dz, ref.size)):        # per discriminator: relative to its largest gradient entry
+        assert _rel(got[lo:hi], ref[lo:hi]) <= 1e-4, _rel(got[lo:hi], ref[lo:hi])
+    # the generator call moved the BatchNorm moving statistics although g is not trained in this step
+    from oracle import bgm as OB
+    OB.bn_update_stats(g64, caches[0])
+    th = eng.egm_read(0)
+    assert np.abs(th[2 * q:3 * q] - g64["bn"]["mean"]).max() <= 1e-6 and np.abs(th[3 * q:4 * q] - g64["bn"]["var"]).max() <= 1e-6
+    # ---- generator step (continues from the moved statistics)
+    out_g = torch.zeros(6, device="cuda")
+    eng.egm_gen_step(d(z), d(xb), d(n1), d(n2), apply=False, out=out_g)
+    losses, gr, caches = OE.bgm_gen_step_grads(g64, e64, dz64, dx64, z.astype(np.float64), xb.astype(np.float64),
+                                               n1.astype(np.float64), n2.astype(np.float64), case["alpha"])
+    got = eng.egm_read(2)
+    assert np.all(np.abs(out_g.cpu().numpy() - losses) <= 3e-5 * np.abs(losses) + 1e-6), (out_g.cpu().numpy(), losses)
+    gl = OE.g_grad_list(gr["g"])
+    ref_g = np.concatenate([gl[0].ravel(), gl[1].ravel(), np.zeros(2 * q)] + [a.ravel() for a in gl[2:]])
+    ref_e = np.concatenate([a.ravel() for Wb in gr["e"] for a in Wb])
+    assert _rel(got[:ref_g.size], ref_g) <= 1e-4, _rel(got[:ref_g.size], ref_g)
+    assert _rel(got[ref_g.size:], ref_e) <= 1e-4, _rel(got[ref_g.size:], ref_e)
+    eng.egm_end()
+
+
+def test_bgm_egm_alternating_adam_steps_track_oracle_and_encoder():
+    import torch
+    from oracle import bgm as OB
+    p, q, B = 20, 10, 32
+    eng, g, e, dz, dx, x, rs = _bgm_setup(p, q, B, gamma=0.5, alpha=0.2)
+    g64, e64, dz64, dx64 = _c64(g, e, dz, dx)
+    st = OE.BgmEgmState(g64, e64, dz64, dx64, dict(lr=1e-3, gamma=0.5, alpha=0.2))
+    d = lambda a: torch.from_numpy(a).cuda()
+    for it in range(4):
+        z = rs.randn(B, q).astype(np.float32); xb = x[rs.choice(len(x), B, replace=False)]
+        n1 = rs.randn(B, p).astype(np.float32); ez, ex = float(rs.rand()), float(rs.rand())
+        eng.egm_disc_step(d(z), d(xb), d(n1), ez, ex)
+        st.disc_step(z.astype(np.float64), xb.astype(np.float64), n1.astype(np.float64), ez, ex)
+        z = rs.randn(B, q).astype(np.float32); xb = x[rs.choice(len(x), B, replace=False)]
+        n1, n2 = rs.randn(B, p).astype(np.float32), rs.randn(B, p).astype(np.float32)
+        eng.egm_gen_step(d(z), d(xb), d(n1), d(n2))
+        st.gen_step(z.astype(np.float64), xb.astype(np.float64), n1.astype(np.float64), n2.astype(np.float64))
+    got_g = eng.egm_read(0)
+    ref_g = np.concatenate([_g_flat(st.g)] + [a.ravel() for Wb in st.e for a in Wb])
+    assert np.abs(got_g - ref_g).max() <= 5e-5, np.abs(got_g - ref_g).max()
+    got_d = eng.egm_read(1)
+    ref_d = np.concatenate([a.ravel() for a in OE.disc_param_list(st.dz) + OE.disc_param_list(st.dx)])
+    inert = np.zeros(ref_d.size, bool)          # hidden-layer biases in front of a BatchNorm: zero exact gradient (see above)
+    o = 0
+    for dd in (st.dz, st.dx):
+        n_w = sum(a.size for a in dd["W"])
+        inert[o + n_w:o + n_w + sum(a.size for a in dd["b"][:-1])] = True
+        o += sum(a.size for a in OE.disc_param_list(dd))
+    assert np.abs(got_d - ref_d)[~inert].max() <= 5e-5
+    # encoder pass over a whole panel == oracle MLP with the trained encoder
+    z_enc = eng.egm_encode(x).cpu().numpy()
+    assert np.abs(z_enc - N.mlp_forward(st.e, x.astype(np.float64))).max() <= 1e-4
+    # end of session: the trained generator (incl. moved BatchNorm statistics) is installed in the engine
+    eng.egm_end()
+    g_tr = eng.get_weights()
+    assert np.abs(g_tr["bn"]["mean"] - st.g["bn"]["mean"]).max() <= 1e-5 and np.abs(g_tr["trunk"][0][0] - st.g["trunk"][0][0]).max() <= 5e-5
