@@ -41,6 +41,7 @@ static int fill_disc(EgmDisc &d, int in_dim, int n_hidden, const int32_t *units)
   for (int l = 0; l < n_hidden; ++l) { d.gamma[l] = o; o += d.dims[l + 1]; }
   for (int l = 0; l < n_hidden; ++l) { d.beta[l] = o; o += d.dims[l + 1]; }
   d.n_params = o;
+  egm_finish_disc(d);
   return o;
 }
 
@@ -71,6 +72,7 @@ extern "C" int bgm_bgm_egm_begin(bgm_handle *h, const bgm_bgm_egm_config *cfg, c
   for (int i = 0; i < NH; ++i) g.mlp.dims[i + 1] = bs->cfg.g_units[i];
   g.mlp.dims[NH + 1] = p;
   g.mlp.off = 4 * q;
+  egm_finish_mlp(g.mlp);
   int o = 4 * q;
   for (int l = 0; l <= NH; ++l) o += g.mlp.dims[l] * g.mlp.dims[l + 1] + g.mlp.dims[l + 1];
   g.wvar = o; o += g.hlast * p;
@@ -84,6 +86,7 @@ extern "C" int bgm_bgm_egm_begin(bgm_handle *h, const bgm_bgm_egm_config *cfg, c
   for (int i = 0; i < cfg->n_hidden_e; ++i) e.dims[i + 1] = cfg->e_units[i];
   e.dims[cfg->n_hidden_e + 1] = q;
   e.off = (int)s->n_g;
+  egm_finish_mlp(e);
   size_t ne = 0;
   for (int l = 0; l < e.n_layers; ++l) ne += (size_t)e.dims[l] * e.dims[l + 1] + e.dims[l + 1];
   s->n_e = ne;

@@ -34,6 +34,7 @@ static bool fill_mlp(const HostNet &n, EgmMlp &m, int off) {
   m.n_layers = L;
   for (int i = 0; i <= L; ++i) m.dims[i] = n.dims[i];
   m.off = off;
+  egm_finish_mlp(m);
   return true;
 }
 
@@ -73,6 +74,7 @@ extern "C" int bgm_causal_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, co
   for (int l = 0; l < L; ++l) { d.gamma[l] = o; o += d.dims[l + 1]; }
   for (int l = 0; l < L; ++l) { d.beta[l] = o; o += d.dims[l + 1]; }
   d.n_params = o;
+  egm_finish_disc(d);
   s->n_dz = (size_t)o;
   if ((int64_t)o != count) {
     bgm_egm_free_state(h);

@@ -22,17 +22,40 @@
 #define EGM_LEAK 0.2f
 #define EGM_BN_EPS 1e-3f
 
+// Prefix tables (woff, aoff, csum, dsum) are filled on the host (egm_finish_mlp / egm_finish_disc): computing
+// them in the kernel meant a loop of dependent scalar loads from the kernel-argument segment at the head of every
+// phase (~2-4k cycles of a ~15k-cycle phase).
 struct EgmMlp {            // BaseFullyConnectedNet: parameters at theta + off as W0,b0,W1,b1,... (Keras order)
   int n_layers;            // Dense layers (hidden + output)
   int dims[EGM_MAX_LAYERS + 1];
   int off;
+  int woff[EGM_MAX_LAYERS];       // offset of W_l in theta (b_l follows it)
+  int aoff[EGM_MAX_LAYERS + 2];   // activation of layer l (l >= 1) at base + B * aoff[l]; aoff[L+1] = total width
 };
 struct EgmDisc {           // Discriminator: hidden layers with BatchNorm + tanh, linear scalar output
   int n_hidden;
   int dims[EGM_MAX_LAYERS + 1];          // in, h1..hL, 1
   int w[EGM_MAX_LAYERS], b[EGM_MAX_LAYERS], gamma[EGM_MAX_LAYERS], beta[EGM_MAX_LAYERS];   // offsets into theta_d
   int n_params;
+  int csum[EGM_MAX_LAYERS + 1];   // dims[1] + ... + dims[l]             (cache block of layer l at (2B+1) * csum[l])
+  int dsum[EGM_MAX_LAYERS + 2];   // dims[0] + ... + dims[l-1]           (gradient-penalty da_l at B * dsum[l])
 };
+inline void egm_finish_mlp(EgmMlp &m) {
+  int o = m.off, a = 0;
+  m.aoff[0] = 0; m.aoff[1] = 0;
+  for (int l = 0; l < m.n_layers; ++l) {
+    m.woff[l] = o;
+    o += m.dims[l] * m.dims[l + 1] + m.dims[l + 1];
+    a += m.dims[l + 1];
+    m.aoff[l + 2] = a;
+  }
+}
+inline void egm_finish_disc(EgmDisc &d) {
+  int c = 0, s_ = 0;
+  d.csum[0] = 0; d.dsum[0] = 0;
+  for (int l = 0; l <= d.n_hidden; ++l) { s_ += d.dims[l]; d.dsum[l + 1] = s_; }
+  for (int l = 0; l < d.n_hidden; ++l) { c += d.dims[l + 1]; d.csum[l + 1] = c; }
+}
 struct EgmAdam { float lr_t, b1, b2, eps; };
 
 struct EgmArgs {
@@ -191,17 +214,10 @@ __device__ __forceinline__ float egm_block_sum(const EgmCtx &c, float v) {
 // head of every phase.
 struct EgmMlpCache { float *in, *base; };
 __device__ __forceinline__ float *egm_act(const EgmMlp &n, const EgmMlpCache &a, int l, int B) {
-  if (l == 0) return a.in;
-  int o = 0;
-  for (int k = 1; k < l; ++k) o += n.dims[k];
-  return a.base + (long long)B * o;
+  return l == 0 ? a.in : a.base + (long long)B * n.aoff[l];
 }
 
-__device__ __forceinline__ const float *egm_W(const float *theta, const EgmMlp &n, int l) {
-  int o = n.off;
-  for (int k = 0; k < l; ++k) o += n.dims[k] * n.dims[k + 1] + n.dims[k + 1];
-  return theta + o;
-}
+__device__ __forceinline__ const float *egm_W(const float *theta, const EgmMlp &n, int l) { return theta + n.woff[l]; }
 __device__ __forceinline__ void egm_mlp_fwd(const EgmCtx &c, const float *theta, const EgmMlp &n, const EgmMlpCache &a, int B) {
   for (int l = 0; l < n.n_layers; ++l) {
     const float *W = egm_W(theta, n, l);
@@ -230,11 +246,7 @@ __device__ __forceinline__ void egm_mlp_bwd(const EgmCtx &c, const float *theta,
 // Forward cache of one discriminator call; computed pointers as above.  Per hidden layer l the block
 // [a_{l+1} (B x w) | uhat_l (B x w) | sigma_l (w)], w = dims[l+1]; the scalar outputs [B] follow the last block.
 struct EgmDiscCache { float *in, *base; };
-__device__ __forceinline__ int egm_dk_off(const EgmDisc &d, int l, int B) {
-  int o = 0;
-  for (int k = 0; k < l; ++k) o += (2 * B + 1) * d.dims[k + 1];
-  return o;
-}
+__device__ __forceinline__ int egm_dk_off(const EgmDisc &d, int l, int B) { return (2 * B + 1) * d.csum[l]; }
 __device__ __forceinline__ float *egm_dk_a(const EgmDisc &d, const EgmDiscCache &k, int l, int B) {   // a_l, l = 0..L
   return l == 0 ? k.in : k.base + egm_dk_off(d, l - 1, B);
 }
@@ -286,22 +298,12 @@ __device__ __forceinline__ void egm_bn_proj_col(float *x, const float *uhat, int
 // Scratch of the gradient-penalty pass (computed pointers).  First the adjoint-network activations da_l [B x dims[l]],
 // l = 0..L; then per hidden layer l the block [dy | dhat | du | a_bar | uhat_bar (B x w each) | sigma_bar (w)].
 struct EgmGpScr { float *base; };
-__device__ __forceinline__ float *egm_gp_da(const EgmDisc &d, const EgmGpScr &g, int l, int B) {
-  int o = 0;
-  for (int k = 0; k < l; ++k) o += d.dims[k];
-  return g.base + B * o;
-}
+__device__ __forceinline__ float *egm_gp_da(const EgmDisc &d, const EgmGpScr &g, int l, int B) { return g.base + B * d.dsum[l]; }
 __device__ __forceinline__ float *egm_gp_blk(const EgmDisc &d, const EgmGpScr &g, int l, int B, int which) {
-  int o = 0;
-  for (int k = 0; k <= d.n_hidden; ++k) o += B * d.dims[k];
-  for (int k = 0; k < l; ++k) o += (5 * B + 1) * d.dims[k + 1];
-  return g.base + o + which * B * d.dims[l + 1];
+  return g.base + B * d.dsum[d.n_hidden + 1] + (5 * B + 1) * d.csum[l] + which * B * d.dims[l + 1];
 }
 __device__ __forceinline__ int egm_gp_floats(const EgmDisc &d, int B) {
-  int o = 0;
-  for (int k = 0; k <= d.n_hidden; ++k) o += B * d.dims[k];
-  for (int k = 0; k < d.n_hidden; ++k) o += (5 * B + 1) * d.dims[k + 1];
-  return (o + 3) & ~3;
+  return (B * d.dsum[d.n_hidden + 1] + (5 * B + 1) * d.csum[d.n_hidden] + 3) & ~3;
 }
 enum { GP_DY = 0, GP_DHAT = 1, GP_DU = 2, GP_ABAR = 3, GP_UBAR = 4, GP_SBAR = 5 };
 
@@ -491,9 +493,7 @@ __device__ __forceinline__ void egm_disc_cache(const EgmDisc &d, int B, float *&
 __device__ __forceinline__ void egm_mlp_cache(const EgmMlp &n, int B, float *&p, EgmMlpCache &a, float *input) {
   auto take = [&](int k) { float *r = p; p += (k + 3) & ~3; return r; };
   a.in = input;
-  int w = 0;
-  for (int l = 1; l <= n.n_layers; ++l) w += n.dims[l];
-  a.base = take(B * w);
+  a.base = take(B * n.aoff[n.n_layers + 1]);
 }
 
 // ---------------------------------------------------------------------------------------------
