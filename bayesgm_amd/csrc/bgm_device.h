@@ -282,12 +282,13 @@ __device__ __forceinline__ void dense_group4_k64_asm(unsigned lds_addr, const f3
       : "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
 }
 __device__ __forceinline__ unsigned lds_byte_addr(const float *p) {
-  // flat -> LDS address = low 32 bits of the flat address (the aperture base lives in the high half); avoids the
-  // null-checked addrspacecast, which hipcc 7.2 mis-selects in some inlining contexts ("Illegal instruction ...
-  // V_CMP_NE_U32 0, $src_shared_base")
-  return (unsigned)(unsigned long long)p;
+  // LDS byte address of an element of the kernel's dynamic shared array, as (offset of that array) + (p - array).
+  // The pointer difference cancels the flat aperture, so no flat <-> LDS cast of `p` is ever materialised: hipcc 7.2
+  // mis-selects those casts in some inlining contexts ("Illegal instruction detected ... $src_shared_base"), both for
+  // an explicit address_space(3) cast and for truncating the flat address.
+  extern __shared__ __attribute__((aligned(16))) float bgm_dynamic_lds[];
+  return (unsigned)__builtin_amdgcn_groupstaticsize() + 4u * (unsigned)(p - bgm_dynamic_lds);
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // The four hidden->hidden layers of the g net (64 x 64 each) as ONE hand-scheduled block.
@@ -935,6 +936,25 @@ __device__ __forceinline__ void lrelu_inplace(f32x4 (&a)[R][NT]) {
       for (int r = 0; r < 4; ++r) a[rr][t][r] = lrelu(a[rr][t][r]);
 }
 
+// Same copy with eight 16-byte loads in flight per thread, for kernels whose run time is the copy: copied one float4 at
+// a time (load, wait, store) the 157 KB blob takes ~25 us per block, which is most of the B = 32 fit kernels (two row
+// tiles = a few microseconds of MFMA work).  Kept separate from lds_fill: hipcc 7.2 fails ("Illegal instruction
+// detected: Operand has incorrect register class") when this body is inlined into the persistent sampling kernels.
+__device__ __forceinline__ void lds_fill_fast(float *lds, const float *blob, int total_floats) {
+  const f32x4 *src = reinterpret_cast<const f32x4 *>(blob);
+  f32x4 *dst = reinterpret_cast<f32x4 *>(lds);
+  const int n4 = total_floats / 4, stride = blockDim.x;
+  int i = threadIdx.x;
+  for (; i + 7 * stride < n4; i += 8 * stride) {
+    f32x4 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = src[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) dst[i + u * stride] = t[u];
+  }
+  for (; i < n4; i += stride) dst[i] = src[i];
+  __syncthreads();
+}
 // copy a packed weight blob (global) into LDS, all threads of the block
 __device__ __forceinline__ void lds_fill(float *lds, const float *blob, int total_floats) {
   const f32x4 *src = reinterpret_cast<const f32x4 *>(blob);

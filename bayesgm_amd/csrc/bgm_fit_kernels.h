@@ -93,7 +93,7 @@ template <int KTQ, int NTX, int NH, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void bgm_fit_fwd_kernel(BgmFitKArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const BgmMeta &m = a.m;
-  lds_fill(lds, a.blob, m.lds_resident);
+  lds_fill_fast(lds, a.blob, m.lds_resident);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
   BgmHeadStream hs;
   if constexpr (NTX == 0) hs.begin(a.blob, m, lds);
@@ -195,7 +195,7 @@ template <int KTQ, int NTX, int NH, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void bgm_fit_bwd_kernel(BgmFitKArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const BgmMeta &m = a.m;
-  lds_fill(lds, a.blob, m.lds_resident);
+  lds_fill_fast(lds, a.blob, m.lds_resident);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
   BgmHeadStream hs;
   if constexpr (NTX == 0) hs.begin(a.blob, m, lds);

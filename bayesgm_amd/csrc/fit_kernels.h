@@ -40,7 +40,7 @@ template <int KT1, int KSL1, int NTL, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void fit_fwd_kernel(FitKArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const CausalMeta &m = a.m;
-  lds_fill(lds, a.blob, m.total);
+  lds_fill_fast(lds, a.blob, m.total);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4, lane_off = 64 * g + j;
   const long long n_tiles = (a.B + 15) / 16;
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(64 * WAVES) void fit_bwd_kernel(FitKArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const CausalMeta &m = a.m;
   const FitMeta &bm = a.bm;
-  lds_fill(lds, a.blob, bm.total);
+  lds_fill_fast(lds, a.blob, bm.total);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4, lane_off = 64 * g + j;
   const long long n_tiles = (a.B + 15) / 16;

@@ -1,7 +1,7 @@
 """Fit-step throughput probe (dev tool): python scripts/probe_fit.py N B [lazy] [steps]"""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from bayesgm_amd.engine import CausalEngine
 from oracle import causal as OC
 N = int(float(sys.argv[1])); B = int(float(sys.argv[2])); lazy = len(sys.argv) > 3 and sys.argv[3] == "lazy"
