@@ -21,6 +21,7 @@ struct BgmState {
   // fit session (device)
   bool fit_active = false;
   int fit_bcap = 0, n_params = 0, rows_per_slice = 256, n_slices_cap = 0;
+  int batch_global = 0;   // > 0: losses are means over this many rows (data-parallel fit); 0: the local batch
   long long t_theta = 0, t_z = 0;
   float *theta_dev = nullptr, *m1_dev = nullptr, *m2_dev = nullptr, *tblob_dev = nullptr, *ws_dev = nullptr,
         *partial_dev = nullptr, *bn_dev = nullptr;

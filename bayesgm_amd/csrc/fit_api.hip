@@ -449,7 +449,7 @@ extern "C" int bgm_bgm_fit_begin(bgm_handle *h, int64_t n_rows, int32_t max_batc
   BGM_HIP_CHECK(hipMemcpy(s->theta_dev, s->theta.data(), sizeof(float) * np, hipMemcpyHostToDevice));
   BGM_HIP_CHECK(hipMemset(s->m1_dev, 0, sizeof(float) * np));
   BGM_HIP_CHECK(hipMemset(s->m2_dev, 0, sizeof(float) * np));
-  s->t_theta = 0; s->t_z = 0;
+  s->t_theta = 0; s->t_z = 0; s->batch_global = 0;
   std::vector<float> blob;
   bgm_pack_training(s, s->theta, blob);
   BGM_HIP_CHECK(hipMalloc(&s->tblob_dev, sizeof(float) * blob.size()));
@@ -520,7 +520,7 @@ static int bgm_fit_fwd_bwd(bgm_handle *h, BgmState *s, const float *x, const flo
   BGM_HIP_CHECK(hipGetLastError());
   BgmFitKArgs ka{};
   ka.blob = s->tblob_dev; ka.m = s->tmeta; ka.ws = s->fit_ws; ka.wsp = s->ws_dev; ka.x = x; ka.data_z = data_z;
-  ka.idx = idx; ka.B = batch; ka.inv_B = 1.0f / (float)batch; ka.bn = s->bn_dev; ka.loss = loss;
+  ka.idx = idx; ka.B = batch; ka.inv_B = 1.0f / (float)(s->batch_global > 0 ? s->batch_global : batch); ka.bn = s->bn_dev; ka.loss = loss;
   const int tiles = (batch + 15) / 16;
   const int grid = std::max(1, std::min((tiles + BGM_FIT_WAVES - 1) / BGM_FIT_WAVES, h->n_cus));
   const int lds = s->fit_lds_bytes;
@@ -549,6 +549,13 @@ static int bgm_fit_check(bgm_handle *h, const void *x, const void *z, const void
   return BGM_OK;
 }
 
+extern "C" int bgm_bgm_fit_set_global_batch(bgm_handle *h, int32_t batch_global) {
+  if (!h || !h->bgm_state || !bst(h)->fit_active) { bgm_set_error("bgm_bgm_fit_set_global_batch: call bgm_bgm_fit_begin first"); return BGM_E_STATE; }
+  if (batch_global < 0) { bgm_set_error("bgm_bgm_fit_set_global_batch: negative batch"); return BGM_E_INVALID; }
+  bst(h)->batch_global = batch_global;
+  return BGM_OK;
+}
+
 extern "C" int bgm_bgm_fit_theta_grad(bgm_handle *h, const float *x, const float *data_z, const int32_t *idx,
                                       int32_t batch, float *grad, double *loss, void *stream_) {
   int rc = bgm_fit_check(h, x, data_z, idx, batch, "bgm_bgm_fit_theta_grad");
@@ -570,7 +577,7 @@ extern "C" int bgm_bgm_fit_theta_grad(bgm_handle *h, const float *x, const float
   BGM_HIP_CHECK(hipGetLastError());
   // d gamma, d beta of the input BatchNorm -> grad[0..2q)
   hipLaunchKernelGGL(bgm_bn_bwd_kernel, dim3(1), dim3(256), 0, stream, s->ws_dev, s->fit_ws, s->bn_dev, batch, q, 16 * s->KTQ,
-                     1.0f / (float)batch, data_z, idx, grad, (float *)nullptr, 0);
+                     1.0f / (float)(s->batch_global > 0 ? s->batch_global : batch), data_z, idx, grad, (float *)nullptr, 0);
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
 }
@@ -605,7 +612,7 @@ extern "C" int bgm_bgm_fit_z_step(bgm_handle *h, const float *x, float *data_z, 
   const int q = s->cfg.z_dim;
   float *dz = s->ws_dev + s->fit_ws.dz;
   hipLaunchKernelGGL(bgm_bn_bwd_kernel, dim3(1), dim3(256), 0, stream, s->ws_dev, s->fit_ws, s->bn_dev, batch, q, 16 * s->KTQ,
-                     1.0f / (float)batch, data_z, idx, (float *)nullptr, dz, 1);
+                     1.0f / (float)(s->batch_global > 0 ? s->batch_global : batch), data_z, idx, (float *)nullptr, dz, 1);
   BGM_HIP_CHECK(hipGetLastError());
   s->t_z += 1;
   const double t = (double)s->t_z;

@@ -530,6 +530,9 @@ class BgmEngine(object):
         self.n_params = n.value
         return n.value
 
+    def fit_set_global_batch(self, batch_global):
+        _lib.check(self.lib.bgm_bgm_fit_set_global_batch(self.h, int(batch_global)), "bgm_bgm_fit_set_global_batch")
+
     def fit_theta_grad(self, x, data_z, idx, grad, loss=None):
         _lib.check(self.lib.bgm_bgm_fit_theta_grad(self.h, _ptr(x), _ptr(data_z), _ptr(idx), int(idx.numel()), _ptr(grad),
                                                    _ptr(loss), self._stream()), "bgm_bgm_fit_theta_grad")

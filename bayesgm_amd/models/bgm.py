@@ -50,8 +50,8 @@ class BGM(object):
                   "mean": (_glorot(self._rs, dims[-1], xd), np.zeros(xd, np.float32)),
                   "var": (_glorot(self._rs, dims[-1], xd), np.zeros(xd, np.float32))}
         self.z_sampler = Gaussian_sampler(mean=np.zeros(q), sd=1.0)
-        if device is None:
-            device = int(os.environ.get("LOCAL_RANK", 0))
+        if device is None:     # BGM_DEVICE: dev aid (several ranks on one GPU over gloo)
+            device = int(os.environ.get("BGM_DEVICE", os.environ.get("LOCAL_RANK", 0)))
         self.engine = BgmEngine(xd, q, g_units=p["g_units"], device=device)
         self.engine.set_weights(self.g)
         if self.timestamp is None:
@@ -179,28 +179,41 @@ class BGM(object):
     def fit(self, data, batch_size=32, epochs=100, epochs_per_eval=5, use_egm_init=True, egm_n_iter=20000,
             egm_batches_per_eval=500, verbose=1):
         """Iterative theta / Z updates (bgm/base.py:343-442).  The incomplete last minibatch of an epoch is
-        skipped (:399) and the batch latents take a fresh-slot Adam step (:402, see bgm_fit_kernels.h)."""
-        if parallel.is_dist():
-            raise NotImplementedError("bayesgm_amd: BGM.fit is single-GPU (BatchNorm batch statistics are not all-reduced)")
+        skipped (:399) and the batch latents take a fresh-slot Adam step (:402, see bgm_fit_kernels.h).
+
+        Under torch.distributed the fit is synchronous data parallel: every rank owns a contiguous
+        shard of the rows and their latents, takes `batch_size` of ITS rows per step (global minibatch = world x
+        batch_size), the theta gradients -- scaled by the global batch size -- are summed with one all-reduce, and
+        every rank applies the same Adam step.  Deviation, stated: the input BatchNorm of each rank normalises with
+        the statistics of its local batch; the moving averages are averaged over the ranks when the fit ends.  The EGM
+        warm start runs replicated (same seed, same minibatches on every rank)."""
+        dist_on = parallel.is_dist()
+        world = parallel.world_size()
         if use_egm_init:
             self.egm_init(data, egm_n_iter=egm_n_iter, batch_size=batch_size,
                           egm_batches_per_eval=egm_batches_per_eval, verbose=verbose)
         data = np.asarray(data, dtype=np.float32)
-        n = len(data)
-        if self._p['save_res']:
+        n_all = len(data)
+        lo_r, hi_r = parallel.shard_range(n_all)
+        data_loc = data[lo_r:hi_r]
+        n = len(data_loc)
+        if self._p['save_res'] and parallel.rank() == 0:
             with open('{}/params.txt'.format(self.save_dir), 'w') as f_params:
                 f_params.write(str(self.params))
         eng = self.engine
         dev = eng.device
-        x = self._dev(data)
+        x = self._dev(data_loc)
         if use_egm_init:
             print('Initialize latent variables Z with e(V)...')
             self.data_z = eng.egm_encode(x).contiguous()                                # :384
         else:
             print('Random initialization of latent variables Z...')
-            data_z_init = np.random.normal(0, 1, size=(n, eng.q)).astype('float32')     # :388
-            self.data_z = self._dev(data_z_init)
+            data_z_init = np.random.normal(0, 1, size=(n_all, eng.q)).astype('float32')     # :388
+            self.data_z = self._dev(data_z_init[lo_r:hi_r])
         n_params = eng.fit_begin(n, batch_size)
+        if dist_on:
+            eng.fit_set_global_batch(batch_size * world)
+        n_steps = len(range(0, n_all // world - batch_size + 1, batch_size))    # the same count on every rank
         grad = torch.empty(n_params, device=dev)
         loss = torch.zeros(4, device=dev, dtype=torch.float64)
         self.history_loss = []
@@ -211,23 +224,25 @@ class BGM(object):
                 sample_idx = torch.from_numpy(np.random.choice(n, n, replace=False).astype(np.int32)).to(dev)
                 loss.zero_()
                 n_used = 0
-                for i in range(0, n - batch_size + 1, batch_size):                  # skip the incomplete last batch
-                    idx = sample_idx[i:i + batch_size]
+                for k in range(n_steps):                                            # skip the incomplete last batch
+                    idx = sample_idx[k * batch_size:(k + 1) * batch_size]
                     eng.fit_theta_grad(x, self.data_z, idx, grad, loss)
+                    if dist_on:
+                        parallel.all_reduce_sum_(grad)
                     eng.fit_theta_apply(grad, self._p['lr_theta'])
                     eng.fit_z_step(x, self.data_z, idx, self._p['lr_z'], loss)
                     n_used += batch_size
                 if epoch % epochs_per_eval == 0:
                     self.g = eng.get_weights()
-                    mse_x = self.evaluate(data, data_z=self.data_z)
+                    mse_x = self._evaluate_sharded(data_loc, self.data_z, n_all)
                     self.history_loss.append(mse_x)
-                    if verbose:
+                    if verbose and parallel.rank() == 0:
                         l = loss.cpu().numpy() / max(1, n_used)
                         print('Epoch [%d/%d]: loss_x [%.4f], loss_mse_x [%.4f], MSE_x: %.4f\n'
-                              % (epoch, epochs, l[0], l[1] / eng.p, mse_x))
-                    if self._p['save_model']:
+                              % (epoch, epochs, l[0] * (world if dist_on else 1), l[1] / eng.p, mse_x))
+                    if self._p['save_model'] and parallel.rank() == 0:
                         self.save_checkpoint(epoch)
-                    if self._p['save_res']:
+                    if self._p['save_res'] and parallel.rank() == 0:
                         gen1, var1 = self.generate(nb_samples=5000)
                         gen12, var12 = self.generate(nb_samples=5000, use_x_sd=False)
                         np.savez('%s/data_gen_at_%d.npz' % (self.save_dir, epoch), gen1=gen1, gen12=gen12,
@@ -235,6 +250,22 @@ class BGM(object):
         finally:
             eng.fit_end()
             self.g = eng.get_weights()
+            if dist_on:     # identical parameters on every rank; the BatchNorm moving averages saw different local batches
+                st = torch.from_numpy(np.concatenate([self.g["bn"]["mean"], self.g["bn"]["var"]]).astype(np.float32)).to(dev)
+                parallel.all_reduce_sum_(st)
+                st = (st / world).cpu().numpy()
+                q = eng.q
+                self.g["bn"]["mean"], self.g["bn"]["var"] = st[:q].copy(), st[q:].copy()
+                eng.set_weights(self.g)
+
+    def _evaluate_sharded(self, data_loc, data_z_loc, n_all):
+        """evaluate() of the rows this rank owns, combined over the ranks (plain evaluate() when not distributed)."""
+        z = data_z_loc.cpu().numpy() if isinstance(data_z_loc, torch.Tensor) else np.asarray(data_z_loc, np.float32)
+        x_pred, _ = self._decode(z, True)
+        sse = torch.tensor([float(np.sum((np.asarray(data_loc, np.float32) - x_pred) ** 2))], dtype=torch.float64,
+                           device=self.engine.device)
+        parallel.all_reduce_sum_(sse)
+        return np.float32(sse.item() / (n_all * data_loc.shape[1]))
 
     def save_checkpoint(self, epoch):
         """Counterpart of g_net.save_weights(...) (bgm/base.py:431-434): generator parameters as .npz."""

@@ -317,12 +317,17 @@ int bgm_bgm_predict_draws(bgm_handle *h, const float *draws_dev, int64_t n, int6
 /* BGM.fit step functions.  replaces: BGM.update_g_net (bgm/base.py:145-164),
  * BGM.update_latent_variable_sgd (:167-187) and the loop body :399-413, with g_net called with
  * training=True (BatchNormalization on z uses the minibatch statistics and updates its moving
- * averages, networks/base.py:100).  Single GPU (the batch statistics are not all-reduced).
+ * averages, networks/base.py:100).  The batch statistics are those of the rows handed to the call (not all-reduced).
  *   theta order = bgm_bgm_set_weights order; the moving statistics receive a zero gradient.
  *   loss_dev (double[4], may be NULL): [0] += sum loss_x, [1] += sum |x-mu|^2 (theta phase),
  *                                      [2] += sum loss_px_z, [3] += sum |x-mu|^2 (z phase). */
 int bgm_bgm_fit_begin(bgm_handle *h, int64_t n_rows, int32_t max_batch, void *stream);
 int bgm_bgm_fit_n_params(bgm_handle *h, int64_t *n_params);
+/* Data-parallel fit: the batch-mean losses of the following steps are means over `batch_global` rows (the sum of the
+ * ranks' local batches), so that the all-reduced SUM of the ranks' gradients is the gradient of the global batch mean.
+ * The input BatchNorm of every rank still uses the statistics of its LOCAL batch (a stated deviation from one global
+ * batch).  0 (default) = the local batch. */
+int bgm_bgm_fit_set_global_batch(bgm_handle *h, int32_t batch_global);
 int bgm_bgm_fit_theta_grad(bgm_handle *h, const float *x_dev, const float *data_z_dev, const int32_t *idx_dev,
                            int32_t batch, float *grad_dev, double *loss_dev, void *stream);
 int bgm_bgm_fit_theta_apply(bgm_handle *h, const float *grad_dev, float lr_theta, void *stream);

@@ -357,3 +357,32 @@ def test_bgm_wide_panel_properties():
     ref = np.stack(ref)
     got = s1.cpu().numpy()[idx]
     assert np.all(np.abs(got - ref) <= 2e-3, axis=1).mean() >= 0.9
+
+
+def test_bgm_fit_global_batch_scaling_and_two_rank_run(tmp_path):
+    """Data-parallel fit: (i) with batch_global = 2 B every gradient entry is exactly half of the local-batch gradient
+    (the loss is a mean over the global batch; the per-rank BatchNorm statistics are unaffected), so the all-reduced
+    SUM over ranks is the global-mean gradient; (ii) a two-rank run (both ranks on this GPU, gloo) ends with bit-identical
+    parameters on both ranks and a falling reconstruction error."""
+    import os, subprocess, sys, torch
+    p, q, n, B = 20, 10, 200, 32
+    m = _model(91, q, p)
+    rs = np.random.RandomState(92)
+    x = torch.from_numpy(rs.randn(n, p).astype(np.float32)).cuda()
+    z = torch.from_numpy(rs.randn(n, q).astype(np.float32)).cuda()
+    idx = torch.from_numpy(rs.choice(n, B, replace=False).astype(np.int32)).cuda()
+    eng = _engine(m)
+    npar = eng.fit_begin(n, B)
+    g1, g2 = torch.empty(npar, device="cuda"), torch.empty(npar, device="cuda")
+    eng.fit_theta_grad(x, z, idx, g1)
+    eng.fit_set_global_batch(2 * B)
+    eng.fit_theta_grad(x, z, idx, g2)
+    assert torch.equal(g2 * 2.0, g1)
+    eng.fit_end()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BGM_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29533", os.path.join(root, "scripts", "dp_bgm_fit_smoke.py"), "gloo"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count('"param_spread": 0.0') == 2, r.stdout[-2000:]
