@@ -64,7 +64,8 @@ static int build_eblob(bgm_handle *h, EncMeta &m, hipStream_t stream) {
   const HostNet &E = h->nets[BGM_NET_E];
   if (!E.set) { bgm_set_error("encoder weights not set"); return BGM_E_STATE; }
   const int p = h->p, q = h->q;
-  const int KTV = (p + 15) / 16, NTQ = (q + 15) / 16;
+  const int KTV = bgm_enc_in_tiles(p), NTQ = (q + 15) / 16;
+  if (KTV < 0 || NTQ > 2) { bgm_set_error("encoder: v_dim > 208 or sum(z_dims) > 32 not compiled"); return BGM_E_UNSUPPORTED; }
   std::memset(&m, 0, sizeof(m));
   m.p = p; m.q = q; m.n_hh = h->cfg.n_hidden_e - 1;
   int off = 0;
@@ -96,7 +97,7 @@ static int build_eblob(bgm_handle *h, EncMeta &m, hipStream_t stream) {
   return BGM_OK;
 }
 
-#define BGM_ENC_VARIANTS(X) X(13, 1) X(7, 2) X(2, 1) X(2, 2)
+#define BGM_ENC_VARIANTS(X) X(13, 1) X(13, 2) X(7, 1) X(7, 2) X(2, 1) X(2, 2)
 static constexpr int ENC_WAVES = 8;
 
 extern "C" int bgm_causal_encode(bgm_handle *h, const float *v, int64_t n, float *z, void *stream_) {
@@ -110,7 +111,7 @@ extern "C" int bgm_causal_encode(bgm_handle *h, const float *v, int64_t n, float
   EncMeta m;
   int rc = build_eblob(h, m, stream);
   if (rc) return rc;
-  const int KTV = (h->p + 15) / 16, NTQ = (h->q + 15) / 16;
+  const int KTV = bgm_enc_in_tiles(h->p), NTQ = (h->q + 15) / 16;
   const long long tiles = (n + 15) / 16;
   const int grid = (int)std::max<long long>(1, std::min<long long>((tiles + ENC_WAVES - 1) / ENC_WAVES, h->n_cus));
   const int lds = m.total * 4;

@@ -79,6 +79,38 @@ struct bgm_handle {
   double timed_ms[3] = {0.0, 0.0, 0.0};
 };
 
+// Compiled kernel shapes.  A model runs on the smallest compiled shape that contains it; the extra K rows / output
+// tiles are zero weights (and zero-padded data), so results are unchanged and only some MFMAs are wasted.
+//   first layers (extended input z, x: q + 1 features):  (KT1, KSL1) = (1, 3) for q + 1 <= 12, (2, 1) for q + 1 <= 20
+//   g's last layer (p + 1 outputs):  NTL in {2, 7, 13} 16-wide tiles ({2, 7, 10} with KT1 = 2: LDS budget)
+// Returns false when no compiled shape contains the model.
+static inline bool bgm_causal_shape(int q1, int p1, int &KT1, int &KSL1, int &NTL) {
+  if (q1 <= 12) { KT1 = 1; KSL1 = 3; }
+  else if (q1 <= 20) { KT1 = 2; KSL1 = 1; }
+  else return false;
+  const int need = (p1 + 15) / 16;
+  const int big = (KT1 == 1) ? 13 : 10;
+  NTL = need <= 2 ? 2 : need <= 7 ? 7 : need <= big ? big : -1;
+  return NTL > 0;
+}
+static inline int bgm_enc_in_tiles(int p) { const int t = (p + 15) / 16; return t <= 2 ? 2 : t <= 7 ? 7 : t <= 13 ? 13 : -1; }
+
+// g's last layer [64 x (p + 1)] laid out for a compiled shape with NTL output tiles: the mean columns keep their natural
+// positions, the variance column (feature p) moves to element p % 16 of the LAST tile (where the sampling kernels look
+// for it at compile time), everything else is zero.  Identity when the shape is exact.
+static inline int bgm_sig_slot(int p, int NTL) { return 16 * (NTL - 1) + p % 16; }
+static inline void bgm_g_last_padded(const float *W, const float *b, int p, int NTL, std::vector<float> &Wp, std::vector<float> &bp) {
+  const int N = 16 * NTL, slot = bgm_sig_slot(p, NTL);
+  Wp.assign((size_t)64 * N, 0.0f);
+  bp.assign(N, 0.0f);
+  for (int i = 0; i < 64; ++i) {
+    for (int k = 0; k < p; ++k) Wp[(size_t)i * N + k] = W[(size_t)i * (p + 1) + k];
+    Wp[(size_t)i * N + slot] = W[(size_t)i * (p + 1) + p];
+  }
+  for (int k = 0; k < p; ++k) bp[k] = b[k];
+  bp[slot] = b[p];
+}
+
 int bgm_causal_build_blob(bgm_handle *h, hipStream_t stream);
 void bgm_bgm_free_state(bgm_handle *h);
 void bgm_egm_free_state(bgm_handle *h);

@@ -120,13 +120,16 @@ int causal_pack_forward(bgm_handle *h, const HostNet &G, const HostNet &F, const
   const int q = h->q, p = h->p;
   const int z0 = h->cfg.z_dims[0], z1 = h->cfg.z_dims[1], z2 = h->cfg.z_dims[2];
   const int q1 = q + 1;
-  const int KT1 = (q1 + 15) / 16;
-  const int KSL1 = (q1 - 16 * (KT1 - 1) + 3) / 4;
-  const int NTL = (p + 1 + 15) / 16;
+  int KT1, KSL1, NTL;
+  if (!bgm_causal_shape(q1, p + 1, KT1, KSL1, NTL)) {
+    bgm_set_error("no compiled kernel shape contains this model (needs sum(z_dims) <= 19 and v_dim <= 207, or <= 159 when sum(z_dims) > 11)");
+    return BGM_E_UNSUPPORTED;
+  }
   h->KT1 = KT1; h->KSL1 = KSL1; h->NTL = NTL;
   CausalMeta &m = h->meta;
   std::memset(&m, 0, sizeof(m));
   m.q = q; m.p = p; m.binary = h->cfg.binary_treatment ? 1 : 0;
+  m.sig_pc = p % 16; m.sig_slot = bgm_sig_slot(p, NTL);
   auto s2 = [](float s) { return s > 0.0f ? s * s : -1.0f; };
   m.sig2_v = s2(h->cfg.sigma_v); m.sig2_x = s2(h->cfg.sigma_x); m.sig2_y = s2(h->cfg.sigma_y);
   m.n_gh = h->cfg.n_hidden_g - 1;
@@ -165,8 +168,12 @@ int causal_pack_forward(bgm_handle *h, const HostNet &G, const HostNet &F, const
     pack_bias(blob, m.bg + l * 64, G.b(1 + l), 64, 4);
   }
   const int LG = (int)G.dims.size() - 2;  // index of last layer
-  pack_layer(blob, m.wgl, G.W(LG), 64, p + 1, 4, NTL, ident);
-  pack_bias(blob, m.bgl, G.b(LG), p + 1, NTL);
+  {
+    std::vector<float> Wp, bp;
+    bgm_g_last_padded(G.W(LG), G.b(LG), p, NTL, Wp, bp);
+    pack_layer(blob, m.wgl, Wp.data(), 64, 16 * NTL, 4, NTL, ident);
+    pack_bias(blob, m.bgl, bp.data(), 16 * NTL, NTL);
+  }
   pack_layer(blob, m.wf2, F.W(1), 64, 32, 4, 2, ident); pack_bias(blob, m.bf2, F.b(1), 32, 2);
   pack_layer(blob, m.wf3, F.W(2), 32, 8, 2, 1, ident); pack_bias(blob, m.bf3, F.b(2), 8, 1);
   pack_layer(blob, m.wf4, F.W(3), 8, 2, 1, 1, ident); pack_bias(blob, m.bf4, F.b(3), 2, 1);
@@ -212,7 +219,7 @@ int bgm_causal_build_blob(bgm_handle *h, hipStream_t stream) {
 #endif
 static constexpr int MH_R = BGM_MH_R, MH_WAVES = BGM_MH_WAVES;
 
-#define BGM_CAUSAL_VARIANTS(X) X(1, 3, 13) X(2, 1, 7) X(1, 3, 2) X(2, 1, 2)
+#define BGM_CAUSAL_VARIANTS(X) X(1, 3, 13) X(1, 3, 7) X(1, 3, 2) X(2, 1, 10) X(2, 1, 7) X(2, 1, 2)
 
 template <class K>
 static int set_lds(K kernel, int bytes) {
@@ -423,7 +430,8 @@ extern "C" int bgm_timing_read(bgm_handle *h, int kind, int64_t *n_launches, dou
 extern "C" int bgm_causal_mh_info(bgm_handle *h, int64_t n, bgm_mh_info *info) {
   if (!h || !h->configured || !info) { bgm_set_error("bgm_causal_mh_info: bad argument"); return BGM_E_INVALID; }
   const int q1 = h->q + 1;
-  const int KT1 = (q1 + 15) / 16, KSL1 = (q1 - 16 * (KT1 - 1) + 3) / 4, NTL = (h->p + 1 + 15) / 16;
+  int KT1, KSL1, NTL;
+  if (!bgm_causal_shape(q1, h->p + 1, KT1, KSL1, NTL)) { bgm_set_error("bgm_causal_mh_info: no compiled kernel shape contains this model"); return BGM_E_UNSUPPORTED; }
   const int ks1 = 4 * (KT1 - 1) + KSL1;
   const int n_gh = h->cfg.n_hidden_g - 1;
   info->rows_per_wave = 16 * MH_R;

@@ -14,7 +14,8 @@
 #include "bgm_device.h"
 
 struct CausalMeta {
-  int q, p, zq_f;       // zq_f unused placeholder (keeps struct 16B friendly)
+  int q, p;
+  int sig_pc, sig_slot; // g's variance column (feature p) sits at element sig_pc of the LAST output tile = padded column sig_slot
   int binary;
   float sig2_v, sig2_x, sig2_y;  // fixed variances (sigma^2) if > 0
   int n_gh;             // number of hidden->hidden 64x64 layers of g
@@ -192,7 +193,7 @@ __device__ __forceinline__ void causal_logp(const float *lds, const CausalMeta &
     PMARK(2);
 #pragma unroll
     for (int rr = 0; rr < R; ++rr) { ssq[rr] = 0.0f; sraw_v[rr] = 0.0f; }
-    const int pc = m.p - 16 * (NTL - 1);  // position of feature p inside the last tile
+    const int pc = m.sig_pc;  // position of the variance column inside the last tile (see bgm_g_last_padded)
     g_last_groups<0, 4, NTL, R>(lds + m.wgl, lds + m.bgl, lane_off, g, pc - 4 * g, h, vreg, ssq, sraw_v);
 #pragma unroll
     for (int rr = 0; rr < R; ++rr) sraw_v[rr] = __shfl(sraw_v[rr], j + 16 * (pc >> 2));
@@ -741,7 +742,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_eval_kernel(CausalEvalKArgs
 #pragma unroll
           for (int r = 0; r < 4; ++r) h[0][t][r] = lrelu(h2[0][t][r]);
       }
-      const int pc = m.p - 16 * (NTL - 1);
+      const int pc = m.sig_pc;
       g_last_groups<0, 4, NTL, 1>(lds + m.wgl, lds + m.bgl, lane_off, g, pc - 4 * g, h, vreg, ssq, sraw);
     }
     float mu_y[1], sr_y[1], mu_x[1], sr_x[1];

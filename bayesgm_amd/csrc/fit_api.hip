@@ -66,7 +66,11 @@ static void causal_pack_backward(bgm_handle *h, const HostNet &G, const HostNet 
   });
   for (int l = 0; l < h->meta.n_gh; ++l) pack_layer_t(blob, bm.wg + l * 4096, G.W(1 + l), 64, 64, 4, 4, ident);
   const int LG = (int)G.dims.size() - 2;
-  pack_layer_t(blob, bm.wgl, G.W(LG), 64, p + 1, NTL, 4, ident);
+  {
+    std::vector<float> Wp, bp;
+    bgm_g_last_padded(G.W(LG), G.b(LG), p, NTL, Wp, bp);
+    pack_layer_t(blob, bm.wgl, Wp.data(), 64, 16 * NTL, NTL, 4, ident);
+  }
   pack_layer_t(blob, bm.wf2, F.W(1), 64, 32, 2, 4, ident);
   pack_layer_t(blob, bm.wf3, F.W(2), 32, 8, 1, 2, ident);
   pack_layer_t(blob, bm.wf4, F.W(3), 8, 2, 1, 1, ident);
@@ -184,14 +188,16 @@ extern "C" int bgm_causal_fit_begin(bgm_handle *h, int64_t n_rows, int32_t max_b
   };
   const int z0 = h->cfg.z_dims[0], z1 = h->cfg.z_dims[1];
   // maps canonical (layer, in, out) -> partial offset
+  int out_slot_from = -1, out_slot_to = -1;   // one output column may live at another padded position (g's variance column)
   auto fill = [&](const HostNet &net, int base, int layer, int li, auto in_map) {
     const DwLayer &L = dw.layer[li];
     const int n_in = net.dims[layer], n_out = net.dims[layer + 1];
     const int wbase = base + (int)(net.W(layer) - net.theta.data());
+    auto om = [&](int o) { return o == out_slot_from ? out_slot_to : o; };
     for (int i = 0; i < n_in; ++i)
-      for (int o = 0; o < n_out; ++o) grad_src[wbase + i * n_out + o] = L.out_off + in_map(i) * L.N + o;
+      for (int o = 0; o < n_out; ++o) grad_src[wbase + i * n_out + o] = L.out_off + in_map(i) * L.N + om(o);
     const int bbase = base + (int)(net.b(layer) - net.theta.data());
-    for (int o = 0; o < n_out; ++o) grad_src[bbase + o] = L.out_off + L.K * L.N + o;
+    for (int o = 0; o < n_out; ++o) grad_src[bbase + o] = L.out_off + L.K * L.N + om(o);
   };
   auto idm = [](int i) { return i; };
   {
@@ -202,7 +208,9 @@ extern "C" int bgm_causal_fit_begin(bgm_handle *h, int64_t n_rows, int32_t max_b
       fill(G, 0, l, li, idm);
     }
     li = add(w.ag + (long long)n_gh * B * 64, w.dgl, 64, 16 * NTL);
+    out_slot_from = h->p; out_slot_to = bgm_sig_slot(h->p, NTL);
     fill(G, 0, n_gh + 1, li, idm);
+    out_slot_from = out_slot_to = -1;
     li = add(w.zin, w.df1, 16 * KT1, 64);
     fill(F, ng, 0, li, [&](int i) { return i < z0 + z1 ? i : q; });
     li = add(w.af1, w.df2, 64, 32); fill(F, ng, 1, li, idm);
@@ -230,7 +238,7 @@ extern "C" int bgm_causal_fit_begin(bgm_handle *h, int64_t n_rows, int32_t max_b
   return BGM_OK;
 }
 
-#define BGM_FIT_VARIANTS(X) X(1, 3, 13) X(2, 1, 7) X(1, 3, 2) X(2, 1, 2)
+#define BGM_FIT_VARIANTS(X) X(1, 3, 13) X(1, 3, 7) X(1, 3, 2) X(2, 1, 10) X(2, 1, 7) X(2, 1, 2)
 
 static int fit_grid(const bgm_handle *h, int B) {
   const int tiles = (B + 15) / 16;

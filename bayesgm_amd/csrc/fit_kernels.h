@@ -93,7 +93,7 @@ __global__ __launch_bounds__(64 * WAVES) void fit_fwd_kernel(FitKArgs a) {
         for (int r = 0; r < 4; ++r) {
           const int c = 16 * t + 4 * g + r;
           if (c < m.p) { const float d = vr[c] - o[0][t][r]; ssq = fmaf(d, d, ssq); }
-          if (c == m.p) sraw_v = o[0][t][r];
+          if (c == m.sig_slot) sraw_v = o[0][t][r];
         }
       ssq = sum_over_g(ssq);
       sraw_v = sum_over_g(sraw_v);  // only one lane group contributed a non-zero term
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(64 * WAVES) void fit_bwd_kernel(FitKArgs a) {
           const int c = 16 * t + 4 * g + r;
           float d = 0.0f;
           if (c < m.p) { d = vr[c] - o[0][t][r]; ssq = fmaf(d, d, ssq); }
-          if (c == m.p) sraw = o[0][t][r];
+          if (c == m.sig_slot) sraw = o[0][t][r];
           o[0][t][r] = d;  // residual v - mu
         }
       ssq = sum_over_g(ssq);
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(64 * WAVES) void fit_bwd_kernel(FitKArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int c = 16 * t + 4 * g + r;
-          o[0][t][r] = (c < m.p) ? cmu * o[0][t][r] : (c == m.p ? dsraw : 0.0f);
+          o[0][t][r] = (c < m.p) ? cmu * o[0][t][r] : (c == m.sig_slot ? dsraw : 0.0f);
         }
       if (theta) store_tiles<NTL>(ws + a.ws.dgl, 16 * NTL, b, ok, g, o);
       f32x4 dh[1][4];

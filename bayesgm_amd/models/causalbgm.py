@@ -60,7 +60,7 @@ class CausalBGM(object):
         }
         self.z_sampler = Gaussian_sampler(mean=np.zeros(q), sd=1.0)
         if device is None:
-            device = int(os.environ.get("LOCAL_RANK", 0))
+            device = int(os.environ.get("BGM_DEVICE", os.environ.get("LOCAL_RANK", 0)))   # BGM_DEVICE: dev aid
         self.engine = CausalEngine(p["v_dim"], z, binary_treatment=p["binary_treatment"], g_units=p["g_units"],
                                    f_units=p["f_units"], h_units=p["h_units"], e_units=p["e_units"],
                                    sigma_v=params.get("sigma_v"), sigma_x=params.get("sigma_x"),

@@ -69,6 +69,9 @@ int bgm_destroy(bgm_handle *h);
 
 /* Declare the model shape.  Synchronous.  replaces: CausalBGM.__init__ network
  * construction, causalbgm/base.py:64-84. */
+/* Supported: g_units = [64]*k, f_units = h_units = [64,32,8], e_units = [64]*k; sum(z_dims) <= 19; v_dim <= 207
+ * (<= 159 when sum(z_dims) > 11).  Any shape inside these limits runs on the smallest compiled kernel shape that
+ * contains it (zero padding, identical results). */
 int bgm_causal_configure(bgm_handle *h, const bgm_causal_config *cfg);
 
 /* Upload one network's parameters from HOST memory, flat float32 in Keras

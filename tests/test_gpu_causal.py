@@ -54,6 +54,12 @@ CASES = [
     dict(z_dims=[1, 1, 1, 7], p=20, binary=False, n=16),      # exactly one tile
     dict(z_dims=[1, 1, 1, 7], p=20, binary=False, n=1),       # single row
     dict(z_dims=[3, 3, 6, 6], p=25, binary=False, n=33),      # ragged tail, p not multiple of 4
+    # shapes between the compiled ones run on the next larger compiled shape (zero-padded tiles / K rows)
+    dict(z_dims=[1, 1, 1, 7], p=50, binary=False, n=70),      # 4 output tiles -> the 7-tile shape
+    dict(z_dims=[3, 3, 6, 6], p=150, binary=True, n=41),      # q+1 = 19, 10 output tiles
+    dict(z_dims=[2, 2, 2, 6], p=120, binary=False, n=35),     # q+1 = 13 -> the two-K-tile first layer; 8 tiles -> 10
+    dict(z_dims=[1, 1, 1, 2], p=5, binary=False, n=20),       # one output tile -> the 2-tile shape
+    dict(z_dims=[1, 1, 1, 7], p=207, binary=False, n=18),     # the largest v_dim (208 outputs)
 ]
 
 
@@ -93,7 +99,8 @@ def test_logpost_rows_are_independent():
 
 def test_encoder_matches_oracle():
     from oracle.nets import mlp_forward
-    for z_dims, p, n in (([1, 1, 1, 7], 200, 500), ([3, 3, 6, 6], 100, 100), ([1, 1, 1, 7], 20, 17)):
+    for z_dims, p, n in (([1, 1, 1, 7], 200, 500), ([3, 3, 6, 6], 100, 100), ([1, 1, 1, 7], 20, 17),
+                         ([3, 3, 6, 6], 150, 33), ([1, 1, 1, 7], 50, 40), ([1, 1, 1, 2], 5, 9)):
         m = _model(11, z_dims, p)
         _, _, v = _data(n, p, 12)
         got = _engine(m).encode(v).cpu().numpy()
@@ -104,7 +111,9 @@ def test_encoder_matches_oracle():
 
 @pytest.mark.parametrize("case", [dict(z_dims=[1, 1, 1, 7], p=200, binary=False, n=200),
                                   dict(z_dims=[3, 3, 6, 6], p=100, binary=True, n=150),
-                                  dict(z_dims=[1, 1, 1, 7], p=20, binary=False, n=40)])
+                                  dict(z_dims=[1, 1, 1, 7], p=20, binary=False, n=40),
+                                  dict(z_dims=[1, 1, 1, 7], p=50, binary=False, n=60),
+                                  dict(z_dims=[2, 2, 2, 6], p=150, binary=True, n=50)])
 def test_mh_chain_matches_oracle_chain(case):
     import torch
     from bayesgm_amd import _lib
