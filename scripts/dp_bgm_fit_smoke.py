@@ -20,7 +20,12 @@ bp = dict(dataset="dp", output_dir="gpurun_out/dp", save_res=False, save_model=F
           kl_weight=5e-5, lr=1e-3, g_d_freq=1, use_z_rec=True, alpha=0.0, gamma=0.0)
 m = BGM(bp, random_seed=3, device=dev)
 m.fit(data, epochs=6, epochs_per_eval=3, use_egm_init=False, verbose=0)
-flat = np.concatenate([m.g["bn"]["gamma"], m.g["bn"]["mean"], m.g["trunk"][0][0].ravel(), m.g["mean"][1]])
+miss = data[:257].copy()
+miss[::3, -1] = np.nan
+miss[1::5, 2] = np.nan                                  # ragged missing pattern, rows sharded over the ranks
+imp, interval = m.predict(miss, n_mcmc=20, burn_in=20)
+iv = np.concatenate([np.asarray(a, np.float32).ravel() for a in interval]) if isinstance(interval, list) else interval.ravel()
+flat = np.concatenate([m.g["bn"]["gamma"], m.g["bn"]["mean"], m.g["trunk"][0][0].ravel(), m.g["mean"][1], imp.ravel(), iv])
 t = torch.from_numpy(flat).cuda()
 mx, mn = t.clone(), t.clone()
 dist.all_reduce(mx, op=dist.ReduceOp.MAX); dist.all_reduce(mn, op=dist.ReduceOp.MIN)
