@@ -18,6 +18,7 @@ params = dict(dataset="dp", output_dir="gpurun_out/dp", save_res=False, save_mod
               z_dims=[1, 1, 1, 7], v_dim=50, lr_theta=1e-3, lr_z=1e-3, g_units=[64] * 5, f_units=[64, 32, 8], h_units=[64, 32, 8],
               e_units=[64] * 5, dz_units=[64, 32, 8], kl_weight=1e-4, lr=2e-4, g_d_freq=5, use_z_rec=True)
 m = CausalBGM(params, random_seed=2, device=dev)
+adrf0, interval0 = m.predict((x, y, v), alpha=0.05, n_mcmc=40, burn_in=40, x_values=np.linspace(0, 3, 6), q_sd=1.0, verbose=0)   # untrained, seeded
 m.fit((x, y, v), epochs=2, epochs_per_eval=1, batch_size=32, use_egm_init=False, verbose=0)
 adrf, interval = m.predict((x, y, v), alpha=0.05, n_mcmc=40, burn_in=40, x_values=np.linspace(0, 3, 6), q_sd=1.0, verbose=0)
 flat = np.concatenate([m.nets["g"][0][0].ravel(), m.nets["f"][-1][1], m.nets["h"][1][0].ravel(), adrf.ravel(), interval.ravel()]).astype(np.float32)
@@ -25,6 +26,7 @@ t = torch.from_numpy(flat).cuda()
 mx, mn = t.clone(), t.clone()
 dist.all_reduce(mx, op=dist.ReduceOp.MAX); dist.all_reduce(mn, op=dist.ReduceOp.MIN)
 spread = float((mx - mn).abs().max().item())
-print(json.dumps(dict(rank=dist.get_rank(), spread=spread, adrf=[float(a) for a in adrf])))
+print(json.dumps(dict(rank=dist.get_rank(), spread=spread, adrf=[float(a) for a in adrf], adrf_untrained=[float(a) for a in adrf0],
+                      interval_untrained=[float(a) for a in interval0.ravel()])))
 assert spread == 0.0 and np.all(np.isfinite(adrf))
 dist.destroy_process_group()
