@@ -123,6 +123,8 @@ SYMBOLS = {
     "bgm_bgm_predict_draws": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                         C.c_uint64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                         C.c_void_p]),
+    "bgm_causal_effects": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_uint64,
+                                     C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bgm_bgm_fit_set_global_batch": (C.c_int, [C.c_void_p, C.c_int32]),
     "bgm_bgm_egm_begin": (C.c_int, [C.c_void_p, C.POINTER(BgmEgmConfig), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                     C.c_int64, C.c_void_p]),

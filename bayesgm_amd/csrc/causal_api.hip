@@ -395,6 +395,48 @@ extern "C" int bgm_causal_evaluate(bgm_handle *h, const float *x, const float *y
   return binary ? launch_eval<2>(h, ka, grid, lds, stream) : launch_eval<1>(h, ka, grid, lds, stream);
 }
 
+template <int EFFECT>
+static int launch_effects(bgm_handle *h, const CausalEffKArgs &ka, int grid, int lds, hipStream_t stream) {
+  int rc;
+#define X(KT1_, KSL1_, NTL_)                                                                   \
+  if (h->KT1 == KT1_ && h->KSL1 == KSL1_ && h->NTL == NTL_) {                                  \
+    auto k = causal_effects_kernel<KT1_, KSL1_, MH_WAVES, EFFECT>;                             \
+    rc = set_lds(k, lds);                                                                      \
+    if (rc) return rc;                                                                         \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * MH_WAVES), lds, stream, ka);                   \
+    BGM_HIP_CHECK(hipGetLastError());                                                          \
+    return BGM_OK;                                                                             \
+  }
+  BGM_CAUSAL_VARIANTS(X)
+#undef X
+  bgm_set_error("no compiled effects kernel variant for this shape");
+  return BGM_E_UNSUPPORTED;
+}
+
+extern "C" int bgm_causal_effects(bgm_handle *h, const float *x, const float *draws, int64_t n, int64_t row_base, int32_t n_keep,
+                                  int32_t burn_in, uint64_t seed, int32_t sample_y, const float *x_values, int32_t n_doses,
+                                  float *adrf_partial, float *ite, void *stream_) {
+  if (!h || !h->configured) { bgm_set_error("bgm_causal_effects: handle not configured"); return BGM_E_STATE; }
+  if (n <= 0 || n_keep <= 0) return BGM_OK;
+  if (!x || !draws) { bgm_set_error("bgm_causal_effects: NULL pointer"); return BGM_E_INVALID; }
+  const bool binary = h->cfg.binary_treatment != 0;
+  if (binary && !ite) { bgm_set_error("bgm_causal_effects: ite_dev required for binary treatment"); return BGM_E_INVALID; }
+  if (!binary && (!x_values || n_doses <= 0 || !adrf_partial)) { bgm_set_error("bgm_causal_effects: x_values / adrf_partial required"); return BGM_E_INVALID; }
+  if (row_base + n > 0xFFFFFFFFll) { bgm_set_error("bgm_causal_effects: row index exceeds the 32-bit RNG counter"); return BGM_E_INVALID; }
+  hipStream_t stream = (hipStream_t)stream_;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  int rc = bgm_causal_build_blob(h, stream);
+  if (rc) return rc;
+  CausalEffKArgs ka{};
+  ka.blob = h->blob_dev; ka.x = x; ka.draws = draws; ka.n = n; ka.row_base = row_base; ka.n_keep = n_keep; ka.burn_in = burn_in;
+  ka.sample_y = sample_y; ka.n_doses = binary ? 2 : n_doses; ka.x_values = x_values; ka.adrf_partial = adrf_partial; ka.ite = ite;
+  ka.k0 = (unsigned)(seed & 0xFFFFFFFFull); ka.k1 = (unsigned)(seed >> 32); ka.m = h->meta;
+  const int64_t tiles = (n + 15) / 16;
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((tiles + MH_WAVES - 1) / MH_WAVES, h->n_cus));
+  const int lds = h->meta.total * 4 + 64;
+  return binary ? launch_effects<2>(h, ka, grid, lds, stream) : launch_effects<1>(h, ka, grid, lds, stream);
+}
+
 extern "C" int bgm_causal_evaluate_slots(bgm_handle *h, int64_t n, int32_t *n_slots) {
   if (!h || !n_slots) { bgm_set_error("bgm_causal_evaluate_slots: NULL"); return BGM_E_INVALID; }
   const int64_t tiles = (n + 15) / 16;

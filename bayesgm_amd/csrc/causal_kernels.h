@@ -783,6 +783,50 @@ __global__ __launch_bounds__(64 * WAVES) void causal_eval_kernel(CausalEvalKArgs
   }
 }
 
+// ---------------------------------------------------------------------------
+// infer_from_latent_posterior (base.py:671-763) on a GIVEN tensor of posterior draws [n_keep x n x q]: the same
+// effect routine and the same noise counters (iteration = burn_in + d) as the pass fused into the MH kernel, so
+// both routes give the same numbers for the same draws.
+// ---------------------------------------------------------------------------
+struct CausalEffKArgs {
+  const float *blob, *x, *draws;
+  long long n, row_base;
+  int n_keep, burn_in, sample_y, n_doses;
+  const float *x_values;
+  float *adrf_partial;   // [n_slots][n_doses][n_keep]
+  float *ite;            // [n][n_keep]
+  unsigned k0, k1;
+  CausalMeta m;
+};
+
+template <int KT1, int KSL1, int WAVES, int EFFECT>
+__global__ __launch_bounds__(64 * WAVES) void causal_effects_kernel(CausalEffKArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const CausalMeta &m = a.m;
+  lds_fill(lds, a.blob, m.total);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4, lane_off = 64 * g + j;
+  const long long n = a.n, n_tiles = (n + 15) / 16;
+  const long long slot = (long long)blockIdx.x * WAVES + wave;
+  for (long long tile = slot; tile < n_tiles; tile += (long long)gridDim.x * WAVES) {
+    const long long row0 = tile * 16;
+    long long row = row0 + j;
+    bool valid[1] = {row < n};
+    row = row < n ? row : n - 1;
+    float xr[1] = {a.x[row]};
+    unsigned rowid[1] = {(unsigned)(a.row_base + row)};
+    for (int d = 0; d < a.n_keep; ++d) {
+      BGM_NO_HOIST();
+      f32x4 zin[1][KT1];
+      load_z_rows<KT1, 1>(a.draws + (long long)d * n * m.q, n, m.q, row0, j, g, xr, zin);
+      causal_effects<KT1, KSL1, 1, EFFECT>(lds, m, lane_off, g, j, lane, zin, rowid, valid, row0, n, (unsigned)(a.burn_in + d), d,
+                                           a.n_keep, a.sample_y, a.n_doses, a.x_values,
+                                           a.adrf_partial ? a.adrf_partial + slot * (long long)a.n_doses * a.n_keep : nullptr, a.ite,
+                                           a.k0, a.k1);
+    }
+  }
+}
+
 // acc[it_begin + i] += sum over wave slots of scratch[slot][i]
 static __global__ void acc_reduce_kernel(const unsigned *scratch, int n_slots, int n_iters, unsigned *acc) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

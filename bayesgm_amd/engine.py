@@ -183,6 +183,27 @@ class CausalEngine(object):
         dose_sums = self.adrf_reduce(partial, ns.value, xv.numel(), 1, 1.0).reshape(-1)
         return sums, dose_sums
 
+    def effects(self, x, draws, burn_in, seed, x_values=None, sample_y=True, row_base=0):
+        """infer_from_latent_posterior (causalbgm/base.py:671-763) for draws [n_keep, n, q] on the device:
+        binary -> ITE draws [n_keep, n]; continuous -> ADRF draws [n_doses, n_keep] (mean over the n rows)."""
+        x = _f32(x, self.device).reshape(-1)
+        draws = _f32(draws, self.device)
+        n_keep, n, _ = draws.shape
+        seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        if self.binary:
+            ite = torch.empty((n, n_keep), device=self.device, dtype=torch.float32)
+            _lib.check(self.lib.bgm_causal_effects(self.h, _ptr(x), _ptr(draws), n, int(row_base), n_keep, int(burn_in), seed,
+                                                   int(bool(sample_y)), None, 0, None, _ptr(ite), self._stream()), "bgm_causal_effects")
+            return ite.t().contiguous()
+        xv = _f32(np.atleast_1d(np.asarray(x_values, dtype=np.float32)), self.device)
+        ns = C.c_int32()
+        _lib.check(self.lib.bgm_causal_evaluate_slots(self.h, n, C.byref(ns)), "bgm_causal_evaluate_slots")
+        partial = torch.zeros((ns.value, xv.numel(), n_keep), device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.bgm_causal_effects(self.h, _ptr(x), _ptr(draws), n, int(row_base), n_keep, int(burn_in), seed,
+                                               int(bool(sample_y)), _ptr(xv), xv.numel(), _ptr(partial), None, self._stream()),
+                   "bgm_causal_effects")
+        return self.adrf_reduce(partial, ns.value, xv.numel(), n_keep, n)
+
     # -- fit step functions ------------------------------------------------------
     def fit_begin(self, n_rows, max_batch):
         _lib.check(self.lib.bgm_causal_fit_begin(self.h, int(n_rows), int(max_batch), self._stream()),

@@ -410,6 +410,18 @@ class CausalBGM(object):
         print(f"Final MCMC Acceptance Rate: {self.last_acceptance_rate:.4f}")
         return out["draws"].cpu().numpy()
 
+    def infer_from_latent_posterior(self, data_posterior_z, x_values=None, sample_y=True, eps=1e-6, seed=None):
+        """Causal effects from posterior draws of Z, shape (n_keep, n, q) (base.py:671-763): binary treatment -> ITE draws
+        (n_keep, n); continuous -> ADRF draws (len(x_values), n_keep).  `predict` computes the same quantities inside the
+        sampling kernel without materialising the draws; this is the stand-alone form of the reference."""
+        draws = self._dev(data_posterior_z)
+        if not self._p["binary_treatment"] and x_values is None:
+            raise ValueError("For continuous treatment, `x_values` must not be None. Provide a list or numpy array.")
+        n = draws.shape[1]
+        x0 = torch.zeros(n, device=self.engine.device)          # the treatment slot is overwritten by the counterfactual dose
+        out = self.engine.effects(x0, draws, 0, self._next_seed() if seed is None else seed, x_values=x_values, sample_y=sample_y)
+        return out.cpu().numpy()
+
     def get_log_posterior(self, data_x, data_y, data_v, data_z, eps=1e-6):
         """log p(z | x, y, v) + const, shape (n,) (base.py:765-817)."""
         return self.engine.logpost(self._dev(data_x).reshape(-1), self._dev(data_y).reshape(-1), self._dev(data_v),

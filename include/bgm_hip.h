@@ -171,6 +171,15 @@ int bgm_causal_evaluate(bgm_handle *h, const float *x_dev, const float *y_dev, c
                         double *sums_dev, float *adrf_partial_dev, float *ite_dev, void *stream);
 int bgm_causal_evaluate_slots(bgm_handle *h, int64_t n, int32_t *n_slots);
 
+/* replaces: CausalBGM.infer_from_latent_posterior, causalbgm/base.py:671-763, on a given tensor of posterior draws
+ * draws_dev [n_keep x n x q] (the pass fused into bgm_causal_mh_run computes the same numbers from the same draws:
+ * outcome noise of draw d = Philox(row_base + row, burn_in + d, dose block)).  binary -> ite_dev [n x n_keep];
+ * continuous -> adrf_partial_dev [n_slots x n_doses x n_keep] (+=; n_slots = bgm_causal_evaluate_slots; reduce with
+ * bgm_adrf_reduce). */
+int bgm_causal_effects(bgm_handle *h, const float *x_dev, const float *draws_dev, int64_t n, int64_t row_base,
+                       int32_t n_keep, int32_t burn_in, uint64_t seed, int32_t sample_y, const float *x_values_dev,
+                       int32_t n_doses, float *adrf_partial_dev, float *ite_dev, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * CausalBGM.fit step functions (iterative theta / Z updates).
  * replaces: update_g_net :156-180, update_h_net :183-214, update_f_net :217-243,

@@ -264,3 +264,36 @@ def test_full_size_panel_properties():
     ref_adrf = OC.infer_from_latent_posterior(m64, small["draws"].cpu().numpy().astype(np.float64), x_values=doses,
                                               sample_y=True, seed=5, row0=lo, burn_in=burn)
     assert np.abs(small["adrf"].cpu().numpy() - ref_adrf).max() <= 5e-4
+
+
+@pytest.mark.parametrize("binary", [False, True])
+def test_standalone_effects_from_draws_match_oracle_and_the_fused_pass(binary):
+    """infer_from_latent_posterior on a given draw tensor (bgm_causal_effects): equals the oracle on the same draws and
+    the numbers the MH kernel's fused effect pass produced for those draws (same noise counters)."""
+    from bayesgm_amd import _lib
+    z_dims, p, n, burn, keep, seed = [1, 1, 1, 7], 50, 83, 6, 5, 21
+    m = _model(41, z_dims, p, binary)
+    x, y, v = _data(n, p, 42, binary)
+    eng = _engine(m)
+    doses = np.linspace(0, 3, 7).astype(np.float32)
+    eff = _lib.EFFECT_ITE if binary else _lib.EFFECT_ADRF
+    fused = eng.mh_sample(x, y, v, burn, keep, 1.0, seed, want_draws=True, effect=eff, x_values=None if binary else doses, sample_y=True)
+    draws = fused["draws"]
+    alone = eng.effects(x, draws, burn, seed, x_values=None if binary else doses, sample_y=True)
+    ref = OC.infer_from_latent_posterior(OC.cast_model(m, np.float64), draws.cpu().numpy().astype(np.float64),
+                                         x_values=None if binary else doses, sample_y=True, seed=seed, burn_in=burn)
+    got = alone.cpu().numpy()
+    assert got.shape == ref.shape and np.abs(got - ref).max() <= 2e-4
+    fused_out = fused["ite"].t().cpu().numpy() if binary else fused["adrf"].cpu().numpy()
+    assert np.abs(got - fused_out).max() <= 1e-5
+    # the class method (reference signature)
+    from bayesgm_amd.models import CausalBGM
+    params = dict(dataset="t", output_dir="/tmp", save_res=False, save_model=False, binary_treatment=binary, use_bnn=False,
+                  z_dims=z_dims, v_dim=p, lr_theta=1e-4, lr_z=1e-4, g_units=[64] * 5, f_units=[64, 32, 8], h_units=[64, 32, 8],
+                  e_units=[64] * 5, dz_units=[64, 32, 8], kl_weight=1e-4, lr=2e-4, g_d_freq=5, use_z_rec=True)
+    model = CausalBGM(params, random_seed=1)
+    out = model.infer_from_latent_posterior(draws.cpu().numpy(), x_values=None if binary else doses, sample_y=False)
+    assert out.shape == ref.shape and np.all(np.isfinite(out))
+    if not binary:
+        with pytest.raises(ValueError):
+            model.infer_from_latent_posterior(draws.cpu().numpy())
