@@ -3,9 +3,19 @@
 import os
 import re
 
+import pytest
+
 from bayesgm_amd import _lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built_library():
+    # The .so is git-ignored: on a fresh checkout build it the same way __graft_entry__.build()
+    # does (hipcc cross-compiles gfx950 without a GPU; a no-op when the library is current).
+    from bayesgm_amd.csrc.build import build
+    build(force=False, verbose=False)
 
 
 def _declared_symbols():
