@@ -1,0 +1,148 @@
+"""Hand-derived gradients of the Bayesian-net step functions (oracle/bnn.py) against PyTorch autograd (fp64),
+and the counter-based noise layout."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import bnn as OB
+
+
+def _t(a):
+    return torch.tensor(np.asarray(a), dtype=torch.float64)
+
+
+def _tnet(net):
+    return {"gamma": _t(net["gamma"]).requires_grad_(), "beta": _t(net["beta"]).requires_grad_(),
+            "layers": [tuple(_t(a).requires_grad_() for a in L) for L in net["layers"]]}
+
+
+def _tfwd(net, x, noise):
+    mu = x.mean(0)
+    var = x.var(0, unbiased=False)
+    h = (x - mu) / torch.sqrt(var + 1e-3) * net["gamma"] + net["beta"]
+    L = len(net["layers"])
+    for l, (loc, rho, bias) in enumerate(net["layers"]):
+        sg = OB.SCALE_EPS + torch.nn.functional.softplus(rho)
+        pre = h @ loc + ((h * _t(noise["sin"][l])) @ (sg * _t(noise["eps"][l]))) * _t(noise["sout"][l]) + bias
+        h = torch.nn.functional.leaky_relu(pre, 0.2) if l < L - 1 else pre
+    return h
+
+
+def _tkl(net):
+    v = 0.0
+    for loc, rho, _ in net["layers"]:
+        sg = OB.SCALE_EPS + torch.nn.functional.softplus(rho)
+        q = torch.distributions.Normal(loc, sg)
+        v = v + torch.distributions.kl_divergence(q, torch.distributions.Normal(torch.zeros_like(loc), 1.0)).sum()
+    return v
+
+
+def _gauss(ssq, raw, dim):
+    s2 = torch.nn.functional.softplus(raw) + 1e-6
+    return (ssq / (2 * s2) + dim * torch.log(s2) / 2).mean()
+
+
+def _model(binary, seed=0):
+    m = OB.init_model(seed, [2, 1, 2, 3], 9, binary, g_units=(12, 10), e_units=(8,), f_units=(7, 5), h_units=(6, 4),
+                      dtype=np.float64)
+    rs = np.random.RandomState(seed + 1)
+    for k in ("g", "f", "h"):        # non-trivial gamma / beta
+        m[k]["gamma"] = 1.0 + 0.3 * rs.standard_normal(m[k]["gamma"].shape)
+        m[k]["beta"] = 0.2 * rs.standard_normal(m[k]["beta"].shape)
+    return m
+
+
+def _data(m, B, seed=3):
+    rs = np.random.RandomState(seed)
+    q = sum(m["z_dims"])
+    z = rs.standard_normal((B, q))
+    v = rs.standard_normal((B, m["v_dim"]))
+    x = (rs.rand(B, 1) > 0.5).astype(np.float64) if m["binary_treatment"] else rs.exponential(size=(B, 1))
+    y = rs.standard_normal((B, 1))
+    return z, x, y, v
+
+
+@pytest.mark.parametrize("binary", [False, True])
+@pytest.mark.parametrize("name", ["g", "h", "f"])
+def test_theta_step_matches_autograd(binary, name):
+    m = _model(binary)
+    z, x, y, v = _data(m, 11)
+    rs = np.random.RandomState(5)
+    noise = OB.random_noise(rs, OB.net_dims(m[name]), len(z))
+    loss, aux, g = OB.theta_step(m, name, z, x, y, v, noise, kl_weight=0.37)
+    tn = _tnet(m[name])
+    fin, hin = OB._inputs(m, z, x)
+    inp = {"g": z, "f": fin, "h": hin}[name]
+    out = _tfwd(tn, _t(inp), noise)
+    if name == "g":
+        p = m["v_dim"]
+        tl = _gauss(((_t(v) - out[:, :p]) ** 2).sum(1), out[:, -1], p)
+    elif name == "h" and binary:
+        tl = torch.nn.functional.binary_cross_entropy_with_logits(out[:, 0], _t(x[:, 0]))
+    else:
+        tgt = x if name == "h" else y
+        tl = _gauss((_t(tgt[:, 0]) - out[:, 0]) ** 2, out[:, -1], 1)
+    tl = tl + 0.37 * _tkl(tn)
+    tl.backward()
+    assert abs(float(tl.detach()) - loss) < 1e-9 * max(1.0, abs(loss))
+    ref = [tn["gamma"].grad, tn["beta"].grad] + [a.grad for L in tn["layers"] for a in L]
+    for a, b in zip(OB.flat_grads(g), ref):
+        np.testing.assert_allclose(a, b.numpy(), rtol=1e-8, atol=1e-11)
+
+
+@pytest.mark.parametrize("binary", [False, True])
+def test_z_step_matches_autograd(binary):
+    m = _model(binary, seed=2)
+    z, x, y, v = _data(m, 9)
+    rs = np.random.RandomState(7)
+    noises = {k: (OB.random_noise(rs, OB.net_dims(m[k]), len(z)), OB.random_noise(rs, OB.net_dims(m[k]), len(z)))
+              for k in ("g", "h", "f")}
+    loss, dz = OB.z_step(m, z, x, y, v, noises)
+    tz = _t(z).requires_grad_()
+    z0d, z1d, z2d, _ = m["z_dims"]
+    fin = torch.cat([tz[:, :z0d + z1d], _t(x)], 1)
+    hin = torch.cat([tz[:, :z0d], tz[:, z0d + z1d:z0d + z1d + z2d]], 1)
+    tg, tf, th = (_tnet(m[k]) for k in ("g", "f", "h"))
+    p = m["v_dim"]
+    o1, o2 = _tfwd(tg, tz, noises["g"][0]), _tfwd(tg, tz, noises["g"][1])
+    tl = _gauss(((_t(v) - o1[:, :p]) ** 2).sum(1), o2[:, -1], p)
+    h1 = _tfwd(th, hin, noises["h"][0])
+    if binary:
+        tl = tl + torch.nn.functional.binary_cross_entropy_with_logits(h1[:, 0], _t(x[:, 0]))
+    else:
+        h2 = _tfwd(th, hin, noises["h"][1])
+        tl = tl + _gauss((_t(x[:, 0]) - h1[:, 0]) ** 2, h2[:, -1], 1)
+    f1, f2 = _tfwd(tf, fin, noises["f"][0]), _tfwd(tf, fin, noises["f"][1])
+    tl = tl + _gauss((_t(y[:, 0]) - f1[:, 0]) ** 2, f2[:, -1], 1) + (tz ** 2).sum(1).mean() / 2
+    tl.backward()
+    assert abs(float(tl.detach()) - loss) < 1e-9 * max(1.0, abs(loss))
+    np.testing.assert_allclose(dz, tz.grad.numpy(), rtol=1e-8, atol=1e-11)
+
+
+def test_fixed_stats_forward_equals_batch_stats_and_logpost_finite():
+    m = _model(False)
+    z, x, y, v = _data(m, 40)
+    dims = {k: OB.net_dims(m[k]) for k in ("g", "h", "f")}
+    noises = {k: OB.draw_noise(dims[k], len(z), key=1234567, stream=5, net_id=OB.NET_ID[k], dtype=np.float64)
+              for k in dims}
+    fin, hin = OB._inputs(m, z, x)
+    stats = {"g": OB.batch_stats(z), "h": OB.batch_stats(hin), "f": OB.batch_stats(fin)}
+    a = OB.log_posterior(m, x, y, v, z, noises)
+    b = OB.log_posterior(m, x, y, v, z, noises, stats)
+    np.testing.assert_allclose(a, b, rtol=1e-12)
+    assert np.isfinite(a).all()
+
+
+def test_noise_layout_is_deterministic_and_balanced():
+    dims = [10, 64, 64, 201]
+    n1 = OB.draw_noise(dims, 300, key=(7 << 32) | 99, stream=3, net_id=0)
+    n2 = OB.draw_noise(dims, 300, key=(7 << 32) | 99, stream=3, net_id=0)
+    n3 = OB.draw_noise(dims, 300, key=(7 << 32) | 99, stream=4, net_id=0)
+    for a, b in zip(n1["eps"] + n1["sin"] + n1["sout"], n2["eps"] + n2["sin"] + n2["sout"]):
+        assert np.array_equal(a, b)
+    assert not np.array_equal(n1["eps"][1], n3["eps"][1])
+    assert n1["sout"][2].shape == (300, 201) and set(np.unique(n1["sin"][1])) == {-1.0, 1.0}
+    assert abs(n1["sout"][2].mean()) < 0.02 and abs(n1["eps"][1].std() - 1.0) < 0.05
+    # rows of a later slice of the batch see the same words as the full batch
+    part = OB.draw_noise(dims, 100, key=(7 << 32) | 99, stream=3, net_id=0, row0=200)
+    assert np.array_equal(part["sin"][1], n1["sin"][1][200:])
