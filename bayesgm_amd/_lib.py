@@ -54,6 +54,12 @@ class HmcArgs(C.Structure):
     ]
 
 
+class BnnConfig(C.Structure):
+    _fields_ = [("v_dim", C.c_int32), ("z_dims", C.c_int32 * 4), ("binary_treatment", C.c_int32),
+                ("n_hidden", C.c_int32 * 4), ("units", (C.c_int32 * BGM_MAX_LAYERS) * 4),
+                ("kl_weight", C.c_float), ("max_batch", C.c_int32)]
+
+
 class EgmConfig(C.Structure):
     _fields_ = [("batch_size", C.c_int32), ("n_hidden_dz", C.c_int32), ("dz_units", C.c_int32 * BGM_MAX_LAYERS),
                 ("lr", C.c_float), ("use_z_rec", C.c_int32)]
@@ -136,6 +142,18 @@ SYMBOLS = {
     "bgm_bgm_egm_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "bgm_bgm_egm_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bgm_bgm_egm_end": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bgm_bnn_begin": (C.c_int, [C.c_void_p, C.POINTER(BnnConfig), C.c_void_p, C.c_int64, C.c_void_p]),
+    "bgm_bnn_layout": (C.c_int, [C.POINTER(BnnConfig), C.POINTER(C.c_int64)]),
+    "bgm_bnn_read": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "bgm_bnn_write": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "bgm_bnn_theta_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                     C.c_float, C.c_uint64, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "bgm_bnn_grad_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "bgm_bnn_theta_apply": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p]),
+    "bgm_bnn_z_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_uint64, C.c_uint32, C.c_void_p,
+                                 C.c_void_p, C.c_void_p]),
+    "bgm_bnn_end": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bgm_debug_group_probe": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     "bgm_causal_egm_begin": (C.c_int, [C.c_void_p, C.POINTER(EgmConfig), C.c_void_p, C.c_int64, C.c_void_p]),
     "bgm_causal_egm_disc_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_void_p,

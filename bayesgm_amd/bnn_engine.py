@@ -1,0 +1,137 @@
+"""Python driver of the Bayesian-network (``use_bnn=True``) session of the C ABI (include/bgm_hip.h, bgm_bnn_*).
+
+PyTorch supplies device memory and the HIP stream only; there is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import _ptr, _f32, DEFAULT_G_UNITS, DEFAULT_FH_UNITS
+
+NETS = ("g", "e", "f", "h")          # parameter order of a session (BGM_BNN_G, _E, _F, _H)
+
+
+def flatten_bnn(net):
+    """{"gamma", "beta", "layers": [(loc, rho, bias), ...]} -> flat float32 in session order."""
+    parts = [net["gamma"], net["beta"]] + [a for L in net["layers"] for a in L]
+    return np.concatenate([np.asarray(a, np.float32).ravel() for a in parts]).astype(np.float32)
+
+
+def unflatten_bnn(theta, dims):
+    o = 0
+
+    def take(shape):
+        nonlocal o
+        n = int(np.prod(shape))
+        a = np.array(theta[o:o + n], dtype=np.float32).reshape(shape)
+        o += n
+        return a
+    net = {"gamma": take((dims[0],)), "beta": take((dims[0],)), "layers": []}
+    for l in range(len(dims) - 1):
+        net["layers"].append((take((dims[l], dims[l + 1])), take((dims[l], dims[l + 1])), take((dims[l + 1],))))
+    assert o == len(theta)
+    return net
+
+
+class BnnEngine(object):
+    """One session: parameters of g, e, f, h with their Adam slots on the device, step and sampling kernels."""
+
+    def __init__(self, v_dim, z_dims, binary_treatment=False, g_units=None, e_units=None, f_units=None, h_units=None,
+                 kl_weight=1e-4, max_batch=32, device=0):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("bayesgm_amd: no HIP device visible; the hot path has no CPU fallback")
+        self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
+        torch.zeros(1, device=self.device)
+        self.v_dim, self.z_dims = int(v_dim), [int(z) for z in z_dims]
+        self.q = sum(self.z_dims)
+        self.binary = bool(binary_treatment)
+        cfg = _lib.BnnConfig()
+        cfg.v_dim = self.v_dim
+        for i in range(4):
+            cfg.z_dims[i] = self.z_dims[i]
+        cfg.binary_treatment = int(self.binary)
+        units = [list(DEFAULT_G_UNITS if g_units is None else g_units), list(DEFAULT_G_UNITS if e_units is None else e_units),
+                 list(DEFAULT_FH_UNITS if f_units is None else f_units), list(DEFAULT_FH_UNITS if h_units is None else h_units)]
+        for k in range(4):
+            if len(units[k]) + 1 > _lib.BGM_MAX_LAYERS:
+                raise ValueError("%s_units: at most %d hidden layers" % (NETS[k], _lib.BGM_MAX_LAYERS - 1))
+            cfg.n_hidden[k] = len(units[k])
+            for i, u in enumerate(units[k]):
+                cfg.units[k][i] = int(u)
+        cfg.kl_weight = float(kl_weight)
+        cfg.max_batch = int(max_batch)
+        self.cfg = cfg
+        z0, z1, z2, _ = self.z_dims
+        ins = [self.q, self.v_dim, z0 + z1 + 1, z0 + z2]
+        outs = [self.v_dim + 1, self.q, 2, 2]
+        self.dims = {NETS[k]: [ins[k]] + units[k] + [outs[k]] for k in range(4)}
+        offs = (C.c_int64 * 5)()
+        _lib.check(self.lib.bgm_bnn_layout(C.byref(cfg), offs), "bgm_bnn_layout")
+        self.offsets = [int(o) for o in offs]
+        self.n_params = self.offsets[4]
+        self.h = C.c_void_p()
+        _lib.check(self.lib.bgm_create(C.byref(self.h), self.device.index), "bgm_create")
+        self.open = False
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.bgm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # -- parameters --------------------------------------------------------------------------------
+    def begin(self, model):
+        """model: {"g": net, "e": net, "f": net, "h": net} (oracle/bnn.py structure) or a flat float32 vector."""
+        theta = model if isinstance(model, np.ndarray) else np.concatenate([flatten_bnn(model[k]) for k in NETS])
+        theta = np.ascontiguousarray(theta, np.float32)
+        _lib.check(self.lib.bgm_bnn_begin(self.h, C.byref(self.cfg), theta.ctypes.data_as(C.c_void_p), theta.size, self._stream()),
+                   "bgm_bnn_begin")
+        self.open = True
+
+    def read(self, what=0):
+        out = np.empty(self.n_params, np.float32)
+        _lib.check(self.lib.bgm_bnn_read(self.h, what, out.ctypes.data_as(C.c_void_p), out.size, self._stream()), "bgm_bnn_read")
+        return out
+
+    def write(self, theta, what=0):
+        theta = np.ascontiguousarray(theta, np.float32)
+        _lib.check(self.lib.bgm_bnn_write(self.h, what, theta.ctypes.data_as(C.c_void_p), theta.size, self._stream()), "bgm_bnn_write")
+
+    def split(self, theta):
+        return {NETS[k]: unflatten_bnn(theta[self.offsets[k]:self.offsets[k + 1]], self.dims[NETS[k]]) for k in range(4)}
+
+    def grad_tensor(self):
+        """The session's gradient buffer as a torch tensor view (for the data-parallel all-reduce)."""
+        ptr, cnt = C.c_void_p(), C.c_int64()
+        _lib.check(self.lib.bgm_bnn_grad_dev(self.h, C.byref(ptr), C.byref(cnt)), "bgm_bnn_grad_dev")
+        raise NotImplementedError
+
+    # -- minibatch steps -----------------------------------------------------------------------------
+    def theta_step(self, data_z, idx, x, y, v, lr_theta, seed, stream_id, apply=True, batch_global=0, out=None):
+        _lib.check(self.lib.bgm_bnn_theta_step(self.h, _ptr(data_z), _ptr(idx), _ptr(x), _ptr(y), _ptr(v), idx.numel(),
+                                               batch_global, float(lr_theta), int(seed), int(stream_id) & 0xFFFFFFFF,
+                                               int(apply), _ptr(out), self._stream()), "bgm_bnn_theta_step")
+
+    def theta_apply(self, lr_theta):
+        _lib.check(self.lib.bgm_bnn_theta_apply(self.h, float(lr_theta), self._stream()), "bgm_bnn_theta_apply")
+
+    def z_step(self, x, y, v, data_z, zm, zv, idx, lr_z, seed, stream_id, lazy=False, batch_global=0, out=None, dz_out=None):
+        _lib.check(self.lib.bgm_bnn_z_step(self.h, _ptr(x), _ptr(y), _ptr(v), _ptr(data_z), _ptr(zm), _ptr(zv), _ptr(idx),
+                                           data_z.shape[0], idx.numel(), batch_global, float(lr_z), int(lazy), int(seed),
+                                           int(stream_id) & 0xFFFFFFFF, _ptr(out), _ptr(dz_out), self._stream()),
+                   "bgm_bnn_z_step")
+
+    def end(self):
+        _lib.check(self.lib.bgm_bnn_end(self.h, self._stream()), "bgm_bnn_end")
+        self.open = False

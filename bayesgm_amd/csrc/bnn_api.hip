@@ -1,0 +1,232 @@
+// bnn_api.hip -- C ABI of the Bayesian-network (use_bnn=True) CausalBGM path: session, minibatch steps.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "bgm_host.h"
+#include "bnn_kernels.h"
+#include "bnn_state.h"
+
+static BnnState *bst(bgm_handle *h) { return static_cast<BnnState *>(h->bnn_state); }
+
+void bgm_bnn_free_state(bgm_handle *h) {
+  if (!h->bnn_state) return;
+  BnnState *s = bst(h);
+  if (s->dev) hipFree(s->dev);
+  bnn_free_sampler(s);
+  delete s;
+  h->bnn_state = nullptr;
+}
+
+static int bnn_fill(const bgm_bnn_config *cfg, BnnNet net[4], int64_t offsets[5]) {
+  if (!cfg) return BGM_E_INVALID;
+  const int q = cfg->z_dims[0] + cfg->z_dims[1] + cfg->z_dims[2] + cfg->z_dims[3], p = cfg->v_dim;
+  if (q < 1 || p < 1 || cfg->z_dims[0] < 0 || cfg->z_dims[1] < 0 || cfg->z_dims[2] < 0 || cfg->z_dims[3] < 0) return BGM_E_INVALID;
+  const int in[4] = {q, p, cfg->z_dims[0] + cfg->z_dims[1] + 1, cfg->z_dims[0] + cfg->z_dims[2]};
+  const int out[4] = {p + 1, q, 2, 2};
+  int off = 0;
+  for (int k = 0; k < 4; ++k) {
+    const int nh = cfg->n_hidden[k];
+    if (nh < 1 || nh + 1 > BNN_MAX_LAYERS || in[k] < 1) return BGM_E_INVALID;
+    BnnNet &n = net[k];
+    std::memset(&n, 0, sizeof(n));
+    n.n_layers = nh + 1;
+    n.dims[0] = in[k];
+    for (int i = 0; i < nh; ++i) { if (cfg->units[k][i] < 1) return BGM_E_INVALID; n.dims[i + 1] = cfg->units[k][i]; }
+    n.dims[nh + 1] = out[k];
+    n.off = off;
+    n.net_id = k;
+    bnn_finish_net(n);
+    offsets[k] = off;
+    off += n.n_params;
+  }
+  offsets[4] = off;
+  return BGM_OK;
+}
+
+extern "C" int bgm_bnn_layout(const bgm_bnn_config *cfg, int64_t offsets[5]) {
+  BnnNet net[4];
+  if (!offsets || bnn_fill(cfg, net, offsets)) { bgm_set_error("bgm_bnn_layout: bad configuration"); return BGM_E_INVALID; }
+  return BGM_OK;
+}
+
+extern "C" int bgm_bnn_begin(bgm_handle *h, const bgm_bnn_config *cfg, const float *theta_host, int64_t count, void *stream_) {
+  (void)stream_;
+  if (!h) { bgm_set_error("bgm_bnn_begin: NULL handle"); return BGM_E_INVALID; }
+  if (!cfg || !theta_host) { bgm_set_error("bgm_bnn_begin: NULL argument"); return BGM_E_INVALID; }
+  if (cfg->max_batch < 2 || cfg->max_batch > 64) { bgm_set_error("bgm_bnn_begin: max_batch must be in [2, 64]"); return BGM_E_UNSUPPORTED; }
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  bgm_bnn_free_state(h);
+  BnnState *s = new BnnState();
+  h->bnn_state = s;
+  s->cfg = *cfg;
+  int64_t offs[5];
+  if (bnn_fill(cfg, s->net, offs)) { bgm_bnn_free_state(h); bgm_set_error("bgm_bnn_begin: bad configuration"); return BGM_E_INVALID; }
+  s->n_params = (int)offs[4];
+  if (count != offs[4]) { bgm_bnn_free_state(h); bgm_set_error("bgm_bnn_begin: wrong parameter count"); return BGM_E_INVALID; }
+  s->q = s->net[BNN_G].dims[0];
+  s->p = cfg->v_dim;
+  int wmax = 0;
+  long long cache_max = 0;
+  const int B = cfg->max_batch;
+  for (int k = 0; k < 4; ++k) {
+    const BnnNet &n = s->net[k];
+    for (int i = 0; i <= n.n_layers; ++i) wmax = std::max(wmax, n.dims[i]);
+    long long c = (long long)B * n.dims[0] + n.dims[0] + 2LL * B * n.hoff[n.n_layers + 1] + 2LL * n.eoff[n.n_layers] + (long long)B * n.swords + 64;
+    cache_max = std::max(cache_max, c);
+  }
+  s->wmax = wmax;
+  const long long gather = (long long)B * (s->q + s->p + 2 + s->net[BNN_F].dims[0] + s->net[BNN_H].dims[0]) + 64;
+  s->ws_floats = (size_t)(gather + 6LL * B * wmax + 64 + 2 * cache_max);
+  const size_t np = ((size_t)s->n_params + 63) & ~(size_t)63;
+  const size_t total = 4 * np + s->ws_floats + 64 + (size_t)B * s->q + 64;
+  BGM_HIP_CHECK(hipMalloc((void **)&s->dev, sizeof(float) * total));
+  BGM_HIP_CHECK(hipMemset(s->dev, 0, sizeof(float) * total));
+  s->theta_dev = s->dev; s->m_dev = s->dev + np; s->v_dev = s->dev + 2 * np; s->grad_dev = s->dev + 3 * np;
+  s->ws_dev = s->dev + 4 * np;
+  s->out_dev = s->ws_dev + s->ws_floats;
+  s->dz_dev = s->out_dev + 64;
+  BGM_HIP_CHECK(hipMemcpy(s->theta_dev, theta_host, sizeof(float) * count, hipMemcpyHostToDevice));
+  s->t_theta = 0; s->t_z = 0;
+  return BGM_OK;
+}
+
+static int bnn_need(bgm_handle *h, const char *who) {
+  if (!h || !h->bnn_state) { bgm_set_error(std::string(who) + ": no session (bgm_bnn_begin)"); return BGM_E_STATE; }
+  return BGM_OK;
+}
+
+static float *bnn_what(BnnState *s, int what) {
+  return what == 0 ? s->theta_dev : what == 1 ? s->grad_dev : what == 2 ? s->m_dev : what == 3 ? s->v_dev : nullptr;
+}
+
+extern "C" int bgm_bnn_read(bgm_handle *h, int32_t what, float *host, int64_t count, void *stream_) {
+  int rc = bnn_need(h, "bgm_bnn_read");
+  if (rc) return rc;
+  BnnState *s = bst(h);
+  float *src = bnn_what(s, what);
+  if (!src || !host || count != s->n_params) { bgm_set_error("bgm_bnn_read: bad argument"); return BGM_E_INVALID; }
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  BGM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_));
+  BGM_HIP_CHECK(hipMemcpy(host, src, sizeof(float) * count, hipMemcpyDeviceToHost));
+  return BGM_OK;
+}
+
+extern "C" int bgm_bnn_write(bgm_handle *h, int32_t what, const float *host, int64_t count, void *stream_) {
+  int rc = bnn_need(h, "bgm_bnn_write");
+  if (rc) return rc;
+  BnnState *s = bst(h);
+  float *dst = bnn_what(s, what);
+  if (!dst || !host || count != s->n_params) { bgm_set_error("bgm_bnn_write: bad argument"); return BGM_E_INVALID; }
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  BGM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_));
+  BGM_HIP_CHECK(hipMemcpy(dst, host, sizeof(float) * count, hipMemcpyHostToDevice));
+  s->packed_valid = false;
+  return BGM_OK;
+}
+
+extern "C" int bgm_bnn_grad_dev(bgm_handle *h, float **grad_dev, int64_t *count) {
+  int rc = bnn_need(h, "bgm_bnn_grad_dev");
+  if (rc) return rc;
+  if (grad_dev) *grad_dev = bst(h)->grad_dev;
+  if (count) *count = bst(h)->n_params;
+  return BGM_OK;
+}
+
+static float adam_lr_t(float lr, long long t_) {
+  const double t = (double)t_;
+  return (float)((double)lr * std::sqrt(1.0 - std::pow((double)BNN_ADAM_B2, t)) / (1.0 - std::pow((double)BNN_ADAM_B1, t)));
+}
+
+static void bnn_base_args(BnnState *s, BnnArgs &a, int batch, int batch_global, uint64_t seed, uint32_t stream_id) {
+  for (int k = 0; k < 4; ++k) a.net[k] = s->net[k];
+  a.theta = s->theta_dev; a.m = s->m_dev; a.v = s->v_dev; a.grad = s->grad_dev;
+  a.B = batch; a.q = s->q; a.p = s->p;
+  a.z0 = s->cfg.z_dims[0]; a.z1 = s->cfg.z_dims[1]; a.z2 = s->cfg.z_dims[2];
+  a.binary = s->cfg.binary_treatment; a.wmax = s->wmax; a.kl_weight = s->cfg.kl_weight;
+  a.k0 = (uint32_t)(seed & 0xFFFFFFFFull); a.k1 = (uint32_t)(seed >> 32); a.stream = stream_id;
+  a.inv_B = 1.0f / (float)(batch_global > 0 ? batch_global : batch);
+  a.ws = s->ws_dev;
+}
+
+extern "C" int bgm_bnn_theta_step(bgm_handle *h, const float *data_z, const int32_t *idx, const float *x, const float *y,
+                                  const float *v, int32_t batch, int32_t batch_global, float lr_theta, uint64_t seed,
+                                  uint32_t stream_id, int32_t apply, float *out, void *stream_) {
+  int rc = bnn_need(h, "bgm_bnn_theta_step");
+  if (rc) return rc;
+  BnnState *s = bst(h);
+  if (!data_z || !idx || !x || !y || !v) { bgm_set_error("bgm_bnn_theta_step: NULL argument"); return BGM_E_INVALID; }
+  if (batch < 2 || batch > s->cfg.max_batch) { bgm_set_error("bgm_bnn_theta_step: batch outside [2, max_batch]"); return BGM_E_INVALID; }
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  BnnArgs a{};
+  bnn_base_args(s, a, batch, batch_global, seed, stream_id);
+  a.data_z = data_z; a.idx = idx; a.x_ = x; a.y_ = y; a.v_ = v;
+  a.apply = apply; a.out = out;
+  if (apply) { s->t_theta += 1; a.adam = BnnAdam{adam_lr_t(lr_theta, s->t_theta), BNN_ADAM_B1, BNN_ADAM_B2, BNN_ADAM_EPS}; }
+  hipLaunchKernelGGL(bnn_theta_step_kernel, dim3(1), dim3(BNN_THREADS), 0, (hipStream_t)stream_, a);
+  BGM_HIP_CHECK(hipGetLastError());
+  if (apply) s->packed_valid = false;
+  return BGM_OK;
+}
+
+extern "C" int bgm_bnn_theta_apply(bgm_handle *h, float lr_theta, void *stream_) {
+  int rc = bnn_need(h, "bgm_bnn_theta_apply");
+  if (rc) return rc;
+  BnnState *s = bst(h);
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  s->t_theta += 1;
+  const BnnAdam ad{adam_lr_t(lr_theta, s->t_theta), BNN_ADAM_B1, BNN_ADAM_B2, BNN_ADAM_EPS};
+  for (int k : {BNN_G, BNN_H, BNN_F}) {   // the encoder is not trained by the iterative updates
+    const BnnNet &n = s->net[k];
+    hipLaunchKernelGGL(bnn_adam_kernel, dim3((n.n_params + 255) / 256), dim3(256), 0, (hipStream_t)stream_, s->theta_dev + n.off,
+                       s->m_dev + n.off, s->v_dev + n.off, s->grad_dev + n.off, n.n_params, ad);
+  }
+  BGM_HIP_CHECK(hipGetLastError());
+  s->packed_valid = false;
+  return BGM_OK;
+}
+
+extern "C" int bgm_bnn_z_step(bgm_handle *h, const float *x, const float *y, const float *v, float *data_z, float *zm, float *zv,
+                              const int32_t *idx, int64_t n_rows, int32_t batch, int32_t batch_global, float lr_z, int32_t lazy,
+                              uint64_t seed, uint32_t stream_id, float *out, float *dz_out, void *stream_) {
+  int rc = bnn_need(h, "bgm_bnn_z_step");
+  if (rc) return rc;
+  BnnState *s = bst(h);
+  if (!data_z || !idx || !x || !y || !v) { bgm_set_error("bgm_bnn_z_step: NULL argument"); return BGM_E_INVALID; }
+  if (batch < 2 || batch > s->cfg.max_batch) { bgm_set_error("bgm_bnn_z_step: batch outside [2, max_batch]"); return BGM_E_INVALID; }
+  if (!dz_out && (!zm || !zv)) { bgm_set_error("bgm_bnn_z_step: NULL Adam slots"); return BGM_E_INVALID; }
+  hipStream_t stream = (hipStream_t)stream_;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  BnnArgs a{};
+  bnn_base_args(s, a, batch, batch_global, seed, stream_id);
+  a.data_z = data_z; a.idx = idx; a.x_ = x; a.y_ = y; a.v_ = v;
+  a.out = out; a.dz = dz_out ? dz_out : s->dz_dev;
+  hipLaunchKernelGGL(bnn_z_grad_kernel, dim3(1), dim3(BNN_THREADS), 0, stream, a);
+  BGM_HIP_CHECK(hipGetLastError());
+  if (dz_out) return BGM_OK;    // gradient only (parity tests)
+  s->t_z += 1;
+  const float lr_t = adam_lr_t(lr_z, s->t_z);
+  const int q = s->q;
+  const long long n = (long long)n_rows * q;
+  const int nb = batch * q;
+  if (lazy) {
+    hipLaunchKernelGGL(bnn_z_rows_kernel, dim3((nb + 255) / 256), dim3(256), 0, stream, data_z, zm, zv, a.dz, idx, batch, q, lr_t,
+                       BNN_ADAM_B1, BNN_ADAM_B2, BNN_ADAM_EPS, 1);
+  } else {
+    hipLaunchKernelGGL(bnn_z_decay_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, zm, zv, n, BNN_ADAM_B1, BNN_ADAM_B2);
+    hipLaunchKernelGGL(bnn_z_rows_kernel, dim3((nb + 255) / 256), dim3(256), 0, stream, data_z, zm, zv, a.dz, idx, batch, q, lr_t,
+                       BNN_ADAM_B1, BNN_ADAM_B2, BNN_ADAM_EPS, 0);
+    hipLaunchKernelGGL(bnn_z_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, data_z, zm, zv, n, lr_t, BNN_ADAM_EPS);
+  }
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+extern "C" int bgm_bnn_end(bgm_handle *h, void *stream_) {
+  if (!h) return BGM_E_INVALID;
+  if (!h->bnn_state) return BGM_OK;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  BGM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_));
+  bgm_bnn_free_state(h);
+  return BGM_OK;
+}

@@ -1,0 +1,570 @@
+// bnn_kernels.h -- CausalBGM with Bayesian networks (use_bnn=True) on gfx950: minibatch steps.
+//
+// replaces (src/bayesgm/models/networks/bnn.py:4-38 BayesianFullyConnectedNet, i.e. input BatchNormalization on BATCH
+// statistics + tfp.layers.DenseFlipout stack) inside
+//   update_g_net / update_h_net / update_f_net   causalbgm/base.py:156-243   -> bnn_theta_step_kernel
+//   update_latent_variable_sgd                   causalbgm/base.py:246-302   -> bnn_z_grad_kernel
+// Semantics (TFP 0.18 DenseFlipout, Keras BatchNormalization) and the counter-based noise layout are restated in
+// oracle/bnn.py, whose hand-derived gradients these kernels follow.
+//
+// Like the EGM steps these are B = 32 minibatch steps where latency, not throughput, is the cost: ONE launch of ONE
+// 512-thread workgroup walks noise generation, forward, backward, KL and Adam with workgroup barriers between the
+// phases.  A Flipout layer is two GEMMs over the same index space, y = h loc + ((h * s_in) dW) * s_out + b: both run
+// in one pass of 16x16 fp32-MFMA tiles with two accumulators (bnn_gemm2), and so do the two halves of each
+// backward product.  eps and dW = sigma * eps of a call are materialised once (they are needed again in backward).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "bgm_device.h"
+
+#define BNN_THREADS 512
+#define BNN_MAX_LAYERS 8
+#define BNN_LEAK 0.2f
+#define BNN_BN_EPS 1e-3f
+#define BNN_SCALE_EPS 1.1920928955078125e-07f
+#define BNN_TAG_EPS 8u
+#define BNN_TAG_SIGN 9u
+
+// One BayesianFullyConnectedNet.  Parameters (flat, at theta + off): gamma[in], beta[in], then per layer
+// loc[in x out], rho[in x out], bias[out].  All prefix tables are filled on the host (bnn_finish_net).
+struct BnnNet {
+  int n_layers;                       // DenseFlipout layers (hidden + output)
+  int dims[BNN_MAX_LAYERS + 1];
+  int off, n_params, net_id;
+  int woff[BNN_MAX_LAYERS];           // loc of layer l (rho at + in*out, bias at + 2*in*out)
+  int hoff[BNN_MAX_LAYERS + 2];       // h_l (input of layer l; h_L = output) at B * hoff[l]; hoff[L+1] = total width
+  int eoff[BNN_MAX_LAYERS + 1];       // eps / dW of layer l inside one call's noise block; eoff[L] = kernel elements
+  int sin_w[BNN_MAX_LAYERS], sout_w[BNN_MAX_LAYERS], swords;   // sign words per row (oracle/bnn.py sign_layout)
+};
+inline void bnn_finish_net(BnnNet &n) {
+  int o = n.off + 2 * n.dims[0], h = 0, e = 0, w = 0;
+  for (int l = 0; l < n.n_layers; ++l) {
+    const int in = n.dims[l], out = n.dims[l + 1];
+    n.woff[l] = o; o += 2 * in * out + out;
+    n.hoff[l] = h; h += in;
+    n.eoff[l] = e; e += in * out;
+    n.sin_w[l] = w; w += (in + 31) / 32;
+    n.sout_w[l] = w; w += (out + 31) / 32;
+  }
+  n.hoff[n.n_layers] = h; n.hoff[n.n_layers + 1] = h + n.dims[n.n_layers];
+  n.eoff[n.n_layers] = e;
+  n.swords = (w + 3) / 4 * 4;
+  n.n_params = o - n.off;
+}
+
+struct BnnAdam { float lr_t, b1, b2, eps; };
+
+struct BnnCtx { int tid; float *red; };
+
+__device__ __forceinline__ float bnn_block_sum(const BnnCtx &c, float v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  __syncthreads();
+  if ((c.tid & 63) == 0) c.red[c.tid >> 6] = v;
+  __syncthreads();
+  float t = 0.0f;
+  for (int w = 0; w < BNN_THREADS / 64; ++w) t += c.red[w];
+  return t;
+}
+
+// sign of (row, column) in the bit string that starts at word w0 of the row: +1 / -1
+__device__ __forceinline__ float bnn_sign(const uint32_t *sg, int swords, int row, int w0, int col) {
+  const uint32_t w = sg[(long long)row * swords + w0 + (col >> 5)];
+  return ((w >> (col & 31)) & 1u) ? -1.0f : 1.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Two GEMMs over one index space: C1 = A1 B1, C2 = A2 B2, [M x K] x [K x N], arbitrary element strides.  One 16x16
+// output tile per wave and round, K in steps of 4 (v_mfma_f32_16x16x4_f32): lane (j = lane & 15, g = lane >> 4)
+// feeds A(m0 + j, 4s + g), B(4s + g, n0 + j) and receives C(m0 + 4g + r, n0 + j) in register r.  K in chunks of 8
+// steps with all 32 operand loads of a chunk in flight before its first MFMA.
+// ---------------------------------------------------------------------------------------------
+struct BnnMat { const float *p; int s0, s1; };   // element (i, j) at p[i * s0 + j * s1]
+
+template <class Epi>
+__device__ __forceinline__ void bnn_gemm2(int tid, BnnMat A1, BnnMat A2, BnnMat B1, BnnMat B2, int M, int N, int K,
+                                          int tile_begin, int tile_stride, Epi epi) {
+  const int lane = tid & 63, j = lane & 15, g = lane >> 4;
+  const int tn_count = (N + 15) >> 4, tiles = ((M + 15) >> 4) * tn_count;
+  for (int t = tile_begin; t < tiles; t += tile_stride) {
+    const int m0 = (t / tn_count) << 4, n0 = (t % tn_count) << 4;
+    const float am = (m0 + j < M) ? 1.0f : 0.0f, bn = (n0 + j < N) ? 1.0f : 0.0f;
+    const long long ao = (long long)min(m0 + j, M - 1) * A1.s0, bo = (long long)min(n0 + j, N - 1) * B1.s1;
+    f32x4 c1 = {0.0f, 0.0f, 0.0f, 0.0f}, c2 = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int k0 = 0; k0 < K; k0 += 32) {
+      float a1[8], a2[8], b1[8], b2[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = k0 + 4 * u + g;
+        const int kc = min(k, K - 1);
+        const float mk = (k < K) ? am : 0.0f;
+        a1[u] = A1.p[ao + (long long)kc * A1.s1] * mk;
+        a2[u] = A2.p[ao + (long long)kc * A1.s1] * mk;
+        b1[u] = B1.p[bo + (long long)kc * B1.s0];
+        b2[u] = B2.p[bo + (long long)kc * B1.s0];
+      }
+      BGM_NO_HOIST();
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        c1 = BGM_MFMA(a1[u], b1[u] * bn, c1);
+        c2 = BGM_MFMA(a2[u], b2[u] * bn, c2);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + 4 * g + r, n = n0 + j;
+      if (m < M && n < N) epi(m, n, c1[r], c2[r]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One call of a net on a batch of B rows: cache, noise, forward, backward
+// ---------------------------------------------------------------------------------------------
+struct BnnCache {
+  const float *x;     // [B x in] raw input of the call
+  float *xhat, *inv;  // normalised input [B x in], 1 / sqrt(var + eps) [in]
+  float *H, *HS;      // h_l and h_l * s_in(l) at B * hoff[l]
+  float *eps, *dW;    // [kernel elements]
+  uint32_t *sg;       // [B x swords]
+};
+__device__ __forceinline__ void bnn_cache(const BnnNet &n, int B, float *&p, BnnCache &k, const float *input) {
+  auto take = [&](long long cnt) { float *r = p; p += (cnt + 3) & ~3LL; return r; };
+  k.x = input;
+  k.xhat = take((long long)B * n.dims[0]);
+  k.inv = take(n.dims[0]);
+  k.H = take((long long)B * n.hoff[n.n_layers + 1]);
+  k.HS = take((long long)B * n.hoff[n.n_layers + 1]);
+  k.eps = take(n.eoff[n.n_layers]);
+  k.dW = take(n.eoff[n.n_layers]);
+  k.sg = (uint32_t *)take((long long)B * n.swords);
+}
+
+// eps, dW = sigma * eps and the sign words of call `stream` (oracle/bnn.py draw_noise).  No barrier at the end.
+__device__ __forceinline__ void bnn_noise(const BnnCtx &c, const float *theta, const BnnNet &n, const BnnCache &k, int B,
+                                          uint32_t k0, uint32_t k1, uint32_t stream) {
+  for (int l = 0; l < n.n_layers; ++l) {
+    const int cnt = n.dims[l] * n.dims[l + 1];
+    const float *rho = theta + n.woff[l] + cnt;
+    float *e = k.eps + n.eoff[l], *d = k.dW + n.eoff[l];
+    for (int i = c.tid; i < (cnt + 3) >> 2; i += BNN_THREADS) {
+      const f32x4 z = box_muller4(philox4x32_10((uint32_t)i, (uint32_t)l | ((uint32_t)n.net_id << 16), stream, BNN_TAG_EPS, k0, k1));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = 4 * i + u;
+        if (idx < cnt) { e[idx] = z[u]; d[idx] = (BNN_SCALE_EPS + softplus_acc(rho[idx])) * z[u]; }
+      }
+    }
+  }
+  const int calls = n.swords >> 2;
+  for (int i = c.tid; i < B * calls; i += BNN_THREADS) {
+    const int r = i / calls, cc = i - r * calls;
+    const uint4 w = philox4x32_10((uint32_t)r, (uint32_t)cc | ((uint32_t)n.net_id << 16), stream, BNN_TAG_SIGN, k0, k1);
+    uint32_t *dst = k.sg + (long long)r * n.swords + 4 * cc;
+    dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
+  }
+}
+
+// BatchNormalization on batch statistics, h_0 = gamma * xhat + beta, and hs_0.  Needs the sign words (barrier before).
+__device__ __forceinline__ void bnn_bn_fwd(const BnnCtx &c, const float *theta, const BnnNet &n, const BnnCache &k, int B) {
+  const int in = n.dims[0];
+  const float *gamma = theta + n.off, *beta = gamma + in;
+  for (int i = c.tid; i < in; i += BNN_THREADS) {
+    float s = 0.0f;
+    for (int b = 0; b < B; ++b) s += k.x[(long long)b * in + i];
+    const float mu = s / (float)B;
+    float v = 0.0f;
+    for (int b = 0; b < B; ++b) { const float d = k.x[(long long)b * in + i] - mu; v = fmaf(d, d, v); }
+    const float inv = 1.0f / sqrtf(v / (float)B + BNN_BN_EPS);
+    k.inv[i] = inv;
+    for (int b = 0; b < B; ++b) {
+      const float xh = (k.x[(long long)b * in + i] - mu) * inv;
+      const float h = xh * gamma[i] + beta[i];
+      k.xhat[(long long)b * in + i] = xh;
+      k.H[(long long)b * in + i] = h;
+      k.HS[(long long)b * in + i] = h * bnn_sign(k.sg, n.swords, b, n.sin_w[0], i);
+    }
+  }
+}
+
+// forward of the Flipout stack (after bnn_noise + barrier + bnn_bn_fwd + barrier)
+__device__ __forceinline__ void bnn_layers_fwd(const BnnCtx &c, const float *theta, const BnnNet &n, const BnnCache &k, int B) {
+  const int L = n.n_layers;
+  for (int l = 0; l < L; ++l) {
+    const int in = n.dims[l], out = n.dims[l + 1];
+    const float *loc = theta + n.woff[l], *bias = loc + 2 * in * out;
+    const float *h = k.H + (long long)B * n.hoff[l], *hs = k.HS + (long long)B * n.hoff[l];
+    float *y = k.H + (long long)B * n.hoff[l + 1], *ys = k.HS + (long long)B * n.hoff[l + 1];
+    const bool last = (l == L - 1);
+    const int so = n.sout_w[l], si = last ? 0 : n.sin_w[l + 1];
+    bnn_gemm2(c.tid, BnnMat{h, in, 1}, BnnMat{hs, in, 1}, BnnMat{loc, out, 1}, BnnMat{k.dW + n.eoff[l], out, 1}, B, out, in,
+              c.tid >> 6, BNN_THREADS / 64, [&](int m, int o, float c1, float c2) {
+                float v = c1 + bias[o] + bnn_sign(k.sg, n.swords, m, so, o) * c2;
+                if (!last) v = fmaxf(v, BNN_LEAK * v);
+                y[(long long)m * out + o] = v;
+                if (!last) ys[(long long)m * out + o] = v * bnn_sign(k.sg, n.swords, m, si, o);
+              });
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ float *bnn_fwd(const BnnCtx &c, const float *theta, const BnnNet &n, const BnnCache &k, int B,
+                                          uint32_t k0, uint32_t k1, uint32_t stream) {
+  bnn_noise(c, theta, n, k, B, k0, k1, stream);
+  __syncthreads();
+  bnn_bn_fwd(c, theta, n, k, B);
+  __syncthreads();
+  bnn_layers_fwd(c, theta, n, k, B);
+  return k.H + (long long)B * n.hoff[n.n_layers];
+}
+
+// Backward of one call.  d [B x out_L]: upstream gradient (destroyed); ds, t0, t1: scratch [B x widest layer];
+// grad (layout of theta) receives / accumulates the parameter gradients when `want_params`; dx [B x in] (may be NULL)
+// receives the gradient w.r.t. the raw input (through the batch statistics).
+__device__ __forceinline__ void bnn_bwd(const BnnCtx &c, const float *theta, float *grad, const BnnNet &n, const BnnCache &k,
+                                        float *d, float *ds, float *t0, float *t1, float *dx, int B, bool want_params,
+                                        bool accumulate) {
+  const int L = n.n_layers, nw = BNN_THREADS / 64, wave = c.tid >> 6;
+  {
+    const int out = n.dims[L];
+    for (int i = c.tid; i < B * out; i += BNN_THREADS) ds[i] = d[i] * bnn_sign(k.sg, n.swords, i / out, n.sout_w[L - 1], i % out);
+  }
+  __syncthreads();
+  float *cur = d, *curs = ds, *nxt = t0, *nxts = t1;
+  for (int l = L - 1; l >= 0; --l) {
+    const int in = n.dims[l], out = n.dims[l + 1];
+    const float *loc = theta + n.woff[l], *rho = loc + in * out;
+    const float *h = k.H + (long long)B * n.hoff[l], *hs = k.HS + (long long)B * n.hoff[l];
+    int first = wave;
+    if (want_params) {
+      float *gloc = grad + n.woff[l], *grho = gloc + in * out, *gb = grho + in * out;
+      const float *eps = k.eps + n.eoff[l];
+      bnn_gemm2(c.tid, BnnMat{h, 1, in}, BnnMat{hs, 1, in}, BnnMat{cur, out, 1}, BnnMat{curs, out, 1}, in, out, B, wave, nw,
+                [&](int i, int o, float c1, float c2) {
+                  const int t = i * out + o;
+                  const float r = c2 * eps[t] * sigmoid_f(rho[t]);
+                  gloc[t] = accumulate ? gloc[t] + c1 : c1;
+                  grho[t] = accumulate ? grho[t] + r : r;
+                });
+      for (int o = c.tid; o < out; o += BNN_THREADS) {
+        float s = 0.0f;
+        for (int b = 0; b < B; ++b) s += cur[(long long)b * out + o];
+        gb[o] = accumulate ? gb[o] + s : s;
+      }
+      const int t_w = ((in + 15) >> 4) * ((out + 15) >> 4);
+      first = (wave - t_w % nw + nw) % nw;
+    }
+    if (l > 0 || dx || want_params) {
+      const int si = n.sin_w[l], sop = l > 0 ? n.sout_w[l - 1] : 0;
+      bnn_gemm2(c.tid, BnnMat{cur, out, 1}, BnnMat{curs, out, 1}, BnnMat{loc, 1, out}, BnnMat{k.dW + n.eoff[l], 1, out}, B, in, out,
+                first, nw, [&](int m, int i, float c1, float c2) {
+                  const long long t = (long long)m * in + i;
+                  float v = c1 + bnn_sign(k.sg, n.swords, m, si, i) * c2;
+                  if (l > 0) {
+                    v *= (h[t] > 0.0f) ? 1.0f : BNN_LEAK;
+                    nxts[t] = v * bnn_sign(k.sg, n.swords, m, sop, i);
+                  }
+                  nxt[t] = v;
+                });
+    }
+    __syncthreads();
+    float *t = cur; cur = nxt; nxt = t;
+    t = curs; curs = nxts; nxts = t;
+  }
+  // cur = dLoss/dh_0 [B x in]: gamma, beta and the input gradient through the batch statistics
+  const int in = n.dims[0];
+  const float *gamma = theta + n.off;
+  for (int i = c.tid; i < in; i += BNN_THREADS) {
+    float sg_ = 0.0f, sb = 0.0f;
+    for (int b = 0; b < B; ++b) { const float v = cur[(long long)b * in + i]; sg_ = fmaf(v, k.xhat[(long long)b * in + i], sg_); sb += v; }
+    if (want_params) {
+      float *gg = grad + n.off, *gbt = gg + in;
+      gg[i] = accumulate ? gg[i] + sg_ : sg_;
+      gbt[i] = accumulate ? gbt[i] + sb : sb;
+    }
+    if (dx) {
+      const float m1 = sb * gamma[i] / (float)B, m2 = sg_ * gamma[i] / (float)B, inv = k.inv[i];
+      for (int b = 0; b < B; ++b) {
+        const long long t = (long long)b * in + i;
+        dx[t] = inv * (cur[t] * gamma[i] - m1 - k.xhat[t] * m2);
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// grad += w * dKL/dtheta for every kernel of the net; returns KL (every thread).  Prior N(0, 1).
+__device__ __forceinline__ float bnn_kl(const BnnCtx &c, const float *theta, float *grad, const BnnNet &n, float w) {
+  float acc = 0.0f;
+  for (int l = 0; l < n.n_layers; ++l) {
+    const int cnt = n.dims[l] * n.dims[l + 1];
+    const float *loc = theta + n.woff[l], *rho = loc + cnt;
+    float *gloc = grad + n.woff[l], *grho = gloc + cnt;
+    for (int i = c.tid; i < cnt; i += BNN_THREADS) {
+      const float sg = BNN_SCALE_EPS + softplus_acc(rho[i]), mu = loc[i];
+      acc += -logf(sg) + 0.5f * (sg * sg + mu * mu) - 0.5f;
+      gloc[i] += w * mu;
+      grho[i] += w * (-1.0f / sg + sg) * sigmoid_f(rho[i]);
+    }
+  }
+  return bnn_block_sum(c, acc);
+}
+
+__device__ __forceinline__ void bnn_adam(const BnnCtx &c, float *theta, float *m, float *v, const float *g, int n, const BnnAdam &a) {
+  for (int i = c.tid; i < n; i += BNN_THREADS) {
+    const float gi = g[i];
+    const float mi = a.b1 * m[i] + (1.0f - a.b1) * gi;
+    const float vi = a.b2 * v[i] + (1.0f - a.b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    theta[i] -= a.lr_t * mi / (sqrtf(vi) + a.eps);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// step kernels
+// ---------------------------------------------------------------------------------------------
+enum { BNN_G = 0, BNN_E = 1, BNN_F = 2, BNN_H = 3 };
+
+struct BnnArgs {
+  BnnNet net[4];                         // g, e, f, h
+  float *theta, *m, *v, *grad;           // flat [g | e | f | h] parameters, Adam slots, gradient
+  int B, q, p, z0, z1, z2, binary, wmax;
+  float kl_weight;
+  const float *data_z;                   // [N x q] latent table (rows gathered through idx)
+  const int *idx;                        // [B] rows of the panel
+  const float *v_, *x_, *y_;             // panel [N x p], [N], [N]
+  uint32_t k0, k1, stream;               // noise key and call id
+  BnnAdam adam;
+  int apply;                             // 1: Adam on g, h, f inside the kernel; 0: gradients stay in grad
+  float inv_B;                           // 1 / global batch (data-parallel steps divide by the global batch)
+  float *ws;                             // workspace
+  float *out;                            // theta: [loss_v, mse_v, loss_x, aux_x, loss_y, mse_y];  z: [loss_posterior]
+  float *dz;                             // z step: [B x q] gradient w.r.t. the batch rows of data_z
+};
+
+// gather the minibatch: zb [B x q], vb [B x p], xb, yb [B], f input [B x nf], h input [B x nh]
+struct BnnBatch { float *zb, *vb, *xb, *yb, *fin, *hin; };
+__device__ __forceinline__ void bnn_gather(const BnnCtx &c, const BnnArgs &a, float *&wp, BnnBatch &bt) {
+  auto take = [&](int n) { float *r = wp; wp += (n + 3) & ~3; return r; };
+  const int B = a.B, q = a.q, p = a.p, nf = a.net[BNN_F].dims[0], nh = a.net[BNN_H].dims[0];
+  bt.zb = take(B * q); bt.vb = take(B * p); bt.xb = take(B); bt.yb = take(B); bt.fin = take(B * nf); bt.hin = take(B * nh);
+  for (int k = c.tid; k < B * p; k += BNN_THREADS) { const int b = k / p; bt.vb[k] = a.v_[(long long)a.idx[b] * p + (k - b * p)]; }
+  for (int k = c.tid; k < B * q; k += BNN_THREADS) { const int b = k / q; bt.zb[k] = a.data_z[(long long)a.idx[b] * q + (k - b * q)]; }
+  for (int b = c.tid; b < B; b += BNN_THREADS) { bt.xb[b] = a.x_[a.idx[b]]; bt.yb[b] = a.y_[a.idx[b]]; }
+  __syncthreads();
+  for (int k = c.tid; k < B * nf; k += BNN_THREADS) {
+    const int b = k / nf, i = k - b * nf;
+    bt.fin[k] = (i < a.z0 + a.z1) ? bt.zb[b * q + i] : bt.xb[b];
+  }
+  for (int k = c.tid; k < B * nh; k += BNN_THREADS) {
+    const int b = k / nh, i = k - b * nh;
+    bt.hin[k] = (i < a.z0) ? bt.zb[b * q + i] : bt.zb[b * q + a.z1 + i];
+  }
+  __syncthreads();
+}
+
+// Gaussian head: loss_b = ssq / (2 s2) + dim * log(s2) / 2 with s2 = softplus(raw) + 1e-6; returns d loss_b / d raw
+__device__ __forceinline__ float bnn_gauss(float ssq, float raw, float dim, float &loss_b, float &s2) {
+  s2 = softplus_acc(raw) + BGM_EPS;
+  loss_b = ssq / (2.0f * s2) + dim * logf(s2) * 0.5f;
+  return (-ssq / (2.0f * s2 * s2) + dim / (2.0f * s2)) * sigmoid_f(raw);
+}
+
+// update_g_net, update_h_net, update_f_net (causalbgm/base.py:156-243) with use_bnn: the three updates are independent
+// given the batch (each reads the latents of BEFORE the step), so one launch does all three.
+static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_step_kernel(BnnArgs a) {
+  __shared__ float red[32];
+  __shared__ float ssq_row[64];
+  BnnCtx c{(int)threadIdx.x, red};
+  const int B = a.B, p = a.p;
+  float *wp = a.ws;
+  auto take = [&](int n) { float *r = wp; wp += (n + 3) & ~3; return r; };
+  BnnBatch bt;
+  bnn_gather(c, a, wp, bt);
+  float *d = take(B * a.wmax), *ds = take(B * a.wmax), *t0 = take(B * a.wmax), *t1 = take(B * a.wmax);
+  float *cache_base = wp;
+  for (int which = 0; which < 3; ++which) {
+    const int id = which == 0 ? BNN_G : (which == 1 ? BNN_H : BNN_F);
+    const BnnNet &n = a.net[id];
+    wp = cache_base;
+    BnnCache k;
+    bnn_cache(n, B, wp, k, id == BNN_G ? bt.zb : (id == BNN_H ? bt.hin : bt.fin));
+    const float *o = bnn_fwd(c, a.theta, n, k, B, a.k0, a.k1, a.stream);
+    const int wo = n.dims[n.n_layers];
+    float loss = 0.0f, aux = 0.0f;
+    if (id == BNN_G) {
+      // per-row sum of squares (ordered), then the head
+      for (int b = c.tid; b < B; b += BNN_THREADS) {
+        float s = 0.0f;
+        for (int j = 0; j < p; ++j) { const float t = bt.vb[b * p + j] - o[b * wo + j]; s = fmaf(t, t, s); }
+        ssq_row[b] = s;
+      }
+      __syncthreads();
+      for (int i = c.tid; i < B * wo; i += BNN_THREADS) {
+        const int b = i / wo, j = i - b * wo;
+        float lb, s2;
+        const float dr = bnn_gauss(ssq_row[b], o[b * wo + wo - 1], (float)p, lb, s2);
+        if (j < p) d[i] = -(bt.vb[b * p + j] - o[i]) / s2 * a.inv_B;
+        else if (j == wo - 1) { d[i] = dr * a.inv_B; loss += lb; aux += ssq_row[b]; }
+        else d[i] = 0.0f;
+      }
+      loss = bnn_block_sum(c, loss) * a.inv_B;
+      aux = bnn_block_sum(c, aux) * a.inv_B / (float)p;
+    } else {
+      const float *tgt = id == BNN_H ? bt.xb : bt.yb;
+      for (int i = c.tid; i < B * wo; i += BNN_THREADS) d[i] = 0.0f;
+      __syncthreads();
+      for (int b = c.tid; b < B; b += BNN_THREADS) {
+        const float l = o[b * wo];
+        if (id == BNN_H && a.binary) {
+          const float e = fmaxf(l, 0.0f) - l * tgt[b] + log1pf(expf(-fabsf(l)));
+          loss += e; aux += e;
+          d[b * wo] = (sigmoid_f(l) - tgt[b]) * a.inv_B;
+        } else {
+          const float r = tgt[b] - l;
+          float lb, s2;
+          const float dr = bnn_gauss(r * r, o[b * wo + wo - 1], 1.0f, lb, s2);
+          loss += lb; aux += r * r;
+          d[b * wo] = -r / s2 * a.inv_B;
+          d[b * wo + wo - 1] += dr * a.inv_B;
+        }
+      }
+      loss = bnn_block_sum(c, loss) * a.inv_B;
+      aux = bnn_block_sum(c, aux) * a.inv_B;
+    }
+    __syncthreads();
+    bnn_bwd(c, a.theta, a.grad, n, k, d, ds, t0, t1, nullptr, B, true, false);
+    const float klv = bnn_kl(c, a.theta, a.grad, n, a.kl_weight);
+    __syncthreads();
+    if (a.apply) bnn_adam(c, a.theta + n.off, a.m + n.off, a.v + n.off, a.grad + n.off, n.n_params, a.adam);
+    if (c.tid == 0 && a.out) { a.out[2 * which] = loss + a.kl_weight * klv; a.out[2 * which + 1] = aux; }
+    __syncthreads();
+  }
+}
+
+// update_latent_variable_sgd (causalbgm/base.py:246-302) with use_bnn: every net is called twice with independent
+// noise (mean from the first call, variance head from the second); dz [B x q] = d loss / d (batch rows of data_z).
+static __global__ __launch_bounds__(BNN_THREADS) void bnn_z_grad_kernel(BnnArgs a) {
+  __shared__ float red[32];
+  __shared__ float ssq_row[64];
+  BnnCtx c{(int)threadIdx.x, red};
+  const int B = a.B, p = a.p, q = a.q;
+  float *wp = a.ws;
+  auto take = [&](int n) { float *r = wp; wp += (n + 3) & ~3; return r; };
+  BnnBatch bt;
+  bnn_gather(c, a, wp, bt);
+  float *d = take(B * a.wmax), *ds = take(B * a.wmax), *t0 = take(B * a.wmax), *t1 = take(B * a.wmax);
+  float *dx1 = take(B * a.wmax), *dx2 = take(B * a.wmax);
+  float *cache_base = wp;
+  float total = 0.0f;
+  for (int i = c.tid; i < B * q; i += BNN_THREADS) { const float z = bt.zb[i]; a.dz[i] = z * a.inv_B; total += 0.5f * z * z; }
+  total = bnn_block_sum(c, total) * a.inv_B;
+  for (int which = 0; which < 3; ++which) {
+    const int id = which == 0 ? BNN_G : (which == 1 ? BNN_H : BNN_F);
+    const BnnNet &n = a.net[id];
+    wp = cache_base;
+    const float *input = id == BNN_G ? bt.zb : (id == BNN_H ? bt.hin : bt.fin);
+    const int wo = n.dims[n.n_layers], in = n.dims[0];
+    const bool two = !(id == BNN_H && a.binary);
+    BnnCache k1, k2;
+    bnn_cache(n, B, wp, k1, input);
+    const float *o1 = bnn_fwd(c, a.theta, n, k1, B, a.k0, a.k1, a.stream);
+    const float *o2 = o1;
+    if (two) { bnn_cache(n, B, wp, k2, input); o2 = bnn_fwd(c, a.theta, n, k2, B, a.k0, a.k1, a.stream + 1u); }
+    float loss = 0.0f;
+    // upstream gradients: d for call 1 (mean), t-buffers reused for call 2 (variance head) after the first backward
+    if (id == BNN_G) {
+      for (int b = c.tid; b < B; b += BNN_THREADS) {
+        float s = 0.0f;
+        for (int j = 0; j < p; ++j) { const float t = bt.vb[b * p + j] - o1[b * wo + j]; s = fmaf(t, t, s); }
+        ssq_row[b] = s;
+      }
+      __syncthreads();
+      for (int i = c.tid; i < B * wo; i += BNN_THREADS) {
+        const int b = i / wo, j = i - b * wo;
+        float lb, s2;
+        bnn_gauss(ssq_row[b], o2[b * wo + wo - 1], (float)p, lb, s2);
+        d[i] = (j < p) ? -(bt.vb[b * p + j] - o1[i]) / s2 * a.inv_B : 0.0f;
+        if (j == wo - 1) loss += lb;
+      }
+    } else {
+      const float *tgt = id == BNN_H ? bt.xb : bt.yb;
+      for (int i = c.tid; i < B * wo; i += BNN_THREADS) d[i] = 0.0f;
+      __syncthreads();
+      for (int b = c.tid; b < B; b += BNN_THREADS) {
+        const float l = o1[b * wo];
+        if (!two) {
+          loss += fmaxf(l, 0.0f) - l * tgt[b] + log1pf(expf(-fabsf(l)));
+          d[b * wo] = (sigmoid_f(l) - tgt[b]) * a.inv_B;
+        } else {
+          const float r = tgt[b] - l;
+          float lb, s2;
+          bnn_gauss(r * r, o2[b * wo + wo - 1], 1.0f, lb, s2);
+          loss += lb;
+          d[b * wo] = -r / s2 * a.inv_B;
+          ssq_row[b] = r * r;
+        }
+      }
+    }
+    total += bnn_block_sum(c, loss) * a.inv_B;
+    __syncthreads();
+    bnn_bwd(c, a.theta, a.grad, n, k1, d, ds, t0, t1, dx1, B, false, false);
+    if (two) {
+      const float dim = id == BNN_G ? (float)p : 1.0f;
+      for (int i = c.tid; i < B * wo; i += BNN_THREADS) {
+        const int b = i / wo, j = i - b * wo;
+        float lb, s2;
+        d[i] = (j == wo - 1) ? bnn_gauss(ssq_row[b], o2[b * wo + wo - 1], dim, lb, s2) * a.inv_B : 0.0f;
+      }
+      __syncthreads();
+      bnn_bwd(c, a.theta, a.grad, n, k2, d, ds, t0, t1, dx2, B, false, false);
+    }
+    // scatter the input gradient into dz
+    for (int i = c.tid; i < B * in; i += BNN_THREADS) {
+      const int b = i / in, j = i - b * in;
+      const float v = dx1[i] + (two ? dx2[i] : 0.0f);
+      int col = -1;
+      if (id == BNN_G) col = j;
+      else if (id == BNN_F) col = (j < a.z0 + a.z1) ? j : -1;
+      else col = (j < a.z0) ? j : j + a.z1;
+      if (col >= 0) a.dz[b * q + col] += v;     // one thread per (b, col) within a net; nets are serialised by barriers
+    }
+    __syncthreads();
+  }
+  if (c.tid == 0 && a.out) a.out[0] = total;
+}
+
+// Adam on the [N x q] latent table, Keras `_resource_apply_sparse` semantics (oracle/fit.py adam_rows):
+// dense-decay = decay every row's slots, add the batch rows' gradient, update EVERY row; lazy = batch rows only.
+static __global__ void bnn_z_decay_kernel(float *zm, float *zv, long long n, float b1, float b2) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { zm[i] *= b1; zv[i] *= b2; }
+}
+static __global__ void bnn_z_rows_kernel(float *data_z, float *zm, float *zv, const float *dz, const int *idx, int B, int q,
+                                         float lr_t, float b1, float b2, float eps, int lazy) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * q) return;
+  const int b = i / q, j = i - b * q;
+  const long long t = (long long)idx[b] * q + j;
+  const float g = dz[i];
+  if (lazy) {
+    const float m = b1 * zm[t] + (1.0f - b1) * g, v = b2 * zv[t] + (1.0f - b2) * g * g;
+    zm[t] = m; zv[t] = v;
+    data_z[t] -= lr_t * m / (sqrtf(v) + eps);
+  } else {
+    zm[t] += (1.0f - b1) * g;
+    zv[t] += (1.0f - b2) * g * g;
+  }
+}
+static __global__ void bnn_z_apply_kernel(float *data_z, const float *zm, const float *zv, long long n, float lr_t, float eps) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) data_z[i] -= lr_t * zm[i] / (sqrtf(zv[i]) + eps);
+}
+static __global__ void bnn_adam_kernel(float *theta, float *m, float *v, const float *g, int n, BnnAdam a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float gi = g[i];
+    const float mi = a.b1 * m[i] + (1.0f - a.b1) * gi, vi = a.b2 * v[i] + (1.0f - a.b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    theta[i] -= a.lr_t * mi / (sqrtf(vi) + a.eps);
+  }
+}

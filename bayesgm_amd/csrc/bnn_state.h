@@ -1,0 +1,32 @@
+// bnn_state.h -- host-side session state of the Bayesian-network path (bnn_api.hip, bnn_sample_api.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/bgm_hip.h"
+#include "bnn_kernels.h"
+
+#define BNN_ADAM_B1 0.9f
+#define BNN_ADAM_B2 0.99f
+#define BNN_ADAM_EPS 1e-7f
+
+struct BnnState {
+  bgm_bnn_config cfg{};
+  BnnNet net[4];
+  int n_params = 0, q = 0, p = 0, wmax = 0;
+  float *dev = nullptr;        // one allocation: theta | m | v | grad | workspace | out | dz
+  float *theta_dev = nullptr, *m_dev = nullptr, *v_dev = nullptr, *grad_dev = nullptr, *ws_dev = nullptr, *out_dev = nullptr,
+        *dz_dev = nullptr;
+  size_t ws_floats = 0;
+  long long t_theta = 0, t_z = 0;
+  // large-batch (sampling / evaluation) side: packed kernels and per-call perturbations, rebuilt when theta changes
+  bool packed_valid = false;
+  float *samp_dev = nullptr;
+  size_t samp_cap = 0;
+};
+
+inline void bnn_free_sampler(BnnState *s) {
+  if (s->samp_dev) hipFree(s->samp_dev);
+  s->samp_dev = nullptr;
+  s->samp_cap = 0;
+  s->packed_valid = false;
+}

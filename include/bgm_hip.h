@@ -392,6 +392,55 @@ int bgm_bgm_egm_encode(bgm_handle *h, const float *x_dev, int64_t n, float *z_de
 int bgm_bgm_egm_sync(bgm_handle *h, void *stream);
 int bgm_bgm_egm_end(bgm_handle *h, void *stream);
 
+/* ==========================================================================================
+ * CausalBGM with Bayesian networks, params['use_bnn'] = True (the default of every causal YAML and of the CLI).
+ * g, e, f, h = BayesianFullyConnectedNet (networks/bnn.py:4-38): BatchNormalization of the input on the
+ * statistics of the batch at hand + tfp.layers.DenseFlipout stack; every call draws fresh weight perturbations.
+ * Semantics and the counter-based noise streams: oracle/bnn.py.  A session owns the parameters
+ *   theta = [g | e | f | h], per net: gamma[in], beta[in], then per layer loc[in x out], rho[in x out], bias[out]
+ * (sigma = finfo(f32).eps + softplus(rho)), their Adam slots and a gradient buffer of the same layout.
+ * Noise of a call: key = seed + (batch_id << 32), stream = 32-bit call id (see each entry point).
+ * ========================================================================================== */
+#define BGM_BNN_G 0
+#define BGM_BNN_E 1
+#define BGM_BNN_F 2
+#define BGM_BNN_H 3
+typedef struct {
+  int32_t v_dim, z_dims[4], binary_treatment;    /* params['v_dim'], ['z_dims'], ['binary_treatment']            */
+  int32_t n_hidden[4];                           /* hidden layers of g, e, f, h (BGM_BNN_* order)                */
+  int32_t units[4][BGM_MAX_LAYERS];              /* params['g_units'], ['e_units'], ['f_units'], ['h_units']      */
+  float kl_weight;                               /* params['kl_weight'], base.py:171-173                          */
+  int32_t max_batch;                             /* largest minibatch of the step kernels (<= 64)                 */
+} bgm_bnn_config;
+
+/* Open a session.  theta_host: `count` floats in the layout above (count from bgm_bnn_layout). */
+int bgm_bnn_begin(bgm_handle *h, const bgm_bnn_config *cfg, const float *theta_host, int64_t count, void *stream);
+/* Parameter count of a configuration and the offsets of g, e, f, h in theta (offsets[4] = total).  No session needed. */
+int bgm_bnn_layout(const bgm_bnn_config *cfg, int64_t offsets[5]);
+/* what = 0 parameters, 1 gradient of the last step, 2 Adam first moments, 3 Adam second moments.  Synchronises. */
+int bgm_bnn_read(bgm_handle *h, int32_t what, float *host, int64_t count, void *stream);
+int bgm_bnn_write(bgm_handle *h, int32_t what, const float *host, int64_t count, void *stream);
+/* replaces: update_g_net, update_h_net, update_f_net with use_bnn, causalbgm/base.py:156-243 (one launch: the three
+ * updates are independent given the batch).  data_z_dev [N x q]; idx_dev [batch] rows of the panel x_dev [N], y_dev [N],
+ * v_dev [N x p].  Losses are batch means over batch_global rows (= batch on one GPU) + kl_weight * sum(KL).
+ * Noise stream `stream_id`.  apply = 1: Adam(lr_theta, 0.9, 0.99) on g, h, f in the same launch; apply = 0: the gradient
+ * stays in the session (bgm_bnn_read what = 1 / bgm_bnn_grad_dev) for an all-reduce, then bgm_bnn_theta_apply.
+ * out_dev: [loss_v, loss_mse_v, loss_x, loss_mse_x|bce, loss_y, loss_mse_y] or NULL. */
+int bgm_bnn_theta_step(bgm_handle *h, const float *data_z_dev, const int32_t *idx_dev, const float *x_dev,
+                       const float *y_dev, const float *v_dev, int32_t batch, int32_t batch_global, float lr_theta,
+                       uint64_t seed, uint32_t stream_id, int32_t apply, float *out_dev, void *stream);
+int bgm_bnn_grad_dev(bgm_handle *h, float **grad_dev, int64_t *count);
+int bgm_bnn_theta_apply(bgm_handle *h, float lr_theta, void *stream);
+/* replaces: update_latent_variable_sgd with use_bnn, base.py:246-302 (every net called twice with independent noise:
+ * streams stream_id and stream_id + 1) + the Adam step on the latent table (zm_dev, zv_dev: its slots, [n_rows x q];
+ * lazy = 0: Keras dense-decay semantics, every row of the table moves; lazy = 1: batch rows only).
+ * out_dev: [loss_postrior_z] or NULL. */
+int bgm_bnn_z_step(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev, float *data_z_dev,
+                   float *zm_dev, float *zv_dev, const int32_t *idx_dev, int64_t n_rows, int32_t batch,
+                   int32_t batch_global, float lr_z, int32_t lazy, uint64_t seed, uint32_t stream_id, float *out_dev,
+                   float *dz_out_dev, void *stream);
+int bgm_bnn_end(bgm_handle *h, void *stream);
+
 /* Debug: throughput of the hand-scheduled 64x4-tile MFMA block alone (mode 1: fragments streamed from LDS; mode 0:
  * register operands only) with `waves_per_cu` waves on every CU. */
 int bgm_debug_group_probe(bgm_handle *h, int32_t mode, int32_t waves_per_cu, int32_t iters, double *mfma_tflops);

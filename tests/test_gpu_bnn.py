@@ -1,0 +1,133 @@
+"""Bayesian-network (use_bnn=True) kernels against oracle/bnn.py through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import bnn as OB
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(binary, z_dims=(1, 1, 1, 7), p=50, seed=0, **units):
+    m = OB.init_model(seed, list(z_dims), p, binary, **units)
+    rs = np.random.RandomState(seed + 11)
+    for k in ("g", "e", "f", "h"):
+        m[k]["gamma"] = (1.0 + 0.2 * rs.standard_normal(m[k]["gamma"].shape)).astype(np.float32)
+        m[k]["beta"] = (0.1 * rs.standard_normal(m[k]["beta"].shape)).astype(np.float32)
+    return m
+
+
+def _panel(m, n, seed=1):
+    rs = np.random.RandomState(seed)
+    q = sum(m["z_dims"])
+    z = rs.standard_normal((n, q)).astype(np.float32)
+    v = rs.standard_normal((n, m["v_dim"])).astype(np.float32)
+    x = ((rs.rand(n, 1) > 0.5) if m["binary_treatment"] else rs.exponential(size=(n, 1))).astype(np.float32)
+    y = (x + rs.standard_normal((n, 1))).astype(np.float32)
+    return z, x, y, v
+
+
+def _engine(m, max_batch=32, kl_weight=1e-4, **units):
+    from bayesgm_amd.bnn_engine import BnnEngine
+    eng = BnnEngine(m["v_dim"], m["z_dims"], m["binary_treatment"], kl_weight=kl_weight, max_batch=max_batch, **units)
+    eng.begin(m)
+    return eng
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.mark.parametrize("binary,B,units", [
+    (False, 32, {}),
+    (True, 32, {}),
+    (False, 19, dict(g_units=(24, 40), e_units=(16,), f_units=(20, 12), h_units=(9, 5))),
+])
+def test_theta_step_gradients_match_oracle(binary, B, units):
+    m = _model(binary, p=50 if not units else 37, **units)
+    z, x, y, v = _panel(m, 200)
+    eng = _engine(m, kl_weight=0.01, **units)
+    dev = eng.device
+    rs = np.random.RandomState(4)
+    idx = rs.choice(200, B, replace=False).astype(np.int32)
+    seed, stream = (5 << 32) | 77, 12
+    out = torch.zeros(8, device=dev)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    eng.theta_step(T(z), T(idx), T(x[:, 0]), T(y[:, 0]), T(v), 1e-3, seed, stream, apply=False, out=out)
+    grad = eng.split(eng.read(1))
+    out = out.cpu().numpy()
+    m64 = OB.cast_model(m, np.float64)
+    for w, name in enumerate(("g", "h", "f")):
+        dims = OB.net_dims(m[name])
+        noise = OB.draw_noise(dims, B, seed, stream, OB.NET_ID[name], dtype=np.float64)
+        loss, aux, g = OB.theta_step(m64, name, z[idx].astype(np.float64), x[idx].astype(np.float64), y[idx].astype(np.float64),
+                                     v[idx].astype(np.float64), noise, 0.01)
+        assert abs(out[2 * w] - loss) < 2e-4 * max(1.0, abs(loss)), (name, out[2 * w], loss)
+        assert abs(out[2 * w + 1] - aux) < 2e-4 * max(1.0, abs(aux)), name
+        got = [grad[name]["gamma"], grad[name]["beta"]] + [a for L in grad[name]["layers"] for a in L]
+        for a, b in zip(got, OB.flat_grads(g)):
+            assert _rel(a, b) < 2e-3, (name, a.shape, _rel(a, b))
+    eng.close()
+
+
+@pytest.mark.parametrize("binary", [False, True])
+def test_z_step_gradient_matches_oracle(binary):
+    m = _model(binary, p=50)
+    z, x, y, v = _panel(m, 100)
+    eng = _engine(m)
+    dev = eng.device
+    B = 32
+    idx = np.random.RandomState(9).choice(100, B, replace=False).astype(np.int32)
+    seed, stream = 123456789, 40
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    out = torch.zeros(4, device=dev)
+    dz = torch.zeros(B, sum(m["z_dims"]), device=dev)
+    eng.z_step(T(x[:, 0]), T(y[:, 0]), T(v), T(z), None, None, T(idx), 1e-3, seed, stream, out=out, dz_out=dz)
+    m64 = OB.cast_model(m, np.float64)
+    noises = {k: tuple(OB.draw_noise(OB.net_dims(m[k]), B, seed, stream + c, OB.NET_ID[k], dtype=np.float64) for c in (0, 1))
+              for k in ("g", "h", "f")}
+    loss, ref = OB.z_step(m64, z[idx].astype(np.float64), x[idx].astype(np.float64), y[idx].astype(np.float64),
+                          v[idx].astype(np.float64), noises)
+    assert abs(float(out[0]) - loss) < 2e-4 * abs(loss)
+    assert _rel(dz.cpu().numpy(), ref) < 2e-3
+    eng.close()
+
+
+def test_steps_apply_adam_like_oracle():
+    """Three full minibatch iterations (theta step + latent step, dense-decay Adam on the table) track the oracle."""
+    from oracle.fit import AdamState, adam_lr_t
+    m = _model(False, p=50)
+    n, B = 64, 32
+    z, x, y, v = _panel(m, n)
+    eng = _engine(m)
+    dev = eng.device
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    dz_t, zm, zv = T(z), torch.zeros(n, z.shape[1], device=dev), torch.zeros(n, z.shape[1], device=dev)
+    xs, ys, vs = T(x[:, 0]), T(y[:, 0]), T(v)
+    seed = 99
+    mo = OB.cast_model(m, np.float32)
+    zo = z.copy()
+    opt = {k: AdamState(OB.flat_params(mo[k])) for k in ("g", "h", "f")}
+    zm_o, zv_o = np.zeros_like(zo), np.zeros_like(zo)
+    rs = np.random.RandomState(3)
+    for it in range(3):
+        idx = rs.choice(n, B, replace=False).astype(np.int32)
+        eng.theta_step(dz_t, T(idx), xs, ys, vs, 1e-3, seed, 4 * it, apply=True)
+        eng.z_step(xs, ys, vs, dz_t, zm, zv, T(idx), 1e-2, seed, 4 * it + 1)
+        for name in ("g", "h", "f"):
+            noise = OB.draw_noise(OB.net_dims(mo[name]), B, seed, 4 * it, OB.NET_ID[name])
+            _, _, g = OB.theta_step(mo, name, zo[idx], x[idx], y[idx], v[idx], noise, 1e-4)
+            opt[name].apply(OB.flat_params(mo[name]), OB.flat_grads(g), 1e-3)
+        noises = {k: tuple(OB.draw_noise(OB.net_dims(mo[k]), B, seed, 4 * it + 1 + c, OB.NET_ID[k]) for c in (0, 1))
+                  for k in ("g", "h", "f")}
+        _, dz = OB.z_step(mo, zo[idx], x[idx], y[idx], v[idx], noises)
+        lr_t = np.float32(adam_lr_t(1e-2, it + 1))
+        zm_o *= np.float32(0.9); zv_o *= np.float32(0.99)
+        zm_o[idx] += np.float32(0.1) * dz; zv_o[idx] += np.float32(0.01) * dz * dz
+        zo -= lr_t * zm_o / (np.sqrt(zv_o) + np.float32(1e-7))
+    got = eng.split(eng.read(0))
+    for name in ("g", "h", "f"):
+        for a, b in zip([got[name]["gamma"], got[name]["beta"]] + [t for L in got[name]["layers"] for t in L], OB.flat_params(mo[name])):
+            assert np.abs(a - b).max() < 2e-3, (name, a.shape, np.abs(a - b).max())   # 3 Adam steps of lr 1e-3
+    assert np.abs(dz_t.cpu().numpy() - zo).max() < 5e-3
+    eng.close()
