@@ -60,6 +60,15 @@ class BnnConfig(C.Structure):
                 ("kl_weight", C.c_float), ("max_batch", C.c_int32)]
 
 
+class BnnMhArgs(C.Structure):
+    _fields_ = [("x_dev", C.c_void_p), ("y_dev", C.c_void_p), ("v_dev", C.c_void_p), ("n", C.c_int64), ("row_base", C.c_int64),
+                ("block_rows", C.c_int32), ("block0", C.c_int32), ("state_dev", C.c_void_p), ("init", C.c_int32),
+                ("it_begin", C.c_int32), ("n_iters", C.c_int32), ("burn_in", C.c_int32), ("q_sd", C.c_float),
+                ("seed", C.c_uint64), ("acc_count_dev", C.c_void_p), ("draws_dev", C.c_void_p), ("n_keep", C.c_int32),
+                ("effect", C.c_int32), ("sample_y", C.c_int32), ("x_values_dev", C.c_void_p), ("n_doses", C.c_int32),
+                ("adrf_sum_dev", C.c_void_p), ("ite_dev", C.c_void_p)]
+
+
 class EgmConfig(C.Structure):
     _fields_ = [("batch_size", C.c_int32), ("n_hidden_dz", C.c_int32), ("dz_units", C.c_int32 * BGM_MAX_LAYERS),
                 ("lr", C.c_float), ("use_z_rec", C.c_int32)]
@@ -153,6 +162,9 @@ SYMBOLS = {
     "bgm_bnn_z_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_uint64, C.c_uint32, C.c_void_p,
                                  C.c_void_p, C.c_void_p]),
+    "bgm_bnn_logpost": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                  C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "bgm_bnn_mh_run": (C.c_int, [C.c_void_p, C.POINTER(BnnMhArgs), C.c_void_p]),
     "bgm_bnn_end": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bgm_debug_group_probe": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     "bgm_causal_egm_begin": (C.c_int, [C.c_void_p, C.POINTER(EgmConfig), C.c_void_p, C.c_int64, C.c_void_p]),

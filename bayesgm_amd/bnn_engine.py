@@ -132,6 +132,29 @@ class BnnEngine(object):
                                            int(stream_id) & 0xFFFFFFFF, _ptr(out), _ptr(dz_out), self._stream()),
                    "bgm_bnn_z_step")
 
+    # -- large-batch side ------------------------------------------------------------------------------
+    def logpost(self, x, y, v, z, block_rows, seed, stream_id, block0=0):
+        out = torch.empty(z.shape[0], device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.bgm_bnn_logpost(self.h, _ptr(x), _ptr(y), _ptr(v), _ptr(z), z.shape[0], int(block_rows), int(block0),
+                                            int(seed), int(stream_id) & 0xFFFFFFFF, _ptr(out), self._stream()), "bgm_bnn_logpost")
+        return out
+
+    def mh_run(self, x, y, v, state, block_rows, it_begin, n_iters, burn_in, q_sd, seed, init=False, row_base=0, block0=0,
+               acc_count=None, draws=None, n_keep=0, effect=0, sample_y=True, x_values=None, adrf_sum=None, ite=None):
+        a = _lib.BnnMhArgs()
+        a.x_dev, a.y_dev, a.v_dev = x.data_ptr(), y.data_ptr(), v.data_ptr()
+        a.n, a.row_base, a.block_rows, a.block0 = state.shape[0], int(row_base), int(block_rows), int(block0)
+        a.state_dev, a.init = state.data_ptr(), int(init)
+        a.it_begin, a.n_iters, a.burn_in, a.q_sd, a.seed = int(it_begin), int(n_iters), int(burn_in), float(q_sd), int(seed)
+        a.acc_count_dev = acc_count.data_ptr() if acc_count is not None else None
+        a.draws_dev = draws.data_ptr() if draws is not None else None
+        a.n_keep, a.effect, a.sample_y = int(n_keep), int(effect), int(bool(sample_y))
+        a.x_values_dev = x_values.data_ptr() if x_values is not None else None
+        a.n_doses = x_values.numel() if x_values is not None else 0
+        a.adrf_sum_dev = adrf_sum.data_ptr() if adrf_sum is not None else None
+        a.ite_dev = ite.data_ptr() if ite is not None else None
+        _lib.check(self.lib.bgm_bnn_mh_run(self.h, C.byref(a), self._stream()), "bgm_bnn_mh_run")
+
     def end(self):
         _lib.check(self.lib.bgm_bnn_end(self.h, self._stream()), "bgm_bnn_end")
         self.open = False

@@ -1,0 +1,193 @@
+// bnn_sample_api.hip -- C ABI of the Bayesian-network CausalBGM path: posterior sampling, effects, evaluation.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "bgm_host.h"
+#include "bnn_sample_kernels.h"
+#include "bnn_state.h"
+
+static BnnState *bst(bgm_handle *h) { return static_cast<BnnState *>(h->bnn_state); }
+
+template <class K>
+static int bns_set_lds(K kernel, int bytes) {
+  BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  return BGM_OK;
+}
+
+struct BnsPlan {
+  BnsNet net[4];
+  long long frag_total = 0;      // packed loc / sigma floats (all four nets)
+  long long set_ghf = 0;         // floats of one perturbation set [g | h | f]
+  long long set_f = 0;           // ... of the outcome net alone
+  long long set_all = 0;         // ... [e | g | h | f] (evaluation)
+  int lds_bytes = 0;
+};
+
+// fragment plan of the session's nets; false when a shape is outside the kernels' limits
+static bool bns_plan(const BnnState *s, BnsPlan &pl) {
+  long long fb = 0;
+  int maxfrag = 0;
+  for (int k = 0; k < 4; ++k) {
+    BnsNet &n = pl.net[k];
+    std::memset(&n, 0, sizeof(n));
+    bns_from(s->net[k], n);
+    if (n.n_layers < 2 || n.swords > BNS_SW || n.K[0] > BNS_MAXK) return false;
+    for (int l = 0; l < n.n_layers; ++l) {
+      if (l < n.n_layers - 1 && n.K[l + 1] > 16 * BNS_MAXT) return false;
+      maxfrag = std::max(maxfrag, n.T[l] * n.MT[l] * 256);
+    }
+    n.fbase = (int)fb;
+    fb += n.foff[n.n_layers];
+  }
+  pl.frag_total = fb;
+  pl.net[BNN_G].dbase = 0;
+  pl.net[BNN_H].dbase = pl.net[BNN_G].foff[pl.net[BNN_G].n_layers];
+  pl.net[BNN_F].dbase = pl.net[BNN_H].dbase + pl.net[BNN_H].foff[pl.net[BNN_H].n_layers];
+  pl.set_ghf = pl.net[BNN_F].dbase + pl.net[BNN_F].foff[pl.net[BNN_F].n_layers];
+  pl.net[BNN_E].dbase = (int)pl.set_ghf;     // evaluation sets: [g | h | f | e]
+  pl.set_all = pl.set_ghf + pl.net[BNN_E].foff[pl.net[BNN_E].n_layers];
+  pl.set_f = pl.net[BNN_F].foff[pl.net[BNN_F].n_layers];
+  pl.lds_bytes = (int)sizeof(float) * (2 * BNS_MAXK + BNS_WAVES * BNS_R * 16 * BNS_SW + 2 * maxfrag);
+  return pl.lds_bytes <= 160 * 1024;
+}
+
+// Device scratch of the sampling side: [lf | sf | zprop | dw sets | stats (doubles) | xstats (doubles)], grown on demand.
+struct BnsBuf { float *lf, *sf, *zprop, *dw; double *stats, *xstats; };
+static int bns_buffers(bgm_handle *h, BnnState *s, const BnsPlan &pl, long long n, int n_blocks, long long dw_floats, BnsBuf &b,
+                       hipStream_t stream) {
+  const long long fr = (pl.frag_total + 63) & ~63LL;
+  const long long zp = (n * s->q + 63) & ~63LL;
+  const long long dwf = (dw_floats + 63) & ~63LL;
+  const long long st_d = 2LL * n_blocks * 256 + 2LL * n_blocks + 64;      // doubles
+  const size_t need = (size_t)(2 * fr + zp + dwf + 2 * st_d + 64);
+  if (need > s->samp_cap) {
+    BGM_HIP_CHECK(hipStreamSynchronize(stream));
+    if (s->samp_dev) BGM_HIP_CHECK(hipFree(s->samp_dev));
+    s->samp_dev = nullptr; s->samp_cap = 0; s->packed_valid = false;
+    BGM_HIP_CHECK(hipMalloc((void **)&s->samp_dev, sizeof(float) * need));
+    s->samp_cap = need;
+  }
+  b.lf = s->samp_dev; b.sf = b.lf + fr; b.zprop = b.sf + fr; b.dw = b.zprop + zp;
+  b.stats = (double *)(b.dw + dwf);
+  b.xstats = b.stats + 2LL * n_blocks * 256;
+  if (!s->packed_valid) {
+    BGM_HIP_CHECK(hipMemsetAsync(b.lf, 0, sizeof(float) * 2 * fr, stream));
+    BnsPackArgs pa{};
+    for (int k = 0; k < 4; ++k) pa.net[k] = pl.net[k];
+    pa.theta = s->theta_dev; pa.lf = b.lf; pa.sf = b.sf; pa.n_nets = 4;
+    hipLaunchKernelGGL(bns_pack_kernel, dim3(32, 4), dim3(256), 0, stream, pa);
+    BGM_HIP_CHECK(hipGetLastError());
+    s->packed_valid = true;
+  }
+  // padding positions of the perturbation sets must be zero: the noise kernel only writes real elements
+  BGM_HIP_CHECK(hipMemsetAsync(b.dw, 0, sizeof(float) * dwf, stream));
+  BGM_HIP_CHECK(hipMemsetAsync(b.stats, 0, sizeof(double) * st_d, stream));
+  return BGM_OK;
+}
+
+static int bns_session(bgm_handle *h, const char *who, BnnState *&s, BnsPlan &pl) {
+  if (!h || !h->bnn_state) { bgm_set_error(std::string(who) + ": no session (bgm_bnn_begin)"); return BGM_E_STATE; }
+  s = bst(h);
+  if (!bns_plan(s, pl)) {
+    bgm_set_error(std::string(who) + ": shape outside the sampling kernels (hidden widths <= 64, inputs <= 208, >= 1 hidden layer)");
+    return BGM_E_UNSUPPORTED;
+  }
+  return BGM_OK;
+}
+
+static void bns_fill_mh(const BnnState *s, const BnsPlan &pl, BnsMhArgs &a) {
+  for (int k = 0; k < 4; ++k) a.net[k] = pl.net[k];
+  a.theta = s->theta_dev;
+  a.q = s->q; a.p = s->p;
+  a.z0 = s->cfg.z_dims[0]; a.z1 = s->cfg.z_dims[1]; a.z2 = s->cfg.z_dims[2];
+  a.binary = s->cfg.binary_treatment;
+  a.set_floats = pl.set_ghf;
+}
+
+static void bns_noise(const BnsPlan &pl, const BnsBuf &b, const int *ids, int n_nets, int n_sets_blocks, int n_calls, long long set_floats,
+                      uint64_t seed, uint32_t stream0, uint32_t stride, int block0, hipStream_t stream) {
+  BnsNoiseArgs na{};
+  for (int i = 0; i < n_nets; ++i) na.net[i] = pl.net[ids[i]];
+  na.n_nets = n_nets; na.n_calls = n_calls; na.sf = b.sf; na.dw = b.dw; na.set_floats = set_floats;
+  na.k0 = (uint32_t)(seed & 0xFFFFFFFFull); na.k1 = (uint32_t)(seed >> 32); na.stream0 = stream0; na.stream_stride = stride;
+  na.block0 = block0;
+  hipLaunchKernelGGL(bns_noise_kernel, dim3(8, n_sets_blocks * n_calls), dim3(256), 0, stream, na);
+}
+
+extern "C" int bgm_bnn_logpost(bgm_handle *h, const float *x, const float *y, const float *v, const float *z, int64_t n,
+                               int32_t block_rows, int32_t block0, uint64_t seed, uint32_t stream_id, float *out, void *stream_) {
+  BnnState *s; BnsPlan pl;
+  int rc = bns_session(h, "bgm_bnn_logpost", s, pl);
+  if (rc) return rc;
+  if (!x || !y || !v || !z || !out || n < 1 || block_rows < 2) { bgm_set_error("bgm_bnn_logpost: bad argument"); return BGM_E_INVALID; }
+  hipStream_t stream = (hipStream_t)stream_;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  const int n_blocks = (int)((n + block_rows - 1) / block_rows);
+  BnsBuf b;
+  rc = bns_buffers(h, s, pl, n, n_blocks, (long long)n_blocks * pl.set_ghf, b, stream);
+  if (rc) return rc;
+  const int ids[3] = {BNN_G, BNN_H, BNN_F};
+  bns_noise(pl, b, ids, 3, n_blocks, 1, pl.set_ghf, seed, stream_id, 0, block0, stream);
+  BnsPropArgs pa{};
+  pa.z = z; pa.zprop = b.zprop; pa.n = n; pa.row_base = 0; pa.q = s->q; pa.bs = block_rows;
+  pa.wg_per_block = (block_rows + 255) / 256; pa.it = 0; pa.init = 0; pa.q_sd = 0.0f;
+  pa.k0 = (uint32_t)seed; pa.k1 = (uint32_t)(seed >> 32);
+  pa.stats = b.stats; pa.n_blocks = n_blocks; pa.par = 0; pa.x = x; pa.xstats = b.xstats;
+  hipLaunchKernelGGL(bns_propose_kernel, dim3(n_blocks * pa.wg_per_block), dim3(256), 0, stream, pa);
+  BnsMhArgs a{};
+  bns_fill_mh(s, pl, a);
+  a.lf = b.lf; a.dw = b.dw; a.stats = b.stats; a.xstats = b.xstats;
+  a.x = x; a.y = y; a.v = v; a.z = const_cast<float *>(z); a.zprop = b.zprop; a.n = n; a.row_base = 0;
+  a.bs = block_rows; a.wg_per_block = (block_rows + BNS_ROWS - 1) / BNS_ROWS; a.block0 = block0; a.mode = 0; a.it = 0;
+  a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32); a.stream0 = stream_id; a.out = out;
+  rc = bns_set_lds(bns_mh_kernel, pl.lds_bytes);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bns_mh_kernel, dim3(n_blocks * a.wg_per_block), dim3(BNS_THREADS), pl.lds_bytes, stream, a);
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+extern "C" int bgm_bnn_mh_run(bgm_handle *h, const bgm_bnn_mh_args *g, void *stream_) {
+  BnnState *s; BnsPlan pl;
+  int rc = bns_session(h, "bgm_bnn_mh_run", s, pl);
+  if (rc) return rc;
+  if (!g || !g->x_dev || !g->y_dev || !g->v_dev || !g->state_dev || g->n < 1 || g->block_rows < 2 || g->n_iters < 0) {
+    bgm_set_error("bgm_bnn_mh_run: bad argument"); return BGM_E_INVALID;
+  }
+  if (g->effect != 0) { bgm_set_error("bgm_bnn_mh_run: effects not built yet"); return BGM_E_UNSUPPORTED; }
+  hipStream_t stream = (hipStream_t)stream_;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  const long long n = g->n;
+  const int bs = g->block_rows, n_blocks = (int)((n + bs - 1) / bs), q = s->q;
+  BnsBuf b;
+  rc = bns_buffers(h, s, pl, n, n_blocks, 2LL * n_blocks * pl.set_ghf, b, stream);
+  if (rc) return rc;
+  rc = bns_set_lds(bns_mh_kernel, pl.lds_bytes);
+  if (rc) return rc;
+  const int ids[3] = {BNN_G, BNN_H, BNN_F};
+  BnsPropArgs pa{};
+  pa.z = g->state_dev; pa.zprop = b.zprop; pa.n = n; pa.row_base = g->row_base; pa.q = q; pa.bs = bs;
+  pa.wg_per_block = (bs + 255) / 256; pa.q_sd = g->q_sd;
+  pa.k0 = (uint32_t)g->seed; pa.k1 = (uint32_t)(g->seed >> 32);
+  pa.stats = b.stats; pa.n_blocks = n_blocks; pa.x = g->x_dev; pa.z_init = g->state_dev;
+  BnsMhArgs a{};
+  bns_fill_mh(s, pl, a);
+  a.lf = b.lf; a.dw = b.dw; a.xstats = b.xstats;
+  a.x = g->x_dev; a.y = g->y_dev; a.v = g->v_dev; a.z = g->state_dev; a.zprop = b.zprop; a.n = n; a.row_base = g->row_base;
+  a.bs = bs; a.wg_per_block = (bs + BNS_ROWS - 1) / BNS_ROWS; a.block0 = g->block0; a.mode = 1;
+  a.k0 = pa.k0; a.k1 = pa.k1; a.acc_count = g->acc_count_dev;
+  for (int i = 0; i < g->n_iters; ++i) {
+    const int it = g->it_begin + i;
+    bns_noise(pl, b, ids, 3, n_blocks, 2, pl.set_ghf, g->seed, 2u * (uint32_t)it, 1u, g->block0, stream);
+    pa.it = it; pa.par = i & 1; pa.init = (i == 0 && g->init) ? 1 : 0; pa.xstats = (i == 0) ? b.xstats : nullptr;
+    hipLaunchKernelGGL(bns_propose_kernel, dim3(n_blocks * pa.wg_per_block), dim3(256), 0, stream, pa);
+    a.it = it; a.stats = b.stats + (long long)(i & 1) * n_blocks * 256;
+    hipLaunchKernelGGL(bns_mh_kernel, dim3(n_blocks * a.wg_per_block), dim3(BNS_THREADS), pl.lds_bytes, stream, a);
+    if (g->draws_dev && it >= g->burn_in && it - g->burn_in < g->n_keep)
+      BGM_HIP_CHECK(hipMemcpyAsync(g->draws_dev + (long long)(it - g->burn_in) * n * q, g->state_dev, sizeof(float) * n * q,
+                                   hipMemcpyDeviceToDevice, stream));
+  }
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}

@@ -1,0 +1,502 @@
+// bnn_sample_kernels.h -- CausalBGM with Bayesian networks (use_bnn=True): large-batch forward kernels on gfx950
+// (posterior sampling, causal effects, evaluation).
+//
+// replaces (src/bayesgm/models/causalbgm/base.py, use_bnn branches):
+//   get_log_posterior :765-817 + metropolis_hastings_sampler :820-904  -> bns_propose_kernel, bns_noise_kernel, bns_mh_kernel
+//   infer_from_latent_posterior :671-763                                -> bns_effects_kernel
+//   evaluate :534-570                                                   -> bns_eval_* kernels
+//
+// With Bayesian nets every log-posterior evaluation normalises its input with the statistics of the block of rows it
+// is given (bs rows of predict) and draws ONE weight perturbation per layer for the whole block.  That couples the
+// chains of a block, and neither the current state's log-posterior nor the weights can be kept across iterations: the
+// persistent weights-in-LDS design of causal_kernels.h does not apply.  Structure here, one MH iteration over ALL
+// blocks of the panel in lock step (blocks are independent, so N / bs of them advance together):
+//   bns_noise_kernel    dW = sigma * eps of every (block, call), written in MFMA fragment order
+//   bns_propose_kernel  proposal z' = z + q_sd * N(0, 1); column sums of z and z' per block (fp64 atomics)
+//   bns_mh_kernel       per workgroup 256 rows of one block: g, h, f forward for z' and z, accept / reject
+// Per net the workgroup runs layer-synchronously: the layer's loc and dW fragments (<= 106 KB) are staged in LDS,
+// every wave keeps the activations of its 2 x 16 rows in registers (swapped MFMA orientation: output units along M,
+// rows along N, so accumulators are the next layer's B operands) and runs both GEMMs of the Flipout layer,
+// y = loc^T h + s_out * (dW^T (s_in * h)) + b, with two accumulators per output tile.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "bnn_kernels.h"
+
+#define BNS_WAVES 8
+#define BNS_THREADS (64 * BNS_WAVES)
+#define BNS_R 2
+#define BNS_ROWS (BNS_WAVES * 16 * BNS_R)
+#define BNS_MAXT 4        // hidden widths <= 64
+#define BNS_SW 32         // sign words reserved per row in LDS
+#define BNS_MAXK 208      // widest network input (padded)
+
+struct BnsNet {
+  int n_layers, net_id;
+  int K[BNN_MAX_LAYERS + 1];
+  int T[BNN_MAX_LAYERS], MT[BNN_MAX_LAYERS];   // input k-tiles / output tiles of layer l
+  int foff[BNN_MAX_LAYERS + 1];                // fragments of layer l inside the net's block; foff[L] = block size
+  int woff[BNN_MAX_LAYERS];                    // loc of layer l in theta (rho, bias follow as in BnnNet)
+  int goff;                                    // gamma in theta (beta follows)
+  int sin_w[BNN_MAX_LAYERS], sout_w[BNN_MAX_LAYERS], swords;
+  int fbase;                                   // this net's block inside the packed loc / sigma arrays
+  int dbase;                                   // ... inside one (block, call) perturbation set
+};
+inline void bns_from(const BnnNet &b, BnsNet &n) {
+  n.n_layers = b.n_layers; n.net_id = b.net_id; n.goff = b.off; n.swords = b.swords;
+  int f = 0;
+  for (int l = 0; l <= b.n_layers; ++l) n.K[l] = b.dims[l];
+  for (int l = 0; l < b.n_layers; ++l) {
+    n.T[l] = (b.dims[l] + 15) / 16; n.MT[l] = (b.dims[l + 1] + 15) / 16;
+    n.foff[l] = f; f += n.T[l] * n.MT[l] * 256;
+    n.woff[l] = b.woff[l]; n.sin_w[l] = b.sin_w[l]; n.sout_w[l] = b.sout_w[l];
+  }
+  n.foff[b.n_layers] = f;
+}
+
+// Fragment order of a kernel [in x out]: float4 per (mt, t, lane): element r = W[k = 16 t + 4 g + r][o = 16 mt + j],
+// lane = 16 g + j, zero outside the matrix.
+__device__ __forceinline__ int bns_frag_pos(int k, int o, int T) {
+  const int t = k >> 4, g = (k >> 2) & 3, r = k & 3, mt = o >> 4, j = o & 15;
+  return (((mt * T + t) << 6) + (g << 4) + j) * 4 + r;
+}
+
+// loc and sigma = eps + softplus(rho) of every layer into fragment order (once per parameter change)
+struct BnsPackArgs { BnsNet net[4]; const float *theta; float *lf, *sf; int n_nets; };
+static __global__ void bns_pack_kernel(BnsPackArgs a) {
+  const int k_ = blockIdx.y;
+  const BnsNet &n = a.net[k_];
+  for (int l = 0; l < n.n_layers; ++l) {
+    const int in = n.K[l], out = n.K[l + 1], cnt = in * out;
+    const float *loc = a.theta + n.woff[l], *rho = loc + cnt;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
+      const int pos = n.fbase + n.foff[l] + bns_frag_pos(i / out, i % out, n.T[l]);
+      a.lf[pos] = loc[i];
+      a.sf[pos] = BNN_SCALE_EPS + softplus_acc(rho[i]);
+    }
+  }
+}
+
+// dW fragments of every (block, call): grid (chunks, n_sets); set s = block * n_calls + call has noise key
+// (k0, k1 + block) and stream stream0 + call * stream_stride.
+struct BnsNoiseArgs {
+  BnsNet net[4];
+  int n_nets, n_calls;
+  const float *sf;
+  float *dw;                 // [n_sets][set_floats]
+  long long set_floats;
+  uint32_t k0, k1, stream0, stream_stride;
+  int block0;                // batch id of the first block (key offset)
+};
+static __global__ void bns_noise_kernel(BnsNoiseArgs a) {
+  const int set = blockIdx.y, blk = set / a.n_calls, call = set - blk * a.n_calls;
+  const uint32_t k1 = a.k1 + (uint32_t)(a.block0 + blk), stream = a.stream0 + (uint32_t)call * a.stream_stride;
+  float *dw = a.dw + (long long)set * a.set_floats;
+  for (int k_ = 0; k_ < a.n_nets; ++k_) {
+    const BnsNet &n = a.net[k_];
+    for (int l = 0; l < n.n_layers; ++l) {
+      const int out = n.K[l + 1], cnt = n.K[l] * out;
+      for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (cnt + 3) >> 2; i += gridDim.x * blockDim.x) {
+        const f32x4 z = box_muller4(philox4x32_10((uint32_t)i, (uint32_t)l | ((uint32_t)n.net_id << 16), stream, BNN_TAG_EPS, a.k0, k1));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = 4 * i + u;
+          if (idx < cnt) {
+            const int pos = n.foff[l] + bns_frag_pos(idx / out, idx % out, n.T[l]);
+            dw[n.dbase + pos] = a.sf[n.fbase + pos] * z[u];
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// proposal + column statistics.  One thread per row, 256 rows of ONE block per workgroup.
+// stats: double [n_blocks][2 (0: proposal, 1: current)][2 (sum, sum of squares)][64]; this launch accumulates into
+// parity `par` and clears parity par ^ 1 for the next iteration.
+// ---------------------------------------------------------------------------------------------
+struct BnsPropArgs {
+  const float *z; float *zprop;
+  long long n, row_base;
+  int q, bs, wg_per_block, it, init;     // init: z itself is drawn here (iteration-0 state, TAG_INIT) before proposing
+  float q_sd;
+  uint32_t k0, k1;
+  double *stats;                         // [2 parities][n_blocks][2][2][64]
+  int n_blocks, par;
+  float *z_init;                         // written when init
+  const float *x; double *xstats;        // when xstats != NULL: column sums of x per block [n_blocks][2] (once per run)
+};
+__device__ __forceinline__ void bns_row_normals(uint32_t row, uint32_t it, int q, uint32_t tag, uint32_t k0, uint32_t k1, float *out) {
+  const int n_s = (q + 3) >> 2;
+  for (int sb = 0; sb < (n_s + 3) >> 2; ++sb)
+    for (int g = 0; g < 4 && g < q; ++g) {
+      const f32x4 e = box_muller4(philox4x32_10(row, it, (uint32_t)(g + 4 * sb), tag, k0, k1));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int f = 16 * sb + 4 * r + g; if (f < q) out[f] = e[r]; }
+    }
+}
+static __global__ __launch_bounds__(256) void bns_propose_kernel(BnsPropArgs a) {
+  __shared__ double red[4][4][64];   // [wave][quantity][column]
+  const int blk = blockIdx.x / a.wg_per_block, wib = blockIdx.x - blk * a.wg_per_block;
+  const long long r_in = (long long)wib * 256 + threadIdx.x;
+  const long long row = (long long)blk * a.bs + r_in;
+  const bool valid = r_in < a.bs && row < a.n;
+  const int q = a.q, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (blockIdx.x == 0) {
+    double *clr = a.stats + (long long)(a.par ^ 1) * a.n_blocks * 256;
+    for (long long i = threadIdx.x; i < (long long)a.n_blocks * 256; i += 256) clr[i] = 0.0;
+  }
+  float zc[64], e[64];
+  if (valid) {
+    const uint32_t rid = (uint32_t)(a.row_base + row);
+    if (a.init) {
+      bns_row_normals(rid, 0u, q, TAG_INIT, a.k0, a.k1, zc);
+      for (int f = 0; f < q; ++f) a.z_init[row * q + f] = zc[f];
+    } else {
+      for (int f = 0; f < q; ++f) zc[f] = a.z[row * q + f];
+    }
+    bns_row_normals(rid, (uint32_t)a.it, q, TAG_PROP, a.k0, a.k1, e);
+    for (int f = 0; f < q; ++f) { e[f] = fmaf(a.q_sd, e[f], zc[f]); a.zprop[row * q + f] = e[f]; }
+  }
+  for (int f = 0; f < q; ++f) {
+    double s[4] = {valid ? (double)e[f] : 0.0, valid ? (double)e[f] * e[f] : 0.0, valid ? (double)zc[f] : 0.0,
+                   valid ? (double)zc[f] * zc[f] : 0.0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_xor(s[k], off);
+      if (lane == 0) red[wave][k][f] = s[k];
+    }
+  }
+  double xs = 0.0, xs2 = 0.0;
+  if (a.xstats) {
+    const double xv = valid ? (double)a.x[row] : 0.0;
+    xs = xv; xs2 = xv * xv;
+    for (int off = 32; off > 0; off >>= 1) { xs += __shfl_xor(xs, off); xs2 += __shfl_xor(xs2, off); }
+  }
+  __syncthreads();
+  double *st = a.stats + ((long long)a.par * a.n_blocks + blk) * 256;
+  for (int i = threadIdx.x; i < 4 * q; i += 256) {
+    const int k = i / q, f = i - k * q;
+    atomicAdd(&st[k * 64 + f], red[0][k][f] + red[1][k][f] + red[2][k][f] + red[3][k][f]);
+  }
+  if (a.xstats && lane == 0) { atomicAdd(&a.xstats[2 * blk], xs); atomicAdd(&a.xstats[2 * blk + 1], xs2); }
+}
+
+// ---------------------------------------------------------------------------------------------
+// network forward of one workgroup's rows
+// ---------------------------------------------------------------------------------------------
+struct BnsCtx {
+  int tid, wave, lane, j, g;
+  float *stage;        // LDS: loc fragments | dW fragments of the current layer
+  uint32_t *sg;        // LDS: sign words [wave][rt][16 rows][BNS_SW]
+  float *bn;           // LDS: scale[BNS_MAXK] | shift[BNS_MAXK]
+};
+
+__device__ __forceinline__ float bns_flip(float x, uint32_t w, int bit) {
+  return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x) ^ ((w >> bit) << 31));
+}
+__device__ __forceinline__ uint32_t bns_sgw(const BnsCtx &c, int rt, int word) {
+  return c.sg[(((c.wave * BNS_R + rt) << 4) + c.j) * BNS_SW + word];
+}
+
+// stat(u) -> (mean, variance) of input column u of this call's batch; in(rt, u) -> raw input value of row (rt, j),
+// column u (< K); epi(rt, mt, y): last layer's outputs, y[r] = unit 16 mt + 4 g + r of row (rt, j).
+// rib0: index of the workgroup's first row inside its block (sign rows).
+template <class Stat, class In, class Epi>
+__device__ __forceinline__ void bns_forward(const BnsCtx &c, const BnsNet &n, const float *theta, const float *lf, const float *dw,
+                                            uint32_t k0, uint32_t k1, uint32_t stream, int rib0, Stat stat, In in, Epi epi) {
+  const int L = n.n_layers, j = c.j, g = c.g, lane = c.lane;
+  __syncthreads();    // previous users of bn / sg / stage are done
+  {
+    const float *gamma = theta + n.goff, *beta = gamma + n.K[0];
+    for (int u = c.tid; u < 16 * n.T[0]; u += BNS_THREADS) {
+      float sc = 0.0f, sh = 0.0f;
+      if (u < n.K[0]) {
+        float mean, var;
+        stat(u, mean, var);
+        sc = gamma[u] / sqrtf(var + BNN_BN_EPS);
+        sh = beta[u] - mean * sc;
+      }
+      c.bn[u] = sc; c.bn[BNS_MAXK + u] = sh;
+    }
+    const int calls = n.swords >> 2;
+#pragma unroll
+    for (int rt = 0; rt < BNS_R; ++rt) {
+      const uint32_t row = (uint32_t)(rib0 + ((c.wave * BNS_R + rt) << 4) + j);
+      for (int cc = g; cc < calls; cc += 4) {
+        const uint4 w = philox4x32_10(row, (uint32_t)cc | ((uint32_t)n.net_id << 16), stream, BNN_TAG_SIGN, k0, k1);
+        uint32_t *dst = c.sg + (((c.wave * BNS_R + rt) << 4) + j) * BNS_SW + 4 * cc;
+        dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
+      }
+    }
+  }
+  float h[BNS_R][BNS_MAXT][4];
+  for (int l = 0; l < L; ++l) {
+    const int T = n.T[l], MT = n.MT[l], M = n.K[l + 1], fcount = T * MT * 64;   // float4 per array
+    __syncthreads();
+    {
+      const f32x4 *s1 = (const f32x4 *)(lf + n.foff[l]), *s2 = (const f32x4 *)(dw + n.foff[l]);
+      f32x4 *d = (f32x4 *)c.stage;
+      for (int i = c.tid; i < fcount; i += BNS_THREADS) { d[i] = s1[i]; d[fcount + i] = s2[i]; }
+    }
+    __syncthreads();
+    const f32x4 *LF = (const f32x4 *)c.stage, *DF = LF + fcount;
+    const float *bias = theta + n.woff[l] + 2 * n.K[l] * M;
+    if (l == 0) {
+      f32x4 a1[BNS_R][BNS_MAXT], a2[BNS_R][BNS_MAXT];
+#pragma unroll
+      for (int rt = 0; rt < BNS_R; ++rt)
+#pragma unroll
+        for (int mt = 0; mt < BNS_MAXT; ++mt) { a1[rt][mt] = f32x4{0.f, 0.f, 0.f, 0.f}; a2[rt][mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int t = 0; t < T; ++t) {
+        float hb[BNS_R][4], hs[BNS_R][4];
+#pragma unroll
+        for (int rt = 0; rt < BNS_R; ++rt) {
+          const uint32_t w = bns_sgw(c, rt, n.sin_w[0] + (t >> 1));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int u = 16 * t + 4 * g + r;
+            const float x = fmaf(in(rt, u), c.bn[u], c.bn[BNS_MAXK + u]);
+            hb[rt][r] = x;
+            hs[rt][r] = bns_flip(x, w, ((t & 1) << 4) + 4 * g + r);
+          }
+        }
+#pragma unroll
+        for (int mt = 0; mt < BNS_MAXT; ++mt)
+          if (mt < MT) {
+            const f32x4 fa = LF[(mt * T + t) * 64 + lane], fd = DF[(mt * T + t) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int rt = 0; rt < BNS_R; ++rt) {
+                a1[rt][mt] = BGM_MFMA(fa[r], hb[rt][r], a1[rt][mt]);
+                a2[rt][mt] = BGM_MFMA(fd[r], hs[rt][r], a2[rt][mt]);
+              }
+          }
+      }
+#pragma unroll
+      for (int mt = 0; mt < BNS_MAXT; ++mt) {
+        float b[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int o = 16 * mt + 4 * g + r; b[r] = (mt < MT && o < M) ? bias[o] : 0.0f; }
+#pragma unroll
+        for (int rt = 0; rt < BNS_R; ++rt) {
+          const uint32_t w = (mt < MT) ? bns_sgw(c, rt, n.sout_w[0] + (mt >> 1)) : 0u;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float y = a1[rt][mt][r] + b[r] + bns_flip(a2[rt][mt][r], w, ((mt & 1) << 4) + 4 * g + r);
+            h[rt][mt][r] = (mt < MT) ? lrelu(y) : 0.0f;
+          }
+        }
+      }
+    } else {
+      float hs[BNS_R][BNS_MAXT][4];
+#pragma unroll
+      for (int rt = 0; rt < BNS_R; ++rt)
+#pragma unroll
+        for (int t = 0; t < BNS_MAXT; ++t) {
+          const uint32_t w = (t < T) ? bns_sgw(c, rt, n.sin_w[l] + (t >> 1)) : 0u;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hs[rt][t][r] = bns_flip(h[rt][t][r], w, ((t & 1) << 4) + 4 * g + r);
+        }
+      const bool last = (l == L - 1);
+      float hn[BNS_R][BNS_MAXT][4];
+      auto tile = [&](int mt, f32x4 (&y)[BNS_R]) {
+        f32x4 a1[BNS_R], a2[BNS_R];
+#pragma unroll
+        for (int rt = 0; rt < BNS_R; ++rt) { a1[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; a2[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int t = 0; t < BNS_MAXT; ++t)
+          if (t < T) {
+            const f32x4 fa = LF[(mt * T + t) * 64 + lane], fd = DF[(mt * T + t) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int rt = 0; rt < BNS_R; ++rt) {
+                a1[rt] = BGM_MFMA(fa[r], h[rt][t][r], a1[rt]);
+                a2[rt] = BGM_MFMA(fd[r], hs[rt][t][r], a2[rt]);
+              }
+          }
+        float b[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int o = 16 * mt + 4 * g + r; b[r] = (o < M) ? bias[o] : 0.0f; }
+#pragma unroll
+        for (int rt = 0; rt < BNS_R; ++rt) {
+          const uint32_t w = bns_sgw(c, rt, n.sout_w[l] + (mt >> 1));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) y[rt][r] = a1[rt][r] + b[r] + bns_flip(a2[rt][r], w, ((mt & 1) << 4) + 4 * g + r);
+        }
+      };
+      if (!last) {
+#pragma unroll
+        for (int mt = 0; mt < BNS_MAXT; ++mt) {
+          f32x4 y[BNS_R];
+          if (mt < MT) tile(mt, y);
+#pragma unroll
+          for (int rt = 0; rt < BNS_R; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hn[rt][mt][r] = (mt < MT) ? lrelu(y[rt][r]) : 0.0f;
+        }
+#pragma unroll
+        for (int rt = 0; rt < BNS_R; ++rt)
+#pragma unroll
+          for (int t = 0; t < BNS_MAXT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[rt][t][r] = hn[rt][t][r];
+      } else {
+        for (int mt = 0; mt < MT; ++mt) {
+          f32x4 y[BNS_R];
+          tile(mt, y);
+#pragma unroll
+          for (int rt = 0; rt < BNS_R; ++rt) epi(rt, mt, y[rt]);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// log-posterior of a block-structured panel / one Metropolis-Hastings iteration
+// ---------------------------------------------------------------------------------------------
+struct BnsMhArgs {
+  BnsNet net[4];                       // g, e, f, h (BNN_* ids); e unused here
+  const float *theta, *lf;
+  const float *dw;                     // [n_blocks * n_calls][set_floats]
+  long long set_floats;
+  const double *stats;                 // [n_blocks][2][2][64] of this iteration's parity (0: proposal, 1: current)
+  const double *xstats;                // [n_blocks][2]
+  const float *x, *y, *v;
+  float *z;                            // current state [n x q] (updated in place by the MH mode)
+  const float *zprop;                  // proposals [n x q]
+  long long n, row_base;
+  int q, p, z0, z1, z2, binary, bs, wg_per_block, block0;
+  int mode;                            // 0: log-posterior of z with the "current" statistics / call slot 0 -> out;  1: MH iteration
+  int it;
+  uint32_t k0, k1, stream0;            // mode 1: streams 2 it (proposal), 2 it + 1 (current); mode 0: stream0
+  float *out;                          // mode 0: [n] log-posterior
+  unsigned *acc_count;                 // mode 1 (optional): accepted proposals
+};
+
+__device__ __forceinline__ void bns_stat(const double *st, int col, double cnt, float &mean, float &var) {
+  const double m = st[col] / cnt, v = st[64 + col] / cnt - m * m;
+  mean = (float)m; var = (float)fmax(v, 0.0);
+}
+
+// -(NLL_v + NLL_x + NLL_y + |z|^2 / 2) of the rows of this wave for one state; zsrc = state, call slot `slot`.
+__device__ __forceinline__ void bns_logpost_rows(const BnsCtx &c, const BnsMhArgs &a, int blk, int rib0, const long long (&row)[BNS_R],
+                                                 const float *zsrc, int stat_slot, int dw_slot, int n_calls, uint32_t k1, uint32_t stream,
+                                                 double cnt, float (&lp)[BNS_R]) {
+  const int q = a.q, p = a.p, z0 = a.z0, z1 = a.z1, g = c.g;
+  const double *st = a.stats + ((long long)blk * 2 + stat_slot) * 128;
+  const double *xst = a.xstats + 2 * blk;
+  const float *dwset = a.dw + ((long long)blk * n_calls + dw_slot) * a.set_floats;
+  float xr[BNS_R], yr[BNS_R];
+#pragma unroll
+  for (int rt = 0; rt < BNS_R; ++rt) { xr[rt] = a.x[row[rt]]; yr[rt] = a.y[row[rt]]; }
+  // ---- g: Gaussian likelihood of the covariates
+  float ssq[BNS_R], raw[BNS_R];
+#pragma unroll
+  for (int rt = 0; rt < BNS_R; ++rt) { ssq[rt] = 0.0f; raw[rt] = 0.0f; }
+  bns_forward(c, a.net[BNN_G], a.theta, a.lf + a.net[BNN_G].fbase, dwset + a.net[BNN_G].dbase, a.k0, k1, stream, rib0,
+              [&](int u, float &m, float &v) { bns_stat(st, u, cnt, m, v); },
+              [&](int rt, int u) { return u < q ? zsrc[row[rt] * q + u] : 0.0f; },
+              [&](int rt, int mt, const f32x4 &y) {
+                const float *vr = a.v + row[rt] * p;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const int u = 16 * mt + 4 * g + r;
+                  if (u < p) { const float d = vr[u] - y[r]; ssq[rt] = fmaf(d, d, ssq[rt]); }
+                  else if (u == p) raw[rt] += y[r];
+                }
+              });
+#pragma unroll
+  for (int rt = 0; rt < BNS_R; ++rt) {
+    const float s = sum_over_g(ssq[rt]), rw = sum_over_g(raw[rt]);
+    const float s2 = softplus_acc(rw) + BGM_EPS;
+    lp[rt] = -(s / (2.0f * s2) + (float)p * logf(s2) * 0.5f);
+  }
+  // ---- h: treatment model, input (z0, z2)
+  float mu[BNS_R];
+#pragma unroll
+  for (int rt = 0; rt < BNS_R; ++rt) { mu[rt] = 0.0f; raw[rt] = 0.0f; }
+  bns_forward(c, a.net[BNN_H], a.theta, a.lf + a.net[BNN_H].fbase, dwset + a.net[BNN_H].dbase, a.k0, k1, stream, rib0,
+              [&](int u, float &m, float &v) { bns_stat(st, u < z0 ? u : u + z1, cnt, m, v); },
+              [&](int rt, int u) { return u < a.net[BNN_H].K[0] ? zsrc[row[rt] * q + (u < z0 ? u : u + z1)] : 0.0f; },
+              [&](int rt, int mt, const f32x4 &y) { if (mt == 0 && g == 0) { mu[rt] += y[0]; raw[rt] += y[1]; } });
+#pragma unroll
+  for (int rt = 0; rt < BNS_R; ++rt) {
+    const float m_ = sum_over_g(mu[rt]), rw = sum_over_g(raw[rt]);
+    if (a.binary) lp[rt] -= fmaxf(m_, 0.0f) - m_ * xr[rt] + log1pf(expf(-fabsf(m_)));
+    else { const float s2 = softplus_acc(rw) + BGM_EPS, d = xr[rt] - m_; lp[rt] -= d * d / (2.0f * s2) + logf(s2) * 0.5f; }
+  }
+  // ---- f: outcome model, input (z0, z1, x)
+#pragma unroll
+  for (int rt = 0; rt < BNS_R; ++rt) { mu[rt] = 0.0f; raw[rt] = 0.0f; }
+  bns_forward(c, a.net[BNN_F], a.theta, a.lf + a.net[BNN_F].fbase, dwset + a.net[BNN_F].dbase, a.k0, k1, stream, rib0,
+              [&](int u, float &m, float &v) {
+                if (u < z0 + z1) bns_stat(st, u, cnt, m, v);
+                else { const double mm = xst[0] / cnt; m = (float)mm; v = (float)fmax(xst[1] / cnt - mm * mm, 0.0); }
+              },
+              [&](int rt, int u) { return u < z0 + z1 ? zsrc[row[rt] * q + u] : (u == z0 + z1 ? xr[rt] : 0.0f); },
+              [&](int rt, int mt, const f32x4 &y) { if (mt == 0 && g == 0) { mu[rt] += y[0]; raw[rt] += y[1]; } });
+#pragma unroll
+  for (int rt = 0; rt < BNS_R; ++rt) {
+    const float m_ = sum_over_g(mu[rt]), rw = sum_over_g(raw[rt]);
+    const float s2 = softplus_acc(rw) + BGM_EPS, d = yr[rt] - m_;
+    lp[rt] -= d * d / (2.0f * s2) + logf(s2) * 0.5f;
+    float zz = 0.0f;
+    for (int u = 0; u < q; ++u) { const float t = zsrc[row[rt] * q + u]; zz = fmaf(t, t, zz); }
+    lp[rt] -= 0.5f * zz;
+  }
+}
+
+static __global__ __launch_bounds__(BNS_THREADS) void bns_mh_kernel(BnsMhArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float bns_lds[];
+  BnsCtx c;
+  c.tid = threadIdx.x; c.wave = c.tid >> 6; c.lane = c.tid & 63; c.j = c.lane & 15; c.g = c.lane >> 4;
+  c.bn = bns_lds;
+  c.sg = (uint32_t *)(bns_lds + 2 * BNS_MAXK);
+  c.stage = bns_lds + 2 * BNS_MAXK + BNS_WAVES * BNS_R * 16 * BNS_SW;
+  const int blk = blockIdx.x / a.wg_per_block, wib = blockIdx.x - blk * a.wg_per_block;
+  const int rib0 = wib * BNS_ROWS;
+  const long long blk_lo = (long long)blk * a.bs;
+  const long long blk_n = min((long long)a.bs, a.n - blk_lo);
+  long long row[BNS_R];
+  bool valid[BNS_R];
+#pragma unroll
+  for (int rt = 0; rt < BNS_R; ++rt) {
+    const long long r = rib0 + ((c.wave * BNS_R + rt) << 4) + c.j;
+    valid[rt] = r < blk_n;
+    row[rt] = blk_lo + (valid[rt] ? r : blk_n - 1);
+  }
+  const uint32_t k1 = a.k1 + (uint32_t)(a.block0 + blk);
+  const double cnt = (double)blk_n;
+  if (a.mode == 0) {
+    float lp[BNS_R];
+    bns_logpost_rows(c, a, blk, rib0, row, a.z, 1, 0, 1, k1, a.stream0, cnt, lp);
+#pragma unroll
+    for (int rt = 0; rt < BNS_R; ++rt)
+      if (valid[rt] && c.g == 0) a.out[row[rt]] = lp[rt];
+    return;
+  }
+  float lpp[BNS_R], lpc[BNS_R];
+  bns_logpost_rows(c, a, blk, rib0, row, a.zprop, 0, 0, 2, k1, 2u * (uint32_t)a.it, cnt, lpp);
+  bns_logpost_rows(c, a, blk, rib0, row, a.z, 1, 1, 2, k1, 2u * (uint32_t)a.it + 1u, cnt, lpc);
+  unsigned nacc = 0;
+#pragma unroll
+  for (int rt = 0; rt < BNS_R; ++rt) {
+    const uint4 w4 = philox4x32_10((uint32_t)(a.row_base + row[rt]), (uint32_t)a.it >> 2, 0u, TAG_ACC, a.k0, a.k1);
+    const int it = a.it;
+    const unsigned w = (it & 2) ? ((it & 1) ? w4.w : w4.z) : ((it & 1) ? w4.y : w4.x);
+    const bool acc = u01_open(w) < expf(fminf(lpp[rt] - lpc[rt], 0.0f));
+    if (valid[rt] && acc) {
+      for (int u = c.g; u < a.q; u += 4) a.z[row[rt] * a.q + u] = a.zprop[row[rt] * a.q + u];
+      if (c.g == 0) ++nacc;
+    }
+  }
+  if (a.acc_count) {
+    for (int off = 32; off > 0; off >>= 1) nacc += __shfl_xor(nacc, off);
+    if (c.lane == 0 && nacc) atomicAdd(a.acc_count, nacc);
+  }
+}

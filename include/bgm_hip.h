@@ -441,6 +441,41 @@ int bgm_bnn_z_step(bgm_handle *h, const float *x_dev, const float *y_dev, const 
                    float *dz_out_dev, void *stream);
 int bgm_bnn_end(bgm_handle *h, void *stream);
 
+/* ---- large-batch side of the session: posterior sampling, causal effects, evaluation.  A "block" is the batch of rows
+ * one reference call sees (bs rows of predict, base.py:640-645; the whole panel for evaluate): its input statistics
+ * normalise the rows and ONE weight perturbation per layer is shared by them.  Noise key of block b = seed + (b << 32). */
+
+/* replaces: get_log_posterior with use_bnn, base.py:765-817.  Rows [0, n) in blocks of block_rows (first block id
+ * block0); one call of g, h, f per block with noise stream stream_id.  out_dev [n]. */
+int bgm_bnn_logpost(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev, const float *z_dev,
+                    int64_t n, int32_t block_rows, int32_t block0, uint64_t seed, uint32_t stream_id, float *out_dev,
+                    void *stream);
+
+typedef struct {
+  const float *x_dev, *y_dev, *v_dev;  /* [n], [n], [n x p]                                                       */
+  int64_t n, row_base;                 /* rows of this call; global index of row 0 (keys the per-row RNG streams)  */
+  int32_t block_rows, block0;          /* bs of predict; id of the first block                                     */
+  float *state_dev;                    /* [n x q] chain states (in / out)                                          */
+  int32_t init;                        /* 1: draw the initial states N(0, I) (base.py:842) before it_begin         */
+  int32_t it_begin, n_iters, burn_in;  /* iterations [it_begin, it_begin + n_iters); kept when it >= burn_in       */
+  float q_sd;                          /* proposal std-dev (fixed)                                                 */
+  uint64_t seed;
+  uint32_t *acc_count_dev;             /* optional: accepted proposals (accumulated)                               */
+  float *draws_dev;                    /* optional [n_keep x n x q]: retained states                               */
+  int32_t n_keep;
+  int32_t effect;                      /* 0 none, 1 ADRF (continuous), 2 ITE (binary)                              */
+  int32_t sample_y;
+  const float *x_values_dev;           /* effect 1: [n_doses]                                                      */
+  int32_t n_doses;
+  double *adrf_sum_dev;                /* effect 1: [n_doses x n_keep] sums over the rows of this call (accumulated) */
+  float *ite_dev;                      /* effect 2: [n x n_keep]                                                    */
+} bgm_bnn_mh_args;
+/* replaces: metropolis_hastings_sampler (fixed q_sd) + infer_from_latent_posterior with use_bnn, base.py:820-904,
+ * 671-763.  All blocks advance in lock step, three launches per iteration (perturbations, proposal + statistics,
+ * g/h/f forward of both states + accept).  Noise streams: 2 it (proposal), 2 it + 1 (current state);
+ * effects of kept draw d at dose k: stream 0x40000000 + d * n_doses + k (ITE: k = 0 for x = 1, 1 for x = 0). */
+int bgm_bnn_mh_run(bgm_handle *h, const bgm_bnn_mh_args *args, void *stream);
+
 /* Debug: throughput of the hand-scheduled 64x4-tile MFMA block alone (mode 1: fragments streamed from LDS; mode 0:
  * register operands only) with `waves_per_cu` waves on every CU. */
 int bgm_debug_group_probe(bgm_handle *h, int32_t mode, int32_t waves_per_cu, int32_t iters, double *mfma_tflops);

@@ -348,3 +348,38 @@ def log_posterior(m, x, y, v, z, noises, stats=None):
     s2y = softplus(of[:, -1]) + t(EPS)
     ly = (y[:, 0] - of[:, 0]) ** 2 / (2 * s2y) + np.log(s2y) / 2
     return -(lv + lx + ly + (z ** 2).sum(axis=1) / 2)
+
+
+# ---------------------------------------------------------------------------------------------------
+# posterior sampling on a block-structured panel (predict, causalbgm/base.py:573-668 with use_bnn)
+# ---------------------------------------------------------------------------------------------------
+def block_key(seed, blk):
+    """Noise key of block `blk`: (seed_lo, seed_hi + blk)."""
+    return (int(seed) & 0xFFFFFFFF) | ((((int(seed) >> 32) + int(blk)) & 0xFFFFFFFF) << 32)
+
+
+def log_posterior_blocks(m, x, y, v, z, block_rows, seed, stream, block0=0):
+    """get_log_posterior applied block by block (each block = one reference call: own statistics, own noise)."""
+    n = len(z)
+    out = np.empty(n, dtype=z.dtype)
+    for b, lo in enumerate(range(0, n, block_rows)):
+        hi = min(n, lo + block_rows)
+        key = block_key(seed, block0 + b)
+        noises = {k: draw_noise(net_dims(m[k]), hi - lo, key, stream, NET_ID[k], dtype=z.dtype) for k in ("g", "h", "f")}
+        out[lo:hi] = log_posterior(m, x[lo:hi], y[lo:hi], v[lo:hi], z[lo:hi], noises)
+    return out
+
+
+def mh_iteration(m, x, y, v, z, it, q_sd, seed, block_rows, block0=0, row_base=0):
+    """One iteration of metropolis_hastings_sampler (:860-871) for every block; both log-posteriors are evaluated
+    afresh (proposal first: stream 2 it, then the current state: stream 2 it + 1).  Returns (new z, accepted)."""
+    n, q = z.shape
+    rows = np.arange(row_base, row_base + n)
+    prop = (z + z.dtype.type(q_sd) * R.normals(rows, it, q, R.TAG_PROP, seed).astype(z.dtype)).astype(z.dtype)
+    lpp = log_posterior_blocks(m, x, y, v, prop, block_rows, seed, 2 * it, block0)
+    lpc = log_posterior_blocks(m, x, y, v, z, block_rows, seed, 2 * it + 1, block0)
+    u = R.uniforms(rows, it, R.TAG_ACC, seed)
+    acc = u < np.exp(np.minimum(lpp - lpc, 0))
+    out = z.copy()
+    out[acc] = prop[acc]
+    return out, acc, lpp, lpc

@@ -131,3 +131,50 @@ def test_steps_apply_adam_like_oracle():
             assert np.abs(a - b).max() < 2e-3, (name, a.shape, np.abs(a - b).max())   # 3 Adam steps of lr 1e-3
     assert np.abs(dz_t.cpu().numpy() - zo).max() < 5e-3
     eng.close()
+
+
+@pytest.mark.parametrize("binary,p,z_dims,n,bs", [
+    (False, 200, (1, 1, 1, 7), 700, 300),      # ragged last block, several workgroups per block
+    (True, 100, (3, 3, 6, 6), 520, 520),
+    (False, 37, (2, 1, 2, 3), 100, 64),
+])
+def test_logpost_blocks_match_oracle(binary, p, z_dims, n, bs):
+    m = _model(binary, z_dims=z_dims, p=p)
+    z, x, y, v = _panel(m, n)
+    eng = _engine(m)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
+    seed, stream = (3 << 32) | 1234, 77
+    got = eng.logpost(T(x[:, 0]), T(y[:, 0]), T(v), T(z), bs, seed, stream, block0=2).cpu().numpy()
+    m64 = OB.cast_model(m, np.float64)
+    ref = OB.log_posterior_blocks(m64, x.astype(np.float64), y.astype(np.float64), v.astype(np.float64), z.astype(np.float64),
+                                  bs, seed, stream, block0=2)
+    assert np.abs(got - ref).max() < 2e-3 * np.abs(ref).max(), np.abs(got - ref).max()
+    eng.close()
+
+
+def test_mh_iterations_match_oracle():
+    m = _model(False, p=50)
+    n, bs = 600, 256
+    z, x, y, v = _panel(m, n)
+    eng = _engine(m)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
+    seed = (9 << 32) | 4321
+    state = T(z)
+    acc = torch.zeros(1, dtype=torch.int32, device=eng.device)
+    eng.mh_run(T(x[:, 0]), T(y[:, 0]), T(v), state, bs, it_begin=5, n_iters=2, burn_in=0, q_sd=0.3, seed=seed, row_base=1000,
+               acc_count=acc)
+    zo = z.astype(np.float64)
+    m64 = OB.cast_model(m, np.float64)
+    n_acc, fragile = 0, np.zeros(n, bool)
+    for it in (5, 6):
+        zo, a, lpp, lpc = OB.mh_iteration(m64, x.astype(np.float64), y.astype(np.float64), v.astype(np.float64), zo, it, 0.3,
+                                          seed, bs, row_base=1000)
+        n_acc += int(a.sum())
+        u = OB.R.uniforms(np.arange(1000, 1000 + n), it, OB.R.TAG_ACC, seed)
+        fragile |= np.abs(u - np.exp(np.minimum(lpp - lpc, 0))) < 1e-3     # accept decisions within fp32 noise
+    got = state.cpu().numpy()
+    ok = ~fragile
+    assert ok.sum() > 0.9 * n
+    assert np.abs(got[ok] - zo[ok]).max() < 1e-5
+    assert abs(int(acc[0]) - n_acc) <= int(fragile.sum())
+    eng.close()
