@@ -155,6 +155,26 @@ class BnnEngine(object):
         a.ite_dev = ite.data_ptr() if ite is not None else None
         _lib.check(self.lib.bgm_bnn_mh_run(self.h, C.byref(a), self._stream()), "bgm_bnn_mh_run")
 
+    def evaluate(self, x, y, v, z=None, x_values=None, seed=0, stream_id=0, want_sums=True, want_effects=True):
+        """evaluate (base.py:534-570) on device tensors; z=None -> z = e(v) (returned).
+        Returns (z, sums fp64[3] or None, causal): causal = dose sums fp64 [n_doses] (continuous) / ITE [n] (binary) / None."""
+        n = v.shape[0]
+        encode = z is None
+        if encode:
+            z = torch.empty((n, self.q), device=self.device, dtype=torch.float32)
+        sums = torch.zeros(3, device=self.device, dtype=torch.float64) if want_sums else None
+        dose, ite, xv = None, None, None
+        if want_effects:
+            if self.binary:
+                ite = torch.empty(n, device=self.device, dtype=torch.float32)
+            else:
+                xv = _f32(np.atleast_1d(np.asarray(x_values, dtype=np.float32)), self.device)
+                dose = torch.zeros(xv.numel(), device=self.device, dtype=torch.float64)
+        _lib.check(self.lib.bgm_bnn_evaluate(self.h, _ptr(x), _ptr(y), _ptr(v), _ptr(z), int(encode), n, _ptr(xv),
+                                             xv.numel() if xv is not None else 0, int(seed), int(stream_id) & 0xFFFFFFFF,
+                                             _ptr(sums), _ptr(dose), _ptr(ite), self._stream()), "bgm_bnn_evaluate")
+        return z, sums, (ite if self.binary else dose)
+
     def end(self):
         _lib.check(self.lib.bgm_bnn_end(self.h, self._stream()), "bgm_bnn_end")
         self.open = False

@@ -53,14 +53,14 @@ static bool bns_plan(const BnnState *s, BnsPlan &pl) {
 }
 
 // Device scratch of the sampling side: [lf | sf | zprop | dw sets | stats (doubles) | xstats (doubles)], grown on demand.
-struct BnsBuf { float *lf, *sf, *zprop, *dw; double *stats, *xstats; };
+struct BnsBuf { float *lf, *sf, *zprop, *dw, *pair; double *stats, *xstats, *vstats; };
 static int bns_buffers(bgm_handle *h, BnnState *s, const BnsPlan &pl, long long n, int n_blocks, long long dw_floats, BnsBuf &b,
                        hipStream_t stream) {
   const long long fr = (pl.frag_total + 63) & ~63LL;
   const long long zp = (n * s->q + 63) & ~63LL;
   const long long dwf = (dw_floats + 63) & ~63LL;
-  const long long st_d = 2LL * n_blocks * 256 + 2LL * n_blocks + 64;      // doubles
-  const size_t need = (size_t)(2 * fr + zp + dwf + 2 * st_d + 64);
+  const long long st_d = 2LL * n_blocks * 256 + 2LL * n_blocks + 2 * BNS_MAXK + 64;      // doubles
+  const size_t need = (size_t)(2 * fr + zp + dwf + 2 * st_d + 128);
   if (need > s->samp_cap) {
     BGM_HIP_CHECK(hipStreamSynchronize(stream));
     if (s->samp_dev) BGM_HIP_CHECK(hipFree(s->samp_dev));
@@ -71,6 +71,8 @@ static int bns_buffers(bgm_handle *h, BnnState *s, const BnsPlan &pl, long long 
   b.lf = s->samp_dev; b.sf = b.lf + fr; b.zprop = b.sf + fr; b.dw = b.zprop + zp;
   b.stats = (double *)(b.dw + dwf);
   b.xstats = b.stats + 2LL * n_blocks * 256;
+  b.vstats = b.xstats + 2LL * n_blocks;
+  b.pair = (float *)(b.stats + st_d);
   if (!s->packed_valid) {
     BGM_HIP_CHECK(hipMemsetAsync(b.lf, 0, sizeof(float) * 2 * fr, stream));
     BnsPackArgs pa{};
@@ -155,16 +157,49 @@ extern "C" int bgm_bnn_mh_run(bgm_handle *h, const bgm_bnn_mh_args *g, void *str
   if (!g || !g->x_dev || !g->y_dev || !g->v_dev || !g->state_dev || g->n < 1 || g->block_rows < 2 || g->n_iters < 0) {
     bgm_set_error("bgm_bnn_mh_run: bad argument"); return BGM_E_INVALID;
   }
-  if (g->effect != 0) { bgm_set_error("bgm_bnn_mh_run: effects not built yet"); return BGM_E_UNSUPPORTED; }
+  if (g->effect == 1 && (!g->x_values_dev || g->n_doses < 1 || !g->adrf_sum_dev)) { bgm_set_error("bgm_bnn_mh_run: ADRF needs x_values_dev and adrf_sum_dev"); return BGM_E_INVALID; }
+  if (g->effect == 2 && !g->ite_dev) { bgm_set_error("bgm_bnn_mh_run: ITE needs ite_dev"); return BGM_E_INVALID; }
+  if (g->effect < 0 || g->effect > 2) { bgm_set_error("bgm_bnn_mh_run: bad effect"); return BGM_E_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
   const long long n = g->n;
   const int bs = g->block_rows, n_blocks = (int)((n + bs - 1) / bs), q = s->q;
   BnsBuf b;
-  rc = bns_buffers(h, s, pl, n, n_blocks, 2LL * n_blocks * pl.set_ghf, b, stream);
+  const int n_doses = g->effect == 1 ? g->n_doses : (g->effect == 2 ? 2 : 0);
+  rc = bns_buffers(h, s, pl, n, n_blocks, 2LL * n_blocks * pl.set_ghf + (long long)n_blocks * n_doses * pl.set_f, b, stream);
   if (rc) return rc;
   rc = bns_set_lds(bns_mh_kernel, pl.lds_bytes);
   if (rc) return rc;
+  rc = bns_set_lds(bns_effects_kernel, pl.lds_bytes);
+  if (rc) return rc;
+  float *dw_eff = b.dw + 2LL * n_blocks * pl.set_ghf;
+  BnsEffArgs ea{};
+  if (g->effect) {
+    if (g->effect == 2) {
+      static const float pair_host[2] = {1.0f, 0.0f};
+      BGM_HIP_CHECK(hipMemcpyAsync(b.pair, pair_host, sizeof(pair_host), hipMemcpyHostToDevice, stream));
+    }
+    ea.f = pl.net[BNN_F]; ea.f.dbase = 0;
+    ea.theta = s->theta_dev; ea.lf = b.lf; ea.dw = dw_eff; ea.set_floats = pl.set_f;
+    ea.z = g->state_dev; ea.n = n; ea.row_base = g->row_base; ea.q = q; ea.z0 = s->cfg.z_dims[0]; ea.z1 = s->cfg.z_dims[1];
+    ea.bs = bs; ea.wg_per_block = (bs + BNS_ROWS - 1) / BNS_ROWS; ea.block0 = g->block0; ea.n_doses = n_doses;
+    ea.xvals = g->effect == 1 ? g->x_values_dev : b.pair;
+    ea.k0 = (uint32_t)g->seed; ea.k1 = (uint32_t)(g->seed >> 32); ea.sample_y = g->sample_y;
+  }
+  // effects of the draw kept by iteration `it_kept`, whose state statistics sit in slot 1 of parity `par`
+  auto effects = [&](int it_kept, int par) {
+    const int d = it_kept - g->burn_in;
+    BnsNoiseArgs na{};
+    na.net[0] = ea.f; na.n_nets = 1; na.n_calls = n_doses; na.sf = b.sf; na.dw = dw_eff; na.set_floats = pl.set_f;
+    na.k0 = ea.k0; na.k1 = ea.k1; na.stream0 = 0x40000000u + (uint32_t)d * (uint32_t)n_doses; na.stream_stride = 1u; na.block0 = g->block0;
+    hipLaunchKernelGGL(bns_noise_kernel, dim3(2, n_blocks * n_doses), dim3(256), 0, stream, na);
+    ea.stats = b.stats + (long long)par * n_blocks * 256;
+    ea.stream0 = na.stream0; ea.it_noise = (uint32_t)it_kept;
+    ea.sum_out = g->effect == 1 ? g->adrf_sum_dev + d : nullptr; ea.sum_stride = g->n_keep;
+    ea.ite_out = g->effect == 2 ? g->ite_dev + d : nullptr; ea.ite_stride = g->n_keep;
+    hipLaunchKernelGGL(bns_effects_kernel, dim3(n_blocks * ea.wg_per_block), dim3(BNS_THREADS), pl.lds_bytes, stream, ea);
+  };
+  auto kept = [&](int it) { return g->effect && it >= g->burn_in && it - g->burn_in < g->n_keep; };
   const int ids[3] = {BNN_G, BNN_H, BNN_F};
   BnsPropArgs pa{};
   pa.z = g->state_dev; pa.zprop = b.zprop; pa.n = n; pa.row_base = g->row_base; pa.q = q; pa.bs = bs;
@@ -182,11 +217,91 @@ extern "C" int bgm_bnn_mh_run(bgm_handle *h, const bgm_bnn_mh_args *g, void *str
     bns_noise(pl, b, ids, 3, n_blocks, 2, pl.set_ghf, g->seed, 2u * (uint32_t)it, 1u, g->block0, stream);
     pa.it = it; pa.par = i & 1; pa.init = (i == 0 && g->init) ? 1 : 0; pa.xstats = (i == 0) ? b.xstats : nullptr;
     hipLaunchKernelGGL(bns_propose_kernel, dim3(n_blocks * pa.wg_per_block), dim3(256), 0, stream, pa);
+    if (i > 0 && kept(it - 1)) effects(it - 1, i & 1);
     a.it = it; a.stats = b.stats + (long long)(i & 1) * n_blocks * 256;
     hipLaunchKernelGGL(bns_mh_kernel, dim3(n_blocks * a.wg_per_block), dim3(BNS_THREADS), pl.lds_bytes, stream, a);
     if (g->draws_dev && it >= g->burn_in && it - g->burn_in < g->n_keep)
       BGM_HIP_CHECK(hipMemcpyAsync(g->draws_dev + (long long)(it - g->burn_in) * n * q, g->state_dev, sizeof(float) * n * q,
                                    hipMemcpyDeviceToDevice, stream));
+  }
+  if (g->n_iters > 0 && kept(g->it_begin + g->n_iters - 1)) {
+    // statistics of the final state: one more statistics pass (its proposal is not used)
+    const int i = g->n_iters;
+    pa.it = g->it_begin + i; pa.par = i & 1; pa.init = 0; pa.xstats = nullptr;
+    hipLaunchKernelGGL(bns_propose_kernel, dim3(n_blocks * pa.wg_per_block), dim3(256), 0, stream, pa);
+    effects(g->it_begin + i - 1, i & 1);
+  }
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+extern "C" int bgm_bnn_evaluate(bgm_handle *h, const float *x, const float *y, const float *v, float *z, int32_t encode, int64_t n,
+                                const float *x_values, int32_t n_doses, uint64_t seed, uint32_t stream_id, double *sums,
+                                double *dose_sums, float *ite, void *stream_) {
+  BnnState *s; BnsPlan pl;
+  int rc = bns_session(h, "bgm_bnn_evaluate", s, pl);
+  if (rc) return rc;
+  if (!v || !z || n < 2 || n > 0x7FFFFFFFLL) { bgm_set_error("bgm_bnn_evaluate: bad argument"); return BGM_E_INVALID; }
+  const bool recon = sums != nullptr;
+  if (recon && (!x || !y)) { bgm_set_error("bgm_bnn_evaluate: x_dev, y_dev required"); return BGM_E_INVALID; }
+  hipStream_t stream = (hipStream_t)stream_;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  const int binary = s->cfg.binary_treatment;
+  const int nd = dose_sums ? n_doses : (ite ? 2 : 0);
+  if (dose_sums && (!x_values || n_doses < 1)) { bgm_set_error("bgm_bnn_evaluate: dose grid missing"); return BGM_E_INVALID; }
+  BnsBuf b;
+  rc = bns_buffers(h, s, pl, n, 1, pl.set_all + (long long)nd * pl.set_f, b, stream);
+  if (rc) return rc;
+  rc = bns_set_lds(bns_eval_kernel, pl.lds_bytes);
+  if (rc) return rc;
+  rc = bns_set_lds(bns_effects_kernel, pl.lds_bytes);
+  if (rc) return rc;
+  const int ids[4] = {BNN_G, BNN_H, BNN_F, BNN_E};
+  bns_noise(pl, b, ids, 4, 1, 1, pl.set_all, seed, stream_id, 0, 0, stream);
+  BnsEvalArgs ev{};
+  for (int k = 0; k < 4; ++k) ev.net[k] = pl.net[k];
+  ev.theta = s->theta_dev; ev.lf = b.lf; ev.dw = b.dw; ev.stats = b.stats; ev.xstats = b.xstats; ev.vstats = b.vstats;
+  ev.x = x; ev.y = y; ev.v = v; ev.z = z; ev.n = n; ev.q = s->q; ev.p = s->p;
+  ev.z0 = s->cfg.z_dims[0]; ev.z1 = s->cfg.z_dims[1]; ev.z2 = s->cfg.z_dims[2]; ev.binary = binary;
+  ev.k0 = (uint32_t)seed; ev.k1 = (uint32_t)(seed >> 32); ev.stream = stream_id; ev.sums = sums;
+  const int wgs = (int)((n + BNS_ROWS - 1) / BNS_ROWS);
+  if (encode) {
+    hipLaunchKernelGGL(bns_colstats_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 256), s->p), dim3(256), 0, stream, v, (long long)n,
+                       s->p, b.vstats);
+    ev.mode = 0;
+    hipLaunchKernelGGL(bns_eval_kernel, dim3(wgs), dim3(BNS_THREADS), pl.lds_bytes, stream, ev);
+  }
+  if (recon || nd) {
+    // statistics of z (slot 1) and of x
+    BnsPropArgs pa{};
+    pa.z = z; pa.zprop = b.zprop; pa.n = n; pa.row_base = 0; pa.q = s->q; pa.bs = (int)n; pa.wg_per_block = (int)((n + 255) / 256);
+    pa.q_sd = 0.0f; pa.k0 = ev.k0; pa.k1 = ev.k1; pa.stats = b.stats; pa.n_blocks = 1; pa.par = 0; pa.x = x; pa.xstats = x ? b.xstats : nullptr;
+    hipLaunchKernelGGL(bns_propose_kernel, dim3(pa.wg_per_block), dim3(256), 0, stream, pa);
+  }
+  if (recon) {
+    BGM_HIP_CHECK(hipMemsetAsync(sums, 0, 3 * sizeof(double), stream));
+    ev.mode = 1;
+    hipLaunchKernelGGL(bns_eval_kernel, dim3(wgs), dim3(BNS_THREADS), pl.lds_bytes, stream, ev);
+  }
+  if (nd) {
+    float *dw_eff = b.dw + pl.set_all;
+    BnsEffArgs ea{};
+    ea.f = pl.net[BNN_F]; ea.f.dbase = 0;
+    if (!dose_sums) {
+      static const float pair_host[2] = {1.0f, 0.0f};
+      BGM_HIP_CHECK(hipMemcpyAsync(b.pair, pair_host, sizeof(pair_host), hipMemcpyHostToDevice, stream));
+    } else {
+      BGM_HIP_CHECK(hipMemsetAsync(dose_sums, 0, sizeof(double) * nd, stream));
+    }
+    BnsNoiseArgs na{};
+    na.net[0] = ea.f; na.n_nets = 1; na.n_calls = nd; na.sf = b.sf; na.dw = dw_eff; na.set_floats = pl.set_f;
+    na.k0 = ev.k0; na.k1 = ev.k1; na.stream0 = stream_id + 1u; na.stream_stride = 1u; na.block0 = 0;
+    hipLaunchKernelGGL(bns_noise_kernel, dim3(2, nd), dim3(256), 0, stream, na);
+    ea.theta = s->theta_dev; ea.lf = b.lf; ea.dw = dw_eff; ea.set_floats = pl.set_f; ea.stats = b.stats;
+    ea.z = z; ea.n = n; ea.row_base = 0; ea.q = s->q; ea.z0 = ev.z0; ea.z1 = ev.z1; ea.bs = (int)n; ea.wg_per_block = wgs; ea.block0 = 0;
+    ea.n_doses = nd; ea.xvals = dose_sums ? x_values : b.pair; ea.k0 = ev.k0; ea.k1 = ev.k1; ea.stream0 = stream_id + 1u;
+    ea.sample_y = 0; ea.sum_out = dose_sums; ea.sum_stride = 1; ea.ite_out = dose_sums ? nullptr : ite; ea.ite_stride = 1;
+    hipLaunchKernelGGL(bns_effects_kernel, dim3(wgs), dim3(BNS_THREADS), pl.lds_bytes, stream, ea);
   }
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;

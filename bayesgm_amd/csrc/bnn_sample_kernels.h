@@ -500,3 +500,202 @@ static __global__ __launch_bounds__(BNS_THREADS) void bns_mh_kernel(BnsMhArgs a)
     if (c.lane == 0 && nacc) atomicAdd(a.acc_count, nacc);
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// causal effects: f-net at counterfactual treatments on one state per row
+//   infer_from_latent_posterior, base.py:671-763 (one kept draw per launch) and the dose loops of evaluate, :553-568.
+// The treatment column is constant over the batch, so its batch-normalised value is 0 * gamma + beta whatever the dose
+// (mean = dose, variance = 0): this is what the reference computes with use_bnn, and what is computed here.
+// ---------------------------------------------------------------------------------------------
+struct BnsEffArgs {
+  BnsNet f;                            // dbase = 0: sets hold the outcome net only
+  const float *theta, *lf;             // lf: packed loc of all nets (f.fbase applies)
+  const float *dw;                     // [n_blocks * n_doses][set_floats]
+  long long set_floats;
+  const double *stats;                 // [n_blocks][2][2][64]; slot 1 = statistics of z
+  const float *z;                      // [n x q]
+  long long n, row_base;
+  int q, z0, z1, bs, wg_per_block, block0, n_doses;
+  const float *xvals;                  // [n_doses]
+  uint32_t k0, k1, stream0;            // dose k uses noise stream stream0 + k
+  int sample_y;                        // 1: y ~ N(mu, s2) with outcome noise (row, it_noise, k >> 2, TAG_YNOISE)[k & 3]
+  uint32_t it_noise;
+  double *sum_out; long long sum_stride;   // dose sums over rows: sum_out[k * sum_stride] += ...   (may be NULL)
+  float *ite_out; long long ite_stride;    // n_doses == 2: ite_out[row * ite_stride] = y(x_0) - y(x_1)  (may be NULL)
+};
+static __global__ __launch_bounds__(BNS_THREADS) void bns_effects_kernel(BnsEffArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float bns_lds[];
+  BnsCtx c;
+  c.tid = threadIdx.x; c.wave = c.tid >> 6; c.lane = c.tid & 63; c.j = c.lane & 15; c.g = c.lane >> 4;
+  c.bn = bns_lds;
+  c.sg = (uint32_t *)(bns_lds + 2 * BNS_MAXK);
+  c.stage = bns_lds + 2 * BNS_MAXK + BNS_WAVES * BNS_R * 16 * BNS_SW;
+  const int blk = blockIdx.x / a.wg_per_block, wib = blockIdx.x - blk * a.wg_per_block;
+  const int rib0 = wib * BNS_ROWS;
+  const long long blk_lo = (long long)blk * a.bs;
+  const long long blk_n = min((long long)a.bs, a.n - blk_lo);
+  long long row[BNS_R];
+  bool valid[BNS_R];
+#pragma unroll
+  for (int rt = 0; rt < BNS_R; ++rt) {
+    const long long r = rib0 + ((c.wave * BNS_R + rt) << 4) + c.j;
+    valid[rt] = r < blk_n;
+    row[rt] = blk_lo + (valid[rt] ? r : blk_n - 1);
+  }
+  const uint32_t k1 = a.k1 + (uint32_t)(a.block0 + blk);
+  const double cnt = (double)blk_n;
+  const double *st = a.stats + ((long long)blk * 2 + 1) * 128;
+  const int q = a.q, zz = a.z0 + a.z1, g = c.g;
+  float y0[BNS_R];
+  f32x4 nz[BNS_R];
+  for (int k = 0; k < a.n_doses; ++k) {
+    const float xv = a.xvals[k];
+    if (a.sample_y && (k & 3) == 0) {
+#pragma unroll
+      for (int rt = 0; rt < BNS_R; ++rt)
+        nz[rt] = box_muller4(philox4x32_10((uint32_t)(a.row_base + row[rt]), a.it_noise, (uint32_t)(k >> 2), TAG_YNOISE, a.k0, a.k1));
+    }
+    float mu[BNS_R], raw[BNS_R];
+#pragma unroll
+    for (int rt = 0; rt < BNS_R; ++rt) { mu[rt] = 0.0f; raw[rt] = 0.0f; }
+    bns_forward(c, a.f, a.theta, a.lf + a.f.fbase, a.dw + ((long long)blk * a.n_doses + k) * a.set_floats, a.k0, k1, a.stream0 + (uint32_t)k,
+                rib0,
+                [&](int u, float &m, float &v) { if (u < zz) bns_stat(st, u, cnt, m, v); else { m = xv; v = 0.0f; } },
+                [&](int rt, int u) { return u < zz ? a.z[row[rt] * q + u] : (u == zz ? xv : 0.0f); },
+                [&](int rt, int mt, const f32x4 &y) { if (mt == 0 && g == 0) { mu[rt] += y[0]; raw[rt] += y[1]; } });
+    float tot = 0.0f;
+#pragma unroll
+    for (int rt = 0; rt < BNS_R; ++rt) {
+      float yk = sum_over_g(mu[rt]);
+      if (a.sample_y) {
+        const float s2 = softplus_acc(sum_over_g(raw[rt])) + BGM_EPS;
+        const int e = k & 3;
+        yk = fmaf(sqrtf(s2), e == 0 ? nz[rt][0] : e == 1 ? nz[rt][1] : e == 2 ? nz[rt][2] : nz[rt][3], yk);
+      }
+      if (valid[rt] && g == 0) tot += yk;
+      if (a.ite_out) {
+        if (k == 0) y0[rt] = yk;
+        else if (k == 1 && valid[rt] && g == 0) a.ite_out[row[rt] * a.ite_stride] = y0[rt] - yk;
+      }
+    }
+    if (a.sum_out) {
+      for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+      if (c.lane == 0) atomicAdd(&a.sum_out[(long long)k * a.sum_stride], (double)tot);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// evaluate (base.py:534-570): the whole panel is ONE batch
+// ---------------------------------------------------------------------------------------------
+// column sums / sums of squares of an [n x d] matrix into doubles st[0..d), st[BNS_MAXK..BNS_MAXK + d)
+static __global__ __launch_bounds__(256) void bns_colstats_kernel(const float *m, long long n, int d, double *st) {
+  __shared__ double red[4][2];
+  for (int col = blockIdx.y; col < d; col += gridDim.y) {
+    double s = 0.0, s2 = 0.0;
+    for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < n; r += (long long)gridDim.x * 256) {
+      const double x = (double)m[r * d + col];
+      s += x; s2 += x * x;
+    }
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); s2 += __shfl_xor(s2, off); }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = s; red[threadIdx.x >> 6][1] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      atomicAdd(&st[col], red[0][0] + red[1][0] + red[2][0] + red[3][0]);
+      atomicAdd(&st[BNS_MAXK + col], red[0][1] + red[1][1] + red[2][1] + red[3][1]);
+    }
+  }
+}
+
+struct BnsEvalArgs {
+  BnsNet net[4];
+  const float *theta, *lf, *dw;        // one perturbation set [g | h | f | e]
+  const double *stats;                 // statistics of z: [1 block][2][2][64], slot 1
+  const double *xstats, *vstats;       // [2]; [2][BNS_MAXK]
+  const float *x, *y, *v;
+  float *z;                            // mode 0: written (e(v)); mode 1: read
+  long long n;
+  int q, p, z0, z1, z2, binary, mode;  // mode 0: z = e(v);  mode 1: reconstruction errors of g, h, f
+  uint32_t k0, k1, stream;
+  double *sums;                        // mode 1: [sum (v - v^)^2, sum (x - x^)^2, sum (y - y^)^2]
+};
+static __global__ __launch_bounds__(BNS_THREADS) void bns_eval_kernel(BnsEvalArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float bns_lds[];
+  BnsCtx c;
+  c.tid = threadIdx.x; c.wave = c.tid >> 6; c.lane = c.tid & 63; c.j = c.lane & 15; c.g = c.lane >> 4;
+  c.bn = bns_lds;
+  c.sg = (uint32_t *)(bns_lds + 2 * BNS_MAXK);
+  c.stage = bns_lds + 2 * BNS_MAXK + BNS_WAVES * BNS_R * 16 * BNS_SW;
+  const int rib0 = blockIdx.x * BNS_ROWS;
+  long long row[BNS_R];
+  bool valid[BNS_R];
+#pragma unroll
+  for (int rt = 0; rt < BNS_R; ++rt) {
+    const long long r = (long long)rib0 + ((c.wave * BNS_R + rt) << 4) + c.j;
+    valid[rt] = r < a.n;
+    row[rt] = valid[rt] ? r : a.n - 1;
+  }
+  const double cnt = (double)a.n;
+  const int q = a.q, p = a.p, z0 = a.z0, z1 = a.z1, g = c.g;
+  if (a.mode == 0) {
+    bns_forward(c, a.net[BNN_E], a.theta, a.lf + a.net[BNN_E].fbase, a.dw + a.net[BNN_E].dbase, a.k0, a.k1, a.stream, rib0,
+                [&](int u, float &m, float &v) {
+                  const double mm = a.vstats[u] / cnt;
+                  m = (float)mm; v = (float)fmax(a.vstats[BNS_MAXK + u] / cnt - mm * mm, 0.0);
+                },
+                [&](int rt, int u) { return u < p ? a.v[row[rt] * p + u] : 0.0f; },
+                [&](int rt, int mt, const f32x4 &y) {
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) {
+                    const int u = 16 * mt + 4 * g + r;
+                    if (u < q && valid[rt]) a.z[row[rt] * q + u] = y[r];
+                  }
+                });
+    return;
+  }
+  const double *st = a.stats + 128;
+  float ev[BNS_R], mu[BNS_R];
+#pragma unroll
+  for (int rt = 0; rt < BNS_R; ++rt) { ev[rt] = 0.0f; mu[rt] = 0.0f; }
+  bns_forward(c, a.net[BNN_G], a.theta, a.lf + a.net[BNN_G].fbase, a.dw + a.net[BNN_G].dbase, a.k0, a.k1, a.stream, rib0,
+              [&](int u, float &m, float &v) { bns_stat(st, u, cnt, m, v); },
+              [&](int rt, int u) { return u < q ? a.z[row[rt] * q + u] : 0.0f; },
+              [&](int rt, int mt, const f32x4 &y) {
+                const float *vr = a.v + row[rt] * p;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const int u = 16 * mt + 4 * g + r;
+                  if (u < p) { const float d = vr[u] - y[r]; ev[rt] = fmaf(d, d, ev[rt]); }
+                }
+              });
+  float sv = 0.0f, sx = 0.0f, sy = 0.0f;
+#pragma unroll
+  for (int rt = 0; rt < BNS_R; ++rt) { const float t = sum_over_g(ev[rt]); if (valid[rt] && g == 0) sv += t; }
+  bns_forward(c, a.net[BNN_H], a.theta, a.lf + a.net[BNN_H].fbase, a.dw + a.net[BNN_H].dbase, a.k0, a.k1, a.stream, rib0,
+              [&](int u, float &m, float &v) { bns_stat(st, u < z0 ? u : u + z1, cnt, m, v); },
+              [&](int rt, int u) { return u < a.net[BNN_H].K[0] ? a.z[row[rt] * q + (u < z0 ? u : u + z1)] : 0.0f; },
+              [&](int rt, int mt, const f32x4 &y) { if (mt == 0 && g == 0) mu[rt] += y[0]; });
+#pragma unroll
+  for (int rt = 0; rt < BNS_R; ++rt) {
+    float m_ = sum_over_g(mu[rt]);
+    if (a.binary) m_ = sigmoid_f(m_);
+    const float d = a.x[row[rt]] - m_;
+    if (valid[rt] && g == 0) sx += d * d;
+    mu[rt] = 0.0f;
+  }
+  bns_forward(c, a.net[BNN_F], a.theta, a.lf + a.net[BNN_F].fbase, a.dw + a.net[BNN_F].dbase, a.k0, a.k1, a.stream, rib0,
+              [&](int u, float &m, float &v) {
+                if (u < z0 + z1) bns_stat(st, u, cnt, m, v);
+                else { const double mm = a.xstats[0] / cnt; m = (float)mm; v = (float)fmax(a.xstats[1] / cnt - mm * mm, 0.0); }
+              },
+              [&](int rt, int u) { return u < z0 + z1 ? a.z[row[rt] * q + u] : (u == z0 + z1 ? a.x[row[rt]] : 0.0f); },
+              [&](int rt, int mt, const f32x4 &y) { if (mt == 0 && g == 0) mu[rt] += y[0]; });
+#pragma unroll
+  for (int rt = 0; rt < BNS_R; ++rt) {
+    const float d = a.y[row[rt]] - sum_over_g(mu[rt]);
+    if (valid[rt] && g == 0) sy += d * d;
+  }
+  for (int off = 32; off > 0; off >>= 1) { sv += __shfl_xor(sv, off); sx += __shfl_xor(sx, off); sy += __shfl_xor(sy, off); }
+  if (c.lane == 0) { atomicAdd(&a.sums[0], (double)sv); atomicAdd(&a.sums[1], (double)sx); atomicAdd(&a.sums[2], (double)sy); }
+}

@@ -475,6 +475,15 @@ typedef struct {
  * g/h/f forward of both states + accept).  Noise streams: 2 it (proposal), 2 it + 1 (current state);
  * effects of kept draw d at dose k: stream 0x40000000 + d * n_doses + k (ITE: k = 0 for x = 1, 1 for x = 0). */
 int bgm_bnn_mh_run(bgm_handle *h, const bgm_bnn_mh_args *args, void *stream);
+/* replaces: evaluate with use_bnn, base.py:534-570 (the whole panel of n rows is ONE batch), and the Z initialisation
+ * data_z = e_net(data_v) of fit, base.py:479.  encode = 1: z_dev [n x q] is WRITTEN with e(v) first (noise stream
+ * stream_id); otherwise it is read.  sums_dev (optional, fp64 [3]): sums over rows of (v - v^)^2 (all p columns),
+ * (x - x^)^2, (y - y^)^2 from one call of g, h, f (stream stream_id).  dose_sums_dev (continuous, fp64 [n_doses]): sums
+ * over rows of mu_y at the doses x_values_dev (stream stream_id + 1 + k).  ite_dev (binary, [n]): mu_y(x = 1) - mu_y(x = 0)
+ * (streams stream_id + 1, + 2).  Any of the three outputs may be NULL. */
+int bgm_bnn_evaluate(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev, float *z_dev, int32_t encode,
+                     int64_t n, const float *x_values_dev, int32_t n_doses, uint64_t seed, uint32_t stream_id,
+                     double *sums_dev, double *dose_sums_dev, float *ite_dev, void *stream);
 
 /* Debug: throughput of the hand-scheduled 64x4-tile MFMA block alone (mode 1: fragments streamed from LDS; mode 0:
  * register operands only) with `waves_per_cu` waves on every CU. */

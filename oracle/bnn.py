@@ -383,3 +383,53 @@ def mh_iteration(m, x, y, v, z, it, q_sd, seed, block_rows, block0=0, row_base=0
     out = z.copy()
     out[acc] = prop[acc]
     return out, acc, lpp, lpc
+
+
+def effects_draw(m, z, xvals, d, n_keep_iter, sample_y, seed, block_rows, block0=0, row_base=0):
+    """infer_from_latent_posterior (:671-763) for ONE kept draw z [n, q] (draw index d, kept by MH iteration
+    n_keep_iter = burn_in + d): f-net at each treatment value of xvals on every block (own statistics, noise stream
+    0x40000000 + d * len(xvals) + k).  Returns y [len(xvals), n] (mu, or mu + sqrt(s2) * outcome noise)."""
+    n = len(z)
+    t = z.dtype.type
+    z0d, z1d = m["z_dims"][0], m["z_dims"][1]
+    nd = len(xvals)
+    out = np.empty((nd, n), dtype=z.dtype)
+    nz = R.normals_seq(np.arange(row_base, row_base + n), n_keep_iter, nd, R.TAG_YNOISE, seed).astype(z.dtype)
+    dims = net_dims(m["f"])
+    for b, lo in enumerate(range(0, n, block_rows)):
+        hi = min(n, lo + block_rows)
+        key = block_key(seed, block0 + b)
+        for k, xv in enumerate(xvals):
+            noise = draw_noise(dims, hi - lo, key, 0x40000000 + d * nd + k, NET_ID["f"], dtype=z.dtype)
+            inp = np.concatenate([z[lo:hi, :z0d + z1d], np.full((hi - lo, 1), xv, dtype=z.dtype)], axis=1)
+            o, _ = forward(m["f"], inp, noise)
+            yk = o[:, 0]
+            if sample_y:
+                yk = yk + np.sqrt(softplus(o[:, 1]) + t(EPS)) * nz[lo:hi, k]
+            out[k, lo:hi] = yk
+    return out
+
+
+def evaluate(m, data, data_z=None, x_values=None, seed=0, stream=0):
+    """evaluate with use_bnn (:534-570); the panel is one batch.  Noise streams: `stream` for e, g, h, f; stream + 1 + k
+    for the k-th counterfactual call of f.  Returns (z, causal_pre, mse_x, mse_y, mse_v)."""
+    x, y, v = data
+    t = v.dtype.type
+    n = len(x)
+    key = block_key(seed, 0)
+    nz = lambda k, s: draw_noise(net_dims(m[k]), n, key, s, NET_ID[k], dtype=v.dtype)
+    if data_z is None:
+        data_z, _ = forward(m["e"], v, nz("e", stream))
+    fin, hin = _inputs(m, data_z, x)
+    v_pred = forward(m["g"], data_z, nz("g", stream))[0][:, :m["v_dim"]]
+    y_pred = forward(m["f"], fin, nz("f", stream))[0][:, 0]
+    x_pred = forward(m["h"], hin, nz("h", stream))[0][:, 0]
+    if m["binary_treatment"]:
+        x_pred = sigmoid(x_pred)
+    mse_v, mse_x, mse_y = ((v - v_pred) ** 2).mean(), ((x[:, 0] - x_pred) ** 2).mean(), ((y[:, 0] - y_pred) ** 2).mean()
+    z01 = fin[:, :-1]
+    vals = [1.0, 0.0] if m["binary_treatment"] else list(x_values)
+    mus = [forward(m["f"], np.concatenate([z01, np.full((n, 1), xv, dtype=v.dtype)], axis=1), nz("f", stream + 1 + k))[0][:, 0]
+           for k, xv in enumerate(vals)]
+    causal = (mus[0] - mus[1]) if m["binary_treatment"] else np.array([mu.mean() for mu in mus], dtype=v.dtype)
+    return data_z, causal, mse_x, mse_y, mse_v

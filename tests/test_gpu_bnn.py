@@ -178,3 +178,63 @@ def test_mh_iterations_match_oracle():
     assert np.abs(got[ok] - zo[ok]).max() < 1e-5
     assert abs(int(acc[0]) - n_acc) <= int(fragile.sum())
     eng.close()
+
+
+@pytest.mark.parametrize("binary", [False, True])
+def test_mh_effects_match_oracle(binary):
+    """Kept draws + causal effects of the sampler against the oracle evaluated on the kernel's own draws."""
+    m = _model(binary, p=50)
+    n, bs, burn, keep = 300, 128, 2, 3
+    z, x, y, v = _panel(m, n)
+    eng = _engine(m)
+    dev = eng.device
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    seed = (2 << 32) | 555
+    state = torch.zeros(n, z.shape[1], device=dev)
+    draws = torch.zeros(keep, n, z.shape[1], device=dev)
+    xs = np.array([0.0, 0.7, 1.5, 2.2, 3.0], np.float32)
+    adrf = torch.zeros(len(xs), keep, device=dev, dtype=torch.float64)
+    ite = torch.zeros(n, keep, device=dev)
+    eng.mh_run(T(x[:, 0]), T(y[:, 0]), T(v), state, bs, 0, burn + keep, burn, 0.4, seed, init=True, row_base=40, block0=1,
+               draws=draws, n_keep=keep, effect=2 if binary else 1, sample_y=True, x_values=None if binary else T(xs),
+               adrf_sum=None if binary else adrf, ite=ite if binary else None)
+    dr = draws.cpu().numpy()
+    init = OB.R.normals(np.arange(40, 40 + n), 0, z.shape[1], OB.R.TAG_INIT, seed)
+    assert np.abs(dr[-1] - state.cpu().numpy()).max() == 0.0
+    assert np.abs(dr[0] - init).max() < 10.0 and np.abs(dr[0] - dr[-1]).max() > 0.0
+    m64 = OB.cast_model(m, np.float64)
+    for d in range(keep):
+        ref = OB.effects_draw(m64, dr[d].astype(np.float64), [1.0, 0.0] if binary else xs.astype(np.float64), d, burn + d, True, seed,
+                              bs, block0=1, row_base=40)
+        if binary:
+            assert np.abs(ite[:, d].cpu().numpy() - (ref[0] - ref[1])).max() < 2e-3
+        else:
+            assert np.abs(adrf[:, d].cpu().numpy() / n - ref.mean(axis=1)).max() < 5e-4
+    eng.close()
+
+
+@pytest.mark.parametrize("binary,p", [(False, 200), (True, 37)])
+def test_evaluate_matches_oracle(binary, p):
+    m = _model(binary, p=p)
+    n = 700
+    z, x, y, v = _panel(m, n)
+    eng = _engine(m)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
+    xs = np.linspace(0.1, 2.5, 7).astype(np.float32)
+    seed, stream = 31337, 900
+    zt, sums, causal = eng.evaluate(T(x[:, 0]), T(y[:, 0]), T(v), None, x_values=xs, seed=seed, stream_id=stream)
+    m64 = OB.cast_model(m, np.float64)
+    zr, cr, mse_x, mse_y, mse_v = OB.evaluate(m64, (x.astype(np.float64), y.astype(np.float64), v.astype(np.float64)), None, xs, seed, stream)
+    assert np.abs(zt.cpu().numpy() - zr).max() < 2e-3 * max(1.0, np.abs(zr).max())
+    s = sums.cpu().numpy()
+    assert abs(s[0] / (n * p) - mse_v) < 1e-3 * mse_v and abs(s[1] / n - mse_x) < 2e-3 * mse_x and abs(s[2] / n - mse_y) < 2e-3 * mse_y
+    if binary:
+        assert np.abs(causal.cpu().numpy() - cr).max() < 2e-3
+    else:
+        assert np.abs(causal.cpu().numpy() / n - cr).max() < 5e-4
+    # with the latents given
+    _, sums2, _ = eng.evaluate(T(x[:, 0]), T(y[:, 0]), T(v), T(z), x_values=xs, seed=seed, stream_id=stream)
+    _, _, mx2, my2, mv2 = OB.evaluate(m64, (x.astype(np.float64), y.astype(np.float64), v.astype(np.float64)), z.astype(np.float64), xs, seed, stream)
+    s2 = sums2.cpu().numpy()
+    assert abs(s2[0] / (n * p) - mv2) < 1e-3 * mv2 and abs(s2[2] / n - my2) < 2e-3 * my2
+    eng.close()
