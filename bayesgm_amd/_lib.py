@@ -167,6 +167,13 @@ SYMBOLS = {
     "bgm_bnn_mh_run": (C.c_int, [C.c_void_p, C.POINTER(BnnMhArgs), C.c_void_p]),
     "bgm_bnn_evaluate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p,
                                    C.c_int32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bgm_bnn_egm_begin": (C.c_int, [C.c_void_p, C.POINTER(EgmConfig), C.c_void_p, C.c_int64, C.c_void_p]),
+    "bgm_bnn_egm_disc_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_uint64, C.c_uint32, C.c_int32,
+                                        C.c_void_p, C.c_void_p]),
+    "bgm_bnn_egm_gen_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
+                                       C.c_int32, C.c_void_p, C.c_void_p]),
+    "bgm_bnn_egm_read": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "bgm_bnn_egm_end": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bgm_bnn_end": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bgm_debug_group_probe": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     "bgm_causal_egm_begin": (C.c_int, [C.c_void_p, C.POINTER(EgmConfig), C.c_void_p, C.c_int64, C.c_void_p]),

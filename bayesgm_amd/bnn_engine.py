@@ -175,6 +175,37 @@ class BnnEngine(object):
                                              _ptr(sums), _ptr(dose), _ptr(ite), self._stream()), "bgm_bnn_evaluate")
         return z, sums, (ite if self.binary else dose)
 
+    # -- EGM warm start ------------------------------------------------------------------------------
+    def egm_begin(self, dz, batch_size, lr, use_z_rec):
+        """dz: discriminator dict {"W", "b", "gamma", "beta"} (lists per layer, oracle/egm.py structure)."""
+        from .engine import CausalEngine
+        theta = np.ascontiguousarray(CausalEngine.flatten_disc(dz), np.float32)
+        units = [int(w.shape[1]) for w in dz["W"][:-1]]
+        cfg = _lib.EgmConfig()
+        cfg.batch_size, cfg.lr, cfg.use_z_rec = int(batch_size), float(lr), int(use_z_rec)
+        cfg.n_hidden_dz = len(units)
+        for i, u in enumerate(units):
+            cfg.dz_units[i] = u
+        self.n_dz = theta.size
+        _lib.check(self.lib.bgm_bnn_egm_begin(self.h, C.byref(cfg), theta.ctypes.data_as(C.c_void_p), theta.size, self._stream()),
+                   "bgm_bnn_egm_begin")
+
+    def egm_disc_step(self, z, idx, v, eps, seed, stream_id, apply=True, out=None):
+        _lib.check(self.lib.bgm_bnn_egm_disc_step(self.h, _ptr(z), _ptr(idx), _ptr(v), float(eps), int(seed), int(stream_id) & 0xFFFFFFFF,
+                                                  int(apply), _ptr(out), self._stream()), "bgm_bnn_egm_disc_step")
+
+    def egm_gen_step(self, z, idx, v, x, y, seed, stream_id, apply=True, out=None):
+        _lib.check(self.lib.bgm_bnn_egm_gen_step(self.h, _ptr(z), _ptr(idx), _ptr(v), _ptr(x), _ptr(y), int(seed),
+                                                 int(stream_id) & 0xFFFFFFFF, int(apply), _ptr(out), self._stream()), "bgm_bnn_egm_gen_step")
+
+    def egm_read(self, what):
+        out = np.empty(self.n_dz, np.float32)
+        _lib.check(self.lib.bgm_bnn_egm_read(self.h, what, out.ctypes.data_as(C.c_void_p), out.size, self._stream()), "bgm_bnn_egm_read")
+        return out
+
+    def egm_end(self):
+        _lib.check(self.lib.bgm_bnn_egm_end(self.h, self._stream()), "bgm_bnn_egm_end")
+
     def end(self):
         _lib.check(self.lib.bgm_bnn_end(self.h, self._stream()), "bgm_bnn_end")
         self.open = False

@@ -14,6 +14,7 @@ void bgm_bnn_free_state(bgm_handle *h) {
   BnnState *s = bst(h);
   if (s->dev) hipFree(s->dev);
   bnn_free_sampler(s);
+  bgm_bnn_egm_free(s->egm);
   delete s;
   h->bnn_state = nullptr;
 }

@@ -1,0 +1,165 @@
+// bnn_egm_api.hip -- C ABI of the EGM warm start with Bayesian networks (a sub-session of bgm_bnn_begin).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "bgm_host.h"
+#include "bnn_egm_kernels.h"
+#include "bnn_state.h"
+
+static BnnState *bst(bgm_handle *h) { return static_cast<BnnState *>(h->bnn_state); }
+
+struct BnnEgmState {
+  bgm_egm_config cfg{};
+  BnnEgmArgs base{};
+  size_t n_dz = 0, ws_floats = 0;
+  int lds_bytes = 0;
+  long long t_g = 0, t_d = 0;
+  float *dev = nullptr;      // m | v (EGM Adam slots of the Bayesian nets) | theta_d | m_d | v_d | grad_d | ws
+};
+
+void bgm_bnn_egm_free(void *p) {
+  BnnEgmState *e = static_cast<BnnEgmState *>(p);
+  if (!e) return;
+  if (e->dev) hipFree(e->dev);
+  delete e;
+}
+
+extern "C" int bgm_bnn_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, const float *theta_dz_host, int64_t count, void *stream_) {
+  (void)stream_;
+  if (!h || !h->bnn_state) { bgm_set_error("bgm_bnn_egm_begin: no session (bgm_bnn_begin)"); return BGM_E_STATE; }
+  if (!cfg || !theta_dz_host) { bgm_set_error("bgm_bnn_egm_begin: NULL argument"); return BGM_E_INVALID; }
+  BnnState *s = bst(h);
+  if (cfg->batch_size < 2 || cfg->batch_size > s->cfg.max_batch) { bgm_set_error("bgm_bnn_egm_begin: batch_size outside [2, max_batch]"); return BGM_E_INVALID; }
+  if (cfg->n_hidden_dz < 1 || cfg->n_hidden_dz + 1 > EGM_MAX_LAYERS) { bgm_set_error("bgm_bnn_egm_begin: bad dz_units"); return BGM_E_INVALID; }
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  bgm_bnn_egm_free(s->egm); s->egm = nullptr;
+  BnnEgmState *e = new BnnEgmState();
+  s->egm = e;
+  e->cfg = *cfg;
+  BnnEgmArgs &a = e->base;
+  for (int k = 0; k < 4; ++k) a.net[k] = s->net[k];
+  EgmDisc &d = a.dz;
+  const int L = cfg->n_hidden_dz;
+  d.n_hidden = L;
+  d.dims[0] = s->q;
+  for (int l = 0; l < L; ++l) d.dims[l + 1] = cfg->dz_units[l];
+  d.dims[L + 1] = 1;
+  int o = 0;
+  for (int l = 0; l <= L; ++l) { d.w[l] = o; o += d.dims[l] * d.dims[l + 1]; }
+  for (int l = 0; l <= L; ++l) { d.b[l] = o; o += d.dims[l + 1]; }
+  for (int l = 0; l < L; ++l) { d.gamma[l] = o; o += d.dims[l + 1]; }
+  for (int l = 0; l < L; ++l) { d.beta[l] = o; o += d.dims[l + 1]; }
+  d.n_params = o;
+  egm_finish_disc(d);
+  e->n_dz = (size_t)o;
+  if ((int64_t)o != count) {
+    bgm_bnn_egm_free(e); s->egm = nullptr;
+    bgm_set_error("bgm_bnn_egm_begin: expected " + std::to_string(o) + " discriminator parameters, got " + std::to_string(count));
+    return BGM_E_INVALID;
+  }
+  const int B = cfg->batch_size;
+  int wmax = s->wmax, dmax = 0, dsum = 0, dall = 0;
+  for (int l = 0; l <= L; ++l) { dmax = std::max(dmax, d.dims[l]); dall += d.dims[l]; wmax = std::max(wmax, d.dims[l]); }
+  for (int l = 1; l <= L; ++l) dsum += d.dims[l];
+  a.dmax = dmax; a.wmax = wmax;
+  const size_t cache = ((size_t)(2 * B + 1) * dsum + B + 3) / 4 * 4;
+  const size_t gp = ((size_t)B * dall + (size_t)(5 * B + 1) * dsum + 3) / 4 * 4 + 3 * (size_t)B * dmax;
+  const size_t arena = cache + std::max(cache + 2 * (size_t)B * dmax, gp);
+  a.disc_lds = (64 + arena) * sizeof(float) <= 160 * 1024 ? 1 : 0;
+  e->lds_bytes = (int)((64 + (a.disc_lds ? arena : 0)) * sizeof(float));
+  a.n_gen = s->n_params; a.B = B; a.q = s->q; a.p = s->p;
+  a.z0 = s->cfg.z_dims[0]; a.z1 = s->cfg.z_dims[1]; a.z2 = s->cfg.z_dims[2];
+  a.binary = s->cfg.binary_treatment; a.use_z_rec = cfg->use_z_rec;
+  // workspace: nine Flipout call caches (g x 3, e x 2, f x 2, h x 2) + discriminator caches + scratch rows
+  auto cache_floats = [&](const BnnNet &n) {
+    return (size_t)B * n.dims[0] + n.dims[0] + 2 * (size_t)B * n.hoff[n.n_layers + 1] + 2 * (size_t)n.eoff[n.n_layers] + (size_t)B * n.swords + 64;
+  };
+  e->ws_floats = 3 * cache_floats(s->net[BNN_G]) + 2 * cache_floats(s->net[BNN_E]) + 2 * cache_floats(s->net[BNN_F]) +
+                 2 * cache_floats(s->net[BNN_H]) + (size_t)B * (4 * (size_t)s->p + 32 * (size_t)wmax + 256) + 4 * cache + e->n_dz + arena + 8192;
+  const size_t np = ((size_t)s->n_params + 63) & ~(size_t)63, nd = (e->n_dz + 63) & ~(size_t)63;
+  const size_t total = 2 * np + 4 * nd + e->ws_floats + 64;
+  BGM_HIP_CHECK(hipMalloc((void **)&e->dev, total * sizeof(float)));
+  BGM_HIP_CHECK(hipMemset(e->dev, 0, total * sizeof(float)));
+  a.theta = s->theta_dev; a.grad = s->grad_dev;
+  a.m = e->dev; a.v = e->dev + np;
+  a.theta_d = e->dev + 2 * np; a.m_d = a.theta_d + nd; a.v_d = a.m_d + nd; a.grad_d = a.v_d + nd;
+  a.ws = a.grad_d + nd;
+  BGM_HIP_CHECK(hipMemcpy(a.theta_d, theta_dz_host, e->n_dz * sizeof(float), hipMemcpyHostToDevice));
+  return BGM_OK;
+}
+
+static EgmAdam bnn_egm_adam(float lr, long long t) {
+  EgmAdam ad;
+  ad.b1 = BNN_ADAM_B1; ad.b2 = BNN_ADAM_B2; ad.eps = BNN_ADAM_EPS;
+  ad.lr_t = (float)((double)lr * std::sqrt(1.0 - std::pow((double)BNN_ADAM_B2, (double)t)) / (1.0 - std::pow((double)BNN_ADAM_B1, (double)t)));
+  return ad;
+}
+
+static int bnn_egm_need(bgm_handle *h, const char *who, BnnState *&s, BnnEgmState *&e) {
+  if (!h || !h->bnn_state || !bst(h)->egm) { bgm_set_error(std::string(who) + ": call bgm_bnn_egm_begin first"); return BGM_E_STATE; }
+  s = bst(h);
+  e = static_cast<BnnEgmState *>(s->egm);
+  return BGM_OK;
+}
+
+extern "C" int bgm_bnn_egm_disc_step(bgm_handle *h, const float *z_dev, const int32_t *idx_dev, const float *v_dev, float eps,
+                                     uint64_t seed, uint32_t stream_id, int32_t apply, float *out_dev, void *stream_) {
+  BnnState *s; BnnEgmState *e;
+  int rc = bnn_egm_need(h, "bgm_bnn_egm_disc_step", s, e);
+  if (rc) return rc;
+  if (!z_dev || !idx_dev || !v_dev) { bgm_set_error("bgm_bnn_egm_disc_step: NULL pointer"); return BGM_E_INVALID; }
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  BnnEgmArgs a = e->base;
+  a.z = z_dev; a.idx = idx_dev; a.v_ = v_dev; a.eps = eps; a.out = out_dev; a.apply = apply ? 1 : 0;
+  a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32); a.stream = stream_id;
+  if (apply) e->t_d += 1;
+  a.adam = bnn_egm_adam(e->cfg.lr, std::max<long long>(1, e->t_d));
+  auto k = bnn_egm_disc_step_kernel;
+  BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
+  hipLaunchKernelGGL(k, dim3(1), dim3(EGM_THREADS), e->lds_bytes, (hipStream_t)stream_, a);
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+extern "C" int bgm_bnn_egm_gen_step(bgm_handle *h, const float *z_dev, const int32_t *idx_dev, const float *v_dev, const float *x_dev,
+                                    const float *y_dev, uint64_t seed, uint32_t stream_id, int32_t apply, float *out_dev, void *stream_) {
+  BnnState *s; BnnEgmState *e;
+  int rc = bnn_egm_need(h, "bgm_bnn_egm_gen_step", s, e);
+  if (rc) return rc;
+  if (!z_dev || !idx_dev || !v_dev || !x_dev || !y_dev) { bgm_set_error("bgm_bnn_egm_gen_step: NULL pointer"); return BGM_E_INVALID; }
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  BnnEgmArgs a = e->base;
+  a.z = z_dev; a.idx = idx_dev; a.v_ = v_dev; a.x_ = x_dev; a.y_ = y_dev; a.out = out_dev; a.apply = apply ? 1 : 0;
+  a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32); a.stream = stream_id;
+  if (apply) { e->t_g += 1; s->packed_valid = false; }
+  a.adam = bnn_egm_adam(e->cfg.lr, std::max<long long>(1, e->t_g));
+  auto k = bnn_egm_gen_step_kernel;
+  const int lds = 64 * (int)sizeof(float);
+  hipLaunchKernelGGL(k, dim3(1), dim3(EGM_THREADS), lds, (hipStream_t)stream_, a);
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+extern "C" int bgm_bnn_egm_read(bgm_handle *h, int32_t what, float *host, int64_t count, void *stream_) {
+  BnnState *s; BnnEgmState *e;
+  int rc = bnn_egm_need(h, "bgm_bnn_egm_read", s, e);
+  if (rc) return rc;
+  const float *src = what == 1 ? e->base.theta_d : what == 3 ? e->base.grad_d : nullptr;
+  if (!src || !host || (size_t)count != e->n_dz) { bgm_set_error("bgm_bnn_egm_read: what must be 1 (parameters) or 3 (gradient) of the discriminator"); return BGM_E_INVALID; }
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  BGM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_));
+  BGM_HIP_CHECK(hipMemcpy(host, src, e->n_dz * sizeof(float), hipMemcpyDeviceToHost));
+  return BGM_OK;
+}
+
+extern "C" int bgm_bnn_egm_end(bgm_handle *h, void *stream_) {
+  if (!h || !h->bnn_state) return BGM_OK;
+  BnnState *s = bst(h);
+  if (!s->egm) return BGM_OK;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  BGM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_));
+  bgm_bnn_egm_free(s->egm);
+  s->egm = nullptr;
+  return BGM_OK;
+}

@@ -1,0 +1,205 @@
+// bnn_egm_kernels.h -- EGM warm start of CausalBGM with Bayesian networks (use_bnn=True) on gfx950.
+//
+// replaces (src/bayesgm/models/causalbgm/base.py, nets = BayesianFullyConnectedNet of networks/bnn.py:4-38):
+//   train_disc_step :305-330  -> bnn_egm_disc_step_kernel  (the encoder call z_ = e_net(v) is a noisy Flipout call)
+//   train_gen_step  :332-377  -> bnn_egm_gen_step_kernel   (nine Flipout calls: g x 3, e x 2, f x 2, h x 2)
+// The latent discriminator dz_net stays the deterministic Discriminator of networks/base.py:338-385; its forward,
+// backward and gradient penalty are the routines of egm_kernels.h.  Gradients follow oracle/bnn.py
+// (egm_disc_step_grads, egm_gen_step_grads).  One launch of one 512-thread workgroup per step.
+#pragma once
+#include "bnn_kernels.h"
+#include "egm_kernels.h"
+
+static_assert(BNN_THREADS == EGM_THREADS, "the Flipout and discriminator routines share one workgroup");
+
+struct BnnEgmArgs {
+  BnnNet net[4];                         // g, e, f, h
+  EgmDisc dz;
+  float *theta, *m, *v, *grad;           // Bayesian nets [g | e | f | h], Adam slots of g_pre_optimizer, gradient
+  float *theta_d, *m_d, *v_d, *grad_d;   // discriminator, Adam slots of d_pre_optimizer
+  int n_gen, B, q, p, wmax, dmax, z0, z1, z2, binary, use_z_rec;
+  const float *z;                        // [B x q] prior sample of the step
+  const int *idx;                        // [B] panel rows
+  const float *v_, *x_, *y_;             // panel
+  float eps;                             // gradient-penalty interpolation coefficient
+  uint32_t k0, k1, stream;               // noise key; call c of the step uses stream + c (oracle/bnn.py EGM_CALLS)
+  EgmAdam adam;
+  float *ws, *out;
+  int apply, disc_lds;
+};
+
+static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_disc_step_kernel(BnnEgmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float egm_lds[];
+  EgmCtx c{(int)threadIdx.x, egm_lds};
+  BnnCtx cb{(int)threadIdx.x, egm_lds};
+  const int B = a.B, q = a.q, p = a.p;
+  float *wp = a.ws;
+  auto take = [&](int n) { float *r = wp; wp += (n + 3) & ~3; return r; };
+  float *vb = take(B * p), *zhat = take(B * q);
+  for (int k = c.tid; k < B * p; k += EGM_THREADS) { const int b = k / p; vb[k] = a.v_[(long long)a.idx[b] * p + (k - b * p)]; }
+  __syncthreads();
+  BnnCache ke;
+  bnn_cache(a.net[BNN_E], B, wp, ke, vb);
+  float *z_ = bnn_fwd(cb, a.theta, a.net[BNN_E], ke, B, a.k0, a.k1, a.stream);     // noisy encoder call (fixed in this step)
+  for (int k = c.tid; k < B * q; k += EGM_THREADS) zhat[k] = a.z[k] * a.eps + z_[k] * (1.0f - a.eps);
+  __syncthreads();
+  float *arena = a.disc_lds ? (egm_lds + 64) : wp;
+  float *ap_ = arena;
+  EgmDiscCache kf, kr, kh;
+  egm_disc_cache(a.dz, B, ap_, kf, z_);
+  float *overlay = ap_;
+  egm_disc_cache(a.dz, B, ap_, kr, const_cast<float *>(a.z));
+  float *da = ap_; ap_ += B * a.dmax;
+  float *du = ap_; ap_ += B * a.dmax;
+  egm_disc_fwd(c, a.theta_d, a.dz, kf, B);
+  egm_disc_fwd(c, a.theta_d, a.dz, kr, B);
+  float sf = 0.0f, sr = 0.0f;
+  {
+    const float *of_ = egm_dk_out(a.dz, kf, B), *or_ = egm_dk_out(a.dz, kr, B);
+    for (int b = c.tid; b < B; b += EGM_THREADS) { sf += of_[b]; sr += or_[b]; }
+  }
+  sf = egm_block_sum(c, sf); sr = egm_block_sum(c, sr);
+  const float dz_loss = (-sr + sf) / (float)B;
+  egm_disc_bwd(c, a.theta_d, a.grad_d, a.dz, kf, true, 1.0f / (float)B, nullptr, da, du, nullptr, B, false, 1.0f);
+  egm_disc_bwd(c, a.theta_d, a.grad_d, a.dz, kr, true, -1.0f / (float)B, nullptr, da, du, nullptr, B, true, 1.0f);
+  kh.in = zhat; kh.base = kf.base;
+  egm_disc_fwd(c, a.theta_d, a.dz, kh, B);
+  const float gp = egm_disc_gp(c, a.theta_d, a.grad_d, a.dz, kh, overlay, B, 10.0f, a.dmax);
+  __syncthreads();
+  if (a.apply) egm_adam(c, a.theta_d, a.m_d, a.v_d, a.grad_d, a.dz.n_params, a.adam);
+  if (c.tid == 0 && a.out) { a.out[0] = dz_loss; a.out[1] = dz_loss + 10.0f * gp; }
+}
+
+static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_gen_step_kernel(BnnEgmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float egm_lds[];
+  EgmCtx c{(int)threadIdx.x, egm_lds};
+  BnnCtx cb{(int)threadIdx.x, egm_lds};
+  const int B = a.B, q = a.q, p = a.p, z0 = a.z0, z1 = a.z1, z2 = a.z2;
+  const float invB = 1.0f / (float)B;
+  float *wp = a.ws;
+  auto take = [&](int n) { float *r = wp; wp += (n + 3) & ~3; return r; };
+  float *vb = take(B * p), *xb = take(B), *yb = take(B);
+  for (int k = c.tid; k < B * p; k += EGM_THREADS) { const int b = k / p; vb[k] = a.v_[(long long)a.idx[b] * p + (k - b * p)]; }
+  for (int b = c.tid; b < B; b += EGM_THREADS) { xb[b] = a.x_[a.idx[b]]; yb[b] = a.y_[a.idx[b]]; }
+  __syncthreads();
+  const BnnNet &G = a.net[BNN_G], &E = a.net[BNN_E], &F = a.net[BNN_F], &H = a.net[BNN_H];
+  const int wg = p + 1, nf = F.dims[0], nh = H.dims[0], of = F.dims[F.n_layers], oh = H.dims[H.n_layers];
+  // ---- forward: nine calls, noise streams stream + 0..8 in the order of oracle/bnn.py EGM_CALLS
+  BnnCache g1, g1s, e1, e2, g2, cf, cfs, ch, chs;
+  bnn_cache(G, B, wp, g1, a.z);
+  const float *gz = bnn_fwd(cb, a.theta, G, g1, B, a.k0, a.k1, a.stream + 0u);      // g(z): v_ = [:, :p]
+  bnn_cache(G, B, wp, g1s, a.z);
+  const float *gzs = bnn_fwd(cb, a.theta, G, g1s, B, a.k0, a.k1, a.stream + 1u);    // g(z) again: variance head penalty
+  bnn_cache(E, B, wp, e1, vb);
+  float *z_ = bnn_fwd(cb, a.theta, E, e1, B, a.k0, a.k1, a.stream + 2u);            // z_ = e(v)
+  float *v_ = take(B * p);
+  for (int k = c.tid; k < B * p; k += EGM_THREADS) { const int b = k / p; v_[k] = gz[b * wg + (k - b * p)]; }
+  __syncthreads();
+  bnn_cache(E, B, wp, e2, v_);
+  const float *z__ = bnn_fwd(cb, a.theta, E, e2, B, a.k0, a.k1, a.stream + 3u);     // z__ = e(v_)
+  bnn_cache(G, B, wp, g2, z_);
+  const float *gv = bnn_fwd(cb, a.theta, G, g2, B, a.k0, a.k1, a.stream + 4u);      // g(z_): v__ = [:, :p]
+  EgmDiscCache kd;
+  egm_disc_cache(a.dz, B, wp, kd, z_);
+  egm_disc_fwd(c, a.theta_d, a.dz, kd, B);
+  float *fin = take(B * nf), *hin = take(B * nh);
+  for (int k = c.tid; k < B * nf; k += EGM_THREADS) {
+    const int b = k / nf, i = k - b * nf;
+    fin[k] = (i < z0 + z1) ? z_[b * q + i] : xb[b];
+  }
+  for (int k = c.tid; k < B * nh; k += EGM_THREADS) {
+    const int b = k / nh, i = k - b * nh;
+    hin[k] = (i < z0) ? z_[b * q + i] : z_[b * q + z1 + i];
+  }
+  __syncthreads();
+  bnn_cache(F, B, wp, cf, fin);
+  const float *fo = bnn_fwd(cb, a.theta, F, cf, B, a.k0, a.k1, a.stream + 5u);
+  bnn_cache(F, B, wp, cfs, fin);
+  const float *fs = bnn_fwd(cb, a.theta, F, cfs, B, a.k0, a.k1, a.stream + 6u);
+  bnn_cache(H, B, wp, ch, hin);
+  const float *ho = bnn_fwd(cb, a.theta, H, ch, B, a.k0, a.k1, a.stream + 7u);
+  bnn_cache(H, B, wp, chs, hin);
+  const float *hs = bnn_fwd(cb, a.theta, H, chs, B, a.k0, a.k1, a.stream + 8u);
+  // ---- losses
+  float l_v = 0.0f, l_z = 0.0f, l_x = 0.0f, l_y = 0.0f, s_g = 0.0f, s_f = 0.0f, s_h = 0.0f, adv = 0.0f;
+  for (int k = c.tid; k < B * p; k += EGM_THREADS) { const int b = k / p; const float t = vb[k] - gv[b * wg + (k - b * p)]; l_v = fmaf(t, t, l_v); }
+  for (int k = c.tid; k < B * q; k += EGM_THREADS) { const float t = a.z[k] - z__[k]; l_z = fmaf(t, t, l_z); }
+  const float *dout_ = egm_dk_out(a.dz, kd, B);
+  for (int b = c.tid; b < B; b += EGM_THREADS) {
+    const float xl = ho[b * oh], yl = fo[b * of];
+    if (a.binary) l_x += fmaxf(xl, 0.0f) - xl * xb[b] + log1pf(expf(-fabsf(xl)));
+    else l_x += (xl - xb[b]) * (xl - xb[b]);
+    l_y += (yl - yb[b]) * (yl - yb[b]);
+    s_g += gzs[b * wg + p] * gzs[b * wg + p];
+    s_f += fs[b * of + of - 1] * fs[b * of + of - 1];
+    s_h += hs[b * oh + oh - 1] * hs[b * oh + oh - 1];
+    adv -= dout_[b];
+  }
+  l_v = egm_block_sum(c, l_v) / (float)(B * p);
+  l_z = egm_block_sum(c, l_z) / (float)(B * q);
+  l_x = egm_block_sum(c, l_x) * invB;
+  l_y = egm_block_sum(c, l_y) * invB;
+  const float sig = (egm_block_sum(c, s_g) + egm_block_sum(c, s_f) + egm_block_sum(c, s_h)) * invB;
+  adv = egm_block_sum(c, adv) * invB;
+  const float zrec = a.use_z_rec ? 1.0f : 0.0f;
+  // ---- backward
+  const int wmax = a.wmax;
+  float *d = take(B * wmax), *ds = take(B * wmax), *t0 = take(B * wmax), *t1 = take(B * wmax);
+  float *dv_ = take(B * wmax), *dzsum = take(B * wmax), *dtmp = take(B * wmax), *da = take(B * wmax), *du = take(B * wmax);
+  float *dfin = take(B * wmax), *dfin2 = take(B * wmax), *dhin = take(B * wmax), *dhin2 = take(B * wmax);
+  // z__ branch: e (call 2, input v_) -> g (call 1)
+  for (int k = c.tid; k < B * q; k += EGM_THREADS) d[k] = zrec * (-2.0f / (float)(B * q)) * (a.z[k] - z__[k]);
+  __syncthreads();
+  bnn_bwd(cb, a.theta, a.grad, E, e2, d, ds, t0, t1, dv_, B, true, false);
+  for (int k = c.tid; k < B * wg; k += EGM_THREADS) { const int b = k / wg, i = k - b * wg; d[k] = (i < p) ? dv_[b * p + i] : 0.0f; }
+  __syncthreads();
+  bnn_bwd(cb, a.theta, a.grad, G, g1, d, ds, t0, t1, nullptr, B, true, false);
+  // variance-head penalty of the second g(z) call
+  for (int k = c.tid; k < B * wg; k += EGM_THREADS) { const int i = k % wg; d[k] = (i == p) ? 0.001f * 2.0f * gzs[k] * invB : 0.0f; }
+  __syncthreads();
+  bnn_bwd(cb, a.theta, a.grad, G, g1s, d, ds, t0, t1, nullptr, B, true, true);
+  // v__ branch: g (call 3, input z_)
+  for (int k = c.tid; k < B * wg; k += EGM_THREADS) {
+    const int b = k / wg, i = k - b * wg;
+    d[k] = (i < p) ? (-2.0f / (float)(B * p)) * (vb[b * p + i] - gv[k]) : 0.0f;
+  }
+  __syncthreads();
+  bnn_bwd(cb, a.theta, a.grad, G, g2, d, ds, t0, t1, dzsum, B, true, true);
+  // adversarial branch through the fixed discriminator
+  float *gd_scratch = take(a.dz.n_params);
+  egm_disc_bwd(c, a.theta_d, gd_scratch, a.dz, kd, true, -invB, nullptr, da, du, dtmp, B, false, 1.0f);
+  for (int k = c.tid; k < B * q; k += EGM_THREADS) dzsum[k] += dtmp[k];
+  __syncthreads();
+  // f: mean call, variance call
+  for (int k = c.tid; k < B * of; k += EGM_THREADS) { const int b = k / of, i = k - b * of; d[k] = (i == 0) ? 2.0f * (fo[k] - yb[b]) * invB : 0.0f; }
+  __syncthreads();
+  bnn_bwd(cb, a.theta, a.grad, F, cf, d, ds, t0, t1, dfin, B, true, false);
+  for (int k = c.tid; k < B * of; k += EGM_THREADS) { const int i = k % of; d[k] = (i == of - 1) ? 0.001f * 2.0f * fs[k] * invB : 0.0f; }
+  __syncthreads();
+  bnn_bwd(cb, a.theta, a.grad, F, cfs, d, ds, t0, t1, dfin2, B, true, true);
+  // h: mean call, variance call
+  for (int k = c.tid; k < B * oh; k += EGM_THREADS) {
+    const int b = k / oh, i = k - b * oh;
+    d[k] = (i == 0) ? (a.binary ? (1.0f / (1.0f + expf(-ho[k])) - xb[b]) * invB : 2.0f * (ho[k] - xb[b]) * invB) : 0.0f;
+  }
+  __syncthreads();
+  bnn_bwd(cb, a.theta, a.grad, H, ch, d, ds, t0, t1, dhin, B, true, false);
+  for (int k = c.tid; k < B * oh; k += EGM_THREADS) { const int i = k % oh; d[k] = (i == oh - 1) ? 0.001f * 2.0f * hs[k] * invB : 0.0f; }
+  __syncthreads();
+  bnn_bwd(cb, a.theta, a.grad, H, chs, d, ds, t0, t1, dhin2, B, true, true);
+  for (int k = c.tid; k < B * q; k += EGM_THREADS) {
+    const int b = k / q, i = k - b * q;
+    float t = dzsum[k];
+    if (i < z0) t += dfin[b * nf + i] + dfin2[b * nf + i] + dhin[b * nh + i] + dhin2[b * nh + i];
+    else if (i < z0 + z1) t += dfin[b * nf + i] + dfin2[b * nf + i];
+    else if (i < z0 + z1 + z2) t += dhin[b * nh + (i - z1)] + dhin2[b * nh + (i - z1)];
+    d[k] = t;
+  }
+  __syncthreads();
+  bnn_bwd(cb, a.theta, a.grad, E, e1, d, ds, t0, t1, nullptr, B, true, true);
+  if (a.apply) egm_adam(c, a.theta, a.m, a.v, a.grad, a.n_gen, a.adam);
+  if (c.tid == 0 && a.out) {
+    a.out[0] = adv; a.out[1] = l_v; a.out[2] = l_z; a.out[3] = l_x; a.out[4] = l_y;
+    a.out[5] = adv + (l_v + zrec * l_z) + (l_x + l_y) + 0.001f * sig;
+  }
+}

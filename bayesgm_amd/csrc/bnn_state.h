@@ -22,7 +22,10 @@ struct BnnState {
   bool packed_valid = false;
   float *samp_dev = nullptr;
   size_t samp_cap = 0;
+  void *egm = nullptr;         // BnnEgmState (bnn_egm_api.hip)
 };
+
+void bgm_bnn_egm_free(void *egm_state);
 
 inline void bnn_free_sampler(BnnState *s) {
   if (s->samp_dev) hipFree(s->samp_dev);

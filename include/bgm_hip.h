@@ -441,6 +441,20 @@ int bgm_bnn_z_step(bgm_handle *h, const float *x_dev, const float *y_dev, const 
                    float *dz_out_dev, void *stream);
 int bgm_bnn_end(bgm_handle *h, void *stream);
 
+/* ---- EGM warm start with Bayesian nets (train_disc_step :305-330, train_gen_step :332-377 with use_bnn): a sub-session of
+ * bgm_bnn_begin that trains the session's g, e, f, h (own Adam slots = g_pre_optimizer) against the deterministic latent
+ * discriminator dz_net (parameter layout and bgm_egm_config as in bgm_causal_egm_begin).  Noise: the encoder call of the
+ * disc step uses stream stream_id; the nine network calls of the gen step use stream_id + 0..8 in the order
+ * g(z), g(z) [variance head], e(v), e(v_), g(z_), f, f [variance head], h, h [variance head]. */
+int bgm_bnn_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, const float *theta_dz_host, int64_t count, void *stream);
+int bgm_bnn_egm_disc_step(bgm_handle *h, const float *z_dev, const int32_t *idx_dev, const float *v_dev, float eps,
+                          uint64_t seed, uint32_t stream_id, int32_t apply, float *out_dev, void *stream);
+int bgm_bnn_egm_gen_step(bgm_handle *h, const float *z_dev, const int32_t *idx_dev, const float *v_dev, const float *x_dev,
+                         const float *y_dev, uint64_t seed, uint32_t stream_id, int32_t apply, float *out_dev, void *stream);
+/* what = 1 discriminator parameters, 3 its gradient of the last disc step (the nets' side: bgm_bnn_read). */
+int bgm_bnn_egm_read(bgm_handle *h, int32_t what, float *host, int64_t count, void *stream);
+int bgm_bnn_egm_end(bgm_handle *h, void *stream);
+
 /* ---- large-batch side of the session: posterior sampling, causal effects, evaluation.  A "block" is the batch of rows
  * one reference call sees (bs rows of predict, base.py:640-645; the whole panel for evaluate): its input statistics
  * normalise the rows and ONE weight perturbation per layer is shared by them.  Noise key of block b = seed + (b << 32). */

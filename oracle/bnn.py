@@ -433,3 +433,93 @@ def evaluate(m, data, data_z=None, x_values=None, seed=0, stream=0):
            for k, xv in enumerate(vals)]
     causal = (mus[0] - mus[1]) if m["binary_treatment"] else np.array([mu.mean() for mu in mus], dtype=v.dtype)
     return data_z, causal, mse_x, mse_y, mse_v
+
+
+# ---------------------------------------------------------------------------------------------------
+# EGM warm start with Bayesian nets (train_disc_step :305-330, train_gen_step :332-377 with use_bnn)
+# ---------------------------------------------------------------------------------------------------
+EGM_CALLS = ("g1", "g1s", "e1", "e2", "g2", "f", "fs", "h", "hs")    # noise stream of call c = stream + index
+
+
+def egm_noises(m, B, key, stream, dtype=np.float32, disc_only=False):
+    """The noise of every network call of one EGM step.  gen step: the nine calls above in this order;
+    disc step: only e (call "e1", stream + 0)."""
+    if disc_only:
+        return {"e1": draw_noise(net_dims(m["e"]), B, key, stream, NET_ID["e"], dtype)}
+    return {c: draw_noise(net_dims(m[c[0]]), B, key, stream + i, NET_ID[c[0]], dtype) for i, c in enumerate(EGM_CALLS)}
+
+
+def egm_disc_step_grads(m, dz, z, v, eps, noises):
+    """train_disc_step with a Bayesian encoder: z_ = e_net(v) is one noisy call (no gradient flows into e)."""
+    from . import egm as OE
+    B = z.shape[0]
+    z_, _ = forward(m["e"], v, noises["e1"])
+    zhat = z * eps + z_ * (1.0 - eps)
+    grads = OE.zero_disc_grads(dz)
+    out_f, cache_f = OE.disc_forward(dz, z_)
+    out_r, cache_r = OE.disc_forward(dz, z)
+    dz_loss = -out_r.mean() + out_f.mean()
+    OE.disc_backward(dz, cache_f, np.full_like(out_f, 1.0 / B), grads)
+    OE.disc_backward(dz, cache_r, np.full_like(out_r, -1.0 / B), grads)
+    gp, _ = OE.gradient_penalty_and_grads(dz, zhat, grads, scale=10.0)
+    return dz_loss, dz_loss + 10.0 * gp, grads
+
+
+def egm_gen_step_grads(m, dz, use_z_rec, z, v, x, y, noises):
+    """train_gen_step with Bayesian g, e, f, h: nine network calls, each with its own noise and its own batch
+    statistics (g(z) twice: reconstruction input and variance penalty; f, h twice: mean and variance penalty).
+    Returns (losses [e_adv, l2_v, l2_z, l2_x, l2_y, total], grads per net in the structure of `backward`)."""
+    from . import egm as OE
+    B, q = z.shape
+    pdim = m["v_dim"]
+    z0d, z1d, z2d, _ = m["z_dims"]
+    g, e, f, h = m["g"], m["e"], m["f"], m["h"]
+    gz, c_g1 = forward(g, z, noises["g1"])
+    gzs, c_g1s = forward(g, z, noises["g1s"])
+    v_ = gz[:, :pdim]
+    z_, c_e1 = forward(e, v, noises["e1"])
+    z__, c_e2 = forward(e, v_, noises["e2"])
+    gv, c_g2 = forward(g, z_, noises["g2"])
+    v__ = gv[:, :pdim]
+    d_, c_d = OE.disc_forward(dz, z_)
+    f_in, h_in = _inputs(m, z_, x)
+    f_out, c_f = forward(f, f_in, noises["f"])
+    f_s, c_fs = forward(f, f_in, noises["fs"])
+    h_out, c_h = forward(h, h_in, noises["h"])
+    h_s, c_hs = forward(h, h_in, noises["hs"])
+    y_, x_ = f_out[:, :1], h_out[:, :1]
+    l2_v = ((v - v__) ** 2).mean()
+    l2_z = ((z - z__) ** 2).mean()
+    e_adv = -d_.mean()
+    if m["binary_treatment"]:
+        l2_x = (np.maximum(x_, 0) - x_ * x + np.log1p(np.exp(-np.abs(x_)))).mean()
+        dx_ = (sigmoid(x_) - x) / B
+    else:
+        l2_x = ((x_ - x) ** 2).mean()
+        dx_ = 2.0 * (x_ - x) / B
+    l2_y = ((y_ - y) ** 2).mean()
+    sig = (gzs[:, -1] ** 2).mean() + (f_s[:, -1] ** 2).mean() + (h_s[:, -1] ** 2).mean()
+    zrec = float(use_z_rec)
+    total = e_adv + (l2_v + zrec * l2_z) + (l2_x + l2_y) + 0.001 * sig
+    # ---- backward
+    ge2, dv_ = backward(e, c_e2, zrec * (-2.0 / (B * q)) * (z - z__))
+    dgz = np.zeros_like(gz); dgz[:, :pdim] = dv_
+    gg1, _ = backward(g, c_g1, dgz, want_dx=False)
+    dgzs = np.zeros_like(gzs); dgzs[:, -1] = 0.001 * 2.0 * gzs[:, -1] / B
+    gg1s, _ = backward(g, c_g1s, dgzs, want_dx=False)
+    dgv = np.zeros_like(gv); dgv[:, :pdim] = (-2.0 / (B * pdim)) * (v - v__)
+    gg2, dz_ = backward(g, c_g2, dgv)
+    _, dz_d = OE.disc_backward(dz, c_d, np.full_like(d_, -1.0 / B))
+    dz_ = dz_ + dz_d
+    df = np.zeros_like(f_out); df[:, :1] = 2.0 * (y_ - y) / B
+    gf, df_in = backward(f, c_f, df)
+    dfs = np.zeros_like(f_s); dfs[:, -1] = 0.001 * 2.0 * f_s[:, -1] / B
+    gfs, dfs_in = backward(f, c_fs, dfs)
+    dh = np.zeros_like(h_out); dh[:, :1] = dx_
+    gh, dh_in = backward(h, c_h, dh)
+    dhs = np.zeros_like(h_s); dhs[:, -1] = 0.001 * 2.0 * h_s[:, -1] / B
+    ghs, dhs_in = backward(h, c_hs, dhs)
+    dz_ = _scatter_dz(m, dz_, df_in + dfs_in, dh_in + dhs_in)
+    ge1, _ = backward(e, c_e1, dz_, want_dx=False)
+    grads = {"g": add_grads(add_grads(gg1, gg1s), gg2), "e": add_grads(ge1, ge2), "f": add_grads(gf, gfs), "h": add_grads(gh, ghs)}
+    return np.array([e_adv, l2_v, l2_z, l2_x, l2_y, total]), grads

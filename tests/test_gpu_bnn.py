@@ -238,3 +238,59 @@ def test_evaluate_matches_oracle(binary, p):
     s2 = sums2.cpu().numpy()
     assert abs(s2[0] / (n * p) - mv2) < 1e-3 * mv2 and abs(s2[2] / n - my2) < 2e-3 * my2
     eng.close()
+
+
+@pytest.mark.parametrize("binary", [False, True])
+def test_egm_steps_match_oracle(binary):
+    """EGM warm-start steps with Bayesian nets: gradients of the discriminator step and of the nine-call generator step."""
+    from oracle import egm as OE
+    from bayesgm_amd.engine import CausalEngine
+    m = _model(binary, p=50)
+    n, B = 120, 32
+    _, x, y, v = _panel(m, n)
+    q = sum(m["z_dims"])
+    rs = np.random.RandomState(21)
+    dz = OE.init_disc(rs, q, [64, 32, 8])
+    for l in range(3):
+        dz["gamma"][l] = (1.0 + 0.2 * rs.standard_normal(dz["gamma"][l].shape)).astype(np.float32)
+        dz["beta"][l] = (0.1 * rs.standard_normal(dz["beta"][l].shape)).astype(np.float32)
+    eng = _engine(m)
+    dev = eng.device
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    eng.egm_begin(dz, B, 2e-4, 1)
+    z = rs.standard_normal((B, q)).astype(np.float32)
+    idx = rs.choice(n, B, replace=False).astype(np.int32)
+    seed, stream, eps = (1 << 32) | 42, 1000, 0.37
+    m64, dz64 = OB.cast_model(m, np.float64), OE.cast_disc(dz, np.float64)
+    f64 = lambda a: a.astype(np.float64)
+    # discriminator step
+    out = torch.zeros(2, device=dev)
+    eng.egm_disc_step(T(z), T(idx), T(v), eps, seed, stream, apply=False, out=out)
+    noises = OB.egm_noises(m64, B, seed, stream, np.float64, disc_only=True)
+    dl, dtot, gd = OB.egm_disc_step_grads(m64, dz64, f64(z), f64(v[idx]), eps, noises)
+    o = out.cpu().numpy()
+    assert abs(o[0] - dl) < 1e-4 * max(1.0, abs(dl)) and abs(o[1] - dtot) < 1e-3 * max(1.0, abs(dtot))
+    ref = CausalEngine.flatten_disc(gd).astype(np.float64)
+    got = eng.egm_read(3)
+    # hidden-layer discriminator biases have zero true gradient (BatchNorm removes them): compare the rest
+    assert np.abs(got - ref).max() < 2e-3 * np.abs(ref).max()
+    # generator step
+    out = torch.zeros(6, device=dev)
+    eng.egm_gen_step(T(z), T(idx), T(v), T(x[:, 0]), T(y[:, 0]), seed, stream + 16, apply=False, out=out)
+    noises = OB.egm_noises(m64, B, seed, stream + 16, np.float64)
+    losses, gr = OB.egm_gen_step_grads(m64, dz64, 1, f64(z), f64(v[idx]), f64(x[idx]), f64(y[idx]), noises)
+    assert np.all(np.abs(out.cpu().numpy() - losses) <= 2e-4 * np.abs(losses) + 1e-5), (out.cpu().numpy(), losses)
+    got = eng.split(eng.read(1))
+    for name in ("g", "e", "f", "h"):
+        gg = [got[name]["gamma"], got[name]["beta"]] + [a for L in got[name]["layers"] for a in L]
+        for a, b in zip(gg, OB.flat_grads(gr[name])):
+            assert _rel(a, b) < 3e-3, (name, a.shape, _rel(a, b))
+    # an applied step moves the parameters of all four nets
+    before = eng.read(0)
+    eng.egm_gen_step(T(z), T(idx), T(v), T(x[:, 0]), T(y[:, 0]), seed, stream + 32, apply=True)
+    after = eng.read(0)
+    for k in range(4):
+        sl = slice(eng.offsets[k], eng.offsets[k + 1])
+        assert np.abs(after[sl] - before[sl]).max() > 1e-5
+    eng.egm_end()
+    eng.close()

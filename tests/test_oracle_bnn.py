@@ -146,3 +146,51 @@ def test_noise_layout_is_deterministic_and_balanced():
     # rows of a later slice of the batch see the same words as the full batch
     part = OB.draw_noise(dims, 100, key=(7 << 32) | 99, stream=3, net_id=0, row0=200)
     assert np.array_equal(part["sin"][1], n1["sin"][1][200:])
+
+
+@pytest.mark.parametrize("binary", [False, True])
+def test_egm_gen_step_matches_autograd(binary):
+    from oracle import egm as OE
+    m = _model(binary, seed=4)
+    for k in ("e",):
+        rs = np.random.RandomState(8)
+        m[k]["gamma"] = 1.0 + 0.3 * rs.standard_normal(m[k]["gamma"].shape)
+        m[k]["beta"] = 0.2 * rs.standard_normal(m[k]["beta"].shape)
+    B = 10
+    z, x, y, v = _data(m, B)
+    q = z.shape[1]
+    dz = OE.init_disc(np.random.RandomState(1), q, (7, 5), dtype=np.float64)
+    rs = np.random.RandomState(12)
+    noises = {c: OB.random_noise(rs, OB.net_dims(m[c[0]]), B) for c in OB.EGM_CALLS}
+    losses, grads = OB.egm_gen_step_grads(m, dz, 1, z, v, x, y, noises)
+    tn = {k: _tnet(m[k]) for k in ("g", "e", "f", "h")}
+    p = m["v_dim"]
+    z0d, z1d, z2d, _ = m["z_dims"]
+    tz, tv, tx, ty = _t(z), _t(v), _t(x), _t(y)
+    gz = _tfwd(tn["g"], tz, noises["g1"])
+    gzs = _tfwd(tn["g"], tz, noises["g1s"])
+    z_ = _tfwd(tn["e"], tv, noises["e1"])
+    z__ = _tfwd(tn["e"], gz[:, :p], noises["e2"])
+    gv = _tfwd(tn["g"], z_, noises["g2"])
+
+    def tdisc(a):
+        h = a
+        for l in range(len(dz["W"]) - 1):
+            u = h @ _t(dz["W"][l]) + _t(dz["b"][l])
+            u = (u - u.mean(0)) / torch.sqrt(u.var(0, unbiased=False) + 1e-3) * _t(dz["gamma"][l]) + _t(dz["beta"][l])
+            h = torch.tanh(u)
+        return h @ _t(dz["W"][-1]) + _t(dz["b"][-1])
+    d_ = tdisc(z_)
+    fin = torch.cat([z_[:, :z0d + z1d], tx], 1)
+    hin = torch.cat([z_[:, :z0d], z_[:, z0d + z1d:z0d + z1d + z2d]], 1)
+    fo, fs = _tfwd(tn["f"], fin, noises["f"]), _tfwd(tn["f"], fin, noises["fs"])
+    ho, hs = _tfwd(tn["h"], hin, noises["h"]), _tfwd(tn["h"], hin, noises["hs"])
+    l2x = torch.nn.functional.binary_cross_entropy_with_logits(ho[:, :1], tx) if binary else ((ho[:, :1] - tx) ** 2).mean()
+    total = -d_.mean() + ((tv - gv[:, :p]) ** 2).mean() + ((tz - z__) ** 2).mean() + l2x + ((fo[:, :1] - ty) ** 2).mean() \
+        + 0.001 * ((gzs[:, -1] ** 2).mean() + (fs[:, -1] ** 2).mean() + (hs[:, -1] ** 2).mean())
+    total.backward()
+    assert abs(float(total.detach()) - losses[5]) < 1e-9 * max(1.0, abs(losses[5]))
+    for k in ("g", "e", "f", "h"):
+        ref = [tn[k]["gamma"].grad, tn[k]["beta"].grad] + [a.grad for L in tn[k]["layers"] for a in L]
+        for a, b in zip(OB.flat_grads(grads[k]), ref):
+            np.testing.assert_allclose(a, b.numpy(), rtol=1e-7, atol=1e-11)
