@@ -158,6 +158,7 @@ SYMBOLS = {
     "bgm_bnn_theta_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                      C.c_float, C.c_uint64, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p]),
     "bgm_bnn_grad_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "bgm_bnn_grad_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "bgm_bnn_theta_apply": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p]),
     "bgm_bnn_z_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_uint64, C.c_uint32, C.c_void_p,

@@ -111,11 +111,20 @@ class BnnEngine(object):
     def split(self, theta):
         return {NETS[k]: unflatten_bnn(theta[self.offsets[k]:self.offsets[k + 1]], self.dims[NETS[k]]) for k in range(4)}
 
-    def grad_tensor(self):
-        """The session's gradient buffer as a torch tensor view (for the data-parallel all-reduce)."""
-        ptr, cnt = C.c_void_p(), C.c_int64()
-        _lib.check(self.lib.bgm_bnn_grad_dev(self.h, C.byref(ptr), C.byref(cnt)), "bgm_bnn_grad_dev")
-        raise NotImplementedError
+    def grad_exchange(self, buf, to_session):
+        """Copy the session's gradient into `buf` (device tensor [n_params]) or back: the data-parallel all-reduce sits between."""
+        _lib.check(self.lib.bgm_bnn_grad_exchange(self.h, _ptr(buf), int(bool(to_session)), self._stream()), "bgm_bnn_grad_exchange")
+
+    def row_mean_quantiles(self, mat, q_lo, q_hi):
+        """mat [n_rows, m] on device -> (mean, lo, hi) each [n_rows]."""
+        mat = mat.contiguous()
+        n_rows, m = mat.shape
+        mean = torch.empty(n_rows, device=self.device, dtype=torch.float32)
+        lo = torch.empty_like(mean)
+        hi = torch.empty_like(mean)
+        _lib.check(self.lib.bgm_row_mean_quantiles(self.h, _ptr(mat), n_rows, m, float(q_lo), float(q_hi),
+                                                   _ptr(mean), _ptr(lo), _ptr(hi), self._stream()), "bgm_row_mean_quantiles")
+        return mean, lo, hi
 
     # -- minibatch steps -----------------------------------------------------------------------------
     def theta_step(self, data_z, idx, x, y, v, lr_theta, seed, stream_id, apply=True, batch_global=0, out=None):

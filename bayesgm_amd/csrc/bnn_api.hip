@@ -134,6 +134,17 @@ extern "C" int bgm_bnn_grad_dev(bgm_handle *h, float **grad_dev, int64_t *count)
   return BGM_OK;
 }
 
+extern "C" int bgm_bnn_grad_exchange(bgm_handle *h, float *buf_dev, int32_t to_session, void *stream_) {
+  int rc = bnn_need(h, "bgm_bnn_grad_exchange");
+  if (rc) return rc;
+  if (!buf_dev) { bgm_set_error("bgm_bnn_grad_exchange: NULL buffer"); return BGM_E_INVALID; }
+  BnnState *s = bst(h);
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  BGM_HIP_CHECK(hipMemcpyAsync(to_session ? s->grad_dev : buf_dev, to_session ? buf_dev : s->grad_dev, sizeof(float) * s->n_params,
+                               hipMemcpyDeviceToDevice, (hipStream_t)stream_));
+  return BGM_OK;
+}
+
 static float adam_lr_t(float lr, long long t_) {
   const double t = (double)t_;
   return (float)((double)lr * std::sqrt(1.0 - std::pow((double)BNN_ADAM_B2, t)) / (1.0 - std::pow((double)BNN_ADAM_B1, t)));
@@ -147,6 +158,8 @@ static void bnn_base_args(BnnState *s, BnnArgs &a, int batch, int batch_global, 
   a.binary = s->cfg.binary_treatment; a.wmax = s->wmax; a.kl_weight = s->cfg.kl_weight;
   a.k0 = (uint32_t)(seed & 0xFFFFFFFFull); a.k1 = (uint32_t)(seed >> 32); a.stream = stream_id;
   a.inv_B = 1.0f / (float)(batch_global > 0 ? batch_global : batch);
+  // data parallel: every rank adds its share of the KL term, the all-reduce (sum) restores kl_weight * KL
+  if (batch_global > batch) a.kl_weight = s->cfg.kl_weight * (float)batch / (float)batch_global;
   a.ws = s->ws_dev;
 }
 

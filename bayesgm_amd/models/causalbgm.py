@@ -5,8 +5,8 @@ gfx950 kernels of libbgm_hip.so.
 Mirrors /root/reference/src/bayesgm/models/causalbgm/base.py:
     __init__ :56-128   get_config :130   fit :434   evaluate :535   predict :573
     metropolis_hastings_sampler :820   infer_from_latent_posterior :672
-Deterministic networks (``use_bnn=False``) are implemented; ``use_bnn=True`` (SURVEY.md
-section 8f row N2) raises NotImplementedError rather than silently changing the model.
+This class holds the deterministic networks (``use_bnn=False``); with ``use_bnn=True`` (the
+reference's default) the constructor returns the Bayesian-network subclass of causalbgm_bnn.py.
 """
 import datetime
 import os
@@ -35,16 +35,19 @@ def _init_mlp(rs, dims):
 
 
 class CausalBGM(object):
+    def __new__(cls, params, *args, **kwargs):
+        # params['use_bnn'] (default True, base.py:64): the Bayesian-network model lives in causalbgm_bnn.py
+        if cls is CausalBGM and dict(_DEFAULTS, **params)["use_bnn"]:
+            from .causalbgm_bnn import CausalBGMBayes
+            return super().__new__(CausalBGMBayes)
+        return super().__new__(cls)
+
     def __init__(self, params, timestamp=None, random_seed=None, device=None):
         self.params = params
         self.timestamp = timestamp
         p = dict(_DEFAULTS)
         p.update(params)
         self._p = p
-        if p["use_bnn"]:
-            raise NotImplementedError(
-                "bayesgm_amd: use_bnn=True (tfp DenseFlipout networks, networks/bnn.py) is not built yet; "
-                "set params['use_bnn']=False")
         self._rs = np.random.RandomState(random_seed) if random_seed is not None else np.random.RandomState()
         if random_seed is not None:
             np.random.seed(random_seed)

@@ -1,0 +1,397 @@
+"""CausalBGM with Bayesian networks (``params['use_bnn'] = True``, the default of the reference's YAML configs and CLI).
+
+Mirrors /root/reference/src/bayesgm/models/causalbgm/base.py with its ``use_bnn`` branches
+(:64-72 network construction, :171-173/:205-207/:234-236 KL terms) and networks/bnn.py:4-38.  Same public methods as
+the deterministic class; every network call is a Flipout call with fresh noise on the statistics of the batch it is
+given, so -- exactly as in the reference -- `predict` depends on ``bs`` (the rows of one block share statistics and
+weight perturbations) and `evaluate` treats the panel it is given as one batch.
+
+Stated differences (DESIGN.md "Bayesian nets"): the noise streams are the build's counter-based ones (oracle/bnn.py);
+minibatches are limited to 64 rows; under torch.distributed every rank normalises with the statistics of ITS rows;
+an adaptive proposal scale (q_sd <= 0) is adapted on the acceptance rate of all blocks together.
+"""
+import datetime
+import os
+
+import numpy as np
+import torch
+
+from .. import parallel
+from ..bnn_engine import BnnEngine, NETS, flatten_bnn
+from ..datasets import Gaussian_sampler
+from ..utils import save_data
+from .causalbgm import CausalBGM, _DEFAULTS, _glorot
+
+
+def _init_bnn(rs, dims):
+    """tfp.layers.DenseFlipout defaults (default_mean_field_normal_fn): loc ~ N(0, 0.1^2), untransformed scale
+    ~ N(-3, 0.1^2), bias ~ N(0, 0.1^2); BatchNormalization gamma = 1, beta = 0."""
+    layers = []
+    for i in range(len(dims) - 1):
+        layers.append(((0.1 * rs.standard_normal((dims[i], dims[i + 1]))).astype(np.float32),
+                       (-3.0 + 0.1 * rs.standard_normal((dims[i], dims[i + 1]))).astype(np.float32),
+                       (0.1 * rs.standard_normal(dims[i + 1])).astype(np.float32)))
+    return {"gamma": np.ones(dims[0], np.float32), "beta": np.zeros(dims[0], np.float32), "layers": layers}
+
+
+class CausalBGMBayes(CausalBGM):
+    def __init__(self, params, timestamp=None, random_seed=None, device=None):
+        self.params = params
+        self.timestamp = timestamp
+        p = dict(_DEFAULTS)
+        p.update(params)
+        self._p = p
+        for k in ("sigma_v", "sigma_x", "sigma_y"):
+            if k in params:
+                raise NotImplementedError("bayesgm_amd: fixed %s together with use_bnn=True is not built" % k)
+        self._rs = np.random.RandomState(random_seed) if random_seed is not None else np.random.RandomState()
+        if random_seed is not None:
+            np.random.seed(random_seed)
+        self._seed_counter = 0
+        self._base_seed = int(random_seed) if random_seed is not None else int(np.random.randint(0, 2 ** 31 - 1))
+        self._stream = 0                       # noise call counter of the minibatch steps
+        z = list(p["z_dims"])
+        q = sum(z)
+        self.nets = {
+            "g": _init_bnn(self._rs, [q] + list(p["g_units"]) + [p["v_dim"] + 1]),
+            "e": _init_bnn(self._rs, [p["v_dim"]] + list(p["e_units"]) + [q]),
+            "f": _init_bnn(self._rs, [z[0] + z[1] + 1] + list(p["f_units"]) + [2]),
+            "h": _init_bnn(self._rs, [z[0] + z[2]] + list(p["h_units"]) + [2]),
+        }
+        self.z_sampler = Gaussian_sampler(mean=np.zeros(q), sd=1.0)
+        if device is None:
+            device = int(os.environ.get("BGM_DEVICE", os.environ.get("LOCAL_RANK", 0)))
+        self.engine = BnnEngine(p["v_dim"], z, binary_treatment=p["binary_treatment"], g_units=p["g_units"], e_units=p["e_units"],
+                                f_units=p["f_units"], h_units=p["h_units"], kl_weight=p["kl_weight"], max_batch=64, device=device)
+        self.engine.begin(self.nets)
+        if self.timestamp is None:
+            self.timestamp = datetime.datetime.now().astimezone().strftime('%Y%m%d_%H%M%S')
+        self.checkpoint_path = "{}/checkpoints/{}/{}".format(params['output_dir'], params['dataset'], self.timestamp)
+        if p['save_model'] and not os.path.exists(self.checkpoint_path):
+            os.makedirs(self.checkpoint_path, exist_ok=True)
+        self.save_dir = "{}/results/{}/{}".format(params['output_dir'], params['dataset'], self.timestamp)
+        if p['save_res'] and not os.path.exists(self.save_dir):
+            os.makedirs(self.save_dir, exist_ok=True)
+        self.data_z = None
+        self.last_acceptance_rate = None
+
+    # ------------------------------------------------------------------ plumbing
+    def _noise_seed(self):
+        """Noise key of the minibatch steps; ranks draw different perturbations."""
+        return (self._base_seed * 2654435761 + 97 * parallel.rank()) & 0x7FFFFFFFFFFFFFFF
+
+    def _streams(self, n):
+        s = self._stream
+        self._stream = (self._stream + n) & 0x3FFFFFFF
+        return s
+
+    def _pull_weights(self, which=None):
+        self.nets = self.engine.split(self.engine.read(0))
+
+    def _push_weights(self, which=None):
+        self.engine.write(np.concatenate([flatten_bnn(self.nets[k]) for k in NETS]))
+
+    def set_weights(self, **nets):
+        """Install network parameters ({"gamma", "beta", "layers": [(loc, rho, bias), ...]} per net)."""
+        for k, v in nets.items():
+            self.nets[k] = {"gamma": np.asarray(v["gamma"], np.float32), "beta": np.asarray(v["beta"], np.float32),
+                            "layers": [tuple(np.asarray(a, np.float32) for a in L) for L in v["layers"]]}
+        self._push_weights()
+
+    def save_checkpoint(self, epoch):
+        path = os.path.join(self.checkpoint_path, "ckpt-%d.npz" % epoch)
+        np.savez(path, theta=self.engine.read(0))
+        print('Saving checkpoint for epoch {} at {}'.format(epoch, path))
+        return path
+
+    def load_checkpoint(self, path):
+        self.engine.write(np.load(path)["theta"])
+        self._pull_weights()
+
+    # ------------------------------------------------------------------ EGM
+    def egm_init(self, data, egm_n_iter=30000, batch_size=32, egm_batches_per_eval=500, verbose=1):
+        """EGM warm start (base.py:380-431) with Bayesian g, e, f, h: csrc/bnn_egm_kernels.h, one launch per step."""
+        data_x, data_y, data_v = data
+        n = len(data_x)
+        eng = self.engine
+        dev = eng.device
+        p_ = self._p
+        xd, yd, vd = self._dev(data_x).reshape(-1), self._dev(data_y).reshape(-1), self._dev(data_v)
+        q = sum(p_["z_dims"])
+        dims = [q] + list(p_["dz_units"]) + [1]
+        dz = {"W": [_glorot(self._rs, dims[i], dims[i + 1]) for i in range(len(dims) - 1)],       # networks/base.py:338-363
+              "b": [np.zeros(dims[i + 1], np.float32) for i in range(len(dims) - 1)],
+              "gamma": [np.ones(dims[i + 1], np.float32) for i in range(len(dims) - 2)],
+              "beta": [np.zeros(dims[i + 1], np.float32) for i in range(len(dims) - 2)]}
+        eng.egm_begin(dz, batch_size, p_["lr"], p_["use_z_rec"])
+        out_d = torch.zeros(2, device=dev)
+        out_g = torch.zeros(6, device=dev)
+        if verbose:
+            print('EGM Initialization Starts ...')
+        g_d_freq = int(p_['g_d_freq'])
+        steps = g_d_freq + 1
+        seed = self._noise_seed()
+        try:
+            batch_iter = 0
+            while batch_iter <= egm_n_iter:
+                stop = min(egm_n_iter, (batch_iter // egm_batches_per_eval + 1) * egm_batches_per_eval
+                           if batch_iter % egm_batches_per_eval else batch_iter)
+                n_it = stop - batch_iter + 1
+                idx_h = np.empty((n_it, steps, batch_size), np.int32)
+                z_h = np.empty((n_it, steps, batch_size, q), np.float32)
+                eps_h = np.empty((n_it, g_d_freq), np.float64)
+                for i in range(n_it):                       # host RNG consumed in the reference's order (base.py:404-417)
+                    for j in range(g_d_freq):
+                        idx_h[i, j] = self._choice_no_replace(n, batch_size)
+                        z_h[i, j] = self.z_sampler.get_batch(batch_size)
+                        eps_h[i, j] = np.random.uniform(0.0, 1.0)
+                    z_h[i, g_d_freq] = self.z_sampler.get_batch(batch_size)
+                    idx_h[i, g_d_freq] = self._choice_no_replace(n, batch_size)
+                idx_d, z_d = torch.from_numpy(idx_h).to(dev), torch.from_numpy(z_h).to(dev)
+                for i in range(n_it):
+                    for j in range(g_d_freq):
+                        eng.egm_disc_step(z_d[i, j], idx_d[i, j], vd, eps_h[i, j], seed, self._streams(1), out=out_d)
+                    eng.egm_gen_step(z_d[i, g_d_freq], idx_d[i, g_d_freq], vd, xd, yd, seed, self._streams(9), out=out_g)
+                batch_iter = stop
+                if batch_iter % egm_batches_per_eval == 0:
+                    if verbose:
+                        lg, ld = out_g.cpu().numpy(), out_d.cpu().numpy()
+                        print('EGM Initialization Iter [%d] : e_loss_adv [%.4f], l2_loss_v [%.4f], l2_loss_z [%.4f], '
+                              'l2_loss_x [%.4f], l2_loss_y [%.4f], g_e_loss [%.4f], dz_loss [%.4f], d_loss [%.4f]'
+                              % (batch_iter, lg[0], lg[1], lg[2], lg[3], lg[4], lg[5], ld[0], ld[1]))
+                    causal_pre, mse_x, mse_y, mse_v = self.evaluate(data=data)
+                    if self._p['save_res'] and parallel.rank() == 0:
+                        save_data('{}/causal_pre_egm_init_iter-{}.txt'.format(self.save_dir, batch_iter), causal_pre)
+                batch_iter += 1
+        finally:
+            eng.egm_end()
+            self._pull_weights()
+        if verbose:
+            print('EGM Initialization Ends.')
+
+    # ------------------------------------------------------------------ fit
+    def fit(self, data, epochs=100, epochs_per_eval=5, batch_size=32, startoff=0, use_egm_init=True,
+            egm_n_iter=30000, egm_batches_per_eval=500, save_format='txt', verbose=1, z_adam="dense"):
+        """Iterative theta / Z updates (base.py:434-532) with the KL terms of the Bayesian nets.  ``batch_size`` is the
+        GLOBAL minibatch (<= 64 per rank); under torch.distributed rows are sharded, the g | h | f gradients all-reduced."""
+        if use_egm_init:
+            self.egm_init(data, egm_n_iter=egm_n_iter, batch_size=batch_size,
+                          egm_batches_per_eval=egm_batches_per_eval, verbose=verbose)
+        data_x, data_y, data_v = data
+        n_total = len(data_x)
+        if self._p['save_res'] and parallel.rank() == 0:
+            with open('{}/params.txt'.format(self.save_dir), 'w') as f_params:
+                f_params.write(str(self.params))
+        eng = self.engine
+        q = eng.q
+        lo_r, hi_r = parallel.shard_range(n_total)
+        n_loc = hi_r - lo_r
+        world = parallel.world_size()
+        dev = eng.device
+        x = self._dev(data_x[lo_r:hi_r]).reshape(-1)
+        y = self._dev(data_y[lo_r:hi_r]).reshape(-1)
+        v = self._dev(data_v[lo_r:hi_r])
+        seed = self._noise_seed()
+        if use_egm_init:
+            if verbose:
+                print('Initialize latent variables Z with e(V)...')
+            self.data_z, _, _ = eng.evaluate(None, None, v, None, seed=seed, stream_id=self._streams(1), want_sums=False,
+                                             want_effects=False)                        # base.py:479: one call of e on the panel
+        else:
+            if verbose:
+                print('Random initialization of latent variables Z...')
+            self.data_z = self._dev(np.random.normal(0, 1, size=(n_total, q)).astype('float32')[lo_r:hi_r])   # base.py:482
+        zm = torch.zeros_like(self.data_z)
+        zv = torch.zeros_like(self.data_z)
+        b_loc = max(2, batch_size // world)
+        grad = torch.empty(eng.n_params, device=dev, dtype=torch.float32) if world > 1 else None
+        out_t = torch.zeros(8, device=dev)
+        out_z = torch.zeros(4, device=dev)
+        lazy = (z_adam == "lazy")
+        best_loss = np.inf
+        if verbose:
+            print('Iterative Updating Starts ...')
+        for epoch in range(epochs + 1):
+            sample_idx = torch.from_numpy(np.random.choice(n_loc, n_loc, replace=False).astype(np.int32)).to(dev)
+            for i in range(0, n_loc, b_loc):
+                idx = sample_idx[i:i + b_loc]
+                if idx.numel() < 2:
+                    continue                      # batch statistics need two rows
+                bg = int(idx.numel()) * world
+                s0 = self._streams(3)
+                if world > 1:
+                    eng.theta_step(self.data_z, idx, x, y, v, self._p['lr_theta'], seed, s0, apply=False, batch_global=bg, out=out_t)
+                    eng.grad_exchange(grad, False)
+                    parallel.all_reduce_sum_(grad)
+                    eng.grad_exchange(grad, True)
+                    eng.theta_apply(self._p['lr_theta'])
+                else:
+                    eng.theta_step(self.data_z, idx, x, y, v, self._p['lr_theta'], seed, s0, apply=True, out=out_t)
+                eng.z_step(x, y, v, self.data_z, zm, zv, idx, self._p['lr_z'], seed, s0 + 1, lazy=lazy, batch_global=bg, out=out_z)
+            if verbose:
+                lt, lz = out_t.cpu().numpy(), out_z.cpu().numpy()
+                print('Epoch [%d/%d]: loss_px_z [%.4f], loss_mse_x [%.4f], loss_py_z [%.4f], loss_mse_y [%.4f], loss_pv_z [%.4f], '
+                      'loss_mse_v [%.4f], loss_postrior_z [%.4f]' % (epoch, epochs, lt[2], lt[3], lt[4], lt[5], lt[0], lt[1], lz[0]))
+            if epoch % epochs_per_eval == 0:
+                causal_pre, mse_x, mse_y, mse_v = self._evaluate_dev(x, y, v, self.data_z, n_total, lo_r)
+                if verbose:
+                    print('Epoch [%d/%d]: MSE_x: %.4f, MSE_y: %.4f, MSE_v: %.4f\n' % (epoch, epochs, mse_x, mse_y, mse_v))
+                if epoch >= startoff and mse_y < best_loss:
+                    best_loss = mse_y
+                    self.best_causal_pre = causal_pre
+                    self.best_epoch = epoch
+                    if self._p['save_model'] and parallel.rank() == 0:
+                        self.save_checkpoint(epoch)
+                if self._p['save_res'] and parallel.rank() == 0:
+                    save_data('{}/causal_pre_at_{}.{}'.format(self.save_dir, epoch, save_format), causal_pre)
+        self._pull_weights()
+
+    # ------------------------------------------------------------------ evaluate
+    def _evaluate_dev(self, x, y, v, z, n_total, lo_r, nb_intervals=200, x_full=None):
+        eng = self.engine
+        seed = self._noise_seed()
+        if self._p['binary_treatment']:
+            z, sums, ite = eng.evaluate(x, y, v, z, seed=seed, stream_id=self._streams(3))
+            parallel.all_reduce_sum_(sums)
+            ite = parallel.all_gather_rows(ite.reshape(-1, 1), n_total)
+            s = sums.cpu().numpy()
+            return (ite.cpu().numpy(), np.float32(s[1] / n_total), np.float32(s[2] / n_total),
+                    np.float32(s[0] / (n_total * eng.v_dim)))
+        xs_all = parallel.all_gather_rows(x.reshape(-1, 1), n_total).cpu().numpy() if x_full is None else x_full
+        x_min = self._percentile_nearest(xs_all, 5.0)
+        x_max = self._percentile_nearest(xs_all, 95.0)
+        x_values = np.linspace(x_min, x_max, nb_intervals).astype(np.float32)
+        z, sums, dose = eng.evaluate(x, y, v, z, x_values=x_values, seed=seed, stream_id=self._streams(1 + nb_intervals))
+        parallel.all_reduce_sum_(sums)
+        parallel.all_reduce_sum_(dose)
+        s = sums.cpu().numpy()
+        return ((dose / n_total).float().cpu().numpy(), np.float32(s[1] / n_total), np.float32(s[2] / n_total),
+                np.float32(s[0] / (n_total * eng.v_dim)))
+
+    def evaluate(self, data, data_z=None, nb_intervals=200):
+        """(causal_pre, mse_x, mse_y, mse_v) (base.py:534-570); data_z=None -> one call of e_net on the panel."""
+        data_x, data_y, data_v = data
+        n_total = len(data_x)
+        lo_r, hi_r = parallel.shard_range(n_total)
+        x = self._dev(data_x[lo_r:hi_r]).reshape(-1)
+        y = self._dev(data_y[lo_r:hi_r]).reshape(-1)
+        v = self._dev(data_v[lo_r:hi_r])
+        z = None
+        if data_z is not None:
+            z = self._dev(data_z[lo_r:hi_r]) if len(data_z) == n_total else self._dev(data_z)
+        return self._evaluate_dev(x, y, v, z, n_total, lo_r, nb_intervals)
+
+    # ------------------------------------------------------------------ predict
+    def _run_chains(self, x, y, v, bs, burn_in, n_keep, q_sd, seed, row_base, block0, adaptive, initial_q_sd=1.0, target=0.25,
+                    tol=0.05, adj_int=50, **outs):
+        """All blocks of the given rows in lock step.  Returns (final states, accepted count of the last <= 100 iterations)."""
+        eng = self.engine
+        n = x.shape[0]
+        state = torch.empty((n, eng.q), device=eng.device, dtype=torch.float32)
+        acc = torch.zeros(1, device=eng.device, dtype=torch.int32)
+        total = burn_in + n_keep
+        tail = min(100, total)
+        cur_sd = float(initial_q_sd if adaptive else q_sd)
+        # segment boundaries: after iteration 50, 100, ... of the burn-in (proposal-scale adjustment, base.py:883-894)
+        # and at the start of the acceptance window of the final report
+        bounds = {total, total - tail}
+        if adaptive:
+            bounds |= {c + 1 for c in range(adj_int, burn_in, adj_int)}
+        it, acc_tail = 0, 0
+        for b in sorted(b for b in bounds if 0 < b <= total):
+            seg = b - it
+            acc.zero_()
+            eng.mh_run(x, y, v, state, bs, it, seg, burn_in, cur_sd, seed, init=(it == 0), row_base=row_base, block0=block0,
+                       acc_count=acc, n_keep=n_keep, **outs)
+            if it >= total - tail:
+                acc_tail += int(acc.item())
+            if adaptive and b <= burn_in and (b - 1) % adj_int == 0:
+                rate = float(acc.item()) / (seg * n)
+                if rate < target - tol:
+                    cur_sd *= 0.9
+                elif rate > target + tol:
+                    cur_sd *= 1.1
+            it = b
+        return state, acc_tail, tail
+
+    def predict(self, data, alpha=0.01, n_mcmc=3000, burn_in=5000, x_values=None, q_sd=1.0, sample_y=True,
+                bs=10000, verbose=1):
+        """Causal effects with posterior intervals (base.py:573-668).  With Bayesian nets the rows of one block of ``bs``
+        rows share their input statistics and weight perturbations, as in the reference; all blocks advance together."""
+        assert 0 < alpha < 1, "The significance level 'alpha' must be greater than 0 and less than 1."
+        binary = bool(self._p['binary_treatment'])
+        if not binary and x_values is None:
+            raise ValueError("For continuous treatment, 'x_values' must not be None. Provide a list or a single treatment value.")
+        if x_values is not None:
+            x_values = np.array([x_values], dtype=float) if np.isscalar(x_values) else np.array(x_values, dtype=float)
+        data_x, data_y, data_v = data
+        n_test = len(data_x)
+        bs = max(2, int(bs))
+        # shard by whole blocks so that a block's statistics never span ranks
+        n_blocks = (n_test + bs - 1) // bs
+        b_lo, b_hi = parallel.shard_range(n_blocks)
+        lo_r, hi_r = min(n_test, b_lo * bs), min(n_test, b_hi * bs)
+        n_loc = hi_r - lo_r
+        eng = self.engine
+        dev = eng.device
+        adaptive = (q_sd is None) or (q_sd <= 0)
+        seed = self._next_seed()
+        if verbose:
+            print('MCMC Latent Variable Sampling ...')
+        x = self._dev(data_x[lo_r:hi_r]).reshape(-1)
+        y = self._dev(data_y[lo_r:hi_r]).reshape(-1)
+        v = self._dev(data_v[lo_r:hi_r])
+        acc_tail, tail = 0, 1
+        if binary:
+            max_rows = max(bs, int((32 << 30) // (4 * max(1, n_mcmc))) // bs * bs)      # whole blocks, draw matrix <= ~32 GiB
+            means, los, his = [], [], []
+            for s in range(0, n_loc, max_rows):
+                e = min(s + max_rows, n_loc)
+                ite = torch.empty((e - s, n_mcmc), device=dev, dtype=torch.float32)
+                _, a_, tail = self._run_chains(x[s:e], y[s:e], v[s:e], bs, burn_in, n_mcmc, q_sd, seed, lo_r + s, b_lo + s // bs,
+                                               adaptive, effect=2, sample_y=sample_y, ite=ite)
+                acc_tail += a_
+                mean, lo, hi = eng.row_mean_quantiles(ite, alpha / 2, 1 - alpha / 2)
+                means.append(mean); los.append(lo); his.append(hi)
+            cat = lambda ts: torch.cat(ts) if ts else torch.empty(0, device=dev)
+            mean = parallel.all_gather_rows_var(cat(means).reshape(-1, 1)).reshape(-1)
+            lo = parallel.all_gather_rows_var(cat(los).reshape(-1, 1)).reshape(-1)
+            hi = parallel.all_gather_rows_var(cat(his).reshape(-1, 1)).reshape(-1)
+            self._report_acceptance(float(acc_tail), tail, n_test, verbose)
+            return mean.cpu().numpy(), torch.stack([lo, hi], dim=1).cpu().numpy()
+        xv = self._dev(x_values.astype(np.float32))
+        sums = torch.zeros((len(x_values), n_mcmc), device=dev, dtype=torch.float64)
+        if n_loc > 0:
+            _, acc_tail, tail = self._run_chains(x, y, v, bs, burn_in, n_mcmc, q_sd, seed, lo_r, b_lo, adaptive, effect=1,
+                                                 sample_y=sample_y, x_values=xv, adrf_sum=sums)
+        parallel.all_reduce_sum_(sums)                        # adrf_draw_sums (base.py:660)
+        causal_effects = (sums / float(n_test)).float().contiguous()
+        adrf, lo, hi = eng.row_mean_quantiles(causal_effects, alpha / 2, 1 - alpha / 2)
+        self._report_acceptance(float(acc_tail), min(100, burn_in + n_mcmc), n_test, verbose)
+        return adrf.cpu().numpy(), torch.stack([lo, hi], dim=1).cpu().numpy()
+
+    def metropolis_hastings_sampler(self, data, initial_q_sd=1.0, q_sd=None, burn_in=5000, n_keep=3000,
+                                    target_acceptance_rate=0.25, tolerance=0.05, adjustment_interval=50,
+                                    adaptive_sd=None, window_size=100):
+        """Posterior samples of Z, shape (n_keep, n, q) (base.py:820-904): the rows given are ONE block."""
+        data_x, data_y, data_v = data
+        if adaptive_sd is None:
+            adaptive_sd = (q_sd is None or q_sd <= 0)
+        n = len(data_x)
+        draws = torch.empty((n_keep, n, self.engine.q), device=self.engine.device, dtype=torch.float32)
+        _, acc_tail, tail = self._run_chains(self._dev(data_x).reshape(-1), self._dev(data_y).reshape(-1), self._dev(data_v), max(2, n),
+                                             burn_in, n_keep, q_sd, self._next_seed(), 0, 0, adaptive_sd, initial_q_sd=initial_q_sd,
+                                             target=target_acceptance_rate, tol=tolerance, adj_int=adjustment_interval, draws=draws)
+        self.last_acceptance_rate = acc_tail / float(tail * n)
+        print(f"Final MCMC Acceptance Rate: {self.last_acceptance_rate:.4f}")
+        return draws.cpu().numpy()
+
+    def infer_from_latent_posterior(self, data_posterior_z, x_values=None, sample_y=True, eps=1e-6, seed=None):
+        raise NotImplementedError("bayesgm_amd: with use_bnn=True the causal effects are computed inside predict() "
+                                  "(the stand-alone form on a given draw tensor is not built)")
+
+    def get_log_posterior(self, data_x, data_y, data_v, data_z, eps=1e-6):
+        """log p(z | x, y, v) + const, shape (n,) (base.py:765-817): one noisy call of g, h, f on the rows given."""
+        n = len(data_x)
+        return self.engine.logpost(self._dev(data_x).reshape(-1), self._dev(data_y).reshape(-1), self._dev(data_v),
+                                   self._dev(data_z), max(2, n), self._next_seed(), 0).cpu().numpy()

@@ -55,3 +55,20 @@ def all_gather_rows(t, n_total):
     outs = [torch.empty_like(pad) for _ in range(w)]
     dist.all_gather(outs, pad)
     return torch.cat([o[:s] for o, s in zip(outs, sizes)], dim=0)
+
+
+def all_gather_rows_var(t):
+    """Concatenate per-rank row blocks (first dim) whose lengths are only known locally (rank order)."""
+    if not is_dist():
+        return t
+    w = world_size()
+    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    ns = [torch.zeros_like(n) for _ in range(w)]
+    dist.all_gather(ns, n)
+    sizes = [int(s.item()) for s in ns]
+    mx = max(max(sizes), 1)
+    pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[:t.shape[0]] = t
+    outs = [torch.empty_like(pad) for _ in range(w)]
+    dist.all_gather(outs, pad)
+    return torch.cat([o[:s] for o, s in zip(outs, sizes)], dim=0)

@@ -430,6 +430,8 @@ int bgm_bnn_theta_step(bgm_handle *h, const float *data_z_dev, const int32_t *id
                        const float *y_dev, const float *v_dev, int32_t batch, int32_t batch_global, float lr_theta,
                        uint64_t seed, uint32_t stream_id, int32_t apply, float *out_dev, void *stream);
 int bgm_bnn_grad_dev(bgm_handle *h, float **grad_dev, int64_t *count);
+/* Copy the session's gradient to buf_dev (to_session = 0) or back (1): [n_params] floats, device to device. */
+int bgm_bnn_grad_exchange(bgm_handle *h, float *buf_dev, int32_t to_session, void *stream);
 int bgm_bnn_theta_apply(bgm_handle *h, float lr_theta, void *stream);
 /* replaces: update_latent_variable_sgd with use_bnn, base.py:246-302 (every net called twice with independent noise:
  * streams stream_id and stream_id + 1) + the Adam step on the latent table (zm_dev, zv_dev: its slots, [n_rows x q];

@@ -294,3 +294,45 @@ def test_egm_steps_match_oracle(binary):
         assert np.abs(after[sl] - before[sl]).max() > 1e-5
     eng.egm_end()
     eng.close()
+
+
+def _params(tmp_path, binary, p=20):
+    return dict(dataset="t", output_dir=str(tmp_path), save_res=True, save_model=False, binary_treatment=binary, use_bnn=True,
+                z_dims=[1, 1, 1, 7], v_dim=p, lr_theta=1e-3, lr_z=1e-3, g_units=[64] * 5, f_units=[64, 32, 8], h_units=[64, 32, 8],
+                e_units=[64] * 5, dz_units=[64, 32, 8], kl_weight=1e-4, lr=2e-4, g_d_freq=5, use_z_rec=True)
+
+
+@pytest.mark.parametrize("binary", [False, True])
+def test_model_surface_with_bayesian_nets(tmp_path, binary):
+    """CausalBGM(use_bnn=True): EGM warm start, iterative updates, evaluate and predict through the reference's class surface."""
+    from bayesgm_amd.models import CausalBGM
+    from bayesgm_amd.datasets import Sim_Hirano_Imbens_sampler
+    x, y, v = Sim_Hirano_Imbens_sampler(N=600, v_dim=20, seed=0).load_all()
+    if binary:
+        x = (x > np.median(x)).astype(np.float32)
+    model = CausalBGM(_params(tmp_path, binary), random_seed=3)
+    assert type(model).__name__ == "CausalBGMBayes" and isinstance(model, CausalBGM)
+    c0, mx0, my0, mv0 = model.evaluate((x, y, v))
+    model.fit((x, y, v), epochs=4, epochs_per_eval=2, batch_size=32, use_egm_init=True, egm_n_iter=40, egm_batches_per_eval=20,
+              verbose=0)
+    assert model.data_z.shape == (600, 10) and torch.isfinite(model.data_z).all()
+    c1, mx1, my1, mv1 = model.evaluate((x, y, v), data_z=model.data_z.cpu().numpy())
+    assert c1.shape == ((600, 1) if binary else (200,)) and isinstance(my1, np.float32)
+    assert np.isfinite([mx1, my1, mv1]).all() and mv1 < mv0
+    if binary:
+        eff, interval = model.predict((x, y, v), alpha=0.05, n_mcmc=40, burn_in=30, q_sd=0.5, bs=256, verbose=0)
+        assert eff.shape == (600,) and interval.shape == (600, 2)
+    else:
+        xs = np.linspace(0, 3, 5)
+        eff, interval = model.predict((x, y, v), alpha=0.05, n_mcmc=40, burn_in=30, x_values=xs, q_sd=0.5, bs=256, verbose=0)
+        assert eff.shape == (5,) and interval.shape == (5, 2)
+        with pytest.raises(ValueError):
+            model.predict((x, y, v), n_mcmc=5, burn_in=5, verbose=0)
+    assert np.isfinite(eff).all() and np.all(interval[:, 0] <= interval[:, 1])
+    assert 0.0 < model.last_acceptance_rate <= 1.0
+    draws = model.metropolis_hastings_sampler((x[:100], y[:100], v[:100]), q_sd=0.5, burn_in=10, n_keep=6)
+    assert draws.shape == (6, 100, 10) and np.isfinite(draws).all()
+    lp = model.get_log_posterior(x[:100], y[:100], v[:100], draws[-1])
+    assert lp.shape == (100,) and np.isfinite(lp).all()
+    # adaptive proposal scale
+    model.predict((x, y, v), alpha=0.05, n_mcmc=10, burn_in=120, x_values=None if binary else [1.0], q_sd=-1, bs=300, verbose=0)
