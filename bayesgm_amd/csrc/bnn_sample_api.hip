@@ -1,5 +1,6 @@
 // bnn_sample_api.hip -- C ABI of the Bayesian-network CausalBGM path: posterior sampling, effects, evaluation.
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -35,6 +36,7 @@ static bool bns_plan(const BnnState *s, BnsPlan &pl) {
     if (n.n_layers < 2 || n.swords > BNS_SW || n.K[0] > BNS_MAXK) return false;
     for (int l = 0; l < n.n_layers; ++l) {
       if (l < n.n_layers - 1 && n.K[l + 1] > 16 * BNS_MAXT) return false;
+      if (16 * n.MT[l] > BNS_MAXB) return false;
       maxfrag = std::max(maxfrag, n.T[l] * n.MT[l] * 256);
     }
     n.fbase = (int)fb;
@@ -48,8 +50,9 @@ static bool bns_plan(const BnnState *s, BnsPlan &pl) {
   pl.net[BNN_E].dbase = (int)pl.set_ghf;     // evaluation sets: [g | h | f | e]
   pl.set_all = pl.set_ghf + pl.net[BNN_E].foff[pl.net[BNN_E].n_layers];
   pl.set_f = pl.net[BNN_F].foff[pl.net[BNN_F].n_layers];
-  pl.lds_bytes = (int)sizeof(float) * (2 * BNS_MAXK + BNS_WAVES * BNS_R * 16 * BNS_SW + 2 * maxfrag);
-  return pl.lds_bytes <= 160 * 1024;
+  (void)maxfrag;
+  pl.lds_bytes = (int)sizeof(float) * (2 * BNS_MAXK + BNS_MAXB + BNS_WAVES * BNS_R * 16 * BNS_SW + 2 * BNS_CHUNK * 256);
+  return true;
 }
 
 // Device scratch of the sampling side: [lf | sf | zprop | dw sets | stats (doubles) | xstats (doubles)], grown on demand.
@@ -212,6 +215,13 @@ extern "C" int bgm_bnn_mh_run(bgm_handle *h, const bgm_bnn_mh_args *g, void *str
   a.x = g->x_dev; a.y = g->y_dev; a.v = g->v_dev; a.z = g->state_dev; a.zprop = b.zprop; a.n = n; a.row_base = g->row_base;
   a.bs = bs; a.wg_per_block = (bs + BNS_ROWS - 1) / BNS_ROWS; a.block0 = g->block0; a.mode = 1;
   a.k0 = pa.k0; a.k1 = pa.k1; a.acc_count = g->acc_count_dev;
+#ifdef BNS_PROF
+  static unsigned long long *prof_dev = nullptr;
+  if (!prof_dev) hipMalloc((void **)&prof_dev, 128);
+  hipMemsetAsync(prof_dev, 0, 128, stream);
+  a.prof = prof_dev;
+  ea.prof = prof_dev + 8;
+#endif
   for (int i = 0; i < g->n_iters; ++i) {
     const int it = g->it_begin + i;
     bns_noise(pl, b, ids, 3, n_blocks, 2, pl.set_ghf, g->seed, 2u * (uint32_t)it, 1u, g->block0, stream);
@@ -224,6 +234,23 @@ extern "C" int bgm_bnn_mh_run(bgm_handle *h, const bgm_bnn_mh_args *g, void *str
       BGM_HIP_CHECK(hipMemcpyAsync(g->draws_dev + (long long)(it - g->burn_in) * n * q, g->state_dev, sizeof(float) * n * q,
                                    hipMemcpyDeviceToDevice, stream));
   }
+#ifdef BNS_PROF
+  {
+    unsigned long long hp[6];
+    hipStreamSynchronize(stream);
+    hipMemcpy(hp, prof_dev, sizeof(hp), hipMemcpyDeviceToHost);
+    const double wgs = (double)n_blocks * a.wg_per_block * std::max(1, g->n_iters);
+    int occ = -1;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, bns_mh_kernel, BNS_THREADS, pl.lds_bytes);
+    fprintf(stderr, "[BNS_PROF] occupancy %d workgroups / CU (lds %d B)\n", occ, pl.lds_bytes);
+    unsigned long long he[6];
+    hipMemcpy(he, prof_dev + 8, sizeof(he), hipMemcpyDeviceToHost);
+    if (g->effect) fprintf(stderr, "[BNS_PROF] effects, cycles per workgroup-launch: prologue %.0f staging %.0f first %.0f middle %.0f last %.0f outside %.0f\n",
+            he[0] / wgs, he[1] / wgs, he[2] / wgs, he[3] / wgs, he[4] / wgs, he[5] / wgs);
+    fprintf(stderr, "[BNS_PROF] cycles per workgroup-iteration (wave 0): prologue %.0f staging %.0f first %.0f middle %.0f last %.0f outside %.0f\n",
+            hp[0] / wgs, hp[1] / wgs, hp[2] / wgs, hp[3] / wgs, hp[4] / wgs, hp[5] / wgs);
+  }
+#endif
   if (g->n_iters > 0 && kept(g->it_begin + g->n_iters - 1)) {
     // statistics of the final state: one more statistics pass (its proposal is not used)
     const int i = g->n_iters;

@@ -13,8 +13,9 @@
 // blocks of the panel in lock step (blocks are independent, so N / bs of them advance together):
 //   bns_noise_kernel    dW = sigma * eps of every (block, call), written in MFMA fragment order
 //   bns_propose_kernel  proposal z' = z + q_sd * N(0, 1); column sums of z and z' per block (fp64 atomics)
-//   bns_mh_kernel       per workgroup 256 rows of one block: g, h, f forward for z' and z, accept / reject
-// Per net the workgroup runs layer-synchronously: the layer's loc and dW fragments (<= 106 KB) are staged in LDS,
+//   bns_mh_kernel       per workgroup 128 rows of one block: g, h, f forward for z' and z, accept / reject
+// Per net the workgroup (4 waves, two workgroups per CU) runs layer-synchronously: the layer's loc and dW fragments are
+// staged in LDS in chunks of 2 x 16 KB,
 // every wave keeps the activations of its 2 x 16 rows in registers (swapped MFMA orientation: output units along M,
 // rows along N, so accumulators are the next layer's B operands) and runs both GEMMs of the Flipout layer,
 // y = loc^T h + s_out * (dW^T (s_in * h)) + b, with two accumulators per output tile.
@@ -25,11 +26,13 @@
 
 #define BNS_WAVES 8
 #define BNS_THREADS (64 * BNS_WAVES)
-#define BNS_R 2
+#define BNS_CHUNK 16      // (output tile, k tile) fragment pairs per staged chunk: 2 arrays x 16 KB
+#define BNS_R 1
 #define BNS_ROWS (BNS_WAVES * 16 * BNS_R)
 #define BNS_MAXT 4        // hidden widths <= 64
 #define BNS_SW 32         // sign words reserved per row in LDS
 #define BNS_MAXK 208      // widest network input (padded)
+#define BNS_MAXB 512      // widest layer output (padded), bias staged in LDS
 
 struct BnsNet {
   int n_layers, net_id;
@@ -186,11 +189,19 @@ static __global__ __launch_bounds__(256) void bns_propose_kernel(BnsPropArgs a) 
 // ---------------------------------------------------------------------------------------------
 // network forward of one workgroup's rows
 // ---------------------------------------------------------------------------------------------
+#ifdef BNS_PROF
+#define BNS_T(c_, k) { BnsCtx &cc_ = const_cast<BnsCtx &>(c_); const unsigned long long t_ = clock64(); cc_.tp[k] += t_ - cc_.t_last; cc_.t_last = t_; }
+#else
+#define BNS_T(c_, k)
+#endif
 struct BnsCtx {
+#ifdef BNS_PROF
+  unsigned long long tp[6] = {0, 0, 0, 0, 0, 0}, t_last = 0;   // 0 prologue, 1 staging, 2 first layer, 3 middle layers, 4 last layer, 5 outside
+#endif
   int tid, wave, lane, j, g;
   float *stage;        // LDS: loc fragments | dW fragments of the current layer
   uint32_t *sg;        // LDS: sign words [wave][rt][16 rows][BNS_SW]
-  float *bn;           // LDS: scale[BNS_MAXK] | shift[BNS_MAXK]
+  float *bn;           // LDS: scale[BNS_MAXK] | shift[BNS_MAXK] | bias of the current layer [BNS_MAXB]
 };
 
 __device__ __forceinline__ float bns_flip(float x, uint32_t w, int bit) {
@@ -203,10 +214,13 @@ __device__ __forceinline__ uint32_t bns_sgw(const BnsCtx &c, int rt, int word) {
 // stat(u) -> (mean, variance) of input column u of this call's batch; in(rt, u) -> raw input value of row (rt, j),
 // column u (< K); epi(rt, mt, y): last layer's outputs, y[r] = unit 16 mt + 4 g + r of row (rt, j).
 // rib0: index of the workgroup's first row inside its block (sign rows).
-template <class Stat, class In, class Epi>
+struct BnsNoPre { __device__ void operator()(int) const {} };
+template <class Stat, class In, class Epi, class Pre = BnsNoPre>
 __device__ __forceinline__ void bns_forward(const BnsCtx &c, const BnsNet &n, const float *theta, const float *lf, const float *dw,
-                                            uint32_t k0, uint32_t k1, uint32_t stream, int rib0, Stat stat, In in, Epi epi) {
+                                            uint32_t k0, uint32_t k1, uint32_t stream, int rib0, Stat stat, In in, Epi epi,
+                                            Pre pre = Pre()) {
   const int L = n.n_layers, j = c.j, g = c.g, lane = c.lane;
+  BNS_T(c, 5);
   __syncthreads();    // previous users of bn / sg / stage are done
   {
     const float *gamma = theta + n.goff, *beta = gamma + n.K[0];
@@ -232,24 +246,68 @@ __device__ __forceinline__ void bns_forward(const BnsCtx &c, const BnsNet &n, co
     }
   }
   float h[BNS_R][BNS_MAXT][4];
-  for (int l = 0; l < L; ++l) {
-    const int T = n.T[l], MT = n.MT[l], M = n.K[l + 1], fcount = T * MT * 64;   // float4 per array
+  // first-layer inputs of narrow nets (one k-tile) are requested before the staging barriers
+  float xin[BNS_R][4];
+  if (n.T[0] == 1) {
+#pragma unroll
+    for (int rt = 0; rt < BNS_R; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xin[rt][r] = in(rt, 4 * g + r);
+  }
+  // A net whose fragments fit one chunk (f, h) is staged whole: one barrier pair per call instead of one per layer.
+  const bool whole = n.foff[L] <= BNS_CHUNK * 256;
+  BNS_T(c, 0);
+  if (whole) {
+    const f32x4 *s1 = (const f32x4 *)lf, *s2 = (const f32x4 *)dw;
+    f32x4 *d = (f32x4 *)c.stage;
     __syncthreads();
-    {
-      const f32x4 *s1 = (const f32x4 *)(lf + n.foff[l]), *s2 = (const f32x4 *)(dw + n.foff[l]);
-      f32x4 *d = (f32x4 *)c.stage;
-      for (int i = c.tid; i < fcount; i += BNS_THREADS) { d[i] = s1[i]; d[fcount + i] = s2[i]; }
+    for (int i = c.tid; i < (n.foff[L] >> 2); i += BNS_THREADS) { d[i] = s1[i]; d[BNS_CHUNK * 64 + i] = s2[i]; }
+    int bo = 0;
+    for (int l = 0; l < L; ++l) {
+      const float *bias = theta + n.woff[l] + 2 * n.K[l] * n.K[l + 1];
+      for (int o = c.tid; o < 16 * n.MT[l]; o += BNS_THREADS) c.bn[2 * BNS_MAXK + bo + o] = (o < n.K[l + 1]) ? bias[o] : 0.0f;
+      bo += 16 * n.MT[l];
     }
     __syncthreads();
-    const f32x4 *LF = (const f32x4 *)c.stage, *DF = LF + fcount;
+    BNS_T(c, 1);
+  }
+  int bias_off = 0;
+  for (int l = 0; l < L; ++l) {
+    const int T = n.T[l], MT = n.MT[l], M = n.K[l + 1];
     const float *bias = theta + n.woff[l] + 2 * n.K[l] * M;
+    // Stage the fragments (mt0 .., t0 ..) of this layer: pair (mt, t) lands at ((mt - mt0) * nt + (t - t0)) * 64 + lane.
+    // Chunks of at most BNS_CHUNK pairs keep the stage at 32 KB, so that two workgroups share a CU and one computes
+    // while the other waits for its fragments.
+    auto stage = [&](int mt0, int nmt, int t0, int nt) {
+      if (whole) return;
+      const f32x4 *s1 = (const f32x4 *)(lf + n.foff[l]), *s2 = (const f32x4 *)(dw + n.foff[l]);
+      f32x4 *d = (f32x4 *)c.stage;
+      const int cnt = nmt * nt * 64;
+      BNS_T(c, (l == 0 ? 2 : (l == L - 1 ? 4 : 3)));
+      __syncthreads();
+      for (int i = c.tid; i < cnt; i += BNS_THREADS) {
+        const int pair = i >> 6, mt = mt0 + pair / nt, t = t0 + pair % nt;
+        const int src = (mt * T + t) * 64 + (i & 63);
+        d[i] = s1[src]; d[BNS_CHUNK * 64 + i] = s2[src];
+      }
+      if (mt0 == 0 && t0 == 0)
+        for (int o = c.tid; o < 16 * MT; o += BNS_THREADS) c.bn[2 * BNS_MAXK + o] = (o < M) ? bias[o] : 0.0f;
+      __syncthreads();
+      BNS_T(c, 1);
+    };
+    const f32x4 *LF = (const f32x4 *)c.stage + (whole ? (n.foff[l] >> 2) : 0), *DF = LF + BNS_CHUNK * 64;
+    const f32x4 *BL = (const f32x4 *)(c.bn + 2 * BNS_MAXK + (whole ? bias_off : 0));   // bias of unit 16 mt + 4 g + r = BL[4 mt + g][r]
+    bias_off += 16 * MT;
     if (l == 0) {
       f32x4 a1[BNS_R][BNS_MAXT], a2[BNS_R][BNS_MAXT];
 #pragma unroll
       for (int rt = 0; rt < BNS_R; ++rt)
 #pragma unroll
         for (int mt = 0; mt < BNS_MAXT; ++mt) { a1[rt][mt] = f32x4{0.f, 0.f, 0.f, 0.f}; a2[rt][mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      const int tc = whole ? T : BNS_CHUNK / BNS_MAXT;
       for (int t = 0; t < T; ++t) {
+        const int t0 = t - t % tc, nt = min(tc, T - t0);
+        if (t == t0) stage(0, MT, t0, nt);
         float hb[BNS_R][4], hs[BNS_R][4];
 #pragma unroll
         for (int rt = 0; rt < BNS_R; ++rt) {
@@ -257,7 +315,7 @@ __device__ __forceinline__ void bns_forward(const BnsCtx &c, const BnsNet &n, co
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int u = 16 * t + 4 * g + r;
-            const float x = fmaf(in(rt, u), c.bn[u], c.bn[BNS_MAXK + u]);
+            const float x = fmaf(T == 1 ? xin[rt][r] : in(rt, u), c.bn[u], c.bn[BNS_MAXK + u]);
             hb[rt][r] = x;
             hs[rt][r] = bns_flip(x, w, ((t & 1) << 4) + 4 * g + r);
           }
@@ -265,7 +323,7 @@ __device__ __forceinline__ void bns_forward(const BnsCtx &c, const BnsNet &n, co
 #pragma unroll
         for (int mt = 0; mt < BNS_MAXT; ++mt)
           if (mt < MT) {
-            const f32x4 fa = LF[(mt * T + t) * 64 + lane], fd = DF[(mt * T + t) * 64 + lane];
+            const f32x4 fa = LF[(mt * nt + (t - t0)) * 64 + lane], fd = DF[(mt * nt + (t - t0)) * 64 + lane];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -277,9 +335,7 @@ __device__ __forceinline__ void bns_forward(const BnsCtx &c, const BnsNet &n, co
       }
 #pragma unroll
       for (int mt = 0; mt < BNS_MAXT; ++mt) {
-        float b[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const int o = 16 * mt + 4 * g + r; b[r] = (mt < MT && o < M) ? bias[o] : 0.0f; }
+        const f32x4 b = (mt < MT) ? BL[4 * mt + g] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int rt = 0; rt < BNS_R; ++rt) {
           const uint32_t w = (mt < MT) ? bns_sgw(c, rt, n.sout_w[0] + (mt >> 1)) : 0u;
@@ -302,6 +358,8 @@ __device__ __forceinline__ void bns_forward(const BnsCtx &c, const BnsNet &n, co
         }
       const bool last = (l == L - 1);
       float hn[BNS_R][BNS_MAXT][4];
+      const int mc = BNS_CHUNK / BNS_MAXT;      // output tiles per staged chunk
+      int mt0 = 0;
       auto tile = [&](int mt, f32x4 (&y)[BNS_R]) {
         f32x4 a1[BNS_R], a2[BNS_R];
 #pragma unroll
@@ -309,7 +367,7 @@ __device__ __forceinline__ void bns_forward(const BnsCtx &c, const BnsNet &n, co
 #pragma unroll
         for (int t = 0; t < BNS_MAXT; ++t)
           if (t < T) {
-            const f32x4 fa = LF[(mt * T + t) * 64 + lane], fd = DF[(mt * T + t) * 64 + lane];
+            const f32x4 fa = LF[((mt - mt0) * T + t) * 64 + lane], fd = DF[((mt - mt0) * T + t) * 64 + lane];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -318,9 +376,7 @@ __device__ __forceinline__ void bns_forward(const BnsCtx &c, const BnsNet &n, co
                 a2[rt] = BGM_MFMA(fd[r], hs[rt][t][r], a2[rt]);
               }
           }
-        float b[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const int o = 16 * mt + 4 * g + r; b[r] = (o < M) ? bias[o] : 0.0f; }
+        const f32x4 b = BL[4 * mt + g];
 #pragma unroll
         for (int rt = 0; rt < BNS_R; ++rt) {
           const uint32_t w = bns_sgw(c, rt, n.sout_w[l] + (mt >> 1));
@@ -329,6 +385,7 @@ __device__ __forceinline__ void bns_forward(const BnsCtx &c, const BnsNet &n, co
         }
       };
       if (!last) {
+        stage(0, MT, 0, T);
 #pragma unroll
         for (int mt = 0; mt < BNS_MAXT; ++mt) {
           f32x4 y[BNS_R];
@@ -345,7 +402,10 @@ __device__ __forceinline__ void bns_forward(const BnsCtx &c, const BnsNet &n, co
 #pragma unroll
             for (int r = 0; r < 4; ++r) h[rt][t][r] = hn[rt][t][r];
       } else {
+        pre(0);
         for (int mt = 0; mt < MT; ++mt) {
+          if (mt % mc == 0) { mt0 = mt; stage(mt0, min(mc, MT - mt0), 0, T); }
+          pre(mt + 1);          // operands of the NEXT tile's epilogue (e.g. the data row) are requested a tile ahead
           f32x4 y[BNS_R];
           tile(mt, y);
 #pragma unroll
@@ -353,6 +413,7 @@ __device__ __forceinline__ void bns_forward(const BnsCtx &c, const BnsNet &n, co
         }
       }
     }
+    BNS_T(c, (l == 0 ? 2 : (l == L - 1 ? 4 : 3)));
   }
 }
 
@@ -376,6 +437,7 @@ struct BnsMhArgs {
   uint32_t k0, k1, stream0;            // mode 1: streams 2 it (proposal), 2 it + 1 (current); mode 0: stream0
   float *out;                          // mode 0: [n] log-posterior
   unsigned *acc_count;                 // mode 1 (optional): accepted proposals
+  unsigned long long *prof;            // -D BNS_PROF: cycles per phase, summed over workgroups (wave 0)
 };
 
 __device__ __forceinline__ void bns_stat(const double *st, int col, double cnt, float &mean, float &var) {
@@ -395,19 +457,33 @@ __device__ __forceinline__ void bns_logpost_rows(const BnsCtx &c, const BnsMhArg
 #pragma unroll
   for (int rt = 0; rt < BNS_R; ++rt) { xr[rt] = a.x[row[rt]]; yr[rt] = a.y[row[rt]]; }
   // ---- g: Gaussian likelihood of the covariates
-  float ssq[BNS_R], raw[BNS_R];
+  float ssq[BNS_R], raw[BNS_R], vcur[BNS_R][4], vnext[BNS_R][4];
 #pragma unroll
-  for (int rt = 0; rt < BNS_R; ++rt) { ssq[rt] = 0.0f; raw[rt] = 0.0f; }
+  for (int rt = 0; rt < BNS_R; ++rt) {
+    ssq[rt] = 0.0f; raw[rt] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { vcur[rt][r] = 0.0f; vnext[rt][r] = 0.0f; }
+  }
   bns_forward(c, a.net[BNN_G], a.theta, a.lf + a.net[BNN_G].fbase, dwset + a.net[BNN_G].dbase, a.k0, k1, stream, rib0,
               [&](int u, float &m, float &v) { bns_stat(st, u, cnt, m, v); },
-              [&](int rt, int u) { return u < q ? zsrc[row[rt] * q + u] : 0.0f; },
+              [&](int rt, int u) { return zsrc[row[rt] * q + min(u, q - 1)]; },     // columns >= q have zero scale and shift
               [&](int rt, int mt, const f32x4 &y) {
-                const float *vr = a.v + row[rt] * p;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                   const int u = 16 * mt + 4 * g + r;
-                  if (u < p) { const float d = vr[u] - y[r]; ssq[rt] = fmaf(d, d, ssq[rt]); }
+                  if (u < p) { const float d = vcur[rt][r] - y[r]; ssq[rt] = fmaf(d, d, ssq[rt]); }
                   else if (u == p) raw[rt] += y[r];
+                }
+              },
+              [&](int mt) {      // data row one tile ahead: vcur <- vnext, vnext <- tile mt
+#pragma unroll
+                for (int rt = 0; rt < BNS_R; ++rt) {
+                  const float *vr = a.v + row[rt] * p;
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) {
+                    vcur[rt][r] = vnext[rt][r];
+                    vnext[rt][r] = vr[min(16 * mt + 4 * g + r, p - 1)];
+                  }
                 }
               });
 #pragma unroll
@@ -422,7 +498,7 @@ __device__ __forceinline__ void bns_logpost_rows(const BnsCtx &c, const BnsMhArg
   for (int rt = 0; rt < BNS_R; ++rt) { mu[rt] = 0.0f; raw[rt] = 0.0f; }
   bns_forward(c, a.net[BNN_H], a.theta, a.lf + a.net[BNN_H].fbase, dwset + a.net[BNN_H].dbase, a.k0, k1, stream, rib0,
               [&](int u, float &m, float &v) { bns_stat(st, u < z0 ? u : u + z1, cnt, m, v); },
-              [&](int rt, int u) { return u < a.net[BNN_H].K[0] ? zsrc[row[rt] * q + (u < z0 ? u : u + z1)] : 0.0f; },
+              [&](int rt, int u) { return zsrc[row[rt] * q + min(u < z0 ? u : u + z1, q - 1)]; },
               [&](int rt, int mt, const f32x4 &y) { if (mt == 0 && g == 0) { mu[rt] += y[0]; raw[rt] += y[1]; } });
 #pragma unroll
   for (int rt = 0; rt < BNS_R; ++rt) {
@@ -438,7 +514,7 @@ __device__ __forceinline__ void bns_logpost_rows(const BnsCtx &c, const BnsMhArg
                 if (u < z0 + z1) bns_stat(st, u, cnt, m, v);
                 else { const double mm = xst[0] / cnt; m = (float)mm; v = (float)fmax(xst[1] / cnt - mm * mm, 0.0); }
               },
-              [&](int rt, int u) { return u < z0 + z1 ? zsrc[row[rt] * q + u] : (u == z0 + z1 ? xr[rt] : 0.0f); },
+              [&](int rt, int u) { const float zv = zsrc[row[rt] * q + min(u, q - 1)]; return u < z0 + z1 ? zv : xr[rt]; },
               [&](int rt, int mt, const f32x4 &y) { if (mt == 0 && g == 0) { mu[rt] += y[0]; raw[rt] += y[1]; } });
 #pragma unroll
   for (int rt = 0; rt < BNS_R; ++rt) {
@@ -451,13 +527,13 @@ __device__ __forceinline__ void bns_logpost_rows(const BnsCtx &c, const BnsMhArg
   }
 }
 
-static __global__ __launch_bounds__(BNS_THREADS) void bns_mh_kernel(BnsMhArgs a) {
+static __global__ __launch_bounds__(BNS_THREADS, 4) void bns_mh_kernel(BnsMhArgs a) {
   extern __shared__ __attribute__((aligned(16))) float bns_lds[];
   BnsCtx c;
   c.tid = threadIdx.x; c.wave = c.tid >> 6; c.lane = c.tid & 63; c.j = c.lane & 15; c.g = c.lane >> 4;
   c.bn = bns_lds;
-  c.sg = (uint32_t *)(bns_lds + 2 * BNS_MAXK);
-  c.stage = bns_lds + 2 * BNS_MAXK + BNS_WAVES * BNS_R * 16 * BNS_SW;
+  c.sg = (uint32_t *)(bns_lds + 2 * BNS_MAXK + BNS_MAXB);
+  c.stage = bns_lds + 2 * BNS_MAXK + BNS_MAXB + BNS_WAVES * BNS_R * 16 * BNS_SW;
   const int blk = blockIdx.x / a.wg_per_block, wib = blockIdx.x - blk * a.wg_per_block;
   const int rib0 = wib * BNS_ROWS;
   const long long blk_lo = (long long)blk * a.bs;
@@ -472,6 +548,9 @@ static __global__ __launch_bounds__(BNS_THREADS) void bns_mh_kernel(BnsMhArgs a)
   }
   const uint32_t k1 = a.k1 + (uint32_t)(a.block0 + blk);
   const double cnt = (double)blk_n;
+#ifdef BNS_PROF
+  c.t_last = clock64();
+#endif
   if (a.mode == 0) {
     float lp[BNS_R];
     bns_logpost_rows(c, a, blk, rib0, row, a.z, 1, 0, 1, k1, a.stream0, cnt, lp);
@@ -497,8 +576,20 @@ static __global__ __launch_bounds__(BNS_THREADS) void bns_mh_kernel(BnsMhArgs a)
   }
   if (a.acc_count) {
     for (int off = 32; off > 0; off >>= 1) nacc += __shfl_xor(nacc, off);
-    if (c.lane == 0 && nacc) atomicAdd(a.acc_count, nacc);
+    __shared__ unsigned acc_part[BNS_WAVES];
+    if (c.lane == 0) acc_part[c.wave] = nacc;
+    __syncthreads();
+    if (c.tid == 0) {
+      unsigned t = 0;
+      for (int w = 0; w < BNS_WAVES; ++w) t += acc_part[w];
+      if (t) atomicAdd(a.acc_count, t);
+    }
   }
+#ifdef BNS_PROF
+  BNS_T(c, 5);
+  if (c.tid == 0 && a.prof)
+    for (int k = 0; k < 6; ++k) atomicAdd(&a.prof[k], c.tp[k]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -522,14 +613,17 @@ struct BnsEffArgs {
   uint32_t it_noise;
   double *sum_out; long long sum_stride;   // dose sums over rows: sum_out[k * sum_stride] += ...   (may be NULL)
   float *ite_out; long long ite_stride;    // n_doses == 2: ite_out[row * ite_stride] = y(x_0) - y(x_1)  (may be NULL)
+  unsigned long long *prof;                // -D BNS_PROF
 };
-static __global__ __launch_bounds__(BNS_THREADS) void bns_effects_kernel(BnsEffArgs a) {
+#define BNS_EFF_DOSES 256
+static __global__ __launch_bounds__(BNS_THREADS, 4) void bns_effects_kernel(BnsEffArgs a) {
   extern __shared__ __attribute__((aligned(16))) float bns_lds[];
+  __shared__ float dose_tot[BNS_WAVES][BNS_EFF_DOSES];
   BnsCtx c;
   c.tid = threadIdx.x; c.wave = c.tid >> 6; c.lane = c.tid & 63; c.j = c.lane & 15; c.g = c.lane >> 4;
   c.bn = bns_lds;
-  c.sg = (uint32_t *)(bns_lds + 2 * BNS_MAXK);
-  c.stage = bns_lds + 2 * BNS_MAXK + BNS_WAVES * BNS_R * 16 * BNS_SW;
+  c.sg = (uint32_t *)(bns_lds + 2 * BNS_MAXK + BNS_MAXB);
+  c.stage = bns_lds + 2 * BNS_MAXK + BNS_MAXB + BNS_WAVES * BNS_R * 16 * BNS_SW;
   const int blk = blockIdx.x / a.wg_per_block, wib = blockIdx.x - blk * a.wg_per_block;
   const int rib0 = wib * BNS_ROWS;
   const long long blk_lo = (long long)blk * a.bs;
@@ -546,6 +640,9 @@ static __global__ __launch_bounds__(BNS_THREADS) void bns_effects_kernel(BnsEffA
   const double cnt = (double)blk_n;
   const double *st = a.stats + ((long long)blk * 2 + 1) * 128;
   const int q = a.q, zz = a.z0 + a.z1, g = c.g;
+#ifdef BNS_PROF
+  c.t_last = clock64();
+#endif
   float y0[BNS_R];
   f32x4 nz[BNS_R];
   for (int k = 0; k < a.n_doses; ++k) {
@@ -561,7 +658,7 @@ static __global__ __launch_bounds__(BNS_THREADS) void bns_effects_kernel(BnsEffA
     bns_forward(c, a.f, a.theta, a.lf + a.f.fbase, a.dw + ((long long)blk * a.n_doses + k) * a.set_floats, a.k0, k1, a.stream0 + (uint32_t)k,
                 rib0,
                 [&](int u, float &m, float &v) { if (u < zz) bns_stat(st, u, cnt, m, v); else { m = xv; v = 0.0f; } },
-                [&](int rt, int u) { return u < zz ? a.z[row[rt] * q + u] : (u == zz ? xv : 0.0f); },
+                [&](int rt, int u) { const float zv = a.z[row[rt] * q + min(u, q - 1)]; return u < zz ? zv : xv; },
                 [&](int rt, int mt, const f32x4 &y) { if (mt == 0 && g == 0) { mu[rt] += y[0]; raw[rt] += y[1]; } });
     float tot = 0.0f;
 #pragma unroll
@@ -580,7 +677,23 @@ static __global__ __launch_bounds__(BNS_THREADS) void bns_effects_kernel(BnsEffA
     }
     if (a.sum_out) {
       for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
-      if (c.lane == 0) atomicAdd(&a.sum_out[(long long)k * a.sum_stride], (double)tot);
+      if (c.lane == 0) {
+        if (k < BNS_EFF_DOSES) dose_tot[c.wave][k] = tot;
+        else atomicAdd(&a.sum_out[(long long)k * a.sum_stride], (double)tot);
+      }
+    }
+  }
+#ifdef BNS_PROF
+  BNS_T(c, 5);
+  if (c.tid == 0 && a.prof)
+    for (int k = 0; k < 6; ++k) atomicAdd(&a.prof[k], c.tp[k]);
+#endif
+  if (a.sum_out) {      // one atomic per workgroup and dose (63 000 atomics per address serialise in the L2 otherwise)
+    __syncthreads();
+    for (int k = c.tid; k < min(a.n_doses, BNS_EFF_DOSES); k += BNS_THREADS) {
+      double t = 0.0;
+      for (int w = 0; w < BNS_WAVES; ++w) t += (double)dose_tot[w][k];
+      atomicAdd(&a.sum_out[(long long)k * a.sum_stride], t);
     }
   }
 }
@@ -620,13 +733,13 @@ struct BnsEvalArgs {
   uint32_t k0, k1, stream;
   double *sums;                        // mode 1: [sum (v - v^)^2, sum (x - x^)^2, sum (y - y^)^2]
 };
-static __global__ __launch_bounds__(BNS_THREADS) void bns_eval_kernel(BnsEvalArgs a) {
+static __global__ __launch_bounds__(BNS_THREADS, 4) void bns_eval_kernel(BnsEvalArgs a) {
   extern __shared__ __attribute__((aligned(16))) float bns_lds[];
   BnsCtx c;
   c.tid = threadIdx.x; c.wave = c.tid >> 6; c.lane = c.tid & 63; c.j = c.lane & 15; c.g = c.lane >> 4;
   c.bn = bns_lds;
-  c.sg = (uint32_t *)(bns_lds + 2 * BNS_MAXK);
-  c.stage = bns_lds + 2 * BNS_MAXK + BNS_WAVES * BNS_R * 16 * BNS_SW;
+  c.sg = (uint32_t *)(bns_lds + 2 * BNS_MAXK + BNS_MAXB);
+  c.stage = bns_lds + 2 * BNS_MAXK + BNS_MAXB + BNS_WAVES * BNS_R * 16 * BNS_SW;
   const int rib0 = blockIdx.x * BNS_ROWS;
   long long row[BNS_R];
   bool valid[BNS_R];
@@ -697,5 +810,12 @@ static __global__ __launch_bounds__(BNS_THREADS) void bns_eval_kernel(BnsEvalArg
     if (valid[rt] && g == 0) sy += d * d;
   }
   for (int off = 32; off > 0; off >>= 1) { sv += __shfl_xor(sv, off); sx += __shfl_xor(sx, off); sy += __shfl_xor(sy, off); }
-  if (c.lane == 0) { atomicAdd(&a.sums[0], (double)sv); atomicAdd(&a.sums[1], (double)sx); atomicAdd(&a.sums[2], (double)sy); }
+  __shared__ float part[BNS_WAVES][3];
+  if (c.lane == 0) { part[c.wave][0] = sv; part[c.wave][1] = sx; part[c.wave][2] = sy; }
+  __syncthreads();
+  if (c.tid < 3) {
+    double t = 0.0;
+    for (int w = 0; w < BNS_WAVES; ++w) t += (double)part[w][c.tid];
+    atomicAdd(&a.sums[c.tid], t);
+  }
 }
