@@ -5,7 +5,8 @@ Mirrors /root/reference/src/bayesgm/models/bgm/base.py:
     predict_on_posteriors :511   predict :527   get_log_posterior :666   tfp_mcmc_sampler :709
 Deterministic generator (``use_bnn=False``: BaseVariationalNet, networks/base.py:53-117) only; the EGM warm
 start runs on the kernels of csrc/bgm_egm_kernels.h;
-``use_bnn=True`` raises NotImplementedError.
+``use_bnn=True`` (BayesianVariationalNet, networks/bnn.py:40-99) raises NotImplementedError: the Bayesian nets are built
+for CausalBGM only.
 """
 import datetime
 import os
