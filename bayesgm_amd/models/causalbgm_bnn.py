@@ -76,9 +76,10 @@ class CausalBGMBayes(CausalBGM):
         self.last_acceptance_rate = None
 
     # ------------------------------------------------------------------ plumbing
-    def _noise_seed(self):
-        """Noise key of the minibatch steps; ranks draw different perturbations."""
-        return (self._base_seed * 2654435761 + 97 * parallel.rank()) & 0x7FFFFFFFFFFFFFFF
+    def _noise_seed(self, per_rank=False):
+        """Noise key of the network calls.  The EGM warm start and evaluate are replicated / reduced over ranks and use one
+        key; the data-parallel minibatch steps of fit draw different perturbations on every rank (per_rank)."""
+        return (self._base_seed * 2654435761 + (97 * parallel.rank() if per_rank else 0)) & 0x7FFFFFFFFFFFFFFF
 
     def _streams(self, n):
         s = self._stream
@@ -191,7 +192,7 @@ class CausalBGMBayes(CausalBGM):
         x = self._dev(data_x[lo_r:hi_r]).reshape(-1)
         y = self._dev(data_y[lo_r:hi_r]).reshape(-1)
         v = self._dev(data_v[lo_r:hi_r])
-        seed = self._noise_seed()
+        seed = self._noise_seed(per_rank=True)
         if use_egm_init:
             if verbose:
                 print('Initialize latent variables Z with e(V)...')

@@ -336,3 +336,24 @@ def test_model_surface_with_bayesian_nets(tmp_path, binary):
     assert lp.shape == (100,) and np.isfinite(lp).all()
     # adaptive proposal scale
     model.predict((x, y, v), alpha=0.05, n_mcmc=10, burn_in=120, x_values=None if binary else [1.0], q_sd=-1, bs=300, verbose=0)
+
+
+def test_two_rank_fit_and_predict_with_bayesian_nets():
+    """Data-parallel paths of the Bayesian model executed for real (two ranks on this GPU over gloo): identical networks on
+    both ranks after EGM + fit; the block-sharded predict equals the single-process predict of the same seeded model."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BGM_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29537", os.path.join(root, "scripts", "dp_bnn_smoke.py"), "gloo"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count('"spread": 0.0') == 2, r.stdout[-2000:]
+    from bayesgm_amd.models import CausalBGM
+    from bayesgm_amd.datasets import Sim_Hirano_Imbens_sampler
+    two = json.loads([l for l in r.stdout.splitlines() if l.startswith("{") and '"rank": 0' in l][0])
+    x, y, v = Sim_Hirano_Imbens_sampler(N=1101, v_dim=30, seed=1).load_all()
+    m = CausalBGM(dict(_params("gpurun_out/dp", False, p=30), save_res=False), random_seed=2)
+    adrf, interval = m.predict((x, y, v), alpha=0.05, n_mcmc=30, burn_in=30, x_values=np.linspace(0, 3, 6), q_sd=0.5, bs=256, verbose=0)
+    assert np.abs(np.array(two["adrf_untrained"]) - adrf).max() <= 1e-5
+    assert np.abs(np.array(two["interval_untrained"]) - interval.ravel()).max() <= 1e-5
