@@ -72,6 +72,27 @@ def cpu_baseline(params, p, z_dims, budget_s=20.0):
                       f"2 log-posterior evals/iter + NumPy RNG as causalbgm/base.py:860-871; {dt:.1f} s"}
 
 
+def bayesian_leg(params, data, x_values, n_loc, args, device):
+    """Secondary measurement (not `value`): the same predict with the reference's default Bayesian nets (use_bnn=True,
+    DESIGN.md section 7) on a tenth of the iterations -- all blocks advance in lock step, three launches per iteration, so
+    the per-transition rate does not depend on the iteration count."""
+    import torch
+    from bayesgm_amd.models import CausalBGM
+    m = CausalBGM(dict(params, use_bnn=True), timestamp="bench_bnn", random_seed=0, device=device.index)
+    burn, keep, bs = max(1, args.burn_in // 10), max(1, args.n_mcmc // 10), 10000
+    m.predict(data, alpha=0.01, n_mcmc=2, burn_in=2, x_values=x_values, q_sd=1.0, sample_y=True, bs=bs, verbose=0)   # packs, allocates
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    m.predict(data, alpha=0.01, n_mcmc=keep, burn_in=burn, x_values=x_values, q_sd=1.0, sample_y=True, bs=bs, verbose=0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    flop_row = 2 * 2 * 2 * 34848 if (args.p == 200) else None      # two states x two GEMMs per Flipout layer x 2 FLOP/MAC
+    return {"value": n_loc * (burn + keep) / dt, "unit": "MH transitions/s", "seconds": dt,
+            "sample": f"CausalBGM(use_bnn=True).predict, N={n_loc}, bs={bs}, burn_in={burn}, n_mcmc={keep}, 20 doses",
+            "ms_per_iteration": 1e3 * dt / (burn + keep), "acceptance_rate": m.last_acceptance_rate,
+            "flop_per_row_transition": flop_row}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,6 +103,7 @@ def main():
     ap.add_argument("--burn-in", type=int, default=5000)
     ap.add_argument("--n-mcmc", type=int, default=3000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bayesian", action="store_true", help="skip the secondary use_bnn=True measurement (N=1 only)")
     args = ap.parse_args()
 
     import torch
@@ -195,6 +217,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(params, p, z_dims)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        if not args.no_bayesian and world == 1:
+            out["bayesian_nets"] = bayesian_leg(params, data, x_values, n_loc, args, device)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
