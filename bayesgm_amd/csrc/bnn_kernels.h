@@ -31,6 +31,7 @@ struct BnnNet {
   int n_layers;                       // DenseFlipout layers (hidden + output)
   int dims[BNN_MAX_LAYERS + 1];
   int off, n_params, net_id;
+  int bn_fixed;                       // 1: normalise with mean 0 / variance 1 instead of the batch statistics
   int woff[BNN_MAX_LAYERS];           // loc of layer l (rho at + in*out, bias at + 2*in*out)
   int hoff[BNN_MAX_LAYERS + 2];       // h_l (input of layer l; h_L = output) at B * hoff[l]; hoff[L+1] = total width
   int eoff[BNN_MAX_LAYERS + 1];       // eps / dW of layer l inside one call's noise block; eoff[L] = kernel elements
@@ -171,10 +172,10 @@ __device__ __forceinline__ void bnn_bn_fwd(const BnnCtx &c, const float *theta, 
   for (int i = c.tid; i < in; i += BNN_THREADS) {
     float s = 0.0f;
     for (int b = 0; b < B; ++b) s += k.x[(long long)b * in + i];
-    const float mu = s / (float)B;
+    const float mu = n.bn_fixed ? 0.0f : s / (float)B;
     float v = 0.0f;
     for (int b = 0; b < B; ++b) { const float d = k.x[(long long)b * in + i] - mu; v = fmaf(d, d, v); }
-    const float inv = 1.0f / sqrtf(v / (float)B + BNN_BN_EPS);
+    const float inv = 1.0f / sqrtf((n.bn_fixed ? 1.0f : v / (float)B) + BNN_BN_EPS);
     k.inv[i] = inv;
     for (int b = 0; b < B; ++b) {
       const float xh = (k.x[(long long)b * in + i] - mu) * inv;
@@ -282,7 +283,7 @@ __device__ __forceinline__ void bnn_bwd(const BnnCtx &c, const float *theta, flo
       gbt[i] = accumulate ? gbt[i] + sb : sb;
     }
     if (dx) {
-      const float m1 = sb * gamma[i] / (float)B, m2 = sg_ * gamma[i] / (float)B, inv = k.inv[i];
+      const float m1 = n.bn_fixed ? 0.0f : sb * gamma[i] / (float)B, m2 = n.bn_fixed ? 0.0f : sg_ * gamma[i] / (float)B, inv = k.inv[i];
       for (int b = 0; b < B; ++b) {
         const long long t = (long long)b * in + i;
         dx[t] = inv * (cur[t] * gamma[i] - m1 - k.xhat[t] * m2);

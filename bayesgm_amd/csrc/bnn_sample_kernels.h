@@ -35,7 +35,7 @@
 #define BNS_MAXB 512      // widest layer output (padded), bias staged in LDS
 
 struct BnsNet {
-  int n_layers, net_id;
+  int n_layers, net_id, bn_fixed;
   int K[BNN_MAX_LAYERS + 1];
   int T[BNN_MAX_LAYERS], MT[BNN_MAX_LAYERS];   // input k-tiles / output tiles of layer l
   int foff[BNN_MAX_LAYERS + 1];                // fragments of layer l inside the net's block; foff[L] = block size
@@ -46,7 +46,7 @@ struct BnsNet {
   int dbase;                                   // ... inside one (block, call) perturbation set
 };
 inline void bns_from(const BnnNet &b, BnsNet &n) {
-  n.n_layers = b.n_layers; n.net_id = b.net_id; n.goff = b.off; n.swords = b.swords;
+  n.n_layers = b.n_layers; n.net_id = b.net_id; n.goff = b.off; n.swords = b.swords; n.bn_fixed = b.bn_fixed;
   int f = 0;
   for (int l = 0; l <= b.n_layers; ++l) n.K[l] = b.dims[l];
   for (int l = 0; l < b.n_layers; ++l) {
@@ -227,8 +227,8 @@ __device__ __forceinline__ void bns_forward(const BnsCtx &c, const BnsNet &n, co
     for (int u = c.tid; u < 16 * n.T[0]; u += BNS_THREADS) {
       float sc = 0.0f, sh = 0.0f;
       if (u < n.K[0]) {
-        float mean, var;
-        stat(u, mean, var);
+        float mean = 0.0f, var = 1.0f;
+        if (!n.bn_fixed) stat(u, mean, var);
         sc = gamma[u] / sqrtf(var + BNN_BN_EPS);
         sh = beta[u] - mean * sc;
       }

@@ -6,6 +6,11 @@ the deterministic class; every network call is a Flipout call with fresh noise o
 given, so -- exactly as in the reference -- `predict` depends on ``bs`` (the rows of one block share statistics and
 weight perturbations) and `evaluate` treats the panel it is given as one batch.
 
+``params['bnn_norm']`` (build option, default "batch"): "batch" = the input BatchNormalization uses the statistics of the
+batch at hand, which is what the reference code does under Keras' training-mode resolution; "fixed" = it normalises with
+mean 0 / variance 1 (inference mode on never-updated moving averages), the alternative reading under which a constant
+counterfactual treatment column is NOT normalised away.
+
 Stated differences (DESIGN.md "Bayesian nets"): the noise streams are the build's counter-based ones (oracle/bnn.py);
 minibatches are limited to 64 rows; under torch.distributed every rank normalises with the statistics of ITS rows;
 an adaptive proposal scale (q_sd <= 0) is adapted on the acceptance rate of all blocks together.
@@ -62,7 +67,8 @@ class CausalBGMBayes(CausalBGM):
         if device is None:
             device = int(os.environ.get("BGM_DEVICE", os.environ.get("LOCAL_RANK", 0)))
         self.engine = BnnEngine(p["v_dim"], z, binary_treatment=p["binary_treatment"], g_units=p["g_units"], e_units=p["e_units"],
-                                f_units=p["f_units"], h_units=p["h_units"], kl_weight=p["kl_weight"], max_batch=64, device=device)
+                                f_units=p["f_units"], h_units=p["h_units"], kl_weight=p["kl_weight"], max_batch=64,
+                                norm_mode={"batch": 0, "fixed": 1}[p.get("bnn_norm", "batch")], device=device)
         self.engine.begin(self.nets)
         if self.timestamp is None:
             self.timestamp = datetime.datetime.now().astimezone().strftime('%Y%m%d_%H%M%S')

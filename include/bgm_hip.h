@@ -411,6 +411,10 @@ typedef struct {
   int32_t units[4][BGM_MAX_LAYERS];              /* params['g_units'], ['e_units'], ['f_units'], ['h_units']      */
   float kl_weight;                               /* params['kl_weight'], base.py:171-173                          */
   int32_t max_batch;                             /* largest minibatch of the step kernels (<= 64)                 */
+  int32_t norm_mode;                             /* input BatchNormalization: 0 = statistics of the batch at hand (the
+                                                    reference as written: inner layer called inside call(training=True));
+                                                    1 = fixed mean 0 / variance 1 (inference mode on never-updated moving
+                                                    averages: the alternative reading, keeps a constant treatment column) */
 } bgm_bnn_config;
 
 /* Open a session.  theta_host: `count` floats in the layout above (count from bgm_bnn_layout). */

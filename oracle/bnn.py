@@ -58,8 +58,11 @@ def init_bnn(rs, dims, dtype=np.float32):
 
 
 def cast_bnn(net, dtype):
-    return {"gamma": net["gamma"].astype(dtype), "beta": net["beta"].astype(dtype),
-            "layers": [tuple(a.astype(dtype) for a in L) for L in net["layers"]]}
+    out = {"gamma": net["gamma"].astype(dtype), "beta": net["beta"].astype(dtype),
+           "layers": [tuple(a.astype(dtype) for a in L) for L in net["layers"]]}
+    if "norm" in net:
+        out["norm"] = net["norm"]
+    return out
 
 
 def init_model(seed, z_dims, v_dim, binary_treatment=False, g_units=(64,) * 5, e_units=(64,) * 5,
@@ -144,6 +147,8 @@ def forward(net, x, noise, stats=None):
     """One call of BayesianFullyConnectedNet (bnn.py:24-38) on the batch x.  `stats` overrides the batch
     statistics (the multi-workgroup kernels receive them from a reduction pass).  Returns (out, cache)."""
     t = x.dtype.type
+    if stats is None and net.get("norm") == "fixed":      # build option bnn_norm="fixed": mean 0 / variance 1
+        stats = (np.zeros(x.shape[1], x.dtype), np.ones(x.shape[1], x.dtype))
     mu, var = batch_stats(x) if stats is None else stats
     inv = 1.0 / np.sqrt(var + t(BN_EPS))
     xhat = (x - mu) * inv

@@ -357,3 +357,41 @@ def test_two_rank_fit_and_predict_with_bayesian_nets():
     adrf, interval = m.predict((x, y, v), alpha=0.05, n_mcmc=30, burn_in=30, x_values=np.linspace(0, 3, 6), q_sd=0.5, bs=256, verbose=0)
     assert np.abs(np.array(two["adrf_untrained"]) - adrf).max() <= 1e-5
     assert np.abs(np.array(two["interval_untrained"]) - interval.ravel()).max() <= 1e-5
+
+
+def test_fixed_statistics_mode_matches_oracle():
+    """Build option bnn_norm="fixed" (mean 0 / variance 1 instead of the batch statistics): steps and log-posterior."""
+    from bayesgm_amd.bnn_engine import BnnEngine
+    m = _model(False, p=50)
+    for k in ("g", "e", "f", "h"):
+        m[k]["norm"] = "fixed"
+    z, x, y, v = _panel(m, 300)
+    eng = BnnEngine(m["v_dim"], m["z_dims"], False, kl_weight=0.01, max_batch=32, norm_mode=1)
+    eng.begin(m)
+    dev = eng.device
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    B, seed, stream = 32, 777, 3
+    idx = np.random.RandomState(0).choice(300, B, replace=False).astype(np.int32)
+    m64 = OB.cast_model(m, np.float64)
+    f64 = lambda a: a.astype(np.float64)
+    eng.theta_step(T(z), T(idx), T(x[:, 0]), T(y[:, 0]), T(v), 1e-3, seed, stream, apply=False)
+    grad = eng.split(eng.read(1))
+    for name in ("g", "h", "f"):
+        noise = OB.draw_noise(OB.net_dims(m[name]), B, seed, stream, OB.NET_ID[name], dtype=np.float64)
+        _, _, g = OB.theta_step(m64, name, f64(z[idx]), f64(x[idx]), f64(y[idx]), f64(v[idx]), noise, 0.01)
+        got = [grad[name]["gamma"], grad[name]["beta"]] + [a for L in grad[name]["layers"] for a in L]
+        for a, b in zip(got, OB.flat_grads(g)):
+            assert _rel(a, b) < 2e-3, (name, a.shape, _rel(a, b))
+    dz = torch.zeros(B, 10, device=dev)
+    eng.z_step(T(x[:, 0]), T(y[:, 0]), T(v), T(z), None, None, T(idx), 1e-3, seed, stream + 4, dz_out=dz)
+    noises = {k: tuple(OB.draw_noise(OB.net_dims(m[k]), B, seed, stream + 4 + c, OB.NET_ID[k], dtype=np.float64) for c in (0, 1))
+              for k in ("g", "h", "f")}
+    _, ref = OB.z_step(m64, f64(z[idx]), f64(x[idx]), f64(y[idx]), f64(v[idx]), noises)
+    assert _rel(dz.cpu().numpy(), ref) < 2e-3
+    got = eng.logpost(T(x[:, 0]), T(y[:, 0]), T(v), T(z), 128, seed, 9).cpu().numpy()
+    ref = OB.log_posterior_blocks(m64, f64(x), f64(y), f64(v), f64(z), 128, seed, 9)
+    assert np.abs(got - ref).max() < 2e-3 * np.abs(ref).max()
+    # a constant treatment column is no longer normalised away: the dose moves the outcome net's prediction
+    xs = np.array([0.0, 3.0], np.float32)
+    _, _, dose = eng.evaluate(T(x[:, 0]), T(y[:, 0]), T(v), T(z), x_values=xs, seed=seed, stream_id=20)
+    eng.close()
