@@ -165,6 +165,23 @@ class BnnEngine(object):
         a.ite_dev = ite.data_ptr() if ite is not None else None
         _lib.check(self.lib.bgm_bnn_mh_run(self.h, C.byref(a), self._stream()), "bgm_bnn_mh_run")
 
+    def effects(self, draws, block_rows, seed, it0=0, x_values=None, sample_y=True, row_base=0, block0=0):
+        """infer_from_latent_posterior (base.py:671-763) for draws [n_keep, n, q] on the device: binary -> ITE draws [n_keep, n];
+        continuous -> ADRF draws [n_doses, n_keep] (mean over the n rows)."""
+        draws = _f32(draws, self.device)
+        n_keep, n, _ = draws.shape
+        if self.binary:
+            ite = torch.empty((n, n_keep), device=self.device, dtype=torch.float32)
+            _lib.check(self.lib.bgm_bnn_effects(self.h, _ptr(draws), n, int(block_rows), int(block0), int(row_base), n_keep, int(it0),
+                                                int(seed), 2, int(bool(sample_y)), None, 0, None, _ptr(ite), self._stream()), "bgm_bnn_effects")
+            return ite.t().contiguous()
+        xv = _f32(np.atleast_1d(np.asarray(x_values, dtype=np.float32)), self.device)
+        sums = torch.zeros((xv.numel(), n_keep), device=self.device, dtype=torch.float64)
+        _lib.check(self.lib.bgm_bnn_effects(self.h, _ptr(draws), n, int(block_rows), int(block0), int(row_base), n_keep, int(it0),
+                                            int(seed), 1, int(bool(sample_y)), _ptr(xv), xv.numel(), _ptr(sums), None, self._stream()),
+                   "bgm_bnn_effects")
+        return (sums / float(n)).float()
+
     def evaluate(self, x, y, v, z=None, x_values=None, seed=0, stream_id=0, want_sums=True, want_effects=True):
         """evaluate (base.py:534-570) on device tensors; z=None -> z = e(v) (returned).
         Returns (z, sums fp64[3] or None, causal): causal = dose sums fp64 [n_doses] (continuous) / ITE [n] (binary) / None."""

@@ -333,3 +333,53 @@ extern "C" int bgm_bnn_evaluate(bgm_handle *h, const float *x, const float *y, c
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
 }
+
+extern "C" int bgm_bnn_effects(bgm_handle *h, const float *draws, int64_t n, int32_t block_rows, int32_t block0, int64_t row_base,
+                               int32_t n_keep, int32_t it0, uint64_t seed, int32_t effect, int32_t sample_y, const float *x_values,
+                               int32_t n_doses, double *adrf_sum, float *ite, void *stream_) {
+  BnnState *s; BnsPlan pl;
+  int rc = bns_session(h, "bgm_bnn_effects", s, pl);
+  if (rc) return rc;
+  if (!draws || n < 1 || block_rows < 2 || n_keep < 1 || (effect != 1 && effect != 2)) { bgm_set_error("bgm_bnn_effects: bad argument"); return BGM_E_INVALID; }
+  if (effect == 1 && (!x_values || n_doses < 1 || !adrf_sum)) { bgm_set_error("bgm_bnn_effects: ADRF needs x_values_dev and adrf_sum_dev"); return BGM_E_INVALID; }
+  if (effect == 2 && !ite) { bgm_set_error("bgm_bnn_effects: ITE needs ite_dev"); return BGM_E_INVALID; }
+  hipStream_t stream = (hipStream_t)stream_;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  const int bs = block_rows, n_blocks = (int)((n + bs - 1) / bs), q = s->q;
+  const int nd = effect == 1 ? n_doses : 2;
+  BnsBuf b;
+  rc = bns_buffers(h, s, pl, n, n_blocks, (long long)n_blocks * nd * pl.set_f, b, stream);
+  if (rc) return rc;
+  rc = bns_set_lds(bns_effects_kernel, pl.lds_bytes);
+  if (rc) return rc;
+  if (effect == 2) {
+    static const float pair_host[2] = {1.0f, 0.0f};
+    BGM_HIP_CHECK(hipMemcpyAsync(b.pair, pair_host, sizeof(pair_host), hipMemcpyHostToDevice, stream));
+  }
+  BnsEffArgs ea{};
+  ea.f = pl.net[BNN_F]; ea.f.dbase = 0;
+  ea.theta = s->theta_dev; ea.lf = b.lf; ea.dw = b.dw; ea.set_floats = pl.set_f;
+  ea.n = n; ea.row_base = row_base; ea.q = q; ea.z0 = s->cfg.z_dims[0]; ea.z1 = s->cfg.z_dims[1];
+  ea.bs = bs; ea.wg_per_block = (bs + BNS_ROWS - 1) / BNS_ROWS; ea.block0 = block0; ea.n_doses = nd;
+  ea.xvals = effect == 1 ? x_values : b.pair;
+  ea.k0 = (uint32_t)seed; ea.k1 = (uint32_t)(seed >> 32); ea.sample_y = sample_y;
+  BnsPropArgs pa{};
+  pa.zprop = b.zprop; pa.n = n; pa.row_base = row_base; pa.q = q; pa.bs = bs; pa.wg_per_block = (bs + 255) / 256; pa.q_sd = 0.0f;
+  pa.k0 = ea.k0; pa.k1 = ea.k1; pa.stats = b.stats; pa.n_blocks = n_blocks;
+  for (int d = 0; d < n_keep; ++d) {
+    const float *z = draws + (long long)d * n * q;
+    pa.z = z; pa.it = d; pa.par = d & 1;                      // statistics of this draw (slot 1 of parity d & 1)
+    hipLaunchKernelGGL(bns_propose_kernel, dim3(n_blocks * pa.wg_per_block), dim3(256), 0, stream, pa);
+    BnsNoiseArgs na{};
+    na.net[0] = ea.f; na.n_nets = 1; na.n_calls = nd; na.sf = b.sf; na.dw = b.dw; na.set_floats = pl.set_f;
+    na.k0 = ea.k0; na.k1 = ea.k1; na.stream0 = 0x40000000u + (uint32_t)d * (uint32_t)nd; na.stream_stride = 1u; na.block0 = block0;
+    hipLaunchKernelGGL(bns_noise_kernel, dim3(2, n_blocks * nd), dim3(256), 0, stream, na);
+    ea.z = z; ea.stats = b.stats + (long long)(d & 1) * n_blocks * 256;
+    ea.stream0 = na.stream0; ea.it_noise = (uint32_t)(it0 + d);
+    ea.sum_out = effect == 1 ? adrf_sum + d : nullptr; ea.sum_stride = n_keep;
+    ea.ite_out = effect == 2 ? ite + d : nullptr; ea.ite_stride = n_keep;
+    hipLaunchKernelGGL(bns_effects_kernel, dim3(n_blocks * ea.wg_per_block), dim3(BNS_THREADS), pl.lds_bytes, stream, ea);
+  }
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}

@@ -394,8 +394,14 @@ class CausalBGMBayes(CausalBGM):
         return draws.cpu().numpy()
 
     def infer_from_latent_posterior(self, data_posterior_z, x_values=None, sample_y=True, eps=1e-6, seed=None):
-        raise NotImplementedError("bayesgm_amd: with use_bnn=True the causal effects are computed inside predict() "
-                                  "(the stand-alone form on a given draw tensor is not built)")
+        """Causal effects from posterior draws of Z, shape (n_keep, n, q) (base.py:671-763): the n rows are ONE block, as in the
+        reference's call; binary -> ITE draws (n_keep, n); continuous -> ADRF draws (len(x_values), n_keep)."""
+        if not self._p["binary_treatment"] and x_values is None:
+            raise ValueError("For continuous treatment, `x_values` must not be None. Provide a list or numpy array.")
+        draws = self._dev(data_posterior_z)
+        out = self.engine.effects(draws, max(2, draws.shape[1]), self._next_seed() if seed is None else seed, x_values=x_values,
+                                  sample_y=sample_y)
+        return out.cpu().numpy()
 
     def get_log_posterior(self, data_x, data_y, data_v, data_z, eps=1e-6):
         """log p(z | x, y, v) + const, shape (n,) (base.py:765-817): one noisy call of g, h, f on the rows given."""

@@ -495,6 +495,13 @@ typedef struct {
  * g/h/f forward of both states + accept).  Noise streams: 2 it (proposal), 2 it + 1 (current state);
  * effects of kept draw d at dose k: stream 0x40000000 + d * n_doses + k (ITE: k = 0 for x = 1, 1 for x = 0). */
 int bgm_bnn_mh_run(bgm_handle *h, const bgm_bnn_mh_args *args, void *stream);
+/* replaces: infer_from_latent_posterior with use_bnn, base.py:671-763, on a given draw tensor draws_dev [n_keep x n x q]
+ * (the stand-alone form; bgm_bnn_mh_run computes the same quantities for the draws it keeps).  Draw d uses the outcome-noise
+ * iteration it0 + d and the Flipout streams 0x40000000 + d * n_doses + k.  effect = 1: adrf_sum_dev [n_doses x n_keep] (fp64,
+ * sums over the n rows, accumulated); effect = 2: ite_dev [n x n_keep]. */
+int bgm_bnn_effects(bgm_handle *h, const float *draws_dev, int64_t n, int32_t block_rows, int32_t block0, int64_t row_base,
+                    int32_t n_keep, int32_t it0, uint64_t seed, int32_t effect, int32_t sample_y, const float *x_values_dev,
+                    int32_t n_doses, double *adrf_sum_dev, float *ite_dev, void *stream);
 /* replaces: evaluate with use_bnn, base.py:534-570 (the whole panel of n rows is ONE batch), and the Z initialisation
  * data_z = e_net(data_v) of fit, base.py:479.  encode = 1: z_dev [n x q] is WRITTEN with e(v) first (noise stream
  * stream_id); otherwise it is read.  sums_dev (optional, fp64 [3]): sums over rows of (v - v^)^2 (all p columns),

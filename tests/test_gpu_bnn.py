@@ -199,6 +199,10 @@ def test_mh_effects_match_oracle(binary):
                draws=draws, n_keep=keep, effect=2 if binary else 1, sample_y=True, x_values=None if binary else T(xs),
                adrf_sum=None if binary else adrf, ite=ite if binary else None)
     dr = draws.cpu().numpy()
+    # the stand-alone form on the kept draws gives the same effects as the fused pass
+    alone = eng.effects(draws, bs, seed, it0=burn, x_values=None if binary else xs, sample_y=True, row_base=40, block0=1).cpu().numpy()
+    fused = ite.t().cpu().numpy() if binary else (adrf / n).float().cpu().numpy()
+    assert np.abs(alone - fused).max() < 1e-5
     init = OB.R.normals(np.arange(40, 40 + n), 0, z.shape[1], OB.R.TAG_INIT, seed)
     assert np.abs(dr[-1] - state.cpu().numpy()).max() == 0.0
     assert np.abs(dr[0] - init).max() < 10.0 and np.abs(dr[0] - dr[-1]).max() > 0.0
@@ -334,6 +338,8 @@ def test_model_surface_with_bayesian_nets(tmp_path, binary):
     assert draws.shape == (6, 100, 10) and np.isfinite(draws).all()
     lp = model.get_log_posterior(x[:100], y[:100], v[:100], draws[-1])
     assert lp.shape == (100,) and np.isfinite(lp).all()
+    eff_alone = model.infer_from_latent_posterior(draws, x_values=None if binary else [0.5, 1.5])
+    assert eff_alone.shape == ((6, 100) if binary else (2, 6)) and np.isfinite(eff_alone).all()
     # adaptive proposal scale
     model.predict((x, y, v), alpha=0.05, n_mcmc=10, burn_in=120, x_values=None if binary else [1.0], q_sd=-1, bs=300, verbose=0)
 
