@@ -80,15 +80,17 @@ extern "C" int bgm_bnn_begin(bgm_handle *h, const bgm_bnn_config *cfg, const flo
   }
   s->wmax = wmax;
   const long long gather = (long long)B * (s->q + s->p + 2 + s->net[BNN_F].dims[0] + s->net[BNN_H].dims[0]) + 64;
-  s->ws_floats = (size_t)(gather + 6LL * B * wmax + 64 + 2 * cache_max);
+  s->ws_stride = (gather + 6LL * B * wmax + 64 + 2 * cache_max + 63) & ~63LL;      // one slice per workgroup (net)
+  s->ws_floats = (size_t)(3 * s->ws_stride);
   const size_t np = ((size_t)s->n_params + 63) & ~(size_t)63;
-  const size_t total = 4 * np + s->ws_floats + 64 + (size_t)B * s->q + 64;
+  const size_t total = 4 * np + s->ws_floats + 64 + 4 * ((size_t)B * s->q + 64);
   BGM_HIP_CHECK(hipMalloc((void **)&s->dev, sizeof(float) * total));
   BGM_HIP_CHECK(hipMemset(s->dev, 0, sizeof(float) * total));
   s->theta_dev = s->dev; s->m_dev = s->dev + np; s->v_dev = s->dev + 2 * np; s->grad_dev = s->dev + 3 * np;
   s->ws_dev = s->dev + 4 * np;
   s->out_dev = s->ws_dev + s->ws_floats;
   s->dz_dev = s->out_dev + 64;
+  s->dz_part_dev = s->dz_dev + (size_t)B * s->q + 64;      // [3][B x q] + 3 loss partials
   BGM_HIP_CHECK(hipMemcpy(s->theta_dev, theta_host, sizeof(float) * count, hipMemcpyHostToDevice));
   s->t_theta = 0; s->t_z = 0;
   return BGM_OK;
@@ -162,7 +164,8 @@ static void bnn_base_args(BnnState *s, BnnArgs &a, int batch, int batch_global, 
   a.inv_B = 1.0f / (float)(batch_global > 0 ? batch_global : batch);
   // data parallel: every rank adds its share of the KL term, the all-reduce (sum) restores kl_weight * KL
   if (batch_global > batch) a.kl_weight = s->cfg.kl_weight * (float)batch / (float)batch_global;
-  a.ws = s->ws_dev;
+  a.ws = s->ws_dev; a.ws_stride = s->ws_stride;
+  a.dz_part = s->dz_part_dev; a.loss_part = s->dz_part_dev + 3 * (size_t)s->cfg.max_batch * s->q;
 }
 
 extern "C" int bgm_bnn_theta_step(bgm_handle *h, const float *data_z, const int32_t *idx, const float *x, const float *y,
@@ -179,7 +182,7 @@ extern "C" int bgm_bnn_theta_step(bgm_handle *h, const float *data_z, const int3
   a.data_z = data_z; a.idx = idx; a.x_ = x; a.y_ = y; a.v_ = v;
   a.apply = apply; a.out = out;
   if (apply) { s->t_theta += 1; a.adam = BnnAdam{adam_lr_t(lr_theta, s->t_theta), BNN_ADAM_B1, BNN_ADAM_B2, BNN_ADAM_EPS}; }
-  hipLaunchKernelGGL(bnn_theta_step_kernel, dim3(1), dim3(BNN_THREADS), 0, (hipStream_t)stream_, a);
+  hipLaunchKernelGGL(bnn_theta_step_kernel, dim3(3), dim3(BNN_THREADS), 0, (hipStream_t)stream_, a);
   BGM_HIP_CHECK(hipGetLastError());
   if (apply) s->packed_valid = false;
   return BGM_OK;
@@ -217,7 +220,8 @@ extern "C" int bgm_bnn_z_step(bgm_handle *h, const float *x, const float *y, con
   bnn_base_args(s, a, batch, batch_global, seed, stream_id);
   a.data_z = data_z; a.idx = idx; a.x_ = x; a.y_ = y; a.v_ = v;
   a.out = out; a.dz = dz_out ? dz_out : s->dz_dev;
-  hipLaunchKernelGGL(bnn_z_grad_kernel, dim3(1), dim3(BNN_THREADS), 0, stream, a);
+  hipLaunchKernelGGL(bnn_z_grad_kernel, dim3(3), dim3(BNN_THREADS), 0, stream, a);
+  hipLaunchKernelGGL(bnn_z_combine_kernel, dim3((batch * s->q + 255) / 256), dim3(256), 0, stream, a.dz_part, a.loss_part, a.dz, out, batch * s->q);
   BGM_HIP_CHECK(hipGetLastError());
   if (dz_out) return BGM_OK;    // gradient only (parity tests)
   s->t_z += 1;

@@ -337,7 +337,9 @@ struct BnnArgs {
   BnnAdam adam;
   int apply;                             // 1: Adam on g, h, f inside the kernel; 0: gradients stay in grad
   float inv_B;                           // 1 / global batch (data-parallel steps divide by the global batch)
-  float *ws;                             // workspace
+  float *ws;                             // workspace (one slice of ws_stride floats per workgroup)
+  long long ws_stride;
+  float *dz_part, *loss_part;            // z step: per-net partials [3][B x q], [3] (summed by bnn_z_combine_kernel)
   float *out;                            // theta: [loss_v, mse_v, loss_x, aux_x, loss_y, mse_y];  z: [loss_posterior]
   float *dz;                             // z step: [B x q] gradient w.r.t. the batch rows of data_z
 };
@@ -371,19 +373,20 @@ __device__ __forceinline__ float bnn_gauss(float ssq, float raw, float dim, floa
 }
 
 // update_g_net, update_h_net, update_f_net (causalbgm/base.py:156-243) with use_bnn: the three updates are independent
-// given the batch (each reads the latents of BEFORE the step), so one launch does all three.
+// given the batch (each reads the latents of BEFORE the step), so one launch does all three, one workgroup per net.
 static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_step_kernel(BnnArgs a) {
   __shared__ float red[32];
   __shared__ float ssq_row[64];
   BnnCtx c{(int)threadIdx.x, red};
   const int B = a.B, p = a.p;
-  float *wp = a.ws;
+  float *wp = a.ws + (long long)blockIdx.x * a.ws_stride;
   auto take = [&](int n) { float *r = wp; wp += (n + 3) & ~3; return r; };
   BnnBatch bt;
   bnn_gather(c, a, wp, bt);
   float *d = take(B * a.wmax), *ds = take(B * a.wmax), *t0 = take(B * a.wmax), *t1 = take(B * a.wmax);
   float *cache_base = wp;
-  for (int which = 0; which < 3; ++which) {
+  {   // grid = 3 workgroups: g, h, f are independent given the batch
+    const int which = blockIdx.x;
     const int id = which == 0 ? BNN_G : (which == 1 ? BNN_H : BNN_F);
     const BnnNet &n = a.net[id];
     wp = cache_base;
@@ -449,17 +452,24 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_z_grad_kernel(BnnArgs 
   __shared__ float ssq_row[64];
   BnnCtx c{(int)threadIdx.x, red};
   const int B = a.B, p = a.p, q = a.q;
-  float *wp = a.ws;
+  float *wp = a.ws + (long long)blockIdx.x * a.ws_stride;
   auto take = [&](int n) { float *r = wp; wp += (n + 3) & ~3; return r; };
   BnnBatch bt;
   bnn_gather(c, a, wp, bt);
   float *d = take(B * a.wmax), *ds = take(B * a.wmax), *t0 = take(B * a.wmax), *t1 = take(B * a.wmax);
   float *dx1 = take(B * a.wmax), *dx2 = take(B * a.wmax);
   float *cache_base = wp;
+  // grid = 3 workgroups (g, h, f); each writes its share of the gradient and of the loss, workgroup 0 also the prior term
+  const int which = blockIdx.x;
+  float *dzp = a.dz_part + (long long)which * B * q;
   float total = 0.0f;
-  for (int i = c.tid; i < B * q; i += BNN_THREADS) { const float z = bt.zb[i]; a.dz[i] = z * a.inv_B; total += 0.5f * z * z; }
+  for (int i = c.tid; i < B * q; i += BNN_THREADS) {
+    const float z = bt.zb[i];
+    dzp[i] = which == 0 ? z * a.inv_B : 0.0f;
+    if (which == 0) total += 0.5f * z * z;
+  }
   total = bnn_block_sum(c, total) * a.inv_B;
-  for (int which = 0; which < 3; ++which) {
+  {
     const int id = which == 0 ? BNN_G : (which == 1 ? BNN_H : BNN_F);
     const BnnNet &n = a.net[id];
     wp = cache_base;
@@ -527,11 +537,18 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_z_grad_kernel(BnnArgs 
       if (id == BNN_G) col = j;
       else if (id == BNN_F) col = (j < a.z0 + a.z1) ? j : -1;
       else col = (j < a.z0) ? j : j + a.z1;
-      if (col >= 0) a.dz[b * q + col] += v;     // one thread per (b, col) within a net; nets are serialised by barriers
+      if (col >= 0) dzp[b * q + col] += v;      // one thread per (b, col)
     }
     __syncthreads();
   }
-  if (c.tid == 0 && a.out) a.out[0] = total;
+  if (c.tid == 0) a.loss_part[which] = total;
+}
+
+// dz = sum of the three per-net partials; loss_postrior_z likewise
+static __global__ void bnn_z_combine_kernel(const float *dz_part, const float *loss_part, float *dz, float *out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dz[i] = dz_part[i] + dz_part[n + i] + dz_part[2 * n + i];
+  if (i == 0 && out) out[0] = loss_part[0] + loss_part[1] + loss_part[2];
 }
 
 // Adam on the [N x q] latent table, Keras `_resource_apply_sparse` semantics (oracle/fit.py adam_rows):

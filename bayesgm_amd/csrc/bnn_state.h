@@ -15,7 +15,8 @@ struct BnnState {
   int n_params = 0, q = 0, p = 0, wmax = 0;
   float *dev = nullptr;        // one allocation: theta | m | v | grad | workspace | out | dz
   float *theta_dev = nullptr, *m_dev = nullptr, *v_dev = nullptr, *grad_dev = nullptr, *ws_dev = nullptr, *out_dev = nullptr,
-        *dz_dev = nullptr;
+        *dz_dev = nullptr, *dz_part_dev = nullptr;
+  long long ws_stride = 0;
   size_t ws_floats = 0;
   long long t_theta = 0, t_z = 0;
   // large-batch (sampling / evaluation) side: packed kernels and per-call perturbations, rebuilt when theta changes
