@@ -49,6 +49,13 @@ class CausalBGMBayes(CausalBGM):
         for k in ("sigma_v", "sigma_x", "sigma_y"):
             if k in params:
                 raise NotImplementedError("bayesgm_amd: fixed %s together with use_bnn=True is not built" % k)
+        if p.get("bnn_norm", "batch") not in ("batch", "fixed"):
+            raise ValueError("params['bnn_norm'] must be 'batch' or 'fixed'")
+        if p.get("bnn_norm", "batch") == "batch":
+            import warnings
+            warnings.warn("bayesgm_amd: use_bnn=True with the reference's input BatchNormalization on batch statistics: a counterfactual "
+                          "treatment column that is constant over the batch is normalised away, so ADRF / ITE estimates do not depend on "
+                          "the treatment value (DESIGN.md section 7); params['bnn_norm'] = 'fixed' selects the other reading.", stacklevel=3)
         self._rs = np.random.RandomState(random_seed) if random_seed is not None else np.random.RandomState()
         if random_seed is not None:
             np.random.seed(random_seed)
