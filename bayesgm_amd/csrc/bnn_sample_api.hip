@@ -36,9 +36,10 @@ static bool bns_plan(const BnnState *s, BnsPlan &pl) {
     if (n.n_layers < 2 || n.swords > BNS_SW || n.K[0] > BNS_MAXK) return false;
     for (int l = 0; l < n.n_layers; ++l) {
       if (l < n.n_layers - 1 && n.K[l + 1] > 16 * BNS_MAXT) return false;
-      if (16 * n.MT[l] > BNS_MAXB) return false;
+
       maxfrag = std::max(maxfrag, n.T[l] * n.MT[l] * 256);
     }
+    { int bsum = 0; for (int l = 0; l < n.n_layers; ++l) bsum += 16 * n.MT[l]; if (bsum > BNS_MAXB) return false; }
     n.fbase = (int)fb;
     fb += n.foff[n.n_layers];
   }

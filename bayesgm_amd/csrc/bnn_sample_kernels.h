@@ -32,7 +32,7 @@
 #define BNS_MAXT 4        // hidden widths <= 64
 #define BNS_SW 32         // sign words reserved per row in LDS
 #define BNS_MAXK 208      // widest network input (padded)
-#define BNS_MAXB 512      // widest layer output (padded), bias staged in LDS
+#define BNS_MAXB 1024     // all biases of a net (each layer padded to whole tiles), staged in LDS
 
 struct BnsNet {
   int n_layers, net_id, bn_fixed;
@@ -234,6 +234,15 @@ __device__ __forceinline__ void bns_forward(const BnsCtx &c, const BnsNet &n, co
       }
       c.bn[u] = sc; c.bn[BNS_MAXK + u] = sh;
     }
+    {   // all biases of the net (layer l at 16 * (MT[0] + ... + MT[l-1])): unconditional loads, nothing waits in a loop
+      int bo = 0;
+      for (int l = 0; l < L; ++l) {
+        const float *bias = theta + n.woff[l] + 2 * n.K[l] * n.K[l + 1];
+        const int M = n.K[l + 1];
+        for (int o = c.tid; o < 16 * n.MT[l]; o += BNS_THREADS) c.bn[2 * BNS_MAXK + bo + o] = bias[min(o, M - 1)] * (o < M ? 1.0f : 0.0f);
+        bo += 16 * n.MT[l];
+      }
+    }
     const int calls = n.swords >> 2;
 #pragma unroll
     for (int rt = 0; rt < BNS_R; ++rt) {
@@ -261,12 +270,14 @@ __device__ __forceinline__ void bns_forward(const BnsCtx &c, const BnsNet &n, co
     const f32x4 *s1 = (const f32x4 *)lf, *s2 = (const f32x4 *)dw;
     f32x4 *d = (f32x4 *)c.stage;
     __syncthreads();
-    for (int i = c.tid; i < (n.foff[L] >> 2); i += BNS_THREADS) { d[i] = s1[i]; d[BNS_CHUNK * 64 + i] = s2[i]; }
-    int bo = 0;
-    for (int l = 0; l < L; ++l) {
-      const float *bias = theta + n.woff[l] + 2 * n.K[l] * n.K[l + 1];
-      for (int o = c.tid; o < 16 * n.MT[l]; o += BNS_THREADS) c.bn[2 * BNS_MAXK + bo + o] = (o < n.K[l + 1]) ? bias[o] : 0.0f;
-      bo += 16 * n.MT[l];
+    {
+      constexpr int PF = (BNS_CHUNK * 64 + BNS_THREADS - 1) / BNS_THREADS;
+      const int cnt = n.foff[L] >> 2;
+      f32x4 v1[PF], v2[PF];
+#pragma unroll
+      for (int u = 0; u < PF; ++u) { const int i = min(c.tid + u * BNS_THREADS, cnt - 1); v1[u] = s1[i]; v2[u] = s2[i]; }
+#pragma unroll
+      for (int u = 0; u < PF; ++u) { const int i = c.tid + u * BNS_THREADS; if (i < cnt) { d[i] = v1[u]; d[BNS_CHUNK * 64 + i] = v2[u]; } }
     }
     __syncthreads();
     BNS_T(c, 1);
@@ -274,7 +285,6 @@ __device__ __forceinline__ void bns_forward(const BnsCtx &c, const BnsNet &n, co
   int bias_off = 0;
   for (int l = 0; l < L; ++l) {
     const int T = n.T[l], MT = n.MT[l], M = n.K[l + 1];
-    const float *bias = theta + n.woff[l] + 2 * n.K[l] * M;
     // Stage the fragments (mt0 .., t0 ..) of this layer: pair (mt, t) lands at ((mt - mt0) * nt + (t - t0)) * 64 + lane.
     // Chunks of at most BNS_CHUNK pairs keep the stage at 32 KB, so that two workgroups share a CU and one computes
     // while the other waits for its fragments.
@@ -285,18 +295,26 @@ __device__ __forceinline__ void bns_forward(const BnsCtx &c, const BnsNet &n, co
       const int cnt = nmt * nt * 64;
       BNS_T(c, (l == 0 ? 2 : (l == L - 1 ? 4 : 3)));
       __syncthreads();
-      for (int i = c.tid; i < cnt; i += BNS_THREADS) {
-        const int pair = i >> 6, mt = mt0 + pair / nt, t = t0 + pair % nt;
-        const int src = (mt * T + t) * 64 + (i & 63);
-        d[i] = s1[src]; d[BNS_CHUNK * 64 + i] = s2[src];
+      if (nt == T) {            // whole output tiles: one contiguous run of fragments; all loads in flight before the writes
+        const f32x4 *r1 = s1 + mt0 * T * 64, *r2 = s2 + mt0 * T * 64;
+        constexpr int PF = (BNS_CHUNK * 64 + BNS_THREADS - 1) / BNS_THREADS;
+        f32x4 v1[PF], v2[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) { const int i = min(c.tid + u * BNS_THREADS, cnt - 1); v1[u] = r1[i]; v2[u] = r2[i]; }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) { const int i = c.tid + u * BNS_THREADS; if (i < cnt) { d[i] = v1[u]; d[BNS_CHUNK * 64 + i] = v2[u]; } }
+      } else {
+        for (int i = c.tid; i < cnt; i += BNS_THREADS) {
+          const int pair = i >> 6, mt = mt0 + pair / nt, t = t0 + pair % nt;
+          const int src = (mt * T + t) * 64 + (i & 63);
+          d[i] = s1[src]; d[BNS_CHUNK * 64 + i] = s2[src];
+        }
       }
-      if (mt0 == 0 && t0 == 0)
-        for (int o = c.tid; o < 16 * MT; o += BNS_THREADS) c.bn[2 * BNS_MAXK + o] = (o < M) ? bias[o] : 0.0f;
       __syncthreads();
       BNS_T(c, 1);
     };
     const f32x4 *LF = (const f32x4 *)c.stage + (whole ? (n.foff[l] >> 2) : 0), *DF = LF + BNS_CHUNK * 64;
-    const f32x4 *BL = (const f32x4 *)(c.bn + 2 * BNS_MAXK + (whole ? bias_off : 0));   // bias of unit 16 mt + 4 g + r = BL[4 mt + g][r]
+    const f32x4 *BL = (const f32x4 *)(c.bn + 2 * BNS_MAXK + bias_off);   // bias of unit 16 mt + 4 g + r = BL[4 mt + g][r]
     bias_off += 16 * MT;
     if (l == 0) {
       f32x4 a1[BNS_R][BNS_MAXT], a2[BNS_R][BNS_MAXT];

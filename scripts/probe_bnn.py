@@ -35,6 +35,8 @@ eng.mh_run(x, y, v, state, bs, 0, 2, 0, 1.0, 1, init=True)      # warm-up, packs
 t = timed(lambda: eng.mh_run(x, y, v, state, bs, 2, iters, 0, 1.0, 1))
 macs = sum(a * b for net in ("g", "f", "h") for a, b in zip(OB.net_dims(m[net])[:-1], OB.net_dims(m[net])[1:]))
 flops = 2 * 2 * 2 * macs * N * iters          # two states x two GEMMs per layer
+if __import__("os").environ.get("BNN_PROBE_MH_ONLY"):
+    print("MH only: %.2f ms / iteration" % (1e3 * t / iters)); sys.exit(0)
 print("MH (burn-in) N=%d p=%d bs=%d: %.2f ms / iteration, %.3e transitions/s, %.1f TFLOP/s (Flipout: 4 x %d MAC per row)"
       % (N, p, bs, 1e3 * t / iters, N * iters / t, flops / t / 1e12, macs))
 xs = torch.linspace(0, 3, 20, device=dev)
