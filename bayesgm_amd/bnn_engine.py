@@ -150,7 +150,8 @@ class BnnEngine(object):
         return out
 
     def mh_run(self, x, y, v, state, block_rows, it_begin, n_iters, burn_in, q_sd, seed, init=False, row_base=0, block0=0,
-               acc_count=None, draws=None, n_keep=0, effect=0, sample_y=True, x_values=None, adrf_sum=None, ite=None):
+               acc_count=None, draws=None, n_keep=0, effect=0, sample_y=True, x_values=None, adrf_sum=None, ite=None,
+               q_sd_blocks=None, acc_blocks=None):
         a = _lib.BnnMhArgs()
         a.x_dev, a.y_dev, a.v_dev = x.data_ptr(), y.data_ptr(), v.data_ptr()
         a.n, a.row_base, a.block_rows, a.block0 = state.shape[0], int(row_base), int(block_rows), int(block0)
@@ -163,6 +164,8 @@ class BnnEngine(object):
         a.n_doses = x_values.numel() if x_values is not None else 0
         a.adrf_sum_dev = adrf_sum.data_ptr() if adrf_sum is not None else None
         a.ite_dev = ite.data_ptr() if ite is not None else None
+        a.q_sd_blocks_dev = q_sd_blocks.data_ptr() if q_sd_blocks is not None else None
+        a.acc_blocks_dev = acc_blocks.data_ptr() if acc_blocks is not None else None
         _lib.check(self.lib.bgm_bnn_mh_run(self.h, C.byref(a), self._stream()), "bgm_bnn_mh_run")
 
     def effects(self, draws, block_rows, seed, it0=0, x_values=None, sample_y=True, row_base=0, block0=0):

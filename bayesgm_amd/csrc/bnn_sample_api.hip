@@ -207,7 +207,7 @@ extern "C" int bgm_bnn_mh_run(bgm_handle *h, const bgm_bnn_mh_args *g, void *str
   const int ids[3] = {BNN_G, BNN_H, BNN_F};
   BnsPropArgs pa{};
   pa.z = g->state_dev; pa.zprop = b.zprop; pa.n = n; pa.row_base = g->row_base; pa.q = q; pa.bs = bs;
-  pa.wg_per_block = (bs + 255) / 256; pa.q_sd = g->q_sd;
+  pa.wg_per_block = (bs + 255) / 256; pa.q_sd = g->q_sd; pa.q_sd_blocks = g->q_sd_blocks_dev;
   pa.k0 = (uint32_t)g->seed; pa.k1 = (uint32_t)(g->seed >> 32);
   pa.stats = b.stats; pa.n_blocks = n_blocks; pa.x = g->x_dev; pa.z_init = g->state_dev;
   BnsMhArgs a{};
@@ -230,6 +230,7 @@ extern "C" int bgm_bnn_mh_run(bgm_handle *h, const bgm_bnn_mh_args *g, void *str
     hipLaunchKernelGGL(bns_propose_kernel, dim3(n_blocks * pa.wg_per_block), dim3(256), 0, stream, pa);
     if (i > 0 && kept(it - 1)) effects(it - 1, i & 1);
     a.it = it; a.stats = b.stats + (long long)(i & 1) * n_blocks * 256;
+    a.acc_blocks = g->acc_blocks_dev ? g->acc_blocks_dev + (long long)i * n_blocks : nullptr;
     hipLaunchKernelGGL(bns_mh_kernel, dim3(n_blocks * a.wg_per_block), dim3(BNS_THREADS), pl.lds_bytes, stream, a);
     if (g->draws_dev && it >= g->burn_in && it - g->burn_in < g->n_keep)
       BGM_HIP_CHECK(hipMemcpyAsync(g->draws_dev + (long long)(it - g->burn_in) * n * q, g->state_dev, sizeof(float) * n * q,

@@ -124,6 +124,7 @@ struct BnsPropArgs {
   long long n, row_base;
   int q, bs, wg_per_block, it, init;     // init: z itself is drawn here (iteration-0 state, TAG_INIT) before proposing
   float q_sd;
+  const float *q_sd_blocks;              // optional per-block proposal scale
   uint32_t k0, k1;
   double *stats;                         // [2 parities][n_blocks][2][2][64]
   int n_blocks, par;
@@ -160,7 +161,8 @@ static __global__ __launch_bounds__(256) void bns_propose_kernel(BnsPropArgs a) 
       for (int f = 0; f < q; ++f) zc[f] = a.z[row * q + f];
     }
     bns_row_normals(rid, (uint32_t)a.it, q, TAG_PROP, a.k0, a.k1, e);
-    for (int f = 0; f < q; ++f) { e[f] = fmaf(a.q_sd, e[f], zc[f]); a.zprop[row * q + f] = e[f]; }
+    const float sd = a.q_sd_blocks ? a.q_sd_blocks[blk] : a.q_sd;
+    for (int f = 0; f < q; ++f) { e[f] = fmaf(sd, e[f], zc[f]); a.zprop[row * q + f] = e[f]; }
   }
   for (int f = 0; f < q; ++f) {
     double s[4] = {valid ? (double)e[f] : 0.0, valid ? (double)e[f] * e[f] : 0.0, valid ? (double)zc[f] : 0.0,
@@ -455,6 +457,7 @@ struct BnsMhArgs {
   uint32_t k0, k1, stream0;            // mode 1: streams 2 it (proposal), 2 it + 1 (current); mode 0: stream0
   float *out;                          // mode 0: [n] log-posterior
   unsigned *acc_count;                 // mode 1 (optional): accepted proposals
+  unsigned *acc_blocks;                // mode 1 (optional): accepted proposals of this iteration per block [n_blocks]
   unsigned long long *prof;            // -D BNS_PROF: cycles per phase, summed over workgroups (wave 0)
 };
 
@@ -592,7 +595,7 @@ static __global__ __launch_bounds__(BNS_THREADS, 4) void bns_mh_kernel(BnsMhArgs
       if (c.g == 0) ++nacc;
     }
   }
-  if (a.acc_count) {
+  if (a.acc_count || a.acc_blocks) {
     for (int off = 32; off > 0; off >>= 1) nacc += __shfl_xor(nacc, off);
     __shared__ unsigned acc_part[BNS_WAVES];
     if (c.lane == 0) acc_part[c.wave] = nacc;
@@ -600,7 +603,8 @@ static __global__ __launch_bounds__(BNS_THREADS, 4) void bns_mh_kernel(BnsMhArgs
     if (c.tid == 0) {
       unsigned t = 0;
       for (int w = 0; w < BNS_WAVES; ++w) t += acc_part[w];
-      if (t) atomicAdd(a.acc_count, t);
+      if (t && a.acc_count) atomicAdd(a.acc_count, t);
+      if (t && a.acc_blocks) atomicAdd(&a.acc_blocks[blk], t);
     }
   }
 #ifdef BNS_PROF

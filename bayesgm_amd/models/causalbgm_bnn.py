@@ -12,8 +12,7 @@ mean 0 / variance 1 (inference mode on never-updated moving averages), the alter
 counterfactual treatment column is NOT normalised away.
 
 Stated differences (DESIGN.md "Bayesian nets"): the noise streams are the build's counter-based ones (oracle/bnn.py);
-minibatches are limited to 64 rows; under torch.distributed every rank normalises with the statistics of ITS rows;
-an adaptive proposal scale (q_sd <= 0) is adapted on the acceptance rate of all blocks together.
+minibatches are limited to 64 rows; under torch.distributed every rank normalises with the statistics of ITS rows.
 """
 import datetime
 import os
@@ -297,35 +296,43 @@ class CausalBGMBayes(CausalBGM):
 
     # ------------------------------------------------------------------ predict
     def _run_chains(self, x, y, v, bs, burn_in, n_keep, q_sd, seed, row_base, block0, adaptive, initial_q_sd=1.0, target=0.25,
-                    tol=0.05, adj_int=50, **outs):
-        """All blocks of the given rows in lock step.  Returns (final states, accepted count of the last <= 100 iterations)."""
+                    tol=0.05, adj_int=50, window=100, **outs):
+        """All blocks of the given rows in lock step.  Every block is its own sampler run of the reference
+        (metropolis_hastings_sampler is called once per block, base.py:640-645), so an adaptive proposal scale is kept PER
+        BLOCK: at counter = 50, 100, ... < burn_in the acceptance rate of the block's last `window` iterations decides
+        q_sd *= 0.9 / 1.1 (base.py:873-892).  Returns (final states, accepted proposals of the last <= 100 iterations, that
+        window's length)."""
         eng = self.engine
+        dev = eng.device
         n = x.shape[0]
-        state = torch.empty((n, eng.q), device=eng.device, dtype=torch.float32)
-        acc = torch.zeros(1, device=eng.device, dtype=torch.int32)
+        n_blocks = (n + bs - 1) // bs
+        rows_b = np.minimum(bs, n - bs * np.arange(n_blocks)).astype(np.float64)
+        state = torch.empty((n, eng.q), device=dev, dtype=torch.float32)
         total = burn_in + n_keep
         tail = min(100, total)
-        cur_sd = float(initial_q_sd if adaptive else q_sd)
-        # segment boundaries: after iteration 50, 100, ... of the burn-in (proposal-scale adjustment, base.py:883-894)
-        # and at the start of the acceptance window of the final report
+        sd = torch.full((n_blocks,), float(initial_q_sd if adaptive else q_sd), device=dev, dtype=torch.float32)
         bounds = {total, total - tail}
         if adaptive:
-            bounds |= {c + 1 for c in range(adj_int, burn_in, adj_int)}
+            bounds |= {c + 1 for c in range(adj_int, burn_in, adj_int)}     # adjust after iteration counter = 50, 100, ...
+        hist = np.zeros((0, n_blocks))                                       # accepted proposals per iteration and block
         it, acc_tail = 0, 0
         for b in sorted(b for b in bounds if 0 < b <= total):
             seg = b - it
-            acc.zero_()
-            eng.mh_run(x, y, v, state, bs, it, seg, burn_in, cur_sd, seed, init=(it == 0), row_base=row_base, block0=block0,
-                       acc_count=acc, n_keep=n_keep, **outs)
+            acc = torch.zeros((seg, n_blocks), device=dev, dtype=torch.int32)
+            eng.mh_run(x, y, v, state, bs, it, seg, burn_in, 1.0, seed, init=(it == 0), row_base=row_base, block0=block0,
+                       n_keep=n_keep, q_sd_blocks=sd, acc_blocks=acc, **outs)
+            a = acc.cpu().numpy().astype(np.float64)
             if it >= total - tail:
-                acc_tail += int(acc.item())
+                acc_tail += int(a.sum())
             if adaptive and b <= burn_in and (b - 1) % adj_int == 0:
-                rate = float(acc.item()) / (seg * n)
-                if rate < target - tol:
-                    cur_sd *= 0.9
-                elif rate > target + tol:
-                    cur_sd *= 1.1
+                hist = np.concatenate([hist, a])[-window:]
+                rate = hist.sum(axis=0) / (len(hist) * rows_b)
+                f = np.where(rate < target - tol, 0.9, np.where(rate > target + tol, 1.1, 1.0))
+                sd = sd * torch.from_numpy(f.astype(np.float32)).to(dev)
+            elif adaptive:
+                hist = np.concatenate([hist, a])[-window:]
             it = b
+        self.last_q_sd = sd.cpu().numpy()
         return state, acc_tail, tail
 
     def predict(self, data, alpha=0.01, n_mcmc=3000, burn_in=5000, x_values=None, q_sd=1.0, sample_y=True,
@@ -395,7 +402,7 @@ class CausalBGMBayes(CausalBGM):
         draws = torch.empty((n_keep, n, self.engine.q), device=self.engine.device, dtype=torch.float32)
         _, acc_tail, tail = self._run_chains(self._dev(data_x).reshape(-1), self._dev(data_y).reshape(-1), self._dev(data_v), max(2, n),
                                              burn_in, n_keep, q_sd, self._next_seed(), 0, 0, adaptive_sd, initial_q_sd=initial_q_sd,
-                                             target=target_acceptance_rate, tol=tolerance, adj_int=adjustment_interval, draws=draws)
+                                             target=target_acceptance_rate, tol=tolerance, adj_int=adjustment_interval, window=window_size, draws=draws)
         self.last_acceptance_rate = acc_tail / float(tail * n)
         print(f"Final MCMC Acceptance Rate: {self.last_acceptance_rate:.4f}")
         return draws.cpu().numpy()

@@ -489,6 +489,10 @@ typedef struct {
   int32_t n_doses;
   double *adrf_sum_dev;                /* effect 1: [n_doses x n_keep] sums over the rows of this call (accumulated) */
   float *ite_dev;                      /* effect 2: [n x n_keep]                                                    */
+  const float *q_sd_blocks_dev;        /* optional [n_blocks]: proposal std-dev per block (overrides q_sd): every block
+                                          of the reference is its own sampler run with its own adaptive scale          */
+  uint32_t *acc_blocks_dev;            /* optional [n_iters x n_blocks]: accepted proposals per iteration and block
+                                          (accumulated; the caller's sliding acceptance window, base.py:873-884)       */
 } bgm_bnn_mh_args;
 /* replaces: metropolis_hastings_sampler (fixed q_sd) + infer_from_latent_posterior with use_bnn, base.py:820-904,
  * 671-763.  All blocks advance in lock step, three launches per iteration (perturbations, proposal + statistics,

@@ -342,6 +342,9 @@ def test_model_surface_with_bayesian_nets(tmp_path, binary):
     assert eff_alone.shape == ((6, 100) if binary else (2, 6)) and np.isfinite(eff_alone).all()
     # adaptive proposal scale
     model.predict((x, y, v), alpha=0.05, n_mcmc=10, burn_in=120, x_values=None if binary else [1.0], q_sd=-1, bs=300, verbose=0)
+    # adaptive proposal scale: one value per block (each block is its own sampler run), moved at counter = 50 and 100
+    allowed = np.array([0.81, 0.9, 0.99, 1.0, 1.1, 1.21])
+    assert model.last_q_sd.shape == (2,) and np.all(np.abs(model.last_q_sd[:, None] - allowed[None, :]).min(axis=1) < 1e-5)
 
 
 def test_two_rank_fit_and_predict_with_bayesian_nets():
