@@ -149,7 +149,8 @@ extern "C" int bgm_bnn_logpost(bgm_handle *h, const float *x, const float *y, co
   a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32); a.stream0 = stream_id; a.out = out;
   rc = bns_set_lds(bns_mh_kernel, pl.lds_bytes);
   if (rc) return rc;
-  hipLaunchKernelGGL(bns_mh_kernel, dim3(n_blocks * a.wg_per_block), dim3(BNS_THREADS), pl.lds_bytes, stream, a);
+  a.n_items = n_blocks * a.wg_per_block;
+  hipLaunchKernelGGL(bns_mh_kernel, dim3((a.n_items + 7) & ~7), dim3(BNS_THREADS), pl.lds_bytes, stream, a);
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
 }
@@ -201,7 +202,8 @@ extern "C" int bgm_bnn_mh_run(bgm_handle *h, const bgm_bnn_mh_args *g, void *str
     ea.stream0 = na.stream0; ea.it_noise = (uint32_t)it_kept;
     ea.sum_out = g->effect == 1 ? g->adrf_sum_dev + d : nullptr; ea.sum_stride = g->n_keep;
     ea.ite_out = g->effect == 2 ? g->ite_dev + d : nullptr; ea.ite_stride = g->n_keep;
-    hipLaunchKernelGGL(bns_effects_kernel, dim3(n_blocks * ea.wg_per_block), dim3(BNS_THREADS), pl.lds_bytes, stream, ea);
+    ea.n_items = n_blocks * ea.wg_per_block;
+    hipLaunchKernelGGL(bns_effects_kernel, dim3((ea.n_items + 7) & ~7), dim3(BNS_THREADS), pl.lds_bytes, stream, ea);
   };
   auto kept = [&](int it) { return g->effect && it >= g->burn_in && it - g->burn_in < g->n_keep; };
   const int ids[3] = {BNN_G, BNN_H, BNN_F};
@@ -231,7 +233,8 @@ extern "C" int bgm_bnn_mh_run(bgm_handle *h, const bgm_bnn_mh_args *g, void *str
     if (i > 0 && kept(it - 1)) effects(it - 1, i & 1);
     a.it = it; a.stats = b.stats + (long long)(i & 1) * n_blocks * 256;
     a.acc_blocks = g->acc_blocks_dev ? g->acc_blocks_dev + (long long)i * n_blocks : nullptr;
-    hipLaunchKernelGGL(bns_mh_kernel, dim3(n_blocks * a.wg_per_block), dim3(BNS_THREADS), pl.lds_bytes, stream, a);
+    a.n_items = n_blocks * a.wg_per_block;
+  hipLaunchKernelGGL(bns_mh_kernel, dim3((a.n_items + 7) & ~7), dim3(BNS_THREADS), pl.lds_bytes, stream, a);
     if (g->draws_dev && it >= g->burn_in && it - g->burn_in < g->n_keep)
       BGM_HIP_CHECK(hipMemcpyAsync(g->draws_dev + (long long)(it - g->burn_in) * n * q, g->state_dev, sizeof(float) * n * q,
                                    hipMemcpyDeviceToDevice, stream));
@@ -330,7 +333,8 @@ extern "C" int bgm_bnn_evaluate(bgm_handle *h, const float *x, const float *y, c
     ea.z = z; ea.n = n; ea.row_base = 0; ea.q = s->q; ea.z0 = ev.z0; ea.z1 = ev.z1; ea.bs = (int)n; ea.wg_per_block = wgs; ea.block0 = 0;
     ea.n_doses = nd; ea.xvals = dose_sums ? x_values : b.pair; ea.k0 = ev.k0; ea.k1 = ev.k1; ea.stream0 = stream_id + 1u;
     ea.sample_y = 0; ea.sum_out = dose_sums; ea.sum_stride = 1; ea.ite_out = dose_sums ? nullptr : ite; ea.ite_stride = 1;
-    hipLaunchKernelGGL(bns_effects_kernel, dim3(wgs), dim3(BNS_THREADS), pl.lds_bytes, stream, ea);
+    ea.n_items = wgs;
+    hipLaunchKernelGGL(bns_effects_kernel, dim3((wgs + 7) & ~7), dim3(BNS_THREADS), pl.lds_bytes, stream, ea);
   }
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
@@ -380,7 +384,8 @@ extern "C" int bgm_bnn_effects(bgm_handle *h, const float *draws, int64_t n, int
     ea.stream0 = na.stream0; ea.it_noise = (uint32_t)(it0 + d);
     ea.sum_out = effect == 1 ? adrf_sum + d : nullptr; ea.sum_stride = n_keep;
     ea.ite_out = effect == 2 ? ite + d : nullptr; ea.ite_stride = n_keep;
-    hipLaunchKernelGGL(bns_effects_kernel, dim3(n_blocks * ea.wg_per_block), dim3(BNS_THREADS), pl.lds_bytes, stream, ea);
+    ea.n_items = n_blocks * ea.wg_per_block;
+    hipLaunchKernelGGL(bns_effects_kernel, dim3((ea.n_items + 7) & ~7), dim3(BNS_THREADS), pl.lds_bytes, stream, ea);
   }
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;

@@ -206,6 +206,15 @@ struct BnsCtx {
   float *bn;           // LDS: scale[BNS_MAXK] | shift[BNS_MAXK] | bias of the current layer [BNS_MAXB]
 };
 
+// Workgroup id -> work item such that the workgroups of ONE block of rows (which share a perturbation set and the packed
+// kernels' cache lines) run on ONE XCD: the dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs, so the
+// ids congruent modulo 8 get a contiguous range of work items.  Returns -1 for the padding ids of the last round.
+__device__ __forceinline__ int bns_xcd_item(int total) {
+  const int per = (total + 7) >> 3;
+  const int item = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  return ((int)(blockIdx.x >> 3) < per && item < total) ? item : -1;
+}
+
 __device__ __forceinline__ float bns_flip(float x, uint32_t w, int bit) {
   return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x) ^ ((w >> bit) << 31));
 }
@@ -452,6 +461,7 @@ struct BnsMhArgs {
   const float *zprop;                  // proposals [n x q]
   long long n, row_base;
   int q, p, z0, z1, z2, binary, bs, wg_per_block, block0;
+  int n_items;                         // workgroups' worth of work: n_blocks * wg_per_block (the grid is rounded up to 8)
   int mode;                            // 0: log-posterior of z with the "current" statistics / call slot 0 -> out;  1: MH iteration
   int it;
   uint32_t k0, k1, stream0;            // mode 1: streams 2 it (proposal), 2 it + 1 (current); mode 0: stream0
@@ -555,7 +565,9 @@ static __global__ __launch_bounds__(BNS_THREADS, 4) void bns_mh_kernel(BnsMhArgs
   c.bn = bns_lds;
   c.sg = (uint32_t *)(bns_lds + 2 * BNS_MAXK + BNS_MAXB);
   c.stage = bns_lds + 2 * BNS_MAXK + BNS_MAXB + BNS_WAVES * BNS_R * 16 * BNS_SW;
-  const int blk = blockIdx.x / a.wg_per_block, wib = blockIdx.x - blk * a.wg_per_block;
+  const int item = bns_xcd_item(a.n_items);
+  if (item < 0) return;
+  const int blk = item / a.wg_per_block, wib = item - blk * a.wg_per_block;
   const int rib0 = wib * BNS_ROWS;
   const long long blk_lo = (long long)blk * a.bs;
   const long long blk_n = min((long long)a.bs, a.n - blk_lo);
@@ -628,7 +640,7 @@ struct BnsEffArgs {
   const double *stats;                 // [n_blocks][2][2][64]; slot 1 = statistics of z
   const float *z;                      // [n x q]
   long long n, row_base;
-  int q, z0, z1, bs, wg_per_block, block0, n_doses;
+  int q, z0, z1, bs, wg_per_block, block0, n_doses, n_items;
   const float *xvals;                  // [n_doses]
   uint32_t k0, k1, stream0;            // dose k uses noise stream stream0 + k
   int sample_y;                        // 1: y ~ N(mu, s2) with outcome noise (row, it_noise, k >> 2, TAG_YNOISE)[k & 3]
@@ -646,7 +658,9 @@ static __global__ __launch_bounds__(BNS_THREADS, 4) void bns_effects_kernel(BnsE
   c.bn = bns_lds;
   c.sg = (uint32_t *)(bns_lds + 2 * BNS_MAXK + BNS_MAXB);
   c.stage = bns_lds + 2 * BNS_MAXK + BNS_MAXB + BNS_WAVES * BNS_R * 16 * BNS_SW;
-  const int blk = blockIdx.x / a.wg_per_block, wib = blockIdx.x - blk * a.wg_per_block;
+  const int item = bns_xcd_item(a.n_items);
+  if (item < 0) return;
+  const int blk = item / a.wg_per_block, wib = item - blk * a.wg_per_block;
   const int rib0 = wib * BNS_ROWS;
   const long long blk_lo = (long long)blk * a.bs;
   const long long blk_n = min((long long)a.bs, a.n - blk_lo);
