@@ -72,6 +72,41 @@ def cpu_baseline(params, p, z_dims, budget_s=20.0):
                       f"2 log-posterior evals/iter + NumPy RNG as causalbgm/base.py:860-871; {dt:.1f} s"}
 
 
+def fit_leg(model, x, y, v, n_loc, steps=2000, batch=32):
+    """Secondary measurement (fit throughput reported separately): minibatch iterations of CausalBGM.fit at
+    the reference's batch size on the bench panel -- theta gradient + Adam + latent step (dense-decay Adam on the whole
+    [N x q] table, the Keras semantics) per iteration."""
+    import torch
+    eng = model.engine
+    dev = eng.device
+    g = torch.Generator(device=dev).manual_seed(1)
+    z = torch.randn(n_loc, eng.q, device=dev, generator=g)
+    zm, zv = torch.zeros_like(z), torch.zeros_like(z)
+    npar = eng.fit_begin(n_loc, batch)
+    grad = torch.empty(npar, device=dev)
+    perm = torch.randperm(n_loc, device=dev, generator=g).to(torch.int32)
+
+    def run(k):
+        for s_ in range(k):
+            i = (s_ * batch) % max(1, n_loc - batch)
+            idx = perm[i:i + batch]
+            eng.fit_theta_grad(x, y, v, z, idx, batch, grad)
+            eng.fit_theta_apply(grad, 1e-4)
+            eng.fit_z_step(x, y, v, z, zm, zv, idx, batch, 1e-4, lazy=False)
+    try:
+        run(20)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        eng.fit_end()
+    return {"value": batch * steps / dt, "unit": "observations x epochs / s", "us_per_minibatch": 1e6 * dt / steps,
+            "sample": f"{steps} minibatch iterations, B={batch}, N={n_loc} (dense-decay Adam on the latent table), deterministic nets",
+            "flop_per_observation": 348480}
+
+
 def bayesian_leg(params, data, x_values, n_loc, args, device):
     """Secondary measurement (not `value`): the same predict with the reference's default Bayesian nets (use_bnn=True,
     DESIGN.md section 7) on a tenth of the iterations -- all blocks advance in lock step, three launches per iteration, so
@@ -104,6 +139,7 @@ def main():
     ap.add_argument("--n-mcmc", type=int, default=3000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bayesian", action="store_true", help="skip the secondary use_bnn=True measurement (N=1 only)")
+    ap.add_argument("--no-fit", action="store_true", help="skip the secondary fit-throughput measurement (N=1 only)")
     args = ap.parse_args()
 
     import torch
@@ -219,6 +255,8 @@ def main():
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         if not args.no_bayesian and world == 1:
             out["bayesian_nets"] = bayesian_leg(params, data, x_values, n_loc, args, device)
+        if not args.no_fit and world == 1:
+            out["fit"] = fit_leg(model, x, y, v, n_loc)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
