@@ -362,7 +362,7 @@ class CausalBGMBayes(CausalBGM):
         x = self._dev(data_x[lo_r:hi_r]).reshape(-1)
         y = self._dev(data_y[lo_r:hi_r]).reshape(-1)
         v = self._dev(data_v[lo_r:hi_r])
-        acc_tail, tail = 0, 1
+        acc_tail, tail = 0, min(100, burn_in + n_mcmc)        # acceptance window of the final report (base.py:899-901)
         if binary:
             max_rows = max(bs, int((32 << 30) // (4 * max(1, n_mcmc))) // bs * bs)      # whole blocks, draw matrix <= ~32 GiB
             means, los, his = [], [], []
@@ -388,7 +388,7 @@ class CausalBGMBayes(CausalBGM):
         parallel.all_reduce_sum_(sums)                        # adrf_draw_sums (base.py:660)
         causal_effects = (sums / float(n_test)).float().contiguous()
         adrf, lo, hi = eng.row_mean_quantiles(causal_effects, alpha / 2, 1 - alpha / 2)
-        self._report_acceptance(float(acc_tail), min(100, burn_in + n_mcmc), n_test, verbose)
+        self._report_acceptance(float(acc_tail), tail, n_test, verbose)
         return adrf.cpu().numpy(), torch.stack([lo, hi], dim=1).cpu().numpy()
 
     def metropolis_hastings_sampler(self, data, initial_q_sd=1.0, q_sd=None, burn_in=5000, n_keep=3000,
