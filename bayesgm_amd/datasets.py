@@ -82,6 +82,41 @@ class Sim_Hirano_Imbens_sampler(Base_sampler):
         super().__init__(x, y, v, batch_size=batch_size, normalize=True)
 
 
+class Sim_Sun_sampler(Base_sampler):
+    """Sun et al. continuous-treatment simulation.  datasets/causal_samplers.py:88-94: v ~ N(0, I) [N x v_dim];
+    x ~ N(-2 sin(2 v0) + (v1^2 - 1/3) + (v2 - 1/2) + cos(v3), 1); y ~ N((v0 - 1/2) + cos(v1) + v4^2 + v5 + x, 1);
+    V standardised per column (true ADRF: utils.get_ADRF(dataset='Sun'))."""
+
+    def __init__(self, batch_size=32, N=20000, v_dim=200, seed=0):
+        np.random.seed(seed)
+        v = np.random.normal(0, 1, size=(N, v_dim))
+        mean_x = -2 * np.sin(2 * v[:, 0]) + (v[:, 1] ** 2 - 1 / 3) + (v[:, 2] - 1 / 2) + np.cos(v[:, 3])
+        x = np.random.normal(mean_x, 1)
+        y = np.random.normal((v[:, 0] - 1 / 2) + np.cos(v[:, 1]) + v[:, 4] ** 2 + v[:, 5] + x, 1)
+        super().__init__(x.reshape(-1, 1), y.reshape(-1, 1), v, batch_size=batch_size, normalize=True)
+
+
+class Sim_Colangelo_sampler(Base_sampler):
+    """Colangelo & Lee continuous-treatment simulation.  datasets/causal_samplers.py:113-127: v ~ N(0, Sigma) with the
+    tridiagonal Sigma (1 on the diagonal, rho beside it); theta_l = 1 / l^2; x = d * Phi(a v.theta) + b nu - 1/2;
+    y = 1.2 x + x^3 + x v0 + 1.2 v.theta + eps; eps, nu ~ N(0, 1) drawn BEFORE v; V standardised per column
+    (true ADRF: utils.get_ADRF(dataset='Lee'))."""
+
+    def __init__(self, batch_size=32, N=20000, v_dim=100, seed=0, rho=0.5, offset=(-1, 0, 1), d=1, a=3, b=0.75):
+        from scipy.stats import norm
+        np.random.seed(seed)
+        sigma = np.zeros((v_dim, v_dim))
+        for off, val in zip(offset, (rho, 1.0, rho)):
+            sigma += np.diag(np.full(v_dim - abs(off), val), off)
+        theta = 1.0 / np.arange(1, v_dim + 1) ** 2
+        epsilon = np.random.normal(0, 1, N)
+        nu = np.random.normal(0, 1, N)
+        v = np.random.multivariate_normal(np.zeros(v_dim), sigma, size=[N, ])
+        x = d * norm.cdf(a * v @ theta) + b * nu - 0.5
+        y = 1.2 * x + x ** 3 + x * v[:, 0] + 1.2 * (v @ theta) + epsilon
+        super().__init__(x.reshape(-1, 1), y.reshape(-1, 1), v, batch_size=batch_size, normalize=True)
+
+
 class Gaussian_sampler(object):
     """N(mean, sd^2 I) sampler.  datasets/prior_samplers.py:4-59 (re-seeds the global
     RNG with 1024 at construction, as the reference does)."""
