@@ -281,6 +281,116 @@ __device__ __forceinline__ void dense_group4_k64_asm(unsigned lds_addr, const f3
         "v"(lds_addr)
       : "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
 }
+// Same block with the accumulators STARTING from separate registers c0..c3 (the C operand of the first K-step): the
+// last layer of g starts from (bias - v), kept in registers for the whole kernel, so its result is (mu - v) and the
+// likelihood epilogue needs neither a bias load nor a subtraction.
+__device__ __forceinline__ void dense_group4_k64_asm_c(unsigned lds_addr, const f32x4 (&in)[4], const f32x4 &c0, const f32x4 &c1, const f32x4 &c2,
+                                                       const f32x4 &c3, f32x4 &a0, f32x4 &a1, f32x4 &a2, f32x4 &a3) {
+  asm volatile(
+      "s_waitcnt lgkmcnt(0)\n"
+      "ds_read_b128 v[244:247], %20 offset:0\n"
+      "ds_read_b128 v[248:251], %20 offset:256\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v244, %4, %21\n"
+      "ds_read_b128 v[252:255], %20 offset:512\n"
+      "v_mfma_f32_16x16x4_f32 %1, v245, %4, %22\n"
+      "v_mfma_f32_16x16x4_f32 %2, v246, %4, %23\n"
+      "v_mfma_f32_16x16x4_f32 %3, v247, %4, %24\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v248, %5, %0\n"
+      "ds_read_b128 v[244:247], %20 offset:768\n"
+      "v_mfma_f32_16x16x4_f32 %1, v249, %5, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v250, %5, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v251, %5, %3\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v252, %6, %0\n"
+      "ds_read_b128 v[248:251], %20 offset:4096\n"
+      "v_mfma_f32_16x16x4_f32 %1, v253, %6, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v254, %6, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v255, %6, %3\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v244, %7, %0\n"
+      "ds_read_b128 v[252:255], %20 offset:4352\n"
+      "v_mfma_f32_16x16x4_f32 %1, v245, %7, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v246, %7, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v247, %7, %3\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v248, %8, %0\n"
+      "ds_read_b128 v[244:247], %20 offset:4608\n"
+      "v_mfma_f32_16x16x4_f32 %1, v249, %8, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v250, %8, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v251, %8, %3\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v252, %9, %0\n"
+      "ds_read_b128 v[248:251], %20 offset:4864\n"
+      "v_mfma_f32_16x16x4_f32 %1, v253, %9, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v254, %9, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v255, %9, %3\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v244, %10, %0\n"
+      "ds_read_b128 v[252:255], %20 offset:8192\n"
+      "v_mfma_f32_16x16x4_f32 %1, v245, %10, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v246, %10, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v247, %10, %3\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v248, %11, %0\n"
+      "ds_read_b128 v[244:247], %20 offset:8448\n"
+      "v_mfma_f32_16x16x4_f32 %1, v249, %11, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v250, %11, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v251, %11, %3\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v252, %12, %0\n"
+      "ds_read_b128 v[248:251], %20 offset:8704\n"
+      "v_mfma_f32_16x16x4_f32 %1, v253, %12, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v254, %12, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v255, %12, %3\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v244, %13, %0\n"
+      "ds_read_b128 v[252:255], %20 offset:8960\n"
+      "v_mfma_f32_16x16x4_f32 %1, v245, %13, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v246, %13, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v247, %13, %3\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v248, %14, %0\n"
+      "ds_read_b128 v[244:247], %20 offset:12288\n"
+      "v_mfma_f32_16x16x4_f32 %1, v249, %14, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v250, %14, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v251, %14, %3\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v252, %15, %0\n"
+      "ds_read_b128 v[248:251], %20 offset:12544\n"
+      "v_mfma_f32_16x16x4_f32 %1, v253, %15, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v254, %15, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v255, %15, %3\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v244, %16, %0\n"
+      "ds_read_b128 v[252:255], %20 offset:12800\n"
+      "v_mfma_f32_16x16x4_f32 %1, v245, %16, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v246, %16, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v247, %16, %3\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v248, %17, %0\n"
+      "ds_read_b128 v[244:247], %20 offset:13056\n"
+      "v_mfma_f32_16x16x4_f32 %1, v249, %17, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v250, %17, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v251, %17, %3\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v252, %18, %0\n"
+      "v_mfma_f32_16x16x4_f32 %1, v253, %18, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v254, %18, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v255, %18, %3\n"
+      "s_waitcnt lgkmcnt(0)\n"
+      "v_mfma_f32_16x16x4_f32 %0, v244, %19, %0\n"
+      "v_mfma_f32_16x16x4_f32 %1, v245, %19, %1\n"
+      "v_mfma_f32_16x16x4_f32 %2, v246, %19, %2\n"
+      "v_mfma_f32_16x16x4_f32 %3, v247, %19, %3\n"
+      "s_nop 15\n"
+      : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3)
+      : "v"(in[0][0]), "v"(in[0][1]), "v"(in[0][2]), "v"(in[0][3]), "v"(in[1][0]), "v"(in[1][1]), "v"(in[1][2]), "v"(in[1][3]),
+        "v"(in[2][0]), "v"(in[2][1]), "v"(in[2][2]), "v"(in[2][3]), "v"(in[3][0]), "v"(in[3][1]), "v"(in[3][2]), "v"(in[3][3]),
+        "v"(lds_addr), "v"(c0), "v"(c1), "v"(c2), "v"(c3)
+      : "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
+}
 __device__ __forceinline__ unsigned lds_byte_addr(const float *p) {
   // LDS byte address of an element of the kernel's dynamic shared array, as (offset of that array) + (p - array).
   // The pointer difference cancels the flat aperture, so no flat <-> LDS cast of `p` is ever materialised: hipcc 7.2

@@ -50,7 +50,7 @@ struct CausalMhKArgs {
 // ---------------------------------------------------------------------------
 // log p(z | x, y, v) for R x 16 chains held by one wave.
 //   zin  : L1 input tiles, feature 16 t + 4 r + g  (z features, then x at index q, then 0)
-//   vreg : V rows, feature 16 t + 4 g + r, zero padded
+//   vreg : (bias of g's last layer) - (V row), feature 16 t + 4 g + r (load_v_rows); the variance slot holds the bias alone
 // Returns logp[rr] replicated over the four lane groups.
 // ---------------------------------------------------------------------------
 template <int T0, int KT, int NTL, int R>
@@ -61,22 +61,23 @@ __device__ __forceinline__ void g_last_groups(const float *wl, const float *bl, 
   if constexpr (T0 < NTL) {
     constexpr int GS = group_size(NTL - T0);
     f32x4 acc[R][NTL];  // only [T0, T0+GS) is touched; the rest is dead and never allocated
-#pragma unroll
-    for (int u = 0; u < GS; ++u) {
-      const f32x4 b = *reinterpret_cast<const f32x4 *>(bl + 16 * (T0 + u) + 4 * g);
-#pragma unroll
-      for (int rr = 0; rr < R; ++rr) acc[rr][T0 + u] = b;
-    }
     constexpr int K_ROWS = 16 * KT;
     constexpr int NKS = 4 * KT;
     const float *base = wl + K_ROWS * 16 * T0 + lane_off * GS;
     bool done = false;
 #ifndef BGM_NO_ASM_DENSE
     if constexpr (R == 1 && KT == 4 && GS == 4) {
-      dense_group4_k64_asm(lds_byte_addr(base), in[0], acc[0][T0], acc[0][T0 + 1], acc[0][T0 + 2], acc[0][T0 + 3]);
+      dense_group4_k64_asm_c(lds_byte_addr(base), in[0], vreg[0][T0], vreg[0][T0 + 1], vreg[0][T0 + 2], vreg[0][T0 + 3], acc[0][T0],
+                             acc[0][T0 + 1], acc[0][T0 + 2], acc[0][T0 + 3]);
       done = true;
     }
 #endif
+    if (!done) {       // accumulators start from bias - v
+#pragma unroll
+      for (int u = 0; u < GS; ++u)
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) acc[rr][T0 + u] = vreg[rr][T0 + u];
+    }
     if constexpr (R == 1 && NKS * GS <= BGM_PREFETCH_ALL_MAX) {   // the single trailing tile: see dense_groups
       AFrag<GS> af[NKS];
 #pragma unroll
@@ -109,7 +110,7 @@ __device__ __forceinline__ void g_last_groups(const float *wl, const float *bl, 
       for (int rr = 0; rr < R; ++rr) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float d = vreg[rr][T0 + u][r] - acc[rr][T0 + u][r];
+          float d = acc[rr][T0 + u][r];            // mu - v
           if (T0 + u == NTL - 1) {  // tile holding the variance column (feature p)
             const bool is_sig = (r == sig_r);
             sraw[rr] = is_sig ? acc[rr][T0 + u][r] : sraw[rr];
@@ -264,6 +265,7 @@ __device__ __forceinline__ void causal_logp(const float *lds, const CausalMeta &
 }
 
 // ---- helpers to move rows between HBM and the register layouts ---------------
+// raw V rows in the same layout (the encoder's input)
 template <int NTL, int R>
 __device__ __forceinline__ void load_v_rows(const float *v, long long n, int p, long long row0, int j,
                                             int g, f32x4 (&vreg)[R][NTL]) {
@@ -278,6 +280,25 @@ __device__ __forceinline__ void load_v_rows(const float *v, long long n, int p, 
       for (int r = 0; r < 4; ++r) {
         const int c = 16 * t + 4 * g + r;
         vreg[rr][t][r] = (c < p) ? vr[c] : 0.0f;
+      }
+  }
+}
+
+// vreg = (bias of g's last layer, from LDS) - (V row): the last layer accumulates on top of it (g_last_groups)
+template <int NTL, int R>
+__device__ __forceinline__ void load_v_rows(const float *v, const float *bl, long long n, int p, long long row0, int j,
+                                            int g, f32x4 (&vreg)[R][NTL]) {
+#pragma unroll
+  for (int rr = 0; rr < R; ++rr) {
+    long long row = row0 + 16 * rr + j;
+    row = row < n ? row : n - 1;
+    const float *vr = v + row * (long long)p;
+#pragma unroll
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 16 * t + 4 * g + r;
+        vreg[rr][t][r] = bl[c] - ((c < p) ? vr[c] : 0.0f);
       }
   }
 }
@@ -347,7 +368,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_logpost_kernel(const float 
       yr[rr] = y[row];
     }
     f32x4 vreg[R][NTL];
-    load_v_rows<NTL, R>(v, n, m.p, row0, j, g, vreg);
+    load_v_rows<NTL, R>(v, lds + m.bgl, n, m.p, row0, j, g, vreg);
     f32x4 zin[R][KT1];
     load_z_rows<KT1, R>(z, n, m.q, row0, j, g, xr, zin);
 #ifdef BGM_PROF
@@ -546,7 +567,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
       rowid[rr] = (unsigned)(a.row_base + row);
     }
     f32x4 vreg[R][NTL];
-    load_v_rows<NTL, R>(a.v, n, m.p, row0, j, g, vreg);
+    load_v_rows<NTL, R>(a.v, lds + m.bgl, n, m.p, row0, j, g, vreg);
     f32x4 zs[R][KT1];
     if (a.init) {
       // current_state ~ N(0,1)  (base.py:842), RNG spec tag 0
@@ -725,7 +746,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_eval_kernel(CausalEvalKArgs
     float xr[1] = {a.x[row]}, yr[1] = {a.y[row]};
     unsigned rowid[1] = {0u};
     f32x4 vreg[1][NTL];
-    load_v_rows<NTL, 1>(a.v, n, m.p, row0, j, g, vreg);
+    load_v_rows<NTL, 1>(a.v, lds + m.bgl, n, m.p, row0, j, g, vreg);
     f32x4 zin[1][KT1];
     load_z_rows<KT1, 1>(a.z, n, m.q, row0, j, g, xr, zin);
     float ssq[1] = {0.0f}, sraw[1] = {0.0f};
