@@ -228,6 +228,9 @@ class CausalBGM(object):
         zm = torch.zeros_like(self.data_z)
         zv = torch.zeros_like(self.data_z)
         b_loc = max(1, batch_size // world)
+        # Every rank must take the same number of steps with the same batch sizes (one all-reduce per step): an epoch uses the
+        # first n_total // world entries of each rank's permutation; a rank that owns one row more leaves one (random) row out.
+        n_use = n_total // world if world > 1 else n_loc
         eng = self.engine
         n_params = eng.fit_begin(n_loc, b_loc)
         grad = torch.empty(n_params, device=dev, dtype=torch.float32)
@@ -242,8 +245,8 @@ class CausalBGM(object):
                 sample_idx = torch.from_numpy(np.random.choice(n_loc, n_loc, replace=False).astype(np.int32)).to(dev)
                 loss.zero_()
                 n_steps = 0
-                for i in range(0, n_loc, b_loc):
-                    idx = sample_idx[i:i + b_loc]
+                for i in range(0, n_use, b_loc):
+                    idx = sample_idx[i:min(i + b_loc, n_use)]
                     bg = int(idx.numel()) * world
                     eng.fit_theta_grad(x, y, v, self.data_z, idx, bg, grad, loss)
                     parallel.all_reduce_sum_(grad)                       # C1: fused g|f|h gradient

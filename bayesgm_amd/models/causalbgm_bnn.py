@@ -217,6 +217,8 @@ class CausalBGMBayes(CausalBGM):
         zm = torch.zeros_like(self.data_z)
         zv = torch.zeros_like(self.data_z)
         b_loc = max(2, batch_size // world)
+        # the same number of steps and batch sizes on every rank (one all-reduce per step): see CausalBGM.fit
+        n_use = n_total // world if world > 1 else n_loc
         grad = torch.empty(eng.n_params, device=dev, dtype=torch.float32) if world > 1 else None
         out_t = torch.zeros(8, device=dev)
         out_z = torch.zeros(4, device=dev)
@@ -226,10 +228,10 @@ class CausalBGMBayes(CausalBGM):
             print('Iterative Updating Starts ...')
         for epoch in range(epochs + 1):
             sample_idx = torch.from_numpy(np.random.choice(n_loc, n_loc, replace=False).astype(np.int32)).to(dev)
-            for i in range(0, n_loc, b_loc):
-                idx = sample_idx[i:i + b_loc]
+            for i in range(0, n_use, b_loc):
+                idx = sample_idx[i:min(i + b_loc, n_use)]
                 if idx.numel() < 2:
-                    continue                      # batch statistics need two rows
+                    continue                      # batch statistics need two rows (the same decision on every rank)
                 bg = int(idx.numel()) * world
                 s0 = self._streams(3)
                 if world > 1:

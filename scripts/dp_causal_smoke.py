@@ -13,7 +13,7 @@ torch.cuda.set_device(dev)
 dist.init_process_group(backend=backend)
 from bayesgm_amd.models import CausalBGM
 from bayesgm_amd.datasets import Sim_Hirano_Imbens_sampler
-x, y, v = Sim_Hirano_Imbens_sampler(N=1501, v_dim=50, seed=1).load_all()
+x, y, v = Sim_Hirano_Imbens_sampler(N=1505, v_dim=50, seed=1).load_all()
 params = dict(dataset="dp", output_dir="gpurun_out/dp", save_res=False, save_model=False, binary_treatment=False, use_bnn=False,
               z_dims=[1, 1, 1, 7], v_dim=50, lr_theta=1e-3, lr_z=1e-3, g_units=[64] * 5, f_units=[64, 32, 8], h_units=[64, 32, 8],
               e_units=[64] * 5, dz_units=[64, 32, 8], kl_weight=1e-4, lr=2e-4, g_d_freq=5, use_z_rec=True)

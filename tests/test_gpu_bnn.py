@@ -362,7 +362,7 @@ def test_two_rank_fit_and_predict_with_bayesian_nets():
     from bayesgm_amd.datasets import Sim_Hirano_Imbens_sampler
     # the two ranks print concurrently: their JSON objects may share a line
     two = json.JSONDecoder().raw_decode(r.stdout[r.stdout.index('{"rank": 0'):])[0]
-    x, y, v = Sim_Hirano_Imbens_sampler(N=1101, v_dim=30, seed=1).load_all()
+    x, y, v = Sim_Hirano_Imbens_sampler(N=1089, v_dim=30, seed=1).load_all()
     m = CausalBGM(dict(_params("gpurun_out/dp", False, p=30), save_res=False), random_seed=2)
     adrf, interval = m.predict((x, y, v), alpha=0.05, n_mcmc=30, burn_in=30, x_values=np.linspace(0, 3, 6), q_sd=0.5, bs=256, verbose=0)
     assert np.abs(np.array(two["adrf_untrained"]) - adrf).max() <= 1e-5

@@ -242,7 +242,7 @@ def test_two_rank_causal_fit_and_predict_run():
     from bayesgm_amd.datasets import Sim_Hirano_Imbens_sampler
     # the two ranks print concurrently: their JSON objects may share a line
     two = json.JSONDecoder().raw_decode(r.stdout[r.stdout.index('{"rank": 0'):])[0]
-    x, y, v = Sim_Hirano_Imbens_sampler(N=1501, v_dim=50, seed=1).load_all()
+    x, y, v = Sim_Hirano_Imbens_sampler(N=1505, v_dim=50, seed=1).load_all()
     params = dict(dataset="dp", output_dir="gpurun_out/dp", save_res=False, save_model=False, binary_treatment=False, use_bnn=False,
                   z_dims=[1, 1, 1, 7], v_dim=50, lr_theta=1e-3, lr_z=1e-3, g_units=[64] * 5, f_units=[64, 32, 8], h_units=[64, 32, 8],
                   e_units=[64] * 5, dz_units=[64, 32, 8], kl_weight=1e-4, lr=2e-4, g_d_freq=5, use_z_rec=True)
