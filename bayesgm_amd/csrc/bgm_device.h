@@ -96,6 +96,17 @@ __device__ __forceinline__ f32x4 box_muller4(uint4 w) {
 // no MFMA->VALU hazard wait states inside asm statements, so it would read stale accumulators.)
 __device__ __forceinline__ float vmax(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
 __device__ __forceinline__ float lrelu(float x) { return vmax(x, BGM_LEAK * x); }
+// LeakyReLU(0.2) up to the positive factor 0.6 in ONE instruction: x + (2/3)|x| = LeakyReLU(x) / 0.6 (v_fma_f32 with the
+// |.| input modifier; max(x, 0.2 x) costs a multiply and a max).  The sampling kernels of CausalBGM use it with the
+// weights of every layer that consumes such an activation scaled by 0.6 in their copy of the packed blob
+// (causal_scale_blob_kernel), so that W'(h / 0.6) = W h: the result differs from the max form by fp32 rounding only.
+#define BGM_LRS 0.6666666865348816f
+#define BGM_LRS_W 0.6f
+__device__ __forceinline__ float lrelu_s(float x) { return fmaf(fabsf(x), BGM_LRS, x); }
+// Same value, pinned in a register by an empty asm: with the plain form at every site of causal_effects hipcc 7.2 dies with
+// "Illegal instruction detected: Operand has incorrect register class ... $src_shared_base" (the mis-selected flat <-> LDS
+// null check also noted at lds_byte_addr); pinning the value at the one hot site moves the code out of that pattern.
+__device__ __forceinline__ float lrelu_s_pinned(float x) { float r = fmaf(fabsf(x), BGM_LRS, x); asm volatile("" : "+v"(r)); return r; }
 // natural log / exp on the hardware transcendental units (v_log_f32 = log2, v_exp_f32 = exp2;
 // ~1 ulp each), used where the argument is O(1) and the result enters a sum of O(1e2) terms.
 __device__ __forceinline__ float fast_log(float x) { return 0.6931471805599453f * __builtin_amdgcn_logf(x); }
@@ -406,16 +417,18 @@ __device__ __forceinline__ unsigned lds_byte_addr(const float *p) {
 // 32-instruction LeakyReLU, ~580 cycles per layer with the matrix pipe empty (measured).  Here the activation sets
 // live in fixed registers (P = v208-v223, Q = v224-v239) and alternate as B operands / accumulators; a layer's
 // accumulator tuples are loaded with the bias as soon as the previous layer has consumed them as inputs, the A
-// fragments stream two K-steps ahead ACROSS layer boundaries, and LeakyReLU is applied to one input element per
-// K-step, just in time.  Software-managed hazards: counted lgkmcnt per LDS load, s_nop between the last MFMA of a
+// fragments stream two K-steps ahead ACROSS layer boundaries, and the (scaled, one-instruction) LeakyReLU lrelu_s is applied
+// to one input element per K-step, just in time (v243 holds the constant 2/3).  Software-managed hazards: counted lgkmcnt per LDS load, s_nop between the last MFMA of a
 // layer and the first VALU read of its result.
 //   w_addr: LDS byte address of this lane's fragment of layer 0, K-step 0 (layers are 16 KiB apart);
 //   b_addr: LDS byte address of bias feature 4g of layer 0 (layers 256 B apart).
-//   p: in = activated input, out = RAW output of the 4th layer (caller applies LeakyReLU);  q: scratch set.
+//   p: in = activated input (lrelu_s), out = RAW output of the 4th layer (caller applies lrelu_s);  q: scratch set.
+//   The weights of all four layers must carry the factor 0.6 (sampling copy of the blob).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void dense_hidden4_asm(unsigned w_addr, unsigned b_addr, f32x4 (&p)[4], f32x4 (&q)[4]) {
   asm volatile(
       "s_waitcnt lgkmcnt(0)\n"
+      "v_mov_b32 v243, 0x3f2aaaab\n"
       "ds_read_b128 v[224:227], %9 offset:0\n"
       "ds_read_b128 v[228:231], %9 offset:64\n"
       "ds_read_b128 v[232:235], %9 offset:128\n"
@@ -523,35 +536,30 @@ __device__ __forceinline__ void dense_hidden4_asm(unsigned w_addr, unsigned b_ad
       "v_mfma_f32_16x16x4_f32 v[236:239], v247, v223, v[236:239]\n"
       "ds_read_b128 v[220:223], %9 offset:448\n"
       "s_nop 15\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v224\n"
-      "v_max_f32 v224, v224, v243\n"
+      "v_fma_f32 v224, |v224|, v243, v224\n"
       "s_waitcnt lgkmcnt(2)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v225\n"
-      "v_max_f32 v225, v225, v243\n"
+      "v_fma_f32 v225, |v225|, v243, v225\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v248, v224, v[208:211]\n"
       "ds_read_b128 v[244:247], %8 offset:16896\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v249, v224, v[212:215]\n"
       "v_mfma_f32_16x16x4_f32 v[216:219], v250, v224, v[216:219]\n"
       "s_waitcnt lgkmcnt(1)\n"
       "v_mfma_f32_16x16x4_f32 v[220:223], v251, v224, v[220:223]\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v226\n"
-      "v_max_f32 v226, v226, v243\n"
+      "v_fma_f32 v226, |v226|, v243, v226\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v252, v225, v[208:211]\n"
       "ds_read_b128 v[248:251], %8 offset:17152\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v253, v225, v[212:215]\n"
       "v_mfma_f32_16x16x4_f32 v[216:219], v254, v225, v[216:219]\n"
       "v_mfma_f32_16x16x4_f32 v[220:223], v255, v225, v[220:223]\n"
       "s_waitcnt lgkmcnt(1)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v227\n"
-      "v_max_f32 v227, v227, v243\n"
+      "v_fma_f32 v227, |v227|, v243, v227\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v244, v226, v[208:211]\n"
       "ds_read_b128 v[252:255], %8 offset:20480\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v245, v226, v[212:215]\n"
       "v_mfma_f32_16x16x4_f32 v[216:219], v246, v226, v[216:219]\n"
       "v_mfma_f32_16x16x4_f32 v[220:223], v247, v226, v[220:223]\n"
       "s_waitcnt lgkmcnt(1)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v228\n"
-      "v_max_f32 v228, v228, v243\n"
+      "v_fma_f32 v228, |v228|, v243, v228\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v248, v227, v[208:211]\n"
       "ds_read_b128 v[244:247], %8 offset:20736\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v249, v227, v[212:215]\n"
@@ -559,32 +567,28 @@ __device__ __forceinline__ void dense_hidden4_asm(unsigned w_addr, unsigned b_ad
       "v_mfma_f32_16x16x4_f32 v[220:223], v251, v227, v[220:223]\n"
       "ds_read_b128 v[224:227], %9 offset:512\n"
       "s_waitcnt lgkmcnt(2)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v229\n"
-      "v_max_f32 v229, v229, v243\n"
+      "v_fma_f32 v229, |v229|, v243, v229\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v252, v228, v[208:211]\n"
       "ds_read_b128 v[248:251], %8 offset:20992\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v253, v228, v[212:215]\n"
       "v_mfma_f32_16x16x4_f32 v[216:219], v254, v228, v[216:219]\n"
       "v_mfma_f32_16x16x4_f32 v[220:223], v255, v228, v[220:223]\n"
       "s_waitcnt lgkmcnt(2)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v230\n"
-      "v_max_f32 v230, v230, v243\n"
+      "v_fma_f32 v230, |v230|, v243, v230\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v244, v229, v[208:211]\n"
       "ds_read_b128 v[252:255], %8 offset:21248\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v245, v229, v[212:215]\n"
       "v_mfma_f32_16x16x4_f32 v[216:219], v246, v229, v[216:219]\n"
       "v_mfma_f32_16x16x4_f32 v[220:223], v247, v229, v[220:223]\n"
       "s_waitcnt lgkmcnt(1)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v231\n"
-      "v_max_f32 v231, v231, v243\n"
+      "v_fma_f32 v231, |v231|, v243, v231\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v248, v230, v[208:211]\n"
       "ds_read_b128 v[244:247], %8 offset:24576\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v249, v230, v[212:215]\n"
       "v_mfma_f32_16x16x4_f32 v[216:219], v250, v230, v[216:219]\n"
       "v_mfma_f32_16x16x4_f32 v[220:223], v251, v230, v[220:223]\n"
       "s_waitcnt lgkmcnt(1)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v232\n"
-      "v_max_f32 v232, v232, v243\n"
+      "v_fma_f32 v232, |v232|, v243, v232\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v252, v231, v[208:211]\n"
       "ds_read_b128 v[248:251], %8 offset:24832\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v253, v231, v[212:215]\n"
@@ -592,32 +596,28 @@ __device__ __forceinline__ void dense_hidden4_asm(unsigned w_addr, unsigned b_ad
       "v_mfma_f32_16x16x4_f32 v[220:223], v255, v231, v[220:223]\n"
       "ds_read_b128 v[228:231], %9 offset:576\n"
       "s_waitcnt lgkmcnt(2)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v233\n"
-      "v_max_f32 v233, v233, v243\n"
+      "v_fma_f32 v233, |v233|, v243, v233\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v244, v232, v[208:211]\n"
       "ds_read_b128 v[252:255], %8 offset:25088\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v245, v232, v[212:215]\n"
       "v_mfma_f32_16x16x4_f32 v[216:219], v246, v232, v[216:219]\n"
       "v_mfma_f32_16x16x4_f32 v[220:223], v247, v232, v[220:223]\n"
       "s_waitcnt lgkmcnt(2)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v234\n"
-      "v_max_f32 v234, v234, v243\n"
+      "v_fma_f32 v234, |v234|, v243, v234\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v248, v233, v[208:211]\n"
       "ds_read_b128 v[244:247], %8 offset:25344\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v249, v233, v[212:215]\n"
       "v_mfma_f32_16x16x4_f32 v[216:219], v250, v233, v[216:219]\n"
       "v_mfma_f32_16x16x4_f32 v[220:223], v251, v233, v[220:223]\n"
       "s_waitcnt lgkmcnt(1)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v235\n"
-      "v_max_f32 v235, v235, v243\n"
+      "v_fma_f32 v235, |v235|, v243, v235\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v252, v234, v[208:211]\n"
       "ds_read_b128 v[248:251], %8 offset:28672\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v253, v234, v[212:215]\n"
       "v_mfma_f32_16x16x4_f32 v[216:219], v254, v234, v[216:219]\n"
       "v_mfma_f32_16x16x4_f32 v[220:223], v255, v234, v[220:223]\n"
       "s_waitcnt lgkmcnt(1)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v236\n"
-      "v_max_f32 v236, v236, v243\n"
+      "v_fma_f32 v236, |v236|, v243, v236\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v244, v235, v[208:211]\n"
       "ds_read_b128 v[252:255], %8 offset:28928\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v245, v235, v[212:215]\n"
@@ -625,24 +625,21 @@ __device__ __forceinline__ void dense_hidden4_asm(unsigned w_addr, unsigned b_ad
       "v_mfma_f32_16x16x4_f32 v[220:223], v247, v235, v[220:223]\n"
       "ds_read_b128 v[232:235], %9 offset:640\n"
       "s_waitcnt lgkmcnt(2)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v237\n"
-      "v_max_f32 v237, v237, v243\n"
+      "v_fma_f32 v237, |v237|, v243, v237\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v248, v236, v[208:211]\n"
       "ds_read_b128 v[244:247], %8 offset:29184\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v249, v236, v[212:215]\n"
       "v_mfma_f32_16x16x4_f32 v[216:219], v250, v236, v[216:219]\n"
       "v_mfma_f32_16x16x4_f32 v[220:223], v251, v236, v[220:223]\n"
       "s_waitcnt lgkmcnt(2)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v238\n"
-      "v_max_f32 v238, v238, v243\n"
+      "v_fma_f32 v238, |v238|, v243, v238\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v252, v237, v[208:211]\n"
       "ds_read_b128 v[248:251], %8 offset:29440\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v253, v237, v[212:215]\n"
       "v_mfma_f32_16x16x4_f32 v[216:219], v254, v237, v[216:219]\n"
       "v_mfma_f32_16x16x4_f32 v[220:223], v255, v237, v[220:223]\n"
       "s_waitcnt lgkmcnt(1)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v239\n"
-      "v_max_f32 v239, v239, v243\n"
+      "v_fma_f32 v239, |v239|, v243, v239\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v244, v238, v[208:211]\n"
       "ds_read_b128 v[252:255], %8 offset:32768\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v245, v238, v[212:215]\n"
@@ -656,35 +653,30 @@ __device__ __forceinline__ void dense_hidden4_asm(unsigned w_addr, unsigned b_ad
       "v_mfma_f32_16x16x4_f32 v[220:223], v251, v239, v[220:223]\n"
       "ds_read_b128 v[236:239], %9 offset:704\n"
       "s_nop 15\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v208\n"
-      "v_max_f32 v208, v208, v243\n"
+      "v_fma_f32 v208, |v208|, v243, v208\n"
       "s_waitcnt lgkmcnt(2)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v209\n"
-      "v_max_f32 v209, v209, v243\n"
+      "v_fma_f32 v209, |v209|, v243, v209\n"
       "v_mfma_f32_16x16x4_f32 v[224:227], v252, v208, v[224:227]\n"
       "ds_read_b128 v[248:251], %8 offset:33280\n"
       "v_mfma_f32_16x16x4_f32 v[228:231], v253, v208, v[228:231]\n"
       "v_mfma_f32_16x16x4_f32 v[232:235], v254, v208, v[232:235]\n"
       "s_waitcnt lgkmcnt(1)\n"
       "v_mfma_f32_16x16x4_f32 v[236:239], v255, v208, v[236:239]\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v210\n"
-      "v_max_f32 v210, v210, v243\n"
+      "v_fma_f32 v210, |v210|, v243, v210\n"
       "v_mfma_f32_16x16x4_f32 v[224:227], v244, v209, v[224:227]\n"
       "ds_read_b128 v[252:255], %8 offset:33536\n"
       "v_mfma_f32_16x16x4_f32 v[228:231], v245, v209, v[228:231]\n"
       "v_mfma_f32_16x16x4_f32 v[232:235], v246, v209, v[232:235]\n"
       "v_mfma_f32_16x16x4_f32 v[236:239], v247, v209, v[236:239]\n"
       "s_waitcnt lgkmcnt(1)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v211\n"
-      "v_max_f32 v211, v211, v243\n"
+      "v_fma_f32 v211, |v211|, v243, v211\n"
       "v_mfma_f32_16x16x4_f32 v[224:227], v248, v210, v[224:227]\n"
       "ds_read_b128 v[244:247], %8 offset:36864\n"
       "v_mfma_f32_16x16x4_f32 v[228:231], v249, v210, v[228:231]\n"
       "v_mfma_f32_16x16x4_f32 v[232:235], v250, v210, v[232:235]\n"
       "v_mfma_f32_16x16x4_f32 v[236:239], v251, v210, v[236:239]\n"
       "s_waitcnt lgkmcnt(1)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v212\n"
-      "v_max_f32 v212, v212, v243\n"
+      "v_fma_f32 v212, |v212|, v243, v212\n"
       "v_mfma_f32_16x16x4_f32 v[224:227], v252, v211, v[224:227]\n"
       "ds_read_b128 v[248:251], %8 offset:37120\n"
       "v_mfma_f32_16x16x4_f32 v[228:231], v253, v211, v[228:231]\n"
@@ -692,32 +684,28 @@ __device__ __forceinline__ void dense_hidden4_asm(unsigned w_addr, unsigned b_ad
       "v_mfma_f32_16x16x4_f32 v[236:239], v255, v211, v[236:239]\n"
       "ds_read_b128 v[208:211], %9 offset:768\n"
       "s_waitcnt lgkmcnt(2)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v213\n"
-      "v_max_f32 v213, v213, v243\n"
+      "v_fma_f32 v213, |v213|, v243, v213\n"
       "v_mfma_f32_16x16x4_f32 v[224:227], v244, v212, v[224:227]\n"
       "ds_read_b128 v[252:255], %8 offset:37376\n"
       "v_mfma_f32_16x16x4_f32 v[228:231], v245, v212, v[228:231]\n"
       "v_mfma_f32_16x16x4_f32 v[232:235], v246, v212, v[232:235]\n"
       "v_mfma_f32_16x16x4_f32 v[236:239], v247, v212, v[236:239]\n"
       "s_waitcnt lgkmcnt(2)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v214\n"
-      "v_max_f32 v214, v214, v243\n"
+      "v_fma_f32 v214, |v214|, v243, v214\n"
       "v_mfma_f32_16x16x4_f32 v[224:227], v248, v213, v[224:227]\n"
       "ds_read_b128 v[244:247], %8 offset:37632\n"
       "v_mfma_f32_16x16x4_f32 v[228:231], v249, v213, v[228:231]\n"
       "v_mfma_f32_16x16x4_f32 v[232:235], v250, v213, v[232:235]\n"
       "v_mfma_f32_16x16x4_f32 v[236:239], v251, v213, v[236:239]\n"
       "s_waitcnt lgkmcnt(1)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v215\n"
-      "v_max_f32 v215, v215, v243\n"
+      "v_fma_f32 v215, |v215|, v243, v215\n"
       "v_mfma_f32_16x16x4_f32 v[224:227], v252, v214, v[224:227]\n"
       "ds_read_b128 v[248:251], %8 offset:40960\n"
       "v_mfma_f32_16x16x4_f32 v[228:231], v253, v214, v[228:231]\n"
       "v_mfma_f32_16x16x4_f32 v[232:235], v254, v214, v[232:235]\n"
       "v_mfma_f32_16x16x4_f32 v[236:239], v255, v214, v[236:239]\n"
       "s_waitcnt lgkmcnt(1)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v216\n"
-      "v_max_f32 v216, v216, v243\n"
+      "v_fma_f32 v216, |v216|, v243, v216\n"
       "v_mfma_f32_16x16x4_f32 v[224:227], v244, v215, v[224:227]\n"
       "ds_read_b128 v[252:255], %8 offset:41216\n"
       "v_mfma_f32_16x16x4_f32 v[228:231], v245, v215, v[228:231]\n"
@@ -725,32 +713,28 @@ __device__ __forceinline__ void dense_hidden4_asm(unsigned w_addr, unsigned b_ad
       "v_mfma_f32_16x16x4_f32 v[236:239], v247, v215, v[236:239]\n"
       "ds_read_b128 v[212:215], %9 offset:832\n"
       "s_waitcnt lgkmcnt(2)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v217\n"
-      "v_max_f32 v217, v217, v243\n"
+      "v_fma_f32 v217, |v217|, v243, v217\n"
       "v_mfma_f32_16x16x4_f32 v[224:227], v248, v216, v[224:227]\n"
       "ds_read_b128 v[244:247], %8 offset:41472\n"
       "v_mfma_f32_16x16x4_f32 v[228:231], v249, v216, v[228:231]\n"
       "v_mfma_f32_16x16x4_f32 v[232:235], v250, v216, v[232:235]\n"
       "v_mfma_f32_16x16x4_f32 v[236:239], v251, v216, v[236:239]\n"
       "s_waitcnt lgkmcnt(2)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v218\n"
-      "v_max_f32 v218, v218, v243\n"
+      "v_fma_f32 v218, |v218|, v243, v218\n"
       "v_mfma_f32_16x16x4_f32 v[224:227], v252, v217, v[224:227]\n"
       "ds_read_b128 v[248:251], %8 offset:41728\n"
       "v_mfma_f32_16x16x4_f32 v[228:231], v253, v217, v[228:231]\n"
       "v_mfma_f32_16x16x4_f32 v[232:235], v254, v217, v[232:235]\n"
       "v_mfma_f32_16x16x4_f32 v[236:239], v255, v217, v[236:239]\n"
       "s_waitcnt lgkmcnt(1)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v219\n"
-      "v_max_f32 v219, v219, v243\n"
+      "v_fma_f32 v219, |v219|, v243, v219\n"
       "v_mfma_f32_16x16x4_f32 v[224:227], v244, v218, v[224:227]\n"
       "ds_read_b128 v[252:255], %8 offset:45056\n"
       "v_mfma_f32_16x16x4_f32 v[228:231], v245, v218, v[228:231]\n"
       "v_mfma_f32_16x16x4_f32 v[232:235], v246, v218, v[232:235]\n"
       "v_mfma_f32_16x16x4_f32 v[236:239], v247, v218, v[236:239]\n"
       "s_waitcnt lgkmcnt(1)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v220\n"
-      "v_max_f32 v220, v220, v243\n"
+      "v_fma_f32 v220, |v220|, v243, v220\n"
       "v_mfma_f32_16x16x4_f32 v[224:227], v248, v219, v[224:227]\n"
       "ds_read_b128 v[244:247], %8 offset:45312\n"
       "v_mfma_f32_16x16x4_f32 v[228:231], v249, v219, v[228:231]\n"
@@ -758,24 +742,21 @@ __device__ __forceinline__ void dense_hidden4_asm(unsigned w_addr, unsigned b_ad
       "v_mfma_f32_16x16x4_f32 v[236:239], v251, v219, v[236:239]\n"
       "ds_read_b128 v[216:219], %9 offset:896\n"
       "s_waitcnt lgkmcnt(2)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v221\n"
-      "v_max_f32 v221, v221, v243\n"
+      "v_fma_f32 v221, |v221|, v243, v221\n"
       "v_mfma_f32_16x16x4_f32 v[224:227], v252, v220, v[224:227]\n"
       "ds_read_b128 v[248:251], %8 offset:45568\n"
       "v_mfma_f32_16x16x4_f32 v[228:231], v253, v220, v[228:231]\n"
       "v_mfma_f32_16x16x4_f32 v[232:235], v254, v220, v[232:235]\n"
       "v_mfma_f32_16x16x4_f32 v[236:239], v255, v220, v[236:239]\n"
       "s_waitcnt lgkmcnt(2)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v222\n"
-      "v_max_f32 v222, v222, v243\n"
+      "v_fma_f32 v222, |v222|, v243, v222\n"
       "v_mfma_f32_16x16x4_f32 v[224:227], v244, v221, v[224:227]\n"
       "ds_read_b128 v[252:255], %8 offset:45824\n"
       "v_mfma_f32_16x16x4_f32 v[228:231], v245, v221, v[228:231]\n"
       "v_mfma_f32_16x16x4_f32 v[232:235], v246, v221, v[232:235]\n"
       "v_mfma_f32_16x16x4_f32 v[236:239], v247, v221, v[236:239]\n"
       "s_waitcnt lgkmcnt(1)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v223\n"
-      "v_max_f32 v223, v223, v243\n"
+      "v_fma_f32 v223, |v223|, v243, v223\n"
       "v_mfma_f32_16x16x4_f32 v[224:227], v248, v222, v[224:227]\n"
       "ds_read_b128 v[244:247], %8 offset:49152\n"
       "v_mfma_f32_16x16x4_f32 v[228:231], v249, v222, v[228:231]\n"
@@ -789,123 +770,107 @@ __device__ __forceinline__ void dense_hidden4_asm(unsigned w_addr, unsigned b_ad
       "v_mfma_f32_16x16x4_f32 v[236:239], v255, v223, v[236:239]\n"
       "ds_read_b128 v[220:223], %9 offset:960\n"
       "s_nop 15\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v224\n"
-      "v_max_f32 v224, v224, v243\n"
+      "v_fma_f32 v224, |v224|, v243, v224\n"
       "s_waitcnt lgkmcnt(2)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v225\n"
-      "v_max_f32 v225, v225, v243\n"
+      "v_fma_f32 v225, |v225|, v243, v225\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v244, v224, v[208:211]\n"
       "ds_read_b128 v[252:255], %8 offset:49664\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v245, v224, v[212:215]\n"
       "v_mfma_f32_16x16x4_f32 v[216:219], v246, v224, v[216:219]\n"
       "s_waitcnt lgkmcnt(1)\n"
       "v_mfma_f32_16x16x4_f32 v[220:223], v247, v224, v[220:223]\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v226\n"
-      "v_max_f32 v226, v226, v243\n"
+      "v_fma_f32 v226, |v226|, v243, v226\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v248, v225, v[208:211]\n"
       "ds_read_b128 v[244:247], %8 offset:49920\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v249, v225, v[212:215]\n"
       "v_mfma_f32_16x16x4_f32 v[216:219], v250, v225, v[216:219]\n"
       "v_mfma_f32_16x16x4_f32 v[220:223], v251, v225, v[220:223]\n"
       "s_waitcnt lgkmcnt(1)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v227\n"
-      "v_max_f32 v227, v227, v243\n"
+      "v_fma_f32 v227, |v227|, v243, v227\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v252, v226, v[208:211]\n"
       "ds_read_b128 v[248:251], %8 offset:53248\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v253, v226, v[212:215]\n"
       "v_mfma_f32_16x16x4_f32 v[216:219], v254, v226, v[216:219]\n"
       "v_mfma_f32_16x16x4_f32 v[220:223], v255, v226, v[220:223]\n"
       "s_waitcnt lgkmcnt(1)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v228\n"
-      "v_max_f32 v228, v228, v243\n"
+      "v_fma_f32 v228, |v228|, v243, v228\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v244, v227, v[208:211]\n"
       "ds_read_b128 v[252:255], %8 offset:53504\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v245, v227, v[212:215]\n"
       "v_mfma_f32_16x16x4_f32 v[216:219], v246, v227, v[216:219]\n"
       "v_mfma_f32_16x16x4_f32 v[220:223], v247, v227, v[220:223]\n"
       "s_waitcnt lgkmcnt(1)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v229\n"
-      "v_max_f32 v229, v229, v243\n"
+      "v_fma_f32 v229, |v229|, v243, v229\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v248, v228, v[208:211]\n"
       "ds_read_b128 v[244:247], %8 offset:53760\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v249, v228, v[212:215]\n"
       "v_mfma_f32_16x16x4_f32 v[216:219], v250, v228, v[216:219]\n"
       "v_mfma_f32_16x16x4_f32 v[220:223], v251, v228, v[220:223]\n"
       "s_waitcnt lgkmcnt(1)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v230\n"
-      "v_max_f32 v230, v230, v243\n"
+      "v_fma_f32 v230, |v230|, v243, v230\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v252, v229, v[208:211]\n"
       "ds_read_b128 v[248:251], %8 offset:54016\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v253, v229, v[212:215]\n"
       "v_mfma_f32_16x16x4_f32 v[216:219], v254, v229, v[216:219]\n"
       "v_mfma_f32_16x16x4_f32 v[220:223], v255, v229, v[220:223]\n"
       "s_waitcnt lgkmcnt(1)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v231\n"
-      "v_max_f32 v231, v231, v243\n"
+      "v_fma_f32 v231, |v231|, v243, v231\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v244, v230, v[208:211]\n"
       "ds_read_b128 v[252:255], %8 offset:57344\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v245, v230, v[212:215]\n"
       "v_mfma_f32_16x16x4_f32 v[216:219], v246, v230, v[216:219]\n"
       "v_mfma_f32_16x16x4_f32 v[220:223], v247, v230, v[220:223]\n"
       "s_waitcnt lgkmcnt(1)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v232\n"
-      "v_max_f32 v232, v232, v243\n"
+      "v_fma_f32 v232, |v232|, v243, v232\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v248, v231, v[208:211]\n"
       "ds_read_b128 v[244:247], %8 offset:57600\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v249, v231, v[212:215]\n"
       "v_mfma_f32_16x16x4_f32 v[216:219], v250, v231, v[216:219]\n"
       "v_mfma_f32_16x16x4_f32 v[220:223], v251, v231, v[220:223]\n"
       "s_waitcnt lgkmcnt(1)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v233\n"
-      "v_max_f32 v233, v233, v243\n"
+      "v_fma_f32 v233, |v233|, v243, v233\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v252, v232, v[208:211]\n"
       "ds_read_b128 v[248:251], %8 offset:57856\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v253, v232, v[212:215]\n"
       "v_mfma_f32_16x16x4_f32 v[216:219], v254, v232, v[216:219]\n"
       "v_mfma_f32_16x16x4_f32 v[220:223], v255, v232, v[220:223]\n"
       "s_waitcnt lgkmcnt(1)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v234\n"
-      "v_max_f32 v234, v234, v243\n"
+      "v_fma_f32 v234, |v234|, v243, v234\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v244, v233, v[208:211]\n"
       "ds_read_b128 v[252:255], %8 offset:58112\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v245, v233, v[212:215]\n"
       "v_mfma_f32_16x16x4_f32 v[216:219], v246, v233, v[216:219]\n"
       "v_mfma_f32_16x16x4_f32 v[220:223], v247, v233, v[220:223]\n"
       "s_waitcnt lgkmcnt(1)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v235\n"
-      "v_max_f32 v235, v235, v243\n"
+      "v_fma_f32 v235, |v235|, v243, v235\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v248, v234, v[208:211]\n"
       "ds_read_b128 v[244:247], %8 offset:61440\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v249, v234, v[212:215]\n"
       "v_mfma_f32_16x16x4_f32 v[216:219], v250, v234, v[216:219]\n"
       "v_mfma_f32_16x16x4_f32 v[220:223], v251, v234, v[220:223]\n"
       "s_waitcnt lgkmcnt(1)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v236\n"
-      "v_max_f32 v236, v236, v243\n"
+      "v_fma_f32 v236, |v236|, v243, v236\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v252, v235, v[208:211]\n"
       "ds_read_b128 v[248:251], %8 offset:61696\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v253, v235, v[212:215]\n"
       "v_mfma_f32_16x16x4_f32 v[216:219], v254, v235, v[216:219]\n"
       "v_mfma_f32_16x16x4_f32 v[220:223], v255, v235, v[220:223]\n"
       "s_waitcnt lgkmcnt(1)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v237\n"
-      "v_max_f32 v237, v237, v243\n"
+      "v_fma_f32 v237, |v237|, v243, v237\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v244, v236, v[208:211]\n"
       "ds_read_b128 v[252:255], %8 offset:61952\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v245, v236, v[212:215]\n"
       "v_mfma_f32_16x16x4_f32 v[216:219], v246, v236, v[216:219]\n"
       "v_mfma_f32_16x16x4_f32 v[220:223], v247, v236, v[220:223]\n"
       "s_waitcnt lgkmcnt(1)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v238\n"
-      "v_max_f32 v238, v238, v243\n"
+      "v_fma_f32 v238, |v238|, v243, v238\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v248, v237, v[208:211]\n"
       "ds_read_b128 v[244:247], %8 offset:62208\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v249, v237, v[212:215]\n"
       "v_mfma_f32_16x16x4_f32 v[216:219], v250, v237, v[216:219]\n"
       "v_mfma_f32_16x16x4_f32 v[220:223], v251, v237, v[220:223]\n"
       "s_waitcnt lgkmcnt(1)\n"
-      "v_mul_f32 v243, 0x3e4ccccd, v239\n"
-      "v_max_f32 v239, v239, v243\n"
+      "v_fma_f32 v239, |v239|, v243, v239\n"
       "v_mfma_f32_16x16x4_f32 v[208:211], v252, v238, v[208:211]\n"
       "v_mfma_f32_16x16x4_f32 v[212:215], v253, v238, v[212:215]\n"
       "v_mfma_f32_16x16x4_f32 v[216:219], v254, v238, v[216:219]\n"
@@ -1034,6 +999,16 @@ __device__ __forceinline__ void dense_pair(const float *wlA, const float *blA, c
       }
     }
   }
+}
+
+template <int NT, int R>
+__device__ __forceinline__ void lrelu_s_inplace(f32x4 (&a)[R][NT]) {
+#pragma unroll
+  for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a[rr][t][r] = lrelu_s(a[rr][t][r]);
 }
 
 template <int NT, int R>

@@ -50,6 +50,11 @@ struct bgm_handle {
   float *blob_dev = nullptr;
   size_t blob_cap = 0;
   bool blob_valid = false;
+  // sampling copy of the blob: the weights of every layer that consumes a LeakyReLU activation carry the factor 0.6 of the
+  // one-instruction activation lrelu_s (bgm_device.h); rebuilt from blob_dev on the device whenever that one changed
+  float *sblob_dev = nullptr;
+  size_t sblob_cap = 0;
+  bool sblob_valid = false;
   // encoder blob
   float *eblob_dev = nullptr;
   size_t eblob_cap = 0;
@@ -113,6 +118,7 @@ static inline void bgm_g_last_padded(const float *W, const float *b, int p, int 
 }
 
 int bgm_causal_build_blob(bgm_handle *h, hipStream_t stream);
+int bgm_causal_sampling_blob(bgm_handle *h, hipStream_t stream);   // build_blob + the scaled sampling copy (sblob_dev)
 void bgm_bgm_free_state(bgm_handle *h);
 void bgm_egm_free_state(bgm_handle *h);
 void bgm_bgm_egm_free_state(bgm_handle *h);

@@ -34,6 +34,7 @@ extern "C" int bgm_destroy(bgm_handle *h) {
   hipSetDevice(h->device);
   if (h->blob_dev) hipFree(h->blob_dev);
   if (h->eblob_dev) hipFree(h->eblob_dev);
+  if (h->sblob_dev) hipFree(h->sblob_dev);
   if (h->acc_scratch) hipFree(h->acc_scratch);
   bgm_causal_fit_end(h, nullptr);
   bgm_bgm_free_state(h);
@@ -185,8 +186,37 @@ int causal_pack_forward(bgm_handle *h, const HostNet &G, const HostNet &F, const
   return BGM_OK;
 }
 
+// sampling copy of the forward blob: dst = src with the weights of the layers behind a LeakyReLU scaled by 0.6
+static __global__ void causal_scale_blob_kernel(const float *src, float *dst, CausalMeta m, int NTL) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.total) return;
+  auto in = [&](int off, int n) { return i >= off && i < off + n; };
+  const bool scaled = in(m.wg, m.n_gh * 4096) || in(m.wgl, 64 * 16 * NTL) || in(m.wf2, 64 * 32) || in(m.wf3, 32 * 16) ||
+                      in(m.wf4, 16 * 16) || in(m.wh2, 64 * 32) || in(m.wh3, 32 * 16) || in(m.wh4, 16 * 16);
+  dst[i] = scaled ? src[i] * BGM_LRS_W : src[i];
+}
+
+int bgm_causal_sampling_blob(bgm_handle *h, hipStream_t stream) {
+  if (!h->blob_valid) h->sblob_valid = false;
+  int rc = bgm_causal_build_blob(h, stream);
+  if (rc) return rc;
+  if (h->sblob_valid) return BGM_OK;
+  const size_t n = (size_t)h->meta.total;
+  if (h->sblob_cap < n) {
+    if (h->sblob_dev) BGM_HIP_CHECK(hipFree(h->sblob_dev));
+    BGM_HIP_CHECK(hipMalloc(&h->sblob_dev, n * sizeof(float)));
+    h->sblob_cap = n;
+  }
+  hipLaunchKernelGGL(causal_scale_blob_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, h->blob_dev, h->sblob_dev,
+                     h->meta, h->NTL);
+  BGM_HIP_CHECK(hipGetLastError());
+  h->sblob_valid = true;
+  return BGM_OK;
+}
+
 int bgm_causal_build_blob(bgm_handle *h, hipStream_t stream) {
   if (h->blob_valid) return BGM_OK;
+  h->sblob_valid = false;
   for (int id : {BGM_NET_G, BGM_NET_F, BGM_NET_H})
     if (!h->nets[id].set) { bgm_set_error("weights of g/f/h not all set"); return BGM_E_STATE; }
   std::vector<float> blob;
@@ -247,7 +277,7 @@ extern "C" int bgm_causal_logpost(bgm_handle *h, const float *x, const float *y,
   if (!x || !y || !v || !z || !out) { bgm_set_error("bgm_causal_logpost: NULL pointer"); return BGM_E_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
-  int rc = bgm_causal_build_blob(h, stream);
+  int rc = bgm_causal_sampling_blob(h, stream);
   if (rc) return rc;
   const int grid = mh_grid(h, n);
   const int lds = h->meta.total * 4;
@@ -256,7 +286,7 @@ extern "C" int bgm_causal_logpost(bgm_handle *h, const float *x, const float *y,
     auto k = causal_logpost_kernel<KT1_, KSL1_, NTL_, MH_R, MH_WAVES>;                         \
     rc = set_lds(k, lds);                                                                      \
     if (rc) return rc;                                                                         \
-    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * MH_WAVES), lds, stream, h->blob_dev, h->meta,  \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * MH_WAVES), lds, stream, h->sblob_dev, h->meta,  \
                        x, y, v, z, (long long)n, out);                                         \
     BGM_HIP_CHECK(hipGetLastError());                                                          \
     return BGM_OK;                                                                             \
@@ -300,13 +330,13 @@ extern "C" int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *a, void *stre
   if ((a->effect != BGM_EFFECT_NONE || a->draws_dev) && it_end - a->burn_in > a->n_keep) { bgm_set_error("bgm_causal_mh_run: iterations beyond burn_in + n_keep"); return BGM_E_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
-  int rc = bgm_causal_build_blob(h, stream);
+  int rc = bgm_causal_sampling_blob(h, stream);
   if (rc) return rc;
   const int grid = mh_grid(h, a->n);
   const int lds = h->meta.total * 4 + 64;   // + per-wave progress counters
 
   CausalMhKArgs ka{};
-  ka.blob = h->blob_dev; ka.x = a->x_dev; ka.y = a->y_dev; ka.v = a->v_dev;
+  ka.blob = h->sblob_dev; ka.x = a->x_dev; ka.y = a->y_dev; ka.v = a->v_dev;
   ka.n = a->n; ka.row_base = a->row_base; ka.state = a->state_dev; ka.logp = a->logp_dev;
   ka.burn_in = a->burn_in; ka.q_sd = a->q_sd;
   ka.k0 = (unsigned)(a->seed & 0xFFFFFFFFull); ka.k1 = (unsigned)(a->seed >> 32);
@@ -385,10 +415,10 @@ extern "C" int bgm_causal_evaluate(bgm_handle *h, const float *x, const float *y
   if (!binary && (!x_values || n_doses <= 0 || !adrf_partial)) { bgm_set_error("bgm_causal_evaluate: x_values / adrf_partial required"); return BGM_E_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
-  int rc = bgm_causal_build_blob(h, stream);
+  int rc = bgm_causal_sampling_blob(h, stream);
   if (rc) return rc;
   CausalEvalKArgs ka{};
-  ka.blob = h->blob_dev; ka.x = x; ka.y = y; ka.v = v; ka.z = z; ka.n = n; ka.sums = sums;
+  ka.blob = h->sblob_dev; ka.x = x; ka.y = y; ka.v = v; ka.z = z; ka.n = n; ka.sums = sums;
   ka.x_values = x_values; ka.n_doses = binary ? 2 : n_doses; ka.adrf_partial = adrf_partial; ka.ite = ite; ka.m = h->meta;
   const int64_t tiles = (n + 15) / 16;
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((tiles + MH_WAVES - 1) / MH_WAVES, h->n_cus));
@@ -426,10 +456,10 @@ extern "C" int bgm_causal_effects(bgm_handle *h, const float *x, const float *dr
   if (row_base + n > 0xFFFFFFFFll) { bgm_set_error("bgm_causal_effects: row index exceeds the 32-bit RNG counter"); return BGM_E_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
-  int rc = bgm_causal_build_blob(h, stream);
+  int rc = bgm_causal_sampling_blob(h, stream);
   if (rc) return rc;
   CausalEffKArgs ka{};
-  ka.blob = h->blob_dev; ka.x = x; ka.draws = draws; ka.n = n; ka.row_base = row_base; ka.n_keep = n_keep; ka.burn_in = burn_in;
+  ka.blob = h->sblob_dev; ka.x = x; ka.draws = draws; ka.n = n; ka.row_base = row_base; ka.n_keep = n_keep; ka.burn_in = burn_in;
   ka.sample_y = sample_y; ka.n_doses = binary ? 2 : n_doses; ka.x_values = x_values; ka.adrf_partial = adrf_partial; ka.ite = ite;
   ka.k0 = (unsigned)(seed & 0xFFFFFFFFull); ka.k1 = (unsigned)(seed >> 32); ka.m = h->meta;
   const int64_t tiles = (n + 15) / 16;

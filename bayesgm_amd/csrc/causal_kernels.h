@@ -133,10 +133,10 @@ __device__ __forceinline__ void fh_tail(const float *lds, int w2, int b2, int w3
                                         const f32x4 (&a1)[R][4], float (&mu)[R], float (&sr)[R]) {
   f32x4 a2[R][2];
   dense<4, 4, 2, R>(lds + w2, lds + b2, lane_off, g, a1, a2);
-  lrelu_inplace<2, R>(a2);
+  lrelu_s_inplace<2, R>(a2);
   f32x4 a3[R][1];
   dense<2, 4, 1, R>(lds + w3, lds + b3, lane_off, g, a2, a3);
-  lrelu_inplace<1, R>(a3);
+  lrelu_s_inplace<1, R>(a3);
   f32x4 a4[R][1];
   dense<1, 4, 1, R>(lds + w4, lds + b4, lane_off, g, a3, a4);
 #pragma unroll
@@ -165,7 +165,7 @@ __device__ __forceinline__ void causal_logp(const float *lds, const CausalMeta &
   {
     f32x4 h[R][4];
     dense<KT1, KSL1, 4, R>(lds + m.w1g, lds + m.b1g, lane_off, g, zin, h);
-    lrelu_inplace<4, R>(h);
+    lrelu_s_inplace<4, R>(h);
     PMARK(1);
     bool hidden_done = false;
 #ifndef BGM_NO_ASM_HIDDEN4
@@ -173,7 +173,7 @@ __device__ __forceinline__ void causal_logp(const float *lds, const CausalMeta &
       if (m.n_gh == 4) {   // g_units = [64]*5 (every shipped config): all four hidden layers as one scheduled block
         f32x4 q[4];
         dense_hidden4_asm(lds_byte_addr(lds + m.wg + lane_off * 4), lds_byte_addr(lds + m.bg + 4 * g), h[0], q);
-        lrelu_inplace<4, 1>(h);
+        lrelu_s_inplace<4, 1>(h);
         hidden_done = true;
       }
     }
@@ -188,7 +188,7 @@ __device__ __forceinline__ void causal_logp(const float *lds, const CausalMeta &
 #pragma unroll
           for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h[rr][t][r] = lrelu(h2[rr][t][r]);
+            for (int r = 0; r < 4; ++r) h[rr][t][r] = lrelu_s(h2[rr][t][r]);
       }
     }
     PMARK(2);
@@ -205,13 +205,13 @@ __device__ __forceinline__ void causal_logp(const float *lds, const CausalMeta &
   if constexpr (R == 1) {   // the two small nets in lock step (see dense_pair)
     f32x4 f1[1][4], h1[1][4];
     dense_pair<KT1, KSL1, 4>(lds + m.w1f, lds + m.b1f, lds + m.w1h, lds + m.b1h, lane_off, g, zin, zin, f1, h1);
-    lrelu_inplace<4, 1>(f1); lrelu_inplace<4, 1>(h1);
+    lrelu_s_inplace<4, 1>(f1); lrelu_s_inplace<4, 1>(h1);
     f32x4 f2[1][2], h2[1][2];
     dense_pair<4, 4, 2>(lds + m.wf2, lds + m.bf2, lds + m.wh2, lds + m.bh2, lane_off, g, f1, h1, f2, h2);
-    lrelu_inplace<2, 1>(f2); lrelu_inplace<2, 1>(h2);
+    lrelu_s_inplace<2, 1>(f2); lrelu_s_inplace<2, 1>(h2);
     f32x4 f3[1][1], h3[1][1];
     dense_pair<2, 4, 1>(lds + m.wf3, lds + m.bf3, lds + m.wh3, lds + m.bh3, lane_off, g, f2, h2, f3, h3);
-    lrelu_inplace<1, 1>(f3); lrelu_inplace<1, 1>(h3);
+    lrelu_s_inplace<1, 1>(f3); lrelu_s_inplace<1, 1>(h3);
     f32x4 f4[1][1], h4[1][1];
     dense_pair<1, 4, 1>(lds + m.wf4, lds + m.bf4, lds + m.wh4, lds + m.bh4, lane_off, g, f3, h3, f4, h4);
     mu_y[0] = f4[0][0][0]; sr_y[0] = f4[0][0][1];
@@ -220,13 +220,13 @@ __device__ __forceinline__ void causal_logp(const float *lds, const CausalMeta &
     {
       f32x4 a1[R][4];
       dense<KT1, KSL1, 4, R>(lds + m.w1f, lds + m.b1f, lane_off, g, zin, a1);
-      lrelu_inplace<4, R>(a1);
+      lrelu_s_inplace<4, R>(a1);
       fh_tail<R>(lds, m.wf2, m.bf2, m.wf3, m.bf3, m.wf4, m.bf4, lane_off, g, a1, mu_y, sr_y);
     }
     {
       f32x4 a1[R][4];
       dense<KT1, KSL1, 4, R>(lds + m.w1h, lds + m.b1h, lane_off, g, zin, a1);
-      lrelu_inplace<4, R>(a1);
+      lrelu_s_inplace<4, R>(a1);
       fh_tail<R>(lds, m.wh2, m.bh2, m.wh3, m.bh3, m.wh4, m.bh4, lane_off, g, a1, mu_x, sr_x);
     }
   }
@@ -429,7 +429,7 @@ __device__ __forceinline__ void causal_effects(const float *lds, const CausalMet
     float mu[DB * R], sr[DB * R];
 #ifndef BGM_NO_JIT_EFFECTS
     if constexpr (R == 1) {
-      // The dose-specific first-layer activations a1[e] = lrelu(base + wx * x_e) are never materialised: element
+      // The dose-specific first-layer activations a1[e] = lrelu_s(base + wx * x_e) are never materialised: element
       // (t, r) is the B operand of K-step 4t + r of the second layer, so it is computed right there, between the
       // MFMAs of the same wave (the two waves of a SIMD share its VALU issue slots as well as its matrix pipe: a
       // separate 768-instruction VALU block per 4 doses cost its full issue time, VALU placed inside the MFMA stream
@@ -449,7 +449,7 @@ __device__ __forceinline__ void causal_effects(const float *lds, const CausalMet
         af.load(w2 + (16 * t + r) * 16 * 2);
         float bop[DB];
 #pragma unroll
-        for (int e = 0; e < DB; ++e) bop[e] = lrelu(fmaf(wx[t][r], xk[e], base[0][t][r]));
+        for (int e = 0; e < DB; ++e) bop[e] = lrelu_s_pinned(fmaf(wx[t][r], xk[e], base[0][t][r]));
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -470,7 +470,7 @@ __device__ __forceinline__ void causal_effects(const float *lds, const CausalMet
         const int t = s >> 2, r = s & 3;
         const float af = w3[(16 * t + r) * 16];
 #pragma unroll
-        for (int e = 0; e < DB; ++e) a3[e] = BGM_MFMA(af, lrelu(a2[e][t][r]), a3[e]);
+        for (int e = 0; e < DB; ++e) a3[e] = BGM_MFMA(af, lrelu_s(a2[e][t][r]), a3[e]);
       }
       f32x4 a4[DB];
       {
@@ -483,7 +483,7 @@ __device__ __forceinline__ void causal_effects(const float *lds, const CausalMet
       for (int s = 0; s < 4; ++s) {
         const float af = w4[s * 16];
 #pragma unroll
-        for (int e = 0; e < DB; ++e) a4[e] = BGM_MFMA(af, lrelu(a3[e][s]), a4[e]);
+        for (int e = 0; e < DB; ++e) a4[e] = BGM_MFMA(af, lrelu_s(a3[e][s]), a4[e]);
       }
 #pragma unroll
       for (int e = 0; e < DB; ++e) { mu[e] = a4[e][0]; sr[e] = a4[e][1]; }
@@ -498,7 +498,7 @@ __device__ __forceinline__ void causal_effects(const float *lds, const CausalMet
 #pragma unroll
           for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) a1[e * R + rr][t][r] = lrelu(fmaf(wx[t][r], xk[e], base[rr][t][r]));
+            for (int r = 0; r < 4; ++r) a1[e * R + rr][t][r] = lrelu_s(fmaf(wx[t][r], xk[e], base[rr][t][r]));
       fh_tail<DB * R>(lds, m.wf2, m.bf2, m.wf3, m.bf3, m.wf4, m.bf4, lane_off, g, a1, mu, sr);
     }
     float yk[DB][R];
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_eval_kernel(CausalEvalKArgs
     {
       f32x4 h[1][4];
       dense<KT1, KSL1, 4, 1>(lds + m.w1g, lds + m.b1g, lane_off, g, zin, h);
-      lrelu_inplace<4, 1>(h);
+      lrelu_s_inplace<4, 1>(h);
       for (int l = 0; l < m.n_gh; ++l) {
         BGM_NO_HOIST();
         f32x4 h2[1][4];
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_eval_kernel(CausalEvalKArgs
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) h[0][t][r] = lrelu(h2[0][t][r]);
+          for (int r = 0; r < 4; ++r) h[0][t][r] = lrelu_s(h2[0][t][r]);
       }
       const int pc = m.sig_pc;
       g_last_groups<0, 4, NTL, 1>(lds + m.wgl, lds + m.bgl, lane_off, g, pc - 4 * g, h, vreg, ssq, sraw);
@@ -770,13 +770,13 @@ __global__ __launch_bounds__(64 * WAVES) void causal_eval_kernel(CausalEvalKArgs
     {
       f32x4 a1[1][4];
       dense<KT1, KSL1, 4, 1>(lds + m.w1f, lds + m.b1f, lane_off, g, zin, a1);
-      lrelu_inplace<4, 1>(a1);
+      lrelu_s_inplace<4, 1>(a1);
       fh_tail<1>(lds, m.wf2, m.bf2, m.wf3, m.bf3, m.wf4, m.bf4, lane_off, g, a1, mu_y, sr_y);
     }
     {
       f32x4 a1[1][4];
       dense<KT1, KSL1, 4, 1>(lds + m.w1h, lds + m.b1h, lane_off, g, zin, a1);
-      lrelu_inplace<4, 1>(a1);
+      lrelu_s_inplace<4, 1>(a1);
       fh_tail<1>(lds, m.wh2, m.bh2, m.wh3, m.bh3, m.wh4, m.bh4, lane_off, g, a1, mu_x, sr_x);
     }
     if (valid[0]) {

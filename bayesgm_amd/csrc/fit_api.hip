@@ -315,6 +315,7 @@ extern "C" int bgm_causal_fit_theta_apply(bgm_handle *h, const float *grad, floa
                      h->m1_dev, h->m2_dev, grad, np, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS, h->blob_dev, h->bblob_dev, tb,
                      tb + np, tb + 2 * (size_t)np);
   BGM_HIP_CHECK(hipGetLastError());
+  h->sblob_valid = false;   // the sampling copy (evaluate between epochs, predict after the fit) follows the new parameters
   return BGM_OK;
 }
 

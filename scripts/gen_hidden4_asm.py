@@ -18,10 +18,10 @@ def wait(tag):
 def frag_load(l, s, k):      # k = global fragment counter -> buffer
     b = BUF[k % 3]
     load(("F", l, s), f"ds_read_b128 v[{b}:{b+3}], %0 offset:{woff(l, s)}")
-def lrelu(reg):
-    emit(f"v_mul_f32 v{TMP}, 0x3e4ccccd, v{reg}")
-    emit(f"v_max_f32 v{reg}, v{reg}, v{TMP}")
+def lrelu(reg):                  # lrelu_s: x + (2/3)|x| = LeakyReLU(x) / 0.6, v{TMP} holds 2/3
+    emit(f"v_fma_f32 v{reg}, |v{reg}|, v{TMP}, v{reg}")
 emit("s_waitcnt lgkmcnt(0)")
+emit(f"v_mov_b32 v{TMP}, 0x3f2aaaab")
 for t in range(4):
     load(("B", 0, t), f"ds_read_b128 v[{Q0+4*t}:{Q0+4*t+3}], %1 offset:{boff(0, t)}")
 frag_load(0, 0, 0); frag_load(0, 1, 1)
