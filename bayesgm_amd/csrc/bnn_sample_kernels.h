@@ -74,8 +74,11 @@ static __global__ void bns_pack_kernel(BnsPackArgs a) {
     const float *loc = a.theta + n.woff[l], *rho = loc + cnt;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
       const int pos = n.fbase + n.foff[l] + bns_frag_pos(i / out, i % out, n.T[l]);
-      a.lf[pos] = loc[i];
-      a.sf[pos] = BNN_SCALE_EPS + softplus_acc(rho[i]);
+      // layers behind a LeakyReLU consume lrelu_s(x) = LeakyReLU(x) / 0.6 (one instruction, bgm_device.h): their loc and
+      // sigma (hence every perturbation sigma * eps) carry the factor 0.6
+      const float sc = l > 0 ? BGM_LRS_W : 1.0f;
+      a.lf[pos] = sc * loc[i];
+      a.sf[pos] = sc * (BNN_SCALE_EPS + softplus_acc(rho[i]));
     }
   }
 }
@@ -371,7 +374,7 @@ __device__ __forceinline__ void bns_forward(const BnsCtx &c, const BnsNet &n, co
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float y = a1[rt][mt][r] + b[r] + bns_flip(a2[rt][mt][r], w, ((mt & 1) << 4) + 4 * g + r);
-            h[rt][mt][r] = (mt < MT) ? lrelu(y) : 0.0f;
+            h[rt][mt][r] = (mt < MT) ? lrelu_s(y) : 0.0f;
           }
         }
       }
@@ -422,7 +425,7 @@ __device__ __forceinline__ void bns_forward(const BnsCtx &c, const BnsNet &n, co
 #pragma unroll
           for (int rt = 0; rt < BNS_R; ++rt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) hn[rt][mt][r] = (mt < MT) ? lrelu(y[rt][r]) : 0.0f;
+            for (int r = 0; r < 4; ++r) hn[rt][mt][r] = (mt < MT) ? lrelu_s(y[rt][r]) : 0.0f;
         }
 #pragma unroll
         for (int rt = 0; rt < BNS_R; ++rt)
