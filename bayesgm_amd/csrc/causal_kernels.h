@@ -661,7 +661,8 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
       }
       // per-(wave slot, iteration) counter, slot-private: a shared per-iteration word would take ~1e8
       // atomics/s on one address and saturate it (measured: -30 % kernel throughput)
-      if (a.acc_count != nullptr && lane == 0) a.acc_count[slot * (long long)a.n_iters + (it - a.it_begin)] += (unsigned)accmask;
+      // (fire-and-forget atomic: the read-modify-write form made the wave wait for the load of its own counter every iteration)
+      if (a.acc_count != nullptr && lane == 0) atomicAdd(&a.acc_count[slot * (long long)a.n_iters + (it - a.it_begin)], (unsigned)accmask);
 
       PMARK(6);
       if (it >= a.burn_in) {
