@@ -89,27 +89,35 @@ def net_dims(net):
     return [net["layers"][0][0].shape[0]] + [L[0].shape[1] for L in net["layers"]]
 
 
+def _shapes(dims):
+    """[(in, out)] per Flipout layer: from a chain of widths, or already a list of pairs (sibling heads)."""
+    if len(dims) and isinstance(dims[0], (tuple, list)):
+        return [tuple(int(v) for v in d) for d in dims]
+    return [(int(dims[l]), int(dims[l + 1])) for l in range(len(dims) - 1)]
+
+
 def sign_layout(dims):
     """Word offsets of the per-row sign bit string: (sin_w[l], sout_w[l], words per row rounded to 4)."""
     sin_w, sout_w, w = [], [], 0
-    for l in range(len(dims) - 1):
+    for fi, fo in _shapes(dims):
         sin_w.append(w)
-        w += (dims[l] + 31) // 32
+        w += (fi + 31) // 32
         sout_w.append(w)
-        w += (dims[l + 1] + 31) // 32
+        w += (fo + 31) // 32
     return sin_w, sout_w, (w + 3) // 4 * 4
 
 
 def draw_noise(dims, B, key, stream, net_id, dtype=np.float32, row0=0):
     """The noise of ONE call of a net on a batch of B rows: {"eps": [...], "sin": [...], "sout": [...]}."""
     k0, k1 = int(key) & 0xFFFFFFFF, (int(key) >> 32) & 0xFFFFFFFF
+    shapes = _shapes(dims)
     eps = []
-    for l in range(len(dims) - 1):
-        n = dims[l] * dims[l + 1]
+    for l, (fi, fo) in enumerate(shapes):
+        n = fi * fo
         calls = np.arange((n + 3) // 4, dtype=np.uint32)
         bm = R.box_muller4(*R.philox4x32_10(calls, l | (net_id << 16), stream, TAG_EPS, k0, k1))
-        eps.append(np.stack(bm, axis=1).reshape(-1)[:n].reshape(dims[l], dims[l + 1]).astype(dtype))
-    sin_w, sout_w, words = sign_layout(dims)
+        eps.append(np.stack(bm, axis=1).reshape(-1)[:n].reshape(fi, fo).astype(dtype))
+    sin_w, sout_w, words = sign_layout(shapes)
     rows = np.arange(row0, row0 + B, dtype=np.uint32)
     W = np.empty((B, words), dtype=np.uint32)
     for c in range(words // 4):
@@ -122,16 +130,17 @@ def draw_noise(dims, B, key, stream, net_id, dtype=np.float32, row0=0):
         b = (W[:, w0 + (cols >> 5)] >> (cols & 31).astype(np.uint32)) & np.uint32(1)
         return (1.0 - 2.0 * b.astype(np.float64)).astype(dtype)
 
-    sin = [bits(sin_w[l], dims[l]) for l in range(len(dims) - 1)]
-    sout = [bits(sout_w[l], dims[l + 1]) for l in range(len(dims) - 1)]
+    sin = [bits(sin_w[l], shapes[l][0]) for l in range(len(shapes))]
+    sout = [bits(sout_w[l], shapes[l][1]) for l in range(len(shapes))]
     return {"eps": eps, "sin": sin, "sout": sout}
 
 
 def random_noise(rs, dims, B, dtype=np.float64):
     """Noise from a NumPy generator (for the autograd cross-checks)."""
-    return {"eps": [rs.standard_normal((dims[l], dims[l + 1])).astype(dtype) for l in range(len(dims) - 1)],
-            "sin": [rs.choice([-1.0, 1.0], size=(B, dims[l])).astype(dtype) for l in range(len(dims) - 1)],
-            "sout": [rs.choice([-1.0, 1.0], size=(B, dims[l + 1])).astype(dtype) for l in range(len(dims) - 1)]}
+    sh = _shapes(dims)
+    return {"eps": [rs.standard_normal(s).astype(dtype) for s in sh],
+            "sin": [rs.choice([-1.0, 1.0], size=(B, s[0])).astype(dtype) for s in sh],
+            "sout": [rs.choice([-1.0, 1.0], size=(B, s[1])).astype(dtype) for s in sh]}
 
 
 def batch_stats(x):
