@@ -60,6 +60,11 @@ class BnnConfig(C.Structure):
                 ("kl_weight", C.c_float), ("max_batch", C.c_int32), ("norm_mode", C.c_int32)]
 
 
+class BvnConfig(C.Structure):
+    _fields_ = [("x_dim", C.c_int32), ("z_dim", C.c_int32), ("n_hidden_g", C.c_int32), ("g_units", C.c_int32 * BGM_MAX_LAYERS),
+                ("kl_weight", C.c_float), ("max_batch", C.c_int32)]
+
+
 class BnnMhArgs(C.Structure):
     _fields_ = [("x_dev", C.c_void_p), ("y_dev", C.c_void_p), ("v_dev", C.c_void_p), ("n", C.c_int64), ("row_base", C.c_int64),
                 ("block_rows", C.c_int32), ("block0", C.c_int32), ("state_dev", C.c_void_p), ("init", C.c_int32),
@@ -151,6 +156,22 @@ SYMBOLS = {
     "bgm_bgm_egm_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "bgm_bgm_egm_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bgm_bgm_egm_end": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bgm_bvn_layout": (C.c_int, [C.POINTER(BvnConfig), C.POINTER(C.c_int64)]),
+    "bgm_bvn_begin": (C.c_int, [C.c_void_p, C.POINTER(BvnConfig), C.c_void_p, C.c_int64, C.c_void_p]),
+    "bgm_bvn_read": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "bgm_bvn_write": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "bgm_bvn_theta_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_uint64,
+                                     C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "bgm_bvn_grad_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "bgm_bvn_theta_apply": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p]),
+    "bgm_bvn_z_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_uint64,
+                                 C.c_uint32, C.c_void_p, C.c_void_p]),
+    "bgm_bvn_logpost": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_uint32, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]),
+    "bgm_bvn_hmc_run": (C.c_int, [C.c_void_p, C.POINTER(HmcArgs), C.c_void_p]),
+    "bgm_bvn_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_uint64, C.c_uint32,
+                                 C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "bgm_bvn_end": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bgm_bnn_begin": (C.c_int, [C.c_void_p, C.POINTER(BnnConfig), C.c_void_p, C.c_int64, C.c_void_p]),
     "bgm_bnn_layout": (C.c_int, [C.POINTER(BnnConfig), C.POINTER(C.c_int64)]),
     "bgm_bnn_read": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -77,6 +77,7 @@ struct bgm_handle {
   void *egm_state = nullptr;  // EgmState (egm_api.hip)
   void *bgm_egm_state = nullptr;  // BgmEgmState (bgm_egm_api.hip)
   void *bnn_state = nullptr;      // BnnState (bnn_api.hip)
+  void *bvn_state = nullptr;      // BgmbState (bgmb_api.hip)
   // timing
   bool timing = false;
   struct Ev { hipEvent_t a, b; int kind; };
@@ -123,6 +124,7 @@ void bgm_bgm_free_state(bgm_handle *h);
 void bgm_egm_free_state(bgm_handle *h);
 void bgm_bgm_egm_free_state(bgm_handle *h);
 void bgm_bnn_free_state(bgm_handle *h);
+void bgm_bvn_free_state(bgm_handle *h);
 int causal_pack_forward(bgm_handle *h, const HostNet &G, const HostNet &F, const HostNet &H, std::vector<float> &blob);
 
 // ---- packing into MFMA fragment order (layout documented in bgm_device.h)

@@ -1,0 +1,292 @@
+// bgmb_api.hip -- C ABI of BGM with the Bayesian generator (use_bnn=True): session, minibatch steps, log posterior, HMC, decode.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+
+#include "bgm_host.h"
+#include "bgmb_kernels.h"
+#include "bgmb_state.h"
+
+void bgm_bvn_egm_free(void *) {}     // EGM session: bgmb_egm_api.hip (not built yet)
+
+static BgmbState *vst(bgm_handle *h) { return static_cast<BgmbState *>(h->bvn_state); }
+
+void bgm_bvn_free_state(bgm_handle *h) {
+  if (!h->bvn_state) return;
+  BgmbState *s = vst(h);
+  if (s->dev) hipFree(s->dev);
+  if (s->big_dev) hipFree(s->big_dev);
+  bgm_bvn_egm_free(s->egm);
+  delete s;
+  h->bvn_state = nullptr;
+}
+
+int bgmb_fill(const bgm_bvn_config *cfg, BnnNet &n) {
+  if (!cfg) return BGM_E_INVALID;
+  const int T = cfg->n_hidden_g;
+  if (cfg->x_dim < 1 || cfg->z_dim < 1 || T < 1 || T + 2 > BNN_MAX_LAYERS) return BGM_E_INVALID;
+  std::memset(&n, 0, sizeof(n));
+  n.n_layers = T + 2;
+  n.dims[0] = cfg->z_dim;
+  for (int i = 0; i < T; ++i) { if (cfg->g_units[i] < 1) return BGM_E_INVALID; n.dims[i + 1] = cfg->g_units[i]; }
+  n.dims[T + 1] = cfg->x_dim;
+  n.dims[T + 2] = cfg->x_dim;
+  n.off = 0; n.net_id = 0; n.bn_fixed = 0; n.heads = 1; n.mv = 1;
+  n.prior_iv = 100.0f; n.prior_logs = logf(0.1f); n.bias_prior = 1;
+  bnn_finish_net(n);
+  return BGM_OK;
+}
+
+extern "C" int bgm_bvn_layout(const bgm_bvn_config *cfg, int64_t *n_params) {
+  BnnNet n;
+  if (!n_params || bgmb_fill(cfg, n)) { bgm_set_error("bgm_bvn_layout: bad configuration"); return BGM_E_INVALID; }
+  *n_params = n.n_params;
+  return BGM_OK;
+}
+
+extern "C" int bgm_bvn_begin(bgm_handle *h, const bgm_bvn_config *cfg, const float *theta_host, int64_t count, void *stream_) {
+  (void)stream_;
+  if (!h || !cfg || !theta_host) { bgm_set_error("bgm_bvn_begin: NULL argument"); return BGM_E_INVALID; }
+  if (cfg->max_batch < 2 || cfg->max_batch > BGMB_RT) { bgm_set_error("bgm_bvn_begin: max_batch must be in [2, 64]"); return BGM_E_UNSUPPORTED; }
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  bgm_bvn_free_state(h);
+  BgmbState *s = new BgmbState();
+  h->bvn_state = s;
+  s->cfg = *cfg;
+  if (bgmb_fill(cfg, s->net)) { bgm_bvn_free_state(h); bgm_set_error("bgm_bvn_begin: bad configuration"); return BGM_E_INVALID; }
+  s->n_params = s->net.n_params;
+  if (count != s->n_params) { bgm_bvn_free_state(h); bgm_set_error("bgm_bvn_begin: wrong parameter count"); return BGM_E_INVALID; }
+  s->q = cfg->z_dim; s->p = cfg->x_dim;
+  int wmax = std::max(2 * s->p, s->q);
+  for (int i = 0; i <= s->net.n_layers; ++i) wmax = std::max(wmax, s->net.dims[i]);
+  s->wmax = wmax;
+  const int B = cfg->max_batch;
+  s->ws_floats = bgmb_ws_floats(B, s->q, s->p, wmax) + bnn_cache_floats(s->net, B) + 256;
+  const size_t np = ((size_t)s->n_params + 63) & ~(size_t)63;
+  const size_t total = 4 * np + s->ws_floats + 64;
+  BGM_HIP_CHECK(hipMalloc((void **)&s->dev, sizeof(float) * total));
+  BGM_HIP_CHECK(hipMemset(s->dev, 0, sizeof(float) * total));
+  s->theta_dev = s->dev; s->m_dev = s->dev + np; s->v_dev = s->dev + 2 * np; s->grad_dev = s->dev + 3 * np;
+  s->ws_dev = s->dev + 4 * np;
+  s->out_dev = s->ws_dev + s->ws_floats;
+  BGM_HIP_CHECK(hipMemcpy(s->theta_dev, theta_host, sizeof(float) * count, hipMemcpyHostToDevice));
+  s->t_theta = 0; s->t_z = 0;
+  return BGM_OK;
+}
+
+static int bvn_need(bgm_handle *h, const char *who) {
+  if (!h || !h->bvn_state) { bgm_set_error(std::string(who) + ": no session (bgm_bvn_begin)"); return BGM_E_STATE; }
+  return BGM_OK;
+}
+
+static float *bvn_what(BgmbState *s, int what) {
+  return what == 0 ? s->theta_dev : what == 1 ? s->grad_dev : what == 2 ? s->m_dev : what == 3 ? s->v_dev : nullptr;
+}
+
+extern "C" int bgm_bvn_read(bgm_handle *h, int32_t what, float *host, int64_t count, void *stream_) {
+  int rc = bvn_need(h, "bgm_bvn_read");
+  if (rc) return rc;
+  BgmbState *s = vst(h);
+  float *src = bvn_what(s, what);
+  if (!src || !host || count != s->n_params) { bgm_set_error("bgm_bvn_read: bad argument"); return BGM_E_INVALID; }
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  BGM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_));
+  BGM_HIP_CHECK(hipMemcpy(host, src, sizeof(float) * count, hipMemcpyDeviceToHost));
+  return BGM_OK;
+}
+
+extern "C" int bgm_bvn_write(bgm_handle *h, int32_t what, const float *host, int64_t count, void *stream_) {
+  int rc = bvn_need(h, "bgm_bvn_write");
+  if (rc) return rc;
+  BgmbState *s = vst(h);
+  float *dst = bvn_what(s, what);
+  if (!dst || !host || count != s->n_params) { bgm_set_error("bgm_bvn_write: bad argument"); return BGM_E_INVALID; }
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  BGM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_));
+  BGM_HIP_CHECK(hipMemcpy(dst, host, sizeof(float) * count, hipMemcpyHostToDevice));
+  return BGM_OK;
+}
+
+static float bvn_lr_t(float lr, long long t_) {
+  const double t = (double)t_;
+  return (float)((double)lr * std::sqrt(1.0 - std::pow((double)BGMB_ADAM_B2, t)) / (1.0 - std::pow((double)BGMB_ADAM_B1, t)));
+}
+
+static int bvn_step_args(bgm_handle *h, const char *who, BgmbArgs &a, const float *x_dev, float *data_z_dev, const int32_t *idx_dev,
+                         int32_t batch, int32_t batch_global, uint64_t seed, uint32_t stream_id, float *out_dev) {
+  int rc = bvn_need(h, who);
+  if (rc) return rc;
+  BgmbState *s = vst(h);
+  if (!x_dev || !data_z_dev || !idx_dev || batch < 2 || batch > s->cfg.max_batch || batch_global < batch) {
+    bgm_set_error(std::string(who) + ": bad argument"); return BGM_E_INVALID;
+  }
+  std::memset(&a, 0, sizeof(a));
+  a.net = s->net;
+  a.theta = s->theta_dev; a.m = s->m_dev; a.v = s->v_dev; a.grad = s->grad_dev;
+  a.B = batch; a.q = s->q; a.p = s->p; a.wmax = s->wmax; a.kl_weight = s->cfg.kl_weight;
+  a.data_z = data_z_dev; a.idx = idx_dev; a.x_ = x_dev;
+  a.k0 = (uint32_t)(seed & 0xFFFFFFFFull); a.k1 = (uint32_t)(seed >> 32); a.stream = stream_id;
+  a.inv_B = 1.0f / (float)batch_global;
+  a.ws = s->ws_dev; a.out = out_dev;
+  return BGM_OK;
+}
+
+extern "C" int bgm_bvn_theta_step(bgm_handle *h, const float *x_dev, float *data_z_dev, const int32_t *idx_dev, int32_t batch,
+                                  int32_t batch_global, float lr, uint64_t seed, uint32_t stream_id, int32_t apply, float *out_dev,
+                                  void *stream_) {
+  BgmbArgs a;
+  int rc = bvn_step_args(h, "bgm_bvn_theta_step", a, x_dev, data_z_dev, idx_dev, batch, batch_global, seed, stream_id, out_dev);
+  if (rc) return rc;
+  BgmbState *s = vst(h);
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  a.apply = apply ? 1 : 0;
+  if (apply) { s->t_theta += 1; a.adam = BnnAdam{bvn_lr_t(lr, s->t_theta), BGMB_ADAM_B1, BGMB_ADAM_B2, BGMB_ADAM_EPS}; }
+  hipLaunchKernelGGL(bgmb_theta_step_kernel, dim3(1), dim3(BNN_THREADS), 0, (hipStream_t)stream_, a);
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+extern "C" int bgm_bvn_grad_exchange(bgm_handle *h, float *buf_dev, int32_t to_session, void *stream_) {
+  int rc = bvn_need(h, "bgm_bvn_grad_exchange");
+  if (rc) return rc;
+  if (!buf_dev) { bgm_set_error("bgm_bvn_grad_exchange: NULL buffer"); return BGM_E_INVALID; }
+  BgmbState *s = vst(h);
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  BGM_HIP_CHECK(hipMemcpyAsync(to_session ? s->grad_dev : buf_dev, to_session ? buf_dev : s->grad_dev, sizeof(float) * s->n_params,
+                               hipMemcpyDeviceToDevice, (hipStream_t)stream_));
+  return BGM_OK;
+}
+
+extern "C" int bgm_bvn_theta_apply(bgm_handle *h, float lr, void *stream_) {
+  int rc = bvn_need(h, "bgm_bvn_theta_apply");
+  if (rc) return rc;
+  BgmbState *s = vst(h);
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  s->t_theta += 1;
+  const BnnAdam ad{bvn_lr_t(lr, s->t_theta), BGMB_ADAM_B1, BGMB_ADAM_B2, BGMB_ADAM_EPS};
+  hipLaunchKernelGGL(bnn_adam_kernel, dim3((s->n_params + 255) / 256), dim3(256), 0, (hipStream_t)stream_, s->theta_dev, s->m_dev,
+                     s->v_dev, s->grad_dev, s->n_params, ad);
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+extern "C" int bgm_bvn_z_step(bgm_handle *h, const float *x_dev, float *data_z_dev, const int32_t *idx_dev, int32_t batch,
+                              int32_t batch_global, float lr_z, uint64_t seed, uint32_t stream_id, float *out_dev, void *stream_) {
+  BgmbArgs a;
+  int rc = bvn_step_args(h, "bgm_bvn_z_step", a, x_dev, data_z_dev, idx_dev, batch, batch_global, seed, stream_id, out_dev);
+  if (rc) return rc;
+  BgmbState *s = vst(h);
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  s->t_z += 1;
+  a.z_lr_t = bvn_lr_t(lr_z, s->t_z); a.z_b1 = BGMB_ADAM_B1; a.z_b2 = BGMB_ADAM_B2; a.z_eps = BGMB_ADAM_EPS;
+  hipLaunchKernelGGL(bgmb_z_step_kernel, dim3(1), dim3(BNN_THREADS), 0, (hipStream_t)stream_, a);
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+// ----------------------------------------------------------------------------------------- large batches
+static int bvn_big_ws(bgm_handle *h, BgmbState *s, long long tiles, float *&ws, long long &stride) {
+  BnnNet n = s->net;
+  n.bn_fixed = 2;
+  stride = (long long)((bgmb_tile_floats(n, s->q, s->p, s->wmax) + 63) & ~(size_t)63);
+  const size_t need = (size_t)stride * (size_t)tiles;
+  if (need > s->big_cap) {
+    if (s->big_dev) { BGM_HIP_CHECK(hipDeviceSynchronize()); hipFree(s->big_dev); s->big_dev = nullptr; s->big_cap = 0; }
+    BGM_HIP_CHECK(hipMalloc((void **)&s->big_dev, sizeof(float) * need));
+    s->big_cap = need;
+  }
+  (void)h;
+  ws = s->big_dev;
+  return BGM_OK;
+}
+
+static void bvn_big_base(BgmbState *s, BgmbBigArgs &a, uint64_t seed) {
+  std::memset(&a, 0, sizeof(a));
+  a.net = s->net;
+  a.net.bn_fixed = 2;
+  a.theta = s->theta_dev;
+  a.q = s->q; a.p = s->p; a.wmax = s->wmax;
+  a.k0 = (uint32_t)(seed & 0xFFFFFFFFull); a.k1 = (uint32_t)(seed >> 32);
+}
+
+extern "C" int bgm_bvn_logpost(bgm_handle *h, const float *z_dev, const float *x_dev, int64_t n, int64_t row_base, uint64_t seed,
+                               uint32_t stream_id, float *out_dev, float *grad_dev, void *stream_) {
+  int rc = bvn_need(h, "bgm_bvn_logpost");
+  if (rc) return rc;
+  if (!z_dev || !x_dev || !out_dev || n < 0) { bgm_set_error("bgm_bvn_logpost: bad argument"); return BGM_E_INVALID; }
+  if (n == 0) return BGM_OK;
+  BgmbState *s = vst(h);
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  const long long tiles = (n + BGMB_RT - 1) / BGMB_RT;
+  BgmbBigArgs a;
+  bvn_big_base(s, a, seed);
+  rc = bvn_big_ws(h, s, tiles, a.ws, a.ws_stride);
+  if (rc) return rc;
+  a.x = x_dev; a.n = n; a.row_base = row_base;
+  a.state = const_cast<float *>(z_dev); a.logp = out_dev; a.grad = grad_dev;
+  a.stream = stream_id;
+  hipLaunchKernelGGL(bgmb_logpost_kernel, dim3((unsigned)tiles), dim3(BNN_THREADS), 0, (hipStream_t)stream_, a);
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+extern "C" int bgm_bvn_hmc_run(bgm_handle *h, const bgm_hmc_args *g, void *stream_) {
+  int rc = bvn_need(h, "bgm_bvn_hmc_run");
+  if (rc) return rc;
+  if (!g || !g->x_dev || !g->state_dev || !g->logp_dev || !g->grad_dev || !g->step_dev || g->n < 0 || g->n_iters < 0 ||
+      g->n_leapfrog < 1) { bgm_set_error("bgm_bvn_hmc_run: bad argument"); return BGM_E_INVALID; }
+  if (g->n == 0 || (g->n_iters == 0 && !g->init)) return BGM_OK;
+  BgmbState *s = vst(h);
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  const long long tiles = (g->n + BGMB_RT - 1) / BGMB_RT;
+  BgmbBigArgs a;
+  bvn_big_base(s, a, g->seed);
+  rc = bvn_big_ws(h, s, tiles, a.ws, a.ws_stride);
+  if (rc) return rc;
+  a.x = g->x_dev; a.n = g->n; a.row_base = g->row_base;
+  a.state = g->state_dev; a.logp = g->logp_dev; a.grad = g->grad_dev;
+  a.init = g->init; a.it_begin = g->it_begin; a.n_iters = g->n_iters; a.burn_in = g->burn_in; a.n_leapfrog = g->n_leapfrog;
+  a.step = g->step_dev;
+  a.acc_prob_sum = g->acc_prob_sum_dev; a.acc_count = g->acc_count_dev; a.draws = g->draws_dev;
+  hipLaunchKernelGGL(bgmb_hmc_kernel, dim3((unsigned)tiles), dim3(BNN_THREADS), 0, (hipStream_t)stream_, a);
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+extern "C" int bgm_bvn_decode(bgm_handle *h, const float *draws_dev, int64_t n, int64_t row_base, int32_t n_draws, int32_t burn_in,
+                              uint64_t seed, uint32_t stream_id, const int32_t *slot_dev, int32_t k_slots, float *cells_dev,
+                              float *full_dev, float *var_full_dev, int32_t add_noise, void *stream_) {
+  int rc = bvn_need(h, "bgm_bvn_decode");
+  if (rc) return rc;
+  if (!draws_dev || n < 0 || n_draws < 0 || (cells_dev && (!slot_dev || k_slots < 1))) {
+    bgm_set_error("bgm_bvn_decode: bad argument"); return BGM_E_INVALID;
+  }
+  const long long total = (long long)n * n_draws;
+  if (total == 0) return BGM_OK;
+  if (total >= (1LL << 32)) { bgm_set_error("bgm_bvn_decode: n_draws * n must stay below 2^32 (split the rows)"); return BGM_E_UNSUPPORTED; }
+  BgmbState *s = vst(h);
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  const long long tiles = std::min<long long>((total + BGMB_RT - 1) / BGMB_RT, 2048);
+  BgmbDecodeArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.net = s->net; a.net.bn_fixed = 2;
+  a.theta = s->theta_dev; a.q = s->q; a.p = s->p;
+  rc = bvn_big_ws(h, s, tiles, a.ws, a.ws_stride);
+  if (rc) return rc;
+  a.draws = draws_dev; a.n = n; a.row_base = row_base; a.n_draws = n_draws; a.burn_in = burn_in;
+  a.k0 = a.x0 = (uint32_t)(seed & 0xFFFFFFFFull); a.k1 = a.x1 = (uint32_t)(seed >> 32); a.stream = stream_id;
+  a.slot = slot_dev; a.k_slots = k_slots; a.cells = cells_dev; a.full = full_dev; a.var_full = var_full_dev; a.add_noise = add_noise;
+  hipLaunchKernelGGL(bgmb_decode_kernel, dim3((unsigned)tiles), dim3(BNN_THREADS), 0, (hipStream_t)stream_, a);
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+extern "C" int bgm_bvn_end(bgm_handle *h, void *stream_) {
+  if (!h) { bgm_set_error("bgm_bvn_end: NULL handle"); return BGM_E_INVALID; }
+  if (!h->bvn_state) return BGM_OK;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  BGM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_));
+  bgm_bvn_free_state(h);
+  return BGM_OK;
+}

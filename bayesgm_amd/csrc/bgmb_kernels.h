@@ -1,0 +1,356 @@
+// bgmb_kernels.h -- BGM with the Bayesian generator (use_bnn=True) on gfx950 (BayesianVariationalNet).
+//
+// replaces (src/bayesgm/models/networks/bnn.py:40-99 BayesianVariationalNet = BatchNormalization that honours `training` +
+// DenseFlipout trunk + two sibling DenseFlipout heads, kernel AND bias prior N(0, 0.1^2)) inside
+//   BGM.update_g_net                 bgm/base.py:145-164 (KL term :155-157)  -> bgmb_theta_step_kernel
+//   BGM.update_latent_variable_sgd   bgm/base.py:167-187                     -> bgmb_z_step_kernel
+//   BGM.get_log_posterior            bgm/base.py:665-705 (training=False)    -> bgmb_logpost_kernel
+//   BGM.tfp_mcmc_sampler             bgm/base.py:709-830                     -> bgmb_hmc_kernel
+//   predict_on_posteriors / generate / evaluate  :511-525, :478-509, :444-476 -> bgmb_decode_kernel
+// Arithmetic and noise layout: oracle/bgm_bnn.py.  DenseFlipout perturbs the kernel in every call, also at inference, so
+// the HMC target is stochastic: each gradient evaluation is one generator call (one perturbation shared by all rows, signs
+// per row keyed by the global row).
+//
+// Everything here is built from the Flipout building blocks of bnn_kernels.h (two-accumulator fp32-MFMA GEMMs over
+// workspace in HBM / L2).  The minibatch steps are one workgroup; the large-batch kernels give each workgroup a tile of
+// BGMB_RT rows which it carries through whole HMC transitions (chains are independent; the per-call perturbation is a pure
+// function of (seed, stream), so every workgroup regenerates the same one).  This is the first correct version of this
+// path, not a tuned one.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "bnn_kernels.h"
+
+#define BGMB_RT 64
+#define BGMB_STREAM_PREDICT 0x40000000u
+#define BGMB_STREAM_DECODE 0x50000000u
+
+// feature f of oracle/rng.py normals(rows, it, n_feat, tag)
+__device__ __forceinline__ float bgmb_normal(uint32_t row, uint32_t it, int f, uint32_t tag, uint32_t k0, uint32_t k1) {
+  const int g = f & 3, s = f >> 2;
+  const f32x4 e = box_muller4(philox4x32_10(row, it, (uint32_t)(g + 4 * (s >> 2)), tag, k0, k1));
+  const int u = s & 3;
+  return u == 0 ? e[0] : (u == 1 ? e[1] : (u == 2 ? e[2] : e[3]));
+}
+
+// Per-cell Gaussian terms of rows [0, B): o = mean [B x p] | raw variance [B x p]; x [B x p] with NaN = missing.
+//   ll[i]      = (x - mean)^2 / (2 s2) + log(s2) / 2           (0 for a missing cell)
+//   d[i]       = w * d ll / d mean,  d[B p + i] = w * d ll / d raw
+// Returns the thread's partial sum of squared residuals.
+__device__ __forceinline__ float bgmb_cells(const BnnCtx &c, const float *o, const float *x, int B, int p, float w, float *d, float *ll) {
+  float sq = 0.0f;
+  const int Bp = B * p;
+  for (int i = c.tid; i < Bp; i += BNN_THREADS) {
+    const float xv = x[i], raw = o[Bp + i];
+    const bool ok = xv == xv;
+    const float r = ok ? xv - o[i] : 0.0f;
+    const float s2 = softplus_acc(raw) + BGM_EPS;
+    ll[i] = ok ? r * r / (2.0f * s2) + 0.5f * logf(s2) : 0.0f;
+    d[i] = -r / s2 * w;
+    d[Bp + i] = ok ? (-r * r / (2.0f * s2 * s2) + 0.5f / s2) * sigmoid_f(raw) * w : 0.0f;
+    sq = fmaf(r, r, sq);
+  }
+  return sq;
+}
+
+struct BgmbArgs {
+  BnnNet net;                            // generator: heads = 1, mv = 1, bn_fixed = 0
+  float *theta, *m, *v, *grad;
+  int B, q, p, wmax;
+  float kl_weight;
+  float *data_z;                         // [N x q]
+  const int *idx;                        // [B]
+  const float *x_;                       // panel [N x p]
+  uint32_t k0, k1, stream;
+  BnnAdam adam;
+  int apply;                             // theta step: 1 = Adam inside the kernel, 0 = gradient stays in grad
+  float inv_B;                           // 1 / global batch
+  float z_lr_t, z_b1, z_b2, z_eps;       // fresh-slot Adam of the batch latents (bgm/base.py:402)
+  float *ws;
+  float *out;                            // theta: [loss_x + kl_weight KL, loss_mse];  z: [loss_postrior_z]
+};
+
+struct BgmbWs { float *zb, *xb, *d, *ds, *t0, *t1, *ll, *dx; };
+__device__ __forceinline__ void bgmb_take(float *&wp, BgmbWs &w, int B, int q, int p, int wmax) {
+  auto take = [&](long long n) { float *r = wp; wp += (n + 3) & ~3LL; return r; };
+  w.zb = take((long long)B * q); w.xb = take((long long)B * p);
+  w.d = take((long long)B * wmax); w.ds = take((long long)B * wmax); w.t0 = take((long long)B * wmax); w.t1 = take((long long)B * wmax);
+  w.ll = take((long long)B * p); w.dx = take((long long)B * q);
+}
+inline size_t bgmb_ws_floats(int B, int q, int p, int wmax) {
+  return (size_t)B * (2 * (size_t)q + 2 * (size_t)p + 4 * (size_t)wmax) + 64;
+}
+
+// update_g_net (bgm/base.py:145-164)
+static __global__ __launch_bounds__(BNN_THREADS) void bgmb_theta_step_kernel(BgmbArgs a) {
+  __shared__ float red[32];
+  __shared__ float rowv[BGMB_RT];
+  BnnCtx c{(int)threadIdx.x, red};
+  const BnnNet &n = a.net;
+  const int B = a.B, p = a.p, q = a.q;
+  float *wp = a.ws;
+  BgmbWs w;
+  bgmb_take(wp, w, B, q, p, a.wmax);
+  for (int i = c.tid; i < B * q; i += BNN_THREADS) w.zb[i] = a.data_z[(long long)a.idx[i / q] * q + i % q];
+  for (int i = c.tid; i < B * p; i += BNN_THREADS) w.xb[i] = a.x_[(long long)a.idx[i / p] * p + i % p];
+  __syncthreads();
+  BnnCache k;
+  bnn_cache(n, B, wp, k, w.zb);
+  const float *o = bnn_fwd(c, a.theta, n, k, B, a.k0, a.k1, a.stream);
+  float sq = bgmb_cells(c, o, w.xb, B, p, a.inv_B, w.d, w.ll);
+  sq = bnn_block_sum(c, sq);
+  for (int b = c.tid; b < B; b += BNN_THREADS) {
+    float s = 0.0f;
+    for (int j = 0; j < p; ++j) s += w.ll[b * p + j];
+    rowv[b] = s;
+  }
+  __syncthreads();
+  float loss = 0.0f;
+  for (int b = 0; b < B; ++b) loss += rowv[b];
+  bnn_bwd(c, a.theta, a.grad, n, k, w.d, w.ds, w.t0, w.t1, nullptr, B, true, false);
+  const float klv = bnn_kl(c, a.theta, a.grad, n, a.kl_weight);
+  __syncthreads();
+  bnn_bn_move(c, a.theta, n, k);
+  __syncthreads();
+  if (a.apply) bnn_adam(c, a.theta + n.off, a.m + n.off, a.v + n.off, a.grad + n.off, n.n_params, a.adam);
+  if (c.tid == 0 && a.out) { a.out[0] = loss * a.inv_B + a.kl_weight * klv; a.out[1] = sq / (float)(B * p); }
+}
+
+// update_latent_variable_sgd (bgm/base.py:167-187) + the fresh-slot Adam step on the batch rows (:402)
+static __global__ __launch_bounds__(BNN_THREADS) void bgmb_z_step_kernel(BgmbArgs a) {
+  __shared__ float red[32];
+  __shared__ float rowv[BGMB_RT];
+  BnnCtx c{(int)threadIdx.x, red};
+  const BnnNet &n = a.net;
+  const int B = a.B, p = a.p, q = a.q;
+  float *wp = a.ws;
+  BgmbWs w;
+  bgmb_take(wp, w, B, q, p, a.wmax);
+  for (int i = c.tid; i < B * q; i += BNN_THREADS) w.zb[i] = a.data_z[(long long)a.idx[i / q] * q + i % q];
+  for (int i = c.tid; i < B * p; i += BNN_THREADS) w.xb[i] = a.x_[(long long)a.idx[i / p] * p + i % p];
+  __syncthreads();
+  BnnCache k;
+  bnn_cache(n, B, wp, k, w.zb);
+  const float *o = bnn_fwd(c, a.theta, n, k, B, a.k0, a.k1, a.stream);
+  bgmb_cells(c, o, w.xb, B, p, a.inv_B, w.d, w.ll);
+  __syncthreads();
+  for (int b = c.tid; b < B; b += BNN_THREADS) {
+    float s = 0.0f, zz = 0.0f;
+    for (int j = 0; j < p; ++j) s += w.ll[b * p + j];
+    for (int j = 0; j < q; ++j) zz = fmaf(w.zb[b * q + j], w.zb[b * q + j], zz);
+    rowv[b] = s + 0.5f * zz;
+  }
+  __syncthreads();
+  float loss = 0.0f;
+  for (int b = 0; b < B; ++b) loss += rowv[b];
+  bnn_bwd(c, a.theta, a.grad, n, k, w.d, w.ds, w.t0, w.t1, w.dx, B, false, false);
+  for (int i = c.tid; i < B * q; i += BNN_THREADS) {
+    const float z = w.zb[i], g = w.dx[i] + z * a.inv_B;
+    const float m = (1.0f - a.z_b1) * g, v = (1.0f - a.z_b2) * g * g;
+    a.data_z[(long long)a.idx[i / q] * q + i % q] = z - a.z_lr_t * m / (sqrtf(v) + a.z_eps);
+  }
+  bnn_bn_move(c, a.theta, n, k);
+  if (c.tid == 0 && a.out) a.out[0] = loss * a.inv_B;
+}
+
+// ---------------------------------------------------------------------------------------------
+// large batches, training = False: row tiles of BGMB_RT rows per workgroup
+// ---------------------------------------------------------------------------------------------
+struct BgmbBigArgs {
+  BnnNet net;                  // generator with bn_fixed = 2 (moving statistics)
+  const float *theta;
+  int q, p, wmax;
+  const float *x;              // [n x p], NaN = missing
+  long long n, row_base;
+  float *state, *logp, *grad;  // HMC: [n x q], [n], [n x q] in/out;  logpost: z in (state), outputs logp / grad (grad may be NULL)
+  int init, it_begin, n_iters, burn_in, n_leapfrog;
+  const float *step;
+  uint32_t k0, k1, stream;
+  double *acc_prob_sum;
+  uint32_t *acc_count;
+  float *draws;                // [n_keep x n x q]
+  float *ws;
+  long long ws_stride;
+};
+
+struct BgmbTile { float *z, *gr, *zc, *pc, *grc, *mom, *xb, *d, *ds, *t0, *t1, *ll; float *cache; };
+__device__ __forceinline__ void bgmb_tile_take(float *wp, BgmbTile &t, int q, int p, int wmax) {
+  auto take = [&](long long n) { float *r = wp; wp += (n + 3) & ~3LL; return r; };
+  const long long B = BGMB_RT;
+  t.z = take(B * q); t.gr = take(B * q); t.zc = take(B * q); t.pc = take(B * q); t.grc = take(B * q); t.mom = take(B * q);
+  t.xb = take(B * p);
+  t.d = take(B * wmax); t.ds = take(B * wmax); t.t0 = take(B * wmax); t.t1 = take(B * wmax);
+  t.ll = take(B * p);
+  t.cache = wp;
+}
+inline size_t bgmb_tile_floats(const BnnNet &n, int q, int p, int wmax) {
+  return (size_t)BGMB_RT * (6 * (size_t)q + 2 * (size_t)p + 4 * (size_t)wmax) + 96 + bnn_cache_floats(n, BGMB_RT);
+}
+
+// log p(z | x_obs) + const and its gradient for the B rows of a tile, ONE generator call (`stream`); lp -> lpv [B] (LDS),
+// gradient -> gr [B x q].  Ends with a barrier.
+__device__ __forceinline__ void bgmb_lpg(const BnnCtx &c, const BgmbBigArgs &a, const BgmbTile &t, const float *zin, int B,
+                                         uint32_t stream, uint32_t row0, float *lpv, float *gr) {
+  const BnnNet &n = a.net;
+  float *wp = t.cache;
+  BnnCache k;
+  bnn_cache(n, B, wp, k, zin);
+  const float *o = bnn_fwd(c, a.theta, n, k, B, a.k0, a.k1, stream, row0);
+  bgmb_cells(c, o, t.xb, B, a.p, -1.0f, t.d, t.ll);
+  __syncthreads();
+  for (int b = c.tid; b < B; b += BNN_THREADS) {
+    float s = 0.0f, zz = 0.0f;
+    for (int j = 0; j < a.p; ++j) s += t.ll[b * a.p + j];
+    for (int j = 0; j < a.q; ++j) zz = fmaf(zin[b * a.q + j], zin[b * a.q + j], zz);
+    lpv[b] = -(s + 0.5f * zz);
+  }
+  if (gr) {
+    bnn_bwd(c, a.theta, nullptr, n, k, t.d, t.ds, t.t0, t.t1, gr, B, false, false);
+    for (int i = c.tid; i < B * a.q; i += BNN_THREADS) gr[i] -= zin[i];
+  }
+  __syncthreads();
+}
+
+// get_log_posterior for given z (state): logp [n], grad [n x q] (optional)
+static __global__ __launch_bounds__(BNN_THREADS) void bgmb_logpost_kernel(BgmbBigArgs a) {
+  __shared__ float red[32];
+  __shared__ float lpv[BGMB_RT];
+  BnnCtx c{(int)threadIdx.x, red};
+  const long long r0 = (long long)blockIdx.x * BGMB_RT;
+  const int B = (int)min((long long)BGMB_RT, a.n - r0), q = a.q, p = a.p;
+  BgmbTile t;
+  bgmb_tile_take(a.ws + (long long)blockIdx.x * a.ws_stride, t, q, p, a.wmax);
+  for (int i = c.tid; i < B * q; i += BNN_THREADS) t.z[i] = a.state[r0 * q + i];
+  for (int i = c.tid; i < B * p; i += BNN_THREADS) t.xb[i] = a.x[r0 * p + i];
+  __syncthreads();
+  bgmb_lpg(c, a, t, t.z, B, a.stream, (uint32_t)(a.row_base + r0), lpv, a.grad ? t.gr : nullptr);
+  for (int b = c.tid; b < B; b += BNN_THREADS) a.logp[r0 + b] = lpv[b];
+  if (a.grad) for (int i = c.tid; i < B * q; i += BNN_THREADS) a.grad[r0 * q + i] = t.gr[i];
+}
+
+// HMC transitions [it_begin, it_begin + n_iters) of the rows of a tile (oracle/bgm_bnn.py hmc_sampler)
+static __global__ __launch_bounds__(BNN_THREADS) void bgmb_hmc_kernel(BgmbBigArgs a) {
+  __shared__ float red[32];
+  __shared__ float lpv[BGMB_RT], lpc[BGMB_RT], ke0[BGMB_RT];
+  __shared__ int accv[BGMB_RT];
+  BnnCtx c{(int)threadIdx.x, red};
+  const long long r0 = (long long)blockIdx.x * BGMB_RT;
+  const int B = (int)min((long long)BGMB_RT, a.n - r0), q = a.q, p = a.p, L = a.n_leapfrog;
+  const uint32_t row0 = (uint32_t)(a.row_base + r0);
+  BgmbTile t;
+  bgmb_tile_take(a.ws + (long long)blockIdx.x * a.ws_stride, t, q, p, a.wmax);
+  for (int i = c.tid; i < B * p; i += BNN_THREADS) t.xb[i] = a.x[r0 * p + i];
+  if (a.init) {
+    for (int i = c.tid; i < B * q; i += BNN_THREADS) t.z[i] = bgmb_normal(row0 + (uint32_t)(i / q), 0u, i % q, TAG_INIT, a.k0, a.k1);
+    __syncthreads();
+    bgmb_lpg(c, a, t, t.z, B, 0u, row0, lpv, t.gr);
+  } else {
+    for (int i = c.tid; i < B * q; i += BNN_THREADS) { t.z[i] = a.state[r0 * q + i]; t.gr[i] = a.grad[r0 * q + i]; }
+    for (int b = c.tid; b < B; b += BNN_THREADS) lpv[b] = a.logp[r0 + b];
+    __syncthreads();
+  }
+  for (int it = a.it_begin; it < a.it_begin + a.n_iters; ++it) {
+    const float e = *a.step;
+    for (int i = c.tid; i < B * q; i += BNN_THREADS) {
+      const float mo = bgmb_normal(row0 + (uint32_t)(i / q), (uint32_t)it, i % q, TAG_MOM, a.k0, a.k1);
+      t.mom[i] = mo;
+      t.zc[i] = t.z[i];
+      t.pc[i] = mo + 0.5f * e * t.gr[i];
+    }
+    __syncthreads();
+    for (int b = c.tid; b < B; b += BNN_THREADS) {
+      float s = 0.0f;
+      for (int j = 0; j < q; ++j) s = fmaf(t.mom[b * q + j], t.mom[b * q + j], s);
+      ke0[b] = s;
+    }
+    for (int l = 0; l < L; ++l) {
+      for (int i = c.tid; i < B * q; i += BNN_THREADS) t.zc[i] = fmaf(e, t.pc[i], t.zc[i]);
+      __syncthreads();
+      bgmb_lpg(c, a, t, t.zc, B, 1u + (uint32_t)it * (uint32_t)L + (uint32_t)l, row0, lpc, t.grc);
+      const float h = (l < L - 1) ? e : 0.5f * e;
+      for (int i = c.tid; i < B * q; i += BNN_THREADS) t.pc[i] = fmaf(h, t.grc[i], t.pc[i]);
+      __syncthreads();
+    }
+    float pa = 0.0f;
+    int na = 0;
+    for (int b = c.tid; b < B; b += BNN_THREADS) {
+      float s = 0.0f;
+      for (int j = 0; j < q; ++j) s = fmaf(t.pc[b * q + j], t.pc[b * q + j], s);
+      float lr = -((-lpc[b] + 0.5f * s) - (-lpv[b] + 0.5f * ke0[b]));
+      lr = (lr == lr && fabsf(lr) != INFINITY) ? lr : -INFINITY;
+      const uint4 w4 = philox4x32_10(row0 + (uint32_t)b, (uint32_t)it >> 2, 0u, TAG_HACC, a.k0, a.k1);
+      const uint32_t w_ = (it & 2) ? ((it & 1) ? w4.w : w4.z) : ((it & 1) ? w4.y : w4.x);
+      const bool acc = logf(u01_open(w_)) < lr;
+      accv[b] = acc ? 1 : 0;
+      if (acc) lpv[b] = lpc[b];
+      pa += expf(fminf(lr, 0.0f));
+      na += acc ? 1 : 0;
+    }
+    __syncthreads();
+    for (int i = c.tid; i < B * q; i += BNN_THREADS)
+      if (accv[i / q]) { t.z[i] = t.zc[i]; t.gr[i] = t.grc[i]; }
+    pa = bnn_block_sum(c, pa);
+    const float nf = bnn_block_sum(c, (float)na);
+    if (c.tid == 0) {
+      if (a.acc_prob_sum) atomicAdd(a.acc_prob_sum + it, (double)pa);
+      if (a.acc_count) atomicAdd(a.acc_count + it, (uint32_t)(nf + 0.5f));
+    }
+    __syncthreads();
+    if (a.draws && it >= a.burn_in)
+      for (int i = c.tid; i < B * q; i += BNN_THREADS) a.draws[((long long)(it - a.burn_in) * a.n + r0) * q + i] = t.z[i];
+  }
+  __syncthreads();
+  for (int i = c.tid; i < B * q; i += BNN_THREADS) { a.state[r0 * q + i] = t.z[i]; a.grad[r0 * q + i] = t.gr[i]; }
+  for (int b = c.tid; b < B; b += BNN_THREADS) a.logp[r0 + b] = lpv[b];
+}
+
+// g_net(z, training=False) over flat rows [n_draws * n] (one call: one perturbation, signs keyed by the flat row), then
+// x = mean + sqrt(var) * noise (tag 6 keyed by the GLOBAL row and burn_in + draw, as the deterministic path).
+struct BgmbDecodeArgs {
+  BnnNet net;
+  const float *theta;
+  int q, p;
+  const float *draws;          // [n_draws x n x q]
+  long long n, row_base;
+  int n_draws, burn_in;
+  uint32_t k0, k1, stream;     // Flipout noise key / stream of the call
+  uint32_t x0, x1;             // key of the x-noise
+  const int *slot; int k_slots;
+  float *cells, *full, *var_full;
+  int add_noise;
+  float *ws;
+  long long ws_stride;
+};
+static __global__ __launch_bounds__(BNN_THREADS) void bgmb_decode_kernel(BgmbDecodeArgs a) {
+  __shared__ float red[32];
+  BnnCtx c{(int)threadIdx.x, red};
+  const long long total = (long long)a.n_draws * a.n;
+  const int q = a.q, p = a.p;
+  float *base = a.ws + (long long)blockIdx.x * a.ws_stride;
+  for (long long f0 = (long long)blockIdx.x * BGMB_RT; f0 < total; f0 += (long long)gridDim.x * BGMB_RT) {
+    const int B = (int)min((long long)BGMB_RT, total - f0);
+    float *wp = base;
+    BnnCache k;
+    bnn_cache(a.net, B, wp, k, a.draws + f0 * q);
+    const float *o = bnn_fwd(c, a.theta, a.net, k, B, a.k0, a.k1, a.stream, (uint32_t)f0);
+    for (int i = c.tid; i < B * p; i += BNN_THREADS) {
+      const long long f = f0 + i / p;
+      const int col = i % p;
+      const long long d = f / a.n, row = f - d * a.n;
+      const float s2 = softplus_acc(o[B * p + i]) + BGM_EPS;
+      float xp = o[i];
+      if (a.add_noise) {
+        const f32x4 e = box_muller4(philox4x32_10((uint32_t)(a.row_base + row), (uint32_t)(a.burn_in + d), (uint32_t)(col >> 2), TAG_XNOISE, a.x0, a.x1));
+        const int u = col & 3;
+        xp = fmaf(sqrtf(s2), u == 0 ? e[0] : (u == 1 ? e[1] : (u == 2 ? e[2] : e[3])), xp);
+      }
+      if (a.full) a.full[f * p + col] = xp;
+      if (a.var_full) a.var_full[f * p + col] = s2;
+      if (a.cells) {
+        const int sl = a.slot[row * (long long)p + col];
+        if (sl >= 0) a.cells[(row * (long long)a.k_slots + sl) * a.n_draws + d] = xp;
+      }
+    }
+    __syncthreads();
+  }
+}

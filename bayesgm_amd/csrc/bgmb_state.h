@@ -1,0 +1,26 @@
+// bgmb_state.h -- host-side session state of BGM with the Bayesian generator (bgmb_api.hip, bgmb_egm_api.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/bgm_hip.h"
+#include "bnn_kernels.h"
+
+#define BGMB_ADAM_B1 0.9f
+#define BGMB_ADAM_B2 0.99f
+#define BGMB_ADAM_EPS 1e-7f
+
+struct BgmbState {
+  bgm_bvn_config cfg{};
+  BnnNet net{};
+  int n_params = 0, q = 0, p = 0, wmax = 0;
+  float *dev = nullptr;        // one allocation: theta | m | v | grad | workspace | out
+  float *theta_dev = nullptr, *m_dev = nullptr, *v_dev = nullptr, *grad_dev = nullptr, *ws_dev = nullptr, *out_dev = nullptr;
+  size_t ws_floats = 0;
+  long long t_theta = 0, t_z = 0;
+  float *big_dev = nullptr;    // row-tile workspace of the large-batch kernels (grown on demand)
+  size_t big_cap = 0;
+  void *egm = nullptr;         // BgmbEgmState (bgmb_egm_api.hip)
+};
+
+int bgmb_fill(const bgm_bvn_config *cfg, BnnNet &n);
+void bgm_bvn_egm_free(void *egm_state);

@@ -28,29 +28,51 @@
 // One BayesianFullyConnectedNet.  Parameters (flat, at theta + off): gamma[in], beta[in], then per layer
 // loc[in x out], rho[in x out], bias[out].  All prefix tables are filled on the host (bnn_finish_net).
 struct BnnNet {
-  int n_layers;                       // DenseFlipout layers (hidden + output)
+  int n_layers;                       // DenseFlipout layers (hidden + output; with `heads` the last two are the sibling heads)
   int dims[BNN_MAX_LAYERS + 1];
   int off, n_params, net_id;
-  int bn_fixed;                       // 1: normalise with mean 0 / variance 1 instead of the batch statistics
+  int bn_fixed;                       // 0: batch statistics; 1: mean 0 / variance 1; 2: the moving statistics (needs mv)
+  int heads;                          // 1: BayesianVariationalNet (networks/bnn.py:40-99): layers L-2 (mean) and L-1 (var) both read
+                                      //    the output of layer L-3; dims = [in, trunk..., p, p]
+  int mv;                             // 1: moving mean[in], moving variance[in] stored after beta (they get a zero gradient)
+  float prior_iv, prior_logs;         // kernel prior N(0, s^2): 1 / s^2 and log s
+  int bias_prior;                     // 1: the bias has the same prior; KL(point mass || prior) = -log prior(bias)
+  int lin[BNN_MAX_LAYERS], lout[BNN_MAX_LAYERS];   // fan-in / fan-out of layer l
+  int hin[BNN_MAX_LAYERS];            // input of layer l at B * hin[l] (H) ...
+  int hsin[BNN_MAX_LAYERS];           // ... and its sign-flipped copy at B * hsin[l] (HS)
+  int hs_total;                       // HS floats per row
   int woff[BNN_MAX_LAYERS];           // loc of layer l (rho at + in*out, bias at + 2*in*out)
-  int hoff[BNN_MAX_LAYERS + 2];       // h_l (input of layer l; h_L = output) at B * hoff[l]; hoff[L+1] = total width
+  int hoff[BNN_MAX_LAYERS + 2];       // output of layer l at B * hoff[l + 1]; hoff[L+1] = total width of H
   int eoff[BNN_MAX_LAYERS + 1];       // eps / dW of layer l inside one call's noise block; eoff[L] = kernel elements
   int sin_w[BNN_MAX_LAYERS], sout_w[BNN_MAX_LAYERS], swords;   // sign words per row (oracle/bnn.py sign_layout)
 };
 inline void bnn_finish_net(BnnNet &n) {
-  int o = n.off + 2 * n.dims[0], h = 0, e = 0, w = 0;
-  for (int l = 0; l < n.n_layers; ++l) {
-    const int in = n.dims[l], out = n.dims[l + 1];
+  const int L = n.n_layers;
+  int o = n.off + (n.mv ? 4 : 2) * n.dims[0], h = 0, e = 0, w = 0;
+  if (n.prior_iv == 0.0f) { n.prior_iv = 1.0f; n.prior_logs = 0.0f; }
+  for (int l = 0; l < L; ++l) {
+    const bool var_head = n.heads && l == L - 1;
+    const int in = var_head ? n.dims[L - 2] : n.dims[l], out = n.dims[l + 1];
+    n.lin[l] = in; n.lout[l] = out;
     n.woff[l] = o; o += 2 * in * out + out;
-    n.hoff[l] = h; h += in;
+    n.hoff[l] = h; h += n.dims[l];
+    n.hin[l] = var_head ? n.hoff[L - 2] : n.hoff[l];
+    n.hsin[l] = n.hin[l];
     n.eoff[l] = e; e += in * out;
     n.sin_w[l] = w; w += (in + 31) / 32;
     n.sout_w[l] = w; w += (out + 31) / 32;
   }
-  n.hoff[n.n_layers] = h; n.hoff[n.n_layers + 1] = h + n.dims[n.n_layers];
-  n.eoff[n.n_layers] = e;
+  n.hoff[L] = h; n.hoff[L + 1] = h + n.dims[L];
+  n.hs_total = n.hoff[L + 1];
+  if (n.heads) { n.hsin[L - 1] = n.hs_total; n.hs_total += n.dims[L - 2]; }
+  n.eoff[L] = e;
   n.swords = (w + 3) / 4 * 4;
   n.n_params = o - n.off;
+}
+// floats of one call cache (bnn_cache) for a batch of B rows
+inline size_t bnn_cache_floats(const BnnNet &n, int B) {
+  return (size_t)B * n.dims[0] + 3 * (size_t)n.dims[0] + (size_t)B * (n.hoff[n.n_layers + 1] + n.hs_total) + 2 * (size_t)n.eoff[n.n_layers] +
+         (size_t)B * n.swords + 64;
 }
 
 struct BnnAdam { float lr_t, b1, b2, eps; };
@@ -124,7 +146,8 @@ __device__ __forceinline__ void bnn_gemm2(int tid, BnnMat A1, BnnMat A2, BnnMat 
 struct BnnCache {
   const float *x;     // [B x in] raw input of the call
   float *xhat, *inv;  // normalised input [B x in], 1 / sqrt(var + eps) [in]
-  float *H, *HS;      // h_l and h_l * s_in(l) at B * hoff[l]
+  float *mu;          // nets with moving statistics: batch mean [in] | batch variance [in]
+  float *H, *HS;      // h_l and h_l * s_in(l) at B * hin[l] / B * hsin[l]
   float *eps, *dW;    // [kernel elements]
   uint32_t *sg;       // [B x swords]
 };
@@ -133,8 +156,9 @@ __device__ __forceinline__ void bnn_cache(const BnnNet &n, int B, float *&p, Bnn
   k.x = input;
   k.xhat = take((long long)B * n.dims[0]);
   k.inv = take(n.dims[0]);
+  k.mu = n.mv ? take(2 * n.dims[0]) : nullptr;     // batch mean | batch variance
   k.H = take((long long)B * n.hoff[n.n_layers + 1]);
-  k.HS = take((long long)B * n.hoff[n.n_layers + 1]);
+  k.HS = take((long long)B * n.hs_total);
   k.eps = take(n.eoff[n.n_layers]);
   k.dW = take(n.eoff[n.n_layers]);
   k.sg = (uint32_t *)take((long long)B * n.swords);
@@ -142,9 +166,9 @@ __device__ __forceinline__ void bnn_cache(const BnnNet &n, int B, float *&p, Bnn
 
 // eps, dW = sigma * eps and the sign words of call `stream` (oracle/bnn.py draw_noise).  No barrier at the end.
 __device__ __forceinline__ void bnn_noise(const BnnCtx &c, const float *theta, const BnnNet &n, const BnnCache &k, int B,
-                                          uint32_t k0, uint32_t k1, uint32_t stream) {
+                                          uint32_t k0, uint32_t k1, uint32_t stream, uint32_t row0 = 0u) {
   for (int l = 0; l < n.n_layers; ++l) {
-    const int cnt = n.dims[l] * n.dims[l + 1];
+    const int cnt = n.lin[l] * n.lout[l];
     const float *rho = theta + n.woff[l] + cnt;
     float *e = k.eps + n.eoff[l], *d = k.dW + n.eoff[l];
     for (int i = c.tid; i < (cnt + 3) >> 2; i += BNN_THREADS) {
@@ -159,24 +183,31 @@ __device__ __forceinline__ void bnn_noise(const BnnCtx &c, const float *theta, c
   const int calls = n.swords >> 2;
   for (int i = c.tid; i < B * calls; i += BNN_THREADS) {
     const int r = i / calls, cc = i - r * calls;
-    const uint4 w = philox4x32_10((uint32_t)r, (uint32_t)cc | ((uint32_t)n.net_id << 16), stream, BNN_TAG_SIGN, k0, k1);
+    const uint4 w = philox4x32_10(row0 + (uint32_t)r, (uint32_t)cc | ((uint32_t)n.net_id << 16), stream, BNN_TAG_SIGN, k0, k1);
     uint32_t *dst = k.sg + (long long)r * n.swords + 4 * cc;
     dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
   }
 }
 
-// BatchNormalization on batch statistics, h_0 = gamma * xhat + beta, and hs_0.  Needs the sign words (barrier before).
+// BatchNormalization, h_0 = gamma * xhat + beta, and hs_0.  Needs the sign words (barrier before).
 __device__ __forceinline__ void bnn_bn_fwd(const BnnCtx &c, const float *theta, const BnnNet &n, const BnnCache &k, int B) {
   const int in = n.dims[0];
-  const float *gamma = theta + n.off, *beta = gamma + in;
+  const float *gamma = theta + n.off, *beta = gamma + in, *mvs = beta + in;
   for (int i = c.tid; i < in; i += BNN_THREADS) {
-    float s = 0.0f;
-    for (int b = 0; b < B; ++b) s += k.x[(long long)b * in + i];
-    const float mu = n.bn_fixed ? 0.0f : s / (float)B;
-    float v = 0.0f;
-    for (int b = 0; b < B; ++b) { const float d = k.x[(long long)b * in + i] - mu; v = fmaf(d, d, v); }
-    const float inv = 1.0f / sqrtf((n.bn_fixed ? 1.0f : v / (float)B) + BNN_BN_EPS);
+    float mu, var;
+    if (n.bn_fixed == 1) { mu = 0.0f; var = 1.0f; }
+    else if (n.bn_fixed == 2) { mu = mvs[i]; var = mvs[in + i]; }
+    else {
+      float s = 0.0f;
+      for (int b = 0; b < B; ++b) s += k.x[(long long)b * in + i];
+      mu = s / (float)B;
+      float v = 0.0f;
+      for (int b = 0; b < B; ++b) { const float d = k.x[(long long)b * in + i] - mu; v = fmaf(d, d, v); }
+      var = v / (float)B;
+    }
+    const float inv = 1.0f / sqrtf(var + BNN_BN_EPS);
     k.inv[i] = inv;
+    if (k.mu) { k.mu[i] = mu; k.mu[in + i] = var; }
     for (int b = 0; b < B; ++b) {
       const float xh = (k.x[(long long)b * in + i] - mu) * inv;
       const float h = xh * gamma[i] + beta[i];
@@ -187,70 +218,131 @@ __device__ __forceinline__ void bnn_bn_fwd(const BnnCtx &c, const float *theta, 
   }
 }
 
+// moving averages of a training-mode call (momentum 0.99, biased batch variance; Keras BatchNormalization)
+__device__ __forceinline__ void bnn_bn_move(const BnnCtx &c, float *theta, const BnnNet &n, const BnnCache &k) {
+  const int in = n.dims[0];
+  float *mvs = theta + n.off + 2 * in;
+  for (int i = c.tid; i < in; i += BNN_THREADS) {
+    mvs[i] = mvs[i] * 0.99f + k.mu[i] * (1.0f - 0.99f);
+    mvs[in + i] = mvs[in + i] * 0.99f + k.mu[in + i] * (1.0f - 0.99f);
+  }
+}
+
 // forward of the Flipout stack (after bnn_noise + barrier + bnn_bn_fwd + barrier)
 __device__ __forceinline__ void bnn_layers_fwd(const BnnCtx &c, const float *theta, const BnnNet &n, const BnnCache &k, int B) {
   const int L = n.n_layers;
   for (int l = 0; l < L; ++l) {
-    const int in = n.dims[l], out = n.dims[l + 1];
+    const int in = n.lin[l], out = n.lout[l];
     const float *loc = theta + n.woff[l], *bias = loc + 2 * in * out;
-    const float *h = k.H + (long long)B * n.hoff[l], *hs = k.HS + (long long)B * n.hoff[l];
+    const float *h = k.H + (long long)B * n.hin[l], *hs = k.HS + (long long)B * n.hsin[l];
     float *y = k.H + (long long)B * n.hoff[l + 1], *ys = k.HS + (long long)B * n.hoff[l + 1];
-    const bool last = (l == L - 1);
-    const int so = n.sout_w[l], si = last ? 0 : n.sin_w[l + 1];
+    const bool last = (l == L - 1) || (n.heads && l == L - 2);
+    const bool feeds_heads = n.heads && l == L - 3;
+    float *ys2 = k.HS + (long long)B * n.hsin[L - 1];
+    const int so = n.sout_w[l], si = last ? 0 : n.sin_w[l + 1], si2 = n.sin_w[L - 1];
     bnn_gemm2(c.tid, BnnMat{h, in, 1}, BnnMat{hs, in, 1}, BnnMat{loc, out, 1}, BnnMat{k.dW + n.eoff[l], out, 1}, B, out, in,
               c.tid >> 6, BNN_THREADS / 64, [&](int m, int o, float c1, float c2) {
                 float v = c1 + bias[o] + bnn_sign(k.sg, n.swords, m, so, o) * c2;
                 if (!last) v = fmaxf(v, BNN_LEAK * v);
                 y[(long long)m * out + o] = v;
                 if (!last) ys[(long long)m * out + o] = v * bnn_sign(k.sg, n.swords, m, si, o);
+                if (feeds_heads) ys2[(long long)m * out + o] = v * bnn_sign(k.sg, n.swords, m, si2, o);
               });
-    __syncthreads();
+    if (!(n.heads && l == L - 2)) __syncthreads();     // the two heads are independent
   }
 }
 
 __device__ __forceinline__ float *bnn_fwd(const BnnCtx &c, const float *theta, const BnnNet &n, const BnnCache &k, int B,
-                                          uint32_t k0, uint32_t k1, uint32_t stream) {
-  bnn_noise(c, theta, n, k, B, k0, k1, stream);
+                                          uint32_t k0, uint32_t k1, uint32_t stream, uint32_t row0 = 0u) {
+  bnn_noise(c, theta, n, k, B, k0, k1, stream, row0);
   __syncthreads();
   bnn_bn_fwd(c, theta, n, k, B);
   __syncthreads();
   bnn_layers_fwd(c, theta, n, k, B);
-  return k.H + (long long)B * n.hoff[n.n_layers];
+  return k.H + (long long)B * n.hoff[n.heads ? n.n_layers - 1 : n.n_layers];     // heads: mean [B x p], then var-raw [B x p]
 }
 
-// Backward of one call.  d [B x out_L]: upstream gradient (destroyed); ds, t0, t1: scratch [B x widest layer];
+// Parameter gradients of layer l from its input (h, hs) and the upstream gradient (cur, curs = cur * s_out).
+__device__ __forceinline__ void bnn_bwd_params(const BnnCtx &c, const float *theta, float *grad, const BnnNet &n, const BnnCache &k,
+                                               int l, const float *cur, const float *curs, int B, bool accumulate) {
+  const int in = n.lin[l], out = n.lout[l], nw = BNN_THREADS / 64, wave = c.tid >> 6;
+  const float *rho = theta + n.woff[l] + in * out;
+  const float *h = k.H + (long long)B * n.hin[l], *hs = k.HS + (long long)B * n.hsin[l];
+  float *gloc = grad + n.woff[l], *grho = gloc + in * out, *gb = grho + in * out;
+  const float *eps = k.eps + n.eoff[l];
+  bnn_gemm2(c.tid, BnnMat{h, 1, in}, BnnMat{hs, 1, in}, BnnMat{cur, out, 1}, BnnMat{curs, out, 1}, in, out, B, wave, nw,
+            [&](int i, int o, float c1, float c2) {
+              const int t = i * out + o;
+              const float r = c2 * eps[t] * sigmoid_f(rho[t]);
+              gloc[t] = accumulate ? gloc[t] + c1 : c1;
+              grho[t] = accumulate ? grho[t] + r : r;
+            });
+  for (int o = c.tid; o < out; o += BNN_THREADS) {
+    float s = 0.0f;
+    for (int b = 0; b < B; ++b) s += cur[(long long)b * out + o];
+    gb[o] = accumulate ? gb[o] + s : s;
+  }
+}
+
+// Backward of one call.  d: upstream gradient (destroyed) -- [B x out_L], or with heads [B x p] for the mean followed by
+// [B x p] for the raw variance; ds, t0, t1: scratch of the same size (at least B x the widest layer);
 // grad (layout of theta) receives / accumulates the parameter gradients when `want_params`; dx [B x in] (may be NULL)
 // receives the gradient w.r.t. the raw input (through the batch statistics).
 __device__ __forceinline__ void bnn_bwd(const BnnCtx &c, const float *theta, float *grad, const BnnNet &n, const BnnCache &k,
                                         float *d, float *ds, float *t0, float *t1, float *dx, int B, bool want_params,
                                         bool accumulate) {
   const int L = n.n_layers, nw = BNN_THREADS / 64, wave = c.tid >> 6;
-  {
-    const int out = n.dims[L];
-    for (int i = c.tid; i < B * out; i += BNN_THREADS) ds[i] = d[i] * bnn_sign(k.sg, n.swords, i / out, n.sout_w[L - 1], i % out);
-  }
-  __syncthreads();
   float *cur = d, *curs = ds, *nxt = t0, *nxts = t1;
-  for (int l = L - 1; l >= 0; --l) {
-    const int in = n.dims[l], out = n.dims[l + 1];
-    const float *loc = theta + n.woff[l], *rho = loc + in * out;
-    const float *h = k.H + (long long)B * n.hoff[l], *hs = k.HS + (long long)B * n.hoff[l];
+  int l_top = L - 1;
+  if (n.heads) {
+    const int p = n.lout[L - 1], in = n.lin[L - 1];
+    float *dv = d + (long long)B * p, *dvs = ds + (long long)B * p;
+    for (int i = c.tid; i < B * p; i += BNN_THREADS) {
+      ds[i] = d[i] * bnn_sign(k.sg, n.swords, i / p, n.sout_w[L - 2], i % p);
+      dvs[i] = dv[i] * bnn_sign(k.sg, n.swords, i / p, n.sout_w[L - 1], i % p);
+    }
+    __syncthreads();
+    if (want_params) {
+      bnn_bwd_params(c, theta, grad, n, k, L - 2, d, ds, B, accumulate);
+      bnn_bwd_params(c, theta, grad, n, k, L - 1, dv, dvs, B, accumulate);
+    }
+    const float *h = k.H + (long long)B * n.hin[L - 1];
+    {   // variance head -> t1 (raw), then mean head adds its share, applies the activation mask of the trunk output
+      const float *loc = theta + n.woff[L - 1];
+      const int si = n.sin_w[L - 1];
+      bnn_gemm2(c.tid, BnnMat{dv, p, 1}, BnnMat{dvs, p, 1}, BnnMat{loc, 1, p}, BnnMat{k.dW + n.eoff[L - 1], 1, p}, B, in, p, wave, nw,
+                [&](int m, int i, float c1, float c2) { t1[(long long)m * in + i] = c1 + bnn_sign(k.sg, n.swords, m, si, i) * c2; });
+    }
+    __syncthreads();
+    {
+      const float *loc = theta + n.woff[L - 2];
+      const int si = n.sin_w[L - 2], sop = L >= 3 ? n.sout_w[L - 3] : 0;
+      bnn_gemm2(c.tid, BnnMat{d, p, 1}, BnnMat{ds, p, 1}, BnnMat{loc, 1, p}, BnnMat{k.dW + n.eoff[L - 2], 1, p}, B, in, p, wave, nw,
+                [&](int m, int i, float c1, float c2) {
+                  const long long t = (long long)m * in + i;
+                  float v = c1 + bnn_sign(k.sg, n.swords, m, si, i) * c2 + t1[t];
+                  if (L >= 3) {
+                    v *= (h[t] > 0.0f) ? 1.0f : BNN_LEAK;
+                    t1[t] = v * bnn_sign(k.sg, n.swords, m, sop, i);
+                  }
+                  t0[t] = v;
+                });
+    }
+    __syncthreads();
+    cur = t0; curs = t1; nxt = d; nxts = ds;
+    l_top = L - 3;
+  } else {
+    const int out = n.lout[L - 1];
+    for (int i = c.tid; i < B * out; i += BNN_THREADS) ds[i] = d[i] * bnn_sign(k.sg, n.swords, i / out, n.sout_w[L - 1], i % out);
+    __syncthreads();
+  }
+  for (int l = l_top; l >= 0; --l) {
+    const int in = n.lin[l], out = n.lout[l];
+    const float *loc = theta + n.woff[l];
+    const float *h = k.H + (long long)B * n.hin[l];
     int first = wave;
     if (want_params) {
-      float *gloc = grad + n.woff[l], *grho = gloc + in * out, *gb = grho + in * out;
-      const float *eps = k.eps + n.eoff[l];
-      bnn_gemm2(c.tid, BnnMat{h, 1, in}, BnnMat{hs, 1, in}, BnnMat{cur, out, 1}, BnnMat{curs, out, 1}, in, out, B, wave, nw,
-                [&](int i, int o, float c1, float c2) {
-                  const int t = i * out + o;
-                  const float r = c2 * eps[t] * sigmoid_f(rho[t]);
-                  gloc[t] = accumulate ? gloc[t] + c1 : c1;
-                  grho[t] = accumulate ? grho[t] + r : r;
-                });
-      for (int o = c.tid; o < out; o += BNN_THREADS) {
-        float s = 0.0f;
-        for (int b = 0; b < B; ++b) s += cur[(long long)b * out + o];
-        gb[o] = accumulate ? gb[o] + s : s;
-      }
+      bnn_bwd_params(c, theta, grad, n, k, l, cur, curs, B, accumulate);
       const int t_w = ((in + 15) >> 4) * ((out + 15) >> 4);
       first = (wave - t_w % nw + nw) % nw;
     }
@@ -271,9 +363,10 @@ __device__ __forceinline__ void bnn_bwd(const BnnCtx &c, const float *theta, flo
     float *t = cur; cur = nxt; nxt = t;
     t = curs; curs = nxts; nxts = t;
   }
-  // cur = dLoss/dh_0 [B x in]: gamma, beta and the input gradient through the batch statistics
+  // cur = dLoss/dh_0 [B x in]: gamma, beta and the input gradient (through the batch statistics unless they are constants)
   const int in = n.dims[0];
   const float *gamma = theta + n.off;
+  const bool fixed = n.bn_fixed != 0;
   for (int i = c.tid; i < in; i += BNN_THREADS) {
     float sg_ = 0.0f, sb = 0.0f;
     for (int b = 0; b < B; ++b) { const float v = cur[(long long)b * in + i]; sg_ = fmaf(v, k.xhat[(long long)b * in + i], sg_); sb += v; }
@@ -283,7 +376,7 @@ __device__ __forceinline__ void bnn_bwd(const BnnCtx &c, const float *theta, flo
       gbt[i] = accumulate ? gbt[i] + sb : sb;
     }
     if (dx) {
-      const float m1 = n.bn_fixed ? 0.0f : sb * gamma[i] / (float)B, m2 = n.bn_fixed ? 0.0f : sg_ * gamma[i] / (float)B, inv = k.inv[i];
+      const float m1 = fixed ? 0.0f : sb * gamma[i] / (float)B, m2 = fixed ? 0.0f : sg_ * gamma[i] / (float)B, inv = k.inv[i];
       for (int b = 0; b < B; ++b) {
         const long long t = (long long)b * in + i;
         dx[t] = inv * (cur[t] * gamma[i] - m1 - k.xhat[t] * m2);
@@ -293,18 +386,27 @@ __device__ __forceinline__ void bnn_bwd(const BnnCtx &c, const float *theta, flo
   __syncthreads();
 }
 
-// grad += w * dKL/dtheta for every kernel of the net; returns KL (every thread).  Prior N(0, 1).
+// grad += w * dKL/dtheta for every kernel (and, with bias_prior, every bias) of the net; returns sum(net.losses) (every thread).
 __device__ __forceinline__ float bnn_kl(const BnnCtx &c, const float *theta, float *grad, const BnnNet &n, float w) {
   float acc = 0.0f;
+  const float iv = n.prior_iv, ls = n.prior_logs;
   for (int l = 0; l < n.n_layers; ++l) {
-    const int cnt = n.dims[l] * n.dims[l + 1];
+    const int cnt = n.lin[l] * n.lout[l];
     const float *loc = theta + n.woff[l], *rho = loc + cnt;
     float *gloc = grad + n.woff[l], *grho = gloc + cnt;
     for (int i = c.tid; i < cnt; i += BNN_THREADS) {
       const float sg = BNN_SCALE_EPS + softplus_acc(rho[i]), mu = loc[i];
-      acc += -logf(sg) + 0.5f * (sg * sg + mu * mu) - 0.5f;
-      gloc[i] += w * mu;
-      grho[i] += w * (-1.0f / sg + sg) * sigmoid_f(rho[i]);
+      acc += -logf(sg) + 0.5f * (sg * sg + mu * mu) * iv - 0.5f + ls;
+      gloc[i] += w * mu * iv;
+      grho[i] += w * (-1.0f / sg + sg * iv) * sigmoid_f(rho[i]);
+    }
+    if (n.bias_prior) {
+      const float *b = rho + cnt;
+      float *gb = grho + cnt;
+      for (int i = c.tid; i < n.lout[l]; i += BNN_THREADS) {
+        acc += 0.5f * b[i] * b[i] * iv + ls + 0.9189385332046727f;
+        gb[i] += w * b[i] * iv;
+      }
     }
   }
   return bnn_block_sum(c, acc);

@@ -41,6 +41,7 @@ extern "C" int bgm_destroy(bgm_handle *h) {
   bgm_egm_free_state(h);
   bgm_bgm_egm_free_state(h);
   bgm_bnn_free_state(h);
+  bgm_bvn_free_state(h);
   for (auto &e : h->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   delete h;
   return BGM_OK;

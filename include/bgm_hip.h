@@ -516,6 +516,54 @@ int bgm_bnn_evaluate(bgm_handle *h, const float *x_dev, const float *y_dev, cons
                      int64_t n, const float *x_values_dev, int32_t n_doses, uint64_t seed, uint32_t stream_id,
                      double *sums_dev, double *dose_sums_dev, float *ite_dev, void *stream);
 
+/* ==========================================================================================
+ * BGM with the Bayesian generator (params['use_bnn'] = True; bgm/base.py:67-69).
+ * g_net = BayesianVariationalNet (networks/bnn.py:40-99): BatchNormalization that honours `training`, DenseFlipout trunk +
+ * LeakyReLU(0.2), two sibling DenseFlipout heads (mean, softplus variance + 1e-6); kernel AND bias prior N(0, 0.1^2).
+ * Flat parameter layout: gamma[q], beta[q], moving_mean[q], moving_variance[q], then loc [in x out], rho [in x out],
+ * bias [out] per layer in the order trunk..., mean head, var head.  Noise: oracle/bgm_bnn.py (key = seed, one stream id per
+ * generator call).  Every call perturbs the kernels, also with training=False.
+ * ========================================================================================== */
+typedef struct {
+  int32_t x_dim, z_dim;
+  int32_t n_hidden_g, g_units[BGM_MAX_LAYERS];
+  float kl_weight;               /* params['kl_weight'] */
+  int32_t max_batch;             /* largest minibatch of the step functions (2..64) */
+} bgm_bvn_config;
+int bgm_bvn_layout(const bgm_bvn_config *cfg, int64_t *n_params);
+/* Open a session with the parameters theta_host (layout above).  Adam slots start at zero. */
+int bgm_bvn_begin(bgm_handle *h, const bgm_bvn_config *cfg, const float *theta_host, int64_t count, void *stream);
+/* what = 0 parameters, 1 gradient of the last theta step, 2 / 3 Adam slots */
+int bgm_bvn_read(bgm_handle *h, int32_t what, float *host, int64_t count, void *stream);
+int bgm_bvn_write(bgm_handle *h, int32_t what, const float *host, int64_t count, void *stream);
+/* replaces: BGM.update_g_net with use_bnn, bgm/base.py:145-164 (loss_x + kl_weight * sum(g_net.losses); training-mode
+ * BatchNormalization incl. its moving averages).  apply = 1: Adam(lr, 0.9, 0.99) inside the call; apply = 0: the gradient
+ * (of the mean over batch_global rows) stays in the session for bgm_bvn_grad_exchange / bgm_bvn_theta_apply.
+ * out_dev [2] = loss_x, loss_mse (may be NULL). */
+int bgm_bvn_theta_step(bgm_handle *h, const float *x_dev, float *data_z_dev, const int32_t *idx_dev, int32_t batch,
+                       int32_t batch_global, float lr, uint64_t seed, uint32_t stream_id, int32_t apply, float *out_dev,
+                       void *stream);
+int bgm_bvn_grad_exchange(bgm_handle *h, float *buf_dev, int32_t to_session, void *stream);
+int bgm_bvn_theta_apply(bgm_handle *h, float lr, void *stream);
+/* replaces: BGM.update_latent_variable_sgd with use_bnn, bgm/base.py:167-187, and the fresh-slot Adam step on the batch rows
+ * of data_z (:402).  out_dev [1] = loss_postrior_z. */
+int bgm_bvn_z_step(bgm_handle *h, const float *x_dev, float *data_z_dev, const int32_t *idx_dev, int32_t batch,
+                   int32_t batch_global, float lr_z, uint64_t seed, uint32_t stream_id, float *out_dev, void *stream);
+/* replaces: BGM.get_log_posterior with use_bnn, bgm/base.py:665-705: ONE generator call (stream_id) over the n rows (global
+ * rows row_base + i key the Flipout signs); x_dev NaN = missing; grad_dev [n x q] may be NULL. */
+int bgm_bvn_logpost(bgm_handle *h, const float *z_dev, const float *x_dev, int64_t n, int64_t row_base, uint64_t seed,
+                    uint32_t stream_id, float *out_dev, float *grad_dev, void *stream);
+/* replaces: tfp.mcmc.HamiltonianMonteCarlo.one_step on the stochastic target (bgm/base.py:798-821): gradient evaluation
+ * `leap` of transition `it` is generator call 1 + it * n_leapfrog + leap (call 0 = bootstrap when init = 1); the cached
+ * log-prob / gradient of the current state are kept, as TFP does.  Same argument struct as bgm_bgm_hmc_run. */
+int bgm_bvn_hmc_run(bgm_handle *h, const bgm_hmc_args *args, void *stream);
+/* replaces: g_net(z, training=False) + reparameterize in predict_on_posteriors / generate / evaluate (:511-525, :478-509,
+ * :444-476): ONE generator call (stream_id) over the flattened [n_draws x n] rows.  Outputs as bgm_bgm_predict_draws. */
+int bgm_bvn_decode(bgm_handle *h, const float *draws_dev, int64_t n, int64_t row_base, int32_t n_draws, int32_t burn_in,
+                   uint64_t seed, uint32_t stream_id, const int32_t *slot_dev, int32_t k_slots, float *cells_dev,
+                   float *full_dev, float *var_full_dev, int32_t add_noise, void *stream);
+int bgm_bvn_end(bgm_handle *h, void *stream);
+
 /* Debug: throughput of the hand-scheduled 64x4-tile MFMA block alone (mode 1: fragments streamed from LDS; mode 0:
  * register operands only) with `waves_per_cu` waves on every CU. */
 int bgm_debug_group_probe(bgm_handle *h, int32_t mode, int32_t waves_per_cu, int32_t iters, double *mfma_tflops);
