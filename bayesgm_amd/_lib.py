@@ -172,6 +172,17 @@ SYMBOLS = {
     "bgm_bvn_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_uint64, C.c_uint32,
                                  C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "bgm_bvn_end": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bgm_bvn_egm_begin": (C.c_int, [C.c_void_p, C.POINTER(BgmEgmConfig), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                    C.c_int64, C.c_void_p]),
+    "bgm_bvn_egm_disc_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_uint64, C.c_uint32,
+                                        C.c_int32, C.c_void_p, C.c_void_p]),
+    "bgm_bvn_egm_gen_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32,
+                                       C.c_void_p, C.c_void_p]),
+    "bgm_bvn_egm_read": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "bgm_bvn_egm_write": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "bgm_bvn_egm_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "bgm_bvn_egm_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bgm_bvn_egm_end": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bgm_bnn_begin": (C.c_int, [C.c_void_p, C.POINTER(BnnConfig), C.c_void_p, C.c_int64, C.c_void_p]),
     "bgm_bnn_layout": (C.c_int, [C.POINTER(BnnConfig), C.POINTER(C.c_int64)]),
     "bgm_bnn_read": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -199,3 +199,59 @@ class BvnEngine(object):
         _lib.check(self.lib.bgm_row_mean_quantiles(self.h, _ptr(mat), n_rows, m, float(q_lo), float(q_hi),
                                                    _ptr(mean), _ptr(lo), _ptr(hi), self._stream()), "bgm_row_mean_quantiles")
         return mean, lo, hi
+
+    # -- EGM warm start (bgm/base.py:190-340) ----------------------------------------------
+    def egm_begin(self, batch_size, e_units, dz_units, dx_units, lr, gamma, alpha, e_net, dz, dx):
+        """Session on top of the open bvn session: copies its generator; encoder `e_net` ([(W, b)..]), discriminators (dicts)."""
+        from .engine import flatten_net, CausalEngine
+        cfg = _lib.BgmEgmConfig()
+        cfg.batch_size = int(batch_size)
+        for name, units in (("e", e_units), ("dz", dz_units), ("dx", dx_units)):
+            setattr(cfg, "n_hidden_" + name, len(units))
+            arr = getattr(cfg, name + "_units")
+            for i, u in enumerate(units):
+                arr[i] = int(u)
+        cfg.lr, cfg.gamma, cfg.alpha = float(lr), float(gamma), float(alpha)
+        te = flatten_net(e_net)
+        tz, tx = CausalEngine.flatten_disc(dz), CausalEngine.flatten_disc(dx)
+        _lib.check(self.lib.bgm_bvn_egm_begin(self.h, C.byref(cfg), te.ctypes.data_as(C.c_void_p), te.size,
+                                              tz.ctypes.data_as(C.c_void_p), tz.size, tx.ctypes.data_as(C.c_void_p), tx.size,
+                                              self._stream()), "bgm_bvn_egm_begin")
+        self._egm_sizes = (self.n_params, te.size, tz.size, tx.size)
+        self.egm_open = True
+
+    def egm_disc_step(self, z, x, noise, eps_z, eps_x, seed, stream_id, apply=True, out=None):
+        _lib.check(self.lib.bgm_bvn_egm_disc_step(self.h, _ptr(z), _ptr(x), _ptr(noise), float(eps_z), float(eps_x),
+                                                  int(seed) & 0xFFFFFFFFFFFFFFFF, int(stream_id) & 0xFFFFFFFF, int(bool(apply)),
+                                                  _ptr(out), self._stream()), "bgm_bvn_egm_disc_step")
+
+    def egm_gen_step(self, z, x, noise1, noise2, seed, stream_id, apply=True, out=None):
+        _lib.check(self.lib.bgm_bvn_egm_gen_step(self.h, _ptr(z), _ptr(x), _ptr(noise1), _ptr(noise2), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                                 int(stream_id) & 0xFFFFFFFF, int(bool(apply)), _ptr(out), self._stream()),
+                   "bgm_bvn_egm_gen_step")
+
+    def egm_read(self, what):
+        """0: generator side [g | e], 1: discriminators [dz | dx], 2 / 3: gradients of the last gen / disc step."""
+        n_g, n_e, n_dz, n_dx = self._egm_sizes
+        buf = np.empty((n_g + n_e) if what in (0, 2) else (n_dz + n_dx), np.float32)
+        _lib.check(self.lib.bgm_bvn_egm_read(self.h, int(what), buf.ctypes.data_as(C.c_void_p), buf.size, self._stream()),
+                   "bgm_bvn_egm_read")
+        return buf
+
+    def egm_write(self, what, buf):
+        buf = np.ascontiguousarray(buf, np.float32)
+        _lib.check(self.lib.bgm_bvn_egm_write(self.h, int(what), buf.ctypes.data_as(C.c_void_p), buf.size, self._stream()),
+                   "bgm_bvn_egm_write")
+
+    def egm_encode(self, x):
+        x = _f32(x, self.device)
+        z = torch.empty((x.shape[0], self.q), device=self.device)
+        _lib.check(self.lib.bgm_bvn_egm_encode(self.h, _ptr(x), x.shape[0], _ptr(z), self._stream()), "bgm_bvn_egm_encode")
+        return z
+
+    def egm_sync(self):
+        _lib.check(self.lib.bgm_bvn_egm_sync(self.h, self._stream()), "bgm_bvn_egm_sync")
+
+    def egm_end(self):
+        _lib.check(self.lib.bgm_bvn_egm_end(self.h, self._stream()), "bgm_bvn_egm_end")
+        self.egm_open = False

@@ -8,8 +8,6 @@
 #include "bgmb_kernels.h"
 #include "bgmb_state.h"
 
-void bgm_bvn_egm_free(void *) {}     // EGM session: bgmb_egm_api.hip (not built yet)
-
 static BgmbState *vst(bgm_handle *h) { return static_cast<BgmbState *>(h->bvn_state); }
 
 void bgm_bvn_free_state(bgm_handle *h) {

@@ -562,6 +562,22 @@ int bgm_bvn_hmc_run(bgm_handle *h, const bgm_hmc_args *args, void *stream);
 int bgm_bvn_decode(bgm_handle *h, const float *draws_dev, int64_t n, int64_t row_base, int32_t n_draws, int32_t burn_in,
                    uint64_t seed, uint32_t stream_id, const int32_t *slot_dev, int32_t k_slots, float *cells_dev,
                    float *full_dev, float *var_full_dev, int32_t add_noise, void *stream);
+/* EGM warm start with the Bayesian generator (bgm/base.py:190-340; e_net, dz_net, dx_net deterministic): as bgm_bgm_egm_* but
+ * on top of the bgm_bvn session, whose generator it copies at _begin and returns at _sync / _end.  (seed, stream_id) key the
+ * Flipout noise: the disc step makes one generator call (stream_id), the gen step two (stream_id, stream_id + 1). */
+int bgm_bvn_egm_begin(bgm_handle *h, const bgm_bgm_egm_config *cfg, const float *theta_e_host, int64_t count_e,
+                      const float *theta_dz_host, int64_t count_dz, const float *theta_dx_host, int64_t count_dx,
+                      void *stream);
+int bgm_bvn_egm_disc_step(bgm_handle *h, const float *z_dev, const float *x_dev, const float *noise_dev, float eps_z,
+                          float eps_x, uint64_t seed, uint32_t stream_id, int32_t apply, float *out_dev, void *stream);
+int bgm_bvn_egm_gen_step(bgm_handle *h, const float *z_dev, const float *x_dev, const float *noise1_dev,
+                         const float *noise2_dev, uint64_t seed, uint32_t stream_id, int32_t apply, float *out_dev,
+                         void *stream);
+int bgm_bvn_egm_read(bgm_handle *h, int32_t what, float *host, int64_t count, void *stream);
+int bgm_bvn_egm_write(bgm_handle *h, int32_t what, const float *host, int64_t count, void *stream);
+int bgm_bvn_egm_encode(bgm_handle *h, const float *x_dev, int64_t n, float *z_dev, void *stream);
+int bgm_bvn_egm_sync(bgm_handle *h, void *stream);
+int bgm_bvn_egm_end(bgm_handle *h, void *stream);
 int bgm_bvn_end(bgm_handle *h, void *stream);
 
 /* Debug: throughput of the hand-scheduled 64x4-tile MFMA block alone (mode 1: fragments streamed from LDS; mode 0:

@@ -175,3 +175,93 @@ def test_decode_matches_oracle_predict_on_posteriors():
     assert _rel(mean_only.cpu().numpy().reshape(nd * n, p), m_ref) < 2e-5
     assert _rel(var.cpu().numpy().reshape(nd * n, p), s2_ref) < 2e-5
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ EGM warm start
+def _egm_setup(p, q, B, units=(64,) * 5, gamma=0.0, alpha=0.0, seed=0, n=128):
+    from oracle import egm as OE
+    from oracle import nets as N
+    net = _net(q, units, p, seed=seed)
+    rs = np.random.RandomState(seed + 100)
+    e = [(W, (0.1 * rs.randn(*b.shape)).astype(np.float32)) for W, b in N.init_mlp(rs, [p] + [64] * 5 + [q])]
+    ds = []
+    for in_dim in (q, p):
+        d = OE.init_disc(rs, in_dim, [64, 32, 8])
+        d["b"] = [(0.1 * rs.randn(*b.shape)).astype(np.float32) for b in d["b"]]
+        d["gamma"] = [(1 + 0.2 * rs.randn(*b.shape)).astype(np.float32) for b in d["gamma"]]
+        d["beta"] = [(0.1 * rs.randn(*b.shape)).astype(np.float32) for b in d["beta"]]
+        ds.append(d)
+    eng = _engine(net, q, units, p)
+    eng.egm_begin(B, [64] * 5, [64, 32, 8], [64, 32, 8], 1e-3, gamma, alpha, e, ds[0], ds[1])
+    x = rs.randn(n, p).astype(np.float32)
+    c64 = (OV.cast_vnet(net, np.float64), N.cast_net(e, np.float64), OE.cast_disc(ds[0], np.float64), OE.cast_disc(ds[1], np.float64))
+    return eng, c64, x, rs
+
+
+@pytest.mark.parametrize("case", [dict(p=20, B=32, gamma=0.0, alpha=0.0), dict(p=37, B=19, gamma=0.5, alpha=0.2)])
+def test_egm_step_gradients_match_oracle(case):
+    from oracle import egm as OE
+    p, B, q = case["p"], case["B"], 10
+    eng, (g64, e64, dz64, dx64), x, rs = _egm_setup(p, q, B, gamma=case["gamma"], alpha=case["alpha"])
+    z = rs.randn(B, q).astype(np.float32)
+    xb = x[rs.choice(len(x), B, replace=False)]
+    n1, n2 = rs.randn(B, p).astype(np.float32), rs.randn(B, p).astype(np.float32)
+    d = lambda a: torch.from_numpy(a).cuda()
+    seed = 555
+    out_d = torch.zeros(3, device="cuda")
+    eng.egm_disc_step(d(z), d(xb), d(n1), 0.31, 0.64, seed, 4, apply=False, out=out_d)
+    losses, gr, caches = OV.egm_disc_step_grads(g64, e64, dz64, dx64, z.astype(np.float64), xb.astype(np.float64), n1.astype(np.float64),
+                                                0.31, 0.64, case["gamma"], OV.draw(g64, B, seed, 4, dtype=np.float64))
+    ref = np.concatenate([a.ravel() for a in OE.disc_param_list(gr["dz"]) + OE.disc_param_list(gr["dx"])])
+    got = eng.egm_read(3)
+    assert np.all(np.abs(out_d.cpu().numpy() - losses) <= 3e-5 * np.abs(losses) + 1e-6), (out_d.cpu().numpy(), losses)
+    n_dz = sum(a.size for a in OE.disc_param_list(gr["dz"]))
+    for lo, hi in ((0, n_dz), (n_dz, ref.size)):
+        assert _rel(got[lo:hi], ref[lo:hi]) <= 1e-4
+    OV.move_stats(g64, caches[0])
+    th = eng.egm_read(0)
+    assert np.abs(th[2 * q:3 * q] - g64["mean_mv"]).max() <= 1e-6 and np.abs(th[3 * q:4 * q] - g64["var_mv"]).max() <= 1e-6
+    out_g = torch.zeros(6, device="cuda")
+    eng.egm_gen_step(d(z), d(xb), d(n1), d(n2), seed, 6, apply=False, out=out_g)
+    losses, gr, caches = OV.egm_gen_step_grads(g64, e64, dz64, dx64, z.astype(np.float64), xb.astype(np.float64), n1.astype(np.float64),
+                                               n2.astype(np.float64), case["alpha"], OV.draw(g64, B, seed, 6, dtype=np.float64),
+                                               OV.draw(g64, B, seed, 7, dtype=np.float64))
+    got = eng.egm_read(2)
+    assert np.all(np.abs(out_g.cpu().numpy() - losses) <= 3e-5 * np.abs(losses) + 1e-6), (out_g.cpu().numpy(), losses)
+    ref_g = _flat(OV.flat_grads(gr["g"]))
+    ref_e = np.concatenate([a.ravel() for Wb in gr["e"] for a in Wb])
+    assert _rel(got[:ref_g.size], ref_g) <= 1e-4
+    assert _rel(got[ref_g.size:], ref_e) <= 1e-4
+    eng.egm_end()
+    eng.close()
+
+
+def test_egm_alternating_adam_steps_track_oracle_and_sync():
+    from oracle import egm as OE
+    from oracle import nets as N
+    p, q, B = 20, 10, 32
+    eng, (g64, e64, dz64, dx64), x, rs = _egm_setup(p, q, B, gamma=0.5, alpha=0.2, seed=3)
+    seed = 99
+    st = OV.EgmState(g64, e64, dz64, dx64, dict(lr=1e-3, gamma=0.5, alpha=0.2), seed)
+    d = lambda a: torch.from_numpy(a).cuda()
+    s = 0
+    for it in range(4):
+        z = rs.randn(B, q).astype(np.float32); xb = x[rs.choice(len(x), B, replace=False)]
+        n1 = rs.randn(B, p).astype(np.float32); ez, ex = float(rs.rand()), float(rs.rand())
+        eng.egm_disc_step(d(z), d(xb), d(n1), ez, ex, seed, 2 * s)
+        st.disc_step(z.astype(np.float64), xb.astype(np.float64), n1.astype(np.float64), ez, ex)
+        s += 1
+        z = rs.randn(B, q).astype(np.float32); xb = x[rs.choice(len(x), B, replace=False)]
+        n1, n2 = rs.randn(B, p).astype(np.float32), rs.randn(B, p).astype(np.float32)
+        eng.egm_gen_step(d(z), d(xb), d(n1), d(n2), seed, 2 * s)
+        st.gen_step(z.astype(np.float64), xb.astype(np.float64), n1.astype(np.float64), n2.astype(np.float64))
+        s += 1
+    got_g = eng.egm_read(0)
+    ref_g = np.concatenate([_flat(OV.flat_params(st.g))] + [a.ravel() for Wb in st.e for a in Wb])
+    assert np.abs(got_g - ref_g).max() <= 1e-4, np.abs(got_g - ref_g).max()
+    z_enc = eng.egm_encode(x).cpu().numpy()
+    assert np.abs(z_enc - N.mlp_forward(st.e, x.astype(np.float64))).max() <= 1e-4
+    eng.egm_end()
+    th = eng.read(0)
+    assert np.abs(th - _flat(OV.flat_params(st.g))).max() <= 1e-4
+    eng.close()
