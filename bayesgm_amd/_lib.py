@@ -62,7 +62,7 @@ class BnnConfig(C.Structure):
 
 class BvnConfig(C.Structure):
     _fields_ = [("x_dim", C.c_int32), ("z_dim", C.c_int32), ("n_hidden_g", C.c_int32), ("g_units", C.c_int32 * BGM_MAX_LAYERS),
-                ("kl_weight", C.c_float), ("max_batch", C.c_int32)]
+                ("kl_weight", C.c_float), ("max_batch", C.c_int32), ("hmc_frozen_noise", C.c_int32)]
 
 
 class BnnMhArgs(C.Structure):
@@ -170,7 +170,8 @@ SYMBOLS = {
                                   C.c_void_p, C.c_void_p]),
     "bgm_bvn_hmc_run": (C.c_int, [C.c_void_p, C.POINTER(HmcArgs), C.c_void_p]),
     "bgm_bvn_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_uint64, C.c_uint32,
-                                 C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+                                 C.c_uint32, C.c_uint32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                 C.c_void_p]),
     "bgm_bvn_end": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bgm_bvn_egm_begin": (C.c_int, [C.c_void_p, C.POINTER(BgmEgmConfig), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                     C.c_int64, C.c_void_p]),

@@ -44,7 +44,7 @@ def unflatten_vnet(theta, q, units, p):
 
 
 class BvnEngine(object):
-    def __init__(self, x_dim, z_dim, g_units=(64,) * 5, kl_weight=5e-5, max_batch=32, device=0):
+    def __init__(self, x_dim, z_dim, g_units=(64,) * 5, kl_weight=5e-5, max_batch=32, device=0, hmc_frozen_noise=False):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("bayesgm_amd: no HIP device visible; the hot path has no CPU fallback")
@@ -59,6 +59,7 @@ class BvnEngine(object):
             cfg.g_units[i] = u
         cfg.kl_weight = float(kl_weight)
         cfg.max_batch = int(max_batch)
+        cfg.hmc_frozen_noise = int(bool(hmc_frozen_noise))
         self.cfg = cfg
         n = C.c_int64()
         _lib.check(self.lib.bgm_bvn_layout(C.byref(cfg), C.byref(n)), "bgm_bvn_layout")
@@ -177,15 +178,18 @@ class BvnEngine(object):
         return dict(draws=draws, step=step, acc_count=acc_count, state=state, logp=logp, grad=grad)
 
     def decode(self, draws, seed, stream_id, burn_in=0, row_base=0, slot=None, k_slots=0, want_full=False, want_var=False,
-               add_noise=True):
-        """One generator call over draws [n_draws x n x q] -> (cells | None, full | None[, var])."""
+               add_noise=True, sign_stride=None, sign_off=0):
+        """One generator call over draws [n_draws x n x q] -> (cells | None, full | None[, var]).  The Flipout signs of
+        draw d, row r are keyed by d * sign_stride + sign_off + r (default stride: n)."""
         draws = _f32(draws, self.device)
         n_draws, n, _ = draws.shape
         cells = torch.empty((n, k_slots, n_draws), device=self.device) if (slot is not None and k_slots > 0) else None
         full = torch.empty((n_draws, n, self.p), device=self.device) if want_full else None
         var = torch.empty((n_draws, n, self.p), device=self.device) if want_var else None
         _lib.check(self.lib.bgm_bvn_decode(self.h, _ptr(draws), n, int(row_base), n_draws, int(burn_in),
-                                           int(seed) & 0xFFFFFFFFFFFFFFFF, int(stream_id) & 0xFFFFFFFF, _ptr(slot) if cells is not None else None,
+                                           int(seed) & 0xFFFFFFFFFFFFFFFF, int(stream_id) & 0xFFFFFFFF,
+                                           int(n if sign_stride is None else sign_stride), int(sign_off),
+                                           _ptr(slot) if cells is not None else None,
                                            int(k_slots), _ptr(cells), _ptr(full), _ptr(var), int(bool(add_noise)), self._stream()),
                    "bgm_bvn_decode")
         return (cells, full, var) if want_var else (cells, full)

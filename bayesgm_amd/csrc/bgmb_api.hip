@@ -246,6 +246,7 @@ extern "C" int bgm_bvn_hmc_run(bgm_handle *h, const bgm_hmc_args *g, void *strea
   a.state = g->state_dev; a.logp = g->logp_dev; a.grad = g->grad_dev;
   a.init = g->init; a.it_begin = g->it_begin; a.n_iters = g->n_iters; a.burn_in = g->burn_in; a.n_leapfrog = g->n_leapfrog;
   a.step = g->step_dev;
+  a.frozen = s->cfg.hmc_frozen_noise ? 1 : 0;
   a.acc_prob_sum = g->acc_prob_sum_dev; a.acc_count = g->acc_count_dev; a.draws = g->draws_dev;
   hipLaunchKernelGGL(bgmb_hmc_kernel, dim3((unsigned)tiles), dim3(BNN_THREADS), 0, (hipStream_t)stream_, a);
   BGM_HIP_CHECK(hipGetLastError());
@@ -253,8 +254,9 @@ extern "C" int bgm_bvn_hmc_run(bgm_handle *h, const bgm_hmc_args *g, void *strea
 }
 
 extern "C" int bgm_bvn_decode(bgm_handle *h, const float *draws_dev, int64_t n, int64_t row_base, int32_t n_draws, int32_t burn_in,
-                              uint64_t seed, uint32_t stream_id, const int32_t *slot_dev, int32_t k_slots, float *cells_dev,
-                              float *full_dev, float *var_full_dev, int32_t add_noise, void *stream_) {
+                              uint64_t seed, uint32_t stream_id, uint32_t sign_stride, uint32_t sign_off, const int32_t *slot_dev,
+                              int32_t k_slots, float *cells_dev, float *full_dev, float *var_full_dev, int32_t add_noise,
+                              void *stream_) {
   int rc = bvn_need(h, "bgm_bvn_decode");
   if (rc) return rc;
   if (!draws_dev || n < 0 || n_draws < 0 || (cells_dev && (!slot_dev || k_slots < 1))) {
@@ -262,10 +264,12 @@ extern "C" int bgm_bvn_decode(bgm_handle *h, const float *draws_dev, int64_t n, 
   }
   const long long total = (long long)n * n_draws;
   if (total == 0) return BGM_OK;
-  if (total >= (1LL << 32)) { bgm_set_error("bgm_bvn_decode: n_draws * n must stay below 2^32 (split the rows)"); return BGM_E_UNSUPPORTED; }
+  if ((long long)n_draws * (long long)sign_stride + (long long)sign_off + n >= (1LL << 32)) {
+    bgm_set_error("bgm_bvn_decode: sign row ids must stay below 2^32 (split the rows)"); return BGM_E_UNSUPPORTED;
+  }
   BgmbState *s = vst(h);
   BGM_HIP_CHECK(hipSetDevice(h->device));
-  const long long tiles = std::min<long long>((total + BGMB_RT - 1) / BGMB_RT, 2048);
+  const long long tiles = std::min<long long>(((n + BGMB_RT - 1) / BGMB_RT) * (long long)n_draws, 2048);
   BgmbDecodeArgs a;
   std::memset(&a, 0, sizeof(a));
   a.net = s->net; a.net.bn_fixed = 2;
@@ -274,6 +278,7 @@ extern "C" int bgm_bvn_decode(bgm_handle *h, const float *draws_dev, int64_t n, 
   if (rc) return rc;
   a.draws = draws_dev; a.n = n; a.row_base = row_base; a.n_draws = n_draws; a.burn_in = burn_in;
   a.k0 = a.x0 = (uint32_t)(seed & 0xFFFFFFFFull); a.k1 = a.x1 = (uint32_t)(seed >> 32); a.stream = stream_id;
+  a.sign_stride = sign_stride; a.sign_off = sign_off;
   a.slot = slot_dev; a.k_slots = k_slots; a.cells = cells_dev; a.full = full_dev; a.var_full = var_full_dev; a.add_noise = add_noise;
   hipLaunchKernelGGL(bgmb_decode_kernel, dim3((unsigned)tiles), dim3(BNN_THREADS), 0, (hipStream_t)stream_, a);
   BGM_HIP_CHECK(hipGetLastError());

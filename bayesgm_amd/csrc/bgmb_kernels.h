@@ -164,6 +164,7 @@ struct BgmbBigArgs {
   long long n, row_base;
   float *state, *logp, *grad;  // HMC: [n x q], [n], [n x q] in/out;  logpost: z in (state), outputs logp / grad (grad may be NULL)
   int init, it_begin, n_iters, burn_in, n_leapfrog;
+  int frozen;                  // 1: every gradient evaluation of the HMC run reuses generator call 0 (deterministic target)
   const float *step;
   uint32_t k0, k1, stream;
   double *acc_prob_sum;
@@ -266,7 +267,7 @@ static __global__ __launch_bounds__(BNN_THREADS) void bgmb_hmc_kernel(BgmbBigArg
     for (int l = 0; l < L; ++l) {
       for (int i = c.tid; i < B * q; i += BNN_THREADS) t.zc[i] = fmaf(e, t.pc[i], t.zc[i]);
       __syncthreads();
-      bgmb_lpg(c, a, t, t.zc, B, 1u + (uint32_t)it * (uint32_t)L + (uint32_t)l, row0, lpc, t.grc);
+      bgmb_lpg(c, a, t, t.zc, B, a.frozen ? 0u : 1u + (uint32_t)it * (uint32_t)L + (uint32_t)l, row0, lpc, t.grc);
       const float h = (l < L - 1) ? e : 0.5f * e;
       for (int i = c.tid; i < B * q; i += BNN_THREADS) t.pc[i] = fmaf(h, t.grc[i], t.pc[i]);
       __syncthreads();
@@ -304,8 +305,9 @@ static __global__ __launch_bounds__(BNN_THREADS) void bgmb_hmc_kernel(BgmbBigArg
   for (int b = c.tid; b < B; b += BNN_THREADS) a.logp[r0 + b] = lpv[b];
 }
 
-// g_net(z, training=False) over flat rows [n_draws * n] (one call: one perturbation, signs keyed by the flat row), then
-// x = mean + sqrt(var) * noise (tag 6 keyed by the GLOBAL row and burn_in + draw, as the deterministic path).
+// g_net(z, training=False) over the flattened rows [n_draws x n] (ONE call: one perturbation; the signs of draw d, row r are
+// keyed by d * sign_stride + sign_off + r), then x = mean + sqrt(var) * noise (tag 6 keyed by the GLOBAL row and
+// burn_in + draw, as the deterministic path).  A workgroup tile never spans two draws.
 struct BgmbDecodeArgs {
   BnnNet net;
   const float *theta;
@@ -314,6 +316,7 @@ struct BgmbDecodeArgs {
   long long n, row_base;
   int n_draws, burn_in;
   uint32_t k0, k1, stream;     // Flipout noise key / stream of the call
+  uint32_t sign_stride, sign_off;
   uint32_t x0, x1;             // key of the x-noise
   const int *slot; int k_slots;
   float *cells, *full, *var_full;
@@ -324,19 +327,20 @@ struct BgmbDecodeArgs {
 static __global__ __launch_bounds__(BNN_THREADS) void bgmb_decode_kernel(BgmbDecodeArgs a) {
   __shared__ float red[32];
   BnnCtx c{(int)threadIdx.x, red};
-  const long long total = (long long)a.n_draws * a.n;
   const int q = a.q, p = a.p;
+  const long long tiles_per_draw = (a.n + BGMB_RT - 1) / BGMB_RT, tiles = tiles_per_draw * a.n_draws;
   float *base = a.ws + (long long)blockIdx.x * a.ws_stride;
-  for (long long f0 = (long long)blockIdx.x * BGMB_RT; f0 < total; f0 += (long long)gridDim.x * BGMB_RT) {
-    const int B = (int)min((long long)BGMB_RT, total - f0);
+  for (long long t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const long long d = t / tiles_per_draw, r0 = (t - d * tiles_per_draw) * BGMB_RT;
+    const int B = (int)min((long long)BGMB_RT, a.n - r0);
+    const long long f0 = d * a.n + r0;
     float *wp = base;
     BnnCache k;
     bnn_cache(a.net, B, wp, k, a.draws + f0 * q);
-    const float *o = bnn_fwd(c, a.theta, a.net, k, B, a.k0, a.k1, a.stream, (uint32_t)f0);
+    const float *o = bnn_fwd(c, a.theta, a.net, k, B, a.k0, a.k1, a.stream, (uint32_t)d * a.sign_stride + a.sign_off + (uint32_t)r0);
     for (int i = c.tid; i < B * p; i += BNN_THREADS) {
-      const long long f = f0 + i / p;
+      const long long row = r0 + i / p, f = d * a.n + row;
       const int col = i % p;
-      const long long d = f / a.n, row = f - d * a.n;
       const float s2 = softplus_acc(o[B * p + i]) + BGM_EPS;
       float xp = o[i];
       if (a.add_noise) {

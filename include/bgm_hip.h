@@ -529,6 +529,8 @@ typedef struct {
   int32_t n_hidden_g, g_units[BGM_MAX_LAYERS];
   float kl_weight;               /* params['kl_weight'] */
   int32_t max_batch;             /* largest minibatch of the step functions (2..64) */
+  int32_t hmc_frozen_noise;      /* 0: every gradient evaluation of HMC draws a fresh perturbation (the reference as written);
+                                    1: the whole HMC run reuses generator call 0 (one weight draw, deterministic target) */
 } bgm_bvn_config;
 int bgm_bvn_layout(const bgm_bvn_config *cfg, int64_t *n_params);
 /* Open a session with the parameters theta_host (layout above).  Adam slots start at zero. */
@@ -558,10 +560,12 @@ int bgm_bvn_logpost(bgm_handle *h, const float *z_dev, const float *x_dev, int64
  * log-prob / gradient of the current state are kept, as TFP does.  Same argument struct as bgm_bgm_hmc_run. */
 int bgm_bvn_hmc_run(bgm_handle *h, const bgm_hmc_args *args, void *stream);
 /* replaces: g_net(z, training=False) + reparameterize in predict_on_posteriors / generate / evaluate (:511-525, :478-509,
- * :444-476): ONE generator call (stream_id) over the flattened [n_draws x n] rows.  Outputs as bgm_bgm_predict_draws. */
+ * :444-476): ONE generator call (stream_id) over the flattened [n_draws x n] rows; the Flipout signs of draw d, row r are
+ * keyed by d * sign_stride + sign_off + r (predict: sign_stride = bs, sign_off = position of the first row inside its
+ * bs-block, so the result does not depend on how a block is split over ranks).  Outputs as bgm_bgm_predict_draws. */
 int bgm_bvn_decode(bgm_handle *h, const float *draws_dev, int64_t n, int64_t row_base, int32_t n_draws, int32_t burn_in,
-                   uint64_t seed, uint32_t stream_id, const int32_t *slot_dev, int32_t k_slots, float *cells_dev,
-                   float *full_dev, float *var_full_dev, int32_t add_noise, void *stream);
+                   uint64_t seed, uint32_t stream_id, uint32_t sign_stride, uint32_t sign_off, const int32_t *slot_dev,
+                   int32_t k_slots, float *cells_dev, float *full_dev, float *var_full_dev, int32_t add_noise, void *stream);
 /* EGM warm start with the Bayesian generator (bgm/base.py:190-340; e_net, dz_net, dx_net deterministic): as bgm_bgm_egm_* but
  * on top of the bgm_bvn session, whose generator it copies at _begin and returns at _sync / _end.  (seed, stream_id) key the
  * Flipout noise: the disc step makes one generator call (stream_id), the gen step two (stream_id, stream_id + 1). */

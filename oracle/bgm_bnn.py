@@ -64,8 +64,8 @@ def shapes(net):
     return [L[0].shape for L in layers_of(net)]
 
 
-def draw(net, B, key, stream, row0=0, dtype=np.float32):
-    return BN.draw_noise(shapes(net), B, key, stream, NET_ID, dtype=dtype, row0=row0)
+def draw(net, B, key, stream, row0=0, dtype=np.float32, rows=None):
+    return BN.draw_noise(shapes(net), B, key, stream, NET_ID, dtype=dtype, row0=row0, rows=rows)
 
 
 def _flip(h, layer, noise, l):
@@ -227,10 +227,11 @@ def hmc_stream(it, leap, n_leapfrog):
     return 1 + it * n_leapfrog + leap
 
 
-def hmc_sampler(net, x, mask, n_mcmc, burn_in, step_size=0.01, n_leapfrog=10, seed=42, row0=0, return_info=False):
+def hmc_sampler(net, x, mask, n_mcmc, burn_in, step_size=0.01, n_leapfrog=10, seed=42, row0=0, return_info=False, frozen=False):
     """tfp_mcmc_sampler (:709-830) on the stochastic target: every evaluation is one g_net call over ALL rows (one
     perturbation shared by the rows, per-row signs keyed by the global row); the cached log-prob / gradient of the current
-    state are NOT refreshed (TFP caches them in the kernel results)."""
+    state are NOT refreshed (TFP caches them in the kernel results).  frozen=True (build option): every evaluation reuses
+    the perturbation of call 0, i.e. HMC on the deterministic target of ONE weight draw."""
     from . import bgm as OB
     n, q = len(x), len(net["gamma"])
     z = OB.hmc_init_state(n, q, seed, row0).astype(x.dtype)
@@ -248,7 +249,7 @@ def hmc_sampler(net, x, mask, n_mcmc, burn_in, step_size=0.01, n_leapfrog=10, se
         zc, pc = z.copy(), mom + e / 2 * gr
         for l in range(n_leapfrog):
             zc = zc + e * pc
-            lpc, grc = log_posterior_and_grad(net, zc, x, mask, draw(net, n, seed, hmc_stream(it, l, n_leapfrog), row0, z.dtype))
+            lpc, grc = log_posterior_and_grad(net, zc, x, mask, draw(net, n, seed, 0 if frozen else hmc_stream(it, l, n_leapfrog), row0, z.dtype))
             pc = pc + (e if l < n_leapfrog - 1 else e / 2) * grc
         h1 = -lpc + (pc ** 2).sum(axis=1) / 2
         lr = -(h1 - h0)
@@ -269,19 +270,23 @@ def hmc_sampler(net, x, mask, n_mcmc, burn_in, step_size=0.01, n_leapfrog=10, se
     return out
 
 
-def decode(net, z, seed, stream, row0=0, x_noise=None):
-    """g_net(z, training=False) -> (mean, var) for one call; rows keyed row0 + i."""
-    mean, s2, _ = vforward(net, z, draw(net, len(z), seed, stream, row0, z.dtype), training=False)
+def decode(net, z, seed, stream, row0=0, rows=None):
+    """g_net(z, training=False) -> (mean, var) for one call; sign rows keyed row0 + i (or rows[i])."""
+    mean, s2, _ = vforward(net, z, draw(net, len(z), seed, stream, row0, z.dtype, rows=rows), training=False)
     return mean, s2
 
 
-def predict_on_posteriors(net, post_z, seed, block=0, row0=0, burn_in=0):
-    """predict_on_posteriors (:511-525) for one row block: ONE g_net call over the flattened [n_mcmc * n_blk] rows (flat
-    row d * n_blk + r keys the signs), stream STREAM_PREDICT + block; x-noise as in oracle.bgm (tag 6, global row)."""
+def predict_on_posteriors(net, post_z, seed, block=0, row0=0, burn_in=0, bs=None, off=0):
+    """predict_on_posteriors (:511-525) for (a part of) one row block of `bs` rows: ONE g_net call over the flattened
+    [n_mcmc * n] rows, stream STREAM_PREDICT + block; draw d of the block's row r (r = off + i for the i-th row handed in)
+    keys its signs with d * bs + r -- independent of how the block is split over ranks.  x-noise as in oracle.bgm (tag 6,
+    global row row0 + i)."""
     n_mcmc, n, q = post_z.shape
+    bs = n if bs is None else bs
     p = net["mean"][0].shape[1]
     flat = post_z.reshape(n_mcmc * n, q)
-    mean, s2 = decode(net, flat, seed, STREAM_PREDICT + block)
+    ids = (np.arange(n_mcmc)[:, None] * bs + off + np.arange(n)[None, :]).reshape(-1)
+    mean, s2 = decode(net, flat, seed, STREAM_PREDICT + block, rows=ids)
     rows = np.arange(row0, row0 + n)
     out = np.empty((n_mcmc, n, p), dtype=post_z.dtype)
     for d in range(n_mcmc):

@@ -107,8 +107,9 @@ def sign_layout(dims):
     return sin_w, sout_w, (w + 3) // 4 * 4
 
 
-def draw_noise(dims, B, key, stream, net_id, dtype=np.float32, row0=0):
-    """The noise of ONE call of a net on a batch of B rows: {"eps": [...], "sin": [...], "sout": [...]}."""
+def draw_noise(dims, B, key, stream, net_id, dtype=np.float32, row0=0, rows=None):
+    """The noise of ONE call of a net on a batch of B rows: {"eps": [...], "sin": [...], "sout": [...]}.
+    The sign words of row i are keyed by row0 + i, or by rows[i] when `rows` is given."""
     k0, k1 = int(key) & 0xFFFFFFFF, (int(key) >> 32) & 0xFFFFFFFF
     shapes = _shapes(dims)
     eps = []
@@ -118,7 +119,7 @@ def draw_noise(dims, B, key, stream, net_id, dtype=np.float32, row0=0):
         bm = R.box_muller4(*R.philox4x32_10(calls, l | (net_id << 16), stream, TAG_EPS, k0, k1))
         eps.append(np.stack(bm, axis=1).reshape(-1)[:n].reshape(fi, fo).astype(dtype))
     sin_w, sout_w, words = sign_layout(shapes)
-    rows = np.arange(row0, row0 + B, dtype=np.uint32)
+    rows = np.arange(row0, row0 + B, dtype=np.uint32) if rows is None else np.asarray(rows, dtype=np.uint32)
     W = np.empty((B, words), dtype=np.uint32)
     for c in range(words // 4):
         ws = R.philox4x32_10(rows, c | (net_id << 16), stream, TAG_SIGN, k0, k1)

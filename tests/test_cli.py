@@ -43,3 +43,23 @@ def test_causalbgm_command_end_to_end(tmp_path, bnn):
     itv = np.loadtxt("%s/causal_effect_posterior_interval.txt" % model.save_dir)
     assert est.shape == (3,) and itv.shape == (3, 2) and np.isfinite(est).all() and np.all(itv[:, 0] <= itv[:, 1])
     assert type(model).__name__ == ("CausalBGMBayes" if bnn else "CausalBGM")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bnn", [True, False])
+def test_bgm_command_end_to_end(tmp_path, bnn):
+    rs = np.random.RandomState(0)
+    z = rs.standard_normal((320, 3))
+    data = (z @ rs.standard_normal((3, 8)) + 0.1 * rs.standard_normal((320, 8))).astype(np.float32)
+    f = tmp_path / "panel.csv"          # complete panel: the reference's command fits and imputes the same file (cli.py:213-255)
+    np.savetxt(f, data, delimiter=",", header=",".join("c%d" % i for i in range(8)), comments="")
+    argv = ["bgm", "-i", str(f), "-o", str(tmp_path), "-t", ",", "--z_dim", "3", "-N", "12", "--egm_batches_per_eval", "6", "-E", "2",
+            "--epochs_per_eval", "1", "-M", "20", "--burn_in", "20", "--g_units", "64", "64", "64", "--e_units", "32", "32",
+            "--use_bnn" if bnn else "--no-use_bnn"]
+    model = cli.main(argv)
+    imp = np.loadtxt("%s/imputed_data.txt" % model.save_dir)
+    assert imp.shape == data.shape and np.isfinite(imp).all()
+    from bayesgm_amd.utils import parse_file
+    np.testing.assert_allclose(imp, parse_file(str(f), sep=","), rtol=1e-5, atol=1e-6)       # nothing missing: observed cells returned as given
+    assert np.load("%s/prediction_intervals.npz" % model.save_dir)["intervals"].shape == (320, 0, 2)
+    assert type(model).__name__ == ("BGMBayes" if bnn else "BGM")

@@ -19,7 +19,7 @@ def _net(q, units, p, seed=0):
     return net
 
 
-def _engine(net, q, units, p, **kw):
+def _engine(net, q, units, p, **kw):          # kw: kl_weight, max_batch, hmc_frozen_noise
     from bayesgm_amd.bvn_engine import BvnEngine
     eng = BvnEngine(p, q, g_units=units, **kw)
     eng.begin(net)
@@ -117,19 +117,20 @@ def test_logpost_and_gradient_match_oracle(n, row_base):
     eng.close()
 
 
-def test_hmc_follows_oracle_over_a_few_transitions():
+@pytest.mark.parametrize("frozen", [False, True])
+def test_hmc_follows_oracle_over_a_few_transitions(frozen):
     q, units, p, n = 3, (16, 16), 8, 100
     net = _net(q, units, p, seed=6)
     rs = np.random.RandomState(7)
     x = rs.standard_normal((n, p)).astype(np.float32)
     x[rs.uniform(size=x.shape) < 0.25] = np.nan
-    eng = _engine(net, q, units, p)
+    eng = _engine(net, q, units, p, hmc_frozen_noise=frozen)
     seed = 42
     out = eng.hmc_sample(x, n_mcmc=3, burn_in=5, step_size=0.05, n_leapfrog=4, seed=seed, row_base=7)
     mask = (~np.isnan(x)).astype(np.float32)
     xc = np.where(np.isnan(x), 0.0, x).astype(np.float32)
     ref, info = OV.hmc_sampler(OV.cast_vnet(net, np.float64), xc.astype(np.float64), mask.astype(np.float64), 3, 5, 0.05, 4, seed, row0=7,
-                               return_info=True)
+                               return_info=True, frozen=frozen)
     got = out["draws"].cpu().numpy()
     assert got.shape == ref.shape
     assert abs(float(out["step"].item()) - info["step"]) < 1e-6
@@ -265,3 +266,78 @@ def test_egm_alternating_adam_steps_track_oracle_and_sync():
     th = eng.read(0)
     assert np.abs(th - _flat(OV.flat_params(st.g))).max() <= 1e-4
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ model class
+def _params(tmp_path, p, q=4, **kw):
+    d = dict(dataset="t", output_dir=str(tmp_path), save_res=False, save_model=False, use_bnn=True, z_dim=q, x_dim=p,
+             g_units=[32, 32], e_units=[32, 32], dz_units=[16, 8], dx_units=[16, 8], lr=1e-3, lr_theta=5e-3, lr_z=5e-3,
+             g_d_freq=1, kl_weight=5e-5, gamma=1.0, alpha=0.01)
+    d.update(kw)
+    return d
+
+
+def _linear_panel(n, p, q, seed=0):
+    rs = np.random.RandomState(seed)
+    z = rs.standard_normal((n, q)).astype(np.float32)
+    return (z @ rs.standard_normal((q, p)) + 0.1 * rs.standard_normal((n, p))).astype(np.float32)
+
+
+def test_model_fit_evaluate_generate_predict(tmp_path):
+    from bayesgm_amd.models import BGM
+    n, p, q = 640, 12, 4
+    data = _linear_panel(n, p, q)
+    model = BGM(_params(tmp_path, p, q, bnn_mcmc_noise="frozen"), random_seed=7)
+    assert type(model).__name__ == "BGMBayes"
+    mse0 = float(model.evaluate(data, data_z=np.zeros((n, q), np.float32), use_x_sd=False))
+    model.fit(data, batch_size=32, epochs=40, epochs_per_eval=10, use_egm_init=True, egm_n_iter=60, egm_batches_per_eval=30, verbose=1)
+    assert model.history_loss[-1] < 0.75 * mse0 and model.history_loss[-1] < model.history_loss[0]
+    assert float(model.evaluate(data, use_x_sd=False)) < 10 * model.history_loss[-1] + 1.0      # encoder of the warm start
+    gen, var = model.generate(nb_samples=500)
+    assert gen.shape == (500, p) and np.isfinite(gen).all() and (var > 0).all()
+    miss = data[:150].copy()
+    rs = np.random.RandomState(5)
+    miss[rs.uniform(size=miss.shape) < 0.2] = np.nan
+    miss[0, :] = data[0, :]
+    miss[0, 3] = np.nan
+    imputed, intervals = model.predict(miss, alpha=0.1, bs=64, n_mcmc=100, burn_in=300, step_size=0.05, num_leapfrog_steps=5, seed=11)
+    assert imputed.shape == miss.shape and np.isfinite(imputed).all()
+    obs = ~np.isnan(miss)
+    np.testing.assert_array_equal(imputed[obs], miss[obs])
+    assert len(intervals) == 150 and intervals[0].shape == (1, 2)
+    truth, est = data[:150][~obs], imputed[~obs]
+    print('imputation mse', np.mean((truth - est) ** 2), 'baseline', np.mean((truth - truth.mean()) ** 2))
+    assert np.mean((truth - est) ** 2) < np.mean((truth - truth.mean()) ** 2)          # better than the column-free mean
+    cover = np.mean([(iv[:, 0] <= data[i][np.isnan(miss[i])]).mean() for i, iv in enumerate(intervals) if len(iv)])
+    assert cover > 0.5
+    samples, _ = model.predict(miss[:70], alpha=0.1, return_samples=True, bs=64, n_mcmc=10, burn_in=10, step_size=0.02,
+                               num_leapfrog_steps=3, seed=11)
+    assert samples.shape == (10, 70, p)
+
+
+def test_model_predict_is_block_consistent_with_the_oracle(tmp_path):
+    """One predictive call per bs-block with signs keyed inside the block: compare the engine's decode of a block part
+    (sign_off > 0) with oracle.predict_on_posteriors."""
+    q, units, p, n, nd = 4, (16, 16), 9, 23, 4
+    net = _net(q, units, p, seed=12)
+    rs = np.random.RandomState(13)
+    post = rs.standard_normal((nd, n, q)).astype(np.float32)
+    eng = _engine(net, q, units, p)
+    from bayesgm_amd.bvn_engine import STREAM_PREDICT
+    _, full = eng.decode(post, 5, STREAM_PREDICT + 3, burn_in=2, row_base=340, want_full=True, sign_stride=100, sign_off=40)
+    ref = OV.predict_on_posteriors(OV.cast_vnet(net, np.float64), post.astype(np.float64), 5, block=3, row0=340, burn_in=2, bs=100, off=40)
+    assert _rel(full.cpu().numpy(), ref) < 2e-5
+    eng.close()
+
+
+def test_model_checkpoint_roundtrip(tmp_path):
+    from bayesgm_amd.models import BGM
+    p, q = 7, 3
+    model = BGM(_params(tmp_path, p, q, save_model=True), random_seed=1)
+    path = model.save_checkpoint(0)
+    other = BGM(_params(tmp_path, p, q), random_seed=2)
+    other.load_checkpoint(path)
+    z = np.random.RandomState(0).standard_normal((10, q)).astype(np.float32)
+    a, _ = model._decode(z, False, seed=3)
+    b, _ = other._decode(z, False, seed=3)
+    np.testing.assert_array_equal(a, b)
