@@ -139,6 +139,7 @@ extern "C" int bgm_bvn_theta_step(bgm_handle *h, const float *x_dev, float *data
   BgmbState *s = vst(h);
   BGM_HIP_CHECK(hipSetDevice(h->device));
   a.apply = apply ? 1 : 0;
+  a.kl_weight *= (float)batch / (float)batch_global;      // data parallel: the ranks' gradients are summed, the KL term counts once
   if (apply) { s->t_theta += 1; a.adam = BnnAdam{bvn_lr_t(lr, s->t_theta), BGMB_ADAM_B1, BGMB_ADAM_B2, BGMB_ADAM_EPS}; }
   hipLaunchKernelGGL(bgmb_theta_step_kernel, dim3(1), dim3(BNN_THREADS), 0, (hipStream_t)stream_, a);
   BGM_HIP_CHECK(hipGetLastError());
