@@ -200,6 +200,12 @@ static int bvn_big_ws(bgm_handle *h, BgmbState *s, long long tiles, float *&ws, 
   return BGM_OK;
 }
 
+// rows per workgroup: whole 64-row tiles once they fill the chip, otherwise 16-row multiples so that every CU gets work
+static int bvn_rt(const bgm_handle *h, long long n) {
+  const long long per_cu = (n + h->n_cus - 1) / h->n_cus;
+  return (int)std::min<long long>(BGMB_RT, std::max<long long>(16, (per_cu + 15) / 16 * 16));
+}
+
 static void bvn_big_base(BgmbState *s, BgmbBigArgs &a, uint64_t seed) {
   std::memset(&a, 0, sizeof(a));
   a.net = s->net;
@@ -217,9 +223,11 @@ extern "C" int bgm_bvn_logpost(bgm_handle *h, const float *z_dev, const float *x
   if (n == 0) return BGM_OK;
   BgmbState *s = vst(h);
   BGM_HIP_CHECK(hipSetDevice(h->device));
-  const long long tiles = (n + BGMB_RT - 1) / BGMB_RT;
+  const int rt = bvn_rt(h, n);
+  const long long tiles = (n + rt - 1) / rt;
   BgmbBigArgs a;
   bvn_big_base(s, a, seed);
+  a.rt = rt;
   rc = bvn_big_ws(h, s, tiles, a.ws, a.ws_stride);
   if (rc) return rc;
   a.x = x_dev; a.n = n; a.row_base = row_base;
@@ -238,9 +246,11 @@ extern "C" int bgm_bvn_hmc_run(bgm_handle *h, const bgm_hmc_args *g, void *strea
   if (g->n == 0 || (g->n_iters == 0 && !g->init)) return BGM_OK;
   BgmbState *s = vst(h);
   BGM_HIP_CHECK(hipSetDevice(h->device));
-  const long long tiles = (g->n + BGMB_RT - 1) / BGMB_RT;
+  const int rt = bvn_rt(h, g->n);
+  const long long tiles = (g->n + rt - 1) / rt;
   BgmbBigArgs a;
   bvn_big_base(s, a, g->seed);
+  a.rt = rt;
   rc = bvn_big_ws(h, s, tiles, a.ws, a.ws_stride);
   if (rc) return rc;
   a.x = g->x_dev; a.n = g->n; a.row_base = g->row_base;

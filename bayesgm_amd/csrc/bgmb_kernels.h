@@ -163,6 +163,7 @@ struct BgmbBigArgs {
   const float *x;              // [n x p], NaN = missing
   long long n, row_base;
   float *state, *logp, *grad;  // HMC: [n x q], [n], [n x q] in/out;  logpost: z in (state), outputs logp / grad (grad may be NULL)
+  int rt;                      // rows per workgroup tile (<= BGMB_RT; smaller when few rows would leave CUs idle)
   int init, it_begin, n_iters, burn_in, n_leapfrog;
   int frozen;                  // 1: every gradient evaluation of the HMC run reuses generator call 0 (deterministic target)
   const float *step;
@@ -217,8 +218,8 @@ static __global__ __launch_bounds__(BNN_THREADS) void bgmb_logpost_kernel(BgmbBi
   __shared__ float red[32];
   __shared__ float lpv[BGMB_RT];
   BnnCtx c{(int)threadIdx.x, red};
-  const long long r0 = (long long)blockIdx.x * BGMB_RT;
-  const int B = (int)min((long long)BGMB_RT, a.n - r0), q = a.q, p = a.p;
+  const long long r0 = (long long)blockIdx.x * a.rt;
+  const int B = (int)min((long long)a.rt, a.n - r0), q = a.q, p = a.p;
   BgmbTile t;
   bgmb_tile_take(a.ws + (long long)blockIdx.x * a.ws_stride, t, q, p, a.wmax);
   for (int i = c.tid; i < B * q; i += BNN_THREADS) t.z[i] = a.state[r0 * q + i];
@@ -235,8 +236,8 @@ static __global__ __launch_bounds__(BNN_THREADS) void bgmb_hmc_kernel(BgmbBigArg
   __shared__ float lpv[BGMB_RT], lpc[BGMB_RT], ke0[BGMB_RT];
   __shared__ int accv[BGMB_RT];
   BnnCtx c{(int)threadIdx.x, red};
-  const long long r0 = (long long)blockIdx.x * BGMB_RT;
-  const int B = (int)min((long long)BGMB_RT, a.n - r0), q = a.q, p = a.p, L = a.n_leapfrog;
+  const long long r0 = (long long)blockIdx.x * a.rt;
+  const int B = (int)min((long long)a.rt, a.n - r0), q = a.q, p = a.p, L = a.n_leapfrog;
   const uint32_t row0 = (uint32_t)(a.row_base + r0);
   BgmbTile t;
   bgmb_tile_take(a.ws + (long long)blockIdx.x * a.ws_stride, t, q, p, a.wmax);
