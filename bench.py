@@ -20,6 +20,8 @@ The JSON line also carries
   cpu_baseline -- the oracle's literal restatement of the reference loop (NumPy, host RNG, two
                   log-posterior evaluations per iteration) timed on this box's host cores on a
                   bounded sample (bs=10000 rows x a few iterations).
+  parity       -- (with the cpu_baseline leg) ADRF of the HIP path vs the oracle on 256 rows, same weights and
+                  Philox streams: the "matches the reference within a stated fp32 tolerance" number of this run.
 Weights are glorot-uniform random (seed 0): throughput does not depend on their values.
 """
 import argparse
@@ -70,6 +72,24 @@ def cpu_baseline(params, p, z_dims, budget_s=20.0):
             "kind": "port",
             "sample": f"oracle.causal.mh_reference_loop: bs={bs} rows x {n_it} iterations, p={p}, "
                       f"2 log-posterior evals/iter + NumPy RNG as causalbgm/base.py:860-871; {dt:.1f} s"}
+
+
+def parity_leg(model, x, y, v, z_dims, p, x_values, rows=256, burn_in=300, n_keep=100):
+    """ADRF of the HIP path against the oracle (the checker) on the first `rows` rows: same weights, same Philox streams."""
+    from oracle import causal as OC
+    sub = slice(0, rows)
+    xs, ys, vs = x[sub].cpu().numpy(), y[sub].cpu().numpy(), v[sub].cpu().numpy()
+    m = dict(g=model.nets["g"], f=model.nets["f"], h=model.nets["h"], e=model.nets["e"], z_dims=list(z_dims), v_dim=p,
+             binary_treatment=False)
+    seed = 20260928
+    out = model.engine.mh_sample(xs.ravel(), ys.ravel(), vs, burn_in, n_keep, 1.0, seed, effect=1, x_values=x_values)
+    post = OC.mh_sampler(m, (xs, ys, vs), burn_in, n_keep, 1.0, seed)
+    ref = OC.infer_from_latent_posterior(m, post, x_values, True, seed, burn_in=burn_in)
+    got = out["adrf"].cpu().numpy()
+    return {"adrf_max_abs_diff_vs_oracle": float(np.abs(got.mean(axis=1) - ref.mean(axis=1)).max()),
+            "adrf_draws_max_abs_diff_vs_oracle": float(np.abs(got - ref).max()),
+            "sample": f"first {rows} rows, {burn_in} burn-in + {n_keep} retained transitions, {len(x_values)} doses, sample_y=True, "
+                      "same weights and Philox streams on both sides (oracle/causal.py)"}
 
 
 def fit_leg(model, x, y, v, n_loc, steps=2000, batch=32):
@@ -253,6 +273,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(params, p, z_dims)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            out["parity"] = parity_leg(model, x, y, v, z_dims, p, x_values)
         if not args.no_bayesian and world == 1:
             out["bayesian_nets"] = bayesian_leg(params, data, x_values, n_loc, args, device)
         if not args.no_fit and world == 1:
