@@ -15,6 +15,7 @@ void bgm_bvn_free_state(bgm_handle *h) {
   BgmbState *s = vst(h);
   if (s->dev) hipFree(s->dev);
   if (s->big_dev) hipFree(s->big_dev);
+  if (s->dw_dev) hipFree(s->dw_dev);
   bgm_bvn_egm_free(s->egm);
   delete s;
   h->bvn_state = nullptr;
@@ -200,6 +201,30 @@ static int bvn_big_ws(bgm_handle *h, BgmbState *s, long long tiles, float *&ws, 
   return BGM_OK;
 }
 
+// perturbations of `slots` generator calls: streams stream0 + s * step for s < n_seq, then (optionally) stream_extra
+static long long bvn_dw_stride(const BgmbState *s) { return ((long long)s->net.eoff[s->net.n_layers] + 63) & ~63LL; }
+static int bvn_noise(bgm_handle *h, BgmbState *s, uint64_t seed, uint32_t stream0, uint32_t step, int n_seq, bool extra,
+                     uint32_t stream_extra, hipStream_t stream) {
+  const long long stride = bvn_dw_stride(s);
+  const int slots = n_seq + (extra ? 1 : 0);
+  const size_t need = (size_t)stride * (size_t)slots;
+  if (need > s->dw_cap) {
+    if (s->dw_dev) { BGM_HIP_CHECK(hipDeviceSynchronize()); hipFree(s->dw_dev); s->dw_dev = nullptr; s->dw_cap = 0; }
+    BGM_HIP_CHECK(hipMalloc((void **)&s->dw_dev, sizeof(float) * need));
+    s->dw_cap = need;
+  }
+  BgmbNoiseArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.net = s->net; a.theta = s->theta_dev; a.dw = s->dw_dev; a.stride = stride;
+  a.k0 = (uint32_t)(seed & 0xFFFFFFFFull); a.k1 = (uint32_t)(seed >> 32);
+  a.stream0 = stream0; a.stream_step = step; a.n_seq = n_seq; a.stream_extra = stream_extra;
+  const int groups = (int)((stride / 4 + 255) / 256);
+  hipLaunchKernelGGL(bgmb_noise_kernel, dim3((unsigned)std::max(1, std::min(groups, 64)), (unsigned)slots), dim3(256), 0, stream, a);
+  BGM_HIP_CHECK(hipGetLastError());
+  (void)h;
+  return BGM_OK;
+}
+
 // rows per workgroup: whole 64-row tiles once they fill the chip, otherwise 16-row multiples so that every CU gets work
 static int bvn_rt(const bgm_handle *h, long long n) {
   const long long per_cu = (n + h->n_cus - 1) / h->n_cus;
@@ -233,6 +258,9 @@ extern "C" int bgm_bvn_logpost(bgm_handle *h, const float *z_dev, const float *x
   a.x = x_dev; a.n = n; a.row_base = row_base;
   a.state = const_cast<float *>(z_dev); a.logp = out_dev; a.grad = grad_dev;
   a.stream = stream_id;
+  rc = bvn_noise(h, s, seed, stream_id, 0u, 1, false, 0u, (hipStream_t)stream_);
+  if (rc) return rc;
+  a.dw = s->dw_dev; a.dw_stride = bvn_dw_stride(s);
   hipLaunchKernelGGL(bgmb_logpost_kernel, dim3((unsigned)tiles), dim3(BNN_THREADS), 0, (hipStream_t)stream_, a);
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
@@ -255,12 +283,30 @@ extern "C" int bgm_bvn_hmc_run(bgm_handle *h, const bgm_hmc_args *g, void *strea
   if (rc) return rc;
   a.x = g->x_dev; a.n = g->n; a.row_base = g->row_base;
   a.state = g->state_dev; a.logp = g->logp_dev; a.grad = g->grad_dev;
-  a.init = g->init; a.it_begin = g->it_begin; a.n_iters = g->n_iters; a.burn_in = g->burn_in; a.n_leapfrog = g->n_leapfrog;
+  a.burn_in = g->burn_in; a.n_leapfrog = g->n_leapfrog;
   a.step = g->step_dev;
   a.frozen = s->cfg.hmc_frozen_noise ? 1 : 0;
   a.acc_prob_sum = g->acc_prob_sum_dev; a.acc_count = g->acc_count_dev; a.draws = g->draws_dev;
-  hipLaunchKernelGGL(bgmb_hmc_kernel, dim3((unsigned)tiles), dim3(BNN_THREADS), 0, (hipStream_t)stream_, a);
-  BGM_HIP_CHECK(hipGetLastError());
+  a.dw_stride = bvn_dw_stride(s);
+  // The perturbations of a launch's generator calls are produced once for all workgroups (bgmb_noise_kernel); a launch covers
+  // as many transitions as fit a 64 MB perturbation buffer.
+  const int L = g->n_leapfrog;
+  const long long per_it = a.dw_stride * (long long)L * (long long)sizeof(float);
+  const int chunk = a.frozen ? g->n_iters : (int)std::max<long long>(1, (64LL << 20) / std::max<long long>(1, per_it));
+  int it = g->it_begin, left = g->n_iters;
+  bool first = true;
+  do {
+    const int c = std::min(left, std::max(chunk, 1));
+    a.init = (first && g->init) ? 1 : 0;
+    a.it_begin = it; a.n_iters = c;
+    if (a.frozen) rc = bvn_noise(h, s, g->seed, 0u, 0u, 1, false, 0u, (hipStream_t)stream_);
+    else rc = bvn_noise(h, s, g->seed, 1u + (uint32_t)it * (uint32_t)L, 1u, c * L, a.init != 0, 0u, (hipStream_t)stream_);
+    if (rc) return rc;
+    a.dw = s->dw_dev;
+    hipLaunchKernelGGL(bgmb_hmc_kernel, dim3((unsigned)tiles), dim3(BNN_THREADS), 0, (hipStream_t)stream_, a);
+    BGM_HIP_CHECK(hipGetLastError());
+    it += c; left -= c; first = false;
+  } while (left > 0);
   return BGM_OK;
 }
 
@@ -290,6 +336,9 @@ extern "C" int bgm_bvn_decode(bgm_handle *h, const float *draws_dev, int64_t n, 
   a.draws = draws_dev; a.n = n; a.row_base = row_base; a.n_draws = n_draws; a.burn_in = burn_in;
   a.k0 = a.x0 = (uint32_t)(seed & 0xFFFFFFFFull); a.k1 = a.x1 = (uint32_t)(seed >> 32); a.stream = stream_id;
   a.sign_stride = sign_stride; a.sign_off = sign_off;
+  rc = bvn_noise(h, s, seed, stream_id, 0u, 1, false, 0u, (hipStream_t)stream_);
+  if (rc) return rc;
+  a.dw = s->dw_dev;
   a.slot = slot_dev; a.k_slots = k_slots; a.cells = cells_dev; a.full = full_dev; a.var_full = var_full_dev; a.add_noise = add_noise;
   hipLaunchKernelGGL(bgmb_decode_kernel, dim3((unsigned)tiles), dim3(BNN_THREADS), 0, (hipStream_t)stream_, a);
   BGM_HIP_CHECK(hipGetLastError());

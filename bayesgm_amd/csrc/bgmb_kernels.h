@@ -171,9 +171,43 @@ struct BgmbBigArgs {
   double *acc_prob_sum;
   uint32_t *acc_count;
   float *draws;                // [n_keep x n x q]
+  const float *dw;             // perturbations of the launch's generator calls (bgmb_noise_kernel), slot-major
+  long long dw_stride;
   float *ws;
   long long ws_stride;
 };
+
+// sigma * eps of whole generator calls, produced ONCE per call for all workgroups (slot s of the launch -> stream[s]):
+// dw[s * stride + eoff[l] + idx] as in a call cache.  grid = (element blocks, slots).
+struct BgmbNoiseArgs {
+  BnnNet net;
+  const float *theta;
+  float *dw;
+  long long stride;
+  uint32_t k0, k1;
+  uint32_t stream0, stream_step;   // slot s < n_seq: stream0 + s * stream_step
+  int n_seq;
+  uint32_t stream_extra;           // slot n_seq (if launched): this stream (the bootstrap evaluation)
+};
+static __global__ __launch_bounds__(256) void bgmb_noise_kernel(BgmbNoiseArgs a) {
+  const int slot = blockIdx.y;
+  const uint32_t stream = slot < a.n_seq ? a.stream0 + (uint32_t)slot * a.stream_step : a.stream_extra;
+  float *dw = a.dw + (long long)slot * a.stride;
+  const BnnNet &n = a.net;
+  for (int l = 0; l < n.n_layers; ++l) {
+    const int cnt = n.lin[l] * n.lout[l];
+    const float *rho = a.theta + n.woff[l] + cnt;
+    float *d = dw + n.eoff[l];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (cnt + 3) >> 2; i += gridDim.x * blockDim.x) {
+      const f32x4 z = box_muller4(philox4x32_10((uint32_t)i, (uint32_t)l | ((uint32_t)n.net_id << 16), stream, BNN_TAG_EPS, a.k0, a.k1));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = 4 * i + u;
+        if (idx < cnt) d[idx] = (BNN_SCALE_EPS + softplus_acc(rho[idx])) * z[u];
+      }
+    }
+  }
+}
 
 struct BgmbTile { float *z, *gr, *zc, *pc, *grc, *mom, *xb, *d, *ds, *t0, *t1, *ll; float *cache; };
 __device__ __forceinline__ void bgmb_tile_take(float *wp, BgmbTile &t, int q, int p, int wmax) {
@@ -192,12 +226,13 @@ inline size_t bgmb_tile_floats(const BnnNet &n, int q, int p, int wmax) {
 // log p(z | x_obs) + const and its gradient for the B rows of a tile, ONE generator call (`stream`); lp -> lpv [B] (LDS),
 // gradient -> gr [B x q].  Ends with a barrier.
 __device__ __forceinline__ void bgmb_lpg(const BnnCtx &c, const BgmbBigArgs &a, const BgmbTile &t, const float *zin, int B,
-                                         uint32_t stream, uint32_t row0, float *lpv, float *gr) {
+                                         uint32_t stream, int slot, uint32_t row0, float *lpv, float *gr) {
   const BnnNet &n = a.net;
   float *wp = t.cache;
   BnnCache k;
   bnn_cache(n, B, wp, k, zin);
-  const float *o = bnn_fwd(c, a.theta, n, k, B, a.k0, a.k1, stream, row0);
+  k.dW = const_cast<float *>(a.dw + (long long)slot * a.dw_stride);      // shared by all workgroups; only the signs are per row
+  const float *o = bnn_fwd(c, a.theta, n, k, B, a.k0, a.k1, stream, row0, true);
   bgmb_cells(c, o, t.xb, B, a.p, -1.0f, t.d, t.ll);
   __syncthreads();
   for (int b = c.tid; b < B; b += BNN_THREADS) {
@@ -225,7 +260,7 @@ static __global__ __launch_bounds__(BNN_THREADS) void bgmb_logpost_kernel(BgmbBi
   for (int i = c.tid; i < B * q; i += BNN_THREADS) t.z[i] = a.state[r0 * q + i];
   for (int i = c.tid; i < B * p; i += BNN_THREADS) t.xb[i] = a.x[r0 * p + i];
   __syncthreads();
-  bgmb_lpg(c, a, t, t.z, B, a.stream, (uint32_t)(a.row_base + r0), lpv, a.grad ? t.gr : nullptr);
+  bgmb_lpg(c, a, t, t.z, B, a.stream, 0, (uint32_t)(a.row_base + r0), lpv, a.grad ? t.gr : nullptr);
   for (int b = c.tid; b < B; b += BNN_THREADS) a.logp[r0 + b] = lpv[b];
   if (a.grad) for (int i = c.tid; i < B * q; i += BNN_THREADS) a.grad[r0 * q + i] = t.gr[i];
 }
@@ -245,7 +280,7 @@ static __global__ __launch_bounds__(BNN_THREADS) void bgmb_hmc_kernel(BgmbBigArg
   if (a.init) {
     for (int i = c.tid; i < B * q; i += BNN_THREADS) t.z[i] = bgmb_normal(row0 + (uint32_t)(i / q), 0u, i % q, TAG_INIT, a.k0, a.k1);
     __syncthreads();
-    bgmb_lpg(c, a, t, t.z, B, 0u, row0, lpv, t.gr);
+    bgmb_lpg(c, a, t, t.z, B, 0u, a.frozen ? 0 : a.n_iters * L, row0, lpv, t.gr);
   } else {
     for (int i = c.tid; i < B * q; i += BNN_THREADS) { t.z[i] = a.state[r0 * q + i]; t.gr[i] = a.grad[r0 * q + i]; }
     for (int b = c.tid; b < B; b += BNN_THREADS) lpv[b] = a.logp[r0 + b];
@@ -268,7 +303,8 @@ static __global__ __launch_bounds__(BNN_THREADS) void bgmb_hmc_kernel(BgmbBigArg
     for (int l = 0; l < L; ++l) {
       for (int i = c.tid; i < B * q; i += BNN_THREADS) t.zc[i] = fmaf(e, t.pc[i], t.zc[i]);
       __syncthreads();
-      bgmb_lpg(c, a, t, t.zc, B, a.frozen ? 0u : 1u + (uint32_t)it * (uint32_t)L + (uint32_t)l, row0, lpc, t.grc);
+      bgmb_lpg(c, a, t, t.zc, B, a.frozen ? 0u : 1u + (uint32_t)it * (uint32_t)L + (uint32_t)l, a.frozen ? 0 : (it - a.it_begin) * L + l, row0,
+               lpc, t.grc);
       const float h = (l < L - 1) ? e : 0.5f * e;
       for (int i = c.tid; i < B * q; i += BNN_THREADS) t.pc[i] = fmaf(h, t.grc[i], t.pc[i]);
       __syncthreads();
@@ -322,6 +358,7 @@ struct BgmbDecodeArgs {
   const int *slot; int k_slots;
   float *cells, *full, *var_full;
   int add_noise;
+  const float *dw;             // the call's perturbation (bgmb_noise_kernel, one slot)
   float *ws;
   long long ws_stride;
 };
@@ -338,7 +375,8 @@ static __global__ __launch_bounds__(BNN_THREADS) void bgmb_decode_kernel(BgmbDec
     float *wp = base;
     BnnCache k;
     bnn_cache(a.net, B, wp, k, a.draws + f0 * q);
-    const float *o = bnn_fwd(c, a.theta, a.net, k, B, a.k0, a.k1, a.stream, (uint32_t)d * a.sign_stride + a.sign_off + (uint32_t)r0);
+    k.dW = const_cast<float *>(a.dw);
+    const float *o = bnn_fwd(c, a.theta, a.net, k, B, a.k0, a.k1, a.stream, (uint32_t)d * a.sign_stride + a.sign_off + (uint32_t)r0, true);
     for (int i = c.tid; i < B * p; i += BNN_THREADS) {
       const long long row = r0 + i / p, f = d * a.n + row;
       const int col = i % p;

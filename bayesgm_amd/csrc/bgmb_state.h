@@ -19,6 +19,8 @@ struct BgmbState {
   long long t_theta = 0, t_z = 0;
   float *big_dev = nullptr;    // row-tile workspace of the large-batch kernels (grown on demand)
   size_t big_cap = 0;
+  float *dw_dev = nullptr;     // perturbations of the generator calls of one large-batch launch (bgmb_noise_kernel)
+  size_t dw_cap = 0;
   void *egm = nullptr;         // BgmbEgmState (bgmb_egm_api.hip)
 };
 

@@ -165,21 +165,23 @@ __device__ __forceinline__ void bnn_cache(const BnnNet &n, int B, float *&p, Bnn
 }
 
 // eps, dW = sigma * eps and the sign words of call `stream` (oracle/bnn.py draw_noise).  No barrier at the end.
+// signs_only: the perturbation dW of the call was produced elsewhere (k.dW points at it); only the per-row sign words are drawn.
 __device__ __forceinline__ void bnn_noise(const BnnCtx &c, const float *theta, const BnnNet &n, const BnnCache &k, int B,
-                                          uint32_t k0, uint32_t k1, uint32_t stream, uint32_t row0 = 0u) {
-  for (int l = 0; l < n.n_layers; ++l) {
-    const int cnt = n.lin[l] * n.lout[l];
-    const float *rho = theta + n.woff[l] + cnt;
-    float *e = k.eps + n.eoff[l], *d = k.dW + n.eoff[l];
-    for (int i = c.tid; i < (cnt + 3) >> 2; i += BNN_THREADS) {
-      const f32x4 z = box_muller4(philox4x32_10((uint32_t)i, (uint32_t)l | ((uint32_t)n.net_id << 16), stream, BNN_TAG_EPS, k0, k1));
+                                          uint32_t k0, uint32_t k1, uint32_t stream, uint32_t row0 = 0u, bool signs_only = false) {
+  if (!signs_only)
+    for (int l = 0; l < n.n_layers; ++l) {
+      const int cnt = n.lin[l] * n.lout[l];
+      const float *rho = theta + n.woff[l] + cnt;
+      float *e = k.eps + n.eoff[l], *d = k.dW + n.eoff[l];
+      for (int i = c.tid; i < (cnt + 3) >> 2; i += BNN_THREADS) {
+        const f32x4 z = box_muller4(philox4x32_10((uint32_t)i, (uint32_t)l | ((uint32_t)n.net_id << 16), stream, BNN_TAG_EPS, k0, k1));
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int idx = 4 * i + u;
-        if (idx < cnt) { e[idx] = z[u]; d[idx] = (BNN_SCALE_EPS + softplus_acc(rho[idx])) * z[u]; }
+        for (int u = 0; u < 4; ++u) {
+          const int idx = 4 * i + u;
+          if (idx < cnt) { e[idx] = z[u]; d[idx] = (BNN_SCALE_EPS + softplus_acc(rho[idx])) * z[u]; }
+        }
       }
     }
-  }
   const int calls = n.swords >> 2;
   for (int i = c.tid; i < B * calls; i += BNN_THREADS) {
     const int r = i / calls, cc = i - r * calls;
@@ -253,8 +255,8 @@ __device__ __forceinline__ void bnn_layers_fwd(const BnnCtx &c, const float *the
 }
 
 __device__ __forceinline__ float *bnn_fwd(const BnnCtx &c, const float *theta, const BnnNet &n, const BnnCache &k, int B,
-                                          uint32_t k0, uint32_t k1, uint32_t stream, uint32_t row0 = 0u) {
-  bnn_noise(c, theta, n, k, B, k0, k1, stream, row0);
+                                          uint32_t k0, uint32_t k1, uint32_t stream, uint32_t row0 = 0u, bool signs_only = false) {
+  bnn_noise(c, theta, n, k, B, k0, k1, stream, row0, signs_only);
   __syncthreads();
   bnn_bn_fwd(c, theta, n, k, B);
   __syncthreads();
