@@ -36,3 +36,31 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def run_two_ranks(script, timeout=240, attempts=2):
+    """Launch scripts/<script> with two ranks on GPU 0 over gloo (torch.distributed.run on 127.0.0.1, a free port) in its own
+    process group; a run that does not finish in `timeout` seconds is killed WITH its ranks and retried once.  Returns the
+    CompletedProcess."""
+    import signal
+    import socket
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BGM_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    last = None
+    for attempt in range(attempts):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        proc = subprocess.Popen([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                                 "127.0.0.1", "--master-port", str(port), os.path.join(root, "scripts", script), "gloo"],
+                                cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            out, err = proc.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)
+            proc.communicate()
+            last = "two-rank run of %s did not finish within %d s (attempt %d)" % (script, timeout, attempt)
+            continue
+        return subprocess.CompletedProcess(proc.args, proc.returncode, out, err)
+    raise AssertionError(last)

@@ -379,10 +379,7 @@ def test_bgm_fit_global_batch_scaling_and_two_rank_run(tmp_path):
     eng.fit_theta_grad(x, z, idx, g2)
     assert torch.equal(g2 * 2.0, g1)
     eng.fit_end()
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, BGM_DEVICE="0", MASTER_ADDR="127.0.0.1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29533", os.path.join(root, "scripts", "dp_bgm_fit_smoke.py"), "gloo"],
-                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    from conftest import run_two_ranks
+    r = run_two_ranks("dp_bgm_fit_smoke.py")
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count('"param_spread": 0.0') == 2, r.stdout[-2000:]

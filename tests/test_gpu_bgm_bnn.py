@@ -346,29 +346,10 @@ def test_model_checkpoint_roundtrip(tmp_path):
 def test_two_rank_fit_and_predict_agree(tmp_path):
     """Two ranks on one GPU over gloo (scripts/dp_bgm_bnn_smoke.py; shards differ by a row, bs-blocks split over the ranks):
     bit-identical generators, imputations and intervals on both ranks."""
-    import os, signal, socket, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, BGM_DEVICE="0", MASTER_ADDR="127.0.0.1")
-    last = None
-    for attempt in range(2):                      # a rendezvous that does not come up is retried once on another free port
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        proc = subprocess.Popen([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                                 "127.0.0.1", "--master-port", str(port), os.path.join(root, "scripts", "dp_bgm_bnn_smoke.py"), "gloo"],
-                                cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
-        try:
-            out, err = proc.communicate(timeout=180)
-        except subprocess.TimeoutExpired:
-            os.killpg(proc.pid, signal.SIGKILL)       # the launcher AND its two ranks (own session)
-            proc.communicate()
-            last = "two-rank run did not finish within 180 s (attempt %d)" % attempt
-            continue
-        r = subprocess.CompletedProcess(proc.args, proc.returncode, out, err)
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        assert r.stdout.count('"param_spread": 0.0') == 2, r.stdout[-2000:]
-        return
-    raise AssertionError(last)
+    from conftest import run_two_ranks
+    r = run_two_ranks("dp_bgm_bnn_smoke.py")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count('"param_spread": 0.0') == 2, r.stdout[-2000:]
 
 
 def test_predict_does_not_depend_on_row_chunking(tmp_path):

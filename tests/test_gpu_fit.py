@@ -228,11 +228,8 @@ def test_two_rank_causal_fit_and_predict_run():
     """The data-parallel code paths of CausalBGM (row shards, fused gradient all-reduce, Z rows local, ADRF all-reduce)
     executed for real: two ranks on this GPU over gloo end with bit-identical networks, ADRF and intervals."""
     import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, BGM_DEVICE="0", MASTER_ADDR="127.0.0.1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29534", os.path.join(root, "scripts", "dp_causal_smoke.py"), "gloo"],
-                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    from conftest import run_two_ranks
+    r = run_two_ranks("dp_causal_smoke.py")
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count('"spread": 0.0') == 2, r.stdout[-2000:]
     # the sharded predict equals the single-process predict of the same (seeded, untrained) model: chains are keyed by the
