@@ -588,6 +588,11 @@ int bgm_bvn_end(bgm_handle *h, void *stream);
  * register operands only) with `waves_per_cu` waves on every CU. */
 int bgm_debug_group_probe(bgm_handle *h, int32_t mode, int32_t waves_per_cu, int32_t iters, double *mfma_tflops);
 int bgm_debug_clock_probe(bgm_handle *h, int32_t iters, double *shader_mhz, double *mfma_tflops);
+/* Measurement aid for the next step: one hidden 64 -> 64 layer + LeakyReLU chained `iters` times per wave
+ * (8 waves on every CU), mode 0 = fp32 MFMA as the MH kernel today, mode 1 = split-precision bf16 x 3 on
+ * v_mfma_f32_16x16x32_bf16.  out_host [16 x 64]: activations after `iters` layers; ns_per_layer: time of one layer. */
+int bgm_debug_bf16x3_probe(bgm_handle *h, int32_t mode, int32_t iters, const float *W_host, const float *x_host, float *out_host,
+                           double *ns_per_layer);
 
 #ifdef __cplusplus
 }
