@@ -172,7 +172,8 @@ class BvnEngine(object):
                          acc_prob=acc_prob, acc_count=acc_count)
             if reduce_fn is not None:
                 reduce_fn(acc_prob[it:it + 1])
-            self.hmc_adapt(step, acc_prob, it, n_chains_global or n)
+            if (n_chains_global or n) > 0:
+                self.hmc_adapt(step, acc_prob, it, n_chains_global or n)
         self.hmc_run(x, state, logp, grad, step, n_adapt, total - n_adapt, burn_in, n_leapfrog, seed, init=(n_adapt == 0),
                      row_base=row_base, acc_prob=acc_prob, acc_count=acc_count, draws=draws)
         return dict(draws=draws, step=step, acc_count=acc_count, state=state, logp=logp, grad=grad)

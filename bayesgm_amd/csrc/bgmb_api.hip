@@ -244,8 +244,8 @@ extern "C" int bgm_bvn_logpost(bgm_handle *h, const float *z_dev, const float *x
                                uint32_t stream_id, float *out_dev, float *grad_dev, void *stream_) {
   int rc = bvn_need(h, "bgm_bvn_logpost");
   if (rc) return rc;
-  if (!z_dev || !x_dev || !out_dev || n < 0) { bgm_set_error("bgm_bvn_logpost: bad argument"); return BGM_E_INVALID; }
   if (n == 0) return BGM_OK;
+  if (!z_dev || !x_dev || !out_dev || n < 0) { bgm_set_error("bgm_bvn_logpost: bad argument"); return BGM_E_INVALID; }
   BgmbState *s = vst(h);
   BGM_HIP_CHECK(hipSetDevice(h->device));
   const int rt = bvn_rt(h, n);
@@ -269,9 +269,10 @@ extern "C" int bgm_bvn_logpost(bgm_handle *h, const float *z_dev, const float *x
 extern "C" int bgm_bvn_hmc_run(bgm_handle *h, const bgm_hmc_args *g, void *stream_) {
   int rc = bvn_need(h, "bgm_bvn_hmc_run");
   if (rc) return rc;
+  if (g && g->n == 0) return BGM_OK;
   if (!g || !g->x_dev || !g->state_dev || !g->logp_dev || !g->grad_dev || !g->step_dev || g->n < 0 || g->n_iters < 0 ||
       g->n_leapfrog < 1) { bgm_set_error("bgm_bvn_hmc_run: bad argument"); return BGM_E_INVALID; }
-  if (g->n == 0 || (g->n_iters == 0 && !g->init)) return BGM_OK;
+  if (g->n_iters == 0 && !g->init) return BGM_OK;
   BgmbState *s = vst(h);
   BGM_HIP_CHECK(hipSetDevice(h->device));
   const int rt = bvn_rt(h, g->n);
@@ -316,11 +317,11 @@ extern "C" int bgm_bvn_decode(bgm_handle *h, const float *draws_dev, int64_t n, 
                               void *stream_) {
   int rc = bvn_need(h, "bgm_bvn_decode");
   if (rc) return rc;
+  const long long total = (long long)n * n_draws;
+  if (total == 0) return BGM_OK;
   if (!draws_dev || n < 0 || n_draws < 0 || (cells_dev && (!slot_dev || k_slots < 1))) {
     bgm_set_error("bgm_bvn_decode: bad argument"); return BGM_E_INVALID;
   }
-  const long long total = (long long)n * n_draws;
-  if (total == 0) return BGM_OK;
   if ((long long)n_draws * (long long)sign_stride + (long long)sign_off + n >= (1LL << 32)) {
     bgm_set_error("bgm_bvn_decode: sign row ids must stay below 2^32 (split the rows)"); return BGM_E_UNSUPPORTED;
   }

@@ -363,3 +363,70 @@ def test_predict_does_not_depend_on_row_chunking(tmp_path):
     np.testing.assert_array_equal(a, b)
     for u, v in zip(ia, ib):
         np.testing.assert_array_equal(u, v)
+
+
+def test_index_and_nan_forms_of_missingness_agree(tmp_path):
+    """The reference passes observed features as index lists + obs_mask (bgm/base.py:578-592, 689-700); the build marks missing
+    cells with NaN.  Both forms must give the same log posterior and the same chains."""
+    from bayesgm_amd.models import BGM
+    p, q, n = 9, 3, 40
+    model = BGM(_params(tmp_path, p, q), random_seed=6)
+    rs = np.random.RandomState(2)
+    data = rs.standard_normal((n, p)).astype(np.float32)
+    z = rs.standard_normal((n, q)).astype(np.float32)
+    keep = [sorted(rs.choice(p, rs.randint(1, p), replace=False).tolist()) for _ in range(n)]
+    nan_form = np.full_like(data, np.nan)
+    for i, r in enumerate(keep):
+        nan_form[i, r] = data[i, r]
+    kmax = max(len(r) for r in keep)
+    ind = np.zeros((n, kmax), np.int64)
+    msk = np.zeros((n, kmax), np.float32)
+    for i, r in enumerate(keep):
+        ind[i, :len(r)] = r
+        msk[i, :len(r)] = 1.0
+    a = model.get_log_posterior(z, nan_form, seed=9)
+    b = model.get_log_posterior(z, data, ind_x1=ind, obs_mask=msk, seed=9)
+    np.testing.assert_array_equal(a, b)
+    d1 = model.tfp_mcmc_sampler(nan_form, n_mcmc=4, burn_in=4, step_size=0.05, num_leapfrog_steps=3, seed=3)
+    d2 = model.tfp_mcmc_sampler(data, ind_x1=keep, n_mcmc=4, burn_in=4, step_size=0.05, num_leapfrog_steps=3, seed=3)
+    np.testing.assert_array_equal(d1, d2)
+    assert d1.shape == (4, n, q)
+    # shared pattern given as one index list
+    d3 = model.tfp_mcmc_sampler(data, ind_x1=[0, 2, 5], n_mcmc=2, burn_in=2, step_size=0.05, num_leapfrog_steps=3, seed=3)
+    shared = np.full_like(data, np.nan)
+    shared[:, [0, 2, 5]] = data[:, [0, 2, 5]]
+    np.testing.assert_array_equal(d3, model.tfp_mcmc_sampler(shared, n_mcmc=2, burn_in=2, step_size=0.05, num_leapfrog_steps=3, seed=3))
+
+
+def test_empty_inputs_are_accepted(tmp_path):
+    q, units, p = 3, (16,), 7
+    net = _net(q, units, p, seed=1)
+    eng = _engine(net, q, units, p)
+    dev = eng.device
+    z0, x0 = torch.empty((0, q), device=dev), torch.empty((0, p), device=dev)
+    lp, gr = eng.logpost(z0, x0, 1, 0, want_grad=True)
+    assert lp.shape == (0,) and gr.shape == (0, q)
+    out = eng.hmc_sample(x0, n_mcmc=2, burn_in=2, seed=1)
+    assert out["draws"].shape == (2, 0, q)
+    _, full = eng.decode(torch.empty((3, 0, q), device=dev), 1, 7, want_full=True)
+    assert full.shape == (3, 0, p)
+    eng.close()
+
+
+def test_session_errors_are_reported(tmp_path):
+    from bayesgm_amd.bvn_engine import BvnEngine
+    eng = BvnEngine(7, 3, g_units=(16,))
+    with pytest.raises(RuntimeError, match="no session"):
+        eng.read(0)
+    with pytest.raises(RuntimeError, match="wrong parameter count"):
+        eng.begin(np.zeros(5, np.float32))
+    with pytest.raises(ValueError):
+        BvnEngine(7, 3, g_units=(16,) * 7)
+    eng.begin(_net(3, (16,), 7))
+    x = torch.zeros((40, 7), device=eng.device)
+    z = torch.zeros((40, 3), device=eng.device)
+    with pytest.raises(RuntimeError, match="bad argument"):
+        eng.theta_step(x, z, torch.zeros(1, dtype=torch.int32, device=eng.device), 1e-3, 1, 0)        # a batch of one row
+    with pytest.raises(RuntimeError, match="bad argument"):
+        eng.theta_step(x, z, torch.zeros(33, dtype=torch.int32, device=eng.device), 1e-3, 1, 0)       # above max_batch
+    eng.close()
