@@ -108,6 +108,7 @@ __device__ __forceinline__ void bnn_gemm2(int tid, BnnMat A1, BnnMat A2, BnnMat 
                                           int tile_begin, int tile_stride, Epi epi) {
   const int lane = tid & 63, j = lane & 15, g = lane >> 4;
   const int tn_count = (N + 15) >> 4, tiles = ((M + 15) >> 4) * tn_count;
+  const bool vec = A1.s1 == 1 && (A1.s0 & 3) == 0 && (((unsigned long long)A1.p | (unsigned long long)A2.p) & 15ull) == 0;
   for (int t = tile_begin; t < tiles; t += tile_stride) {
     const int m0 = (t / tn_count) << 4, n0 = (t % tn_count) << 4;
     const float am = (m0 + j < M) ? 1.0f : 0.0f, bn = (n0 + j < N) ? 1.0f : 0.0f;
@@ -115,15 +116,33 @@ __device__ __forceinline__ void bnn_gemm2(int tid, BnnMat A1, BnnMat A2, BnnMat 
     f32x4 c1 = {0.0f, 0.0f, 0.0f, 0.0f}, c2 = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int k0 = 0; k0 < K; k0 += 32) {
       float a1[8], a2[8], b1[8], b2[8];
+      if (vec && k0 + 32 <= K) {
+        // row-major A: a lane's four K values of a group of four steps are adjacent -> one 16-byte load per operand and
+        // group instead of four scalar loads that each touch 16 cache lines (the activation rows).  Step u then uses
+        // k = k0 + 16 (u / 4) + 4 g + u % 4 on BOTH operands (the sum over k is over the same set, in another order).
+        // (The same trick on the transposed weights of the input-gradient product, B with unit K stride, measured no gain:
+        // those lines are shared by all workgroups and stay in L2.)
+        const f32x4 *q1 = reinterpret_cast<const f32x4 *>(A1.p + ao + k0 + 4 * g), *q2 = reinterpret_cast<const f32x4 *>(A2.p + ao + k0 + 4 * g);
+        const f32x4 v10 = q1[0], v11 = q1[4], v20 = q2[0], v21 = q2[4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int k = k0 + 4 * u + g;
-        const int kc = min(k, K - 1);
-        const float mk = (k < K) ? am : 0.0f;
-        a1[u] = A1.p[ao + (long long)kc * A1.s1] * mk;
-        a2[u] = A2.p[ao + (long long)kc * A1.s1] * mk;
-        b1[u] = B1.p[bo + (long long)kc * B1.s0];
-        b2[u] = B2.p[bo + (long long)kc * B1.s0];
+        for (int u = 0; u < 4; ++u) { a1[u] = v10[u] * am; a1[4 + u] = v11[u] * am; a2[u] = v20[u] * am; a2[4 + u] = v21[u] * am; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const long long kk = (long long)(k0 + 16 * (u >> 2) + 4 * g + (u & 3)) * B1.s0;
+          b1[u] = B1.p[bo + kk];
+          b2[u] = B2.p[bo + kk];
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = k0 + 4 * u + g;
+          const int kc = min(k, K - 1);
+          const float mk = (k < K) ? am : 0.0f;
+          a1[u] = A1.p[ao + (long long)kc * A1.s1] * mk;
+          a2[u] = A2.p[ao + (long long)kc * A1.s1] * mk;
+          b1[u] = B1.p[bo + (long long)kc * B1.s0];
+          b2[u] = B2.p[bo + (long long)kc * B1.s0];
+        }
       }
       BGM_NO_HOIST();
 #pragma unroll
