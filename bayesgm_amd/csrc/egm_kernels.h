@@ -100,6 +100,7 @@ __device__ __forceinline__ void egm_gemm_tiles(const EgmCtx &c, EgmMat A, EgmMat
                                                int tile_stride, Epi epi) {
   const int lane = c.tid & 63, j = lane & 15, g = lane >> 4;
   const int tn_count = (N + 15) >> 4, tiles = ((M + 15) >> 4) * tn_count;
+  const bool vec = A.s1 == 1 && (A.s0 & 3) == 0 && ((unsigned long long)A.p & 15ull) == 0;
   for (int t = tile_begin; t < tiles; t += tile_stride) {
     const int m0 = (t / tn_count) << 4, n0 = (t % tn_count) << 4;
     // Loads are unconditional (indices clamped into the matrix, contributions masked to zero).
@@ -109,12 +110,27 @@ __device__ __forceinline__ void egm_gemm_tiles(const EgmCtx &c, EgmMat A, EgmMat
     // K in chunks of 16 steps: all 32 operand loads of a chunk are in flight before its first MFMA.
     for (int k0 = 0; k0 < K; k0 += 64) {
       float av[16], bv[16];
+      if (vec && k0 + 64 <= K) {
+        // row-major A (activation rows): a lane's four K values of a group of four steps are adjacent -> one 16-byte load per
+        // group instead of four scalar loads that each touch 16 cache lines; step u then uses
+        // k = k0 + 16 (u / 4) + 4 g + u % 4 on BOTH operands (same set of k, another summation order).  See DESIGN.md 7b.
+        const f32x4 *q = reinterpret_cast<const f32x4 *>(ap + k0 + 4 * g);
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int k = k0 + 4 * u + g;
-        const int kc = min(k, K - 1);
-        av[u] = ap[kc * A.s1] * ((k < K) ? am : 0.0f);
-        bv[u] = bp[kc * Bm.s0];
+        for (int c4 = 0; c4 < 4; ++c4) {
+          const f32x4 v = q[4 * c4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) av[4 * c4 + r] = v[r] * am;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) bv[u] = bp[(long long)(k0 + 16 * (u >> 2) + 4 * g + (u & 3)) * Bm.s0];
+      } else {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int k = k0 + 4 * u + g;
+          const int kc = min(k, K - 1);
+          av[u] = ap[kc * A.s1] * ((k < K) ? am : 0.0f);
+          bv[u] = bp[kc * Bm.s0];
+        }
       }
       BGM_NO_HOIST();
 #pragma unroll
