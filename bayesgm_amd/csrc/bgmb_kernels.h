@@ -53,6 +53,20 @@ __device__ __forceinline__ float bgmb_cells(const BnnCtx &c, const float *o, con
   return sq;
 }
 
+// rowv[b] = sign * (sum_j ll[b p + j] (+ 0.5 |z_b|^2 when z != NULL)): one wave per row, lanes stride over the columns (coalesced), fixed
+// reduction order.  No barrier at the end.
+__device__ __forceinline__ void bgmb_row_sums(const BnnCtx &c, const float *ll, int B, int p, const float *z, int q, float *rowv,
+                                              float sign = 1.0f) {
+  const int lane = c.tid & 63, wave = c.tid >> 6;
+  for (int b = wave; b < B; b += BNN_THREADS / 64) {
+    float s = 0.0f;
+    for (int j = lane; j < p; j += 64) s += ll[b * p + j];
+    if (z) for (int j = lane; j < q; j += 64) s = fmaf(0.5f * z[b * q + j], z[b * q + j], s);
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) rowv[b] = sign * s;
+  }
+}
+
 struct BgmbArgs {
   BnnNet net;                            // generator: heads = 1, mv = 1, bn_fixed = 0
   float *theta, *m, *v, *grad;
@@ -99,11 +113,7 @@ static __global__ __launch_bounds__(BNN_THREADS) void bgmb_theta_step_kernel(Bgm
   const float *o = bnn_fwd(c, a.theta, n, k, B, a.k0, a.k1, a.stream);
   float sq = bgmb_cells(c, o, w.xb, B, p, a.inv_B, w.d, w.ll);
   sq = bnn_block_sum(c, sq);
-  for (int b = c.tid; b < B; b += BNN_THREADS) {
-    float s = 0.0f;
-    for (int j = 0; j < p; ++j) s += w.ll[b * p + j];
-    rowv[b] = s;
-  }
+  bgmb_row_sums(c, w.ll, B, p, nullptr, 0, rowv);
   __syncthreads();
   float loss = 0.0f;
   for (int b = 0; b < B; ++b) loss += rowv[b];
@@ -134,12 +144,7 @@ static __global__ __launch_bounds__(BNN_THREADS) void bgmb_z_step_kernel(BgmbArg
   const float *o = bnn_fwd(c, a.theta, n, k, B, a.k0, a.k1, a.stream);
   bgmb_cells(c, o, w.xb, B, p, a.inv_B, w.d, w.ll);
   __syncthreads();
-  for (int b = c.tid; b < B; b += BNN_THREADS) {
-    float s = 0.0f, zz = 0.0f;
-    for (int j = 0; j < p; ++j) s += w.ll[b * p + j];
-    for (int j = 0; j < q; ++j) zz = fmaf(w.zb[b * q + j], w.zb[b * q + j], zz);
-    rowv[b] = s + 0.5f * zz;
-  }
+  bgmb_row_sums(c, w.ll, B, p, w.zb, q, rowv);
   __syncthreads();
   float loss = 0.0f;
   for (int b = 0; b < B; ++b) loss += rowv[b];
@@ -235,12 +240,7 @@ __device__ __forceinline__ void bgmb_lpg(const BnnCtx &c, const BgmbBigArgs &a, 
   const float *o = bnn_fwd(c, a.theta, n, k, B, a.k0, a.k1, stream, row0, true);
   bgmb_cells(c, o, t.xb, B, a.p, -1.0f, t.d, t.ll);
   __syncthreads();
-  for (int b = c.tid; b < B; b += BNN_THREADS) {
-    float s = 0.0f, zz = 0.0f;
-    for (int j = 0; j < a.p; ++j) s += t.ll[b * a.p + j];
-    for (int j = 0; j < a.q; ++j) zz = fmaf(zin[b * a.q + j], zin[b * a.q + j], zz);
-    lpv[b] = -(s + 0.5f * zz);
-  }
+  bgmb_row_sums(c, t.ll, B, a.p, zin, a.q, lpv, -1.0f);
   if (gr) {
     bnn_bwd(c, a.theta, nullptr, n, k, t.d, t.ds, t.t0, t.t1, gr, B, false, false);
     for (int i = c.tid; i < B * a.q; i += BNN_THREADS) gr[i] -= zin[i];

@@ -488,6 +488,17 @@ __device__ __forceinline__ void bnn_gather(const BnnCtx &c, const BnnArgs &a, fl
   __syncthreads();
 }
 
+// ssq[b] = sum_j (v[b p + j] - o[b wo + j])^2: one wave per row, lanes stride over the columns (coalesced), fixed order.
+__device__ __forceinline__ void bnn_row_ssq(const BnnCtx &c, const float *v, const float *o, int B, int p, int wo, float *ssq) {
+  const int lane = c.tid & 63, wave = c.tid >> 6;
+  for (int b = wave; b < B; b += BNN_THREADS / 64) {
+    float s = 0.0f;
+    for (int j = lane; j < p; j += 64) { const float t = v[b * p + j] - o[b * wo + j]; s = fmaf(t, t, s); }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) ssq[b] = s;
+  }
+}
+
 // Gaussian head: loss_b = ssq / (2 s2) + dim * log(s2) / 2 with s2 = softplus(raw) + 1e-6; returns d loss_b / d raw
 __device__ __forceinline__ float bnn_gauss(float ssq, float raw, float dim, float &loss_b, float &s2) {
   s2 = softplus_acc(raw) + BGM_EPS;
@@ -519,12 +530,8 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_step_kernel(BnnA
     const int wo = n.dims[n.n_layers];
     float loss = 0.0f, aux = 0.0f;
     if (id == BNN_G) {
-      // per-row sum of squares (ordered), then the head
-      for (int b = c.tid; b < B; b += BNN_THREADS) {
-        float s = 0.0f;
-        for (int j = 0; j < p; ++j) { const float t = bt.vb[b * p + j] - o[b * wo + j]; s = fmaf(t, t, s); }
-        ssq_row[b] = s;
-      }
+      // per-row sum of squares, then the head
+      bnn_row_ssq(c, bt.vb, o, B, p, wo, ssq_row);
       __syncthreads();
       for (int i = c.tid; i < B * wo; i += BNN_THREADS) {
         const int b = i / wo, j = i - b * wo;
@@ -607,11 +614,7 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_z_grad_kernel(BnnArgs 
     float loss = 0.0f;
     // upstream gradients: d for call 1 (mean), t-buffers reused for call 2 (variance head) after the first backward
     if (id == BNN_G) {
-      for (int b = c.tid; b < B; b += BNN_THREADS) {
-        float s = 0.0f;
-        for (int j = 0; j < p; ++j) { const float t = bt.vb[b * p + j] - o1[b * wo + j]; s = fmaf(t, t, s); }
-        ssq_row[b] = s;
-      }
+      bnn_row_ssq(c, bt.vb, o1, B, p, wo, ssq_row);
       __syncthreads();
       for (int i = c.tid; i < B * wo; i += BNN_THREADS) {
         const int b = i / wo, j = i - b * wo;
