@@ -363,18 +363,26 @@ __global__ __launch_bounds__(256) void fit_dw_kernel(DwArgs a) {
     float bsum[NT_MAX];
 #pragma unroll
     for (int to = 0; to < NT_MAX; ++to) bsum[to] = 0.0f;
-    for (long long r = r0; r < r1; r += 4) {
-      const long long rr = r + kk;
-      const bool ok = rr < r1;
-      const float av = ok ? A[rr * L.K + 16 * ti + i] : 0.0f;
+    constexpr int G = 2;                        // groups of four rows per trip: their loads are in flight together (4: no further gain)
+    for (long long r = r0; r < r1; r += 4 * G) {
+      float av[G], dv[G][NT_MAX];
 #pragma unroll
-      for (int to = 0; to < NT_MAX; ++to) {
-        if (to0 + to < NT) {
-          const float dv = ok ? D[rr * L.N + 16 * (to0 + to) + i] : 0.0f;
-          acc[to] = BGM_MFMA(av, dv, acc[to]);
-          bsum[to] += dv;
-        }
+      for (int u = 0; u < G; ++u) {
+        const long long rr = r + 4 * u + kk;
+        const bool ok = rr < r1;
+        av[u] = ok ? A[rr * L.K + 16 * ti + i] : 0.0f;
+#pragma unroll
+        for (int to = 0; to < NT_MAX; ++to) dv[u][to] = (ok && to0 + to < NT) ? D[rr * L.N + 16 * (to0 + to) + i] : 0.0f;
       }
+#pragma unroll
+      for (int u = 0; u < G; ++u)
+#pragma unroll
+        for (int to = 0; to < NT_MAX; ++to) {
+          if (to0 + to < NT) {
+            acc[to] = BGM_MFMA(av[u], dv[u][to], acc[to]);
+            bsum[to] += dv[u][to];
+          }
+        }
     }
     // D tile [in feature 16 ti + 4 kk + r][out feature 16 to + i]
 #pragma unroll
