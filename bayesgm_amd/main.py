@@ -5,7 +5,8 @@ src/configs/*.yaml (``dataset``, ``output_dir``, ``use_bnn``, ``z_dims`` / ``z_d
 loaded with ``yaml.safe_load`` and handed to the model class unchanged; the two simulated workflows of the reference are
 wired: ``Sim_Hirano_Imbens`` (CausalBGM: fit, ADRF on linspace(0, 3, 20)) and ``Sim_heteroskedastic`` (BGM: fit on 90 % of
 the rows, impute the response of the held-out rows, main.py:66-84).  The reference hard-codes the run lengths; here they are
-flags whose defaults are the reference's values.
+flags whose defaults are the reference's values.  No config files are shipped: the reference's own YAML files (or any file with
+their keys, plus the build options `bnn_norm` / `bnn_mcmc_noise`) are read as they are; tests/test_main_yaml.py writes small ones.
 """
 import argparse
 
