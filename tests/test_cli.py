@@ -63,3 +63,11 @@ def test_bgm_command_end_to_end(tmp_path, bnn):
     np.testing.assert_allclose(imp, parse_file(str(f), sep=","), rtol=1e-5, atol=1e-6)       # nothing missing: observed cells returned as given
     assert np.load("%s/prediction_intervals.npz" % model.save_dir)["intervals"].shape == (320, 0, 2)
     assert type(model).__name__ == ("BGMBayes" if bnn else "BGM")
+
+
+def test_package_resolves_submodules_lazily():
+    import bayesgm_amd as bayesgm
+    assert bayesgm.models.CausalBGM.__name__ == "CausalBGM" and bayesgm.models.BGM.__name__ == "BGM"
+    assert callable(bayesgm.datasets.Sim_Hirano_Imbens_sampler) and callable(bayesgm.utils.get_ADRF)
+    with pytest.raises(AttributeError):
+        bayesgm.no_such_module
