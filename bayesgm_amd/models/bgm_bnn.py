@@ -54,6 +54,8 @@ class BGMBayes(BGM):
         mode = params.get("bnn_mcmc_noise", "fresh")
         if mode not in ("fresh", "frozen"):
             raise ValueError("params['bnn_mcmc_noise'] must be 'fresh' or 'frozen'")
+        self._mcmc_noise = mode
+        self._warned_noise = False
         self.engine = BvnEngine(xd, q, g_units=p["g_units"], kl_weight=p["kl_weight"], max_batch=self._max_batch, device=device,
                                 hmc_frozen_noise=(mode == "frozen"))
         self.engine.begin(self.g)
@@ -287,6 +289,15 @@ class BGMBayes(BGM):
         self.set_weights(g)
 
     # ------------------------------------------------------------------ inference helpers
+    def _warn_fresh_noise(self):
+        if self._mcmc_noise == "fresh" and not self._warned_noise:
+            import warnings
+            warnings.warn("bayesgm_amd: use_bnn=True re-perturbs the generator at every HMC gradient evaluation, as the reference does: "
+                          "the acceptance probability stays below the adaptation target whatever the step, SimpleStepSizeAdaptation "
+                          "shrinks the step geometrically and the chains freeze (DESIGN.md section 7b); "
+                          "params['bnn_mcmc_noise'] = 'frozen' samples on one weight draw per HMC run instead.")
+            self._warned_noise = True
+
     def _new_seed(self):
         return int(np.random.randint(0, 2 ** 31 - 1))
 
@@ -317,6 +328,7 @@ class BGMBayes(BGM):
             else:
                 keep[:, list(ind_x1)] = True
             x[~keep] = np.nan
+        self._warn_fresh_noise()
         out = self.engine.hmc_sample(self._dev(x), n_mcmc, burn_in, step_size, num_leapfrog_steps, seed)
         self.last_acceptance_rate = float(out["acc_count"][burn_in:].sum().item()) / max(1, n_mcmc * x.shape[0])
         print(f"TFP MCMC Acceptance Rate: {self.last_acceptance_rate:.4f}")
@@ -341,6 +353,7 @@ class BGMBayes(BGM):
         """Posterior-predictive imputation of the NaN cells (bgm/base.py:527-663).  HMC over ALL rows as in the reference
         (one generator call per gradient evaluation), then one predictive generator call per block of `bs` rows."""
         assert 0 < alpha < 1, "The significance level 'alpha' must be greater than 0 and less than 1."
+        self._warn_fresh_noise()
         data_np = data.cpu().numpy() if isinstance(data, torch.Tensor) else np.asarray(data, dtype=np.float32)
         data_np = data_np.astype(np.float32)
         n, p = data_np.shape

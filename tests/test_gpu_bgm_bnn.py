@@ -330,6 +330,19 @@ def test_model_predict_is_block_consistent_with_the_oracle(tmp_path):
     eng.close()
 
 
+def test_default_mcmc_noise_is_the_reference_reading_and_warns(tmp_path):
+    from bayesgm_amd.models import BGM
+    p, q = 6, 2
+    model = BGM(_params(tmp_path, p, q), random_seed=3)
+    assert model._mcmc_noise == "fresh" and model.engine.cfg.hmc_frozen_noise == 0
+    x = np.random.RandomState(0).standard_normal((20, p)).astype(np.float32)
+    x[:, 1] = np.nan
+    with pytest.warns(UserWarning, match="bnn_mcmc_noise"):
+        model.predict(x, n_mcmc=3, burn_in=3, num_leapfrog_steps=2)
+    with pytest.raises(ValueError):
+        BGM(_params(tmp_path, p, q, bnn_mcmc_noise="other"), random_seed=3)
+
+
 def test_model_checkpoint_roundtrip(tmp_path):
     from bayesgm_amd.models import BGM
     p, q = 7, 3
