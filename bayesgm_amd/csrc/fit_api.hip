@@ -231,8 +231,8 @@ extern "C" int bgm_causal_fit_begin(bgm_handle *h, int64_t n_rows, int32_t max_b
   BGM_HIP_CHECK(hipMalloc(&h->tables_dev, sizeof(int) * tables.size()));
   BGM_HIP_CHECK(hipMemcpy(h->tables_dev, tables.data(), sizeof(int) * tables.size(), hipMemcpyHostToDevice));
   h->fit_rows = n_rows;
-  BGM_HIP_CHECK(hipMalloc(&h->pos_dev, sizeof(int) * n_rows));
-  BGM_HIP_CHECK(hipMemset(h->pos_dev, 0xFF, sizeof(int) * n_rows));
+  BGM_HIP_CHECK(hipMalloc(&h->pos_dev, sizeof(int) * 2 * n_rows));      // [position in the batch | step stamp]
+  BGM_HIP_CHECK(hipMemset(h->pos_dev, 0xFF, sizeof(int) * 2 * n_rows));
   BGM_HIP_CHECK(hipDeviceSynchronize());
   h->fit_active = true;
   return BGM_OK;
@@ -342,13 +342,13 @@ extern "C" int bgm_causal_fit_z_step(bgm_handle *h, const float *x, const float 
   if (lazy) {
     const long long n = (long long)batch * q;
     hipLaunchKernelGGL(fit_adam_z_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, data_z, zm, zv, dz,
-                       h->pos_dev, h->fit_rows, q, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS, 1, idx, batch);
+                       h->pos_dev, h->fit_rows, q, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS, 1, idx, batch, 0);
   } else {
-    hipLaunchKernelGGL(fit_set_pos_kernel, dim3((batch + 255) / 256), dim3(256), 0, stream, h->pos_dev, idx, batch, 1);
+    const int epoch = (int)(h->t_z & 0x3FFFFFFF);      // stamps of earlier steps never match (2^30 steps before a wrap)
+    hipLaunchKernelGGL(fit_set_pos_kernel, dim3((batch + 255) / 256), dim3(256), 0, stream, h->pos_dev, h->fit_rows, idx, batch, epoch);
     const long long n = h->fit_rows * q;
     hipLaunchKernelGGL(fit_adam_z_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, data_z, zm, zv, dz,
-                       h->pos_dev, h->fit_rows, q, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS, 0, idx, batch);
-    hipLaunchKernelGGL(fit_set_pos_kernel, dim3((batch + 255) / 256), dim3(256), 0, stream, h->pos_dev, idx, batch, 0);
+                       h->pos_dev, h->fit_rows, q, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS, 0, idx, batch, epoch);
   }
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;

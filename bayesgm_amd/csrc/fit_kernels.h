@@ -432,9 +432,10 @@ __global__ void fit_adam_theta_kernel(float *theta, float *m1, float *m2, const 
 }
 
 // Adam on the latent matrix.  mode 0 = Keras sparse path (decay + apply on ALL rows, base.py:301),
-// mode 1 = lazy (batch rows only).  `pos[row]` = position of the row in the batch or -1.
+// mode 1 = lazy (batch rows only).  `pos[row]` = position of the row in the batch of step `epoch` if pos[n + row] == epoch
+// (fit_set_pos_kernel stamps the rows of a batch; older stamps are simply stale, nothing has to be cleared).
 __global__ void fit_adam_z_kernel(float *z, float *zm, float *zv, const float *dz, const int *pos, long long n,
-                                  int q, float lr_t, float b1, float b2, float eps, int lazy, const int *idx, int B) {
+                                  int q, float lr_t, float b1, float b2, float eps, int lazy, const int *idx, int B, int epoch) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (lazy) {
     if (i >= (long long)B * q) return;
@@ -451,7 +452,7 @@ __global__ void fit_adam_z_kernel(float *z, float *zm, float *zv, const float *d
   if (i >= n * q) return;
   const long long row = i / q;
   const int f = (int)(i - row * q);
-  const int pb = pos[row];
+  const int pb = (pos[n + row] == epoch) ? pos[row] : -1;
   float m = b1 * zm[i], v = b2 * zv[i];
   if (pb >= 0) {
     const float g = dz[(long long)pb * q + f];
@@ -462,7 +463,7 @@ __global__ void fit_adam_z_kernel(float *z, float *zm, float *zv, const float *d
   z[i] -= lr_t * m / (sqrtf(v) + eps);
 }
 
-__global__ void fit_set_pos_kernel(int *pos, const int *idx, int B, int set) {
+__global__ void fit_set_pos_kernel(int *pos, long long n, const int *idx, int B, int epoch) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < B) pos[idx[b]] = set ? b : -1;
+  if (b < B) { pos[idx[b]] = b; pos[n + idx[b]] = epoch; }
 }
