@@ -26,6 +26,31 @@ from ..datasets import Gaussian_sampler
 from .bgm import BGM, _DEFAULTS, _glorot
 
 
+def block_plan(lo_r, n_loc, bs, rows_chunk):
+    """Row chunks of the sampling phase and the predictive calls inside them for the local rows [lo_r, lo_r + n_loc) of a
+    panel whose predictive calls are the blocks of `bs` GLOBAL rows: [(s, e, [(b, be, block, off), ...]), ...] with local
+    row ranges [s, e) / [b, be); `off` = position of global row lo_r + b inside its block.  Chunks end on block
+    boundaries, so no call spans two chunks; a block split over two ranks is two calls with the same stream (block id)
+    whose Flipout signs are keyed by the position inside the block."""
+    plan = []
+    s = 0
+    rows_chunk = max(bs, rows_chunk // bs * bs)
+    while s < n_loc:
+        g0 = lo_r + s
+        e = min(n_loc, s + rows_chunk - (g0 % bs))
+        calls = []
+        b = s
+        while b < e:
+            gb = lo_r + b
+            blk, off = gb // bs, gb % bs
+            be = min(e, b + bs - off)
+            calls.append((b, be, blk, off))
+            b = be
+        plan.append((s, e, calls))
+        s = e
+    return plan
+
+
 class BGMBayes(BGM):
     def __init__(self, params, timestamp=None, random_seed=None, device=None):
         self.params = params
@@ -393,22 +418,14 @@ class BGMBayes(BGM):
         los = torch.zeros_like(means)
         his = torch.zeros_like(means)
         samples = []
-        # chunks start on a bs-block boundary of the GLOBAL rows so that a predictive call never spans two chunks
-        s = 0
-        while s < n_loc:
-            g0 = lo_r + s
-            e = min(n_loc, s + rows_chunk - (g0 % bs))
+        for s, e, calls in block_plan(lo_r, n_loc, bs, rows_chunk):
             draws = torch.empty((n_mcmc, e - s, q), device=dev)
             eng.hmc_run(x[s:e], state[s:e], logp[s:e], grad[s:e], step, burn_in, n_mcmc, burn_in, num_leapfrog_steps,
                         seed, init=(burn_in == 0), row_base=lo_r + s, acc_count=acc_count, draws=draws)
-            b = s
-            while b < e:
-                gb = lo_r + b
-                blk, off = gb // bs, gb % bs
-                be = min(e, b + bs - off)
+            for b, be, blk, off in calls:
                 if k_slots > 0 or return_samples:
                     cells, full = eng.decode(draws[:, b - s:be - s].contiguous(), seed, STREAM_PREDICT + blk, burn_in=burn_in,
-                                             row_base=gb, slot=slot_dev[b:be].contiguous() if k_slots > 0 else None, k_slots=k_slots,
+                                             row_base=lo_r + b, slot=slot_dev[b:be].contiguous() if k_slots > 0 else None, k_slots=k_slots,
                                              want_full=return_samples, sign_stride=bs, sign_off=off)
                     if k_slots > 0:
                         mean, lo, hi = eng.row_mean_quantiles(cells.reshape((be - b) * k_slots, n_mcmc), alpha / 2.0, 1.0 - alpha / 2.0)
@@ -417,9 +434,7 @@ class BGMBayes(BGM):
                         his[b:be] = hi.reshape(be - b, k_slots)
                     if return_samples:
                         samples.append(full.cpu().numpy())
-                b = be
             del draws
-            s = e
         acc = acc_count[burn_in:].sum().double().reshape(1)
         parallel.all_reduce_sum_(acc)
         self.last_acceptance_rate = float(acc.item()) / max(1, n_mcmc * n)

@@ -151,3 +151,31 @@ def test_bayesian_dp_host_logic():
     res = _run(_bnn_dp_fn)
     assert all(r[0] for r in res)
     assert all(r[1] < 1e-12 for r in res) and all(r[2] for r in res)
+
+
+def test_bayesian_generator_block_plan_covers_every_row_once_for_any_sharding():
+    """BGM(use_bnn=True).predict: predictive calls are blocks of `bs` GLOBAL rows; ranks own contiguous shards.  Whatever the
+    world size and memory chunk, the union of the ranks' calls covers each row exactly once, every call stays inside one
+    block and one chunk, and (block, offset-in-block) of a row do not depend on the sharding."""
+    from bayesgm_amd.models.bgm_bnn import block_plan
+    from bayesgm_amd.parallel import shard_range
+    for n, bs, chunk in ((257, 100, 100), (1025, 64, 256), (1000, 100, 10 ** 9), (37, 100, 50), (640, 64, 1)):
+        ref = {}
+        for world in (1, 2, 3, 8):
+            seen = {}
+            for r in range(world):
+                lo, hi = shard_range(n, r, world)
+                for s, e, calls in block_plan(lo, hi - lo, bs, chunk):
+                    assert 0 <= s < e <= hi - lo
+                    assert (lo + e) % bs == 0 or e == hi - lo                 # chunks end on block boundaries (or at the shard end)
+                    assert calls[0][0] == s and calls[-1][1] == e
+                    for b, be, blk, off in calls:
+                        assert s <= b < be <= e and off + (be - b) <= bs and (lo + b) // bs == blk == (lo + be - 1) // bs
+                        for i in range(b, be):
+                            g = lo + i
+                            assert g not in seen
+                            seen[g] = (blk, off + (i - b))
+            assert sorted(seen) == list(range(n))
+            if not ref:
+                ref = seen
+            assert seen == ref
