@@ -1,6 +1,7 @@
 // bgmb_api.hip -- C ABI of BGM with the Bayesian generator (use_bnn=True): session, minibatch steps, log posterior, HMC, decode.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -293,7 +294,9 @@ extern "C" int bgm_bvn_hmc_run(bgm_handle *h, const bgm_hmc_args *g, void *strea
   // as many transitions as fit a 64 MB perturbation buffer.
   const int L = g->n_leapfrog;
   const long long per_it = a.dw_stride * (long long)L * (long long)sizeof(float);
-  const int chunk = a.frozen ? g->n_iters : (int)std::max<long long>(1, (64LL << 20) / std::max<long long>(1, per_it));
+  const char *budget_env = std::getenv("BGM_BVN_NOISE_BYTES");        // test hook: force several launches per segment
+  const long long budget = budget_env ? std::max<long long>(1, std::atoll(budget_env)) : (64LL << 20);
+  const int chunk = a.frozen ? g->n_iters : (int)std::max<long long>(1, budget / std::max<long long>(1, per_it));
   int it = g->it_begin, left = g->n_iters;
   bool first = true;
   do {

@@ -140,6 +140,32 @@ def test_hmc_follows_oracle_over_a_few_transitions(frozen):
     eng.close()
 
 
+def test_hmc_segment_split_over_several_launches_is_identical(monkeypatch):
+    """A segment of transitions is cut into launches by the size of the perturbation buffer; the cut must not change a bit."""
+    q, units, p, n = 3, (16, 16), 8, 90
+    net = _net(q, units, p, seed=6)
+    x = np.random.RandomState(7).standard_normal((n, p)).astype(np.float32)
+    x[np.random.RandomState(8).uniform(size=x.shape) < 0.25] = np.nan
+    outs = []
+    for budget in (None, "1"):                      # default: one launch; 1 byte: one transition per launch
+        if budget is None:
+            monkeypatch.delenv("BGM_BVN_NOISE_BYTES", raising=False)
+        else:
+            monkeypatch.setenv("BGM_BVN_NOISE_BYTES", budget)
+        eng = _engine(net, q, units, p)
+        dev = eng.device
+        xd = torch.from_numpy(x).to(dev)
+        state, logp, grad = torch.empty((n, q), device=dev), torch.empty(n, device=dev), torch.empty((n, q), device=dev)
+        step = torch.full((1,), 0.05, device=dev)
+        draws = torch.empty((5, n, q), device=dev)
+        acc = torch.zeros(7, device=dev, dtype=torch.int32)
+        eng.hmc_run(xd, state, logp, grad, step, 0, 7, 2, 4, 42, init=True, row_base=3, acc_count=acc, draws=draws)
+        outs.append((draws.cpu().numpy(), state.cpu().numpy(), logp.cpu().numpy(), acc.cpu().numpy()))
+        eng.close()
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_hmc_all_missing_rows_sample_the_prior():
     q, units, p, n = 2, (8,), 5, 4096
     net = _net(q, units, p, seed=8)
