@@ -250,10 +250,11 @@ extern "C" int bgm_bvn_logpost(bgm_handle *h, const float *z_dev, const float *x
   BgmbState *s = vst(h);
   BGM_HIP_CHECK(hipSetDevice(h->device));
   const int rt = bvn_rt(h, n);
-  const long long tiles = (n + rt - 1) / rt;
+  const long long n_tiles = (n + rt - 1) / rt;
+  const long long tiles = std::min<long long>(n_tiles, 8LL * h->n_cus);       // workgroups (one workspace slice each)
   BgmbBigArgs a;
   bvn_big_base(s, a, seed);
-  a.rt = rt;
+  a.rt = rt; a.n_tiles = n_tiles;
   rc = bvn_big_ws(h, s, tiles, a.ws, a.ws_stride);
   if (rc) return rc;
   a.x = x_dev; a.n = n; a.row_base = row_base;
@@ -277,10 +278,11 @@ extern "C" int bgm_bvn_hmc_run(bgm_handle *h, const bgm_hmc_args *g, void *strea
   BgmbState *s = vst(h);
   BGM_HIP_CHECK(hipSetDevice(h->device));
   const int rt = bvn_rt(h, g->n);
-  const long long tiles = (g->n + rt - 1) / rt;
+  const long long n_tiles = (g->n + rt - 1) / rt;
+  const long long tiles = std::min<long long>(n_tiles, 8LL * h->n_cus);       // workgroups (one workspace slice each)
   BgmbBigArgs a;
   bvn_big_base(s, a, g->seed);
-  a.rt = rt;
+  a.rt = rt; a.n_tiles = n_tiles;
   rc = bvn_big_ws(h, s, tiles, a.ws, a.ws_stride);
   if (rc) return rc;
   a.x = g->x_dev; a.n = g->n; a.row_base = g->row_base;
@@ -330,7 +332,7 @@ extern "C" int bgm_bvn_decode(bgm_handle *h, const float *draws_dev, int64_t n, 
   }
   BgmbState *s = vst(h);
   BGM_HIP_CHECK(hipSetDevice(h->device));
-  const long long tiles = std::min<long long>(((n + BGMB_RT - 1) / BGMB_RT) * (long long)n_draws, 2048);
+  const long long tiles = std::min<long long>(((n + BGMB_RT - 1) / BGMB_RT) * (long long)n_draws, 4LL * h->n_cus);
   BgmbDecodeArgs a;
   std::memset(&a, 0, sizeof(a));
   a.net = s->net; a.net.bn_fixed = 2;

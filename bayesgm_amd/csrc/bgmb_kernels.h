@@ -169,6 +169,7 @@ struct BgmbBigArgs {
   long long n, row_base;
   float *state, *logp, *grad;  // HMC: [n x q], [n], [n x q] in/out;  logpost: z in (state), outputs logp / grad (grad may be NULL)
   int rt;                      // rows per workgroup tile (<= BGMB_RT; smaller when few rows would leave CUs idle)
+  long long n_tiles;           // ceil(n / rt); a workgroup walks tiles blockIdx.x, + gridDim.x, ... with ONE workspace slice
   int init, it_begin, n_iters, burn_in, n_leapfrog;
   int frozen;                  // 1: every gradient evaluation of the HMC run reuses generator call 0 (deterministic target)
   const float *step;
@@ -253,16 +254,20 @@ static __global__ __launch_bounds__(BNN_THREADS) void bgmb_logpost_kernel(BgmbBi
   __shared__ float red[32];
   __shared__ float lpv[BGMB_RT];
   BnnCtx c{(int)threadIdx.x, red};
-  const long long r0 = (long long)blockIdx.x * a.rt;
-  const int B = (int)min((long long)a.rt, a.n - r0), q = a.q, p = a.p;
+  const int q = a.q, p = a.p;
   BgmbTile t;
   bgmb_tile_take(a.ws + (long long)blockIdx.x * a.ws_stride, t, q, p, a.wmax);
-  for (int i = c.tid; i < B * q; i += BNN_THREADS) t.z[i] = a.state[r0 * q + i];
-  for (int i = c.tid; i < B * p; i += BNN_THREADS) t.xb[i] = a.x[r0 * p + i];
-  __syncthreads();
-  bgmb_lpg(c, a, t, t.z, B, a.stream, 0, (uint32_t)(a.row_base + r0), lpv, a.grad ? t.gr : nullptr);
-  for (int b = c.tid; b < B; b += BNN_THREADS) a.logp[r0 + b] = lpv[b];
-  if (a.grad) for (int i = c.tid; i < B * q; i += BNN_THREADS) a.grad[r0 * q + i] = t.gr[i];
+  for (long long tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const long long r0 = tile * a.rt;
+    const int B = (int)min((long long)a.rt, a.n - r0);
+    for (int i = c.tid; i < B * q; i += BNN_THREADS) t.z[i] = a.state[r0 * q + i];
+    for (int i = c.tid; i < B * p; i += BNN_THREADS) t.xb[i] = a.x[r0 * p + i];
+    __syncthreads();
+    bgmb_lpg(c, a, t, t.z, B, a.stream, 0, (uint32_t)(a.row_base + r0), lpv, a.grad ? t.gr : nullptr);
+    for (int b = c.tid; b < B; b += BNN_THREADS) a.logp[r0 + b] = lpv[b];
+    if (a.grad) for (int i = c.tid; i < B * q; i += BNN_THREADS) a.grad[r0 * q + i] = t.gr[i];
+    __syncthreads();
+  }
 }
 
 // HMC transitions [it_begin, it_begin + n_iters) of the rows of a tile (oracle/bgm_bnn.py hmc_sampler)
@@ -271,11 +276,13 @@ static __global__ __launch_bounds__(BNN_THREADS) void bgmb_hmc_kernel(BgmbBigArg
   __shared__ float lpv[BGMB_RT], lpc[BGMB_RT], ke0[BGMB_RT];
   __shared__ int accv[BGMB_RT];
   BnnCtx c{(int)threadIdx.x, red};
-  const long long r0 = (long long)blockIdx.x * a.rt;
-  const int B = (int)min((long long)a.rt, a.n - r0), q = a.q, p = a.p, L = a.n_leapfrog;
-  const uint32_t row0 = (uint32_t)(a.row_base + r0);
+  const int q = a.q, p = a.p, L = a.n_leapfrog;
   BgmbTile t;
   bgmb_tile_take(a.ws + (long long)blockIdx.x * a.ws_stride, t, q, p, a.wmax);
+  for (long long tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+  const long long r0 = tile * a.rt;
+  const int B = (int)min((long long)a.rt, a.n - r0);
+  const uint32_t row0 = (uint32_t)(a.row_base + r0);
   for (int i = c.tid; i < B * p; i += BNN_THREADS) t.xb[i] = a.x[r0 * p + i];
   if (a.init) {
     for (int i = c.tid; i < B * q; i += BNN_THREADS) t.z[i] = bgmb_normal(row0 + (uint32_t)(i / q), 0u, i % q, TAG_INIT, a.k0, a.k1);
@@ -340,6 +347,8 @@ static __global__ __launch_bounds__(BNN_THREADS) void bgmb_hmc_kernel(BgmbBigArg
   __syncthreads();
   for (int i = c.tid; i < B * q; i += BNN_THREADS) { a.state[r0 * q + i] = t.z[i]; a.grad[r0 * q + i] = t.gr[i]; }
   for (int b = c.tid; b < B; b += BNN_THREADS) a.logp[r0 + b] = lpv[b];
+  __syncthreads();
+  }   // tiles of this workgroup
 }
 
 // g_net(z, training=False) over the flattened rows [n_draws x n] (ONE call: one perturbation; the signs of draw d, row r are

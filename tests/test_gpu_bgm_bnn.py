@@ -469,3 +469,32 @@ def test_session_errors_are_reported(tmp_path):
     with pytest.raises(RuntimeError, match="bad argument"):
         eng.theta_step(x, z, torch.zeros(33, dtype=torch.int32, device=eng.device), 1e-3, 1, 0)       # above max_batch
     eng.close()
+
+
+def test_logpost_and_hmc_when_workgroups_walk_several_tiles():
+    """More row tiles than launched workgroups (8 per CU): a workgroup then walks tiles with one workspace slice."""
+    q, units, p, n = 3, (16,), 8, 140000
+    net = _net(q, units, p, seed=14)
+    rs = np.random.RandomState(15)
+    z = rs.standard_normal((n, q)).astype(np.float32)
+    x = rs.standard_normal((n, p)).astype(np.float32)
+    x[rs.uniform(size=x.shape) < 0.2] = np.nan
+    eng = _engine(net, q, units, p)
+    lp, gr = eng.logpost(z, x, 77, 5, row_base=11, want_grad=True)
+    n64 = OV.cast_vnet(net, np.float64)
+    mask = (~np.isnan(x)).astype(np.float64)
+    xc = np.where(np.isnan(x), 0.0, x).astype(np.float64)
+    ref_lp, ref_gr = OV.log_posterior_and_grad(n64, z.astype(np.float64), xc, mask, OV.draw(n64, n, 77, 5, 11, np.float64))
+    assert _rel(lp.cpu().numpy(), ref_lp) < 1e-5 and _rel(gr.cpu().numpy(), ref_gr) < 1e-4
+    # two transitions for all rows in one launch == the same rows run as two halves (chains are independent)
+    dev = eng.device
+    xd = torch.from_numpy(x).to(dev)
+    step = torch.full((1,), 0.05, device=dev)
+    def run(lo, hi):
+        st, lg, gd = torch.empty((hi - lo, q), device=dev), torch.empty(hi - lo, device=dev), torch.empty((hi - lo, q), device=dev)
+        eng.hmc_run(xd[lo:hi], st, lg, gd, step, 0, 2, 0, 3, 9, init=True, row_base=lo)
+        return st.cpu().numpy()
+    whole = run(0, n)
+    np.testing.assert_array_equal(whole[:1000], run(0, 1000))
+    np.testing.assert_array_equal(whole[n - 3000:], run(n - 3000, n))
+    eng.close()
