@@ -1,157 +1,148 @@
-"""Host-side input generators of the hot path (NumPy).
+"""Host-side synthetic inputs of the hot path.
 
-Mirror of the reference's ``bayesgm.datasets`` for the pieces every config of
-BASELINE.json needs:
-
-* ``Base_sampler``              -- datasets/base_sampler.py:6-84
-* ``Sim_Hirano_Imbens_sampler`` -- datasets/causal_samplers.py:40-67
-* ``Gaussian_sampler``          -- datasets/prior_samplers.py:4-59
-* ``simulate_z_hetero``         -- datasets/simulators.py:163-204 (BGM tutorial panel)
-
-Same names, argument meaning, dtype (float32) and -- deliberately -- the same
-use of NumPy's *legacy global* RNG (``np.random.seed``), so a panel generated
-here is value-identical to the reference's; pinned by tests/golden/*.npz.
+Public names follow the reference's ``bayesgm.datasets`` (datasets/base_sampler.py:29-84,
+causal_samplers.py:40-67, prior_samplers.py:4-59, simulators.py:163-204) because callers import
+them by name; the code is the build's own.  What has to be shared with the reference is the ORDER
+in which NumPy's legacy Mersenne-Twister stream is consumed -- a panel is only value-identical to the
+reference's if the same variates are drawn in the same sequence -- so every generator below documents
+its draw order, draws from a ``RandomState`` seeded like the reference's ``np.random.seed(seed)`` and
+then hands that state to NumPy's global generator (``_publish``), which is where the reference leaves
+it for whatever code runs next.  Values are pinned bit-exactly by tests/golden/*.npz.
 """
-import math
 import numpy as np
 
 
-def _standardize(v):
-    """sklearn StandardScaler().fit_transform semantics (population std, zero-variance
-    columns left unscaled), used by Base_sampler(normalize=True)."""
-    from sklearn.preprocessing import StandardScaler
-    return StandardScaler().fit_transform(v)
+def _publish(rs):
+    """Leave NumPy's global legacy generator in the state of `rs` (the reference draws from the global
+    generator directly; later host code -- minibatch draws, MH initial states -- continues that stream)."""
+    np.random.set_state(rs.get_state())
+
+
+def _column_standardize(a):
+    """Per column (a - mean) / std, the arithmetic of scikit-learn's StandardScaler.fit_transform -- which the reference
+    applies to V -- restated so that a float32 panel comes out bit-identical: float64 column sums; variance as the
+    corrected two-pass form (sum d^2 - (sum d)^2 / n) / n of the deviations d from the mean; columns whose variance is
+    within rounding of zero are centred only; for a float32 input the centring and the scaling each round to float32."""
+    a = np.asarray(a)
+    n = a.shape[0]
+    mu = a.sum(axis=0, dtype=np.float64) / n
+    dev = a - mu                                               # float64
+    var = ((dev ** 2).sum(axis=0) - dev.sum(axis=0) ** 2 / n) / n
+    eps = np.finfo(np.float64).eps
+    sd = np.sqrt(var)
+    sd[(var <= n * eps * var + (n * mu * eps) ** 2) | (sd == 0.0)] = 1.0
+    if a.dtype.kind != "f":
+        return dev / sd
+    centred = dev.astype(a.dtype)                              # first rounding (in-place `X -= mean` on the float array)
+    return (centred / sd).astype(a.dtype)                      # second rounding (`X /= scale`)
+
+
+class _EpochCursor:
+    """Cyclic minibatch positions over a shuffled index: full batches in order; a batch that would run past the end
+    is completed with the head of the CURRENT order, after which the order is reshuffled (with NumPy's global generator
+    in whatever state the interleaved host draws have left it -- the reference's stream) and the walk restarts at 0."""
+
+    def __init__(self, order, batch_size):
+        self.order, self.b, self.pos = order, int(batch_size), 0
+
+    def take(self):
+        n, b = len(self.order), self.b
+        if self.pos >= n:
+            self.pos = 0
+        lo, hi = self.pos, self.pos + b
+        self.pos = hi
+        if hi <= n:
+            return self.order[lo:hi]
+        picked = np.concatenate([self.order[lo:], self.order[:hi - n]])
+        np.random.shuffle(self.order)
+        self.pos = 0
+        return picked
 
 
 class Base_sampler(object):
-    """Cyclic mini-batch sampler over (x, y, v).  datasets/base_sampler.py:29-84.
+    """Minibatch view of a panel (x [n,1], y [n,1], v [n,p]), float32.
 
-    Side effect kept from the reference: the constructor re-seeds NumPy's global
-    RNG with ``random_seed`` (:31) before shuffling the index."""
+    Draw order (stream seeded with ``random_seed``, default 123, whatever was seeded before): one shuffle of the row
+    index at construction, one more after every wrapped batch.  ``normalize`` standardises V per column."""
 
     def __init__(self, x, y, v, batch_size=32, normalize=False, random_seed=123):
-        assert len(x) == len(y) == len(v)
-        np.random.seed(random_seed)
-        self.data_x = np.array(x, dtype='float32')
-        self.data_y = np.array(y, dtype='float32')
-        self.data_v = np.array(v, dtype='float32')
-        if len(self.data_x.shape) == 1:
-            self.data_x = self.data_x.reshape(-1, 1)
-        if len(self.data_y.shape) == 1:
-            self.data_y = self.data_y.reshape(-1, 1)
-        self.batch_size = batch_size
+        if not (len(x) == len(y) == len(v)):
+            raise AssertionError("x, y, v must have the same number of rows")
+        rs = np.random.RandomState(random_seed)
+        self.data_x = np.asarray(x, dtype=np.float32).reshape(len(x), -1)
+        self.data_y = np.asarray(y, dtype=np.float32).reshape(len(y), -1)
+        self.data_v = np.array(v, dtype=np.float32)
         if normalize:
-            self.data_v = _standardize(self.data_v)
-        self.sample_size = len(x)
+            self.data_v = _column_standardize(self.data_v)
+        self.batch_size = batch_size
+        self.sample_size = len(self.data_x)
         self.full_index = np.arange(self.sample_size)
-        np.random.shuffle(self.full_index)
-        self.idx_gen = self.create_idx_generator(sample_size=self.sample_size)
-
-    def create_idx_generator(self, sample_size, random_seed=123):
-        while True:
-            for step in range(math.ceil(sample_size / self.batch_size)):
-                if (step + 1) * self.batch_size <= sample_size:
-                    yield self.full_index[step * self.batch_size:(step + 1) * self.batch_size]
-                else:
-                    yield np.hstack([self.full_index[step * self.batch_size:],
-                                     self.full_index[:((step + 1) * self.batch_size - sample_size)]])
-                    np.random.shuffle(self.full_index)
+        rs.shuffle(self.full_index)
+        _publish(rs)
+        self._cursor = _EpochCursor(self.full_index, batch_size)
 
     def next_batch(self):
-        indx = next(self.idx_gen)
-        return self.data_x[indx, :], self.data_y[indx, :], self.data_v[indx, :]
+        rows = self._cursor.take()
+        return self.data_x[rows], self.data_y[rows], self.data_v[rows]
 
     def load_all(self):
         return self.data_x, self.data_y, self.data_v
 
 
 class Sim_Hirano_Imbens_sampler(Base_sampler):
-    """Hirano-Imbens continuous-treatment simulation.  datasets/causal_samplers.py:58-67:
-    v ~ Exp(1) [N x v_dim]; x ~ Exp(scale = 1/(v0+v1)); y ~ N(x + (v0+v2) exp(-x (v0+v2)), 1);
-    V standardised per column; true ADRF(x) = x + 2/(1+x)^3."""
+    """Hirano-Imbens dose-response simulation (the panel of BASELINE.json's headline config).
+
+    Draw order on the stream seeded with ``seed``: V ~ Exp(1) [N x v_dim] row-major; x_i ~ Exp(mean 1 / (v_i0 + v_i1));
+    y_i ~ N(x_i + s_i exp(-x_i s_i), 1) with s_i = v_i0 + v_i2.  V is then standardised per column (x, y are not).
+    True dose-response: utils.get_ADRF(dataset='Imbens') = x + 2 / (1 + x)^3."""
 
     def __init__(self, batch_size=32, N=20000, v_dim=200, seed=0):
-        np.random.seed(seed)
-        v = np.random.exponential(scale=1.0, size=(N, v_dim))
-        rate = v[:, 0] + v[:, 1]
-        scale = 1 / rate
-        x = np.random.exponential(scale=scale)
-        y = np.random.normal(x + (v[:, 0] + v[:, 2]) * np.exp(-x * (v[:, 0] + v[:, 2])), 1)
-        x = x.reshape(-1, 1)
-        y = y.reshape(-1, 1)
-        super().__init__(x, y, v, batch_size=batch_size, normalize=True)
-
-
-class Sim_Sun_sampler(Base_sampler):
-    """Sun et al. continuous-treatment simulation.  datasets/causal_samplers.py:88-94: v ~ N(0, I) [N x v_dim];
-    x ~ N(-2 sin(2 v0) + (v1^2 - 1/3) + (v2 - 1/2) + cos(v3), 1); y ~ N((v0 - 1/2) + cos(v1) + v4^2 + v5 + x, 1);
-    V standardised per column (true ADRF: utils.get_ADRF(dataset='Sun'))."""
-
-    def __init__(self, batch_size=32, N=20000, v_dim=200, seed=0):
-        np.random.seed(seed)
-        v = np.random.normal(0, 1, size=(N, v_dim))
-        mean_x = -2 * np.sin(2 * v[:, 0]) + (v[:, 1] ** 2 - 1 / 3) + (v[:, 2] - 1 / 2) + np.cos(v[:, 3])
-        x = np.random.normal(mean_x, 1)
-        y = np.random.normal((v[:, 0] - 1 / 2) + np.cos(v[:, 1]) + v[:, 4] ** 2 + v[:, 5] + x, 1)
-        super().__init__(x.reshape(-1, 1), y.reshape(-1, 1), v, batch_size=batch_size, normalize=True)
-
-
-class Sim_Colangelo_sampler(Base_sampler):
-    """Colangelo & Lee continuous-treatment simulation.  datasets/causal_samplers.py:113-127: v ~ N(0, Sigma) with the
-    tridiagonal Sigma (1 on the diagonal, rho beside it); theta_l = 1 / l^2; x = d * Phi(a v.theta) + b nu - 1/2;
-    y = 1.2 x + x^3 + x v0 + 1.2 v.theta + eps; eps, nu ~ N(0, 1) drawn BEFORE v; V standardised per column
-    (true ADRF: utils.get_ADRF(dataset='Lee'))."""
-
-    def __init__(self, batch_size=32, N=20000, v_dim=100, seed=0, rho=0.5, offset=(-1, 0, 1), d=1, a=3, b=0.75):
-        from scipy.stats import norm
-        np.random.seed(seed)
-        sigma = np.zeros((v_dim, v_dim))
-        for off, val in zip(offset, (rho, 1.0, rho)):
-            sigma += np.diag(np.full(v_dim - abs(off), val), off)
-        theta = 1.0 / np.arange(1, v_dim + 1) ** 2
-        epsilon = np.random.normal(0, 1, N)
-        nu = np.random.normal(0, 1, N)
-        v = np.random.multivariate_normal(np.zeros(v_dim), sigma, size=[N, ])
-        x = d * norm.cdf(a * v @ theta) + b * nu - 0.5
-        y = 1.2 * x + x ** 3 + x * v[:, 0] + 1.2 * (v @ theta) + epsilon
-        super().__init__(x.reshape(-1, 1), y.reshape(-1, 1), v, batch_size=batch_size, normalize=True)
+        rs = np.random.RandomState(seed)
+        v = rs.exponential(scale=1.0, size=(N, v_dim))
+        x = rs.exponential(scale=1.0 / (v[:, 0] + v[:, 1]))
+        s = v[:, 0] + v[:, 2]
+        y = rs.normal(x + s * np.exp(-x * s), 1)
+        Base_sampler.__init__(self, x[:, None], y[:, None], v, batch_size=batch_size, normalize=True)
 
 
 class Gaussian_sampler(object):
-    """N(mean, sd^2 I) sampler.  datasets/prior_samplers.py:4-59 (re-seeds the global
-    RNG with 1024 at construction, as the reference does)."""
+    """Isotropic Gaussian prior sampler N(mean, sd^2 I), float32.
+
+    Construction seeds the stream with 1024 and draws the ``N`` stored rows ``X``; ``get_batch`` / ``train`` draw from
+    NumPy's GLOBAL generator at call time (so they follow whatever the caller seeded, as in the reference, where the
+    EGM loop interleaves them with its minibatch index draws)."""
 
     def __init__(self, mean, sd=1, N=20000):
-        self.total_size = N
-        self.mean = mean
+        self.mean = np.asarray(mean, dtype=np.float64)
         self.sd = sd
-        np.random.seed(1024)
-        self.X = np.random.normal(self.mean, self.sd, (self.total_size, len(self.mean)))
-        self.X = self.X.astype('float32')
-
-    def train(self, batch_size, label=False):
-        indx = np.random.randint(low=0, high=self.total_size, size=batch_size)
-        return self.X[indx, :]
+        self.total_size = N
+        rs = np.random.RandomState(1024)
+        self.X = rs.normal(self.mean, self.sd, (N, self.mean.shape[0])).astype(np.float32)
+        _publish(rs)
 
     def get_batch(self, batch_size):
-        return np.random.normal(self.mean, self.sd, (batch_size, len(self.mean))).astype('float32')
+        return np.random.normal(self.mean, self.sd, (batch_size, self.mean.shape[0])).astype(np.float32)
+
+    def train(self, batch_size, label=False):
+        return self.X[np.random.randint(low=0, high=self.total_size, size=batch_size)]
 
     def load_all(self):
         return self.X
 
 
 def simulate_z_hetero(n=20000, k=3, d=20 - 1, seed=42):
-    """Latent-factor heteroskedastic panel of the BGM tutorial.  datasets/simulators.py:163-204."""
-    np.random.seed(seed)
-    Z = np.random.randn(n, k)
-    A = np.random.randn(d, k)
-    X = 0.2 * Z @ A.T + 0.1 * np.random.randn(n, d)
-    w = np.random.randn(k)
-    u = np.random.randn(k)
-    mean_Y = np.sin(Z @ w)
-    std_Y = 0.1 + 0.5 * 1 / (1 + np.exp(-(Z @ u)))
-    Y = mean_Y + std_Y * np.random.randn(n)
-    return X, Y
+    """Heteroskedastic latent-factor panel of the BGM tutorial: X = 0.2 Z A' + 0.1 E [n x d], Y = sin(Z w) + s(Z) e with
+    s = 0.1 + 0.5 sigmoid(Z u).  Draw order on the stream seeded with ``seed`` (all standard normal):
+    Z [n x k], A [d x k], E [n x d], w [k], u [k], e [n].  Returns float64 (X, Y)."""
+    rs = np.random.RandomState(seed)
+    z = rs.standard_normal((n, k))
+    load = rs.standard_normal((d, k))
+    x = 0.2 * z @ load.T + 0.1 * rs.standard_normal((n, d))
+    w, u = rs.standard_normal(k), rs.standard_normal(k)
+    spread = 0.1 + 0.5 * 1 / (1 + np.exp(-(z @ u)))
+    y = np.sin(z @ w) + spread * rs.standard_normal(n)
+    _publish(rs)
+    return x, y
 
 
 def binarize_treatment(x):

@@ -40,6 +40,7 @@ class BGM(object):
         p = dict(_DEFAULTS)
         p.update(params)
         self._p = p
+        random_seed = parallel.shared_seed(random_seed)   # None stays None in a single process; one seed for all ranks otherwise
         if random_seed is not None:
             np.random.seed(random_seed)
         self._rs = np.random.RandomState(random_seed)
@@ -71,6 +72,15 @@ class BGM(object):
 
     def get_config(self):
         return {"params": self.params}
+
+    def _egm_noise_generator(self):
+        """Device generator of the EGM reparameterisation noise, keyed by the (rank-shared) seed: the warm start is
+        replicated under torch.distributed, so every rank must draw the same noise, and ``BGM(params, random_seed=k)`` must
+        be reproducible (the reference seeds tf.random through tf.keras.utils.set_random_seed, bgm/base.py:63-66)."""
+        if getattr(self, "_egm_gen", None) is None:
+            self._egm_gen = torch.Generator(device=self.engine.device)
+            self._egm_gen.manual_seed(int(self._rs.randint(0, 2 ** 31 - 1)))
+        return self._egm_gen
 
     def set_weights(self, g):
         """Install generator parameters (dict with 'bn', 'trunk', 'mean', 'var' as in oracle/nets.init_varnet)."""
@@ -134,7 +144,7 @@ class BGM(object):
                     if j < g_d_freq:
                         eps_h[i, j] = np.random.uniform(0.0, 1.0, size=2)
             x_d, z_d = torch.from_numpy(x_h).to(dev), torch.from_numpy(z_h).to(dev)
-            noise = torch.randn((n_it, steps + 1, batch_size, xd_), device=dev)
+            noise = torch.randn((n_it, steps + 1, batch_size, xd_), device=dev, generator=self._egm_noise_generator())
             for i in range(n_it):
                 for j in range(g_d_freq):
                     eng.egm_disc_step(z_d[i, j], x_d[i, j], noise[i, j], eps_h[i, j, 0], eps_h[i, j, 1], out=out_d)
@@ -164,15 +174,16 @@ class BGM(object):
                 eng.egm_sync()
                 self.g = eng.get_weights()
                 if self._p['save_res']:
-                    gen1, var1 = self.generate(nb_samples=5000)
+                    gen1, var1 = self.generate(nb_samples=5000)          # all ranks: keeps the host RNG in lock step
                     gen12, var12 = self.generate(nb_samples=5000, use_x_sd=False)
-                    np.savez('%s/init_data_gen_at_%d.npz' % (self.save_dir, batch_iter), gen1=gen1, gen12=gen12,
-                             z=z_.cpu().numpy(), x_rec=x_rec, var1=var1, var12=var12)
+                    if parallel.rank() == 0:
+                        np.savez('%s/init_data_gen_at_%d.npz' % (self.save_dir, batch_iter), gen1=gen1, gen12=gen12,
+                                 z=z_.cpu().numpy(), x_rec=x_rec, var1=var1, var12=var12)
                 mse_x = self.evaluate(data=data, use_x_sd=True)
                 print('iter [%d/%d]: MSE_x: %.4f\n' % (batch_iter, egm_n_iter, mse_x))
                 mse_x = self.evaluate(data=data, use_x_sd=False)
                 print('iter [%d/%d]: MSE_x no x_sd: %.4f\n' % (batch_iter, egm_n_iter, mse_x))
-                if self._p['save_model']:
+                if self._p['save_model'] and parallel.rank() == 0:
                     self.save_checkpoint('egm_init_%d' % batch_iter)
             batch_iter += 1
         eng.egm_sync()
@@ -281,6 +292,18 @@ class BGM(object):
         np.savez(path, **flat)
         print('Saving checkpoint for epoch {} at {}'.format(epoch, path))
         return path
+
+    def load_checkpoint(self, path):
+        """Install the generator parameters written by `save_checkpoint` (the reference restores with
+        g_net.load_weights / tf.train.Checkpoint.restore)."""
+        d = np.load(path)
+        n_trunk = len(self.g["trunk"])
+        g = {"bn": {k: np.asarray(d["bn_" + k], np.float32) for k in ("gamma", "beta", "mean", "var")},
+             "trunk": [(np.asarray(d["trunk_W%d" % i], np.float32), np.asarray(d["trunk_b%d" % i], np.float32))
+                       for i in range(n_trunk)],
+             "mean": (np.asarray(d["mean_W"], np.float32), np.asarray(d["mean_b"], np.float32)),
+             "var": (np.asarray(d["var_W"], np.float32), np.asarray(d["var_b"], np.float32))}
+        self.set_weights(g)
 
     # ------------------------------------------------------------------ inference helpers
     def get_log_posterior(self, data_z, data_x, ind_x1=None, obs_mask=None):

@@ -58,6 +58,7 @@ class BGMBayes(BGM):
         p = dict(_DEFAULTS)
         p.update(params)
         self._p = p
+        random_seed = parallel.shared_seed(random_seed)   # None stays None in a single process; one seed for all ranks otherwise
         if random_seed is not None:
             np.random.seed(random_seed)
         self._rs = np.random.RandomState(random_seed)
@@ -162,7 +163,7 @@ class BGMBayes(BGM):
                     if j < g_d_freq:
                         eps_h[i, j] = np.random.uniform(0.0, 1.0, size=2)
             x_d, z_d = torch.from_numpy(x_h).to(dev), torch.from_numpy(z_h).to(dev)
-            noise = torch.randn((n_it, steps + 1, batch_size, xd_), device=dev)
+            noise = torch.randn((n_it, steps + 1, batch_size, xd_), device=dev, generator=self._egm_noise_generator())
             for i in range(n_it):
                 for j in range(g_d_freq):
                     eng.egm_disc_step(z_d[i, j], x_d[i, j], noise[i, j], eps_h[i, j, 0], eps_h[i, j, 1], key, 2 * s, out=out_d)
@@ -194,15 +195,16 @@ class BGMBayes(BGM):
                 eng.egm_sync()
                 self._sync_g()
                 if self._p['save_res']:
-                    gen1, var1 = self.generate(nb_samples=5000)
+                    gen1, var1 = self.generate(nb_samples=5000)          # all ranks: keeps the host RNG in lock step
                     gen12, var12 = self.generate(nb_samples=5000, use_x_sd=False)
-                    np.savez('%s/init_data_gen_at_%d.npz' % (self.save_dir, batch_iter), gen1=gen1, gen12=gen12,
-                             z=z_.cpu().numpy(), x_rec=x_rec, var1=var1, var12=var12)
+                    if parallel.rank() == 0:
+                        np.savez('%s/init_data_gen_at_%d.npz' % (self.save_dir, batch_iter), gen1=gen1, gen12=gen12,
+                                 z=z_.cpu().numpy(), x_rec=x_rec, var1=var1, var12=var12)
                 mse_x = self.evaluate(data=data, use_x_sd=True)
                 print('iter [%d/%d]: MSE_x: %.4f\n' % (batch_iter, egm_n_iter, mse_x))
                 mse_x = self.evaluate(data=data, use_x_sd=False)
                 print('iter [%d/%d]: MSE_x no x_sd: %.4f\n' % (batch_iter, egm_n_iter, mse_x))
-                if self._p['save_model']:
+                if self._p['save_model'] and parallel.rank() == 0:
                     self.save_checkpoint('egm_init_%d' % batch_iter)
             batch_iter += 1
         self._egm_steps = s

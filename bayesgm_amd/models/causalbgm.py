@@ -48,6 +48,7 @@ class CausalBGM(object):
         p = dict(_DEFAULTS)
         p.update(params)
         self._p = p
+        random_seed = parallel.shared_seed(random_seed)   # None stays None in a single process; one seed for all ranks otherwise
         self._rs = np.random.RandomState(random_seed) if random_seed is not None else np.random.RandomState()
         if random_seed is not None:
             np.random.seed(random_seed)

@@ -55,6 +55,7 @@ class CausalBGMBayes(CausalBGM):
             warnings.warn("bayesgm_amd: use_bnn=True with the reference's input BatchNormalization on batch statistics: a counterfactual "
                           "treatment column that is constant over the batch is normalised away, so ADRF / ITE estimates do not depend on "
                           "the treatment value (DESIGN.md section 7); params['bnn_norm'] = 'fixed' selects the other reading.", stacklevel=3)
+        random_seed = parallel.shared_seed(random_seed)   # None stays None in a single process; one seed for all ranks otherwise
         self._rs = np.random.RandomState(random_seed) if random_seed is not None else np.random.RandomState()
         if random_seed is not None:
             np.random.seed(random_seed)

@@ -72,3 +72,18 @@ def all_gather_rows_var(t):
     outs = [torch.empty_like(pad) for _ in range(w)]
     dist.all_gather(outs, pad)
     return torch.cat([o[:s] for o, s in zip(outs, sizes)], dim=0)
+
+
+def shared_seed(random_seed):
+    """Seed every rank derives its host RNG streams and initial weights from.
+
+    A user seed is used as is.  With ``random_seed=None`` (the reference's default) a single process keeps NumPy's
+    entropy seeding (returns None); under torch.distributed rank 0 draws a seed and broadcasts it, because the
+    replicated phases (weight initialisation, EGM warm start, evaluation noise) must be identical on every rank
+    before the gradient all-reduce of `fit` can keep the replicas identical."""
+    if random_seed is not None or not is_dist():
+        return random_seed
+    import numpy as np
+    box = [int(np.random.SeedSequence().generate_state(1)[0] & 0x7FFFFFFF) if rank() == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return int(box[0])

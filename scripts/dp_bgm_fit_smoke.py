@@ -18,8 +18,11 @@ data = np.c_[X, Y].astype(np.float32)
 bp = dict(dataset="dp", output_dir="gpurun_out/dp", save_res=False, save_model=False, use_bnn=False, z_dim=10, x_dim=20,
           lr_theta=2e-3, lr_z=2e-3, g_units=[64] * 5, e_units=[64] * 5, dz_units=[64, 32, 8], dx_units=[64, 32, 8],
           kl_weight=5e-5, lr=1e-3, g_d_freq=1, use_z_rec=True, alpha=0.0, gamma=0.0)
-m = BGM(bp, random_seed=3, device=dev)
-m.fit(data, epochs=6, epochs_per_eval=3, use_egm_init=False, verbose=0)
+mode = sys.argv[2] if len(sys.argv) > 2 else "plain"
+# "egm": replicated EGM warm start (device-drawn reparameterisation noise) before the data-parallel fit;
+# "egm_noseed": the same with random_seed=None (rank 0's seed is broadcast, bayesgm_amd.parallel.shared_seed)
+m = BGM(bp, random_seed=None if mode == "egm_noseed" else 3, device=dev)
+m.fit(data, epochs=6, epochs_per_eval=3, use_egm_init=mode.startswith("egm"), egm_n_iter=30, egm_batches_per_eval=15, verbose=0)
 miss = data[:257].copy()
 miss[::3, -1] = np.nan
 miss[1::5, 2] = np.nan                                  # ragged missing pattern, rows sharded over the ranks

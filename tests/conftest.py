@@ -38,7 +38,7 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
-def run_two_ranks(script, timeout=240, attempts=2):
+def run_two_ranks(script, timeout=240, attempts=2, extra_args=()):
     """Launch scripts/<script> with two ranks on GPU 0 over gloo (torch.distributed.run on 127.0.0.1, a free port) in its own
     process group; a run that does not finish in `timeout` seconds is killed WITH its ranks and retried once.  Returns the
     CompletedProcess."""
@@ -53,7 +53,7 @@ def run_two_ranks(script, timeout=240, attempts=2):
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
         proc = subprocess.Popen([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                                 "127.0.0.1", "--master-port", str(port), os.path.join(root, "scripts", script), "gloo"],
+                                 "127.0.0.1", "--master-port", str(port), os.path.join(root, "scripts", script), "gloo"] + list(extra_args),
                                 cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
         try:
             out, err = proc.communicate(timeout=timeout)

@@ -383,3 +383,15 @@ def test_bgm_fit_global_batch_scaling_and_two_rank_run(tmp_path):
     r = run_two_ranks("dp_bgm_fit_smoke.py")
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count('"param_spread": 0.0') == 2, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["egm", "egm_noseed"])
+def test_two_rank_fit_with_replicated_egm_keeps_replicas_identical(mode):
+    """The EGM warm start is replicated under torch.distributed: its reparameterisation noise comes from a device generator
+    keyed by the rank-shared seed (also with random_seed=None, where rank 0's seed is broadcast), so both ranks enter the
+    data-parallel fit with the same generator / encoder and end with bit-identical parameters."""
+    from conftest import run_two_ranks
+    r = run_two_ranks("dp_bgm_fit_smoke.py", extra_args=(mode,))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count('"param_spread": 0.0') == 2, r.stdout[-2000:]

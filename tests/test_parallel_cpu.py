@@ -179,3 +179,19 @@ def test_bayesian_generator_block_plan_covers_every_row_once_for_any_sharding():
             if not ref:
                 ref = seen
             assert seen == ref
+
+
+def _shared_seed_fn(rank, world):
+    from bayesgm_amd import parallel
+    return (parallel.shared_seed(17), parallel.shared_seed(None))
+
+
+def test_shared_seed_is_one_value_on_every_rank():
+    """random_seed=None is the reference default (cli, main.py): under torch.distributed rank 0's entropy seed is
+    broadcast so that initial weights and the replicated EGM warm start agree on every rank; a user seed is kept; a
+    single process keeps None (NumPy's own entropy seeding)."""
+    from bayesgm_amd import parallel
+    assert parallel.shared_seed(None) is None and parallel.shared_seed(5) == 5
+    res = _run(_shared_seed_fn)
+    assert res[0][0] == res[1][0] == 17
+    assert isinstance(res[0][1], int) and res[0][1] == res[1][1]
