@@ -98,6 +98,8 @@ SYMBOLS = {
     "bgm_last_error": (C.c_char_p, []),
     "bgm_version": (C.c_char_p, []),
     "bgm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "bgm_set_disc_norm": (C.c_int, [C.c_void_p, C.c_int32]),
+    "bgm_causal_set_precision": (C.c_int, [C.c_void_p, C.c_int32]),
     "bgm_destroy": (C.c_int, [C.c_void_p]),
     "bgm_causal_configure": (C.c_int, [C.c_void_p, C.POINTER(CausalConfig)]),
     "bgm_causal_set_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -111,7 +113,6 @@ SYMBOLS = {
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bgm_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "bgm_timing_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int]),
-    "bgm_debug_clock_probe": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "bgm_causal_mh_info": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(MhInfo)]),
     "bgm_causal_evaluate": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int64, C.c_void_p, C.c_int32,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -211,8 +212,6 @@ SYMBOLS = {
     "bgm_bnn_egm_read": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "bgm_bnn_egm_end": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bgm_bnn_end": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "bgm_debug_bf16x3_probe": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
-    "bgm_debug_group_probe": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     "bgm_causal_egm_begin": (C.c_int, [C.c_void_p, C.POINTER(EgmConfig), C.c_void_p, C.c_int64, C.c_void_p]),
     "bgm_causal_egm_disc_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_void_p,
                                            C.c_void_p]),

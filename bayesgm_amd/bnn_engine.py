@@ -77,6 +77,10 @@ class BnnEngine(object):
         _lib.check(self.lib.bgm_create(C.byref(self.h), self.device.index), "bgm_create")
         self.open = False
 
+    def set_disc_norm(self, mode):
+        """BatchNormalization mode of the EGM discriminators opened afterwards: "batch" | "fixed" (bgm_set_disc_norm)."""
+        _lib.check(self.lib.bgm_set_disc_norm(self.h, {"batch": 0, "fixed": 1}[mode]), "bgm_set_disc_norm")
+
     def close(self):
         if getattr(self, "h", None) is not None and self.h:
             self.lib.bgm_destroy(self.h)

@@ -233,94 +233,3 @@ extern "C" int bgm_row_mean_quantiles(bgm_handle *h, const float *in, int64_t n_
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
 }
-
-// ---------------------------------------------------------------------------
-// Measurement aid (bench / DESIGN.md): effective shader clock under an fp32-MFMA load.
-// Every wave issues `iters` x 16 back-to-back v_mfma_f32_16x16x4_f32 on 4 independent accumulators;
-// wave 0 of block 0 reports shader cycles (s_memtime) and the 100 MHz real-time counter.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void clock_probe_kernel(int iters, unsigned long long *out, float *sink) {
-  f32x4 acc[4];
-  for (int k = 0; k < 4; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const float a = 1.0f + threadIdx.x * 1e-6f, b = 0.5f;
-  const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
-  for (int i = 0; i < iters; ++i) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) acc[k] = BGM_MFMA(a, b, acc[k]);
-  }
-  const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
-  float s = 0.f;
-  for (int k = 0; k < 4; ++k) s += acc[k][0];
-  if (s == 123.456f) sink[0] = s;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
-}
-
-// Micro-benchmark of the scheduled tile-group block alone: every wave loops over dense_group4_k64_asm (64 MFMAs +
-// 16 ds_read_b128 from a 16 KiB LDS region) -- mode 1 -- or over 64 MFMAs with register operands only -- mode 0.
-template <int MODE>
-__global__ __launch_bounds__(512) void group_probe_kernel(int iters, float *sink) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  for (int i = threadIdx.x; i < 4 * 4096; i += blockDim.x) lds[i] = 1e-3f * (float)(i & 255);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4, lane_off = 64 * g + j;
-  f32x4 in[4], acc[4];
-  for (int k = 0; k < 4; ++k) { in[k] = f32x4{1.f + lane * 1e-3f, 0.5f, 0.25f, 0.125f}; acc[k] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  for (int i = 0; i < iters; ++i) {
-    if constexpr (MODE == 1) {
-      dense_group4_k64_asm(lds_byte_addr(lds + (i & 3) * 4096 + lane_off * 4), in, acc[0], acc[1], acc[2], acc[3]);
-    } else {
-#pragma unroll
-      for (int s = 0; s < 16; ++s)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] = BGM_MFMA(in[s >> 2][s & 3], in[k][s & 3], acc[k]);
-    }
-  }
-  float t = 0.f;
-  for (int k = 0; k < 4; ++k) t += acc[k][0];
-  if (t == 123.456f) sink[0] = t;
-}
-extern "C" int bgm_debug_group_probe(bgm_handle *h, int32_t mode, int32_t waves_per_cu, int32_t iters, double *mfma_tflops) {
-  if (!h || iters <= 0) { bgm_set_error("bgm_debug_group_probe: bad argument"); return BGM_E_INVALID; }
-  BGM_HIP_CHECK(hipSetDevice(h->device));
-  float *sink;
-  BGM_HIP_CHECK(hipMalloc(&sink, 4));
-  hipEvent_t e0, e1;
-  BGM_HIP_CHECK(hipEventCreate(&e0)); BGM_HIP_CHECK(hipEventCreate(&e1));
-  const int threads = 64 * waves_per_cu, ldsb = 4 * 4096 * 4;
-  for (int rep = 0; rep < 2; ++rep) {
-    if (rep == 1) BGM_HIP_CHECK(hipEventRecord(e0, 0));
-    if (mode == 1) hipLaunchKernelGGL(group_probe_kernel<1>, dim3(h->n_cus), dim3(threads), ldsb, 0, iters, sink);
-    else hipLaunchKernelGGL(group_probe_kernel<0>, dim3(h->n_cus), dim3(threads), ldsb, 0, iters, sink);
-  }
-  BGM_HIP_CHECK(hipEventRecord(e1, 0));
-  BGM_HIP_CHECK(hipEventSynchronize(e1));
-  float ms = 0.f;
-  BGM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-  if (mfma_tflops) *mfma_tflops = (double)h->n_cus * waves_per_cu * iters * 64.0 * 2048.0 / (ms * 1e-3) / 1e12;
-  hipFree(sink); hipEventDestroy(e0); hipEventDestroy(e1);
-  return BGM_OK;
-}
-
-extern "C" int bgm_debug_clock_probe(bgm_handle *h, int32_t iters, double *shader_mhz, double *mfma_tflops) {
-  if (!h || iters <= 0) { bgm_set_error("bgm_debug_clock_probe: bad argument"); return BGM_E_INVALID; }
-  BGM_HIP_CHECK(hipSetDevice(h->device));
-  unsigned long long *out; float *sink;
-  BGM_HIP_CHECK(hipMalloc(&out, 16)); BGM_HIP_CHECK(hipMalloc(&sink, 4));
-  hipEvent_t e0, e1;
-  BGM_HIP_CHECK(hipEventCreate(&e0)); BGM_HIP_CHECK(hipEventCreate(&e1));
-  hipLaunchKernelGGL(clock_probe_kernel, dim3(h->n_cus), dim3(512), 0, 0, iters / 8 + 1, out, sink);   // warm
-  BGM_HIP_CHECK(hipEventRecord(e0, 0));
-  hipLaunchKernelGGL(clock_probe_kernel, dim3(h->n_cus), dim3(512), 0, 0, iters, out, sink);
-  BGM_HIP_CHECK(hipEventRecord(e1, 0));
-  BGM_HIP_CHECK(hipEventSynchronize(e1));
-  float ms = 0.f;
-  BGM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-  unsigned long long host[2];
-  BGM_HIP_CHECK(hipMemcpy(host, out, 16, hipMemcpyDeviceToHost));
-  if (shader_mhz) *shader_mhz = (double)host[0] / ((double)host[1] / 100.0);   // real-time counter = 100 MHz
-  if (mfma_tflops) *mfma_tflops = (double)h->n_cus * 8.0 * iters * 16.0 * 2048.0 / (ms * 1e-3) / 1e12;
-  hipFree(out); hipFree(sink); hipEventDestroy(e0); hipEventDestroy(e1);
-  return BGM_OK;
-}

@@ -42,6 +42,7 @@ static int fill_disc(EgmDisc &d, int in_dim, int n_hidden, const int32_t *units)
   for (int l = 0; l < n_hidden; ++l) { d.beta[l] = o; o += d.dims[l + 1]; }
   d.n_params = o;
   egm_finish_disc(d);
+  d.fixed_norm = 0;
   return o;
 }
 
@@ -93,6 +94,7 @@ extern "C" int bgm_bgm_egm_begin(bgm_handle *h, const bgm_bgm_egm_config *cfg, c
   s->n_gen = s->n_g + s->n_e;
   s->n_dz = (size_t)fill_disc(a.dz, q, cfg->n_hidden_dz, cfg->dz_units);
   s->n_dx = (size_t)fill_disc(a.dx, p, cfg->n_hidden_dx, cfg->dx_units);
+  a.dz.fixed_norm = a.dx.fixed_norm = h->disc_norm;
   s->n_disc = s->n_dz + s->n_dx;
   if ((int64_t)s->n_e != count_e || (int64_t)s->n_dz != count_dz || (int64_t)s->n_dx != count_dx) {
     const std::string msg = "bgm_bgm_egm_begin: expected " + std::to_string(s->n_e) + " / " + std::to_string(s->n_dz) + " / " +

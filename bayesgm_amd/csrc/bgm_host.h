@@ -40,6 +40,7 @@ struct HostNet {
 struct bgm_handle {
   int device = 0;
   int n_cus = 256;
+  int disc_norm = 0;   // Discriminator BatchNormalization: 0 batch statistics, 1 inference mode (bgm_set_disc_norm)
   bool configured = false;
   bgm_causal_config cfg{};
   int q = 0, p = 0;
@@ -55,6 +56,12 @@ struct bgm_handle {
   float *sblob_dev = nullptr;
   size_t sblob_cap = 0;
   bool sblob_valid = false;
+  // split-precision (bf16 x 3) sampling blob (causal_bx3_api.hip); precision: 0 fp32 (default), 1 bf16x3 (bgm_causal_set_precision)
+  int precision = 0;
+  void *bx_blob_dev = nullptr;
+  size_t bx_cap = 0;
+  bool bx_valid = false;
+  alignas(8) unsigned char bx_meta_store[192];
   // encoder blob
   float *eblob_dev = nullptr;
   size_t eblob_cap = 0;
@@ -126,6 +133,11 @@ void bgm_bgm_egm_free_state(bgm_handle *h);
 void bgm_bnn_free_state(bgm_handle *h);
 void bgm_bvn_free_state(bgm_handle *h);
 int causal_pack_forward(bgm_handle *h, const HostNet &G, const HostNet &F, const HostNet &H, std::vector<float> &blob);
+// split-precision sampling path (causal_bx3_api.hip)
+int bgm_causal_bx3_blob(bgm_handle *h, hipStream_t stream);
+int bgm_causal_bx3_logpost(bgm_handle *h, const float *x, const float *y, const float *v, const float *z, int64_t n, float *out, int grid,
+                           hipStream_t stream);
+int bgm_causal_bx3_mh_launch(bgm_handle *h, const CausalMhKArgs &a, int effect, int grid, hipStream_t stream);
 
 // ---- packing into MFMA fragment order (layout documented in bgm_device.h)
 // rowmap(rho) -> source input-feature row of W (or -1 for a zero row)

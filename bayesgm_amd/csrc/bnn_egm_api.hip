@@ -52,6 +52,7 @@ extern "C" int bgm_bnn_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, const
   for (int l = 0; l < L; ++l) { d.beta[l] = o; o += d.dims[l + 1]; }
   d.n_params = o;
   egm_finish_disc(d);
+  d.fixed_norm = h->disc_norm;
   e->n_dz = (size_t)o;
   if ((int64_t)o != count) {
     bgm_bnn_egm_free(e); s->egm = nullptr;

@@ -13,8 +13,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libbgm_hip.so")
-SOURCES = ["causal_api.hip", "aux_kernels.hip", "fit_api.hip", "bgm_api.hip", "egm_api.hip", "bgm_egm_api.hip", "bnn_api.hip", "bnn_sample_api.hip", "bnn_egm_api.hip", "bgmb_api.hip", "bgmb_egm_api.hip", "probe_bf16x3.hip"]
-HEADERS = ["bgm_device.h", "causal_kernels.h", "fit_kernels.h", "fit_types.h", "bgm_kernels.h", "bgm_fit_kernels.h", "bgm_state.h", "bgm_host.h", "egm_kernels.h", "bgm_egm_kernels.h", "bnn_kernels.h", "bnn_state.h", "bnn_sample_kernels.h", "bnn_egm_kernels.h", "bgmb_kernels.h", "bgmb_state.h", "bgmb_egm_kernels.h", os.path.join("..", "..", "include", "bgm_hip.h")]
+SOURCES = ["causal_api.hip", "causal_bx3_api.hip", "aux_kernels.hip", "fit_api.hip", "bgm_api.hip", "egm_api.hip", "bgm_egm_api.hip", "bnn_api.hip", "bnn_sample_api.hip", "bnn_egm_api.hip", "bgmb_api.hip", "bgmb_egm_api.hip"]
+HEADERS = ["bgm_device.h", "causal_kernels.h", "causal_bx3_kernels.h", "fit_kernels.h", "fit_types.h", "bgm_kernels.h", "bgm_fit_kernels.h", "bgm_state.h", "bgm_host.h", "egm_kernels.h", "bgm_egm_kernels.h", "bnn_kernels.h", "bnn_state.h", "bnn_sample_kernels.h", "bnn_egm_kernels.h", "bgmb_kernels.h", "bgmb_state.h", "bgmb_egm_kernels.h", os.path.join("..", "..", "include", "bgm_hip.h")]
 FLAGS = os.environ.get("BGM_EXTRA_FLAGS", "").split() + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wno-unused-value", "-Wno-unused-result"]
 
@@ -52,7 +52,27 @@ def build(force=False, defines=(), verbose=True, out=None):
     return OUT
 
 
+def build_probes(verbose=True):
+    """Measurement aids (probes/probe_kernels.hip -> probes/libbgm_probe.so): micro-benchmarks used by scripts/probe_*.py only;
+    not part of the product library or its header."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    src = os.path.join(HERE, "probes", "probe_kernels.hip")
+    out = os.path.join(HERE, "probes", "libbgm_probe.so")
+    if os.path.exists(out) and not _newer(src, out) and not _newer(os.path.join(HERE, "bgm_device.h"), out):
+        return out
+    cmd = [hipcc] + FLAGS + ["-shared", "-I", HERE, src, "-o", out]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
+    if "--probes" in sys.argv[1:]:
+        print(build_probes())
+        sys.exit(0)
     defs = []
     argv = sys.argv[1:]
     force = "--force" in argv

@@ -29,12 +29,19 @@ extern "C" int bgm_create(bgm_handle **out, int device) {
   return BGM_OK;
 }
 
+extern "C" int bgm_set_disc_norm(bgm_handle *h, int32_t mode) {
+  if (!h || (mode != 0 && mode != 1)) { bgm_set_error("bgm_set_disc_norm: mode must be 0 (batch statistics) or 1 (inference mode)"); return BGM_E_INVALID; }
+  h->disc_norm = mode;
+  return BGM_OK;
+}
+
 extern "C" int bgm_destroy(bgm_handle *h) {
   if (!h) return BGM_OK;
   hipSetDevice(h->device);
   if (h->blob_dev) hipFree(h->blob_dev);
   if (h->eblob_dev) hipFree(h->eblob_dev);
   if (h->sblob_dev) hipFree(h->sblob_dev);
+  if (h->bx_blob_dev) hipFree(h->bx_blob_dev);
   if (h->acc_scratch) hipFree(h->acc_scratch);
   bgm_causal_fit_end(h, nullptr);
   bgm_bgm_free_state(h);
@@ -93,6 +100,7 @@ extern "C" int bgm_causal_configure(bgm_handle *h, const bgm_causal_config *cfg)
   mk(h->nets[BGM_NET_E], p, cfg->e_units, cfg->n_hidden_e, q);
   h->configured = true;
   h->blob_valid = false;
+  h->bx_valid = false;
   h->eblob_valid = false;
   return BGM_OK;
 }
@@ -109,7 +117,7 @@ extern "C" int bgm_causal_set_weights(bgm_handle *h, int net_id, const float *th
   }
   std::memcpy(n.theta.data(), theta_host, sizeof(float) * count);
   n.set = true;
-  if (net_id == BGM_NET_E) h->eblob_valid = false; else h->blob_valid = false;
+  if (net_id == BGM_NET_E) h->eblob_valid = false; else { h->blob_valid = false; h->bx_valid = false; }
   return BGM_OK;
 }
 
@@ -187,13 +195,42 @@ int causal_pack_forward(bgm_handle *h, const HostNet &G, const HostNet &F, const
   return BGM_OK;
 }
 
-// sampling copy of the forward blob: dst = src with the weights of the layers behind a LeakyReLU scaled by 0.6
+// sampling copy of the forward blob: dst = src with the weights of the layers behind a LeakyReLU scaled by 0.6, and the tails of
+// the two small nets (f, h: ... -> 8 -> 2) re-laid out for the sampling kernels (causal_kernels.h, above causal_effects):
+//   layer 3 [32 x 8]: output column f moves to tile position pos(f) = 4 (f >> 1) + (f & 1) (weights and bias), so that the 8
+//                     activations sit in accumulator registers 0, 1 of every lane group;
+//   layer 4 [8 x 2] : input row f moves to K row pos(f) (K-steps 0 and 1 only), and the two output columns (mu, s) are
+//                     replicated at positions 4 g' + {0, 1} (weights and bias): every lane group receives (mu, s).
+static __device__ __forceinline__ int tail_pos_to_feature(int pos) { return ((pos & 3) < 2) ? 2 * (pos >> 2) + (pos & 1) : -1; }
 static __global__ void causal_scale_blob_kernel(const float *src, float *dst, CausalMeta m, int NTL) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m.total) return;
   auto in = [&](int off, int n) { return i >= off && i < off + n; };
-  const bool scaled = in(m.wg, m.n_gh * 4096) || in(m.wgl, 64 * 16 * NTL) || in(m.wf2, 64 * 32) || in(m.wf3, 32 * 16) ||
-                      in(m.wf4, 16 * 16) || in(m.wh2, 64 * 32) || in(m.wh3, 32 * 16) || in(m.wh4, 16 * 16);
+  const int w3[2] = {m.wf3, m.wh3}, b3[2] = {m.bf3, m.bh3}, w4[2] = {m.wf4, m.wh4}, b4[2] = {m.bf4, m.bh4};
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (in(w3[k], 32 * 16)) {            // [K row rho][tile position]
+      const int rho = (i - w3[k]) >> 4, f = tail_pos_to_feature((i - w3[k]) & 15);
+      dst[i] = f >= 0 ? src[w3[k] + rho * 16 + f] * BGM_LRS_W : 0.0f;
+      return;
+    }
+    if (in(b3[k], 16)) {
+      const int f = tail_pos_to_feature(i - b3[k]);
+      dst[i] = f >= 0 ? src[b3[k] + f] : 0.0f;
+      return;
+    }
+    if (in(w4[k], 16 * 16)) {
+      const int f = tail_pos_to_feature((i - w4[k]) >> 4), c = (i - w4[k]) & 3;
+      dst[i] = (f >= 0 && c < 2) ? src[w4[k] + f * 16 + c] * BGM_LRS_W : 0.0f;
+      return;
+    }
+    if (in(b4[k], 16)) {
+      const int c = (i - b4[k]) & 3;
+      dst[i] = c < 2 ? src[b4[k] + c] : 0.0f;
+      return;
+    }
+  }
+  const bool scaled = in(m.wg, m.n_gh * 4096) || in(m.wgl, 64 * 16 * NTL) || in(m.wf2, 64 * 32) || in(m.wh2, 64 * 32);
   dst[i] = scaled ? src[i] * BGM_LRS_W : src[i];
 }
 
@@ -281,6 +318,7 @@ extern "C" int bgm_causal_logpost(bgm_handle *h, const float *x, const float *y,
   int rc = bgm_causal_sampling_blob(h, stream);
   if (rc) return rc;
   const int grid = mh_grid(h, n);
+  if (h->precision == 1) return bgm_causal_bx3_logpost(h, x, y, v, z, n, out, grid, stream);
   const int lds = h->meta.total * 4;
 #define X(KT1_, KSL1_, NTL_)                                                                   \
   if (h->KT1 == KT1_ && h->KSL1 == KSL1_ && h->NTL == NTL_) {                                  \
@@ -370,7 +408,8 @@ extern "C" int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *a, void *stre
       BGM_HIP_CHECK(hipEventCreate(&e0)); BGM_HIP_CHECK(hipEventCreate(&e1));
       BGM_HIP_CHECK(hipEventRecord(e0, stream));
     }
-    if (segs[s].effect == BGM_EFFECT_ADRF) rc = launch_mh<1>(h, ka, grid, lds, stream);
+    if (h->precision == 1) rc = bgm_causal_bx3_mh_launch(h, ka, segs[s].effect, grid, stream);
+    else if (segs[s].effect == BGM_EFFECT_ADRF) rc = launch_mh<1>(h, ka, grid, lds, stream);
     else if (segs[s].effect == BGM_EFFECT_ITE) rc = launch_mh<2>(h, ka, grid, lds, stream);
     else rc = launch_mh<0>(h, ka, grid, lds, stream);
     if (rc) return rc;

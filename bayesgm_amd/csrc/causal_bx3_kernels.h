@@ -1,0 +1,485 @@
+// causal_bx3_kernels.h -- split-precision ("bf16 x 3") variant of the CausalBGM sampling kernels (gfx950), opt-in
+// (`bgm_causal_set_precision(h, 1)`, params['mh_precision'] = 'bf16x3'); fp32 (causal_kernels.h) stays the default.
+//
+// replaces (src/bayesgm/models/causalbgm/base.py): get_log_posterior :765-817, metropolis_hastings_sampler :820-904,
+// infer_from_latent_posterior :671-763 -- the same algorithm, RNG streams and data layout as causal_kernels.h; only the dense
+// contractions change: every weight matrix and every activation is split into two bf16 numbers, x = x_hi + x_lo, and
+//     W h  ~=  W_hi h_hi + W_hi h_lo + W_lo h_hi          (fp32 accumulation, the W_lo h_lo term ~2^-16 |W h| is dropped)
+// on v_mfma_f32_16x16x32_bf16 (K = 32 per instruction at ~17 cycles, against K = 4 at 32 cycles for the fp32 MFMA): a
+// 64 -> 64 layer is 24 matrix instructions instead of 64.  Relative error of one layer against float64: ~6e-6 (fp32: 2.4e-7).
+//
+// Layout.  M = output feature, N = chain (16 rows per wave), K = input feature, as in the fp32 kernels, so a layer's
+// accumulators (lane (j, g), tile t, register r = feature 16 t + 4 g + r of row j) are again the next layer's B operands:
+// a K block of 32 is the pair of tiles (2T, 2T+1), lane group g supplies k-slots 8 g + u, u = 4 s + r  <->  feature
+// 16 (2T + s) + 4 g + r, and the weights are packed in that K order.  An odd last tile (16 inputs: the first layers at
+// z_dims [1,1,1,7], the 8 -> 2 output layers of f / h) uses v_mfma_f32_16x16x16_bf16, k-slot 4 g + r.
+// Blob (LDS resident, bytes): per layer the A fragments [tile][K block][hi | lo][64 lanes] of 16 B (8 B for a K = 16 block),
+// then the fp32 biases / x-row of f in accumulator order (float offsets).  Weights behind a LeakyReLU carry the factor 0.6 of
+// the one-instruction activation lrelu_s, as in the fp32 sampling blob.
+#pragma once
+#include "causal_kernels.h"
+
+typedef __bf16 bx_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bx_bf16x4 __attribute__((ext_vector_type(4)));
+
+struct BxMeta {
+  int q, p, sig_pc, binary, n_gh;
+  float sig2_v, sig2_x, sig2_y;
+  // byte offsets of the packed weights
+  int w1g, w1f, w1h, wg, wgl, wf2, wf3, wf4, wh2, wh3, wh4;
+  // float offsets (from the blob start) of the fp32 vectors
+  int b1g, b1f, b1h, bg, bgl, bf2, bf3, bf4, bh2, bh3, bh4, wxf;
+  int total_bytes;
+};
+
+struct CausalBxKArgs {
+  CausalMhKArgs a;        // the fp32 kernel's arguments (a.blob / a.m unused)
+  const unsigned char *bblob;
+  BxMeta bx;
+};
+
+// ---- activation split: 8 (or 4) fp32 values -> bf16 hi / lo -------------------------------------------------
+__device__ __forceinline__ void bx_split8(const f32x4 &a, const f32x4 &b, bx_bf16x8 &hi, bx_bf16x8 &lo) {
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const float v = (u < 4) ? a[u] : b[u - 4];
+    const __bf16 h = (__bf16)v;
+    hi[u] = h;
+    lo[u] = (__bf16)(v - (float)h);
+  }
+}
+__device__ __forceinline__ void bx_split4(const f32x4 &a, bx_bf16x4 &hi, bx_bf16x4 &lo) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const __bf16 h = (__bf16)a[u];
+    hi[u] = h;
+    lo[u] = (__bf16)(a[u] - (float)h);
+  }
+}
+
+__host__ __device__ constexpr int bx_layer_bytes(int KT, int NT) { return NT * ((KT / 2) * 2048 + (KT & 1) * 1024); }
+
+// acc[NT] += W^T in   for one layer; `w` = LDS byte address of the layer's fragments, `in` = KT activated input tiles.
+// The input is split once; the output tiles are processed in groups of up to four (A fragments of a group: 32 registers), and
+// per K block the three products of a group are issued tile-major per product, so that consecutive MFMAs write different
+// accumulators.
+template <int KT, int NT>
+__device__ __forceinline__ void bx_dense_acc(const unsigned char *w, int lane, const f32x4 (&in)[KT], f32x4 (&acc)[NT]) {
+  constexpr int NK32 = KT / 2, K16 = KT & 1;
+  constexpr int TILE_BYTES = NK32 * 2048 + K16 * 1024;
+  bx_bf16x8 bh[NK32 > 0 ? NK32 : 1], bl[NK32 > 0 ? NK32 : 1];
+#pragma unroll
+  for (int T = 0; T < NK32; ++T) bx_split8(in[2 * T], in[2 * T + 1], bh[T], bl[T]);
+  bx_bf16x4 ch, cl;
+  if constexpr (K16) bx_split4(in[KT - 1], ch, cl);
+#pragma unroll
+  for (int m0 = 0; m0 < NT; m0 += 4) {
+    constexpr int GSMAX = 4;
+    const int gs = (NT - m0 < GSMAX) ? NT - m0 : GSMAX;      // compile-time after unrolling
+#pragma unroll
+    for (int T = 0; T < NK32; ++T) {
+      bx_bf16x8 ah[GSMAX], al[GSMAX];
+#pragma unroll
+      for (int u = 0; u < GSMAX; ++u)
+        if (u < gs) {
+          const unsigned char *f = w + (m0 + u) * TILE_BYTES + T * 2048 + lane * 16;
+          ah[u] = *reinterpret_cast<const bx_bf16x8 *>(f);
+          al[u] = *reinterpret_cast<const bx_bf16x8 *>(f + 1024);
+        }
+#pragma unroll
+      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[u], bh[T], acc[m0 + u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[u], bl[T], acc[m0 + u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[u], bh[T], acc[m0 + u], 0, 0, 0);
+    }
+    if constexpr (K16) {
+      bx_bf16x4 ah[GSMAX], al[GSMAX];
+#pragma unroll
+      for (int u = 0; u < GSMAX; ++u)
+        if (u < gs) {
+          const unsigned char *f = w + (m0 + u) * TILE_BYTES + NK32 * 2048 + lane * 8;
+          ah[u] = *reinterpret_cast<const bx_bf16x4 *>(f);
+          al[u] = *reinterpret_cast<const bx_bf16x4 *>(f + 512);
+        }
+#pragma unroll
+      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al[u], ch, acc[m0 + u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[u], cl, acc[m0 + u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[u], ch, acc[m0 + u], 0, 0, 0);
+    }
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void bx_bias(const float *ldsf, int boff, int g, f32x4 (&acc)[NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = *reinterpret_cast<const f32x4 *>(ldsf + boff + 16 * t + 4 * g);
+}
+template <int NT>
+__device__ __forceinline__ void bx_lrelu(f32x4 (&a)[NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[t][r] = lrelu_s(a[t][r]);
+}
+
+// f / h tail 64 -> 32 -> 8 -> 2 from the activated first hidden layer; (mu, s) valid in every lane (replicated columns)
+__device__ __forceinline__ void bx_tail(const unsigned char *lds, const float *ldsf, int w2, int b2, int w3, int b3, int w4, int b4,
+                                        int lane, int g, const f32x4 (&a1)[4], float &mu, float &sr) {
+  f32x4 a2[2];
+  bx_bias<2>(ldsf, b2, g, a2);
+  bx_dense_acc<4, 2>(lds + w2, lane, a1, a2);
+  bx_lrelu<2>(a2);
+  f32x4 a3[1];
+  bx_bias<1>(ldsf, b3, g, a3);
+  bx_dense_acc<2, 1>(lds + w3, lane, a2, a3);
+  bx_lrelu<1>(a3);
+  f32x4 a4[1];
+  bx_bias<1>(ldsf, b4, g, a4);
+  bx_dense_acc<1, 1>(lds + w4, lane, a3, a4);
+  mu = a4[0][0];
+  sr = a4[0][1];
+}
+
+// log p(z | x, y, v) of the wave's 16 chains (causal_logp of causal_kernels.h in split precision)
+template <int KT1, int NTL>
+__device__ __forceinline__ float causal_logp_bx3(const unsigned char *lds, const BxMeta &m, int lane, int g, int j,
+                                                 const f32x4 (&zin)[KT1], const f32x4 (&vreg)[NTL], float xr, float yr) {
+  const float *ldsf = reinterpret_cast<const float *>(lds);
+  float ssq = 0.0f, sraw_v = 0.0f;
+  {
+    f32x4 h[4];
+    bx_bias<4>(ldsf, m.b1g, g, h);
+    bx_dense_acc<KT1, 4>(lds + m.w1g, lane, zin, h);
+    bx_lrelu<4>(h);
+    for (int l = 0; l < m.n_gh; ++l) {
+      BGM_NO_HOIST();
+      f32x4 h2[4];
+      bx_bias<4>(ldsf, m.bg + 64 * l, g, h2);
+      bx_dense_acc<4, 4>(lds + m.wg + l * bx_layer_bytes(4, 4), lane, h, h2);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[t][r] = lrelu_s(h2[t][r]);
+    }
+    // last layer on top of (bias - v): mu - v per covariate, the variance column at element sig_pc of the last tile
+    f32x4 acc[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) acc[t] = vreg[t];
+    bx_dense_acc<4, NTL>(lds + m.wgl, lane, h, acc);
+    const int sig_r = m.sig_pc - 4 * g;
+#pragma unroll
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float d = acc[t][r];
+        if (t == NTL - 1) {
+          const bool is_sig = (r == sig_r);
+          sraw_v = is_sig ? d : sraw_v;
+          d = is_sig ? 0.0f : d;
+        }
+        ssq = fmaf(d, d, ssq);
+      }
+    sraw_v = __shfl(sraw_v, j + 16 * (m.sig_pc >> 2));
+  }
+  float mu_y, sr_y, mu_x, sr_x;
+  {
+    f32x4 f1[4], h1[4];
+    bx_bias<4>(ldsf, m.b1f, g, f1);
+    bx_bias<4>(ldsf, m.b1h, g, h1);
+    bx_dense_acc<KT1, 4>(lds + m.w1f, lane, zin, f1);
+    bx_dense_acc<KT1, 4>(lds + m.w1h, lane, zin, h1);
+    bx_lrelu<4>(f1);
+    bx_lrelu<4>(h1);
+    bx_tail(lds, ldsf, m.wf2, m.bf2, m.wf3, m.bf3, m.wf4, m.bf4, lane, g, f1, mu_y, sr_y);
+    bx_tail(lds, ldsf, m.wh2, m.bh2, m.wh3, m.bh3, m.wh4, m.bh4, lane, g, h1, mu_x, sr_x);
+  }
+  float zsq = 0.0f;
+#pragma unroll
+  for (int t = 0; t < KT1; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float zz = zin[t][r];
+      zsq = (16 * t + 4 * r + g < m.q) ? fmaf(zz, zz, zsq) : zsq;
+    }
+  const float s2v = (m.sig2_v > 0.0f) ? m.sig2_v : softplus_f(sraw_v) + BGM_EPS;
+  float loss_x;
+  if (m.binary) {
+    const float l = mu_x;
+    const float e = fast_exp(-fabsf(l));
+    loss_x = vmax(l, 0.0f) - l * xr + ((e < 2.44140625e-4f) ? e * (1.0f - 0.5f * e) : fast_log(1.0f + e));
+  } else {
+    const float s2x = (m.sig2_x > 0.0f) ? m.sig2_x : softplus_f(sr_x) + BGM_EPS;
+    const float dx = xr - mu_x;
+    loss_x = 0.5f * (dx * dx * fast_rcp(s2x) + fast_log(s2x));
+  }
+  const float s2y = (m.sig2_y > 0.0f) ? m.sig2_y : softplus_f(sr_y) + BGM_EPS;
+  const float dy = yr - mu_y;
+  const float loss_y = 0.5f * (dy * dy * fast_rcp(s2y) + fast_log(s2y));
+  float part = 0.5f * (ssq * fast_rcp(s2v) + zsq);
+  part += (g == 0) ? (loss_x + loss_y) : 0.0f;
+  return -(sum_over_g(part) + 0.5f * (float)m.p * fast_log(s2v));
+}
+
+// vreg = (bias of g's last layer) - (V row), accumulator layout (the bx3 blob keeps its fp32 vectors at float offsets)
+template <int NTL>
+__device__ __forceinline__ void bx_load_v(const float *v, const float *bl, long long n, int p, long long row0, int j, int g,
+                                          f32x4 (&vreg)[NTL]) {
+  long long row = row0 + j;
+  row = row < n ? row : n - 1;
+  const float *vr = v + row * (long long)p;
+#pragma unroll
+  for (int t = 0; t < NTL; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = 16 * t + 4 * g + r;
+      vreg[t][r] = bl[c] - ((c < p) ? vr[c] : 0.0f);
+    }
+}
+
+__device__ __forceinline__ void bx_lds_fill(unsigned char *lds, const unsigned char *blob, int total_bytes) {
+  const f32x4 *src = reinterpret_cast<const f32x4 *>(blob);
+  f32x4 *dst = reinterpret_cast<f32x4 *>(lds);
+  for (int i = threadIdx.x; i < total_bytes / 16; i += blockDim.x) dst[i] = src[i];
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// get_log_posterior for n rows
+// ---------------------------------------------------------------------------
+template <int KT1, int NTL, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void causal_logpost_bx3_kernel(const unsigned char *blob, BxMeta m, const float *x,
+                                                                        const float *y, const float *v, const float *z,
+                                                                        long long n, float *out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bx_lds[];
+  bx_lds_fill(bx_lds, blob, m.total_bytes);
+  const float *ldsf = reinterpret_cast<const float *>(bx_lds);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const long long n_tiles = (n + 15) / 16;
+  for (long long tile = (long long)blockIdx.x * WAVES + wave; tile < n_tiles; tile += (long long)gridDim.x * WAVES) {
+    BGM_NO_HOIST();
+    const long long row0 = tile * 16;
+    long long row = row0 + j;
+    row = row < n ? row : n - 1;
+    const float xr[1] = {x[row]}, yr = y[row];
+    f32x4 vreg[NTL];
+    bx_load_v<NTL>(v, ldsf + m.bgl, n, m.p, row0, j, g, vreg);
+    f32x4 zin[1][KT1];
+    load_z_rows<KT1, 1>(z, n, m.q, row0, j, g, xr, zin);
+    const float lp = causal_logp_bx3<KT1, NTL>(bx_lds, m, lane, g, j, zin[0], vreg, xr[0], yr);
+    if (g == 0 && row0 + j < n) out[row0 + j] = lp;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// infer_from_latent_posterior for the wave's 16 states (causal_effects of causal_kernels.h in split precision):
+// f's first layer once at x = 0 (fp32 accumulators), doses as fp32 rank-1 updates, four doses per pass sharing the A
+// fragments, lane group g finishing dose e = g of the pass; same noise plan (Philox calls in groups of four).
+// ---------------------------------------------------------------------------
+template <int KT1, int EFFECT>
+__device__ __forceinline__ void causal_effects_bx3(const unsigned char *lds, const BxMeta &m, int lane, int g, int j,
+                                                   const f32x4 (&zs)[KT1], unsigned rowid, bool valid, long long row, long long n,
+                                                   unsigned it, long long d, int n_keep, int sample_y, int n_doses,
+                                                   const float *x_values, float *adrf_slot, float *ite, unsigned k0, unsigned k1) {
+  BGM_NO_HOIST();
+  const float *ldsf = reinterpret_cast<const float *>(lds);
+  f32x4 z0in[KT1];
+#pragma unroll
+  for (int t = 0; t < KT1; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) z0in[t][r] = (16 * t + 4 * r + g == m.q) ? 0.0f : zs[t][r];
+  f32x4 base[4];
+  bx_bias<4>(ldsf, m.b1f, g, base);
+  bx_dense_acc<KT1, 4>(lds + m.w1f, lane, z0in, base);
+  f32x4 wx[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) wx[t] = *reinterpret_cast<const f32x4 *>(ldsf + m.wxf + 16 * t + 4 * g);
+  constexpr int DB = (EFFECT == 2) ? 2 : 4;
+  const int nd = (EFFECT == 2) ? 2 : n_doses;
+  const int n_calls = (nd + 3) >> 2, n_own = (EFFECT == 1) ? (n_calls & ~3) : 0;
+  f32x4 nz = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int kb = 0; kb < n_calls; ++kb) {
+    BGM_NO_HOIST();
+    const bool own = kb < n_own;
+    const int c4 = kb & ~3, p4 = kb & 3;
+    if (sample_y && (!own || p4 == 0)) nz = box_muller4(philox4x32_10(rowid, it, (unsigned)(own ? c4 + g : kb), TAG_YNOISE, k0, k1));
+    float xk[DB];
+#pragma unroll
+    for (int e = 0; e < DB; ++e) {
+      const int k = own ? 4 * (c4 + e) + p4 : 4 * kb + e;
+      xk[e] = (EFFECT == 2) ? (e == 0 ? 1.0f : 0.0f) : x_values[k < nd ? k : nd - 1];
+    }
+    // layer 2 (64 -> 32): A fragments of a K block shared by the DB doses
+    f32x4 a2[DB][2];
+#pragma unroll
+    for (int e = 0; e < DB; ++e) bx_bias<2>(ldsf, m.bf2, g, a2[e]);
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+      bx_bf16x8 ah[2], al[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const unsigned char *f = lds + m.wf2 + mt * 4096 + T * 2048 + lane * 16;
+        ah[mt] = *reinterpret_cast<const bx_bf16x8 *>(f);
+        al[mt] = *reinterpret_cast<const bx_bf16x8 *>(f + 1024);
+      }
+#pragma unroll
+      for (int e = 0; e < DB; ++e) {
+        f32x4 u0, u1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          u0[r] = lrelu_s(fmaf(wx[2 * T][r], xk[e], base[2 * T][r]));
+          u1[r] = lrelu_s(fmaf(wx[2 * T + 1][r], xk[e], base[2 * T + 1][r]));
+        }
+        bx_bf16x8 bh, bl;
+        bx_split8(u0, u1, bh, bl);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) a2[e][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh, a2[e][mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) a2[e][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl, a2[e][mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) a2[e][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh, a2[e][mt], 0, 0, 0);
+      }
+    }
+    float mu[DB], sr[DB];
+#pragma unroll
+    for (int e = 0; e < DB; ++e) {
+      bx_lrelu<2>(a2[e]);
+      f32x4 a3[1];
+      bx_bias<1>(ldsf, m.bf3, g, a3);
+      bx_dense_acc<2, 1>(lds + m.wf3, lane, a2[e], a3);
+      bx_lrelu<1>(a3);
+      f32x4 a4[1];
+      bx_bias<1>(ldsf, m.bf4, g, a4);
+      bx_dense_acc<1, 1>(lds + m.wf4, lane, a3, a4);
+      mu[e] = a4[0][0];
+      sr[e] = a4[0][1];
+    }
+    if constexpr (EFFECT == 1) {
+      const int k = own ? 4 * (c4 + g) + p4 : 4 * kb + g;
+      const float mu_m = pick_by_group(g, mu[0], mu[1], mu[2], mu[3]), sr_m = pick_by_group(g, sr[0], sr[1], sr[2], sr[3]);
+      const float s2 = (m.sig2_y > 0.0f) ? m.sig2_y : softplus_f(sr_m) + BGM_EPS;
+      const float noise = own ? nz[0] : pick_by_group(g, nz[0], nz[1], nz[2], nz[3]);
+      if (own) nz = f32x4{nz[1], nz[2], nz[3], nz[0]};
+      float y = sample_y ? fmaf(__builtin_sqrtf(s2), noise, mu_m) : mu_m;
+      y = (valid && k < nd) ? y : 0.0f;
+      const float tot = sum_over_j_to_lane15(y);
+      if (j == 15 && k < nd) unsafeAtomicAdd(adrf_slot + (long long)k * n_keep + d, tot);
+    } else {
+      float yk[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float s2 = (m.sig2_y > 0.0f) ? m.sig2_y : softplus_f(sr[e]) + BGM_EPS;
+        yk[e] = sample_y ? fmaf(__builtin_sqrtf(s2), nz[e], mu[e]) : mu[e];
+      }
+      if (g == 0 && row < n) ite[row * (long long)n_keep + d] = yk[0] - yk[1];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Persistent random-walk Metropolis-Hastings over a segment of iterations (causal_mh_kernel in split precision; one row tile
+// per wave, 8 waves per block: the two waves of a SIMD balance their progress through LDS as in the fp32 kernel).
+// ---------------------------------------------------------------------------
+template <int KT1, int NTL, int WAVES, int EFFECT>
+__global__ __launch_bounds__(64 * WAVES) void causal_mh_bx3_kernel(CausalBxKArgs ka) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bx_lds[];
+  const CausalMhKArgs &a = ka.a;
+  const BxMeta &m = ka.bx;
+  bx_lds_fill(bx_lds, ka.bblob, m.total_bytes);
+  const float *ldsf = reinterpret_cast<const float *>(bx_lds);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const long long n = a.n;
+  const long long n_tiles = (n + 15) / 16;
+  const long long slot = (long long)blockIdx.x * WAVES + wave;
+  const long long n_slots = (long long)gridDim.x * WAVES;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  volatile int *prog = reinterpret_cast<volatile int *>(bx_lds + m.total_bytes);   // [WAVES] progress counters after the blob
+  if (lane == 0) prog[wave_u] = 0;
+  int tiles_done = 0;
+  for (long long tile = slot; tile < n_tiles; tile += n_slots) {
+    const long long row0 = tile * 16;
+    long long row = row0 + j;
+    const bool valid = row < n;
+    const long long rowc = valid ? row : n - 1;
+    const float xr[1] = {a.x[rowc]}, yr = a.y[rowc];
+    const unsigned rowid = (unsigned)(a.row_base + rowc);
+    f32x4 vreg[NTL];
+    bx_load_v<NTL>(a.v, ldsf + m.bgl, n, m.p, row0, j, g, vreg);
+    f32x4 zs[1][KT1];
+    float lp;
+    if (a.init) {
+#pragma unroll
+      for (int t = 0; t < KT1; ++t) {
+        const f32x4 e = box_muller4(philox4x32_10(rowid, 0u, (unsigned)(g + 4 * t), TAG_INIT, a.k0, a.k1));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 16 * t + 4 * r + g;
+          zs[0][t][r] = (f < m.q) ? e[r] : (f == m.q ? xr[0] : 0.0f);
+        }
+      }
+      lp = causal_logp_bx3<KT1, NTL>(bx_lds, m, lane, g, j, zs[0], vreg, xr[0], yr);
+    } else {
+      load_z_rows<KT1, 1>(a.state, n, m.q, row0, j, g, xr, zs);
+      lp = a.logp[rowc];
+    }
+    uint4 uacc = make_uint4(0u, 0u, 0u, 0u);
+    for (int it = a.it_begin; it < a.it_begin + a.n_iters; ++it) {
+      BGM_NO_HOIST();
+      if constexpr (WAVES == 8) {
+        const int mine = tiles_done * a.n_iters + (it - a.it_begin);
+        if (lane == 0) prog[wave_u] = mine;
+        const int other = __builtin_amdgcn_readfirstlane(prog[wave_u ^ 4]);
+        if (mine < other) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+      }
+      f32x4 zp[KT1];
+#pragma unroll
+      for (int t = 0; t < KT1; ++t) {
+        const f32x4 e = box_muller4(philox4x32_10(rowid, (unsigned)it, (unsigned)(g + 4 * t), TAG_PROP, a.k0, a.k1));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 16 * t + 4 * r + g;
+          zp[t][r] = (f < m.q) ? fmaf(a.q_sd, e[r], zs[0][t][r]) : zs[0][t][r];
+        }
+      }
+      const float lpp = causal_logp_bx3<KT1, NTL>(bx_lds, m, lane, g, j, zp, vreg, xr[0], yr);
+      if ((it & 3) == 0 || it == a.it_begin) uacc = philox4x32_10(rowid, (unsigned)it >> 2, 0u, TAG_ACC, a.k0, a.k1);
+      const unsigned w = (it & 2) ? ((it & 1) ? uacc.w : uacc.z) : ((it & 1) ? uacc.y : uacc.x);
+      const float u = u01_open(w);
+      const float ratio = fast_exp(fminf(lpp - lp, 0.0f));
+      const bool acc = u < ratio;
+#pragma unroll
+      for (int t = 0; t < KT1; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zs[0][t][r] = acc ? zp[t][r] : zs[0][t][r];
+      lp = acc ? lpp : lp;
+      const unsigned accmask = (unsigned)__popcll(__ballot(acc && valid && g == 0));
+      if (a.acc_count != nullptr && lane == 0) atomicAdd(&a.acc_count[slot * (long long)a.n_iters + (it - a.it_begin)], accmask);
+      if (it >= a.burn_in) {
+        const long long d = it - a.burn_in;
+        if (a.draws != nullptr && valid) {
+          float *dr = a.draws + (d * n + row) * (long long)m.q;
+#pragma unroll
+          for (int t = 0; t < KT1; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int f = 16 * t + 4 * r + g;
+              if (f < m.q) dr[f] = zs[0][t][r];
+            }
+        }
+        if constexpr (EFFECT != 0) {
+          causal_effects_bx3<KT1, EFFECT>(bx_lds, m, lane, g, j, zs[0], rowid, valid, row, n, (unsigned)it, d, a.n_keep, a.sample_y,
+                                          a.n_doses, a.x_values,
+                                          a.adrf_partial + slot * (long long)((EFFECT == 2) ? 2 : a.n_doses) * a.n_keep, a.ite, a.k0, a.k1);
+        }
+      }
+    }
+    store_z_rows<KT1, 1>(a.state, n, m.q, row0, j, g, zs);
+    if (g == 0 && valid) a.logp[row] = lp;
+    ++tiles_done;
+  }
+  if (lane == 0) prog[wave_u] = 0x7fffffff;
+}

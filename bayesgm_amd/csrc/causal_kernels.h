@@ -125,8 +125,8 @@ __device__ __forceinline__ void g_last_groups(const float *wl, const float *bl, 
 }
 
 // f / h tail:  64 -> 32 -> 8 -> 2   (f_units = h_units = [64, 32, 8]); a1 is the
-// activated first hidden layer.  Returns the raw outputs (mu, s) of every row group;
-// they are VALID IN LANE GROUP g = 0 ONLY (output features 0,1 live there).
+// activated first hidden layer.  Returns the raw outputs (mu, s) of every row group, valid in every lane
+// (the sampling blob replicates the two output columns for all lane groups, see above causal_effects).
 template <int R>
 __device__ __forceinline__ void fh_tail(const float *lds, int w2, int b2, int w3, int b3, int w4,
                                         int b4, int lane_off, int g,
@@ -138,7 +138,7 @@ __device__ __forceinline__ void fh_tail(const float *lds, int w2, int b2, int w3
   dense<2, 4, 1, R>(lds + w3, lds + b3, lane_off, g, a2, a3);
   lrelu_s_inplace<1, R>(a3);
   f32x4 a4[R][1];
-  dense<1, 4, 1, R>(lds + w4, lds + b4, lane_off, g, a3, a4);
+  dense<1, 2, 1, R>(lds + w4, lds + b4, lane_off, g, a3, a4);   // two K-steps: see the sampling-blob layout above causal_effects
 #pragma unroll
   for (int rr = 0; rr < R; ++rr) {
     mu[rr] = a4[rr][0][0];
@@ -213,7 +213,7 @@ __device__ __forceinline__ void causal_logp(const float *lds, const CausalMeta &
     dense_pair<2, 4, 1>(lds + m.wf3, lds + m.bf3, lds + m.wh3, lds + m.bh3, lane_off, g, f2, h2, f3, h3);
     lrelu_s_inplace<1, 1>(f3); lrelu_s_inplace<1, 1>(h3);
     f32x4 f4[1][1], h4[1][1];
-    dense_pair<1, 4, 1>(lds + m.wf4, lds + m.bf4, lds + m.wh4, lds + m.bh4, lane_off, g, f3, h3, f4, h4);
+    dense_pair<1, 2, 1>(lds + m.wf4, lds + m.bf4, lds + m.wh4, lds + m.bh4, lane_off, g, f3, h3, f4, h4);   // two K-steps (permuted layer-3 outputs)
     mu_y[0] = f4[0][0][0]; sr_y[0] = f4[0][0][1];
     mu_x[0] = h4[0][0][0]; sr_x[0] = h4[0][0][1];
   } else {
@@ -232,7 +232,7 @@ __device__ __forceinline__ void causal_logp(const float *lds, const CausalMeta &
   }
   PMARK(4);
   // ---- assemble -(loss_v + loss_x + loss_y + |z|^2/2)   (base.py:800-816)
-  // mu_x/sr_x/mu_y/sr_y are valid in lane group 0 only: their losses are evaluated there and
+  // the x / y losses are identical in the four lane groups of a row: they are counted once (lane group 0) and
   // folded into the per-lane partial that is summed over g, so one reduction serves all terms.
 #pragma unroll
   for (int rr = 0; rr < R; ++rr) {
@@ -390,7 +390,22 @@ __global__ __launch_bounds__(64 * WAVES) void causal_logpost_kernel(const float 
 // f first layer once at x = 0, doses as rank-1 updates, DB doses per pass.
 //   EFFECT 1: adrf_slot[k * n_keep + d] += sum over the wave's valid rows of y_k
 //   EFFECT 2: ite[row * n_keep + d] = y(x=1) - y(x=0)
+// Sampling-blob layout of the two small nets' tails (causal_scale_blob_kernel): the 8 outputs of layer 3 sit at tile positions
+// 4 (f >> 1) + (f & 1) -- accumulator registers r = 0, 1 of every lane group -- so layer 4 contracts over two K-steps instead of
+// four, and the two output columns of layer 4 (mu, s) are replicated at positions 4 g' + {0, 1}: every lane holds (mu, s) of its
+// row in registers 0 / 1 of the output tile.
+// Dose-response sums (EFFECT 1, one row tile per wave): a pass evaluates four doses at once (independent MFMA chains sharing the
+// A fragments); afterwards lane group g owns dose e = g of the pass: ONE softplus / sqrt / noise FMA, ONE DPP row reduction and
+// ONE 4-lane atomic per pass instead of four of each.  Outcome noise of dose k = word (k & 3) of Philox(row, it, k >> 2,
+// TAG_YNOISE) (oracle/causal.py).  Sixteen doses at a time, lane group g evaluates Philox call 4c + g ONCE and pass p uses its
+// word p for dose 16c + 4g + p, so the noise is consumed by the lane group that produced it (2 instead of 5 Philox evaluations
+// per kept draw at 20 doses); a remainder of fewer than four calls is evaluated by all lane groups (call t, dose 4t + g = word g).
 // ---------------------------------------------------------------------------
+// value of the lane's own group: v[g]
+__device__ __forceinline__ float pick_by_group(int g, float v0, float v1, float v2, float v3) {
+  return g == 0 ? v0 : (g == 1 ? v1 : (g == 2 ? v2 : v3));
+}
+
 template <int KT1, int KSL1, int R, int EFFECT>
 __device__ __forceinline__ void causal_effects(const float *lds, const CausalMeta &m, int lane_off, int g, int j,
                                                int lane, const f32x4 (&zs)[R][KT1], const unsigned (&rowid)[R],
@@ -413,17 +428,23 @@ __device__ __forceinline__ void causal_effects(const float *lds, const CausalMet
   for (int t = 0; t < 4; ++t) wx[t] = *reinterpret_cast<const f32x4 *>(lds + m.wxf + 16 * t + 4 * g);
   const int nd = (EFFECT == 2) ? 2 : n_doses;
   constexpr int DB = (EFFECT == 2) ? 2 : 4;  // doses evaluated per pass (independent MFMA chains)
-  for (int kb = 0; kb < (nd + 3) / 4; ++kb) {
-    BGM_NO_HOIST();
-    f32x4 nz[R];
+  constexpr bool GROUPED = (EFFECT == 1 && R == 1);   // lane group g finishes dose e = g of a pass (see above)
+  const int n_calls = (nd + 3) >> 2, n_own = GROUPED ? (n_calls & ~3) : 0;   // Philox calls [0, n_own) in groups of four
+  f32x4 nz[R];
 #pragma unroll
-    for (int rr = 0; rr < R; ++rr)
-      nz[rr] = sample_y ? box_muller4(philox4x32_10(rowid[rr], it, (unsigned)kb, TAG_YNOISE, k0, k1))
-                        : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int rr = 0; rr < R; ++rr) nz[rr] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int kb = 0; kb < n_calls; ++kb) {       // one pass of DB doses per Philox call
+    BGM_NO_HOIST();
+    const bool own = kb < n_own;
+    const int c4 = kb & ~3, p4 = kb & 3;
+    if (sample_y && (!own || p4 == 0)) {
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr) nz[rr] = box_muller4(philox4x32_10(rowid[rr], it, (unsigned)(own ? c4 + g : kb), TAG_YNOISE, k0, k1));
+    }
     float xk[DB];
 #pragma unroll
     for (int e = 0; e < DB; ++e) {
-      const int k = 4 * kb + e;
+      const int k = own ? 4 * (c4 + e) + p4 : 4 * kb + e;
       xk[e] = (EFFECT == 2) ? (e == 0 ? 1.0f : 0.0f) : x_values[k < nd ? k : nd - 1];
     }
     float mu[DB * R], sr[DB * R];
@@ -480,7 +501,7 @@ __device__ __forceinline__ void causal_effects(const float *lds, const CausalMet
       }
       const float *w4 = lds + m.wf4 + lane_off;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < 2; ++s) {        // the 8 inputs occupy K-steps 0 and 1 (permuted layer-3 outputs)
         const float af = w4[s * 16];
 #pragma unroll
         for (int e = 0; e < DB; ++e) a4[e] = BGM_MFMA(af, lrelu_s(a3[e][s]), a4[e]);
@@ -500,6 +521,19 @@ __device__ __forceinline__ void causal_effects(const float *lds, const CausalMet
 #pragma unroll
             for (int r = 0; r < 4; ++r) a1[e * R + rr][t][r] = lrelu_s(fmaf(wx[t][r], xk[e], base[rr][t][r]));
       fh_tail<DB * R>(lds, m.wf2, m.bf2, m.wf3, m.bf3, m.wf4, m.bf4, lane_off, g, a1, mu, sr);
+    }
+    if constexpr (GROUPED) {
+      const int k = own ? 4 * (c4 + g) + p4 : 4 * kb + g;          // this lane group's dose of the pass ...
+      const float mu_m = pick_by_group(g, mu[0], mu[1], mu[2], mu[3]), sr_m = pick_by_group(g, sr[0], sr[1], sr[2], sr[3]);
+      const float s2 = (m.sig2_y > 0.0f) ? m.sig2_y : softplus_f(sr_m) + BGM_EPS;
+      // ... and its noise word: word p4 of its own call (rotated into word 0 pass by pass), or word g of the shared call
+      const float noise = own ? nz[0][0] : pick_by_group(g, nz[0][0], nz[0][1], nz[0][2], nz[0][3]);
+      if (own) nz[0] = f32x4{nz[0][1], nz[0][2], nz[0][3], nz[0][0]};
+      float y = sample_y ? fmaf(__builtin_sqrtf(s2), noise, mu_m) : mu_m;
+      y = (valid[0] && k < nd) ? y : 0.0f;
+      const float tot = sum_over_j_to_lane15(y);
+      if (j == 15 && k < nd) unsafeAtomicAdd(adrf_slot + (long long)k * n_keep + d, tot);
+      continue;
     }
     float yk[DB][R];
 #pragma unroll
@@ -843,7 +877,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_effects_kernel(CausalEffKAr
       load_z_rows<KT1, 1>(a.draws + (long long)d * n * m.q, n, m.q, row0, j, g, xr, zin);
       causal_effects<KT1, KSL1, 1, EFFECT>(lds, m, lane_off, g, j, lane, zin, rowid, valid, row0, n, (unsigned)(a.burn_in + d), d,
                                            a.n_keep, a.sample_y, a.n_doses, a.x_values,
-                                           a.adrf_partial ? a.adrf_partial + slot * (long long)a.n_doses * a.n_keep : nullptr, a.ite,
+                                           a.adrf_partial + slot * (long long)a.n_doses * a.n_keep /* unused when EFFECT == 2 */, a.ite,
                                            a.k0, a.k1);
     }
   }

@@ -75,6 +75,7 @@ extern "C" int bgm_causal_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, co
   for (int l = 0; l < L; ++l) { d.beta[l] = o; o += d.dims[l + 1]; }
   d.n_params = o;
   egm_finish_disc(d);
+  d.fixed_norm = h->disc_norm;
   s->n_dz = (size_t)o;
   if ((int64_t)o != count) {
     bgm_egm_free_state(h);
@@ -202,7 +203,7 @@ extern "C" int bgm_causal_egm_sync(bgm_handle *h, void *stream_) {
     std::memcpy(n.theta.data(), tg.data() + off, n.count() * sizeof(float));
     off += n.count();
   }
-  h->blob_valid = false; h->eblob_valid = false;
+  h->blob_valid = false; h->bx_valid = false; h->eblob_valid = false;
   return BGM_OK;
 }
 

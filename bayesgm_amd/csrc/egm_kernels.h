@@ -37,6 +37,7 @@ struct EgmDisc {           // Discriminator: hidden layers with BatchNorm + tanh
   int dims[EGM_MAX_LAYERS + 1];          // in, h1..hL, 1
   int w[EGM_MAX_LAYERS], b[EGM_MAX_LAYERS], gamma[EGM_MAX_LAYERS], beta[EGM_MAX_LAYERS];   // offsets into theta_d
   int n_params;
+  int fixed_norm;                  // 0: BatchNormalization on batch statistics; 1: inference mode on the initial moving averages (mean 0, variance 1)
   int csum[EGM_MAX_LAYERS + 1];   // dims[1] + ... + dims[l]             (cache block of layer l at (2B+1) * csum[l])
   int dsum[EGM_MAX_LAYERS + 2];   // dims[0] + ... + dims[l-1]           (gradient-penalty da_l at B * dsum[l])
 };
@@ -283,12 +284,14 @@ __device__ __forceinline__ void egm_disc_fwd(const EgmCtx &c, const float *th, c
     float *uh_ = egm_dk_uhat(d, k, l, B), *sg_ = egm_dk_sigma(d, k, l, B), *ao_ = egm_dk_a(d, k, l + 1, B);
     egm_fwd(c, egm_dk_a(d, k, l, B), in, th + d.w[l], th + d.b[l], uh_, out, B, in, out, false);   // u (normalised in place below)
     for (int o = c.tid; o < out; o += EGM_THREADS) {
-      float mu = 0.0f;
-      for (int b = 0; b < B; ++b) mu += uh_[b * out + o];
-      mu /= (float)B;
-      float var = 0.0f;
-      for (int b = 0; b < B; ++b) { const float t = uh_[b * out + o] - mu; var = fmaf(t, t, var); }
-      var /= (float)B;
+      float mu = 0.0f, var = 1.0f;
+      if (!d.fixed_norm) {
+        for (int b = 0; b < B; ++b) mu += uh_[b * out + o];
+        mu /= (float)B;
+        var = 0.0f;
+        for (int b = 0; b < B; ++b) { const float t = uh_[b * out + o] - mu; var = fmaf(t, t, var); }
+        var /= (float)B;
+      }
       const float sg = sqrtf(var + EGM_BN_EPS);
       sg_[o] = sg;
       const float ga = th[d.gamma[l] + o], be = th[d.beta[l] + o];
@@ -304,7 +307,12 @@ __device__ __forceinline__ void egm_disc_fwd(const EgmCtx &c, const float *th, c
 }
 
 // x - mean_b x - uhat * mean_b(x uhat), per feature column o (one thread per column)
-__device__ __forceinline__ void egm_bn_proj_col(float *x, const float *uhat, int B, int out, int o, float scale) {
+// (fixed statistics: the normalisation is a constant per-column scale, nothing flows through mean / variance)
+__device__ __forceinline__ void egm_bn_proj_col(float *x, const float *uhat, int B, int out, int o, float scale, int fixed_norm = 0) {
+  if (fixed_norm) {
+    for (int b = 0; b < B; ++b) x[b * out + o] *= scale;
+    return;
+  }
   float m1 = 0.0f, m2 = 0.0f;
   for (int b = 0; b < B; ++b) { m1 += x[b * out + o]; m2 = fmaf(x[b * out + o], uhat[b * out + o], m2); }
   m1 /= (float)B; m2 /= (float)B;
@@ -371,8 +379,8 @@ __device__ __forceinline__ void egm_disc_bwd(const EgmCtx &c, const float *th, f
       float *pg = gr + d.gamma[l] + o, *pb = gr + d.beta[l] + o;
       *pg = accumulate ? *pg + s * gg : s * gg;
       *pb = accumulate ? *pb + s * gb : s * gb;
-      egm_bn_proj_col(du, uh_, B, out, o, 1.0f / sg_[o]);
-      if (sbar) {
+      egm_bn_proj_col(du, uh_, B, out, o, 1.0f / sg_[o], d.fixed_norm);
+      if (sbar && !d.fixed_norm) {
         const float sb = sbar[o] / (float)B;
         for (int b = 0; b < B; ++b) du[b * out + o] = fmaf(sb, uh_[b * out + o], du[b * out + o]);
       }
@@ -415,7 +423,7 @@ __device__ __forceinline__ float egm_disc_gp(const EgmCtx &c, const float *th, f
         dhat_[t] = dy * ga;
         du_[t] = dy * ga;
       }
-      egm_bn_proj_col(du_, uh_, B, out, o, 1.0f / sg_[o]);
+      egm_bn_proj_col(du_, uh_, B, out, o, 1.0f / sg_[o], d.fixed_norm);
     }
     __syncthreads();
     egm_bwd_in(c, du_, out, th + d.w[l], egm_gp_da(d, G, l, B), in, B, in, out, false);
@@ -454,15 +462,15 @@ __device__ __forceinline__ float egm_disc_gp(const EgmCtx &c, const float *th, f
         m2 = fmaf(dhat_[t], uh_[t], m2);
         tu = fmaf(du_bar[t] / sg, uh_[t], tu);
       }
-      sbar[o] = -sb / sg;
+      sbar[o] = d.fixed_norm ? 0.0f : -sb / sg;
       m2 /= (float)B; tu /= (float)B;
       for (int b = 0; b < B; ++b) {
         const int t = b * out + o;
         const float tt = du_bar[t] / sg;
-        ubar[t] = -(tt * m2 + dhat_[t] * tu);
+        ubar[t] = d.fixed_norm ? 0.0f : -(tt * m2 + dhat_[t] * tu);
         tmp[t] = tt;
       }
-      egm_bn_proj_col(tmp, uh_, B, out, o, 1.0f);          // dhat_bar
+      egm_bn_proj_col(tmp, uh_, B, out, o, 1.0f, d.fixed_norm);          // dhat_bar
       float gg = 0.0f;
       for (int b = 0; b < B; ++b) {
         const int t = b * out + o;

@@ -382,6 +382,7 @@ extern "C" int bgm_causal_fit_end(bgm_handle *h, void *stream_) {
     BGM_HIP_CHECK(hipMemcpy(n.theta.data(), h->theta_dev + off, sizeof(float) * n.count(), hipMemcpyDeviceToHost));
     off += n.count();
   }
+  h->bx_valid = false;   // the split-precision sampling blob is packed from the host copies refreshed above
   fit_free(h);   // forward blob on the device is already current (blob_valid stays true)
   return BGM_OK;
 }

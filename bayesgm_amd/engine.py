@@ -68,6 +68,14 @@ class CausalEngine(object):
         _lib.check(self.lib.bgm_create(C.byref(self.h), self.device.index), "bgm_create")
         _lib.check(self.lib.bgm_causal_configure(self.h, C.byref(cfg)), "bgm_causal_configure")
 
+    def set_precision(self, mode):
+        """Arithmetic of logpost / mh_run launched afterwards: "fp32" (default) | "bf16x3" (bgm_causal_set_precision)."""
+        _lib.check(self.lib.bgm_causal_set_precision(self.h, {"fp32": 0, "bf16x3": 1}[mode]), "bgm_causal_set_precision")
+
+    def set_disc_norm(self, mode):
+        """BatchNormalization mode of the EGM discriminators opened afterwards: "batch" | "fixed" (bgm_set_disc_norm)."""
+        _lib.check(self.lib.bgm_set_disc_norm(self.h, {"batch": 0, "fixed": 1}[mode]), "bgm_set_disc_norm")
+
     def close(self):
         if getattr(self, "h", None) is not None and self.h:
             self.lib.bgm_destroy(self.h)
@@ -288,12 +296,6 @@ class CausalEngine(object):
     def egm_end(self):
         _lib.check(self.lib.bgm_causal_egm_end(self.h, self._stream()), "bgm_causal_egm_end")
 
-    def clock_probe(self, iters=200000):
-        """(shader MHz, fp32-MFMA TFLOP/s) sustained under a pure 16x16x4 fp32 MFMA load."""
-        mhz, tf = C.c_double(), C.c_double()
-        _lib.check(self.lib.bgm_debug_clock_probe(self.h, int(iters), C.byref(mhz), C.byref(tf)), "bgm_debug_clock_probe")
-        return mhz.value, tf.value
-
     def timing_enable(self, on=True):
         _lib.check(self.lib.bgm_timing_enable(self.h, int(on)), "bgm_timing_enable")
 
@@ -391,6 +393,10 @@ class BgmEngine(object):
         self.h = C.c_void_p()
         _lib.check(self.lib.bgm_create(C.byref(self.h), self.device.index), "bgm_create")
         _lib.check(self.lib.bgm_bgm_configure(self.h, C.byref(cfg)), "bgm_bgm_configure")
+
+    def set_disc_norm(self, mode):
+        """BatchNormalization mode of the EGM discriminators opened afterwards: "batch" | "fixed" (bgm_set_disc_norm)."""
+        _lib.check(self.lib.bgm_set_disc_norm(self.h, {"batch": 0, "fixed": 1}[mode]), "bgm_set_disc_norm")
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:

@@ -57,6 +57,8 @@ class BGM(object):
         if device is None:     # BGM_DEVICE: dev aid (several ranks on one GPU over gloo)
             device = int(os.environ.get("BGM_DEVICE", os.environ.get("LOCAL_RANK", 0)))
         self.engine = BgmEngine(xd, q, g_units=p["g_units"], device=device)
+        from .causalbgm import _disc_norm
+        self.engine.set_disc_norm(_disc_norm(p))
         self.engine.set_weights(self.g)
         if self.timestamp is None:
             self.timestamp = datetime.datetime.now().astimezone().strftime('%Y%m%d_%H%M%S')
@@ -231,6 +233,7 @@ class BGM(object):
         grad = torch.empty(n_params, device=dev)
         loss = torch.zeros(4, device=dev, dtype=torch.float64)
         self.history_loss = []
+        self.fit_history = []       # per-epoch row means of the theta-phase losses (the reference shows them in its progress bar)
         if verbose:
             print('Iterative Updating Starts ...')
         try:
@@ -246,12 +249,14 @@ class BGM(object):
                     eng.fit_theta_apply(grad, self._p['lr_theta'])
                     eng.fit_z_step(x, self.data_z, idx, self._p['lr_z'], loss)
                     n_used += batch_size
+                l = loss.cpu().numpy() / max(1, n_used)
+                self.fit_history.append(dict(epoch=epoch, loss_x=float(l[0] * (world if dist_on else 1)), loss_mse_x=float(l[1] / eng.p),
+                                             loss_px_z=float(l[2] * (world if dist_on else 1))))
                 if epoch % epochs_per_eval == 0:
                     self.g = eng.get_weights()
                     mse_x = self._evaluate_sharded(data_loc, self.data_z, n_all)
                     self.history_loss.append(mse_x)
                     if verbose and parallel.rank() == 0:
-                        l = loss.cpu().numpy() / max(1, n_used)
                         print('Epoch [%d/%d]: loss_x [%.4f], loss_mse_x [%.4f], MSE_x: %.4f\n'
                               % (epoch, epochs, l[0] * (world if dist_on else 1), l[1] / eng.p, mse_x))
                     if self._p['save_model'] and parallel.rank() == 0:

@@ -84,6 +84,8 @@ class BGMBayes(BGM):
         self._warned_noise = False
         self.engine = BvnEngine(xd, q, g_units=p["g_units"], kl_weight=p["kl_weight"], max_batch=self._max_batch, device=device,
                                 hmc_frozen_noise=(mode == "frozen"))
+        from .causalbgm import _disc_norm
+        self.engine.set_disc_norm(_disc_norm(p))
         self.engine.begin(self.g)
         if self.timestamp is None:
             self.timestamp = datetime.datetime.now().astimezone().strftime('%Y%m%d_%H%M%S')

@@ -14,6 +14,8 @@ import os
 import numpy as np
 import torch
 
+DISC_NORM_DEFAULT = "batch"
+
 from .. import _lib, parallel
 from ..engine import CausalEngine
 from ..datasets import Gaussian_sampler
@@ -32,6 +34,15 @@ def _glorot(rs, fan_in, fan_out):
 def _init_mlp(rs, dims):
     """Keras Dense defaults: glorot-uniform kernel, zero bias (networks/base.py:17-26)."""
     return [(_glorot(rs, dims[i], dims[i + 1]), np.zeros(dims[i + 1], np.float32)) for i in range(len(dims) - 1)]
+
+
+def _disc_norm(p):
+    """params['disc_norm'] (build option): BatchNormalization mode of the EGM discriminators, "batch" | "fixed"
+    (include/bgm_hip.h bgm_set_disc_norm)."""
+    mode = p.get("disc_norm", DISC_NORM_DEFAULT)
+    if mode not in ("batch", "fixed"):
+        raise ValueError("params['disc_norm'] must be 'batch' or 'fixed'")
+    return mode
 
 
 class CausalBGM(object):
@@ -69,6 +80,13 @@ class CausalBGM(object):
                                    f_units=p["f_units"], h_units=p["h_units"], e_units=p["e_units"],
                                    sigma_v=params.get("sigma_v"), sigma_x=params.get("sigma_x"),
                                    sigma_y=params.get("sigma_y"), device=device)
+        self.engine.set_disc_norm(_disc_norm(p))
+        # params['mh_precision'] (build option): arithmetic of the posterior-sampling kernels of predict /
+        # metropolis_hastings_sampler / get_log_posterior: "fp32" (default, the reference's arithmetic) or "bf16x3" (split
+        # precision on the bf16 matrix pipe)
+        if p.get("mh_precision", "fp32") not in ("fp32", "bf16x3"):
+            raise ValueError("params['mh_precision'] must be 'fp32' or 'bf16x3'")
+        self.engine.set_precision(p.get("mh_precision", "fp32"))
         self._push_weights()
         if self.timestamp is None:
             self.timestamp = datetime.datetime.now().astimezone().strftime('%Y%m%d_%H%M%S')
@@ -235,9 +253,12 @@ class CausalBGM(object):
         eng = self.engine
         n_params = eng.fit_begin(n_loc, b_loc)
         grad = torch.empty(n_params, device=dev, dtype=torch.float32)
-        loss = torch.zeros(8, device=dev, dtype=torch.float64)
+        loss = torch.zeros(8, device=dev, dtype=torch.float64)       # theta phase: row sums of loss_v, |v-mu|^2, loss_x, ...
+        loss_z = torch.zeros(8, device=dev, dtype=torch.float64)     # Z phase: [6] = row sums of the negative log joint
         lazy = (z_adam == "lazy")
         best_loss = np.inf
+        # per-epoch trace (row means over the epoch's minibatches; the reference shows the last minibatch in its progress bar)
+        self.fit_history = []
         if verbose:
             print('Iterative Updating Starts ...')
         try:
@@ -245,21 +266,27 @@ class CausalBGM(object):
                 # permutation of the LOCAL rows (np.random.choice(N, N, replace=False), base.py:489)
                 sample_idx = torch.from_numpy(np.random.choice(n_loc, n_loc, replace=False).astype(np.int32)).to(dev)
                 loss.zero_()
-                n_steps = 0
+                loss_z.zero_()
+                n_rows = 0
                 for i in range(0, n_use, b_loc):
                     idx = sample_idx[i:min(i + b_loc, n_use)]
                     bg = int(idx.numel()) * world
                     eng.fit_theta_grad(x, y, v, self.data_z, idx, bg, grad, loss)
                     parallel.all_reduce_sum_(grad)                       # C1: fused g|f|h gradient
                     eng.fit_theta_apply(grad, self._p['lr_theta'])
-                    eng.fit_z_step(x, y, v, self.data_z, zm, zv, idx, bg, self._p['lr_z'], lazy, loss)
-                    n_steps += 1
+                    eng.fit_z_step(x, y, v, self.data_z, zm, zv, idx, bg, self._p['lr_z'], lazy, loss_z)
+                    n_rows += int(idx.numel())
+                l = loss.cpu().numpy() / max(1, n_rows)
+                lz = loss_z.cpu().numpy() / max(1, n_rows)
+                self.fit_history.append(dict(epoch=epoch, loss_v=float(l[0]), loss_mse_v=float(l[1] / eng.v_dim), loss_x=float(l[2]),
+                                             loss_mse_x=float(l[3]), loss_y=float(l[4]), loss_mse_y=float(l[5]),
+                                             loss_postrior_z=float(lz[6])))
                 if verbose:
-                    l = loss.cpu().numpy() / max(1, n_loc)
-                    print('Epoch [%d/%d]: loss_px_z [%.4f], loss_py_z [%.4f], loss_pv_z [%.4f], loss_postrior_z [%.4f]'
-                          % (epoch, epochs, l[2], l[4], l[0], l[6]))
+                    print('Epoch [%d/%d]: loss_px_z [%.4f], loss_mse_x [%.4f], loss_py_z [%.4f], loss_mse_y [%.4f], loss_pv_z [%.4f], '
+                          'loss_mse_v [%.4f], loss_postrior_z [%.4f]' % (epoch, epochs, l[2], l[3], l[4], l[5], l[0], l[1] / eng.v_dim, lz[6]))
                 if epoch % epochs_per_eval == 0:
                     causal_pre, mse_x, mse_y, mse_v = self._evaluate_dev(x, y, v, self.data_z, n_total, lo_r)
+                    self.fit_history[-1].update(mse_x=float(mse_x), mse_y=float(mse_y), mse_v=float(mse_v))
                     if verbose:
                         print('Epoch [%d/%d]: MSE_x: %.4f, MSE_y: %.4f, MSE_v: %.4f\n' % (epoch, epochs, mse_x, mse_y, mse_v))
                     if epoch >= startoff and mse_y < best_loss:
@@ -355,42 +382,55 @@ class CausalBGM(object):
             x_values = np.array([x_values], dtype=float) if np.isscalar(x_values) else np.array(x_values, dtype=float)
         data_x, data_y, data_v = data
         n_test = len(data_x)
-        lo_r, hi_r = parallel.shard_range(n_test)
-        x = self._dev(data_x[lo_r:hi_r]).reshape(-1)
-        y = self._dev(data_y[lo_r:hi_r]).reshape(-1)
-        v = self._dev(data_v[lo_r:hi_r])
-        n_loc = hi_r - lo_r
+        bs = max(1, int(bs))
         adaptive = (q_sd is None) or (q_sd <= 0)
         seed = self._next_seed()
         if verbose:
             print('MCMC Latent Variable Sampling ...')
         eng = self.engine
+        dev = eng.device
         total_it = burn_in + n_mcmc
+        world, rank = parallel.world_size(), parallel.rank()
+        # Row blocks.  A fixed proposal scale makes every chain independent of its block (the Philox stream is keyed by the
+        # global row), so each rank samples its contiguous shard in one piece.  With the adaptive scale (q_sd <= 0) the
+        # reference adapts q_sd per `bs`-block from that block's acceptance window (base.py:632-637, 880-893): the blocks are
+        # the reference's [start, start + bs) and are dealt to the ranks whole.
+        if adaptive:
+            blocks = [(s0, min(s0 + bs, n_test)) for s0 in range(0, n_test, bs)][rank::world]
+        else:
+            lo_r, hi_r = parallel.shard_range(n_test)
+            blocks = [(lo_r, hi_r)] if hi_r > lo_r else []
+        if binary:        # keep the [rows x n_mcmc] draw matrix of one launch below ~32 GiB
+            max_rows = max(16, int((32 << 30) // (4 * max(1, n_mcmc))))
+            if not adaptive:
+                blocks = [(s0, min(s0 + max_rows, e0)) for (b0, e0) in blocks for s0 in range(b0, e0, max_rows)]
         acc_tail = 0.0
         if binary:
-            # row blocks so that the [rows x n_mcmc] draw matrix stays below ~32 GiB
-            max_rows = max(16, int((32 << 30) // (4 * max(1, n_mcmc))))
-            means, los, his = [], [], []
-            for s in range(0, n_loc, max_rows):
-                e = min(s + max_rows, n_loc)
-                out = eng.mh_sample(x[s:e], y[s:e], v[s:e], burn_in, n_mcmc, q_sd, seed, effect=_lib.EFFECT_ITE,
-                                    sample_y=sample_y, row_base=lo_r + s, adaptive=adaptive)
+            res = torch.zeros((3, n_test), device=dev, dtype=torch.float32)     # mean, lower, upper (this rank's rows filled)
+        else:
+            sums = torch.zeros((len(x_values), n_mcmc), device=dev, dtype=torch.float64)   # adrf_draw_sums (base.py:660)
+        for (s0, e0) in blocks:
+            x = self._dev(data_x[s0:e0]).reshape(-1)
+            y = self._dev(data_y[s0:e0]).reshape(-1)
+            v = self._dev(data_v[s0:e0])
+            if binary:
+                out = eng.mh_sample(x, y, v, burn_in, n_mcmc, q_sd, seed, effect=_lib.EFFECT_ITE, sample_y=sample_y,
+                                    row_base=s0, adaptive=adaptive)
                 mean, lo, hi = eng.row_mean_quantiles(out["ite"], alpha / 2, 1 - alpha / 2)
-                means.append(mean); los.append(lo); his.append(hi)
-                acc_tail += float(out["acc_count"][max(0, total_it - 100):].sum().item())
-            mean = parallel.all_gather_rows(torch.cat(means), n_test)
-            lo = parallel.all_gather_rows(torch.cat(los), n_test)
-            hi = parallel.all_gather_rows(torch.cat(his), n_test)
-            self._report_acceptance(acc_tail, min(100, total_it), n_test, verbose)
-            return mean.cpu().numpy(), torch.stack([lo, hi], dim=1).cpu().numpy()
-        out = eng.mh_sample(x, y, v, burn_in, n_mcmc, q_sd, seed, effect=_lib.EFFECT_ADRF, x_values=x_values,
-                            sample_y=sample_y, row_base=lo_r, adaptive=adaptive)
-        acc_tail = float(out["acc_count"][max(0, total_it - 100):].sum().item())
-        sums = out["adrf"].double() * float(n_loc)           # adrf_draw_sums (base.py:660)
-        parallel.all_reduce_sum_(sums)                        # C3: [n_doses x n_mcmc]
+                res[0, s0:e0], res[1, s0:e0], res[2, s0:e0] = mean, lo, hi
+            else:
+                out = eng.mh_sample(x, y, v, burn_in, n_mcmc, q_sd, seed, effect=_lib.EFFECT_ADRF, x_values=x_values,
+                                    sample_y=sample_y, row_base=s0, adaptive=adaptive)
+                sums += out["adrf"].double() * float(e0 - s0)
+            acc_tail += float(out["acc_count"][max(0, total_it - 100):].sum().item())
+        self._report_acceptance(acc_tail, min(100, total_it), n_test, verbose)
+        if binary:
+            parallel.all_reduce_sum_(res)                         # disjoint row sets: the sum is the gather
+            res = res.cpu().numpy()
+            return res[0], np.stack([res[1], res[2]], axis=1)
+        parallel.all_reduce_sum_(sums)                            # C3: [n_doses x n_mcmc]
         causal_effects = (sums / float(n_test)).float().contiguous()
         adrf, lo, hi = eng.row_mean_quantiles(causal_effects, alpha / 2, 1 - alpha / 2)
-        self._report_acceptance(acc_tail, min(100, total_it), n_test, verbose)
         return adrf.cpu().numpy(), torch.stack([lo, hi], dim=1).cpu().numpy()
 
     def _report_acceptance(self, acc_tail, window, n_test, verbose):

@@ -24,7 +24,7 @@ from .. import parallel
 from ..bnn_engine import BnnEngine, NETS, flatten_bnn
 from ..datasets import Gaussian_sampler
 from ..utils import save_data
-from .causalbgm import CausalBGM, _DEFAULTS, _glorot
+from .causalbgm import CausalBGM, _DEFAULTS, _glorot, _disc_norm
 
 
 def _init_bnn(rs, dims):
@@ -76,6 +76,7 @@ class CausalBGMBayes(CausalBGM):
         self.engine = BnnEngine(p["v_dim"], z, binary_treatment=p["binary_treatment"], g_units=p["g_units"], e_units=p["e_units"],
                                 f_units=p["f_units"], h_units=p["h_units"], kl_weight=p["kl_weight"], max_batch=64,
                                 norm_mode={"batch": 0, "fixed": 1}[p.get("bnn_norm", "batch")], device=device)
+        self.engine.set_disc_norm(_disc_norm(p))
         self.engine.begin(self.nets)
         if self.timestamp is None:
             self.timestamp = datetime.datetime.now().astimezone().strftime('%Y%m%d_%H%M%S')

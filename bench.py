@@ -148,6 +148,48 @@ def bayesian_leg(params, data, x_values, n_loc, args, device):
             "flop_per_row_transition": flop_row}
 
 
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
+
+
+def bf16x3_leg(model, data, x_values, n_loc, args, z_dims, flop_row_transition, flop_row_keep, seed_counter):
+    """Secondary measurement (not `value`, which stays fp32 = the reference's arithmetic): the same predict with the opt-in
+    split-precision kernels (params['mh_precision'] = 'bf16x3').  `achieved` prices the ALGORITHMIC FLOP
+    (the fp32 count) -- an "fp32-equivalent" rate; `executed_bf16_tflops` counts the three bf16 products per contraction that
+    the matrix pipe actually runs, against the dense bf16 peak."""
+    import torch
+    eng = model.engine
+    eng.set_precision("bf16x3")
+    try:
+        model.predict(data, alpha=0.01, n_mcmc=8, burn_in=8, x_values=x_values, q_sd=1.0, sample_y=True, verbose=0)   # packs
+        torch.cuda.synchronize()
+        eng.timing_enable(True)
+        eng.timing_read(kind=-1, reset=True)
+        model._seed_counter = seed_counter - 1       # the Philox streams of the last fp32 step: the two ADRFs are comparable
+        t0 = time.perf_counter()
+        adrf, _ = model.predict(data, alpha=0.01, n_mcmc=args.n_mcmc, burn_in=args.burn_in, x_values=x_values, q_sd=1.0,
+                                sample_y=True, verbose=0)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n_b, ms_b = eng.timing_read(kind=0, reset=False)
+        n_k, ms_k = eng.timing_read(kind=1, reset=True)
+        eng.timing_enable(False)
+    finally:
+        eng.set_precision("fp32")
+    flop = (flop_row_transition * args.burn_in + flop_row_keep * args.n_mcmc) * n_loc
+    kern_s = (ms_b + ms_k) * 1e-3
+    ach = flop / kern_s / 1e12 if kern_s > 0 else None
+    return {"value": n_loc * (args.burn_in + args.n_mcmc) / dt, "unit": "MH transitions/s", "seconds": dt,
+            "sample": f"CausalBGM(mh_precision='bf16x3').predict, N={n_loc}, burn_in={args.burn_in}, n_mcmc={args.n_mcmc}, "
+                      f"{len(x_values)} doses (one call)",
+            "acceptance_rate": model.last_acceptance_rate, "adrf_head": [float(a) for a in adrf[:3]],
+            "burn_in_kernel_ms": ms_b / max(1, n_b), "keep_kernel_ms": ms_k / max(1, n_k),
+            "roofline": {"bound": "mfma", "kernel": "causal_mh_bx3_kernel (burn-in + keep launches)",
+                         "achieved": ach, "unit": "TFLOP/s (algorithmic fp32-equivalent FLOP)",
+                         "executed_bf16_tflops": 3.0 * ach if ach else None, "peak": PEAK_BF16_MFMA_TFLOPS,
+                         "frac": (3.0 * ach / PEAK_BF16_MFMA_TFLOPS) if ach else None,
+                         "note": "three bf16 products per contraction; frac = executed bf16 FLOP/s over the dense bf16 peak"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,6 +202,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bayesian", action="store_true", help="skip the secondary use_bnn=True measurement (N=1 only)")
     ap.add_argument("--no-fit", action="store_true", help="skip the secondary fit-throughput measurement (N=1 only)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --rows per GPU (default); strong: --rows in TOTAL, sharded over the GPUs (BASELINE configs[3]: N=1e6 over 8 GPUs)")
+    ap.add_argument("--no-bf16x3", action="store_true", help="skip the secondary split-precision (bf16 x 3) measurement (N=1 only)")
+    ap.add_argument("--no-accuracy", action="store_true", help="skip the accuracy leg (fit on the tutorial panel + ADRF error; N=1 only)")
     args = ap.parse_args()
 
     import torch
@@ -186,7 +232,11 @@ def main():
     from bayesgm_amd.models import CausalBGM
     from bayesgm_amd import parallel
 
-    n_loc, p = int(args.n), args.p
+    p = args.p
+    if args.scaling == "strong":       # total work fixed: this rank's share of --rows
+        n_loc = int(args.n) // world + (1 if rank < int(args.n) % world else 0)
+    else:
+        n_loc = int(args.n)
     z_dims = [1, 1, 1, 7]
     params = dict(dataset="Sim_Hirano_Imbens", output_dir=".", save_res=False, save_model=False,
                   binary_treatment=False, use_bnn=False, z_dims=z_dims, v_dim=p, lr_theta=1e-4, lr_z=1e-4,
@@ -196,7 +246,12 @@ def main():
     eng = model.engine
     x, y, v = make_panel(n_loc, p, seed=rank, device=device)  # each rank its own panel (weak scaling)
     x_values = np.linspace(0, 3, 20)
-    n_total = n_loc * world
+    n_total = int(args.n) if args.scaling == "strong" else n_loc * world
+    n_ranks_seen = world
+    if world > 1:      # the collective the run depends on works, and every rank is there
+        t1 = torch.ones(1, device=device)
+        dist.all_reduce(t1)
+        n_ranks_seen = int(t1.item())
 
     class Shard:  # predict() shards data[lo:hi] by rank; hand it this rank's rows for any slice
         def __init__(self, t): self.t = t
@@ -227,6 +282,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     eng.timing_enable(False)
+    seed_counter_last = model._seed_counter
+
+    # the one collective of the step (C3: ADRF draw sums [n_doses x n_mcmc], float64) timed alone, for its share of a step
+    allreduce_ms = None
+    if world > 1:
+        buf = torch.zeros((len(x_values), args.n_mcmc), dtype=torch.float64, device=device)
+        dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        allreduce_ms = 1e2 * (time.perf_counter() - t1)
 
     if rank == 0:
         iters = args.burn_in + args.n_mcmc
@@ -234,37 +302,64 @@ def main():
         info = eng.mh_info(n_loc)
         n_burn, ms_burn = eng.timing_read(kind=0, reset=False)
         n_keep_l, ms_keep = eng.timing_read(kind=1, reset=False)
-        roof = None
-        # HBM traffic cannot be collected from inside this process: use the committed PMC pass of the same kernel on the
-        # same panel shape, if there is one (per-launch read traffic is independent of the iteration count, see the file)
-        traffic = traffic_src = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                pm = json.load(f)
-            if pm["rows"] == n_loc and pm["p"] == p:
-                traffic, traffic_src = pm["hbm_read_bytes_per_launch"], "profiles/r01_pmc_traffic.json"
-        except (OSError, KeyError, ValueError):
-            pass
+        # HBM traffic cannot be collected from inside this process: use the committed PMC passes of the same kernels on the
+        # same panel shape, if there are any (per-launch read traffic is independent of the iteration count, see the file)
+        traffic = {}
+        traffic_src = None
+        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    pm = json.load(f)
+                if pm["rows"] == n_loc and pm["p"] == p:
+                    traffic = {"burn_in": pm.get("hbm_read_bytes_per_launch"), "keep": pm.get("hbm_read_bytes_per_launch_keep")}
+                    traffic_src = "profiles/" + name
+                    break
+            except (OSError, KeyError, ValueError):
+                pass
+        # algorithmic work: a transition = 2 MACs(g+f+h) FLOP per row (the cached current log-posterior is not
+        # re-evaluated); a retained draw adds the outcome net at every dose: 2 MACs(f) FLOP per row and dose
+        macs_f = (z_dims[0] + z_dims[1] + 1) * 64 + 64 * 32 + 32 * 8 + 8 * 2
+        n_doses = len(x_values)
+        flop_keep_row = info.flop_per_row_transition + n_doses * 2 * macs_f
+        inst = []
         if n_burn:
             avg = ms_burn / n_burn
             flop = info.flop_per_row_transition * n_loc * args.burn_in
-            ach = flop / (avg * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "causal_mh_kernel<EFFECT=0> (burn-in transitions)",
-                    "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "HBM read bytes per launch",
+            inst.append({"kernel": "causal_mh_kernel<EFFECT=0> (burn-in: transitions only)", "avg_launch_ms": avg, "launches": n_burn,
+                         "flop_per_row_iteration": info.flop_per_row_transition, "flop_per_launch": flop,
+                         "achieved": flop / (avg * 1e-3) / 1e12, "traffic": traffic.get("burn_in")})
+        if n_keep_l:
+            avg = ms_keep / n_keep_l
+            flop = flop_keep_row * n_loc * args.n_mcmc
+            inst.append({"kernel": "causal_mh_kernel<EFFECT=1> (keep phase: transition + outcome net at %d doses per retained draw)" % n_doses,
+                         "avg_launch_ms": avg, "launches": n_keep_l, "flop_per_row_iteration": flop_keep_row, "flop_per_launch": flop,
+                         "achieved": flop / (avg * 1e-3) / 1e12, "traffic": traffic.get("keep")})
+        roof = None
+        if inst:
+            tot_ms = sum(k["avg_launch_ms"] * k["launches"] for k in inst)
+            for k in inst:
+                k["frac"] = k["achieved"] / PEAK_FP32_MFMA_TFLOPS
+                k["share_of_kernel_time"] = k["avg_launch_ms"] * k["launches"] / tot_ms
+            dom = max(inst, key=lambda k: k["share_of_kernel_time"])       # the dominant instance is the one reported
+            roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": PEAK_FP32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": dom["frac"], "traffic": dom["traffic"], "traffic_unit": "HBM read bytes per launch",
                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": n_loc * (4 * p + 8),
-                    "avg_launch_ms": avg, "launches": n_burn, "flop_per_launch": flop,
-                    "keep_phase_avg_launch_ms": (ms_keep / n_keep_l) if n_keep_l else None}
+                    "avg_launch_ms": dom["avg_launch_ms"], "launches": dom["launches"], "flop_per_launch": dom["flop_per_launch"],
+                    "share_of_kernel_time": dom["share_of_kernel_time"], "instances": inst,
+                    "whole_predict_achieved": sum(k["flop_per_launch"] * k["launches"] for k in inst) / (tot_ms * 1e-3) / 1e12}
         out = {
             "metric": "posterior samples/sec (whole node), CausalBGM N=1e6 p=200",
             "value": value, "unit": "MH transitions/s (rows x (burn_in+n_mcmc) / t_predict)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (Sim_Hirano_Imbens generator, random-init glorot weights)",
-            "config": {"workload": f"CausalBGM.predict continuous treatment, N={n_loc} rows/GPU, p={p}, "
+            "config": {"workload": f"CausalBGM.predict continuous treatment, N={n_loc} rows/GPU ({n_total} in total), p={p}, "
                                    f"z_dims {z_dims}, burn_in={args.burn_in}, n_mcmc={args.n_mcmc}, q_sd=1.0, "
                                    f"20 doses, sample_y=True",
-                       "rows_per_gpu": n_loc, "p": p, "parallelism": f"dp{world} (rows sharded, ADRF all-reduce)"},
+                       "rows_per_gpu": n_loc, "rows_total": n_total, "p": p,
+                       "parallelism": f"dp{world} (rows sharded, ADRF all-reduce)"},
+            "n_ranks_in_collective": n_ranks_seen, "adrf_allreduce_ms": allreduce_ms,
+            "adrf_allreduce_share_of_step": (allreduce_ms / (1e3 * elapsed / args.steps)) if allreduce_ms is not None else None,
             "retained_draws_per_s": n_total * args.n_mcmc * args.steps / elapsed,
             "acceptance_rate": model.last_acceptance_rate,
             "adrf_head": [float(a) for a in adrf[:3]],
@@ -278,6 +373,10 @@ def main():
             out["bayesian_nets"] = bayesian_leg(params, data, x_values, n_loc, args, device)
         if not args.no_fit and world == 1:
             out["fit"] = fit_leg(model, x, y, v, n_loc)
+        if not args.no_bf16x3 and world == 1:
+            out["bf16x3"] = bf16x3_leg(model, data, x_values, n_loc, args, z_dims, info.flop_per_row_transition, flop_keep_row, seed_counter_last)
+            out["bf16x3"]["speedup_vs_fp32"] = out["bf16x3"]["value"] / value
+            out["bf16x3"]["adrf_max_abs_diff_vs_fp32_head"] = float(np.abs(np.array(out["bf16x3"]["adrf_head"]) - adrf[:3]).max())
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

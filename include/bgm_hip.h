@@ -65,6 +65,19 @@ const char *bgm_version(void);
 
 /* Create / destroy a per-device handle.  Synchronous. */
 int bgm_create(bgm_handle **out, int device);
+/* BatchNormalization mode of the Discriminator networks (networks/base.py:338-385) of every EGM warm-start session opened
+ * afterwards on this handle (bgm_causal_egm_begin, bgm_bnn_egm_begin, bgm_bgm_egm_begin, bgm_bvn_egm_begin):
+ *   0 (default of the library)  batch statistics -- `norm_layer(x)` inside a Model.call(training=True) under Keras' rule that an
+ *                               inner layer inherits the outer call's training mode;
+ *   1                           inference mode on the layer's initial moving averages (mean 0, variance 1), the behaviour the
+ *                               reference's published training log is consistent with. */
+int bgm_set_disc_norm(bgm_handle *h, int32_t mode);
+/* Arithmetic of the CausalBGM sampling kernels launched afterwards through bgm_causal_logpost / bgm_causal_mh_run:
+ *   0 (default)  fp32 MFMA -- the reference's arithmetic (causalbgm/base.py:765-904 run in float32);
+ *   1            split precision "bf16 x 3": weights and activations as sums of two bf16 numbers, three bf16 MFMA products per
+ *                contraction with fp32 accumulation (relative error ~6e-6 per layer against 2.4e-7 in fp32).  Same algorithm,
+ *                RNG streams and outputs; chains agree with the fp32 ones statistically, not draw for draw. */
+int bgm_causal_set_precision(bgm_handle *h, int32_t mode);
 int bgm_destroy(bgm_handle *h);
 
 /* Declare the model shape.  Synchronous.  replaces: CausalBGM.__init__ network
@@ -583,16 +596,6 @@ int bgm_bvn_egm_encode(bgm_handle *h, const float *x_dev, int64_t n, float *z_de
 int bgm_bvn_egm_sync(bgm_handle *h, void *stream);
 int bgm_bvn_egm_end(bgm_handle *h, void *stream);
 int bgm_bvn_end(bgm_handle *h, void *stream);
-
-/* Debug: throughput of the hand-scheduled 64x4-tile MFMA block alone (mode 1: fragments streamed from LDS; mode 0:
- * register operands only) with `waves_per_cu` waves on every CU. */
-int bgm_debug_group_probe(bgm_handle *h, int32_t mode, int32_t waves_per_cu, int32_t iters, double *mfma_tflops);
-int bgm_debug_clock_probe(bgm_handle *h, int32_t iters, double *shader_mhz, double *mfma_tflops);
-/* Measurement aid for the next step: one hidden 64 -> 64 layer + LeakyReLU chained `iters` times per wave
- * (8 waves on every CU), mode 0 = fp32 MFMA as the MH kernel today, mode 1 = split-precision bf16 x 3 on
- * v_mfma_f32_16x16x32_bf16.  out_host [16 x 64]: activations after `iters` layers; ns_per_layer: time of one layer. */
-int bgm_debug_bf16x3_probe(bgm_handle *h, int32_t mode, int32_t iters, const float *W_host, const float *x_host, float *out_host,
-                           double *ns_per_layer);
 
 #ifdef __cplusplus
 }

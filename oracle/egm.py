@@ -45,7 +45,14 @@ def init_disc(rng, in_dim, units, dtype=np.float32):
 
 
 def cast_disc(d, dtype):
-    return {k: [a.astype(dtype) for a in v] for k, v in d.items()}
+    return {k: ([a.astype(dtype) for a in v] if isinstance(v, list) else v) for k, v in d.items()}
+
+
+def _fixed(d):
+    """d["fixed_norm"] = True: the discriminator's BatchNormalization layers run in inference mode on their initial
+    moving averages (mean 0, variance 1) -- a constant per-column scale 1/sqrt(1 + eps) -- instead of on batch statistics
+    (the build's `disc_norm` option)."""
+    return bool(d.get("fixed_norm", False))
 
 
 def disc_forward(d, x):
@@ -55,8 +62,11 @@ def disc_forward(d, x):
     cache = []
     for l in range(L):
         u = a @ d["W"][l] + d["b"][l]
-        mu = u.mean(axis=0)
-        var = ((u - mu) ** 2).mean(axis=0)
+        if _fixed(d):
+            mu, var = np.zeros_like(u[0]), np.ones_like(u[0])
+        else:
+            mu = u.mean(axis=0)
+            var = ((u - mu) ** 2).mean(axis=0)
         sigma = np.sqrt(var + BN_EPS)
         uhat = (u - mu) / sigma
         a_out = np.tanh(uhat * d["gamma"][l] + d["beta"][l])
@@ -66,13 +76,15 @@ def disc_forward(d, x):
     return out, cache
 
 
-def _bn_proj(x, uhat):
-    """x - mean_b x - uhat * mean_b(x * uhat)   (the symmetric batch-norm backward projection)."""
+def _bn_proj(x, uhat, fixed=False):
+    """x - mean_b x - uhat * mean_b(x * uhat)   (the symmetric batch-norm backward projection); identity for fixed statistics."""
+    if fixed:
+        return x
     return x - x.mean(axis=0) - uhat * (x * uhat).mean(axis=0)
 
 
 def zero_disc_grads(d):
-    return {k: [np.zeros_like(a) for a in v] for k, v in d.items()}
+    return {k: [np.zeros_like(a) for a in v] for k, v in d.items() if isinstance(v, list)}
 
 
 def disc_backward(d, cache, dout, grads=None, a_bar=None, uhat_bar=None, sigma_bar=None, scale=1.0):
@@ -99,8 +111,8 @@ def disc_backward(d, cache, dout, grads=None, a_bar=None, uhat_bar=None, sigma_b
         duhat = dy * d["gamma"][l]
         if uhat_bar is not None:
             duhat = duhat + uhat_bar[l]
-        du = _bn_proj(duhat, uhat) / sigma
-        if sigma_bar is not None:       # explicit use of sigma_l in the adjoint network: d sigma / d u = uhat / B
+        du = _bn_proj(duhat, uhat, _fixed(d)) / sigma
+        if sigma_bar is not None and not _fixed(d):       # explicit use of sigma_l in the adjoint network: d sigma / d u = uhat / B
             du = du + sigma_bar[l] * uhat / uhat.shape[0]
         grads["W"][l] += scale * (a_in.T @ du)
         grads["b"][l] += scale * du.sum(axis=0)
@@ -118,7 +130,7 @@ def disc_input_gradient(d, cache):
         a_in, uhat, sigma, a_out = cache[l]
         dy = da * (1.0 - a_out ** 2)
         dhat = dy * d["gamma"][l]
-        du = _bn_proj(dhat, uhat) / sigma
+        du = _bn_proj(dhat, uhat, _fixed(d)) / sigma
         adj.append((da, dy, dhat, du))
         da = du @ d["W"][l].T
     return da, adj[::-1]
@@ -148,7 +160,9 @@ def gradient_penalty_and_grads(d, xhat, grads=None, scale=1.0):
         t = du_bar / sigma
         m2 = (dhat * uhat).mean(axis=0)
         uhat_bar[l] = -(t * m2 + dhat * (t * uhat).mean(axis=0))
-        dhat_bar = _bn_proj(t, uhat)
+        if _fixed(d):       # constant statistics: nothing flows through sigma or the projection
+            sigma_bar[l], uhat_bar[l] = np.zeros_like(sigma), np.zeros_like(uhat)
+        dhat_bar = _bn_proj(t, uhat, _fixed(d))
         # dhat = dy * gamma
         grads["gamma"][l] += scale * (dhat_bar * dy).sum(axis=0)
         dy_bar = dhat_bar * d["gamma"][l]

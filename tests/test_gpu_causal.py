@@ -151,12 +151,15 @@ def test_mh_row_base_offsets_rng_stream():
     assert torch.equal(full[:, 32:80], part)
 
 
-def test_adrf_effects_match_oracle_on_same_draws():
+@pytest.mark.parametrize("n_doses", [1, 3, 4, 7, 16, 17, 20, 33])
+def test_adrf_effects_match_oracle_on_same_draws(n_doses):
+    """Dose counts cover the kernel's pass plan: Philox calls in groups of four (each lane group evaluates its own call: 16, 20,
+    33 doses), a remainder of one to three shared calls (1 ... 7, 17, 20, 33) and a partial last call (1, 3, 7, 17, 33)."""
     from bayesgm_amd import _lib
     burn, keep, seed = 10, 12, 99
     m = _model(41, [1, 1, 1, 7], 200)
     x, y, v = _data(333, 200, 42)
-    xs = np.linspace(0, 3, 7)
+    xs = np.linspace(0, 3, n_doses)
     eng = _engine(m)
     for sample_y in (True, False):
         out = eng.mh_sample(x, y, v, burn, keep, 0.4, seed, want_draws=True, effect=_lib.EFFECT_ADRF,
@@ -165,7 +168,7 @@ def test_adrf_effects_match_oracle_on_same_draws():
         ref = OC.infer_from_latent_posterior(OC.cast_model(m, np.float64), draws.astype(np.float64), xs, sample_y,
                                              seed, burn_in=burn)
         got = out["adrf"].cpu().numpy()
-        assert got.shape == (7, keep)
+        assert got.shape == (n_doses, keep)
         assert np.abs(got - ref).max() <= 2e-4, np.abs(got - ref).max()
 
 

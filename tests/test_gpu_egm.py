@@ -45,12 +45,17 @@ def _rel(a, b):
 
 @pytest.mark.parametrize("case", [dict(binary=False, p=23, z_dims=(1, 1, 1, 7), B=32),
                                   dict(binary=True, p=200, z_dims=(3, 3, 6, 6), B=32),
-                                  dict(binary=False, p=50, z_dims=(2, 1, 3, 4), B=17)])
+                                  dict(binary=False, p=50, z_dims=(2, 1, 3, 4), B=17),
+                                  dict(binary=False, p=23, z_dims=(1, 1, 1, 7), B=32, disc_norm="fixed"),
+                                  dict(binary=True, p=200, z_dims=(3, 3, 6, 6), B=19, disc_norm="fixed")])
 def test_egm_step_gradients_match_oracle(case):
     import torch
     B = case["B"]
     eng, nets, dz, params, (x, y, v), dev, rs, dz_units = _setup(case["binary"], case["p"], case["z_dims"], B)
     q = sum(case["z_dims"])
+    if case.get("disc_norm") == "fixed":      # discriminator BatchNormalization in inference mode (bgm_set_disc_norm)
+        eng.set_disc_norm("fixed")
+        dz["fixed_norm"] = True
     eng.egm_begin(B, dz_units, params["lr"], True, dz)
     n_gen = sum(W.size + b.size for k in ("g", "e", "f", "h") for W, b in nets[k])
     n_dz = CausalEngineFlat(dz).size
@@ -87,11 +92,15 @@ def CausalEngineFlat(dz):
     return CausalEngine.flatten_disc(dz)
 
 
-def test_egm_alternating_adam_steps_track_oracle():
+@pytest.mark.parametrize("disc_norm", ["batch", "fixed"])
+def test_egm_alternating_adam_steps_track_oracle(disc_norm):
     import torch
     B = 32
     eng, nets, dz, params, (x, y, v), dev, rs, dz_units = _setup(False, 23, (1, 1, 1, 7), B)
     q = 10
+    if disc_norm == "fixed":
+        eng.set_disc_norm("fixed")
+        dz["fixed_norm"] = True
     eng.egm_begin(B, dz_units, params["lr"], True, dz)
     st = OE.EgmState({k: N.cast_net(nets[k], np.float64) for k in nets}, OE.cast_disc(dz, np.float64), params)
     for it in range(5):
@@ -114,9 +123,10 @@ def test_egm_alternating_adam_steps_track_oracle():
     # influence the function; exclude them from the parameter comparison.
     n_w = sum(a.size for a in st.dz["W"])
     inert = np.zeros(ref_d.size, bool)
-    inert[n_w:n_w + sum(a.size for a in st.dz["b"][:-1])] = True
+    if disc_norm == "batch":
+        inert[n_w:n_w + sum(a.size for a in st.dz["b"][:-1])] = True
     assert np.abs(got_g - ref_g).max() <= 2e-5 and np.abs(got_d - ref_d)[~inert].max() <= 2e-5
-    assert np.abs(got_d - ref_d)[inert].max() <= 12 * params["lr"]
+    assert (not inert.any()) or np.abs(got_d - ref_d)[inert].max() <= 12 * params["lr"]
     # parameters actually moved (Adam's first steps are ~lr each)
     assert np.abs(got_g - np.concatenate([a.ravel() for k in ("g", "e", "f", "h") for Wb in nets[k] for a in Wb])).max() > 5e-4
     # end of session: the trained networks are installed in the handle

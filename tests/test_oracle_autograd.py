@@ -277,6 +277,60 @@ def test_egm_disc_step_double_backward_matches_autograd():
     assert abs(gpo - gp.item()) < 1e-12 and _max_err(OE.disc_param_list(gr), tg) < 1e-12
 
 
+def _tdisc_fixed(d, x):
+    h = x
+    L = len(d["gamma"])
+    for l in range(L):
+        h = h @ d["W"][l] + d["b"][l]
+        h = torch.tanh(h / np.sqrt(1.0 + 1e-3) * d["gamma"][l] + d["beta"][l])
+    return h @ d["W"][L] + d["b"][L]
+
+
+def test_egm_disc_step_fixed_norm_matches_autograd():
+    """`disc_norm='fixed'`: BatchNormalization in inference mode on its initial moving averages (a constant scale)."""
+    from oracle import egm as OE
+    rs = np.random.RandomState(3)
+    nets, dz = _egm_setup(rs)
+    dz["fixed_norm"] = True
+    B, q, pdim = 32, 10, 23
+    z, v = rs.randn(B, q), rs.randn(B, pdim)
+    eps = 0.61
+    tdz = {k: [_t(a).requires_grad_() for a in vv] for k, vv in dz.items() if isinstance(vv, list)}
+    te = [(_t(W), _t(b)) for W, b in nets["e"]]
+    z_ = _fwd(te, _t(v))
+    zhat = (_t(z) * eps + z_ * (1 - eps)).requires_grad_(True)
+    dz_loss = -_tdisc_fixed(tdz, _t(z)).mean() + _tdisc_fixed(tdz, z_).mean()
+    (gz,) = torch.autograd.grad(_tdisc_fixed(tdz, zhat).sum(), zhat, create_graph=True)
+    gp = ((torch.sqrt((gz ** 2).sum(1)) - 1) ** 2).mean()
+    d_loss = dz_loss + 10 * gp
+    plist = tdz["W"] + tdz["b"] + tdz["gamma"] + tdz["beta"]
+    tg = [np.zeros(tuple(p_.shape)) if g is None else g.numpy()
+          for g, p_ in zip(torch.autograd.grad(d_loss, plist, allow_unused=True), plist)]
+    l1, l2, gr = OE.disc_step_grads(nets, dz, z, v, eps)
+    assert abs(l1 - dz_loss.item()) < 1e-12 and abs(l2 - d_loss.item()) < 1e-12
+    assert _max_err(OE.disc_param_list(gr), tg) < 1e-12
+    # generator side: d(-mean D(e(v)))/d e(v) through the fixed-norm discriminator
+    p = dict(v_dim=pdim, z_dims=[1, 1, 1, 7], binary_treatment=False, use_z_rec=True, lr=2e-4)
+    x, y = rs.rand(B, 1), rs.randn(B, 1)
+    tn = {k: _torch_net(nets[k]) for k in nets}
+    tdz2 = {k: [_t(a) for a in vv] for k, vv in dz.items() if isinstance(vv, list)}
+    tz, tv, tx, ty = _t(z), _t(v), _t(x), _t(y)
+    g_z = _fwd(tn["g"], tz)
+    z_ = _fwd(tn["e"], tv)
+    z__ = _fwd(tn["e"], g_z[:, :pdim])
+    v__ = _fwd(tn["g"], z_)[:, :pdim]
+    fo = _fwd(tn["f"], torch.cat([z_[:, :1], z_[:, 1:2], tx], 1))
+    ho = _fwd(tn["h"], torch.cat([z_[:, :1], z_[:, 2:3]], 1))
+    sig = (g_z[:, -1] ** 2).mean() + (fo[:, -1] ** 2).mean() + (ho[:, -1] ** 2).mean()
+    loss = (-_tdisc_fixed(tdz2, z_).mean() + ((tv - v__) ** 2).mean() + ((tz - z__) ** 2).mean() + ((ho[:, :1] - tx) ** 2).mean() +
+            ((fo[:, :1] - ty) ** 2).mean() + 0.001 * sig)
+    pl = [a for k in ("g", "e", "f", "h") for Wb in tn[k] for a in Wb]
+    tg = [g.numpy() for g in torch.autograd.grad(loss, pl)]
+    losses, gr = OE.gen_step_grads(nets, dz, p, z, v, x, y)
+    assert abs(losses[-1] - loss.item()) < 1e-12
+    assert _max_err(OE.gen_param_list(gr), tg) < 1e-12
+
+
 def test_egm_gen_step_gradients_match_autograd():
     from oracle import egm as OE
     rs = np.random.RandomState(1)
