@@ -6,10 +6,11 @@ the deterministic class; every network call is a Flipout call with fresh noise o
 given, so -- exactly as in the reference -- `predict` depends on ``bs`` (the rows of one block share statistics and
 weight perturbations) and `evaluate` treats the panel it is given as one batch.
 
-``params['bnn_norm']`` (build option, default "batch"): "batch" = the input BatchNormalization uses the statistics of the
-batch at hand, which is what the reference code does under Keras' training-mode resolution; "fixed" = it normalises with
-mean 0 / variance 1 (inference mode on never-updated moving averages), the alternative reading under which a constant
-counterfactual treatment column is NOT normalised away.
+``params['bnn_norm']`` (build option, default "fixed"): "fixed" = the input BatchNormalization runs in inference mode on its
+never-updated moving averages (mean 0 / variance 1), the reading under which the build reproduces the reference's published
+training log, acceptance rate and ADRF error; "batch" = it uses the statistics of the batch at hand,
+which is what Keras 2.10's documented training-mode propagation implies for the code as written -- a constant counterfactual
+treatment column is then normalised away and the ADRF is flat.
 
 Stated differences (DESIGN.md "Bayesian nets"): the noise streams are the build's counter-based ones (oracle/bnn.py);
 minibatches are limited to 64 rows; under torch.distributed every rank normalises with the statistics of ITS rows.
@@ -24,7 +25,7 @@ from .. import parallel
 from ..bnn_engine import BnnEngine, NETS, flatten_bnn
 from ..datasets import Gaussian_sampler
 from ..utils import save_data
-from .causalbgm import CausalBGM, _DEFAULTS, _glorot, _disc_norm
+from .causalbgm import CausalBGM, _DEFAULTS, _glorot, _disc_norm, BNN_NORM_DEFAULT
 
 
 def _init_bnn(rs, dims):
@@ -48,13 +49,15 @@ class CausalBGMBayes(CausalBGM):
         for k in ("sigma_v", "sigma_x", "sigma_y"):
             if k in params:
                 raise NotImplementedError("bayesgm_amd: fixed %s together with use_bnn=True is not built" % k)
-        if p.get("bnn_norm", "batch") not in ("batch", "fixed"):
+        self._bnn_norm = p.get("bnn_norm", BNN_NORM_DEFAULT)
+        if self._bnn_norm not in ("batch", "fixed"):
             raise ValueError("params['bnn_norm'] must be 'batch' or 'fixed'")
-        if p.get("bnn_norm", "batch") == "batch":
+        if self._bnn_norm == "batch":
             import warnings
-            warnings.warn("bayesgm_amd: use_bnn=True with the reference's input BatchNormalization on batch statistics: a counterfactual "
+            warnings.warn("bayesgm_amd: params['bnn_norm'] = 'batch' (input BatchNormalization on batch statistics): a counterfactual "
                           "treatment column that is constant over the batch is normalised away, so ADRF / ITE estimates do not depend on "
-                          "the treatment value (DESIGN.md section 7); params['bnn_norm'] = 'fixed' selects the other reading.", stacklevel=3)
+                          "the treatment value, and the reference's published results are not reproduced (DESIGN.md sections 2b, 7).",
+                          stacklevel=3)
         random_seed = parallel.shared_seed(random_seed)   # None stays None in a single process; one seed for all ranks otherwise
         self._rs = np.random.RandomState(random_seed) if random_seed is not None else np.random.RandomState()
         if random_seed is not None:
@@ -75,7 +78,7 @@ class CausalBGMBayes(CausalBGM):
             device = int(os.environ.get("BGM_DEVICE", os.environ.get("LOCAL_RANK", 0)))
         self.engine = BnnEngine(p["v_dim"], z, binary_treatment=p["binary_treatment"], g_units=p["g_units"], e_units=p["e_units"],
                                 f_units=p["f_units"], h_units=p["h_units"], kl_weight=p["kl_weight"], max_batch=64,
-                                norm_mode={"batch": 0, "fixed": 1}[p.get("bnn_norm", "batch")], device=device)
+                                norm_mode={"batch": 0, "fixed": 1}[self._bnn_norm], device=device)
         self.engine.set_disc_norm(_disc_norm(p))
         self.engine.begin(self.nets)
         if self.timestamp is None:

@@ -36,15 +36,29 @@ model.fit((x, y, v), epochs=int(kv.get("epochs", 100)), epochs_per_eval=10, batc
           use_egm_init=egm > 0, egm_n_iter=egm, egm_batches_per_eval=500, verbose=1)
 t_fit = time.time() - t0
 xs = np.linspace(0, 3, 20)
-t0 = time.time()
-q_sd = float(kv.get("q_sd", 1.0))
-adrf, interval = model.predict((x, y, v), alpha=0.01, n_mcmc=int(kv.get("n_mcmc", 3000)), burn_in=int(kv.get("burn_in", 5000)),
-                               x_values=xs, q_sd=q_sd, bs=int(kv.get("bs", 20000)))
-t_pred = time.time() - t0
 truth = get_ADRF(x_values=list(xs), dataset="Imbens")
-rmse = float(np.sqrt(np.mean((adrf - truth) ** 2)))
-mape = float(np.mean(np.abs((adrf - truth) / truth)))
-cover = float(np.mean((interval[:, 0] <= truth) & (truth <= interval[:, 1])))
-print("RESULT " + json.dumps(dict(name=name, args=kv, fit_s=t_fit, predict_s=t_pred, adrf_rmse=rmse, adrf_mape=mape,
-                                   interval_coverage=cover, acceptance=float(model.last_acceptance_rate),
-                                   adrf=[float(a) for a in adrf], truth=[float(t) for t in truth])))
+variants = [("q_sd=%g" % float(kv.get("q_sd", 1.0)), float(kv.get("q_sd", 1.0)), "fp32")]
+if int(kv.get("extra", 1)):
+    variants.append(("q_sd adaptive", -1.0, "fp32"))
+    if not use_bnn:
+        variants.append(("bf16x3 q_sd=%g" % float(kv.get("q_sd", 1.0)), float(kv.get("q_sd", 1.0)), "bf16x3"))
+preds = []
+for label, q_sd, prec in variants:
+    if not use_bnn:
+        model.engine.set_precision(prec)
+    t0 = time.time()
+    adrf, interval = model.predict((x, y, v), alpha=0.01, n_mcmc=int(kv.get("n_mcmc", 3000)), burn_in=int(kv.get("burn_in", 5000)),
+                                   x_values=xs, q_sd=q_sd, bs=int(kv.get("bs", 20000)))
+    t_pred = time.time() - t0
+    preds.append(dict(variant=label, predict_s=t_pred, adrf_rmse=float(np.sqrt(np.mean((adrf - truth) ** 2))),
+                      adrf_mape=float(np.mean(np.abs((adrf - truth) / truth))),
+                      interval_coverage=float(np.mean((interval[:, 0] <= truth) & (truth <= interval[:, 1]))),
+                      acceptance=float(model.last_acceptance_rate), adrf=[float(a) for a in adrf]))
+    print("PREDICT " + json.dumps(preds[-1]))
+if not use_bnn:
+    model.engine.set_precision("fp32")
+first = preds[0]
+print("RESULT " + json.dumps(dict(name=name, args=kv, fit_s=t_fit, predict_s=first["predict_s"], adrf_rmse=first["adrf_rmse"],
+                                   adrf_mape=first["adrf_mape"], interval_coverage=first["interval_coverage"],
+                                   acceptance=first["acceptance"], adrf=first["adrf"], truth=[float(t) for t in truth],
+                                   variants=preds)))
