@@ -125,6 +125,7 @@ SYMBOLS = {
     "bgm_causal_fit_z_step": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_int32, C.c_float,
                                         C.c_int32, C.c_void_p, C.c_void_p]),
     "bgm_causal_get_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "bgm_causal_fit_state": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
     "bgm_causal_fit_end": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bgm_bgm_configure": (C.c_int, [C.c_void_p, C.POINTER(BgmConfig)]),
     "bgm_bgm_fit_begin": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),

@@ -64,10 +64,67 @@ static void bx_pack_layer(std::vector<unsigned char> &blob, int off, const float
     }
 }
 
-static int bx_pack(bgm_handle *h, std::vector<unsigned char> &blob, BxMeta &m) {
+template <int KT1, int NTL>
+static void bx_fill(bgm_handle *h, std::vector<unsigned char> &blob, BxMeta &m) {
+  using L = BxLayout<KT1, NTL>;
   const HostNet &G = h->nets[BGM_NET_G], &F = h->nets[BGM_NET_F], &H = h->nets[BGM_NET_H];
   const int q = h->q, p = h->p;
   const int z0 = h->cfg.z_dims[0], z1 = h->cfg.z_dims[1], z2 = h->cfg.z_dims[2];
+  m.total_bytes = L::total(m.n_gh);
+  blob.assign((size_t)m.total_bytes, 0);
+  float *bf = reinterpret_cast<float *>(blob.data());
+  auto ident_col = [](int o) { return o; };
+  // first layers: input tile t, lane group g, register r  <->  extended input feature 16 t + 4 r + g of [z, x, 0 ...]
+  auto l1 = [](int t, int g, int r) { return 16 * t + 4 * r + g; };
+  // hidden layers: accumulator order, feature 16 t + 4 g + r
+  auto acc_feat = [](int t, int g, int r) { return 16 * t + 4 * g + r; };
+  bx_pack_layer(blob, L::w1g, G.W(0), 64, KT1, 4, 1.0f, [&](int t, int g, int r) { const int f = l1(t, g, r); return f < q ? f : -1; }, ident_col);
+  bx_pack_layer(blob, L::w1f, F.W(0), 64, KT1, 4, 1.0f, [&](int t, int g, int r) {
+    const int f = l1(t, g, r);
+    if (f < z0 + z1) return f;
+    if (f == q) return z0 + z1;          // treatment column
+    return -1;
+  }, ident_col);
+  bx_pack_layer(blob, L::w1h, H.W(0), 64, KT1, 4, 1.0f, [&](int t, int g, int r) {
+    const int f = l1(t, g, r);
+    if (f < z0) return f;
+    if (f >= z0 + z1 && f < z0 + z1 + z2) return z0 + (f - z0 - z1);
+    return -1;
+  }, ident_col);
+  for (int i = 0; i < 64; ++i) { bf[L::b1g + i] = G.b(0)[i]; bf[L::b1f + i] = F.b(0)[i]; bf[L::b1h + i] = H.b(0)[i]; }
+  const float S = BGM_LRS_W;      // weights behind a one-instruction LeakyReLU (lrelu_s) carry the factor 0.6
+  for (int l = 0; l < m.n_gh; ++l) {
+    bx_pack_layer(blob, L::wg(m.n_gh) + l * bx_layer_bytes(4, 4), G.W(1 + l), 64, 4, 4, S, acc_feat, ident_col);
+    for (int i = 0; i < 64; ++i) bf[L::bg + 64 * l + i] = G.b(1 + l)[i];
+  }
+  {
+    const int LG = (int)G.dims.size() - 2;
+    std::vector<float> Wp, bp;
+    bgm_g_last_padded(G.W(LG), G.b(LG), p, NTL, Wp, bp);
+    bx_pack_layer(blob, L::wgl, Wp.data(), 16 * NTL, 4, NTL, S, acc_feat, ident_col);
+    for (int i = 0; i < 16 * NTL; ++i) bf[L::bgl + i] = bp[i];
+  }
+  auto rows_lt = [&](int n_in) { return [=](int t, int g, int r) { const int f = 16 * t + 4 * g + r; return f < n_in ? f : -1; }; };
+  auto cols_lt = [&](int n_out) { return [=](int o) { return o < n_out ? o : -1; }; };
+  auto rep2 = [](int o) { return (o & 3) < 2 ? (o & 3) : -1; };       // (mu, s) replicated at positions 4 g' + {0, 1}
+  const HostNet *nets[2] = {&F, &H};
+  const int w2[2] = {L::wf2, L::wh2}, w3[2] = {L::wf3, L::wh3}, w4[2] = {L::wf4, L::wh4};
+  const int b2[2] = {L::bf2, L::bh2}, b3[2] = {L::bf3, L::bh3}, b4[2] = {L::bf4, L::bh4};
+  for (int k = 0; k < 2; ++k) {
+    const HostNet &N = *nets[k];
+    bx_pack_layer(blob, w2[k], N.W(1), 32, 4, 2, S, rows_lt(64), cols_lt(32));
+    bx_pack_layer(blob, w3[k], N.W(2), 8, 2, 1, S, rows_lt(32), cols_lt(8));
+    bx_pack_layer(blob, w4[k], N.W(3), 2, 1, 1, S, rows_lt(8), rep2);
+    for (int i = 0; i < 32; ++i) bf[b2[k] + i] = N.b(1)[i];
+    for (int i = 0; i < 8; ++i) bf[b3[k] + i] = N.b(2)[i];
+    for (int i = 0; i < 16; ++i) bf[b4[k] + i] = (i & 3) < 2 ? N.b(3)[i & 3] : 0.0f;
+  }
+  for (int o = 0; o < 64; ++o) bf[L::wxf + o] = F.W(0)[(size_t)(z0 + z1) * 64 + o];
+}
+
+static int bx_pack(bgm_handle *h, std::vector<unsigned char> &blob, BxMeta &m) {
+  const HostNet &G = h->nets[BGM_NET_G], &F = h->nets[BGM_NET_F], &H = h->nets[BGM_NET_H];
+  const int q = h->q, p = h->p;
   int KT1, KSL1, NTL;
   if (!bgm_causal_shape(q + 1, p + 1, KT1, KSL1, NTL)) { bgm_set_error("bf16x3: no compiled kernel shape contains this model"); return BGM_E_UNSUPPORTED; }
   if (F.dims.size() != 5 || H.dims.size() != 5 || F.dims[1] != 64 || F.dims[2] != 32 || F.dims[3] != 8 || H.dims[1] != 64 ||
@@ -79,74 +136,15 @@ static int bx_pack(bgm_handle *h, std::vector<unsigned char> &blob, BxMeta &m) {
   auto s2 = [](float s) { return s > 0.0f ? s * s : -1.0f; };
   m.sig2_v = s2(h->cfg.sigma_v); m.sig2_x = s2(h->cfg.sigma_x); m.sig2_y = s2(h->cfg.sigma_y);
   m.n_gh = h->cfg.n_hidden_g - 1;
-  int off = 0;
-  auto take_b = [&](int bytes) { int o = off; off += (bytes + 15) / 16 * 16; return o; };
-  m.w1g = take_b(bx_layer_bytes(KT1, 4)); m.w1f = take_b(bx_layer_bytes(KT1, 4)); m.w1h = take_b(bx_layer_bytes(KT1, 4));
-  m.wg = take_b(m.n_gh * bx_layer_bytes(4, 4));
-  m.wgl = take_b(bx_layer_bytes(4, NTL));
-  m.wf2 = take_b(bx_layer_bytes(4, 2)); m.wf3 = take_b(bx_layer_bytes(2, 1)); m.wf4 = take_b(bx_layer_bytes(1, 1));
-  m.wh2 = take_b(bx_layer_bytes(4, 2)); m.wh3 = take_b(bx_layer_bytes(2, 1)); m.wh4 = take_b(bx_layer_bytes(1, 1));
-  auto take_f = [&](int n) { int o = off / 4; off += (n + 3) / 4 * 16; return o; };   // float offset, 16-byte aligned
-  m.b1g = take_f(64); m.b1f = take_f(64); m.b1h = take_f(64);
-  m.bg = take_f(64 * m.n_gh); m.bgl = take_f(16 * NTL);
-  m.bf2 = take_f(32); m.bf3 = take_f(16); m.bf4 = take_f(16);
-  m.bh2 = take_f(32); m.bh3 = take_f(16); m.bh4 = take_f(16);
-  m.wxf = take_f(64);
-  m.total_bytes = off;
+  bool done = false;
+#define X(KT1_, NTL_) if (KT1 == KT1_ && NTL == NTL_) { bx_fill<KT1_, NTL_>(h, blob, m); done = true; }
+  BGM_BX3_VARIANTS(X)
+#undef X
+  if (!done) { bgm_set_error("bf16x3: no compiled kernel variant for this shape"); return BGM_E_UNSUPPORTED; }
   if (m.total_bytes + 64 > 160 * 1024) {
     bgm_set_error("bf16x3: model does not fit the 160 KiB LDS-resident layout (" + std::to_string(m.total_bytes) + " B)");
     return BGM_E_UNSUPPORTED;
   }
-  blob.assign((size_t)m.total_bytes, 0);
-  float *bf = reinterpret_cast<float *>(blob.data());
-  auto ident_col = [](int o) { return o; };
-  // first layers: input tile t, lane group g, register r  <->  extended input feature 16 t + 4 r + g of [z, x, 0 ...]
-  auto l1 = [](int t, int g, int r) { return 16 * t + 4 * r + g; };
-  // hidden layers: accumulator order, feature 16 t + 4 g + r
-  auto acc_feat = [](int t, int g, int r) { return 16 * t + 4 * g + r; };
-  bx_pack_layer(blob, m.w1g, G.W(0), 64, KT1, 4, 1.0f, [&](int t, int g, int r) { const int f = l1(t, g, r); return f < q ? f : -1; },
-                [&](int o) { return o < 64 ? o : -1; });
-  bx_pack_layer(blob, m.w1f, F.W(0), 64, KT1, 4, 1.0f, [&](int t, int g, int r) {
-    const int f = l1(t, g, r);
-    if (f < z0 + z1) return f;
-    if (f == q) return z0 + z1;          // treatment column
-    return -1;
-  }, ident_col);
-  bx_pack_layer(blob, m.w1h, H.W(0), 64, KT1, 4, 1.0f, [&](int t, int g, int r) {
-    const int f = l1(t, g, r);
-    if (f < z0) return f;
-    if (f >= z0 + z1 && f < z0 + z1 + z2) return z0 + (f - z0 - z1);
-    return -1;
-  }, ident_col);
-  for (int i = 0; i < 64; ++i) { bf[m.b1g + i] = G.b(0)[i]; bf[m.b1f + i] = F.b(0)[i]; bf[m.b1h + i] = H.b(0)[i]; }
-  const float S = BGM_LRS_W;      // weights behind a one-instruction LeakyReLU (lrelu_s) carry the factor 0.6
-  for (int l = 0; l < m.n_gh; ++l) {
-    bx_pack_layer(blob, m.wg + l * bx_layer_bytes(4, 4), G.W(1 + l), 64, 4, 4, S, acc_feat, ident_col);
-    for (int i = 0; i < 64; ++i) bf[m.bg + 64 * l + i] = G.b(1 + l)[i];
-  }
-  {
-    const int LG = (int)G.dims.size() - 2;
-    std::vector<float> Wp, bp;
-    bgm_g_last_padded(G.W(LG), G.b(LG), p, NTL, Wp, bp);
-    bx_pack_layer(blob, m.wgl, Wp.data(), 16 * NTL, 4, NTL, S, acc_feat, ident_col);
-    for (int i = 0; i < 16 * NTL; ++i) bf[m.bgl + i] = bp[i];
-  }
-  auto rows_lt = [&](int n_in) { return [=](int t, int g, int r) { const int f = 16 * t + 4 * g + r; return f < n_in ? f : -1; }; };
-  auto cols_lt = [&](int n_out) { return [=](int o) { return o < n_out ? o : -1; }; };
-  auto rep2 = [](int o) { return (o & 3) < 2 ? (o & 3) : -1; };       // (mu, s) replicated at positions 4 g' + {0, 1}
-  const HostNet *nets[2] = {&F, &H};
-  const int w2[2] = {m.wf2, m.wh2}, w3[2] = {m.wf3, m.wh3}, w4[2] = {m.wf4, m.wh4};
-  const int b2[2] = {m.bf2, m.bh2}, b3[2] = {m.bf3, m.bh3}, b4[2] = {m.bf4, m.bh4};
-  for (int k = 0; k < 2; ++k) {
-    const HostNet &N = *nets[k];
-    bx_pack_layer(blob, w2[k], N.W(1), 32, 4, 2, S, rows_lt(64), cols_lt(32));
-    bx_pack_layer(blob, w3[k], N.W(2), 8, 2, 1, S, rows_lt(32), cols_lt(8));
-    bx_pack_layer(blob, w4[k], N.W(3), 2, 1, 1, S, rows_lt(8), rep2);
-    for (int i = 0; i < 32; ++i) bf[b2[k] + i] = N.b(1)[i];
-    for (int i = 0; i < 8; ++i) bf[b3[k] + i] = N.b(2)[i];
-    for (int i = 0; i < 16; ++i) bf[b4[k] + i] = (i & 3) < 2 ? N.b(3)[i & 3] : 0.0f;
-  }
-  for (int o = 0; o < 64; ++o) bf[m.wxf + o] = F.W(0)[(size_t)(z0 + z1) * 64 + o];
   h->KT1 = KT1; h->KSL1 = KSL1; h->NTL = NTL;
   return BGM_OK;
 }

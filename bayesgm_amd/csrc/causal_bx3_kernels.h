@@ -22,14 +22,31 @@
 typedef __bf16 bx_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bx_bf16x4 __attribute__((ext_vector_type(4)));
 
-struct BxMeta {
+struct BxMeta {                 // run-time part of the model description
   int q, p, sig_pc, binary, n_gh;
   float sig2_v, sig2_x, sig2_y;
-  // byte offsets of the packed weights
-  int w1g, w1f, w1h, wg, wgl, wf2, wf3, wf4, wh2, wh3, wh4;
-  // float offsets (from the blob start) of the fp32 vectors
-  int b1g, b1f, b1h, bg, bgl, bf2, bf3, bf4, bh2, bh3, bh4, wxf;
   int total_bytes;
+};
+
+__host__ __device__ constexpr int bx_layer_bytes(int KT, int NT) { return NT * ((KT / 2) * 2048 + (KT & 1) * 1024); }
+
+// Blob layout of a compiled shape (KT1 first-layer input tiles, NTL output tiles of g's last layer): every offset except the
+// hidden stack of g (n_gh layers, placed last) is a compile-time constant, so the kernels carry no offset table in scalar
+// registers.  Float vectors first (float offsets), then the packed weights (byte offsets), then g's hidden biases and weights.
+template <int KT1, int NTL>
+struct BxLayout {
+  // fp32 vectors, float offsets
+  static constexpr int b1g = 0, b1f = 64, b1h = 128, bgl = 192, bf2 = bgl + 16 * NTL, bf3 = bf2 + 32, bf4 = bf3 + 16, bh2 = bf4 + 16,
+                       bh3 = bh2 + 32, bh4 = bh3 + 16, wxf = bh4 + 16, n_floats = wxf + 64;
+  // packed weights, byte offsets
+  static constexpr int w1g = 4 * n_floats, w1f = w1g + bx_layer_bytes(KT1, 4), w1h = w1f + bx_layer_bytes(KT1, 4),
+                       wgl = w1h + bx_layer_bytes(KT1, 4), wf2 = wgl + bx_layer_bytes(4, NTL), wf3 = wf2 + bx_layer_bytes(4, 2),
+                       wf4 = wf3 + bx_layer_bytes(2, 1), wh2 = wf4 + bx_layer_bytes(1, 1), wh3 = wh2 + bx_layer_bytes(4, 2),
+                       wh4 = wh3 + bx_layer_bytes(2, 1), fixed_bytes = wh4 + bx_layer_bytes(1, 1);
+  // hidden stack of g: n_gh x 64 biases (float offset bg), then n_gh layers of 16 KiB (byte offset wg(n_gh))
+  static constexpr int bg = fixed_bytes / 4;
+  __host__ __device__ static constexpr int wg(int n_gh) { return fixed_bytes + 256 * n_gh; }
+  __host__ __device__ static constexpr int total(int n_gh) { return fixed_bytes + 256 * n_gh + n_gh * bx_layer_bytes(4, 4); }
 };
 
 struct CausalBxKArgs {
@@ -57,21 +74,27 @@ __device__ __forceinline__ void bx_split4(const f32x4 &a, bx_bf16x4 &hi, bx_bf16
   }
 }
 
-__host__ __device__ constexpr int bx_layer_bytes(int KT, int NT) { return NT * ((KT / 2) * 2048 + (KT & 1) * 1024); }
-
 // acc[NT] += W^T in   for one layer; `w` = LDS byte address of the layer's fragments, `in` = KT activated input tiles.
 // The input is split once; the output tiles are processed in groups of up to four (A fragments of a group: 32 registers), and
 // per K block the three products of a group are issued tile-major per product, so that consecutive MFMAs write different
 // accumulators.
+// split form of KT activated input tiles: K = 32 blocks (hi, lo) and, for odd KT, the trailing K = 16 block
+template <int KT>
+struct BxIn {
+  static constexpr int NK32 = KT / 2, K16 = KT & 1;
+  bx_bf16x8 bh[NK32 > 0 ? NK32 : 1], bl[NK32 > 0 ? NK32 : 1];
+  bx_bf16x4 ch, cl;
+  __device__ __forceinline__ void split(const f32x4 (&in)[KT]) {
+#pragma unroll
+    for (int T = 0; T < NK32; ++T) bx_split8(in[2 * T], in[2 * T + 1], bh[T], bl[T]);
+    if constexpr (K16) bx_split4(in[KT - 1], ch, cl);
+  }
+};
+
 template <int KT, int NT>
-__device__ __forceinline__ void bx_dense_acc(const unsigned char *w, int lane, const f32x4 (&in)[KT], f32x4 (&acc)[NT]) {
+__device__ __forceinline__ void bx_dense_mm(const unsigned char *w, int lane, const BxIn<KT> &b, f32x4 (&acc)[NT]) {
   constexpr int NK32 = KT / 2, K16 = KT & 1;
   constexpr int TILE_BYTES = NK32 * 2048 + K16 * 1024;
-  bx_bf16x8 bh[NK32 > 0 ? NK32 : 1], bl[NK32 > 0 ? NK32 : 1];
-#pragma unroll
-  for (int T = 0; T < NK32; ++T) bx_split8(in[2 * T], in[2 * T + 1], bh[T], bl[T]);
-  bx_bf16x4 ch, cl;
-  if constexpr (K16) bx_split4(in[KT - 1], ch, cl);
 #pragma unroll
   for (int m0 = 0; m0 < NT; m0 += 4) {
     constexpr int GSMAX = 4;
@@ -87,11 +110,11 @@ __device__ __forceinline__ void bx_dense_acc(const unsigned char *w, int lane, c
           al[u] = *reinterpret_cast<const bx_bf16x8 *>(f + 1024);
         }
 #pragma unroll
-      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[u], bh[T], acc[m0 + u], 0, 0, 0);
+      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[u], b.bh[T], acc[m0 + u], 0, 0, 0);
 #pragma unroll
-      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[u], bl[T], acc[m0 + u], 0, 0, 0);
+      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[u], b.bl[T], acc[m0 + u], 0, 0, 0);
 #pragma unroll
-      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[u], bh[T], acc[m0 + u], 0, 0, 0);
+      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[u], b.bh[T], acc[m0 + u], 0, 0, 0);
     }
     if constexpr (K16) {
       bx_bf16x4 ah[GSMAX], al[GSMAX];
@@ -103,13 +126,20 @@ __device__ __forceinline__ void bx_dense_acc(const unsigned char *w, int lane, c
           al[u] = *reinterpret_cast<const bx_bf16x4 *>(f + 512);
         }
 #pragma unroll
-      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al[u], ch, acc[m0 + u], 0, 0, 0);
+      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al[u], b.ch, acc[m0 + u], 0, 0, 0);
 #pragma unroll
-      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[u], cl, acc[m0 + u], 0, 0, 0);
+      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[u], b.cl, acc[m0 + u], 0, 0, 0);
 #pragma unroll
-      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[u], ch, acc[m0 + u], 0, 0, 0);
+      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[u], b.ch, acc[m0 + u], 0, 0, 0);
     }
   }
+}
+
+template <int KT, int NT>
+__device__ __forceinline__ void bx_dense_acc(const unsigned char *w, int lane, const f32x4 (&in)[KT], f32x4 (&acc)[NT]) {
+  BxIn<KT> b;
+  b.split(in);
+  bx_dense_mm<KT, NT>(w, lane, b, acc);
 }
 
 template <int NT>
@@ -125,40 +155,121 @@ __device__ __forceinline__ void bx_lrelu(f32x4 (&a)[NT]) {
     for (int r = 0; r < 4; ++r) a[t][r] = lrelu_s(a[t][r]);
 }
 
-// f / h tail 64 -> 32 -> 8 -> 2 from the activated first hidden layer; (mu, s) valid in every lane (replicated columns)
-__device__ __forceinline__ void bx_tail(const unsigned char *lds, const float *ldsf, int w2, int b2, int w3, int b3, int w4, int b4,
-                                        int lane, int g, const f32x4 (&a1)[4], float &mu, float &sr) {
-  f32x4 a2[2];
-  bx_bias<2>(ldsf, b2, g, a2);
-  bx_dense_acc<4, 2>(lds + w2, lane, a1, a2);
-  bx_lrelu<2>(a2);
-  f32x4 a3[1];
-  bx_bias<1>(ldsf, b3, g, a3);
-  bx_dense_acc<2, 1>(lds + w3, lane, a2, a3);
-  bx_lrelu<1>(a3);
-  f32x4 a4[1];
-  bx_bias<1>(ldsf, b4, g, a4);
-  bx_dense_acc<1, 1>(lds + w4, lane, a3, a4);
-  mu = a4[0][0];
-  sr = a4[0][1];
+// Two layers of the same shape (the f and h nets) in lock step: their products are interleaved so that twice as many independent
+// accumulators are in flight (alone, the narrow tail layers are chains of dependent MFMAs on one or two accumulators).  NT <= 4.
+template <int KT, int NT>
+__device__ __forceinline__ void bx_dense_mm2(const unsigned char *wa, const unsigned char *wb, int lane, const BxIn<KT> &ba,
+                                             const BxIn<KT> &bb, f32x4 (&acca)[NT], f32x4 (&accb)[NT]) {
+  static_assert(NT <= 4, "bx_dense_mm2: one tile group");
+  constexpr int NK32 = KT / 2, K16 = KT & 1;
+  constexpr int TILE_BYTES = NK32 * 2048 + K16 * 1024;
+#pragma unroll
+  for (int T = 0; T < NK32; ++T) {
+    bx_bf16x8 ah[NT], al[NT], bh[NT], bl[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      const unsigned char *fa = wa + u * TILE_BYTES + T * 2048 + lane * 16, *fb = wb + u * TILE_BYTES + T * 2048 + lane * 16;
+      ah[u] = *reinterpret_cast<const bx_bf16x8 *>(fa); al[u] = *reinterpret_cast<const bx_bf16x8 *>(fa + 1024);
+      bh[u] = *reinterpret_cast<const bx_bf16x8 *>(fb); bl[u] = *reinterpret_cast<const bx_bf16x8 *>(fb + 1024);
+    }
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      acca[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[u], ba.bh[T], acca[u], 0, 0, 0);
+      accb[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[u], bb.bh[T], accb[u], 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      acca[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[u], ba.bl[T], acca[u], 0, 0, 0);
+      accb[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[u], bb.bl[T], accb[u], 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      acca[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[u], ba.bh[T], acca[u], 0, 0, 0);
+      accb[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[u], bb.bh[T], accb[u], 0, 0, 0);
+    }
+  }
+  if constexpr (K16) {
+    bx_bf16x4 ah[NT], al[NT], bh[NT], bl[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      const unsigned char *fa = wa + u * TILE_BYTES + NK32 * 2048 + lane * 8, *fb = wb + u * TILE_BYTES + NK32 * 2048 + lane * 8;
+      ah[u] = *reinterpret_cast<const bx_bf16x4 *>(fa); al[u] = *reinterpret_cast<const bx_bf16x4 *>(fa + 512);
+      bh[u] = *reinterpret_cast<const bx_bf16x4 *>(fb); bl[u] = *reinterpret_cast<const bx_bf16x4 *>(fb + 512);
+    }
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      acca[u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al[u], ba.ch, acca[u], 0, 0, 0);
+      accb[u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bl[u], bb.ch, accb[u], 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      acca[u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[u], ba.cl, acca[u], 0, 0, 0);
+      accb[u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh[u], bb.cl, accb[u], 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      acca[u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[u], ba.ch, acca[u], 0, 0, 0);
+      accb[u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh[u], bb.ch, accb[u], 0, 0, 0);
+    }
+  }
+}
+
+// f and h from the shared (split) extended input: first layers and tails 64 -> 32 -> 8 -> 2 in lock step; (mu, s) of both nets
+// are valid in every lane (replicated output columns)
+template <int KT1, class L>
+__device__ __forceinline__ void bx_fh(const unsigned char *lds, const float *ldsf, int lane, int g, const BxIn<KT1> &zsplit, float &mu_y,
+                                      float &sr_y, float &mu_x, float &sr_x) {
+  f32x4 f1[4], h1[4];
+  bx_bias<4>(ldsf, L::b1f, g, f1);
+  bx_bias<4>(ldsf, L::b1h, g, h1);
+  bx_dense_mm2<KT1, 4>(lds + L::w1f, lds + L::w1h, lane, zsplit, zsplit, f1, h1);
+  bx_lrelu<4>(f1);
+  bx_lrelu<4>(h1);
+  BxIn<4> sf1, sh1;
+  sf1.split(f1); sh1.split(h1);
+  f32x4 f2[2], h2[2];
+  bx_bias<2>(ldsf, L::bf2, g, f2);
+  bx_bias<2>(ldsf, L::bh2, g, h2);
+  bx_dense_mm2<4, 2>(lds + L::wf2, lds + L::wh2, lane, sf1, sh1, f2, h2);
+  bx_lrelu<2>(f2);
+  bx_lrelu<2>(h2);
+  BxIn<2> sf2, sh2;
+  sf2.split(f2); sh2.split(h2);
+  f32x4 f3[1], h3[1];
+  bx_bias<1>(ldsf, L::bf3, g, f3);
+  bx_bias<1>(ldsf, L::bh3, g, h3);
+  bx_dense_mm2<2, 1>(lds + L::wf3, lds + L::wh3, lane, sf2, sh2, f3, h3);
+  bx_lrelu<1>(f3);
+  bx_lrelu<1>(h3);
+  BxIn<1> sf3, sh3;
+  sf3.split(f3); sh3.split(h3);
+  f32x4 f4[1], h4[1];
+  bx_bias<1>(ldsf, L::bf4, g, f4);
+  bx_bias<1>(ldsf, L::bh4, g, h4);
+  bx_dense_mm2<1, 1>(lds + L::wf4, lds + L::wh4, lane, sf3, sh3, f4, h4);
+  mu_y = f4[0][0]; sr_y = f4[0][1];
+  mu_x = h4[0][0]; sr_x = h4[0][1];
 }
 
 // log p(z | x, y, v) of the wave's 16 chains (causal_logp of causal_kernels.h in split precision)
 template <int KT1, int NTL>
 __device__ __forceinline__ float causal_logp_bx3(const unsigned char *lds, const BxMeta &m, int lane, int g, int j,
                                                  const f32x4 (&zin)[KT1], const f32x4 (&vreg)[NTL], float xr, float yr) {
+  using L = BxLayout<KT1, NTL>;
   const float *ldsf = reinterpret_cast<const float *>(lds);
+  BxIn<KT1> zsplit;           // the extended input [z, x, 0 ...] feeds the first layers of g, f and h: split once
+  zsplit.split(zin);
   float ssq = 0.0f, sraw_v = 0.0f;
   {
     f32x4 h[4];
-    bx_bias<4>(ldsf, m.b1g, g, h);
-    bx_dense_acc<KT1, 4>(lds + m.w1g, lane, zin, h);
+    bx_bias<4>(ldsf, L::b1g, g, h);
+    bx_dense_mm<KT1, 4>(lds + L::w1g, lane, zsplit, h);
     bx_lrelu<4>(h);
     for (int l = 0; l < m.n_gh; ++l) {
       BGM_NO_HOIST();
       f32x4 h2[4];
-      bx_bias<4>(ldsf, m.bg + 64 * l, g, h2);
-      bx_dense_acc<4, 4>(lds + m.wg + l * bx_layer_bytes(4, 4), lane, h, h2);
+      bx_bias<4>(ldsf, L::bg + 64 * l, g, h2);
+      bx_dense_acc<4, 4>(lds + L::wg(m.n_gh) + l * bx_layer_bytes(4, 4), lane, h, h2);
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -168,7 +279,7 @@ __device__ __forceinline__ float causal_logp_bx3(const unsigned char *lds, const
     f32x4 acc[NTL];
 #pragma unroll
     for (int t = 0; t < NTL; ++t) acc[t] = vreg[t];
-    bx_dense_acc<4, NTL>(lds + m.wgl, lane, h, acc);
+    bx_dense_acc<4, NTL>(lds + L::wgl, lane, h, acc);
     const int sig_r = m.sig_pc - 4 * g;
 #pragma unroll
     for (int t = 0; t < NTL; ++t)
@@ -185,17 +296,7 @@ __device__ __forceinline__ float causal_logp_bx3(const unsigned char *lds, const
     sraw_v = __shfl(sraw_v, j + 16 * (m.sig_pc >> 2));
   }
   float mu_y, sr_y, mu_x, sr_x;
-  {
-    f32x4 f1[4], h1[4];
-    bx_bias<4>(ldsf, m.b1f, g, f1);
-    bx_bias<4>(ldsf, m.b1h, g, h1);
-    bx_dense_acc<KT1, 4>(lds + m.w1f, lane, zin, f1);
-    bx_dense_acc<KT1, 4>(lds + m.w1h, lane, zin, h1);
-    bx_lrelu<4>(f1);
-    bx_lrelu<4>(h1);
-    bx_tail(lds, ldsf, m.wf2, m.bf2, m.wf3, m.bf3, m.wf4, m.bf4, lane, g, f1, mu_y, sr_y);
-    bx_tail(lds, ldsf, m.wh2, m.bh2, m.wh3, m.bh3, m.wh4, m.bh4, lane, g, h1, mu_x, sr_x);
-  }
+  bx_fh<KT1, L>(lds, ldsf, lane, g, zsplit, mu_y, sr_y, mu_x, sr_x);
   float zsq = 0.0f;
 #pragma unroll
   for (int t = 0; t < KT1; ++t)
@@ -254,6 +355,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_logpost_bx3_kernel(const un
                                                                         const float *y, const float *v, const float *z,
                                                                         long long n, float *out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bx_lds[];
+  using L = BxLayout<KT1, NTL>;
   bx_lds_fill(bx_lds, blob, m.total_bytes);
   const float *ldsf = reinterpret_cast<const float *>(bx_lds);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -266,7 +368,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_logpost_bx3_kernel(const un
     row = row < n ? row : n - 1;
     const float xr[1] = {x[row]}, yr = y[row];
     f32x4 vreg[NTL];
-    bx_load_v<NTL>(v, ldsf + m.bgl, n, m.p, row0, j, g, vreg);
+    bx_load_v<NTL>(v, ldsf + L::bgl, n, m.p, row0, j, g, vreg);
     f32x4 zin[1][KT1];
     load_z_rows<KT1, 1>(z, n, m.q, row0, j, g, xr, zin);
     const float lp = causal_logp_bx3<KT1, NTL>(bx_lds, m, lane, g, j, zin[0], vreg, xr[0], yr);
@@ -279,12 +381,13 @@ __global__ __launch_bounds__(64 * WAVES) void causal_logpost_bx3_kernel(const un
 // f's first layer once at x = 0 (fp32 accumulators), doses as fp32 rank-1 updates, four doses per pass sharing the A
 // fragments, lane group g finishing dose e = g of the pass; same noise plan (Philox calls in groups of four).
 // ---------------------------------------------------------------------------
-template <int KT1, int EFFECT>
+template <int KT1, int NTL, int EFFECT>
 __device__ __forceinline__ void causal_effects_bx3(const unsigned char *lds, const BxMeta &m, int lane, int g, int j,
                                                    const f32x4 (&zs)[KT1], unsigned rowid, bool valid, long long row, long long n,
                                                    unsigned it, long long d, int n_keep, int sample_y, int n_doses,
                                                    const float *x_values, float *adrf_slot, float *ite, unsigned k0, unsigned k1) {
   BGM_NO_HOIST();
+  using L = BxLayout<KT1, NTL>;
   const float *ldsf = reinterpret_cast<const float *>(lds);
   f32x4 z0in[KT1];
 #pragma unroll
@@ -292,11 +395,11 @@ __device__ __forceinline__ void causal_effects_bx3(const unsigned char *lds, con
 #pragma unroll
     for (int r = 0; r < 4; ++r) z0in[t][r] = (16 * t + 4 * r + g == m.q) ? 0.0f : zs[t][r];
   f32x4 base[4];
-  bx_bias<4>(ldsf, m.b1f, g, base);
-  bx_dense_acc<KT1, 4>(lds + m.w1f, lane, z0in, base);
+  bx_bias<4>(ldsf, L::b1f, g, base);
+  bx_dense_acc<KT1, 4>(lds + L::w1f, lane, z0in, base);
   f32x4 wx[4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) wx[t] = *reinterpret_cast<const f32x4 *>(ldsf + m.wxf + 16 * t + 4 * g);
+  for (int t = 0; t < 4; ++t) wx[t] = *reinterpret_cast<const f32x4 *>(ldsf + L::wxf + 16 * t + 4 * g);
   constexpr int DB = (EFFECT == 2) ? 2 : 4;
   const int nd = (EFFECT == 2) ? 2 : n_doses;
   const int n_calls = (nd + 3) >> 2, n_own = (EFFECT == 1) ? (n_calls & ~3) : 0;
@@ -315,13 +418,13 @@ __device__ __forceinline__ void causal_effects_bx3(const unsigned char *lds, con
     // layer 2 (64 -> 32): A fragments of a K block shared by the DB doses
     f32x4 a2[DB][2];
 #pragma unroll
-    for (int e = 0; e < DB; ++e) bx_bias<2>(ldsf, m.bf2, g, a2[e]);
+    for (int e = 0; e < DB; ++e) bx_bias<2>(ldsf, L::bf2, g, a2[e]);
 #pragma unroll
     for (int T = 0; T < 2; ++T) {
       bx_bf16x8 ah[2], al[2];
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
-        const unsigned char *f = lds + m.wf2 + mt * 4096 + T * 2048 + lane * 16;
+        const unsigned char *f = lds + L::wf2 + mt * 4096 + T * 2048 + lane * 16;
         ah[mt] = *reinterpret_cast<const bx_bf16x8 *>(f);
         al[mt] = *reinterpret_cast<const bx_bf16x8 *>(f + 1024);
       }
@@ -348,12 +451,12 @@ __device__ __forceinline__ void causal_effects_bx3(const unsigned char *lds, con
     for (int e = 0; e < DB; ++e) {
       bx_lrelu<2>(a2[e]);
       f32x4 a3[1];
-      bx_bias<1>(ldsf, m.bf3, g, a3);
-      bx_dense_acc<2, 1>(lds + m.wf3, lane, a2[e], a3);
+      bx_bias<1>(ldsf, L::bf3, g, a3);
+      bx_dense_acc<2, 1>(lds + L::wf3, lane, a2[e], a3);
       bx_lrelu<1>(a3);
       f32x4 a4[1];
-      bx_bias<1>(ldsf, m.bf4, g, a4);
-      bx_dense_acc<1, 1>(lds + m.wf4, lane, a3, a4);
+      bx_bias<1>(ldsf, L::bf4, g, a4);
+      bx_dense_acc<1, 1>(lds + L::wf4, lane, a3, a4);
       mu[e] = a4[0][0];
       sr[e] = a4[0][1];
     }
@@ -388,6 +491,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_bx3_kernel(CausalBxKArgs
   extern __shared__ __attribute__((aligned(16))) unsigned char bx_lds[];
   const CausalMhKArgs &a = ka.a;
   const BxMeta &m = ka.bx;
+  using L = BxLayout<KT1, NTL>;
   bx_lds_fill(bx_lds, ka.bblob, m.total_bytes);
   const float *ldsf = reinterpret_cast<const float *>(bx_lds);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -408,7 +512,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_bx3_kernel(CausalBxKArgs
     const float xr[1] = {a.x[rowc]}, yr = a.y[rowc];
     const unsigned rowid = (unsigned)(a.row_base + rowc);
     f32x4 vreg[NTL];
-    bx_load_v<NTL>(a.v, ldsf + m.bgl, n, m.p, row0, j, g, vreg);
+    bx_load_v<NTL>(a.v, ldsf + L::bgl, n, m.p, row0, j, g, vreg);
     f32x4 zs[1][KT1];
     float lp;
     if (a.init) {
@@ -471,7 +575,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_bx3_kernel(CausalBxKArgs
             }
         }
         if constexpr (EFFECT != 0) {
-          causal_effects_bx3<KT1, EFFECT>(bx_lds, m, lane, g, j, zs[0], rowid, valid, row, n, (unsigned)it, d, a.n_keep, a.sample_y,
+          causal_effects_bx3<KT1, NTL, EFFECT>(bx_lds, m, lane, g, j, zs[0], rowid, valid, row, n, (unsigned)it, d, a.n_keep, a.sample_y,
                                           a.n_doses, a.x_values,
                                           a.adrf_partial + slot * (long long)((EFFECT == 2) ? 2 : a.n_doses) * a.n_keep, a.ite, a.k0, a.k1);
         }

@@ -371,6 +371,25 @@ extern "C" int bgm_causal_get_weights(bgm_handle *h, int net_id, float *theta_ho
   return BGM_OK;
 }
 
+extern "C" int bgm_causal_fit_state(bgm_handle *h, int32_t write, float *m_host, float *v_host, int64_t count, int64_t *steps,
+                                    void *stream_) {
+  if (!h || !h->fit_active) { bgm_set_error("bgm_causal_fit_state: call bgm_causal_fit_begin first"); return BGM_E_STATE; }
+  if (!m_host || !v_host || !steps || count != (int64_t)h->n_params) { bgm_set_error("bgm_causal_fit_state: bad argument (count must be n_params)"); return BGM_E_INVALID; }
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  BGM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_));
+  const size_t bytes = sizeof(float) * (size_t)count;
+  if (write) {
+    BGM_HIP_CHECK(hipMemcpy(h->m1_dev, m_host, bytes, hipMemcpyHostToDevice));
+    BGM_HIP_CHECK(hipMemcpy(h->m2_dev, v_host, bytes, hipMemcpyHostToDevice));
+    h->t_theta = steps[0]; h->t_z = steps[1];
+  } else {
+    BGM_HIP_CHECK(hipMemcpy(m_host, h->m1_dev, bytes, hipMemcpyDeviceToHost));
+    BGM_HIP_CHECK(hipMemcpy(v_host, h->m2_dev, bytes, hipMemcpyDeviceToHost));
+    steps[0] = h->t_theta; steps[1] = h->t_z;
+  }
+  return BGM_OK;
+}
+
 extern "C" int bgm_causal_fit_end(bgm_handle *h, void *stream_) {
   if (!h) return BGM_E_INVALID;
   if (!h->fit_active) return BGM_OK;

@@ -251,6 +251,23 @@ class CausalEngine(object):
             off += nw + dims[i + 1]
         return out
 
+    def fit_state(self, state=None):
+        """Optimizer state of the open fit session (bgm_causal_fit_state): read -> dict(m, v, t_theta, t_z); pass such a
+        dict to install it."""
+        n = self.n_params
+        steps = (C.c_int64 * 2)()
+        if state is None:
+            m, v = np.empty(n, np.float32), np.empty(n, np.float32)
+            _lib.check(self.lib.bgm_causal_fit_state(self.h, 0, m.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), n, steps,
+                                                     self._stream()), "bgm_causal_fit_state")
+            return dict(m=m, v=v, t_theta=int(steps[0]), t_z=int(steps[1]))
+        m = np.ascontiguousarray(state["m"], np.float32)
+        v = np.ascontiguousarray(state["v"], np.float32)
+        steps[0], steps[1] = int(state["t_theta"]), int(state["t_z"])
+        _lib.check(self.lib.bgm_causal_fit_state(self.h, 1, m.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), n, steps,
+                                                 self._stream()), "bgm_causal_fit_state")
+        return None
+
     def fit_end(self):
         _lib.check(self.lib.bgm_causal_fit_end(self.h, self._stream()), "bgm_causal_fit_end")
 

@@ -26,6 +26,7 @@ from .. import _lib, parallel
 from ..engine import CausalEngine
 from ..datasets import Gaussian_sampler
 from ..utils import save_data
+from ._checkpoint import CheckpointManager
 
 _DEFAULTS = dict(use_bnn=True, g_units=[64] * 5, e_units=[64] * 5, f_units=[64, 32, 8], h_units=[64, 32, 8],
                  dz_units=[64, 32, 8], lr=0.0002, lr_theta=0.0001, lr_z=0.0001, g_d_freq=5, save_model=False,
@@ -104,6 +105,17 @@ class CausalBGM(object):
             os.makedirs(self.save_dir, exist_ok=True)
         self.data_z = None
         self.last_acceptance_rate = None
+        self._fit_live = None            # (zm, zv) of the running fit, for checkpoints
+        self._restored_opt = None        # optimizer slots of a restored checkpoint, installed by the next fit
+        self._restore_latest()
+
+    def _restore_latest(self):
+        """tf.train.CheckpointManager(..., max_to_keep=5) + restore of the latest checkpoint at construction (base.py:124-128)."""
+        self.ckpt_manager = CheckpointManager(self.checkpoint_path, max_to_keep=5)
+        latest = self.ckpt_manager.latest_checkpoint
+        if latest:
+            self.load_checkpoint(latest)
+            print('Latest checkpoint restored!!')
 
     # ------------------------------------------------------------------ plumbing
     def get_config(self):
@@ -258,6 +270,10 @@ class CausalBGM(object):
         n_use = n_total // world if world > 1 else n_loc
         eng = self.engine
         n_params = eng.fit_begin(n_loc, b_loc)
+        if self._restored_opt is not None and len(self._restored_opt["m"]) == n_params:
+            eng.fit_state(self._restored_opt)          # g / f / h_optimizer slots and step counters of the restored checkpoint
+        self._restored_opt = None
+        self._fit_live = (zm, zv)
         grad = torch.empty(n_params, device=dev, dtype=torch.float32)
         loss = torch.zeros(8, device=dev, dtype=torch.float64)       # theta phase: row sums of loss_v, |v-mu|^2, loss_x, ...
         loss_z = torch.zeros(8, device=dev, dtype=torch.float64)     # Z phase: [6] = row sums of the negative log joint
@@ -305,19 +321,25 @@ class CausalBGM(object):
                     if self._p['save_res'] and parallel.rank() == 0:
                         save_data('{}/causal_pre_at_{}.{}'.format(self.save_dir, epoch, save_format), causal_pre)
         finally:
+            self._fit_live = None
             eng.fit_end()
             self._pull_weights()
 
     def save_checkpoint(self, epoch):
-        """The reference checkpoints with tf.train.CheckpointManager (base.py:112-128, 529); the build writes
-        the same information (network parameters) as an .npz at the same directory."""
-        path = os.path.join(self.checkpoint_path, "ckpt-%d.npz" % epoch)
+        """ckpt_manager.save(epoch) (base.py:527-529).  The archive holds what the reference's tf.train.Checkpoint tracks
+        (:112-122) -- the parameters of g, e, f, h, and, when written from inside `fit`, the Adam slots and step counters of the
+        g / f / h optimizers and of the latent optimizer -- plus the latent table itself (this rank's rows); at most 5 are kept."""
         flat = {}
         for k, net in self.nets.items():
             for i, (W, b) in enumerate(net):
                 flat["%s_W%d" % (k, i)] = W
                 flat["%s_b%d" % (k, i)] = b
-        np.savez(path, **flat)
+        if self._fit_live is not None:
+            st = self.engine.fit_state()
+            flat.update(opt_m=st["m"], opt_v=st["v"], opt_steps=np.array([st["t_theta"], st["t_z"]], np.int64),
+                        data_z=self.data_z.cpu().numpy(), z_m=self._fit_live[0].cpu().numpy(), z_v=self._fit_live[1].cpu().numpy())
+        flat["seed_state"] = np.array([self._base_seed, self._seed_counter], np.int64)
+        path = self.ckpt_manager.save("ckpt-%s.npz" % epoch, flat)
         print('Saving checkpoint for epoch {} at {}'.format(epoch, path))
         return path
 
@@ -326,6 +348,10 @@ class CausalBGM(object):
         for k in list(self.nets):
             self.nets[k] = [(d["%s_W%d" % (k, i)], d["%s_b%d" % (k, i)]) for i in range(len(self.nets[k]))]
         self._push_weights()
+        if "opt_m" in d.files:
+            self._restored_opt = dict(m=d["opt_m"], v=d["opt_v"], t_theta=int(d["opt_steps"][0]), t_z=int(d["opt_steps"][1]))
+        if "seed_state" in d.files and int(d["seed_state"][0]) == self._base_seed:
+            self._seed_counter = int(d["seed_state"][1])
 
     # ------------------------------------------------------------------ evaluate
     @staticmethod

@@ -91,6 +91,7 @@ class CausalBGMBayes(CausalBGM):
             os.makedirs(self.save_dir, exist_ok=True)
         self.data_z = None
         self.last_acceptance_rate = None
+        self._restore_latest()
 
     # ------------------------------------------------------------------ plumbing
     def _noise_seed(self, per_rank=False):
@@ -117,13 +118,23 @@ class CausalBGMBayes(CausalBGM):
         self._push_weights()
 
     def save_checkpoint(self, epoch):
-        path = os.path.join(self.checkpoint_path, "ckpt-%d.npz" % epoch)
-        np.savez(path, theta=self.engine.read(0))
+        """ckpt_manager.save(epoch): parameters and the Adam slots of the session (g / f / h_optimizer), the noise-stream counter,
+        the latent table when written from inside `fit`; at most 5 kept (base.py:112-128, 527-529)."""
+        flat = dict(theta=self.engine.read(0), opt_m=self.engine.read(2), opt_v=self.engine.read(3),
+                    stream=np.array([self._stream], np.int64))
+        if self.data_z is not None:
+            flat["data_z"] = self.data_z.cpu().numpy()
+        path = self.ckpt_manager.save("ckpt-%s.npz" % epoch, flat)
         print('Saving checkpoint for epoch {} at {}'.format(epoch, path))
         return path
 
     def load_checkpoint(self, path):
-        self.engine.write(np.load(path)["theta"])
+        d = np.load(path)
+        self.engine.write(d["theta"])
+        if "opt_m" in d.files:
+            self.engine.write(d["opt_m"], 2)
+            self.engine.write(d["opt_v"], 3)
+            self._stream = int(d["stream"][0])
         self._pull_weights()
 
     # ------------------------------------------------------------------ EGM

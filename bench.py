@@ -181,7 +181,7 @@ def bf16x3_leg(model, data, x_values, n_loc, args, z_dims, flop_row_transition, 
     return {"value": n_loc * (args.burn_in + args.n_mcmc) / dt, "unit": "MH transitions/s", "seconds": dt,
             "sample": f"CausalBGM(mh_precision='bf16x3').predict, N={n_loc}, burn_in={args.burn_in}, n_mcmc={args.n_mcmc}, "
                       f"{len(x_values)} doses (one call)",
-            "acceptance_rate": model.last_acceptance_rate, "adrf_head": [float(a) for a in adrf[:3]],
+            "acceptance_rate": model.last_acceptance_rate, "adrf_head": [float(a) for a in adrf[:3]], "adrf": np.asarray(adrf),
             "burn_in_kernel_ms": ms_b / max(1, n_b), "keep_kernel_ms": ms_k / max(1, n_k),
             "roofline": {"bound": "mfma", "kernel": "causal_mh_bx3_kernel (burn-in + keep launches)",
                          "achieved": ach, "unit": "TFLOP/s (algorithmic fp32-equivalent FLOP)",
@@ -369,14 +369,14 @@ def main():
             out["cpu_baseline"] = cpu_baseline(params, p, z_dims)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
             out["parity"] = parity_leg(model, x, y, v, z_dims, p, x_values)
+        if not args.no_bf16x3 and world == 1:      # before the fit leg, which trains (changes) the weights of `model`
+            out["bf16x3"] = bf16x3_leg(model, data, x_values, n_loc, args, z_dims, info.flop_per_row_transition, flop_keep_row, seed_counter_last)
+            out["bf16x3"]["speedup_vs_fp32"] = out["bf16x3"]["value"] / value
+            out["bf16x3"]["adrf_max_abs_diff_vs_fp32"] = float(np.abs(out["bf16x3"].pop("adrf") - adrf).max())
         if not args.no_bayesian and world == 1:
             out["bayesian_nets"] = bayesian_leg(params, data, x_values, n_loc, args, device)
         if not args.no_fit and world == 1:
             out["fit"] = fit_leg(model, x, y, v, n_loc)
-        if not args.no_bf16x3 and world == 1:
-            out["bf16x3"] = bf16x3_leg(model, data, x_values, n_loc, args, z_dims, info.flop_per_row_transition, flop_keep_row, seed_counter_last)
-            out["bf16x3"]["speedup_vs_fp32"] = out["bf16x3"]["value"] / value
-            out["bf16x3"]["adrf_max_abs_diff_vs_fp32_head"] = float(np.abs(np.array(out["bf16x3"]["adrf_head"]) - adrf[:3]).max())
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -241,6 +241,11 @@ int bgm_causal_fit_z_step(bgm_handle *h, const float *x_dev, const float *y_dev,
  * handle's host copy.  Synchronous. */
 int bgm_causal_get_weights(bgm_handle *h, int net_id, float *theta_host, int64_t count, void *stream);
 
+/* Optimizer state of the open fit session, for checkpoints (the reference's tf.train.Checkpoint holds g/f/h_optimizer and
+ * posterior_optimizer, causalbgm/base.py:112-122): Adam first / second moments of theta_g | theta_f | theta_h [n_params each] and
+ * the step counters steps[0] = theta steps, steps[1] = latent steps.  write = 0 reads them into the host buffers, write = 1
+ * installs them (after bgm_causal_fit_begin, which zeroes them).  The latent table's slots zm / zv are the caller's buffers. */
+int bgm_causal_fit_state(bgm_handle *h, int32_t write, float *m_host, float *v_host, int64_t count, int64_t *steps, void *stream);
 /* End the fit session (frees the workspace; the trained parameters stay installed). */
 int bgm_causal_fit_end(bgm_handle *h, void *stream);
 

@@ -1,0 +1,34 @@
+#!/bin/bash
+# Round-2 rocprofv3 evidence, run on the GPU box from the repo root (gpurun): kernel traces and PMC passes of the SHIPPED kernels.
+# Counters in their own runs (no trace domains besides --kernel-trace), as MI355X_MICROARCH.md prescribes: SQ set | FETCH_SIZE | WRITE_SIZE.
+# usage: bash scripts/collect_r02_profiles.sh [what ...]   what in: bench mh encode hmc fit   (default: all)
+set -u
+OUT=gpurun_out/r02prof
+mkdir -p $OUT
+export TMPDIR=/tmp
+SQ="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY"
+WHAT="${*:-bench mh encode hmc fit}"
+summ() { for db in $(find $1 -name "*_results.db" 2>/dev/null); do python scripts/prof_summary.py $db; done; }
+pmc3() {   # name, command...
+  local name=$1; shift
+  timeout 900 rocprofv3 --kernel-trace --pmc $SQ -d $OUT/${name}_sq -o sq -- "$@" > $OUT/${name}_sq.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $OUT/${name}_fetch -o fetch -- "$@" > $OUT/${name}_fetch.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/${name}_write -o write -- "$@" > $OUT/${name}_write.log 2>&1
+  { echo "# command: $*"; echo "# pass 1: --pmc $SQ"; summ $OUT/${name}_sq; echo "# pass 2: --pmc FETCH_SIZE GRBM_GUI_ACTIVE"; summ $OUT/${name}_fetch;
+    echo "# pass 3: --pmc WRITE_SIZE"; summ $OUT/${name}_write; } > $OUT/r02_pmc_${name}.txt
+}
+for w in $WHAT; do
+  case $w in
+    bench)
+      python bench.py --steps 2 --warmup 1 > $OUT/r02_bench_N1e6_1gpu.json 2> $OUT/bench.err
+      timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/kt_bench -o kt -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-bayesian --no-fit --no-accuracy > $OUT/kt_bench.log 2>&1
+      { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-bayesian --no-fit --no-accuracy"; summ $OUT/kt_bench; } > $OUT/r02_kernel_trace_bench_N1e6.txt ;;
+    mh) pmc3 mh_N1e6_60burn_40keep python scripts/probe_mh.py 1e6 100 40 ;;
+    encode)
+      python scripts/probe_encode.py 1e6 200 20 > $OUT/r02_encode_N1e6.json 2> $OUT/encode.err
+      pmc3 encode_N1e6 python scripts/probe_encode.py 1e6 200 5 ;;
+    hmc) pmc3 bgm_hmc python scripts/probe_bgm_wide.py 200000 10 ;;
+    fit) pmc3 fit_B65536 python scripts/probe_fit.py 1e6 65536 dense 20 ;;
+  esac
+done
+ls -la $OUT | head -40

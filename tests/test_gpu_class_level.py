@@ -17,7 +17,7 @@ import os
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+gpu = pytest.mark.gpu
 
 from oracle import causal as OC  # noqa: E402
 from oracle import fit as OF     # noqa: E402
@@ -41,6 +41,7 @@ def _flat(net):
     return np.concatenate([np.concatenate([np.asarray(W, np.float64).ravel(), np.asarray(b, np.float64).ravel()]) for W, b in net])
 
 
+@gpu
 @pytest.mark.parametrize("lr", [1e-4, 1e-3])
 def test_causalbgm_fit_trace_matches_oracle(lr):
     from bayesgm_amd.models import CausalBGM
@@ -90,6 +91,7 @@ def test_causalbgm_fit_trace_matches_oracle(lr):
     assert dz <= 0.02 * moved_z + 1e-7
 
 
+@gpu
 @pytest.mark.parametrize("q_sd", [1.0, -1.0])
 def test_causalbgm_predict_continuous_blocks_vs_oracle(q_sd):
     """3 `bs`-blocks (250 + 250 + 100 rows); q_sd = -1 adapts the proposal scale per block at iterations 50 and 100."""
@@ -113,6 +115,7 @@ def test_causalbgm_predict_continuous_blocks_vs_oracle(q_sd):
     assert np.all(interval[:, 0] <= adrf) and np.all(adrf <= interval[:, 1])
 
 
+@gpu
 @pytest.mark.parametrize("q_sd", [1.0, 0.0])
 def test_causalbgm_predict_binary_blocks_vs_oracle(q_sd):
     """Binary treatment: per-row ITE means and np.quantile intervals over 3 blocks, z_dims of the CLI default."""
@@ -132,6 +135,7 @@ def test_causalbgm_predict_binary_blocks_vs_oracle(q_sd):
     assert abs(float(ite.mean()) - float(ref_ite.mean())) <= 2e-3            # ATE = mean(ITE) (tutorial cell 31)
 
 
+@gpu
 def test_bgm_fit_trace_matches_oracle():
     """BGM.fit (bgm/base.py:343-442): Z ~ N(0,1) from the host stream, np.random.choice permutation per epoch, the incomplete
     last batch SKIPPED (2000 rows -> 62 minibatches), theta step (training-mode BatchNorm, moving averages) + fresh-slot Z
@@ -170,3 +174,44 @@ def test_bgm_fit_trace_matches_oracle():
     wm = max(np.abs(m["g"][k][0] - np.asarray(BGM(prm, random_seed=9).g[k][0], np.float64)).max() for k in ("mean", "var"))
     print("BGM fit: head weights moved %.3e, |hip - oracle| %.3e" % (wm, wd))
     assert wd <= 0.02 * wm + 1e-7
+
+
+@gpu
+def test_checkpoint_manager_semantics(tmp_path):
+    """tf.train.CheckpointManager(max_to_keep=5) + restore-latest-at-construction (causalbgm/base.py:112-128, 524-530): a fit that
+    improves mse_y at every evaluation saves ckpt-<epoch>; at most five stay; a model constructed with the same timestamp
+    restores the latest one -- parameters, and (installed by its next fit) the Adam slots and step counters."""
+    from bayesgm_amd.models import CausalBGM
+    g = np.load(GOLD)
+    x, y, v = g["x"][:512], g["y"][:512], g["v"][:512]
+    prm = dict(_params(), output_dir=str(tmp_path), save_model=True, lr_theta=1e-3, lr_z=1e-3)
+    model = CausalBGM(prm, timestamp="run1", random_seed=4)
+    model.fit((x, y, v), epochs=7, epochs_per_eval=1, batch_size=64, use_egm_init=False, verbose=0)
+    files = sorted(f for f in os.listdir(model.checkpoint_path) if f.startswith("ckpt-"))
+    assert 1 <= len(files) <= 5, files
+    latest = model.ckpt_manager.latest_checkpoint
+    assert latest is not None and os.path.basename(latest) in files
+    d = np.load(latest)
+    assert {"opt_m", "opt_v", "opt_steps", "data_z", "z_m", "z_v", "g_W0", "e_W0"} <= set(d.files)
+    epoch_saved = int(os.path.basename(latest)[5:-4])
+    assert int(d["opt_steps"][0]) == 8 * (epoch_saved + 1)          # 8 minibatches of 64 per epoch
+    again = CausalBGM(prm, timestamp="run1", random_seed=99)        # other seed: the weights must come from the checkpoint
+    for k in "gfhe":
+        for (W, b), i in zip(again.nets[k], range(99)):
+            assert np.array_equal(W, d["%s_W%d" % (k, i)]) and np.array_equal(b, d["%s_b%d" % (k, i)])
+    assert again._restored_opt is not None and again._restored_opt["t_theta"] == int(d["opt_steps"][0])
+    again.fit((x, y, v), epochs=0, epochs_per_eval=1, batch_size=64, use_egm_init=False, verbose=0)   # slots installed, steps go on
+    assert again._restored_opt is None
+    fresh = CausalBGM(prm, timestamp="run2", random_seed=99)        # another run directory: nothing to restore
+    assert fresh.ckpt_manager.latest_checkpoint is None
+
+
+def test_checkpoint_manager_prunes_on_cpu_arrays(tmp_path):
+    from bayesgm_amd.models._checkpoint import CheckpointManager
+    m = CheckpointManager(str(tmp_path / "c"), max_to_keep=5)
+    assert m.latest_checkpoint is None
+    for e in range(8):
+        m.save("ckpt-%d.npz" % e, dict(a=np.arange(3) + e))
+    names = sorted(f for f in os.listdir(m.directory) if f.endswith(".npz"))
+    assert names == ["ckpt-%d.npz" % e for e in range(3, 8)]
+    assert os.path.basename(m.latest_checkpoint) == "ckpt-7.npz" and np.load(m.latest_checkpoint)["a"][0] == 7
