@@ -148,6 +148,48 @@ def bayesian_leg(params, data, x_values, n_loc, args, device):
             "flop_per_row_transition": flop_row}
 
 
+def accuracy_leg(params, data, x_values, n_loc, args):
+    """The accuracy half of the metric ("... + ATE abs-error"): the model class of the headline number (deterministic nets)
+    is TRAINED with the reference's default schedule on the tutorial panel (Hirano-Imbens N = 20000, p = 200; 30000 EGM
+    iterations + 100 epochs, causalbgm/base.py:434 defaults), then predicts on the bench panel (N rows of the same generator,
+    other seed) with the bench's MCMC settings, in fp32 and in split precision; errors against the analytic dose-response
+    curve utils.get_ADRF(..., 'Imbens').  (The reference's default Bayesian-network configuration reaches ADRF RMSE
+    0.016-0.024 against the published 0.0188: profiles/r02_accuracy/, tests/test_tutorial_trace.py.)"""
+    import contextlib
+    import torch
+    from bayesgm_amd.models import CausalBGM
+    from bayesgm_amd.datasets import Sim_Hirano_Imbens_sampler
+    from bayesgm_amd.utils import get_ADRF
+    truth = get_ADRF(x_values=list(x_values), dataset="Imbens")
+    x, y, v = Sim_Hirano_Imbens_sampler(N=20000, v_dim=args.p, seed=0).load_all()
+    out = {}
+    with contextlib.redirect_stdout(sys.stderr):
+        m = CausalBGM(dict(params, use_bnn=False), timestamp="bench_acc", random_seed=123)
+        t0 = time.perf_counter()
+        m.fit((x, y, v), epochs=100, epochs_per_eval=100, use_egm_init=True, egm_n_iter=30000, egm_batches_per_eval=30000, verbose=0)
+        torch.cuda.synchronize()
+        out["fit_seconds"] = time.perf_counter() - t0
+        for mode in ("fp32", "bf16x3"):
+            m.engine.set_precision(mode)
+            m._seed_counter = 0
+            t0 = time.perf_counter()
+            adrf, interval = m.predict(data, alpha=0.01, n_mcmc=args.n_mcmc, burn_in=args.burn_in, x_values=x_values, q_sd=1.0,
+                                       sample_y=True, verbose=0)
+            torch.cuda.synchronize()
+            err = adrf - truth
+            out[mode] = {"adrf_rmse": float(np.sqrt(np.mean(err ** 2))), "adrf_mape": float(np.mean(np.abs(err / truth))),
+                         "average_effect_abs_error": float(abs(err.mean())), "max_abs_error": float(np.abs(err).max()),
+                         "interval_coverage": float(np.mean((interval[:, 0] <= truth) & (truth <= interval[:, 1]))),
+                         "acceptance_rate": m.last_acceptance_rate, "predict_seconds": time.perf_counter() - t0}
+        m.engine.set_precision("fp32")
+    out["sample"] = (f"CausalBGM(use_bnn=False): fit on Sim_Hirano_Imbens N=20000 p={args.p} seed 0 (reference defaults: 30000 EGM "
+                     f"iterations + 100 epochs, batch 32), predict on the bench panel N={n_loc} with burn_in={args.burn_in}, "
+                     f"n_mcmc={args.n_mcmc}, {len(x_values)} doses; truth = x + 2/(1+x)^3")
+    out["reference_published"] = {"adrf_rmse": 0.0188, "adrf_mape": 0.0103,
+                                  "note": "docs/source/causalbgm/tutorial_py.ipynb (use_bnn=True, N=20000 train = test panel)"}
+    return out
+
+
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
 
 
@@ -352,7 +394,8 @@ def main():
             "value": value, "unit": "MH transitions/s (rows x (burn_in+n_mcmc) / t_predict)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic (Sim_Hirano_Imbens generator, random-init glorot weights)",
+            "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (Sim_Hirano_Imbens generator; throughput legs on random-init glorot weights, accuracy leg on trained weights)",
             "config": {"workload": f"CausalBGM.predict continuous treatment, N={n_loc} rows/GPU ({n_total} in total), p={p}, "
                                    f"z_dims {z_dims}, burn_in={args.burn_in}, n_mcmc={args.n_mcmc}, q_sd=1.0, "
                                    f"20 doses, sample_y=True",
@@ -373,6 +416,8 @@ def main():
             out["bf16x3"] = bf16x3_leg(model, data, x_values, n_loc, args, z_dims, info.flop_per_row_transition, flop_keep_row, seed_counter_last)
             out["bf16x3"]["speedup_vs_fp32"] = out["bf16x3"]["value"] / value
             out["bf16x3"]["adrf_max_abs_diff_vs_fp32"] = float(np.abs(out["bf16x3"].pop("adrf") - adrf).max())
+        if not args.no_accuracy and world == 1:
+            out["accuracy"] = accuracy_leg(params, data, x_values, n_loc, args)
         if not args.no_bayesian and world == 1:
             out["bayesian_nets"] = bayesian_leg(params, data, x_values, n_loc, args, device)
         if not args.no_fit and world == 1:
