@@ -100,6 +100,7 @@ SYMBOLS = {
     "bgm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "bgm_set_disc_norm": (C.c_int, [C.c_void_p, C.c_int32]),
     "bgm_causal_set_precision": (C.c_int, [C.c_void_p, C.c_int32]),
+    "bgm_causal_set_prior": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "bgm_destroy": (C.c_int, [C.c_void_p]),
     "bgm_causal_configure": (C.c_int, [C.c_void_p, C.POINTER(CausalConfig)]),
     "bgm_causal_set_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -125,6 +126,7 @@ SYMBOLS = {
     "bgm_causal_fit_z_step": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_int32, C.c_float,
                                         C.c_int32, C.c_void_p, C.c_void_p]),
     "bgm_causal_get_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "bgm_causal_fit_z_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bgm_causal_fit_state": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
     "bgm_causal_fit_end": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bgm_bgm_configure": (C.c_int, [C.c_void_p, C.POINTER(BgmConfig)]),

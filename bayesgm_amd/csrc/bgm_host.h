@@ -62,6 +62,10 @@ struct bgm_handle {
   size_t bx_cap = 0;
   bool bx_valid = false;
   alignas(8) unsigned char bx_meta_store[192];
+  // per-row conditional latent prior of the sampling kernels (causal_prior_api.hip, bgm_causal_set_prior); NULL = standard normal
+  const int32_t *prior_seg = nullptr;
+  const float *prior_tab = nullptr;
+  int prior_segments = 0;
   // encoder blob
   float *eblob_dev = nullptr;
   size_t eblob_cap = 0;
@@ -133,6 +137,10 @@ void bgm_bgm_egm_free_state(bgm_handle *h);
 void bgm_bnn_free_state(bgm_handle *h);
 void bgm_bvn_free_state(bgm_handle *h);
 int causal_pack_forward(bgm_handle *h, const HostNet &G, const HostNet &F, const HostNet &H, std::vector<float> &blob);
+// conditional-prior sampling path (causal_prior_api.hip)
+int bgm_causal_prior_logpost(bgm_handle *h, const float *x, const float *y, const float *v, const float *z, int64_t n, float *out, int grid,
+                             hipStream_t stream);
+int bgm_causal_prior_mh_launch(bgm_handle *h, const CausalMhKArgs &a, int effect, int grid, int lds, hipStream_t stream);
 // split-precision sampling path (causal_bx3_api.hip)
 int bgm_causal_bx3_blob(bgm_handle *h, hipStream_t stream);
 int bgm_causal_bx3_logpost(bgm_handle *h, const float *x, const float *y, const float *v, const float *z, int64_t n, float *out, int grid,

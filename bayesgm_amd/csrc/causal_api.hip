@@ -318,6 +318,10 @@ extern "C" int bgm_causal_logpost(bgm_handle *h, const float *x, const float *y,
   int rc = bgm_causal_sampling_blob(h, stream);
   if (rc) return rc;
   const int grid = mh_grid(h, n);
+  if (h->prior_seg) {
+    if (h->precision == 1) { bgm_set_error("bgm_causal_logpost: the conditional prior is built for the fp32 kernels only"); return BGM_E_UNSUPPORTED; }
+    return bgm_causal_prior_logpost(h, x, y, v, z, n, out, grid, stream);
+  }
   if (h->precision == 1) return bgm_causal_bx3_logpost(h, x, y, v, z, n, out, grid, stream);
   const int lds = h->meta.total * 4;
 #define X(KT1_, KSL1_, NTL_)                                                                   \
@@ -326,7 +330,7 @@ extern "C" int bgm_causal_logpost(bgm_handle *h, const float *x, const float *y,
     rc = set_lds(k, lds);                                                                      \
     if (rc) return rc;                                                                         \
     hipLaunchKernelGGL(k, dim3(grid), dim3(64 * MH_WAVES), lds, stream, h->sblob_dev, h->meta,  \
-                       x, y, v, z, (long long)n, out);                                         \
+                       x, y, v, z, (long long)n, out, (const int *)nullptr, (const float *)nullptr); \
     BGM_HIP_CHECK(hipGetLastError());                                                          \
     return BGM_OK;                                                                             \
   }
@@ -408,7 +412,10 @@ extern "C" int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *a, void *stre
       BGM_HIP_CHECK(hipEventCreate(&e0)); BGM_HIP_CHECK(hipEventCreate(&e1));
       BGM_HIP_CHECK(hipEventRecord(e0, stream));
     }
-    if (h->precision == 1) rc = bgm_causal_bx3_mh_launch(h, ka, segs[s].effect, grid, stream);
+    if (h->prior_seg) {
+      if (h->precision == 1) { bgm_set_error("bgm_causal_mh_run: the conditional prior is built for the fp32 kernels only"); return BGM_E_UNSUPPORTED; }
+      rc = bgm_causal_prior_mh_launch(h, ka, segs[s].effect, grid, lds, stream);
+    } else if (h->precision == 1) rc = bgm_causal_bx3_mh_launch(h, ka, segs[s].effect, grid, stream);
     else if (segs[s].effect == BGM_EFFECT_ADRF) rc = launch_mh<1>(h, ka, grid, lds, stream);
     else if (segs[s].effect == BGM_EFFECT_ITE) rc = launch_mh<2>(h, ka, grid, lds, stream);
     else rc = launch_mh<0>(h, ka, grid, lds, stream);

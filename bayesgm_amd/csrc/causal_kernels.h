@@ -44,6 +44,8 @@ struct CausalMhKArgs {
   float *adrf_partial;
   float *ite;
   unsigned long long *clk;
+  const int *seg;           // conditional prior (IdentifiableCausalBGM): segment of every local row, or NULL
+  const float *prior_tab;   // [n_segments][q + 2]: mu(u) [q], 1 / sigma^2(u), (q / 2) log sigma^2(u)
   CausalMeta m;
 };
 
@@ -343,13 +345,54 @@ __device__ __forceinline__ void store_z_rows(float *z, long long n, int q, long 
 
 
 // ---------------------------------------------------------------------------
+// Conditional latent prior of IdentifiableCausalBGM (models/causalbgm/identifiable.py:195-211, 541-551):
+// Z | U ~ N(mu(U), sigma^2(U) I) with U the one-hot segment of the row, so -log p(z | u) = |z - mu|^2 / (2 sigma^2) + (q/2) log sigma^2
+// replaces |z|^2 / 2.  causal_logp keeps the standard-normal term; kernels instantiated with PRIOR = 1 hold the row's
+// (mu, 1/sigma^2, (q/2) log sigma^2) in registers and add the difference to every log-posterior they evaluate.
+// ---------------------------------------------------------------------------
+template <int KT1>
+struct PriorRow {
+  f32x4 mu[KT1];      // feature 16 t + 4 r + g, as the L1 input tiles
+  float is2, lc;
+  __device__ __forceinline__ void load(const int *seg, const float *tab, long long row, int q, int g) {
+    const float *t = tab + (long long)seg[row] * (q + 2);
+#pragma unroll
+    for (int tt = 0; tt < KT1; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = 16 * tt + 4 * r + g;
+        const float val = t[f < q ? f : q + 1];       // unconditional in-bounds load (the row has q + 2 entries), then mask: a load under
+                                                      // the select makes hipcc 7.2 fail with its "$src_shared_base" illegal-instruction error
+        mu[tt][r] = (f < q) ? val : 0.0f;
+      }
+    is2 = t[q];
+    lc = t[q + 1];
+  }
+  // log p_cond(z) - log p_std(z) = |z|^2 / 2 - is2 |z - mu|^2 / 2 - lc      (same value in the four lane groups)
+  __device__ __forceinline__ float correction(const f32x4 (&z)[KT1], int q, int g) const {
+    float part = 0.0f;
+#pragma unroll
+    for (int tt = 0; tt < KT1; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float zz = z[tt][r], d = zz - mu[tt][r];
+        const float term = 0.5f * (zz * zz - is2 * d * d);
+        part += (16 * tt + 4 * r + g < q) ? term : 0.0f;
+      }
+    return sum_over_g(part) - lc;
+  }
+};
+
+// ---------------------------------------------------------------------------
 // get_log_posterior for n rows (one evaluation)
 // ---------------------------------------------------------------------------
-template <int KT1, int KSL1, int NTL, int R, int WAVES>
+template <int KT1, int KSL1, int NTL, int R, int WAVES, int PRIOR = 0>
 __global__ __launch_bounds__(64 * WAVES) void causal_logpost_kernel(const float *blob, CausalMeta m,
                                                                     const float *x, const float *y,
                                                                     const float *v, const float *z,
-                                                                    long long n, float *out) {
+                                                                    long long n, float *out, const int *seg = nullptr,
+                                                                    const float *prior_tab = nullptr) {
+  static_assert(PRIOR == 0 || R == 1, "conditional prior: one row tile per wave");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   lds_fill(lds, blob, m.total);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -377,6 +420,12 @@ __global__ __launch_bounds__(64 * WAVES) void causal_logpost_kernel(const float 
 #else
     causal_logp<KT1, KSL1, NTL, R>(lds, m, lane_off, g, j, zin, vreg, xr, yr, lp);
 #endif
+    if constexpr (PRIOR) {
+      PriorRow<KT1> pr;
+      const long long rowc = (row0 + j < n) ? row0 + j : n - 1;
+      pr.load(seg, prior_tab, rowc, m.q, g);
+      lp[0] += pr.correction(zin[0], m.q, g);
+    }
 #pragma unroll
     for (int rr = 0; rr < R; ++rr) {
       const long long row = row0 + 16 * rr + j;
@@ -406,7 +455,7 @@ __device__ __forceinline__ float pick_by_group(int g, float v0, float v1, float 
   return g == 0 ? v0 : (g == 1 ? v1 : (g == 2 ? v2 : v3));
 }
 
-template <int KT1, int KSL1, int R, int EFFECT>
+template <int KT1, int KSL1, int R, int EFFECT, bool GROUPING = true>
 __device__ __forceinline__ void causal_effects(const float *lds, const CausalMeta &m, int lane_off, int g, int j,
                                                int lane, const f32x4 (&zs)[R][KT1], const unsigned (&rowid)[R],
                                                const bool (&valid)[R], long long row0, long long n, unsigned it,
@@ -428,7 +477,7 @@ __device__ __forceinline__ void causal_effects(const float *lds, const CausalMet
   for (int t = 0; t < 4; ++t) wx[t] = *reinterpret_cast<const f32x4 *>(lds + m.wxf + 16 * t + 4 * g);
   const int nd = (EFFECT == 2) ? 2 : n_doses;
   constexpr int DB = (EFFECT == 2) ? 2 : 4;  // doses evaluated per pass (independent MFMA chains)
-  constexpr bool GROUPED = (EFFECT == 1 && R == 1);   // lane group g finishes dose e = g of a pass (see above)
+  constexpr bool GROUPED = (EFFECT == 1 && R == 1 && GROUPING);   // lane group g finishes dose e = g of a pass (see above)
   const int n_calls = (nd + 3) >> 2, n_own = GROUPED ? (n_calls & ~3) : 0;   // Philox calls [0, n_own) in groups of four
   f32x4 nz[R];
 #pragma unroll
@@ -566,8 +615,9 @@ __device__ __forceinline__ void causal_effects(const float *lds, const CausalMet
 // ---------------------------------------------------------------------------
 // Persistent random-walk Metropolis-Hastings over a segment of iterations.
 // ---------------------------------------------------------------------------
-template <int KT1, int KSL1, int NTL, int R, int WAVES, int EFFECT>
+template <int KT1, int KSL1, int NTL, int R, int WAVES, int EFFECT, int PRIOR = 0>
 __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) {
+  static_assert(PRIOR == 0 || R == 1, "conditional prior: one row tile per wave");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const CausalMeta &m = a.m;
   lds_fill(lds, a.blob, m.total);
@@ -602,6 +652,8 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
     }
     f32x4 vreg[R][NTL];
     load_v_rows<NTL, R>(a.v, lds + m.bgl, n, m.p, row0, j, g, vreg);
+    PriorRow<KT1> pr;
+    if constexpr (PRIOR) pr.load(a.seg, a.prior_tab, (row0 + j < n) ? row0 + j : n - 1, m.q, g);
     f32x4 zs[R][KT1];
     if (a.init) {
       // current_state ~ N(0,1)  (base.py:842), RNG spec tag 0
@@ -622,6 +674,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
 #else
       causal_logp<KT1, KSL1, NTL, R>(lds, m, lane_off, g, j, zs, vreg, xr, yr, lp);
 #endif
+      if constexpr (PRIOR) lp[0] += pr.correction(zs[0], m.q, g);
     } else {
       load_z_rows<KT1, R>(a.state, n, m.q, row0, j, g, xr, zs);
 #pragma unroll
@@ -673,6 +726,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
 #else
       causal_logp<KT1, KSL1, NTL, R>(lds, m, lane_off, g, j, zp, vreg, xr, yr, lpp);
 #endif
+      if constexpr (PRIOR) lpp[0] += pr.correction(zp[0], m.q, g);
       PMARK(5);
       // ---- accept / reject   (base.py:868-871).  u(it) = word (it & 3) of Philox(row, it >> 2, 0, TAG_ACC)
       if ((it & 3) == 0 || it == a.it_begin) {

@@ -371,6 +371,24 @@ extern "C" int bgm_causal_get_weights(bgm_handle *h, int net_id, float *theta_ho
   return BGM_OK;
 }
 
+extern "C" int bgm_causal_fit_z_grad(bgm_handle *h, const float *x, const float *y, const float *v, const float *data_z,
+                                     const int32_t *idx, int64_t row_lo, int32_t batch, int32_t batch_global, float *dz_out,
+                                     double *loss, void *stream_) {
+  int rc = fit_check(h, x, y, v, data_z, batch, batch_global, "bgm_causal_fit_z_grad");
+  if (rc) return rc;
+  if (!dz_out) { bgm_set_error("bgm_causal_fit_z_grad: dz_out_dev is NULL"); return BGM_E_INVALID; }
+  hipStream_t stream = (hipStream_t)stream_;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  FitKArgs ka{};
+  ka.m = h->meta; ka.bm = h->fit_meta; ka.ws = h->fit_ws; ka.wsp = h->ws_dev;
+  ka.x = x; ka.y = y; ka.v = v; ka.data_z = data_z; ka.idx = idx; ka.row_lo = row_lo; ka.B = batch;
+  ka.inv_B = 1.0f / (float)batch_global; ka.z_mode = 1; ka.loss = loss;
+  rc = launch_fwd_bwd(h, ka, stream);
+  if (rc) return rc;
+  BGM_HIP_CHECK(hipMemcpyAsync(dz_out, h->ws_dev + h->fit_ws.dz, sizeof(float) * (size_t)batch * h->q, hipMemcpyDeviceToDevice, stream));
+  return BGM_OK;
+}
+
 extern "C" int bgm_causal_fit_state(bgm_handle *h, int32_t write, float *m_host, float *v_host, int64_t count, int64_t *steps,
                                     void *stream_) {
   if (!h || !h->fit_active) { bgm_set_error("bgm_causal_fit_state: call bgm_causal_fit_begin first"); return BGM_E_STATE; }

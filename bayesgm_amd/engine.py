@@ -237,6 +237,18 @@ class CausalEngine(object):
                                                   int(bool(lazy)), _ptr(loss), self._stream()),
                    "bgm_causal_fit_z_step")
 
+    def fit_z_grad(self, x, y, v, data_z, idx, batch_global, dz_out, loss=None):
+        """d(batch-mean negative log joint, standard-normal prior)/d(batch rows of data_z) -> dz_out [batch x q]; no update."""
+        _lib.check(self.lib.bgm_causal_fit_z_grad(self.h, _ptr(x), _ptr(y), _ptr(v), _ptr(data_z), _ptr(idx), 0, int(idx.numel()),
+                                                  int(batch_global), _ptr(dz_out), _ptr(loss), self._stream()), "bgm_causal_fit_z_grad")
+
+    def set_prior(self, seg=None, tab=None):
+        """Conditional latent prior of the sampling calls made afterwards (bgm_causal_set_prior): seg int32 [n] (device), tab float32
+        [n_segments x (q + 2)] = mu, 1 / sigma^2, (q / 2) log sigma^2 per segment (device).  None clears it."""
+        self._prior_keep = (seg, tab)          # keep the buffers alive while set
+        _lib.check(self.lib.bgm_causal_set_prior(self.h, _ptr(seg), _ptr(tab), 0 if tab is None else int(tab.shape[0])),
+                   "bgm_causal_set_prior")
+
     def get_weights(self, net_id, dims):
         """Device parameters of one net -> [(W, b), ...] (Keras order)."""
         count = sum(dims[i] * dims[i + 1] + dims[i + 1] for i in range(len(dims) - 1))

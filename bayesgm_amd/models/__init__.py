@@ -1,5 +1,6 @@
 """Drop-in mirror of ``bayesgm.models`` for the hot path."""
 from .causalbgm import CausalBGM
 from .bgm import BGM
+from .identifiable import IdentifiableCausalBGM
 
-__all__ = ["CausalBGM", "BGM"]
+__all__ = ["CausalBGM", "BGM", "IdentifiableCausalBGM"]

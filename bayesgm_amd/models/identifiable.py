@@ -1,0 +1,242 @@
+"""IdentifiableCausalBGM: CausalBGM with the iVAE-style conditional latent prior  Z | U ~ N(mu(U), sigma^2(U) I),  U the one-hot
+of a random segment of the row (/root/reference/src/bayesgm/models/causalbgm/identifiable.py:15-616).
+
+What is on the device: everything CausalBGM has (EGM warm start, theta steps, evaluate), the Z-gradient of the minibatch
+(`bgm_causal_fit_z_grad`) and the MH / log-posterior kernels with the per-row conditional prior (`bgm_causal_set_prior`, the
+PRIOR = 1 instantiations of csrc/causal_kernels.h).  What stays on the host side of the C ABI, as torch ops on [32 x q] tensors: the
+prior network (n_segments -> prior_units -> q + 1, a few thousand parameters), its Adam step and the fresh-slot Adam step on the
+batch latents -- the reference's `update_latent_variable_sgd` (:150-226) restated in oracle/identifiable.py.
+
+Stated differences.  (i) The reference's `fit` unpacks seven values from `evaluate`, which returns four (:334 vs base.py:555,570),
+so it fails at the first evaluation; the build evaluates as CausalBGM does.  (ii) `use_bnn=True` (a Bayesian prior network on the
+Bayesian-network kernels) is not built: NotImplementedError.  (iii) Single process only (no torch.distributed sharding)."""
+import numpy as np
+import torch
+
+from .. import _lib, parallel
+from ..utils import save_data
+from .causalbgm import CausalBGM, _init_mlp
+
+ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.99, 1e-7          # tf.keras.optimizers.Adam(lr, beta_1=0.9, beta_2=0.99) (:88-95)
+
+
+def _lr_t(lr, t):
+    return lr * np.sqrt(1.0 - ADAM_B2 ** t) / (1.0 - ADAM_B1 ** t)
+
+
+class IdentifiableCausalBGM(CausalBGM):
+    def __new__(cls, params=None, *args, **kwargs):
+        return object.__new__(cls)
+
+    def __init__(self, params, timestamp=None, random_seed=None, device=None):
+        if params.get('use_bnn', False):
+            raise NotImplementedError("bayesgm_amd: IdentifiableCausalBGM is built for use_bnn=False (deterministic networks) only")
+        if 'n_segments' not in params:
+            params['n_segments'] = 10                                                         # :50-51
+        CausalBGM.__init__(self, params, timestamp=timestamp, random_seed=random_seed, device=device)
+        q = self.engine.q
+        dims = [int(params['n_segments'])] + list(params.get('prior_units', [64])) + [q + 1]          # :76-78
+        dev = self.engine.device
+        self.prior_net = [(torch.from_numpy(W).to(dev).requires_grad_(True), torch.from_numpy(b).to(dev).requires_grad_(True))
+                          for W, b in _init_mlp(self._rs, dims)]
+        self._prior_m = [(torch.zeros_like(W), torch.zeros_like(b)) for W, b in self.prior_net]
+        self._prior_v = [(torch.zeros_like(W), torch.zeros_like(b)) for W, b in self.prior_net]
+        self._prior_t = 0
+        self._z_t = 0
+
+    # ------------------------------------------------------------------ prior network
+    def _prior_forward(self, u_onehot):
+        h = u_onehot
+        for i, (W, b) in enumerate(self.prior_net):
+            h = h @ W + b
+            if i < len(self.prior_net) - 1:
+                h = torch.nn.functional.leaky_relu(h, 0.2)
+        return h
+
+    def prior_parameters(self):
+        """[(W, b), ...] of the prior network as NumPy arrays (Keras order)."""
+        return [(W.detach().cpu().numpy(), b.detach().cpu().numpy()) for W, b in self.prior_net]
+
+    def set_prior_parameters(self, net):
+        dev = self.engine.device
+        self.prior_net = [(torch.from_numpy(np.asarray(W, np.float32)).to(dev).requires_grad_(True),
+                           torch.from_numpy(np.asarray(b, np.float32)).to(dev).requires_grad_(True)) for W, b in net]
+
+    def _prior_table(self):
+        """Per segment: mu [q], 1 / sigma^2, (q / 2) log sigma^2 -- what the sampling kernels read (bgm_causal_set_prior)."""
+        k, q = int(self.params['n_segments']), self.engine.q
+        with torch.no_grad():
+            out = self._prior_forward(torch.eye(k, device=self.engine.device))
+            s2 = torch.nn.functional.softplus(out[:, -1]) + 1e-6
+            tab = torch.cat([out[:, :q], (1.0 / s2)[:, None], (0.5 * q * torch.log(s2))[:, None]], dim=1)
+        return tab.contiguous()
+
+    def _with_prior(self, seg_dev):
+        self.engine.set_prior(seg_dev.to(torch.int32).contiguous(), self._prior_table())
+
+    # ------------------------------------------------------------------ latent / prior step (:150-226)
+    def _z_and_prior_step(self, x, y, v, idx, seg_dev, lr_z, lr_theta, dz, loss_z):
+        eng = self.engine
+        B, q = int(idx.numel()), eng.q
+        eng.fit_z_grad(x, y, v, self.data_z, idx, B, dz, loss_z)                      # NLL terms + z / B (standard prior)
+        idx64 = idx.long()
+        zb = self.data_z[idx64].detach().clone().requires_grad_(True)
+        out = self._prior_forward(torch.nn.functional.one_hot(seg_dev[idx64].long(), int(self.params['n_segments'])).float())
+        s2 = torch.nn.functional.softplus(out[:, -1]) + 1e-6
+        loss_prior = (((zb - out[:, :q]) ** 2).sum(dim=1) / (2.0 * s2) + q * torch.log(s2) / 2.0).mean()
+        flat = [a for Wb in self.prior_net for a in Wb]
+        grads = torch.autograd.grad(loss_prior, [zb] + flat)
+        with torch.no_grad():
+            g = dz[:B] - zb / B + grads[0]
+            self._z_t += 1
+            lr_t = float(_lr_t(lr_z, self._z_t))
+            m_, v_ = (1 - ADAM_B1) * g, (1 - ADAM_B2) * g * g                          # fresh slots: batch_z is a new Variable (:304)
+            self.data_z[idx64] = zb - lr_t * m_ / (torch.sqrt(v_) + ADAM_EPS)
+            self._prior_t += 1
+            lr_p = float(_lr_t(lr_theta, self._prior_t))
+            k = 1
+            for li, (W, b) in enumerate(self.prior_net):
+                for pi, par in enumerate((W, b)):
+                    gk = grads[k]
+                    k += 1
+                    mm, vv = self._prior_m[li][pi], self._prior_v[li][pi]
+                    mm.mul_(ADAM_B1).add_(gk, alpha=1 - ADAM_B1)
+                    vv.mul_(ADAM_B2).addcmul_(gk, gk, value=1 - ADAM_B2)
+                    par.sub_(lr_p * mm / (torch.sqrt(vv) + ADAM_EPS))
+        return float(loss_prior.item()), float((0.5 * (zb.detach() ** 2).sum(dim=1)).mean().item())
+
+    # ------------------------------------------------------------------ fit (:228-346)
+    def fit(self, data, batch_size=32, epochs=100, epochs_per_eval=5, startoff=0, use_egm_init=True, egm_n_iter=30000,
+            egm_batches_per_eval=500, verbose=1, save_format='txt'):
+        if parallel.is_dist():
+            raise NotImplementedError("bayesgm_amd: IdentifiableCausalBGM.fit runs in a single process")
+        data_x, data_y, data_v = data
+        n = len(data_x)
+        eng, dev, q = self.engine, self.engine.device, self.engine.q
+        k = int(self.params['n_segments'])
+        if verbose:
+            print(f"Generating auxiliary variable U for {k} segments.")
+        self.segments = np.random.randint(0, k, size=n)                                                     # :283
+        seg_dev = torch.from_numpy(self.segments.astype(np.int32)).to(dev)
+        if self._p['save_res']:
+            with open('{}/params.txt'.format(self.save_dir), 'w') as f_params:
+                f_params.write(str(self.params))
+        if use_egm_init:
+            self.egm_init(data, egm_n_iter=egm_n_iter, egm_batches_per_eval=egm_batches_per_eval, batch_size=batch_size, verbose=verbose)
+        x = self._dev(data_x).reshape(-1)
+        y = self._dev(data_y).reshape(-1)
+        v = self._dev(data_v)
+        if use_egm_init:
+            if verbose:
+                print('Initialize latent variables Z with e(V)...')
+            self.data_z = eng.encode(v)
+        else:
+            if verbose:
+                print('Random initialization of latent variables Z...')
+            self.data_z = self._dev(np.random.normal(0, 1, size=(n, q)).astype('float32'))
+        n_params = eng.fit_begin(n, batch_size)
+        grad = torch.empty(n_params, device=dev)
+        dz = torch.empty((batch_size, q), device=dev)
+        loss = torch.zeros(8, device=dev, dtype=torch.float64)
+        loss_z = torch.zeros(8, device=dev, dtype=torch.float64)
+        best_loss = np.inf
+        self.fit_history = []
+        if verbose:
+            print('Iterative Updating Starts ...')
+        try:
+            for epoch in range(epochs + 1):
+                sample_idx = torch.from_numpy(np.random.choice(n, n, replace=False).astype(np.int32)).to(dev)
+                loss.zero_()
+                loss_z.zero_()
+                n_rows, prior_sum, std_sum = 0, 0.0, 0.0
+                for i in range(0, n - batch_size + 1, batch_size):                                          # incomplete last batch skipped (:299)
+                    idx = sample_idx[i:i + batch_size]
+                    eng.fit_theta_grad(x, y, v, self.data_z, idx, batch_size, grad, loss)
+                    eng.fit_theta_apply(grad, self._p['lr_theta'])
+                    lp, ls = self._z_and_prior_step(x, y, v, idx, seg_dev, self._p['lr_z'], self._p['lr_theta'], dz, loss_z)
+                    prior_sum += lp * batch_size
+                    std_sum += ls * batch_size
+                    n_rows += batch_size
+                l = loss.cpu().numpy() / max(1, n_rows)
+                lz = loss_z.cpu().numpy() / max(1, n_rows)
+                post = float(lz[6]) + (prior_sum - std_sum) / max(1, n_rows)        # kernel sum carries |z|^2 / 2: exchange the prior term
+                self.fit_history.append(dict(epoch=epoch, loss_v=float(l[0]), loss_mse_v=float(l[1] / eng.v_dim), loss_x=float(l[2]),
+                                             loss_mse_x=float(l[3]), loss_y=float(l[4]), loss_mse_y=float(l[5]), loss_postrior_z=post))
+                if verbose:
+                    print('Epoch [%d/%d]: loss_px_z [%.4f], loss_mse_x [%.4f], loss_py_z [%.4f], loss_mse_y [%.4f], loss_pv_z [%.4f], '
+                          'loss_mse_v [%.4f], loss_postrior_z [%.4f]' % (epoch, epochs, l[2], l[3], l[4], l[5], l[0], l[1] / eng.v_dim, post))
+                if epoch % epochs_per_eval == 0:
+                    causal_pre, mse_x, mse_y, mse_v = self._evaluate_dev(x, y, v, self.data_z, n, 0)
+                    self.fit_history[-1].update(mse_x=float(mse_x), mse_y=float(mse_y), mse_v=float(mse_v))
+                    if verbose:
+                        print('Epoch [%d/%d]: MSE_x: %.4f, MSE_y: %.4f, MSE_v: %.4f\n' % (epoch, epochs, mse_x, mse_y, mse_v))
+                    if epoch >= startoff and mse_y < best_loss:
+                        best_loss = mse_y
+                        self.best_causal_pre = causal_pre
+                        self.best_epoch = epoch
+                    if self._p['save_res']:
+                        save_data('{}/causal_pre_at_{}.{}'.format(self.save_dir, epoch, save_format), causal_pre)
+        finally:
+            eng.fit_end()
+            self._pull_weights()
+
+    # ------------------------------------------------------------------ sampling (:521-614)
+    def _segments_for(self, n, data_u=None):
+        k = int(self.params['n_segments'])
+        if data_u is None:
+            return np.random.randint(0, k, size=n)                                                # fresh U at predict time (:563-564)
+        return np.asarray(data_u).argmax(axis=1)
+
+    def get_log_posterior(self, data_x, data_y, data_v, data_z, data_u, eps=1e-6):
+        """log p(z | x, y, v, u) + const, shape (n,) (:521-555); data_u one-hot [n, n_segments]."""
+        seg = torch.from_numpy(self._segments_for(len(data_x), data_u).astype(np.int32)).to(self.engine.device)
+        self._with_prior(seg)
+        try:
+            return CausalBGM.get_log_posterior(self, data_x, data_y, data_v, data_z)
+        finally:
+            self.engine.set_prior(None, None)
+
+    def metropolis_hastings_sampler(self, data, initial_q_sd=1.0, q_sd=None, burn_in=5000, n_keep=3000, target_acceptance_rate=0.25,
+                                    tolerance=0.05, adjustment_interval=50, adaptive_sd=None, window_size=100):
+        """(samples [n_keep, n, q], data_u one-hot [n, n_segments]) (:557-614)."""
+        data_x = data[0]
+        segs = self._segments_for(len(data_x))
+        self._with_prior(torch.from_numpy(segs.astype(np.int32)).to(self.engine.device))
+        try:
+            samples = CausalBGM.metropolis_hastings_sampler(self, data, initial_q_sd=initial_q_sd, q_sd=q_sd, burn_in=burn_in, n_keep=n_keep,
+                                                            target_acceptance_rate=target_acceptance_rate, tolerance=tolerance,
+                                                            adjustment_interval=adjustment_interval, adaptive_sd=adaptive_sd,
+                                                            window_size=window_size)
+        finally:
+            self.engine.set_prior(None, None)
+        return samples, np.eye(int(self.params['n_segments']), dtype=np.float32)[segs]
+
+    def predict(self, data, alpha=0.01, n_mcmc=3000, x_values=None, q_sd=1.0, sample_y=True, bs=100, burn_in=5000, verbose=1):
+        """Causal effects with posterior intervals (:348-420): one MH run over all rows with a fresh random U (burn-in 5000, the
+        sampler's default there), effects fused into the sampling kernel; `bs` only chunked the host-side effect pass of the
+        reference and does not change the result."""
+        assert 0 < alpha < 1, "The significance level 'alpha' must be greater than 0 and less than 1."
+        binary = bool(self._p['binary_treatment'])
+        if not binary and x_values is None:
+            raise ValueError("For continuous treatment, 'x_values' must not be None.")
+        if x_values is not None:
+            x_values = np.array([x_values], dtype=float) if np.isscalar(x_values) else np.array(x_values, dtype=float)
+        data_x, data_y, data_v = data
+        n = len(data_x)
+        eng = self.engine
+        if verbose:
+            print('MCMC Latent Variable Sampling ...')
+        segs = self._segments_for(n)
+        self._with_prior(torch.from_numpy(segs.astype(np.int32)).to(eng.device))
+        adaptive = (q_sd is None) or (q_sd <= 0)
+        try:
+            out = eng.mh_sample(self._dev(data_x).reshape(-1), self._dev(data_y).reshape(-1), self._dev(data_v), burn_in, n_mcmc, q_sd,
+                                self._next_seed(), effect=_lib.EFFECT_ITE if binary else _lib.EFFECT_ADRF, x_values=x_values,
+                                sample_y=sample_y, adaptive=adaptive)
+        finally:
+            eng.set_prior(None, None)
+        total = burn_in + n_mcmc
+        self._report_acceptance(float(out["acc_count"][max(0, total - 100):].sum().item()), min(100, total), n, verbose)
+        eff = out["ite"] if binary else out["adrf"].contiguous()
+        mean, lo, hi = eng.row_mean_quantiles(eff, alpha / 2, 1 - alpha / 2)
+        return mean.cpu().numpy(), torch.stack([lo, hi], dim=1).cpu().numpy()

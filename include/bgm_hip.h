@@ -78,6 +78,11 @@ int bgm_set_disc_norm(bgm_handle *h, int32_t mode);
  *                contraction with fp32 accumulation (relative error ~6e-6 per layer against 2.4e-7 in fp32).  Same algorithm,
  *                RNG streams and outputs; chains agree with the fp32 ones statistically, not draw for draw. */
 int bgm_causal_set_precision(bgm_handle *h, int32_t mode);
+/* Conditional latent prior Z | U ~ N(mu(U), sigma^2(U) I) of IdentifiableCausalBGM (models/causalbgm/identifiable.py:195-211,
+ * 541-551) for the sampling calls made afterwards (bgm_causal_logpost, bgm_causal_mh_run; fp32 kernels): seg_dev [n] = segment of
+ * every LOCAL row of those calls (int32), tab_dev [n_segments x (q + 2)] = per segment mu [q], 1 / sigma^2, (q / 2) log sigma^2.
+ * Both NULL: back to the standard-normal prior.  The buffers must stay valid while set. */
+int bgm_causal_set_prior(bgm_handle *h, const int32_t *seg_dev, const float *tab_dev, int32_t n_segments);
 int bgm_destroy(bgm_handle *h);
 
 /* Declare the model shape.  Synchronous.  replaces: CausalBGM.__init__ network
@@ -240,6 +245,14 @@ int bgm_causal_fit_z_step(bgm_handle *h, const float *x_dev, const float *y_dev,
 /* Copy the device parameters of one network back to the host (Keras order) and make them the
  * handle's host copy.  Synchronous. */
 int bgm_causal_get_weights(bgm_handle *h, int net_id, float *theta_host, int64_t count, void *stream);
+
+/* The gradient half of bgm_causal_fit_z_step: d(batch-mean negative log joint)/d(batch rows of data_z) with the CURRENT networks and
+ * the standard-normal latent prior, written to dz_out_dev [batch x q]; no optimizer step.  loss_dev as in bgm_causal_fit_z_step.
+ * Used by the host side of IdentifiableCausalBGM (identifiable.py:150-226), which exchanges the prior term for the conditional one
+ * and applies its own latent / prior-network updates. */
+int bgm_causal_fit_z_grad(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev, const float *data_z_dev,
+                          const int32_t *idx_dev, int64_t row_lo, int32_t batch, int32_t batch_global, float *dz_out_dev,
+                          double *loss_dev, void *stream);
 
 /* Optimizer state of the open fit session, for checkpoints (the reference's tf.train.Checkpoint holds g/f/h_optimizer and
  * posterior_optimizer, causalbgm/base.py:112-122): Adam first / second moments of theta_g | theta_f | theta_h [n_params each] and

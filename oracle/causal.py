@@ -55,8 +55,9 @@ def _sig2(m, key, raw, t):
     return softplus(raw) + t(EPS)
 
 
-def log_posterior(m, x, y, v, z):
-    """get_log_posterior, base.py:765-817.  x,y [n,1]; v [n,p]; z [n,q] -> [n]."""
+def log_posterior(m, x, y, v, z, prior=None):
+    """get_log_posterior, base.py:765-817.  x,y [n,1]; v [n,p]; z [n,q] -> [n].  prior = (mu [n,q], sigma^2 [n]): the conditional
+    latent prior of IdentifiableCausalBGM (identifiable.py:521-555) instead of N(0, I)."""
     t = z.dtype.type
     p = m["v_dim"]
     z0, z1, z2 = split_z(m, z)
@@ -77,7 +78,11 @@ def log_posterior(m, x, y, v, z):
     else:
         loss_x = ((x - mu_x) ** 2).sum(axis=1) / (2 * s2x) + np.log(s2x) / 2
     loss_y = ((y - mu_y) ** 2).sum(axis=1) / (2 * s2y) + np.log(s2y) / 2
-    loss_prior = (z ** 2).sum(axis=1) / 2
+    if prior is None:
+        loss_prior = (z ** 2).sum(axis=1) / 2
+    else:     # Z | U ~ N(mu(U), sigma^2(U) I): identifiable.py:541-551 (prior = (mu [n, q], sigma^2 [n]))
+        mu_p, s2_p = prior
+        loss_prior = ((z - mu_p) ** 2).sum(axis=1) / (2 * s2_p) + t(z.shape[1]) * np.log(s2_p) / 2
     return -(loss_v + loss_x + loss_y + loss_prior)
 
 
@@ -86,7 +91,7 @@ def mh_init_state(n, q, seed, row0=0):
     return R.normals(np.arange(row0, row0 + n), 0, q, R.TAG_INIT, seed)
 
 
-def mh_transition(m, x, y, v, state, logp, it, q_sd, seed, row0=0, eps=None, u=None):
+def mh_transition(m, x, y, v, state, logp, it, q_sd, seed, row0=0, eps=None, u=None, prior=None):
     """One iteration of the while-loop body, base.py:860-871.
 
     The reference evaluates get_log_posterior on the current state every
@@ -101,7 +106,7 @@ def mh_transition(m, x, y, v, state, logp, it, q_sd, seed, row0=0, eps=None, u=N
         u = R.uniforms(rows, it, R.TAG_ACC, seed)
     t = state.dtype.type
     prop = state + t(q_sd) * eps.astype(state.dtype)
-    lp_prop = log_posterior(m, x, y, v, prop)
+    lp_prop = log_posterior(m, x, y, v, prop, prior)
     ratio = np.exp(np.minimum(lp_prop - logp, 0))
     acc = u.astype(state.dtype) < ratio
     state = np.where(acc[:, None], prop, state)
@@ -111,20 +116,20 @@ def mh_transition(m, x, y, v, state, logp, it, q_sd, seed, row0=0, eps=None, u=N
 
 def mh_sampler(m, data, burn_in, n_keep, q_sd, seed, row0=0, adaptive=False,
                initial_q_sd=1.0, target=0.25, tol=0.05, adj_int=50, window=100,
-               return_acc=False):
+               return_acc=False, prior=None):
     """metropolis_hastings_sampler, base.py:820-904 -> samples [n_keep, n, q]."""
     x, y, v = data
     n = len(x)
     q = int(sum(m["z_dims"]))
     dt = v.dtype
     state = mh_init_state(n, q, seed, row0).astype(dt)
-    logp = log_posterior(m, x, y, v, state)
+    logp = log_posterior(m, x, y, v, state, prior)
     if adaptive:
         q_sd = initial_q_sd
     samples, recent, acc_hist = [], [], []
     counter = 0
     while len(samples) < n_keep:
-        state, logp, acc = mh_transition(m, x, y, v, state, logp, counter, q_sd, seed, row0)
+        state, logp, acc = mh_transition(m, x, y, v, state, logp, counter, q_sd, seed, row0, prior=prior)
         recent.append(acc)
         acc_hist.append(acc.sum())
         if len(recent) > window:

@@ -3,7 +3,7 @@ params['mh_precision'] = 'bf16x3') against the float64 oracle and against the fp
 
 The arithmetic differs from the reference's fp32 (three bf16 products per contraction, fp32 accumulation, ~6e-6 relative per
 layer), so parity is stated as tolerances, written here:
-  log-posterior   |bx3 - float64 oracle| <= 5e-5 * |lp| + 5e-3      (fp32 kernel: 2e-6 * |lp| + 2e-4)
+  log-posterior   |bx3 - float64 oracle| <= 2e-5 * |lp| + 2e-3      (fp32 kernel: 2e-6 * |lp| + 2e-4; observed 3e-5 ... 9e-4)
   chains          same Philox streams as the fp32 kernel; accept / reject decisions flip where |log u - dlogp| is below the
                   arithmetic's error, so chains agree statistically: acceptance rate within 0.01, per-row posterior means
                   of z within 0.15 posterior sd on average, ADRF within 0.02 of the fp32 kernel's on the same draws' law
@@ -36,7 +36,7 @@ def test_bx3_log_posterior_matches_oracle(case):
     eng.set_precision("fp32")
     err32, errbx = np.abs(lp32 - ref), np.abs(lpbx - ref)
     print("logpost err: fp32 max %.2e, bf16x3 max %.2e (|lp| ~ %.0f)" % (err32.max(), errbx.max(), np.abs(ref).mean()))
-    assert np.all(errbx <= 5e-5 * np.abs(ref) + 5e-3), errbx.max()
+    assert np.all(errbx <= 2e-5 * np.abs(ref) + 2e-3), errbx.max()
 
 
 def test_bx3_chains_agree_statistically_with_fp32():
