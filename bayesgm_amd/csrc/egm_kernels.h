@@ -277,46 +277,68 @@ __device__ __forceinline__ float *egm_dk_out(const EgmDisc &d, const EgmDiscCach
   return k.base + egm_dk_off(d, d.n_hidden, B);
 }
 
+// Per-column passes of the discriminator (BatchNormalization statistics, their backward projections, gamma / beta gradients)
+// are reductions over the B rows of a column.  A wave handles two columns at a time, its 32-lane halves the rows of one column
+// each (rows beyond 32 in further rounds), and a column sum is five cross-lane adds -- instead of one thread walking the B rows
+// of its column in a chain of dependent LDS accesses (the first version: ~9 k cycles per pass, ~90 passes per discriminator step).
+// The strided row accesses of a column are bank-conflicted (stride = layer width), which costs tens of cycles, not thousands.
+__device__ __forceinline__ float egm_sum32(float v) {          // sum over the 32 lanes of this half-wave, result in all of them
+  v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+  return v;
+}
+// f(o, valid column, row lane bl in [0, 32)) for every column o of a layer of width `out`; all 64 lanes of a wave call f together
+template <class F>
+__device__ __forceinline__ void egm_for_cols(const EgmCtx &c, int out, F f) {
+  const int lane = c.tid & 63, w = c.tid >> 6;
+  for (int o0 = 2 * w; o0 < out; o0 += 2 * (EGM_THREADS / 64)) {
+    const int o = o0 + (lane >> 5);
+    f(o < out ? o : out - 1, o < out, lane & 31);
+  }
+}
+
 __device__ __forceinline__ void egm_disc_fwd(const EgmCtx &c, const float *th, const EgmDisc &d, const EgmDiscCache &k, int B) {
   const int L = d.n_hidden;
   for (int l = 0; l < L; ++l) {
     const int in = d.dims[l], out = d.dims[l + 1];
     float *uh_ = egm_dk_uhat(d, k, l, B), *sg_ = egm_dk_sigma(d, k, l, B), *ao_ = egm_dk_a(d, k, l + 1, B);
     egm_fwd(c, egm_dk_a(d, k, l, B), in, th + d.w[l], th + d.b[l], uh_, out, B, in, out, false);   // u (normalised in place below)
-    for (int o = c.tid; o < out; o += EGM_THREADS) {
+    egm_for_cols(c, out, [&](int o, bool ok, int bl) {
       float mu = 0.0f, var = 1.0f;
       if (!d.fixed_norm) {
-        for (int b = 0; b < B; ++b) mu += uh_[b * out + o];
-        mu /= (float)B;
-        var = 0.0f;
-        for (int b = 0; b < B; ++b) { const float t = uh_[b * out + o] - mu; var = fmaf(t, t, var); }
-        var /= (float)B;
+        float s1 = 0.0f;
+        for (int b = bl; b < B; b += 32) s1 += uh_[b * out + o];
+        mu = egm_sum32(s1) / (float)B;
+        float s2 = 0.0f;
+        for (int b = bl; b < B; b += 32) { const float t = uh_[b * out + o] - mu; s2 = fmaf(t, t, s2); }
+        var = egm_sum32(s2) / (float)B;
       }
       const float sg = sqrtf(var + EGM_BN_EPS);
-      sg_[o] = sg;
       const float ga = th[d.gamma[l] + o], be = th[d.beta[l] + o];
-      for (int b = 0; b < B; ++b) {
-        const float uh = (uh_[b * out + o] - mu) / sg;
-        uh_[b * out + o] = uh;
-        ao_[b * out + o] = tanhf(fmaf(uh, ga, be));
+      if (ok) {
+        if (bl == 0) sg_[o] = sg;
+        for (int b = bl; b < B; b += 32) {
+          const float uh = (uh_[b * out + o] - mu) / sg;
+          uh_[b * out + o] = uh;
+          ao_[b * out + o] = tanhf(fmaf(uh, ga, be));
+        }
       }
-    }
+    });
     __syncthreads();
   }
   egm_fwd(c, egm_dk_a(d, k, L, B), d.dims[L], th + d.w[L], th + d.b[L], egm_dk_out(d, k, B), 1, B, d.dims[L], 1, false);
 }
 
-// x - mean_b x - uhat * mean_b(x uhat), per feature column o (one thread per column)
+// x - mean_b x - uhat * mean_b(x uhat), per feature column o, by the 32 row lanes of a half-wave (see egm_for_cols)
 // (fixed statistics: the normalisation is a constant per-column scale, nothing flows through mean / variance)
-__device__ __forceinline__ void egm_bn_proj_col(float *x, const float *uhat, int B, int out, int o, float scale, int fixed_norm = 0) {
-  if (fixed_norm) {
-    for (int b = 0; b < B; ++b) x[b * out + o] *= scale;
-    return;
-  }
+__device__ __forceinline__ void egm_bn_proj_col(float *x, const float *uhat, int B, int out, int o, bool ok, int bl, float scale,
+                                                int fixed_norm) {
   float m1 = 0.0f, m2 = 0.0f;
-  for (int b = 0; b < B; ++b) { m1 += x[b * out + o]; m2 = fmaf(x[b * out + o], uhat[b * out + o], m2); }
-  m1 /= (float)B; m2 /= (float)B;
-  for (int b = 0; b < B; ++b) x[b * out + o] = (x[b * out + o] - m1 - uhat[b * out + o] * m2) * scale;
+  if (!fixed_norm) {
+    for (int b = bl; b < B; b += 32) { m1 += x[b * out + o]; m2 = fmaf(x[b * out + o], uhat[b * out + o], m2); }
+    m1 = egm_sum32(m1) / (float)B; m2 = egm_sum32(m2) / (float)B;
+  }
+  if (ok)
+    for (int b = bl; b < B; b += 32) x[b * out + o] = (x[b * out + o] - m1 - uhat[b * out + o] * m2) * scale;
 }
 
 // Scratch of the gradient-penalty pass (computed pointers).  First the adjoint-network activations da_l [B x dims[l]],
@@ -361,10 +383,10 @@ __device__ __forceinline__ void egm_disc_bwd(const EgmCtx &c, const float *th, f
     const float *ubar = adj ? egm_gp_blk(d, *adj, l, B, GP_UBAR) : nullptr;
     const float *sbar = adj ? egm_gp_blk(d, *adj, l, B, GP_SBAR) : nullptr;
     // dy = (da + a_bar) (1 - a^2);  dgamma, dbeta;  duhat = dy gamma + uhat_bar;  du = proj(duhat)/sigma + sigma_bar uhat / B
-    for (int o = c.tid; o < out; o += EGM_THREADS) {
+    egm_for_cols(c, out, [&](int o, bool ok, int bl) {
       float gg = 0.0f, gb = 0.0f;
       const float ga = th[d.gamma[l] + o];
-      for (int b = 0; b < B; ++b) {
+      for (int b = bl; b < B; b += 32) {
         const int t = b * out + o;
         float dav = da[t];
         if (abar) dav += abar[t];
@@ -374,17 +396,20 @@ __device__ __forceinline__ void egm_disc_bwd(const EgmCtx &c, const float *th, f
         gb += dy;
         float dh = dy * ga;
         if (ubar) dh += ubar[t];
-        du[t] = dh;
+        if (ok) du[t] = dh;
       }
-      float *pg = gr + d.gamma[l] + o, *pb = gr + d.beta[l] + o;
-      *pg = accumulate ? *pg + s * gg : s * gg;
-      *pb = accumulate ? *pb + s * gb : s * gb;
-      egm_bn_proj_col(du, uh_, B, out, o, 1.0f / sg_[o], d.fixed_norm);
-      if (sbar && !d.fixed_norm) {
+      gg = egm_sum32(gg); gb = egm_sum32(gb);
+      if (ok && bl == 0) {
+        float *pg = gr + d.gamma[l] + o, *pb = gr + d.beta[l] + o;
+        *pg = accumulate ? *pg + s * gg : s * gg;
+        *pb = accumulate ? *pb + s * gb : s * gb;
+      }
+      egm_bn_proj_col(du, uh_, B, out, o, ok, bl, 1.0f / sg_[o], d.fixed_norm);
+      if (sbar && !d.fixed_norm && ok) {
         const float sb = sbar[o] / (float)B;
-        for (int b = 0; b < B; ++b) du[b * out + o] = fmaf(sb, uh_[b * out + o], du[b * out + o]);
+        for (int b = bl; b < B; b += 32) du[b * out + o] = fmaf(sb, uh_[b * out + o], du[b * out + o]);
       }
-    }
+    });
     __syncthreads();
     const float *ai_ = egm_dk_a(d, k, l, B);
     egm_bwd_w(c, ai_, in, du, out, gr + d.w[l], gr + d.b[l], B, in, out, accumulate, s);
@@ -413,18 +438,19 @@ __device__ __forceinline__ float egm_disc_gp(const EgmCtx &c, const float *th, f
     const float *uh_ = egm_dk_uhat(d, k, l, B), *sg_ = egm_dk_sigma(d, k, l, B), *ao_ = egm_dk_a(d, k, l + 1, B);
     const float *da_up = egm_gp_da(d, G, l + 1, B);
     float *dy_ = egm_gp_blk(d, G, l, B, GP_DY), *dhat_ = egm_gp_blk(d, G, l, B, GP_DHAT), *du_ = egm_gp_blk(d, G, l, B, GP_DU);
-    for (int o = c.tid; o < out; o += EGM_THREADS) {
+    egm_for_cols(c, out, [&](int o, bool ok, int bl) {
       const float ga = th[d.gamma[l] + o];
-      for (int b = 0; b < B; ++b) {
-        const int t = b * out + o;
-        const float av = ao_[t];
-        const float dy = da_up[t] * (1.0f - av * av);
-        dy_[t] = dy;
-        dhat_[t] = dy * ga;
-        du_[t] = dy * ga;
-      }
-      egm_bn_proj_col(du_, uh_, B, out, o, 1.0f / sg_[o], d.fixed_norm);
-    }
+      if (ok)
+        for (int b = bl; b < B; b += 32) {
+          const int t = b * out + o;
+          const float av = ao_[t];
+          const float dy = da_up[t] * (1.0f - av * av);
+          dy_[t] = dy;
+          dhat_[t] = dy * ga;
+          du_[t] = dy * ga;
+        }
+      egm_bn_proj_col(du_, uh_, B, out, o, ok, bl, 1.0f / sg_[o], d.fixed_norm);
+    });
     __syncthreads();
     egm_bwd_in(c, du_, out, th + d.w[l], egm_gp_da(d, G, l, B), in, B, in, out, false);
   }
@@ -453,35 +479,40 @@ __device__ __forceinline__ float egm_disc_gp(const EgmCtx &c, const float *th, f
     egm_bwd_w(c, da_bar, in, du_, out, gr + d.w[l], nullptr, B, in, out, true, s);
     egm_fwd(c, da_bar, in, th + d.w[l], nullptr, du_bar, out, B, in, out, false);
     // du = (dhat - m1 - uhat m2) / sigma
-    for (int o = c.tid; o < out; o += EGM_THREADS) {
+    egm_for_cols(c, out, [&](int o, bool ok, int bl) {
       const float sg = sg_[o], ga = th[d.gamma[l] + o];
       float sb = 0.0f, m2 = 0.0f, tu = 0.0f;
-      for (int b = 0; b < B; ++b) {
+      for (int b = bl; b < B; b += 32) {
         const int t = b * out + o;
         sb = fmaf(du_bar[t], du_[t], sb);
         m2 = fmaf(dhat_[t], uh_[t], m2);
         tu = fmaf(du_bar[t] / sg, uh_[t], tu);
       }
-      sbar[o] = d.fixed_norm ? 0.0f : -sb / sg;
-      m2 /= (float)B; tu /= (float)B;
-      for (int b = 0; b < B; ++b) {
-        const int t = b * out + o;
-        const float tt = du_bar[t] / sg;
-        ubar[t] = d.fixed_norm ? 0.0f : -(tt * m2 + dhat_[t] * tu);
-        tmp[t] = tt;
+      sb = egm_sum32(sb); m2 = egm_sum32(m2) / (float)B; tu = egm_sum32(tu) / (float)B;
+      if (ok) {
+        if (bl == 0) sbar[o] = d.fixed_norm ? 0.0f : -sb / sg;
+        for (int b = bl; b < B; b += 32) {
+          const int t = b * out + o;
+          const float tt = du_bar[t] / sg;
+          ubar[t] = d.fixed_norm ? 0.0f : -(tt * m2 + dhat_[t] * tu);
+          tmp[t] = tt;
+        }
       }
-      egm_bn_proj_col(tmp, uh_, B, out, o, 1.0f, d.fixed_norm);          // dhat_bar
+      egm_bn_proj_col(tmp, uh_, B, out, o, ok, bl, 1.0f, d.fixed_norm);          // dhat_bar
       float gg = 0.0f;
-      for (int b = 0; b < B; ++b) {
+      for (int b = bl; b < B; b += 32) {
         const int t = b * out + o;
         gg = fmaf(tmp[t], dy_[t], gg);
         const float dyb = tmp[t] * ga;
         const float av = ao_[t];
-        abar[t] = dyb * da_up[t] * (-2.0f * av);
-        tmp[t] = dyb * (1.0f - av * av);                    // da_bar of the layer above
+        if (ok) {
+          abar[t] = dyb * da_up[t] * (-2.0f * av);
+          tmp[t] = dyb * (1.0f - av * av);                    // da_bar of the layer above
+        }
       }
-      gr[d.gamma[l] + o] += s * gg;
-    }
+      gg = egm_sum32(gg);
+      if (ok && bl == 0) gr[d.gamma[l] + o] += s * gg;
+    });
     __syncthreads();
     // tmp now holds da_bar for layer l+1 : move it into the ping-pong buffer
     for (int t = c.tid; t < B * out; t += EGM_THREADS) da_bar[t] = tmp[t];
