@@ -6,6 +6,7 @@
 
 #include "bgm_host.h"
 #include "egm_kernels.h"
+#include "egm_chain.h"
 
 static constexpr float EGM_B1 = 0.9f, EGM_B2 = 0.99f, EGM_ADAM_EPS = 1e-7f;   // causalbgm/base.py:86-87, Keras epsilon
 
@@ -14,6 +15,7 @@ struct EgmState {
   EgmArgs base{};              // network descriptions + device pointers shared by both kernels
   size_t n_gen = 0, n_dz = 0, ws_floats = 0;
   int lds_bytes = 0;
+  int chain_disc_lds = 0;      // > 0: the discriminator step runs as register-chained row tiles (egm_chain.h) with this much LDS
   long long t_g = 0, t_d = 0;  // Adam iteration counters of g_pre_optimizer / d_pre_optimizer
   float *dev = nullptr;        // one allocation: theta_g|m_g|v_g|grad_g|theta_d|m_d|v_d|grad_d|ws
 };
@@ -105,6 +107,14 @@ extern "C" int bgm_causal_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, co
   const size_t arena = cache + std::max(cache + 2 * (size_t)B * dmax, gp);
   a.disc_lds = (64 + arena) * sizeof(float) <= 160 * 1024 ? 1 : 0;
   s->lds_bytes = (int)((64 + (a.disc_lds ? arena : 0)) * sizeof(float));
+  {   // register-chained discriminator step: fixed normalisation, the default layer shapes, one or two 16-row tiles
+    bool chain = d.fixed_norm && L == 3 && d.dims[0] <= 16 && (d.dims[1] + 15) / 16 == 4 && (d.dims[2] + 15) / 16 == 2 &&
+                 d.dims[3] <= 16 && (B == 16 || B == 32) && a.e.n_layers >= 2 && a.e.dims[a.e.n_layers] == h->q && h->q <= 16;
+    for (int l = 1; l < a.e.n_layers; ++l) chain = chain && a.e.dims[l] == 64;
+    const size_t bytes = chain ? sizeof(float) * (size_t)ech_disc_lds_floats<4, 2, 1>(d, B) : 0;
+    if (std::getenv("BGM_EGM_NO_CHAIN")) chain = false;   // A/B switch for measurements
+    s->chain_disc_lds = (chain && bytes <= 160 * 1024) ? (int)bytes : 0;
+  }
   a.n_gen = (int)s->n_gen; a.B = B; a.q = h->q; a.p = h->p; a.wmax = wmax;
   a.z0 = h->cfg.z_dims[0]; a.z1 = h->cfg.z_dims[1]; a.z2 = h->cfg.z_dims[2];
   a.binary = h->cfg.binary_treatment; a.use_z_rec = cfg->use_z_rec;
@@ -130,6 +140,24 @@ extern "C" int bgm_causal_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, co
   return BGM_OK;
 }
 
+#ifdef EGM_PHASE_CLOCK
+#include <cstdio>
+static unsigned long long *egm_stamp_buf() {
+  static unsigned long long *buf = nullptr;
+  if (!buf) hipMalloc(&buf, sizeof(unsigned long long) * 8192);
+  return buf;
+}
+static void egm_stamp_report(const char *what, int *calls) {
+  if (++*calls != 40) return;
+  hipDeviceSynchronize();
+  std::vector<unsigned long long> st(8192);
+  hipMemcpy(st.data(), egm_stamp_buf(), sizeof(unsigned long long) * 8192, hipMemcpyDeviceToHost);
+  std::fprintf(stderr, "EGM_PHASE %s\n", what);
+  for (int i = 1; i < 4096 && st[2 * i]; ++i)
+    std::fprintf(stderr, "EGM_PHASE %s %3d line %4llu cycles %8llu\n", what, i, st[2 * i], st[2 * i + 1] - st[2 * i - 1]);
+}
+#endif
+
 static EgmAdam egm_adam_coeffs(float lr, long long t) {
   EgmAdam ad;
   ad.b1 = EGM_B1; ad.b2 = EGM_B2; ad.eps = EGM_ADAM_EPS;
@@ -147,10 +175,24 @@ extern "C" int bgm_causal_egm_disc_step(bgm_handle *h, const float *z_dev, const
   a.z = z_dev; a.idx = idx_dev; a.v = v_dev; a.x = nullptr; a.y = nullptr; a.eps = eps; a.out = out_dev; a.apply = apply ? 1 : 0;
   if (apply) s->t_d += 1;
   a.adam = egm_adam_coeffs(s->cfg.lr, std::max<long long>(1, s->t_d));
+  if (s->chain_disc_lds > 0) {
+    auto kc = egm_disc_chain_kernel<4, 4, 2, 1>;
+    BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, s->chain_disc_lds));
+    hipLaunchKernelGGL(kc, dim3(1), dim3(ECH_THREADS), s->chain_disc_lds, (hipStream_t)stream_, a);
+    BGM_HIP_CHECK(hipGetLastError());
+    return BGM_OK;
+  }
   auto k = egm_disc_step_kernel;
   BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
+#ifdef EGM_PHASE_CLOCK
+  a.stamps = egm_stamp_buf();
+  hipMemsetAsync(a.stamps, 0, sizeof(unsigned long long) * 8192, (hipStream_t)stream_);
+#endif
   hipLaunchKernelGGL(k, dim3(1), dim3(EGM_THREADS), s->lds_bytes, (hipStream_t)stream_, a);
   BGM_HIP_CHECK(hipGetLastError());
+#ifdef EGM_PHASE_CLOCK
+  { static int calls = 0; egm_stamp_report("disc", &calls); }
+#endif
   return BGM_OK;
 }
 
@@ -166,8 +208,15 @@ extern "C" int bgm_causal_egm_gen_step(bgm_handle *h, const float *z_dev, const 
   a.adam = egm_adam_coeffs(s->cfg.lr, std::max<long long>(1, s->t_g));
   auto k = egm_gen_step_kernel;
   BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
+#ifdef EGM_PHASE_CLOCK
+  a.stamps = egm_stamp_buf();
+  hipMemsetAsync(a.stamps, 0, sizeof(unsigned long long) * 8192, (hipStream_t)stream_);
+#endif
   hipLaunchKernelGGL(k, dim3(1), dim3(EGM_THREADS), s->lds_bytes, (hipStream_t)stream_, a);
   BGM_HIP_CHECK(hipGetLastError());
+#ifdef EGM_PHASE_CLOCK
+  { static int calls = 0; egm_stamp_report("gen", &calls); }
+#endif
   return BGM_OK;
 }
 

@@ -1,0 +1,534 @@
+// egm_chain.h -- train_disc_step of the EGM warm start as register-chained row tiles (CausalBGM base.py:305-330,
+// Discriminator of models/networks/base.py:338-385 in inference-mode normalisation, the shipped default).
+//
+// The phase machine of egm_kernels.h spends a workgroup barrier, an operand round trip and a few hundred address
+// instructions on every one of the ~80 tiny dense ops of a step (measured: 6 k cycles for a single 64x64 layer on 32 rows,
+// 650 k cycles per step).  With fixed normalisation statistics every row of the minibatch is independent until the
+// parameter gradients are summed, so here ONE WAVE OWNS A 16-ROW TILE and walks a whole network with the activations in
+// registers: the MFMA accumulator of a layer (lane (j, g), tile t, register r = feature 16 t + 4 g + r of row j) is
+// directly the B operand of the next layer's K-step (t, r); the A operand of that step is W[16 t + 4 g + r][16 u + i],
+// read in place from the canonical Keras array (64 contiguous bytes per lane group, no packing pass).
+//
+//   waves 0,1  encoder forward on the two row tiles (weights streamed from L2) -> z_ ; then D(z_): forward + backward
+//   waves 2,3  D(z) forward + backward, concurrently with the encoder
+//   waves 4,5  (after z_ is known) D(zhat): forward, adjoint network, gradient-penalty reverse pass, backward
+//   all waves  (after one more barrier) parameter gradients as X^T D GEMMs over the rows stashed in LDS, Adam.
+//
+// The discriminator's parameters (3 k floats) and their transposes sit in LDS with padded leading dimensions.
+// The formulas are those of egm_disc_fwd / egm_disc_bwd / egm_disc_gp in egm_kernels.h with fixed_norm = 1
+// (oracle/egm.py); the batch-statistics mode couples the rows and stays on the phase machine.
+#pragma once
+#include "egm_kernels.h"
+
+#define ECH_WAVES 8
+#define ECH_THREADS (64 * ECH_WAVES)
+#define ECH_ROLE_WAVES 6          // waves that own a discriminator pass (and a slot of per-wave partial sums)
+
+__device__ __forceinline__ float ech_ld(const float *p, int i, int n) {   // p[i] for i < n, else 0; the load itself is unconditional
+  const float v = p[i < n ? i : n - 1];
+  return i < n ? v : 0.0f;
+}
+
+// out[16 u + 4 g + r] (+ bias) = sum_f in[f] W[f * ld + o]: one row tile through one Dense layer.
+template <int KT, int NT, bool EXACT>
+__device__ __forceinline__ void ech_dense(const float *W, int ld, const float *bias, int n_in, int n_out, const f32x4 (&in)[KT],
+                                          f32x4 (&out)[NT], int j, int g) {
+#pragma unroll
+  for (int u = 0; u < NT; ++u)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = 16 * u + 4 * g + r;
+      out[u][r] = bias ? (EXACT ? bias[o] : ech_ld(bias, o, n_out)) : 0.0f;
+    }
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = 16 * t + 4 * g + r;
+      const bool fok = EXACT || f < n_in;
+      const float *wr = W + (EXACT ? f : min(f, n_in - 1)) * ld;
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        const int o = 16 * u + j;
+        float a;
+        if (EXACT) a = wr[o];
+        else {
+          const float w = wr[min(o, n_out - 1)];
+          a = (fok && o < n_out) ? w : 0.0f;
+        }
+        out[u] = BGM_MFMA(a, in[t][r], out[u]);
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS parameter block of a three-hidden-layer discriminator (offsets in floats from its base)
+// ---------------------------------------------------------------------------------------------
+struct EchP {
+  int d0, d1, d2, d3;
+  int ld0, ld1, ld2, lt0, lt1, lt2;     // leading dimensions of W_l (n_out + 4) and W_l^T (n_in + 4): lane groups land on distinct banks
+  int W0, W1, W2, T0, T1, T2;           // W_l [n_in x ld_l], W_l^T [n_out x lt_l]
+  int b0, b1, b2, ga0, ga1, ga2, be0, be1, be2, wo, bo;
+  int total;
+};
+__host__ __device__ inline EchP ech_layout(const EgmDisc &d) {
+  EchP P;
+  P.d0 = d.dims[0]; P.d1 = d.dims[1]; P.d2 = d.dims[2]; P.d3 = d.dims[3];
+  P.ld0 = P.d1 + 4; P.ld1 = P.d2 + 4; P.ld2 = P.d3 + 4;
+  P.lt0 = P.d0 + 4; P.lt1 = P.d1 + 4; P.lt2 = P.d2 + 4;
+  int o = 0;
+  auto take = [&](int n) { const int r = o; o += (n + 3) & ~3; return r; };
+  P.W0 = take(P.d0 * P.ld0); P.W1 = take(P.d1 * P.ld1); P.W2 = take(P.d2 * P.ld2);
+  P.T0 = take(P.d1 * P.lt0); P.T1 = take(P.d2 * P.lt1); P.T2 = take(P.d3 * P.lt2);
+  P.b0 = take(P.d1); P.b1 = take(P.d2); P.b2 = take(P.d3);
+  P.ga0 = take(P.d1); P.ga1 = take(P.d2); P.ga2 = take(P.d3);
+  P.be0 = take(P.d1); P.be1 = take(P.d2); P.be2 = take(P.d3);
+  P.wo = take(P.d3); P.bo = take(1);
+  P.total = o;
+  return P;
+}
+// stash of one pass (floats per row): inputs X_l of the three hidden layers, then their (scaled) pre-activation gradients D_l
+template <int T1, int T2, int T3> struct EchDims {
+  static constexpr int XW = 16 * (1 + T1 + T2), DW = 16 * (T1 + T2 + T3), SW = XW + DW;
+  static constexpr int SL = 16 * (T1 + T2 + T3);            // per-wave partial sums: gamma [SL] | beta [SL] | w_out [16 T3] | scalars [16]
+  static constexpr int SLOT = 2 * SL + 16 * T3 + 16;
+  static constexpr int TILES = T1 + T1 * T2 + T2 * T3;      // weight-gradient tiles
+};
+template <int T1, int T2, int T3>
+__host__ __device__ inline int ech_disc_lds_floats(const EgmDisc &d, int B) {
+  using D = EchDims<T1, T2, T3>;
+  return 64 + ech_layout(d).total + ECH_ROLE_WAVES * D::SLOT + 16 * B + 4 * B * D::SW;
+}
+
+__device__ __forceinline__ void ech_fill_params(float *par, const EchP &P, const float *th, const EgmDisc &d, int tid) {
+  const int dims_in[3] = {P.d0, P.d1, P.d2}, dims_out[3] = {P.d1, P.d2, P.d3};
+  const int ld[3] = {P.ld0, P.ld1, P.ld2}, lt[3] = {P.lt0, P.lt1, P.lt2}, ow[3] = {P.W0, P.W1, P.W2}, ot[3] = {P.T0, P.T1, P.T2};
+  const int ob[3] = {P.b0, P.b1, P.b2}, og[3] = {P.ga0, P.ga1, P.ga2}, oe[3] = {P.be0, P.be1, P.be2};
+#pragma unroll
+  for (int l = 0; l < 3; ++l) {
+    const int n_in = dims_in[l], n_out = dims_out[l];
+    for (int e = tid; e < n_in * n_out; e += ECH_THREADS) {
+      const int f = e / n_out, o = e - f * n_out;
+      const float w = th[d.w[l] + e];
+      par[ow[l] + f * ld[l] + o] = w;
+      par[ot[l] + o * lt[l] + f] = w;
+    }
+    for (int o = tid; o < n_out; o += ECH_THREADS) {
+      par[ob[l] + o] = th[d.b[l] + o];
+      par[og[l] + o] = th[d.gamma[l] + o];
+      par[oe[l] + o] = th[d.beta[l] + o];
+    }
+  }
+  for (int f = tid; f < P.d3; f += ECH_THREADS) par[P.wo + f] = th[d.w[3] + f];
+  if (tid == 0) par[P.bo] = th[d.b[3]];
+}
+
+// ---------------------------------------------------------------------------------------------
+// one discriminator evaluation on a row tile
+// ---------------------------------------------------------------------------------------------
+template <int T1, int T2, int T3>
+struct EchFwd {
+  f32x4 a0[1], a1[T1], a2[T2], a3[T3];     // layer inputs / tanh outputs
+  f32x4 u1[T1], u2[T2], u3[T3];            // normalised pre-activations (uhat)
+  float out;
+};
+template <int T1, int T2, int T3>
+struct EchAcc {                            // per-row contributions to the vector-parameter gradients (summed over rows at the end)
+  f32x4 gam1[T1], gam2[T2], gam3[T3], bet1[T1], bet2[T2], bet3[T3], wo[T3];
+};
+template <int NT>
+__device__ __forceinline__ void ech_zero(f32x4 (&x)[NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) x[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+}
+__device__ __forceinline__ float ech_c() { return 1.0f / sqrtf(1.0f + EGM_BN_EPS); }   // 1 / sqrt(moving variance 1 + epsilon)
+
+template <int NT>
+__device__ __forceinline__ void ech_act(const float *ga, const float *be, int n, int g, const f32x4 (&u)[NT], f32x4 (&uh)[NT],
+                                        f32x4 (&a)[NT]) {
+  const float c = ech_c();
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = 16 * t + 4 * g + r;
+      uh[t][r] = u[t][r] * c;
+      a[t][r] = tanhf(fmaf(uh[t][r], ech_ld(ga, o, n), ech_ld(be, o, n)));
+    }
+}
+template <int NT>
+__device__ __forceinline__ void ech_stash(float *base, int row, int g, const f32x4 (&x)[NT], float s) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4 *>(base + row * (16 * NT) + 16 * t + 4 * g) = x[t] * s;
+}
+
+template <int T1, int T2, int T3>
+__device__ __forceinline__ void ech_disc_fwd(const float *par, const EchP &P, EchFwd<T1, T2, T3> &F, int j, int g) {
+  f32x4 u1[T1], u2[T2], u3[T3];
+  ech_dense<1, T1, false>(par + P.W0, P.ld0, par + P.b0, P.d0, P.d1, F.a0, u1, j, g);
+  ech_act<T1>(par + P.ga0, par + P.be0, P.d1, g, u1, F.u1, F.a1);
+  ech_dense<T1, T2, false>(par + P.W1, P.ld1, par + P.b1, P.d1, P.d2, F.a1, u2, j, g);
+  ech_act<T2>(par + P.ga1, par + P.be1, P.d2, g, u2, F.u2, F.a2);
+  ech_dense<T2, T3, false>(par + P.W2, P.ld2, par + P.b2, P.d2, P.d3, F.a2, u3, j, g);
+  ech_act<T3>(par + P.ga2, par + P.be2, P.d3, g, u3, F.u3, F.a3);
+  float s = 0.0f;
+#pragma unroll
+  for (int t = 0; t < T3; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s = fmaf(F.a3[t][r], ech_ld(par + P.wo, 16 * t + 4 * g + r, P.d3), s);
+  F.out = sum_over_g(s) + par[P.bo];
+}
+
+// dy = da (1 - a^2);  gamma / beta contributions;  du = dy gamma c
+template <int NT>
+__device__ __forceinline__ void ech_bwd_act(const float *ga, int n, int g, const f32x4 (&da)[NT], const f32x4 (&a)[NT], const f32x4 (&uh)[NT],
+                                            float s, f32x4 (&gam)[NT], f32x4 (&bet)[NT], f32x4 (&du)[NT]) {
+  const float c = ech_c();
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float av = a[t][r];
+      const float dy = da[t][r] * (1.0f - av * av);
+      gam[t][r] = fmaf(s * dy, uh[t][r], gam[t][r]);
+      bet[t][r] = fmaf(s, dy, bet[t][r]);
+      du[t][r] = dy * ech_ld(ga, 16 * t + 4 * g + r, n) * c;
+    }
+}
+
+// Ordinary backward of one evaluation: dLoss/dout = dout on every row (ADJ = false), or no output gradient but node adjoints
+// ab* on the tanh outputs (ADJ = true: the second half of the gradient penalty).  Stashes (a_{l-1}, s du_l) of the three
+// hidden layers for the weight-gradient GEMMs of the last phase; `st` = this pass's stash block.
+template <int T1, int T2, int T3, bool ADJ>
+__device__ __forceinline__ void ech_disc_bwd(const float *par, const EchP &P, const EchFwd<T1, T2, T3> &F, float dout, const f32x4 (&ab1)[T1],
+                                             const f32x4 (&ab2)[T2], const f32x4 (&ab3)[T3], float s, float *st, int B, int row,
+                                             EchAcc<T1, T2, T3> &acc, int j, int g) {
+  using D = EchDims<T1, T2, T3>;
+  float *X0 = st, *X1 = st + B * 16, *X2 = st + B * (16 + 16 * T1);
+  float *D0 = st + B * D::XW, *D1 = D0 + B * 16 * T1, *D2 = D1 + B * 16 * T2;
+  f32x4 da3[T3], du3[T3];
+#pragma unroll
+  for (int t = 0; t < T3; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      da3[t][r] = ADJ ? ab3[t][r] : dout * ech_ld(par + P.wo, 16 * t + 4 * g + r, P.d3);
+      if (!ADJ) acc.wo[t][r] = fmaf(dout, F.a3[t][r], acc.wo[t][r]);
+    }
+  ech_bwd_act<T3>(par + P.ga2, P.d3, g, da3, F.a3, F.u3, s, acc.gam3, acc.bet3, du3);
+  ech_stash<T2>(X2, row, g, F.a2, 1.0f);
+  ech_stash<T3>(D2, row, g, du3, s);
+  f32x4 da2[T2], du2[T2];
+  ech_dense<T3, T2, false>(par + P.T2, P.lt2, nullptr, P.d3, P.d2, du3, da2, j, g);
+  if (ADJ) {
+#pragma unroll
+    for (int t = 0; t < T2; ++t) da2[t] += ab2[t];
+  }
+  ech_bwd_act<T2>(par + P.ga1, P.d2, g, da2, F.a2, F.u2, s, acc.gam2, acc.bet2, du2);
+  ech_stash<T1>(X1, row, g, F.a1, 1.0f);
+  ech_stash<T2>(D1, row, g, du2, s);
+  f32x4 da1[T1], du1[T1];
+  ech_dense<T2, T1, false>(par + P.T1, P.lt1, nullptr, P.d2, P.d1, du2, da1, j, g);
+  if (ADJ) {
+#pragma unroll
+    for (int t = 0; t < T1; ++t) da1[t] += ab1[t];
+  }
+  ech_bwd_act<T1>(par + P.ga0, P.d1, g, da1, F.a1, F.u1, s, acc.gam1, acc.bet1, du1);
+  ech_stash<1>(X0, row, g, F.a0, 1.0f);
+  ech_stash<T1>(D0, row, g, du1, s);
+}
+
+// adjoint-network layer: dy = dA (1 - a^2), du = dy gamma c
+template <int NT>
+__device__ __forceinline__ void ech_adj_act(const float *ga, int n, int g, const f32x4 (&dA)[NT], const f32x4 (&a)[NT], f32x4 (&dy)[NT],
+                                            f32x4 (&du)[NT]) {
+  const float c = ech_c();
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float av = a[t][r];
+      dy[t][r] = dA[t][r] * (1.0f - av * av);
+      du[t][r] = dy[t][r] * ech_ld(ga, 16 * t + 4 * g + r, n) * c;
+    }
+}
+// reverse of an adjoint-network layer: dub = abar_{l-1} W_l;  gamma contribution;  abar on the forward node;  abar_l for the layer above
+template <int NT>
+__device__ __forceinline__ void ech_rev_act(const float *ga, int n, int g, const f32x4 (&dub)[NT], const f32x4 (&dy)[NT], const f32x4 (&dA)[NT],
+                                            const f32x4 (&a)[NT], float s, f32x4 (&gam)[NT], f32x4 (&ab)[NT], f32x4 (&an)[NT]) {
+  const float c = ech_c();
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float tt = dub[t][r] * c;
+      gam[t][r] = fmaf(s * tt, dy[t][r], gam[t][r]);
+      const float dyb = tt * ech_ld(ga, 16 * t + 4 * g + r, n);
+      const float av = a[t][r];
+      ab[t][r] = dyb * dA[t][r] * (-2.0f * av);
+      an[t][r] = dyb * (1.0f - av * av);
+    }
+}
+
+// Gradient penalty on the evaluation F (of zhat): s * d/dtheta mean_b (||d out_b / d input_b|| - 1)^2.  st_rev / st_bwd: stash blocks of
+// the reverse pass through the adjoint network and of the backward pass through the forward network.  Returns (||g|| - 1)^2 of the row.
+template <int T1, int T2, int T3>
+__device__ __forceinline__ float ech_disc_gp(const float *par, const EchP &P, const EchFwd<T1, T2, T3> &F, float s, float *st_rev,
+                                             float *st_bwd, int B, int row, EchAcc<T1, T2, T3> &acc, int j, int g) {
+  using D = EchDims<T1, T2, T3>;
+  // ---- adjoint network: g = d out / d input
+  f32x4 dA3[T3], dy3[T3], du3[T3];
+#pragma unroll
+  for (int t = 0; t < T3; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dA3[t][r] = ech_ld(par + P.wo, 16 * t + 4 * g + r, P.d3);
+  ech_adj_act<T3>(par + P.ga2, P.d3, g, dA3, F.a3, dy3, du3);
+  f32x4 dA2[T2], dy2[T2], du2[T2];
+  ech_dense<T3, T2, false>(par + P.T2, P.lt2, nullptr, P.d3, P.d2, du3, dA2, j, g);
+  ech_adj_act<T2>(par + P.ga1, P.d2, g, dA2, F.a2, dy2, du2);
+  f32x4 dA1[T1], dy1[T1], du1[T1];
+  ech_dense<T2, T1, false>(par + P.T1, P.lt1, nullptr, P.d2, P.d1, du2, dA1, j, g);
+  ech_adj_act<T1>(par + P.ga0, P.d1, g, dA1, F.a1, dy1, du1);
+  f32x4 g0[1];
+  ech_dense<T1, 1, false>(par + P.T0, P.lt0, nullptr, P.d1, P.d0, du1, g0, j, g);
+  float n2 = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) n2 = fmaf(g0[0][r], g0[0][r], n2);
+  n2 = sum_over_g(n2);
+  const float nrm = sqrtf(n2);
+  const float part = (nrm - 1.0f) * (nrm - 1.0f);
+  const float coef = 2.0f * (nrm - 1.0f) / nrm / (float)B;
+  // ---- reverse through the adjoint network, bottom to top
+  float *X0 = st_rev, *X1 = st_rev + B * 16, *X2 = st_rev + B * (16 + 16 * T1);
+  float *D0 = st_rev + B * D::XW, *D1 = D0 + B * 16 * T1, *D2 = D1 + B * 16 * T2;
+  f32x4 an0[1];
+  an0[0] = g0[0] * coef;
+  ech_stash<1>(X0, row, g, an0, 1.0f);
+  ech_stash<T1>(D0, row, g, du1, s);
+  f32x4 dub1[T1], ab1[T1], an1[T1];
+  ech_dense<1, T1, false>(par + P.W0, P.ld0, nullptr, P.d0, P.d1, an0, dub1, j, g);
+  ech_rev_act<T1>(par + P.ga0, P.d1, g, dub1, dy1, dA1, F.a1, s, acc.gam1, ab1, an1);
+  ech_stash<T1>(X1, row, g, an1, 1.0f);
+  ech_stash<T2>(D1, row, g, du2, s);
+  f32x4 dub2[T2], ab2[T2], an2[T2];
+  ech_dense<T1, T2, false>(par + P.W1, P.ld1, nullptr, P.d1, P.d2, an1, dub2, j, g);
+  ech_rev_act<T2>(par + P.ga1, P.d2, g, dub2, dy2, dA2, F.a2, s, acc.gam2, ab2, an2);
+  ech_stash<T2>(X2, row, g, an2, 1.0f);
+  ech_stash<T3>(D2, row, g, du3, s);
+  f32x4 dub3[T3], ab3[T3], an3[T3];
+  ech_dense<T2, T3, false>(par + P.W2, P.ld2, nullptr, P.d2, P.d3, an2, dub3, j, g);
+  ech_rev_act<T3>(par + P.ga2, P.d3, g, dub3, dy3, dA3, F.a3, s, acc.gam3, ab3, an3);
+#pragma unroll
+  for (int t = 0; t < T3; ++t) acc.wo[t] += an3[t] * s;      // d out / d a_L = w_out: its adjoint is abar_L summed over rows
+  // ---- ... and on through the forward pass
+  ech_disc_bwd<T1, T2, T3, true>(par, P, F, 0.0f, ab1, ab2, ab3, s, st_bwd, B, row, acc, j, g);
+  return part;
+}
+
+// sums over the 16 rows of the tile -> this wave's slot (lane j = 15 of each group holds the totals)
+template <int T1, int T2, int T3>
+__device__ __forceinline__ void ech_write_slot(float *slot, const EchAcc<T1, T2, T3> &acc, float out_signed, float gp_part, int j, int g) {
+  using D = EchDims<T1, T2, T3>;
+  auto put = [&](float *dst, const f32x4 &v) {
+    f32x4 s;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[r] = sum_over_j_to_lane15(v[r]);
+    if (j == 15) *reinterpret_cast<f32x4 *>(dst + 4 * g) = s;
+  };
+#pragma unroll
+  for (int t = 0; t < T1; ++t) { put(slot + 16 * t, acc.gam1[t]); put(slot + D::SL + 16 * t, acc.bet1[t]); }
+#pragma unroll
+  for (int t = 0; t < T2; ++t) { put(slot + 16 * (T1 + t), acc.gam2[t]); put(slot + D::SL + 16 * (T1 + t), acc.bet2[t]); }
+#pragma unroll
+  for (int t = 0; t < T3; ++t) {
+    put(slot + 16 * (T1 + T2 + t), acc.gam3[t]); put(slot + D::SL + 16 * (T1 + T2 + t), acc.bet3[t]);
+    put(slot + 2 * D::SL + 16 * t, acc.wo[t]);
+  }
+  const float so = sum_over_j_to_lane15(out_signed), sg = sum_over_j_to_lane15(gp_part);
+  if (j == 15 && g == 0) { slot[2 * D::SL + 16 * T3] = so; slot[2 * D::SL + 16 * T3 + 1] = sg; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// encoder forward on one row tile (weights streamed from the canonical array in L2; hidden width 16 HT)
+// ---------------------------------------------------------------------------------------------
+template <int HT>
+__device__ __forceinline__ void ech_encoder(const float *theta, const EgmMlp &n, const float *vrow, f32x4 (&z)[1], int j, int g) {
+  const int p = n.dims[0], L = n.n_layers, q = n.dims[L];
+  constexpr int H = 16 * HT;
+  f32x4 h[HT];
+  {
+    const float *W = theta + n.woff[0], *bias = W + p * H;
+#pragma unroll
+    for (int u = 0; u < HT; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[u][r] = bias[16 * u + 4 * g + r];
+    const int KT = (p + 15) >> 4;
+    float ac[4][HT], xc[4];
+    auto load = [&](int t, float (&av)[4][HT], float (&xv)[4]) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = 16 * t + 4 * g + r;
+        const int fc = min(f, p - 1);
+        const float x = vrow[fc];
+        xv[r] = f < p ? x : 0.0f;
+#pragma unroll
+        for (int u = 0; u < HT; ++u) av[r][u] = W[fc * H + 16 * u + j];
+      }
+    };
+    load(0, ac, xc);
+    for (int t = 0; t < KT; ++t) {
+      float an[4][HT], xn[4];
+      load(min(t + 1, KT - 1), an, xn);      // next K tile in flight under this tile's MFMAs
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int u = 0; u < HT; ++u) h[u] = BGM_MFMA(ac[r][u], xc[r], h[u]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        xc[r] = xn[r];
+#pragma unroll
+        for (int u = 0; u < HT; ++u) ac[r][u] = an[r][u];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < HT; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[u][r] = fmaxf(h[u][r], EGM_LEAK * h[u][r]);
+  }
+  for (int l = 1; l < L - 1; ++l) {
+    BGM_NO_HOIST();
+    const float *W = theta + n.woff[l];
+    f32x4 h2[HT];
+    ech_dense<HT, HT, true>(W, H, W + H * H, H, H, h, h2, j, g);
+#pragma unroll
+    for (int u = 0; u < HT; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[u][r] = fmaxf(h2[u][r], EGM_LEAK * h2[u][r]);
+  }
+  const float *W = theta + n.woff[L - 1];
+  ech_dense<HT, 1, false>(W, q, W + H * q, H, q, h, z, j, g);
+}
+
+// ---------------------------------------------------------------------------------------------
+// the step
+// ---------------------------------------------------------------------------------------------
+template <int HT, int T1, int T2, int T3>
+static __global__ __launch_bounds__(ECH_THREADS) void egm_disc_chain_kernel(EgmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float ech_lds[];
+  using D = EchDims<T1, T2, T3>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  const int B = a.B, q = a.q;
+  const EchP P = ech_layout(a.dz);
+  float *par = ech_lds + 64;
+  float *slots = par + P.total;
+  float *zt = slots + ECH_ROLE_WAVES * D::SLOT;      // z_ = e(v), [B x 16]
+  float *stash = zt + 16 * B;                         // 4 passes x [B x SW]: D(z_), D(z), penalty reverse, penalty backward
+  ech_fill_params(par, P, a.theta_d, a.dz, tid);
+  __syncthreads();
+  const int role = wave >> 1, tile = wave & 1;
+  const int n_tiles = B >> 4;
+  const bool active = tile < n_tiles;
+  const int row = 16 * tile + j;                      // row of the minibatch owned by this lane
+  const float invB = 1.0f / (float)B;
+  EchAcc<T1, T2, T3> acc;
+  ech_zero<T1>(acc.gam1); ech_zero<T2>(acc.gam2); ech_zero<T3>(acc.gam3);
+  ech_zero<T1>(acc.bet1); ech_zero<T2>(acc.bet2); ech_zero<T3>(acc.bet3); ech_zero<T3>(acc.wo);
+  f32x4 nul1[T1], nul2[T2], nul3[T3];
+  ech_zero<T1>(nul1); ech_zero<T2>(nul2); ech_zero<T3>(nul3);
+  EchFwd<T1, T2, T3> F;
+  f32x4 zf[1];
+  ech_zero<1>(zf);
+  if (role == 0 && active) {
+    ech_encoder<HT>(a.theta_g, a.e, a.v + (long long)a.idx[row] * a.p, zf, j, g);
+    *reinterpret_cast<f32x4 *>(zt + row * 16 + 4 * g) = zf[0];
+  } else if (role == 1 && active) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) F.a0[0][r] = ech_ld(a.z + (long long)row * q, 4 * g + r, q);
+    ech_disc_fwd<T1, T2, T3>(par, P, F, j, g);
+    ech_disc_bwd<T1, T2, T3, false>(par, P, F, -invB, nul1, nul2, nul3, 1.0f, stash + 1 * B * D::SW, B, row, acc, j, g);
+    ech_write_slot<T1, T2, T3>(slots + wave * D::SLOT, acc, -F.out, 0.0f, j, g);
+  }
+  __syncthreads();
+  if (role == 0 && active) {
+    F.a0[0] = zf[0];
+    ech_disc_fwd<T1, T2, T3>(par, P, F, j, g);
+    ech_disc_bwd<T1, T2, T3, false>(par, P, F, invB, nul1, nul2, nul3, 1.0f, stash, B, row, acc, j, g);
+    ech_write_slot<T1, T2, T3>(slots + wave * D::SLOT, acc, F.out, 0.0f, j, g);
+  } else if (role == 2 && active) {
+    const f32x4 ze = *reinterpret_cast<const f32x4 *>(zt + row * 16 + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) F.a0[0][r] = ech_ld(a.z + (long long)row * q, 4 * g + r, q) * a.eps + ze[r] * (1.0f - a.eps);
+    ech_disc_fwd<T1, T2, T3>(par, P, F, j, g);
+    const float part = ech_disc_gp<T1, T2, T3>(par, P, F, 10.0f, stash + 2 * B * D::SW, stash + 3 * B * D::SW, B, row, acc, j, g);
+    ech_write_slot<T1, T2, T3>(slots + wave * D::SLOT, acc, 0.0f, part, j, g);
+  }
+  __syncthreads();
+  // ---- parameter gradients: W_l += sum over the four passes of X^T D (rows = K), one 16x16 tile per wave and round
+  const float c = ech_c();
+  for (int tau = wave; tau < D::TILES; tau += ECH_WAVES) {
+    int l, u, v, xw, dw, xo, dofs, n_in, n_out;
+    if (tau < T1) { l = 0; u = 0; v = tau; xw = 16; dw = 16 * T1; xo = 0; dofs = 0; n_in = P.d0; n_out = P.d1; }
+    else if (tau < T1 + T1 * T2) { const int k = tau - T1; l = 1; u = k / T2; v = k - u * T2; xw = 16 * T1; dw = 16 * T2; xo = 16; dofs = 16 * T1; n_in = P.d1; n_out = P.d2; }
+    else { const int k = tau - T1 - T1 * T2; l = 2; u = k / T3; v = k - u * T3; xw = 16 * T2; dw = 16 * T3; xo = 16 + 16 * T1; dofs = 16 * (T1 + T2); n_in = P.d2; n_out = P.d3; }
+    f32x4 w = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int pass = 0; pass < 4; ++pass) {
+      const float *xb = stash + pass * B * D::SW + B * xo + 16 * u + j;
+      const float *db = stash + pass * B * D::SW + B * (D::XW + dofs) + 16 * v + j;
+      for (int s4 = 0; s4 < n_tiles * 4; ++s4) {
+        const int rr = 4 * s4 + g;
+        w = BGM_MFMA(xb[rr * xw], db[rr * dw], w);
+      }
+    }
+    const int o = 16 * v + j;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = 16 * u + 4 * g + r;
+      if (f < n_in && o < n_out) {
+        const int e = a.dz.w[l] + f * n_out + o;
+        const float gi = w[r];
+        a.grad_d[e] = gi;
+        if (a.apply) {
+          const float mi = a.adam.b1 * a.m_d[e] + (1.0f - a.adam.b1) * gi;
+          const float vi = a.adam.b2 * a.v_d[e] + (1.0f - a.adam.b2) * gi * gi;
+          a.m_d[e] = mi; a.v_d[e] = vi;
+          a.theta_d[e] -= a.adam.lr_t * mi / (sqrtf(vi) + a.adam.eps);
+        }
+      }
+    }
+  }
+  // ---- vector parameters: fixed-order sums of the per-wave partials
+  auto adam1 = [&](int e, float gi) {
+    a.grad_d[e] = gi;
+    if (a.apply) {
+      const float mi = a.adam.b1 * a.m_d[e] + (1.0f - a.adam.b1) * gi;
+      const float vi = a.adam.b2 * a.v_d[e] + (1.0f - a.adam.b2) * gi * gi;
+      a.m_d[e] = mi; a.v_d[e] = vi;
+      a.theta_d[e] -= a.adam.lr_t * mi / (sqrtf(vi) + a.adam.eps);
+    }
+  };
+  const int n_role = 3 * n_tiles;    // waves 0..5 when B = 32; the slots of inactive waves are skipped
+  auto slot_sum = [&](int k) {
+    float s = 0.0f;
+    for (int w = 0; w < ECH_ROLE_WAVES; ++w)
+      if ((w & 1) < n_tiles) s += slots[w * D::SLOT + k];
+    return s;
+  };
+  (void)n_role;
+  for (int k = tid; k < D::SL; k += ECH_THREADS) {
+    int l, o;
+    if (k < 16 * T1) { l = 0; o = k; } else if (k < 16 * (T1 + T2)) { l = 1; o = k - 16 * T1; } else { l = 2; o = k - 16 * (T1 + T2); }
+    const int n_out = l == 0 ? P.d1 : (l == 1 ? P.d2 : P.d3);
+    if (o < n_out) {
+      const float gg = slot_sum(k), gb = slot_sum(D::SL + k);
+      const float ga = par[(l == 0 ? P.ga0 : (l == 1 ? P.ga1 : P.ga2)) + o];
+      adam1(a.dz.gamma[l] + o, gg);
+      adam1(a.dz.beta[l] + o, gb);
+      adam1(a.dz.b[l] + o, ga * c * gb);        // du = dy gamma c on every pass: the bias gradient is the beta gradient scaled
+    }
+  }
+  for (int f = tid; f < P.d3; f += ECH_THREADS) adam1(a.dz.w[3] + f, slot_sum(2 * D::SL + f));
+  if (tid == 0) {
+    adam1(a.dz.b[3], 0.0f);                      // sum_b dLoss/dout_b = B / B - B / B
+    const float dz_loss = slot_sum(2 * D::SL + 16 * T3) * invB, gp = slot_sum(2 * D::SL + 16 * T3 + 1) * invB;
+    if (a.out) { a.out[0] = dz_loss; a.out[1] = dz_loss + 10.0f * gp; }
+  }
+}

@@ -78,12 +78,25 @@ struct EgmArgs {
   float *out;                            // disc: [dz_loss, d_loss]   gen: [e_adv, l2_v, l2_z, l2_x, l2_y, total]
   int apply;                             // 1: Adam step; 0: leave the gradients in grad_* (parity tests)
   int disc_lds;                          // 1: the discriminator working set of the step lives in LDS (it fits)
+#ifdef EGM_PHASE_CLOCK
+  unsigned long long *stamps;
+#endif
 };
 
 struct EgmCtx {
   int tid;
   float *red;      // [32] reduction scratch (LDS)
+#ifdef EGM_PHASE_CLOCK
+  unsigned long long *stamps;
+#endif
 };
+// Development aid (-DEGM_PHASE_CLOCK, never in the shipped library): thread 0 records (source line, shader clock) after every
+// workgroup barrier of a step; egm_api.hip prints the per-phase cycle counts of one step.
+#ifdef EGM_PHASE_CLOCK
+#define EGM_STAMP(c) do { if ((c).tid == 0) { int *n_ = reinterpret_cast<int *>((c).red + 48); (c).stamps[2 * *n_] = __LINE__; (c).stamps[2 * *n_ + 1] = clock64(); ++*n_; } } while (0)
+#else
+#define EGM_STAMP(c) do {} while (0)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Tiny GEMMs on the matrix pipe.  C[M x N] = A[M x K] B[K x N] with arbitrary element strides, one
@@ -155,6 +168,7 @@ __device__ __forceinline__ void egm_fwd(const EgmCtx &c, const float *X, int ldx
                    Y[(long long)m * ldy + n] = v;
                  });
   __syncthreads();
+  EGM_STAMP(c);
 }
 // dX (+)= dY W^T
 __device__ __forceinline__ void egm_bwd_in(const EgmCtx &c, const float *dY, int ldy, const float *W, float *dX, int ldx, int B,
@@ -165,6 +179,7 @@ __device__ __forceinline__ void egm_bwd_in(const EgmCtx &c, const float *dY, int
                    *dst = accumulate ? *dst + v : v;
                  });
   __syncthreads();
+  EGM_STAMP(c);
 }
 __device__ __forceinline__ void egm_colsum(const EgmCtx &c, const float *dY, int ldy, float *gb, int B, int out, bool accumulate,
                                            float s) {
@@ -184,6 +199,7 @@ __device__ __forceinline__ void egm_bwd_w(const EgmCtx &c, const float *X, int l
                  });
   if (gb) egm_colsum(c, dY, ldy, gb, B, out, accumulate, s);
   __syncthreads();
+  EGM_STAMP(c);
 }
 // One backward phase of a Dense layer: gW, gb (+)= X^T dY, sums of dY;  dX = (dY W^T) * lrelu'(X) when `mask`
 // (X is the LeakyReLU output of the layer below, so dX is that layer's PRE-activation gradient), all behind one
@@ -210,6 +226,7 @@ __device__ __forceinline__ void egm_bwd_layer(const EgmCtx &c, const float *X, c
   }
   egm_colsum(c, dY, out, gb, B, out, accumulate, 1.0f);
   __syncthreads();
+  EGM_STAMP(c);
 }
 // workgroup sum (every thread gets the result)
 __device__ __forceinline__ float egm_block_sum(const EgmCtx &c, float v) {
@@ -324,6 +341,7 @@ __device__ __forceinline__ void egm_disc_fwd(const EgmCtx &c, const float *th, c
       }
     });
     __syncthreads();
+    EGM_STAMP(c);
   }
   egm_fwd(c, egm_dk_a(d, k, L, B), d.dims[L], th + d.w[L], th + d.b[L], egm_dk_out(d, k, B), 1, B, d.dims[L], 1, false);
 }
@@ -376,6 +394,7 @@ __device__ __forceinline__ void egm_disc_bwd(const EgmCtx &c, const float *th, f
       for (int i = c.tid; i < nL + 1; i += EGM_THREADS) gr[i < nL ? d.w[L] + i : d.b[L]] = 0.0f;
   }
   __syncthreads();
+  EGM_STAMP(c);
   for (int l = L - 1; l >= 0; --l) {
     const int in = d.dims[l], out = d.dims[l + 1];
     const float *uh_ = egm_dk_uhat(d, k, l, B), *sg_ = egm_dk_sigma(d, k, l, B), *ao_ = egm_dk_a(d, k, l + 1, B);
@@ -411,6 +430,7 @@ __device__ __forceinline__ void egm_disc_bwd(const EgmCtx &c, const float *th, f
       }
     });
     __syncthreads();
+    EGM_STAMP(c);
     const float *ai_ = egm_dk_a(d, k, l, B);
     egm_bwd_w(c, ai_, in, du, out, gr + d.w[l], gr + d.b[l], B, in, out, accumulate, s);
     if (l > 0) egm_bwd_in(c, du, out, th + d.w[l], da, in, B, in, out, false);
@@ -433,6 +453,7 @@ __device__ __forceinline__ float egm_disc_gp(const EgmCtx &c, const float *th, f
     for (int t = c.tid; t < B * nL; t += EGM_THREADS) daL[t] = th[d.w[L] + (t % nL)];
   }
   __syncthreads();
+  EGM_STAMP(c);
   for (int l = L - 1; l >= 0; --l) {
     const int in = d.dims[l], out = d.dims[l + 1];
     const float *uh_ = egm_dk_uhat(d, k, l, B), *sg_ = egm_dk_sigma(d, k, l, B), *ao_ = egm_dk_a(d, k, l + 1, B);
@@ -452,6 +473,7 @@ __device__ __forceinline__ float egm_disc_gp(const EgmCtx &c, const float *th, f
       egm_bn_proj_col(du_, uh_, B, out, o, ok, bl, 1.0f / sg_[o], d.fixed_norm);
     });
     __syncthreads();
+    EGM_STAMP(c);
     egm_bwd_in(c, du_, out, th + d.w[l], egm_gp_da(d, G, l, B), in, B, in, out, false);
   }
   // ---- penalty and its adjoint on g = da_0
@@ -514,9 +536,11 @@ __device__ __forceinline__ float egm_disc_gp(const EgmCtx &c, const float *th, f
       if (ok && bl == 0) gr[d.gamma[l] + o] += s * gg;
     });
     __syncthreads();
+    EGM_STAMP(c);
     // tmp now holds da_bar for layer l+1 : move it into the ping-pong buffer
     for (int t = c.tid; t < B * out; t += EGM_THREADS) da_bar[t] = tmp[t];
     __syncthreads();
+    EGM_STAMP(c);
   }
   for (int i = c.tid; i < nL; i += EGM_THREADS) {
     float acc = 0.0f;
@@ -524,6 +548,7 @@ __device__ __forceinline__ float egm_disc_gp(const EgmCtx &c, const float *th, f
     gr[d.w[L] + i] += s * acc;
   }
   __syncthreads();
+  EGM_STAMP(c);
   // ---- ... and on through the forward pass (scratch: bar_b, tmp)
   egm_disc_bwd(c, th, gr, d, k, false, 0.0f, &G, bar_b, tmp, nullptr, B, true, s);
   return gp;
@@ -557,18 +582,25 @@ __device__ __forceinline__ void egm_mlp_cache(const EgmMlp &n, int B, float *&p,
 static __global__ __launch_bounds__(EGM_THREADS) void egm_disc_step_kernel(EgmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float egm_lds[];
   EgmCtx c{(int)threadIdx.x, egm_lds};
+#ifdef EGM_PHASE_CLOCK
+  c.stamps = a.stamps;
+  if (c.tid == 0) *reinterpret_cast<int *>(c.red + 48) = 0;
+  EGM_STAMP(c);
+#endif
   const int B = a.B, q = a.q, p = a.p;
   float *wp = a.ws;
   auto take = [&](int n) { float *r = wp; wp += (n + 3) & ~3; return r; };
   float *vb = take(B * p), *zhat = take(B * q);
   for (int k = c.tid; k < B * p; k += EGM_THREADS) { const int b = k / p; vb[k] = a.v[(long long)a.idx[b] * p + (k - b * p)]; }
   __syncthreads();
+  EGM_STAMP(c);
   EgmMlpCache ce;
   egm_mlp_cache(a.e, B, wp, ce, vb);
   egm_mlp_fwd(c, a.theta_g, a.e, ce, B);                      // z_ = e(v)   (encoder fixed in this step)
   float *z_ = egm_act(a.e, ce, a.e.n_layers, B);
   for (int k = c.tid; k < B * q; k += EGM_THREADS) zhat[k] = a.z[k] * a.eps + z_[k] * (1.0f - a.eps);
   __syncthreads();
+  EGM_STAMP(c);
   // Discriminator working set: [cache A | cache B, da, du  (later overlaid by the gradient-penalty scratch)].
   // In LDS when it fits (B = 32, dz_units [64, 32, 8]: 147 KB): its many small per-column passes are chains of
   // dependent accesses and an LDS access costs ~1/15 of an L2 round trip.  Cache A holds D(z_) first and
@@ -596,8 +628,10 @@ static __global__ __launch_bounds__(EGM_THREADS) void egm_disc_step_kernel(EgmAr
   egm_disc_fwd(c, a.theta_d, a.dz, kh, B);
   const float gp = egm_disc_gp(c, a.theta_d, a.grad_d, a.dz, kh, overlay, B, 10.0f, a.dmax);
   __syncthreads();
+  EGM_STAMP(c);
   if (a.apply) egm_adam(c, a.theta_d, a.m_d, a.v_d, a.grad_d, a.dz.n_params, a.adam);
   if (c.tid == 0 && a.out) { a.out[0] = dz_loss; a.out[1] = dz_loss + 10.0f * gp; }
+  EGM_STAMP(c);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -606,6 +640,11 @@ static __global__ __launch_bounds__(EGM_THREADS) void egm_disc_step_kernel(EgmAr
 static __global__ __launch_bounds__(EGM_THREADS) void egm_gen_step_kernel(EgmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float egm_lds[];
   EgmCtx c{(int)threadIdx.x, egm_lds};
+#ifdef EGM_PHASE_CLOCK
+  c.stamps = a.stamps;
+  if (c.tid == 0) *reinterpret_cast<int *>(c.red + 48) = 0;
+  EGM_STAMP(c);
+#endif
   const int B = a.B, q = a.q, p = a.p, z0 = a.z0, z1 = a.z1, z2 = a.z2;
   const float invB = 1.0f / (float)B;
   float *wp = a.ws;
@@ -614,6 +653,7 @@ static __global__ __launch_bounds__(EGM_THREADS) void egm_gen_step_kernel(EgmArg
   for (int k = c.tid; k < B * p; k += EGM_THREADS) { const int b = k / p; vb[k] = a.v[(long long)a.idx[b] * p + (k - b * p)]; }
   for (int b = c.tid; b < B; b += EGM_THREADS) { xb[b] = a.x[a.idx[b]]; yb[b] = a.y[a.idx[b]]; }
   __syncthreads();
+  EGM_STAMP(c);
   const int Lg = a.g.n_layers, Le = a.e.n_layers, Lf = a.f.n_layers, Lh = a.h.n_layers;
   const int wg = p + 1, nf = a.f.dims[0], nh = a.h.dims[0], of = a.f.dims[Lf], oh = a.h.dims[Lh];
   // ---- forward
@@ -627,6 +667,7 @@ static __global__ __launch_bounds__(EGM_THREADS) void egm_gen_step_kernel(EgmArg
   float *v_ = take(B * p);                                     // contiguous copy of g(z)[:, :p]
   for (int k = c.tid; k < B * p; k += EGM_THREADS) { const int b = k / p; v_[k] = gz[b * wg + (k - b * p)]; }
   __syncthreads();
+  EGM_STAMP(c);
   egm_mlp_cache(a.e, B, wp, e2, v_);
   egm_mlp_fwd(c, a.theta_g, a.e, e2, B);                       // z__ = e(v_)
   float *z__ = egm_act(a.e, e2, Le, B);
@@ -646,6 +687,7 @@ static __global__ __launch_bounds__(EGM_THREADS) void egm_gen_step_kernel(EgmArg
     hin[k] = (i < z0) ? z_[b * q + i] : z_[b * q + z1 + i];     // z2 block starts at z0 + z1
   }
   __syncthreads();
+  EGM_STAMP(c);
   egm_mlp_cache(a.f, B, wp, cf, fin);
   egm_mlp_fwd(c, a.theta_g, a.f, cf, B);
   egm_mlp_cache(a.h, B, wp, ch, hin);
@@ -680,12 +722,14 @@ static __global__ __launch_bounds__(EGM_THREADS) void egm_gen_step_kernel(EgmArg
   // z__ branch: e (call 2, input v_) -> g (call 1)
   for (int k = c.tid; k < B * q; k += EGM_THREADS) d0[k] = zrec * (-2.0f / (float)(B * q)) * (a.z[k] - z__[k]);
   __syncthreads();
+  EGM_STAMP(c);
   egm_mlp_bwd(c, a.theta_g, a.grad_g, a.e, e2, d0, d1, dtmp, B, false);                // dtmp = dLoss/dv_  [B x p]
   for (int k = c.tid; k < B * wg; k += EGM_THREADS) {
     const int b = k / wg, i = k - b * wg;
     d0[k] = (i < p) ? dtmp[b * p + i] : 0.001f * 2.0f * gz[k] * invB;
   }
   __syncthreads();
+  EGM_STAMP(c);
   egm_mlp_bwd(c, a.theta_g, a.grad_g, a.g, g1, d0, d1, nullptr, B, false);
   // v__ branch: g (call 2, input z_)
   for (int k = c.tid; k < B * wg; k += EGM_THREADS) {
@@ -693,12 +737,14 @@ static __global__ __launch_bounds__(EGM_THREADS) void egm_gen_step_kernel(EgmArg
     d0[k] = (i < p) ? (-2.0f / (float)(B * p)) * (vb[b * p + i] - gv[k]) : 0.0f;
   }
   __syncthreads();
+  EGM_STAMP(c);
   egm_mlp_bwd(c, a.theta_g, a.grad_g, a.g, g2, d0, d1, dzsum, B, true);                // dzsum = dLoss/dz_ (so far)
   // adversarial branch through the fixed discriminator (its gradients go to a scratch area past the workspace use)
   float *gd_scratch = take(a.dz.n_params);
   egm_disc_bwd(c, a.theta_d, gd_scratch, a.dz, kd, true, -invB, nullptr, da, du, dtmp, B, false, 1.0f);
   for (int k = c.tid; k < B * q; k += EGM_THREADS) dzsum[k] += dtmp[k];
   __syncthreads();
+  EGM_STAMP(c);
   // f, h branches
   for (int k = c.tid; k < B * of; k += EGM_THREADS) {
     const int b = k / of, i = k - b * of;
@@ -708,6 +754,7 @@ static __global__ __launch_bounds__(EGM_THREADS) void egm_gen_step_kernel(EgmArg
     d0[k] = t;
   }
   __syncthreads();
+  EGM_STAMP(c);
   egm_mlp_bwd(c, a.theta_g, a.grad_g, a.f, cf, d0, d1, dfin, B, false);
   for (int k = c.tid; k < B * oh; k += EGM_THREADS) {
     const int b = k / oh, i = k - b * oh;
@@ -717,6 +764,7 @@ static __global__ __launch_bounds__(EGM_THREADS) void egm_gen_step_kernel(EgmArg
     d0[k] = t;
   }
   __syncthreads();
+  EGM_STAMP(c);
   egm_mlp_bwd(c, a.theta_g, a.grad_g, a.h, ch, d0, d1, dhin, B, false);
   for (int k = c.tid; k < B * q; k += EGM_THREADS) {
     const int b = k / q, i = k - b * q;
@@ -727,10 +775,12 @@ static __global__ __launch_bounds__(EGM_THREADS) void egm_gen_step_kernel(EgmArg
     d0[k] = t;
   }
   __syncthreads();
+  EGM_STAMP(c);
   egm_mlp_bwd(c, a.theta_g, a.grad_g, a.e, e1, d0, d1, nullptr, B, true);
   if (a.apply) egm_adam(c, a.theta_g, a.m_g, a.v_g, a.grad_g, a.n_gen, a.adam);
   if (c.tid == 0 && a.out) {
     a.out[0] = adv; a.out[1] = l_v; a.out[2] = l_z; a.out[3] = l_x; a.out[4] = l_y;
     a.out[5] = adv + (l_v + zrec * l_z) + (l_x + l_y) + 0.001f * sig;
   }
+  EGM_STAMP(c);
 }

@@ -382,6 +382,7 @@ class BGM(object):
         the sampling phase then runs in row blocks sized so that the latent draws and the predictive cells of
         a block stay below ``max_draw_bytes`` (the reference materialises [n_mcmc, n, x_dim] on the host)."""
         assert 0 < alpha < 1, "The significance level 'alpha' must be greater than 0 and less than 1."
+        parallel.check_n_mcmc(n_mcmc)
         import time as _time
         _t = {"_last": _time.perf_counter()}
 

@@ -382,6 +382,7 @@ class BGMBayes(BGM):
         """Posterior-predictive imputation of the NaN cells (bgm/base.py:527-663).  HMC over ALL rows as in the reference
         (one generator call per gradient evaluation), then one predictive generator call per block of `bs` rows."""
         assert 0 < alpha < 1, "The significance level 'alpha' must be greater than 0 and less than 1."
+        parallel.check_n_mcmc(n_mcmc)
         self._warn_fresh_noise()
         data_np = data.cpu().numpy() if isinstance(data, torch.Tensor) else np.asarray(data, dtype=np.float32)
         data_np = data_np.astype(np.float32)

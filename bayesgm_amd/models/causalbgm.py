@@ -407,6 +407,7 @@ class CausalBGM(object):
         segment (row-blocked only if the ITE draw matrix would exceed device memory) and the result does
         not depend on it.  Under torch.distributed the rows are sharded by rank and results gathered."""
         assert 0 < alpha < 1, "The significance level 'alpha' must be greater than 0 and less than 1."
+        parallel.check_n_mcmc(n_mcmc)
         binary = bool(self._p['binary_treatment'])
         if not binary and x_values is None:
             raise ValueError("For continuous treatment, 'x_values' must not be None. Provide a list or a single treatment value.")

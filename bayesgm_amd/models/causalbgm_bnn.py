@@ -358,6 +358,7 @@ class CausalBGMBayes(CausalBGM):
         """Causal effects with posterior intervals (base.py:573-668).  With Bayesian nets the rows of one block of ``bs``
         rows share their input statistics and weight perturbations, as in the reference; all blocks advance together."""
         assert 0 < alpha < 1, "The significance level 'alpha' must be greater than 0 and less than 1."
+        parallel.check_n_mcmc(n_mcmc)
         binary = bool(self._p['binary_treatment'])
         if not binary and x_values is None:
             raise ValueError("For continuous treatment, 'x_values' must not be None. Provide a list or a single treatment value.")

@@ -216,6 +216,7 @@ class IdentifiableCausalBGM(CausalBGM):
         sampler's default there), effects fused into the sampling kernel; `bs` only chunked the host-side effect pass of the
         reference and does not change the result."""
         assert 0 < alpha < 1, "The significance level 'alpha' must be greater than 0 and less than 1."
+        parallel.check_n_mcmc(n_mcmc)
         binary = bool(self._p['binary_treatment'])
         if not binary and x_values is None:
             raise ValueError("For continuous treatment, 'x_values' must not be None.")

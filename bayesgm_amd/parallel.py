@@ -87,3 +87,13 @@ def shared_seed(random_seed):
     box = [int(np.random.SeedSequence().generate_state(1)[0] & 0x7FFFFFFF) if rank() == 0 else None]
     dist.broadcast_object_list(box, src=0)
     return int(box[0])
+
+MAX_INTERVAL_DRAWS = 32768   # bgm_row_mean_quantiles sorts one row of draws in LDS (aux_kernels.hip)
+
+
+def check_n_mcmc(n_mcmc):
+    """predict() reduces n_mcmc kept draws per row to mean + posterior interval in one workgroup-local sort; say so before
+    the sampler has run rather than after."""
+    if int(n_mcmc) < 1 or int(n_mcmc) > MAX_INTERVAL_DRAWS:
+        raise ValueError("n_mcmc must be in [1, %d] (the interval reduction sorts the draws of a row in LDS); got %r"
+                         % (MAX_INTERVAL_DRAWS, n_mcmc))

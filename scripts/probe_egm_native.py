@@ -1,4 +1,5 @@
-"""Latency of the native EGM steps (one launch each):  python scripts/probe_egm_native.py [p] [iters]"""
+"""Latency of the native EGM steps (one launch each):  python scripts/probe_egm_native.py [p] [iters] [fixed|batch]
+(fixed = the shipped discriminator normalisation; BGM_EGM_NO_CHAIN=1 forces the phase-machine kernels)"""
 import sys, os, time, json
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -22,6 +23,8 @@ nets = {"g": _mlp(rs, [q] + [64] * 5 + [p + 1]), "e": _mlp(rs, [p] + [64] * 5 + 
 dz = _disc(rs, [q, 64, 32, 8, 1])
 eng = CausalEngine(p, z_dims)
 eng.set_model(g=nets["g"], f=nets["f"], h=nets["h"], e=nets["e"])
+norm = sys.argv[3] if len(sys.argv) > 3 else "fixed"
+eng.set_disc_norm(norm)
 eng.egm_begin(B, [64, 32, 8], 2e-4, True, dz)
 v = torch.randn(n, p, device="cuda"); x = torch.rand(n, device="cuda"); y = torch.randn(n, device="cuda")
 zs = torch.randn(iters * 6, B, q, device="cuda")
@@ -39,5 +42,5 @@ torch.cuda.synchronize(); td = (time.perf_counter() - t1) / iters
 t1 = time.perf_counter()
 for it in range(iters): eng.egm_gen_step(zs[it], idx[it], v, x, y)
 torch.cuda.synchronize(); tg = (time.perf_counter() - t1) / iters
-print(json.dumps(dict(p=p, ms_per_iteration=1e3 * dt / iters, disc_step_us=1e6 * td, gen_step_us=1e6 * tg,
+print(json.dumps(dict(p=p, disc_norm=norm, ms_per_iteration=1e3 * dt / iters, disc_step_us=1e6 * td, gen_step_us=1e6 * tg,
                       est_30000_iters_s=30000 * dt / iters)))

@@ -195,3 +195,13 @@ def test_shared_seed_is_one_value_on_every_rank():
     res = _run(_shared_seed_fn)
     assert res[0][0] == res[1][0] == 17
     assert isinstance(res[0][1], int) and res[0][1] == res[1][1]
+
+
+def test_check_n_mcmc_limits():
+    """predict() rejects a draw count the interval reduction cannot hold before any sampling happens."""
+    from bayesgm_amd import parallel
+    parallel.check_n_mcmc(1)
+    parallel.check_n_mcmc(parallel.MAX_INTERVAL_DRAWS)
+    for bad in (0, parallel.MAX_INTERVAL_DRAWS + 1):
+        with pytest.raises(ValueError, match="n_mcmc"):
+            parallel.check_n_mcmc(bad)
