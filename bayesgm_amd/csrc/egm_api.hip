@@ -108,7 +108,7 @@ extern "C" int bgm_causal_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, co
   a.disc_lds = (64 + arena) * sizeof(float) <= 160 * 1024 ? 1 : 0;
   s->lds_bytes = (int)((64 + (a.disc_lds ? arena : 0)) * sizeof(float));
   {   // register-chained discriminator step: fixed normalisation, the default layer shapes, one or two 16-row tiles
-    bool chain = d.fixed_norm && L == 3 && d.dims[0] <= 16 && (d.dims[1] + 15) / 16 == 4 && (d.dims[2] + 15) / 16 == 2 &&
+    bool chain = d.fixed_norm && L == 3 && d.dims[0] <= 16 && (d.dims[1] + 15) / 16 == 4 && (d.dims[2] + 15) / 16 == 2 && d.dims[3] >= 1 &&
                  d.dims[3] <= 16 && (B == 16 || B == 32) && a.e.n_layers >= 2 && a.e.dims[a.e.n_layers] == h->q && h->q <= 16;
     for (int l = 1; l < a.e.n_layers; ++l) chain = chain && a.e.dims[l] == 64;
     const size_t bytes = chain ? sizeof(float) * (size_t)ech_disc_lds_floats<4, 2, 1>(d, B) : 0;
@@ -158,6 +158,21 @@ static void egm_stamp_report(const char *what, int *calls) {
 }
 #endif
 
+#ifdef EGM_PHASE_CLOCK
+static void egm_chain_report(const char *what, int *calls) {
+  if (++*calls != 40) return;
+  hipDeviceSynchronize();
+  std::vector<unsigned long long> st(8192);
+  hipMemcpy(st.data(), egm_stamp_buf(), sizeof(unsigned long long) * 8192, hipMemcpyDeviceToHost);
+  for (int w = 0; w < 8; ++w) {
+    std::fprintf(stderr, "ECH_PHASE %s wave %d:", what, w);
+    for (int k = 1; k < 16; ++k) if (st[4096 + w * 16 + k] && st[4096 + w * 16 + k - 1]) std::fprintf(stderr, " %d:%llu", k, st[4096 + w * 16 + k] - st[4096 + w * 16 + k - 1]);
+    if (st[4096 + w * 16 + 8]) std::fprintf(stderr, "  enc_start-k0:%llu", st[4096 + w * 16 + 8] - st[4096 + w * 16]);
+    std::fprintf(stderr, "\n");
+  }
+}
+#endif
+
 static EgmAdam egm_adam_coeffs(float lr, long long t) {
   EgmAdam ad;
   ad.b1 = EGM_B1; ad.b2 = EGM_B2; ad.eps = EGM_ADAM_EPS;
@@ -176,10 +191,18 @@ extern "C" int bgm_causal_egm_disc_step(bgm_handle *h, const float *z_dev, const
   if (apply) s->t_d += 1;
   a.adam = egm_adam_coeffs(s->cfg.lr, std::max<long long>(1, s->t_d));
   if (s->chain_disc_lds > 0) {
-    auto kc = egm_disc_chain_kernel<4, 4, 2, 1>;
+    const int kt0 = (a.p + 15) / 16;     // compiled first-layer extents: p in (192, 208] and (96, 112]; any other p takes the streaming variant
+    auto kc = a.B == 32 ? (kt0 == 13 ? egm_disc_chain_kernel<4, 13, 4, 2, 1, 2> : kt0 == 7 ? egm_disc_chain_kernel<4, 7, 4, 2, 1, 2> : egm_disc_chain_kernel<4, 0, 4, 2, 1, 2>)
+                        : egm_disc_chain_kernel<4, 0, 4, 2, 1, 1>;
     BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, s->chain_disc_lds));
+#ifdef EGM_PHASE_CLOCK
+    a.stamps = egm_stamp_buf();
+#endif
     hipLaunchKernelGGL(kc, dim3(1), dim3(ECH_THREADS), s->chain_disc_lds, (hipStream_t)stream_, a);
     BGM_HIP_CHECK(hipGetLastError());
+#ifdef EGM_PHASE_CLOCK
+    { static int calls = 0; egm_chain_report("disc", &calls); }
+#endif
     return BGM_OK;
   }
   auto k = egm_disc_step_kernel;

@@ -50,7 +50,8 @@ def _rel(a, b):
                                   dict(binary=True, p=200, z_dims=(3, 3, 6, 6), B=19, disc_norm="fixed"),
                                   # the shapes of the register-chained discriminator step (egm_chain.h): one and two 16-row tiles
                                   dict(binary=False, p=200, z_dims=(1, 1, 1, 7), B=32, disc_norm="fixed"),
-                                  dict(binary=True, p=37, z_dims=(2, 3, 4, 5), B=16, disc_norm="fixed")])
+                                  dict(binary=True, p=37, z_dims=(2, 3, 4, 5), B=16, disc_norm="fixed"),
+                                  dict(binary=False, p=100, z_dims=(3, 3, 3, 3), B=32, disc_norm="fixed")])
 def test_egm_step_gradients_match_oracle(case):
     import torch
     B = case["B"]
