@@ -3,10 +3,12 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "bgm_host.h"
 #include "egm_kernels.h"
 #include "egm_chain.h"
+#include "egm_chain_gen.h"
 
 static constexpr float EGM_B1 = 0.9f, EGM_B2 = 0.99f, EGM_ADAM_EPS = 1e-7f;   // causalbgm/base.py:86-87, Keras epsilon
 
@@ -16,6 +18,12 @@ struct EgmState {
   size_t n_gen = 0, n_dz = 0, ws_floats = 0;
   int lds_bytes = 0;
   int chain_disc_lds = 0;      // > 0: the discriminator step runs as register-chained row tiles (egm_chain.h) with this much LDS
+  int chain_gen_lds = 0;       // > 0: likewise the generator step (egm_chain_gen.h)
+  int chain_ntl = 0;           // its compiled output-tile count of g
+  EcgTab gen_tab{};
+  std::vector<int> gen_tiles;
+  float *thetaT_dev = nullptr;
+  int *tiles_dev = nullptr;
   long long t_g = 0, t_d = 0;  // Adam iteration counters of g_pre_optimizer / d_pre_optimizer
   float *dev = nullptr;        // one allocation: theta_g|m_g|v_g|grad_g|theta_d|m_d|v_d|grad_d|ws
 };
@@ -26,6 +34,8 @@ void bgm_egm_free_state(bgm_handle *h) {
   if (!h->egm_state) return;
   EgmState *s = est(h);
   if (s->dev) hipFree(s->dev);
+  if (s->thetaT_dev) hipFree(s->thetaT_dev);
+  if (s->tiles_dev) hipFree(s->tiles_dev);
   delete s;
   h->egm_state = nullptr;
 }
@@ -115,6 +125,53 @@ extern "C" int bgm_causal_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, co
     if (std::getenv("BGM_EGM_NO_CHAIN")) chain = false;   // A/B switch for measurements
     s->chain_disc_lds = (chain && bytes <= 160 * 1024) ? (int)bytes : 0;
   }
+  size_t gen_stash = 0;
+  {   // register-chained generator step: same discriminator / encoder shapes, g with 64-wide hidden layers and a compiled output
+      // extent, the head networks f, h with the 64-32-8 default
+    const int ntl = (h->p + 1 + 15) / 16;
+    bool chain = s->chain_disc_lds > 0 && (ntl == 13 || ntl == 7) && a.g.n_layers >= 2 && a.g.dims[0] == h->q;
+    for (int l = 1; l < a.g.n_layers; ++l) chain = chain && a.g.dims[l] == 64;
+    for (const EgmMlp *m : {&a.f, &a.h})
+      chain = chain && m->n_layers == 4 && m->dims[0] <= 16 && m->dims[1] == 64 && m->dims[2] == 32 && m->dims[3] >= 1 && m->dims[3] <= 16 &&
+              m->dims[4] >= 1 && m->dims[4] <= 16;
+    if (std::getenv("BGM_EGM_NO_CHAIN_GEN")) chain = false;
+    if (chain) {
+      EcgTab &T = s->gen_tab;
+      size_t off = 0;
+      auto take = [&](size_t n) { const size_t r = off; off += (n + 3) / 4 * 4; return (int)r; };
+      auto tiles_of = [](int n) { return (n + 15) / 16; };
+      const EgmMlp *nets[6] = {&a.g, &a.e, &a.e, &a.g, &a.f, &a.h};
+      int xw[6][EGM_MAX_LAYERS], dw[6][EGM_MAX_LAYERS];
+      for (int ps = 0; ps < 6; ++ps) {
+        const EgmMlp &m = *nets[ps];
+        for (int l = 0; l < m.n_layers; ++l) {
+          xw[ps][l] = 16 * tiles_of(m.dims[l]);
+          dw[ps][l] = 16 * tiles_of(m.dims[l + 1]);
+        }
+        if (nets[ps] == &a.e) xw[ps][0] = 16 * ntl;                   // the encoder's input tiles are the generator's output tiles
+        if (nets[ps] == &a.g) dw[ps][m.n_layers - 1] = 16 * ntl;
+        for (int l = 0; l < m.n_layers; ++l) { T.x[ps][l] = take((size_t)B * xw[ps][l]); T.d[ps][l] = take((size_t)B * dw[ps][l]); }
+      }
+      gen_stash = off;
+      // weight-gradient tiles: (layer, 16 input features, 16 output features), the passes that feed the layer
+      auto add = [&](const EgmMlp &m, int p0, int p1) {
+        for (int l = 0; l < m.n_layers; ++l) {
+          const int ni = m.dims[l], no = m.dims[l + 1];
+          for (int u = 0; u < tiles_of(ni); ++u)
+            for (int v = 0; v < tiles_of(no); ++v) {
+              int e[ECG_TILE_INTS] = {T.x[p0][l], p1 >= 0 ? T.x[p1][l] : -1, T.d[p0][l], p1 >= 0 ? T.d[p1][l] : -1, xw[p0][l], dw[p0][l], u, v,
+                                      m.woff[l], ni, no, u == 0 ? m.woff[l] + ni * no : -1, 0, 0, 0, 0};
+              s->gen_tiles.insert(s->gen_tiles.end(), e, e + ECG_TILE_INTS);
+            }
+        }
+      };
+      add(a.g, ECG_PASS_G1, ECG_PASS_G2); add(a.e, ECG_PASS_E2, ECG_PASS_E1); add(a.f, ECG_PASS_F, -1); add(a.h, ECG_PASS_H, -1);
+      T.n_tiles = (int)(s->gen_tiles.size() / ECG_TILE_INTS);
+      T.n_warm = (int)s->n_gen;
+      s->chain_ntl = ntl;
+      s->chain_gen_lds = (int)(sizeof(float) * (size_t)ecg_lds_floats<4, 2, 1>(d, B));
+    }
+  }
   a.n_gen = (int)s->n_gen; a.B = B; a.q = h->q; a.p = h->p; a.wmax = wmax;
   a.z0 = h->cfg.z_dims[0]; a.z1 = h->cfg.z_dims[1]; a.z2 = h->cfg.z_dims[2];
   a.binary = h->cfg.binary_treatment; a.use_z_rec = cfg->use_z_rec;
@@ -123,7 +180,7 @@ extern "C" int bgm_causal_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, co
   auto widths = [&](const int *dims, int n_layers) { size_t t = 0; for (int l = 0; l <= n_layers; ++l) t += dims[l] + 4; return t; };
   acts += 2 * widths(a.g.dims, a.g.n_layers) + 2 * widths(a.e.dims, a.e.n_layers) + widths(a.f.dims, a.f.n_layers) +
           widths(a.h.dims, a.h.n_layers) + 3 * 3 * widths(d.dims, L + 1) + 12 * widths(d.dims, L + 1);
-  s->ws_floats = (size_t)B * (acts + 16 * (size_t)wmax + 4 * (size_t)h->p + 64) + s->n_dz + arena + 4096;
+  s->ws_floats = std::max((size_t)B * (acts + 16 * (size_t)wmax + 4 * (size_t)h->p + 64) + s->n_dz + arena + 4096, gen_stash + 64);
   const size_t total = 4 * s->n_gen + 4 * s->n_dz + s->ws_floats + 64;
   BGM_HIP_CHECK(hipMalloc(&s->dev, total * sizeof(float)));
   BGM_HIP_CHECK(hipMemset(s->dev, 0, total * sizeof(float)));
@@ -137,6 +194,24 @@ extern "C" int bgm_causal_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, co
   for (const HostNet *n : {&G, &E, &F, &H}) tg.insert(tg.end(), n->theta.begin(), n->theta.end());
   BGM_HIP_CHECK(hipMemcpy(a.theta_g, tg.data(), tg.size() * sizeof(float), hipMemcpyHostToDevice));
   BGM_HIP_CHECK(hipMemcpy(a.theta_d, theta_dz_host, s->n_dz * sizeof(float), hipMemcpyHostToDevice));
+  if (s->chain_gen_lds > 0) {
+    // transposed mirror of the weight matrices (the backward chains read W^T rows contiguously); kept current by the kernel's Adam
+    std::vector<float> tT(s->n_gen, 0.0f);
+    auto mirror = [&](const EgmMlp &m) {
+      for (int l = 0; l < m.n_layers; ++l) {
+        const int ni = m.dims[l], no = m.dims[l + 1];
+        for (int f = 0; f < ni; ++f)
+          for (int o = 0; o < no; ++o) tT[m.woff[l] + (size_t)o * ni + f] = tg[m.woff[l] + (size_t)f * no + o];
+      }
+    };
+    mirror(a.g); mirror(a.e); mirror(a.f); mirror(a.h);
+    BGM_HIP_CHECK(hipMalloc(&s->thetaT_dev, sizeof(float) * s->n_gen));
+    BGM_HIP_CHECK(hipMemcpy(s->thetaT_dev, tT.data(), sizeof(float) * s->n_gen, hipMemcpyHostToDevice));
+    BGM_HIP_CHECK(hipMalloc(&s->tiles_dev, sizeof(int) * s->gen_tiles.size()));
+    BGM_HIP_CHECK(hipMemcpy(s->tiles_dev, s->gen_tiles.data(), sizeof(int) * s->gen_tiles.size(), hipMemcpyHostToDevice));
+    s->gen_tab.thetaT = s->thetaT_dev;
+    s->gen_tab.tiles = s->tiles_dev;
+  }
   return BGM_OK;
 }
 
@@ -197,6 +272,7 @@ extern "C" int bgm_causal_egm_disc_step(bgm_handle *h, const float *z_dev, const
     BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, s->chain_disc_lds));
 #ifdef EGM_PHASE_CLOCK
     a.stamps = egm_stamp_buf();
+    hipMemsetAsync(a.stamps, 0, sizeof(unsigned long long) * 8192, (hipStream_t)stream_);
 #endif
     hipLaunchKernelGGL(kc, dim3(1), dim3(ECH_THREADS), s->chain_disc_lds, (hipStream_t)stream_, a);
     BGM_HIP_CHECK(hipGetLastError());
@@ -229,6 +305,21 @@ extern "C" int bgm_causal_egm_gen_step(bgm_handle *h, const float *z_dev, const 
   a.z = z_dev; a.idx = idx_dev; a.v = v_dev; a.x = x_dev; a.y = y_dev; a.eps = 0.0f; a.out = out_dev; a.apply = apply ? 1 : 0;
   if (apply) s->t_g += 1;
   a.adam = egm_adam_coeffs(s->cfg.lr, std::max<long long>(1, s->t_g));
+  if (s->chain_gen_lds > 0) {
+    auto kc = a.B == 32 ? (s->chain_ntl == 13 ? egm_gen_chain_kernel<4, 13, 4, 2, 1, 2> : egm_gen_chain_kernel<4, 7, 4, 2, 1, 2>)
+                        : (s->chain_ntl == 13 ? egm_gen_chain_kernel<4, 13, 4, 2, 1, 1> : egm_gen_chain_kernel<4, 7, 4, 2, 1, 1>);
+    BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, s->chain_gen_lds));
+#ifdef EGM_PHASE_CLOCK
+    a.stamps = egm_stamp_buf();
+    hipMemsetAsync(a.stamps, 0, sizeof(unsigned long long) * 8192, (hipStream_t)stream_);
+#endif
+    hipLaunchKernelGGL(kc, dim3(1), dim3(ECH_THREADS), s->chain_gen_lds, (hipStream_t)stream_, a, s->gen_tab);
+    BGM_HIP_CHECK(hipGetLastError());
+#ifdef EGM_PHASE_CLOCK
+    { static int calls = 0; egm_chain_report("gen", &calls); }
+#endif
+    return BGM_OK;
+  }
   auto k = egm_gen_step_kernel;
   BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
 #ifdef EGM_PHASE_CLOCK

@@ -96,11 +96,13 @@ def CausalEngineFlat(dz):
     return CausalEngine.flatten_disc(dz)
 
 
-@pytest.mark.parametrize("disc_norm", ["batch", "fixed"])
-def test_egm_alternating_adam_steps_track_oracle(disc_norm):
+@pytest.mark.parametrize("disc_norm,p", [("batch", 23), ("fixed", 23), ("fixed", 100), ("fixed", 200)])
+def test_egm_alternating_adam_steps_track_oracle(disc_norm, p):
+    """p = 100 / 200 with fixed normalisation: both steps run as register-chained row tiles (egm_chain.h, egm_chain_gen.h), whose
+    Adam step also maintains the transposed weight mirror the next step's backward chains read."""
     import torch
     B = 32
-    eng, nets, dz, params, (x, y, v), dev, rs, dz_units = _setup(False, 23, (1, 1, 1, 7), B)
+    eng, nets, dz, params, (x, y, v), dev, rs, dz_units = _setup(False, p, (1, 1, 1, 7), B)
     q = 10
     if disc_norm == "fixed":
         eng.set_disc_norm("fixed")
@@ -135,7 +137,7 @@ def test_egm_alternating_adam_steps_track_oracle(disc_norm):
     assert np.abs(got_g - np.concatenate([a.ravel() for k in ("g", "e", "f", "h") for Wb in nets[k] for a in Wb])).max() > 5e-4
     # end of session: the trained networks are installed in the handle
     eng.egm_end()
-    g_tr = eng.get_weights(0, [q] + [64] * 5 + [24])
+    g_tr = eng.get_weights(0, [q] + [64] * 5 + [p + 1])
     assert np.abs(g_tr[0][0] - st.nets["g"][0][0]).max() <= 2e-5
 
 
