@@ -315,6 +315,9 @@ extern "C" int bgm_causal_egm_gen_step(bgm_handle *h, const float *z_dev, const 
 #endif
     hipLaunchKernelGGL(kc, dim3(1), dim3(ECH_THREADS), s->chain_gen_lds, (hipStream_t)stream_, a, s->gen_tab);
     BGM_HIP_CHECK(hipGetLastError());
+    auto kd = a.B == 32 ? egm_gen_dw_kernel<2> : egm_gen_dw_kernel<1>;
+    hipLaunchKernelGGL(kd, dim3((s->gen_tab.n_tiles + ECH_WAVES - 1) / ECH_WAVES), dim3(ECH_THREADS), 0, (hipStream_t)stream_, a, s->gen_tab);
+    BGM_HIP_CHECK(hipGetLastError());
 #ifdef EGM_PHASE_CLOCK
     { static int calls = 0; egm_chain_report("gen", &calls); }
 #endif

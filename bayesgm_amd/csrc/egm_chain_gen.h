@@ -6,8 +6,10 @@
 // and every row of the minibatch is independent until the parameter gradients are summed.  Waves 0,1 walk chain A on the two
 // 16-row tiles, waves 2,3 chain B; the activations stay in registers, the weights are read in place from the canonical arrays
 // (forward) and from a transposed mirror kept by the Adam step (backward), always two K tiles ahead of the MFMAs that consume
-// them.  Layer inputs X_l and pre-activation gradients D_l go to an HBM/L2 workspace; after one barrier all eight waves turn
-// them into parameter gradients (X^T D, rows = K) tile by tile from a host-built table and apply Adam.
+// them.  Layer inputs X_l and pre-activation gradients D_l go to an HBM/L2 workspace; a second launch over ~35 workgroups
+// (egm_gen_dw_kernel: one 16x16 tile of one layer per wave, from a host-built table) turns them into parameter gradients
+// (X^T D, rows = K) and applies Adam.  (Inside the single chain workgroup the same phase took as long as the chains: 270 tiles x
+// ~70 vector-memory instructions through one CU's address unit.)
 // Formulas: egm_gen_step_kernel (egm_kernels.h) / oracle/egm.py gen_step_grads; discriminator in inference-mode normalisation.
 #pragma once
 #include "egm_chain.h"
@@ -34,33 +36,40 @@ struct EcgTab {
 struct EcgW { const float *W; int ld, n_in, n_out, col0; };
 template <int NT> struct EcgA { float v[3][4][NT]; };      // v[0], v[1]: K tiles 0, 1 of the sub-layer about to run; v[2]: third buffer
 
-template <int NT>
-__device__ __forceinline__ void ecg_load_tile(const EcgW &w, int t, float (&av)[4][NT], int j, int g) {
+// CX: the columns col0 .. col0 + 16 NT all exist (no column clamp / mask: one lane base + immediate offsets);  clamp_rows: the K tile
+// may reach beyond n_in (only the last K tile of a layer can)
+template <int NT, bool CX>
+__device__ __forceinline__ void ecg_load_tile(const EcgW &w, int t, float (&av)[4][NT], int j, int g, bool clamp_rows) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const float *wr = w.W + (long long)min(16 * t + 4 * g + r, w.n_in - 1) * w.ld;
+    int row = 16 * t + 4 * g + r;
+    if (clamp_rows) row = min(row, w.n_in - 1);
+    const float *wr = w.W + (row * w.ld + w.col0 + j);
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
-      const int o = w.col0 + 16 * u + j;
-      const float x = wr[min(o, w.n_out - 1)];
-      av[r][u] = o < w.n_out ? x : 0.0f;        // padded output columns stay exactly zero (they are the next layer's padded inputs)
+      if (CX) av[r][u] = wr[16 * u];
+      else {
+        const int o = w.col0 + 16 * u + j;
+        const float x = w.W[row * w.ld + min(o, w.n_out - 1)];
+        av[r][u] = o < w.n_out ? x : 0.0f;      // padded output columns stay exactly zero (they are the next layer's padded inputs)
+      }
     }
   }
 }
-template <int NT>
+template <int NT, bool CX>
 __device__ __forceinline__ void ecg_prime(const EcgW &w, EcgA<NT> &A, int j, int g) {
-  ecg_load_tile<NT>(w, 0, A.v[0], j, g);
-  ecg_load_tile<NT>(w, 1, A.v[1], j, g);       // (a one-tile sub-layer reads a clamped duplicate)
+  ecg_load_tile<NT, CX>(w, 0, A.v[0], j, g, true);
+  ecg_load_tile<NT, CX>(w, 1, A.v[1], j, g, true);       // (a one-tile sub-layer reads a clamped duplicate)
 }
 // Runs the sub-layer whose first two K tiles are in A and leaves the first two K tiles of the next sub-layer `wn` in An.
-template <int KT, int NT, int NTN>
+template <int KT, int NT, int NTN, bool CX, bool CXN>
 __device__ __forceinline__ void ecg_sub(const EcgW &w, const f32x4 (&in)[KT], f32x4 (&out)[NT], EcgA<NT> &A, const EcgW &wn, EcgA<NTN> &An,
                                         int j, int g) {
 #pragma unroll
   for (int t = 0; t < KT; ++t) {
-    if (t + 2 < KT) ecg_load_tile<NT>(w, t + 2, A.v[(t + 2) % 3], j, g);
-    if (t == (KT >= 2 ? KT - 2 : 0)) ecg_load_tile<NTN>(wn, 0, An.v[0], j, g);
-    if (t == KT - 1) ecg_load_tile<NTN>(wn, 1, An.v[1], j, g);
+    if (t + 2 < KT) ecg_load_tile<NT, CX>(w, t + 2, A.v[(t + 2) % 3], j, g, t + 2 == KT - 1);
+    if (t == (KT >= 2 ? KT - 2 : 0)) ecg_load_tile<NTN, CXN>(wn, 0, An.v[0], j, g, true);
+    if (t == KT - 1) ecg_load_tile<NTN, CXN>(wn, 1, An.v[1], j, g, true);
     BGM_NO_HOIST();          // pins the issue order (the scheduler would sink every load to just above its MFMA)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -116,17 +125,25 @@ template <int KT, int NT>
 __device__ __forceinline__ void ecg_wide(const float *W, int ld, int n_in, int n_out, const f32x4 (&in)[KT], f32x4 (&out)[NT], int j, int g) {
   constexpr int Q = NT / 4, R = NT % 4;
   ech_zero<NT>(out);
-  EcgA<4> A, An;
   EcgW w{W, ld, n_in, n_out, 0};
   if constexpr (Q > 0) {
-    ecg_prime<4>(w, A, j, g);
+    // 16 (NT - 1) < n_out <= 16 NT: every group but the very last is complete
+    EcgA<4> A, An;
+    ecg_prime<4, (Q > 1 || R > 0)>(w, A, j, g);
 #pragma unroll
     for (int c = 0; c < Q; ++c) {
       f32x4 o4[4];
       ech_zero<4>(o4);
       EcgW wn{W, ld, n_in, n_out, 64 * (c + 1 < Q ? c + 1 : c)};
       w.col0 = 64 * c;
-      ecg_sub<KT, 4, 4>(w, in, o4, A, wn, An, j, g);
+      constexpr bool last_full = R > 0;      // the last group of four is complete when a remainder group follows
+      if (c + 1 < Q) {
+        if (c + 2 < Q || last_full) ecg_sub<KT, 4, 4, true, true>(w, in, o4, A, wn, An, j, g);
+        else ecg_sub<KT, 4, 4, true, false>(w, in, o4, A, wn, An, j, g);
+      } else {
+        if (last_full) ecg_sub<KT, 4, 4, true, true>(w, in, o4, A, wn, An, j, g);
+        else ecg_sub<KT, 4, 4, false, false>(w, in, o4, A, wn, An, j, g);
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u) out[4 * c + u] = o4[u];
       ecg_copy<4>(A, An);
@@ -135,10 +152,10 @@ __device__ __forceinline__ void ecg_wide(const float *W, int ld, int n_in, int n
   if constexpr (R > 0) {
     EcgA<R> Ar, Ad;
     EcgW wr{W, ld, n_in, n_out, 64 * Q};
-    ecg_prime<R>(wr, Ar, j, g);
+    ecg_prime<R, false>(wr, Ar, j, g);
     f32x4 orr[R];
     ech_zero<R>(orr);
-    ecg_sub<KT, R, R>(wr, in, orr, Ar, wr, Ad, j, g);
+    ecg_sub<KT, R, R, false, false>(wr, in, orr, Ar, wr, Ad, j, g);
 #pragma unroll
     for (int u = 0; u < R; ++u) out[4 * Q + u] = orr[u];
   }
@@ -155,7 +172,7 @@ __device__ __forceinline__ void ecg_hidden_fwd(const float *theta, const EgmMlp 
   if (L <= 2) return;
   EcgA<HT> A, An;
   EcgW w{theta + n.woff[1], H, H, H, 0};
-  ecg_prime<HT>(w, A, j, g);
+  ecg_prime<HT, true>(w, A, j, g);
   for (int l = 1; l < L - 1; ++l) {
     BGM_NO_HOIST();
     ecg_put<HT>(ws + xo[l], row, g, h);
@@ -163,7 +180,7 @@ __device__ __forceinline__ void ecg_hidden_fwd(const float *theta, const EgmMlp 
     EcgW wn{theta + n.woff[min(l + 1, L - 2)], H, H, H, 0};
     f32x4 h2[HT];
     ech_zero<HT>(h2);
-    ecg_sub<HT, HT, HT>(w, h, h2, A, wn, An, j, g);
+    ecg_sub<HT, HT, HT, true, true>(w, h, h2, A, wn, An, j, g);
     ecg_bias<HT>(w.W + H * H, H, 0, g, h2);
     ecg_lrelu<HT>(h2);
 #pragma unroll
@@ -180,7 +197,7 @@ __device__ __forceinline__ void ecg_hidden_bwd(const float *thetaT, const EgmMlp
   if (L <= 2) return;
   EcgA<HT> A, An;
   EcgW w{thetaT + n.woff[L - 2], H, H, H, 0};
-  ecg_prime<HT>(w, A, j, g);
+  ecg_prime<HT, true>(w, A, j, g);
   for (int l = L - 2; l >= 1; --l) {
     BGM_NO_HOIST();
     ecg_put<HT>(ws + dofs[l], row, g, dh);
@@ -189,7 +206,7 @@ __device__ __forceinline__ void ecg_hidden_bwd(const float *thetaT, const EgmMlp
     f32x4 d2[HT], xl[HT];
     ech_zero<HT>(d2);
     ecg_get<HT>(ws + xo[l], row, g, xl);          // x_l = LeakyReLU output of layer l-1
-    ecg_sub<HT, HT, HT>(w, dh, d2, A, wn, An, j, g);
+    ecg_sub<HT, HT, HT, true, true>(w, dh, d2, A, wn, An, j, g);
     ecg_mask<HT>(d2, xl);
 #pragma unroll
     for (int u = 0; u < HT; ++u) dh[u] = d2[u];
@@ -208,9 +225,9 @@ __device__ __forceinline__ void ecg_g_fwd(const float *theta, const EgmMlp &n, c
   {
     EcgA<HT> A, Ad;
     EcgW w{theta + n.woff[0], H, q, H, 0};
-    ecg_prime<HT>(w, A, j, g);
+    ecg_prime<HT, true>(w, A, j, g);
     ech_zero<HT>(h);
-    ecg_sub<1, HT, HT>(w, zin, h, A, w, Ad, j, g);
+    ecg_sub<1, HT, HT, true, true>(w, zin, h, A, w, Ad, j, g);
     ecg_bias<HT>(w.W + q * H, H, 0, g, h);
     ecg_lrelu<HT>(h);
   }
@@ -231,10 +248,10 @@ __device__ __forceinline__ void ecg_g_bwd(const float *thetaT, const EgmMlp &n, 
   {
     EcgA<HT> A, Ad;
     EcgW w{thetaT + n.woff[L - 1], H, no, H, 0};      // W^T [n_out x H]
-    ecg_prime<HT>(w, A, j, g);
+    ecg_prime<HT, true>(w, A, j, g);
     ech_zero<HT>(dh);
     ecg_get<HT>(ws + xo[L - 1], row, g, xl);
-    ecg_sub<NTL, HT, HT>(w, dout, dh, A, w, Ad, j, g);
+    ecg_sub<NTL, HT, HT, true, true>(w, dout, dh, A, w, Ad, j, g);
     ecg_mask<HT>(dh, xl);
   }
   ecg_hidden_bwd<HT>(thetaT, n, xo, dofs, ws, row, dh, j, g);
@@ -242,9 +259,9 @@ __device__ __forceinline__ void ecg_g_bwd(const float *thetaT, const EgmMlp &n, 
   if (WANT_DX) {
     EcgA<1> A, Ad;
     EcgW w{thetaT + n.woff[0], q, H, q, 0};           // W^T [H x q]
-    ecg_prime<1>(w, A, j, g);
+    ecg_prime<1, false>(w, A, j, g);
     ech_zero<1>(dx);
-    ecg_sub<HT, 1, 1>(w, dh, dx, A, w, Ad, j, g);
+    ecg_sub<HT, 1, 1, false, false>(w, dh, dx, A, w, Ad, j, g);
   }
 }
 
@@ -258,9 +275,9 @@ __device__ __forceinline__ void ecg_e_fwd(const float *theta, const EgmMlp &n, c
   {
     EcgA<HT> A, Ad;
     EcgW w{theta + n.woff[0], H, p, H, 0};
-    ecg_prime<HT>(w, A, j, g);
+    ecg_prime<HT, true>(w, A, j, g);
     ech_zero<HT>(h);
-    ecg_sub<NTL, HT, HT>(w, xin, h, A, w, Ad, j, g);
+    ecg_sub<NTL, HT, HT, true, true>(w, xin, h, A, w, Ad, j, g);
     ecg_bias<HT>(w.W + p * H, H, 0, g, h);
     ecg_lrelu<HT>(h);
   }
@@ -269,9 +286,9 @@ __device__ __forceinline__ void ecg_e_fwd(const float *theta, const EgmMlp &n, c
   {
     EcgA<1> A, Ad;
     EcgW w{theta + n.woff[L - 1], q, H, q, 0};
-    ecg_prime<1>(w, A, j, g);
+    ecg_prime<1, false>(w, A, j, g);
     ech_zero<1>(z);
-    ecg_sub<HT, 1, 1>(w, h, z, A, w, Ad, j, g);
+    ecg_sub<HT, 1, 1, false, false>(w, h, z, A, w, Ad, j, g);
     ecg_bias<1>(w.W + H * q, q, 0, g, z);
   }
 }
@@ -285,10 +302,10 @@ __device__ __forceinline__ void ecg_e_bwd(const float *thetaT, const EgmMlp &n, 
   {
     EcgA<HT> A, Ad;
     EcgW w{thetaT + n.woff[L - 1], H, q, H, 0};       // W^T [q x H]
-    ecg_prime<HT>(w, A, j, g);
+    ecg_prime<HT, true>(w, A, j, g);
     ech_zero<HT>(dh);
     ecg_get<HT>(ws + xo[L - 1], row, g, xl);
-    ecg_sub<1, HT, HT>(w, dz, dh, A, w, Ad, j, g);
+    ecg_sub<1, HT, HT, true, true>(w, dz, dh, A, w, Ad, j, g);
     ecg_mask<HT>(dh, xl);
   }
   ecg_hidden_bwd<HT>(thetaT, n, xo, dofs, ws, row, dh, j, g);
@@ -306,24 +323,24 @@ __device__ __forceinline__ void ecg_head_fwd(const float *theta, const EgmMlp &n
   EcgA<T1> A1; EcgA<T2> A2; EcgA<T3> A3; EcgA<1> A4, Ad;
   EcgW w0{theta + n.woff[0], d1, d0, d1, 0}, w1{theta + n.woff[1], d2, d1, d2, 0}, w2{theta + n.woff[2], d3, d2, d3, 0},
        w3{theta + n.woff[3], d4, d3, d4, 0};
-  ecg_prime<T1>(w0, A1, j, g);
+  ecg_prime<T1, true>(w0, A1, j, g);
   ech_zero<T1>(a1);
-  ecg_sub<1, T1, T2>(w0, in, a1, A1, w1, A2, j, g);
+  ecg_sub<1, T1, T2, true, true>(w0, in, a1, A1, w1, A2, j, g);
   ecg_bias<T1>(w0.W + d0 * d1, d1, 0, g, a1);
   ecg_lrelu<T1>(a1);
   ecg_put<T1>(ws + xo[1], row, g, a1);
   ech_zero<T2>(a2);
-  ecg_sub<T1, T2, T3>(w1, a1, a2, A2, w2, A3, j, g);
+  ecg_sub<T1, T2, T3, true, false>(w1, a1, a2, A2, w2, A3, j, g);
   ecg_bias<T2>(w1.W + d1 * d2, d2, 0, g, a2);
   ecg_lrelu<T2>(a2);
   ecg_put<T2>(ws + xo[2], row, g, a2);
   ech_zero<T3>(a3);
-  ecg_sub<T2, T3, 1>(w2, a2, a3, A3, w3, A4, j, g);
+  ecg_sub<T2, T3, 1, false, false>(w2, a2, a3, A3, w3, A4, j, g);
   ecg_bias<T3>(w2.W + d2 * d3, d3, 0, g, a3);
   ecg_lrelu<T3>(a3);
   ecg_put<T3>(ws + xo[3], row, g, a3);
   ech_zero<1>(out);
-  ecg_sub<T3, 1, 1>(w3, a3, out, A4, w3, Ad, j, g);
+  ecg_sub<T3, 1, 1, false, false>(w3, a3, out, A4, w3, Ad, j, g);
   ecg_bias<1>(w3.W + d3 * d4, d4, 0, g, out);
 }
 template <int T1, int T2, int T3>
@@ -335,24 +352,24 @@ __device__ __forceinline__ void ecg_head_bwd(const float *thetaT, const EgmMlp &
   EcgW w3{thetaT + n.woff[3], d3, d4, d3, 0}, w2{thetaT + n.woff[2], d2, d3, d2, 0}, w1{thetaT + n.woff[1], d1, d2, d1, 0},
        w0{thetaT + n.woff[0], d0, d1, d0, 0};
   f32x4 e3[T3], e2[T2], e1[T1], x3[T3], x2[T2], x1[T1];
-  ecg_prime<T3>(w3, A3, j, g);
+  ecg_prime<T3, false>(w3, A3, j, g);
   ecg_get<T3>(ws + xo[3], row, g, x3);
   ech_zero<T3>(e3);
-  ecg_sub<1, T3, T2>(w3, dout, e3, A3, w2, A2, j, g);
+  ecg_sub<1, T3, T2, false, true>(w3, dout, e3, A3, w2, A2, j, g);
   ecg_mask<T3>(e3, x3);
   ecg_put<T3>(ws + dofs[2], row, g, e3);
   ecg_get<T2>(ws + xo[2], row, g, x2);
   ech_zero<T2>(e2);
-  ecg_sub<T3, T2, T1>(w2, e3, e2, A2, w1, A1, j, g);
+  ecg_sub<T3, T2, T1, true, true>(w2, e3, e2, A2, w1, A1, j, g);
   ecg_mask<T2>(e2, x2);
   ecg_put<T2>(ws + dofs[1], row, g, e2);
   ecg_get<T1>(ws + xo[1], row, g, x1);
   ech_zero<T1>(e1);
-  ecg_sub<T2, T1, 1>(w1, e2, e1, A1, w0, A0, j, g);
+  ecg_sub<T2, T1, 1, true, false>(w1, e2, e1, A1, w0, A0, j, g);
   ecg_mask<T1>(e1, x1);
   ecg_put<T1>(ws + dofs[0], row, g, e1);
   ech_zero<1>(dx);
-  ecg_sub<T1, 1, 1>(w0, e1, dx, A0, w0, Ad, j, g);
+  ecg_sub<T1, 1, 1, false, false>(w0, e1, dx, A0, w0, Ad, j, g);
 }
 
 // dLoss/d input of the (fixed) discriminator for dLoss/d out = dout on every row
@@ -580,9 +597,16 @@ static __global__ __launch_bounds__(ECH_THREADS) void egm_gen_chain_kernel(EgmAr
     __threadfence_block();
     if (lane == 0) atomicAdd(const_cast<int *>(flag), 1);
     float sink = 0.0f;
-    for (int i = tid - 256; i < tab.n_warm; i += 256 * 8) {
+    const int n4 = tab.n_warm >> 2;                         // both arrays start 16-byte aligned
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { const int e = min(i + 256 * k, tab.n_warm - 1); sink += th[e] + tT[e]; }
+    for (int arr = 0; arr < 2; ++arr) {
+      const f32x4 *src = reinterpret_cast<const f32x4 *>(arr == 0 ? th : tT);
+      for (int i = tid - 256; i < n4; i += 256 * 16) {
+        f32x4 acc4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc4 += src[min(i + 256 * k, n4 - 1)];
+        sink += acc4[0] + acc4[1] + acc4[2] + acc4[3];
+      }
     }
     asm volatile("" ::"v"(sink));
   }
@@ -593,60 +617,8 @@ static __global__ __launch_bounds__(ECH_THREADS) void egm_gen_chain_kernel(EgmAr
     if (j == 15 && g == 0) part[wave * 16 + k] = s;
   }
   ECH_STAMP(4);
-  __threadfence();           // the stash went to global memory: visible to every wave of the workgroup after the barrier
   __syncthreads();
   ECH_STAMP(5);
-  // ================= parameter gradients + Adam: one 16x16 tile of one layer per wave and round =================
-  for (int tau = wave; tau < tab.n_tiles; tau += ECH_WAVES) {
-    const int *td = tab.tiles + tau * ECG_TILE_INTS;
-    const int xo0 = td[0], xo1 = td[1], do0 = td[2], do1 = td[3], xw = td[4], dw = td[5], u = td[6], v = td[7], woff = td[8],
-              n_in = td[9], n_out = td[10], boff = td[11];
-    const int o = 16 * v + j;
-    int e[4]; float t0[4], m0[4], v0[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      e[r] = woff + min(16 * u + 4 * g + r, n_in - 1) * n_out + min(o, n_out - 1);
-      t0[r] = a.theta_g[e[r]]; m0[r] = a.m_g[e[r]]; v0[r] = a.v_g[e[r]];
-    }
-    const int eb = boff + min(o, n_out - 1);
-    const float tb = a.theta_g[max(eb, 0)], mb = a.m_g[max(eb, 0)], vb = a.v_g[max(eb, 0)];
-    f32x4 w = {0.0f, 0.0f, 0.0f, 0.0f};
-    float bs = 0.0f;
-    float xa[2][NB * 4], da[2][NB * 4];
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      const int xo = pass == 0 ? xo0 : max(xo1, 0), dofs = pass == 0 ? do0 : max(do1, 0);
-#pragma unroll
-      for (int s4 = 0; s4 < NB * 4; ++s4) {
-        const int rr = 4 * s4 + g;
-        xa[pass][s4] = ws[xo + rr * xw + 16 * u + j];
-        da[pass][s4] = ws[dofs + rr * dw + 16 * v + j];
-      }
-    }
-    BGM_NO_HOIST();
-    const float second = xo1 >= 0 ? 1.0f : 0.0f;
-#pragma unroll
-    for (int s4 = 0; s4 < NB * 4; ++s4) { w = BGM_MFMA(xa[0][s4], da[0][s4], w); bs += da[0][s4]; }
-#pragma unroll
-    for (int s4 = 0; s4 < NB * 4; ++s4) { w = BGM_MFMA(xa[1][s4] * second, da[1][s4], w); bs += da[1][s4] * second; }
-    bs = sum_over_g(bs);
-    auto adam = [&](int ei, float gi, float th0, float m_0, float v_0, int et) {
-      a.grad_g[ei] = gi;
-      if (a.apply) {
-        const float mi = a.adam.b1 * m_0 + (1.0f - a.adam.b1) * gi;
-        const float vi = a.adam.b2 * v_0 + (1.0f - a.adam.b2) * gi * gi;
-        const float tn = th0 - a.adam.lr_t * mi / (sqrtf(vi) + a.adam.eps);
-        a.m_g[ei] = mi; a.v_g[ei] = vi; a.theta_g[ei] = tn;
-        if (et >= 0) tab.thetaT[et] = tn;
-      }
-    };
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int f = 16 * u + 4 * g + r;
-      if (f < n_in && o < n_out) adam(e[r], w[r], t0[r], m0[r], v0[r], woff + o * n_in + f);
-    }
-    if (boff >= 0 && g == 0 && o < n_out) adam(eb, bs, tb, mb, vb, -1);
-  }
   ECH_STAMP(6);
   if (tid == 0 && a.out) {
     float s[8];
@@ -657,4 +629,59 @@ static __global__ __launch_bounds__(ECH_THREADS) void egm_gen_chain_kernel(EgmAr
     a.out[0] = adv; a.out[1] = l_v; a.out[2] = l_z; a.out[3] = l_x; a.out[4] = l_y;
     a.out[5] = adv + (l_v + zrec * l_z) + (l_x + l_y) + 0.001f * sig;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// parameter gradients + Adam: one 16x16 tile of one layer per wave
+// ---------------------------------------------------------------------------------------------
+template <int NB>
+static __global__ __launch_bounds__(ECH_THREADS) void egm_gen_dw_kernel(EgmArgs a, EcgTab tab) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  const int tau = blockIdx.x * ECH_WAVES + wave;
+  if (tau >= tab.n_tiles) return;
+  const int *td = tab.tiles + tau * ECG_TILE_INTS;
+  const int xo0 = td[0], xo1 = td[1], do0 = td[2], do1 = td[3], xw = td[4], dw = td[5], u = td[6], v = td[7], woff = td[8],
+            n_in = td[9], n_out = td[10], boff = td[11];
+  const float *ws = a.ws;
+  const int o = 16 * v + j;
+  int e[4]; float t0[4], m0[4], v0[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    e[r] = woff + min(16 * u + 4 * g + r, n_in - 1) * n_out + min(o, n_out - 1);
+    t0[r] = a.theta_g[e[r]]; m0[r] = a.m_g[e[r]]; v0[r] = a.v_g[e[r]];
+  }
+  const int eb = max(boff + min(o, n_out - 1), 0);
+  const float tb = a.theta_g[eb], mb = a.m_g[eb], vb = a.v_g[eb];
+  float xa[2][NB * 4], da[2][NB * 4];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int xo = pass == 0 ? xo0 : max(xo1, 0), dofs = pass == 0 ? do0 : max(do1, 0);
+    const float *xp = ws + xo + g * xw + 16 * u + j, *dp = ws + dofs + g * dw + 16 * v + j;
+#pragma unroll
+    for (int s4 = 0; s4 < NB * 4; ++s4) { xa[pass][s4] = xp[4 * s4 * xw]; da[pass][s4] = dp[4 * s4 * dw]; }
+  }
+  f32x4 w = {0.0f, 0.0f, 0.0f, 0.0f};
+  float bs = 0.0f;
+  const float second = xo1 >= 0 ? 1.0f : 0.0f;
+#pragma unroll
+  for (int s4 = 0; s4 < NB * 4; ++s4) { w = BGM_MFMA(xa[0][s4], da[0][s4], w); bs += da[0][s4]; }
+#pragma unroll
+  for (int s4 = 0; s4 < NB * 4; ++s4) { w = BGM_MFMA(xa[1][s4] * second, da[1][s4], w); bs += da[1][s4] * second; }
+  bs = sum_over_g(bs);
+  auto adam = [&](int ei, float gi, float th0, float m_0, float v_0, int et) {
+    a.grad_g[ei] = gi;
+    if (a.apply) {
+      const float mi = a.adam.b1 * m_0 + (1.0f - a.adam.b1) * gi;
+      const float vi = a.adam.b2 * v_0 + (1.0f - a.adam.b2) * gi * gi;
+      const float tn = th0 - a.adam.lr_t * mi / (sqrtf(vi) + a.adam.eps);
+      a.m_g[ei] = mi; a.v_g[ei] = vi; a.theta_g[ei] = tn;
+      if (et >= 0) tab.thetaT[et] = tn;
+    }
+  };
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int f = 16 * u + 4 * g + r;
+    if (f < n_in && o < n_out) adam(e[r], w[r], t0[r], m0[r], v0[r], woff + o * n_in + f);
+  }
+  if (boff >= 0 && g == 0 && o < n_out) adam(boff + o, bs, tb, mb, vb, -1);
 }
