@@ -1,6 +1,7 @@
 // bnn_egm_api.hip -- C ABI of the EGM warm start with Bayesian networks (a sub-session of bgm_bnn_begin).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "bgm_host.h"
@@ -116,6 +117,19 @@ extern "C" int bgm_bnn_egm_disc_step(bgm_handle *h, const float *z_dev, const in
   a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32); a.stream = stream_id;
   if (apply) e->t_d += 1;
   a.adam = bnn_egm_adam(e->cfg.lr, std::max<long long>(1, e->t_d));
+  {   // discriminator passes as register-chained row tiles when the shapes are the compiled ones (egm_chain.h)
+    const EgmDisc &d = a.dz;
+    const bool chain = d.fixed_norm && d.n_hidden == 3 && d.dims[0] <= 16 && (d.dims[1] + 15) / 16 == 4 && (d.dims[2] + 15) / 16 == 2 &&
+                       d.dims[3] >= 1 && d.dims[3] <= 16 && (a.B == 16 || a.B == 32) && !std::getenv("BGM_EGM_NO_CHAIN");
+    const size_t bytes = chain ? sizeof(float) * (size_t)ech_disc_lds_floats<4, 2, 1>(d, a.B) : 0;
+    if (chain && bytes <= 160 * 1024) {
+      auto kc = a.B == 32 ? bnn_egm_disc_chain_kernel<4, 2, 1, 2> : bnn_egm_disc_chain_kernel<4, 2, 1, 1>;
+      BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+      hipLaunchKernelGGL(kc, dim3(1), dim3(EGM_THREADS), bytes, (hipStream_t)stream_, a);
+      BGM_HIP_CHECK(hipGetLastError());
+      return BGM_OK;
+    }
+  }
   auto k = bnn_egm_disc_step_kernel;
   BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
   hipLaunchKernelGGL(k, dim3(1), dim3(EGM_THREADS), e->lds_bytes, (hipStream_t)stream_, a);

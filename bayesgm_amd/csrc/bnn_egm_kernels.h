@@ -9,6 +9,7 @@
 #pragma once
 #include "bnn_kernels.h"
 #include "egm_kernels.h"
+#include "egm_chain.h"
 
 static_assert(BNN_THREADS == EGM_THREADS, "the Flipout and discriminator routines share one workgroup");
 
@@ -68,6 +69,31 @@ static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_disc_step_kernel(B
   __syncthreads();
   if (a.apply) egm_adam(c, a.theta_d, a.m_d, a.v_d, a.grad_d, a.dz.n_params, a.adam);
   if (c.tid == 0 && a.out) { a.out[0] = dz_loss; a.out[1] = dz_loss + 10.0f * gp; }
+}
+
+// train_disc_step with the discriminator passes as register-chained row tiles (egm_chain.h; inference-mode normalisation, the
+// default layer shapes, B = 16 / 32): the noisy encoder call stays on the Flipout routines, its output z_ is laid out as row
+// tiles in LDS, and the three discriminator passes, the gradient GEMMs and Adam are ech_disc_tail.
+template <int T1, int T2, int T3, int NB>
+static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_disc_chain_kernel(BnnEgmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float egm_lds[];
+  BnnCtx cb{(int)threadIdx.x, egm_lds};
+  const int tid = threadIdx.x, B = a.B, q = a.q, p = a.p;
+  float *wp = a.ws;
+  auto take = [&](int n) { float *r = wp; wp += (n + 3) & ~3; return r; };
+  float *vb = take(B * p);
+  for (int k = tid; k < B * p; k += EGM_THREADS) { const int b = k / p; vb[k] = a.v_[(long long)a.idx[b] * p + (k - b * p)]; }
+  __syncthreads();
+  BnnCache ke;
+  bnn_cache(a.net[BNN_E], B, wp, ke, vb);
+  const float *z_ = bnn_fwd(cb, a.theta, a.net[BNN_E], ke, B, a.k0, a.k1, a.stream);     // noisy encoder call (fixed in this step)
+  const EchP P = ech_layout<T1, T2, T3>(a.dz);
+  const EchLds<T1, T2, T3> M(egm_lds, P, B);
+  for (int k = tid; k < 16 * B; k += EGM_THREADS) { const int b = k >> 4, i = k & 15; const float t = z_[b * q + min(i, q - 1)]; M.zt[k] = i < q ? t : 0.0f; }
+  ech_fill_params<T1, T2, T3>(M.par, P, a.theta_d, a.dz, tid, EGM_THREADS);
+  __syncthreads();
+  const EchDiscIo io{a.theta_d, a.m_d, a.v_d, a.grad_d, a.adam, a.apply, q, a.out, a.z, a.eps};
+  ech_disc_tail<T1, T2, T3, NB>(io, a.dz, P, M, tid);
 }
 
 static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_gen_step_kernel(BnnEgmArgs a) {

@@ -541,8 +541,17 @@ __device__ __forceinline__ void ech_encoder(const float *theta, const EgmMlp &n,
   z[0] += bz;
 }
 
+// what the discriminator passes need from a step's arguments (CausalBGM and its Bayesian-network variant share them)
+struct EchDiscIo {
+  float *theta_d, *m_d, *v_d, *grad_d;
+  EgmAdam adam;
+  int apply, q;
+  float *out;
+  const float *z;      // [B x q] prior sample
+  float eps;           // gradient-penalty interpolation coefficient
+};
 // Adam on one parameter with its state already loaded
-__device__ __forceinline__ void ech_adam(const EgmArgs &a, int e, float gi, float th, float m0, float v0) {
+__device__ __forceinline__ void ech_adam(const EchDiscIo &a, int e, float gi, float th, float m0, float v0) {
   a.grad_d[e] = gi;
   if (a.apply) {
     const float mi = a.adam.b1 * m0 + (1.0f - a.adam.b1) * gi;
@@ -552,53 +561,39 @@ __device__ __forceinline__ void ech_adam(const EgmArgs &a, int e, float gi, floa
   }
 }
 
-template <int HT, int KT0, int T1, int T2, int T3, int NB>
-static __global__ __launch_bounds__(ECH_THREADS) void egm_disc_chain_kernel(EgmArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float ech_lds[];
+// LDS map behind the 64 reduction words: parameter block | per-wave partial sums | z_ tiles [B x 16] | stash of the four passes
+template <int T1, int T2, int T3>
+struct EchLds {
+  float *par, *slots, *zt, *stash;
+  __device__ __forceinline__ EchLds(float *lds, const EchP &P, int B) {
+    using D = EchDims<T1, T2, T3>;
+    par = lds + 64;
+    slots = par + P.total;
+    zt = slots + ECH_ROLE_WAVES * D::SLOT;
+    stash = zt + 16 * B;
+  }
+};
+
+// The three discriminator passes, the gradient GEMMs and Adam.  On entry (after a workgroup barrier): `par` filled, z_ = e(v) of
+// the minibatch in `zt` ([B x 16], zero beyond q).  Waves 0,1: D(z_); 2,3: D(z); 4,5: D(zhat) with the gradient penalty.
+template <int T1, int T2, int T3, int NB>
+__device__ __forceinline__ void ech_disc_tail(const EchDiscIo &a, const EgmDisc &dz, const EchP &P, const EchLds<T1, T2, T3> &M, int tid) {
   using D = EchDims<T1, T2, T3>;
   constexpr int B = 16 * NB;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  const int lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const int q = a.q;
-  const EchP P = ech_layout<T1, T2, T3>(a.dz);
-  float *par = ech_lds + 64;
-  float *slots = par + P.total;
-  float *zt = slots + ECH_ROLE_WAVES * D::SLOT;      // z_ = e(v), [B x 16]
-  float *stash = zt + 16 * B;                         // 4 passes x [B x SW]: D(z_), D(z), penalty reverse, penalty backward
-  ECH_STAMP(0);
+  float *par = M.par, *slots = M.slots, *zt = M.zt, *stash = M.stash;
   const int role = wave >> 1, tile = wave & 1;
   const bool active = tile < NB;
   const int row = 16 * tile + j;                      // row of the minibatch owned by this lane
   const float invB = 1.0f / (float)B;
   f32x4 nul1[T1], nul2[T2], nul3[T3];
   ech_zero<T1>(nul1); ech_zero<T2>(nul2); ech_zero<T3>(nul3);
-  f32x4 zf[1];
-  ech_zero<1>(zf);
-  if (role == 0) {
-    if (active) {
-            ech_encoder<HT, KT0>(a.theta_g, a.e, a.v + (long long)a.idx[row] * a.p, zf, j, g);
-      *reinterpret_cast<f32x4 *>(zt + row * 16 + 4 * g) = zf[0];
-    }
-  } else {
-    // the other six waves: the discriminator's parameter block, then pull the encoder's weights into this XCD's L2 ahead of
-    // the two waves that stream them
-    const float *w = a.theta_g + a.e.off;
-    const int n = a.e.woff[a.e.n_layers - 1] - a.e.off;
-    float sink = 0.0f;
-    for (int i = tid - 128; i < n; i += (ECH_THREADS - 128) * 8) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) sink += w[min(i + (ECH_THREADS - 128) * k, n - 1)];
-    }
-    asm volatile("" ::"v"(sink));
-    ech_fill_params<T1, T2, T3>(par, P, a.theta_d, a.dz, tid - 128, ECH_THREADS - 128);
-  }
-  ECH_STAMP(1);
-  __syncthreads();
-  ECH_STAMP(2);
   if (role == 0 && active) {
     EchAcc<T1, T2, T3> acc;
     ech_zero_acc(acc);
     EchFwd<T1, T2, T3> F;
-    F.a0[0] = zf[0];
+    F.a0[0] = *reinterpret_cast<const f32x4 *>(zt + row * 16 + 4 * g);
     ech_disc_fwd<T1, T2, T3>(par, P, F, j, g);
     ech_disc_bwd<T1, T2, T3, false>(par, P, F, invB, nul1, nul2, nul3, 1.0f, stash, B, row, acc, j, g);
     ech_write_slot<T1, T2, T3>(slots + wave * D::SLOT, acc, F.out, 0.0f, j, g);
@@ -622,9 +617,7 @@ static __global__ __launch_bounds__(ECH_THREADS) void egm_disc_chain_kernel(EgmA
     const float part = ech_disc_gp<T1, T2, T3>(par, P, F, 10.0f, stash + 2 * B * D::SW, stash + 3 * B * D::SW, B, row, acc, j, g);
     ech_write_slot<T1, T2, T3>(slots + wave * D::SLOT, acc, 0.0f, part, j, g);
   }
-  ECH_STAMP(3);
   __syncthreads();
-  ECH_STAMP(4);
   // ---- parameter gradients: W_l += sum over the four passes of X^T D (rows = K), one 16x16 tile per wave and round
   const float c = ech_c();
   for (int tau = wave; tau < D::TILES; tau += ECH_WAVES) {
@@ -638,7 +631,7 @@ static __global__ __launch_bounds__(ECH_THREADS) void egm_disc_chain_kernel(EgmA
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int f = 16 * u + 4 * g + r;
-      e[r] = a.dz.w[l] + min(f, n_in - 1) * n_out + min(o, n_out - 1);
+      e[r] = dz.w[l] + min(f, n_in - 1) * n_out + min(o, n_out - 1);
       th[r] = a.theta_d[e[r]]; m0[r] = a.m_d[e[r]]; v0[r] = a.v_d[e[r]];
     }
     BGM_NO_HOIST();
@@ -659,7 +652,6 @@ static __global__ __launch_bounds__(ECH_THREADS) void egm_disc_chain_kernel(EgmA
       if (f < n_in && o < n_out) ech_adam(a, e[r], w[r], th[r], m0[r], v0[r]);
     }
   }
-  ECH_STAMP(5);
   // ---- vector parameters: fixed-order sums of the per-wave partials
   auto slot_sum = [&](int k) {
     float s = 0.0f;
@@ -676,17 +668,53 @@ static __global__ __launch_bounds__(ECH_THREADS) void egm_disc_chain_kernel(EgmA
     if (o < n_out) {
       const float gg = slot_sum(k), gb = slot_sum(D::SL + k);
       const float ga = par[(l == 0 ? P.ga0 : (l == 1 ? P.ga1 : P.ga2)) + o];
-      adam1(a.dz.gamma[l] + o, gg);
-      adam1(a.dz.beta[l] + o, gb);
-      adam1(a.dz.b[l] + o, ga * c * gb);        // du = dy gamma c on every pass: the bias gradient is the beta gradient scaled
+      adam1(dz.gamma[l] + o, gg);
+      adam1(dz.beta[l] + o, gb);
+      adam1(dz.b[l] + o, ga * c * gb);          // du = dy gamma c on every pass: the bias gradient is the beta gradient scaled
     }
   }
   // the output layer's vector and bias on another wave than the one that starts the loop above
-  if (tid >= 256 && tid < 256 + P.d3) adam1(a.dz.w[3] + tid - 256, slot_sum(2 * D::SL + tid - 256));
+  if (tid >= 256 && tid < 256 + P.d3) adam1(dz.w[3] + tid - 256, slot_sum(2 * D::SL + tid - 256));
   if (tid == 320) {
-    adam1(a.dz.b[3], 0.0f);                      // sum_b dLoss/dout_b = B / B - B / B
+    adam1(dz.b[3], 0.0f);                        // sum_b dLoss/dout_b = B / B - B / B
     const float dz_loss = slot_sum(2 * D::SL + 16 * T3) * invB, gp = slot_sum(2 * D::SL + 16 * T3 + 1) * invB;
     if (a.out) { a.out[0] = dz_loss; a.out[1] = dz_loss + 10.0f * gp; }
   }
+}
+
+template <int HT, int KT0, int T1, int T2, int T3, int NB>
+static __global__ __launch_bounds__(ECH_THREADS) void egm_disc_chain_kernel(EgmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float ech_lds[];
+  constexpr int B = 16 * NB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  const EchP P = ech_layout<T1, T2, T3>(a.dz);
+  const EchLds<T1, T2, T3> M(ech_lds, P, B);
+  ECH_STAMP(0);
+  const int role = wave >> 1, tile = wave & 1;
+  const int row = 16 * tile + j;
+  if (role == 0) {
+    if (tile < NB) {
+      f32x4 zf[1];
+      ech_encoder<HT, KT0>(a.theta_g, a.e, a.v + (long long)a.idx[row] * a.p, zf, j, g);
+      *reinterpret_cast<f32x4 *>(M.zt + row * 16 + 4 * g) = zf[0];
+    }
+  } else {
+    // the other six waves: the discriminator's parameter block, then pull the encoder's weights into this XCD's L2 ahead of
+    // the two waves that stream them
+    const float *w = a.theta_g + a.e.off;
+    const int n = a.e.woff[a.e.n_layers - 1] - a.e.off;
+    float sink = 0.0f;
+    for (int i = tid - 128; i < n; i += (ECH_THREADS - 128) * 8) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sink += w[min(i + (ECH_THREADS - 128) * k, n - 1)];
+    }
+    asm volatile("" ::"v"(sink));
+    ech_fill_params<T1, T2, T3>(M.par, P, a.theta_d, a.dz, tid - 128, ECH_THREADS - 128);
+  }
+  ECH_STAMP(1);
+  __syncthreads();
+  ECH_STAMP(2);
+  const EchDiscIo io{a.theta_d, a.m_d, a.v_d, a.grad_d, a.adam, a.apply, a.q, a.out, a.z, a.eps};
+  ech_disc_tail<T1, T2, T3, NB>(io, a.dz, P, M, tid);
   ECH_STAMP(6);
 }

@@ -53,8 +53,12 @@ eng.theta_step(z, idx, x, y, v, 1e-4, 1, 0)
 tt = timed(lambda: eng.theta_step(z, idx, x, y, v, 1e-4, 1, 0), 50)
 tz = timed(lambda: eng.z_step(x, y, v, z, zm, zv, idx, 1e-4, 1, 1), 50)
 print("fit minibatch (B=32): theta step %.0f us, latent step %.0f us -> %.1f s per epoch of N=20000" % (1e6 * tt, 1e6 * tz, (tt + tz) * 625))
-from oracle import egm as OE
-dz = OE.init_disc(np.random.RandomState(0), 10, [64, 32, 8])
+_rs = np.random.RandomState(0)
+_dd = [10, 64, 32, 8, 1]
+dz = {"W": [_rs.uniform(-1, 1, (_dd[i], _dd[i + 1])).astype(np.float32) * np.float32(np.sqrt(6.0 / (_dd[i] + _dd[i + 1]))) for i in range(4)],
+      "b": [np.zeros(d, np.float32) for d in _dd[1:]], "gamma": [np.ones(d, np.float32) for d in _dd[1:-1]],
+      "beta": [np.zeros(d, np.float32) for d in _dd[1:-1]]}
+eng.set_disc_norm("fixed")      # the models' default
 eng.egm_begin(dz, 32, 2e-4, 1)
 zp = torch.randn(32, 10, device=dev)
 eng.egm_disc_step(zp, idx, v, 0.3, 1, 0); eng.egm_gen_step(zp, idx, v, x, y, 1, 1)

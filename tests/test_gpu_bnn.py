@@ -244,9 +244,10 @@ def test_evaluate_matches_oracle(binary, p):
     eng.close()
 
 
-@pytest.mark.parametrize("binary", [False, True])
-def test_egm_steps_match_oracle(binary):
-    """EGM warm-start steps with Bayesian nets: gradients of the discriminator step and of the nine-call generator step."""
+@pytest.mark.parametrize("binary,disc_norm", [(False, "batch"), (True, "batch"), (False, "fixed"), (True, "fixed")])
+def test_egm_steps_match_oracle(binary, disc_norm):
+    """EGM warm-start steps with Bayesian nets: gradients of the discriminator step and of the nine-call generator step.
+    disc_norm = "fixed" (the models' default): the discriminator passes of the step run as register-chained row tiles."""
     from oracle import egm as OE
     from bayesgm_amd.engine import CausalEngine
     m = _model(binary, p=50)
@@ -261,6 +262,9 @@ def test_egm_steps_match_oracle(binary):
     eng = _engine(m)
     dev = eng.device
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    if disc_norm == "fixed":
+        eng.set_disc_norm("fixed")
+        dz["fixed_norm"] = True
     eng.egm_begin(dz, B, 2e-4, 1)
     z = rs.standard_normal((B, q)).astype(np.float32)
     idx = rs.choice(n, B, replace=False).astype(np.int32)
