@@ -397,9 +397,10 @@ __device__ __forceinline__ void ecg_disc_dx(const float *par, const EchP &P, con
   ech_dense<T1, 1, true>(par + P.T0, P.lt0, nullptr, P.d1, P.d0, du1, dx, j, g);
 }
 
-// LDS words behind the parameter block: per-wave loss partials [8 x 16] | flag | z_ tiles [B x 16] | dz tiles [B x 16]
+// LDS words behind the parameter block: per-wave loss partials [8 x 16] | flags [16] | z_ tiles | head-input gradient tiles | head
+// contribution to dLoss/dz_  (each [B x 16])
 template <int T1, int T2, int T3>
-__host__ __device__ inline int ecg_lds_floats(const EgmDisc &d, int B) { return 64 + ech_layout<T1, T2, T3>(d).total + 8 * 16 + 16 + 2 * 16 * B; }
+__host__ __device__ inline int ecg_lds_floats(const EgmDisc &d, int B) { return 64 + ech_layout<T1, T2, T3>(d).total + 8 * 16 + 16 + 3 * 16 * B; }
 
 // ---------------------------------------------------------------------------------------------
 // the step
@@ -413,10 +414,12 @@ static __global__ __launch_bounds__(ECH_THREADS) void egm_gen_chain_kernel(EgmAr
   const EchP P = ech_layout<T1, T2, T3>(a.dz);
   float *par = ech_lds + 64;
   float *part = par + P.total;                 // [8 waves][16] loss partial sums
-  volatile int *flag = reinterpret_cast<volatile int *>(part + 8 * 16);
+  volatile int *flag = reinterpret_cast<volatile int *>(part + 8 * 16);   // [0]: parameter block filled (counts 4 waves); [2 + tile]: z_ of
+                                                                          // the tile written; [4 + tile]: head contribution to dz written
   float *zt = part + 8 * 16 + 16;              // z_ of chain B, [B x 16]
-  float *dzt = zt + 16 * B;                    // dLoss/d hin of chain B, [B x 16]
-  if (tid == 0) *flag = 0;
+  float *dzt = zt + 16 * B;                    // dLoss/d hin, [B x 16] (lane permutation scratch of the head waves)
+  float *dzh = dzt + 16 * B;                   // dLoss/dz_ through D, f and h, [B x 16]
+  if (tid < 16) flag[tid] = 0;
   __syncthreads();
   ECH_STAMP(0);
   const int role = wave >> 1, tile = wave & 1;
@@ -478,15 +481,26 @@ static __global__ __launch_bounds__(ECH_THREADS) void egm_gen_chain_kernel(EgmAr
     const float xv = a.x[prow], yv = a.y[prow];
     const float *vrow = a.v + prow * p;
     f32x4 vin[NTL];
+    if ((p & 3) == 0 && (reinterpret_cast<unsigned long long>(vrow) & 15ull) == 0) {      // one 16-byte request per tile and lane
 #pragma unroll
-    for (int t = 0; t < NTL; ++t)
+      for (int t = 0; t < NTL; ++t) {
+        const int f = 16 * t + 4 * g;
+        const f32x4 x = *reinterpret_cast<const f32x4 *>(vrow + min(f, p - 4));
+        vin[t] = f < p ? x : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      }
+    } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) vin[t][r] = ech_ld(vrow, 16 * t + 4 * g + r, p);
+      for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vin[t][r] = ech_ld(vrow, 16 * t + 4 * g + r, p);
+    }
     ecg_put<NTL>(ws + tab.x[ECG_PASS_E1][0], row, g, vin);
     f32x4 ze[1];
     ecg_e_fwd<HT, NTL>(th, a.e, tab.x[ECG_PASS_E1], ws, row, vin, ze, j, g);
     ECH_STAMP(1);
     *reinterpret_cast<f32x4 *>(zt + row * 16 + 4 * g) = ze[0];
+    __threadfence_block();
+    if (lane == 0) flag[2 + tile] = 1;         // waves 4,5 take D, f and h from here
     f32x4 dz[1];                               // dLoss/dz_ accumulates here
     {
       f32x4 gv[NTL];
@@ -506,9 +520,40 @@ static __global__ __launch_bounds__(ECH_THREADS) void egm_gen_chain_kernel(EgmAr
       ecg_g_bwd<HT, NTL, true>(tT, a.g, tab.x[ECG_PASS_G2], tab.d[ECG_PASS_G2], ws, row, gv, dz, j, g);
     }
     ECH_STAMP(2);
-    // ---- adversarial term through the fixed discriminator (its parameter block is filled by waves 4..7)
-    while (*flag < 4) __builtin_amdgcn_s_sleep(2);
+    // D, f, h ran on waves 4,5 meanwhile: add their part of dLoss/dz_
+    while (flag[4 + tile] == 0) __builtin_amdgcn_s_sleep(2);
     __threadfence_block();
+    dz[0] += *reinterpret_cast<const f32x4 *>(dzh + row * 16 + 4 * g);
+    ECH_STAMP(3);
+    f32x4 dnone[NTL];
+    ecg_e_bwd<HT, NTL, false>(tT, a.e, tab.x[ECG_PASS_E1], tab.d[ECG_PASS_E1], ws, row, dz, dnone, j, g);
+  } else if (role >= 2) {
+    // ================= waves 4..7: the discriminator's parameter block; pull the generator-side weights into this XCD's L2 (waves
+    // 4,5 the forward arrays, 6,7 the transposed mirror); then waves 4,5 take D, f and h of chain B as soon as its z_ exists ======
+    ech_fill_params<T1, T2, T3>(par, P, a.theta_d, a.dz, tid - 256, 256);
+    __threadfence_block();
+    if (lane == 0) atomicAdd(const_cast<int *>(flag), 1);
+    {
+      float sink = 0.0f;
+      const int n4 = tab.n_warm >> 2;                         // both arrays start 16-byte aligned
+      const f32x4 *src = reinterpret_cast<const f32x4 *>(role == 2 ? th : tT);
+      for (int i = (tid & 127); i < n4; i += 128 * 16) {
+        f32x4 acc4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc4 += src[min(i + 128 * k, n4 - 1)];
+        sink += acc4[0] + acc4[1] + acc4[2] + acc4[3];
+      }
+      asm volatile("" ::"v"(sink));
+    }
+    if (role == 2 && active) {
+      const long long prow = a.idx[row];
+      const float xv = a.x[prow], yv = a.y[prow];
+      while (flag[0] < 4) __builtin_amdgcn_s_sleep(2);
+      while (flag[2 + tile] == 0) __builtin_amdgcn_s_sleep(2);
+      __threadfence_block();
+      f32x4 ze[1], dz[1];
+      ze[0] = *reinterpret_cast<const f32x4 *>(zt + row * 16 + 4 * g);
+    // ---- adversarial term through the fixed discriminator
     {
       EchFwd<T1, T2, T3> F;
       F.a0[0] = ze[0];
@@ -516,7 +561,7 @@ static __global__ __launch_bounds__(ECH_THREADS) void egm_gen_chain_kernel(EgmAr
       ls[7] = -F.out;
       f32x4 dd[1];
       ecg_disc_dx<T1, T2, T3>(par, P, F, -invB, dd, j, g);
-      dz[0] += dd[0];
+      dz[0] = dd[0];
     }
     // ---- f(z0, z1, x) -> y
     {
@@ -588,27 +633,10 @@ static __global__ __launch_bounds__(ECH_THREADS) void egm_gen_chain_kernel(EgmAr
         dz[0][r] += (f < z0 || (f >= z0 + z1 && f < z0 + z1 + z2)) ? t : 0.0f;
       }
     }
-    ECH_STAMP(3);
-    f32x4 dnone[NTL];
-    ecg_e_bwd<HT, NTL, false>(tT, a.e, tab.x[ECG_PASS_E1], tab.d[ECG_PASS_E1], ws, row, dz, dnone, j, g);
-  } else if (role >= 2) {
-    // ================= waves 4..7: discriminator parameter block, then pull the generator-side weights into this XCD's L2 ====
-    ech_fill_params<T1, T2, T3>(par, P, a.theta_d, a.dz, tid - 256, 256);
-    __threadfence_block();
-    if (lane == 0) atomicAdd(const_cast<int *>(flag), 1);
-    float sink = 0.0f;
-    const int n4 = tab.n_warm >> 2;                         // both arrays start 16-byte aligned
-#pragma unroll
-    for (int arr = 0; arr < 2; ++arr) {
-      const f32x4 *src = reinterpret_cast<const f32x4 *>(arr == 0 ? th : tT);
-      for (int i = tid - 256; i < n4; i += 256 * 16) {
-        f32x4 acc4 = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int k = 0; k < 16; ++k) acc4 += src[min(i + 256 * k, n4 - 1)];
-        sink += acc4[0] + acc4[1] + acc4[2] + acc4[3];
-      }
+      *reinterpret_cast<f32x4 *>(dzh + row * 16 + 4 * g) = dz[0];
+      __threadfence_block();
+      if (lane == 0) flag[4 + tile] = 1;
     }
-    asm volatile("" ::"v"(sink));
   }
   // per-row loss terms -> per-wave sums (lane j = 15 of group 0 holds the totals)
 #pragma unroll
@@ -623,7 +651,7 @@ static __global__ __launch_bounds__(ECH_THREADS) void egm_gen_chain_kernel(EgmAr
   if (tid == 0 && a.out) {
     float s[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { s[k] = 0.0f; for (int w = 0; w < 4; ++w) if ((w & 1) < NB) s[k] += part[w * 16 + k]; }
+    for (int k = 0; k < 8; ++k) { s[k] = 0.0f; for (int w = 0; w < 6; ++w) if ((w & 1) < NB) s[k] += part[w * 16 + k]; }
     const float l_v = s[0] / (float)(B * p), l_z = s[1] / (float)(B * q), l_x = s[2] * invB, l_y = s[3] * invB;
     const float sig = (s[4] + s[5] + s[6]) * invB, adv = s[7] * invB;
     a.out[0] = adv; a.out[1] = l_v; a.out[2] = l_z; a.out[3] = l_x; a.out[4] = l_y;
