@@ -123,7 +123,13 @@ extern "C" int bgm_bnn_egm_disc_step(bgm_handle *h, const float *z_dev, const in
                        d.dims[3] >= 1 && d.dims[3] <= 16 && (a.B == 16 || a.B == 32) && !std::getenv("BGM_EGM_NO_CHAIN");
     const size_t bytes = chain ? sizeof(float) * (size_t)ech_disc_lds_floats<4, 2, 1>(d, a.B) : 0;
     if (chain && bytes <= 160 * 1024) {
-      auto kc = a.B == 32 ? bnn_egm_disc_chain_kernel<4, 2, 1, 2> : bnn_egm_disc_chain_kernel<4, 2, 1, 1>;
+      // the Flipout encoder as a row-tile chain when its shape is a compiled one
+      const BnnNet &E = a.net[BNN_E];
+      bool ech = E.bn_fixed == 1 && !E.heads && E.n_layers >= 2 && E.dims[E.n_layers] == a.q && a.q <= 16 && !std::getenv("BGM_EGM_NO_CHAIN_BNN");
+      for (int l = 1; l < E.n_layers; ++l) ech = ech && E.dims[l] == 64;
+      const int ntl = ech ? (a.p + 15) / 16 : 0;
+      auto kc = a.B == 32 ? (ntl == 13 ? bnn_egm_disc_chain_kernel<13, 4, 2, 1, 2> : ntl == 7 ? bnn_egm_disc_chain_kernel<7, 4, 2, 1, 2> : bnn_egm_disc_chain_kernel<0, 4, 2, 1, 2>)
+                          : (ntl == 13 ? bnn_egm_disc_chain_kernel<13, 4, 2, 1, 1> : ntl == 7 ? bnn_egm_disc_chain_kernel<7, 4, 2, 1, 1> : bnn_egm_disc_chain_kernel<0, 4, 2, 1, 1>);
       BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
       hipLaunchKernelGGL(kc, dim3(1), dim3(EGM_THREADS), bytes, (hipStream_t)stream_, a);
       BGM_HIP_CHECK(hipGetLastError());

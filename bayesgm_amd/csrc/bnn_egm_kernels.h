@@ -10,6 +10,7 @@
 #include "bnn_kernels.h"
 #include "egm_kernels.h"
 #include "egm_chain.h"
+#include "egm_chain_bnn.h"
 
 static_assert(BNN_THREADS == EGM_THREADS, "the Flipout and discriminator routines share one workgroup");
 
@@ -74,7 +75,9 @@ static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_disc_step_kernel(B
 // train_disc_step with the discriminator passes as register-chained row tiles (egm_chain.h; inference-mode normalisation, the
 // default layer shapes, B = 16 / 32): the noisy encoder call stays on the Flipout routines, its output z_ is laid out as row
 // tiles in LDS, and the three discriminator passes, the gradient GEMMs and Adam are ech_disc_tail.
-template <int T1, int T2, int T3, int NB>
+// NTL > 0: the Flipout encoder runs as a row-tile chain too (egm_chain_bnn.h: inference-mode input normalisation, 64-wide hidden
+// layers, ceil(p / 16) = NTL); NTL = 0: it stays on the phase-machine routines.
+template <int NTL, int T1, int T2, int T3, int NB>
 static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_disc_chain_kernel(BnnEgmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float egm_lds[];
   BnnCtx cb{(int)threadIdx.x, egm_lds};
@@ -82,16 +85,33 @@ static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_disc_chain_kernel(
   float *wp = a.ws;
   auto take = [&](int n) { float *r = wp; wp += (n + 3) & ~3; return r; };
   float *vb = take(B * p);
-  for (int k = tid; k < B * p; k += EGM_THREADS) { const int b = k / p; vb[k] = a.v_[(long long)a.idx[b] * p + (k - b * p)]; }
-  __syncthreads();
-  BnnCache ke;
-  bnn_cache(a.net[BNN_E], B, wp, ke, vb);
-  const float *z_ = bnn_fwd(cb, a.theta, a.net[BNN_E], ke, B, a.k0, a.k1, a.stream);     // noisy encoder call (fixed in this step)
   const EchP P = ech_layout<T1, T2, T3>(a.dz);
   const EchLds<T1, T2, T3> M(egm_lds, P, B);
-  for (int k = tid; k < 16 * B; k += EGM_THREADS) { const int b = k >> 4, i = k & 15; const float t = z_[b * q + min(i, q - 1)]; M.zt[k] = i < q ? t : 0.0f; }
-  ech_fill_params<T1, T2, T3>(M.par, P, a.theta_d, a.dz, tid, EGM_THREADS);
-  __syncthreads();
+  if constexpr (NTL > 0) {
+    BnnCache ke;
+    bnn_cache(a.net[BNN_E], B, wp, ke, vb);
+    bnn_noise(cb, a.theta, a.net[BNN_E], ke, B, a.k0, a.k1, a.stream);       // eps, dW = sigma * eps, sign words of the call
+    ech_fill_params<T1, T2, T3>(M.par, P, a.theta_d, a.dz, tid, EGM_THREADS);
+    __threadfence();
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+    if (wave < NB) {
+      const int row = 16 * wave + j;
+      f32x4 zf[1];
+      ecb_encoder<4, NTL>(a.theta, a.net[BNN_E], ke.dW, ke.sg + (long long)row * a.net[BNN_E].swords, a.v_ + (long long)a.idx[row] * p, zf, j, g);
+      *reinterpret_cast<f32x4 *>(M.zt + row * 16 + 4 * g) = zf[0];
+    }
+    __syncthreads();
+  } else {
+    for (int k = tid; k < B * p; k += EGM_THREADS) { const int b = k / p; vb[k] = a.v_[(long long)a.idx[b] * p + (k - b * p)]; }
+    __syncthreads();
+    BnnCache ke;
+    bnn_cache(a.net[BNN_E], B, wp, ke, vb);
+    const float *z_ = bnn_fwd(cb, a.theta, a.net[BNN_E], ke, B, a.k0, a.k1, a.stream);     // noisy encoder call (fixed in this step)
+    for (int k = tid; k < 16 * B; k += EGM_THREADS) { const int b = k >> 4, i = k & 15; const float t = z_[b * q + min(i, q - 1)]; M.zt[k] = i < q ? t : 0.0f; }
+    ech_fill_params<T1, T2, T3>(M.par, P, a.theta_d, a.dz, tid, EGM_THREADS);
+    __syncthreads();
+  }
   const EchDiscIo io{a.theta_d, a.m_d, a.v_d, a.grad_d, a.adam, a.apply, q, a.out, a.z, a.eps};
   ech_disc_tail<T1, T2, T3, NB>(io, a.dz, P, M, tid);
 }

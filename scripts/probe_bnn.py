@@ -12,7 +12,7 @@ p = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 z_dims = [1, 1, 1, 7]
 m = OB.init_model(0, z_dims, p, False)
-eng = BnnEngine(p, z_dims, False, max_batch=64)
+eng = BnnEngine(p, z_dims, False, max_batch=64, norm_mode=1)      # inference-mode input normalisation, the models' default
 eng.begin(m)
 dev = eng.device
 g = torch.Generator(device=dev); g.manual_seed(0)

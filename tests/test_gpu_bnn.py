@@ -244,13 +244,15 @@ def test_evaluate_matches_oracle(binary, p):
     eng.close()
 
 
-@pytest.mark.parametrize("binary,disc_norm", [(False, "batch"), (True, "batch"), (False, "fixed"), (True, "fixed")])
-def test_egm_steps_match_oracle(binary, disc_norm):
+@pytest.mark.parametrize("binary,disc_norm,p", [(False, "batch", 50), (True, "batch", 50), (False, "fixed", 50), (True, "fixed", 50),
+                                                (False, "fixed", 100), (True, "fixed", 200)])
+def test_egm_steps_match_oracle(binary, disc_norm, p):
     """EGM warm-start steps with Bayesian nets: gradients of the discriminator step and of the nine-call generator step.
-    disc_norm = "fixed" (the models' default): the discriminator passes of the step run as register-chained row tiles."""
+    disc_norm = "fixed" (the models' default): the discriminator passes of the step run as register-chained row tiles; at
+    p = 100 / 200 (with the inference-mode input normalisation of `_model`, when it has it) so does the Flipout encoder call."""
     from oracle import egm as OE
     from bayesgm_amd.engine import CausalEngine
-    m = _model(binary, p=50)
+    m = _model(binary, p=p)
     n, B = 120, 32
     _, x, y, v = _panel(m, n)
     q = sum(m["z_dims"])
@@ -259,7 +261,10 @@ def test_egm_steps_match_oracle(binary, disc_norm):
     for l in range(3):
         dz["gamma"][l] = (1.0 + 0.2 * rs.standard_normal(dz["gamma"][l].shape)).astype(np.float32)
         dz["beta"][l] = (0.1 * rs.standard_normal(dz["beta"][l].shape)).astype(np.float32)
-    eng = _engine(m)
+    if p >= 100:          # the models' default input normalisation as well (bnn_norm = "fixed")
+        for k in ("g", "e", "f", "h"):
+            m[k]["norm"] = "fixed"
+    eng = _engine(m, norm_mode=1) if p >= 100 else _engine(m)
     dev = eng.device
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     if disc_norm == "fixed":
