@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "bgm_host.h"
 #include "bnn_egm_kernels.h"
@@ -17,12 +18,20 @@ struct BnnEgmState {
   int lds_bytes = 0;
   long long t_g = 0, t_d = 0;
   float *dev = nullptr;      // m | v (EGM Adam slots of the Bayesian nets) | theta_d | m_d | v_d | grad_d | ws
+  // generator step as row-tile chains (egm_chain_bnn.h)
+  int chain_gen_lds = 0, chain_ntl = 0, n_tiles = 0;
+  EcbTab *tab_dev = nullptr;
+  int *tiles_dev = nullptr;
+  float *thetaT_dev = nullptr;
 };
 
 void bgm_bnn_egm_free(void *p) {
   BnnEgmState *e = static_cast<BnnEgmState *>(p);
   if (!e) return;
   if (e->dev) hipFree(e->dev);
+  if (e->tab_dev) hipFree(e->tab_dev);
+  if (e->tiles_dev) hipFree(e->tiles_dev);
+  if (e->thetaT_dev) hipFree(e->thetaT_dev);
   delete e;
 }
 
@@ -77,7 +86,75 @@ extern "C" int bgm_bnn_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, const
   auto cache_floats = [&](const BnnNet &n) {
     return (size_t)B * n.dims[0] + n.dims[0] + 2 * (size_t)B * n.hoff[n.n_layers + 1] + 2 * (size_t)n.eoff[n.n_layers] + (size_t)B * n.swords + 64;
   };
-  e->ws_floats = 3 * cache_floats(s->net[BNN_G]) + 2 * cache_floats(s->net[BNN_E]) + 2 * cache_floats(s->net[BNN_F]) +
+  size_t gen_ws = 0;
+  EcbTab tab{};
+  std::vector<int> tiles;
+  {
+    const int ntl = (s->p + 1 + 15) / 16;
+    bool chain = d.fixed_norm && L == 3 && d.dims[0] <= 16 && (d.dims[1] + 15) / 16 == 4 && (d.dims[2] + 15) / 16 == 2 && d.dims[3] >= 1 &&
+                 d.dims[3] <= 16 && (B == 16 || B == 32) && (ntl == 13 || ntl == 7) && s->q <= 16 && !std::getenv("BGM_EGM_NO_CHAIN_GEN");
+    for (int k = 0; k < 4; ++k) chain = chain && s->net[k].bn_fixed == 1 && !s->net[k].heads && !s->net[k].mv;
+    const BnnNet &G = s->net[BNN_G], &E = s->net[BNN_E];
+    chain = chain && G.n_layers >= 3 && E.n_layers >= 3 && G.dims[0] == s->q && E.dims[E.n_layers] == s->q && G.dims[G.n_layers] == s->p + 1 &&
+            E.dims[0] == s->p;
+    for (int l = 1; l < G.n_layers; ++l) chain = chain && G.dims[l] == 64;
+    for (int l = 1; l < E.n_layers; ++l) chain = chain && E.dims[l] == 64;
+    for (int k : {BNN_F, BNN_H}) {
+      const BnnNet &m = s->net[k];
+      chain = chain && m.n_layers == 4 && m.dims[0] <= 16 && m.dims[1] == 64 && m.dims[2] == 32 && m.dims[3] >= 1 && m.dims[3] <= 16 &&
+              m.dims[4] >= 1 && m.dims[4] <= 16;
+    }
+    if (chain) {
+      auto tl = [](int n) { return (n + 15) / 16; };
+      const int call_net[ECB_CALLS] = {BNN_G, BNN_G, BNN_E, BNN_E, BNN_G, BNN_F, BNN_F, BNN_H, BNN_H};
+      size_t off = 0;
+      auto take = [&](size_t n) { const size_t r = off; off += (n + 3) / 4 * 4; return (int)r; };
+      const int NBt = B / 16;
+      for (int k = 0; k < 4; ++k) { tab.net_ncalls[k] = 0; tab.kt0[k] = k == BNN_E ? ntl : 1; }
+      int xw[ECB_CALLS][BNN_MAX_LAYERS], dw[ECB_CALLS][BNN_MAX_LAYERS];
+      for (int c = 0; c < ECB_CALLS; ++c) {
+        const BnnNet &m = s->net[call_net[c]];
+        EcbCall &C = tab.c[c];
+        C.net = call_net[c];
+        tab.net_calls[C.net][tab.net_ncalls[C.net]++] = c;
+        const size_t E_ = (size_t)m.eoff[m.n_layers];
+        C.eps = take(E_); C.dW = take(E_); C.dWT = take(E_);
+        C.sg = take((size_t)B * m.swords);
+        const int kt0 = tab.kt0[C.net];
+        C.xh = take((size_t)B * 16 * kt0);
+        C.bnp = take((size_t)NBt * 2 * 16 * kt0);
+        for (int l = 0; l < m.n_layers; ++l) {
+          xw[c][l] = 16 * tl(m.dims[l]); dw[c][l] = 16 * tl(m.dims[l + 1]);
+          if (C.net == BNN_E && l == 0) xw[c][l] = 16 * ntl;
+          if (C.net == BNN_G && l == m.n_layers - 1) dw[c][l] = 16 * ntl;
+          C.x[l] = take((size_t)B * xw[c][l]); C.xs[l] = take((size_t)B * xw[c][l]);
+          C.d[l] = take((size_t)B * dw[c][l]); C.ds[l] = take((size_t)B * dw[c][l]);
+        }
+      }
+      gen_ws = off;
+      for (int k = 0; k < 4; ++k) {
+        const BnnNet &m = s->net[k];
+        for (int l = 0; l < m.n_layers; ++l) {
+          const int ni = m.dims[l], no = m.dims[l + 1], c0 = tab.net_calls[k][0];
+          for (int u = 0; u < tl(ni); ++u)
+            for (int v = 0; v < tl(no); ++v) {
+              int en[ECB_TILE_INTS] = {m.woff[l], ni, no, u, v, xw[c0][l], dw[c0][l], tab.net_ncalls[k]};
+              for (int c = 0; c < tab.net_ncalls[k]; ++c) {
+                const EcbCall &C = tab.c[tab.net_calls[k][c]];
+                en[8 + 5 * c] = C.x[l]; en[9 + 5 * c] = C.xs[l]; en[10 + 5 * c] = C.d[l]; en[11 + 5 * c] = C.ds[l]; en[12 + 5 * c] = C.eps + m.eoff[l];
+              }
+              tiles.insert(tiles.end(), en, en + ECB_TILE_INTS);
+            }
+        }
+      }
+      tab.n_tiles = (int)(tiles.size() / ECB_TILE_INTS);
+      tab.n_warm = s->n_params;
+      e->chain_ntl = ntl;
+      e->n_tiles = tab.n_tiles;
+      e->chain_gen_lds = (int)(sizeof(float) * (size_t)ecb_lds_floats<4, 2, 1>(d, B));
+    }
+  }
+  e->ws_floats = gen_ws + 3 * cache_floats(s->net[BNN_G]) + 2 * cache_floats(s->net[BNN_E]) + 2 * cache_floats(s->net[BNN_F]) +
                  2 * cache_floats(s->net[BNN_H]) + (size_t)B * (4 * (size_t)s->p + 32 * (size_t)wmax + 256) + 4 * cache + e->n_dz + arena + 8192;
   const size_t np = ((size_t)s->n_params + 63) & ~(size_t)63, nd = (e->n_dz + 63) & ~(size_t)63;
   const size_t total = 2 * np + 4 * nd + e->ws_floats + 64;
@@ -88,6 +165,25 @@ extern "C" int bgm_bnn_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, const
   a.theta_d = e->dev + 2 * np; a.m_d = a.theta_d + nd; a.v_d = a.m_d + nd; a.grad_d = a.v_d + nd;
   a.ws = a.grad_d + nd;
   BGM_HIP_CHECK(hipMemcpy(a.theta_d, theta_dz_host, e->n_dz * sizeof(float), hipMemcpyHostToDevice));
+  if (e->chain_gen_lds > 0) {
+    // transposed mirror of every `loc` (the backward chains read W^T rows contiguously); the gradient kernel's Adam keeps it current
+    std::vector<float> th(s->n_params), tT(s->n_params, 0.0f);
+    BGM_HIP_CHECK(hipMemcpy(th.data(), s->theta_dev, sizeof(float) * s->n_params, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 4; ++k) {
+      const BnnNet &m = s->net[k];
+      for (int l = 0; l < m.n_layers; ++l) {
+        const int ni = m.lin[l], no = m.lout[l];
+        for (int f = 0; f < ni; ++f)
+          for (int o2 = 0; o2 < no; ++o2) tT[m.woff[l] + (size_t)o2 * ni + f] = th[m.woff[l] + (size_t)f * no + o2];
+      }
+    }
+    BGM_HIP_CHECK(hipMalloc((void **)&e->thetaT_dev, sizeof(float) * s->n_params));
+    BGM_HIP_CHECK(hipMemcpy(e->thetaT_dev, tT.data(), sizeof(float) * s->n_params, hipMemcpyHostToDevice));
+    BGM_HIP_CHECK(hipMalloc((void **)&e->tab_dev, sizeof(EcbTab)));
+    BGM_HIP_CHECK(hipMemcpy(e->tab_dev, &tab, sizeof(EcbTab), hipMemcpyHostToDevice));
+    BGM_HIP_CHECK(hipMalloc((void **)&e->tiles_dev, sizeof(int) * tiles.size()));
+    BGM_HIP_CHECK(hipMemcpy(e->tiles_dev, tiles.data(), sizeof(int) * tiles.size(), hipMemcpyHostToDevice));
+  }
   return BGM_OK;
 }
 
@@ -155,6 +251,18 @@ extern "C" int bgm_bnn_egm_gen_step(bgm_handle *h, const float *z_dev, const int
   a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32); a.stream = stream_id;
   if (apply) { e->t_g += 1; s->packed_valid = false; }
   a.adam = bnn_egm_adam(e->cfg.lr, std::max<long long>(1, e->t_g));
+  if (e->chain_gen_lds > 0) {
+    auto kc = a.B == 32 ? (e->chain_ntl == 13 ? bnn_egm_gen_chain_kernel<13, 2> : bnn_egm_gen_chain_kernel<7, 2>)
+                        : (e->chain_ntl == 13 ? bnn_egm_gen_chain_kernel<13, 1> : bnn_egm_gen_chain_kernel<7, 1>);
+    BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, e->chain_gen_lds));
+    hipLaunchKernelGGL(kc, dim3(1), dim3(EGM_THREADS), e->chain_gen_lds, (hipStream_t)stream_, a, e->tab_dev, e->thetaT_dev);
+    BGM_HIP_CHECK(hipGetLastError());
+    auto kd = a.B == 32 ? bnn_egm_gen_dw_kernel<2> : bnn_egm_gen_dw_kernel<1>;
+    hipLaunchKernelGGL(kd, dim3((e->n_tiles + ECH_WAVES - 1) / ECH_WAVES + 1), dim3(EGM_THREADS), 0, (hipStream_t)stream_, a, e->tab_dev, e->tiles_dev,
+                       e->thetaT_dev);
+    BGM_HIP_CHECK(hipGetLastError());
+    return BGM_OK;
+  }
   auto k = bnn_egm_gen_step_kernel;
   const int lds = 64 * (int)sizeof(float);
   hipLaunchKernelGGL(k, dim3(1), dim3(EGM_THREADS), lds, (hipStream_t)stream_, a);

@@ -249,3 +249,14 @@ static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_gen_step_kernel(Bn
     a.out[5] = adv + (l_v + zrec * l_z) + (l_x + l_y) + 0.001f * sig;
   }
 }
+
+// train_gen_step as row-tile chains (egm_chain_bnn.h) + its gradient / Adam launch
+template <int NTL, int NB>
+static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_gen_chain_kernel(BnnEgmArgs a, const EcbTab *tab, float *thetaT) {
+  extern __shared__ __attribute__((aligned(16))) float egm_lds[];
+  ecb_gen_chain<BnnEgmArgs, 4, NTL, 4, 2, 1, NB>(a, *tab, thetaT, egm_lds);
+}
+template <int NB>
+static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_gen_dw_kernel(BnnEgmArgs a, const EcbTab *tab, const int *tiles, float *thetaT) {
+  ecb_gen_dw<BnnEgmArgs, NB>(a, *tab, tiles, thetaT);
+}

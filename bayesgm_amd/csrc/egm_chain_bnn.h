@@ -93,3 +93,604 @@ __device__ __forceinline__ void ecb_encoder(const float *theta, const BnnNet &n,
     ecb_layer<HT, 1, 1, false, false>(loc, dW + n.eoff[L - 1], loc + 2 * H * q, q, H, q, roww, n.sout_w[L - 1], h, hs, z, A1, wl, Ad, j, g);
   }
 }
+
+// =============================================================================================
+// train_gen_step with Bayesian nets (nine Flipout calls: g x 3, e x 2, f x 2, h x 2; bnn_egm_gen_step_kernel) as row-tile chains
+// =============================================================================================
+#define ECB_CALLS 9
+#define ECB_TILE_INTS 24
+// call indices = noise streams of the step (oracle/bnn.py EGM_CALLS)
+enum { ECB_G1 = 0, ECB_G1S = 1, ECB_E1 = 2, ECB_E2 = 3, ECB_G2 = 4, ECB_F = 5, ECB_FS = 6, ECB_H = 7, ECB_HS = 8 };
+
+struct EcbCall {
+  int net;                               // BNN_G / BNN_E / BNN_F / BNN_H
+  int eps, dW, dWT;                      // workspace offsets (floats) of the call's noise: eps, sigma * eps, and its per-layer transpose
+  int sg;                                // sign words [B x swords]
+  int xh;                                // normalised input xhat [B x 16 KT0]
+  int bnp;                               // per-row-tile sums for the input normalisation's gamma / beta: [NB][2][16 KT0]
+  int x[BNN_MAX_LAYERS], xs[BNN_MAX_LAYERS], d[BNN_MAX_LAYERS], ds[BNN_MAX_LAYERS];    // layer inputs h, h * s_in; gradients cur, cur * s_out
+};
+struct EcbTab {
+  EcbCall c[ECB_CALLS];
+  int n_tiles;                           // weight-gradient tiles (tiles[] = [n_tiles][ECB_TILE_INTS])
+  int kt0[4];                            // input tiles of the four nets
+  int net_ncalls[4], net_calls[4][3];
+  int n_warm;
+};
+
+// eps, dW, dW^T and the sign words of one call (bnn_noise + the transpose the backward chains read)
+__device__ __forceinline__ void ecb_noise(const float *theta, const BnnNet &n, const EcbCall &C, float *ws, int B, uint32_t k0, uint32_t k1,
+                                          uint32_t stream, int tid) {
+  for (int l = 0; l < n.n_layers; ++l) {
+    const int in = n.lin[l], out = n.lout[l], cnt = in * out;
+    const float *rho = theta + n.woff[l] + cnt;
+    float *e = ws + C.eps + n.eoff[l], *d = ws + C.dW + n.eoff[l], *dt = ws + C.dWT + n.eoff[l];
+    for (int i = tid; i < (cnt + 3) >> 2; i += BNN_THREADS) {
+      const f32x4 z = box_muller4(philox4x32_10((uint32_t)i, (uint32_t)l | ((uint32_t)n.net_id << 16), stream, BNN_TAG_EPS, k0, k1));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = 4 * i + u;
+        if (idx < cnt) {
+          const float dv = (BNN_SCALE_EPS + softplus_acc(rho[idx])) * z[u];
+          const int f = idx / out, o = idx - f * out;
+          e[idx] = z[u]; d[idx] = dv; dt[o * in + f] = dv;
+        }
+      }
+    }
+  }
+  const int calls = n.swords >> 2;
+  uint32_t *sg = reinterpret_cast<uint32_t *>(ws + C.sg);
+  for (int i = tid; i < B * calls; i += BNN_THREADS) {
+    const int r = i / calls, cc = i - r * calls;
+    const uint4 w = philox4x32_10((uint32_t)r, (uint32_t)cc | ((uint32_t)n.net_id << 16), stream, BNN_TAG_SIGN, k0, k1);
+    uint32_t *dst = sg + (long long)r * n.swords + 4 * cc;
+    dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
+  }
+}
+
+// v = a W1 + flip(as W2) (+ bias): the Flipout product pair in either direction
+template <int KT, int NT>
+__device__ __forceinline__ void ecb_pair_wide(const float *W1, const float *W2, int ld, int n_in, int n_out, const uint32_t *roww, int flipw,
+                                              const f32x4 (&a)[KT], const f32x4 (&as)[KT], f32x4 (&v)[NT], int j, int g) {
+  f32x4 c2[NT], c2s[NT];
+  ecg_wide<KT, NT>(W1, ld, n_in, n_out, a, v, j, g);
+  ecg_wide<KT, NT>(W2, ld, n_in, n_out, as, c2, j, g);
+  ecb_flip<NT>(roww, flipw, g, c2, c2s);
+#pragma unroll
+  for (int u = 0; u < NT; ++u) v[u] += c2s[u];
+}
+template <int KT, int NT, bool CX>
+__device__ __forceinline__ void ecb_pair(const float *W1, const float *W2, int ld, int n_in, int n_out, const uint32_t *roww, int flipw,
+                                         const f32x4 (&a)[KT], const f32x4 (&as)[KT], f32x4 (&v)[NT], int j, int g) {
+  if constexpr (NT > 4) ecb_pair_wide<KT, NT>(W1, W2, ld, n_in, n_out, roww, flipw, a, as, v, j, g);
+  else {
+    const EcgW w1{W1, ld, n_in, n_out, 0}, w2{W2, ld, n_in, n_out, 0};
+    EcgA<NT> A, Ad, Ad2;
+    ecg_prime<NT, CX>(w1, A, j, g);
+    f32x4 c2[NT], c2s[NT];
+    ech_zero<NT>(v);
+    ech_zero<NT>(c2);
+    ecg_sub<KT, NT, NT, CX, CX>(w1, a, v, A, w2, Ad, j, g);
+    ecg_sub<KT, NT, NT, CX, CX>(w2, as, c2, Ad, w2, Ad2, j, g);
+    ecb_flip<NT>(roww, flipw, g, c2, c2s);
+#pragma unroll
+    for (int u = 0; u < NT; ++u) v[u] += c2s[u];
+  }
+}
+template <int NT>
+__device__ __forceinline__ void ecb_add_bias(const float *bias, int n, int g, f32x4 (&v)[NT]) { ecg_bias<NT>(bias, n, 0, g, v); }
+
+// Flipout MLP with hidden width 16 HT (g: KT0 = 1, NTO = output tiles; e: KT0 = input tiles, NTO = 1): forward with stash.
+// xraw: the raw input tiles (zero beyond dims[0]).
+template <int KT0, int HT, int NTO>
+__device__ __forceinline__ void ecb_mlp_fwd(const float *theta, const BnnNet &n, const EcbCall &C, float *ws, int row, const f32x4 (&xraw)[KT0],
+                                            f32x4 (&out)[NTO], int j, int g) {
+  constexpr int H = 16 * HT;
+  const int L = n.n_layers, d0 = n.dims[0], no = n.dims[L];
+  const uint32_t *roww = reinterpret_cast<const uint32_t *>(ws + C.sg) + (long long)row * n.swords;
+  const float *dW = ws + C.dW;
+  const float *gamma = theta + n.off, *beta = gamma + d0;
+  const float inv = 1.0f / sqrtf(1.0f + BNN_BN_EPS);
+  f32x4 xh[KT0], h0[KT0], hs0[KT0];
+#pragma unroll
+  for (int t = 0; t < KT0; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = 16 * t + 4 * g + r, fc = min(f, d0 - 1);
+      xh[t][r] = xraw[t][r] * inv;
+      h0[t][r] = f < d0 ? fmaf(xh[t][r], gamma[fc], beta[fc]) : 0.0f;
+    }
+  ecb_flip<KT0>(roww, n.sin_w[0], g, h0, hs0);
+  ecg_put<KT0>(ws + C.xh, row, g, xh);
+  ecg_put<KT0>(ws + C.x[0], row, g, h0);
+  ecg_put<KT0>(ws + C.xs[0], row, g, hs0);
+  f32x4 h[HT], hs[HT];
+  {
+    const float *loc = theta + n.woff[0];
+    ecb_pair<KT0, HT, true>(loc, dW + n.eoff[0], H, d0, H, roww, n.sout_w[0], h0, hs0, h, j, g);
+    ecb_add_bias<HT>(loc + 2 * d0 * H, H, g, h);
+    ecg_lrelu<HT>(h);
+    ecb_flip<HT>(roww, n.sin_w[1], g, h, hs);
+  }
+  if (L > 2) {
+    EcgA<HT> A, An;
+    ecg_prime<HT, true>(EcgW{theta + n.woff[1], H, H, H, 0}, A, j, g);
+    for (int l = 1; l < L - 1; ++l) {
+      BGM_NO_HOIST();
+      ecg_put<HT>(ws + C.x[l], row, g, h);
+      ecg_put<HT>(ws + C.xs[l], row, g, hs);
+      const float *loc = theta + n.woff[l];
+      const EcgW wn{theta + n.woff[min(l + 1, L - 2)], H, H, H, 0};
+      f32x4 v[HT];
+      ecb_layer<HT, HT, HT, true, true>(loc, dW + n.eoff[l], loc + 2 * H * H, H, H, H, roww, n.sout_w[l], h, hs, v, A, wn, An, j, g);
+      ecg_lrelu<HT>(v);
+#pragma unroll
+      for (int u = 0; u < HT; ++u) h[u] = v[u];
+      ecb_flip<HT>(roww, n.sin_w[l + 1], g, h, hs);
+      ecg_copy<HT>(A, An);
+    }
+  }
+  ecg_put<HT>(ws + C.x[L - 1], row, g, h);
+  ecg_put<HT>(ws + C.xs[L - 1], row, g, hs);
+  const float *loc = theta + n.woff[L - 1];
+  ecb_pair<HT, NTO, false>(loc, dW + n.eoff[L - 1], no, H, no, roww, n.sout_w[L - 1], h, hs, out, j, g);
+  ecb_add_bias<NTO>(loc + 2 * H * no, no, g, out);
+}
+
+// backward with stash.  dout: dLoss/d output (zero beyond n_out).  dxraw (WANT_DX): dLoss/d raw input.  The per-row products for the
+// input normalisation's gamma / beta are summed over the tile's rows into bnp [2][16 KT0] (this tile's slot).
+template <int KT0, int HT, int NTO, bool WANT_DX>
+__device__ __forceinline__ void ecb_mlp_bwd(const float *theta, const float *thetaT, const BnnNet &n, const EcbCall &C, float *ws, int row, int tile,
+                                            const f32x4 (&dout)[NTO], f32x4 (&dxraw)[KT0], int j, int g) {
+  constexpr int H = 16 * HT;
+  const int L = n.n_layers, d0 = n.dims[0], no = n.dims[L];
+  const uint32_t *roww = reinterpret_cast<const uint32_t *>(ws + C.sg) + (long long)row * n.swords;
+  const float *dWT = ws + C.dWT;
+  f32x4 dh[HT], dhs[HT], xl[HT];
+  {
+    f32x4 douts[NTO];
+    ecb_flip<NTO>(roww, n.sout_w[L - 1], g, dout, douts);
+    ecg_put<NTO>(ws + C.d[L - 1], row, g, dout);
+    ecg_put<NTO>(ws + C.ds[L - 1], row, g, douts);
+    ecb_pair<NTO, HT, true>(thetaT + n.woff[L - 1], dWT + n.eoff[L - 1], H, no, H, roww, n.sin_w[L - 1], dout, douts, dh, j, g);
+    ecg_get<HT>(ws + C.x[L - 1], row, g, xl);
+    ecg_mask<HT>(dh, xl);
+  }
+  for (int l = L - 2; l >= 1; --l) {
+    BGM_NO_HOIST();
+    ecb_flip<HT>(roww, n.sout_w[l], g, dh, dhs);
+    ecg_put<HT>(ws + C.d[l], row, g, dh);
+    ecg_put<HT>(ws + C.ds[l], row, g, dhs);
+    f32x4 d2[HT];
+    ecb_pair<HT, HT, true>(thetaT + n.woff[l], dWT + n.eoff[l], H, H, H, roww, n.sin_w[l], dh, dhs, d2, j, g);
+    ecg_get<HT>(ws + C.x[l], row, g, xl);
+    ecg_mask<HT>(d2, xl);
+#pragma unroll
+    for (int u = 0; u < HT; ++u) dh[u] = d2[u];
+  }
+  ecb_flip<HT>(roww, n.sout_w[0], g, dh, dhs);
+  ecg_put<HT>(ws + C.d[0], row, g, dh);
+  ecg_put<HT>(ws + C.ds[0], row, g, dhs);
+  f32x4 dh0[KT0], xh[KT0];
+  ecb_pair<HT, KT0, false>(thetaT + n.woff[0], dWT + n.eoff[0], d0, H, d0, roww, n.sin_w[0], dh, dhs, dh0, j, g);
+  ecg_get<KT0>(ws + C.xh, row, g, xh);
+  float *bnp = ws + C.bnp + tile * (2 * 16 * KT0);
+  const float *gamma = theta + n.off;
+  const float inv = 1.0f / sqrtf(1.0f + BNN_BN_EPS);
+#pragma unroll
+  for (int t = 0; t < KT0; ++t) {
+    f32x4 sg_, sb;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      sg_[r] = sum_over_j_to_lane15(dh0[t][r] * xh[t][r]);
+      sb[r] = sum_over_j_to_lane15(dh0[t][r]);
+      if (WANT_DX) dxraw[t][r] = inv * dh0[t][r] * ech_ld(gamma, 16 * t + 4 * g + r, d0);
+    }
+    if (j == 15) {
+      *reinterpret_cast<f32x4 *>(bnp + 16 * t + 4 * g) = sg_;
+      *reinterpret_cast<f32x4 *>(bnp + 16 * KT0 + 16 * t + 4 * g) = sb;
+    }
+  }
+}
+
+// head networks f, h: [in <= 16] -> 16 T1 -> 16 T2 -> 16 T3 -> [out <= 16]
+template <int T1, int T2, int T3>
+__device__ __forceinline__ void ecb_head_fwd(const float *theta, const BnnNet &n, const EcbCall &C, float *ws, int row, const f32x4 (&xraw)[1],
+                                             f32x4 (&out)[1], int j, int g) {
+  const int d0 = n.dims[0], d1 = n.dims[1], d2 = n.dims[2], d3 = n.dims[3], d4 = n.dims[4];
+  const uint32_t *roww = reinterpret_cast<const uint32_t *>(ws + C.sg) + (long long)row * n.swords;
+  const float *dW = ws + C.dW;
+  const float *gamma = theta + n.off, *beta = gamma + d0;
+  const float inv = 1.0f / sqrtf(1.0f + BNN_BN_EPS);
+  f32x4 xh[1], h0[1], hs0[1];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int f = 4 * g + r, fc = min(f, d0 - 1);
+    xh[0][r] = xraw[0][r] * inv;
+    h0[0][r] = f < d0 ? fmaf(xh[0][r], gamma[fc], beta[fc]) : 0.0f;
+  }
+  ecb_flip<1>(roww, n.sin_w[0], g, h0, hs0);
+  ecg_put<1>(ws + C.xh, row, g, xh);
+  ecg_put<1>(ws + C.x[0], row, g, h0);
+  ecg_put<1>(ws + C.xs[0], row, g, hs0);
+  f32x4 a1[T1], a1s[T1], a2[T2], a2s[T2], a3[T3], a3s[T3];
+  const float *l0 = theta + n.woff[0], *l1 = theta + n.woff[1], *l2 = theta + n.woff[2], *l3 = theta + n.woff[3];
+  ecb_pair<1, T1, true>(l0, dW + n.eoff[0], d1, d0, d1, roww, n.sout_w[0], h0, hs0, a1, j, g);
+  ecb_add_bias<T1>(l0 + 2 * d0 * d1, d1, g, a1);
+  ecg_lrelu<T1>(a1);
+  ecb_flip<T1>(roww, n.sin_w[1], g, a1, a1s);
+  ecg_put<T1>(ws + C.x[1], row, g, a1);
+  ecg_put<T1>(ws + C.xs[1], row, g, a1s);
+  ecb_pair<T1, T2, true>(l1, dW + n.eoff[1], d2, d1, d2, roww, n.sout_w[1], a1, a1s, a2, j, g);
+  ecb_add_bias<T2>(l1 + 2 * d1 * d2, d2, g, a2);
+  ecg_lrelu<T2>(a2);
+  ecb_flip<T2>(roww, n.sin_w[2], g, a2, a2s);
+  ecg_put<T2>(ws + C.x[2], row, g, a2);
+  ecg_put<T2>(ws + C.xs[2], row, g, a2s);
+  ecb_pair<T2, T3, false>(l2, dW + n.eoff[2], d3, d2, d3, roww, n.sout_w[2], a2, a2s, a3, j, g);
+  ecb_add_bias<T3>(l2 + 2 * d2 * d3, d3, g, a3);
+  ecg_lrelu<T3>(a3);
+  ecb_flip<T3>(roww, n.sin_w[3], g, a3, a3s);
+  ecg_put<T3>(ws + C.x[3], row, g, a3);
+  ecg_put<T3>(ws + C.xs[3], row, g, a3s);
+  ecb_pair<T3, 1, false>(l3, dW + n.eoff[3], d4, d3, d4, roww, n.sout_w[3], a3, a3s, out, j, g);
+  ecb_add_bias<1>(l3 + 2 * d3 * d4, d4, g, out);
+}
+template <int T1, int T2, int T3>
+__device__ __forceinline__ void ecb_head_bwd(const float *theta, const float *thetaT, const BnnNet &n, const EcbCall &C, float *ws, int row, int tile,
+                                             const f32x4 (&dout)[1], f32x4 (&dxraw)[1], int j, int g) {
+  const int d0 = n.dims[0], d1 = n.dims[1], d2 = n.dims[2], d3 = n.dims[3], d4 = n.dims[4];
+  const uint32_t *roww = reinterpret_cast<const uint32_t *>(ws + C.sg) + (long long)row * n.swords;
+  const float *dWT = ws + C.dWT;
+  f32x4 douts[1], e3[T3], e3s[T3], e2[T2], e2s[T2], e1[T1], e1s[T1], x3[T3], x2[T2], x1[T1], dh0[1], xh[1];
+  ecb_flip<1>(roww, n.sout_w[3], g, dout, douts);
+  ecg_put<1>(ws + C.d[3], row, g, dout);
+  ecg_put<1>(ws + C.ds[3], row, g, douts);
+  ecb_pair<1, T3, false>(thetaT + n.woff[3], dWT + n.eoff[3], d3, d4, d3, roww, n.sin_w[3], dout, douts, e3, j, g);
+  ecg_get<T3>(ws + C.x[3], row, g, x3);
+  ecg_mask<T3>(e3, x3);
+  ecb_flip<T3>(roww, n.sout_w[2], g, e3, e3s);
+  ecg_put<T3>(ws + C.d[2], row, g, e3);
+  ecg_put<T3>(ws + C.ds[2], row, g, e3s);
+  ecb_pair<T3, T2, true>(thetaT + n.woff[2], dWT + n.eoff[2], d2, d3, d2, roww, n.sin_w[2], e3, e3s, e2, j, g);
+  ecg_get<T2>(ws + C.x[2], row, g, x2);
+  ecg_mask<T2>(e2, x2);
+  ecb_flip<T2>(roww, n.sout_w[1], g, e2, e2s);
+  ecg_put<T2>(ws + C.d[1], row, g, e2);
+  ecg_put<T2>(ws + C.ds[1], row, g, e2s);
+  ecb_pair<T2, T1, true>(thetaT + n.woff[1], dWT + n.eoff[1], d1, d2, d1, roww, n.sin_w[1], e2, e2s, e1, j, g);
+  ecg_get<T1>(ws + C.x[1], row, g, x1);
+  ecg_mask<T1>(e1, x1);
+  ecb_flip<T1>(roww, n.sout_w[0], g, e1, e1s);
+  ecg_put<T1>(ws + C.d[0], row, g, e1);
+  ecg_put<T1>(ws + C.ds[0], row, g, e1s);
+  ecb_pair<T1, 1, false>(thetaT + n.woff[0], dWT + n.eoff[0], d0, d1, d0, roww, n.sin_w[0], e1, e1s, dh0, j, g);
+  ecg_get<1>(ws + C.xh, row, g, xh);
+  float *bnp = ws + C.bnp + tile * (2 * 16);
+  const float *gamma = theta + n.off;
+  const float inv = 1.0f / sqrtf(1.0f + BNN_BN_EPS);
+  f32x4 sg_, sb;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    sg_[r] = sum_over_j_to_lane15(dh0[0][r] * xh[0][r]);
+    sb[r] = sum_over_j_to_lane15(dh0[0][r]);
+    dxraw[0][r] = inv * dh0[0][r] * ech_ld(gamma, 4 * g + r, d0);
+  }
+  if (j == 15) {
+    *reinterpret_cast<f32x4 *>(bnp + 4 * g) = sg_;
+    *reinterpret_cast<f32x4 *>(bnp + 16 + 4 * g) = sb;
+  }
+}
+
+// LDS behind the discriminator's parameter block: loss partials [8 x 16] | flags [16] | z_ | head-input gradient scratch | head
+// contribution to dLoss/dz_  (each [B x 16])
+template <int T1, int T2, int T3>
+__host__ __device__ inline int ecb_lds_floats(const EgmDisc &d, int B) { return 64 + ech_layout<T1, T2, T3>(d).total + 8 * 16 + 16 + 3 * 16 * B; }
+
+struct BnnEgmArgs;   // bnn_egm_kernels.h
+
+// Chains (waves):  0,1  g(z) [G1] -> v_ -> e(v_) [E2] -> backward of both          (latent reconstruction)
+//                  2,3  e(v) [E1] -> z_ -> g(z_) [G2] -> backward, then e backward with the summed dLoss/dz_
+//                  4,5  g(z) [G1S] (variance-head penalty) forward + backward; then, from z_: D, f [F, FS], h [H, HS]
+//                  6,7  discriminator parameter block, L2 warm-up
+// after the noise of the nine calls has been drawn by all waves.
+template <class Args, int HT, int NTL, int T1, int T2, int T3, int NB>
+__device__ __forceinline__ void ecb_gen_chain(const Args &a, const EcbTab &tab, float *thetaT_, float *ech_lds) {
+  constexpr int B = 16 * NB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  const int q = a.q, p = a.p, z0 = a.z0, z1 = a.z1, z2 = a.z2;
+  const EchP P = ech_layout<T1, T2, T3>(a.dz);
+  float *par = ech_lds + 64;
+  float *part = par + P.total;
+  volatile int *flag = reinterpret_cast<volatile int *>(part + 8 * 16);
+  float *zt = part + 8 * 16 + 16, *dzt = zt + 16 * B, *dzh = dzt + 16 * B;
+  float *ws = a.ws;
+  const float *th = a.theta, *tT = thetaT_;
+  if (tid < 16) flag[tid] = 0;
+  for (int c = 0; c < ECB_CALLS; ++c) ecb_noise(th, a.net[tab.c[c].net], tab.c[c], ws, B, a.k0, a.k1, a.stream + (uint32_t)c, tid);
+  __threadfence();
+  __syncthreads();
+  const int role = wave >> 1, tile = wave & 1;
+  const bool active = tile < NB;
+  const int row = 16 * tile + j;
+  const float invB = 1.0f / (float)B;
+  const float zrec = a.use_z_rec ? 1.0f : 0.0f;
+  const BnnNet &G = a.net[BNN_G], &E = a.net[BNN_E], &F = a.net[BNN_F], &Hn = a.net[BNN_H];
+  float ls[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};     // l_v, l_z, l_x, l_y, s_g, s_f, s_h, adv
+  if (role == 0 && active) {
+    f32x4 zin[1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zin[0][r] = ech_ld(a.z + (long long)row * q, 4 * g + r, q);
+    f32x4 gz[NTL];
+    ecb_mlp_fwd<1, HT, NTL>(th, G, tab.c[ECB_G1], ws, row, zin, gz, j, g);
+    f32x4 vin[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vin[t][r] = (16 * t + 4 * g + r < p) ? gz[t][r] : 0.0f;
+    f32x4 zz[1];
+    ecb_mlp_fwd<NTL, HT, 1>(th, E, tab.c[ECB_E2], ws, row, vin, zz, j, g);
+    f32x4 dzz[1];
+    float lz = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float t = zin[0][r] - zz[0][r];
+      lz = fmaf(t, t, lz);
+      dzz[0][r] = zrec * (-2.0f / (float)(B * q)) * t;
+    }
+    ls[1] = sum_over_g(lz);
+    f32x4 dv[NTL];
+    ecb_mlp_bwd<NTL, HT, 1, true>(th, tT, E, tab.c[ECB_E2], ws, row, tile, dzz, dv, j, g);
+#pragma unroll
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dv[t][r] = (16 * t + 4 * g + r < p) ? dv[t][r] : 0.0f;
+    f32x4 dnone[1];
+    ecb_mlp_bwd<1, HT, NTL, false>(th, tT, G, tab.c[ECB_G1], ws, row, tile, dv, dnone, j, g);
+  } else if (role == 1 && active) {
+    const float *vrow = a.v_ + (long long)a.idx[row] * p;
+    f32x4 vin[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vin[t][r] = ech_ld(vrow, 16 * t + 4 * g + r, p);
+    f32x4 ze[1];
+    ecb_mlp_fwd<NTL, HT, 1>(th, E, tab.c[ECB_E1], ws, row, vin, ze, j, g);
+    *reinterpret_cast<f32x4 *>(zt + row * 16 + 4 * g) = ze[0];
+    __threadfence_block();
+    if (lane == 0) flag[2 + tile] = 1;
+    f32x4 dz[1];
+    {
+      f32x4 gv[NTL];
+      ecb_mlp_fwd<1, HT, NTL>(th, G, tab.c[ECB_G2], ws, row, ze, gv, j, g);
+      float lv = 0.0f;
+#pragma unroll
+      for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 16 * t + 4 * g + r;
+          const float d = f < p ? ech_ld(vrow, f, p) - gv[t][r] : 0.0f;
+          lv = fmaf(d, d, lv);
+          gv[t][r] = (-2.0f / (float)(B * p)) * d;
+        }
+      ls[0] = sum_over_g(lv);
+      ecb_mlp_bwd<1, HT, NTL, true>(th, tT, G, tab.c[ECB_G2], ws, row, tile, gv, dz, j, g);
+    }
+    while (flag[4 + tile] == 0) __builtin_amdgcn_s_sleep(2);
+    __threadfence_block();
+    dz[0] += *reinterpret_cast<const f32x4 *>(dzh + row * 16 + 4 * g);
+    f32x4 dnone[NTL];
+    ecb_mlp_bwd<NTL, HT, 1, false>(th, tT, E, tab.c[ECB_E1], ws, row, tile, dz, dnone, j, g);
+  } else if (role == 2 && active) {
+    {   // second g(z) call: the variance-head penalty
+      f32x4 zin[1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) zin[0][r] = ech_ld(a.z + (long long)row * q, 4 * g + r, q);
+      f32x4 gzs[NTL];
+      ecb_mlp_fwd<1, HT, NTL>(th, G, tab.c[ECB_G1S], ws, row, zin, gzs, j, g);
+      float sgv = 0.0f;
+#pragma unroll
+      for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sgv += (16 * t + 4 * g + r == p) ? gzs[t][r] : 0.0f;
+      sgv = sum_over_g(sgv);
+      ls[4] = sgv * sgv;
+#pragma unroll
+      for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gzs[t][r] = (16 * t + 4 * g + r == p) ? 0.001f * 2.0f * sgv * invB : 0.0f;
+      f32x4 dnone[1];
+      ecb_mlp_bwd<1, HT, NTL, false>(th, tT, G, tab.c[ECB_G1S], ws, row, tile, gzs, dnone, j, g);
+    }
+    const long long prow = a.idx[row];
+    const float xv = a.x_[prow], yv = a.y_[prow];
+    while (flag[0] < 2) __builtin_amdgcn_s_sleep(2);
+    while (flag[2 + tile] == 0) __builtin_amdgcn_s_sleep(2);
+    __threadfence_block();
+    f32x4 ze[1], dz[1];
+    ze[0] = *reinterpret_cast<const f32x4 *>(zt + row * 16 + 4 * g);
+    {
+      EchFwd<T1, T2, T3> Fw;
+      Fw.a0[0] = ze[0];
+      ech_disc_fwd<T1, T2, T3>(par, P, Fw, j, g);
+      ls[7] = -Fw.out;
+      ecg_disc_dx<T1, T2, T3>(par, P, Fw, -invB, dz, j, g);
+    }
+    {   // f: mean call, variance-penalty call
+      f32x4 fin[1], fo[1], dfo[1], dfin[1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int f = 4 * g + r; fin[0][r] = f < z0 + z1 ? ze[0][r] : (f == z0 + z1 ? xv : 0.0f); }
+      const int of = F.dims[F.n_layers];
+      ecb_head_fwd<T1, T2, T3>(th, F, tab.c[ECB_F], ws, row, fin, fo, j, g);
+      const float mu = __shfl(fo[0][0], j);
+      ls[3] = (mu - yv) * (mu - yv);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dfo[0][r] = (4 * g + r == 0) ? 2.0f * (mu - yv) * invB : 0.0f;
+      ecb_head_bwd<T1, T2, T3>(th, tT, F, tab.c[ECB_F], ws, row, tile, dfo, dfin, j, g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dz[0][r] += (4 * g + r < z0 + z1) ? dfin[0][r] : 0.0f;
+      ecb_head_fwd<T1, T2, T3>(th, F, tab.c[ECB_FS], ws, row, fin, fo, j, g);
+      float sg = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sg += (4 * g + r == of - 1) ? fo[0][r] : 0.0f;
+      sg = sum_over_g(sg);
+      ls[5] = sg * sg;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dfo[0][r] = (4 * g + r == of - 1) ? 0.001f * 2.0f * sg * invB : 0.0f;
+      ecb_head_bwd<T1, T2, T3>(th, tT, F, tab.c[ECB_FS], ws, row, tile, dfo, dfin, j, g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dz[0][r] += (4 * g + r < z0 + z1) ? dfin[0][r] : 0.0f;
+    }
+    {   // h: mean call, variance-penalty call (input: z_[0:z0] and z_[z0+z1 : z0+z1+z2], a lane permutation through LDS)
+      f32x4 hin[1], ho[1], dho[1], dhin[1], dhin2[1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = 4 * g + r;
+        const float t = zt[row * 16 + min(f < z0 ? f : f + z1, 15)];
+        hin[0][r] = f < z0 + z2 ? t : 0.0f;
+      }
+      const int oh = Hn.dims[Hn.n_layers];
+      ecb_head_fwd<T1, T2, T3>(th, Hn, tab.c[ECB_H], ws, row, hin, ho, j, g);
+      const float mu = __shfl(ho[0][0], j);
+      float dmu;
+      if (a.binary) {
+        ls[2] = fmaxf(mu, 0.0f) - mu * xv + log1pf(expf(-fabsf(mu)));
+        dmu = (1.0f / (1.0f + expf(-mu)) - xv) * invB;
+      } else {
+        ls[2] = (mu - xv) * (mu - xv);
+        dmu = 2.0f * (mu - xv) * invB;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dho[0][r] = (4 * g + r == 0) ? dmu : 0.0f;
+      ecb_head_bwd<T1, T2, T3>(th, tT, Hn, tab.c[ECB_H], ws, row, tile, dho, dhin, j, g);
+      ecb_head_fwd<T1, T2, T3>(th, Hn, tab.c[ECB_HS], ws, row, hin, ho, j, g);
+      float sg = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sg += (4 * g + r == oh - 1) ? ho[0][r] : 0.0f;
+      sg = sum_over_g(sg);
+      ls[6] = sg * sg;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dho[0][r] = (4 * g + r == oh - 1) ? 0.001f * 2.0f * sg * invB : 0.0f;
+      ecb_head_bwd<T1, T2, T3>(th, tT, Hn, tab.c[ECB_HS], ws, row, tile, dho, dhin2, j, g);
+      dhin[0] += dhin2[0];
+      *reinterpret_cast<f32x4 *>(dzt + row * 16 + 4 * g) = dhin[0];
+      __threadfence_block();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = 4 * g + r;
+        const int src = f < z0 ? f : f - z1;
+        const float t = dzt[row * 16 + min(max(src, 0), 15)];
+        dz[0][r] += (f < z0 || (f >= z0 + z1 && f < z0 + z1 + z2)) ? t : 0.0f;
+      }
+    }
+    *reinterpret_cast<f32x4 *>(dzh + row * 16 + 4 * g) = dz[0];
+    __threadfence_block();
+    if (lane == 0) flag[4 + tile] = 1;
+  } else if (role == 3) {
+    ech_fill_params<T1, T2, T3>(par, P, a.theta_d, a.dz, tid - 384, 128);
+    __threadfence_block();
+    if (lane == 0) atomicAdd(const_cast<int *>(flag), 1);
+    float sink = 0.0f;
+    const int n4 = tab.n_warm >> 2;
+#pragma unroll
+    for (int arr = 0; arr < 2; ++arr) {
+      const f32x4 *src = reinterpret_cast<const f32x4 *>(arr == 0 ? th : tT);
+      for (int i = tid - 384; i < n4; i += 128 * 16) {
+        f32x4 acc4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc4 += src[min(i + 128 * k, n4 - 1)];
+        sink += acc4[0] + acc4[1] + acc4[2] + acc4[3];
+      }
+    }
+    asm volatile("" ::"v"(sink));
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float s = sum_over_j_to_lane15(ls[k]);
+    if (j == 15 && g == 0) part[wave * 16 + k] = s;
+  }
+  __syncthreads();
+  if (tid == 0 && a.out) {
+    float s[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s[k] = 0.0f; for (int w = 0; w < 6; ++w) if ((w & 1) < NB) s[k] += part[w * 16 + k]; }
+    const float l_v = s[0] / (float)(B * p), l_z = s[1] / (float)(B * q), l_x = s[2] * invB, l_y = s[3] * invB;
+    const float sig = (s[4] + s[5] + s[6]) * invB, adv = s[7] * invB;
+    a.out[0] = adv; a.out[1] = l_v; a.out[2] = l_z; a.out[3] = l_x; a.out[4] = l_y;
+    a.out[5] = adv + (l_v + zrec * l_z) + (l_x + l_y) + 0.001f * sig;
+  }
+}
+
+// Parameter gradients + Adam of the Flipout nets: per 16x16 tile of a layer, loc gets sum_calls h^T cur, rho gets
+// sum_calls (hs^T curs) * eps_call * sigmoid(rho) (bnn_bwd_params); bias from the column sums of cur.  The last workgroup
+// reduces the per-tile sums of the input normalisations' gamma / beta.  Tile entry (ints): woff, n_in, n_out, u, v, xw, dw, ncalls,
+// then per call: x, xs, d, ds, eps (workspace offsets of that layer).
+template <class Args, int NB>
+__device__ __forceinline__ void ecb_gen_dw(const Args &a, const EcbTab &tab, const int *tiles, float *thetaT) {
+  constexpr int B = 16 * NB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  const float *ws = a.ws;
+  auto adam = [&](int ei, float gi, int et) {
+    a.grad[ei] = gi;
+    if (a.apply) {
+      const float mi = a.adam.b1 * a.m[ei] + (1.0f - a.adam.b1) * gi;
+      const float vi = a.adam.b2 * a.v[ei] + (1.0f - a.adam.b2) * gi * gi;
+      const float tn = a.theta[ei] - a.adam.lr_t * mi / (sqrtf(vi) + a.adam.eps);
+      a.m[ei] = mi; a.v[ei] = vi; a.theta[ei] = tn;
+      if (et >= 0) thetaT[et] = tn;
+    }
+  };
+  const int n_tile_blocks = (tab.n_tiles + ECH_WAVES - 1) / ECH_WAVES;
+  if ((int)blockIdx.x == n_tile_blocks) {     // gamma / beta of the four input normalisations
+    for (int k = 0; k < 4; ++k) {
+      const BnnNet &n = a.net[k];
+      const int in = n.dims[0], w16 = 16 * tab.kt0[k];
+      for (int f = tid; f < in; f += ECH_THREADS) {
+        float sg = 0.0f, sb = 0.0f;
+        for (int c = 0; c < tab.net_ncalls[k]; ++c) {
+          const float *bp = ws + tab.c[tab.net_calls[k][c]].bnp;
+          for (int t = 0; t < NB; ++t) { sg += bp[t * 2 * w16 + f]; sb += bp[t * 2 * w16 + w16 + f]; }
+        }
+        adam(n.off + f, sg, -1);
+        adam(n.off + in + f, sb, -1);
+      }
+    }
+    return;
+  }
+  const int tau = blockIdx.x * ECH_WAVES + wave;
+  if (tau >= tab.n_tiles) return;
+  const int *td = tiles + tau * ECB_TILE_INTS;
+  const int woff = td[0], n_in = td[1], n_out = td[2], u = td[3], v = td[4], xw = td[5], dw = td[6], ncalls = td[7];
+  const int o = 16 * v + j;
+  f32x4 c1 = {0.0f, 0.0f, 0.0f, 0.0f}, rr = {0.0f, 0.0f, 0.0f, 0.0f};
+  float bs = 0.0f;
+  for (int c = 0; c < ncalls; ++c) {
+    const int xo = td[8 + 5 * c], xso = td[9 + 5 * c], dofs = td[10 + 5 * c], dso = td[11 + 5 * c], eo = td[12 + 5 * c];
+    f32x4 c2 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int s4 = 0; s4 < NB * 4; ++s4) {
+      const int r_ = 4 * s4 + g;
+      const float dv = ws[dofs + r_ * dw + o];
+      c1 = BGM_MFMA(ws[xo + r_ * xw + 16 * u + j], dv, c1);
+      c2 = BGM_MFMA(ws[xso + r_ * xw + 16 * u + j], ws[dso + r_ * dw + o], c2);
+      bs += dv;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = min(16 * u + 4 * g + r, n_in - 1);
+      rr[r] = fmaf(c2[r], ws[eo + f * n_out + min(o, n_out - 1)], rr[r]);
+    }
+  }
+  bs = sum_over_g(bs);
+  const int cnt = n_in * n_out;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int f = 16 * u + 4 * g + r;
+    if (f < n_in && o < n_out) {
+      const int t = f * n_out + o;
+      adam(woff + t, c1[r], woff + o * n_in + f);
+      adam(woff + cnt + t, rr[r] * sigmoid_f(a.theta[woff + cnt + t]), -1);
+    }
+  }
+  if (u == 0 && g == 0 && o < n_out) adam(woff + 2 * cnt + o, bs, -1);
+}
