@@ -118,7 +118,7 @@ extern "C" int bgm_bnn_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, const
         C.net = call_net[c];
         tab.net_calls[C.net][tab.net_ncalls[C.net]++] = c;
         const size_t E_ = (size_t)m.eoff[m.n_layers];
-        C.eps = take(E_); C.dW = take(E_); C.dWT = take(E_);
+        C.eps = 0; C.dW = take(E_ + 16); C.dWT = 0;
         C.sg = take((size_t)B * m.swords);
         const int kt0 = tab.kt0[C.net];
         C.xh = take((size_t)B * 16 * kt0);
@@ -141,7 +141,7 @@ extern "C" int bgm_bnn_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, const
               int en[ECB_TILE_INTS] = {m.woff[l], ni, no, u, v, xw[c0][l], dw[c0][l], tab.net_ncalls[k]};
               for (int c = 0; c < tab.net_ncalls[k]; ++c) {
                 const EcbCall &C = tab.c[tab.net_calls[k][c]];
-                en[8 + 5 * c] = C.x[l]; en[9 + 5 * c] = C.xs[l]; en[10 + 5 * c] = C.d[l]; en[11 + 5 * c] = C.ds[l]; en[12 + 5 * c] = C.eps + m.eoff[l];
+                en[8 + 5 * c] = C.x[l]; en[9 + 5 * c] = C.xs[l]; en[10 + 5 * c] = C.d[l]; en[11 + 5 * c] = C.ds[l]; en[12 + 5 * c] = C.dW + m.eoff[l];
               }
               tiles.insert(tiles.end(), en, en + ECB_TILE_INTS);
             }
@@ -255,6 +255,8 @@ extern "C" int bgm_bnn_egm_gen_step(bgm_handle *h, const float *z_dev, const int
     auto kc = a.B == 32 ? (e->chain_ntl == 13 ? bnn_egm_gen_chain_kernel<13, 2> : bnn_egm_gen_chain_kernel<7, 2>)
                         : (e->chain_ntl == 13 ? bnn_egm_gen_chain_kernel<13, 1> : bnn_egm_gen_chain_kernel<7, 1>);
     BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, e->chain_gen_lds));
+    hipLaunchKernelGGL(bnn_egm_gen_noise_kernel, dim3(ECB_CALLS * ECB_NOISE_PARTS), dim3(EGM_THREADS), 0, (hipStream_t)stream_, a, e->tab_dev);
+    BGM_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(kc, dim3(1), dim3(EGM_THREADS), e->chain_gen_lds, (hipStream_t)stream_, a, e->tab_dev, e->thetaT_dev);
     BGM_HIP_CHECK(hipGetLastError());
     auto kd = a.B == 32 ? bnn_egm_gen_dw_kernel<2> : bnn_egm_gen_dw_kernel<1>;

@@ -118,60 +118,65 @@ struct EcbTab {
   int n_warm;
 };
 
-// eps, dW, dW^T and the sign words of one call (bnn_noise + the transpose the backward chains read)
+// dW = sigma * eps and the sign words of one call (bnn_noise; eps itself is not stored: the gradient kernel recovers it as dW / sigma).
+// `part` of `parts` workgroup-sized slices: the noise of the nine calls is 40 k Philox blocks -- 110 us on the chain kernel's one CU
+// (integer multiplies at quarter rate, two waves per SIMD), a few microseconds as its own launch over 144 workgroups.
 __device__ __forceinline__ void ecb_noise(const float *theta, const BnnNet &n, const EcbCall &C, float *ws, int B, uint32_t k0, uint32_t k1,
-                                          uint32_t stream, int tid) {
+                                          uint32_t stream, int tid, int part, int parts) {
   for (int l = 0; l < n.n_layers; ++l) {
-    const int in = n.lin[l], out = n.lout[l], cnt = in * out;
+    const int cnt = n.lin[l] * n.lout[l];
     const float *rho = theta + n.woff[l] + cnt;
-    float *e = ws + C.eps + n.eoff[l], *d = ws + C.dW + n.eoff[l], *dt = ws + C.dWT + n.eoff[l];
-    for (int i = tid; i < (cnt + 3) >> 2; i += BNN_THREADS) {
+    float *d = ws + C.dW + n.eoff[l];
+    for (int i = part * BNN_THREADS + tid; i < (cnt + 3) >> 2; i += parts * BNN_THREADS) {
       const f32x4 z = box_muller4(philox4x32_10((uint32_t)i, (uint32_t)l | ((uint32_t)n.net_id << 16), stream, BNN_TAG_EPS, k0, k1));
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int idx = 4 * i + u;
-        if (idx < cnt) {
-          const float dv = (BNN_SCALE_EPS + softplus_acc(rho[idx])) * z[u];
-          const int f = idx / out, o = idx - f * out;
-          e[idx] = z[u]; d[idx] = dv; dt[o * in + f] = dv;
-        }
+        if (idx < cnt) d[idx] = (BNN_SCALE_EPS + softplus_f(rho[idx])) * z[u];      // transcendental-unit softplus: ~2 ulp on the scale of a random perturbation
       }
     }
   }
   const int calls = n.swords >> 2;
   uint32_t *sg = reinterpret_cast<uint32_t *>(ws + C.sg);
-  for (int i = tid; i < B * calls; i += BNN_THREADS) {
+  for (int i = part * BNN_THREADS + tid; i < B * calls; i += parts * BNN_THREADS) {
     const int r = i / calls, cc = i - r * calls;
     const uint4 w = philox4x32_10((uint32_t)r, (uint32_t)cc | ((uint32_t)n.net_id << 16), stream, BNN_TAG_SIGN, k0, k1);
     uint32_t *dst = sg + (long long)r * n.swords + 4 * cc;
     dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
   }
 }
+#define ECB_NOISE_PARTS 16
+template <class Args>
+__device__ __forceinline__ void ecb_gen_noise(const Args &a, const EcbTab &tab) {      // grid: ECB_CALLS * ECB_NOISE_PARTS workgroups
+  const int c = blockIdx.x / ECB_NOISE_PARTS, part = blockIdx.x % ECB_NOISE_PARTS;
+  ecb_noise(a.theta, a.net[tab.c[c].net], tab.c[c], a.ws, a.B, a.k0, a.k1, a.stream + (uint32_t)c, threadIdx.x, part, ECB_NOISE_PARTS);
+}
 
-// v = a W1 + flip(as W2) (+ bias): the Flipout product pair in either direction
-template <int KT, int NT>
+// v = a W1 + flip(as W2): the Flipout product pair in either direction.  KC: W1, W2 are given K-contiguously (ecg_load_tile): the
+// backward products read the canonical `loc` and the canonical perturbation that way, so neither needs a transposed copy.
+template <int KT, int NT, bool KC>
 __device__ __forceinline__ void ecb_pair_wide(const float *W1, const float *W2, int ld, int n_in, int n_out, const uint32_t *roww, int flipw,
                                               const f32x4 (&a)[KT], const f32x4 (&as)[KT], f32x4 (&v)[NT], int j, int g) {
   f32x4 c2[NT], c2s[NT];
-  ecg_wide<KT, NT>(W1, ld, n_in, n_out, a, v, j, g);
-  ecg_wide<KT, NT>(W2, ld, n_in, n_out, as, c2, j, g);
+  ecg_wide<KT, NT, KC>(W1, ld, n_in, n_out, a, v, j, g);
+  ecg_wide<KT, NT, KC>(W2, ld, n_in, n_out, as, c2, j, g);
   ecb_flip<NT>(roww, flipw, g, c2, c2s);
 #pragma unroll
   for (int u = 0; u < NT; ++u) v[u] += c2s[u];
 }
-template <int KT, int NT, bool CX>
+template <int KT, int NT, bool CX, bool KC = false>
 __device__ __forceinline__ void ecb_pair(const float *W1, const float *W2, int ld, int n_in, int n_out, const uint32_t *roww, int flipw,
                                          const f32x4 (&a)[KT], const f32x4 (&as)[KT], f32x4 (&v)[NT], int j, int g) {
-  if constexpr (NT > 4) ecb_pair_wide<KT, NT>(W1, W2, ld, n_in, n_out, roww, flipw, a, as, v, j, g);
+  if constexpr (NT > 4) ecb_pair_wide<KT, NT, KC>(W1, W2, ld, n_in, n_out, roww, flipw, a, as, v, j, g);
   else {
     const EcgW w1{W1, ld, n_in, n_out, 0}, w2{W2, ld, n_in, n_out, 0};
     EcgA<NT> A, Ad, Ad2;
-    ecg_prime<NT, CX>(w1, A, j, g);
+    ecg_prime<NT, CX, KC>(w1, A, j, g);
     f32x4 c2[NT], c2s[NT];
     ech_zero<NT>(v);
     ech_zero<NT>(c2);
-    ecg_sub<KT, NT, NT, CX, CX>(w1, a, v, A, w2, Ad, j, g);
-    ecg_sub<KT, NT, NT, CX, CX>(w2, as, c2, Ad, w2, Ad2, j, g);
+    ecg_sub<KT, NT, NT, CX, CX, KC, KC>(w1, a, v, A, w2, Ad, j, g);
+    ecg_sub<KT, NT, NT, CX, CX, KC, KC>(w2, as, c2, Ad, w2, Ad2, j, g);
     ecb_flip<NT>(roww, flipw, g, c2, c2s);
 #pragma unroll
     for (int u = 0; u < NT; ++u) v[u] += c2s[u];
@@ -245,14 +250,14 @@ __device__ __forceinline__ void ecb_mlp_bwd(const float *theta, const float *the
   constexpr int H = 16 * HT;
   const int L = n.n_layers, d0 = n.dims[0], no = n.dims[L];
   const uint32_t *roww = reinterpret_cast<const uint32_t *>(ws + C.sg) + (long long)row * n.swords;
-  const float *dWT = ws + C.dWT;
+  const float *dW = ws + C.dW;
   f32x4 dh[HT], dhs[HT], xl[HT];
   {
     f32x4 douts[NTO];
     ecb_flip<NTO>(roww, n.sout_w[L - 1], g, dout, douts);
     ecg_put<NTO>(ws + C.d[L - 1], row, g, dout);
     ecg_put<NTO>(ws + C.ds[L - 1], row, g, douts);
-    ecb_pair<NTO, HT, true>(thetaT + n.woff[L - 1], dWT + n.eoff[L - 1], H, no, H, roww, n.sin_w[L - 1], dout, douts, dh, j, g);
+    ecb_pair<NTO, HT, true, true>(theta + n.woff[L - 1], dW + n.eoff[L - 1], no, no, H, roww, n.sin_w[L - 1], dout, douts, dh, j, g);
     ecg_get<HT>(ws + C.x[L - 1], row, g, xl);
     ecg_mask<HT>(dh, xl);
   }
@@ -262,7 +267,7 @@ __device__ __forceinline__ void ecb_mlp_bwd(const float *theta, const float *the
     ecg_put<HT>(ws + C.d[l], row, g, dh);
     ecg_put<HT>(ws + C.ds[l], row, g, dhs);
     f32x4 d2[HT];
-    ecb_pair<HT, HT, true>(thetaT + n.woff[l], dWT + n.eoff[l], H, H, H, roww, n.sin_w[l], dh, dhs, d2, j, g);
+    ecb_pair<HT, HT, true, true>(theta + n.woff[l], dW + n.eoff[l], H, H, H, roww, n.sin_w[l], dh, dhs, d2, j, g);
     ecg_get<HT>(ws + C.x[l], row, g, xl);
     ecg_mask<HT>(d2, xl);
 #pragma unroll
@@ -272,7 +277,7 @@ __device__ __forceinline__ void ecb_mlp_bwd(const float *theta, const float *the
   ecg_put<HT>(ws + C.d[0], row, g, dh);
   ecg_put<HT>(ws + C.ds[0], row, g, dhs);
   f32x4 dh0[KT0], xh[KT0];
-  ecb_pair<HT, KT0, false>(thetaT + n.woff[0], dWT + n.eoff[0], d0, H, d0, roww, n.sin_w[0], dh, dhs, dh0, j, g);
+  ecb_pair<HT, KT0, false, true>(theta + n.woff[0], dW + n.eoff[0], H, H, d0, roww, n.sin_w[0], dh, dhs, dh0, j, g);
   ecg_get<KT0>(ws + C.xh, row, g, xh);
   float *bnp = ws + C.bnp + tile * (2 * 16 * KT0);
   const float *gamma = theta + n.off;
@@ -341,30 +346,30 @@ __device__ __forceinline__ void ecb_head_bwd(const float *theta, const float *th
                                              const f32x4 (&dout)[1], f32x4 (&dxraw)[1], int j, int g) {
   const int d0 = n.dims[0], d1 = n.dims[1], d2 = n.dims[2], d3 = n.dims[3], d4 = n.dims[4];
   const uint32_t *roww = reinterpret_cast<const uint32_t *>(ws + C.sg) + (long long)row * n.swords;
-  const float *dWT = ws + C.dWT;
+  const float *dW = ws + C.dW;
   f32x4 douts[1], e3[T3], e3s[T3], e2[T2], e2s[T2], e1[T1], e1s[T1], x3[T3], x2[T2], x1[T1], dh0[1], xh[1];
   ecb_flip<1>(roww, n.sout_w[3], g, dout, douts);
   ecg_put<1>(ws + C.d[3], row, g, dout);
   ecg_put<1>(ws + C.ds[3], row, g, douts);
-  ecb_pair<1, T3, false>(thetaT + n.woff[3], dWT + n.eoff[3], d3, d4, d3, roww, n.sin_w[3], dout, douts, e3, j, g);
+  ecb_pair<1, T3, false, true>(theta + n.woff[3], dW + n.eoff[3], d4, d4, d3, roww, n.sin_w[3], dout, douts, e3, j, g);
   ecg_get<T3>(ws + C.x[3], row, g, x3);
   ecg_mask<T3>(e3, x3);
   ecb_flip<T3>(roww, n.sout_w[2], g, e3, e3s);
   ecg_put<T3>(ws + C.d[2], row, g, e3);
   ecg_put<T3>(ws + C.ds[2], row, g, e3s);
-  ecb_pair<T3, T2, true>(thetaT + n.woff[2], dWT + n.eoff[2], d2, d3, d2, roww, n.sin_w[2], e3, e3s, e2, j, g);
+  ecb_pair<T3, T2, true, true>(theta + n.woff[2], dW + n.eoff[2], d3, d3, d2, roww, n.sin_w[2], e3, e3s, e2, j, g);
   ecg_get<T2>(ws + C.x[2], row, g, x2);
   ecg_mask<T2>(e2, x2);
   ecb_flip<T2>(roww, n.sout_w[1], g, e2, e2s);
   ecg_put<T2>(ws + C.d[1], row, g, e2);
   ecg_put<T2>(ws + C.ds[1], row, g, e2s);
-  ecb_pair<T2, T1, true>(thetaT + n.woff[1], dWT + n.eoff[1], d1, d2, d1, roww, n.sin_w[1], e2, e2s, e1, j, g);
+  ecb_pair<T2, T1, true, true>(theta + n.woff[1], dW + n.eoff[1], d2, d2, d1, roww, n.sin_w[1], e2, e2s, e1, j, g);
   ecg_get<T1>(ws + C.x[1], row, g, x1);
   ecg_mask<T1>(e1, x1);
   ecb_flip<T1>(roww, n.sout_w[0], g, e1, e1s);
   ecg_put<T1>(ws + C.d[0], row, g, e1);
   ecg_put<T1>(ws + C.ds[0], row, g, e1s);
-  ecb_pair<T1, 1, false>(thetaT + n.woff[0], dWT + n.eoff[0], d0, d1, d0, roww, n.sin_w[0], e1, e1s, dh0, j, g);
+  ecb_pair<T1, 1, false, true>(theta + n.woff[0], dW + n.eoff[0], d1, d1, d0, roww, n.sin_w[0], e1, e1s, dh0, j, g);
   ecg_get<1>(ws + C.xh, row, g, xh);
   float *bnp = ws + C.bnp + tile * (2 * 16);
   const float *gamma = theta + n.off;
@@ -393,7 +398,7 @@ struct BnnEgmArgs;   // bnn_egm_kernels.h
 //                  2,3  e(v) [E1] -> z_ -> g(z_) [G2] -> backward, then e backward with the summed dLoss/dz_
 //                  4,5  g(z) [G1S] (variance-head penalty) forward + backward; then, from z_: D, f [F, FS], h [H, HS]
 //                  6,7  discriminator parameter block, L2 warm-up
-// after the noise of the nine calls has been drawn by all waves.
+// The noise of the nine calls has been drawn by the launch before (ecb_gen_noise).
 template <class Args, int HT, int NTL, int T1, int T2, int T3, int NB>
 __device__ __forceinline__ void ecb_gen_chain(const Args &a, const EcbTab &tab, float *thetaT_, float *ech_lds) {
   constexpr int B = 16 * NB;
@@ -407,8 +412,6 @@ __device__ __forceinline__ void ecb_gen_chain(const Args &a, const EcbTab &tab, 
   float *ws = a.ws;
   const float *th = a.theta, *tT = thetaT_;
   if (tid < 16) flag[tid] = 0;
-  for (int c = 0; c < ECB_CALLS; ++c) ecb_noise(th, a.net[tab.c[c].net], tab.c[c], ws, B, a.k0, a.k1, a.stream + (uint32_t)c, tid);
-  __threadfence();
   __syncthreads();
   const int role = wave >> 1, tile = wave & 1;
   const bool active = tile < NB;
@@ -678,7 +681,7 @@ __device__ __forceinline__ void ecb_gen_dw(const Args &a, const EcbTab &tab, con
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int f = min(16 * u + 4 * g + r, n_in - 1);
-      rr[r] = fmaf(c2[r], ws[eo + f * n_out + min(o, n_out - 1)], rr[r]);
+      rr[r] = fmaf(c2[r], ws[eo + f * n_out + min(o, n_out - 1)], rr[r]);      // eo: the call's dW of this layer; divided by sigma below
     }
   }
   bs = sum_over_g(bs);
@@ -689,7 +692,8 @@ __device__ __forceinline__ void ecb_gen_dw(const Args &a, const EcbTab &tab, con
     if (f < n_in && o < n_out) {
       const int t = f * n_out + o;
       adam(woff + t, c1[r], woff + o * n_in + f);
-      adam(woff + cnt + t, rr[r] * sigmoid_f(a.theta[woff + cnt + t]), -1);
+      const float rho_ = a.theta[woff + cnt + t];
+      adam(woff + cnt + t, rr[r] / (BNN_SCALE_EPS + softplus_acc(rho_)) * sigmoid_f(rho_), -1);      // sum_calls c2 eps, eps = dW / sigma
     }
   }
   if (u == 0 && g == 0 && o < n_out) adam(woff + 2 * cnt + o, bs, -1);

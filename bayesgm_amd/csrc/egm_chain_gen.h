@@ -37,39 +37,56 @@ struct EcgW { const float *W; int ld, n_in, n_out, col0; };
 template <int NT> struct EcgA { float v[3][4][NT]; };      // v[0], v[1]: K tiles 0, 1 of the sub-layer about to run; v[2]: third buffer
 
 // CX: the columns col0 .. col0 + 16 NT all exist (no column clamp / mask: one lane base + immediate offsets);  clamp_rows: the K tile
-// may reach beyond n_in (only the last K tile of a layer can)
-template <int NT, bool CX>
+// may reach beyond n_in (only the last K tile of a layer can).
+// KC ("K-contiguous"): the matrix is given in the layout in which the contraction index is the fast one, element (k, col) at
+// W[col * ld + k] -- the canonical [in x out] array seen from a BACKWARD product (k = output feature), or a transposed mirror seen
+// from a forward one.  A lane's four K values of a tile are then one 16-byte load (a quarter of the vector-memory instructions; the
+// chains are bound by the CU's address unit at one 4-byte request per MFMA).  K values beyond n_in read neighbouring finite numbers
+// that meet zero B operands.
+template <int NT, bool CX, bool KC = false>
 __device__ __forceinline__ void ecg_load_tile(const EcgW &w, int t, float (&av)[4][NT], int j, int g, bool clamp_rows) {
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    int row = 16 * t + 4 * g + r;
-    if (clamp_rows) row = min(row, w.n_in - 1);
-    const float *wr = w.W + (row * w.ld + w.col0 + j);
+  if constexpr (KC) {
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
-      if (CX) av[r][u] = wr[16 * u];
-      else {
-        const int o = w.col0 + 16 * u + j;
-        const float x = w.W[row * w.ld + min(o, w.n_out - 1)];
-        av[r][u] = o < w.n_out ? x : 0.0f;      // padded output columns stay exactly zero (they are the next layer's padded inputs)
+      const int o = w.col0 + 16 * u + j;
+      const int oc = CX ? o : min(o, w.n_out - 1);
+      const float *q = w.W + (oc * w.ld + 16 * t + 4 * g);
+      float x0 = q[0], x1 = q[1], x2 = q[2], x3 = q[3];      // contiguous: the compiler merges them into one dwordx4 request
+      if (!CX && o >= w.n_out) { x0 = 0.0f; x1 = 0.0f; x2 = 0.0f; x3 = 0.0f; }
+      av[0][u] = x0; av[1][u] = x1; av[2][u] = x2; av[3][u] = x3;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int row = 16 * t + 4 * g + r;
+      if (clamp_rows) row = min(row, w.n_in - 1);
+      const float *wr = w.W + (row * w.ld + w.col0 + j);
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        if (CX) av[r][u] = wr[16 * u];
+        else {
+          const int o = w.col0 + 16 * u + j;
+          const float x = w.W[row * w.ld + min(o, w.n_out - 1)];
+          av[r][u] = o < w.n_out ? x : 0.0f;      // padded output columns stay exactly zero (they are the next layer's padded inputs)
+        }
       }
     }
   }
 }
-template <int NT, bool CX>
+template <int NT, bool CX, bool KC = false>
 __device__ __forceinline__ void ecg_prime(const EcgW &w, EcgA<NT> &A, int j, int g) {
-  ecg_load_tile<NT, CX>(w, 0, A.v[0], j, g, true);
-  ecg_load_tile<NT, CX>(w, 1, A.v[1], j, g, true);       // (a one-tile sub-layer reads a clamped duplicate)
+  ecg_load_tile<NT, CX, KC>(w, 0, A.v[0], j, g, true);
+  ecg_load_tile<NT, CX, KC>(w, 1, A.v[1], j, g, true);       // (a one-tile sub-layer reads a clamped duplicate)
 }
 // Runs the sub-layer whose first two K tiles are in A and leaves the first two K tiles of the next sub-layer `wn` in An.
-template <int KT, int NT, int NTN, bool CX, bool CXN>
+template <int KT, int NT, int NTN, bool CX, bool CXN, bool KC = false, bool KCN = false>
 __device__ __forceinline__ void ecg_sub(const EcgW &w, const f32x4 (&in)[KT], f32x4 (&out)[NT], EcgA<NT> &A, const EcgW &wn, EcgA<NTN> &An,
                                         int j, int g) {
 #pragma unroll
   for (int t = 0; t < KT; ++t) {
-    if (t + 2 < KT) ecg_load_tile<NT, CX>(w, t + 2, A.v[(t + 2) % 3], j, g, t + 2 == KT - 1);
-    if (t == (KT >= 2 ? KT - 2 : 0)) ecg_load_tile<NTN, CXN>(wn, 0, An.v[0], j, g, true);
-    if (t == KT - 1) ecg_load_tile<NTN, CXN>(wn, 1, An.v[1], j, g, true);
+    if (t + 2 < KT) ecg_load_tile<NT, CX, KC>(w, t + 2, A.v[(t + 2) % 3], j, g, t + 2 == KT - 1);
+    if (t == (KT >= 2 ? KT - 2 : 0)) ecg_load_tile<NTN, CXN, KCN>(wn, 0, An.v[0], j, g, true);
+    if (t == KT - 1) ecg_load_tile<NTN, CXN, KCN>(wn, 1, An.v[1], j, g, true);
     BGM_NO_HOIST();          // pins the issue order (the scheduler would sink every load to just above its MFMA)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -121,7 +138,7 @@ __device__ __forceinline__ void ecg_get(const float *base, int row, int g, f32x4
 
 // Wide layers (more than four output tiles) run as column groups of four tiles, each a full K sweep over the same input.
 // NT = 4 Q + R column tiles, R in {0, 1, 2, 3}.
-template <int KT, int NT>
+template <int KT, int NT, bool KC = false>
 __device__ __forceinline__ void ecg_wide(const float *W, int ld, int n_in, int n_out, const f32x4 (&in)[KT], f32x4 (&out)[NT], int j, int g) {
   constexpr int Q = NT / 4, R = NT % 4;
   ech_zero<NT>(out);
@@ -129,7 +146,7 @@ __device__ __forceinline__ void ecg_wide(const float *W, int ld, int n_in, int n
   if constexpr (Q > 0) {
     // 16 (NT - 1) < n_out <= 16 NT: every group but the very last is complete
     EcgA<4> A, An;
-    ecg_prime<4, (Q > 1 || R > 0)>(w, A, j, g);
+    ecg_prime<4, (Q > 1 || R > 0), KC>(w, A, j, g);
 #pragma unroll
     for (int c = 0; c < Q; ++c) {
       f32x4 o4[4];
@@ -138,11 +155,11 @@ __device__ __forceinline__ void ecg_wide(const float *W, int ld, int n_in, int n
       w.col0 = 64 * c;
       constexpr bool last_full = R > 0;      // the last group of four is complete when a remainder group follows
       if (c + 1 < Q) {
-        if (c + 2 < Q || last_full) ecg_sub<KT, 4, 4, true, true>(w, in, o4, A, wn, An, j, g);
-        else ecg_sub<KT, 4, 4, true, false>(w, in, o4, A, wn, An, j, g);
+        if (c + 2 < Q || last_full) ecg_sub<KT, 4, 4, true, true, KC, KC>(w, in, o4, A, wn, An, j, g);
+        else ecg_sub<KT, 4, 4, true, false, KC, KC>(w, in, o4, A, wn, An, j, g);
       } else {
-        if (last_full) ecg_sub<KT, 4, 4, true, true>(w, in, o4, A, wn, An, j, g);
-        else ecg_sub<KT, 4, 4, false, false>(w, in, o4, A, wn, An, j, g);
+        if (last_full) ecg_sub<KT, 4, 4, true, true, KC, KC>(w, in, o4, A, wn, An, j, g);
+        else ecg_sub<KT, 4, 4, false, false, KC, KC>(w, in, o4, A, wn, An, j, g);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) out[4 * c + u] = o4[u];
@@ -152,10 +169,10 @@ __device__ __forceinline__ void ecg_wide(const float *W, int ld, int n_in, int n
   if constexpr (R > 0) {
     EcgA<R> Ar, Ad;
     EcgW wr{W, ld, n_in, n_out, 64 * Q};
-    ecg_prime<R, false>(wr, Ar, j, g);
+    ecg_prime<R, false, KC>(wr, Ar, j, g);
     f32x4 orr[R];
     ech_zero<R>(orr);
-    ecg_sub<KT, R, R, false, false>(wr, in, orr, Ar, wr, Ad, j, g);
+    ecg_sub<KT, R, R, false, false, KC, KC>(wr, in, orr, Ar, wr, Ad, j, g);
 #pragma unroll
     for (int u = 0; u < R; ++u) out[4 * Q + u] = orr[u];
   }
