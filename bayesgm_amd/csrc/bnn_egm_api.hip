@@ -20,6 +20,7 @@ struct BnnEgmState {
   float *dev = nullptr;      // m | v (EGM Adam slots of the Bayesian nets) | theta_d | m_d | v_d | grad_d | ws
   // generator step as row-tile chains (egm_chain_bnn.h)
   int chain_gen_lds = 0, chain_ntl = 0, n_tiles = 0;
+  EcbCall disc_call{};         // noise of the discriminator step's encoder call (workspace offsets)
   EcbTab *tab_dev = nullptr;
   int *tiles_dev = nullptr;
   float *thetaT_dev = nullptr;
@@ -154,6 +155,14 @@ extern "C" int bgm_bnn_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, const
       e->chain_gen_lds = (int)(sizeof(float) * (size_t)ecb_lds_floats<4, 2, 1>(d, B));
     }
   }
+  {   // noise block of the discriminator step's encoder call, behind the generator chain's region
+    const BnnNet &E = s->net[BNN_E];
+    size_t off = (gen_ws + 3) / 4 * 4;
+    e->disc_call.net = BNN_E;
+    e->disc_call.dW = (int)off; off += ((size_t)E.eoff[E.n_layers] + 16 + 3) / 4 * 4;
+    e->disc_call.sg = (int)off; off += ((size_t)B * E.swords + 3) / 4 * 4;
+    gen_ws = off;
+  }
   e->ws_floats = gen_ws + 3 * cache_floats(s->net[BNN_G]) + 2 * cache_floats(s->net[BNN_E]) + 2 * cache_floats(s->net[BNN_F]) +
                  2 * cache_floats(s->net[BNN_H]) + (size_t)B * (4 * (size_t)s->p + 32 * (size_t)wmax + 256) + 4 * cache + e->n_dz + arena + 8192;
   const size_t np = ((size_t)s->n_params + 63) & ~(size_t)63, nd = (e->n_dz + 63) & ~(size_t)63;
@@ -227,7 +236,11 @@ extern "C" int bgm_bnn_egm_disc_step(bgm_handle *h, const float *z_dev, const in
       auto kc = a.B == 32 ? (ntl == 13 ? bnn_egm_disc_chain_kernel<13, 4, 2, 1, 2> : ntl == 7 ? bnn_egm_disc_chain_kernel<7, 4, 2, 1, 2> : bnn_egm_disc_chain_kernel<0, 4, 2, 1, 2>)
                           : (ntl == 13 ? bnn_egm_disc_chain_kernel<13, 4, 2, 1, 1> : ntl == 7 ? bnn_egm_disc_chain_kernel<7, 4, 2, 1, 1> : bnn_egm_disc_chain_kernel<0, 4, 2, 1, 1>);
       BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-      hipLaunchKernelGGL(kc, dim3(1), dim3(EGM_THREADS), bytes, (hipStream_t)stream_, a);
+      if (ntl == 13 || ntl == 7) {
+        hipLaunchKernelGGL(bnn_egm_disc_noise_kernel, dim3(ECB_NOISE_PARTS), dim3(EGM_THREADS), 0, (hipStream_t)stream_, a, e->disc_call);
+        BGM_HIP_CHECK(hipGetLastError());
+      }
+      hipLaunchKernelGGL(kc, dim3(1), dim3(EGM_THREADS), bytes, (hipStream_t)stream_, a, e->disc_call);
       BGM_HIP_CHECK(hipGetLastError());
       return BGM_OK;
     }

@@ -77,8 +77,11 @@ static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_disc_step_kernel(B
 // tiles in LDS, and the three discriminator passes, the gradient GEMMs and Adam are ech_disc_tail.
 // NTL > 0: the Flipout encoder runs as a row-tile chain too (egm_chain_bnn.h: inference-mode input normalisation, 64-wide hidden
 // layers, ceil(p / 16) = NTL); NTL = 0: it stays on the phase-machine routines.
+static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_disc_noise_kernel(BnnEgmArgs a, EcbCall C) {     // grid: ECB_NOISE_PARTS
+  ecb_noise(a.theta, a.net[BNN_E], C, a.ws, a.B, a.k0, a.k1, a.stream, threadIdx.x, blockIdx.x, ECB_NOISE_PARTS);
+}
 template <int NTL, int T1, int T2, int T3, int NB>
-static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_disc_chain_kernel(BnnEgmArgs a) {
+static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_disc_chain_kernel(BnnEgmArgs a, EcbCall C) {
   extern __shared__ __attribute__((aligned(16))) float egm_lds[];
   BnnCtx cb{(int)threadIdx.x, egm_lds};
   const int tid = threadIdx.x, B = a.B, q = a.q, p = a.p;
@@ -88,17 +91,15 @@ static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_disc_chain_kernel(
   const EchP P = ech_layout<T1, T2, T3>(a.dz);
   const EchLds<T1, T2, T3> M(egm_lds, P, B);
   if constexpr (NTL > 0) {
-    BnnCache ke;
-    bnn_cache(a.net[BNN_E], B, wp, ke, vb);
-    bnn_noise(cb, a.theta, a.net[BNN_E], ke, B, a.k0, a.k1, a.stream);       // eps, dW = sigma * eps, sign words of the call
+    // the call's perturbations and sign words were drawn by the launch before (bnn_egm_disc_noise_kernel)
     ech_fill_params<T1, T2, T3>(M.par, P, a.theta_d, a.dz, tid, EGM_THREADS);
-    __threadfence();
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
     if (wave < NB) {
       const int row = 16 * wave + j;
       f32x4 zf[1];
-      ecb_encoder<4, NTL>(a.theta, a.net[BNN_E], ke.dW, ke.sg + (long long)row * a.net[BNN_E].swords, a.v_ + (long long)a.idx[row] * p, zf, j, g);
+      ecb_encoder<4, NTL>(a.theta, a.net[BNN_E], a.ws + C.dW, reinterpret_cast<const uint32_t *>(a.ws + C.sg) + (long long)row * a.net[BNN_E].swords,
+                          a.v_ + (long long)a.idx[row] * p, zf, j, g);
       *reinterpret_cast<f32x4 *>(M.zt + row * 16 + 4 * g) = zf[0];
     }
     __syncthreads();
