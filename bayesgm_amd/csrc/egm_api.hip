@@ -205,7 +205,8 @@ extern "C" int bgm_causal_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, co
       }
     };
     mirror(a.g); mirror(a.e); mirror(a.f); mirror(a.h);
-    BGM_HIP_CHECK(hipMalloc(&s->thetaT_dev, sizeof(float) * s->n_gen));
+    BGM_HIP_CHECK(hipMalloc(&s->thetaT_dev, sizeof(float) * (s->n_gen + 64)));     // K-contiguous tile loads read up to 15 floats past a row
+    BGM_HIP_CHECK(hipMemset(s->thetaT_dev, 0, sizeof(float) * (s->n_gen + 64)));
     BGM_HIP_CHECK(hipMemcpy(s->thetaT_dev, tT.data(), sizeof(float) * s->n_gen, hipMemcpyHostToDevice));
     BGM_HIP_CHECK(hipMalloc(&s->tiles_dev, sizeof(int) * s->gen_tiles.size()));
     BGM_HIP_CHECK(hipMemcpy(s->tiles_dev, s->gen_tiles.data(), sizeof(int) * s->gen_tiles.size(), hipMemcpyHostToDevice));

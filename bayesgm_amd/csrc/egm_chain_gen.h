@@ -40,9 +40,11 @@ template <int NT> struct EcgA { float v[3][4][NT]; };      // v[0], v[1]: K tile
 // may reach beyond n_in (only the last K tile of a layer can).
 // KC ("K-contiguous"): the matrix is given in the layout in which the contraction index is the fast one, element (k, col) at
 // W[col * ld + k] -- the canonical [in x out] array seen from a BACKWARD product (k = output feature), or a transposed mirror seen
-// from a forward one.  A lane's four K values of a tile are then one 16-byte load (a quarter of the vector-memory instructions; the
-// chains are bound by the CU's address unit at one 4-byte request per MFMA).  K values beyond n_in read neighbouring finite numbers
-// that meet zero B operands.
+// from a forward one.  A lane's four K values of a tile are then one 16-byte load.  That removes the need for a transposed copy (the
+// Bayesian chains read their per-call perturbations this way: nothing to transpose, nothing to scatter), but it is NOT faster per
+// se: the address unit pays per cache line touched (16 lines per request here, 4 for the row-contiguous 4-byte form), and the
+// deterministic generator step measured 73 -> 88 us with every product switched to it -- so those chains keep the mirror.
+// K values beyond n_in read neighbouring finite numbers that meet zero B operands.
 template <int NT, bool CX, bool KC = false>
 __device__ __forceinline__ void ecg_load_tile(const EcgW &w, int t, float (&av)[4][NT], int j, int g, bool clamp_rows) {
   if constexpr (KC) {
