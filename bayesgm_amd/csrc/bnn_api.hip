@@ -4,8 +4,66 @@
 #include <vector>
 
 #include "bgm_host.h"
+#include <cstdlib>
+
 #include "bnn_kernels.h"
 #include "bnn_state.h"
+#include "egm_chain_bnn.h"
+
+// ---- iterative-update steps as row-tile chains (egm_chain_bnn.h) when the shapes are the compiled ones
+struct BnnFitChain {
+  int ntl = 0, n_tiles = 0;
+  EcbTab *tab_theta = nullptr, *tab_z = nullptr;
+  int *tiles_theta = nullptr;
+  float *ws = nullptr;
+};
+static __global__ __launch_bounds__(BNN_THREADS) void bnn_fit_noise_kernel(BnnArgs a, const EcbTab *tab, float *ws) { ecb_gen_noise<BnnArgs>(a, *tab, ws); }
+template <int NTL, int NB>
+static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_chain_kernel(BnnArgs a, const EcbTab *tab, float *ws) {
+  extern __shared__ __attribute__((aligned(16))) float bnn_chain_lds[];
+  ecb_theta_chain<BnnArgs, 4, NTL, 4, 2, 1, NB>(a, *tab, ws, bnn_chain_lds);
+}
+template <int NB>
+static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_dw_kernel(BnnArgs a, const EcbTab *tab, const int *tiles, const float *ws) {
+  ecb_theta_dw<BnnArgs, NB>(a, *tab, tiles, ws);
+}
+template <int NTL, int NB>
+static __global__ __launch_bounds__(BNN_THREADS) void bnn_z_chain_kernel(BnnArgs a, const EcbTab *tab, float *ws) {
+  extern __shared__ __attribute__((aligned(16))) float bnn_chain_lds[];
+  ecb_z_chain<BnnArgs, 4, NTL, 4, 2, 1, NB>(a, *tab, ws, bnn_chain_lds);
+}
+static void bnn_chain_free(BnnState *s) {
+  BnnFitChain *c = static_cast<BnnFitChain *>(s->chain);
+  if (!c) return;
+  for (void *p : {(void *)c->tab_theta, (void *)c->tab_z, (void *)c->tiles_theta, (void *)c->ws})
+    if (p) hipFree(p);
+  delete c;
+  s->chain = nullptr;
+}
+static int bnn_chain_setup(BnnState *s) {
+  if (std::getenv("BGM_BNN_NO_CHAIN") || !ecb_shapes_ok(s->net, s->q, s->p, false)) return BGM_OK;
+  const int ntl = (s->p + 1 + 15) / 16, B = 32;
+  BnnFitChain *c = new BnnFitChain();
+  s->chain = c;
+  c->ntl = ntl;
+  EcbTab tt{}, tz{};
+  std::vector<int> tiles, none;
+  const int tnet[3] = {BNN_G, BNN_H, BNN_F}, tso[3] = {0, 0, 0}, trained[3] = {BNN_G, BNN_H, BNN_F};
+  const size_t w1 = ecb_build_tab(s->net, tnet, tso, 3, B, ntl, tt, tiles, trained, 3);
+  const int znet[6] = {BNN_G, BNN_G, BNN_H, BNN_H, BNN_F, BNN_F}, zso[6] = {0, 1, 0, 1, 0, 1};
+  const size_t w2 = ecb_build_tab(s->net, znet, zso, 6, B, ntl, tz, none, trained, 0);
+  c->n_tiles = tt.n_tiles;
+  const size_t wsf = std::max(w1, w2) + 64;
+  BGM_HIP_CHECK(hipMalloc((void **)&c->ws, sizeof(float) * wsf));
+  BGM_HIP_CHECK(hipMemset(c->ws, 0, sizeof(float) * wsf));
+  BGM_HIP_CHECK(hipMalloc((void **)&c->tab_theta, sizeof(EcbTab)));
+  BGM_HIP_CHECK(hipMalloc((void **)&c->tab_z, sizeof(EcbTab)));
+  BGM_HIP_CHECK(hipMemcpy(c->tab_theta, &tt, sizeof(EcbTab), hipMemcpyHostToDevice));
+  BGM_HIP_CHECK(hipMemcpy(c->tab_z, &tz, sizeof(EcbTab), hipMemcpyHostToDevice));
+  BGM_HIP_CHECK(hipMalloc((void **)&c->tiles_theta, sizeof(int) * tiles.size()));
+  BGM_HIP_CHECK(hipMemcpy(c->tiles_theta, tiles.data(), sizeof(int) * tiles.size(), hipMemcpyHostToDevice));
+  return BGM_OK;
+}
 
 static BnnState *bst(bgm_handle *h) { return static_cast<BnnState *>(h->bnn_state); }
 
@@ -15,6 +73,7 @@ void bgm_bnn_free_state(bgm_handle *h) {
   if (s->dev) hipFree(s->dev);
   bnn_free_sampler(s);
   bgm_bnn_egm_free(s->egm);
+  bnn_chain_free(s);
   delete s;
   h->bnn_state = nullptr;
 }
@@ -93,7 +152,7 @@ extern "C" int bgm_bnn_begin(bgm_handle *h, const bgm_bnn_config *cfg, const flo
   s->dz_part_dev = s->dz_dev + (size_t)B * s->q + 64;      // [3][B x q] + 3 loss partials
   BGM_HIP_CHECK(hipMemcpy(s->theta_dev, theta_host, sizeof(float) * count, hipMemcpyHostToDevice));
   s->t_theta = 0; s->t_z = 0;
-  return BGM_OK;
+  return bnn_chain_setup(s);
 }
 
 static int bnn_need(bgm_handle *h, const char *who) {
@@ -182,7 +241,18 @@ extern "C" int bgm_bnn_theta_step(bgm_handle *h, const float *data_z, const int3
   a.data_z = data_z; a.idx = idx; a.x_ = x; a.y_ = y; a.v_ = v;
   a.apply = apply; a.out = out;
   if (apply) { s->t_theta += 1; a.adam = BnnAdam{adam_lr_t(lr_theta, s->t_theta), BNN_ADAM_B1, BNN_ADAM_B2, BNN_ADAM_EPS}; }
-  hipLaunchKernelGGL(bnn_theta_step_kernel, dim3(3), dim3(BNN_THREADS), 0, (hipStream_t)stream_, a);
+  BnnFitChain *fc = static_cast<BnnFitChain *>(s->chain);
+  if (fc && (batch == 16 || batch == 32)) {
+    hipStream_t st = (hipStream_t)stream_;
+    hipLaunchKernelGGL(bnn_fit_noise_kernel, dim3(3 * ECB_NOISE_PARTS), dim3(BNN_THREADS), 0, st, a, fc->tab_theta, fc->ws);
+    auto kc = batch == 32 ? (fc->ntl == 13 ? bnn_theta_chain_kernel<13, 2> : bnn_theta_chain_kernel<7, 2>)
+                          : (fc->ntl == 13 ? bnn_theta_chain_kernel<13, 1> : bnn_theta_chain_kernel<7, 1>);
+    hipLaunchKernelGGL(kc, dim3(1), dim3(BNN_THREADS), (64 + 3 * 128) * sizeof(float), st, a, fc->tab_theta, fc->ws);
+    auto kd = batch == 32 ? bnn_theta_dw_kernel<2> : bnn_theta_dw_kernel<1>;
+    hipLaunchKernelGGL(kd, dim3((fc->n_tiles + ECH_WAVES - 1) / ECH_WAVES + 1), dim3(BNN_THREADS), 0, st, a, fc->tab_theta, fc->tiles_theta, fc->ws);
+  } else {
+    hipLaunchKernelGGL(bnn_theta_step_kernel, dim3(3), dim3(BNN_THREADS), 0, (hipStream_t)stream_, a);
+  }
   BGM_HIP_CHECK(hipGetLastError());
   if (apply) s->packed_valid = false;
   return BGM_OK;
@@ -220,8 +290,16 @@ extern "C" int bgm_bnn_z_step(bgm_handle *h, const float *x, const float *y, con
   bnn_base_args(s, a, batch, batch_global, seed, stream_id);
   a.data_z = data_z; a.idx = idx; a.x_ = x; a.y_ = y; a.v_ = v;
   a.out = out; a.dz = dz_out ? dz_out : s->dz_dev;
-  hipLaunchKernelGGL(bnn_z_grad_kernel, dim3(3), dim3(BNN_THREADS), 0, stream, a);
-  hipLaunchKernelGGL(bnn_z_combine_kernel, dim3((batch * s->q + 255) / 256), dim3(256), 0, stream, a.dz_part, a.loss_part, a.dz, out, batch * s->q);
+  BnnFitChain *fc = static_cast<BnnFitChain *>(s->chain);
+  if (fc && (batch == 16 || batch == 32)) {
+    hipLaunchKernelGGL(bnn_fit_noise_kernel, dim3(6 * ECB_NOISE_PARTS), dim3(BNN_THREADS), 0, stream, a, fc->tab_z, fc->ws);
+    auto kc = batch == 32 ? (fc->ntl == 13 ? bnn_z_chain_kernel<13, 2> : bnn_z_chain_kernel<7, 2>)
+                          : (fc->ntl == 13 ? bnn_z_chain_kernel<13, 1> : bnn_z_chain_kernel<7, 1>);
+    hipLaunchKernelGGL(kc, dim3(1), dim3(BNN_THREADS), (32 + 2 * batch + 4 * 16 * batch) * sizeof(float), stream, a, fc->tab_z, fc->ws);
+  } else {
+    hipLaunchKernelGGL(bnn_z_grad_kernel, dim3(3), dim3(BNN_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(bnn_z_combine_kernel, dim3((batch * s->q + 255) / 256), dim3(256), 0, stream, a.dz_part, a.loss_part, a.dz, out, batch * s->q);
+  }
   BGM_HIP_CHECK(hipGetLastError());
   if (dz_out) return BGM_OK;    // gradient only (parity tests)
   s->t_z += 1;

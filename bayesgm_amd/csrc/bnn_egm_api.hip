@@ -106,49 +106,10 @@ extern "C" int bgm_bnn_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, const
               m.dims[4] >= 1 && m.dims[4] <= 16;
     }
     if (chain) {
-      auto tl = [](int n) { return (n + 15) / 16; };
       const int call_net[ECB_CALLS] = {BNN_G, BNN_G, BNN_E, BNN_E, BNN_G, BNN_F, BNN_F, BNN_H, BNN_H};
-      size_t off = 0;
-      auto take = [&](size_t n) { const size_t r = off; off += (n + 3) / 4 * 4; return (int)r; };
-      const int NBt = B / 16;
-      for (int k = 0; k < 4; ++k) { tab.net_ncalls[k] = 0; tab.kt0[k] = k == BNN_E ? ntl : 1; }
-      int xw[ECB_CALLS][BNN_MAX_LAYERS], dw[ECB_CALLS][BNN_MAX_LAYERS];
-      for (int c = 0; c < ECB_CALLS; ++c) {
-        const BnnNet &m = s->net[call_net[c]];
-        EcbCall &C = tab.c[c];
-        C.net = call_net[c];
-        tab.net_calls[C.net][tab.net_ncalls[C.net]++] = c;
-        const size_t E_ = (size_t)m.eoff[m.n_layers];
-        C.eps = 0; C.dW = take(E_ + 16); C.dWT = 0;
-        C.sg = take((size_t)B * m.swords);
-        const int kt0 = tab.kt0[C.net];
-        C.xh = take((size_t)B * 16 * kt0);
-        C.bnp = take((size_t)NBt * 2 * 16 * kt0);
-        for (int l = 0; l < m.n_layers; ++l) {
-          xw[c][l] = 16 * tl(m.dims[l]); dw[c][l] = 16 * tl(m.dims[l + 1]);
-          if (C.net == BNN_E && l == 0) xw[c][l] = 16 * ntl;
-          if (C.net == BNN_G && l == m.n_layers - 1) dw[c][l] = 16 * ntl;
-          C.x[l] = take((size_t)B * xw[c][l]); C.xs[l] = take((size_t)B * xw[c][l]);
-          C.d[l] = take((size_t)B * dw[c][l]); C.ds[l] = take((size_t)B * dw[c][l]);
-        }
-      }
-      gen_ws = off;
-      for (int k = 0; k < 4; ++k) {
-        const BnnNet &m = s->net[k];
-        for (int l = 0; l < m.n_layers; ++l) {
-          const int ni = m.dims[l], no = m.dims[l + 1], c0 = tab.net_calls[k][0];
-          for (int u = 0; u < tl(ni); ++u)
-            for (int v = 0; v < tl(no); ++v) {
-              int en[ECB_TILE_INTS] = {m.woff[l], ni, no, u, v, xw[c0][l], dw[c0][l], tab.net_ncalls[k]};
-              for (int c = 0; c < tab.net_ncalls[k]; ++c) {
-                const EcbCall &C = tab.c[tab.net_calls[k][c]];
-                en[8 + 5 * c] = C.x[l]; en[9 + 5 * c] = C.xs[l]; en[10 + 5 * c] = C.d[l]; en[11 + 5 * c] = C.ds[l]; en[12 + 5 * c] = C.dW + m.eoff[l];
-              }
-              tiles.insert(tiles.end(), en, en + ECB_TILE_INTS);
-            }
-        }
-      }
-      tab.n_tiles = (int)(tiles.size() / ECB_TILE_INTS);
+      const int call_soff[ECB_CALLS] = {0, 1, 2, 3, 4, 5, 6, 7, 8};
+      const int all_nets[4] = {BNN_G, BNN_E, BNN_F, BNN_H};
+      gen_ws = ecb_build_tab(s->net, call_net, call_soff, ECB_CALLS, B, ntl, tab, tiles, all_nets, 4);
       tab.n_warm = s->n_params;
       e->chain_ntl = ntl;
       e->n_tiles = tab.n_tiles;

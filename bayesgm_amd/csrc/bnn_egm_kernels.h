@@ -257,7 +257,7 @@ static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_gen_chain_kernel(B
   extern __shared__ __attribute__((aligned(16))) float egm_lds[];
   ecb_gen_chain<BnnEgmArgs, 4, NTL, 4, 2, 1, NB>(a, *tab, thetaT, egm_lds);
 }
-static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_gen_noise_kernel(BnnEgmArgs a, const EcbTab *tab) { ecb_gen_noise<BnnEgmArgs>(a, *tab); }
+static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_gen_noise_kernel(BnnEgmArgs a, const EcbTab *tab) { ecb_gen_noise<BnnEgmArgs>(a, *tab, a.ws); }
 template <int NB>
 static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_gen_dw_kernel(BnnEgmArgs a, const EcbTab *tab, const int *tiles, float *thetaT) {
   ecb_gen_dw<BnnEgmArgs, NB>(a, *tab, tiles, thetaT);

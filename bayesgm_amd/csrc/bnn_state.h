@@ -24,6 +24,7 @@ struct BnnState {
   float *samp_dev = nullptr;
   size_t samp_cap = 0;
   void *egm = nullptr;         // BnnEgmState (bnn_egm_api.hip)
+  void *chain = nullptr;       // BnnFitChain (bnn_api.hip): tables / workspace of the row-tile-chain step kernels, or NULL
 };
 
 void bgm_bnn_egm_free(void *egm_state);

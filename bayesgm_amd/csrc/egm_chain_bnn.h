@@ -104,6 +104,7 @@ enum { ECB_G1 = 0, ECB_G1S = 1, ECB_E1 = 2, ECB_E2 = 3, ECB_G2 = 4, ECB_F = 5, E
 
 struct EcbCall {
   int net;                               // BNN_G / BNN_E / BNN_F / BNN_H
+  int soff;                              // noise stream of the call = the step's stream id + soff
   int eps, dW, dWT;                      // workspace offsets (floats) of the call's noise: eps, sigma * eps, and its per-layer transpose
   int sg;                                // sign words [B x swords]
   int xh;                                // normalised input xhat [B x 16 KT0]
@@ -147,9 +148,9 @@ __device__ __forceinline__ void ecb_noise(const float *theta, const BnnNet &n, c
 }
 #define ECB_NOISE_PARTS 16
 template <class Args>
-__device__ __forceinline__ void ecb_gen_noise(const Args &a, const EcbTab &tab) {      // grid: ECB_CALLS * ECB_NOISE_PARTS workgroups
+__device__ __forceinline__ void ecb_gen_noise(const Args &a, const EcbTab &tab, float *ws_) {      // grid: n_calls * ECB_NOISE_PARTS workgroups
   const int c = blockIdx.x / ECB_NOISE_PARTS, part = blockIdx.x % ECB_NOISE_PARTS;
-  ecb_noise(a.theta, a.net[tab.c[c].net], tab.c[c], a.ws, a.B, a.k0, a.k1, a.stream + (uint32_t)c, threadIdx.x, part, ECB_NOISE_PARTS);
+  ecb_noise(a.theta, a.net[tab.c[c].net], tab.c[c], ws_, a.B, a.k0, a.k1, a.stream + (uint32_t)tab.c[c].soff, threadIdx.x, part, ECB_NOISE_PARTS);
 }
 
 // v = a W1 + flip(as W2): the Flipout product pair in either direction.  KC: W1, W2 are given K-contiguously (ecg_load_tile): the
@@ -697,4 +698,438 @@ __device__ __forceinline__ void ecb_gen_dw(const Args &a, const EcbTab &tab, con
     }
   }
   if (u == 0 && g == 0 && o < n_out) adam(woff + 2 * cnt + o, bs, -1);
+}
+
+
+// =============================================================================================
+// Iterative-update steps of CausalBGM with Bayesian nets as row-tile chains (bnn_theta_step_kernel / bnn_z_grad_kernel):
+// update_g_net / update_h_net / update_f_net (causalbgm/base.py:156-243) and update_latent_variable_sgd (:246-302).
+// Calls of the theta step: [0] g, [1] h, [2] f (one noise stream); of the latent step: [0,1] g, [2,3] h, [4,5] f (mean call on the
+// step's stream, variance-head call on stream + 1; a binary treatment head has no variance call).
+// =============================================================================================
+__device__ __forceinline__ float ecb_gauss(float ssq, float raw, float dim, float &loss_b, float &s2) {   // bnn_gauss
+  s2 = softplus_acc(raw) + BGM_EPS;
+  loss_b = ssq / (2.0f * s2) + dim * logf(s2) * 0.5f;
+  return (-ssq / (2.0f * s2 * s2) + dim / (2.0f * s2)) * sigmoid_f(raw);
+}
+// value of feature `f` of a one-row tile set (held by one lane group), in every lane of the row
+template <int NT>
+__device__ __forceinline__ float ecb_pick(const f32x4 (&x)[NT], int f, int g) {
+  float v = 0.0f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v += (16 * t + 4 * g + r == f) ? x[t][r] : 0.0f;
+  return sum_over_g(v);
+}
+// inputs of the three nets from a row of the latent table
+__device__ __forceinline__ void ecb_inputs(const float *zrow, float xv, int q, int z0, int z1, int z2, int g, f32x4 (&zin)[1], f32x4 (&fin)[1],
+                                           f32x4 (&hin)[1]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int f = 4 * g + r;
+    zin[0][r] = ech_ld(zrow, f, q);
+    fin[0][r] = f < z0 + z1 ? ech_ld(zrow, f, q) : (f == z0 + z1 ? xv : 0.0f);
+    const float t = ech_ld(zrow, f < z0 ? f : f + z1, q);
+    hin[0][r] = f < z0 + z2 ? t : 0.0f;
+  }
+}
+
+// sum over this net's kernels (and biases) of KL(q || prior) (bnn_kl, value only), by `nthr` threads
+__device__ __forceinline__ float ecb_kl_value(const float *theta, const BnnNet &n, int t, int nthr) {
+  float acc = 0.0f;
+  const float iv = n.prior_iv, ls = n.prior_logs;
+  for (int l = 0; l < n.n_layers; ++l) {
+    const int cnt = n.lin[l] * n.lout[l];
+    const float *loc = theta + n.woff[l], *rho = loc + cnt;
+    for (int i = t; i < cnt; i += nthr) {
+      const float sg = BNN_SCALE_EPS + softplus_acc(rho[i]), mu = loc[i];
+      acc += -logf(sg) + 0.5f * (sg * sg + mu * mu) * iv - 0.5f + ls;
+    }
+    if (n.bias_prior) {
+      const float *b = rho + cnt;
+      for (int i = t; i < n.lout[l]; i += nthr) acc += 0.5f * b[i] * b[i] * iv + ls + 0.9189385332046727f;
+    }
+  }
+  return acc;
+}
+
+template <class Args, int HT, int NTL, int T1, int T2, int T3, int NB>
+__device__ __forceinline__ void ecb_theta_chain(const Args &a, const EcbTab &tab, float *ws, float *lds) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  const int q = a.q, p = a.p;
+  const int role = wave >> 1, tile = wave & 1;
+  const bool active = tile < NB;
+  const int row = 16 * tile + j;
+  const float *th = a.theta;
+  float *part = lds;                 // [8 waves][4]: loss, aux   | kl partials [128][3] behind
+  float *klp = lds + 64;
+  float ls0 = 0.0f, ls1 = 0.0f;
+  if (role < 3 && active) {
+    const long long prow = a.idx[row];
+    const float xv = a.x_[prow], yv = a.y_[prow];
+    f32x4 zin[1], fin[1], hin[1];
+    ecb_inputs(a.data_z + prow * q, xv, q, a.z0, a.z1, a.z2, g, zin, fin, hin);
+    if (role == 0) {
+      const BnnNet &G = a.net[BNN_G];
+      f32x4 o[NTL];
+      ecb_mlp_fwd<1, HT, NTL>(th, G, tab.c[0], ws, row, zin, o, j, g);
+      const float *vrow = a.v_ + prow * p;
+      float ssq = 0.0f;
+#pragma unroll
+      for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 16 * t + 4 * g + r;
+          const float d = f < p ? ech_ld(vrow, f, p) - o[t][r] : 0.0f;
+          ssq = fmaf(d, d, ssq);
+        }
+      ssq = sum_over_g(ssq);
+      const float raw = ecb_pick<NTL>(o, p, g);
+      float lb, s2;
+      const float dr = ecb_gauss(ssq, raw, (float)p, lb, s2);
+#pragma unroll
+      for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 16 * t + 4 * g + r;
+          o[t][r] = f < p ? -(ech_ld(vrow, f, p) - o[t][r]) / s2 * a.inv_B : (f == p ? dr * a.inv_B : 0.0f);
+        }
+      ls0 = lb; ls1 = ssq;
+      f32x4 dnone[1];
+      ecb_mlp_bwd<1, HT, NTL, false>(th, th, G, tab.c[0], ws, row, tile, o, dnone, j, g);
+    } else {
+      const bool is_h = role == 1;
+      const BnnNet &N = a.net[is_h ? BNN_H : BNN_F];
+      const EcbCall &C = tab.c[is_h ? 1 : 2];
+      f32x4 o[1], d[1], dnone[1];
+      ecb_head_fwd<T1, T2, T3>(th, N, C, ws, row, is_h ? hin : fin, o, j, g);
+      const int wo = N.dims[N.n_layers];
+      const float l = __shfl(o[0][0], j), raw = ecb_pick<1>(o, wo - 1, g), tgt = is_h ? xv : yv;
+      float d0, dl = 0.0f;
+      if (is_h && a.binary) {
+        const float e = fmaxf(l, 0.0f) - l * tgt + log1pf(expf(-fabsf(l)));
+        ls0 = e; ls1 = e;
+        d0 = (sigmoid_f(l) - tgt) * a.inv_B;
+      } else {
+        const float r_ = tgt - l;
+        float lb, s2;
+        const float dr = ecb_gauss(r_ * r_, raw, 1.0f, lb, s2);
+        ls0 = lb; ls1 = r_ * r_;
+        d0 = -r_ / s2 * a.inv_B;
+        dl = dr * a.inv_B;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int f = 4 * g + r; d[0][r] = (f == 0 ? d0 : 0.0f) + (f == wo - 1 ? dl : 0.0f); }
+      ecb_head_bwd<T1, T2, T3>(th, th, N, C, ws, row, tile, d, dnone, j, g);
+    }
+  } else if (role == 3) {
+    const int t = tid - 384;
+    klp[3 * t + 0] = ecb_kl_value(th, a.net[BNN_G], t, 128);
+    klp[3 * t + 1] = ecb_kl_value(th, a.net[BNN_H], t, 128);
+    klp[3 * t + 2] = ecb_kl_value(th, a.net[BNN_F], t, 128);
+  }
+  {
+    const float s0 = sum_over_j_to_lane15(ls0), s1 = sum_over_j_to_lane15(ls1);
+    if (j == 15 && g == 0) { part[wave * 4] = s0; part[wave * 4 + 1] = s1; }
+  }
+  __syncthreads();
+  if (tid < 3 && a.out) {            // which = 0 g, 1 h, 2 f
+    float kl = 0.0f;
+    for (int t = 0; t < 128; ++t) kl += klp[3 * t + tid];
+    float l0 = 0.0f, l1 = 0.0f;
+    for (int w = 2 * tid; w < 2 * tid + NB; ++w) { l0 += part[w * 4]; l1 += part[w * 4 + 1]; }
+    a.out[2 * tid] = l0 * a.inv_B + a.kl_weight * kl;
+    a.out[2 * tid + 1] = tid == 0 ? l1 * a.inv_B / (float)p : l1 * a.inv_B;
+  }
+}
+
+// gradient tiles of the theta step: ecb_gen_dw with one call per net, plus the KL terms of bnn_kl; Adam when a.apply
+template <class Args, int NB>
+__device__ __forceinline__ void ecb_theta_dw(const Args &a, const EcbTab &tab, const int *tiles, const float *ws) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  auto adam = [&](int ei, float gi) {
+    a.grad[ei] = gi;
+    if (a.apply) {
+      const float mi = a.adam.b1 * a.m[ei] + (1.0f - a.adam.b1) * gi;
+      const float vi = a.adam.b2 * a.v[ei] + (1.0f - a.adam.b2) * gi * gi;
+      a.m[ei] = mi; a.v[ei] = vi;
+      a.theta[ei] -= a.adam.lr_t * mi / (sqrtf(vi) + a.adam.eps);
+    }
+  };
+  const int n_tile_blocks = (tab.n_tiles + ECH_WAVES - 1) / ECH_WAVES;
+  if ((int)blockIdx.x == n_tile_blocks) {
+    for (int k = 0; k < 4; ++k) {
+      if (tab.net_ncalls[k] == 0) continue;
+      const BnnNet &n = a.net[k];
+      const int in = n.dims[0], w16 = 16 * tab.kt0[k];
+      for (int f = tid; f < in; f += ECH_THREADS) {
+        float sg = 0.0f, sb = 0.0f;
+        for (int c = 0; c < tab.net_ncalls[k]; ++c) {
+          const float *bp = ws + tab.c[tab.net_calls[k][c]].bnp;
+          for (int t = 0; t < NB; ++t) { sg += bp[t * 2 * w16 + f]; sb += bp[t * 2 * w16 + w16 + f]; }
+        }
+        adam(n.off + f, sg);
+        adam(n.off + in + f, sb);
+      }
+    }
+    return;
+  }
+  const int tau = blockIdx.x * ECH_WAVES + wave;
+  if (tau >= tab.n_tiles) return;
+  const int *td = tiles + tau * ECB_TILE_INTS;
+  const int woff = td[0], n_in = td[1], n_out = td[2], u = td[3], v = td[4], xw = td[5], dw = td[6], ncalls = td[7], net = td[23];
+  const float iv = a.net[net].prior_iv, klw = a.kl_weight;
+  const int bias_prior = a.net[net].bias_prior;
+  const int o = 16 * v + j;
+  f32x4 c1 = {0.0f, 0.0f, 0.0f, 0.0f}, rr = {0.0f, 0.0f, 0.0f, 0.0f};
+  float bs = 0.0f;
+  for (int c = 0; c < ncalls; ++c) {
+    const int xo = td[8 + 5 * c], xso = td[9 + 5 * c], dofs = td[10 + 5 * c], dso = td[11 + 5 * c], eo = td[12 + 5 * c];
+    f32x4 c2 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int s4 = 0; s4 < NB * 4; ++s4) {
+      const int r_ = 4 * s4 + g;
+      const float dv = ws[dofs + r_ * dw + o];
+      c1 = BGM_MFMA(ws[xo + r_ * xw + 16 * u + j], dv, c1);
+      c2 = BGM_MFMA(ws[xso + r_ * xw + 16 * u + j], ws[dso + r_ * dw + o], c2);
+      bs += dv;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = min(16 * u + 4 * g + r, n_in - 1);
+      rr[r] = fmaf(c2[r], ws[eo + f * n_out + min(o, n_out - 1)], rr[r]);
+    }
+  }
+  bs = sum_over_g(bs);
+  const int cnt = n_in * n_out;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int f = 16 * u + 4 * g + r;
+    if (f < n_in && o < n_out) {
+      const int t = f * n_out + o;
+      const float mu = a.theta[woff + t], rho_ = a.theta[woff + cnt + t];
+      const float sg = BNN_SCALE_EPS + softplus_acc(rho_), sgm = sigmoid_f(rho_);
+      adam(woff + t, c1[r] + klw * mu * iv);
+      adam(woff + cnt + t, rr[r] / sg * sgm + klw * (-1.0f / sg + sg * iv) * sgm);
+    }
+  }
+  if (u == 0 && g == 0 && o < n_out) {
+    const float b = a.theta[woff + 2 * cnt + o];
+    adam(woff + 2 * cnt + o, bs + (bias_prior ? klw * b * iv : 0.0f));
+  }
+}
+
+// latent step: dz [B x q] = d loss / d (batch rows of data_z), out[0] = loss_postrior_z.  Waves 0,1: g mean call; 2,3: g variance-head
+// call (they exchange the row's sum of squares and raw variance through LDS); 4,5: h (both calls); 6,7: f (both calls).
+template <class Args, int HT, int NTL, int T1, int T2, int T3, int NB>
+__device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, float *ws, float *lds) {
+  constexpr int B = 16 * NB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  const int q = a.q, p = a.p, z0 = a.z0, z1 = a.z1, z2 = a.z2;
+  const int role = wave >> 1, tile = wave & 1;
+  const bool active = tile < NB;
+  const int row = 16 * tile + j;
+  const float *th = a.theta;
+  float *part = lds;                                   // [8 waves] loss partials
+  volatile int *flag = reinterpret_cast<volatile int *>(lds + 16);    // [0 + tile]: ssq written; [2 + tile]: raw written
+  float *xch = lds + 32;                               // [B] ssq | [B] raw of the g calls
+  float *dzc = lds + 32 + 2 * B;                       // [4 roles][B x 16] input gradients
+  if (tid < 16) flag[tid] = 0;
+  __syncthreads();
+  float lsum = 0.0f;
+  if (active) {
+    const long long prow = a.idx[row];
+    const float xv = a.x_[prow], yv = a.y_[prow];
+    const float *zrow = a.data_z + prow * q;
+    f32x4 zin[1], fin[1], hin[1], dx[1];
+    ecb_inputs(zrow, xv, q, z0, z1, z2, g, zin, fin, hin);
+    ech_zero<1>(dx);
+    if (role == 0) {
+      const BnnNet &G = a.net[BNN_G];
+      f32x4 o[NTL];
+      ecb_mlp_fwd<1, HT, NTL>(th, G, tab.c[0], ws, row, zin, o, j, g);
+      const float *vrow = a.v_ + prow * p;
+      float ssq = 0.0f;
+#pragma unroll
+      for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 16 * t + 4 * g + r;
+          const float d = f < p ? ech_ld(vrow, f, p) - o[t][r] : 0.0f;
+          ssq = fmaf(d, d, ssq);
+          o[t][r] = d;
+        }
+      ssq = sum_over_g(ssq);
+      if (g == 0) xch[row] = ssq;
+      __threadfence_block();
+      if (lane == 0) flag[tile] = 1;
+      while (flag[2 + tile] == 0) __builtin_amdgcn_s_sleep(2);
+      __threadfence_block();
+      const float raw = xch[B + row];
+      float lb, s2;
+      ecb_gauss(ssq, raw, (float)p, lb, s2);
+      lsum = lb;
+#pragma unroll
+      for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[t][r] = (16 * t + 4 * g + r < p) ? -o[t][r] / s2 * a.inv_B : 0.0f;
+      ecb_mlp_bwd<1, HT, NTL, true>(th, th, G, tab.c[0], ws, row, tile, o, dx, j, g);
+    } else if (role == 1) {
+      const BnnNet &G = a.net[BNN_G];
+      f32x4 o[NTL];
+      ecb_mlp_fwd<1, HT, NTL>(th, G, tab.c[1], ws, row, zin, o, j, g);
+      const float raw = ecb_pick<NTL>(o, p, g);
+      if (g == 0) xch[B + row] = raw;
+      __threadfence_block();
+      if (lane == 0) flag[2 + tile] = 1;
+      while (flag[tile] == 0) __builtin_amdgcn_s_sleep(2);
+      __threadfence_block();
+      const float ssq = xch[row];
+      float lb, s2;
+      const float dr = ecb_gauss(ssq, raw, (float)p, lb, s2);
+#pragma unroll
+      for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[t][r] = (16 * t + 4 * g + r == p) ? dr * a.inv_B : 0.0f;
+      ecb_mlp_bwd<1, HT, NTL, true>(th, th, G, tab.c[1], ws, row, tile, o, dx, j, g);
+    } else {
+      const bool is_h = role == 2;
+      const BnnNet &N = a.net[is_h ? BNN_H : BNN_F];
+      const int c0 = is_h ? 2 : 4;
+      const bool two = !(is_h && a.binary);
+      f32x4 o1[1], o2[1], d[1], dx2[1];
+      ecb_head_fwd<T1, T2, T3>(th, N, tab.c[c0], ws, row, is_h ? hin : fin, o1, j, g);
+      if (two) ecb_head_fwd<T1, T2, T3>(th, N, tab.c[c0 + 1], ws, row, is_h ? hin : fin, o2, j, g);
+      const int wo = N.dims[N.n_layers];
+      const float l = __shfl(o1[0][0], j), tgt = is_h ? xv : yv;
+      float d0, dl = 0.0f;
+      if (!two) {
+        lsum = fmaxf(l, 0.0f) - l * tgt + log1pf(expf(-fabsf(l)));
+        d0 = (sigmoid_f(l) - tgt) * a.inv_B;
+      } else {
+        const float raw = ecb_pick<1>(o2, wo - 1, g), r_ = tgt - l;
+        float lb, s2;
+        const float dr = ecb_gauss(r_ * r_, raw, 1.0f, lb, s2);
+        lsum = lb;
+        d0 = -r_ / s2 * a.inv_B;
+        dl = dr * a.inv_B;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d[0][r] = (4 * g + r == 0) ? d0 : 0.0f;
+      ecb_head_bwd<T1, T2, T3>(th, th, N, tab.c[c0], ws, row, tile, d, dx, j, g);
+      if (two) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[0][r] = (4 * g + r == wo - 1) ? dl : 0.0f;
+        ecb_head_bwd<T1, T2, T3>(th, th, N, tab.c[c0 + 1], ws, row, tile, d, dx2, j, g);
+        dx[0] += dx2[0];
+      }
+    }
+    *reinterpret_cast<f32x4 *>(dzc + (role * B + row) * 16 + 4 * g) = dx[0];
+    if (role == 0) {            // the prior term of the row
+      float zz = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) zz = fmaf(zin[0][r], zin[0][r], zz);
+      lsum += 0.5f * sum_over_g(zz);
+    }
+  }
+  {
+    const float s0 = sum_over_j_to_lane15(lsum);
+    if (j == 15 && g == 0) part[wave] = s0;
+  }
+  __syncthreads();
+  for (int i = tid; i < B * q; i += ECH_THREADS) {
+    const int b = i / q, col = i - b * q;
+    float v = a.data_z[(long long)a.idx[b] * q + col] * a.inv_B + dzc[(0 * B + b) * 16 + col] + dzc[(1 * B + b) * 16 + col];
+    if (col < z0 + z1) v += dzc[(3 * B + b) * 16 + col];                                  // f: (z0, z1, x)
+    if (col < z0) v += dzc[(2 * B + b) * 16 + col];                                       // h: (z0, z2)
+    else if (col >= z0 + z1 && col < z0 + z1 + z2) v += dzc[(2 * B + b) * 16 + col - z1];
+    a.dz[i] = v;
+  }
+  if (tid == 0 && a.out) {
+    float t = 0.0f;
+    for (int w = 0; w < 8; ++w) if ((w & 1) < NB) t += part[w];
+    a.out[0] = t * a.inv_B;
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// host: workspace layout of a list of calls + the gradient-tile table (shared by the EGM and the iterative-update steps)
+// ---------------------------------------------------------------------------------------------
+#include <vector>
+// Returns the workspace floats used.  tile_nets: the nets whose parameters the step trains (tiles are emitted for them).
+inline size_t ecb_build_tab(const BnnNet *nets, const int *call_net, const int *call_soff, int n_calls, int B, int ntl, EcbTab &tab,
+                            std::vector<int> &tiles, const int *tile_nets, int n_tile_nets) {
+  auto tl = [](int n) { return (n + 15) / 16; };
+  size_t off = 0;
+  auto take = [&](size_t n) { const size_t r = off; off += (n + 3) / 4 * 4; return (int)r; };
+  const int NBt = (B + 15) / 16;
+  for (int k = 0; k < 4; ++k) { tab.net_ncalls[k] = 0; tab.kt0[k] = k == BNN_E ? ntl : 1; }
+  int xw[ECB_CALLS][BNN_MAX_LAYERS], dw[ECB_CALLS][BNN_MAX_LAYERS];
+  for (int c = 0; c < n_calls; ++c) {
+    const BnnNet &m = nets[call_net[c]];
+    EcbCall &C = tab.c[c];
+    C.net = call_net[c];
+    C.soff = call_soff[c];
+    tab.net_calls[C.net][tab.net_ncalls[C.net]++] = c;
+    const size_t E_ = (size_t)m.eoff[m.n_layers];
+    C.eps = 0; C.dWT = 0;
+    C.dW = take(E_ + 16);
+    C.sg = take((size_t)B * m.swords);
+    const int kt0 = tab.kt0[C.net];
+    C.xh = take((size_t)B * 16 * kt0);
+    C.bnp = take((size_t)NBt * 2 * 16 * kt0);
+    for (int l = 0; l < m.n_layers; ++l) {
+      xw[c][l] = 16 * tl(m.dims[l]); dw[c][l] = 16 * tl(m.dims[l + 1]);
+      if (C.net == BNN_E && l == 0) xw[c][l] = 16 * ntl;
+      if (C.net == BNN_G && l == m.n_layers - 1) dw[c][l] = 16 * ntl;
+      C.x[l] = take((size_t)B * xw[c][l]); C.xs[l] = take((size_t)B * xw[c][l]);
+      C.d[l] = take((size_t)B * dw[c][l]); C.ds[l] = take((size_t)B * dw[c][l]);
+    }
+  }
+  tiles.clear();
+  for (int kk = 0; kk < n_tile_nets; ++kk) {
+    const int k = tile_nets[kk];
+    const BnnNet &m = nets[k];
+    if (tab.net_ncalls[k] == 0) continue;
+    for (int l = 0; l < m.n_layers; ++l) {
+      const int ni = m.dims[l], no = m.dims[l + 1], c0 = tab.net_calls[k][0];
+      for (int u = 0; u < tl(ni); ++u)
+        for (int v = 0; v < tl(no); ++v) {
+          int en[ECB_TILE_INTS] = {m.woff[l], ni, no, u, v, xw[c0][l], dw[c0][l], tab.net_ncalls[k]};
+          for (int c = 0; c < tab.net_ncalls[k]; ++c) {
+            const EcbCall &C = tab.c[tab.net_calls[k][c]];
+            en[8 + 5 * c] = C.x[l]; en[9 + 5 * c] = C.xs[l]; en[10 + 5 * c] = C.d[l]; en[11 + 5 * c] = C.ds[l]; en[12 + 5 * c] = C.dW + m.eoff[l];
+          }
+          en[23] = k;
+          tiles.insert(tiles.end(), en, en + ECB_TILE_INTS);
+        }
+    }
+  }
+  tab.n_tiles = (int)(tiles.size() / ECB_TILE_INTS);
+  return off + 64;
+}
+// shapes the row-tile chains are compiled for
+inline bool ecb_shapes_ok(const BnnNet *nets, int q, int p, bool need_e) {
+  bool ok = q <= 16;
+  const int ntl = (p + 1 + 15) / 16;
+  ok = ok && (ntl == 13 || ntl == 7);
+  for (int k = 0; k < 4; ++k) {
+    if (k == BNN_E && !need_e) continue;
+    ok = ok && nets[k].bn_fixed == 1 && !nets[k].heads && !nets[k].mv;
+  }
+  const BnnNet &G = nets[BNN_G], &E = nets[BNN_E];
+  ok = ok && G.n_layers >= 3 && G.dims[0] == q && G.dims[G.n_layers] == p + 1;
+  for (int l = 1; l < G.n_layers; ++l) ok = ok && G.dims[l] == 64;
+  if (need_e) {
+    ok = ok && E.n_layers >= 3 && E.dims[E.n_layers] == q && E.dims[0] == p;
+    for (int l = 1; l < E.n_layers; ++l) ok = ok && E.dims[l] == 64;
+  }
+  for (int k : {BNN_F, BNN_H}) {
+    const BnnNet &m = nets[k];
+    ok = ok && m.n_layers == 4 && m.dims[0] <= 16 && m.dims[1] == 64 && m.dims[2] == 32 && m.dims[3] >= 1 && m.dims[3] <= 16 && m.dims[4] >= 1 &&
+         m.dims[4] <= 16;
+  }
+  return ok;
 }

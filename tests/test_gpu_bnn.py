@@ -8,8 +8,13 @@ from oracle import bnn as OB
 pytestmark = pytest.mark.gpu
 
 
-def _model(binary, z_dims=(1, 1, 1, 7), p=50, seed=0, **units):
+def _model(binary, z_dims=(1, 1, 1, 7), p=50, seed=0, fixed=False, **units):
+    """fixed=True: inference-mode input normalisation (the models' default); at p = 100 / 200 with the default units the minibatch
+    steps then run as row-tile chains (egm_chain_bnn.h)."""
     m = OB.init_model(seed, list(z_dims), p, binary, **units)
+    if fixed:
+        for k in ("g", "e", "f", "h"):
+            m[k]["norm"] = "fixed"
     rs = np.random.RandomState(seed + 11)
     for k in ("g", "e", "f", "h"):
         m[k]["gamma"] = (1.0 + 0.2 * rs.standard_normal(m[k]["gamma"].shape)).astype(np.float32)
@@ -38,15 +43,17 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
-@pytest.mark.parametrize("binary,B,units", [
-    (False, 32, {}),
-    (True, 32, {}),
-    (False, 19, dict(g_units=(24, 40), e_units=(16,), f_units=(20, 12), h_units=(9, 5))),
+@pytest.mark.parametrize("binary,B,units,p", [
+    (False, 32, {}, 50),
+    (True, 32, {}, 50),
+    (False, 19, dict(g_units=(24, 40), e_units=(16,), f_units=(20, 12), h_units=(9, 5)), 37),
+    (False, 32, {}, 200), (True, 32, {}, 100), (False, 16, {}, 100),       # row-tile chains
 ])
-def test_theta_step_gradients_match_oracle(binary, B, units):
-    m = _model(binary, p=50 if not units else 37, **units)
+def test_theta_step_gradients_match_oracle(binary, B, units, p):
+    chain = p >= 100
+    m = _model(binary, p=p, fixed=chain, **units)
     z, x, y, v = _panel(m, 200)
-    eng = _engine(m, kl_weight=0.01, **units)
+    eng = _engine(m, kl_weight=0.01, **(dict(norm_mode=1) if chain else {}), **units)
     dev = eng.device
     rs = np.random.RandomState(4)
     idx = rs.choice(200, B, replace=False).astype(np.int32)
@@ -70,13 +77,13 @@ def test_theta_step_gradients_match_oracle(binary, B, units):
     eng.close()
 
 
-@pytest.mark.parametrize("binary", [False, True])
-def test_z_step_gradient_matches_oracle(binary):
-    m = _model(binary, p=50)
+@pytest.mark.parametrize("binary,p,B", [(False, 50, 32), (True, 50, 32), (False, 200, 32), (True, 100, 32), (False, 100, 16)])
+def test_z_step_gradient_matches_oracle(binary, p, B):
+    chain = p >= 100
+    m = _model(binary, p=p, fixed=chain)
     z, x, y, v = _panel(m, 100)
-    eng = _engine(m)
+    eng = _engine(m, norm_mode=1) if chain else _engine(m)
     dev = eng.device
-    B = 32
     idx = np.random.RandomState(9).choice(100, B, replace=False).astype(np.int32)
     seed, stream = 123456789, 40
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -93,13 +100,16 @@ def test_z_step_gradient_matches_oracle(binary):
     eng.close()
 
 
-def test_steps_apply_adam_like_oracle():
-    """Three full minibatch iterations (theta step + latent step, dense-decay Adam on the table) track the oracle."""
+@pytest.mark.parametrize("p", [50, 100])
+def test_steps_apply_adam_like_oracle(p):
+    """Three full minibatch iterations (theta step + latent step, dense-decay Adam on the table) track the oracle
+    (p = 100 with inference-mode input normalisation: the row-tile-chain kernels)."""
     from oracle.fit import AdamState, adam_lr_t
-    m = _model(False, p=50)
+    chain = p >= 100
+    m = _model(False, p=p, fixed=chain)
     n, B = 64, 32
     z, x, y, v = _panel(m, n)
-    eng = _engine(m)
+    eng = _engine(m, norm_mode=1) if chain else _engine(m)
     dev = eng.device
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     dz_t, zm, zv = T(z), torch.zeros(n, z.shape[1], device=dev), torch.zeros(n, z.shape[1], device=dev)
