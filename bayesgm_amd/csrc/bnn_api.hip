@@ -17,7 +17,15 @@ struct BnnFitChain {
   int *tiles_theta = nullptr;
   float *ws = nullptr;
 };
-static __global__ __launch_bounds__(BNN_THREADS) void bnn_fit_noise_kernel(BnnArgs a, const EcbTab *tab, float *ws) { ecb_gen_noise<BnnArgs>(a, *tab, ws); }
+template <bool KL>
+static __global__ __launch_bounds__(BNN_THREADS) void bnn_fit_noise_kernel(BnnArgs a, const EcbTab *tab, float *ws) {
+  __shared__ float red[16];
+  ecb_gen_noise<BnnArgs>(a, *tab, ws);
+  if (KL) {     // theta step: the value of the KL term, summed by the chain kernel (one call per net there)
+    const int c = blockIdx.x / ECB_NOISE_PARTS, part = blockIdx.x % ECB_NOISE_PARTS;
+    ecb_kl_partial(a.theta, a.net[tab->c[c].net], ws + tab->klp + blockIdx.x, part, ECB_NOISE_PARTS, red);
+  }
+}
 template <int NTL, int NB>
 static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_chain_kernel(BnnArgs a, const EcbTab *tab, float *ws) {
   extern __shared__ __attribute__((aligned(16))) float bnn_chain_lds[];
@@ -49,7 +57,8 @@ static int bnn_chain_setup(BnnState *s) {
   EcbTab tt{}, tz{};
   std::vector<int> tiles, none;
   const int tnet[3] = {BNN_G, BNN_H, BNN_F}, tso[3] = {0, 0, 0}, trained[3] = {BNN_G, BNN_H, BNN_F};
-  const size_t w1 = ecb_build_tab(s->net, tnet, tso, 3, B, ntl, tt, tiles, trained, 3);
+  size_t w1 = ecb_build_tab(s->net, tnet, tso, 3, B, ntl, tt, tiles, trained, 3);
+  tt.klp = (int)w1; w1 += 3 * ECB_NOISE_PARTS + 16;
   const int znet[6] = {BNN_G, BNN_G, BNN_H, BNN_H, BNN_F, BNN_F}, zso[6] = {0, 1, 0, 1, 0, 1};
   const size_t w2 = ecb_build_tab(s->net, znet, zso, 6, B, ntl, tz, none, trained, 0);
   c->n_tiles = tt.n_tiles;
@@ -244,10 +253,10 @@ extern "C" int bgm_bnn_theta_step(bgm_handle *h, const float *data_z, const int3
   BnnFitChain *fc = static_cast<BnnFitChain *>(s->chain);
   if (fc && (batch == 16 || batch == 32)) {
     hipStream_t st = (hipStream_t)stream_;
-    hipLaunchKernelGGL(bnn_fit_noise_kernel, dim3(3 * ECB_NOISE_PARTS), dim3(BNN_THREADS), 0, st, a, fc->tab_theta, fc->ws);
+    hipLaunchKernelGGL(bnn_fit_noise_kernel<true>, dim3(3 * ECB_NOISE_PARTS), dim3(BNN_THREADS), 0, st, a, fc->tab_theta, fc->ws);
     auto kc = batch == 32 ? (fc->ntl == 13 ? bnn_theta_chain_kernel<13, 2> : bnn_theta_chain_kernel<7, 2>)
                           : (fc->ntl == 13 ? bnn_theta_chain_kernel<13, 1> : bnn_theta_chain_kernel<7, 1>);
-    hipLaunchKernelGGL(kc, dim3(1), dim3(BNN_THREADS), (64 + 3 * 128) * sizeof(float), st, a, fc->tab_theta, fc->ws);
+    hipLaunchKernelGGL(kc, dim3(1), dim3(BNN_THREADS), 64 * sizeof(float), st, a, fc->tab_theta, fc->ws);
     auto kd = batch == 32 ? bnn_theta_dw_kernel<2> : bnn_theta_dw_kernel<1>;
     hipLaunchKernelGGL(kd, dim3((fc->n_tiles + ECH_WAVES - 1) / ECH_WAVES + 1), dim3(BNN_THREADS), 0, st, a, fc->tab_theta, fc->tiles_theta, fc->ws);
   } else {
@@ -292,7 +301,7 @@ extern "C" int bgm_bnn_z_step(bgm_handle *h, const float *x, const float *y, con
   a.out = out; a.dz = dz_out ? dz_out : s->dz_dev;
   BnnFitChain *fc = static_cast<BnnFitChain *>(s->chain);
   if (fc && (batch == 16 || batch == 32)) {
-    hipLaunchKernelGGL(bnn_fit_noise_kernel, dim3(6 * ECB_NOISE_PARTS), dim3(BNN_THREADS), 0, stream, a, fc->tab_z, fc->ws);
+    hipLaunchKernelGGL(bnn_fit_noise_kernel<false>, dim3(6 * ECB_NOISE_PARTS), dim3(BNN_THREADS), 0, stream, a, fc->tab_z, fc->ws);
     auto kc = batch == 32 ? (fc->ntl == 13 ? bnn_z_chain_kernel<13, 2> : bnn_z_chain_kernel<7, 2>)
                           : (fc->ntl == 13 ? bnn_z_chain_kernel<13, 1> : bnn_z_chain_kernel<7, 1>);
     hipLaunchKernelGGL(kc, dim3(1), dim3(BNN_THREADS), (32 + 2 * batch + 4 * 16 * batch) * sizeof(float), stream, a, fc->tab_z, fc->ws);

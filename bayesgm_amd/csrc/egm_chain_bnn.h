@@ -117,6 +117,7 @@ struct EcbTab {
   int kt0[4];                            // input tiles of the four nets
   int net_ncalls[4], net_calls[4][3];
   int n_warm;
+  int klp;                               // theta step: per-workgroup KL partial sums of the noise launch, [n_calls][ECB_NOISE_PARTS]
 };
 
 // dW = sigma * eps and the sign words of one call (bnn_noise; eps itself is not stored: the gradient kernel recovers it as dW / sigma).
@@ -147,6 +148,34 @@ __device__ __forceinline__ void ecb_noise(const float *theta, const BnnNet &n, c
   }
 }
 #define ECB_NOISE_PARTS 16
+// sum over this net's kernels (and biases) of KL(q || prior) (bnn_kl, value only), by `nthr` threads
+__device__ __forceinline__ float ecb_kl_value(const float *theta, const BnnNet &n, int t, int nthr) {
+  float acc = 0.0f;
+  const float iv = n.prior_iv, ls = n.prior_logs;
+  for (int l = 0; l < n.n_layers; ++l) {
+    const int cnt = n.lin[l] * n.lout[l];
+    const float *loc = theta + n.woff[l], *rho = loc + cnt;
+    for (int i = t; i < cnt; i += nthr) {
+      const float sg = BNN_SCALE_EPS + softplus_acc(rho[i]), mu = loc[i];
+      acc += -logf(sg) + 0.5f * (sg * sg + mu * mu) * iv - 0.5f + ls;
+    }
+    if (n.bias_prior) {
+      const float *b = rho + cnt;
+      for (int i = t; i < n.lout[l]; i += nthr) acc += 0.5f * b[i] * b[i] * iv + ls + 0.9189385332046727f;
+    }
+  }
+  return acc;
+}
+
+// KL(q || prior) of the slice of the call's net this workgroup visits (bnn_kl, value only) -> ws[klp + blockIdx.x]; fixed order.
+__device__ __forceinline__ void ecb_kl_partial(const float *theta, const BnnNet &n, float *dst, int part, int parts, float *red) {
+  const int tid = threadIdx.x;
+  float acc = ecb_kl_value(theta, n, part * BNN_THREADS + tid, parts * BNN_THREADS);
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) { float t = 0.0f; for (int w = 0; w < BNN_THREADS / 64; ++w) t += red[w]; *dst = t; }
+}
 template <class Args>
 __device__ __forceinline__ void ecb_gen_noise(const Args &a, const EcbTab &tab, float *ws_) {      // grid: n_calls * ECB_NOISE_PARTS workgroups
   const int c = blockIdx.x / ECB_NOISE_PARTS, part = blockIdx.x % ECB_NOISE_PARTS;
@@ -735,25 +764,6 @@ __device__ __forceinline__ void ecb_inputs(const float *zrow, float xv, int q, i
   }
 }
 
-// sum over this net's kernels (and biases) of KL(q || prior) (bnn_kl, value only), by `nthr` threads
-__device__ __forceinline__ float ecb_kl_value(const float *theta, const BnnNet &n, int t, int nthr) {
-  float acc = 0.0f;
-  const float iv = n.prior_iv, ls = n.prior_logs;
-  for (int l = 0; l < n.n_layers; ++l) {
-    const int cnt = n.lin[l] * n.lout[l];
-    const float *loc = theta + n.woff[l], *rho = loc + cnt;
-    for (int i = t; i < cnt; i += nthr) {
-      const float sg = BNN_SCALE_EPS + softplus_acc(rho[i]), mu = loc[i];
-      acc += -logf(sg) + 0.5f * (sg * sg + mu * mu) * iv - 0.5f + ls;
-    }
-    if (n.bias_prior) {
-      const float *b = rho + cnt;
-      for (int i = t; i < n.lout[l]; i += nthr) acc += 0.5f * b[i] * b[i] * iv + ls + 0.9189385332046727f;
-    }
-  }
-  return acc;
-}
-
 template <class Args, int HT, int NTL, int T1, int T2, int T3, int NB>
 __device__ __forceinline__ void ecb_theta_chain(const Args &a, const EcbTab &tab, float *ws, float *lds) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
@@ -762,8 +772,7 @@ __device__ __forceinline__ void ecb_theta_chain(const Args &a, const EcbTab &tab
   const bool active = tile < NB;
   const int row = 16 * tile + j;
   const float *th = a.theta;
-  float *part = lds;                 // [8 waves][4]: loss, aux   | kl partials [128][3] behind
-  float *klp = lds + 64;
+  float *part = lds;                 // [8 waves][4]: loss, aux
   float ls0 = 0.0f, ls1 = 0.0f;
   if (role < 3 && active) {
     const long long prow = a.idx[row];
@@ -823,11 +832,6 @@ __device__ __forceinline__ void ecb_theta_chain(const Args &a, const EcbTab &tab
       for (int r = 0; r < 4; ++r) { const int f = 4 * g + r; d[0][r] = (f == 0 ? d0 : 0.0f) + (f == wo - 1 ? dl : 0.0f); }
       ecb_head_bwd<T1, T2, T3>(th, th, N, C, ws, row, tile, d, dnone, j, g);
     }
-  } else if (role == 3) {
-    const int t = tid - 384;
-    klp[3 * t + 0] = ecb_kl_value(th, a.net[BNN_G], t, 128);
-    klp[3 * t + 1] = ecb_kl_value(th, a.net[BNN_H], t, 128);
-    klp[3 * t + 2] = ecb_kl_value(th, a.net[BNN_F], t, 128);
   }
   {
     const float s0 = sum_over_j_to_lane15(ls0), s1 = sum_over_j_to_lane15(ls1);
@@ -835,8 +839,8 @@ __device__ __forceinline__ void ecb_theta_chain(const Args &a, const EcbTab &tab
   }
   __syncthreads();
   if (tid < 3 && a.out) {            // which = 0 g, 1 h, 2 f
-    float kl = 0.0f;
-    for (int t = 0; t < 128; ++t) kl += klp[3 * t + tid];
+    float kl = 0.0f;             // call tid of the theta step is net which = tid; its KL partials come from the noise launch
+    for (int t = 0; t < ECB_NOISE_PARTS; ++t) kl += ws[tab.klp + tid * ECB_NOISE_PARTS + t];
     float l0 = 0.0f, l1 = 0.0f;
     for (int w = 2 * tid; w < 2 * tid + NB; ++w) { l0 += part[w * 4]; l1 += part[w * 4 + 1]; }
     a.out[2 * tid] = l0 * a.inv_B + a.kl_weight * kl;
