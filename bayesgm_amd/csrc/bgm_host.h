@@ -72,6 +72,7 @@ struct bgm_handle {
   bool eblob_valid = false;
   // fit state (device)
   bool fit_active = false;
+  void *fit_chain = nullptr;     // FitChainState (fit_api.hip): row-tile-chain step kernels at B = 16 / 32, or NULL
   long long fit_rows = 0;
   int fit_bcap = 0, n_params = 0, n_slices_cap = 0, rows_per_slice = 0;
   long long t_theta = 0, t_z = 0;

@@ -6,6 +6,109 @@
 
 #include "bgm_host.h"
 #include "fit_kernels.h"
+#include "fit_chain.h"
+
+#include <cstdlib>
+#include <vector>
+
+// ---- row-tile-chain step kernels (fit_chain.h) for the reference batch sizes
+struct FitChainState {
+  FitChainArgs base{};
+  int ntl = 0;
+  float *thetaT = nullptr, *ws = nullptr;
+  int *tiles = nullptr, *mirror_dst = nullptr;
+};
+static void fit_chain_free(bgm_handle *h) {
+  FitChainState *c = static_cast<FitChainState *>(h->fit_chain);
+  if (!c) return;
+  for (void *p : {(void *)c->thetaT, (void *)c->ws, (void *)c->tiles, (void *)c->mirror_dst})
+    if (p) hipFree(p);
+  delete c;
+  h->fit_chain = nullptr;
+}
+static bool fit_fill_mlp(const HostNet &n, EgmMlp &m, int off) {
+  const int L = (int)n.dims.size() - 1;
+  if (L < 1 || L > EGM_MAX_LAYERS) return false;
+  m.n_layers = L;
+  for (int i = 0; i <= L; ++i) m.dims[i] = n.dims[i];
+  m.off = off;
+  egm_finish_mlp(m);
+  return true;
+}
+// called at the end of bgm_causal_fit_begin (theta_dev holds [g | f | h])
+static int fit_chain_setup(bgm_handle *h, const std::vector<float> &theta) {
+  const HostNet &G = h->nets[BGM_NET_G], &F = h->nets[BGM_NET_F], &H = h->nets[BGM_NET_H];
+  const int ng = (int)G.count(), nf = (int)F.count(), np = h->n_params, q = h->q, p = h->p;
+  const int ntl = (p + 1 + 15) / 16;
+  FitChainArgs a{};
+  bool ok = !std::getenv("BGM_FIT_NO_CHAIN") && q <= 16 && (ntl == 13 || ntl == 7) && fit_fill_mlp(G, a.g, 0) && fit_fill_mlp(F, a.f, ng) &&
+            fit_fill_mlp(H, a.h, ng + nf);
+  ok = ok && a.g.n_layers >= 3 && a.g.dims[0] == q && a.g.dims[a.g.n_layers] == p + 1;
+  for (int l = 1; ok && l < a.g.n_layers; ++l) ok = a.g.dims[l] == 64;
+  for (const EgmMlp *m : {&a.f, &a.h})
+    ok = ok && m->n_layers == 4 && m->dims[0] <= 16 && m->dims[1] == 64 && m->dims[2] == 32 && m->dims[3] >= 1 && m->dims[3] <= 16 && m->dims[4] == 2;
+  if (!ok) return BGM_OK;
+  FitChainState *c = new FitChainState();
+  h->fit_chain = c;
+  c->ntl = ntl;
+  const int B = 32;
+  auto tl = [](int n) { return (n + 15) / 16; };
+  size_t off = 0;
+  auto take = [&](size_t n) { const size_t r = off; off += (n + 3) / 4 * 4; return (int)r; };
+  const EgmMlp *nets[3] = {&a.g, &a.f, &a.h};
+  int xw[3][EGM_MAX_LAYERS], dw[3][EGM_MAX_LAYERS];
+  std::vector<int> tiles, mdst(np, -1);
+  std::vector<float> tT((size_t)np + 64, 0.0f);
+  for (int k = 0; k < 3; ++k) {
+    const EgmMlp &m = *nets[k];
+    for (int l = 0; l < m.n_layers; ++l) {
+      xw[k][l] = 16 * tl(m.dims[l]); dw[k][l] = 16 * tl(m.dims[l + 1]);
+      if (k == 0 && l == m.n_layers - 1) dw[k][l] = 16 * ntl;
+      a.xo[k][l] = take((size_t)B * xw[k][l]); a.dofs[k][l] = take((size_t)B * dw[k][l]);
+    }
+    for (int l = 0; l < m.n_layers; ++l) {
+      const int ni = m.dims[l], no = m.dims[l + 1];
+      for (int f = 0; f < ni; ++f)
+        for (int o = 0; o < no; ++o) {
+          mdst[m.woff[l] + f * no + o] = m.woff[l] + o * ni + f;
+          tT[m.woff[l] + (size_t)o * ni + f] = theta[m.woff[l] + (size_t)f * no + o];
+        }
+      for (int u = 0; u < tl(ni); ++u)
+        for (int v = 0; v < tl(no); ++v) {
+          int e[ECG_TILE_INTS] = {a.xo[k][l], -1, a.dofs[k][l], -1, xw[k][l], dw[k][l], u, v, m.woff[l], ni, no, u == 0 ? m.woff[l] + ni * no : -1, 0, 0, 0, 0};
+          tiles.insert(tiles.end(), e, e + ECG_TILE_INTS);
+        }
+    }
+  }
+  a.n_tiles = (int)(tiles.size() / ECG_TILE_INTS);
+  BGM_HIP_CHECK(hipMalloc((void **)&c->ws, sizeof(float) * (off + 64)));
+  BGM_HIP_CHECK(hipMemset(c->ws, 0, sizeof(float) * (off + 64)));
+  BGM_HIP_CHECK(hipMalloc((void **)&c->thetaT, sizeof(float) * tT.size()));
+  BGM_HIP_CHECK(hipMemcpy(c->thetaT, tT.data(), sizeof(float) * tT.size(), hipMemcpyHostToDevice));
+  BGM_HIP_CHECK(hipMalloc((void **)&c->tiles, sizeof(int) * tiles.size()));
+  BGM_HIP_CHECK(hipMemcpy(c->tiles, tiles.data(), sizeof(int) * tiles.size(), hipMemcpyHostToDevice));
+  BGM_HIP_CHECK(hipMalloc((void **)&c->mirror_dst, sizeof(int) * np));
+  BGM_HIP_CHECK(hipMemcpy(c->mirror_dst, mdst.data(), sizeof(int) * np, hipMemcpyHostToDevice));
+  a.theta = h->theta_dev; a.thetaT = c->thetaT; a.ws = c->ws; a.tiles = c->tiles;
+  a.q = q; a.p = p; a.z0 = h->cfg.z_dims[0]; a.z1 = h->cfg.z_dims[1]; a.z2 = h->cfg.z_dims[2];
+  a.binary = h->cfg.binary_treatment;
+  a.sig2_v = h->meta.sig2_v; a.sig2_x = h->meta.sig2_x; a.sig2_y = h->meta.sig2_y;
+  c->base = a;
+  return BGM_OK;
+}
+// one launch of the chains; Z_MODE 0 also the gradient tiles into `grad`
+static void fit_chain_launch(const FitChainState *c, FitChainArgs &a, int batch, int z_mode, hipStream_t stream) {
+#define FC(NTL_, NB_) \
+  if (c->ntl == NTL_ && batch == 16 * NB_) { \
+    if (z_mode) hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, NB_, 1>), dim3(1), dim3(ECH_THREADS), 0, stream, a); \
+    else { \
+      hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, NB_, 0>), dim3(1), dim3(ECH_THREADS), 0, stream, a); \
+      hipLaunchKernelGGL(fit_chain_dw_kernel<NB_>, dim3((a.n_tiles + ECH_WAVES - 1) / ECH_WAVES), dim3(ECH_THREADS), 0, stream, a); \
+    } \
+  }
+  FC(13, 2) FC(13, 1) FC(7, 2) FC(7, 1)
+#undef FC
+}
 
 static constexpr int FIT_WAVES = 8;
 static constexpr float ADAM_B1 = 0.9f, ADAM_B2 = 0.99f, ADAM_EPS = 1e-7f;  // causalbgm/base.py:90-93
@@ -86,6 +189,7 @@ static void fit_free(bgm_handle *h) {
   h->theta_dev = h->m1_dev = h->m2_dev = h->bblob_dev = h->ws_dev = h->partial_dev = nullptr;
   h->tables_dev = h->pos_dev = nullptr;
   h->fit_active = false;
+  fit_chain_free(h);
 }
 
 static HostNet iota_net(const HostNet &n, int base) {
@@ -235,7 +339,7 @@ extern "C" int bgm_causal_fit_begin(bgm_handle *h, int64_t n_rows, int32_t max_b
   BGM_HIP_CHECK(hipMemset(h->pos_dev, 0xFF, sizeof(int) * 2 * n_rows));
   BGM_HIP_CHECK(hipDeviceSynchronize());
   h->fit_active = true;
-  return BGM_OK;
+  return fit_chain_setup(h, theta);
 }
 
 #define BGM_FIT_VARIANTS(X) X(1, 3, 13) X(1, 3, 7) X(1, 3, 2) X(2, 1, 10) X(2, 1, 7) X(2, 1, 2)
@@ -284,6 +388,14 @@ extern "C" int bgm_causal_fit_theta_grad(bgm_handle *h, const float *x, const fl
   if (!grad) { bgm_set_error("bgm_causal_fit_theta_grad: grad_dev is NULL"); return BGM_E_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
+  if (FitChainState *fc = static_cast<FitChainState *>(h->fit_chain); fc && (batch == 16 || batch == 32)) {
+    FitChainArgs ca = fc->base;
+    ca.x = x; ca.y = y; ca.v = v; ca.data_z = data_z; ca.idx = idx; ca.row_lo = row_lo; ca.inv_B = 1.0f / (float)batch_global;
+    ca.loss = loss; ca.grad = grad;
+    fit_chain_launch(fc, ca, batch, 0, stream);
+    BGM_HIP_CHECK(hipGetLastError());
+    return BGM_OK;
+  }
   FitKArgs ka{};
   ka.m = h->meta; ka.bm = h->fit_meta; ka.ws = h->fit_ws; ka.wsp = h->ws_dev;
   ka.x = x; ka.y = y; ka.v = v; ka.data_z = data_z; ka.idx = idx; ka.row_lo = row_lo; ka.B = batch;
@@ -313,7 +425,8 @@ extern "C" int bgm_causal_fit_theta_apply(bgm_handle *h, const float *grad, floa
   const int *tb = h->tables_dev;
   hipLaunchKernelGGL(fit_adam_theta_kernel, dim3((np + 255) / 256), dim3(256), 0, (hipStream_t)stream_, h->theta_dev,
                      h->m1_dev, h->m2_dev, grad, np, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS, h->blob_dev, h->bblob_dev, tb,
-                     tb + np, tb + 2 * (size_t)np);
+                     tb + np, tb + 2 * (size_t)np, h->fit_chain ? static_cast<FitChainState *>(h->fit_chain)->thetaT : nullptr,
+                     h->fit_chain ? static_cast<FitChainState *>(h->fit_chain)->mirror_dst : nullptr);
   BGM_HIP_CHECK(hipGetLastError());
   h->sblob_valid = false;   // the sampling copy (evaluate between epochs, predict after the fit) follows the new parameters
   return BGM_OK;
@@ -332,7 +445,13 @@ extern "C" int bgm_causal_fit_z_step(bgm_handle *h, const float *x, const float 
   ka.m = h->meta; ka.bm = h->fit_meta; ka.ws = h->fit_ws; ka.wsp = h->ws_dev;
   ka.x = x; ka.y = y; ka.v = v; ka.data_z = data_z; ka.idx = idx; ka.row_lo = row_lo; ka.B = batch;
   ka.inv_B = 1.0f / (float)batch_global; ka.z_mode = 1; ka.loss = loss;
-  rc = launch_fwd_bwd(h, ka, stream);
+  if (FitChainState *fc = static_cast<FitChainState *>(h->fit_chain); fc && (batch == 16 || batch == 32)) {
+    FitChainArgs ca = fc->base;
+    ca.x = x; ca.y = y; ca.v = v; ca.data_z = data_z; ca.idx = idx; ca.row_lo = row_lo; ca.inv_B = ka.inv_B;
+    ca.loss = loss; ca.dz = h->ws_dev + h->fit_ws.dz;
+    fit_chain_launch(fc, ca, batch, 1, stream);
+    rc = BGM_OK;
+  } else rc = launch_fwd_bwd(h, ka, stream);
   if (rc) return rc;
   h->t_z += 1;
   const double t = (double)h->t_z;
@@ -383,7 +502,13 @@ extern "C" int bgm_causal_fit_z_grad(bgm_handle *h, const float *x, const float 
   ka.m = h->meta; ka.bm = h->fit_meta; ka.ws = h->fit_ws; ka.wsp = h->ws_dev;
   ka.x = x; ka.y = y; ka.v = v; ka.data_z = data_z; ka.idx = idx; ka.row_lo = row_lo; ka.B = batch;
   ka.inv_B = 1.0f / (float)batch_global; ka.z_mode = 1; ka.loss = loss;
-  rc = launch_fwd_bwd(h, ka, stream);
+  if (FitChainState *fc = static_cast<FitChainState *>(h->fit_chain); fc && (batch == 16 || batch == 32)) {
+    FitChainArgs ca = fc->base;
+    ca.x = x; ca.y = y; ca.v = v; ca.data_z = data_z; ca.idx = idx; ca.row_lo = row_lo; ca.inv_B = ka.inv_B;
+    ca.loss = loss; ca.dz = h->ws_dev + h->fit_ws.dz;
+    fit_chain_launch(fc, ca, batch, 1, stream);
+    rc = BGM_OK;
+  } else rc = launch_fwd_bwd(h, ka, stream);
   if (rc) return rc;
   BGM_HIP_CHECK(hipMemcpyAsync(dz_out, h->ws_dev + h->fit_ws.dz, sizeof(float) * (size_t)batch * h->q, hipMemcpyDeviceToDevice, stream));
   return BGM_OK;

@@ -1,0 +1,183 @@
+// fit_chain.h -- CausalBGM iterative-update steps at the reference batch size (B = 16 / 32) as register-chained row tiles.
+//
+// replaces, for that case, the LDS-blob kernels of fit_kernels.h (update_g_net / update_h_net / update_f_net,
+// causalbgm/base.py:156-243, and update_latent_variable_sgd :246-302): at two row tiles the 157 KB blob fill of every launch
+// (4 per minibatch) costs more than the arithmetic.  Here the weights are read in place (canonical array forward, transposed
+// mirror backward), one wave per 16-row tile and network:
+//   theta phase   waves 0,1: g forward + backward;  2,3: f;  4,5: h   -> stash of layer inputs / pre-activation gradients
+//                 fit_chain_dw_kernel (34 workgroups): gradient tiles X^T D -> grad[] in canonical parameter order
+//                 (then the optional all-reduce and fit_adam_theta_kernel, which also refreshes the blobs and the mirror)
+//   latent phase  the same chains with input gradients; dz = sum of the three + z / B -> the Adam-on-Z kernels.
+// Loss bookkeeping and gradient formulas are those of fit_fwd_kernel / fit_bwd_kernel.
+#pragma once
+#include "egm_chain_gen.h"
+#include "fit_types.h"
+
+struct FitChainArgs {
+  EgmMlp g, f, h;                 // offsets into theta (canonical [g | f | h])
+  const float *theta, *thetaT;
+  float *ws;
+  int xo[3][EGM_MAX_LAYERS], dofs[3][EGM_MAX_LAYERS];     // stash offsets per net (g, f, h)
+  const int *tiles; int n_tiles;  // ECG_TILE_INTS per tile (single pass)
+  float *grad;                    // [n_params]
+  const float *x, *y, *v, *data_z;
+  const int *idx; long long row_lo;
+  int q, p, z0, z1, z2, binary;
+  float sig2_v, sig2_x, sig2_y;   // > 0: fixed variances
+  float inv_B;
+  double *loss;                   // [7] accumulators or NULL
+  float *dz;                      // latent phase: [B x q]
+};
+
+__device__ __forceinline__ long long fitc_row(const FitChainArgs &a, int b) { return a.idx ? (long long)a.idx[b] : a.row_lo + b; }
+
+// Z_MODE 0: theta phase (stash, no input gradients); 1: latent phase (input gradients -> dz)
+template <int HT, int NTL, int T1, int T2, int T3, int NB, int Z_MODE>
+static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_kernel(FitChainArgs a) {
+  __shared__ float dzc[3 * 32 * 16];
+  __shared__ double lsum[8 * 8];
+  constexpr int B = 16 * NB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  const int role = wave >> 1, tile = wave & 1;
+  const bool active = tile < NB && role < 3;
+  const int row = 16 * tile + j;
+  const int q = a.q, p = a.p, z0 = a.z0, z1 = a.z1, z2 = a.z2;
+  const float *th = a.theta, *tT = a.thetaT;
+  float *ws = a.ws;
+  float l0 = 0.0f, l1 = 0.0f, l2 = 0.0f;          // this wave's loss terms per row: (nll, sse) of its net; role 0 also 0.5 |z|^2
+  if (active) {
+    const long long prow = fitc_row(a, row);
+    const float xv = a.x[prow], yv = a.y[prow];
+    const float *zrow = a.data_z + prow * q;
+    f32x4 dx[1];
+    ech_zero<1>(dx);
+    if (role == 0) {
+      f32x4 zin[1];
+      float zsq = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { zin[0][r] = ech_ld(zrow, 4 * g + r, q); zsq = fmaf(zin[0][r], zin[0][r], zsq); }
+      l2 = 0.5f * sum_over_g(zsq);
+      f32x4 o[NTL];
+      ecg_g_fwd<HT, NTL>(th, a.g, a.xo[0], ws, row, zin, o, j, g);
+      const float *vrow = a.v + prow * p;
+      float ssq = 0.0f, sraw = 0.0f;
+#pragma unroll
+      for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 16 * t + 4 * g + r;
+          const float d = f < p ? ech_ld(vrow, f, p) - o[t][r] : 0.0f;
+          ssq = fmaf(d, d, ssq);
+          sraw += f == p ? o[t][r] : 0.0f;
+          o[t][r] = d;
+        }
+      ssq = sum_over_g(ssq);
+      sraw = sum_over_g(sraw);
+      float s2, dsraw;
+      if (a.sig2_v > 0.0f) { s2 = a.sig2_v; dsraw = 0.0f; }
+      else {
+        s2 = softplus_acc(sraw) + BGM_EPS;
+        dsraw = (-ssq / (2.0f * s2 * s2) + 0.5f * (float)p / s2) * a.inv_B * sigmoid_f(sraw);
+      }
+      l0 = ssq / (2.0f * s2) + 0.5f * (float)p * logf(s2);
+      l1 = ssq;
+      const float cmu = -a.inv_B / s2;
+#pragma unroll
+      for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 16 * t + 4 * g + r;
+          o[t][r] = f < p ? cmu * o[t][r] : (f == p ? dsraw : 0.0f);
+        }
+      ecg_g_bwd<HT, NTL, Z_MODE == 1>(tT, a.g, a.xo[0], a.dofs[0], ws, row, o, dx, j, g);
+    } else {
+      const bool is_f = role == 1;
+      const EgmMlp &N = is_f ? a.f : a.h;
+      f32x4 in[1], o[1], d[1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = 4 * g + r;
+        if (is_f) in[0][r] = f < z0 + z1 ? ech_ld(zrow, f, q) : (f == z0 + z1 ? xv : 0.0f);
+        else { const float t = ech_ld(zrow, f < z0 ? f : f + z1, q); in[0][r] = f < z0 + z2 ? t : 0.0f; }
+      }
+      ecg_head_fwd<T1, T2, T3>(th, N, a.xo[role], ws, row, in, o, j, g);
+      const float mu = __shfl(o[0][0], j), sr = __shfl(o[0][1], j);       // outputs (mu, s_raw) live in lane group 0
+      const float tgt = is_f ? yv : xv, fixed = is_f ? a.sig2_y : a.sig2_x;
+      float dmu, dsr;
+      if (!is_f && a.binary) {
+        l0 = fmaxf(mu, 0.0f) - mu * tgt + log1pf(expf(-fabsf(mu)));
+        l1 = l0;
+        dmu = (sigmoid_f(mu) - tgt) * a.inv_B;
+        dsr = 0.0f;
+      } else {
+        const float dd = tgt - mu;
+        float s2;
+        if (fixed > 0.0f) { s2 = fixed; dsr = 0.0f; }
+        else {
+          s2 = softplus_acc(sr) + BGM_EPS;
+          dsr = (-dd * dd / (2.0f * s2 * s2) + 0.5f / s2) * a.inv_B * sigmoid_f(sr);
+        }
+        l0 = dd * dd / (2.0f * s2) + 0.5f * logf(s2);
+        l1 = dd * dd;
+        dmu = -dd / s2 * a.inv_B;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int f = 4 * g + r; d[0][r] = f == 0 ? dmu : (f == 1 ? dsr : 0.0f); }
+      ecg_head_bwd<T1, T2, T3>(tT, N, a.xo[role], a.dofs[role], ws, row, d, dx, j, g);
+    }
+    if (Z_MODE == 1) *reinterpret_cast<f32x4 *>(dzc + (role * 32 + row) * 16 + 4 * g) = dx[0];
+  }
+  {   // per-wave sums in double (the accumulators are doubles)
+    const float s0 = sum_over_j_to_lane15(l0), s1 = sum_over_j_to_lane15(l1), s2_ = sum_over_j_to_lane15(l2);
+    if (j == 15 && g == 0) { lsum[wave * 8] = s0; lsum[wave * 8 + 1] = s1; lsum[wave * 8 + 2] = s2_; }
+  }
+  __syncthreads();
+  if (Z_MODE == 1) {
+    for (int i = tid; i < B * q; i += ECH_THREADS) {
+      const int b = i / q, col = i - b * q;
+      float v = a.data_z[fitc_row(a, b) * q + col] * a.inv_B + dzc[(0 * 32 + b) * 16 + col];
+      if (col < z0 + z1) v += dzc[(1 * 32 + b) * 16 + col];                                  // f: (z0, z1, x)
+      if (col < z0) v += dzc[(2 * 32 + b) * 16 + col];                                       // h: (z0, z2)
+      else if (col >= z0 + z1 && col < z0 + z1 + z2) v += dzc[(2 * 32 + b) * 16 + col - z1];
+      a.dz[i] = v;
+    }
+  }
+  if (tid == 0 && a.loss) {
+    double s[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int rl = 0; rl < 3; ++rl)
+      for (int t = 0; t < NB; ++t)
+        for (int k = 0; k < 3; ++k) s[rl][k] += lsum[(2 * rl + t) * 8 + k];
+    // [loss_v, sse_v, loss_x, sse_x | bce, loss_y, sse_y, total]   (roles: 0 g -> v, 1 f -> y, 2 h -> x)
+    atomicAdd(a.loss + 0, s[0][0]); atomicAdd(a.loss + 1, s[0][1]);
+    atomicAdd(a.loss + 2, s[2][0]); atomicAdd(a.loss + 3, s[2][1]);
+    atomicAdd(a.loss + 4, s[1][0]); atomicAdd(a.loss + 5, s[1][1]);
+    atomicAdd(a.loss + 6, s[0][0] + s[2][0] + s[1][0] + s[0][2]);
+  }
+}
+
+// gradient tiles: grad[W_l] = X_l^T D_l, grad[b_l] = column sums of D_l  (one pass; canonical parameter order)
+template <int NB>
+static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_dw_kernel(FitChainArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  const int tau = blockIdx.x * ECH_WAVES + wave;
+  if (tau >= a.n_tiles) return;
+  const int *td = a.tiles + tau * ECG_TILE_INTS;
+  const int xo = td[0], dofs = td[2], xw = td[4], dw = td[5], u = td[6], v = td[7], woff = td[8], n_in = td[9], n_out = td[10], boff = td[11];
+  const float *ws = a.ws;
+  const int o = 16 * v + j;
+  f32x4 w = {0.0f, 0.0f, 0.0f, 0.0f};
+  float bs = 0.0f;
+  const float *xp = ws + xo + g * xw + 16 * u + j, *dp = ws + dofs + g * dw + o;
+  float xa[NB * 4], da[NB * 4];
+#pragma unroll
+  for (int s4 = 0; s4 < NB * 4; ++s4) { xa[s4] = xp[4 * s4 * xw]; da[s4] = dp[4 * s4 * dw]; }
+#pragma unroll
+  for (int s4 = 0; s4 < NB * 4; ++s4) { w = BGM_MFMA(xa[s4], da[s4], w); bs += da[s4]; }
+  bs = sum_over_g(bs);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int f = 16 * u + 4 * g + r;
+    if (f < n_in && o < n_out) a.grad[woff + f * n_out + o] = w[r];
+  }
+  if (boff >= 0 && g == 0 && o < n_out) a.grad[boff + o] = bs;
+}

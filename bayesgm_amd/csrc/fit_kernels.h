@@ -416,7 +416,8 @@ __global__ void fit_grad_reduce_kernel(const float *partial, long long stride, i
 // Keras Adam (optimizer_v2) on the canonical parameters + scatter into both packed blobs.
 __global__ void fit_adam_theta_kernel(float *theta, float *m1, float *m2, const float *grad, int n_params,
                                       float lr_t, float b1, float b2, float eps, float *fwd_blob,
-                                      float *bwd_blob, const int *fwd_dst, const int *fwd_dst2, const int *bwd_dst) {
+                                      float *bwd_blob, const int *fwd_dst, const int *fwd_dst2, const int *bwd_dst,
+                                      float *mirror = nullptr, const int *mirror_dst = nullptr) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_params) return;
   const float g = grad[c];
@@ -429,6 +430,7 @@ __global__ void fit_adam_theta_kernel(float *theta, float *m1, float *m2, const 
   if (fwd_dst[c] >= 0) fwd_blob[fwd_dst[c]] = w;
   if (fwd_dst2[c] >= 0) fwd_blob[fwd_dst2[c]] = w;
   if (bwd_dst[c] >= 0) bwd_blob[bwd_dst[c]] = w;
+  if (mirror && mirror_dst[c] >= 0) mirror[mirror_dst[c]] = w;      // transposed weights of the row-tile-chain kernels (fit_chain.h)
 }
 
 // Adam on the latent matrix.  mode 0 = Keras sparse path (decay + apply on ALL rows, base.py:301),
