@@ -1,0 +1,75 @@
+"""Host random numbers of a block of EGM iterations, from NumPy's legacy global generator in the reference's order
+(causalbgm/base.py:399-416), drawn by a small C routine (csrc/host/host_rng.c).
+
+np.random.choice(n, B, replace=False) permutes all n indices per call; at the tutorial's n = 20 000 that is ~0.3 ms, 180 000
+times per warm start -- more than the GPU side of the whole fit once the step kernels were rebuilt.  The C routine runs the
+same Fisher-Yates sweeps, polar-method normals and 53-bit uniforms on the same MT19937 state, bit-identically (outputs and
+final generator state: tests/test_host_rng.py), about 1.4x faster; the floor is the ~24 000 sequential Mersenne-Twister draws
+per index batch that stream parity with the reference prescribes.  This is host bookkeeping, not the GPU product path: without
+a C compiler the NumPy loop below is used (same numbers)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SRC = os.path.join(_HERE, "csrc", "host", "host_rng.c")
+_SO = os.path.join(_HERE, "libbgm_hostrng.so")
+_lib = None
+
+
+def build(force=False):
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SRC) > os.path.getmtime(_SO):
+        subprocess.check_call(["gcc", "-O3", "-shared", "-fPIC", "-o", _SO, _SRC, "-lm"])
+    return _SO
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        try:
+            _lib = C.CDLL(build())
+            _lib.bgm_host_egm_block.restype = C.c_int
+        except Exception:            # no compiler / read-only tree: NumPy path
+            _lib = False
+    return _lib
+
+
+def egm_block_numpy(n, batch_size, q, n_it, g_d_freq, n_eps=1):
+    """The reference's draw order, call by call."""
+    steps = g_d_freq + 1
+    idx = np.empty((n_it, steps, batch_size), np.int32)
+    z = np.empty((n_it, steps, batch_size, q), np.float32)
+    eps = np.empty((n_it, g_d_freq, n_eps), np.float64)
+    mean = np.zeros(q)
+    for i in range(n_it):
+        for j in range(g_d_freq):
+            idx[i, j] = np.random.choice(n, batch_size, replace=False)
+            z[i, j] = np.random.normal(mean, 1.0, (batch_size, q)).astype(np.float32)
+            eps[i, j] = np.random.uniform(0.0, 1.0, size=n_eps)
+        z[i, g_d_freq] = np.random.normal(mean, 1.0, (batch_size, q)).astype(np.float32)
+        idx[i, g_d_freq] = np.random.choice(n, batch_size, replace=False)
+    return idx, z, eps
+
+
+def egm_block(n, batch_size, q, n_it, g_d_freq, n_eps=1):
+    """-> idx [n_it, g_d_freq + 1, B] int32, z [n_it, g_d_freq + 1, B, q] float32, eps [n_it, g_d_freq, n_eps] float64; advances
+    np.random's global state exactly as the call-by-call loop does."""
+    lib = _load()
+    if not lib or n_it == 0:
+        return egm_block_numpy(n, batch_size, q, n_it, g_d_freq, n_eps)
+    st = np.random.get_state(legacy=True)
+    key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+    pos, has_gauss, gauss = C.c_int(int(st[2])), C.c_int(int(st[3])), C.c_double(float(st[4]))
+    steps = g_d_freq + 1
+    idx = np.empty((n_it, steps, batch_size), np.int32)
+    z = np.empty((n_it, steps, batch_size, q), np.float32)
+    eps = np.empty((n_it, g_d_freq, n_eps), np.float64)
+    rc = lib.bgm_host_egm_block(key.ctypes.data_as(C.c_void_p), C.byref(pos), C.byref(has_gauss), C.byref(gauss), int(n), int(batch_size),
+                                int(q), int(n_it), int(g_d_freq), int(n_eps), idx.ctypes.data_as(C.c_void_p),
+                                z.ctypes.data_as(C.c_void_p), eps.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise ValueError("bgm_host_egm_block: bad argument")
+    np.random.set_state(("MT19937", key, pos.value, has_gauss.value, gauss.value))
+    return idx, z, eps

@@ -22,7 +22,7 @@ import torch
 DISC_NORM_DEFAULT = "fixed"
 BNN_NORM_DEFAULT = "fixed"
 
-from .. import _lib, parallel
+from .. import _lib, host_rng, parallel
 from ..engine import CausalEngine
 from ..datasets import Gaussian_sampler
 from ..utils import save_data
@@ -194,16 +194,22 @@ class CausalBGM(object):
                 stop = min(egm_n_iter, (batch_iter // egm_batches_per_eval + 1) * egm_batches_per_eval
                            if batch_iter % egm_batches_per_eval else batch_iter)
                 n_it = stop - batch_iter + 1
-                idx_h = np.empty((n_it, steps, batch_size), np.int32)
-                z_h = np.empty((n_it, steps, batch_size, q), np.float32)
-                eps_h = np.empty((n_it, g_d_freq), np.float64)
-                for i in range(n_it):                       # host RNG consumed in the reference's order
-                    for j in range(g_d_freq):
-                        idx_h[i, j] = self._choice_no_replace(n, batch_size)
-                        z_h[i, j] = self.z_sampler.get_batch(batch_size)
-                        eps_h[i, j] = np.random.uniform(0.0, 1.0)
-                    z_h[i, g_d_freq] = self.z_sampler.get_batch(batch_size)
-                    idx_h[i, g_d_freq] = self._choice_no_replace(n, batch_size)
+                # host RNG consumed in the reference's order (base.py:404-417); drawn by the C routine of host_rng when the
+                # panel is small enough for np.random.choice's full permutation (the rejection sampler otherwise)
+                if n <= 200000 or batch_size * 20 > n:
+                    idx_h, z_h, eps3 = host_rng.egm_block(n, batch_size, q, n_it, g_d_freq)
+                    eps_h = eps3[:, :, 0]
+                else:
+                    idx_h = np.empty((n_it, steps, batch_size), np.int32)
+                    z_h = np.empty((n_it, steps, batch_size, q), np.float32)
+                    eps_h = np.empty((n_it, g_d_freq), np.float64)
+                    for i in range(n_it):
+                        for j in range(g_d_freq):
+                            idx_h[i, j] = self._choice_no_replace(n, batch_size)
+                            z_h[i, j] = self.z_sampler.get_batch(batch_size)
+                            eps_h[i, j] = np.random.uniform(0.0, 1.0)
+                        z_h[i, g_d_freq] = self.z_sampler.get_batch(batch_size)
+                        idx_h[i, g_d_freq] = self._choice_no_replace(n, batch_size)
                 idx_d, z_d = torch.from_numpy(idx_h).to(dev), torch.from_numpy(z_h).to(dev)
                 for i in range(n_it):
                     for j in range(g_d_freq):
