@@ -188,28 +188,38 @@ class CausalBGM(object):
         g_d_freq = int(p_['g_d_freq'])
         steps = g_d_freq + 1
         try:
-            batch_iter = 0
-            while batch_iter <= egm_n_iter:
-                # iterations up to and including the next evaluation point
-                stop = min(egm_n_iter, (batch_iter // egm_batches_per_eval + 1) * egm_batches_per_eval
-                           if batch_iter % egm_batches_per_eval else batch_iter)
-                n_it = stop - batch_iter + 1
-                # host RNG consumed in the reference's order (base.py:404-417); drawn by the C routine of host_rng when the
-                # panel is small enough for np.random.choice's full permutation (the rejection sampler otherwise)
-                if n <= 200000 or batch_size * 20 > n:
+            # Blocks of iterations up to and including the next evaluation point.  The host random numbers of block k + 1 are drawn
+            # (reference order, host_rng / NumPy) on a worker thread while the GPU runs block k and its evaluation pass: nothing
+            # else touches np.random in between, so the global stream is consumed exactly as in the sequential loop.
+            blocks, bi = [], 0
+            while bi <= egm_n_iter:
+                stop = min(egm_n_iter, (bi // egm_batches_per_eval + 1) * egm_batches_per_eval if bi % egm_batches_per_eval else bi)
+                blocks.append((bi, stop))
+                bi = stop + 1
+
+            def draw(n_it):
+                if n <= 200000 or batch_size * 20 > n:     # np.random.choice's full permutation, in C (bit-identical)
                     idx_h, z_h, eps3 = host_rng.egm_block(n, batch_size, q, n_it, g_d_freq)
-                    eps_h = eps3[:, :, 0]
-                else:
-                    idx_h = np.empty((n_it, steps, batch_size), np.int32)
-                    z_h = np.empty((n_it, steps, batch_size, q), np.float32)
-                    eps_h = np.empty((n_it, g_d_freq), np.float64)
-                    for i in range(n_it):
-                        for j in range(g_d_freq):
-                            idx_h[i, j] = self._choice_no_replace(n, batch_size)
-                            z_h[i, j] = self.z_sampler.get_batch(batch_size)
-                            eps_h[i, j] = np.random.uniform(0.0, 1.0)
-                        z_h[i, g_d_freq] = self.z_sampler.get_batch(batch_size)
-                        idx_h[i, g_d_freq] = self._choice_no_replace(n, batch_size)
+                    return idx_h, z_h, eps3[:, :, 0]
+                idx_h = np.empty((n_it, steps, batch_size), np.int32)
+                z_h = np.empty((n_it, steps, batch_size, q), np.float32)
+                eps_h = np.empty((n_it, g_d_freq), np.float64)
+                for i in range(n_it):
+                    for j in range(g_d_freq):
+                        idx_h[i, j] = self._choice_no_replace(n, batch_size)
+                        z_h[i, j] = self.z_sampler.get_batch(batch_size)
+                        eps_h[i, j] = np.random.uniform(0.0, 1.0)
+                    z_h[i, g_d_freq] = self.z_sampler.get_batch(batch_size)
+                    idx_h[i, g_d_freq] = self._choice_no_replace(n, batch_size)
+                return idx_h, z_h, eps_h
+
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(max_workers=1)
+            pending = pool.submit(draw, blocks[0][1] - blocks[0][0] + 1)
+            for kb, (batch_iter, stop) in enumerate(blocks):
+                n_it = stop - batch_iter + 1
+                idx_h, z_h, eps_h = pending.result()
+                pending = pool.submit(draw, blocks[kb + 1][1] - blocks[kb + 1][0] + 1) if kb + 1 < len(blocks) else None
                 idx_d, z_d = torch.from_numpy(idx_h).to(dev), torch.from_numpy(z_h).to(dev)
                 for i in range(n_it):
                     for j in range(g_d_freq):
@@ -227,8 +237,9 @@ class CausalBGM(object):
                     causal_pre, mse_x, mse_y, mse_v = self.evaluate(data=data)
                     if self._p['save_res'] and parallel.rank() == 0:
                         save_data('{}/causal_pre_egm_init_iter-{}.txt'.format(self.save_dir, batch_iter), causal_pre)
-                batch_iter += 1
         finally:
+            if 'pool' in locals():
+                pool.shutdown(wait=True)
             eng.egm_end()
             self._pull_weights(("g", "f", "h", "e"))
         if verbose:
