@@ -395,3 +395,30 @@ def test_two_rank_fit_with_replicated_egm_keeps_replicas_identical(mode):
     r = run_two_ranks("dp_bgm_fit_smoke.py", extra_args=(mode,))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count('"param_spread": 0.0') == 2, r.stdout[-2000:]
+
+
+def test_bgm_c4_one_gpu_share_through_the_class(tmp_path):
+    """One GPU's share of BASELINE configs[4] (BGM imputation, N = 5e6 over 8 GPUs, p = 500) through BGM.predict itself -- the wide
+    variant of the HMC kernel, row-blocked draw buffers, per-cell intervals -- at the full 625 000 x 500 panel with short chains,
+    checked through size-independent properties (the oracle covers small panels in the tests above)."""
+    from bayesgm_amd.models import BGM
+    n, p, q = 625_000, 500, 10
+    m = _model(91, q, p)
+    rs = np.random.RandomState(92)
+    x = rs.standard_normal((n, p)).astype(np.float32)
+    x[:, rs.choice(p, 50, replace=False)] = np.nan            # 10 % of the cells, one pattern (C4's 3.1e7 missing cells)
+    model = BGM(_bgm_params(tmp_path, p), random_seed=0)
+    model.set_weights(m["g"])
+    kw = dict(alpha=0.1, n_mcmc=12, burn_in=12, step_size=0.02, num_leapfrog_steps=5, seed=7)
+    imp, interval = model.predict(x, **kw)
+    miss = np.isnan(x)
+    assert imp.shape == (n, p) and interval.shape == (n, 50, 2)
+    assert np.array_equal(imp[~miss], x[~miss]) and np.isfinite(imp).all() and np.isfinite(interval).all()
+    assert np.all(interval[..., 0] <= interval[..., 1])
+    cells = imp[miss].reshape(n, 50)
+    assert np.all((cells >= interval[..., 0] - 1e-4) & (cells <= interval[..., 1] + 1e-4))     # a posterior mean lies inside its interval
+    t = model.last_predict_timing
+    assert t and all(v >= 0.0 for v in t.values())
+    # deterministic: the same call reproduces every imputed cell and interval bit for bit
+    imp2, int2 = model.predict(x, **kw)
+    assert np.array_equal(imp2, imp) and np.array_equal(int2, interval)
