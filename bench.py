@@ -127,6 +127,77 @@ def fit_leg(model, x, y, v, n_loc, steps=2000, batch=32):
             "flop_per_observation": 348480}
 
 
+def training_leg(params, x, y, v, device, n=20000, batch=32, reps=200):
+    """Secondary measurement: latencies of the training-side steps at the reference batch size on the first `n` rows of the bench
+    panel (the tutorial's N) -- EGM discriminator / generator step and the minibatch theta / latent steps, for deterministic and
+    Bayesian networks.  Each is one call through the C ABI (1-3 launches); see DESIGN.md section 4c."""
+    import torch
+    from bayesgm_amd.models import CausalBGM
+    q, p = sum(params["z_dims"]), params["v_dim"]
+    xs, ys, vs = x[:n].contiguous(), y[:n].contiguous(), v[:n].contiguous()
+    g = torch.Generator(device=device).manual_seed(3)
+    zb = torch.randn(batch, q, device=device, generator=g)
+    idx = torch.randperm(n, device=device, generator=g)[:batch].to(torch.int32)
+    z = torch.randn(n, q, device=device, generator=g)
+    zm, zv = torch.zeros_like(z), torch.zeros_like(z)
+
+    def timed(fn):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return 1e6 * (time.perf_counter() - t0) / reps
+
+    rs = np.random.RandomState(5)
+    dims = [q] + list(params["dz_units"]) + [1]
+    dz = {"W": [(rs.uniform(-1, 1, (dims[i], dims[i + 1])) * np.sqrt(6.0 / (dims[i] + dims[i + 1]))).astype(np.float32) for i in range(len(dims) - 1)],
+          "b": [np.zeros(d, np.float32) for d in dims[1:]], "gamma": [np.ones(d, np.float32) for d in dims[1:-1]],
+          "beta": [np.zeros(d, np.float32) for d in dims[1:-1]]}
+    out = {"sample": f"B={batch}, N={n}, p={p}, dz_units {list(params['dz_units'])}, g_d_freq {params['g_d_freq']}; microseconds per call, {reps} calls each"}
+    # deterministic nets
+    m = CausalBGM(dict(params, use_bnn=False), timestamp="bench_train_det", random_seed=0, device=device.index)
+    eng = m.engine
+    eng.set_disc_norm("fixed")            # the models' default (DESIGN.md section 2b)
+    eng.egm_begin(batch, list(params["dz_units"]), float(params["lr"]), bool(params["use_z_rec"]), dz)
+    try:
+        d_us = timed(lambda: eng.egm_disc_step(zb, idx, vs, 0.5))
+        g_us = timed(lambda: eng.egm_gen_step(zb, idx, vs, xs, ys))
+    finally:
+        eng.egm_end()
+    npar = eng.fit_begin(n, batch)
+    grad = torch.empty(npar, device=device)
+    try:
+        def step():
+            eng.fit_theta_grad(xs, ys, vs, z, idx, batch, grad)
+            eng.fit_theta_apply(grad, 1e-4)
+            eng.fit_z_step(xs, ys, vs, z, zm, zv, idx, batch, 1e-4, lazy=False)
+        f_us = timed(step)
+    finally:
+        eng.fit_end()
+    out["deterministic"] = {"egm_disc_step_us": d_us, "egm_gen_step_us": g_us, "egm_iteration_ms": 1e-3 * (params["g_d_freq"] * d_us + g_us),
+                            "fit_minibatch_us": f_us}
+    # Bayesian nets (the reference's default)
+    mb = CausalBGM(dict(params, use_bnn=True), timestamp="bench_train_bnn", random_seed=0, device=device.index)
+    be = mb.engine
+    be.set_disc_norm("fixed")
+    be.egm_begin(dz, batch, float(params["lr"]), 1 if params["use_z_rec"] else 0)
+    try:
+        d_us = timed(lambda: be.egm_disc_step(zb, idx, vs, 0.5, 1, 0))
+        g_us = timed(lambda: be.egm_gen_step(zb, idx, vs, xs, ys, 1, 1))
+    finally:
+        be.egm_end()
+    t_us = timed(lambda: be.theta_step(z, idx, xs, ys, vs, 1e-4, 1, 0))
+    zz = z.clone()
+    l_us = timed(lambda: be.z_step(xs, ys, vs, zz, zm, zv, idx, 1e-4, 1, 1))
+    out["bayesian"] = {"egm_disc_step_us": d_us, "egm_gen_step_us": g_us, "egm_iteration_ms": 1e-3 * (params["g_d_freq"] * d_us + g_us),
+                       "theta_step_us": t_us, "latent_step_us": l_us}
+    return out
+
+
+
 def bayesian_leg(params, data, x_values, n_loc, args, device):
     """Secondary measurement (not `value`): the same predict with the reference's default Bayesian nets (use_bnn=True,
     DESIGN.md section 7) on a tenth of the iterations -- all blocks advance in lock step, three launches per iteration, so
@@ -422,6 +493,7 @@ def main():
             out["bayesian_nets"] = bayesian_leg(params, data, x_values, n_loc, args, device)
         if not args.no_fit and world == 1:
             out["fit"] = fit_leg(model, x, y, v, n_loc)
+            out["training_steps"] = training_leg(params, x, y, v, device)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
