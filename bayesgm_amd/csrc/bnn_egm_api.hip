@@ -20,6 +20,7 @@ struct BnnEgmState {
   float *dev = nullptr;      // m | v (EGM Adam slots of the Bayesian nets) | theta_d | m_d | v_d | grad_d | ws
   // generator step as row-tile chains (egm_chain_bnn.h)
   int chain_gen_lds = 0, chain_ntl = 0, n_tiles = 0;
+  bool chain_pad = false;
   EcbCall disc_call{};         // noise of the discriminator step's encoder call (workspace offsets)
   EcbTab *tab_dev = nullptr;
   int *tiles_dev = nullptr;
@@ -91,9 +92,10 @@ extern "C" int bgm_bnn_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, const
   EcbTab tab{};
   std::vector<int> tiles;
   {
-    const int ntl = (s->p + 1 + 15) / 16;
+    const int ntl_need = (s->p + 1 + 15) / 16;
+    const int ntl = (ntl_need == 13 || ntl_need == 7) ? ntl_need : 13;       // narrower outputs: the 13-tile kernels with masked columns (B = 32)
     bool chain = d.fixed_norm && L == 3 && d.dims[0] <= 16 && (d.dims[1] + 15) / 16 == 4 && (d.dims[2] + 15) / 16 == 2 && d.dims[3] >= 1 &&
-                 d.dims[3] <= 16 && (B == 16 || B == 32) && (ntl == 13 || ntl == 7) && s->q <= 16 && !std::getenv("BGM_EGM_NO_CHAIN_GEN");
+                 d.dims[3] <= 16 && (B == 16 || B == 32) && ntl_need <= 13 && (ntl == ntl_need || B == 32) && s->q <= 16 && !std::getenv("BGM_EGM_NO_CHAIN_GEN");
     for (int k = 0; k < 4; ++k) chain = chain && s->net[k].bn_fixed == 1 && !s->net[k].heads && !s->net[k].mv;
     const BnnNet &G = s->net[BNN_G], &E = s->net[BNN_E];
     chain = chain && G.n_layers >= 3 && E.n_layers >= 3 && G.dims[0] == s->q && E.dims[E.n_layers] == s->q && G.dims[G.n_layers] == s->p + 1 &&
@@ -112,6 +114,7 @@ extern "C" int bgm_bnn_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, const
       gen_ws = ecb_build_tab(s->net, call_net, call_soff, ECB_CALLS, B, ntl, tab, tiles, all_nets, 4);
       tab.n_warm = s->n_params;
       e->chain_ntl = ntl;
+      e->chain_pad = ntl != ntl_need;
       e->n_tiles = tab.n_tiles;
       e->chain_gen_lds = (int)(sizeof(float) * (size_t)ecb_lds_floats<4, 2, 1>(d, B));
     }
@@ -193,7 +196,8 @@ extern "C" int bgm_bnn_egm_disc_step(bgm_handle *h, const float *z_dev, const in
       const BnnNet &E = a.net[BNN_E];
       bool ech = E.bn_fixed == 1 && !E.heads && E.n_layers >= 2 && E.dims[E.n_layers] == a.q && a.q <= 16 && !std::getenv("BGM_EGM_NO_CHAIN_BNN");
       for (int l = 1; l < E.n_layers; ++l) ech = ech && E.dims[l] == 64;
-      const int ntl = ech ? (a.p + 15) / 16 : 0;
+      int ntl = ech ? (a.p + 15) / 16 : 0;
+      if (ntl != 13 && ntl != 7 && ntl > 0 && ntl < 13) ntl = 13;      // the 13-tile encoder chain masks the inputs beyond p
       auto kc = a.B == 32 ? (ntl == 13 ? bnn_egm_disc_chain_kernel<13, 4, 2, 1, 2> : ntl == 7 ? bnn_egm_disc_chain_kernel<7, 4, 2, 1, 2> : bnn_egm_disc_chain_kernel<0, 4, 2, 1, 2>)
                           : (ntl == 13 ? bnn_egm_disc_chain_kernel<13, 4, 2, 1, 1> : ntl == 7 ? bnn_egm_disc_chain_kernel<7, 4, 2, 1, 1> : bnn_egm_disc_chain_kernel<0, 4, 2, 1, 1>);
       BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -226,7 +230,8 @@ extern "C" int bgm_bnn_egm_gen_step(bgm_handle *h, const float *z_dev, const int
   if (apply) { e->t_g += 1; s->packed_valid = false; }
   a.adam = bnn_egm_adam(e->cfg.lr, std::max<long long>(1, e->t_g));
   if (e->chain_gen_lds > 0) {
-    auto kc = a.B == 32 ? (e->chain_ntl == 13 ? bnn_egm_gen_chain_kernel<13, 2> : bnn_egm_gen_chain_kernel<7, 2>)
+    auto kc = e->chain_pad ? bnn_egm_gen_chain_kernel<13, 2, true>
+              : a.B == 32 ? (e->chain_ntl == 13 ? bnn_egm_gen_chain_kernel<13, 2> : bnn_egm_gen_chain_kernel<7, 2>)
                         : (e->chain_ntl == 13 ? bnn_egm_gen_chain_kernel<13, 1> : bnn_egm_gen_chain_kernel<7, 1>);
     BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, e->chain_gen_lds));
     hipLaunchKernelGGL(bnn_egm_gen_noise_kernel, dim3(ECB_CALLS * ECB_NOISE_PARTS), dim3(EGM_THREADS), 0, (hipStream_t)stream_, a, e->tab_dev);

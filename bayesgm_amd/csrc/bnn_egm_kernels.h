@@ -252,10 +252,10 @@ static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_gen_step_kernel(Bn
 }
 
 // train_gen_step as row-tile chains (egm_chain_bnn.h) + its gradient / Adam launch
-template <int NTL, int NB>
+template <int NTL, int NB, bool PAD = false>
 static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_gen_chain_kernel(BnnEgmArgs a, const EcbTab *tab, float *thetaT) {
   extern __shared__ __attribute__((aligned(16))) float egm_lds[];
-  ecb_gen_chain<BnnEgmArgs, 4, NTL, 4, 2, 1, NB>(a, *tab, thetaT, egm_lds);
+  ecb_gen_chain<BnnEgmArgs, 4, NTL, 4, 2, 1, NB, PAD>(a, *tab, thetaT, egm_lds);
 }
 static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_gen_noise_kernel(BnnEgmArgs a, const EcbTab *tab) { ecb_gen_noise<BnnEgmArgs>(a, *tab, a.ws); }
 template <int NB>

@@ -184,20 +184,20 @@ __device__ __forceinline__ void ecb_gen_noise(const Args &a, const EcbTab &tab, 
 
 // v = a W1 + flip(as W2): the Flipout product pair in either direction.  KC: W1, W2 are given K-contiguously (ecg_load_tile): the
 // backward products read the canonical `loc` and the canonical perturbation that way, so neither needs a transposed copy.
-template <int KT, int NT, bool KC>
+template <int KT, int NT, bool KC, bool PAD>
 __device__ __forceinline__ void ecb_pair_wide(const float *W1, const float *W2, int ld, int n_in, int n_out, const uint32_t *roww, int flipw,
                                               const f32x4 (&a)[KT], const f32x4 (&as)[KT], f32x4 (&v)[NT], int j, int g) {
   f32x4 c2[NT], c2s[NT];
-  ecg_wide<KT, NT, KC>(W1, ld, n_in, n_out, a, v, j, g);
-  ecg_wide<KT, NT, KC>(W2, ld, n_in, n_out, as, c2, j, g);
+  ecg_wide<KT, NT, KC, PAD>(W1, ld, n_in, n_out, a, v, j, g);
+  ecg_wide<KT, NT, KC, PAD>(W2, ld, n_in, n_out, as, c2, j, g);
   ecb_flip<NT>(roww, flipw, g, c2, c2s);
 #pragma unroll
   for (int u = 0; u < NT; ++u) v[u] += c2s[u];
 }
-template <int KT, int NT, bool CX, bool KC = false>
+template <int KT, int NT, bool CX, bool KC = false, bool PAD = false>
 __device__ __forceinline__ void ecb_pair(const float *W1, const float *W2, int ld, int n_in, int n_out, const uint32_t *roww, int flipw,
                                          const f32x4 (&a)[KT], const f32x4 (&as)[KT], f32x4 (&v)[NT], int j, int g) {
-  if constexpr (NT > 4) ecb_pair_wide<KT, NT, KC>(W1, W2, ld, n_in, n_out, roww, flipw, a, as, v, j, g);
+  if constexpr (NT > 4) ecb_pair_wide<KT, NT, KC, PAD>(W1, W2, ld, n_in, n_out, roww, flipw, a, as, v, j, g);
   else {
     const EcgW w1{W1, ld, n_in, n_out, 0}, w2{W2, ld, n_in, n_out, 0};
     EcgA<NT> A, Ad, Ad2;
@@ -217,7 +217,7 @@ __device__ __forceinline__ void ecb_add_bias(const float *bias, int n, int g, f3
 
 // Flipout MLP with hidden width 16 HT (g: KT0 = 1, NTO = output tiles; e: KT0 = input tiles, NTO = 1): forward with stash.
 // xraw: the raw input tiles (zero beyond dims[0]).
-template <int KT0, int HT, int NTO>
+template <int KT0, int HT, int NTO, bool PAD = false>
 __device__ __forceinline__ void ecb_mlp_fwd(const float *theta, const BnnNet &n, const EcbCall &C, float *ws, int row, const f32x4 (&xraw)[KT0],
                                             f32x4 (&out)[NTO], int j, int g) {
   constexpr int H = 16 * HT;
@@ -268,13 +268,13 @@ __device__ __forceinline__ void ecb_mlp_fwd(const float *theta, const BnnNet &n,
   ecg_put<HT>(ws + C.x[L - 1], row, g, h);
   ecg_put<HT>(ws + C.xs[L - 1], row, g, hs);
   const float *loc = theta + n.woff[L - 1];
-  ecb_pair<HT, NTO, false>(loc, dW + n.eoff[L - 1], no, H, no, roww, n.sout_w[L - 1], h, hs, out, j, g);
+  ecb_pair<HT, NTO, false, false, PAD>(loc, dW + n.eoff[L - 1], no, H, no, roww, n.sout_w[L - 1], h, hs, out, j, g);
   ecb_add_bias<NTO>(loc + 2 * H * no, no, g, out);
 }
 
 // backward with stash.  dout: dLoss/d output (zero beyond n_out).  dxraw (WANT_DX): dLoss/d raw input.  The per-row products for the
 // input normalisation's gamma / beta are summed over the tile's rows into bnp [2][16 KT0] (this tile's slot).
-template <int KT0, int HT, int NTO, bool WANT_DX>
+template <int KT0, int HT, int NTO, bool WANT_DX, bool PAD = false>
 __device__ __forceinline__ void ecb_mlp_bwd(const float *theta, const float *thetaT, const BnnNet &n, const EcbCall &C, float *ws, int row, int tile,
                                             const f32x4 (&dout)[NTO], f32x4 (&dxraw)[KT0], int j, int g) {
   constexpr int H = 16 * HT;
@@ -307,7 +307,7 @@ __device__ __forceinline__ void ecb_mlp_bwd(const float *theta, const float *the
   ecg_put<HT>(ws + C.d[0], row, g, dh);
   ecg_put<HT>(ws + C.ds[0], row, g, dhs);
   f32x4 dh0[KT0], xh[KT0];
-  ecb_pair<HT, KT0, false, true>(theta + n.woff[0], dW + n.eoff[0], H, H, d0, roww, n.sin_w[0], dh, dhs, dh0, j, g);
+  ecb_pair<HT, KT0, false, true, PAD>(theta + n.woff[0], dW + n.eoff[0], H, H, d0, roww, n.sin_w[0], dh, dhs, dh0, j, g);
   ecg_get<KT0>(ws + C.xh, row, g, xh);
   float *bnp = ws + C.bnp + tile * (2 * 16 * KT0);
   const float *gamma = theta + n.off;
@@ -429,7 +429,7 @@ struct BnnEgmArgs;   // bnn_egm_kernels.h
 //                  4,5  g(z) [G1S] (variance-head penalty) forward + backward; then, from z_: D, f [F, FS], h [H, HS]
 //                  6,7  discriminator parameter block, L2 warm-up
 // The noise of the nine calls has been drawn by the launch before (ecb_gen_noise).
-template <class Args, int HT, int NTL, int T1, int T2, int T3, int NB>
+template <class Args, int HT, int NTL, int T1, int T2, int T3, int NB, bool PAD = false>
 __device__ __forceinline__ void ecb_gen_chain(const Args &a, const EcbTab &tab, float *thetaT_, float *ech_lds) {
   constexpr int B = 16 * NB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
@@ -455,14 +455,14 @@ __device__ __forceinline__ void ecb_gen_chain(const Args &a, const EcbTab &tab, 
 #pragma unroll
     for (int r = 0; r < 4; ++r) zin[0][r] = ech_ld(a.z + (long long)row * q, 4 * g + r, q);
     f32x4 gz[NTL];
-    ecb_mlp_fwd<1, HT, NTL>(th, G, tab.c[ECB_G1], ws, row, zin, gz, j, g);
+    ecb_mlp_fwd<1, HT, NTL, PAD>(th, G, tab.c[ECB_G1], ws, row, zin, gz, j, g);
     f32x4 vin[NTL];
 #pragma unroll
     for (int t = 0; t < NTL; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) vin[t][r] = (16 * t + 4 * g + r < p) ? gz[t][r] : 0.0f;
     f32x4 zz[1];
-    ecb_mlp_fwd<NTL, HT, 1>(th, E, tab.c[ECB_E2], ws, row, vin, zz, j, g);
+    ecb_mlp_fwd<NTL, HT, 1, PAD>(th, E, tab.c[ECB_E2], ws, row, vin, zz, j, g);
     f32x4 dzz[1];
     float lz = 0.0f;
 #pragma unroll
@@ -473,13 +473,13 @@ __device__ __forceinline__ void ecb_gen_chain(const Args &a, const EcbTab &tab, 
     }
     ls[1] = sum_over_g(lz);
     f32x4 dv[NTL];
-    ecb_mlp_bwd<NTL, HT, 1, true>(th, tT, E, tab.c[ECB_E2], ws, row, tile, dzz, dv, j, g);
+    ecb_mlp_bwd<NTL, HT, 1, true, PAD>(th, tT, E, tab.c[ECB_E2], ws, row, tile, dzz, dv, j, g);
 #pragma unroll
     for (int t = 0; t < NTL; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) dv[t][r] = (16 * t + 4 * g + r < p) ? dv[t][r] : 0.0f;
     f32x4 dnone[1];
-    ecb_mlp_bwd<1, HT, NTL, false>(th, tT, G, tab.c[ECB_G1], ws, row, tile, dv, dnone, j, g);
+    ecb_mlp_bwd<1, HT, NTL, false, PAD>(th, tT, G, tab.c[ECB_G1], ws, row, tile, dv, dnone, j, g);
   } else if (role == 1 && active) {
     const float *vrow = a.v_ + (long long)a.idx[row] * p;
     f32x4 vin[NTL];
@@ -488,14 +488,14 @@ __device__ __forceinline__ void ecb_gen_chain(const Args &a, const EcbTab &tab, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) vin[t][r] = ech_ld(vrow, 16 * t + 4 * g + r, p);
     f32x4 ze[1];
-    ecb_mlp_fwd<NTL, HT, 1>(th, E, tab.c[ECB_E1], ws, row, vin, ze, j, g);
+    ecb_mlp_fwd<NTL, HT, 1, PAD>(th, E, tab.c[ECB_E1], ws, row, vin, ze, j, g);
     *reinterpret_cast<f32x4 *>(zt + row * 16 + 4 * g) = ze[0];
     __threadfence_block();
     if (lane == 0) flag[2 + tile] = 1;
     f32x4 dz[1];
     {
       f32x4 gv[NTL];
-      ecb_mlp_fwd<1, HT, NTL>(th, G, tab.c[ECB_G2], ws, row, ze, gv, j, g);
+      ecb_mlp_fwd<1, HT, NTL, PAD>(th, G, tab.c[ECB_G2], ws, row, ze, gv, j, g);
       float lv = 0.0f;
 #pragma unroll
       for (int t = 0; t < NTL; ++t)
@@ -507,20 +507,20 @@ __device__ __forceinline__ void ecb_gen_chain(const Args &a, const EcbTab &tab, 
           gv[t][r] = (-2.0f / (float)(B * p)) * d;
         }
       ls[0] = sum_over_g(lv);
-      ecb_mlp_bwd<1, HT, NTL, true>(th, tT, G, tab.c[ECB_G2], ws, row, tile, gv, dz, j, g);
+      ecb_mlp_bwd<1, HT, NTL, true, PAD>(th, tT, G, tab.c[ECB_G2], ws, row, tile, gv, dz, j, g);
     }
     while (flag[4 + tile] == 0) __builtin_amdgcn_s_sleep(2);
     __threadfence_block();
     dz[0] += *reinterpret_cast<const f32x4 *>(dzh + row * 16 + 4 * g);
     f32x4 dnone[NTL];
-    ecb_mlp_bwd<NTL, HT, 1, false>(th, tT, E, tab.c[ECB_E1], ws, row, tile, dz, dnone, j, g);
+    ecb_mlp_bwd<NTL, HT, 1, false, PAD>(th, tT, E, tab.c[ECB_E1], ws, row, tile, dz, dnone, j, g);
   } else if (role == 2 && active) {
     {   // second g(z) call: the variance-head penalty
       f32x4 zin[1];
 #pragma unroll
       for (int r = 0; r < 4; ++r) zin[0][r] = ech_ld(a.z + (long long)row * q, 4 * g + r, q);
       f32x4 gzs[NTL];
-      ecb_mlp_fwd<1, HT, NTL>(th, G, tab.c[ECB_G1S], ws, row, zin, gzs, j, g);
+      ecb_mlp_fwd<1, HT, NTL, PAD>(th, G, tab.c[ECB_G1S], ws, row, zin, gzs, j, g);
       float sgv = 0.0f;
 #pragma unroll
       for (int t = 0; t < NTL; ++t)
@@ -533,7 +533,7 @@ __device__ __forceinline__ void ecb_gen_chain(const Args &a, const EcbTab &tab, 
 #pragma unroll
         for (int r = 0; r < 4; ++r) gzs[t][r] = (16 * t + 4 * g + r == p) ? 0.001f * 2.0f * sgv * invB : 0.0f;
       f32x4 dnone[1];
-      ecb_mlp_bwd<1, HT, NTL, false>(th, tT, G, tab.c[ECB_G1S], ws, row, tile, gzs, dnone, j, g);
+      ecb_mlp_bwd<1, HT, NTL, false, PAD>(th, tT, G, tab.c[ECB_G1S], ws, row, tile, gzs, dnone, j, g);
     }
     const long long prow = a.idx[row];
     const float xv = a.x_[prow], yv = a.y_[prow];
@@ -764,7 +764,7 @@ __device__ __forceinline__ void ecb_inputs(const float *zrow, float xv, int q, i
   }
 }
 
-template <class Args, int HT, int NTL, int T1, int T2, int T3, int NB>
+template <class Args, int HT, int NTL, int T1, int T2, int T3, int NB, bool PAD = false>
 __device__ __forceinline__ void ecb_theta_chain(const Args &a, const EcbTab &tab, float *ws, float *lds) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const int q = a.q, p = a.p;
@@ -782,7 +782,7 @@ __device__ __forceinline__ void ecb_theta_chain(const Args &a, const EcbTab &tab
     if (role == 0) {
       const BnnNet &G = a.net[BNN_G];
       f32x4 o[NTL];
-      ecb_mlp_fwd<1, HT, NTL>(th, G, tab.c[0], ws, row, zin, o, j, g);
+      ecb_mlp_fwd<1, HT, NTL, PAD>(th, G, tab.c[0], ws, row, zin, o, j, g);
       const float *vrow = a.v_ + prow * p;
       float ssq = 0.0f;
 #pragma unroll
@@ -806,7 +806,7 @@ __device__ __forceinline__ void ecb_theta_chain(const Args &a, const EcbTab &tab
         }
       ls0 = lb; ls1 = ssq;
       f32x4 dnone[1];
-      ecb_mlp_bwd<1, HT, NTL, false>(th, th, G, tab.c[0], ws, row, tile, o, dnone, j, g);
+      ecb_mlp_bwd<1, HT, NTL, false, PAD>(th, th, G, tab.c[0], ws, row, tile, o, dnone, j, g);
     } else {
       const bool is_h = role == 1;
       const BnnNet &N = a.net[is_h ? BNN_H : BNN_F];
@@ -926,7 +926,7 @@ __device__ __forceinline__ void ecb_theta_dw(const Args &a, const EcbTab &tab, c
 
 // latent step: dz [B x q] = d loss / d (batch rows of data_z), out[0] = loss_postrior_z.  Waves 0,1: g mean call; 2,3: g variance-head
 // call (they exchange the row's sum of squares and raw variance through LDS); 4,5: h (both calls); 6,7: f (both calls).
-template <class Args, int HT, int NTL, int T1, int T2, int T3, int NB>
+template <class Args, int HT, int NTL, int T1, int T2, int T3, int NB, bool PAD = false>
 __device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, float *ws, float *lds) {
   constexpr int B = 16 * NB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
@@ -952,7 +952,7 @@ __device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, fl
     if (role == 0) {
       const BnnNet &G = a.net[BNN_G];
       f32x4 o[NTL];
-      ecb_mlp_fwd<1, HT, NTL>(th, G, tab.c[0], ws, row, zin, o, j, g);
+      ecb_mlp_fwd<1, HT, NTL, PAD>(th, G, tab.c[0], ws, row, zin, o, j, g);
       const float *vrow = a.v_ + prow * p;
       float ssq = 0.0f;
 #pragma unroll
@@ -978,11 +978,11 @@ __device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, fl
       for (int t = 0; t < NTL; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[t][r] = (16 * t + 4 * g + r < p) ? -o[t][r] / s2 * a.inv_B : 0.0f;
-      ecb_mlp_bwd<1, HT, NTL, true>(th, th, G, tab.c[0], ws, row, tile, o, dx, j, g);
+      ecb_mlp_bwd<1, HT, NTL, true, PAD>(th, th, G, tab.c[0], ws, row, tile, o, dx, j, g);
     } else if (role == 1) {
       const BnnNet &G = a.net[BNN_G];
       f32x4 o[NTL];
-      ecb_mlp_fwd<1, HT, NTL>(th, G, tab.c[1], ws, row, zin, o, j, g);
+      ecb_mlp_fwd<1, HT, NTL, PAD>(th, G, tab.c[1], ws, row, zin, o, j, g);
       const float raw = ecb_pick<NTL>(o, p, g);
       if (g == 0) xch[B + row] = raw;
       __threadfence_block();
@@ -996,7 +996,7 @@ __device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, fl
       for (int t = 0; t < NTL; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[t][r] = (16 * t + 4 * g + r == p) ? dr * a.inv_B : 0.0f;
-      ecb_mlp_bwd<1, HT, NTL, true>(th, th, G, tab.c[1], ws, row, tile, o, dx, j, g);
+      ecb_mlp_bwd<1, HT, NTL, true, PAD>(th, th, G, tab.c[1], ws, row, tile, o, dx, j, g);
     } else {
       const bool is_h = role == 2;
       const BnnNet &N = a.net[is_h ? BNN_H : BNN_F];
@@ -1079,7 +1079,7 @@ inline size_t ecb_build_tab(const BnnNet *nets, const int *call_net, const int *
     tab.net_calls[C.net][tab.net_ncalls[C.net]++] = c;
     const size_t E_ = (size_t)m.eoff[m.n_layers];
     C.eps = 0; C.dWT = 0;
-    C.dW = take(E_ + 16);
+    C.dW = take(E_ + 256);          // K-contiguous tile loads of padded shapes read up to ~200 floats past the last layer: zeros, never written
     C.sg = take((size_t)B * m.swords);
     const int kt0 = tab.kt0[C.net];
     C.xh = take((size_t)B * 16 * kt0);
@@ -1118,7 +1118,7 @@ inline size_t ecb_build_tab(const BnnNet *nets, const int *call_net, const int *
 inline bool ecb_shapes_ok(const BnnNet *nets, int q, int p, bool need_e) {
   bool ok = q <= 16;
   const int ntl = (p + 1 + 15) / 16;
-  ok = ok && (ntl == 13 || ntl == 7);
+  ok = ok && ntl <= 13;            // 13 and 7 are compiled exactly; anything narrower runs the 13-tile kernels with masked columns
   for (int k = 0; k < 4; ++k) {
     if (k == BNN_E && !need_e) continue;
     ok = ok && nets[k].bn_fixed == 1 && !nets[k].heads && !nets[k].mv;

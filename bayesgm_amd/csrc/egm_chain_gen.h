@@ -86,7 +86,7 @@ __device__ __forceinline__ void ecg_sub(const EcgW &w, const f32x4 (&in)[KT], f3
                                         int j, int g) {
 #pragma unroll
   for (int t = 0; t < KT; ++t) {
-    if (t + 2 < KT) ecg_load_tile<NT, CX, KC>(w, t + 2, A.v[(t + 2) % 3], j, g, t + 2 == KT - 1);
+    if (t + 2 < KT) ecg_load_tile<NT, CX, KC>(w, t + 2, A.v[(t + 2) % 3], j, g, KT > 4 || t + 2 == KT - 1);
     if (t == (KT >= 2 ? KT - 2 : 0)) ecg_load_tile<NTN, CXN, KCN>(wn, 0, An.v[0], j, g, true);
     if (t == KT - 1) ecg_load_tile<NTN, CXN, KCN>(wn, 1, An.v[1], j, g, true);
     BGM_NO_HOIST();          // pins the issue order (the scheduler would sink every load to just above its MFMA)
@@ -140,7 +140,8 @@ __device__ __forceinline__ void ecg_get(const float *base, int row, int g, f32x4
 
 // Wide layers (more than four output tiles) run as column groups of four tiles, each a full K sweep over the same input.
 // NT = 4 Q + R column tiles, R in {0, 1, 2, 3}.
-template <int KT, int NT, bool KC = false>
+// PAD: n_out may be anywhere in (0, 16 NT] (a compiled extent used for a narrower layer): every group masks its columns.
+template <int KT, int NT, bool KC = false, bool PAD = false>
 __device__ __forceinline__ void ecg_wide(const float *W, int ld, int n_in, int n_out, const f32x4 (&in)[KT], f32x4 (&out)[NT], int j, int g) {
   constexpr int Q = NT / 4, R = NT % 4;
   ech_zero<NT>(out);
@@ -148,15 +149,16 @@ __device__ __forceinline__ void ecg_wide(const float *W, int ld, int n_in, int n
   if constexpr (Q > 0) {
     // 16 (NT - 1) < n_out <= 16 NT: every group but the very last is complete
     EcgA<4> A, An;
-    ecg_prime<4, (Q > 1 || R > 0), KC>(w, A, j, g);
+    ecg_prime<4, !PAD && (Q > 1 || R > 0), KC>(w, A, j, g);
 #pragma unroll
     for (int c = 0; c < Q; ++c) {
       f32x4 o4[4];
       ech_zero<4>(o4);
       EcgW wn{W, ld, n_in, n_out, 64 * (c + 1 < Q ? c + 1 : c)};
       w.col0 = 64 * c;
-      constexpr bool last_full = R > 0;      // the last group of four is complete when a remainder group follows
-      if (c + 1 < Q) {
+      constexpr bool last_full = R > 0 && !PAD;      // the last group of four is complete when a remainder group follows
+      if (PAD) ecg_sub<KT, 4, 4, false, false, KC, KC>(w, in, o4, A, wn, An, j, g);
+      else if (c + 1 < Q) {
         if (c + 2 < Q || last_full) ecg_sub<KT, 4, 4, true, true, KC, KC>(w, in, o4, A, wn, An, j, g);
         else ecg_sub<KT, 4, 4, true, false, KC, KC>(w, in, o4, A, wn, An, j, g);
       } else {
@@ -234,7 +236,7 @@ __device__ __forceinline__ void ecg_hidden_bwd(const float *thetaT, const EgmMlp
 }
 
 // generator g: [q <= 16] -> 16 HT x (L-2) -> [n_out = p + 1], NTL output tiles
-template <int HT, int NTL>
+template <int HT, int NTL, bool PAD = false>
 __device__ __forceinline__ void ecg_g_fwd(const float *theta, const EgmMlp &n, const int *xo, float *ws, int row, const f32x4 (&zin)[1],
                                           f32x4 (&out)[NTL], int j, int g) {
   constexpr int H = 16 * HT;
@@ -253,7 +255,7 @@ __device__ __forceinline__ void ecg_g_fwd(const float *theta, const EgmMlp &n, c
   ecg_hidden_fwd<HT>(theta, n, xo, ws, row, h, j, g);
   ecg_put<HT>(ws + xo[L - 1], row, g, h);
   const float *Wl = theta + n.woff[L - 1];
-  ecg_wide<HT, NTL>(Wl, no, H, no, h, out, j, g);
+  ecg_wide<HT, NTL, false, PAD>(Wl, no, H, no, h, out, j, g);
   ecg_bias<NTL>(Wl + H * no, no, 0, g, out);
 }
 // dout: dLoss/d output (NTL tiles, zero beyond n_out).  dx (WANT_DX): dLoss/d input.
@@ -311,7 +313,7 @@ __device__ __forceinline__ void ecg_e_fwd(const float *theta, const EgmMlp &n, c
     ecg_bias<1>(w.W + H * q, q, 0, g, z);
   }
 }
-template <int HT, int NTL, bool WANT_DX>
+template <int HT, int NTL, bool WANT_DX, bool PAD = false>
 __device__ __forceinline__ void ecg_e_bwd(const float *thetaT, const EgmMlp &n, const int *xo, const int *dofs, float *ws, int row,
                                           const f32x4 (&dz)[1], f32x4 (&dx)[NTL], int j, int g) {
   constexpr int H = 16 * HT;
@@ -329,7 +331,7 @@ __device__ __forceinline__ void ecg_e_bwd(const float *thetaT, const EgmMlp &n, 
   }
   ecg_hidden_bwd<HT>(thetaT, n, xo, dofs, ws, row, dh, j, g);
   ecg_put<HT>(ws + dofs[0], row, g, dh);
-  if (WANT_DX) ecg_wide<HT, NTL>(thetaT + n.woff[0], p, H, p, dh, dx, j, g);      // W^T [H x p]
+  if (WANT_DX) ecg_wide<HT, NTL, false, PAD>(thetaT + n.woff[0], p, H, p, dh, dx, j, g);      // W^T [H x p]
 }
 
 // head networks f, h: [in <= 16] -> 16 T1 -> 16 T2 -> 16 T3 -> [out <= 16], LeakyReLU
@@ -424,7 +426,7 @@ __host__ __device__ inline int ecg_lds_floats(const EgmDisc &d, int B) { return 
 // ---------------------------------------------------------------------------------------------
 // the step
 // ---------------------------------------------------------------------------------------------
-template <int HT, int NTL, int T1, int T2, int T3, int NB>
+template <int HT, int NTL, int T1, int T2, int T3, int NB, bool PAD = false>
 static __global__ __launch_bounds__(ECH_THREADS) void egm_gen_chain_kernel(EgmArgs a, EcgTab tab) {
   extern __shared__ __attribute__((aligned(16))) float ech_lds[];
   constexpr int B = 16 * NB;
@@ -455,7 +457,7 @@ static __global__ __launch_bounds__(ECH_THREADS) void egm_gen_chain_kernel(EgmAr
 #pragma unroll
     for (int r = 0; r < 4; ++r) zin[0][r] = ech_ld(a.z + (long long)row * q, 4 * g + r, q);
     f32x4 gz[NTL];
-    ecg_g_fwd<HT, NTL>(th, a.g, tab.x[ECG_PASS_G1], ws, row, zin, gz, j, g);
+    ecg_g_fwd<HT, NTL, PAD>(th, a.g, tab.x[ECG_PASS_G1], ws, row, zin, gz, j, g);
     ECH_STAMP(1);
     float sgv = 0.0f;                          // variance head g(z)[:, p] of this row (held by one lane group)
     f32x4 vin[NTL];
@@ -483,7 +485,7 @@ static __global__ __launch_bounds__(ECH_THREADS) void egm_gen_chain_kernel(EgmAr
     }
     ls[1] = sum_over_g(lz);
     f32x4 dv[NTL];
-    ecg_e_bwd<HT, NTL, true>(tT, a.e, tab.x[ECG_PASS_E2], tab.d[ECG_PASS_E2], ws, row, dzz, dv, j, g);
+    ecg_e_bwd<HT, NTL, true, PAD>(tT, a.e, tab.x[ECG_PASS_E2], tab.d[ECG_PASS_E2], ws, row, dzz, dv, j, g);
     ECH_STAMP(3);
 #pragma unroll
     for (int t = 0; t < NTL; ++t)
@@ -523,7 +525,7 @@ static __global__ __launch_bounds__(ECH_THREADS) void egm_gen_chain_kernel(EgmAr
     f32x4 dz[1];                               // dLoss/dz_ accumulates here
     {
       f32x4 gv[NTL];
-      ecg_g_fwd<HT, NTL>(th, a.g, tab.x[ECG_PASS_G2], ws, row, ze, gv, j, g);
+      ecg_g_fwd<HT, NTL, PAD>(th, a.g, tab.x[ECG_PASS_G2], ws, row, ze, gv, j, g);
       float lv = 0.0f;
       ecg_get<NTL>(ws + tab.x[ECG_PASS_E1][0], row, g, vin);
 #pragma unroll

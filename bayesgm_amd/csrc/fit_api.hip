@@ -15,6 +15,7 @@
 struct FitChainState {
   FitChainArgs base{};
   int ntl = 0;
+  bool pad = false;      // the 13-tile kernels on a narrower p + 1 (B = 32 only)
   float *thetaT = nullptr, *ws = nullptr;
   int *tiles = nullptr, *mirror_dst = nullptr;
 };
@@ -39,9 +40,10 @@ static bool fit_fill_mlp(const HostNet &n, EgmMlp &m, int off) {
 static int fit_chain_setup(bgm_handle *h, const std::vector<float> &theta) {
   const HostNet &G = h->nets[BGM_NET_G], &F = h->nets[BGM_NET_F], &H = h->nets[BGM_NET_H];
   const int ng = (int)G.count(), nf = (int)F.count(), np = h->n_params, q = h->q, p = h->p;
-  const int ntl = (p + 1 + 15) / 16;
+  const int ntl_need = (p + 1 + 15) / 16;
+  const int ntl = (ntl_need == 13 || ntl_need == 7) ? ntl_need : 13;
   FitChainArgs a{};
-  bool ok = !std::getenv("BGM_FIT_NO_CHAIN") && q <= 16 && (ntl == 13 || ntl == 7) && fit_fill_mlp(G, a.g, 0) && fit_fill_mlp(F, a.f, ng) &&
+  bool ok = !std::getenv("BGM_FIT_NO_CHAIN") && q <= 16 && ntl_need <= 13 && fit_fill_mlp(G, a.g, 0) && fit_fill_mlp(F, a.f, ng) &&
             fit_fill_mlp(H, a.h, ng + nf);
   ok = ok && a.g.n_layers >= 3 && a.g.dims[0] == q && a.g.dims[a.g.n_layers] == p + 1;
   for (int l = 1; ok && l < a.g.n_layers; ++l) ok = a.g.dims[l] == 64;
@@ -51,6 +53,7 @@ static int fit_chain_setup(bgm_handle *h, const std::vector<float> &theta) {
   FitChainState *c = new FitChainState();
   h->fit_chain = c;
   c->ntl = ntl;
+  c->pad = ntl != ntl_need;
   const int B = 32;
   auto tl = [](int n) { return (n + 15) / 16; };
   size_t off = 0;
@@ -105,6 +108,14 @@ static void fit_chain_launch(const FitChainState *c, FitChainArgs &a, int batch,
       hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, NB_, 0>), dim3(1), dim3(ECH_THREADS), 0, stream, a); \
       hipLaunchKernelGGL(fit_chain_dw_kernel<NB_>, dim3((a.n_tiles + ECH_WAVES - 1) / ECH_WAVES), dim3(ECH_THREADS), 0, stream, a); \
     } \
+  }
+  if (c->pad) {
+    if (z_mode) hipLaunchKernelGGL((fit_chain_kernel<4, 13, 4, 2, 1, 2, 1, true>), dim3(1), dim3(ECH_THREADS), 0, stream, a);
+    else {
+      hipLaunchKernelGGL((fit_chain_kernel<4, 13, 4, 2, 1, 2, 0, true>), dim3(1), dim3(ECH_THREADS), 0, stream, a);
+      hipLaunchKernelGGL(fit_chain_dw_kernel<2>, dim3((a.n_tiles + ECH_WAVES - 1) / ECH_WAVES), dim3(ECH_THREADS), 0, stream, a);
+    }
+    return;
   }
   FC(13, 2) FC(13, 1) FC(7, 2) FC(7, 1)
 #undef FC
@@ -388,7 +399,7 @@ extern "C" int bgm_causal_fit_theta_grad(bgm_handle *h, const float *x, const fl
   if (!grad) { bgm_set_error("bgm_causal_fit_theta_grad: grad_dev is NULL"); return BGM_E_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
-  if (FitChainState *fc = static_cast<FitChainState *>(h->fit_chain); fc && (batch == 16 || batch == 32)) {
+  if (FitChainState *fc = static_cast<FitChainState *>(h->fit_chain); fc && (batch == 32 || (batch == 16 && !fc->pad))) {
     FitChainArgs ca = fc->base;
     ca.x = x; ca.y = y; ca.v = v; ca.data_z = data_z; ca.idx = idx; ca.row_lo = row_lo; ca.inv_B = 1.0f / (float)batch_global;
     ca.loss = loss; ca.grad = grad;
@@ -445,7 +456,7 @@ extern "C" int bgm_causal_fit_z_step(bgm_handle *h, const float *x, const float 
   ka.m = h->meta; ka.bm = h->fit_meta; ka.ws = h->fit_ws; ka.wsp = h->ws_dev;
   ka.x = x; ka.y = y; ka.v = v; ka.data_z = data_z; ka.idx = idx; ka.row_lo = row_lo; ka.B = batch;
   ka.inv_B = 1.0f / (float)batch_global; ka.z_mode = 1; ka.loss = loss;
-  if (FitChainState *fc = static_cast<FitChainState *>(h->fit_chain); fc && (batch == 16 || batch == 32)) {
+  if (FitChainState *fc = static_cast<FitChainState *>(h->fit_chain); fc && (batch == 32 || (batch == 16 && !fc->pad))) {
     FitChainArgs ca = fc->base;
     ca.x = x; ca.y = y; ca.v = v; ca.data_z = data_z; ca.idx = idx; ca.row_lo = row_lo; ca.inv_B = ka.inv_B;
     ca.loss = loss; ca.dz = h->ws_dev + h->fit_ws.dz;
@@ -502,7 +513,7 @@ extern "C" int bgm_causal_fit_z_grad(bgm_handle *h, const float *x, const float 
   ka.m = h->meta; ka.bm = h->fit_meta; ka.ws = h->fit_ws; ka.wsp = h->ws_dev;
   ka.x = x; ka.y = y; ka.v = v; ka.data_z = data_z; ka.idx = idx; ka.row_lo = row_lo; ka.B = batch;
   ka.inv_B = 1.0f / (float)batch_global; ka.z_mode = 1; ka.loss = loss;
-  if (FitChainState *fc = static_cast<FitChainState *>(h->fit_chain); fc && (batch == 16 || batch == 32)) {
+  if (FitChainState *fc = static_cast<FitChainState *>(h->fit_chain); fc && (batch == 32 || (batch == 16 && !fc->pad))) {
     FitChainArgs ca = fc->base;
     ca.x = x; ca.y = y; ca.v = v; ca.data_z = data_z; ca.idx = idx; ca.row_lo = row_lo; ca.inv_B = ka.inv_B;
     ca.loss = loss; ca.dz = h->ws_dev + h->fit_ws.dz;

@@ -32,7 +32,7 @@ struct FitChainArgs {
 __device__ __forceinline__ long long fitc_row(const FitChainArgs &a, int b) { return a.idx ? (long long)a.idx[b] : a.row_lo + b; }
 
 // Z_MODE 0: theta phase (stash, no input gradients); 1: latent phase (input gradients -> dz)
-template <int HT, int NTL, int T1, int T2, int T3, int NB, int Z_MODE>
+template <int HT, int NTL, int T1, int T2, int T3, int NB, int Z_MODE, bool PAD = false>
 static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_kernel(FitChainArgs a) {
   __shared__ float dzc[3 * 32 * 16];
   __shared__ double lsum[8 * 8];
@@ -58,7 +58,7 @@ static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_kernel(FitChainA
       for (int r = 0; r < 4; ++r) { zin[0][r] = ech_ld(zrow, 4 * g + r, q); zsq = fmaf(zin[0][r], zin[0][r], zsq); }
       l2 = 0.5f * sum_over_g(zsq);
       f32x4 o[NTL];
-      ecg_g_fwd<HT, NTL>(th, a.g, a.xo[0], ws, row, zin, o, j, g);
+      ecg_g_fwd<HT, NTL, PAD>(th, a.g, a.xo[0], ws, row, zin, o, j, g);
       const float *vrow = a.v + prow * p;
       float ssq = 0.0f, sraw = 0.0f;
 #pragma unroll

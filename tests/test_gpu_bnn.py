@@ -48,9 +48,10 @@ def _rel(a, b):
     (True, 32, {}, 50),
     (False, 19, dict(g_units=(24, 40), e_units=(16,), f_units=(20, 12), h_units=(9, 5)), 37),
     (False, 32, {}, 200), (True, 32, {}, 100), (False, 16, {}, 100),       # row-tile chains
+    (False, 32, {}, 45),                                                     # ... the 13-tile kernels on a narrower panel (masked columns)
 ])
 def test_theta_step_gradients_match_oracle(binary, B, units, p):
-    chain = p >= 100
+    chain = p >= 100 or p == 45
     m = _model(binary, p=p, fixed=chain, **units)
     z, x, y, v = _panel(m, 200)
     eng = _engine(m, kl_weight=0.01, **(dict(norm_mode=1) if chain else {}), **units)
@@ -77,9 +78,9 @@ def test_theta_step_gradients_match_oracle(binary, B, units, p):
     eng.close()
 
 
-@pytest.mark.parametrize("binary,p,B", [(False, 50, 32), (True, 50, 32), (False, 200, 32), (True, 100, 32), (False, 100, 16)])
+@pytest.mark.parametrize("binary,p,B", [(False, 50, 32), (True, 50, 32), (False, 200, 32), (True, 100, 32), (False, 100, 16), (True, 45, 32)])
 def test_z_step_gradient_matches_oracle(binary, p, B):
-    chain = p >= 100
+    chain = p >= 100 or p == 45
     m = _model(binary, p=p, fixed=chain)
     z, x, y, v = _panel(m, 100)
     eng = _engine(m, norm_mode=1) if chain else _engine(m)
@@ -255,7 +256,7 @@ def test_evaluate_matches_oracle(binary, p):
 
 
 @pytest.mark.parametrize("binary,disc_norm,p", [(False, "batch", 50), (True, "batch", 50), (False, "fixed", 50), (True, "fixed", 50),
-                                                (False, "fixed", 100), (True, "fixed", 200)])
+                                                (False, "fixed", 100), (True, "fixed", 200), (False, "fixed", 45)])
 def test_egm_steps_match_oracle(binary, disc_norm, p):
     """EGM warm-start steps with Bayesian nets: gradients of the discriminator step and of the nine-call generator step.
     disc_norm = "fixed" (the models' default): the discriminator passes of the step run as register-chained row tiles; at
@@ -271,10 +272,10 @@ def test_egm_steps_match_oracle(binary, disc_norm, p):
     for l in range(3):
         dz["gamma"][l] = (1.0 + 0.2 * rs.standard_normal(dz["gamma"][l].shape)).astype(np.float32)
         dz["beta"][l] = (0.1 * rs.standard_normal(dz["beta"][l].shape)).astype(np.float32)
-    if p >= 100:          # the models' default input normalisation as well (bnn_norm = "fixed")
+    if p >= 100 or p == 45:          # the models' default input normalisation as well (bnn_norm = "fixed")
         for k in ("g", "e", "f", "h"):
             m[k]["norm"] = "fixed"
-    eng = _engine(m, norm_mode=1) if p >= 100 else _engine(m)
+    eng = _engine(m, norm_mode=1) if (p >= 100 or p == 45) else _engine(m)
     dev = eng.device
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     if disc_norm == "fixed":
