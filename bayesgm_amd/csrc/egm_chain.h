@@ -85,15 +85,15 @@ struct EchP {
   int b0, b1, b2, ga0, ga1, ga2, be0, be1, be2, wo, bo;
   int total;
 };
-template <int T1, int T2, int T3>
+template <int T1, int T2, int T3, int T0 = 1>
 __host__ __device__ inline EchP ech_layout(const EgmDisc &d) {
   EchP P;
   P.d0 = d.dims[0]; P.d1 = d.dims[1]; P.d2 = d.dims[2]; P.d3 = d.dims[3];
   P.ld0 = 16 * T1 + 4; P.ld1 = 16 * T2 + 4; P.ld2 = 16 * T3 + 4;
-  P.lt0 = 16 + 4; P.lt1 = 16 * T1 + 4; P.lt2 = 16 * T2 + 4;
+  P.lt0 = 16 * T0 + 4; P.lt1 = 16 * T1 + 4; P.lt2 = 16 * T2 + 4;
   int o = 0;
   auto take = [&](int n) { const int r = o; o += (n + 3) & ~3; return r; };
-  P.W0 = take(16 * P.ld0); P.W1 = take(16 * T1 * P.ld1); P.W2 = take(16 * T2 * P.ld2);
+  P.W0 = take(16 * T0 * P.ld0); P.W1 = take(16 * T1 * P.ld1); P.W2 = take(16 * T2 * P.ld2);
   P.T0 = take(16 * T1 * P.lt0); P.T1 = take(16 * T2 * P.lt1); P.T2 = take(16 * T3 * P.lt2);
   P.b0 = take(16 * T1); P.b1 = take(16 * T2); P.b2 = take(16 * T3);
   P.ga0 = take(16 * T1); P.ga1 = take(16 * T2); P.ga2 = take(16 * T3);
@@ -103,22 +103,22 @@ __host__ __device__ inline EchP ech_layout(const EgmDisc &d) {
   return P;
 }
 // stash of one pass (floats per row): inputs X_l of the three hidden layers, then their (scaled) pre-activation gradients D_l
-template <int T1, int T2, int T3> struct EchDims {
-  static constexpr int XW = 16 * (1 + T1 + T2), DW = 16 * (T1 + T2 + T3), SW = XW + DW;
+template <int T1, int T2, int T3, int T0 = 1> struct EchDims {
+  static constexpr int XW = 16 * (T0 + T1 + T2), DW = 16 * (T1 + T2 + T3), SW = XW + DW;
   static constexpr int SL = 16 * (T1 + T2 + T3);            // per-wave partial sums: gamma [SL] | beta [SL] | w_out [16 T3] | scalars [16]
   static constexpr int SLOT = 2 * SL + 16 * T3 + 16;
-  static constexpr int TILES = T1 + T1 * T2 + T2 * T3;      // weight-gradient tiles
+  static constexpr int TILES = T0 * T1 + T1 * T2 + T2 * T3;      // weight-gradient tiles
 };
-template <int T1, int T2, int T3>
+template <int T1, int T2, int T3, int T0 = 1>
 __host__ __device__ inline int ech_disc_lds_floats(const EgmDisc &d, int B) {
-  using D = EchDims<T1, T2, T3>;
-  return 64 + ech_layout<T1, T2, T3>(d).total + ECH_ROLE_WAVES * D::SLOT + 16 * B + 4 * B * D::SW;
+  using D = EchDims<T1, T2, T3, T0>;
+  return 64 + ech_layout<T1, T2, T3, T0>(d).total + ECH_ROLE_WAVES * D::SLOT + 16 * T0 * B + 4 * B * D::SW;
 }
 
-template <int T1, int T2, int T3>
+template <int T1, int T2, int T3, int T0 = 1>
 __device__ __forceinline__ void ech_fill_params(float *par, const EchP &P, const float *th, const EgmDisc &d, int tid, int nthr) {
   const int dims_in[3] = {P.d0, P.d1, P.d2}, dims_out[3] = {P.d1, P.d2, P.d3};
-  const int kp[3] = {16, 16 * T1, 16 * T2}, np_[3] = {16 * T1, 16 * T2, 16 * T3};       // padded extents
+  const int kp[3] = {16 * T0, 16 * T1, 16 * T2}, np_[3] = {16 * T1, 16 * T2, 16 * T3};       // padded extents
   const int ld[3] = {P.ld0, P.ld1, P.ld2}, lt[3] = {P.lt0, P.lt1, P.lt2}, ow[3] = {P.W0, P.W1, P.W2}, ot[3] = {P.T0, P.T1, P.T2};
   const int ob[3] = {P.b0, P.b1, P.b2}, og[3] = {P.ga0, P.ga1, P.ga2}, oe[3] = {P.be0, P.be1, P.be2};
 #pragma unroll
@@ -146,13 +146,13 @@ __device__ __forceinline__ void ech_fill_params(float *par, const EchP &P, const
 // ---------------------------------------------------------------------------------------------
 // one discriminator evaluation on a row tile
 // ---------------------------------------------------------------------------------------------
-template <int T1, int T2, int T3>
+template <int T1, int T2, int T3, int T0 = 1>
 struct EchFwd {
-  f32x4 a0[1], a1[T1], a2[T2], a3[T3];     // layer inputs / tanh outputs
+  f32x4 a0[T0], a1[T1], a2[T2], a3[T3];    // layer inputs / tanh outputs (T0 tiles of input: q <= 16 T0)
   f32x4 u1[T1], u2[T2], u3[T3];            // normalised pre-activations (uhat)
   float out;
 };
-template <int T1, int T2, int T3>
+template <int T1, int T2, int T3, int T0 = 1>
 struct EchAcc {                            // per-row contributions to the vector-parameter gradients (summed over rows at the end)
   f32x4 gam1[T1], gam2[T2], gam3[T3], bet1[T1], bet2[T2], bet3[T3], wo[T3];
 };
@@ -161,8 +161,8 @@ __device__ __forceinline__ void ech_zero(f32x4 (&x)[NT]) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) x[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 }
-template <int T1, int T2, int T3>
-__device__ __forceinline__ void ech_zero_acc(EchAcc<T1, T2, T3> &acc) {
+template <int T1, int T2, int T3, int T0 = 1>
+__device__ __forceinline__ void ech_zero_acc(EchAcc<T1, T2, T3, T0> &acc) {
   ech_zero<T1>(acc.gam1); ech_zero<T2>(acc.gam2); ech_zero<T3>(acc.gam3);
   ech_zero<T1>(acc.bet1); ech_zero<T2>(acc.bet2); ech_zero<T3>(acc.bet3); ech_zero<T3>(acc.wo);
 }
@@ -190,10 +190,10 @@ __device__ __forceinline__ void ech_stash(float *base, int row, int g, const f32
   for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4 *>(base + row * (16 * NT) + 16 * t + 4 * g) = x[t] * s;
 }
 
-template <int T1, int T2, int T3>
-__device__ __forceinline__ void ech_disc_fwd(const float *par, const EchP &P, EchFwd<T1, T2, T3> &F, int j, int g) {
+template <int T1, int T2, int T3, int T0 = 1>
+__device__ __forceinline__ void ech_disc_fwd(const float *par, const EchP &P, EchFwd<T1, T2, T3, T0> &F, int j, int g) {
   f32x4 u1[T1], u2[T2], u3[T3];
-  ech_dense<1, T1, true>(par + P.W0, P.ld0, par + P.b0, P.d0, P.d1, F.a0, u1, j, g);
+  ech_dense<T0, T1, true>(par + P.W0, P.ld0, par + P.b0, P.d0, P.d1, F.a0, u1, j, g);
   ech_act<T1>(par + P.ga0, par + P.be0, P.d1, g, u1, F.u1, F.a1);
   ech_dense<T1, T2, true>(par + P.W1, P.ld1, par + P.b1, P.d1, P.d2, F.a1, u2, j, g);
   ech_act<T2>(par + P.ga1, par + P.be1, P.d2, g, u2, F.u2, F.a2);
@@ -227,12 +227,12 @@ __device__ __forceinline__ void ech_bwd_act(const float *ga, int n, int g, const
 // Ordinary backward of one evaluation: dLoss/dout = dout on every row (ADJ = false), or no output gradient but node adjoints
 // ab* on the tanh outputs (ADJ = true: the second half of the gradient penalty).  Stashes (a_{l-1}, s du_l) of the three
 // hidden layers for the weight-gradient GEMMs of the last phase; `st` = this pass's stash block.
-template <int T1, int T2, int T3, bool ADJ>
-__device__ __forceinline__ void ech_disc_bwd(const float *par, const EchP &P, const EchFwd<T1, T2, T3> &F, float dout, const f32x4 (&ab1)[T1],
+template <int T1, int T2, int T3, bool ADJ, int T0 = 1>
+__device__ __forceinline__ void ech_disc_bwd(const float *par, const EchP &P, const EchFwd<T1, T2, T3, T0> &F, float dout, const f32x4 (&ab1)[T1],
                                              const f32x4 (&ab2)[T2], const f32x4 (&ab3)[T3], float s, float *st, int B, int row,
-                                             EchAcc<T1, T2, T3> &acc, int j, int g) {
-  using D = EchDims<T1, T2, T3>;
-  float *X0 = st, *X1 = st + B * 16, *X2 = st + B * (16 + 16 * T1);
+                                             EchAcc<T1, T2, T3, T0> &acc, int j, int g) {
+  using D = EchDims<T1, T2, T3, T0>;
+  float *X0 = st, *X1 = st + B * 16 * T0, *X2 = st + B * (16 * T0 + 16 * T1);
   float *D0 = st + B * D::XW, *D1 = D0 + B * 16 * T1, *D2 = D1 + B * 16 * T2;
   f32x4 da3[T3], du3[T3];
 #pragma unroll
@@ -261,7 +261,7 @@ __device__ __forceinline__ void ech_disc_bwd(const float *par, const EchP &P, co
     for (int t = 0; t < T1; ++t) da1[t] += ab1[t];
   }
   ech_bwd_act<T1>(par + P.ga0, P.d1, g, da1, F.a1, F.u1, s, acc.gam1, acc.bet1, du1);
-  ech_stash<1>(X0, row, g, F.a0, 1.0f);
+  ech_stash<T0>(X0, row, g, F.a0, 1.0f);
   ech_stash<T1>(D0, row, g, du1, s);
 }
 
@@ -297,14 +297,14 @@ __device__ __forceinline__ void ech_rev_act(const float *ga, int g, const f32x4 
 
 // Gradient penalty on the evaluation F (of zhat): s * d/dtheta mean_b (||d out_b / d input_b|| - 1)^2.  st_rev / st_bwd: stash blocks of
 // the reverse pass through the adjoint network and of the backward pass through the forward network.  Returns (||g|| - 1)^2 of the row.
-template <int T1, int T2, int T3>
-__device__ __forceinline__ float ech_disc_gp(const float *par, const EchP &P, const EchFwd<T1, T2, T3> &F, float s, float *st_rev,
-                                             float *st_bwd, int B, int row, EchAcc<T1, T2, T3> &acc, int j, int g) {
-  using D = EchDims<T1, T2, T3>;
-  float *X0 = st_rev, *X1 = st_rev + B * 16, *X2 = st_rev + B * (16 + 16 * T1);
+template <int T1, int T2, int T3, int T0 = 1>
+__device__ __forceinline__ float ech_disc_gp(const float *par, const EchP &P, const EchFwd<T1, T2, T3, T0> &F, float s, float *st_rev,
+                                             float *st_bwd, int B, int row, EchAcc<T1, T2, T3, T0> &acc, int j, int g) {
+  using D = EchDims<T1, T2, T3, T0>;
+  float *X0 = st_rev, *X1 = st_rev + B * 16 * T0, *X2 = st_rev + B * (16 * T0 + 16 * T1);
   float *D0 = st_rev + B * D::XW, *D1 = D0 + B * 16 * T1, *D2 = D1 + B * 16 * T2;
   // ---- adjoint network: g = d out / d input  (its du_l go straight to the stash: W_l receives abar_{l-1}^T du_l below)
-  f32x4 dA3[T3], dA2[T2], dA1[T1], g0[1];
+  f32x4 dA3[T3], dA2[T2], dA1[T1], g0[T0];
   {
     f32x4 du3[T3];
 #pragma unroll
@@ -321,11 +321,13 @@ __device__ __forceinline__ float ech_disc_gp(const float *par, const EchP &P, co
     f32x4 du1[T1];
     ech_adj_act<T1>(par + P.ga0, g, dA1, F.a1, du1);
     ech_stash<T1>(D0, row, g, du1, s);
-    ech_dense<T1, 1, true>(par + P.T0, P.lt0, nullptr, P.d1, P.d0, du1, g0, j, g);
+    ech_dense<T1, T0, true>(par + P.T0, P.lt0, nullptr, P.d1, P.d0, du1, g0, j, g);
   }
   float n2 = 0.0f;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) n2 = fmaf(g0[0][r], g0[0][r], n2);
+  for (int t = 0; t < T0; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) n2 = fmaf(g0[t][r], g0[t][r], n2);
   n2 = sum_over_g(n2);
   const float nrm = sqrtf(n2);
   const float part = (nrm - 1.0f) * (nrm - 1.0f);
@@ -333,11 +335,12 @@ __device__ __forceinline__ float ech_disc_gp(const float *par, const EchP &P, co
   // ---- reverse through the adjoint network, bottom to top
   f32x4 ab1[T1], ab2[T2], ab3[T3];
   {
-    f32x4 an0[1];
-    an0[0] = g0[0] * coef;
-    ech_stash<1>(X0, row, g, an0, 1.0f);
+    f32x4 an0[T0];
+#pragma unroll
+    for (int t = 0; t < T0; ++t) an0[t] = g0[t] * coef;
+    ech_stash<T0>(X0, row, g, an0, 1.0f);
     f32x4 dub1[T1], an1[T1];
-    ech_dense<1, T1, true>(par + P.W0, P.ld0, nullptr, P.d0, P.d1, an0, dub1, j, g);
+    ech_dense<T0, T1, true>(par + P.W0, P.ld0, nullptr, P.d0, P.d1, an0, dub1, j, g);
     ech_rev_act<T1>(par + P.ga0, g, dub1, dA1, F.a1, s, acc.gam1, ab1, an1);
     ech_stash<T1>(X1, row, g, an1, 1.0f);
     f32x4 dub2[T2], an2[T2];
@@ -351,14 +354,14 @@ __device__ __forceinline__ float ech_disc_gp(const float *par, const EchP &P, co
     for (int t = 0; t < T3; ++t) acc.wo[t] += an3[t] * s;      // d out / d a_L = w_out: its adjoint is abar_L summed over rows
   }
   // ---- ... and on through the forward pass
-  ech_disc_bwd<T1, T2, T3, true>(par, P, F, 0.0f, ab1, ab2, ab3, s, st_bwd, B, row, acc, j, g);
+  ech_disc_bwd<T1, T2, T3, true, T0>(par, P, F, 0.0f, ab1, ab2, ab3, s, st_bwd, B, row, acc, j, g);
   return part;
 }
 
 // sums over the 16 rows of the tile -> this wave's slot (lane j = 15 of each group holds the totals)
-template <int T1, int T2, int T3>
-__device__ __forceinline__ void ech_write_slot(float *slot, const EchAcc<T1, T2, T3> &acc, float out_signed, float gp_part, int j, int g) {
-  using D = EchDims<T1, T2, T3>;
+template <int T1, int T2, int T3, int T0 = 1>
+__device__ __forceinline__ void ech_write_slot(float *slot, const EchAcc<T1, T2, T3, T0> &acc, float out_signed, float gp_part, int j, int g) {
+  using D = EchDims<T1, T2, T3, T0>;
   auto put = [&](float *dst, const f32x4 &v) {
     f32x4 s;
 #pragma unroll
@@ -478,8 +481,8 @@ __device__ __forceinline__ void ech_encoder_l1(const float *W, int p, const floa
 }
 
 // KT0 = ceil(p / 16) when that shape is compiled, 0 = any p
-template <int HT, int KT0>
-__device__ __forceinline__ void ech_encoder(const float *theta, const EgmMlp &n, const float *vrow, f32x4 (&z)[1], int j, int g) {
+template <int HT, int KT0, int T0 = 1>
+__device__ __forceinline__ void ech_encoder(const float *theta, const EgmMlp &n, const float *vrow, f32x4 (&z)[T0], int j, int g) {
   const int p = n.dims[0], L = n.n_layers, q = n.dims[L];
   constexpr int H = 16 * HT;
   f32x4 h[HT];
@@ -529,16 +532,20 @@ __device__ __forceinline__ void ech_encoder(const float *theta, const EgmMlp &n,
       for (int u = 0; u < HT; ++u) wa[k][u] = wn[k][u];
   }
 #pragma unroll
-  for (int k = 0; k < 4 * HT; ++k) wz[k] = Wl[(16 * (k >> 2) + 4 * g + (k & 3)) * q + min(j, q - 1)];
-  f32x4 bz;
+  for (int tz = 0; tz < T0; ++tz) {            // output tiles (q <= 16 T0)
+    const int o = 16 * tz + j;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) { bz[r] = ech_ld(Wl + H * q, 4 * g + r, q); z[0][r] = 0.0f; }
-  const float jm = j < q ? 1.0f : 0.0f;
+    for (int k = 0; k < 4 * HT; ++k) wz[k] = Wl[(16 * (k >> 2) + 4 * g + (k & 3)) * q + min(o, q - 1)];
+    f32x4 bz;
 #pragma unroll
-  for (int t = 0; t < HT; ++t)
+    for (int r = 0; r < 4; ++r) { bz[r] = ech_ld(Wl + H * q, 16 * tz + 4 * g + r, q); z[tz][r] = 0.0f; }
+    const float jm = o < q ? 1.0f : 0.0f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) z[0] = BGM_MFMA(wz[4 * t + r] * jm, h[t][r], z[0]);
-  z[0] += bz;
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) z[tz] = BGM_MFMA(wz[4 * t + r] * jm, h[t][r], z[tz]);
+    z[tz] += bz;
+  }
 }
 
 // what the discriminator passes need from a step's arguments (CausalBGM and its Bayesian-network variant share them)
@@ -562,23 +569,23 @@ __device__ __forceinline__ void ech_adam(const EchDiscIo &a, int e, float gi, fl
 }
 
 // LDS map behind the 64 reduction words: parameter block | per-wave partial sums | z_ tiles [B x 16] | stash of the four passes
-template <int T1, int T2, int T3>
+template <int T1, int T2, int T3, int T0 = 1>
 struct EchLds {
   float *par, *slots, *zt, *stash;
   __device__ __forceinline__ EchLds(float *lds, const EchP &P, int B) {
-    using D = EchDims<T1, T2, T3>;
+    using D = EchDims<T1, T2, T3, T0>;
     par = lds + 64;
     slots = par + P.total;
     zt = slots + ECH_ROLE_WAVES * D::SLOT;
-    stash = zt + 16 * B;
+    stash = zt + 16 * T0 * B;
   }
 };
 
 // The three discriminator passes, the gradient GEMMs and Adam.  On entry (after a workgroup barrier): `par` filled, z_ = e(v) of
 // the minibatch in `zt` ([B x 16], zero beyond q).  Waves 0,1: D(z_); 2,3: D(z); 4,5: D(zhat) with the gradient penalty.
-template <int T1, int T2, int T3, int NB>
-__device__ __forceinline__ void ech_disc_tail(const EchDiscIo &a, const EgmDisc &dz, const EchP &P, const EchLds<T1, T2, T3> &M, int tid) {
-  using D = EchDims<T1, T2, T3>;
+template <int T1, int T2, int T3, int NB, int T0 = 1>
+__device__ __forceinline__ void ech_disc_tail(const EchDiscIo &a, const EgmDisc &dz, const EchP &P, const EchLds<T1, T2, T3, T0> &M, int tid) {
+  using D = EchDims<T1, T2, T3, T0>;
   constexpr int B = 16 * NB;
   const int lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const int q = a.q;
@@ -590,41 +597,47 @@ __device__ __forceinline__ void ech_disc_tail(const EchDiscIo &a, const EgmDisc 
   f32x4 nul1[T1], nul2[T2], nul3[T3];
   ech_zero<T1>(nul1); ech_zero<T2>(nul2); ech_zero<T3>(nul3);
   if (role == 0 && active) {
-    EchAcc<T1, T2, T3> acc;
+    EchAcc<T1, T2, T3, T0> acc;
     ech_zero_acc(acc);
-    EchFwd<T1, T2, T3> F;
-    F.a0[0] = *reinterpret_cast<const f32x4 *>(zt + row * 16 + 4 * g);
-    ech_disc_fwd<T1, T2, T3>(par, P, F, j, g);
-    ech_disc_bwd<T1, T2, T3, false>(par, P, F, invB, nul1, nul2, nul3, 1.0f, stash, B, row, acc, j, g);
-    ech_write_slot<T1, T2, T3>(slots + wave * D::SLOT, acc, F.out, 0.0f, j, g);
+    EchFwd<T1, T2, T3, T0> F;
+#pragma unroll
+    for (int t = 0; t < T0; ++t) F.a0[t] = *reinterpret_cast<const f32x4 *>(zt + row * (16 * T0) + 16 * t + 4 * g);
+    ech_disc_fwd<T1, T2, T3, T0>(par, P, F, j, g);
+    ech_disc_bwd<T1, T2, T3, false, T0>(par, P, F, invB, nul1, nul2, nul3, 1.0f, stash, B, row, acc, j, g);
+    ech_write_slot<T1, T2, T3, T0>(slots + wave * D::SLOT, acc, F.out, 0.0f, j, g);
   } else if (role == 1 && active) {
-    EchAcc<T1, T2, T3> acc;
+    EchAcc<T1, T2, T3, T0> acc;
     ech_zero_acc(acc);
-    EchFwd<T1, T2, T3> F;
+    EchFwd<T1, T2, T3, T0> F;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) F.a0[0][r] = ech_ld(a.z + (long long)row * q, 4 * g + r, q);
-    ech_disc_fwd<T1, T2, T3>(par, P, F, j, g);
-    ech_disc_bwd<T1, T2, T3, false>(par, P, F, -invB, nul1, nul2, nul3, 1.0f, stash + 1 * B * D::SW, B, row, acc, j, g);
-    ech_write_slot<T1, T2, T3>(slots + wave * D::SLOT, acc, -F.out, 0.0f, j, g);
+    for (int t = 0; t < T0; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) F.a0[t][r] = ech_ld(a.z + (long long)row * q, 16 * t + 4 * g + r, q);
+    ech_disc_fwd<T1, T2, T3, T0>(par, P, F, j, g);
+    ech_disc_bwd<T1, T2, T3, false, T0>(par, P, F, -invB, nul1, nul2, nul3, 1.0f, stash + 1 * B * D::SW, B, row, acc, j, g);
+    ech_write_slot<T1, T2, T3, T0>(slots + wave * D::SLOT, acc, -F.out, 0.0f, j, g);
   } else if (role == 2 && active) {
-    EchAcc<T1, T2, T3> acc;
+    EchAcc<T1, T2, T3, T0> acc;
     ech_zero_acc(acc);
-    EchFwd<T1, T2, T3> F;
-    const f32x4 ze = *reinterpret_cast<const f32x4 *>(zt + row * 16 + 4 * g);
+    EchFwd<T1, T2, T3, T0> F;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) F.a0[0][r] = ech_ld(a.z + (long long)row * q, 4 * g + r, q) * a.eps + ze[r] * (1.0f - a.eps);
-    ech_disc_fwd<T1, T2, T3>(par, P, F, j, g);
-    const float part = ech_disc_gp<T1, T2, T3>(par, P, F, 10.0f, stash + 2 * B * D::SW, stash + 3 * B * D::SW, B, row, acc, j, g);
-    ech_write_slot<T1, T2, T3>(slots + wave * D::SLOT, acc, 0.0f, part, j, g);
+    for (int t = 0; t < T0; ++t) {
+      const f32x4 ze = *reinterpret_cast<const f32x4 *>(zt + row * (16 * T0) + 16 * t + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) F.a0[t][r] = ech_ld(a.z + (long long)row * q, 16 * t + 4 * g + r, q) * a.eps + ze[r] * (1.0f - a.eps);
+    }
+    ech_disc_fwd<T1, T2, T3, T0>(par, P, F, j, g);
+    const float part = ech_disc_gp<T1, T2, T3, T0>(par, P, F, 10.0f, stash + 2 * B * D::SW, stash + 3 * B * D::SW, B, row, acc, j, g);
+    ech_write_slot<T1, T2, T3, T0>(slots + wave * D::SLOT, acc, 0.0f, part, j, g);
   }
   __syncthreads();
   // ---- parameter gradients: W_l += sum over the four passes of X^T D (rows = K), one 16x16 tile per wave and round
   const float c = ech_c();
   for (int tau = wave; tau < D::TILES; tau += ECH_WAVES) {
     int l, u, v, xw, dw, xo, dofs, n_in, n_out;
-    if (tau < T1) { l = 0; u = 0; v = tau; xw = 16; dw = 16 * T1; xo = 0; dofs = 0; n_in = P.d0; n_out = P.d1; }
-    else if (tau < T1 + T1 * T2) { const int k = tau - T1; l = 1; u = k / T2; v = k - u * T2; xw = 16 * T1; dw = 16 * T2; xo = 16; dofs = 16 * T1; n_in = P.d1; n_out = P.d2; }
-    else { const int k = tau - T1 - T1 * T2; l = 2; u = k / T3; v = k - u * T3; xw = 16 * T2; dw = 16 * T3; xo = 16 + 16 * T1; dofs = 16 * (T1 + T2); n_in = P.d2; n_out = P.d3; }
+    if (tau < T0 * T1) { l = 0; u = tau / T1; v = tau - u * T1; xw = 16 * T0; dw = 16 * T1; xo = 0; dofs = 0; n_in = P.d0; n_out = P.d1; }
+    else if (tau < T0 * T1 + T1 * T2) { const int k = tau - T0 * T1; l = 1; u = k / T2; v = k - u * T2; xw = 16 * T1; dw = 16 * T2; xo = 16 * T0; dofs = 16 * T1; n_in = P.d1; n_out = P.d2; }
+    else { const int k = tau - T0 * T1 - T1 * T2; l = 2; u = k / T3; v = k - u * T3; xw = 16 * T2; dw = 16 * T3; xo = 16 * T0 + 16 * T1; dofs = 16 * (T1 + T2); n_in = P.d2; n_out = P.d3; }
     // Adam state of this lane's four elements: requested before the GEMM, consumed after it
     const int o = 16 * v + j;
     int e[4]; float th[4], m0[4], v0[4];
@@ -682,21 +695,22 @@ __device__ __forceinline__ void ech_disc_tail(const EchDiscIo &a, const EgmDisc 
   }
 }
 
-template <int HT, int KT0, int T1, int T2, int T3, int NB>
+template <int HT, int KT0, int T1, int T2, int T3, int NB, int T0 = 1>
 static __global__ __launch_bounds__(ECH_THREADS) void egm_disc_chain_kernel(EgmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float ech_lds[];
   constexpr int B = 16 * NB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
-  const EchP P = ech_layout<T1, T2, T3>(a.dz);
-  const EchLds<T1, T2, T3> M(ech_lds, P, B);
+  const EchP P = ech_layout<T1, T2, T3, T0>(a.dz);
+  const EchLds<T1, T2, T3, T0> M(ech_lds, P, B);
   ECH_STAMP(0);
   const int role = wave >> 1, tile = wave & 1;
   const int row = 16 * tile + j;
   if (role == 0) {
     if (tile < NB) {
-      f32x4 zf[1];
-      ech_encoder<HT, KT0>(a.theta_g, a.e, a.v + (long long)a.idx[row] * a.p, zf, j, g);
-      *reinterpret_cast<f32x4 *>(M.zt + row * 16 + 4 * g) = zf[0];
+      f32x4 zf[T0];
+      ech_encoder<HT, KT0, T0>(a.theta_g, a.e, a.v + (long long)a.idx[row] * a.p, zf, j, g);
+#pragma unroll
+      for (int t = 0; t < T0; ++t) *reinterpret_cast<f32x4 *>(M.zt + row * (16 * T0) + 16 * t + 4 * g) = zf[t];
     }
   } else {
     // the other six waves: the discriminator's parameter block, then pull the encoder's weights into this XCD's L2 ahead of
@@ -709,12 +723,12 @@ static __global__ __launch_bounds__(ECH_THREADS) void egm_disc_chain_kernel(EgmA
       for (int k = 0; k < 8; ++k) sink += w[min(i + (ECH_THREADS - 128) * k, n - 1)];
     }
     asm volatile("" ::"v"(sink));
-    ech_fill_params<T1, T2, T3>(M.par, P, a.theta_d, a.dz, tid - 128, ECH_THREADS - 128);
+    ech_fill_params<T1, T2, T3, T0>(M.par, P, a.theta_d, a.dz, tid - 128, ECH_THREADS - 128);
   }
   ECH_STAMP(1);
   __syncthreads();
   ECH_STAMP(2);
   const EchDiscIo io{a.theta_d, a.m_d, a.v_d, a.grad_d, a.adam, a.apply, a.q, a.out, a.z, a.eps};
-  ech_disc_tail<T1, T2, T3, NB>(io, a.dz, P, M, tid);
+  ech_disc_tail<T1, T2, T3, NB, T0>(io, a.dz, P, M, tid);
   ECH_STAMP(6);
 }
