@@ -13,7 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-typedef struct { uint32_t key[624]; int pos; int has_gauss; double gauss; } bgm_mt_state;
+typedef struct { uint32_t key[624]; uint32_t out[624]; int pos; int has_gauss; double gauss; } bgm_mt_state;   /* out: key, tempered */
 
 static void mt_gen(bgm_mt_state *s) {
   const uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MATRIX_A = 0x9908b0dfu;
@@ -25,12 +25,16 @@ static void mt_gen(bgm_mt_state *s) {
   s->key[623] = s->key[396] ^ (y >> 1) ^ (-(y & 1) & MATRIX_A);
   s->pos = 0;
 }
+static void mt_temper(bgm_mt_state *s) {          /* the whole block at once: a vectorisable loop instead of four dependent ops per draw */
+  for (int i = 0; i < 624; i++) {
+    uint32_t y = s->key[i];
+    y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= (y >> 18);
+    s->out[i] = y;
+  }
+}
 static inline uint32_t mt_u32(bgm_mt_state *s) {
-  uint32_t y;
-  if (s->pos == 624) mt_gen(s);
-  y = s->key[s->pos++];
-  y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= (y >> 18);
-  return y;
+  if (__builtin_expect(s->pos == 624, 0)) { mt_gen(s); mt_temper(s); }
+  return s->out[s->pos++];
 }
 static inline double mt_double(bgm_mt_state *s) {
   const int32_t a = (int32_t)(mt_u32(s) >> 5), b = (int32_t)(mt_u32(s) >> 6);
@@ -68,6 +72,7 @@ int bgm_host_egm_block(uint32_t *key, int *pos, int *has_gauss, double *gauss, i
   bgm_mt_state s;
   memcpy(s.key, key, sizeof(s.key));
   s.pos = *pos; s.has_gauss = *has_gauss; s.gauss = *gauss;
+  mt_temper(&s);
   int32_t *perm = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
   if (!perm) return -1;
   const int steps = g_d_freq + 1;
