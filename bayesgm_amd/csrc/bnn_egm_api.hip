@@ -217,6 +217,11 @@ extern "C" int bgm_bnn_egm_disc_step(bgm_handle *h, const float *z_dev, const in
   return BGM_OK;
 }
 
+// the generator chain's instantiations live in bnn_egm_gen_chain_{a,b,c}.hip (compile time)
+int bnn_egm_gen_chain_launch_a(const BnnEgmArgs &a, int nb, int lds, const EcbTab *tab, float *thetaT, hipStream_t stream);
+int bnn_egm_gen_chain_launch_b(const BnnEgmArgs &a, int nb, int lds, const EcbTab *tab, float *thetaT, hipStream_t stream);
+int bnn_egm_gen_chain_launch_c(const BnnEgmArgs &a, int nb, int lds, const EcbTab *tab, float *thetaT, hipStream_t stream);
+
 extern "C" int bgm_bnn_egm_gen_step(bgm_handle *h, const float *z_dev, const int32_t *idx_dev, const float *v_dev, const float *x_dev,
                                     const float *y_dev, uint64_t seed, uint32_t stream_id, int32_t apply, float *out_dev, void *stream_) {
   BnnState *s; BnnEgmState *e;
@@ -230,14 +235,13 @@ extern "C" int bgm_bnn_egm_gen_step(bgm_handle *h, const float *z_dev, const int
   if (apply) { e->t_g += 1; s->packed_valid = false; }
   a.adam = bnn_egm_adam(e->cfg.lr, std::max<long long>(1, e->t_g));
   if (e->chain_gen_lds > 0) {
-    auto kc = e->chain_pad ? bnn_egm_gen_chain_kernel<13, 2, true>
-              : a.B == 32 ? (e->chain_ntl == 13 ? bnn_egm_gen_chain_kernel<13, 2> : bnn_egm_gen_chain_kernel<7, 2>)
-                        : (e->chain_ntl == 13 ? bnn_egm_gen_chain_kernel<13, 1> : bnn_egm_gen_chain_kernel<7, 1>);
-    BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, e->chain_gen_lds));
     hipLaunchKernelGGL(bnn_egm_gen_noise_kernel, dim3(ECB_CALLS * ECB_NOISE_PARTS), dim3(EGM_THREADS), 0, (hipStream_t)stream_, a, e->tab_dev);
     BGM_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(kc, dim3(1), dim3(EGM_THREADS), e->chain_gen_lds, (hipStream_t)stream_, a, e->tab_dev, e->thetaT_dev);
-    BGM_HIP_CHECK(hipGetLastError());
+    const int nb = a.B / 16;
+    rc = e->chain_pad ? bnn_egm_gen_chain_launch_c(a, nb, e->chain_gen_lds, e->tab_dev, e->thetaT_dev, (hipStream_t)stream_)
+         : e->chain_ntl == 13 ? bnn_egm_gen_chain_launch_a(a, nb, e->chain_gen_lds, e->tab_dev, e->thetaT_dev, (hipStream_t)stream_)
+                              : bnn_egm_gen_chain_launch_b(a, nb, e->chain_gen_lds, e->tab_dev, e->thetaT_dev, (hipStream_t)stream_);
+    if (rc) return rc;
     auto kd = a.B == 32 ? bnn_egm_gen_dw_kernel<2> : bnn_egm_gen_dw_kernel<1>;
     hipLaunchKernelGGL(kd, dim3((e->n_tiles + ECH_WAVES - 1) / ECH_WAVES + 1), dim3(EGM_THREADS), 0, (hipStream_t)stream_, a, e->tab_dev, e->tiles_dev,
                        e->thetaT_dev);
