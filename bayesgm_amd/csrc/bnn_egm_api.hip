@@ -139,19 +139,7 @@ extern "C" int bgm_bnn_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, const
   a.ws = a.grad_d + nd;
   BGM_HIP_CHECK(hipMemcpy(a.theta_d, theta_dz_host, e->n_dz * sizeof(float), hipMemcpyHostToDevice));
   if (e->chain_gen_lds > 0) {
-    // transposed mirror of every `loc` (the backward chains read W^T rows contiguously); the gradient kernel's Adam keeps it current
-    std::vector<float> th(s->n_params), tT(s->n_params, 0.0f);
-    BGM_HIP_CHECK(hipMemcpy(th.data(), s->theta_dev, sizeof(float) * s->n_params, hipMemcpyDeviceToHost));
-    for (int k = 0; k < 4; ++k) {
-      const BnnNet &m = s->net[k];
-      for (int l = 0; l < m.n_layers; ++l) {
-        const int ni = m.lin[l], no = m.lout[l];
-        for (int f = 0; f < ni; ++f)
-          for (int o2 = 0; o2 < no; ++o2) tT[m.woff[l] + (size_t)o2 * ni + f] = th[m.woff[l] + (size_t)f * no + o2];
-      }
-    }
-    BGM_HIP_CHECK(hipMalloc((void **)&e->thetaT_dev, sizeof(float) * s->n_params));
-    BGM_HIP_CHECK(hipMemcpy(e->thetaT_dev, tT.data(), sizeof(float) * s->n_params, hipMemcpyHostToDevice));
+    // (no transposed mirror: the backward products read the canonical arrays K-contiguously, egm_chain_gen.h)
     BGM_HIP_CHECK(hipMalloc((void **)&e->tab_dev, sizeof(EcbTab)));
     BGM_HIP_CHECK(hipMemcpy(e->tab_dev, &tab, sizeof(EcbTab), hipMemcpyHostToDevice));
     BGM_HIP_CHECK(hipMalloc((void **)&e->tiles_dev, sizeof(int) * tiles.size()));

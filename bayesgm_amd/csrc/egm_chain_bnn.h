@@ -105,7 +105,7 @@ enum { ECB_G1 = 0, ECB_G1S = 1, ECB_E1 = 2, ECB_E2 = 3, ECB_G2 = 4, ECB_F = 5, E
 struct EcbCall {
   int net;                               // BNN_G / BNN_E / BNN_F / BNN_H
   int soff;                              // noise stream of the call = the step's stream id + soff
-  int eps, dW, dWT;                      // workspace offsets (floats) of the call's noise: eps, sigma * eps, and its per-layer transpose
+  int eps, dW, dWT;                      // workspace offset (floats) of the call's perturbations dW = sigma * eps (eps, dWT: unused, 0)
   int sg;                                // sign words [B x swords]
   int xh;                                // normalised input xhat [B x 16 KT0]
   int bnp;                               // per-row-tile sums for the input normalisation's gamma / beta: [NB][2][16 KT0]
@@ -625,8 +625,7 @@ __device__ __forceinline__ void ecb_gen_chain(const Args &a, const EcbTab &tab, 
     if (lane == 0) atomicAdd(const_cast<int *>(flag), 1);
     float sink = 0.0f;
     const int n4 = tab.n_warm >> 2;
-#pragma unroll
-    for (int arr = 0; arr < 2; ++arr) {
+    for (int arr = 0; arr < (tT ? 2 : 1); ++arr) {
       const f32x4 *src = reinterpret_cast<const f32x4 *>(arr == 0 ? th : tT);
       for (int i = tid - 384; i < n4; i += 128 * 16) {
         f32x4 acc4 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -670,7 +669,7 @@ __device__ __forceinline__ void ecb_gen_dw(const Args &a, const EcbTab &tab, con
       const float vi = a.adam.b2 * a.v[ei] + (1.0f - a.adam.b2) * gi * gi;
       const float tn = a.theta[ei] - a.adam.lr_t * mi / (sqrtf(vi) + a.adam.eps);
       a.m[ei] = mi; a.v[ei] = vi; a.theta[ei] = tn;
-      if (et >= 0) thetaT[et] = tn;
+      if (thetaT && et >= 0) thetaT[et] = tn;      // (no mirror in the Bayesian chains: both directions read the canonical array)
     }
   };
   const int n_tile_blocks = (tab.n_tiles + ECH_WAVES - 1) / ECH_WAVES;
