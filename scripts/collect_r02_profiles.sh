@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 rocprofv3 evidence, run on the GPU box from the repo root (gpurun): kernel traces and PMC passes of the SHIPPED kernels.
 # Counters in their own runs (no trace domains besides --kernel-trace), as MI355X_MICROARCH.md prescribes: SQ set | FETCH_SIZE | WRITE_SIZE.
-# usage: bash scripts/collect_r02_profiles.sh [what ...]   what in: bench mh encode hmc fit   (default: all)
+# usage: bash scripts/collect_r02_profiles.sh [what ...]   what in: bench mh encode hmc fit egm bnn   (default: all)
 set -u
 OUT=gpurun_out/r02prof
 mkdir -p $OUT
@@ -29,6 +29,8 @@ for w in $WHAT; do
       pmc3 encode_N1e6 python scripts/probe_encode.py 1e6 200 5 ;;
     hmc) pmc3 bgm_hmc python scripts/probe_bgm_wide.py 200000 10 ;;
     fit) pmc3 fit_B65536 python scripts/probe_fit.py 1e6 65536 dense 20 ;;
+    egm) pmc3 egm_chain python scripts/probe_egm_native.py 200 200 ;;
+    bnn) pmc3 bnn_chain env BNN_PROBE_SKIP_MH=1 python scripts/probe_bnn.py 20000 200 5 ;;
   esac
 done
 ls -la $OUT | head -40

@@ -30,7 +30,7 @@ for db in sys.argv[1:]:
                            "group by kernel_name, counter_name order by kernel_name").fetchall()
         last = None
         for k, c, v, n in rows:
-            if "bgm" not in k and "causal" not in k and "kernel" not in k.split("(")[0][-8:]:
+            if "bgm" not in k and "causal" not in k and "_kernel" not in k:
                 continue
             if k != last:
                 print("-- counters (summed over %d dispatches):" % n, short(k))
