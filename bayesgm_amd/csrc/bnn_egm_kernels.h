@@ -113,7 +113,7 @@ static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_disc_chain_kernel(
     ech_fill_params<T1, T2, T3>(M.par, P, a.theta_d, a.dz, tid, EGM_THREADS);
     __syncthreads();
   }
-  const EchDiscIo io{a.theta_d, a.m_d, a.v_d, a.grad_d, a.adam, a.apply, q, a.out, a.z, a.eps};
+  const EchDiscIo io{a.theta_d, a.m_d, a.v_d, a.grad_d, a.adam, a.apply, q, a.out, a.z, a.eps, a.ws};
   ech_disc_tail<T1, T2, T3, NB>(io, a.dz, P, M, tid);
 }
 

@@ -17,6 +17,7 @@ struct EgmState {
   EgmArgs base{};              // network descriptions + device pointers shared by both kernels
   size_t n_gen = 0, n_dz = 0, ws_floats = 0;
   int lds_bytes = 0;
+  int chain_t0 = 1;            // latent input tiles of the chain kernels (q <= 16 t0)
   int chain_disc_lds = 0;      // > 0: the discriminator step runs as register-chained row tiles (egm_chain.h) with this much LDS
   int chain_gen_lds = 0;       // > 0: likewise the generator step (egm_chain_gen.h)
   int chain_ntl = 0;           // its compiled output-tile count of g
@@ -119,10 +120,13 @@ extern "C" int bgm_causal_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, co
   a.disc_lds = (64 + arena) * sizeof(float) <= 160 * 1024 ? 1 : 0;
   s->lds_bytes = (int)((64 + (a.disc_lds ? arena : 0)) * sizeof(float));
   {   // register-chained discriminator step: fixed normalisation, the default layer shapes, one or two 16-row tiles
-    bool chain = d.fixed_norm && L == 3 && d.dims[0] <= 16 && (d.dims[1] + 15) / 16 == 4 && (d.dims[2] + 15) / 16 == 2 && d.dims[3] >= 1 &&
-                 d.dims[3] <= 16 && (B == 16 || B == 32) && a.e.n_layers >= 2 && a.e.dims[a.e.n_layers] == h->q && h->q <= 16;
+    // latent width: one input tile (q <= 16), or two (q <= 32: B = 32 only, the fourth pass's stash in global scratch)
+    const int t0 = h->q <= 16 ? 1 : 2;
+    bool chain = d.fixed_norm && L == 3 && d.dims[0] <= 32 && (t0 == 1 || B == 32) && (d.dims[1] + 15) / 16 == 4 && (d.dims[2] + 15) / 16 == 2 &&
+                 d.dims[3] >= 1 && d.dims[3] <= 16 && (B == 16 || B == 32) && a.e.n_layers >= 2 && a.e.dims[a.e.n_layers] == h->q && h->q <= 32;
     for (int l = 1; l < a.e.n_layers; ++l) chain = chain && a.e.dims[l] == 64;
-    const size_t bytes = chain ? sizeof(float) * (size_t)ech_disc_lds_floats<4, 2, 1>(d, B) : 0;
+    const size_t bytes = !chain ? 0 : sizeof(float) * (size_t)(t0 == 1 ? ech_disc_lds_floats<4, 2, 1>(d, B) : ech_disc_lds_floats<4, 2, 1, 2>(d, B));
+    s->chain_t0 = t0;
     if (std::getenv("BGM_EGM_NO_CHAIN")) chain = false;   // A/B switch for measurements
     s->chain_disc_lds = (chain && bytes <= 160 * 1024) ? (int)bytes : 0;
   }
@@ -132,7 +136,7 @@ extern "C" int bgm_causal_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, co
     // compiled output extents of g: 13 and 7 tiles exactly; a narrower p + 1 runs the 13-tile kernel with masked columns (B = 32)
     const int ntl_need = (h->p + 1 + 15) / 16;
     const int ntl = (ntl_need == 13 || ntl_need == 7) ? ntl_need : 13;
-    bool chain = s->chain_disc_lds > 0 && ntl_need <= 13 && (ntl == ntl_need || B == 32) && a.g.n_layers >= 2 && a.g.dims[0] == h->q;
+    bool chain = s->chain_disc_lds > 0 && s->chain_t0 == 1 && ntl_need <= 13 && (ntl == ntl_need || B == 32) && a.g.n_layers >= 2 && a.g.dims[0] == h->q;
     for (int l = 1; l < a.g.n_layers; ++l) chain = chain && a.g.dims[l] == 64;
     for (const EgmMlp *m : {&a.f, &a.h})
       chain = chain && m->n_layers == 4 && m->dims[0] <= 16 && m->dims[1] == 64 && m->dims[2] == 32 && m->dims[3] >= 1 && m->dims[3] <= 16 &&
@@ -272,7 +276,8 @@ extern "C" int bgm_causal_egm_disc_step(bgm_handle *h, const float *z_dev, const
   a.adam = egm_adam_coeffs(s->cfg.lr, std::max<long long>(1, s->t_d));
   if (s->chain_disc_lds > 0) {
     const int kt0 = (a.p + 15) / 16;     // compiled first-layer extents: p in (192, 208] and (96, 112]; any other p takes the streaming variant
-    auto kc = a.B == 32 ? (kt0 == 13 ? egm_disc_chain_kernel<4, 13, 4, 2, 1, 2> : kt0 == 7 ? egm_disc_chain_kernel<4, 7, 4, 2, 1, 2> : egm_disc_chain_kernel<4, 0, 4, 2, 1, 2>)
+    auto kc = s->chain_t0 == 2 ? egm_disc_chain_kernel<4, 0, 4, 2, 1, 2, 2> :
+              a.B == 32 ? (kt0 == 13 ? egm_disc_chain_kernel<4, 13, 4, 2, 1, 2> : kt0 == 7 ? egm_disc_chain_kernel<4, 7, 4, 2, 1, 2> : egm_disc_chain_kernel<4, 0, 4, 2, 1, 2>)
                         : egm_disc_chain_kernel<4, 0, 4, 2, 1, 1>;
     BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, s->chain_disc_lds));
 #ifdef EGM_PHASE_CLOCK

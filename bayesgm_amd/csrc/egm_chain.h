@@ -112,7 +112,7 @@ template <int T1, int T2, int T3, int T0 = 1> struct EchDims {
 template <int T1, int T2, int T3, int T0 = 1>
 __host__ __device__ inline int ech_disc_lds_floats(const EgmDisc &d, int B) {
   using D = EchDims<T1, T2, T3, T0>;
-  return 64 + ech_layout<T1, T2, T3, T0>(d).total + ECH_ROLE_WAVES * D::SLOT + 16 * T0 * B + 4 * B * D::SW;
+  return 64 + ech_layout<T1, T2, T3, T0>(d).total + ECH_ROLE_WAVES * D::SLOT + 16 * T0 * B + (T0 > 1 ? 3 : 4) * B * D::SW;
 }
 
 template <int T1, int T2, int T3, int T0 = 1>
@@ -556,6 +556,7 @@ struct EchDiscIo {
   float *out;
   const float *z;      // [B x q] prior sample
   float eps;           // gradient-penalty interpolation coefficient
+  float *gstash;       // T0 > 1 only: [B x SW] floats of global scratch for the fourth pass's stash (LDS holds three passes then)
 };
 // Adam on one parameter with its state already loaded
 __device__ __forceinline__ void ech_adam(const EchDiscIo &a, int e, float gi, float th, float m0, float v0) {
@@ -627,9 +628,10 @@ __device__ __forceinline__ void ech_disc_tail(const EchDiscIo &a, const EgmDisc 
       for (int r = 0; r < 4; ++r) F.a0[t][r] = ech_ld(a.z + (long long)row * q, 16 * t + 4 * g + r, q) * a.eps + ze[r] * (1.0f - a.eps);
     }
     ech_disc_fwd<T1, T2, T3, T0>(par, P, F, j, g);
-    const float part = ech_disc_gp<T1, T2, T3, T0>(par, P, F, 10.0f, stash + 2 * B * D::SW, stash + 3 * B * D::SW, B, row, acc, j, g);
+    const float part = ech_disc_gp<T1, T2, T3, T0>(par, P, F, 10.0f, stash + 2 * B * D::SW, T0 > 1 ? a.gstash : stash + 3 * B * D::SW, B, row, acc, j, g);
     ech_write_slot<T1, T2, T3, T0>(slots + wave * D::SLOT, acc, 0.0f, part, j, g);
   }
+  if (T0 > 1) __threadfence();
   __syncthreads();
   // ---- parameter gradients: W_l += sum over the four passes of X^T D (rows = K), one 16x16 tile per wave and round
   const float c = ech_c();
@@ -651,8 +653,9 @@ __device__ __forceinline__ void ech_disc_tail(const EchDiscIo &a, const EgmDisc 
     f32x4 w = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
-      const float *xb = stash + pass * B * D::SW + B * xo + 16 * u + j;
-      const float *db = stash + pass * B * D::SW + B * (D::XW + dofs) + 16 * v + j;
+      const float *pb = (T0 > 1 && pass == 3) ? a.gstash : stash + pass * B * D::SW;      // (unrolled: the address space is static)
+      const float *xb = pb + B * xo + 16 * u + j;
+      const float *db = pb + B * (D::XW + dofs) + 16 * v + j;
 #pragma unroll
       for (int s4 = 0; s4 < NB * 4; ++s4) {
         const int rr = 4 * s4 + g;
@@ -728,7 +731,7 @@ static __global__ __launch_bounds__(ECH_THREADS) void egm_disc_chain_kernel(EgmA
   ECH_STAMP(1);
   __syncthreads();
   ECH_STAMP(2);
-  const EchDiscIo io{a.theta_d, a.m_d, a.v_d, a.grad_d, a.adam, a.apply, a.q, a.out, a.z, a.eps};
+  const EchDiscIo io{a.theta_d, a.m_d, a.v_d, a.grad_d, a.adam, a.apply, a.q, a.out, a.z, a.eps, a.ws};
   ech_disc_tail<T1, T2, T3, NB, T0>(io, a.dz, P, M, tid);
   ECH_STAMP(6);
 }

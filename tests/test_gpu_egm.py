@@ -51,7 +51,9 @@ def _rel(a, b):
                                   # the shapes of the register-chained discriminator step (egm_chain.h): one and two 16-row tiles
                                   dict(binary=False, p=200, z_dims=(1, 1, 1, 7), B=32, disc_norm="fixed"),
                                   dict(binary=True, p=37, z_dims=(2, 3, 4, 5), B=16, disc_norm="fixed"),
-                                  dict(binary=False, p=100, z_dims=(3, 3, 3, 3), B=32, disc_norm="fixed")])
+                                  dict(binary=False, p=100, z_dims=(3, 3, 3, 3), B=32, disc_norm="fixed"),
+                                  # the binary-treatment configs' latent layout: q = 18, two latent input tiles
+                                  dict(binary=True, p=177, z_dims=(3, 3, 6, 6), B=32, disc_norm="fixed")])
 def test_egm_step_gradients_match_oracle(case):
     import torch
     B = case["B"]
