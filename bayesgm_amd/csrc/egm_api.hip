@@ -135,8 +135,8 @@ extern "C" int bgm_causal_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, co
       // extent, the head networks f, h with the 64-32-8 default
     // compiled output extents of g: 13 and 7 tiles exactly; a narrower p + 1 runs the 13-tile kernel with masked columns (B = 32)
     const int ntl_need = (h->p + 1 + 15) / 16;
-    const int ntl = (ntl_need == 13 || ntl_need == 7) ? ntl_need : 13;
-    bool chain = s->chain_disc_lds > 0 && s->chain_t0 == 1 && ntl_need <= 13 && (ntl == ntl_need || B == 32) && a.g.n_layers >= 2 && a.g.dims[0] == h->q;
+    const int ntl = ((ntl_need == 13 || ntl_need == 7) && s->chain_t0 == 1) ? ntl_need : 13;      // two latent tiles: the masked 13-tile variant only
+    bool chain = s->chain_disc_lds > 0 && ntl_need <= 13 && (ntl == ntl_need || B == 32) && a.g.n_layers >= 2 && a.g.dims[0] == h->q;
     for (int l = 1; l < a.g.n_layers; ++l) chain = chain && a.g.dims[l] == 64;
     for (const EgmMlp *m : {&a.f, &a.h})
       chain = chain && m->n_layers == 4 && m->dims[0] <= 16 && m->dims[1] == 64 && m->dims[2] == 32 && m->dims[3] >= 1 && m->dims[3] <= 16 &&
@@ -176,8 +176,8 @@ extern "C" int bgm_causal_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, co
       T.n_tiles = (int)(s->gen_tiles.size() / ECG_TILE_INTS);
       T.n_warm = (int)s->n_gen;
       s->chain_ntl = ntl;
-      s->chain_pad = ntl != ntl_need;
-      s->chain_gen_lds = (int)(sizeof(float) * (size_t)ecg_lds_floats<4, 2, 1>(d, B));
+      s->chain_pad = ntl != ntl_need || s->chain_t0 == 2;
+      s->chain_gen_lds = (int)(sizeof(float) * (size_t)(s->chain_t0 == 1 ? ecg_lds_floats<4, 2, 1>(d, B) : ecg_lds_floats<4, 2, 1, 2>(d, B)));
     }
   }
   a.n_gen = (int)s->n_gen; a.B = B; a.q = h->q; a.p = h->p; a.wmax = wmax;
@@ -316,7 +316,8 @@ extern "C" int bgm_causal_egm_gen_step(bgm_handle *h, const float *z_dev, const 
   if (apply) s->t_g += 1;
   a.adam = egm_adam_coeffs(s->cfg.lr, std::max<long long>(1, s->t_g));
   if (s->chain_gen_lds > 0) {
-    auto kc = s->chain_pad ? egm_gen_chain_kernel<4, 13, 4, 2, 1, 2, true>
+    auto kc = s->chain_t0 == 2 ? egm_gen_chain_kernel<4, 13, 4, 2, 1, 2, true, 2>
+              : s->chain_pad ? egm_gen_chain_kernel<4, 13, 4, 2, 1, 2, true>
               : a.B == 32 ? (s->chain_ntl == 13 ? egm_gen_chain_kernel<4, 13, 4, 2, 1, 2> : egm_gen_chain_kernel<4, 7, 4, 2, 1, 2>)
                         : (s->chain_ntl == 13 ? egm_gen_chain_kernel<4, 13, 4, 2, 1, 1> : egm_gen_chain_kernel<4, 7, 4, 2, 1, 1>);
     BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, s->chain_gen_lds));

@@ -236,19 +236,19 @@ __device__ __forceinline__ void ecg_hidden_bwd(const float *thetaT, const EgmMlp
 }
 
 // generator g: [q <= 16] -> 16 HT x (L-2) -> [n_out = p + 1], NTL output tiles
-template <int HT, int NTL, bool PAD = false>
-__device__ __forceinline__ void ecg_g_fwd(const float *theta, const EgmMlp &n, const int *xo, float *ws, int row, const f32x4 (&zin)[1],
+template <int HT, int NTL, bool PAD = false, int T0 = 1>
+__device__ __forceinline__ void ecg_g_fwd(const float *theta, const EgmMlp &n, const int *xo, float *ws, int row, const f32x4 (&zin)[T0],
                                           f32x4 (&out)[NTL], int j, int g) {
   constexpr int H = 16 * HT;
   const int L = n.n_layers, q = n.dims[0], no = n.dims[L];
-  ecg_put<1>(ws + xo[0], row, g, zin);
+  ecg_put<T0>(ws + xo[0], row, g, zin);
   f32x4 h[HT];
   {
     EcgA<HT> A, Ad;
     EcgW w{theta + n.woff[0], H, q, H, 0};
     ecg_prime<HT, true>(w, A, j, g);
     ech_zero<HT>(h);
-    ecg_sub<1, HT, HT, true, true>(w, zin, h, A, w, Ad, j, g);
+    ecg_sub<T0, HT, HT, true, true>(w, zin, h, A, w, Ad, j, g);
     ecg_bias<HT>(w.W + q * H, H, 0, g, h);
     ecg_lrelu<HT>(h);
   }
@@ -259,9 +259,9 @@ __device__ __forceinline__ void ecg_g_fwd(const float *theta, const EgmMlp &n, c
   ecg_bias<NTL>(Wl + H * no, no, 0, g, out);
 }
 // dout: dLoss/d output (NTL tiles, zero beyond n_out).  dx (WANT_DX): dLoss/d input.
-template <int HT, int NTL, bool WANT_DX>
+template <int HT, int NTL, bool WANT_DX, int T0 = 1>
 __device__ __forceinline__ void ecg_g_bwd(const float *thetaT, const EgmMlp &n, const int *xo, const int *dofs, float *ws, int row,
-                                          const f32x4 (&dout)[NTL], f32x4 (&dx)[1], int j, int g) {
+                                          const f32x4 (&dout)[NTL], f32x4 (&dx)[T0], int j, int g) {
   constexpr int H = 16 * HT;
   const int L = n.n_layers, q = n.dims[0], no = n.dims[L];
   ecg_put<NTL>(ws + dofs[L - 1], row, g, dout);
@@ -278,18 +278,18 @@ __device__ __forceinline__ void ecg_g_bwd(const float *thetaT, const EgmMlp &n, 
   ecg_hidden_bwd<HT>(thetaT, n, xo, dofs, ws, row, dh, j, g);
   ecg_put<HT>(ws + dofs[0], row, g, dh);
   if (WANT_DX) {
-    EcgA<1> A, Ad;
+    EcgA<T0> A, Ad;
     EcgW w{thetaT + n.woff[0], q, H, q, 0};           // W^T [H x q]
-    ecg_prime<1, false>(w, A, j, g);
-    ech_zero<1>(dx);
-    ecg_sub<HT, 1, 1, false, false>(w, dh, dx, A, w, Ad, j, g);
+    ecg_prime<T0, false>(w, A, j, g);
+    ech_zero<T0>(dx);
+    ecg_sub<HT, T0, T0, false, false>(w, dh, dx, A, w, Ad, j, g);
   }
 }
 
 // encoder e: [p] -> 16 HT x (L-2) -> [q <= 16];  xin: the NTL input tiles (zero beyond p), already in the stash as X_0
-template <int HT, int NTL>
+template <int HT, int NTL, int T0 = 1>
 __device__ __forceinline__ void ecg_e_fwd(const float *theta, const EgmMlp &n, const int *xo, float *ws, int row, const f32x4 (&xin)[NTL],
-                                          f32x4 (&z)[1], int j, int g) {
+                                          f32x4 (&z)[T0], int j, int g) {
   constexpr int H = 16 * HT;
   const int L = n.n_layers, p = n.dims[0], q = n.dims[L];
   f32x4 h[HT];
@@ -305,20 +305,20 @@ __device__ __forceinline__ void ecg_e_fwd(const float *theta, const EgmMlp &n, c
   ecg_hidden_fwd<HT>(theta, n, xo, ws, row, h, j, g);
   ecg_put<HT>(ws + xo[L - 1], row, g, h);
   {
-    EcgA<1> A, Ad;
+    EcgA<T0> A, Ad;
     EcgW w{theta + n.woff[L - 1], q, H, q, 0};
-    ecg_prime<1, false>(w, A, j, g);
-    ech_zero<1>(z);
-    ecg_sub<HT, 1, 1, false, false>(w, h, z, A, w, Ad, j, g);
-    ecg_bias<1>(w.W + H * q, q, 0, g, z);
+    ecg_prime<T0, false>(w, A, j, g);
+    ech_zero<T0>(z);
+    ecg_sub<HT, T0, T0, false, false>(w, h, z, A, w, Ad, j, g);
+    ecg_bias<T0>(w.W + H * q, q, 0, g, z);
   }
 }
-template <int HT, int NTL, bool WANT_DX, bool PAD = false>
+template <int HT, int NTL, bool WANT_DX, bool PAD = false, int T0 = 1>
 __device__ __forceinline__ void ecg_e_bwd(const float *thetaT, const EgmMlp &n, const int *xo, const int *dofs, float *ws, int row,
-                                          const f32x4 (&dz)[1], f32x4 (&dx)[NTL], int j, int g) {
+                                          const f32x4 (&dz)[T0], f32x4 (&dx)[NTL], int j, int g) {
   constexpr int H = 16 * HT;
   const int L = n.n_layers, p = n.dims[0], q = n.dims[L];
-  ecg_put<1>(ws + dofs[L - 1], row, g, dz);
+  ecg_put<T0>(ws + dofs[L - 1], row, g, dz);
   f32x4 dh[HT], xl[HT];
   {
     EcgA<HT> A, Ad;
@@ -326,7 +326,7 @@ __device__ __forceinline__ void ecg_e_bwd(const float *thetaT, const EgmMlp &n, 
     ecg_prime<HT, true>(w, A, j, g);
     ech_zero<HT>(dh);
     ecg_get<HT>(ws + xo[L - 1], row, g, xl);
-    ecg_sub<1, HT, HT, true, true>(w, dz, dh, A, w, Ad, j, g);
+    ecg_sub<T0, HT, HT, true, true>(w, dz, dh, A, w, Ad, j, g);
     ecg_mask<HT>(dh, xl);
   }
   ecg_hidden_bwd<HT>(thetaT, n, xo, dofs, ws, row, dh, j, g);
@@ -394,8 +394,8 @@ __device__ __forceinline__ void ecg_head_bwd(const float *thetaT, const EgmMlp &
 }
 
 // dLoss/d input of the (fixed) discriminator for dLoss/d out = dout on every row
-template <int T1, int T2, int T3>
-__device__ __forceinline__ void ecg_disc_dx(const float *par, const EchP &P, const EchFwd<T1, T2, T3> &F, float dout, f32x4 (&dx)[1], int j, int g) {
+template <int T1, int T2, int T3, int T0 = 1>
+__device__ __forceinline__ void ecg_disc_dx(const float *par, const EchP &P, const EchFwd<T1, T2, T3, T0> &F, float dout, f32x4 (&dx)[T0], int j, int g) {
   const float c = ech_c();
   f32x4 du3[T3], du2[T2], du1[T1], da2[T2], da1[T1];
 #pragma unroll
@@ -415,31 +415,32 @@ __device__ __forceinline__ void ecg_disc_dx(const float *par, const EchP &P, con
   for (int t = 0; t < T1; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { const float av = F.a1[t][r]; du1[t][r] = da1[t][r] * (1.0f - av * av) * par[P.ga0 + 16 * t + 4 * g + r] * c; }
-  ech_dense<T1, 1, true>(par + P.T0, P.lt0, nullptr, P.d1, P.d0, du1, dx, j, g);
+  ech_dense<T1, T0, true>(par + P.T0, P.lt0, nullptr, P.d1, P.d0, du1, dx, j, g);
 }
 
 // LDS words behind the parameter block: per-wave loss partials [8 x 16] | flags [16] | z_ tiles | head-input gradient tiles | head
 // contribution to dLoss/dz_  (each [B x 16])
-template <int T1, int T2, int T3>
-__host__ __device__ inline int ecg_lds_floats(const EgmDisc &d, int B) { return 64 + ech_layout<T1, T2, T3>(d).total + 8 * 16 + 16 + 3 * 16 * B; }
+template <int T1, int T2, int T3, int T0 = 1>
+__host__ __device__ inline int ecg_lds_floats(const EgmDisc &d, int B) { return 64 + ech_layout<T1, T2, T3, T0>(d).total + 8 * 16 + 16 + 3 * 16 * T0 * B; }
 
 // ---------------------------------------------------------------------------------------------
 // the step
 // ---------------------------------------------------------------------------------------------
-template <int HT, int NTL, int T1, int T2, int T3, int NB, bool PAD = false>
+template <int HT, int NTL, int T1, int T2, int T3, int NB, bool PAD = false, int T0 = 1>
 static __global__ __launch_bounds__(ECH_THREADS) void egm_gen_chain_kernel(EgmArgs a, EcgTab tab) {
   extern __shared__ __attribute__((aligned(16))) float ech_lds[];
   constexpr int B = 16 * NB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const int q = a.q, p = a.p, z0 = a.z0, z1 = a.z1, z2 = a.z2;
-  const EchP P = ech_layout<T1, T2, T3>(a.dz);
+  constexpr int ZW = 16 * T0;                 // floats per row of the latent tiles in LDS
+  const EchP P = ech_layout<T1, T2, T3, T0>(a.dz);
   float *par = ech_lds + 64;
   float *part = par + P.total;                 // [8 waves][16] loss partial sums
   volatile int *flag = reinterpret_cast<volatile int *>(part + 8 * 16);   // [0]: parameter block filled (counts 4 waves); [2 + tile]: z_ of
                                                                           // the tile written; [4 + tile]: head contribution to dz written
   float *zt = part + 8 * 16 + 16;              // z_ of chain B, [B x 16]
-  float *dzt = zt + 16 * B;                    // dLoss/d hin, [B x 16] (lane permutation scratch of the head waves)
-  float *dzh = dzt + 16 * B;                   // dLoss/dz_ through D, f and h, [B x 16]
+  float *dzt = zt + ZW * B;                    // dLoss/d hin, [B x 16] (lane permutation scratch of the head waves)
+  float *dzh = dzt + ZW * B;                   // dLoss/dz_ through D, f and h, [B x ZW]
   if (tid < 16) flag[tid] = 0;
   __syncthreads();
   ECH_STAMP(0);
@@ -453,11 +454,13 @@ static __global__ __launch_bounds__(ECH_THREADS) void egm_gen_chain_kernel(EgmAr
   float ls[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};     // l_v, l_z, l_x, l_y, s_g, s_f, s_h, adv (sums over this lane's row)
   if (role == 0 && active) {
     // ================= chain A =================
-    f32x4 zin[1];
+    f32x4 zin[T0];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) zin[0][r] = ech_ld(a.z + (long long)row * q, 4 * g + r, q);
+    for (int t = 0; t < T0; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) zin[t][r] = ech_ld(a.z + (long long)row * q, 16 * t + 4 * g + r, q);
     f32x4 gz[NTL];
-    ecg_g_fwd<HT, NTL, PAD>(th, a.g, tab.x[ECG_PASS_G1], ws, row, zin, gz, j, g);
+    ecg_g_fwd<HT, NTL, PAD, T0>(th, a.g, tab.x[ECG_PASS_G1], ws, row, zin, gz, j, g);
     ECH_STAMP(1);
     float sgv = 0.0f;                          // variance head g(z)[:, p] of this row (held by one lane group)
     f32x4 vin[NTL];
@@ -472,20 +475,22 @@ static __global__ __launch_bounds__(ECH_THREADS) void egm_gen_chain_kernel(EgmAr
     sgv = sum_over_g(sgv);
     ls[4] = sgv * sgv;
     ecg_put<NTL>(ws + tab.x[ECG_PASS_E2][0], row, g, vin);
-    f32x4 zz[1];
-    ecg_e_fwd<HT, NTL>(th, a.e, tab.x[ECG_PASS_E2], ws, row, vin, zz, j, g);
+    f32x4 zz[T0];
+    ecg_e_fwd<HT, NTL, T0>(th, a.e, tab.x[ECG_PASS_E2], ws, row, vin, zz, j, g);
     ECH_STAMP(2);
-    f32x4 dzz[1];
+    f32x4 dzz[T0];
     float lz = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float t = zin[0][r] - zz[0][r];    // both are zero beyond q
-      lz = fmaf(t, t, lz);
-      dzz[0][r] = zrec * (-2.0f / (float)(B * q)) * t;
-    }
+    for (int tz = 0; tz < T0; ++tz)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float t = zin[tz][r] - zz[tz][r];    // both are zero beyond q
+        lz = fmaf(t, t, lz);
+        dzz[tz][r] = zrec * (-2.0f / (float)(B * q)) * t;
+      }
     ls[1] = sum_over_g(lz);
     f32x4 dv[NTL];
-    ecg_e_bwd<HT, NTL, true, PAD>(tT, a.e, tab.x[ECG_PASS_E2], tab.d[ECG_PASS_E2], ws, row, dzz, dv, j, g);
+    ecg_e_bwd<HT, NTL, true, PAD, T0>(tT, a.e, tab.x[ECG_PASS_E2], tab.d[ECG_PASS_E2], ws, row, dzz, dv, j, g);
     ECH_STAMP(3);
 #pragma unroll
     for (int t = 0; t < NTL; ++t)
@@ -494,8 +499,8 @@ static __global__ __launch_bounds__(ECH_THREADS) void egm_gen_chain_kernel(EgmAr
         const int f = 16 * t + 4 * g + r;
         dv[t][r] = f < p ? dv[t][r] : (f == p ? 0.001f * 2.0f * sgv * invB : 0.0f);
       }
-    f32x4 dnone[1];
-    ecg_g_bwd<HT, NTL, false>(tT, a.g, tab.x[ECG_PASS_G1], tab.d[ECG_PASS_G1], ws, row, dv, dnone, j, g);
+    f32x4 dnone[T0];
+    ecg_g_bwd<HT, NTL, false, T0>(tT, a.g, tab.x[ECG_PASS_G1], tab.d[ECG_PASS_G1], ws, row, dv, dnone, j, g);
   } else if (role == 1 && active) {
     // ================= chain B =================
     const long long prow = a.idx[row];
@@ -516,16 +521,17 @@ static __global__ __launch_bounds__(ECH_THREADS) void egm_gen_chain_kernel(EgmAr
         for (int r = 0; r < 4; ++r) vin[t][r] = ech_ld(vrow, 16 * t + 4 * g + r, p);
     }
     ecg_put<NTL>(ws + tab.x[ECG_PASS_E1][0], row, g, vin);
-    f32x4 ze[1];
-    ecg_e_fwd<HT, NTL>(th, a.e, tab.x[ECG_PASS_E1], ws, row, vin, ze, j, g);
+    f32x4 ze[T0];
+    ecg_e_fwd<HT, NTL, T0>(th, a.e, tab.x[ECG_PASS_E1], ws, row, vin, ze, j, g);
     ECH_STAMP(1);
-    *reinterpret_cast<f32x4 *>(zt + row * 16 + 4 * g) = ze[0];
+#pragma unroll
+    for (int t = 0; t < T0; ++t) *reinterpret_cast<f32x4 *>(zt + row * ZW + 16 * t + 4 * g) = ze[t];
     __threadfence_block();
     if (lane == 0) flag[2 + tile] = 1;         // waves 4,5 take D, f and h from here
-    f32x4 dz[1];                               // dLoss/dz_ accumulates here
+    f32x4 dz[T0];                              // dLoss/dz_ accumulates here
     {
       f32x4 gv[NTL];
-      ecg_g_fwd<HT, NTL, PAD>(th, a.g, tab.x[ECG_PASS_G2], ws, row, ze, gv, j, g);
+      ecg_g_fwd<HT, NTL, PAD, T0>(th, a.g, tab.x[ECG_PASS_G2], ws, row, ze, gv, j, g);
       float lv = 0.0f;
       ecg_get<NTL>(ws + tab.x[ECG_PASS_E1][0], row, g, vin);
 #pragma unroll
@@ -538,20 +544,21 @@ static __global__ __launch_bounds__(ECH_THREADS) void egm_gen_chain_kernel(EgmAr
           gv[t][r] = (-2.0f / (float)(B * p)) * d;
         }
       ls[0] = sum_over_g(lv);
-      ecg_g_bwd<HT, NTL, true>(tT, a.g, tab.x[ECG_PASS_G2], tab.d[ECG_PASS_G2], ws, row, gv, dz, j, g);
+      ecg_g_bwd<HT, NTL, true, T0>(tT, a.g, tab.x[ECG_PASS_G2], tab.d[ECG_PASS_G2], ws, row, gv, dz, j, g);
     }
     ECH_STAMP(2);
     // D, f, h ran on waves 4,5 meanwhile: add their part of dLoss/dz_
     while (flag[4 + tile] == 0) __builtin_amdgcn_s_sleep(2);
     __threadfence_block();
-    dz[0] += *reinterpret_cast<const f32x4 *>(dzh + row * 16 + 4 * g);
+#pragma unroll
+    for (int t = 0; t < T0; ++t) dz[t] += *reinterpret_cast<const f32x4 *>(dzh + row * ZW + 16 * t + 4 * g);
     ECH_STAMP(3);
     f32x4 dnone[NTL];
-    ecg_e_bwd<HT, NTL, false>(tT, a.e, tab.x[ECG_PASS_E1], tab.d[ECG_PASS_E1], ws, row, dz, dnone, j, g);
+    ecg_e_bwd<HT, NTL, false, false, T0>(tT, a.e, tab.x[ECG_PASS_E1], tab.d[ECG_PASS_E1], ws, row, dz, dnone, j, g);
   } else if (role >= 2) {
     // ================= waves 4..7: the discriminator's parameter block; pull the generator-side weights into this XCD's L2 (waves
     // 4,5 the forward arrays, 6,7 the transposed mirror); then waves 4,5 take D, f and h of chain B as soon as its z_ exists ======
-    ech_fill_params<T1, T2, T3>(par, P, a.theta_d, a.dz, tid - 256, 256);
+    ech_fill_params<T1, T2, T3, T0>(par, P, a.theta_d, a.dz, tid - 256, 256);
     __threadfence_block();
     if (lane == 0) atomicAdd(const_cast<int *>(flag), 1);
     {
@@ -572,17 +579,17 @@ static __global__ __launch_bounds__(ECH_THREADS) void egm_gen_chain_kernel(EgmAr
       while (flag[0] < 4) __builtin_amdgcn_s_sleep(2);
       while (flag[2 + tile] == 0) __builtin_amdgcn_s_sleep(2);
       __threadfence_block();
-      f32x4 ze[1], dz[1];
-      ze[0] = *reinterpret_cast<const f32x4 *>(zt + row * 16 + 4 * g);
+      f32x4 ze[T0], dz[T0];
+#pragma unroll
+      for (int t = 0; t < T0; ++t) ze[t] = *reinterpret_cast<const f32x4 *>(zt + row * ZW + 16 * t + 4 * g);
     // ---- adversarial term through the fixed discriminator
     {
-      EchFwd<T1, T2, T3> F;
-      F.a0[0] = ze[0];
-      ech_disc_fwd<T1, T2, T3>(par, P, F, j, g);
+      EchFwd<T1, T2, T3, T0> F;
+#pragma unroll
+      for (int t = 0; t < T0; ++t) F.a0[t] = ze[t];
+      ech_disc_fwd<T1, T2, T3, T0>(par, P, F, j, g);
       ls[7] = -F.out;
-      f32x4 dd[1];
-      ecg_disc_dx<T1, T2, T3>(par, P, F, -invB, dd, j, g);
-      dz[0] = dd[0];
+      ecg_disc_dx<T1, T2, T3, T0>(par, P, F, -invB, dz, j, g);
     }
     // ---- f(z0, z1, x) -> y
     {
@@ -616,7 +623,7 @@ static __global__ __launch_bounds__(ECH_THREADS) void egm_gen_chain_kernel(EgmAr
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int f = 4 * g + r;
-        const float t = zt[row * 16 + min(f < z0 ? f : f + z1, 15)];
+        const float t = zt[row * ZW + min(f < z0 ? f : f + z1, ZW - 1)];
         hin[0][r] = f < z0 + z2 ? t : 0.0f;
       }
       ecg_head_fwd<T1, T2, T3>(th, a.h, tab.x[ECG_PASS_H], ws, row, hin, ho, j, g);
@@ -647,14 +654,17 @@ static __global__ __launch_bounds__(ECH_THREADS) void egm_gen_chain_kernel(EgmAr
       *reinterpret_cast<f32x4 *>(dzt + row * 16 + 4 * g) = dhin[0];
       __threadfence_block();
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int f = 4 * g + r;
-        const int src = f < z0 ? f : f - z1;            // z_[f] fed hin[f] (f < z0) or hin[f - z1] (z0 + z1 <= f < z0 + z1 + z2)
-        const float t = dzt[row * 16 + min(max(src, 0), 15)];
-        dz[0][r] += (f < z0 || (f >= z0 + z1 && f < z0 + z1 + z2)) ? t : 0.0f;
-      }
+      for (int tz = 0; tz < T0; ++tz)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 16 * tz + 4 * g + r;
+          const int src = f < z0 ? f : f - z1;            // z_[f] fed hin[f] (f < z0) or hin[f - z1] (z0 + z1 <= f < z0 + z1 + z2)
+          const float t = dzt[row * 16 + min(max(src, 0), 15)];
+          dz[tz][r] += (f < z0 || (f >= z0 + z1 && f < z0 + z1 + z2)) ? t : 0.0f;
+        }
     }
-      *reinterpret_cast<f32x4 *>(dzh + row * 16 + 4 * g) = dz[0];
+#pragma unroll
+      for (int t = 0; t < T0; ++t) *reinterpret_cast<f32x4 *>(dzh + row * ZW + 16 * t + 4 * g) = dz[t];
       __threadfence_block();
       if (lane == 0) flag[4 + tile] = 1;
     }

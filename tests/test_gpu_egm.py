@@ -98,14 +98,15 @@ def CausalEngineFlat(dz):
     return CausalEngine.flatten_disc(dz)
 
 
-@pytest.mark.parametrize("disc_norm,p", [("batch", 23), ("fixed", 23), ("fixed", 100), ("fixed", 200)])
-def test_egm_alternating_adam_steps_track_oracle(disc_norm, p):
+@pytest.mark.parametrize("disc_norm,p,z_dims", [("batch", 23, (1, 1, 1, 7)), ("fixed", 23, (1, 1, 1, 7)), ("fixed", 100, (1, 1, 1, 7)),
+                                                ("fixed", 200, (1, 1, 1, 7)), ("fixed", 177, (3, 3, 6, 6))])
+def test_egm_alternating_adam_steps_track_oracle(disc_norm, p, z_dims):
     """p = 100 / 200 with fixed normalisation: both steps run as register-chained row tiles (egm_chain.h, egm_chain_gen.h), whose
     Adam step also maintains the transposed weight mirror the next step's backward chains read."""
     import torch
     B = 32
-    eng, nets, dz, params, (x, y, v), dev, rs, dz_units = _setup(False, p, (1, 1, 1, 7), B)
-    q = 10
+    eng, nets, dz, params, (x, y, v), dev, rs, dz_units = _setup(False, p, z_dims, B)
+    q = sum(z_dims)
     if disc_norm == "fixed":
         eng.set_disc_norm("fixed")
         dz["fixed_norm"] = True
