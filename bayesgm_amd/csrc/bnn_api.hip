@@ -13,6 +13,7 @@
 // ---- iterative-update steps as row-tile chains (egm_chain_bnn.h) when the shapes are the compiled ones
 struct BnnFitChain {
   int ntl = 0, n_tiles = 0;
+  int t0 = 1;               // latent input tiles of g (q <= 16 t0); two tiles: the masked 13-tile kernels, B = 32
   bool pad = false;         // the 13-tile kernels on a narrower p + 1 (B = 32 only)
   EcbTab *tab_theta = nullptr, *tab_z = nullptr;
   int *tiles_theta = nullptr;
@@ -27,19 +28,19 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_fit_noise_kernel(BnnAr
     ecb_kl_partial(a.theta, a.net[tab->c[c].net], ws + tab->klp + blockIdx.x, part, ECB_NOISE_PARTS, red);
   }
 }
-template <int NTL, int NB, bool PAD = false>
+template <int NTL, int NB, bool PAD = false, int T0 = 1>
 static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_chain_kernel(BnnArgs a, const EcbTab *tab, float *ws) {
   extern __shared__ __attribute__((aligned(16))) float bnn_chain_lds[];
-  ecb_theta_chain<BnnArgs, 4, NTL, 4, 2, 1, NB, PAD>(a, *tab, ws, bnn_chain_lds);
+  ecb_theta_chain<BnnArgs, 4, NTL, 4, 2, 1, NB, PAD, T0>(a, *tab, ws, bnn_chain_lds);
 }
 template <int NB>
 static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_dw_kernel(BnnArgs a, const EcbTab *tab, const int *tiles, const float *ws) {
   ecb_theta_dw<BnnArgs, NB>(a, *tab, tiles, ws);
 }
-template <int NTL, int NB, bool PAD = false>
+template <int NTL, int NB, bool PAD = false, int T0 = 1>
 static __global__ __launch_bounds__(BNN_THREADS) void bnn_z_chain_kernel(BnnArgs a, const EcbTab *tab, float *ws) {
   extern __shared__ __attribute__((aligned(16))) float bnn_chain_lds[];
-  ecb_z_chain<BnnArgs, 4, NTL, 4, 2, 1, NB, PAD>(a, *tab, ws, bnn_chain_lds);
+  ecb_z_chain<BnnArgs, 4, NTL, 4, 2, 1, NB, PAD, T0>(a, *tab, ws, bnn_chain_lds);
 }
 static void bnn_chain_free(BnnState *s) {
   BnnFitChain *c = static_cast<BnnFitChain *>(s->chain);
@@ -52,11 +53,13 @@ static void bnn_chain_free(BnnState *s) {
 static int bnn_chain_setup(BnnState *s) {
   if (std::getenv("BGM_BNN_NO_CHAIN") || !ecb_shapes_ok(s->net, s->q, s->p, false)) return BGM_OK;
   const int ntl_need = (s->p + 1 + 15) / 16, B = 32;
-  const int ntl = (ntl_need == 13 || ntl_need == 7) ? ntl_need : 13;
+  const int t0 = s->q <= 16 ? 1 : 2;
+  const int ntl = ((ntl_need == 13 || ntl_need == 7) && t0 == 1) ? ntl_need : 13;
   BnnFitChain *c = new BnnFitChain();
   s->chain = c;
   c->ntl = ntl;
-  c->pad = ntl != ntl_need;
+  c->t0 = t0;
+  c->pad = ntl != ntl_need || t0 == 2;
   EcbTab tt{}, tz{};
   std::vector<int> tiles, none;
   const int tnet[3] = {BNN_G, BNN_H, BNN_F}, tso[3] = {0, 0, 0}, trained[3] = {BNN_G, BNN_H, BNN_F};
@@ -257,7 +260,7 @@ extern "C" int bgm_bnn_theta_step(bgm_handle *h, const float *data_z, const int3
   if (fc && (batch == 32 || (batch == 16 && !fc->pad))) {
     hipStream_t st = (hipStream_t)stream_;
     hipLaunchKernelGGL(bnn_fit_noise_kernel<true>, dim3(3 * ECB_NOISE_PARTS), dim3(BNN_THREADS), 0, st, a, fc->tab_theta, fc->ws);
-    auto kc = fc->pad ? bnn_theta_chain_kernel<13, 2, true>
+    auto kc = fc->t0 == 2 ? bnn_theta_chain_kernel<13, 2, true, 2> : fc->pad ? bnn_theta_chain_kernel<13, 2, true>
               : batch == 32 ? (fc->ntl == 13 ? bnn_theta_chain_kernel<13, 2> : bnn_theta_chain_kernel<7, 2>)
                           : (fc->ntl == 13 ? bnn_theta_chain_kernel<13, 1> : bnn_theta_chain_kernel<7, 1>);
     hipLaunchKernelGGL(kc, dim3(1), dim3(BNN_THREADS), 64 * sizeof(float), st, a, fc->tab_theta, fc->ws);
@@ -306,10 +309,10 @@ extern "C" int bgm_bnn_z_step(bgm_handle *h, const float *x, const float *y, con
   BnnFitChain *fc = static_cast<BnnFitChain *>(s->chain);
   if (fc && (batch == 32 || (batch == 16 && !fc->pad))) {
     hipLaunchKernelGGL(bnn_fit_noise_kernel<false>, dim3(6 * ECB_NOISE_PARTS), dim3(BNN_THREADS), 0, stream, a, fc->tab_z, fc->ws);
-    auto kc = fc->pad ? bnn_z_chain_kernel<13, 2, true>
+    auto kc = fc->t0 == 2 ? bnn_z_chain_kernel<13, 2, true, 2> : fc->pad ? bnn_z_chain_kernel<13, 2, true>
               : batch == 32 ? (fc->ntl == 13 ? bnn_z_chain_kernel<13, 2> : bnn_z_chain_kernel<7, 2>)
                           : (fc->ntl == 13 ? bnn_z_chain_kernel<13, 1> : bnn_z_chain_kernel<7, 1>);
-    hipLaunchKernelGGL(kc, dim3(1), dim3(BNN_THREADS), (32 + 2 * batch + 4 * 16 * batch) * sizeof(float), stream, a, fc->tab_z, fc->ws);
+    hipLaunchKernelGGL(kc, dim3(1), dim3(BNN_THREADS), (32 + 2 * batch + 4 * 16 * fc->t0 * batch) * sizeof(float), stream, a, fc->tab_z, fc->ws);
   } else {
     hipLaunchKernelGGL(bnn_z_grad_kernel, dim3(3), dim3(BNN_THREADS), 0, stream, a);
     hipLaunchKernelGGL(bnn_z_combine_kernel, dim3((batch * s->q + 255) / 256), dim3(256), 0, stream, a.dz_part, a.loss_part, a.dz, out, batch * s->q);

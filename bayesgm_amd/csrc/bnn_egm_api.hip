@@ -20,6 +20,7 @@ struct BnnEgmState {
   float *dev = nullptr;      // m | v (EGM Adam slots of the Bayesian nets) | theta_d | m_d | v_d | grad_d | ws
   // generator step as row-tile chains (egm_chain_bnn.h)
   int chain_gen_lds = 0, chain_ntl = 0, n_tiles = 0;
+  int chain_t0 = 1;            // latent input tiles of the chain kernels (q <= 16 t0; two tiles: B = 32, 13-tile kernels)
   bool chain_pad = false;
   EcbCall disc_call{};         // noise of the discriminator step's encoder call (workspace offsets)
   EcbTab *tab_dev = nullptr;
@@ -93,9 +94,12 @@ extern "C" int bgm_bnn_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, const
   std::vector<int> tiles;
   {
     const int ntl_need = (s->p + 1 + 15) / 16;
-    const int ntl = (ntl_need == 13 || ntl_need == 7) ? ntl_need : 13;       // narrower outputs: the 13-tile kernels with masked columns (B = 32)
-    bool chain = d.fixed_norm && L == 3 && d.dims[0] <= 16 && (d.dims[1] + 15) / 16 == 4 && (d.dims[2] + 15) / 16 == 2 && d.dims[3] >= 1 &&
-                 d.dims[3] <= 16 && (B == 16 || B == 32) && ntl_need <= 13 && (ntl == ntl_need || B == 32) && s->q <= 16 && !std::getenv("BGM_EGM_NO_CHAIN_GEN");
+    const int t0 = s->q <= 16 ? 1 : 2;
+    e->chain_t0 = t0;
+    const int ntl = ((ntl_need == 13 || ntl_need == 7) && t0 == 1) ? ntl_need : 13;       // narrower outputs: the 13-tile kernels with masked columns (B = 32)
+    bool chain = d.fixed_norm && L == 3 && d.dims[0] <= 32 && (d.dims[1] + 15) / 16 == 4 && (d.dims[2] + 15) / 16 == 2 && d.dims[3] >= 1 &&
+                 d.dims[3] <= 16 && (B == 16 || B == 32) && ntl_need <= 13 && (ntl == ntl_need || B == 32) && s->q <= 32 && (t0 == 1 || B == 32) &&
+                 !std::getenv("BGM_EGM_NO_CHAIN_GEN");
     for (int k = 0; k < 4; ++k) chain = chain && s->net[k].bn_fixed == 1 && !s->net[k].heads && !s->net[k].mv;
     const BnnNet &G = s->net[BNN_G], &E = s->net[BNN_E];
     chain = chain && G.n_layers >= 3 && E.n_layers >= 3 && G.dims[0] == s->q && E.dims[E.n_layers] == s->q && G.dims[G.n_layers] == s->p + 1 &&
@@ -114,9 +118,9 @@ extern "C" int bgm_bnn_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, const
       gen_ws = ecb_build_tab(s->net, call_net, call_soff, ECB_CALLS, B, ntl, tab, tiles, all_nets, 4);
       tab.n_warm = s->n_params;
       e->chain_ntl = ntl;
-      e->chain_pad = ntl != ntl_need;
+      e->chain_pad = ntl != ntl_need || t0 == 2;
       e->n_tiles = tab.n_tiles;
-      e->chain_gen_lds = (int)(sizeof(float) * (size_t)ecb_lds_floats<4, 2, 1>(d, B));
+      e->chain_gen_lds = (int)(sizeof(float) * (size_t)(t0 == 1 ? ecb_lds_floats<4, 2, 1>(d, B) : ecb_lds_floats<4, 2, 1, 2>(d, B)));
     }
   }
   {   // noise block of the discriminator step's encoder call, behind the generator chain's region
@@ -125,6 +129,7 @@ extern "C" int bgm_bnn_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, const
     e->disc_call.net = BNN_E;
     e->disc_call.dW = (int)off; off += ((size_t)E.eoff[E.n_layers] + 16 + 3) / 4 * 4;
     e->disc_call.sg = (int)off; off += ((size_t)B * E.swords + 3) / 4 * 4;
+    e->disc_call.xh = (int)off; off += (size_t)B * EchDims<4, 2, 1, 2>::SW;      // two latent tiles: the tail's fourth stash (EchDiscIo::gstash)
     gen_ws = off;
   }
   e->ws_floats = gen_ws + 3 * cache_floats(s->net[BNN_G]) + 2 * cache_floats(s->net[BNN_E]) + 2 * cache_floats(s->net[BNN_F]) +
@@ -176,17 +181,21 @@ extern "C" int bgm_bnn_egm_disc_step(bgm_handle *h, const float *z_dev, const in
   a.adam = bnn_egm_adam(e->cfg.lr, std::max<long long>(1, e->t_d));
   {   // discriminator passes as register-chained row tiles when the shapes are the compiled ones (egm_chain.h)
     const EgmDisc &d = a.dz;
-    const bool chain = d.fixed_norm && d.n_hidden == 3 && d.dims[0] <= 16 && (d.dims[1] + 15) / 16 == 4 && (d.dims[2] + 15) / 16 == 2 &&
+    const int t0 = a.q <= 16 ? 1 : 2;
+    const bool chain = d.fixed_norm && d.n_hidden == 3 && d.dims[0] <= 32 && (t0 == 1 || a.B == 32) && (d.dims[1] + 15) / 16 == 4 && (d.dims[2] + 15) / 16 == 2 &&
                        d.dims[3] >= 1 && d.dims[3] <= 16 && (a.B == 16 || a.B == 32) && !std::getenv("BGM_EGM_NO_CHAIN");
-    const size_t bytes = chain ? sizeof(float) * (size_t)ech_disc_lds_floats<4, 2, 1>(d, a.B) : 0;
+    const size_t bytes = !chain ? 0 : sizeof(float) * (size_t)(t0 == 1 ? ech_disc_lds_floats<4, 2, 1>(d, a.B) : ech_disc_lds_floats<4, 2, 1, 2>(d, a.B));
     if (chain && bytes <= 160 * 1024) {
       // the Flipout encoder as a row-tile chain when its shape is a compiled one
       const BnnNet &E = a.net[BNN_E];
-      bool ech = E.bn_fixed == 1 && !E.heads && E.n_layers >= 2 && E.dims[E.n_layers] == a.q && a.q <= 16 && !std::getenv("BGM_EGM_NO_CHAIN_BNN");
+      bool ech = E.bn_fixed == 1 && !E.heads && E.n_layers >= 2 && E.dims[E.n_layers] == a.q && a.q <= 32 && !std::getenv("BGM_EGM_NO_CHAIN_BNN");
       for (int l = 1; l < E.n_layers; ++l) ech = ech && E.dims[l] == 64;
       int ntl = ech ? (a.p + 15) / 16 : 0;
       if (ntl != 13 && ntl != 7 && ntl > 0 && ntl < 13) ntl = 13;      // the 13-tile encoder chain masks the inputs beyond p
-      auto kc = a.B == 32 ? (ntl == 13 ? bnn_egm_disc_chain_kernel<13, 4, 2, 1, 2> : ntl == 7 ? bnn_egm_disc_chain_kernel<7, 4, 2, 1, 2> : bnn_egm_disc_chain_kernel<0, 4, 2, 1, 2>)
+      if (t0 == 2 && ntl == 7) ntl = 13;
+      if (ntl > 13) ntl = 0;
+      auto kc = t0 == 2 ? (ntl == 13 ? bnn_egm_disc_chain_kernel<13, 4, 2, 1, 2, 2> : bnn_egm_disc_chain_kernel<0, 4, 2, 1, 2, 2>) :
+                a.B == 32 ? (ntl == 13 ? bnn_egm_disc_chain_kernel<13, 4, 2, 1, 2> : ntl == 7 ? bnn_egm_disc_chain_kernel<7, 4, 2, 1, 2> : bnn_egm_disc_chain_kernel<0, 4, 2, 1, 2>)
                           : (ntl == 13 ? bnn_egm_disc_chain_kernel<13, 4, 2, 1, 1> : ntl == 7 ? bnn_egm_disc_chain_kernel<7, 4, 2, 1, 1> : bnn_egm_disc_chain_kernel<0, 4, 2, 1, 1>);
       BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
       if (ntl == 13 || ntl == 7) {
@@ -209,6 +218,7 @@ extern "C" int bgm_bnn_egm_disc_step(bgm_handle *h, const float *z_dev, const in
 int bnn_egm_gen_chain_launch_a(const BnnEgmArgs &a, int nb, int lds, const EcbTab *tab, float *thetaT, hipStream_t stream);
 int bnn_egm_gen_chain_launch_b(const BnnEgmArgs &a, int nb, int lds, const EcbTab *tab, float *thetaT, hipStream_t stream);
 int bnn_egm_gen_chain_launch_c(const BnnEgmArgs &a, int nb, int lds, const EcbTab *tab, float *thetaT, hipStream_t stream);
+int bnn_egm_gen_chain_launch_d(const BnnEgmArgs &a, int nb, int lds, const EcbTab *tab, float *thetaT, hipStream_t stream);
 
 extern "C" int bgm_bnn_egm_gen_step(bgm_handle *h, const float *z_dev, const int32_t *idx_dev, const float *v_dev, const float *x_dev,
                                     const float *y_dev, uint64_t seed, uint32_t stream_id, int32_t apply, float *out_dev, void *stream_) {
@@ -226,7 +236,8 @@ extern "C" int bgm_bnn_egm_gen_step(bgm_handle *h, const float *z_dev, const int
     hipLaunchKernelGGL(bnn_egm_gen_noise_kernel, dim3(ECB_CALLS * ECB_NOISE_PARTS), dim3(EGM_THREADS), 0, (hipStream_t)stream_, a, e->tab_dev);
     BGM_HIP_CHECK(hipGetLastError());
     const int nb = a.B / 16;
-    rc = e->chain_pad ? bnn_egm_gen_chain_launch_c(a, nb, e->chain_gen_lds, e->tab_dev, e->thetaT_dev, (hipStream_t)stream_)
+    rc = e->chain_t0 == 2 ? bnn_egm_gen_chain_launch_d(a, nb, e->chain_gen_lds, e->tab_dev, e->thetaT_dev, (hipStream_t)stream_)
+         : e->chain_pad ? bnn_egm_gen_chain_launch_c(a, nb, e->chain_gen_lds, e->tab_dev, e->thetaT_dev, (hipStream_t)stream_)
          : e->chain_ntl == 13 ? bnn_egm_gen_chain_launch_a(a, nb, e->chain_gen_lds, e->tab_dev, e->thetaT_dev, (hipStream_t)stream_)
                               : bnn_egm_gen_chain_launch_b(a, nb, e->chain_gen_lds, e->tab_dev, e->thetaT_dev, (hipStream_t)stream_);
     if (rc) return rc;

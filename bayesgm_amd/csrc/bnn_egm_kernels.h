@@ -80,7 +80,8 @@ static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_disc_step_kernel(B
 static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_disc_noise_kernel(BnnEgmArgs a, EcbCall C) {     // grid: ECB_NOISE_PARTS
   ecb_noise(a.theta, a.net[BNN_E], C, a.ws, a.B, a.k0, a.k1, a.stream, threadIdx.x, blockIdx.x, ECB_NOISE_PARTS);
 }
-template <int NTL, int T1, int T2, int T3, int NB>
+// T0: latent input tiles (q <= 16 T0); with two, the fourth pass's stash of the tail lives in global scratch (workspace offset C.xh)
+template <int NTL, int T1, int T2, int T3, int NB, int T0 = 1>
 static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_disc_chain_kernel(BnnEgmArgs a, EcbCall C) {
   extern __shared__ __attribute__((aligned(16))) float egm_lds[];
   BnnCtx cb{(int)threadIdx.x, egm_lds};
@@ -88,19 +89,21 @@ static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_disc_chain_kernel(
   float *wp = a.ws;
   auto take = [&](int n) { float *r = wp; wp += (n + 3) & ~3; return r; };
   float *vb = take(B * p);
-  const EchP P = ech_layout<T1, T2, T3>(a.dz);
-  const EchLds<T1, T2, T3> M(egm_lds, P, B);
+  constexpr int ZW = 16 * T0;
+  const EchP P = ech_layout<T1, T2, T3, T0>(a.dz);
+  const EchLds<T1, T2, T3, T0> M(egm_lds, P, B);
   if constexpr (NTL > 0) {
     // the call's perturbations and sign words were drawn by the launch before (bnn_egm_disc_noise_kernel)
-    ech_fill_params<T1, T2, T3>(M.par, P, a.theta_d, a.dz, tid, EGM_THREADS);
+    ech_fill_params<T1, T2, T3, T0>(M.par, P, a.theta_d, a.dz, tid, EGM_THREADS);
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
     if (wave < NB) {
       const int row = 16 * wave + j;
-      f32x4 zf[1];
-      ecb_encoder<4, NTL>(a.theta, a.net[BNN_E], a.ws + C.dW, reinterpret_cast<const uint32_t *>(a.ws + C.sg) + (long long)row * a.net[BNN_E].swords,
-                          a.v_ + (long long)a.idx[row] * p, zf, j, g);
-      *reinterpret_cast<f32x4 *>(M.zt + row * 16 + 4 * g) = zf[0];
+      f32x4 zf[T0];
+      ecb_encoder<4, NTL, T0>(a.theta, a.net[BNN_E], a.ws + C.dW, reinterpret_cast<const uint32_t *>(a.ws + C.sg) + (long long)row * a.net[BNN_E].swords,
+                              a.v_ + (long long)a.idx[row] * p, zf, j, g);
+#pragma unroll
+      for (int t = 0; t < T0; ++t) *reinterpret_cast<f32x4 *>(M.zt + row * ZW + 16 * t + 4 * g) = zf[t];
     }
     __syncthreads();
   } else {
@@ -109,12 +112,12 @@ static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_disc_chain_kernel(
     BnnCache ke;
     bnn_cache(a.net[BNN_E], B, wp, ke, vb);
     const float *z_ = bnn_fwd(cb, a.theta, a.net[BNN_E], ke, B, a.k0, a.k1, a.stream);     // noisy encoder call (fixed in this step)
-    for (int k = tid; k < 16 * B; k += EGM_THREADS) { const int b = k >> 4, i = k & 15; const float t = z_[b * q + min(i, q - 1)]; M.zt[k] = i < q ? t : 0.0f; }
-    ech_fill_params<T1, T2, T3>(M.par, P, a.theta_d, a.dz, tid, EGM_THREADS);
+    for (int k = tid; k < ZW * B; k += EGM_THREADS) { const int b = k / ZW, i = k - b * ZW; const float t = z_[b * q + min(i, q - 1)]; M.zt[k] = i < q ? t : 0.0f; }
+    ech_fill_params<T1, T2, T3, T0>(M.par, P, a.theta_d, a.dz, tid, EGM_THREADS);
     __syncthreads();
   }
-  const EchDiscIo io{a.theta_d, a.m_d, a.v_d, a.grad_d, a.adam, a.apply, q, a.out, a.z, a.eps, a.ws};
-  ech_disc_tail<T1, T2, T3, NB>(io, a.dz, P, M, tid);
+  const EchDiscIo io{a.theta_d, a.m_d, a.v_d, a.grad_d, a.adam, a.apply, q, a.out, a.z, a.eps, a.ws + C.xh};
+  ech_disc_tail<T1, T2, T3, NB, T0>(io, a.dz, P, M, tid);
 }
 
 static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_gen_step_kernel(BnnEgmArgs a) {
@@ -252,10 +255,10 @@ static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_gen_step_kernel(Bn
 }
 
 // train_gen_step as row-tile chains (egm_chain_bnn.h) + its gradient / Adam launch
-template <int NTL, int NB, bool PAD = false>
+template <int NTL, int NB, bool PAD = false, int T0 = 1>
 static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_gen_chain_kernel(BnnEgmArgs a, const EcbTab *tab, float *thetaT) {
   extern __shared__ __attribute__((aligned(16))) float egm_lds[];
-  ecb_gen_chain<BnnEgmArgs, 4, NTL, 4, 2, 1, NB, PAD>(a, *tab, thetaT, egm_lds);
+  ecb_gen_chain<BnnEgmArgs, 4, NTL, 4, 2, 1, NB, PAD, T0>(a, *tab, thetaT, egm_lds);
 }
 static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_gen_noise_kernel(BnnEgmArgs a, const EcbTab *tab) { ecb_gen_noise<BnnEgmArgs>(a, *tab, a.ws); }
 template <int NB>

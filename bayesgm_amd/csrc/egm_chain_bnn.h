@@ -42,10 +42,10 @@ __device__ __forceinline__ void ecb_layer(const float *loc, const float *dW, con
 }
 
 // Noisy encoder call z_ = e(v) on one row tile (no gradient: train_disc_step keeps the encoder fixed).  dW: the call's
-// perturbations (BnnCache::dW), roww: this row's sign words.  Hidden width 16 HT, NTL input tiles, q <= 16 outputs.
-template <int HT, int NTL>
+// perturbations (BnnCache::dW), roww: this row's sign words.  Hidden width 16 HT, NTL input tiles, q <= 16 T0 outputs.
+template <int HT, int NTL, int T0 = 1>
 __device__ __forceinline__ void ecb_encoder(const float *theta, const BnnNet &n, const float *dW, const uint32_t *roww, const float *vrow,
-                                            f32x4 (&z)[1], int j, int g) {
+                                            f32x4 (&z)[T0], int j, int g) {
   constexpr int H = 16 * HT;
   const int L = n.n_layers, p = n.dims[0], q = n.dims[L];
   const float *gamma = theta + n.off, *beta = gamma + p;
@@ -88,9 +88,9 @@ __device__ __forceinline__ void ecb_encoder(const float *theta, const BnnNet &n,
   {
     const float *loc = theta + n.woff[L - 1];
     const EcgW wl{loc, q, H, q, 0};
-    EcgA<1> A1, Ad;
-    ecg_prime<1, false>(wl, A1, j, g);
-    ecb_layer<HT, 1, 1, false, false>(loc, dW + n.eoff[L - 1], loc + 2 * H * q, q, H, q, roww, n.sout_w[L - 1], h, hs, z, A1, wl, Ad, j, g);
+    EcgA<T0> A1, Ad;
+    ecg_prime<T0, false>(wl, A1, j, g);
+    ecb_layer<HT, T0, T0, false, false>(loc, dW + n.eoff[L - 1], loc + 2 * H * q, q, H, q, roww, n.sout_w[L - 1], h, hs, z, A1, wl, Ad, j, g);
   }
 }
 
@@ -418,9 +418,11 @@ __device__ __forceinline__ void ecb_head_bwd(const float *theta, const float *th
 }
 
 // LDS behind the discriminator's parameter block: loss partials [8 x 16] | flags [16] | z_ | head-input gradient scratch | head
-// contribution to dLoss/dz_  (each [B x 16])
-template <int T1, int T2, int T3>
-__host__ __device__ inline int ecb_lds_floats(const EgmDisc &d, int B) { return 64 + ech_layout<T1, T2, T3>(d).total + 8 * 16 + 16 + 3 * 16 * B; }
+// contribution to dLoss/dz_  ([B x 16 T0], [B x 16], [B x 16 T0])
+template <int T1, int T2, int T3, int T0 = 1>
+__host__ __device__ inline int ecb_lds_floats(const EgmDisc &d, int B) {
+  return 64 + ech_layout<T1, T2, T3, T0>(d).total + 8 * 16 + 16 + (2 * 16 * T0 + 16) * B;
+}
 
 struct BnnEgmArgs;   // bnn_egm_kernels.h
 
@@ -429,16 +431,16 @@ struct BnnEgmArgs;   // bnn_egm_kernels.h
 //                  4,5  g(z) [G1S] (variance-head penalty) forward + backward; then, from z_: D, f [F, FS], h [H, HS]
 //                  6,7  discriminator parameter block, L2 warm-up
 // The noise of the nine calls has been drawn by the launch before (ecb_gen_noise).
-template <class Args, int HT, int NTL, int T1, int T2, int T3, int NB, bool PAD = false>
+template <class Args, int HT, int NTL, int T1, int T2, int T3, int NB, bool PAD = false, int T0 = 1>
 __device__ __forceinline__ void ecb_gen_chain(const Args &a, const EcbTab &tab, float *thetaT_, float *ech_lds) {
-  constexpr int B = 16 * NB;
+  constexpr int B = 16 * NB, ZW = 16 * T0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const int q = a.q, p = a.p, z0 = a.z0, z1 = a.z1, z2 = a.z2;
-  const EchP P = ech_layout<T1, T2, T3>(a.dz);
+  const EchP P = ech_layout<T1, T2, T3, T0>(a.dz);
   float *par = ech_lds + 64;
   float *part = par + P.total;
   volatile int *flag = reinterpret_cast<volatile int *>(part + 8 * 16);
-  float *zt = part + 8 * 16 + 16, *dzt = zt + 16 * B, *dzh = dzt + 16 * B;
+  float *zt = part + 8 * 16 + 16, *dzt = zt + ZW * B, *dzh = dzt + 16 * B;
   float *ws = a.ws;
   const float *th = a.theta, *tT = thetaT_;
   if (tid < 16) flag[tid] = 0;
@@ -451,35 +453,39 @@ __device__ __forceinline__ void ecb_gen_chain(const Args &a, const EcbTab &tab, 
   const BnnNet &G = a.net[BNN_G], &E = a.net[BNN_E], &F = a.net[BNN_F], &Hn = a.net[BNN_H];
   float ls[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};     // l_v, l_z, l_x, l_y, s_g, s_f, s_h, adv
   if (role == 0 && active) {
-    f32x4 zin[1];
+    f32x4 zin[T0];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) zin[0][r] = ech_ld(a.z + (long long)row * q, 4 * g + r, q);
+    for (int t = 0; t < T0; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) zin[t][r] = ech_ld(a.z + (long long)row * q, 16 * t + 4 * g + r, q);
     f32x4 gz[NTL];
-    ecb_mlp_fwd<1, HT, NTL, PAD>(th, G, tab.c[ECB_G1], ws, row, zin, gz, j, g);
+    ecb_mlp_fwd<T0, HT, NTL, PAD>(th, G, tab.c[ECB_G1], ws, row, zin, gz, j, g);
     f32x4 vin[NTL];
 #pragma unroll
     for (int t = 0; t < NTL; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) vin[t][r] = (16 * t + 4 * g + r < p) ? gz[t][r] : 0.0f;
-    f32x4 zz[1];
-    ecb_mlp_fwd<NTL, HT, 1, PAD>(th, E, tab.c[ECB_E2], ws, row, vin, zz, j, g);
-    f32x4 dzz[1];
+    f32x4 zz[T0];
+    ecb_mlp_fwd<NTL, HT, T0, PAD>(th, E, tab.c[ECB_E2], ws, row, vin, zz, j, g);
+    f32x4 dzz[T0];
     float lz = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float t = zin[0][r] - zz[0][r];
-      lz = fmaf(t, t, lz);
-      dzz[0][r] = zrec * (-2.0f / (float)(B * q)) * t;
-    }
+    for (int tz = 0; tz < T0; ++tz)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float t = (16 * tz + 4 * g + r < q) ? zin[tz][r] - zz[tz][r] : 0.0f;
+        lz = fmaf(t, t, lz);
+        dzz[tz][r] = zrec * (-2.0f / (float)(B * q)) * t;
+      }
     ls[1] = sum_over_g(lz);
     f32x4 dv[NTL];
-    ecb_mlp_bwd<NTL, HT, 1, true, PAD>(th, tT, E, tab.c[ECB_E2], ws, row, tile, dzz, dv, j, g);
+    ecb_mlp_bwd<NTL, HT, T0, true, PAD>(th, tT, E, tab.c[ECB_E2], ws, row, tile, dzz, dv, j, g);
 #pragma unroll
     for (int t = 0; t < NTL; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) dv[t][r] = (16 * t + 4 * g + r < p) ? dv[t][r] : 0.0f;
-    f32x4 dnone[1];
-    ecb_mlp_bwd<1, HT, NTL, false, PAD>(th, tT, G, tab.c[ECB_G1], ws, row, tile, dv, dnone, j, g);
+    f32x4 dnone[T0];
+    ecb_mlp_bwd<T0, HT, NTL, false, PAD>(th, tT, G, tab.c[ECB_G1], ws, row, tile, dv, dnone, j, g);
   } else if (role == 1 && active) {
     const float *vrow = a.v_ + (long long)a.idx[row] * p;
     f32x4 vin[NTL];
@@ -487,15 +493,16 @@ __device__ __forceinline__ void ecb_gen_chain(const Args &a, const EcbTab &tab, 
     for (int t = 0; t < NTL; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) vin[t][r] = ech_ld(vrow, 16 * t + 4 * g + r, p);
-    f32x4 ze[1];
-    ecb_mlp_fwd<NTL, HT, 1, PAD>(th, E, tab.c[ECB_E1], ws, row, vin, ze, j, g);
-    *reinterpret_cast<f32x4 *>(zt + row * 16 + 4 * g) = ze[0];
+    f32x4 ze[T0];
+    ecb_mlp_fwd<NTL, HT, T0, PAD>(th, E, tab.c[ECB_E1], ws, row, vin, ze, j, g);
+#pragma unroll
+    for (int t = 0; t < T0; ++t) *reinterpret_cast<f32x4 *>(zt + row * ZW + 16 * t + 4 * g) = ze[t];
     __threadfence_block();
     if (lane == 0) flag[2 + tile] = 1;
-    f32x4 dz[1];
+    f32x4 dz[T0];
     {
       f32x4 gv[NTL];
-      ecb_mlp_fwd<1, HT, NTL, PAD>(th, G, tab.c[ECB_G2], ws, row, ze, gv, j, g);
+      ecb_mlp_fwd<T0, HT, NTL, PAD>(th, G, tab.c[ECB_G2], ws, row, ze, gv, j, g);
       float lv = 0.0f;
 #pragma unroll
       for (int t = 0; t < NTL; ++t)
@@ -507,20 +514,23 @@ __device__ __forceinline__ void ecb_gen_chain(const Args &a, const EcbTab &tab, 
           gv[t][r] = (-2.0f / (float)(B * p)) * d;
         }
       ls[0] = sum_over_g(lv);
-      ecb_mlp_bwd<1, HT, NTL, true, PAD>(th, tT, G, tab.c[ECB_G2], ws, row, tile, gv, dz, j, g);
+      ecb_mlp_bwd<T0, HT, NTL, true, PAD>(th, tT, G, tab.c[ECB_G2], ws, row, tile, gv, dz, j, g);
     }
     while (flag[4 + tile] == 0) __builtin_amdgcn_s_sleep(2);
     __threadfence_block();
-    dz[0] += *reinterpret_cast<const f32x4 *>(dzh + row * 16 + 4 * g);
+#pragma unroll
+    for (int t = 0; t < T0; ++t) dz[t] += *reinterpret_cast<const f32x4 *>(dzh + row * ZW + 16 * t + 4 * g);
     f32x4 dnone[NTL];
-    ecb_mlp_bwd<NTL, HT, 1, false, PAD>(th, tT, E, tab.c[ECB_E1], ws, row, tile, dz, dnone, j, g);
+    ecb_mlp_bwd<NTL, HT, T0, false, PAD>(th, tT, E, tab.c[ECB_E1], ws, row, tile, dz, dnone, j, g);
   } else if (role == 2 && active) {
     {   // second g(z) call: the variance-head penalty
-      f32x4 zin[1];
+      f32x4 zin[T0];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) zin[0][r] = ech_ld(a.z + (long long)row * q, 4 * g + r, q);
+      for (int t = 0; t < T0; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zin[t][r] = ech_ld(a.z + (long long)row * q, 16 * t + 4 * g + r, q);
       f32x4 gzs[NTL];
-      ecb_mlp_fwd<1, HT, NTL, PAD>(th, G, tab.c[ECB_G1S], ws, row, zin, gzs, j, g);
+      ecb_mlp_fwd<T0, HT, NTL, PAD>(th, G, tab.c[ECB_G1S], ws, row, zin, gzs, j, g);
       float sgv = 0.0f;
 #pragma unroll
       for (int t = 0; t < NTL; ++t)
@@ -532,22 +542,24 @@ __device__ __forceinline__ void ecb_gen_chain(const Args &a, const EcbTab &tab, 
       for (int t = 0; t < NTL; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) gzs[t][r] = (16 * t + 4 * g + r == p) ? 0.001f * 2.0f * sgv * invB : 0.0f;
-      f32x4 dnone[1];
-      ecb_mlp_bwd<1, HT, NTL, false, PAD>(th, tT, G, tab.c[ECB_G1S], ws, row, tile, gzs, dnone, j, g);
+      f32x4 dnone[T0];
+      ecb_mlp_bwd<T0, HT, NTL, false, PAD>(th, tT, G, tab.c[ECB_G1S], ws, row, tile, gzs, dnone, j, g);
     }
     const long long prow = a.idx[row];
     const float xv = a.x_[prow], yv = a.y_[prow];
     while (flag[0] < 2) __builtin_amdgcn_s_sleep(2);
     while (flag[2 + tile] == 0) __builtin_amdgcn_s_sleep(2);
     __threadfence_block();
-    f32x4 ze[1], dz[1];
-    ze[0] = *reinterpret_cast<const f32x4 *>(zt + row * 16 + 4 * g);
+    f32x4 ze[T0], dz[T0];
+#pragma unroll
+    for (int t = 0; t < T0; ++t) ze[t] = *reinterpret_cast<const f32x4 *>(zt + row * ZW + 16 * t + 4 * g);
     {
-      EchFwd<T1, T2, T3> Fw;
-      Fw.a0[0] = ze[0];
-      ech_disc_fwd<T1, T2, T3>(par, P, Fw, j, g);
+      EchFwd<T1, T2, T3, T0> Fw;
+#pragma unroll
+      for (int t = 0; t < T0; ++t) Fw.a0[t] = ze[t];
+      ech_disc_fwd<T1, T2, T3, T0>(par, P, Fw, j, g);
       ls[7] = -Fw.out;
-      ecg_disc_dx<T1, T2, T3>(par, P, Fw, -invB, dz, j, g);
+      ecg_disc_dx<T1, T2, T3, T0>(par, P, Fw, -invB, dz, j, g);
     }
     {   // f: mean call, variance-penalty call
       f32x4 fin[1], fo[1], dfo[1], dfin[1];
@@ -579,7 +591,7 @@ __device__ __forceinline__ void ecb_gen_chain(const Args &a, const EcbTab &tab, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int f = 4 * g + r;
-        const float t = zt[row * 16 + min(f < z0 ? f : f + z1, 15)];
+        const float t = zt[row * ZW + min(f < z0 ? f : f + z1, ZW - 1)];
         hin[0][r] = f < z0 + z2 ? t : 0.0f;
       }
       const int oh = Hn.dims[Hn.n_layers];
@@ -609,18 +621,21 @@ __device__ __forceinline__ void ecb_gen_chain(const Args &a, const EcbTab &tab, 
       *reinterpret_cast<f32x4 *>(dzt + row * 16 + 4 * g) = dhin[0];
       __threadfence_block();
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int f = 4 * g + r;
-        const int src = f < z0 ? f : f - z1;
-        const float t = dzt[row * 16 + min(max(src, 0), 15)];
-        dz[0][r] += (f < z0 || (f >= z0 + z1 && f < z0 + z1 + z2)) ? t : 0.0f;
-      }
+      for (int tz = 0; tz < T0; ++tz)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 16 * tz + 4 * g + r;
+          const int src = f < z0 ? f : f - z1;
+          const float t = dzt[row * 16 + min(max(src, 0), 15)];
+          dz[tz][r] += (f < z0 || (f >= z0 + z1 && f < z0 + z1 + z2)) ? t : 0.0f;
+        }
     }
-    *reinterpret_cast<f32x4 *>(dzh + row * 16 + 4 * g) = dz[0];
+#pragma unroll
+    for (int t = 0; t < T0; ++t) *reinterpret_cast<f32x4 *>(dzh + row * ZW + 16 * t + 4 * g) = dz[t];
     __threadfence_block();
     if (lane == 0) flag[4 + tile] = 1;
   } else if (role == 3) {
-    ech_fill_params<T1, T2, T3>(par, P, a.theta_d, a.dz, tid - 384, 128);
+    ech_fill_params<T1, T2, T3, T0>(par, P, a.theta_d, a.dz, tid - 384, 128);
     __threadfence_block();
     if (lane == 0) atomicAdd(const_cast<int *>(flag), 1);
     float sink = 0.0f;
@@ -751,8 +766,13 @@ __device__ __forceinline__ float ecb_pick(const f32x4 (&x)[NT], int f, int g) {
   return sum_over_g(v);
 }
 // inputs of the three nets from a row of the latent table
-__device__ __forceinline__ void ecb_inputs(const float *zrow, float xv, int q, int z0, int z1, int z2, int g, f32x4 (&zin)[1], f32x4 (&fin)[1],
+template <int T0>
+__device__ __forceinline__ void ecb_inputs(const float *zrow, float xv, int q, int z0, int z1, int z2, int g, f32x4 (&zin)[T0], f32x4 (&fin)[1],
                                            f32x4 (&hin)[1]) {
+#pragma unroll
+  for (int t = 1; t < T0; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zin[t][r] = ech_ld(zrow, 16 * t + 4 * g + r, q);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int f = 4 * g + r;
@@ -763,7 +783,7 @@ __device__ __forceinline__ void ecb_inputs(const float *zrow, float xv, int q, i
   }
 }
 
-template <class Args, int HT, int NTL, int T1, int T2, int T3, int NB, bool PAD = false>
+template <class Args, int HT, int NTL, int T1, int T2, int T3, int NB, bool PAD = false, int T0 = 1>
 __device__ __forceinline__ void ecb_theta_chain(const Args &a, const EcbTab &tab, float *ws, float *lds) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const int q = a.q, p = a.p;
@@ -776,12 +796,12 @@ __device__ __forceinline__ void ecb_theta_chain(const Args &a, const EcbTab &tab
   if (role < 3 && active) {
     const long long prow = a.idx[row];
     const float xv = a.x_[prow], yv = a.y_[prow];
-    f32x4 zin[1], fin[1], hin[1];
-    ecb_inputs(a.data_z + prow * q, xv, q, a.z0, a.z1, a.z2, g, zin, fin, hin);
+    f32x4 zin[T0], fin[1], hin[1];
+    ecb_inputs<T0>(a.data_z + prow * q, xv, q, a.z0, a.z1, a.z2, g, zin, fin, hin);
     if (role == 0) {
       const BnnNet &G = a.net[BNN_G];
       f32x4 o[NTL];
-      ecb_mlp_fwd<1, HT, NTL, PAD>(th, G, tab.c[0], ws, row, zin, o, j, g);
+      ecb_mlp_fwd<T0, HT, NTL, PAD>(th, G, tab.c[0], ws, row, zin, o, j, g);
       const float *vrow = a.v_ + prow * p;
       float ssq = 0.0f;
 #pragma unroll
@@ -804,8 +824,8 @@ __device__ __forceinline__ void ecb_theta_chain(const Args &a, const EcbTab &tab
           o[t][r] = f < p ? -(ech_ld(vrow, f, p) - o[t][r]) / s2 * a.inv_B : (f == p ? dr * a.inv_B : 0.0f);
         }
       ls0 = lb; ls1 = ssq;
-      f32x4 dnone[1];
-      ecb_mlp_bwd<1, HT, NTL, false, PAD>(th, th, G, tab.c[0], ws, row, tile, o, dnone, j, g);
+      f32x4 dnone[T0];
+      ecb_mlp_bwd<T0, HT, NTL, false, PAD>(th, th, G, tab.c[0], ws, row, tile, o, dnone, j, g);
     } else {
       const bool is_h = role == 1;
       const BnnNet &N = a.net[is_h ? BNN_H : BNN_F];
@@ -925,9 +945,9 @@ __device__ __forceinline__ void ecb_theta_dw(const Args &a, const EcbTab &tab, c
 
 // latent step: dz [B x q] = d loss / d (batch rows of data_z), out[0] = loss_postrior_z.  Waves 0,1: g mean call; 2,3: g variance-head
 // call (they exchange the row's sum of squares and raw variance through LDS); 4,5: h (both calls); 6,7: f (both calls).
-template <class Args, int HT, int NTL, int T1, int T2, int T3, int NB, bool PAD = false>
+template <class Args, int HT, int NTL, int T1, int T2, int T3, int NB, bool PAD = false, int T0 = 1>
 __device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, float *ws, float *lds) {
-  constexpr int B = 16 * NB;
+  constexpr int B = 16 * NB, ZW = 16 * T0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const int q = a.q, p = a.p, z0 = a.z0, z1 = a.z1, z2 = a.z2;
   const int role = wave >> 1, tile = wave & 1;
@@ -937,7 +957,7 @@ __device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, fl
   float *part = lds;                                   // [8 waves] loss partials
   volatile int *flag = reinterpret_cast<volatile int *>(lds + 16);    // [0 + tile]: ssq written; [2 + tile]: raw written
   float *xch = lds + 32;                               // [B] ssq | [B] raw of the g calls
-  float *dzc = lds + 32 + 2 * B;                       // [4 roles][B x 16] input gradients
+  float *dzc = lds + 32 + 2 * B;                       // [4 roles][B x 16 T0] input gradients (the head nets use the first 16 columns)
   if (tid < 16) flag[tid] = 0;
   __syncthreads();
   float lsum = 0.0f;
@@ -945,13 +965,13 @@ __device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, fl
     const long long prow = a.idx[row];
     const float xv = a.x_[prow], yv = a.y_[prow];
     const float *zrow = a.data_z + prow * q;
-    f32x4 zin[1], fin[1], hin[1], dx[1];
-    ecb_inputs(zrow, xv, q, z0, z1, z2, g, zin, fin, hin);
-    ech_zero<1>(dx);
+    f32x4 zin[T0], fin[1], hin[1], dx[T0];
+    ecb_inputs<T0>(zrow, xv, q, z0, z1, z2, g, zin, fin, hin);
+    ech_zero<T0>(dx);
     if (role == 0) {
       const BnnNet &G = a.net[BNN_G];
       f32x4 o[NTL];
-      ecb_mlp_fwd<1, HT, NTL, PAD>(th, G, tab.c[0], ws, row, zin, o, j, g);
+      ecb_mlp_fwd<T0, HT, NTL, PAD>(th, G, tab.c[0], ws, row, zin, o, j, g);
       const float *vrow = a.v_ + prow * p;
       float ssq = 0.0f;
 #pragma unroll
@@ -977,11 +997,11 @@ __device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, fl
       for (int t = 0; t < NTL; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[t][r] = (16 * t + 4 * g + r < p) ? -o[t][r] / s2 * a.inv_B : 0.0f;
-      ecb_mlp_bwd<1, HT, NTL, true, PAD>(th, th, G, tab.c[0], ws, row, tile, o, dx, j, g);
+      ecb_mlp_bwd<T0, HT, NTL, true, PAD>(th, th, G, tab.c[0], ws, row, tile, o, dx, j, g);
     } else if (role == 1) {
       const BnnNet &G = a.net[BNN_G];
       f32x4 o[NTL];
-      ecb_mlp_fwd<1, HT, NTL, PAD>(th, G, tab.c[1], ws, row, zin, o, j, g);
+      ecb_mlp_fwd<T0, HT, NTL, PAD>(th, G, tab.c[1], ws, row, zin, o, j, g);
       const float raw = ecb_pick<NTL>(o, p, g);
       if (g == 0) xch[B + row] = raw;
       __threadfence_block();
@@ -995,13 +1015,13 @@ __device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, fl
       for (int t = 0; t < NTL; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[t][r] = (16 * t + 4 * g + r == p) ? dr * a.inv_B : 0.0f;
-      ecb_mlp_bwd<1, HT, NTL, true, PAD>(th, th, G, tab.c[1], ws, row, tile, o, dx, j, g);
+      ecb_mlp_bwd<T0, HT, NTL, true, PAD>(th, th, G, tab.c[1], ws, row, tile, o, dx, j, g);
     } else {
       const bool is_h = role == 2;
       const BnnNet &N = a.net[is_h ? BNN_H : BNN_F];
       const int c0 = is_h ? 2 : 4;
       const bool two = !(is_h && a.binary);
-      f32x4 o1[1], o2[1], d[1], dx2[1];
+      f32x4 o1[1], o2[1], d[1], dx1[1], dx2[1];
       ecb_head_fwd<T1, T2, T3>(th, N, tab.c[c0], ws, row, is_h ? hin : fin, o1, j, g);
       if (two) ecb_head_fwd<T1, T2, T3>(th, N, tab.c[c0 + 1], ws, row, is_h ? hin : fin, o2, j, g);
       const int wo = N.dims[N.n_layers];
@@ -1020,7 +1040,8 @@ __device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, fl
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) d[0][r] = (4 * g + r == 0) ? d0 : 0.0f;
-      ecb_head_bwd<T1, T2, T3>(th, th, N, tab.c[c0], ws, row, tile, d, dx, j, g);
+      ecb_head_bwd<T1, T2, T3>(th, th, N, tab.c[c0], ws, row, tile, d, dx1, j, g);
+      dx[0] = dx1[0];
       if (two) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) d[0][r] = (4 * g + r == wo - 1) ? dl : 0.0f;
@@ -1028,11 +1049,14 @@ __device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, fl
         dx[0] += dx2[0];
       }
     }
-    *reinterpret_cast<f32x4 *>(dzc + (role * B + row) * 16 + 4 * g) = dx[0];
+#pragma unroll
+    for (int t = 0; t < T0; ++t) *reinterpret_cast<f32x4 *>(dzc + (role * B + row) * ZW + 16 * t + 4 * g) = dx[t];
     if (role == 0) {            // the prior term of the row
       float zz = 0.0f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) zz = fmaf(zin[0][r], zin[0][r], zz);
+      for (int t = 0; t < T0; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zz = fmaf(zin[t][r], zin[t][r], zz);
       lsum += 0.5f * sum_over_g(zz);
     }
   }
@@ -1043,10 +1067,10 @@ __device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, fl
   __syncthreads();
   for (int i = tid; i < B * q; i += ECH_THREADS) {
     const int b = i / q, col = i - b * q;
-    float v = a.data_z[(long long)a.idx[b] * q + col] * a.inv_B + dzc[(0 * B + b) * 16 + col] + dzc[(1 * B + b) * 16 + col];
-    if (col < z0 + z1) v += dzc[(3 * B + b) * 16 + col];                                  // f: (z0, z1, x)
-    if (col < z0) v += dzc[(2 * B + b) * 16 + col];                                       // h: (z0, z2)
-    else if (col >= z0 + z1 && col < z0 + z1 + z2) v += dzc[(2 * B + b) * 16 + col - z1];
+    float v = a.data_z[(long long)a.idx[b] * q + col] * a.inv_B + dzc[(0 * B + b) * ZW + col] + dzc[(1 * B + b) * ZW + col];
+    if (col < z0 + z1) v += dzc[(3 * B + b) * ZW + col];                                  // f: (z0, z1, x)
+    if (col < z0) v += dzc[(2 * B + b) * ZW + col];                                       // h: (z0, z2)
+    else if (col >= z0 + z1 && col < z0 + z1 + z2) v += dzc[(2 * B + b) * ZW + col - z1];
     a.dz[i] = v;
   }
   if (tid == 0 && a.out) {
@@ -1068,7 +1092,7 @@ inline size_t ecb_build_tab(const BnnNet *nets, const int *call_net, const int *
   size_t off = 0;
   auto take = [&](size_t n) { const size_t r = off; off += (n + 3) / 4 * 4; return (int)r; };
   const int NBt = (B + 15) / 16;
-  for (int k = 0; k < 4; ++k) { tab.net_ncalls[k] = 0; tab.kt0[k] = k == BNN_E ? ntl : 1; }
+  for (int k = 0; k < 4; ++k) { tab.net_ncalls[k] = 0; tab.kt0[k] = k == BNN_E ? ntl : (k == BNN_G ? tl(nets[BNN_G].dims[0]) : 1); }
   int xw[ECB_CALLS][BNN_MAX_LAYERS], dw[ECB_CALLS][BNN_MAX_LAYERS];
   for (int c = 0; c < n_calls; ++c) {
     const BnnNet &m = nets[call_net[c]];
@@ -1115,7 +1139,7 @@ inline size_t ecb_build_tab(const BnnNet *nets, const int *call_net, const int *
 }
 // shapes the row-tile chains are compiled for
 inline bool ecb_shapes_ok(const BnnNet *nets, int q, int p, bool need_e) {
-  bool ok = q <= 16;
+  bool ok = q <= 32;               // one latent input tile, or two (B = 32, 13-tile kernels)
   const int ntl = (p + 1 + 15) / 16;
   ok = ok && ntl <= 13;            // 13 and 7 are compiled exactly; anything narrower runs the 13-tile kernels with masked columns
   for (int k = 0; k < 4; ++k) {

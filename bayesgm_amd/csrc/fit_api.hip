@@ -15,6 +15,7 @@
 struct FitChainState {
   FitChainArgs base{};
   int ntl = 0;
+  int t0 = 1;            // latent input tiles of g (q <= 16 t0); two tiles run the padded B = 32 variant only
   bool pad = false;      // the 13-tile kernels on a narrower p + 1 (B = 32 only)
   float *thetaT = nullptr, *ws = nullptr;
   int *tiles = nullptr, *mirror_dst = nullptr;
@@ -41,9 +42,10 @@ static int fit_chain_setup(bgm_handle *h, const std::vector<float> &theta) {
   const HostNet &G = h->nets[BGM_NET_G], &F = h->nets[BGM_NET_F], &H = h->nets[BGM_NET_H];
   const int ng = (int)G.count(), nf = (int)F.count(), np = h->n_params, q = h->q, p = h->p;
   const int ntl_need = (p + 1 + 15) / 16;
-  const int ntl = (ntl_need == 13 || ntl_need == 7) ? ntl_need : 13;
+  const int t0 = q <= 16 ? 1 : 2;
+  const int ntl = ((ntl_need == 13 || ntl_need == 7) && t0 == 1) ? ntl_need : 13;
   FitChainArgs a{};
-  bool ok = !std::getenv("BGM_FIT_NO_CHAIN") && q <= 16 && ntl_need <= 13 && fit_fill_mlp(G, a.g, 0) && fit_fill_mlp(F, a.f, ng) &&
+  bool ok = !std::getenv("BGM_FIT_NO_CHAIN") && q <= 32 && ntl_need <= 13 && fit_fill_mlp(G, a.g, 0) && fit_fill_mlp(F, a.f, ng) &&
             fit_fill_mlp(H, a.h, ng + nf);
   ok = ok && a.g.n_layers >= 3 && a.g.dims[0] == q && a.g.dims[a.g.n_layers] == p + 1;
   for (int l = 1; ok && l < a.g.n_layers; ++l) ok = a.g.dims[l] == 64;
@@ -53,7 +55,8 @@ static int fit_chain_setup(bgm_handle *h, const std::vector<float> &theta) {
   FitChainState *c = new FitChainState();
   h->fit_chain = c;
   c->ntl = ntl;
-  c->pad = ntl != ntl_need;
+  c->t0 = t0;
+  c->pad = ntl != ntl_need || t0 == 2;
   const int B = 32;
   auto tl = [](int n) { return (n + 15) / 16; };
   size_t off = 0;
@@ -108,6 +111,14 @@ static void fit_chain_launch(const FitChainState *c, FitChainArgs &a, int batch,
       hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, NB_, 0>), dim3(1), dim3(ECH_THREADS), 0, stream, a); \
       hipLaunchKernelGGL(fit_chain_dw_kernel<NB_>, dim3((a.n_tiles + ECH_WAVES - 1) / ECH_WAVES), dim3(ECH_THREADS), 0, stream, a); \
     } \
+  }
+  if (c->t0 == 2) {
+    if (z_mode) hipLaunchKernelGGL((fit_chain_kernel<4, 13, 4, 2, 1, 2, 1, true, 2>), dim3(1), dim3(ECH_THREADS), 0, stream, a);
+    else {
+      hipLaunchKernelGGL((fit_chain_kernel<4, 13, 4, 2, 1, 2, 0, true, 2>), dim3(1), dim3(ECH_THREADS), 0, stream, a);
+      hipLaunchKernelGGL(fit_chain_dw_kernel<2>, dim3((a.n_tiles + ECH_WAVES - 1) / ECH_WAVES), dim3(ECH_THREADS), 0, stream, a);
+    }
+    return;
   }
   if (c->pad) {
     if (z_mode) hipLaunchKernelGGL((fit_chain_kernel<4, 13, 4, 2, 1, 2, 1, true>), dim3(1), dim3(ECH_THREADS), 0, stream, a);

@@ -32,9 +32,11 @@ struct FitChainArgs {
 __device__ __forceinline__ long long fitc_row(const FitChainArgs &a, int b) { return a.idx ? (long long)a.idx[b] : a.row_lo + b; }
 
 // Z_MODE 0: theta phase (stash, no input gradients); 1: latent phase (input gradients -> dz)
-template <int HT, int NTL, int T1, int T2, int T3, int NB, int Z_MODE, bool PAD = false>
+// T0: latent input tiles of g (q <= 16 T0); the head networks' inputs (z0 + z1 + 1, z0 + z2) stay within one tile
+template <int HT, int NTL, int T1, int T2, int T3, int NB, int Z_MODE, bool PAD = false, int T0 = 1>
 static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_kernel(FitChainArgs a) {
-  __shared__ float dzc[3 * 32 * 16];
+  constexpr int ZW = 16 * T0;
+  __shared__ float dzc[3 * 32 * ZW];
   __shared__ double lsum[8 * 8];
   constexpr int B = 16 * NB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
@@ -49,16 +51,17 @@ static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_kernel(FitChainA
     const long long prow = fitc_row(a, row);
     const float xv = a.x[prow], yv = a.y[prow];
     const float *zrow = a.data_z + prow * q;
-    f32x4 dx[1];
-    ech_zero<1>(dx);
     if (role == 0) {
-      f32x4 zin[1];
+      f32x4 zin[T0], dx[T0];
+      ech_zero<T0>(dx);
       float zsq = 0.0f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { zin[0][r] = ech_ld(zrow, 4 * g + r, q); zsq = fmaf(zin[0][r], zin[0][r], zsq); }
+      for (int t = 0; t < T0; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { zin[t][r] = ech_ld(zrow, 16 * t + 4 * g + r, q); zsq = fmaf(zin[t][r], zin[t][r], zsq); }
       l2 = 0.5f * sum_over_g(zsq);
       f32x4 o[NTL];
-      ecg_g_fwd<HT, NTL, PAD>(th, a.g, a.xo[0], ws, row, zin, o, j, g);
+      ecg_g_fwd<HT, NTL, PAD, T0>(th, a.g, a.xo[0], ws, row, zin, o, j, g);
       const float *vrow = a.v + prow * p;
       float ssq = 0.0f, sraw = 0.0f;
 #pragma unroll
@@ -89,11 +92,16 @@ static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_kernel(FitChainA
           const int f = 16 * t + 4 * g + r;
           o[t][r] = f < p ? cmu * o[t][r] : (f == p ? dsraw : 0.0f);
         }
-      ecg_g_bwd<HT, NTL, Z_MODE == 1>(tT, a.g, a.xo[0], a.dofs[0], ws, row, o, dx, j, g);
+      ecg_g_bwd<HT, NTL, Z_MODE == 1, T0>(tT, a.g, a.xo[0], a.dofs[0], ws, row, o, dx, j, g);
+      if (Z_MODE == 1) {
+#pragma unroll
+        for (int t = 0; t < T0; ++t) *reinterpret_cast<f32x4 *>(dzc + row * ZW + 16 * t + 4 * g) = dx[t];
+      }
     } else {
       const bool is_f = role == 1;
       const EgmMlp &N = is_f ? a.f : a.h;
-      f32x4 in[1], o[1], d[1];
+      f32x4 in[1], o[1], d[1], dx[1];
+      ech_zero<1>(dx);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int f = 4 * g + r;
@@ -124,8 +132,8 @@ static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_kernel(FitChainA
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const int f = 4 * g + r; d[0][r] = f == 0 ? dmu : (f == 1 ? dsr : 0.0f); }
       ecg_head_bwd<T1, T2, T3>(tT, N, a.xo[role], a.dofs[role], ws, row, d, dx, j, g);
+      if (Z_MODE == 1) *reinterpret_cast<f32x4 *>(dzc + (role * 32 + row) * ZW + 4 * g) = dx[0];
     }
-    if (Z_MODE == 1) *reinterpret_cast<f32x4 *>(dzc + (role * 32 + row) * 16 + 4 * g) = dx[0];
   }
   {   // per-wave sums in double (the accumulators are doubles)
     const float s0 = sum_over_j_to_lane15(l0), s1 = sum_over_j_to_lane15(l1), s2_ = sum_over_j_to_lane15(l2);
@@ -135,10 +143,10 @@ static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_kernel(FitChainA
   if (Z_MODE == 1) {
     for (int i = tid; i < B * q; i += ECH_THREADS) {
       const int b = i / q, col = i - b * q;
-      float v = a.data_z[fitc_row(a, b) * q + col] * a.inv_B + dzc[(0 * 32 + b) * 16 + col];
-      if (col < z0 + z1) v += dzc[(1 * 32 + b) * 16 + col];                                  // f: (z0, z1, x)
-      if (col < z0) v += dzc[(2 * 32 + b) * 16 + col];                                       // h: (z0, z2)
-      else if (col >= z0 + z1 && col < z0 + z1 + z2) v += dzc[(2 * 32 + b) * 16 + col - z1];
+      float v = a.data_z[fitc_row(a, b) * q + col] * a.inv_B + dzc[(0 * 32 + b) * ZW + col];
+      if (col < z0 + z1) v += dzc[(1 * 32 + b) * ZW + col];                                  // f: (z0, z1, x)
+      if (col < z0) v += dzc[(2 * 32 + b) * ZW + col];                                       // h: (z0, z2)
+      else if (col >= z0 + z1 && col < z0 + z1 + z2) v += dzc[(2 * 32 + b) * ZW + col - z1];
       a.dz[i] = v;
     }
   }

@@ -1,5 +1,5 @@
 """Timing of the Bayesian-network (use_bnn=True) kernels on one MI355X: MH iterations at the north-star panel size,
-minibatch steps, EGM steps.  python scripts/probe_bnn.py [N] [p] [iters]"""
+minibatch steps, EGM steps.  python scripts/probe_bnn.py [N] [p] [iters] [z_dims, e.g. 3,6,3,6]"""
 import sys, time
 import numpy as np
 import torch
@@ -10,7 +10,8 @@ from bayesgm_amd.bnn_engine import BnnEngine
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 p = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
-z_dims = [1, 1, 1, 7]
+z_dims = [int(t) for t in sys.argv[4].split(",")] if len(sys.argv) > 4 else [1, 1, 1, 7]
+q = sum(z_dims)
 m = OB.init_model(0, z_dims, p, False)
 eng = BnnEngine(p, z_dims, False, max_batch=64, norm_mode=1)      # inference-mode input normalisation, the models' default
 eng.begin(m)
@@ -19,7 +20,7 @@ g = torch.Generator(device=dev); g.manual_seed(0)
 v = torch.randn(N, p, device=dev, generator=g)
 x = torch.rand(N, device=dev, generator=g)
 y = torch.randn(N, device=dev, generator=g)
-state = torch.empty(N, 10, device=dev)
+state = torch.empty(N, q, device=dev)
 bs = 10000
 
 
@@ -47,20 +48,20 @@ print("predict(burn_in=5000, n_mcmc=3000) estimate: %.1f s" % (5000 * t / iters 
 # minibatch steps
 n = 20000
 idx = torch.randperm(n, device=dev)[:32].int()
-z = torch.randn(n, 10, device=dev)
+z = torch.randn(n, q, device=dev)
 zm, zv = torch.zeros_like(z), torch.zeros_like(z)
 eng.theta_step(z, idx, x, y, v, 1e-4, 1, 0)
 tt = timed(lambda: eng.theta_step(z, idx, x, y, v, 1e-4, 1, 0), 50)
 tz = timed(lambda: eng.z_step(x, y, v, z, zm, zv, idx, 1e-4, 1, 1), 50)
 print("fit minibatch (B=32): theta step %.0f us, latent step %.0f us -> %.1f s per epoch of N=20000" % (1e6 * tt, 1e6 * tz, (tt + tz) * 625))
 _rs = np.random.RandomState(0)
-_dd = [10, 64, 32, 8, 1]
+_dd = [q, 64, 32, 8, 1]
 dz = {"W": [_rs.uniform(-1, 1, (_dd[i], _dd[i + 1])).astype(np.float32) * np.float32(np.sqrt(6.0 / (_dd[i] + _dd[i + 1]))) for i in range(4)],
       "b": [np.zeros(d, np.float32) for d in _dd[1:]], "gamma": [np.ones(d, np.float32) for d in _dd[1:-1]],
       "beta": [np.zeros(d, np.float32) for d in _dd[1:-1]]}
 eng.set_disc_norm("fixed")      # the models' default
 eng.egm_begin(dz, 32, 2e-4, 1)
-zp = torch.randn(32, 10, device=dev)
+zp = torch.randn(32, q, device=dev)
 eng.egm_disc_step(zp, idx, v, 0.3, 1, 0); eng.egm_gen_step(zp, idx, v, x, y, 1, 1)
 td = timed(lambda: eng.egm_disc_step(zp, idx, v, 0.3, 1, 0), 50)
 tg = timed(lambda: eng.egm_gen_step(zp, idx, v, x, y, 1, 1), 50)

@@ -1,4 +1,4 @@
-"""Latency of the native EGM steps (one launch each):  python scripts/probe_egm_native.py [p] [iters] [fixed|batch]
+"""Latency of the native EGM steps (one launch each):  python scripts/probe_egm_native.py [p] [iters] [fixed|batch] [z_dims, e.g. 3,3,6,6]
 (fixed = the shipped discriminator normalisation; BGM_EGM_NO_CHAIN=1 forces the phase-machine kernels)"""
 import sys, os, time, json
 import numpy as np
@@ -16,10 +16,11 @@ def _disc(rs, dims):
 
 p = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-z_dims = [1, 1, 1, 7]; q = 10; B = 32; n = 20000
+z_dims = [int(t) for t in sys.argv[4].split(",")] if len(sys.argv) > 4 else [1, 1, 1, 7]
+q = sum(z_dims); B = 32; n = 20000
 rs = np.random.RandomState(0)
 nets = {"g": _mlp(rs, [q] + [64] * 5 + [p + 1]), "e": _mlp(rs, [p] + [64] * 5 + [q]),
-        "f": _mlp(rs, [3, 64, 32, 8, 2]), "h": _mlp(rs, [2, 64, 32, 8, 2])}
+        "f": _mlp(rs, [z_dims[0] + z_dims[1] + 1, 64, 32, 8, 2]), "h": _mlp(rs, [z_dims[0] + z_dims[2], 64, 32, 8, 2])}
 dz = _disc(rs, [q, 64, 32, 8, 1])
 eng = CausalEngine(p, z_dims)
 eng.set_model(g=nets["g"], f=nets["f"], h=nets["h"], e=nets["e"])
@@ -42,5 +43,5 @@ torch.cuda.synchronize(); td = (time.perf_counter() - t1) / iters
 t1 = time.perf_counter()
 for it in range(iters): eng.egm_gen_step(zs[it], idx[it], v, x, y)
 torch.cuda.synchronize(); tg = (time.perf_counter() - t1) / iters
-print(json.dumps(dict(p=p, disc_norm=norm, ms_per_iteration=1e3 * dt / iters, disc_step_us=1e6 * td, gen_step_us=1e6 * tg,
+print(json.dumps(dict(p=p, z_dims=z_dims, disc_norm=norm, ms_per_iteration=1e3 * dt / iters, disc_step_us=1e6 * td, gen_step_us=1e6 * tg,
                       est_30000_iters_s=30000 * dt / iters)))

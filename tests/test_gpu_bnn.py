@@ -43,16 +43,21 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
-@pytest.mark.parametrize("binary,B,units,p", [
-    (False, 32, {}, 50),
-    (True, 32, {}, 50),
-    (False, 19, dict(g_units=(24, 40), e_units=(16,), f_units=(20, 12), h_units=(9, 5)), 37),
-    (False, 32, {}, 200), (True, 32, {}, 100), (False, 16, {}, 100),       # row-tile chains
-    (False, 32, {}, 45),                                                     # ... the 13-tile kernels on a narrower panel (masked columns)
+ZD = (1, 1, 1, 7)
+ACIC = (3, 6, 3, 6)       # Semi_acic.yaml: q = 18, two latent input tiles on the chains
+
+
+@pytest.mark.parametrize("binary,B,units,p,zd", [
+    (False, 32, {}, 50, ZD),
+    (True, 32, {}, 50, ZD),
+    (False, 19, dict(g_units=(24, 40), e_units=(16,), f_units=(20, 12), h_units=(9, 5)), 37, ZD),
+    (False, 32, {}, 200, ZD), (True, 32, {}, 100, ZD), (False, 16, {}, 100, ZD),       # row-tile chains
+    (False, 32, {}, 45, ZD),                                                     # ... the 13-tile kernels on a narrower panel (masked columns)
+    (True, 32, {}, 177, ACIC), (False, 32, {}, 100, (5, 5, 5, 5)),               # ... with two latent input tiles (Semi_acic, Sim_Colangelo)
 ])
-def test_theta_step_gradients_match_oracle(binary, B, units, p):
+def test_theta_step_gradients_match_oracle(binary, B, units, p, zd):
     chain = p >= 100 or p == 45
-    m = _model(binary, p=p, fixed=chain, **units)
+    m = _model(binary, z_dims=zd, p=p, fixed=chain, **units)
     z, x, y, v = _panel(m, 200)
     eng = _engine(m, kl_weight=0.01, **(dict(norm_mode=1) if chain else {}), **units)
     dev = eng.device
@@ -78,10 +83,11 @@ def test_theta_step_gradients_match_oracle(binary, B, units, p):
     eng.close()
 
 
-@pytest.mark.parametrize("binary,p,B", [(False, 50, 32), (True, 50, 32), (False, 200, 32), (True, 100, 32), (False, 100, 16), (True, 45, 32)])
-def test_z_step_gradient_matches_oracle(binary, p, B):
+@pytest.mark.parametrize("binary,p,B,zd", [(False, 50, 32, ZD), (True, 50, 32, ZD), (False, 200, 32, ZD), (True, 100, 32, ZD), (False, 100, 16, ZD),
+                                           (True, 45, 32, ZD), (True, 177, 32, ACIC), (False, 100, 32, (5, 5, 5, 5))])
+def test_z_step_gradient_matches_oracle(binary, p, B, zd):
     chain = p >= 100 or p == 45
-    m = _model(binary, p=p, fixed=chain)
+    m = _model(binary, z_dims=zd, p=p, fixed=chain)
     z, x, y, v = _panel(m, 100)
     eng = _engine(m, norm_mode=1) if chain else _engine(m)
     dev = eng.device
@@ -255,15 +261,16 @@ def test_evaluate_matches_oracle(binary, p):
     eng.close()
 
 
-@pytest.mark.parametrize("binary,disc_norm,p", [(False, "batch", 50), (True, "batch", 50), (False, "fixed", 50), (True, "fixed", 50),
-                                                (False, "fixed", 100), (True, "fixed", 200), (False, "fixed", 45)])
-def test_egm_steps_match_oracle(binary, disc_norm, p):
+@pytest.mark.parametrize("binary,disc_norm,p,zd", [(False, "batch", 50, ZD), (True, "batch", 50, ZD), (False, "fixed", 50, ZD), (True, "fixed", 50, ZD),
+                                                   (False, "fixed", 100, ZD), (True, "fixed", 200, ZD), (False, "fixed", 45, ZD),
+                                                   (True, "fixed", 177, ACIC), (False, "fixed", 100, (5, 5, 5, 5))])
+def test_egm_steps_match_oracle(binary, disc_norm, p, zd):
     """EGM warm-start steps with Bayesian nets: gradients of the discriminator step and of the nine-call generator step.
     disc_norm = "fixed" (the models' default): the discriminator passes of the step run as register-chained row tiles; at
     p = 100 / 200 (with the inference-mode input normalisation of `_model`, when it has it) so does the Flipout encoder call."""
     from oracle import egm as OE
     from bayesgm_amd.engine import CausalEngine
-    m = _model(binary, p=p)
+    m = _model(binary, z_dims=zd, p=p)
     n, B = 120, 32
     _, x, y, v = _panel(m, n)
     q = sum(m["z_dims"])

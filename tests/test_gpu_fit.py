@@ -37,7 +37,10 @@ def _setup(z_dims, p, binary, n, seed):
                                   # the row-tile-chain kernels (fit_chain.h): B = 16 / 32 at p in (96, 112] or (192, 208]
                                   dict(z_dims=[2, 2, 2, 6], p=100, binary=True, n=300, B=16),
                                   dict(z_dims=[1, 2, 3, 4], p=105, binary=False, n=300, B=32),
-                                  dict(z_dims=[1, 1, 1, 7], p=45, binary=False, n=300, B=32)])     # 13-tile kernels, masked columns
+                                  dict(z_dims=[1, 1, 1, 7], p=45, binary=False, n=300, B=32),      # 13-tile kernels, masked columns
+                                  # two latent input tiles (16 < q <= 19, the widest latent of the deterministic engine's sampling kernels)
+                                  dict(z_dims=[3, 3, 6, 6], p=150, binary=True, n=300, B=32),
+                                  dict(z_dims=[5, 5, 5, 4], p=60, binary=False, n=300, B=32)])
 def test_theta_gradients_and_z_gradient_match_oracle(case):
     import torch
     m, x, y, v, z = _setup(case["z_dims"], case["p"], case["binary"], case["n"], 7)
