@@ -374,6 +374,25 @@ def test_model_surface_with_bayesian_nets(tmp_path, binary):
     assert model.last_q_sd.shape == (2,) and np.all(np.abs(model.last_q_sd[:, None] - allowed[None, :]).min(axis=1) < 1e-5)
 
 
+def test_semi_acic_configuration_through_the_class(tmp_path):
+    """The reference's Semi_acic.yaml shape (binary treatment, z_dims [3, 6, 3, 6], v_dim 177, use_bnn): warm start, iterative
+    updates and predict through the class surface; with 16 < q <= 32 the training steps run the two-latent-tile row chains."""
+    from bayesgm_amd.models import CausalBGM
+    from bayesgm_amd.datasets import Sim_Hirano_Imbens_sampler
+    x, y, v = Sim_Hirano_Imbens_sampler(N=320, v_dim=177, seed=1).load_all()
+    x = (x > np.median(x)).astype(np.float32)
+    params = _params(tmp_path, True, p=177)
+    params["z_dims"] = [3, 6, 3, 6]
+    model = CausalBGM(params, random_seed=5)
+    _, mx0, my0, mv0 = model.evaluate((x, y, v))
+    model.fit((x, y, v), epochs=3, epochs_per_eval=3, batch_size=32, use_egm_init=True, egm_n_iter=30, egm_batches_per_eval=30, verbose=0)
+    assert model.data_z.shape == (320, 18) and torch.isfinite(model.data_z).all()
+    _, mx1, my1, mv1 = model.evaluate((x, y, v), data_z=model.data_z.cpu().numpy())
+    assert np.isfinite([mx1, my1, mv1]).all() and mv1 < mv0
+    ite, interval = model.predict((x, y, v), alpha=0.05, n_mcmc=30, burn_in=30, q_sd=0.5, bs=160, verbose=0)
+    assert ite.shape == (320,) and interval.shape == (320, 2) and np.isfinite(ite).all() and np.all(interval[:, 0] <= interval[:, 1])
+
+
 def test_two_rank_fit_and_predict_with_bayesian_nets():
     """Data-parallel paths of the Bayesian model executed for real (two ranks on this GPU over gloo): identical networks on
     both ranks after EGM + fit; the block-sharded predict equals the single-process predict of the same seeded model."""
