@@ -23,6 +23,7 @@ struct BnsPlan {
   long long set_f = 0;           // ... of the outcome net alone
   long long set_all = 0;         // ... [e | g | h | f] (evaluation)
   int lds_bytes = 0;
+  int eff_lds_bytes = 0;       // effects kernel: + the second perturbation buffer of its pipelined dose loop
 };
 
 // fragment plan of the session's nets; false when a shape is outside the kernels' limits
@@ -53,7 +54,17 @@ static bool bns_plan(const BnnState *s, BnsPlan &pl) {
   pl.set_f = pl.net[BNN_F].foff[pl.net[BNN_F].n_layers];
   (void)maxfrag;
   pl.lds_bytes = (int)sizeof(float) * (2 * BNS_MAXK + BNS_MAXB + BNS_WAVES * BNS_R * 16 * BNS_SW + 2 * BNS_CHUNK * 256);
+  pl.eff_lds_bytes = pl.lds_bytes + (int)sizeof(float) * BNS_CHUNK * 256;
   return true;
+}
+
+// effects kernel: the pipelined dose loop when the outcome net's shape allows it (bns_eff_fast_ok), else the generic routine
+static auto bns_eff_kernel(const BnsEffArgs &ea) -> void (*)(BnsEffArgs) {
+  return bns_eff_fast_ok(ea.f) ? bns_effects_kernel<true> : bns_effects_kernel<false>;
+}
+static int bns_set_lds_eff(const BnsPlan &pl) {
+  int rc = bns_set_lds(bns_effects_kernel<true>, pl.eff_lds_bytes);
+  return rc ? rc : bns_set_lds(bns_effects_kernel<false>, pl.eff_lds_bytes);
 }
 
 // Device scratch of the sampling side: [lf | sf | zprop | dw sets | stats (doubles) | xstats (doubles)], grown on demand.
@@ -175,7 +186,7 @@ extern "C" int bgm_bnn_mh_run(bgm_handle *h, const bgm_bnn_mh_args *g, void *str
   if (rc) return rc;
   rc = bns_set_lds(bns_mh_kernel, pl.lds_bytes);
   if (rc) return rc;
-  rc = bns_set_lds(bns_effects_kernel, pl.lds_bytes);
+  rc = bns_set_lds_eff(pl);
   if (rc) return rc;
   float *dw_eff = b.dw + 2LL * n_blocks * pl.set_ghf;
   BnsEffArgs ea{};
@@ -203,7 +214,7 @@ extern "C" int bgm_bnn_mh_run(bgm_handle *h, const bgm_bnn_mh_args *g, void *str
     ea.sum_out = g->effect == 1 ? g->adrf_sum_dev + d : nullptr; ea.sum_stride = g->n_keep;
     ea.ite_out = g->effect == 2 ? g->ite_dev + d : nullptr; ea.ite_stride = g->n_keep;
     ea.n_items = n_blocks * ea.wg_per_block;
-    hipLaunchKernelGGL(bns_effects_kernel, dim3((ea.n_items + 7) & ~7), dim3(BNS_THREADS), pl.lds_bytes, stream, ea);
+    hipLaunchKernelGGL(bns_eff_kernel(ea), dim3((ea.n_items + 7) & ~7), dim3(BNS_THREADS), pl.eff_lds_bytes, stream, ea);
   };
   auto kept = [&](int it) { return g->effect && it >= g->burn_in && it - g->burn_in < g->n_keep; };
   const int ids[3] = {BNN_G, BNN_H, BNN_F};
@@ -286,7 +297,7 @@ extern "C" int bgm_bnn_evaluate(bgm_handle *h, const float *x, const float *y, c
   if (rc) return rc;
   rc = bns_set_lds(bns_eval_kernel, pl.lds_bytes);
   if (rc) return rc;
-  rc = bns_set_lds(bns_effects_kernel, pl.lds_bytes);
+  rc = bns_set_lds_eff(pl);
   if (rc) return rc;
   const int ids[4] = {BNN_G, BNN_H, BNN_F, BNN_E};
   bns_noise(pl, b, ids, 4, 1, 1, pl.set_all, seed, stream_id, 0, 0, stream);
@@ -334,7 +345,7 @@ extern "C" int bgm_bnn_evaluate(bgm_handle *h, const float *x, const float *y, c
     ea.n_doses = nd; ea.xvals = dose_sums ? x_values : b.pair; ea.k0 = ev.k0; ea.k1 = ev.k1; ea.stream0 = stream_id + 1u;
     ea.sample_y = 0; ea.sum_out = dose_sums; ea.sum_stride = 1; ea.ite_out = dose_sums ? nullptr : ite; ea.ite_stride = 1;
     ea.n_items = wgs;
-    hipLaunchKernelGGL(bns_effects_kernel, dim3((wgs + 7) & ~7), dim3(BNS_THREADS), pl.lds_bytes, stream, ea);
+    hipLaunchKernelGGL(bns_eff_kernel(ea), dim3((wgs + 7) & ~7), dim3(BNS_THREADS), pl.eff_lds_bytes, stream, ea);
   }
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
@@ -356,7 +367,7 @@ extern "C" int bgm_bnn_effects(bgm_handle *h, const float *draws, int64_t n, int
   BnsBuf b;
   rc = bns_buffers(h, s, pl, n, n_blocks, (long long)n_blocks * nd * pl.set_f, b, stream);
   if (rc) return rc;
-  rc = bns_set_lds(bns_effects_kernel, pl.lds_bytes);
+  rc = bns_set_lds_eff(pl);
   if (rc) return rc;
   if (effect == 2) {
     static const float pair_host[2] = {1.0f, 0.0f};
@@ -385,7 +396,7 @@ extern "C" int bgm_bnn_effects(bgm_handle *h, const float *draws, int64_t n, int
     ea.sum_out = effect == 1 ? adrf_sum + d : nullptr; ea.sum_stride = n_keep;
     ea.ite_out = effect == 2 ? ite + d : nullptr; ea.ite_stride = n_keep;
     ea.n_items = n_blocks * ea.wg_per_block;
-    hipLaunchKernelGGL(bns_effects_kernel, dim3((ea.n_items + 7) & ~7), dim3(BNS_THREADS), pl.lds_bytes, stream, ea);
+    hipLaunchKernelGGL(bns_eff_kernel(ea), dim3((ea.n_items + 7) & ~7), dim3(BNS_THREADS), pl.eff_lds_bytes, stream, ea);
   }
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;

@@ -653,6 +653,113 @@ struct BnsEffArgs {
   unsigned long long *prof;                // -D BNS_PROF
 };
 #define BNS_EFF_DOSES 256
+
+// ---- pipelined dose loop of the effects kernel -------------------------------------------------
+// Over the doses of one kept draw only the perturbation set and the sign words change: the input normalisation (the treatment
+// column normalises to beta whatever the dose), the biases, the packed loc fragments and the rows' inputs are the same.  They
+// are set up once per workgroup; per dose the next set's fragments (16 KB) are requested before the current dose is computed and
+// stored behind it into the other half of a double buffer, the next dose's sign words are drawn into the other half of the sign
+// buffer, and ONE barrier separates two doses (three, and a full prologue, in the generic routine).  Arithmetic and its order
+// are those of bns_forward: identical results.
+// Requirements (else the generic loop runs): the outcome net's input fits one k-tile, its fragments one chunk, its sign words
+// half a row of the sign buffer.
+__host__ __device__ inline bool bns_eff_fast_ok(const BnsNet &n) {
+  return BNS_R == 1 && n.T[0] == 1 && n.n_layers >= 2 && n.foff[n.n_layers] <= BNS_CHUNK * 256 && n.swords <= BNS_SW / 2;
+}
+// one Flipout forward of the staged net for this wave's 16 rows: LF / DF = loc / perturbation fragments of the whole net in LDS,
+// sgr = this lane's row of sign words, hb0 = the normalised input (k-tile 0).  epi(mt, y) receives the last layer's tiles.
+template <class Epi>
+__device__ __forceinline__ void bns_eff_net(const BnsCtx &c, const BnsNet &n, const f32x4 *LFn, const f32x4 *DFn, const uint32_t *sgr,
+                                            const float (&hb0)[4], Epi epi) {
+  const int L = n.n_layers, g = c.g, lane = c.lane;
+  float h[BNS_MAXT][4];
+  int bias_off = 0;
+  for (int l = 0; l < L; ++l) {
+    const int T = n.T[l], MT = n.MT[l];
+    const f32x4 *LF = LFn + (n.foff[l] >> 2), *DF = DFn + (n.foff[l] >> 2);
+    const f32x4 *BL = (const f32x4 *)(c.bn + 2 * BNS_MAXK + bias_off);
+    bias_off += 16 * MT;
+    if (l == 0) {
+      f32x4 a1[BNS_MAXT], a2[BNS_MAXT];
+#pragma unroll
+      for (int mt = 0; mt < BNS_MAXT; ++mt) { a1[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; a2[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      float hs[4];
+      {
+        const uint32_t w = sgr[n.sin_w[0]];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hs[r] = bns_flip(hb0[r], w, 4 * g + r);
+      }
+#pragma unroll
+      for (int mt = 0; mt < BNS_MAXT; ++mt)
+        if (mt < MT) {
+          const f32x4 fa = LF[mt * 64 + lane], fd = DF[mt * 64 + lane];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            a1[mt] = BGM_MFMA(fa[r], hb0[r], a1[mt]);
+            a2[mt] = BGM_MFMA(fd[r], hs[r], a2[mt]);
+          }
+        }
+#pragma unroll
+      for (int mt = 0; mt < BNS_MAXT; ++mt) {
+        const f32x4 b = (mt < MT) ? BL[4 * mt + g] : f32x4{0.f, 0.f, 0.f, 0.f};
+        const uint32_t w = (mt < MT) ? sgr[n.sout_w[0] + (mt >> 1)] : 0u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float y = a1[mt][r] + b[r] + bns_flip(a2[mt][r], w, ((mt & 1) << 4) + 4 * g + r);
+          h[mt][r] = (mt < MT) ? lrelu_s(y) : 0.0f;
+        }
+      }
+    } else {
+      float hs[BNS_MAXT][4];
+#pragma unroll
+      for (int t = 0; t < BNS_MAXT; ++t) {
+        const uint32_t w = (t < T) ? sgr[n.sin_w[l] + (t >> 1)] : 0u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hs[t][r] = bns_flip(h[t][r], w, ((t & 1) << 4) + 4 * g + r);
+      }
+      const bool last = (l == L - 1);
+      auto tile = [&](int mt, f32x4 &y) {
+        f32x4 a1 = f32x4{0.f, 0.f, 0.f, 0.f}, a2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < BNS_MAXT; ++t)
+          if (t < T) {
+            const f32x4 fa = LF[(mt * T + t) * 64 + lane], fd = DF[(mt * T + t) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              a1 = BGM_MFMA(fa[r], h[t][r], a1);
+              a2 = BGM_MFMA(fd[r], hs[t][r], a2);
+            }
+          }
+        const f32x4 b = BL[4 * mt + g];
+        const uint32_t w = sgr[n.sout_w[l] + (mt >> 1)];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[r] = a1[r] + b[r] + bns_flip(a2[r], w, ((mt & 1) << 4) + 4 * g + r);
+      };
+      if (!last) {
+        float hn[BNS_MAXT][4];
+#pragma unroll
+        for (int mt = 0; mt < BNS_MAXT; ++mt) {
+          f32x4 y;
+          if (mt < MT) tile(mt, y);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hn[mt][r] = (mt < MT) ? lrelu_s(y[r]) : 0.0f;
+        }
+#pragma unroll
+        for (int t = 0; t < BNS_MAXT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[t][r] = hn[t][r];
+      } else {
+        for (int mt = 0; mt < MT; ++mt) {
+          f32x4 y;
+          tile(mt, y);
+          epi(mt, y);
+        }
+      }
+    }
+  }
+}
+// FAST: the pipelined dose loop (host: bns_eff_fast_ok(a.f)); otherwise one generic bns_forward per dose
+template <bool FAST>
 static __global__ __launch_bounds__(BNS_THREADS, 4) void bns_effects_kernel(BnsEffArgs a) {
   extern __shared__ __attribute__((aligned(16))) float bns_lds[];
   __shared__ float dose_tot[BNS_WAVES][BNS_EFF_DOSES];
@@ -684,6 +791,117 @@ static __global__ __launch_bounds__(BNS_THREADS, 4) void bns_effects_kernel(BnsE
 #endif
   float y0[BNS_R];
   f32x4 nz[BNS_R];
+  if constexpr (FAST) {
+    const BnsNet &n = a.f;
+    const int L = n.n_layers, j = c.j, lane = c.lane;
+    const float *gamma = a.theta + n.goff, *beta = gamma + n.K[0];
+    // ---- once per workgroup: scale / shift of the latent columns, scale and beta of the treatment column, biases, loc fragments
+    for (int u = c.tid; u < 16; u += BNS_THREADS) {
+      float sc = 0.0f, sh = 0.0f;
+      if (u < n.K[0]) {
+        float mean = 0.0f, var = 1.0f;
+        if (!n.bn_fixed) { if (u < zz) bns_stat(st, u, cnt, mean, var); else var = 0.0f; }
+        sc = gamma[u] / sqrtf(var + BNN_BN_EPS);
+        sh = u < zz ? beta[u] - mean * sc : beta[u];      // treatment column: the dose enters below (mean = dose)
+      }
+      c.bn[u] = sc; c.bn[BNS_MAXK + u] = sh;
+    }
+    {
+      int bo = 0;
+      for (int l = 0; l < L; ++l) {
+        const float *bias = a.theta + n.woff[l] + 2 * n.K[l] * n.K[l + 1];
+        const int M = n.K[l + 1];
+        for (int o = c.tid; o < 16 * n.MT[l]; o += BNS_THREADS) c.bn[2 * BNS_MAXK + bo + o] = bias[min(o, M - 1)] * (o < M ? 1.0f : 0.0f);
+        bo += 16 * n.MT[l];
+      }
+    }
+    const int cnt4 = n.foff[L] >> 2;
+    constexpr int PF = (BNS_CHUNK * 64 + BNS_THREADS - 1) / BNS_THREADS;
+    f32x4 *locs = (f32x4 *)c.stage, *dwb0 = locs + BNS_CHUNK * 64, *dwb1 = dwb0 + BNS_CHUNK * 64;
+    {
+      const f32x4 *s1 = (const f32x4 *)(a.lf + n.fbase);
+#pragma unroll
+      for (int u = 0; u < PF; ++u) { const int i = c.tid + u * BNS_THREADS; if (i < cnt4) locs[i] = s1[i]; }
+    }
+    const int calls = n.swords >> 2;
+    const uint32_t srow = (uint32_t)(rib0 + (c.wave << 4) + j);
+    uint32_t *sgrow = c.sg + ((c.wave << 4) + j) * BNS_SW;
+    auto signs = [&](int k, int b) {
+      for (int cc = g; cc < calls; cc += 4) {
+        const uint4 w = philox4x32_10(srow, (uint32_t)cc | ((uint32_t)n.net_id << 16), a.stream0 + (uint32_t)k, BNN_TAG_SIGN, a.k0, k1);
+        uint32_t *dst = sgrow + b * (BNS_SW / 2) + 4 * cc;
+        dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
+      }
+    };
+    auto dwset = [&](int k) { return (const f32x4 *)(a.dw + ((long long)blk * a.n_doses + k) * a.set_floats); };
+    float zraw[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zraw[r] = a.z[row[0] * q + min(4 * g + r, q - 1)];
+    signs(0, 0);
+    {
+      const f32x4 *s2 = dwset(0);
+#pragma unroll
+      for (int u = 0; u < PF; ++u) { const int i = c.tid + u * BNS_THREADS; if (i < cnt4) dwb0[i] = s2[i]; }
+    }
+    __syncthreads();
+    float hbz[4], scx = 0.0f, bex = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int u = 4 * g + r;
+      hbz[r] = fmaf(zraw[r], c.bn[u], c.bn[BNS_MAXK + u]);
+    }
+    scx = c.bn[min(zz, 15)]; bex = c.bn[BNS_MAXK + min(zz, 15)];
+    BNS_T(c, 0);
+    for (int k = 0; k < a.n_doses; ++k) {
+      const int b = k & 1;
+      const bool more = k + 1 < a.n_doses;
+      const float xv = a.xvals[k];
+      f32x4 nx[PF];
+      if (more) {
+        const f32x4 *s2 = dwset(k + 1);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) nx[u] = s2[min(c.tid + u * BNS_THREADS, cnt4 - 1)];
+        signs(k + 1, b ^ 1);
+      }
+      if (a.sample_y && (k & 3) == 0)
+        nz[0] = box_muller4(philox4x32_10((uint32_t)(a.row_base + row[0]), a.it_noise, (uint32_t)(k >> 2), TAG_YNOISE, a.k0, a.k1));
+      BNS_T(c, 0);
+      float hb0[4];
+      const float shx = n.bn_fixed ? bex : bex - xv * scx;      // shift of the treatment column for this dose (batch statistics: mean = dose, variance = 0)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hb0[r] = (4 * g + r == zz) ? fmaf(xv, scx, shx) : hbz[r];
+      float mu = 0.0f, raw = 0.0f;
+      bns_eff_net(c, n, locs, b ? dwb1 : dwb0, sgrow + b * (BNS_SW / 2), hb0,
+                  [&](int mt, const f32x4 &y) { if (mt == 0 && g == 0) { mu += y[0]; raw += y[1]; } });
+      BNS_T(c, 3);
+      float yk = sum_over_g(mu);
+      if (a.sample_y) {
+        const float s2 = softplus_acc(sum_over_g(raw)) + BGM_EPS;
+        const int e = k & 3;
+        yk = fmaf(sqrtf(s2), e == 0 ? nz[0][0] : e == 1 ? nz[0][1] : e == 2 ? nz[0][2] : nz[0][3], yk);
+      }
+      float tot = (valid[0] && g == 0) ? yk : 0.0f;
+      if (a.ite_out) {
+        if (k == 0) y0[0] = yk;
+        else if (k == 1 && valid[0] && g == 0) a.ite_out[row[0] * a.ite_stride] = y0[0] - yk;
+      }
+      if (a.sum_out) {
+        for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+        if (lane == 0) {
+          if (k < BNS_EFF_DOSES) dose_tot[c.wave][k] = tot;
+          else atomicAdd(&a.sum_out[(long long)k * a.sum_stride], (double)tot);
+        }
+      }
+      BNS_T(c, 5);
+      if (more) {
+        f32x4 *d = b ? dwb0 : dwb1;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) { const int i = c.tid + u * BNS_THREADS; if (i < cnt4) d[i] = nx[u]; }
+      }
+      __syncthreads();
+      BNS_T(c, 1);
+    }
+  } else
   for (int k = 0; k < a.n_doses; ++k) {
     const float xv = a.xvals[k];
     if (a.sample_y && (k & 3) == 0) {
