@@ -60,11 +60,12 @@ static bool bns_plan(const BnnState *s, BnsPlan &pl) {
 
 // effects kernel: the pipelined dose loop when the outcome net's shape allows it (bns_eff_fast_ok), else the generic routine
 static auto bns_eff_kernel(const BnsEffArgs &ea) -> void (*)(BnsEffArgs) {
-  return bns_eff_fast_ok(ea.f) ? bns_effects_kernel<true> : bns_effects_kernel<false>;
+  return bns_eff_default_ok(ea.f) ? bns_effects_kernel<2> : bns_eff_fast_ok(ea.f) ? bns_effects_kernel<1> : bns_effects_kernel<0>;
 }
 static int bns_set_lds_eff(const BnsPlan &pl) {
-  int rc = bns_set_lds(bns_effects_kernel<true>, pl.eff_lds_bytes);
-  return rc ? rc : bns_set_lds(bns_effects_kernel<false>, pl.eff_lds_bytes);
+  int rc = bns_set_lds(bns_effects_kernel<2>, pl.eff_lds_bytes);
+  if (!rc) rc = bns_set_lds(bns_effects_kernel<1>, pl.eff_lds_bytes);
+  return rc ? rc : bns_set_lds(bns_effects_kernel<0>, pl.eff_lds_bytes);
 }
 
 // Device scratch of the sampling side: [lf | sf | zprop | dw sets | stats (doubles) | xstats (doubles)], grown on demand.

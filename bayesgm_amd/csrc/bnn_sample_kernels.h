@@ -758,8 +758,67 @@ __device__ __forceinline__ void bns_eff_net(const BnsCtx &c, const BnsNet &n, co
     }
   }
 }
-// FAST: the pipelined dose loop (host: bns_eff_fast_ok(a.f)); otherwise one generic bns_forward per dose
-template <bool FAST>
+// The default outcome net [in <= 16] -> 64 -> 32 -> 8 -> [out <= 16] with every extent a compile-time constant: straight-line code, sign
+// flips and epilogues only for the tiles that exist (the run-time-shaped routine above spends 6.5 VALU instructions per MFMA here)
+__host__ __device__ inline bool bns_eff_default_ok(const BnsNet &n) {
+  return bns_eff_fast_ok(n) && n.n_layers == 4 && n.MT[0] == 4 && n.MT[1] == 2 && n.MT[2] == 1 && n.MT[3] == 1;
+}
+template <int KT, int NT>
+__device__ __forceinline__ void bns_eff_layer(const f32x4 *LF, const f32x4 *DF, const f32x4 *BL, const uint32_t *sgr, int sin_w, int sout_w, int lane,
+                                              int g, const float (&h)[KT][4], float (&y)[NT][4]) {
+  float hs[KT][4];
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    const uint32_t w = sgr[sin_w + (t >> 1)];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hs[t][r] = bns_flip(h[t][r], w, ((t & 1) << 4) + 4 * g + r);
+  }
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt) {
+    f32x4 a1 = f32x4{0.f, 0.f, 0.f, 0.f}, a2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      const f32x4 fa = LF[(mt * KT + t) * 64 + lane], fd = DF[(mt * KT + t) * 64 + lane];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        a1 = BGM_MFMA(fa[r], h[t][r], a1);
+        a2 = BGM_MFMA(fd[r], hs[t][r], a2);
+      }
+    }
+    const f32x4 b = BL[4 * mt + g];
+    const uint32_t w = sgr[sout_w + (mt >> 1)];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[mt][r] = a1[r] + b[r] + bns_flip(a2[r], w, ((mt & 1) << 4) + 4 * g + r);
+  }
+}
+template <int NT>
+__device__ __forceinline__ void bns_eff_act(float (&y)[NT][4]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[t][r] = lrelu_s(y[t][r]);
+}
+template <int T1, int T2, int T3, class Epi>
+__device__ __forceinline__ void bns_eff_net4(const BnsCtx &c, const BnsNet &n, const f32x4 *LFn, const f32x4 *DFn, const uint32_t *sgr,
+                                             const float (&hb0)[4], Epi epi) {
+  const int g = c.g, lane = c.lane;
+  const f32x4 *BL = (const f32x4 *)(c.bn + 2 * BNS_MAXK);
+  float h0[1][4], h1[T1][4], h2[T2][4], h3[T3][4], y[1][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) h0[0][r] = hb0[r];
+  bns_eff_layer<1, T1>(LFn + (n.foff[0] >> 2), DFn + (n.foff[0] >> 2), BL, sgr, n.sin_w[0], n.sout_w[0], lane, g, h0, h1);
+  bns_eff_act<T1>(h1);
+  bns_eff_layer<T1, T2>(LFn + (n.foff[1] >> 2), DFn + (n.foff[1] >> 2), BL + 4 * T1, sgr, n.sin_w[1], n.sout_w[1], lane, g, h1, h2);
+  bns_eff_act<T2>(h2);
+  bns_eff_layer<T2, T3>(LFn + (n.foff[2] >> 2), DFn + (n.foff[2] >> 2), BL + 4 * (T1 + T2), sgr, n.sin_w[2], n.sout_w[2], lane, g, h2, h3);
+  bns_eff_act<T3>(h3);
+  bns_eff_layer<T3, 1>(LFn + (n.foff[3] >> 2), DFn + (n.foff[3] >> 2), BL + 4 * (T1 + T2 + T3), sgr, n.sin_w[3], n.sout_w[3], lane, g, h3, y);
+  epi(0, f32x4{y[0][0], y[0][1], y[0][2], y[0][3]});
+}
+
+// FAST 1: the pipelined dose loop (host: bns_eff_fast_ok(a.f)); 2: the same with the default outcome net's compile-time shape
+// (bns_eff_default_ok); 0: one generic bns_forward per dose
+template <int FAST>
 static __global__ __launch_bounds__(BNS_THREADS, 4) void bns_effects_kernel(BnsEffArgs a) {
   extern __shared__ __attribute__((aligned(16))) float bns_lds[];
   __shared__ float dose_tot[BNS_WAVES][BNS_EFF_DOSES];
@@ -791,7 +850,7 @@ static __global__ __launch_bounds__(BNS_THREADS, 4) void bns_effects_kernel(BnsE
 #endif
   float y0[BNS_R];
   f32x4 nz[BNS_R];
-  if constexpr (FAST) {
+  if constexpr (FAST != 0) {
     const BnsNet &n = a.f;
     const int L = n.n_layers, j = c.j, lane = c.lane;
     const float *gamma = a.theta + n.goff, *beta = gamma + n.K[0];
@@ -871,8 +930,9 @@ static __global__ __launch_bounds__(BNS_THREADS, 4) void bns_effects_kernel(BnsE
 #pragma unroll
       for (int r = 0; r < 4; ++r) hb0[r] = (4 * g + r == zz) ? fmaf(xv, scx, shx) : hbz[r];
       float mu = 0.0f, raw = 0.0f;
-      bns_eff_net(c, n, locs, b ? dwb1 : dwb0, sgrow + b * (BNS_SW / 2), hb0,
-                  [&](int mt, const f32x4 &y) { if (mt == 0 && g == 0) { mu += y[0]; raw += y[1]; } });
+      auto out = [&](int mt, const f32x4 &y) { if (mt == 0 && g == 0) { mu += y[0]; raw += y[1]; } };
+      if constexpr (FAST == 2) bns_eff_net4<4, 2, 1>(c, n, locs, b ? dwb1 : dwb0, sgrow + b * (BNS_SW / 2), hb0, out);
+      else bns_eff_net(c, n, locs, b ? dwb1 : dwb0, sgrow + b * (BNS_SW / 2), hb0, out);
       BNS_T(c, 3);
       float yk = sum_over_g(mu);
       if (a.sample_y) {

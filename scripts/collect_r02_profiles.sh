@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 rocprofv3 evidence, run on the GPU box from the repo root (gpurun): kernel traces and PMC passes of the SHIPPED kernels.
 # Counters in their own runs (no trace domains besides --kernel-trace), as MI355X_MICROARCH.md prescribes: SQ set | FETCH_SIZE | WRITE_SIZE.
-# usage: bash scripts/collect_r02_profiles.sh [what ...]   what in: bench mh encode hmc fit egm bnn   (default: all)
+# usage: bash scripts/collect_r02_profiles.sh [what ...]   what in: bench mh encode hmc fit egm bnn bnnmh   (default: all)
 set -u
 OUT=gpurun_out/r02prof
 mkdir -p $OUT
@@ -31,6 +31,10 @@ for w in $WHAT; do
     fit) pmc3 fit_B65536 python scripts/probe_fit.py 1e6 65536 dense 20 ;;
     egm) pmc3 egm_chain python scripts/probe_egm_native.py 200 200 ;;
     bnn) pmc3 bnn_chain env BNN_PROBE_SKIP_MH=1 python scripts/probe_bnn.py 20000 200 5 ;;
+    bnnmh)   # sampling side of the Bayesian networks at the north-star panel size: MH iterations (burn-in, kept with 20 doses)
+      timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/kt_bnnmh -o kt -- env BNN_PROBE_SAMPLING_ONLY=1 python scripts/probe_bnn.py 1000000 200 10 > $OUT/kt_bnnmh.log 2>&1
+      { echo "# rocprofv3 --kernel-trace --stats -- env BNN_PROBE_SAMPLING_ONLY=1 python scripts/probe_bnn.py 1000000 200 10"; grep -E "^MH|^predict" $OUT/kt_bnnmh.log | sed 's/^/# /'; summ $OUT/kt_bnnmh; } > $OUT/r02_kernel_trace_bnn_sampling_N1e6.txt
+      pmc3 bnn_sampling_N1e6 env BNN_PROBE_SAMPLING_ONLY=1 python scripts/probe_bnn.py 1000000 200 5 ;;
   esac
 done
 ls -la $OUT | head -40

@@ -45,6 +45,8 @@ adrf = torch.zeros(20, iters, device=dev, dtype=torch.float64)
 t2 = timed(lambda: eng.mh_run(x, y, v, state, bs, 100, iters, 100, 1.0, 1, n_keep=iters, effect=1, x_values=xs, adrf_sum=adrf))
 print("MH (keep, 20 doses): %.2f ms / iteration" % (1e3 * t2 / iters))
 print("predict(burn_in=5000, n_mcmc=3000) estimate: %.1f s" % (5000 * t / iters + 3000 * t2 / iters))
+if __import__("os").environ.get("BNN_PROBE_SAMPLING_ONLY"):
+    sys.exit(0)
 # minibatch steps
 n = 20000
 idx = torch.randperm(n, device=dev)[:32].int()
