@@ -95,7 +95,7 @@ static int fit_chain_setup(bgm_handle *h, const std::vector<float> &theta) {
   BGM_HIP_CHECK(hipMemcpy(c->tiles, tiles.data(), sizeof(int) * tiles.size(), hipMemcpyHostToDevice));
   BGM_HIP_CHECK(hipMalloc((void **)&c->mirror_dst, sizeof(int) * np));
   BGM_HIP_CHECK(hipMemcpy(c->mirror_dst, mdst.data(), sizeof(int) * np, hipMemcpyHostToDevice));
-  a.theta = h->theta_dev; a.thetaT = c->thetaT; a.ws = c->ws; a.tiles = c->tiles;
+  a.theta = h->theta_dev; a.thetaT = c->thetaT; a.ws = c->ws; a.tiles = c->tiles; a.n_warm = np;
   a.q = q; a.p = p; a.z0 = h->cfg.z_dims[0]; a.z1 = h->cfg.z_dims[1]; a.z2 = h->cfg.z_dims[2];
   a.binary = h->cfg.binary_treatment;
   a.sig2_v = h->meta.sig2_v; a.sig2_x = h->meta.sig2_x; a.sig2_y = h->meta.sig2_y;

@@ -27,6 +27,7 @@ struct FitChainArgs {
   float inv_B;
   double *loss;                   // [7] accumulators or NULL
   float *dz;                      // latent phase: [B x q]
+  int n_warm;                     // floats of theta (= of the transposed mirror) the idle wave pair pulls into this XCD's L2
 };
 
 __device__ __forceinline__ long long fitc_row(const FitChainArgs &a, int b) { return a.idx ? (long long)a.idx[b] : a.row_lo + b; }
@@ -134,6 +135,21 @@ static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_kernel(FitChainA
       ecg_head_bwd<T1, T2, T3>(tT, N, a.xo[role], a.dofs[role], ws, row, d, dx, j, g);
       if (Z_MODE == 1) *reinterpret_cast<f32x4 *>(dzc + (role * 32 + row) * ZW + 4 * g) = dx[0];
     }
+  }
+  if (role == 3) {
+    // waves 6,7: Adam rewrote theta and its mirror from other CUs since the last launch, so the chains' first touch of every weight
+    // tile would be a serial trip to memory; stream both arrays through this XCD's L2 while the chains start (wave 6 the forward
+    // array, wave 7 the mirror the backward sweeps read)
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(tile == 0 ? th : tT);
+    const int n4 = a.n_warm >> 2;
+    float sink = 0.0f;
+    for (int i = lane; i < n4; i += 64 * 16) {
+      f32x4 acc4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc4 += src[min(i + 64 * k, n4 - 1)];
+      sink += acc4[0] + acc4[1] + acc4[2] + acc4[3];
+    }
+    asm volatile("" ::"v"(sink));
   }
   {   // per-wave sums in double (the accumulators are doubles)
     const float s0 = sum_over_j_to_lane15(l0), s1 = sum_over_j_to_lane15(l1), s2_ = sum_over_j_to_lane15(l2);
