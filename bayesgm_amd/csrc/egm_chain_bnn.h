@@ -765,6 +765,24 @@ __device__ __forceinline__ float ecb_pick(const f32x4 (&x)[NT], int f, int g) {
     for (int r = 0; r < 4; ++r) v += (16 * t + 4 * g + r == f) ? x[t][r] : 0.0f;
   return sum_over_g(v);
 }
+// the data row of a minibatch row as NTL register tiles (zero beyond p), requested up front: a random row of the panel is a trip to HBM,
+// and loaded where the likelihood consumes it that latency sits on the chain's critical path
+template <int NTL>
+__device__ __forceinline__ void ecb_load_row(const float *vrow, int p, int g, f32x4 (&vv)[NTL]) {
+  if ((p & 3) == 0 && (reinterpret_cast<unsigned long long>(vrow) & 15ull) == 0) {      // one 16-byte request per tile and lane
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+      const int f = 16 * t + 4 * g;
+      const f32x4 x_ = *reinterpret_cast<const f32x4 *>(vrow + min(f, p - 4));
+      vv[t] = f < p ? x_ : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vv[t][r] = ech_ld(vrow, 16 * t + 4 * g + r, p);
+  }
+}
 // inputs of the three nets from a row of the latent table
 template <int T0>
 __device__ __forceinline__ void ecb_inputs(const float *zrow, float xv, int q, int z0, int z1, int z2, int g, f32x4 (&zin)[T0], f32x4 (&fin)[1],
@@ -800,16 +818,16 @@ __device__ __forceinline__ void ecb_theta_chain(const Args &a, const EcbTab &tab
     ecb_inputs<T0>(a.data_z + prow * q, xv, q, a.z0, a.z1, a.z2, g, zin, fin, hin);
     if (role == 0) {
       const BnnNet &G = a.net[BNN_G];
-      f32x4 o[NTL];
+      f32x4 o[NTL], vv[NTL];
+      ecb_load_row<NTL>(a.v_ + prow * p, p, g, vv);
       ecb_mlp_fwd<T0, HT, NTL, PAD>(th, G, tab.c[0], ws, row, zin, o, j, g);
-      const float *vrow = a.v_ + prow * p;
       float ssq = 0.0f;
 #pragma unroll
       for (int t = 0; t < NTL; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int f = 16 * t + 4 * g + r;
-          const float d = f < p ? ech_ld(vrow, f, p) - o[t][r] : 0.0f;
+          const float d = f < p ? vv[t][r] - o[t][r] : 0.0f;
           ssq = fmaf(d, d, ssq);
         }
       ssq = sum_over_g(ssq);
@@ -821,7 +839,7 @@ __device__ __forceinline__ void ecb_theta_chain(const Args &a, const EcbTab &tab
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int f = 16 * t + 4 * g + r;
-          o[t][r] = f < p ? -(ech_ld(vrow, f, p) - o[t][r]) / s2 * a.inv_B : (f == p ? dr * a.inv_B : 0.0f);
+          o[t][r] = f < p ? -(vv[t][r] - o[t][r]) / s2 * a.inv_B : (f == p ? dr * a.inv_B : 0.0f);
         }
       ls0 = lb; ls1 = ssq;
       f32x4 dnone[T0];
@@ -970,16 +988,16 @@ __device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, fl
     ech_zero<T0>(dx);
     if (role == 0) {
       const BnnNet &G = a.net[BNN_G];
-      f32x4 o[NTL];
+      f32x4 o[NTL], vv[NTL];
+      ecb_load_row<NTL>(a.v_ + prow * p, p, g, vv);
       ecb_mlp_fwd<T0, HT, NTL, PAD>(th, G, tab.c[0], ws, row, zin, o, j, g);
-      const float *vrow = a.v_ + prow * p;
       float ssq = 0.0f;
 #pragma unroll
       for (int t = 0; t < NTL; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int f = 16 * t + 4 * g + r;
-          const float d = f < p ? ech_ld(vrow, f, p) - o[t][r] : 0.0f;
+          const float d = f < p ? vv[t][r] - o[t][r] : 0.0f;
           ssq = fmaf(d, d, ssq);
           o[t][r] = d;
         }

@@ -22,6 +22,14 @@
 #define ECG_PASS_H 5
 #define ECG_TILE_INTS 16
 
+// -D FITC_CLOCK: cycle stamps of the first wave of fit_chain_kernel along the g chain (dev tool: scripts/probe_fit.py prints them)
+#ifdef FITC_CLOCK
+__device__ unsigned long long g_fitc[64];
+#define FITC_T(k) { if (threadIdx.x == 0) g_fitc[k] = clock64(); }
+#else
+#define FITC_T(k)
+#endif
+
 struct EcgTab {
   int x[6][EGM_MAX_LAYERS], d[6][EGM_MAX_LAYERS];   // workspace offsets (floats) of X_l [B x 16 KT_l] and D_l [B x 16 NT_l] per pass
   const int *tiles;                                 // [n_tiles][ECG_TILE_INTS]: xo0, xo1, do0, do1, xw, dw, u, v, woff, n_in, n_out, boff
@@ -31,10 +39,14 @@ struct EcgTab {
 };
 
 // ---------------------------------------------------------------------------------------------
-// pipelined sub-layer: out (+)= in W[:, col0 : col0 + 16 NT], A fragments two K tiles ahead
+// pipelined sub-layer: out (+)= in W[:, col0 : col0 + 16 NT], A fragments ECG_DEPTH K tiles ahead
 // ---------------------------------------------------------------------------------------------
 struct EcgW { const float *W; int ld, n_in, n_out, col0; };
-template <int NT> struct EcgA { float v[3][4][NT]; };      // v[0], v[1]: K tiles 0, 1 of the sub-layer about to run; v[2]: third buffer
+#ifndef ECG_DEPTH
+#define ECG_DEPTH 2       // K tiles requested ahead of the one being multiplied (ring of ECG_DEPTH + 1 buffers); 3 measured +2 % on the fit
+                          // chains, nothing on the EGM chains, for 32 more registers per fragment set -- the loads are not what the chains wait for
+#endif
+template <int NT> struct EcgA { float v[ECG_DEPTH + 1][4][NT]; };      // v[0 .. DEPTH-1]: the first K tiles of the sub-layer about to run
 
 // CX: the columns col0 .. col0 + 16 NT all exist (no column clamp / mask: one lane base + immediate offsets);  clamp_rows: the K tile
 // may reach beyond n_in (only the last K tile of a layer can).
@@ -77,8 +89,8 @@ __device__ __forceinline__ void ecg_load_tile(const EcgW &w, int t, float (&av)[
 }
 template <int NT, bool CX, bool KC = false>
 __device__ __forceinline__ void ecg_prime(const EcgW &w, EcgA<NT> &A, int j, int g) {
-  ecg_load_tile<NT, CX, KC>(w, 0, A.v[0], j, g, true);
-  ecg_load_tile<NT, CX, KC>(w, 1, A.v[1], j, g, true);       // (a one-tile sub-layer reads a clamped duplicate)
+#pragma unroll
+  for (int k = 0; k < ECG_DEPTH; ++k) ecg_load_tile<NT, CX, KC>(w, k, A.v[k], j, g, true);       // (a short sub-layer reads clamped duplicates)
 }
 // Runs the sub-layer whose first two K tiles are in A and leaves the first two K tiles of the next sub-layer `wn` in An.
 template <int KT, int NT, int NTN, bool CX, bool CXN, bool KC = false, bool KCN = false>
@@ -86,21 +98,22 @@ __device__ __forceinline__ void ecg_sub(const EcgW &w, const f32x4 (&in)[KT], f3
                                         int j, int g) {
 #pragma unroll
   for (int t = 0; t < KT; ++t) {
-    if (t + 2 < KT) ecg_load_tile<NT, CX, KC>(w, t + 2, A.v[(t + 2) % 3], j, g, KT > 4 || t + 2 == KT - 1);
-    if (t == (KT >= 2 ? KT - 2 : 0)) ecg_load_tile<NTN, CXN, KCN>(wn, 0, An.v[0], j, g, true);
-    if (t == KT - 1) ecg_load_tile<NTN, CXN, KCN>(wn, 1, An.v[1], j, g, true);
+    if (t + ECG_DEPTH < KT) ecg_load_tile<NT, CX, KC>(w, t + ECG_DEPTH, A.v[(t + ECG_DEPTH) % (ECG_DEPTH + 1)], j, g, KT > 4 || t + ECG_DEPTH == KT - 1);
+#pragma unroll
+    for (int k = 0; k < ECG_DEPTH; ++k)      // tile k of the next sub-layer takes the request slot this one no longer needs
+      if (t == (KT - ECG_DEPTH + k > 0 ? KT - ECG_DEPTH + k : 0)) ecg_load_tile<NTN, CXN, KCN>(wn, k, An.v[k], j, g, true);
     BGM_NO_HOIST();          // pins the issue order (the scheduler would sink every load to just above its MFMA)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int u = 0; u < NT; ++u) out[u] = BGM_MFMA(A.v[t % 3][r][u], in[t][r], out[u]);
+      for (int u = 0; u < NT; ++u) out[u] = BGM_MFMA(A.v[t % (ECG_DEPTH + 1)][r][u], in[t][r], out[u]);
     BGM_NO_HOIST();
   }
 }
 template <int NT>
 __device__ __forceinline__ void ecg_copy(EcgA<NT> &A, const EcgA<NT> &An) {
 #pragma unroll
-  for (int b = 0; b < 2; ++b)
+  for (int b = 0; b < ECG_DEPTH; ++b)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -202,11 +215,13 @@ __device__ __forceinline__ void ecg_hidden_fwd(const float *theta, const EgmMlp 
     f32x4 h2[HT];
     ech_zero<HT>(h2);
     ecg_sub<HT, HT, HT, true, true>(w, h, h2, A, wn, An, j, g);
+    FITC_T(30 + 2 * l);
     ecg_bias<HT>(w.W + H * H, H, 0, g, h2);
     ecg_lrelu<HT>(h2);
 #pragma unroll
     for (int u = 0; u < HT; ++u) h[u] = h2[u];
     ecg_copy<HT>(A, An);
+    FITC_T(31 + 2 * l);
   }
 }
 // dh: gradient with respect to the OUTPUT of layer L-2 on entry (already masked: D_{L-2}); on exit D_0.  Stashes D_{L-2} .. D_1 (not D_0).
@@ -228,10 +243,12 @@ __device__ __forceinline__ void ecg_hidden_bwd(const float *thetaT, const EgmMlp
     ech_zero<HT>(d2);
     ecg_get<HT>(ws + xo[l], row, g, xl);          // x_l = LeakyReLU output of layer l-1
     ecg_sub<HT, HT, HT, true, true>(w, dh, d2, A, wn, An, j, g);
+    FITC_T(40 + 2 * l);
     ecg_mask<HT>(d2, xl);
 #pragma unroll
     for (int u = 0; u < HT; ++u) dh[u] = d2[u];
     ecg_copy<HT>(A, An);
+    FITC_T(41 + 2 * l);
   }
 }
 
@@ -252,10 +269,13 @@ __device__ __forceinline__ void ecg_g_fwd(const float *theta, const EgmMlp &n, c
     ecg_bias<HT>(w.W + q * H, H, 0, g, h);
     ecg_lrelu<HT>(h);
   }
+  FITC_T(2);
   ecg_hidden_fwd<HT>(theta, n, xo, ws, row, h, j, g);
+  FITC_T(3);
   ecg_put<HT>(ws + xo[L - 1], row, g, h);
   const float *Wl = theta + n.woff[L - 1];
   ecg_wide<HT, NTL, false, PAD>(Wl, no, H, no, h, out, j, g);
+  FITC_T(4);
   ecg_bias<NTL>(Wl + H * no, no, 0, g, out);
 }
 // dout: dLoss/d output (NTL tiles, zero beyond n_out).  dx (WANT_DX): dLoss/d input.
@@ -275,7 +295,9 @@ __device__ __forceinline__ void ecg_g_bwd(const float *thetaT, const EgmMlp &n, 
     ecg_sub<NTL, HT, HT, true, true>(w, dout, dh, A, w, Ad, j, g);
     ecg_mask<HT>(dh, xl);
   }
+  FITC_T(7);
   ecg_hidden_bwd<HT>(thetaT, n, xo, dofs, ws, row, dh, j, g);
+  FITC_T(8);
   ecg_put<HT>(ws + dofs[0], row, g, dh);
   if (WANT_DX) {
     EcgA<T0> A, Ad;

@@ -130,6 +130,21 @@ static void fit_chain_launch(const FitChainState *c, FitChainArgs &a, int batch,
   }
   FC(13, 2) FC(13, 1) FC(7, 2) FC(7, 1)
 #undef FC
+#ifdef FITC_CLOCK
+  {
+    static int calls = 0;
+    if (++calls == 300 || calls == 301) {
+      hipStreamSynchronize(stream);
+      unsigned long long t[64];
+      hipMemcpyFromSymbol(t, HIP_SYMBOL(g_fitc), sizeof(t));
+      fprintf(stderr, "[FITC z_mode=%d] in %llu | L0 %llu | hidden fwd %llu (", z_mode, t[1] - t[0], t[2] - t[1], t[3] - t[2]);
+      for (int l = 1; l <= 4; ++l) fprintf(stderr, "k%llu+e%llu ", t[30 + 2 * l] - (l == 1 ? t[2] : t[31 + 2 * (l - 1)]), t[31 + 2 * l] - t[30 + 2 * l]);
+      fprintf(stderr, ") | last %llu | loss %llu | bwd last %llu | hidden bwd %llu (", t[4] - t[3], t[6] - t[5], t[7] - t[6], t[8] - t[7]);
+      for (int l = 4; l >= 1; --l) fprintf(stderr, "k%llu+e%llu ", t[40 + 2 * l] - (l == 4 ? t[7] : t[41 + 2 * (l + 1)]), t[41 + 2 * l] - t[40 + 2 * l]);
+      fprintf(stderr, ") | tail %llu | end %llu | total %llu\n", t[9] - t[8], t[10] - t[9], t[10] - t[0]);
+    }
+  }
+#endif
 }
 
 static constexpr int FIT_WAVES = 8;

@@ -48,11 +48,29 @@ static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_kernel(FitChainA
   const float *th = a.theta, *tT = a.thetaT;
   float *ws = a.ws;
   float l0 = 0.0f, l1 = 0.0f, l2 = 0.0f;          // this wave's loss terms per row: (nll, sse) of its net; role 0 also 0.5 |z|^2
+  FITC_T(0);
   if (active) {
     const long long prow = fitc_row(a, row);
     const float xv = a.x[prow], yv = a.y[prow];
     const float *zrow = a.data_z + prow * q;
     if (role == 0) {
+      // the data row is requested first (a random row of the panel: a trip to HBM) and consumed by the likelihood after the forward
+      // pass -- loaded there, that latency sat on the chain's critical path (a quarter of the kernel)
+      const float *vrow = a.v + prow * p;
+      f32x4 vv[NTL];
+      if ((p & 3) == 0 && (reinterpret_cast<unsigned long long>(vrow) & 15ull) == 0) {      // one 16-byte request per tile and lane
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+          const int f = 16 * t + 4 * g;
+          const f32x4 x_ = *reinterpret_cast<const f32x4 *>(vrow + min(f, p - 4));
+          vv[t] = f < p ? x_ : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < NTL; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vv[t][r] = ech_ld(vrow, 16 * t + 4 * g + r, p);
+      }
       f32x4 zin[T0], dx[T0];
       ech_zero<T0>(dx);
       float zsq = 0.0f;
@@ -62,15 +80,16 @@ static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_kernel(FitChainA
         for (int r = 0; r < 4; ++r) { zin[t][r] = ech_ld(zrow, 16 * t + 4 * g + r, q); zsq = fmaf(zin[t][r], zin[t][r], zsq); }
       l2 = 0.5f * sum_over_g(zsq);
       f32x4 o[NTL];
+      FITC_T(1);
       ecg_g_fwd<HT, NTL, PAD, T0>(th, a.g, a.xo[0], ws, row, zin, o, j, g);
-      const float *vrow = a.v + prow * p;
+      FITC_T(5);
       float ssq = 0.0f, sraw = 0.0f;
 #pragma unroll
       for (int t = 0; t < NTL; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int f = 16 * t + 4 * g + r;
-          const float d = f < p ? ech_ld(vrow, f, p) - o[t][r] : 0.0f;
+          const float d = f < p ? vv[t][r] - o[t][r] : 0.0f;
           ssq = fmaf(d, d, ssq);
           sraw += f == p ? o[t][r] : 0.0f;
           o[t][r] = d;
@@ -93,7 +112,9 @@ static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_kernel(FitChainA
           const int f = 16 * t + 4 * g + r;
           o[t][r] = f < p ? cmu * o[t][r] : (f == p ? dsraw : 0.0f);
         }
+      FITC_T(6);
       ecg_g_bwd<HT, NTL, Z_MODE == 1, T0>(tT, a.g, a.xo[0], a.dofs[0], ws, row, o, dx, j, g);
+      FITC_T(9);
       if (Z_MODE == 1) {
 #pragma unroll
         for (int t = 0; t < T0; ++t) *reinterpret_cast<f32x4 *>(dzc + row * ZW + 16 * t + 4 * g) = dx[t];
@@ -166,6 +187,7 @@ static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_kernel(FitChainA
       a.dz[i] = v;
     }
   }
+  FITC_T(10);
   if (tid == 0 && a.loss) {
     double s[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     for (int rl = 0; rl < 3; ++rl)
