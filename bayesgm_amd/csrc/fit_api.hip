@@ -482,10 +482,12 @@ extern "C" int bgm_causal_fit_z_step(bgm_handle *h, const float *x, const float 
   ka.m = h->meta; ka.bm = h->fit_meta; ka.ws = h->fit_ws; ka.wsp = h->ws_dev;
   ka.x = x; ka.y = y; ka.v = v; ka.data_z = data_z; ka.idx = idx; ka.row_lo = row_lo; ka.B = batch;
   ka.inv_B = 1.0f / (float)batch_global; ka.z_mode = 1; ka.loss = loss;
+  bool pos_set = false;
   if (FitChainState *fc = static_cast<FitChainState *>(h->fit_chain); fc && (batch == 32 || (batch == 16 && !fc->pad))) {
     FitChainArgs ca = fc->base;
     ca.x = x; ca.y = y; ca.v = v; ca.data_z = data_z; ca.idx = idx; ca.row_lo = row_lo; ca.inv_B = ka.inv_B;
     ca.loss = loss; ca.dz = h->ws_dev + h->fit_ws.dz;
+    if (!lazy) { ca.pos = h->pos_dev; ca.pos_n = h->fit_rows; ca.epoch = (int)((h->t_z + 1) & 0x3FFFFFFF); pos_set = true; }
     fit_chain_launch(fc, ca, batch, 1, stream);
     rc = BGM_OK;
   } else rc = launch_fwd_bwd(h, ka, stream);
@@ -501,7 +503,8 @@ extern "C" int bgm_causal_fit_z_step(bgm_handle *h, const float *x, const float 
                        h->pos_dev, h->fit_rows, q, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS, 1, idx, batch, 0);
   } else {
     const int epoch = (int)(h->t_z & 0x3FFFFFFF);      // stamps of earlier steps never match (2^30 steps before a wrap)
-    hipLaunchKernelGGL(fit_set_pos_kernel, dim3((batch + 255) / 256), dim3(256), 0, stream, h->pos_dev, h->fit_rows, idx, batch, epoch);
+    if (!pos_set)      // (the chain kernel of the latent phase has written the map already)
+      hipLaunchKernelGGL(fit_set_pos_kernel, dim3((batch + 255) / 256), dim3(256), 0, stream, h->pos_dev, h->fit_rows, idx, batch, epoch);
     const long long n = h->fit_rows * q;
     hipLaunchKernelGGL(fit_adam_z_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, data_z, zm, zv, dz,
                        h->pos_dev, h->fit_rows, q, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS, 0, idx, batch, epoch);

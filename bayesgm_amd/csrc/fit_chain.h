@@ -27,6 +27,7 @@ struct FitChainArgs {
   float inv_B;
   double *loss;                   // [7] accumulators or NULL
   float *dz;                      // latent phase: [B x q]
+  int *pos; long long pos_n; int epoch;      // latent phase, dense Adam on Z: batch position / step stamp of the minibatch rows (fit_set_pos_kernel's job)
   int n_warm;                     // floats of theta (= of the transposed mirror) the idle wave pair pulls into this XCD's L2
 };
 
@@ -156,6 +157,11 @@ static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_kernel(FitChainA
       ecg_head_bwd<T1, T2, T3>(tT, N, a.xo[role], a.dofs[role], ws, row, d, dx, j, g);
       if (Z_MODE == 1) *reinterpret_cast<f32x4 *>(dzc + (role * 32 + row) * ZW + 4 * g) = dx[0];
     }
+  }
+  if (Z_MODE == 1 && a.pos && tid >= 384 && tid - 384 < B) {      // row -> batch position map of the dense Adam step that follows
+    const int b = tid - 384;
+    const long long r_ = fitc_row(a, b);
+    a.pos[r_] = b; a.pos[a.pos_n + r_] = a.epoch;
   }
   if (role == 3) {
     // waves 6,7: Adam rewrote theta and its mirror from other CUs since the last launch, so the chains' first touch of every weight
