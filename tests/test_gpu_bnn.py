@@ -197,13 +197,16 @@ def test_mh_iterations_match_oracle():
     eng.close()
 
 
-@pytest.mark.parametrize("binary", [False, True])
-def test_mh_effects_match_oracle(binary):
-    """Kept draws + causal effects of the sampler against the oracle evaluated on the kernel's own draws."""
-    m = _model(binary, p=50)
+@pytest.mark.parametrize("binary,units", [(False, {}), (True, {}),
+                                          (False, dict(f_units=(20, 12))),          # pipelined dose loop, run-time layer extents
+                                          (True, dict(f_units=(64, 64, 64)))])      # outcome net wider than one staged chunk: the generic routine
+def test_mh_effects_match_oracle(binary, units):
+    """Kept draws + causal effects of the sampler against the oracle evaluated on the kernel's own draws.  The default outcome net
+    runs the effects kernel's compile-time-shaped dose loop; the two other shapes its run-time-shaped and its generic form."""
+    m = _model(binary, p=50, **units)
     n, bs, burn, keep = 300, 128, 2, 3
     z, x, y, v = _panel(m, n)
-    eng = _engine(m)
+    eng = _engine(m, **units)
     dev = eng.device
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     seed = (2 << 32) | 555
