@@ -54,7 +54,8 @@ def _rel(a, b):
                                   dict(binary=False, p=100, z_dims=(3, 3, 3, 3), B=32, disc_norm="fixed"),
                                   # the binary-treatment configs' latent layout: q = 18, two latent input tiles
                                   dict(binary=True, p=177, z_dims=(3, 3, 6, 6), B=32, disc_norm="fixed"),
-                                  dict(binary=False, p=60, z_dims=(5, 5, 5, 16), B=32, disc_norm="fixed")])    # q = 31, the widest configurable latent
+                                  dict(binary=False, p=60, z_dims=(5, 5, 5, 16), B=32, disc_norm="fixed"),     # q = 31, the widest configurable latent
+                                  dict(binary=True, p=177, z_dims=(3, 3, 6, 6), B=16, disc_norm="fixed")])     # two latent tiles at B = 16: phase machine
 def test_egm_step_gradients_match_oracle(case):
     import torch
     B = case["B"]
