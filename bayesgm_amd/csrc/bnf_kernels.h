@@ -1,0 +1,925 @@
+// bnf_kernels.h -- CausalBGM with Bayesian networks, input normalisation in inference mode (params['bnn_norm'] = "fixed", the
+// shipped default): posterior sampling and causal effects on gfx950.
+//
+// replaces (src/bayesgm/models/causalbgm/base.py, use_bnn branches; networks/bnn.py:4-38):
+//   get_log_posterior :765-817 + metropolis_hastings_sampler :820-904  -> bnf_noise_kernel, bnf_signs_kernel, bnf_mh_kernel
+//   infer_from_latent_posterior :671-763                                -> bnf_effects_kernel
+//
+// With the input BatchNormalization on its (never updated) moving averages the rows of a block are independent: what a block of
+// `bs` rows still shares is ONE weight perturbation dW = sigma * eps per (layer, call).  The batch-statistics kernels of
+// bnn_sample_kernels.h (layer-synchronous staging of loc AND dW through 32 KB of LDS, three barriers per layer) stay for
+// bnn_norm = "batch"; this file is built around the independence:
+//   * persistent workgroups, one per CU; the `loc` fragments of g | h | f (150 KB at p = 200), the biases and the per-column
+//     normalisation live in LDS for the whole launch (one fill per launch, one barrier in the kernel);
+//   * a wave owns R 16-row tiles of ONE block at a time and walks g, h, f for the proposal and for the current state with the
+//     activations in registers (swapped MFMA orientation: a layer's accumulators are the next layer's B operands);
+//   * the call's perturbation fragments are read by every wave straight from L2 into registers, one output tile ahead of
+//     their use (1 KB per 8 R MFMAs): no staging, no barriers; the workgroups of an XCD walk the blocks in the same order so
+//     that a block's 150 KB set is fetched from HBM once per XCD;
+//   * Rademacher sign words and perturbations are produced by their own launches (bnf_signs_kernel, bnf_noise_kernel): a
+//     Philox call costs ~110 VALU instructions, 26 of them per row and iteration would sit in the matrix pipe's shadow
+//     otherwise; the words come back as 16-byte loads one layer ahead;
+//   * every layer extent is a compile-time constant (the default nets: g [q, 64 x 5, p + 1], f / h [., 64, 32, 8, 2]); a sign
+//     flip is shift + v_and_or (-> +-1.0f) + one fma; LeakyReLU is one fma (lrelu_s, factor 0.6 folded into the packed weights).
+// Fragment layouts (bnf_api.hip builds the index tables): the first layer of each net contracts over the SHARED extended input
+// e = [z (q), x]: slot (lane group gg, register r) of k-tile sb holds e[16 sb + 4 r + gg] -- the layout one Philox call per lane
+// fills (oracle/rng.py) -- with zero rows where a net does not read a component (h: z1, z3 and x; g: x; f: z2, z3); hidden layers
+// are natural (feature 16 t + 4 gg + r); the 8 outputs of f / h's third layer sit at lane group f >> 1, register f & 1, so the
+// last layer contracts over two k-steps; its two output columns are replicated over the four lane groups.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "bnn_kernels.h"
+
+#define BNF_NG_G 6            // 16-byte sign groups of one g call per row: G0 = [w0 w1 w2 -], Gl = [w(4l-1) .. w(4l+2)] (l = 1..4), G5 = [w19 w20 - -]
+#define BNF_NG_H 3            // ... of one h / f call: H0 = [w0 w1 w2 -], H1 = [w3 w4 w5 w6], H2 = [w7 w8 w9 -]
+#define BNF_GOUT 8            // sign words of the outputs of g's last layer, w21 .. w27 (p + 1 <= 208 columns), one spare
+#define BNF_MAX_DOSES 256
+// hipcc sinks every load to just above its first use; a compiler-only memory fence behind a group of prefetch loads keeps them
+// where they were requested (one output tile / one layer / one dose ahead of their use)
+#define BNF_PIN() asm volatile("" ::: "memory")
+
+struct BnfPlan {
+  int q, p, z0, z1, z2, binary;
+  int KS;                     // k-steps of the first layers: ceil((q + 1) / 4); k-tiles T0 = (KS + 3) / 4
+  int NTL;                    // output tiles of g's last layer: ceil((p + 1) / 16)
+  int fg0, fgh, fgl, fh, ff;  // first fragment (256 floats) of g's first / hidden / last layers, of h, of f
+  int n_frags;
+  int bias_off, norm_off, shift_off, blob_floats;   // float offsets inside the LDS blob [frags | bias tiles | norm | shift]
+  int bg0, bgh, bgl, bh, bf;  // bias tiles (16 floats) of the same
+  int set_floats;             // one perturbation set: n_frags * 256
+  // effects blob (outcome net only): [f frags | f bias tiles | f norm | f shift]
+  int e_frags, e_bias_off, e_norm_off, e_shift_off, e_blob_floats;
+};
+
+struct BnfSigns {             // n_states = 2 (MH: proposal, current) or n_doses (effects)
+  const uint4 *g;             // [n_states][BNF_NG_G][n]
+  const uint32_t *gout;       // [n_states][n][BNF_GOUT]
+  const uint4 *h, *f;         // [n_states][BNF_NG_H][n]
+};
+
+// +-1.0f from the bit at position 31 of m
+__device__ __forceinline__ float bnf_pm1(uint32_t m) { return __builtin_bit_cast(float, (m & 0x80000000u) | 0x3f800000u); }
+// sign words are pre-shifted per lane so that bit (4 gg + 19) of the word sits at position 31: feature 16 t + 4 gg + r of a
+// 32-feature word <-> bit B = 16 (t & 1) + r of the lane's view, at position 12 + B
+__device__ __forceinline__ uint32_t bnf_preshift(uint32_t w, int g) { return w << (12 - 4 * g); }
+template <int B>
+__device__ __forceinline__ float bnf_sign(uint32_t wsh) { return bnf_pm1(B == 19 ? wsh : wsh << (19 - B)); }
+__device__ __forceinline__ float bnf_sign_rt(uint32_t wsh, int b) { return bnf_pm1(wsh << (19 - b)); }
+
+struct BnfLds {
+  const f32x4 *frag;          // fragment f at frag + 64 f (one f32x4 per lane)
+  const f32x4 *bias;          // tile t, lane group gg at bias[4 t + gg]
+  const f32x4 *norm;          // net N (0 g, 1 h, 2 f), k-tile sb: scale at norm[((N * T0 + sb) * 2) * 4 + gg], shift at [... + 1) * 4 + gg]
+  const int4 *shift;          // net N, k-tile sb: left shifts that bring the slot's input-sign bit to position 31, [(N * T0 + sb) * 4 + gg]
+};
+
+// ---------------------------------------------------------------------------------------------
+// first layer: extended input e (KS slots per lane) -> 64 units.  ze: raw slots; the layer normalises (scale / shift per slot and
+// net), flips with the input-sign word w_in, runs both products and finishes the four output tiles.
+// wo: output-sign words (pre-shifted), wi: input-sign words of the NEXT layer (pre-shifted).
+// ---------------------------------------------------------------------------------------------
+template <int KS, int R>
+__device__ __forceinline__ void bnf_first(const f32x4 *LF, const f32x4 *__restrict__ DW, const f32x4 *BL, const f32x4 *NORM, const int4 *SHIFT,
+                                          int lane, int g, const float (&ze)[R][KS], const uint32_t (&w_in)[R], const uint32_t (&wo)[R][2],
+                                          const uint32_t (&wi)[R][2], float (&h)[R][4][4], float (&hs)[R][4][4]) {
+  constexpr int T0 = (KS + 3) / 4;
+  f32x4 fd[4][T0];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int sb = 0; sb < T0; ++sb) fd[mt][sb] = DW[(mt * T0 + sb) * 64 + lane];
+  BNF_PIN();
+  float hb[R][KS], hsb[R][KS];
+#pragma unroll
+  for (int sb = 0; sb < T0; ++sb) {
+    const f32x4 sc = NORM[(sb * 2) * 4 + g], sh = NORM[(sb * 2 + 1) * 4 + g];
+    const int4 st = SHIFT[sb * 4 + g];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ks = 4 * sb + r;
+      if (ks < KS) {
+        const int sft = r == 0 ? st.x : r == 1 ? st.y : r == 2 ? st.z : st.w;
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) {
+          const float x = fmaf(ze[rt][ks], sc[r], sh[r]);
+          hb[rt][ks] = x;
+          hsb[rt][ks] = x * bnf_pm1(w_in[rt] << sft);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    f32x4 a1[R], a2[R];
+    const f32x4 b = BL[4 * mt + g];
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) { a1[rt] = b; a2[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int sb = 0; sb < T0; ++sb) {
+      const f32x4 fa = LF[(mt * T0 + sb) * 64 + lane];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * sb + r < KS) {
+#pragma unroll
+          for (int rt = 0; rt < R; ++rt) {
+            a1[rt] = BGM_MFMA(fa[r], hb[rt][4 * sb + r], a1[rt]);
+            a2[rt] = BGM_MFMA(fd[mt][sb][r], hsb[rt][4 * sb + r], a2[rt]);
+          }
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float y = fmaf(a2[rt][r], bnf_sign_rt(wo[rt][mt >> 1], 16 * (mt & 1) + r), a1[rt][r]);
+        const float v = lrelu_s(y);
+        h[rt][mt][r] = v;
+        hs[rt][mt][r] = v * bnf_sign_rt(wi[rt][mt >> 1], 16 * (mt & 1) + r);
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// hidden layer 64 -> 64 of g: h, hs are replaced by the next layer's inputs.  fd: this layer's first tile's perturbation
+// fragments (requested by the caller); on return the fragments at DWnext (the next layer's / section's first tile).
+// ---------------------------------------------------------------------------------------------
+template <int R>
+__device__ __forceinline__ void bnf_hidden(const f32x4 *LF, const f32x4 *__restrict__ DW, const f32x4 *__restrict__ DWnext, const f32x4 *BL, int lane,
+                                           int g, const uint32_t (&wo)[R][2], const uint32_t (&wi)[R][2], float (&h)[R][4][4],
+                                           float (&hs)[R][4][4], f32x4 (&fd)[4]) {
+  float hn[R][4][4], hsn[R][4][4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    f32x4 fn[4];
+    const f32x4 *nx = (mt < 3) ? DW + (mt + 1) * 4 * 64 : DWnext;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) fn[t] = nx[t * 64 + lane];
+    BNF_PIN();
+    f32x4 a1[R], a2[R];
+    const f32x4 b = BL[4 * mt + g];
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) { a1[rt] = b; a2[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x4 fa = LF[(mt * 4 + t) * 64 + lane];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) {
+          a1[rt] = BGM_MFMA(fa[r], h[rt][t][r], a1[rt]);
+          a2[rt] = BGM_MFMA(fd[t][r], hs[rt][t][r], a2[rt]);
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float y = fmaf(a2[rt][r], bnf_sign_rt(wo[rt][mt >> 1], 16 * (mt & 1) + r), a1[rt][r]);
+        const float v = lrelu_s(y);
+        hn[rt][mt][r] = v;
+        hsn[rt][mt][r] = v * bnf_sign_rt(wi[rt][mt >> 1], 16 * (mt & 1) + r);
+      }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) fd[t] = fn[t];
+  }
+#pragma unroll
+  for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { h[rt][t][r] = hn[rt][t][r]; hs[rt][t][r] = hsn[rt][t][r]; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// outcome / treatment net  e -> 64 -> 32 -> 8 -> 2  (f, h of the default configuration).  G: the call's three sign groups per
+// row tile.  Returns the two outputs (mean, raw variance) of every row, valid in all four lane groups.
+// LF / DW: the net's first fragment in LDS / in the call's perturbation set; BL: its first bias tile.
+// ---------------------------------------------------------------------------------------------
+template <int KS, int R>
+__device__ __forceinline__ void bnf_head(const f32x4 *LF, const f32x4 *__restrict__ DW, const f32x4 *BL, const f32x4 *NORM, const int4 *SHIFT, int lane,
+                                         int g, const float (&ze)[R][KS], const uint4 (&G)[R][BNF_NG_H], float (&mu)[R], float (&raw)[R]) {
+  constexpr int T0 = (KS + 3) / 4;
+  // perturbation fragments of layers 2..4 requested up front (11 KB per wave): the small layers have no tile loop to hide them in
+  f32x4 fd2[2][4], fd3[2], fd4;
+  {
+    const f32x4 *D2 = DW + 4 * T0 * 64;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fd2[mt][t] = D2[(mt * 4 + t) * 64 + lane];
+    fd3[0] = D2[8 * 64 + lane]; fd3[1] = D2[9 * 64 + lane];
+    fd4 = D2[10 * 64 + lane];
+  }
+  BNF_PIN();
+  float h1[R][4][4], hs1[R][4][4];
+  {
+    uint32_t w_in[R], wo[R][2], wi[R][2];
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) {
+      w_in[rt] = G[rt][0].x;
+      wo[rt][0] = bnf_preshift(G[rt][0].y, g); wo[rt][1] = bnf_preshift(G[rt][0].z, g);
+      wi[rt][0] = bnf_preshift(G[rt][1].x, g); wi[rt][1] = bnf_preshift(G[rt][1].y, g);
+    }
+    bnf_first<KS, R>(LF, DW, BL, NORM, SHIFT, lane, g, ze, w_in, wo, wi, h1, hs1);
+  }
+  // layer 2: 64 -> 32
+  const f32x4 *L2 = LF + 4 * T0 * 64;
+  float h2[R][2][4], hs2[R][2][4];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    f32x4 a1[R], a2[R];
+    const f32x4 b = BL[4 * (4 + mt) + g];
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) { a1[rt] = b; a2[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x4 fa = L2[(mt * 4 + t) * 64 + lane];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) {
+          a1[rt] = BGM_MFMA(fa[r], h1[rt][t][r], a1[rt]);
+          a2[rt] = BGM_MFMA(fd2[mt][t][r], hs1[rt][t][r], a2[rt]);
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) {
+      const uint32_t so = bnf_preshift(G[rt][1].z, g), si = bnf_preshift(G[rt][1].w, g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float y = fmaf(a2[rt][r], bnf_sign_rt(so, 16 * mt + r), a1[rt][r]);
+        const float v = lrelu_s(y);
+        h2[rt][mt][r] = v;
+        hs2[rt][mt][r] = v * bnf_sign_rt(si, 16 * mt + r);
+      }
+    }
+  }
+  // layer 3: 32 -> 8, output feature f at lane group f >> 1, register f & 1
+  const f32x4 *L3 = L2 + 8 * 64;
+  float h3[R][2], hs3[R][2];
+  {
+    f32x4 a1[R], a2[R];
+    const f32x4 b = BL[4 * 6 + g];
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) { a1[rt] = b; a2[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const f32x4 fa = L3[t * 64 + lane];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) {
+          a1[rt] = BGM_MFMA(fa[r], h2[rt][t][r], a1[rt]);
+          a2[rt] = BGM_MFMA(fd3[t][r], hs2[rt][t][r], a2[rt]);
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) {
+      const uint32_t so = G[rt][2].x << (30 - 2 * g), si = G[rt][2].y << (30 - 2 * g);   // bit 2 gg + r at position 30 + r
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const float y = fmaf(a2[rt][r], bnf_pm1(r ? so : so << 1), a1[rt][r]);
+        const float v = lrelu_s(y);
+        h3[rt][r] = v;
+        hs3[rt][r] = v * bnf_pm1(r ? si : si << 1);
+      }
+    }
+  }
+  // layer 4: 8 -> 2 over two k-steps; column o at every 4 gg + o
+  {
+    const f32x4 fa = L3[2 * 64 + lane];
+    const f32x4 b = BL[4 * 7 + g];
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) {
+      f32x4 a1 = b, a2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        a1 = BGM_MFMA(fa[r], h3[rt][r], a1);
+        a2 = BGM_MFMA(fd4[r], hs3[rt][r], a2);
+      }
+      const uint32_t so = G[rt][2].z;
+      mu[rt] = fmaf(a2[0], bnf_pm1(so << 31), a1[0]);
+      raw[rt] = fmaf(a2[1], bnf_pm1(so << 30), a1[1]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// log posterior of R row tiles for one state (one noisy call of g, h, f)
+// ---------------------------------------------------------------------------------------------
+struct BnfMhArgs {
+  BnfPlan pl;
+  const float *blob;                   // [blob_floats]
+  const float *dw;                     // [n_blocks][n_states][set_floats]
+  BnfSigns sg;
+  const float *x, *y, *v;
+  float *z;                            // [n x q] state (mode 1: updated in place; mode 0: read)
+  long long n, row_base;
+  int bs, n_blocks, block0, groups_per_block, n_items, n_states;
+  int mode;                            // 0: log posterior of z (state slot 0) -> out; 1: one MH iteration
+  int it, init;
+  float q_sd;
+  const float *q_sd_blocks;
+  uint32_t k0, k1;
+  float *out;
+  unsigned *acc_count, *acc_blocks;
+};
+
+template <int KS, int R>
+__device__ __forceinline__ void bnf_logpost_rows(const BnfMhArgs &a, const BnfLds &L, int lane, int j, int g, long long blk_lo, const int (&rib)[R],
+                                                 const float (&ze)[R][KS], const float (&xr)[R], const float (&yr)[R], const float *dwset, int s,
+                                                 const float (&zz)[R], float (&lp)[R]) {
+  constexpr int T0 = (KS + 3) / 4;
+  const BnfPlan &P = a.pl;
+  const int p = P.p;
+  const f32x4 *DW = (const f32x4 *)dwset;
+  BGM_NO_HOIST();       // the LDS-resident fragments never change: without a fence LICM hoists their reads out of the item loop and spills
+  // ---- g
+  float ssq[R], rawv[R];
+  {
+    float h[R][4][4], hs[R][4][4];
+    // wave-uniform bases of the block's rows; per-lane offsets stay 32-bit
+    const uint4 *SG = a.sg.g + ((long long)s * BNF_NG_G * a.n + blk_lo);
+    uint4 Gc[R], Gn[R];
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) { Gc[rt] = SG[rib[rt]]; Gn[rt] = (SG + a.n)[rib[rt]]; }
+    BNF_PIN();
+    uint32_t wo[R][2], wi[R][2];
+    {
+      uint32_t w_in[R];
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) {
+        w_in[rt] = Gc[rt].x;
+        wo[rt][0] = bnf_preshift(Gc[rt].y, g); wo[rt][1] = bnf_preshift(Gc[rt].z, g);
+        wi[rt][0] = bnf_preshift(Gn[rt].x, g); wi[rt][1] = bnf_preshift(Gn[rt].y, g);
+      }
+      bnf_first<KS, R>(L.frag + P.fg0 * 64, DW + P.fg0 * 64, L.bias + 4 * P.bg0, L.norm, L.shift, lane, g, ze, w_in, wo, wi, h, hs);
+    }
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) { wo[rt][0] = bnf_preshift(Gn[rt].z, g); wo[rt][1] = bnf_preshift(Gn[rt].w, g); }
+    f32x4 fd[4];
+    {
+      const f32x4 *D = DW + P.fgh * 64;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fd[t] = D[t * 64 + lane];
+    }
+#pragma nounroll
+    for (int l = 1; l <= 4; ++l) {
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) Gn[rt] = (SG + (long long)(l + 1) * a.n)[rib[rt]];
+      BNF_PIN();
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) { wi[rt][0] = bnf_preshift(Gn[rt].x, g); wi[rt][1] = bnf_preshift(Gn[rt].y, g); }
+      const int fo = (P.fgh + 16 * (l - 1)) * 64;
+      bnf_hidden<R>(L.frag + fo, DW + fo, DW + fo + 16 * 64, L.bias + 4 * (P.bgh + 4 * (l - 1)), lane, g, wo, wi, h, hs, fd);
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) { wo[rt][0] = bnf_preshift(Gn[rt].z, g); wo[rt][1] = bnf_preshift(Gn[rt].w, g); }
+    }
+    // last layer: 64 -> p + 1, tile by tile against the data row; fd holds tile 0's perturbation fragments
+    const int NTL = P.NTL;
+    const f32x4 *LFl = L.frag + P.fgl * 64, *DWl = DW + P.fgl * 64, *BLl = L.bias + 4 * P.bgl;
+    const uint32_t *GO = a.sg.gout + ((long long)s * a.n + blk_lo) * BNF_GOUT;
+    const float *vblk = a.v + blk_lo * p;
+    const bool vec = (p & 3) == 0;
+    auto load_v = [&](int rt, int mt) __attribute__((always_inline)) -> f32x4 {
+      const int u0 = 16 * mt + 4 * g;
+      const float *vr = vblk + rib[rt] * p;
+      f32x4 o;
+      if (vec) {
+        o = *(const f32x4 *)(vr + min(u0, p - 4));
+        if (u0 >= p) o = f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float t = vr[min(u0 + r, p - 1)]; o[r] = (u0 + r < p) ? t : 0.0f; }
+      }
+      return o;
+    };
+    f32x4 vn[R];
+    uint32_t wn[R];
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) { vn[rt] = load_v(rt, 0); wn[rt] = GO[rib[rt] * BNF_GOUT]; ssq[rt] = 0.0f; rawv[rt] = 0.0f; }
+    auto tile = [&](int mt, bool last, const f32x4 (&vc)[R], const uint32_t (&wc)[R], const f32x4 (&fc)[4]) __attribute__((always_inline)) {
+      f32x4 a1[R], a2[R];
+      const f32x4 b = BLl[4 * mt + g];
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) { a1[rt] = b - vc[rt]; a2[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f32x4 fa = LFl[(mt * 4 + t) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int rt = 0; rt < R; ++rt) {
+            a1[rt] = BGM_MFMA(fa[r], h[rt][t][r], a1[rt]);
+            a2[rt] = BGM_MFMA(fc[t][r], hs[rt][t][r], a2[rt]);
+          }
+      }
+      const int pos = 16 * (mt & 1);
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) {
+        const uint32_t wsh = bnf_preshift(wc[rt], g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = fmaf(a2[rt][r], bnf_sign_rt(wsh, pos + r), a1[rt][r]);
+          if (!last) ssq[rt] = fmaf(d, d, ssq[rt]);
+          else {
+            const int u = 16 * mt + 4 * g + r;
+            ssq[rt] = fmaf(u < p ? d : 0.0f, d, ssq[rt]);
+            rawv[rt] += (u == p) ? d : 0.0f;
+          }
+        }
+      }
+    };
+#pragma nounroll
+    for (int mt = 0; mt < NTL - 1; ++mt) {
+      f32x4 vc[R], fc[4];
+      uint32_t wc[R];
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) { vc[rt] = vn[rt]; wc[rt] = wn[rt]; }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fc[t] = fd[t];
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) { vn[rt] = load_v(rt, mt + 1); wn[rt] = GO[rib[rt] * BNF_GOUT + ((mt + 1) >> 1)]; }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fd[t] = DWl[((mt + 1) * 4 + t) * 64 + lane];
+      BNF_PIN();
+      tile(mt, false, vc, wc, fc);
+    }
+    tile(NTL - 1, true, vn, wn, fd);
+  }
+  float part[R];
+#pragma unroll
+  for (int rt = 0; rt < R; ++rt) {
+    const float rw = sum_over_g(rawv[rt]);
+    const float s2 = softplus_f(rw) + BGM_EPS;
+    // the per-lane share of -(ssq / (2 s2) + |z|^2 / 2); the log term is added once after the cross-lane sum
+    part[rt] = -(ssq[rt] * fast_rcp(2.0f * s2) + 0.5f * zz[rt]);
+    lp[rt] = -0.5f * (float)p * fast_log(s2);
+  }
+  // ---- h (treatment) and f (outcome)
+  {
+    float mu[R], raw[R];
+    uint4 G[R][BNF_NG_H];
+    const uint4 *SH = a.sg.h + ((long long)s * BNF_NG_H * a.n + blk_lo);
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+      for (int k = 0; k < BNF_NG_H; ++k) G[rt][k] = (SH + (long long)k * a.n)[rib[rt]];
+    BGM_NO_HOIST();
+    bnf_head<KS, R>(L.frag + P.fh * 64, DW + P.fh * 64, L.bias + 4 * P.bh, L.norm + 1 * T0 * 8, L.shift + 1 * T0 * 4, lane, g, ze, G, mu, raw);
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) {
+      const float m_ = mu[rt];
+      if (P.binary) lp[rt] -= fmaxf(m_, 0.0f) - m_ * xr[rt] + softplus_f(-fabsf(m_));
+      else { const float s2 = softplus_f(raw[rt]) + BGM_EPS, d = xr[rt] - m_; lp[rt] -= d * d * fast_rcp(2.0f * s2) + 0.5f * fast_log(s2); }
+    }
+    const uint4 *SF = a.sg.f + ((long long)s * BNF_NG_H * a.n + blk_lo);
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+      for (int k = 0; k < BNF_NG_H; ++k) G[rt][k] = (SF + (long long)k * a.n)[rib[rt]];
+    BGM_NO_HOIST();
+    bnf_head<KS, R>(L.frag + P.ff * 64, DW + P.ff * 64, L.bias + 4 * P.bf, L.norm + 2 * T0 * 8, L.shift + 2 * T0 * 4, lane, g, ze, G, mu, raw);
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) {
+      const float s2 = softplus_f(raw[rt]) + BGM_EPS, d = yr[rt] - mu[rt];
+      lp[rt] -= d * d * fast_rcp(2.0f * s2) + 0.5f * fast_log(s2);
+    }
+  }
+#pragma unroll
+  for (int rt = 0; rt < R; ++rt) lp[rt] += sum_over_g(part[rt]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// persistent sampler kernel: grid = a multiple of 8 workgroups (one per CU), WAVES waves each.  Items = groups of R row tiles of
+// one block; the workgroups of XCD x (blockIdx % 8) take the x-th contiguous eighth of the items and walk it in lock step.
+// ---------------------------------------------------------------------------------------------
+template <int KS, int R, int WAVES, int MODE>
+static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_mh_kernel(BnfMhArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float bnf_lds[];
+  const BnfPlan &P = a.pl;
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {
+    const f32x4 *src = (const f32x4 *)a.blob;
+    f32x4 *dst = (f32x4 *)bnf_lds;
+    const int cnt = P.blob_floats >> 2;
+    for (int i = tid; i < cnt; i += 64 * WAVES) dst[i] = src[i];
+  }
+  __syncthreads();
+  BnfLds L;
+  L.frag = (const f32x4 *)bnf_lds;
+  L.bias = (const f32x4 *)(bnf_lds + P.bias_off);
+  L.norm = (const f32x4 *)(bnf_lds + P.norm_off);
+  L.shift = (const int4 *)(bnf_lds + P.shift_off);
+  const int q = P.q;
+  const int xcd = blockIdx.x & 7, cu = blockIdx.x >> 3, cus = gridDim.x >> 3;
+  const int per = (a.n_items + 7) >> 3, lo = xcd * per, hi = min(a.n_items, lo + per);
+  unsigned nacc_total = 0;
+  for (int item = lo + cu * WAVES + wave; item < hi; item += cus * WAVES) {
+    const int blk = item / a.groups_per_block, grp = item - blk * a.groups_per_block;
+    const long long blk_lo = (long long)blk * a.bs;
+    const int blk_n = (int)min((long long)a.bs, a.n - blk_lo);
+    const int rib0 = grp * 16 * R;
+    if (rib0 >= blk_n) continue;
+    int rib[R];
+    bool valid[R];
+    float xr[R], yr[R];
+    const float *xblk = a.x + blk_lo, *yblk = a.y + blk_lo;
+    float *zblk = a.z + blk_lo * q;
+    const uint32_t rid0 = (uint32_t)(a.row_base + blk_lo);
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) {
+      const int r_ = rib0 + 16 * rt + j;
+      valid[rt] = r_ < blk_n;
+      rib[rt] = min(r_, blk_n - 1);
+      xr[rt] = xblk[rib[rt]]; yr[rt] = yblk[rib[rt]];
+    }
+    const float *dwblk = a.dw + (long long)blk * a.n_states * P.set_floats;
+    float zc[R][KS], zzc[R];
+    if (MODE == 1 && a.init) {
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) {
+        const uint32_t rid = rid0 + (uint32_t)rib[rt];
+#pragma unroll
+        for (int sb = 0; sb < (KS + 3) / 4; ++sb) {
+          const f32x4 e = box_muller4(philox4x32_10(rid, 0u, (uint32_t)(g + 4 * sb), TAG_INIT, a.k0, a.k1));
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (4 * sb + r < KS) {
+              const int f = 16 * sb + 4 * r + g;
+              zc[rt][4 * sb + r] = f < q ? e[r] : 0.0f;
+              if (f < q && valid[rt]) zblk[rib[rt] * q + f] = e[r];
+            }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int f = 16 * (ks >> 2) + 4 * (ks & 3) + g;
+          const float t = zblk[rib[rt] * q + min(f, q - 1)];
+          zc[rt][ks] = f < q ? t : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) {
+      float s = 0.0f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) s = fmaf(zc[rt][ks], zc[rt][ks], s);
+      zzc[rt] = s;
+    }
+    if constexpr (MODE == 0) {
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          if (16 * (ks >> 2) + 4 * (ks & 3) + g == q) zc[rt][ks] = xr[rt];
+      float lp[R];
+      bnf_logpost_rows<KS, R>(a, L, lane, j, g, blk_lo, rib, zc, xr, yr, dwblk, 0, zzc, lp);
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt)
+        if (valid[rt] && g == 0) a.out[blk_lo + rib[rt]] = lp[rt];
+      continue;
+    }
+    // proposal
+    float zp[R][KS], zzp[R];
+    const float sd = a.q_sd_blocks ? a.q_sd_blocks[blk] : a.q_sd;
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) {
+      const uint32_t rid = rid0 + (uint32_t)rib[rt];
+      float s = 0.0f;
+#pragma unroll
+      for (int sb = 0; sb < (KS + 3) / 4; ++sb) {
+        const f32x4 e = box_muller4(philox4x32_10(rid, (uint32_t)a.it, (uint32_t)(g + 4 * sb), TAG_PROP, a.k0, a.k1));
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (4 * sb + r < KS) {
+            const int f = 16 * sb + 4 * r + g;
+            const float t = f < q ? fmaf(sd, e[r], zc[rt][4 * sb + r]) : 0.0f;
+            zp[rt][4 * sb + r] = t;
+            s = fmaf(t, t, s);
+          }
+      }
+      zzp[rt] = s;
+    }
+    // the treatment rides in slot q of the extended input
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        if (16 * (ks >> 2) + 4 * (ks & 3) + g == q) { zc[rt][ks] = xr[rt]; zp[rt][ks] = xr[rt]; }
+    // both states through ONE copy of the network code (the kernel is ~25 KB of instructions instead of ~70): state 0 = proposal
+    // (perturbation set 0, sign groups 0), state 1 = current
+    float lpp[R], lpc[R];
+#pragma nounroll
+    for (int st = 0; st < 2; ++st) {
+      float zs[R][KS], zzs[R], lp[R];
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) {
+        zzs[rt] = st ? zzc[rt] : zzp[rt];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) zs[rt][ks] = st ? zc[rt][ks] : zp[rt][ks];
+      }
+      bnf_logpost_rows<KS, R>(a, L, lane, j, g, blk_lo, rib, zs, xr, yr, dwblk + (long long)st * P.set_floats, st, zzs, lp);
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) { if (st) lpc[rt] = lp[rt]; else lpp[rt] = lp[rt]; }
+    }
+    unsigned nacc = 0;
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) {
+      const uint4 w4 = philox4x32_10(rid0 + (uint32_t)rib[rt], (uint32_t)a.it >> 2, 0u, TAG_ACC, a.k0, a.k1);
+      const int it = a.it;
+      const unsigned w = (it & 2) ? ((it & 1) ? w4.w : w4.z) : ((it & 1) ? w4.y : w4.x);
+      const bool acc = u01_open(w) < fast_exp(fminf(lpp[rt] - lpc[rt], 0.0f));
+      if (valid[rt] && acc) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int f = 16 * (ks >> 2) + 4 * (ks & 3) + g;
+          if (f < q) zblk[rib[rt] * q + f] = zp[rt][ks];
+        }
+        if (g == 0) ++nacc;
+      }
+    }
+    if (a.acc_count || a.acc_blocks) {
+      for (int off = 32; off > 0; off >>= 1) nacc += __shfl_xor(nacc, off);
+      if (lane == 0 && nacc) {
+        if (a.acc_blocks) atomicAdd(&a.acc_blocks[blk], nacc);
+        nacc_total += nacc;
+      }
+    }
+  }
+  if (a.acc_count && lane == 0 && nacc_total) atomicAdd(a.acc_count, nacc_total);
+}
+
+// ---------------------------------------------------------------------------------------------
+// causal effects: the outcome net at n_doses treatments on one state per row (infer_from_latent_posterior :671-763, one kept
+// draw per launch).  Dose k is its own noisy call (perturbation set k of the block, sign groups k of the row).
+// ---------------------------------------------------------------------------------------------
+struct BnfEffArgs {
+  BnfPlan pl;
+  const float *eblob;                  // [e_blob_floats]: outcome net only
+  const float *dw;                     // [n_blocks][n_doses][e_frags * 256]
+  const uint4 *sgf;                    // [n_doses][BNF_NG_H][n]
+  const float *z;                      // [n x q]
+  long long n, row_base;
+  int bs, n_blocks, block0, groups_per_block, n_items, n_doses;
+  const float *xvals;
+  uint32_t k0, k1;
+  int sample_y;
+  uint32_t it_noise;
+  double *sum_out; long long sum_stride;
+  float *ite_out; long long ite_stride;
+};
+
+template <int KS, int R, int WAVES>
+static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_effects_kernel(BnfEffArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float bnf_lds[];
+  constexpr int T0 = (KS + 3) / 4;
+  const BnfPlan &P = a.pl;
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float *acc_lds = bnf_lds + ((P.e_blob_floats + 3) & ~3);     // [WAVES][BNF_MAX_DOSES]
+  {
+    const f32x4 *src = (const f32x4 *)a.eblob;
+    f32x4 *dst = (f32x4 *)bnf_lds;
+    const int cnt = P.e_blob_floats >> 2;
+    for (int i = tid; i < cnt; i += 64 * WAVES) dst[i] = src[i];
+    for (int i = tid; i < WAVES * BNF_MAX_DOSES; i += 64 * WAVES) acc_lds[i] = 0.0f;
+  }
+  __syncthreads();
+  const f32x4 *LF = (const f32x4 *)bnf_lds;
+  const f32x4 *BL = (const f32x4 *)(bnf_lds + P.e_bias_off);
+  const f32x4 *NORM = (const f32x4 *)(bnf_lds + P.e_norm_off);
+  const int4 *SHIFT = (const int4 *)(bnf_lds + P.e_shift_off);
+  float *myacc = acc_lds + wave * BNF_MAX_DOSES;
+  const int q = P.q, nd = a.n_doses;
+  const long long eset = (long long)P.e_frags * 256;
+  const int xcd = blockIdx.x & 7, cu = blockIdx.x >> 3, cus = gridDim.x >> 3;
+  const int per = (a.n_items + 7) >> 3, lo = xcd * per, hi = min(a.n_items, lo + per);
+  for (int item = lo + cu * WAVES + wave; item < hi; item += cus * WAVES) {
+    const int blk = item / a.groups_per_block, grp = item - blk * a.groups_per_block;
+    const long long blk_lo = (long long)blk * a.bs;
+    const int blk_n = (int)min((long long)a.bs, a.n - blk_lo);
+    const int rib0 = grp * 16 * R;
+    if (rib0 >= blk_n) continue;
+    int rib[R];
+    bool valid[R];
+    float ze[R][KS];
+    const float *zblk = a.z + blk_lo * q;
+    const uint4 *SGb = a.sgf + blk_lo;
+    const uint32_t rid0 = (uint32_t)(a.row_base + blk_lo);
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) {
+      const int r_ = rib0 + 16 * rt + j;
+      valid[rt] = r_ < blk_n;
+      rib[rt] = min(r_, blk_n - 1);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int f = 16 * (ks >> 2) + 4 * (ks & 3) + g;
+        const float t = zblk[rib[rt] * q + min(f, q - 1)];
+        ze[rt][ks] = f < q ? t : 0.0f;
+      }
+    }
+    const float *dwblk = a.dw + (long long)blk * nd * eset;
+    float y0[R];
+    f32x4 nz[R];
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) { y0[rt] = 0.0f; nz[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    uint4 Gn[R][BNF_NG_H];
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+      for (int k = 0; k < BNF_NG_H; ++k) Gn[rt][k] = (SGb + (long long)k * a.n)[rib[rt]];
+#pragma nounroll
+    for (int k = 0; k < nd; ++k) {
+      const float xv = a.xvals[k];
+      uint4 G[R][BNF_NG_H];
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+        for (int c = 0; c < BNF_NG_H; ++c) G[rt][c] = Gn[rt][c];
+      if (k + 1 < nd) {
+        const uint4 *S = SGb + (long long)(k + 1) * BNF_NG_H * a.n;
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+          for (int c = 0; c < BNF_NG_H; ++c) Gn[rt][c] = (S + (long long)c * a.n)[rib[rt]];
+      }
+      BNF_PIN();
+      // outcome noise: lane group gg draws call 4 (k >> 4) + gg once per 16 doses; dose k is finished by lane group (k >> 2) & 3
+      if (a.sample_y && (k & 15) == 0) {
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt)
+          nz[rt] = box_muller4(philox4x32_10(rid0 + (uint32_t)rib[rt], a.it_noise, (uint32_t)((k >> 2) + g), TAG_YNOISE, a.k0, a.k1));
+      }
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          if (16 * (ks >> 2) + 4 * (ks & 3) + g == q) ze[rt][ks] = xv;
+      float mu[R], raw[R];
+      BGM_NO_HOIST();
+      bnf_head<KS, R>(LF, (const f32x4 *)(dwblk + (long long)k * eset), BL, NORM, SHIFT, lane, g, ze, G, mu, raw);
+      const int own = (k >> 2) & 3, e = k & 3;
+      float tot = 0.0f;
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) {
+        float yk = mu[rt];
+        if (a.sample_y) {
+          const float s2 = softplus_f(raw[rt]) + BGM_EPS;
+          yk = fmaf(__builtin_sqrtf(s2), e == 0 ? nz[rt][0] : e == 1 ? nz[rt][1] : e == 2 ? nz[rt][2] : nz[rt][3], yk);
+        }
+        if (a.ite_out) {
+          if (k == 0) y0[rt] = yk;
+          else if (k == 1 && valid[rt] && g == own) a.ite_out[(blk_lo + rib[rt]) * a.ite_stride] = y0[rt] - yk;
+        }
+        tot += valid[rt] ? yk : 0.0f;
+      }
+      if (a.sum_out) {
+        tot = sum_over_j_to_lane15(tot);
+        if (lane == 16 * own + 15) myacc[k] += tot;
+      }
+    }
+  }
+  if (a.sum_out) {
+    __syncthreads();
+    for (int k = tid; k < nd; k += 64 * WAVES) {
+      double t = 0.0;
+      for (int w = 0; w < WAVES; ++w) t += (double)acc_lds[w * BNF_MAX_DOSES + k];
+      atomicAdd(&a.sum_out[(long long)k * a.sum_stride], t);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// packing, perturbations, sign words
+// ---------------------------------------------------------------------------------------------
+// Element tables (host-built, bnf_api.hip).  A kernel element: theta offsets of loc / rho, position in the set, replication.
+struct BnfWElem { int loc, rho, pos, rep; float scale; };     // rep copies at pos, pos + 16, ...; scale 0.6 behind a LeakyReLU
+struct BnfBElem { int src, pos, rep; };                       // bias -> bias tiles (float offset from bias_off)
+struct BnfNElem { int gamma, beta, pos_sc, pos_sh, pos_shift, shift; };   // one slot of one net's extended input (gamma < 0: unused)
+
+struct BnfPackArgs {
+  const float *theta;
+  const BnfWElem *w; int n_w;
+  const BnfBElem *b; int n_b;
+  const BnfNElem *ne; int n_n;
+  float *blob, *sf;           // blob [blob_floats]; sigma fragments [set_floats]
+  int bias_off;
+  // effects blob: the outcome net's part of the blob, re-based
+  float *eblob; int f_frag0, e_frags, f_bias_tile0, e_bias_off, f_norm0, e_norm_off, f_shift0, e_shift_off, T0, norm_off, shift_off;
+};
+static __global__ void bnf_pack_kernel(BnfPackArgs a) {
+  const int i0 = blockIdx.x * blockDim.x + threadIdx.x, str = gridDim.x * blockDim.x;
+  for (int i = i0; i < a.n_w; i += str) {
+    const BnfWElem e = a.w[i];
+    const float lv = e.scale * a.theta[e.loc], sv = e.scale * (BNN_SCALE_EPS + softplus_acc(a.theta[e.rho]));
+    for (int c = 0; c < e.rep; ++c) {
+      a.blob[e.pos + 16 * c] = lv; a.sf[e.pos + 16 * c] = sv;
+      const int fr = (e.pos + 16 * c) - a.f_frag0 * 256;
+      if (fr >= 0 && fr < a.e_frags * 256) a.eblob[fr] = lv;
+    }
+  }
+  for (int i = i0; i < a.n_b; i += str) {
+    const BnfBElem e = a.b[i];
+    const float v = a.theta[e.src];
+    for (int c = 0; c < e.rep; ++c) {
+      a.blob[a.bias_off + e.pos + 4 * c] = v;
+      const int t = e.pos + 4 * c - 16 * a.f_bias_tile0;
+      if (t >= 0 && t < 16 * 8) a.eblob[a.e_bias_off + t] = v;
+    }
+  }
+  for (int i = i0; i < a.n_n; i += str) {
+    const BnfNElem e = a.ne[i];
+    const float sc = e.gamma >= 0 ? a.theta[e.gamma] / sqrtf(1.0f + BNN_BN_EPS) : 0.0f, sh = e.gamma >= 0 ? a.theta[e.beta] : 0.0f;
+    a.blob[e.pos_sc] = sc; a.blob[e.pos_sh] = sh;
+    ((int *)a.blob)[e.pos_shift] = e.shift;
+    const int n0 = e.pos_sc - a.norm_off - a.f_norm0, n1 = e.pos_sh - a.norm_off - a.f_norm0, s0 = e.pos_shift - a.shift_off - a.f_shift0;
+    if (n0 >= 0 && n0 < a.T0 * 32) { a.eblob[a.e_norm_off + n0] = sc; a.eblob[a.e_norm_off + n1] = sh; ((int *)a.eblob)[a.e_shift_off + s0] = e.shift; }
+  }
+}
+
+// dW = sigma * eps of every (block, state): grid (chunks, n_blocks * n_states).  Layer descriptors give the canonical element
+// range of each Flipout kernel; element idx of Philox call i = idx >> 2 (oracle/bnn.py draw_noise).
+struct BnfLayerDesc { int e_base, cnt, l, net_id; };
+struct BnfNoiseArgs {
+  BnfLayerDesc lay[14];
+  int n_lay;
+  const BnfWElem *w;
+  const float *sf;            // sigma fragments (positions of the FULL set)
+  int pos_base;               // subtracted from an element's position (effects sets hold the outcome net only)
+  float *dw; long long set_floats;
+  int n_states;
+  uint32_t k0, k1, stream0;
+  int block0;
+};
+static __global__ void bnf_noise_kernel(BnfNoiseArgs a) {
+  const int set = blockIdx.y, blk = set / a.n_states, s = set - blk * a.n_states;
+  const uint32_t k1 = a.k1 + (uint32_t)(a.block0 + blk), stream = a.stream0 + (uint32_t)s;
+  float *dw = a.dw + (long long)set * a.set_floats;
+  for (int d = 0; d < a.n_lay; ++d) {
+    const BnfLayerDesc L = a.lay[d];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (L.cnt + 3) >> 2; i += gridDim.x * blockDim.x) {
+      const f32x4 z = box_muller4(philox4x32_10((uint32_t)i, (uint32_t)L.l | ((uint32_t)L.net_id << 16), stream, BNN_TAG_EPS, a.k0, k1));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = 4 * i + u;
+        if (idx < L.cnt) {
+          const BnfWElem e = a.w[L.e_base + idx];
+          const float v = a.sf[e.pos] * z[u];
+          for (int c = 0; c < e.rep; ++c) dw[e.pos - a.pos_base + 16 * c] = v;
+        }
+      }
+    }
+  }
+}
+
+// Rademacher sign words of every (row, state) in the layer-aligned groups the sampler loads.  nets: bit 0 g, 1 h, 2 f.
+struct BnfSignArgs {
+  uint4 *g; uint32_t *gout; uint4 *h, *f;
+  long long n;
+  int bs, block0, n_states, nets;
+  uint32_t k0, k1, stream0;
+};
+static __global__ __launch_bounds__(256) void bnf_signs_kernel(BnfSignArgs a) {
+  const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int s = blockIdx.y;
+  if (row >= a.n) return;
+  const int blk = (int)(row / a.bs);
+  const uint32_t rib = (uint32_t)(row - (long long)blk * a.bs);
+  const uint32_t k1 = a.k1 + (uint32_t)(a.block0 + blk), stream = a.stream0 + (uint32_t)s;
+  if (a.nets & 1) {
+    uint32_t w[28];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) {
+      const uint4 t = philox4x32_10(rib, (uint32_t)c | ((uint32_t)BNN_G << 16), stream, BNN_TAG_SIGN, a.k0, k1);
+      w[4 * c] = t.x; w[4 * c + 1] = t.y; w[4 * c + 2] = t.z; w[4 * c + 3] = t.w;
+    }
+    uint4 *G = a.g + (long long)s * BNF_NG_G * a.n + row;
+    G[0] = make_uint4(w[0], w[1], w[2], 0u);
+#pragma unroll
+    for (int l = 1; l <= 4; ++l) G[(long long)l * a.n] = make_uint4(w[4 * l - 1], w[4 * l], w[4 * l + 1], w[4 * l + 2]);
+    G[5LL * a.n] = make_uint4(w[19], w[20], 0u, 0u);
+    uint4 *O = (uint4 *)(a.gout + ((long long)s * a.n + row) * BNF_GOUT);
+    O[0] = make_uint4(w[21], w[22], w[23], w[24]);
+    O[1] = make_uint4(w[25], w[26], w[27], 0u);
+  }
+#pragma unroll
+  for (int hn = 0; hn < 2; ++hn) {
+    if (!(a.nets & (2 << hn))) continue;
+    const uint32_t net_id = hn == 0 ? (uint32_t)BNN_H : (uint32_t)BNN_F;
+    uint32_t w[12];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const uint4 t = philox4x32_10(rib, (uint32_t)c | (net_id << 16), stream, BNN_TAG_SIGN, a.k0, k1);
+      w[4 * c] = t.x; w[4 * c + 1] = t.y; w[4 * c + 2] = t.z; w[4 * c + 3] = t.w;
+    }
+    uint4 *H = (hn == 0 ? a.h : a.f) + (long long)s * BNF_NG_H * a.n + row;
+    H[0] = make_uint4(w[0], w[1], w[2], 0u);
+    H[a.n] = make_uint4(w[3], w[4], w[5], w[6]);
+    H[2LL * a.n] = make_uint4(w[7], w[8], w[9], 0u);
+  }
+}

@@ -200,7 +200,7 @@ extern "C" int bgm_bnn_write(bgm_handle *h, int32_t what, const float *host, int
   BGM_HIP_CHECK(hipSetDevice(h->device));
   BGM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_));
   BGM_HIP_CHECK(hipMemcpy(dst, host, sizeof(float) * count, hipMemcpyHostToDevice));
-  s->packed_valid = false;
+  s->packed_valid = false; s->bnf_valid = false;
   return BGM_OK;
 }
 
@@ -270,7 +270,7 @@ extern "C" int bgm_bnn_theta_step(bgm_handle *h, const float *data_z, const int3
     hipLaunchKernelGGL(bnn_theta_step_kernel, dim3(3), dim3(BNN_THREADS), 0, (hipStream_t)stream_, a);
   }
   BGM_HIP_CHECK(hipGetLastError());
-  if (apply) s->packed_valid = false;
+  if (apply) { s->packed_valid = false; s->bnf_valid = false; }
   return BGM_OK;
 }
 
@@ -287,7 +287,7 @@ extern "C" int bgm_bnn_theta_apply(bgm_handle *h, float lr_theta, void *stream_)
                        s->m_dev + n.off, s->v_dev + n.off, s->grad_dev + n.off, n.n_params, ad);
   }
   BGM_HIP_CHECK(hipGetLastError());
-  s->packed_valid = false;
+  s->packed_valid = false; s->bnf_valid = false;
   return BGM_OK;
 }
 

@@ -230,7 +230,7 @@ extern "C" int bgm_bnn_egm_gen_step(bgm_handle *h, const float *z_dev, const int
   BnnEgmArgs a = e->base;
   a.z = z_dev; a.idx = idx_dev; a.v_ = v_dev; a.x_ = x_dev; a.y_ = y_dev; a.out = out_dev; a.apply = apply ? 1 : 0;
   a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32); a.stream = stream_id;
-  if (apply) { e->t_g += 1; s->packed_valid = false; }
+  if (apply) { e->t_g += 1; s->packed_valid = false; s->bnf_valid = false; }
   a.adam = bnn_egm_adam(e->cfg.lr, std::max<long long>(1, e->t_g));
   if (e->chain_gen_lds > 0) {
     hipLaunchKernelGGL(bnn_egm_gen_noise_kernel, dim3(ECB_CALLS * ECB_NOISE_PARTS), dim3(EGM_THREADS), 0, (hipStream_t)stream_, a, e->tab_dev);

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "bgm_host.h"
+#include "bnf_host.h"
 #include "bnn_sample_kernels.h"
 #include "bnn_state.h"
 
@@ -141,6 +142,8 @@ extern "C" int bgm_bnn_logpost(bgm_handle *h, const float *x, const float *y, co
   if (!x || !y || !v || !z || !out || n < 1 || block_rows < 2) { bgm_set_error("bgm_bnn_logpost: bad argument"); return BGM_E_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
+  rc = bnf_logpost(h, s, x, y, v, z, n, block_rows, block0, seed, stream_id, out, stream);     // inference-mode normalisation, default shapes
+  if (rc <= 0) return rc;
   const int n_blocks = (int)((n + block_rows - 1) / block_rows);
   BnsBuf b;
   rc = bns_buffers(h, s, pl, n, n_blocks, (long long)n_blocks * pl.set_ghf, b, stream);
@@ -179,6 +182,8 @@ extern "C" int bgm_bnn_mh_run(bgm_handle *h, const bgm_bnn_mh_args *g, void *str
   if (g->effect < 0 || g->effect > 2) { bgm_set_error("bgm_bnn_mh_run: bad effect"); return BGM_E_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
+  rc = bnf_mh_run(h, s, g, stream);
+  if (rc <= 0) return rc;
   const long long n = g->n;
   const int bs = g->block_rows, n_blocks = (int)((n + bs - 1) / bs), q = s->q;
   BnsBuf b;
@@ -363,6 +368,8 @@ extern "C" int bgm_bnn_effects(bgm_handle *h, const float *draws, int64_t n, int
   if (effect == 2 && !ite) { bgm_set_error("bgm_bnn_effects: ITE needs ite_dev"); return BGM_E_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
+  rc = bnf_effects(h, s, draws, n, block_rows, block0, row_base, n_keep, it0, seed, effect, sample_y, x_values, n_doses, adrf_sum, ite, stream);
+  if (rc <= 0) return rc;
   const int bs = block_rows, n_blocks = (int)((n + bs - 1) / bs), q = s->q;
   const int nd = effect == 1 ? n_doses : 2;
   BnsBuf b;

@@ -23,15 +23,21 @@ struct BnnState {
   bool packed_valid = false;
   float *samp_dev = nullptr;
   size_t samp_cap = 0;
+  void *bnf = nullptr;         // BnfState (bnf_api.hip): the fixed-normalisation sampling path's tables, packed blob, buffers
+  bool bnf_valid = false, bnf_unsupported = false;
   void *egm = nullptr;         // BnnEgmState (bnn_egm_api.hip)
   void *chain = nullptr;       // BnnFitChain (bnn_api.hip): tables / workspace of the row-tile-chain step kernels, or NULL
 };
 
 void bgm_bnn_egm_free(void *egm_state);
+void bnf_free(void *state);
 
 inline void bnn_free_sampler(BnnState *s) {
   if (s->samp_dev) hipFree(s->samp_dev);
   s->samp_dev = nullptr;
   s->samp_cap = 0;
   s->packed_valid = false;
+  if (s->bnf) bnf_free(s->bnf);
+  s->bnf = nullptr;
+  s->bnf_valid = false;
 }

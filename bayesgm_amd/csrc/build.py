@@ -13,8 +13,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libbgm_hip.so")
-SOURCES = ["causal_api.hip", "causal_bx3_api.hip", "causal_prior_api.hip", "aux_kernels.hip", "fit_api.hip", "bgm_api.hip", "egm_api.hip", "bgm_egm_api.hip", "bnn_api.hip", "bnn_sample_api.hip", "bnn_egm_api.hip", "bnn_egm_gen_chain_a.hip", "bnn_egm_gen_chain_b.hip", "bnn_egm_gen_chain_c.hip", "bnn_egm_gen_chain_d.hip", "bgmb_api.hip", "bgmb_egm_api.hip"]
-HEADERS = ["bgm_device.h", "causal_kernels.h", "causal_bx3_kernels.h", "fit_kernels.h", "fit_types.h", "bgm_kernels.h", "bgm_fit_kernels.h", "bgm_state.h", "bgm_host.h", "egm_kernels.h", "egm_chain.h", "egm_chain_gen.h", "egm_chain_bnn.h", "bnn_egm_gen_chain.inc", "fit_chain.h", "bgm_egm_kernels.h", "bnn_kernels.h", "bnn_state.h", "bnn_sample_kernels.h", "bnn_egm_kernels.h", "bgmb_kernels.h", "bgmb_state.h", "bgmb_egm_kernels.h", os.path.join("..", "..", "include", "bgm_hip.h")]
+SOURCES = ["causal_api.hip", "causal_bx3_api.hip", "causal_prior_api.hip", "aux_kernels.hip", "fit_api.hip", "bgm_api.hip", "egm_api.hip", "bgm_egm_api.hip", "bnn_api.hip", "bnn_sample_api.hip", "bnf_api.hip", "bnn_egm_api.hip", "bnn_egm_gen_chain_a.hip", "bnn_egm_gen_chain_b.hip", "bnn_egm_gen_chain_c.hip", "bnn_egm_gen_chain_d.hip", "bgmb_api.hip", "bgmb_egm_api.hip"]
+HEADERS = ["bgm_device.h", "causal_kernels.h", "causal_bx3_kernels.h", "fit_kernels.h", "fit_types.h", "bgm_kernels.h", "bgm_fit_kernels.h", "bgm_state.h", "bgm_host.h", "egm_kernels.h", "egm_chain.h", "egm_chain_gen.h", "egm_chain_bnn.h", "bnn_egm_gen_chain.inc", "fit_chain.h", "bgm_egm_kernels.h", "bnn_kernels.h", "bnn_state.h", "bnn_sample_kernels.h", "bnf_kernels.h", "bnf_host.h", "bnn_egm_kernels.h", "bgmb_kernels.h", "bgmb_state.h", "bgmb_egm_kernels.h", os.path.join("..", "..", "include", "bgm_hip.h")]
 FLAGS = os.environ.get("BGM_EXTRA_FLAGS", "").split() + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wno-unused-value", "-Wno-unused-result"]
 
@@ -35,12 +35,26 @@ def build(force=False, defines=(), verbose=True, out=None):
         return OUT
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
 
+    def fresh(obj):
+        """obj is newer than every file its last compilation read (hipcc -MMD dependency file) and was built with the same flags"""
+        dep, tag = obj + ".d", obj + ".flags"
+        if not (os.path.exists(obj) and os.path.exists(dep) and os.path.exists(tag)):
+            return False
+        if open(tag).read() != " ".join(FLAGS + list(defines)):
+            return False
+        words = open(dep).read().replace("\\\n", " ").split()
+        t = os.path.getmtime(obj)
+        return all(os.path.exists(w) and os.path.getmtime(w) <= t for w in words[1:] if not w.endswith(":"))
+
     def cc(src):
         obj = os.path.join(HERE, "build", os.path.basename(OUT) + "." + os.path.basename(src) + ".o")
-        cmd = [hipcc] + FLAGS + ["-D" + d for d in defines] + ["-I", HERE, "-c", src, "-o", obj]
+        if not force and fresh(obj):
+            return obj
+        cmd = [hipcc] + FLAGS + ["-D" + d for d in defines] + ["-I", HERE, "-MMD", "-MF", obj + ".d", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        open(obj + ".flags", "w").write(" ".join(FLAGS + list(defines)))
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
