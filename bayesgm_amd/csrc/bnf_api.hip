@@ -28,6 +28,7 @@ struct BnfState {
   float *dw_dev = nullptr; size_t dw_cap = 0;          // perturbation sets
   void *sg_dev = nullptr; size_t sg_cap = 0;           // sign groups
   float *pair_dev = nullptr;                           // (1, 0): the two treatments of a binary model
+  unsigned *queue_dev = nullptr;                       // [16] item counters: 0..7 sampler, 8..15 effects
   int lds_mh = 0, lds_eff = 0;
 };
 
@@ -126,7 +127,7 @@ bool bnf_build(const BnnState *s, BnfState &st, std::vector<BnfWElem> &W, std::v
 void bnf_release(BnfState *st) {
   if (!st) return;
   for (void *p : {(void *)st->w_dev, (void *)st->b_dev, (void *)st->n_dev, (void *)st->blob_dev, (void *)st->eblob_dev, (void *)st->sf_dev,
-                  (void *)st->dw_dev, st->sg_dev, (void *)st->pair_dev})
+                  (void *)st->dw_dev, st->sg_dev, (void *)st->pair_dev, (void *)st->queue_dev})
     if (p) hipFree(p);
   delete st;
 }
@@ -220,7 +221,8 @@ int bnf_session(bgm_handle *h, BnnState *s, BnfState *&st, hipStream_t stream) {
               up((void **)&n->n_dev, N.data(), N.size() * sizeof(BnfNElem)) && up((void **)&n->pair_dev, pair_host, sizeof(pair_host));
     ok = ok && hipMalloc((void **)&n->blob_dev, sizeof(float) * n->P.blob_floats) == hipSuccess &&
          hipMalloc((void **)&n->eblob_dev, sizeof(float) * n->P.e_blob_floats) == hipSuccess &&
-         hipMalloc((void **)&n->sf_dev, sizeof(float) * n->P.set_floats) == hipSuccess;
+         hipMalloc((void **)&n->sf_dev, sizeof(float) * n->P.set_floats) == hipSuccess &&
+         hipMalloc((void **)&n->queue_dev, 16 * sizeof(unsigned)) == hipSuccess;
     if (!ok) { bnf_release(n); bgm_set_error("bnf: device allocation failed"); return BGM_E_HIP; }
     s->bnf = n; s->bnf_valid = false;
     st = n;
@@ -287,10 +289,11 @@ void launch_noise(const BnfState *st, int first_lay, int n_lay, int pos_base, fl
   hipLaunchKernelGGL(bnf_noise_kernel, dim3(n_lay > 4 ? 8 : 2, n_blocks * n_states), dim3(256), 0, stream, na);
 }
 
-void launch_signs(const SgLayout &L, long long n, int bs, int block0, int n_states, int nets, uint64_t seed, uint32_t stream0, hipStream_t stream) {
+void launch_signs(const SgLayout &L, long long n, int bs, int block0, int n_states, int nets, uint64_t seed, uint32_t stream0, unsigned *queue,
+                  hipStream_t stream) {
   BnfSignArgs sa{};
   sa.g = L.g; sa.gout = L.gout; sa.h = L.h; sa.f = L.f; sa.n = n; sa.bs = bs; sa.block0 = block0; sa.n_states = n_states; sa.nets = nets;
-  sa.k0 = (uint32_t)seed; sa.k1 = (uint32_t)(seed >> 32); sa.stream0 = stream0;
+  sa.k0 = (uint32_t)seed; sa.k1 = (uint32_t)(seed >> 32); sa.stream0 = stream0; sa.queue = queue;
   hipLaunchKernelGGL(bnf_signs_kernel, dim3((unsigned)((n + 255) / 256), n_states), dim3(256), 0, stream, sa);
 }
 
@@ -319,14 +322,14 @@ int bnf_logpost(bgm_handle *h, BnnState *s, const float *x, const float *y, cons
   if (rc) return rc;
   L = sg_layout(st->sg_dev, n, 1, 0);
   launch_noise(st, 0, 14, 0, st->dw_dev, P.set_floats, n_blocks, 1, seed, stream_id, block0, stream);
-  launch_signs(L, n, block_rows, block0, 1, 7, seed, stream_id, stream);
+  launch_signs(L, n, block_rows, block0, 1, 7, seed, stream_id, st->queue_dev, stream);
   BnfMhArgs a{};
   a.pl = P; a.blob = st->blob_dev; a.dw = st->dw_dev;
   a.sg.g = L.g; a.sg.gout = L.gout; a.sg.h = L.h; a.sg.f = L.f;
   a.x = x; a.y = y; a.v = v; a.z = const_cast<float *>(z); a.n = n; a.row_base = 0;
   a.bs = block_rows; a.n_blocks = n_blocks; a.block0 = block0;
   a.groups_per_block = ((block_rows + 15) / 16 + c.R - 1) / c.R; a.n_items = n_blocks * a.groups_per_block; a.n_states = 1;
-  a.mode = 0; a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32); a.out = out;
+  a.mode = 0; a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32); a.out = out; a.queue = st->queue_dev;
   rc = set_lds(fn, st->lds_mh);
   if (rc) return rc;
   hipLaunchKernelGGL(fn, dim3(grid_for(h)), dim3(64 * c.W), st->lds_mh, stream, a);
@@ -344,13 +347,13 @@ int effects_of(bgm_handle *h, BnfState *st, const float *z, long long n, int bs,
   EffFn fn = eff_fn(st->KSc, c);
   const long long eset = (long long)P.e_frags * 256;
   launch_noise(st, 10, 4, P.ff * 256, dw_eff, eset, n_blocks, n_doses, seed, stream0, block0, stream);
-  launch_signs(L, n, bs, block0, n_doses, 4, seed, stream0, stream);
+  launch_signs(L, n, bs, block0, n_doses, 4, seed, stream0, st->queue_dev + 8, stream);
   BnfEffArgs ea{};
   ea.pl = P; ea.eblob = st->eblob_dev; ea.dw = dw_eff; ea.sgf = L.f; ea.z = z; ea.n = n; ea.row_base = row_base;
   ea.bs = bs; ea.n_blocks = n_blocks; ea.block0 = block0;
   ea.groups_per_block = ((bs + 15) / 16 + c.R - 1) / c.R; ea.n_items = n_blocks * ea.groups_per_block; ea.n_doses = n_doses;
   ea.xvals = xvals; ea.k0 = (uint32_t)seed; ea.k1 = (uint32_t)(seed >> 32); ea.sample_y = sample_y; ea.it_noise = it_noise;
-  ea.sum_out = sum_out; ea.sum_stride = sum_stride; ea.ite_out = ite_out; ea.ite_stride = ite_stride;
+  ea.sum_out = sum_out; ea.sum_stride = sum_stride; ea.ite_out = ite_out; ea.ite_stride = ite_stride; ea.queue = st->queue_dev + 8;
   int rc = set_lds(fn, st->lds_eff);
   if (rc) return rc;
   hipLaunchKernelGGL(fn, dim3(grid_for(h)), dim3(64 * c.W), st->lds_eff, stream, ea);
@@ -386,14 +389,20 @@ int bnf_mh_run(bgm_handle *h, BnnState *s, const bgm_bnn_mh_args *g, hipStream_t
   a.bs = bs; a.n_blocks = n_blocks; a.block0 = g->block0;
   a.groups_per_block = ((bs + 15) / 16 + c.R - 1) / c.R; a.n_items = n_blocks * a.groups_per_block; a.n_states = 2;
   a.mode = 1; a.q_sd = g->q_sd; a.q_sd_blocks = g->q_sd_blocks_dev;
-  a.k0 = (uint32_t)g->seed; a.k1 = (uint32_t)(g->seed >> 32); a.acc_count = g->acc_count_dev;
+  a.k0 = (uint32_t)g->seed; a.k1 = (uint32_t)(g->seed >> 32); a.acc_count = g->acc_count_dev; a.queue = st->queue_dev;
   rc = set_lds(fn, st->lds_mh);
   if (rc) return rc;
   const int grid = grid_for(h);
+#ifdef BNF_PROF
+  static unsigned long long *prof_dev = nullptr;
+  if (!prof_dev) hipMalloc((void **)&prof_dev, 256);
+  hipMemsetAsync(prof_dev, 0, 256, stream);
+  a.prof = prof_dev;
+#endif
   for (int i = 0; i < g->n_iters; ++i) {
     const int it = g->it_begin + i;
     launch_noise(st, 0, 14, 0, st->dw_dev, P.set_floats, n_blocks, 2, g->seed, 2u * (uint32_t)it, g->block0, stream);
-    launch_signs(L, n, bs, g->block0, 2, 7, g->seed, 2u * (uint32_t)it, stream);
+    launch_signs(L, n, bs, g->block0, 2, 7, g->seed, 2u * (uint32_t)it, st->queue_dev, stream);
     a.it = it; a.init = (i == 0 && g->init) ? 1 : 0;
     a.acc_blocks = g->acc_blocks_dev ? g->acc_blocks_dev + (long long)i * n_blocks : nullptr;
     hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * c.W), st->lds_mh, stream, a);
@@ -410,6 +419,20 @@ int bnf_mh_run(bgm_handle *h, BnnState *s, const bgm_bnn_mh_args *g, hipStream_t
       }
     }
   }
+#ifdef BNF_PROF
+  {
+    unsigned long long hp[32];
+    hipStreamSynchronize(stream);
+    hipMemcpy(hp, prof_dev, sizeof(hp), hipMemcpyDeviceToHost);
+    const double d = (double)grid * std::max(1, g->n_iters);
+    fprintf(stderr, "[BNF_PROF] cycles per workgroup-launch (wave 0, R=%d W=%d): prologue %.0f g-first %.0f g-hidden %.0f g-last %.0f h %.0f f %.0f rest %.0f\n",
+            c.R, c.W, hp[0] / d, hp[1] / d, hp[2] / d, hp[3] / d, hp[4] / d, hp[5] / d, hp[6] / d);
+    const double dw = d * c.W;
+    fprintf(stderr, "[BNF_PROF] wave busy cycles per launch: mean %.0f, max (over all launches) %llu; by wave index:", hp[7] / dw, hp[8]);
+    for (int w = 0; w < c.W; ++w) fprintf(stderr, " %.0f", hp[9 + w] / d);
+    fprintf(stderr, "\n");
+  }
+#endif
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
 }

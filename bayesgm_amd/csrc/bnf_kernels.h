@@ -38,6 +38,19 @@
 // hipcc sinks every load to just above its first use; a compiler-only memory fence behind a group of prefetch loads keeps them
 // where they were requested (one output tile / one layer / one dose ahead of their use)
 #define BNF_PIN() asm volatile("" ::: "memory")
+// -D BNF_PROF: cycle stamps of wave 0 of every workgroup per section (0 prologue, 1 g first, 2 g hidden, 3 g last, 4 h, 5 f, 6 accept / rest),
+// summed into BnfMhArgs::prof
+#ifdef BNF_PROF
+#define BNF_T(k) { const unsigned long long t__ = __builtin_readcyclecounter(); bnf_tp[k] += t__ - bnf_tl; bnf_tl = t__; }
+#define BNF_PROF_PARAM , unsigned long long (&bnf_tp)[8], unsigned long long &bnf_tl
+#define BNF_PROF_ARG , bnf_tp, bnf_tl
+#else
+#define BNF_T(k)
+#define BNF_PROF_PARAM
+#define BNF_PROF_ARG
+#endif
+
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
 
 struct BnfPlan {
   int q, p, z0, z1, z2, binary;
@@ -58,8 +71,19 @@ struct BnfSigns {             // n_states = 2 (MH: proposal, current) or n_doses
   const uint4 *h, *f;         // [n_states][BNF_NG_H][n]
 };
 
+// softplus_f (bgm_device.h) without control flow: both branches of its small-argument split are evaluated and selected (hipcc
+// turns the plain ternary into an exec-mask branch around the v_log_f32, which splits the scheduling regions of the callers)
+__device__ __forceinline__ float bnf_softplus(float x) {
+  const float e = fast_exp(-fabsf(x));
+  float l = fast_log(1.0f + e), sm = e * (1.0f - 0.5f * e);
+  asm volatile("" : "+v"(l), "+v"(sm));
+  return vmax(x, 0.0f) + ((e < 2.44140625e-4f) ? sm : l);
+}
 // +-1.0f from the bit at position 31 of m
-__device__ __forceinline__ float bnf_pm1(uint32_t m) { return __builtin_bit_cast(float, (m & 0x80000000u) | 0x3f800000u); }
+// The mask comes out of an (opaque, CSE-able) asm so that it lives in an SGPR: with the literal 0x80000000 the compiler emits
+// v_and_b32 + v_or_b32 (VOP3 takes no literal on gfx9), with a register operand one v_and_or_b32.
+__device__ __forceinline__ uint32_t bnf_k80() { uint32_t k; asm("s_mov_b32 %0, 0x80000000" : "=s"(k)); return k; }
+__device__ __forceinline__ float bnf_pm1(uint32_t m) { return __builtin_bit_cast(float, (m & bnf_k80()) | 0x3f800000u); }
 // sign words are pre-shifted per lane so that bit (4 gg + 19) of the word sits at position 31: feature 16 t + 4 gg + r of a
 // 32-feature word <-> bit B = 16 (t & 1) + r of the lane's view, at position 12 + B
 __device__ __forceinline__ uint32_t bnf_preshift(uint32_t w, int g) { return w << (12 - 4 * g); }
@@ -82,7 +106,7 @@ struct BnfLds {
 template <int KS, int R>
 __device__ __forceinline__ void bnf_first(const f32x4 *LF, const f32x4 *__restrict__ DW, const f32x4 *BL, const f32x4 *NORM, const int4 *SHIFT,
                                           int lane, int g, const float (&ze)[R][KS], const uint32_t (&w_in)[R], const uint32_t (&wo)[R][2],
-                                          const uint32_t (&wi)[R][2], float (&h)[R][4][4], float (&hs)[R][4][4]) {
+                                          const uint4 (&Gn)[R], float (&h)[R][4][4], float (&hs)[R][4][4]) {
   constexpr int T0 = (KS + 3) / 4;
   f32x4 fd[4][T0];
 #pragma unroll
@@ -135,7 +159,7 @@ __device__ __forceinline__ void bnf_first(const f32x4 *LF, const f32x4 *__restri
         const float y = fmaf(a2[rt][r], bnf_sign_rt(wo[rt][mt >> 1], 16 * (mt & 1) + r), a1[rt][r]);
         const float v = lrelu_s(y);
         h[rt][mt][r] = v;
-        hs[rt][mt][r] = v * bnf_sign_rt(wi[rt][mt >> 1], 16 * (mt & 1) + r);
+        hs[rt][mt][r] = v * bnf_sign_rt(bnf_preshift(mt < 2 ? Gn[rt].x : Gn[rt].y, g), 16 * (mt & 1) + r);
       }
   }
 }
@@ -144,15 +168,22 @@ __device__ __forceinline__ void bnf_first(const f32x4 *LF, const f32x4 *__restri
 // hidden layer 64 -> 64 of g: h, hs are replaced by the next layer's inputs.  fd: this layer's first tile's perturbation
 // fragments (requested by the caller); on return the fragments at DWnext (the next layer's / section's first tile).
 // ---------------------------------------------------------------------------------------------
+// development ablations (never defined in the product build): BNF_ABL_NODW reads the perturbation fragments from LDS (the loc
+// fragments) instead of L2; BNF_ABL_NOEPI replaces the sign / activation epilogues of g's hidden and last layers by a copy
+#ifdef BNF_ABL_NODW
+#define BNF_DWSRC(dw, lf) (lf)
+#else
+#define BNF_DWSRC(dw, lf) (dw)
+#endif
 template <int R>
 __device__ __forceinline__ void bnf_hidden(const f32x4 *LF, const f32x4 *__restrict__ DW, const f32x4 *__restrict__ DWnext, const f32x4 *BL, int lane,
-                                           int g, const uint32_t (&wo)[R][2], const uint32_t (&wi)[R][2], float (&h)[R][4][4],
+                                           int g, const uint32_t (&wo)[R][2], const uint4 (&Gn)[R], float (&h)[R][4][4],
                                            float (&hs)[R][4][4], f32x4 (&fd)[4]) {
   float hn[R][4][4], hsn[R][4][4];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     f32x4 fn[4];
-    const f32x4 *nx = (mt < 3) ? DW + (mt + 1) * 4 * 64 : DWnext;
+    const f32x4 *nx = (mt < 3) ? BNF_DWSRC(DW, LF) + (mt + 1) * 4 * 64 : BNF_DWSRC(DWnext, LF);
 #pragma unroll
     for (int t = 0; t < 4; ++t) fn[t] = nx[t * 64 + lane];
     BNF_PIN();
@@ -175,10 +206,14 @@ __device__ __forceinline__ void bnf_hidden(const f32x4 *LF, const f32x4 *__restr
     for (int rt = 0; rt < R; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
+#ifdef BNF_ABL_NOEPI
+        hn[rt][mt][r] = a1[rt][r]; hsn[rt][mt][r] = a2[rt][r];
+#else
         const float y = fmaf(a2[rt][r], bnf_sign_rt(wo[rt][mt >> 1], 16 * (mt & 1) + r), a1[rt][r]);
         const float v = lrelu_s(y);
         hn[rt][mt][r] = v;
-        hsn[rt][mt][r] = v * bnf_sign_rt(wi[rt][mt >> 1], 16 * (mt & 1) + r);
+        hsn[rt][mt][r] = v * bnf_sign_rt(bnf_preshift(mt < 2 ? Gn[rt].x : Gn[rt].y, g), 16 * (mt & 1) + r);      // Gn: requested at the layer's start, first touched here
+#endif
       }
 #pragma unroll
     for (int t = 0; t < 4; ++t) fd[t] = fn[t];
@@ -214,14 +249,15 @@ __device__ __forceinline__ void bnf_head(const f32x4 *LF, const f32x4 *__restric
   BNF_PIN();
   float h1[R][4][4], hs1[R][4][4];
   {
-    uint32_t w_in[R], wo[R][2], wi[R][2];
+    uint32_t w_in[R], wo[R][2];
+    uint4 Gn[R];
 #pragma unroll
     for (int rt = 0; rt < R; ++rt) {
       w_in[rt] = G[rt][0].x;
       wo[rt][0] = bnf_preshift(G[rt][0].y, g); wo[rt][1] = bnf_preshift(G[rt][0].z, g);
-      wi[rt][0] = bnf_preshift(G[rt][1].x, g); wi[rt][1] = bnf_preshift(G[rt][1].y, g);
+      Gn[rt] = G[rt][1];
     }
-    bnf_first<KS, R>(LF, DW, BL, NORM, SHIFT, lane, g, ze, w_in, wo, wi, h1, hs1);
+    bnf_first<KS, R>(LF, DW, BL, NORM, SHIFT, lane, g, ze, w_in, wo, Gn, h1, hs1);
   }
   // layer 2: 64 -> 32
   const f32x4 *L2 = LF + 4 * T0 * 64;
@@ -324,19 +360,23 @@ struct BnfMhArgs {
   uint32_t k0, k1;
   float *out;
   unsigned *acc_count, *acc_blocks;
+  unsigned *queue;                     // [8] item counters, one per XCD (zeroed by bnf_signs_kernel)
+  unsigned long long *prof;            // -D BNF_PROF
 };
 
 template <int KS, int R>
 __device__ __forceinline__ void bnf_logpost_rows(const BnfMhArgs &a, const BnfLds &L, int lane, int j, int g, long long blk_lo, const int (&rib)[R],
                                                  const float (&ze)[R][KS], const float (&xr)[R], const float (&yr)[R], const float *dwset, int s,
-                                                 const float (&zz)[R], float (&lp)[R]) {
+                                                 const float (&zz)[R], float (&lp)[R] BNF_PROF_PARAM) {
   constexpr int T0 = (KS + 3) / 4;
   const BnfPlan &P = a.pl;
   const int p = P.p;
   const f32x4 *DW = (const f32x4 *)dwset;
   BGM_NO_HOIST();       // the LDS-resident fragments never change: without a fence LICM hoists their reads out of the item loop and spills
+  BNF_T(0);
   // ---- g
   float ssq[R], rawv[R];
+  uint4 GH[R][BNF_NG_H];       // sign groups of the h call: requested before g's last layer, first touched after it
   {
     float h[R][4][4], hs[R][4][4];
     // wave-uniform bases of the block's rows; per-lane offsets stay 32-bit
@@ -345,19 +385,17 @@ __device__ __forceinline__ void bnf_logpost_rows(const BnfMhArgs &a, const BnfLd
 #pragma unroll
     for (int rt = 0; rt < R; ++rt) { Gc[rt] = SG[rib[rt]]; Gn[rt] = (SG + a.n)[rib[rt]]; }
     BNF_PIN();
-    uint32_t wo[R][2], wi[R][2];
+    uint32_t wo[R][2];
     {
       uint32_t w_in[R];
 #pragma unroll
       for (int rt = 0; rt < R; ++rt) {
         w_in[rt] = Gc[rt].x;
         wo[rt][0] = bnf_preshift(Gc[rt].y, g); wo[rt][1] = bnf_preshift(Gc[rt].z, g);
-        wi[rt][0] = bnf_preshift(Gn[rt].x, g); wi[rt][1] = bnf_preshift(Gn[rt].y, g);
       }
-      bnf_first<KS, R>(L.frag + P.fg0 * 64, DW + P.fg0 * 64, L.bias + 4 * P.bg0, L.norm, L.shift, lane, g, ze, w_in, wo, wi, h, hs);
+      bnf_first<KS, R>(L.frag + P.fg0 * 64, DW + P.fg0 * 64, L.bias + 4 * P.bg0, L.norm, L.shift, lane, g, ze, w_in, wo, Gn, h, hs);
     }
-#pragma unroll
-    for (int rt = 0; rt < R; ++rt) { wo[rt][0] = bnf_preshift(Gn[rt].z, g); wo[rt][1] = bnf_preshift(Gn[rt].w, g); }
+    BNF_T(1);
     f32x4 fd[4];
     {
       const f32x4 *D = DW + P.fgh * 64;
@@ -366,34 +404,35 @@ __device__ __forceinline__ void bnf_logpost_rows(const BnfMhArgs &a, const BnfLd
     }
 #pragma nounroll
     for (int l = 1; l <= 4; ++l) {
+      // out-sign words of this layer: the second half of the group requested one layer ago; the next group is requested now and
+      // first touched in this layer's first epilogue
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) { wo[rt][0] = bnf_preshift(Gn[rt].z, g); wo[rt][1] = bnf_preshift(Gn[rt].w, g); }
 #pragma unroll
       for (int rt = 0; rt < R; ++rt) Gn[rt] = (SG + (long long)(l + 1) * a.n)[rib[rt]];
       BNF_PIN();
-#pragma unroll
-      for (int rt = 0; rt < R; ++rt) { wi[rt][0] = bnf_preshift(Gn[rt].x, g); wi[rt][1] = bnf_preshift(Gn[rt].y, g); }
       const int fo = (P.fgh + 16 * (l - 1)) * 64;
-      bnf_hidden<R>(L.frag + fo, DW + fo, DW + fo + 16 * 64, L.bias + 4 * (P.bgh + 4 * (l - 1)), lane, g, wo, wi, h, hs, fd);
+      bnf_hidden<R>(L.frag + fo, DW + fo, DW + fo + 16 * 64, L.bias + 4 * (P.bgh + 4 * (l - 1)), lane, g, wo, Gn, h, hs, fd);
+    }
+    BNF_T(2);
+    {
+      const uint4 *SH = a.sg.h + ((long long)s * BNF_NG_H * a.n + blk_lo);
 #pragma unroll
-      for (int rt = 0; rt < R; ++rt) { wo[rt][0] = bnf_preshift(Gn[rt].z, g); wo[rt][1] = bnf_preshift(Gn[rt].w, g); }
+      for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+        for (int k = 0; k < BNF_NG_H; ++k) GH[rt][k] = (SH + (long long)k * a.n)[rib[rt]];
     }
     // last layer: 64 -> p + 1, tile by tile against the data row; fd holds tile 0's perturbation fragments
     const int NTL = P.NTL;
     const f32x4 *LFl = L.frag + P.fgl * 64, *DWl = DW + P.fgl * 64, *BLl = L.bias + 4 * P.bgl;
     const uint32_t *GO = a.sg.gout + ((long long)s * a.n + blk_lo) * BNF_GOUT;
     const float *vblk = a.v + blk_lo * p;
-    const bool vec = (p & 3) == 0;
+    // the lane's four columns of the data row as ONE 16-byte request (dword-aligned: p need not be a multiple of 4); nothing is
+    // done with the value before the tile that consumes it, so the request stays in flight for a whole tile.  Only the last tile
+    // has columns >= p: it clamps the address and masks at its use.
     auto load_v = [&](int rt, int mt) __attribute__((always_inline)) -> f32x4 {
-      const int u0 = 16 * mt + 4 * g;
-      const float *vr = vblk + rib[rt] * p;
-      f32x4 o;
-      if (vec) {
-        o = *(const f32x4 *)(vr + min(u0, p - 4));
-        if (u0 >= p) o = f32x4{0.f, 0.f, 0.f, 0.f};
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const float t = vr[min(u0 + r, p - 1)]; o[r] = (u0 + r < p) ? t : 0.0f; }
-      }
-      return o;
+      const float *vr = vblk + rib[rt] * p + min(16 * mt + 4 * g, p - 4);
+      return *(const f32x4_u *)vr;
     };
     f32x4 vn[R];
     uint32_t wn[R];
@@ -403,7 +442,19 @@ __device__ __forceinline__ void bnf_logpost_rows(const BnfMhArgs &a, const BnfLd
       f32x4 a1[R], a2[R];
       const f32x4 b = BLl[4 * mt + g];
 #pragma unroll
-      for (int rt = 0; rt < R; ++rt) { a1[rt] = b - vc[rt]; a2[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int rt = 0; rt < R; ++rt) {
+        a1[rt] = b - vc[rt];
+        if (last) {      // columns u >= p (the variance column and the padding) have no data; a clamped request is shifted back
+          const int u0 = 16 * mt + 4 * g, sh = u0 - min(u0, p - 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float vv = sh == 0 ? vc[rt][r] : sh == 1 ? (r < 3 ? vc[rt][r + 1 > 3 ? 3 : r + 1] : 0.f) : sh == 2 ? (r < 2 ? vc[rt][r + 2 > 3 ? 3 : r + 2] : 0.f)
+                                   : sh == 3 ? (r < 1 ? vc[rt][3] : 0.f) : 0.f;
+            a1[rt][r] = b[r] - (u0 + r < p ? vv : 0.0f);
+          }
+        }
+        a2[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const f32x4 fa = LFl[(mt * 4 + t) * 64 + lane];
@@ -421,7 +472,11 @@ __device__ __forceinline__ void bnf_logpost_rows(const BnfMhArgs &a, const BnfLd
         const uint32_t wsh = bnf_preshift(wc[rt], g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+#ifdef BNF_ABL_NOEPI
+          const float d = a1[rt][r] + a2[rt][r];
+#else
           const float d = fmaf(a2[rt][r], bnf_sign_rt(wsh, pos + r), a1[rt][r]);
+#endif
           if (!last) ssq[rt] = fmaf(d, d, ssq[rt]);
           else {
             const int u = 16 * mt + 4 * g + r;
@@ -442,17 +497,18 @@ __device__ __forceinline__ void bnf_logpost_rows(const BnfMhArgs &a, const BnfLd
 #pragma unroll
       for (int rt = 0; rt < R; ++rt) { vn[rt] = load_v(rt, mt + 1); wn[rt] = GO[rib[rt] * BNF_GOUT + ((mt + 1) >> 1)]; }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) fd[t] = DWl[((mt + 1) * 4 + t) * 64 + lane];
+      for (int t = 0; t < 4; ++t) fd[t] = BNF_DWSRC(DWl, LFl)[((mt + 1) * 4 + t) * 64 + lane];
       BNF_PIN();
       tile(mt, false, vc, wc, fc);
     }
     tile(NTL - 1, true, vn, wn, fd);
+    BNF_T(3);
   }
   float part[R];
 #pragma unroll
   for (int rt = 0; rt < R; ++rt) {
     const float rw = sum_over_g(rawv[rt]);
-    const float s2 = softplus_f(rw) + BGM_EPS;
+    const float s2 = bnf_softplus(rw) + BGM_EPS;
     // the per-lane share of -(ssq / (2 s2) + |z|^2 / 2); the log term is added once after the cross-lane sum
     part[rt] = -(ssq[rt] * fast_rcp(2.0f * s2) + 0.5f * zz[rt]);
     lp[rt] = -0.5f * (float)p * fast_log(s2);
@@ -461,34 +517,33 @@ __device__ __forceinline__ void bnf_logpost_rows(const BnfMhArgs &a, const BnfLd
   {
     float mu[R], raw[R];
     uint4 G[R][BNF_NG_H];
-    const uint4 *SH = a.sg.h + ((long long)s * BNF_NG_H * a.n + blk_lo);
+    {     // the f call's groups are requested before the h call and first touched after it
+      const uint4 *SF = a.sg.f + ((long long)s * BNF_NG_H * a.n + blk_lo);
 #pragma unroll
-    for (int rt = 0; rt < R; ++rt)
+      for (int rt = 0; rt < R; ++rt)
 #pragma unroll
-      for (int k = 0; k < BNF_NG_H; ++k) G[rt][k] = (SH + (long long)k * a.n)[rib[rt]];
+        for (int k = 0; k < BNF_NG_H; ++k) G[rt][k] = (SF + (long long)k * a.n)[rib[rt]];
+    }
     BGM_NO_HOIST();
-    bnf_head<KS, R>(L.frag + P.fh * 64, DW + P.fh * 64, L.bias + 4 * P.bh, L.norm + 1 * T0 * 8, L.shift + 1 * T0 * 4, lane, g, ze, G, mu, raw);
+    bnf_head<KS, R>(L.frag + P.fh * 64, DW + P.fh * 64, L.bias + 4 * P.bh, L.norm + 1 * T0 * 8, L.shift + 1 * T0 * 4, lane, g, ze, GH, mu, raw);
 #pragma unroll
     for (int rt = 0; rt < R; ++rt) {
       const float m_ = mu[rt];
-      if (P.binary) lp[rt] -= fmaxf(m_, 0.0f) - m_ * xr[rt] + softplus_f(-fabsf(m_));
-      else { const float s2 = softplus_f(raw[rt]) + BGM_EPS, d = xr[rt] - m_; lp[rt] -= d * d * fast_rcp(2.0f * s2) + 0.5f * fast_log(s2); }
+      if (P.binary) lp[rt] -= fmaxf(m_, 0.0f) - m_ * xr[rt] + bnf_softplus(-fabsf(m_));
+      else { const float s2 = bnf_softplus(raw[rt]) + BGM_EPS, d = xr[rt] - m_; lp[rt] -= d * d * fast_rcp(2.0f * s2) + 0.5f * fast_log(s2); }
     }
-    const uint4 *SF = a.sg.f + ((long long)s * BNF_NG_H * a.n + blk_lo);
-#pragma unroll
-    for (int rt = 0; rt < R; ++rt)
-#pragma unroll
-      for (int k = 0; k < BNF_NG_H; ++k) G[rt][k] = (SF + (long long)k * a.n)[rib[rt]];
+    BNF_T(4);
     BGM_NO_HOIST();
     bnf_head<KS, R>(L.frag + P.ff * 64, DW + P.ff * 64, L.bias + 4 * P.bf, L.norm + 2 * T0 * 8, L.shift + 2 * T0 * 4, lane, g, ze, G, mu, raw);
 #pragma unroll
     for (int rt = 0; rt < R; ++rt) {
-      const float s2 = softplus_f(raw[rt]) + BGM_EPS, d = yr[rt] - mu[rt];
+      const float s2 = bnf_softplus(raw[rt]) + BGM_EPS, d = yr[rt] - mu[rt];
       lp[rt] -= d * d * fast_rcp(2.0f * s2) + 0.5f * fast_log(s2);
     }
   }
 #pragma unroll
   for (int rt = 0; rt < R; ++rt) lp[rt] += sum_over_g(part[rt]);
+  BNF_T(5);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -514,15 +569,28 @@ static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_mh_kernel(Bn
   L.norm = (const f32x4 *)(bnf_lds + P.norm_off);
   L.shift = (const int4 *)(bnf_lds + P.shift_off);
   const int q = P.q;
-  const int xcd = blockIdx.x & 7, cu = blockIdx.x >> 3, cus = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7;
   const int per = (a.n_items + 7) >> 3, lo = xcd * per, hi = min(a.n_items, lo + per);
   unsigned nacc_total = 0;
-  for (int item = lo + cu * WAVES + wave; item < hi; item += cus * WAVES) {
+#ifdef BNF_PROF
+  unsigned long long bnf_tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bnf_tl = __builtin_readcyclecounter();
+  const unsigned long long bnf_t0 = bnf_tl;
+#endif
+  // Items are handed out by one counter per XCD (zeroed by the sign-word launch that precedes this one): a wave asks for its next
+  // item when it starts the current one (the returning atomic is ~1 us, an item ~100 us).  With a static deal the four older waves
+  // of a workgroup -- which win the SIMD's issue arbitration -- finished at 80 % of the kernel and left the younger four running
+  // one per SIMD; the queue also trims the last round (15.26 items per wave on the bench panel).
+  unsigned *queue = a.queue + xcd;
+  unsigned tn = 0;
+  if (lane == 0) tn = atomicAdd(queue, 1u);
+  for (int item = lo + (int)__builtin_amdgcn_readfirstlane(tn); item < hi; item = lo + (int)__builtin_amdgcn_readfirstlane(tn)) {
+    if (lane == 0) tn = atomicAdd(queue, 1u);
     const int blk = item / a.groups_per_block, grp = item - blk * a.groups_per_block;
     const long long blk_lo = (long long)blk * a.bs;
     const int blk_n = (int)min((long long)a.bs, a.n - blk_lo);
     const int rib0 = grp * 16 * R;
     if (rib0 >= blk_n) continue;
+    BNF_T(6);
     int rib[R];
     bool valid[R];
     float xr[R], yr[R];
@@ -578,7 +646,7 @@ static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_mh_kernel(Bn
         for (int ks = 0; ks < KS; ++ks)
           if (16 * (ks >> 2) + 4 * (ks & 3) + g == q) zc[rt][ks] = xr[rt];
       float lp[R];
-      bnf_logpost_rows<KS, R>(a, L, lane, j, g, blk_lo, rib, zc, xr, yr, dwblk, 0, zzc, lp);
+      bnf_logpost_rows<KS, R>(a, L, lane, j, g, blk_lo, rib, zc, xr, yr, dwblk, 0, zzc, lp BNF_PROF_ARG);
 #pragma unroll
       for (int rt = 0; rt < R; ++rt)
         if (valid[rt] && g == 0) a.out[blk_lo + rib[rt]] = lp[rt];
@@ -623,7 +691,7 @@ static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_mh_kernel(Bn
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) zs[rt][ks] = st ? zc[rt][ks] : zp[rt][ks];
       }
-      bnf_logpost_rows<KS, R>(a, L, lane, j, g, blk_lo, rib, zs, xr, yr, dwblk + (long long)st * P.set_floats, st, zzs, lp);
+      bnf_logpost_rows<KS, R>(a, L, lane, j, g, blk_lo, rib, zs, xr, yr, dwblk + (long long)st * P.set_floats, st, zzs, lp BNF_PROF_ARG);
 #pragma unroll
       for (int rt = 0; rt < R; ++rt) { if (st) lpc[rt] = lp[rt]; else lpp[rt] = lp[rt]; }
     }
@@ -652,6 +720,17 @@ static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_mh_kernel(Bn
     }
   }
   if (a.acc_count && lane == 0 && nacc_total) atomicAdd(a.acc_count, nacc_total);
+#ifdef BNF_PROF
+  BNF_T(6);
+  if (a.prof && tid == 0)
+    for (int k = 0; k < 7; ++k) atomicAdd(&a.prof[k], bnf_tp[k]);
+  if (a.prof && lane == 0) {      // every wave: its busy time (sum and maximum over the waves of the launch), by wave index
+    const unsigned long long tot = __builtin_readcyclecounter() - bnf_t0;
+    atomicAdd(&a.prof[7], tot);
+    atomicMax(&a.prof[8], tot);
+    atomicAdd(&a.prof[9 + wave], tot);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -672,6 +751,7 @@ struct BnfEffArgs {
   uint32_t it_noise;
   double *sum_out; long long sum_stride;
   float *ite_out; long long ite_stride;
+  unsigned *queue;                     // [8] item counters, one per XCD (zeroed by bnf_signs_kernel)
 };
 
 template <int KS, int R, int WAVES>
@@ -697,9 +777,13 @@ static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_effects_kern
   float *myacc = acc_lds + wave * BNF_MAX_DOSES;
   const int q = P.q, nd = a.n_doses;
   const long long eset = (long long)P.e_frags * 256;
-  const int xcd = blockIdx.x & 7, cu = blockIdx.x >> 3, cus = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7;
   const int per = (a.n_items + 7) >> 3, lo = xcd * per, hi = min(a.n_items, lo + per);
-  for (int item = lo + cu * WAVES + wave; item < hi; item += cus * WAVES) {
+  unsigned *queue = a.queue + xcd;
+  unsigned tn = 0;
+  if (lane == 0) tn = atomicAdd(queue, 1u);
+  for (int item = lo + (int)__builtin_amdgcn_readfirstlane(tn); item < hi; item = lo + (int)__builtin_amdgcn_readfirstlane(tn)) {
+    if (lane == 0) tn = atomicAdd(queue, 1u);
     const int blk = item / a.groups_per_block, grp = item - blk * a.groups_per_block;
     const long long blk_lo = (long long)blk * a.bs;
     const int blk_n = (int)min((long long)a.bs, a.n - blk_lo);
@@ -769,7 +853,7 @@ static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_effects_kern
       for (int rt = 0; rt < R; ++rt) {
         float yk = mu[rt];
         if (a.sample_y) {
-          const float s2 = softplus_f(raw[rt]) + BGM_EPS;
+          const float s2 = bnf_softplus(raw[rt]) + BGM_EPS;
           yk = fmaf(__builtin_sqrtf(s2), e == 0 ? nz[rt][0] : e == 1 ? nz[rt][1] : e == 2 ? nz[rt][2] : nz[rt][3], yk);
         }
         if (a.ite_out) {
@@ -883,10 +967,12 @@ struct BnfSignArgs {
   long long n;
   int bs, block0, n_states, nets;
   uint32_t k0, k1, stream0;
+  unsigned *queue;            // [8] item counters of the sampler / effects launch that follows: cleared here
 };
 static __global__ __launch_bounds__(256) void bnf_signs_kernel(BnfSignArgs a) {
   const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
   const int s = blockIdx.y;
+  if (blockIdx.x == 0 && s == 0 && threadIdx.x < 8) a.queue[threadIdx.x] = 0u;
   if (row >= a.n) return;
   const int blk = (int)(row / a.bs);
   const uint32_t rib = (uint32_t)(row - (long long)blk * a.bs);

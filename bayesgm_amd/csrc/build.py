@@ -19,6 +19,11 @@ FLAGS = os.environ.get("BGM_EXTRA_FLAGS", "").split() + ["--offload-arch=gfx950"
          "-Wno-unused-value", "-Wno-unused-result"]
 
 
+# per-source flags.  bnf_api.hip: hipcc's SLP vectoriser packs the epilogues' scalar fma / mul pairs into v_pk_fma_f32 / v_pk_mul_f32, which
+# cannot carry the |x| modifier of the one-instruction LeakyReLU (an extra v_and per element) and issue no faster next to MFMAs.
+SOURCE_FLAGS = {"bnf_api.hip": ["-fno-slp-vectorize"]}
+
+
 def _newer(src, dst):
     return (not os.path.exists(dst)) or os.path.getmtime(src) > os.path.getmtime(dst)
 
@@ -40,21 +45,22 @@ def build(force=False, defines=(), verbose=True, out=None):
         dep, tag = obj + ".d", obj + ".flags"
         if not (os.path.exists(obj) and os.path.exists(dep) and os.path.exists(tag)):
             return False
-        if open(tag).read() != " ".join(FLAGS + list(defines)):
+        if open(tag).read() != " ".join(FLAGS + SOURCE_FLAGS.get(os.path.basename(obj).split(".so.")[-1][:-2], []) + list(defines)):
             return False
         words = open(dep).read().replace("\\\n", " ").split()
         t = os.path.getmtime(obj)
         return all(os.path.exists(w) and os.path.getmtime(w) <= t for w in words[1:] if not w.endswith(":"))
 
     def cc(src):
-        obj = os.path.join(HERE, "build", os.path.basename(OUT) + "." + os.path.basename(src) + ".o")
+        obj = os.path.join(os.path.dirname(OUT) if out else os.path.join(HERE, "build"), os.path.basename(OUT) + "." + os.path.basename(src) + ".o")
         if not force and fresh(obj):
             return obj
-        cmd = [hipcc] + FLAGS + ["-D" + d for d in defines] + ["-I", HERE, "-MMD", "-MF", obj + ".d", "-c", src, "-o", obj]
+        extra = SOURCE_FLAGS.get(os.path.basename(src), [])
+        cmd = [hipcc] + FLAGS + extra + ["-D" + d for d in defines] + ["-I", HERE, "-MMD", "-MF", obj + ".d", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-        open(obj + ".flags", "w").write(" ".join(FLAGS + list(defines)))
+        open(obj + ".flags", "w").write(" ".join(FLAGS + extra + list(defines)))
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
@@ -98,4 +104,4 @@ if __name__ == "__main__":
             defs.append(a[2:])
         elif a == "-o":
             out = os.path.abspath(argv[i + 1])
-    print(build(force=force or bool(defs), defines=defs, out=out))
+    print(build(force=force, defines=defs, out=out))
