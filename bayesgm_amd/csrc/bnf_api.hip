@@ -18,12 +18,13 @@ namespace {
 struct BnfState {
   BnfPlan P{};
   int KSc = 0;                          // compiled k-step count (>= P.KS)
-  BnfLayerDesc lay[14];
-  int n_w = 0, n_b = 0, n_n = 0;
-  BnfWElem *w_dev = nullptr;
-  BnfBElem *b_dev = nullptr;
-  BnfNElem *n_dev = nullptr;
-  float *blob_dev = nullptr, *eblob_dev = nullptr, *sf_dev = nullptr;
+  int KSFc = 0;                         // compiled k-step count of the effects kernel (>= P.KSF)
+  BnfLayerDesc lay[14], lay_e[4];       // Flipout kernels of g | h | f (sampler sets) and of f in the effects layout
+  int n_w = 0, n_b = 0, n_n = 0, n_we = 0, n_be = 0, n_ne = 0;
+  BnfWElem *w_dev = nullptr, *we_dev = nullptr;
+  BnfBElem *b_dev = nullptr, *be_dev = nullptr;
+  BnfNElem *n_dev = nullptr, *ne_dev = nullptr;
+  float *blob_dev = nullptr, *eblob_dev = nullptr, *sf_dev = nullptr, *esf_dev = nullptr;
   // per-run buffers, grown on demand
   float *dw_dev = nullptr; size_t dw_cap = 0;          // perturbation sets
   void *sg_dev = nullptr; size_t sg_cap = 0;           // sign groups
@@ -33,6 +34,7 @@ struct BnfState {
 };
 
 const int kKS[] = {3, 4, 5, 6, 8};
+const int kKSF[] = {1, 2, 3, 4, 8};
 
 bool default_head(const BnnNet &n, int in) {
   return n.bn_fixed == 1 && !n.heads && !n.mv && n.n_layers == 4 && n.dims[0] == in && n.dims[1] == 64 && n.dims[2] == 32 && n.dims[3] == 8 &&
@@ -40,14 +42,16 @@ bool default_head(const BnnNet &n, int in) {
 }
 
 // plan + element tables; false when the session is outside this path
-bool bnf_build(const BnnState *s, BnfState &st, std::vector<BnfWElem> &W, std::vector<BnfBElem> &B, std::vector<BnfNElem> &N) {
+struct BnfTabs { std::vector<BnfWElem> W, WE; std::vector<BnfBElem> B, BE; std::vector<BnfNElem> N, NE; };
+bool bnf_build(const BnnState *s, BnfState &st, BnfTabs &tb) {
+  std::vector<BnfWElem> &W = tb.W; std::vector<BnfBElem> &B = tb.B; std::vector<BnfNElem> &N = tb.N;
   const bgm_bnn_config &c = s->cfg;
   const int q = s->q, p = s->p, z0 = c.z_dims[0], z1 = c.z_dims[1], z2 = c.z_dims[2];
   const BnnNet &G = s->net[BNN_G], &H = s->net[BNN_H], &F = s->net[BNN_F];
   if (G.bn_fixed != 1 || G.heads || G.mv || G.n_layers != 6 || G.dims[0] != q || G.dims[6] != p + 1) return false;
   for (int l = 1; l <= 5; ++l) if (G.dims[l] != 64) return false;
   if (z0 + z2 < 1 || !default_head(H, z0 + z2) || !default_head(F, z0 + z1 + 1)) return false;
-  if (q < 1 || q > 31 || p + 1 > 208) return false;
+  if (q < 1 || q > 31 || p + 1 > 208 || p < 4) return false;
   const int need = (q + 1 + 3) / 4;
   int KS = 0;
   for (int k : kKS) if (k >= need) { KS = k; break; }
@@ -64,11 +68,18 @@ bool bnf_build(const BnnState *s, BnfState &st, std::vector<BnfWElem> &W, std::v
   P.shift_off = P.norm_off + 3 * T0 * 32;
   P.blob_floats = P.shift_off + 3 * T0 * 16;
   P.set_floats = P.n_frags * 256;
-  P.e_frags = head;
-  P.e_bias_off = head * 256;
+  const int f_in = z0 + z1 + 1, need_f = (f_in + 3) / 4;
+  int KSF = 0;
+  for (int k : kKSF) if (k >= need_f) { KSF = k; break; }
+  if (!KSF) return false;
+  const int T0F = (KSF + 3) / 4;
+  P.KSF = KSF;
+  P.e_frags = 4 * T0F + 11;
+  P.e_bias_off = P.e_frags * 256;
   P.e_norm_off = P.e_bias_off + 16 * 8;
-  P.e_shift_off = P.e_norm_off + T0 * 32;
-  P.e_blob_floats = P.e_shift_off + T0 * 16;
+  P.e_shift_off = P.e_norm_off + T0F * 32;
+  P.e_blob_floats = P.e_shift_off + T0F * 16;
+  st.KSFc = KSF;
   if ((size_t)P.blob_floats * 4 > 160 * 1024) return false;
   st.KSc = KS;
   st.lds_mh = P.blob_floats * 4;
@@ -121,12 +132,56 @@ bool bnf_build(const BnnState *s, BnfState &st, std::vector<BnfWElem> &W, std::v
       N.push_back(e);
     }
   }
+  // effects layout: the outcome net alone, first layer over its own input (z0, z1, x)
+  tb.WE.clear(); tb.BE.clear(); tb.NE.clear();
+  {
+    const BnnNet &n = F;
+    int fb = 0, bt = 0;
+    for (int l = 0; l < n.n_layers; ++l) {
+      const int in = n.dims[l], out = n.dims[l + 1], T = l == 0 ? T0F : (in + 15) / 16, MT = (out + 15) / 16;
+      st.lay_e[l] = BnfLayerDesc{(int)tb.WE.size(), in * out, l, n.net_id};
+      const bool head3 = l == 2, head4 = l == 3;
+      for (int k = 0; k < in; ++k)
+        for (int o = 0; o < out; ++o) {
+          BnfWElem e{};
+          e.loc = n.woff[l] + k * out + o; e.rho = e.loc + in * out; e.rep = 1; e.scale = l > 0 ? BGM_LRS_W : 1.0f;
+          int t_, gg, r, mt = o >> 4, j = o & 15;
+          if (l == 0) { t_ = k >> 4; r = (k & 15) >> 2; gg = k & 3; }
+          else if (head4) { t_ = 0; gg = k >> 1; r = k & 1; e.rep = 4; }
+          else { t_ = k >> 4; gg = (k & 15) >> 2; r = k & 3; }
+          if (head3) j = 4 * (o >> 1) + (o & 1);
+          e.pos = (((fb + mt * T + t_) * 64) + gg * 16 + j) * 4 + r;
+          tb.WE.push_back(e);
+        }
+      const int boff = n.woff[l] + 2 * in * out;
+      for (int o = 0; o < out; ++o) {
+        BnfBElem e{};
+        e.src = boff + o; e.rep = head4 ? 4 : 1;
+        const int j = head3 ? 4 * (o >> 1) + (o & 1) : (o & 15);
+        e.pos = 16 * (bt + (o >> 4)) + j;
+        tb.BE.push_back(e);
+      }
+      fb += T * MT; bt += MT;
+    }
+    for (int x = 0; x < 16 * T0F; ++x) {
+      const int k = x < n.dims[0] ? x : -1;
+      const int sb = x >> 4, r = (x & 15) >> 2, gg = x & 3;
+      BnfNElem e{};
+      e.gamma = k >= 0 ? n.off + k : -1; e.beta = k >= 0 ? n.off + n.dims[0] + k : -1;
+      e.pos_sc = P.e_norm_off + (sb * 2) * 16 + gg * 4 + r;
+      e.pos_sh = e.pos_sc + 16;
+      e.pos_shift = P.e_shift_off + sb * 16 + gg * 4 + r;
+      e.shift = k >= 0 ? 31 - k : 0;
+      tb.NE.push_back(e);
+    }
+  }
   return nl == 14;
 }
 
 void bnf_release(BnfState *st) {
   if (!st) return;
-  for (void *p : {(void *)st->w_dev, (void *)st->b_dev, (void *)st->n_dev, (void *)st->blob_dev, (void *)st->eblob_dev, (void *)st->sf_dev,
+  for (void *p : {(void *)st->w_dev, (void *)st->b_dev, (void *)st->n_dev, (void *)st->we_dev, (void *)st->be_dev, (void *)st->ne_dev,
+                  (void *)st->esf_dev, (void *)st->blob_dev, (void *)st->eblob_dev, (void *)st->sf_dev,
                   (void *)st->dw_dev, st->sg_dev, (void *)st->pair_dev, (void *)st->queue_dev})
     if (p) hipFree(p);
   delete st;
@@ -171,7 +226,7 @@ MhFn mh_fn_ks(BnfCfg &c) {
 template <int KS>
 EffFn eff_fn_ks(BnfCfg &c) {
 #ifdef BNF_ALL_CFGS
-  if constexpr (KS == 3) {
+  if constexpr (KS == 1) {
     if (c.R == 1 && c.W == 8) return bnf_effects_kernel<KS, 1, 8>;
     if (c.R == 2 && c.W == 8) return bnf_effects_kernel<KS, 2, 8>;
     if (c.R == 2 && c.W == 4) return bnf_effects_kernel<KS, 2, 4>;
@@ -193,13 +248,13 @@ MhFn mh_fn(int KS, BnfCfg &c) {
     default: return mh_fn_ks<8, MODE>(c);
   }
 }
-EffFn eff_fn(int KS, BnfCfg &c) {
+EffFn eff_fn(int KSF, BnfCfg &c) {
   c = env_cfg("BGM_BNF_ECFG", BnfCfg{BNF_ER, BNF_EW});
-  switch (KS) {
+  switch (KSF) {
+    case 1: return eff_fn_ks<1>(c);
+    case 2: return eff_fn_ks<2>(c);
     case 3: return eff_fn_ks<3>(c);
     case 4: return eff_fn_ks<4>(c);
-    case 5: return eff_fn_ks<5>(c);
-    case 6: return eff_fn_ks<6>(c);
     default: return eff_fn_ks<8>(c);
   }
 }
@@ -209,19 +264,23 @@ int bnf_session(bgm_handle *h, BnnState *s, BnfState *&st, hipStream_t stream) {
   if (!st) {
     if (std::getenv("BGM_BNF_OFF")) return 1;
     BnfState *n = new BnfState();
-    std::vector<BnfWElem> W; std::vector<BnfBElem> B; std::vector<BnfNElem> N;
-    if (!bnf_build(s, *n, W, B, N)) { delete n; s->bnf_unsupported = true; return 1; }
-    n->n_w = (int)W.size(); n->n_b = (int)B.size(); n->n_n = (int)N.size();
+    BnfTabs tb;
+    if (!bnf_build(s, *n, tb)) { delete n; s->bnf_unsupported = true; return 1; }
+    n->n_w = (int)tb.W.size(); n->n_b = (int)tb.B.size(); n->n_n = (int)tb.N.size();
+    n->n_we = (int)tb.WE.size(); n->n_be = (int)tb.BE.size(); n->n_ne = (int)tb.NE.size();
     auto up = [&](void **dst, const void *src, size_t bytes) {
       if (hipMalloc(dst, bytes) != hipSuccess) return false;
       return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
     };
     static const float pair_host[2] = {1.0f, 0.0f};
-    bool ok = up((void **)&n->w_dev, W.data(), W.size() * sizeof(BnfWElem)) && up((void **)&n->b_dev, B.data(), B.size() * sizeof(BnfBElem)) &&
-              up((void **)&n->n_dev, N.data(), N.size() * sizeof(BnfNElem)) && up((void **)&n->pair_dev, pair_host, sizeof(pair_host));
+    bool ok = up((void **)&n->w_dev, tb.W.data(), tb.W.size() * sizeof(BnfWElem)) && up((void **)&n->b_dev, tb.B.data(), tb.B.size() * sizeof(BnfBElem)) &&
+              up((void **)&n->n_dev, tb.N.data(), tb.N.size() * sizeof(BnfNElem)) && up((void **)&n->we_dev, tb.WE.data(), tb.WE.size() * sizeof(BnfWElem)) &&
+              up((void **)&n->be_dev, tb.BE.data(), tb.BE.size() * sizeof(BnfBElem)) && up((void **)&n->ne_dev, tb.NE.data(), tb.NE.size() * sizeof(BnfNElem)) &&
+              up((void **)&n->pair_dev, pair_host, sizeof(pair_host));
     ok = ok && hipMalloc((void **)&n->blob_dev, sizeof(float) * n->P.blob_floats) == hipSuccess &&
          hipMalloc((void **)&n->eblob_dev, sizeof(float) * n->P.e_blob_floats) == hipSuccess &&
          hipMalloc((void **)&n->sf_dev, sizeof(float) * n->P.set_floats) == hipSuccess &&
+         hipMalloc((void **)&n->esf_dev, sizeof(float) * n->P.e_frags * 256) == hipSuccess &&
          hipMalloc((void **)&n->queue_dev, 16 * sizeof(unsigned)) == hipSuccess;
     if (!ok) { bnf_release(n); bgm_set_error("bnf: device allocation failed"); return BGM_E_HIP; }
     s->bnf = n; s->bnf_valid = false;
@@ -232,14 +291,14 @@ int bnf_session(bgm_handle *h, BnnState *s, BnfState *&st, hipStream_t stream) {
     BGM_HIP_CHECK(hipMemsetAsync(st->blob_dev, 0, sizeof(float) * P.blob_floats, stream));
     BGM_HIP_CHECK(hipMemsetAsync(st->eblob_dev, 0, sizeof(float) * P.e_blob_floats, stream));
     BGM_HIP_CHECK(hipMemsetAsync(st->sf_dev, 0, sizeof(float) * P.set_floats, stream));
-    const int T0 = (P.KS + 3) / 4;
+    BGM_HIP_CHECK(hipMemsetAsync(st->esf_dev, 0, sizeof(float) * P.e_frags * 256, stream));
     BnfPackArgs pa{};
     pa.theta = s->theta_dev; pa.w = st->w_dev; pa.n_w = st->n_w; pa.b = st->b_dev; pa.n_b = st->n_b; pa.ne = st->n_dev; pa.n_n = st->n_n;
     pa.blob = st->blob_dev; pa.sf = st->sf_dev; pa.bias_off = P.bias_off;
-    pa.eblob = st->eblob_dev; pa.f_frag0 = P.ff; pa.e_frags = P.e_frags; pa.f_bias_tile0 = P.bf; pa.e_bias_off = P.e_bias_off;
-    pa.f_norm0 = 2 * T0 * 32; pa.e_norm_off = P.e_norm_off; pa.f_shift0 = 2 * T0 * 16; pa.e_shift_off = P.e_shift_off; pa.T0 = T0;
-    pa.norm_off = P.norm_off; pa.shift_off = P.shift_off;
     hipLaunchKernelGGL(bnf_pack_kernel, dim3(64), dim3(256), 0, stream, pa);
+    pa.w = st->we_dev; pa.n_w = st->n_we; pa.b = st->be_dev; pa.n_b = st->n_be; pa.ne = st->ne_dev; pa.n_n = st->n_ne;
+    pa.blob = st->eblob_dev; pa.sf = st->esf_dev; pa.bias_off = P.e_bias_off;
+    hipLaunchKernelGGL(bnf_pack_kernel, dim3(16), dim3(256), 0, stream, pa);
     BGM_HIP_CHECK(hipGetLastError());
     s->bnf_valid = true;
   }
@@ -280,11 +339,13 @@ int set_lds(K kernel, int bytes) {
   return BGM_OK;
 }
 
-void launch_noise(const BnfState *st, int first_lay, int n_lay, int pos_base, float *dw, long long set_floats, int n_blocks, int n_states,
-                  uint64_t seed, uint32_t stream0, int block0, hipStream_t stream) {
+// effects = true: sets of the outcome net in the effects layout
+void launch_noise(const BnfState *st, bool effects, float *dw, long long set_floats, int n_blocks, int n_states, uint64_t seed, uint32_t stream0,
+                  int block0, hipStream_t stream) {
   BnfNoiseArgs na{};
-  for (int i = 0; i < n_lay; ++i) na.lay[i] = st->lay[first_lay + i];
-  na.n_lay = n_lay; na.w = st->w_dev; na.sf = st->sf_dev; na.pos_base = pos_base; na.dw = dw; na.set_floats = set_floats;
+  const int n_lay = effects ? 4 : 14;
+  for (int i = 0; i < n_lay; ++i) na.lay[i] = effects ? st->lay_e[i] : st->lay[i];
+  na.n_lay = n_lay; na.w = effects ? st->we_dev : st->w_dev; na.sf = effects ? st->esf_dev : st->sf_dev; na.dw = dw; na.set_floats = set_floats;
   na.n_states = n_states; na.k0 = (uint32_t)seed; na.k1 = (uint32_t)(seed >> 32); na.stream0 = stream0; na.block0 = block0;
   hipLaunchKernelGGL(bnf_noise_kernel, dim3(n_lay > 4 ? 8 : 2, n_blocks * n_states), dim3(256), 0, stream, na);
 }
@@ -321,7 +382,7 @@ int bnf_logpost(bgm_handle *h, BnnState *s, const float *x, const float *y, cons
   rc = grow(&st->sg_dev, &st->sg_cap, L.bytes, stream, false);
   if (rc) return rc;
   L = sg_layout(st->sg_dev, n, 1, 0);
-  launch_noise(st, 0, 14, 0, st->dw_dev, P.set_floats, n_blocks, 1, seed, stream_id, block0, stream);
+  launch_noise(st, false, st->dw_dev, P.set_floats, n_blocks, 1, seed, stream_id, block0, stream);
   launch_signs(L, n, block_rows, block0, 1, 7, seed, stream_id, st->queue_dev, stream);
   BnfMhArgs a{};
   a.pl = P; a.blob = st->blob_dev; a.dw = st->dw_dev;
@@ -344,9 +405,9 @@ int effects_of(bgm_handle *h, BnfState *st, const float *z, long long n, int bs,
                float *ite_out, long long ite_stride, float *dw_eff, const SgLayout &L, hipStream_t stream) {
   const BnfPlan &P = st->P;
   BnfCfg c;
-  EffFn fn = eff_fn(st->KSc, c);
+  EffFn fn = eff_fn(st->KSFc, c);
   const long long eset = (long long)P.e_frags * 256;
-  launch_noise(st, 10, 4, P.ff * 256, dw_eff, eset, n_blocks, n_doses, seed, stream0, block0, stream);
+  launch_noise(st, true, dw_eff, eset, n_blocks, n_doses, seed, stream0, block0, stream);
   launch_signs(L, n, bs, block0, n_doses, 4, seed, stream0, st->queue_dev + 8, stream);
   BnfEffArgs ea{};
   ea.pl = P; ea.eblob = st->eblob_dev; ea.dw = dw_eff; ea.sgf = L.f; ea.z = z; ea.n = n; ea.row_base = row_base;
@@ -401,7 +462,7 @@ int bnf_mh_run(bgm_handle *h, BnnState *s, const bgm_bnn_mh_args *g, hipStream_t
 #endif
   for (int i = 0; i < g->n_iters; ++i) {
     const int it = g->it_begin + i;
-    launch_noise(st, 0, 14, 0, st->dw_dev, P.set_floats, n_blocks, 2, g->seed, 2u * (uint32_t)it, g->block0, stream);
+    launch_noise(st, false, st->dw_dev, P.set_floats, n_blocks, 2, g->seed, 2u * (uint32_t)it, g->block0, stream);
     launch_signs(L, n, bs, g->block0, 2, 7, g->seed, 2u * (uint32_t)it, st->queue_dev, stream);
     a.it = it; a.init = (i == 0 && g->init) ? 1 : 0;
     a.acc_blocks = g->acc_blocks_dev ? g->acc_blocks_dev + (long long)i * n_blocks : nullptr;

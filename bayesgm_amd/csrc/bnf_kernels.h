@@ -61,8 +61,10 @@ struct BnfPlan {
   int bias_off, norm_off, shift_off, blob_floats;   // float offsets inside the LDS blob [frags | bias tiles | norm | shift]
   int bg0, bgh, bgl, bh, bf;  // bias tiles (16 floats) of the same
   int set_floats;             // one perturbation set: n_frags * 256
-  // effects blob (outcome net only): [f frags | f bias tiles | f norm | f shift]
-  int e_frags, e_bias_off, e_norm_off, e_shift_off, e_blob_floats;
+  // effects blob (outcome net only): [f frags | f bias tiles | f norm | f shift].  Its first layer contracts over the net's OWN input
+  // (z0, z1, x) -- slot (gg, r) of k-tile sb = input 16 sb + 4 r + gg -- in KSF = ceil((z0 + z1 + 1) / 4) k-steps (1 for z_dims
+  // [1, 1, 1, 7] against the 3 of the shared extended input)
+  int KSF, e_frags, e_bias_off, e_norm_off, e_shift_off, e_blob_floats;
 };
 
 struct BnfSigns {             // n_states = 2 (MH: proposal, current) or n_doses (effects)
@@ -754,7 +756,7 @@ struct BnfEffArgs {
   unsigned *queue;                     // [8] item counters, one per XCD (zeroed by bnf_signs_kernel)
 };
 
-template <int KS, int R, int WAVES>
+template <int KS, int R, int WAVES>      // KS: k-steps of the outcome net's own first layer (BnfPlan::KSF or a larger compiled value)
 static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_effects_kernel(BnfEffArgs a) {
   extern __shared__ __attribute__((aligned(16))) float bnf_lds[];
   constexpr int T0 = (KS + 3) / 4;
@@ -775,7 +777,7 @@ static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_effects_kern
   const f32x4 *NORM = (const f32x4 *)(bnf_lds + P.e_norm_off);
   const int4 *SHIFT = (const int4 *)(bnf_lds + P.e_shift_off);
   float *myacc = acc_lds + wave * BNF_MAX_DOSES;
-  const int q = P.q, nd = a.n_doses;
+  const int q = P.q, nd = a.n_doses, zz = P.z0 + P.z1;
   const long long eset = (long long)P.e_frags * 256;
   const int xcd = blockIdx.x & 7;
   const int per = (a.n_items + 7) >> 3, lo = xcd * per, hi = min(a.n_items, lo + per);
@@ -803,8 +805,8 @@ static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_effects_kern
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int f = 16 * (ks >> 2) + 4 * (ks & 3) + g;
-        const float t = zblk[rib[rt] * q + min(f, q - 1)];
-        ze[rt][ks] = f < q ? t : 0.0f;
+        const float t = zblk[rib[rt] * q + min(f, max(zz, 1) - 1)];
+        ze[rt][ks] = f < zz ? t : 0.0f;
       }
     }
     const float *dwblk = a.dw + (long long)blk * nd * eset;
@@ -843,7 +845,7 @@ static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_effects_kern
       for (int rt = 0; rt < R; ++rt)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
-          if (16 * (ks >> 2) + 4 * (ks & 3) + g == q) ze[rt][ks] = xv;
+          if (16 * (ks >> 2) + 4 * (ks & 3) + g == zz) ze[rt][ks] = xv;
       float mu[R], raw[R];
       BGM_NO_HOIST();
       bnf_head<KS, R>(LF, (const f32x4 *)(dwblk + (long long)k * eset), BL, NORM, SHIFT, lane, g, ze, G, mu, raw);
@@ -891,38 +893,26 @@ struct BnfPackArgs {
   const BnfWElem *w; int n_w;
   const BnfBElem *b; int n_b;
   const BnfNElem *ne; int n_n;
-  float *blob, *sf;           // blob [blob_floats]; sigma fragments [set_floats]
+  float *blob, *sf;           // blob [frags | bias tiles | norm | shift]; sigma fragments [n_frags * 256]
   int bias_off;
-  // effects blob: the outcome net's part of the blob, re-based
-  float *eblob; int f_frag0, e_frags, f_bias_tile0, e_bias_off, f_norm0, e_norm_off, f_shift0, e_shift_off, T0, norm_off, shift_off;
 };
 static __global__ void bnf_pack_kernel(BnfPackArgs a) {
   const int i0 = blockIdx.x * blockDim.x + threadIdx.x, str = gridDim.x * blockDim.x;
   for (int i = i0; i < a.n_w; i += str) {
     const BnfWElem e = a.w[i];
     const float lv = e.scale * a.theta[e.loc], sv = e.scale * (BNN_SCALE_EPS + softplus_acc(a.theta[e.rho]));
-    for (int c = 0; c < e.rep; ++c) {
-      a.blob[e.pos + 16 * c] = lv; a.sf[e.pos + 16 * c] = sv;
-      const int fr = (e.pos + 16 * c) - a.f_frag0 * 256;
-      if (fr >= 0 && fr < a.e_frags * 256) a.eblob[fr] = lv;
-    }
+    for (int c = 0; c < e.rep; ++c) { a.blob[e.pos + 16 * c] = lv; a.sf[e.pos + 16 * c] = sv; }
   }
   for (int i = i0; i < a.n_b; i += str) {
     const BnfBElem e = a.b[i];
     const float v = a.theta[e.src];
-    for (int c = 0; c < e.rep; ++c) {
-      a.blob[a.bias_off + e.pos + 4 * c] = v;
-      const int t = e.pos + 4 * c - 16 * a.f_bias_tile0;
-      if (t >= 0 && t < 16 * 8) a.eblob[a.e_bias_off + t] = v;
-    }
+    for (int c = 0; c < e.rep; ++c) a.blob[a.bias_off + e.pos + 4 * c] = v;
   }
   for (int i = i0; i < a.n_n; i += str) {
     const BnfNElem e = a.ne[i];
-    const float sc = e.gamma >= 0 ? a.theta[e.gamma] / sqrtf(1.0f + BNN_BN_EPS) : 0.0f, sh = e.gamma >= 0 ? a.theta[e.beta] : 0.0f;
-    a.blob[e.pos_sc] = sc; a.blob[e.pos_sh] = sh;
+    a.blob[e.pos_sc] = e.gamma >= 0 ? a.theta[e.gamma] / sqrtf(1.0f + BNN_BN_EPS) : 0.0f;
+    a.blob[e.pos_sh] = e.gamma >= 0 ? a.theta[e.beta] : 0.0f;
     ((int *)a.blob)[e.pos_shift] = e.shift;
-    const int n0 = e.pos_sc - a.norm_off - a.f_norm0, n1 = e.pos_sh - a.norm_off - a.f_norm0, s0 = e.pos_shift - a.shift_off - a.f_shift0;
-    if (n0 >= 0 && n0 < a.T0 * 32) { a.eblob[a.e_norm_off + n0] = sc; a.eblob[a.e_norm_off + n1] = sh; ((int *)a.eblob)[a.e_shift_off + s0] = e.shift; }
   }
 }
 
@@ -933,8 +923,7 @@ struct BnfNoiseArgs {
   BnfLayerDesc lay[14];
   int n_lay;
   const BnfWElem *w;
-  const float *sf;            // sigma fragments (positions of the FULL set)
-  int pos_base;               // subtracted from an element's position (effects sets hold the outcome net only)
+  const float *sf;            // sigma fragments in the layout of the element table
   float *dw; long long set_floats;
   int n_states;
   uint32_t k0, k1, stream0;
@@ -954,7 +943,7 @@ static __global__ void bnf_noise_kernel(BnfNoiseArgs a) {
         if (idx < L.cnt) {
           const BnfWElem e = a.w[L.e_base + idx];
           const float v = a.sf[e.pos] * z[u];
-          for (int c = 0; c < e.rep; ++c) dw[e.pos - a.pos_base + 16 * c] = v;
+          for (int c = 0; c < e.rep; ++c) dw[e.pos + 16 * c] = v;
         }
       }
     }
