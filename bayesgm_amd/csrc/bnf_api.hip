@@ -22,6 +22,8 @@ struct BnfState {
   BnfLayerDesc lay[14], lay_e[4];       // Flipout kernels of g | h | f (sampler sets) and of f in the effects layout
   int n_w = 0, n_b = 0, n_n = 0, n_we = 0, n_be = 0, n_ne = 0;
   BnfWElem *w_dev = nullptr, *we_dev = nullptr;
+  int *npos_dev = nullptr, *npos_e_dev = nullptr;      // noise kernel's position tables
+  int n_calls = 0, n_calls_e = 0;
   BnfBElem *b_dev = nullptr, *be_dev = nullptr;
   BnfNElem *n_dev = nullptr, *ne_dev = nullptr;
   float *blob_dev = nullptr, *eblob_dev = nullptr, *sf_dev = nullptr, *esf_dev = nullptr;
@@ -83,10 +85,11 @@ bool bnf_build(const BnnState *s, BnfState &st, BnfTabs &tb) {
   if ((size_t)P.blob_floats * 4 > 160 * 1024) return false;
   st.KSc = KS;
   st.lds_mh = P.blob_floats * 4;
-  st.lds_eff = (((P.e_blob_floats + 3) & ~3) + 8 * BNF_MAX_DOSES) * 4;
+  st.lds_eff = (((P.e_blob_floats + 3) & ~3) + 16 * BNF_MAX_DOSES) * 4;      // blob + per-wave dose accumulators (<= 16 waves)
 
   auto ext = [&](int net, int k) { return net == 0 ? k : net == 1 ? (k < z0 ? k : k + z1) : (k < z0 + z1 ? k : q); };
   W.clear(); B.clear(); N.clear();
+  st.n_calls = 0; st.n_calls_e = 0;
   const BnnNet *nets[3] = {&G, &H, &F};
   const int fbase[3] = {P.fg0, P.fh, P.ff}, bbase[3] = {P.bg0, P.bh, P.bf};
   int nl = 0;
@@ -95,7 +98,8 @@ bool bnf_build(const BnnState *s, BnfState &st, BnfTabs &tb) {
     int fb = fbase[ni], bt = bbase[ni];
     for (int l = 0; l < n.n_layers; ++l) {
       const int in = n.dims[l], out = n.dims[l + 1], T = l == 0 ? T0 : (in + 15) / 16, MT = (out + 15) / 16;
-      st.lay[nl++] = BnfLayerDesc{(int)W.size(), in * out, l, n.net_id};
+      st.lay[nl] = BnfLayerDesc{(int)W.size(), in * out, l, n.net_id, st.n_calls};
+      st.n_calls += (in * out + 3) / 4; ++nl;
       const bool head3 = ni > 0 && l == 2, head4 = ni > 0 && l == 3;
       for (int k = 0; k < in; ++k)
         for (int o = 0; o < out; ++o) {
@@ -139,7 +143,8 @@ bool bnf_build(const BnnState *s, BnfState &st, BnfTabs &tb) {
     int fb = 0, bt = 0;
     for (int l = 0; l < n.n_layers; ++l) {
       const int in = n.dims[l], out = n.dims[l + 1], T = l == 0 ? T0F : (in + 15) / 16, MT = (out + 15) / 16;
-      st.lay_e[l] = BnfLayerDesc{(int)tb.WE.size(), in * out, l, n.net_id};
+      st.lay_e[l] = BnfLayerDesc{(int)tb.WE.size(), in * out, l, n.net_id, st.n_calls_e};
+      st.n_calls_e += (in * out + 3) / 4;
       const bool head3 = l == 2, head4 = l == 3;
       for (int k = 0; k < in; ++k)
         for (int o = 0; o < out; ++o) {
@@ -181,7 +186,7 @@ bool bnf_build(const BnnState *s, BnfState &st, BnfTabs &tb) {
 void bnf_release(BnfState *st) {
   if (!st) return;
   for (void *p : {(void *)st->w_dev, (void *)st->b_dev, (void *)st->n_dev, (void *)st->we_dev, (void *)st->be_dev, (void *)st->ne_dev,
-                  (void *)st->esf_dev, (void *)st->blob_dev, (void *)st->eblob_dev, (void *)st->sf_dev,
+                  (void *)st->esf_dev, (void *)st->npos_dev, (void *)st->npos_e_dev, (void *)st->blob_dev, (void *)st->eblob_dev, (void *)st->sf_dev,
                   (void *)st->dw_dev, st->sg_dev, (void *)st->pair_dev, (void *)st->queue_dev})
     if (p) hipFree(p);
   delete st;
@@ -191,11 +196,11 @@ void bnf_release(BnfState *st) {
 // (-D BNF_ALL_CFGS) also carries the others for the bench shape (KS = 3) and picks by the environment variable BGM_BNF_CFG=r<R>w<W>.
 #ifndef BNF_R
 #define BNF_R 2
-#define BNF_W 4
+#define BNF_W 8
 #endif
 #ifndef BNF_ER
-#define BNF_ER 2
-#define BNF_EW 8
+#define BNF_ER 1
+#define BNF_EW 12
 #endif
 struct BnfCfg { int R, W; };
 BnfCfg env_cfg(const char *name, BnfCfg d) {
@@ -218,6 +223,7 @@ MhFn mh_fn_ks(BnfCfg &c) {
     if (c.R == 2 && c.W == 8) return bnf_mh_kernel<KS, 2, 8, MODE>;
     if (c.R == 2 && c.W == 4) return bnf_mh_kernel<KS, 2, 4, MODE>;
     if (c.R == 3 && c.W == 4) return bnf_mh_kernel<KS, 3, 4, MODE>;
+    if (c.R == 1 && c.W == 12) return bnf_mh_kernel<KS, 1, 12, MODE>;
   }
 #endif
   c = BnfCfg{BNF_R, BNF_W};
@@ -231,6 +237,9 @@ EffFn eff_fn_ks(BnfCfg &c) {
     if (c.R == 2 && c.W == 8) return bnf_effects_kernel<KS, 2, 8>;
     if (c.R == 2 && c.W == 4) return bnf_effects_kernel<KS, 2, 4>;
     if (c.R == 4 && c.W == 4) return bnf_effects_kernel<KS, 4, 4>;
+    if (c.R == 1 && c.W == 12) return bnf_effects_kernel<KS, 1, 12>;
+    if (c.R == 1 && c.W == 16) return bnf_effects_kernel<KS, 1, 16>;
+    if (c.R == 2 && c.W == 12) return bnf_effects_kernel<KS, 2, 12>;
   }
 #endif
   c = BnfCfg{BNF_ER, BNF_EW};
@@ -273,7 +282,10 @@ int bnf_session(bgm_handle *h, BnnState *s, BnfState *&st, hipStream_t stream) {
       return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
     };
     static const float pair_host[2] = {1.0f, 0.0f};
-    bool ok = up((void **)&n->w_dev, tb.W.data(), tb.W.size() * sizeof(BnfWElem)) && up((void **)&n->b_dev, tb.B.data(), tb.B.size() * sizeof(BnfBElem)) &&
+    std::vector<int> np(tb.W.size()), npe(tb.WE.size());
+    for (size_t i = 0; i < tb.W.size(); ++i) np[i] = tb.W[i].pos | ((tb.W[i].rep - 1) << 28);
+    for (size_t i = 0; i < tb.WE.size(); ++i) npe[i] = tb.WE[i].pos | ((tb.WE[i].rep - 1) << 28);
+    bool ok = up((void **)&n->npos_dev, np.data(), np.size() * sizeof(int)) && up((void **)&n->npos_e_dev, npe.data(), npe.size() * sizeof(int)) && up((void **)&n->w_dev, tb.W.data(), tb.W.size() * sizeof(BnfWElem)) && up((void **)&n->b_dev, tb.B.data(), tb.B.size() * sizeof(BnfBElem)) &&
               up((void **)&n->n_dev, tb.N.data(), tb.N.size() * sizeof(BnfNElem)) && up((void **)&n->we_dev, tb.WE.data(), tb.WE.size() * sizeof(BnfWElem)) &&
               up((void **)&n->be_dev, tb.BE.data(), tb.BE.size() * sizeof(BnfBElem)) && up((void **)&n->ne_dev, tb.NE.data(), tb.NE.size() * sizeof(BnfNElem)) &&
               up((void **)&n->pair_dev, pair_host, sizeof(pair_host));
@@ -345,9 +357,10 @@ void launch_noise(const BnfState *st, bool effects, float *dw, long long set_flo
   BnfNoiseArgs na{};
   const int n_lay = effects ? 4 : 14;
   for (int i = 0; i < n_lay; ++i) na.lay[i] = effects ? st->lay_e[i] : st->lay[i];
-  na.n_lay = n_lay; na.w = effects ? st->we_dev : st->w_dev; na.sf = effects ? st->esf_dev : st->sf_dev; na.dw = dw; na.set_floats = set_floats;
+  na.n_lay = n_lay; na.n_calls = effects ? st->n_calls_e : st->n_calls; na.npos = effects ? st->npos_e_dev : st->npos_dev;
+  na.sf = effects ? st->esf_dev : st->sf_dev; na.dw = dw; na.set_floats = set_floats;
   na.n_states = n_states; na.k0 = (uint32_t)seed; na.k1 = (uint32_t)(seed >> 32); na.stream0 = stream0; na.block0 = block0;
-  hipLaunchKernelGGL(bnf_noise_kernel, dim3(n_lay > 4 ? 8 : 2, n_blocks * n_states), dim3(256), 0, stream, na);
+  hipLaunchKernelGGL(bnf_noise_kernel, dim3((na.n_calls + 1023) / 1024, n_blocks * n_states), dim3(256), 0, stream, na);
 }
 
 void launch_signs(const SgLayout &L, long long n, int bs, int block0, int n_states, int nets, uint64_t seed, uint32_t stream0, unsigned *queue,

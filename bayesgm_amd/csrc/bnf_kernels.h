@@ -179,9 +179,8 @@ __device__ __forceinline__ void bnf_first(const f32x4 *LF, const f32x4 *__restri
 #endif
 template <int R>
 __device__ __forceinline__ void bnf_hidden(const f32x4 *LF, const f32x4 *__restrict__ DW, const f32x4 *__restrict__ DWnext, const f32x4 *BL, int lane,
-                                           int g, const uint32_t (&wo)[R][2], const uint4 (&Gn)[R], float (&h)[R][4][4],
-                                           float (&hs)[R][4][4], f32x4 (&fd)[4]) {
-  float hn[R][4][4], hsn[R][4][4];
+                                           int g, const uint32_t (&wo)[R][2], const uint4 (&Gn)[R], const float (&h)[R][4][4],
+                                           const float (&hs)[R][4][4], float (&hn)[R][4][4], float (&hsn)[R][4][4], f32x4 (&fd)[4]) {
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     f32x4 fn[4];
@@ -220,12 +219,6 @@ __device__ __forceinline__ void bnf_hidden(const f32x4 *LF, const f32x4 *__restr
 #pragma unroll
     for (int t = 0; t < 4; ++t) fd[t] = fn[t];
   }
-#pragma unroll
-  for (int rt = 0; rt < R; ++rt)
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { h[rt][t][r] = hn[rt][t][r]; hs[rt][t][r] = hsn[rt][t][r]; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -404,17 +397,26 @@ __device__ __forceinline__ void bnf_logpost_rows(const BnfMhArgs &a, const BnfLd
 #pragma unroll
       for (int t = 0; t < 4; ++t) fd[t] = D[t * 64 + lane];
     }
+    // two layers per trip: h -> hb -> h, so that no activation is copied at the loop's back edge
 #pragma nounroll
-    for (int l = 1; l <= 4; ++l) {
-      // out-sign words of this layer: the second half of the group requested one layer ago; the next group is requested now and
-      // first touched in this layer's first epilogue
+    for (int l = 1; l <= 4; l += 2) {
+      float hb[R][4][4], hsb[R][4][4];
+      // out-sign words of a layer: the second half of the group requested one layer ago; the next group is requested now and first
+      // touched in this layer's first epilogue
 #pragma unroll
       for (int rt = 0; rt < R; ++rt) { wo[rt][0] = bnf_preshift(Gn[rt].z, g); wo[rt][1] = bnf_preshift(Gn[rt].w, g); }
 #pragma unroll
       for (int rt = 0; rt < R; ++rt) Gn[rt] = (SG + (long long)(l + 1) * a.n)[rib[rt]];
       BNF_PIN();
-      const int fo = (P.fgh + 16 * (l - 1)) * 64;
-      bnf_hidden<R>(L.frag + fo, DW + fo, DW + fo + 16 * 64, L.bias + 4 * (P.bgh + 4 * (l - 1)), lane, g, wo, Gn, h, hs, fd);
+      int fo = (P.fgh + 16 * (l - 1)) * 64;
+      bnf_hidden<R>(L.frag + fo, DW + fo, DW + fo + 16 * 64, L.bias + 4 * (P.bgh + 4 * (l - 1)), lane, g, wo, Gn, h, hs, hb, hsb, fd);
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) { wo[rt][0] = bnf_preshift(Gn[rt].z, g); wo[rt][1] = bnf_preshift(Gn[rt].w, g); }
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) Gn[rt] = (SG + (long long)(l + 2) * a.n)[rib[rt]];
+      BNF_PIN();
+      fo += 16 * 64;
+      bnf_hidden<R>(L.frag + fo, DW + fo, DW + fo + 16 * 64, L.bias + 4 * (P.bgh + 4 * l), lane, g, wo, Gn, hb, hsb, h, hs, fd);
     }
     BNF_T(2);
     {
@@ -917,34 +919,38 @@ static __global__ void bnf_pack_kernel(BnfPackArgs a) {
 }
 
 // dW = sigma * eps of every (block, state): grid (chunks, n_blocks * n_states).  Layer descriptors give the canonical element
-// range of each Flipout kernel; element idx of Philox call i = idx >> 2 (oracle/bnn.py draw_noise).
-struct BnfLayerDesc { int e_base, cnt, l, net_id; };
+// range of each Flipout kernel; element idx of a layer belongs to Philox call idx >> 2 (oracle/bnn.py draw_noise).  All layers of
+// a set form ONE index space of Philox calls (c_base = calls before the layer) so that every thread of the launch has work; the
+// positions come from a 4-byte table (position | (copies - 1) << 28).
+struct BnfLayerDesc { int e_base, cnt, l, net_id, c_base; };
 struct BnfNoiseArgs {
   BnfLayerDesc lay[14];
-  int n_lay;
-  const BnfWElem *w;
-  const float *sf;            // sigma fragments in the layout of the element table
+  int n_lay, n_calls;
+  const int *npos;            // [elements] position in the set, copies - 1 in the top nibble
+  const float *sf;            // sigma fragments in the layout of the position table
   float *dw; long long set_floats;
   int n_states;
   uint32_t k0, k1, stream0;
   int block0;
 };
-static __global__ void bnf_noise_kernel(BnfNoiseArgs a) {
+static __global__ __launch_bounds__(256) void bnf_noise_kernel(BnfNoiseArgs a) {
   const int set = blockIdx.y, blk = set / a.n_states, s = set - blk * a.n_states;
   const uint32_t k1 = a.k1 + (uint32_t)(a.block0 + blk), stream = a.stream0 + (uint32_t)s;
   float *dw = a.dw + (long long)set * a.set_floats;
-  for (int d = 0; d < a.n_lay; ++d) {
-    const BnfLayerDesc L = a.lay[d];
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (L.cnt + 3) >> 2; i += gridDim.x * blockDim.x) {
-      const f32x4 z = box_muller4(philox4x32_10((uint32_t)i, (uint32_t)L.l | ((uint32_t)L.net_id << 16), stream, BNN_TAG_EPS, a.k0, k1));
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < a.n_calls; c += gridDim.x * blockDim.x) {
+    int d = 0;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int idx = 4 * i + u;
-        if (idx < L.cnt) {
-          const BnfWElem e = a.w[L.e_base + idx];
-          const float v = a.sf[e.pos] * z[u];
-          for (int c = 0; c < e.rep; ++c) dw[e.pos + 16 * c] = v;
-        }
+    for (int k = 1; k < 14; ++k) d += (k < a.n_lay && c >= a.lay[k].c_base) ? 1 : 0;
+    const BnfLayerDesc L = a.lay[d];
+    const int i = c - L.c_base;
+    const f32x4 z = box_muller4(philox4x32_10((uint32_t)i, (uint32_t)L.l | ((uint32_t)L.net_id << 16), stream, BNN_TAG_EPS, a.k0, k1));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = 4 * i + u;
+      if (idx < L.cnt) {
+        const int pe = a.npos[L.e_base + idx], pos = pe & 0x0FFFFFFF, rep = (pe >> 28) & 15;
+        const float v = a.sf[pos] * z[u];
+        for (int r = 0; r <= rep; ++r) dw[pos + 16 * r] = v;
       }
     }
   }
