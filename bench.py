@@ -213,10 +213,36 @@ def bayesian_leg(params, data, x_values, n_loc, args, device):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     flop_row = 2 * 2 * 2 * 34848 if (args.p == 200) else None      # two states x two GEMMs per Flipout layer x 2 FLOP/MAC
-    return {"value": n_loc * (burn + keep) / dt, "unit": "MH transitions/s", "seconds": dt,
-            "sample": f"CausalBGM(use_bnn=True).predict, N={n_loc}, bs={bs}, burn_in={burn}, n_mcmc={keep}, 20 doses",
-            "ms_per_iteration": 1e3 * dt / (burn + keep), "acceptance_rate": m.last_acceptance_rate,
-            "flop_per_row_transition": flop_row}
+    out = {"value": n_loc * (burn + keep) / dt, "unit": "MH transitions/s", "seconds": dt,
+           "sample": f"CausalBGM(use_bnn=True).predict, N={n_loc}, bs={bs}, burn_in={burn}, n_mcmc={keep}, 20 doses",
+           "ms_per_iteration": 1e3 * dt / (burn + keep), "acceptance_rate": m.last_acceptance_rate,
+           "flop_per_row_transition": flop_row}
+    # per-iteration cost of the two launch groups (HIP events on the stream the library launches on): a burn-in iteration =
+    # perturbations + sign words + sampler kernel; a kept iteration adds the 20 outcome-net calls.  Fractions are of the fp32-MFMA
+    # peak with the ALGORITHMIC work (2 states x 2 products x 34 848 MAC; 20 doses x 2 products x 2 512 MAC).
+    eng = m.engine
+    xs = torch.as_tensor(np.asarray(x_values, np.float32), device=eng.device)
+    # `data` holds this rank's device tensors behind the Shard wrapper of main()
+    x_, y_, v_ = (a_.t if hasattr(a_, "t") else torch.as_tensor(np.ascontiguousarray(a_, dtype=np.float32), device=eng.device) for a_ in data)
+    x_, y_ = x_.reshape(-1).float().contiguous(), y_.reshape(-1).float().contiguous()
+    v_ = v_.float().contiguous()
+    state = torch.empty((n_loc, eng.q), device=eng.device)
+    its = 20
+    eng.mh_run(x_, y_, v_, state, bs, 0, 2, 0, 1.0, 1, init=True)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    adrf = torch.zeros((len(x_values), its), device=eng.device, dtype=torch.float64)
+    ev[0].record()
+    eng.mh_run(x_, y_, v_, state, bs, 2, its, 10 ** 6, 1.0, 1)
+    ev[1].record()
+    eng.mh_run(x_, y_, v_, state, bs, 100, its, 100, 1.0, 1, n_keep=its, effect=1, x_values=xs, adrf_sum=adrf)
+    ev[2].record()
+    torch.cuda.synchronize()
+    t_mh, t_keep = ev[0].elapsed_time(ev[1]) / its, ev[1].elapsed_time(ev[2]) / its
+    out["burn_in_iteration_ms"], out["kept_iteration_ms"] = t_mh, t_keep
+    if flop_row:
+        out["sampler_frac_of_fp32_mfma_peak"] = flop_row * n_loc / (t_mh * 1e-3) / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+        out["effects_frac_of_fp32_mfma_peak"] = len(x_values) * 2 * 2 * 2512 * n_loc / (max(t_keep - t_mh, 1e-9) * 1e-3) / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+    return out
 
 
 def accuracy_leg(params, data, x_values, n_loc, args):
