@@ -85,6 +85,8 @@ struct bgm_handle {
   DwArgs dw{};
   unsigned *acc_scratch = nullptr;   // [n_slots x n_iters] per-launch acceptance counters
   size_t acc_scratch_cap = 0;
+  void *det_state = nullptr;  // BnfState (bnf_det_api.hip): general-shape sampling path of the deterministic nets
+  bool det_valid = false;
   void *bgm_state = nullptr;  // BgmState (bgm_api.hip)
   void *egm_state = nullptr;  // EgmState (egm_api.hip)
   void *bgm_egm_state = nullptr;  // BgmEgmState (bgm_egm_api.hip)

@@ -10,186 +10,34 @@
 
 #include "bgm_host.h"
 #include "bnf_host.h"
+#include "bnf_build.h"
 #include "bnf_kernels.h"
 #include "bnn_state.h"
 
 namespace {
 
-struct BnfState {
-  BnfPlan P{};
-  int KSc = 0;                          // compiled k-step count (>= P.KS)
-  int KSFc = 0;                         // compiled k-step count of the effects kernel (>= P.KSF)
-  BnfLayerDesc lay[14], lay_e[4];       // Flipout kernels of g | h | f (sampler sets) and of f in the effects layout
-  int n_w = 0, n_b = 0, n_n = 0, n_we = 0, n_be = 0, n_ne = 0;
-  BnfWElem *w_dev = nullptr, *we_dev = nullptr;
-  int *npos_dev = nullptr, *npos_e_dev = nullptr;      // noise kernel's position tables
-  int n_calls = 0, n_calls_e = 0;
-  BnfBElem *b_dev = nullptr, *be_dev = nullptr;
-  BnfNElem *n_dev = nullptr, *ne_dev = nullptr;
-  float *blob_dev = nullptr, *eblob_dev = nullptr, *sf_dev = nullptr, *esf_dev = nullptr;
-  // per-run buffers, grown on demand
-  float *dw_dev = nullptr; size_t dw_cap = 0;          // perturbation sets
-  void *sg_dev = nullptr; size_t sg_cap = 0;           // sign groups
-  float *pair_dev = nullptr;                           // (1, 0): the two treatments of a binary model
-  unsigned *queue_dev = nullptr;                       // [16] item counters: 0..7 sampler, 8..15 effects
-  int lds_mh = 0, lds_eff = 0;
-};
-
-const int kKS[] = {3, 4, 5, 6, 8};
-const int kKSF[] = {1, 2, 3, 4, 8};
-
-bool default_head(const BnnNet &n, int in) {
-  return n.bn_fixed == 1 && !n.heads && !n.mv && n.n_layers == 4 && n.dims[0] == in && n.dims[1] == 64 && n.dims[2] == 32 && n.dims[3] == 8 &&
-         n.dims[4] == 2;
-}
-
-// plan + element tables; false when the session is outside this path
-struct BnfTabs { std::vector<BnfWElem> W, WE; std::vector<BnfBElem> B, BE; std::vector<BnfNElem> N, NE; };
-bool bnf_build(const BnnState *s, BnfState &st, BnfTabs &tb) {
-  std::vector<BnfWElem> &W = tb.W; std::vector<BnfBElem> &B = tb.B; std::vector<BnfNElem> &N = tb.N;
-  const bgm_bnn_config &c = s->cfg;
-  const int q = s->q, p = s->p, z0 = c.z_dims[0], z1 = c.z_dims[1], z2 = c.z_dims[2];
-  const BnnNet &G = s->net[BNN_G], &H = s->net[BNN_H], &F = s->net[BNN_F];
-  if (G.bn_fixed != 1 || G.heads || G.mv || G.n_layers != 6 || G.dims[0] != q || G.dims[6] != p + 1) return false;
-  for (int l = 1; l <= 5; ++l) if (G.dims[l] != 64) return false;
-  if (z0 + z2 < 1 || !default_head(H, z0 + z2) || !default_head(F, z0 + z1 + 1)) return false;
-  if (q < 1 || q > 31 || p + 1 > 208 || p < 4) return false;
-  const int need = (q + 1 + 3) / 4;
-  int KS = 0;
-  for (int k : kKS) if (k >= need) { KS = k; break; }
-  if (!KS) return false;
-  const int T0 = (KS + 3) / 4, NTL = (p + 1 + 15) / 16, head = 4 * T0 + 11;
-  BnfPlan &P = st.P;
-  P = BnfPlan{};
-  P.q = q; P.p = p; P.z0 = z0; P.z1 = z1; P.z2 = z2; P.binary = c.binary_treatment;
-  P.KS = KS; P.NTL = NTL;
-  P.fg0 = 0; P.fgh = 4 * T0; P.fgl = P.fgh + 64; P.fh = P.fgl + 4 * NTL; P.ff = P.fh + head; P.n_frags = P.ff + head;
-  P.bg0 = 0; P.bgh = 4; P.bgl = 20; P.bh = 20 + NTL; P.bf = P.bh + 8;
-  P.bias_off = P.n_frags * 256;
-  P.norm_off = P.bias_off + 16 * (P.bf + 8);
-  P.shift_off = P.norm_off + 3 * T0 * 32;
-  P.blob_floats = P.shift_off + 3 * T0 * 16;
-  P.set_floats = P.n_frags * 256;
-  const int f_in = z0 + z1 + 1, need_f = (f_in + 3) / 4;
-  int KSF = 0;
-  for (int k : kKSF) if (k >= need_f) { KSF = k; break; }
-  if (!KSF) return false;
-  const int T0F = (KSF + 3) / 4;
-  P.KSF = KSF;
-  P.e_frags = 4 * T0F + 11;
-  P.e_bias_off = P.e_frags * 256;
-  P.e_norm_off = P.e_bias_off + 16 * 8;
-  P.e_shift_off = P.e_norm_off + T0F * 32;
-  P.e_blob_floats = P.e_shift_off + T0F * 16;
-  st.KSFc = KSF;
-  if ((size_t)P.blob_floats * 4 > 160 * 1024) return false;
-  st.KSc = KS;
-  st.lds_mh = P.blob_floats * 4;
-  st.lds_eff = (((P.e_blob_floats + 3) & ~3) + 16 * BNF_MAX_DOSES) * 4;      // blob + per-wave dose accumulators (<= 16 waves)
-
-  auto ext = [&](int net, int k) { return net == 0 ? k : net == 1 ? (k < z0 ? k : k + z1) : (k < z0 + z1 ? k : q); };
-  W.clear(); B.clear(); N.clear();
-  st.n_calls = 0; st.n_calls_e = 0;
-  const BnnNet *nets[3] = {&G, &H, &F};
-  const int fbase[3] = {P.fg0, P.fh, P.ff}, bbase[3] = {P.bg0, P.bh, P.bf};
-  int nl = 0;
-  for (int ni = 0; ni < 3; ++ni) {
-    const BnnNet &n = *nets[ni];
-    int fb = fbase[ni], bt = bbase[ni];
-    for (int l = 0; l < n.n_layers; ++l) {
-      const int in = n.dims[l], out = n.dims[l + 1], T = l == 0 ? T0 : (in + 15) / 16, MT = (out + 15) / 16;
-      st.lay[nl] = BnfLayerDesc{(int)W.size(), in * out, l, n.net_id, st.n_calls};
-      st.n_calls += (in * out + 3) / 4; ++nl;
-      const bool head3 = ni > 0 && l == 2, head4 = ni > 0 && l == 3;
-      for (int k = 0; k < in; ++k)
-        for (int o = 0; o < out; ++o) {
-          BnfWElem e{};
-          e.loc = n.woff[l] + k * out + o; e.rho = e.loc + in * out; e.rep = 1; e.scale = l > 0 ? BGM_LRS_W : 1.0f;
-          int t, gg, r, mt = o >> 4, j = o & 15;
-          if (l == 0) { const int x = ext(ni, k); t = x >> 4; r = (x & 15) >> 2; gg = x & 3; }
-          else if (head4) { t = 0; gg = k >> 1; r = k & 1; e.rep = 4; }
-          else { t = k >> 4; gg = (k & 15) >> 2; r = k & 3; }
-          if (head3) j = 4 * (o >> 1) + (o & 1);
-          e.pos = (((fb + mt * T + t) * 64) + gg * 16 + j) * 4 + r;
-          W.push_back(e);
-        }
-      const int boff = n.woff[l] + 2 * in * out;
-      for (int o = 0; o < out; ++o) {
-        BnfBElem e{};
-        e.src = boff + o; e.rep = head4 ? 4 : 1;
-        const int j = head3 ? 4 * (o >> 1) + (o & 1) : (o & 15);
-        e.pos = 16 * (bt + (o >> 4)) + j;
-        B.push_back(e);
-      }
-      fb += T * MT; bt += MT;
-    }
-    for (int x = 0; x < 16 * T0; ++x) {
-      int k = -1;
-      for (int kk = 0; kk < n.dims[0]; ++kk) if (ext(ni, kk) == x) k = kk;
-      const int sb = x >> 4, r = (x & 15) >> 2, gg = x & 3;
-      BnfNElem e{};
-      e.gamma = k >= 0 ? n.off + k : -1; e.beta = k >= 0 ? n.off + n.dims[0] + k : -1;
-      e.pos_sc = P.norm_off + ((ni * T0 + sb) * 2) * 16 + gg * 4 + r;
-      e.pos_sh = e.pos_sc + 16;
-      e.pos_shift = P.shift_off + (ni * T0 + sb) * 16 + gg * 4 + r;
-      e.shift = k >= 0 ? 31 - k : 0;
-      N.push_back(e);
-    }
+BnfNetSrc src_of(const BnnNet &b) {
+  BnfNetSrc n;
+  n.n_layers = b.n_layers; n.net_id = b.net_id;
+  for (int l = 0; l <= b.n_layers && l < 9; ++l) n.dims[l] = b.dims[l];
+  for (int l = 0; l < b.n_layers && l < 8; ++l) {
+    const int cnt = b.dims[l] * b.dims[l + 1];
+    n.woff[l] = b.woff[l]; n.roff[l] = b.woff[l] + cnt; n.boff[l] = b.woff[l] + 2 * cnt;
   }
-  // effects layout: the outcome net alone, first layer over its own input (z0, z1, x)
-  tb.WE.clear(); tb.BE.clear(); tb.NE.clear();
-  {
-    const BnnNet &n = F;
-    int fb = 0, bt = 0;
-    for (int l = 0; l < n.n_layers; ++l) {
-      const int in = n.dims[l], out = n.dims[l + 1], T = l == 0 ? T0F : (in + 15) / 16, MT = (out + 15) / 16;
-      st.lay_e[l] = BnfLayerDesc{(int)tb.WE.size(), in * out, l, n.net_id, st.n_calls_e};
-      st.n_calls_e += (in * out + 3) / 4;
-      const bool head3 = l == 2, head4 = l == 3;
-      for (int k = 0; k < in; ++k)
-        for (int o = 0; o < out; ++o) {
-          BnfWElem e{};
-          e.loc = n.woff[l] + k * out + o; e.rho = e.loc + in * out; e.rep = 1; e.scale = l > 0 ? BGM_LRS_W : 1.0f;
-          int t_, gg, r, mt = o >> 4, j = o & 15;
-          if (l == 0) { t_ = k >> 4; r = (k & 15) >> 2; gg = k & 3; }
-          else if (head4) { t_ = 0; gg = k >> 1; r = k & 1; e.rep = 4; }
-          else { t_ = k >> 4; gg = (k & 15) >> 2; r = k & 3; }
-          if (head3) j = 4 * (o >> 1) + (o & 1);
-          e.pos = (((fb + mt * T + t_) * 64) + gg * 16 + j) * 4 + r;
-          tb.WE.push_back(e);
-        }
-      const int boff = n.woff[l] + 2 * in * out;
-      for (int o = 0; o < out; ++o) {
-        BnfBElem e{};
-        e.src = boff + o; e.rep = head4 ? 4 : 1;
-        const int j = head3 ? 4 * (o >> 1) + (o & 1) : (o & 15);
-        e.pos = 16 * (bt + (o >> 4)) + j;
-        tb.BE.push_back(e);
-      }
-      fb += T * MT; bt += MT;
-    }
-    for (int x = 0; x < 16 * T0F; ++x) {
-      const int k = x < n.dims[0] ? x : -1;
-      const int sb = x >> 4, r = (x & 15) >> 2, gg = x & 3;
-      BnfNElem e{};
-      e.gamma = k >= 0 ? n.off + k : -1; e.beta = k >= 0 ? n.off + n.dims[0] + k : -1;
-      e.pos_sc = P.e_norm_off + (sb * 2) * 16 + gg * 4 + r;
-      e.pos_sh = e.pos_sc + 16;
-      e.pos_shift = P.e_shift_off + sb * 16 + gg * 4 + r;
-      e.shift = k >= 0 ? 31 - k : 0;
-      tb.NE.push_back(e);
-    }
-  }
-  return nl == 14;
+  n.gamma = b.off; n.beta = b.off + b.dims[0];
+  return n;
 }
-
-void bnf_release(BnfState *st) {
-  if (!st) return;
-  for (void *p : {(void *)st->w_dev, (void *)st->b_dev, (void *)st->n_dev, (void *)st->we_dev, (void *)st->be_dev, (void *)st->ne_dev,
-                  (void *)st->esf_dev, (void *)st->npos_dev, (void *)st->npos_e_dev, (void *)st->blob_dev, (void *)st->eblob_dev, (void *)st->sf_dev,
-                  (void *)st->dw_dev, st->sg_dev, (void *)st->pair_dev, (void *)st->queue_dev})
-    if (p) hipFree(p);
-  delete st;
+// false when the session is outside this path (inference-mode normalisation, default widths, q <= 31, 4 <= p <= 207)
+bool bnf_build_bnn(const BnnState *s, BnfState &st, BnfTabs &tb) {
+  for (int k : {BNN_G, BNN_H, BNN_F}) {
+    const BnnNet &b = s->net[k];
+    if (b.bn_fixed != 1 || b.heads || b.mv || b.n_layers > 8) return false;
+  }
+  BnfSrc S;
+  S.g = src_of(s->net[BNN_G]); S.h = src_of(s->net[BNN_H]); S.f = src_of(s->net[BNN_F]);
+  S.q = s->q; S.p = s->p; S.z0 = s->cfg.z_dims[0]; S.z1 = s->cfg.z_dims[1]; S.z2 = s->cfg.z_dims[2]; S.binary = s->cfg.binary_treatment;
+  S.det = false;
+  return bnf_build(S, st, tb);
 }
 
 // ---- kernel variants: (R row tiles per wave, WAVES per workgroup).  The shipped one is (BNF_R, BNF_W); a development build
@@ -274,44 +122,14 @@ int bnf_session(bgm_handle *h, BnnState *s, BnfState *&st, hipStream_t stream) {
     if (std::getenv("BGM_BNF_OFF")) return 1;
     BnfState *n = new BnfState();
     BnfTabs tb;
-    if (!bnf_build(s, *n, tb)) { delete n; s->bnf_unsupported = true; return 1; }
-    n->n_w = (int)tb.W.size(); n->n_b = (int)tb.B.size(); n->n_n = (int)tb.N.size();
-    n->n_we = (int)tb.WE.size(); n->n_be = (int)tb.BE.size(); n->n_ne = (int)tb.NE.size();
-    auto up = [&](void **dst, const void *src, size_t bytes) {
-      if (hipMalloc(dst, bytes) != hipSuccess) return false;
-      return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
-    };
-    static const float pair_host[2] = {1.0f, 0.0f};
-    std::vector<int> np(tb.W.size()), npe(tb.WE.size());
-    for (size_t i = 0; i < tb.W.size(); ++i) np[i] = tb.W[i].pos | ((tb.W[i].rep - 1) << 28);
-    for (size_t i = 0; i < tb.WE.size(); ++i) npe[i] = tb.WE[i].pos | ((tb.WE[i].rep - 1) << 28);
-    bool ok = up((void **)&n->npos_dev, np.data(), np.size() * sizeof(int)) && up((void **)&n->npos_e_dev, npe.data(), npe.size() * sizeof(int)) && up((void **)&n->w_dev, tb.W.data(), tb.W.size() * sizeof(BnfWElem)) && up((void **)&n->b_dev, tb.B.data(), tb.B.size() * sizeof(BnfBElem)) &&
-              up((void **)&n->n_dev, tb.N.data(), tb.N.size() * sizeof(BnfNElem)) && up((void **)&n->we_dev, tb.WE.data(), tb.WE.size() * sizeof(BnfWElem)) &&
-              up((void **)&n->be_dev, tb.BE.data(), tb.BE.size() * sizeof(BnfBElem)) && up((void **)&n->ne_dev, tb.NE.data(), tb.NE.size() * sizeof(BnfNElem)) &&
-              up((void **)&n->pair_dev, pair_host, sizeof(pair_host));
-    ok = ok && hipMalloc((void **)&n->blob_dev, sizeof(float) * n->P.blob_floats) == hipSuccess &&
-         hipMalloc((void **)&n->eblob_dev, sizeof(float) * n->P.e_blob_floats) == hipSuccess &&
-         hipMalloc((void **)&n->sf_dev, sizeof(float) * n->P.set_floats) == hipSuccess &&
-         hipMalloc((void **)&n->esf_dev, sizeof(float) * n->P.e_frags * 256) == hipSuccess &&
-         hipMalloc((void **)&n->queue_dev, 16 * sizeof(unsigned)) == hipSuccess;
-    if (!ok) { bnf_release(n); bgm_set_error("bnf: device allocation failed"); return BGM_E_HIP; }
+    if (!bnf_build_bnn(s, *n, tb)) { delete n; s->bnf_unsupported = true; return 1; }
+    if (!bnf_upload(n, tb)) { bnf_release(n); bgm_set_error("bnf: device allocation failed"); return BGM_E_HIP; }
     s->bnf = n; s->bnf_valid = false;
     st = n;
   }
   if (!s->bnf_valid) {
-    const BnfPlan &P = st->P;
-    BGM_HIP_CHECK(hipMemsetAsync(st->blob_dev, 0, sizeof(float) * P.blob_floats, stream));
-    BGM_HIP_CHECK(hipMemsetAsync(st->eblob_dev, 0, sizeof(float) * P.e_blob_floats, stream));
-    BGM_HIP_CHECK(hipMemsetAsync(st->sf_dev, 0, sizeof(float) * P.set_floats, stream));
-    BGM_HIP_CHECK(hipMemsetAsync(st->esf_dev, 0, sizeof(float) * P.e_frags * 256, stream));
-    BnfPackArgs pa{};
-    pa.theta = s->theta_dev; pa.w = st->w_dev; pa.n_w = st->n_w; pa.b = st->b_dev; pa.n_b = st->n_b; pa.ne = st->n_dev; pa.n_n = st->n_n;
-    pa.blob = st->blob_dev; pa.sf = st->sf_dev; pa.bias_off = P.bias_off;
-    hipLaunchKernelGGL(bnf_pack_kernel, dim3(64), dim3(256), 0, stream, pa);
-    pa.w = st->we_dev; pa.n_w = st->n_we; pa.b = st->be_dev; pa.n_b = st->n_be; pa.ne = st->ne_dev; pa.n_n = st->n_ne;
-    pa.blob = st->eblob_dev; pa.sf = st->esf_dev; pa.bias_off = P.e_bias_off;
-    hipLaunchKernelGGL(bnf_pack_kernel, dim3(16), dim3(256), 0, stream, pa);
-    BGM_HIP_CHECK(hipGetLastError());
+    int rc = bnf_pack(st, s->theta_dev, stream);
+    if (rc) return rc;
     s->bnf_valid = true;
   }
   (void)h;

@@ -61,6 +61,7 @@ struct BnfPlan {
   int bias_off, norm_off, shift_off, blob_floats;   // float offsets inside the LDS blob [frags | bias tiles | norm | shift]
   int bg0, bgh, bgl, bh, bf;  // bias tiles (16 floats) of the same
   int set_floats;             // one perturbation set: n_frags * 256
+  int lds_skip;               // floats of the blob that stay out of the LDS (WIDE: g's last layer, placed last among the fragments), else 0
   // effects blob (outcome net only): [f frags | f bias tiles | f norm | f shift].  Its first layer contracts over the net's OWN input
   // (z0, z1, x) -- slot (gg, r) of k-tile sb = input 16 sb + 4 r + gg -- in KSF = ceil((z0 + z1 + 1) / 4) k-steps (1 for z_dims
   // [1, 1, 1, 7] against the 3 of the shared extended input)
@@ -105,17 +106,21 @@ struct BnfLds {
 // net), flips with the input-sign word w_in, runs both products and finishes the four output tiles.
 // wo: output-sign words (pre-shifted), wi: input-sign words of the NEXT layer (pre-shifted).
 // ---------------------------------------------------------------------------------------------
-template <int KS, int R>
+// DET: deterministic nets (BaseFullyConnectedNet, networks/base.py:4-51) = the same walk without the perturbation product, the sign
+// flips and their loads: y = loc^T h + b
+template <int KS, int R, bool DET = false>
 __device__ __forceinline__ void bnf_first(const f32x4 *LF, const f32x4 *__restrict__ DW, const f32x4 *BL, const f32x4 *NORM, const int4 *SHIFT,
                                           int lane, int g, const float (&ze)[R][KS], const uint32_t (&w_in)[R], const uint32_t (&wo)[R][2],
                                           const uint4 (&Gn)[R], float (&h)[R][4][4], float (&hs)[R][4][4]) {
   constexpr int T0 = (KS + 3) / 4;
   f32x4 fd[4][T0];
+  if constexpr (!DET) {
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-    for (int sb = 0; sb < T0; ++sb) fd[mt][sb] = DW[(mt * T0 + sb) * 64 + lane];
-  BNF_PIN();
+      for (int sb = 0; sb < T0; ++sb) fd[mt][sb] = DW[(mt * T0 + sb) * 64 + lane];
+    BNF_PIN();
+  }
   float hb[R][KS], hsb[R][KS];
 #pragma unroll
   for (int sb = 0; sb < T0; ++sb) {
@@ -130,7 +135,7 @@ __device__ __forceinline__ void bnf_first(const f32x4 *LF, const f32x4 *__restri
         for (int rt = 0; rt < R; ++rt) {
           const float x = fmaf(ze[rt][ks], sc[r], sh[r]);
           hb[rt][ks] = x;
-          hsb[rt][ks] = x * bnf_pm1(w_in[rt] << sft);
+          if constexpr (!DET) hsb[rt][ks] = x * bnf_pm1(w_in[rt] << sft);
         }
       }
     }
@@ -150,7 +155,7 @@ __device__ __forceinline__ void bnf_first(const f32x4 *LF, const f32x4 *__restri
 #pragma unroll
           for (int rt = 0; rt < R; ++rt) {
             a1[rt] = BGM_MFMA(fa[r], hb[rt][4 * sb + r], a1[rt]);
-            a2[rt] = BGM_MFMA(fd[mt][sb][r], hsb[rt][4 * sb + r], a2[rt]);
+            if constexpr (!DET) a2[rt] = BGM_MFMA(fd[mt][sb][r], hsb[rt][4 * sb + r], a2[rt]);
           }
         }
     }
@@ -158,10 +163,13 @@ __device__ __forceinline__ void bnf_first(const f32x4 *LF, const f32x4 *__restri
     for (int rt = 0; rt < R; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float y = fmaf(a2[rt][r], bnf_sign_rt(wo[rt][mt >> 1], 16 * (mt & 1) + r), a1[rt][r]);
-        const float v = lrelu_s(y);
-        h[rt][mt][r] = v;
-        hs[rt][mt][r] = v * bnf_sign_rt(bnf_preshift(mt < 2 ? Gn[rt].x : Gn[rt].y, g), 16 * (mt & 1) + r);
+        if constexpr (DET) h[rt][mt][r] = lrelu_s(a1[rt][r]);
+        else {
+          const float y = fmaf(a2[rt][r], bnf_sign_rt(wo[rt][mt >> 1], 16 * (mt & 1) + r), a1[rt][r]);
+          const float v = lrelu_s(y);
+          h[rt][mt][r] = v;
+          hs[rt][mt][r] = v * bnf_sign_rt(bnf_preshift(mt < 2 ? Gn[rt].x : Gn[rt].y, g), 16 * (mt & 1) + r);
+        }
       }
   }
 }
@@ -177,17 +185,19 @@ __device__ __forceinline__ void bnf_first(const f32x4 *LF, const f32x4 *__restri
 #else
 #define BNF_DWSRC(dw, lf) (dw)
 #endif
-template <int R>
+template <int R, bool DET = false>
 __device__ __forceinline__ void bnf_hidden(const f32x4 *LF, const f32x4 *__restrict__ DW, const f32x4 *__restrict__ DWnext, const f32x4 *BL, int lane,
                                            int g, const uint32_t (&wo)[R][2], const uint4 (&Gn)[R], const float (&h)[R][4][4],
                                            const float (&hs)[R][4][4], float (&hn)[R][4][4], float (&hsn)[R][4][4], f32x4 (&fd)[4]) {
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     f32x4 fn[4];
-    const f32x4 *nx = (mt < 3) ? BNF_DWSRC(DW, LF) + (mt + 1) * 4 * 64 : BNF_DWSRC(DWnext, LF);
+    if constexpr (!DET) {
+      const f32x4 *nx = (mt < 3) ? BNF_DWSRC(DW, LF) + (mt + 1) * 4 * 64 : BNF_DWSRC(DWnext, LF);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) fn[t] = nx[t * 64 + lane];
-    BNF_PIN();
+      for (int t = 0; t < 4; ++t) fn[t] = nx[t * 64 + lane];
+      BNF_PIN();
+    } else BGM_NO_HOIST();
     f32x4 a1[R], a2[R];
     const f32x4 b = BL[4 * mt + g];
 #pragma unroll
@@ -200,13 +210,14 @@ __device__ __forceinline__ void bnf_hidden(const f32x4 *LF, const f32x4 *__restr
 #pragma unroll
         for (int rt = 0; rt < R; ++rt) {
           a1[rt] = BGM_MFMA(fa[r], h[rt][t][r], a1[rt]);
-          a2[rt] = BGM_MFMA(fd[t][r], hs[rt][t][r], a2[rt]);
+          if constexpr (!DET) a2[rt] = BGM_MFMA(fd[t][r], hs[rt][t][r], a2[rt]);
         }
     }
 #pragma unroll
     for (int rt = 0; rt < R; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
+        if constexpr (DET) { hn[rt][mt][r] = lrelu_s(a1[rt][r]); continue; }
 #ifdef BNF_ABL_NOEPI
         hn[rt][mt][r] = a1[rt][r]; hsn[rt][mt][r] = a2[rt][r];
 #else
@@ -216,8 +227,10 @@ __device__ __forceinline__ void bnf_hidden(const f32x4 *LF, const f32x4 *__restr
         hsn[rt][mt][r] = v * bnf_sign_rt(bnf_preshift(mt < 2 ? Gn[rt].x : Gn[rt].y, g), 16 * (mt & 1) + r);      // Gn: requested at the layer's start, first touched here
 #endif
       }
+    if constexpr (!DET) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) fd[t] = fn[t];
+      for (int t = 0; t < 4; ++t) fd[t] = fn[t];
+    }
   }
 }
 
@@ -226,13 +239,13 @@ __device__ __forceinline__ void bnf_hidden(const f32x4 *LF, const f32x4 *__restr
 // row tile.  Returns the two outputs (mean, raw variance) of every row, valid in all four lane groups.
 // LF / DW: the net's first fragment in LDS / in the call's perturbation set; BL: its first bias tile.
 // ---------------------------------------------------------------------------------------------
-template <int KS, int R>
+template <int KS, int R, bool DET = false>
 __device__ __forceinline__ void bnf_head(const f32x4 *LF, const f32x4 *__restrict__ DW, const f32x4 *BL, const f32x4 *NORM, const int4 *SHIFT, int lane,
                                          int g, const float (&ze)[R][KS], const uint4 (&G)[R][BNF_NG_H], float (&mu)[R], float (&raw)[R]) {
   constexpr int T0 = (KS + 3) / 4;
   // perturbation fragments of layers 2..4 requested up front (11 KB per wave): the small layers have no tile loop to hide them in
   f32x4 fd2[2][4], fd3[2], fd4;
-  {
+  if constexpr (!DET) {
     const f32x4 *D2 = DW + 4 * T0 * 64;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -240,8 +253,8 @@ __device__ __forceinline__ void bnf_head(const f32x4 *LF, const f32x4 *__restric
       for (int t = 0; t < 4; ++t) fd2[mt][t] = D2[(mt * 4 + t) * 64 + lane];
     fd3[0] = D2[8 * 64 + lane]; fd3[1] = D2[9 * 64 + lane];
     fd4 = D2[10 * 64 + lane];
+    BNF_PIN();
   }
-  BNF_PIN();
   float h1[R][4][4], hs1[R][4][4];
   {
     uint32_t w_in[R], wo[R][2];
@@ -252,7 +265,7 @@ __device__ __forceinline__ void bnf_head(const f32x4 *LF, const f32x4 *__restric
       wo[rt][0] = bnf_preshift(G[rt][0].y, g); wo[rt][1] = bnf_preshift(G[rt][0].z, g);
       Gn[rt] = G[rt][1];
     }
-    bnf_first<KS, R>(LF, DW, BL, NORM, SHIFT, lane, g, ze, w_in, wo, Gn, h1, hs1);
+    bnf_first<KS, R, DET>(LF, DW, BL, NORM, SHIFT, lane, g, ze, w_in, wo, Gn, h1, hs1);
   }
   // layer 2: 64 -> 32
   const f32x4 *L2 = LF + 4 * T0 * 64;
@@ -271,18 +284,23 @@ __device__ __forceinline__ void bnf_head(const f32x4 *LF, const f32x4 *__restric
 #pragma unroll
         for (int rt = 0; rt < R; ++rt) {
           a1[rt] = BGM_MFMA(fa[r], h1[rt][t][r], a1[rt]);
-          a2[rt] = BGM_MFMA(fd2[mt][t][r], hs1[rt][t][r], a2[rt]);
+          if constexpr (!DET) a2[rt] = BGM_MFMA(fd2[mt][t][r], hs1[rt][t][r], a2[rt]);
         }
     }
 #pragma unroll
     for (int rt = 0; rt < R; ++rt) {
-      const uint32_t so = bnf_preshift(G[rt][1].z, g), si = bnf_preshift(G[rt][1].w, g);
+      if constexpr (DET) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float y = fmaf(a2[rt][r], bnf_sign_rt(so, 16 * mt + r), a1[rt][r]);
-        const float v = lrelu_s(y);
-        h2[rt][mt][r] = v;
-        hs2[rt][mt][r] = v * bnf_sign_rt(si, 16 * mt + r);
+        for (int r = 0; r < 4; ++r) h2[rt][mt][r] = lrelu_s(a1[rt][r]);
+      } else {
+        const uint32_t so = bnf_preshift(G[rt][1].z, g), si = bnf_preshift(G[rt][1].w, g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float y = fmaf(a2[rt][r], bnf_sign_rt(so, 16 * mt + r), a1[rt][r]);
+          const float v = lrelu_s(y);
+          h2[rt][mt][r] = v;
+          hs2[rt][mt][r] = v * bnf_sign_rt(si, 16 * mt + r);
+        }
       }
     }
   }
@@ -302,18 +320,22 @@ __device__ __forceinline__ void bnf_head(const f32x4 *LF, const f32x4 *__restric
 #pragma unroll
         for (int rt = 0; rt < R; ++rt) {
           a1[rt] = BGM_MFMA(fa[r], h2[rt][t][r], a1[rt]);
-          a2[rt] = BGM_MFMA(fd3[t][r], hs2[rt][t][r], a2[rt]);
+          if constexpr (!DET) a2[rt] = BGM_MFMA(fd3[t][r], hs2[rt][t][r], a2[rt]);
         }
     }
 #pragma unroll
     for (int rt = 0; rt < R; ++rt) {
-      const uint32_t so = G[rt][2].x << (30 - 2 * g), si = G[rt][2].y << (30 - 2 * g);   // bit 2 gg + r at position 30 + r
+      if constexpr (DET) {
+        h3[rt][0] = lrelu_s(a1[rt][0]); h3[rt][1] = lrelu_s(a1[rt][1]);
+      } else {
+        const uint32_t so = G[rt][2].x << (30 - 2 * g), si = G[rt][2].y << (30 - 2 * g);   // bit 2 gg + r at position 30 + r
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const float y = fmaf(a2[rt][r], bnf_pm1(r ? so : so << 1), a1[rt][r]);
-        const float v = lrelu_s(y);
-        h3[rt][r] = v;
-        hs3[rt][r] = v * bnf_pm1(r ? si : si << 1);
+        for (int r = 0; r < 2; ++r) {
+          const float y = fmaf(a2[rt][r], bnf_pm1(r ? so : so << 1), a1[rt][r]);
+          const float v = lrelu_s(y);
+          h3[rt][r] = v;
+          hs3[rt][r] = v * bnf_pm1(r ? si : si << 1);
+        }
       }
     }
   }
@@ -327,11 +349,14 @@ __device__ __forceinline__ void bnf_head(const f32x4 *LF, const f32x4 *__restric
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         a1 = BGM_MFMA(fa[r], h3[rt][r], a1);
-        a2 = BGM_MFMA(fd4[r], hs3[rt][r], a2);
+        if constexpr (!DET) a2 = BGM_MFMA(fd4[r], hs3[rt][r], a2);
       }
-      const uint32_t so = G[rt][2].z;
-      mu[rt] = fmaf(a2[0], bnf_pm1(so << 31), a1[0]);
-      raw[rt] = fmaf(a2[1], bnf_pm1(so << 30), a1[1]);
+      if constexpr (DET) { mu[rt] = a1[0]; raw[rt] = a1[1]; }
+      else {
+        const uint32_t so = G[rt][2].z;
+        mu[rt] = fmaf(a2[0], bnf_pm1(so << 31), a1[0]);
+        raw[rt] = fmaf(a2[1], bnf_pm1(so << 30), a1[1]);
+      }
     }
   }
 }
@@ -355,14 +380,21 @@ struct BnfMhArgs {
   uint32_t k0, k1;
   float *out;
   unsigned *acc_count, *acc_blocks;
-  unsigned *queue;                     // [8] item counters, one per XCD (zeroed by bnf_signs_kernel)
+  unsigned *queue;                     // [8] item counters, one per XCD (zeroed by bnf_signs_kernel / by the host for deterministic nets)
+  float *lp_cache;                     // deterministic nets, MODE 1: [n] log posterior of the current states (in / out)
+  double *sums;                        // MODE 2: [3] += sum |v - mu_v|^2, sum (x - x_pred)^2, sum (y - mu_y)^2
+  float sig2_v, sig2_x, sig2_y;        // deterministic nets: fixed variances params['sigma_*']^2 (<= 0: the networks' variance heads)
   unsigned long long *prof;            // -D BNF_PROF
 };
 
-template <int KS, int R>
+// DET: deterministic nets.  WIDE: g's last layer does not fit the LDS next to the rest (p > 207 at the default widths): its loc
+// fragments stay in the packed blob in HBM / L2 and are requested one output tile ahead, like the perturbations (the workgroups of
+// an XCD walk the same fragments at about the same time, so they come from L2).  EVAL: instead of the log posterior return the
+// pieces CausalBGM.evaluate needs (base.py:534-570): aux = {sum_j (mu_v - v)^2, mu_x (logit for a binary model), mu_y}.
+template <int KS, int R, bool DET = false, bool WIDE = false, bool EVAL = false>
 __device__ __forceinline__ void bnf_logpost_rows(const BnfMhArgs &a, const BnfLds &L, int lane, int j, int g, long long blk_lo, const int (&rib)[R],
                                                  const float (&ze)[R][KS], const float (&xr)[R], const float (&yr)[R], const float *dwset, int s,
-                                                 const float (&zz)[R], float (&lp)[R] BNF_PROF_PARAM) {
+                                                 const float (&zz)[R], float (&lp)[R], float (&aux)[R][3] BNF_PROF_PARAM) {
   constexpr int T0 = (KS + 3) / 4;
   const BnfPlan &P = a.pl;
   const int p = P.p;
@@ -375,24 +407,28 @@ __device__ __forceinline__ void bnf_logpost_rows(const BnfMhArgs &a, const BnfLd
   {
     float h[R][4][4], hs[R][4][4];
     // wave-uniform bases of the block's rows; per-lane offsets stay 32-bit
-    const uint4 *SG = a.sg.g + ((long long)s * BNF_NG_G * a.n + blk_lo);
+    const uint4 *SG = DET ? nullptr : a.sg.g + ((long long)s * BNF_NG_G * a.n + blk_lo);
     uint4 Gc[R], Gn[R];
+    if constexpr (!DET) {
 #pragma unroll
-    for (int rt = 0; rt < R; ++rt) { Gc[rt] = SG[rib[rt]]; Gn[rt] = (SG + a.n)[rib[rt]]; }
-    BNF_PIN();
+      for (int rt = 0; rt < R; ++rt) { Gc[rt] = SG[rib[rt]]; Gn[rt] = (SG + a.n)[rib[rt]]; }
+      BNF_PIN();
+    }
     uint32_t wo[R][2];
     {
       uint32_t w_in[R];
+      if constexpr (!DET) {
 #pragma unroll
-      for (int rt = 0; rt < R; ++rt) {
-        w_in[rt] = Gc[rt].x;
-        wo[rt][0] = bnf_preshift(Gc[rt].y, g); wo[rt][1] = bnf_preshift(Gc[rt].z, g);
+        for (int rt = 0; rt < R; ++rt) {
+          w_in[rt] = Gc[rt].x;
+          wo[rt][0] = bnf_preshift(Gc[rt].y, g); wo[rt][1] = bnf_preshift(Gc[rt].z, g);
+        }
       }
-      bnf_first<KS, R>(L.frag + P.fg0 * 64, DW + P.fg0 * 64, L.bias + 4 * P.bg0, L.norm, L.shift, lane, g, ze, w_in, wo, Gn, h, hs);
+      bnf_first<KS, R, DET>(L.frag + P.fg0 * 64, DW + P.fg0 * 64, L.bias + 4 * P.bg0, L.norm, L.shift, lane, g, ze, w_in, wo, Gn, h, hs);
     }
     BNF_T(1);
     f32x4 fd[4];
-    {
+    if constexpr (!DET) {
       const f32x4 *D = DW + P.fgh * 64;
 #pragma unroll
       for (int t = 0; t < 4; ++t) fd[t] = D[t * 64 + lane];
@@ -403,23 +439,29 @@ __device__ __forceinline__ void bnf_logpost_rows(const BnfMhArgs &a, const BnfLd
       float hb[R][4][4], hsb[R][4][4];
       // out-sign words of a layer: the second half of the group requested one layer ago; the next group is requested now and first
       // touched in this layer's first epilogue
+      if constexpr (!DET) {
 #pragma unroll
-      for (int rt = 0; rt < R; ++rt) { wo[rt][0] = bnf_preshift(Gn[rt].z, g); wo[rt][1] = bnf_preshift(Gn[rt].w, g); }
+        for (int rt = 0; rt < R; ++rt) { wo[rt][0] = bnf_preshift(Gn[rt].z, g); wo[rt][1] = bnf_preshift(Gn[rt].w, g); }
 #pragma unroll
-      for (int rt = 0; rt < R; ++rt) Gn[rt] = (SG + (long long)(l + 1) * a.n)[rib[rt]];
-      BNF_PIN();
+        for (int rt = 0; rt < R; ++rt) Gn[rt] = (SG + (long long)(l + 1) * a.n)[rib[rt]];
+        BNF_PIN();
+      }
       int fo = (P.fgh + 16 * (l - 1)) * 64;
-      bnf_hidden<R>(L.frag + fo, DW + fo, DW + fo + 16 * 64, L.bias + 4 * (P.bgh + 4 * (l - 1)), lane, g, wo, Gn, h, hs, hb, hsb, fd);
+      bnf_hidden<R, DET>(L.frag + fo, DW + fo, DW + fo + 16 * 64, L.bias + 4 * (P.bgh + 4 * (l - 1)), lane, g, wo, Gn, h, hs, hb, hsb, fd);
+      if constexpr (!DET) {
 #pragma unroll
-      for (int rt = 0; rt < R; ++rt) { wo[rt][0] = bnf_preshift(Gn[rt].z, g); wo[rt][1] = bnf_preshift(Gn[rt].w, g); }
+        for (int rt = 0; rt < R; ++rt) { wo[rt][0] = bnf_preshift(Gn[rt].z, g); wo[rt][1] = bnf_preshift(Gn[rt].w, g); }
 #pragma unroll
-      for (int rt = 0; rt < R; ++rt) Gn[rt] = (SG + (long long)(l + 2) * a.n)[rib[rt]];
-      BNF_PIN();
+        for (int rt = 0; rt < R; ++rt) Gn[rt] = (SG + (long long)(l + 2) * a.n)[rib[rt]];
+        BNF_PIN();
+      }
       fo += 16 * 64;
-      bnf_hidden<R>(L.frag + fo, DW + fo, DW + fo + 16 * 64, L.bias + 4 * (P.bgh + 4 * l), lane, g, wo, Gn, hb, hsb, h, hs, fd);
+      // the fragments behind the last hidden layer are those of g's last layer, wherever the plan put them
+      bnf_hidden<R, DET>(L.frag + fo, DW + fo, (l + 1 < 4) ? DW + fo + 16 * 64 : DW + P.fgl * 64, L.bias + 4 * (P.bgh + 4 * l), lane, g, wo, Gn, hb,
+                         hsb, h, hs, fd);
     }
     BNF_T(2);
-    {
+    if constexpr (!DET) {
       const uint4 *SH = a.sg.h + ((long long)s * BNF_NG_H * a.n + blk_lo);
 #pragma unroll
       for (int rt = 0; rt < R; ++rt)
@@ -429,7 +471,8 @@ __device__ __forceinline__ void bnf_logpost_rows(const BnfMhArgs &a, const BnfLd
     // last layer: 64 -> p + 1, tile by tile against the data row; fd holds tile 0's perturbation fragments
     const int NTL = P.NTL;
     const f32x4 *LFl = L.frag + P.fgl * 64, *DWl = DW + P.fgl * 64, *BLl = L.bias + 4 * P.bgl;
-    const uint32_t *GO = a.sg.gout + ((long long)s * a.n + blk_lo) * BNF_GOUT;
+    const f32x4 *LFg = (const f32x4 *)a.blob + P.fgl * 64;          // WIDE: the same fragments in the packed blob (HBM / L2)
+    const uint32_t *GO = DET ? nullptr : a.sg.gout + ((long long)s * a.n + blk_lo) * BNF_GOUT;
     const float *vblk = a.v + blk_lo * p;
     // the lane's four columns of the data row as ONE 16-byte request (dword-aligned: p need not be a multiple of 4); nothing is
     // done with the value before the tile that consumes it, so the request stays in flight for a whole tile.  Only the last tile
@@ -438,11 +481,15 @@ __device__ __forceinline__ void bnf_logpost_rows(const BnfMhArgs &a, const BnfLd
       const float *vr = vblk + rib[rt] * p + min(16 * mt + 4 * g, p - 4);
       return *(const f32x4_u *)vr;
     };
-    f32x4 vn[R];
+    f32x4 vn[R], fw[4];
     uint32_t wn[R];
 #pragma unroll
-    for (int rt = 0; rt < R; ++rt) { vn[rt] = load_v(rt, 0); wn[rt] = GO[rib[rt] * BNF_GOUT]; ssq[rt] = 0.0f; rawv[rt] = 0.0f; }
-    auto tile = [&](int mt, bool last, const f32x4 (&vc)[R], const uint32_t (&wc)[R], const f32x4 (&fc)[4]) __attribute__((always_inline)) {
+    for (int rt = 0; rt < R; ++rt) { vn[rt] = load_v(rt, 0); wn[rt] = DET ? 0u : GO[rib[rt] * BNF_GOUT]; ssq[rt] = 0.0f; rawv[rt] = 0.0f; }
+    if constexpr (WIDE) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fw[t] = LFg[t * 64 + lane];
+    }
+    auto tile = [&](int mt, bool last, const f32x4 (&vc)[R], const uint32_t (&wc)[R], const f32x4 (&fc)[4], const f32x4 (&fwc)[4]) __attribute__((always_inline)) {
       f32x4 a1[R], a2[R];
       const f32x4 b = BLl[4 * mt + g];
 #pragma unroll
@@ -461,13 +508,14 @@ __device__ __forceinline__ void bnf_logpost_rows(const BnfMhArgs &a, const BnfLd
       }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const f32x4 fa = LFl[(mt * 4 + t) * 64 + lane];
+        f32x4 fa;
+        if constexpr (WIDE) fa = fwc[t]; else fa = LFl[(mt * 4 + t) * 64 + lane];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
           for (int rt = 0; rt < R; ++rt) {
             a1[rt] = BGM_MFMA(fa[r], h[rt][t][r], a1[rt]);
-            a2[rt] = BGM_MFMA(fc[t][r], hs[rt][t][r], a2[rt]);
+            if constexpr (!DET) a2[rt] = BGM_MFMA(fc[t][r], hs[rt][t][r], a2[rt]);
           }
       }
       const int pos = 16 * (mt & 1);
@@ -476,11 +524,15 @@ __device__ __forceinline__ void bnf_logpost_rows(const BnfMhArgs &a, const BnfLd
         const uint32_t wsh = bnf_preshift(wc[rt], g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+          float d;
+          if constexpr (DET) d = a1[rt][r];
+          else {
 #ifdef BNF_ABL_NOEPI
-          const float d = a1[rt][r] + a2[rt][r];
+            d = a1[rt][r] + a2[rt][r];
 #else
-          const float d = fmaf(a2[rt][r], bnf_sign_rt(wsh, pos + r), a1[rt][r]);
+            d = fmaf(a2[rt][r], bnf_sign_rt(wsh, pos + r), a1[rt][r]);
 #endif
+          }
           if (!last) ssq[rt] = fmaf(d, d, ssq[rt]);
           else {
             const int u = 16 * mt + 4 * g + r;
@@ -492,36 +544,45 @@ __device__ __forceinline__ void bnf_logpost_rows(const BnfMhArgs &a, const BnfLd
     };
 #pragma nounroll
     for (int mt = 0; mt < NTL - 1; ++mt) {
-      f32x4 vc[R], fc[4];
+      f32x4 vc[R], fc[4], fwc[4];
       uint32_t wc[R];
 #pragma unroll
       for (int rt = 0; rt < R; ++rt) { vc[rt] = vn[rt]; wc[rt] = wn[rt]; }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) fc[t] = fd[t];
+      for (int t = 0; t < 4; ++t) { fc[t] = fd[t]; fwc[t] = fw[t]; }
 #pragma unroll
-      for (int rt = 0; rt < R; ++rt) { vn[rt] = load_v(rt, mt + 1); wn[rt] = GO[rib[rt] * BNF_GOUT + ((mt + 1) >> 1)]; }
+      for (int rt = 0; rt < R; ++rt) { vn[rt] = load_v(rt, mt + 1); if constexpr (!DET) wn[rt] = GO[rib[rt] * BNF_GOUT + ((mt + 1) >> 1)]; }
+      if constexpr (!DET) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) fd[t] = BNF_DWSRC(DWl, LFl)[((mt + 1) * 4 + t) * 64 + lane];
+        for (int t = 0; t < 4; ++t) fd[t] = BNF_DWSRC(DWl, LFl)[((mt + 1) * 4 + t) * 64 + lane];
+      }
+      if constexpr (WIDE) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fw[t] = LFg[((mt + 1) * 4 + t) * 64 + lane];
+      }
       BNF_PIN();
-      tile(mt, false, vc, wc, fc);
+      tile(mt, false, vc, wc, fc, fwc);
     }
-    tile(NTL - 1, true, vn, wn, fd);
+    tile(NTL - 1, true, vn, wn, fd, fw);
     BNF_T(3);
   }
   float part[R];
 #pragma unroll
   for (int rt = 0; rt < R; ++rt) {
-    const float rw = sum_over_g(rawv[rt]);
-    const float s2 = bnf_softplus(rw) + BGM_EPS;
-    // the per-lane share of -(ssq / (2 s2) + |z|^2 / 2); the log term is added once after the cross-lane sum
-    part[rt] = -(ssq[rt] * fast_rcp(2.0f * s2) + 0.5f * zz[rt]);
-    lp[rt] = -0.5f * (float)p * fast_log(s2);
+    if constexpr (EVAL) { aux[rt][0] = sum_over_g(ssq[rt]); part[rt] = 0.0f; lp[rt] = 0.0f; }
+    else {
+      const float rw = sum_over_g(rawv[rt]);
+      const float s2 = (DET && a.sig2_v > 0.0f) ? a.sig2_v : bnf_softplus(rw) + BGM_EPS;
+      // the per-lane share of -(ssq / (2 s2) + |z|^2 / 2); the log term is added once after the cross-lane sum
+      part[rt] = -(ssq[rt] * fast_rcp(2.0f * s2) + 0.5f * zz[rt]);
+      lp[rt] = -0.5f * (float)p * fast_log(s2);
+    }
   }
   // ---- h (treatment) and f (outcome)
   {
     float mu[R], raw[R];
     uint4 G[R][BNF_NG_H];
-    {     // the f call's groups are requested before the h call and first touched after it
+    if constexpr (!DET) {     // the f call's groups are requested before the h call and first touched after it
       const uint4 *SF = a.sg.f + ((long long)s * BNF_NG_H * a.n + blk_lo);
 #pragma unroll
       for (int rt = 0; rt < R; ++rt)
@@ -529,24 +590,33 @@ __device__ __forceinline__ void bnf_logpost_rows(const BnfMhArgs &a, const BnfLd
         for (int k = 0; k < BNF_NG_H; ++k) G[rt][k] = (SF + (long long)k * a.n)[rib[rt]];
     }
     BGM_NO_HOIST();
-    bnf_head<KS, R>(L.frag + P.fh * 64, DW + P.fh * 64, L.bias + 4 * P.bh, L.norm + 1 * T0 * 8, L.shift + 1 * T0 * 4, lane, g, ze, GH, mu, raw);
+    bnf_head<KS, R, DET>(L.frag + P.fh * 64, DW + P.fh * 64, L.bias + 4 * P.bh, L.norm + 1 * T0 * 8, L.shift + 1 * T0 * 4, lane, g, ze, GH, mu, raw);
 #pragma unroll
     for (int rt = 0; rt < R; ++rt) {
       const float m_ = mu[rt];
-      if (P.binary) lp[rt] -= fmaxf(m_, 0.0f) - m_ * xr[rt] + bnf_softplus(-fabsf(m_));
-      else { const float s2 = bnf_softplus(raw[rt]) + BGM_EPS, d = xr[rt] - m_; lp[rt] -= d * d * fast_rcp(2.0f * s2) + 0.5f * fast_log(s2); }
+      if constexpr (EVAL) aux[rt][1] = m_;
+      else if (P.binary) lp[rt] -= fmaxf(m_, 0.0f) - m_ * xr[rt] + bnf_softplus(-fabsf(m_));
+      else {
+        const float s2 = (DET && a.sig2_x > 0.0f) ? a.sig2_x : bnf_softplus(raw[rt]) + BGM_EPS, d = xr[rt] - m_;
+        lp[rt] -= d * d * fast_rcp(2.0f * s2) + 0.5f * fast_log(s2);
+      }
     }
     BNF_T(4);
     BGM_NO_HOIST();
-    bnf_head<KS, R>(L.frag + P.ff * 64, DW + P.ff * 64, L.bias + 4 * P.bf, L.norm + 2 * T0 * 8, L.shift + 2 * T0 * 4, lane, g, ze, G, mu, raw);
+    bnf_head<KS, R, DET>(L.frag + P.ff * 64, DW + P.ff * 64, L.bias + 4 * P.bf, L.norm + 2 * T0 * 8, L.shift + 2 * T0 * 4, lane, g, ze, G, mu, raw);
 #pragma unroll
     for (int rt = 0; rt < R; ++rt) {
-      const float s2 = bnf_softplus(raw[rt]) + BGM_EPS, d = yr[rt] - mu[rt];
-      lp[rt] -= d * d * fast_rcp(2.0f * s2) + 0.5f * fast_log(s2);
+      if constexpr (EVAL) aux[rt][2] = mu[rt];
+      else {
+        const float s2 = (DET && a.sig2_y > 0.0f) ? a.sig2_y : bnf_softplus(raw[rt]) + BGM_EPS, d = yr[rt] - mu[rt];
+        lp[rt] -= d * d * fast_rcp(2.0f * s2) + 0.5f * fast_log(s2);
+      }
     }
   }
+  if constexpr (!EVAL) {
 #pragma unroll
-  for (int rt = 0; rt < R; ++rt) lp[rt] += sum_over_g(part[rt]);
+    for (int rt = 0; rt < R; ++rt) lp[rt] += sum_over_g(part[rt]);
+  }
   BNF_T(5);
 }
 
@@ -554,24 +624,28 @@ __device__ __forceinline__ void bnf_logpost_rows(const BnfMhArgs &a, const BnfLd
 // persistent sampler kernel: grid = a multiple of 8 workgroups (one per CU), WAVES waves each.  Items = groups of R row tiles of
 // one block; the workgroups of XCD x (blockIdx % 8) take the x-th contiguous eighth of the items and walk it in lock step.
 // ---------------------------------------------------------------------------------------------
-template <int KS, int R, int WAVES, int MODE>
+// MODE 0: log posterior of the given states -> out.  MODE 1: one Metropolis-Hastings iteration; with Bayesian nets both states are
+// evaluated afresh, with deterministic nets (DET) the current state's value is carried in lp_cache like the reference's
+// deterministic result would be (oracle/causal.py mh_transition).  MODE 2 (DET): the sums of CausalBGM.evaluate.
+template <int KS, int R, int WAVES, int MODE, bool DET = false, bool WIDE = false>
 static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_mh_kernel(BnfMhArgs a) {
   extern __shared__ __attribute__((aligned(16))) float bnf_lds[];
   const BnfPlan &P = a.pl;
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  {
+  {   // LDS <- blob; a WIDE plan keeps g's last layer (the last fragments of the blob) out: lds_skip floats before the bias tiles
     const f32x4 *src = (const f32x4 *)a.blob;
     f32x4 *dst = (f32x4 *)bnf_lds;
-    const int cnt = P.blob_floats >> 2;
-    for (int i = tid; i < cnt; i += 64 * WAVES) dst[i] = src[i];
+    const int head = (WIDE ? P.fgl * 256 : P.blob_floats) >> 2, cnt = (P.blob_floats - P.lds_skip) >> 2, skip = P.lds_skip >> 2;
+    for (int i = tid; i < cnt; i += 64 * WAVES) dst[i] = src[i < head ? i : i + skip];
   }
   __syncthreads();
   BnfLds L;
   L.frag = (const f32x4 *)bnf_lds;
-  L.bias = (const f32x4 *)(bnf_lds + P.bias_off);
-  L.norm = (const f32x4 *)(bnf_lds + P.norm_off);
-  L.shift = (const int4 *)(bnf_lds + P.shift_off);
+  L.bias = (const f32x4 *)(bnf_lds + P.bias_off - P.lds_skip);
+  L.norm = (const f32x4 *)(bnf_lds + P.norm_off - P.lds_skip);
+  L.shift = (const int4 *)(bnf_lds + P.shift_off - P.lds_skip);
+  float ev[3] = {0.0f, 0.0f, 0.0f};
   const int q = P.q;
   const int xcd = blockIdx.x & 7;
   const int per = (a.n_items + 7) >> 3, lo = xcd * per, hi = min(a.n_items, lo + per);
@@ -649,11 +723,28 @@ static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_mh_kernel(Bn
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
           if (16 * (ks >> 2) + 4 * (ks & 3) + g == q) zc[rt][ks] = xr[rt];
-      float lp[R];
-      bnf_logpost_rows<KS, R>(a, L, lane, j, g, blk_lo, rib, zc, xr, yr, dwblk, 0, zzc, lp BNF_PROF_ARG);
+      float lp[R], aux[R][3];
+      bnf_logpost_rows<KS, R, DET, WIDE>(a, L, lane, j, g, blk_lo, rib, zc, xr, yr, dwblk, 0, zzc, lp, aux BNF_PROF_ARG);
 #pragma unroll
       for (int rt = 0; rt < R; ++rt)
         if (valid[rt] && g == 0) a.out[blk_lo + rib[rt]] = lp[rt];
+      continue;
+    }
+    if constexpr (MODE == 2) {      // evaluate: reconstruction errors of g, h, f at the given latents
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          if (16 * (ks >> 2) + 4 * (ks & 3) + g == q) zc[rt][ks] = xr[rt];
+      float lp[R], aux[R][3];
+      bnf_logpost_rows<KS, R, DET, WIDE, true>(a, L, lane, j, g, blk_lo, rib, zc, xr, yr, dwblk, 0, zzc, lp, aux BNF_PROF_ARG);
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt)
+        if (valid[rt] && g == 0) {
+          const float xp = P.binary ? 1.0f / (1.0f + __expf(-aux[rt][1])) : aux[rt][1];
+          const float dx = xr[rt] - xp, dy = yr[rt] - aux[rt][2];
+          ev[0] += aux[rt][0]; ev[1] = fmaf(dx, dx, ev[1]); ev[2] = fmaf(dy, dy, ev[2]);
+        }
       continue;
     }
     // proposal
@@ -684,18 +775,28 @@ static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_mh_kernel(Bn
       for (int ks = 0; ks < KS; ++ks)
         if (16 * (ks >> 2) + 4 * (ks & 3) + g == q) { zc[rt][ks] = xr[rt]; zp[rt][ks] = xr[rt]; }
     // both states through ONE copy of the network code (the kernel is ~25 KB of instructions instead of ~70): state 0 = proposal
-    // (perturbation set 0, sign groups 0), state 1 = current
+    // (perturbation set 0, sign groups 0), state 1 = current.  Deterministic nets: the current state's value is cached per row
+    // (evaluated here only when the chain is initialised).
     float lpp[R], lpc[R];
+    float *lpblk = DET ? a.lp_cache + blk_lo : nullptr;
+    const int st_hi = DET ? (a.init ? 2 : 1) : 2;
+    if constexpr (DET) {
+      if (!a.init) {
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) lpc[rt] = lpblk[rib[rt]];
+      }
+    }
 #pragma nounroll
-    for (int st = 0; st < 2; ++st) {
-      float zs[R][KS], zzs[R], lp[R];
+    for (int st = 0; st < st_hi; ++st) {
+      float zs[R][KS], zzs[R], lp[R], aux[R][3];
 #pragma unroll
       for (int rt = 0; rt < R; ++rt) {
         zzs[rt] = st ? zzc[rt] : zzp[rt];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) zs[rt][ks] = st ? zc[rt][ks] : zp[rt][ks];
       }
-      bnf_logpost_rows<KS, R>(a, L, lane, j, g, blk_lo, rib, zs, xr, yr, dwblk + (long long)st * P.set_floats, st, zzs, lp BNF_PROF_ARG);
+      bnf_logpost_rows<KS, R, DET, WIDE>(a, L, lane, j, g, blk_lo, rib, zs, xr, yr, DET ? nullptr : dwblk + (long long)st * P.set_floats, st, zzs,
+                                         lp, aux BNF_PROF_ARG);
 #pragma unroll
       for (int rt = 0; rt < R; ++rt) { if (st) lpc[rt] = lp[rt]; else lpp[rt] = lp[rt]; }
     }
@@ -714,6 +815,9 @@ static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_mh_kernel(Bn
         }
         if (g == 0) ++nacc;
       }
+      if constexpr (DET) {
+        if (valid[rt] && g == 0 && (acc || a.init)) lpblk[rib[rt]] = acc ? lpp[rt] : lpc[rt];
+      }
     }
     if (a.acc_count || a.acc_blocks) {
       for (int off = 32; off > 0; off >>= 1) nacc += __shfl_xor(nacc, off);
@@ -724,6 +828,14 @@ static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_mh_kernel(Bn
     }
   }
   if (a.acc_count && lane == 0 && nacc_total) atomicAdd(a.acc_count, nacc_total);
+  if constexpr (MODE == 2) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float t = ev[k];
+      for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+      if (lane == 0) atomicAdd(&a.sums[k], (double)t);
+    }
+  }
 #ifdef BNF_PROF
   BNF_T(6);
   if (a.prof && tid == 0)
@@ -756,9 +868,11 @@ struct BnfEffArgs {
   double *sum_out; long long sum_stride;
   float *ite_out; long long ite_stride;
   unsigned *queue;                     // [8] item counters, one per XCD (zeroed by bnf_signs_kernel)
+  float *fsum_out; long long fsum_slot_stride;   // deterministic API: per-workgroup partial sums [grid][...] += (bgm_adrf_reduce adds the slots)
+  float sig2_y;                        // deterministic nets: fixed params['sigma_y']^2 (<= 0: the variance head)
 };
 
-template <int KS, int R, int WAVES>      // KS: k-steps of the outcome net's own first layer (BnfPlan::KSF or a larger compiled value)
+template <int KS, int R, int WAVES, bool DET = false>      // KS: k-steps of the outcome net's own first layer (BnfPlan::KSF or a larger compiled value)
 static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_effects_kernel(BnfEffArgs a) {
   extern __shared__ __attribute__((aligned(16))) float bnf_lds[];
   constexpr int T0 = (KS + 3) / 4;
@@ -817,19 +931,23 @@ static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_effects_kern
 #pragma unroll
     for (int rt = 0; rt < R; ++rt) { y0[rt] = 0.0f; nz[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     uint4 Gn[R][BNF_NG_H];
+    if constexpr (!DET) {
 #pragma unroll
-    for (int rt = 0; rt < R; ++rt)
+      for (int rt = 0; rt < R; ++rt)
 #pragma unroll
-      for (int k = 0; k < BNF_NG_H; ++k) Gn[rt][k] = (SGb + (long long)k * a.n)[rib[rt]];
+        for (int k = 0; k < BNF_NG_H; ++k) Gn[rt][k] = (SGb + (long long)k * a.n)[rib[rt]];
+    }
 #pragma nounroll
     for (int k = 0; k < nd; ++k) {
       const float xv = a.xvals[k];
       uint4 G[R][BNF_NG_H];
+      if constexpr (!DET) {
 #pragma unroll
-      for (int rt = 0; rt < R; ++rt)
+        for (int rt = 0; rt < R; ++rt)
 #pragma unroll
-        for (int c = 0; c < BNF_NG_H; ++c) G[rt][c] = Gn[rt][c];
-      if (k + 1 < nd) {
+          for (int c = 0; c < BNF_NG_H; ++c) G[rt][c] = Gn[rt][c];
+      }
+      if (!DET && k + 1 < nd) {
         const uint4 *S = SGb + (long long)(k + 1) * BNF_NG_H * a.n;
 #pragma unroll
         for (int rt = 0; rt < R; ++rt)
@@ -850,14 +968,14 @@ static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_effects_kern
           if (16 * (ks >> 2) + 4 * (ks & 3) + g == zz) ze[rt][ks] = xv;
       float mu[R], raw[R];
       BGM_NO_HOIST();
-      bnf_head<KS, R>(LF, (const f32x4 *)(dwblk + (long long)k * eset), BL, NORM, SHIFT, lane, g, ze, G, mu, raw);
+      bnf_head<KS, R, DET>(LF, (const f32x4 *)(dwblk + (long long)k * eset), BL, NORM, SHIFT, lane, g, ze, G, mu, raw);
       const int own = (k >> 2) & 3, e = k & 3;
       float tot = 0.0f;
 #pragma unroll
       for (int rt = 0; rt < R; ++rt) {
         float yk = mu[rt];
         if (a.sample_y) {
-          const float s2 = bnf_softplus(raw[rt]) + BGM_EPS;
+          const float s2 = (DET && a.sig2_y > 0.0f) ? a.sig2_y : bnf_softplus(raw[rt]) + BGM_EPS;
           yk = fmaf(__builtin_sqrtf(s2), e == 0 ? nz[rt][0] : e == 1 ? nz[rt][1] : e == 2 ? nz[rt][2] : nz[rt][3], yk);
         }
         if (a.ite_out) {
@@ -866,18 +984,19 @@ static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_effects_kern
         }
         tot += valid[rt] ? yk : 0.0f;
       }
-      if (a.sum_out) {
+      if (a.sum_out || a.fsum_out) {
         tot = sum_over_j_to_lane15(tot);
         if (lane == 16 * own + 15) myacc[k] += tot;
       }
     }
   }
-  if (a.sum_out) {
+  if (a.sum_out || a.fsum_out) {
     __syncthreads();
     for (int k = tid; k < nd; k += 64 * WAVES) {
       double t = 0.0;
       for (int w = 0; w < WAVES; ++w) t += (double)acc_lds[w * BNF_MAX_DOSES + k];
-      atomicAdd(&a.sum_out[(long long)k * a.sum_stride], t);
+      if (a.sum_out) atomicAdd(&a.sum_out[(long long)k * a.sum_stride], t);
+      else a.fsum_out[(long long)blockIdx.x * a.fsum_slot_stride + (long long)k * a.sum_stride] += (float)t;      // this workgroup's slot
     }
   }
 }
@@ -902,7 +1021,7 @@ static __global__ void bnf_pack_kernel(BnfPackArgs a) {
   const int i0 = blockIdx.x * blockDim.x + threadIdx.x, str = gridDim.x * blockDim.x;
   for (int i = i0; i < a.n_w; i += str) {
     const BnfWElem e = a.w[i];
-    const float lv = e.scale * a.theta[e.loc], sv = e.scale * (BNN_SCALE_EPS + softplus_acc(a.theta[e.rho]));
+    const float lv = e.scale * a.theta[e.loc], sv = e.rho >= 0 ? e.scale * (BNN_SCALE_EPS + softplus_acc(a.theta[e.rho])) : 0.0f;
     for (int c = 0; c < e.rep; ++c) { a.blob[e.pos + 16 * c] = lv; a.sf[e.pos + 16 * c] = sv; }
   }
   for (int i = i0; i < a.n_b; i += str) {
@@ -912,7 +1031,8 @@ static __global__ void bnf_pack_kernel(BnfPackArgs a) {
   }
   for (int i = i0; i < a.n_n; i += str) {
     const BnfNElem e = a.ne[i];
-    a.blob[e.pos_sc] = e.gamma >= 0 ? a.theta[e.gamma] / sqrtf(1.0f + BNN_BN_EPS) : 0.0f;
+    // gamma >= 0: inference-mode BatchNormalization of a used slot; -2: a used slot of a net without input normalisation; -1: unused
+    a.blob[e.pos_sc] = e.gamma >= 0 ? a.theta[e.gamma] / sqrtf(1.0f + BNN_BN_EPS) : (e.gamma == -2 ? 1.0f : 0.0f);
     a.blob[e.pos_sh] = e.gamma >= 0 ? a.theta[e.beta] : 0.0f;
     ((int *)a.blob)[e.pos_shift] = e.shift;
   }

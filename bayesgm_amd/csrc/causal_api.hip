@@ -6,6 +6,7 @@
 #include <cstring>
 
 #include "bgm_host.h"
+#include "bnf_det_host.h"
 
 static thread_local std::string g_err;
 void bgm_set_error(const std::string &msg) { g_err = msg; }
@@ -43,6 +44,7 @@ extern "C" int bgm_destroy(bgm_handle *h) {
   if (h->sblob_dev) hipFree(h->sblob_dev);
   if (h->bx_blob_dev) hipFree(h->bx_blob_dev);
   if (h->acc_scratch) hipFree(h->acc_scratch);
+  bnf_det_free(h);
   bgm_causal_fit_end(h, nullptr);
   bgm_bgm_free_state(h);
   bgm_egm_free_state(h);
@@ -98,6 +100,7 @@ extern "C" int bgm_causal_configure(bgm_handle *h, const bgm_causal_config *cfg)
   mk(h->nets[BGM_NET_F], cfg->z_dims[0] + cfg->z_dims[1] + 1, cfg->f_units, cfg->n_hidden_f, 2);
   mk(h->nets[BGM_NET_H], cfg->z_dims[0] + cfg->z_dims[2], cfg->h_units, cfg->n_hidden_h, 2);
   mk(h->nets[BGM_NET_E], p, cfg->e_units, cfg->n_hidden_e, q);
+  bnf_det_free(h);
   h->configured = true;
   h->blob_valid = false;
   h->bx_valid = false;
@@ -117,7 +120,7 @@ extern "C" int bgm_causal_set_weights(bgm_handle *h, int net_id, const float *th
   }
   std::memcpy(n.theta.data(), theta_host, sizeof(float) * count);
   n.set = true;
-  if (net_id == BGM_NET_E) h->eblob_valid = false; else { h->blob_valid = false; h->bx_valid = false; }
+  if (net_id == BGM_NET_E) h->eblob_valid = false; else { h->blob_valid = false; h->bx_valid = false; h->det_valid = false; }
   return BGM_OK;
 }
 
@@ -304,6 +307,7 @@ static int mh_grid(const bgm_handle *h, int64_t n) {
 
 extern "C" int bgm_causal_mh_slots(bgm_handle *h, int64_t n, int32_t *n_slots) {
   if (!h || !n_slots) { bgm_set_error("bgm_causal_mh_slots: NULL"); return BGM_E_INVALID; }
+  if (h->configured && bnf_det_wanted(h)) { *n_slots = bnf_det_slots(h); return BGM_OK; }      // general path: one slot per workgroup
   *n_slots = mh_grid(h, n) * MH_WAVES;
   return BGM_OK;
 }
@@ -315,6 +319,10 @@ extern "C" int bgm_causal_logpost(bgm_handle *h, const float *x, const float *y,
   if (!x || !y || !v || !z || !out) { bgm_set_error("bgm_causal_logpost: NULL pointer"); return BGM_E_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
+  if (bnf_det_wanted(h)) {     // no LDS-resident compiled shape holds the model: the streamed-fragment kernels (bnf_det_api.hip)
+    if (h->prior_seg || h->precision == 1) { bgm_set_error("bgm_causal_logpost: the conditional prior / split precision exist for the LDS-resident shapes only"); return BGM_E_UNSUPPORTED; }
+    return bnf_det_logpost(h, x, y, v, z, n, out, stream);
+  }
   int rc = bgm_causal_sampling_blob(h, stream);
   if (rc) return rc;
   const int grid = mh_grid(h, n);
@@ -373,6 +381,10 @@ extern "C" int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *a, void *stre
   if ((a->effect != BGM_EFFECT_NONE || a->draws_dev) && it_end - a->burn_in > a->n_keep) { bgm_set_error("bgm_causal_mh_run: iterations beyond burn_in + n_keep"); return BGM_E_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
+  if (bnf_det_wanted(h)) {
+    if (h->prior_seg || h->precision == 1) { bgm_set_error("bgm_causal_mh_run: the conditional prior / split precision exist for the LDS-resident shapes only"); return BGM_E_UNSUPPORTED; }
+    return bnf_det_mh_run(h, a, stream);
+  }
   int rc = bgm_causal_sampling_blob(h, stream);
   if (rc) return rc;
   const int grid = mh_grid(h, a->n);
@@ -462,6 +474,7 @@ extern "C" int bgm_causal_evaluate(bgm_handle *h, const float *x, const float *y
   if (!binary && (!x_values || n_doses <= 0 || !adrf_partial)) { bgm_set_error("bgm_causal_evaluate: x_values / adrf_partial required"); return BGM_E_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
+  if (bnf_det_wanted(h)) return bnf_det_evaluate(h, x, y, v, z, n, x_values, n_doses, sums, adrf_partial, ite, stream);
   int rc = bgm_causal_sampling_blob(h, stream);
   if (rc) return rc;
   CausalEvalKArgs ka{};
@@ -503,6 +516,7 @@ extern "C" int bgm_causal_effects(bgm_handle *h, const float *x, const float *dr
   if (row_base + n > 0xFFFFFFFFll) { bgm_set_error("bgm_causal_effects: row index exceeds the 32-bit RNG counter"); return BGM_E_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
+  if (bnf_det_wanted(h)) return bnf_det_effects(h, draws, n, row_base, n_keep, burn_in, seed, sample_y, x_values, n_doses, adrf_partial, ite, stream);
   int rc = bgm_causal_sampling_blob(h, stream);
   if (rc) return rc;
   CausalEffKArgs ka{};
@@ -517,6 +531,7 @@ extern "C" int bgm_causal_effects(bgm_handle *h, const float *x, const float *dr
 
 extern "C" int bgm_causal_evaluate_slots(bgm_handle *h, int64_t n, int32_t *n_slots) {
   if (!h || !n_slots) { bgm_set_error("bgm_causal_evaluate_slots: NULL"); return BGM_E_INVALID; }
+  if (h->configured && bnf_det_wanted(h)) { *n_slots = bnf_det_slots(h); return BGM_OK; }
   const int64_t tiles = (n + 15) / 16;
   *n_slots = (int)std::max<int64_t>(1, std::min<int64_t>((tiles + MH_WAVES - 1) / MH_WAVES, h->n_cus)) * MH_WAVES;
   return BGM_OK;

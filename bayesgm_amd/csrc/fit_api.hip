@@ -466,6 +466,7 @@ extern "C" int bgm_causal_fit_theta_apply(bgm_handle *h, const float *grad, floa
                      h->fit_chain ? static_cast<FitChainState *>(h->fit_chain)->mirror_dst : nullptr);
   BGM_HIP_CHECK(hipGetLastError());
   h->sblob_valid = false;   // the sampling copy (evaluate between epochs, predict after the fit) follows the new parameters
+  h->det_valid = false;
   return BGM_OK;
 }
 

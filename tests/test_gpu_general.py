@@ -1,0 +1,178 @@
+"""General-shape sampling path of the deterministic CausalBGM (csrc/bnf_det_api.hip: the streamed-fragment kernels of bnf_kernels.h
+without the Flipout half) against oracle/causal.py through the C ABI: the shapes no LDS-resident compiled kernel contains --
+sum(z_dims) = 18 / 20 at the data widths of the reference's Semi_acic.yaml / Sim_Colangelo.yaml, sum(z_dims) up to 31, and data widths
+beyond 207 where g's last layer is streamed from L2 ("wide", here p = 500 and p = 1001).  Same tolerances as test_gpu_causal.py.
+BGM_FORCE_GENERAL=1 (set for a subprocess below) sends a shape the resident kernels DO hold through the same path."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import causal as OC  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _engine(m, **kw):
+    from bayesgm_amd.engine import CausalEngine
+    eng = CausalEngine(m["v_dim"], m["z_dims"], binary_treatment=m["binary_treatment"],
+                       sigma_v=m.get("sigma_v"), sigma_x=m.get("sigma_x"), sigma_y=m.get("sigma_y"), **kw)
+    eng.set_model(g=m["g"], f=m["f"], h=m["h"], e=m["e"])
+    return eng
+
+
+def _data(n, p, seed, binary=False):
+    rs = np.random.RandomState(seed)
+    v = rs.randn(n, p).astype(np.float32)
+    x = rs.exponential(size=(n, 1)).astype(np.float32)
+    if binary:
+        x = (x > np.median(x)).astype(np.float32)
+    y = (x + rs.randn(n, 1)).astype(np.float32)
+    return x, y, v
+
+
+def _model(seed, z_dims, p, binary=False, **kw):
+    m = OC.init_model(seed, z_dims, p, binary_treatment=binary, **kw)
+    rs = np.random.RandomState(seed + 99)
+    for k in ("g", "f", "h", "e"):
+        m[k] = [(W.astype(np.float32), (0.1 * rs.randn(*b.shape)).astype(np.float32)) for W, b in m[k]]
+    return m
+
+
+def _as64(m, *arrs):
+    return OC.cast_model(m, np.float64), [a.astype(np.float64) for a in arrs]
+
+
+CASES = [
+    dict(z_dims=[3, 6, 3, 6], p=177, binary=True, n=333),      # configs/Semi_acic.yaml: sum(z_dims) = 18 at 12 output tiles
+    dict(z_dims=[5, 5, 5, 5], p=100, binary=False, n=130),     # configs/Sim_Colangelo.yaml: sum(z_dims) = 20
+    dict(z_dims=[8, 8, 8, 7], p=50, binary=False, n=65),       # sum(z_dims) = 31
+    dict(z_dims=[1, 1, 1, 7], p=500, binary=False, n=200),     # wide: g's last layer (128 KB) streamed from L2
+    dict(z_dims=[3, 3, 6, 6], p=1001, binary=True, n=48),      # wide, p % 4 != 0, 63 output tiles
+    dict(z_dims=[4, 4, 4, 4], p=207, binary=False, n=40),      # the treatment alone in the second k-tile, largest resident data width
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_logpost_matches_oracle(case):
+    m = _model(1, case["z_dims"], case["p"], case["binary"])
+    x, y, v = _data(case["n"], case["p"], 2, case["binary"])
+    z = np.random.RandomState(3).randn(case["n"], sum(case["z_dims"])).astype(np.float32)
+    eng = _engine(m)
+    got = eng.logpost(x.ravel(), y.ravel(), v, z).cpu().numpy()
+    m64, (x64, y64, v64, z64) = _as64(m, x, y, v, z)
+    ref = OC.log_posterior(m64, x64, y64, v64, z64)
+    err = np.abs(got - ref)
+    assert np.all(err <= 1e-5 * np.abs(ref) + 1e-3), (err.max(), np.abs(ref).max())
+
+
+def test_logpost_fixed_sigmas():
+    m = _model(5, [3, 6, 3, 6], 177, False, sigma_v=0.8, sigma_x=1.3, sigma_y=0.5)
+    x, y, v = _data(100, 177, 6)
+    z = np.random.RandomState(7).randn(100, 18).astype(np.float32)
+    got = _engine(m).logpost(x.ravel(), y.ravel(), v, z).cpu().numpy()
+    m64, (x64, y64, v64, z64) = _as64(m, x, y, v, z)
+    ref = OC.log_posterior(m64, x64, y64, v64, z64)
+    assert np.all(np.abs(got - ref) <= 1e-5 * np.abs(ref) + 1e-3)
+
+
+@pytest.mark.parametrize("case", [dict(z_dims=[3, 6, 3, 6], p=177, binary=True, n=150),
+                                  dict(z_dims=[5, 5, 5, 5], p=100, binary=False, n=90),
+                                  dict(z_dims=[1, 1, 1, 7], p=500, binary=False, n=70)])
+def test_mh_chain_and_effects_match_oracle(case):
+    from bayesgm_amd import _lib
+    burn, keep, q_sd, seed = 20, 15, 0.3, 1234567890123
+    m = _model(21, case["z_dims"], case["p"], case["binary"])
+    x, y, v = _data(case["n"], case["p"], 22, case["binary"])
+    eng = _engine(m)
+    xs = np.linspace(0, 3, 21)
+    kw = dict(effect=_lib.EFFECT_ITE) if case["binary"] else dict(effect=_lib.EFFECT_ADRF, x_values=xs)
+    out = eng.mh_sample(x, y, v, burn, keep, q_sd, seed, want_draws=True, chunk=11, sample_y=True, **kw)
+    draws = out["draws"].cpu().numpy()
+    acc = out["acc_count"].cpu().numpy()
+    ref, ref_acc, _ = OC.mh_sampler(m, (x, y, v), burn, keep, q_sd, seed, return_acc=True)
+    assert draws.shape == ref.shape
+    row_ok = np.all(np.abs(draws[-1] - ref[-1]) <= 1e-4, axis=1)
+    assert row_ok.mean() >= 0.97, row_ok.mean()
+    assert np.abs(acc.astype(np.int64) - ref_acc).max() <= max(2, int((~row_ok).sum()))
+    ref_eff = OC.infer_from_latent_posterior(OC.cast_model(m, np.float64), draws.astype(np.float64), None if case["binary"] else xs, True,
+                                             seed, burn_in=burn)
+    if case["binary"]:
+        assert np.abs(out["ite"].cpu().numpy().T - ref_eff).max() <= 5e-4
+    else:
+        assert np.abs(out["adrf"].cpu().numpy() - ref_eff).max() <= 2e-4
+    # the stand-alone form on the kept draws
+    alone = eng.effects(x, out["draws"], burn, seed, x_values=None if case["binary"] else xs, sample_y=True)
+    alone = alone.cpu().numpy()
+    assert np.abs((alone if case["binary"] else alone) - (ref_eff if not case["binary"] else ref_eff)).max() <= 5e-4
+
+
+@pytest.mark.parametrize("case", [dict(z_dims=[3, 6, 3, 6], p=177, binary=True, n=200), dict(z_dims=[1, 1, 1, 7], p=500, binary=False, n=120)])
+def test_evaluate_matches_oracle(case):
+    m = _model(31, case["z_dims"], case["p"], case["binary"])
+    x, y, v = _data(case["n"], case["p"], 32, case["binary"])
+    z = np.random.RandomState(33).randn(case["n"], sum(case["z_dims"])).astype(np.float32)
+    import torch
+    eng = _engine(m)
+    xs = np.linspace(0.1, 2.9, 200)
+    T = lambda a_: torch.from_numpy(np.ascontiguousarray(a_)).to(eng.device)
+    sums, causal = eng.evaluate(T(x.ravel()), T(y.ravel()), T(v), T(z), x_values=None if case["binary"] else xs)
+    sums = sums.cpu().numpy()
+    n = case["n"]
+    gv, gx, gy = sums[0] / (n * case["p"]), sums[1] / n, sums[2] / n
+    causal = causal.cpu().numpy() if case["binary"] else causal.cpu().numpy() / n
+    # reconstruction errors and plug-in effects from first principles (oracle network forward)
+    from oracle.nets import mlp_forward
+    m64 = OC.cast_model(m, np.float64)
+    z64 = z.astype(np.float64)
+    z0d, z1d, z2d, _ = case["z_dims"]
+    g_out = mlp_forward(m64["g"], z64)
+    mv = ((v - g_out[:, :case["p"]]) ** 2).mean()
+    h_out = mlp_forward(m64["h"], np.concatenate([z64[:, :z0d], z64[:, z0d + z1d:z0d + z1d + z2d]], axis=1))[:, 0]
+    xp = 1.0 / (1.0 + np.exp(-h_out)) if case["binary"] else h_out
+    mx = ((x[:, 0] - xp) ** 2).mean()
+    fy = lambda xv: mlp_forward(m64["f"], np.concatenate([z64[:, :z0d + z1d], xv], axis=1))[:, 0]
+    my = ((y[:, 0] - fy(x.astype(np.float64))) ** 2).mean()
+    assert abs(gv - mv) <= 1e-4 * mv and abs(gx - mx) <= 1e-4 * max(mx, 1e-3) and abs(gy - my) <= 1e-4 * my
+    if case["binary"]:
+        ref = fy(np.ones((case["n"], 1))) - fy(np.zeros((case["n"], 1)))
+        assert np.abs(np.asarray(causal) - ref).max() <= 2e-4
+    else:
+        ref = np.array([fy(np.full((case["n"], 1), t)).mean() for t in xs])
+        assert np.abs(np.asarray(causal) - ref).max() <= 2e-4
+
+
+def test_forced_general_path_equals_resident_kernels():
+    """The bench shape through both kernel families: chains, effects and log-posteriors agree to rounding."""
+    code = r'''
+import numpy as np, sys, json
+sys.path.insert(0, %r)
+from oracle import causal as OC
+from bayesgm_amd.engine import CausalEngine
+from bayesgm_amd import _lib
+m = OC.init_model(3, [1, 1, 1, 7], 200)
+rs = np.random.RandomState(4)
+n = 400
+v = rs.randn(n, 200).astype(np.float32); x = rs.exponential(size=(n, 1)).astype(np.float32); y = (x + rs.randn(n, 1)).astype(np.float32)
+eng = CausalEngine(200, [1, 1, 1, 7]); eng.set_model(g=m["g"], f=m["f"], h=m["h"], e=m["e"])
+z = rs.randn(n, 10).astype(np.float32)
+lp = eng.logpost(x.ravel(), y.ravel(), v, z).cpu().numpy()
+out = eng.mh_sample(x, y, v, 30, 10, 0.4, 77, want_draws=True, effect=_lib.EFFECT_ADRF, x_values=np.linspace(0, 3, 20))
+np.savez(sys.argv[1], lp=lp, draws=out["draws"].cpu().numpy(), adrf=out["adrf"].cpu().numpy())
+''' % ROOT
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        res = {}
+        for tag, env in (("resident", {}), ("general", {"BGM_FORCE_GENERAL": "1"})):
+            path = os.path.join(d, tag + ".npz")
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, **env), timeout=600)
+            res[tag] = np.load(path)
+        a, b = res["resident"], res["general"]
+        assert np.abs(a["lp"] - b["lp"]).max() <= 1e-5 * np.abs(a["lp"]).max() + 1e-3
+        same = np.all(np.abs(a["draws"][-1] - b["draws"][-1]) <= 1e-4, axis=1).mean()
+        assert same >= 0.97, same
+        assert np.abs(a["adrf"] - b["adrf"]).max() <= 5e-3
