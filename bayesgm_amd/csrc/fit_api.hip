@@ -5,6 +5,7 @@
 #include <numeric>
 
 #include "bgm_host.h"
+#include "bnf_det_host.h"
 #include "fit_kernels.h"
 #include "fit_chain.h"
 
@@ -104,8 +105,10 @@ static int fit_chain_setup(bgm_handle *h, const std::vector<float> &theta) {
 }
 // one launch of the chains; Z_MODE 0 also the gradient tiles into `grad`
 static void fit_chain_launch(const FitChainState *c, FitChainArgs &a, int batch, int z_mode, hipStream_t stream) {
+  a.n_valid = batch;                                 // rows of this minibatch; the tile rows behind them are masked
+  const int nb = batch <= 16 ? 1 : 2;                // row tiles (the padded / two-k-tile instantiations are compiled for two only)
 #define FC(NTL_, NB_) \
-  if (c->ntl == NTL_ && batch == 16 * NB_) { \
+  if (c->ntl == NTL_ && nb == NB_) { \
     if (z_mode) hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, NB_, 1>), dim3(1), dim3(ECH_THREADS), 0, stream, a); \
     else { \
       hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, NB_, 0>), dim3(1), dim3(ECH_THREADS), 0, stream, a); \
@@ -249,8 +252,11 @@ extern "C" int bgm_causal_fit_begin(bgm_handle *h, int64_t n_rows, int32_t max_b
   if (n_rows <= 0 || max_batch <= 0) { bgm_set_error("bgm_causal_fit_begin: n_rows / max_batch must be positive"); return BGM_E_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
-  int rc = bgm_causal_build_blob(h, stream);   // forward blob + meta from the host weights
-  if (rc) return rc;
+  // forward blob + meta from the host weights.  A model that no LDS-resident shape holds (sum(z_dims) > 19, ...) is fitted by the
+  // row-tile chains alone: they read the canonical parameters in place (fit_chain.h) and need neither blob.
+  int rc = bnf_det_wanted(h) ? BGM_E_UNSUPPORTED : bgm_causal_build_blob(h, stream);
+  const bool chain_only = rc == BGM_E_UNSUPPORTED;
+  if (rc && !chain_only) return rc;
   fit_free(h);
   const HostNet &G = h->nets[BGM_NET_G], &F = h->nets[BGM_NET_F], &H = h->nets[BGM_NET_H];
   const int ng = (int)G.count(), nf = (int)F.count(), nh = (int)H.count();
@@ -270,6 +276,30 @@ extern "C" int bgm_causal_fit_begin(bgm_handle *h, int64_t n_rows, int32_t max_b
   BGM_HIP_CHECK(hipMemset(h->m1_dev, 0, sizeof(float) * np));
   BGM_HIP_CHECK(hipMemset(h->m2_dev, 0, sizeof(float) * np));
   h->t_theta = 0; h->t_z = 0;
+  if (chain_only) {
+    if (max_batch > 32) { bgm_set_error("bgm_causal_fit_begin: this model shape is fitted by the row-tile chains only: minibatches of at most 32 rows"); fit_free(h); return BGM_E_UNSUPPORTED; }
+    auto s2 = [](float s) { return s > 0.0f ? s * s : -1.0f; };
+    h->meta.sig2_v = s2(h->cfg.sigma_v); h->meta.sig2_x = s2(h->cfg.sigma_x); h->meta.sig2_y = s2(h->cfg.sigma_y);
+    std::vector<int> tables(4 * (size_t)np, -1);          // no blob positions to refresh after an Adam step
+    BGM_HIP_CHECK(hipMalloc(&h->tables_dev, sizeof(int) * tables.size()));
+    BGM_HIP_CHECK(hipMemcpy(h->tables_dev, tables.data(), sizeof(int) * tables.size(), hipMemcpyHostToDevice));
+    std::memset(&h->fit_ws, 0, sizeof(h->fit_ws));
+    h->fit_ws.B = 32; h->fit_ws.dz = 0; h->fit_ws.total = 32 * (long long)h->q;
+    BGM_HIP_CHECK(hipMalloc(&h->ws_dev, sizeof(float) * h->fit_ws.total));
+    BGM_HIP_CHECK(hipMemset(h->ws_dev, 0, sizeof(float) * h->fit_ws.total));
+    h->fit_bcap = 32;
+    h->fit_rows = n_rows;
+    BGM_HIP_CHECK(hipMalloc(&h->pos_dev, sizeof(int) * 2 * n_rows));
+    BGM_HIP_CHECK(hipMemset(h->pos_dev, 0xFF, sizeof(int) * 2 * n_rows));
+    BGM_HIP_CHECK(hipDeviceSynchronize());
+    h->fit_active = true;
+    rc = fit_chain_setup(h, theta);
+    if (rc || !h->fit_chain) {
+      fit_free(h);
+      if (!rc) { bgm_set_error("bgm_causal_fit_begin: no fit kernel for this model (needs g_units [64] x k, f / h [64, 32, 8], sum(z_dims) <= 32, v_dim <= 207)"); rc = BGM_E_UNSUPPORTED; }
+    }
+    return rc;
+  }
   // ---- transposed blob
   fit_layout_backward(h, h->fit_meta);
   if ((size_t)h->fit_meta.total * 4 > 160 * 1024) { bgm_set_error("transposed weights do not fit in LDS"); return BGM_E_UNSUPPORTED; }
@@ -425,7 +455,7 @@ extern "C" int bgm_causal_fit_theta_grad(bgm_handle *h, const float *x, const fl
   if (!grad) { bgm_set_error("bgm_causal_fit_theta_grad: grad_dev is NULL"); return BGM_E_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
-  if (FitChainState *fc = static_cast<FitChainState *>(h->fit_chain); fc && (batch == 32 || (batch == 16 && !fc->pad))) {
+  if (FitChainState *fc = static_cast<FitChainState *>(h->fit_chain); fc && batch <= 32) {
     FitChainArgs ca = fc->base;
     ca.x = x; ca.y = y; ca.v = v; ca.data_z = data_z; ca.idx = idx; ca.row_lo = row_lo; ca.inv_B = 1.0f / (float)batch_global;
     ca.loss = loss; ca.grad = grad;
@@ -484,7 +514,7 @@ extern "C" int bgm_causal_fit_z_step(bgm_handle *h, const float *x, const float 
   ka.x = x; ka.y = y; ka.v = v; ka.data_z = data_z; ka.idx = idx; ka.row_lo = row_lo; ka.B = batch;
   ka.inv_B = 1.0f / (float)batch_global; ka.z_mode = 1; ka.loss = loss;
   bool pos_set = false;
-  if (FitChainState *fc = static_cast<FitChainState *>(h->fit_chain); fc && (batch == 32 || (batch == 16 && !fc->pad))) {
+  if (FitChainState *fc = static_cast<FitChainState *>(h->fit_chain); fc && batch <= 32) {
     FitChainArgs ca = fc->base;
     ca.x = x; ca.y = y; ca.v = v; ca.data_z = data_z; ca.idx = idx; ca.row_lo = row_lo; ca.inv_B = ka.inv_B;
     ca.loss = loss; ca.dz = h->ws_dev + h->fit_ws.dz;
@@ -543,7 +573,7 @@ extern "C" int bgm_causal_fit_z_grad(bgm_handle *h, const float *x, const float 
   ka.m = h->meta; ka.bm = h->fit_meta; ka.ws = h->fit_ws; ka.wsp = h->ws_dev;
   ka.x = x; ka.y = y; ka.v = v; ka.data_z = data_z; ka.idx = idx; ka.row_lo = row_lo; ka.B = batch;
   ka.inv_B = 1.0f / (float)batch_global; ka.z_mode = 1; ka.loss = loss;
-  if (FitChainState *fc = static_cast<FitChainState *>(h->fit_chain); fc && (batch == 32 || (batch == 16 && !fc->pad))) {
+  if (FitChainState *fc = static_cast<FitChainState *>(h->fit_chain); fc && batch <= 32) {
     FitChainArgs ca = fc->base;
     ca.x = x; ca.y = y; ca.v = v; ca.data_z = data_z; ca.idx = idx; ca.row_lo = row_lo; ca.inv_B = ka.inv_B;
     ca.loss = loss; ca.dz = h->ws_dev + h->fit_ws.dz;

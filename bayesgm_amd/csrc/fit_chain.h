@@ -29,9 +29,14 @@ struct FitChainArgs {
   float *dz;                      // latent phase: [B x q]
   int *pos; long long pos_n; int epoch;      // latent phase, dense Adam on Z: batch position / step stamp of the minibatch rows (fit_set_pos_kernel's job)
   int n_warm;                     // floats of theta (= of the transposed mirror) the idle wave pair pulls into this XCD's L2
+  int n_valid;                    // rows of the minibatch (<= 16 NB): the tile rows behind them are masked -- they read row n_valid - 1,
+                                  // contribute zero loss and zero output gradients, hence nothing to any parameter gradient
 };
 
-__device__ __forceinline__ long long fitc_row(const FitChainArgs &a, int b) { return a.idx ? (long long)a.idx[b] : a.row_lo + b; }
+__device__ __forceinline__ long long fitc_row(const FitChainArgs &a, int b) {
+  b = min(b, a.n_valid - 1);
+  return a.idx ? (long long)a.idx[b] : a.row_lo + b;
+}
 
 // Z_MODE 0: theta phase (stash, no input gradients); 1: latent phase (input gradients -> dz)
 // T0: latent input tiles of g (q <= 16 T0); the head networks' inputs (z0 + z1 + 1, z0 + z2) stay within one tile
@@ -45,6 +50,7 @@ static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_kernel(FitChainA
   const int role = wave >> 1, tile = wave & 1;
   const bool active = tile < NB && role < 3;
   const int row = 16 * tile + j;
+  const float mk = row < a.n_valid ? 1.0f : 0.0f;       // short minibatches (the last one of an epoch, a rank's share under data parallelism)
   const int q = a.q, p = a.p, z0 = a.z0, z1 = a.z1, z2 = a.z2;
   const float *th = a.theta, *tT = a.thetaT;
   float *ws = a.ws;
@@ -79,7 +85,7 @@ static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_kernel(FitChainA
       for (int t = 0; t < T0; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { zin[t][r] = ech_ld(zrow, 16 * t + 4 * g + r, q); zsq = fmaf(zin[t][r], zin[t][r], zsq); }
-      l2 = 0.5f * sum_over_g(zsq);
+      l2 = mk * 0.5f * sum_over_g(zsq);
       f32x4 o[NTL];
       FITC_T(1);
       ecg_g_fwd<HT, NTL, PAD, T0>(th, a.g, a.xo[0], ws, row, zin, o, j, g);
@@ -101,11 +107,11 @@ static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_kernel(FitChainA
       if (a.sig2_v > 0.0f) { s2 = a.sig2_v; dsraw = 0.0f; }
       else {
         s2 = softplus_acc(sraw) + BGM_EPS;
-        dsraw = (-ssq / (2.0f * s2 * s2) + 0.5f * (float)p / s2) * a.inv_B * sigmoid_f(sraw);
+        dsraw = mk * (-ssq / (2.0f * s2 * s2) + 0.5f * (float)p / s2) * a.inv_B * sigmoid_f(sraw);
       }
-      l0 = ssq / (2.0f * s2) + 0.5f * (float)p * logf(s2);
-      l1 = ssq;
-      const float cmu = -a.inv_B / s2;
+      l0 = mk * (ssq / (2.0f * s2) + 0.5f * (float)p * logf(s2));
+      l1 = mk * ssq;
+      const float cmu = -mk * a.inv_B / s2;
 #pragma unroll
       for (int t = 0; t < NTL; ++t)
 #pragma unroll
@@ -136,9 +142,9 @@ static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_kernel(FitChainA
       const float tgt = is_f ? yv : xv, fixed = is_f ? a.sig2_y : a.sig2_x;
       float dmu, dsr;
       if (!is_f && a.binary) {
-        l0 = fmaxf(mu, 0.0f) - mu * tgt + log1pf(expf(-fabsf(mu)));
+        l0 = mk * (fmaxf(mu, 0.0f) - mu * tgt + log1pf(expf(-fabsf(mu))));
         l1 = l0;
-        dmu = (sigmoid_f(mu) - tgt) * a.inv_B;
+        dmu = mk * (sigmoid_f(mu) - tgt) * a.inv_B;
         dsr = 0.0f;
       } else {
         const float dd = tgt - mu;
@@ -146,11 +152,11 @@ static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_kernel(FitChainA
         if (fixed > 0.0f) { s2 = fixed; dsr = 0.0f; }
         else {
           s2 = softplus_acc(sr) + BGM_EPS;
-          dsr = (-dd * dd / (2.0f * s2 * s2) + 0.5f / s2) * a.inv_B * sigmoid_f(sr);
+          dsr = mk * (-dd * dd / (2.0f * s2 * s2) + 0.5f / s2) * a.inv_B * sigmoid_f(sr);
         }
-        l0 = dd * dd / (2.0f * s2) + 0.5f * logf(s2);
-        l1 = dd * dd;
-        dmu = -dd / s2 * a.inv_B;
+        l0 = mk * (dd * dd / (2.0f * s2) + 0.5f * logf(s2));
+        l1 = mk * dd * dd;
+        dmu = -mk * dd / s2 * a.inv_B;
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const int f = 4 * g + r; d[0][r] = f == 0 ? dmu : (f == 1 ? dsr : 0.0f); }
@@ -158,7 +164,7 @@ static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_kernel(FitChainA
       if (Z_MODE == 1) *reinterpret_cast<f32x4 *>(dzc + (role * 32 + row) * ZW + 4 * g) = dx[0];
     }
   }
-  if (Z_MODE == 1 && a.pos && tid >= 384 && tid - 384 < B) {      // row -> batch position map of the dense Adam step that follows
+  if (Z_MODE == 1 && a.pos && tid >= 384 && tid - 384 < min(B, a.n_valid)) {      // row -> batch position map of the dense Adam step that follows
     const int b = tid - 384;
     const long long r_ = fitc_row(a, b);
     a.pos[r_] = b; a.pos[a.pos_n + r_] = a.epoch;
@@ -184,7 +190,7 @@ static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_kernel(FitChainA
   }
   __syncthreads();
   if (Z_MODE == 1) {
-    for (int i = tid; i < B * q; i += ECH_THREADS) {
+    for (int i = tid; i < min(B, a.n_valid) * q; i += ECH_THREADS) {
       const int b = i / q, col = i - b * q;
       float v = a.data_z[fitc_row(a, b) * q + col] * a.inv_B + dzc[(0 * 32 + b) * ZW + col];
       if (col < z0 + z1) v += dzc[(1 * 32 + b) * ZW + col];                                  // f: (z0, z1, x)

@@ -176,3 +176,94 @@ np.savez(sys.argv[1], lp=lp, draws=out["draws"].cpu().numpy(), adrf=out["adrf"].
         same = np.all(np.abs(a["draws"][-1] - b["draws"][-1]) <= 1e-4, axis=1).mean()
         assert same >= 0.97, same
         assert np.abs(a["adrf"] - b["adrf"]).max() <= 5e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# fit of the same shapes: no LDS blob holds them, the row-tile chains (fit_chain.h) read the canonical parameters in place; short
+# minibatches (the last one of an epoch, a rank's share under data parallelism) run on the same kernels with the tail rows masked
+# ---------------------------------------------------------------------------------------------------------------------------
+from oracle import fit as OF      # noqa: E402
+
+
+def _flat(grads):
+    return np.concatenate([np.concatenate([dW.ravel(), db.ravel()]) for dW, db in grads])
+
+
+@pytest.mark.parametrize("case", [dict(z_dims=[3, 6, 3, 6], p=177, binary=True, n=300, B=32),     # Semi_acic.yaml
+                                  dict(z_dims=[3, 6, 3, 6], p=177, binary=True, n=300, B=20),     # ... a short last minibatch
+                                  dict(z_dims=[5, 5, 5, 5], p=100, binary=False, n=300, B=32),    # Sim_Colangelo.yaml
+                                  dict(z_dims=[5, 5, 5, 5], p=100, binary=False, n=300, B=7),
+                                  dict(z_dims=[4, 4, 4, 15], p=50, binary=False, n=100, B=4)])      # sum(z_dims) = 27; head inputs within one tile
+def test_fit_gradients_match_oracle(case):
+    import torch
+    m = _model(7, case["z_dims"], case["p"], case["binary"])
+    x, y, v = _data(case["n"], case["p"], 8, case["binary"])
+    z = np.random.RandomState(9).randn(case["n"], sum(case["z_dims"])).astype(np.float32)
+    eng = _engine(m)
+    dev = eng.device
+    xd, yd, vd, zd = (torch.from_numpy(a).to(dev) for a in (x.ravel(), y.ravel(), v, z))
+    B = case["B"]
+    idx_np = np.random.RandomState(3).choice(case["n"], B, replace=False).astype(np.int32)
+    idx = torch.from_numpy(idx_np).to(dev)
+    npar = eng.fit_begin(case["n"], 32)
+    grad = torch.empty(npar, device=dev)
+    loss = torch.zeros(8, device=dev, dtype=torch.float64)
+    eng.fit_theta_grad(xd, yd, vd, zd, idx, B, grad, loss)
+    m64 = OC.cast_model(m, np.float64)
+    bz, bx, by, bv = (a[idx_np].astype(np.float64) for a in (z, x, y, v))
+    lv, mse_v, gg, _ = OF.g_loss_and_grads(m64, bz, bv)
+    lx, _, gh, _ = OF.h_loss_and_grads(m64, bz, bx)
+    ly, mse_y, gf, _ = OF.f_loss_and_grads(m64, bz, bx, by)
+    got = grad.cpu().numpy()
+    o = 0
+    for part in (_flat(gg), _flat(gf), _flat(gh)):
+        g_ = got[o:o + part.size]
+        assert np.abs(g_ - part).max() <= 5e-5 * np.abs(part).max() + 1e-7, (np.abs(g_ - part).max(), np.abs(part).max())
+        o += part.size
+    l = loss.cpu().numpy()
+    assert np.allclose([l[0] / B, l[2] / B, l[4] / B], [lv, lx, ly], rtol=5e-5)
+    zm = torch.zeros_like(zd); zv = torch.zeros_like(zd)
+    z_before = zd.clone()
+    loss.zero_()
+    eng.fit_z_step(xd, yd, vd, zd, zm, zv, idx, B, 1e-3, lazy=True, loss=loss)
+    lz_ref, dz_ref = OF.z_loss_and_grad(m64, bz, bx, by, bv)
+    assert np.isclose(loss.cpu().numpy()[6] / B, lz_ref, rtol=5e-5)
+    gm = zm.cpu().numpy()[idx_np] / 0.1
+    assert np.abs(gm - dz_ref).max() <= 5e-5 * np.abs(dz_ref).max() + 1e-8
+    untouched = np.setdiff1d(np.arange(case["n"]), idx_np)
+    assert torch.equal(zd[untouched], z_before[untouched])
+    eng.fit_end()
+
+
+def test_fit_steps_then_sampling_with_the_trained_parameters():
+    """Four Adam iterations (the last minibatch short) on the Semi_acic shape track the oracle; evaluate / log-posterior DURING the
+    fit session read the device parameters (general sampling path), and after fit_end the host copies."""
+    import torch
+    z_dims, p, n = [3, 6, 3, 6], 177, 96
+    m = _model(11, z_dims, p, True)
+    x, y, v = _data(n, p, 12, True)
+    z = np.random.RandomState(13).randn(n, sum(z_dims)).astype(np.float32)
+    eng = _engine(m)
+    dev = eng.device
+    xd, yd, vd, zd = (torch.from_numpy(a).to(dev) for a in (x.ravel(), y.ravel(), v, z.copy()))
+    zm = torch.zeros_like(zd); zv = torch.zeros_like(zd)
+    B, lr = 32, 1e-3
+    npar = eng.fit_begin(n, B)
+    grad = torch.empty(npar, device=dev)
+    st = OF.FitState(OC.cast_model(m, np.float64), z.astype(np.float64), lr, lr)
+    x64, y64, v64 = (a.astype(np.float64) for a in (x, y, v))
+    rs = np.random.RandomState(5)
+    for step in range(4):
+        idx_np = rs.choice(n, B if step < 3 else 17, replace=False).astype(np.int32)
+        idx = torch.from_numpy(idx_np).to(dev)
+        eng.fit_theta_grad(xd, yd, vd, zd, idx, len(idx_np), grad)
+        eng.fit_theta_apply(grad, lr)
+        eng.fit_z_step(xd, yd, vd, zd, zm, zv, idx, len(idx_np), lr, lazy=False)
+        OF.fit_step(st, x64, y64, v64, idx_np, lazy_z=False)
+    assert np.abs(zd.cpu().numpy() - st.data_z).max() <= 3e-4
+    lp = eng.logpost(xd, yd, vd, zd).cpu().numpy()
+    ref = OC.log_posterior(dict(st.m), x64, y64, v64, st.data_z)
+    assert np.abs(lp - ref).max() <= 5e-2
+    eng.fit_end()
+    lp2 = eng.logpost(xd, yd, vd, zd).cpu().numpy()
+    assert np.abs(lp - lp2).max() <= 1e-4 * np.abs(lp).max()
