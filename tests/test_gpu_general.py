@@ -267,3 +267,30 @@ def test_fit_steps_then_sampling_with_the_trained_parameters():
     eng.fit_end()
     lp2 = eng.logpost(xd, yd, vd, zd).cpu().numpy()
     assert np.abs(lp - lp2).max() <= 1e-4 * np.abs(lp).max()
+
+
+@pytest.mark.parametrize("name,z_dims,p,binary", [("Semi_acic", [3, 6, 3, 6], 177, True), ("Sim_Colangelo", [5, 5, 5, 5], 100, False)])
+def test_reference_yaml_shapes_through_the_class_with_deterministic_nets(tmp_path, name, z_dims, p, binary):
+    """configs/Semi_acic.yaml and configs/Sim_Colangelo.yaml with use_bnn = False: EGM warm start, iterative updates (short last
+    minibatch), evaluation every epoch and predict run end to end -- warm start and fit on the row-tile chains, evaluate / predict on
+    the general sampling path."""
+    from bayesgm_amd.models import CausalBGM
+    rs = np.random.RandomState(0)
+    n = 203
+    v = rs.randn(n, p).astype(np.float32)
+    x = ((rs.rand(n, 1) > 0.5) if binary else rs.exponential(size=(n, 1))).astype(np.float32)
+    y = (x + 0.3 * v[:, :1] + rs.randn(n, 1)).astype(np.float32)
+    params = dict(dataset=name, output_dir=str(tmp_path), save_res=False, save_model=False, binary_treatment=binary, use_bnn=False,
+                  z_dims=z_dims, v_dim=p, lr_theta=1e-4, lr_z=1e-4, lr=2e-4, g_d_freq=5, use_z_rec=True, kl_weight=1e-4,
+                  g_units=[64] * 5, e_units=[64] * 5, f_units=[64, 32, 8], h_units=[64, 32, 8], dz_units=[64, 32, 8])
+    m = CausalBGM(params, timestamp="t", random_seed=1)
+    m.fit((x, y, v), epochs=2, epochs_per_eval=1, batch_size=32, use_egm_init=True, egm_n_iter=30, egm_batches_per_eval=15, verbose=0)
+    assert m.data_z.shape == (n, sum(z_dims)) and np.isfinite(np.asarray(m.best_causal_pre)).all()
+    if binary:
+        eff, iv = m.predict((x, y, v), alpha=0.05, n_mcmc=24, burn_in=16, q_sd=0.5, verbose=0)
+        assert eff.shape == (n,) and iv.shape == (n, 2) and np.isfinite(eff).all() and (iv[:, 0] <= iv[:, 1]).all()
+    else:
+        xs = np.linspace(0, 2, 5)
+        eff, iv = m.predict((x, y, v), alpha=0.05, n_mcmc=24, burn_in=16, x_values=xs, q_sd=0.5, verbose=0)
+        assert eff.shape == (5,) and iv.shape == (5, 2) and np.isfinite(eff).all()
+    assert 0.0 < m.last_acceptance_rate < 1.0
