@@ -243,16 +243,14 @@ template <int KS, int R, bool DET = false>
 __device__ __forceinline__ void bnf_head(const f32x4 *LF, const f32x4 *__restrict__ DW, const f32x4 *BL, const f32x4 *NORM, const int4 *SHIFT, int lane,
                                          int g, const float (&ze)[R][KS], const uint4 (&G)[R][BNF_NG_H], float (&mu)[R], float (&raw)[R]) {
   constexpr int T0 = (KS + 3) / 4;
-  // perturbation fragments of layers 2..4 requested up front (11 KB per wave): the small layers have no tile loop to hide them in
+  // perturbation fragments of the small layers 2..4 are requested one layer ahead (they have no tile loop to hide them in): layer 2's
+  // first output tile before layer 1, its second tile and layers 3 / 4 behind layer 1 -- all eleven up front cost 44 registers at the
+  // point where the two-tile sampler is fullest (43 spilled)
   f32x4 fd2[2][4], fd3[2], fd4;
+  const f32x4 *D2 = DW + 4 * T0 * 64;
   if constexpr (!DET) {
-    const f32x4 *D2 = DW + 4 * T0 * 64;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) fd2[mt][t] = D2[(mt * 4 + t) * 64 + lane];
-    fd3[0] = D2[8 * 64 + lane]; fd3[1] = D2[9 * 64 + lane];
-    fd4 = D2[10 * 64 + lane];
+    for (int t = 0; t < 4; ++t) fd2[0][t] = D2[t * 64 + lane];
     BNF_PIN();
   }
   float h1[R][4][4], hs1[R][4][4];
@@ -266,6 +264,13 @@ __device__ __forceinline__ void bnf_head(const f32x4 *LF, const f32x4 *__restric
       Gn[rt] = G[rt][1];
     }
     bnf_first<KS, R, DET>(LF, DW, BL, NORM, SHIFT, lane, g, ze, w_in, wo, Gn, h1, hs1);
+  }
+  if constexpr (!DET) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) fd2[1][t] = D2[(4 + t) * 64 + lane];
+    fd3[0] = D2[8 * 64 + lane]; fd3[1] = D2[9 * 64 + lane];
+    fd4 = D2[10 * 64 + lane];
+    BNF_PIN();
   }
   // layer 2: 64 -> 32
   const f32x4 *L2 = LF + 4 * T0 * 64;
