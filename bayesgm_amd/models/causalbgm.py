@@ -356,12 +356,21 @@ class CausalBGM(object):
             flat.update(opt_m=st["m"], opt_v=st["v"], opt_steps=np.array([st["t_theta"], st["t_z"]], np.int64),
                         data_z=self.data_z.cpu().numpy(), z_m=self._fit_live[0].cpu().numpy(), z_v=self._fit_live[1].cpu().numpy())
         flat["seed_state"] = np.array([self._base_seed, self._seed_counter], np.int64)
+        flat.update(self._checkpoint_extra())
         path = self.ckpt_manager.save("ckpt-%s.npz" % epoch, flat)
         print('Saving checkpoint for epoch {} at {}'.format(epoch, path))
         return path
 
+    def _checkpoint_extra(self):
+        """Further tracked objects of a subclass (IdentifiableCausalBGM: prior_net, prior_optimizer) as named arrays."""
+        return {}
+
+    def _restore_extra(self, d):
+        pass
+
     def load_checkpoint(self, path):
         d = np.load(path)
+        self._restore_extra(d)
         for k in list(self.nets):
             self.nets[k] = [(d["%s_W%d" % (k, i)], d["%s_b%d" % (k, i)]) for i in range(len(self.nets[k]))]
         self._push_weights()

@@ -43,6 +43,43 @@ class IdentifiableCausalBGM(CausalBGM):
         self._prior_v = [(torch.zeros_like(W), torch.zeros_like(b)) for W, b in self.prior_net]
         self._prior_t = 0
         self._z_t = 0
+        if getattr(self, "_pending_prior", None) is not None:      # a checkpoint was restored by CausalBGM.__init__ before the prior net existed
+            self._apply_prior_arrays(self._pending_prior)
+            self._pending_prior = None
+
+    # ------------------------------------------------------------------ checkpoints: prior_net and prior_optimizer are tracked too (:112-128)
+    def _checkpoint_extra(self):
+        flat = {}
+        for i, (W, b) in enumerate(self.prior_net):
+            flat["prior_W%d" % i] = W.detach().cpu().numpy()
+            flat["prior_b%d" % i] = b.detach().cpu().numpy()
+            flat["prior_mW%d" % i] = self._prior_m[i][0].cpu().numpy(); flat["prior_mb%d" % i] = self._prior_m[i][1].cpu().numpy()
+            flat["prior_vW%d" % i] = self._prior_v[i][0].cpu().numpy(); flat["prior_vb%d" % i] = self._prior_v[i][1].cpu().numpy()
+        flat["prior_steps"] = np.array([self._prior_t, self._z_t], np.int64)
+        if getattr(self, "segments", None) is not None:
+            flat["segments"] = np.asarray(self.segments, np.int64)
+        return flat
+
+    def _apply_prior_arrays(self, d):
+        dev = self.engine.device
+        n = len(self.prior_net)
+        if any(("prior_W%d" % i) not in d for i in range(n)):
+            return
+        T = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+        self.prior_net = [(T(d["prior_W%d" % i]).requires_grad_(True), T(d["prior_b%d" % i]).requires_grad_(True)) for i in range(n)]
+        if ("prior_mW0") in d:
+            self._prior_m = [(T(d["prior_mW%d" % i]), T(d["prior_mb%d" % i])) for i in range(n)]
+            self._prior_v = [(T(d["prior_vW%d" % i]), T(d["prior_vb%d" % i])) for i in range(n)]
+            self._prior_t, self._z_t = int(d["prior_steps"][0]), int(d["prior_steps"][1])
+        if "segments" in d:
+            self.segments = np.asarray(d["segments"])
+
+    def _restore_extra(self, d):
+        arrays = {k: d[k] for k in d.files if k.startswith("prior_") or k == "segments"}
+        if hasattr(self, "prior_net"):
+            self._apply_prior_arrays(arrays)
+        else:
+            self._pending_prior = arrays
 
     # ------------------------------------------------------------------ prior network
     def _prior_forward(self, u_onehot):

@@ -99,3 +99,28 @@ def test_identifiable_fit_trace_and_predict():
     assert samples.shape == (5, n, q) and data_u.shape == (n, 6) and np.all(data_u.sum(axis=1) == 1)
     with pytest.raises(NotImplementedError):
         IdentifiableCausalBGM(dict(prm, use_bnn=True))
+
+
+def test_checkpoint_round_trip_restores_the_prior_network(tmp_path):
+    """tf.train.Checkpoint of the reference tracks prior_net and prior_optimizer (identifiable.py:112-128): a model re-created on the
+    timestamp of a saved run must continue with the TRAINED prior network, its Adam slots and step counters, not a fresh one."""
+    from bayesgm_amd.models import IdentifiableCausalBGM
+    g = np.load(GOLD)
+    x, y, v = g["x"][:256], g["y"][:256], g["v"][:256]
+    prm = dict(_params(), n_segments=5, output_dir=str(tmp_path), save_model=True)
+    a = IdentifiableCausalBGM(prm, timestamp="ck", random_seed=3)
+    a.fit((x, y, v), batch_size=32, epochs=1, epochs_per_eval=1, use_egm_init=False, verbose=0)
+    a.save_checkpoint("final")
+    z = np.random.RandomState(0).randn(len(x), 10).astype(np.float32)
+    u = np.eye(5, dtype=np.float32)[a.segments]
+    want = a.get_log_posterior(x, y, v, z, u)
+    b = IdentifiableCausalBGM(prm, timestamp="ck", random_seed=99)       # restores the latest checkpoint of the directory
+    for (Wa, ba), (Wb, bb) in zip(a.prior_parameters(), b.prior_parameters()):
+        assert np.array_equal(Wa, Wb) and np.array_equal(ba, bb)
+    assert (b._prior_t, b._z_t) == (a._prior_t, a._z_t) and a._prior_t > 0
+    for (ma, _), (mb, _) in zip(a._prior_m, b._prior_m):
+        assert np.array_equal(ma.cpu().numpy(), mb.cpu().numpy())
+    got = b.get_log_posterior(x, y, v, z, u)
+    assert np.array_equal(want, got)
+    c = IdentifiableCausalBGM(prm, timestamp="other", random_seed=99)    # a fresh directory: a fresh prior network
+    assert not np.array_equal(c.prior_parameters()[0][0], a.prior_parameters()[0][0])
