@@ -21,7 +21,11 @@ _lib = None
 
 def build(force=False):
     if force or not os.path.exists(_SO) or os.path.getmtime(_SRC) > os.path.getmtime(_SO):
-        subprocess.check_call(["gcc", "-O3", "-shared", "-fPIC", "-o", _SO, _SRC, "-lm"])
+        # link to a private name and rename: ranks of one torchrun job reach this at the same time, and a rank must never map a
+        # half-written library (os.replace is atomic; whoever loses the race just replaces an identical file)
+        tmp = "%s.%d.tmp" % (_SO, os.getpid())
+        subprocess.check_call(["gcc", "-O3", "-shared", "-fPIC", "-o", tmp, _SRC, "-lm"])
+        os.replace(tmp, _SO)
     return _SO
 
 
