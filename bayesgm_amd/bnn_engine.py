@@ -146,6 +146,11 @@ class BnnEngine(object):
                                            int(stream_id) & 0xFFFFFFFF, _ptr(out), _ptr(dz_out), self._stream()),
                    "bgm_bnn_z_step")
 
+    def z_sync(self, data_z, zm, zv, idx, lr_z):
+        """Replay mode (lazy = 2): bring the rows idx (None = every row) of the latent table and its Adam slots up to the current step."""
+        _lib.check(self.lib.bgm_bnn_z_sync(self.h, _ptr(data_z), _ptr(zm), _ptr(zv), _ptr(idx), data_z.shape[0],
+                                           0 if idx is None else int(idx.numel()), float(lr_z), self._stream()), "bgm_bnn_z_sync")
+
     # -- large-batch side ------------------------------------------------------------------------------
     def logpost(self, x, y, v, z, block_rows, seed, stream_id, block0=0):
         out = torch.empty(z.shape[0], device=self.device, dtype=torch.float32)

@@ -80,6 +80,8 @@ struct bgm_handle {
         *partial_dev = nullptr;
   int *tables_dev = nullptr;  // fwd_dst | fwd_dst2 | bwd_dst | grad_src, n_params each
   int *pos_dev = nullptr;
+  int *tlast_dev = nullptr;   // replay mode of the latent Adam (bgm_causal_fit_z_sync): step each row's (z, m, v) are current to
+  long long z_synced = -1;    // the minibatch step whose rows bgm_causal_fit_z_sync has brought up to date
   FitMeta fit_meta{};
   FitWs fit_ws{};
   DwArgs dw{};

@@ -86,6 +86,7 @@ void bgm_bnn_free_state(bgm_handle *h) {
   if (!h->bnn_state) return;
   BnnState *s = bst(h);
   if (s->dev) hipFree(s->dev);
+  if (s->tlast_dev) hipFree(s->tlast_dev);
   bnn_free_sampler(s);
   bgm_bnn_egm_free(s->egm);
   bnn_chain_free(s);
@@ -300,6 +301,17 @@ extern "C" int bgm_bnn_z_step(bgm_handle *h, const float *x, const float *y, con
   if (!data_z || !idx || !x || !y || !v) { bgm_set_error("bgm_bnn_z_step: NULL argument"); return BGM_E_INVALID; }
   if (batch < 2 || batch > s->cfg.max_batch) { bgm_set_error("bgm_bnn_z_step: batch outside [2, max_batch]"); return BGM_E_INVALID; }
   if (!dz_out && (!zm || !zv)) { bgm_set_error("bgm_bnn_z_step: NULL Adam slots"); return BGM_E_INVALID; }
+  if (!dz_out) {
+    if (lazy < 0 || lazy > 2) { bgm_set_error("bgm_bnn_z_step: lazy must be 0 (dense), 1 (batch rows only) or 2 (replay)"); return BGM_E_INVALID; }
+    if (lazy == 2 && (!s->tlast_dev || s->tlast_rows != n_rows || s->z_synced != s->t_z + 1)) {
+      bgm_set_error("bgm_bnn_z_step: lazy = 2 needs bgm_bnn_z_sync on this minibatch's rows first (before its theta steps)");
+      return BGM_E_STATE;
+    }
+    if (lazy != 2 && s->tlast_dev && s->z_synced != -2) {
+      bgm_set_error("bgm_bnn_z_step: rows have pending replay steps; flush with bgm_bnn_z_sync(idx = NULL) before changing mode");
+      return BGM_E_STATE;
+    }
+  }
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
   BnnArgs a{};
@@ -324,7 +336,10 @@ extern "C" int bgm_bnn_z_step(bgm_handle *h, const float *x, const float *y, con
   const int q = s->q;
   const long long n = (long long)n_rows * q;
   const int nb = batch * q;
-  if (lazy) {
+  if (lazy == 2) {
+    hipLaunchKernelGGL(bnn_z_rows_kernel, dim3((nb + 255) / 256), dim3(256), 0, stream, data_z, zm, zv, a.dz, idx, batch, q, lr_t,
+                       BNN_ADAM_B1, BNN_ADAM_B2, BNN_ADAM_EPS, 1, s->tlast_dev, (int)s->t_z);
+  } else if (lazy) {
     hipLaunchKernelGGL(bnn_z_rows_kernel, dim3((nb + 255) / 256), dim3(256), 0, stream, data_z, zm, zv, a.dz, idx, batch, q, lr_t,
                        BNN_ADAM_B1, BNN_ADAM_B2, BNN_ADAM_EPS, 1);
   } else {
@@ -333,6 +348,32 @@ extern "C" int bgm_bnn_z_step(bgm_handle *h, const float *x, const float *y, con
                        BNN_ADAM_B1, BNN_ADAM_B2, BNN_ADAM_EPS, 0);
     hipLaunchKernelGGL(bnn_z_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, data_z, zm, zv, n, lr_t, BNN_ADAM_EPS);
   }
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+extern "C" int bgm_bnn_z_sync(bgm_handle *h, float *data_z, float *zm, float *zv, const int32_t *idx, int64_t n_rows, int32_t batch,
+                              float lr_z, void *stream_) {
+  int rc = bnn_need(h, "bgm_bnn_z_sync");
+  if (rc) return rc;
+  BnnState *s = bst(h);
+  if (!data_z || !zm || !zv || n_rows < 1 || (idx && batch < 1)) { bgm_set_error("bgm_bnn_z_sync: bad argument"); return BGM_E_INVALID; }
+  hipStream_t stream = (hipStream_t)stream_;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  if (s->tlast_dev && s->tlast_rows != n_rows) { bgm_set_error("bgm_bnn_z_sync: n_rows differs from the table the replay state belongs to"); return BGM_E_INVALID; }
+  if (!s->tlast_dev) {                               // every row is current at the step the mode is entered
+    BGM_HIP_CHECK(hipMalloc(&s->tlast_dev, sizeof(int) * n_rows));
+    s->tlast_rows = n_rows;
+    hipLaunchKernelGGL(fit_fill_int_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, s->tlast_dev, (long long)n_rows, (int)s->t_z);
+  }
+  const long long n_sel = idx ? batch : n_rows;
+  const long long threads = n_sel * s->q * 16;
+  hipLaunchKernelGGL(fit_adam_z_replay_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, data_z, zm, zv,
+                     s->tlast_dev, s->q, idx, n_sel, (int)s->t_z, lr_z, BNN_ADAM_B1, BNN_ADAM_B2, BNN_ADAM_EPS);
+  if (!idx) {
+    hipLaunchKernelGGL(fit_fill_int_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, s->tlast_dev, (long long)n_rows, (int)s->t_z);
+    s->z_synced = -2;
+  } else s->z_synced = s->t_z + 1;
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
 }

@@ -19,6 +19,8 @@ struct BnnState {
   long long ws_stride = 0;
   size_t ws_floats = 0;
   long long t_theta = 0, t_z = 0;
+  int *tlast_dev = nullptr;    // replay mode of the latent Adam (bgm_bnn_z_sync): step each row's (z, m, v) are current to
+  long long tlast_rows = 0, z_synced = -1;
   // large-batch (sampling / evaluation) side: packed kernels and per-call perturbations, rebuilt when theta changes
   bool packed_valid = false;
   float *samp_dev = nullptr;

@@ -224,8 +224,10 @@ static void causal_pack_backward(bgm_handle *h, const HostNet &G, const HostNet 
 
 static void fit_free(bgm_handle *h) {
   for (void *p : {(void *)h->theta_dev, (void *)h->m1_dev, (void *)h->m2_dev, (void *)h->bblob_dev, (void *)h->ws_dev,
-                  (void *)h->partial_dev, (void *)h->tables_dev, (void *)h->pos_dev})
+                  (void *)h->partial_dev, (void *)h->tables_dev, (void *)h->pos_dev, (void *)h->tlast_dev})
     if (p) hipFree(p);
+  h->tlast_dev = nullptr;
+  h->z_synced = -1;
   h->theta_dev = h->m1_dev = h->m2_dev = h->bblob_dev = h->ws_dev = h->partial_dev = nullptr;
   h->tables_dev = h->pos_dev = nullptr;
   h->fit_active = false;
@@ -507,6 +509,15 @@ extern "C" int bgm_causal_fit_z_step(bgm_handle *h, const float *x, const float 
   if (rc) return rc;
   if (!zm || !zv) { bgm_set_error("bgm_causal_fit_z_step: NULL Adam slots"); return BGM_E_INVALID; }
   if (!idx) { bgm_set_error("bgm_causal_fit_z_step: idx_dev is required"); return BGM_E_INVALID; }
+  if (lazy < 0 || lazy > 2) { bgm_set_error("bgm_causal_fit_z_step: lazy must be 0 (dense), 1 (batch rows only) or 2 (replay)"); return BGM_E_INVALID; }
+  if (lazy == 2 && (!h->tlast_dev || h->z_synced != h->t_z + 1)) {
+    bgm_set_error("bgm_causal_fit_z_step: lazy = 2 needs bgm_causal_fit_z_sync on this minibatch's rows first (before its theta phase)");
+    return BGM_E_STATE;
+  }
+  if (lazy != 2 && h->tlast_dev && h->z_synced != -2) {
+    bgm_set_error("bgm_causal_fit_z_step: rows have pending replay steps; flush with bgm_causal_fit_z_sync(idx = NULL) before changing mode");
+    return BGM_E_STATE;
+  }
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
   FitKArgs ka{};
@@ -528,7 +539,11 @@ extern "C" int bgm_causal_fit_z_step(bgm_handle *h, const float *x, const float 
   const float lr_t = (float)((double)lr_z * std::sqrt(1.0 - std::pow((double)ADAM_B2, t)) / (1.0 - std::pow((double)ADAM_B1, t)));
   const int q = h->q;
   const float *dz = h->ws_dev + h->fit_ws.dz;
-  if (lazy) {
+  if (lazy == 2) {
+    const long long n = (long long)batch * q;
+    hipLaunchKernelGGL(fit_adam_z_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, data_z, zm, zv, dz,
+                       h->tlast_dev, h->fit_rows, q, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS, 2, idx, batch, (int)h->t_z);
+  } else if (lazy) {
     const long long n = (long long)batch * q;
     hipLaunchKernelGGL(fit_adam_z_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, data_z, zm, zv, dz,
                        h->pos_dev, h->fit_rows, q, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS, 1, idx, batch, 0);
@@ -540,6 +555,29 @@ extern "C" int bgm_causal_fit_z_step(bgm_handle *h, const float *x, const float 
     hipLaunchKernelGGL(fit_adam_z_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, data_z, zm, zv, dz,
                        h->pos_dev, h->fit_rows, q, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS, 0, idx, batch, epoch);
   }
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+extern "C" int bgm_causal_fit_z_sync(bgm_handle *h, float *data_z, float *zm, float *zv, const int32_t *idx, int32_t batch, float lr_z,
+                                     void *stream_) {
+  if (!h || !h->fit_active) { bgm_set_error("bgm_causal_fit_z_sync: call bgm_causal_fit_begin first"); return BGM_E_STATE; }
+  if (!data_z || !zm || !zv || (idx && batch < 1)) { bgm_set_error("bgm_causal_fit_z_sync: bad argument"); return BGM_E_INVALID; }
+  hipStream_t stream = (hipStream_t)stream_;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  const long long n_rows = h->fit_rows;
+  if (!h->tlast_dev) {                               // every row is current at the step the mode is entered
+    BGM_HIP_CHECK(hipMalloc(&h->tlast_dev, sizeof(int) * n_rows));
+    hipLaunchKernelGGL(fit_fill_int_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, h->tlast_dev, n_rows, (int)h->t_z);
+  }
+  const long long n_sel = idx ? batch : n_rows;
+  const long long threads = n_sel * h->q * 16;
+  hipLaunchKernelGGL(fit_adam_z_replay_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, data_z, zm, zv,
+                     h->tlast_dev, h->q, idx, n_sel, (int)h->t_z, lr_z, ADAM_B1, ADAM_B2, ADAM_EPS);
+  if (!idx) {
+    hipLaunchKernelGGL(fit_fill_int_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, h->tlast_dev, n_rows, (int)h->t_z);
+    h->z_synced = -2;                                // flushed: any mode may follow
+  } else h->z_synced = h->t_z + 1;
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
 }
@@ -596,6 +634,7 @@ extern "C" int bgm_causal_fit_state(bgm_handle *h, int32_t write, float *m_host,
     BGM_HIP_CHECK(hipMemcpy(h->m1_dev, m_host, bytes, hipMemcpyHostToDevice));
     BGM_HIP_CHECK(hipMemcpy(h->m2_dev, v_host, bytes, hipMemcpyHostToDevice));
     h->t_theta = steps[0]; h->t_z = steps[1];
+    if (h->tlast_dev) { hipFree(h->tlast_dev); h->tlast_dev = nullptr; h->z_synced = -1; }   // rows count as current at the restored step
   } else {
     BGM_HIP_CHECK(hipMemcpy(m_host, h->m1_dev, bytes, hipMemcpyDeviceToHost));
     BGM_HIP_CHECK(hipMemcpy(v_host, h->m2_dev, bytes, hipMemcpyDeviceToHost));

@@ -10,6 +10,7 @@
 // layer activations round-trip through an HBM workspace in row-major [batch][width] form, which is
 // also exactly what the weight-gradient GEMM (contraction over rows) wants to read.
 #pragma once
+#include "z_replay.h"
 #include "fit_types.h"
 
 
@@ -449,6 +450,7 @@ __global__ void fit_adam_z_kernel(float *z, float *zm, float *zv, const float *d
     const float v = b2 * zv[e] + (1.0f - b2) * g * g;
     zm[e] = m; zv[e] = v;
     z[e] -= lr_t * m / (sqrtf(v) + eps);
+    if (lazy == 2 && f == 0) const_cast<int *>(pos)[idx[b]] = epoch;      // replay mode: `pos` is t_last, `epoch` this step
     return;
   }
   if (i >= n * q) return;

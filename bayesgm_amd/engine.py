@@ -232,10 +232,16 @@ class CausalEngine(object):
                    "bgm_causal_fit_theta_apply")
 
     def fit_z_step(self, x, y, v, data_z, zm, zv, idx, batch_global, lr_z, lazy=False, loss=None):
+        """lazy: False / 0 = dense-decay Adam on the whole table, True / 1 = batch rows only, 2 = replay (fit_z_sync first)."""
         _lib.check(self.lib.bgm_causal_fit_z_step(self.h, _ptr(x), _ptr(y), _ptr(v), _ptr(data_z), _ptr(zm), _ptr(zv),
                                                   _ptr(idx), 0, int(idx.numel()), int(batch_global), float(lr_z),
-                                                  int(bool(lazy)), _ptr(loss), self._stream()),
+                                                  int(lazy), _ptr(loss), self._stream()),
                    "bgm_causal_fit_z_step")
+
+    def fit_z_sync(self, data_z, zm, zv, idx, lr_z):
+        """Replay mode: bring the rows idx (None = every row) of the latent table and its Adam slots up to the current step."""
+        _lib.check(self.lib.bgm_causal_fit_z_sync(self.h, _ptr(data_z), _ptr(zm), _ptr(zv), _ptr(idx), 0 if idx is None else int(idx.numel()),
+                                                  float(lr_z), self._stream()), "bgm_causal_fit_z_sync")
 
     def fit_z_grad(self, x, y, v, data_z, idx, batch_global, dz_out, loss=None):
         """d(batch-mean negative log joint, standard-normal prior)/d(batch rows of data_z) -> dz_out [batch x q]; no update."""

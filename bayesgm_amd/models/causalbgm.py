@@ -246,14 +246,18 @@ class CausalBGM(object):
             print('EGM Initialization Ends.')
 
     def fit(self, data, epochs=100, epochs_per_eval=5, batch_size=32, startoff=0, use_egm_init=True,
-            egm_n_iter=30000, egm_batches_per_eval=500, save_format='txt', verbose=1, z_adam="dense"):
+            egm_n_iter=30000, egm_batches_per_eval=500, save_format='txt', verbose=1, z_adam="replay"):
         """Iterative theta / Z updates (base.py:434-532).
 
         ``batch_size`` is the GLOBAL minibatch; under torch.distributed every rank owns a contiguous row
         shard, draws its share of each minibatch from its own rows, and the g/f/h gradients are
         all-reduced (RCCL) before the Adam step, so all ranks hold identical networks.
-        ``z_adam``: "dense" = Keras sparse-gradient Adam semantics of the reference (moment decay and update
-        on ALL rows every step, base.py:301), "lazy" = batch rows only (build option, O(B) per step)."""
+        ``z_adam`` -- the latent optimizer (base.py:246-302 applies a sparse gradient with Keras' Adam, whose sparse path decays the
+        moments of and updates ALL rows at every minibatch):
+          "replay" (default) the same recursion with the zero-gradient steps of the rows outside a minibatch deferred until the row
+                   is next used (O(batch) per step; equal to "dense" up to fp32 rounding of a 256-term series, csrc/z_replay.h);
+          "dense"  the recursion as Keras executes it: a sweep over the [N x q] table per minibatch (bit-faithful order of operations);
+          "lazy"   batch rows only -- a different optimizer (build option)."""
         if use_egm_init:
             self.egm_init(data, egm_n_iter=egm_n_iter, batch_size=batch_size,
                           egm_batches_per_eval=egm_batches_per_eval, verbose=verbose)
@@ -294,7 +298,11 @@ class CausalBGM(object):
         grad = torch.empty(n_params, device=dev, dtype=torch.float32)
         loss = torch.zeros(8, device=dev, dtype=torch.float64)       # theta phase: row sums of loss_v, |v-mu|^2, loss_x, ...
         loss_z = torch.zeros(8, device=dev, dtype=torch.float64)     # Z phase: [6] = row sums of the negative log joint
-        lazy = (z_adam == "lazy")
+        if z_adam not in ("dense", "lazy", "replay"):
+            raise ValueError("z_adam must be 'replay', 'dense' or 'lazy'")
+        lazy = {"dense": 0, "lazy": 1, "replay": 2}[z_adam]
+        replay = (lazy == 2)
+        lr_z = self._p['lr_z']
         best_loss = np.inf
         # per-epoch trace (row means over the epoch's minibatches; the reference shows the last minibatch in its progress bar)
         self.fit_history = []
@@ -310,6 +318,8 @@ class CausalBGM(object):
                 for i in range(0, n_use, b_loc):
                     idx = sample_idx[i:min(i + b_loc, n_use)]
                     bg = int(idx.numel()) * world
+                    if replay:
+                        eng.fit_z_sync(self.data_z, zm, zv, idx, lr_z)           # this minibatch's rows, current before they are read
                     eng.fit_theta_grad(x, y, v, self.data_z, idx, bg, grad, loss)
                     parallel.all_reduce_sum_(grad)                       # C1: fused g|f|h gradient
                     eng.fit_theta_apply(grad, self._p['lr_theta'])
@@ -324,6 +334,8 @@ class CausalBGM(object):
                     print('Epoch [%d/%d]: loss_px_z [%.4f], loss_mse_x [%.4f], loss_py_z [%.4f], loss_mse_y [%.4f], loss_pv_z [%.4f], '
                           'loss_mse_v [%.4f], loss_postrior_z [%.4f]' % (epoch, epochs, l[2], l[3], l[4], l[5], l[0], l[1] / eng.v_dim, lz[6]))
                 if epoch % epochs_per_eval == 0:
+                    if replay:
+                        eng.fit_z_sync(self.data_z, zm, zv, None, lr_z)          # flush: evaluate / checkpoints read the whole table
                     causal_pre, mse_x, mse_y, mse_v = self._evaluate_dev(x, y, v, self.data_z, n_total, lo_r)
                     self.fit_history[-1].update(mse_x=float(mse_x), mse_y=float(mse_y), mse_v=float(mse_v))
                     if verbose:
@@ -339,6 +351,8 @@ class CausalBGM(object):
                         save_data('{}/causal_pre_at_{}.{}'.format(self.save_dir, epoch, save_format), causal_pre)
         finally:
             self._fit_live = None
+            if replay:
+                eng.fit_z_sync(self.data_z, zm, zv, None, lr_z)
             eng.fit_end()
             self._pull_weights()
 

@@ -218,7 +218,7 @@ class CausalBGMBayes(CausalBGM):
 
     # ------------------------------------------------------------------ fit
     def fit(self, data, epochs=100, epochs_per_eval=5, batch_size=32, startoff=0, use_egm_init=True,
-            egm_n_iter=30000, egm_batches_per_eval=500, save_format='txt', verbose=1, z_adam="dense"):
+            egm_n_iter=30000, egm_batches_per_eval=500, save_format='txt', verbose=1, z_adam="replay"):
         """Iterative theta / Z updates (base.py:434-532) with the KL terms of the Bayesian nets.  ``batch_size`` is the
         GLOBAL minibatch (<= 64 per rank); under torch.distributed rows are sharded, the g | h | f gradients all-reduced."""
         if use_egm_init:
@@ -256,7 +256,11 @@ class CausalBGMBayes(CausalBGM):
         grad = torch.empty(eng.n_params, device=dev, dtype=torch.float32) if world > 1 else None
         out_t = torch.zeros(8, device=dev)
         out_z = torch.zeros(4, device=dev)
-        lazy = (z_adam == "lazy")
+        if z_adam not in ("dense", "lazy", "replay"):
+            raise ValueError("z_adam must be 'replay', 'dense' or 'lazy'")
+        lazy = {"dense": 0, "lazy": 1, "replay": 2}[z_adam]      # see CausalBGM.fit
+        replay = (lazy == 2)
+        lr_z = self._p['lr_z']
         best_loss = np.inf
         if verbose:
             print('Iterative Updating Starts ...')
@@ -268,6 +272,8 @@ class CausalBGMBayes(CausalBGM):
                     continue                      # batch statistics need two rows (the same decision on every rank)
                 bg = int(idx.numel()) * world
                 s0 = self._streams(3)
+                if replay:
+                    eng.z_sync(self.data_z, zm, zv, idx, lr_z)
                 if world > 1:
                     eng.theta_step(self.data_z, idx, x, y, v, self._p['lr_theta'], seed, s0, apply=False, batch_global=bg, out=out_t)
                     eng.grad_exchange(grad, False)
@@ -281,6 +287,8 @@ class CausalBGMBayes(CausalBGM):
                 lt, lz = out_t.cpu().numpy(), out_z.cpu().numpy()
                 print('Epoch [%d/%d]: loss_px_z [%.4f], loss_mse_x [%.4f], loss_py_z [%.4f], loss_mse_y [%.4f], loss_pv_z [%.4f], '
                       'loss_mse_v [%.4f], loss_postrior_z [%.4f]' % (epoch, epochs, lt[2], lt[3], lt[4], lt[5], lt[0], lt[1], lz[0]))
+            if replay and (epoch % epochs_per_eval == 0 or epoch == epochs):
+                eng.z_sync(self.data_z, zm, zv, None, lr_z)                      # flush: evaluate / checkpoints read the whole table
             if epoch % epochs_per_eval == 0:
                 causal_pre, mse_x, mse_y, mse_v = self._evaluate_dev(x, y, v, self.data_z, n_total, lo_r)
                 if verbose:

@@ -14,9 +14,11 @@ every row, the fused dose-response inference for the retained draws, the slot re
 ADRF all-reduce, and the posterior mean / quantiles.
 
 The JSON line also carries
-  roofline     -- the dominant kernel (burn-in MH transition kernel, fp32 MFMA): algorithmic
-                  FLOP/launch (2*MACs(g+f+h) = 69,696 FLOP per row-transition) over
-                  its hipEvent-measured duration, against the 157.3 TF dense fp32-MFMA peak.
+  roofline     -- the dominant kernel instance by share of kernel time (at the BASELINE iteration counts that is the keep-phase
+                  instance causal_mh_kernel<EFFECT=1>: one transition + the outcome net at 20 doses per retained draw; the
+                  burn-in instance <EFFECT=0> is listed beside it under "instances"), fp32 MFMA: algorithmic FLOP/launch
+                  (2*MACs(g+f+h) = 69,696 FLOP per row-transition, + 2*MACs(f) per row and dose for a retained draw,
+                  SURVEY.md 8d) over its hipEvent-measured duration, against the 157.3 TF dense fp32-MFMA peak.
   cpu_baseline -- the oracle's literal restatement of the reference loop (NumPy, host RNG, two
                   log-posterior evaluations per iteration) timed on this box's host cores on a
                   bounded sample (bs=10000 rows x a few iterations).
@@ -94,36 +96,46 @@ def parity_leg(model, x, y, v, z_dims, p, x_values, rows=256, burn_in=300, n_kee
 
 def fit_leg(model, x, y, v, n_loc, steps=2000, batch=32):
     """Secondary measurement (fit throughput reported separately): minibatch iterations of CausalBGM.fit at
-    the reference's batch size on the bench panel -- theta gradient + Adam + latent step (dense-decay Adam on the whole
-    [N x q] table, the Keras semantics) per iteration."""
+    the reference's batch size on the bench panel -- theta gradient + Adam + latent step per iteration.  The latent optimizer is
+    Keras' dense-decay Adam on the [N x q] table in both legs: "replay" (the classes' default: the untouched rows' zero-gradient
+    steps deferred until a row is next used, csrc/z_replay.h) and "dense" (one sweep over the table per minibatch)."""
     import torch
     eng = model.engine
     dev = eng.device
-    g = torch.Generator(device=dev).manual_seed(1)
-    z = torch.randn(n_loc, eng.q, device=dev, generator=g)
-    zm, zv = torch.zeros_like(z), torch.zeros_like(z)
-    npar = eng.fit_begin(n_loc, batch)
-    grad = torch.empty(npar, device=dev)
-    perm = torch.randperm(n_loc, device=dev, generator=g).to(torch.int32)
+    res = {}
+    for mode, lazy in (("replay", 2), ("dense", 0)):
+        g = torch.Generator(device=dev).manual_seed(1)
+        z = torch.randn(n_loc, eng.q, device=dev, generator=g)
+        zm, zv = torch.zeros_like(z), torch.zeros_like(z)
+        npar = eng.fit_begin(n_loc, batch)
+        grad = torch.empty(npar, device=dev)
+        perm = torch.randperm(n_loc, device=dev, generator=g).to(torch.int32)
 
-    def run(k):
-        for s_ in range(k):
-            i = (s_ * batch) % max(1, n_loc - batch)
-            idx = perm[i:i + batch]
-            eng.fit_theta_grad(x, y, v, z, idx, batch, grad)
-            eng.fit_theta_apply(grad, 1e-4)
-            eng.fit_z_step(x, y, v, z, zm, zv, idx, batch, 1e-4, lazy=False)
-    try:
-        run(20)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run(steps)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    finally:
-        eng.fit_end()
+        def run(k, s0):
+            for s_ in range(s0, s0 + k):
+                i = (s_ * batch) % max(1, n_loc - batch)
+                idx = perm[i:i + batch]
+                if lazy == 2:
+                    eng.fit_z_sync(z, zm, zv, idx, 1e-4)
+                eng.fit_theta_grad(x, y, v, z, idx, batch, grad)
+                eng.fit_theta_apply(grad, 1e-4)
+                eng.fit_z_step(x, y, v, z, zm, zv, idx, batch, 1e-4, lazy=lazy)
+        try:
+            run(20, 0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(steps, 20)
+            if lazy == 2:
+                eng.fit_z_sync(z, zm, zv, None, 1e-4)          # the flush a fit ends with, inside the timed region
+            torch.cuda.synchronize()
+            res[mode] = time.perf_counter() - t0
+        finally:
+            eng.fit_end()
+    dt = res["replay"]
     return {"value": batch * steps / dt, "unit": "observations x epochs / s", "us_per_minibatch": 1e6 * dt / steps,
-            "sample": f"{steps} minibatch iterations, B={batch}, N={n_loc} (dense-decay Adam on the latent table), deterministic nets",
+            "us_per_minibatch_dense_sweep": 1e6 * res["dense"] / steps,
+            "sample": f"{steps} minibatch iterations, B={batch}, N={n_loc}, deterministic nets; latent optimizer = dense-decay Adam "
+                      "in replay form (value, us_per_minibatch) and as a sweep over the table per minibatch (us_per_minibatch_dense_sweep)",
             "flop_per_observation": 348480}
 
 
@@ -171,9 +183,10 @@ def training_leg(params, x, y, v, device, n=20000, batch=32, reps=200):
     grad = torch.empty(npar, device=device)
     try:
         def step():
+            eng.fit_z_sync(z, zm, zv, idx, 1e-4)
             eng.fit_theta_grad(xs, ys, vs, z, idx, batch, grad)
             eng.fit_theta_apply(grad, 1e-4)
-            eng.fit_z_step(xs, ys, vs, z, zm, zv, idx, batch, 1e-4, lazy=False)
+            eng.fit_z_step(xs, ys, vs, z, zm, zv, idx, batch, 1e-4, lazy=2)
         f_us = timed(step)
     finally:
         eng.fit_end()
@@ -191,7 +204,10 @@ def training_leg(params, x, y, v, device, n=20000, batch=32, reps=200):
         be.egm_end()
     t_us = timed(lambda: be.theta_step(z, idx, xs, ys, vs, 1e-4, 1, 0))
     zz = z.clone()
-    l_us = timed(lambda: be.z_step(xs, ys, vs, zz, zm, zv, idx, 1e-4, 1, 1))
+    def latent():
+        be.z_sync(zz, zm, zv, idx, 1e-4)
+        be.z_step(xs, ys, vs, zz, zm, zv, idx, 1e-4, 1, 1, lazy=2)
+    l_us = timed(latent)
     out["bayesian"] = {"egm_disc_step_us": d_us, "egm_gen_step_us": g_us, "egm_iteration_ms": 1e-3 * (params["g_d_freq"] * d_us + g_us),
                        "theta_step_us": t_us, "latent_step_us": l_us}
     return out
@@ -279,6 +295,9 @@ def accuracy_leg(params, data, x_values, n_loc, args):
                          "interval_coverage": float(np.mean((interval[:, 0] <= truth) & (truth <= interval[:, 1]))),
                          "acceptance_rate": m.last_acceptance_rate, "predict_seconds": time.perf_counter() - t0}
         m.engine.set_precision("fp32")
+    out["interval_coverage_note"] = (f"the interval is the posterior interval of a MEAN over {n_loc} rows (width ~ sd/sqrt(N)): it "
+                                     "covers Monte-Carlo error of the chains, not the fit's bias, so coverage of the truth well below "
+                                     "1 - alpha is expected and is not a calibration statement")
     out["sample"] = (f"CausalBGM(use_bnn=False): fit on Sim_Hirano_Imbens N=20000 p={args.p} seed 0 (reference defaults: 30000 EGM "
                      f"iterations + 100 epochs, batch 32), predict on the bench panel N={n_loc} with burn_in={args.burn_in}, "
                      f"n_mcmc={args.n_mcmc}, {len(x_values)} doses; truth = x + 2/(1+x)^3")
@@ -482,7 +501,10 @@ def main():
             dom = max(inst, key=lambda k: k["share_of_kernel_time"])       # the dominant instance is the one reported
             roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": PEAK_FP32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": dom["frac"], "traffic": dom["traffic"], "traffic_unit": "HBM read bytes per launch",
-                    "traffic_source": traffic_src, "algorithmic_bytes_per_launch": n_loc * (4 * p + 8),
+                    "traffic_source": traffic_src,
+                    # per launch every row's x, y, v row is read once, its chain state (q floats + the cached log-posterior) read
+                    # and written back once: the same accounting as profiles/r02_pmc_traffic.json (852 B per row at p = 200, q = 10)
+                    "algorithmic_bytes_per_launch": n_loc * (4 * p + 8 + 4 * sum(z_dims) + 4),
                     "avg_launch_ms": dom["avg_launch_ms"], "launches": dom["launches"], "flop_per_launch": dom["flop_per_launch"],
                     "share_of_kernel_time": dom["share_of_kernel_time"], "instances": inst,
                     "whole_predict_achieved": sum(k["flop_per_launch"] * k["launches"] for k in inst) / (tot_ms * 1e-3) / 1e12}

@@ -236,11 +236,24 @@ int bgm_causal_fit_theta_apply(bgm_handle *h, const float *grad_dev, float lr_th
  * batch-mean negative log joint w.r.t. the batch rows of data_z and one Adam step on the latent
  * matrix.  zm/zv [n_rows x q] are the Adam slots.  lazy = 0 reproduces Keras' sparse-gradient Adam
  * (moment decay and update applied to ALL n_rows rows every step), lazy = 1 touches the batch rows
- * only.  loss_dev[6] += sum over local rows of the per-row negative log joint. */
+ * only (a different optimizer), lazy = 2 is lazy = 0 with the untouched rows' steps deferred (bgm_causal_fit_z_sync).  loss_dev[6] += sum over local rows of the per-row negative log joint. */
 int bgm_causal_fit_z_step(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev,
                           float *data_z_dev, float *zm_dev, float *zv_dev, const int32_t *idx_dev,
                           int64_t row_lo, int32_t batch, int32_t batch_global, float lr_z, int32_t lazy,
                           double *loss_dev, void *stream);
+
+/* Replay mode of the latent optimizer (lazy = 2 in bgm_causal_fit_z_step): the same dense-decay Adam as lazy = 0, with the
+ * zero-gradient steps of the rows outside a minibatch deferred until the row is next used.  For such a row a step is m <- b1 m,
+ * v <- b2 v, z <- z - lr_t m / (sqrt(v) + eps): k pending steps are two powers and a geometric-like series of which 256 terms are
+ * summed (the rest is < 1e-11 of the first), so a minibatch costs O(batch) instead of a sweep over the [n_rows x q] table, and the
+ * table differs from the lazy = 0 one by fp32 rounding of the series only (tests/test_gpu_fit.py states the bound).
+ *   idx_dev != NULL: bring the `batch` listed rows up to date.  Call it on a minibatch's rows BEFORE bgm_causal_fit_theta_grad
+ *                    (which reads them) and bgm_causal_fit_z_step(lazy = 2), which refuses to run otherwise.
+ *   idx_dev == NULL: flush -- bring every row up to date (before evaluate / predict / a checkpoint / reading data_z, and before
+ *                    switching to another lazy mode).
+ * lr_z is the (constant) learning rate of the latent optimizer (causalbgm/base.py:93). */
+int bgm_causal_fit_z_sync(bgm_handle *h, float *data_z_dev, float *zm_dev, float *zv_dev, const int32_t *idx_dev, int32_t batch,
+                          float lr_z, void *stream);
 
 /* Copy the device parameters of one network back to the host (Keras order) and make them the
  * handle's host copy.  Synchronous. */
@@ -470,12 +483,16 @@ int bgm_bnn_grad_exchange(bgm_handle *h, float *buf_dev, int32_t to_session, voi
 int bgm_bnn_theta_apply(bgm_handle *h, float lr_theta, void *stream);
 /* replaces: update_latent_variable_sgd with use_bnn, base.py:246-302 (every net called twice with independent noise:
  * streams stream_id and stream_id + 1) + the Adam step on the latent table (zm_dev, zv_dev: its slots, [n_rows x q];
- * lazy = 0: Keras dense-decay semantics, every row of the table moves; lazy = 1: batch rows only).
- * out_dev: [loss_postrior_z] or NULL. */
+ * lazy = 0: Keras dense-decay semantics, every row of the table moves; lazy = 1: batch rows only; lazy = 2: lazy = 0 with the
+ * untouched rows' steps deferred, see bgm_bnn_z_sync).  out_dev: [loss_postrior_z] or NULL. */
 int bgm_bnn_z_step(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev, float *data_z_dev,
                    float *zm_dev, float *zv_dev, const int32_t *idx_dev, int64_t n_rows, int32_t batch,
                    int32_t batch_global, float lr_z, int32_t lazy, uint64_t seed, uint32_t stream_id, float *out_dev,
                    float *dz_out_dev, void *stream);
+/* Replay mode of the latent optimizer with Bayesian nets; semantics and call order as bgm_causal_fit_z_sync (idx_dev rows before the
+ * minibatch's bgm_bnn_theta_step calls; idx_dev = NULL flushes the whole [n_rows x q] table). */
+int bgm_bnn_z_sync(bgm_handle *h, float *data_z_dev, float *zm_dev, float *zv_dev, const int32_t *idx_dev, int64_t n_rows,
+                   int32_t batch, float lr_z, void *stream);
 int bgm_bnn_end(bgm_handle *h, void *stream);
 
 /* ---- EGM warm start with Bayesian nets (train_disc_step :305-330, train_gen_step :332-377 with use_bnn): a sub-session of

@@ -346,17 +346,24 @@ def test_bgm_wide_panel_properties():
     assert torch.equal(a1, a3 + a4 + a5)                           # per-iteration acceptance counts add up over blocks
     idx = np.sort(rs.choice(n, 24, replace=False))
     obs, clean = OB.obs_mask_of(x[idx])
-    ref = []
+    ref, fragile = [], np.zeros(len(idx), bool)
+    m64 = OB.cast_model(m, np.float64)
     for k, i in enumerate(idx):                       # fixed step size (hmc_run does not adapt): oracle transitions directly
-        xk, mk = clean[k:k + 1], obs[k:k + 1].astype(np.float32)
-        z = OB.hmc_init_state(1, q, 9, int(i)).astype(np.float32)
-        lp, gr = OB.log_posterior_and_grad(m, z, xk, mk)
+        xk, mk = clean[k:k + 1].astype(np.float64), obs[k:k + 1].astype(np.float64)
+        z = OB.hmc_init_state(1, q, 9, int(i)).astype(np.float64)
+        lp, gr = OB.log_posterior_and_grad(m64, z, xk, mk)
         for it in range(burn + keep):
-            z, lp, gr, _, _ = OB.hmc_transition(m, z, xk, mk, 0.02, L, it, 9, int(i), lp, gr)
+            u = OB.R.uniforms(np.array([int(i)]), it, OB.R.TAG_HACC, 9)
+            z, lp, gr, lr, _ = OB.hmc_transition(m64, z, xk, mk, 0.02, L, it, 9, int(i), lp, gr)
+            fragile[k] |= bool(abs(np.log(u[0]) - lr[0]) < 5e-3)    # accept decision within fp32 rounding of the energy difference
         ref.append(z[0])
     ref = np.stack(ref)
     got = s1.cpu().numpy()[idx]
-    assert np.all(np.abs(got - ref) <= 2e-3, axis=1).mean() >= 0.9
+    # a chain is a deterministic function of its Philox streams except at the accept decisions: every sampled row whose decisions
+    # all had a margin matches the float64 oracle to fp32 rounding through 9 transitions x 5 leapfrog steps of p = 500 residuals
+    ok = ~fragile
+    assert ok.sum() >= 20, fragile
+    assert np.abs(got[ok] - ref[ok]).max() <= 5e-4, np.abs(got[ok] - ref[ok]).max(axis=1)
 
 
 def test_bgm_fit_global_batch_scaling_and_two_rank_run(tmp_path):

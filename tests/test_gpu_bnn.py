@@ -150,6 +150,38 @@ def test_steps_apply_adam_like_oracle(p):
     eng.close()
 
 
+def test_replayed_latent_adam_equals_the_dense_sweep():
+    """bgm_bnn_z_sync + lazy = 2 against lazy = 0 over 120 minibatches of a 1024-row table with the same noise streams: the tables
+    differ by the fp32 rounding of the deferred zero-gradient steps only (bound as in test_gpu_fit.py)."""
+    m = _model(False, p=100, fixed=True)
+    n, B, steps = 1024, 32, 120
+    z, x, y, v = _panel(m, n)
+    rs = np.random.RandomState(4)
+    order = [rs.choice(n, B, replace=False).astype(np.int32) for _ in range(steps)]
+    out = {}
+    for mode in (0, 2):
+        eng = _engine(m, norm_mode=1)
+        dev = eng.device
+        T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        zt, zm, zv = T(z), torch.zeros(n, z.shape[1], device=dev), torch.zeros(n, z.shape[1], device=dev)
+        xs, ys, vs = T(x[:, 0]), T(y[:, 0]), T(v)
+        for it, idx in enumerate(order):
+            if mode == 2:
+                eng.z_sync(zt, zm, zv, T(idx), 1e-3)
+            eng.theta_step(zt, T(idx), xs, ys, vs, 1e-3, 7, 4 * it, apply=True)
+            eng.z_step(xs, ys, vs, zt, zm, zv, T(idx), 1e-3, 7, 4 * it + 1, lazy=mode)
+        if mode == 2:
+            with pytest.raises(RuntimeError, match="z_sync"):
+                eng.z_step(xs, ys, vs, zt, zm, zv, T(idx), 1e-3, 7, 1, lazy=2)
+            eng.z_sync(zt, zm, zv, None, 1e-3)
+        out[mode] = (zt.cpu().numpy(), zm.cpu().numpy(), zv.cpu().numpy())
+        eng.close()
+    (z0, m0, v0), (z2, m2, v2) = out[0], out[2]
+    assert np.abs(z0 - z).max() > 1e-3
+    assert np.abs(z2 - z0).max() <= 1.5e-6, np.abs(z2 - z0).max()
+    assert np.abs(m2 - m0).max() <= 2e-5 * np.abs(m0).max() and np.abs(v2 - v0).max() <= 2e-5 * np.abs(v0).max()
+
+
 @pytest.mark.parametrize("binary,p,z_dims,n,bs", [
     (False, 200, (1, 1, 1, 7), 700, 300),      # ragged last block, several workgroups per block
     (True, 100, (3, 3, 6, 6), 520, 520),

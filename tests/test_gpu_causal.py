@@ -269,6 +269,48 @@ def test_full_size_panel_properties():
     assert np.abs(small["adrf"].cpu().numpy() - ref_adrf).max() <= 5e-4
 
 
+def test_binary_treatment_full_size_panel_properties():
+    """BASELINE.json configs[1] at full size (binary treatment, N = 1e5 rows, p = 100, z_dims [3,3,6,6] = the reference CLI's
+    defaults, src/main.py) through size-independent properties: determinism; sharding invariance of states, cached log-posteriors
+    and per-row ITE draws for a ragged block; the float64 oracle chain on a sample of rows; the per-row ITE of a block and its
+    row quantiles against the oracle's effects on the same draws."""
+    import torch
+    from bayesgm_amd import _lib
+    n, p, burn, keep, seed = 100_000, 100, 8, 16, 7
+    zd = [3, 3, 6, 6]
+    m = _model(73, zd, p, binary=True)
+    x, y, v = _data(n, p, 74, binary=True)
+    eng = _engine(m)
+    xd, yd, vd = (torch.from_numpy(a).cuda() for a in (x.reshape(-1), y.reshape(-1), v))
+
+    def run(lo, hi, want_draws=False):
+        return eng.mh_sample(xd[lo:hi], yd[lo:hi], vd[lo:hi], burn, keep, 0.5, seed, want_draws=want_draws, row_base=lo,
+                             effect=_lib.EFFECT_ITE, sample_y=True)
+    a = run(0, n)
+    b = run(0, n)
+    assert torch.equal(a["state"], b["state"]) and torch.equal(a["logp"], b["logp"]) and torch.equal(a["ite"], b["ite"])
+    lo, hi = 34_560, 34_560 + 7_001
+    part = run(lo, hi, want_draws=True)
+    assert torch.equal(a["state"][lo:hi], part["state"]) and torch.equal(a["logp"][lo:hi], part["logp"])
+    assert torch.equal(a["ite"][lo:hi], part["ite"])
+    acc_rate = float(a["acc_count"].sum().item()) / (n * (burn + keep))
+    assert 0.0 < acc_rate < 1.0
+    idx = np.sort(np.random.RandomState(75).choice(n, 40, replace=False))
+    got = a["state"].cpu().numpy()[idx]
+    ref = np.stack([OC.mh_sampler(m, (x[i:i + 1], y[i:i + 1], v[i:i + 1]), burn, keep, 0.5, seed, row0=int(i))[-1, 0] for i in idx])
+    assert np.all(np.abs(got - ref) <= 1e-4, axis=1).mean() >= 0.95
+    draws = part["draws"].cpu().numpy()[:, :96]
+    ref_ite = OC.infer_from_latent_posterior(OC.cast_model(m, np.float64), draws.astype(np.float64), None, True, seed, row0=lo,
+                                             burn_in=burn)                                                  # [keep, 96]
+    ite = part["ite"].cpu().numpy()[:96]
+    assert np.abs(ite.T - ref_ite).max() <= 2e-4
+    mean, ql, qh = eng.row_mean_quantiles(a["ite"], 0.005, 0.995)
+    full = a["ite"].cpu().numpy()
+    assert np.allclose(mean.cpu().numpy(), full.mean(axis=1), atol=1e-6)
+    assert np.allclose(ql.cpu().numpy(), np.quantile(full, 0.005, axis=1), atol=1e-6)
+    assert np.allclose(qh.cpu().numpy(), np.quantile(full, 0.995, axis=1), atol=1e-6)
+
+
 @pytest.mark.parametrize("binary", [False, True])
 def test_standalone_effects_from_draws_match_oracle_and_the_fused_pass(binary):
     """infer_from_latent_posterior on a given draw tensor (bgm_causal_effects): equals the oracle on the same draws and
