@@ -524,17 +524,25 @@ extern "C" int bgm_causal_fit_z_step(bgm_handle *h, const float *x, const float 
   ka.m = h->meta; ka.bm = h->fit_meta; ka.ws = h->fit_ws; ka.wsp = h->ws_dev;
   ka.x = x; ka.y = y; ka.v = v; ka.data_z = data_z; ka.idx = idx; ka.row_lo = row_lo; ka.B = batch;
   ka.inv_B = 1.0f / (float)batch_global; ka.z_mode = 1; ka.loss = loss;
-  bool pos_set = false;
+  bool pos_set = false, adam_fused = false;
   if (FitChainState *fc = static_cast<FitChainState *>(h->fit_chain); fc && batch <= 32) {
     FitChainArgs ca = fc->base;
     ca.x = x; ca.y = y; ca.v = v; ca.data_z = data_z; ca.idx = idx; ca.row_lo = row_lo; ca.inv_B = ka.inv_B;
     ca.loss = loss; ca.dz = h->ws_dev + h->fit_ws.dz;
     if (!lazy) { ca.pos = h->pos_dev; ca.pos_n = h->fit_rows; ca.epoch = (int)((h->t_z + 1) & 0x3FFFFFFF); pos_set = true; }
+    else {                      // the batch rows' Adam step rides on the chain kernel's epilogue
+      const double t1 = (double)(h->t_z + 1);
+      ca.zm = zm; ca.zv = zv; ca.z_out = data_z; ca.t_last = lazy == 2 ? h->tlast_dev : nullptr; ca.t_now = (int)(h->t_z + 1);
+      ca.lr_t = (float)((double)lr_z * std::sqrt(1.0 - std::pow((double)ADAM_B2, t1)) / (1.0 - std::pow((double)ADAM_B1, t1)));
+      ca.b1 = ADAM_B1; ca.b2 = ADAM_B2; ca.eps = ADAM_EPS;
+      adam_fused = true;
+    }
     fit_chain_launch(fc, ca, batch, 1, stream);
     rc = BGM_OK;
   } else rc = launch_fwd_bwd(h, ka, stream);
   if (rc) return rc;
   h->t_z += 1;
+  if (adam_fused) { BGM_HIP_CHECK(hipGetLastError()); return BGM_OK; }
   const double t = (double)h->t_z;
   const float lr_t = (float)((double)lr_z * std::sqrt(1.0 - std::pow((double)ADAM_B2, t)) / (1.0 - std::pow((double)ADAM_B1, t)));
   const int q = h->q;

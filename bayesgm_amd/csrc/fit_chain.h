@@ -28,6 +28,8 @@ struct FitChainArgs {
   double *loss;                   // [7] accumulators or NULL
   float *dz;                      // latent phase: [B x q]
   int *pos; long long pos_n; int epoch;      // latent phase, dense Adam on Z: batch position / step stamp of the minibatch rows (fit_set_pos_kernel's job)
+  float *zm, *zv; float *z_out; int *t_last; int t_now; float lr_t, b1, b2, eps;   // latent phase, zm != NULL: the Adam step on the
+                                  // minibatch rows is applied here (lazy = 1 / 2; t_last != NULL marks the rows current to step t_now)
   int n_warm;                     // floats of theta (= of the transposed mirror) the idle wave pair pulls into this XCD's L2
   int n_valid;                    // rows of the minibatch (<= 16 NB): the tile rows behind them are masked -- they read row n_valid - 1,
                                   // contribute zero loss and zero output gradients, hence nothing to any parameter gradient
@@ -197,6 +199,13 @@ static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_kernel(FitChainA
       if (col < z0) v += dzc[(2 * 32 + b) * ZW + col];                                       // h: (z0, z2)
       else if (col >= z0 + z1 && col < z0 + z1 + z2) v += dzc[(2 * 32 + b) * ZW + col - z1];
       a.dz[i] = v;
+      if (a.zm) {                                            // fit_adam_z_kernel's batch-rows form, fused
+        const long long e = fitc_row(a, b) * q + col;
+        const float m_ = a.b1 * a.zm[e] + (1.0f - a.b1) * v, v_ = a.b2 * a.zv[e] + (1.0f - a.b2) * v * v;
+        a.zm[e] = m_; a.zv[e] = v_;
+        a.z_out[e] -= a.lr_t * m_ / (sqrtf(v_) + a.eps);
+        if (a.t_last && col == 0) a.t_last[fitc_row(a, b)] = a.t_now;
+      }
     }
   }
   FITC_T(10);

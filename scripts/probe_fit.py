@@ -1,10 +1,10 @@
-"""Fit-step throughput probe (dev tool): python scripts/probe_fit.py N B [lazy] [steps]"""
+"""Fit-step throughput probe (dev tool): python scripts/probe_fit.py N B [dense|lazy|replay] [steps]"""
 import sys, time
 import numpy as np, torch
 import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from bayesgm_amd.engine import CausalEngine
 from oracle import causal as OC
-N = int(float(sys.argv[1])); B = int(float(sys.argv[2])); lazy = len(sys.argv) > 3 and sys.argv[3] == "lazy"
+N = int(float(sys.argv[1])); B = int(float(sys.argv[2])); lazy = {"dense": 0, "lazy": 1, "replay": 2}[sys.argv[3]] if len(sys.argv) > 3 else 0
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 200
 z_dims, p = [1, 1, 1, 7], 200
 m = OC.init_model(0, z_dims, p)
@@ -18,6 +18,8 @@ def run(k):
     for s in range(k):
         i = (s * B) % max(1, N - B)
         idx = perm[i:i + B]
+        if lazy == 2:
+            eng.fit_z_sync(z, zm, zv, idx, 1e-4)
         eng.fit_theta_grad(x, y, v, z, idx, B, grad); eng.fit_theta_apply(grad, 1e-4)
         eng.fit_z_step(x, y, v, z, zm, zv, idx, B, 1e-4, lazy=lazy)
 run(5); torch.cuda.synchronize(); t0 = time.time(); run(steps); torch.cuda.synchronize(); dt = time.time() - t0
