@@ -132,12 +132,16 @@ extern "C" int bgm_causal_encode(bgm_handle *h, const float *v, int64_t n, float
 // ---------------------------------------------------------------------------
 // ADRF slot reduction (fixed summation order -> deterministic)
 // ---------------------------------------------------------------------------
-__global__ void adrf_reduce_kernel(const float *partial, int n_slots, long long kd, double inv_n, float *out) {
+// partial [n_slots][n_keep][n_doses] (draw-major, as the sampling kernels accumulate it) -> out [n_doses][n_keep] (the reference's
+// orientation of the dose-response draws, base.py:660)
+__global__ void adrf_reduce_kernel(const float *partial, int n_slots, long long kd, int n_doses, int n_keep, double inv_n, float *out) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= kd) return;
   double s = 0.0;
   for (int sl = 0; sl < n_slots; ++sl) s += (double)partial[(long long)sl * kd + i];
-  out[i] = (float)(s * inv_n);
+  const long long d = i / n_doses;
+  const int k = (int)(i - d * n_doses);
+  out[(long long)k * n_keep + d] = (float)(s * inv_n);
 }
 
 extern "C" int bgm_adrf_reduce(bgm_handle *h, const float *partial, int32_t n_slots, int32_t n_doses,
@@ -148,7 +152,7 @@ extern "C" int bgm_adrf_reduce(bgm_handle *h, const float *partial, int32_t n_sl
   BGM_HIP_CHECK(hipSetDevice(h->device));
   const long long kd = (long long)n_doses * n_keep;
   hipLaunchKernelGGL(adrf_reduce_kernel, dim3((unsigned)((kd + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
-                     partial, n_slots, kd, 1.0 / n_total, out);
+                     partial, n_slots, kd, n_doses, n_keep, 1.0 / n_total, out);
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
 }

@@ -167,9 +167,22 @@ extern "C" int bgm_bgm_hmc_run(bgm_handle *h, const bgm_hmc_args *a, void *strea
   ka.acc_prob_sum = a->acc_prob_sum_dev; ka.acc_count = a->acc_count_dev; ka.draws = a->draws_dev; ka.m = s->meta;
   const int lds = s->lds_bytes;
   const long long tiles = (a->n + 15) / 16;
-#define X(KTQ_, NTX_, NH_)                                                                                          \
-  if (s->KTQ == KTQ_ && s->NTX == NTX_ && s->NH == NH_) {                                                           \
-    constexpr int W = (NTX_ == 0) ? BGM_WAVES_WIDE_HMC : BGM_WAVES;                                                 \
+  // The wide variant's unit of work is a block pass (W row tiles x all iterations of the launch) and every block makes the same
+  // number of passes, so the last round of passes can be nearly empty (12 500 tiles at W = 12: 4.07 rounds run as 5 = 81 %).  A
+  // round costs what the busiest SIMD's waves cost, so only whole waves per SIMD are worth compiling: 12 (3 per SIMD, the fastest
+  // per tile by ~4 %) and 8 (2 per SIMD); take the one that wastes less of its last round.
+  auto wide_waves = [&](void) {
+    int best = BGM_WAVES_WIDE_HMC; double best_eff = 0.0;
+    for (int w : {12, 8}) {
+      const long long per_round = (long long)w * h->n_cus, rounds = (tiles + per_round - 1) / per_round;
+      const double eff = (double)tiles / (double)(rounds * per_round) * (w == 12 ? 1.0 : 0.96);
+      if (eff > best_eff + 1e-9) { best_eff = eff; best = w; }
+    }
+    return best;
+  };
+  const int ww = wide_waves();
+#define LAUNCH_HMC(KTQ_, NTX_, NH_, W)                                                                              \
+  {                                                                                                                 \
     const int grid = (int)std::max<long long>(1, std::min<long long>((tiles + W - 1) / W, h->n_cus));               \
     auto k = bgm_hmc_kernel<KTQ_, NTX_, NH_, W>;                                                                    \
     BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
@@ -177,8 +190,16 @@ extern "C" int bgm_bgm_hmc_run(bgm_handle *h, const bgm_hmc_args *a, void *strea
     BGM_HIP_CHECK(hipGetLastError());                                                                               \
     return BGM_OK;                                                                                                  \
   }
+#define X(KTQ_, NTX_, NH_)                                                                                          \
+  if (s->KTQ == KTQ_ && s->NTX == NTX_ && s->NH == NH_) {                                                           \
+    if constexpr (NTX_ == 0) {                                                                                      \
+      if (ww == 8) LAUNCH_HMC(KTQ_, NTX_, NH_, 8)                                                                   \
+      LAUNCH_HMC(KTQ_, NTX_, NH_, BGM_WAVES_WIDE_HMC)                                                               \
+    } else LAUNCH_HMC(KTQ_, NTX_, NH_, BGM_WAVES)                                                                   \
+  }
   BGM_BGM_VARIANTS(X)
 #undef X
+#undef LAUNCH_HMC
   BGM_NO_VARIANT(s)
 }
 

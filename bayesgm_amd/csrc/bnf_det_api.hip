@@ -207,10 +207,10 @@ int bnf_det_effects(bgm_handle *h, const float *draws, int64_t n, int64_t row_ba
   const int q = h->q;
   for (int d = 0; d < n_keep; ++d) {
     const float *z = draws + (long long)d * n * q;
-    // adrf_partial [n_slots][n_doses][n_keep]; ite [n][n_keep]
+    // adrf_partial [n_slots][n_keep][n_doses]; ite [n][n_keep]
     rc = binary ? launch_effects(h, st, z, n, row_base, 2, st->pair_dev, seed, (uint32_t)(burn_in + d), sample_y, nullptr, 0, 0, ite + d, n_keep, stream)
-                : launch_effects(h, st, z, n, row_base, nd, x_values, seed, (uint32_t)(burn_in + d), sample_y, adrf_partial + d,
-                                 (long long)nd * n_keep, n_keep, nullptr, 0, stream);
+                : launch_effects(h, st, z, n, row_base, nd, x_values, seed, (uint32_t)(burn_in + d), sample_y, adrf_partial + (long long)d * nd,
+                                 (long long)nd * n_keep, 1, nullptr, 0, stream);
     if (rc) return rc;
   }
   return BGM_OK;
@@ -244,7 +244,7 @@ int bnf_det_mh_run(bgm_handle *h, const bgm_mh_args *g, hipStream_t stream) {
         BGM_HIP_CHECK(hipMemcpyAsync(g->draws_dev + (long long)d * n * q, g->state_dev, sizeof(float) * n * q, hipMemcpyDeviceToDevice, stream));
       if (g->effect == BGM_EFFECT_ADRF)
         rc = launch_effects(h, st, g->state_dev, n, g->row_base, n_doses, g->x_values_dev, g->seed, (uint32_t)it, g->sample_y,
-                            g->adrf_partial_dev + d, (long long)n_doses * g->n_keep, g->n_keep, nullptr, 0, stream);
+                            g->adrf_partial_dev + (long long)d * n_doses, (long long)n_doses * g->n_keep, 1, nullptr, 0, stream);
       else if (g->effect == BGM_EFFECT_ITE)
         rc = launch_effects(h, st, g->state_dev, n, g->row_base, 2, st->pair_dev, g->seed, (uint32_t)it, g->sample_y, nullptr, 0, 0,
                             g->ite_dev + d, g->n_keep, stream);

@@ -437,7 +437,8 @@ __global__ __launch_bounds__(64 * WAVES) void causal_logpost_kernel(const float 
 // ---------------------------------------------------------------------------
 // infer_from_latent_posterior (base.py:671-763) for the R x 16 states held by one wave:
 // f first layer once at x = 0, doses as rank-1 updates, DB doses per pass.
-//   EFFECT 1: adrf_slot[k * n_keep + d] += sum over the wave's valid rows of y_k
+//   EFFECT 1: adrf_slot[d * n_doses + k] += sum over the wave's valid rows of y_k   (draw-major: the doses of a retained draw share one
+//             or two cache lines, so the 4-lane atomics of its passes are one L2 line instead of one line per dose)
 //   EFFECT 2: ite[row * n_keep + d] = y(x=1) - y(x=0)
 // Sampling-blob layout of the two small nets' tails (causal_scale_blob_kernel): the 8 outputs of layer 3 sit at tile positions
 // 4 (f >> 1) + (f & 1) -- accumulator registers r = 0, 1 of every lane group -- so layer 4 contracts over two K-steps instead of
@@ -581,7 +582,7 @@ __device__ __forceinline__ void causal_effects(const float *lds, const CausalMet
       float y = sample_y ? fmaf(__builtin_sqrtf(s2), noise, mu_m) : mu_m;
       y = (valid[0] && k < nd) ? y : 0.0f;
       const float tot = sum_over_j_to_lane15(y);
-      if (j == 15 && k < nd) unsafeAtomicAdd(adrf_slot + (long long)k * n_keep + d, tot);
+      if (j == 15 && k < nd) unsafeAtomicAdd(adrf_slot + d * nd + k, tot);
       continue;
     }
     float yk[DB][R];
@@ -600,7 +601,7 @@ __device__ __forceinline__ void causal_effects(const float *lds, const CausalMet
         for (int rr = 0; rr < R; ++rr) tot += valid[rr] ? yk[e][rr] : 0.0f;
         tot = sum_over_j_to_lane15(tot);  // values are valid in lane group 0 -> lane 15
         const int k = 4 * kb + e;
-        if (lane == 15 && k < nd) unsafeAtomicAdd(adrf_slot + (long long)k * n_keep + d, tot);
+        if (lane == 15 && k < nd) unsafeAtomicAdd(adrf_slot + d * nd + k, tot);
       }
     } else {
 #pragma unroll
@@ -903,7 +904,7 @@ struct CausalEffKArgs {
   long long n, row_base;
   int n_keep, burn_in, sample_y, n_doses;
   const float *x_values;
-  float *adrf_partial;   // [n_slots][n_doses][n_keep]
+  float *adrf_partial;   // [n_slots][n_keep][n_doses]
   float *ite;            // [n][n_keep]
   unsigned k0, k1;
   CausalMeta m;

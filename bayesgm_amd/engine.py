@@ -206,7 +206,7 @@ class CausalEngine(object):
         xv = _f32(np.atleast_1d(np.asarray(x_values, dtype=np.float32)), self.device)
         ns = C.c_int32()
         _lib.check(self.lib.bgm_causal_evaluate_slots(self.h, n, C.byref(ns)), "bgm_causal_evaluate_slots")
-        partial = torch.zeros((ns.value, xv.numel(), n_keep), device=self.device, dtype=torch.float32)
+        partial = torch.zeros((ns.value, n_keep, xv.numel()), device=self.device, dtype=torch.float32)
         _lib.check(self.lib.bgm_causal_effects(self.h, _ptr(x), _ptr(draws), n, int(row_base), n_keep, int(burn_in), seed,
                                                int(bool(sample_y)), _ptr(xv), xv.numel(), _ptr(partial), None, self._stream()),
                    "bgm_causal_effects")
@@ -364,7 +364,7 @@ class CausalEngine(object):
         n_slots = self.mh_slots(n)
         if effect == _lib.EFFECT_ADRF:
             xv = _f32(np.atleast_1d(np.asarray(x_values, dtype=np.float32)), dev)
-            partial = torch.zeros((n_slots, xv.numel(), n_keep), device=dev, dtype=torch.float32)
+            partial = torch.zeros((n_slots, n_keep, xv.numel()), device=dev, dtype=torch.float32)
         elif effect == _lib.EFFECT_ITE:
             ite = torch.empty((n, n_keep), device=dev, dtype=torch.float32)
         if adaptive:

@@ -134,7 +134,7 @@ typedef struct {
   int32_t sample_y;                   /* base.py:703,752                      */
   const float *x_values_dev;          /* [n_doses] (ADRF)                     */
   int32_t n_doses;
-  float *adrf_partial_dev;            /* ADRF: [n_slots x n_doses x n_keep]
+  float *adrf_partial_dev;            /* ADRF: [n_slots x n_keep x n_doses]
                                          per-wave-slot sums over rows (+=);
                                          n_slots from bgm_causal_mh_slots()   */
   float *ite_dev;                     /* ITE: [n x n_keep] draws, row-major
@@ -149,7 +149,8 @@ int bgm_causal_mh_slots(bgm_handle *h, int64_t n, int32_t *n_slots);
 
 int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *args, void *stream);
 
-/* out[k][d] = sum_s partial[s][k][d] / n_total  (fixed order => deterministic).
+/* out[k][d] = sum_s partial[s][d][k] / n_total  (fixed order => deterministic; the slots are draw-major -- a retained draw's doses
+ * share a cache line in the sampling kernels' accumulation -- the result has the reference's [n_doses x n_keep] orientation).
  * replaces: adrf_draw_sums / n_seen, causalbgm/base.py:660-663. */
 int bgm_adrf_reduce(bgm_handle *h, const float *partial_dev, int32_t n_slots, int32_t n_doses,
                     int32_t n_keep, double n_total, float *out_dev, void *stream);
@@ -192,7 +193,7 @@ int bgm_causal_evaluate_slots(bgm_handle *h, int64_t n, int32_t *n_slots);
 /* replaces: CausalBGM.infer_from_latent_posterior, causalbgm/base.py:671-763, on a given tensor of posterior draws
  * draws_dev [n_keep x n x q] (the pass fused into bgm_causal_mh_run computes the same numbers from the same draws:
  * outcome noise of draw d = Philox(row_base + row, burn_in + d, dose block)).  binary -> ite_dev [n x n_keep];
- * continuous -> adrf_partial_dev [n_slots x n_doses x n_keep] (+=; n_slots = bgm_causal_evaluate_slots; reduce with
+ * continuous -> adrf_partial_dev [n_slots x n_keep x n_doses] (+=; n_slots = bgm_causal_evaluate_slots; reduce with
  * bgm_adrf_reduce). */
 int bgm_causal_effects(bgm_handle *h, const float *x_dev, const float *draws_dev, int64_t n, int64_t row_base,
                        int32_t n_keep, int32_t burn_in, uint64_t seed, int32_t sample_y, const float *x_values_dev,

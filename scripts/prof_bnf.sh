@@ -1,6 +1,8 @@
 #!/bin/bash
 # rocprofv3 evidence for the fixed-normalisation Bayesian-network sampling kernels (bnf_*), run on the GPU box from the repo root.
-# usage: bash scripts/prof_bnf.sh <tag> [kt] [sq] [mem]     environment (BGM_BNF_CFG, ...) is inherited by the probe
+# usage: bash scripts/prof_bnf.sh <tag> [kt] [sq] [sq2] [mem]     environment (BGM_BNF_CFG, ...) is inherited by the probe
+# PROF_CMD="..." profiles another command with the same passes (wide HMC: "python scripts/probe_bgm_wide.py 196608 5"; the
+# deterministic sampler's keep phase: "python scripts/probe_mh.py 1e6 40 40")
 set -u
 TAG=${1:-bnf}; shift
 WHAT="${*:-kt sq}"
@@ -9,7 +11,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 SQ="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY"
 SQ2="SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM"
-CMD="env BNN_PROBE_SAMPLING_ONLY=1 python scripts/probe_bnn.py 1000000 200 5"
+CMD=${PROF_CMD:-"env BNN_PROBE_SAMPLING_ONLY=1 python scripts/probe_bnn.py 1000000 200 5"}
 summ() { for db in $(find $1 -name "*_results.db" 2>/dev/null); do python scripts/prof_summary.py $db; done; }
 for w in $WHAT; do
   case $w in
@@ -25,3 +27,5 @@ for w in $WHAT; do
          { echo "# --pmc FETCH_SIZE GRBM_GUI_ACTIVE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum -- $CMD"; summ $OUT/${TAG}_fetch; summ $OUT/${TAG}_write; summ $OUT/${TAG}_tcc; } > $OUT/r03_pmc_mem_${TAG}.txt ;;
   esac
 done
+# the raw rocprofv3 databases are tens of MB each and gpurun carries at most 64 MiB back: keep the summaries and logs only
+find $OUT -mindepth 1 -maxdepth 1 -type d -name "${TAG}_*" -exec rm -rf {} +
