@@ -125,6 +125,7 @@ SYMBOLS = {
     "bgm_causal_fit_theta_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     "bgm_causal_fit_z_step": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_int32, C.c_float,
                                         C.c_int32, C.c_void_p, C.c_void_p]),
+    "bgm_causal_describe": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32]),
     "bgm_causal_fit_z_sync": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p]),
     "bgm_causal_get_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "bgm_causal_fit_z_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -2,6 +2,8 @@
 // (declared in include/bgm_hip.h) + host-side packing of the Keras-order weights
 // into the LDS fragment order of causal_kernels.h.
 #include <algorithm>
+#include <string>
+#include <cstdio>
 #include <cmath>
 #include <cstring>
 
@@ -559,6 +561,20 @@ extern "C" int bgm_timing_read(bgm_handle *h, int kind, int64_t *n_launches, dou
   if (n_launches) *n_launches = n;
   if (total_ms) *total_ms = ms;
   if (reset) for (int k = 0; k < 3; ++k) if (kind < 0 || kind == k) { h->timed_launches[k] = 0; h->timed_ms[k] = 0.0; }
+  return BGM_OK;
+}
+
+extern "C" int bgm_causal_describe(bgm_handle *h, int32_t batch, char *out, int32_t cap) {
+  if (!h || !h->configured || !out || cap < 1) { bgm_set_error("bgm_causal_describe: bad argument"); return BGM_E_INVALID; }
+  std::string s = "sampler=";
+  s += bnf_det_wanted(h) ? "bnf_mh_kernel<DET> / bnf_effects_kernel<DET> (general shapes: persistent workgroups, weights streamed from L2)"
+                         : "causal_mh_kernel (weights LDS-resident, one launch per rank shard)";
+  if (h->fit_active) {
+    s += "; fit=";
+    if (h->fit_chain && batch <= 32) s += "fit_chain_kernel (register-chained row tiles, rows masked to the " + std::to_string(batch) + "-row local minibatch)";
+    else s += "fit_fwd_kernel / fit_bwd_kernel / fit_dw_kernel (LDS-blob phase kernels)";
+  }
+  std::snprintf(out, (size_t)cap, "%s", s.c_str());
   return BGM_OK;
 }
 

@@ -238,6 +238,12 @@ class CausalEngine(object):
                                                   int(lazy), _ptr(loss), self._stream()),
                    "bgm_causal_fit_z_step")
 
+    def describe(self, batch=32):
+        """Kernel paths of this handle (sampling; minibatch steps when a fit session is open) as text."""
+        buf = C.create_string_buffer(512)
+        _lib.check(self.lib.bgm_causal_describe(self.h, int(batch), buf, 512), "bgm_causal_describe")
+        return buf.value.decode()
+
     def fit_z_sync(self, data_z, zm, zv, idx, lr_z):
         """Replay mode: bring the rows idx (None = every row) of the latent table and its Adam slots up to the current step."""
         _lib.check(self.lib.bgm_causal_fit_z_sync(self.h, _ptr(data_z), _ptr(zm), _ptr(zv), _ptr(idx), 0 if idx is None else int(idx.numel()),

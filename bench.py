@@ -40,12 +40,25 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 
 
-def make_panel(n, p, seed, device):
+def plan_rows(n, world, rank, scaling):
+    """(rows of this rank, first global row of this rank, rows of the whole job).  weak: every rank its own panel of n rows;
+    strong (BASELINE configs[3]: ONE N-row panel over all GPUs): the contiguous share bayesgm_amd.parallel.shard_range gives the rank."""
+    n = int(n)
+    if scaling == "strong":
+        base, rem = divmod(n, world)
+        lo = rank * base + min(rank, rem)
+        return base + (1 if rank < rem else 0), lo, n
+    return n, rank * n, n * world
+
+
+def make_panel(n, p, seed, device, lo=0, n_gen=None):
     """Hirano-Imbens panel, generated per rank on the host with the reference's generator
     restatement (bayesgm_amd.datasets, pinned by tests/golden) and moved to HBM."""
     import torch
     from bayesgm_amd.datasets import Sim_Hirano_Imbens_sampler
-    x, y, v = Sim_Hirano_Imbens_sampler(N=n, v_dim=p, seed=seed).load_all()
+    x, y, v = Sim_Hirano_Imbens_sampler(N=n if n_gen is None else n_gen, v_dim=p, seed=seed).load_all()
+    if n_gen is not None:          # strong scaling: rows [lo, lo + n) of the one n_gen-row panel every rank generates identically
+        x, y, v = (np.ascontiguousarray(a[lo:lo + n]) for a in (x, y, v))
     return (torch.from_numpy(x).to(device), torch.from_numpy(y).to(device), torch.from_numpy(v).to(device))
 
 
@@ -391,10 +404,7 @@ def main():
     from bayesgm_amd import parallel
 
     p = args.p
-    if args.scaling == "strong":       # total work fixed: this rank's share of --rows
-        n_loc = int(args.n) // world + (1 if rank < int(args.n) % world else 0)
-    else:
-        n_loc = int(args.n)
+    n_loc, row_lo, n_total = plan_rows(args.n, world, rank, args.scaling)
     z_dims = [1, 1, 1, 7]
     params = dict(dataset="Sim_Hirano_Imbens", output_dir=".", save_res=False, save_model=False,
                   binary_treatment=False, use_bnn=False, z_dims=z_dims, v_dim=p, lr_theta=1e-4, lr_z=1e-4,
@@ -402,9 +412,11 @@ def main():
                   g_d_freq=5, use_z_rec=True, e_units=[64] * 5, dz_units=[64, 32, 8])
     model = CausalBGM(params, timestamp="bench", random_seed=0, device=local_rank)
     eng = model.engine
-    x, y, v = make_panel(n_loc, p, seed=rank, device=device)  # each rank its own panel (weak scaling)
+    if args.scaling == "strong":
+        x, y, v = make_panel(n_loc, p, seed=0, device=device, lo=row_lo, n_gen=n_total)
+    else:
+        x, y, v = make_panel(n_loc, p, seed=rank, device=device)  # each rank its own panel (weak scaling)
     x_values = np.linspace(0, 3, 20)
-    n_total = int(args.n) if args.scaling == "strong" else n_loc * world
     n_ranks_seen = world
     if world > 1:      # the collective the run depends on works, and every rank is there
         t1 = torch.ones(1, device=device)
@@ -453,6 +465,22 @@ def main():
             dist.all_reduce(buf)
         torch.cuda.synchronize()
         allreduce_ms = 1e2 * (time.perf_counter() - t1)
+
+    # which kernels each rank ran: the sampling path, and the minibatch-step path a data-parallel fit at the reference batch size
+    # (32 rows in total, 32 // world per rank) would take on this rank (bgm_causal_describe inside a fit session)
+    b_fit = max(1, 32 // world)
+    eng.fit_begin(n_loc, b_fit)
+    try:
+        path = f"rank {rank}: rows [{row_lo}, {row_lo + n_loc}) {eng.describe(b_fit)}"
+    finally:
+        eng.fit_end()
+    paths = [path]
+    if world > 1:
+        paths = [None] * world
+        dist.all_gather_object(paths, path)
+    if rank == 0:
+        for line in paths:
+            print(line, file=sys.stderr)
 
     if rank == 0:
         iters = args.burn_in + args.n_mcmc
@@ -526,6 +554,7 @@ def main():
             "acceptance_rate": model.last_acceptance_rate,
             "adrf_head": [float(a) for a in adrf[:3]],
             "roofline": roof,
+            "kernel_paths": paths,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(params, p, z_dims)

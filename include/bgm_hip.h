@@ -179,6 +179,11 @@ typedef struct {
 } bgm_mh_info;
 int bgm_causal_mh_info(bgm_handle *h, int64_t n, bgm_mh_info *info);
 
+/* Which kernels this handle runs, as text (diagnostics: bench.py prints it per rank): the sampling path, and -- between
+ * bgm_causal_fit_begin and bgm_causal_fit_end -- the minibatch-step path for a local minibatch of `batch` rows (under data
+ * parallelism batch = batch_size / world).  out: cap bytes, NUL-terminated. */
+int bgm_causal_describe(bgm_handle *h, int32_t batch, char *out, int32_t cap);
+
 /* evaluate at a given latent matrix z [n x q]: accumulates sums[0..2] += {sum |v - mu_v|^2,
  * sum (x - x_pred)^2, sum (y - mu_y)^2} (divide by n*p, n, n for the MSEs) and the plug-in causal
  * estimate: binary -> ite_dev[n] = f(z0,z1,1) - f(z0,z1,0); continuous -> adrf_partial_dev

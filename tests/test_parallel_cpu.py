@@ -181,6 +181,50 @@ def test_bayesian_generator_block_plan_covers_every_row_once_for_any_sharding():
             assert seen == ref
 
 
+def _strong_plan_fn(rank, world):
+    """bench.py --scaling strong (BASELINE configs[3]: ONE N-row panel over all GPUs): every rank's share, its first row, the job size."""
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import bench
+    from bayesgm_amd import parallel
+    out = []
+    for n in (1_000_000, 1_000_003, 37, 2):
+        n_loc, lo, n_total = bench.plan_rows(n, world, rank, "strong")
+        assert (lo, lo + n_loc) == parallel.shard_range(n)                 # the rows CausalBGM.predict gives this rank
+        t = torch.tensor([n_loc], dtype=torch.int64)
+        dist.all_reduce(t)
+        spans = [None] * world
+        dist.all_gather_object(spans, (lo, lo + n_loc))
+        out.append((int(t.item()), n_total, spans))
+        # whole-job throughput of a strong-scaling step counts the job's rows once, a weak-scaling one every rank's panel
+        assert bench.plan_rows(n, world, rank, "weak") == (n, rank * n, n * world)
+    return out
+
+
+def test_strong_scaling_shards_partition_the_one_panel():
+    res = _run(_strong_plan_fn)
+    for per_rank in res:
+        for total, n_total, spans in per_rank:
+            assert total == n_total
+            assert spans[0][0] == 0 and spans[-1][1] == n_total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))
+
+
+def test_strong_scaling_panel_is_the_slice_of_the_single_gpu_panel():
+    """make_panel(..., lo, n_gen): rank r of a strong-scaling run holds rows [lo, lo + n) of the panel a one-GPU run of the same
+    --rows holds (same generator seed), so the SCALE line at N GPUs is the configs[3] workload, not N different panels."""
+    sys.path.insert(0, ROOT)
+    import bench
+    full = [t.numpy() for t in bench.make_panel(101, 7, seed=0, device="cpu")]
+    for world in (2, 3):
+        parts = []
+        for r in range(world):
+            n_loc, lo, n_total = bench.plan_rows(101, world, r, "strong")
+            parts.append([t.numpy() for t in bench.make_panel(n_loc, 7, seed=0, device="cpu", lo=lo, n_gen=n_total)])
+        for k in range(3):
+            assert np.array_equal(np.concatenate([p_[k] for p_ in parts]), full[k])
+
+
 def _shared_seed_fn(rank, world):
     from bayesgm_amd import parallel
     return (parallel.shared_seed(17), parallel.shared_seed(None))
