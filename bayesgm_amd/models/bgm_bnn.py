@@ -6,12 +6,23 @@ generate :479, predict_on_posteriors :511, predict :527, get_log_posterior :666,
 stay deterministic.  Kernels: csrc/bgmb_kernels.h, csrc/bgmb_egm_kernels.h through the C ABI bgm_bvn_*; arithmetic and the
 counter-based Flipout noise are restated in oracle/bgm_bnn.py.
 
-DenseFlipout perturbs the kernels in EVERY call, also with training=False, so evaluate / generate / the HMC target / the
-predictive draws are stochastic in the weights, as in the reference.  Consequence for HMC: the
-acceptance ratio compares two DIFFERENT perturbations, so the acceptance probability is bounded away from 1 however small the
-step, and SimpleStepSizeAdaptation (target 0.75) shrinks the step geometrically -- the chains freeze.  That is the reference as
-written and the default here (``params['bnn_mcmc_noise'] = 'fresh'``); ``'frozen'`` (build option) runs each HMC on ONE weight
-draw (generator call 0 for every gradient evaluation), a deterministic target.  Noise keys: the fit uses random_seed (stream 2t for the
+DenseFlipout perturbs the kernels in EVERY call, also with training=False (tfp.layers.DenseFlipout._apply_variational_kernel draws
+the perturbation and the sign vectors inside `call`, with stateful random ops when the layer's seed is None, and has no training
+switch), so evaluate / generate / the predictive draws are stochastic in the weights, as in the reference.
+
+The HMC target (``params['bnn_mcmc_noise']``; DESIGN.md section 7b gives the argument in full).  Under tfp.mcmc.sample_chain the
+target_log_prob_fn is traced once and EXECUTED at every leapfrog step, so as written (bgm/base.py:709-830) every gradient
+evaluation of a transition sees a different weight draw while the cached log-prob of the current state stays: the acceptance ratio
+compares two different perturbations, the acceptance probability is bounded away from 1 however small the step (~0.54 measured),
+SimpleStepSizeAdaptation (target 0.75) shrinks the step by 1/1.01 at each of its 0.8 burn_in steps and the chains stop moving (draw
+variance 5e-11; imputations worse than the column mean).  tfp.mcmc.HamiltonianMonteCarlo documents target_log_prob_fn as a function
+of the state that returns its log-density -- a deterministic function; a fresh draw per call is outside that contract and outside
+anything Metropolis-Hastings corrects for -- and what predict() documents itself to return (posterior draws of Z given the observed
+entries) exists only for a fixed generator.  So, decided the way ``bnn_norm`` was:
+  'frozen' (DEFAULT)  one weight draw per HMC run (generator call 0 for every gradient evaluation): a deterministic target, the
+                      reading on which the documented behaviour holds (adaptation reaches 0.75, imputation beats the column mean);
+  'fresh'             the reference as executed, an explicit choice: reproduced exactly, with a warning that the chains freeze.
+Noise keys: the fit uses random_seed (stream 2t for the
 theta step and 2t + 1 for the Z step of minibatch t), the EGM warm start random_seed + 2^40, predict the `seed` argument.
 """
 import datetime
@@ -77,7 +88,7 @@ class BGMBayes(BGM):
         if device is None:
             device = int(os.environ.get("BGM_DEVICE", os.environ.get("LOCAL_RANK", 0)))
         self._max_batch = 64
-        mode = params.get("bnn_mcmc_noise", "fresh")
+        mode = params.get("bnn_mcmc_noise", "frozen")
         if mode not in ("fresh", "frozen"):
             raise ValueError("params['bnn_mcmc_noise'] must be 'fresh' or 'frozen'")
         self._mcmc_noise = mode
@@ -321,10 +332,10 @@ class BGMBayes(BGM):
     def _warn_fresh_noise(self):
         if self._mcmc_noise == "fresh" and not self._warned_noise:
             import warnings
-            warnings.warn("bayesgm_amd: use_bnn=True re-perturbs the generator at every HMC gradient evaluation, as the reference does: "
-                          "the acceptance probability stays below the adaptation target whatever the step, SimpleStepSizeAdaptation "
-                          "shrinks the step geometrically and the chains freeze (DESIGN.md section 7b); "
-                          "params['bnn_mcmc_noise'] = 'frozen' samples on one weight draw per HMC run instead.")
+            warnings.warn("bayesgm_amd: params['bnn_mcmc_noise'] = 'fresh' re-perturbs the generator at every HMC gradient evaluation, as "
+                          "the reference executes it: the acceptance probability stays below the adaptation target whatever the step, "
+                          "SimpleStepSizeAdaptation shrinks the step geometrically and the chains freeze (DESIGN.md section 7b); "
+                          "the default 'frozen' samples on one weight draw per HMC run instead.")
             self._warned_noise = True
 
     def _new_seed(self):

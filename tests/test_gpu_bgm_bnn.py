@@ -356,13 +356,21 @@ def test_model_predict_is_block_consistent_with_the_oracle(tmp_path):
     eng.close()
 
 
-def test_default_mcmc_noise_is_the_reference_reading_and_warns(tmp_path):
+def test_mcmc_noise_default_is_one_weight_draw_and_the_as_written_mode_warns(tmp_path):
+    """params['bnn_mcmc_noise']: the default samples each HMC run on one weight draw (a deterministic target); 'fresh' -- the
+    reference as executed, chains freeze -- is an explicit choice and says so (models/bgm_bnn.py)."""
+    import warnings
     from bayesgm_amd.models import BGM
     p, q = 6, 2
-    model = BGM(_params(tmp_path, p, q), random_seed=3)
-    assert model._mcmc_noise == "fresh" and model.engine.cfg.hmc_frozen_noise == 0
     x = np.random.RandomState(0).standard_normal((20, p)).astype(np.float32)
     x[:, 1] = np.nan
+    model = BGM(_params(tmp_path, p, q), random_seed=3)
+    assert model._mcmc_noise == "frozen" and model.engine.cfg.hmc_frozen_noise == 1
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        model.predict(x, n_mcmc=3, burn_in=3, num_leapfrog_steps=2)
+    model = BGM(_params(tmp_path, p, q, bnn_mcmc_noise="fresh"), random_seed=3)
+    assert model._mcmc_noise == "fresh" and model.engine.cfg.hmc_frozen_noise == 0
     with pytest.warns(UserWarning, match="bnn_mcmc_noise"):
         model.predict(x, n_mcmc=3, burn_in=3, num_leapfrog_steps=2)
     with pytest.raises(ValueError):
