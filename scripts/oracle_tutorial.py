@@ -8,9 +8,12 @@ Prints the log lines the reference prints (EGM every 500 iterations; last-miniba
 one RESULT line, in the format scripts/compare_trace.py parses.
 
 usage: python scripts/oracle_tutorial.py NAME [seed=123] [N=20000] [egm=30000] [epochs=100] [burn_in=5000] [n_mcmc=3000] [mh_rows=0]
-  mh_rows > 0: the MH chains / dose-response curve run on the first mh_rows rows only (one block; the published run uses all N)."""
+  mh_rows > 0: the MH chains / dose-response curve run on the first mh_rows rows only (one block; the published run uses all N).
+A run takes hours: its state is pickled to gpurun_out/oracle_ckpt/NAME.pkl after the EGM phase, every 10 epochs and every 250 MH
+iterations, and a restart with the same NAME resumes there (append the output to the same log: `>> log`)."""
 import json
 import os
+import pickle
 import sys
 import time
 
@@ -61,12 +64,35 @@ def net_grads(g):
     return OB.flat_grads(g)
 
 
-t0 = time.time()
+CKPT = os.path.join(ROOT, "gpurun_out", "oracle_ckpt", name + ".pkl")
+os.makedirs(os.path.dirname(CKPT), exist_ok=True)
+
+
+class ZState:
+    pass
+
+
+def save_ckpt(**state):
+    state.update(m=m, stream=stream[0], rs=rs.get_state(), elapsed=time.time() - t0)
+    with open(CKPT + ".tmp", "wb") as f:
+        pickle.dump(state, f)
+    os.replace(CKPT + ".tmp", CKPT)
+
+
+ck = None
+if os.path.exists(CKPT):
+    with open(CKPT, "rb") as f:
+        ck = pickle.load(f)
+    m, stream[0] = ck["m"], ck["stream"]
+    rs.set_state(ck["rs"])
+    print("(resumed from %s: phase %s)" % (os.path.relpath(CKPT, ROOT), ck["phase"]), flush=True)
+t0 = time.time() - (ck["elapsed"] if ck else 0.0)
 # ---- EGM warm start (causalbgm/base.py:380-431)
-print("EGM Initialization Starts ...")
+if ck is None:
+    print("EGM Initialization Starts ...")
 g_opt = OE.Adam([a for k in ("g", "e", "f", "h") for a in net_params(m[k])], LR)
 d_opt = OE.Adam(OE.disc_param_list(dz), LR)
-for it in range(EGM_IT + 1):
+for it in range(EGM_IT + 1 if ck is None else 0):
     for _ in range(GD):
         idx = rs.choice(N, B, replace=False)
         bz = rs.normal(0, 1, (B, q)).astype(f32)
@@ -80,24 +106,24 @@ for it in range(EGM_IT + 1):
     if it % 500 == 0:
         print("EGM Initialization Iter [%d] : e_loss_adv [%.4f], l2_loss_v [%.4f], l2_loss_z [%.4f], l2_loss_x [%.4f], l2_loss_y [%.4f], "
               "g_e_loss [%.4f], dz_loss [%.4f], d_loss [%.4f]" % (it, lg[0], lg[1], lg[2], lg[3], lg[4], lg[5], dz_loss, d_loss), flush=True)
-print("EGM Initialization Ends.  (%.0f s)" % (time.time() - t0))
+if ck is None:
+    print("EGM Initialization Ends.  (%.0f s)" % (time.time() - t0))
 
 # ---- iterative updates (base.py:434-532)
-xs200 = None
-data_z, _, _, _, _ = OB.evaluate(m, (x, y, v), None, [0.0], noise_key, streams(1))       # base.py:479: Z = e(V), one noisy call on the panel
-data_z = data_z.astype(f32)
-opt = {k: OF.AdamState(net_params(m[k])) for k in ("g", "h", "f")}
-
-
-class ZState:
-    pass
-
-
-zst = ZState()
-zst.data_z, zst.zm, zst.zv, zst.zt, zst.lr_z = data_z, np.zeros_like(data_z), np.zeros_like(data_z), 0, LR_Z
-print("Iterative Updating Starts ...")
+if ck is None:
+    data_z, _, _, _, _ = OB.evaluate(m, (x, y, v), None, [0.0], noise_key, streams(1))   # base.py:479: Z = e(V), one noisy call on the panel
+    data_z = data_z.astype(f32)
+    opt = {k: OF.AdamState(net_params(m[k])) for k in ("g", "h", "f")}
+    zst = ZState()
+    zst.data_z, zst.zm, zst.zv, zst.zt, zst.lr_z = data_z, np.zeros_like(data_z), np.zeros_like(data_z), 0, LR_Z
+    first_epoch = 0
+    save_ckpt(phase="fit", opt=opt, zst=zst, next_epoch=0)
+    print("Iterative Updating Starts ...")
+else:
+    opt, zst = ck.get("opt"), ck.get("zst")
+    first_epoch = ck["next_epoch"] if ck["phase"] == "fit" else EPOCHS + 1
 t1 = time.time()
-for epoch in range(EPOCHS + 1):
+for epoch in range(first_epoch, EPOCHS + 1):
     perm = rs.choice(N, N, replace=False)
     for i in range(0, N, B):
         idx = perm[i:i + B]
@@ -118,8 +144,12 @@ for epoch in range(EPOCHS + 1):
     if epoch % 10 == 0:
         _, _, mse_x, mse_y, mse_v = OB.evaluate(m, (x, y, v), zst.data_z, np.linspace(0.0, 3.0, 5), noise_key, streams(8))
         print("Epoch [%d/%d]: MSE_x: %.4f, MSE_y: %.4f, MSE_v: %.4f\n" % (epoch, EPOCHS, mse_x, mse_y, mse_v), flush=True)
-t_fit = time.time() - t0
-print("fit %.0f s (iterative part %.0f s)" % (t_fit, time.time() - t1))
+        save_ckpt(phase="fit", opt=opt, zst=zst, next_epoch=epoch + 1)
+if ck is None or ck["phase"] == "fit":
+    t_fit = time.time() - t0
+    print("fit %.0f s (iterative part %.0f s of this process)" % (t_fit, time.time() - t1))
+else:
+    t_fit = ck["t_fit"]
 
 # ---- predict (base.py:573-668): one block of MH_ROWS rows, q_sd = 1
 t2 = time.time()
@@ -129,8 +159,11 @@ n = MH_ROWS
 xm, ym, vm = x[:n], y[:n], v[:n]
 pseed = seed + 17
 z = OB.R.normals(np.arange(n), 0, q, OB.R.TAG_INIT, pseed).astype(f32)
-acc_tail, adrf_draws = 0, np.zeros((len(xs), KEEP))
-for it in range(BURN + KEEP):
+acc_tail, adrf_draws, first_it, t_pred0 = 0, np.zeros((len(xs), KEEP)), 0, 0.0
+if ck is not None and ck["phase"] == "mh":
+    z, acc_tail, adrf_draws, first_it, t_pred0 = ck["z"], ck["acc_tail"], ck["adrf_draws"], ck["next_it"], ck["t_pred"]
+t2 -= t_pred0
+for it in range(first_it, BURN + KEEP):
     z, acc, _, _ = OB.mh_iteration(m, xm, ym, vm, z, it, 1.0, pseed, n)
     if it >= BURN + KEEP - 100:
         acc_tail += int(acc.sum())
@@ -139,6 +172,8 @@ for it in range(BURN + KEEP):
         adrf_draws[:, d] = OB.effects_draw(m, z, xs, d, it, True, pseed, n).mean(axis=1)
     if it % 500 == 0:
         print("MH iteration %d (%.0f s)" % (it, time.time() - t2), flush=True)
+    if it % 250 == 249:
+        save_ckpt(phase="mh", t_fit=t_fit, z=z, acc_tail=acc_tail, adrf_draws=adrf_draws, next_it=it + 1, t_pred=time.time() - t2)
 adrf = adrf_draws.mean(axis=1)
 acc_rate = acc_tail / (100.0 * n)
 print("Final MCMC Acceptance Rate: %.4f" % acc_rate)
