@@ -19,8 +19,12 @@ def parse_log(text):
                     r"loss_mse_v %s, loss_postrior_z %s" % ((NUM,) * 7), text)
     ev = re.findall(r"Epoch \[(\d+)/\d+\]: MSE_x: ([-\d.]+), MSE_y: ([-\d.]+), MSE_v: ([-\d.]+)", text)
     res = re.search(r"RESULT (\{.*\})", text)
-    return (np.array(egm, float).reshape(-1, 9), np.array(mb, float).reshape(-1, 8), np.array(ev, float).reshape(-1, 4),
-            json.loads(res.group(1)) if res else None)
+
+    def table(rows, width):      # a run resumed from a checkpoint (scripts/oracle_tutorial.py) prints some lines twice: keep the last
+        a = np.array(rows, float).reshape(-1, width)
+        keep = {int(k): i for i, k in enumerate(a[:, 0])}
+        return a[sorted(keep.values())]
+    return table(egm, 9), table(mb, 8), table(ev, 4), json.loads(res.group(1)) if res else None
 
 
 def summary(egm, mb, ev):
