@@ -135,9 +135,10 @@ def test_replayed_latent_adam_equals_the_dense_sweep():
     runs separate like any two fp32 Adam trajectories do -- a parameter whose gradient is rounding noise moves by +-lr -- which says
     nothing about the latent optimizer; the class-level traces cover the full loop).  The gradients of a row are then the same
     function of its z in both runs, and the tables may differ only by the fp32 rounding of the deferred steps: dense rounds z after
-    every step (<= 0.5 ulp each: a random walk of ~0.3 ulp sqrt(k) over the k ~ 128 steps a row waits, i.e. ~1e-6 at |z| in [2, 4),
-    whose maximum over 4e4 elements and ~3 waits reaches 2e-6 -- measured 2.1e-6), replay sums the 256-term series in fp32 and rounds
-    once, so replay is if anything the more accurate of the two.  Bound: 5e-6 absolute on z (the drift itself is up to ~1e-2 at
+    every step, so it random-walks (~0.3 ulp sqrt(k)) AND stagnates: once a step's update is below half an ulp of z (after ~90
+    steps at lr = 1e-3) it is dropped altogether, ~1e-6 (|z| in [1, 2)) to ~2.5e-6 (|z| in [2, 4)) per waiting period that the
+    replay's series keeps.  Over 400 minibatches (a row is used ~3 times) the two tables end up to 1.1e-5 apart (measured), with
+    replay the closer one to the exact recursion.  Bound: 2.5e-5 absolute on z (the drift itself is up to ~1e-2 at
     lr = 1e-3), 2e-5 relative on the Adam slots.  Also: the mode guards."""
     import torch
     n, B, lr, steps = 4096, 32, 1e-3, 400
@@ -170,7 +171,8 @@ def test_replayed_latent_adam_equals_the_dense_sweep():
     assert np.abs(z0 - z).max() > 1e-3                                # the table moved
     untouched = np.setdiff1d(np.arange(n), np.concatenate(order))
     assert len(untouched) > 0 and np.array_equal(z2[untouched], z[untouched]) and np.array_equal(z0[untouched], z[untouched])
-    assert np.abs(z2 - z0).max() <= 5e-6, np.abs(z2 - z0).max()
+    assert np.abs(z2 - z0).max() <= 2.5e-5, np.abs(z2 - z0).max()
+    assert np.median(np.abs(z2 - z0)) <= 3e-7
     assert np.abs(m2 - m0).max() <= 2e-5 * np.abs(m0).max() and np.abs(v2 - v0).max() <= 2e-5 * np.abs(v0).max()
 
 
