@@ -87,6 +87,10 @@ class BgmEgmConfig(C.Structure):
                 ("lr", C.c_float), ("gamma", C.c_float), ("alpha", C.c_float)]
 
 
+class PriorConfig(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("dims", C.c_int32 * 5)]
+
+
 class MhInfo(C.Structure):
     _fields_ = [("rows_per_wave", C.c_int32), ("waves_per_block", C.c_int32), ("grid_blocks", C.c_int32),
                 ("mfma_per_transition_per_wave", C.c_int32), ("lds_bytes", C.c_int32),
@@ -125,6 +129,10 @@ SYMBOLS = {
     "bgm_causal_fit_theta_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     "bgm_causal_fit_z_step": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_int32, C.c_float,
                                         C.c_int32, C.c_void_p, C.c_void_p]),
+    "bgm_prior_n_params": (C.c_int, [C.POINTER(PriorConfig), C.POINTER(C.c_int64)]),
+    "bgm_prior_table": (C.c_int, [C.c_void_p, C.POINTER(PriorConfig), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bgm_prior_step": (C.c_int, [C.c_void_p, C.POINTER(PriorConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "bgm_causal_describe": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32]),
     "bgm_causal_fit_z_sync": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p]),
     "bgm_causal_get_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -2,9 +2,12 @@
 // models/causalbgm/identifiable.py:195-211 update_latent_variable_sgd, :521-555 get_log_posterior, :557-614
 // metropolis_hastings_sampler): the PRIOR = 1 instantiations of causal_kernels.h, kept in their own translation unit.
 // Selected by bgm_causal_set_prior (include/bgm_hip.h); the default path (causal_api.hip) is untouched.
+#include <algorithm>
+#include <cmath>
 #include <string>
 
 #include "bgm_host.h"
+#include "prior_kernels.h"
 
 static constexpr int PR_WAVES = 8;
 #define BGM_PRIOR_VARIANTS(X) X(1, 3, 13) X(1, 3, 7) X(1, 3, 2) X(2, 1, 10) X(2, 1, 7) X(2, 1, 2)
@@ -67,4 +70,76 @@ int bgm_causal_prior_mh_launch(bgm_handle *h, const CausalMhKArgs &a, int effect
   if (effect == BGM_EFFECT_ADRF) return pr_launch_mh<1>(h, ka, grid, lds, stream);
   if (effect == BGM_EFFECT_ITE) return pr_launch_mh<2>(h, ka, grid, lds, stream);
   return pr_launch_mh<0>(h, ka, grid, lds, stream);
+}
+
+
+// ---- the prior network itself (prior_kernels.h)
+static int prior_net_of(const bgm_prior_config *cfg, int rows, PriorNet &n, int &lds_floats, const char *who) {
+  if (!cfg || cfg->n_layers < 1 || cfg->n_layers > PRIOR_MAX_LAYERS) { bgm_set_error(std::string(who) + ": prior net needs 1.." + std::to_string(PRIOR_MAX_LAYERS) + " dense layers"); return BGM_E_INVALID; }
+  n = PriorNet{};
+  n.n_layers = cfg->n_layers;
+  int off = 0, a = 0, wmax = 0;
+  for (int l = 0; l <= cfg->n_layers; ++l) {
+    if (cfg->dims[l] < 1) { bgm_set_error(std::string(who) + ": bad layer width"); return BGM_E_INVALID; }
+    n.dims[l] = cfg->dims[l];
+    if (l) wmax = std::max(wmax, cfg->dims[l]);
+  }
+  for (int l = 0; l < cfg->n_layers; ++l) {
+    n.w_off[l] = off; off += n.dims[l] * n.dims[l + 1];
+    n.b_off[l] = off; off += n.dims[l + 1];
+    n.a_off[l] = a; a += rows * n.dims[l + 1];
+  }
+  n.a_off[cfg->n_layers] = a;
+  n.n_params = off; n.wmax = wmax;
+  lds_floats = a;
+  return BGM_OK;
+}
+
+extern "C" int bgm_prior_n_params(const bgm_prior_config *cfg, int64_t *count) {
+  PriorNet n; int lf;
+  int rc = prior_net_of(cfg, 1, n, lf, "bgm_prior_n_params");
+  if (rc) return rc;
+  if (!count) { bgm_set_error("bgm_prior_n_params: NULL count"); return BGM_E_INVALID; }
+  *count = n.n_params;
+  return BGM_OK;
+}
+
+extern "C" int bgm_prior_table(bgm_handle *h, const bgm_prior_config *cfg, const float *theta_dev, float *table_dev, void *stream_) {
+  if (!h || !h->configured || !theta_dev || !table_dev) { bgm_set_error("bgm_prior_table: bad argument"); return BGM_E_INVALID; }
+  PriorNet n; int lf;
+  int rc = prior_net_of(cfg, cfg ? cfg->dims[0] : 0, n, lf, "bgm_prior_table");
+  if (rc) return rc;
+  if (n.dims[n.n_layers] != h->q + 1) { bgm_set_error("bgm_prior_table: the prior net must end in q + 1 outputs"); return BGM_E_INVALID; }
+  if ((size_t)lf * 4 > 150 * 1024) { bgm_set_error("bgm_prior_table: prior net too wide for one workgroup's LDS"); return BGM_E_UNSUPPORTED; }
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(prior_table_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lf * 4));
+  hipLaunchKernelGGL(prior_table_kernel, dim3(1), dim3(PRIOR_THREADS), lf * 4, (hipStream_t)stream_, n, theta_dev, table_dev, h->q);
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+extern "C" int bgm_prior_step(bgm_handle *h, const bgm_prior_config *cfg, float *theta_dev, float *m_dev, float *v_dev, const int32_t *seg_dev,
+                              float *data_z_dev, const int32_t *idx_dev, int32_t batch, const float *dz_dev, float lr_z, float lr_prior,
+                              int64_t t_z, int64_t t_prior, float *out_dev, void *stream_) {
+  if (!h || !h->configured || !theta_dev || !m_dev || !v_dev || !seg_dev || !data_z_dev || !idx_dev || !dz_dev || batch < 1 || t_z < 1 || t_prior < 1) {
+    bgm_set_error("bgm_prior_step: bad argument"); return BGM_E_INVALID;
+  }
+  PriorNet n; int lf;
+  int rc = prior_net_of(cfg, batch, n, lf, "bgm_prior_step");
+  if (rc) return rc;
+  const int q = h->q;
+  if (n.dims[n.n_layers] != q + 1) { bgm_set_error("bgm_prior_step: the prior net must end in q + 1 outputs"); return BGM_E_INVALID; }
+  const size_t bytes = ((size_t)lf + (size_t)batch * q + 2 * (size_t)batch * n.wmax + 3 * (size_t)batch) * 4;
+  if (bytes > 150 * 1024) { bgm_set_error("bgm_prior_step: minibatch x prior-net widths exceed one workgroup's LDS"); return BGM_E_UNSUPPORTED; }
+  auto lr_t = [](double lr, double t) { return (float)(lr * std::sqrt(1.0 - std::pow(0.99, t)) / (1.0 - std::pow(0.9, t))); };
+  PriorStepArgs a{};
+  a.net = n; a.theta = theta_dev; a.m = m_dev; a.v = v_dev; a.seg = seg_dev; a.data_z = data_z_dev; a.idx = idx_dev; a.dz = dz_dev;
+  a.B = batch; a.q = q; a.lr_t_z = lr_t(lr_z, (double)t_z); a.lr_t_p = lr_t(lr_prior, (double)t_prior);
+  a.b1 = 0.9f; a.b2 = 0.99f; a.eps = 1e-7f;        // tf.keras.optimizers.Adam(lr, beta_1=0.9, beta_2=0.99), identifiable.py:88-95
+  a.out = out_dev;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(prior_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  hipLaunchKernelGGL(prior_step_kernel, dim3(1), dim3(PRIOR_THREADS), bytes, (hipStream_t)stream_, a);
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
 }

@@ -2,14 +2,17 @@
 of a random segment of the row (/root/reference/src/bayesgm/models/causalbgm/identifiable.py:15-616).
 
 What is on the device: everything CausalBGM has (EGM warm start, theta steps, evaluate), the Z-gradient of the minibatch
-(`bgm_causal_fit_z_grad`) and the MH / log-posterior kernels with the per-row conditional prior (`bgm_causal_set_prior`, the
-PRIOR = 1 instantiations of csrc/causal_kernels.h).  What stays on the host side of the C ABI, as torch ops on [32 x q] tensors: the
-prior network (n_segments -> prior_units -> q + 1, a few thousand parameters), its Adam step and the fresh-slot Adam step on the
-batch latents -- the reference's `update_latent_variable_sgd` (:150-226) restated in oracle/identifiable.py.
+(`bgm_causal_fit_z_grad`), the prior network (n_segments -> prior_units -> q + 1): its forward / backward, its Adam step and the
+fresh-slot Adam step on the batch latents in one small kernel (`bgm_prior_step`, csrc/prior_kernels.h; the reference's
+`update_latent_variable_sgd` :150-226, restated in oracle/identifiable.py), the per-segment table of the prior (`bgm_prior_table`)
+and the MH / log-posterior kernels that read it (`bgm_causal_set_prior`, the PRIOR = 1 instantiations of csrc/causal_kernels.h).
+torch holds the arrays and nothing else.
 
 Stated differences.  (i) The reference's `fit` unpacks seven values from `evaluate`, which returns four (:334 vs base.py:555,570),
 so it fails at the first evaluation; the build evaluates as CausalBGM does.  (ii) `use_bnn=True` (a Bayesian prior network on the
 Bayesian-network kernels) is not built: NotImplementedError.  (iii) Single process only (no torch.distributed sharding)."""
+import ctypes as C
+
 import numpy as np
 import torch
 
@@ -17,11 +20,17 @@ from .. import _lib, parallel
 from ..utils import save_data
 from .causalbgm import CausalBGM, _init_mlp
 
-ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.99, 1e-7          # tf.keras.optimizers.Adam(lr, beta_1=0.9, beta_2=0.99) (:88-95)
+def _flatten(net):
+    return np.concatenate([np.concatenate([np.asarray(W, np.float32).ravel(), np.asarray(b, np.float32).ravel()]) for W, b in net])
 
 
-def _lr_t(lr, t):
-    return lr * np.sqrt(1.0 - ADAM_B2 ** t) / (1.0 - ADAM_B1 ** t)
+def _unflatten(flat, dims):
+    out, o = [], 0
+    for i in range(len(dims) - 1):
+        W = flat[o:o + dims[i] * dims[i + 1]].reshape(dims[i], dims[i + 1]).copy(); o += dims[i] * dims[i + 1]
+        b = flat[o:o + dims[i + 1]].copy(); o += dims[i + 1]
+        out.append((W, b))
+    return out
 
 
 class IdentifiableCausalBGM(CausalBGM):
@@ -37,10 +46,13 @@ class IdentifiableCausalBGM(CausalBGM):
         q = self.engine.q
         dims = [int(params['n_segments'])] + list(params.get('prior_units', [64])) + [q + 1]          # :76-78
         dev = self.engine.device
-        self.prior_net = [(torch.from_numpy(W).to(dev).requires_grad_(True), torch.from_numpy(b).to(dev).requires_grad_(True))
-                          for W, b in _init_mlp(self._rs, dims)]
-        self._prior_m = [(torch.zeros_like(W), torch.zeros_like(b)) for W, b in self.prior_net]
-        self._prior_v = [(torch.zeros_like(W), torch.zeros_like(b)) for W, b in self.prior_net]
+        if len(dims) - 1 > 4:
+            raise NotImplementedError("bayesgm_amd: prior_units with more than 3 hidden layers")
+        self._prior_dims = dims
+        self._prior_cfg = _lib.PriorConfig(len(dims) - 1, (C.c_int32 * 5)(*(dims + [0] * (5 - len(dims)))))
+        self._prior_theta = torch.from_numpy(_flatten(_init_mlp(self._rs, dims))).to(dev)       # Keras order: W0, b0, W1, b1, ...
+        self._prior_m = torch.zeros_like(self._prior_theta)
+        self._prior_v = torch.zeros_like(self._prior_theta)
         self._prior_t = 0
         self._z_t = 0
         if getattr(self, "_pending_prior", None) is not None:      # a checkpoint was restored by CausalBGM.__init__ before the prior net existed
@@ -50,11 +62,10 @@ class IdentifiableCausalBGM(CausalBGM):
     # ------------------------------------------------------------------ checkpoints: prior_net and prior_optimizer are tracked too (:112-128)
     def _checkpoint_extra(self):
         flat = {}
-        for i, (W, b) in enumerate(self.prior_net):
-            flat["prior_W%d" % i] = W.detach().cpu().numpy()
-            flat["prior_b%d" % i] = b.detach().cpu().numpy()
-            flat["prior_mW%d" % i] = self._prior_m[i][0].cpu().numpy(); flat["prior_mb%d" % i] = self._prior_m[i][1].cpu().numpy()
-            flat["prior_vW%d" % i] = self._prior_v[i][0].cpu().numpy(); flat["prior_vb%d" % i] = self._prior_v[i][1].cpu().numpy()
+        for name, t in (("", self._prior_theta), ("m", self._prior_m), ("v", self._prior_v)):
+            for i, (W, b) in enumerate(_unflatten(t.cpu().numpy(), self._prior_dims)):
+                flat["prior_%sW%d" % (name, i)] = W
+                flat["prior_%sb%d" % (name, i)] = b
         flat["prior_steps"] = np.array([self._prior_t, self._z_t], np.int64)
         if getattr(self, "segments", None) is not None:
             flat["segments"] = np.asarray(self.segments, np.int64)
@@ -62,85 +73,56 @@ class IdentifiableCausalBGM(CausalBGM):
 
     def _apply_prior_arrays(self, d):
         dev = self.engine.device
-        n = len(self.prior_net)
+        n = len(self._prior_dims) - 1
         if any(("prior_W%d" % i) not in d for i in range(n)):
             return
-        T = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
-        self.prior_net = [(T(d["prior_W%d" % i]).requires_grad_(True), T(d["prior_b%d" % i]).requires_grad_(True)) for i in range(n)]
-        if ("prior_mW0") in d:
-            self._prior_m = [(T(d["prior_mW%d" % i]), T(d["prior_mb%d" % i])) for i in range(n)]
-            self._prior_v = [(T(d["prior_vW%d" % i]), T(d["prior_vb%d" % i])) for i in range(n)]
+        T = lambda pre: torch.from_numpy(_flatten([(d["prior_%sW%d" % (pre, i)], d["prior_%sb%d" % (pre, i)]) for i in range(n)])).to(dev)
+        self._prior_theta = T("")
+        if "prior_mW0" in d:
+            self._prior_m, self._prior_v = T("m"), T("v")
             self._prior_t, self._z_t = int(d["prior_steps"][0]), int(d["prior_steps"][1])
         if "segments" in d:
             self.segments = np.asarray(d["segments"])
 
     def _restore_extra(self, d):
         arrays = {k: d[k] for k in d.files if k.startswith("prior_") or k == "segments"}
-        if hasattr(self, "prior_net"):
+        if hasattr(self, "_prior_theta"):
             self._apply_prior_arrays(arrays)
         else:
             self._pending_prior = arrays
 
     # ------------------------------------------------------------------ prior network
-    def _prior_forward(self, u_onehot):
-        h = u_onehot
-        for i, (W, b) in enumerate(self.prior_net):
-            h = h @ W + b
-            if i < len(self.prior_net) - 1:
-                h = torch.nn.functional.leaky_relu(h, 0.2)
-        return h
-
     def prior_parameters(self):
         """[(W, b), ...] of the prior network as NumPy arrays (Keras order)."""
-        return [(W.detach().cpu().numpy(), b.detach().cpu().numpy()) for W, b in self.prior_net]
+        return _unflatten(self._prior_theta.cpu().numpy(), self._prior_dims)
 
     def set_prior_parameters(self, net):
-        dev = self.engine.device
-        self.prior_net = [(torch.from_numpy(np.asarray(W, np.float32)).to(dev).requires_grad_(True),
-                           torch.from_numpy(np.asarray(b, np.float32)).to(dev).requires_grad_(True)) for W, b in net]
+        self._prior_theta = torch.from_numpy(_flatten(net)).to(self.engine.device)
 
     def _prior_table(self):
         """Per segment: mu [q], 1 / sigma^2, (q / 2) log sigma^2 -- what the sampling kernels read (bgm_causal_set_prior)."""
-        k, q = int(self.params['n_segments']), self.engine.q
-        with torch.no_grad():
-            out = self._prior_forward(torch.eye(k, device=self.engine.device))
-            s2 = torch.nn.functional.softplus(out[:, -1]) + 1e-6
-            tab = torch.cat([out[:, :q], (1.0 / s2)[:, None], (0.5 * q * torch.log(s2))[:, None]], dim=1)
-        return tab.contiguous()
+        eng = self.engine
+        tab = torch.empty((int(self.params['n_segments']), eng.q + 2), device=eng.device, dtype=torch.float32)
+        _lib.check(eng.lib.bgm_prior_table(eng.h, C.byref(self._prior_cfg), self._prior_theta.data_ptr(), tab.data_ptr(), eng._stream()),
+                   "bgm_prior_table")
+        return tab
 
     def _with_prior(self, seg_dev):
         self.engine.set_prior(seg_dev.to(torch.int32).contiguous(), self._prior_table())
 
     # ------------------------------------------------------------------ latent / prior step (:150-226)
-    def _z_and_prior_step(self, x, y, v, idx, seg_dev, lr_z, lr_theta, dz, loss_z):
+    def _z_and_prior_step(self, x, y, v, idx, seg_dev, lr_z, lr_theta, dz, loss_z, out):
+        """NLL gradients of the batch latents (bgm_causal_fit_z_grad), then the joint latent / prior-net step (bgm_prior_step);
+        out [2] receives the batch means of the conditional-prior term and of |z|^2 / 2."""
         eng = self.engine
-        B, q = int(idx.numel()), eng.q
+        B = int(idx.numel())
         eng.fit_z_grad(x, y, v, self.data_z, idx, B, dz, loss_z)                      # NLL terms + z / B (standard prior)
-        idx64 = idx.long()
-        zb = self.data_z[idx64].detach().clone().requires_grad_(True)
-        out = self._prior_forward(torch.nn.functional.one_hot(seg_dev[idx64].long(), int(self.params['n_segments'])).float())
-        s2 = torch.nn.functional.softplus(out[:, -1]) + 1e-6
-        loss_prior = (((zb - out[:, :q]) ** 2).sum(dim=1) / (2.0 * s2) + q * torch.log(s2) / 2.0).mean()
-        flat = [a for Wb in self.prior_net for a in Wb]
-        grads = torch.autograd.grad(loss_prior, [zb] + flat)
-        with torch.no_grad():
-            g = dz[:B] - zb / B + grads[0]
-            self._z_t += 1
-            lr_t = float(_lr_t(lr_z, self._z_t))
-            m_, v_ = (1 - ADAM_B1) * g, (1 - ADAM_B2) * g * g                          # fresh slots: batch_z is a new Variable (:304)
-            self.data_z[idx64] = zb - lr_t * m_ / (torch.sqrt(v_) + ADAM_EPS)
-            self._prior_t += 1
-            lr_p = float(_lr_t(lr_theta, self._prior_t))
-            k = 1
-            for li, (W, b) in enumerate(self.prior_net):
-                for pi, par in enumerate((W, b)):
-                    gk = grads[k]
-                    k += 1
-                    mm, vv = self._prior_m[li][pi], self._prior_v[li][pi]
-                    mm.mul_(ADAM_B1).add_(gk, alpha=1 - ADAM_B1)
-                    vv.mul_(ADAM_B2).addcmul_(gk, gk, value=1 - ADAM_B2)
-                    par.sub_(lr_p * mm / (torch.sqrt(vv) + ADAM_EPS))
-        return float(loss_prior.item()), float((0.5 * (zb.detach() ** 2).sum(dim=1)).mean().item())
+        self._z_t += 1
+        self._prior_t += 1
+        _lib.check(eng.lib.bgm_prior_step(eng.h, C.byref(self._prior_cfg), self._prior_theta.data_ptr(), self._prior_m.data_ptr(),
+                                          self._prior_v.data_ptr(), seg_dev.data_ptr(), self.data_z.data_ptr(), idx.data_ptr(), B,
+                                          dz.data_ptr(), float(lr_z), float(lr_theta), self._z_t, self._prior_t, out.data_ptr(),
+                                          eng._stream()), "bgm_prior_step")
 
     # ------------------------------------------------------------------ fit (:228-346)
     def fit(self, data, batch_size=32, epochs=100, epochs_per_eval=5, startoff=0, use_egm_init=True, egm_n_iter=30000,
@@ -176,6 +158,8 @@ class IdentifiableCausalBGM(CausalBGM):
         dz = torch.empty((batch_size, q), device=dev)
         loss = torch.zeros(8, device=dev, dtype=torch.float64)
         loss_z = torch.zeros(8, device=dev, dtype=torch.float64)
+        step_out = torch.zeros(2, device=dev)
+        prior_acc = torch.zeros(2, device=dev, dtype=torch.float64)
         best_loss = np.inf
         self.fit_history = []
         if verbose:
@@ -185,15 +169,16 @@ class IdentifiableCausalBGM(CausalBGM):
                 sample_idx = torch.from_numpy(np.random.choice(n, n, replace=False).astype(np.int32)).to(dev)
                 loss.zero_()
                 loss_z.zero_()
-                n_rows, prior_sum, std_sum = 0, 0.0, 0.0
+                n_rows = 0
+                prior_acc.zero_()
                 for i in range(0, n - batch_size + 1, batch_size):                                          # incomplete last batch skipped (:299)
                     idx = sample_idx[i:i + batch_size]
                     eng.fit_theta_grad(x, y, v, self.data_z, idx, batch_size, grad, loss)
                     eng.fit_theta_apply(grad, self._p['lr_theta'])
-                    lp, ls = self._z_and_prior_step(x, y, v, idx, seg_dev, self._p['lr_z'], self._p['lr_theta'], dz, loss_z)
-                    prior_sum += lp * batch_size
-                    std_sum += ls * batch_size
+                    self._z_and_prior_step(x, y, v, idx, seg_dev, self._p['lr_z'], self._p['lr_theta'], dz, loss_z, step_out)
+                    prior_acc += step_out                                                       # (device-side: no sync per minibatch)
                     n_rows += batch_size
+                prior_sum, std_sum = (float(a) * batch_size for a in prior_acc.cpu().numpy())
                 l = loss.cpu().numpy() / max(1, n_rows)
                 lz = loss_z.cpu().numpy() / max(1, n_rows)
                 post = float(lz[6]) + (prior_sum - std_sum) / max(1, n_rows)        # kernel sum carries |z|^2 / 2: exchange the prior term

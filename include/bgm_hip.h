@@ -83,6 +83,27 @@ int bgm_causal_set_precision(bgm_handle *h, int32_t mode);
  * every LOCAL row of those calls (int32), tab_dev [n_segments x (q + 2)] = per segment mu [q], 1 / sigma^2, (q / 2) log sigma^2.
  * Both NULL: back to the standard-normal prior.  The buffers must stay valid while set. */
 int bgm_causal_set_prior(bgm_handle *h, const int32_t *seg_dev, const float *tab_dev, int32_t n_segments);
+
+/* The prior network of IdentifiableCausalBGM, prior_net = BaseFullyConnectedNet(n_segments -> prior_units -> q + 1)
+ * (identifiable.py:76-78; LeakyReLU(0.2) hidden layers, linear output).  Parameters, gradients and Adam slots live in caller-owned
+ * device arrays in Keras order (W_0 [in x out] row-major, b_0, W_1, b_1, ...); bgm_prior_n_params gives their length. */
+typedef struct {
+  int32_t n_layers;          /* dense layers, 1..4 */
+  int32_t dims[5];           /* n_segments, prior_units..., q + 1 */
+} bgm_prior_config;
+int bgm_prior_n_params(const bgm_prior_config *cfg, int64_t *count);
+/* table_dev [n_segments x (q + 2)] = per segment mu [q], 1 / sigma^2, (q / 2) log sigma^2 with sigma^2 = softplus(out[q]) + 1e-6
+ * (identifiable.py:541-551): the tab_dev of bgm_causal_set_prior. */
+int bgm_prior_table(bgm_handle *h, const bgm_prior_config *cfg, const float *theta_dev, float *table_dev, void *stream);
+/* replaces: the conditional-prior half of update_latent_variable_sgd, identifiable.py:195-226.  dz_dev [batch x q] is the output of
+ * bgm_causal_fit_z_grad on the same rows (gradient of the batch-mean negative log joint with the standard-normal prior); the call
+ * exchanges the prior term (- z / B + (z - mu(u)) / (sigma^2(u) B)), applies the latent step with FRESH Adam slots and step count
+ * t_z (the batch latents are a new Variable in every minibatch, :304), and takes one Adam step (slots m_dev / v_dev, step count
+ * t_prior, learning rate lr_prior) on the prior net with the gradient of the batch-mean prior term.  seg_dev [n_rows]: segment of
+ * every row.  out_dev [2] (or NULL) = batch means of the conditional-prior term and of |z|^2 / 2. */
+int bgm_prior_step(bgm_handle *h, const bgm_prior_config *cfg, float *theta_dev, float *m_dev, float *v_dev, const int32_t *seg_dev,
+                   float *data_z_dev, const int32_t *idx_dev, int32_t batch, const float *dz_dev, float lr_z, float lr_prior,
+                   int64_t t_z, int64_t t_prior, float *out_dev, void *stream);
 int bgm_destroy(bgm_handle *h);
 
 /* Declare the model shape.  Synchronous.  replaces: CausalBGM.__init__ network

@@ -1,7 +1,7 @@
 """IdentifiableCausalBGM (models/causalbgm/identifiable.py of the reference): the conditional latent prior in
 the sampling kernels (through the C ABI: bgm_causal_set_prior) and the class's fit / predict against oracle/identifiable.py and
 oracle/causal.py (prior=...).  Tolerances as for the standard-prior kernels: log-posterior 2e-6 |lp| + 5e-4; chains identical on
->= 97 % of the rows; fit traces 2e-5 relative (torch fp32 prior-network ops on the host side of the ABI)."""
+>= 97 % of the rows; fit traces 2e-5 relative; the prior-network kernels (bgm_prior_table / bgm_prior_step) 1e-5."""
 import os
 
 import numpy as np
@@ -49,6 +49,78 @@ def test_conditional_prior_log_posterior_and_chains(case):
     eng.set_prior(None, None)
     lp0 = eng.logpost(x.ravel(), y.ravel(), v, z).cpu().numpy()
     assert np.all(np.abs(lp0 - std) <= 2e-6 * np.abs(std) + 2e-4)          # cleared: back to N(0, I)
+
+
+@pytest.mark.parametrize("units,k,B", [((64,), 10, 32), ((24, 40), 7, 17), ((), 5, 8), ((16, 16, 16), 3, 64)])
+def test_prior_network_kernels_match_oracle(units, k, B):
+    """bgm_prior_table and two consecutive bgm_prior_step calls (so that the Adam slots matter) against the float64 restatement of
+    identifiable.py:195-226 in oracle/identifiable.py: latent step with fresh slots, prior-net gradients through the one-hot first
+    layer, Adam on every prior parameter.  Shapes: the default, two hidden layers with an odd batch, no hidden layer, three."""
+    import ctypes as C
+    import torch
+    from bayesgm_amd import _lib
+    from oracle.nets import mlp_backward, sigmoid
+    from oracle.fit import AdamState, adam_lr_t, flat_params, flat_grads, B1, B2, ADAM_EPS
+    rs = np.random.RandomState(11)
+    z_dims, p, n = [1, 1, 1, 7], 20, 90
+    q = sum(z_dims)
+    eng = _engine(_model(5, z_dims, p, False))
+    dev = eng.device
+    pn32 = [(W, (0.3 * rs.randn(*b.shape)).astype(np.float32)) for W, b in OI.init_prior_net(rs, k, q, units)]
+    pn = [(W.astype(np.float64), b.astype(np.float64)) for W, b in pn32]
+    dims = [k] + list(units) + [q + 1]
+    cfg = _lib.PriorConfig(len(dims) - 1, (C.c_int32 * 5)(*(dims + [0] * (5 - len(dims)))))
+    cnt = C.c_int64()
+    _lib.check(eng.lib.bgm_prior_n_params(C.byref(cfg), C.byref(cnt)))
+    flat = np.concatenate([np.concatenate([W.ravel(), b.ravel()]) for W, b in pn32])
+    assert cnt.value == flat.size
+    theta = torch.from_numpy(flat).to(dev)
+    m_, v_ = torch.zeros_like(theta), torch.zeros_like(theta)
+    tab = torch.empty((k, q + 2), device=dev)
+    _lib.check(eng.lib.bgm_prior_table(eng.h, C.byref(cfg), theta.data_ptr(), tab.data_ptr(), None), "bgm_prior_table")
+    ref_tab = OI.prior_table(pn, q)
+    assert np.abs(tab.cpu().numpy() - ref_tab).max() <= 1e-5 * np.abs(ref_tab).max()
+    z = rs.randn(n, q)
+    seg = rs.randint(0, k, n)
+    zd = torch.from_numpy(z.astype(np.float32)).to(dev)
+    segd = torch.from_numpy(seg.astype(np.int32)).to(dev)
+    z64 = z.astype(np.float32).astype(np.float64)
+    opt = AdamState(flat_params(pn))
+    out = torch.zeros(2, device=dev)
+    lr_z, lr_p = 3e-3, 2e-3
+    used = []
+    for step, (tz, tp) in enumerate(((3, 5), (4, 6))):
+        idx = rs.choice(n, B, replace=False).astype(np.int32)
+        used.append(idx)
+        dz = rs.randn(B, q).astype(np.float32)
+        idx_d, dz_d = torch.from_numpy(idx).to(dev), torch.from_numpy(dz).to(dev)          # (held: the call takes raw pointers)
+        _lib.check(eng.lib.bgm_prior_step(eng.h, C.byref(cfg), theta.data_ptr(), m_.data_ptr(), v_.data_ptr(), segd.data_ptr(), zd.data_ptr(),
+                                          idx_d.data_ptr(), B, dz_d.data_ptr(), lr_z, lr_p, tz, tp, out.data_ptr(), None), "bgm_prior_step")
+        torch.cuda.synchronize()
+        zb = z64[idx].copy()
+        mu, s2, (o, cache) = OI.prior_params(pn, seg[idx])
+        d = zb - mu
+        ssq = (d ** 2).sum(axis=1)
+        loss_prior = (ssq / (2 * s2) + q * np.log(s2) / 2).mean()
+        g = dz.astype(np.float64) - zb / B + d / s2[:, None] / B
+        dout = np.zeros_like(o)
+        dout[:, :-1] = -d / s2[:, None] / B
+        dout[:, -1] = (-ssq / (2 * s2 * s2) + q / (2 * s2)) / B * sigmoid(o[:, -1])
+        pgrads, _ = mlp_backward(pn, cache, dout)
+        if step == 0:
+            opt.t = tp - 1                                   # the step counter the call was given
+        z64[idx] = zb - adam_lr_t(lr_z, tz) * ((1 - B1) * g) / (np.sqrt((1 - B2) * g * g) + ADAM_EPS)
+        opt.apply(flat_params(pn), flat_grads(pgrads), lr_p)
+        got = out.cpu().numpy()
+        assert abs(got[0] - loss_prior) <= 1e-5 * abs(loss_prior) + 1e-6 and abs(got[1] - 0.5 * (zb ** 2).sum(axis=1).mean()) <= 1e-5
+    # Adam normalises a step to ~lr whatever the gradient's size: compare against the distance moved (as the fit tests do)
+    ref_flat = np.concatenate([np.concatenate([W.ravel(), b.ravel()]) for W, b in pn])
+    moved = np.abs(ref_flat - flat).max()
+    assert moved > 1e-3 and np.abs(theta.cpu().numpy() - ref_flat).max() <= 2e-3 * moved
+    zmoved = np.abs(z64 - z.astype(np.float32)).max()
+    assert np.abs(zd.cpu().numpy() - z64).max() <= 2e-3 * zmoved
+    untouched = ~np.isin(np.arange(n), np.concatenate(used))
+    assert untouched.any() and np.array_equal(zd.cpu().numpy()[untouched], z.astype(np.float32)[untouched])
 
 
 def test_identifiable_fit_trace_and_predict():
@@ -118,8 +190,8 @@ def test_checkpoint_round_trip_restores_the_prior_network(tmp_path):
     for (Wa, ba), (Wb, bb) in zip(a.prior_parameters(), b.prior_parameters()):
         assert np.array_equal(Wa, Wb) and np.array_equal(ba, bb)
     assert (b._prior_t, b._z_t) == (a._prior_t, a._z_t) and a._prior_t > 0
-    for (ma, _), (mb, _) in zip(a._prior_m, b._prior_m):
-        assert np.array_equal(ma.cpu().numpy(), mb.cpu().numpy())
+    assert np.array_equal(a._prior_m.cpu().numpy(), b._prior_m.cpu().numpy()) and np.array_equal(a._prior_v.cpu().numpy(), b._prior_v.cpu().numpy())
+    assert float(a._prior_m.abs().max()) > 0
     got = b.get_log_posterior(x, y, v, z, u)
     assert np.array_equal(want, got)
     c = IdentifiableCausalBGM(prm, timestamp="other", random_seed=99)    # a fresh directory: a fresh prior network
