@@ -10,7 +10,8 @@ torch holds the arrays and nothing else.
 
 Stated differences.  (i) The reference's `fit` unpacks seven values from `evaluate`, which returns four (:334 vs base.py:555,570),
 so it fails at the first evaluation; the build evaluates as CausalBGM does.  (ii) `use_bnn=True` (a Bayesian prior network on the
-Bayesian-network kernels) is not built: NotImplementedError.  (iii) Single process only (no torch.distributed sharding)."""
+Bayesian-network kernels) is not built: NotImplementedError.  (iii) `fit` runs in a single process; `predict` shards the rows over
+the ranks of torch.distributed (fixed proposal scale)."""
 import ctypes as C
 
 import numpy as np
@@ -249,17 +250,30 @@ class IdentifiableCausalBGM(CausalBGM):
         eng = self.engine
         if verbose:
             print('MCMC Latent Variable Sampling ...')
-        segs = self._segments_for(n)
-        self._with_prior(torch.from_numpy(segs.astype(np.int32)).to(eng.device))
         adaptive = (q_sd is None) or (q_sd <= 0)
+        if adaptive and parallel.is_dist():
+            raise NotImplementedError("bayesgm_amd: IdentifiableCausalBGM.predict with the adaptive proposal scale (one acceptance window "
+                                      "over ALL rows, identifiable.py:585-606) runs in a single process; pass q_sd > 0 to shard the rows")
+        # fresh U for all rows (:563-564), drawn once: rank 0's draw is everybody's
+        seg_all = parallel.broadcast_(torch.from_numpy(self._segments_for(n).astype(np.int32)).to(eng.device))
+        lo_r, hi_r = parallel.shard_range(n)                       # a fixed proposal scale: chains are keyed by the global row
+        tab = self._prior_table()
+        eng.set_prior(seg_all[lo_r:hi_r].contiguous(), tab)
         try:
-            out = eng.mh_sample(self._dev(data_x).reshape(-1), self._dev(data_y).reshape(-1), self._dev(data_v), burn_in, n_mcmc, q_sd,
-                                self._next_seed(), effect=_lib.EFFECT_ITE if binary else _lib.EFFECT_ADRF, x_values=x_values,
-                                sample_y=sample_y, adaptive=adaptive)
+            out = eng.mh_sample(self._dev(data_x[lo_r:hi_r]).reshape(-1), self._dev(data_y[lo_r:hi_r]).reshape(-1), self._dev(data_v[lo_r:hi_r]),
+                                burn_in, n_mcmc, q_sd, self._next_seed(), effect=_lib.EFFECT_ITE if binary else _lib.EFFECT_ADRF,
+                                x_values=x_values, sample_y=sample_y, adaptive=adaptive, row_base=lo_r)
         finally:
             eng.set_prior(None, None)
         total = burn_in + n_mcmc
         self._report_acceptance(float(out["acc_count"][max(0, total - 100):].sum().item()), min(100, total), n, verbose)
-        eff = out["ite"] if binary else out["adrf"].contiguous()
+        if binary:
+            mean, lo, hi = eng.row_mean_quantiles(out["ite"], alpha / 2, 1 - alpha / 2)
+            res = torch.zeros((3, n), device=eng.device, dtype=torch.float32)
+            res[0, lo_r:hi_r], res[1, lo_r:hi_r], res[2, lo_r:hi_r] = mean, lo, hi
+            res = parallel.all_reduce_sum_(res).cpu().numpy()          # disjoint row sets: the sum is the gather
+            return res[0], np.stack([res[1], res[2]], axis=1)
+        sums = parallel.all_reduce_sum_(out["adrf"].double() * float(hi_r - lo_r))       # [n_doses x n_mcmc] draw sums over all rows
+        eff = (sums / float(n)).float().contiguous()
         mean, lo, hi = eng.row_mean_quantiles(eff, alpha / 2, 1 - alpha / 2)
         return mean.cpu().numpy(), torch.stack([lo, hi], dim=1).cpu().numpy()

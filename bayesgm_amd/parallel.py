@@ -36,6 +36,13 @@ def all_reduce_sum_(t):
     return t
 
 
+def broadcast_(t, src=0):
+    """In-place broadcast of a tensor from rank `src` (a host-side random draw every rank must agree on)."""
+    if is_dist():
+        dist.broadcast(t, src)
+    return t
+
+
 def all_reduce_max_(t):
     """In-place MAX all-reduce (no-op when not distributed)."""
     if is_dist():

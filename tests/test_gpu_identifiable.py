@@ -196,3 +196,41 @@ def test_checkpoint_round_trip_restores_the_prior_network(tmp_path):
     assert np.array_equal(want, got)
     c = IdentifiableCausalBGM(prm, timestamp="other", random_seed=99)    # a fresh directory: a fresh prior network
     assert not np.array_equal(c.prior_parameters()[0][0], a.prior_parameters()[0][0])
+
+
+def test_two_rank_predict_equals_the_single_process_predict():
+    """IdentifiableCausalBGM.predict under torch.distributed (two ranks on this GPU over gloo): rank 0's segment draw is broadcast,
+    rows are sharded, the ADRF draw sums / per-row ITE results reduced -- the result equals the single-process predict of the same
+    seeded model (chains keyed by the global row; only the order of the partial sums differs)."""
+    import json
+    from conftest import run_two_ranks
+    from bayesgm_amd.models import IdentifiableCausalBGM
+    from bayesgm_amd.datasets import Sim_Hirano_Imbens_sampler
+    r = run_two_ranks("dp_ident_smoke.py")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    objs, pos, dec = [], 0, json.JSONDecoder()
+    while True:
+        pos = r.stdout.find('{"rank"', pos)
+        if pos < 0:
+            break
+        o, end = dec.raw_decode(r.stdout[pos:])
+        objs.append(o)
+        pos += end
+    assert len(objs) == 2 and objs[0]["adrf"] == objs[1]["adrf"] and objs[0]["ite_sum"] == objs[1]["ite_sum"]
+    two = objs[0]
+    x, y, v = Sim_Hirano_Imbens_sampler(N=1205, v_dim=50, seed=1).load_all()
+
+    def params(binary):
+        return dict(dataset="dpi", output_dir="gpurun_out/dpi", save_res=False, save_model=False, binary_treatment=binary, use_bnn=False,
+                    z_dims=[1, 1, 1, 7], v_dim=50, lr_theta=1e-3, lr_z=1e-3, g_units=[64] * 5, f_units=[64, 32, 8], h_units=[64, 32, 8],
+                    e_units=[64] * 5, dz_units=[64, 32, 8], kl_weight=1e-4, lr=2e-4, g_d_freq=5, use_z_rec=True, n_segments=6)
+    m = IdentifiableCausalBGM(params(False), random_seed=2)
+    np.random.seed(5)
+    adrf, interval = m.predict((x, y, v), alpha=0.05, n_mcmc=40, burn_in=40, x_values=np.linspace(0, 3, 6), q_sd=0.5, verbose=0)
+    assert np.abs(np.array(two["adrf"]) - adrf).max() <= 1e-5 and np.abs(np.array(two["interval"]) - interval.ravel()).max() <= 1e-5
+    assert abs(two["acc"] - m.last_acceptance_rate) < 1e-12
+    mb = IdentifiableCausalBGM(params(True), random_seed=3)
+    np.random.seed(6)
+    ite, iv = mb.predict(((x > np.median(x)).astype(np.float32), y, v), alpha=0.05, n_mcmc=40, burn_in=40, q_sd=0.5, verbose=0)
+    assert np.abs(np.array(two["ite_head"]) - ite[:5]).max() <= 1e-6 and np.abs(np.array(two["ite_tail"]) - ite[-5:]).max() <= 1e-6
+    assert abs(two["ite_sum"] - float(ite.sum())) <= 1e-3 and abs(two["iv_sum"] - float(iv.sum())) <= 1e-3
