@@ -217,6 +217,72 @@ __global__ __launch_bounds__(256) void row_mean_quantiles_kernel(const float *in
   }
 }
 
+// More than 32768 values per row: no sort, the order statistics the two quantiles need are SELECTED -- four 8-bit radix passes
+// over the row (read from memory each pass) per order statistic, on an order-preserving integer image of the floats.
+__device__ __forceinline__ unsigned rq_key(float x) {
+  const unsigned u = __float_as_uint(x);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float rq_val(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
+
+__global__ __launch_bounds__(256) void row_mean_quantiles_select_kernel(const float *in, long long n_rows, int m, double q_lo,
+                                                                       double q_hi, float *mean, float *lo, float *hi) {
+  __shared__ double red[256];
+  __shared__ unsigned hist[256];
+  __shared__ unsigned sel_prefix, sel_rank;
+  for (long long row = blockIdx.x; row < n_rows; row += gridDim.x) {
+    const float *src = in + row * (long long)m;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < m; i += 256) s += (double)src[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+      if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+      __syncthreads();
+    }
+    const double qs[2] = {q_lo, q_hi};
+    float res[2];
+    for (int t = 0; t < 2; ++t) {
+      const double vi = qs[t] * (double)(m - 1);
+      int i0 = (int)floor(vi);
+      i0 = i0 < 0 ? 0 : (i0 > m - 1 ? m - 1 : i0);
+      const int i1 = i0 + 1 > m - 1 ? m - 1 : i0 + 1;
+      float v01[2];
+      for (int w = 0; w < 2; ++w) {
+        if (w == 1 && i1 == i0) { v01[1] = v01[0]; break; }
+        unsigned prefix = 0u, mask = 0u;
+        if (threadIdx.x == 0) sel_rank = (unsigned)(w ? i1 : i0);
+        for (int shift = 24; shift >= 0; shift -= 8) {
+          hist[threadIdx.x] = 0u;
+          __syncthreads();
+          for (int i = threadIdx.x; i < m; i += 256) {
+            const unsigned k = rq_key(src[i]);
+            if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+          }
+          __syncthreads();
+          if (threadIdx.x == 0) {
+            unsigned r = sel_rank, b = 0u;
+            while (r >= hist[b]) { r -= hist[b]; ++b; }
+            sel_rank = r;
+            sel_prefix = prefix | (b << shift);
+          }
+          __syncthreads();
+          prefix = sel_prefix;
+          mask |= 255u << shift;
+        }
+        v01[w] = rq_val(prefix);
+      }
+      res[t] = np_lerp(v01[0], v01[1], vi - (double)i0);
+    }
+    if (threadIdx.x == 0) {
+      mean[row] = (float)(red[0] / (double)m);
+      lo[row] = res[0];
+      hi[row] = res[1];
+    }
+    __syncthreads();
+  }
+}
+
 extern "C" int bgm_row_mean_quantiles(bgm_handle *h, const float *in, int64_t n_rows, int32_t m, double q_lo,
                                       double q_hi, float *mean, float *lo, float *hi, void *stream_) {
   if (!h || !in || !mean || !lo || !hi || m <= 0 || q_lo < 0 || q_lo > 1 || q_hi < 0 || q_hi > 1) {
@@ -226,8 +292,14 @@ extern "C" int bgm_row_mean_quantiles(bgm_handle *h, const float *in, int64_t n_
   int m_pow2 = 1;
   while (m_pow2 < m) m_pow2 <<= 1;
   if (m_pow2 < 2) m_pow2 = 2;
-  if (m_pow2 > 32768) { bgm_set_error("bgm_row_mean_quantiles: more than 32768 values per row not supported"); return BGM_E_UNSUPPORTED; }
   BGM_HIP_CHECK(hipSetDevice(h->device));
+  if (m_pow2 > 32768) {          // the row does not fit one workgroup's LDS sort: radix selection of the order statistics
+    const int grid = (int)std::min<int64_t>(n_rows, (int64_t)h->n_cus * 8);
+    hipLaunchKernelGGL(row_mean_quantiles_select_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream_, in, (long long)n_rows, m,
+                       q_lo, q_hi, mean, lo, hi);
+    BGM_HIP_CHECK(hipGetLastError());
+    return BGM_OK;
+  }
   const int lds = m_pow2 * 4;
   BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(row_mean_quantiles_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));

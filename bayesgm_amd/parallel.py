@@ -95,12 +95,11 @@ def shared_seed(random_seed):
     dist.broadcast_object_list(box, src=0)
     return int(box[0])
 
-MAX_INTERVAL_DRAWS = 32768   # bgm_row_mean_quantiles sorts one row of draws in LDS (aux_kernels.hip)
+MAX_INTERVAL_DRAWS = 1 << 24   # kept draws per row; bgm_row_mean_quantiles sorts a row in LDS up to 32768 values and selects the
+#                                order statistics by radix passes beyond (aux_kernels.hip); the bound is the iteration counter's headroom
 
 
 def check_n_mcmc(n_mcmc):
-    """predict() reduces n_mcmc kept draws per row to mean + posterior interval in one workgroup-local sort; say so before
-    the sampler has run rather than after."""
+    """predict() reduces n_mcmc kept draws per row to mean + posterior interval; reject a nonsensical count before the sampler runs."""
     if int(n_mcmc) < 1 or int(n_mcmc) > MAX_INTERVAL_DRAWS:
-        raise ValueError("n_mcmc must be in [1, %d] (the interval reduction sorts the draws of a row in LDS); got %r"
-                         % (MAX_INTERVAL_DRAWS, n_mcmc))
+        raise ValueError("n_mcmc must be in [1, %d]; got %r" % (MAX_INTERVAL_DRAWS, n_mcmc))

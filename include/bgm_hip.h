@@ -178,7 +178,8 @@ int bgm_adrf_reduce(bgm_handle *h, const float *partial_dev, int32_t n_slots, in
 
 /* Per-row mean and linear-interpolated quantiles over m contiguous values:
  * in [n_rows x m] -> mean [n_rows], lo [n_rows], hi [n_rows].
- * replaces: np.mean / np.quantile(..., axis) at causalbgm/base.py:640-642,664-666. */
+ * replaces: np.mean / np.quantile(..., axis) at causalbgm/base.py:640-642,664-666.  Any m: rows of up to 32768 values are sorted
+ * in LDS, longer rows have their order statistics selected by radix passes over memory (same results). */
 int bgm_row_mean_quantiles(bgm_handle *h, const float *in_dev, int64_t n_rows, int32_t m,
                            double q_lo, double q_hi, float *mean_dev, float *lo_dev,
                            float *hi_dev, void *stream);

@@ -195,9 +195,13 @@ def test_row_quantiles_edge_cases():
     from bayesgm_amd.engine import CausalEngine
     eng = CausalEngine(20, [1, 1, 1, 7])
     rs = np.random.RandomState(0)
-    for m_, ql, qh in ((1, 0.1, 0.9), (2, 0.25, 0.75), (3000, 0.005, 0.995), (4096, 0.0, 1.0), (777, 0.5, 0.5)):
+    # up to 32768 values per row: LDS sort; beyond: radix selection of the order statistics (negative values, ties, constants)
+    for m_, ql, qh in ((1, 0.1, 0.9), (2, 0.25, 0.75), (3000, 0.005, 0.995), (4096, 0.0, 1.0), (777, 0.5, 0.5), (32768, 0.005, 0.995),
+                       (32769, 0.005, 0.995), (70001, 0.025, 0.975), (100000, 0.0, 1.0), (65536, 0.5, 0.5)):
         a = rs.randn(9, m_).astype(np.float32)
         a[0] = 3.0  # constant row
+        if m_ > 10:
+            a[1, ::3] = np.round(a[1, ::3], 1)      # ties
         t = torch.from_numpy(a).cuda()
         mean, lo, hi = eng.row_mean_quantiles(t, ql, qh)
         assert np.allclose(mean.cpu().numpy(), a.mean(axis=1), atol=2e-6)

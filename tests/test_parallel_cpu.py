@@ -242,10 +242,11 @@ def test_shared_seed_is_one_value_on_every_rank():
 
 
 def test_check_n_mcmc_limits():
-    """predict() rejects a draw count the interval reduction cannot hold before any sampling happens."""
+    """predict() rejects a nonsensical draw count before any sampling happens; 32768 is no longer a limit."""
     from bayesgm_amd import parallel
     parallel.check_n_mcmc(1)
     parallel.check_n_mcmc(parallel.MAX_INTERVAL_DRAWS)
+    parallel.check_n_mcmc(100000)
     for bad in (0, parallel.MAX_INTERVAL_DRAWS + 1):
         with pytest.raises(ValueError, match="n_mcmc"):
             parallel.check_n_mcmc(bad)
