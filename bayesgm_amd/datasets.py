@@ -105,6 +105,43 @@ class Sim_Hirano_Imbens_sampler(Base_sampler):
         Base_sampler.__init__(self, x[:, None], y[:, None], v, batch_size=batch_size, normalize=True)
 
 
+class Sim_Sun_sampler(Base_sampler):
+    """Sun et al. dose-response simulation (configs/Sim_Sun.yaml of the reference).
+
+    Draw order on the stream seeded with ``seed``: V ~ N(0, 1) [N x v_dim] row-major; x_i ~ N(m_i, 1) with
+    m_i = -2 sin(2 v_i0) + v_i1^2 - 1/3 + v_i2 - 1/2 + cos(v_i3); y_i ~ N(v_i0 - 1/2 + cos(v_i1) + v_i4^2 + v_i5 + x_i, 1).  V is then
+    standardised per column.  True dose-response: utils.get_ADRF(dataset='Sun')."""
+
+    def __init__(self, batch_size=32, N=20000, v_dim=200, seed=0):
+        rs = np.random.RandomState(seed)
+        v = rs.normal(0, 1, size=(N, v_dim))
+        x = rs.normal(-2 * np.sin(2 * v[:, 0]) + (v[:, 1] ** 2 - 1 / 3) + (v[:, 2] - 1 / 2) + np.cos(v[:, 3]), 1)
+        y = rs.normal((v[:, 0] - 1 / 2) + np.cos(v[:, 1]) + v[:, 4] ** 2 + v[:, 5] + x, 1)
+        Base_sampler.__init__(self, x[:, None], y[:, None], v, batch_size=batch_size, normalize=True)
+
+
+class Sim_Colangelo_sampler(Base_sampler):
+    """Colangelo-Lee dose-response simulation (configs/Sim_Colangelo.yaml of the reference).
+
+    Draw order on the stream seeded with ``seed``: eps ~ N(0, 1) [N], nu ~ N(0, 1) [N], THEN V ~ N(0, Sigma) [N x v_dim] with the
+    tridiagonal Sigma (1 on the diagonal, ``rho`` beside it; NumPy's multivariate_normal, i.e. through an SVD of Sigma).  With
+    theta_l = 1 / l^2: x = d Phi(a V theta) + b nu - 1/2, y = 1.2 x + x^3 + x v_0 + 1.2 V theta + eps.  V is then standardised per
+    column.  True dose-response: utils.get_ADRF(dataset='Lee')."""
+
+    def __init__(self, batch_size=32, N=20000, v_dim=100, seed=0, rho=0.5, offset=(-1, 0, 1), d=1, a=3, b=0.75):
+        from scipy.special import ndtr
+        rs = np.random.RandomState(seed)
+        sigma = sum(np.diag(np.full(v_dim - abs(o), val), o) for o, val in zip(offset, (rho, 1.0, rho)))
+        theta = 1.0 / np.arange(1, v_dim + 1) ** 2
+        eps = rs.normal(0, 1, N)
+        nu = rs.normal(0, 1, N)
+        v = rs.multivariate_normal(np.zeros(v_dim), sigma, size=[N, ])
+        lin = v @ theta
+        x = d * ndtr(a * lin) + b * nu - 0.5
+        y = 1.2 * x + x ** 3 + x * v[:, 0] + 1.2 * lin + eps
+        Base_sampler.__init__(self, x[:, None], y[:, None], v, batch_size=batch_size, normalize=True)
+
+
 class Gaussian_sampler(object):
     """Isotropic Gaussian prior sampler N(mean, sd^2 I), float32.
 

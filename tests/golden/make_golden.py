@@ -89,6 +89,15 @@ def main():
     np.savez_compressed(os.path.join(HERE, "z_hetero_n2000.npz"), X=X.astype(np.float32),
                         Y=Y.astype(np.float32), X_sha64=np.array(sha(X)), Y_sha64=np.array(sha(Y)))
 
+    # the other continuous-treatment simulators of the YAML configs (Sim_Sun.yaml, Sim_Colangelo.yaml)
+    from bayesgm.datasets import Sim_Sun_sampler, Sim_Colangelo_sampler
+    sims = {}
+    for name, cls, kw in (("sun", Sim_Sun_sampler, dict(N=1500, v_dim=12, seed=2)),
+                          ("colangelo", Sim_Colangelo_sampler, dict(N=1200, v_dim=9, seed=4))):
+        sx, sy, sv = cls(**kw).load_all()
+        sims[name + "_x"], sims[name + "_y"], sims[name + "_v"] = sx, sy, sv
+    np.savez_compressed(os.path.join(HERE, "sun_colangelo.npz"), **sims)
+
     # Base_sampler batching on a tiny deterministic panel, incl. the wrap-around batch
     xx = np.arange(10, dtype=np.float32)
     bs = Base_sampler(xx, xx * 2, np.stack([xx, -xx], 1), batch_size=4, normalize=False)
