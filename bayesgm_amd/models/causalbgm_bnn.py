@@ -162,37 +162,21 @@ class CausalBGMBayes(CausalBGM):
         seed = self._noise_seed()
         try:
             # Blocks of iterations up to and including the next evaluation point.  The host random numbers of block k + 1 are drawn
-            # (reference order, host_rng / NumPy) on a worker thread while the GPU runs block k and its evaluation pass: nothing
-            # else touches np.random in between, so the global stream is consumed exactly as in the sequential loop.
+            # (reference order) on a worker thread, on a PRIVATE copy of the generator state, while the GPU runs block k and its
+            # evaluation pass; np.random's global state moves only here, at hand-over, to where the sequential loop would have left
+            # it (host_rng.EgmDrawPipeline: a block is redrawn if anything consumed np.random in between).
             blocks, bi = [], 0
             while bi <= egm_n_iter:
                 stop = min(egm_n_iter, (bi // egm_batches_per_eval + 1) * egm_batches_per_eval if bi % egm_batches_per_eval else bi)
                 blocks.append((bi, stop))
                 bi = stop + 1
 
-            def draw(n_it):
-                if n <= 200000 or batch_size * 20 > n:     # np.random.choice's full permutation, in C (bit-identical)
-                    idx_h, z_h, eps3 = host_rng.egm_block(n, batch_size, q, n_it, g_d_freq)
-                    return idx_h, z_h, eps3[:, :, 0]
-                idx_h = np.empty((n_it, steps, batch_size), np.int32)
-                z_h = np.empty((n_it, steps, batch_size, q), np.float32)
-                eps_h = np.empty((n_it, g_d_freq), np.float64)
-                for i in range(n_it):
-                    for j in range(g_d_freq):
-                        idx_h[i, j] = self._choice_no_replace(n, batch_size)
-                        z_h[i, j] = self.z_sampler.get_batch(batch_size)
-                        eps_h[i, j] = np.random.uniform(0.0, 1.0)
-                    z_h[i, g_d_freq] = self.z_sampler.get_batch(batch_size)
-                    idx_h[i, g_d_freq] = self._choice_no_replace(n, batch_size)
-                return idx_h, z_h, eps_h
-
-            from concurrent.futures import ThreadPoolExecutor
-            pool = ThreadPoolExecutor(max_workers=1)
-            pending = pool.submit(draw, blocks[0][1] - blocks[0][0] + 1)
+            pipe = host_rng.EgmDrawPipeline(n, batch_size, q, g_d_freq)
+            pipe.request(blocks[0][1] - blocks[0][0] + 1)
             for kb, (batch_iter, stop) in enumerate(blocks):
                 n_it = stop - batch_iter + 1
-                idx_h, z_h, eps_h = pending.result()
-                pending = pool.submit(draw, blocks[kb + 1][1] - blocks[kb + 1][0] + 1) if kb + 1 < len(blocks) else None
+                idx_h, z_h, eps3 = pipe.take(blocks[kb + 1][1] - blocks[kb + 1][0] + 1 if kb + 1 < len(blocks) else 0)
+                eps_h = eps3[:, :, 0]
                 idx_d, z_d = torch.from_numpy(idx_h).to(dev), torch.from_numpy(z_h).to(dev)
                 for i in range(n_it):
                     for j in range(g_d_freq):
@@ -209,8 +193,8 @@ class CausalBGMBayes(CausalBGM):
                     if self._p['save_res'] and parallel.rank() == 0:
                         save_data('{}/causal_pre_egm_init_iter-{}.txt'.format(self.save_dir, batch_iter), causal_pre)
         finally:
-            if 'pool' in locals():
-                pool.shutdown(wait=True)
+            if 'pipe' in locals():
+                pipe.close()
             eng.egm_end()
             self._pull_weights()
         if verbose:
