@@ -275,8 +275,13 @@ class CausalBGM(object):
         n_use = n_total // world if world > 1 else n_loc
         eng = self.engine
         n_params = eng.fit_begin(n_loc, b_loc)
-        if self._restored_opt is not None and len(self._restored_opt["m"]) == n_params:
-            eng.fit_state(self._restored_opt)          # g / f / h_optimizer slots and step counters of the restored checkpoint
+        if self._restored_opt is not None:
+            if len(self._restored_opt["m"]) == n_params:
+                eng.fit_state(self._restored_opt)      # g / f / h_optimizer slots and step counters of the restored checkpoint
+            else:
+                import warnings
+                warnings.warn("bayesgm_amd: the restored checkpoint's optimizer slots (%d values) do not match this model's %d "
+                              "parameters and are discarded: the fit starts with fresh Adam state" % (len(self._restored_opt["m"]), n_params))
         self._restored_opt = None
         self._fit_live = (zm, zv)
         grad = torch.empty(n_params, device=dev, dtype=torch.float32)
@@ -343,7 +348,7 @@ class CausalBGM(object):
     def save_checkpoint(self, epoch):
         """ckpt_manager.save(epoch) (base.py:527-529).  The archive holds what the reference's tf.train.Checkpoint tracks
         (:112-122) -- the parameters of g, e, f, h, and, when written from inside `fit`, the Adam slots and step counters of the
-        g / f / h optimizers and of the latent optimizer -- plus the latent table itself (this rank's rows); at most 5 are kept."""
+        g / f / h optimizers and the latent optimizer's step counter; at most 5 are kept."""
         flat = {}
         for k, net in self.nets.items():
             for i, (W, b) in enumerate(net):
@@ -351,8 +356,9 @@ class CausalBGM(object):
                 flat["%s_b%d" % (k, i)] = b
         if self._fit_live is not None:
             st = self.engine.fit_state()
-            flat.update(opt_m=st["m"], opt_v=st["v"], opt_steps=np.array([st["t_theta"], st["t_z"]], np.int64),
-                        data_z=self.data_z.cpu().numpy(), z_m=self._fit_live[0].cpu().numpy(), z_v=self._fit_live[1].cpu().numpy())
+            # (the latent table and its slots are not among the objects the reference's tf.train.Checkpoint tracks, :112-122: a
+            # restored model re-initialises Z with e(V) or N(0, I) in fit, as the reference does -- they are not written)
+            flat.update(opt_m=st["m"], opt_v=st["v"], opt_steps=np.array([st["t_theta"], st["t_z"]], np.int64))
         flat["seed_state"] = np.array([self._base_seed, self._seed_counter], np.int64)
         flat.update(self._checkpoint_extra())
         path = self.ckpt_manager.save("ckpt-%s.npz" % epoch, flat)
