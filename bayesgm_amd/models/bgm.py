@@ -287,7 +287,10 @@ class BGM(object):
         return np.float32(sse.item() / (n_all * data_loc.shape[1]))
 
     def save_checkpoint(self, epoch):
-        """Counterpart of g_net.save_weights(...) (bgm/base.py:431-434): generator parameters as .npz."""
+        """Counterpart of g_net.save_weights(...) (bgm/base.py:431-434): generator parameters as .npz.  The reference's BGM builds a
+        tf.train.CheckpointManager (max_to_keep=100, restore-latest at construction, bgm/base.py:108-121) but its fit / egm_init
+        never call ckpt_manager.save -- they write these weight files (:335-336, :433) -- so no managed checkpoint ever exists and
+        nothing is auto-restored; the plain files here are that behaviour, not an omission."""
         path = os.path.join(self.checkpoint_path, "weights_at_%s_generator.npz" % epoch)
         flat = {"bn_" + k: v for k, v in self.g["bn"].items()}
         for i, (W, b) in enumerate(self.g["trunk"]):

@@ -308,7 +308,10 @@ class BGMBayes(BGM):
         self._sync_g()
 
     def save_checkpoint(self, epoch):
-        """Counterpart of g_net.save_weights(...) (bgm/base.py:431-434): generator parameters as .npz."""
+        """Counterpart of g_net.save_weights(...) (bgm/base.py:431-434): generator parameters as .npz.  The reference's BGM builds a
+        tf.train.CheckpointManager (max_to_keep=100, restore-latest at construction, bgm/base.py:108-121) but its fit / egm_init
+        never call ckpt_manager.save -- they write these weight files (:335-336, :433) -- so no managed checkpoint ever exists and
+        nothing is auto-restored; the plain files here are that behaviour, not an omission."""
         path = os.path.join(self.checkpoint_path, "weights_at_%s_generator.npz" % epoch)
         g = self._sync_g()
         flat = {k: g[k] for k in ("gamma", "beta", "mean_mv", "var_mv")}
