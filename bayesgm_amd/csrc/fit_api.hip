@@ -105,13 +105,14 @@ static int fit_chain_setup(bgm_handle *h, const std::vector<float> &theta) {
 }
 // one launch of the chains; Z_MODE 0 also the gradient tiles into `grad`
 static void fit_chain_launch(const FitChainState *c, FitChainArgs &a, int batch, int z_mode, hipStream_t stream) {
+  static const bool one_wg_ = std::getenv("BGM_FIT_ONE_WG") != nullptr;
   a.n_valid = batch;                                 // rows of this minibatch; the tile rows behind them are masked
   const int nb = batch <= 16 ? 1 : 2;                // row tiles (the padded / two-k-tile instantiations are compiled for two only)
 #define FC(NTL_, NB_) \
   if (c->ntl == NTL_ && nb == NB_) { \
     if (z_mode) hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, NB_, 1>), dim3(1), dim3(ECH_THREADS), 0, stream, a); \
     else { \
-      hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, NB_, 0>), dim3(1), dim3(ECH_THREADS), 0, stream, a); \
+      hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, NB_, 0>), dim3(1, one_wg_ ? 1 : 3), dim3(ECH_THREADS), 0, stream, a); \
       hipLaunchKernelGGL(fit_chain_dw_kernel<NB_>, dim3((a.n_tiles + ECH_WAVES - 1) / ECH_WAVES), dim3(ECH_THREADS), 0, stream, a); \
     } \
   }
@@ -129,6 +130,23 @@ static void fit_chain_launch(const FitChainState *c, FitChainArgs &a, int batch,
       hipLaunchKernelGGL((fit_chain_kernel<4, 13, 4, 2, 1, 2, 0, true>), dim3(1), dim3(ECH_THREADS), 0, stream, a);
       hipLaunchKernelGGL(fit_chain_dw_kernel<2>, dim3((a.n_tiles + ECH_WAVES - 1) / ECH_WAVES), dim3(ECH_THREADS), 0, stream, a);
     }
+    return;
+  }
+  // 17..32 rows: the two row tiles on two workgroups -- on one CU the six chain waves share one address unit for their weight
+  // streams (83.0 -> 77.4 us per minibatch at N = 1e6) -- and, in the theta phase (no cross-network term), one network per workgroup
+  // as well (-> 75.8 us); the gradient tiles run over both row tiles as before.  BGM_FIT_ONE_WG=1: everything in one workgroup (dev A/B)
+  static const bool one_wg = std::getenv("BGM_FIT_ONE_WG") != nullptr;
+  if (nb == 2 && !one_wg && (c->ntl == 13 || c->ntl == 7)) {
+#define FS(NTL_) \
+    if (c->ntl == NTL_) { \
+      if (z_mode) hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, 1, 1>), dim3(2), dim3(ECH_THREADS), 0, stream, a); \
+      else { \
+        hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, 1, 0>), dim3(2, 3), dim3(ECH_THREADS), 0, stream, a); \
+        hipLaunchKernelGGL(fit_chain_dw_kernel<2>, dim3((a.n_tiles + ECH_WAVES - 1) / ECH_WAVES), dim3(ECH_THREADS), 0, stream, a); \
+      } \
+    }
+    FS(13) FS(7)
+#undef FS
     return;
   }
   FC(13, 2) FC(13, 1) FC(7, 2) FC(7, 1)

@@ -50,8 +50,9 @@ static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_kernel(FitChainA
   constexpr int B = 16 * NB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const int role = wave >> 1, tile = wave & 1;
-  const bool active = tile < NB && role < 3;
-  const int row = 16 * tile + j;
+  const bool active = tile < NB && role < 3 && (gridDim.y == 1 || role == (int)blockIdx.y);     // gridDim.y = 3: one network per workgroup
+  const int rb = 16 * NB * (int)blockIdx.x;          // a minibatch may be split over workgroups (blockIdx.x: NB row tiles each): rows rb ..
+  const int row = rb + 16 * tile + j;
   const float mk = row < a.n_valid ? 1.0f : 0.0f;       // short minibatches (the last one of an epoch, a rank's share under data parallelism)
   const int q = a.q, p = a.p, z0 = a.z0, z1 = a.z1, z2 = a.z2;
   const float *th = a.theta, *tT = a.thetaT;
@@ -166,8 +167,8 @@ static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_kernel(FitChainA
       if (Z_MODE == 1) *reinterpret_cast<f32x4 *>(dzc + (role * 32 + row) * ZW + 4 * g) = dx[0];
     }
   }
-  if (Z_MODE == 1 && a.pos && tid >= 384 && tid - 384 < min(B, a.n_valid)) {      // row -> batch position map of the dense Adam step that follows
-    const int b = tid - 384;
+  if (Z_MODE == 1 && a.pos && tid >= 384 && tid - 384 < min(B, a.n_valid - rb)) {      // row -> batch position map of the dense Adam step that follows
+    const int b = rb + tid - 384;
     const long long r_ = fitc_row(a, b);
     a.pos[r_] = b; a.pos[a.pos_n + r_] = a.epoch;
   }
@@ -192,8 +193,8 @@ static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_kernel(FitChainA
   }
   __syncthreads();
   if (Z_MODE == 1) {
-    for (int i = tid; i < min(B, a.n_valid) * q; i += ECH_THREADS) {
-      const int b = i / q, col = i - b * q;
+    for (int i0 = tid; i0 < min(B, a.n_valid - rb) * q; i0 += ECH_THREADS) {
+      const int b = rb + i0 / q, col = i0 % q, i = b * q + col;
       float v = a.data_z[fitc_row(a, b) * q + col] * a.inv_B + dzc[(0 * 32 + b) * ZW + col];
       if (col < z0 + z1) v += dzc[(1 * 32 + b) * ZW + col];                                  // f: (z0, z1, x)
       if (col < z0) v += dzc[(2 * 32 + b) * ZW + col];                                       // h: (z0, z2)
