@@ -23,6 +23,7 @@ template <bool KL>
 static __global__ __launch_bounds__(BNN_THREADS) void bnn_fit_noise_kernel(BnnArgs a, const EcbTab *tab, float *ws) {
   __shared__ float red[16];
   ecb_gen_noise<BnnArgs>(a, *tab, ws);
+  if (KL && blockIdx.x == 0 && threadIdx.x < 6 && a.out) a.out[threadIdx.x] = 0.0f;      // the chain workgroups accumulate into it
   if (KL) {     // theta step: the value of the KL term, summed by the chain kernel (one call per net there)
     const int c = blockIdx.x / ECB_NOISE_PARTS, part = blockIdx.x % ECB_NOISE_PARTS;
     ecb_kl_partial(a.theta, a.net[tab->c[c].net], ws + tab->klp + blockIdx.x, part, ECB_NOISE_PARTS, red);
@@ -264,7 +265,12 @@ extern "C" int bgm_bnn_theta_step(bgm_handle *h, const float *data_z, const int3
     auto kc = fc->t0 == 2 ? bnn_theta_chain_kernel<13, 2, true, 2> : fc->pad ? bnn_theta_chain_kernel<13, 2, true>
               : batch == 32 ? (fc->ntl == 13 ? bnn_theta_chain_kernel<13, 2> : bnn_theta_chain_kernel<7, 2>)
                           : (fc->ntl == 13 ? bnn_theta_chain_kernel<13, 1> : bnn_theta_chain_kernel<7, 1>);
-    hipLaunchKernelGGL(kc, dim3(1), dim3(BNN_THREADS), 64 * sizeof(float), st, a, fc->tab_theta, fc->ws);
+    static const bool one_wg = std::getenv("BGM_FIT_ONE_WG") != nullptr;
+    if (batch == 32 && !fc->pad && fc->t0 == 1 && !one_wg) {      // row tiles and networks on their own workgroups (see ecb_theta_chain)
+      auto ks = fc->ntl == 13 ? bnn_theta_chain_kernel<13, 1> : bnn_theta_chain_kernel<7, 1>;
+      hipLaunchKernelGGL(ks, dim3(2, 3), dim3(BNN_THREADS), 64 * sizeof(float), st, a, fc->tab_theta, fc->ws);
+    } else
+      hipLaunchKernelGGL(kc, dim3(1), dim3(BNN_THREADS), 64 * sizeof(float), st, a, fc->tab_theta, fc->ws);
     auto kd = batch == 32 ? bnn_theta_dw_kernel<2> : bnn_theta_dw_kernel<1>;
     hipLaunchKernelGGL(kd, dim3((fc->n_tiles + ECH_WAVES - 1) / ECH_WAVES + 1), dim3(BNN_THREADS), 0, st, a, fc->tab_theta, fc->tiles_theta, fc->ws);
   } else {

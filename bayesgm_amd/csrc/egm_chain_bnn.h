@@ -805,8 +805,10 @@ template <class Args, int HT, int NTL, int T1, int T2, int T3, int NB, bool PAD 
 __device__ __forceinline__ void ecb_theta_chain(const Args &a, const EcbTab &tab, float *ws, float *lds) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const int q = a.q, p = a.p;
-  const int role = wave >> 1, tile = wave & 1;
-  const bool active = tile < NB;
+  // a minibatch may be spread over workgroups: blockIdx.x owns NB row tiles, blockIdx.y (gridDim.y = 3) one network -- on one CU the
+  // six chain waves share one address unit for their weight streams; a.out is then accumulated (zeroed by the noise launch)
+  const int role = wave >> 1, ltile = wave & 1, tile = NB * (int)blockIdx.x + ltile;
+  const bool active = ltile < NB && (gridDim.y == 1 || role == (int)blockIdx.y);
   const int row = 16 * tile + j;
   const float *th = a.theta;
   float *part = lds;                 // [8 waves][4]: loss, aux
@@ -880,8 +882,14 @@ __device__ __forceinline__ void ecb_theta_chain(const Args &a, const EcbTab &tab
     for (int t = 0; t < ECB_NOISE_PARTS; ++t) kl += ws[tab.klp + tid * ECB_NOISE_PARTS + t];
     float l0 = 0.0f, l1 = 0.0f;
     for (int w = 2 * tid; w < 2 * tid + NB; ++w) { l0 += part[w * 4]; l1 += part[w * 4 + 1]; }
-    a.out[2 * tid] = l0 * a.inv_B + a.kl_weight * kl;
-    a.out[2 * tid + 1] = tid == 0 ? l1 * a.inv_B / (float)p : l1 * a.inv_B;
+    const bool kl_here = blockIdx.x == 0 && (gridDim.y == 1 || (int)blockIdx.y == tid);
+    if (gridDim.x * gridDim.y == 1) {
+      a.out[2 * tid] = l0 * a.inv_B + a.kl_weight * kl;
+      a.out[2 * tid + 1] = tid == 0 ? l1 * a.inv_B / (float)p : l1 * a.inv_B;
+    } else {
+      atomicAdd(a.out + 2 * tid, l0 * a.inv_B + (kl_here ? a.kl_weight * kl : 0.0f));
+      atomicAdd(a.out + 2 * tid + 1, tid == 0 ? l1 * a.inv_B / (float)p : l1 * a.inv_B);
+    }
   }
 }
 
