@@ -23,7 +23,7 @@ template <bool KL>
 static __global__ __launch_bounds__(BNN_THREADS) void bnn_fit_noise_kernel(BnnArgs a, const EcbTab *tab, float *ws) {
   __shared__ float red[16];
   ecb_gen_noise<BnnArgs>(a, *tab, ws);
-  if (KL && blockIdx.x == 0 && threadIdx.x < 6 && a.out) a.out[threadIdx.x] = 0.0f;      // the chain workgroups accumulate into it
+  if (blockIdx.x == 0 && threadIdx.x < (KL ? 6 : 1) && a.out) a.out[threadIdx.x] = 0.0f;      // the chain workgroups accumulate into it
   if (KL) {     // theta step: the value of the KL term, summed by the chain kernel (one call per net there)
     const int c = blockIdx.x / ECB_NOISE_PARTS, part = blockIdx.x % ECB_NOISE_PARTS;
     ecb_kl_partial(a.theta, a.net[tab->c[c].net], ws + tab->klp + blockIdx.x, part, ECB_NOISE_PARTS, red);
@@ -330,7 +330,13 @@ extern "C" int bgm_bnn_z_step(bgm_handle *h, const float *x, const float *y, con
     auto kc = fc->t0 == 2 ? bnn_z_chain_kernel<13, 2, true, 2> : fc->pad ? bnn_z_chain_kernel<13, 2, true>
               : batch == 32 ? (fc->ntl == 13 ? bnn_z_chain_kernel<13, 2> : bnn_z_chain_kernel<7, 2>)
                           : (fc->ntl == 13 ? bnn_z_chain_kernel<13, 1> : bnn_z_chain_kernel<7, 1>);
-    hipLaunchKernelGGL(kc, dim3(1), dim3(BNN_THREADS), (32 + 2 * batch + 4 * 16 * fc->t0 * batch) * sizeof(float), stream, a, fc->tab_z, fc->ws);
+    static const bool one_wg = std::getenv("BGM_FIT_ONE_WG") != nullptr;
+    const size_t lds_z = (32 + 2 * batch + 4 * 16 * fc->t0 * batch) * sizeof(float);
+    if (batch == 32 && !fc->pad && fc->t0 == 1 && !one_wg) {      // one row tile per workgroup (see ecb_z_chain)
+      auto ks = fc->ntl == 13 ? bnn_z_chain_kernel<13, 1> : bnn_z_chain_kernel<7, 1>;
+      hipLaunchKernelGGL(ks, dim3(2), dim3(BNN_THREADS), lds_z, stream, a, fc->tab_z, fc->ws);
+    } else
+      hipLaunchKernelGGL(kc, dim3(1), dim3(BNN_THREADS), lds_z, stream, a, fc->tab_z, fc->ws);
   } else {
     hipLaunchKernelGGL(bnn_z_grad_kernel, dim3(3), dim3(BNN_THREADS), 0, stream, a);
     hipLaunchKernelGGL(bnn_z_combine_kernel, dim3((batch * s->q + 255) / 256), dim3(256), 0, stream, a.dz_part, a.loss_part, a.dz, out, batch * s->q);

@@ -976,9 +976,11 @@ __device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, fl
   constexpr int B = 16 * NB, ZW = 16 * T0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const int q = a.q, p = a.p, z0 = a.z0, z1 = a.z1, z2 = a.z2;
-  const int role = wave >> 1, tile = wave & 1;
-  const bool active = tile < NB;
-  const int row = 16 * tile + j;
+  // blockIdx.x owns NB row tiles of the minibatch (two workgroups of one tile each instead of one of two: the chain waves of a CU share
+  // its address unit): `lt` / `lrow` index this workgroup's LDS, `tile` / `row` the minibatch
+  const int role = wave >> 1, lt = wave & 1, tile = NB * (int)blockIdx.x + lt;
+  const bool active = lt < NB;
+  const int lrow = 16 * lt + j, row = 16 * tile + j;
   const float *th = a.theta;
   float *part = lds;                                   // [8 waves] loss partials
   volatile int *flag = reinterpret_cast<volatile int *>(lds + 16);    // [0 + tile]: ssq written; [2 + tile]: raw written
@@ -1010,12 +1012,12 @@ __device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, fl
           o[t][r] = d;
         }
       ssq = sum_over_g(ssq);
-      if (g == 0) xch[row] = ssq;
+      if (g == 0) xch[lrow] = ssq;
       __threadfence_block();
-      if (lane == 0) flag[tile] = 1;
-      while (flag[2 + tile] == 0) __builtin_amdgcn_s_sleep(2);
+      if (lane == 0) flag[lt] = 1;
+      while (flag[2 + lt] == 0) __builtin_amdgcn_s_sleep(2);
       __threadfence_block();
-      const float raw = xch[B + row];
+      const float raw = xch[B + lrow];
       float lb, s2;
       ecb_gauss(ssq, raw, (float)p, lb, s2);
       lsum = lb;
@@ -1029,12 +1031,12 @@ __device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, fl
       f32x4 o[NTL];
       ecb_mlp_fwd<T0, HT, NTL, PAD>(th, G, tab.c[1], ws, row, zin, o, j, g);
       const float raw = ecb_pick<NTL>(o, p, g);
-      if (g == 0) xch[B + row] = raw;
+      if (g == 0) xch[B + lrow] = raw;
       __threadfence_block();
-      if (lane == 0) flag[2 + tile] = 1;
-      while (flag[tile] == 0) __builtin_amdgcn_s_sleep(2);
+      if (lane == 0) flag[2 + lt] = 1;
+      while (flag[lt] == 0) __builtin_amdgcn_s_sleep(2);
       __threadfence_block();
-      const float ssq = xch[row];
+      const float ssq = xch[lrow];
       float lb, s2;
       const float dr = ecb_gauss(ssq, raw, (float)p, lb, s2);
 #pragma unroll
@@ -1076,7 +1078,7 @@ __device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, fl
       }
     }
 #pragma unroll
-    for (int t = 0; t < T0; ++t) *reinterpret_cast<f32x4 *>(dzc + (role * B + row) * ZW + 16 * t + 4 * g) = dx[t];
+    for (int t = 0; t < T0; ++t) *reinterpret_cast<f32x4 *>(dzc + (role * B + lrow) * ZW + 16 * t + 4 * g) = dx[t];
     if (role == 0) {            // the prior term of the row
       float zz = 0.0f;
 #pragma unroll
@@ -1091,9 +1093,10 @@ __device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, fl
     if (j == 15 && g == 0) part[wave] = s0;
   }
   __syncthreads();
-  for (int i = tid; i < B * q; i += ECH_THREADS) {
-    const int b = i / q, col = i - b * q;
-    float v = a.data_z[(long long)a.idx[b] * q + col] * a.inv_B + dzc[(0 * B + b) * ZW + col] + dzc[(1 * B + b) * ZW + col];
+  const int rb = B * (int)blockIdx.x;
+  for (int i0 = tid; i0 < B * q; i0 += ECH_THREADS) {
+    const int b = i0 / q, col = i0 - b * q, i = (rb + b) * q + col;
+    float v = a.data_z[(long long)a.idx[rb + b] * q + col] * a.inv_B + dzc[(0 * B + b) * ZW + col] + dzc[(1 * B + b) * ZW + col];
     if (col < z0 + z1) v += dzc[(3 * B + b) * ZW + col];                                  // f: (z0, z1, x)
     if (col < z0) v += dzc[(2 * B + b) * ZW + col];                                       // h: (z0, z2)
     else if (col >= z0 + z1 && col < z0 + z1 + z2) v += dzc[(2 * B + b) * ZW + col - z1];
@@ -1102,7 +1105,8 @@ __device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, fl
   if (tid == 0 && a.out) {
     float t = 0.0f;
     for (int w = 0; w < 8; ++w) if ((w & 1) < NB) t += part[w];
-    a.out[0] = t * a.inv_B;
+    if (gridDim.x == 1) a.out[0] = t * a.inv_B;
+    else atomicAdd(a.out, t * a.inv_B);             // (zeroed by the noise launch)
   }
 }
 
