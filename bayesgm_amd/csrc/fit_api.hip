@@ -136,12 +136,16 @@ static void fit_chain_launch(const FitChainState *c, FitChainArgs &a, int batch,
   // streams (83.0 -> 77.4 us per minibatch at N = 1e6) -- and, in the theta phase (no cross-network term), one network per workgroup
   // as well (-> 75.8 us); the gradient tiles run over both row tiles as before.  BGM_FIT_ONE_WG=1: everything in one workgroup (dev A/B)
   static const bool one_wg = std::getenv("BGM_FIT_ONE_WG") != nullptr;
+  static const bool no_ws = std::getenv("BGM_FIT_NO_WORKERS") != nullptr;      // dev A/B: g's last layer on the chain wave alone
   if (nb == 2 && !one_wg && (c->ntl == 13 || c->ntl == 7)) {
 #define FS(NTL_) \
     if (c->ntl == NTL_) { \
-      if (z_mode) hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, 1, 1>), dim3(2), dim3(ECH_THREADS), 0, stream, a); \
-      else { \
-        hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, 1, 0>), dim3(2, 3), dim3(ECH_THREADS), 0, stream, a); \
+      if (z_mode) { \
+        if (no_ws) hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, 1, 1>), dim3(2), dim3(ECH_THREADS), 0, stream, a); \
+        else hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, 1, 1, false, 1, true>), dim3(2), dim3(ECH_THREADS), 0, stream, a); \
+      } else { \
+        if (no_ws) hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, 1, 0>), dim3(2, 3), dim3(ECH_THREADS), 0, stream, a); \
+        else hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, 1, 0, false, 1, true>), dim3(2, 3), dim3(ECH_THREADS), 0, stream, a); \
         hipLaunchKernelGGL(fit_chain_dw_kernel<2>, dim3((a.n_tiles + ECH_WAVES - 1) / ECH_WAVES), dim3(ECH_THREADS), 0, stream, a); \
       } \
     }

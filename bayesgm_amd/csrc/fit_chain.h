@@ -42,11 +42,22 @@ __device__ __forceinline__ long long fitc_row(const FitChainArgs &a, int b) {
 
 // Z_MODE 0: theta phase (stash, no input gradients); 1: latent phase (input gradients -> dz)
 // T0: latent input tiles of g (q <= 16 T0); the head networks' inputs (z0 + z1 + 1, z0 + z2) stay within one tile
-template <int HT, int NTL, int T1, int T2, int T3, int NB, int Z_MODE, bool PAD = false, int T0 = 1>
+// WS (one row tile per workgroup, HT = 4, T0 = 1): g's last layer -- 13 of the chain's ~60 output tiles but 40 % of its time, a
+// straight line of 2 x 208 dependent MFMAs -- is spread over the workgroup's idle waves.  The chain wave publishes the last hidden
+// activation in LDS; it and the waves 1, 3, 5 each take one column group of four output tiles: forward product, their part of the
+// row's residual sum (met in LDS), the output gradients of their columns (stashed for the gradient-tile kernel) and their share
+// of the backward product into the hidden layer, summed by the chain wave, which walks on.  Three LDS flags order the phases.
+template <int HT, int NTL, int T1, int T2, int T3, int NB, int Z_MODE, bool PAD = false, int T0 = 1, bool WS = false>
 static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_kernel(FitChainArgs a) {
   constexpr int ZW = 16 * T0;
   __shared__ float dzc[3 * 32 * ZW];
   __shared__ double lsum[8 * 8];
+  constexpr int NW = WS ? (NTL + 3) / 4 : 1;           // column groups of g's last layer = worker waves
+  __shared__ float ws_h[WS ? 16 * 64 : 4];
+  __shared__ float ws_part[2][WS ? 4 : 1][16];
+  __shared__ float ws_dh[WS ? 4 : 1][WS ? 16 * 64 : 4];
+  __shared__ int ws_flag[4];
+  static_assert(!WS || (NB == 1 && HT == 4 && T0 == 1 && !PAD), "worker split: one plain row tile per workgroup");
   constexpr int B = 16 * NB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const int role = wave >> 1, tile = wave & 1;
@@ -59,7 +70,159 @@ static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_kernel(FitChainA
   float *ws = a.ws;
   float l0 = 0.0f, l1 = 0.0f, l2 = 0.0f;          // this wave's loss terms per row: (nll, sse) of its net; role 0 also 0.5 |z|^2
   FITC_T(0);
-  if (active) {
+  if constexpr (WS) {
+    if (tid < 4) ws_flag[tid] = 0;
+    __syncthreads();
+    const int wk = wave == 0 ? 0 : ((wave & 1) && wave < 6 ? 1 + (wave >> 1) : -1);       // waves 0 | 1, 3, 5
+    if ((gridDim.y == 1 || blockIdx.y == 0) && wk >= 0 && wk < NW) {
+#define FITC_WAIT(f, need) { while (__hip_atomic_load(&ws_flag[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (need)) __builtin_amdgcn_s_sleep(1); __threadfence_block(); }
+#define FITC_POST(f) { __threadfence_block(); if (lane == 0) __hip_atomic_fetch_add(&ws_flag[f], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+      const EgmMlp &G = a.g;
+      const int L = G.n_layers, no = G.dims[L];
+      const int wrow = rb + j;
+      const float wmk = wrow < a.n_valid ? 1.0f : 0.0f;
+      const long long prow = fitc_row(a, wrow);
+      const float *vrow = a.v + prow * p;
+      f32x4 vv[4];                                   // this worker's four tiles of the data row, requested first (a trip to HBM)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vv[t][r] = ech_ld(vrow, 64 * wk + 16 * t + 4 * g + r, p);
+      f32x4 h[4], zin[1];
+      if (wk == 0) {                                 // the chain wave: input, first layer, hidden layers (ecg_g_fwd up to the last layer)
+        const float *zrow = a.data_z + prow * q;
+        float zsq = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { zin[0][r] = ech_ld(zrow, 4 * g + r, q); zsq = fmaf(zin[0][r], zin[0][r], zsq); }
+        l2 = wmk * 0.5f * sum_over_g(zsq);
+        FITC_T(1);
+        ecg_put<1>(ws + a.xo[0][0], wrow, g, zin);
+        {
+          EcgA<4> A, Ad;
+          EcgW w{th + G.woff[0], 64, q, 64, 0};
+          ecg_prime<4, true>(w, A, j, g);
+          ech_zero<4>(h);
+          ecg_sub<1, 4, 4, true, true>(w, zin, h, A, w, Ad, j, g);
+          ecg_bias<4>(w.W + q * 64, 64, 0, g, h);
+          ecg_lrelu<4>(h);
+        }
+        ecg_hidden_fwd<4>(th, G, a.xo[0], ws, wrow, h, j, g);
+        ecg_put<4>(ws + a.xo[0][L - 1], wrow, g, h);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4 *>(ws_h + j * 64 + 16 * t + 4 * g) = h[t];
+        FITC_POST(0);
+      } else {
+        FITC_WAIT(0, 1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) h[t] = *reinterpret_cast<const f32x4 *>(ws_h + j * 64 + 16 * t + 4 * g);
+      }
+      // forward of this worker's column group
+      const float *Wl = th + G.woff[L - 1];
+      f32x4 o4[4];
+      ech_zero<4>(o4);
+      {
+        EcgW w{Wl, no, 64, no, 64 * wk};
+        EcgA<4> A, Ad;
+        ecg_prime<4, false>(w, A, j, g);
+        ecg_sub<4, 4, 4, false, false>(w, h, o4, A, w, Ad, j, g);
+      }
+      ecg_bias<4>(Wl + 64 * no, no, 64 * wk, g, o4);
+      FITC_T(5);
+      float ssq = 0.0f, sraw = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 64 * wk + 16 * t + 4 * g + r;
+          const float d = f < p ? vv[t][r] - o4[t][r] : 0.0f;
+          ssq = fmaf(d, d, ssq);
+          sraw += f == p ? o4[t][r] : 0.0f;
+          o4[t][r] = d;
+        }
+      ssq = sum_over_g(ssq);
+      sraw = sum_over_g(sraw);
+      if (g == 0) { ws_part[0][wk][j] = ssq; ws_part[1][wk][j] = sraw; }
+      FITC_POST(1);
+      FITC_WAIT(1, NW);
+      ssq = 0.0f; sraw = 0.0f;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) { ssq += ws_part[0][k][j]; sraw += ws_part[1][k][j]; }
+      float s2, dsraw;
+      if (a.sig2_v > 0.0f) { s2 = a.sig2_v; dsraw = 0.0f; }
+      else {
+        s2 = softplus_acc(sraw) + BGM_EPS;
+        dsraw = wmk * (-ssq / (2.0f * s2 * s2) + 0.5f * (float)p / s2) * a.inv_B * sigmoid_f(sraw);
+      }
+      if (wk == 0) {
+        l0 = wmk * (ssq / (2.0f * s2) + 0.5f * (float)p * logf(s2));
+        l1 = wmk * ssq;
+      }
+      const float cmu = -wmk * a.inv_B / s2;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 64 * wk + 16 * t + 4 * g + r;
+          o4[t][r] = f < p ? cmu * o4[t][r] : (f == p ? dsraw : 0.0f);
+        }
+        if (4 * wk + t < NTL) *reinterpret_cast<f32x4 *>(ws + a.dofs[0][L - 1] + (long long)wrow * (16 * NTL) + 16 * (4 * wk + t) + 4 * g) = o4[t];
+      }
+      FITC_T(6);
+      // this worker's share of dh = W_last^T dout: the K range is its 64 output columns (rows of the mirror), clamped to the matrix
+      {
+        const float *WT = tT + G.woff[L - 1];
+        f32x4 dh[4];
+        ech_zero<4>(dh);
+        float av[2][4][4];
+        auto ld = [&](int t, float (&x)[4][4]) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float *wr = WT + (long long)min(64 * wk + 16 * t + 4 * g + r, no - 1) * 64 + j;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[r][u] = wr[16 * u];
+          }
+        };
+        ld(0, av[0]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (t + 1 < 4) ld(t + 1, av[(t + 1) & 1]);
+          BGM_NO_HOIST();
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dh[u] = BGM_MFMA(av[t & 1][r][u], o4[t][r], dh[u]);
+          BGM_NO_HOIST();
+        }
+        if (wk != 0) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4 *>(&ws_dh[wk][j * 64 + 16 * u + 4 * g]) = dh[u];
+          FITC_POST(2);
+        } else {
+          FITC_WAIT(2, NW - 1);
+#pragma unroll
+          for (int k = 1; k < NW; ++k)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dh[u] += *reinterpret_cast<const f32x4 *>(&ws_dh[k][j * 64 + 16 * u + 4 * g]);
+          ecg_mask<4>(dh, h);
+          FITC_T(7);
+          ecg_hidden_bwd<4>(tT, G, a.xo[0], a.dofs[0], ws, wrow, dh, j, g);
+          FITC_T(8);
+          ecg_put<4>(ws + a.dofs[0][0], wrow, g, dh);
+          if (Z_MODE == 1) {
+            f32x4 dx[1];
+            EcgA<1> A, Ad;
+            EcgW w{tT + G.woff[0], q, 64, q, 0};           // W^T [H x q]
+            ecg_prime<1, false>(w, A, j, g);
+            ech_zero<1>(dx);
+            ecg_sub<4, 1, 1, false, false>(w, dh, dx, A, w, Ad, j, g);
+            *reinterpret_cast<f32x4 *>(dzc + wrow * ZW + 4 * g) = dx[0];
+          }
+          FITC_T(9);
+        }
+      }
+    }
+  }
+  if (active && !(WS && role == 0)) {
     const long long prow = fitc_row(a, row);
     const float xv = a.x[prow], yv = a.y[prow];
     const float *zrow = a.data_z + prow * q;
