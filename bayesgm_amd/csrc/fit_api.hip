@@ -153,6 +153,19 @@ static void fit_chain_launch(const FitChainState *c, FitChainArgs &a, int batch,
 #undef FS
     return;
   }
+  if (nb == 1 && !one_wg && !no_ws && (c->ntl == 13 || c->ntl == 7)) {      // <= 16 rows (a rank's share under data parallelism): the same worker split
+#define FW(NTL_) \
+    if (c->ntl == NTL_) { \
+      if (z_mode) hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, 1, 1, false, 1, true>), dim3(1), dim3(ECH_THREADS), 0, stream, a); \
+      else { \
+        hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, 1, 0, false, 1, true>), dim3(1, 3), dim3(ECH_THREADS), 0, stream, a); \
+        hipLaunchKernelGGL(fit_chain_dw_kernel<1>, dim3((a.n_tiles + ECH_WAVES - 1) / ECH_WAVES), dim3(ECH_THREADS), 0, stream, a); \
+      } \
+    }
+    FW(13) FW(7)
+#undef FW
+    return;
+  }
   FC(13, 2) FC(13, 1) FC(7, 2) FC(7, 1)
 #undef FC
 #ifdef FITC_CLOCK
