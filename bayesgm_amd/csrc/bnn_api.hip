@@ -29,10 +29,10 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_fit_noise_kernel(BnnAr
     ecb_kl_partial(a.theta, a.net[tab->c[c].net], ws + tab->klp + blockIdx.x, part, ECB_NOISE_PARTS, red);
   }
 }
-template <int NTL, int NB, bool PAD = false, int T0 = 1>
+template <int NTL, int NB, bool PAD = false, int T0 = 1, bool WS = false>
 static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_chain_kernel(BnnArgs a, const EcbTab *tab, float *ws) {
   extern __shared__ __attribute__((aligned(16))) float bnn_chain_lds[];
-  ecb_theta_chain<BnnArgs, 4, NTL, 4, 2, 1, NB, PAD, T0>(a, *tab, ws, bnn_chain_lds);
+  ecb_theta_chain<BnnArgs, 4, NTL, 4, 2, 1, NB, PAD, T0, WS>(a, *tab, ws, bnn_chain_lds);
 }
 template <int NB>
 static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_dw_kernel(BnnArgs a, const EcbTab *tab, const int *tiles, const float *ws) {
@@ -267,8 +267,14 @@ extern "C" int bgm_bnn_theta_step(bgm_handle *h, const float *data_z, const int3
                           : (fc->ntl == 13 ? bnn_theta_chain_kernel<13, 1> : bnn_theta_chain_kernel<7, 1>);
     static const bool one_wg = std::getenv("BGM_FIT_ONE_WG") != nullptr;
     if (batch == 32 && !fc->pad && fc->t0 == 1 && !one_wg) {      // row tiles and networks on their own workgroups (see ecb_theta_chain)
-      auto ks = fc->ntl == 13 ? bnn_theta_chain_kernel<13, 1> : bnn_theta_chain_kernel<7, 1>;
-      hipLaunchKernelGGL(ks, dim3(2, 3), dim3(BNN_THREADS), 64 * sizeof(float), st, a, fc->tab_theta, fc->ws);
+      static const bool no_ws = std::getenv("BGM_FIT_NO_WORKERS") != nullptr;
+      if (no_ws) {
+        auto ks = fc->ntl == 13 ? bnn_theta_chain_kernel<13, 1> : bnn_theta_chain_kernel<7, 1>;
+        hipLaunchKernelGGL(ks, dim3(2, 3), dim3(BNN_THREADS), 64 * sizeof(float), st, a, fc->tab_theta, fc->ws);
+      } else {      // g's last layer over the idle waves of its workgroup (ecb_theta_chain<WS>)
+        auto ks = fc->ntl == 13 ? bnn_theta_chain_kernel<13, 1, false, 1, true> : bnn_theta_chain_kernel<7, 1, false, 1, true>;
+        hipLaunchKernelGGL(ks, dim3(2, 3), dim3(BNN_THREADS), ECB_WS_LDS_FLOATS * sizeof(float), st, a, fc->tab_theta, fc->ws);
+      }
     } else
       hipLaunchKernelGGL(kc, dim3(1), dim3(BNN_THREADS), 64 * sizeof(float), st, a, fc->tab_theta, fc->ws);
     auto kd = batch == 32 ? bnn_theta_dw_kernel<2> : bnn_theta_dw_kernel<1>;

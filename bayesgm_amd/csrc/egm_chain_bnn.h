@@ -217,11 +217,12 @@ __device__ __forceinline__ void ecb_add_bias(const float *bias, int n, int g, f3
 
 // Flipout MLP with hidden width 16 HT (g: KT0 = 1, NTO = output tiles; e: KT0 = input tiles, NTO = 1): forward with stash.
 // xraw: the raw input tiles (zero beyond dims[0]).
-template <int KT0, int HT, int NTO, bool PAD = false>
-__device__ __forceinline__ void ecb_mlp_fwd(const float *theta, const BnnNet &n, const EcbCall &C, float *ws, int row, const f32x4 (&xraw)[KT0],
-                                            f32x4 (&out)[NTO], int j, int g) {
+// ecb_mlp_fwd_hidden: everything up to the input (h, flipped copy hs) of the last layer, stashed; ecb_mlp_fwd adds the last layer.
+template <int KT0, int HT, bool PAD = false>
+__device__ __forceinline__ void ecb_mlp_fwd_hidden(const float *theta, const BnnNet &n, const EcbCall &C, float *ws, int row, const f32x4 (&xraw)[KT0],
+                                                   f32x4 (&h)[HT], f32x4 (&hs)[HT], int j, int g) {
   constexpr int H = 16 * HT;
-  const int L = n.n_layers, d0 = n.dims[0], no = n.dims[L];
+  const int L = n.n_layers, d0 = n.dims[0];
   const uint32_t *roww = reinterpret_cast<const uint32_t *>(ws + C.sg) + (long long)row * n.swords;
   const float *dW = ws + C.dW;
   const float *gamma = theta + n.off, *beta = gamma + d0;
@@ -239,7 +240,6 @@ __device__ __forceinline__ void ecb_mlp_fwd(const float *theta, const BnnNet &n,
   ecg_put<KT0>(ws + C.xh, row, g, xh);
   ecg_put<KT0>(ws + C.x[0], row, g, h0);
   ecg_put<KT0>(ws + C.xs[0], row, g, hs0);
-  f32x4 h[HT], hs[HT];
   {
     const float *loc = theta + n.woff[0];
     ecb_pair<KT0, HT, true>(loc, dW + n.eoff[0], H, d0, H, roww, n.sout_w[0], h0, hs0, h, j, g);
@@ -267,6 +267,16 @@ __device__ __forceinline__ void ecb_mlp_fwd(const float *theta, const BnnNet &n,
   }
   ecg_put<HT>(ws + C.x[L - 1], row, g, h);
   ecg_put<HT>(ws + C.xs[L - 1], row, g, hs);
+}
+template <int KT0, int HT, int NTO, bool PAD = false>
+__device__ __forceinline__ void ecb_mlp_fwd(const float *theta, const BnnNet &n, const EcbCall &C, float *ws, int row, const f32x4 (&xraw)[KT0],
+                                            f32x4 (&out)[NTO], int j, int g) {
+  constexpr int H = 16 * HT;
+  const int L = n.n_layers, no = n.dims[L];
+  const uint32_t *roww = reinterpret_cast<const uint32_t *>(ws + C.sg) + (long long)row * n.swords;
+  const float *dW = ws + C.dW;
+  f32x4 h[HT], hs[HT];
+  ecb_mlp_fwd_hidden<KT0, HT, PAD>(theta, n, C, ws, row, xraw, h, hs, j, g);
   const float *loc = theta + n.woff[L - 1];
   ecb_pair<HT, NTO, false, false, PAD>(loc, dW + n.eoff[L - 1], no, H, no, roww, n.sout_w[L - 1], h, hs, out, j, g);
   ecb_add_bias<NTO>(loc + 2 * H * no, no, g, out);
@@ -274,14 +284,19 @@ __device__ __forceinline__ void ecb_mlp_fwd(const float *theta, const BnnNet &n,
 
 // backward with stash.  dout: dLoss/d output (zero beyond n_out).  dxraw (WANT_DX): dLoss/d raw input.  The per-row products for the
 // input normalisation's gamma / beta are summed over the tile's rows into bnp [2][16 KT0] (this tile's slot).
+// ecb_mlp_bwd_hidden: from dh = dLoss / d(pre-activation of layer L - 2) (already masked) down to the input; ecb_mlp_bwd runs the last
+// layer's backward product first.
+template <int KT0, int HT, bool WANT_DX, bool PAD = false>
+__device__ __forceinline__ void ecb_mlp_bwd_hidden(const float *theta, const BnnNet &n, const EcbCall &C, float *ws, int row, int tile, f32x4 (&dh)[HT],
+                                                   f32x4 (&dxraw)[KT0], int j, int g);
 template <int KT0, int HT, int NTO, bool WANT_DX, bool PAD = false>
 __device__ __forceinline__ void ecb_mlp_bwd(const float *theta, const float *thetaT, const BnnNet &n, const EcbCall &C, float *ws, int row, int tile,
                                             const f32x4 (&dout)[NTO], f32x4 (&dxraw)[KT0], int j, int g) {
   constexpr int H = 16 * HT;
-  const int L = n.n_layers, d0 = n.dims[0], no = n.dims[L];
+  const int L = n.n_layers, no = n.dims[L];
   const uint32_t *roww = reinterpret_cast<const uint32_t *>(ws + C.sg) + (long long)row * n.swords;
   const float *dW = ws + C.dW;
-  f32x4 dh[HT], dhs[HT], xl[HT];
+  f32x4 dh[HT], xl[HT];
   {
     f32x4 douts[NTO];
     ecb_flip<NTO>(roww, n.sout_w[L - 1], g, dout, douts);
@@ -291,6 +306,17 @@ __device__ __forceinline__ void ecb_mlp_bwd(const float *theta, const float *the
     ecg_get<HT>(ws + C.x[L - 1], row, g, xl);
     ecg_mask<HT>(dh, xl);
   }
+  ecb_mlp_bwd_hidden<KT0, HT, WANT_DX, PAD>(theta, n, C, ws, row, tile, dh, dxraw, j, g);
+  (void)thetaT;
+}
+template <int KT0, int HT, bool WANT_DX, bool PAD>
+__device__ __forceinline__ void ecb_mlp_bwd_hidden(const float *theta, const BnnNet &n, const EcbCall &C, float *ws, int row, int tile, f32x4 (&dh)[HT],
+                                                   f32x4 (&dxraw)[KT0], int j, int g) {
+  constexpr int H = 16 * HT;
+  const int L = n.n_layers, d0 = n.dims[0];
+  const uint32_t *roww = reinterpret_cast<const uint32_t *>(ws + C.sg) + (long long)row * n.swords;
+  const float *dW = ws + C.dW;
+  f32x4 dhs[HT], xl[HT];
   for (int l = L - 2; l >= 1; --l) {
     BGM_NO_HOIST();
     ecb_flip<HT>(roww, n.sout_w[l], g, dh, dhs);
@@ -801,7 +827,11 @@ __device__ __forceinline__ void ecb_inputs(const float *zrow, float xv, int q, i
   }
 }
 
-template <class Args, int HT, int NTL, int T1, int T2, int T3, int NB, bool PAD = false, int T0 = 1>
+// WS (NB = 1, HT = 4, T0 = 1): g's last layer on the workgroup's idle waves, as fit_chain_kernel<WS> does for the deterministic nets --
+// here every column group is TWO products (loc and the call's perturbation) and two sign flips.  LDS behind the 64 loss words:
+// h | hs [16 x 64 each] | residual partials [2][4][16] | backward partials [4][16 x 64] | three counters.
+#define ECB_WS_LDS_FLOATS (64 + 2 * 1024 + 128 + 4 * 1024 + 8)
+template <class Args, int HT, int NTL, int T1, int T2, int T3, int NB, bool PAD = false, int T0 = 1, bool WS = false>
 __device__ __forceinline__ void ecb_theta_chain(const Args &a, const EcbTab &tab, float *ws, float *lds) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const int q = a.q, p = a.p;
@@ -813,7 +843,130 @@ __device__ __forceinline__ void ecb_theta_chain(const Args &a, const EcbTab &tab
   const float *th = a.theta;
   float *part = lds;                 // [8 waves][4]: loss, aux
   float ls0 = 0.0f, ls1 = 0.0f;
-  if (role < 3 && active) {
+  if constexpr (WS) {
+    static_assert(NB == 1 && HT == 4 && T0 == 1 && !PAD, "worker split: one plain row tile per workgroup");
+    constexpr int NW = (NTL + 3) / 4;
+    float *hb = lds + 64, *hsb = hb + 1024, *pp = hsb + 1024, *dhp = pp + 128;
+    int *fl = reinterpret_cast<int *>(dhp + 4096);
+    if (tid < 8) fl[tid] = 0;
+    __syncthreads();
+#define ECB_WAIT(f, need) { while (__hip_atomic_load(fl + (f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (need)) __builtin_amdgcn_s_sleep(1); __threadfence_block(); }
+#define ECB_POST(f) { __threadfence_block(); if (lane == 0) __hip_atomic_fetch_add(fl + (f), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    const int wk = wave == 0 ? 0 : ((wave & 1) && wave < 6 ? 1 + (wave >> 1) : -1);       // waves 0 | 1, 3, 5
+    if ((gridDim.y == 1 || blockIdx.y == 0) && wk >= 0 && wk < NW) {
+      const BnnNet &G = a.net[BNN_G];
+      const EcbCall &C = tab.c[0];
+      const int L = G.n_layers, no = G.dims[L];
+      const int wrow = 16 * (int)blockIdx.x + j;
+      const long long prow = a.idx[wrow];
+      const uint32_t *roww = reinterpret_cast<const uint32_t *>(ws + C.sg) + (long long)wrow * G.swords;
+      const float *loc = th + G.woff[L - 1], *dWl = ws + C.dW + G.eoff[L - 1];
+      f32x4 vv[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vv[t][r] = ech_ld(a.v_ + prow * p, 64 * wk + 16 * t + 4 * g + r, p);
+      f32x4 h[4], hs[4];
+      if (wk == 0) {
+        f32x4 zin[1], fin[1], hin[1];
+        ecb_inputs<1>(a.data_z + prow * q, a.x_[prow], q, a.z0, a.z1, a.z2, g, zin, fin, hin);
+        ecb_mlp_fwd_hidden<1, 4, false>(th, G, C, ws, wrow, zin, h, hs, j, g);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          *reinterpret_cast<f32x4 *>(hb + j * 64 + 16 * t + 4 * g) = h[t];
+          *reinterpret_cast<f32x4 *>(hsb + j * 64 + 16 * t + 4 * g) = hs[t];
+        }
+        ECB_POST(0);
+      } else {
+        ECB_WAIT(0, 1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          h[t] = *reinterpret_cast<const f32x4 *>(hb + j * 64 + 16 * t + 4 * g);
+          hs[t] = *reinterpret_cast<const f32x4 *>(hsb + j * 64 + 16 * t + 4 * g);
+        }
+      }
+      f32x4 o4[4], c2[4], c2s[4];
+      ech_zero<4>(o4);
+      ech_zero<4>(c2);
+      {
+        const EcgW w1{loc, no, 64, no, 64 * wk}, w2{dWl, no, 64, no, 64 * wk};
+        EcgA<4> A, Ad, Ad2;
+        ecg_prime<4, false>(w1, A, j, g);
+        ecg_sub<4, 4, 4, false, false>(w1, h, o4, A, w2, Ad, j, g);
+        ecg_sub<4, 4, 4, false, false>(w2, hs, c2, Ad, w2, Ad2, j, g);
+      }
+      ecb_flip<4>(roww, G.sout_w[L - 1] + 2 * wk, g, c2, c2s);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) o4[u] += c2s[u];
+      ecg_bias<4>(loc + 2 * 64 * no, no, 64 * wk, g, o4);
+      float ssq = 0.0f, raw = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 64 * wk + 16 * t + 4 * g + r;
+          const float d = f < p ? vv[t][r] - o4[t][r] : 0.0f;
+          ssq = fmaf(d, d, ssq);
+          raw += f == p ? o4[t][r] : 0.0f;
+          o4[t][r] = d;
+        }
+      ssq = sum_over_g(ssq);
+      raw = sum_over_g(raw);
+      if (g == 0) { pp[wk * 16 + j] = ssq; pp[64 + wk * 16 + j] = raw; }
+      ECB_POST(1);
+      ECB_WAIT(1, NW);
+      ssq = 0.0f; raw = 0.0f;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) { ssq += pp[k * 16 + j]; raw += pp[64 + k * 16 + j]; }
+      float lb, s2;
+      const float dr = ecb_gauss(ssq, raw, (float)p, lb, s2);
+      if (wk == 0) { ls0 = lb; ls1 = ssq; }
+      f32x4 douts[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 64 * wk + 16 * t + 4 * g + r;
+          o4[t][r] = f < p ? -o4[t][r] / s2 * a.inv_B : (f == p ? dr * a.inv_B : 0.0f);
+        }
+      ecb_flip<4>(roww, G.sout_w[L - 1] + 2 * wk, g, o4, douts);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (4 * wk + t < NTL) {
+          *reinterpret_cast<f32x4 *>(ws + C.d[L - 1] + (long long)wrow * (16 * NTL) + 16 * (4 * wk + t) + 4 * g) = o4[t];
+          *reinterpret_cast<f32x4 *>(ws + C.ds[L - 1] + (long long)wrow * (16 * NTL) + 16 * (4 * wk + t) + 4 * g) = douts[t];
+        }
+      // backward partial over this worker's 64 output features (K-contiguous reads of the canonical arrays, offset by 64 wk)
+      f32x4 dh[4];
+      {
+        const EcgW w1{loc + 64 * wk, no, no, 64, 0}, w2{dWl + 64 * wk, no, no, 64, 0};
+        EcgA<4> A, Ad, Ad2;
+        ecg_prime<4, true, true>(w1, A, j, g);
+        ech_zero<4>(dh);
+        ech_zero<4>(c2);
+        ecg_sub<4, 4, 4, true, true, true, true>(w1, o4, dh, A, w2, Ad, j, g);
+        ecg_sub<4, 4, 4, true, true, true, true>(w2, douts, c2, Ad, w2, Ad2, j, g);
+        ecb_flip<4>(roww, G.sin_w[L - 1], g, c2, c2s);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) dh[u] += c2s[u];
+      }
+      if (wk != 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4 *>(dhp + wk * 1024 + j * 64 + 16 * u + 4 * g) = dh[u];
+        ECB_POST(2);
+      } else {
+        ECB_WAIT(2, NW - 1);
+#pragma unroll
+        for (int k = 1; k < NW; ++k)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) dh[u] += *reinterpret_cast<const f32x4 *>(dhp + k * 1024 + j * 64 + 16 * u + 4 * g);
+        ecg_mask<4>(dh, h);
+        f32x4 dnone[1];
+        ecb_mlp_bwd_hidden<1, 4, false, false>(th, G, C, ws, wrow, (int)blockIdx.x, dh, dnone, j, g);
+      }
+    }
+  }
+  if (role < 3 && active && !(WS && role == 0)) {
     const long long prow = a.idx[row];
     const float xv = a.x_[prow], yv = a.y_[prow];
     f32x4 zin[T0], fin[1], hin[1];
