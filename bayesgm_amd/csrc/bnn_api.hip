@@ -38,10 +38,10 @@ template <int NB>
 static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_dw_kernel(BnnArgs a, const EcbTab *tab, const int *tiles, const float *ws) {
   ecb_theta_dw<BnnArgs, NB>(a, *tab, tiles, ws);
 }
-template <int NTL, int NB, bool PAD = false, int T0 = 1>
+template <int NTL, int NB, bool PAD = false, int T0 = 1, bool WS = false>
 static __global__ __launch_bounds__(BNN_THREADS) void bnn_z_chain_kernel(BnnArgs a, const EcbTab *tab, float *ws) {
   extern __shared__ __attribute__((aligned(16))) float bnn_chain_lds[];
-  ecb_z_chain<BnnArgs, 4, NTL, 4, 2, 1, NB, PAD, T0>(a, *tab, ws, bnn_chain_lds);
+  ecb_z_chain<BnnArgs, 4, NTL, 4, 2, 1, NB, PAD, T0, WS>(a, *tab, ws, bnn_chain_lds);
 }
 static void bnn_chain_free(BnnState *s) {
   BnnFitChain *c = static_cast<BnnFitChain *>(s->chain);
@@ -339,8 +339,15 @@ extern "C" int bgm_bnn_z_step(bgm_handle *h, const float *x, const float *y, con
     static const bool one_wg = std::getenv("BGM_FIT_ONE_WG") != nullptr;
     const size_t lds_z = (32 + 2 * batch + 4 * 16 * fc->t0 * batch) * sizeof(float);
     if (batch == 32 && !fc->pad && fc->t0 == 1 && !one_wg) {      // one row tile per workgroup (see ecb_z_chain)
-      auto ks = fc->ntl == 13 ? bnn_z_chain_kernel<13, 1> : bnn_z_chain_kernel<7, 1>;
-      hipLaunchKernelGGL(ks, dim3(2), dim3(BNN_THREADS), lds_z, stream, a, fc->tab_z, fc->ws);
+      static const bool no_ws = std::getenv("BGM_FIT_NO_WORKERS") != nullptr;
+      if (no_ws) {
+        auto ks = fc->ntl == 13 ? bnn_z_chain_kernel<13, 1> : bnn_z_chain_kernel<7, 1>;
+        hipLaunchKernelGGL(ks, dim3(2), dim3(BNN_THREADS), lds_z, stream, a, fc->tab_z, fc->ws);
+      } else {      // the mean call's last layer over the idle waves, the variance-head call on its one column (ecb_z_chain<WS>)
+        auto ks = fc->ntl == 13 ? bnn_z_chain_kernel<13, 1, false, 1, true> : bnn_z_chain_kernel<7, 1, false, 1, true>;
+        const size_t lds_ws = (32 + 2 * 16 + 4 * 16 * 16 + 2 * 1024 + 64 + 4 * 1024 + 8) * sizeof(float);
+        hipLaunchKernelGGL(ks, dim3(2), dim3(BNN_THREADS), std::max(lds_z, lds_ws), stream, a, fc->tab_z, fc->ws);
+      }
     } else
       hipLaunchKernelGGL(kc, dim3(1), dim3(BNN_THREADS), lds_z, stream, a, fc->tab_z, fc->ws);
   } else {

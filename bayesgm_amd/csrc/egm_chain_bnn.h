@@ -1124,7 +1124,7 @@ __device__ __forceinline__ void ecb_theta_dw(const Args &a, const EcbTab &tab, c
 
 // latent step: dz [B x q] = d loss / d (batch rows of data_z), out[0] = loss_postrior_z.  Waves 0,1: g mean call; 2,3: g variance-head
 // call (they exchange the row's sum of squares and raw variance through LDS); 4,5: h (both calls); 6,7: f (both calls).
-template <class Args, int HT, int NTL, int T1, int T2, int T3, int NB, bool PAD = false, int T0 = 1>
+template <class Args, int HT, int NTL, int T1, int T2, int T3, int NB, bool PAD = false, int T0 = 1, bool WS = false>
 __device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, float *ws, float *lds) {
   constexpr int B = 16 * NB, ZW = 16 * T0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
@@ -1142,7 +1142,130 @@ __device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, fl
   if (tid < 16) flag[tid] = 0;
   __syncthreads();
   float lsum = 0.0f;
-  if (active) {
+  // WS (NB = 1): the mean call's last layer over waves 0 | 1, 3, 5 (as ecb_theta_chain<WS>); the variance-head call (wave 2) needs ONE
+  // output column of its last layer -- it multiplies that column's tile alone, forward and backward.  LDS behind the latent-gradient
+  // tiles: h | hs [16 x 64] | residual partials [4][16] | backward partials [4][16 x 64] | three counters.
+  if constexpr (WS) {
+    static_assert(NB == 1 && HT == 4 && T0 == 1 && !PAD, "worker split: one plain row tile per workgroup");
+    constexpr int NW = (NTL + 3) / 4;
+    float *hb = dzc + 4 * B * ZW, *hsb = hb + 1024, *pp = hsb + 1024, *dhp = pp + 64;
+    int *fl = reinterpret_cast<int *>(dhp + 4096);
+    if (tid < 8) fl[tid] = 0;
+    __syncthreads();
+    const int wk = wave == 0 ? 0 : ((wave & 1) && wave < 6 ? 1 + (wave >> 1) : -1);       // waves 0 | 1, 3, 5
+    if (wk >= 0 && wk < NW) {
+      const BnnNet &G = a.net[BNN_G];
+      const EcbCall &C = tab.c[0];
+      const int L = G.n_layers, no = G.dims[L];
+      const int wrow = 16 * (int)blockIdx.x + j;
+      const long long prow = a.idx[wrow];
+      const uint32_t *roww = reinterpret_cast<const uint32_t *>(ws + C.sg) + (long long)wrow * G.swords;
+      const float *loc = th + G.woff[L - 1], *dWl = ws + C.dW + G.eoff[L - 1];
+      f32x4 vv[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vv[t][r] = ech_ld(a.v_ + prow * p, 64 * wk + 16 * t + 4 * g + r, p);
+      f32x4 h[4], hs[4], zin[1], fin[1], hin[1];
+      if (wk == 0) {
+        ecb_inputs<1>(a.data_z + prow * q, a.x_[prow], q, z0, z1, z2, g, zin, fin, hin);
+        ecb_mlp_fwd_hidden<1, 4, false>(th, G, C, ws, wrow, zin, h, hs, j, g);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          *reinterpret_cast<f32x4 *>(hb + j * 64 + 16 * t + 4 * g) = h[t];
+          *reinterpret_cast<f32x4 *>(hsb + j * 64 + 16 * t + 4 * g) = hs[t];
+        }
+        ECB_POST(0);
+      } else {
+        ECB_WAIT(0, 1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          h[t] = *reinterpret_cast<const f32x4 *>(hb + j * 64 + 16 * t + 4 * g);
+          hs[t] = *reinterpret_cast<const f32x4 *>(hsb + j * 64 + 16 * t + 4 * g);
+        }
+      }
+      f32x4 o4[4], c2[4], c2s[4];
+      ech_zero<4>(o4);
+      ech_zero<4>(c2);
+      {
+        const EcgW w1{loc, no, 64, no, 64 * wk}, w2{dWl, no, 64, no, 64 * wk};
+        EcgA<4> A, Ad, Ad2;
+        ecg_prime<4, false>(w1, A, j, g);
+        ecg_sub<4, 4, 4, false, false>(w1, h, o4, A, w2, Ad, j, g);
+        ecg_sub<4, 4, 4, false, false>(w2, hs, c2, Ad, w2, Ad2, j, g);
+      }
+      ecb_flip<4>(roww, G.sout_w[L - 1] + 2 * wk, g, c2, c2s);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) o4[u] += c2s[u];
+      ecg_bias<4>(loc + 2 * 64 * no, no, 64 * wk, g, o4);
+      float ssq = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 64 * wk + 16 * t + 4 * g + r;
+          const float d = f < p ? vv[t][r] - o4[t][r] : 0.0f;
+          ssq = fmaf(d, d, ssq);
+          o4[t][r] = d;
+        }
+      ssq = sum_over_g(ssq);
+      if (g == 0) pp[wk * 16 + j] = ssq;
+      ECB_POST(1);
+      ECB_WAIT(1, NW);
+      ssq = 0.0f;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) ssq += pp[k * 16 + j];
+      if (wk == 0) {                                  // hand the row's sum of squares to the variance-head call
+        if (g == 0) xch[j] = ssq;
+        __threadfence_block();
+        if (lane == 0) flag[0] = 1;
+      }
+      while (flag[2] == 0) __builtin_amdgcn_s_sleep(2);
+      __threadfence_block();
+      const float raw = xch[B + j];
+      float lb, s2;
+      ecb_gauss(ssq, raw, (float)p, lb, s2);
+      f32x4 douts[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o4[t][r] = (64 * wk + 16 * t + 4 * g + r < p) ? -o4[t][r] / s2 * a.inv_B : 0.0f;
+      ecb_flip<4>(roww, G.sout_w[L - 1] + 2 * wk, g, o4, douts);
+      f32x4 dh[4];
+      {
+        const EcgW w1{loc + 64 * wk, no, no, 64, 0}, w2{dWl + 64 * wk, no, no, 64, 0};
+        EcgA<4> A, Ad, Ad2;
+        ecg_prime<4, true, true>(w1, A, j, g);
+        ech_zero<4>(dh);
+        ech_zero<4>(c2);
+        ecg_sub<4, 4, 4, true, true, true, true>(w1, o4, dh, A, w2, Ad, j, g);
+        ecg_sub<4, 4, 4, true, true, true, true>(w2, douts, c2, Ad, w2, Ad2, j, g);
+        ecb_flip<4>(roww, G.sin_w[L - 1], g, c2, c2s);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) dh[u] += c2s[u];
+      }
+      if (wk != 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4 *>(dhp + wk * 1024 + j * 64 + 16 * u + 4 * g) = dh[u];
+        ECB_POST(2);
+      } else {
+        ECB_WAIT(2, NW - 1);
+#pragma unroll
+        for (int k = 1; k < NW; ++k)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) dh[u] += *reinterpret_cast<const f32x4 *>(dhp + k * 1024 + j * 64 + 16 * u + 4 * g);
+        ecg_mask<4>(dh, h);
+        f32x4 dx[1];
+        ecb_mlp_bwd_hidden<1, 4, true, false>(th, G, C, ws, wrow, (int)blockIdx.x, dh, dx, j, g);
+        *reinterpret_cast<f32x4 *>(dzc + (0 * B + j) * ZW + 4 * g) = dx[0];
+        float zz = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zz = fmaf(zin[0][r], zin[0][r], zz);
+        lsum = lb + 0.5f * sum_over_g(zz);             // the row's likelihood term of v and its prior term
+      }
+    }
+  }
+  if (active && !(WS && role == 0)) {
     const long long prow = a.idx[row];
     const float xv = a.x_[prow], yv = a.y_[prow];
     const float *zrow = a.data_z + prow * q;
@@ -1180,6 +1303,63 @@ __device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, fl
         for (int r = 0; r < 4; ++r) o[t][r] = (16 * t + 4 * g + r < p) ? -o[t][r] / s2 * a.inv_B : 0.0f;
       ecb_mlp_bwd<T0, HT, NTL, true, PAD>(th, th, G, tab.c[0], ws, row, tile, o, dx, j, g);
     } else if (role == 1) {
+     if constexpr (WS) {
+      // the variance-head call: only output column p of the last layer is used -- its tile alone, forward and backward
+      const BnnNet &G = a.net[BNN_G];
+      const EcbCall &C = tab.c[1];
+      const int L = G.n_layers, no = G.dims[L], tp = p >> 4;
+      const uint32_t *roww = reinterpret_cast<const uint32_t *>(ws + C.sg) + (long long)row * G.swords;
+      const float *loc = th + G.woff[L - 1], *dWl = ws + C.dW + G.eoff[L - 1];
+      f32x4 h[4], hs[4];
+      ecb_mlp_fwd_hidden<1, 4, false>(th, G, C, ws, row, zin, h, hs, j, g);
+      f32x4 o1[1], c2[1];
+      ech_zero<1>(o1);
+      ech_zero<1>(c2);
+      {
+        const EcgW w1{loc, no, 64, no, 16 * tp}, w2{dWl, no, 64, no, 16 * tp};
+        EcgA<1> A, Ad, Ad2;
+        ecg_prime<1, false>(w1, A, j, g);
+        ecg_sub<4, 1, 1, false, false>(w1, h, o1, A, w2, Ad, j, g);
+        ecg_sub<4, 1, 1, false, false>(w2, hs, c2, Ad, w2, Ad2, j, g);
+      }
+      const uint32_t so = roww[G.sout_w[L - 1] + (tp >> 1)] >> (16 * (tp & 1) + 4 * g);       // sign bits of tile tp (ecb_flip's layout)
+      float raw = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = o1[0][r] + __uint_as_float(__float_as_uint(c2[0][r]) ^ (((so >> r) & 1u) << 31)) + ech_ld(loc + 2 * 64 * no, 16 * tp + 4 * g + r, no);
+        raw += (16 * tp + 4 * g + r == p) ? v : 0.0f;
+      }
+      raw = sum_over_g(raw);
+      if (g == 0) xch[B + lrow] = raw;
+      __threadfence_block();
+      if (lane == 0) flag[2 + lt] = 1;
+      while (flag[lt] == 0) __builtin_amdgcn_s_sleep(2);
+      __threadfence_block();
+      const float ssq = xch[lrow];
+      float lb, s2;
+      const float dr = ecb_gauss(ssq, raw, (float)p, lb, s2);
+      f32x4 d1[1], d1s[1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        d1[0][r] = (16 * tp + 4 * g + r == p) ? dr * a.inv_B : 0.0f;
+        d1s[0][r] = __uint_as_float(__float_as_uint(d1[0][r]) ^ (((so >> r) & 1u) << 31));
+      }
+      f32x4 dh[4], c4[4], c4s[4];
+      {
+        const EcgW w1{loc + 16 * tp, no, no, 64, 0}, w2{dWl + 16 * tp, no, no, 64, 0};
+        EcgA<4> A, Ad, Ad2;
+        ecg_prime<4, true, true>(w1, A, j, g);
+        ech_zero<4>(dh);
+        ech_zero<4>(c4);
+        ecg_sub<1, 4, 4, true, true, true, true>(w1, d1, dh, A, w2, Ad, j, g);
+        ecg_sub<1, 4, 4, true, true, true, true>(w2, d1s, c4, Ad, w2, Ad2, j, g);
+        ecb_flip<4>(roww, G.sin_w[L - 1], g, c4, c4s);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) dh[u] += c4s[u];
+      }
+      ecg_mask<4>(dh, h);
+      ecb_mlp_bwd_hidden<1, 4, true, false>(th, G, C, ws, row, tile, dh, dx, j, g);
+     } else {
       const BnnNet &G = a.net[BNN_G];
       f32x4 o[NTL];
       ecb_mlp_fwd<T0, HT, NTL, PAD>(th, G, tab.c[1], ws, row, zin, o, j, g);
@@ -1197,6 +1377,7 @@ __device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, fl
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[t][r] = (16 * t + 4 * g + r == p) ? dr * a.inv_B : 0.0f;
       ecb_mlp_bwd<T0, HT, NTL, true, PAD>(th, th, G, tab.c[1], ws, row, tile, o, dx, j, g);
+     }
     } else {
       const bool is_h = role == 2;
       const BnnNet &N = a.net[is_h ? BNN_H : BNN_F];
