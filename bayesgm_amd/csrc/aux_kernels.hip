@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include "bgm_host.h"
+#include "gx_host.h"
 
 // ---------------------------------------------------------------------------
 // Encoder  z = e(v):  p -> 64 x n_hidden -> q.  One wave = 16 rows; V rows are
@@ -104,10 +105,9 @@ extern "C" int bgm_causal_encode(bgm_handle *h, const float *v, int64_t n, float
   if (!h || !h->configured) { bgm_set_error("bgm_causal_encode: handle not configured"); return BGM_E_STATE; }
   if (n <= 0) return BGM_OK;
   if (!v || !z) { bgm_set_error("bgm_causal_encode: NULL pointer"); return BGM_E_INVALID; }
-  for (int i = 0; i < h->cfg.n_hidden_e; ++i)
-    if (h->cfg.e_units[i] != 64) { bgm_set_error("bgm_causal_encode: only e_units=[64]*k is compiled"); return BGM_E_UNSUPPORTED; }
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
+  if (gx_enc_wanted(h)) return gx_encode(h, v, n, z, stream);     // e_units other than [64]*k, v_dim > 208: the general-width engine
   EncMeta m;
   int rc = build_eblob(h, m, stream);
   if (rc) return rc;

@@ -89,6 +89,8 @@ struct bgm_handle {
   size_t acc_scratch_cap = 0;
   void *det_state = nullptr;  // BnfState (bnf_det_api.hip): general-shape sampling path of the deterministic nets
   bool det_valid = false;
+  void *gx_state = nullptr;   // GxState (gx_api.hip): general-width engine (hidden widths / depths outside the compiled families)
+  bool gx_valid = false;      // its padded packs hold the handle's current g, f, h, e
   void *bgm_state = nullptr;  // BgmState (bgm_api.hip)
   void *egm_state = nullptr;  // EgmState (egm_api.hip)
   void *bgm_egm_state = nullptr;  // BgmEgmState (bgm_egm_api.hip)

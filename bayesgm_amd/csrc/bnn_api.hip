@@ -385,7 +385,12 @@ extern "C" int bgm_bnn_z_sync(bgm_handle *h, float *data_z, float *zm, float *zv
   if (!data_z || !zm || !zv || n_rows < 1 || (idx && batch < 1)) { bgm_set_error("bgm_bnn_z_sync: bad argument"); return BGM_E_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
-  if (s->tlast_dev && s->tlast_rows != n_rows) { bgm_set_error("bgm_bnn_z_sync: n_rows differs from the table the replay state belongs to"); return BGM_E_INVALID; }
+  if (s->tlast_dev && s->tlast_rows != n_rows) {
+    // another latent table (a second fit() on a panel of another size, another shard): legal once the previous table is flushed
+    if (s->z_synced != -2) { bgm_set_error("bgm_bnn_z_sync: n_rows differs from the table the replay state belongs to, and that table has pending steps (flush it with idx = NULL first)"); return BGM_E_STATE; }
+    BGM_HIP_CHECK(hipFree(s->tlast_dev));
+    s->tlast_dev = nullptr; s->tlast_rows = 0;
+  }
   if (!s->tlast_dev) {                               // every row is current at the step the mode is entered
     BGM_HIP_CHECK(hipMalloc(&s->tlast_dev, sizeof(int) * n_rows));
     s->tlast_rows = n_rows;
@@ -398,7 +403,10 @@ extern "C" int bgm_bnn_z_sync(bgm_handle *h, float *data_z, float *zm, float *zv
   if (!idx) {
     hipLaunchKernelGGL(fit_fill_int_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, s->tlast_dev, (long long)n_rows, (int)s->t_z);
     s->z_synced = -2;
-  } else s->z_synced = s->t_z + 1;
+  } else {
+    hipLaunchKernelGGL(fit_mark_rows_kernel, dim3((unsigned)((n_sel + 255) / 256)), dim3(256), 0, stream, s->tlast_dev, idx, n_sel, (int)s->t_z);
+    s->z_synced = s->t_z + 1;
+  }
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
 }

@@ -9,6 +9,7 @@
 
 #include "bgm_host.h"
 #include "bnf_det_host.h"
+#include "gx_host.h"
 
 static thread_local std::string g_err;
 void bgm_set_error(const std::string &msg) { g_err = msg; }
@@ -48,6 +49,7 @@ extern "C" int bgm_destroy(bgm_handle *h) {
   if (h->acc_scratch) hipFree(h->acc_scratch);
   bnf_det_free(h);
   bgm_causal_fit_end(h, nullptr);
+  gx_free(h);
   bgm_bgm_free_state(h);
   bgm_egm_free_state(h);
   bgm_bgm_egm_free_state(h);
@@ -77,16 +79,18 @@ extern "C" int bgm_causal_configure(bgm_handle *h, const bgm_causal_config *cfg)
   }
   for (int n : {cfg->n_hidden_g, cfg->n_hidden_f, cfg->n_hidden_h, cfg->n_hidden_e})
     if (n < 1 || n > BGM_MAX_LAYERS) { bgm_set_error("bgm_causal_configure: hidden layer count out of range"); return BGM_E_INVALID; }
-  // The fused kernels are specialised to the reference's default widths
-  // (g_units [64]*k, f_units = h_units = [64,32,8]; configs/*.yaml, cli/cli.py).
-  bool g_ok = true;
-  for (int i = 0; i < cfg->n_hidden_g; ++i) g_ok &= (cfg->g_units[i] == 64);
-  if (!g_ok || !units_are(cfg->f_units, cfg->n_hidden_f, {64, 32, 8}) ||
-      !units_are(cfg->h_units, cfg->n_hidden_h, {64, 32, 8})) {
-    bgm_set_error("bgm_causal_configure: only g_units=[64]*k, f_units=h_units=[64,32,8] are compiled");
-    return BGM_E_UNSUPPORTED;
-  }
-  if (q + 1 > 32) { bgm_set_error("bgm_causal_configure: sum(z_dims) > 31 not compiled"); return BGM_E_UNSUPPORTED; }
+  // Any hidden widths / depths (networks/base.py:7-28 takes any nb_units): the reference defaults (g_units [64]*k, f_units = h_units =
+  // [64,32,8]; configs/*.yaml, cli/cli.py) run on the specialised kernel families, every other shape on the general-width engine
+  // (gx_api.hip).
+  for (const int32_t *u : {cfg->g_units, cfg->f_units, cfg->h_units, cfg->e_units})
+    for (int i = 0; i < BGM_MAX_LAYERS; ++i)
+      if (u[i] < 0 || u[i] > 4096) { bgm_set_error("bgm_causal_configure: hidden widths must be in [1, 4096]"); return BGM_E_INVALID; }
+  for (int i = 0; i < cfg->n_hidden_g; ++i) if (cfg->g_units[i] < 1) { bgm_set_error("bgm_causal_configure: g_units must be positive"); return BGM_E_INVALID; }
+  for (int i = 0; i < cfg->n_hidden_f; ++i) if (cfg->f_units[i] < 1) { bgm_set_error("bgm_causal_configure: f_units must be positive"); return BGM_E_INVALID; }
+  for (int i = 0; i < cfg->n_hidden_h; ++i) if (cfg->h_units[i] < 1) { bgm_set_error("bgm_causal_configure: h_units must be positive"); return BGM_E_INVALID; }
+  for (int i = 0; i < cfg->n_hidden_e; ++i) if (cfg->e_units[i] < 1) { bgm_set_error("bgm_causal_configure: e_units must be positive"); return BGM_E_INVALID; }
+  h->cfg = *cfg;
+  if (q + 1 > 32 && !gx_wanted(h)) { bgm_set_error("bgm_causal_configure: sum(z_dims) > 31 with the default hidden widths is not compiled"); h->configured = false; return BGM_E_UNSUPPORTED; }
   h->cfg = *cfg;
   h->q = q;
   h->p = p;
@@ -103,6 +107,7 @@ extern "C" int bgm_causal_configure(bgm_handle *h, const bgm_causal_config *cfg)
   mk(h->nets[BGM_NET_H], cfg->z_dims[0] + cfg->z_dims[2], cfg->h_units, cfg->n_hidden_h, 2);
   mk(h->nets[BGM_NET_E], p, cfg->e_units, cfg->n_hidden_e, q);
   bnf_det_free(h);
+  gx_free(h);
   h->configured = true;
   h->blob_valid = false;
   h->bx_valid = false;
@@ -123,6 +128,7 @@ extern "C" int bgm_causal_set_weights(bgm_handle *h, int net_id, const float *th
   std::memcpy(n.theta.data(), theta_host, sizeof(float) * count);
   n.set = true;
   if (net_id == BGM_NET_E) h->eblob_valid = false; else { h->blob_valid = false; h->bx_valid = false; h->det_valid = false; }
+  h->gx_valid = false;
   return BGM_OK;
 }
 
@@ -309,6 +315,7 @@ static int mh_grid(const bgm_handle *h, int64_t n) {
 
 extern "C" int bgm_causal_mh_slots(bgm_handle *h, int64_t n, int32_t *n_slots) {
   if (!h || !n_slots) { bgm_set_error("bgm_causal_mh_slots: NULL"); return BGM_E_INVALID; }
+  if (h->configured && gx_wanted(h)) { *n_slots = gx_slots(h, n); return BGM_OK; }            // general-width engine: one slot per workgroup
   if (h->configured && bnf_det_wanted(h)) { *n_slots = bnf_det_slots(h); return BGM_OK; }      // general path: one slot per workgroup
   *n_slots = mh_grid(h, n) * MH_WAVES;
   return BGM_OK;
@@ -321,6 +328,10 @@ extern "C" int bgm_causal_logpost(bgm_handle *h, const float *x, const float *y,
   if (!x || !y || !v || !z || !out) { bgm_set_error("bgm_causal_logpost: NULL pointer"); return BGM_E_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
+  if (gx_wanted(h)) {          // hidden widths / depths outside the compiled families: the general-width engine (gx_api.hip)
+    if (h->precision == 1) { bgm_set_error("bgm_causal_logpost: split precision exists for the default hidden widths only"); return BGM_E_UNSUPPORTED; }
+    return gx_logpost(h, x, y, v, z, n, out, stream);
+  }
   if (bnf_det_wanted(h)) {     // no LDS-resident compiled shape holds the model: the streamed-fragment kernels (bnf_det_api.hip)
     if (h->prior_seg || h->precision == 1) { bgm_set_error("bgm_causal_logpost: the conditional prior / split precision exist for the LDS-resident shapes only"); return BGM_E_UNSUPPORTED; }
     return bnf_det_logpost(h, x, y, v, z, n, out, stream);
@@ -383,6 +394,10 @@ extern "C" int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *a, void *stre
   if ((a->effect != BGM_EFFECT_NONE || a->draws_dev) && it_end - a->burn_in > a->n_keep) { bgm_set_error("bgm_causal_mh_run: iterations beyond burn_in + n_keep"); return BGM_E_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
+  if (gx_wanted(h)) {
+    if (h->precision == 1) { bgm_set_error("bgm_causal_mh_run: split precision exists for the default hidden widths only"); return BGM_E_UNSUPPORTED; }
+    return gx_mh_run(h, a, stream);
+  }
   if (bnf_det_wanted(h)) {
     if (h->prior_seg || h->precision == 1) { bgm_set_error("bgm_causal_mh_run: the conditional prior / split precision exist for the LDS-resident shapes only"); return BGM_E_UNSUPPORTED; }
     return bnf_det_mh_run(h, a, stream);
@@ -476,6 +491,7 @@ extern "C" int bgm_causal_evaluate(bgm_handle *h, const float *x, const float *y
   if (!binary && (!x_values || n_doses <= 0 || !adrf_partial)) { bgm_set_error("bgm_causal_evaluate: x_values / adrf_partial required"); return BGM_E_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
+  if (gx_wanted(h)) return gx_evaluate(h, x, y, v, z, n, x_values, n_doses, sums, adrf_partial, ite, stream);
   if (bnf_det_wanted(h)) return bnf_det_evaluate(h, x, y, v, z, n, x_values, n_doses, sums, adrf_partial, ite, stream);
   int rc = bgm_causal_sampling_blob(h, stream);
   if (rc) return rc;
@@ -518,6 +534,7 @@ extern "C" int bgm_causal_effects(bgm_handle *h, const float *x, const float *dr
   if (row_base + n > 0xFFFFFFFFll) { bgm_set_error("bgm_causal_effects: row index exceeds the 32-bit RNG counter"); return BGM_E_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
+  if (gx_wanted(h)) return gx_effects(h, draws, n, row_base, n_keep, burn_in, seed, sample_y, x_values, n_doses, adrf_partial, ite, stream);
   if (bnf_det_wanted(h)) return bnf_det_effects(h, draws, n, row_base, n_keep, burn_in, seed, sample_y, x_values, n_doses, adrf_partial, ite, stream);
   int rc = bgm_causal_sampling_blob(h, stream);
   if (rc) return rc;
@@ -533,6 +550,7 @@ extern "C" int bgm_causal_effects(bgm_handle *h, const float *x, const float *dr
 
 extern "C" int bgm_causal_evaluate_slots(bgm_handle *h, int64_t n, int32_t *n_slots) {
   if (!h || !n_slots) { bgm_set_error("bgm_causal_evaluate_slots: NULL"); return BGM_E_INVALID; }
+  if (h->configured && gx_wanted(h)) { *n_slots = gx_slots(h, n); return BGM_OK; }
   if (h->configured && bnf_det_wanted(h)) { *n_slots = bnf_det_slots(h); return BGM_OK; }
   const int64_t tiles = (n + 15) / 16;
   *n_slots = (int)std::max<int64_t>(1, std::min<int64_t>((tiles + MH_WAVES - 1) / MH_WAVES, h->n_cus)) * MH_WAVES;
@@ -567,11 +585,12 @@ extern "C" int bgm_timing_read(bgm_handle *h, int kind, int64_t *n_launches, dou
 extern "C" int bgm_causal_describe(bgm_handle *h, int32_t batch, char *out, int32_t cap) {
   if (!h || !h->configured || !out || cap < 1) { bgm_set_error("bgm_causal_describe: bad argument"); return BGM_E_INVALID; }
   std::string s = "sampler=";
-  s += bnf_det_wanted(h) ? "bnf_mh_kernel<DET> / bnf_effects_kernel<DET> (general shapes: persistent workgroups, weights streamed from L2)"
+  s += gx_wanted(h) ? "gx_causal_mh_kernel (general-width engine: 32-row LDS activation tiles, padded weights streamed from L2)" : bnf_det_wanted(h) ? "bnf_mh_kernel<DET> / bnf_effects_kernel<DET> (general shapes: persistent workgroups, weights streamed from L2)"
                          : "causal_mh_kernel (weights LDS-resident, one launch per rank shard)";
   if (h->fit_active) {
     s += "; fit=";
-    if (h->fit_chain && batch <= 32) s += "fit_chain_kernel (register-chained row tiles, rows masked to the " + std::to_string(batch) + "-row local minibatch)";
+    if (gx_fit_active(h)) s += "gx_causal_fit_kernel / fit_dw_kernel (general-width engine)";
+    else if (h->fit_chain && batch <= 32) s += "fit_chain_kernel (register-chained row tiles, rows masked to the " + std::to_string(batch) + "-row local minibatch)";
     else s += "fit_fwd_kernel / fit_bwd_kernel / fit_dw_kernel (LDS-blob phase kernels)";
   }
   std::snprintf(out, (size_t)cap, "%s", s.c_str());
@@ -580,6 +599,21 @@ extern "C" int bgm_causal_describe(bgm_handle *h, int32_t batch, char *out, int3
 
 extern "C" int bgm_causal_mh_info(bgm_handle *h, int64_t n, bgm_mh_info *info) {
   if (!h || !h->configured || !info) { bgm_set_error("bgm_causal_mh_info: bad argument"); return BGM_E_INVALID; }
+  if (gx_wanted(h)) {
+    double macs = 0.0, pmacs = 0.0;
+    for (int id : {BGM_NET_G, BGM_NET_F, BGM_NET_H}) {
+      const HostNet &nn = h->nets[id];
+      for (size_t l = 0; l + 1 < nn.dims.size(); ++l) {
+        macs += (double)nn.dims[l] * nn.dims[l + 1];
+        pmacs += (double)((nn.dims[l] + 31) / 32 * 32) * ((nn.dims[l + 1] + 31) / 32 * 32);
+      }
+    }
+    info->rows_per_wave = 8; info->waves_per_block = 4; info->grid_blocks = gx_slots(h, n);
+    info->mfma_per_transition_per_wave = (int)(pmacs * 32.0 / 1024.0 / 4.0);   // issued 16x16x4 MFMAs per 32-row tile and transition, per wave
+    info->lds_bytes = 0;
+    info->flop_per_row_transition = 2.0 * macs;
+    return BGM_OK;
+  }
   const int q1 = h->q + 1;
   int KT1, KSL1, NTL;
   if (!bgm_causal_shape(q1, h->p + 1, KT1, KSL1, NTL)) { bgm_set_error("bgm_causal_mh_info: no compiled kernel shape contains this model"); return BGM_E_UNSUPPORTED; }

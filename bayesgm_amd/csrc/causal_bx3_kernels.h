@@ -469,7 +469,7 @@ __device__ __forceinline__ void causal_effects_bx3(const unsigned char *lds, con
       float y = sample_y ? fmaf(__builtin_sqrtf(s2), noise, mu_m) : mu_m;
       y = (valid && k < nd) ? y : 0.0f;
       const float tot = sum_over_j_to_lane15(y);
-      if (j == 15 && k < nd) unsafeAtomicAdd(adrf_slot + d * nd + k, tot);
+      if (j == 15 && k < nd) unsafeAtomicAdd(adrf_slot + (long long)d * nd + k, tot);
     } else {
       float yk[2];
 #pragma unroll

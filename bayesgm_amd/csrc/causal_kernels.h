@@ -582,7 +582,7 @@ __device__ __forceinline__ void causal_effects(const float *lds, const CausalMet
       float y = sample_y ? fmaf(__builtin_sqrtf(s2), noise, mu_m) : mu_m;
       y = (valid[0] && k < nd) ? y : 0.0f;
       const float tot = sum_over_j_to_lane15(y);
-      if (j == 15 && k < nd) unsafeAtomicAdd(adrf_slot + d * nd + k, tot);
+      if (j == 15 && k < nd) unsafeAtomicAdd(adrf_slot + (long long)d * nd + k, tot);
       continue;
     }
     float yk[DB][R];
@@ -601,7 +601,7 @@ __device__ __forceinline__ void causal_effects(const float *lds, const CausalMet
         for (int rr = 0; rr < R; ++rr) tot += valid[rr] ? yk[e][rr] : 0.0f;
         tot = sum_over_j_to_lane15(tot);  // values are valid in lane group 0 -> lane 15
         const int k = 4 * kb + e;
-        if (lane == 15 && k < nd) unsafeAtomicAdd(adrf_slot + d * nd + k, tot);
+        if (lane == 15 && k < nd) unsafeAtomicAdd(adrf_slot + (long long)d * nd + k, tot);
       }
     } else {
 #pragma unroll

@@ -382,6 +382,8 @@ extern "C" int bgm_causal_egm_sync(bgm_handle *h, void *stream_) {
     off += n.count();
   }
   h->blob_valid = false; h->bx_valid = false; h->eblob_valid = false;
+  h->det_valid = false;   // the general sampling path's packed copy follows the refreshed networks as well
+  h->gx_valid = false;
   return BGM_OK;
 }
 

@@ -6,6 +6,7 @@
 
 #include "bgm_host.h"
 #include "bnf_det_host.h"
+#include "gx_host.h"
 #include "fit_kernels.h"
 #include "fit_chain.h"
 
@@ -267,6 +268,7 @@ static void fit_free(bgm_handle *h) {
   h->tables_dev = h->pos_dev = nullptr;
   h->fit_active = false;
   fit_chain_free(h);
+  gx_fit_end(h);
 }
 
 static HostNet iota_net(const HostNet &n, int base) {
@@ -291,7 +293,8 @@ extern "C" int bgm_causal_fit_begin(bgm_handle *h, int64_t n_rows, int32_t max_b
   BGM_HIP_CHECK(hipSetDevice(h->device));
   // forward blob + meta from the host weights.  A model that no LDS-resident shape holds (sum(z_dims) > 19, ...) is fitted by the
   // row-tile chains alone: they read the canonical parameters in place (fit_chain.h) and need neither blob.
-  int rc = bnf_det_wanted(h) ? BGM_E_UNSUPPORTED : bgm_causal_build_blob(h, stream);
+  const bool gx = gx_wanted(h);     // hidden widths / depths outside the compiled families: the general-width engine (gx_api.hip)
+  int rc = (gx || bnf_det_wanted(h)) ? BGM_E_UNSUPPORTED : bgm_causal_build_blob(h, stream);
   const bool chain_only = rc == BGM_E_UNSUPPORTED;
   if (rc && !chain_only) return rc;
   fit_free(h);
@@ -313,29 +316,41 @@ extern "C" int bgm_causal_fit_begin(bgm_handle *h, int64_t n_rows, int32_t max_b
   BGM_HIP_CHECK(hipMemset(h->m1_dev, 0, sizeof(float) * np));
   BGM_HIP_CHECK(hipMemset(h->m2_dev, 0, sizeof(float) * np));
   h->t_theta = 0; h->t_z = 0;
-  if (chain_only) {
-    if (max_batch > 32) { bgm_set_error("bgm_causal_fit_begin: this model shape is fitted by the row-tile chains only: minibatches of at most 32 rows"); fit_free(h); return BGM_E_UNSUPPORTED; }
-    auto s2 = [](float s) { return s > 0.0f ? s * s : -1.0f; };
-    h->meta.sig2_v = s2(h->cfg.sigma_v); h->meta.sig2_x = s2(h->cfg.sigma_x); h->meta.sig2_y = s2(h->cfg.sigma_y);
-    std::vector<int> tables(4 * (size_t)np, -1);          // no blob positions to refresh after an Adam step
-    BGM_HIP_CHECK(hipMalloc(&h->tables_dev, sizeof(int) * tables.size()));
-    BGM_HIP_CHECK(hipMemcpy(h->tables_dev, tables.data(), sizeof(int) * tables.size(), hipMemcpyHostToDevice));
-    std::memset(&h->fit_ws, 0, sizeof(h->fit_ws));
-    h->fit_ws.B = 32; h->fit_ws.dz = 0; h->fit_ws.total = 32 * (long long)h->q;
-    BGM_HIP_CHECK(hipMalloc(&h->ws_dev, sizeof(float) * h->fit_ws.total));
-    BGM_HIP_CHECK(hipMemset(h->ws_dev, 0, sizeof(float) * h->fit_ws.total));
-    h->fit_bcap = 32;
-    h->fit_rows = n_rows;
-    BGM_HIP_CHECK(hipMalloc(&h->pos_dev, sizeof(int) * 2 * n_rows));
-    BGM_HIP_CHECK(hipMemset(h->pos_dev, 0xFF, sizeof(int) * 2 * n_rows));
-    BGM_HIP_CHECK(hipDeviceSynchronize());
+  if (gx) {
+    rc = gx_fit_begin(h, n_rows, max_batch, stream);
+    if (rc) { fit_free(h); return rc; }
     h->fit_active = true;
-    rc = fit_chain_setup(h, theta);
-    if (rc || !h->fit_chain) {
-      fit_free(h);
-      if (!rc) { bgm_set_error("bgm_causal_fit_begin: no fit kernel for this model (needs g_units [64] x k, f / h [64, 32, 8], sum(z_dims) <= 32, v_dim <= 207)"); rc = BGM_E_UNSUPPORTED; }
+    return BGM_OK;
+  }
+  if (chain_only) {
+    // default hidden widths, but no LDS-resident blob holds the model: the row-tile chains where they apply (minibatches of at most 32
+    // rows, v_dim <= 207), the general-width engine otherwise (any minibatch size, any v_dim)
+    if (max_batch <= 32) {
+      auto s2 = [](float s) { return s > 0.0f ? s * s : -1.0f; };
+      h->meta.sig2_v = s2(h->cfg.sigma_v); h->meta.sig2_x = s2(h->cfg.sigma_x); h->meta.sig2_y = s2(h->cfg.sigma_y);
+      std::vector<int> tables(4 * (size_t)np, -1);          // no blob positions to refresh after an Adam step
+      BGM_HIP_CHECK(hipMalloc(&h->tables_dev, sizeof(int) * tables.size()));
+      BGM_HIP_CHECK(hipMemcpy(h->tables_dev, tables.data(), sizeof(int) * tables.size(), hipMemcpyHostToDevice));
+      std::memset(&h->fit_ws, 0, sizeof(h->fit_ws));
+      h->fit_ws.B = 32; h->fit_ws.dz = 0; h->fit_ws.total = 32 * (long long)h->q;
+      BGM_HIP_CHECK(hipMalloc(&h->ws_dev, sizeof(float) * h->fit_ws.total));
+      BGM_HIP_CHECK(hipMemset(h->ws_dev, 0, sizeof(float) * h->fit_ws.total));
+      h->fit_bcap = 32;
+      h->fit_rows = n_rows;
+      BGM_HIP_CHECK(hipMalloc(&h->pos_dev, sizeof(int) * 2 * n_rows));
+      BGM_HIP_CHECK(hipMemset(h->pos_dev, 0xFF, sizeof(int) * 2 * n_rows));
+      BGM_HIP_CHECK(hipDeviceSynchronize());
+      h->fit_active = true;
+      rc = fit_chain_setup(h, theta);
+      if (rc) { fit_free(h); return rc; }
+      if (h->fit_chain) return BGM_OK;
+      for (void *p : {(void *)h->tables_dev, (void *)h->ws_dev, (void *)h->pos_dev}) if (p) hipFree(p);
+      h->tables_dev = nullptr; h->ws_dev = nullptr; h->pos_dev = nullptr; h->fit_active = false;
     }
-    return rc;
+    rc = gx_fit_begin(h, n_rows, max_batch, stream);
+    if (rc) { fit_free(h); return rc; }
+    h->fit_active = true;
+    return BGM_OK;
   }
   // ---- transposed blob
   fit_layout_backward(h, h->fit_meta);
@@ -504,7 +519,7 @@ extern "C" int bgm_causal_fit_theta_grad(bgm_handle *h, const float *x, const fl
   ka.m = h->meta; ka.bm = h->fit_meta; ka.ws = h->fit_ws; ka.wsp = h->ws_dev;
   ka.x = x; ka.y = y; ka.v = v; ka.data_z = data_z; ka.idx = idx; ka.row_lo = row_lo; ka.B = batch;
   ka.inv_B = 1.0f / (float)batch_global; ka.z_mode = 0; ka.loss = loss;
-  rc = launch_fwd_bwd(h, ka, stream);
+  rc = gx_fit_active(h) ? gx_fit_grads(h, x, y, v, data_z, idx, row_lo, batch, batch_global, 0, grad, loss, stream) : launch_fwd_bwd(h, ka, stream);
   if (rc) return rc;
   DwArgs dw = h->dw;
   dw.ws = h->ws_dev; dw.partial = h->partial_dev; dw.B = batch; dw.rows_per_slice = h->rows_per_slice;
@@ -528,7 +543,8 @@ extern "C" int bgm_causal_fit_theta_apply(bgm_handle *h, const float *grad, floa
   const int np = h->n_params;
   const int *tb = h->tables_dev;
   hipLaunchKernelGGL(fit_adam_theta_kernel, dim3((np + 255) / 256), dim3(256), 0, (hipStream_t)stream_, h->theta_dev,
-                     h->m1_dev, h->m2_dev, grad, np, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS, h->blob_dev, h->bblob_dev, tb,
+                     h->m1_dev, h->m2_dev, grad, np, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS, gx_fit_active(h) ? gx_pack(h) : h->blob_dev,
+                     gx_fit_active(h) ? gx_packT(h) : h->bblob_dev, tb,
                      tb + np, tb + 2 * (size_t)np, h->fit_chain ? static_cast<FitChainState *>(h->fit_chain)->thetaT : nullptr,
                      h->fit_chain ? static_cast<FitChainState *>(h->fit_chain)->mirror_dst : nullptr);
   BGM_HIP_CHECK(hipGetLastError());
@@ -574,7 +590,8 @@ extern "C" int bgm_causal_fit_z_step(bgm_handle *h, const float *x, const float 
     }
     fit_chain_launch(fc, ca, batch, 1, stream);
     rc = BGM_OK;
-  } else rc = launch_fwd_bwd(h, ka, stream);
+  } else if (gx_fit_active(h)) rc = gx_fit_grads(h, x, y, v, data_z, idx, row_lo, batch, batch_global, 1, nullptr, loss, stream);
+  else rc = launch_fwd_bwd(h, ka, stream);
   if (rc) return rc;
   h->t_z += 1;
   if (adam_fused) { BGM_HIP_CHECK(hipGetLastError()); return BGM_OK; }
@@ -620,7 +637,10 @@ extern "C" int bgm_causal_fit_z_sync(bgm_handle *h, float *data_z, float *zm, fl
   if (!idx) {
     hipLaunchKernelGGL(fit_fill_int_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, h->tlast_dev, n_rows, (int)h->t_z);
     h->z_synced = -2;                                // flushed: any mode may follow
-  } else h->z_synced = h->t_z + 1;
+  } else {
+    hipLaunchKernelGGL(fit_mark_rows_kernel, dim3((unsigned)((n_sel + 255) / 256)), dim3(256), 0, stream, h->tlast_dev, idx, n_sel, (int)h->t_z);
+    h->z_synced = h->t_z + 1;
+  }
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
 }
@@ -660,7 +680,8 @@ extern "C" int bgm_causal_fit_z_grad(bgm_handle *h, const float *x, const float 
     ca.loss = loss; ca.dz = h->ws_dev + h->fit_ws.dz;
     fit_chain_launch(fc, ca, batch, 1, stream);
     rc = BGM_OK;
-  } else rc = launch_fwd_bwd(h, ka, stream);
+  } else if (gx_fit_active(h)) rc = gx_fit_grads(h, x, y, v, data_z, idx, row_lo, batch, batch_global, 1, nullptr, loss, stream);
+  else rc = launch_fwd_bwd(h, ka, stream);
   if (rc) return rc;
   BGM_HIP_CHECK(hipMemcpyAsync(dz_out, h->ws_dev + h->fit_ws.dz, sizeof(float) * (size_t)batch * h->q, hipMemcpyDeviceToDevice, stream));
   return BGM_OK;

@@ -44,7 +44,7 @@ struct FitKArgs {
 };
 
 struct DwLayer { long long a_off, d_off; int K, N, out_off; };  // widths (multiples of 16); offset in the partial
-#define BGM_MAX_DW_LAYERS 20
+#define BGM_MAX_DW_LAYERS 32
 struct DwArgs {
   const float *ws;
   float *partial;          // [n_slices][partial_stride]

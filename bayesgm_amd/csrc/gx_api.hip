@@ -1,0 +1,349 @@
+// gx_api.hip -- host side of the general-width engine (gx_device.h, gx_causal_kernels.h, gx_fit_kernels.h): CausalBGM models with
+// arbitrary params['g_units' | 'e_units' | 'f_units' | 'h_units'] (causalbgm/base.py:64-81 forwards any list to
+// BaseFullyConnectedNet, networks/base.py:7-28), entered from bgm_causal_logpost / _mh_run / _effects / _evaluate / _encode /
+// _fit_* (causal_api.hip, aux_kernels.hip, fit_api.hip) whenever the hidden layers are not the reference defaults the other
+// kernel families are compiled for.  Also the fit path of default-width models that the row-tile chains do not hold
+// (v_dim > 207, minibatches > 32 rows of a chain-only shape) and the encoder beyond v_dim = 208.
+//
+// Device state: ONE padded copy of the Keras-order parameters of g, f, h, e (every layer [K][N] with K, N rounded up to multiples of
+// 32, zero filled) and one transposed copy for the backward products.  During a fit session the Adam kernel scatters each updated
+// parameter into both copies through index tables (fit_adam_theta_kernel), so sampling between epochs always sees the current nets.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bgm_host.h"
+#include "gx_fit_kernels.h"
+#include "gx_host.h"
+
+namespace {
+
+struct GxState {
+  GxCausalModel m{};
+  float *pack = nullptr, *packT = nullptr;
+  size_t pack_floats = 0, packT_floats = 0;
+  std::vector<int> fwd_map[4], bwd_map[4];     // canonical parameter of net (G, F, H, E) -> position in pack / packT (-1: none)
+  int ld_enc = 0, kc = 0;
+  int lds_bytes = 0, lds_enc = 0, lds_fit = 0, occ = 1;
+  bool fit = false;
+  GxFitNet wg{}, wf{}, wh{};
+};
+
+GxState *gst(const bgm_handle *h) { return static_cast<GxState *>(h->gx_state); }
+
+bool force_gx() { const char *e = std::getenv("BGM_FORCE_GX"); return e && e[0] == '1'; }
+
+template <class K>
+int set_lds(K kernel, int bytes) {
+  BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  return BGM_OK;
+}
+
+void plan_net(const HostNet &n, GxNet &g, size_t &off, size_t &offT, std::vector<int> &fwd, std::vector<int> &bwd) {
+  g.L = (int)n.dims.size() - 1;
+  for (int l = 0; l <= g.L; ++l) { g.dim[l] = n.dims[l]; g.pad[l] = gx_pad32(n.dims[l]); }
+  fwd.assign(n.count(), -1); bwd.assign(n.count(), -1);
+  size_t c = 0;
+  for (int l = 0; l < g.L; ++l) {
+    const int K = g.dim[l], N = g.dim[l + 1], Kp = g.pad[l], Np = g.pad[l + 1];
+    g.w[l] = (int)off; off += (size_t)Kp * Np;
+    g.b[l] = (int)off; off += Np;
+    g.wt[l] = (int)offT; offT += (size_t)Np * Kp;
+    for (int i = 0; i < K; ++i)
+      for (int o = 0; o < N; ++o) { fwd[c] = g.w[l] + i * Np + o; bwd[c] = g.wt[l] + o * Kp + i; ++c; }
+    for (int o = 0; o < N; ++o) fwd[c++] = g.b[l] + o;
+  }
+}
+
+int gx_session(bgm_handle *h, GxState *&st, hipStream_t stream, bool need_ghf = true) {
+  const HostNet *nets[4] = {&h->nets[BGM_NET_G], &h->nets[BGM_NET_F], &h->nets[BGM_NET_H], &h->nets[BGM_NET_E]};
+  if (need_ghf && (!nets[0]->set || !nets[1]->set || !nets[2]->set)) { bgm_set_error("weights of g, f, h must be set (bgm_causal_set_weights)"); return BGM_E_STATE; }
+  st = gst(h);
+  if (!st) {
+    for (const HostNet *n : nets)
+      if ((int)n->dims.size() - 1 > GX_MAXL) { bgm_set_error("general-width engine: too many layers"); return BGM_E_UNSUPPORTED; }
+    GxState *s = new GxState();
+    GxCausalModel &m = s->m;
+    size_t off = 0, offT = 0;
+    GxNet *gn[4] = {&m.g, &m.f, &m.h, &m.e};
+    for (int k = 0; k < 4; ++k) plan_net(*nets[k], *gn[k], off, offT, s->fwd_map[k], s->bwd_map[k]);
+    if (off >= (1u << 30) || offT >= (1u << 30)) { delete s; bgm_set_error("general-width engine: networks too large for 32-bit offsets"); return BGM_E_UNSUPPORTED; }
+    s->pack_floats = off; s->packT_floats = offT;
+    m.q = h->q; m.p = h->p; m.z0 = h->cfg.z_dims[0]; m.z1 = h->cfg.z_dims[1]; m.z2 = h->cfg.z_dims[2]; m.binary = h->cfg.binary_treatment ? 1 : 0;
+    auto s2 = [](float s_) { return s_ > 0.0f ? s_ * s_ : -1.0f; };
+    m.sig2_v = s2(h->cfg.sigma_v); m.sig2_x = s2(h->cfg.sigma_x); m.sig2_y = s2(h->cfg.sigma_y);
+    // widest activation that lives in LDS: every layer input of g, f, h and the (2-wide) outputs of f, h -- not g's p-wide output
+    int wmax = 32;
+    for (int l = 0; l < m.g.L; ++l) wmax = std::max(wmax, m.g.pad[l]);
+    for (int l = 0; l <= m.f.L; ++l) wmax = std::max(wmax, m.f.pad[l]);
+    for (int l = 0; l <= m.h.L; ++l) wmax = std::max(wmax, m.h.pad[l]);
+    m.ld = gx_ld(wmax);
+    m.ncg = m.g.pad[m.g.L] / 32;
+    s->lds_bytes = 4 * gx_causal_lds_floats(m.ld, m.q, m.ncg);
+    s->lds_fit = 4 * gx_fit_lds_floats(m.ld, m.q);
+    int wenc = 32;
+    for (int l = 1; l <= m.e.L; ++l) wenc = std::max(wenc, m.e.pad[l]);
+    s->kc = std::min(m.e.pad[0], std::max(wenc, 256));       // columns of V staged per chunk
+    s->ld_enc = gx_ld(std::max(wenc, s->kc));
+    s->lds_enc = 4 * 2 * GX_ROWS * s->ld_enc;
+    if (std::max(s->lds_bytes, std::max(s->lds_fit, s->lds_enc)) > 160 * 1024) {
+      delete s; bgm_set_error("general-width engine: a hidden layer is too wide for the 32-row LDS tiles (hidden widths up to ~550)"); return BGM_E_UNSUPPORTED;
+    }
+    s->occ = std::max(1, std::min(2, (160 * 1024) / std::max(s->lds_bytes, 1)));
+    if (hipMalloc((void **)&s->pack, sizeof(float) * std::max<size_t>(off, 1)) != hipSuccess ||
+        hipMalloc((void **)&s->packT, sizeof(float) * std::max<size_t>(offT, 1)) != hipSuccess) {
+      if (s->pack) hipFree(s->pack);
+      delete s; bgm_set_error("general-width engine: device allocation failed"); return BGM_E_HIP;
+    }
+    m.pack = s->pack;
+    h->gx_state = s; h->gx_valid = false;
+    st = s;
+  }
+  st->m.prior_seg = h->prior_seg; st->m.prior_tab = h->prior_tab;
+  if (!h->gx_valid) {
+    std::vector<float> pk(st->pack_floats, 0.0f), pt(st->packT_floats, 0.0f);
+    for (int k = 0; k < 4; ++k) {
+      const HostNet &n = *nets[k];
+      if (!n.set) continue;
+      for (size_t c = 0; c < n.theta.size(); ++c) {
+        if (st->fwd_map[k][c] >= 0) pk[st->fwd_map[k][c]] = n.theta[c];
+        if (st->bwd_map[k][c] >= 0) pt[st->bwd_map[k][c]] = n.theta[c];
+      }
+    }
+    BGM_HIP_CHECK(hipStreamSynchronize(stream));
+    BGM_HIP_CHECK(hipMemcpy(st->pack, pk.data(), sizeof(float) * pk.size(), hipMemcpyHostToDevice));
+    BGM_HIP_CHECK(hipMemcpy(st->packT, pt.data(), sizeof(float) * pt.size(), hipMemcpyHostToDevice));
+    h->gx_valid = true;
+  }
+  return BGM_OK;
+}
+
+int grid_for(const bgm_handle *h, const GxState *s, int64_t n) {
+  const int64_t tiles = (n + GX_ROWS - 1) / GX_ROWS;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(tiles, (int64_t)h->n_cus * s->occ));
+}
+
+bool default_units(const int32_t *u, int n, bool fh) {
+  if (fh) return n == 3 && u[0] == 64 && u[1] == 32 && u[2] == 8;
+  for (int i = 0; i < n; ++i) if (u[i] != 64) return false;
+  return true;
+}
+
+}  // namespace
+
+bool gx_wanted(const bgm_handle *h) {
+  if (force_gx()) return true;
+  const bgm_causal_config &c = h->cfg;
+  return !(default_units(c.g_units, c.n_hidden_g, false) && default_units(c.f_units, c.n_hidden_f, true) && default_units(c.h_units, c.n_hidden_h, true));
+}
+bool gx_enc_wanted(const bgm_handle *h) {
+  if (force_gx()) return true;
+  const bgm_causal_config &c = h->cfg;
+  return !default_units(c.e_units, c.n_hidden_e, false) || h->p > 208 || h->q > 32;
+}
+
+int gx_slots(bgm_handle *h, int64_t n) {
+  GxState *s = gst(h);
+  if (!s) {      // plan without touching the device contents: the slot count only needs the LDS budget
+    hipStream_t st = nullptr;
+    if (gx_session(h, s, st, false) != BGM_OK) return h->n_cus;
+    h->gx_valid = false;
+  }
+  return grid_for(h, s, n);
+}
+
+int gx_logpost(bgm_handle *h, const float *x, const float *y, const float *v, const float *z, int64_t n, float *out, hipStream_t stream) {
+  GxState *s;
+  int rc = gx_session(h, s, stream);
+  if (rc) return rc;
+  rc = set_lds(gx_causal_logpost_kernel, s->lds_bytes);
+  if (rc) return rc;
+  hipLaunchKernelGGL(gx_causal_logpost_kernel, dim3(grid_for(h, s, n)), dim3(GX_THREADS), s->lds_bytes, stream, s->m, x, y, v, z, (long long)n, out);
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+int gx_mh_run(bgm_handle *h, const bgm_mh_args *a, hipStream_t stream) {
+  GxState *s;
+  int rc = gx_session(h, s, stream);
+  if (rc) return rc;
+  GxMhArgs k{};
+  k.m = s->m; k.x = a->x_dev; k.y = a->y_dev; k.v = a->v_dev; k.n = a->n; k.row_base = a->row_base;
+  k.state = a->state_dev; k.logp = a->logp_dev; k.init = a->init; k.it_begin = a->it_begin; k.n_iters = a->n_iters; k.burn_in = a->burn_in;
+  k.q_sd = a->q_sd; k.k0 = (unsigned)(a->seed & 0xFFFFFFFFull); k.k1 = (unsigned)(a->seed >> 32);
+  k.acc_count = a->acc_count_dev; k.draws = a->draws_dev;
+  k.e.n_keep = a->n_keep; k.e.sample_y = a->sample_y; k.e.n_doses = a->n_doses; k.e.x_values = a->x_values_dev; k.e.adrf_slot = nullptr;
+  k.e.ite = a->ite_dev; k.e.k0 = k.k0; k.e.k1 = k.k1;
+  k.adrf_partial = a->adrf_partial_dev;
+  const int grid = grid_for(h, s, a->n);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (h->timing) { BGM_HIP_CHECK(hipEventCreate(&e0)); BGM_HIP_CHECK(hipEventCreate(&e1)); BGM_HIP_CHECK(hipEventRecord(e0, stream)); }
+  auto launch = [&](auto kern) {
+    int r = set_lds(kern, s->lds_bytes);
+    if (r) return r;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(GX_THREADS), s->lds_bytes, stream, k);
+    BGM_HIP_CHECK(hipGetLastError());
+    return (int)BGM_OK;
+  };
+  if (a->effect == BGM_EFFECT_ADRF) rc = launch(gx_causal_mh_kernel<1>);
+  else if (a->effect == BGM_EFFECT_ITE) rc = launch(gx_causal_mh_kernel<2>);
+  else rc = launch(gx_causal_mh_kernel<0>);
+  if (rc) return rc;
+  if (h->timing) { BGM_HIP_CHECK(hipEventRecord(e1, stream)); h->events.push_back({e0, e1, a->effect}); }
+  return BGM_OK;
+}
+
+int gx_evaluate(bgm_handle *h, const float *x, const float *y, const float *v, const float *z, int64_t n, const float *x_values,
+                int32_t n_doses, double *sums, float *adrf_partial, float *ite, hipStream_t stream) {
+  GxState *s;
+  int rc = gx_session(h, s, stream);
+  if (rc) return rc;
+  GxEvalArgs k{};
+  k.m = s->m; k.m.prior_seg = nullptr; k.m.prior_tab = nullptr;
+  k.x = x; k.y = y; k.v = v; k.z = z; k.n = n; k.x_values = x_values; k.n_doses = n_doses; k.sums = sums; k.adrf_partial = adrf_partial; k.ite = ite;
+  rc = set_lds(gx_causal_eval_kernel, s->lds_bytes);
+  if (rc) return rc;
+  hipLaunchKernelGGL(gx_causal_eval_kernel, dim3(grid_for(h, s, n)), dim3(GX_THREADS), s->lds_bytes, stream, k);
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+int gx_effects(bgm_handle *h, const float *draws, int64_t n, int64_t row_base, int32_t n_keep, int32_t burn_in, uint64_t seed,
+               int32_t sample_y, const float *x_values, int32_t n_doses, float *adrf_partial, float *ite, hipStream_t stream) {
+  GxState *s;
+  int rc = gx_session(h, s, stream);
+  if (rc) return rc;
+  GxEffKArgs k{};
+  k.m = s->m; k.draws = draws; k.n = n; k.row_base = row_base; k.burn_in = burn_in;
+  k.e.n_keep = n_keep; k.e.sample_y = sample_y; k.e.n_doses = n_doses; k.e.x_values = x_values; k.e.ite = ite;
+  k.e.k0 = (unsigned)(seed & 0xFFFFFFFFull); k.e.k1 = (unsigned)(seed >> 32);
+  k.adrf_partial = adrf_partial;
+  const int grid = grid_for(h, s, n);
+  const bool binary = h->cfg.binary_treatment != 0;
+  if (binary) {
+    rc = set_lds(gx_causal_effects_kernel<2>, s->lds_bytes);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gx_causal_effects_kernel<2>, dim3(grid), dim3(GX_THREADS), s->lds_bytes, stream, k);
+  } else {
+    rc = set_lds(gx_causal_effects_kernel<1>, s->lds_bytes);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gx_causal_effects_kernel<1>, dim3(grid), dim3(GX_THREADS), s->lds_bytes, stream, k);
+  }
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+int gx_encode(bgm_handle *h, const float *v, int64_t n, float *z, hipStream_t stream) {
+  if (!h->nets[BGM_NET_E].set) { bgm_set_error("bgm_causal_encode: encoder weights not set"); return BGM_E_STATE; }
+  GxState *s;
+  int rc = gx_session(h, s, stream, false);
+  if (rc) return rc;
+  GxEncArgs k{};
+  k.e = s->m.e; k.pack = s->pack; k.p = h->p; k.q = h->q; k.ld = s->ld_enc; k.kc = s->kc; k.v = v; k.n = n; k.z = z;
+  rc = set_lds(gx_encode_kernel, s->lds_enc);
+  if (rc) return rc;
+  const int64_t tiles = (n + GX_ROWS - 1) / GX_ROWS;
+  const int occ = std::max(1, std::min(2, (160 * 1024) / s->lds_enc));
+  hipLaunchKernelGGL(gx_encode_kernel, dim3((int)std::max<int64_t>(1, std::min<int64_t>(tiles, (int64_t)h->n_cus * occ))), dim3(GX_THREADS), s->lds_enc, stream, k);
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// fit session
+// ---------------------------------------------------------------------------------------------------------------------------
+bool gx_fit_active(const bgm_handle *h) { return gst(h) && gst(h)->fit; }
+float *gx_pack(bgm_handle *h) { return gst(h) ? gst(h)->pack : nullptr; }
+float *gx_packT(bgm_handle *h) { return gst(h) ? gst(h)->packT : nullptr; }
+void gx_fit_end(bgm_handle *h) { if (gst(h)) gst(h)->fit = false; }
+
+// Called by bgm_causal_fit_begin once theta_dev / m1_dev / m2_dev (g | f | h, Keras order) are on the device.  Fills the handle's
+// workspace, weight-gradient layer list (fit_dw_kernel), gradient source table and the Adam scatter tables for the padded packs.
+int gx_fit_begin(bgm_handle *h, int64_t n_rows, int32_t max_batch, hipStream_t stream) {
+  GxState *s;
+  int rc = gx_session(h, s, stream);
+  if (rc) return rc;
+  const HostNet &G = h->nets[BGM_NET_G], &F = h->nets[BGM_NET_F], &H = h->nets[BGM_NET_H];
+  const int ng = (int)G.count(), nf = (int)F.count(), np = h->n_params;
+  const int B = (max_batch + GX_ROWS - 1) / GX_ROWS * GX_ROWS;
+  const GxCausalModel &m = s->m;
+  // ---- workspace: per net and layer the layer input and the pre-activation gradient, [B][padded width] each
+  long long off = 0;
+  auto take = [&](long long n) { long long o = off; off += (n + 31) / 32 * 32; return o; };
+  DwArgs &dw = h->dw;
+  std::memset(&dw, 0, sizeof(dw));
+  int nl = 0, poff = 0;
+  std::vector<int> tables(4 * (size_t)np, -1);
+  int *fwd_dst = tables.data(), *bwd_dst = fwd_dst + 2 * (size_t)np, *grad_src = bwd_dst + np;
+  const GxNet *gn[3] = {&m.g, &m.f, &m.h};
+  GxFitNet *fw[3] = {&s->wg, &s->wf, &s->wh};
+  const HostNet *hn[3] = {&G, &F, &H};
+  const int base[3] = {0, ng, ng + nf};
+  for (int k = 0; k < 3; ++k) {
+    const GxNet &n = *gn[k];
+    if (nl + n.L > BGM_MAX_DW_LAYERS) { bgm_set_error("bgm_causal_fit_begin: too many layers"); return BGM_E_UNSUPPORTED; }
+    size_t c = base[k];
+    for (int l = 0; l < n.L; ++l) {
+      fw[k]->act[l] = take((long long)B * n.pad[l]);
+      fw[k]->dy[l] = take((long long)B * n.pad[l + 1]);
+      DwLayer &L = dw.layer[nl++];
+      L.a_off = fw[k]->act[l]; L.d_off = fw[k]->dy[l]; L.K = n.pad[l]; L.N = n.pad[l + 1]; L.out_off = poff;
+      for (int i = 0; i < n.dim[l]; ++i)
+        for (int o = 0; o < n.dim[l + 1]; ++o) grad_src[c++] = poff + i * L.N + o;
+      for (int o = 0; o < n.dim[l + 1]; ++o) grad_src[c++] = poff + L.K * L.N + o;
+      poff += L.K * L.N + L.N;
+    }
+    for (size_t i = 0; i < hn[k]->count(); ++i) { fwd_dst[base[k] + i] = s->fwd_map[k][i]; bwd_dst[base[k] + i] = s->bwd_map[k][i]; }
+  }
+  dw.n_layers = nl;
+  dw.partial_stride = (poff + 3) / 4 * 4;
+  std::memset(&h->fit_ws, 0, sizeof(h->fit_ws));
+  h->fit_ws.B = B;
+  h->fit_ws.dz = take((long long)B * h->q);
+  h->fit_ws.total = off;
+  h->fit_bcap = B;
+  h->rows_per_slice = 256;
+  h->n_slices_cap = (B + h->rows_per_slice - 1) / h->rows_per_slice;
+  BGM_HIP_CHECK(hipMalloc(&h->ws_dev, sizeof(float) * off));
+  BGM_HIP_CHECK(hipMemset(h->ws_dev, 0, sizeof(float) * off));
+  BGM_HIP_CHECK(hipMalloc(&h->partial_dev, sizeof(float) * dw.partial_stride * h->n_slices_cap));
+  BGM_HIP_CHECK(hipMalloc(&h->tables_dev, sizeof(int) * tables.size()));
+  BGM_HIP_CHECK(hipMemcpy(h->tables_dev, tables.data(), sizeof(int) * tables.size(), hipMemcpyHostToDevice));
+  h->fit_rows = n_rows;
+  BGM_HIP_CHECK(hipMalloc(&h->pos_dev, sizeof(int) * 2 * n_rows));
+  BGM_HIP_CHECK(hipMemset(h->pos_dev, 0xFF, sizeof(int) * 2 * n_rows));
+  BGM_HIP_CHECK(hipDeviceSynchronize());
+  s->fit = true;
+  return BGM_OK;
+}
+
+// forward + backward of one local minibatch: z_mode 0 leaves every layer's input and pre-activation gradient in the workspace (the
+// caller runs fit_dw_kernel / fit_grad_reduce_kernel on them), z_mode 1 leaves d loss / d z [batch x q] at ws + fit_ws.dz.
+int gx_fit_grads(bgm_handle *h, const float *x, const float *y, const float *v, const float *data_z, const int32_t *idx, int64_t row_lo,
+                 int32_t batch, int32_t batch_global, int z_mode, float *grad, double *loss, hipStream_t stream) {
+  (void)grad;
+  GxState *s = gst(h);
+  if (!s || !s->fit) { bgm_set_error("general-width engine: no fit session"); return BGM_E_STATE; }
+  GxFitArgs a{};
+  a.m = s->m; a.m.prior_seg = nullptr; a.m.prior_tab = nullptr;
+  a.packT = s->packT; a.wg = s->wg; a.wf = s->wf; a.wh = s->wh; a.ws = h->ws_dev; a.dz_off = h->fit_ws.dz;
+  a.x = x; a.y = y; a.v = v; a.data_z = data_z; a.idx = idx; a.row_lo = row_lo; a.B = batch; a.inv_B = 1.0f / (float)batch_global;
+  a.z_mode = z_mode; a.loss = loss;
+  int rc = set_lds(gx_causal_fit_kernel, s->lds_fit);
+  if (rc) return rc;
+  const int tiles = (batch + GX_ROWS - 1) / GX_ROWS;
+  hipLaunchKernelGGL(gx_causal_fit_kernel, dim3(std::min(tiles, h->n_cus * 2)), dim3(GX_THREADS), s->lds_fit, stream, a);
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+void gx_free(bgm_handle *h) {
+  GxState *s = gst(h);
+  if (!s) return;
+  if (s->pack) hipFree(s->pack);
+  if (s->packT) hipFree(s->packT);
+  delete s;
+  h->gx_state = nullptr; h->gx_valid = false;
+}

@@ -1,0 +1,173 @@
+// gx_device.h -- the general-width MLP engine of the gfx950 library ("gx"): dense layers of ANY width and depth on the fp32 matrix
+// pipe, for the models whose hidden layers are not the reference defaults (g / e [64] x k, f / h [64, 32, 8]) that the resident and
+// streamed-fragment kernel families are compiled for.
+//
+// replaces: BaseFullyConnectedNet / BaseVariationalNet of models/networks/base.py:4-117 with arbitrary `nb_units`
+// (networks/base.py:7 default [256, 256, 256]; r-package/bayesgm/tests/testthat/test-causalbgm.R:28-34 uses (8, 8) / (8, 4)).
+//
+// Execution layout.  A workgroup of 4 waves owns a tile of 32 rows (observations / chains).  Activations live in LDS, row-major
+// [32][ld] with ld = 8 (mod 64) floats -- the stride at which the 16-byte A-operand reads below are bank-conflict free on gfx950
+// (ds_read_b128 is serviced in four 16-lane groups, MI355X_MICROARCH.md "LDS").  Weights stay in HBM / L2 in a PADDED copy of the
+// Keras-order parameters: every layer W [K][N] row-major with K and N rounded up to multiples of 32 and zero filled, so no inner
+// loop carries a bound check and padded features are exact zeros end to end (LeakyReLU(0) = 0, zero rows / columns / biases).
+// The backward products read a second, transposed padded copy (W^T [N][K]) through the same routine.
+//
+// One layer  Y[32 x N] = A[32 x K] W[K x N]  is dealt to the waves in units of (16-row tile, 32-column group).  A unit contracts K in
+// blocks of 16 on v_mfma_f32_16x16x4_f32 (exact fp32 multiply-add chains, M = rows, N = output features): lane (j = lane & 15,
+// g = lane >> 4) reads ONE 16-byte A fragment A[row j][k0 + 4g .. + 3] from LDS and four 8-byte weight pairs
+// W[k0 + 4g + s][n0 + 2j, n0 + 2j + 1] (coalesced 128-byte row segments) per block and issues 8 MFMAs; K-step s contracts over
+// {k0 + 4g + s : g} on both operands.  The two accumulators of a lane hold columns n0 + 2j and n0 + 2j + 1 of rows 16 rt + 4g + r, so
+// an epilogue stores 8-byte pairs.  Per 8 MFMAs (256 matrix-pipe cycles) a wave issues 5 loads.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bgm_device.h"
+
+#define GX_THREADS 256
+#define GX_WAVES 4
+#define GX_ROWS 32
+#define GX_MAXL 9           // dense layers of one network: up to BGM_MAX_LAYERS hidden + the output layer
+
+struct GxNet {              // one fully connected network inside the padded packs
+  int L;                    // dense layers
+  int dim[GX_MAXL + 1];     // true widths  [in, h1, ..., out]
+  int pad[GX_MAXL + 1];     // padded widths (multiples of 32)
+  int w[GX_MAXL];           // W_l  [pad[l]][pad[l+1]]   at pack + w[l]
+  int b[GX_MAXL];           // b_l  [pad[l+1]]           at pack + b[l]
+  int wt[GX_MAXL];          // W_l^T [pad[l+1]][pad[l]]  at packT + wt[l]
+  int base;                 // first canonical (Keras-order) parameter of the net in the model's flat parameter vector
+};
+
+__host__ __device__ inline int gx_pad32(int n) { return (n + 31) & ~31; }
+// LDS row stride for activations of up to `width` (padded) floats: the smallest ld >= width + 4 with ld = 8 (mod 64)
+__host__ __device__ inline int gx_ld(int width) { return ((width + 59) / 64) * 64 + 8; }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Y = A W for the workgroup's 32 rows.  W [K][N] (padded, global), A [32][lda] in LDS (A_GLOBAL = false) or in global memory
+// (true: row r of the tile at A + r * lda).  epi(rt, n0, acc0, acc1): lane (j, g) holds rows 16 rt + 4g + r (r = 0..3) of columns
+// n0 + 2j (acc0[r]) and n0 + 2j + 1 (acc1[r]).  No barriers inside: the caller separates producers and consumers of A.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <bool A_GLOBAL = false, class Epi>
+__device__ __forceinline__ void gx_dense(const float *__restrict__ W, int K, int N, const float *A, int lda, Epi epi) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  const int units = 2 * (N >> 5);
+  for (int u = wave; u < units; u += GX_WAVES) {
+    const int rt = u & 1, n0 = (u >> 1) << 5;
+    f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float *ap = A + (size_t)(16 * rt + j) * lda + 4 * g;
+    const float *wk = W + (size_t)(4 * g) * N + n0 + 2 * j;
+    const size_t wstep = (size_t)16 * N;
+    // software pipeline: the operands of K block k0 + 16 are requested before the MFMAs of block k0 issue
+    f32x4 a = *reinterpret_cast<const f32x4 *>(ap);
+    f32x2 b0 = *reinterpret_cast<const f32x2 *>(wk);
+    f32x2 b1 = *reinterpret_cast<const f32x2 *>(wk + N);
+    f32x2 b2 = *reinterpret_cast<const f32x2 *>(wk + 2 * (size_t)N);
+    f32x2 b3 = *reinterpret_cast<const f32x2 *>(wk + 3 * (size_t)N);
+    for (int k0 = 16; k0 < K; k0 += 16) {
+      wk += wstep;
+      const f32x4 an = *reinterpret_cast<const f32x4 *>(ap + k0);
+      const f32x2 c0 = *reinterpret_cast<const f32x2 *>(wk);
+      const f32x2 c1 = *reinterpret_cast<const f32x2 *>(wk + N);
+      const f32x2 c2 = *reinterpret_cast<const f32x2 *>(wk + 2 * (size_t)N);
+      const f32x2 c3 = *reinterpret_cast<const f32x2 *>(wk + 3 * (size_t)N);
+      acc0 = BGM_MFMA(a[0], b0[0], acc0); acc1 = BGM_MFMA(a[0], b0[1], acc1);
+      acc0 = BGM_MFMA(a[1], b1[0], acc0); acc1 = BGM_MFMA(a[1], b1[1], acc1);
+      acc0 = BGM_MFMA(a[2], b2[0], acc0); acc1 = BGM_MFMA(a[2], b2[1], acc1);
+      acc0 = BGM_MFMA(a[3], b3[0], acc0); acc1 = BGM_MFMA(a[3], b3[1], acc1);
+      a = an; b0 = c0; b1 = c1; b2 = c2; b3 = c3;
+    }
+    acc0 = BGM_MFMA(a[0], b0[0], acc0); acc1 = BGM_MFMA(a[0], b0[1], acc1);
+    acc0 = BGM_MFMA(a[1], b1[0], acc0); acc1 = BGM_MFMA(a[1], b1[1], acc1);
+    acc0 = BGM_MFMA(a[2], b2[0], acc0); acc1 = BGM_MFMA(a[2], b2[1], acc1);
+    acc0 = BGM_MFMA(a[3], b3[0], acc0); acc1 = BGM_MFMA(a[3], b3[1], acc1);
+    epi(rt, n0, acc0, acc1);
+  }
+}
+
+// Epilogue helpers -------------------------------------------------------------------------------------------------------------
+// y = act(acc + b) -> Y (LDS [32][ldy]); LEAKY: LeakyReLU(0.2), else linear
+template <bool LEAKY>
+struct GxStore {
+  float *Y; int ldy; const float *bias;
+  __device__ __forceinline__ void operator()(int rt, int n0, const f32x4 &a0, const f32x4 &a1) const {
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const f32x2 bb = *reinterpret_cast<const f32x2 *>(bias + n0 + 2 * j);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float y0 = a0[r] + bb[0], y1 = a1[r] + bb[1];
+      if (LEAKY) { y0 = lrelu(y0); y1 = lrelu(y1); }
+      f32x2 o = {y0, y1};
+      *reinterpret_cast<f32x2 *>(Y + (size_t)(16 * rt + 4 * g + r) * ldy + n0 + 2 * j) = o;
+    }
+  }
+};
+
+// The same, and a copy of the activation rows to a global workspace G [rows][ldg] (fit: what the weight-gradient GEMM reads)
+template <bool LEAKY>
+struct GxStoreWs {
+  float *Y; int ldy; const float *bias; float *G; int ldg;
+  __device__ __forceinline__ void operator()(int rt, int n0, const f32x4 &a0, const f32x4 &a1) const {
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const f32x2 bb = *reinterpret_cast<const f32x2 *>(bias + n0 + 2 * j);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float y0 = a0[r] + bb[0], y1 = a1[r] + bb[1];
+      if (LEAKY) { y0 = lrelu(y0); y1 = lrelu(y1); }
+      f32x2 o = {y0, y1};
+      const int row = 16 * rt + 4 * g + r;
+      if (Y) *reinterpret_cast<f32x2 *>(Y + (size_t)row * ldy + n0 + 2 * j) = o;
+      *reinterpret_cast<f32x2 *>(G + (size_t)row * ldg + n0 + 2 * j) = o;
+    }
+  }
+};
+
+// Backward through a LeakyReLU layer: d(pre-activation) = dX * (h > 0 ? 1 : 0.2) with h the stored post-activation of that layer
+// (sign(h) = sign(pre-activation)); written to LDS (next A operand) and to the global workspace D (weight gradients), H global.
+struct GxBackStore {
+  float *Y; int ldy; const float *H; int ldh; float *D; int ldd;
+  __device__ __forceinline__ void operator()(int rt, int n0, const f32x4 &a0, const f32x4 &a1) const {
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * rt + 4 * g + r;
+      const f32x2 hh = *reinterpret_cast<const f32x2 *>(H + (size_t)row * ldh + n0 + 2 * j);
+      f32x2 o = {a0[r] * (hh[0] > 0.0f ? 1.0f : BGM_LEAK), a1[r] * (hh[1] > 0.0f ? 1.0f : BGM_LEAK)};
+      *reinterpret_cast<f32x2 *>(Y + (size_t)row * ldy + n0 + 2 * j) = o;
+      if (D) *reinterpret_cast<f32x2 *>(D + (size_t)row * ldd + n0 + 2 * j) = o;
+    }
+  }
+};
+
+// plain store of the accumulators (gradient with respect to a network input)
+struct GxRawStore {
+  float *Y; int ldy;
+  __device__ __forceinline__ void operator()(int rt, int n0, const f32x4 &a0, const f32x4 &a1) const {
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      f32x2 o = {a0[r], a1[r]};
+      *reinterpret_cast<f32x2 *>(Y + (size_t)(16 * rt + 4 * g + r) * ldy + n0 + 2 * j) = o;
+    }
+  }
+};
+
+// Hidden layers l = l_begin .. l_end - 1 of `net` (LeakyReLU), ping-ponging between two LDS buffers; the input is in `cur`.
+// Returns with the last output in the returned buffer (a barrier has been passed after its last store).
+__device__ __forceinline__ float *gx_hidden(const GxNet &net, const float *pack, int l_begin, int l_end, float *cur, float *oth, int ld) {
+  for (int l = l_begin; l < l_end; ++l) {
+    gx_dense(pack + net.w[l], net.pad[l], net.pad[l + 1], cur, ld, GxStore<true>{oth, ld, pack + net.b[l]});
+    __syncthreads();
+    float *t = cur; cur = oth; oth = t;
+  }
+  return cur;
+}
+
+// Sum of v over the 16 lanes j of a lane group (all lanes get the total).
+__device__ __forceinline__ float gx_sum_j(float v) {
+  v += __shfl_xor(v, 1, 16);
+  v += __shfl_xor(v, 2, 16);
+  v += __shfl_xor(v, 4, 16);
+  v += __shfl_xor(v, 8, 16);
+  return v;
+}

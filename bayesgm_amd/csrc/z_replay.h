@@ -47,6 +47,14 @@ static __global__ void fit_adam_z_replay_kernel(float *z, float *zm, float *zv, 
   }
 }
 
+// After a replay of the rows idx[0..n_sel) their (z, m, v) are current to `value`: recorded in a launch of its own (the replay kernel's
+// threads of one row read t_last[row] concurrently), so that a second replay of the same rows -- a flush after an interrupted
+// minibatch -- finds nothing pending.
+static __global__ void fit_mark_rows_kernel(int *t_last, const int *idx, long long n_sel, int value) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_sel) t_last[idx[i]] = value;
+}
+
 static __global__ void fit_fill_int_kernel(int *a, long long n, int value) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) a[i] = value;

@@ -248,43 +248,50 @@ class CausalBGMBayes(CausalBGM):
         best_loss = np.inf
         if verbose:
             print('Iterative Updating Starts ...')
-        for epoch in range(epochs + 1):
-            sample_idx = torch.from_numpy(np.random.choice(n_loc, n_loc, replace=False).astype(np.int32)).to(dev)
-            for i in range(0, n_use, b_loc):
-                idx = sample_idx[i:min(i + b_loc, n_use)]
-                if idx.numel() < 2:
-                    continue                      # batch statistics need two rows (the same decision on every rank)
-                bg = int(idx.numel()) * world
-                s0 = self._streams(3)
-                if replay:
-                    eng.z_sync(self.data_z, zm, zv, idx, lr_z)
-                if world > 1:
-                    eng.theta_step(self.data_z, idx, x, y, v, self._p['lr_theta'], seed, s0, apply=False, batch_global=bg, out=out_t)
-                    eng.grad_exchange(grad, False)
-                    parallel.all_reduce_sum_(grad)
-                    eng.grad_exchange(grad, True)
-                    eng.theta_apply(self._p['lr_theta'])
-                else:
-                    eng.theta_step(self.data_z, idx, x, y, v, self._p['lr_theta'], seed, s0, apply=True, out=out_t)
-                eng.z_step(x, y, v, self.data_z, zm, zv, idx, self._p['lr_z'], seed, s0 + 1, lazy=lazy, batch_global=bg, out=out_z)
-            if verbose:
-                lt, lz = out_t.cpu().numpy(), out_z.cpu().numpy()
-                print('Epoch [%d/%d]: loss_px_z [%.4f], loss_mse_x [%.4f], loss_py_z [%.4f], loss_mse_y [%.4f], loss_pv_z [%.4f], '
-                      'loss_mse_v [%.4f], loss_postrior_z [%.4f]' % (epoch, epochs, lt[2], lt[3], lt[4], lt[5], lt[0], lt[1], lz[0]))
-            if replay and (epoch % epochs_per_eval == 0 or epoch == epochs):
-                eng.z_sync(self.data_z, zm, zv, None, lr_z)                      # flush: evaluate / checkpoints read the whole table
-            if epoch % epochs_per_eval == 0:
-                causal_pre, mse_x, mse_y, mse_v = self._evaluate_dev(x, y, v, self.data_z, n_total, lo_r)
+        try:
+            for epoch in range(epochs + 1):
+                sample_idx = torch.from_numpy(np.random.choice(n_loc, n_loc, replace=False).astype(np.int32)).to(dev)
+                for i in range(0, n_use, b_loc):
+                    idx = sample_idx[i:min(i + b_loc, n_use)]
+                    if idx.numel() < 2:
+                        continue                      # batch statistics need two rows (the same decision on every rank)
+                    bg = int(idx.numel()) * world
+                    s0 = self._streams(3)
+                    if replay:
+                        eng.z_sync(self.data_z, zm, zv, idx, lr_z)
+                    if world > 1:
+                        eng.theta_step(self.data_z, idx, x, y, v, self._p['lr_theta'], seed, s0, apply=False, batch_global=bg, out=out_t)
+                        eng.grad_exchange(grad, False)
+                        parallel.all_reduce_sum_(grad)
+                        eng.grad_exchange(grad, True)
+                        eng.theta_apply(self._p['lr_theta'])
+                    else:
+                        eng.theta_step(self.data_z, idx, x, y, v, self._p['lr_theta'], seed, s0, apply=True, out=out_t)
+                    eng.z_step(x, y, v, self.data_z, zm, zv, idx, self._p['lr_z'], seed, s0 + 1, lazy=lazy, batch_global=bg, out=out_z)
                 if verbose:
-                    print('Epoch [%d/%d]: MSE_x: %.4f, MSE_y: %.4f, MSE_v: %.4f\n' % (epoch, epochs, mse_x, mse_y, mse_v))
-                if epoch >= startoff and mse_y < best_loss:
-                    best_loss = mse_y
-                    self.best_causal_pre = causal_pre
-                    self.best_epoch = epoch
-                    if self._p['save_model'] and parallel.rank() == 0:
-                        self.save_checkpoint(epoch)
-                if self._p['save_res'] and parallel.rank() == 0:
-                    save_data('{}/causal_pre_at_{}.{}'.format(self.save_dir, epoch, save_format), causal_pre)
+                    lt, lz = out_t.cpu().numpy(), out_z.cpu().numpy()
+                    print('Epoch [%d/%d]: loss_px_z [%.4f], loss_mse_x [%.4f], loss_py_z [%.4f], loss_mse_y [%.4f], loss_pv_z [%.4f], '
+                          'loss_mse_v [%.4f], loss_postrior_z [%.4f]' % (epoch, epochs, lt[2], lt[3], lt[4], lt[5], lt[0], lt[1], lz[0]))
+                if replay and (epoch % epochs_per_eval == 0 or epoch == epochs):
+                    eng.z_sync(self.data_z, zm, zv, None, lr_z)                      # flush: evaluate / checkpoints read the whole table
+                if epoch % epochs_per_eval == 0:
+                    causal_pre, mse_x, mse_y, mse_v = self._evaluate_dev(x, y, v, self.data_z, n_total, lo_r)
+                    if verbose:
+                        print('Epoch [%d/%d]: MSE_x: %.4f, MSE_y: %.4f, MSE_v: %.4f\n' % (epoch, epochs, mse_x, mse_y, mse_v))
+                    if epoch >= startoff and mse_y < best_loss:
+                        best_loss = mse_y
+                        self.best_causal_pre = causal_pre
+                        self.best_epoch = epoch
+                        if self._p['save_model'] and parallel.rank() == 0:
+                            self.save_checkpoint(epoch)
+                    if self._p['save_res'] and parallel.rank() == 0:
+                        save_data('{}/causal_pre_at_{}.{}'.format(self.save_dir, epoch, save_format), causal_pre)
+        finally:
+            if replay:          # an interrupted fit must not leave rows of data_z with unreplayed steps
+                try:
+                    eng.z_sync(self.data_z, zm, zv, None, lr_z)
+                except Exception:
+                    pass
         self._pull_weights()
 
     # ------------------------------------------------------------------ evaluate

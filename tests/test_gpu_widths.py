@@ -1,0 +1,391 @@
+"""Arbitrary hidden widths / depths of the deterministic CausalBGM (the general-width engine, csrc/gx_api.hip) against the oracle
+through the C ABI.  The reference forwards ANY `nb_units` list to BaseFullyConnectedNet (models/networks/base.py:7-28, default
+[256, 256, 256]; models/causalbgm/base.py:64-81) and its own integration tests construct g_units (8, 8), f / h / dz_units (8, 4)
+(r-package/bayesgm/tests/testthat/test-causalbgm.R:28-34).  Shapes here: those, [128, 128], [256, 256, 256], mixed depths.
+Same tolerances as test_gpu_causal.py / test_gpu_general.py.  BGM_FORCE_GX=1 sends a default-width model through the same engine."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import causal as OC  # noqa: E402
+from oracle import fit as OF      # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SHAPES = {
+    "r_test": dict(g_units=(8, 8), e_units=(8, 8), f_units=(8, 4), h_units=(8, 4)),                  # test-causalbgm.R:28-34
+    "w128": dict(g_units=(128, 128), e_units=(128, 128), f_units=(128, 128), h_units=(128, 128)),
+    "w256": dict(g_units=(256, 256, 256), e_units=(256, 256, 256), f_units=(256, 256, 256), h_units=(256, 256, 256)),   # networks/base.py:7
+    "mixed": dict(g_units=(48, 100, 17), e_units=(33,), f_units=(20, 7, 5, 3), h_units=(10,)),
+}
+
+
+def _engine(m, units):
+    from bayesgm_amd.engine import CausalEngine
+    eng = CausalEngine(m["v_dim"], m["z_dims"], binary_treatment=m["binary_treatment"],
+                       sigma_v=m.get("sigma_v"), sigma_x=m.get("sigma_x"), sigma_y=m.get("sigma_y"),
+                       **{k: list(v) for k, v in units.items()})
+    eng.set_model(g=m["g"], f=m["f"], h=m["h"], e=m["e"])
+    return eng
+
+
+def _data(n, p, seed, binary=False):
+    rs = np.random.RandomState(seed)
+    v = rs.randn(n, p).astype(np.float32)
+    x = rs.exponential(size=(n, 1)).astype(np.float32)
+    if binary:
+        x = (x > np.median(x)).astype(np.float32)
+    y = (x + rs.randn(n, 1)).astype(np.float32)
+    return x, y, v
+
+
+def _model(seed, z_dims, p, binary=False, **kw):
+    m = OC.init_model(seed, z_dims, p, binary_treatment=binary, **kw)
+    rs = np.random.RandomState(seed + 99)
+    for k in ("g", "f", "h", "e"):
+        m[k] = [(W.astype(np.float32), (0.1 * rs.randn(*b.shape)).astype(np.float32)) for W, b in m[k]]
+    return m
+
+
+def _as64(m, *arrs):
+    return OC.cast_model(m, np.float64), [a.astype(np.float64) for a in arrs]
+
+
+CASES = [
+    dict(shape="r_test", z_dims=[1, 1, 1, 1], p=4, binary=True, n=64),          # the R integration test, binary treatment
+    dict(shape="r_test", z_dims=[1, 1, 1, 1], p=4, binary=False, n=64),         # ... continuous treatment
+    dict(shape="w128", z_dims=[1, 1, 1, 7], p=200, binary=False, n=150),
+    dict(shape="w256", z_dims=[3, 3, 6, 6], p=100, binary=True, n=101),
+    dict(shape="mixed", z_dims=[2, 3, 4, 5], p=77, binary=False, n=45),
+    dict(shape="w128", z_dims=[10, 10, 10, 10], p=500, binary=False, n=70),     # sum(z_dims) = 40, wide data
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_logpost_matches_oracle(case):
+    u = SHAPES[case["shape"]]
+    m = _model(1, case["z_dims"], case["p"], case["binary"], **u)
+    x, y, v = _data(case["n"], case["p"], 2, case["binary"])
+    z = np.random.RandomState(3).randn(case["n"], sum(case["z_dims"])).astype(np.float32)
+    eng = _engine(m, u)
+    got = eng.logpost(x.ravel(), y.ravel(), v, z).cpu().numpy()
+    m64, (x64, y64, v64, z64) = _as64(m, x, y, v, z)
+    ref = OC.log_posterior(m64, x64, y64, v64, z64)
+    err = np.abs(got - ref)
+    assert np.all(err <= 1e-5 * np.abs(ref) + 1e-3), (err.max(), np.abs(ref).max())
+
+
+def test_logpost_fixed_sigmas():
+    u = SHAPES["mixed"]
+    m = _model(5, [2, 3, 4, 5], 77, False, sigma_v=0.8, sigma_x=1.3, sigma_y=0.5, **u)
+    x, y, v = _data(100, 77, 6)
+    z = np.random.RandomState(7).randn(100, 14).astype(np.float32)
+    got = _engine(m, u).logpost(x.ravel(), y.ravel(), v, z).cpu().numpy()
+    m64, (x64, y64, v64, z64) = _as64(m, x, y, v, z)
+    ref = OC.log_posterior(m64, x64, y64, v64, z64)
+    assert np.all(np.abs(got - ref) <= 1e-5 * np.abs(ref) + 1e-3)
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[2], CASES[3], CASES[4]])
+def test_encoder_matches_oracle(case):
+    from oracle.nets import mlp_forward
+    u = SHAPES[case["shape"]]
+    m = _model(41, case["z_dims"], case["p"], case["binary"], **u)
+    _, _, v = _data(case["n"], case["p"], 42, case["binary"])
+    got = _engine(m, u).encode(v).cpu().numpy()
+    ref = mlp_forward(OC.cast_model(m, np.float64)["e"], v.astype(np.float64))
+    assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max() + 1e-5
+
+
+def test_encoder_wide_data_default_widths():
+    """e_units = [64] x 5 at v_dim = 500: no LDS-resident encoder shape holds it, the general-width engine streams the V rows."""
+    from oracle.nets import mlp_forward
+    m = _model(43, [1, 1, 1, 7], 500)
+    _, _, v = _data(77, 500, 44)
+    from bayesgm_amd.engine import CausalEngine
+    eng = CausalEngine(500, [1, 1, 1, 7]); eng.set_model(g=m["g"], f=m["f"], h=m["h"], e=m["e"])
+    got = eng.encode(v).cpu().numpy()
+    ref = mlp_forward(OC.cast_model(m, np.float64)["e"], v.astype(np.float64))
+    assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max() + 1e-5
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[2], CASES[3], CASES[4]])
+def test_mh_chain_and_effects_match_oracle(case):
+    from bayesgm_amd import _lib
+    burn, keep, q_sd, seed = 20, 15, 0.3, 1234567890123
+    u = SHAPES[case["shape"]]
+    m = _model(21, case["z_dims"], case["p"], case["binary"], **u)
+    x, y, v = _data(case["n"], case["p"], 22, case["binary"])
+    eng = _engine(m, u)
+    xs = np.linspace(0, 3, 21)
+    kw = dict(effect=_lib.EFFECT_ITE) if case["binary"] else dict(effect=_lib.EFFECT_ADRF, x_values=xs)
+    out = eng.mh_sample(x, y, v, burn, keep, q_sd, seed, want_draws=True, chunk=11, sample_y=True, **kw)
+    draws = out["draws"].cpu().numpy()
+    acc = out["acc_count"].cpu().numpy()
+    ref, ref_acc, _ = OC.mh_sampler(m, (x, y, v), burn, keep, q_sd, seed, return_acc=True)
+    assert draws.shape == ref.shape
+    row_ok = np.all(np.abs(draws[-1] - ref[-1]) <= 1e-4, axis=1)
+    assert row_ok.mean() >= 0.97, row_ok.mean()
+    assert np.abs(acc.astype(np.int64) - ref_acc).max() <= max(2, int((~row_ok).sum()))
+    ref_eff = OC.infer_from_latent_posterior(OC.cast_model(m, np.float64), draws.astype(np.float64), None if case["binary"] else xs, True,
+                                             seed, burn_in=burn)
+    if case["binary"]:
+        assert np.abs(out["ite"].cpu().numpy().T - ref_eff).max() <= 5e-4
+    else:
+        assert np.abs(out["adrf"].cpu().numpy() - ref_eff).max() <= 2e-4
+    alone = eng.effects(x, out["draws"], burn, seed, x_values=None if case["binary"] else xs, sample_y=True).cpu().numpy()
+    assert np.abs(alone - ref_eff).max() <= 5e-4
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[2], CASES[3]])
+def test_evaluate_matches_oracle(case):
+    import torch
+    from oracle.nets import mlp_forward
+    u = SHAPES[case["shape"]]
+    m = _model(31, case["z_dims"], case["p"], case["binary"], **u)
+    x, y, v = _data(case["n"], case["p"], 32, case["binary"])
+    z = np.random.RandomState(33).randn(case["n"], sum(case["z_dims"])).astype(np.float32)
+    eng = _engine(m, u)
+    xs = np.linspace(0.1, 2.9, 200)
+    T = lambda a_: torch.from_numpy(np.ascontiguousarray(a_)).to(eng.device)
+    sums, causal = eng.evaluate(T(x.ravel()), T(y.ravel()), T(v), T(z), x_values=None if case["binary"] else xs)
+    sums = sums.cpu().numpy()
+    n = case["n"]
+    gv, gx, gy = sums[0] / (n * case["p"]), sums[1] / n, sums[2] / n
+    causal = causal.cpu().numpy() if case["binary"] else causal.cpu().numpy() / n
+    m64 = OC.cast_model(m, np.float64)
+    z64 = z.astype(np.float64)
+    z0d, z1d, z2d, _ = case["z_dims"]
+    g_out = mlp_forward(m64["g"], z64)
+    mv = ((v - g_out[:, :case["p"]]) ** 2).mean()
+    h_out = mlp_forward(m64["h"], np.concatenate([z64[:, :z0d], z64[:, z0d + z1d:z0d + z1d + z2d]], axis=1))[:, 0]
+    xp = 1.0 / (1.0 + np.exp(-h_out)) if case["binary"] else h_out
+    mx = ((x[:, 0] - xp) ** 2).mean()
+    fy = lambda xv: mlp_forward(m64["f"], np.concatenate([z64[:, :z0d + z1d], xv], axis=1))[:, 0]
+    my = ((y[:, 0] - fy(x.astype(np.float64))) ** 2).mean()
+    assert abs(gv - mv) <= 1e-4 * mv and abs(gx - mx) <= 1e-4 * max(mx, 1e-3) and abs(gy - my) <= 1e-4 * my
+    if case["binary"]:
+        ref = fy(np.ones((n, 1))) - fy(np.zeros((n, 1)))
+    else:
+        ref = np.array([fy(np.full((n, 1), t)).mean() for t in xs])
+    assert np.abs(np.asarray(causal) - ref).max() <= 2e-4
+
+
+def _flat(grads):
+    return np.concatenate([np.concatenate([dW.ravel(), db.ravel()]) for dW, db in grads])
+
+
+@pytest.mark.parametrize("case,B", [(CASES[0], 32), (CASES[1], 20), (CASES[2], 32), (CASES[3], 7), (CASES[4], 32), (CASES[4], 100), (CASES[5], 45)])
+def test_fit_gradients_match_oracle(case, B):
+    """theta gradients (g, f, h), the reported losses and the latent gradient of one minibatch -- including minibatches that are not
+    a multiple of the 32-row tile and one larger than it."""
+    import torch
+    u = SHAPES[case["shape"]]
+    n = max(case["n"], B + 5)
+    m = _model(7, case["z_dims"], case["p"], case["binary"], **u)
+    x, y, v = _data(n, case["p"], 8, case["binary"])
+    z = np.random.RandomState(9).randn(n, sum(case["z_dims"])).astype(np.float32)
+    eng = _engine(m, u)
+    dev = eng.device
+    xd, yd, vd, zd = (torch.from_numpy(a).to(dev) for a in (x.ravel(), y.ravel(), v, z))
+    idx_np = np.random.RandomState(3).choice(n, B, replace=False).astype(np.int32)
+    idx = torch.from_numpy(idx_np).to(dev)
+    npar = eng.fit_begin(n, B)
+    assert "gx_causal_fit_kernel" in eng.describe(B)
+    grad = torch.empty(npar, device=dev)
+    loss = torch.zeros(8, device=dev, dtype=torch.float64)
+    eng.fit_theta_grad(xd, yd, vd, zd, idx, B, grad, loss)
+    m64 = OC.cast_model(m, np.float64)
+    bz, bx, by, bv = (a[idx_np].astype(np.float64) for a in (z, x, y, v))
+    lv, _, gg, _ = OF.g_loss_and_grads(m64, bz, bv)
+    lx, _, gh, _ = OF.h_loss_and_grads(m64, bz, bx)
+    ly, _, gf, _ = OF.f_loss_and_grads(m64, bz, bx, by)
+    got = grad.cpu().numpy()
+    o = 0
+    for part in (_flat(gg), _flat(gf), _flat(gh)):
+        g_ = got[o:o + part.size]
+        assert np.abs(g_ - part).max() <= 5e-5 * np.abs(part).max() + 1e-7, (np.abs(g_ - part).max(), np.abs(part).max())
+        o += part.size
+    l = loss.cpu().numpy()
+    assert np.allclose([l[0] / B, l[2] / B, l[4] / B], [lv, lx, ly], rtol=5e-5)
+    zm = torch.zeros_like(zd); zv = torch.zeros_like(zd)
+    z_before = zd.clone()
+    loss.zero_()
+    eng.fit_z_step(xd, yd, vd, zd, zm, zv, idx, B, 1e-3, lazy=True, loss=loss)
+    lz_ref, dz_ref = OF.z_loss_and_grad(m64, bz, bx, by, bv)
+    assert np.isclose(loss.cpu().numpy()[6] / B, lz_ref, rtol=5e-5)
+    gm = zm.cpu().numpy()[idx_np] / 0.1
+    assert np.abs(gm - dz_ref).max() <= 5e-5 * np.abs(dz_ref).max() + 1e-8
+    untouched = np.setdiff1d(np.arange(n), idx_np)
+    assert torch.equal(zd[untouched], z_before[untouched])
+    eng.fit_end()
+
+
+@pytest.mark.parametrize("shape", ["r_test", "w256"])
+def test_fit_steps_then_sampling_with_the_trained_parameters(shape):
+    """Four Adam iterations (the last minibatch short) track the oracle; the log-posterior DURING the fit session reads the padded
+    copies the Adam kernel keeps current, and after fit_end the copies rebuilt from the host parameters give the same values."""
+    import torch
+    u = SHAPES[shape]
+    z_dims, p, n = [3, 6, 3, 6], 50, 96
+    m = _model(11, z_dims, p, True, **u)
+    x, y, v = _data(n, p, 12, True)
+    z = np.random.RandomState(13).randn(n, sum(z_dims)).astype(np.float32)
+    eng = _engine(m, u)
+    dev = eng.device
+    xd, yd, vd, zd = (torch.from_numpy(a).to(dev) for a in (x.ravel(), y.ravel(), v, z.copy()))
+    zm = torch.zeros_like(zd); zv = torch.zeros_like(zd)
+    B, lr = 32, 1e-3
+    npar = eng.fit_begin(n, B)
+    grad = torch.empty(npar, device=dev)
+    st = OF.FitState(OC.cast_model(m, np.float64), z.astype(np.float64), lr, lr)
+    x64, y64, v64 = (a.astype(np.float64) for a in (x, y, v))
+    rs = np.random.RandomState(5)
+    for step in range(4):
+        idx_np = rs.choice(n, B if step < 3 else 17, replace=False).astype(np.int32)
+        idx = torch.from_numpy(idx_np).to(dev)
+        eng.fit_theta_grad(xd, yd, vd, zd, idx, len(idx_np), grad)
+        eng.fit_theta_apply(grad, lr)
+        eng.fit_z_step(xd, yd, vd, zd, zm, zv, idx, len(idx_np), lr, lazy=False)
+        OF.fit_step(st, x64, y64, v64, idx_np, lazy_z=False)
+    assert np.abs(zd.cpu().numpy() - st.data_z).max() <= 3e-4
+    lp = eng.logpost(xd, yd, vd, zd).cpu().numpy()
+    ref = OC.log_posterior(dict(st.m), x64, y64, v64, st.data_z)
+    assert np.abs(lp - ref).max() <= 2e-2 + 1e-4 * np.abs(ref).max()
+    eng.fit_end()
+    lp2 = eng.logpost(xd, yd, vd, zd).cpu().numpy()
+    assert np.abs(lp - lp2).max() <= 1e-5 * np.abs(lp).max()
+
+
+def test_default_widths_fit_beyond_the_chain_envelope():
+    """Default hidden widths at v_dim = 500 (no row-tile chain, no LDS blob): fit on the general-width engine, a p = 500 CausalBGM
+    trains and its four-step Adam trace tracks oracle.fit; and a 100-row minibatch of a chain-only shape."""
+    import torch
+    from bayesgm_amd.engine import CausalEngine
+    z_dims, p, n = [1, 1, 1, 7], 500, 128
+    m = _model(51, z_dims, p, False)
+    x, y, v = _data(n, p, 52)
+    z = np.random.RandomState(53).randn(n, sum(z_dims)).astype(np.float32)
+    eng = CausalEngine(p, z_dims); eng.set_model(g=m["g"], f=m["f"], h=m["h"], e=m["e"])
+    dev = eng.device
+    xd, yd, vd, zd = (torch.from_numpy(a).to(dev) for a in (x.ravel(), y.ravel(), v, z.copy()))
+    zm = torch.zeros_like(zd); zv = torch.zeros_like(zd)
+    B, lr = 32, 1e-3
+    npar = eng.fit_begin(n, B)
+    assert "gx_causal_fit_kernel" in eng.describe(B)
+    grad = torch.empty(npar, device=dev)
+    st = OF.FitState(OC.cast_model(m, np.float64), z.astype(np.float64), lr, lr)
+    x64, y64, v64 = (a.astype(np.float64) for a in (x, y, v))
+    rs = np.random.RandomState(5)
+    for step in range(4):
+        idx_np = rs.choice(n, B if step < 3 else 17, replace=False).astype(np.int32)
+        idx = torch.from_numpy(idx_np).to(dev)
+        eng.fit_theta_grad(xd, yd, vd, zd, idx, len(idx_np), grad)
+        eng.fit_theta_apply(grad, lr)
+        eng.fit_z_step(xd, yd, vd, zd, zm, zv, idx, len(idx_np), lr, lazy=False)
+        OF.fit_step(st, x64, y64, v64, idx_np, lazy_z=False)
+    assert np.abs(zd.cpu().numpy() - st.data_z).max() <= 3e-4
+    lp = eng.logpost(xd, yd, vd, zd).cpu().numpy()          # (streamed-fragment sampling path, repacked from the device parameters)
+    ref = OC.log_posterior(dict(st.m), x64, y64, v64, st.data_z)
+    assert np.abs(lp - ref).max() <= 2e-2 + 1e-4 * np.abs(ref).max()
+    eng.fit_end()
+
+
+def test_forced_general_width_engine_equals_resident_kernels():
+    """The bench shape through both kernel families: chains, effects and log-posteriors agree to rounding."""
+    code = r'''
+import numpy as np, sys
+sys.path.insert(0, %r)
+from oracle import causal as OC
+from bayesgm_amd.engine import CausalEngine
+from bayesgm_amd import _lib
+m = OC.init_model(3, [1, 1, 1, 7], 200)
+rs = np.random.RandomState(4)
+n = 400
+v = rs.randn(n, 200).astype(np.float32); x = rs.exponential(size=(n, 1)).astype(np.float32); y = (x + rs.randn(n, 1)).astype(np.float32)
+eng = CausalEngine(200, [1, 1, 1, 7]); eng.set_model(g=m["g"], f=m["f"], h=m["h"], e=m["e"])
+z = rs.randn(n, 10).astype(np.float32)
+lp = eng.logpost(x.ravel(), y.ravel(), v, z).cpu().numpy()
+enc = eng.encode(v).cpu().numpy()
+out = eng.mh_sample(x, y, v, 30, 10, 0.4, 77, want_draws=True, effect=_lib.EFFECT_ADRF, x_values=np.linspace(0, 3, 20))
+np.savez(sys.argv[1], lp=lp, enc=enc, draws=out["draws"].cpu().numpy(), adrf=out["adrf"].cpu().numpy(), path=eng.describe())
+''' % ROOT
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        res = {}
+        for tag, env in (("resident", {}), ("gx", {"BGM_FORCE_GX": "1"})):
+            path = os.path.join(d, tag + ".npz")
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, **env), timeout=600)
+            res[tag] = np.load(path)
+        a, b = res["resident"], res["gx"]
+        assert "gx_causal_mh_kernel" in str(b["path"]) and "gx_causal_mh_kernel" not in str(a["path"])
+        assert np.abs(a["lp"] - b["lp"]).max() <= 1e-5 * np.abs(a["lp"]).max() + 1e-3
+        assert np.abs(a["enc"] - b["enc"]).max() <= 1e-5
+        same = np.all(np.abs(a["draws"][-1] - b["draws"][-1]) <= 1e-4, axis=1).mean()
+        assert same >= 0.97, same
+        assert np.abs(a["adrf"] - b["adrf"]).max() <= 5e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the class surface on the parameter dicts of the reference's own integration tests
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("binary", [True, False])
+def test_r_integration_test_parameters_through_the_class(tmp_path, binary):
+    """r-package/bayesgm/tests/testthat/test-causalbgm.R:17-60 / :62-120: n = 64, v_dim = 4, z_dims (1,1,1,1), g / e_units (8, 8),
+    f / h / dz_units (8, 4), fit(epochs = 0, use_egm_init = False), predict(n_mcmc = 5, burn_in = 10, q_sd = 0.5) -- and the same
+    model through egm_init, fit(epochs = 5), evaluate."""
+    from bayesgm_amd.models import CausalBGM
+    rs = np.random.RandomState(123)
+    n = 64
+    v = rs.randn(n, 4).astype(np.float32)
+    if binary:
+        x = (rs.rand(n, 1) < 0.5).astype(np.float32)
+        y = (1.5 * x[:, :1] + 0.7 * v[:, :1] - 0.3 * v[:, 1:2] + 0.25 * rs.randn(n, 1)).astype(np.float32)
+    else:
+        x = rs.exponential(size=(n, 1)).astype(np.float32)
+        y = (x + 0.5 * v[:, :1] + 0.3 * rs.randn(n, 1)).astype(np.float32)
+    params = dict(dataset="RBinary" if binary else "RContinuous", output_dir=str(tmp_path), save_res=False, save_model=False,
+                  binary_treatment=binary, use_bnn=False, z_dims=[1, 1, 1, 1], v_dim=4, lr_theta=1e-4, lr_z=1e-4, lr=2e-4, g_d_freq=5,
+                  use_z_rec=True, kl_weight=1e-4, g_units=[8, 8], e_units=[8, 8], f_units=[8, 4], h_units=[8, 4], dz_units=[8, 4])
+    m = CausalBGM(dict(params), timestamp="t", random_seed=1)
+    m.fit((x, y, v), epochs=0, epochs_per_eval=1, batch_size=32, use_egm_init=False, egm_n_iter=0, egm_batches_per_eval=1, verbose=0)
+    kw = {} if binary else dict(x_values=[0.0, 1.0, 2.0])
+    eff, iv = m.predict((x, y, v), n_mcmc=5, burn_in=10, q_sd=0.5, **kw)
+    if binary:
+        assert eff.shape == (n,) and iv.shape == (n, 2)
+    else:
+        assert eff.shape == (3,) and iv.shape == (3, 2)
+    assert np.isfinite(eff).all() and np.isfinite(iv).all()
+    m2 = CausalBGM(dict(params), timestamp="t2", random_seed=2)
+    m2.egm_init((x, y, v), egm_n_iter=40, batch_size=32, egm_batches_per_eval=20, verbose=0)
+    m2.fit((x, y, v), epochs=5, epochs_per_eval=1, batch_size=32, use_egm_init=False, verbose=0)
+    causal_pre, mse_x, mse_y, mse_v = m2.evaluate((x, y, v))
+    assert np.isfinite(np.asarray(causal_pre)).all() and np.isfinite([mse_x, mse_y, mse_v]).all()
+    eff, iv = m2.predict((x, y, v), n_mcmc=5, burn_in=10, q_sd=0.5, **kw)
+    assert np.isfinite(eff).all()
+
+
+def test_reference_default_nb_units_through_the_class(tmp_path):
+    """nb_units = [256, 256, 256] (the default of BaseFullyConnectedNet, networks/base.py:7) for every network: warm start, five
+    epochs (short last minibatch), evaluate, predict."""
+    from bayesgm_amd.models import CausalBGM
+    rs = np.random.RandomState(0)
+    n, p = 150, 30
+    v = rs.randn(n, p).astype(np.float32)
+    x = rs.exponential(size=(n, 1)).astype(np.float32)
+    y = (x + 0.3 * v[:, :1] + rs.randn(n, 1)).astype(np.float32)
+    params = dict(dataset="w256", output_dir=str(tmp_path), save_res=False, save_model=False, binary_treatment=False, use_bnn=False,
+                  z_dims=[1, 1, 1, 7], v_dim=p, lr_theta=1e-4, lr_z=1e-4, lr=2e-4, g_d_freq=5, use_z_rec=True, kl_weight=1e-4,
+                  g_units=[256] * 3, e_units=[256] * 3, f_units=[256] * 3, h_units=[256] * 3, dz_units=[256] * 3)
+    m = CausalBGM(params, timestamp="t", random_seed=1)
+    m.fit((x, y, v), epochs=5, epochs_per_eval=5, batch_size=32, use_egm_init=True, egm_n_iter=20, egm_batches_per_eval=10, verbose=0)
+    assert m.data_z.shape == (n, 10)
+    causal_pre, mse_x, mse_y, mse_v = m.evaluate((x, y, v))
+    assert np.isfinite(np.asarray(causal_pre)).all() and np.isfinite([mse_x, mse_y, mse_v]).all()
+    eff, iv = m.predict((x, y, v), alpha=0.05, n_mcmc=5, burn_in=10, x_values=np.linspace(0, 2, 4), q_sd=0.5)
+    assert eff.shape == (4,) and iv.shape == (4, 2) and np.isfinite(eff).all()
