@@ -6,6 +6,7 @@
 #include "bgm_host.h"
 #include "bgm_kernels.h"
 #include "bgm_state.h"
+#include "gx_bgm_host.h"
 
 static constexpr int BGM_WAVES = 8;
 #ifndef BGM_WAVES_WIDE_HMC
@@ -17,6 +18,7 @@ void bgm_bgm_free_state(bgm_handle *h) {
   if (!h->bgm_state) return;
   BgmState *s = static_cast<BgmState *>(h->bgm_state);
   bgm_bgm_fit_free(h);
+  gxb_free(s);
   if (s->blob_dev) hipFree(s->blob_dev);
   delete s;
   h->bgm_state = nullptr;
@@ -36,10 +38,12 @@ extern "C" int bgm_bgm_configure(bgm_handle *h, const bgm_bgm_config *cfg) {
   if (cfg->x_dim < 1 || cfg->z_dim < 1 || cfg->n_hidden_g < 1 || cfg->n_hidden_g > BGM_MAX_LAYERS) {
     bgm_set_error("bgm_bgm_configure: bad dimensions"); return BGM_E_INVALID;
   }
+  // any trunk (networks/base.py:53-117 takes any nb_units): [64] x 3 / [64] x 5 at z_dim <= 16 run on the dual-access-blob kernels,
+  // every other shape on the general-width engine (gx_bgm_api.hip)
   for (int i = 0; i < cfg->n_hidden_g; ++i)
-    if (cfg->g_units[i] != 64) { bgm_set_error("bgm_bgm_configure: only g_units=[64]*k is compiled"); return BGM_E_UNSUPPORTED; }
-  if (cfg->z_dim > 16) { bgm_set_error("bgm_bgm_configure: z_dim > 16 not compiled"); return BGM_E_UNSUPPORTED; }
+    if (cfg->g_units[i] < 1 || cfg->g_units[i] > 4096) { bgm_set_error("bgm_bgm_configure: g_units must be in [1, 4096]"); return BGM_E_INVALID; }
   BgmState *s = bst(h);
+  gxb_free(s);
   s->cfg = *cfg;
   s->configured = true; s->set = false; s->blob_valid = false;
   s->theta.assign(bgm_count(*cfg), 0.0f);
@@ -54,7 +58,7 @@ extern "C" int bgm_bgm_set_weights(bgm_handle *h, const float *theta, int64_t co
     bgm_set_error("bgm_bgm_set_weights: expected " + std::to_string(s->theta.size()) + " floats"); return BGM_E_INVALID;
   }
   std::memcpy(s->theta.data(), theta, sizeof(float) * count);
-  s->set = true; s->blob_valid = false;
+  s->set = true; s->blob_valid = false; s->gx_valid = false;
   return BGM_OK;
 }
 
@@ -130,6 +134,7 @@ extern "C" int bgm_bgm_logpost(bgm_handle *h, const float *z, const float *x, in
   if (!z || !x || !out) { bgm_set_error("bgm_bgm_logpost: NULL pointer"); return BGM_E_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
+  if (gxb_wanted(bst(h))) return gxb_logpost(h, bst(h), z, x, n, out, grad, stream);
   int rc = bgm_build_blob(h, stream);
   if (rc) return rc;
   BgmState *s = bst(h);
@@ -156,6 +161,7 @@ extern "C" int bgm_bgm_hmc_run(bgm_handle *h, const bgm_hmc_args *a, void *strea
   if (a->row_base + a->n > 0xFFFFFFFFll) { bgm_set_error("bgm_bgm_hmc_run: row index exceeds the 32-bit RNG counter"); return BGM_E_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
+  if (gxb_wanted(bst(h))) return gxb_hmc_run(h, bst(h), a, stream);
   int rc = bgm_build_blob(h, stream);
   if (rc) return rc;
   BgmState *s = bst(h);
@@ -220,6 +226,7 @@ extern "C" int bgm_bgm_predict_draws(bgm_handle *h, const float *draws, int64_t 
   if (!draws || (!cells && !full && !var_full) || (cells && (!slot || k_slots <= 0))) { bgm_set_error("bgm_bgm_predict_draws: bad pointers"); return BGM_E_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
+  if (gxb_wanted(bst(h))) return gxb_predict_draws(h, bst(h), draws, n, row_base, n_draws, burn_in, seed, slot, k_slots, cells, full, var_full, add_noise, stream);
   int rc = bgm_build_blob(h, stream);
   if (rc) return rc;
   BgmState *s = bst(h);

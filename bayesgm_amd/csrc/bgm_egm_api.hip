@@ -229,7 +229,7 @@ extern "C" int bgm_bgm_egm_sync(bgm_handle *h, void *stream_) {
   BGM_HIP_CHECK(hipSetDevice(h->device));
   BGM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_));
   BGM_HIP_CHECK(hipMemcpy(bs->theta.data(), s->base.theta_g, s->n_g * sizeof(float), hipMemcpyDeviceToHost));
-  bs->set = true; bs->blob_valid = false;
+  bs->set = true; bs->blob_valid = false; bs->gx_valid = false;
   return BGM_OK;
 }
 

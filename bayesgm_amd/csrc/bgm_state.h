@@ -29,6 +29,9 @@ struct BgmState {
   BgmMeta tmeta{};             // training blob layout (same offsets as meta)
   BgmFitWs fit_ws{};
   DwArgs dw{};
+  // general-width engine (gx_bgm_api.hip): trunk widths other than [64] x {3, 5}, z_dim > 16
+  void *gx = nullptr;
+  bool gx_valid = false, gx_fit = false;
 };
 
 static inline BgmState *bst(bgm_handle *h) {

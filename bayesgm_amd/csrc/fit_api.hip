@@ -727,6 +727,7 @@ extern "C" int bgm_causal_fit_end(bgm_handle *h, void *stream_) {
 // BGM.fit step functions (bgm/base.py:145-187, 399-413) -- see bgm_fit_kernels.h
 // ===========================================================================================
 #include "bgm_state.h"
+#include "gx_bgm_host.h"
 
 static constexpr int BGM_FIT_WAVES = 8;
 
@@ -738,7 +739,7 @@ void bgm_bgm_fit_free(bgm_handle *h) {
     if (p) hipFree(p);
   s->theta_dev = s->m1_dev = s->m2_dev = s->tblob_dev = s->ws_dev = s->partial_dev = s->bn_dev = nullptr;
   s->tables_dev = nullptr;
-  s->fit_active = false;
+  s->fit_active = false; s->gx_fit = false;
 }
 
 // training blob: same layout as the inference blob but WITHOUT folding the BatchNorm into layer 1
@@ -779,6 +780,11 @@ extern "C" int bgm_bgm_fit_begin(bgm_handle *h, int64_t n_rows, int32_t max_batc
   BgmState *s = bst(h);
   BGM_HIP_CHECK(hipSetDevice(h->device));
   bgm_bgm_fit_free(h);
+  if (gxb_wanted(s)) {         // trunk widths / depth outside the compiled blob kernels: the general-width engine (gx_bgm_api.hip)
+    int rc = gxb_fit_begin(h, s, n_rows, max_batch, (hipStream_t)stream_);
+    if (rc) bgm_bgm_fit_free(h);
+    return rc;
+  }
   const int q = s->cfg.z_dim, p = s->cfg.x_dim, NH = s->cfg.n_hidden_g;
   const int KTQ = (q + 15) / 16, NTX = (p + 15) / 16, KQ = 16 * KTQ;
   BgmMeta &m = s->tmeta;
@@ -864,6 +870,7 @@ static int bgm_fit_fwd_bwd(bgm_handle *h, BgmState *s, const float *x, const flo
   hipLaunchKernelGGL(bgm_bn_stats_kernel, dim3(1), dim3(256), 0, stream, data_z, idx, batch, q, KQ, s->theta_dev, s->bn_dev,
                      s->theta_dev + 2 * q, update_moving);
   BGM_HIP_CHECK(hipGetLastError());
+  if (s->gx_fit) return gxb_fit_fwd_bwd(h, s, x, data_z, idx, batch, loss, stream);
   BgmFitKArgs ka{};
   ka.blob = s->tblob_dev; ka.m = s->tmeta; ka.ws = s->fit_ws; ka.wsp = s->ws_dev; ka.x = x; ka.data_z = data_z;
   ka.idx = idx; ka.B = batch; ka.inv_B = 1.0f / (float)(s->batch_global > 0 ? s->batch_global : batch); ka.bn = s->bn_dev; ka.loss = loss;
@@ -940,7 +947,8 @@ extern "C" int bgm_bgm_fit_theta_apply(bgm_handle *h, const float *grad, float l
   const int *tb = s->tables_dev;
   // moving mean/var sit in theta but receive a zero gradient (m = v = 0 -> no Adam movement)
   hipLaunchKernelGGL(fit_adam_theta_kernel, dim3((np + 255) / 256), dim3(256), 0, (hipStream_t)stream_, s->theta_dev, s->m1_dev,
-                     s->m2_dev, grad, np, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS, s->tblob_dev, s->tblob_dev, tb, tb + np, tb + 2 * (size_t)np);
+                     s->m2_dev, grad, np, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS, s->gx_fit ? gxb_pack(s) : s->tblob_dev, s->gx_fit ? gxb_packT(s) : s->tblob_dev, tb,
+                     tb + np, tb + 2 * (size_t)np);
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
 }
@@ -993,5 +1001,6 @@ extern "C" int bgm_bgm_fit_end(bgm_handle *h, void *stream_) {
   BGM_HIP_CHECK(hipMemcpy(s->theta.data(), s->theta_dev, sizeof(float) * s->theta.size(), hipMemcpyDeviceToHost));
   bgm_bgm_fit_free(h);
   s->blob_valid = false;   // inference blob (BN folded with the new moving statistics) is rebuilt on next use
+  s->gx_valid = false;
   return BGM_OK;
 }

@@ -45,32 +45,32 @@ __host__ __device__ inline int gx_ld(int width) { return ((width + 59) / 64) * 6
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Y = A W for the workgroup's 32 rows.  W [K][N] (padded, global), A [32][lda] in LDS (A_GLOBAL = false) or in global memory
-// (true: row r of the tile at A + r * lda).  epi(rt, n0, acc0, acc1): lane (j, g) holds rows 16 rt + 4g + r (r = 0..3) of columns
+// (true: row r of the tile at A + r * lda); gx_dense_ld: the N columns processed are a slice of rows of stride ldw.  epi(rt, n0, acc0, acc1): lane (j, g) holds rows 16 rt + 4g + r (r = 0..3) of columns
 // n0 + 2j (acc0[r]) and n0 + 2j + 1 (acc1[r]).  No barriers inside: the caller separates producers and consumers of A.
 // ---------------------------------------------------------------------------------------------------------------------------
 template <bool A_GLOBAL = false, class Epi>
-__device__ __forceinline__ void gx_dense(const float *__restrict__ W, int K, int N, const float *A, int lda, Epi epi) {
+__device__ __forceinline__ void gx_dense_ld(const float *__restrict__ W, int ldw, int K, int N, const float *A, int lda, Epi epi) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
   const int units = 2 * (N >> 5);
   for (int u = wave; u < units; u += GX_WAVES) {
     const int rt = u & 1, n0 = (u >> 1) << 5;
     f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
     const float *ap = A + (size_t)(16 * rt + j) * lda + 4 * g;
-    const float *wk = W + (size_t)(4 * g) * N + n0 + 2 * j;
-    const size_t wstep = (size_t)16 * N;
+    const float *wk = W + (size_t)(4 * g) * ldw + n0 + 2 * j;
+    const size_t wstep = (size_t)16 * ldw;
     // software pipeline: the operands of K block k0 + 16 are requested before the MFMAs of block k0 issue
     f32x4 a = *reinterpret_cast<const f32x4 *>(ap);
     f32x2 b0 = *reinterpret_cast<const f32x2 *>(wk);
-    f32x2 b1 = *reinterpret_cast<const f32x2 *>(wk + N);
-    f32x2 b2 = *reinterpret_cast<const f32x2 *>(wk + 2 * (size_t)N);
-    f32x2 b3 = *reinterpret_cast<const f32x2 *>(wk + 3 * (size_t)N);
+    f32x2 b1 = *reinterpret_cast<const f32x2 *>(wk + ldw);
+    f32x2 b2 = *reinterpret_cast<const f32x2 *>(wk + 2 * (size_t)ldw);
+    f32x2 b3 = *reinterpret_cast<const f32x2 *>(wk + 3 * (size_t)ldw);
     for (int k0 = 16; k0 < K; k0 += 16) {
       wk += wstep;
       const f32x4 an = *reinterpret_cast<const f32x4 *>(ap + k0);
       const f32x2 c0 = *reinterpret_cast<const f32x2 *>(wk);
-      const f32x2 c1 = *reinterpret_cast<const f32x2 *>(wk + N);
-      const f32x2 c2 = *reinterpret_cast<const f32x2 *>(wk + 2 * (size_t)N);
-      const f32x2 c3 = *reinterpret_cast<const f32x2 *>(wk + 3 * (size_t)N);
+      const f32x2 c1 = *reinterpret_cast<const f32x2 *>(wk + ldw);
+      const f32x2 c2 = *reinterpret_cast<const f32x2 *>(wk + 2 * (size_t)ldw);
+      const f32x2 c3 = *reinterpret_cast<const f32x2 *>(wk + 3 * (size_t)ldw);
       acc0 = BGM_MFMA(a[0], b0[0], acc0); acc1 = BGM_MFMA(a[0], b0[1], acc1);
       acc0 = BGM_MFMA(a[1], b1[0], acc0); acc1 = BGM_MFMA(a[1], b1[1], acc1);
       acc0 = BGM_MFMA(a[2], b2[0], acc0); acc1 = BGM_MFMA(a[2], b2[1], acc1);
@@ -83,6 +83,12 @@ __device__ __forceinline__ void gx_dense(const float *__restrict__ W, int K, int
     acc0 = BGM_MFMA(a[3], b3[0], acc0); acc1 = BGM_MFMA(a[3], b3[1], acc1);
     epi(rt, n0, acc0, acc1);
   }
+}
+
+// W [K][N] with row stride N
+template <bool A_GLOBAL = false, class Epi>
+__device__ __forceinline__ void gx_dense(const float *__restrict__ W, int K, int N, const float *A, int lda, Epi epi) {
+  gx_dense_ld<A_GLOBAL>(W, N, K, N, A, lda, epi);
 }
 
 // Epilogue helpers -------------------------------------------------------------------------------------------------------------

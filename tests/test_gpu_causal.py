@@ -222,7 +222,7 @@ def test_mh_adaptive_q_sd_follows_reference_schedule():
 def test_errors_are_loud():
     from bayesgm_amd.engine import CausalEngine
     with pytest.raises(RuntimeError):
-        CausalEngine(200, [1, 1, 1, 7], g_units=[64, 48])           # uncompiled width
+        CausalEngine(200, [1, 1, 1, 7], g_units=[64, 0])            # not a width (any positive width is accepted: tests/test_gpu_widths.py)
     eng = CausalEngine(200, [1, 1, 1, 7])
     with pytest.raises(RuntimeError):                               # weights not set
         eng.logpost(np.zeros(4, np.float32), np.zeros(4, np.float32), np.zeros((4, 200), np.float32),

@@ -389,3 +389,212 @@ def test_reference_default_nb_units_through_the_class(tmp_path):
     assert np.isfinite(np.asarray(causal_pre)).all() and np.isfinite([mse_x, mse_y, mse_v]).all()
     eff, iv = m.predict((x, y, v), alpha=0.05, n_mcmc=5, burn_in=10, x_values=np.linspace(0, 2, 4), q_sd=0.5)
     assert eff.shape == (4,) and iv.shape == (4, 2) and np.isfinite(eff).all()
+
+
+# ===========================================================================================================================
+# BGM: generators g_net = BaseVariationalNet with arbitrary trunk widths / depth / latent width (csrc/gx_bgm_api.hip)
+# ===========================================================================================================================
+from oracle import bgm as OB  # noqa: E402
+
+
+def _bgm_model(seed, q, p, units):
+    m = OB.init_model(seed, q, p, g_units=tuple(units))
+    rs = np.random.RandomState(seed + 7)
+    g = m["g"]
+    g["bn"].update(gamma=(1 + 0.1 * rs.randn(q)).astype(np.float32), beta=(0.1 * rs.randn(q)).astype(np.float32),
+                   mean=(0.2 * rs.randn(q)).astype(np.float32), var=(0.5 + rs.rand(q)).astype(np.float32))
+    g["trunk"] = [(W, (0.1 * rs.randn(*b.shape)).astype(np.float32)) for W, b in g["trunk"]]
+    g["mean"] = (g["mean"][0], (0.1 * rs.randn(p)).astype(np.float32))
+    g["var"] = (g["var"][0], (0.1 * rs.randn(p)).astype(np.float32))
+    return m
+
+
+def _bgm_data(n, p, seed, miss=0.2):
+    rs = np.random.RandomState(seed)
+    x = rs.randn(n, p).astype(np.float32)
+    x[rs.rand(n, p) < miss] = np.nan
+    x[0, :] = np.nan
+    if n > 1:
+        x[1, :] = rs.randn(p)
+    return x
+
+
+def _bgm_engine(m):
+    from bayesgm_amd.engine import BgmEngine
+    eng = BgmEngine(m["x_dim"], m["z_dim"], g_units=[W.shape[1] for W, _ in m["g"]["trunk"]])
+    eng.set_weights(m["g"])
+    return eng
+
+
+BGM_CASES = [
+    dict(q=3, p=8, n=96, units=(8, 8)),                  # r-package/bayesgm/tests/testthat/test-bgm.R:17-50
+    dict(q=10, p=100, n=333, units=(128, 128)),
+    dict(q=10, p=50, n=70, units=(256, 256, 256)),       # networks/base.py:56 default nb_units
+    dict(q=20, p=500, n=130, units=(64, 64)),            # z_dim > 16, two hidden layers, wide data
+    dict(q=5, p=37, n=33, units=(40, 24, 100, 9)),
+]
+
+
+@pytest.mark.parametrize("case", BGM_CASES)
+def test_bgm_logpost_and_gradient_match_oracle(case):
+    m = _bgm_model(1, case["q"], case["p"], case["units"])
+    x = _bgm_data(case["n"], case["p"], 2)
+    z = np.random.RandomState(3).randn(case["n"], case["q"]).astype(np.float32)
+    eng = _bgm_engine(m)
+    lp, gr = eng.logpost(z, x, want_grad=True)
+    lp0 = eng.logpost(z, x)
+    obs, clean = OB.obs_mask_of(x)
+    m64 = OB.cast_model(m, np.float64)
+    ref_lp, ref_gr = OB.log_posterior_and_grad(m64, z.astype(np.float64), clean.astype(np.float64), obs.astype(np.float64))
+    lp, gr, lp0 = lp.cpu().numpy(), gr.cpu().numpy(), lp0.cpu().numpy()
+    assert np.abs(lp - lp0).max() <= 1e-5 * np.abs(lp).max()
+    assert np.all(np.abs(lp - ref_lp) <= 2e-6 * np.abs(ref_lp) + 2e-4), np.abs(lp - ref_lp).max()
+    assert np.abs(gr - ref_gr).max() <= 2e-5 * np.abs(ref_gr).max() + 2e-5, np.abs(gr - ref_gr).max()
+    assert abs(lp[0] + 0.5 * (z[0] ** 2).sum()) < 1e-5 and np.allclose(gr[0], -z[0], atol=1e-6)
+
+
+@pytest.mark.parametrize("case", BGM_CASES[:4])
+def test_bgm_hmc_chain_and_step_adaptation_match_oracle(case):
+    import torch
+    m = _bgm_model(11, case["q"], case["p"], case["units"])
+    x = _bgm_data(case["n"], case["p"], 12)
+    burn, keep, L, seed = 20, 10, 4, 77
+    eng = _bgm_engine(m)
+    out = eng.hmc_sample(x, keep, burn, step_size=0.02, n_leapfrog=L, seed=seed)
+    obs, clean = OB.obs_mask_of(x)
+    ref, info = OB.hmc_sampler(m, clean, obs.astype(np.float32), keep, burn, 0.02, L, seed, return_info=True)
+    draws = out["draws"].cpu().numpy()
+    assert draws.shape == ref.shape
+    ok = np.all(np.abs(draws[-1] - ref[-1]) <= 2e-3, axis=1)
+    assert ok.mean() >= 0.97, ok.mean()
+    assert abs(float(out["step"].item()) / info["step"] - 1) < 1e-5
+    acc = out["acc_count"].cpu().numpy()[burn:].sum() / (keep * case["n"])
+    assert abs(acc - info["accept_rate"]) < 0.03 and acc > 0.5
+    out2 = eng.hmc_sample(x, keep, burn, step_size=0.02, n_leapfrog=L, seed=seed)
+    assert torch.equal(out2["draws"], out["draws"])
+
+
+@pytest.mark.parametrize("case", [BGM_CASES[0], BGM_CASES[2], BGM_CASES[3]])
+def test_bgm_predictive_draws_match_oracle_on_same_latents(case):
+    import torch
+    q, p = case["q"], case["p"]
+    m = _bgm_model(31, q, p, case["units"])
+    rs = np.random.RandomState(32)
+    draws = rs.randn(6, 40, q).astype(np.float32)
+    eng = _bgm_engine(m)
+    ref = OB.predict_on_posteriors(OB.cast_model(m, np.float64), draws.astype(np.float64), seed=9, burn_in=13)
+    _, full = eng.predict_draws(torch.from_numpy(draws).cuda(), 13, 9, want_full=True)
+    assert np.abs(full.cpu().numpy() - ref).max() <= 2e-4
+    miss = rs.rand(40, p) < 0.2
+    slot = np.full((40, p), -1, np.int32)
+    k = 0
+    for i in range(40):
+        c = np.where(miss[i])[0]
+        slot[i, c] = np.arange(len(c))
+        k = max(k, len(c))
+    cells, _ = eng.predict_draws(torch.from_numpy(draws).cuda(), 13, 9, slot=torch.from_numpy(slot).cuda(), k_slots=k)
+    cells = cells.cpu().numpy().reshape(40, k, 6)
+    for i in range(40):
+        c = np.where(miss[i])[0]
+        if len(c):
+            assert np.abs(cells[i, :len(c)] - ref[:, i, c].T).max() <= 2e-4
+
+
+@pytest.mark.parametrize("case,B", [(BGM_CASES[0], 32), (BGM_CASES[1], 20), (BGM_CASES[2], 32), (BGM_CASES[3], 77)])
+def test_bgm_fit_steps_match_oracle(case, B):
+    """BGM fit step functions (training-mode BatchNorm, per-dimension variance head, fresh-slot Adam on Z) on the general engine."""
+    import torch
+    q, p, lr = case["q"], case["p"], 2e-3
+    n = max(96, B + 40)
+    m = _bgm_model(61, q, p, case["units"])
+    rs = np.random.RandomState(62)
+    x = rs.randn(n, p).astype(np.float32)
+    z = rs.randn(n, q).astype(np.float32)
+    eng = _bgm_engine(m)
+    xd, zd = torch.from_numpy(x).cuda(), torch.from_numpy(z.copy()).cuda()
+    npar = eng.fit_begin(n, B)
+    grad = torch.empty(npar, device="cuda")
+    loss = torch.zeros(4, device="cuda", dtype=torch.float64)
+    m64 = OB.cast_model(m, np.float64)
+    st = OB.BgmFitState(m64, z.astype(np.float64), lr, lr)
+    x64 = x.astype(np.float64)
+    idx_np = rs.choice(n, B, replace=False).astype(np.int32)
+    idx = torch.from_numpy(idx_np).cuda()
+    eng.fit_theta_grad(xd, zd, idx, grad, loss)
+    l_ref, mse_ref, gr, _, _ = OB.g_loss_and_grads(m64, st.data_z[idx_np], x64[idx_np])
+    ref = np.concatenate([a.ravel() for a in OB._flat_bgm_grads(gr)])
+    got = grad.cpu().numpy()
+    got_t = np.concatenate([got[:2 * q], got[4 * q:]])
+    assert np.all(got[2 * q:4 * q] == 0)
+    assert np.abs(got_t - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-7, np.abs(got_t - ref).max()
+    assert np.isclose(loss.cpu().numpy()[0] / B, l_ref, rtol=2e-5)
+    eng.fit_end()
+    eng.set_weights(m["g"])
+    eng.fit_begin(n, B)
+    for step in range(3):
+        idx_np = rs.choice(n, B, replace=False).astype(np.int32)
+        idx = torch.from_numpy(idx_np).cuda()
+        eng.fit_theta_grad(xd, zd, idx, grad)
+        eng.fit_theta_apply(grad, lr)
+        eng.fit_z_step(xd, zd, idx, lr)
+        OB.fit_step(st, x64, idx_np)
+    assert np.abs(zd.cpu().numpy() - st.data_z).max() <= 5e-4
+    # the log posterior DURING the session reads the packs the Adam kernel keeps current and the device BatchNorm statistics
+    lp_in = eng.logpost(zd, xd).cpu().numpy()
+    g_tr = eng.get_weights()
+    for k in ("gamma", "beta", "mean", "var"):
+        assert np.abs(g_tr["bn"][k] - m64["g"]["bn"][k]).max() <= 5e-4, k
+    for (W, b), (Wr, br) in zip(g_tr["trunk"], m64["g"]["trunk"]):
+        assert np.abs(W - Wr).max() <= 5e-4 and np.abs(b - br).max() <= 5e-4
+    for k in ("mean", "var"):
+        assert np.abs(g_tr[k][0] - m64["g"][k][0]).max() <= 5e-4
+    eng.fit_end()
+    lp = eng.logpost(zd, xd).cpu().numpy()
+    ref_lp = OB.log_posterior(m64, st.data_z, x64)
+    assert np.abs(lp - ref_lp).max() <= 0.1
+    assert np.abs(lp - lp_in).max() <= 1e-5 * np.abs(lp).max() + 1e-4
+
+
+def test_bgm_r_integration_test_parameters_through_the_class(tmp_path):
+    """r-package/bayesgm/tests/testthat/test-bgm.R:17-66: x_dim 8, z_dim 3, g / e_units (8, 8), dz / dx_units (8, 4); fit(epochs = 0,
+    use_egm_init = False); predict(bs = 16, n_mcmc = 5, burn_in = 10, step_size 0.01, num_leapfrog_steps = 3) on rows whose last column
+    is missing -- and the same model through egm_init, fit(epochs = 5), evaluate, generate."""
+    from bayesgm_amd.models import BGM
+    from bayesgm_amd.datasets import simulate_z_hetero
+    X, Y = simulate_z_hetero(n=128, k=3, d=7, seed=42)
+    data = np.c_[X, Y].astype(np.float32)
+    train, test = data[:96], data[96:].copy()
+    test[:, -1] = np.nan
+    params = dict(dataset="RSimHetero", output_dir=str(tmp_path), save_res=False, save_model=False, use_bnn=False, z_dim=3, x_dim=8,
+                  lr_theta=5e-3, lr_z=5e-3, g_units=[8, 8], e_units=[8, 8], dz_units=[8, 4], dx_units=[8, 4], kl_weight=5e-5, lr=1e-3,
+                  g_d_freq=1, use_z_rec=True, alpha=0.0, gamma=0.0)
+    model = BGM(dict(params), random_seed=1)
+    model.fit(train, batch_size=32, epochs=0, epochs_per_eval=1, use_egm_init=False, egm_n_iter=0, egm_batches_per_eval=1, verbose=0)
+    imputed, interval = model.predict(test, alpha=0.05, bs=16, n_mcmc=5, burn_in=10, step_size=0.01, num_leapfrog_steps=3, seed=42)
+    assert imputed.shape == test.shape and np.asarray(interval).shape == (len(test), 1, 2)
+    assert not np.isnan(imputed[:, -1]).any()
+    m2 = BGM(dict(params), random_seed=2)
+    m2.fit(train, batch_size=32, epochs=5, epochs_per_eval=5, use_egm_init=True, egm_n_iter=40, egm_batches_per_eval=20, verbose=0)
+    res = m2.evaluate(train)
+    assert np.isfinite(np.asarray(res[0] if isinstance(res, (tuple, list)) else res)).all()
+    gen = m2.generate(nb_samples=10)
+    assert np.asarray(gen).shape[-1] == 8 and np.isfinite(np.asarray(gen)).all()
+    imputed, interval = m2.predict(test, alpha=0.05, bs=16, n_mcmc=5, burn_in=10, step_size=0.01, num_leapfrog_steps=3, seed=42)
+    assert np.isfinite(imputed).all()
+
+
+def test_bgm_default_nb_units_through_the_class(tmp_path):
+    """g_units = e_units = [256, 256, 256] (networks/base.py:56): warm start, five epochs, predict."""
+    from bayesgm_amd.models import BGM
+    from bayesgm_amd.datasets import simulate_z_hetero
+    X, Y = simulate_z_hetero(n=200, k=3, d=19, seed=1)
+    data = np.c_[X, Y].astype(np.float32)
+    params = dict(dataset="w256", output_dir=str(tmp_path), save_res=False, save_model=False, use_bnn=False, z_dim=10, x_dim=20,
+                  lr_theta=2e-3, lr_z=2e-3, g_units=[256] * 3, e_units=[256] * 3, dz_units=[256] * 3, dx_units=[256] * 3, kl_weight=5e-5,
+                  lr=1e-3, g_d_freq=1, use_z_rec=True, alpha=0.0, gamma=0.0)
+    model = BGM(params, random_seed=3)
+    model.fit(data, batch_size=32, epochs=5, epochs_per_eval=5, use_egm_init=True, egm_n_iter=20, egm_batches_per_eval=10, verbose=0)
+    test = data[:40].copy()
+    test[:, -1] = np.nan
+    imputed, interval = model.predict(test, alpha=0.05, bs=20, n_mcmc=5, burn_in=10, step_size=0.01, num_leapfrog_steps=3, seed=4)
+    assert imputed.shape == test.shape and np.isfinite(imputed).all() and np.asarray(interval).shape == (40, 1, 2)
