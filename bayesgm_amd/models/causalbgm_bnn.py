@@ -21,7 +21,7 @@ import os
 import numpy as np
 import torch
 
-from .. import host_rng, parallel
+from .. import diagnostics, host_rng, parallel
 from ..bnn_engine import BnnEngine, NETS, flatten_bnn
 from ..datasets import Gaussian_sampler
 from ..utils import save_data
@@ -155,6 +155,7 @@ class CausalBGMBayes(CausalBGM):
         eng.egm_begin(dz, batch_size, p_["lr"], p_["use_z_rec"])
         out_d = torch.zeros(2, device=dev)
         out_g = torch.zeros(6, device=dev)
+        egm_log = []
         if verbose:
             print('EGM Initialization Starts ...')
         g_d_freq = int(p_['g_d_freq'])
@@ -184,8 +185,9 @@ class CausalBGMBayes(CausalBGM):
                     eng.egm_gen_step(z_d[i, g_d_freq], idx_d[i, g_d_freq], vd, xd, yd, seed, self._streams(9), out=out_g)
                 batch_iter = stop
                 if batch_iter % egm_batches_per_eval == 0:
+                    lg, ld = out_g.cpu().numpy(), out_d.cpu().numpy()
+                    egm_log.append((batch_iter, float(lg[2])))          # l2_loss_z of this log line (diagnostics.py)
                     if verbose:
-                        lg, ld = out_g.cpu().numpy(), out_d.cpu().numpy()
                         print('EGM Initialization Iter [%d] : e_loss_adv [%.4f], l2_loss_v [%.4f], l2_loss_z [%.4f], '
                               'l2_loss_x [%.4f], l2_loss_y [%.4f], g_e_loss [%.4f], dz_loss [%.4f], d_loss [%.4f]'
                               % (batch_iter, lg[0], lg[1], lg[2], lg[3], lg[4], lg[5], ld[0], ld[1]))
@@ -197,6 +199,8 @@ class CausalBGMBayes(CausalBGM):
                 pipe.close()
             eng.egm_end()
             self._pull_weights()
+        self._egm_late_l2z = diagnostics.late_l2_loss_z([a for a, _ in egm_log], [b for _, b in egm_log], egm_n_iter) if egm_log else None
+        self._second_optimum_warned = False
         if verbose:
             print('EGM Initialization Ends.')
 
@@ -276,6 +280,8 @@ class CausalBGMBayes(CausalBGM):
                     eng.z_sync(self.data_z, zm, zv, None, lr_z)                      # flush: evaluate / checkpoints read the whole table
                 if epoch % epochs_per_eval == 0:
                     causal_pre, mse_x, mse_y, mse_v = self._evaluate_dev(x, y, v, self.data_z, n_total, lo_r)
+                    self._second_optimum_warned = diagnostics.warn_if_second_optimum(getattr(self, '_egm_late_l2z', None), float(mse_v),
+                                                                                                 getattr(self, '_second_optimum_warned', False))
                     if verbose:
                         print('Epoch [%d/%d]: MSE_x: %.4f, MSE_y: %.4f, MSE_v: %.4f\n' % (epoch, epochs, mse_x, mse_y, mse_v))
                     if epoch >= startoff and mse_y < best_loss:

@@ -28,6 +28,9 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: the entry points below are its only exported symbols. */
+#define BGM_API __attribute__((visibility("default")))
+
 #define BGM_OK 0
 #define BGM_E_INVALID (-1)     /* bad argument / unsupported shape            */
 #define BGM_E_HIP (-2)         /* HIP runtime error                           */
@@ -60,29 +63,29 @@ typedef struct {
                                       variance head softplus(.)+1e-6           */
 } bgm_causal_config;
 
-const char *bgm_last_error(void);
-const char *bgm_version(void);
+BGM_API const char *bgm_last_error(void);
+BGM_API const char *bgm_version(void);
 
 /* Create / destroy a per-device handle.  Synchronous. */
-int bgm_create(bgm_handle **out, int device);
+BGM_API int bgm_create(bgm_handle **out, int device);
 /* BatchNormalization mode of the Discriminator networks (networks/base.py:338-385) of every EGM warm-start session opened
  * afterwards on this handle (bgm_causal_egm_begin, bgm_bnn_egm_begin, bgm_bgm_egm_begin, bgm_bvn_egm_begin):
  *   0 (default of the library)  batch statistics -- `norm_layer(x)` inside a Model.call(training=True) under Keras' rule that an
  *                               inner layer inherits the outer call's training mode;
  *   1                           inference mode on the layer's initial moving averages (mean 0, variance 1), the behaviour the
  *                               reference's published training log is consistent with. */
-int bgm_set_disc_norm(bgm_handle *h, int32_t mode);
+BGM_API int bgm_set_disc_norm(bgm_handle *h, int32_t mode);
 /* Arithmetic of the CausalBGM sampling kernels launched afterwards through bgm_causal_logpost / bgm_causal_mh_run:
  *   0 (default)  fp32 MFMA -- the reference's arithmetic (causalbgm/base.py:765-904 run in float32);
  *   1            split precision "bf16 x 3": weights and activations as sums of two bf16 numbers, three bf16 MFMA products per
  *                contraction with fp32 accumulation (relative error ~6e-6 per layer against 2.4e-7 in fp32).  Same algorithm,
  *                RNG streams and outputs; chains agree with the fp32 ones statistically, not draw for draw. */
-int bgm_causal_set_precision(bgm_handle *h, int32_t mode);
+BGM_API int bgm_causal_set_precision(bgm_handle *h, int32_t mode);
 /* Conditional latent prior Z | U ~ N(mu(U), sigma^2(U) I) of IdentifiableCausalBGM (models/causalbgm/identifiable.py:195-211,
  * 541-551) for the sampling calls made afterwards (bgm_causal_logpost, bgm_causal_mh_run; fp32 kernels): seg_dev [n] = segment of
  * every LOCAL row of those calls (int32), tab_dev [n_segments x (q + 2)] = per segment mu [q], 1 / sigma^2, (q / 2) log sigma^2.
  * Both NULL: back to the standard-normal prior.  The buffers must stay valid while set. */
-int bgm_causal_set_prior(bgm_handle *h, const int32_t *seg_dev, const float *tab_dev, int32_t n_segments);
+BGM_API int bgm_causal_set_prior(bgm_handle *h, const int32_t *seg_dev, const float *tab_dev, int32_t n_segments);
 
 /* The prior network of IdentifiableCausalBGM, prior_net = BaseFullyConnectedNet(n_segments -> prior_units -> q + 1)
  * (identifiable.py:76-78; LeakyReLU(0.2) hidden layers, linear output).  Parameters, gradients and Adam slots live in caller-owned
@@ -91,45 +94,45 @@ typedef struct {
   int32_t n_layers;          /* dense layers, 1..4 */
   int32_t dims[5];           /* n_segments, prior_units..., q + 1 */
 } bgm_prior_config;
-int bgm_prior_n_params(const bgm_prior_config *cfg, int64_t *count);
+BGM_API int bgm_prior_n_params(const bgm_prior_config *cfg, int64_t *count);
 /* table_dev [n_segments x (q + 2)] = per segment mu [q], 1 / sigma^2, (q / 2) log sigma^2 with sigma^2 = softplus(out[q]) + 1e-6
  * (identifiable.py:541-551): the tab_dev of bgm_causal_set_prior. */
-int bgm_prior_table(bgm_handle *h, const bgm_prior_config *cfg, const float *theta_dev, float *table_dev, void *stream);
+BGM_API int bgm_prior_table(bgm_handle *h, const bgm_prior_config *cfg, const float *theta_dev, float *table_dev, void *stream);
 /* replaces: the conditional-prior half of update_latent_variable_sgd, identifiable.py:195-226.  dz_dev [batch x q] is the output of
  * bgm_causal_fit_z_grad on the same rows (gradient of the batch-mean negative log joint with the standard-normal prior); the call
  * exchanges the prior term (- z / B + (z - mu(u)) / (sigma^2(u) B)), applies the latent step with FRESH Adam slots and step count
  * t_z (the batch latents are a new Variable in every minibatch, :304), and takes one Adam step (slots m_dev / v_dev, step count
  * t_prior, learning rate lr_prior) on the prior net with the gradient of the batch-mean prior term.  seg_dev [n_rows]: segment of
  * every row.  out_dev [2] (or NULL) = batch means of the conditional-prior term and of |z|^2 / 2. */
-int bgm_prior_step(bgm_handle *h, const bgm_prior_config *cfg, float *theta_dev, float *m_dev, float *v_dev, const int32_t *seg_dev,
+BGM_API int bgm_prior_step(bgm_handle *h, const bgm_prior_config *cfg, float *theta_dev, float *m_dev, float *v_dev, const int32_t *seg_dev,
                    float *data_z_dev, const int32_t *idx_dev, int32_t batch, const float *dz_dev, float lr_z, float lr_prior,
                    int64_t t_z, int64_t t_prior, float *out_dev, void *stream);
-int bgm_destroy(bgm_handle *h);
+BGM_API int bgm_destroy(bgm_handle *h);
 
 /* Declare the model shape.  Synchronous.  replaces: CausalBGM.__init__ network
  * construction, causalbgm/base.py:64-84. */
 /* Supported: g_units = [64]*k, f_units = h_units = [64,32,8], e_units = [64]*k; sum(z_dims) <= 19; v_dim <= 207
  * (<= 159 when sum(z_dims) > 11).  Any shape inside these limits runs on the smallest compiled kernel shape that
  * contains it (zero padding, identical results). */
-int bgm_causal_configure(bgm_handle *h, const bgm_causal_config *cfg);
+BGM_API int bgm_causal_configure(bgm_handle *h, const bgm_causal_config *cfg);
 
 /* Upload one network's parameters from HOST memory, flat float32 in Keras
  * order: for each Dense layer  W [in x out] row-major, then b [out]
  * (networks/base.py:17-26).  `count` = number of floats.  Synchronous on
  * `stream`.  Packs the weights into the MFMA fragment order used by the
  * kernels. */
-int bgm_causal_set_weights(bgm_handle *h, int net_id, const float *theta_host, int64_t count,
+BGM_API int bgm_causal_set_weights(bgm_handle *h, int net_id, const float *theta_host, int64_t count,
                            void *stream);
 
 /* log p(z | x, y, v) up to a constant for n rows.
  * replaces: CausalBGM.get_log_posterior, causalbgm/base.py:765-817.
  * x,y [n], v [n x p], z [n x q] -> out [n]. */
-int bgm_causal_logpost(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev,
+BGM_API int bgm_causal_logpost(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev,
                        const float *z_dev, int64_t n, float *out_dev, void *stream);
 
 /* Encoder forward  z = e(v)  for n rows (Z initialisation of fit and
  * evaluate(data_z=None)).  replaces: self.e_net(data_v), causalbgm/base.py:479,538. */
-int bgm_causal_encode(bgm_handle *h, const float *v_dev, int64_t n, float *z_dev, void *stream);
+BGM_API int bgm_causal_encode(bgm_handle *h, const float *v_dev, int64_t n, float *z_dev, void *stream);
 
 /* Arguments of one segment of the random-walk Metropolis-Hastings sampler.
  * replaces: CausalBGM.metropolis_hastings_sampler loop body, causalbgm/base.py:860-898,
@@ -166,21 +169,21 @@ typedef struct {
 } bgm_mh_args;
 
 /* Number of wave slots (leading dim of adrf_partial) the MH kernel uses for n rows. */
-int bgm_causal_mh_slots(bgm_handle *h, int64_t n, int32_t *n_slots);
+BGM_API int bgm_causal_mh_slots(bgm_handle *h, int64_t n, int32_t *n_slots);
 
-int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *args, void *stream);
+BGM_API int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *args, void *stream);
 
 /* out[k][d] = sum_s partial[s][d][k] / n_total  (fixed order => deterministic; the slots are draw-major -- a retained draw's doses
  * share a cache line in the sampling kernels' accumulation -- the result has the reference's [n_doses x n_keep] orientation).
  * replaces: adrf_draw_sums / n_seen, causalbgm/base.py:660-663. */
-int bgm_adrf_reduce(bgm_handle *h, const float *partial_dev, int32_t n_slots, int32_t n_doses,
+BGM_API int bgm_adrf_reduce(bgm_handle *h, const float *partial_dev, int32_t n_slots, int32_t n_doses,
                     int32_t n_keep, double n_total, float *out_dev, void *stream);
 
 /* Per-row mean and linear-interpolated quantiles over m contiguous values:
  * in [n_rows x m] -> mean [n_rows], lo [n_rows], hi [n_rows].
  * replaces: np.mean / np.quantile(..., axis) at causalbgm/base.py:640-642,664-666.  Any m: rows of up to 32768 values are sorted
  * in LDS, longer rows have their order statistics selected by radix passes over memory (same results). */
-int bgm_row_mean_quantiles(bgm_handle *h, const float *in_dev, int64_t n_rows, int32_t m,
+BGM_API int bgm_row_mean_quantiles(bgm_handle *h, const float *in_dev, int64_t n_rows, int32_t m,
                            double q_lo, double q_hi, float *mean_dev, float *lo_dev,
                            float *hi_dev, void *stream);
 
@@ -189,8 +192,8 @@ int bgm_row_mean_quantiles(bgm_handle *h, const float *in_dev, int64_t n_rows, i
  * accumulates (launches, milliseconds) per kernel kind = BGM_EFFECT_* of the
  * launch (BGM_EFFECT_NONE = the pure-transition kernel); kind -1 = all.
  * Reading synchronises the pending events. */
-int bgm_timing_enable(bgm_handle *h, int enable);
-int bgm_timing_read(bgm_handle *h, int kind, int64_t *n_launches, double *total_ms, int reset);
+BGM_API int bgm_timing_enable(bgm_handle *h, int enable);
+BGM_API int bgm_timing_read(bgm_handle *h, int kind, int64_t *n_launches, double *total_ms, int reset);
 
 /* Static facts of the selected MH kernel variant (for roofline accounting). */
 typedef struct {
@@ -199,12 +202,12 @@ typedef struct {
   int32_t lds_bytes;
   double flop_per_row_transition;       /* algorithmic 2*MACs(g+f+h)           */
 } bgm_mh_info;
-int bgm_causal_mh_info(bgm_handle *h, int64_t n, bgm_mh_info *info);
+BGM_API int bgm_causal_mh_info(bgm_handle *h, int64_t n, bgm_mh_info *info);
 
 /* Which kernels this handle runs, as text (diagnostics: bench.py prints it per rank): the sampling path, and -- between
  * bgm_causal_fit_begin and bgm_causal_fit_end -- the minibatch-step path for a local minibatch of `batch` rows (under data
  * parallelism batch = batch_size / world).  out: cap bytes, NUL-terminated. */
-int bgm_causal_describe(bgm_handle *h, int32_t batch, char *out, int32_t cap);
+BGM_API int bgm_causal_describe(bgm_handle *h, int32_t batch, char *out, int32_t cap);
 
 /* evaluate at a given latent matrix z [n x q]: accumulates sums[0..2] += {sum |v - mu_v|^2,
  * sum (x - x_pred)^2, sum (y - mu_y)^2} (divide by n*p, n, n for the MSEs) and the plug-in causal
@@ -212,17 +215,17 @@ int bgm_causal_describe(bgm_handle *h, int32_t batch, char *out, int32_t cap);
  * [n_slots x n_doses] += per-wave sums over rows of f(z0,z1,x_k) (reduce with bgm_adrf_reduce,
  * n_keep = 1; n_slots from bgm_causal_evaluate_slots).
  * replaces: CausalBGM.evaluate, causalbgm/base.py:534-570 (the dose grid / percentiles stay on the host). */
-int bgm_causal_evaluate(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev,
+BGM_API int bgm_causal_evaluate(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev,
                         const float *z_dev, int64_t n, const float *x_values_dev, int32_t n_doses,
                         double *sums_dev, float *adrf_partial_dev, float *ite_dev, void *stream);
-int bgm_causal_evaluate_slots(bgm_handle *h, int64_t n, int32_t *n_slots);
+BGM_API int bgm_causal_evaluate_slots(bgm_handle *h, int64_t n, int32_t *n_slots);
 
 /* replaces: CausalBGM.infer_from_latent_posterior, causalbgm/base.py:671-763, on a given tensor of posterior draws
  * draws_dev [n_keep x n x q] (the pass fused into bgm_causal_mh_run computes the same numbers from the same draws:
  * outcome noise of draw d = Philox(row_base + row, burn_in + d, dose block)).  binary -> ite_dev [n x n_keep];
  * continuous -> adrf_partial_dev [n_slots x n_keep x n_doses] (+=; n_slots = bgm_causal_evaluate_slots; reduce with
  * bgm_adrf_reduce). */
-int bgm_causal_effects(bgm_handle *h, const float *x_dev, const float *draws_dev, int64_t n, int64_t row_base,
+BGM_API int bgm_causal_effects(bgm_handle *h, const float *x_dev, const float *draws_dev, int64_t n, int64_t row_base,
                        int32_t n_keep, int32_t burn_in, uint64_t seed, int32_t sample_y, const float *x_values_dev,
                        int32_t n_doses, float *adrf_partial_dev, float *ite_dev, void *stream);
 
@@ -241,31 +244,31 @@ int bgm_causal_effects(bgm_handle *h, const float *x_dev, const float *draws_dev
 /* Start a fit session: uploads the current g/f/h parameters to the device, zeroes the Adam slots
  * and step counters, sizes the workspace for minibatches of up to max_batch LOCAL rows out of
  * n_rows local rows.  Synchronous. */
-int bgm_causal_fit_begin(bgm_handle *h, int64_t n_rows, int32_t max_batch, void *stream);
+BGM_API int bgm_causal_fit_begin(bgm_handle *h, int64_t n_rows, int32_t max_batch, void *stream);
 
 /* Number of trainable parameters of g, f, h (= length of grad_dev). */
-int bgm_causal_fit_n_params(bgm_handle *h, int64_t *n_params);
+BGM_API int bgm_causal_fit_n_params(bgm_handle *h, int64_t *n_params);
 
 /* Gradients of the three batch-mean losses w.r.t. theta_g | theta_f | theta_h (Keras order) for the
  * local minibatch rows idx_dev[0..batch) (int32 row indices into x/y/v/data_z; NULL = rows
  * row_lo .. row_lo+batch-1).  grad_dev [n_params] is overwritten.  loss_dev (double[8], may be NULL)
  * is incremented by {sum loss_v, sum |v-mu|^2, sum loss_x, sum (x-mu_x)^2 | sum bce, sum loss_y,
  * sum (y-mu_y)^2, unused, unused} over the local rows. */
-int bgm_causal_fit_theta_grad(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev,
+BGM_API int bgm_causal_fit_theta_grad(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev,
                               const float *data_z_dev, const int32_t *idx_dev, int64_t row_lo,
                               int32_t batch, int32_t batch_global, float *grad_dev, double *loss_dev,
                               void *stream);
 
 /* One Adam step on theta with the (all-reduced) gradient; refreshes the packed weights used by
  * every other kernel of the handle. */
-int bgm_causal_fit_theta_apply(bgm_handle *h, const float *grad_dev, float lr_theta, void *stream);
+BGM_API int bgm_causal_fit_theta_apply(bgm_handle *h, const float *grad_dev, float lr_theta, void *stream);
 
 /* update_latent_variable_sgd for the local minibatch with the CURRENT networks: gradient of the
  * batch-mean negative log joint w.r.t. the batch rows of data_z and one Adam step on the latent
  * matrix.  zm/zv [n_rows x q] are the Adam slots.  lazy = 0 reproduces Keras' sparse-gradient Adam
  * (moment decay and update applied to ALL n_rows rows every step), lazy = 1 touches the batch rows
  * only (a different optimizer), lazy = 2 is lazy = 0 with the untouched rows' steps deferred (bgm_causal_fit_z_sync).  loss_dev[6] += sum over local rows of the per-row negative log joint. */
-int bgm_causal_fit_z_step(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev,
+BGM_API int bgm_causal_fit_z_step(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev,
                           float *data_z_dev, float *zm_dev, float *zv_dev, const int32_t *idx_dev,
                           int64_t row_lo, int32_t batch, int32_t batch_global, float lr_z, int32_t lazy,
                           double *loss_dev, void *stream);
@@ -280,18 +283,18 @@ int bgm_causal_fit_z_step(bgm_handle *h, const float *x_dev, const float *y_dev,
  *   idx_dev == NULL: flush -- bring every row up to date (before evaluate / predict / a checkpoint / reading data_z, and before
  *                    switching to another lazy mode).
  * lr_z is the (constant) learning rate of the latent optimizer (causalbgm/base.py:93). */
-int bgm_causal_fit_z_sync(bgm_handle *h, float *data_z_dev, float *zm_dev, float *zv_dev, const int32_t *idx_dev, int32_t batch,
+BGM_API int bgm_causal_fit_z_sync(bgm_handle *h, float *data_z_dev, float *zm_dev, float *zv_dev, const int32_t *idx_dev, int32_t batch,
                           float lr_z, void *stream);
 
 /* Copy the device parameters of one network back to the host (Keras order) and make them the
  * handle's host copy.  Synchronous. */
-int bgm_causal_get_weights(bgm_handle *h, int net_id, float *theta_host, int64_t count, void *stream);
+BGM_API int bgm_causal_get_weights(bgm_handle *h, int net_id, float *theta_host, int64_t count, void *stream);
 
 /* The gradient half of bgm_causal_fit_z_step: d(batch-mean negative log joint)/d(batch rows of data_z) with the CURRENT networks and
  * the standard-normal latent prior, written to dz_out_dev [batch x q]; no optimizer step.  loss_dev as in bgm_causal_fit_z_step.
  * Used by the host side of IdentifiableCausalBGM (identifiable.py:150-226), which exchanges the prior term for the conditional one
  * and applies its own latent / prior-network updates. */
-int bgm_causal_fit_z_grad(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev, const float *data_z_dev,
+BGM_API int bgm_causal_fit_z_grad(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev, const float *data_z_dev,
                           const int32_t *idx_dev, int64_t row_lo, int32_t batch, int32_t batch_global, float *dz_out_dev,
                           double *loss_dev, void *stream);
 
@@ -299,9 +302,9 @@ int bgm_causal_fit_z_grad(bgm_handle *h, const float *x_dev, const float *y_dev,
  * posterior_optimizer, causalbgm/base.py:112-122): Adam first / second moments of theta_g | theta_f | theta_h [n_params each] and
  * the step counters steps[0] = theta steps, steps[1] = latent steps.  write = 0 reads them into the host buffers, write = 1
  * installs them (after bgm_causal_fit_begin, which zeroes them).  The latent table's slots zm / zv are the caller's buffers. */
-int bgm_causal_fit_state(bgm_handle *h, int32_t write, float *m_host, float *v_host, int64_t count, int64_t *steps, void *stream);
+BGM_API int bgm_causal_fit_state(bgm_handle *h, int32_t write, float *m_host, float *v_host, int64_t count, int64_t *steps, void *stream);
 /* End the fit session (frees the workspace; the trained parameters stay installed). */
-int bgm_causal_fit_end(bgm_handle *h, void *stream);
+BGM_API int bgm_causal_fit_end(bgm_handle *h, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * EGM warm start (causalbgm/base.py:305-431): alternating WGAN-GP steps on the latent
@@ -318,24 +321,24 @@ typedef struct {
 /* Start a warm-start session from the networks currently installed with bgm_causal_set_weights (all four:
  * g, e, f, h).  theta_dz_host: discriminator parameters [W0..WL | b0..bL | gamma0.. | beta0..] (W_l row-major
  * [in x out], L = n_hidden_dz hidden layers + the scalar output layer). */
-int bgm_causal_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, const float *theta_dz_host, int64_t count,
+BGM_API int bgm_causal_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, const float *theta_dz_host, int64_t count,
                          void *stream);
 /* replaces: train_disc_step, base.py:305-330.  z_dev [B x q] prior sample, idx_dev [B] panel rows,
  * v_dev [N x p] panel, eps = interpolation coefficient (tf.random.uniform([])).  apply = 0 leaves the
  * gradient in the session (bgm_causal_egm_read) without the Adam step.  out_dev: [dz_loss, d_loss] or NULL. */
-int bgm_causal_egm_disc_step(bgm_handle *h, const float *z_dev, const int32_t *idx_dev, const float *v_dev, float eps,
+BGM_API int bgm_causal_egm_disc_step(bgm_handle *h, const float *z_dev, const int32_t *idx_dev, const float *v_dev, float eps,
                              int32_t apply, float *out_dev, void *stream);
 /* replaces: train_gen_step, base.py:332-377.  out_dev: [e_loss_adv, l2_loss_v, l2_loss_z, l2_loss_x, l2_loss_y,
  * g_e_loss] or NULL. */
-int bgm_causal_egm_gen_step(bgm_handle *h, const float *z_dev, const int32_t *idx_dev, const float *v_dev,
+BGM_API int bgm_causal_egm_gen_step(bgm_handle *h, const float *z_dev, const int32_t *idx_dev, const float *v_dev,
                             const float *x_dev, const float *y_dev, int32_t apply, float *out_dev, void *stream);
 /* Copy session state to the host: what = 0 generator-side parameters [g | e | f | h] (Keras order), 1 discriminator
  * parameters, 2 / 3 the gradients of the last gen / disc step.  Synchronises the stream. */
-int bgm_causal_egm_read(bgm_handle *h, int32_t what, float *host, int64_t count, void *stream);
+BGM_API int bgm_causal_egm_read(bgm_handle *h, int32_t what, float *host, int64_t count, void *stream);
 /* Install the session's current g, e, f, h in the handle (as bgm_causal_set_weights would); the session continues. */
-int bgm_causal_egm_sync(bgm_handle *h, void *stream);
+BGM_API int bgm_causal_egm_sync(bgm_handle *h, void *stream);
 /* bgm_causal_egm_sync + free the session. */
-int bgm_causal_egm_end(bgm_handle *h, void *stream);
+BGM_API int bgm_causal_egm_end(bgm_handle *h, void *stream);
 
 /* ==========================================================================================
  * BGM (bgm/base.py): posterior of Z given partially observed rows, HMC, predictive draws.
@@ -350,17 +353,17 @@ typedef struct {
  * the trunk (x_dim <= ~2000).  x_dim in (16,32] and (96,112] run with the whole generator resident in LDS;
  * every other width (e.g. config C4, x_dim = 500) streams the 2 x 64 x x_dim head weights through an LDS
  * stage shared by the waves of a block. */
-int bgm_bgm_configure(bgm_handle *h, const bgm_bgm_config *cfg);
+BGM_API int bgm_bgm_configure(bgm_handle *h, const bgm_bgm_config *cfg);
 
 /* Generator parameters from HOST memory, flat float32:
  *   BatchNormalization gamma[q], beta[q], moving_mean[q], moving_variance[q]   (networks/base.py:76),
  *   then per trunk Dense layer W [in x out], b [out], then mean_layer W, b, then var_layer W, b. */
-int bgm_bgm_set_weights(bgm_handle *h, const float *theta_host, int64_t count, void *stream);
+BGM_API int bgm_bgm_set_weights(bgm_handle *h, const float *theta_host, int64_t count, void *stream);
 
 /* log p(z | x_obs) + const for n rows; x_dev [n x p] with NaN marking missing cells
  * (the reference passes index lists + obs_mask: bgm/base.py:578-592, 689-700).  grad_dev
  * [n x q] (dlogp/dz) may be NULL.  replaces: BGM.get_log_posterior, bgm/base.py:665-705. */
-int bgm_bgm_logpost(bgm_handle *h, const float *z_dev, const float *x_dev, int64_t n, float *out_dev,
+BGM_API int bgm_bgm_logpost(bgm_handle *h, const float *z_dev, const float *x_dev, int64_t n, float *out_dev,
                     float *grad_dev, void *stream);
 
 /* One segment of HMC transitions for all rows.
@@ -380,12 +383,12 @@ typedef struct {
   uint32_t *acc_count_dev;     /* [>= it_begin+n_iters] += accepted chains, or NULL */
   float *draws_dev;            /* [n_keep x n x q] states after burn_in, or NULL  */
 } bgm_hmc_args;
-int bgm_bgm_hmc_run(bgm_handle *h, const bgm_hmc_args *args, void *stream);
+BGM_API int bgm_bgm_hmc_run(bgm_handle *h, const bgm_hmc_args *args, void *stream);
 
 /* tfp.mcmc.SimpleStepSizeAdaptation update after iteration `it`:  *step_dev *= (1+rate) if
  * acc_prob_sum_dev[it] / n_chains > target else /= (1+rate).  (bgm/base.py:805-809: target 0.75;
  * TFP default adaptation_rate 0.01.)  With several ranks, all-reduce acc_prob_sum_dev[it] first. */
-int bgm_bgm_hmc_adapt(bgm_handle *h, float *step_dev, const double *acc_prob_sum_dev, int32_t it,
+BGM_API int bgm_bgm_hmc_adapt(bgm_handle *h, float *step_dev, const double *acc_prob_sum_dev, int32_t it,
                       double n_chains, float target, float rate, void *stream);
 
 /* Posterior-predictive draws x ~ N(mu(z_d), sigma^2(z_d)) for draws_dev [n_draws x n x q]:
@@ -393,7 +396,7 @@ int bgm_bgm_hmc_adapt(bgm_handle *h, float *step_dev, const double *acc_prob_sum
  * the cells with slot_dev[row*p + c] >= 0 (or NULL); var_full_dev [n_draws x n x p] receives sigma^2
  * (or NULL); add_noise = 0 returns the mean instead of a draw (use_x_sd=False in generate/evaluate,
  * :470-473,505-508).  replaces: predict_on_posteriors, :511-525; g_net(z, training=False), :468,503. */
-int bgm_bgm_predict_draws(bgm_handle *h, const float *draws_dev, int64_t n, int64_t row_base, int32_t n_draws,
+BGM_API int bgm_bgm_predict_draws(bgm_handle *h, const float *draws_dev, int64_t n, int64_t row_base, int32_t n_draws,
                           int32_t burn_in, uint64_t seed, const int32_t *slot_dev, int32_t k_slots,
                           float *cells_dev, float *full_dev, float *var_full_dev, int32_t add_noise,
                           void *stream);
@@ -405,22 +408,22 @@ int bgm_bgm_predict_draws(bgm_handle *h, const float *draws_dev, int64_t n, int6
  *   theta order = bgm_bgm_set_weights order; the moving statistics receive a zero gradient.
  *   loss_dev (double[4], may be NULL): [0] += sum loss_x, [1] += sum |x-mu|^2 (theta phase),
  *                                      [2] += sum loss_px_z, [3] += sum |x-mu|^2 (z phase). */
-int bgm_bgm_fit_begin(bgm_handle *h, int64_t n_rows, int32_t max_batch, void *stream);
-int bgm_bgm_fit_n_params(bgm_handle *h, int64_t *n_params);
+BGM_API int bgm_bgm_fit_begin(bgm_handle *h, int64_t n_rows, int32_t max_batch, void *stream);
+BGM_API int bgm_bgm_fit_n_params(bgm_handle *h, int64_t *n_params);
 /* Data-parallel fit: the batch-mean losses of the following steps are means over `batch_global` rows (the sum of the
  * ranks' local batches), so that the all-reduced SUM of the ranks' gradients is the gradient of the global batch mean.
  * The input BatchNorm of every rank still uses the statistics of its LOCAL batch (a stated deviation from one global
  * batch).  0 (default) = the local batch. */
-int bgm_bgm_fit_set_global_batch(bgm_handle *h, int32_t batch_global);
-int bgm_bgm_fit_theta_grad(bgm_handle *h, const float *x_dev, const float *data_z_dev, const int32_t *idx_dev,
+BGM_API int bgm_bgm_fit_set_global_batch(bgm_handle *h, int32_t batch_global);
+BGM_API int bgm_bgm_fit_theta_grad(bgm_handle *h, const float *x_dev, const float *data_z_dev, const int32_t *idx_dev,
                            int32_t batch, float *grad_dev, double *loss_dev, void *stream);
-int bgm_bgm_fit_theta_apply(bgm_handle *h, const float *grad_dev, float lr_theta, void *stream);
+BGM_API int bgm_bgm_fit_theta_apply(bgm_handle *h, const float *grad_dev, float lr_theta, void *stream);
 /* Z step: the batch latents are a FRESH variable every minibatch in the reference (:402), i.e. Adam
  * slots start at zero while the step counter keeps running; the updated rows are written back. */
-int bgm_bgm_fit_z_step(bgm_handle *h, const float *x_dev, float *data_z_dev, const int32_t *idx_dev,
+BGM_API int bgm_bgm_fit_z_step(bgm_handle *h, const float *x_dev, float *data_z_dev, const int32_t *idx_dev,
                        int32_t batch, float lr_z, double *loss_dev, void *stream);
-int bgm_bgm_get_weights(bgm_handle *h, float *theta_host, int64_t count, void *stream);
-int bgm_bgm_fit_end(bgm_handle *h, void *stream);
+BGM_API int bgm_bgm_get_weights(bgm_handle *h, float *theta_host, int64_t count, void *stream);
+BGM_API int bgm_bgm_fit_end(bgm_handle *h, void *stream);
 
 /* Measurement aid: effective shader clock (MHz) and fp32-MFMA rate (TFLOP/s) of this device under a
  * back-to-back v_mfma_f32_16x16x4_f32 load on every CU (8 waves/CU, `iters` x 16 MFMAs per wave).
@@ -442,27 +445,27 @@ typedef struct {
 
 /* Start a session from the generator installed with bgm_bgm_set_weights.  theta_e: encoder [W0,b0,...] (x_dim ->
  * e_units -> z_dim); theta_dz / theta_dx: discriminators [W0..WL | b0..bL | gamma.. | beta..]. */
-int bgm_bgm_egm_begin(bgm_handle *h, const bgm_bgm_egm_config *cfg, const float *theta_e_host, int64_t count_e,
+BGM_API int bgm_bgm_egm_begin(bgm_handle *h, const bgm_bgm_egm_config *cfg, const float *theta_e_host, int64_t count_e,
                       const float *theta_dz_host, int64_t count_dz, const float *theta_dx_host, int64_t count_dx,
                       void *stream);
 /* replaces: train_disc_step, bgm/base.py:190-244.  z_dev [B x z_dim] prior sample, x_dev [B x x_dim] data rows,
  * noise_dev [B x x_dim] standard normals of the reparameterisation, eps_* the interpolation coefficients of the
  * gradient penalties (used when gamma != 0).  out_dev: [dz_loss, dx_loss, d_loss] or NULL. */
-int bgm_bgm_egm_disc_step(bgm_handle *h, const float *z_dev, const float *x_dev, const float *noise_dev, float eps_z,
+BGM_API int bgm_bgm_egm_disc_step(bgm_handle *h, const float *z_dev, const float *x_dev, const float *noise_dev, float eps_z,
                           float eps_x, int32_t apply, float *out_dev, void *stream);
 /* replaces: train_gen_step, bgm/base.py:246-289.  out_dev: [g_loss_adv, e_loss_adv, l2_loss_z, l2_loss_x, reg_loss,
  * g_e_loss] or NULL. */
-int bgm_bgm_egm_gen_step(bgm_handle *h, const float *z_dev, const float *x_dev, const float *noise1_dev,
+BGM_API int bgm_bgm_egm_gen_step(bgm_handle *h, const float *z_dev, const float *x_dev, const float *noise1_dev,
                          const float *noise2_dev, int32_t apply, float *out_dev, void *stream);
 /* Session state <-> host: what = 0 generator side [g (bgm_bgm_set_weights order) | e], 1 discriminators [dz | dx],
  * 2 / 3 gradients of the last gen / disc step (read only). */
-int bgm_bgm_egm_read(bgm_handle *h, int32_t what, float *host, int64_t count, void *stream);
-int bgm_bgm_egm_write(bgm_handle *h, int32_t what, const float *host, int64_t count, void *stream);
+BGM_API int bgm_bgm_egm_read(bgm_handle *h, int32_t what, float *host, int64_t count, void *stream);
+BGM_API int bgm_bgm_egm_write(bgm_handle *h, int32_t what, const float *host, int64_t count, void *stream);
 /* z = e_net(x) for n rows with the session's encoder (Z initialisation bgm/base.py:384, evaluate :466). */
-int bgm_bgm_egm_encode(bgm_handle *h, const float *x_dev, int64_t n, float *z_dev, void *stream);
+BGM_API int bgm_bgm_egm_encode(bgm_handle *h, const float *x_dev, int64_t n, float *z_dev, void *stream);
 /* Install the session's generator in the handle (as bgm_bgm_set_weights would); _end also frees the session. */
-int bgm_bgm_egm_sync(bgm_handle *h, void *stream);
-int bgm_bgm_egm_end(bgm_handle *h, void *stream);
+BGM_API int bgm_bgm_egm_sync(bgm_handle *h, void *stream);
+BGM_API int bgm_bgm_egm_end(bgm_handle *h, void *stream);
 
 /* ==========================================================================================
  * CausalBGM with Bayesian networks, params['use_bnn'] = True (the default of every causal YAML and of the CLI).
@@ -490,52 +493,52 @@ typedef struct {
 } bgm_bnn_config;
 
 /* Open a session.  theta_host: `count` floats in the layout above (count from bgm_bnn_layout). */
-int bgm_bnn_begin(bgm_handle *h, const bgm_bnn_config *cfg, const float *theta_host, int64_t count, void *stream);
+BGM_API int bgm_bnn_begin(bgm_handle *h, const bgm_bnn_config *cfg, const float *theta_host, int64_t count, void *stream);
 /* Parameter count of a configuration and the offsets of g, e, f, h in theta (offsets[4] = total).  No session needed. */
-int bgm_bnn_layout(const bgm_bnn_config *cfg, int64_t offsets[5]);
+BGM_API int bgm_bnn_layout(const bgm_bnn_config *cfg, int64_t offsets[5]);
 /* what = 0 parameters, 1 gradient of the last step, 2 Adam first moments, 3 Adam second moments.  Synchronises. */
-int bgm_bnn_read(bgm_handle *h, int32_t what, float *host, int64_t count, void *stream);
-int bgm_bnn_write(bgm_handle *h, int32_t what, const float *host, int64_t count, void *stream);
+BGM_API int bgm_bnn_read(bgm_handle *h, int32_t what, float *host, int64_t count, void *stream);
+BGM_API int bgm_bnn_write(bgm_handle *h, int32_t what, const float *host, int64_t count, void *stream);
 /* replaces: update_g_net, update_h_net, update_f_net with use_bnn, causalbgm/base.py:156-243 (one launch: the three
  * updates are independent given the batch).  data_z_dev [N x q]; idx_dev [batch] rows of the panel x_dev [N], y_dev [N],
  * v_dev [N x p].  Losses are batch means over batch_global rows (= batch on one GPU) + kl_weight * sum(KL).
  * Noise stream `stream_id`.  apply = 1: Adam(lr_theta, 0.9, 0.99) on g, h, f in the same launch; apply = 0: the gradient
  * stays in the session (bgm_bnn_read what = 1 / bgm_bnn_grad_dev) for an all-reduce, then bgm_bnn_theta_apply.
  * out_dev: [loss_v, loss_mse_v, loss_x, loss_mse_x|bce, loss_y, loss_mse_y] or NULL. */
-int bgm_bnn_theta_step(bgm_handle *h, const float *data_z_dev, const int32_t *idx_dev, const float *x_dev,
+BGM_API int bgm_bnn_theta_step(bgm_handle *h, const float *data_z_dev, const int32_t *idx_dev, const float *x_dev,
                        const float *y_dev, const float *v_dev, int32_t batch, int32_t batch_global, float lr_theta,
                        uint64_t seed, uint32_t stream_id, int32_t apply, float *out_dev, void *stream);
-int bgm_bnn_grad_dev(bgm_handle *h, float **grad_dev, int64_t *count);
+BGM_API int bgm_bnn_grad_dev(bgm_handle *h, float **grad_dev, int64_t *count);
 /* Copy the session's gradient to buf_dev (to_session = 0) or back (1): [n_params] floats, device to device. */
-int bgm_bnn_grad_exchange(bgm_handle *h, float *buf_dev, int32_t to_session, void *stream);
-int bgm_bnn_theta_apply(bgm_handle *h, float lr_theta, void *stream);
+BGM_API int bgm_bnn_grad_exchange(bgm_handle *h, float *buf_dev, int32_t to_session, void *stream);
+BGM_API int bgm_bnn_theta_apply(bgm_handle *h, float lr_theta, void *stream);
 /* replaces: update_latent_variable_sgd with use_bnn, base.py:246-302 (every net called twice with independent noise:
  * streams stream_id and stream_id + 1) + the Adam step on the latent table (zm_dev, zv_dev: its slots, [n_rows x q];
  * lazy = 0: Keras dense-decay semantics, every row of the table moves; lazy = 1: batch rows only; lazy = 2: lazy = 0 with the
  * untouched rows' steps deferred, see bgm_bnn_z_sync).  out_dev: [loss_postrior_z] or NULL. */
-int bgm_bnn_z_step(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev, float *data_z_dev,
+BGM_API int bgm_bnn_z_step(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev, float *data_z_dev,
                    float *zm_dev, float *zv_dev, const int32_t *idx_dev, int64_t n_rows, int32_t batch,
                    int32_t batch_global, float lr_z, int32_t lazy, uint64_t seed, uint32_t stream_id, float *out_dev,
                    float *dz_out_dev, void *stream);
 /* Replay mode of the latent optimizer with Bayesian nets; semantics and call order as bgm_causal_fit_z_sync (idx_dev rows before the
  * minibatch's bgm_bnn_theta_step calls; idx_dev = NULL flushes the whole [n_rows x q] table). */
-int bgm_bnn_z_sync(bgm_handle *h, float *data_z_dev, float *zm_dev, float *zv_dev, const int32_t *idx_dev, int64_t n_rows,
+BGM_API int bgm_bnn_z_sync(bgm_handle *h, float *data_z_dev, float *zm_dev, float *zv_dev, const int32_t *idx_dev, int64_t n_rows,
                    int32_t batch, float lr_z, void *stream);
-int bgm_bnn_end(bgm_handle *h, void *stream);
+BGM_API int bgm_bnn_end(bgm_handle *h, void *stream);
 
 /* ---- EGM warm start with Bayesian nets (train_disc_step :305-330, train_gen_step :332-377 with use_bnn): a sub-session of
  * bgm_bnn_begin that trains the session's g, e, f, h (own Adam slots = g_pre_optimizer) against the deterministic latent
  * discriminator dz_net (parameter layout and bgm_egm_config as in bgm_causal_egm_begin).  Noise: the encoder call of the
  * disc step uses stream stream_id; the nine network calls of the gen step use stream_id + 0..8 in the order
  * g(z), g(z) [variance head], e(v), e(v_), g(z_), f, f [variance head], h, h [variance head]. */
-int bgm_bnn_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, const float *theta_dz_host, int64_t count, void *stream);
-int bgm_bnn_egm_disc_step(bgm_handle *h, const float *z_dev, const int32_t *idx_dev, const float *v_dev, float eps,
+BGM_API int bgm_bnn_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, const float *theta_dz_host, int64_t count, void *stream);
+BGM_API int bgm_bnn_egm_disc_step(bgm_handle *h, const float *z_dev, const int32_t *idx_dev, const float *v_dev, float eps,
                           uint64_t seed, uint32_t stream_id, int32_t apply, float *out_dev, void *stream);
-int bgm_bnn_egm_gen_step(bgm_handle *h, const float *z_dev, const int32_t *idx_dev, const float *v_dev, const float *x_dev,
+BGM_API int bgm_bnn_egm_gen_step(bgm_handle *h, const float *z_dev, const int32_t *idx_dev, const float *v_dev, const float *x_dev,
                          const float *y_dev, uint64_t seed, uint32_t stream_id, int32_t apply, float *out_dev, void *stream);
 /* what = 1 discriminator parameters, 3 its gradient of the last disc step (the nets' side: bgm_bnn_read). */
-int bgm_bnn_egm_read(bgm_handle *h, int32_t what, float *host, int64_t count, void *stream);
-int bgm_bnn_egm_end(bgm_handle *h, void *stream);
+BGM_API int bgm_bnn_egm_read(bgm_handle *h, int32_t what, float *host, int64_t count, void *stream);
+BGM_API int bgm_bnn_egm_end(bgm_handle *h, void *stream);
 
 /* ---- large-batch side of the session: posterior sampling, causal effects, evaluation.  A "block" is the batch of rows
  * one reference call sees (bs rows of predict, base.py:640-645; the whole panel for evaluate): its input statistics
@@ -543,7 +546,7 @@ int bgm_bnn_egm_end(bgm_handle *h, void *stream);
 
 /* replaces: get_log_posterior with use_bnn, base.py:765-817.  Rows [0, n) in blocks of block_rows (first block id
  * block0); one call of g, h, f per block with noise stream stream_id.  out_dev [n]. */
-int bgm_bnn_logpost(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev, const float *z_dev,
+BGM_API int bgm_bnn_logpost(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev, const float *z_dev,
                     int64_t n, int32_t block_rows, int32_t block0, uint64_t seed, uint32_t stream_id, float *out_dev,
                     void *stream);
 
@@ -574,12 +577,12 @@ typedef struct {
  * 671-763.  All blocks advance in lock step, three launches per iteration (perturbations, proposal + statistics,
  * g/h/f forward of both states + accept).  Noise streams: 2 it (proposal), 2 it + 1 (current state);
  * effects of kept draw d at dose k: stream 0x40000000 + d * n_doses + k (ITE: k = 0 for x = 1, 1 for x = 0). */
-int bgm_bnn_mh_run(bgm_handle *h, const bgm_bnn_mh_args *args, void *stream);
+BGM_API int bgm_bnn_mh_run(bgm_handle *h, const bgm_bnn_mh_args *args, void *stream);
 /* replaces: infer_from_latent_posterior with use_bnn, base.py:671-763, on a given draw tensor draws_dev [n_keep x n x q]
  * (the stand-alone form; bgm_bnn_mh_run computes the same quantities for the draws it keeps).  Draw d uses the outcome-noise
  * iteration it0 + d and the Flipout streams 0x40000000 + d * n_doses + k.  effect = 1: adrf_sum_dev [n_doses x n_keep] (fp64,
  * sums over the n rows, accumulated); effect = 2: ite_dev [n x n_keep]. */
-int bgm_bnn_effects(bgm_handle *h, const float *draws_dev, int64_t n, int32_t block_rows, int32_t block0, int64_t row_base,
+BGM_API int bgm_bnn_effects(bgm_handle *h, const float *draws_dev, int64_t n, int32_t block_rows, int32_t block0, int64_t row_base,
                     int32_t n_keep, int32_t it0, uint64_t seed, int32_t effect, int32_t sample_y, const float *x_values_dev,
                     int32_t n_doses, double *adrf_sum_dev, float *ite_dev, void *stream);
 /* replaces: evaluate with use_bnn, base.py:534-570 (the whole panel of n rows is ONE batch), and the Z initialisation
@@ -588,7 +591,7 @@ int bgm_bnn_effects(bgm_handle *h, const float *draws_dev, int64_t n, int32_t bl
  * (x - x^)^2, (y - y^)^2 from one call of g, h, f (stream stream_id).  dose_sums_dev (continuous, fp64 [n_doses]): sums
  * over rows of mu_y at the doses x_values_dev (stream stream_id + 1 + k).  ite_dev (binary, [n]): mu_y(x = 1) - mu_y(x = 0)
  * (streams stream_id + 1, + 2).  Any of the three outputs may be NULL. */
-int bgm_bnn_evaluate(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev, float *z_dev, int32_t encode,
+BGM_API int bgm_bnn_evaluate(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev, float *z_dev, int32_t encode,
                      int64_t n, const float *x_values_dev, int32_t n_doses, uint64_t seed, uint32_t stream_id,
                      double *sums_dev, double *dose_sums_dev, float *ite_dev, void *stream);
 
@@ -608,57 +611,57 @@ typedef struct {
   int32_t hmc_frozen_noise;      /* 0: every gradient evaluation of HMC draws a fresh perturbation (the reference as written);
                                     1: the whole HMC run reuses generator call 0 (one weight draw, deterministic target) */
 } bgm_bvn_config;
-int bgm_bvn_layout(const bgm_bvn_config *cfg, int64_t *n_params);
+BGM_API int bgm_bvn_layout(const bgm_bvn_config *cfg, int64_t *n_params);
 /* Open a session with the parameters theta_host (layout above).  Adam slots start at zero. */
-int bgm_bvn_begin(bgm_handle *h, const bgm_bvn_config *cfg, const float *theta_host, int64_t count, void *stream);
+BGM_API int bgm_bvn_begin(bgm_handle *h, const bgm_bvn_config *cfg, const float *theta_host, int64_t count, void *stream);
 /* what = 0 parameters, 1 gradient of the last theta step, 2 / 3 Adam slots */
-int bgm_bvn_read(bgm_handle *h, int32_t what, float *host, int64_t count, void *stream);
-int bgm_bvn_write(bgm_handle *h, int32_t what, const float *host, int64_t count, void *stream);
+BGM_API int bgm_bvn_read(bgm_handle *h, int32_t what, float *host, int64_t count, void *stream);
+BGM_API int bgm_bvn_write(bgm_handle *h, int32_t what, const float *host, int64_t count, void *stream);
 /* replaces: BGM.update_g_net with use_bnn, bgm/base.py:145-164 (loss_x + kl_weight * sum(g_net.losses); training-mode
  * BatchNormalization incl. its moving averages).  apply = 1: Adam(lr, 0.9, 0.99) inside the call; apply = 0: the gradient
  * (of the mean over batch_global rows) stays in the session for bgm_bvn_grad_exchange / bgm_bvn_theta_apply.
  * out_dev [2] = loss_x, loss_mse (may be NULL). */
-int bgm_bvn_theta_step(bgm_handle *h, const float *x_dev, float *data_z_dev, const int32_t *idx_dev, int32_t batch,
+BGM_API int bgm_bvn_theta_step(bgm_handle *h, const float *x_dev, float *data_z_dev, const int32_t *idx_dev, int32_t batch,
                        int32_t batch_global, float lr, uint64_t seed, uint32_t stream_id, int32_t apply, float *out_dev,
                        void *stream);
-int bgm_bvn_grad_exchange(bgm_handle *h, float *buf_dev, int32_t to_session, void *stream);
-int bgm_bvn_theta_apply(bgm_handle *h, float lr, void *stream);
+BGM_API int bgm_bvn_grad_exchange(bgm_handle *h, float *buf_dev, int32_t to_session, void *stream);
+BGM_API int bgm_bvn_theta_apply(bgm_handle *h, float lr, void *stream);
 /* replaces: BGM.update_latent_variable_sgd with use_bnn, bgm/base.py:167-187, and the fresh-slot Adam step on the batch rows
  * of data_z (:402).  out_dev [1] = loss_postrior_z. */
-int bgm_bvn_z_step(bgm_handle *h, const float *x_dev, float *data_z_dev, const int32_t *idx_dev, int32_t batch,
+BGM_API int bgm_bvn_z_step(bgm_handle *h, const float *x_dev, float *data_z_dev, const int32_t *idx_dev, int32_t batch,
                    int32_t batch_global, float lr_z, uint64_t seed, uint32_t stream_id, float *out_dev, void *stream);
 /* replaces: BGM.get_log_posterior with use_bnn, bgm/base.py:665-705: ONE generator call (stream_id) over the n rows (global
  * rows row_base + i key the Flipout signs); x_dev NaN = missing; grad_dev [n x q] may be NULL. */
-int bgm_bvn_logpost(bgm_handle *h, const float *z_dev, const float *x_dev, int64_t n, int64_t row_base, uint64_t seed,
+BGM_API int bgm_bvn_logpost(bgm_handle *h, const float *z_dev, const float *x_dev, int64_t n, int64_t row_base, uint64_t seed,
                     uint32_t stream_id, float *out_dev, float *grad_dev, void *stream);
 /* replaces: tfp.mcmc.HamiltonianMonteCarlo.one_step on the stochastic target (bgm/base.py:798-821): gradient evaluation
  * `leap` of transition `it` is generator call 1 + it * n_leapfrog + leap (call 0 = bootstrap when init = 1); the cached
  * log-prob / gradient of the current state are kept, as TFP does.  Same argument struct as bgm_bgm_hmc_run. */
-int bgm_bvn_hmc_run(bgm_handle *h, const bgm_hmc_args *args, void *stream);
+BGM_API int bgm_bvn_hmc_run(bgm_handle *h, const bgm_hmc_args *args, void *stream);
 /* replaces: g_net(z, training=False) + reparameterize in predict_on_posteriors / generate / evaluate (:511-525, :478-509,
  * :444-476): ONE generator call (stream_id) over the flattened [n_draws x n] rows; the Flipout signs of draw d, row r are
  * keyed by d * sign_stride + sign_off + r (predict: sign_stride = bs, sign_off = position of the first row inside its
  * bs-block, so the result does not depend on how a block is split over ranks).  Outputs as bgm_bgm_predict_draws. */
-int bgm_bvn_decode(bgm_handle *h, const float *draws_dev, int64_t n, int64_t row_base, int32_t n_draws, int32_t burn_in,
+BGM_API int bgm_bvn_decode(bgm_handle *h, const float *draws_dev, int64_t n, int64_t row_base, int32_t n_draws, int32_t burn_in,
                    uint64_t seed, uint32_t stream_id, uint32_t sign_stride, uint32_t sign_off, const int32_t *slot_dev,
                    int32_t k_slots, float *cells_dev, float *full_dev, float *var_full_dev, int32_t add_noise, void *stream);
 /* EGM warm start with the Bayesian generator (bgm/base.py:190-340; e_net, dz_net, dx_net deterministic): as bgm_bgm_egm_* but
  * on top of the bgm_bvn session, whose generator it copies at _begin and returns at _sync / _end.  (seed, stream_id) key the
  * Flipout noise: the disc step makes one generator call (stream_id), the gen step two (stream_id, stream_id + 1). */
-int bgm_bvn_egm_begin(bgm_handle *h, const bgm_bgm_egm_config *cfg, const float *theta_e_host, int64_t count_e,
+BGM_API int bgm_bvn_egm_begin(bgm_handle *h, const bgm_bgm_egm_config *cfg, const float *theta_e_host, int64_t count_e,
                       const float *theta_dz_host, int64_t count_dz, const float *theta_dx_host, int64_t count_dx,
                       void *stream);
-int bgm_bvn_egm_disc_step(bgm_handle *h, const float *z_dev, const float *x_dev, const float *noise_dev, float eps_z,
+BGM_API int bgm_bvn_egm_disc_step(bgm_handle *h, const float *z_dev, const float *x_dev, const float *noise_dev, float eps_z,
                           float eps_x, uint64_t seed, uint32_t stream_id, int32_t apply, float *out_dev, void *stream);
-int bgm_bvn_egm_gen_step(bgm_handle *h, const float *z_dev, const float *x_dev, const float *noise1_dev,
+BGM_API int bgm_bvn_egm_gen_step(bgm_handle *h, const float *z_dev, const float *x_dev, const float *noise1_dev,
                          const float *noise2_dev, uint64_t seed, uint32_t stream_id, int32_t apply, float *out_dev,
                          void *stream);
-int bgm_bvn_egm_read(bgm_handle *h, int32_t what, float *host, int64_t count, void *stream);
-int bgm_bvn_egm_write(bgm_handle *h, int32_t what, const float *host, int64_t count, void *stream);
-int bgm_bvn_egm_encode(bgm_handle *h, const float *x_dev, int64_t n, float *z_dev, void *stream);
-int bgm_bvn_egm_sync(bgm_handle *h, void *stream);
-int bgm_bvn_egm_end(bgm_handle *h, void *stream);
-int bgm_bvn_end(bgm_handle *h, void *stream);
+BGM_API int bgm_bvn_egm_read(bgm_handle *h, int32_t what, float *host, int64_t count, void *stream);
+BGM_API int bgm_bvn_egm_write(bgm_handle *h, int32_t what, const float *host, int64_t count, void *stream);
+BGM_API int bgm_bvn_egm_encode(bgm_handle *h, const float *x_dev, int64_t n, float *z_dev, void *stream);
+BGM_API int bgm_bvn_egm_sync(bgm_handle *h, void *stream);
+BGM_API int bgm_bvn_egm_end(bgm_handle *h, void *stream);
+BGM_API int bgm_bvn_end(bgm_handle *h, void *stream);
 
 #ifdef __cplusplus
 }

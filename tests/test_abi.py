@@ -47,3 +47,17 @@ def test_struct_layouts_match_header():
     a = _lib.MhArgs()
     assert C.sizeof(a) % 8 == 0
     assert _lib.MhArgs.n.offset == 24 and _lib.MhArgs.state_dev.offset == 40
+
+
+def test_library_exports_nothing_of_its_own_besides_the_abi():
+    """-fvisibility=hidden + BGM_API: no host helper or state struct of the library leaks into the dynamic symbol table.  (hipcc gives
+    the host stubs of __global__ functions default visibility whatever the flag says; they are the only other names of the library
+    left there, next to a few std:: template instantiations and the toolchain's __hip_cuid markers.)"""
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    so = os.path.join(ROOT, "bayesgm_amd", "libbgm_hip.so")
+    out = subprocess.run([nm, "-D", "--defined-only", so], check=True, capture_output=True, text=True).stdout
+    syms = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+    own = [s for s in syms if re.search(r"bgm|gx_|Gx|bnf|Bnf|bnn|Bnn|causal|egm|Egm|fit_", s) and not re.match(r"_Z\d+[A-Za-z0-9_]*_kernel", s)]
+    assert sorted(own) == _declared_symbols(), sorted(set(own) - set(_declared_symbols()))

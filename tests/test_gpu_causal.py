@@ -264,6 +264,7 @@ def test_full_size_panel_properties():
     idx = np.sort(rs.choice(n, 40, replace=False))
     got = a["state"].cpu().numpy()[idx]
     ref = np.stack([OC.mh_sampler(m, (x[i:i + 1], y[i:i + 1], v[i:i + 1]), burn, keep, 1.0, 5, row0=int(i))[-1, 0] for i in idx])
+    print('MEASURED causal sampled-row agreement', int(np.all(np.abs(got - ref) <= 1e-4, axis=1).sum()), 'of', len(idx))
     assert np.all(np.abs(got - ref) <= 1e-4, axis=1).mean() >= 0.95
     # (iv) ADRF of a 64-row block vs the oracle's effects on the same draws
     small = run(lo, lo + 64, want_draws=True)
@@ -302,6 +303,7 @@ def test_binary_treatment_full_size_panel_properties():
     idx = np.sort(np.random.RandomState(75).choice(n, 40, replace=False))
     got = a["state"].cpu().numpy()[idx]
     ref = np.stack([OC.mh_sampler(m, (x[i:i + 1], y[i:i + 1], v[i:i + 1]), burn, keep, 0.5, seed, row0=int(i))[-1, 0] for i in idx])
+    print('MEASURED causal sampled-row agreement', int(np.all(np.abs(got - ref) <= 1e-4, axis=1).sum()), 'of', len(idx))
     assert np.all(np.abs(got - ref) <= 1e-4, axis=1).mean() >= 0.95
     draws = part["draws"].cpu().numpy()[:, :96]
     ref_ite = OC.infer_from_latent_posterior(OC.cast_model(m, np.float64), draws.astype(np.float64), None, True, seed, row0=lo,

@@ -256,6 +256,7 @@ def test_fit_steps_then_sampling_with_the_trained_parameters(shape):
     assert np.abs(zd.cpu().numpy() - st.data_z).max() <= 3e-4
     lp = eng.logpost(xd, yd, vd, zd).cpu().numpy()
     ref = OC.log_posterior(dict(st.m), x64, y64, v64, st.data_z)
+    print('MEASURED widths logp after 4 steps', float(np.abs(lp - ref).max()), float(np.abs(ref).max()))
     assert np.abs(lp - ref).max() <= 2e-2 + 1e-4 * np.abs(ref).max()
     eng.fit_end()
     lp2 = eng.logpost(xd, yd, vd, zd).cpu().numpy()

@@ -184,3 +184,30 @@ def test_tutorial_run_reproduces_published_trace(capsys):
     assert not out, out
     assert s["adrf_rmse"] <= 0.05 and s["adrf_mape"] <= 0.02
     assert abs(float(np.mean(adrf)) - float(np.mean(truth))) <= 0.01      # |average effect error| over the dose grid
+
+
+def test_second_optimum_warning_on_the_committed_runs():
+    """bayesgm_amd/diagnostics.py: the one warnings.warn of CausalBGM.fit.  Replayed on the committed logs exactly as the class sees
+    them -- the EGM log lines give the late l2_loss_z, every fit evaluation gives a panel MSE_v -- it fires at the FIRST evaluation of
+    the five runs that ended in the second optimum (product seeds 2026 and 99 -- the latter the run with ADRF RMSE 0.53 -- and oracle
+    seeds 1, 11, 123) and on no evaluation of the eleven runs that reproduce the published trace."""
+    import warnings
+    from bayesgm_amd import diagnostics as D
+    runs = [("hip_s%d" % sd, os.path.join(ROOT, "profiles", "r03_accuracy", "bnn_s%d.log" % sd)) for sd in SEEDS]
+    runs += [("oracle_s%d" % sd, os.path.join(ROOT, "profiles", "r03_oracle_anchor", "oracle_s%d.log" % sd)) for sd in SEEDS]
+    fired = {}
+    for name, path in runs:
+        egm, _, ev, _ = parse_log(open(path, errors="replace").read())
+        l2z = D.late_l2_loss_z(egm[:, 0], egm[:, 3], 30000)
+        msgs = [D.second_optimum_message(l2z, mv) for mv in ev[:, 3]]
+        fired[name] = [m is not None for m in msgs]
+        if any(fired[name]):
+            assert fired[name][0] and "another random_seed" in msgs[0], name        # at the first evaluation, naming the remedy
+    assert sorted(k for k, v in fired.items() if any(v)) == ["hip_s2026", "hip_s99", "oracle_s1", "oracle_s11", "oracle_s123"]
+    with pytest.warns(D.SecondOptimumWarning, match="second optimum"):
+        assert D.warn_if_second_optimum(0.436, 0.9985) is True                      # product seed 99
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert D.warn_if_second_optimum(0.248, 0.9744) is False                     # product seed 123 (published: 0.247 / 0.9665)
+        assert D.warn_if_second_optimum(0.436, 0.9985, already=True) is True        # once per fit
+        assert D.warn_if_second_optimum(None, 0.99) is False                        # no warm start in this process
