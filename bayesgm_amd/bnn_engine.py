@@ -151,6 +151,16 @@ class BnnEngine(object):
         _lib.check(self.lib.bgm_bnn_z_sync(self.h, _ptr(data_z), _ptr(zm), _ptr(zv), _ptr(idx), data_z.shape[0],
                                            0 if idx is None else int(idx.numel()), float(lr_z), self._stream()), "bgm_bnn_z_sync")
 
+    def fit_epoch(self, x, y, v, data_z, zm, zv, perm, batch, lr_theta, lr_z, lazy, seed, stream_id0, out_t=None, out_z=None):
+        """All minibatches perm[0:batch], perm[batch:2 batch], ... of one epoch with the loop inside the library (bgm_bnn_fit_epoch;
+        single process).  Returns the number of minibatches run (each consumed three noise streams)."""
+        n_done = C.c_int32(0)
+        _lib.check(self.lib.bgm_bnn_fit_epoch(self.h, _ptr(x), _ptr(y), _ptr(v), _ptr(data_z), _ptr(zm), _ptr(zv), _ptr(perm),
+                                              data_z.shape[0], int(perm.numel()), int(batch), float(lr_theta), float(lr_z), int(lazy),
+                                              int(seed), int(stream_id0) & 0xFFFFFFFF, _ptr(out_t), _ptr(out_z), C.byref(n_done),
+                                              self._stream()), "bgm_bnn_fit_epoch")
+        return n_done.value
+
     # -- large-batch side ------------------------------------------------------------------------------
     def logpost(self, x, y, v, z, block_rows, seed, stream_id, block0=0):
         out = torch.empty(z.shape[0], device=self.device, dtype=torch.float32)

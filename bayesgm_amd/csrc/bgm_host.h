@@ -89,6 +89,10 @@ struct bgm_handle {
   size_t acc_scratch_cap = 0;
   void *det_state = nullptr;  // BnfState (bnf_det_api.hip): general-shape sampling path of the deterministic nets
   bool det_valid = false;
+  // bgm_causal_fit_epoch: gradient buffer, second stream and the events that order the two phases
+  float *epoch_grad = nullptr; int epoch_grad_n = 0;
+  hipStream_t epoch_stream = nullptr;
+  hipEvent_t epoch_ev_t[2] = {nullptr, nullptr}, epoch_ev_z[2] = {nullptr, nullptr}, epoch_ev_s = nullptr;
   void *gx_state = nullptr;   // GxState (gx_api.hip): general-width engine (hidden widths / depths outside the compiled families)
   bool gx_valid = false;      // its padded packs hold the handle's current g, f, h, e
   void *bgm_state = nullptr;  // BgmState (bgm_api.hip)

@@ -18,6 +18,7 @@ struct BnnFitChain {
   EcbTab *tab_theta = nullptr, *tab_z = nullptr;
   int *tiles_theta = nullptr;
   float *ws = nullptr;
+  float *ws_z = nullptr;     // the latent phase's own workspace: it may run beside the next minibatch's theta phase (bgm_bnn_fit_epoch)
 };
 template <bool KL>
 static __global__ __launch_bounds__(BNN_THREADS) void bnn_fit_noise_kernel(BnnArgs a, const EcbTab *tab, float *ws) {
@@ -46,7 +47,7 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_z_chain_kernel(BnnArgs
 static void bnn_chain_free(BnnState *s) {
   BnnFitChain *c = static_cast<BnnFitChain *>(s->chain);
   if (!c) return;
-  for (void *p : {(void *)c->tab_theta, (void *)c->tab_z, (void *)c->tiles_theta, (void *)c->ws})
+  for (void *p : {(void *)c->tab_theta, (void *)c->tab_z, (void *)c->tiles_theta, (void *)c->ws, (void *)c->ws_z})
     if (p) hipFree(p);
   delete c;
   s->chain = nullptr;
@@ -72,6 +73,8 @@ static int bnn_chain_setup(BnnState *s) {
   const size_t wsf = std::max(w1, w2) + 64;
   BGM_HIP_CHECK(hipMalloc((void **)&c->ws, sizeof(float) * wsf));
   BGM_HIP_CHECK(hipMemset(c->ws, 0, sizeof(float) * wsf));
+  BGM_HIP_CHECK(hipMalloc((void **)&c->ws_z, sizeof(float) * wsf));
+  BGM_HIP_CHECK(hipMemset(c->ws_z, 0, sizeof(float) * wsf));
   BGM_HIP_CHECK(hipMalloc((void **)&c->tab_theta, sizeof(EcbTab)));
   BGM_HIP_CHECK(hipMalloc((void **)&c->tab_z, sizeof(EcbTab)));
   BGM_HIP_CHECK(hipMemcpy(c->tab_theta, &tt, sizeof(EcbTab), hipMemcpyHostToDevice));
@@ -244,23 +247,12 @@ static void bnn_base_args(BnnState *s, BnnArgs &a, int batch, int batch_global, 
   a.dz_part = s->dz_part_dev; a.loss_part = s->dz_part_dev + 3 * (size_t)s->cfg.max_batch * s->q;
 }
 
-extern "C" int bgm_bnn_theta_step(bgm_handle *h, const float *data_z, const int32_t *idx, const float *x, const float *y,
-                                  const float *v, int32_t batch, int32_t batch_global, float lr_theta, uint64_t seed,
-                                  uint32_t stream_id, int32_t apply, float *out, void *stream_) {
-  int rc = bnn_need(h, "bgm_bnn_theta_step");
-  if (rc) return rc;
-  BnnState *s = bst(h);
-  if (!data_z || !idx || !x || !y || !v) { bgm_set_error("bgm_bnn_theta_step: NULL argument"); return BGM_E_INVALID; }
-  if (batch < 2 || batch > s->cfg.max_batch) { bgm_set_error("bgm_bnn_theta_step: batch outside [2, max_batch]"); return BGM_E_INVALID; }
-  BGM_HIP_CHECK(hipSetDevice(h->device));
-  BnnArgs a{};
-  bnn_base_args(s, a, batch, batch_global, seed, stream_id);
-  a.data_z = data_z; a.idx = idx; a.x_ = x; a.y_ = y; a.v_ = v;
-  a.apply = apply; a.out = out;
-  if (apply) { s->t_theta += 1; a.adam = BnnAdam{adam_lr_t(lr_theta, s->t_theta), BNN_ADAM_B1, BNN_ADAM_B2, BNN_ADAM_EPS}; }
+// The launches of one theta step.  parts & 1: noise + forward / backward chains (read the parameters); parts & 2: the gradient tiles
+// and, with a.apply, the Adam step on them (write the parameters).  bgm_bnn_fit_epoch puts a stream dependency between the two.
+static void bnn_theta_launch(BnnState *s, BnnArgs &a, int batch, int parts, hipStream_t st) {
   BnnFitChain *fc = static_cast<BnnFitChain *>(s->chain);
   if (fc && (batch == 32 || (batch == 16 && !fc->pad))) {
-    hipStream_t st = (hipStream_t)stream_;
+    if (parts & 1) {
     hipLaunchKernelGGL(bnn_fit_noise_kernel<true>, dim3(3 * ECB_NOISE_PARTS), dim3(BNN_THREADS), 0, st, a, fc->tab_theta, fc->ws);
     auto kc = fc->t0 == 2 ? bnn_theta_chain_kernel<13, 2, true, 2> : fc->pad ? bnn_theta_chain_kernel<13, 2, true>
               : batch == 32 ? (fc->ntl == 13 ? bnn_theta_chain_kernel<13, 2> : bnn_theta_chain_kernel<7, 2>)
@@ -277,11 +269,31 @@ extern "C" int bgm_bnn_theta_step(bgm_handle *h, const float *data_z, const int3
       }
     } else
       hipLaunchKernelGGL(kc, dim3(1), dim3(BNN_THREADS), 64 * sizeof(float), st, a, fc->tab_theta, fc->ws);
+    }
+    if (parts & 2) {
     auto kd = batch == 32 ? bnn_theta_dw_kernel<2> : bnn_theta_dw_kernel<1>;
     hipLaunchKernelGGL(kd, dim3((fc->n_tiles + ECH_WAVES - 1) / ECH_WAVES + 1), dim3(BNN_THREADS), 0, st, a, fc->tab_theta, fc->tiles_theta, fc->ws);
-  } else {
-    hipLaunchKernelGGL(bnn_theta_step_kernel, dim3(3), dim3(BNN_THREADS), 0, (hipStream_t)stream_, a);
+    }
+  } else if (parts & 2) {          // (the phase machine is one launch: it runs at the point of the parameter write)
+    hipLaunchKernelGGL(bnn_theta_step_kernel, dim3(3), dim3(BNN_THREADS), 0, st, a);
   }
+}
+
+extern "C" int bgm_bnn_theta_step(bgm_handle *h, const float *data_z, const int32_t *idx, const float *x, const float *y,
+                                  const float *v, int32_t batch, int32_t batch_global, float lr_theta, uint64_t seed,
+                                  uint32_t stream_id, int32_t apply, float *out, void *stream_) {
+  int rc = bnn_need(h, "bgm_bnn_theta_step");
+  if (rc) return rc;
+  BnnState *s = bst(h);
+  if (!data_z || !idx || !x || !y || !v) { bgm_set_error("bgm_bnn_theta_step: NULL argument"); return BGM_E_INVALID; }
+  if (batch < 2 || batch > s->cfg.max_batch) { bgm_set_error("bgm_bnn_theta_step: batch outside [2, max_batch]"); return BGM_E_INVALID; }
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  BnnArgs a{};
+  bnn_base_args(s, a, batch, batch_global, seed, stream_id);
+  a.data_z = data_z; a.idx = idx; a.x_ = x; a.y_ = y; a.v_ = v;
+  a.apply = apply; a.out = out;
+  if (apply) { s->t_theta += 1; a.adam = BnnAdam{adam_lr_t(lr_theta, s->t_theta), BNN_ADAM_B1, BNN_ADAM_B2, BNN_ADAM_EPS}; }
+  bnn_theta_launch(s, a, batch, 3, (hipStream_t)stream_);
   BGM_HIP_CHECK(hipGetLastError());
   if (apply) { s->packed_valid = false; s->bnf_valid = false; }
   return BGM_OK;
@@ -332,7 +344,7 @@ extern "C" int bgm_bnn_z_step(bgm_handle *h, const float *x, const float *y, con
   a.out = out; a.dz = dz_out ? dz_out : s->dz_dev;
   BnnFitChain *fc = static_cast<BnnFitChain *>(s->chain);
   if (fc && (batch == 32 || (batch == 16 && !fc->pad))) {
-    hipLaunchKernelGGL(bnn_fit_noise_kernel<false>, dim3(6 * ECB_NOISE_PARTS), dim3(BNN_THREADS), 0, stream, a, fc->tab_z, fc->ws);
+    hipLaunchKernelGGL(bnn_fit_noise_kernel<false>, dim3(6 * ECB_NOISE_PARTS), dim3(BNN_THREADS), 0, stream, a, fc->tab_z, fc->ws_z);
     auto kc = fc->t0 == 2 ? bnn_z_chain_kernel<13, 2, true, 2> : fc->pad ? bnn_z_chain_kernel<13, 2, true>
               : batch == 32 ? (fc->ntl == 13 ? bnn_z_chain_kernel<13, 2> : bnn_z_chain_kernel<7, 2>)
                           : (fc->ntl == 13 ? bnn_z_chain_kernel<13, 1> : bnn_z_chain_kernel<7, 1>);
@@ -342,14 +354,14 @@ extern "C" int bgm_bnn_z_step(bgm_handle *h, const float *x, const float *y, con
       static const bool no_ws = std::getenv("BGM_FIT_NO_WORKERS") != nullptr;
       if (no_ws) {
         auto ks = fc->ntl == 13 ? bnn_z_chain_kernel<13, 1> : bnn_z_chain_kernel<7, 1>;
-        hipLaunchKernelGGL(ks, dim3(2), dim3(BNN_THREADS), lds_z, stream, a, fc->tab_z, fc->ws);
+        hipLaunchKernelGGL(ks, dim3(2), dim3(BNN_THREADS), lds_z, stream, a, fc->tab_z, fc->ws_z);
       } else {      // the mean call's last layer over the idle waves, the variance-head call on its one column (ecb_z_chain<WS>)
         auto ks = fc->ntl == 13 ? bnn_z_chain_kernel<13, 1, false, 1, true> : bnn_z_chain_kernel<7, 1, false, 1, true>;
         const size_t lds_ws = (32 + 2 * 16 + 4 * 16 * 16 + 2 * 1024 + 64 + 4 * 1024 + 8) * sizeof(float);
-        hipLaunchKernelGGL(ks, dim3(2), dim3(BNN_THREADS), std::max(lds_z, lds_ws), stream, a, fc->tab_z, fc->ws);
+        hipLaunchKernelGGL(ks, dim3(2), dim3(BNN_THREADS), std::max(lds_z, lds_ws), stream, a, fc->tab_z, fc->ws_z);
       }
     } else
-      hipLaunchKernelGGL(kc, dim3(1), dim3(BNN_THREADS), lds_z, stream, a, fc->tab_z, fc->ws);
+      hipLaunchKernelGGL(kc, dim3(1), dim3(BNN_THREADS), lds_z, stream, a, fc->tab_z, fc->ws_z);
   } else {
     hipLaunchKernelGGL(bnn_z_grad_kernel, dim3(3), dim3(BNN_THREADS), 0, stream, a);
     hipLaunchKernelGGL(bnn_z_combine_kernel, dim3((batch * s->q + 255) / 256), dim3(256), 0, stream, a.dz_part, a.loss_part, a.dz, out, batch * s->q);
@@ -408,6 +420,73 @@ extern "C" int bgm_bnn_z_sync(bgm_handle *h, float *data_z, float *zm, float *zv
     s->z_synced = s->t_z + 1;
   }
   BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// A list of minibatches with the loop inside the library (single process).  replaces: the loop body causalbgm/base.py:490-505 with
+// use_bnn for the minibatches perm[0 .. n_use) taken `batch` rows at a time: bgm_bnn_z_sync (lazy = 2), bgm_bnn_theta_step(apply = 1),
+// bgm_bnn_z_step in that order, noise streams stream_id0 + 3 k (theta step) and + 3 k + 1 (latent step) for the k-th minibatch
+// of at least two rows (a one-row tail is skipped, as the host loop does).  *n_done = minibatches run.
+// On the row-tile chains with lazy = 1 / 2 the latent phase of minibatch k runs on a second stream beside the noise / forward /
+// backward chains of minibatch k + 1 (both read the parameters of step k + 1; disjoint rows of the latent table); the gradient-tile
+// kernel of minibatch k + 1, which applies Adam, waits for it.  Results are those of the sequential order.
+// ---------------------------------------------------------------------------------------------------------------------------
+extern "C" int bgm_bnn_fit_epoch(bgm_handle *h, const float *x, const float *y, const float *v, float *data_z, float *zm, float *zv,
+                                 const int32_t *perm, int64_t n_rows, int64_t n_use, int32_t batch, float lr_theta, float lr_z, int32_t lazy,
+                                 uint64_t seed, uint32_t stream_id0, float *out_t, float *out_z, int32_t *n_done, void *stream_) {
+  int rc = bnn_need(h, "bgm_bnn_fit_epoch");
+  if (rc) return rc;
+  BnnState *s = bst(h);
+  if (!x || !y || !v || !data_z || !zm || !zv || !perm || n_use < 1 || batch < 2 || batch > s->cfg.max_batch) { bgm_set_error("bgm_bnn_fit_epoch: bad argument"); return BGM_E_INVALID; }
+  hipStream_t sA = (hipStream_t)stream_;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  BnnFitChain *fc = static_cast<BnnFitChain *>(s->chain);
+  static const bool no_overlap = std::getenv("BGM_FIT_NO_OVERLAP") != nullptr;
+  const bool overlap = !no_overlap && lazy != 0 && fc && (batch == 32 || (batch == 16 && !fc->pad));
+  if (overlap && !h->epoch_stream) {
+    BGM_HIP_CHECK(hipStreamCreateWithFlags(&h->epoch_stream, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) {
+      BGM_HIP_CHECK(hipEventCreateWithFlags(&h->epoch_ev_t[k], hipEventDisableTiming));
+      BGM_HIP_CHECK(hipEventCreateWithFlags(&h->epoch_ev_z[k], hipEventDisableTiming));
+    }
+  }
+  hipStream_t sB = overlap ? h->epoch_stream : sA;
+  long long k = 0;
+  for (int64_t i = 0; i < n_use; i += batch) {
+    const int32_t *idx = perm + i;
+    const int b = (int)std::min<int64_t>(batch, n_use - i);
+    if (b < 2) continue;                     // batch statistics need two rows
+    const bool ov = overlap && b == batch;   // (a short last minibatch runs on the phase machine: in stream order)
+    const uint32_t s0 = stream_id0 + (uint32_t)(3 * k);
+    if (lazy == 2 && (rc = bgm_bnn_z_sync(h, data_z, zm, zv, idx, n_rows, b, lr_z, sA))) return rc;
+    if (overlap && k == 0) {                 // the second stream starts behind everything queued on the caller's so far
+      BGM_HIP_CHECK(hipEventRecord(h->epoch_ev_t[1], sA));
+      BGM_HIP_CHECK(hipStreamWaitEvent(sB, h->epoch_ev_t[1], 0));
+    }
+    BnnArgs a{};
+    bnn_base_args(s, a, b, 0, seed, s0);
+    a.data_z = data_z; a.idx = idx; a.x_ = x; a.y_ = y; a.v_ = v; a.apply = 1; a.out = out_t;
+    s->t_theta += 1;
+    a.adam = BnnAdam{adam_lr_t(lr_theta, s->t_theta), BNN_ADAM_B1, BNN_ADAM_B2, BNN_ADAM_EPS};
+    bnn_theta_launch(s, a, b, 1, sA);
+    if (overlap && k > 0) BGM_HIP_CHECK(hipStreamWaitEvent(sA, h->epoch_ev_z[(k - 1) & 1], 0));
+    bnn_theta_launch(s, a, b, 2, sA);
+    BGM_HIP_CHECK(hipGetLastError());
+    s->packed_valid = false; s->bnf_valid = false;
+    if (overlap) {
+      BGM_HIP_CHECK(hipEventRecord(h->epoch_ev_t[k & 1], sA));
+      BGM_HIP_CHECK(hipStreamWaitEvent(sB, h->epoch_ev_t[k & 1], 0));
+    }
+    if ((rc = bgm_bnn_z_step(h, x, y, v, data_z, zm, zv, idx, n_rows, b, 0, lr_z, lazy, seed, s0 + 1, out_z, nullptr, ov ? sB : sB))) return rc;
+    if (overlap) BGM_HIP_CHECK(hipEventRecord(h->epoch_ev_z[k & 1], sB));
+    ++k;
+  }
+  if (overlap && k > 0) {
+    BGM_HIP_CHECK(hipEventRecord(h->epoch_ev_z[0], sB));
+    BGM_HIP_CHECK(hipStreamWaitEvent(sA, h->epoch_ev_z[0], 0));
+  }
+  if (n_done) *n_done = (int32_t)k;
   return BGM_OK;
 }
 

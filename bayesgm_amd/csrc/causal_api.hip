@@ -50,6 +50,11 @@ extern "C" int bgm_destroy(bgm_handle *h) {
   bnf_det_free(h);
   bgm_causal_fit_end(h, nullptr);
   gx_free(h);
+  if (h->epoch_stream) {
+    hipStreamDestroy(h->epoch_stream);
+    for (int k = 0; k < 2; ++k) { hipEventDestroy(h->epoch_ev_t[k]); hipEventDestroy(h->epoch_ev_z[k]); }
+    if (h->epoch_ev_s) hipEventDestroy(h->epoch_ev_s);
+  }
   bgm_bgm_free_state(h);
   bgm_egm_free_state(h);
   bgm_bgm_egm_free_state(h);

@@ -20,12 +20,15 @@ struct FitChainState {
   int t0 = 1;            // latent input tiles of g (q <= 16 t0); two tiles run the padded B = 32 variant only
   bool pad = false;      // the 13-tile kernels on a narrower p + 1 (B = 32 only)
   float *thetaT = nullptr, *ws = nullptr;
+  float *theta2 = nullptr, *thetaT2 = nullptr;      // second parameter buffer + its transposed mirror (bgm_causal_fit_epoch)
+  const float *theta_use = nullptr, *thetaT_use = nullptr;   // when set: the buffers the next chain launch reads
+  float *ws_z = nullptr;   // the latent phase's own stash, so that it may overlap the next minibatch's theta phase (bgm_causal_fit_epoch)
   int *tiles = nullptr, *mirror_dst = nullptr;
 };
 static void fit_chain_free(bgm_handle *h) {
   FitChainState *c = static_cast<FitChainState *>(h->fit_chain);
   if (!c) return;
-  for (void *p : {(void *)c->thetaT, (void *)c->ws, (void *)c->tiles, (void *)c->mirror_dst})
+  for (void *p : {(void *)c->thetaT, (void *)c->ws, (void *)c->ws_z, (void *)c->tiles, (void *)c->mirror_dst, (void *)c->theta2, (void *)c->thetaT2})
     if (p) hipFree(p);
   delete c;
   h->fit_chain = nullptr;
@@ -91,6 +94,8 @@ static int fit_chain_setup(bgm_handle *h, const std::vector<float> &theta) {
   a.n_tiles = (int)(tiles.size() / ECG_TILE_INTS);
   BGM_HIP_CHECK(hipMalloc((void **)&c->ws, sizeof(float) * (off + 64)));
   BGM_HIP_CHECK(hipMemset(c->ws, 0, sizeof(float) * (off + 64)));
+  BGM_HIP_CHECK(hipMalloc((void **)&c->ws_z, sizeof(float) * (off + 64)));
+  BGM_HIP_CHECK(hipMemset(c->ws_z, 0, sizeof(float) * (off + 64)));
   BGM_HIP_CHECK(hipMalloc((void **)&c->thetaT, sizeof(float) * tT.size()));
   BGM_HIP_CHECK(hipMemcpy(c->thetaT, tT.data(), sizeof(float) * tT.size(), hipMemcpyHostToDevice));
   BGM_HIP_CHECK(hipMalloc((void **)&c->tiles, sizeof(int) * tiles.size()));
@@ -106,6 +111,7 @@ static int fit_chain_setup(bgm_handle *h, const std::vector<float> &theta) {
 }
 // one launch of the chains; Z_MODE 0 also the gradient tiles into `grad`
 static void fit_chain_launch(const FitChainState *c, FitChainArgs &a, int batch, int z_mode, hipStream_t stream) {
+  if (c->theta_use) { a.theta = c->theta_use; a.thetaT = c->thetaT_use; }
   static const bool one_wg_ = std::getenv("BGM_FIT_ONE_WG") != nullptr;
   a.n_valid = batch;                                 // rows of this minibatch; the tile rows behind them are masked
   const int nb = batch <= 16 ? 1 : 2;                // row tiles (the padded / two-k-tile instantiations are compiled for two only)
@@ -264,6 +270,7 @@ static void fit_free(bgm_handle *h) {
     if (p) hipFree(p);
   h->tlast_dev = nullptr;
   h->z_synced = -1;
+  if (h->epoch_grad) { hipFree(h->epoch_grad); h->epoch_grad = nullptr; h->epoch_grad_n = 0; }
   h->theta_dev = h->m1_dev = h->m2_dev = h->bblob_dev = h->ws_dev = h->partial_dev = nullptr;
   h->tables_dev = h->pos_dev = nullptr;
   h->fit_active = false;
@@ -579,7 +586,7 @@ extern "C" int bgm_causal_fit_z_step(bgm_handle *h, const float *x, const float 
   if (FitChainState *fc = static_cast<FitChainState *>(h->fit_chain); fc && batch <= 32) {
     FitChainArgs ca = fc->base;
     ca.x = x; ca.y = y; ca.v = v; ca.data_z = data_z; ca.idx = idx; ca.row_lo = row_lo; ca.inv_B = ka.inv_B;
-    ca.loss = loss; ca.dz = h->ws_dev + h->fit_ws.dz;
+    ca.loss = loss; ca.dz = h->ws_dev + h->fit_ws.dz; ca.ws = fc->ws_z;
     if (!lazy) { ca.pos = h->pos_dev; ca.pos_n = h->fit_rows; ca.epoch = (int)((h->t_z + 1) & 0x3FFFFFFF); pos_set = true; }
     else {                      // the batch rows' Adam step rides on the chain kernel's epilogue
       const double t1 = (double)(h->t_z + 1);
@@ -619,6 +626,18 @@ extern "C" int bgm_causal_fit_z_step(bgm_handle *h, const float *x, const float 
   return BGM_OK;
 }
 
+// the replay launches: rows idx[0 .. n_sel) (NULL: all rows) of (z, zm, zv) brought from their t_last to step t_to
+static int fit_z_sync_rows(bgm_handle *h, float *data_z, float *zm, float *zv, const int32_t *idx, long long n_sel, int t_to, float lr_z,
+                           hipStream_t stream) {
+  const long long threads = n_sel * h->q * 16;
+  hipLaunchKernelGGL(fit_adam_z_replay_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, data_z, zm, zv,
+                     h->tlast_dev, h->q, idx, n_sel, t_to, lr_z, ADAM_B1, ADAM_B2, ADAM_EPS);
+  if (!idx) hipLaunchKernelGGL(fit_fill_int_kernel, dim3((unsigned)((n_sel + 255) / 256)), dim3(256), 0, stream, h->tlast_dev, n_sel, t_to);
+  else hipLaunchKernelGGL(fit_mark_rows_kernel, dim3((unsigned)((n_sel + 255) / 256)), dim3(256), 0, stream, h->tlast_dev, idx, n_sel, t_to);
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
 extern "C" int bgm_causal_fit_z_sync(bgm_handle *h, float *data_z, float *zm, float *zv, const int32_t *idx, int32_t batch, float lr_z,
                                      void *stream_) {
   if (!h || !h->fit_active) { bgm_set_error("bgm_causal_fit_z_sync: call bgm_causal_fit_begin first"); return BGM_E_STATE; }
@@ -630,19 +649,102 @@ extern "C" int bgm_causal_fit_z_sync(bgm_handle *h, float *data_z, float *zm, fl
     BGM_HIP_CHECK(hipMalloc(&h->tlast_dev, sizeof(int) * n_rows));
     hipLaunchKernelGGL(fit_fill_int_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, h->tlast_dev, n_rows, (int)h->t_z);
   }
-  const long long n_sel = idx ? batch : n_rows;
-  const long long threads = n_sel * h->q * 16;
-  hipLaunchKernelGGL(fit_adam_z_replay_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, data_z, zm, zv,
-                     h->tlast_dev, h->q, idx, n_sel, (int)h->t_z, lr_z, ADAM_B1, ADAM_B2, ADAM_EPS);
-  if (!idx) {
-    hipLaunchKernelGGL(fit_fill_int_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, h->tlast_dev, n_rows, (int)h->t_z);
-    h->z_synced = -2;                                // flushed: any mode may follow
-  } else {
-    hipLaunchKernelGGL(fit_mark_rows_kernel, dim3((unsigned)((n_sel + 255) / 256)), dim3(256), 0, stream, h->tlast_dev, idx, n_sel, (int)h->t_z);
-    h->z_synced = h->t_z + 1;
-  }
-  BGM_HIP_CHECK(hipGetLastError());
+  int rc = fit_z_sync_rows(h, data_z, zm, zv, idx, idx ? batch : n_rows, (int)h->t_z, lr_z, stream);
+  if (rc) return rc;
+  h->z_synced = idx ? h->t_z + 1 : -2;               // -2: flushed, any mode may follow
   return BGM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// One pass over a list of minibatches with the loop inside the library (single process: no all-reduce between the phases).
+// replaces: the loop body causalbgm/base.py:490-505 for every minibatch of an epoch -- the same calls, in the same order, as the
+// host loop bgm_causal_fit_z_sync / _theta_grad / _theta_apply / _z_step, issued from C++.
+// With the latent optimizer in batch-rows or replay mode (lazy = 1 / 2) and the row-tile chains, the latent phase of minibatch k
+// runs on a second stream beside the theta phase of minibatch k + 1: the two touch disjoint rows of the latent table (the
+// minibatches of one call must be disjoint -- a permutation), the theta phase k + 1 needs the parameters after step k (same
+// stream); the parameters are double-buffered (step k's Adam reads one buffer and writes the other), so the update k + 1 never
+// waits for the latent phase k -- only for the latent phase k - 1, which read the buffer it overwrites.  Results are those of the
+// sequential order bit for bit; a minibatch then costs max(theta phase, latent phase) instead of their sum (N = 1e6, B = 32:
+// 69.5 -> 51.5 us with the replayed latent Adam, 60.0 -> 41.8 us with the batch-rows one; what remains is the issue cost of the ~12
+// API calls of a minibatch).  Measured and dropped: a single parameter buffer (56.5 us: two cross-stream event hops of ~10 us on the
+// critical cycle); replaying the next minibatch's rows on the second stream (52.2 us: the extra cross-stream wait costs what it saves).
+// ---------------------------------------------------------------------------------------------------------------------------
+extern "C" int bgm_causal_fit_epoch(bgm_handle *h, const float *x, const float *y, const float *v, float *data_z, float *zm, float *zv,
+                                    const int32_t *perm, int64_t n_use, int32_t batch, float lr_theta, float lr_z, int32_t lazy,
+                                    double *loss, double *loss_z, void *stream_) {
+  if (!h || !h->fit_active) { bgm_set_error("bgm_causal_fit_epoch: call bgm_causal_fit_begin first"); return BGM_E_STATE; }
+  if (!perm || n_use < 1 || batch < 1) { bgm_set_error("bgm_causal_fit_epoch: bad minibatch list"); return BGM_E_INVALID; }
+  hipStream_t sA = (hipStream_t)stream_;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  if (!h->epoch_grad || h->epoch_grad_n < h->n_params) {
+    if (h->epoch_grad) BGM_HIP_CHECK(hipFree(h->epoch_grad));
+    BGM_HIP_CHECK(hipMalloc(&h->epoch_grad, sizeof(float) * h->n_params));
+    h->epoch_grad_n = h->n_params;
+  }
+  static const bool no_overlap = std::getenv("BGM_FIT_NO_OVERLAP") != nullptr;       // dev A/B
+  const bool overlap = !no_overlap && lazy != 0 && h->fit_chain != nullptr && batch <= 32;
+  if (overlap && !h->epoch_stream) {
+    BGM_HIP_CHECK(hipStreamCreateWithFlags(&h->epoch_stream, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) {
+      BGM_HIP_CHECK(hipEventCreateWithFlags(&h->epoch_ev_t[k], hipEventDisableTiming));
+      BGM_HIP_CHECK(hipEventCreateWithFlags(&h->epoch_ev_z[k], hipEventDisableTiming));
+    }
+  }
+  hipStream_t sB = overlap ? h->epoch_stream : sA;
+  int rc = BGM_OK;
+  long long k = 0;
+  // Two parameter buffers: step k's Adam reads buffer k & 1 and writes the other one, so the latent phase of minibatch k (reading the
+  // new buffer) never holds up the parameter update of minibatch k + 1 -- that one overwrites the buffer the latent phase k - 1 read.
+  FitChainState *fc = static_cast<FitChainState *>(h->fit_chain);
+  const int np = h->n_params;
+  if (overlap && !fc->theta2) {
+    BGM_HIP_CHECK(hipMalloc((void **)&fc->theta2, sizeof(float) * np));
+    BGM_HIP_CHECK(hipMalloc((void **)&fc->thetaT2, sizeof(float) * ((size_t)np + 64)));
+  }
+  float *tb[2] = {h->theta_dev, overlap ? fc->theta2 : nullptr}, *tTb[2] = {overlap ? fc->thetaT : nullptr, overlap ? fc->thetaT2 : nullptr};
+  if (overlap) BGM_HIP_CHECK(hipMemcpyAsync(fc->thetaT2, fc->thetaT, sizeof(float) * ((size_t)np + 64), hipMemcpyDeviceToDevice, sA));   // (rows no parameter maps to)
+  int cur = 0;
+  for (int64_t i = 0; i < n_use; i += batch, ++k) {
+    const int32_t *idx = perm + i;
+    const int b = (int)std::min<int64_t>(batch, n_use - i);
+    if (lazy == 2 && (rc = bgm_causal_fit_z_sync(h, data_z, zm, zv, idx, b, lr_z, sA))) break;
+    if (overlap && k == 0) {       // the second stream starts behind everything queued on the caller's so far (incl. the first replay)
+      BGM_HIP_CHECK(hipEventRecord(h->epoch_ev_t[1], sA));
+      BGM_HIP_CHECK(hipStreamWaitEvent(sB, h->epoch_ev_t[1], 0));
+    }
+    if (overlap) { fc->theta_use = tb[cur]; fc->thetaT_use = tTb[cur]; }
+    if ((rc = bgm_causal_fit_theta_grad(h, x, y, v, data_z, idx, 0, b, b, h->epoch_grad, loss, sA))) break;
+    if (overlap) {
+      if (k > 1) BGM_HIP_CHECK(hipStreamWaitEvent(sA, h->epoch_ev_z[k & 1], 0));       // latent phase k - 2 (same slot): it read the buffer written now
+      h->t_theta += 1;
+      const double t = (double)h->t_theta;
+      const float lr_t = (float)((double)lr_theta * std::sqrt(1.0 - std::pow((double)ADAM_B2, t)) / (1.0 - std::pow((double)ADAM_B1, t)));
+      const int *tbl = h->tables_dev;
+      hipLaunchKernelGGL(fit_adam_theta_kernel, dim3((np + 255) / 256), dim3(256), 0, sA, tb[cur], h->m1_dev, h->m2_dev, h->epoch_grad, np, lr_t,
+                         ADAM_B1, ADAM_B2, ADAM_EPS, h->blob_dev, h->bblob_dev, tbl, tbl + np, tbl + 2 * (size_t)np, tTb[cur ^ 1], fc->mirror_dst,
+                         tb[cur ^ 1]);
+      BGM_HIP_CHECK(hipGetLastError());
+      h->sblob_valid = false; h->det_valid = false;
+      cur ^= 1;
+      fc->theta_use = tb[cur]; fc->thetaT_use = tTb[cur];
+      BGM_HIP_CHECK(hipEventRecord(h->epoch_ev_t[k & 1], sA));
+      BGM_HIP_CHECK(hipStreamWaitEvent(sB, h->epoch_ev_t[k & 1], 0));
+    } else if ((rc = bgm_causal_fit_theta_apply(h, h->epoch_grad, lr_theta, sA))) break;
+    if ((rc = bgm_causal_fit_z_step(h, x, y, v, data_z, zm, zv, idx, 0, b, b, lr_z, lazy, loss_z, sB))) break;
+    if (overlap) BGM_HIP_CHECK(hipEventRecord(h->epoch_ev_z[k & 1], sB));
+  }
+  if (overlap) {
+    fc->theta_use = nullptr; fc->thetaT_use = nullptr;
+    if (k > 0) {      // join: whatever follows on the caller's stream sees the last latent phase ...
+      BGM_HIP_CHECK(hipEventRecord(h->epoch_ev_z[0], sB));
+      BGM_HIP_CHECK(hipStreamWaitEvent(sA, h->epoch_ev_z[0], 0));
+    }
+    if (cur == 1) {   // ... and the parameters in the session's own buffers
+      BGM_HIP_CHECK(hipMemcpyAsync(h->theta_dev, fc->theta2, sizeof(float) * np, hipMemcpyDeviceToDevice, sA));
+      BGM_HIP_CHECK(hipMemcpyAsync(fc->thetaT, fc->thetaT2, sizeof(float) * ((size_t)np + 64), hipMemcpyDeviceToDevice, sA));
+    }
+  }
+  return rc;
 }
 
 extern "C" int bgm_causal_get_weights(bgm_handle *h, int net_id, float *theta_host, int64_t count, void *stream_) {
@@ -677,7 +779,7 @@ extern "C" int bgm_causal_fit_z_grad(bgm_handle *h, const float *x, const float 
   if (FitChainState *fc = static_cast<FitChainState *>(h->fit_chain); fc && batch <= 32) {
     FitChainArgs ca = fc->base;
     ca.x = x; ca.y = y; ca.v = v; ca.data_z = data_z; ca.idx = idx; ca.row_lo = row_lo; ca.inv_B = ka.inv_B;
-    ca.loss = loss; ca.dz = h->ws_dev + h->fit_ws.dz;
+    ca.loss = loss; ca.dz = h->ws_dev + h->fit_ws.dz; ca.ws = fc->ws_z;
     fit_chain_launch(fc, ca, batch, 1, stream);
     rc = BGM_OK;
   } else if (gx_fit_active(h)) rc = gx_fit_grads(h, x, y, v, data_z, idx, row_lo, batch, batch_global, 1, nullptr, loss, stream);

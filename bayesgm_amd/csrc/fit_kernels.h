@@ -418,7 +418,7 @@ __global__ void fit_grad_reduce_kernel(const float *partial, long long stride, i
 __global__ void fit_adam_theta_kernel(float *theta, float *m1, float *m2, const float *grad, int n_params,
                                       float lr_t, float b1, float b2, float eps, float *fwd_blob,
                                       float *bwd_blob, const int *fwd_dst, const int *fwd_dst2, const int *bwd_dst,
-                                      float *mirror = nullptr, const int *mirror_dst = nullptr) {
+                                      float *mirror = nullptr, const int *mirror_dst = nullptr, float *theta_out = nullptr) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_params) return;
   const float g = grad[c];
@@ -427,7 +427,7 @@ __global__ void fit_adam_theta_kernel(float *theta, float *m1, float *m2, const 
   m1[c] = m;
   m2[c] = v;
   const float w = theta[c] - lr_t * m / (sqrtf(v) + eps);
-  theta[c] = w;
+  (theta_out ? theta_out : theta)[c] = w;      // theta_out: the other of two parameter buffers (bgm_causal_fit_epoch)
   if (fwd_dst[c] >= 0) fwd_blob[fwd_dst[c]] = w;
   if (fwd_dst2[c] >= 0) fwd_blob[fwd_dst2[c]] = w;
   if (bwd_dst[c] >= 0) bwd_blob[bwd_dst[c]] = w;

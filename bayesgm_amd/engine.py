@@ -238,6 +238,13 @@ class CausalEngine(object):
                                                   int(lazy), _ptr(loss), self._stream()),
                    "bgm_causal_fit_z_step")
 
+    def fit_epoch(self, x, y, v, data_z, zm, zv, perm, batch, lr_theta, lr_z, lazy, loss=None, loss_z=None):
+        """All minibatches perm[0:batch], perm[batch:2 batch], ... of one epoch with the loop inside the library
+        (bgm_causal_fit_epoch; single process)."""
+        _lib.check(self.lib.bgm_causal_fit_epoch(self.h, _ptr(x), _ptr(y), _ptr(v), _ptr(data_z), _ptr(zm), _ptr(zv), _ptr(perm),
+                                                 int(perm.numel()), int(batch), float(lr_theta), float(lr_z), int(lazy), _ptr(loss),
+                                                 _ptr(loss_z), self._stream()), "bgm_causal_fit_epoch")
+
     def describe(self, batch=32):
         """Kernel paths of this handle (sampling; minibatch steps when a fit session is open) as text."""
         buf = C.create_string_buffer(512)

@@ -234,8 +234,12 @@ class CausalBGM(object):
             print('EGM Initialization Ends.')
 
     def fit(self, data, epochs=100, epochs_per_eval=5, batch_size=32, startoff=0, use_egm_init=True,
-            egm_n_iter=30000, egm_batches_per_eval=500, save_format='txt', verbose=1, z_adam="replay"):
+            egm_n_iter=30000, egm_batches_per_eval=500, save_format='txt', verbose=1, z_adam="replay", host_loop=False):
         """Iterative theta / Z updates (base.py:434-532).
+
+        ``host_loop=False`` (single process): the minibatches of an epoch are issued by ONE library call (bgm_causal_fit_epoch), the
+        latent phase of a minibatch overlapping the theta phase of the next on a second stream; ``True`` keeps the per-minibatch
+        calls from Python (same results bit for bit; the only form under torch.distributed, where the all-reduce sits between them).
 
         ``batch_size`` is the GLOBAL minibatch; under torch.distributed every rank owns a contiguous row
         shard, draws its share of each minibatch from its own rows, and the g/f/h gradients are
@@ -308,7 +312,10 @@ class CausalBGM(object):
                 loss.zero_()
                 loss_z.zero_()
                 n_rows = 0
-                for i in range(0, n_use, b_loc):
+                if world == 1 and host_loop is False:          # the minibatch loop inside the library (bgm_causal_fit_epoch)
+                    eng.fit_epoch(x, y, v, self.data_z, zm, zv, sample_idx[:n_use], b_loc, self._p['lr_theta'], lr_z, lazy, loss, loss_z)
+                    n_rows = n_use
+                for i in (range(0, n_use, b_loc) if n_rows == 0 else ()):
                     idx = sample_idx[i:min(i + b_loc, n_use)]
                     bg = int(idx.numel()) * world
                     if replay:

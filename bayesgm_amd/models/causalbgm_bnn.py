@@ -206,9 +206,11 @@ class CausalBGMBayes(CausalBGM):
 
     # ------------------------------------------------------------------ fit
     def fit(self, data, epochs=100, epochs_per_eval=5, batch_size=32, startoff=0, use_egm_init=True,
-            egm_n_iter=30000, egm_batches_per_eval=500, save_format='txt', verbose=1, z_adam="replay"):
+            egm_n_iter=30000, egm_batches_per_eval=500, save_format='txt', verbose=1, z_adam="replay", host_loop=False):
         """Iterative theta / Z updates (base.py:434-532) with the KL terms of the Bayesian nets.  ``batch_size`` is the
-        GLOBAL minibatch (<= 64 per rank); under torch.distributed rows are sharded, the g | h | f gradients all-reduced."""
+        GLOBAL minibatch (<= 64 per rank); under torch.distributed rows are sharded, the g | h | f gradients all-reduced.
+        ``host_loop=False`` (single process): one library call per epoch (bgm_bnn_fit_epoch), the latent phase of a minibatch beside
+        the chains of the next on a second stream; ``True``: the per-minibatch calls from Python (same results)."""
         if use_egm_init:
             self.egm_init(data, egm_n_iter=egm_n_iter, batch_size=batch_size,
                           egm_batches_per_eval=egm_batches_per_eval, verbose=verbose)
@@ -255,7 +257,12 @@ class CausalBGMBayes(CausalBGM):
         try:
             for epoch in range(epochs + 1):
                 sample_idx = torch.from_numpy(np.random.choice(n_loc, n_loc, replace=False).astype(np.int32)).to(dev)
-                for i in range(0, n_use, b_loc):
+                in_library = (world == 1 and not host_loop)      # the minibatch loop inside the library (bgm_bnn_fit_epoch)
+                if in_library:
+                    done = eng.fit_epoch(x, y, v, self.data_z, zm, zv, sample_idx[:n_use], b_loc, self._p['lr_theta'], lr_z, lazy, seed,
+                                         self._stream, out_t, out_z)
+                    self._streams(3 * done)
+                for i in (() if in_library else range(0, n_use, b_loc)):
                     idx = sample_idx[i:min(i + b_loc, n_use)]
                     if idx.numel() < 2:
                         continue                      # batch statistics need two rows (the same decision on every rank)

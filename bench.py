@@ -116,7 +116,7 @@ def fit_leg(model, x, y, v, n_loc, steps=2000, batch=32):
     eng = model.engine
     dev = eng.device
     res = {}
-    for mode, lazy in (("replay", 2), ("dense", 0)):
+    for mode, lazy in (("replay", 2), ("dense", 0), ("replay_host_loop", 2)):
         g = torch.Generator(device=dev).manual_seed(1)
         z = torch.randn(n_loc, eng.q, device=dev, generator=g)
         zm, zv = torch.zeros_like(z), torch.zeros_like(z)
@@ -125,11 +125,12 @@ def fit_leg(model, x, y, v, n_loc, steps=2000, batch=32):
         perm = torch.randperm(n_loc, device=dev, generator=g).to(torch.int32)
 
         def run(k, s0):
-            for s_ in range(s0, s0 + k):
-                i = (s_ * batch) % max(1, n_loc - batch)
-                idx = perm[i:i + batch]
-                if lazy == 2:
-                    eng.fit_z_sync(z, zm, zv, idx, 1e-4)
+            if mode != "replay_host_loop":          # what CausalBGM.fit does in a single process: one library call per epoch
+                eng.fit_epoch(x, y, v, z, zm, zv, perm[s0 * batch:(s0 + k) * batch], batch, 1e-4, 1e-4, lazy)
+                return
+            for s_ in range(s0, s0 + k):            # the per-minibatch calls from Python (the form used under torch.distributed)
+                idx = perm[s_ * batch:(s_ + 1) * batch]
+                eng.fit_z_sync(z, zm, zv, idx, 1e-4)
                 eng.fit_theta_grad(x, y, v, z, idx, batch, grad)
                 eng.fit_theta_apply(grad, 1e-4)
                 eng.fit_z_step(x, y, v, z, zm, zv, idx, batch, 1e-4, lazy=lazy)
@@ -147,8 +148,12 @@ def fit_leg(model, x, y, v, n_loc, steps=2000, batch=32):
     dt = res["replay"]
     return {"value": batch * steps / dt, "unit": "observations x epochs / s", "us_per_minibatch": 1e6 * dt / steps,
             "us_per_minibatch_dense_sweep": 1e6 * res["dense"] / steps,
-            "sample": f"{steps} minibatch iterations, B={batch}, N={n_loc}, deterministic nets; latent optimizer = dense-decay Adam "
-                      "in replay form (value, us_per_minibatch) and as a sweep over the table per minibatch (us_per_minibatch_dense_sweep)",
+            "us_per_minibatch_host_loop": 1e6 * res["replay_host_loop"] / steps,
+            "sample": f"{steps} DISJOINT minibatches of a permutation, B={batch}, N={n_loc}, deterministic nets, issued by one "
+                      "bgm_causal_fit_epoch call as CausalBGM.fit does (latent phase of minibatch k beside the theta phase of k + 1, "
+                      "double-buffered parameters); latent optimizer = dense-decay Adam in replay form (value, us_per_minibatch), as a "
+                      "sweep over the table per minibatch (us_per_minibatch_dense_sweep: no overlap possible), and the replay form "
+                      "issued per minibatch from Python (us_per_minibatch_host_loop: the form used under torch.distributed)",
             "flop_per_observation": 348480}
 
 
@@ -176,6 +181,17 @@ def training_leg(params, x, y, v, device, n=20000, batch=32, reps=200):
         torch.cuda.synchronize()
         return 1e6 * (time.perf_counter() - t0) / reps
 
+    perm = torch.randperm(n, device=device, generator=g).to(torch.int32)[:(n // batch) * batch]
+
+    def epoch_us(fn):
+        """microseconds per minibatch of one epoch (n // batch disjoint minibatches) issued by ONE library call, as the classes do"""
+        fn(perm[:20 * batch])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn(perm)
+        torch.cuda.synchronize()
+        return 1e6 * (time.perf_counter() - t0) / (n // batch)
+
     rs = np.random.RandomState(5)
     dims = [q] + list(params["dz_units"]) + [1]
     dz = {"W": [(rs.uniform(-1, 1, (dims[i], dims[i + 1])) * np.sqrt(6.0 / (dims[i] + dims[i + 1]))).astype(np.float32) for i in range(len(dims) - 1)],
@@ -201,10 +217,12 @@ def training_leg(params, x, y, v, device, n=20000, batch=32, reps=200):
             eng.fit_theta_apply(grad, 1e-4)
             eng.fit_z_step(xs, ys, vs, z, zm, zv, idx, batch, 1e-4, lazy=2)
         f_us = timed(step)
+        eng.fit_z_sync(z, zm, zv, None, 1e-4)
+        fe_us = epoch_us(lambda pm: eng.fit_epoch(xs, ys, vs, z, zm, zv, pm, batch, 1e-4, 1e-4, 2))
     finally:
         eng.fit_end()
     out["deterministic"] = {"egm_disc_step_us": d_us, "egm_gen_step_us": g_us, "egm_iteration_ms": 1e-3 * (params["g_d_freq"] * d_us + g_us),
-                            "fit_minibatch_us": f_us}
+                            "fit_minibatch_us": f_us, "fit_minibatch_us_epoch_call": fe_us}
     # Bayesian nets (the reference's default)
     mb = CausalBGM(dict(params, use_bnn=True), timestamp="bench_train_bnn", random_seed=0, device=device.index)
     be = mb.engine
@@ -221,8 +239,13 @@ def training_leg(params, x, y, v, device, n=20000, batch=32, reps=200):
         be.z_sync(zz, zm, zv, idx, 1e-4)
         be.z_step(xs, ys, vs, zz, zm, zv, idx, 1e-4, 1, 1, lazy=2)
     l_us = timed(latent)
+    be.z_sync(zz, zm, zv, None, 1e-4)
+    be_us = epoch_us(lambda pm: be.fit_epoch(xs, ys, vs, zz, zm, zv, pm, batch, 1e-4, 1e-4, 2, 1, 0))
     out["bayesian"] = {"egm_disc_step_us": d_us, "egm_gen_step_us": g_us, "egm_iteration_ms": 1e-3 * (params["g_d_freq"] * d_us + g_us),
-                       "theta_step_us": t_us, "latent_step_us": l_us}
+                       "theta_step_us": t_us, "latent_step_us": l_us, "fit_minibatch_us_epoch_call": be_us}
+    out["fit_minibatch_us_epoch_call_note"] = ("theta + latent step of one minibatch when the epoch's minibatches are issued by one "
+                                               "bgm_causal_fit_epoch / bgm_bnn_fit_epoch call (what CausalBGM.fit does in a single "
+                                               "process): the latent phase of minibatch k overlaps the theta phase of minibatch k + 1")
     return out
 
 

@@ -286,6 +286,17 @@ BGM_API int bgm_causal_fit_z_step(bgm_handle *h, const float *x_dev, const float
 BGM_API int bgm_causal_fit_z_sync(bgm_handle *h, float *data_z_dev, float *zm_dev, float *zv_dev, const int32_t *idx_dev, int32_t batch,
                           float lr_z, void *stream);
 
+/* A whole list of minibatches with the loop inside the library (single process; under data parallelism the host loop above stays,
+ * because the all-reduce sits between its calls).  replaces: the loop body causalbgm/base.py:490-505 for the minibatches
+ * perm_dev[0 .. n_use) taken `batch` rows at a time (the last one may be short): bgm_causal_fit_z_sync (lazy = 2), _theta_grad,
+ * _theta_apply, _z_step with batch_global = the minibatch's own size, in that order.  loss_dev / loss_z_dev: the accumulators of
+ * _theta_grad / _z_step.  With lazy = 1 / 2 on the row-tile chains the latent phase of minibatch k runs on a second stream beside the
+ * theta phase of minibatch k + 1 (disjoint rows of the latent table: the minibatches of one call must not share rows -- a permutation);
+ * results are those of the sequential order. */
+BGM_API int bgm_causal_fit_epoch(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev, float *data_z_dev, float *zm_dev,
+                         float *zv_dev, const int32_t *perm_dev, int64_t n_use, int32_t batch, float lr_theta, float lr_z, int32_t lazy,
+                         double *loss_dev, double *loss_z_dev, void *stream);
+
 /* Copy the device parameters of one network back to the host (Keras order) and make them the
  * handle's host copy.  Synchronous. */
 BGM_API int bgm_causal_get_weights(bgm_handle *h, int net_id, float *theta_host, int64_t count, void *stream);
@@ -524,6 +535,15 @@ BGM_API int bgm_bnn_z_step(bgm_handle *h, const float *x_dev, const float *y_dev
  * minibatch's bgm_bnn_theta_step calls; idx_dev = NULL flushes the whole [n_rows x q] table). */
 BGM_API int bgm_bnn_z_sync(bgm_handle *h, float *data_z_dev, float *zm_dev, float *zv_dev, const int32_t *idx_dev, int64_t n_rows,
                    int32_t batch, float lr_z, void *stream);
+/* A whole list of minibatches with the loop inside the library (single process): for the minibatches perm_dev[0 .. n_use) taken
+ * `batch` rows at a time (a one-row tail is skipped) bgm_bnn_z_sync (lazy = 2), bgm_bnn_theta_step(apply = 1, noise stream
+ * stream_id0 + 3 k) and bgm_bnn_z_step (streams stream_id0 + 3 k + 1, + 2) in that order; *n_done = minibatches run (the caller advances
+ * its stream counter by 3 * n_done).  replaces: the loop body causalbgm/base.py:490-505 with use_bnn.  With lazy = 1 / 2 on the
+ * row-tile chains the latent phase of minibatch k runs on a second stream beside the forward / backward chains of minibatch k + 1
+ * (the minibatches of one call must not share rows); results are those of the sequential order. */
+BGM_API int bgm_bnn_fit_epoch(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev, float *data_z_dev, float *zm_dev,
+                      float *zv_dev, const int32_t *perm_dev, int64_t n_rows, int64_t n_use, int32_t batch, float lr_theta, float lr_z,
+                      int32_t lazy, uint64_t seed, uint32_t stream_id0, float *out_t_dev, float *out_z_dev, int32_t *n_done, void *stream);
 BGM_API int bgm_bnn_end(bgm_handle *h, void *stream);
 
 /* ---- EGM warm start with Bayesian nets (train_disc_step :305-330, train_gen_step :332-377 with use_bnn): a sub-session of

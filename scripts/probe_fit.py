@@ -23,6 +23,11 @@ def run(k):
         eng.fit_theta_grad(x, y, v, z, idx, B, grad); eng.fit_theta_apply(grad, 1e-4)
         eng.fit_z_step(x, y, v, z, zm, zv, idx, B, 1e-4, lazy=lazy)
 run(5); torch.cuda.synchronize(); t0 = time.time(); run(steps); torch.cuda.synchronize(); dt = time.time() - t0
+if lazy != 0 or True:      # the same minibatches from ONE library call (bgm_causal_fit_epoch)
+    k = min(steps * B, (N // B) * B)
+    eng.fit_epoch(x, y, v, z, zm, zv, perm[:5 * B], B, 1e-4, 1e-4, lazy); torch.cuda.synchronize()
+    t0 = time.time(); eng.fit_epoch(x, y, v, z, zm, zv, perm[:k], B, 1e-4, 1e-4, lazy); torch.cuda.synchronize(); de = time.time() - t0
+    print(f"  library epoch loop: {de / (k // B) * 1e6:.1f} us/step over {k // B} minibatches")
 flop = 348480.0 * B * steps
 print(f"N={N} B={B} lazy={lazy}: {dt/steps*1e6:.1f} us/step, {B*steps/dt:.3e} obs/s, {flop/dt/1e12:.2f} TFLOP/s algorithmic")
 eng.fit_end()

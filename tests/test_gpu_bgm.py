@@ -149,11 +149,10 @@ def test_bgm_class_predict_matches_oracle_and_reference_shapes(tmp_path):
     obs = ~np.isnan(x)
     assert np.array_equal(imp[obs], x[obs]) and not np.isnan(imp).any()
     ref_imp, ref_int = OB.predict(m, x, alpha=0.1, n_mcmc=60, burn_in=30, step_size=0.05, n_leapfrog=4, seed=5)
-    # chains agree row-by-row for >= 95 % of the rows; compare those rows tightly, the rest loosely
     d = np.abs(imp[:, [3, 17]] - ref_imp[:, [3, 17]]).max(axis=1)
-    print('MEASURED bgm predict rows within 5e-3:', int((d < 5e-3).sum()), 'of', n, 'max of those', float(d[d < 5e-3].max()))
-    assert (d < 5e-3).mean() >= 0.9, d
-    assert np.abs(interval - ref_int).max(axis=(1, 2))[d < 5e-3].max() < 2e-2
+    # measured: 48 of 48 rows within 1.8e-7; one chain may flip an accept decision that lies within fp32 rounding of its uniform
+    assert (d < 1e-4).sum() >= n - 1, d
+    assert np.abs(interval - ref_int).max(axis=(1, 2))[d < 1e-4].max() < 2e-3
     assert np.all(interval[..., 0] <= interval[..., 1])
     # return_samples
     smp, _ = model.predict(x, alpha=0.1, return_samples=True, n_mcmc=12, burn_in=10, step_size=0.05,

@@ -100,8 +100,7 @@ def test_mh_iterations_match_oracle(binary, p, z_dims):
         fragile |= np.abs(u - np.exp(np.minimum(lpp - lpc, 0))) < 1e-3     # accept decisions within fp32 noise
     got = state.cpu().numpy()
     ok = ~fragile
-    print('MEASURED bnf fragile rows', int(fragile.sum()), 'of', n)
-    assert ok.sum() > 0.9 * n
+    assert ok.sum() >= 0.98 * n          # rows whose accept decision lies within fp32 noise of u: measured 1 - 4 of 600 (expected 2 x 2e-3 x n)
     assert np.abs(got[ok] - zo[ok]).max() < 1e-5
     assert abs(int(acc[0]) - n_acc) <= int(fragile.sum())
     assert int(accb.sum()) == int(acc[0])

@@ -222,8 +222,7 @@ def test_mh_iterations_match_oracle():
         fragile |= np.abs(u - np.exp(np.minimum(lpp - lpc, 0))) < 1e-3     # accept decisions within fp32 noise
     got = state.cpu().numpy()
     ok = ~fragile
-    print('MEASURED bnn fragile rows', int(fragile.sum()), 'of', n)
-    assert ok.sum() > 0.9 * n
+    assert ok.sum() >= 0.98 * n          # rows whose accept decision lies within fp32 noise of u: measured 4 of 600 (expected 2 x 2e-3 x n)
     assert np.abs(got[ok] - zo[ok]).max() < 1e-5
     assert abs(int(acc[0]) - n_acc) <= int(fragile.sum())
     eng.close()
@@ -513,3 +512,27 @@ def test_full_size_panel_blocks_are_independent_sampler_runs():
         differ = ((sub - state[lo:hi]).abs().amax(dim=1) > 1e-5).float().mean().item()
         assert differ < 2e-3, differ
     eng.close()
+
+
+@pytest.mark.parametrize("z_adam", ["replay", "lazy"])
+def test_epoch_loop_inside_the_library_equals_the_host_loop(tmp_path, z_adam):
+    """CausalBGM(use_bnn=True).fit(host_loop=False) -- one bgm_bnn_fit_epoch call per epoch, the latent phase of a minibatch on a second
+    stream beside the chains of the next -- gives the parameters and the latent table of the per-minibatch calls from Python bit for
+    bit (n = 200 = 6 x 32 + 8: the short last minibatch runs on the phase machine)."""
+    from bayesgm_amd.models import CausalBGM
+    rs = np.random.RandomState(0)
+    n, p = 200, 100
+    v = rs.randn(n, p).astype(np.float32)
+    x = rs.exponential(size=(n, 1)).astype(np.float32)
+    y = (x + 0.3 * v[:, :1] + rs.randn(n, 1)).astype(np.float32)
+    params = dict(dataset="t", output_dir=str(tmp_path), save_res=False, save_model=False, binary_treatment=False, use_bnn=True,
+                  z_dims=[1, 1, 1, 7], v_dim=p, lr_theta=1e-3, lr_z=1e-3, lr=2e-4, g_d_freq=5, use_z_rec=True, kl_weight=1e-4,
+                  g_units=[64] * 5, e_units=[64] * 5, f_units=[64, 32, 8], h_units=[64, 32, 8], dz_units=[64, 32, 8])
+    res = []
+    for host_loop in (True, False):
+        m = CausalBGM(dict(params), timestamp="t%d" % host_loop, random_seed=3)
+        m.fit((x, y, v), epochs=2, epochs_per_eval=1, batch_size=32, use_egm_init=False, verbose=0, z_adam=z_adam, host_loop=host_loop)
+        res.append((m.data_z.cpu().numpy().copy(), m.engine.read(0).copy(), m._stream))
+    (za, ta, sa), (zb, tb, sb) = res
+    assert sa == sb
+    assert np.array_equal(za, zb) and np.array_equal(ta, tb)

@@ -264,8 +264,8 @@ def test_full_size_panel_properties():
     idx = np.sort(rs.choice(n, 40, replace=False))
     got = a["state"].cpu().numpy()[idx]
     ref = np.stack([OC.mh_sampler(m, (x[i:i + 1], y[i:i + 1], v[i:i + 1]), burn, keep, 1.0, 5, row0=int(i))[-1, 0] for i in idx])
-    print('MEASURED causal sampled-row agreement', int(np.all(np.abs(got - ref) <= 1e-4, axis=1).sum()), 'of', len(idx))
-    assert np.all(np.abs(got - ref) <= 1e-4, axis=1).mean() >= 0.95
+    # measured: 40 of 40 chains identical to 1e-4; one chain may flip an accept decision that lies within fp32 rounding of its uniform
+    assert np.all(np.abs(got - ref) <= 1e-4, axis=1).sum() >= len(idx) - 1
     # (iv) ADRF of a 64-row block vs the oracle's effects on the same draws
     small = run(lo, lo + 64, want_draws=True)
     m64 = OC.cast_model(m, np.float64)
@@ -303,8 +303,8 @@ def test_binary_treatment_full_size_panel_properties():
     idx = np.sort(np.random.RandomState(75).choice(n, 40, replace=False))
     got = a["state"].cpu().numpy()[idx]
     ref = np.stack([OC.mh_sampler(m, (x[i:i + 1], y[i:i + 1], v[i:i + 1]), burn, keep, 0.5, seed, row0=int(i))[-1, 0] for i in idx])
-    print('MEASURED causal sampled-row agreement', int(np.all(np.abs(got - ref) <= 1e-4, axis=1).sum()), 'of', len(idx))
-    assert np.all(np.abs(got - ref) <= 1e-4, axis=1).mean() >= 0.95
+    # measured: 40 of 40 chains identical to 1e-4; one chain may flip an accept decision that lies within fp32 rounding of its uniform
+    assert np.all(np.abs(got - ref) <= 1e-4, axis=1).sum() >= len(idx) - 1
     draws = part["draws"].cpu().numpy()[:, :96]
     ref_ite = OC.infer_from_latent_posterior(OC.cast_model(m, np.float64), draws.astype(np.float64), None, True, seed, row0=lo,
                                              burn_in=burn)                                                  # [keep, 96]

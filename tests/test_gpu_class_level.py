@@ -215,3 +215,26 @@ def test_checkpoint_manager_prunes_on_cpu_arrays(tmp_path):
     names = sorted(f for f in os.listdir(m.directory) if f.endswith(".npz"))
     assert names == ["ckpt-%d.npz" % e for e in range(3, 8)]
     assert os.path.basename(m.latest_checkpoint) == "ckpt-7.npz" and np.load(m.latest_checkpoint)["a"][0] == 7
+
+
+@gpu
+@pytest.mark.parametrize("z_adam", ["replay", "lazy", "dense"])
+def test_epoch_loop_inside_the_library_equals_the_host_loop(z_adam):
+    """CausalBGM.fit(host_loop=False) -- one bgm_causal_fit_epoch call per epoch, the latent phase of a minibatch on a second stream
+    beside the theta phase of the next -- gives the networks, the latent table and the per-epoch losses of the per-minibatch calls
+    from Python bit for bit (2000 = 62 x 32 + 16: the short last minibatch included)."""
+    from bayesgm_amd.models import CausalBGM
+    g = np.load(GOLD)
+    x, y, v = g["x"], g["y"], g["v"]
+    res = []
+    for host_loop in (True, False):
+        model = CausalBGM(dict(_params(), lr_theta=1e-3, lr_z=1e-3), random_seed=5)
+        model.fit((x, y, v), epochs=2, epochs_per_eval=1, batch_size=32, use_egm_init=False, verbose=0, z_adam=z_adam, host_loop=host_loop)
+        res.append((model.data_z.cpu().numpy().copy(), {k: _flat(model.nets[k]) for k in "gfh"}, [dict(h) for h in model.fit_history]))
+    (za, wa, ha), (zb, wb, hb) = res
+    assert np.array_equal(za, zb)
+    for k in "gfh":
+        assert np.array_equal(wa[k], wb[k]), k
+    for a, b in zip(ha, hb):
+        for key in ("loss_v", "loss_x", "loss_y", "loss_postrior_z", "mse_v", "mse_y"):
+            assert abs(a[key] - b[key]) <= 1e-6 * max(1.0, abs(a[key])), (key, a[key], b[key])     # (fp64 atomics: summation order)

@@ -263,8 +263,7 @@ def test_fit_steps_then_sampling_with_the_trained_parameters():
     assert np.abs(zd.cpu().numpy() - st.data_z).max() <= 3e-4
     lp = eng.logpost(xd, yd, vd, zd).cpu().numpy()
     ref = OC.log_posterior(dict(st.m), x64, y64, v64, st.data_z)
-    print('MEASURED general logp after 4 steps', float(np.abs(lp - ref).max()), float(np.abs(ref).max()))
-    assert np.abs(lp - ref).max() <= 5e-2
+    assert np.abs(lp - ref).max() <= 1e-3          # measured 4.1e-5 on |log p| <= 143 (fp32 kernels vs the float64 oracle after four Adam steps)
     eng.fit_end()
     lp2 = eng.logpost(xd, yd, vd, zd).cpu().numpy()
     assert np.abs(lp - lp2).max() <= 1e-4 * np.abs(lp).max()

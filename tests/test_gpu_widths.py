@@ -256,8 +256,7 @@ def test_fit_steps_then_sampling_with_the_trained_parameters(shape):
     assert np.abs(zd.cpu().numpy() - st.data_z).max() <= 3e-4
     lp = eng.logpost(xd, yd, vd, zd).cpu().numpy()
     ref = OC.log_posterior(dict(st.m), x64, y64, v64, st.data_z)
-    print('MEASURED widths logp after 4 steps', float(np.abs(lp - ref).max()), float(np.abs(ref).max()))
-    assert np.abs(lp - ref).max() <= 2e-2 + 1e-4 * np.abs(ref).max()
+    assert np.abs(lp - ref).max() <= 5e-4          # measured 7.5e-6 on |log p| <= 75
     eng.fit_end()
     lp2 = eng.logpost(xd, yd, vd, zd).cpu().numpy()
     assert np.abs(lp - lp2).max() <= 1e-5 * np.abs(lp).max()
@@ -293,7 +292,7 @@ def test_default_widths_fit_beyond_the_chain_envelope():
     assert np.abs(zd.cpu().numpy() - st.data_z).max() <= 3e-4
     lp = eng.logpost(xd, yd, vd, zd).cpu().numpy()          # (streamed-fragment sampling path, repacked from the device parameters)
     ref = OC.log_posterior(dict(st.m), x64, y64, v64, st.data_z)
-    assert np.abs(lp - ref).max() <= 2e-2 + 1e-4 * np.abs(ref).max()
+    assert np.abs(lp - ref).max() <= 1e-3
     eng.fit_end()
 
 
