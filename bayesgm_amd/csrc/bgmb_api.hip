@@ -8,8 +8,10 @@
 #include "bgm_host.h"
 #include "bgmb_kernels.h"
 #include "bgmb_state.h"
+#include "gx_flipout.h"
 
 static BgmbState *vst(bgm_handle *h) { return static_cast<BgmbState *>(h->bvn_state); }
+static void gxf_free(BgmbState *s);
 
 void bgm_bvn_free_state(bgm_handle *h) {
   if (!h->bvn_state) return;
@@ -17,6 +19,7 @@ void bgm_bvn_free_state(bgm_handle *h) {
   if (s->dev) hipFree(s->dev);
   if (s->big_dev) hipFree(s->big_dev);
   if (s->dw_dev) hipFree(s->dw_dev);
+  gxf_free(s);
   bgm_bvn_egm_free(s->egm);
   delete s;
   h->bvn_state = nullptr;
@@ -268,6 +271,73 @@ extern "C" int bgm_bvn_logpost(bgm_handle *h, const float *z_dev, const float *x
   return BGM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// frozen-noise HMC on 32-row LDS tiles (gx_flipout.h): plan + packs
+// ---------------------------------------------------------------------------------------------------------------------------
+struct GxfState {
+  GxfModel f{};
+  GxfPackArgs pk{};
+  float *pack = nullptr, *packT = nullptr, *dw = nullptr, *dwT = nullptr;
+  int lds_bytes = 0;
+};
+static void gxf_free(BgmbState *s) {
+  GxfState *g = static_cast<GxfState *>(s->gxf);
+  if (!g) return;
+  for (void *p : {(void *)g->pack, (void *)g->packT, (void *)g->dw, (void *)g->dwT}) if (p) hipFree(p);
+  delete g;
+  s->gxf = nullptr;
+}
+// 1: this generator is outside the LDS tiles (too wide / too deep): the workspace kernel serves it
+static int gxf_session(BgmbState *s, GxfState *&g) {
+  g = static_cast<GxfState *>(s->gxf);
+  if (g) return BGM_OK;
+  const BnnNet &n = s->net;
+  const int NF = n.n_layers, T = NF - 2, q = s->q, p = s->p;          // Flipout layers: T trunk layers, mean head, variance head
+  if (T < 1 || T + 1 > GX_MAXL) return 1;
+  GxfState *st = new GxfState();
+  GxBgmModel &m = st->f.m;
+  const int Pp = gx_pad32(p);
+  m.q = q; m.p = p; m.Pp = Pp;
+  GxNet &G = m.g;
+  G.L = T + 1;
+  G.dim[0] = q; G.pad[0] = gx_pad32(q);
+  for (int l = 0; l < T; ++l) { G.dim[l + 1] = n.lout[l]; G.pad[l + 1] = gx_pad32(n.lout[l]); }
+  G.dim[T + 1] = 2 * Pp; G.pad[T + 1] = 2 * Pp;
+  size_t off = 0, offT = 0;
+  int wmax = 32, mb = 0, w = 0;
+  for (int l = 0; l <= T; ++l) {
+    const int Kp = G.pad[l], Np = G.pad[l + 1];
+    G.w[l] = (int)off; off += (size_t)Kp * Np;
+    G.b[l] = (int)off; off += Np;
+    G.wt[l] = (int)offT; offT += (size_t)Np * Kp;
+    wmax = std::max(wmax, Kp);
+    if (l < T) { m.moff[l] = mb; mb += GX_ROWS * (Np >> 1); }
+  }
+  for (int l = 0; l < NF; ++l) {        // oracle/bnn.py sign_layout over the (in, out) pairs trunk ..., mean, var
+    st->f.sin_w[l] = w; w += (n.lin[l] + 31) / 32;
+    st->f.sout_w[l] = w; w += (n.lout[l] + 31) / 32;
+    st->pk.lin[l] = n.lin[l]; st->pk.lout[l] = n.lout[l]; st->pk.woff[l] = n.woff[l]; st->pk.eoff[l] = n.eoff[l];
+  }
+  st->f.swords = (w + 3) / 4 * 4;
+  m.mask_bytes = mb;
+  m.ld = gx_ld(wmax);
+  m.ch = std::min(Pp, (m.ld - 8) / 32 * 32);
+  st->lds_bytes = gx_bgm_lds_bytes(m.ld, q, mb) + GX_ROWS * st->f.swords * 4;
+  if (st->lds_bytes > 160 * 1024 || off >= (1u << 30)) { delete st; return 1; }
+  for (float **p_ : {&st->pack, &st->dw}) {
+    if (hipMalloc((void **)p_, sizeof(float) * off) != hipSuccess || hipMemset(*p_, 0, sizeof(float) * off) != hipSuccess) { s->gxf = st; gxf_free(s); bgm_set_error("frozen-noise HMC: device allocation failed"); return BGM_E_HIP; }
+  }
+  for (float **p_ : {&st->packT, &st->dwT}) {
+    if (hipMalloc((void **)p_, sizeof(float) * offT) != hipSuccess || hipMemset(*p_, 0, sizeof(float) * offT) != hipSuccess) { s->gxf = st; gxf_free(s); bgm_set_error("frozen-noise HMC: device allocation failed"); return BGM_E_HIP; }
+  }
+  m.pack = st->pack; m.packT = st->packT; st->f.dw = st->dw; st->f.dwT = st->dwT;
+  st->pk.g = G; st->pk.n_flip = NF; st->pk.Pp = Pp;
+  st->pk.pack = st->pack; st->pk.packT = st->packT; st->pk.dw = st->dw; st->pk.dwT = st->dwT;
+  s->gxf = st;
+  g = st;
+  return BGM_OK;
+}
+
 extern "C" int bgm_bvn_hmc_run(bgm_handle *h, const bgm_hmc_args *g, void *stream_) {
   int rc = bvn_need(h, "bgm_bvn_hmc_run");
   if (rc) return rc;
@@ -277,6 +347,34 @@ extern "C" int bgm_bvn_hmc_run(bgm_handle *h, const bgm_hmc_args *g, void *strea
   if (g->n_iters == 0 && !g->init) return BGM_OK;
   BgmbState *s = vst(h);
   BGM_HIP_CHECK(hipSetDevice(h->device));
+  static const bool no_gxf = std::getenv("BGM_BVN_NO_TILES") != nullptr;      // dev A/B: the workspace kernel also for frozen noise
+  if (s->cfg.hmc_frozen_noise && !no_gxf) {
+    // frozen noise (the shipped default): one perturbation and one sign string per row for the whole run -> 32-chain LDS tiles with
+    // the posterior means and the perturbation as two padded packs in L2 (gx_flipout.h)
+    GxfState *gx;
+    rc = gxf_session(s, gx);
+    if (rc < 0) return rc;
+    if (rc == 0) {
+      hipStream_t st = (hipStream_t)stream_;
+      rc = bvn_noise(h, s, g->seed, 0u, 0u, 1, false, 0u, st);              // the run's one perturbation (generator call 0), as the workspace kernel draws it
+      if (rc) return rc;
+      GxfPackArgs pk = gx->pk;
+      pk.theta = s->theta_dev; pk.dwc = s->dw_dev;
+      hipLaunchKernelGGL(gxf_pack_kernel, dim3(64, pk.n_flip), dim3(256), 0, st, pk);       // packs of the CURRENT parameters (they may have been trained since)
+      GxfHmcArgs k{};
+      k.f = gx->f; k.f.m.bnp = s->theta_dev + s->net.off;
+      k.x = g->x_dev; k.n = g->n; k.row_base = g->row_base; k.state = g->state_dev; k.logp = g->logp_dev; k.grad = g->grad_dev;
+      k.init = g->init; k.it_begin = g->it_begin; k.n_iters = g->n_iters; k.burn_in = g->burn_in; k.n_leapfrog = g->n_leapfrog; k.step = g->step_dev;
+      k.k0 = (uint32_t)(g->seed & 0xFFFFFFFFull); k.k1 = (uint32_t)(g->seed >> 32); k.acc_prob_sum = g->acc_prob_sum_dev; k.acc_count = g->acc_count_dev; k.draws = g->draws_dev;
+      BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gxf_bgm_hmc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, gx->lds_bytes));
+      const long long tiles32 = (g->n + GX_ROWS - 1) / GX_ROWS;
+      const int occ = std::max(1, std::min(4, (160 * 1024) / gx->lds_bytes));
+      hipLaunchKernelGGL(gxf_bgm_hmc_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(tiles32, (long long)h->n_cus * occ))), dim3(GX_THREADS),
+                         gx->lds_bytes, st, k);
+      BGM_HIP_CHECK(hipGetLastError());
+      return BGM_OK;
+    }
+  }
   const int rt = bvn_rt(h, g->n);
   const long long n_tiles = (g->n + rt - 1) / rt;
   const long long tiles = std::min<long long>(n_tiles, 8LL * h->n_cus);       // workgroups (one workspace slice each)

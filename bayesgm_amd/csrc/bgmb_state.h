@@ -22,6 +22,7 @@ struct BgmbState {
   float *dw_dev = nullptr;     // perturbations of the generator calls of one large-batch launch (bgmb_noise_kernel)
   size_t dw_cap = 0;
   void *egm = nullptr;         // BgmbEgmState (bgmb_egm_api.hip)
+  void *gxf = nullptr;         // GxfState (bgmb_api.hip): packs of the LDS-tiled frozen-noise HMC kernel (gx_flipout.h)
 };
 
 int bgmb_fill(const bgm_bvn_config *cfg, BnnNet &n);

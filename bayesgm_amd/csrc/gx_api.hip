@@ -91,7 +91,7 @@ int gx_session(bgm_handle *h, GxState *&st, hipStream_t stream, bool need_ghf = 
     if (std::max(s->lds_bytes, std::max(s->lds_fit, s->lds_enc)) > 160 * 1024) {
       delete s; bgm_set_error("general-width engine: a hidden layer is too wide for the 32-row LDS tiles (hidden widths up to ~550)"); return BGM_E_UNSUPPORTED;
     }
-    s->occ = std::max(1, std::min(2, (160 * 1024) / std::max(s->lds_bytes, 1)));
+    s->occ = std::max(1, std::min(4, (160 * 1024) / std::max(s->lds_bytes, 1)));      // up to 16 waves per CU hide each other's L2 latencies
     if (hipMalloc((void **)&s->pack, sizeof(float) * std::max<size_t>(off, 1)) != hipSuccess ||
         hipMalloc((void **)&s->packT, sizeof(float) * std::max<size_t>(offT, 1)) != hipSuccess) {
       if (s->pack) hipFree(s->pack);
@@ -245,7 +245,7 @@ int gx_encode(bgm_handle *h, const float *v, int64_t n, float *z, hipStream_t st
   rc = set_lds(gx_encode_kernel, s->lds_enc);
   if (rc) return rc;
   const int64_t tiles = (n + GX_ROWS - 1) / GX_ROWS;
-  const int occ = std::max(1, std::min(2, (160 * 1024) / s->lds_enc));
+  const int occ = std::max(1, std::min(4, (160 * 1024) / s->lds_enc));
   hipLaunchKernelGGL(gx_encode_kernel, dim3((int)std::max<int64_t>(1, std::min<int64_t>(tiles, (int64_t)h->n_cus * occ))), dim3(GX_THREADS), s->lds_enc, stream, k);
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;

@@ -69,6 +69,7 @@ int session(bgm_handle *h, BgmState *s, GxbState *&g, hipStream_t stream) {
     }
     m.mask_bytes = mb;
     m.ld = gx_ld(wmax);
+    if (const char *e = std::getenv("BGM_GX_LD")) m.ld = std::max(m.ld, gx_ld(std::atoi(e)));      // dev: wider head chunks
     m.ch = std::min(Pp, (m.ld - 8) / 32 * 32);
     n->lds_bytes = gx_bgm_lds_bytes(m.ld, q, mb);
     n->lds_fit = 4 * (2 * GX_ROWS * m.ld + 64);
@@ -98,7 +99,11 @@ int session(bgm_handle *h, BgmState *s, GxbState *&g, hipStream_t stream) {
   return BGM_OK;
 }
 
-int grid_for(const bgm_handle *h, long long tiles) { return (int)std::max<long long>(1, std::min<long long>(tiles, h->n_cus)); }
+// persistent workgroups: as many per CU as the LDS holds (up to four: 16 waves per CU hide each other's L2 latencies)
+int grid_for(const bgm_handle *h, long long tiles, int lds_bytes) {
+  const int occ = std::max(1, std::min(4, (160 * 1024) / std::max(lds_bytes, 1)));
+  return (int)std::max<long long>(1, std::min<long long>(tiles, (long long)h->n_cus * occ));
+}
 
 }  // namespace
 
@@ -124,7 +129,7 @@ int gxb_logpost(bgm_handle *h, BgmState *s, const float *z, const float *x, int6
   if (rc) return rc;
   rc = set_lds(gx_bgm_logpost_kernel, g->lds_bytes);
   if (rc) return rc;
-  hipLaunchKernelGGL(gx_bgm_logpost_kernel, dim3(grid_for(h, (n + GX_ROWS - 1) / GX_ROWS)), dim3(GX_THREADS), g->lds_bytes, stream, g->m, z, x,
+  hipLaunchKernelGGL(gx_bgm_logpost_kernel, dim3(grid_for(h, (n + GX_ROWS - 1) / GX_ROWS, g->lds_bytes)), dim3(GX_THREADS), g->lds_bytes, stream, g->m, z, x,
                      (long long)n, out, grad);
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
@@ -141,7 +146,7 @@ int gxb_hmc_run(bgm_handle *h, BgmState *s, const bgm_hmc_args *a, hipStream_t s
   k.acc_prob_sum = a->acc_prob_sum_dev; k.acc_count = a->acc_count_dev; k.draws = a->draws_dev;
   rc = set_lds(gx_bgm_hmc_kernel, g->lds_bytes);
   if (rc) return rc;
-  hipLaunchKernelGGL(gx_bgm_hmc_kernel, dim3(grid_for(h, (a->n + GX_ROWS - 1) / GX_ROWS)), dim3(GX_THREADS), g->lds_bytes, stream, k);
+  hipLaunchKernelGGL(gx_bgm_hmc_kernel, dim3(grid_for(h, (a->n + GX_ROWS - 1) / GX_ROWS, g->lds_bytes)), dim3(GX_THREADS), g->lds_bytes, stream, k);
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
 }
@@ -159,7 +164,7 @@ int gxb_predict_draws(bgm_handle *h, BgmState *s, const float *draws, int64_t n,
   rc = set_lds(gx_bgm_predict_kernel, g->lds_bytes);
   if (rc) return rc;
   const long long work = ((n + GX_ROWS - 1) / GX_ROWS) * (long long)n_draws;
-  hipLaunchKernelGGL(gx_bgm_predict_kernel, dim3(grid_for(h, work)), dim3(GX_THREADS), g->lds_bytes, stream, k);
+  hipLaunchKernelGGL(gx_bgm_predict_kernel, dim3(grid_for(h, work, g->lds_bytes)), dim3(GX_THREADS), g->lds_bytes, stream, k);
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
 }

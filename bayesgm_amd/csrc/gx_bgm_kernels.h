@@ -178,7 +178,7 @@ __device__ __forceinline__ void gx_bgm_logp_grad(const GxBgmModel &m, const GxBg
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(GX_THREADS) void gx_bgm_logpost_kernel(GxBgmModel m, const float *z, const float *x, long long n, float *out,
+static __global__ __launch_bounds__(GX_THREADS) void gx_bgm_logpost_kernel(GxBgmModel m, const float *z, const float *x, long long n, float *out,
                                                                     float *grad) {
   extern __shared__ float lds[];
   const GxBgmLds L = gx_bgm_carve(lds, m.ld, m.q);
@@ -218,7 +218,7 @@ struct GxHmcArgs {
 };
 
 // One HamiltonianMonteCarlo.one_step per iteration for the tile's 32 chains (bgm/base.py:798-821; oracle/bgm.py hmc_transition).
-__global__ __launch_bounds__(GX_THREADS) void gx_bgm_hmc_kernel(GxHmcArgs a) {
+static __global__ __launch_bounds__(GX_THREADS) void gx_bgm_hmc_kernel(GxHmcArgs a) {
   extern __shared__ float lds[];
   const GxBgmModel &m = a.m;
   const GxBgmLds L = gx_bgm_carve(lds, m.ld, m.q);
@@ -323,7 +323,7 @@ struct GxPredArgs {
   int add_noise;
   unsigned k0, k1;
 };
-__global__ __launch_bounds__(GX_THREADS) void gx_bgm_predict_kernel(GxPredArgs a) {
+static __global__ __launch_bounds__(GX_THREADS) void gx_bgm_predict_kernel(GxPredArgs a) {
   extern __shared__ float lds[];
   const GxBgmModel &m = a.m;
   const GxBgmLds L = gx_bgm_carve(lds, m.ld, m.q);
@@ -386,7 +386,7 @@ struct GxBgmFitArgs {
   const float *bn;                         // [4 KQ]: mu_B | inv_std | gamma | beta (bgm_bn_stats_kernel)
   double *loss;                            // [2] += sum loss_x, sum |x - mu|^2
 };
-__global__ __launch_bounds__(GX_THREADS) void gx_bgm_fit_kernel(GxBgmFitArgs a) {
+static __global__ __launch_bounds__(GX_THREADS) void gx_bgm_fit_kernel(GxBgmFitArgs a) {
   extern __shared__ float lds[];
   const GxBgmModel &m = a.m;
   const int q = m.q, ld = m.ld, Ln = m.g.L, T = Ln - 1, KQ = m.g.pad[0], P2 = m.g.pad[Ln], Pp = m.Pp, p = m.p;

@@ -71,6 +71,7 @@ __device__ __forceinline__ void gx_dense_ld(const float *__restrict__ W, int ldw
       const f32x2 c1 = *reinterpret_cast<const f32x2 *>(wk + ldw);
       const f32x2 c2 = *reinterpret_cast<const f32x2 *>(wk + 2 * (size_t)ldw);
       const f32x2 c3 = *reinterpret_cast<const f32x2 *>(wk + 3 * (size_t)ldw);
+      __builtin_amdgcn_sched_barrier(0);      // keep the requests above the MFMAs of the previous block (hipcc sinks loads to their first use)
       acc0 = BGM_MFMA(a[0], b0[0], acc0); acc1 = BGM_MFMA(a[0], b0[1], acc1);
       acc0 = BGM_MFMA(a[1], b1[0], acc0); acc1 = BGM_MFMA(a[1], b1[1], acc1);
       acc0 = BGM_MFMA(a[2], b2[0], acc0); acc1 = BGM_MFMA(a[2], b2[1], acc1);
