@@ -358,11 +358,12 @@ class CausalEngine(object):
     # -- whole-sampler conveniences -------------------------------------------
     def mh_sample(self, x, y, v, burn_in, n_keep, q_sd, seed, chunk=None, want_draws=False,
                   effect=_lib.EFFECT_NONE, x_values=None, sample_y=True, row_base=0, adaptive=False,
-                  initial_q_sd=1.0, target=0.25, tol=0.05, adj_int=50, window=100):
+                  initial_q_sd=1.0, target=0.25, tol=0.05, adj_int=50, window=100, acc_reduce=None, n_total=None):
         """metropolis_hastings_sampler (+ fused infer_from_latent_posterior) over all rows.
 
         Returns dict(state, logp, acc_count [burn_in+n_keep], draws | None, adrf [n_doses,n_keep] | None,
-        ite [n, n_keep] | None, q_sd)."""
+        ite [n, n_keep] | None, q_sd).  acc_reduce / n_total: with the rows of one sampler run sharded over ranks, the all-reduce (sum)
+        of the window's acceptance count and the total number of rows, so that every rank adapts the proposal scale identically."""
         dev = self.device
         x, y, v = (_f32(t, dev) for t in (x, y, v))
         x = x.reshape(-1)
@@ -400,7 +401,10 @@ class CausalEngine(object):
             last = it - 1  # counter value of the iteration just finished
             if adaptive and last < burn_in and last % adj_int == 0 and last > 0:
                 w0 = max(0, last + 1 - window)
-                rate = float(acc[w0:last + 1].sum().item()) / ((last + 1 - w0) * n)
+                cnt = acc[w0:last + 1].sum().double().reshape(1)
+                if acc_reduce is not None:          # rows sharded over ranks: ONE acceptance window over all rows, the same decision everywhere
+                    cnt = acc_reduce(cnt)
+                rate = float(cnt.item()) / ((last + 1 - w0) * (n if n_total is None else n_total))
                 if rate < target - tol:
                     q_sd *= 0.9
                 elif rate > target + tol:

@@ -11,7 +11,7 @@ torch holds the arrays and nothing else.
 Stated differences.  (i) The reference's `fit` unpacks seven values from `evaluate`, which returns four (:334 vs base.py:555,570),
 so it fails at the first evaluation; the build evaluates as CausalBGM does.  (ii) `use_bnn=True` (a Bayesian prior network on the
 Bayesian-network kernels) is not built: NotImplementedError.  (iii) `fit` runs in a single process; `predict` shards the rows over
-the ranks of torch.distributed (fixed proposal scale)."""
+the ranks of torch.distributed (with the adaptive proposal scale the window's acceptance count is all-reduced)."""
 import ctypes as C
 
 import numpy as np
@@ -251,18 +251,17 @@ class IdentifiableCausalBGM(CausalBGM):
         if verbose:
             print('MCMC Latent Variable Sampling ...')
         adaptive = (q_sd is None) or (q_sd <= 0)
-        if adaptive and parallel.is_dist():
-            raise NotImplementedError("bayesgm_amd: IdentifiableCausalBGM.predict with the adaptive proposal scale (one acceptance window "
-                                      "over ALL rows, identifiable.py:585-606) runs in a single process; pass q_sd > 0 to shard the rows")
         # fresh U for all rows (:563-564), drawn once: rank 0's draw is everybody's
         seg_all = parallel.broadcast_(torch.from_numpy(self._segments_for(n).astype(np.int32)).to(eng.device))
-        lo_r, hi_r = parallel.shard_range(n)                       # a fixed proposal scale: chains are keyed by the global row
+        lo_r, hi_r = parallel.shard_range(n)                       # chains are keyed by the global row; an adaptive proposal scale uses ONE
+                                                                   # acceptance window over all rows (:585-606): its count is all-reduced
         tab = self._prior_table()
         eng.set_prior(seg_all[lo_r:hi_r].contiguous(), tab)
         try:
             out = eng.mh_sample(self._dev(data_x[lo_r:hi_r]).reshape(-1), self._dev(data_y[lo_r:hi_r]).reshape(-1), self._dev(data_v[lo_r:hi_r]),
                                 burn_in, n_mcmc, q_sd, self._next_seed(), effect=_lib.EFFECT_ITE if binary else _lib.EFFECT_ADRF,
-                                x_values=x_values, sample_y=sample_y, adaptive=adaptive, row_base=lo_r)
+                                x_values=x_values, sample_y=sample_y, adaptive=adaptive, row_base=lo_r,
+                                acc_reduce=parallel.all_reduce_sum_ if (adaptive and parallel.is_dist()) else None, n_total=n)
         finally:
             eng.set_prior(None, None)
         total = burn_in + n_mcmc

@@ -30,5 +30,10 @@ xb = (x > np.median(x)).astype(np.float32)
 np.random.seed(6 + 100 * dist.get_rank())
 ite, iv = mb.predict((xb, y, v), alpha=0.05, n_mcmc=40, burn_in=40, q_sd=0.5, verbose=0)
 out.update(ite_head=[float(a) for a in ite[:5]], ite_tail=[float(a) for a in ite[-5:]], ite_sum=float(ite.sum()), iv_sum=float(iv.sum()))
+# adaptive proposal scale (q_sd <= 0): ONE acceptance window over all rows -- its count is all-reduced, every rank adapts identically
+ma = IdentifiableCausalBGM(params(False), random_seed=2, device=dev)
+np.random.seed(5 + 100 * dist.get_rank())
+adrf_a, _ = ma.predict((x, y, v), alpha=0.05, n_mcmc=20, burn_in=160, x_values=np.linspace(0, 3, 6), q_sd=-1.0, verbose=0)
+out.update(adrf_adaptive=[float(a) for a in adrf_a], acc_adaptive=ma.last_acceptance_rate)
 print(json.dumps(out))
 dist.destroy_process_group()

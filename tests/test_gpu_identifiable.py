@@ -234,3 +234,11 @@ def test_two_rank_predict_equals_the_single_process_predict():
     ite, iv = mb.predict(((x > np.median(x)).astype(np.float32), y, v), alpha=0.05, n_mcmc=40, burn_in=40, q_sd=0.5, verbose=0)
     assert np.abs(np.array(two["ite_head"]) - ite[:5]).max() <= 1e-6 and np.abs(np.array(two["ite_tail"]) - ite[-5:]).max() <= 1e-6
     assert abs(two["ite_sum"] - float(ite.sum())) <= 1e-3 and abs(two["iv_sum"] - float(iv.sum())) <= 1e-3
+    # adaptive proposal scale under data parallelism (identifiable.py:585-606: one acceptance window over ALL rows): the window's
+    # count is all-reduced, so the two-rank run walks the single-process schedule of scales and returns its curve
+    assert objs[0]["adrf_adaptive"] == objs[1]["adrf_adaptive"]
+    ma = IdentifiableCausalBGM(params(False), random_seed=2)
+    np.random.seed(5)
+    adrf_a, _ = ma.predict((x, y, v), alpha=0.05, n_mcmc=20, burn_in=160, x_values=np.linspace(0, 3, 6), q_sd=-1.0, verbose=0)
+    assert np.abs(np.array(two["adrf_adaptive"]) - adrf_a).max() <= 1e-5
+    assert abs(two["acc_adaptive"] - ma.last_acceptance_rate) < 1e-12
