@@ -538,7 +538,7 @@ def main():
         # same panel shape, if there are any (per-launch read traffic is independent of the iteration count, see the file)
         traffic = {}
         traffic_src = None
-        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r04_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     pm = json.load(f)

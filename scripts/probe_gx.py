@@ -15,6 +15,9 @@ if forced:
     cases += [("g/f/h [8, 8] / [8, 4] (R test)", dict(g_units=(8, 8), e_units=(8, 8), f_units=(8, 4), h_units=(8, 4)), N),
               ("[128, 128]", dict(g_units=(128, 128), e_units=(128, 128), f_units=(128, 128), h_units=(128, 128)), N // 2),
               ("[256, 256, 256]", dict(g_units=(256,) * 3, e_units=(256,) * 3, f_units=(256,) * 3, h_units=(256,) * 3), N // 4)]
+only = os.environ.get("GX_ONLY")
+if only == "w256":
+    cases = [c for c in cases if c[0].startswith("[256")]
 z_dims, p = [1, 1, 1, 7], 200
 for name, u, n in cases:
     m = OC.init_model(0, z_dims, p, **u)
