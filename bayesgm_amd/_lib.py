@@ -226,6 +226,9 @@ SYMBOLS = {
     "bgm_bnn_egm_gen_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
                                        C.c_int32, C.c_void_p, C.c_void_p]),
     "bgm_bnn_egm_read": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "bgm_bnn_egm_set_share": (C.c_int, [C.c_void_p, C.c_int32]),
+    "bgm_bnn_egm_grad": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
+    "bgm_bnn_egm_apply": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "bgm_bnn_egm_end": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bgm_bnn_end": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bgm_causal_egm_begin": (C.c_int, [C.c_void_p, C.POINTER(EgmConfig), C.c_void_p, C.c_int64, C.c_void_p]),
@@ -234,6 +237,8 @@ SYMBOLS = {
     "bgm_causal_egm_gen_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                           C.c_void_p, C.c_void_p]),
     "bgm_causal_egm_read": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "bgm_causal_egm_grad": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
+    "bgm_causal_egm_apply": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "bgm_causal_egm_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bgm_causal_egm_end": (C.c_int, [C.c_void_p, C.c_void_p]),
 }

@@ -247,6 +247,20 @@ class BnnEngine(object):
         _lib.check(self.lib.bgm_bnn_egm_gen_step(self.h, _ptr(z), _ptr(idx), _ptr(v), _ptr(x), _ptr(y), int(seed),
                                                  int(stream_id) & 0xFFFFFFFF, int(apply), _ptr(out), self._stream()), "bgm_bnn_egm_gen_step")
 
+    def egm_sizes(self):
+        return int(self.n_params), int(self.n_dz)
+
+    def egm_set_share(self, row0):
+        """This rank's minibatch rows are rows row0 ... of the global minibatch (keys their Flipout sign vectors)."""
+        _lib.check(self.lib.bgm_bnn_egm_set_share(self.h, int(row0)), "bgm_bnn_egm_set_share")
+
+    def egm_grad(self, which, scale, out):
+        """Data-parallel warm start: the gradient of the last step run with apply=False, times `scale`, into the device tensor `out`."""
+        _lib.check(self.lib.bgm_bnn_egm_grad(self.h, int(which), float(scale), _ptr(out), out.numel(), self._stream()), "bgm_bnn_egm_grad")
+
+    def egm_apply(self, which, grad):
+        _lib.check(self.lib.bgm_bnn_egm_apply(self.h, int(which), _ptr(grad), grad.numel(), self._stream()), "bgm_bnn_egm_apply")
+
     def egm_read(self, what):
         out = np.empty(self.n_dz, np.float32)
         _lib.check(self.lib.bgm_bnn_egm_read(self.h, what, out.ctypes.data_as(C.c_void_p), out.size, self._stream()), "bgm_bnn_egm_read")

@@ -139,6 +139,7 @@ extern "C" int bgm_bnn_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, const
   BGM_HIP_CHECK(hipMalloc((void **)&e->dev, total * sizeof(float)));
   BGM_HIP_CHECK(hipMemset(e->dev, 0, total * sizeof(float)));
   a.theta = s->theta_dev; a.grad = s->grad_dev;
+  BGM_HIP_CHECK(hipMemset(s->grad_dev, 0, sizeof(float) * (size_t)s->n_params));   // entries no step writes stay zero (bgm_bnn_egm_apply runs Adam over all of them)
   a.m = e->dev; a.v = e->dev + np;
   a.theta_d = e->dev + 2 * np; a.m_d = a.theta_d + nd; a.v_d = a.m_d + nd; a.grad_d = a.v_d + nd;
   a.ws = a.grad_d + nd;
@@ -250,6 +251,47 @@ extern "C" int bgm_bnn_egm_gen_step(bgm_handle *h, const float *z_dev, const int
   auto k = bnn_egm_gen_step_kernel;
   const int lds = 64 * (int)sizeof(float);
   hipLaunchKernelGGL(k, dim3(1), dim3(EGM_THREADS), lds, (hipStream_t)stream_, a);
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+extern "C" int bgm_bnn_egm_set_share(bgm_handle *h, int32_t row0) {
+  BnnState *s; BnnEgmState *e;
+  int rc = bnn_egm_need(h, "bgm_bnn_egm_set_share", s, e);
+  if (rc) return rc;
+  if (row0 < 0) { bgm_set_error("bgm_bnn_egm_set_share: row0 < 0"); return BGM_E_INVALID; }
+  e->base.row0 = (uint32_t)row0;
+  return BGM_OK;
+}
+
+extern "C" int bgm_bnn_egm_grad(bgm_handle *h, int32_t which, float scale, float *grad_dev, int64_t count, void *stream_) {
+  BnnState *s; BnnEgmState *e;
+  int rc = bnn_egm_need(h, "bgm_bnn_egm_grad", s, e);
+  if (rc) return rc;
+  const size_t n = which == 0 ? (size_t)s->n_params : e->n_dz;
+  if ((which != 0 && which != 1) || !grad_dev || (size_t)count != n) {
+    bgm_set_error("bgm_bnn_egm_grad: which must be 0 (g|e|f|h: " + std::to_string(s->n_params) + " floats) or 1 (discriminator: " + std::to_string(e->n_dz) + ")");
+    return BGM_E_INVALID;
+  }
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(egm_dp_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
+                     which == 0 ? e->base.grad : e->base.grad_d, grad_dev, (int)n, scale);
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+extern "C" int bgm_bnn_egm_apply(bgm_handle *h, int32_t which, const float *grad_dev, int64_t count, void *stream_) {
+  BnnState *s; BnnEgmState *e;
+  int rc = bnn_egm_need(h, "bgm_bnn_egm_apply", s, e);
+  if (rc) return rc;
+  const size_t n = which == 0 ? (size_t)s->n_params : e->n_dz;
+  if ((which != 0 && which != 1) || !grad_dev || (size_t)count != n) { bgm_set_error("bgm_bnn_egm_apply: bad which / count"); return BGM_E_INVALID; }
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  const BnnEgmArgs &a = e->base;
+  const EgmAdam ad = bnn_egm_adam(e->cfg.lr, which == 0 ? ++e->t_g : ++e->t_d);
+  if (which == 0) { s->packed_valid = false; s->bnf_valid = false; }
+  hipLaunchKernelGGL(egm_dp_adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, which == 0 ? a.theta : a.theta_d,
+                     which == 0 ? a.m : a.m_d, which == 0 ? a.v : a.v_d, grad_dev, (int)n, ad, (float *)nullptr, (const int *)nullptr);
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
 }

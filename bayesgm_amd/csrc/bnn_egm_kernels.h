@@ -25,6 +25,7 @@ struct BnnEgmArgs {
   const float *v_, *x_, *y_;             // panel
   float eps;                             // gradient-penalty interpolation coefficient
   uint32_t k0, k1, stream;               // noise key; call c of the step uses stream + c (oracle/bnn.py EGM_CALLS)
+  uint32_t row0;                         // sign words of minibatch row b are keyed by row0 + b (a rank's share of a global minibatch; 0 otherwise)
   EgmAdam adam;
   float *ws, *out;
   int apply, disc_lds;
@@ -42,7 +43,7 @@ static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_disc_step_kernel(B
   __syncthreads();
   BnnCache ke;
   bnn_cache(a.net[BNN_E], B, wp, ke, vb);
-  float *z_ = bnn_fwd(cb, a.theta, a.net[BNN_E], ke, B, a.k0, a.k1, a.stream);     // noisy encoder call (fixed in this step)
+  float *z_ = bnn_fwd(cb, a.theta, a.net[BNN_E], ke, B, a.k0, a.k1, a.stream, a.row0);     // noisy encoder call (fixed in this step)
   for (int k = c.tid; k < B * q; k += EGM_THREADS) zhat[k] = a.z[k] * a.eps + z_[k] * (1.0f - a.eps);
   __syncthreads();
   float *arena = a.disc_lds ? (egm_lds + 64) : wp;
@@ -78,7 +79,7 @@ static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_disc_step_kernel(B
 // NTL > 0: the Flipout encoder runs as a row-tile chain too (egm_chain_bnn.h: inference-mode input normalisation, 64-wide hidden
 // layers, ceil(p / 16) = NTL); NTL = 0: it stays on the phase-machine routines.
 static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_disc_noise_kernel(BnnEgmArgs a, EcbCall C) {     // grid: ECB_NOISE_PARTS
-  ecb_noise(a.theta, a.net[BNN_E], C, a.ws, a.B, a.k0, a.k1, a.stream, threadIdx.x, blockIdx.x, ECB_NOISE_PARTS);
+  ecb_noise(a.theta, a.net[BNN_E], C, a.ws, a.B, a.k0, a.k1, a.stream, threadIdx.x, blockIdx.x, ECB_NOISE_PARTS, a.row0);
 }
 // T0: latent input tiles (q <= 16 T0); with two, the fourth pass's stash of the tail lives in global scratch (workspace offset C.xh)
 template <int NTL, int T1, int T2, int T3, int NB, int T0 = 1>
@@ -111,7 +112,7 @@ static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_disc_chain_kernel(
     __syncthreads();
     BnnCache ke;
     bnn_cache(a.net[BNN_E], B, wp, ke, vb);
-    const float *z_ = bnn_fwd(cb, a.theta, a.net[BNN_E], ke, B, a.k0, a.k1, a.stream);     // noisy encoder call (fixed in this step)
+    const float *z_ = bnn_fwd(cb, a.theta, a.net[BNN_E], ke, B, a.k0, a.k1, a.stream, a.row0);     // noisy encoder call (fixed in this step)
     for (int k = tid; k < ZW * B; k += EGM_THREADS) { const int b = k / ZW, i = k - b * ZW; const float t = z_[b * q + min(i, q - 1)]; M.zt[k] = i < q ? t : 0.0f; }
     ech_fill_params<T1, T2, T3, T0>(M.par, P, a.theta_d, a.dz, tid, EGM_THREADS);
     __syncthreads();
@@ -137,18 +138,18 @@ static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_gen_step_kernel(Bn
   // ---- forward: nine calls, noise streams stream + 0..8 in the order of oracle/bnn.py EGM_CALLS
   BnnCache g1, g1s, e1, e2, g2, cf, cfs, ch, chs;
   bnn_cache(G, B, wp, g1, a.z);
-  const float *gz = bnn_fwd(cb, a.theta, G, g1, B, a.k0, a.k1, a.stream + 0u);      // g(z): v_ = [:, :p]
+  const float *gz = bnn_fwd(cb, a.theta, G, g1, B, a.k0, a.k1, a.stream + 0u, a.row0);      // g(z): v_ = [:, :p]
   bnn_cache(G, B, wp, g1s, a.z);
-  const float *gzs = bnn_fwd(cb, a.theta, G, g1s, B, a.k0, a.k1, a.stream + 1u);    // g(z) again: variance head penalty
+  const float *gzs = bnn_fwd(cb, a.theta, G, g1s, B, a.k0, a.k1, a.stream + 1u, a.row0);    // g(z) again: variance head penalty
   bnn_cache(E, B, wp, e1, vb);
-  float *z_ = bnn_fwd(cb, a.theta, E, e1, B, a.k0, a.k1, a.stream + 2u);            // z_ = e(v)
+  float *z_ = bnn_fwd(cb, a.theta, E, e1, B, a.k0, a.k1, a.stream + 2u, a.row0);            // z_ = e(v)
   float *v_ = take(B * p);
   for (int k = c.tid; k < B * p; k += EGM_THREADS) { const int b = k / p; v_[k] = gz[b * wg + (k - b * p)]; }
   __syncthreads();
   bnn_cache(E, B, wp, e2, v_);
-  const float *z__ = bnn_fwd(cb, a.theta, E, e2, B, a.k0, a.k1, a.stream + 3u);     // z__ = e(v_)
+  const float *z__ = bnn_fwd(cb, a.theta, E, e2, B, a.k0, a.k1, a.stream + 3u, a.row0);     // z__ = e(v_)
   bnn_cache(G, B, wp, g2, z_);
-  const float *gv = bnn_fwd(cb, a.theta, G, g2, B, a.k0, a.k1, a.stream + 4u);      // g(z_): v__ = [:, :p]
+  const float *gv = bnn_fwd(cb, a.theta, G, g2, B, a.k0, a.k1, a.stream + 4u, a.row0);      // g(z_): v__ = [:, :p]
   EgmDiscCache kd;
   egm_disc_cache(a.dz, B, wp, kd, z_);
   egm_disc_fwd(c, a.theta_d, a.dz, kd, B);
@@ -163,13 +164,13 @@ static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_gen_step_kernel(Bn
   }
   __syncthreads();
   bnn_cache(F, B, wp, cf, fin);
-  const float *fo = bnn_fwd(cb, a.theta, F, cf, B, a.k0, a.k1, a.stream + 5u);
+  const float *fo = bnn_fwd(cb, a.theta, F, cf, B, a.k0, a.k1, a.stream + 5u, a.row0);
   bnn_cache(F, B, wp, cfs, fin);
-  const float *fs = bnn_fwd(cb, a.theta, F, cfs, B, a.k0, a.k1, a.stream + 6u);
+  const float *fs = bnn_fwd(cb, a.theta, F, cfs, B, a.k0, a.k1, a.stream + 6u, a.row0);
   bnn_cache(H, B, wp, ch, hin);
-  const float *ho = bnn_fwd(cb, a.theta, H, ch, B, a.k0, a.k1, a.stream + 7u);
+  const float *ho = bnn_fwd(cb, a.theta, H, ch, B, a.k0, a.k1, a.stream + 7u, a.row0);
   bnn_cache(H, B, wp, chs, hin);
-  const float *hs = bnn_fwd(cb, a.theta, H, chs, B, a.k0, a.k1, a.stream + 8u);
+  const float *hs = bnn_fwd(cb, a.theta, H, chs, B, a.k0, a.k1, a.stream + 8u, a.row0);
   // ---- losses
   float l_v = 0.0f, l_z = 0.0f, l_x = 0.0f, l_y = 0.0f, s_g = 0.0f, s_f = 0.0f, s_h = 0.0f, adv = 0.0f;
   for (int k = c.tid; k < B * p; k += EGM_THREADS) { const int b = k / p; const float t = vb[k] - gv[b * wg + (k - b * p)]; l_v = fmaf(t, t, l_v); }
@@ -260,7 +261,7 @@ static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_gen_chain_kernel(B
   extern __shared__ __attribute__((aligned(16))) float egm_lds[];
   ecb_gen_chain<BnnEgmArgs, 4, NTL, 4, 2, 1, NB, PAD, T0>(a, *tab, thetaT, egm_lds);
 }
-static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_gen_noise_kernel(BnnEgmArgs a, const EcbTab *tab) { ecb_gen_noise<BnnEgmArgs>(a, *tab, a.ws); }
+static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_gen_noise_kernel(BnnEgmArgs a, const EcbTab *tab) { ecb_gen_noise<BnnEgmArgs>(a, *tab, a.ws, a.row0); }
 template <int NB>
 static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_gen_dw_kernel(BnnEgmArgs a, const EcbTab *tab, const int *tiles, float *thetaT) {
   ecb_gen_dw<BnnEgmArgs, NB>(a, *tab, tiles, thetaT);

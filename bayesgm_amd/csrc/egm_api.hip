@@ -26,6 +26,7 @@ struct EgmState {
   std::vector<int> gen_tiles;
   float *thetaT_dev = nullptr;
   int *tiles_dev = nullptr;
+  int *mirror_dev = nullptr;   // [n_gen] index of a parameter's copy in thetaT_dev, -1 for biases (data-parallel Adam, bgm_causal_egm_apply)
   long long t_g = 0, t_d = 0;  // Adam iteration counters of g_pre_optimizer / d_pre_optimizer
   float *dev = nullptr;        // one allocation: theta_g|m_g|v_g|grad_g|theta_d|m_d|v_d|grad_d|ws
 };
@@ -38,6 +39,7 @@ void bgm_egm_free_state(bgm_handle *h) {
   if (s->dev) hipFree(s->dev);
   if (s->thetaT_dev) hipFree(s->thetaT_dev);
   if (s->tiles_dev) hipFree(s->tiles_dev);
+  if (s->mirror_dev) hipFree(s->mirror_dev);
   delete s;
   h->egm_state = nullptr;
 }
@@ -205,14 +207,20 @@ extern "C" int bgm_causal_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, co
   if (s->chain_gen_lds > 0) {
     // transposed mirror of the weight matrices (the backward chains read W^T rows contiguously); kept current by the kernel's Adam
     std::vector<float> tT(s->n_gen, 0.0f);
+    std::vector<int> mdst(s->n_gen, -1);
     auto mirror = [&](const EgmMlp &m) {
       for (int l = 0; l < m.n_layers; ++l) {
         const int ni = m.dims[l], no = m.dims[l + 1];
         for (int f = 0; f < ni; ++f)
-          for (int o = 0; o < no; ++o) tT[m.woff[l] + (size_t)o * ni + f] = tg[m.woff[l] + (size_t)f * no + o];
+          for (int o = 0; o < no; ++o) {
+            tT[m.woff[l] + (size_t)o * ni + f] = tg[m.woff[l] + (size_t)f * no + o];
+            mdst[m.woff[l] + (size_t)f * no + o] = m.woff[l] + o * ni + f;
+          }
       }
     };
     mirror(a.g); mirror(a.e); mirror(a.f); mirror(a.h);
+    BGM_HIP_CHECK(hipMalloc(&s->mirror_dev, sizeof(int) * s->n_gen));
+    BGM_HIP_CHECK(hipMemcpy(s->mirror_dev, mdst.data(), sizeof(int) * s->n_gen, hipMemcpyHostToDevice));
     BGM_HIP_CHECK(hipMalloc(&s->thetaT_dev, sizeof(float) * (s->n_gen + 64)));     // K-contiguous tile loads read up to 15 floats past a row
     BGM_HIP_CHECK(hipMemset(s->thetaT_dev, 0, sizeof(float) * (s->n_gen + 64)));
     BGM_HIP_CHECK(hipMemcpy(s->thetaT_dev, tT.data(), sizeof(float) * s->n_gen, hipMemcpyHostToDevice));
@@ -346,6 +354,39 @@ extern "C" int bgm_causal_egm_gen_step(bgm_handle *h, const float *z_dev, const 
 #ifdef EGM_PHASE_CLOCK
   { static int calls = 0; egm_stamp_report("gen", &calls); }
 #endif
+  return BGM_OK;
+}
+
+extern "C" int bgm_causal_egm_grad(bgm_handle *h, int32_t which, float scale, float *grad_dev, int64_t count, void *stream_) {
+  if (!h || !h->egm_state) { bgm_set_error("bgm_causal_egm_grad: call bgm_causal_egm_begin first"); return BGM_E_STATE; }
+  EgmState *s = est(h);
+  const size_t n = which == 0 ? s->n_gen : s->n_dz;
+  if ((which != 0 && which != 1) || !grad_dev || (size_t)count != n) {
+    bgm_set_error("bgm_causal_egm_grad: which must be 0 (g|e|f|h: " + std::to_string(s->n_gen) + " floats) or 1 (discriminator: " + std::to_string(s->n_dz) + ")");
+    return BGM_E_INVALID;
+  }
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(egm_dp_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
+                     which == 0 ? s->base.grad_g : s->base.grad_d, grad_dev, (int)n, scale);
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+extern "C" int bgm_causal_egm_apply(bgm_handle *h, int32_t which, const float *grad_dev, int64_t count, void *stream_) {
+  if (!h || !h->egm_state) { bgm_set_error("bgm_causal_egm_apply: call bgm_causal_egm_begin first"); return BGM_E_STATE; }
+  EgmState *s = est(h);
+  const size_t n = which == 0 ? s->n_gen : s->n_dz;
+  if ((which != 0 && which != 1) || !grad_dev || (size_t)count != n) { bgm_set_error("bgm_causal_egm_apply: bad which / count"); return BGM_E_INVALID; }
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  const EgmArgs &a = s->base;
+  const EgmAdam ad = egm_adam_coeffs(s->cfg.lr, which == 0 ? ++s->t_g : ++s->t_d);
+  if (which == 0)
+    hipLaunchKernelGGL(egm_dp_adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, a.theta_g, a.m_g, a.v_g, grad_dev, (int)n, ad,
+                       s->thetaT_dev, (const int *)s->mirror_dev);
+  else
+    hipLaunchKernelGGL(egm_dp_adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, a.theta_d, a.m_d, a.v_d, grad_dev, (int)n, ad,
+                       (float *)nullptr, (const int *)nullptr);
+  BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
 }
 

@@ -124,7 +124,7 @@ struct EcbTab {
 // `part` of `parts` workgroup-sized slices: the noise of the nine calls is 40 k Philox blocks -- 110 us on the chain kernel's one CU
 // (integer multiplies at quarter rate, two waves per SIMD), a few microseconds as its own launch over 144 workgroups.
 __device__ __forceinline__ void ecb_noise(const float *theta, const BnnNet &n, const EcbCall &C, float *ws, int B, uint32_t k0, uint32_t k1,
-                                          uint32_t stream, int tid, int part, int parts) {
+                                          uint32_t stream, int tid, int part, int parts, uint32_t row0 = 0u) {
   for (int l = 0; l < n.n_layers; ++l) {
     const int cnt = n.lin[l] * n.lout[l];
     const float *rho = theta + n.woff[l] + cnt;
@@ -142,7 +142,7 @@ __device__ __forceinline__ void ecb_noise(const float *theta, const BnnNet &n, c
   uint32_t *sg = reinterpret_cast<uint32_t *>(ws + C.sg);
   for (int i = part * BNN_THREADS + tid; i < B * calls; i += parts * BNN_THREADS) {
     const int r = i / calls, cc = i - r * calls;
-    const uint4 w = philox4x32_10((uint32_t)r, (uint32_t)cc | ((uint32_t)n.net_id << 16), stream, BNN_TAG_SIGN, k0, k1);
+    const uint4 w = philox4x32_10(row0 + (uint32_t)r, (uint32_t)cc | ((uint32_t)n.net_id << 16), stream, BNN_TAG_SIGN, k0, k1);   // row0: first row of this rank's share (data-parallel warm start)
     uint32_t *dst = sg + (long long)r * n.swords + 4 * cc;
     dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
   }
@@ -177,9 +177,9 @@ __device__ __forceinline__ void ecb_kl_partial(const float *theta, const BnnNet 
   if (tid == 0) { float t = 0.0f; for (int w = 0; w < BNN_THREADS / 64; ++w) t += red[w]; *dst = t; }
 }
 template <class Args>
-__device__ __forceinline__ void ecb_gen_noise(const Args &a, const EcbTab &tab, float *ws_) {      // grid: n_calls * ECB_NOISE_PARTS workgroups
+__device__ __forceinline__ void ecb_gen_noise(const Args &a, const EcbTab &tab, float *ws_, uint32_t row0 = 0u) {      // grid: n_calls * ECB_NOISE_PARTS workgroups
   const int c = blockIdx.x / ECB_NOISE_PARTS, part = blockIdx.x % ECB_NOISE_PARTS;
-  ecb_noise(a.theta, a.net[tab.c[c].net], tab.c[c], ws_, a.B, a.k0, a.k1, a.stream + (uint32_t)tab.c[c].soff, threadIdx.x, part, ECB_NOISE_PARTS);
+  ecb_noise(a.theta, a.net[tab.c[c].net], tab.c[c], ws_, a.B, a.k0, a.k1, a.stream + (uint32_t)tab.c[c].soff, threadIdx.x, part, ECB_NOISE_PARTS, row0);
 }
 
 // v = a W1 + flip(as W2): the Flipout product pair in either direction.  KC: W1, W2 are given K-contiguously (ecg_load_tile): the

@@ -564,6 +564,26 @@ __device__ __forceinline__ void egm_adam(const EgmCtx &c, float *theta, float *m
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// data-parallel warm start: a step run with apply = 0 leaves its gradient in the session; the caller all-reduces it across ranks
+// and the Adam step follows from the reduced buffer (bgm_causal_egm_grad / _apply, bgm_bnn_egm_grad / _apply)
+// ---------------------------------------------------------------------------------------------
+static __global__ void egm_dp_scale_kernel(const float *src, float *dst, int n, float scale) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i] * scale;
+}
+// thetaT / mirror: the transposed copy the generator chains read (NULL when the session keeps none)
+static __global__ void egm_dp_adam_kernel(float *theta, float *m, float *v, const float *g, int n, EgmAdam a, float *thetaT, const int *mirror) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i];
+  const float mi = a.b1 * m[i] + (1.0f - a.b1) * gi;
+  const float vi = a.b2 * v[i] + (1.0f - a.b2) * gi * gi;
+  const float tn = theta[i] - a.lr_t * mi / (sqrtf(vi) + a.eps);
+  m[i] = mi; v[i] = vi; theta[i] = tn;
+  if (thetaT) { const int e = mirror[i]; if (e >= 0) thetaT[e] = tn; }
+}
+
 // carve a discriminator cache out of the workspace
 __device__ __forceinline__ void egm_disc_cache(const EgmDisc &d, int B, float *&p, EgmDiscCache &k, float *input) {
   k.in = input;

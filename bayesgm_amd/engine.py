@@ -95,6 +95,9 @@ class CausalEngine(object):
         theta = flatten_net(net) if not isinstance(net, np.ndarray) else np.ascontiguousarray(net, np.float32)
         _lib.check(self.lib.bgm_causal_set_weights(self.h, net_id, theta.ctypes.data_as(C.c_void_p),
                                                    theta.size, self._stream()), "bgm_causal_set_weights")
+        if not hasattr(self, "_w_count"):
+            self._w_count = {}
+        self._w_count[int(net_id)] = int(theta.size)
 
     def set_model(self, g=None, f=None, h=None, e=None):
         for nid, net in ((_lib.NET_G, g), (_lib.NET_F, f), (_lib.NET_H, h), (_lib.NET_E, e)):
@@ -330,6 +333,18 @@ class CausalEngine(object):
     def egm_gen_step(self, z, idx, v, x, y, apply=True, out=None):
         _lib.check(self.lib.bgm_causal_egm_gen_step(self.h, _ptr(z), _ptr(idx), _ptr(v), _ptr(x), _ptr(y),
                                                     int(bool(apply)), _ptr(out), self._stream()), "bgm_causal_egm_gen_step")
+
+    def egm_sizes(self):
+        """(parameters of g | e | f | h, parameters of the discriminator): the buffer sizes of egm_grad / egm_apply."""
+        return sum(self._w_count[k] for k in (_lib.NET_G, _lib.NET_E, _lib.NET_F, _lib.NET_H)), int(self._egm_n_dz)
+
+    def egm_grad(self, which, scale, out):
+        """Data-parallel warm start: the gradient of the last step run with apply=False, times `scale`, into the device tensor `out`."""
+        _lib.check(self.lib.bgm_causal_egm_grad(self.h, int(which), float(scale), _ptr(out), out.numel(), self._stream()), "bgm_causal_egm_grad")
+
+    def egm_apply(self, which, grad):
+        """... and the Adam step of that optimizer from the (all-reduced) gradient."""
+        _lib.check(self.lib.bgm_causal_egm_apply(self.h, int(which), _ptr(grad), grad.numel(), self._stream()), "bgm_causal_egm_apply")
 
     def egm_read(self, what, count):
         """what: 0 generator-side parameters [g|e|f|h], 1 discriminator, 2 / 3 last gen / disc gradients."""

@@ -123,6 +123,15 @@ def egm_block_from(state, n, batch_size, q, n_it, g_d_freq, n_eps=1):
     return idx, z, eps, rs.get_state()
 
 
+def egm_rank_share(idx, z, n_total, n_loc, b_loc, rank):
+    """Data-parallel warm start: every rank draws the GLOBAL minibatches from the shared stream (np.random stays in lockstep on all
+    ranks and moves as in a single-process run) and keeps slots [rank * b_loc, (rank + 1) * b_loc) of each: their prior samples as
+    drawn, their panel rows mapped onto the rank's own n_loc rows (floor(idx * n_loc / n_total): uniform over the shard)."""
+    sl = slice(rank * b_loc, (rank + 1) * b_loc)
+    loc = (idx[:, :, sl].astype(np.int64) * int(n_loc)) // int(n_total)
+    return np.ascontiguousarray(loc.astype(np.int32)), np.ascontiguousarray(z[:, :, sl])
+
+
 def _same_state(a, b):
     return a[2] == b[2] and a[3] == b[3] and a[4] == b[4] and np.array_equal(a[1], b[1])
 

@@ -172,7 +172,19 @@ class CausalBGM(object):
         eng = self.engine
         dev = eng.device
         p_ = self._p
-        xd, yd, vd = self._dev(data_x).reshape(-1), self._dev(data_y).reshape(-1), self._dev(data_v)
+        # Under torch.distributed the warm start is data parallel (north_star's collective, base.py:305-377): every rank holds ITS rows
+        # of the panel, runs each step on its batch_size // world share of the global minibatch, and the discriminator / generator
+        # gradients are all-reduced (RCCL) before the Adam step, so all ranks hold identical networks throughout.
+        world, rank = parallel.world_size(), parallel.rank()
+        lo_r, hi_r = parallel.shard_range(n)
+        n_loc, b_loc = hi_r - lo_r, batch_size // world
+        if world > 1 and b_loc < 2:
+            raise ValueError("egm_init under torch.distributed: batch_size // world_size must be at least 2")
+        # tests: ONE process steps on the minibatches a `_egm_emulate_world`-rank run forms (the ranks' shares side by side)
+        emu = int(getattr(self, "_egm_emulate_world", 0)) if world == 1 else 0
+        if emu > 1:
+            b_loc = (batch_size // emu) * emu
+        xd, yd, vd = self._dev(data_x[lo_r:hi_r]).reshape(-1), self._dev(data_y[lo_r:hi_r]).reshape(-1), self._dev(data_v[lo_r:hi_r])
         q = sum(p_["z_dims"])
         dims = [q] + list(p_["dz_units"]) + [1]
         dz = {"W": [_glorot(self._rs, dims[i], dims[i + 1]) for i in range(len(dims) - 1)],       # networks/base.py:338-363
@@ -180,9 +192,12 @@ class CausalBGM(object):
               "gamma": [np.ones(dims[i + 1], np.float32) for i in range(len(dims) - 2)],
               "beta": [np.zeros(dims[i + 1], np.float32) for i in range(len(dims) - 2)]}
         self._push_weights()
-        eng.egm_begin(batch_size, p_["dz_units"], p_["lr"], p_["use_z_rec"], dz)
+        eng.egm_begin(b_loc, p_["dz_units"], p_["lr"], p_["use_z_rec"], dz)
         out_d = torch.zeros(2, device=dev)
         out_g = torch.zeros(6, device=dev)
+        if world > 1:
+            n_gen, n_dz = eng.egm_sizes()
+            buf_g, buf_d = torch.empty(n_gen, device=dev), torch.empty(n_dz, device=dev)
         egm_log = []
         if verbose:
             print('EGM Initialization Starts ...')
@@ -205,15 +220,36 @@ class CausalBGM(object):
                 n_it = stop - batch_iter + 1
                 idx_h, z_h, eps3 = pipe.take(blocks[kb + 1][1] - blocks[kb + 1][0] + 1 if kb + 1 < len(blocks) else 0)
                 eps_h = eps3[:, :, 0]
+                if world > 1:
+                    idx_h, z_h = host_rng.egm_rank_share(idx_h, z_h, n, n_loc, b_loc, rank)
+                elif emu > 1:
+                    parts = []
+                    for r in range(emu):
+                        lo_e, hi_e = parallel.shard_range(n, r, emu)
+                        parts.append(host_rng.egm_rank_share(idx_h, z_h, n, hi_e - lo_e, b_loc // emu, r)[0] + lo_e)
+                    idx_h, z_h = np.ascontiguousarray(np.concatenate(parts, axis=2)), np.ascontiguousarray(z_h[:, :, :b_loc])
                 idx_d, z_d = torch.from_numpy(idx_h).to(dev), torch.from_numpy(z_h).to(dev)
-                for i in range(n_it):
+                for i in range(n_it if world == 1 else 0):
                     for j in range(g_d_freq):
                         eng.egm_disc_step(z_d[i, j], idx_d[i, j], vd, eps_h[i, j], out=out_d)
                     eng.egm_gen_step(z_d[i, g_d_freq], idx_d[i, g_d_freq], vd, xd, yd, out=out_g)
+                for i in range(n_it if world > 1 else 0):
+                    for j in range(g_d_freq):
+                        eng.egm_disc_step(z_d[i, j], idx_d[i, j], vd, eps_h[i, j], apply=False, out=out_d)
+                        eng.egm_grad(1, 1.0 / world, buf_d)
+                        parallel.all_reduce_sum_(buf_d)                      # dz gradient of the global minibatch
+                        eng.egm_apply(1, buf_d)
+                    eng.egm_gen_step(z_d[i, g_d_freq], idx_d[i, g_d_freq], vd, xd, yd, apply=False, out=out_g)
+                    eng.egm_grad(0, 1.0 / world, buf_g)
+                    parallel.all_reduce_sum_(buf_g)                          # fused g | e | f | h gradient
+                    eng.egm_apply(0, buf_g)
                 batch_iter = stop
                 if batch_iter % egm_batches_per_eval == 0:
                     eng.egm_sync()
                     self._pull_weights(("g", "f", "h", "e"))
+                    if world > 1:                                            # the log line shows means over the global minibatch
+                        parallel.all_reduce_sum_(out_g); parallel.all_reduce_sum_(out_d)
+                        out_g /= world; out_d /= world
                     lg, ld = out_g.cpu().numpy(), out_d.cpu().numpy()
                     egm_log.append((batch_iter, float(lg[2])))          # l2_loss_z of this log line (diagnostics.py)
                     if verbose:

@@ -343,6 +343,16 @@ BGM_API int bgm_causal_egm_disc_step(bgm_handle *h, const float *z_dev, const in
  * g_e_loss] or NULL. */
 BGM_API int bgm_causal_egm_gen_step(bgm_handle *h, const float *z_dev, const int32_t *idx_dev, const float *v_dev,
                             const float *x_dev, const float *y_dev, int32_t apply, float *out_dev, void *stream);
+/* Data-parallel warm start (one process per GPU, every rank holds ITS rows of the panel; the literal collective of north_star,
+ * causalbgm/base.py:305-377 under a distribution strategy).  Per step and rank:
+ *     bgm_causal_egm_{disc,gen}_step(..., apply = 0, ...)   on the rank's share of the minibatch (session batch_size = B_local)
+ *     bgm_causal_egm_grad(which, B_local / B_global, buf)   -> [caller: RCCL all-reduce(SUM) of buf across ranks]
+ *     bgm_causal_egm_apply(which, buf)                      the Adam step the apply = 1 call would have taken, from the reduced gradient
+ * which = 0: generator side [g | e | f | h] (count = their parameters, Keras order), 1: discriminator.  The means over the minibatch
+ * (losses, gradient penalty) become means over the global minibatch; a discriminator with batch statistics (disc_norm = 0) normalises
+ * with its rank's rows, as unsynchronised batch normalisation does under any data-parallel scheme. */
+BGM_API int bgm_causal_egm_grad(bgm_handle *h, int32_t which, float scale, float *grad_dev, int64_t count, void *stream);
+BGM_API int bgm_causal_egm_apply(bgm_handle *h, int32_t which, const float *grad_dev, int64_t count, void *stream);
 /* Copy session state to the host: what = 0 generator-side parameters [g | e | f | h] (Keras order), 1 discriminator
  * parameters, 2 / 3 the gradients of the last gen / disc step.  Synchronises the stream. */
 BGM_API int bgm_causal_egm_read(bgm_handle *h, int32_t what, float *host, int64_t count, void *stream);
@@ -556,6 +566,13 @@ BGM_API int bgm_bnn_egm_disc_step(bgm_handle *h, const float *z_dev, const int32
                           uint64_t seed, uint32_t stream_id, int32_t apply, float *out_dev, void *stream);
 BGM_API int bgm_bnn_egm_gen_step(bgm_handle *h, const float *z_dev, const int32_t *idx_dev, const float *v_dev, const float *x_dev,
                          const float *y_dev, uint64_t seed, uint32_t stream_id, int32_t apply, float *out_dev, void *stream);
+/* Data-parallel form, as bgm_causal_egm_grad / _apply: which = 0 the session's Bayesian nets (count = bgm_bnn_begin's parameter count,
+ * gradient incl. the KL terms, identical on every rank), 1 the discriminator.  All ranks pass the same (seed, stream_id): one weight
+ * perturbation per step for the global minibatch, as Flipout has it. */
+BGM_API int bgm_bnn_egm_set_share(bgm_handle *h, int32_t row0);   /* this rank's rows are rows row0 .. row0 + batch_size - 1 of the global
+                                                                    * minibatch: the Flipout sign vector of its row b is the one of global row row0 + b */
+BGM_API int bgm_bnn_egm_grad(bgm_handle *h, int32_t which, float scale, float *grad_dev, int64_t count, void *stream);
+BGM_API int bgm_bnn_egm_apply(bgm_handle *h, int32_t which, const float *grad_dev, int64_t count, void *stream);
 /* what = 1 discriminator parameters, 3 its gradient of the last disc step (the nets' side: bgm_bnn_read). */
 BGM_API int bgm_bnn_egm_read(bgm_handle *h, int32_t what, float *host, int64_t count, void *stream);
 BGM_API int bgm_bnn_egm_end(bgm_handle *h, void *stream);

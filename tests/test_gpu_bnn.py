@@ -295,6 +295,54 @@ def test_evaluate_matches_oracle(binary, p):
     eng.close()
 
 
+@pytest.mark.parametrize("p,B", [(100, 32), (100, 16), (50, 4)])
+def test_egm_split_step_equals_fused_step(p, B):
+    """Data-parallel form of the warm start with Bayesian nets: step(apply = 0) + bgm_bnn_egm_grad + bgm_bnn_egm_apply takes the Adam
+    steps of the fused step (chains at p = 100; B = 4: a rank's share of a 32-row minibatch at 8 GPUs, the phase-machine kernels)."""
+    from oracle import egm as OE
+    res = []
+    for split in (False, True):
+        m = _model(False, z_dims=ZD, p=p)
+        n = 120
+        _, x, y, v = _panel(m, n)
+        q = sum(m["z_dims"])
+        rs = np.random.RandomState(33)
+        dz = OE.init_disc(rs, q, [64, 32, 8])
+        dz["fixed_norm"] = True
+        for k in ("g", "e", "f", "h"):
+            m[k]["norm"] = "fixed"
+        eng = _engine(m, norm_mode=1)
+        dev = eng.device
+        T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        eng.set_disc_norm("fixed")
+        eng.egm_begin(dz, B, 2e-4, 1)
+        n_gen, n_dz = eng.egm_sizes()
+        bg, bd = torch.empty(n_gen, device=dev), torch.empty(n_dz, device=dev)
+        seed, stream = (1 << 32) | 7, 500
+        for it in range(3):
+            for _ in range(2):
+                z = rs.standard_normal((B, q)).astype(np.float32)
+                idx = rs.choice(n, B, replace=False).astype(np.int32)
+                eng.egm_disc_step(T(z), T(idx), T(v), float(rs.rand()), seed, stream, apply=not split)
+                stream += 1
+                if split:
+                    eng.egm_grad(1, 1.0, bd)
+                    eng.egm_apply(1, bd)
+            z = rs.standard_normal((B, q)).astype(np.float32)
+            idx = rs.choice(n, B, replace=False).astype(np.int32)
+            eng.egm_gen_step(T(z), T(idx), T(v), T(x[:, 0]), T(y[:, 0]), seed, stream, apply=not split)
+            stream += 9
+            if split:
+                eng.egm_grad(0, 1.0, bg)
+                eng.egm_apply(0, bg)
+        res.append((eng.read(0).copy(), eng.egm_read(1).copy()))
+        eng.egm_end()
+        eng.close()
+    (t0, d0), (t1, d1) = res
+    # (one ulp of a parameter of magnitude ~3: the two Adam expressions may be contracted differently)
+    assert np.abs(t0 - t1).max() <= 5e-7 and np.abs(d0 - d1).max() <= 1e-7, (np.abs(t0 - t1).max(), np.abs(d0 - d1).max())
+
+
 @pytest.mark.parametrize("binary,disc_norm,p,zd", [(False, "batch", 50, ZD), (True, "batch", 50, ZD), (False, "fixed", 50, ZD), (True, "fixed", 50, ZD),
                                                    (False, "fixed", 100, ZD), (True, "fixed", 200, ZD), (False, "fixed", 45, ZD),
                                                    (True, "fixed", 177, ACIC), (False, "fixed", 100, (5, 5, 5, 5))])

@@ -146,6 +146,77 @@ def test_egm_alternating_adam_steps_track_oracle(disc_norm, p, z_dims):
     assert np.abs(g_tr[0][0] - st.nets["g"][0][0]).max() <= 2e-5
 
 
+@pytest.mark.parametrize("disc_norm,p,B", [("fixed", 200, 32), ("fixed", 200, 16), ("batch", 23, 8), ("fixed", 50, 4)])
+def test_egm_split_step_equals_fused_step(disc_norm, p, B):
+    """The data-parallel form -- step with apply = 0, bgm_causal_egm_grad, [all-reduce], bgm_causal_egm_apply -- takes the Adam steps the
+    fused step takes (chains at p = 200: the transposed mirror is maintained by the apply kernel; small B: the rank share at 4 / 8 GPUs)."""
+    import torch
+    z_dims = (1, 1, 1, 7)
+    q = sum(z_dims)
+    outs = []
+    for split in (False, True):
+        eng, nets, dz, params, (x, y, v), dev, rs, dz_units = _setup(False, p, z_dims, B, seed=5)
+        if disc_norm == "fixed":
+            eng.set_disc_norm("fixed")
+            dz["fixed_norm"] = True
+        eng.egm_begin(B, dz_units, params["lr"], True, dz)
+        n_gen, n_dz = eng.egm_sizes()
+        bg, bd = torch.empty(n_gen, device="cuda"), torch.empty(n_dz, device="cuda")
+        for it in range(4):
+            for _ in range(2):
+                z = torch.from_numpy(rs.randn(B, q).astype(np.float32)).cuda()
+                idx = torch.from_numpy(rs.choice(len(x), B, replace=False).astype(np.int32)).cuda()
+                eps = float(rs.rand())
+                eng.egm_disc_step(z, idx, dev["v"], eps, apply=not split)
+                if split:
+                    eng.egm_grad(1, 1.0, bd)
+                    eng.egm_apply(1, bd)
+            z = torch.from_numpy(rs.randn(B, q).astype(np.float32)).cuda()
+            idx = torch.from_numpy(rs.choice(len(x), B, replace=False).astype(np.int32)).cuda()
+            eng.egm_gen_step(z, idx, dev["v"], dev["x"], dev["y"], apply=not split)
+            if split:
+                eng.egm_grad(0, 1.0, bg)
+                eng.egm_apply(0, bg)
+        outs.append((eng.egm_read(0, n_gen), eng.egm_read(1, n_dz)))
+        eng.egm_end()
+    (g0, d0), (g1, d1) = outs
+    keep = np.ones(d0.size, bool)
+    if disc_norm == "batch":       # hidden-layer biases in front of a BatchNorm: zero true gradient, rounding noise amplified by Adam (see above)
+        n_w = sum(a.size for a in dz["W"])
+        keep[n_w:n_w + sum(a.size for a in dz["b"][:-1])] = False
+    # same arithmetic per parameter; the compiler may contract the two Adam expressions differently (1 ulp of a step of ~lr)
+    assert np.abs(g0 - g1).max() <= 1e-7 and np.abs(d0 - d1)[keep].max() <= 1e-7, (np.abs(g0 - g1).max(), np.abs(d0 - d1)[keep].max())
+
+
+def test_two_rank_egm_equals_one_process_on_the_same_global_minibatches(tmp_path):
+    """Data-parallel warm start (north_star's collective): two ranks, each with ITS rows only, all-reducing the dz and the
+    fused g | e | f | h gradients, end with identical networks that equal -- to fp32 summation order -- those of ONE process stepping on
+    the global minibatches the two ranks formed.  Deterministic and Bayesian networks."""
+    import json
+    import os
+    import sys
+    from conftest import run_two_ranks
+    out = str(tmp_path / "dp_egm.npz")
+    r = run_two_ranks("dp_egm_smoke.py", timeout=400, extra_args=(out,))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    objs = [json.loads(l) for l in r.stdout.splitlines() if l.startswith('{"rank"')]
+    assert len(objs) == 2
+    for o in objs:
+        for key in ("det", "bnn"):
+            assert o[key]["spread"] == 0.0 and o[key]["finite"] and o[key]["moved"] > 1e-3, o
+    two = np.load(out)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import dp_egm_common as CM
+    for use_bnn, key in ((False, "det"), (True, "bnn")):
+        m = CM.build(use_bnn, 0)
+        m._egm_emulate_world = 2
+        m.egm_init(CM.DATA, egm_n_iter=CM.N_ITER, batch_size=CM.BATCH, egm_batches_per_eval=CM.PER_EVAL, verbose=0)
+        one = CM.flat_weights(m)
+        d = float(np.abs(one - two[key]).max())
+        print("MEASURED two-rank EGM vs one process (%s): max |dtheta| %.3g" % (key, d))
+        assert d <= 2e-5, (key, d)
+
+
 # ---------------------------------------------------------------------------------------------
 # BGM EGM (bgm_egm_kernels.h) vs oracle.egm.bgm_*_step_grads
 # ---------------------------------------------------------------------------------------------

@@ -85,6 +85,55 @@ def test_dp_gradient_allreduce_equals_global_batch_gradient():
     assert all(r < 1e-12 for r in res), res
 
 
+def _egm_share_fn(rank, world):
+    """Host logic of the data-parallel warm start: the ranks' shares of a global draw partition its first world * b_loc slots, every
+    mapped row lies in the rank's shard, and the mean of the ranks' oracle gradients on their shares (each scaled 1 / world, summed by
+    the all-reduce) is the oracle gradient of the global minibatch."""
+    from oracle import egm as OE
+    from oracle import nets as NN
+    from bayesgm_amd import parallel, host_rng
+    n, B, q, p, g_d_freq, n_it = 101, 8, 10, 12, 2, 3
+    np.random.seed(4)
+    idx, z, eps, _ = host_rng.egm_block_from(np.random.get_state(), n, B, q, n_it, g_d_freq)
+    lo, hi = parallel.shard_range(n)
+    b_loc = B // world
+    li, lz = host_rng.egm_rank_share(idx, z, n, hi - lo, b_loc, rank)
+    ok = li.shape == (n_it, g_d_freq + 1, b_loc) and li.min() >= 0 and li.max() < hi - lo
+    ok = ok and np.array_equal(lz, z[:, :, rank * b_loc:(rank + 1) * b_loc])
+    rs = np.random.RandomState(0)
+    z_dims = [1, 1, 1, 7]
+    nets = {"g": NN.init_mlp(rs, [q, 16, p + 1]), "e": NN.init_mlp(rs, [p, 16, q]), "f": NN.init_mlp(rs, [3, 8, 2]), "h": NN.init_mlp(rs, [2, 8, 2])}
+    nets = {k: NN.cast_net(v, np.float64) for k, v in nets.items()}
+    dz = OE.cast_disc(OE.init_disc(rs, q, [8, 4]), np.float64)
+    dz["fixed_norm"] = True                      # per-row normalisation: a mean over rows splits over ranks exactly
+    v = rs.randn(n, p); x = rs.rand(n, 1); y = rs.randn(n, 1)
+    params = dict(v_dim=p, z_dims=z_dims, binary_treatment=False, use_z_rec=True, lr=2e-4)
+    rows = lo + li[0, g_d_freq].astype(np.int64)
+    _, gr = OE.gen_step_grads(nets, dz, params, lz[0, g_d_freq].astype(np.float64), v[rows], x[rows], y[rows])
+    mine = torch.from_numpy(np.concatenate([a.ravel() for a in OE.gen_param_list(gr)]) / world)
+    parallel.all_reduce_sum_(mine)
+    rows_all = torch.zeros(world * b_loc, dtype=torch.int64)
+    rows_all[rank * b_loc:(rank + 1) * b_loc] = torch.from_numpy(rows)
+    parallel.all_reduce_sum_(rows_all)
+    ra = rows_all.numpy()
+    _, gr_all = OE.gen_step_grads(nets, dz, params, z[0, g_d_freq, :world * b_loc].astype(np.float64), v[ra], x[ra], y[ra])
+    ref = np.concatenate([a.ravel() for a in OE.gen_param_list(gr_all)])
+    _, _, gd = OE.disc_step_grads(nets, dz, lz[0, 0].astype(np.float64), v[lo + li[0, 0]], float(eps[0, 0, 0]))
+    mine_d = torch.from_numpy(np.concatenate([a.ravel() for a in OE.disc_param_list(gd)]) / world)
+    parallel.all_reduce_sum_(mine_d)
+    rows_d = torch.zeros(world * b_loc, dtype=torch.int64)
+    rows_d[rank * b_loc:(rank + 1) * b_loc] = torch.from_numpy(lo + li[0, 0].astype(np.int64))
+    parallel.all_reduce_sum_(rows_d)
+    _, _, gd_all = OE.disc_step_grads(nets, dz, z[0, 0, :world * b_loc].astype(np.float64), v[rows_d.numpy()], float(eps[0, 0, 0]))
+    ref_d = np.concatenate([a.ravel() for a in OE.disc_param_list(gd_all)])
+    return (bool(ok), float(np.abs(mine.numpy() - ref).max() / np.abs(ref).max()), float(np.abs(mine_d.numpy() - ref_d).max() / np.abs(ref_d).max()))
+
+
+def test_dp_egm_shares_and_gradient_allreduce_equal_the_global_minibatch():
+    res = _run(_egm_share_fn)
+    assert all(ok and a < 1e-10 and b < 1e-10 for ok, a, b in res), res
+
+
 def _adrf_fn(rank, world):
     from oracle import causal as OC
     from bayesgm_amd import parallel
