@@ -20,6 +20,7 @@ void bgm_bvn_free_state(bgm_handle *h) {
   if (s->big_dev) hipFree(s->big_dev);
   if (s->dw_dev) hipFree(s->dw_dev);
   gxf_free(s);
+  bgmf_free(s);
   bgm_bvn_egm_free(s->egm);
   delete s;
   h->bvn_state = nullptr;
@@ -351,6 +352,8 @@ extern "C" int bgm_bvn_hmc_run(bgm_handle *h, const bgm_hmc_args *g, void *strea
   if (s->cfg.hmc_frozen_noise && !no_gxf) {
     // frozen noise (the shipped default): one perturbation and one sign string per row for the whole run -> 32-chain LDS tiles with
     // the posterior means and the perturbation as two padded packs in L2 (gx_flipout.h)
+    // ... or, for the reference's generator shape (hidden layers of 64 units), register-chained 16-chain row tiles with the posterior
+    // means LDS-resident and the perturbation streamed through an LDS stage (bgmf_kernels.h)
     GxfState *gx;
     rc = gxf_session(s, gx);
     if (rc < 0) return rc;
@@ -358,6 +361,8 @@ extern "C" int bgm_bvn_hmc_run(bgm_handle *h, const bgm_hmc_args *g, void *strea
       hipStream_t st = (hipStream_t)stream_;
       rc = bvn_noise(h, s, g->seed, 0u, 0u, 1, false, 0u, st);              // the run's one perturbation (generator call 0), as the workspace kernel draws it
       if (rc) return rc;
+      rc = bgmf_hmc_try(h, s, g, st);
+      if (rc <= 0) return rc;
       GxfPackArgs pk = gx->pk;
       pk.theta = s->theta_dev; pk.dwc = s->dw_dev;
       hipLaunchKernelGGL(gxf_pack_kernel, dim3(64, pk.n_flip), dim3(256), 0, st, pk);       // packs of the CURRENT parameters (they may have been trained since)

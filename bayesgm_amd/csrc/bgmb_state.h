@@ -23,7 +23,10 @@ struct BgmbState {
   size_t dw_cap = 0;
   void *egm = nullptr;         // BgmbEgmState (bgmb_egm_api.hip)
   void *gxf = nullptr;         // GxfState (bgmb_api.hip): packs of the LDS-tiled frozen-noise HMC kernel (gx_flipout.h)
+  void *bgmf = nullptr;        // BgmfState (bgmf_api.hip): blob of the register-chained frozen-noise HMC kernel (bgmf_kernels.h)
 };
 
 int bgmb_fill(const bgm_bvn_config *cfg, BnnNet &n);
 void bgm_bvn_egm_free(void *egm_state);
+void bgmf_free(BgmbState *s);
+int bgmf_hmc_try(bgm_handle *h, BgmbState *s, const bgm_hmc_args *g, hipStream_t st);     // 0 launched, 1 not its shape, < 0 error

@@ -1,0 +1,93 @@
+// bgmf_api.hip -- host side of the register-chained frozen-noise HMC of BGM with the Bayesian generator (bgmf_kernels.h):
+// blob layout, eligibility, pack + launch.  Called from bgm_bvn_hmc_run (bgmb_api.hip).
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "bgm_host.h"
+#include "bgmb_state.h"
+#include "bgmf_kernels.h"
+
+struct BgmfState {
+  BgmfMeta m{};
+  BgmfPackArgs pk{};
+  float *blob = nullptr;
+  int lds_bytes = 0, ktq = 1;
+};
+
+void bgmf_free(BgmbState *s) {
+  BgmfState *f = static_cast<BgmfState *>(s->bgmf);
+  if (!f) return;
+  if (f->blob) hipFree(f->blob);
+  delete f;
+  s->bgmf = nullptr;
+}
+
+// 1: this generator is outside the compiled chains (hidden widths other than 64, depth, latent width, LDS): the LDS-tile engine serves it
+static int bgmf_session(BgmbState *s, BgmfState *&out) {
+  out = static_cast<BgmfState *>(s->bgmf);
+  if (out) return out->blob ? BGM_OK : 1;
+  const BnnNet &n = s->net;
+  const int NF = n.n_layers, nh = NF - 2, q = s->q, p = s->p;
+  BgmfState *f = new BgmfState();
+  s->bgmf = f;                                             // (kept also when not eligible: the answer does not change for this session)
+  bool ok = (nh == 3 || nh == 5) && q >= 1 && q <= 32 && p >= 1 && !std::getenv("BGM_BVN_NO_CHAINS");
+  for (int l = 0; l < nh && ok; ++l) ok = n.lout[l] == 64;
+  if (!ok) return 1;
+  const int ktq = (q + 15) / 16, ntx = (p + 15) / 16;
+  BgmfMeta &m = f->m;
+  m.q = q; m.p = p; m.nh = nh; m.ntx = ntx;
+  int off = 0;
+  auto take = [&](int cnt) { const int o = off; off += (cnt + 3) / 4 * 4; return o; };
+  m.w1 = take(4 * 16 * ktq * 17); m.d1 = take(4 * 16 * ktq * 17); m.b1 = take(64);
+  m.wh = take((nh - 1) * 4 * 64 * 17); m.bh = take((nh - 1) * 64);
+  m.bhd = take(2 * 16 * ntx);
+  m.sc = take(16 * ktq); m.sh = take(16 * ktq);
+  m.resident = off;
+  m.chunks = off; off += (nh - 1 + ntx) * BGMF_CHUNK;
+  m.total = off;
+  for (int l = 0; l < NF; ++l) { m.sin_w[l] = n.sin_w[l]; m.sout_w[l] = n.sout_w[l]; f->pk.woff[l] = n.woff[l]; f->pk.eoff[l] = n.eoff[l]; }
+  m.swords = (n.swords + 3) / 4 * 4;
+  m.swp = m.swords | 1;
+  m.stage = m.resident;
+  m.sign = m.stage + 2 * BGMF_CHUNK;
+  f->lds_bytes = (int)sizeof(float) * (m.sign + 16 * BGMF_WAVES * m.swp);
+  f->ktq = ktq;
+  if (f->lds_bytes > 160 * 1024) return 1;
+  if (hipMalloc((void **)&f->blob, sizeof(float) * (size_t)m.total) != hipSuccess || hipMemset(f->blob, 0, sizeof(float) * (size_t)m.total) != hipSuccess) {
+    f->blob = nullptr;
+    bgm_set_error("frozen-noise HMC: device allocation failed");
+    return BGM_E_HIP;
+  }
+  f->pk.m = m; f->pk.blob = f->blob; f->pk.ktq = ktq;
+  out = f;
+  return BGM_OK;
+}
+
+// 0: launched; 1: not this kernel's shape; < 0: error
+int bgmf_hmc_try(bgm_handle *h, BgmbState *s, const bgm_hmc_args *g, hipStream_t st) {
+  BgmfState *f;
+  int rc = bgmf_session(s, f);
+  if (rc) return rc;
+  BgmfPackArgs pk = f->pk;
+  pk.theta = s->theta_dev; pk.dwc = s->dw_dev; pk.bnp = s->theta_dev + s->net.off;
+  hipLaunchKernelGGL(bgmf_pack_kernel, dim3(32, f->m.nh + 1), dim3(256), 0, st, pk);        // blob of the CURRENT parameters and of this run's perturbation
+  BGM_HIP_CHECK(hipGetLastError());
+  BgmfHmcKArgs k{};
+  k.blob = f->blob; k.x = g->x_dev; k.n = g->n; k.row_base = g->row_base; k.state = g->state_dev; k.logp = g->logp_dev; k.grad = g->grad_dev;
+  k.init = g->init; k.it_begin = g->it_begin; k.n_iters = g->n_iters; k.burn_in = g->burn_in; k.n_leapfrog = g->n_leapfrog; k.step = g->step_dev;
+  k.k0 = (uint32_t)(g->seed & 0xFFFFFFFFull); k.k1 = (uint32_t)(g->seed >> 32);
+  k.acc_prob_sum = g->acc_prob_sum_dev; k.acc_count = g->acc_count_dev; k.draws = g->draws_dev;
+  k.m = f->m;
+  const long long tiles = (g->n + 15) / 16;
+  const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((tiles + BGMF_WAVES - 1) / BGMF_WAVES, h->n_cus));
+  auto launch = [&](auto kern) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, f->lds_bytes) != hipSuccess) return BGM_E_HIP;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * BGMF_WAVES), f->lds_bytes, st, k);
+    return hipGetLastError() == hipSuccess ? BGM_OK : BGM_E_HIP;
+  };
+  if (f->ktq == 1) rc = f->m.nh == 5 ? launch(bgmf_hmc_kernel<1, 5>) : launch(bgmf_hmc_kernel<1, 3>);
+  else rc = f->m.nh == 5 ? launch(bgmf_hmc_kernel<2, 5>) : launch(bgmf_hmc_kernel<2, 3>);
+  if (rc) bgm_set_error("frozen-noise HMC (bgmf_hmc_kernel): launch failed");
+  return rc;
+}

@@ -1,5 +1,6 @@
 """BGM(use_bnn=True) HMC kernel alone at BASELINE config C4's shape (p = 500, q = 10, L = 10), frozen noise (the shipped default):
-LDS-tiled Flipout kernel (gx_flipout.h) vs the workspace kernel (BGM_BVN_NO_TILES=1).  python scripts/probe_bvn_hmc.py [N] [iters]"""
+register-chained row tiles (bgmf_kernels.h; default) vs the LDS-tile engine (gx_flipout.h; BGM_BVN_NO_CHAINS=1) vs the workspace kernel
+(BGM_BVN_NO_TILES=1).  python scripts/probe_bvn_hmc.py [N] [iters]"""
 import json, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -21,5 +22,5 @@ eng.hmc_run(x, state, logp, grad, step, 1, iters, 2 ** 30, L, 1)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 macs = q * 64 + 4 * 4096 + 2 * 64 * p
 flop = L * 4 * macs * 2 * N * iters          # L gradient evaluations (forward + backward to the input) of TWO products per Flipout layer
-print(json.dumps(dict(kernel="workspace (bgmb_hmc_kernel)" if os.environ.get("BGM_BVN_NO_TILES") else "LDS tiles (gxf_bgm_hmc_kernel)", N=N, iters=iters,
+print(json.dumps(dict(kernel="workspace (bgmb_hmc_kernel)" if os.environ.get("BGM_BVN_NO_TILES") else "LDS tiles (gxf_bgm_hmc_kernel)" if os.environ.get("BGM_BVN_NO_CHAINS") else "row-tile chains (bgmf_hmc_kernel)", N=N, iters=iters,
                       ms_per_transition=1e3 * dt / iters, transitions_per_s=N * iters / dt, tflops=flop / dt / 1e12, frac_of_157_3=flop / dt / 1e12 / 157.3)))

@@ -24,11 +24,15 @@ for rep in range(2):
     torch.cuda.synchronize(); dt = time.time() - t0
 out["C1_causal_binary_N1e5_p100"] = dict(predict_s=dt, transitions_per_s=N * 8000 / dt, acceptance=m.last_acceptance_rate,
                                          ate=float(ite.mean()), shapes=[list(ite.shape), list(interval.shape)])
-cases = [(2000, 20, 5000, 5000), (100000, 100, 1000, 1000)]
+cases = [(2000, 20, 5000, 5000, False), (100000, 100, 1000, 1000, False)]
+if "--only-c4" in sys.argv:
+    cases = []
 if "--c4" in sys.argv:
-    cases.append((625000, 500, 1000, 1000))
-for (N, p, n_mcmc, burn) in cases:
-    bp = dict(dataset="t", output_dir="gpurun_out/sec", save_res=False, save_model=False, use_bnn=False, z_dim=10, x_dim=p,
+    cases.append((625000, 500, 1000, 1000, False))
+if "--c4-bnn" in sys.argv:          # the same share with the Bayesian generator (use_bnn=True, frozen noise: bgmf_hmc_kernel), two products per layer
+    cases.append((625000, 500, 1000, 1000, True))
+for (N, p, n_mcmc, burn, use_bnn) in cases:
+    bp = dict(dataset="t", output_dir="gpurun_out/sec", save_res=False, save_model=False, use_bnn=use_bnn, z_dim=10, x_dim=p,
               lr_theta=5e-3, lr_z=5e-3, g_units=[64] * 5, e_units=[64] * 5, dz_units=[64, 32, 8], dx_units=[64, 32, 8],
               kl_weight=5e-5, lr=1e-3, g_d_freq=1, use_z_rec=True, alpha=0.0, gamma=0.0)
     bm = BGM(bp, random_seed=0)
@@ -40,7 +44,7 @@ for (N, p, n_mcmc, burn) in cases:
         imp, interval = bm.predict(data, n_mcmc=n_mcmc, burn_in=burn)
         torch.cuda.synchronize(); dt = time.time() - t0
     macs = 10 * 64 + 4 * 4096 + 2 * 64 * p
-    out[f"BGM_impute_N{N}_p{p}"] = dict(predict_s=dt, hmc_transitions_per_s=N * (n_mcmc + burn) / dt,
-                                        tflops_executed=N * (n_mcmc + burn) * 40 * macs / dt / 1e12,
+    out[f"BGM_impute_N{N}_p{p}" + ("_use_bnn" if use_bnn else "")] = dict(predict_s=dt, hmc_transitions_per_s=N * (n_mcmc + burn) / dt,
+                                        tflops_executed=N * (n_mcmc + burn) * 40 * macs * (2 if use_bnn else 1) / dt / 1e12,
                                         acceptance=bm.last_acceptance_rate)
 print(json.dumps(out))

@@ -506,3 +506,65 @@ def test_logpost_and_hmc_when_workgroups_walk_several_tiles():
     np.testing.assert_array_equal(whole[:1000], run(0, 1000))
     np.testing.assert_array_equal(whole[n - 3000:], run(n - 3000, n))
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# frozen-noise HMC as register-chained row tiles (csrc/bgmf_kernels.h): the reference's generator shape, hidden layers of 64 units
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("q,units,p,n", [(3, (64,) * 3, 40, 100), (10, (64,) * 5, 50, 150), (20, (64,) * 5, 23, 70)])
+def test_frozen_hmc_row_tile_chains_follow_oracle(q, units, p, n):
+    """Same criterion as test_hmc_follows_oracle_over_a_few_transitions on the shapes bgmf_hmc_kernel serves (3 / 5 hidden layers of 64
+    units; q = 20: two latent tiles; p not a multiple of 16: masked head columns; a row count that is no multiple of the 16-chain tile)."""
+    net = _net(q, units, p, seed=16)
+    rs = np.random.RandomState(17)
+    x = rs.standard_normal((n, p)).astype(np.float32)
+    x[rs.uniform(size=x.shape) < 0.25] = np.nan
+    eng = _engine(net, q, units, p, hmc_frozen_noise=True)
+    seed = 43
+    out = eng.hmc_sample(x, n_mcmc=3, burn_in=5, step_size=0.03, n_leapfrog=4, seed=seed, row_base=9)
+    mask = (~np.isnan(x)).astype(np.float32)
+    xc = np.where(np.isnan(x), 0.0, x).astype(np.float32)
+    ref, info = OV.hmc_sampler(OV.cast_vnet(net, np.float64), xc.astype(np.float64), mask.astype(np.float64), 3, 5, 0.03, 4, seed, row0=9,
+                               return_info=True, frozen=True)
+    got = out["draws"].cpu().numpy()
+    assert got.shape == ref.shape
+    assert abs(float(out["step"].item()) - info["step"]) < 1e-6
+    close = np.abs(got - ref).max(axis=(0, 2)) < 1e-3
+    print("MEASURED frozen chains close to the oracle: %d of %d" % (close.sum(), n))
+    assert close.mean() > 0.95
+    eng.close()
+
+
+@pytest.mark.parametrize("q,units,p,n", [(10, (64,) * 5, 500, 3000), (5, (64,) * 3, 100, 40000)])
+def test_frozen_hmc_row_tile_chains_equal_the_lds_tile_engine(monkeypatch, q, units, p, n):
+    """bgmf_hmc_kernel against gxf_bgm_hmc_kernel (BGM_BVN_NO_CHAINS=1) at BASELINE C4's shape and on a panel with more row tiles than one
+    pass of the grid covers: same target, same random numbers, different summation orders -> the chains agree except where an
+    accept / reject decision sat on the threshold."""
+    net = _net(q, units, p, seed=18)
+    rs = np.random.RandomState(19)
+    x = rs.standard_normal((n, p)).astype(np.float32)
+    x[rs.uniform(size=x.shape) < 0.1] = np.nan
+    res = []
+    for no_chains in (False, True):
+        if no_chains:
+            monkeypatch.setenv("BGM_BVN_NO_CHAINS", "1")
+        else:
+            monkeypatch.delenv("BGM_BVN_NO_CHAINS", raising=False)
+        eng = _engine(net, q, units, p, hmc_frozen_noise=True)
+        dev = eng.device
+        xd = torch.from_numpy(x).to(dev)
+        state, logp, grad = torch.empty((n, q), device=dev), torch.empty(n, device=dev), torch.empty((n, q), device=dev)
+        step = torch.full((1,), 0.02, device=dev)
+        acc = torch.zeros(4, device=dev, dtype=torch.int32)
+        eng.hmc_run(xd, state, logp, grad, step, 0, 2, 2 ** 30, 5, 11, init=True, row_base=5, acc_count=acc)
+        eng.hmc_run(xd, state, logp, grad, step, 2, 2, 2 ** 30, 5, 11, row_base=5, acc_count=acc)          # continued from the stored state
+        res.append((state.cpu().numpy(), logp.cpu().numpy(), grad.cpu().numpy(), acc.cpu().numpy()))
+        eng.close()
+    (s0, l0, g0, a0), (s1, l1, g1, a1) = res
+    close = np.abs(s0 - s1).max(axis=1) < 1e-3
+    print("MEASURED chains equal to the tile engine: %d of %d, acceptance %s vs %s" % (close.sum(), n, a0.tolist(), a1.tolist()))
+    assert close.mean() > 0.99 and np.abs(a0 - a1).max() <= 0.01 * n
+    assert np.abs(l0 - l1)[close].max() < 2e-3 * max(1.0, np.abs(l1).max())
+    # dlogp/dz jumps where a LeakyReLU input changes sign, so two states 1e-4 apart may sit on different sides of a kink: per row
+    g_close = np.abs(g0 - g1).max(axis=1) < 2e-3 * np.abs(g1).max()
+    assert g_close[close].mean() > 0.99, g_close[close].mean()
