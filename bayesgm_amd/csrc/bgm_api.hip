@@ -1,6 +1,7 @@
 // bgm_api.hip -- C-ABI entry points of the BGM posterior path (include/bgm_hip.h, BGM section).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "bgm_host.h"
@@ -174,18 +175,9 @@ extern "C" int bgm_bgm_hmc_run(bgm_handle *h, const bgm_hmc_args *a, void *strea
   const int lds = s->lds_bytes;
   const long long tiles = (a->n + 15) / 16;
   // The wide variant's unit of work is a block pass (W row tiles x all iterations of the launch) and every block makes the same
-  // number of passes, so the last round of passes can be nearly empty (12 500 tiles at W = 12: 4.07 rounds run as 5 = 81 %).  A
-  // round costs what the busiest SIMD's waves cost, so only whole waves per SIMD are worth compiling: 12 (3 per SIMD, the fastest
-  // per tile by ~4 %) and 8 (2 per SIMD); take the one that wastes less of its last round.
-  auto wide_waves = [&](void) {
-    int best = BGM_WAVES_WIDE_HMC; double best_eff = 0.0;
-    for (int w : {12, 8}) {
-      const long long per_round = (long long)w * h->n_cus, rounds = (tiles + per_round - 1) / per_round;
-      const double eff = (double)tiles / (double)(rounds * per_round) * (w == 12 ? 1.0 : 0.96);
-      if (eff > best_eff + 1e-9) { best_eff = eff; best = w; }
-    }
-    return best;
-  };
+  // number of passes.  Tiles are dealt wave-major and tile-less waves skip the matrix work (bgm_hmc_kernel), so a partly filled
+  // last round costs its ceil(active waves / 4) waves per SIMD: 12 waves (3 per SIMD, the fastest per tile by ~4 %) always.
+  auto wide_waves = [&](void) { return std::getenv("BGM_WIDE_W8") ? 8 : BGM_WAVES_WIDE_HMC; };
   const int ww = wide_waves();
 #define LAUNCH_HMC(KTQ_, NTX_, NH_, W)                                                                              \
   {                                                                                                                 \

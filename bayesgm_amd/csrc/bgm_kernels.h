@@ -392,9 +392,20 @@ __global__ __launch_bounds__(64 * WAVES) void bgm_hmc_kernel(BgmHmcKArgs a) {
   const long long n = a.n, n_tiles = (n + 15) / 16, passes = bgm_block_passes(n_tiles, WAVES);
   const float eps = *a.step;
   for (long long ps = 0; ps < passes; ++ps) {
-    long long tile = (ps * gridDim.x + blockIdx.x) * WAVES + wave;
+    // Wide variant: tiles are dealt wave-major (wave w of every block before wave w + 1 of any), so the tiles of a partly filled last
+    // round spread over ALL blocks as whole waves; a wave without a tile only keeps the block's head stream moving (no matrix work).
+    // The round then costs what its ceil(active waves / 4) waves per SIMD cost instead of a full round on some CUs.
+    long long tile = NTX == 0 ? (ps * WAVES + wave) * gridDim.x + blockIdx.x : (ps * gridDim.x + blockIdx.x) * WAVES + wave;
     const bool tile_ok = tile < n_tiles;
     if (NTX > 0 && !tile_ok) break;
+    if constexpr (NTX == 0) {
+      if (!tile_ok) {
+        const int evals = (a.init ? 1 : 0) + a.n_iters * a.n_leapfrog;
+        for (int e = 0; e < evals; ++e)
+          for (int tx = 0; tx < m.ntx; ++tx) { hs.fetch(tx + 1 < m.ntx ? tx + 1 : 0); hs.commit(); }
+        continue;
+      }
+    }
     tile = tile_ok ? tile : n_tiles - 1;
     long long row = tile * 16 + j;
     const bool ok = tile_ok && row < n;

@@ -354,7 +354,8 @@ __global__ __launch_bounds__(64 * BGMF_WAVES) void bgmf_hmc_kernel(BgmfHmcKArgs 
   const long long n = a.n, n_tiles = (n + 15) / 16, passes = bgm_block_passes(n_tiles, BGMF_WAVES);
   const float eps = *a.step;
   for (long long ps = 0; ps < passes; ++ps) {
-    long long tile = (ps * gridDim.x + blockIdx.x) * BGMF_WAVES + wave;
+    // tiles dealt wave-major; a wave without a tile in a partly filled last round only keeps the stream moving (bgm_hmc_kernel)
+    long long tile = (ps * BGMF_WAVES + wave) * gridDim.x + blockIdx.x;
     const bool tile_ok = tile < n_tiles;
     tile = tile_ok ? tile : n_tiles - 1;
     long long row = tile * 16 + j;
@@ -365,6 +366,12 @@ __global__ __launch_bounds__(64 * BGMF_WAVES) void bgmf_hmc_kernel(BgmfHmcKArgs 
     BgmfSigns<NH> S;
     __syncthreads();           // (the previous pass's readers of the sign rows are done)
     bgmf_signs<KTQ, NH>(m, sg_row, rowid, g, a.k0, a.k1, S);
+    if (!tile_ok) {
+      const int evals = (a.init ? 1 : 0) + a.n_iters * a.n_leapfrog;
+      for (int e = 0; e < evals; ++e)
+        for (int k = 0; k < st.cycle; ++k) { st.fetch_next(); st.commit(); }
+      continue;
+    }
     f32x4 z[KTQ], gr[KTQ];
     float lp;
     if (a.init) {   // initial_state ~ N(0,1)  (bgm/base.py:778), RNG tag 0
