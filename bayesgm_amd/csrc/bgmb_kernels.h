@@ -15,7 +15,7 @@
 // workspace in HBM / L2).  The minibatch steps are one workgroup; the large-batch kernels give each workgroup a tile of
 // BGMB_RT rows which it carries through whole HMC transitions (chains are independent; the per-call perturbation is a pure
 // function of (seed, stream), so every workgroup regenerates the same one).  This is the first correct version of this
-// path, not a tuned one.
+// path, not a tuned one (DESIGN_HISTORY.md section 7).
 #pragma once
 #include <hip/hip_runtime.h>
 

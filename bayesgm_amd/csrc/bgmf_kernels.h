@@ -7,7 +7,7 @@
 // layer's B operand, weights are read from LDS in the dual-access [out tile][in row][17] layout.  A Flipout layer
 //     y = h loc + ((h * s_in) dW) * s_out + b
 // is two such products: the posterior means `loc` of the trunk are LDS-resident for the whole launch; the run's ONE perturbation
-// dW = sigma * eps (frozen noise) does not fit beside them and is streamed from L2 through a double-buffered
+// dW = sigma * eps (frozen noise, DESIGN_HISTORY.md section 7b) does not fit beside them and is streamed from L2 through a double-buffered
 // LDS stage, one 64 x 64 layer (or one 16-feature block of both heads, loc and dW) per step, fetched one step ahead and shared by
 // the eight waves of the workgroup, which walk the layers in lock step (one barrier per step).  The rows' sign strings are drawn once
 // per row tile (Philox, oracle/bnn.py draw_noise: word w of row r = Philox(ctr = (r, w >> 2, stream 0, TAG_SIGN))[w & 3]) into LDS,

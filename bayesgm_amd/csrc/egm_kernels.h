@@ -127,7 +127,7 @@ __device__ __forceinline__ void egm_gemm_tiles(const EgmCtx &c, EgmMat A, EgmMat
       if (vec && k0 + 64 <= K) {
         // row-major A (activation rows): a lane's four K values of a group of four steps are adjacent -> one 16-byte load per
         // group instead of four scalar loads that each touch 16 cache lines; step u then uses
-        // k = k0 + 16 (u / 4) + 4 g + u % 4 on BOTH operands (same set of k, another summation order).  See DESIGN.md 7b.
+        // k = k0 + 16 (u / 4) + 4 g + u % 4 on BOTH operands (same set of k, another summation order).  See DESIGN_HISTORY.md 7b.
         const f32x4 *q = reinterpret_cast<const f32x4 *>(ap + k0 + 4 * g);
 #pragma unroll
         for (int c4 = 0; c4 < 4; ++c4) {

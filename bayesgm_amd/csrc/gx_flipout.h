@@ -1,6 +1,6 @@
 // gx_flipout.h -- DenseFlipout layers on the general-width engine (gx_device.h), and on them the HMC sampler of BGM with the
 // Bayesian generator in the shipped noise mode (params['bnn_mcmc_noise'] = 'frozen': ONE weight perturbation and one sign string per
-// row for a whole run).
+// row for a whole run, DESIGN_HISTORY.md section 7b).
 //
 // replaces: BGM.tfp_mcmc_sampler bgm/base.py:709-830 on the target bgm/base.py:665-705 with g_net = BayesianVariationalNet
 // (networks/bnn.py:40-99; tfp.layers.DenseFlipout restated in oracle/bnn.py, oracle/bgm_bnn.py) -- the job of bgmb_hmc_kernel

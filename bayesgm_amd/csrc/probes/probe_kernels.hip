@@ -1,4 +1,4 @@
-// probe_kernels.hip -- measurement aids (NOT part of libbgm_hip.so / include/bgm_hip.h): micro-benchmarks quoted in DESIGN.md section 4.
+// probe_kernels.hip -- measurement aids (NOT part of libbgm_hip.so / include/bgm_hip.h): micro-benchmarks quoted in DESIGN_HISTORY.md section 4.
 // Built into bayesgm_amd/csrc/probes/libbgm_probe.so by `python -m bayesgm_amd.csrc.build --probes`; used by scripts/probe_*.py only.
 #include <hip/hip_runtime.h>
 
@@ -108,7 +108,7 @@ extern "C" int bgm_probe_clock(int device, int32_t iters, double *shader_mhz, do
   return 0;
 }
 
-// probe_bf16x3.hip -- measurement aid for the NEXT step of the MH kernel ("what comes next"): one hidden
+// probe_bf16x3.hip -- measurement aid for the NEXT step of the MH kernel (DESIGN_HISTORY.md section 4, "what comes next"): one hidden
 // 64 -> 64 layer + LeakyReLU of the swapped-orientation MLP, chained `iters` times per wave, either
 //   mode 0: fp32 MFMA (v_mfma_f32_16x16x4_f32), 64 MFMAs per layer and 16 chains -- what causal_mh_kernel does today, or
 //   mode 1: split-precision bf16 x 3 (v_mfma_f32_16x16x32_bf16): W = W_hi + W_lo, h = h_hi + h_lo (bf16 each),

@@ -1,6 +1,6 @@
 """Run-time diagnostics of CausalBGM.fit: the second optimum of the EGM warm start.
 
-Sixteen end-to-end runs of the published tutorial setting (eight of the product, eight of the NumPy oracle: DESIGN.md section 2c,
+Sixteen end-to-end runs of the published tutorial setting (eight of the product, eight of the NumPy oracle: DESIGN_HISTORY.md section 2c,
 profiles/r03_accuracy/, profiles/r03_oracle_anchor/) end in one of two places.  Eleven land where the reference's published run
 landed: late `l2_loss_z` 0.22 - 0.25 (published 0.247), panel `MSE_v` 0.964 - 0.976, MH acceptance 0.097 - 0.101.  Five land in a
 second optimum of the warm start -- late `l2_loss_z` 0.35 - 0.44, `MSE_v` 0.975 - 0.999 at EVERY evaluation, acceptance 0.11 - 0.12

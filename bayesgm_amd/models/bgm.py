@@ -5,7 +5,7 @@ Mirrors /root/reference/src/bayesgm/models/bgm/base.py:
     predict_on_posteriors :511   predict :527   get_log_posterior :666   tfp_mcmc_sampler :709
 This class is the deterministic generator (``use_bnn=False``: BaseVariationalNet, networks/base.py:53-117); the EGM warm
 start runs on the kernels of csrc/bgm_egm_kernels.h.  ``BGM(params)`` with ``params['use_bnn'] = True``
-(BayesianVariationalNet, networks/bnn.py:40-99) returns the subclass models/bgm_bnn.py::BGMBayes (DESIGN.md section 7).
+(BayesianVariationalNet, networks/bnn.py:40-99) returns the subclass models/bgm_bnn.py::BGMBayes (DESIGN_HISTORY.md section 7).
 """
 import datetime
 import os

@@ -10,7 +10,7 @@ DenseFlipout perturbs the kernels in EVERY call, also with training=False (tfp.l
 the perturbation and the sign vectors inside `call`, with stateful random ops when the layer's seed is None, and has no training
 switch), so evaluate / generate / the predictive draws are stochastic in the weights, as in the reference.
 
-The HMC target (``params['bnn_mcmc_noise']``; DESIGN.md section 7b gives the argument in full).  Under tfp.mcmc.sample_chain the
+The HMC target (``params['bnn_mcmc_noise']``; DESIGN_HISTORY.md section 7b gives the argument in full).  Under tfp.mcmc.sample_chain the
 target_log_prob_fn is traced once and EXECUTED at every leapfrog step, so as written (bgm/base.py:709-830) every gradient
 evaluation of a transition sees a different weight draw while the cached log-prob of the current state stays: the acceptance ratio
 compares two different perturbations, the acceptance probability is bounded away from 1 however small the step (~0.54 measured),
@@ -337,7 +337,7 @@ class BGMBayes(BGM):
             import warnings
             warnings.warn("bayesgm_amd: params['bnn_mcmc_noise'] = 'fresh' re-perturbs the generator at every HMC gradient evaluation, as "
                           "the reference executes it: the acceptance probability stays below the adaptation target whatever the step, "
-                          "SimpleStepSizeAdaptation shrinks the step geometrically and the chains freeze (DESIGN.md section 7b); "
+                          "SimpleStepSizeAdaptation shrinks the step geometrically and the chains freeze (DESIGN_HISTORY.md section 7b); "
                           "the default 'frozen' samples on one weight draw per HMC run instead.")
             self._warned_noise = True
 

@@ -16,7 +16,7 @@ import torch
 
 # Default BatchNormalization reading of the layers the reference calls without `training=` (Discriminator, networks/base.py:378;
 # BayesianFullyConnectedNet, networks/bnn.py:26): inference mode.  This is the reading under which the build reproduces the
-# training log, acceptance rate and ADRF error the reference published (tests/golden/tutorial_trace.json);
+# training log, acceptance rate and ADRF error the reference published (tests/golden/tutorial_trace.json, DESIGN_HISTORY.md section 2b);
 # "batch" (batch statistics, what Keras 2.10's documented training-mode propagation implies for the code as written) stays
 # available as params['disc_norm'] / params['bnn_norm'] = "batch".
 DISC_NORM_DEFAULT = "fixed"
@@ -45,7 +45,7 @@ def _init_mlp(rs, dims):
 
 def _disc_norm(p):
     """params['disc_norm'] (build option): BatchNormalization mode of the EGM discriminators, "batch" | "fixed"
-    (include/bgm_hip.h bgm_set_disc_norm)."""
+    (include/bgm_hip.h bgm_set_disc_norm, DESIGN_HISTORY.md section 2b)."""
     mode = p.get("disc_norm", DISC_NORM_DEFAULT)
     if mode not in ("batch", "fixed"):
         raise ValueError("params['disc_norm'] must be 'batch' or 'fixed'")
@@ -90,7 +90,7 @@ class CausalBGM(object):
         self.engine.set_disc_norm(_disc_norm(p))
         # params['mh_precision'] (build option): arithmetic of the posterior-sampling kernels of predict /
         # metropolis_hastings_sampler / get_log_posterior: "fp32" (default, the reference's arithmetic) or "bf16x3" (split
-        # precision on the bf16 matrix pipe)
+        # precision on the bf16 matrix pipe, DESIGN_HISTORY.md section 4b)
         if p.get("mh_precision", "fp32") not in ("fp32", "bf16x3"):
             raise ValueError("params['mh_precision'] must be 'fp32' or 'bf16x3'")
         self.engine.set_precision(p.get("mh_precision", "fp32"))

@@ -8,9 +8,9 @@ weight perturbations) and `evaluate` treats the panel it is given as one batch.
 
 ``params['bnn_norm']`` (build option, default "fixed"): "fixed" = the input BatchNormalization runs in inference mode on its
 never-updated moving averages (mean 0 / variance 1), the reading under which the build reproduces the reference's published
-training log, acceptance rate and ADRF error; "batch" = it uses the statistics of the batch at hand,
+training log, acceptance rate and ADRF error (DESIGN_HISTORY.md section 2b); "batch" = it uses the statistics of the batch at hand,
 which is what Keras 2.10's documented training-mode propagation implies for the code as written -- a constant counterfactual
-treatment column is then normalised away and the ADRF is flat.
+treatment column is then normalised away and the ADRF is flat (DESIGN_HISTORY.md section 7).
 
 Stated differences (DESIGN.md "Bayesian nets"): the noise streams are the build's counter-based ones (oracle/bnn.py);
 minibatches are limited to 64 rows; under torch.distributed every rank normalises with the statistics of ITS rows.
@@ -56,7 +56,7 @@ class CausalBGMBayes(CausalBGM):
             import warnings
             warnings.warn("bayesgm_amd: params['bnn_norm'] = 'batch' (input BatchNormalization on batch statistics): a counterfactual "
                           "treatment column that is constant over the batch is normalised away, so ADRF / ITE estimates do not depend on "
-                          "the treatment value, and the reference's published results are not reproduced (DESIGN.md sections 2b, 7).",
+                          "the treatment value, and the reference's published results are not reproduced (DESIGN_HISTORY.md sections 2b, 7).",
                           stacklevel=3)
         random_seed = parallel.shared_seed(random_seed)   # None stays None in a single process; one seed for all ranks otherwise
         self._rs = np.random.RandomState(random_seed) if random_seed is not None else np.random.RandomState()

@@ -160,7 +160,7 @@ def fit_leg(model, x, y, v, n_loc, steps=2000, batch=32):
 def training_leg(params, x, y, v, device, n=20000, batch=32, reps=200):
     """Secondary measurement: latencies of the training-side steps at the reference batch size on the first `n` rows of the bench
     panel (the tutorial's N) -- EGM discriminator / generator step and the minibatch theta / latent steps, for deterministic and
-    Bayesian networks.  Each is one call through the C ABI (1-3 launches); see DESIGN.md section 4c."""
+    Bayesian networks.  Each is one call through the C ABI (1-3 launches); see DESIGN_HISTORY.md section 4c."""
     import torch
     from bayesgm_amd.models import CausalBGM
     q, p = sum(params["z_dims"]), params["v_dim"]
@@ -201,7 +201,7 @@ def training_leg(params, x, y, v, device, n=20000, batch=32, reps=200):
     # deterministic nets
     m = CausalBGM(dict(params, use_bnn=False), timestamp="bench_train_det", random_seed=0, device=device.index)
     eng = m.engine
-    eng.set_disc_norm("fixed")            # the models' default
+    eng.set_disc_norm("fixed")            # the models' default (DESIGN_HISTORY.md section 2b)
     eng.egm_begin(batch, list(params["dz_units"]), float(params["lr"]), bool(params["use_z_rec"]), dz)
     try:
         d_us = timed(lambda: eng.egm_disc_step(zb, idx, vs, 0.5))
@@ -252,7 +252,7 @@ def training_leg(params, x, y, v, device, n=20000, batch=32, reps=200):
 
 def bayesian_leg(params, data, x_values, n_loc, args, device):
     """Secondary measurement (not `value`): the same predict with the reference's default Bayesian nets (use_bnn=True,
-    DESIGN.md section 7) on a tenth of the iterations -- all blocks advance in lock step, three launches per iteration, so
+    DESIGN_HISTORY.md section 7) on a tenth of the iterations -- all blocks advance in lock step, three launches per iteration, so
     the per-transition rate does not depend on the iteration count."""
     import torch
     from bayesgm_amd.models import CausalBGM
@@ -370,7 +370,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (den
 
 def bf16x3_leg(model, data, x_values, n_loc, args, z_dims, flop_row_transition, flop_row_keep, seed_counter):
     """Secondary measurement (not `value`, which stays fp32 = the reference's arithmetic): the same predict with the opt-in
-    split-precision kernels (params['mh_precision'] = 'bf16x3').  `achieved` prices the ALGORITHMIC FLOP
+    split-precision kernels (params['mh_precision'] = 'bf16x3', DESIGN_HISTORY.md section 4b).  `achieved` prices the ALGORITHMIC FLOP
     (the fp32 count) -- an "fp32-equivalent" rate; `executed_bf16_tflops` counts the three bf16 products per contraction that
     the matrix pipe actually runs, against the dense bf16 peak."""
     import torch

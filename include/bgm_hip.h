@@ -73,13 +73,13 @@ BGM_API int bgm_create(bgm_handle **out, int device);
  *   0 (default of the library)  batch statistics -- `norm_layer(x)` inside a Model.call(training=True) under Keras' rule that an
  *                               inner layer inherits the outer call's training mode;
  *   1                           inference mode on the layer's initial moving averages (mean 0, variance 1), the behaviour the
- *                               reference's published training log is consistent with. */
+ *                               reference's published training log is consistent with (DESIGN_HISTORY.md section 2b). */
 BGM_API int bgm_set_disc_norm(bgm_handle *h, int32_t mode);
 /* Arithmetic of the CausalBGM sampling kernels launched afterwards through bgm_causal_logpost / bgm_causal_mh_run:
  *   0 (default)  fp32 MFMA -- the reference's arithmetic (causalbgm/base.py:765-904 run in float32);
  *   1            split precision "bf16 x 3": weights and activations as sums of two bf16 numbers, three bf16 MFMA products per
  *                contraction with fp32 accumulation (relative error ~6e-6 per layer against 2.4e-7 in fp32).  Same algorithm,
- *                RNG streams and outputs; chains agree with the fp32 ones statistically, not draw for draw. */
+ *                RNG streams and outputs; chains agree with the fp32 ones statistically, not draw for draw (DESIGN_HISTORY.md section 4b). */
 BGM_API int bgm_causal_set_precision(bgm_handle *h, int32_t mode);
 /* Conditional latent prior Z | U ~ N(mu(U), sigma^2(U) I) of IdentifiableCausalBGM (models/causalbgm/identifiable.py:195-211,
  * 541-551) for the sampling calls made afterwards (bgm_causal_logpost, bgm_causal_mh_run; fp32 kernels): seg_dev [n] = segment of
@@ -111,9 +111,14 @@ BGM_API int bgm_destroy(bgm_handle *h);
 
 /* Declare the model shape.  Synchronous.  replaces: CausalBGM.__init__ network
  * construction, causalbgm/base.py:64-84. */
-/* Supported: g_units = [64]*k, f_units = h_units = [64,32,8], e_units = [64]*k; sum(z_dims) <= 19; v_dim <= 207
- * (<= 159 when sum(z_dims) > 11).  Any shape inside these limits runs on the smallest compiled kernel shape that
- * contains it (zero padding, identical results). */
+/* Any hidden widths in [1, 4096] and up to 8 hidden layers per net are accepted (networks/base.py:4-51 takes any nb_units).  Two kernel
+ * families serve them:
+ *   - the reference's defaults (g_units = e_units = [64]*k, f_units = h_units = [64,32,8]): LDS-resident kernels when sum(z_dims) <= 19
+ *     and v_dim <= 207 (<= 159 when sum(z_dims) > 11) -- the model runs on the smallest compiled kernel shape that contains it (zero
+ *     padding, identical results); the general path of the same kernels for sum(z_dims) <= 31 at any v_dim;
+ *   - everything else: the general-width engine (32-row activation tiles in LDS, padded weight packs streamed from L2; csrc/gx_api.hip).
+ *     Its limit is the LDS tile: a call whose widest layer does not fit (hidden widths beyond ~550) returns BGM_E_UNSUPPORTED and says so.
+ * Same entry points, RNG streams and results either way. */
 BGM_API int bgm_causal_configure(bgm_handle *h, const bgm_causal_config *cfg);
 
 /* Upload one network's parameters from HOST memory, flat float32 in Keras
@@ -370,10 +375,10 @@ typedef struct {
   int32_t n_hidden_g, g_units[BGM_MAX_LAYERS];
 } bgm_bgm_config;
 
-/* Supported shapes: z_dim <= 16, g_units = [64]*3 or [64]*5, any x_dim whose head biases fit the LDS beside
- * the trunk (x_dim <= ~2000).  x_dim in (16,32] and (96,112] run with the whole generator resident in LDS;
- * every other width (e.g. config C4, x_dim = 500) streams the 2 x 64 x x_dim head weights through an LDS
- * stage shared by the waves of a block. */
+/* Any g_units in [1, 4096], any depth up to 8, any z_dim are accepted.  g_units = [64]*3 or [64]*5 with z_dim <= 16 run on the
+ * register-chained kernels: x_dim in (16,32] and (96,112] with the whole generator resident in LDS, every other width (e.g. config C4,
+ * x_dim = 500) with the 2 x 64 x x_dim head weights streamed through an LDS stage shared by the waves of a block (x_dim <= ~2000).
+ * Every other shape runs on the general-width engine (csrc/gx_bgm_api.hip; hidden widths up to ~280 fit its LDS tiles). */
 BGM_API int bgm_bgm_configure(bgm_handle *h, const bgm_bgm_config *cfg);
 
 /* Generator parameters from HOST memory, flat float32:

@@ -51,7 +51,7 @@ def cast_disc(d, dtype):
 def _fixed(d):
     """d["fixed_norm"] = True: the discriminator's BatchNormalization layers run in inference mode on their initial
     moving averages (mean 0, variance 1) -- a constant per-column scale 1/sqrt(1 + eps) -- instead of on batch statistics
-    (the build's `disc_norm` option)."""
+    (the build's `disc_norm` option, DESIGN_HISTORY.md section 2b)."""
     return bool(d.get("fixed_norm", False))
 
 

@@ -1,5 +1,5 @@
 """BGM(use_bnn=True): HMC on the re-perturbed target (reference as written, 'fresh') vs one weight draw ('frozen') -- draw
-variance, reconstruction and imputation error of a small model.
+variance, reconstruction and imputation error of a small model (DESIGN_HISTORY.md section 7b).
 usage: python scripts/bvn_hmc_noise.py [fresh|frozen]"""
 import sys, numpy as np, torch
 sys.path.insert(0, ".")

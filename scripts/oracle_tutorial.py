@@ -42,7 +42,7 @@ x, y, v = Sim_Hirano_Imbens_sampler(N=N, v_dim=P, seed=0).load_all()
 rs = np.random.RandomState(seed)
 m = OB.init_model(seed, ZD, P, False)
 for k in ("g", "e", "f", "h"):
-    m[k]["norm"] = "fixed"                      # params['bnn_norm'] = "fixed": the shipped reading
+    m[k]["norm"] = "fixed"                      # params['bnn_norm'] = "fixed": the shipped reading (DESIGN_HISTORY.md section 2b)
 q = sum(ZD)
 dz = OE.init_disc(rs, q, [64, 32, 8])
 dz["fixed_norm"] = True                         # params['disc_norm'] = "fixed"

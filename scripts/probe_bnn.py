@@ -61,7 +61,7 @@ _dd = [q, 64, 32, 8, 1]
 dz = {"W": [_rs.uniform(-1, 1, (_dd[i], _dd[i + 1])).astype(np.float32) * np.float32(np.sqrt(6.0 / (_dd[i] + _dd[i + 1]))) for i in range(4)],
       "b": [np.zeros(d, np.float32) for d in _dd[1:]], "gamma": [np.ones(d, np.float32) for d in _dd[1:-1]],
       "beta": [np.zeros(d, np.float32) for d in _dd[1:-1]]}
-eng.set_disc_norm("fixed")      # the models' default
+eng.set_disc_norm("fixed")      # the models' default (DESIGN_HISTORY.md section 2b)
 eng.egm_begin(dz, 32, 2e-4, 1)
 zp = torch.randn(32, q, device=dev)
 eng.egm_disc_step(zp, idx, v, 0.3, 1, 0); eng.egm_gen_step(zp, idx, v, x, y, 1, 1)

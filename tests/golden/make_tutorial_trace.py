@@ -7,7 +7,7 @@ docs/source/causalbgm/tutorial_py.ipynb (package v1.0.1, use_bnn=True, Hirano-Im
 predict(n_mcmc=3000, burn_in=5000, x_values=linspace(0,3,20), q_sd=1.0, bs=20000)): the EGM log every 500 iterations,
 the last-minibatch losses of the 101 epochs, the panel MSEs every 10 epochs, the final MH acceptance rate and the ADRF
 RMSE / MAPE.  They are written to tutorial_trace.json -- numbers only -- and used as a statistical envelope for the
-build's own end-to-end runs (tests/test_tutorial_trace.py, scripts/compare_trace.py)."""
+build's own end-to-end runs (tests/test_tutorial_trace.py, scripts/compare_trace.py, DESIGN_HISTORY.md section 7)."""
 import json
 import os
 import re

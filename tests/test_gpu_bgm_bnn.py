@@ -358,7 +358,7 @@ def test_model_predict_is_block_consistent_with_the_oracle(tmp_path):
 
 def test_mcmc_noise_default_is_one_weight_draw_and_the_as_written_mode_warns(tmp_path):
     """params['bnn_mcmc_noise']: the default samples each HMC run on one weight draw (a deterministic target); 'fresh' -- the
-    reference as executed, chains freeze -- is an explicit choice and says so (models/bgm_bnn.py)."""
+    reference as executed, chains freeze -- is an explicit choice and says so (models/bgm_bnn.py, DESIGN_HISTORY.md section 7b)."""
     import warnings
     from bayesgm_amd.models import BGM
     p, q = 6, 2

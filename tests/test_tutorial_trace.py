@@ -6,7 +6,7 @@ tests/golden/make_tutorial_trace.py): EGM log, per-epoch minibatch losses, panel
  * CPU: the committed logs of the build's own runs of the same setting (profiles/r02_accuracy/, scripts/accuracy_runs.py)
    are laid next to it: the default reading (BatchNormalization layers that the reference calls without `training=` run in
    inference mode) must sit inside the envelope, the literal batch-statistics reading must not -- this is the evidence the
-   defaults of params['bnn_norm'] / params['disc_norm'] rest on.
+   defaults of params['bnn_norm'] / params['disc_norm'] rest on (DESIGN_HISTORY.md section 2b).
  * GPU: one full run of the tutorial (N = 20000, p = 200, 30000 EGM iterations + 100 epochs, predict 5000 + 3000 at 20
    doses, bs = 20000; about three minutes) must land inside the same envelope.
 Envelope = published value +- a tolerance that covers the seed-to-seed spread observed over the build's runs (stated per
