@@ -208,7 +208,7 @@ __device__ __forceinline__ void gx_causal_effects(const GxCausalModel &m, const 
       if (EFFECT == 1) {
         float tot = valid ? yv : 0.0f;
         tot += __shfl_xor(tot, 1); tot += __shfl_xor(tot, 2); tot += __shfl_xor(tot, 4); tot += __shfl_xor(tot, 8); tot += __shfl_xor(tot, 16);
-        if (r == 0) e.adrf_slot[d * nd + k] += tot;        // the slot is private to this workgroup: no atomics, fixed order
+        if (r == 0) e.adrf_slot[(long long)d * nd + k] += tot;        // the slot is private to this workgroup: no atomics, fixed order
       } else {
         if (k == 0) ykeep = yv;
         else if (valid) e.ite[(row0 + r) * (long long)e.n_keep + d] = ykeep - yv;

@@ -50,3 +50,15 @@ def warn_if_second_optimum(l2z_late, mse_v, already=False):
         return False
     warnings.warn(msg, SecondOptimumWarning, stacklevel=3)
     return True
+
+
+_NOTICED = set()
+
+
+def notice_once(key, message):
+    """One line on stderr, once per process: a default of this build that differs from the reference as written was taken implicitly."""
+    import sys
+    if key in _NOTICED:
+        return
+    _NOTICED.add(key)
+    print("bayesgm_amd: " + message, file=sys.stderr)

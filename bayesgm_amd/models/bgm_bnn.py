@@ -89,6 +89,10 @@ class BGMBayes(BGM):
             device = int(os.environ.get("BGM_DEVICE", os.environ.get("LOCAL_RANK", 0)))
         self._max_batch = 64
         mode = params.get("bnn_mcmc_noise", "frozen")
+        if "bnn_mcmc_noise" not in params:
+            from .. import diagnostics
+            diagnostics.notice_once("bnn_mcmc_noise", "params['bnn_mcmc_noise'] not given: HMC runs on ONE weight perturbation per run ('frozen'); "
+                                    "'fresh' re-perturbs at every gradient evaluation as the reference is written (DESIGN_HISTORY.md section 7b)")
         if mode not in ("fresh", "frozen"):
             raise ValueError("params['bnn_mcmc_noise'] must be 'fresh' or 'frozen'")
         self._mcmc_noise = mode

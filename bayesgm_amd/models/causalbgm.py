@@ -270,7 +270,7 @@ class CausalBGM(object):
             print('EGM Initialization Ends.')
 
     def fit(self, data, epochs=100, epochs_per_eval=5, batch_size=32, startoff=0, use_egm_init=True,
-            egm_n_iter=30000, egm_batches_per_eval=500, save_format='txt', verbose=1, z_adam="replay", host_loop=False):
+            egm_n_iter=30000, egm_batches_per_eval=500, save_format='txt', verbose=1, z_adam=None, host_loop=False):
         """Iterative theta / Z updates (base.py:434-532).
 
         ``host_loop=False`` (single process): the minibatches of an epoch are issued by ONE library call (bgm_causal_fit_epoch), the
@@ -286,6 +286,10 @@ class CausalBGM(object):
                    is next used (O(batch) per step; equal to "dense" up to fp32 rounding of a 256-term series, csrc/z_replay.h);
           "dense"  the recursion as Keras executes it: a sweep over the [N x q] table per minibatch (bit-faithful order of operations);
           "lazy"   batch rows only -- a different optimizer (build option)."""
+        if z_adam is None:
+            z_adam = "replay"
+            diagnostics.notice_once("z_adam", "fit(z_adam=...) not given: the latent Adam runs in its replayed form ('replay': equal to Keras' "
+                                    "dense-decay sweep up to fp32 rounding); 'dense' executes the sweep as the reference does (DESIGN_HISTORY.md section 4d)")
         if use_egm_init:
             self.egm_init(data, egm_n_iter=egm_n_iter, batch_size=batch_size,
                           egm_batches_per_eval=egm_batches_per_eval, verbose=verbose)

@@ -243,11 +243,15 @@ class CausalBGMBayes(CausalBGM):
 
     # ------------------------------------------------------------------ fit
     def fit(self, data, epochs=100, epochs_per_eval=5, batch_size=32, startoff=0, use_egm_init=True,
-            egm_n_iter=30000, egm_batches_per_eval=500, save_format='txt', verbose=1, z_adam="replay", host_loop=False):
+            egm_n_iter=30000, egm_batches_per_eval=500, save_format='txt', verbose=1, z_adam=None, host_loop=False):
         """Iterative theta / Z updates (base.py:434-532) with the KL terms of the Bayesian nets.  ``batch_size`` is the
         GLOBAL minibatch (<= 64 per rank); under torch.distributed rows are sharded, the g | h | f gradients all-reduced.
         ``host_loop=False`` (single process): one library call per epoch (bgm_bnn_fit_epoch), the latent phase of a minibatch beside
         the chains of the next on a second stream; ``True``: the per-minibatch calls from Python (same results)."""
+        if z_adam is None:
+            z_adam = "replay"
+            diagnostics.notice_once("z_adam", "fit(z_adam=...) not given: the latent Adam runs in its replayed form ('replay': equal to Keras' "
+                                    "dense-decay sweep up to fp32 rounding); 'dense' executes the sweep as the reference does (DESIGN_HISTORY.md section 4d)")
         if use_egm_init:
             self.egm_init(data, egm_n_iter=egm_n_iter, batch_size=batch_size,
                           egm_batches_per_eval=egm_batches_per_eval, verbose=verbose)
