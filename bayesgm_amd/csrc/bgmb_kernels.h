@@ -22,6 +22,7 @@
 #include "bnn_kernels.h"
 
 #define BGMB_RT 64
+#define BGMB_MAX_BATCH 256         // rows of a minibatch step (bgmb_theta_step_kernel, bgmb_z_step_kernel)
 #define BGMB_STREAM_PREDICT 0x40000000u
 #define BGMB_STREAM_DECODE 0x50000000u
 
@@ -98,7 +99,7 @@ inline size_t bgmb_ws_floats(int B, int q, int p, int wmax) {
 // update_g_net (bgm/base.py:145-164)
 static __global__ __launch_bounds__(BNN_THREADS) void bgmb_theta_step_kernel(BgmbArgs a) {
   __shared__ float red[32];
-  __shared__ float rowv[BGMB_RT];
+  __shared__ float rowv[BGMB_MAX_BATCH];
   BnnCtx c{(int)threadIdx.x, red};
   const BnnNet &n = a.net;
   const int B = a.B, p = a.p, q = a.q;
@@ -129,7 +130,7 @@ static __global__ __launch_bounds__(BNN_THREADS) void bgmb_theta_step_kernel(Bgm
 // update_latent_variable_sgd (bgm/base.py:167-187) + the fresh-slot Adam step on the batch rows (:402)
 static __global__ __launch_bounds__(BNN_THREADS) void bgmb_z_step_kernel(BgmbArgs a) {
   __shared__ float red[32];
-  __shared__ float rowv[BGMB_RT];
+  __shared__ float rowv[BGMB_MAX_BATCH];
   BnnCtx c{(int)threadIdx.x, red};
   const BnnNet &n = a.net;
   const int B = a.B, p = a.p, q = a.q;

@@ -25,6 +25,7 @@
 #define BNN_SCALE_EPS 1.1920928955078125e-07f
 #define BNN_TAG_EPS 8u
 #define BNN_TAG_SIGN 9u
+#define BNN_MAX_BATCH 256          // rows of a minibatch step (one workgroup per net walks them; the row-tile chains serve 16 / 32)
 
 // One BayesianFullyConnectedNet.  Parameters (flat, at theta + off): gamma[in], beta[in], then per layer
 // loc[in x out], rho[in x out], bias[out].  All prefix tables are filled on the host (bnn_finish_net).
@@ -511,7 +512,7 @@ __device__ __forceinline__ float bnn_gauss(float ssq, float raw, float dim, floa
 // given the batch (each reads the latents of BEFORE the step), so one launch does all three, one workgroup per net.
 static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_step_kernel(BnnArgs a) {
   __shared__ float red[32];
-  __shared__ float ssq_row[64];
+  __shared__ float ssq_row[BNN_MAX_BATCH];
   BnnCtx c{(int)threadIdx.x, red};
   const int B = a.B, p = a.p;
   float *wp = a.ws + (long long)blockIdx.x * a.ws_stride;
@@ -580,7 +581,7 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_step_kernel(BnnA
 // noise (mean from the first call, variance head from the second); dz [B x q] = d loss / d (batch rows of data_z).
 static __global__ __launch_bounds__(BNN_THREADS) void bnn_z_grad_kernel(BnnArgs a) {
   __shared__ float red[32];
-  __shared__ float ssq_row[64];
+  __shared__ float ssq_row[BNN_MAX_BATCH];
   BnnCtx c{(int)threadIdx.x, red};
   const int B = a.B, p = a.p, q = a.q;
   float *wp = a.ws + (long long)blockIdx.x * a.ws_stride;

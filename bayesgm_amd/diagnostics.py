@@ -12,6 +12,7 @@ import warnings
 
 import numpy as np
 
+MIN_EGM_ITER = 10000        # warm starts shorter than this are not diagnosed (the sixteen runs used the reference's 30 000)
 L2Z_LATE_MAX = 0.33     # median l2_loss_z of the EGM log lines of the last third of the warm start: main optimum <= 0.253, second >= 0.351
 MSE_V_MAX = 0.975       # panel MSE_v of a fit evaluation (standardised V): second optimum >= 0.9753 at every evaluation
 

@@ -87,7 +87,7 @@ class BGMBayes(BGM):
         self.z_sampler = Gaussian_sampler(mean=np.zeros(q), sd=1.0)
         if device is None:
             device = int(os.environ.get("BGM_DEVICE", os.environ.get("LOCAL_RANK", 0)))
-        self._max_batch = 64
+        self._max_batch = 256
         mode = params.get("bnn_mcmc_noise", "frozen")
         if "bnn_mcmc_noise" not in params:
             from .. import diagnostics

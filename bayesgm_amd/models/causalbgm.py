@@ -264,7 +264,8 @@ class CausalBGM(object):
                 pipe.close()
             eng.egm_end()
             self._pull_weights(("g", "f", "h", "e"))
-        self._egm_late_l2z = diagnostics.late_l2_loss_z([a for a, _ in egm_log], [b for _, b in egm_log], egm_n_iter) if egm_log else None
+        # (the thresholds describe the full-length warm start: a short one is merely unconverged and gets no diagnosis)
+        self._egm_late_l2z = diagnostics.late_l2_loss_z([a for a, _ in egm_log], [b for _, b in egm_log], egm_n_iter) if (egm_log and egm_n_iter >= diagnostics.MIN_EGM_ITER) else None
         self._second_optimum_warned = False
         if verbose:
             print('EGM Initialization Ends.')

@@ -13,7 +13,7 @@ which is what Keras 2.10's documented training-mode propagation implies for the 
 treatment column is then normalised away and the ADRF is flat (DESIGN_HISTORY.md section 7).
 
 Stated differences (DESIGN.md "Bayesian nets"): the noise streams are the build's counter-based ones (oracle/bnn.py);
-minibatches are limited to 64 rows; under torch.distributed every rank normalises with the statistics of ITS rows.
+minibatches are limited to 256 rows (16 and 32 run on the row-tile chains, other sizes on the one-workgroup-per-net kernels); under torch.distributed every rank normalises with the statistics of ITS rows.
 """
 import datetime
 import os
@@ -77,7 +77,7 @@ class CausalBGMBayes(CausalBGM):
         if device is None:
             device = int(os.environ.get("BGM_DEVICE", os.environ.get("LOCAL_RANK", 0)))
         self.engine = BnnEngine(p["v_dim"], z, binary_treatment=p["binary_treatment"], g_units=p["g_units"], e_units=p["e_units"],
-                                f_units=p["f_units"], h_units=p["h_units"], kl_weight=p["kl_weight"], max_batch=64,
+                                f_units=p["f_units"], h_units=p["h_units"], kl_weight=p["kl_weight"], max_batch=256,
                                 norm_mode={"batch": 0, "fixed": 1}[self._bnn_norm], device=device)
         self.engine.set_disc_norm(_disc_norm(p))
         self.engine.begin(self.nets)
@@ -236,7 +236,8 @@ class CausalBGMBayes(CausalBGM):
                 pipe.close()
             eng.egm_end()
             self._pull_weights()
-        self._egm_late_l2z = diagnostics.late_l2_loss_z([a for a, _ in egm_log], [b for _, b in egm_log], egm_n_iter) if egm_log else None
+        # (the thresholds describe the full-length warm start: a short one is merely unconverged and gets no diagnosis)
+        self._egm_late_l2z = diagnostics.late_l2_loss_z([a for a, _ in egm_log], [b for _, b in egm_log], egm_n_iter) if (egm_log and egm_n_iter >= diagnostics.MIN_EGM_ITER) else None
         self._second_optimum_warned = False
         if verbose:
             print('EGM Initialization Ends.')
@@ -245,7 +246,7 @@ class CausalBGMBayes(CausalBGM):
     def fit(self, data, epochs=100, epochs_per_eval=5, batch_size=32, startoff=0, use_egm_init=True,
             egm_n_iter=30000, egm_batches_per_eval=500, save_format='txt', verbose=1, z_adam=None, host_loop=False):
         """Iterative theta / Z updates (base.py:434-532) with the KL terms of the Bayesian nets.  ``batch_size`` is the
-        GLOBAL minibatch (<= 64 per rank); under torch.distributed rows are sharded, the g | h | f gradients all-reduced.
+        GLOBAL minibatch (<= 256 per rank); under torch.distributed rows are sharded, the g | h | f gradients all-reduced.
         ``host_loop=False`` (single process): one library call per epoch (bgm_bnn_fit_epoch), the latent phase of a minibatch beside
         the chains of the next on a second stream; ``True``: the per-minibatch calls from Python (same results)."""
         if z_adam is None:

@@ -34,7 +34,8 @@ def _flat(parts):
     return np.concatenate([np.asarray(a, np.float64).ravel() for a in parts])
 
 
-@pytest.mark.parametrize("q,units,p,B", [(10, (64,) * 5, 20, 32), (5, (24, 40), 37, 19), (3, (16,), 9, 64)])
+@pytest.mark.parametrize("q,units,p,B", [(10, (64,) * 5, 20, 32), (5, (24, 40), 37, 19), (3, (16,), 9, 64),
+                                         (10, (64,) * 5, 20, 160), (4, (32, 32), 12, 200)])      # minibatches beyond 64 rows (any batch_size, bgm/base.py:343)
 def test_theta_step_gradient_matches_oracle(q, units, p, B):
     net = _net(q, units, p)
     rs = np.random.RandomState(1)
@@ -42,7 +43,7 @@ def test_theta_step_gradient_matches_oracle(q, units, p, B):
     z = rs.standard_normal((N, q)).astype(np.float32)
     x = rs.standard_normal((N, p)).astype(np.float32)
     idx = rs.choice(N, B, replace=False).astype(np.int32)
-    eng = _engine(net, q, units, p, kl_weight=0.01, max_batch=64)
+    eng = _engine(net, q, units, p, kl_weight=0.01, max_batch=max(64, B))
     dev = eng.device
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     seed, stream = (3 << 32) | 17, 6
@@ -568,3 +569,16 @@ def test_frozen_hmc_row_tile_chains_equal_the_lds_tile_engine(monkeypatch, q, un
     # dlogp/dz jumps where a LeakyReLU input changes sign, so two states 1e-4 apart may sit on different sides of a kink: per row
     g_close = np.abs(g0 - g1).max(axis=1) < 2e-3 * np.abs(g1).max()
     assert g_close[close].mean() > 0.99, g_close[close].mean()
+
+
+def test_model_fit_with_minibatches_beyond_64_rows(tmp_path):
+    """BGM(use_bnn=True).fit(batch_size=128): any batch size in the reference (bgm/base.py:343); up to 256 rows here."""
+    from bayesgm_amd.models import BGM
+    n, p, q = 640, 12, 4
+    data = _linear_panel(n, p, q)
+    model = BGM(_params(tmp_path, p, q, bnn_mcmc_noise="frozen"), random_seed=7)
+    mse0 = float(model.evaluate(data, data_z=np.zeros((n, q), np.float32), use_x_sd=False))
+    model.fit(data, batch_size=128, epochs=40, epochs_per_eval=20, use_egm_init=True, egm_n_iter=40, egm_batches_per_eval=20, verbose=0)
+    assert model.history_loss[-1] < mse0 and np.isfinite(model.history_loss).all()
+    with pytest.raises(ValueError):
+        model.fit(data, batch_size=300, epochs=1, use_egm_init=False, verbose=0)
