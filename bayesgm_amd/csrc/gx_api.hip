@@ -17,6 +17,7 @@
 #include "bgm_host.h"
 #include "gx_fit_kernels.h"
 #include "gx_host.h"
+#include "bnf_det_host.h"
 
 namespace {
 
@@ -136,7 +137,10 @@ bool default_units(const int32_t *u, int n, bool fh) {
 bool gx_wanted(const bgm_handle *h) {
   if (force_gx()) return true;
   const bgm_causal_config &c = h->cfg;
-  return !(default_units(c.g_units, c.n_hidden_g, false) && default_units(c.f_units, c.n_hidden_f, true) && default_units(c.h_units, c.n_hidden_h, true));
+  if (!(default_units(c.g_units, c.n_hidden_g, false) && default_units(c.f_units, c.n_hidden_f, true) && default_units(c.h_units, c.n_hidden_h, true))) return true;
+  // default widths outside the LDS-resident shapes WITH a conditional latent prior (IdentifiableCausalBGM): the streamed-fragment
+  // kernels (bnf_det_api.hip) carry no prior table, this engine does
+  return h->prior_seg != nullptr && bnf_det_wanted(h);
 }
 bool gx_enc_wanted(const bgm_handle *h) {
   if (force_gx()) return true;

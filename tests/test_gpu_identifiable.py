@@ -22,7 +22,9 @@ def _prior(rs, k, q):
 
 @pytest.mark.parametrize("case", [dict(z_dims=[1, 1, 1, 7], p=200, binary=False, n=333),
                                   dict(z_dims=[3, 3, 6, 6], p=100, binary=True, n=200),
-                                  dict(z_dims=[1, 1, 1, 7], p=20, binary=False, n=50)])
+                                  dict(z_dims=[1, 1, 1, 7], p=20, binary=False, n=50),
+                                  # outside the LDS-resident shapes (sum(z_dims) = 20; v_dim = 300): served by the general-width engine
+                                  dict(z_dims=[5, 5, 5, 5], p=100, binary=False, n=90), dict(z_dims=[1, 1, 1, 7], p=300, binary=True, n=64)])
 def test_conditional_prior_log_posterior_and_chains(case):
     import torch
     rs = np.random.RandomState(3)

@@ -66,6 +66,39 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("shape,z_dims,p,binary", [("mixed", [2, 3, 4, 5], 77, False), ("w128", [1, 1, 1, 7], 200, True)])
+def test_conditional_prior_on_the_general_width_engine(shape, z_dims, p, binary):
+    """IdentifiableCausalBGM's per-row latent prior N(mu(u), sigma^2(u) I) (identifiable.py:541-551; bgm_causal_set_prior) in the
+    general-width engine's log posterior and chains, against oracle.causal(prior=...) -- the checks of test_gpu_identifiable.py."""
+    import torch
+    from oracle import identifiable as OI
+    rs = np.random.RandomState(3)
+    units = SHAPES[shape]
+    m = _model(5, z_dims, p, binary, **{k: list(v) for k, v in units.items()})
+    q, k, n = sum(z_dims), 7, 120
+    x, y, v = _data(n, p, 6, binary)
+    z = rs.randn(n, q).astype(np.float32)
+    seg = rs.randint(0, k, n)
+    pn = [(W, (0.3 * rs.randn(*b.shape)).astype(np.float32)) for W, b in OI.init_prior_net(rs, k, q)]
+    tab = OI.prior_table(pn, q)
+    mu, s2, _ = OI.prior_params([(W.astype(np.float64), b.astype(np.float64)) for W, b in pn], seg)
+    eng = _engine(m, units)
+    eng.set_prior(torch.from_numpy(seg.astype(np.int32)).cuda(), torch.from_numpy(tab).cuda())
+    m64, (x64, y64, v64, z64) = _as64(m, x, y, v, z)
+    lp = eng.logpost(x.ravel(), y.ravel(), v, z).cpu().numpy()
+    ref = OC.log_posterior(m64, x64, y64, v64, z64, prior=(mu, s2))
+    assert np.all(np.abs(lp - ref) <= 2e-6 * np.abs(ref) + 5e-4), np.abs(lp - ref).max()
+    std = OC.log_posterior(m64, x64, y64, v64, z64)
+    assert np.abs(ref - std).max() > 0.1                      # the prior matters in this test
+    out = eng.mh_sample(x, y, v, 30, 10, 0.4, 77, want_draws=True)
+    ref_draws = OC.mh_sampler(m, (x, y, v), 30, 10, 0.4, 77, prior=(mu.astype(np.float32), s2.astype(np.float32)))
+    same = np.all(np.abs(out["draws"].cpu().numpy()[-1] - ref_draws[-1]) <= 1e-4, axis=1).mean()
+    assert same >= 0.97, same
+    eng.set_prior(None, None)
+    lp0 = eng.logpost(x.ravel(), y.ravel(), v, z).cpu().numpy()
+    assert np.all(np.abs(lp0 - std) <= 2e-6 * np.abs(std) + 2e-4)          # cleared: back to N(0, I)
+
+
 @pytest.mark.parametrize("case", CASES)
 def test_logpost_matches_oracle(case):
     u = SHAPES[case["shape"]]
