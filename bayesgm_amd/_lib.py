@@ -57,7 +57,8 @@ class HmcArgs(C.Structure):
 class BnnConfig(C.Structure):
     _fields_ = [("v_dim", C.c_int32), ("z_dims", C.c_int32 * 4), ("binary_treatment", C.c_int32),
                 ("n_hidden", C.c_int32 * 4), ("units", (C.c_int32 * BGM_MAX_LAYERS) * 4),
-                ("kl_weight", C.c_float), ("max_batch", C.c_int32), ("norm_mode", C.c_int32)]
+                ("kl_weight", C.c_float), ("max_batch", C.c_int32), ("norm_mode", C.c_int32),
+                ("sigma_v", C.c_float), ("sigma_x", C.c_float), ("sigma_y", C.c_float)]
 
 
 class BvnConfig(C.Structure):

@@ -39,7 +39,7 @@ class BnnEngine(object):
     """One session: parameters of g, e, f, h with their Adam slots on the device, step and sampling kernels."""
 
     def __init__(self, v_dim, z_dims, binary_treatment=False, g_units=None, e_units=None, f_units=None, h_units=None,
-                 kl_weight=1e-4, max_batch=32, norm_mode=0, device=0):
+                 kl_weight=1e-4, max_batch=32, norm_mode=0, device=0, sigma_v=None, sigma_x=None, sigma_y=None):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("bayesgm_amd: no HIP device visible; the hot path has no CPU fallback")
@@ -64,6 +64,7 @@ class BnnEngine(object):
         cfg.kl_weight = float(kl_weight)
         cfg.max_batch = int(max_batch)
         cfg.norm_mode = int(norm_mode)          # 0: batch statistics (reference as written), 1: fixed mean 0 / variance 1
+        cfg.sigma_v, cfg.sigma_x, cfg.sigma_y = (float(sv) if sv else 0.0 for sv in (sigma_v, sigma_x, sigma_y))     # fixed likelihood sd (0: variance head)
         self.cfg = cfg
         z0, z1, z2, _ = self.z_dims
         ins = [self.q, self.v_dim, z0 + z1 + 1, z0 + z2]

@@ -217,6 +217,9 @@ int bnf_logpost(bgm_handle *h, BnnState *s, const float *x, const float *y, cons
   launch_signs(L, n, block_rows, block0, 1, 7, seed, stream_id, st->queue_dev, stream);
   BnfMhArgs a{};
   a.pl = P; a.blob = st->blob_dev; a.dw = st->dw_dev;
+  a.sig2_v = s->cfg.sigma_v > 0.0f ? s->cfg.sigma_v * s->cfg.sigma_v : 0.0f;      // fixed params['sigma_*'] (0: the variance heads)
+  a.sig2_x = s->cfg.sigma_x > 0.0f ? s->cfg.sigma_x * s->cfg.sigma_x : 0.0f;
+  a.sig2_y = s->cfg.sigma_y > 0.0f ? s->cfg.sigma_y * s->cfg.sigma_y : 0.0f;
   a.sg.g = L.g; a.sg.gout = L.gout; a.sg.h = L.h; a.sg.f = L.f;
   a.x = x; a.y = y; a.v = v; a.z = const_cast<float *>(z); a.n = n; a.row_base = 0;
   a.bs = block_rows; a.n_blocks = n_blocks; a.block0 = block0;
@@ -242,6 +245,7 @@ int effects_of(bgm_handle *h, BnfState *st, const float *z, long long n, int bs,
   launch_signs(L, n, bs, block0, n_doses, 4, seed, stream0, st->queue_dev + 8, stream);
   BnfEffArgs ea{};
   ea.pl = P; ea.eblob = st->eblob_dev; ea.dw = dw_eff; ea.sgf = L.f; ea.z = z; ea.n = n; ea.row_base = row_base;
+  { const BnnState *bs_ = static_cast<const BnnState *>(h->bnn_state); ea.sig2_y = (bs_ && bs_->cfg.sigma_y > 0.0f) ? bs_->cfg.sigma_y * bs_->cfg.sigma_y : 0.0f; }
   ea.bs = bs; ea.n_blocks = n_blocks; ea.block0 = block0;
   ea.groups_per_block = ((bs + 15) / 16 + c.R - 1) / c.R; ea.n_items = n_blocks * ea.groups_per_block; ea.n_doses = n_doses;
   ea.xvals = xvals; ea.k0 = (uint32_t)seed; ea.k1 = (uint32_t)(seed >> 32); ea.sample_y = sample_y; ea.it_noise = it_noise;
@@ -276,6 +280,9 @@ int bnf_mh_run(bgm_handle *h, BnnState *s, const bgm_bnn_mh_args *g, hipStream_t
   float *dw_eff_dev = st->dw_dev + dw_mh;
   BnfMhArgs a{};
   a.pl = P; a.blob = st->blob_dev; a.dw = st->dw_dev;
+  a.sig2_v = s->cfg.sigma_v > 0.0f ? s->cfg.sigma_v * s->cfg.sigma_v : 0.0f;      // fixed params['sigma_*'] (0: the variance heads)
+  a.sig2_x = s->cfg.sigma_x > 0.0f ? s->cfg.sigma_x * s->cfg.sigma_x : 0.0f;
+  a.sig2_y = s->cfg.sigma_y > 0.0f ? s->cfg.sigma_y * s->cfg.sigma_y : 0.0f;
   a.sg.g = L.g; a.sg.gout = L.gout; a.sg.h = L.h; a.sg.f = L.f;
   a.x = g->x_dev; a.y = g->y_dev; a.v = g->v_dev; a.z = g->state_dev; a.n = n; a.row_base = g->row_base;
   a.bs = bs; a.n_blocks = n_blocks; a.block0 = g->block0;

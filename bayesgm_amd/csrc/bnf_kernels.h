@@ -388,7 +388,7 @@ struct BnfMhArgs {
   unsigned *queue;                     // [8] item counters, one per XCD (zeroed by bnf_signs_kernel / by the host for deterministic nets)
   float *lp_cache;                     // deterministic nets, MODE 1: [n] log posterior of the current states (in / out)
   double *sums;                        // MODE 2: [3] += sum |v - mu_v|^2, sum (x - x_pred)^2, sum (y - mu_y)^2
-  float sig2_v, sig2_x, sig2_y;        // deterministic nets: fixed variances params['sigma_*']^2 (<= 0: the networks' variance heads)
+  float sig2_v, sig2_x, sig2_y;        // fixed variances params['sigma_*']^2 (<= 0: the networks' variance heads)
   unsigned long long *prof;            // -D BNF_PROF
 };
 
@@ -577,7 +577,7 @@ __device__ __forceinline__ void bnf_logpost_rows(const BnfMhArgs &a, const BnfLd
     if constexpr (EVAL) { aux[rt][0] = sum_over_g(ssq[rt]); part[rt] = 0.0f; lp[rt] = 0.0f; }
     else {
       const float rw = sum_over_g(rawv[rt]);
-      const float s2 = (DET && a.sig2_v > 0.0f) ? a.sig2_v : bnf_softplus(rw) + BGM_EPS;
+      const float s2 = (a.sig2_v > 0.0f) ? a.sig2_v : bnf_softplus(rw) + BGM_EPS;
       // the per-lane share of -(ssq / (2 s2) + |z|^2 / 2); the log term is added once after the cross-lane sum
       part[rt] = -(ssq[rt] * fast_rcp(2.0f * s2) + 0.5f * zz[rt]);
       lp[rt] = -0.5f * (float)p * fast_log(s2);
@@ -602,7 +602,7 @@ __device__ __forceinline__ void bnf_logpost_rows(const BnfMhArgs &a, const BnfLd
       if constexpr (EVAL) aux[rt][1] = m_;
       else if (P.binary) lp[rt] -= fmaxf(m_, 0.0f) - m_ * xr[rt] + bnf_softplus(-fabsf(m_));
       else {
-        const float s2 = (DET && a.sig2_x > 0.0f) ? a.sig2_x : bnf_softplus(raw[rt]) + BGM_EPS, d = xr[rt] - m_;
+        const float s2 = (a.sig2_x > 0.0f) ? a.sig2_x : bnf_softplus(raw[rt]) + BGM_EPS, d = xr[rt] - m_;
         lp[rt] -= d * d * fast_rcp(2.0f * s2) + 0.5f * fast_log(s2);
       }
     }
@@ -613,7 +613,7 @@ __device__ __forceinline__ void bnf_logpost_rows(const BnfMhArgs &a, const BnfLd
     for (int rt = 0; rt < R; ++rt) {
       if constexpr (EVAL) aux[rt][2] = mu[rt];
       else {
-        const float s2 = (DET && a.sig2_y > 0.0f) ? a.sig2_y : bnf_softplus(raw[rt]) + BGM_EPS, d = yr[rt] - mu[rt];
+        const float s2 = (a.sig2_y > 0.0f) ? a.sig2_y : bnf_softplus(raw[rt]) + BGM_EPS, d = yr[rt] - mu[rt];
         lp[rt] -= d * d * fast_rcp(2.0f * s2) + 0.5f * fast_log(s2);
       }
     }
@@ -874,7 +874,7 @@ struct BnfEffArgs {
   float *ite_out; long long ite_stride;
   unsigned *queue;                     // [8] item counters, one per XCD (zeroed by bnf_signs_kernel)
   float *fsum_out; long long fsum_slot_stride;   // deterministic API: per-workgroup partial sums [grid][...] += (bgm_adrf_reduce adds the slots)
-  float sig2_y;                        // deterministic nets: fixed params['sigma_y']^2 (<= 0: the variance head)
+  float sig2_y;                        // fixed params['sigma_y']^2 (<= 0: the variance head)
 };
 
 template <int KS, int R, int WAVES, bool DET = false>      // KS: k-steps of the outcome net's own first layer (BnfPlan::KSF or a larger compiled value)
@@ -980,7 +980,7 @@ static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_effects_kern
       for (int rt = 0; rt < R; ++rt) {
         float yk = mu[rt];
         if (a.sample_y) {
-          const float s2 = (DET && a.sig2_y > 0.0f) ? a.sig2_y : bnf_softplus(raw[rt]) + BGM_EPS;
+          const float s2 = (a.sig2_y > 0.0f) ? a.sig2_y : bnf_softplus(raw[rt]) + BGM_EPS;
           yk = fmaf(__builtin_sqrtf(s2), e == 0 ? nz[rt][0] : e == 1 ? nz[rt][1] : e == 2 ? nz[rt][2] : nz[rt][3], yk);
         }
         if (a.ite_out) {

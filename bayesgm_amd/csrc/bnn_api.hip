@@ -241,6 +241,9 @@ static void bnn_base_args(BnnState *s, BnnArgs &a, int batch, int batch_global, 
   a.binary = s->cfg.binary_treatment; a.wmax = s->wmax; a.kl_weight = s->cfg.kl_weight;
   a.k0 = (uint32_t)(seed & 0xFFFFFFFFull); a.k1 = (uint32_t)(seed >> 32); a.stream = stream_id;
   a.inv_B = 1.0f / (float)(batch_global > 0 ? batch_global : batch);
+  a.sig2[0] = s->cfg.sigma_v > 0.0f ? s->cfg.sigma_v * s->cfg.sigma_v : 0.0f;
+  a.sig2[1] = s->cfg.sigma_x > 0.0f ? s->cfg.sigma_x * s->cfg.sigma_x : 0.0f;
+  a.sig2[2] = s->cfg.sigma_y > 0.0f ? s->cfg.sigma_y * s->cfg.sigma_y : 0.0f;
   // data parallel: every rank adds its share of the KL term, the all-reduce (sum) restores kl_weight * KL
   if (batch_global > batch) a.kl_weight = s->cfg.kl_weight * (float)batch / (float)batch_global;
   a.ws = s->ws_dev; a.ws_stride = s->ws_stride;

@@ -467,6 +467,7 @@ struct BnnArgs {
   float *dz_part, *loss_part;            // z step: per-net partials [3][B x q], [3] (summed by bnn_z_combine_kernel)
   float *out;                            // theta: [loss_v, mse_v, loss_x, aux_x, loss_y, mse_y];  z: [loss_posterior]
   float *dz;                             // z step: [B x q] gradient w.r.t. the batch rows of data_z
+  float sig2[3];                         // fixed sigma_v^2, sigma_x^2, sigma_y^2 (params['sigma_*']); <= 0: the net's variance head
 };
 
 // gather the minibatch: zb [B x q], vb [B x p], xb, yb [B], f input [B x nf], h input [B x nh]
@@ -501,8 +502,15 @@ __device__ __forceinline__ void bnn_row_ssq(const BnnCtx &c, const float *v, con
   }
 }
 
-// Gaussian head: loss_b = ssq / (2 s2) + dim * log(s2) / 2 with s2 = softplus(raw) + 1e-6; returns d loss_b / d raw
-__device__ __forceinline__ float bnn_gauss(float ssq, float raw, float dim, float &loss_b, float &s2) {
+// Gaussian head: loss_b = ssq / (2 s2) + dim * log(s2) / 2 with s2 = softplus(raw) + 1e-6; returns d loss_b / d raw.
+// fix2 > 0: params['sigma_v' | 'sigma_x' | 'sigma_y'] given (causalbgm/base.py:161,195,224,257,268,283): s2 = sigma^2, the variance head
+// is not read and receives no gradient.
+__device__ __forceinline__ float bnn_gauss(float ssq, float raw, float dim, float &loss_b, float &s2, float fix2 = 0.0f) {
+  if (fix2 > 0.0f) {
+    s2 = fix2;
+    loss_b = ssq / (2.0f * s2) + dim * logf(s2) * 0.5f;
+    return 0.0f;
+  }
   s2 = softplus_acc(raw) + BGM_EPS;
   loss_b = ssq / (2.0f * s2) + dim * logf(s2) * 0.5f;
   return (-ssq / (2.0f * s2 * s2) + dim / (2.0f * s2)) * sigmoid_f(raw);
@@ -538,7 +546,7 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_step_kernel(BnnA
       for (int i = c.tid; i < B * wo; i += BNN_THREADS) {
         const int b = i / wo, j = i - b * wo;
         float lb, s2;
-        const float dr = bnn_gauss(ssq_row[b], o[b * wo + wo - 1], (float)p, lb, s2);
+        const float dr = bnn_gauss(ssq_row[b], o[b * wo + wo - 1], (float)p, lb, s2, a.sig2[0]);
         if (j < p) d[i] = -(bt.vb[b * p + j] - o[i]) / s2 * a.inv_B;
         else if (j == wo - 1) { d[i] = dr * a.inv_B; loss += lb; aux += ssq_row[b]; }
         else d[i] = 0.0f;
@@ -558,7 +566,7 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_step_kernel(BnnA
         } else {
           const float r = tgt[b] - l;
           float lb, s2;
-          const float dr = bnn_gauss(r * r, o[b * wo + wo - 1], 1.0f, lb, s2);
+          const float dr = bnn_gauss(r * r, o[b * wo + wo - 1], 1.0f, lb, s2, a.sig2[id == BNN_H ? 1 : 2]);
           loss += lb; aux += r * r;
           d[b * wo] = -r / s2 * a.inv_B;
           d[b * wo + wo - 1] += dr * a.inv_B;
@@ -621,7 +629,7 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_z_grad_kernel(BnnArgs 
       for (int i = c.tid; i < B * wo; i += BNN_THREADS) {
         const int b = i / wo, j = i - b * wo;
         float lb, s2;
-        bnn_gauss(ssq_row[b], o2[b * wo + wo - 1], (float)p, lb, s2);
+        bnn_gauss(ssq_row[b], o2[b * wo + wo - 1], (float)p, lb, s2, a.sig2[0]);
         d[i] = (j < p) ? -(bt.vb[b * p + j] - o1[i]) / s2 * a.inv_B : 0.0f;
         if (j == wo - 1) loss += lb;
       }
@@ -637,7 +645,7 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_z_grad_kernel(BnnArgs 
         } else {
           const float r = tgt[b] - l;
           float lb, s2;
-          bnn_gauss(r * r, o2[b * wo + wo - 1], 1.0f, lb, s2);
+          bnn_gauss(r * r, o2[b * wo + wo - 1], 1.0f, lb, s2, a.sig2[id == BNN_H ? 1 : 2]);
           loss += lb;
           d[b * wo] = -r / s2 * a.inv_B;
           ssq_row[b] = r * r;
@@ -652,7 +660,7 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_z_grad_kernel(BnnArgs 
       for (int i = c.tid; i < B * wo; i += BNN_THREADS) {
         const int b = i / wo, j = i - b * wo;
         float lb, s2;
-        d[i] = (j == wo - 1) ? bnn_gauss(ssq_row[b], o2[b * wo + wo - 1], dim, lb, s2) * a.inv_B : 0.0f;
+        d[i] = (j == wo - 1) ? bnn_gauss(ssq_row[b], o2[b * wo + wo - 1], dim, lb, s2, a.sig2[id == BNN_G ? 0 : (id == BNN_H ? 1 : 2)]) * a.inv_B : 0.0f;
       }
       __syncthreads();
       bnn_bwd(c, a.theta, a.grad, n, k2, d, ds, t0, t1, dx2, B, false, false);

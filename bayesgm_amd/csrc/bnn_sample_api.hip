@@ -122,6 +122,9 @@ static void bns_fill_mh(const BnnState *s, const BnsPlan &pl, BnsMhArgs &a) {
   a.z0 = s->cfg.z_dims[0]; a.z1 = s->cfg.z_dims[1]; a.z2 = s->cfg.z_dims[2];
   a.binary = s->cfg.binary_treatment;
   a.set_floats = pl.set_ghf;
+  a.sig2[0] = s->cfg.sigma_v > 0.0f ? s->cfg.sigma_v * s->cfg.sigma_v : 0.0f;
+  a.sig2[1] = s->cfg.sigma_x > 0.0f ? s->cfg.sigma_x * s->cfg.sigma_x : 0.0f;
+  a.sig2[2] = s->cfg.sigma_y > 0.0f ? s->cfg.sigma_y * s->cfg.sigma_y : 0.0f;
 }
 
 static void bns_noise(const BnsPlan &pl, const BnsBuf &b, const int *ids, int n_nets, int n_sets_blocks, int n_calls, long long set_floats,
@@ -201,7 +204,7 @@ extern "C" int bgm_bnn_mh_run(bgm_handle *h, const bgm_bnn_mh_args *g, void *str
       static const float pair_host[2] = {1.0f, 0.0f};
       BGM_HIP_CHECK(hipMemcpyAsync(b.pair, pair_host, sizeof(pair_host), hipMemcpyHostToDevice, stream));
     }
-    ea.f = pl.net[BNN_F]; ea.f.dbase = 0;
+    ea.f = pl.net[BNN_F]; ea.f.dbase = 0; ea.sig2_y = s->cfg.sigma_y > 0.0f ? s->cfg.sigma_y * s->cfg.sigma_y : 0.0f;
     ea.theta = s->theta_dev; ea.lf = b.lf; ea.dw = dw_eff; ea.set_floats = pl.set_f;
     ea.z = g->state_dev; ea.n = n; ea.row_base = g->row_base; ea.q = q; ea.z0 = s->cfg.z_dims[0]; ea.z1 = s->cfg.z_dims[1];
     ea.bs = bs; ea.wg_per_block = (bs + BNS_ROWS - 1) / BNS_ROWS; ea.block0 = g->block0; ea.n_doses = n_doses;
@@ -335,7 +338,7 @@ extern "C" int bgm_bnn_evaluate(bgm_handle *h, const float *x, const float *y, c
   if (nd) {
     float *dw_eff = b.dw + pl.set_all;
     BnsEffArgs ea{};
-    ea.f = pl.net[BNN_F]; ea.f.dbase = 0;
+    ea.f = pl.net[BNN_F]; ea.f.dbase = 0; ea.sig2_y = s->cfg.sigma_y > 0.0f ? s->cfg.sigma_y * s->cfg.sigma_y : 0.0f;
     if (!dose_sums) {
       static const float pair_host[2] = {1.0f, 0.0f};
       BGM_HIP_CHECK(hipMemcpyAsync(b.pair, pair_host, sizeof(pair_host), hipMemcpyHostToDevice, stream));
@@ -382,7 +385,7 @@ extern "C" int bgm_bnn_effects(bgm_handle *h, const float *draws, int64_t n, int
     BGM_HIP_CHECK(hipMemcpyAsync(b.pair, pair_host, sizeof(pair_host), hipMemcpyHostToDevice, stream));
   }
   BnsEffArgs ea{};
-  ea.f = pl.net[BNN_F]; ea.f.dbase = 0;
+  ea.f = pl.net[BNN_F]; ea.f.dbase = 0; ea.sig2_y = s->cfg.sigma_y > 0.0f ? s->cfg.sigma_y * s->cfg.sigma_y : 0.0f;
   ea.theta = s->theta_dev; ea.lf = b.lf; ea.dw = b.dw; ea.set_floats = pl.set_f;
   ea.n = n; ea.row_base = row_base; ea.q = q; ea.z0 = s->cfg.z_dims[0]; ea.z1 = s->cfg.z_dims[1];
   ea.bs = bs; ea.wg_per_block = (bs + BNS_ROWS - 1) / BNS_ROWS; ea.block0 = block0; ea.n_doses = nd;

@@ -453,6 +453,7 @@ __device__ __forceinline__ void bns_forward(const BnsCtx &c, const BnsNet &n, co
 // log-posterior of a block-structured panel / one Metropolis-Hastings iteration
 // ---------------------------------------------------------------------------------------------
 struct BnsMhArgs {
+  float sig2[3];                       // fixed sigma_v^2, sigma_x^2, sigma_y^2 (params['sigma_*']); <= 0: the variance heads
   BnsNet net[4];                       // g, e, f, h (BNN_* ids); e unused here
   const float *theta, *lf;
   const float *dw;                     // [n_blocks * n_calls][set_floats]
@@ -523,7 +524,7 @@ __device__ __forceinline__ void bns_logpost_rows(const BnsCtx &c, const BnsMhArg
 #pragma unroll
   for (int rt = 0; rt < BNS_R; ++rt) {
     const float s = sum_over_g(ssq[rt]), rw = sum_over_g(raw[rt]);
-    const float s2 = softplus_acc(rw) + BGM_EPS;
+    const float s2 = a.sig2[0] > 0.0f ? a.sig2[0] : softplus_acc(rw) + BGM_EPS;
     lp[rt] = -(s / (2.0f * s2) + (float)p * logf(s2) * 0.5f);
   }
   // ---- h: treatment model, input (z0, z2)
@@ -538,7 +539,7 @@ __device__ __forceinline__ void bns_logpost_rows(const BnsCtx &c, const BnsMhArg
   for (int rt = 0; rt < BNS_R; ++rt) {
     const float m_ = sum_over_g(mu[rt]), rw = sum_over_g(raw[rt]);
     if (a.binary) lp[rt] -= fmaxf(m_, 0.0f) - m_ * xr[rt] + log1pf(expf(-fabsf(m_)));
-    else { const float s2 = softplus_acc(rw) + BGM_EPS, d = xr[rt] - m_; lp[rt] -= d * d / (2.0f * s2) + logf(s2) * 0.5f; }
+    else { const float s2 = a.sig2[1] > 0.0f ? a.sig2[1] : softplus_acc(rw) + BGM_EPS, d = xr[rt] - m_; lp[rt] -= d * d / (2.0f * s2) + logf(s2) * 0.5f; }
   }
   // ---- f: outcome model, input (z0, z1, x)
 #pragma unroll
@@ -553,7 +554,7 @@ __device__ __forceinline__ void bns_logpost_rows(const BnsCtx &c, const BnsMhArg
 #pragma unroll
   for (int rt = 0; rt < BNS_R; ++rt) {
     const float m_ = sum_over_g(mu[rt]), rw = sum_over_g(raw[rt]);
-    const float s2 = softplus_acc(rw) + BGM_EPS, d = yr[rt] - m_;
+    const float s2 = a.sig2[2] > 0.0f ? a.sig2[2] : softplus_acc(rw) + BGM_EPS, d = yr[rt] - m_;
     lp[rt] -= d * d / (2.0f * s2) + logf(s2) * 0.5f;
     float zz = 0.0f;
     for (int u = 0; u < q; ++u) { const float t = zsrc[row[rt] * q + u]; zz = fmaf(t, t, zz); }
@@ -636,6 +637,7 @@ static __global__ __launch_bounds__(BNS_THREADS, 4) void bns_mh_kernel(BnsMhArgs
 // (mean = dose, variance = 0): this is what the reference computes with use_bnn, and what is computed here.
 // ---------------------------------------------------------------------------------------------
 struct BnsEffArgs {
+  float sig2_y;                        // fixed sigma_y^2 (params['sigma_y']); <= 0: the variance head
   BnsNet f;                            // dbase = 0: sets hold the outcome net only
   const float *theta, *lf;             // lf: packed loc of all nets (f.fbase applies)
   const float *dw;                     // [n_blocks * n_doses][set_floats]
@@ -936,7 +938,7 @@ static __global__ __launch_bounds__(BNS_THREADS, 4) void bns_effects_kernel(BnsE
       BNS_T(c, 3);
       float yk = sum_over_g(mu);
       if (a.sample_y) {
-        const float s2 = softplus_acc(sum_over_g(raw)) + BGM_EPS;
+        const float s2 = a.sig2_y > 0.0f ? a.sig2_y : softplus_acc(sum_over_g(raw)) + BGM_EPS;
         const int e = k & 3;
         yk = fmaf(sqrtf(s2), e == 0 ? nz[0][0] : e == 1 ? nz[0][1] : e == 2 ? nz[0][2] : nz[0][3], yk);
       }
@@ -982,7 +984,7 @@ static __global__ __launch_bounds__(BNS_THREADS, 4) void bns_effects_kernel(BnsE
     for (int rt = 0; rt < BNS_R; ++rt) {
       float yk = sum_over_g(mu[rt]);
       if (a.sample_y) {
-        const float s2 = softplus_acc(sum_over_g(raw[rt])) + BGM_EPS;
+        const float s2 = a.sig2_y > 0.0f ? a.sig2_y : softplus_acc(sum_over_g(raw[rt])) + BGM_EPS;
         const int e = k & 3;
         yk = fmaf(sqrtf(s2), e == 0 ? nz[rt][0] : e == 1 ? nz[rt][1] : e == 2 ? nz[rt][2] : nz[rt][3], yk);
       }

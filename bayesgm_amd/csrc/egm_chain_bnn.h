@@ -776,7 +776,12 @@ __device__ __forceinline__ void ecb_gen_dw(const Args &a, const EcbTab &tab, con
 // Calls of the theta step: [0] g, [1] h, [2] f (one noise stream); of the latent step: [0,1] g, [2,3] h, [4,5] f (mean call on the
 // step's stream, variance-head call on stream + 1; a binary treatment head has no variance call).
 // =============================================================================================
-__device__ __forceinline__ float ecb_gauss(float ssq, float raw, float dim, float &loss_b, float &s2) {   // bnn_gauss
+__device__ __forceinline__ float ecb_gauss(float ssq, float raw, float dim, float &loss_b, float &s2, float fix2) {   // bnn_gauss
+  if (fix2 > 0.0f) {          // fixed params['sigma_*']: the variance head is not read and gets no gradient
+    s2 = fix2;
+    loss_b = ssq / (2.0f * s2) + dim * logf(s2) * 0.5f;
+    return 0.0f;
+  }
   s2 = softplus_acc(raw) + BGM_EPS;
   loss_b = ssq / (2.0f * s2) + dim * logf(s2) * 0.5f;
   return (-ssq / (2.0f * s2 * s2) + dim / (2.0f * s2)) * sigmoid_f(raw);
@@ -919,7 +924,7 @@ __device__ __forceinline__ void ecb_theta_chain(const Args &a, const EcbTab &tab
 #pragma unroll
       for (int k = 0; k < NW; ++k) { ssq += pp[k * 16 + j]; raw += pp[64 + k * 16 + j]; }
       float lb, s2;
-      const float dr = ecb_gauss(ssq, raw, (float)p, lb, s2);
+      const float dr = ecb_gauss(ssq, raw, (float)p, lb, s2, a.sig2[0]);
       if (wk == 0) { ls0 = lb; ls1 = ssq; }
       f32x4 douts[4];
 #pragma unroll
@@ -988,7 +993,7 @@ __device__ __forceinline__ void ecb_theta_chain(const Args &a, const EcbTab &tab
       ssq = sum_over_g(ssq);
       const float raw = ecb_pick<NTL>(o, p, g);
       float lb, s2;
-      const float dr = ecb_gauss(ssq, raw, (float)p, lb, s2);
+      const float dr = ecb_gauss(ssq, raw, (float)p, lb, s2, a.sig2[0]);
 #pragma unroll
       for (int t = 0; t < NTL; ++t)
 #pragma unroll
@@ -1015,7 +1020,7 @@ __device__ __forceinline__ void ecb_theta_chain(const Args &a, const EcbTab &tab
       } else {
         const float r_ = tgt - l;
         float lb, s2;
-        const float dr = ecb_gauss(r_ * r_, raw, 1.0f, lb, s2);
+        const float dr = ecb_gauss(r_ * r_, raw, 1.0f, lb, s2, a.sig2[is_h ? 1 : 2]);
         ls0 = lb; ls1 = r_ * r_;
         d0 = -r_ / s2 * a.inv_B;
         dl = dr * a.inv_B;
@@ -1224,7 +1229,7 @@ __device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, fl
       __threadfence_block();
       const float raw = xch[B + j];
       float lb, s2;
-      ecb_gauss(ssq, raw, (float)p, lb, s2);
+      ecb_gauss(ssq, raw, (float)p, lb, s2, a.sig2[0]);
       f32x4 douts[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -1295,7 +1300,7 @@ __device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, fl
       __threadfence_block();
       const float raw = xch[B + lrow];
       float lb, s2;
-      ecb_gauss(ssq, raw, (float)p, lb, s2);
+      ecb_gauss(ssq, raw, (float)p, lb, s2, a.sig2[0]);
       lsum = lb;
 #pragma unroll
       for (int t = 0; t < NTL; ++t)
@@ -1337,7 +1342,7 @@ __device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, fl
       __threadfence_block();
       const float ssq = xch[lrow];
       float lb, s2;
-      const float dr = ecb_gauss(ssq, raw, (float)p, lb, s2);
+      const float dr = ecb_gauss(ssq, raw, (float)p, lb, s2, a.sig2[0]);
       f32x4 d1[1], d1s[1];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -1371,7 +1376,7 @@ __device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, fl
       __threadfence_block();
       const float ssq = xch[lrow];
       float lb, s2;
-      const float dr = ecb_gauss(ssq, raw, (float)p, lb, s2);
+      const float dr = ecb_gauss(ssq, raw, (float)p, lb, s2, a.sig2[0]);
 #pragma unroll
       for (int t = 0; t < NTL; ++t)
 #pragma unroll
@@ -1395,7 +1400,7 @@ __device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, fl
       } else {
         const float raw = ecb_pick<1>(o2, wo - 1, g), r_ = tgt - l;
         float lb, s2;
-        const float dr = ecb_gauss(r_ * r_, raw, 1.0f, lb, s2);
+        const float dr = ecb_gauss(r_ * r_, raw, 1.0f, lb, s2, a.sig2[is_h ? 1 : 2]);
         lsum = lb;
         d0 = -r_ / s2 * a.inv_B;
         dl = dr * a.inv_B;

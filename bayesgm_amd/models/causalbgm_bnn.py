@@ -46,9 +46,9 @@ class CausalBGMBayes(CausalBGM):
         p = dict(_DEFAULTS)
         p.update(params)
         self._p = p
-        for k in ("sigma_v", "sigma_x", "sigma_y"):
-            if k in params:
-                raise NotImplementedError("bayesgm_amd: fixed %s together with use_bnn=True is not built" % k)
+        for k in ("sigma_v", "sigma_x", "sigma_y"):          # fixed likelihood standard deviations (base.py:161,195,224): > 0
+            if k in params and not float(params[k]) > 0.0:
+                raise ValueError("params['%s'] must be positive" % k)
         self._bnn_norm = p.get("bnn_norm", BNN_NORM_DEFAULT)
         if self._bnn_norm not in ("batch", "fixed"):
             raise ValueError("params['bnn_norm'] must be 'batch' or 'fixed'")
@@ -78,7 +78,8 @@ class CausalBGMBayes(CausalBGM):
             device = int(os.environ.get("BGM_DEVICE", os.environ.get("LOCAL_RANK", 0)))
         self.engine = BnnEngine(p["v_dim"], z, binary_treatment=p["binary_treatment"], g_units=p["g_units"], e_units=p["e_units"],
                                 f_units=p["f_units"], h_units=p["h_units"], kl_weight=p["kl_weight"], max_batch=256,
-                                norm_mode={"batch": 0, "fixed": 1}[self._bnn_norm], device=device)
+                                norm_mode={"batch": 0, "fixed": 1}[self._bnn_norm], device=device,
+                                sigma_v=params.get("sigma_v"), sigma_x=params.get("sigma_x"), sigma_y=params.get("sigma_y"))
         self.engine.set_disc_norm(_disc_norm(p))
         self.engine.begin(self.nets)
         if self.timestamp is None:

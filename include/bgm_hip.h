@@ -511,11 +511,14 @@ typedef struct {
   int32_t n_hidden[4];                           /* hidden layers of g, e, f, h (BGM_BNN_* order)                */
   int32_t units[4][BGM_MAX_LAYERS];              /* params['g_units'], ['e_units'], ['f_units'], ['h_units']      */
   float kl_weight;                               /* params['kl_weight'], base.py:171-173                          */
-  int32_t max_batch;                             /* largest minibatch of the step kernels (<= 64)                 */
+  int32_t max_batch;                             /* largest minibatch of the step kernels (<= 256)                */
   int32_t norm_mode;                             /* input BatchNormalization: 0 = statistics of the batch at hand (the
                                                     reference as written: inner layer called inside call(training=True));
                                                     1 = fixed mean 0 / variance 1 (inference mode on never-updated moving
                                                     averages: the alternative reading, keeps a constant treatment column) */
+  float sigma_v, sigma_x, sigma_y;               /* params['sigma_v' | 'sigma_x' | 'sigma_y'] (base.py:161,195,224,257,268,283,698): > 0 = the
+                                                    fixed standard deviation of that likelihood (the net's variance head is then
+                                                    neither read nor trained by the data terms); 0 = the variance head                 */
 } bgm_bnn_config;
 
 /* Open a session.  theta_host: `count` floats in the layout above (count from bgm_bnn_layout). */

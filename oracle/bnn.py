@@ -254,7 +254,12 @@ def _scatter_dz(m, dz, dfin=None, dhin=None):
     return dz
 
 
-def _gauss(ssq, s_raw, dim, Bn, t):
+def _gauss(ssq, s_raw, dim, Bn, t, fixed=None):
+    """fixed: params['sigma_v' | 'sigma_x' | 'sigma_y'] (causalbgm/base.py:161,195,224,257,268,283): the variance is sigma^2, the
+    variance head is not read (zero gradient)."""
+    if fixed is not None:
+        s2 = np.full_like(ssq, t(fixed) * t(fixed))
+        return ssq / (2 * s2) + t(dim) * np.log(s2) / 2, s2, np.zeros_like(ssq)
     s2 = softplus(s_raw) + t(EPS)
     loss_b = ssq / (2 * s2) + t(dim) * np.log(s2) / 2
     ds_raw = (-ssq / (2 * s2 * s2) + t(dim) / (2 * s2)) / t(Bn) * sigmoid(s_raw)
@@ -274,7 +279,7 @@ def theta_step(m, name, z, x, y, v, noise, kl_weight):
     if name == "g":
         p = m["v_dim"]
         d = v - out[:, :p]
-        loss_b, s2, ds = _gauss((d ** 2).sum(axis=1), out[:, -1], p, Bn, t)
+        loss_b, s2, ds = _gauss((d ** 2).sum(axis=1), out[:, -1], p, Bn, t, m.get("sigma_v"))
         dout[:, :p] = -d / s2[:, None] / t(Bn)
         dout[:, -1] = ds
         loss, aux = loss_b.mean(), (d ** 2).mean()
@@ -286,7 +291,7 @@ def theta_step(m, name, z, x, y, v, noise, kl_weight):
     else:
         tgt = x if name == "h" else y
         d = tgt[:, 0] - out[:, 0]
-        loss_b, s2, ds = _gauss(d ** 2, out[:, -1], 1, Bn, t)
+        loss_b, s2, ds = _gauss(d ** 2, out[:, -1], 1, Bn, t, m.get("sigma_x" if name == "h" else "sigma_y"))
         dout[:, 0] = -d / s2 / t(Bn)
         dout[:, -1] = ds
         loss, aux = loss_b.mean(), (d ** 2).mean()
@@ -309,7 +314,7 @@ def z_step(m, z, x, y, v, noises):
     o1, c1 = forward(m["g"], z, noises["g"][0])
     o2, c2 = forward(m["g"], z, noises["g"][1])
     d = v - o1[:, :p]
-    loss_b, s2, ds = _gauss((d ** 2).sum(axis=1), o2[:, -1], p, Bn, t)
+    loss_b, s2, ds = _gauss((d ** 2).sum(axis=1), o2[:, -1], p, Bn, t, m.get("sigma_v"))
     total = total + loss_b.mean()
     do1 = np.zeros_like(o1); do1[:, :p] = -d / s2[:, None] / t(Bn)
     do2 = np.zeros_like(o2); do2[:, -1] = ds
@@ -325,7 +330,7 @@ def z_step(m, z, x, y, v, noises):
     else:
         o2, c2 = forward(m["h"], hin, noises["h"][1])
         d = x[:, 0] - o1[:, 0]
-        loss_b, s2, ds = _gauss(d ** 2, o2[:, -1], 1, Bn, t)
+        loss_b, s2, ds = _gauss(d ** 2, o2[:, -1], 1, Bn, t, m.get("sigma_x"))
         total = total + loss_b.mean()
         do1[:, 0] = -d / s2 / t(Bn)
         do2 = np.zeros_like(o2); do2[:, -1] = ds
@@ -334,7 +339,7 @@ def z_step(m, z, x, y, v, noises):
     o1, c1 = forward(m["f"], fin, noises["f"][0])
     o2, c2 = forward(m["f"], fin, noises["f"][1])
     d = y[:, 0] - o1[:, 0]
-    loss_b, s2, ds = _gauss(d ** 2, o2[:, -1], 1, Bn, t)
+    loss_b, s2, ds = _gauss(d ** 2, o2[:, -1], 1, Bn, t, m.get("sigma_y"))
     total = total + loss_b.mean()
     do1 = np.zeros_like(o1); do1[:, 0] = -d / s2 / t(Bn)
     do2 = np.zeros_like(o2); do2[:, -1] = ds
@@ -352,15 +357,15 @@ def log_posterior(m, x, y, v, z, noises, stats=None):
     og, _ = forward(m["g"], z, noises["g"], st.get("g"))
     oh, _ = forward(m["h"], hin, noises["h"], st.get("h"))
     of, _ = forward(m["f"], fin, noises["f"], st.get("f"))
-    s2v = softplus(og[:, -1]) + t(EPS)
+    s2v = softplus(og[:, -1]) + t(EPS) if m.get("sigma_v") is None else t(m["sigma_v"]) ** 2
     lv = ((v - og[:, :p]) ** 2).sum(axis=1) / (2 * s2v) + t(p) * np.log(s2v) / 2
     if m["binary_treatment"]:
         l = oh[:, 0]
         lx = np.maximum(l, 0) - l * x[:, 0] + np.log1p(np.exp(-np.abs(l)))
     else:
-        s2x = softplus(oh[:, -1]) + t(EPS)
+        s2x = softplus(oh[:, -1]) + t(EPS) if m.get("sigma_x") is None else t(m["sigma_x"]) ** 2
         lx = (x[:, 0] - oh[:, 0]) ** 2 / (2 * s2x) + np.log(s2x) / 2
-    s2y = softplus(of[:, -1]) + t(EPS)
+    s2y = softplus(of[:, -1]) + t(EPS) if m.get("sigma_y") is None else t(m["sigma_y"]) ** 2
     ly = (y[:, 0] - of[:, 0]) ** 2 / (2 * s2y) + np.log(s2y) / 2
     return -(lv + lx + ly + (z ** 2).sum(axis=1) / 2)
 
@@ -420,7 +425,7 @@ def effects_draw(m, z, xvals, d, n_keep_iter, sample_y, seed, block_rows, block0
             o, _ = forward(m["f"], inp, noise)
             yk = o[:, 0]
             if sample_y:
-                yk = yk + np.sqrt(softplus(o[:, 1]) + t(EPS)) * nz[lo:hi, k]
+                yk = yk + (np.sqrt(softplus(o[:, 1]) + t(EPS)) if m.get("sigma_y") is None else t(m["sigma_y"])) * nz[lo:hi, k]
             out[k, lo:hi] = yk
     return out
 

@@ -34,7 +34,8 @@ def _panel(m, n, seed=1):
 
 def _engine(m, max_batch=32, kl_weight=1e-4, **units):
     from bayesgm_amd.bnn_engine import BnnEngine
-    eng = BnnEngine(m["v_dim"], m["z_dims"], m["binary_treatment"], kl_weight=kl_weight, max_batch=max_batch, **units)
+    eng = BnnEngine(m["v_dim"], m["z_dims"], m["binary_treatment"], kl_weight=kl_weight, max_batch=max_batch,
+                    sigma_v=m.get("sigma_v"), sigma_x=m.get("sigma_x"), sigma_y=m.get("sigma_y"), **units)
     eng.begin(m)
     return eng
 
@@ -601,3 +602,72 @@ def test_fit_with_minibatches_beyond_64_rows(tmp_path):
     assert np.isfinite([mx1, my1, mv1]).all() and mv1 < mv0
     with pytest.raises(Exception):
         model.fit((x, y, v), epochs=1, batch_size=300, use_egm_init=False, verbose=0)
+
+
+@pytest.mark.parametrize("fixed_norm,p,B", [(True, 100, 32), (True, 100, 16), (False, 50, 19), (True, 50, 40)])
+def test_fixed_sigmas_with_bayesian_nets(fixed_norm, p, B):
+    """params['sigma_v' | 'sigma_x' | 'sigma_y'] with use_bnn=True (causalbgm/base.py:161,195,224 theta steps, :257,268,283 latent step,
+    :698 outcome noise, :765-817 log posterior): the likelihood variances are the given constants, the variance heads are neither read
+    nor trained by the data terms.  Row-tile chains (p = 100, B = 16 / 32), the one-workgroup-per-net kernels, both sampling families."""
+    m = _model(False, p=p, fixed=fixed_norm)
+    m.update(sigma_v=0.8, sigma_x=1.3, sigma_y=0.6)
+    n = 160
+    z, x, y, v = _panel(m, n)
+    eng = _engine(m, max_batch=max(32, B), kl_weight=0.01, **(dict(norm_mode=1) if fixed_norm else {}))
+    dev = eng.device
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    m64 = OB.cast_model(m, np.float64)
+    f64 = lambda a: a.astype(np.float64)
+    idx = np.random.RandomState(4).choice(n, B, replace=False).astype(np.int32)
+    seed, stream = (5 << 32) | 77, 12
+    # theta step
+    out = torch.zeros(8, device=dev)
+    eng.theta_step(T(z), T(idx), T(x[:, 0]), T(y[:, 0]), T(v), 1e-3, seed, stream, apply=False, out=out)
+    grad = eng.split(eng.read(1))
+    o = out.cpu().numpy()
+    for w, name in enumerate(("g", "h", "f")):
+        noise = OB.draw_noise(OB.net_dims(m[name]), B, seed, stream, OB.NET_ID[name], dtype=np.float64)
+        loss, aux, g = OB.theta_step(m64, name, f64(z[idx]), f64(x[idx]), f64(y[idx]), f64(v[idx]), noise, 0.01)
+        assert abs(o[2 * w] - loss) < 2e-4 * max(1.0, abs(loss)), (name, o[2 * w], loss)
+        got = [grad[name]["gamma"], grad[name]["beta"]] + [a for L in grad[name]["layers"] for a in L]
+        for a, b in zip(got, OB.flat_grads(g)):
+            assert _rel(a, b) < 2e-3, (name, a.shape, _rel(a, b))
+    # latent step
+    out = torch.zeros(4, device=dev)
+    dz = torch.zeros(B, sum(m["z_dims"]), device=dev)
+    eng.z_step(T(x[:, 0]), T(y[:, 0]), T(v), T(z), None, None, T(idx), 1e-3, seed, stream + 20, out=out, dz_out=dz)
+    noises = {k: tuple(OB.draw_noise(OB.net_dims(m[k]), B, seed, stream + 20 + c, OB.NET_ID[k], dtype=np.float64) for c in (0, 1))
+              for k in ("g", "h", "f")}
+    loss, ref = OB.z_step(m64, f64(z[idx]), f64(x[idx]), f64(y[idx]), f64(v[idx]), noises)
+    assert abs(float(out[0]) - loss) < 2e-4 * abs(loss)
+    assert _rel(dz.cpu().numpy(), ref) < 2e-3
+    # log posterior on blocks, and its value changes with the fixed scale (the option is live)
+    bs = 64
+    got = eng.logpost(T(x[:, 0]), T(y[:, 0]), T(v), T(z), bs, seed, 77, block0=2).cpu().numpy()
+    ref = OB.log_posterior_blocks(m64, f64(x), f64(y), f64(v), f64(z), bs, seed, 77, block0=2)
+    assert np.abs(got - ref).max() < 2e-3 * np.abs(ref).max(), np.abs(got - ref).max()
+    free = dict(m64); [free.pop(k) for k in ("sigma_v", "sigma_x", "sigma_y")]
+    assert np.abs(OB.log_posterior_blocks(free, f64(x), f64(y), f64(v), f64(z), bs, seed, 77, block0=2) - ref).max() > 1.0
+    # outcome draws of the effects pass use sigma_y
+    keep = 2
+    draws = T(np.stack([z, z[::-1].copy()]))
+    xs = np.array([0.0, 1.1, 2.4], np.float32)
+    alone = eng.effects(draws, bs, seed, it0=3, x_values=xs, sample_y=True, row_base=40, block0=1).cpu().numpy()
+    for d in range(keep):
+        refd = OB.effects_draw(m64, f64(draws[d].cpu().numpy()), f64(xs), d, 3 + d, True, seed, bs, block0=1, row_base=40)
+        assert np.abs(alone[:, d] - refd.mean(axis=1)).max() < 5e-4, (d, alone[:, d], refd.mean(axis=1))
+    eng.close()
+
+
+def test_class_accepts_fixed_sigmas_with_bayesian_nets(tmp_path):
+    from bayesgm_amd.models import CausalBGM
+    from bayesgm_amd.datasets import Sim_Hirano_Imbens_sampler
+    x, y, v = Sim_Hirano_Imbens_sampler(N=400, v_dim=20, seed=0).load_all()
+    prm = dict(_params(tmp_path, False), sigma_v=1.0, sigma_y=0.5)
+    model = CausalBGM(prm, random_seed=3)
+    assert model.engine.cfg.sigma_v == 1.0 and model.engine.cfg.sigma_x == 0.0 and model.engine.cfg.sigma_y == 0.5
+    model.fit((x, y, v), epochs=2, epochs_per_eval=2, batch_size=32, use_egm_init=True, egm_n_iter=20, egm_batches_per_eval=20, verbose=0)
+    eff, interval = model.predict((x, y, v), alpha=0.05, n_mcmc=20, burn_in=20, x_values=np.linspace(0, 3, 4), q_sd=0.5, bs=128, verbose=0)
+    assert eff.shape == (4,) and np.isfinite(eff).all() and np.isfinite(interval).all()
+    with pytest.raises(ValueError):
+        CausalBGM(dict(prm, sigma_x=-1.0), random_seed=3)
