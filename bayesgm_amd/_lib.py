@@ -134,6 +134,10 @@ SYMBOLS = {
     "bgm_prior_table": (C.c_int, [C.c_void_p, C.POINTER(PriorConfig), C.c_void_p, C.c_void_p, C.c_void_p]),
     "bgm_prior_step": (C.c_int, [C.c_void_p, C.POINTER(PriorConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "bgm_prior_grad": (C.c_int, [C.c_void_p, C.POINTER(PriorConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                 C.c_void_p, C.c_float, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bgm_prior_apply": (C.c_int, [C.c_void_p, C.POINTER(PriorConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64,
+                                  C.c_void_p]),
     "bgm_causal_describe": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32]),
     "bgm_causal_fit_z_sync": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p]),
     "bgm_causal_fit_epoch": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -118,28 +118,57 @@ extern "C" int bgm_prior_table(bgm_handle *h, const bgm_prior_config *cfg, const
   return BGM_OK;
 }
 
-extern "C" int bgm_prior_step(bgm_handle *h, const bgm_prior_config *cfg, float *theta_dev, float *m_dev, float *v_dev, const int32_t *seg_dev,
-                              float *data_z_dev, const int32_t *idx_dev, int32_t batch, const float *dz_dev, float lr_z, float lr_prior,
-                              int64_t t_z, int64_t t_prior, float *out_dev, void *stream_) {
-  if (!h || !h->configured || !theta_dev || !m_dev || !v_dev || !seg_dev || !data_z_dev || !idx_dev || !dz_dev || batch < 1 || t_z < 1 || t_prior < 1) {
-    bgm_set_error("bgm_prior_step: bad argument"); return BGM_E_INVALID;
+static int prior_step_impl(bgm_handle *h, const bgm_prior_config *cfg, float *theta_dev, float *m_dev, float *v_dev, const int32_t *seg_dev,
+                           float *data_z_dev, const int32_t *idx_dev, int32_t batch, int32_t batch_global, const float *dz_dev, float lr_z,
+                           float lr_prior, int64_t t_z, int64_t t_prior, float *grad_dev, int apply, float *out_dev, void *stream_, const char *who) {
+  if (!h || !h->configured || !theta_dev || (apply && (!m_dev || !v_dev)) || !seg_dev || !data_z_dev || !idx_dev || !dz_dev || batch < 1 ||
+      batch_global < batch || t_z < 1 || (apply && t_prior < 1) || (!apply && !grad_dev)) {
+    bgm_set_error(std::string(who) + ": bad argument"); return BGM_E_INVALID;
   }
   PriorNet n; int lf;
-  int rc = prior_net_of(cfg, batch, n, lf, "bgm_prior_step");
+  int rc = prior_net_of(cfg, batch, n, lf, who);
   if (rc) return rc;
   const int q = h->q;
-  if (n.dims[n.n_layers] != q + 1) { bgm_set_error("bgm_prior_step: the prior net must end in q + 1 outputs"); return BGM_E_INVALID; }
+  if (n.dims[n.n_layers] != q + 1) { bgm_set_error(std::string(who) + ": the prior net must end in q + 1 outputs"); return BGM_E_INVALID; }
   const size_t bytes = ((size_t)lf + (size_t)batch * q + 2 * (size_t)batch * n.wmax + 3 * (size_t)batch) * 4;
-  if (bytes > 150 * 1024) { bgm_set_error("bgm_prior_step: minibatch x prior-net widths exceed one workgroup's LDS"); return BGM_E_UNSUPPORTED; }
+  if (bytes > 150 * 1024) { bgm_set_error(std::string(who) + ": minibatch x prior-net widths exceed one workgroup's LDS"); return BGM_E_UNSUPPORTED; }
   auto lr_t = [](double lr, double t) { return (float)(lr * std::sqrt(1.0 - std::pow(0.99, t)) / (1.0 - std::pow(0.9, t))); };
   PriorStepArgs a{};
   a.net = n; a.theta = theta_dev; a.m = m_dev; a.v = v_dev; a.seg = seg_dev; a.data_z = data_z_dev; a.idx = idx_dev; a.dz = dz_dev;
-  a.B = batch; a.q = q; a.lr_t_z = lr_t(lr_z, (double)t_z); a.lr_t_p = lr_t(lr_prior, (double)t_prior);
+  a.B = batch; a.q = q; a.lr_t_z = lr_t(lr_z, (double)t_z); a.lr_t_p = apply ? lr_t(lr_prior, (double)t_prior) : 0.0f;
   a.b1 = 0.9f; a.b2 = 0.99f; a.eps = 1e-7f;        // tf.keras.optimizers.Adam(lr, beta_1=0.9, beta_2=0.99), identifiable.py:88-95
-  a.out = out_dev;
+  a.out = out_dev; a.inv_B = 1.0f / (float)batch_global; a.grad = grad_dev; a.apply = apply;
   BGM_HIP_CHECK(hipSetDevice(h->device));
   BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(prior_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   hipLaunchKernelGGL(prior_step_kernel, dim3(1), dim3(PRIOR_THREADS), bytes, (hipStream_t)stream_, a);
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+extern "C" int bgm_prior_step(bgm_handle *h, const bgm_prior_config *cfg, float *theta_dev, float *m_dev, float *v_dev, const int32_t *seg_dev,
+                              float *data_z_dev, const int32_t *idx_dev, int32_t batch, const float *dz_dev, float lr_z, float lr_prior,
+                              int64_t t_z, int64_t t_prior, float *out_dev, void *stream_) {
+  return prior_step_impl(h, cfg, theta_dev, m_dev, v_dev, seg_dev, data_z_dev, idx_dev, batch, batch, dz_dev, lr_z, lr_prior, t_z, t_prior, nullptr, 1,
+                         out_dev, stream_, "bgm_prior_step");
+}
+
+extern "C" int bgm_prior_grad(bgm_handle *h, const bgm_prior_config *cfg, const float *theta_dev, const int32_t *seg_dev, float *data_z_dev,
+                              const int32_t *idx_dev, int32_t batch, int32_t batch_global, const float *dz_dev, float lr_z, int64_t t_z,
+                              float *grad_dev, float *out_dev, void *stream_) {
+  return prior_step_impl(h, cfg, const_cast<float *>(theta_dev), nullptr, nullptr, seg_dev, data_z_dev, idx_dev, batch, batch_global, dz_dev, lr_z, 0.0f,
+                         t_z, 0, grad_dev, 0, out_dev, stream_, "bgm_prior_grad");
+}
+
+extern "C" int bgm_prior_apply(bgm_handle *h, const bgm_prior_config *cfg, float *theta_dev, float *m_dev, float *v_dev, const float *grad_dev,
+                               float lr_prior, int64_t t_prior, void *stream_) {
+  if (!h || !theta_dev || !m_dev || !v_dev || !grad_dev || t_prior < 1) { bgm_set_error("bgm_prior_apply: bad argument"); return BGM_E_INVALID; }
+  int64_t count = 0;
+  int rc = bgm_prior_n_params(cfg, &count);
+  if (rc) return rc;
+  const float lr_t = (float)((double)lr_prior * std::sqrt(1.0 - std::pow(0.99, (double)t_prior)) / (1.0 - std::pow(0.9, (double)t_prior)));
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(prior_adam_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, theta_dev, m_dev, v_dev, grad_dev, (int)count,
+                     lr_t, 0.9f, 0.99f, 1e-7f);
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
 }

@@ -33,6 +33,9 @@ struct PriorStepArgs {
   int B, q;
   float lr_t_z, lr_t_p, b1, b2, eps;
   float *out;                          // [2]: batch-mean conditional-prior term, batch-mean |z|^2 / 2
+  float inv_B;                         // 1 / (global) minibatch: data-parallel steps pass the rows of all ranks (the local sums then add up)
+  float *grad;                         // data-parallel: the prior net's gradient goes here [n_params] and the Adam step is left to
+  int apply;                           //   prior_adam_kernel after the caller's all-reduce (apply = 0); apply = 1: Adam in place
 };
 
 __device__ __forceinline__ float prior_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
@@ -84,7 +87,7 @@ static __global__ __launch_bounds__(PRIOR_THREADS) void prior_step_kernel(PriorS
   __syncthreads();
   prior_forward(n, a.theta, lds, B, [sg](int b) { return sg[b]; });
   const float *out = lds + n.a_off[L - 1];
-  const float invB = 1.0f / (float)B;
+  const float invB = a.inv_B;
   // loss and d loss / d out (:203-211); one thread per row for the row sums
   for (int b = tid; b < B; b += blockDim.x) {
     const float s2 = prior_softplus(out[b * (q + 1) + q]) + PRIOR_EPS;
@@ -115,6 +118,8 @@ static __global__ __launch_bounds__(PRIOR_THREADS) void prior_step_kernel(PriorS
   }
   // backward through the prior net, Adam on every parameter by its owner thread (:220-222)
   auto adam = [&](int p, float g) {
+    if (a.grad) a.grad[p] = g;
+    if (!a.apply) return;
     const float m_ = a.b1 * a.m[p] + (1.0f - a.b1) * g, v_ = a.b2 * a.v[p] + (1.0f - a.b2) * g * g;
     a.m[p] = m_; a.v[p] = v_;
     a.theta[p] -= a.lr_t_p * m_ / (sqrtf(v_) + a.eps);
@@ -148,4 +153,15 @@ static __global__ __launch_bounds__(PRIOR_THREADS) void prior_step_kernel(PriorS
     __syncthreads();
     float *t = dlt; dlt = dprev; dprev = t;
   }
+}
+
+
+// the Adam step of prior_step_kernel from a gradient buffer (data-parallel fit: after the all-reduce)
+static __global__ void prior_adam_kernel(float *theta, float *m, float *v, const float *grad, int n, float lr_t, float b1, float b2, float eps) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const float g = grad[p];
+  const float m_ = b1 * m[p] + (1.0f - b1) * g, v_ = b2 * v[p] + (1.0f - b2) * g * g;
+  m[p] = m_; v[p] = v_;
+  theta[p] -= lr_t * m_ / (sqrtf(v_) + eps);
 }

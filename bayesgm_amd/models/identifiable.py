@@ -10,7 +10,7 @@ torch holds the arrays and nothing else.
 
 Stated differences.  (i) The reference's `fit` unpacks seven values from `evaluate`, which returns four (:334 vs base.py:555,570),
 so it fails at the first evaluation; the build evaluates as CausalBGM does.  (ii) `use_bnn=True` (a Bayesian prior network on the
-Bayesian-network kernels) is not built: NotImplementedError.  (iii) `fit` runs in a single process; `predict` shards the rows over
+Bayesian-network kernels) is not built: NotImplementedError.  (iii) `fit` and `predict` shard the rows over
 the ranks of torch.distributed (with the adaptive proposal scale the window's acceptance count is all-reduced)."""
 import ctypes as C
 
@@ -117,6 +117,24 @@ class IdentifiableCausalBGM(CausalBGM):
         out [2] receives the batch means of the conditional-prior term and of |z|^2 / 2."""
         eng = self.engine
         B = int(idx.numel())
+        world = parallel.world_size()
+        if world > 1:
+            # data parallel: the batch means run over the rows of all ranks; the latent step is local, the prior net's gradient is
+            # all-reduced before its Adam step, so every rank holds the same prior net
+            bg = B * world
+            eng.fit_z_grad(x, y, v, self.data_z, idx, bg, dz, loss_z)
+            self._z_t += 1
+            self._prior_t += 1
+            if getattr(self, "_prior_grad", None) is None or self._prior_grad.numel() != self._prior_theta.numel():
+                self._prior_grad = torch.empty_like(self._prior_theta)
+            _lib.check(eng.lib.bgm_prior_grad(eng.h, C.byref(self._prior_cfg), self._prior_theta.data_ptr(), seg_dev.data_ptr(),
+                                              self.data_z.data_ptr(), idx.data_ptr(), B, bg, dz.data_ptr(), float(lr_z), self._z_t,
+                                              self._prior_grad.data_ptr(), out.data_ptr(), eng._stream()), "bgm_prior_grad")
+            parallel.all_reduce_sum_(self._prior_grad)
+            _lib.check(eng.lib.bgm_prior_apply(eng.h, C.byref(self._prior_cfg), self._prior_theta.data_ptr(), self._prior_m.data_ptr(),
+                                               self._prior_v.data_ptr(), self._prior_grad.data_ptr(), float(lr_theta), self._prior_t,
+                                               eng._stream()), "bgm_prior_apply")
+            return
         eng.fit_z_grad(x, y, v, self.data_z, idx, B, dz, loss_z)                      # NLL terms + z / B (standard prior)
         self._z_t += 1
         self._prior_t += 1
@@ -128,24 +146,29 @@ class IdentifiableCausalBGM(CausalBGM):
     # ------------------------------------------------------------------ fit (:228-346)
     def fit(self, data, batch_size=32, epochs=100, epochs_per_eval=5, startoff=0, use_egm_init=True, egm_n_iter=30000,
             egm_batches_per_eval=500, verbose=1, save_format='txt'):
-        if parallel.is_dist():
-            raise NotImplementedError("bayesgm_amd: IdentifiableCausalBGM.fit runs in a single process")
+        # Under torch.distributed: rows (and their segments, latents) are sharded, batch_size is the GLOBAL minibatch, the fused g | f | h
+        # gradient and the prior net's gradient are all-reduced before their Adam steps (all ranks hold identical networks).
         data_x, data_y, data_v = data
-        n = len(data_x)
+        n_total = len(data_x)
+        world = parallel.world_size()
+        lo_r, hi_r = parallel.shard_range(n_total)
+        n = hi_r - lo_r
+        b_loc = max(1, batch_size // world)
+        n_use = n_total // world if world > 1 else n             # every rank takes the same number of steps (one all-reduce per step)
         eng, dev, q = self.engine, self.engine.device, self.engine.q
         k = int(self.params['n_segments'])
         if verbose:
             print(f"Generating auxiliary variable U for {k} segments.")
-        self.segments = np.random.randint(0, k, size=n)                                                     # :283
-        seg_dev = torch.from_numpy(self.segments.astype(np.int32)).to(dev)
-        if self._p['save_res']:
+        self.segments = np.random.randint(0, k, size=n_total)                                               # :283 (the shared host stream: same draw on every rank)
+        seg_dev = torch.from_numpy(self.segments[lo_r:hi_r].astype(np.int32)).to(dev)
+        if self._p['save_res'] and parallel.rank() == 0:
             with open('{}/params.txt'.format(self.save_dir), 'w') as f_params:
                 f_params.write(str(self.params))
         if use_egm_init:
             self.egm_init(data, egm_n_iter=egm_n_iter, egm_batches_per_eval=egm_batches_per_eval, batch_size=batch_size, verbose=verbose)
-        x = self._dev(data_x).reshape(-1)
-        y = self._dev(data_y).reshape(-1)
-        v = self._dev(data_v)
+        x = self._dev(data_x[lo_r:hi_r]).reshape(-1)
+        y = self._dev(data_y[lo_r:hi_r]).reshape(-1)
+        v = self._dev(data_v[lo_r:hi_r])
         if use_egm_init:
             if verbose:
                 print('Initialize latent variables Z with e(V)...')
@@ -153,7 +176,8 @@ class IdentifiableCausalBGM(CausalBGM):
         else:
             if verbose:
                 print('Random initialization of latent variables Z...')
-            self.data_z = self._dev(np.random.normal(0, 1, size=(n, q)).astype('float32'))
+            self.data_z = self._dev(np.random.normal(0, 1, size=(n_total, q)).astype('float32')[lo_r:hi_r])
+        batch_size = b_loc
         n_params = eng.fit_begin(n, batch_size)
         grad = torch.empty(n_params, device=dev)
         dz = torch.empty((batch_size, q), device=dev)
@@ -172,14 +196,19 @@ class IdentifiableCausalBGM(CausalBGM):
                 loss_z.zero_()
                 n_rows = 0
                 prior_acc.zero_()
-                for i in range(0, n - batch_size + 1, batch_size):                                          # incomplete last batch skipped (:299)
+                for i in range(0, n_use - batch_size + 1, batch_size):                                      # incomplete last batch skipped (:299)
                     idx = sample_idx[i:i + batch_size]
-                    eng.fit_theta_grad(x, y, v, self.data_z, idx, batch_size, grad, loss)
+                    eng.fit_theta_grad(x, y, v, self.data_z, idx, batch_size * world, grad, loss)
+                    parallel.all_reduce_sum_(grad)                                                          # fused g | f | h gradient
                     eng.fit_theta_apply(grad, self._p['lr_theta'])
                     self._z_and_prior_step(x, y, v, idx, seg_dev, self._p['lr_z'], self._p['lr_theta'], dz, loss_z, step_out)
                     prior_acc += step_out                                                       # (device-side: no sync per minibatch)
                     n_rows += batch_size
-                prior_sum, std_sum = (float(a) * batch_size for a in prior_acc.cpu().numpy())
+                if world > 1:                        # epoch statistics over all ranks (the step outputs are shares of global batch means)
+                    for t_ in (loss, loss_z, prior_acc):
+                        parallel.all_reduce_sum_(t_)
+                    n_rows *= world
+                prior_sum, std_sum = (float(a) * batch_size * world for a in prior_acc.cpu().numpy())
                 l = loss.cpu().numpy() / max(1, n_rows)
                 lz = loss_z.cpu().numpy() / max(1, n_rows)
                 post = float(lz[6]) + (prior_sum - std_sum) / max(1, n_rows)        # kernel sum carries |z|^2 / 2: exchange the prior term
@@ -189,7 +218,7 @@ class IdentifiableCausalBGM(CausalBGM):
                     print('Epoch [%d/%d]: loss_px_z [%.4f], loss_mse_x [%.4f], loss_py_z [%.4f], loss_mse_y [%.4f], loss_pv_z [%.4f], '
                           'loss_mse_v [%.4f], loss_postrior_z [%.4f]' % (epoch, epochs, l[2], l[3], l[4], l[5], l[0], l[1] / eng.v_dim, post))
                 if epoch % epochs_per_eval == 0:
-                    causal_pre, mse_x, mse_y, mse_v = self._evaluate_dev(x, y, v, self.data_z, n, 0)
+                    causal_pre, mse_x, mse_y, mse_v = self._evaluate_dev(x, y, v, self.data_z, n_total, lo_r)
                     self.fit_history[-1].update(mse_x=float(mse_x), mse_y=float(mse_y), mse_v=float(mse_v))
                     if verbose:
                         print('Epoch [%d/%d]: MSE_x: %.4f, MSE_y: %.4f, MSE_v: %.4f\n' % (epoch, epochs, mse_x, mse_y, mse_v))
@@ -197,7 +226,7 @@ class IdentifiableCausalBGM(CausalBGM):
                         best_loss = mse_y
                         self.best_causal_pre = causal_pre
                         self.best_epoch = epoch
-                    if self._p['save_res']:
+                    if self._p['save_res'] and parallel.rank() == 0:
                         save_data('{}/causal_pre_at_{}.{}'.format(self.save_dir, epoch, save_format), causal_pre)
         finally:
             eng.fit_end()

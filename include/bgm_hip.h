@@ -107,6 +107,15 @@ BGM_API int bgm_prior_table(bgm_handle *h, const bgm_prior_config *cfg, const fl
 BGM_API int bgm_prior_step(bgm_handle *h, const bgm_prior_config *cfg, float *theta_dev, float *m_dev, float *v_dev, const int32_t *seg_dev,
                    float *data_z_dev, const int32_t *idx_dev, int32_t batch, const float *dz_dev, float lr_z, float lr_prior,
                    int64_t t_z, int64_t t_prior, float *out_dev, void *stream);
+/* Data-parallel form of bgm_prior_step (one process per GPU, rows sharded): bgm_prior_grad takes the latent step on the rank's `batch`
+ * rows (all batch means over batch_global = the rows of all ranks; dz_dev from bgm_causal_fit_z_grad with the same batch_global) and
+ * leaves the prior net's gradient in grad_dev [bgm_prior_n_params] -> [caller: RCCL all-reduce(SUM)] -> bgm_prior_apply takes the Adam
+ * step bgm_prior_step would have taken.  out_dev [2]: this rank's share of the two batch means (they add up over ranks). */
+BGM_API int bgm_prior_grad(bgm_handle *h, const bgm_prior_config *cfg, const float *theta_dev, const int32_t *seg_dev, float *data_z_dev,
+                   const int32_t *idx_dev, int32_t batch, int32_t batch_global, const float *dz_dev, float lr_z, int64_t t_z,
+                   float *grad_dev, float *out_dev, void *stream);
+BGM_API int bgm_prior_apply(bgm_handle *h, const bgm_prior_config *cfg, float *theta_dev, float *m_dev, float *v_dev, const float *grad_dev,
+                    float lr_prior, int64_t t_prior, void *stream);
 BGM_API int bgm_destroy(bgm_handle *h);
 
 /* Declare the model shape.  Synchronous.  replaces: CausalBGM.__init__ network

@@ -125,6 +125,57 @@ def test_prior_network_kernels_match_oracle(units, k, B):
     assert untouched.any() and np.array_equal(zd.cpu().numpy()[untouched], z.astype(np.float32)[untouched])
 
 
+def test_prior_grad_and_apply_equal_the_fused_step():
+    """Data-parallel form of the prior step: two "ranks" run bgm_prior_grad on the halves of a minibatch (batch means over the whole
+    minibatch), their gradients are added (the all-reduce) and bgm_prior_apply takes the Adam step -> the parameters, slots and latents
+    bgm_prior_step produces on the whole minibatch."""
+    import ctypes as C
+    import torch
+    from bayesgm_amd import _lib
+    rs = np.random.RandomState(12)
+    z_dims, p, n, k, B = [1, 1, 1, 7], 20, 90, 6, 32
+    q = sum(z_dims)
+    eng = _engine(_model(5, z_dims, p, False))
+    dev = eng.device
+    pn32 = [(W, (0.3 * rs.randn(*b.shape)).astype(np.float32)) for W, b in OI.init_prior_net(rs, k, q, (64,))]
+    dims = [k, 64, q + 1]
+    cfg = _lib.PriorConfig(len(dims) - 1, (C.c_int32 * 5)(*(dims + [0] * (5 - len(dims)))))
+    flat = np.concatenate([np.concatenate([W.ravel(), b.ravel()]) for W, b in pn32])
+    z = rs.randn(n, q).astype(np.float32)
+    segd = torch.from_numpy(rs.randint(0, k, n).astype(np.int32)).to(dev)
+    idx = rs.choice(n, B, replace=False).astype(np.int32)
+    dz = rs.randn(B, q).astype(np.float32)
+    res = []
+    for split in (False, True):
+        theta = torch.from_numpy(flat.copy()).to(dev)
+        m_, v_ = torch.full_like(theta, 0.01), torch.full_like(theta, 0.002)
+        zd = torch.from_numpy(z.copy()).to(dev)
+        out = torch.zeros(2, device=dev)
+        idx_d, dz_d = torch.from_numpy(idx).to(dev), torch.from_numpy(dz).to(dev)
+        if not split:
+            _lib.check(eng.lib.bgm_prior_step(eng.h, C.byref(cfg), theta.data_ptr(), m_.data_ptr(), v_.data_ptr(), segd.data_ptr(), zd.data_ptr(),
+                                              idx_d.data_ptr(), B, dz_d.data_ptr(), 3e-3, 2e-3, 3, 5, out.data_ptr(), None), "bgm_prior_step")
+            tot = out.cpu().numpy()
+        else:
+            gsum, tot = torch.zeros_like(theta), np.zeros(2)
+            for r in range(2):
+                g = torch.zeros_like(theta)
+                i_r, d_r = idx_d[16 * r:16 * r + 16].contiguous(), dz_d[16 * r:16 * r + 16].contiguous()
+                _lib.check(eng.lib.bgm_prior_grad(eng.h, C.byref(cfg), theta.data_ptr(), segd.data_ptr(), zd.data_ptr(), i_r.data_ptr(), 16, B,
+                                                  d_r.data_ptr(), 3e-3, 3, g.data_ptr(), out.data_ptr(), None), "bgm_prior_grad")
+                gsum += g
+                tot += out.cpu().numpy()
+            _lib.check(eng.lib.bgm_prior_apply(eng.h, C.byref(cfg), theta.data_ptr(), m_.data_ptr(), v_.data_ptr(), gsum.data_ptr(), 2e-3, 5, None),
+                       "bgm_prior_apply")
+        torch.cuda.synchronize()
+        res.append((theta.cpu().numpy(), m_.cpu().numpy(), v_.cpu().numpy(), zd.cpu().numpy(), tot))
+    a, b = res
+    assert np.abs(a[0] - b[0]).max() <= 1e-6 and np.abs(a[1] - b[1]).max() <= 1e-6 * np.abs(a[1]).max() + 1e-9
+    assert np.abs(a[2] - b[2]).max() <= 1e-6 * np.abs(a[2]).max() + 1e-12 and np.abs(a[3] - b[3]).max() <= 1e-6
+    assert np.abs(a[4] - b[4]).max() <= 1e-5 * np.abs(a[4]).max()
+    assert np.abs(a[0] - flat).max() > 1e-4                   # the step moved the prior net
+
+
 def test_identifiable_fit_trace_and_predict():
     from bayesgm_amd.models import IdentifiableCausalBGM
     g = np.load(GOLD)
@@ -219,6 +270,9 @@ def test_two_rank_predict_equals_the_single_process_predict():
         objs.append(o)
         pos += end
     assert len(objs) == 2 and objs[0]["adrf"] == objs[1]["adrf"] and objs[0]["ite_sum"] == objs[1]["ite_sum"]
+    # data-parallel fit: identical networks and prior net on both ranks, finite and identical epoch statistics
+    assert all(o["fit_spread"] == 0.0 and o["fit_finite"] for o in objs) and objs[0]["fit_loss"] == objs[1]["fit_loss"]
+    assert np.all(np.isfinite(objs[0]["fit_loss"])) and len(objs[0]["fit_mse_v"]) == 2
     two = objs[0]
     x, y, v = Sim_Hirano_Imbens_sampler(N=1205, v_dim=50, seed=1).load_all()
 
