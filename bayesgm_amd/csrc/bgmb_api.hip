@@ -412,8 +412,15 @@ extern "C" int bgm_bvn_hmc_run(bgm_handle *h, const bgm_hmc_args *g, void *strea
     else rc = bvn_noise(h, s, g->seed, 1u + (uint32_t)it * (uint32_t)L, 1u, c * L, a.init != 0, 0u, (hipStream_t)stream_);
     if (rc) return rc;
     a.dw = s->dw_dev;
-    hipLaunchKernelGGL(bgmb_hmc_kernel, dim3((unsigned)tiles), dim3(BNN_THREADS), 0, (hipStream_t)stream_, a);
-    BGM_HIP_CHECK(hipGetLastError());
+    rc = 1;
+    if (!a.frozen) {       // fresh noise on the row-tile chains (bgmf_kernels.h) for the reference's generator shape, else the workspace kernel
+      rc = bgmf_hmc_fresh(h, s, g, it, c, a.init, a.dw_stride, (hipStream_t)stream_);
+      if (rc < 0) return rc;
+    }
+    if (rc == 1) {
+      hipLaunchKernelGGL(bgmb_hmc_kernel, dim3((unsigned)tiles), dim3(BNN_THREADS), 0, (hipStream_t)stream_, a);
+      BGM_HIP_CHECK(hipGetLastError());
+    }
     it += c; left -= c; first = false;
   } while (left > 0);
   return BGM_OK;

@@ -30,3 +30,4 @@ int bgmb_fill(const bgm_bvn_config *cfg, BnnNet &n);
 void bgm_bvn_egm_free(void *egm_state);
 void bgmf_free(BgmbState *s);
 int bgmf_hmc_try(bgm_handle *h, BgmbState *s, const bgm_hmc_args *g, hipStream_t st);     // 0 launched, 1 not its shape, < 0 error
+int bgmf_hmc_fresh(bgm_handle *h, BgmbState *s, const bgm_hmc_args *g, int it_begin, int n_iters, int init, long long dw_stride, hipStream_t st);

@@ -11,7 +11,9 @@
 struct BgmfState {
   BgmfMeta m{};
   BgmfPackArgs pk{};
-  float *blob = nullptr;
+  float *blob = nullptr;       // frozen noise: resident part + one slot of chunks
+  float *blob_fresh = nullptr; // fresh noise: resident part + fresh_slots slots [dW first layer | dW hidden | head blocks]
+  int fresh_slots = 0;
   int lds_bytes = 0, ktq = 1;
 };
 
@@ -19,6 +21,7 @@ void bgmf_free(BgmbState *s) {
   BgmfState *f = static_cast<BgmfState *>(s->bgmf);
   if (!f) return;
   if (f->blob) hipFree(f->blob);
+  if (f->blob_fresh) hipFree(f->blob_fresh);
   delete f;
   s->bgmf = nullptr;
 }
@@ -46,6 +49,7 @@ static int bgmf_session(BgmbState *s, BgmfState *&out) {
   m.resident = off;
   m.chunks = off; off += (nh - 1 + ntx) * BGMF_CHUNK;
   m.total = off;
+  m.slot_floats = (nh + ntx) * BGMF_CHUNK;
   for (int l = 0; l < NF; ++l) { m.sin_w[l] = n.sin_w[l]; m.sout_w[l] = n.sout_w[l]; f->pk.woff[l] = n.woff[l]; f->pk.eoff[l] = n.eoff[l]; }
   m.swords = (n.swords + 3) / 4 * 4;
   m.swp = m.swords | 1;
@@ -70,8 +74,8 @@ int bgmf_hmc_try(bgm_handle *h, BgmbState *s, const bgm_hmc_args *g, hipStream_t
   int rc = bgmf_session(s, f);
   if (rc) return rc;
   BgmfPackArgs pk = f->pk;
-  pk.theta = s->theta_dev; pk.dwc = s->dw_dev; pk.bnp = s->theta_dev + s->net.off;
-  hipLaunchKernelGGL(bgmf_pack_kernel, dim3(32, f->m.nh + 1), dim3(256), 0, st, pk);        // blob of the CURRENT parameters and of this run's perturbation
+  pk.theta = s->theta_dev; pk.dwc = s->dw_dev; pk.bnp = s->theta_dev + s->net.off; pk.fresh = 0; pk.dw_stride = 0;
+  hipLaunchKernelGGL(bgmf_pack_kernel, dim3(32, f->m.nh + 1, 1), dim3(256), 0, st, pk);        // blob of the CURRENT parameters and of this run's perturbation
   BGM_HIP_CHECK(hipGetLastError());
   BgmfHmcKArgs k{};
   k.blob = f->blob; k.x = g->x_dev; k.n = g->n; k.row_base = g->row_base; k.state = g->state_dev; k.logp = g->logp_dev; k.grad = g->grad_dev;
@@ -86,8 +90,49 @@ int bgmf_hmc_try(bgm_handle *h, BgmbState *s, const bgm_hmc_args *g, hipStream_t
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * BGMF_WAVES), f->lds_bytes, st, k);
     return hipGetLastError() == hipSuccess ? BGM_OK : BGM_E_HIP;
   };
-  if (f->ktq == 1) rc = f->m.nh == 5 ? launch(bgmf_hmc_kernel<1, 5>) : launch(bgmf_hmc_kernel<1, 3>);
-  else rc = f->m.nh == 5 ? launch(bgmf_hmc_kernel<2, 5>) : launch(bgmf_hmc_kernel<2, 3>);
+  if (f->ktq == 1) rc = f->m.nh == 5 ? launch(bgmf_hmc_kernel<1, 5, false>) : launch(bgmf_hmc_kernel<1, 3, false>);
+  else rc = f->m.nh == 5 ? launch(bgmf_hmc_kernel<2, 5, false>) : launch(bgmf_hmc_kernel<2, 3, false>);
   if (rc) bgm_set_error("frozen-noise HMC (bgmf_hmc_kernel): launch failed");
+  return rc;
+}
+
+
+// Fresh noise: one launch of transitions [it_begin, it_begin + n_iters) whose perturbations (n_iters * L slots, then the initial
+// evaluation's when `init`) lie in s->dw_dev, dw_stride floats apart (bvn_noise).  0: launched; 1: not this kernel's shape; < 0: error
+int bgmf_hmc_fresh(bgm_handle *h, BgmbState *s, const bgm_hmc_args *g, int it_begin, int n_iters, int init, long long dw_stride, hipStream_t st) {
+  BgmfState *f;
+  int rc = bgmf_session(s, f);
+  if (rc) return rc;
+  const int slots = n_iters * g->n_leapfrog + (init ? 1 : 0);
+  if (slots > f->fresh_slots) {
+    if (f->blob_fresh) { BGM_HIP_CHECK(hipDeviceSynchronize()); hipFree(f->blob_fresh); f->blob_fresh = nullptr; f->fresh_slots = 0; }
+    const size_t floats = (size_t)f->m.chunks + (size_t)slots * (size_t)f->m.slot_floats;
+    if (hipMalloc((void **)&f->blob_fresh, sizeof(float) * floats) != hipSuccess || hipMemset(f->blob_fresh, 0, sizeof(float) * floats) != hipSuccess) {
+      f->blob_fresh = nullptr;
+      bgm_set_error("fresh-noise HMC: device allocation failed");
+      return BGM_E_HIP;
+    }
+    f->fresh_slots = slots;
+  }
+  BgmfPackArgs pk = f->pk;
+  pk.blob = f->blob_fresh; pk.theta = s->theta_dev; pk.dwc = s->dw_dev; pk.bnp = s->theta_dev + s->net.off; pk.fresh = 1; pk.dw_stride = dw_stride;
+  hipLaunchKernelGGL(bgmf_pack_kernel, dim3(16, f->m.nh + 1, (unsigned)slots), dim3(256), 0, st, pk);
+  BGM_HIP_CHECK(hipGetLastError());
+  BgmfHmcKArgs k{};
+  k.blob = f->blob_fresh; k.x = g->x_dev; k.n = g->n; k.row_base = g->row_base; k.state = g->state_dev; k.logp = g->logp_dev; k.grad = g->grad_dev;
+  k.init = init; k.it_begin = it_begin; k.n_iters = n_iters; k.burn_in = g->burn_in; k.n_leapfrog = g->n_leapfrog; k.step = g->step_dev;
+  k.k0 = (uint32_t)(g->seed & 0xFFFFFFFFull); k.k1 = (uint32_t)(g->seed >> 32);
+  k.acc_prob_sum = g->acc_prob_sum_dev; k.acc_count = g->acc_count_dev; k.draws = g->draws_dev;
+  k.m = f->m;
+  const long long tiles = (g->n + 15) / 16;
+  const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((tiles + BGMF_WAVES - 1) / BGMF_WAVES, h->n_cus));
+  auto launch = [&](auto kern) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, f->lds_bytes) != hipSuccess) return BGM_E_HIP;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * BGMF_WAVES), f->lds_bytes, st, k);
+    return hipGetLastError() == hipSuccess ? BGM_OK : BGM_E_HIP;
+  };
+  if (f->ktq == 1) rc = f->m.nh == 5 ? launch(bgmf_hmc_kernel<1, 5, true>) : launch(bgmf_hmc_kernel<1, 3, true>);
+  else rc = f->m.nh == 5 ? launch(bgmf_hmc_kernel<2, 5, true>) : launch(bgmf_hmc_kernel<2, 3, true>);
+  if (rc) bgm_set_error("fresh-noise HMC (bgmf_hmc_kernel): launch failed");
   return rc;
 }

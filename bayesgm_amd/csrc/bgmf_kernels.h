@@ -14,6 +14,8 @@
 // the trunk's into 16-bit register masks.  Other generator shapes run on the LDS-tile engine (gx_flipout.h).
 #pragma once
 #include "bgm_kernels.h"
+#include <type_traits>
+
 #include "bnn_kernels.h"
 
 #define BGMF_CHUNK (2 * BGM_PAIR)      // floats per stream step: one hidden dW layer [4][64][17], or [loc mean | loc var | dW mean | dW var] of a head block
@@ -28,6 +30,8 @@ struct BgmfMeta {
   int sc, sh;                          // input BatchNorm (inference mode) as z * sc + sh, [16 KTQ] by feature, zero beyond q
   int resident;                        // floats copied to LDS at kernel start (everything above)
   int chunks;                          // blob offset of the stream: dW of hidden layers 1 .. nh-1, then the head blocks; BGMF_CHUNK floats each
+                                       // fresh noise: per gradient evaluation (slot) [dW of the first layer | hidden 1 .. nh-1 | head blocks]
+  int slot_floats;                     // fresh noise: floats of one slot = (nh + ntx) chunks
   int total;
   int stage, sign;                     // LDS offsets (floats): [2][BGMF_CHUNK], sign words [16 BGMF_WAVES][swp]
   int swp, swords;                     // row stride of the sign words in LDS (odd: conflict-free across rows), words drawn per row (multiple of 4)
@@ -61,12 +65,57 @@ struct BgmfStream {
     pos = pos + 1 == cycle ? 0 : pos + 1;
   }
   __device__ __forceinline__ const float *tile() const { return buf + cur * BGMF_CHUNK; }
+  __device__ __forceinline__ int cycle_len() const { return cycle; }
   __device__ __forceinline__ void begin(const float *blob, const BgmfMeta &m, float *lds) {
     src = blob + m.chunks; buf = lds + m.stage; tid = threadIdx.x;
     nhh = m.nh - 1; ntx = m.ntx; cycle = nhh + ntx + (nhh - 1);
     cur = 1; pos = cycle - 1;
     fetch_next();
     commit();                          // dW_1 is current on entry to every gradient evaluation
+  }
+};
+
+// Fresh noise (params['bnn_mcmc_noise'] = 'fresh', the reference as written: a new perturbation at every gradient evaluation): the
+// stream is linear.  Evaluation e of a pass reads slot(e); its steps are  dW_0, dW_1 .. dW_{nh-1}, H_0 .. H_{ntx-1}, dW_{nh-1} .. dW_1, dW_0
+// (the first layer's perturbation is a chunk too); the step after an evaluation's last one is the first of the next evaluation, after
+// the pass's last evaluation the first of the pass (every pass of the block replays the same slots).
+struct BgmfStreamFresh {
+  const float *src;
+  float *buf;
+  int cur, tid, pos, nhh, ntx, steps, ev, n_ev, slot_floats, init_first;
+  f32x4 r0, r1, r2;
+  __device__ __forceinline__ int slot_of(int e) const { return init_first ? (e == 0 ? n_ev - 1 : e - 1) : e; }      // the initial evaluation's slot is the last one
+  __device__ __forceinline__ int chunk_of(int k) const {
+    if (k == 0 || k == steps - 1) return 0;
+    if (k <= nhh + ntx) return k;
+    return nhh - (k - nhh - ntx - 1);
+  }
+  __device__ __forceinline__ void fetch_next() {
+    int nk = pos + 1, ne = ev;
+    if (nk == steps) { nk = 0; ne = ev + 1 == n_ev ? 0 : ev + 1; }
+    const f32x4 *s = reinterpret_cast<const f32x4 *>(src + (long long)slot_of(ne) * slot_floats + (long long)chunk_of(nk) * BGMF_CHUNK);
+    r0 = s[tid];
+    r1 = s[tid + 64 * BGMF_WAVES];
+    if (tid + 2 * 64 * BGMF_WAVES < BGMF_CHUNK / 4) r2 = s[tid + 2 * 64 * BGMF_WAVES];
+  }
+  __device__ __forceinline__ void commit() {
+    f32x4 *d = reinterpret_cast<f32x4 *>(buf + (cur ^ 1) * BGMF_CHUNK);
+    d[tid] = r0;
+    d[tid + 64 * BGMF_WAVES] = r1;
+    if (tid + 2 * 64 * BGMF_WAVES < BGMF_CHUNK / 4) d[tid + 2 * 64 * BGMF_WAVES] = r2;
+    __syncthreads();
+    cur ^= 1;
+    if (++pos == steps) { pos = 0; ev = ev + 1 == n_ev ? 0 : ev + 1; }
+  }
+  __device__ __forceinline__ const float *tile() const { return buf + cur * BGMF_CHUNK; }
+  __device__ __forceinline__ int cycle_len() const { return steps; }
+  __device__ __forceinline__ void begin(const float *blob, const BgmfMeta &m, float *lds, int n_evals, int init) {
+    src = blob + m.chunks; buf = lds + m.stage; tid = threadIdx.x;
+    nhh = m.nh - 1; ntx = m.ntx; steps = 2 * nhh + ntx + 2; slot_floats = m.slot_floats;
+    n_ev = n_evals; init_first = init;
+    cur = 1; pos = steps - 1; ev = n_ev - 1;
+    fetch_next();
+    commit();                          // the first evaluation's first-layer perturbation is current
   }
 };
 
@@ -144,15 +193,20 @@ __device__ __forceinline__ unsigned bgmf_mask64(const unsigned *sg, int w0, int 
   const unsigned a = sg[w0], b = sg[w0 + 1];
   return ((a >> (4 * g)) & 0xFu) | (((a >> (16 + 4 * g)) & 0xFu) << 4) | (((b >> (4 * g)) & 0xFu) << 8) | (((b >> (16 + 4 * g)) & 0xFu) << 12);
 }
-// Draw the sign words of the wave's 16 rows into its LDS rows and gather the lane's trunk masks.  All waves of the block call this
-// together (block barrier inside).
-template <int KTQ, int NH>
-__device__ __forceinline__ void bgmf_signs(const BgmfMeta &m, unsigned *sg_row, unsigned rowid, int g, unsigned k0, unsigned k1, BgmfSigns<NH> &S) {
+// Draw the sign words of the wave's 16 rows (noise stream `stream`) into its LDS rows and gather the lane's trunk masks.  BLOCK: all
+// waves of the block call this together (block barrier inside); otherwise the wave orders its own LDS traffic: the rows are private to
+// the wave, whose LDS instructions execute in issue order (fresh noise redraws the signs at every gradient evaluation, and a wave
+// without a tile must not have to match a barrier there).
+template <int KTQ, int NH, bool BLOCK>
+__device__ __forceinline__ void bgmf_signs(const BgmfMeta &m, unsigned *sg_row, unsigned rowid, int g, unsigned k0, unsigned k1, unsigned stream,
+                                           BgmfSigns<NH> &S) {
+  if (!BLOCK) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the previous evaluation's reads of these rows have returned
   for (int c = g; c < (m.swords >> 2); c += 4) {
-    const uint4 w4 = philox4x32_10(rowid, (unsigned)c, 0u, BNN_TAG_SIGN, k0, k1);
+    const uint4 w4 = philox4x32_10(rowid, (unsigned)c, stream, BNN_TAG_SIGN, k0, k1);
     sg_row[4 * c] = w4.x; sg_row[4 * c + 1] = w4.y; sg_row[4 * c + 2] = w4.z; sg_row[4 * c + 3] = w4.w;
   }
-  __syncthreads();
+  if (BLOCK) __syncthreads();
+  else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   // layer 0 reads z: feature 16t + 4r + g in register r of tile t (q <= 32: one word)
   const unsigned w = sg_row[m.sin_w[0]];
   unsigned m0 = 0u;
@@ -188,9 +242,9 @@ __device__ __forceinline__ void bgmf_activate(const f32x4 (&al)[4], const f32x4 
 // log p(z | x_obs) and dlogp/dz of the wave's 16 chains under the frozen perturbation.  Layouts as bgm_logp_grad (wide variant): z has
 // feature 16t + 4r + g in register r of tile t; xrow = the (clamped) data row, NaN = missing.  Every wave of the block must call
 // this the same number of times (the stream's barriers).
-template <int KTQ, int NH, bool WANT_GRAD>
+template <int KTQ, int NH, bool WANT_GRAD, bool FRESH, class Stream>
 __device__ __forceinline__ void bgmf_logp_grad(const float *lds, const BgmfMeta &m, int j, int g, const f32x4 (&z)[KTQ], const float *xrow,
-                                               BgmfStream &st, const BgmfSigns<NH> &S, const unsigned *sg_row, float &logp, f32x4 (&grad)[KTQ]) {
+                                               Stream &st, const BgmfSigns<NH> &S, const unsigned *sg_row, float &logp, f32x4 (&grad)[KTQ]) {
   unsigned sgn[NH];
   f32x4 h[4];
   {
@@ -203,11 +257,13 @@ __device__ __forceinline__ void bgmf_logp_grad(const float *lds, const BgmfMeta 
         zin[t][r] = fmaf(z[t][r], lds[m.sc + f], lds[m.sh + f]);
       }
     bgmf_flip_tiles<KTQ>(zin, S.in[0], zs);
+    if (FRESH) st.fetch_next();
     bias17<4>(lds + m.b1, g, al);
     fwd17<KTQ, 4>(lds + m.w1, j, g, zin, al);
     bgmf_zero<4>(ad);
-    fwd17<KTQ, 4>(lds + m.d1, j, g, zs, ad);
+    fwd17<KTQ, 4>(FRESH ? st.tile() : lds + m.d1, j, g, zs, ad);
     bgmf_activate(al, ad, S.out[0], sgn[0], h);
+    if (FRESH) st.commit();
   }
 #pragma unroll
   for (int l = 1; l < NH; ++l) {
@@ -290,7 +346,7 @@ __device__ __forceinline__ void bgmf_logp_grad(const float *lds, const BgmfMeta 
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dh[t][r] *= ((sgn[l] >> (4 * t + r)) & 1u) ? 1.0f : BGM_LEAK;
-      if (l > 1) st.fetch_next();      // (layer 1's dW stays current for the next evaluation's forward pass)
+      if (FRESH || l > 1) st.fetch_next();      // (frozen noise: layer 1's dW stays current for the next evaluation's forward pass)
       f32x4 dn[4], dd[4], ds[4];
       bgmf_zero<4>(dn); bgmf_zero<4>(dd);
       bwd17<4, 4>(lds + m.wh + (l - 1) * (4 * 64 * 17), j, g, dh, dn);
@@ -304,7 +360,7 @@ __device__ __forceinline__ void bgmf_logp_grad(const float *lds, const BgmfMeta 
           const float d = dd[t][r];
           dh[t][r] = dn[t][r] + bgmf_flip(d, (il >> (4 * t + r)) & 1u);
         }
-      if (l > 1) st.commit();
+      if (FRESH || l > 1) st.commit();
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -312,9 +368,11 @@ __device__ __forceinline__ void bgmf_logp_grad(const float *lds, const BgmfMeta 
       for (int r = 0; r < 4; ++r) dh[t][r] *= ((sgn[0] >> (4 * t + r)) & 1u) ? 1.0f : BGM_LEAK;
     f32x4 ds[4], gd[KTQ];
     bgmf_zero<KTQ>(grad); bgmf_zero<KTQ>(gd);
+    if (FRESH) st.fetch_next();        // (the next evaluation's first-layer perturbation)
     bwd17<KTQ, 4>(lds + m.w1, j, g, dh, grad);
     bgmf_flip_tiles<4>(dh, S.out[0], ds);
-    bwd17<KTQ, 4>(lds + m.d1, j, g, ds, gd);
+    bwd17<KTQ, 4>(FRESH ? st.tile() : lds + m.d1, j, g, ds, gd);
+    if (FRESH) st.commit();
     const unsigned i0 = bgmf_here(S.in[0]);
 #pragma unroll
     for (int t = 0; t < KTQ; ++t)
@@ -341,15 +399,21 @@ struct BgmfHmcKArgs {
   BgmfMeta m;
 };
 
-// The transition logic of bgm_hmc_kernel on the frozen-noise target.
-template <int KTQ, int NH>
+// The transition logic of bgm_hmc_kernel on the Flipout target.  FRESH = false: one perturbation and one sign string per row for the
+// whole run (stream 0).  FRESH = true (the reference as written; oracle/bgm_bnn.py hmc_sampler(frozen=False)): gradient evaluation l of
+// transition `it` draws perturbation and signs from stream 1 + it * L + l (slot (it - it_begin) * L + l of the launch's noise), the
+// initial evaluation from stream 0 (the launch's last slot).
+template <int KTQ, int NH, bool FRESH>
 __global__ __launch_bounds__(64 * BGMF_WAVES) void bgmf_hmc_kernel(BgmfHmcKArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const BgmfMeta &m = a.m;
   lds_fill(lds, a.blob, m.resident);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
-  BgmfStream st;
-  st.begin(a.blob, m, lds);
+  const int evals = (a.init ? 1 : 0) + a.n_iters * a.n_leapfrog;
+  using Stream = typename std::conditional<FRESH, BgmfStreamFresh, BgmfStream>::type;
+  Stream st;
+  if constexpr (FRESH) st.begin(a.blob, m, lds, evals, a.init ? 1 : 0);
+  else st.begin(a.blob, m, lds);
   unsigned *sg_row = reinterpret_cast<unsigned *>(lds + m.sign) + (16 * wave + j) * m.swp;
   const long long n = a.n, n_tiles = (n + 15) / 16, passes = bgm_block_passes(n_tiles, BGMF_WAVES);
   const float eps = *a.step;
@@ -364,12 +428,14 @@ __global__ __launch_bounds__(64 * BGMF_WAVES) void bgmf_hmc_kernel(BgmfHmcKArgs 
     const unsigned rowid = (unsigned)(a.row_base + row);
     const float *xrow = a.x + row * (long long)m.p;
     BgmfSigns<NH> S;
-    __syncthreads();           // (the previous pass's readers of the sign rows are done)
-    bgmf_signs<KTQ, NH>(m, sg_row, rowid, g, a.k0, a.k1, S);
+    if constexpr (!FRESH) {
+      __syncthreads();         // (the previous pass's readers of the sign rows are done)
+      bgmf_signs<KTQ, NH, true>(m, sg_row, rowid, g, a.k0, a.k1, 0u, S);
+    }
     if (!tile_ok) {
-      const int evals = (a.init ? 1 : 0) + a.n_iters * a.n_leapfrog;
+      const int steps = st.cycle_len();
       for (int e = 0; e < evals; ++e)
-        for (int k = 0; k < st.cycle; ++k) { st.fetch_next(); st.commit(); }
+        for (int k = 0; k < steps; ++k) { st.fetch_next(); st.commit(); }
       continue;
     }
     f32x4 z[KTQ], gr[KTQ];
@@ -381,7 +447,8 @@ __global__ __launch_bounds__(64 * BGMF_WAVES) void bgmf_hmc_kernel(BgmfHmcKArgs 
 #pragma unroll
         for (int r = 0; r < 4; ++r) z[t][r] = (16 * t + 4 * r + g < m.q) ? e[r] : 0.0f;
       }
-      bgmf_logp_grad<KTQ, NH, true>(lds, m, j, g, z, xrow, st, S, sg_row, lp, gr);
+      if constexpr (FRESH) bgmf_signs<KTQ, NH, false>(m, sg_row, rowid, g, a.k0, a.k1, 0u, S);
+      bgmf_logp_grad<KTQ, NH, true, FRESH>(lds, m, j, g, z, xrow, st, S, sg_row, lp, gr);
     } else {
       bgm_load_z<KTQ>(a.state, m.q, row, g, z);
       bgm_load_z<KTQ>(a.grad, m.q, row, g, gr);
@@ -410,7 +477,8 @@ __global__ __launch_bounds__(64 * BGMF_WAVES) void bgmf_hmc_kernel(BgmfHmcKArgs 
         for (int t = 0; t < KTQ; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) zc[t][r] = fmaf(eps, mom[t][r], zc[t][r]);
-        bgmf_logp_grad<KTQ, NH, true>(lds, m, j, g, zc, xrow, st, S, sg_row, lpc, gc);
+        if constexpr (FRESH) bgmf_signs<KTQ, NH, false>(m, sg_row, rowid, g, a.k0, a.k1, 1u + (unsigned)it * (unsigned)a.n_leapfrog + (unsigned)l, S);
+        bgmf_logp_grad<KTQ, NH, true, FRESH>(lds, m, j, g, zc, xrow, st, S, sg_row, lpc, gc);
         const float kick = (l < a.n_leapfrog - 1) ? eps : 0.5f * eps;
 #pragma unroll
         for (int t = 0; t < KTQ; ++t)
@@ -465,52 +533,59 @@ struct BgmfPackArgs {
   BgmfMeta m;
   int woff[BGMF_MAXNH + 2], eoff[BGMF_MAXNH + 2];     // BnnNet::woff / eoff of the Flipout layers
   const float *bnp;            // gamma | beta | moving mean | moving variance, q each
-  const float *theta, *dwc;
+  const float *theta, *dwc;    // dwc: perturbations in the parameter vector's order, one slot of dw_stride floats per generator call
   float *blob;
-  int ktq;
+  int ktq, fresh;              // fresh: grid.z slots, each [dW first layer | dW hidden | head blocks]; else one slot, first-layer dW resident
+  long long dw_stride;
 };
 static __global__ __launch_bounds__(256) void bgmf_pack_kernel(BgmfPackArgs a) {
   const BgmfMeta &m = a.m;
-  const int sec = blockIdx.y, q = m.q, p = m.p, nh = m.nh;
+  const int sec = blockIdx.y, slot = blockIdx.z, q = m.q, p = m.p, nh = m.nh, nhh = nh - 1;
   const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+  const float *dwc = a.dwc + (long long)slot * a.dw_stride;
+  float *chunks = a.blob + m.chunks + (long long)slot * m.slot_floats;        // (frozen noise: one slot, slot_floats unused)
+  const int c_hid = a.fresh ? 1 : 0, c_head = a.fresh ? nhh + 1 : nhh;        // first chunk of the hidden layers / of the head blocks
   if (sec == 0) {
     const int kr = 16 * a.ktq;
-    const float *loc = a.theta + a.woff[0], *bias = loc + 2 * q * 64, *dw = a.dwc + a.eoff[0];
+    const float *loc = a.theta + a.woff[0], *bias = loc + 2 * q * 64, *dw = dwc + a.eoff[0];
+    float *d1 = a.fresh ? chunks : a.blob + m.d1;
     for (int i = gtid; i < 4 * kr * 16; i += gsz) {
-      const int jj = i & 15, slot = (i >> 4) % kr, t = (i >> 4) / kr;
-      const int tt = slot >> 4, gg = (slot >> 2) & 3, rr = slot & 3, f = 16 * tt + 4 * rr + gg;     // slot 16t + 4g + r holds input feature 16t + 4r + g
+      const int jj = i & 15, sl = (i >> 4) % kr, t = (i >> 4) / kr;
+      const int tt = sl >> 4, gg = (sl >> 2) & 3, rr = sl & 3, f = 16 * tt + 4 * rr + gg;     // slot 16t + 4g + r holds input feature 16t + 4r + g
       if (f < q) {
-        a.blob[m.w1 + (t * kr + slot) * 17 + jj] = loc[f * 64 + 16 * t + jj];
-        a.blob[m.d1 + (t * kr + slot) * 17 + jj] = dw[f * 64 + 16 * t + jj];
+        if (slot == 0) a.blob[m.w1 + (t * kr + sl) * 17 + jj] = loc[f * 64 + 16 * t + jj];
+        d1[(t * kr + sl) * 17 + jj] = dw[f * 64 + 16 * t + jj];
       }
     }
-    for (int i = gtid; i < 64; i += gsz) a.blob[m.b1 + i] = bias[i];
-    for (int c = gtid; c < q; c += gsz) {
-      const float scale = a.bnp[c] / sqrtf(a.bnp[3 * q + c] + 1e-3f);
-      a.blob[m.sc + c] = scale; a.blob[m.sh + c] = a.bnp[q + c] - a.bnp[2 * q + c] * scale;
+    if (slot == 0) {
+      for (int i = gtid; i < 64; i += gsz) a.blob[m.b1 + i] = bias[i];
+      for (int c = gtid; c < q; c += gsz) {
+        const float scale = a.bnp[c] / sqrtf(a.bnp[3 * q + c] + 1e-3f);
+        a.blob[m.sc + c] = scale; a.blob[m.sh + c] = a.bnp[q + c] - a.bnp[2 * q + c] * scale;
+      }
     }
   } else if (sec < nh) {
     const int l = sec;
-    const float *loc = a.theta + a.woff[l], *bias = loc + 2 * 4096, *dw = a.dwc + a.eoff[l];
-    float *wl = a.blob + m.wh + (l - 1) * (4 * 64 * 17), *wd = a.blob + m.chunks + (long long)(l - 1) * BGMF_CHUNK;
+    const float *loc = a.theta + a.woff[l], *bias = loc + 2 * 4096, *dw = dwc + a.eoff[l];
+    float *wl = a.blob + m.wh + (l - 1) * (4 * 64 * 17), *wd = chunks + (long long)(c_hid + l - 1) * BGMF_CHUNK;
     for (int i = gtid; i < 4 * 64 * 16; i += gsz) {
       const int jj = i & 15, rho = (i >> 4) & 63, t = i >> 10;
-      wl[(t * 64 + rho) * 17 + jj] = loc[rho * 64 + 16 * t + jj];
+      if (slot == 0) wl[(t * 64 + rho) * 17 + jj] = loc[rho * 64 + 16 * t + jj];
       wd[(t * 64 + rho) * 17 + jj] = dw[rho * 64 + 16 * t + jj];
     }
-    for (int i = gtid; i < 64; i += gsz) a.blob[m.bh + (l - 1) * 64 + i] = bias[i];
+    if (slot == 0) for (int i = gtid; i < 64; i += gsz) a.blob[m.bh + (l - 1) * 64 + i] = bias[i];
   } else {
     for (int head = 0; head < 2; ++head) {
-      const float *loc = a.theta + a.woff[nh + head], *bias = loc + 2 * 64 * p, *dw = a.dwc + a.eoff[nh + head];
+      const float *loc = a.theta + a.woff[nh + head], *bias = loc + 2 * 64 * p, *dw = dwc + a.eoff[nh + head];
       for (int i = gtid; i < m.ntx * 64 * 16; i += gsz) {
         const int jj = i & 15, rho = (i >> 4) & 63, tx = i >> 10, o = 16 * tx + jj;
         if (o < p) {
-          float *c = a.blob + m.chunks + (long long)(nh - 1 + tx) * BGMF_CHUNK;
+          float *c = chunks + (long long)(c_head + tx) * BGMF_CHUNK;
           c[head * 64 * 17 + rho * 17 + jj] = loc[rho * p + o];
           c[BGM_PAIR + head * 64 * 17 + rho * 17 + jj] = dw[rho * p + o];
         }
       }
-      for (int o = gtid; o < p; o += gsz) a.blob[m.bhd + head * 16 * m.ntx + o] = bias[o];
+      if (slot == 0) for (int o = gtid; o < p; o += gsz) a.blob[m.bhd + head * 16 * m.ntx + o] = bias[o];
     }
   }
 }

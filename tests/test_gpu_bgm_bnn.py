@@ -512,21 +512,23 @@ def test_logpost_and_hmc_when_workgroups_walk_several_tiles():
 # ---------------------------------------------------------------------------------------------------------------------------
 # frozen-noise HMC as register-chained row tiles (csrc/bgmf_kernels.h): the reference's generator shape, hidden layers of 64 units
 # ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("frozen", [True, False])
 @pytest.mark.parametrize("q,units,p,n", [(3, (64,) * 3, 40, 100), (10, (64,) * 5, 50, 150), (20, (64,) * 5, 23, 70)])
-def test_frozen_hmc_row_tile_chains_follow_oracle(q, units, p, n):
+def test_frozen_hmc_row_tile_chains_follow_oracle(q, units, p, n, frozen):
     """Same criterion as test_hmc_follows_oracle_over_a_few_transitions on the shapes bgmf_hmc_kernel serves (3 / 5 hidden layers of 64
-    units; q = 20: two latent tiles; p not a multiple of 16: masked head columns; a row count that is no multiple of the 16-chain tile)."""
+    units; q = 20: two latent tiles; p not a multiple of 16: masked head columns; a row count that is no multiple of the 16-chain tile).
+    frozen = False: the reference as written -- a new perturbation and new signs at every gradient evaluation (the linear stream)."""
     net = _net(q, units, p, seed=16)
     rs = np.random.RandomState(17)
     x = rs.standard_normal((n, p)).astype(np.float32)
     x[rs.uniform(size=x.shape) < 0.25] = np.nan
-    eng = _engine(net, q, units, p, hmc_frozen_noise=True)
+    eng = _engine(net, q, units, p, hmc_frozen_noise=frozen)
     seed = 43
     out = eng.hmc_sample(x, n_mcmc=3, burn_in=5, step_size=0.03, n_leapfrog=4, seed=seed, row_base=9)
     mask = (~np.isnan(x)).astype(np.float32)
     xc = np.where(np.isnan(x), 0.0, x).astype(np.float32)
     ref, info = OV.hmc_sampler(OV.cast_vnet(net, np.float64), xc.astype(np.float64), mask.astype(np.float64), 3, 5, 0.03, 4, seed, row0=9,
-                               return_info=True, frozen=True)
+                               return_info=True, frozen=frozen)
     got = out["draws"].cpu().numpy()
     assert got.shape == ref.shape
     assert abs(float(out["step"].item()) - info["step"]) < 1e-6
@@ -534,6 +536,42 @@ def test_frozen_hmc_row_tile_chains_follow_oracle(q, units, p, n):
     print("MEASURED frozen chains close to the oracle: %d of %d" % (close.sum(), n))
     assert close.mean() > 0.95
     eng.close()
+
+
+@pytest.mark.parametrize("budget", [None, "1"])
+def test_fresh_hmc_row_tile_chains_equal_the_workspace_kernel(monkeypatch, budget):
+    """Fresh noise on bgmf_hmc_kernel<FRESH> against bgmb_hmc_kernel (BGM_BVN_NO_CHAINS=1) at BASELINE C4's shape; budget "1": one
+    transition per launch (the perturbation buffer's size cuts a segment into launches) -- the cut must not change the chains."""
+    q, units, p, n = 10, (64,) * 5, 500, 2500
+    net = _net(q, units, p, seed=18)
+    rs = np.random.RandomState(19)
+    x = rs.standard_normal((n, p)).astype(np.float32)
+    x[rs.uniform(size=x.shape) < 0.1] = np.nan
+    if budget is None:
+        monkeypatch.delenv("BGM_BVN_NOISE_BYTES", raising=False)
+    else:
+        monkeypatch.setenv("BGM_BVN_NOISE_BYTES", budget)
+    res = []
+    for no_chains in (False, True):
+        if no_chains:
+            monkeypatch.setenv("BGM_BVN_NO_CHAINS", "1")
+        else:
+            monkeypatch.delenv("BGM_BVN_NO_CHAINS", raising=False)
+        eng = _engine(net, q, units, p, hmc_frozen_noise=False)
+        dev = eng.device
+        xd = torch.from_numpy(x).to(dev)
+        state, logp, grad = torch.empty((n, q), device=dev), torch.empty(n, device=dev), torch.empty((n, q), device=dev)
+        step = torch.full((1,), 0.02, device=dev)
+        acc = torch.zeros(5, device=dev, dtype=torch.int32)
+        eng.hmc_run(xd, state, logp, grad, step, 0, 3, 2 ** 30, 4, 11, init=True, row_base=5, acc_count=acc)
+        eng.hmc_run(xd, state, logp, grad, step, 3, 2, 2 ** 30, 4, 11, row_base=5, acc_count=acc)
+        res.append((state.cpu().numpy(), logp.cpu().numpy(), acc.cpu().numpy()))
+        eng.close()
+    (s0, l0, a0), (s1, l1, a1) = res
+    close = np.abs(s0 - s1).max(axis=1) < 1e-3
+    print("MEASURED fresh chains equal to the workspace kernel: %d of %d, acceptance %s vs %s" % (close.sum(), n, a0.tolist(), a1.tolist()))
+    assert close.mean() > 0.99 and np.abs(a0 - a1).max() <= 0.01 * n
+    assert np.abs(l0 - l1)[close].max() < 2e-3 * max(1.0, np.abs(l1).max())
 
 
 @pytest.mark.parametrize("q,units,p,n", [(10, (64,) * 5, 500, 3000), (5, (64,) * 3, 100, 40000)])
