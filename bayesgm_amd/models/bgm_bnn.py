@@ -437,6 +437,9 @@ class BGMBayes(BGM):
         slot_dev.masked_fill_(~miss_dev, -1)
         per_row = 4 * n_mcmc * (2 * q + max(k_slots, 1) + (p if return_samples else 0))
         rows_chunk = max(bs, int(max_draw_bytes // max(1, per_row)) // bs * bs)
+        quantum = 16 * 8 * torch.cuda.get_device_properties(dev).multi_processor_count      # one round of the sampler: 8 waves per CU x 16 chains
+        if rows_chunk > quantum:           # whole rounds per launch (a chunk of 1.4 rounds costs nearly 2), kept a multiple of bs
+            rows_chunk = max(bs, (rows_chunk // quantum * quantum) // bs * bs)
         means = torch.zeros((n_loc, max(k_slots, 1)), device=dev)
         los = torch.zeros_like(means)
         his = torch.zeros_like(means)
