@@ -105,13 +105,11 @@ static int bns_buffers(bgm_handle *h, BnnState *s, const BnsPlan &pl, long long 
   return BGM_OK;
 }
 
+static thread_local bool bns_wide = false;
 static int bns_session(bgm_handle *h, const char *who, BnnState *&s, BnsPlan &pl) {
   if (!h || !h->bnn_state) { bgm_set_error(std::string(who) + ": no session (bgm_bnn_begin)"); return BGM_E_STATE; }
   s = bst(h);
-  if (!bns_plan(s, pl)) {
-    bgm_set_error(std::string(who) + ": shape outside the sampling kernels (hidden widths <= 64, inputs <= 208, >= 1 hidden layer)");
-    return BGM_E_UNSUPPORTED;
-  }
+  bns_wide = !bns_plan(s, pl);      // outside the LDS-fragment kernels (hidden widths <= 64, inputs <= 208): the any-width path, bnw_api.hip
   return BGM_OK;
 }
 
@@ -147,6 +145,7 @@ extern "C" int bgm_bnn_logpost(bgm_handle *h, const float *x, const float *y, co
   BGM_HIP_CHECK(hipSetDevice(h->device));
   rc = bnf_logpost(h, s, x, y, v, z, n, block_rows, block0, seed, stream_id, out, stream);     // inference-mode normalisation, default shapes
   if (rc <= 0) return rc;
+  if (bns_wide) return bnw_logpost(h, s, x, y, v, z, n, block_rows, block0, seed, stream_id, out, stream);
   const int n_blocks = (int)((n + block_rows - 1) / block_rows);
   BnsBuf b;
   rc = bns_buffers(h, s, pl, n, n_blocks, (long long)n_blocks * pl.set_ghf, b, stream);
@@ -187,6 +186,7 @@ extern "C" int bgm_bnn_mh_run(bgm_handle *h, const bgm_bnn_mh_args *g, void *str
   BGM_HIP_CHECK(hipSetDevice(h->device));
   rc = bnf_mh_run(h, s, g, stream);
   if (rc <= 0) return rc;
+  if (bns_wide) return bnw_mh_run(h, s, g, stream);
   const long long n = g->n;
   const int bs = g->block_rows, n_blocks = (int)((n + bs - 1) / bs), q = s->q;
   BnsBuf b;
@@ -301,6 +301,7 @@ extern "C" int bgm_bnn_evaluate(bgm_handle *h, const float *x, const float *y, c
   const int binary = s->cfg.binary_treatment;
   const int nd = dose_sums ? n_doses : (ite ? 2 : 0);
   if (dose_sums && (!x_values || n_doses < 1)) { bgm_set_error("bgm_bnn_evaluate: dose grid missing"); return BGM_E_INVALID; }
+  if (bns_wide) return bnw_evaluate(h, s, x, y, v, z, encode, n, x_values, n_doses, seed, stream_id, sums, dose_sums, ite, stream);
   BnsBuf b;
   rc = bns_buffers(h, s, pl, n, 1, pl.set_all + (long long)nd * pl.set_f, b, stream);
   if (rc) return rc;
@@ -373,6 +374,7 @@ extern "C" int bgm_bnn_effects(bgm_handle *h, const float *draws, int64_t n, int
   BGM_HIP_CHECK(hipSetDevice(h->device));
   rc = bnf_effects(h, s, draws, n, block_rows, block0, row_base, n_keep, it0, seed, effect, sample_y, x_values, n_doses, adrf_sum, ite, stream);
   if (rc <= 0) return rc;
+  if (bns_wide) return bnw_effects(h, s, draws, n, block_rows, block0, row_base, n_keep, it0, seed, effect, sample_y, x_values, n_doses, adrf_sum, ite, stream);
   const int bs = block_rows, n_blocks = (int)((n + bs - 1) / bs), q = s->q;
   const int nd = effect == 1 ? n_doses : 2;
   BnsBuf b;

@@ -29,10 +29,20 @@ struct BnnState {
   bool bnf_valid = false, bnf_unsupported = false;
   void *egm = nullptr;         // BnnEgmState (bnn_egm_api.hip)
   void *chain = nullptr;       // BnnFitChain (bnn_api.hip): tables / workspace of the row-tile-chain step kernels, or NULL
+  void *bnw = nullptr;         // BnwState (bnw_api.hip): buffers of the any-width sampling path
 };
 
 void bgm_bnn_egm_free(void *egm_state);
 void bnf_free(void *state);
+void bnw_free(void *state);
+int bnw_logpost(bgm_handle *h, BnnState *s, const float *x, const float *y, const float *v, const float *z, int64_t n, int32_t bs, int32_t block0,
+                uint64_t seed, uint32_t stream_id, float *out, hipStream_t stream);
+int bnw_mh_run(bgm_handle *h, BnnState *s, const bgm_bnn_mh_args *g, hipStream_t stream);
+int bnw_effects(bgm_handle *h, BnnState *s, const float *draws, int64_t n, int32_t bs, int32_t block0, int64_t row_base, int32_t n_keep, int32_t it0,
+                uint64_t seed, int32_t effect, int32_t sample_y, const float *x_values, int32_t n_doses, double *adrf_sum, float *ite,
+                hipStream_t stream);
+int bnw_evaluate(bgm_handle *h, BnnState *s, const float *x, const float *y, const float *v, float *z, int32_t encode, int64_t n, const float *x_values,
+                 int32_t n_doses, uint64_t seed, uint32_t stream_id, double *sums, double *dose_sums, float *ite, hipStream_t stream);
 
 inline void bnn_free_sampler(BnnState *s) {
   if (s->samp_dev) hipFree(s->samp_dev);
@@ -41,5 +51,7 @@ inline void bnn_free_sampler(BnnState *s) {
   s->packed_valid = false;
   if (s->bnf) bnf_free(s->bnf);
   s->bnf = nullptr;
+  if (s->bnw) bnw_free(s->bnw);
+  s->bnw = nullptr;
   s->bnf_valid = false;
 }

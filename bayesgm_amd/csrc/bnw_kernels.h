@@ -1,0 +1,319 @@
+// bnw_kernels.h -- posterior sampling, causal effects and evaluation of CausalBGM with Bayesian networks of ANY hidden width
+// (inference-mode input normalisation, params['bnn_norm'] = "fixed") on gfx950.
+//
+// replaces (src/bayesgm/models/causalbgm/base.py, use_bnn branches; networks/bnn.py:4-38 with any nb_units):
+//   get_log_posterior :765-817, metropolis_hastings_sampler :820-904   -> bnw_noise_kernel + bnw_rows_kernel (modes 0 / 1)
+//   infer_from_latent_posterior :671-763                               -> bnw_effects_kernel
+//   evaluate :534-570, data_z = e_net(data_v) :479                     -> bnw_rows_kernel (modes 2 / 3) + bnw_effects_kernel
+// The fast families (bnf_kernels.h: default shapes; bnn_sample_kernels.h: hidden widths <= 64) hold every layer in LDS fragments; this
+// one is the correctness path for everything wider: a workgroup owns a tile of up to 64 rows of ONE block and walks the nets with the
+// Flipout routines of the minibatch steps (bnn_kernels.h: activations in a per-workgroup global workspace, both products of a layer as
+// one MFMA pass over 16 x 16 tiles).  With inference-mode normalisation the rows of a block share only the perturbation
+// dW = sigma * eps of a (block, call), produced once per launch for all tiles (bnw_noise_kernel); the sign words are keyed by the row's
+// position inside its block.  Noise specification: oracle/bnn.py (log_posterior_blocks, mh_iteration, effects_draw, evaluate).
+#pragma once
+#include <algorithm>
+
+#include "bnn_kernels.h"
+
+#define BNW_RT 64                       // rows of a workgroup tile
+
+struct BnwNets {
+  BnnNet net[4];                        // g, e, f, h (BNN_* ids) with bn_fixed = 1
+  const float *theta;
+  int noff[4];                          // offset of net k's perturbation inside a set (-1: not in the sets of this launch)
+  long long set_floats;
+  int q, p, z0, z1, z2, binary;
+  float sig2[3];                        // fixed sigma_v^2, sigma_x^2, sigma_y^2 (<= 0: the variance heads)
+};
+
+// dW of `n_calls` calls per block: set (blk * n_calls + c) = [net .. | net ..] with key of block block0 + blk, stream stream0 + c * stride
+struct BnwNoiseArgs {
+  BnwNets m;
+  float *dw;
+  int n_calls, block0;
+  uint32_t k0, k1, stream0, stream_stride;
+};
+static __global__ __launch_bounds__(256) void bnw_noise_kernel(BnwNoiseArgs a) {
+  const int set = blockIdx.y, blk = set / a.n_calls, call = set - blk * a.n_calls;
+  const uint32_t stream = a.stream0 + (uint32_t)call * a.stream_stride, k1 = a.k1 + (uint32_t)(a.block0 + blk);
+  float *base = a.dw + (long long)set * a.m.set_floats;
+  for (int k = 0; k < 4; ++k) {
+    if (a.m.noff[k] < 0) continue;
+    const BnnNet &n = a.m.net[k];
+    for (int l = 0; l < n.n_layers; ++l) {
+      const int cnt = n.lin[l] * n.lout[l];
+      const float *rho = a.m.theta + n.woff[l] + cnt;
+      float *d = base + a.m.noff[k] + n.eoff[l];
+      for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (cnt + 3) >> 2; i += gridDim.x * blockDim.x) {
+        const f32x4 z = box_muller4(philox4x32_10((uint32_t)i, (uint32_t)l | ((uint32_t)n.net_id << 16), stream, BNN_TAG_EPS, a.k0, k1));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = 4 * i + u;
+          if (idx < cnt) d[idx] = (BNN_SCALE_EPS + softplus_acc(rho[idx])) * z[u];
+        }
+      }
+    }
+  }
+}
+
+// call cache without private perturbation arrays (the call's dW is shared by all tiles of the block)
+__device__ __forceinline__ void bnw_cache(const BnnNet &n, int B, float *p, BnnCache &k, const float *input, const float *dw) {
+  auto take = [&](long long cnt) { float *r = p; p += (cnt + 3) & ~3LL; return r; };
+  k.x = input;
+  k.xhat = take((long long)B * n.dims[0]);
+  k.inv = take(n.dims[0]);
+  k.mu = nullptr;
+  k.H = take((long long)B * n.hoff[n.n_layers + 1]);
+  k.HS = take((long long)B * n.hs_total);
+  k.eps = nullptr;
+  k.dW = const_cast<float *>(dw);
+  k.sg = (uint32_t *)take((long long)B * n.swords);
+}
+inline size_t bnw_cache_floats(const BnnNet &n, int B) {
+  return (size_t)B * n.dims[0] + n.dims[0] + (size_t)B * (n.hoff[n.n_layers + 1] + n.hs_total) + (size_t)B * n.swords + 64;
+}
+// per-workgroup workspace: two latent tiles, the f / h inputs, the call cache
+inline size_t bnw_ws_floats(const BnwNets &m) {
+  size_t c = 0;
+  for (int k = 0; k < 4; ++k) c = std::max(c, bnw_cache_floats(m.net[k], BNW_RT));
+  return (size_t)BNW_RT * (2 * (size_t)m.q + m.net[BNN_F].dims[0] + m.net[BNN_H].dims[0] + 8) + c + 256;
+}
+struct BnwWs { float *zp, *zc, *fin, *hin, *cache; };
+__device__ __forceinline__ void bnw_take(float *wp, const BnwNets &m, BnwWs &w) {
+  auto take = [&](long long cnt) { float *r = wp; wp += (cnt + 3) & ~3LL; return r; };
+  w.zp = take((long long)BNW_RT * m.q); w.zc = take((long long)BNW_RT * m.q);
+  w.fin = take((long long)BNW_RT * m.net[BNN_F].dims[0]); w.hin = take((long long)BNW_RT * m.net[BNN_H].dims[0]);
+  w.cache = wp;
+}
+
+// feature f of the row's normals(row, it, q, tag): Philox call (f & 3) + 4 (f >> 4), output (f >> 2) & 3   (oracle/rng.py normals)
+__device__ __forceinline__ float bnw_normal(uint32_t row, uint32_t it, int f, uint32_t tag, uint32_t k0, uint32_t k1) {
+  const f32x4 e = box_muller4(philox4x32_10(row, it, (uint32_t)((f & 3) + 4 * (f >> 4)), tag, k0, k1));
+  const int r = (f >> 2) & 3;
+  return r == 0 ? e[0] : (r == 1 ? e[1] : (r == 2 ? e[2] : e[3]));
+}
+
+// one call of net `id` on the tile's B rows (input [B x in] in the workspace or the panel); returns its output [B x wo]
+__device__ __forceinline__ const float *bnw_call(const BnnCtx &c, const BnwNets &m, int id, const BnwWs &w, const float *input, int B,
+                                                 const float *set, uint32_t k0, uint32_t k1, uint32_t stream, uint32_t row0) {
+  BnnCache k;
+  bnw_cache(m.net[id], B, w.cache, k, input, set + m.noff[id]);
+  const float *o = bnn_fwd(c, m.theta, m.net[id], k, B, k0, k1, stream, row0, true);
+  __syncthreads();
+  return o;
+}
+__device__ __forceinline__ void bnw_inputs(const BnnCtx &c, const BnwNets &m, const BnwWs &w, const float *zs, const float *xrow, int B) {
+  const int q = m.q, nf = m.net[BNN_F].dims[0], nh = m.net[BNN_H].dims[0], zf = m.z0 + m.z1;
+  for (int i = c.tid; i < B * nf; i += BNN_THREADS) { const int b = i / nf, j = i - b * nf; w.fin[i] = j < zf ? zs[b * q + j] : xrow[b]; }
+  for (int i = c.tid; i < B * nh; i += BNN_THREADS) { const int b = i / nh, j = i - b * nh; w.hin[i] = j < m.z0 ? zs[b * q + j] : zs[b * q + m.z1 + j]; }
+  __syncthreads();
+}
+
+// log p(z | x, y, v) + const of the tile's rows under the calls (set, stream): lp[b]   (base.py:765-817)
+__device__ __forceinline__ void bnw_logp(const BnnCtx &c, const BnwNets &m, const BnwWs &w, const float *zs, const float *x, const float *y,
+                                         const float *v, int B, const float *set, uint32_t k0, uint32_t k1, uint32_t stream, uint32_t row0,
+                                         float *ssq, float *lp) {
+  const int p = m.p, q = m.q;
+  {
+    const float *o = bnw_call(c, m, BNN_G, w, zs, B, set, k0, k1, stream, row0);
+    const int wo = p + 1;
+    bnn_row_ssq(c, v, o, B, p, wo, ssq);
+    __syncthreads();
+    for (int b = c.tid; b < B; b += BNN_THREADS) {
+      const float s2 = m.sig2[0] > 0.0f ? m.sig2[0] : softplus_acc(o[b * wo + p]) + BGM_EPS;
+      float zz = 0.0f;
+      for (int j = 0; j < q; ++j) zz = fmaf(zs[b * q + j], zs[b * q + j], zz);
+      lp[b] = -(ssq[b] / (2.0f * s2) + (float)p * logf(s2) * 0.5f) - 0.5f * zz;
+    }
+    __syncthreads();
+  }
+  bnw_inputs(c, m, w, zs, x, B);
+  {
+    const float *o = bnw_call(c, m, BNN_H, w, w.hin, B, set, k0, k1, stream, row0);
+    for (int b = c.tid; b < B; b += BNN_THREADS) {
+      const float l = o[2 * b];
+      if (m.binary) lp[b] -= fmaxf(l, 0.0f) - l * x[b] + log1pf(expf(-fabsf(l)));
+      else { const float s2 = m.sig2[1] > 0.0f ? m.sig2[1] : softplus_acc(o[2 * b + 1]) + BGM_EPS, d = x[b] - l; lp[b] -= d * d / (2.0f * s2) + logf(s2) * 0.5f; }
+    }
+    __syncthreads();
+  }
+  {
+    const float *o = bnw_call(c, m, BNN_F, w, w.fin, B, set, k0, k1, stream, row0);
+    for (int b = c.tid; b < B; b += BNN_THREADS) {
+      const float s2 = m.sig2[2] > 0.0f ? m.sig2[2] : softplus_acc(o[2 * b + 1]) + BGM_EPS, d = y[b] - o[2 * b];
+      lp[b] -= d * d / (2.0f * s2) + logf(s2) * 0.5f;
+    }
+    __syncthreads();
+  }
+}
+
+struct BnwRowsArgs {
+  BnwNets m;
+  const float *dw;
+  int n_calls;                          // sets per block
+  const float *x, *y, *v;
+  float *z;                             // [n x q]: state (modes 0, 1, 2), written by mode 3
+  long long n, row_base;
+  int bs, block0, tiles_per_block, n_items;
+  int mode;                             // 0: log posterior of z -> out;  1: MH iteration `it`;  2: reconstruction sums;  3: z = e(v)
+  int it, init;
+  float q_sd;
+  const float *q_sd_blocks;
+  uint32_t k0, k1, stream0;
+  float *out;                           // mode 0: [n]
+  unsigned *acc_count, *acc_blocks;     // mode 1 (optional)
+  double *sums;                         // mode 2: [3] += sums over rows of |v - v^|^2, (x - x^)^2, (y - y^)^2
+  float *ws;
+  long long ws_stride;
+};
+
+static __global__ __launch_bounds__(BNN_THREADS) void bnw_rows_kernel(BnwRowsArgs a) {
+  __shared__ float red[32];
+  __shared__ float ssq[BNW_RT], lpp[BNW_RT], lpc[BNW_RT];
+  __shared__ unsigned nacc_s;
+  BnnCtx c{(int)threadIdx.x, red};
+  const BnwNets &m = a.m;
+  const int q = m.q, p = m.p;
+  BnwWs w;
+  bnw_take(a.ws + (long long)blockIdx.x * a.ws_stride, m, w);
+  for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+    const int blk = item / a.tiles_per_block, t = item - blk * a.tiles_per_block;
+    const long long blk_lo = (long long)blk * a.bs;
+    const int blk_n = (int)min((long long)a.bs, a.n - blk_lo), rib0 = t * BNW_RT;
+    if (rib0 >= blk_n) continue;
+    const int B = min(BNW_RT, blk_n - rib0);
+    const long long r0 = blk_lo + rib0;
+    const uint32_t k1b = a.k1 + (uint32_t)(a.block0 + blk);
+    const float *xr = a.x ? a.x + r0 : nullptr, *yr = a.y ? a.y + r0 : nullptr, *vr = a.v ? a.v + r0 * p : nullptr;
+    const float *set0 = a.dw + (long long)blk * a.n_calls * m.set_floats;
+    if (a.mode == 3) {                  // data_z = e_net(data_v)
+      const float *o = bnw_call(c, m, BNN_E, w, vr, B, set0, a.k0, k1b, a.stream0, (uint32_t)rib0);
+      for (int i = c.tid; i < B * q; i += BNN_THREADS) a.z[r0 * q + i] = o[i];
+      __syncthreads();
+      continue;
+    }
+    {
+      const float sd = a.q_sd_blocks ? a.q_sd_blocks[blk] : a.q_sd;
+      for (int i = c.tid; i < B * q; i += BNN_THREADS) {
+        const uint32_t rid = (uint32_t)(a.row_base + r0 + i / q);
+        float zv;
+        if (a.mode == 1 && a.init) { zv = bnw_normal(rid, 0u, i % q, TAG_INIT, a.k0, a.k1); a.z[r0 * q + i] = zv; }      // current_state ~ N(0, 1), base.py:842
+        else zv = a.z[r0 * q + i];
+        w.zc[i] = zv;
+        if (a.mode == 1) w.zp[i] = fmaf(sd, bnw_normal(rid, (uint32_t)a.it, i % q, TAG_PROP, a.k0, a.k1), zv);
+      }
+    }
+    __syncthreads();
+    if (a.mode == 0) {
+      bnw_logp(c, m, w, w.zc, xr, yr, vr, B, set0, a.k0, k1b, a.stream0, (uint32_t)rib0, ssq, lpc);
+      for (int b = c.tid; b < B; b += BNN_THREADS) a.out[r0 + b] = lpc[b];
+      __syncthreads();
+    } else if (a.mode == 1) {
+      bnw_logp(c, m, w, w.zp, xr, yr, vr, B, set0, a.k0, k1b, 2u * (uint32_t)a.it, (uint32_t)rib0, ssq, lpp);
+      bnw_logp(c, m, w, w.zc, xr, yr, vr, B, set0 + m.set_floats, a.k0, k1b, 2u * (uint32_t)a.it + 1u, (uint32_t)rib0, ssq, lpc);
+      if (c.tid == 0) nacc_s = 0u;
+      __syncthreads();
+      for (int b = c.tid; b < B; b += BNN_THREADS) {
+        const uint4 w4 = philox4x32_10((uint32_t)(a.row_base + r0 + b), (uint32_t)a.it >> 2, 0u, TAG_ACC, a.k0, a.k1);
+        const int it = a.it;
+        const unsigned wd = (it & 2) ? ((it & 1) ? w4.w : w4.z) : ((it & 1) ? w4.y : w4.x);
+        if (u01_open(wd) < expf(fminf(lpp[b] - lpc[b], 0.0f))) {
+          for (int j = 0; j < q; ++j) a.z[(r0 + b) * q + j] = w.zp[b * q + j];
+          atomicAdd(&nacc_s, 1u);
+        }
+      }
+      __syncthreads();
+      if (c.tid == 0 && nacc_s) {
+        if (a.acc_count) atomicAdd(a.acc_count, nacc_s);
+        if (a.acc_blocks) atomicAdd(&a.acc_blocks[blk], nacc_s);
+      }
+      __syncthreads();
+    } else {                            // mode 2: one call of g, h, f -> squared reconstruction errors (base.py:541-552)
+      float sv = 0.0f, sx = 0.0f, sy = 0.0f;
+      {
+        const float *o = bnw_call(c, m, BNN_G, w, w.zc, B, set0, a.k0, k1b, a.stream0, (uint32_t)rib0);
+        bnn_row_ssq(c, vr, o, B, p, p + 1, ssq);
+        __syncthreads();
+        for (int b = c.tid; b < B; b += BNN_THREADS) sv += ssq[b];
+        __syncthreads();
+      }
+      bnw_inputs(c, m, w, w.zc, xr, B);
+      {
+        const float *o = bnw_call(c, m, BNN_H, w, w.hin, B, set0, a.k0, k1b, a.stream0, (uint32_t)rib0);
+        for (int b = c.tid; b < B; b += BNN_THREADS) { const float l = o[2 * b], xp = m.binary ? sigmoid_f(l) : l, d = xr[b] - xp; sx = fmaf(d, d, sx); }
+        __syncthreads();
+      }
+      {
+        const float *o = bnw_call(c, m, BNN_F, w, w.fin, B, set0, a.k0, k1b, a.stream0, (uint32_t)rib0);
+        for (int b = c.tid; b < B; b += BNN_THREADS) { const float d = yr[b] - o[2 * b]; sy = fmaf(d, d, sy); }
+        __syncthreads();
+      }
+      sv = bnn_block_sum(c, sv); sx = bnn_block_sum(c, sx); sy = bnn_block_sum(c, sy);
+      if (c.tid == 0) { atomicAdd(&a.sums[0], (double)sv); atomicAdd(&a.sums[1], (double)sx); atomicAdd(&a.sums[2], (double)sy); }
+      __syncthreads();
+    }
+  }
+}
+
+// f-net at the treatment values xvals[0 .. n_doses) on one state per row (infer_from_latent_posterior, one kept draw per launch; the
+// dose loops of evaluate).  Set of (block, dose k) = blk * n_doses + k, stream stream0 + k.
+struct BnwEffArgs {
+  BnwNets m;
+  const float *dw;
+  const float *z;                       // [n x q]
+  long long n, row_base;
+  int bs, block0, tiles_per_block, n_items, n_doses;
+  const float *xvals;
+  uint32_t k0, k1, stream0, it_noise;
+  int sample_y;
+  double *sum_out; long long sum_stride;    // dose k: sum_out[k * sum_stride] += sum over rows (or NULL)
+  float *ite_out; long long ite_stride;     // binary: ite_out[row * ite_stride] = y(dose 0) - y(dose 1) (or NULL)
+  float *ws;
+  long long ws_stride;
+};
+static __global__ __launch_bounds__(BNN_THREADS) void bnw_effects_kernel(BnwEffArgs a) {
+  __shared__ float red[32];
+  __shared__ float y0[BNW_RT];
+  BnnCtx c{(int)threadIdx.x, red};
+  const BnwNets &m = a.m;
+  const int q = m.q, nf = m.net[BNN_F].dims[0], zf = m.z0 + m.z1;
+  BnwWs w;
+  bnw_take(a.ws + (long long)blockIdx.x * a.ws_stride, m, w);
+  for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+    const int blk = item / a.tiles_per_block, t = item - blk * a.tiles_per_block;
+    const long long blk_lo = (long long)blk * a.bs;
+    const int blk_n = (int)min((long long)a.bs, a.n - blk_lo), rib0 = t * BNW_RT;
+    if (rib0 >= blk_n) continue;
+    const int B = min(BNW_RT, blk_n - rib0);
+    const long long r0 = blk_lo + rib0;
+    const uint32_t k1b = a.k1 + (uint32_t)(a.block0 + blk);
+    for (int k = 0; k < a.n_doses; ++k) {
+      const float xv = a.xvals[k];
+      for (int i = c.tid; i < B * nf; i += BNN_THREADS) { const int b = i / nf, j = i - b * nf; w.fin[i] = j < zf ? a.z[(r0 + b) * q + j] : xv; }
+      __syncthreads();
+      const float *set = a.dw + ((long long)blk * a.n_doses + k) * m.set_floats;
+      const float *o = bnw_call(c, m, BNN_F, w, w.fin, B, set, a.k0, k1b, a.stream0 + (uint32_t)k, (uint32_t)rib0);
+      float tot = 0.0f;
+      for (int b = c.tid; b < B; b += BNN_THREADS) {
+        float yk = o[2 * b];
+        if (a.sample_y) {
+          const float s2 = m.sig2[2] > 0.0f ? m.sig2[2] : softplus_acc(o[2 * b + 1]) + BGM_EPS;
+          const f32x4 nz = box_muller4(philox4x32_10((uint32_t)(a.row_base + r0 + b), a.it_noise, (uint32_t)(k >> 2), TAG_YNOISE, a.k0, a.k1));
+          const int e = k & 3;
+          yk = fmaf(sqrtf(s2), e == 0 ? nz[0] : (e == 1 ? nz[1] : (e == 2 ? nz[2] : nz[3])), yk);
+        }
+        tot += yk;
+        if (a.ite_out) {
+          if (k == 0) y0[b] = yk;
+          else if (k == 1) a.ite_out[(r0 + b) * a.ite_stride] = y0[b] - yk;
+        }
+      }
+      if (a.sum_out) {
+        tot = bnn_block_sum(c, tot);
+        if (c.tid == 0) atomicAdd(&a.sum_out[(long long)k * a.sum_stride], (double)tot);
+      }
+      __syncthreads();
+    }
+  }
+}
