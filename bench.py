@@ -250,6 +250,58 @@ def training_leg(params, x, y, v, device, n=20000, batch=32, reps=200):
 
 
 
+def bgm_hmc_leg(device, n=200000, p=500, q=10, L=10, iters=4):
+    """Secondary measurement (not `value`): the HMC transition kernels of BGM imputation at BASELINE config C4's shape (x_dim 500, z_dim 10,
+    g_units [64] x 5, 10 leapfrog steps, 10 % cells missing) -- deterministic generator (bgm_hmc_kernel, head weights streamed) and the
+    Bayesian generator under both noise modes (bgmf_hmc_kernel).  FLOP: L gradient evaluations x 4 MACs(g) per row-transition (forward + backward to the input, 2 FLOP per MAC), twice
+    that with Flipout's two products per layer.  Random-init weights; timing only."""
+    import time
+    import torch
+    from bayesgm_amd.engine import BgmEngine
+    from bayesgm_amd.bvn_engine import BvnEngine
+    rs = np.random.RandomState(0)
+    macs = q * 64 + 4 * 4096 + 2 * 64 * p
+    x = torch.randn(n, p, device=device)
+    x[torch.rand(n, p, device=device) < 0.1] = float("nan")
+    step = torch.full((1,), 0.01, device=device)
+
+    def timed(eng):
+        state, logp, grad = torch.empty((n, q), device=device), torch.empty(n, device=device), torch.empty((n, q), device=device)
+        eng.hmc_run(x, state, logp, grad, step, 0, 1, 2 ** 30, L, 1, init=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.hmc_run(x, state, logp, grad, step, 1, iters, 2 ** 30, L, 1)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters
+
+    def glorot(a, b):
+        lim = np.sqrt(6.0 / (a + b))
+        return rs.uniform(-lim, lim, (a, b)).astype(np.float32)
+
+    def entry(kernel, dt, products):
+        return {"kernel": kernel, "ms_per_transition": 1e3 * dt, "transitions_per_s": n / dt,
+                "frac_of_fp32_mfma_peak": L * 4 * macs * products * n / dt / 1e12 / 157.3}
+    out = {"sample": "N=%d rows, x_dim=%d, z_dim=%d, g_units [64] x 5, %d leapfrog steps, 10 %% cells missing, %d transitions timed" % (n, p, q, L, iters)}
+    g = {"bn": dict(gamma=np.ones(q, np.float32), beta=np.zeros(q, np.float32), mean=np.zeros(q, np.float32), var=np.ones(q, np.float32)),
+         "trunk": [(glorot(q if i == 0 else 64, 64), np.zeros(64, np.float32)) for i in range(5)],
+         "mean": (glorot(64, p), np.zeros(p, np.float32)), "var": (glorot(64, p), np.zeros(p, np.float32))}
+    eng = BgmEngine(p, q, g_units=[64] * 5)
+    eng.set_weights(g)
+    out["deterministic"] = entry("bgm_hmc_kernel (head weights streamed)", timed(eng), 1)
+
+    def flip(a, b):
+        return ((0.1 * rs.standard_normal((a, b))).astype(np.float32), (-3.0 + 0.1 * rs.standard_normal((a, b))).astype(np.float32),
+                (0.1 * rs.standard_normal(b)).astype(np.float32))
+    vnet = {"gamma": np.ones(q, np.float32), "beta": np.zeros(q, np.float32), "mean_mv": np.zeros(q, np.float32), "var_mv": np.ones(q, np.float32),
+            "trunk": [flip(q if i == 0 else 64, 64) for i in range(5)], "mean": flip(64, p), "var": flip(64, p)}
+    for mode, frozen in (("bayesian_frozen_noise", True), ("bayesian_fresh_noise", False)):
+        be = BvnEngine(p, q, g_units=[64] * 5, hmc_frozen_noise=frozen)
+        be.begin(vnet)
+        out[mode] = entry("bgmf_hmc_kernel (posterior means LDS-resident, perturbation streamed)", timed(be), 2)
+        be.close()
+    return out
+
+
 def bayesian_leg(params, data, x_values, n_loc, args, device):
     """Secondary measurement (not `value`): the same predict with the reference's default Bayesian nets (use_bnn=True,
     DESIGN_HISTORY.md section 7) on a tenth of the iterations -- all blocks advance in lock step, three launches per iteration, so
@@ -419,6 +471,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bayesian", action="store_true", help="skip the secondary use_bnn=True measurement (N=1 only)")
     ap.add_argument("--no-fit", action="store_true", help="skip the secondary fit-throughput measurement (N=1 only)")
+    ap.add_argument("--no-bgm", action="store_true", help="skip the secondary BGM HMC measurement at config C4's shape (N=1 only)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --rows per GPU (default); strong: --rows in TOTAL, sharded over the GPUs (BASELINE configs[3]: N=1e6 over 8 GPUs)")
     ap.add_argument("--no-bf16x3", action="store_true", help="skip the secondary split-precision (bf16 x 3) measurement (N=1 only)")
@@ -614,6 +667,8 @@ def main():
             out["accuracy"] = accuracy_leg(params, data, x_values, n_loc, args)
         if not args.no_bayesian and world == 1:
             out["bayesian_nets"] = bayesian_leg(params, data, x_values, n_loc, args, device)
+        if not args.no_bgm and world == 1:
+            out["bgm_hmc"] = bgm_hmc_leg(device)
         if not args.no_fit and world == 1:
             out["fit"] = fit_leg(model, x, y, v, n_loc)
             out["training_steps"] = training_leg(params, x, y, v, device)

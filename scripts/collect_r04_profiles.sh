@@ -25,8 +25,8 @@ for w in $WHAT; do
   case $w in
     bench)
       python bench.py --steps 2 --warmup 1 > $OUT/r04_bench_N1e6_1gpu.json 2> $OUT/bench.err
-      timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/kt_bench -o kt -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-bayesian --no-fit --no-accuracy > $OUT/kt_bench.log 2>&1
-      { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-bayesian --no-fit --no-accuracy"; summ $OUT/kt_bench; } > $OUT/r04_kernel_trace_bench_N1e6.txt
+      timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/kt_bench -o kt -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-bayesian --no-fit --no-accuracy --no-bgm > $OUT/kt_bench.log 2>&1
+      { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-bayesian --no-fit --no-accuracy --no-bgm"; summ $OUT/kt_bench; } > $OUT/r04_kernel_trace_bench_N1e6.txt
       rm -rf $OUT/kt_bench ;;
     keep) passes causal_mh python scripts/probe_mh.py 1e6 100 40 ;;
     gx) passes gx_w256 env BGM_FORCE_GX=1 GX_ONLY=w256 python scripts/probe_gx.py 250000 ;;
