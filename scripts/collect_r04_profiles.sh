@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-4 rocprofv3 evidence, run on the GPU box from the repo root (gpurun).  Counters in their own passes (--kernel-trace only beside
 # --pmc), as MI355X_MICROARCH.md prescribes.  Summaries land in gpurun_out/r04prof/ and are copied to profiles/ by hand.
-# usage: bash scripts/collect_r04_profiles.sh [what ...]   what in: bench keep gx bvn bvnc fit   (default: all)
+# usage: bash scripts/collect_r04_profiles.sh [what ...]   what in: bench keep gx bvn bvnc bvnf fit   (default: all)
 set -u
 OUT=gpurun_out/r04prof
 mkdir -p $OUT
@@ -31,6 +31,7 @@ for w in $WHAT; do
     keep) passes causal_mh python scripts/probe_mh.py 1e6 100 40 ;;
     gx) passes gx_w256 env BGM_FORCE_GX=1 GX_ONLY=w256 python scripts/probe_gx.py 250000 ;;
     bvn) passes bvn_hmc_frozen env BGM_BVN_NO_CHAINS=1 python scripts/probe_bvn_hmc.py 400000 3 ;;      # the LDS-tile engine (gxf_bgm_hmc_kernel)
+    bvnf) passes bvn_hmc_fresh python scripts/probe_bvn_hmc.py 400000 3 fresh ;;                        # row-tile chains, fresh noise (linear stream)
     bvnc) passes bvn_hmc_chains python scripts/probe_bvn_hmc.py 400000 3 ;;                            # row-tile chains (bgmf_hmc_kernel)
     fit) timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/fit_kt -o kt -- python scripts/probe_fit.py 1e6 32 replay 2000 > $OUT/fit_kt.log 2>&1
          { echo "# rocprofv3 --kernel-trace --stats -- python scripts/probe_fit.py 1e6 32 replay 2000   (2005 minibatches from Python + 2005 from bgm_causal_fit_epoch)"; grep -E "^(N=|  library)" $OUT/fit_kt.log | sed 's/^/# /'; summ $OUT/fit_kt; } > $OUT/r04_kernel_trace_fit_B32.txt
