@@ -620,3 +620,26 @@ def test_model_fit_with_minibatches_beyond_64_rows(tmp_path):
     assert model.history_loss[-1] < mse0 and np.isfinite(model.history_loss).all()
     with pytest.raises(ValueError):
         model.fit(data, batch_size=300, epochs=1, use_egm_init=False, verbose=0)
+
+
+@pytest.mark.parametrize("n", [1, 17, 129])
+@pytest.mark.parametrize("frozen", [True, False])
+def test_row_tile_chains_on_tiny_panels(monkeypatch, n, frozen):
+    """One row, one row more than a tile, one row more than a workgroup's eight tiles: the chain kernel against the kernels it replaced."""
+    q, units, p = 4, (64,) * 3, 21
+    net = _net(q, units, p, seed=20)
+    rs = np.random.RandomState(21)
+    x = rs.standard_normal((n, p)).astype(np.float32)
+    x[rs.uniform(size=x.shape) < 0.3] = np.nan
+    res = []
+    for no_chains in (False, True):
+        if no_chains:
+            monkeypatch.setenv("BGM_BVN_NO_CHAINS", "1")
+        else:
+            monkeypatch.delenv("BGM_BVN_NO_CHAINS", raising=False)
+        eng = _engine(net, q, units, p, hmc_frozen_noise=frozen)
+        out = eng.hmc_sample(x, n_mcmc=2, burn_in=3, step_size=0.05, n_leapfrog=3, seed=5, row_base=2)
+        res.append(out["draws"].cpu().numpy())
+        eng.close()
+    assert res[0].shape == (2, n, q) and np.isfinite(res[0]).all()
+    assert (np.abs(res[0] - res[1]).max(axis=(0, 2)) < 1e-3).mean() >= (1.0 if n == 1 else 0.9)

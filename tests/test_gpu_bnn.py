@@ -746,3 +746,17 @@ def test_class_with_wide_bayesian_nets(tmp_path):
     assert np.isfinite([mx1, my1, mv1]).all() and mv1 < mv0
     eff, interval = model.predict((x, y, v), alpha=0.05, n_mcmc=10, burn_in=10, x_values=np.linspace(0, 3, 4), q_sd=0.5, bs=128, verbose=0)
     assert eff.shape == (4,) and np.isfinite(eff).all() and np.isfinite(interval).all()
+
+
+def test_wide_bayesian_nets_on_tiny_blocks():
+    """Blocks smaller than a tile, a last block of one row (any-width path)."""
+    m = _model(False, p=11, fixed=True, **WIDE)
+    n, bs = 7, 3
+    z, x, y, v = _panel(m, n)
+    eng = _engine(m, norm_mode=1, **WIDE)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
+    got = eng.logpost(T(x[:, 0]), T(y[:, 0]), T(v), T(z), bs, 99, 5).cpu().numpy()
+    m64 = OB.cast_model(m, np.float64)
+    ref = OB.log_posterior_blocks(m64, x.astype(np.float64), y.astype(np.float64), v.astype(np.float64), z.astype(np.float64), bs, 99, 5)
+    assert np.abs(got - ref).max() < 2e-3 * np.abs(ref).max()
+    eng.close()
