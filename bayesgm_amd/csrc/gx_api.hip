@@ -82,7 +82,23 @@ int gx_session(bgm_handle *h, GxState *&st, hipStream_t stream, bool need_ghf = 
     for (int l = 0; l <= m.h.L; ++l) wmax = std::max(wmax, m.h.pad[l]);
     m.ld = gx_ld(wmax);
     m.ncg = m.g.pad[m.g.L] / 32;
-    s->lds_bytes = 4 * gx_causal_lds_floats(m.ld, m.q, m.ncg);
+    {   // doses per pass of the effect routine (more rows per barrier and per weight fetch for the small outcome net): as many as leave
+        // two workgroups per CU (measured, profiles/r04_gx_cost.txt: the kept phase gains 10-25 %, the transitions lose ~7 % at 2 instead of 4)
+      int wf = 32;
+      for (int l = 0; l <= m.f.L; ++l) wf = std::max(wf, m.f.pad[l]);
+      m.ldf = gx_ld(wf);
+      auto occ_of = [](int bytes) { return std::max(1, std::min(4, (160 * 1024) / std::max(bytes, 1))); };
+      const int occ1 = occ_of(4 * gx_causal_lds_floats(m.ld, m.q, m.ncg, m.ldf, 1));
+      m.db = 1;
+      static const bool no_db = std::getenv("BGM_GX_NO_DOSE_BATCH") != nullptr;
+      for (int cand : {4, 3, 2})
+        if (!no_db && 4 * gx_causal_lds_floats(m.ld, m.q, m.ncg, m.ldf, cand) <= 160 * 1024 && occ_of(4 * gx_causal_lds_floats(m.ld, m.q, m.ncg, m.ldf, cand)) >= std::min(occ1, 2)) { m.db = cand; break; }
+    }
+    if (const char *f_ = std::getenv("BGM_GX_DB")) {      // dev: force the dose batch
+        const int want = std::max(1, std::min(GX_MAXDB, std::atoi(f_)));
+        if (4 * gx_causal_lds_floats(m.ld, m.q, m.ncg, m.ldf, want) <= 160 * 1024) m.db = want;
+      }
+      s->lds_bytes = 4 * gx_causal_lds_floats(m.ld, m.q, m.ncg, m.ldf, m.db);
     s->lds_fit = 4 * gx_fit_lds_floats(m.ld, m.q);
     int wenc = 32;
     for (int l = 1; l <= m.e.L; ++l) wenc = std::max(wenc, m.e.pad[l]);

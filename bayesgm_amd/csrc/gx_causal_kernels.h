@@ -23,6 +23,8 @@ struct GxCausalModel {
   int q, p, z0, z1, z2, binary;
   float sig2_v, sig2_x, sig2_y;      // fixed variances (params['sigma_*'] ** 2) or < 0: learned heads
   int ld;                            // LDS row stride of the activation buffers
+  int ldf, db;                       // row stride of the outcome net's activations; doses evaluated per pass of the effect routine (their rows
+                                     // stacked in the activation buffers: db x 32 rows x ldf floats fit a buffer)
   int ncg;                           // 32-column groups of g's output
   const int *prior_seg;              // conditional latent prior of IdentifiableCausalBGM (bgm_causal_set_prior) or NULL
   const float *prior_tab;            // [n_segments x (q + 2)]: mu [q], 1 / sigma^2, (q / 2) log sigma^2
@@ -32,13 +34,18 @@ struct GxCausalModel {
 struct GxLds {
   float *bufA, *bufB, *zc, *zp, *ssep, *sraw, *fo, *ho, *lpn, *lpc, *red;
 };
-__host__ __device__ inline int gx_causal_lds_floats(int ld, int q, int ncg) { return 2 * GX_ROWS * ld + 2 * GX_ROWS * q + ncg * GX_ROWS + 8 * GX_ROWS + 64; }
-__device__ __forceinline__ GxLds gx_carve(float *lds, int ld, int q, int ncg) {
+#define GX_MAXDB 4
+__host__ __device__ inline int gx_buf_floats(int ld, int ldf, int db) { return GX_ROWS * (ld > db * ldf ? ld : db * ldf); }
+__host__ __device__ inline int gx_causal_lds_floats(int ld, int q, int ncg, int ldf = 0, int db = 1) {
+  return 2 * gx_buf_floats(ld, ldf, db) + 2 * GX_ROWS * q + ncg * GX_ROWS + (6 + 2 * GX_MAXDB) * GX_ROWS + 64;
+}
+__device__ __forceinline__ GxLds gx_carve(float *lds, int ld, int q, int ncg, int ldf = 0, int db = 1) {
   GxLds L;
-  L.bufA = lds; L.bufB = L.bufA + GX_ROWS * ld;
-  L.zc = L.bufB + GX_ROWS * ld; L.zp = L.zc + GX_ROWS * q;
+  const int bf = gx_buf_floats(ld, ldf, db);
+  L.bufA = lds; L.bufB = L.bufA + bf;
+  L.zc = L.bufB + bf; L.zp = L.zc + GX_ROWS * q;
   L.ssep = L.zp + GX_ROWS * q; L.sraw = L.ssep + ncg * GX_ROWS;
-  L.fo = L.sraw + GX_ROWS; L.ho = L.fo + 2 * GX_ROWS; L.lpn = L.ho + 2 * GX_ROWS; L.lpc = L.lpn + GX_ROWS; L.red = L.lpc + GX_ROWS;
+  L.fo = L.sraw + GX_ROWS; L.ho = L.fo + 2 * GX_MAXDB * GX_ROWS; L.lpn = L.ho + 2 * GX_ROWS; L.lpc = L.lpn + GX_ROWS; L.red = L.lpc + GX_ROWS;
   return L;
 }
 
@@ -66,25 +73,26 @@ struct GxGLastEpi {
 
 // Stage the 32 rows of a network input into an LDS activation buffer (zero beyond the true width); src(row, col) gives the value.
 template <class Src>
-__device__ __forceinline__ void gx_stage(float *buf, int ld, int width_pad, Src src) {
-  for (int i = threadIdx.x; i < GX_ROWS * width_pad; i += GX_THREADS) {
+__device__ __forceinline__ void gx_stage(float *buf, int ld, int width_pad, Src src, int rows = GX_ROWS) {
+  for (int i = threadIdx.x; i < rows * width_pad; i += GX_THREADS) {
     const int r = i / width_pad, c = i - r * width_pad;
     buf[r * ld + c] = src(r, c);
   }
 }
 
-// f at treatment value xin(row) for the latents z (LDS [32][q]) -> fo[row] = (mu_y, raw_y).  Collective; ends after a barrier.
+// f at treatment values xin(row, dose) for the latents z (LDS [32][q]) -> fo[dose * 64 + 2 * row] = (mu_y, raw_y); nd <= m.db doses per call,
+// their rows stacked in the activation buffers (row 32 d + r, stride m.ldf).  Collective; ends after a barrier.
 template <class XIn>
-__device__ __forceinline__ void gx_f_forward(const GxCausalModel &m, const GxLds &L, const float *z, XIn xin) {
-  const int zf = m.z0 + m.z1, q = m.q;
-  gx_stage(L.bufA, m.ld, m.f.pad[0], [&](int r, int c) { return c < zf ? z[r * q + c] : (c == zf ? xin(r) : 0.0f); });
+__device__ __forceinline__ void gx_f_forward(const GxCausalModel &m, const GxLds &L, const float *z, XIn xin, int nd = 1) {
+  const int zf = m.z0 + m.z1, q = m.q, ld = m.ldf, rows = GX_ROWS * nd, nrt = 2 * nd;
+  gx_stage(L.bufA, ld, m.f.pad[0], [&](int r, int c) { return c < zf ? z[(r & (GX_ROWS - 1)) * q + c] : (c == zf ? xin(r & (GX_ROWS - 1), r / GX_ROWS) : 0.0f); }, rows);
   __syncthreads();
-  float *cur = gx_hidden(m.f, m.pack, 0, m.f.L - 1, L.bufA, L.bufB, m.ld);
+  float *cur = gx_hidden(m.f, m.pack, 0, m.f.L - 1, L.bufA, L.bufB, ld, nrt);
   float *oth = (cur == L.bufA) ? L.bufB : L.bufA;
   const int l = m.f.L - 1;
-  gx_dense(m.pack + m.f.w[l], m.f.pad[l], m.f.pad[l + 1], cur, m.ld, GxStore<false>{oth, m.ld, m.pack + m.f.b[l]});
+  gx_dense(m.pack + m.f.w[l], m.f.pad[l], m.f.pad[l + 1], cur, ld, GxStore<false>{oth, ld, m.pack + m.f.b[l]}, nrt);
   __syncthreads();
-  if (threadIdx.x < 2 * GX_ROWS) L.fo[threadIdx.x] = oth[(threadIdx.x >> 1) * m.ld + (threadIdx.x & 1)];
+  for (int i = threadIdx.x; i < 2 * rows; i += GX_THREADS) L.fo[i] = oth[(i >> 1) * ld + (i & 1)];
   __syncthreads();
 }
 
@@ -102,7 +110,7 @@ __device__ __forceinline__ void gx_causal_logp(const GxCausalModel &m, const GxL
     __syncthreads();
   }
   // ---- f: (z0, z1, x) -> (mu_y, raw_y)
-  gx_f_forward(m, L, z, [&](int r) { long long gr = row0 + r; gr = gr < n ? gr : n - 1; return x[gr]; });
+  gx_f_forward(m, L, z, [&](int r, int) { long long gr = row0 + r; gr = gr < n ? gr : n - 1; return x[gr]; });
   // ---- h: (z0, z2) -> (mu_x | logit, raw_x)
   {
     const int z0 = m.z0, z1 = m.z1, z2 = m.z2;
@@ -157,7 +165,7 @@ __device__ __forceinline__ void gx_causal_logp(const GxCausalModel &m, const GxL
 __global__ __launch_bounds__(GX_THREADS) void gx_causal_logpost_kernel(GxCausalModel m, const float *x, const float *y, const float *v,
                                                                        const float *z, long long n, float *out) {
   extern __shared__ float lds[];
-  const GxLds L = gx_carve(lds, m.ld, m.q, m.ncg);
+  const GxLds L = gx_carve(lds, m.ld, m.q, m.ncg, m.ldf, m.db);
   const long long tiles = (n + GX_ROWS - 1) / GX_ROWS;
   for (long long t = blockIdx.x; t < tiles; t += gridDim.x) {
     const long long row0 = t * GX_ROWS;
@@ -190,28 +198,31 @@ __device__ __forceinline__ void gx_causal_effects(const GxCausalModel &m, const 
                                                   long long row_base, unsigned it, long long d, const GxEffArgs &e) {
   const int nd = (EFFECT == 2) ? 2 : e.n_doses;
   float ykeep = 0.0f;        // EFFECT 2: y(x = 1) of thread `row`
-  for (int k = 0; k < nd; ++k) {
-    const float xv = (EFFECT == 2) ? (k == 0 ? 1.0f : 0.0f) : e.x_values[k];
-    gx_f_forward(m, L, z, [&](int) { return xv; });
+  for (int k0 = 0; k0 < nd; k0 += m.db) {
+    const int nb = min(m.db, nd - k0);
+    gx_f_forward(m, L, z, [&](int, int dd) { const int k = k0 + dd; return (EFFECT == 2) ? (k == 0 ? 1.0f : 0.0f) : e.x_values[k]; }, nb);
     if (threadIdx.x < GX_ROWS) {
       const int r = threadIdx.x;
       const bool valid = row0 + r < n;
-      float yv = L.fo[2 * r];
-      if (e.sample_y) {
-        const float s2y = (m.sig2_y > 0.0f) ? m.sig2_y : softplus_f(L.fo[2 * r + 1]) + BGM_EPS;
-        const unsigned rowid = (unsigned)(row_base + row0 + r);
-        const f32x4 nz = box_muller4(philox4x32_10(rowid, it, (unsigned)(k >> 2), TAG_YNOISE, e.k0, e.k1));
-        const int w = k & 3;
-        const float eps = w == 0 ? nz[0] : (w == 1 ? nz[1] : (w == 2 ? nz[2] : nz[3]));
-        yv = fmaf(__builtin_sqrtf(s2y), eps, yv);
-      }
-      if (EFFECT == 1) {
-        float tot = valid ? yv : 0.0f;
-        tot += __shfl_xor(tot, 1); tot += __shfl_xor(tot, 2); tot += __shfl_xor(tot, 4); tot += __shfl_xor(tot, 8); tot += __shfl_xor(tot, 16);
-        if (r == 0) e.adrf_slot[(long long)d * nd + k] += tot;        // the slot is private to this workgroup: no atomics, fixed order
-      } else {
-        if (k == 0) ykeep = yv;
-        else if (valid) e.ite[(row0 + r) * (long long)e.n_keep + d] = ykeep - yv;
+      for (int dd = 0; dd < nb; ++dd) {
+        const int k = k0 + dd;
+        float yv = L.fo[2 * (GX_ROWS * dd + r)];
+        if (e.sample_y) {
+          const float s2y = (m.sig2_y > 0.0f) ? m.sig2_y : softplus_f(L.fo[2 * (GX_ROWS * dd + r) + 1]) + BGM_EPS;
+          const unsigned rowid = (unsigned)(row_base + row0 + r);
+          const f32x4 nz = box_muller4(philox4x32_10(rowid, it, (unsigned)(k >> 2), TAG_YNOISE, e.k0, e.k1));
+          const int w = k & 3;
+          const float eps = w == 0 ? nz[0] : (w == 1 ? nz[1] : (w == 2 ? nz[2] : nz[3]));
+          yv = fmaf(__builtin_sqrtf(s2y), eps, yv);
+        }
+        if (EFFECT == 1) {
+          float tot = valid ? yv : 0.0f;
+          tot += __shfl_xor(tot, 1); tot += __shfl_xor(tot, 2); tot += __shfl_xor(tot, 4); tot += __shfl_xor(tot, 8); tot += __shfl_xor(tot, 16);
+          if (r == 0) e.adrf_slot[(long long)d * nd + k] += tot;        // the slot is private to this workgroup: no atomics, fixed order
+        } else {
+          if (k == 0) ykeep = yv;
+          else if (valid) e.ite[(row0 + r) * (long long)e.n_keep + d] = ykeep - yv;
+        }
       }
     }
     __syncthreads();
@@ -236,7 +247,7 @@ template <int EFFECT>
 __global__ __launch_bounds__(GX_THREADS) void gx_causal_mh_kernel(GxMhArgs a) {
   extern __shared__ float lds[];
   const GxCausalModel &m = a.m;
-  const GxLds L = gx_carve(lds, m.ld, m.q, m.ncg);
+  const GxLds L = gx_carve(lds, m.ld, m.q, m.ncg, m.ldf, m.db);
   const int q = m.q;
   const long long n = a.n, tiles = (n + GX_ROWS - 1) / GX_ROWS;
   GxEffArgs e = a.e;
@@ -327,7 +338,7 @@ template <int EFFECT>
 __global__ __launch_bounds__(GX_THREADS) void gx_causal_effects_kernel(GxEffKArgs a) {
   extern __shared__ float lds[];
   const GxCausalModel &m = a.m;
-  const GxLds L = gx_carve(lds, m.ld, m.q, m.ncg);
+  const GxLds L = gx_carve(lds, m.ld, m.q, m.ncg, m.ldf, m.db);
   const int q = m.q;
   const long long n = a.n, tiles = (n + GX_ROWS - 1) / GX_ROWS;
   GxEffArgs e = a.e;
@@ -358,7 +369,7 @@ struct GxEvalArgs {
 __global__ __launch_bounds__(GX_THREADS) void gx_causal_eval_kernel(GxEvalArgs a) {
   extern __shared__ float lds[];
   const GxCausalModel &m = a.m;
-  const GxLds L = gx_carve(lds, m.ld, m.q, m.ncg);
+  const GxLds L = gx_carve(lds, m.ld, m.q, m.ncg, m.ldf, m.db);
   const int q = m.q;
   const long long n = a.n, tiles = (n + GX_ROWS - 1) / GX_ROWS;
   double sv = 0.0, sx = 0.0, sy = 0.0;       // thread r < 32 accumulates its rows
@@ -383,7 +394,7 @@ __global__ __launch_bounds__(GX_THREADS) void gx_causal_eval_kernel(GxEvalArgs a
       float y1 = 0.0f;
       for (int k = 0; k < 2; ++k) {
         const float xv = k == 0 ? 1.0f : 0.0f;
-        gx_f_forward(m, L, L.zc, [&](int) { return xv; });
+        gx_f_forward(m, L, L.zc, [&](int, int) { return xv; });
         if (threadIdx.x < GX_ROWS) {
           if (k == 0) y1 = L.fo[2 * threadIdx.x];
           else if (row0 + threadIdx.x < n) a.ite[row0 + threadIdx.x] = y1 - L.fo[2 * threadIdx.x];
@@ -393,7 +404,7 @@ __global__ __launch_bounds__(GX_THREADS) void gx_causal_eval_kernel(GxEvalArgs a
     } else {
       for (int k = 0; k < a.n_doses; ++k) {
         const float xv = a.x_values[k];
-        gx_f_forward(m, L, L.zc, [&](int) { return xv; });
+        gx_f_forward(m, L, L.zc, [&](int, int) { return xv; });
         if (threadIdx.x < GX_ROWS) {
           float tot = (row0 + threadIdx.x < n) ? L.fo[2 * threadIdx.x] : 0.0f;
           tot += __shfl_xor(tot, 1); tot += __shfl_xor(tot, 2); tot += __shfl_xor(tot, 4); tot += __shfl_xor(tot, 8); tot += __shfl_xor(tot, 16);

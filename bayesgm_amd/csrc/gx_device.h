@@ -48,12 +48,13 @@ __host__ __device__ inline int gx_ld(int width) { return ((width + 59) / 64) * 6
 // (true: row r of the tile at A + r * lda); gx_dense_ld: the N columns processed are a slice of rows of stride ldw.  epi(rt, n0, acc0, acc1): lane (j, g) holds rows 16 rt + 4g + r (r = 0..3) of columns
 // n0 + 2j (acc0[r]) and n0 + 2j + 1 (acc1[r]).  No barriers inside: the caller separates producers and consumers of A.
 // ---------------------------------------------------------------------------------------------------------------------------
+// nrt: 16-row tiles of A (2 = the workgroup's 32 rows; the effect pass stacks several doses' rows: 2 x doses)
 template <bool A_GLOBAL = false, class Epi>
-__device__ __forceinline__ void gx_dense_ld(const float *__restrict__ W, int ldw, int K, int N, const float *A, int lda, Epi epi) {
+__device__ __forceinline__ void gx_dense_ld(const float *__restrict__ W, int ldw, int K, int N, const float *A, int lda, Epi epi, int nrt = 2) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
-  const int units = 2 * (N >> 5);
+  const int units = nrt * (N >> 5);
   for (int u = wave; u < units; u += GX_WAVES) {
-    const int rt = u & 1, n0 = (u >> 1) << 5;
+    const int rt = u % nrt, n0 = (u / nrt) << 5;
     f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
     const float *ap = A + (size_t)(16 * rt + j) * lda + 4 * g;
     const float *wk = W + (size_t)(4 * g) * ldw + n0 + 2 * j;
@@ -88,8 +89,8 @@ __device__ __forceinline__ void gx_dense_ld(const float *__restrict__ W, int ldw
 
 // W [K][N] with row stride N
 template <bool A_GLOBAL = false, class Epi>
-__device__ __forceinline__ void gx_dense(const float *__restrict__ W, int K, int N, const float *A, int lda, Epi epi) {
-  gx_dense_ld<A_GLOBAL>(W, N, K, N, A, lda, epi);
+__device__ __forceinline__ void gx_dense(const float *__restrict__ W, int K, int N, const float *A, int lda, Epi epi, int nrt = 2) {
+  gx_dense_ld<A_GLOBAL>(W, N, K, N, A, lda, epi, nrt);
 }
 
 // Epilogue helpers -------------------------------------------------------------------------------------------------------------
@@ -161,9 +162,9 @@ struct GxRawStore {
 
 // Hidden layers l = l_begin .. l_end - 1 of `net` (LeakyReLU), ping-ponging between two LDS buffers; the input is in `cur`.
 // Returns with the last output in the returned buffer (a barrier has been passed after its last store).
-__device__ __forceinline__ float *gx_hidden(const GxNet &net, const float *pack, int l_begin, int l_end, float *cur, float *oth, int ld) {
+__device__ __forceinline__ float *gx_hidden(const GxNet &net, const float *pack, int l_begin, int l_end, float *cur, float *oth, int ld, int nrt = 2) {
   for (int l = l_begin; l < l_end; ++l) {
-    gx_dense(pack + net.w[l], net.pad[l], net.pad[l + 1], cur, ld, GxStore<true>{oth, ld, pack + net.b[l]});
+    gx_dense(pack + net.w[l], net.pad[l], net.pad[l + 1], cur, ld, GxStore<true>{oth, ld, pack + net.b[l]}, nrt);
     __syncthreads();
     float *t = cur; cur = oth; oth = t;
   }
