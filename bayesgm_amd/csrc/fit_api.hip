@@ -24,6 +24,7 @@ struct FitChainState {
   const float *theta_use = nullptr, *thetaT_use = nullptr;   // when set: the buffers the next chain launch reads
   float *ws_z = nullptr;   // the latent phase's own stash, so that it may overlap the next minibatch's theta phase (bgm_causal_fit_epoch)
   int *tiles = nullptr, *mirror_dst = nullptr;
+  FitAdamTheta fused{};    // fused.on: the next theta-phase launch applies the Adam step in its gradient-tile kernel (bgm_causal_fit_epoch)
 };
 static void fit_chain_free(bgm_handle *h) {
   FitChainState *c = static_cast<FitChainState *>(h->fit_chain);
@@ -112,6 +113,7 @@ static int fit_chain_setup(bgm_handle *h, const std::vector<float> &theta) {
 // one launch of the chains; Z_MODE 0 also the gradient tiles into `grad`
 static void fit_chain_launch(const FitChainState *c, FitChainArgs &a, int batch, int z_mode, hipStream_t stream) {
   if (c->theta_use) { a.theta = c->theta_use; a.thetaT = c->thetaT_use; }
+  a.ad = z_mode ? FitAdamTheta{} : c->fused;
   static const bool one_wg_ = std::getenv("BGM_FIT_ONE_WG") != nullptr;
   a.n_valid = batch;                                 // rows of this minibatch; the tile rows behind them are masked
   const int nb = batch <= 16 ? 1 : 2;                // row tiles (the padded / two-k-tile instantiations are compiled for two only)
@@ -627,19 +629,30 @@ extern "C" int bgm_causal_fit_z_step(bgm_handle *h, const float *x, const float 
 }
 
 // the replay launches: rows idx[0 .. n_sel) (NULL: all rows) of (z, zm, zv) brought from their t_last to step t_to
+static void fit_mark_rows(bgm_handle *h, const int32_t *idx, int n_sel, long long t_to, hipStream_t stream) {      // replayed rows are current to t_to
+  hipLaunchKernelGGL(fit_mark_rows_kernel, dim3((unsigned)((n_sel + 255) / 256)), dim3(256), 0, stream, h->tlast_dev, idx, (long long)n_sel, (int)t_to);
+}
+// mark = false: the caller guarantees the latent step of these rows follows (its Adam epilogue stamps them with t_to + 1)
 static int fit_z_sync_rows(bgm_handle *h, float *data_z, float *zm, float *zv, const int32_t *idx, long long n_sel, int t_to, float lr_z,
-                           hipStream_t stream) {
+                           hipStream_t stream, bool mark = true) {
   const long long threads = n_sel * h->q * 16;
   hipLaunchKernelGGL(fit_adam_z_replay_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, data_z, zm, zv,
                      h->tlast_dev, h->q, idx, n_sel, t_to, lr_z, ADAM_B1, ADAM_B2, ADAM_EPS);
+  if (!mark) { BGM_HIP_CHECK(hipGetLastError()); return BGM_OK; }
   if (!idx) hipLaunchKernelGGL(fit_fill_int_kernel, dim3((unsigned)((n_sel + 255) / 256)), dim3(256), 0, stream, h->tlast_dev, n_sel, t_to);
   else hipLaunchKernelGGL(fit_mark_rows_kernel, dim3((unsigned)((n_sel + 255) / 256)), dim3(256), 0, stream, h->tlast_dev, idx, n_sel, t_to);
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
 }
 
+static int fit_z_sync_impl(bgm_handle *h, float *data_z, float *zm, float *zv, const int32_t *idx, int32_t batch, float lr_z, void *stream_,
+                           bool mark);
 extern "C" int bgm_causal_fit_z_sync(bgm_handle *h, float *data_z, float *zm, float *zv, const int32_t *idx, int32_t batch, float lr_z,
                                      void *stream_) {
+  return fit_z_sync_impl(h, data_z, zm, zv, idx, batch, lr_z, stream_, true);
+}
+static int fit_z_sync_impl(bgm_handle *h, float *data_z, float *zm, float *zv, const int32_t *idx, int32_t batch, float lr_z, void *stream_,
+                           bool mark) {
   if (!h || !h->fit_active) { bgm_set_error("bgm_causal_fit_z_sync: call bgm_causal_fit_begin first"); return BGM_E_STATE; }
   if (!data_z || !zm || !zv || (idx && batch < 1)) { bgm_set_error("bgm_causal_fit_z_sync: bad argument"); return BGM_E_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
@@ -649,7 +662,7 @@ extern "C" int bgm_causal_fit_z_sync(bgm_handle *h, float *data_z, float *zm, fl
     BGM_HIP_CHECK(hipMalloc(&h->tlast_dev, sizeof(int) * n_rows));
     hipLaunchKernelGGL(fit_fill_int_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, h->tlast_dev, n_rows, (int)h->t_z);
   }
-  int rc = fit_z_sync_rows(h, data_z, zm, zv, idx, idx ? batch : n_rows, (int)h->t_z, lr_z, stream);
+  int rc = fit_z_sync_rows(h, data_z, zm, zv, idx, idx ? batch : n_rows, (int)h->t_z, lr_z, stream, mark || !idx);
   if (rc) return rc;
   h->z_synced = idx ? h->t_z + 1 : -2;               // -2: flushed, any mode may follow
   return BGM_OK;
@@ -704,33 +717,70 @@ extern "C" int bgm_causal_fit_epoch(bgm_handle *h, const float *x, const float *
   float *tb[2] = {h->theta_dev, overlap ? fc->theta2 : nullptr}, *tTb[2] = {overlap ? fc->thetaT : nullptr, overlap ? fc->thetaT2 : nullptr};
   if (overlap) BGM_HIP_CHECK(hipMemcpyAsync(fc->thetaT2, fc->thetaT, sizeof(float) * ((size_t)np + 64), hipMemcpyDeviceToDevice, sA));   // (rows no parameter maps to)
   int cur = 0;
+  static const bool no_fuse = std::getenv("BGM_FIT_NO_FUSED_ADAM") != nullptr;       // dev A/B: separate Adam launch + explicit row marks
+  const bool fuse = overlap && !no_fuse;
+  // Replay mode: the pending zero-gradient steps of minibatch j's rows are replayed two minibatches ahead, on the second stream behind
+  // the latent phase j - 2 -- off the parameter stream's critical path (replay + chains + gradient tiles), and covered by the event the
+  // theta phase j waits for anyway.  Legal because the minibatches of one call are disjoint: nothing touches those rows in between,
+  // and the step a replay runs to (the latent step count when minibatch j starts) is known in advance.
+  static const bool no_ahead = std::getenv("BGM_FIT_NO_REPLAY_AHEAD") != nullptr;    // dev A/B
+  const bool ahead = fuse && lazy == 2 && !no_ahead;
+  const long long tz0 = h->t_z, n_mb = (n_use + batch - 1) / batch;
+  long long replayed = 0;          // minibatches [k, replayed) have been replayed but not stepped
+  auto replay = [&](long long j, hipStream_t st) -> int {
+    if (j >= n_mb) return BGM_OK;
+    const int bj = (int)std::min<int64_t>(batch, n_use - j * batch);
+    replayed = j + 1;
+    return fit_z_sync_rows(h, data_z, zm, zv, perm + j * batch, bj, (int)(tz0 + j), lr_z, st, false);
+  };
+  auto mark_pending = [&](hipStream_t st) {      // a failure: the rows replayed ahead count as current to the step they were brought to
+    if (lazy != 2 || !fuse) return;
+    for (long long j = k; j < std::max(replayed, k + 1) && j < n_mb; ++j)
+      fit_mark_rows(h, perm + j * batch, (int)std::min<int64_t>(batch, n_use - j * batch), tz0 + j, st);
+  };
   for (int64_t i = 0; i < n_use; i += batch, ++k) {
     const int32_t *idx = perm + i;
     const int b = (int)std::min<int64_t>(batch, n_use - i);
-    if (lazy == 2 && (rc = bgm_causal_fit_z_sync(h, data_z, zm, zv, idx, b, lr_z, sA))) break;
+    // (the replayed rows are stamped by the latent step below; only a failure in between needs the explicit mark)
+    if (lazy == 2 && (!ahead || k == 0) && (rc = fit_z_sync_impl(h, data_z, zm, zv, idx, b, lr_z, sA, !fuse))) break;
+    if (ahead && k == 0 && (rc = replay(1, sA))) break;
     if (overlap && k == 0) {       // the second stream starts behind everything queued on the caller's so far (incl. the first replay)
       BGM_HIP_CHECK(hipEventRecord(h->epoch_ev_t[1], sA));
       BGM_HIP_CHECK(hipStreamWaitEvent(sB, h->epoch_ev_t[1], 0));
     }
     if (overlap) { fc->theta_use = tb[cur]; fc->thetaT_use = tTb[cur]; }
-    if ((rc = bgm_causal_fit_theta_grad(h, x, y, v, data_z, idx, 0, b, b, h->epoch_grad, loss, sA))) break;
+    const int *tbl = h->tables_dev;
+    const double t = (double)(h->t_theta + 1);
+    const float lr_t = (float)((double)lr_theta * std::sqrt(1.0 - std::pow((double)ADAM_B2, t)) / (1.0 - std::pow((double)ADAM_B1, t)));
+    if (fuse) {                    // the Adam step rides on the gradient-tile kernel: it writes the other buffer, which the latent
+      if (k > 1) BGM_HIP_CHECK(hipStreamWaitEvent(sA, h->epoch_ev_z[k & 1], 0));       // phase k - 2 (same slot) has read
+      FitAdamTheta &ad = fc->fused;
+      ad.on = 1; ad.lr_t = lr_t; ad.b1 = ADAM_B1; ad.b2 = ADAM_B2; ad.eps = ADAM_EPS;
+      ad.m1 = h->m1_dev; ad.m2 = h->m2_dev; ad.theta_out = tb[cur ^ 1];
+      ad.fwd_blob = h->blob_dev; ad.bwd_blob = h->bblob_dev; ad.mirror = tTb[cur ^ 1];
+      ad.fwd_dst = tbl; ad.fwd_dst2 = tbl + np; ad.bwd_dst = tbl + 2 * (size_t)np; ad.mirror_dst = fc->mirror_dst;
+    }
+    rc = bgm_causal_fit_theta_grad(h, x, y, v, data_z, idx, 0, b, b, h->epoch_grad, loss, sA);
+    if (fuse) fc->fused.on = 0;
+    if (rc) { hipStreamSynchronize(sB); mark_pending(sA); break; }
     if (overlap) {
-      if (k > 1) BGM_HIP_CHECK(hipStreamWaitEvent(sA, h->epoch_ev_z[k & 1], 0));       // latent phase k - 2 (same slot): it read the buffer written now
+      if (!fuse) {
+        if (k > 1) BGM_HIP_CHECK(hipStreamWaitEvent(sA, h->epoch_ev_z[k & 1], 0));       // latent phase k - 2 (same slot): it read the buffer written now
+        hipLaunchKernelGGL(fit_adam_theta_kernel, dim3((np + 255) / 256), dim3(256), 0, sA, tb[cur], h->m1_dev, h->m2_dev, h->epoch_grad, np, lr_t,
+                           ADAM_B1, ADAM_B2, ADAM_EPS, h->blob_dev, h->bblob_dev, tbl, tbl + np, tbl + 2 * (size_t)np, tTb[cur ^ 1], fc->mirror_dst,
+                           tb[cur ^ 1]);
+        BGM_HIP_CHECK(hipGetLastError());
+      }
       h->t_theta += 1;
-      const double t = (double)h->t_theta;
-      const float lr_t = (float)((double)lr_theta * std::sqrt(1.0 - std::pow((double)ADAM_B2, t)) / (1.0 - std::pow((double)ADAM_B1, t)));
-      const int *tbl = h->tables_dev;
-      hipLaunchKernelGGL(fit_adam_theta_kernel, dim3((np + 255) / 256), dim3(256), 0, sA, tb[cur], h->m1_dev, h->m2_dev, h->epoch_grad, np, lr_t,
-                         ADAM_B1, ADAM_B2, ADAM_EPS, h->blob_dev, h->bblob_dev, tbl, tbl + np, tbl + 2 * (size_t)np, tTb[cur ^ 1], fc->mirror_dst,
-                         tb[cur ^ 1]);
-      BGM_HIP_CHECK(hipGetLastError());
       h->sblob_valid = false; h->det_valid = false;
       cur ^= 1;
       fc->theta_use = tb[cur]; fc->thetaT_use = tTb[cur];
       BGM_HIP_CHECK(hipEventRecord(h->epoch_ev_t[k & 1], sA));
       BGM_HIP_CHECK(hipStreamWaitEvent(sB, h->epoch_ev_t[k & 1], 0));
     } else if ((rc = bgm_causal_fit_theta_apply(h, h->epoch_grad, lr_theta, sA))) break;
-    if ((rc = bgm_causal_fit_z_step(h, x, y, v, data_z, zm, zv, idx, 0, b, b, lr_z, lazy, loss_z, sB))) break;
+    if (ahead) h->z_synced = h->t_z + 1;       // (minibatch k's rows were replayed to step tz0 + k = t_z)
+    if ((rc = bgm_causal_fit_z_step(h, x, y, v, data_z, zm, zv, idx, 0, b, b, lr_z, lazy, loss_z, sB))) { mark_pending(sB); break; }
+    if (ahead && (rc = replay(k + 2, sB))) { ++k; mark_pending(sB); break; }
     if (overlap) BGM_HIP_CHECK(hipEventRecord(h->epoch_ev_z[k & 1], sB));
   }
   if (overlap) {

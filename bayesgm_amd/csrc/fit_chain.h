@@ -33,6 +33,7 @@ struct FitChainArgs {
   int n_warm;                     // floats of theta (= of the transposed mirror) the idle wave pair pulls into this XCD's L2
   int n_valid;                    // rows of the minibatch (<= 16 NB): the tile rows behind them are masked -- they read row n_valid - 1,
                                   // contribute zero loss and zero output gradients, hence nothing to any parameter gradient
+  FitAdamTheta ad;                // theta phase, ad.on: the gradient-tile kernel applies the Adam step itself (bgm_causal_fit_epoch)
 };
 
 __device__ __forceinline__ long long fitc_row(const FitChainArgs &a, int b) {
@@ -408,7 +409,13 @@ static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_dw_kernel(FitCha
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int f = 16 * u + 4 * g + r;
-    if (f < n_in && o < n_out) a.grad[woff + f * n_out + o] = w[r];
+    if (f < n_in && o < n_out) {
+      if (a.ad.on) fit_adam_theta_one(woff + f * n_out + o, w[r], a.theta, a.ad);      // (every parameter belongs to exactly one tile)
+      else a.grad[woff + f * n_out + o] = w[r];
+    }
   }
-  if (boff >= 0 && g == 0 && o < n_out) a.grad[boff + o] = bs;
+  if (boff >= 0 && g == 0 && o < n_out) {
+    if (a.ad.on) fit_adam_theta_one(boff + o, bs, a.theta, a.ad);
+    else a.grad[boff + o] = bs;
+  }
 }

@@ -421,17 +421,12 @@ __global__ void fit_adam_theta_kernel(float *theta, float *m1, float *m2, const 
                                       float *mirror = nullptr, const int *mirror_dst = nullptr, float *theta_out = nullptr) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_params) return;
-  const float g = grad[c];
-  const float m = b1 * m1[c] + (1.0f - b1) * g;
-  const float v = b2 * m2[c] + (1.0f - b2) * g * g;
-  m1[c] = m;
-  m2[c] = v;
-  const float w = theta[c] - lr_t * m / (sqrtf(v) + eps);
-  (theta_out ? theta_out : theta)[c] = w;      // theta_out: the other of two parameter buffers (bgm_causal_fit_epoch)
-  if (fwd_dst[c] >= 0) fwd_blob[fwd_dst[c]] = w;
-  if (fwd_dst2[c] >= 0) fwd_blob[fwd_dst2[c]] = w;
-  if (bwd_dst[c] >= 0) bwd_blob[bwd_dst[c]] = w;
-  if (mirror && mirror_dst[c] >= 0) mirror[mirror_dst[c]] = w;      // transposed weights of the row-tile-chain kernels (fit_chain.h)
+  FitAdamTheta ad;
+  ad.on = 1; ad.lr_t = lr_t; ad.b1 = b1; ad.b2 = b2; ad.eps = eps;
+  ad.m1 = m1; ad.m2 = m2; ad.theta_out = theta_out ? theta_out : theta;      // theta_out: the other of two parameter buffers (bgm_causal_fit_epoch)
+  ad.fwd_blob = fwd_blob; ad.bwd_blob = bwd_blob; ad.mirror = mirror;
+  ad.fwd_dst = fwd_dst; ad.fwd_dst2 = fwd_dst2; ad.bwd_dst = bwd_dst; ad.mirror_dst = mirror_dst;
+  fit_adam_theta_one(c, grad[c], theta, ad);
 }
 
 // Adam on the latent matrix.  mode 0 = Keras sparse path (decay + apply on ALL rows, base.py:301),

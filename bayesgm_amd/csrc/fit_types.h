@@ -43,6 +43,28 @@ struct FitKArgs {
   double *loss;            // [8] accumulators: loss_v*B, sse_v, loss_x*B, sse_x|bce, loss_y*B, sse_y, loss_z*B
 };
 
+// Keras Adam (optimizer_v2) on canonical parameter c + scatter into the packed blobs / the transposed mirror.  One expression
+// for the stand-alone kernel (fit_adam_theta_kernel) and the gradient-tile kernel's fused epilogue (fit_chain_dw_kernel).
+struct FitAdamTheta {
+  int on;                  // fit_chain_dw_kernel: apply the step on the tile's own parameters instead of storing the gradient
+  float lr_t, b1, b2, eps;
+  float *m1, *m2, *theta_out;        // theta_out: the buffer the new parameters go to (may be the one read)
+  float *fwd_blob, *bwd_blob, *mirror;
+  const int *fwd_dst, *fwd_dst2, *bwd_dst, *mirror_dst;
+};
+__device__ __forceinline__ void fit_adam_theta_one(int c, float g, const float *theta, const FitAdamTheta &ad) {
+  const float m = ad.b1 * ad.m1[c] + (1.0f - ad.b1) * g;
+  const float v = ad.b2 * ad.m2[c] + (1.0f - ad.b2) * g * g;
+  ad.m1[c] = m;
+  ad.m2[c] = v;
+  const float w = theta[c] - ad.lr_t * m / (sqrtf(v) + ad.eps);
+  ad.theta_out[c] = w;
+  if (ad.fwd_dst[c] >= 0) ad.fwd_blob[ad.fwd_dst[c]] = w;
+  if (ad.fwd_dst2[c] >= 0) ad.fwd_blob[ad.fwd_dst2[c]] = w;
+  if (ad.bwd_dst[c] >= 0) ad.bwd_blob[ad.bwd_dst[c]] = w;
+  if (ad.mirror && ad.mirror_dst[c] >= 0) ad.mirror[ad.mirror_dst[c]] = w;      // transposed weights of the row-tile-chain kernels (fit_chain.h)
+}
+
 struct DwLayer { long long a_off, d_off; int K, N, out_off; };  // widths (multiples of 16); offset in the partial
 #define BGM_MAX_DW_LAYERS 32
 struct DwArgs {
