@@ -92,7 +92,9 @@ struct bgm_handle {
   // bgm_causal_fit_epoch: gradient buffer, second stream and the events that order the two phases
   float *epoch_grad = nullptr; int epoch_grad_n = 0;
   hipStream_t epoch_stream = nullptr;
-  hipEvent_t epoch_ev_t[2] = {nullptr, nullptr}, epoch_ev_z[2] = {nullptr, nullptr}, epoch_ev_s = nullptr;
+  unsigned *epoch_ctr = nullptr;      // device: [0] gradient-tile workgroups done, [1] latent-phase workgroups done, [2] a wait gave up (fit_types.h FitSync)
+  unsigned epoch_theta_done = 0, epoch_z_done = 0;      // the counters' values once everything issued so far is done
+  hipEvent_t epoch_ev_t[4] = {}, epoch_ev_z[4] = {}, epoch_ev_s = nullptr;      // one pair per minibatch in flight (BGM_EPOCH_DEPTH_MAX)
   void *gx_state = nullptr;   // GxState (gx_api.hip): general-width engine (hidden widths / depths outside the compiled families)
   bool gx_valid = false;      // its padded packs hold the handle's current g, f, h, e
   void *bgm_state = nullptr;  // BgmState (bgm_api.hip)

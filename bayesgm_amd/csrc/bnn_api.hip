@@ -449,7 +449,7 @@ extern "C" int bgm_bnn_fit_epoch(bgm_handle *h, const float *x, const float *y, 
   const bool overlap = !no_overlap && lazy != 0 && fc && (batch == 32 || (batch == 16 && !fc->pad));
   if (overlap && !h->epoch_stream) {
     BGM_HIP_CHECK(hipStreamCreateWithFlags(&h->epoch_stream, hipStreamNonBlocking));
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 4; ++k) {
       BGM_HIP_CHECK(hipEventCreateWithFlags(&h->epoch_ev_t[k], hipEventDisableTiming));
       BGM_HIP_CHECK(hipEventCreateWithFlags(&h->epoch_ev_z[k], hipEventDisableTiming));
     }

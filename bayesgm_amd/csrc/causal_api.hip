@@ -50,9 +50,10 @@ extern "C" int bgm_destroy(bgm_handle *h) {
   bnf_det_free(h);
   bgm_causal_fit_end(h, nullptr);
   gx_free(h);
+  if (h->epoch_ctr) { hipFree(h->epoch_ctr); h->epoch_ctr = nullptr; }
   if (h->epoch_stream) {
     hipStreamDestroy(h->epoch_stream);
-    for (int k = 0; k < 2; ++k) { hipEventDestroy(h->epoch_ev_t[k]); hipEventDestroy(h->epoch_ev_z[k]); }
+    for (int k = 0; k < 4; ++k) { if (h->epoch_ev_t[k]) hipEventDestroy(h->epoch_ev_t[k]); if (h->epoch_ev_z[k]) hipEventDestroy(h->epoch_ev_z[k]); }
     if (h->epoch_ev_s) hipEventDestroy(h->epoch_ev_s);
   }
   bgm_bgm_free_state(h);

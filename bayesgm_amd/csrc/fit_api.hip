@@ -20,16 +20,20 @@ struct FitChainState {
   int t0 = 1;            // latent input tiles of g (q <= 16 t0); two tiles run the padded B = 32 variant only
   bool pad = false;      // the 13-tile kernels on a narrower p + 1 (B = 32 only)
   float *thetaT = nullptr, *ws = nullptr;
-  float *theta2 = nullptr, *thetaT2 = nullptr;      // second parameter buffer + its transposed mirror (bgm_causal_fit_epoch)
+  float *theta_x[3] = {}, *thetaT_x[3] = {};        // further parameter buffers + their transposed mirrors (bgm_causal_fit_epoch)
   const float *theta_use = nullptr, *thetaT_use = nullptr;   // when set: the buffers the next chain launch reads
   float *ws_z = nullptr;   // the latent phase's own stash, so that it may overlap the next minibatch's theta phase (bgm_causal_fit_epoch)
   int *tiles = nullptr, *mirror_dst = nullptr;
+  FitSync sync_t{}, sync_z{};     // device-side ordering of the next theta-phase / latent-phase launch (bgm_causal_fit_epoch)
+  const int *rp_idx = nullptr, *rp_tlast = nullptr; int rp_n = 0, rp_t_to = 0; float rp_lr = 0.0f;   // rider of the next latent-phase launch
+  int last_z_blocks = 0;          // workgroups of the last latent-phase launch (what its done counter advanced by)
   FitAdamTheta fused{};    // fused.on: the next theta-phase launch applies the Adam step in its gradient-tile kernel (bgm_causal_fit_epoch)
 };
 static void fit_chain_free(bgm_handle *h) {
   FitChainState *c = static_cast<FitChainState *>(h->fit_chain);
   if (!c) return;
-  for (void *p : {(void *)c->thetaT, (void *)c->ws, (void *)c->ws_z, (void *)c->tiles, (void *)c->mirror_dst, (void *)c->theta2, (void *)c->thetaT2})
+  for (void *p : {(void *)c->thetaT, (void *)c->ws, (void *)c->ws_z, (void *)c->tiles, (void *)c->mirror_dst, (void *)c->theta_x[0], (void *)c->thetaT_x[0],
+                  (void *)c->theta_x[1], (void *)c->thetaT_x[1], (void *)c->theta_x[2], (void *)c->thetaT_x[2]})
     if (p) hipFree(p);
   delete c;
   h->fit_chain = nullptr;
@@ -111,22 +115,28 @@ static int fit_chain_setup(bgm_handle *h, const std::vector<float> &theta) {
   return BGM_OK;
 }
 // one launch of the chains; Z_MODE 0 also the gradient tiles into `grad`
-static void fit_chain_launch(const FitChainState *c, FitChainArgs &a, int batch, int z_mode, hipStream_t stream) {
+static void fit_chain_launch(FitChainState *c, FitChainArgs &a, int batch, int z_mode, hipStream_t stream) {
   if (c->theta_use) { a.theta = c->theta_use; a.thetaT = c->thetaT_use; }
   a.ad = z_mode ? FitAdamTheta{} : c->fused;
+  a.sy = z_mode ? c->sync_z : c->sync_t;
   static const bool one_wg_ = std::getenv("BGM_FIT_ONE_WG") != nullptr;
   a.n_valid = batch;                                 // rows of this minibatch; the tile rows behind them are masked
   const int nb = batch <= 16 ? 1 : 2;                // row tiles (the padded / two-k-tile instantiations are compiled for two only)
+  // latent phase: workgroups of the chains, then the riders that replay a later minibatch's rows (bgm_causal_fit_epoch)
+  const int nchain = (c->t0 != 2 && !c->pad && nb == 2 && !one_wg_ && (c->ntl == 13 || c->ntl == 7)) ? 2 : 1;
+  const int rpb = (z_mode && c->rp_n > 0 && a.zm) ? (int)(((long long)c->rp_n * a.q * 16 + ECH_THREADS - 1) / ECH_THREADS) : 0;
+  a.rp_first = nchain; a.rp_n = rpb ? c->rp_n : 0; a.rp_idx = c->rp_idx; a.rp_t_to = c->rp_t_to; a.rp_lr = c->rp_lr; a.rp_tlast = c->rp_tlast;
+  if (z_mode) c->last_z_blocks = nchain + rpb;
 #define FC(NTL_, NB_) \
   if (c->ntl == NTL_ && nb == NB_) { \
-    if (z_mode) hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, NB_, 1>), dim3(1), dim3(ECH_THREADS), 0, stream, a); \
+    if (z_mode) hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, NB_, 1>), dim3(nchain + rpb), dim3(ECH_THREADS), 0, stream, a); \
     else { \
       hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, NB_, 0>), dim3(1, one_wg_ ? 1 : 3), dim3(ECH_THREADS), 0, stream, a); \
       hipLaunchKernelGGL(fit_chain_dw_kernel<NB_>, dim3((a.n_tiles + ECH_WAVES - 1) / ECH_WAVES), dim3(ECH_THREADS), 0, stream, a); \
     } \
   }
   if (c->t0 == 2) {
-    if (z_mode) hipLaunchKernelGGL((fit_chain_kernel<4, 13, 4, 2, 1, 2, 1, true, 2>), dim3(1), dim3(ECH_THREADS), 0, stream, a);
+    if (z_mode) hipLaunchKernelGGL((fit_chain_kernel<4, 13, 4, 2, 1, 2, 1, true, 2>), dim3(nchain + rpb), dim3(ECH_THREADS), 0, stream, a);
     else {
       hipLaunchKernelGGL((fit_chain_kernel<4, 13, 4, 2, 1, 2, 0, true, 2>), dim3(1), dim3(ECH_THREADS), 0, stream, a);
       hipLaunchKernelGGL(fit_chain_dw_kernel<2>, dim3((a.n_tiles + ECH_WAVES - 1) / ECH_WAVES), dim3(ECH_THREADS), 0, stream, a);
@@ -134,7 +144,7 @@ static void fit_chain_launch(const FitChainState *c, FitChainArgs &a, int batch,
     return;
   }
   if (c->pad) {
-    if (z_mode) hipLaunchKernelGGL((fit_chain_kernel<4, 13, 4, 2, 1, 2, 1, true>), dim3(1), dim3(ECH_THREADS), 0, stream, a);
+    if (z_mode) hipLaunchKernelGGL((fit_chain_kernel<4, 13, 4, 2, 1, 2, 1, true>), dim3(nchain + rpb), dim3(ECH_THREADS), 0, stream, a);
     else {
       hipLaunchKernelGGL((fit_chain_kernel<4, 13, 4, 2, 1, 2, 0, true>), dim3(1), dim3(ECH_THREADS), 0, stream, a);
       hipLaunchKernelGGL(fit_chain_dw_kernel<2>, dim3((a.n_tiles + ECH_WAVES - 1) / ECH_WAVES), dim3(ECH_THREADS), 0, stream, a);
@@ -150,8 +160,8 @@ static void fit_chain_launch(const FitChainState *c, FitChainArgs &a, int batch,
 #define FS(NTL_) \
     if (c->ntl == NTL_) { \
       if (z_mode) { \
-        if (no_ws) hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, 1, 1>), dim3(2), dim3(ECH_THREADS), 0, stream, a); \
-        else hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, 1, 1, false, 1, true>), dim3(2), dim3(ECH_THREADS), 0, stream, a); \
+        if (no_ws) hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, 1, 1>), dim3(nchain + rpb), dim3(ECH_THREADS), 0, stream, a); \
+        else hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, 1, 1, false, 1, true>), dim3(nchain + rpb), dim3(ECH_THREADS), 0, stream, a); \
       } else { \
         if (no_ws) hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, 1, 0>), dim3(2, 3), dim3(ECH_THREADS), 0, stream, a); \
         else hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, 1, 0, false, 1, true>), dim3(2, 3), dim3(ECH_THREADS), 0, stream, a); \
@@ -165,7 +175,7 @@ static void fit_chain_launch(const FitChainState *c, FitChainArgs &a, int batch,
   if (nb == 1 && !one_wg && !no_ws && (c->ntl == 13 || c->ntl == 7)) {      // <= 16 rows (a rank's share under data parallelism): the same worker split
 #define FW(NTL_) \
     if (c->ntl == NTL_) { \
-      if (z_mode) hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, 1, 1, false, 1, true>), dim3(1), dim3(ECH_THREADS), 0, stream, a); \
+      if (z_mode) hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, 1, 1, false, 1, true>), dim3(nchain + rpb), dim3(ECH_THREADS), 0, stream, a); \
       else { \
         hipLaunchKernelGGL((fit_chain_kernel<4, NTL_, 4, 2, 1, 1, 0, false, 1, true>), dim3(1, 3), dim3(ECH_THREADS), 0, stream, a); \
         hipLaunchKernelGGL(fit_chain_dw_kernel<1>, dim3((a.n_tiles + ECH_WAVES - 1) / ECH_WAVES), dim3(ECH_THREADS), 0, stream, a); \
@@ -670,18 +680,37 @@ static int fit_z_sync_impl(bgm_handle *h, float *data_z, float *zm, float *zv, c
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // One pass over a list of minibatches with the loop inside the library (single process: no all-reduce between the phases).
-// replaces: the loop body causalbgm/base.py:490-505 for every minibatch of an epoch -- the same calls, in the same order, as the
-// host loop bgm_causal_fit_z_sync / _theta_grad / _theta_apply / _z_step, issued from C++.
-// With the latent optimizer in batch-rows or replay mode (lazy = 1 / 2) and the row-tile chains, the latent phase of minibatch k
-// runs on a second stream beside the theta phase of minibatch k + 1: the two touch disjoint rows of the latent table (the
-// minibatches of one call must be disjoint -- a permutation), the theta phase k + 1 needs the parameters after step k (same
-// stream); the parameters are double-buffered (step k's Adam reads one buffer and writes the other), so the update k + 1 never
-// waits for the latent phase k -- only for the latent phase k - 1, which read the buffer it overwrites.  Results are those of the
-// sequential order bit for bit; a minibatch then costs max(theta phase, latent phase) instead of their sum (N = 1e6, B = 32:
-// 69.5 -> 51.5 us with the replayed latent Adam, 60.0 -> 41.8 us with the batch-rows one; what remains is the issue cost of the ~12
-// API calls of a minibatch).  Measured and dropped: a single parameter buffer (56.5 us: two cross-stream event hops of ~10 us on the
-// critical cycle); replaying the next minibatch's rows on the second stream (52.2 us: the extra cross-stream wait costs what it saves).
+// replaces: the loop body causalbgm/base.py:490-505 for every minibatch of an epoch -- the same updates, in the same order, as the
+// host loop bgm_causal_fit_z_sync / _theta_grad / _theta_apply / _z_step; results are those of the sequential order bit for bit.
+// With the latent optimizer in batch-rows or replay mode (lazy = 1 / 2) and the row-tile chains:
+//   * the latent phase of minibatch k runs on a second stream beside the theta phase of minibatch k + 1: the two touch disjoint rows of
+//     the latent table (the minibatches of one call must be disjoint -- a permutation); the parameters live in a ring of D buffers
+//     (step k's Adam reads one and writes the next), so the update k + 1 never waits for the latent phase k;
+//   * the Adam step rides on the gradient-tile kernel (one expression, fit_adam_theta_one), the replay of a minibatch's pending latent
+//     steps rides D minibatches ahead on the latent phase's kernel (rider workgroups), no separate row-mark launch: three launches
+//     per minibatch (theta chains, gradient tiles + Adam, latent chains + Adam-on-Z + replay);
+//   * the two streams are ordered by counters in device memory the kernels themselves wait on and advance (FitSync), not by HIP
+//     events: a record / wait pair costs the stream it sits in 4-6 us of command-processor time per minibatch.
+// N = 1e6, B = 32, replayed latent Adam, per minibatch: 69.5 us in one stream; 51.5 with two streams, two buffers and events (round-4
+// start); 50.0 with the fused Adam; 46.9 with the replay ahead; 35.9 with device-side ordering = the parameter stream's own chain
+// (theta chains 26.5 + gradient tiles / Adam 8).  Measured and dropped: a single parameter buffer (56.5 us); ring depth 2 / 3 / 4 under
+// events (46.8 / 45.6 / 45.8 us: the events, not the dependency distance, were the cost); a release fence by every wave of the
+// gradient-tile kernel before its count (39.2 us: 272 L2 write-back sweeps; one per workgroup is enough).
 // ---------------------------------------------------------------------------------------------------------------------------
+// a device-side wait of the previous bgm_causal_fit_epoch call gave up (FitSync): that call's results are void
+static int fit_epoch_check(bgm_handle *h, hipStream_t stream) {
+  if (!h->epoch_ctr) return BGM_OK;
+  unsigned c[4];
+  BGM_HIP_CHECK(hipMemcpyAsync(c, h->epoch_ctr, sizeof(c), hipMemcpyDeviceToHost, stream));
+  BGM_HIP_CHECK(hipStreamSynchronize(stream));
+  if (!c[2]) return BGM_OK;
+  BGM_HIP_CHECK(hipMemset(h->epoch_ctr, 0, sizeof(c)));
+  h->epoch_theta_done = h->epoch_z_done = 0;
+  bgm_set_error("bgm_causal_fit_epoch: a device-side ordering wait timed out in the previous call (its updates are unordered); "
+                "BGM_FIT_NO_FLAGS=1 orders the two streams with HIP events instead");
+  return BGM_E_HIP;
+}
+
 extern "C" int bgm_causal_fit_epoch(bgm_handle *h, const float *x, const float *y, const float *v, float *data_z, float *zm, float *zv,
                                     const int32_t *perm, int64_t n_use, int32_t batch, float lr_theta, float lr_z, int32_t lazy,
                                     double *loss, double *loss_z, void *stream_) {
@@ -698,7 +727,7 @@ extern "C" int bgm_causal_fit_epoch(bgm_handle *h, const float *x, const float *
   const bool overlap = !no_overlap && lazy != 0 && h->fit_chain != nullptr && batch <= 32;
   if (overlap && !h->epoch_stream) {
     BGM_HIP_CHECK(hipStreamCreateWithFlags(&h->epoch_stream, hipStreamNonBlocking));
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 4; ++k) {
       BGM_HIP_CHECK(hipEventCreateWithFlags(&h->epoch_ev_t[k], hipEventDisableTiming));
       BGM_HIP_CHECK(hipEventCreateWithFlags(&h->epoch_ev_z[k], hipEventDisableTiming));
     }
@@ -706,26 +735,47 @@ extern "C" int bgm_causal_fit_epoch(bgm_handle *h, const float *x, const float *
   hipStream_t sB = overlap ? h->epoch_stream : sA;
   int rc = BGM_OK;
   long long k = 0;
-  // Two parameter buffers: step k's Adam reads buffer k & 1 and writes the other one, so the latent phase of minibatch k (reading the
-  // new buffer) never holds up the parameter update of minibatch k + 1 -- that one overwrites the buffer the latent phase k - 1 read.
+  // D parameter buffers in a ring: step k's Adam reads buffer k % D and writes the next one, so the latent phase of minibatch k (reading
+  // the new buffer) holds up nothing before the parameter update of minibatch k + D - 1, which overwrites the buffer the latent phase
+  // k - 1 read.  With D = 2 the cycle  latent phase k -> (event) -> theta phase k + 2 -> (event) -> latent phase k + 2  carries two
+  // cross-stream hops of ~10 us per two minibatches (46.3 us per minibatch measured = 36 + 10); D = 4 spreads them over four.
+  static const int depth_env = std::getenv("BGM_FIT_EPOCH_DEPTH") ? std::atoi(std::getenv("BGM_FIT_EPOCH_DEPTH")) : 4;
+  const int D = overlap ? std::min(4, std::max(2, depth_env)) : 1;
   FitChainState *fc = static_cast<FitChainState *>(h->fit_chain);
   const int np = h->n_params;
-  if (overlap && !fc->theta2) {
-    BGM_HIP_CHECK(hipMalloc((void **)&fc->theta2, sizeof(float) * np));
-    BGM_HIP_CHECK(hipMalloc((void **)&fc->thetaT2, sizeof(float) * ((size_t)np + 64)));
+  float *tb[4] = {h->theta_dev, nullptr, nullptr, nullptr}, *tTb[4] = {overlap ? fc->thetaT : nullptr, nullptr, nullptr, nullptr};
+  for (int d = 1; d < D; ++d) {
+    if (!fc->theta_x[d - 1]) {
+      BGM_HIP_CHECK(hipMalloc((void **)&fc->theta_x[d - 1], sizeof(float) * np));
+      BGM_HIP_CHECK(hipMalloc((void **)&fc->thetaT_x[d - 1], sizeof(float) * ((size_t)np + 64)));
+    }
+    tb[d] = fc->theta_x[d - 1]; tTb[d] = fc->thetaT_x[d - 1];
+    BGM_HIP_CHECK(hipMemcpyAsync(tTb[d], fc->thetaT, sizeof(float) * ((size_t)np + 64), hipMemcpyDeviceToDevice, sA));   // (rows no parameter maps to)
   }
-  float *tb[2] = {h->theta_dev, overlap ? fc->theta2 : nullptr}, *tTb[2] = {overlap ? fc->thetaT : nullptr, overlap ? fc->thetaT2 : nullptr};
-  if (overlap) BGM_HIP_CHECK(hipMemcpyAsync(fc->thetaT2, fc->thetaT, sizeof(float) * ((size_t)np + 64), hipMemcpyDeviceToDevice, sA));   // (rows no parameter maps to)
   int cur = 0;
   static const bool no_fuse = std::getenv("BGM_FIT_NO_FUSED_ADAM") != nullptr;       // dev A/B: separate Adam launch + explicit row marks
   const bool fuse = overlap && !no_fuse;
-  // Replay mode: the pending zero-gradient steps of minibatch j's rows are replayed two minibatches ahead, on the second stream behind
-  // the latent phase j - 2 -- off the parameter stream's critical path (replay + chains + gradient tiles), and covered by the event the
+  // Replay mode: the pending zero-gradient steps of minibatch j's rows are replayed D minibatches ahead, on the second stream behind
+  // the latent phase j - D -- off the parameter stream's critical path (replay + chains + gradient tiles), and covered by the event the
   // theta phase j waits for anyway.  Legal because the minibatches of one call are disjoint: nothing touches those rows in between,
   // and the step a replay runs to (the latent step count when minibatch j starts) is known in advance.
   static const bool no_ahead = std::getenv("BGM_FIT_NO_REPLAY_AHEAD") != nullptr;    // dev A/B
   const bool ahead = fuse && lazy == 2 && !no_ahead;
   const long long tz0 = h->t_z, n_mb = (n_use + batch - 1) / batch;
+  // Ordering between the two streams without events (each record / wait pair costs the stream it sits in 4-6 us of command-processor
+  // time: 45.0 us per minibatch with them, 34.7 with the dependencies dropped -- unsafe, measured for the bound): the gradient-tile
+  // kernel counts its workgroups into a device counter the latent phase's kernel spins on at entry, and the latent kernel's workgroups
+  // (chains + replay riders) count into a second one the theta phase D minibatches later waits for (fit_types.h FitSync).
+  static const bool no_flags = std::getenv("BGM_FIT_NO_FLAGS") != nullptr;           // dev A/B: HIP events
+  const bool flags = fuse && !no_flags && (lazy != 2 || ahead);
+  unsigned zt[4] = {0, 0, 0, 0};   // the latent counter's value once minibatch (slot)'s kernel is done
+  if (flags) {
+    if (!h->epoch_ctr) {
+      BGM_HIP_CHECK(hipMalloc((void **)&h->epoch_ctr, sizeof(unsigned) * 4));
+      BGM_HIP_CHECK(hipMemsetAsync(h->epoch_ctr, 0, sizeof(unsigned) * 4, sA));
+      h->epoch_theta_done = h->epoch_z_done = 0;
+    } else if ((rc = fit_epoch_check(h, sA))) return rc;
+  }
   long long replayed = 0;          // minibatches [k, replayed) have been replayed but not stepped
   auto replay = [&](long long j, hipStream_t st) -> int {
     if (j >= n_mb) return BGM_OK;
@@ -743,7 +793,10 @@ extern "C" int bgm_causal_fit_epoch(bgm_handle *h, const float *x, const float *
     const int b = (int)std::min<int64_t>(batch, n_use - i);
     // (the replayed rows are stamped by the latent step below; only a failure in between needs the explicit mark)
     if (lazy == 2 && (!ahead || k == 0) && (rc = fit_z_sync_impl(h, data_z, zm, zv, idx, b, lr_z, sA, !fuse))) break;
-    if (ahead && k == 0 && (rc = replay(1, sA))) break;
+    if (ahead && k == 0) {
+      for (int d = 1; d < D && !rc; ++d) rc = replay(d, sA);
+      if (rc) break;
+    }
     if (overlap && k == 0) {       // the second stream starts behind everything queued on the caller's so far (incl. the first replay)
       BGM_HIP_CHECK(hipEventRecord(h->epoch_ev_t[1], sA));
       BGM_HIP_CHECK(hipStreamWaitEvent(sB, h->epoch_ev_t[1], 0));
@@ -753,35 +806,53 @@ extern "C" int bgm_causal_fit_epoch(bgm_handle *h, const float *x, const float *
     const double t = (double)(h->t_theta + 1);
     const float lr_t = (float)((double)lr_theta * std::sqrt(1.0 - std::pow((double)ADAM_B2, t)) / (1.0 - std::pow((double)ADAM_B1, t)));
     if (fuse) {                    // the Adam step rides on the gradient-tile kernel: it writes the other buffer, which the latent
-      if (k > 1) BGM_HIP_CHECK(hipStreamWaitEvent(sA, h->epoch_ev_z[k & 1], 0));       // phase k - 2 (same slot) has read
+      if (flags) {               // ... phase k - D (same slot) has read: waited for in the chain kernel itself (and the rows' replay with it)
+        fc->sync_t = FitSync{k >= D ? h->epoch_ctr + 1 : nullptr, zt[k % D], h->epoch_ctr, (int *)(h->epoch_ctr + 2)};
+      } else if (k >= D) BGM_HIP_CHECK(hipStreamWaitEvent(sA, h->epoch_ev_z[k % D], 0));
       FitAdamTheta &ad = fc->fused;
       ad.on = 1; ad.lr_t = lr_t; ad.b1 = ADAM_B1; ad.b2 = ADAM_B2; ad.eps = ADAM_EPS;
-      ad.m1 = h->m1_dev; ad.m2 = h->m2_dev; ad.theta_out = tb[cur ^ 1];
-      ad.fwd_blob = h->blob_dev; ad.bwd_blob = h->bblob_dev; ad.mirror = tTb[cur ^ 1];
+      ad.m1 = h->m1_dev; ad.m2 = h->m2_dev; ad.theta_out = tb[(cur + 1) % D];
+      ad.fwd_blob = h->blob_dev; ad.bwd_blob = h->bblob_dev; ad.mirror = tTb[(cur + 1) % D];
       ad.fwd_dst = tbl; ad.fwd_dst2 = tbl + np; ad.bwd_dst = tbl + 2 * (size_t)np; ad.mirror_dst = fc->mirror_dst;
     }
     rc = bgm_causal_fit_theta_grad(h, x, y, v, data_z, idx, 0, b, b, h->epoch_grad, loss, sA);
-    if (fuse) fc->fused.on = 0;
+    if (fuse) { fc->fused.on = 0; fc->sync_t = FitSync{}; }
     if (rc) { hipStreamSynchronize(sB); mark_pending(sA); break; }
+    if (flags) h->epoch_theta_done += (unsigned)((fc->base.n_tiles + ECH_WAVES - 1) / ECH_WAVES);      // (the gradient-tile kernel's workgroups)
     if (overlap) {
       if (!fuse) {
-        if (k > 1) BGM_HIP_CHECK(hipStreamWaitEvent(sA, h->epoch_ev_z[k & 1], 0));       // latent phase k - 2 (same slot): it read the buffer written now
+        if (k >= D) BGM_HIP_CHECK(hipStreamWaitEvent(sA, h->epoch_ev_z[k % D], 0));       // latent phase k - D (same slot): it read the buffer written now
         hipLaunchKernelGGL(fit_adam_theta_kernel, dim3((np + 255) / 256), dim3(256), 0, sA, tb[cur], h->m1_dev, h->m2_dev, h->epoch_grad, np, lr_t,
-                           ADAM_B1, ADAM_B2, ADAM_EPS, h->blob_dev, h->bblob_dev, tbl, tbl + np, tbl + 2 * (size_t)np, tTb[cur ^ 1], fc->mirror_dst,
-                           tb[cur ^ 1]);
+                           ADAM_B1, ADAM_B2, ADAM_EPS, h->blob_dev, h->bblob_dev, tbl, tbl + np, tbl + 2 * (size_t)np, tTb[(cur + 1) % D], fc->mirror_dst,
+                           tb[(cur + 1) % D]);
         BGM_HIP_CHECK(hipGetLastError());
       }
       h->t_theta += 1;
       h->sblob_valid = false; h->det_valid = false;
-      cur ^= 1;
+      cur = (cur + 1) % D;
       fc->theta_use = tb[cur]; fc->thetaT_use = tTb[cur];
-      BGM_HIP_CHECK(hipEventRecord(h->epoch_ev_t[k & 1], sA));
-      BGM_HIP_CHECK(hipStreamWaitEvent(sB, h->epoch_ev_t[k & 1], 0));
+      if (!flags) {
+        BGM_HIP_CHECK(hipEventRecord(h->epoch_ev_t[k % D], sA));
+        BGM_HIP_CHECK(hipStreamWaitEvent(sB, h->epoch_ev_t[k % D], 0));
+      }
     } else if ((rc = bgm_causal_fit_theta_apply(h, h->epoch_grad, lr_theta, sA))) break;
     if (ahead) h->z_synced = h->t_z + 1;       // (minibatch k's rows were replayed to step tz0 + k = t_z)
-    if ((rc = bgm_causal_fit_z_step(h, x, y, v, data_z, zm, zv, idx, 0, b, b, lr_z, lazy, loss_z, sB))) { mark_pending(sB); break; }
-    if (ahead && (rc = replay(k + 2, sB))) { ++k; mark_pending(sB); break; }
-    if (overlap) BGM_HIP_CHECK(hipEventRecord(h->epoch_ev_z[k & 1], sB));
+    if (flags) {                               // the latent phase waits for this minibatch's Adam step in the kernel; the replay rides along
+      fc->sync_z = FitSync{h->epoch_ctr, h->epoch_theta_done, h->epoch_ctr + 1, (int *)(h->epoch_ctr + 2)};
+      if (ahead && k + D < n_mb) {
+        fc->rp_idx = perm + (k + D) * batch; fc->rp_n = (int)std::min<int64_t>(batch, n_use - (k + D) * batch);
+        fc->rp_t_to = (int)(tz0 + k + D); fc->rp_lr = lr_z; fc->rp_tlast = h->tlast_dev;
+        replayed = k + D + 1;
+      }
+    }
+    rc = bgm_causal_fit_z_step(h, x, y, v, data_z, zm, zv, idx, 0, b, b, lr_z, lazy, loss_z, sB);
+    if (flags) {
+      fc->sync_z = FitSync{}; fc->rp_n = 0;
+      if (!rc) { h->epoch_z_done += (unsigned)fc->last_z_blocks; zt[k % D] = h->epoch_z_done; }
+    }
+    if (rc) { mark_pending(sB); break; }
+    if (ahead && !flags && (rc = replay(k + D, sB))) { ++k; mark_pending(sB); break; }
+    if (overlap && !flags) BGM_HIP_CHECK(hipEventRecord(h->epoch_ev_z[k % D], sB));
   }
   if (overlap) {
     fc->theta_use = nullptr; fc->thetaT_use = nullptr;
@@ -789,9 +860,9 @@ extern "C" int bgm_causal_fit_epoch(bgm_handle *h, const float *x, const float *
       BGM_HIP_CHECK(hipEventRecord(h->epoch_ev_z[0], sB));
       BGM_HIP_CHECK(hipStreamWaitEvent(sA, h->epoch_ev_z[0], 0));
     }
-    if (cur == 1) {   // ... and the parameters in the session's own buffers
-      BGM_HIP_CHECK(hipMemcpyAsync(h->theta_dev, fc->theta2, sizeof(float) * np, hipMemcpyDeviceToDevice, sA));
-      BGM_HIP_CHECK(hipMemcpyAsync(fc->thetaT, fc->thetaT2, sizeof(float) * ((size_t)np + 64), hipMemcpyDeviceToDevice, sA));
+    if (cur != 0) {   // ... and the parameters in the session's own buffers
+      BGM_HIP_CHECK(hipMemcpyAsync(h->theta_dev, tb[cur], sizeof(float) * np, hipMemcpyDeviceToDevice, sA));
+      BGM_HIP_CHECK(hipMemcpyAsync(fc->thetaT, tTb[cur], sizeof(float) * ((size_t)np + 64), hipMemcpyDeviceToDevice, sA));
     }
   }
   return rc;
@@ -864,6 +935,7 @@ extern "C" int bgm_causal_fit_end(bgm_handle *h, void *stream_) {
   if (!h->fit_active) return BGM_OK;
   BGM_HIP_CHECK(hipSetDevice(h->device));
   BGM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_));
+  const int rc_epoch = fit_epoch_check(h, (hipStream_t)stream_);      // (reported after the session is closed)
   size_t off = 0;
   for (int id : {BGM_NET_G, BGM_NET_F, BGM_NET_H}) {   // theta order g | f | h
     HostNet &n = h->nets[id];
@@ -872,7 +944,7 @@ extern "C" int bgm_causal_fit_end(bgm_handle *h, void *stream_) {
   }
   h->bx_valid = false;   // the split-precision sampling blob is packed from the host copies refreshed above
   fit_free(h);   // forward blob on the device is already current (blob_valid stays true)
-  return BGM_OK;
+  return rc_epoch;
 }
 
 // ===========================================================================================

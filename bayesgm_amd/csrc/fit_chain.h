@@ -12,6 +12,7 @@
 #pragma once
 #include "egm_chain_gen.h"
 #include "fit_types.h"
+#include "z_replay.h"
 
 struct FitChainArgs {
   EgmMlp g, f, h;                 // offsets into theta (canonical [g | f | h])
@@ -33,6 +34,10 @@ struct FitChainArgs {
   int n_warm;                     // floats of theta (= of the transposed mirror) the idle wave pair pulls into this XCD's L2
   int n_valid;                    // rows of the minibatch (<= 16 NB): the tile rows behind them are masked -- they read row n_valid - 1,
                                   // contribute zero loss and zero output gradients, hence nothing to any parameter gradient
+  FitSync sy;                     // bgm_causal_fit_epoch: the chain kernel waits at entry (both phases); the latent phase's workgroups and
+                                  // the gradient-tile kernel's count themselves done at their end
+  int rp_first, rp_n, rp_t_to;    // latent phase, rp_n > 0: workgroups blockIdx.x >= rp_first replay the pending zero-gradient steps of
+  const int *rp_idx; const int *rp_tlast; float rp_lr;      // the rows rp_idx[0 .. rp_n) to step rp_t_to (fit_adam_z_replay_kernel's job, riding along)
   FitAdamTheta ad;                // theta phase, ad.on: the gradient-tile kernel applies the Adam step itself (bgm_causal_fit_epoch)
 };
 
@@ -61,6 +66,13 @@ static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_kernel(FitChainA
   static_assert(!WS || (NB == 1 && HT == 4 && T0 == 1 && !PAD), "worker split: one plain row tile per workgroup");
   constexpr int B = 16 * NB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  if (Z_MODE == 1 && a.rp_n > 0 && (int)blockIdx.x >= a.rp_first) {      // a rider workgroup: rows of a later minibatch, nothing to wait for
+    fit_adam_z_replay_one((long long)((int)blockIdx.x - a.rp_first) * ECH_THREADS + tid, tid & 15, a.z_out, a.zm, a.zv, a.rp_tlast, a.q, a.rp_idx,
+                          a.rp_n, a.rp_t_to, a.rp_lr, a.b1, a.b2, a.eps);
+    fit_sync_done(a.sy);
+    return;
+  }
+  fit_sync_wait(a.sy);
   const int role = wave >> 1, tile = wave & 1;
   const bool active = tile < NB && role < 3 && (gridDim.y == 1 || role == (int)blockIdx.y);     // gridDim.y = 3: one network per workgroup
   const int rb = 16 * NB * (int)blockIdx.x;          // a minibatch may be split over workgroups (blockIdx.x: NB row tiles each): rows rb ..
@@ -385,6 +397,7 @@ static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_kernel(FitChainA
     atomicAdd(a.loss + 4, s[1][0]); atomicAdd(a.loss + 5, s[1][1]);
     atomicAdd(a.loss + 6, s[0][0] + s[2][0] + s[1][0] + s[0][2]);
   }
+  if (Z_MODE == 1) fit_sync_done(a.sy);
 }
 
 // gradient tiles: grad[W_l] = X_l^T D_l, grad[b_l] = column sums of D_l  (one pass; canonical parameter order)
@@ -392,7 +405,7 @@ template <int NB>
 static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_dw_kernel(FitChainArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const int tau = blockIdx.x * ECH_WAVES + wave;
-  if (tau >= a.n_tiles) return;
+  if (tau < a.n_tiles) {
   const int *td = a.tiles + tau * ECG_TILE_INTS;
   const int xo = td[0], dofs = td[2], xw = td[4], dw = td[5], u = td[6], v = td[7], woff = td[8], n_in = td[9], n_out = td[10], boff = td[11];
   const float *ws = a.ws;
@@ -418,4 +431,6 @@ static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_dw_kernel(FitCha
     if (a.ad.on) fit_adam_theta_one(boff + o, bs, a.theta, a.ad);
     else a.grad[boff + o] = bs;
   }
+  }
+  fit_sync_done(a.sy);
 }

@@ -15,11 +15,9 @@ __device__ __forceinline__ float fit_adam_lr_t(float lr, float t, float ln_b1, f
   return lr * sqrtf(-expm1f(t * ln_b2)) / (-expm1f(t * ln_b1));          // lr sqrt(1 - b2^t) / (1 - b1^t) without cancellation
 }
 
-static __global__ void fit_adam_z_replay_kernel(float *z, float *zm, float *zv, const int *t_last, int q, const int *idx, long long n_sel,
-                                         int t_to, float lr, float b1, float b2, float eps) {
-  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void fit_adam_z_replay_one(long long gid, int l, float *z, float *zm, float *zv, const int *t_last, int q,
+                                                      const int *idx, long long n_sel, int t_to, float lr, float b1, float b2, float eps) {
   const long long el = gid >> 4;
-  const int l = (int)(threadIdx.x & 15);
   if (el >= n_sel * q) return;                     // (whole 16-lane groups leave together)
   const long long s = el / q;
   const int f = (int)(el - s * q);
@@ -45,6 +43,12 @@ static __global__ void fit_adam_z_replay_kernel(float *z, float *zm, float *zv, 
     zm[e] = m * exp2f((float)k * l2b1);
     zv[e] = v * exp2f((float)k * l2b2);
   }
+}
+
+static __global__ void fit_adam_z_replay_kernel(float *z, float *zm, float *zv, const int *t_last, int q, const int *idx, long long n_sel,
+                                         int t_to, float lr, float b1, float b2, float eps) {
+  fit_adam_z_replay_one((long long)blockIdx.x * blockDim.x + threadIdx.x, (int)(threadIdx.x & 15), z, zm, zv, t_last, q, idx, n_sel, t_to, lr, b1, b2,
+                        eps);
 }
 
 // After a replay of the rows idx[0..n_sel) their (z, m, v) are current to `value`: recorded in a launch of its own (the replay kernel's
