@@ -19,10 +19,14 @@ struct BnnFitChain {
   int *tiles_theta = nullptr;
   float *ws = nullptr;
   float *ws_z = nullptr;     // the latent phase's own workspace: it may run beside the next minibatch's theta phase (bgm_bnn_fit_epoch)
+  // bgm_bnn_fit_epoch, device-side ordering (fit_sync.h) of the next launches: the gradient-tile kernel (waits for the previous latent
+  // phase, counts the Adam step done), the latent phase's noise kernel (waits for the Adam step), its row-update kernel (counts it done)
+  FitSync sync_dw{}, sync_zn{}, sync_zr{};
 };
 template <bool KL>
-static __global__ __launch_bounds__(BNN_THREADS) void bnn_fit_noise_kernel(BnnArgs a, const EcbTab *tab, float *ws) {
+static __global__ __launch_bounds__(BNN_THREADS) void bnn_fit_noise_kernel(BnnArgs a, const EcbTab *tab, float *ws, FitSync sy) {
   __shared__ float red[16];
+  fit_sync_wait(sy);
   ecb_gen_noise<BnnArgs>(a, *tab, ws);
   if (blockIdx.x == 0 && threadIdx.x < (KL ? 6 : 1) && a.out) a.out[threadIdx.x] = 0.0f;      // the chain workgroups accumulate into it
   if (KL) {     // theta step: the value of the KL term, summed by the chain kernel (one call per net there)
@@ -36,8 +40,10 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_chain_kernel(Bnn
   ecb_theta_chain<BnnArgs, 4, NTL, 4, 2, 1, NB, PAD, T0, WS>(a, *tab, ws, bnn_chain_lds);
 }
 template <int NB>
-static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_dw_kernel(BnnArgs a, const EcbTab *tab, const int *tiles, const float *ws) {
+static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_dw_kernel(BnnArgs a, const EcbTab *tab, const int *tiles, const float *ws, FitSync sy) {
+  fit_sync_wait(sy);
   ecb_theta_dw<BnnArgs, NB>(a, *tab, tiles, ws);
+  fit_sync_done(sy);
 }
 template <int NTL, int NB, bool PAD = false, int T0 = 1, bool WS = false>
 static __global__ __launch_bounds__(BNN_THREADS) void bnn_z_chain_kernel(BnnArgs a, const EcbTab *tab, float *ws) {
@@ -256,7 +262,7 @@ static void bnn_theta_launch(BnnState *s, BnnArgs &a, int batch, int parts, hipS
   BnnFitChain *fc = static_cast<BnnFitChain *>(s->chain);
   if (fc && (batch == 32 || (batch == 16 && !fc->pad))) {
     if (parts & 1) {
-    hipLaunchKernelGGL(bnn_fit_noise_kernel<true>, dim3(3 * ECB_NOISE_PARTS), dim3(BNN_THREADS), 0, st, a, fc->tab_theta, fc->ws);
+    hipLaunchKernelGGL(bnn_fit_noise_kernel<true>, dim3(3 * ECB_NOISE_PARTS), dim3(BNN_THREADS), 0, st, a, fc->tab_theta, fc->ws, FitSync{});
     auto kc = fc->t0 == 2 ? bnn_theta_chain_kernel<13, 2, true, 2> : fc->pad ? bnn_theta_chain_kernel<13, 2, true>
               : batch == 32 ? (fc->ntl == 13 ? bnn_theta_chain_kernel<13, 2> : bnn_theta_chain_kernel<7, 2>)
                           : (fc->ntl == 13 ? bnn_theta_chain_kernel<13, 1> : bnn_theta_chain_kernel<7, 1>);
@@ -275,7 +281,7 @@ static void bnn_theta_launch(BnnState *s, BnnArgs &a, int batch, int parts, hipS
     }
     if (parts & 2) {
     auto kd = batch == 32 ? bnn_theta_dw_kernel<2> : bnn_theta_dw_kernel<1>;
-    hipLaunchKernelGGL(kd, dim3((fc->n_tiles + ECH_WAVES - 1) / ECH_WAVES + 1), dim3(BNN_THREADS), 0, st, a, fc->tab_theta, fc->tiles_theta, fc->ws);
+    hipLaunchKernelGGL(kd, dim3((fc->n_tiles + ECH_WAVES - 1) / ECH_WAVES + 1), dim3(BNN_THREADS), 0, st, a, fc->tab_theta, fc->tiles_theta, fc->ws, fc->sync_dw);
     }
   } else if (parts & 2) {          // (the phase machine is one launch: it runs at the point of the parameter write)
     hipLaunchKernelGGL(bnn_theta_step_kernel, dim3(3), dim3(BNN_THREADS), 0, st, a);
@@ -347,7 +353,7 @@ extern "C" int bgm_bnn_z_step(bgm_handle *h, const float *x, const float *y, con
   a.out = out; a.dz = dz_out ? dz_out : s->dz_dev;
   BnnFitChain *fc = static_cast<BnnFitChain *>(s->chain);
   if (fc && (batch == 32 || (batch == 16 && !fc->pad))) {
-    hipLaunchKernelGGL(bnn_fit_noise_kernel<false>, dim3(6 * ECB_NOISE_PARTS), dim3(BNN_THREADS), 0, stream, a, fc->tab_z, fc->ws_z);
+    hipLaunchKernelGGL(bnn_fit_noise_kernel<false>, dim3(6 * ECB_NOISE_PARTS), dim3(BNN_THREADS), 0, stream, a, fc->tab_z, fc->ws_z, fc->sync_zn);
     auto kc = fc->t0 == 2 ? bnn_z_chain_kernel<13, 2, true, 2> : fc->pad ? bnn_z_chain_kernel<13, 2, true>
               : batch == 32 ? (fc->ntl == 13 ? bnn_z_chain_kernel<13, 2> : bnn_z_chain_kernel<7, 2>)
                           : (fc->ntl == 13 ? bnn_z_chain_kernel<13, 1> : bnn_z_chain_kernel<7, 1>);
@@ -378,10 +384,10 @@ extern "C" int bgm_bnn_z_step(bgm_handle *h, const float *x, const float *y, con
   const int nb = batch * q;
   if (lazy == 2) {
     hipLaunchKernelGGL(bnn_z_rows_kernel, dim3((nb + 255) / 256), dim3(256), 0, stream, data_z, zm, zv, a.dz, idx, batch, q, lr_t,
-                       BNN_ADAM_B1, BNN_ADAM_B2, BNN_ADAM_EPS, 1, s->tlast_dev, (int)s->t_z);
+                       BNN_ADAM_B1, BNN_ADAM_B2, BNN_ADAM_EPS, 1, s->tlast_dev, (int)s->t_z, fc ? fc->sync_zr : FitSync{});
   } else if (lazy) {
     hipLaunchKernelGGL(bnn_z_rows_kernel, dim3((nb + 255) / 256), dim3(256), 0, stream, data_z, zm, zv, a.dz, idx, batch, q, lr_t,
-                       BNN_ADAM_B1, BNN_ADAM_B2, BNN_ADAM_EPS, 1);
+                       BNN_ADAM_B1, BNN_ADAM_B2, BNN_ADAM_EPS, 1, nullptr, 0, fc ? fc->sync_zr : FitSync{});
   } else {
     hipLaunchKernelGGL(bnn_z_decay_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, zm, zv, n, BNN_ADAM_B1, BNN_ADAM_B2);
     hipLaunchKernelGGL(bnn_z_rows_kernel, dim3((nb + 255) / 256), dim3(256), 0, stream, data_z, zm, zv, a.dz, idx, batch, q, lr_t,
@@ -392,8 +398,16 @@ extern "C" int bgm_bnn_z_step(bgm_handle *h, const float *x, const float *y, con
   return BGM_OK;
 }
 
+static int bnn_z_sync_impl(bgm_handle *h, float *data_z, float *zm, float *zv, const int32_t *idx, int64_t n_rows, int32_t batch, float lr_z,
+                           void *stream_, int t_to_ofs, bool mark);
 extern "C" int bgm_bnn_z_sync(bgm_handle *h, float *data_z, float *zm, float *zv, const int32_t *idx, int64_t n_rows, int32_t batch,
                               float lr_z, void *stream_) {
+  return bnn_z_sync_impl(h, data_z, zm, zv, idx, n_rows, batch, lr_z, stream_, 0, true);
+}
+// t_to_ofs: the rows are brought to step t_z + t_to_ofs (a minibatch that many latent steps ahead, bgm_bnn_fit_epoch);
+// mark = false: the caller guarantees the latent step of these rows follows (bnn_z_rows_kernel stamps them)
+static int bnn_z_sync_impl(bgm_handle *h, float *data_z, float *zm, float *zv, const int32_t *idx, int64_t n_rows, int32_t batch, float lr_z,
+                           void *stream_, int t_to_ofs, bool mark) {
   int rc = bnn_need(h, "bgm_bnn_z_sync");
   if (rc) return rc;
   BnnState *s = bst(h);
@@ -414,8 +428,10 @@ extern "C" int bgm_bnn_z_sync(bgm_handle *h, float *data_z, float *zm, float *zv
   const long long n_sel = idx ? batch : n_rows;
   const long long threads = n_sel * s->q * 16;
   hipLaunchKernelGGL(fit_adam_z_replay_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, data_z, zm, zv,
-                     s->tlast_dev, s->q, idx, n_sel, (int)s->t_z, lr_z, BNN_ADAM_B1, BNN_ADAM_B2, BNN_ADAM_EPS);
-  if (!idx) {
+                     s->tlast_dev, s->q, idx, n_sel, (int)s->t_z + t_to_ofs, lr_z, BNN_ADAM_B1, BNN_ADAM_B2, BNN_ADAM_EPS);
+  if (idx && !mark) {
+    if (t_to_ofs == 0) s->z_synced = s->t_z + 1;
+  } else if (!idx) {
     hipLaunchKernelGGL(fit_fill_int_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, s->tlast_dev, (long long)n_rows, (int)s->t_z);
     s->z_synced = -2;
   } else {
@@ -435,6 +451,20 @@ extern "C" int bgm_bnn_z_sync(bgm_handle *h, float *data_z, float *zm, float *zv
 // backward chains of minibatch k + 1 (both read the parameters of step k + 1; disjoint rows of the latent table); the gradient-tile
 // kernel of minibatch k + 1, which applies Adam, waits for it.  Results are those of the sequential order.
 // ---------------------------------------------------------------------------------------------------------------------------
+// a device-side wait of the previous bgm_bnn_fit_epoch call gave up (fit_sync.h): that call's results are void
+static int bnn_epoch_check(bgm_handle *h, hipStream_t stream) {
+  if (!h->epoch_ctr) return BGM_OK;
+  unsigned c[4];
+  BGM_HIP_CHECK(hipMemcpyAsync(c, h->epoch_ctr, sizeof(c), hipMemcpyDeviceToHost, stream));
+  BGM_HIP_CHECK(hipStreamSynchronize(stream));
+  if (!c[2]) return BGM_OK;
+  BGM_HIP_CHECK(hipMemset(h->epoch_ctr, 0, sizeof(c)));
+  h->epoch_theta_done = h->epoch_z_done = 0;
+  bgm_set_error("bgm_bnn_fit_epoch: a device-side ordering wait timed out in the previous call (its updates are unordered); "
+                "BGM_FIT_NO_FLAGS=1 orders the two streams with HIP events instead");
+  return BGM_E_HIP;
+}
+
 extern "C" int bgm_bnn_fit_epoch(bgm_handle *h, const float *x, const float *y, const float *v, float *data_z, float *zm, float *zv,
                                  const int32_t *perm, int64_t n_rows, int64_t n_use, int32_t batch, float lr_theta, float lr_z, int32_t lazy,
                                  uint64_t seed, uint32_t stream_id0, float *out_t, float *out_z, int32_t *n_done, void *stream_) {
@@ -456,16 +486,43 @@ extern "C" int bgm_bnn_fit_epoch(bgm_handle *h, const float *x, const float *y, 
   }
   hipStream_t sB = overlap ? h->epoch_stream : sA;
   long long k = 0;
+  // Ordering of the two streams by counters in device memory the kernels wait on / advance themselves (fit_sync.h) instead of HIP
+  // events (4-6 us of command-processor time per record / wait pair in the stream it sits in); the replay of a minibatch's pending
+  // latent steps runs two minibatches ahead on the second stream (in front of the latent phase k - 2, whose completion the
+  // gradient-tile kernel k - 1 waits for), and the latent step itself stamps the rows (no mark launch).  BGM_FIT_NO_FLAGS: events.
+  static const bool no_flags = std::getenv("BGM_FIT_NO_FLAGS") != nullptr;
+  const bool flags = overlap && !no_flags;
+  if (flags) {
+    if (!h->epoch_ctr) {
+      BGM_HIP_CHECK(hipMalloc((void **)&h->epoch_ctr, sizeof(unsigned) * 4));
+      BGM_HIP_CHECK(hipMemsetAsync(h->epoch_ctr, 0, sizeof(unsigned) * 4, sA));
+      h->epoch_theta_done = h->epoch_z_done = 0;
+    } else if ((rc = bnn_epoch_check(h, sA))) return rc;
+  }
+  int *err = flags ? (int *)(h->epoch_ctr + 2) : nullptr;
+  const int q = s->q;
+  const unsigned dw_blocks = fc ? (unsigned)((fc->n_tiles + ECH_WAVES - 1) / ECH_WAVES + 1) : 0, zr_blocks = (unsigned)((batch * q + 255) / 256);
+  auto rows_of = [&](int64_t i) { return (int)std::max<int64_t>(0, std::min<int64_t>(batch, n_use - i)); };
+  auto replay_ahead = [&](int64_t i, int ofs, hipStream_t st) -> int {      // minibatch at perm + i, `ofs` latent steps from now
+    const int bj = rows_of(i);
+    if (bj < 2) return BGM_OK;
+    return bnn_z_sync_impl(h, data_z, zm, zv, perm + i, n_rows, bj, lr_z, st, ofs, false);
+  };
   for (int64_t i = 0; i < n_use; i += batch) {
     const int32_t *idx = perm + i;
-    const int b = (int)std::min<int64_t>(batch, n_use - i);
+    const int b = rows_of(i);
     if (b < 2) continue;                     // batch statistics need two rows
-    const bool ov = overlap && b == batch;   // (a short last minibatch runs on the phase machine: in stream order)
+    const bool ov = flags && b == batch;     // (a short last minibatch runs on the phase machine: in stream order, on the caller's stream)
     const uint32_t s0 = stream_id0 + (uint32_t)(3 * k);
-    if (lazy == 2 && (rc = bgm_bnn_z_sync(h, data_z, zm, zv, idx, n_rows, b, lr_z, sA))) return rc;
+    if (lazy == 2 && !flags && (rc = bnn_z_sync_impl(h, data_z, zm, zv, idx, n_rows, b, lr_z, sA, 0, !overlap))) return rc;
+    if (lazy == 2 && flags && k == 0 && ((rc = replay_ahead(i, 0, sA)) || (rc = replay_ahead(i + batch, 1, sA)))) return rc;
     if (overlap && k == 0) {                 // the second stream starts behind everything queued on the caller's so far
       BGM_HIP_CHECK(hipEventRecord(h->epoch_ev_t[1], sA));
       BGM_HIP_CHECK(hipStreamWaitEvent(sB, h->epoch_ev_t[1], 0));
+    }
+    if (flags && !ov && k > 0) {             // the short tail: everything of the earlier minibatches first
+      BGM_HIP_CHECK(hipEventRecord(h->epoch_ev_z[0], sB));
+      BGM_HIP_CHECK(hipStreamWaitEvent(sA, h->epoch_ev_z[0], 0));
     }
     BnnArgs a{};
     bnn_base_args(s, a, b, 0, seed, s0);
@@ -473,16 +530,28 @@ extern "C" int bgm_bnn_fit_epoch(bgm_handle *h, const float *x, const float *y, 
     s->t_theta += 1;
     a.adam = BnnAdam{adam_lr_t(lr_theta, s->t_theta), BNN_ADAM_B1, BNN_ADAM_B2, BNN_ADAM_EPS};
     bnn_theta_launch(s, a, b, 1, sA);
-    if (overlap && k > 0) BGM_HIP_CHECK(hipStreamWaitEvent(sA, h->epoch_ev_z[(k - 1) & 1], 0));
+    if (ov) fc->sync_dw = FitSync{k > 0 ? h->epoch_ctr + 1 : nullptr, h->epoch_z_done, h->epoch_ctr, err};
+    else if (overlap && !flags && k > 0) BGM_HIP_CHECK(hipStreamWaitEvent(sA, h->epoch_ev_z[(k - 1) & 1], 0));
     bnn_theta_launch(s, a, b, 2, sA);
     BGM_HIP_CHECK(hipGetLastError());
     s->packed_valid = false; s->bnf_valid = false;
-    if (overlap) {
+    if (ov) {
+      fc->sync_dw = FitSync{};
+      h->epoch_theta_done += dw_blocks;
+      fc->sync_zn = FitSync{h->epoch_ctr, h->epoch_theta_done, nullptr, err};
+      fc->sync_zr = FitSync{nullptr, 0, h->epoch_ctr + 1, err};
+      if (lazy == 2 && (rc = replay_ahead(i + 2 * (int64_t)batch, 2, sB))) return rc;      // (in front of this latent phase: its count covers it)
+      s->z_synced = s->t_z + 1;
+    } else if (overlap && !flags) {
       BGM_HIP_CHECK(hipEventRecord(h->epoch_ev_t[k & 1], sA));
       BGM_HIP_CHECK(hipStreamWaitEvent(sB, h->epoch_ev_t[k & 1], 0));
     }
-    if ((rc = bgm_bnn_z_step(h, x, y, v, data_z, zm, zv, idx, n_rows, b, 0, lr_z, lazy, seed, s0 + 1, out_z, nullptr, ov ? sB : sB))) return rc;
-    if (overlap) BGM_HIP_CHECK(hipEventRecord(h->epoch_ev_z[k & 1], sB));
+    hipStream_t sz = (flags && !ov) ? sA : sB;
+    if (flags && !ov) s->z_synced = s->t_z + 1;
+    rc = bgm_bnn_z_step(h, x, y, v, data_z, zm, zv, idx, n_rows, b, 0, lr_z, lazy, seed, s0 + 1, out_z, nullptr, sz);
+    if (ov) { fc->sync_zn = FitSync{}; fc->sync_zr = FitSync{}; if (!rc) h->epoch_z_done += zr_blocks; }
+    if (rc) return rc;
+    if (overlap && !flags) BGM_HIP_CHECK(hipEventRecord(h->epoch_ev_z[k & 1], sB));
     ++k;
   }
   if (overlap && k > 0) {
@@ -498,6 +567,7 @@ extern "C" int bgm_bnn_end(bgm_handle *h, void *stream_) {
   if (!h->bnn_state) return BGM_OK;
   BGM_HIP_CHECK(hipSetDevice(h->device));
   BGM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_));
+  const int rc_epoch = bnn_epoch_check(h, (hipStream_t)stream_);
   bgm_bnn_free_state(h);
-  return BGM_OK;
+  return rc_epoch;
 }

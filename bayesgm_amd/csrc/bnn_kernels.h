@@ -14,6 +14,7 @@
 // backward product.  eps and dW = sigma * eps of a call are materialised once (they are needed again in backward).
 #pragma once
 #include "z_replay.h"
+#include "fit_sync.h"
 #include <hip/hip_runtime.h>
 
 #include "bgm_device.h"
@@ -694,21 +695,24 @@ static __global__ void bnn_z_decay_kernel(float *zm, float *zv, long long n, flo
   if (i < n) { zm[i] *= b1; zv[i] *= b2; }
 }
 static __global__ void bnn_z_rows_kernel(float *data_z, float *zm, float *zv, const float *dz, const int *idx, int B, int q,
-                                         float lr_t, float b1, float b2, float eps, int lazy, int *t_last = nullptr, int t_now = 0) {
+                                         float lr_t, float b1, float b2, float eps, int lazy, int *t_last = nullptr, int t_now = 0,
+                                         FitSync sy = FitSync{}) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * q) return;
-  const int b = i / q, j = i - b * q;
-  const long long t = (long long)idx[b] * q + j;
-  const float g = dz[i];
-  if (lazy) {
-    const float m = b1 * zm[t] + (1.0f - b1) * g, v = b2 * zv[t] + (1.0f - b2) * g * g;
-    zm[t] = m; zv[t] = v;
-    data_z[t] -= lr_t * m / (sqrtf(v) + eps);
-    if (t_last && j == 0) t_last[idx[b]] = t_now;      // replay mode (z_replay.h): the row is current to this step
-  } else {
-    zm[t] += (1.0f - b1) * g;
-    zv[t] += (1.0f - b2) * g * g;
+  if (i < B * q) {
+    const int b = i / q, j = i - b * q;
+    const long long t = (long long)idx[b] * q + j;
+    const float g = dz[i];
+    if (lazy) {
+      const float m = b1 * zm[t] + (1.0f - b1) * g, v = b2 * zv[t] + (1.0f - b2) * g * g;
+      zm[t] = m; zv[t] = v;
+      data_z[t] -= lr_t * m / (sqrtf(v) + eps);
+      if (t_last && j == 0) t_last[idx[b]] = t_now;      // replay mode (z_replay.h): the row is current to this step
+    } else {
+      zm[t] += (1.0f - b1) * g;
+      zv[t] += (1.0f - b2) * g * g;
+    }
   }
+  fit_sync_done(sy);      // bgm_bnn_fit_epoch: the latent phase of this minibatch is complete
 }
 static __global__ void bnn_z_apply_kernel(float *data_z, const float *zm, const float *zv, long long n, float lr_t, float eps) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
