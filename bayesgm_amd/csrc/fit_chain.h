@@ -413,6 +413,17 @@ static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_dw_kernel(FitCha
   f32x4 w = {0.0f, 0.0f, 0.0f, 0.0f};
   float bs = 0.0f;
   const float *xp = ws + xo + g * xw + 16 * u + j, *dp = ws + dofs + g * dw + o;
+  // fused Adam: the parameters' state is requested before the stash, so that the two trips to memory overlap
+  const bool fused = a.ad.on != 0, own_b = boff >= 0 && g == 0 && o < n_out;
+  bool own[4];
+  FitAdamPre pre[4], pre_b;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int f = 16 * u + 4 * g + r;
+    own[r] = f < n_in && o < n_out;
+    if (fused && own[r]) pre[r] = fit_adam_theta_load(woff + f * n_out + o, a.theta, a.ad);
+  }
+  if (fused && own_b) pre_b = fit_adam_theta_load(boff + o, a.theta, a.ad);
   float xa[NB * 4], da[NB * 4];
 #pragma unroll
   for (int s4 = 0; s4 < NB * 4; ++s4) { xa[s4] = xp[4 * s4 * xw]; da[s4] = dp[4 * s4 * dw]; }
@@ -422,13 +433,13 @@ static __global__ __launch_bounds__(ECH_THREADS) void fit_chain_dw_kernel(FitCha
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int f = 16 * u + 4 * g + r;
-    if (f < n_in && o < n_out) {
-      if (a.ad.on) fit_adam_theta_one(woff + f * n_out + o, w[r], a.theta, a.ad);      // (every parameter belongs to exactly one tile)
+    if (own[r]) {
+      if (fused) fit_adam_theta_apply(woff + f * n_out + o, w[r], pre[r], a.ad);      // (every parameter belongs to exactly one tile)
       else a.grad[woff + f * n_out + o] = w[r];
     }
   }
-  if (boff >= 0 && g == 0 && o < n_out) {
-    if (a.ad.on) fit_adam_theta_one(boff + o, bs, a.theta, a.ad);
+  if (own_b) {
+    if (fused) fit_adam_theta_apply(boff + o, bs, pre_b, a.ad);
     else a.grad[boff + o] = bs;
   }
   }

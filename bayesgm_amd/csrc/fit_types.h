@@ -53,17 +53,28 @@ struct FitAdamTheta {
   float *fwd_blob, *bwd_blob, *mirror;
   const int *fwd_dst, *fwd_dst2, *bwd_dst, *mirror_dst;
 };
-__device__ __forceinline__ void fit_adam_theta_one(int c, float g, const float *theta, const FitAdamTheta &ad) {
-  const float m = ad.b1 * ad.m1[c] + (1.0f - ad.b1) * g;
-  const float v = ad.b2 * ad.m2[c] + (1.0f - ad.b2) * g * g;
+struct FitAdamPre { float th, m1, m2; int d0, d1, d2, d3; };      // parameter c's state, requested ahead of the gradient
+__device__ __forceinline__ FitAdamPre fit_adam_theta_load(int c, const float *theta, const FitAdamTheta &ad) {
+  FitAdamPre p;
+  p.th = theta[c]; p.m1 = ad.m1[c]; p.m2 = ad.m2[c];
+  p.d0 = ad.fwd_dst[c]; p.d1 = ad.fwd_dst2[c]; p.d2 = ad.bwd_dst[c]; p.d3 = ad.mirror ? ad.mirror_dst[c] : -1;
+  return p;
+}
+__device__ __forceinline__ void fit_adam_theta_apply(int c, float g, const FitAdamPre &p, const FitAdamTheta &ad) {
+  // every rounding spelled out: the stand-alone kernel and the fused epilogue must agree bit for bit whatever the compiler would contract
+  const float m = __fmaf_rn(ad.b1, p.m1, __fmul_rn(1.0f - ad.b1, g));
+  const float v = __fmaf_rn(ad.b2, p.m2, __fmul_rn(__fmul_rn(1.0f - ad.b2, g), g));
   ad.m1[c] = m;
   ad.m2[c] = v;
-  const float w = theta[c] - ad.lr_t * m / (sqrtf(v) + ad.eps);
+  const float w = __fsub_rn(p.th, __fdiv_rn(__fmul_rn(ad.lr_t, m), __fadd_rn(__fsqrt_rn(v), ad.eps)));
   ad.theta_out[c] = w;
-  if (ad.fwd_dst[c] >= 0) ad.fwd_blob[ad.fwd_dst[c]] = w;
-  if (ad.fwd_dst2[c] >= 0) ad.fwd_blob[ad.fwd_dst2[c]] = w;
-  if (ad.bwd_dst[c] >= 0) ad.bwd_blob[ad.bwd_dst[c]] = w;
-  if (ad.mirror && ad.mirror_dst[c] >= 0) ad.mirror[ad.mirror_dst[c]] = w;      // transposed weights of the row-tile-chain kernels (fit_chain.h)
+  if (p.d0 >= 0) ad.fwd_blob[p.d0] = w;
+  if (p.d1 >= 0) ad.fwd_blob[p.d1] = w;
+  if (p.d2 >= 0) ad.bwd_blob[p.d2] = w;
+  if (p.d3 >= 0) ad.mirror[p.d3] = w;      // transposed weights of the row-tile-chain kernels (fit_chain.h)
+}
+__device__ __forceinline__ void fit_adam_theta_one(int c, float g, const float *theta, const FitAdamTheta &ad) {
+  fit_adam_theta_apply(c, g, fit_adam_theta_load(c, theta, ad), ad);
 }
 
 struct DwLayer { long long a_off, d_off; int K, N, out_off; };  // widths (multiples of 16); offset in the partial
