@@ -151,7 +151,7 @@ def fit_leg(model, x, y, v, n_loc, steps=2000, batch=32):
             "us_per_minibatch_host_loop": 1e6 * res["replay_host_loop"] / steps,
             "sample": f"{steps} DISJOINT minibatches of a permutation, B={batch}, N={n_loc}, deterministic nets, issued by one "
                       "bgm_causal_fit_epoch call as CausalBGM.fit does (latent phase of minibatch k beside the theta phase of k + 1, "
-                      "double-buffered parameters); latent optimizer = dense-decay Adam in replay form (value, us_per_minibatch), as a "
+                      "ring of parameter buffers, streams ordered by device-side counters); latent optimizer = dense-decay Adam in replay form (value, us_per_minibatch), as a "
                       "sweep over the table per minibatch (us_per_minibatch_dense_sweep: no overlap possible), and the replay form "
                       "issued per minibatch from Python (us_per_minibatch_host_loop: the form used under torch.distributed)",
             "flop_per_observation": 348480}

@@ -306,7 +306,9 @@ BGM_API int bgm_causal_fit_z_sync(bgm_handle *h, float *data_z_dev, float *zm_de
  * _theta_apply, _z_step with batch_global = the minibatch's own size, in that order.  loss_dev / loss_z_dev: the accumulators of
  * _theta_grad / _z_step.  With lazy = 1 / 2 on the row-tile chains the latent phase of minibatch k runs on a second stream beside the
  * theta phase of minibatch k + 1 (disjoint rows of the latent table: the minibatches of one call must not share rows -- a permutation);
- * results are those of the sequential order. */
+ * results are those of the sequential order.  The two streams are ordered by counters in device memory that the kernels wait on and
+ * advance (csrc/fit_sync.h); a wait that gives up (20 ms bound) voids the call and is reported as BGM_E_HIP by the next
+ * bgm_causal_fit_epoch / bgm_causal_fit_end (bgm_bnn_fit_epoch / bgm_bnn_end).  BGM_FIT_NO_FLAGS=1 orders them with HIP events. */
 BGM_API int bgm_causal_fit_epoch(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev, float *data_z_dev, float *zm_dev,
                          float *zv_dev, const int32_t *perm_dev, int64_t n_use, int32_t batch, float lr_theta, float lr_z, int32_t lazy,
                          double *loss_dev, double *loss_z_dev, void *stream);
