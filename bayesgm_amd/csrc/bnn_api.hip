@@ -491,13 +491,19 @@ extern "C" int bgm_bnn_fit_epoch(bgm_handle *h, const float *x, const float *y, 
   // latent steps runs two minibatches ahead on the second stream (in front of the latent phase k - 2, whose completion the
   // gradient-tile kernel k - 1 waits for), and the latent step itself stamps the rows (no mark launch).  BGM_FIT_NO_FLAGS: events.
   static const bool no_flags = std::getenv("BGM_FIT_NO_FLAGS") != nullptr;
-  const bool flags = overlap && !no_flags;
+  bool flags = overlap && !no_flags;
   if (flags) {
     if (!h->epoch_ctr) {
-      BGM_HIP_CHECK(hipMalloc((void **)&h->epoch_ctr, sizeof(unsigned) * 4));
-      BGM_HIP_CHECK(hipMemsetAsync(h->epoch_ctr, 0, sizeof(unsigned) * 4, sA));
+      BGM_HIP_CHECK(hipMalloc((void **)&h->epoch_ctr, sizeof(unsigned) * 8));
+      BGM_HIP_CHECK(hipMemsetAsync(h->epoch_ctr, 0, sizeof(unsigned) * 8, sA));
       h->epoch_theta_done = h->epoch_z_done = 0;
     } else if ((rc = bnn_epoch_check(h, sA))) return rc;
+    if (!h->epoch_flags_ok) {      // once per handle: do the two streams run side by side (fit_sync.h)?
+      int ok = 0;
+      BGM_HIP_CHECK(fit_sync_probe(sA, sB, h->epoch_ctr + 4, &ok));
+      h->epoch_flags_ok = ok ? 1 : -1;
+    }
+    if (h->epoch_flags_ok < 0) flags = false;      // (a profiler serialising kernels, one hardware queue): HIP events
   }
   int *err = flags ? (int *)(h->epoch_ctr + 2) : nullptr;
   const int q = s->q;

@@ -767,14 +767,20 @@ extern "C" int bgm_causal_fit_epoch(bgm_handle *h, const float *x, const float *
   // kernel counts its workgroups into a device counter the latent phase's kernel spins on at entry, and the latent kernel's workgroups
   // (chains + replay riders) count into a second one the theta phase D minibatches later waits for (fit_types.h FitSync).
   static const bool no_flags = std::getenv("BGM_FIT_NO_FLAGS") != nullptr;           // dev A/B: HIP events
-  const bool flags = fuse && !no_flags && (lazy != 2 || ahead);
+  bool flags = fuse && !no_flags && (lazy != 2 || ahead);
   unsigned zt[4] = {0, 0, 0, 0};   // the latent counter's value once minibatch (slot)'s kernel is done
   if (flags) {
     if (!h->epoch_ctr) {
-      BGM_HIP_CHECK(hipMalloc((void **)&h->epoch_ctr, sizeof(unsigned) * 4));
-      BGM_HIP_CHECK(hipMemsetAsync(h->epoch_ctr, 0, sizeof(unsigned) * 4, sA));
+      BGM_HIP_CHECK(hipMalloc((void **)&h->epoch_ctr, sizeof(unsigned) * 8));
+      BGM_HIP_CHECK(hipMemsetAsync(h->epoch_ctr, 0, sizeof(unsigned) * 8, sA));
       h->epoch_theta_done = h->epoch_z_done = 0;
     } else if ((rc = fit_epoch_check(h, sA))) return rc;
+    if (!h->epoch_flags_ok) {      // once per handle: do the two streams run side by side (fit_sync.h)?
+      int ok = 0;
+      BGM_HIP_CHECK(fit_sync_probe(sA, sB, h->epoch_ctr + 4, &ok));
+      h->epoch_flags_ok = ok ? 1 : -1;
+    }
+    if (h->epoch_flags_ok < 0) flags = false;      // (a profiler serialising kernels, one hardware queue): HIP events
   }
   long long replayed = 0;          // minibatches [k, replayed) have been replayed but not stepped
   auto replay = [&](long long j, hipStream_t st) -> int {
