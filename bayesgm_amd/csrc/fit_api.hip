@@ -960,14 +960,15 @@ extern "C" int bgm_causal_fit_end(bgm_handle *h, void *stream_) {
 #include "gx_bgm_host.h"
 
 static constexpr int BGM_FIT_WAVES = 8;
+static constexpr int BGM_SPLIT_MAX_WG = 8;      // workgroups of a small-minibatch pass (bgm_fit_kernels.h BgmFitSplit)
 
 void bgm_bgm_fit_free(bgm_handle *h) {
   if (!h->bgm_state) return;
   BgmState *s = static_cast<BgmState *>(h->bgm_state);
   for (void *p : {(void *)s->theta_dev, (void *)s->m1_dev, (void *)s->m2_dev, (void *)s->tblob_dev, (void *)s->ws_dev,
-                  (void *)s->partial_dev, (void *)s->bn_dev, (void *)s->tables_dev})
+                  (void *)s->partial_dev, (void *)s->bn_dev, (void *)s->tables_dev, (void *)s->split_part_dev})
     if (p) hipFree(p);
-  s->theta_dev = s->m1_dev = s->m2_dev = s->tblob_dev = s->ws_dev = s->partial_dev = s->bn_dev = nullptr;
+  s->theta_dev = s->m1_dev = s->m2_dev = s->tblob_dev = s->ws_dev = s->partial_dev = s->bn_dev = s->split_part_dev = nullptr;
   s->tables_dev = nullptr;
   s->fit_active = false; s->gx_fit = false;
 }
@@ -1084,6 +1085,8 @@ extern "C" int bgm_bgm_fit_begin(bgm_handle *h, int64_t n_rows, int32_t max_batc
   dw.partial_stride = (poff + 3) / 4 * 4;
   s->n_slices_cap = (B + s->rows_per_slice - 1) / s->rows_per_slice;
   BGM_HIP_CHECK(hipMalloc(&s->partial_dev, sizeof(float) * dw.partial_stride * s->n_slices_cap));
+  BGM_HIP_CHECK(hipMalloc(&s->split_part_dev, sizeof(float) * ((size_t)BGM_SPLIT_MAX_WG * BGM_FIT_S * 32 * 64 + 4)));
+  BGM_HIP_CHECK(hipMemset(s->split_part_dev, 0, sizeof(float) * ((size_t)BGM_SPLIT_MAX_WG * BGM_FIT_S * 32 * 64 + 4)));
   BGM_HIP_CHECK(hipMalloc(&s->tables_dev, sizeof(int) * tables.size()));
   BGM_HIP_CHECK(hipMemcpy(s->tables_dev, tables.data(), sizeof(int) * tables.size(), hipMemcpyHostToDevice));
   BGM_HIP_CHECK(hipDeviceSynchronize());
@@ -1105,8 +1108,18 @@ static int bgm_fit_fwd_bwd(bgm_handle *h, BgmState *s, const float *x, const flo
   ka.blob = s->tblob_dev; ka.m = s->tmeta; ka.ws = s->fit_ws; ka.wsp = s->ws_dev; ka.x = x; ka.data_z = data_z;
   ka.idx = idx; ka.B = batch; ka.inv_B = 1.0f / (float)(s->batch_global > 0 ? s->batch_global : batch); ka.bn = s->bn_dev; ka.loss = loss;
   const int tiles = (batch + 15) / 16;
-  const int grid = std::max(1, std::min((tiles + BGM_FIT_WAVES - 1) / BGM_FIT_WAVES, h->n_cus));
-  const int lds = s->fit_lds_bytes;
+  int grid = std::max(1, std::min((tiles + BGM_FIT_WAVES - 1) / BGM_FIT_WAVES, h->n_cus));
+  int lds = s->fit_lds_bytes;
+  // <= 32 rows (the reference's batch_size): head tiles dealt over the waves of a few workgroups instead of one wave per row tile
+  static const bool no_split = std::getenv("BGM_BGM_FIT_NO_SPLIT") != nullptr;       // dev A/B
+  if (tiles <= 2 && !no_split) {
+    const int ntx = s->tmeta.ntx, rounds = (ntx + BGM_FIT_S - 1) / BGM_FIT_S;
+    ka.split = 1;
+    ka.part = s->split_part_dev;
+    ka.part_ctr = reinterpret_cast<unsigned *>(s->split_part_dev + (size_t)BGM_SPLIT_MAX_WG * BGM_FIT_S * 32 * 64);
+    grid = std::max(1, std::min(BGM_SPLIT_MAX_WG, s->NTX == 0 ? rounds : (rounds + 1) / 2));
+    if (s->NTX == 0) lds += (BGM_FIT_S - 2) * BGM_PAIR * (int)sizeof(float);      // the stage holds BGM_FIT_S tile pairs
+  }
 #define X(KTQ_, NTX_, NH_)                                                                                          \
   if (s->KTQ == KTQ_ && s->NTX == NTX_ && s->NH == NH_) {                                                           \
     auto kf = bgm_fit_fwd_kernel<KTQ_, NTX_, NH_, BGM_FIT_WAVES>;                                                   \

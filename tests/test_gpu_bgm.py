@@ -194,7 +194,7 @@ def test_bgm_class_predict_ragged_pattern_and_edge_cases(tmp_path):
     assert np.allclose(lp_idx, OB.log_posterior(m, z, full, mk), rtol=1e-5, atol=1e-3)
 
 
-@pytest.mark.parametrize("p,B", [(20, 32), (500, 32), (45, 200)])
+@pytest.mark.parametrize("p,B", [(20, 32), (500, 32), (45, 200), (100, 32), (500, 20), (131, 9)])
 def test_bgm_fit_steps_match_oracle(tmp_path, p, B):
     """BGM fit step functions (training-mode BatchNorm, per-dimension variance head, fresh-slot Adam on Z)."""
     import torch
