@@ -153,6 +153,8 @@ SYMBOLS = {
     "bgm_bgm_fit_theta_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     "bgm_bgm_fit_z_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p,
                                      C.c_void_p]),
+    "bgm_bgm_fit_epoch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_void_p,
+                                    C.c_void_p]),
     "bgm_bgm_get_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "bgm_bgm_fit_end": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bgm_bgm_set_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

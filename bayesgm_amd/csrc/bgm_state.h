@@ -25,6 +25,7 @@ struct BgmState {
   long long t_theta = 0, t_z = 0;
   float *theta_dev = nullptr, *m1_dev = nullptr, *m2_dev = nullptr, *tblob_dev = nullptr, *ws_dev = nullptr,
         *partial_dev = nullptr, *bn_dev = nullptr;
+  float *epoch_grad_dev = nullptr;      // bgm_bgm_fit_epoch: the gradient between _theta_grad and _theta_apply
   float *split_part_dev = nullptr;      // small-minibatch passes (BgmFitKArgs::part): [8 * BGM_FIT_S][32][64] floats + one counter word
   int *tables_dev = nullptr;   // dst | dst2(-1) | bwd(-1) | grad_src
   BgmMeta tmeta{};             // training blob layout (same offsets as meta)

@@ -966,9 +966,10 @@ void bgm_bgm_fit_free(bgm_handle *h) {
   if (!h->bgm_state) return;
   BgmState *s = static_cast<BgmState *>(h->bgm_state);
   for (void *p : {(void *)s->theta_dev, (void *)s->m1_dev, (void *)s->m2_dev, (void *)s->tblob_dev, (void *)s->ws_dev,
-                  (void *)s->partial_dev, (void *)s->bn_dev, (void *)s->tables_dev, (void *)s->split_part_dev})
+                  (void *)s->partial_dev, (void *)s->bn_dev, (void *)s->tables_dev, (void *)s->split_part_dev,
+                  (void *)s->epoch_grad_dev})
     if (p) hipFree(p);
-  s->theta_dev = s->m1_dev = s->m2_dev = s->tblob_dev = s->ws_dev = s->partial_dev = s->bn_dev = s->split_part_dev = nullptr;
+  s->theta_dev = s->m1_dev = s->m2_dev = s->tblob_dev = s->ws_dev = s->partial_dev = s->bn_dev = s->split_part_dev = s->epoch_grad_dev = nullptr;
   s->tables_dev = nullptr;
   s->fit_active = false; s->gx_fit = false;
 }
@@ -1218,6 +1219,28 @@ extern "C" int bgm_bgm_fit_z_step(bgm_handle *h, const float *x, float *data_z, 
   hipLaunchKernelGGL(bgm_fit_z_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, data_z, dz, idx, batch, q,
                      lr_t, ADAM_B1, ADAM_B2, ADAM_EPS);
   BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The minibatch loop of BGM.fit inside the library (single process).  replaces: the loop body bgm/base.py:399-413 for the minibatches
+// perm[k * batch .. (k + 1) * batch), k = 0 .. n_steps - 1: bgm_bgm_fit_theta_grad, _theta_apply, _z_step in that order (the same
+// launches, issued from C++; results identical to the per-minibatch calls).
+// ---------------------------------------------------------------------------------------------------------------------------
+extern "C" int bgm_bgm_fit_epoch(bgm_handle *h, const float *x, float *data_z, const int32_t *perm, int64_t n_steps, int32_t batch,
+                                 float lr_theta, float lr_z, double *loss, void *stream_) {
+  int rc = bgm_fit_check(h, x, data_z, perm, batch, "bgm_bgm_fit_epoch");
+  if (rc) return rc;
+  if (n_steps < 0) { bgm_set_error("bgm_bgm_fit_epoch: negative step count"); return BGM_E_INVALID; }
+  BgmState *s = bst(h);
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  if (!s->epoch_grad_dev) BGM_HIP_CHECK(hipMalloc(&s->epoch_grad_dev, sizeof(float) * s->n_params));
+  for (int64_t k = 0; k < n_steps; ++k) {
+    const int32_t *idx = perm + k * batch;
+    if ((rc = bgm_bgm_fit_theta_grad(h, x, data_z, idx, batch, s->epoch_grad_dev, loss, stream_))) return rc;
+    if ((rc = bgm_bgm_fit_theta_apply(h, s->epoch_grad_dev, lr_theta, stream_))) return rc;
+    if ((rc = bgm_bgm_fit_z_step(h, x, data_z, idx, batch, lr_z, loss, stream_))) return rc;
+  }
   return BGM_OK;
 }
 

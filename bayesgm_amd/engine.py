@@ -639,6 +639,11 @@ class BgmEngine(object):
         _lib.check(self.lib.bgm_bgm_fit_z_step(self.h, _ptr(x), _ptr(data_z), _ptr(idx), int(idx.numel()), float(lr_z),
                                                _ptr(loss), self._stream()), "bgm_bgm_fit_z_step")
 
+    def fit_epoch(self, x, data_z, perm, n_steps, batch, lr_theta, lr_z, loss=None):
+        """The minibatches perm[k * batch : (k + 1) * batch], k < n_steps, in ONE library call (bgm_bgm_fit_epoch)."""
+        _lib.check(self.lib.bgm_bgm_fit_epoch(self.h, _ptr(x), _ptr(data_z), _ptr(perm), int(n_steps), int(batch), float(lr_theta),
+                                              float(lr_z), _ptr(loss), self._stream()), "bgm_bgm_fit_epoch")
+
     def get_weights(self):
         """Device parameters -> generator dict (bn / trunk / mean / var)."""
         buf = np.empty(self.n_theta(), np.float32)

@@ -193,8 +193,10 @@ class BGM(object):
         print('EGM Initialization Ends.')
 
     def fit(self, data, batch_size=32, epochs=100, epochs_per_eval=5, use_egm_init=True, egm_n_iter=20000,
-            egm_batches_per_eval=500, verbose=1):
-        """Iterative theta / Z updates (bgm/base.py:343-442).  The incomplete last minibatch of an epoch is
+            egm_batches_per_eval=500, verbose=1, host_loop=False):
+        """Iterative theta / Z updates (bgm/base.py:343-442).  ``host_loop=False`` (single process): the minibatches of an epoch are
+        issued by one library call; ``True`` keeps the per-minibatch calls from Python (same results; the only form under
+        torch.distributed, where the all-reduce sits between them).  The incomplete last minibatch of an epoch is
         skipped (:399) and the batch latents take a fresh-slot Adam step (:402, see bgm_fit_kernels.h).
 
         Under torch.distributed the fit is synchronous data parallel: every rank owns a contiguous
@@ -241,7 +243,10 @@ class BGM(object):
                 sample_idx = torch.from_numpy(np.random.choice(n, n, replace=False).astype(np.int32)).to(dev)
                 loss.zero_()
                 n_used = 0
-                for k in range(n_steps):                                            # skip the incomplete last batch
+                if not dist_on and host_loop is False:      # the minibatch loop inside the library (bgm_bgm_fit_epoch)
+                    eng.fit_epoch(x, self.data_z, sample_idx, n_steps, batch_size, self._p['lr_theta'], self._p['lr_z'], loss)
+                    n_used = n_steps * batch_size
+                for k in (range(n_steps) if n_used == 0 else ()):                   # skip the incomplete last batch
                     idx = sample_idx[k * batch_size:(k + 1) * batch_size]
                     eng.fit_theta_grad(x, self.data_z, idx, grad, loss)
                     if dist_on:

@@ -459,6 +459,11 @@ BGM_API int bgm_bgm_fit_theta_apply(bgm_handle *h, const float *grad_dev, float 
  * slots start at zero while the step counter keeps running; the updated rows are written back. */
 BGM_API int bgm_bgm_fit_z_step(bgm_handle *h, const float *x_dev, float *data_z_dev, const int32_t *idx_dev,
                        int32_t batch, float lr_z, double *loss_dev, void *stream);
+/* The minibatch loop of BGM.fit inside the library (single process; under data parallelism the three calls above stay, the all-reduce
+ * sits between the first two).  replaces: the loop body bgm/base.py:399-413 for the n_steps minibatches perm_dev[k * batch ..
+ * (k + 1) * batch): _theta_grad, _theta_apply, _z_step in that order; loss_dev as in those calls ([4] accumulators). */
+BGM_API int bgm_bgm_fit_epoch(bgm_handle *h, const float *x_dev, float *data_z_dev, const int32_t *perm_dev, int64_t n_steps, int32_t batch,
+                      float lr_theta, float lr_z, double *loss_dev, void *stream);
 BGM_API int bgm_bgm_get_weights(bgm_handle *h, float *theta_host, int64_t count, void *stream);
 BGM_API int bgm_bgm_fit_end(bgm_handle *h, void *stream);
 

@@ -248,6 +248,32 @@ def test_bgm_fit_steps_match_oracle(tmp_path, p, B):
     assert np.abs(lp - ref_lp).max() <= 0.1
 
 
+@pytest.mark.parametrize("p", [20, 500])
+def test_bgm_epoch_loop_inside_the_library_equals_the_host_loop(tmp_path, p):
+    """BGM.fit(host_loop=False) -- one bgm_bgm_fit_epoch call per epoch -- gives the generator, the latents and the per-epoch losses of
+    the per-minibatch calls from Python bit for bit (batch 32: the small-minibatch passes with the head tiles dealt over the waves)."""
+    from bayesgm_amd.models import BGM
+    rs = np.random.RandomState(11)
+    data = rs.randn(700, p).astype(np.float32)
+    res = []
+    for host_loop in (True, False):
+        np.random.seed(5)
+        model = BGM(_bgm_params(tmp_path, p), random_seed=3)
+        model.fit(data, epochs=2, epochs_per_eval=100, use_egm_init=False, verbose=0, host_loop=host_loop)
+        g = model.engine.get_weights()
+        flat = np.concatenate([g["bn"][k] for k in ("gamma", "beta", "mean", "var")] + [a.ravel() for W, b in g["trunk"] for a in (W, b)]
+                              + [a.ravel() for k in ("mean", "var") for a in g[k]])
+        res.append((model.data_z.cpu().numpy().copy(), flat, [dict(h) for h in model.fit_history]))
+    (za, wa, ha), (zb, wb, hb) = res
+    assert np.array_equal(za, zb)
+    assert np.array_equal(wa, wb)
+    assert len(ha) == len(hb) == 3
+    for a, b in zip(ha, hb):
+        assert a == b
+
+
+
+
 def test_bgm_class_fit_reduces_reconstruction_error(tmp_path):
     from bayesgm_amd.models import BGM
     from bayesgm_amd.datasets import simulate_z_hetero
