@@ -40,6 +40,9 @@ struct BgmFitKArgs {
   int split;
   float *part;            // [gridDim.x * BGM_FIT_S][32][64]: each wave's share of d loss / d (last hidden activation)
   unsigned *part_ctr;     // workgroups done (the last one adds the shares up and walks the trunk back)
+  // split mode: the batch statistics of the input BatchNorm are formed at the head of the forward kernel (every workgroup for itself,
+  // workgroup 0 publishes them in bn_w for the backward kernels and moves the running averages) -- bgm_bn_stats_kernel's job
+  float *bn_w; const float *bn_theta; float *bn_moving; int bn_update;
 };
 
 // Minibatches of <= 32 rows (the reference's batch_size): with one row tile per wave only two of a workgroup's waves had work and walked
@@ -74,10 +77,9 @@ struct BgmHeadRounds {
 };
 
 // ---- batch-norm statistics of the batch latents (single block) + moving-average update
-static __global__ __launch_bounds__(256) void bgm_bn_stats_kernel(const float *data_z, const int *idx, int B, int q, int KQ,
-                                                          const float *theta /* gamma|beta|mmean|mvar */, float *bn,
-                                                          float *moving /* mmean|mvar in theta, updated */,
-                                                          int update_moving) {
+// threads 0..255 of a workgroup; `out` = bn (global) or an LDS copy, `pub` != NULL: also published there (+ the running averages)
+__device__ __forceinline__ void bgm_bn_stats_body(const float *data_z, const int *idx, int B, int q, int KQ, const float *theta, float *out,
+                                                  float *pub, float *moving, int update_moving) {
   // 16 features at a time, 16 lanes per feature (rows lane, lane + 16, ...), double sums met through shuffles: no block barrier
   const int fl = threadIdx.x >> 4, l = threadIdx.x & 15;
   for (int f = fl; f < KQ; f += 16) {
@@ -90,21 +92,28 @@ static __global__ __launch_bounds__(256) void bgm_bn_stats_kernel(const float *d
 #pragma unroll
     for (int o = 8; o; o >>= 1) { a += __shfl_xor(a, o, 16); b2 += __shfl_xor(b2, o, 16); }
     if (l == 0) {
+      float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
       if (f < q) {
         const double mu = a / B, var = fmax(b2 / B - mu * mu, 0.0);   // biased variance, as Keras
-        bn[f] = (float)mu;
-        bn[KQ + f] = (float)(1.0 / sqrt(var + 1e-3));
-        bn[2 * KQ + f] = theta[f];
-        bn[3 * KQ + f] = theta[q + f];
-        if (update_moving) {   // moving = moving * 0.99 + batch * 0.01
+        v0 = (float)mu;
+        v1 = (float)(1.0 / sqrt(var + 1e-3));
+        v2 = theta[f];
+        v3 = theta[q + f];
+        if (update_moving && moving) {   // moving = moving * 0.99 + batch * 0.01
           moving[f] = moving[f] * 0.99f + (float)mu * 0.01f;
           moving[q + f] = moving[q + f] * 0.99f + (float)var * 0.01f;
         }
-      } else {
-        bn[f] = 0.0f; bn[KQ + f] = 0.0f; bn[2 * KQ + f] = 0.0f; bn[3 * KQ + f] = 0.0f;
       }
+      out[f] = v0; out[KQ + f] = v1; out[2 * KQ + f] = v2; out[3 * KQ + f] = v3;
+      if (pub) { pub[f] = v0; pub[KQ + f] = v1; pub[2 * KQ + f] = v2; pub[3 * KQ + f] = v3; }
     }
   }
+}
+static __global__ __launch_bounds__(256) void bgm_bn_stats_kernel(const float *data_z, const int *idx, int B, int q, int KQ,
+                                                          const float *theta /* gamma|beta|mmean|mvar */, float *bn,
+                                                          float *moving /* mmean|mvar in theta, updated */,
+                                                          int update_moving) {
+  bgm_bn_stats_body(data_z, idx, B, q, KQ, theta, bn, nullptr, moving, update_moving);
 }
 
 template <int NT>
@@ -142,6 +151,11 @@ __global__ __launch_bounds__(64 * WAVES) void bgm_fit_fwd_kernel(BgmFitKArgs a) 
       hr.src = a.blob + m.whd; hr.buf = lds + m.stage; hr.tid = threadIdx.x; hr.ntx = m.ntx;
       hr.fetch((int)blockIdx.x * BGM_FIT_S);
     }
+    __shared__ float bnl[4 * KQ];
+    if (threadIdx.x < 256)
+      bgm_bn_stats_body(a.data_z, a.idx, a.B, m.q, KQ, a.bn_theta, bnl, blockIdx.x == 0 ? a.bn_w : nullptr,
+                        blockIdx.x == 0 ? a.bn_moving : nullptr, a.bn_update);
+    __syncthreads();
     f32x4 zn[KTQ];
 #pragma unroll
     for (int t = 0; t < KTQ; ++t)
@@ -150,8 +164,8 @@ __global__ __launch_bounds__(64 * WAVES) void bgm_fit_fwd_kernel(BgmFitKArgs a) 
         const int f = 16 * t + 4 * r + g;
         float zh = 0.0f, v = 0.0f;
         if (f < m.q) {
-          zh = (a.data_z[row * (long long)m.q + f] - a.bn[f]) * a.bn[KQ + f];
-          v = fmaf(zh, a.bn[2 * KQ + f], a.bn[3 * KQ + f]);
+          zh = (a.data_z[row * (long long)m.q + f] - bnl[f]) * bnl[KQ + f];
+          v = fmaf(zh, bnl[2 * KQ + f], bnl[3 * KQ + f]);
         }
         zn[t][r] = v;
         if (lead) { ws[a.ws.zn + b * KQ + f] = v; ws[a.ws.zhat + b * KQ + f] = zh; }
@@ -504,7 +518,8 @@ __global__ __launch_bounds__(64 * WAVES) void bgm_fit_bwd_kernel(BgmFitKArgs a) 
 static __global__ __launch_bounds__(256) void bgm_bn_bwd_kernel(const float *wsp, BgmFitWs w, const float *bn, int B, int q,
                                                         int KQ, float inv_B, const float *data_z, const int *idx,
                                                         float *grad_gamma_beta /* [2q] or NULL */, float *dz_out,
-                                                        int add_prior) {
+                                                        int add_prior, float *z_rw = nullptr, float lr_t = 0.0f, float b1 = 0.0f,
+                                                        float b2 = 0.0f, float eps = 0.0f) {
   // 16 features at a time, 16 lanes per feature, double sums through shuffles (no block barrier)
   const int fl = threadIdx.x >> 4, l = threadIdx.x & 15;
   for (int f = fl; f < q; f += 16) {
@@ -526,6 +541,10 @@ static __global__ __launch_bounds__(256) void bgm_bn_bwd_kernel(const float *wsp
         float v = inv * dzh_centered;
         if (add_prior) v += data_z[(long long)idx[b] * q + f] * inv_B;   // d/dz of mean(|z|^2/2)
         dz_out[(long long)b * q + f] = v;
+        if (z_rw) {      // update_latent_variable_sgd's optimizer step on a FRESH variable (see the note below the kernel)
+          const float m = (1.0f - b1) * v, vv = (1.0f - b2) * v * v;
+          z_rw[(long long)idx[b] * q + f] -= lr_t * m / (sqrtf(vv) + eps);
+        }
       }
     }
   }
@@ -534,13 +553,4 @@ static __global__ __launch_bounds__(256) void bgm_bn_bwd_kernel(const float *wsp
 // update_latent_variable_sgd's optimizer step: `batch_z` is a FRESH tf.Variable every minibatch
 // (bgm/base.py:402), so the Adam slots start at zero while `iterations` keeps counting:
 //   m = (1-b1) g, v = (1-b2) g^2, z -= lr_t * m / (sqrt(v) + eps)
-static __global__ void bgm_fit_z_update_kernel(float *data_z, const float *dz, const int *idx, int B, int q, float lr_t,
-                                        float b1, float b2, float eps) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)B * q) return;
-  const long long b = i / q;
-  const int f = (int)(i - b * q);
-  const float g = dz[i];
-  const float m = (1.0f - b1) * g, v = (1.0f - b2) * g * g;
-  data_z[(long long)idx[b] * q + f] -= lr_t * m / (sqrtf(v) + eps);
-}
+// (applied in bgm_bn_bwd_kernel, on the gradient it has just formed)

@@ -543,7 +543,7 @@ extern "C" int bgm_causal_fit_theta_grad(bgm_handle *h, const float *x, const fl
   DwArgs dw = h->dw;
   dw.ws = h->ws_dev; dw.partial = h->partial_dev; dw.B = batch; dw.rows_per_slice = h->rows_per_slice;
   const int n_slices = (batch + h->rows_per_slice - 1) / h->rows_per_slice;
-  hipLaunchKernelGGL(fit_dw_kernel, dim3(n_slices, dw.n_layers), dim3(256), 0, stream, dw);
+  hipLaunchKernelGGL(fit_dw_kernel, dim3(n_slices, dw.n_layers, fit_dw_chunks(dw)), dim3(256), 0, stream, dw);
   BGM_HIP_CHECK(hipGetLastError());
   const int np = h->n_params;
   hipLaunchKernelGGL(fit_grad_reduce_kernel, dim3((np + 255) / 256), dim3(256), 0, stream, h->partial_dev,
@@ -1101,23 +1101,28 @@ extern "C" int bgm_bgm_fit_begin(bgm_handle *h, int64_t n_rows, int32_t max_batc
 static int bgm_fit_fwd_bwd(bgm_handle *h, BgmState *s, const float *x, const float *data_z, const int32_t *idx, int batch,
                            double *loss, int update_moving, hipStream_t stream) {
   const int q = s->cfg.z_dim, KQ = 16 * s->KTQ;
-  hipLaunchKernelGGL(bgm_bn_stats_kernel, dim3(1), dim3(256), 0, stream, data_z, idx, batch, q, KQ, s->theta_dev, s->bn_dev,
-                     s->theta_dev + 2 * q, update_moving);
-  BGM_HIP_CHECK(hipGetLastError());
+  const int tiles = (batch + 15) / 16;
+  // <= 32 rows (the reference's batch_size): head tiles dealt over the waves of a few workgroups instead of one wave per row tile,
+  // the batch statistics formed at the head of the forward kernel
+  static const bool no_split = std::getenv("BGM_BGM_FIT_NO_SPLIT") != nullptr;       // dev A/B
+  const bool split = tiles <= 2 && !no_split && !s->gx_fit;
+  if (!split) {
+    hipLaunchKernelGGL(bgm_bn_stats_kernel, dim3(1), dim3(256), 0, stream, data_z, idx, batch, q, KQ, s->theta_dev, s->bn_dev,
+                       s->theta_dev + 2 * q, update_moving);
+    BGM_HIP_CHECK(hipGetLastError());
+  }
   if (s->gx_fit) return gxb_fit_fwd_bwd(h, s, x, data_z, idx, batch, loss, stream);
   BgmFitKArgs ka{};
   ka.blob = s->tblob_dev; ka.m = s->tmeta; ka.ws = s->fit_ws; ka.wsp = s->ws_dev; ka.x = x; ka.data_z = data_z;
   ka.idx = idx; ka.B = batch; ka.inv_B = 1.0f / (float)(s->batch_global > 0 ? s->batch_global : batch); ka.bn = s->bn_dev; ka.loss = loss;
-  const int tiles = (batch + 15) / 16;
   int grid = std::max(1, std::min((tiles + BGM_FIT_WAVES - 1) / BGM_FIT_WAVES, h->n_cus));
   int lds = s->fit_lds_bytes;
-  // <= 32 rows (the reference's batch_size): head tiles dealt over the waves of a few workgroups instead of one wave per row tile
-  static const bool no_split = std::getenv("BGM_BGM_FIT_NO_SPLIT") != nullptr;       // dev A/B
-  if (tiles <= 2 && !no_split) {
+  if (split) {
     const int ntx = s->tmeta.ntx, rounds = (ntx + BGM_FIT_S - 1) / BGM_FIT_S;
     ka.split = 1;
     ka.part = s->split_part_dev;
     ka.part_ctr = reinterpret_cast<unsigned *>(s->split_part_dev + (size_t)BGM_SPLIT_MAX_WG * BGM_FIT_S * 32 * 64);
+    ka.bn_w = s->bn_dev; ka.bn_theta = s->theta_dev; ka.bn_moving = s->theta_dev + 2 * q; ka.bn_update = update_moving;
     grid = std::max(1, std::min(BGM_SPLIT_MAX_WG, s->NTX == 0 ? rounds : (rounds + 1) / 2));
     if (s->NTX == 0) lds += (BGM_FIT_S - 2) * BGM_PAIR * (int)sizeof(float);      // the stage holds BGM_FIT_S tile pairs
   }
@@ -1166,7 +1171,7 @@ extern "C" int bgm_bgm_fit_theta_grad(bgm_handle *h, const float *x, const float
   DwArgs dw = s->dw;
   dw.ws = s->ws_dev; dw.partial = s->partial_dev; dw.B = batch; dw.rows_per_slice = s->rows_per_slice;
   const int n_slices = (batch + s->rows_per_slice - 1) / s->rows_per_slice;
-  hipLaunchKernelGGL(fit_dw_kernel, dim3(n_slices, dw.n_layers), dim3(256), 0, stream, dw);
+  hipLaunchKernelGGL(fit_dw_kernel, dim3(n_slices, dw.n_layers, fit_dw_chunks(dw)), dim3(256), 0, stream, dw);
   BGM_HIP_CHECK(hipGetLastError());
   const int np = s->n_params, q = s->cfg.z_dim;
   hipLaunchKernelGGL(fit_grad_reduce_kernel, dim3((np + 255) / 256), dim3(256), 0, stream, s->partial_dev, dw.partial_stride,
@@ -1209,15 +1214,13 @@ extern "C" int bgm_bgm_fit_z_step(bgm_handle *h, const float *x, float *data_z, 
   if (rc) return rc;
   const int q = s->cfg.z_dim;
   float *dz = s->ws_dev + s->fit_ws.dz;
-  hipLaunchKernelGGL(bgm_bn_bwd_kernel, dim3(1), dim3(256), 0, stream, s->ws_dev, s->fit_ws, s->bn_dev, batch, q, 16 * s->KTQ,
-                     1.0f / (float)(s->batch_global > 0 ? s->batch_global : batch), data_z, idx, (float *)nullptr, dz, 1);
-  BGM_HIP_CHECK(hipGetLastError());
   s->t_z += 1;
   const double t = (double)s->t_z;
   const float lr_t = (float)((double)lr_z * std::sqrt(1.0 - std::pow((double)ADAM_B2, t)) / (1.0 - std::pow((double)ADAM_B1, t)));
-  const long long n = (long long)batch * q;
-  hipLaunchKernelGGL(bgm_fit_z_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, data_z, dz, idx, batch, q,
-                     lr_t, ADAM_B1, ADAM_B2, ADAM_EPS);
+  // batch-norm backward -> d loss / d z (+ the prior term), and the fresh-slot Adam step on the batch rows in the same launch
+  hipLaunchKernelGGL(bgm_bn_bwd_kernel, dim3(1), dim3(256), 0, stream, s->ws_dev, s->fit_ws, s->bn_dev, batch, q, 16 * s->KTQ,
+                     1.0f / (float)(s->batch_global > 0 ? s->batch_global : batch), data_z, idx, (float *)nullptr, dz, 1, data_z, lr_t,
+                     ADAM_B1, ADAM_B2, ADAM_EPS);
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
 }

@@ -356,7 +356,8 @@ __global__ __launch_bounds__(256) void fit_dw_kernel(DwArgs a) {
   float *out = a.partial + (long long)blockIdx.x * a.partial_stride + L.out_off;
   const float *A = a.ws + L.a_off, *D = a.ws + L.d_off;
   constexpr int NT_MAX = 13;
-  for (int to0 = 0; to0 < NT; to0 += NT_MAX)   // output tiles in register-sized chunks (one chunk up to N = 208)
+  // output tiles in register-sized chunks (one chunk up to N = 208), the chunks of a wide layer on gridDim.z workgroups
+  for (int to0 = (int)blockIdx.z * NT_MAX; to0 < NT; to0 += (int)gridDim.z * NT_MAX)
   for (int ti = wave; ti < KT; ti += 4) {
     f32x4 acc[NT_MAX];
 #pragma unroll
@@ -400,6 +401,14 @@ __global__ __launch_bounds__(256) void fit_dw_kernel(DwArgs a) {
       }
     }
   }
+}
+
+// gridDim.z of a fit_dw_kernel launch: one workgroup per 13-tile chunk of the widest layer (at most 8)
+static inline int fit_dw_chunks(const DwArgs &a) {
+  int nt = 1;
+  for (int l = 0; l < a.n_layers; ++l) nt = nt > a.layer[l].N / 16 ? nt : a.layer[l].N / 16;
+  const int z = (nt + 12) / 13;
+  return z < 8 ? z : 8;
 }
 
 // grad[c] = sum over slices of partial[slice][src[c]]   (fixed order -> deterministic)

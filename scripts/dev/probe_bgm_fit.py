@@ -12,7 +12,7 @@ params = dict(dataset="t", output_dir="/tmp/bgmfit", save_res=False, save_model=
 rs = np.random.RandomState(0)
 x = rs.randn(N, p).astype(np.float32)
 m = BGM(params, random_seed=1)
-for ep in (0, 2):
+for ep in (0, 0, 4):      # the first call warms up (allocations, module load)
     torch.cuda.synchronize(); t0 = time.time()
     with contextlib.redirect_stdout(io.StringIO()):
         m.fit(x, batch_size=32, epochs=ep, epochs_per_eval=1000, use_egm_init=False, verbose=0)
