@@ -21,7 +21,7 @@ FLAGS = os.environ.get("BGM_EXTRA_FLAGS", "").split() + ["--offload-arch=gfx950"
 
 # per-source flags.  bnf_api.hip: hipcc's SLP vectoriser packs the epilogues' scalar fma / mul pairs into v_pk_fma_f32 / v_pk_mul_f32, which
 # cannot carry the |x| modifier of the one-instruction LeakyReLU (an extra v_and per element) and issue no faster next to MFMAs.
-SOURCE_FLAGS = {"bnf_api.hip": ["-fno-slp-vectorize"], "bnf_det_api.hip": ["-fno-slp-vectorize"]}
+SOURCE_FLAGS = {"bnf_api.hip": ["-fno-slp-vectorize"], "bnf_det_api.hip": ["-fno-slp-vectorize"], "causal_bx3_api.hip": ["-fno-slp-vectorize"]}
 
 
 def _newer(src, dst):

@@ -55,23 +55,51 @@ struct CausalBxKArgs {
   BxMeta bx;
 };
 
+// ---- fragment reads.  The blob is larger than the 16-bit offset field of ds_read, and hipcc folds a layer's constant blob offset into
+// every read's own address (one v_add_u32 per ds_read_b128 in the ISA).  The per-lane base of a layer is therefore made opaque once
+// (LDS byte offset in a VGPR) and every fragment of the layer is read at base + immediate.
+typedef const __attribute__((address_space(3))) unsigned char *bx_lds_ptr;
+__device__ __forceinline__ bx_lds_ptr bx_frag_base(const unsigned char *w, int lane_bytes) {
+  unsigned off = (unsigned)(unsigned long long)(bx_lds_ptr)w + (unsigned)lane_bytes;
+  asm volatile("" : "+v"(off));
+  return (bx_lds_ptr)(unsigned long long)off;
+}
+__device__ __forceinline__ bx_bf16x8 bx_ld8(bx_lds_ptr b, int off) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) bx_bf16x8 *>(b + off);
+}
+__device__ __forceinline__ bx_bf16x4 bx_ld4(bx_lds_ptr b, int off) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) bx_bf16x4 *>(b + off);
+}
+
 // ---- activation split: 8 (or 4) fp32 values -> bf16 hi / lo -------------------------------------------------
+// One pair per step: v_cvt_pk_bf16_f32 (hi pair, RNE), the two hi values back in fp32 as shift / mask of the packed word, two exact
+// subtractions, v_cvt_pk_bf16_f32 (lo pair): 3 VALU instructions per element.
+typedef float bx_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bx_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned bx_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned bx_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void bx_split_pair(float a, float b, unsigned &hi, unsigned &lo) {
+  const bx_bf16x2 h = __builtin_convertvector(bx_f32x2{a, b}, bx_bf16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  const float ha = __builtin_bit_cast(float, hi << 16), hb = __builtin_bit_cast(float, hi & 0xffff0000u);
+  const bx_bf16x2 l = __builtin_convertvector(bx_f32x2{a - ha, b - hb}, bx_bf16x2);
+  lo = __builtin_bit_cast(unsigned, l);
+}
 __device__ __forceinline__ void bx_split8(const f32x4 &a, const f32x4 &b, bx_bf16x8 &hi, bx_bf16x8 &lo) {
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const float v = (u < 4) ? a[u] : b[u - 4];
-    const __bf16 h = (__bf16)v;
-    hi[u] = h;
-    lo[u] = (__bf16)(v - (float)h);
-  }
+  unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+  bx_split_pair(a[0], a[1], h0, l0);
+  bx_split_pair(a[2], a[3], h1, l1);
+  bx_split_pair(b[0], b[1], h2, l2);
+  bx_split_pair(b[2], b[3], h3, l3);
+  hi = __builtin_bit_cast(bx_bf16x8, bx_u32x4{h0, h1, h2, h3});
+  lo = __builtin_bit_cast(bx_bf16x8, bx_u32x4{l0, l1, l2, l3});
 }
 __device__ __forceinline__ void bx_split4(const f32x4 &a, bx_bf16x4 &hi, bx_bf16x4 &lo) {
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const __bf16 h = (__bf16)a[u];
-    hi[u] = h;
-    lo[u] = (__bf16)(a[u] - (float)h);
-  }
+  unsigned h0, h1, l0, l1;
+  bx_split_pair(a[0], a[1], h0, l0);
+  bx_split_pair(a[2], a[3], h1, l1);
+  hi = __builtin_bit_cast(bx_bf16x4, bx_u32x2{h0, h1});
+  lo = __builtin_bit_cast(bx_bf16x4, bx_u32x2{l0, l1});
 }
 
 // acc[NT] += W^T in   for one layer; `w` = LDS byte address of the layer's fragments, `in` = KT activated input tiles.
@@ -95,6 +123,8 @@ template <int KT, int NT>
 __device__ __forceinline__ void bx_dense_mm(const unsigned char *w, int lane, const BxIn<KT> &b, f32x4 (&acc)[NT]) {
   constexpr int NK32 = KT / 2, K16 = KT & 1;
   constexpr int TILE_BYTES = NK32 * 2048 + K16 * 1024;
+  const bx_lds_ptr w16 = bx_frag_base(w, lane * 16);
+  const bx_lds_ptr w8 = K16 ? bx_frag_base(w + NK32 * 2048, lane * 8) : w16;
 #pragma unroll
   for (int m0 = 0; m0 < NT; m0 += 4) {
     constexpr int GSMAX = 4;
@@ -105,9 +135,8 @@ __device__ __forceinline__ void bx_dense_mm(const unsigned char *w, int lane, co
 #pragma unroll
       for (int u = 0; u < GSMAX; ++u)
         if (u < gs) {
-          const unsigned char *f = w + (m0 + u) * TILE_BYTES + T * 2048 + lane * 16;
-          ah[u] = *reinterpret_cast<const bx_bf16x8 *>(f);
-          al[u] = *reinterpret_cast<const bx_bf16x8 *>(f + 1024);
+          ah[u] = bx_ld8(w16, (m0 + u) * TILE_BYTES + T * 2048);
+          al[u] = bx_ld8(w16, (m0 + u) * TILE_BYTES + T * 2048 + 1024);
         }
 #pragma unroll
       for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[u], b.bh[T], acc[m0 + u], 0, 0, 0);
@@ -121,9 +150,8 @@ __device__ __forceinline__ void bx_dense_mm(const unsigned char *w, int lane, co
 #pragma unroll
       for (int u = 0; u < GSMAX; ++u)
         if (u < gs) {
-          const unsigned char *f = w + (m0 + u) * TILE_BYTES + NK32 * 2048 + lane * 8;
-          ah[u] = *reinterpret_cast<const bx_bf16x4 *>(f);
-          al[u] = *reinterpret_cast<const bx_bf16x4 *>(f + 512);
+          ah[u] = bx_ld4(w8, (m0 + u) * TILE_BYTES);
+          al[u] = bx_ld4(w8, (m0 + u) * TILE_BYTES + 512);
         }
 #pragma unroll
       for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al[u], b.ch, acc[m0 + u], 0, 0, 0);
@@ -163,14 +191,15 @@ __device__ __forceinline__ void bx_dense_mm2(const unsigned char *wa, const unsi
   static_assert(NT <= 4, "bx_dense_mm2: one tile group");
   constexpr int NK32 = KT / 2, K16 = KT & 1;
   constexpr int TILE_BYTES = NK32 * 2048 + K16 * 1024;
+  const bx_lds_ptr wa16 = bx_frag_base(wa, lane * 16), wb16 = bx_frag_base(wb, lane * 16);
+  const bx_lds_ptr wa8 = K16 ? bx_frag_base(wa + NK32 * 2048, lane * 8) : wa16, wb8 = K16 ? bx_frag_base(wb + NK32 * 2048, lane * 8) : wb16;
 #pragma unroll
   for (int T = 0; T < NK32; ++T) {
     bx_bf16x8 ah[NT], al[NT], bh[NT], bl[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
-      const unsigned char *fa = wa + u * TILE_BYTES + T * 2048 + lane * 16, *fb = wb + u * TILE_BYTES + T * 2048 + lane * 16;
-      ah[u] = *reinterpret_cast<const bx_bf16x8 *>(fa); al[u] = *reinterpret_cast<const bx_bf16x8 *>(fa + 1024);
-      bh[u] = *reinterpret_cast<const bx_bf16x8 *>(fb); bl[u] = *reinterpret_cast<const bx_bf16x8 *>(fb + 1024);
+      ah[u] = bx_ld8(wa16, u * TILE_BYTES + T * 2048); al[u] = bx_ld8(wa16, u * TILE_BYTES + T * 2048 + 1024);
+      bh[u] = bx_ld8(wb16, u * TILE_BYTES + T * 2048); bl[u] = bx_ld8(wb16, u * TILE_BYTES + T * 2048 + 1024);
     }
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
@@ -192,9 +221,8 @@ __device__ __forceinline__ void bx_dense_mm2(const unsigned char *wa, const unsi
     bx_bf16x4 ah[NT], al[NT], bh[NT], bl[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
-      const unsigned char *fa = wa + u * TILE_BYTES + NK32 * 2048 + lane * 8, *fb = wb + u * TILE_BYTES + NK32 * 2048 + lane * 8;
-      ah[u] = *reinterpret_cast<const bx_bf16x4 *>(fa); al[u] = *reinterpret_cast<const bx_bf16x4 *>(fa + 512);
-      bh[u] = *reinterpret_cast<const bx_bf16x4 *>(fb); bl[u] = *reinterpret_cast<const bx_bf16x4 *>(fb + 512);
+      ah[u] = bx_ld4(wa8, u * TILE_BYTES); al[u] = bx_ld4(wa8, u * TILE_BYTES + 512);
+      bh[u] = bx_ld4(wb8, u * TILE_BYTES); bl[u] = bx_ld4(wb8, u * TILE_BYTES + 512);
     }
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
@@ -419,14 +447,14 @@ __device__ __forceinline__ void causal_effects_bx3(const unsigned char *lds, con
     f32x4 a2[DB][2];
 #pragma unroll
     for (int e = 0; e < DB; ++e) bx_bias<2>(ldsf, L::bf2, g, a2[e]);
+    const bx_lds_ptr wf2 = bx_frag_base(lds + L::wf2, lane * 16);
 #pragma unroll
     for (int T = 0; T < 2; ++T) {
       bx_bf16x8 ah[2], al[2];
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
-        const unsigned char *f = lds + L::wf2 + mt * 4096 + T * 2048 + lane * 16;
-        ah[mt] = *reinterpret_cast<const bx_bf16x8 *>(f);
-        al[mt] = *reinterpret_cast<const bx_bf16x8 *>(f + 1024);
+        ah[mt] = bx_ld8(wf2, mt * 4096 + T * 2048);
+        al[mt] = bx_ld8(wf2, mt * 4096 + T * 2048 + 1024);
       }
 #pragma unroll
       for (int e = 0; e < DB; ++e) {
