@@ -56,7 +56,7 @@ struct bgm_handle {
   float *sblob_dev = nullptr;
   size_t sblob_cap = 0;
   bool sblob_valid = false;
-  // split-precision (bf16 x 3) sampling blob (causal_bx3_api.hip); precision: 0 fp32 (default), 1 bf16x3 (bgm_causal_set_precision)
+  // split-precision (bf16 x 3) sampling blob (causal_bx3_api.hip); precision: 0 fp32 (default), 1 bf16x3, 2 f16x3 (bgm_causal_set_precision)
   int precision = 0;
   void *bx_blob_dev = nullptr;
   size_t bx_cap = 0;

@@ -335,21 +335,21 @@ extern "C" int bgm_causal_logpost(bgm_handle *h, const float *x, const float *y,
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
   if (gx_wanted(h)) {          // hidden widths / depths outside the compiled families: the general-width engine (gx_api.hip)
-    if (h->precision == 1) { bgm_set_error("bgm_causal_logpost: split precision exists for the default hidden widths only"); return BGM_E_UNSUPPORTED; }
+    if (h->precision != 0) { bgm_set_error("bgm_causal_logpost: split precision exists for the default hidden widths only"); return BGM_E_UNSUPPORTED; }
     return gx_logpost(h, x, y, v, z, n, out, stream);
   }
   if (bnf_det_wanted(h)) {     // no LDS-resident compiled shape holds the model: the streamed-fragment kernels (bnf_det_api.hip)
-    if (h->prior_seg || h->precision == 1) { bgm_set_error("bgm_causal_logpost: the conditional prior / split precision exist for the LDS-resident shapes only"); return BGM_E_UNSUPPORTED; }
+    if (h->prior_seg || h->precision != 0) { bgm_set_error("bgm_causal_logpost: the conditional prior / split precision exist for the LDS-resident shapes only"); return BGM_E_UNSUPPORTED; }
     return bnf_det_logpost(h, x, y, v, z, n, out, stream);
   }
   int rc = bgm_causal_sampling_blob(h, stream);
   if (rc) return rc;
   const int grid = mh_grid(h, n);
   if (h->prior_seg) {
-    if (h->precision == 1) { bgm_set_error("bgm_causal_logpost: the conditional prior is built for the fp32 kernels only"); return BGM_E_UNSUPPORTED; }
+    if (h->precision != 0) { bgm_set_error("bgm_causal_logpost: the conditional prior is built for the fp32 kernels only"); return BGM_E_UNSUPPORTED; }
     return bgm_causal_prior_logpost(h, x, y, v, z, n, out, grid, stream);
   }
-  if (h->precision == 1) return bgm_causal_bx3_logpost(h, x, y, v, z, n, out, grid, stream);
+  if (h->precision != 0) return bgm_causal_bx3_logpost(h, x, y, v, z, n, out, grid, stream);
   const int lds = h->meta.total * 4;
 #define X(KT1_, KSL1_, NTL_)                                                                   \
   if (h->KT1 == KT1_ && h->KSL1 == KSL1_ && h->NTL == NTL_) {                                  \
@@ -401,11 +401,11 @@ extern "C" int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *a, void *stre
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
   if (gx_wanted(h)) {
-    if (h->precision == 1) { bgm_set_error("bgm_causal_mh_run: split precision exists for the default hidden widths only"); return BGM_E_UNSUPPORTED; }
+    if (h->precision != 0) { bgm_set_error("bgm_causal_mh_run: split precision exists for the default hidden widths only"); return BGM_E_UNSUPPORTED; }
     return gx_mh_run(h, a, stream);
   }
   if (bnf_det_wanted(h)) {
-    if (h->prior_seg || h->precision == 1) { bgm_set_error("bgm_causal_mh_run: the conditional prior / split precision exist for the LDS-resident shapes only"); return BGM_E_UNSUPPORTED; }
+    if (h->prior_seg || h->precision != 0) { bgm_set_error("bgm_causal_mh_run: the conditional prior / split precision exist for the LDS-resident shapes only"); return BGM_E_UNSUPPORTED; }
     return bnf_det_mh_run(h, a, stream);
   }
   int rc = bgm_causal_sampling_blob(h, stream);
@@ -448,9 +448,9 @@ extern "C" int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *a, void *stre
       BGM_HIP_CHECK(hipEventRecord(e0, stream));
     }
     if (h->prior_seg) {
-      if (h->precision == 1) { bgm_set_error("bgm_causal_mh_run: the conditional prior is built for the fp32 kernels only"); return BGM_E_UNSUPPORTED; }
+      if (h->precision != 0) { bgm_set_error("bgm_causal_mh_run: the conditional prior is built for the fp32 kernels only"); return BGM_E_UNSUPPORTED; }
       rc = bgm_causal_prior_mh_launch(h, ka, segs[s].effect, grid, lds, stream);
-    } else if (h->precision == 1) rc = bgm_causal_bx3_mh_launch(h, ka, segs[s].effect, grid, stream);
+    } else if (h->precision != 0) rc = bgm_causal_bx3_mh_launch(h, ka, segs[s].effect, grid, stream);
     else if (segs[s].effect == BGM_EFFECT_ADRF) rc = launch_mh<1>(h, ka, grid, lds, stream);
     else if (segs[s].effect == BGM_EFFECT_ITE) rc = launch_mh<2>(h, ka, grid, lds, stream);
     else rc = launch_mh<0>(h, ka, grid, lds, stream);

@@ -1,5 +1,6 @@
-// causal_bx3_api.hip -- host side of the split-precision (bf16 x 3) CausalBGM sampling kernels (causal_bx3_kernels.h):
-// packing of the Keras-order weights into bf16 hi / lo MFMA fragments, launchers, and the precision switch
+// causal_bx3_api.hip -- host side of the split-precision (bf16 x 3 / f16 x 3) CausalBGM sampling kernels (causal_bx3_kernels.h,
+// compiled once per 16-bit operand format: namespaces bxb / bxh): packing of the Keras-order weights into hi / lo MFMA fragments,
+// launchers, and the precision switch
 // bgm_causal_set_precision (include/bgm_hip.h).  The fp32 path (causal_api.hip) is the default and is untouched.
 #include <algorithm>
 #include <cmath>
@@ -8,7 +9,16 @@
 #include <vector>
 
 #include "bgm_host.h"
+#define BX_NS bxb
+#define BX_F16 0
 #include "causal_bx3_kernels.h"
+#undef BX_NS
+#undef BX_F16
+#define BX_NS bxh
+#define BX_F16 1
+#include "causal_bx3_kernels.h"
+#undef BX_NS
+#undef BX_F16
 
 static constexpr int BX_WAVES = 8;
 #define BGM_BX3_VARIANTS(X) X(1, 13) X(1, 7) X(1, 2) X(2, 10) X(2, 7) X(2, 2)
@@ -26,16 +36,31 @@ static inline float bx_bf16_value(uint16_t b) {
   std::memcpy(&f, &u, 4);
   return f;
 }
+// the same pair for fp16 (round to nearest even; |w| beyond 65504 saturates instead of overflowing to infinity)
+static inline uint16_t bx_f16_bits(float f) {
+  f = f > 65504.0f ? 65504.0f : (f < -65504.0f ? -65504.0f : f);
+  const _Float16 h = (_Float16)f;
+  uint16_t b;
+  std::memcpy(&b, &h, 2);
+  return b;
+}
+static inline float bx_f16_value(uint16_t b) {
+  _Float16 h;
+  std::memcpy(&h, &b, 2);
+  return (float)h;
+}
+static inline uint16_t bx_bits(float f, bool f16) { return f16 ? bx_f16_bits(f) : bx_bf16_bits(f); }
+static inline float bx_value(uint16_t b, bool f16) { return f16 ? bx_f16_value(b) : bx_bf16_value(b); }
 
 // One layer's A fragments.  W: [n_in x n_out] row-major (Keras); feat(KT tile, lane group g, r) -> source input row of W
 // (or -1 for a zero row); `col(o)` -> source output column of padded position o (or -1); `scale` multiplies every weight.
 template <class Feat, class Col>
-static void bx_pack_layer(std::vector<unsigned char> &blob, int off, const float *W, int n_out_src, int KT, int NT, float scale,
+static void bx_pack_layer(std::vector<unsigned char> &blob, bool f16, int off, const float *W, int n_out_src, int KT, int NT, float scale,
                           Feat feat, Col col) {
   const int NK32 = KT / 2, K16 = KT & 1;
   const int tile_bytes = NK32 * 2048 + K16 * 1024;
   auto put = [&](size_t byte_off, float w) {   // hi at byte_off, lo at the caller-supplied distance
-    const uint16_t hi = bx_bf16_bits(w);
+    const uint16_t hi = bx_bits(w, f16);
     std::memcpy(blob.data() + byte_off, &hi, 2);
     return hi;
   };
@@ -49,7 +74,7 @@ static void bx_pack_layer(std::vector<unsigned char> &blob, int off, const float
           const float w = (src >= 0 && o >= 0) ? W[(size_t)src * n_out_src + o] * scale : 0.0f;
           const size_t at = (size_t)off + (size_t)mt * tile_bytes + (size_t)T * 2048 + (size_t)lane * 16 + (size_t)u * 2;
           const uint16_t hi = put(at, w);
-          const uint16_t lo = bx_bf16_bits(w - bx_bf16_value(hi));
+          const uint16_t lo = bx_bits(w - bx_value(hi, f16), f16);
           std::memcpy(blob.data() + at + 1024, &lo, 2);
         }
       if (K16)
@@ -58,7 +83,7 @@ static void bx_pack_layer(std::vector<unsigned char> &blob, int off, const float
           const float w = (src >= 0 && o >= 0) ? W[(size_t)src * n_out_src + o] * scale : 0.0f;
           const size_t at = (size_t)off + (size_t)mt * tile_bytes + (size_t)NK32 * 2048 + (size_t)lane * 8 + (size_t)u * 2;
           const uint16_t hi = put(at, w);
-          const uint16_t lo = bx_bf16_bits(w - bx_bf16_value(hi));
+          const uint16_t lo = bx_bits(w - bx_value(hi, f16), f16);
           std::memcpy(blob.data() + at + 512, &lo, 2);
         }
     }
@@ -66,6 +91,7 @@ static void bx_pack_layer(std::vector<unsigned char> &blob, int off, const float
 
 template <int KT1, int NTL>
 static void bx_fill(bgm_handle *h, std::vector<unsigned char> &blob, BxMeta &m) {
+  const bool f16 = h->precision == 2;
   using L = BxLayout<KT1, NTL>;
   const HostNet &G = h->nets[BGM_NET_G], &F = h->nets[BGM_NET_F], &H = h->nets[BGM_NET_H];
   const int q = h->q, p = h->p;
@@ -78,14 +104,14 @@ static void bx_fill(bgm_handle *h, std::vector<unsigned char> &blob, BxMeta &m) 
   auto l1 = [](int t, int g, int r) { return 16 * t + 4 * r + g; };
   // hidden layers: accumulator order, feature 16 t + 4 g + r
   auto acc_feat = [](int t, int g, int r) { return 16 * t + 4 * g + r; };
-  bx_pack_layer(blob, L::w1g, G.W(0), 64, KT1, 4, 1.0f, [&](int t, int g, int r) { const int f = l1(t, g, r); return f < q ? f : -1; }, ident_col);
-  bx_pack_layer(blob, L::w1f, F.W(0), 64, KT1, 4, 1.0f, [&](int t, int g, int r) {
+  bx_pack_layer(blob, f16, L::w1g, G.W(0), 64, KT1, 4, 1.0f, [&](int t, int g, int r) { const int f = l1(t, g, r); return f < q ? f : -1; }, ident_col);
+  bx_pack_layer(blob, f16, L::w1f, F.W(0), 64, KT1, 4, 1.0f, [&](int t, int g, int r) {
     const int f = l1(t, g, r);
     if (f < z0 + z1) return f;
     if (f == q) return z0 + z1;          // treatment column
     return -1;
   }, ident_col);
-  bx_pack_layer(blob, L::w1h, H.W(0), 64, KT1, 4, 1.0f, [&](int t, int g, int r) {
+  bx_pack_layer(blob, f16, L::w1h, H.W(0), 64, KT1, 4, 1.0f, [&](int t, int g, int r) {
     const int f = l1(t, g, r);
     if (f < z0) return f;
     if (f >= z0 + z1 && f < z0 + z1 + z2) return z0 + (f - z0 - z1);
@@ -94,14 +120,14 @@ static void bx_fill(bgm_handle *h, std::vector<unsigned char> &blob, BxMeta &m) 
   for (int i = 0; i < 64; ++i) { bf[L::b1g + i] = G.b(0)[i]; bf[L::b1f + i] = F.b(0)[i]; bf[L::b1h + i] = H.b(0)[i]; }
   const float S = BGM_LRS_W;      // weights behind a one-instruction LeakyReLU (lrelu_s) carry the factor 0.6
   for (int l = 0; l < m.n_gh; ++l) {
-    bx_pack_layer(blob, L::wg(m.n_gh) + l * bx_layer_bytes(4, 4), G.W(1 + l), 64, 4, 4, S, acc_feat, ident_col);
+    bx_pack_layer(blob, f16, L::wg(m.n_gh) + l * bx_layer_bytes(4, 4), G.W(1 + l), 64, 4, 4, S, acc_feat, ident_col);
     for (int i = 0; i < 64; ++i) bf[L::bg + 64 * l + i] = G.b(1 + l)[i];
   }
   {
     const int LG = (int)G.dims.size() - 2;
     std::vector<float> Wp, bp;
     bgm_g_last_padded(G.W(LG), G.b(LG), p, NTL, Wp, bp);
-    bx_pack_layer(blob, L::wgl, Wp.data(), 16 * NTL, 4, NTL, S, acc_feat, ident_col);
+    bx_pack_layer(blob, f16, L::wgl, Wp.data(), 16 * NTL, 4, NTL, S, acc_feat, ident_col);
     for (int i = 0; i < 16 * NTL; ++i) bf[L::bgl + i] = bp[i];
   }
   auto rows_lt = [&](int n_in) { return [=](int t, int g, int r) { const int f = 16 * t + 4 * g + r; return f < n_in ? f : -1; }; };
@@ -112,9 +138,9 @@ static void bx_fill(bgm_handle *h, std::vector<unsigned char> &blob, BxMeta &m) 
   const int b2[2] = {L::bf2, L::bh2}, b3[2] = {L::bf3, L::bh3}, b4[2] = {L::bf4, L::bh4};
   for (int k = 0; k < 2; ++k) {
     const HostNet &N = *nets[k];
-    bx_pack_layer(blob, w2[k], N.W(1), 32, 4, 2, S, rows_lt(64), cols_lt(32));
-    bx_pack_layer(blob, w3[k], N.W(2), 8, 2, 1, S, rows_lt(32), cols_lt(8));
-    bx_pack_layer(blob, w4[k], N.W(3), 2, 1, 1, S, rows_lt(8), rep2);
+    bx_pack_layer(blob, f16, w2[k], N.W(1), 32, 4, 2, S, rows_lt(64), cols_lt(32));
+    bx_pack_layer(blob, f16, w3[k], N.W(2), 8, 2, 1, S, rows_lt(32), cols_lt(8));
+    bx_pack_layer(blob, f16, w4[k], N.W(3), 2, 1, 1, S, rows_lt(8), rep2);
     for (int i = 0; i < 32; ++i) bf[b2[k] + i] = N.b(1)[i];
     for (int i = 0; i < 8; ++i) bf[b3[k] + i] = N.b(2)[i];
     for (int i = 0; i < 16; ++i) bf[b4[k] + i] = (i & 3) < 2 ? N.b(3)[i & 3] : 0.0f;
@@ -173,7 +199,8 @@ int bgm_causal_bx3_blob(bgm_handle *h, hipStream_t stream) {
 }
 
 extern "C" int bgm_causal_set_precision(bgm_handle *h, int32_t mode) {
-  if (!h || (mode != 0 && mode != 1)) { bgm_set_error("bgm_causal_set_precision: mode must be 0 (fp32) or 1 (bf16x3)"); return BGM_E_INVALID; }
+  if (!h || mode < 0 || mode > 2) { bgm_set_error("bgm_causal_set_precision: mode must be 0 (fp32), 1 (bf16x3) or 2 (f16x3)"); return BGM_E_INVALID; }
+  if (mode != h->precision) h->bx_valid = false;      // the packed blob is per operand format
   h->precision = mode;
   return BGM_OK;
 }
@@ -193,7 +220,7 @@ int bgm_causal_bx3_logpost(bgm_handle *h, const float *x, const float *y, const 
   const int lds = m.total_bytes;
 #define X(KT1_, NTL_)                                                                                              \
   if (h->KT1 == KT1_ && h->NTL == NTL_) {                                                                          \
-    auto k = causal_logpost_bx3_kernel<KT1_, NTL_, BX_WAVES>;                                                      \
+    auto k = h->precision == 2 ? bxh::causal_logpost_bx3_kernel<KT1_, NTL_, BX_WAVES> : bxb::causal_logpost_bx3_kernel<KT1_, NTL_, BX_WAVES>; \
     rc = bx_set_lds(k, lds);                                                                                       \
     if (rc) return rc;                                                                                             \
     hipLaunchKernelGGL(k, dim3(grid), dim3(64 * BX_WAVES), lds, stream, (const unsigned char *)h->bx_blob_dev, m, x, y, v, z, \
@@ -212,7 +239,7 @@ static int bx_launch_mh(bgm_handle *h, const CausalBxKArgs &ka, int grid, int ld
   int rc;
 #define X(KT1_, NTL_)                                                                          \
   if (h->KT1 == KT1_ && h->NTL == NTL_) {                                                      \
-    auto k = causal_mh_bx3_kernel<KT1_, NTL_, BX_WAVES, EFFECT>;                               \
+    auto k = h->precision == 2 ? bxh::causal_mh_bx3_kernel<KT1_, NTL_, BX_WAVES, EFFECT> : bxb::causal_mh_bx3_kernel<KT1_, NTL_, BX_WAVES, EFFECT>; \
     rc = bx_set_lds(k, lds);                                                                   \
     if (rc) return rc;                                                                         \
     hipLaunchKernelGGL(k, dim3(grid), dim3(64 * BX_WAVES), lds, stream, ka);                   \

@@ -1,5 +1,7 @@
-// causal_bx3_kernels.h -- split-precision ("bf16 x 3") variant of the CausalBGM sampling kernels (gfx950), opt-in
-// (`bgm_causal_set_precision(h, 1)`, params['mh_precision'] = 'bf16x3'); fp32 (causal_kernels.h) stays the default.
+// causal_bx3_kernels.h -- split-precision ("bf16 x 3" / "f16 x 3") variant of the CausalBGM sampling kernels (gfx950), opt-in
+// (`bgm_causal_set_precision(h, 1 | 2)`, params['mh_precision'] = 'bf16x3' | 'f16x3'); fp32 (causal_kernels.h) stays the default.
+// Two 16-bit operand formats, one source: bf16 (hi + lo = 16 mantissa bits, fp32 range) and fp16 (22 bits -- the log posterior
+// is as close to float64 as the fp32 kernel's -- operands beyond 65504 saturate); same instruction count, same matrix rate.
 //
 // replaces (src/bayesgm/models/causalbgm/base.py): get_log_posterior :765-817, metropolis_hastings_sampler :820-904,
 // infer_from_latent_posterior :671-763 -- the same algorithm, RNG streams and data layout as causal_kernels.h; only the dense
@@ -16,12 +18,12 @@
 // Blob (LDS resident, bytes): per layer the A fragments [tile][K block][hi | lo][64 lanes] of 16 B (8 B for a K = 16 block),
 // then the fp32 biases / x-row of f in accumulator order (float offsets).  Weights behind a LeakyReLU carry the factor 0.6 of
 // the one-instruction activation lrelu_s, as in the fp32 sampling blob.
-#pragma once
+// The unit is written once for a 16-bit operand format and compiled per format: the including file defines BX_NS (namespace) and
+// BX_F16 (0: bf16, v_mfma_f32_16x16x32_bf16; 1: fp16, v_mfma_f32_16x16x32_f16) before each inclusion.
 #include "causal_kernels.h"
 
-typedef __bf16 bx_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bx_bf16x4 __attribute__((ext_vector_type(4)));
-
+#ifndef BX_COMMON_DEFINED
+#define BX_COMMON_DEFINED
 struct BxMeta {                 // run-time part of the model description
   int q, p, sig_pc, binary, n_gh;
   float sig2_v, sig2_x, sig2_y;
@@ -55,6 +57,22 @@ struct CausalBxKArgs {
   BxMeta bx;
 };
 
+#endif  // BX_COMMON_DEFINED
+
+namespace BX_NS {
+#if BX_F16
+typedef _Float16 bx_elem;
+#define BX_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define BX_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0)
+#else
+typedef __bf16 bx_elem;
+#define BX_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define BX_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0)
+#endif
+typedef bx_elem bx_x8 __attribute__((ext_vector_type(8)));
+typedef bx_elem bx_x4 __attribute__((ext_vector_type(4)));
+typedef bx_elem bx_x2 __attribute__((ext_vector_type(2)));
+
 // ---- fragment reads.  The blob is larger than the 16-bit offset field of ds_read, and hipcc folds a layer's constant blob offset into
 // every read's own address (one v_add_u32 per ds_read_b128 in the ISA).  The per-lane base of a layer is therefore made opaque once
 // (LDS byte offset in a VGPR) and every fragment of the layer is read at base + immediate.
@@ -64,42 +82,48 @@ __device__ __forceinline__ bx_lds_ptr bx_frag_base(const unsigned char *w, int l
   asm volatile("" : "+v"(off));
   return (bx_lds_ptr)(unsigned long long)off;
 }
-__device__ __forceinline__ bx_bf16x8 bx_ld8(bx_lds_ptr b, int off) {
-  return *reinterpret_cast<const __attribute__((address_space(3))) bx_bf16x8 *>(b + off);
+__device__ __forceinline__ bx_x8 bx_ld8(bx_lds_ptr b, int off) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) bx_x8 *>(b + off);
 }
-__device__ __forceinline__ bx_bf16x4 bx_ld4(bx_lds_ptr b, int off) {
-  return *reinterpret_cast<const __attribute__((address_space(3))) bx_bf16x4 *>(b + off);
+__device__ __forceinline__ bx_x4 bx_ld4(bx_lds_ptr b, int off) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) bx_x4 *>(b + off);
 }
 
 // ---- activation split: 8 (or 4) fp32 values -> bf16 hi / lo -------------------------------------------------
 // One pair per step: v_cvt_pk_bf16_f32 (hi pair, RNE), the two hi values back in fp32 as shift / mask of the packed word, two exact
 // subtractions, v_cvt_pk_bf16_f32 (lo pair): 3 VALU instructions per element.
 typedef float bx_f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bx_bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned bx_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned bx_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void bx_split_pair(float a, float b, unsigned &hi, unsigned &lo) {
-  const bx_bf16x2 h = __builtin_convertvector(bx_f32x2{a, b}, bx_bf16x2);
+  const bx_x2 h = __builtin_convertvector(bx_f32x2{a, b}, bx_x2);
   hi = __builtin_bit_cast(unsigned, h);
+#if BX_F16
+  // (v_fma_mix_f32 would form a - float(hi) in one instruction, but it reads a subnormal fp16 operand as zero whatever the mode
+  // register says: |a| < 2^-14 came out counted twice, 6e-3 on a sensitive row of the log-posterior test.  v_cvt_f32_f16 does not.)
+  const float la = a - (float)h[0], lb = b - (float)h[1];
+  const bx_x2 l = __builtin_convertvector(bx_f32x2{la, lb}, bx_x2);
+#else
   const float ha = __builtin_bit_cast(float, hi << 16), hb = __builtin_bit_cast(float, hi & 0xffff0000u);
-  const bx_bf16x2 l = __builtin_convertvector(bx_f32x2{a - ha, b - hb}, bx_bf16x2);
+  const bx_x2 l = __builtin_convertvector(bx_f32x2{a - ha, b - hb}, bx_x2);
+#endif
   lo = __builtin_bit_cast(unsigned, l);
 }
-__device__ __forceinline__ void bx_split8(const f32x4 &a, const f32x4 &b, bx_bf16x8 &hi, bx_bf16x8 &lo) {
+__device__ __forceinline__ void bx_split8(const f32x4 &a, const f32x4 &b, bx_x8 &hi, bx_x8 &lo) {
   unsigned h0, h1, h2, h3, l0, l1, l2, l3;
   bx_split_pair(a[0], a[1], h0, l0);
   bx_split_pair(a[2], a[3], h1, l1);
   bx_split_pair(b[0], b[1], h2, l2);
   bx_split_pair(b[2], b[3], h3, l3);
-  hi = __builtin_bit_cast(bx_bf16x8, bx_u32x4{h0, h1, h2, h3});
-  lo = __builtin_bit_cast(bx_bf16x8, bx_u32x4{l0, l1, l2, l3});
+  hi = __builtin_bit_cast(bx_x8, bx_u32x4{h0, h1, h2, h3});
+  lo = __builtin_bit_cast(bx_x8, bx_u32x4{l0, l1, l2, l3});
 }
-__device__ __forceinline__ void bx_split4(const f32x4 &a, bx_bf16x4 &hi, bx_bf16x4 &lo) {
+__device__ __forceinline__ void bx_split4(const f32x4 &a, bx_x4 &hi, bx_x4 &lo) {
   unsigned h0, h1, l0, l1;
   bx_split_pair(a[0], a[1], h0, l0);
   bx_split_pair(a[2], a[3], h1, l1);
-  hi = __builtin_bit_cast(bx_bf16x4, bx_u32x2{h0, h1});
-  lo = __builtin_bit_cast(bx_bf16x4, bx_u32x2{l0, l1});
+  hi = __builtin_bit_cast(bx_x4, bx_u32x2{h0, h1});
+  lo = __builtin_bit_cast(bx_x4, bx_u32x2{l0, l1});
 }
 
 // acc[NT] += W^T in   for one layer; `w` = LDS byte address of the layer's fragments, `in` = KT activated input tiles.
@@ -110,8 +134,8 @@ __device__ __forceinline__ void bx_split4(const f32x4 &a, bx_bf16x4 &hi, bx_bf16
 template <int KT>
 struct BxIn {
   static constexpr int NK32 = KT / 2, K16 = KT & 1;
-  bx_bf16x8 bh[NK32 > 0 ? NK32 : 1], bl[NK32 > 0 ? NK32 : 1];
-  bx_bf16x4 ch, cl;
+  bx_x8 bh[NK32 > 0 ? NK32 : 1], bl[NK32 > 0 ? NK32 : 1];
+  bx_x4 ch, cl;
   __device__ __forceinline__ void split(const f32x4 (&in)[KT]) {
 #pragma unroll
     for (int T = 0; T < NK32; ++T) bx_split8(in[2 * T], in[2 * T + 1], bh[T], bl[T]);
@@ -131,7 +155,7 @@ __device__ __forceinline__ void bx_dense_mm(const unsigned char *w, int lane, co
     const int gs = (NT - m0 < GSMAX) ? NT - m0 : GSMAX;      // compile-time after unrolling
 #pragma unroll
     for (int T = 0; T < NK32; ++T) {
-      bx_bf16x8 ah[GSMAX], al[GSMAX];
+      bx_x8 ah[GSMAX], al[GSMAX];
 #pragma unroll
       for (int u = 0; u < GSMAX; ++u)
         if (u < gs) {
@@ -139,14 +163,14 @@ __device__ __forceinline__ void bx_dense_mm(const unsigned char *w, int lane, co
           al[u] = bx_ld8(w16, (m0 + u) * TILE_BYTES + T * 2048 + 1024);
         }
 #pragma unroll
-      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[u], b.bh[T], acc[m0 + u], 0, 0, 0);
+      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = BX_MFMA32(al[u], b.bh[T], acc[m0 + u]);
 #pragma unroll
-      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[u], b.bl[T], acc[m0 + u], 0, 0, 0);
+      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = BX_MFMA32(ah[u], b.bl[T], acc[m0 + u]);
 #pragma unroll
-      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[u], b.bh[T], acc[m0 + u], 0, 0, 0);
+      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = BX_MFMA32(ah[u], b.bh[T], acc[m0 + u]);
     }
     if constexpr (K16) {
-      bx_bf16x4 ah[GSMAX], al[GSMAX];
+      bx_x4 ah[GSMAX], al[GSMAX];
 #pragma unroll
       for (int u = 0; u < GSMAX; ++u)
         if (u < gs) {
@@ -154,11 +178,11 @@ __device__ __forceinline__ void bx_dense_mm(const unsigned char *w, int lane, co
           al[u] = bx_ld4(w8, (m0 + u) * TILE_BYTES + 512);
         }
 #pragma unroll
-      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al[u], b.ch, acc[m0 + u], 0, 0, 0);
+      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = BX_MFMA16(al[u], b.ch, acc[m0 + u]);
 #pragma unroll
-      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[u], b.cl, acc[m0 + u], 0, 0, 0);
+      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = BX_MFMA16(ah[u], b.cl, acc[m0 + u]);
 #pragma unroll
-      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[u], b.ch, acc[m0 + u], 0, 0, 0);
+      for (int u = 0; u < GSMAX; ++u) if (u < gs) acc[m0 + u] = BX_MFMA16(ah[u], b.ch, acc[m0 + u]);
     }
   }
 }
@@ -195,7 +219,7 @@ __device__ __forceinline__ void bx_dense_mm2(const unsigned char *wa, const unsi
   const bx_lds_ptr wa8 = K16 ? bx_frag_base(wa + NK32 * 2048, lane * 8) : wa16, wb8 = K16 ? bx_frag_base(wb + NK32 * 2048, lane * 8) : wb16;
 #pragma unroll
   for (int T = 0; T < NK32; ++T) {
-    bx_bf16x8 ah[NT], al[NT], bh[NT], bl[NT];
+    bx_x8 ah[NT], al[NT], bh[NT], bl[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
       ah[u] = bx_ld8(wa16, u * TILE_BYTES + T * 2048); al[u] = bx_ld8(wa16, u * TILE_BYTES + T * 2048 + 1024);
@@ -203,22 +227,22 @@ __device__ __forceinline__ void bx_dense_mm2(const unsigned char *wa, const unsi
     }
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
-      acca[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[u], ba.bh[T], acca[u], 0, 0, 0);
-      accb[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[u], bb.bh[T], accb[u], 0, 0, 0);
+      acca[u] = BX_MFMA32(al[u], ba.bh[T], acca[u]);
+      accb[u] = BX_MFMA32(bl[u], bb.bh[T], accb[u]);
     }
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
-      acca[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[u], ba.bl[T], acca[u], 0, 0, 0);
-      accb[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[u], bb.bl[T], accb[u], 0, 0, 0);
+      acca[u] = BX_MFMA32(ah[u], ba.bl[T], acca[u]);
+      accb[u] = BX_MFMA32(bh[u], bb.bl[T], accb[u]);
     }
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
-      acca[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[u], ba.bh[T], acca[u], 0, 0, 0);
-      accb[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[u], bb.bh[T], accb[u], 0, 0, 0);
+      acca[u] = BX_MFMA32(ah[u], ba.bh[T], acca[u]);
+      accb[u] = BX_MFMA32(bh[u], bb.bh[T], accb[u]);
     }
   }
   if constexpr (K16) {
-    bx_bf16x4 ah[NT], al[NT], bh[NT], bl[NT];
+    bx_x4 ah[NT], al[NT], bh[NT], bl[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
       ah[u] = bx_ld4(wa8, u * TILE_BYTES); al[u] = bx_ld4(wa8, u * TILE_BYTES + 512);
@@ -226,18 +250,18 @@ __device__ __forceinline__ void bx_dense_mm2(const unsigned char *wa, const unsi
     }
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
-      acca[u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al[u], ba.ch, acca[u], 0, 0, 0);
-      accb[u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bl[u], bb.ch, accb[u], 0, 0, 0);
+      acca[u] = BX_MFMA16(al[u], ba.ch, acca[u]);
+      accb[u] = BX_MFMA16(bl[u], bb.ch, accb[u]);
     }
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
-      acca[u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[u], ba.cl, acca[u], 0, 0, 0);
-      accb[u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh[u], bb.cl, accb[u], 0, 0, 0);
+      acca[u] = BX_MFMA16(ah[u], ba.cl, acca[u]);
+      accb[u] = BX_MFMA16(bh[u], bb.cl, accb[u]);
     }
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
-      acca[u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[u], ba.ch, acca[u], 0, 0, 0);
-      accb[u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh[u], bb.ch, accb[u], 0, 0, 0);
+      acca[u] = BX_MFMA16(ah[u], ba.ch, acca[u]);
+      accb[u] = BX_MFMA16(bh[u], bb.ch, accb[u]);
     }
   }
 }
@@ -450,7 +474,7 @@ __device__ __forceinline__ void causal_effects_bx3(const unsigned char *lds, con
     const bx_lds_ptr wf2 = bx_frag_base(lds + L::wf2, lane * 16);
 #pragma unroll
     for (int T = 0; T < 2; ++T) {
-      bx_bf16x8 ah[2], al[2];
+      bx_x8 ah[2], al[2];
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         ah[mt] = bx_ld8(wf2, mt * 4096 + T * 2048);
@@ -464,14 +488,14 @@ __device__ __forceinline__ void causal_effects_bx3(const unsigned char *lds, con
           u0[r] = lrelu_s(fmaf(wx[2 * T][r], xk[e], base[2 * T][r]));
           u1[r] = lrelu_s(fmaf(wx[2 * T + 1][r], xk[e], base[2 * T + 1][r]));
         }
-        bx_bf16x8 bh, bl;
+        bx_x8 bh, bl;
         bx_split8(u0, u1, bh, bl);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) a2[e][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh, a2[e][mt], 0, 0, 0);
+        for (int mt = 0; mt < 2; ++mt) a2[e][mt] = BX_MFMA32(al[mt], bh, a2[e][mt]);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) a2[e][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl, a2[e][mt], 0, 0, 0);
+        for (int mt = 0; mt < 2; ++mt) a2[e][mt] = BX_MFMA32(ah[mt], bl, a2[e][mt]);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) a2[e][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh, a2[e][mt], 0, 0, 0);
+        for (int mt = 0; mt < 2; ++mt) a2[e][mt] = BX_MFMA32(ah[mt], bh, a2[e][mt]);
       }
     }
     float mu[DB], sr[DB];
@@ -615,3 +639,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_bx3_kernel(CausalBxKArgs
   }
   if (lane == 0) prog[wave_u] = 0x7fffffff;
 }
+
+#undef BX_MFMA32
+#undef BX_MFMA16
+}  // namespace BX_NS

@@ -69,8 +69,8 @@ class CausalEngine(object):
         _lib.check(self.lib.bgm_causal_configure(self.h, C.byref(cfg)), "bgm_causal_configure")
 
     def set_precision(self, mode):
-        """Arithmetic of logpost / mh_run launched afterwards: "fp32" (default) | "bf16x3" (bgm_causal_set_precision)."""
-        _lib.check(self.lib.bgm_causal_set_precision(self.h, {"fp32": 0, "bf16x3": 1}[mode]), "bgm_causal_set_precision")
+        """Arithmetic of logpost / mh_run launched afterwards: "fp32" (default) | "bf16x3" | "f16x3" (bgm_causal_set_precision)."""
+        _lib.check(self.lib.bgm_causal_set_precision(self.h, {"fp32": 0, "bf16x3": 1, "f16x3": 2}[mode]), "bgm_causal_set_precision")
 
     def set_disc_norm(self, mode):
         """BatchNormalization mode of the EGM discriminators opened afterwards: "batch" | "fixed" (bgm_set_disc_norm)."""

@@ -91,8 +91,8 @@ class CausalBGM(object):
         # params['mh_precision'] (build option): arithmetic of the posterior-sampling kernels of predict /
         # metropolis_hastings_sampler / get_log_posterior: "fp32" (default, the reference's arithmetic) or "bf16x3" (split
         # precision on the bf16 matrix pipe, DESIGN_HISTORY.md section 4b)
-        if p.get("mh_precision", "fp32") not in ("fp32", "bf16x3"):
-            raise ValueError("params['mh_precision'] must be 'fp32' or 'bf16x3'")
+        if p.get("mh_precision", "fp32") not in ("fp32", "bf16x3", "f16x3"):
+            raise ValueError("params['mh_precision'] must be 'fp32', 'bf16x3' or 'f16x3'")
         self.engine.set_precision(p.get("mh_precision", "fp32"))
         self._push_weights()
         if self.timestamp is None:

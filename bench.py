@@ -370,7 +370,7 @@ def accuracy_leg(params, data, x_values, n_loc, args):
         m.fit((x, y, v), epochs=100, epochs_per_eval=100, use_egm_init=True, egm_n_iter=30000, egm_batches_per_eval=30000, verbose=0)
         torch.cuda.synchronize()
         out["fit_seconds"] = time.perf_counter() - t0
-        for mode in ("fp32", "bf16x3"):
+        for mode in ("fp32", "bf16x3", "f16x3"):
             m.engine.set_precision(mode)
             m._seed_counter = 0
             t0 = time.perf_counter()
@@ -420,14 +420,14 @@ def accuracy_leg(params, data, x_values, n_loc, args):
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
 
 
-def bf16x3_leg(model, data, x_values, n_loc, args, z_dims, flop_row_transition, flop_row_keep, seed_counter):
+def bf16x3_leg(model, data, x_values, n_loc, args, z_dims, flop_row_transition, flop_row_keep, seed_counter, mode="bf16x3"):
     """Secondary measurement (not `value`, which stays fp32 = the reference's arithmetic): the same predict with the opt-in
     split-precision kernels (params['mh_precision'] = 'bf16x3', DESIGN_HISTORY.md section 4b).  `achieved` prices the ALGORITHMIC FLOP
     (the fp32 count) -- an "fp32-equivalent" rate; `executed_bf16_tflops` counts the three bf16 products per contraction that
     the matrix pipe actually runs, against the dense bf16 peak."""
     import torch
     eng = model.engine
-    eng.set_precision("bf16x3")
+    eng.set_precision(mode)
     try:
         model.predict(data, alpha=0.01, n_mcmc=8, burn_in=8, x_values=x_values, q_sd=1.0, sample_y=True, verbose=0)   # packs
         torch.cuda.synchronize()
@@ -448,7 +448,7 @@ def bf16x3_leg(model, data, x_values, n_loc, args, z_dims, flop_row_transition, 
     kern_s = (ms_b + ms_k) * 1e-3
     ach = flop / kern_s / 1e12 if kern_s > 0 else None
     return {"value": n_loc * (args.burn_in + args.n_mcmc) / dt, "unit": "MH transitions/s", "seconds": dt,
-            "sample": f"CausalBGM(mh_precision='bf16x3').predict, N={n_loc}, burn_in={args.burn_in}, n_mcmc={args.n_mcmc}, "
+            "sample": f"CausalBGM(mh_precision='{mode}').predict, N={n_loc}, burn_in={args.burn_in}, n_mcmc={args.n_mcmc}, "
                       f"{len(x_values)} doses (one call)",
             "acceptance_rate": model.last_acceptance_rate, "adrf_head": [float(a) for a in adrf[:3]], "adrf": np.asarray(adrf),
             "burn_in_kernel_ms": ms_b / max(1, n_b), "keep_kernel_ms": ms_k / max(1, n_k),
@@ -456,7 +456,8 @@ def bf16x3_leg(model, data, x_values, n_loc, args, z_dims, flop_row_transition, 
                          "achieved": ach, "unit": "TFLOP/s (algorithmic fp32-equivalent FLOP)",
                          "executed_bf16_tflops": 3.0 * ach if ach else None, "peak": PEAK_BF16_MFMA_TFLOPS,
                          "frac": (3.0 * ach / PEAK_BF16_MFMA_TFLOPS) if ach else None,
-                         "note": "three bf16 products per contraction; frac = executed bf16 FLOP/s over the dense bf16 peak"}}
+                         "note": "three 16-bit products per contraction; frac = executed bf16 / fp16 FLOP/s over the dense peak of the "
+                                 "16-bit matrix pipe (the same for both formats)"}}
 
 
 def main():
@@ -663,6 +664,11 @@ def main():
             out["bf16x3"] = bf16x3_leg(model, data, x_values, n_loc, args, z_dims, info.flop_per_row_transition, flop_keep_row, seed_counter_last)
             out["bf16x3"]["speedup_vs_fp32"] = out["bf16x3"]["value"] / value
             out["bf16x3"]["adrf_max_abs_diff_vs_fp32"] = float(np.abs(out["bf16x3"].pop("adrf") - adrf).max())
+            # the same kernels on fp16 operands (params['mh_precision'] = 'f16x3'): 22 instead of 16 mantissa bits per contraction
+            f16 = bf16x3_leg(model, data, x_values, n_loc, args, z_dims, info.flop_per_row_transition, flop_keep_row, seed_counter_last, mode="f16x3")
+            f16["speedup_vs_fp32"] = f16["value"] / value
+            f16["adrf_max_abs_diff_vs_fp32"] = float(np.abs(f16.pop("adrf") - adrf).max())
+            out["bf16x3"]["f16x3"] = f16
         if not args.no_accuracy and world == 1:
             out["accuracy"] = accuracy_leg(params, data, x_values, n_loc, args)
         if not args.no_bayesian and world == 1:

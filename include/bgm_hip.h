@@ -79,7 +79,9 @@ BGM_API int bgm_set_disc_norm(bgm_handle *h, int32_t mode);
  *   0 (default)  fp32 MFMA -- the reference's arithmetic (causalbgm/base.py:765-904 run in float32);
  *   1            split precision "bf16 x 3": weights and activations as sums of two bf16 numbers, three bf16 MFMA products per
  *                contraction with fp32 accumulation (relative error ~6e-6 per layer against 2.4e-7 in fp32).  Same algorithm,
- *                RNG streams and outputs; chains agree with the fp32 ones statistically, not draw for draw (DESIGN_HISTORY.md section 4b). */
+ *                RNG streams and outputs; chains agree with the fp32 ones statistically, not draw for draw (DESIGN_HISTORY.md section 4b);
+ *   2            the same kernels on fp16 operands ("f16 x 3": hi + lo carry 22 mantissa bits, the log posterior is within the
+ *                fp32 kernel's own distance of float64; activations or weights beyond 65504 saturate). */
 BGM_API int bgm_causal_set_precision(bgm_handle *h, int32_t mode);
 /* Conditional latent prior Z | U ~ N(mu(U), sigma^2(U) I) of IdentifiableCausalBGM (models/causalbgm/identifiable.py:195-211,
  * 541-551) for the sampling calls made afterwards (bgm_causal_logpost, bgm_causal_mh_run; fp32 kernels): seg_dev [n] = segment of
