@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-4 rocprofv3 evidence, run on the GPU box from the repo root (gpurun).  Counters in their own passes (--kernel-trace only beside
 # --pmc), as MI355X_MICROARCH.md prescribes.  Summaries land in gpurun_out/r04prof/ and are copied to profiles/ by hand.
-# usage: bash scripts/collect_r04_profiles.sh [what ...]   what in: bench keep gx bvn bvnc bvnf fit   (default: all)
+# usage: bash scripts/collect_r04_profiles.sh [what ...]   what in: bench keep bx3 hx3 gx bvn bvnc bvnf fit   (default: all)
 set -u
 OUT=gpurun_out/r04prof
 mkdir -p $OUT
@@ -29,6 +29,8 @@ for w in $WHAT; do
       { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-bayesian --no-fit --no-accuracy --no-bgm"; summ $OUT/kt_bench; } > $OUT/r04_kernel_trace_bench_N1e6.txt
       rm -rf $OUT/kt_bench ;;
     keep) passes causal_mh python scripts/probe_mh.py 1e6 100 40 ;;
+    bx3) passes causal_mh_bf16x3 python scripts/probe_mh.py 1e6 100 40 bf16x3 ;;
+    hx3) passes causal_mh_f16x3 python scripts/probe_mh.py 1e6 100 40 f16x3 ;;
     gx) passes gx_w256 env BGM_FORCE_GX=1 GX_ONLY=w256 python scripts/probe_gx.py 250000 ;;
     bvn) passes bvn_hmc_frozen env BGM_BVN_NO_CHAINS=1 python scripts/probe_bvn_hmc.py 400000 3 ;;      # the LDS-tile engine (gxf_bgm_hmc_kernel)
     bvnf) passes bvn_hmc_fresh python scripts/probe_bvn_hmc.py 400000 3 fresh ;;                        # row-tile chains, fresh noise (linear stream)

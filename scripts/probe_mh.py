@@ -1,4 +1,4 @@
-"""Quick MH-kernel throughput probe (dev tool): python scripts/probe_mh.py N iters [keep]"""
+"""Quick MH-kernel throughput probe (dev tool): python scripts/probe_mh.py N iters [keep [fp32|bf16x3|f16x3]]"""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -9,10 +9,13 @@ from oracle import causal as OC
 N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100000
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 keep = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+prec = sys.argv[4] if len(sys.argv) > 4 else "fp32"
 z_dims, p = [1, 1, 1, 7], 200
 m = OC.init_model(0, z_dims, p)
 eng = CausalEngine(p, z_dims)
 eng.set_model(g=m["g"], f=m["f"], h=m["h"], e=m["e"])
+eng.set_precision(prec)
+print("precision", prec)
 g = torch.Generator(device="cuda").manual_seed(0)
 v = torch.randn(N, p, device="cuda", generator=g)
 x = torch.rand(N, device="cuda", generator=g)
