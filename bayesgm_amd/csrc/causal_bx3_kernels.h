@@ -1,7 +1,7 @@
 // causal_bx3_kernels.h -- split-precision ("bf16 x 3" / "f16 x 3") variant of the CausalBGM sampling kernels (gfx950), opt-in
 // (`bgm_causal_set_precision(h, 1 | 2)`, params['mh_precision'] = 'bf16x3' | 'f16x3'); fp32 (causal_kernels.h) stays the default.
 // Two 16-bit operand formats, one source: bf16 (hi + lo = 16 mantissa bits, fp32 range) and fp16 (22 bits -- the log posterior
-// is as close to float64 as the fp32 kernel's -- operands beyond 65504 saturate); same instruction count, same matrix rate.
+// is as close to float64 as the fp32 kernel's -- weights beyond 65504 are clamped by the packer, an activation beyond 65504 overflows); same instruction count, same matrix rate.
 //
 // replaces (src/bayesgm/models/causalbgm/base.py): get_log_posterior :765-817, metropolis_hastings_sampler :820-904,
 // infer_from_latent_posterior :671-763 -- the same algorithm, RNG streams and data layout as causal_kernels.h; only the dense

@@ -81,7 +81,7 @@ BGM_API int bgm_set_disc_norm(bgm_handle *h, int32_t mode);
  *                contraction with fp32 accumulation (relative error ~6e-6 per layer against 2.4e-7 in fp32).  Same algorithm,
  *                RNG streams and outputs; chains agree with the fp32 ones statistically, not draw for draw (DESIGN_HISTORY.md section 4b);
  *   2            the same kernels on fp16 operands ("f16 x 3": hi + lo carry 22 mantissa bits, the log posterior is within the
- *                fp32 kernel's own distance of float64; activations or weights beyond 65504 saturate). */
+ *                fp32 kernel's own distance of float64; weights beyond 65504 are clamped, an activation beyond 65504 overflows: fp16 range). */
 BGM_API int bgm_causal_set_precision(bgm_handle *h, int32_t mode);
 /* Conditional latent prior Z | U ~ N(mu(U), sigma^2(U) I) of IdentifiableCausalBGM (models/causalbgm/identifiable.py:195-211,
  * 541-551) for the sampling calls made afterwards (bgm_causal_logpost, bgm_causal_mh_run; fp32 kernels): seg_dev [n] = segment of

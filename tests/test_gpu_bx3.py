@@ -1,6 +1,6 @@
 """Split-precision sampling kernels (csrc/causal_bx3_kernels.h, opt-in through bgm_causal_set_precision /
 params['mh_precision'] = 'bf16x3' | 'f16x3') against the float64 oracle and against the fp32 kernels.  The unit is compiled for two
-16-bit operand formats: bf16 (8 + 8 mantissa bits per hi / lo pair, fp32 range) and fp16 (11 + 11 bits, saturating at 65504).
+16-bit operand formats: bf16 (8 + 8 mantissa bits per hi / lo pair, fp32 range) and fp16 (11 + 11 bits, fp16 range: |activation| < 65504).
 
 The arithmetic differs from the reference's fp32 (three bf16 products per contraction, fp32 accumulation, ~6e-6 relative per
 layer), so parity is stated as tolerances, written here:
