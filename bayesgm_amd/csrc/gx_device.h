@@ -17,7 +17,7 @@
 // g = lane >> 4) reads ONE 16-byte A fragment A[row j][k0 + 4g .. + 3] from LDS and four 8-byte weight pairs
 // W[k0 + 4g + s][n0 + 2j, n0 + 2j + 1] (coalesced 128-byte row segments) per block and issues 8 MFMAs; K-step s contracts over
 // {k0 + 4g + s : g} on both operands.  The two accumulators of a lane hold columns n0 + 2j and n0 + 2j + 1 of rows 16 rt + 4g + r, so
-// an epilogue stores 8-byte pairs.  Per 8 MFMAs (256 matrix-pipe cycles) a wave issues 5 loads, two K blocks ahead of their use.
+// an epilogue stores 8-byte pairs.  Per 8 MFMAs (256 matrix-pipe cycles) a wave issues 5 loads.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -49,65 +49,64 @@ __host__ __device__ inline int gx_ld(int width) { return ((width + 59) / 64) * 6
 // n0 + 2j (acc0[r]) and n0 + 2j + 1 (acc1[r]).  No barriers inside: the caller separates producers and consumers of A.
 // ---------------------------------------------------------------------------------------------------------------------------
 // nrt: 16-row tiles of A (2 = the workgroup's 32 rows; the effect pass stacks several doses' rows: 2 x doses)
-// One K block of 16: the lane's A fragment and its four weight pairs.
-struct GxBlk { f32x4 a; f32x2 b[4]; };
-__device__ __forceinline__ void gx_blk_mfma(const GxBlk &x, f32x4 &acc0, f32x4 &acc1) {
-  acc0 = BGM_MFMA(x.a[0], x.b[0][0], acc0); acc1 = BGM_MFMA(x.a[0], x.b[0][1], acc1);
-  acc0 = BGM_MFMA(x.a[1], x.b[1][0], acc0); acc1 = BGM_MFMA(x.a[1], x.b[1][1], acc1);
-  acc0 = BGM_MFMA(x.a[2], x.b[2][0], acc0); acc1 = BGM_MFMA(x.a[2], x.b[2][1], acc1);
-  acc0 = BGM_MFMA(x.a[3], x.b[3][0], acc0); acc1 = BGM_MFMA(x.a[3], x.b[3][1], acc1);
-}
-
 template <bool A_GLOBAL = false, class Epi>
 __device__ __forceinline__ void gx_dense_ld(const float *__restrict__ W, int ldw, int K, int N, const float *A, int lda, Epi epi, int nrt = 2) {
-  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // the unit walk below is wave-uniform: scalar addresses
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
   const int units = nrt * (N >> 5);
-  const int nb = K >> 4;                                                  // K blocks (K is a multiple of 32: nb >= 2)
-  // Weight addresses = (scalar row base of the block) + (one 32-bit byte offset per lane that never changes): the loads take the
-  // base from SGPRs (global_load ... v_off, s[base]) and the K walk costs scalar adds only.  The first version kept four 64-bit
-  // per-lane pointers and rotated its operand registers: 8 v_lshl_add_u64 + 12 register moves per 8 MFMAs, and it waited for
-  // block k + 1 at the top of block k + 1 (one block = 256 matrix cycles of cover for an L2 round trip).
-  const unsigned boff = ((unsigned)(4 * g) * (unsigned)ldw + 2u * (unsigned)j) * 4u;
-  const size_t rstep = (size_t)ldw * 4;                                   // bytes per weight row
-  for (int u = wave; u < units; u += GX_WAVES) {
-    const int rt = u % nrt, n0 = (u / nrt) << 5;
+  int u = wave;
+  if (u >= units) return;
+  const size_t wstep = (size_t)16 * ldw;
+  // software pipeline over K blocks AND over the wave's units: the operands of K block k0 + 16 are requested before the MFMAs of
+  // block k0 issue, and block 0 of the wave's NEXT unit before the MFMAs of the current unit's last block -- a unit of a 64-wide
+  // layer is 4 blocks (1024 matrix cycles), and starting each one on a cold L2 round trip cost more than the unit itself
+  int rt = u % nrt, n0 = (u / nrt) << 5;
+  const float *ap = A + (size_t)(16 * rt + j) * lda + 4 * g;
+  const float *wk = W + (size_t)(4 * g) * ldw + n0 + 2 * j;
+  f32x4 a = *reinterpret_cast<const f32x4 *>(ap);
+  f32x2 b0 = *reinterpret_cast<const f32x2 *>(wk);
+  f32x2 b1 = *reinterpret_cast<const f32x2 *>(wk + ldw);
+  f32x2 b2 = *reinterpret_cast<const f32x2 *>(wk + 2 * (size_t)ldw);
+  f32x2 b3 = *reinterpret_cast<const f32x2 *>(wk + 3 * (size_t)ldw);
+  for (;;) {
     f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
-    const float *ap = A + (size_t)(16 * rt + j) * lda + 4 * g;
-    const char *wb = reinterpret_cast<const char *>(W + n0);             // uniform
-    auto load = [&](int blk, GxBlk &x) {
-      blk = blk < nb ? blk : nb - 1;                                      // (requests past the end repeat the last block; never used)
-      x.a = *reinterpret_cast<const f32x4 *>(ap + 16 * blk);
-      const char *rb = wb + (size_t)(16 * blk) * rstep;
-      unsigned bo = boff;
-      asm volatile("" : "+v"(bo));      // keeps the zero-extension next to the loads (hoisted, it turns the address into a 64-bit VGPR sum)
-#pragma unroll
-      for (int s_ = 0; s_ < 4; ++s_) {
-        const char *rs = rb + (size_t)s_ * rstep;                       // scalar ...
-        asm volatile("" : "+s"(rs));                                    // ... and kept there (else the row step is re-associated into vector adds)
-        x.b[s_] = *reinterpret_cast<const f32x2 *>(rs + bo);             // + zero-extended 32-bit lane offset
-      }
-    };
-    // operand ring of three blocks: the requests of blocks k + 1 and k + 2 are in flight under the MFMAs of block k
-    GxBlk x, y, z;
-    load(0, x);
-    load(1, y);
-    for (int k0 = 0; k0 < nb; k0 += 3) {
-      load(k0 + 2, z);
-      __builtin_amdgcn_sched_barrier(0);      // keep the requests above the MFMAs (hipcc sinks loads to their first use)
-      gx_blk_mfma(x, acc0, acc1);
-      if (k0 + 1 < nb) {
-        load(k0 + 3, x);
-        __builtin_amdgcn_sched_barrier(0);
-        gx_blk_mfma(y, acc0, acc1);
-      }
-      if (k0 + 2 < nb) {
-        load(k0 + 4, y);
-        __builtin_amdgcn_sched_barrier(0);
-        gx_blk_mfma(z, acc0, acc1);
-      }
+    for (int k0 = 16; k0 < K; k0 += 16) {
+      wk += wstep;
+      const f32x4 an = *reinterpret_cast<const f32x4 *>(ap + k0);
+      const f32x2 c0 = *reinterpret_cast<const f32x2 *>(wk);
+      const f32x2 c1 = *reinterpret_cast<const f32x2 *>(wk + ldw);
+      const f32x2 c2 = *reinterpret_cast<const f32x2 *>(wk + 2 * (size_t)ldw);
+      const f32x2 c3 = *reinterpret_cast<const f32x2 *>(wk + 3 * (size_t)ldw);
+      __builtin_amdgcn_sched_barrier(0);      // keep the requests above the MFMAs of the previous block (hipcc sinks loads to their first use)
+      acc0 = BGM_MFMA(a[0], b0[0], acc0); acc1 = BGM_MFMA(a[0], b0[1], acc1);
+      acc0 = BGM_MFMA(a[1], b1[0], acc0); acc1 = BGM_MFMA(a[1], b1[1], acc1);
+      acc0 = BGM_MFMA(a[2], b2[0], acc0); acc1 = BGM_MFMA(a[2], b2[1], acc1);
+      acc0 = BGM_MFMA(a[3], b3[0], acc0); acc1 = BGM_MFMA(a[3], b3[1], acc1);
+      a = an; b0 = c0; b1 = c1; b2 = c2; b3 = c3;
     }
+    // last block of this unit; block 0 of the next one is requested first
+    const int un = u + GX_WAVES;
+    const bool more = un < units;
+    const int rtn = un % nrt, n0n = (un / nrt) << 5;
+    f32x4 an = a;
+    f32x2 c0 = b0, c1 = b1, c2 = b2, c3 = b3;
+    if (more) {
+      ap = A + (size_t)(16 * rtn + j) * lda + 4 * g;
+      wk = W + (size_t)(4 * g) * ldw + n0n + 2 * j;
+      an = *reinterpret_cast<const f32x4 *>(ap);
+      c0 = *reinterpret_cast<const f32x2 *>(wk);
+      c1 = *reinterpret_cast<const f32x2 *>(wk + ldw);
+      c2 = *reinterpret_cast<const f32x2 *>(wk + 2 * (size_t)ldw);
+      c3 = *reinterpret_cast<const f32x2 *>(wk + 3 * (size_t)ldw);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    acc0 = BGM_MFMA(a[0], b0[0], acc0); acc1 = BGM_MFMA(a[0], b0[1], acc1);
+    acc0 = BGM_MFMA(a[1], b1[0], acc0); acc1 = BGM_MFMA(a[1], b1[1], acc1);
+    acc0 = BGM_MFMA(a[2], b2[0], acc0); acc1 = BGM_MFMA(a[2], b2[1], acc1);
+    acc0 = BGM_MFMA(a[3], b3[0], acc0); acc1 = BGM_MFMA(a[3], b3[1], acc1);
     epi(rt, n0, acc0, acc1);
+    if (!more) break;
+    u = un; rt = rtn; n0 = n0n;
+    a = an; b0 = c0; b1 = c1; b2 = c2; b3 = c3;
   }
 }
 
