@@ -60,6 +60,11 @@ struct bgm_handle {
   int precision = 0;
   void *bx_blob_dev = nullptr;
   size_t bx_cap = 0;
+  // per-wave-slot (mean, sd) of the outcome net at every dose, kept between the retained iterations of an ADRF launch (causal_kernels.h)
+  float *eff_cache = nullptr;
+  size_t eff_cache_cap = 0;
+  int outcome_cache = 1;                          // bgm_causal_set_outcome_cache
+  unsigned long long *eff_stats_dev = nullptr;    // [2]: retained tile-iterations served from the cache, retained tile-iterations
   bool bx_valid = false;
   alignas(8) unsigned char bx_meta_store[192];
   // per-row conditional latent prior of the sampling kernels (causal_prior_api.hip, bgm_causal_set_prior); NULL = standard normal

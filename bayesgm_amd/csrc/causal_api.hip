@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 
 #include "bgm_host.h"
 #include "bnf_det_host.h"
@@ -47,6 +48,8 @@ extern "C" int bgm_destroy(bgm_handle *h) {
   if (h->sblob_dev) hipFree(h->sblob_dev);
   if (h->bx_blob_dev) hipFree(h->bx_blob_dev);
   if (h->acc_scratch) hipFree(h->acc_scratch);
+  if (h->eff_cache) hipFree(h->eff_cache);
+  if (h->eff_stats_dev) hipFree(h->eff_stats_dev);
   bnf_det_free(h);
   bgm_causal_fit_end(h, nullptr);
   gx_free(h);
@@ -430,6 +433,21 @@ extern "C" int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *a, void *stre
   if (split > a->it_begin) segs[nseg++] = {a->it_begin, split - a->it_begin, BGM_EFFECT_NONE, a->init};
   if (it_end > split) segs[nseg++] = {split, it_end - split, a->effect, (nseg == 0) ? a->init : 0};
   const int n_slots = grid * MH_WAVES;
+  if (a->effect == BGM_EFFECT_ADRF && it_end > split) {      // (mean, sd) of the outcome net per wave slot, pass and lane: causal_effects_cached
+    const size_t need = (size_t)n_slots * (size_t)((a->n_doses + 3) / 4) * 64 * 2;
+    if (h->eff_cache_cap < need) {
+      if (h->eff_cache) BGM_HIP_CHECK(hipFree(h->eff_cache));
+      BGM_HIP_CHECK(hipMalloc(&h->eff_cache, need * sizeof(float)));
+      h->eff_cache_cap = need;
+    }
+    ka.eff_cache = h->eff_cache;
+    ka.eff_skip = h->outcome_cache ? 1 : 0;
+    if (!h->eff_stats_dev) {
+      BGM_HIP_CHECK(hipMalloc(&h->eff_stats_dev, 2 * sizeof(unsigned long long)));
+      BGM_HIP_CHECK(hipMemsetAsync(h->eff_stats_dev, 0, 2 * sizeof(unsigned long long), stream));
+    }
+    ka.eff_stats = h->eff_stats_dev;
+  }
   for (int s = 0; s < nseg; ++s) {
     ka.it_begin = segs[s].begin; ka.n_iters = segs[s].n; ka.init = segs[s].init;
     if (a->acc_count_dev) {   // slot-private counters for this launch, reduced into acc_count_dev afterwards
@@ -560,6 +578,25 @@ extern "C" int bgm_causal_evaluate_slots(bgm_handle *h, int64_t n, int32_t *n_sl
   if (h->configured && bnf_det_wanted(h)) { *n_slots = bnf_det_slots(h); return BGM_OK; }
   const int64_t tiles = (n + 15) / 16;
   *n_slots = (int)std::max<int64_t>(1, std::min<int64_t>((tiles + MH_WAVES - 1) / MH_WAVES, h->n_cus)) * MH_WAVES;
+  return BGM_OK;
+}
+
+extern "C" int bgm_causal_set_outcome_cache(bgm_handle *h, int32_t on) {
+  if (!h) { bgm_set_error("bgm_causal_set_outcome_cache: null handle"); return BGM_E_INVALID; }
+  h->outcome_cache = on != 0;
+  return BGM_OK;
+}
+
+extern "C" int bgm_causal_outcome_cache_stats(bgm_handle *h, int64_t *out2, int32_t reset) {
+  if (!h || !out2) { bgm_set_error("bgm_causal_outcome_cache_stats: bad argument"); return BGM_E_INVALID; }
+  out2[0] = out2[1] = 0;
+  if (!h->eff_stats_dev) return BGM_OK;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  BGM_HIP_CHECK(hipDeviceSynchronize());
+  unsigned long long v[2];
+  BGM_HIP_CHECK(hipMemcpy(v, h->eff_stats_dev, sizeof(v), hipMemcpyDeviceToHost));
+  out2[0] = (int64_t)v[0]; out2[1] = (int64_t)v[1];
+  if (reset) BGM_HIP_CHECK(hipMemset(h->eff_stats_dev, 0, sizeof(v)));
   return BGM_OK;
 }
 

@@ -553,7 +553,9 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_bx3_kernel(CausalBxKArgs
   const long long slot = (long long)blockIdx.x * WAVES + wave;
   const long long n_slots = (long long)gridDim.x * WAVES;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  volatile int *prog = reinterpret_cast<volatile int *>(bx_lds + m.total_bytes);   // [WAVES] progress counters after the blob
+  // [WAVES] progress counters after the blob (LDS-typed: see causal_mh_kernel)
+  volatile __attribute__((address_space(3))) int *prog =
+      (volatile __attribute__((address_space(3))) int *)((__attribute__((address_space(3))) unsigned char *)bx_lds + m.total_bytes);
   if (lane == 0) prog[wave_u] = 0;
   int tiles_done = 0;
   for (long long tile = slot; tile < n_tiles; tile += n_slots) {

@@ -46,6 +46,9 @@ struct CausalMhKArgs {
   unsigned long long *clk;
   const int *seg;           // conditional prior (IdentifiableCausalBGM): segment of every local row, or NULL
   const float *prior_tab;   // [n_segments][q + 2]: mu(u) [q], 1 / sigma^2(u), (q / 2) log sigma^2(u)
+  float *eff_cache;         // ADRF kernels with one row tile per wave: [n_slots][ceil(n_doses / 4)][64][2] (mean, sd) of the lane's dose
+  int eff_skip;             // 1: a retained iteration in which no chain of the wave moved reuses the cached (mean, sd)
+  unsigned long long *eff_stats;   // [2] += (retained tile-iterations served from the cache, retained tile-iterations), or NULL
   CausalMeta m;
 };
 
@@ -456,13 +459,13 @@ __device__ __forceinline__ float pick_by_group(int g, float v0, float v1, float 
   return g == 0 ? v0 : (g == 1 ? v1 : (g == 2 ? v2 : v3));
 }
 
-template <int KT1, int KSL1, int R, int EFFECT, bool GROUPING = true>
+template <int KT1, int KSL1, int R, int EFFECT, bool GROUPING = true, bool CACHE = false>
 __device__ __forceinline__ void causal_effects(const float *lds, const CausalMeta &m, int lane_off, int g, int j,
                                                int lane, const f32x4 (&zs)[R][KT1], const unsigned (&rowid)[R],
                                                const bool (&valid)[R], long long row0, long long n, unsigned it,
                                                long long d, int n_keep, int sample_y, int n_doses,
                                                const float *x_values, float *adrf_slot, float *ite, unsigned k0,
-                                               unsigned k1) {
+                                               unsigned k1, float2 *cache = nullptr) {
   BGM_NO_HOIST();
   f32x4 z0in[R][KT1];
 #pragma unroll
@@ -576,10 +579,12 @@ __device__ __forceinline__ void causal_effects(const float *lds, const CausalMet
       const int k = own ? 4 * (c4 + g) + p4 : 4 * kb + g;          // this lane group's dose of the pass ...
       const float mu_m = pick_by_group(g, mu[0], mu[1], mu[2], mu[3]), sr_m = pick_by_group(g, sr[0], sr[1], sr[2], sr[3]);
       const float s2 = (m.sig2_y > 0.0f) ? m.sig2_y : softplus_f(sr_m) + BGM_EPS;
+      const float sd_m = __builtin_sqrtf(s2);
+      if constexpr (CACHE) cache[kb * 64 + lane] = make_float2(mu_m, sd_m);        // for causal_effects_cached below
       // ... and its noise word: word p4 of its own call (rotated into word 0 pass by pass), or word g of the shared call
       const float noise = own ? nz[0][0] : pick_by_group(g, nz[0][0], nz[0][1], nz[0][2], nz[0][3]);
       if (own) nz[0] = f32x4{nz[0][1], nz[0][2], nz[0][3], nz[0][0]};
-      float y = sample_y ? fmaf(__builtin_sqrtf(s2), noise, mu_m) : mu_m;
+      float y = sample_y ? fmaf(sd_m, noise, mu_m) : mu_m;
       y = (valid[0] && k < nd) ? y : 0.0f;
       const float tot = sum_over_j_to_lane15(y);
       if (j == 15 && k < nd) unsafeAtomicAdd(adrf_slot + (long long)d * nd + k, tot);
@@ -613,6 +618,34 @@ __device__ __forceinline__ void causal_effects(const float *lds, const CausalMet
   }
 }
 
+// The ADRF contribution of a retained iteration in which none of the wave's 16 chains moved.  The outcome net is a deterministic
+// function of the chain state, so (mean, sd) of every dose are those of the previous retained iteration -- causal_effects left them in
+// `cache` ([pass][lane]: the dose this lane group finishes in that pass) -- and only the outcome noise is new: same Philox calls, same
+// fma, same reduction order as the GROUPED path of causal_effects, i.e. bit-identical sums without the 20 dose evaluations.  (With the
+// reference's q_sd = 1 a trained model accepts 2-10 % of its proposals: 27-80 % of the tiles see no move in an iteration.)
+__device__ __forceinline__ void causal_effects_cached(int g, int j, int lane, unsigned rowid, bool valid, unsigned it, long long d,
+                                                      int sample_y, int n_doses, float *adrf_slot, unsigned k0, unsigned k1,
+                                                      const float2 *cache) {
+  const int nd = n_doses;
+  const int n_calls = (nd + 3) >> 2, n_own = n_calls & ~3;
+  f32x4 nz = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  float2 c = cache[lane];
+  for (int kb = 0; kb < n_calls; ++kb) {
+    const float2 cn = cache[(kb + 1 < n_calls ? kb + 1 : kb) * 64 + lane];     // next pass's pair under this pass's Philox call
+    const bool own = kb < n_own;
+    const int c4 = kb & ~3, p4 = kb & 3;
+    if (sample_y && (!own || p4 == 0)) nz = box_muller4(philox4x32_10(rowid, it, (unsigned)(own ? c4 + g : kb), TAG_YNOISE, k0, k1));
+    const int k = own ? 4 * (c4 + g) + p4 : 4 * kb + g;
+    const float noise = own ? nz[0] : pick_by_group(g, nz[0], nz[1], nz[2], nz[3]);
+    if (own) nz = f32x4{nz[1], nz[2], nz[3], nz[0]};
+    float y = sample_y ? fmaf(c.y, noise, c.x) : c.x;
+    y = (valid && k < nd) ? y : 0.0f;
+    const float tot = sum_over_j_to_lane15(y);
+    if (j == 15 && k < nd) unsafeAtomicAdd(adrf_slot + (long long)d * nd + k, tot);
+    c = cn;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Persistent random-walk Metropolis-Hastings over a segment of iterations.
 // ---------------------------------------------------------------------------
@@ -633,7 +666,11 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
   unsigned long long tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
 #endif
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  volatile int *prog = reinterpret_cast<volatile int *>(lds + m.total);   // [WAVES] progress counters after the blob
+  // [WAVES] progress counters after the blob.  An LDS-typed pointer: as a generic one its volatile accesses stay FLAT, and the
+  // "{offset, src_shared_base} != null" test that comes with them is what hipcc 7.2 intermittently fails to encode ("$src_shared_base"
+  // illegal instruction) when unrelated code in the kernel changes
+  volatile __attribute__((address_space(3))) int *prog =
+      (volatile __attribute__((address_space(3))) int *)((__attribute__((address_space(3))) float *)lds + m.total);
   if (lane == 0) prog[wave_u] = 0;
   int tiles_done = 0;
 
@@ -687,6 +724,8 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
     }
 
     uint4 uacc[R];
+    bool eff_cached = false;      // the slot's cache holds the outcome-net values of the tile's current states
+    unsigned n_eff_skipped = 0u, n_eff_total = 0u;
 #ifdef BGM_PROF
     tlast = __builtin_readcyclecounter();
 #endif
@@ -772,12 +811,29 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
             }
           }
         }
-        if constexpr (EFFECT != 0) {
+        if constexpr (EFFECT == 1 && R == 1) {
+          float2 *cache = reinterpret_cast<float2 *>(a.eff_cache) + slot * (long long)((a.n_doses + 3) >> 2) * 64;
+          float *adrf_slot = a.adrf_partial + slot * (long long)a.n_doses * a.n_keep;
+          const bool skip = a.eff_skip && eff_cached && accmask == 0ull;                // wave-uniform: nobody moved
+          // (the evaluation is switched off through its trip count: its first layer -- 12 MFMAs -- still runs)
+          causal_effects<KT1, KSL1, R, EFFECT, true, true>(lds, m, lane_off, g, j, lane, zs, rowid, valid, row0, n, (unsigned)it, d, a.n_keep,
+                                                            a.sample_y, skip ? 0 : a.n_doses, a.x_values, adrf_slot, a.ite, a.k0, a.k1, cache);
+          if (skip) causal_effects_cached(g, j, lane, rowid[0], valid[0], (unsigned)it, d, a.sample_y, a.n_doses, adrf_slot, a.k0, a.k1, cache);
+          eff_cached = true;
+          n_eff_skipped += skip ? 1u : 0u;
+          ++n_eff_total;
+        } else if constexpr (EFFECT != 0) {
           causal_effects<KT1, KSL1, R, EFFECT>(lds, m, lane_off, g, j, lane, zs, rowid, valid, row0, n, (unsigned)it, d,
                                                 a.n_keep, a.sample_y, a.n_doses, a.x_values,
                                                 a.adrf_partial + slot * (long long)((EFFECT == 2) ? 2 : a.n_doses) * a.n_keep,
                                                 a.ite, a.k0, a.k1);
         }
+      }
+    }
+    if constexpr (EFFECT == 1 && R == 1) {
+      if (a.eff_stats != nullptr && lane == 0 && n_eff_total != 0u) {
+        atomicAdd(&a.eff_stats[0], (unsigned long long)n_eff_skipped);
+        atomicAdd(&a.eff_stats[1], (unsigned long long)n_eff_total);
       }
     }
     // ---- write the chain state back

@@ -359,6 +359,16 @@ class CausalEngine(object):
     def egm_end(self):
         _lib.check(self.lib.bgm_causal_egm_end(self.h, self._stream()), "bgm_causal_egm_end")
 
+    def set_outcome_cache(self, on=True):
+        """Fused ADRF sampler: reuse the outcome net's (mean, sd) of a tile whose chains all stayed put (bit-identical sums; default on)."""
+        _lib.check(self.lib.bgm_causal_set_outcome_cache(self.h, int(bool(on))), "bgm_causal_set_outcome_cache")
+
+    def outcome_cache_stats(self, reset=True):
+        """(retained tile-iterations served from the cache, retained tile-iterations) since the last reset."""
+        out = (C.c_int64 * 2)()
+        _lib.check(self.lib.bgm_causal_outcome_cache_stats(self.h, out, int(reset)), "bgm_causal_outcome_cache_stats")
+        return int(out[0]), int(out[1])
+
     def timing_enable(self, on=True):
         _lib.check(self.lib.bgm_timing_enable(self.h, int(on)), "bgm_timing_enable")
 

@@ -94,6 +94,9 @@ class CausalBGM(object):
         if p.get("mh_precision", "fp32") not in ("fp32", "bf16x3", "f16x3"):
             raise ValueError("params['mh_precision'] must be 'fp32', 'bf16x3' or 'f16x3'")
         self.engine.set_precision(p.get("mh_precision", "fp32"))
+        # params['outcome_cache'] (build option, default True): predict's fused ADRF sampler reuses the outcome net's (mean, sd) of the
+        # chains that did not move in a retained iteration (identical results; False = evaluate f at every retained draw as the reference)
+        self.engine.set_outcome_cache(bool(p.get("outcome_cache", True)))
         self._push_weights()
         if self.timestamp is None:
             self.timestamp = datetime.datetime.now().astimezone().strftime('%Y%m%d_%H%M%S')

@@ -348,3 +348,34 @@ def test_standalone_effects_from_draws_match_oracle_and_the_fused_pass(binary):
     if not binary:
         with pytest.raises(ValueError):
             model.infer_from_latent_posterior(draws.cpu().numpy())
+
+
+def test_outcome_cache_is_bit_identical():
+    """bgm_causal_set_outcome_cache: a retained iteration in which no chain of a wave moved takes the outcome net's (mean, sd) at every
+    dose from the previous evaluation (csrc/causal_kernels.h causal_effects_cached).  Same Philox streams with the cache on and off: the
+    ADRF draw sums, the chains and the acceptance counts are equal to the last bit, and the cache is actually used."""
+    from bayesgm_amd import _lib
+    m = _model(11, [1, 1, 1, 7], 200)
+    x, y, v = _data(3000, 200, 12)          # 188 tiles, the last one ragged
+    xs = np.linspace(0, 3, 20)
+    eng = _engine(m)
+    outs = {}
+    for on in (True, False):
+        eng.set_outcome_cache(on)
+        eng.outcome_cache_stats(reset=True)
+        out = eng.mh_sample(x, y, v, 40, 60, 1.0, 5, want_draws=True, effect=_lib.EFFECT_ADRF, x_values=xs)
+        outs[on] = (out["adrf"].cpu().numpy(), out["draws"].cpu().numpy(), out["acc_count"].cpu().numpy(), eng.outcome_cache_stats())
+    eng.set_outcome_cache(True)
+    (a1, d1, c1, s1), (a0, d0, c0, s0) = outs[True], outs[False]
+    print("served from cache: %d of %d retained tile-iterations (off: %d of %d)" % (s1 + s0))
+    assert s1[1] == 188 * 60 and s0 == (0, 188 * 60)
+    assert s1[0] > 0.05 * s1[1]                              # q_sd = 1: most proposals are rejected
+    assert np.array_equal(a1, a0) and np.array_equal(d1, d0) and np.array_equal(c1, c0)
+    # 7 doses (two passes, the second partial) and sample_y=False
+    for kw in (dict(x_values=np.linspace(0, 2, 7)), dict(x_values=xs, sample_y=False)):
+        res = []
+        for on in (True, False):
+            eng.set_outcome_cache(on)
+            res.append(eng.mh_sample(x, y, v, 10, 30, 1.0, 6, effect=_lib.EFFECT_ADRF, **kw)["adrf"].cpu().numpy())
+        eng.set_outcome_cache(True)
+        assert np.array_equal(res[0], res[1])
