@@ -433,11 +433,12 @@ __global__ __launch_bounds__(64 * WAVES) void causal_logpost_bx3_kernel(const un
 // f's first layer once at x = 0 (fp32 accumulators), doses as fp32 rank-1 updates, four doses per pass sharing the A
 // fragments, lane group g finishing dose e = g of the pass; same noise plan (Philox calls in groups of four).
 // ---------------------------------------------------------------------------
-template <int KT1, int NTL, int EFFECT>
+template <int KT1, int NTL, int EFFECT, bool CACHE = false>
 __device__ __forceinline__ void causal_effects_bx3(const unsigned char *lds, const BxMeta &m, int lane, int g, int j,
                                                    const f32x4 (&zs)[KT1], unsigned rowid, bool valid, long long row, long long n,
                                                    unsigned it, long long d, int n_keep, int sample_y, int n_doses,
-                                                   const float *x_values, float *adrf_slot, float *ite, unsigned k0, unsigned k1) {
+                                                   const float *x_values, float *adrf_slot, float *ite, unsigned k0, unsigned k1,
+                                                   float2 *cache = nullptr) {
   BGM_NO_HOIST();
   using L = BxLayout<KT1, NTL>;
   const float *ldsf = reinterpret_cast<const float *>(lds);
@@ -516,9 +517,11 @@ __device__ __forceinline__ void causal_effects_bx3(const unsigned char *lds, con
       const int k = own ? 4 * (c4 + g) + p4 : 4 * kb + g;
       const float mu_m = pick_by_group(g, mu[0], mu[1], mu[2], mu[3]), sr_m = pick_by_group(g, sr[0], sr[1], sr[2], sr[3]);
       const float s2 = (m.sig2_y > 0.0f) ? m.sig2_y : softplus_f(sr_m) + BGM_EPS;
+      const float sd_m = __builtin_sqrtf(s2);
+      if constexpr (CACHE) cache[kb * 64 + lane] = make_float2(mu_m, sd_m);      // for causal_effects_cached (causal_kernels.h)
       const float noise = own ? nz[0] : pick_by_group(g, nz[0], nz[1], nz[2], nz[3]);
       if (own) nz = f32x4{nz[1], nz[2], nz[3], nz[0]};
-      float y = sample_y ? fmaf(__builtin_sqrtf(s2), noise, mu_m) : mu_m;
+      float y = sample_y ? fmaf(sd_m, noise, mu_m) : mu_m;
       y = (valid && k < nd) ? y : 0.0f;
       const float tot = sum_over_j_to_lane15(y);
       if (j == 15 && k < nd) unsafeAtomicAdd(adrf_slot + (long long)d * nd + k, tot);
@@ -585,6 +588,8 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_bx3_kernel(CausalBxKArgs
       lp = a.logp[rowc];
     }
     uint4 uacc = make_uint4(0u, 0u, 0u, 0u);
+    bool eff_cached = false;      // outcome-net cache of the retained iterations: see causal_mh_kernel
+    unsigned n_eff_skipped = 0u, n_eff_total = 0u;
     for (int it = a.it_begin; it < a.it_begin + a.n_iters; ++it) {
       BGM_NO_HOIST();
       if constexpr (WAVES == 8) {
@@ -628,11 +633,27 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_bx3_kernel(CausalBxKArgs
               if (f < m.q) dr[f] = zs[0][t][r];
             }
         }
-        if constexpr (EFFECT != 0) {
+        if constexpr (EFFECT == 1) {
+          float2 *cache = reinterpret_cast<float2 *>(a.eff_cache) + slot * (long long)((a.n_doses + 3) >> 2) * 64;
+          float *adrf_slot = a.adrf_partial + slot * (long long)a.n_doses * a.n_keep;
+          const bool skip = a.eff_skip && eff_cached && accmask == 0u;                   // wave-uniform: nobody moved
+          causal_effects_bx3<KT1, NTL, EFFECT, true>(bx_lds, m, lane, g, j, zs[0], rowid, valid, row, n, (unsigned)it, d, a.n_keep, a.sample_y,
+                                                     skip ? 0 : a.n_doses, a.x_values, adrf_slot, a.ite, a.k0, a.k1, cache);
+          if (skip) causal_effects_cached(g, j, lane, rowid, valid, (unsigned)it, d, a.sample_y, a.n_doses, adrf_slot, a.k0, a.k1, cache);
+          eff_cached = true;
+          n_eff_skipped += skip ? 1u : 0u;
+          ++n_eff_total;
+        } else if constexpr (EFFECT != 0) {
           causal_effects_bx3<KT1, NTL, EFFECT>(bx_lds, m, lane, g, j, zs[0], rowid, valid, row, n, (unsigned)it, d, a.n_keep, a.sample_y,
                                           a.n_doses, a.x_values,
                                           a.adrf_partial + slot * (long long)((EFFECT == 2) ? 2 : a.n_doses) * a.n_keep, a.ite, a.k0, a.k1);
         }
+      }
+    }
+    if constexpr (EFFECT == 1) {
+      if (a.eff_stats != nullptr && lane == 0 && n_eff_total != 0u) {
+        atomicAdd(&a.eff_stats[0], (unsigned long long)n_eff_skipped);
+        atomicAdd(&a.eff_stats[1], (unsigned long long)n_eff_total);
       }
     }
     store_z_rows<KT1, 1>(a.state, n, m.q, row0, j, g, zs);

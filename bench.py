@@ -475,7 +475,20 @@ def bf16x3_leg(model, data, x_values, n_loc, args, z_dims, flop_row_transition, 
         n_b, ms_b = eng.timing_read(kind=0, reset=False)
         n_k, ms_k = eng.timing_read(kind=1, reset=True)
         eng.timing_enable(False)
+        # the same call with the product's default outcome-net cache (off for the numbers above, as for the headline)
+        eng.set_outcome_cache(True)
+        eng.outcome_cache_stats(reset=True)
+        model._seed_counter = seed_counter - 1
+        t0 = time.perf_counter()
+        adrf_c, _ = model.predict(data, alpha=0.01, n_mcmc=args.n_mcmc, burn_in=args.burn_in, x_values=x_values, q_sd=1.0,
+                                  sample_y=True, verbose=0)
+        torch.cuda.synchronize()
+        dt_c = time.perf_counter() - t0
+        served, total = eng.outcome_cache_stats(reset=True)
+        cached = {"value": n_loc * (args.burn_in + args.n_mcmc) / dt_c, "seconds": dt_c, "served_fraction": served / max(1, total),
+                  "adrf_max_abs_diff": float(np.abs(np.asarray(adrf_c) - np.asarray(adrf)).max())}
     finally:
+        eng.set_outcome_cache(False)
         eng.set_precision("fp32")
     flop = (flop_row_transition * args.burn_in + flop_row_keep * args.n_mcmc) * n_loc
     kern_s = (ms_b + ms_k) * 1e-3
@@ -484,7 +497,7 @@ def bf16x3_leg(model, data, x_values, n_loc, args, z_dims, flop_row_transition, 
             "sample": f"CausalBGM(mh_precision='{mode}').predict, N={n_loc}, burn_in={args.burn_in}, n_mcmc={args.n_mcmc}, "
                       f"{len(x_values)} doses (one call)",
             "acceptance_rate": model.last_acceptance_rate, "adrf_head": [float(a) for a in adrf[:3]], "adrf": np.asarray(adrf),
-            "burn_in_kernel_ms": ms_b / max(1, n_b), "keep_kernel_ms": ms_k / max(1, n_k),
+            "burn_in_kernel_ms": ms_b / max(1, n_b), "keep_kernel_ms": ms_k / max(1, n_k), "with_outcome_cache": cached,
             "roofline": {"bound": "mfma", "kernel": "causal_mh_bx3_kernel (burn-in + keep launches)",
                          "achieved": ach, "unit": "TFLOP/s (algorithmic fp32-equivalent FLOP)",
                          "executed_bf16_tflops": 3.0 * ach if ach else None, "peak": PEAK_BF16_MFMA_TFLOPS,

@@ -350,7 +350,8 @@ def test_standalone_effects_from_draws_match_oracle_and_the_fused_pass(binary):
             model.infer_from_latent_posterior(draws.cpu().numpy())
 
 
-def test_outcome_cache_is_bit_identical():
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16x3"])
+def test_outcome_cache_is_bit_identical(precision):
     """bgm_causal_set_outcome_cache: a retained iteration in which no chain of a wave moved takes the outcome net's (mean, sd) at every
     dose from the previous evaluation (csrc/causal_kernels.h causal_effects_cached).  Same Philox streams with the cache on and off: the
     ADRF draw sums, the chains and the acceptance counts are equal to the last bit, and the cache is actually used."""
@@ -359,6 +360,7 @@ def test_outcome_cache_is_bit_identical():
     x, y, v = _data(3000, 200, 12)          # 188 tiles, the last one ragged
     xs = np.linspace(0, 3, 20)
     eng = _engine(m)
+    eng.set_precision(precision)
     outs = {}
     for on in (True, False):
         eng.set_outcome_cache(on)
