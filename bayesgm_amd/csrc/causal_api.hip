@@ -433,14 +433,16 @@ extern "C" int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *a, void *stre
   if (split > a->it_begin) segs[nseg++] = {a->it_begin, split - a->it_begin, BGM_EFFECT_NONE, a->init};
   if (it_end > split) segs[nseg++] = {split, it_end - split, a->effect, (nseg == 0) ? a->init : 0};
   const int n_slots = grid * MH_WAVES;
-  if (a->effect == BGM_EFFECT_ADRF && it_end > split) {      // (mean, sd) of the outcome net per wave slot, pass and lane: causal_effects_cached
-    const size_t need = (size_t)n_slots * (size_t)((a->n_doses + 3) / 4) * 64 * 2;
-    if (h->eff_cache_cap < need) {
-      if (h->eff_cache) BGM_HIP_CHECK(hipFree(h->eff_cache));
-      BGM_HIP_CHECK(hipMalloc(&h->eff_cache, need * sizeof(float)));
-      h->eff_cache_cap = need;
-    }
-    ka.eff_cache = h->eff_cache;
+  if (a->effect != BGM_EFFECT_NONE && it_end > split) {
+    if (a->effect == BGM_EFFECT_ADRF) {      // (mean, sd) of the outcome net per wave slot, pass and lane: causal_effects_cached
+      const size_t need = (size_t)n_slots * (size_t)((a->n_doses + 3) / 4) * 64 * 2;
+      if (h->eff_cache_cap < need) {
+        if (h->eff_cache) BGM_HIP_CHECK(hipFree(h->eff_cache));
+        BGM_HIP_CHECK(hipMalloc(&h->eff_cache, need * sizeof(float)));
+        h->eff_cache_cap = need;
+      }
+      ka.eff_cache = h->eff_cache;
+    }                                        // (binary treatment: the two arms' pairs stay in registers, causal_ite_cached)
     ka.eff_skip = h->outcome_cache ? 1 : 0;
     if (!h->eff_stats_dev) {
       BGM_HIP_CHECK(hipMalloc(&h->eff_stats_dev, 2 * sizeof(unsigned long long)));

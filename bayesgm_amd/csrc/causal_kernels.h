@@ -465,7 +465,8 @@ __device__ __forceinline__ void causal_effects(const float *lds, const CausalMet
                                                const bool (&valid)[R], long long row0, long long n, unsigned it,
                                                long long d, int n_keep, int sample_y, int n_doses,
                                                const float *x_values, float *adrf_slot, float *ite, unsigned k0,
-                                               unsigned k1, float2 *cache = nullptr) {
+                                               unsigned k1, float2 *cache = nullptr, float *ite_c = nullptr) {
+  // ite_c (EFFECT == 2, one row tile per wave, CACHE): [4] registers of the caller receiving (mean, sd) of the two arms
   BGM_NO_HOIST();
   f32x4 z0in[R][KT1];
 #pragma unroll
@@ -479,7 +480,7 @@ __device__ __forceinline__ void causal_effects(const float *lds, const CausalMet
   f32x4 wx[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) wx[t] = *reinterpret_cast<const f32x4 *>(lds + m.wxf + 16 * t + 4 * g);
-  const int nd = (EFFECT == 2) ? 2 : n_doses;
+  const int nd = (EFFECT == 2) ? (CACHE && n_doses == 0 ? 0 : 2) : n_doses;     // (CACHE: n_doses = 0 switches the evaluation off)
   constexpr int DB = (EFFECT == 2) ? 2 : 4;  // doses evaluated per pass (independent MFMA chains)
   constexpr bool GROUPED = (EFFECT == 1 && R == 1 && GROUPING);   // lane group g finishes dose e = g of a pass (see above)
   const int n_calls = (nd + 3) >> 2, n_own = GROUPED ? (n_calls & ~3) : 0;   // Philox calls [0, n_own) in groups of four
@@ -596,7 +597,9 @@ __device__ __forceinline__ void causal_effects(const float *lds, const CausalMet
 #pragma unroll
       for (int rr = 0; rr < R; ++rr) {
         const float s2 = (m.sig2_y > 0.0f) ? m.sig2_y : softplus_f(sr[e * R + rr]) + BGM_EPS;
-        yk[e][rr] = sample_y ? fmaf(__builtin_sqrtf(s2), nz[rr][e], mu[e * R + rr]) : mu[e * R + rr];
+        const float sd = __builtin_sqrtf(s2);
+        if constexpr (CACHE && EFFECT == 2 && R == 1) { ite_c[2 * e] = mu[e * R + rr]; ite_c[2 * e + 1] = sd; }
+        yk[e][rr] = sample_y ? fmaf(sd, nz[rr][e], mu[e * R + rr]) : mu[e * R + rr];
       }
     if constexpr (EFFECT == 1) {
 #pragma unroll
@@ -644,6 +647,18 @@ __device__ __forceinline__ void causal_effects_cached(int g, int j, int lane, un
     if (j == 15 && k < nd) unsafeAtomicAdd(adrf_slot + (long long)d * nd + k, tot);
     c = cn;
   }
+}
+
+// The same for the individual treatment effects of a binary treatment (EFFECT == 2): y(1) - y(0) of a retained iteration in which no
+// chain of the wave moved, from the (mean, sd) of the two arms kept in registers; the ungrouped noise plan of causal_effects (one
+// Philox call, word e for arm e).
+__device__ __forceinline__ void causal_ite_cached(int g, int j, unsigned rowid, long long row, long long n, unsigned it, long long d,
+                                                  int n_keep, int sample_y, float *ite, unsigned k0, unsigned k1, const float (&c)[4]) {
+  f32x4 nz = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  if (sample_y) nz = box_muller4(philox4x32_10(rowid, it, 0u, TAG_YNOISE, k0, k1));
+  const float y1 = sample_y ? fmaf(c[1], nz[0], c[0]) : c[0];
+  const float y0 = sample_y ? fmaf(c[3], nz[1], c[2]) : c[2];
+  if (g == 0 && row < n) ite[row * (long long)n_keep + d] = y1 - y0;
 }
 
 // ---------------------------------------------------------------------------
@@ -726,6 +741,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
     uint4 uacc[R];
     bool eff_cached = false;      // the slot's cache holds the outcome-net values of the tile's current states
     unsigned n_eff_skipped = 0u, n_eff_total = 0u;
+    float ite_c[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // EFFECT == 2: (mean, sd) of the two arms at the tile's current states
 #ifdef BGM_PROF
     tlast = __builtin_readcyclecounter();
 #endif
@@ -822,6 +838,14 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
           eff_cached = true;
           n_eff_skipped += skip ? 1u : 0u;
           ++n_eff_total;
+        } else if constexpr (EFFECT == 2 && R == 1) {
+          const bool skip = a.eff_skip && eff_cached && accmask == 0ull;                // wave-uniform: nobody moved
+          causal_effects<KT1, KSL1, R, EFFECT, true, true>(lds, m, lane_off, g, j, lane, zs, rowid, valid, row0, n, (unsigned)it, d, a.n_keep,
+                                                            a.sample_y, skip ? 0 : 2, a.x_values, a.adrf_partial, a.ite, a.k0, a.k1, nullptr, ite_c);
+          if (skip) causal_ite_cached(g, j, rowid[0], row0 + j, n, (unsigned)it, d, a.n_keep, a.sample_y, a.ite, a.k0, a.k1, ite_c);
+          eff_cached = true;
+          n_eff_skipped += skip ? 1u : 0u;
+          ++n_eff_total;
         } else if constexpr (EFFECT != 0) {
           causal_effects<KT1, KSL1, R, EFFECT>(lds, m, lane_off, g, j, lane, zs, rowid, valid, row0, n, (unsigned)it, d,
                                                 a.n_keep, a.sample_y, a.n_doses, a.x_values,
@@ -830,7 +854,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
         }
       }
     }
-    if constexpr (EFFECT == 1 && R == 1) {
+    if constexpr (EFFECT != 0 && R == 1) {
       if (a.eff_stats != nullptr && lane == 0 && n_eff_total != 0u) {
         atomicAdd(&a.eff_stats[0], (unsigned long long)n_eff_skipped);
         atomicAdd(&a.eff_stats[1], (unsigned long long)n_eff_total);

@@ -203,12 +203,12 @@ BGM_API int bgm_row_mean_quantiles(bgm_handle *h, const float *in_dev, int64_t n
                            double q_lo, double q_hi, float *mean_dev, float *lo_dev,
                            float *hi_dev, void *stream);
 
-/* Outcome-net cache of the fused ADRF sampler (bgm_causal_mh_run with BGM_EFFECT_ADRF on the LDS-resident fp32 kernels).
+/* Outcome-net cache of the fused effect samplers (bgm_causal_mh_run with BGM_EFFECT_ADRF / BGM_EFFECT_ITE on the LDS-resident kernels).
  * infer_from_latent_posterior (causalbgm/base.py:671-763) evaluates f(z, x_e) for every retained draw; consecutive draws of a
  * Metropolis-Hastings chain are equal whenever the proposal was rejected (base.py:868-871), and f is deterministic, so its (mean, sd)
  * at every dose are unchanged.  With the cache on (default), a retained iteration in which none of the 16 chains of a wave moved takes
- * them from the previous evaluation and only draws the new outcome noise: the ADRF sums are bit-identical, the 20 dose evaluations
- * are skipped.  on = 0 evaluates the outcome net at every retained iteration, as the reference does.
+ * them from the previous evaluation and only draws the new outcome noise: the ADRF sums / treatment effects are bit-identical, the
+ * dose evaluations are skipped.  on = 0 evaluates the outcome net at every retained iteration, as the reference does.
  * bgm_causal_outcome_cache_stats: out2[0] = retained tile-iterations served from the cache, out2[1] = retained tile-iterations. */
 BGM_API int bgm_causal_set_outcome_cache(bgm_handle *h, int32_t on);
 BGM_API int bgm_causal_outcome_cache_stats(bgm_handle *h, int64_t *out2, int32_t reset);

@@ -32,7 +32,9 @@ mx, mn = t.clone(), t.clone()
 dist.all_reduce(mx, op=dist.ReduceOp.MAX); dist.all_reduce(mn, op=dist.ReduceOp.MIN)
 spread = float((mx - mn).abs().max().item())
 digest = float(np.abs(imp[np.isnan(miss)]).sum())
-print(json.dumps(dict(rank=dist.get_rank(), rows=int(m.data_z.shape[0]), history=[float(h) for h in m.history_loss], param_spread=spread,
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from dp_print import print_in_rank_order
+print_in_rank_order(json.dumps(dict(rank=dist.get_rank(), rows=int(m.data_z.shape[0]), history=[float(h) for h in m.history_loss], param_spread=spread,
                       imputed_digest=digest)))
 assert spread == 0.0 and np.isfinite(flat).all()      # (8 epochs from random latents do not reduce the noisy MSE yet)
 dist.destroy_process_group()

@@ -33,6 +33,8 @@ t = torch.from_numpy(flat).cuda()
 mx, mn = t.clone(), t.clone()
 dist.all_reduce(mx, op=dist.ReduceOp.MAX); dist.all_reduce(mn, op=dist.ReduceOp.MIN)
 spread = float((mx - mn).abs().max().item())
-print(json.dumps(dict(rank=dist.get_rank(), rows=int(m.data_z.shape[0]), history=[float(h) for h in m.history_loss], param_spread=spread)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from dp_print import print_in_rank_order
+print_in_rank_order(json.dumps(dict(rank=dist.get_rank(), rows=int(m.data_z.shape[0]), history=[float(h) for h in m.history_loss], param_spread=spread)))
 assert spread == 0.0 and m.history_loss[-1] < m.history_loss[0]
 dist.destroy_process_group()

@@ -27,7 +27,9 @@ t = torch.from_numpy(np.concatenate([theta, adrf.ravel(), interval.ravel()]).ast
 mx, mn = t.clone(), t.clone()
 dist.all_reduce(mx, op=dist.ReduceOp.MAX); dist.all_reduce(mn, op=dist.ReduceOp.MIN)
 spread = float((mx - mn).abs().max().item())
-print(json.dumps(dict(rank=dist.get_rank(), spread=spread, adrf=[float(a) for a in adrf], adrf_untrained=[float(a) for a in adrf0],
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from dp_print import print_in_rank_order
+print_in_rank_order(json.dumps(dict(rank=dist.get_rank(), spread=spread, adrf=[float(a) for a in adrf], adrf_untrained=[float(a) for a in adrf0],
                       interval_untrained=[float(a) for a in interval0.ravel()])))
 assert spread == 0.0 and np.all(np.isfinite(adrf)) and np.all(np.isfinite(theta))
 dist.destroy_process_group()

@@ -27,7 +27,9 @@ for use_bnn in (False, True):
     res[key] = dict(spread=float((mx - mn).abs().max().item()), moved=float(np.abs(w - w0).max()), finite=bool(np.all(np.isfinite(w))),
                     late_l2z=m._egm_late_l2z)
     saved[key] = w
-print(json.dumps(dict(rank=dist.get_rank(), **res)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from dp_print import print_in_rank_order
+print_in_rank_order(json.dumps(dict(rank=dist.get_rank(), **res)))
 if out_path and dist.get_rank() == 0:
     np.savez(out_path, **saved)
 assert all(r["spread"] == 0.0 and r["finite"] for r in res.values())

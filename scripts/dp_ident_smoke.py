@@ -45,6 +45,8 @@ mx, mn = t.clone(), t.clone()
 dist.all_reduce(mx, op=dist.ReduceOp.MAX); dist.all_reduce(mn, op=dist.ReduceOp.MIN)
 out.update(fit_spread=float((mx - mn).abs().max().item()), fit_finite=bool(np.all(np.isfinite(flat))),
            fit_loss=[h["loss_postrior_z"] for h in mf.fit_history], fit_mse_v=[h.get("mse_v") for h in mf.fit_history if "mse_v" in h])
-print(json.dumps(out))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from dp_print import print_in_rank_order
+print_in_rank_order(json.dumps(out))
 assert out["fit_spread"] == 0.0 and out["fit_finite"]
 dist.destroy_process_group()

@@ -381,3 +381,21 @@ def test_outcome_cache_is_bit_identical(precision):
             res.append(eng.mh_sample(x, y, v, 10, 30, 1.0, 6, effect=_lib.EFFECT_ADRF, **kw)["adrf"].cpu().numpy())
         eng.set_outcome_cache(True)
         assert np.array_equal(res[0], res[1])
+
+
+def test_outcome_cache_binary_treatment_is_bit_identical():
+    """The same for the individual treatment effects of a binary treatment (causal_ite_cached: the two arms' (mean, sd) in registers)."""
+    from bayesgm_amd import _lib
+    m = _model(13, [3, 3, 6, 6], 100, True)
+    x, y, v = _data(2000, 100, 14, True)
+    eng = _engine(m)
+    res = {}
+    for on in (True, False):
+        eng.set_outcome_cache(on)
+        eng.outcome_cache_stats(reset=True)
+        out = eng.mh_sample(x, y, v, 30, 50, 1.0, 9, effect=_lib.EFFECT_ITE)
+        res[on] = (out["ite"].cpu().numpy(), eng.outcome_cache_stats())
+    eng.set_outcome_cache(True)
+    print("served from cache: %d of %d" % res[True][1])
+    assert res[True][1][1] == 125 * 50 and res[True][1][0] > 0 and res[False][1][0] == 0
+    assert np.array_equal(res[True][0], res[False][0])
