@@ -64,7 +64,8 @@ struct bgm_handle {
   float *eff_cache = nullptr;
   size_t eff_cache_cap = 0;
   int outcome_cache = 1;                          // bgm_causal_set_outcome_cache
-  unsigned long long *eff_stats_dev = nullptr;    // [2]: retained tile-iterations served from the cache, retained tile-iterations
+  unsigned long long *eff_stats_dev = nullptr;    // [0]: retained tile-iterations served from the cache
+  unsigned long long eff_total = 0;               // retained tile-iterations launched since the last reset
   bool bx_valid = false;
   alignas(8) unsigned char bx_meta_store[192];
   // per-row conditional latent prior of the sampling kernels (causal_prior_api.hip, bgm_causal_set_prior); NULL = standard normal

@@ -449,6 +449,7 @@ extern "C" int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *a, void *stre
       BGM_HIP_CHECK(hipMemsetAsync(h->eff_stats_dev, 0, 2 * sizeof(unsigned long long), stream));
     }
     ka.eff_stats = h->eff_stats_dev;
+    h->eff_total += (unsigned long long)((a->n + 15) / 16) * (unsigned long long)(it_end - split);      // retained tile-iterations launched
   }
   for (int s = 0; s < nseg; ++s) {
     ka.it_begin = segs[s].begin; ka.n_iters = segs[s].n; ka.init = segs[s].init;
@@ -597,8 +598,8 @@ extern "C" int bgm_causal_outcome_cache_stats(bgm_handle *h, int64_t *out2, int3
   BGM_HIP_CHECK(hipDeviceSynchronize());
   unsigned long long v[2];
   BGM_HIP_CHECK(hipMemcpy(v, h->eff_stats_dev, sizeof(v), hipMemcpyDeviceToHost));
-  out2[0] = (int64_t)v[0]; out2[1] = (int64_t)v[1];
-  if (reset) BGM_HIP_CHECK(hipMemset(h->eff_stats_dev, 0, sizeof(v)));
+  out2[0] = (int64_t)v[0]; out2[1] = (int64_t)h->eff_total;
+  if (reset) { BGM_HIP_CHECK(hipMemset(h->eff_stats_dev, 0, sizeof(v))); h->eff_total = 0; }
   return BGM_OK;
 }
 

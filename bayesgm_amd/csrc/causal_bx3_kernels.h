@@ -589,7 +589,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_bx3_kernel(CausalBxKArgs
     }
     uint4 uacc = make_uint4(0u, 0u, 0u, 0u);
     bool eff_cached = false;      // outcome-net cache of the retained iterations: see causal_mh_kernel
-    unsigned n_eff_skipped = 0u, n_eff_total = 0u;
+    unsigned n_eff_skipped = 0u;
     for (int it = a.it_begin; it < a.it_begin + a.n_iters; ++it) {
       BGM_NO_HOIST();
       if constexpr (WAVES == 8) {
@@ -642,7 +642,6 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_bx3_kernel(CausalBxKArgs
           if (skip) causal_effects_cached(g, j, lane, rowid, valid, (unsigned)it, d, a.sample_y, a.n_doses, adrf_slot, a.k0, a.k1, cache);
           eff_cached = true;
           n_eff_skipped += skip ? 1u : 0u;
-          ++n_eff_total;
         } else if constexpr (EFFECT != 0) {
           causal_effects_bx3<KT1, NTL, EFFECT>(bx_lds, m, lane, g, j, zs[0], rowid, valid, row, n, (unsigned)it, d, a.n_keep, a.sample_y,
                                           a.n_doses, a.x_values,
@@ -651,10 +650,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_bx3_kernel(CausalBxKArgs
       }
     }
     if constexpr (EFFECT == 1) {
-      if (a.eff_stats != nullptr && lane == 0 && n_eff_total != 0u) {
-        atomicAdd(&a.eff_stats[0], (unsigned long long)n_eff_skipped);
-        atomicAdd(&a.eff_stats[1], (unsigned long long)n_eff_total);
-      }
+      if (a.eff_stats != nullptr && lane == 0 && n_eff_skipped != 0u) atomicAdd(&a.eff_stats[0], (unsigned long long)n_eff_skipped);
     }
     store_z_rows<KT1, 1>(a.state, n, m.q, row0, j, g, zs);
     if (g == 0 && valid) a.logp[row] = lp;

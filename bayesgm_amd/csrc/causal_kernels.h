@@ -48,7 +48,7 @@ struct CausalMhKArgs {
   const float *prior_tab;   // [n_segments][q + 2]: mu(u) [q], 1 / sigma^2(u), (q / 2) log sigma^2(u)
   float *eff_cache;         // ADRF kernels with one row tile per wave: [n_slots][ceil(n_doses / 4)][64][2] (mean, sd) of the lane's dose
   int eff_skip;             // 1: a retained iteration in which no chain of the wave moved reuses the cached (mean, sd)
-  unsigned long long *eff_stats;   // [2] += (retained tile-iterations served from the cache, retained tile-iterations), or NULL
+  unsigned long long *eff_stats;   // [0] += retained tile-iterations served from the cache (the total is known on the host), or NULL
   CausalMeta m;
 };
 
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
 
     uint4 uacc[R];
     bool eff_cached = false;      // the slot's cache holds the outcome-net values of the tile's current states
-    unsigned n_eff_skipped = 0u, n_eff_total = 0u;
+    unsigned n_eff_skipped = 0u;
     float ite_c[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // EFFECT == 2: (mean, sd) of the two arms at the tile's current states
 #ifdef BGM_PROF
     tlast = __builtin_readcyclecounter();
@@ -837,7 +837,6 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
           if (skip) causal_effects_cached(g, j, lane, rowid[0], valid[0], (unsigned)it, d, a.sample_y, a.n_doses, adrf_slot, a.k0, a.k1, cache);
           eff_cached = true;
           n_eff_skipped += skip ? 1u : 0u;
-          ++n_eff_total;
         } else if constexpr (EFFECT == 2 && R == 1) {
           const bool skip = a.eff_skip && eff_cached && accmask == 0ull;                // wave-uniform: nobody moved
           causal_effects<KT1, KSL1, R, EFFECT, true, true>(lds, m, lane_off, g, j, lane, zs, rowid, valid, row0, n, (unsigned)it, d, a.n_keep,
@@ -845,7 +844,6 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
           if (skip) causal_ite_cached(g, j, rowid[0], row0 + j, n, (unsigned)it, d, a.n_keep, a.sample_y, a.ite, a.k0, a.k1, ite_c);
           eff_cached = true;
           n_eff_skipped += skip ? 1u : 0u;
-          ++n_eff_total;
         } else if constexpr (EFFECT != 0) {
           causal_effects<KT1, KSL1, R, EFFECT>(lds, m, lane_off, g, j, lane, zs, rowid, valid, row0, n, (unsigned)it, d,
                                                 a.n_keep, a.sample_y, a.n_doses, a.x_values,
@@ -855,10 +853,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
       }
     }
     if constexpr (EFFECT != 0 && R == 1) {
-      if (a.eff_stats != nullptr && lane == 0 && n_eff_total != 0u) {
-        atomicAdd(&a.eff_stats[0], (unsigned long long)n_eff_skipped);
-        atomicAdd(&a.eff_stats[1], (unsigned long long)n_eff_total);
-      }
+      if (a.eff_stats != nullptr && lane == 0 && n_eff_skipped != 0u) atomicAdd(&a.eff_stats[0], (unsigned long long)n_eff_skipped);
     }
     // ---- write the chain state back
     store_z_rows<KT1, R>(a.state, n, m.q, row0, j, g, zs);
