@@ -22,8 +22,17 @@ for rep in range(2):
     torch.cuda.synchronize(); t0 = time.time()
     ite, interval = m.predict((xb, y, v), alpha=0.01, n_mcmc=3000, burn_in=5000, verbose=0)
     torch.cuda.synchronize(); dt = time.time() - t0
+served, total = m.engine.outcome_cache_stats(reset=True)
+m.engine.set_outcome_cache(False)       # the same call with the outcome net evaluated at every retained draw (the reference's work)
+m._seed_counter -= 1
+torch.cuda.synchronize(); t0 = time.time()
+ite_full, _ = m.predict((xb, y, v), alpha=0.01, n_mcmc=3000, burn_in=5000, verbose=0)
+torch.cuda.synchronize(); dt_full = time.time() - t0
+m.engine.set_outcome_cache(True)
 out["C1_causal_binary_N1e5_p100"] = dict(predict_s=dt, transitions_per_s=N * 8000 / dt, acceptance=m.last_acceptance_rate,
-                                         ate=float(ite.mean()), shapes=[list(ite.shape), list(interval.shape)])
+                                         ate=float(ite.mean()), shapes=[list(ite.shape), list(interval.shape)],
+                                         outcome_cache_served_fraction=served / max(1, total), predict_s_cache_off=dt_full,
+                                         ite_identical_with_cache_off=bool(np.array_equal(ite, ite_full)))
 cases = [(2000, 20, 5000, 5000, False), (100000, 100, 1000, 1000, False)]
 if "--only-c4" in sys.argv:
     cases = []
