@@ -198,6 +198,23 @@ int gx_mh_run(bgm_handle *h, const bgm_mh_args *a, hipStream_t stream) {
   k.e.ite = a->ite_dev; k.e.k0 = k.k0; k.e.k1 = k.k1;
   k.adrf_partial = a->adrf_partial_dev;
   const int grid = grid_for(h, s, a->n);
+  const int it_end = a->it_begin + a->n_iters;
+  if (a->effect != BGM_EFFECT_NONE && it_end > a->burn_in) {      // outcome-net cache of the retained iterations (bgm_causal_set_outcome_cache)
+    const size_t need = (size_t)grid * (size_t)(a->effect == BGM_EFFECT_ITE ? 2 : a->n_doses) * GX_ROWS * 2;
+    if (h->eff_cache_cap < need) {
+      if (h->eff_cache) BGM_HIP_CHECK(hipFree(h->eff_cache));
+      BGM_HIP_CHECK(hipMalloc(&h->eff_cache, need * sizeof(float)));
+      h->eff_cache_cap = need;
+    }
+    if (!h->eff_stats_dev) {
+      BGM_HIP_CHECK(hipMalloc(&h->eff_stats_dev, 2 * sizeof(unsigned long long)));
+      BGM_HIP_CHECK(hipMemsetAsync(h->eff_stats_dev, 0, 2 * sizeof(unsigned long long), stream));
+    }
+    k.e.cache = reinterpret_cast<float2 *>(h->eff_cache);
+    k.e.eff_skip = h->outcome_cache ? 1 : 0;
+    k.e.stats = h->eff_stats_dev;
+    h->eff_total += (unsigned long long)((a->n + 15) / 16) * (unsigned long long)(it_end - std::max(a->burn_in, a->it_begin));
+  }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (h->timing) { BGM_HIP_CHECK(hipEventCreate(&e0)); BGM_HIP_CHECK(hipEventCreate(&e1)); BGM_HIP_CHECK(hipEventRecord(e0, stream)); }
   auto launch = [&](auto kern) {

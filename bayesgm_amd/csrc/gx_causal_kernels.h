@@ -191,29 +191,44 @@ struct GxEffArgs {
   float *adrf_slot;      // this workgroup's [n_keep][n_doses] block (EFFECT 1)
   float *ite;            // [n][n_keep] (EFFECT 2)
   unsigned k0, k1;
+  // outcome-net cache of the fused sampler (see causal_effects_cached in causal_kernels.h; here per workgroup = 32 chains):
+  float2 *cache;         // this workgroup's [n_doses][GX_ROWS] (mean, sd), or NULL (stand-alone effects, evaluate)
+  int eff_skip;          // 1: a retained iteration in which none of the workgroup's chains moved reuses them
+  unsigned long long *stats;   // [0] += retained tile-iterations served from the cache (2 row tiles per workgroup), or NULL
 };
 
+// skip (block-uniform): the chains of the workgroup did not move since the last evaluation: (mean, sd) of every dose come from e.cache
+// and only the outcome noise is new -- same operations in the same order, bit-identical sums.
 template <int EFFECT>
 __device__ __forceinline__ void gx_causal_effects(const GxCausalModel &m, const GxLds &L, const float *z, long long row0, long long n,
-                                                  long long row_base, unsigned it, long long d, const GxEffArgs &e) {
+                                                  long long row_base, unsigned it, long long d, const GxEffArgs &e, bool skip = false) {
   const int nd = (EFFECT == 2) ? 2 : e.n_doses;
   float ykeep = 0.0f;        // EFFECT 2: y(x = 1) of thread `row`
   for (int k0 = 0; k0 < nd; k0 += m.db) {
     const int nb = min(m.db, nd - k0);
-    gx_f_forward(m, L, z, [&](int, int dd) { const int k = k0 + dd; return (EFFECT == 2) ? (k == 0 ? 1.0f : 0.0f) : e.x_values[k]; }, nb);
+    if (!skip) gx_f_forward(m, L, z, [&](int, int dd) { const int k = k0 + dd; return (EFFECT == 2) ? (k == 0 ? 1.0f : 0.0f) : e.x_values[k]; }, nb);
     if (threadIdx.x < GX_ROWS) {
       const int r = threadIdx.x;
       const bool valid = row0 + r < n;
       for (int dd = 0; dd < nb; ++dd) {
         const int k = k0 + dd;
-        float yv = L.fo[2 * (GX_ROWS * dd + r)];
-        if (e.sample_y) {
+        float mean, sd;
+        if (!skip) {
+          mean = L.fo[2 * (GX_ROWS * dd + r)];
           const float s2y = (m.sig2_y > 0.0f) ? m.sig2_y : softplus_f(L.fo[2 * (GX_ROWS * dd + r) + 1]) + BGM_EPS;
+          sd = __builtin_sqrtf(s2y);
+          if (e.cache) e.cache[k * GX_ROWS + r] = make_float2(mean, sd);
+        } else {
+          const float2 c = e.cache[k * GX_ROWS + r];
+          mean = c.x; sd = c.y;
+        }
+        float yv = mean;
+        if (e.sample_y) {
           const unsigned rowid = (unsigned)(row_base + row0 + r);
           const f32x4 nz = box_muller4(philox4x32_10(rowid, it, (unsigned)(k >> 2), TAG_YNOISE, e.k0, e.k1));
           const int w = k & 3;
           const float eps = w == 0 ? nz[0] : (w == 1 ? nz[1] : (w == 2 ? nz[2] : nz[3]));
-          yv = fmaf(__builtin_sqrtf(s2y), eps, yv);
+          yv = fmaf(sd, eps, yv);
         }
         if (EFFECT == 1) {
           float tot = valid ? yv : 0.0f;
@@ -252,9 +267,12 @@ __global__ __launch_bounds__(GX_THREADS) void gx_causal_mh_kernel(GxMhArgs a) {
   const long long n = a.n, tiles = (n + GX_ROWS - 1) / GX_ROWS;
   GxEffArgs e = a.e;
   if (EFFECT == 1) e.adrf_slot = a.adrf_partial + (long long)blockIdx.x * e.n_keep * e.n_doses;
+  if (EFFECT != 0 && e.cache) e.cache += (long long)blockIdx.x * ((EFFECT == 2) ? 2 : e.n_doses) * GX_ROWS;
+  unsigned n_served = 0u;
   const int ncall = (q + 15) >> 4;            // Philox calls per lane group: features 16 t + 4 e + g  <-  call g + 4 t, output e
   for (long long t = blockIdx.x; t < tiles; t += gridDim.x) {
     const long long row0 = t * GX_ROWS;
+    bool eff_cached = false;      // e.cache holds the outcome-net values of this tile's current states
     // ---- chain state
     if (a.init) {            // current_state ~ N(0, 1), base.py:842 (tag 0, iteration 0)
       for (int i = threadIdx.x; i < GX_ROWS * 4 * ncall; i += GX_THREADS) {
@@ -299,8 +317,10 @@ __global__ __launch_bounds__(GX_THREADS) void gx_causal_mh_kernel(GxMhArgs a) {
         }
         const unsigned long long bal = __ballot(acc && (row0 + r < n) && threadIdx.x < GX_ROWS);
         if (a.acc_count && threadIdx.x == 0) atomicAdd(&a.acc_count[it], (unsigned)__popcll(bal));
+        if (threadIdx.x == 0) L.red[GX_ROWS] = bal != 0ull ? 1.0f : 0.0f;        // did any chain of the workgroup move?
       }
       __syncthreads();
+      const bool moved = L.red[GX_ROWS] != 0.0f;
       for (int i = threadIdx.x; i < GX_ROWS * q; i += GX_THREADS)
         if (L.red[i / q] != 0.0f) L.zc[i] = L.zp[i];
       __syncthreads();
@@ -312,7 +332,12 @@ __global__ __launch_bounds__(GX_THREADS) void gx_causal_mh_kernel(GxMhArgs a) {
             if (gr < n) a.draws[(d * n + gr) * q + i % q] = L.zc[i];
           }
         }
-        if (EFFECT != 0) gx_causal_effects<EFFECT>(m, L, L.zc, row0, n, a.row_base, (unsigned)it, d, e);
+        if (EFFECT != 0) {
+          const bool skip = e.cache != nullptr && e.eff_skip && eff_cached && !moved;      // block-uniform
+          gx_causal_effects<EFFECT>(m, L, L.zc, row0, n, a.row_base, (unsigned)it, d, e, skip);
+          eff_cached = true;
+          n_served += skip ? 2u : 0u;
+        }
       }
     }
     // ---- write the chain state back
@@ -323,6 +348,7 @@ __global__ __launch_bounds__(GX_THREADS) void gx_causal_mh_kernel(GxMhArgs a) {
     if (threadIdx.x < GX_ROWS && row0 + threadIdx.x < n) a.logp[row0 + threadIdx.x] = L.lpc[threadIdx.x];
     __syncthreads();
   }
+  if (EFFECT != 0 && e.stats != nullptr && threadIdx.x == 0 && n_served != 0u) atomicAdd(&e.stats[0], (unsigned long long)n_served);
 }
 
 // stand-alone effects on a tensor of draws [n_keep][n][q]

@@ -175,6 +175,31 @@ def test_mh_chain_and_effects_match_oracle(case):
     assert np.abs(alone - ref_eff).max() <= 5e-4
 
 
+@pytest.mark.parametrize("shape,binary", [("r_test", False), ("w128", False), ("mixed", True)])
+def test_outcome_cache_on_the_general_width_engine_is_bit_identical(shape, binary):
+    """bgm_causal_set_outcome_cache on the general-width engine (gx_causal_mh_kernel: a workgroup of 32 chains reuses the outcome net's
+    (mean, sd) when none of them moved): effects, chains and acceptance counts equal to the last bit with the cache on and off."""
+    from bayesgm_amd import _lib
+    u = SHAPES[shape]
+    m = _model(31, [2, 2, 2, 6], 60, binary, **u)
+    x, y, v = _data(700, 60, 32, binary)
+    eng = _engine(m, u)
+    xs = np.linspace(0, 3, 9)
+    kw = dict(effect=_lib.EFFECT_ITE) if binary else dict(effect=_lib.EFFECT_ADRF, x_values=xs)
+    res = {}
+    for on in (True, False):
+        eng.set_outcome_cache(on)
+        eng.outcome_cache_stats(reset=True)
+        out = eng.mh_sample(x, y, v, 20, 40, 1.5, 77, want_draws=True, sample_y=True, **kw)
+        eff = (out["ite"] if binary else out["adrf"]).cpu().numpy()
+        res[on] = (eff, out["draws"].cpu().numpy(), out["acc_count"].cpu().numpy(), eng.outcome_cache_stats())
+    eng.set_outcome_cache(True)
+    print("served from cache: %d of %d retained tile-iterations" % res[True][3])
+    assert res[True][3][0] > 0 and res[False][3][0] == 0 and res[True][3][1] == 44 * 40
+    for a, b in zip(res[True][:3], res[False][:3]):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("case", [CASES[0], CASES[2], CASES[3]])
 def test_evaluate_matches_oracle(case):
     import torch
