@@ -47,8 +47,8 @@ bool bnf_build_bnn(const BnnState *s, BnfState &st, BnfTabs &tb) {
 #define BNF_W 8
 #endif
 #ifndef BNF_ER
-#define BNF_ER 1
-#define BNF_EW 12
+#define BNF_ER 2
+#define BNF_EW 8
 #endif
 struct BnfCfg { int R, W; };
 BnfCfg env_cfg(const char *name, BnfCfg d) {
