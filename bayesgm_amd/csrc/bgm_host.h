@@ -100,6 +100,7 @@ struct bgm_handle {
   hipStream_t epoch_stream = nullptr;
   unsigned *epoch_ctr = nullptr;      // device: [0] gradient-tile workgroups done, [1] latent-phase workgroups done, [2] a wait gave up (fit_types.h FitSync)
   int epoch_flags_ok = 0;             // 0: not probed yet, 1: the two streams run side by side (device-side ordering is safe), -1: they do not
+  void *epoch_probe_stream = nullptr; // the caller stream that probe was made with (a different one is probed again)
   unsigned epoch_theta_done = 0, epoch_z_done = 0;      // the counters' values once everything issued so far is done
   hipEvent_t epoch_ev_t[4] = {}, epoch_ev_z[4] = {}, epoch_ev_s = nullptr;      // one pair per minibatch in flight (BGM_EPOCH_DEPTH_MAX)
   void *gx_state = nullptr;   // GxState (gx_api.hip): general-width engine (hidden widths / depths outside the compiled families)

@@ -498,10 +498,11 @@ extern "C" int bgm_bnn_fit_epoch(bgm_handle *h, const float *x, const float *y, 
       BGM_HIP_CHECK(hipMemsetAsync(h->epoch_ctr, 0, sizeof(unsigned) * 8, sA));
       h->epoch_theta_done = h->epoch_z_done = 0;
     } else if ((rc = bnn_epoch_check(h, sA))) return rc;
-    if (!h->epoch_flags_ok) {      // once per handle: do the two streams run side by side (fit_sync.h)?
+    if (!h->epoch_flags_ok || h->epoch_probe_stream != (void *)sA) {      // once per handle and caller stream: do the two streams run side by side (fit_sync.h)?
       int ok = 0;
       BGM_HIP_CHECK(fit_sync_probe(sA, sB, h->epoch_ctr + 4, &ok));
       h->epoch_flags_ok = ok ? 1 : -1;
+      h->epoch_probe_stream = (void *)sA;
     }
     if (h->epoch_flags_ok < 0) flags = false;      // (a profiler serialising kernels, one hardware queue): HIP events
   }
@@ -509,10 +510,27 @@ extern "C" int bgm_bnn_fit_epoch(bgm_handle *h, const float *x, const float *y, 
   const int q = s->q;
   const unsigned dw_blocks = fc ? (unsigned)((fc->n_tiles + ECH_WAVES - 1) / ECH_WAVES + 1) : 0, zr_blocks = (unsigned)((batch * q + 255) / 256);
   auto rows_of = [&](int64_t i) { return (int)std::max<int64_t>(0, std::min<int64_t>(batch, n_use - i)); };
+  const long long tz0 = s->t_z;
+  long long replayed_to = 0;                 // minibatches (ordinals) [k, replayed_to) have been replayed ahead but not stepped
   auto replay_ahead = [&](int64_t i, int ofs, hipStream_t st) -> int {      // minibatch at perm + i, `ofs` latent steps from now
     const int bj = rows_of(i);
     if (bj < 2) return BGM_OK;
-    return bnn_z_sync_impl(h, data_z, zm, zv, perm + i, n_rows, bj, lr_z, st, ofs, false);
+    const int rc_ = bnn_z_sync_impl(h, data_z, zm, zv, perm + i, n_rows, bj, lr_z, st, ofs, false);
+    if (!rc_) replayed_to = std::max<long long>(replayed_to, i / batch + 1);
+    return rc_;
+  };
+  // an error exit: nothing stays in flight on the private stream, and the rows replayed ahead without their latent step count as
+  // current to the step they were brought to (minibatch j -> tz0 + j), so that the caller's flush does not replay them twice
+  auto fail = [&](int rc_) -> int {
+    if (overlap) hipStreamSynchronize(sB);
+    if (lazy == 2 && flags && s->tlast_dev)
+      for (long long j = k; j < replayed_to; ++j) {
+        const int bj = rows_of(j * (int64_t)batch);
+        if (bj >= 2) hipLaunchKernelGGL(fit_mark_rows_kernel, dim3((unsigned)((bj + 255) / 256)), dim3(256), 0, sA, s->tlast_dev,
+                                        perm + j * (int64_t)batch, (long long)bj, (int)(tz0 + j));
+      }
+    if (n_done) *n_done = (int32_t)k;
+    return rc_;
   };
   for (int64_t i = 0; i < n_use; i += batch) {
     const int32_t *idx = perm + i;
@@ -520,8 +538,8 @@ extern "C" int bgm_bnn_fit_epoch(bgm_handle *h, const float *x, const float *y, 
     if (b < 2) continue;                     // batch statistics need two rows
     const bool ov = flags && b == batch;     // (a short last minibatch runs on the phase machine: in stream order, on the caller's stream)
     const uint32_t s0 = stream_id0 + (uint32_t)(3 * k);
-    if (lazy == 2 && !flags && (rc = bnn_z_sync_impl(h, data_z, zm, zv, idx, n_rows, b, lr_z, sA, 0, !overlap))) return rc;
-    if (lazy == 2 && flags && k == 0 && ((rc = replay_ahead(i, 0, sA)) || (rc = replay_ahead(i + batch, 1, sA)))) return rc;
+    if (lazy == 2 && !flags && (rc = bnn_z_sync_impl(h, data_z, zm, zv, idx, n_rows, b, lr_z, sA, 0, !overlap))) return fail(rc);
+    if (lazy == 2 && flags && k == 0 && ((rc = replay_ahead(i, 0, sA)) || (rc = replay_ahead(i + batch, 1, sA)))) return fail(rc);
     if (overlap && k == 0) {                 // the second stream starts behind everything queued on the caller's so far
       BGM_HIP_CHECK(hipEventRecord(h->epoch_ev_t[1], sA));
       BGM_HIP_CHECK(hipStreamWaitEvent(sB, h->epoch_ev_t[1], 0));
@@ -546,7 +564,7 @@ extern "C" int bgm_bnn_fit_epoch(bgm_handle *h, const float *x, const float *y, 
       h->epoch_theta_done += dw_blocks;
       fc->sync_zn = FitSync{h->epoch_ctr, h->epoch_theta_done, nullptr, err};
       fc->sync_zr = FitSync{nullptr, 0, h->epoch_ctr + 1, err};
-      if (lazy == 2 && (rc = replay_ahead(i + 2 * (int64_t)batch, 2, sB))) return rc;      // (in front of this latent phase: its count covers it)
+      if (lazy == 2 && (rc = replay_ahead(i + 2 * (int64_t)batch, 2, sB))) return fail(rc);      // (in front of this latent phase: its count covers it)
       s->z_synced = s->t_z + 1;
     } else if (overlap && !flags) {
       BGM_HIP_CHECK(hipEventRecord(h->epoch_ev_t[k & 1], sA));
@@ -556,7 +574,7 @@ extern "C" int bgm_bnn_fit_epoch(bgm_handle *h, const float *x, const float *y, 
     if (flags && !ov) s->z_synced = s->t_z + 1;
     rc = bgm_bnn_z_step(h, x, y, v, data_z, zm, zv, idx, n_rows, b, 0, lr_z, lazy, seed, s0 + 1, out_z, nullptr, sz);
     if (ov) { fc->sync_zn = FitSync{}; fc->sync_zr = FitSync{}; if (!rc) h->epoch_z_done += zr_blocks; }
-    if (rc) return rc;
+    if (rc) return fail(rc);
     if (overlap && !flags) BGM_HIP_CHECK(hipEventRecord(h->epoch_ev_z[k & 1], sB));
     ++k;
   }
@@ -565,7 +583,8 @@ extern "C" int bgm_bnn_fit_epoch(bgm_handle *h, const float *x, const float *y, 
     BGM_HIP_CHECK(hipStreamWaitEvent(sA, h->epoch_ev_z[0], 0));
   }
   if (n_done) *n_done = (int32_t)k;
-  return BGM_OK;
+  // a device-side wait that gave up voids THIS call: reported now, before the caller evaluates or checkpoints the state
+  return flags ? bnn_epoch_check(h, sA) : BGM_OK;
 }
 
 extern "C" int bgm_bnn_end(bgm_handle *h, void *stream_) {

@@ -775,10 +775,11 @@ extern "C" int bgm_causal_fit_epoch(bgm_handle *h, const float *x, const float *
       BGM_HIP_CHECK(hipMemsetAsync(h->epoch_ctr, 0, sizeof(unsigned) * 8, sA));
       h->epoch_theta_done = h->epoch_z_done = 0;
     } else if ((rc = fit_epoch_check(h, sA))) return rc;
-    if (!h->epoch_flags_ok) {      // once per handle: do the two streams run side by side (fit_sync.h)?
+    if (!h->epoch_flags_ok || h->epoch_probe_stream != (void *)sA) {      // once per handle and caller stream: do the two streams run side by side (fit_sync.h)?
       int ok = 0;
       BGM_HIP_CHECK(fit_sync_probe(sA, sB, h->epoch_ctr + 4, &ok));
       h->epoch_flags_ok = ok ? 1 : -1;
+      h->epoch_probe_stream = (void *)sA;
     }
     if (h->epoch_flags_ok < 0) flags = false;      // (a profiler serialising kernels, one hardware queue): HIP events
   }
@@ -871,6 +872,9 @@ extern "C" int bgm_causal_fit_epoch(bgm_handle *h, const float *x, const float *
       BGM_HIP_CHECK(hipMemcpyAsync(fc->thetaT, tTb[cur], sizeof(float) * ((size_t)np + 64), hipMemcpyDeviceToDevice, sA));
     }
   }
+  // a device-side wait that gave up voids THIS call: say so now, before the caller evaluates or checkpoints the state (one small read
+  // per epoch behind the join above)
+  if (flags && !rc) rc = fit_epoch_check(h, sA);
   return rc;
 }
 
@@ -949,6 +953,7 @@ extern "C" int bgm_causal_fit_end(bgm_handle *h, void *stream_) {
     off += n.count();
   }
   h->bx_valid = false;   // the split-precision sampling blob is packed from the host copies refreshed above
+  h->gx_valid = false;   // ... and so are the general-width packs, unless this session stepped on them (then they are re-uploaded once: harmless)
   fit_free(h);   // forward blob on the device is already current (blob_valid stays true)
   return rc_epoch;
 }

@@ -6,13 +6,14 @@
 // Device-side ordering between the two streams of bgm_causal_fit_epoch / bgm_bnn_fit_epoch: a kernel may spin at entry until a counter in device memory
 // reaches a target, and every workgroup of a kernel may add 1 to a counter at its end.  The producer of a wait is always issued
 // before its consumer (host order), both grids are a handful of workgroups, so the producer is never starved; the spin is bounded all
-// the same (FIT_SYNC_TIMEOUT_TICKS of the 100 MHz wall clock, then *err = 1 and every later wait falls through).
+// the same (FIT_SYNC_TIMEOUT_TICKS of the 100 MHz wall clock, then *err = 1 and every later wait falls through; the epoch call reads
+// the word behind its join and fails).
 struct FitSync {
   unsigned *wait_ctr; unsigned wait_target;
   unsigned *done_ctr;
   int *err;
 };
-#define FIT_SYNC_TIMEOUT_TICKS 2000000ull      // 20 ms
+#define FIT_SYNC_TIMEOUT_TICKS 200000000ull    // 2 s: a GPU shared with another process or a debugger attach must not void an epoch
 __device__ __forceinline__ void fit_sync_wait(const FitSync &s) {
   if (!s.wait_ctr) return;
   if (threadIdx.x == 0) {

@@ -144,6 +144,15 @@ class CausalBGM(object):
             return a.to(device=self.engine.device, dtype=torch.float32).contiguous()
         return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.engine.device)
 
+    def _panel_v_var(self, v):
+        """mean per-column variance of this rank's rows of V (1 for a standardised panel), cached per tensor: diagnostics.py compares
+        MSE_v / var(V)"""
+        key = (v.data_ptr(), tuple(v.shape))
+        if getattr(self, '_v_var_key', None) != key:
+            self._v_var_key = key
+            self._v_var = float(v.var(dim=0, unbiased=False).mean().item()) if v.shape[0] > 1 else 1.0
+        return self._v_var
+
     # ------------------------------------------------------------------ fit
     def _net_dims(self, k):
         return [self.nets[k][0][0].shape[0]] + [W.shape[1] for W, _ in self.nets[k]]
@@ -382,8 +391,10 @@ class CausalBGM(object):
                         eng.fit_z_sync(self.data_z, zm, zv, None, lr_z)          # flush: evaluate / checkpoints read the whole table
                     causal_pre, mse_x, mse_y, mse_v = self._evaluate_dev(x, y, v, self.data_z, n_total, lo_r)
                     self.fit_history[-1].update(mse_x=float(mse_x), mse_y=float(mse_y), mse_v=float(mse_v))
-                    self._second_optimum_warned = diagnostics.warn_if_second_optimum(getattr(self, '_egm_late_l2z', None), float(mse_v),
-                                                                                                 getattr(self, '_second_optimum_warned', False))
+                    if self.params.get('second_optimum_check', True):
+                        self._second_optimum_warned = diagnostics.warn_if_second_optimum(getattr(self, '_egm_late_l2z', None), float(mse_v),
+                                                                                         getattr(self, '_second_optimum_warned', False),
+                                                                                         v_var=self._panel_v_var(v))
                     if verbose:
                         print('Epoch [%d/%d]: MSE_x: %.4f, MSE_y: %.4f, MSE_v: %.4f\n' % (epoch, epochs, mse_x, mse_y, mse_v))
                     if epoch >= startoff and mse_y < best_loss:

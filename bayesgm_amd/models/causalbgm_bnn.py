@@ -330,8 +330,10 @@ class CausalBGMBayes(CausalBGM):
                     eng.z_sync(self.data_z, zm, zv, None, lr_z)                      # flush: evaluate / checkpoints read the whole table
                 if epoch % epochs_per_eval == 0:
                     causal_pre, mse_x, mse_y, mse_v = self._evaluate_dev(x, y, v, self.data_z, n_total, lo_r)
-                    self._second_optimum_warned = diagnostics.warn_if_second_optimum(getattr(self, '_egm_late_l2z', None), float(mse_v),
-                                                                                                 getattr(self, '_second_optimum_warned', False))
+                    if self.params.get('second_optimum_check', True):
+                        self._second_optimum_warned = diagnostics.warn_if_second_optimum(getattr(self, '_egm_late_l2z', None), float(mse_v),
+                                                                                         getattr(self, '_second_optimum_warned', False),
+                                                                                         v_var=self._panel_v_var(v))
                     if verbose:
                         print('Epoch [%d/%d]: MSE_x: %.4f, MSE_y: %.4f, MSE_v: %.4f\n' % (epoch, epochs, mse_x, mse_y, mse_v))
                     if epoch >= startoff and mse_y < best_loss:

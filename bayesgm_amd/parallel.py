@@ -5,6 +5,8 @@ contiguous per-rank ranges, MCMC chains never communicate, and the only
 exchanges are (C1) the network-gradient all-reduce in fit, (C3) the ADRF
 partial sums [n_doses x n_keep] once per predict and gathers of per-row results.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -30,23 +32,45 @@ def shard_range(n, r=None, w=None):
     return lo, lo + base + (1 if r < rem else 0)
 
 
+def _device_view(t):
+    """RCCL moves device memory only.  A host tensor handed to a collective is staged through the current HIP device when the backend is
+    nccl (returns (device tensor, host tensor to copy the result back into)); BGM_STRICT_COLLECTIVES=1 turns that case into an error
+    under ANY backend, so that the two-rank gloo runs of a one-GPU box find what an RCCL run would have to stage."""
+    if t.is_cuda:
+        return t, None
+    if os.environ.get("BGM_STRICT_COLLECTIVES") == "1":
+        raise RuntimeError("collective on a host tensor of shape %s: the data-parallel path keeps its exchanges in HBM" % (tuple(t.shape),))
+    if dist.get_backend() != "nccl":
+        return t, None
+    return t.to(torch.device("cuda", torch.cuda.current_device())), t
+
+
 def all_reduce_sum_(t):
     if is_dist():
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        d, host = _device_view(t)
+        dist.all_reduce(d, op=dist.ReduceOp.SUM)
+        if host is not None:
+            host.copy_(d)
     return t
 
 
 def broadcast_(t, src=0):
     """In-place broadcast of a tensor from rank `src` (a host-side random draw every rank must agree on)."""
     if is_dist():
-        dist.broadcast(t, src)
+        d, host = _device_view(t)
+        dist.broadcast(d, src)
+        if host is not None:
+            host.copy_(d)
     return t
 
 
 def all_reduce_max_(t):
     """In-place MAX all-reduce (no-op when not distributed)."""
     if is_dist():
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        d, host = _device_view(t)
+        dist.all_reduce(d, op=dist.ReduceOp.MAX)
+        if host is not None:
+            host.copy_(d)
     return t
 
 
@@ -55,13 +79,15 @@ def all_gather_rows(t, n_total):
     if not is_dist():
         return t
     w = world_size()
+    t, host = _device_view(t)
     sizes = [shard_range(n_total, r, w)[1] - shard_range(n_total, r, w)[0] for r in range(w)]
     mx = max(sizes)
     pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     pad[:t.shape[0]] = t
     outs = [torch.empty_like(pad) for _ in range(w)]
     dist.all_gather(outs, pad)
-    return torch.cat([o[:s] for o, s in zip(outs, sizes)], dim=0)
+    res = torch.cat([o[:s] for o, s in zip(outs, sizes)], dim=0)
+    return res if host is None else res.cpu()
 
 
 def all_gather_rows_var(t):
@@ -69,6 +95,7 @@ def all_gather_rows_var(t):
     if not is_dist():
         return t
     w = world_size()
+    t, host = _device_view(t)
     n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
     ns = [torch.zeros_like(n) for _ in range(w)]
     dist.all_gather(ns, n)
@@ -78,7 +105,8 @@ def all_gather_rows_var(t):
     pad[:t.shape[0]] = t
     outs = [torch.empty_like(pad) for _ in range(w)]
     dist.all_gather(outs, pad)
-    return torch.cat([o[:s] for o, s in zip(outs, sizes)], dim=0)
+    res = torch.cat([o[:s] for o, s in zip(outs, sizes)], dim=0)
+    return res if host is None else res.cpu()
 
 
 def shared_seed(random_seed):

@@ -506,6 +506,59 @@ def bf16x3_leg(model, data, x_values, n_loc, args, z_dims, flop_row_transition, 
                                  "16-bit matrix pipe (the same for both formats)"}}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: run this same command line as N ranks, one per GPU, under
+    torch.distributed.run on 127.0.0.1 (a free port), exactly the form the docstring gives.  Fails loudly when the box has fewer than N
+    devices (BGM_BENCH_SINGLE_DEVICE=1, the one-GPU development aid, and --plumbing-only, which touches no device, are exempt).
+    Returns the launcher's exit code; the ranks' stdout / stderr are this process's."""
+    import socket
+    import subprocess
+    if not args.plumbing_only and os.environ.get("BGM_BENCH_SINGLE_DEVICE") != "1":
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but this box shows {have} HIP device(s); refusing to run fewer ranks than asked for",
+                  file=sys.stderr)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: launching %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
+def plumbing_only(args, world):
+    """The launch path without a device (see --plumbing-only)."""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        print(f"--gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
+    seen = world
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+        t1 = torch.ones(1)
+        dist.all_reduce(t1)
+        seen = int(t1.item())
+        rows = [None] * world
+        dist.all_gather_object(rows, plan_rows(args.n, world, rank, args.scaling))
+    else:
+        rows = [plan_rows(args.n, 1, 0, args.scaling)]
+    if rank == 0:
+        print(json.dumps({"plumbing_only": True, "n_gpus": world, "n_ranks_in_collective": seen, "scaling": args.scaling,
+                          "rows": [list(r) for r in rows]}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if seen == args.gpus else 3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -523,14 +576,23 @@ def main():
                     help="weak: --rows per GPU (default); strong: --rows in TOTAL, sharded over the GPUs (BASELINE configs[3]: N=1e6 over 8 GPUs)")
     ap.add_argument("--no-bf16x3", action="store_true", help="skip the secondary split-precision (bf16 x 3) measurement (N=1 only)")
     ap.add_argument("--no-accuracy", action="store_true", help="skip the accuracy leg (fit on the tutorial panel + ADRF error; N=1 only)")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="launch / rendezvous check without a device: every rank joins the process group over gloo on the CPU, the rank "
+                         "count is all-reduced and rank 0 prints {n_gpus, n_ranks_in_collective}; no kernel runs (tests/test_bench_launch.py)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: this process becomes the launcher of N ranks (one per GPU) and relays rank 0's JSON line
+        raise SystemExit(self_launch(args))
 
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.plumbing_only:
+        raise SystemExit(plumbing_only(args, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # Dev aid (1-GPU box): BGM_BENCH_SINGLE_DEVICE=1 BGM_BENCH_BACKEND=gloo runs all ranks on cuda:0 over gloo so
     # that the N>1 code path (sharding, ADRF all-reduce, max-over-ranks timing) can be exercised without N GPUs.
@@ -572,6 +634,8 @@ def main():
         t1 = torch.ones(1, device=device)
         dist.all_reduce(t1)
         n_ranks_seen = int(t1.item())
+        if n_ranks_seen != args.gpus:       # nothing is timed unless every requested rank is inside the collective
+            raise SystemExit(f"--gpus {args.gpus} but {n_ranks_seen} ranks answered the all-reduce")
 
     class Shard:  # predict() shards data[lo:hi] by rank; hand it this rank's rows for any slice
         def __init__(self, t): self.t = t

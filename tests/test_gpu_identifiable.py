@@ -298,3 +298,43 @@ def test_two_rank_predict_equals_the_single_process_predict():
     adrf_a, _ = ma.predict((x, y, v), alpha=0.05, n_mcmc=20, burn_in=160, x_values=np.linspace(0, 3, 6), q_sd=-1.0, verbose=0)
     assert np.abs(np.array(two["adrf_adaptive"]) - adrf_a).max() <= 1e-5
     assert abs(two["acc_adaptive"] - ma.last_acceptance_rate) < 1e-12
+
+
+def test_general_width_pack_follows_a_fit_on_the_row_tile_chains():
+    """default widths on a shape that is not LDS-resident, WITH a conditional prior, sample on the general-width
+    engine's packed weights, while a minibatch fit of that shape steps on the row-tile chains and refreshes the host nets only.  The
+    pack must be rebuilt after bgm_causal_fit_end: log posterior after the fit = log posterior of a fresh handle given the fitted nets
+    (and differs from the pre-fit one)."""
+    import torch
+    rs = np.random.RandomState(8)
+    z_dims, p, n, k = [5, 5, 5, 5], 100, 96, 4
+    q = sum(z_dims)
+    m = _model(5, z_dims, p, False)
+    x, y, v = _data(n, p, 6, False)
+    z = rs.randn(n, q).astype(np.float32)
+    seg = torch.from_numpy(rs.randint(0, k, n).astype(np.int32)).cuda()
+    tab = torch.from_numpy(OI.prior_table(_prior(rs, k, q), q)).cuda()
+    eng = _engine(m)
+    eng.set_prior(seg, tab)
+    lp0 = eng.logpost(x.ravel(), y.ravel(), v, z).cpu().numpy()          # builds the general-width pack
+    assert eng.describe().startswith("sampler=gx_causal_mh_kernel")
+    dev = eng.device
+    xd, yd, vd = (torch.from_numpy(a).to(dev) for a in (x.ravel(), y.ravel(), v))
+    zd = torch.from_numpy(z).to(dev)
+    zm, zv = torch.zeros_like(zd), torch.zeros_like(zd)
+    npar = eng.fit_begin(n, 32)
+    assert "general-width" not in eng.describe(32).split("fit=")[-1]     # the minibatch steps do NOT run on the general-width engine
+    grad = torch.empty(npar, device=dev)
+    for s_ in range(3):
+        idx = torch.arange(32 * s_, 32 * s_ + 32, device=dev, dtype=torch.int32)
+        eng.fit_theta_grad(xd, yd, vd, zd, idx, 32, grad)
+        eng.fit_theta_apply(grad, 1e-2)
+    eng.fit_end()
+    nets = {name: eng.get_weights(i, [W.shape[0] for W, _ in m[name]] + [m[name][-1][0].shape[1]]) for i, name in enumerate(("g", "f", "h"))}
+    assert np.abs(nets["g"][0][0] - m["g"][0][0]).max() > 1e-3           # the fit moved the weights
+    lp1 = eng.logpost(x.ravel(), y.ravel(), v, z).cpu().numpy()
+    fresh = _engine(dict(m, **nets))
+    fresh.set_prior(seg, tab)
+    ref = fresh.logpost(x.ravel(), y.ravel(), v, z).cpu().numpy()
+    assert np.abs(lp1 - lp0).max() > 1e-2
+    np.testing.assert_allclose(lp1, ref, rtol=1e-6, atol=1e-5)

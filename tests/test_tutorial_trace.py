@@ -211,3 +211,8 @@ def test_second_optimum_warning_on_the_committed_runs():
         assert D.warn_if_second_optimum(0.248, 0.9744) is False                     # product seed 123 (published: 0.247 / 0.9665)
         assert D.warn_if_second_optimum(0.436, 0.9985, already=True) is True        # once per fit
         assert D.warn_if_second_optimum(None, 0.99) is False                        # no warm start in this process
+        # unstandardised covariates: the statistic is MSE_v / var(V): a panel with var(V) = 4 and MSE_v 3.2 explains 20 %
+        assert D.warn_if_second_optimum(0.436, 3.2, v_var=4.0) is False
+        assert D.warn_if_second_optimum(0.436, 0.99, v_var=0.0) is False            # nothing to explain: not diagnosed
+    with pytest.warns(D.SecondOptimumWarning):
+        assert D.warn_if_second_optimum(0.436, 3.95, v_var=4.0) is True
