@@ -120,6 +120,7 @@ SYMBOLS = {
     "bgm_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "bgm_timing_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int]),
     "bgm_causal_set_outcome_cache": (C.c_int, [C.c_void_p, C.c_int32]),
+    "bgm_causal_set_event_budget": (C.c_int, [C.c_void_p, C.c_int64]),
     "bgm_causal_outcome_cache_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int32]),
     "bgm_causal_mh_info": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(MhInfo)]),
     "bgm_causal_evaluate": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int64, C.c_void_p, C.c_int32,

@@ -63,9 +63,15 @@ struct bgm_handle {
   // per-wave-slot (mean, sd) of the outcome net at every dose, kept between the retained iterations of an ADRF launch (causal_kernels.h)
   float *eff_cache = nullptr;
   size_t eff_cache_cap = 0;
-  int outcome_cache = 1;                          // bgm_causal_set_outcome_cache
+  int outcome_cache = 2;                          // bgm_causal_set_outcome_cache: 0 off, 1 per wave of 16 chains, 2 per chain (event form where it exists, else 1)
   unsigned long long *eff_stats_dev = nullptr;    // [0]: retained tile-iterations served from the cache
   unsigned long long eff_total = 0;               // retained tile-iterations launched since the last reset
+  unsigned long long ev_total = 0;                // event form: retained chain-iterations launched since the last reset
+  // event form of the retained phase (causal_event_api.hip; outcome_cache == 2): per-slot event regions of one segment of retained
+  // iterations, the outcome net's (mean, sd) per event, and the chains' current pairs carried between the segments of a call
+  float *ev_z = nullptr; unsigned *ev_meta = nullptr; int *ev_tile = nullptr, *ev_slot_cnt = nullptr; float *ev_out = nullptr, *ev_carry = nullptr;
+  size_t ev_z_cap = 0, ev_meta_cap = 0, ev_tile_cap = 0, ev_slot_cap = 0, ev_out_cap = 0, ev_carry_cap = 0;
+  long long ev_budget_bytes = 0;                  // bgm_causal_set_event_budget (0: BGM_EVENT_BUDGET_MB or 8 GiB)
   bool bx_valid = false;
   alignas(8) unsigned char bx_meta_store[192];
   // per-row conditional latent prior of the sampling kernels (causal_prior_api.hip, bgm_causal_set_prior); NULL = standard normal
@@ -199,4 +205,10 @@ static inline int l1_feature(int rho) {
   return 16 * t + 4 * r + g;
 }
 
-
+// causal_event_api.hip: the retained phase as transitions + events + dense outcome-net tiles + spread (causal_event_kernels.h)
+struct CausalMhKArgs;
+bool bgm_causal_event_wanted(const bgm_handle *h, int effect, int n_doses);
+int bgm_causal_event_plan(bgm_handle *h, long long n, int n_slots, int n_doses, int n_iters, int *seg_len, long long *ev_cap);
+int bgm_causal_event_mh_launch(bgm_handle *h, CausalMhKArgs &ka, int grid, int lds, hipStream_t stream);
+int bgm_causal_event_finish(bgm_handle *h, const CausalMhKArgs &ka, int grid, int first, hipStream_t stream);
+void bgm_causal_event_free(bgm_handle *h);

@@ -3,6 +3,7 @@
 // into the LDS fragment order of causal_kernels.h.
 #include <algorithm>
 #include <string>
+#include <vector>
 #include <cstdio>
 #include <cmath>
 #include <cstring>
@@ -50,6 +51,7 @@ extern "C" int bgm_destroy(bgm_handle *h) {
   if (h->acc_scratch) hipFree(h->acc_scratch);
   if (h->eff_cache) hipFree(h->eff_cache);
   if (h->eff_stats_dev) hipFree(h->eff_stats_dev);
+  bgm_causal_event_free(h);
   bnf_det_free(h);
   bgm_causal_fit_end(h, nullptr);
   gx_free(h);
@@ -426,13 +428,24 @@ extern "C" int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *a, void *stre
   ka.adrf_partial = a->adrf_partial_dev; ka.ite = a->ite_dev; ka.clk = (unsigned long long *)a->clock_dev; ka.m = h->meta;
 
   // Split the segment at burn_in: the burn-in part runs the pure-transition kernel.
-  struct Seg { int begin, n, effect, init; };
-  Seg segs[2];
-  int nseg = 0;
+  struct Seg { int begin, n, effect, init, ev; };       // ev: 0 fused kernels; 1 / 2 = first / later segment of the event form
+  std::vector<Seg> segs;
   const int split = std::min(std::max(a->burn_in, a->it_begin), it_end);
-  if (split > a->it_begin) segs[nseg++] = {a->it_begin, split - a->it_begin, BGM_EFFECT_NONE, a->init};
-  if (it_end > split) segs[nseg++] = {split, it_end - split, a->effect, (nseg == 0) ? a->init : 0};
+  if (split > a->it_begin) segs.push_back({a->it_begin, split - a->it_begin, BGM_EFFECT_NONE, a->init, 0});
   const int n_slots = grid * MH_WAVES;
+  // the retained iterations: the fused sampler + outcome-net kernel, or (outcome cache mode 2, causal_event_api.hip) segments of
+  // transitions that append events, each followed by the outcome net on dense event tiles and the spread over the segment's draws
+  const bool ev_form = it_end > split && bgm_causal_event_wanted(h, a->effect, a->n_doses);
+  if (ev_form) {
+    int S = 0;
+    long long cap = 0;
+    if ((rc = bgm_causal_event_plan(h, a->n, n_slots, a->n_doses, it_end - split, &S, &cap))) return rc;
+    ka.ev_cap = cap;
+    for (int b = split; b < it_end; b += S)
+      segs.push_back({b, std::min(S, it_end - b), a->effect, (segs.empty() && b == split) ? a->init : 0, b == split ? 1 : 2});
+    h->ev_total += (unsigned long long)a->n * (unsigned long long)(it_end - split);
+  } else if (it_end > split) segs.push_back({split, it_end - split, a->effect, segs.empty() ? a->init : 0, 0});
+  const int nseg = (int)segs.size();
   if (a->effect != BGM_EFFECT_NONE && it_end > split) {
     if (a->effect == BGM_EFFECT_ADRF) {      // (mean, sd) of the outcome net per wave slot, pass and lane: causal_effects_cached
       const size_t need = (size_t)n_slots * (size_t)((a->n_doses + 3) / 4) * 64 * 2;
@@ -449,8 +462,9 @@ extern "C" int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *a, void *stre
       BGM_HIP_CHECK(hipMemsetAsync(h->eff_stats_dev, 0, 2 * sizeof(unsigned long long), stream));
     }
     ka.eff_stats = h->eff_stats_dev;
-    h->eff_total += (unsigned long long)((a->n + 15) / 16) * (unsigned long long)(it_end - split);      // retained tile-iterations launched
+    if (!ev_form) h->eff_total += (unsigned long long)((a->n + 15) / 16) * (unsigned long long)(it_end - split);      // retained tile-iterations launched
   }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
   for (int s = 0; s < nseg; ++s) {
     ka.it_begin = segs[s].begin; ka.n_iters = segs[s].n; ka.init = segs[s].init;
     if (a->acc_count_dev) {   // slot-private counters for this launch, reduced into acc_count_dev afterwards
@@ -463,12 +477,17 @@ extern "C" int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *a, void *stre
       BGM_HIP_CHECK(hipMemsetAsync(h->acc_scratch, 0, need * sizeof(unsigned), stream));
       ka.acc_count = h->acc_scratch;
     }
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (h->timing) {
+    // (the segments of the event form are timed as ONE interval: the retained phase)
+    const bool t_open = h->timing && segs[s].ev != 2, t_close = h->timing && (segs[s].ev == 0 || s + 1 == nseg);
+    if (t_open) {
       BGM_HIP_CHECK(hipEventCreate(&e0)); BGM_HIP_CHECK(hipEventCreate(&e1));
       BGM_HIP_CHECK(hipEventRecord(e0, stream));
     }
-    if (h->prior_seg) {
+    if (segs[s].ev) {
+      ka.ev_first = segs[s].ev == 1 ? 1 : 0;
+      if ((rc = bgm_causal_event_mh_launch(h, ka, grid, lds, stream))) return rc;
+      rc = bgm_causal_event_finish(h, ka, grid, ka.ev_first, stream);
+    } else if (h->prior_seg) {
       if (h->precision != 0) { bgm_set_error("bgm_causal_mh_run: the conditional prior is built for the fp32 kernels only"); return BGM_E_UNSUPPORTED; }
       rc = bgm_causal_prior_mh_launch(h, ka, segs[s].effect, grid, lds, stream);
     } else if (h->precision != 0) rc = bgm_causal_bx3_mh_launch(h, ka, segs[s].effect, grid, stream);
@@ -481,7 +500,7 @@ extern "C" int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *a, void *stre
                          segs[s].n, a->acc_count_dev + segs[s].begin);
       BGM_HIP_CHECK(hipGetLastError());
     }
-    if (h->timing) {
+    if (t_close) {
       BGM_HIP_CHECK(hipEventRecord(e1, stream));
       h->events.push_back({e0, e1, segs[s].effect});
     }
@@ -585,8 +604,8 @@ extern "C" int bgm_causal_evaluate_slots(bgm_handle *h, int64_t n, int32_t *n_sl
 }
 
 extern "C" int bgm_causal_set_outcome_cache(bgm_handle *h, int32_t on) {
-  if (!h) { bgm_set_error("bgm_causal_set_outcome_cache: null handle"); return BGM_E_INVALID; }
-  h->outcome_cache = on != 0;
+  if (!h || on < 0 || on > 2) { bgm_set_error("bgm_causal_set_outcome_cache: mode must be 0 (off), 1 (per wave) or 2 (per chain: event form)"); return BGM_E_INVALID; }
+  h->outcome_cache = on;
   return BGM_OK;
 }
 
@@ -598,8 +617,10 @@ extern "C" int bgm_causal_outcome_cache_stats(bgm_handle *h, int64_t *out2, int3
   BGM_HIP_CHECK(hipDeviceSynchronize());
   unsigned long long v[2];
   BGM_HIP_CHECK(hipMemcpy(v, h->eff_stats_dev, sizeof(v), hipMemcpyDeviceToHost));
-  out2[0] = (int64_t)v[0]; out2[1] = (int64_t)h->eff_total;
-  if (reset) { BGM_HIP_CHECK(hipMemset(h->eff_stats_dev, 0, sizeof(v))); h->eff_total = 0; }
+  // wave cache: retained tile-iterations served / launched; event form: retained chain-iterations that needed no outcome-net
+  // evaluation (all of them minus the events) / retained chain-iterations
+  out2[0] = (int64_t)v[0] + (int64_t)(h->ev_total - std::min<unsigned long long>(v[1], h->ev_total)); out2[1] = (int64_t)(h->eff_total + h->ev_total);
+  if (reset) { BGM_HIP_CHECK(hipMemset(h->eff_stats_dev, 0, sizeof(v))); h->eff_total = 0; h->ev_total = 0; }
   return BGM_OK;
 }
 

@@ -1,0 +1,133 @@
+// causal_event_api.hip -- host side of the event form of CausalBGM.predict's retained phase (causal_event_kernels.h):
+// the EFFECT = 3 instantiations of causal_mh_kernel (transitions + event append), the dense outcome-net tiles and the spread pass,
+// the per-segment buffers, and the segment length that fits the memory budget.  Called from bgm_causal_mh_run (causal_api.hip).
+// replaces: the retained iterations of metropolis_hastings_sampler (causalbgm/base.py:860-899) + infer_from_latent_posterior (:671-763).
+#include <algorithm>
+#include <cstdlib>
+#include <string>
+
+#include "bgm_host.h"
+#include "causal_event_kernels.h"
+
+#ifndef BGM_MH_R
+#define BGM_MH_R 1
+#endif
+#ifndef BGM_MH_WAVES
+#define BGM_MH_WAVES 8
+#endif
+static constexpr int EV_MH_R = BGM_MH_R, EV_MH_WAVES = BGM_MH_WAVES, EV_SPREAD_WAVES = 4;
+#define BGM_CAUSAL_VARIANTS(X) X(1, 3, 13) X(1, 3, 7) X(1, 3, 2) X(2, 1, 10) X(2, 1, 7) X(2, 1, 2)
+
+// served by the event form: dose-response sums on the fp32 LDS-resident kernels with the standard-normal prior, doses in registers
+bool bgm_causal_event_wanted(const bgm_handle *h, int effect, int n_doses) {
+  static const bool off = std::getenv("BGM_NO_EVENT_SPLIT") != nullptr;      // dev A/B
+  return !off && EV_MH_R == 1 && h->outcome_cache == 2 && effect == BGM_EFFECT_ADRF && h->precision == 0 && !h->prior_seg &&
+         n_doses >= 1 && (n_doses + 3) / 4 <= EV_NCMAX;
+}
+
+template <class T>
+static int ev_reserve(T *&ptr, size_t &cap, size_t need) {
+  if (cap >= need) return BGM_OK;
+  if (ptr) BGM_HIP_CHECK(hipFree(ptr));
+  ptr = nullptr; cap = 0;
+  BGM_HIP_CHECK(hipMalloc((void **)&ptr, need * sizeof(T)));
+  cap = need;
+  return BGM_OK;
+}
+
+// Segment length: a slot's region must hold the worst case (every chain of every one of its tiles moves at every iteration), so a
+// segment of S iterations needs  n_slots * tiles_per_slot * 16 * S  events of  4 q + 4 + 32 n_calls  bytes; S is the largest length
+// that fits the budget (bgm_causal_set_event_budget, else BGM_EVENT_BUDGET_MB, else 8 GiB), at least 8.  Typical use touches a
+// fraction `acceptance rate` of it.
+int bgm_causal_event_plan(bgm_handle *h, long long n, int n_slots, int n_doses, int n_iters, int *seg_len, long long *ev_cap) {
+  const long long n_tiles = (n + 15) / 16, tps = (n_tiles + n_slots - 1) / n_slots;
+  const int n_calls = (n_doses + 3) / 4;
+  long long budget = h->ev_budget_bytes;
+  if (budget <= 0) {
+    const char *e = std::getenv("BGM_EVENT_BUDGET_MB");
+    budget = (e ? std::max(1ll, std::atoll(e)) : 8192ll) << 20;
+  }
+  const long long per_iter = (long long)n_slots * tps * 16 * (4ll * h->q + 4 + 32ll * n_calls);
+  long long S = std::max(8ll, budget / std::max(1ll, per_iter));
+  S = std::min<long long>(S, n_iters);
+  S = std::min<long long>(S, (1ll << 27) / std::max(1ll, tps * 16));      // event indices of a slot stay far inside 32 bits
+  S = std::max(1ll, S);
+  const long long cap = tps * 16 * S;
+  const size_t ev_total = (size_t)n_slots * (size_t)cap;
+  int rc;
+  if ((rc = ev_reserve(h->ev_z, h->ev_z_cap, ev_total * (size_t)h->q))) return rc;
+  if ((rc = ev_reserve(h->ev_meta, h->ev_meta_cap, ev_total))) return rc;
+  if ((rc = ev_reserve(h->ev_tile, h->ev_tile_cap, (size_t)n_tiles * 2))) return rc;
+  if ((rc = ev_reserve(h->ev_slot_cnt, h->ev_slot_cap, (size_t)n_slots))) return rc;
+  if ((rc = ev_reserve(h->ev_out, h->ev_out_cap, ev_total / 16 * (size_t)n_calls * 64 * 2))) return rc;
+  if ((rc = ev_reserve(h->ev_carry, h->ev_carry_cap, (size_t)n_tiles * (size_t)n_calls * 64 * 2))) return rc;
+  *seg_len = (int)S; *ev_cap = cap;
+  return BGM_OK;
+}
+
+void bgm_causal_event_free(bgm_handle *h) {
+  for (void *p : {(void *)h->ev_z, (void *)h->ev_meta, (void *)h->ev_tile, (void *)h->ev_slot_cnt, (void *)h->ev_out, (void *)h->ev_carry})
+    if (p) hipFree(p);
+  h->ev_z = nullptr; h->ev_meta = nullptr; h->ev_tile = nullptr; h->ev_slot_cnt = nullptr; h->ev_out = nullptr; h->ev_carry = nullptr;
+  h->ev_z_cap = h->ev_meta_cap = h->ev_tile_cap = h->ev_slot_cap = h->ev_out_cap = h->ev_carry_cap = 0;
+}
+
+template <class K>
+static int ev_set_lds(K kernel, int bytes) {
+  BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  return BGM_OK;
+}
+
+// transitions of one segment; ka carries the segment (it_begin, n_iters, ev_first) and everything bgm_causal_mh_run filled in
+int bgm_causal_event_mh_launch(bgm_handle *h, CausalMhKArgs &ka, int grid, int lds, hipStream_t stream) {
+  ka.ev_z = h->ev_z; ka.ev_meta = h->ev_meta; ka.tile_ev = h->ev_tile; ka.slot_cnt = h->ev_slot_cnt;
+  int rc;
+#define X(KT1_, KSL1_, NTL_)                                                                   \
+  if (h->KT1 == KT1_ && h->KSL1 == KSL1_ && h->NTL == NTL_) {                                  \
+    auto k = causal_mh_kernel<KT1_, KSL1_, NTL_, EV_MH_R, EV_MH_WAVES, 3>;                     \
+    if ((rc = ev_set_lds(k, lds))) return rc;                                                  \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * EV_MH_WAVES), lds, stream, ka);                \
+    BGM_HIP_CHECK(hipGetLastError());                                                          \
+    return BGM_OK;                                                                             \
+  }
+  BGM_CAUSAL_VARIANTS(X)
+#undef X
+  bgm_set_error("no compiled MH kernel variant for this shape (event form)");
+  return BGM_E_UNSUPPORTED;
+}
+
+// outcome net on the segment's events, then the spread over its retained iterations
+int bgm_causal_event_finish(bgm_handle *h, const CausalMhKArgs &ka, int grid, int first, hipStream_t stream) {
+  CausalEventFArgs fa{};
+  fa.blob = ka.blob; fa.ev_z = h->ev_z; fa.slot_cnt = h->ev_slot_cnt; fa.ev_cap = ka.ev_cap; fa.n_doses = ka.n_doses;
+  fa.x_values = ka.x_values; fa.ev_out = reinterpret_cast<float2 *>(h->ev_out); fa.eff_stats = ka.eff_stats; fa.m = ka.m;
+  const int lds = ka.m.total * 4;
+  int rc = BGM_E_UNSUPPORTED;
+  bool done = false;
+#define X(KT1_, KSL1_)                                                                         \
+  if (!done && h->KT1 == KT1_ && h->KSL1 == KSL1_) {                                           \
+    auto k = causal_event_f_kernel<KT1_, KSL1_, EV_MH_WAVES>;                                  \
+    if ((rc = ev_set_lds(k, lds))) return rc;                                                  \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * EV_MH_WAVES), lds, stream, fa);                \
+    BGM_HIP_CHECK(hipGetLastError());                                                          \
+    done = true;                                                                               \
+  }
+  X(1, 3) X(2, 1)
+#undef X
+  if (!done) { bgm_set_error("no compiled outcome-net kernel for this shape (event form)"); return BGM_E_UNSUPPORTED; }
+  CausalEventSpreadArgs sa{};
+  sa.n = ka.n; sa.row_base = ka.row_base; sa.it_begin = ka.it_begin; sa.n_iters = ka.n_iters; sa.burn_in = ka.burn_in; sa.n_keep = ka.n_keep;
+  sa.sample_y = ka.sample_y; sa.n_doses = ka.n_doses; sa.k0 = ka.k0; sa.k1 = ka.k1;
+  sa.ev_meta = h->ev_meta; sa.tile_ev = h->ev_tile; sa.ev_cap = ka.ev_cap; sa.ev_out = reinterpret_cast<const float2 *>(h->ev_out);
+  sa.carry = reinterpret_cast<float2 *>(h->ev_carry); sa.first = first; sa.adrf_partial = ka.adrf_partial;
+  static_assert(EV_MH_WAVES % EV_SPREAD_WAVES == 0, "one spread wave per sampler slot");
+  hipLaunchKernelGGL(causal_event_spread_kernel<EV_SPREAD_WAVES>, dim3(grid * (EV_MH_WAVES / EV_SPREAD_WAVES)), dim3(64 * EV_SPREAD_WAVES), 0, stream, sa);
+  BGM_HIP_CHECK(hipGetLastError());
+  return BGM_OK;
+}
+
+extern "C" int bgm_causal_set_event_budget(bgm_handle *h, int64_t bytes) {
+  if (!h || bytes < 0) { bgm_set_error("bgm_causal_set_event_budget: bad argument"); return BGM_E_INVALID; }
+  h->ev_budget_bytes = bytes;
+  return BGM_OK;
+}

@@ -49,6 +49,14 @@ struct CausalMhKArgs {
   float *eff_cache;         // ADRF kernels with one row tile per wave: [n_slots][ceil(n_doses / 4)][64][2] (mean, sd) of the lane's dose
   int eff_skip;             // 1: a retained iteration in which no chain of the wave moved reuses the cached (mean, sd)
   unsigned long long *eff_stats;   // [0] += retained tile-iterations served from the cache (the total is known on the host), or NULL
+  // EFFECT == 3 (causal_event_kernels.h): the retained iterations only append EVENTS -- (chain, first retained draw, state) of every
+  // accepted move -- to the wave slot's region; the outcome net runs on dense event tiles afterwards
+  float *ev_z;              // [n_slots * ev_cap][q]
+  unsigned *ev_meta;        // [n_slots * ev_cap]: (iteration - it_begin) << 4 | chain of the tile
+  int *tile_ev;             // [n_tiles][2]: first event of the tile within its slot's region, number of events
+  int *slot_cnt;            // [n_slots]: events of the slot
+  long long ev_cap;         // events a slot's region holds (a multiple of 16)
+  int ev_first;             // 1: every chain emits its state at the launch's first iteration (nothing is carried from an earlier launch)
   CausalMeta m;
 };
 
@@ -459,7 +467,7 @@ __device__ __forceinline__ float pick_by_group(int g, float v0, float v1, float 
   return g == 0 ? v0 : (g == 1 ? v1 : (g == 2 ? v2 : v3));
 }
 
-template <int KT1, int KSL1, int R, int EFFECT, bool GROUPING = true, bool CACHE = false>
+template <int KT1, int KSL1, int R, int EFFECT, bool GROUPING = true, bool CACHE = false, bool EVAL_ONLY = false>
 __device__ __forceinline__ void causal_effects(const float *lds, const CausalMeta &m, int lane_off, int g, int j,
                                                int lane, const f32x4 (&zs)[R][KT1], const unsigned (&rowid)[R],
                                                const bool (&valid)[R], long long row0, long long n, unsigned it,
@@ -491,7 +499,7 @@ __device__ __forceinline__ void causal_effects(const float *lds, const CausalMet
     BGM_NO_HOIST();
     const bool own = kb < n_own;
     const int c4 = kb & ~3, p4 = kb & 3;
-    if (sample_y && (!own || p4 == 0)) {
+    if (!EVAL_ONLY && sample_y && (!own || p4 == 0)) {
 #pragma unroll
       for (int rr = 0; rr < R; ++rr) nz[rr] = box_muller4(philox4x32_10(rowid[rr], it, (unsigned)(own ? c4 + g : kb), TAG_YNOISE, k0, k1));
     }
@@ -582,6 +590,7 @@ __device__ __forceinline__ void causal_effects(const float *lds, const CausalMet
       const float s2 = (m.sig2_y > 0.0f) ? m.sig2_y : softplus_f(sr_m) + BGM_EPS;
       const float sd_m = __builtin_sqrtf(s2);
       if constexpr (CACHE) cache[kb * 64 + lane] = make_float2(mu_m, sd_m);        // for causal_effects_cached below
+      if constexpr (EVAL_ONLY) continue;                                             // (causal_event_f_kernel: the pairs are all that is wanted)
       // ... and its noise word: word p4 of its own call (rotated into word 0 pass by pass), or word g of the shared call
       const float noise = own ? nz[0][0] : pick_by_group(g, nz[0][0], nz[0][1], nz[0][2], nz[0][3]);
       if (own) nz[0] = f32x4{nz[0][1], nz[0][2], nz[0][3], nz[0][0]};
@@ -688,6 +697,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
       (volatile __attribute__((address_space(3))) int *)((__attribute__((address_space(3))) float *)lds + m.total);
   if (lane == 0) prog[wave_u] = 0;
   int tiles_done = 0;
+  [[maybe_unused]] int ev_cnt = 0;          // EFFECT == 3: events this wave slot has appended
 
   for (long long tile = slot; tile < n_tiles; tile += n_slots) {
     const long long row0 = tile * 16 * R;
@@ -739,6 +749,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
     }
 
     uint4 uacc[R];
+    [[maybe_unused]] const int ev_tile0 = ev_cnt;
     bool eff_cached = false;      // the slot's cache holds the outcome-net values of the tile's current states
     unsigned n_eff_skipped = 0u;
     float ite_c[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // EFFECT == 2: (mean, sd) of the two arms at the tile's current states
@@ -790,12 +801,14 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
         for (int rr = 0; rr < R; ++rr) uacc[rr] = philox4x32_10(rowid[rr], (unsigned)it >> 2, 0u, TAG_ACC, a.k0, a.k1);
       }
       unsigned long long accmask = 0ull;
+      [[maybe_unused]] bool moved[R];      // (the same in the four lanes of a chain: lp / lpp are replicated over the lane groups)
 #pragma unroll
       for (int rr = 0; rr < R; ++rr) {
         const unsigned w = (it & 2) ? ((it & 1) ? uacc[rr].w : uacc[rr].z) : ((it & 1) ? uacc[rr].y : uacc[rr].x);
         const float u = u01_open(w);
         const float ratio = fast_exp(fminf(lpp[rr] - lp[rr], 0.0f));
         const bool acc = u < ratio;
+        moved[rr] = acc;
 #pragma unroll
         for (int t = 0; t < KT1; ++t)
 #pragma unroll
@@ -827,7 +840,28 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
             }
           }
         }
-        if constexpr (EFFECT == 1 && R == 1) {
+        if constexpr (EFFECT == 3) {
+          // event mode: a chain whose proposal was accepted (or every chain at the launch's first iteration, ev_first) appends
+          // (chain, iteration, state) to the slot's region, in time order; nothing else happens at a retained iteration
+          static_assert(R == 1, "event mode: one row tile per wave");
+          const bool ev = valid[0] && (moved[0] || (a.ev_first && it == a.it_begin));
+          const unsigned m16 = (unsigned)(__ballot(ev && g == 0) & 0xFFFFull);
+          if (m16 != 0u) {
+            if (ev) {
+              const long long e = slot * a.ev_cap + ev_cnt + __popc(m16 & ((1u << j) - 1u));
+              float *ez = a.ev_z + e * (long long)m.q;
+#pragma unroll
+              for (int t = 0; t < KT1; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const int f = 16 * t + 4 * r + g;
+                  if (f < m.q) ez[f] = zs[0][t][r];
+                }
+              if (g == 0) a.ev_meta[e] = ((unsigned)(it - a.it_begin) << 4) | (unsigned)j;
+            }
+            ev_cnt += __popc(m16);
+          }
+        } else if constexpr (EFFECT == 1 && R == 1) {
           float2 *cache = reinterpret_cast<float2 *>(a.eff_cache) + slot * (long long)((a.n_doses + 3) >> 2) * 64;
           float *adrf_slot = a.adrf_partial + slot * (long long)a.n_doses * a.n_keep;
           const bool skip = a.eff_skip && eff_cached && accmask == 0ull;                // wave-uniform: nobody moved
@@ -855,6 +889,9 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
     if constexpr (EFFECT != 0 && R == 1) {
       if (a.eff_stats != nullptr && lane == 0 && n_eff_skipped != 0u) atomicAdd(&a.eff_stats[0], (unsigned long long)n_eff_skipped);
     }
+    if constexpr (EFFECT == 3) {
+      if (lane == 0) { a.tile_ev[2 * tile] = ev_tile0; a.tile_ev[2 * tile + 1] = ev_cnt - ev_tile0; }
+    }
     // ---- write the chain state back
     store_z_rows<KT1, R>(a.state, n, m.q, row0, j, g, zs);
 #pragma unroll
@@ -865,6 +902,9 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
     ++tiles_done;
   }
   if (lane == 0) prog[wave_u] = 0x7fffffff;   // finished: the partner never needs to catch up
+  if constexpr (EFFECT == 3) {
+    if (lane == 0) a.slot_cnt[slot] = ev_cnt;
+  }
 #ifdef BGM_PROF
   if (a.clk != nullptr && lane == 0 && slot == 0) for (int i = 0; i < 8; ++i) a.clk[4ll * gridDim.x * WAVES + i] = tsec[i];
 #endif

@@ -359,12 +359,23 @@ class CausalEngine(object):
     def egm_end(self):
         _lib.check(self.lib.bgm_causal_egm_end(self.h, self._stream()), "bgm_causal_egm_end")
 
+    OUTCOME_CACHE_MODES = {False: 0, "off": 0, 0: 0, "wave": 1, 1: 1, True: 2, "chain": 2, 2: 2}
+
     def set_outcome_cache(self, on=True):
-        """Fused ADRF sampler: reuse the outcome net's (mean, sd) of a tile whose chains all stayed put (bit-identical sums; default on)."""
-        _lib.check(self.lib.bgm_causal_set_outcome_cache(self.h, int(bool(on))), "bgm_causal_set_outcome_cache")
+        """Retained phase of the effect samplers: False / 'off' = the outcome net at every retained draw (the reference); 'wave' = reuse
+        the (mean, sd) of a 16-chain tile none of whose chains moved; True / 'chain' (default) = per chain, through the event form of the
+        retained phase where it exists (csrc/causal_event_kernels.h), else 'wave'.  Bit-identical sums in every mode."""
+        if on not in self.OUTCOME_CACHE_MODES:
+            raise ValueError("outcome cache mode must be False / 'off', 'wave' or True / 'chain'; got %r" % (on,))
+        _lib.check(self.lib.bgm_causal_set_outcome_cache(self.h, self.OUTCOME_CACHE_MODES[on]), "bgm_causal_set_outcome_cache")
+
+    def set_event_budget(self, n_bytes):
+        """Upper bound on the event buffers of one segment of the retained phase in its event form (0: BGM_EVENT_BUDGET_MB or 8 GiB)."""
+        _lib.check(self.lib.bgm_causal_set_event_budget(self.h, int(n_bytes)), "bgm_causal_set_event_budget")
 
     def outcome_cache_stats(self, reset=True):
-        """(retained tile-iterations served from the cache, retained tile-iterations) since the last reset."""
+        """(served, total) since the last reset: retained tile-iterations for the per-wave cache, retained chain-iterations for the
+        event form (served = those that needed no outcome-net evaluation)."""
         out = (C.c_int64 * 2)()
         _lib.check(self.lib.bgm_causal_outcome_cache_stats(self.h, out, int(reset)), "bgm_causal_outcome_cache_stats")
         return int(out[0]), int(out[1])

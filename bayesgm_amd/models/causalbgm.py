@@ -94,9 +94,12 @@ class CausalBGM(object):
         if p.get("mh_precision", "fp32") not in ("fp32", "bf16x3", "f16x3"):
             raise ValueError("params['mh_precision'] must be 'fp32', 'bf16x3' or 'f16x3'")
         self.engine.set_precision(p.get("mh_precision", "fp32"))
-        # params['outcome_cache'] (build option, default True): predict's fused ADRF sampler reuses the outcome net's (mean, sd) of the
-        # chains that did not move in a retained iteration (identical results; False = evaluate f at every retained draw as the reference)
-        self.engine.set_outcome_cache(bool(p.get("outcome_cache", True)))
+        # params['outcome_cache'] (build option, default True): predict's ADRF sampler evaluates the outcome net only for the chains that
+        # moved since the last retained draw (identical results; 'wave' = per 16-chain tile, the round-4 form; False = evaluate f at
+        # every retained draw as the reference).  params['event_budget_mb']: bound on the event buffers of one segment (default 8192).
+        self.engine.set_outcome_cache(p.get("outcome_cache", True))
+        if p.get("event_budget_mb"):
+            self.engine.set_event_budget(int(p["event_budget_mb"]) << 20)
         self._push_weights()
         if self.timestamp is None:
             self.timestamp = datetime.datetime.now().astimezone().strftime('%Y%m%d_%H%M%S')

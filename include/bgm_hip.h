@@ -210,7 +210,17 @@ BGM_API int bgm_row_mean_quantiles(bgm_handle *h, const float *in_dev, int64_t n
  * them from the previous evaluation and only draws the new outcome noise: the ADRF sums / treatment effects are bit-identical, the
  * dose evaluations are skipped.  on = 0 evaluates the outcome net at every retained iteration, as the reference does.
  * bgm_causal_outcome_cache_stats: out2[0] = retained tile-iterations served from the cache, out2[1] = retained tile-iterations. */
+/* on = 2 (the default since round 5): the cache works per CHAIN where the event form of the retained phase exists (dose-response sums on
+ * the fp32 LDS-resident kernels, standard-normal prior, up to 32 doses; csrc/causal_event_kernels.h): the retained iterations run as the
+ * pure-transition kernel, every accepted move appends an event (chain, iteration, state), the outcome net runs on dense 16-event tiles
+ * and a third pass adds mean + sd * noise for every (row, retained draw) with the fused kernel's Philox calls, reductions and slot
+ * order -- the sums are bit-identical to on = 0 / 1, only a fraction `acceptance rate` of the outcome-net evaluations remains.
+ * Everywhere else on = 2 behaves as on = 1.  The event buffers of one segment of retained iterations are sized for the worst case
+ * (every chain moves at every iteration); bgm_causal_set_event_budget bounds them (bytes; 0 = BGM_EVENT_BUDGET_MB or 8 GiB): the
+ * retained phase is cut into segments that fit.  Stats in that form: out2[0] = retained chain-iterations that needed no evaluation,
+ * out2[1] = retained chain-iterations. */
 BGM_API int bgm_causal_set_outcome_cache(bgm_handle *h, int32_t on);
+BGM_API int bgm_causal_set_event_budget(bgm_handle *h, int64_t bytes);
 BGM_API int bgm_causal_outcome_cache_stats(bgm_handle *h, int64_t *out2, int32_t reset);
 
 /* Kernel duration bookkeeping for bench.py: when enabled, bgm_causal_mh_run

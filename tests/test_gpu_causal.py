@@ -362,13 +362,13 @@ def test_outcome_cache_is_bit_identical(precision):
     eng = _engine(m)
     eng.set_precision(precision)
     outs = {}
-    for on in (True, False):
+    for on in ('wave', False):
         eng.set_outcome_cache(on)
         eng.outcome_cache_stats(reset=True)
         out = eng.mh_sample(x, y, v, 40, 60, 1.0, 5, want_draws=True, effect=_lib.EFFECT_ADRF, x_values=xs)
         outs[on] = (out["adrf"].cpu().numpy(), out["draws"].cpu().numpy(), out["acc_count"].cpu().numpy(), eng.outcome_cache_stats())
     eng.set_outcome_cache(True)
-    (a1, d1, c1, s1), (a0, d0, c0, s0) = outs[True], outs[False]
+    (a1, d1, c1, s1), (a0, d0, c0, s0) = outs['wave'], outs[False]
     print("served from cache: %d of %d retained tile-iterations (off: %d of %d)" % (s1 + s0))
     assert s1[1] == 188 * 60 and s0 == (0, 188 * 60)
     assert s1[0] > 0.05 * s1[1]                              # q_sd = 1: most proposals are rejected
@@ -376,7 +376,7 @@ def test_outcome_cache_is_bit_identical(precision):
     # 7 doses (two passes, the second partial) and sample_y=False
     for kw in (dict(x_values=np.linspace(0, 2, 7)), dict(x_values=xs, sample_y=False)):
         res = []
-        for on in (True, False):
+        for on in ('wave', False):
             eng.set_outcome_cache(on)
             res.append(eng.mh_sample(x, y, v, 10, 30, 1.0, 6, effect=_lib.EFFECT_ADRF, **kw)["adrf"].cpu().numpy())
         eng.set_outcome_cache(True)
@@ -399,3 +399,66 @@ def test_outcome_cache_binary_treatment_is_bit_identical():
     print("served from cache: %d of %d" % res[True][1])
     assert res[True][1][1] == 125 * 50 and res[True][1][0] > 0 and res[False][1][0] == 0
     assert np.array_equal(res[True][0], res[False][0])
+
+
+@pytest.mark.parametrize("case", [dict(z_dims=[1, 1, 1, 7], p=200, n=3000, doses=20), dict(z_dims=[1, 1, 1, 7], p=200, n=1000, doses=7),
+                                  dict(z_dims=[3, 3, 6, 6], p=100, n=2500, doses=32), dict(z_dims=[1, 1, 1, 7], p=20, n=40000, doses=5),
+                                  dict(z_dims=[1, 1, 1, 7], p=200, n=777, doses=20, sample_y=False)])
+def test_event_form_of_the_retained_phase_is_bit_identical(case):
+    """Outcome cache mode 2 (csrc/causal_event_kernels.h): the retained iterations run as transitions that append an event per accepted
+    move, the outcome net runs on dense 16-event tiles, a spread pass adds mean + sd * noise per (row, draw).  Against the fused kernel
+    with every dose evaluated at every retained draw (mode 0), same Philox streams: chains, acceptance counts and the per-slot ADRF
+    partial sums are equal to the last bit -- in one segment, in several (a small event budget), and with the retained phase split
+    over several calls.  reference: causalbgm/base.py:671-763, 860-899."""
+    from bayesgm_amd import _lib
+    binary = False
+    m = _model(21, case["z_dims"], case["p"], binary)
+    x, y, v = _data(case["n"], case["p"], 22)
+    xs = np.linspace(0, 3, case["doses"])
+    kw = dict(effect=_lib.EFFECT_ADRF, x_values=xs, sample_y=case.get("sample_y", True), want_draws=True)
+    eng = _engine(m)
+    eng.set_outcome_cache(False)
+    ref = eng.mh_sample(x, y, v, 25, 70, 1.0, 5, **kw)
+    eng.set_outcome_cache(True)
+    eng.outcome_cache_stats(reset=True)
+    got = eng.mh_sample(x, y, v, 25, 70, 1.0, 5, **kw)
+    served, total = eng.outcome_cache_stats()
+    acc = float(got["acc_count"].cpu().numpy()[25:].sum()) / (case["n"] * 70)
+    print("event form: %d of %d retained chain-iterations without an outcome-net evaluation (acceptance %.3f)" % (served, total, acc))
+    assert total == case["n"] * 70                                         # the event form ran
+    events = total - served                                                # one per accepted move + one per chain at the first retained iteration
+    assert events == int(got["acc_count"].cpu().numpy()[26:].sum()) + case["n"]
+    for k in ("adrf_partial", "draws", "acc_count", "state", "logp"):
+        assert np.array_equal(got[k].cpu().numpy(), ref[k].cpu().numpy()), k
+    assert np.array_equal(got["adrf"].cpu().numpy(), ref["adrf"].cpu().numpy())
+    # several segments: a budget that holds ~9 retained iterations of this panel
+    n_slots = eng.mh_slots(case["n"])
+    tiles = (case["n"] + 15) // 16
+    per_iter = n_slots * ((tiles + n_slots - 1) // n_slots) * 16 * (4 * sum(case["z_dims"]) + 4 + 32 * ((case["doses"] + 3) // 4))
+    eng.set_event_budget(9 * per_iter + 100)
+    seg = eng.mh_sample(x, y, v, 25, 70, 1.0, 5, **kw)
+    # the retained phase over three calls (chunks of 30 iterations: 25 + 5, 30, 30, 10)
+    chunked = eng.mh_sample(x, y, v, 25, 70, 1.0, 5, chunk=30, **kw)
+    eng.set_event_budget(0)
+    for other in (seg, chunked):
+        for k in ("adrf_partial", "draws", "acc_count", "state"):
+            assert np.array_equal(other[k].cpu().numpy(), ref[k].cpu().numpy()), k
+
+
+def test_event_form_falls_back_where_it_does_not_exist():
+    """more than 32 doses, split precision, a conditional prior: mode 2 runs the fused kernel with the per-wave cache; results unchanged"""
+    from bayesgm_amd import _lib
+    m = _model(23, [1, 1, 1, 7], 200)
+    x, y, v = _data(1500, 200, 24)
+    xs = np.linspace(0, 3, 33)
+    eng = _engine(m)
+    res = {}
+    for on in (True, False):
+        eng.set_outcome_cache(on)
+        eng.outcome_cache_stats(reset=True)
+        res[on] = (eng.mh_sample(x, y, v, 10, 30, 1.0, 6, effect=_lib.EFFECT_ADRF, x_values=xs)["adrf"].cpu().numpy(), eng.outcome_cache_stats())
+    eng.set_outcome_cache(True)
+    assert res[True][1][1] == 94 * 30 and res[True][1][0] > 0           # tile-iterations: the per-wave cache
+    assert np.array_equal(res[True][0], res[False][0])
+    with pytest.raises(ValueError):
+        eng.set_outcome_cache("sometimes")

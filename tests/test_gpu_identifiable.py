@@ -322,6 +322,7 @@ def test_general_width_pack_follows_a_fit_on_the_row_tile_chains():
     xd, yd, vd = (torch.from_numpy(a).to(dev) for a in (x.ravel(), y.ravel(), v))
     zd = torch.from_numpy(z).to(dev)
     zm, zv = torch.zeros_like(zd), torch.zeros_like(zd)
+    eng.set_prior(None, None)            # as IdentifiableCausalBGM.fit does: the minibatch steps take the prior through bgm_prior_step
     npar = eng.fit_begin(n, 32)
     assert "general-width" not in eng.describe(32).split("fit=")[-1]     # the minibatch steps do NOT run on the general-width engine
     grad = torch.empty(npar, device=dev)
@@ -330,6 +331,7 @@ def test_general_width_pack_follows_a_fit_on_the_row_tile_chains():
         eng.fit_theta_grad(xd, yd, vd, zd, idx, 32, grad)
         eng.fit_theta_apply(grad, 1e-2)
     eng.fit_end()
+    eng.set_prior(seg, tab)
     nets = {name: eng.get_weights(i, [W.shape[0] for W, _ in m[name]] + [m[name][-1][0].shape[1]]) for i, name in enumerate(("g", "f", "h"))}
     assert np.abs(nets["g"][0][0] - m["g"][0][0]).max() > 1e-3           # the fit moved the weights
     lp1 = eng.logpost(x.ravel(), y.ravel(), v, z).cpu().numpy()
