@@ -71,6 +71,7 @@ struct bgm_handle {
   // iterations, the outcome net's (mean, sd) per event, and the chains' current pairs carried between the segments of a call
   float *ev_z = nullptr; unsigned *ev_meta = nullptr; int *ev_tile = nullptr, *ev_slot_cnt = nullptr; float *ev_out = nullptr, *ev_carry = nullptr;
   size_t ev_z_cap = 0, ev_meta_cap = 0, ev_tile_cap = 0, ev_slot_cap = 0, ev_out_cap = 0, ev_carry_cap = 0;
+  int ev_carry_flip = 0;
   long long ev_budget_bytes = 0;                  // bgm_causal_set_event_budget (0: BGM_EVENT_BUDGET_MB or 8 GiB)
   bool bx_valid = false;
   alignas(8) unsigned char bx_meta_store[192];

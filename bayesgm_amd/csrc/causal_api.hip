@@ -496,7 +496,7 @@ extern "C" int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *a, void *stre
     else rc = launch_mh<0>(h, ka, grid, lds, stream);
     if (rc) return rc;
     if (a->acc_count_dev) {
-      hipLaunchKernelGGL(acc_reduce_kernel, dim3((segs[s].n + 255) / 256), dim3(256), 0, stream, h->acc_scratch, n_slots,
+      hipLaunchKernelGGL(acc_reduce_kernel, dim3((segs[s].n + 63) / 64), dim3(1024), 0, stream, h->acc_scratch, n_slots,
                          segs[s].n, a->acc_count_dev + segs[s].begin);
       BGM_HIP_CHECK(hipGetLastError());
     }

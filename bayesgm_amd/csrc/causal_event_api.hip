@@ -15,7 +15,7 @@
 #ifndef BGM_MH_WAVES
 #define BGM_MH_WAVES 8
 #endif
-static constexpr int EV_MH_R = BGM_MH_R, EV_MH_WAVES = BGM_MH_WAVES, EV_SPREAD_WAVES = 4;
+static constexpr int EV_MH_R = BGM_MH_R, EV_MH_WAVES = BGM_MH_WAVES, EV_SPREAD_WAVES = 4, EV_SPREAD_LDS_FLOATS = 8192;
 #define BGM_CAUSAL_VARIANTS(X) X(1, 3, 13) X(1, 3, 7) X(1, 3, 2) X(2, 1, 10) X(2, 1, 7) X(2, 1, 2)
 
 // served by the event form: dose-response sums on the fp32 LDS-resident kernels with the standard-normal prior, doses in registers
@@ -51,6 +51,7 @@ int bgm_causal_event_plan(bgm_handle *h, long long n, int n_slots, int n_doses, 
   long long S = std::max(8ll, budget / std::max(1ll, per_iter));
   S = std::min<long long>(S, n_iters);
   S = std::min<long long>(S, (1ll << 27) / std::max(1ll, tps * 16));      // event indices of a slot stay far inside 32 bits
+  S = std::min<long long>(S, std::max(1, EV_SPREAD_LDS_FLOATS / std::max(1, n_doses)));      // the spread pass keeps [S][n_doses] sums in LDS
   S = std::max(1ll, S);
   const long long cap = tps * 16 * S;
   const size_t ev_total = (size_t)n_slots * (size_t)cap;
@@ -60,7 +61,7 @@ int bgm_causal_event_plan(bgm_handle *h, long long n, int n_slots, int n_doses, 
   if ((rc = ev_reserve(h->ev_tile, h->ev_tile_cap, (size_t)n_tiles * 2))) return rc;
   if ((rc = ev_reserve(h->ev_slot_cnt, h->ev_slot_cap, (size_t)n_slots))) return rc;
   if ((rc = ev_reserve(h->ev_out, h->ev_out_cap, ev_total / 16 * (size_t)n_calls * 64 * 2))) return rc;
-  if ((rc = ev_reserve(h->ev_carry, h->ev_carry_cap, (size_t)n_tiles * (size_t)n_calls * 64 * 2))) return rc;
+  if ((rc = ev_reserve(h->ev_carry, h->ev_carry_cap, 2 * (size_t)n_tiles * (size_t)n_calls * 64 * 2))) return rc;      // two buffers, alternating
   *seg_len = (int)S; *ev_cap = cap;
   return BGM_OK;
 }
@@ -101,14 +102,15 @@ int bgm_causal_event_finish(bgm_handle *h, const CausalMhKArgs &ka, int grid, in
   CausalEventFArgs fa{};
   fa.blob = ka.blob; fa.ev_z = h->ev_z; fa.slot_cnt = h->ev_slot_cnt; fa.ev_cap = ka.ev_cap; fa.n_doses = ka.n_doses;
   fa.x_values = ka.x_values; fa.ev_out = reinterpret_cast<float2 *>(h->ev_out); fa.eff_stats = ka.eff_stats; fa.m = ka.m;
-  const int lds = ka.m.total * 4;
   int rc = BGM_E_UNSUPPORTED;
   bool done = false;
+  constexpr int FW = 4, WPS = 2;       // waves per workgroup, waves per sampler slot
 #define X(KT1_, KSL1_)                                                                         \
   if (!done && h->KT1 == KT1_ && h->KSL1 == KSL1_) {                                           \
-    auto k = causal_event_f_kernel<KT1_, KSL1_, EV_MH_WAVES>;                                  \
+    const int lds = 4 * (16 * KT1_ * 64 + 64 + 64 * 32 + 32 + 32 * 16 + 16 + 16 * 16 + 16 + 64); \
+    auto k = causal_event_f_kernel<KT1_, KSL1_, FW, WPS>;                                      \
     if ((rc = ev_set_lds(k, lds))) return rc;                                                  \
-    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * EV_MH_WAVES), lds, stream, fa);                \
+    hipLaunchKernelGGL(k, dim3(grid * EV_MH_WAVES * WPS / FW), dim3(64 * FW), lds, stream, fa); \
     BGM_HIP_CHECK(hipGetLastError());                                                          \
     done = true;                                                                               \
   }
@@ -119,9 +121,14 @@ int bgm_causal_event_finish(bgm_handle *h, const CausalMhKArgs &ka, int grid, in
   sa.n = ka.n; sa.row_base = ka.row_base; sa.it_begin = ka.it_begin; sa.n_iters = ka.n_iters; sa.burn_in = ka.burn_in; sa.n_keep = ka.n_keep;
   sa.sample_y = ka.sample_y; sa.n_doses = ka.n_doses; sa.k0 = ka.k0; sa.k1 = ka.k1;
   sa.ev_meta = h->ev_meta; sa.tile_ev = h->ev_tile; sa.ev_cap = ka.ev_cap; sa.ev_out = reinterpret_cast<const float2 *>(h->ev_out);
-  sa.carry = reinterpret_cast<float2 *>(h->ev_carry); sa.first = first; sa.adrf_partial = ka.adrf_partial;
-  static_assert(EV_MH_WAVES % EV_SPREAD_WAVES == 0, "one spread wave per sampler slot");
-  hipLaunchKernelGGL(causal_event_spread_kernel<EV_SPREAD_WAVES>, dim3(grid * (EV_MH_WAVES / EV_SPREAD_WAVES)), dim3(64 * EV_SPREAD_WAVES), 0, stream, sa);
+  const size_t carry_floats = (size_t)((ka.n + 15) / 16) * (size_t)((ka.n_doses + 3) / 4) * 64 * 2;
+  h->ev_carry_flip = first ? 0 : (h->ev_carry_flip ^ 1);
+  sa.carry_in = reinterpret_cast<const float2 *>(h->ev_carry + (h->ev_carry_flip ^ 1) * carry_floats);
+  sa.carry_out = reinterpret_cast<float2 *>(h->ev_carry + h->ev_carry_flip * carry_floats);
+  sa.first = first; sa.adrf_partial = ka.adrf_partial;
+  // one block of EV_SPREAD_WAVES waves per sampler slot
+  hipLaunchKernelGGL(causal_event_spread_kernel<EV_SPREAD_WAVES>, dim3(grid * EV_MH_WAVES), dim3(64 * EV_SPREAD_WAVES),
+                     sizeof(float) * (size_t)ka.n_iters * (size_t)ka.n_doses, stream, sa);
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
 }

@@ -33,18 +33,35 @@ struct CausalEventFArgs {
   CausalMeta m;
 };
 
-template <int KT1, int KSL1, int WAVES>
+// Only the outcome net's weights go to LDS (16-20 KB of the ~150 KB sampling blob: first layer, x row, the 64 -> 32 -> 8 -> 2 tail), so
+// that four 4-wave workgroups share a CU instead of one 8-wave workgroup: the dose passes are short dependent MFMA chains, and it is
+// other waves that fill their gaps.  WPS waves deal a slot's event tiles among themselves.
+template <int KT1, int KSL1, int WAVES, int WPS>
 __global__ __launch_bounds__(64 * WAVES) void causal_event_f_kernel(CausalEventFArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const CausalMeta &m = a.m;
-  lds_fill(lds, a.blob, m.total);
+  CausalMeta m = a.m;
+  {
+    int off = 0;
+    auto put = [&](int src, int nfl) {
+      for (int i = threadIdx.x; i < nfl; i += 64 * WAVES) lds[off + i] = a.blob[src + i];
+      const int o = off;
+      off += nfl;
+      return o;
+    };
+    m.w1f = put(a.m.w1f, 16 * KT1 * 64); m.b1f = put(a.m.b1f, 64);
+    m.wf2 = put(a.m.wf2, 64 * 32); m.bf2 = put(a.m.bf2, 32); m.wf3 = put(a.m.wf3, 32 * 16); m.bf3 = put(a.m.bf3, 16);
+    m.wf4 = put(a.m.wf4, 16 * 16); m.bf4 = put(a.m.bf4, 16); m.wxf = put(a.m.wxf, 64);
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4, lane_off = 64 * g + j;
-  const long long slot = (long long)blockIdx.x * WAVES + wave;
+  const long long wid = (long long)blockIdx.x * WAVES + wave;
+  const long long slot = wid / WPS;
+  const int sub = (int)(wid % WPS);
   const int cnt = a.slot_cnt[slot];
   const int n_calls = (a.n_doses + 3) >> 2;
-  if (a.eff_stats != nullptr && lane == 0 && cnt > 0) atomicAdd(&a.eff_stats[1], (unsigned long long)cnt);
-  for (int e0 = 0; e0 < cnt; e0 += 16) {
+  if (a.eff_stats != nullptr && lane == 0 && sub == 0 && cnt > 0) atomicAdd(&a.eff_stats[1], (unsigned long long)cnt);
+  for (int e0 = 16 * sub; e0 < cnt; e0 += 16 * WPS) {
     BGM_NO_HOIST();
     const int el = (e0 + j < cnt) ? e0 + j : cnt - 1;           // a partly filled last tile repeats the last event (its columns are not read)
     const float *zr = a.ev_z + (slot * a.ev_cap + el) * (long long)m.q;
@@ -73,46 +90,79 @@ struct CausalEventSpreadArgs {
   const int *tile_ev;
   long long ev_cap;
   const float2 *ev_out;
-  float2 *carry;                     // [n_tiles][n_calls][64]: (mean, sd) of every chain's current state between the segments of a call
-  int first;                         // 1: the segment starts the call (every chain has an event at its first iteration; carry is not read)
+  const float2 *carry_in;            // [n_tiles][n_calls][64]: (mean, sd) of every chain's state at the end of the previous segment of the call
+  float2 *carry_out;                 // the same at the end of this one (another buffer: the block's waves read carry_in at different times)
+  int first;                         // 1: the segment starts the call (every chain has an event at its first iteration; carry_in is not read)
   float *adrf_partial;               // [n_slots][n_keep][n_doses]
 };
 
-// One wave per sampler slot (the same slot -> tile mapping and order as causal_mh_kernel), WAVES waves per block, no LDS.
-template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void causal_event_spread_kernel(CausalEventSpreadArgs a) {
+// One BLOCK of SW waves per sampler slot (the same slot -> tile mapping and tile order as causal_mh_kernel).  The segment's retained
+// iterations are dealt to the block's waves in contiguous sub-ranges: the sums of different draws are different words, so every
+// word still receives its tiles' contributions in tile order (what makes the result independent of the split, and equal to the
+// fused kernel's), while the slot has SW times the waves in flight to cover the latency of the event loads.  A wave finds its
+// chains' states at the start of its sub-range by walking the tile's earlier events (event words only) and loading the pairs of the
+// last one per chain (the carried pairs if there is none).  The sums are accumulated in LDS ([iterations of the segment][doses],
+// LDS float adds: the same fp32 addition, in the same order, as the fused kernel's slot-private L2 atomics) and added to the slot's
+// partial sums once per segment with plain coalesced stores.
+template <int SW>
+__global__ __launch_bounds__(64 * SW) void causal_event_spread_kernel(CausalEventSpreadArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float acc_lds[];      // [n_iters][n_doses]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
   const long long n = a.n, n_tiles = (n + 15) / 16;
-  const long long slot = (long long)blockIdx.x * WAVES + wave, n_slots = (long long)gridDim.x * WAVES;
+  const long long slot = blockIdx.x, n_slots = gridDim.x;
   const int nd = a.n_doses, n_calls = (nd + 3) >> 2, n_own = n_calls & ~3;
-  float *adrf_slot = a.adrf_partial + slot * (long long)nd * a.n_keep;
+  for (int i = threadIdx.x; i < a.n_iters * nd; i += 64 * SW) acc_lds[i] = 0.0f;
+  __syncthreads();
+  // this wave's iterations of the segment
+  const int per = (a.n_iters + SW - 1) / SW;
+  const int dl0 = wave * per < a.n_iters ? wave * per : a.n_iters, dl1 = dl0 + per < a.n_iters ? dl0 + per : a.n_iters;
   for (long long tile = slot; tile < n_tiles; tile += n_slots) {
     const long long row = tile * 16 + j;
     const bool valid = row < n;
     const unsigned rowid = (unsigned)(a.row_base + (valid ? row : n - 1));
-    float2 cur[EV_NCMAX];
-#pragma unroll
-    for (int kb = 0; kb < EV_NCMAX; ++kb) cur[kb] = make_float2(0.0f, 0.0f);
-    float2 *cr = a.carry + tile * (long long)n_calls * 64 + lane;
-    if (!a.first) {
-#pragma unroll
-      for (int kb = 0; kb < EV_NCMAX; ++kb)
-        if (kb < n_calls) cur[kb] = cr[kb * 64];
-    }
     const int eb = a.tile_ev[2 * tile], ec = a.tile_ev[2 * tile + 1];
     const long long base = slot * a.ev_cap + eb;      // the tile's first event
     // the tile's event words, 64 at a time, one per lane
     int p = 0, chunk0 = 0;
     unsigned mchunk = (lane < ec) ? a.ev_meta[base + lane] : 0xFFFFFFFFu;
-    for (int dl = 0; dl < a.n_iters; ++dl) {
+    auto word = [&](int pp) -> unsigned {
+      if (pp - chunk0 >= 64) { chunk0 = pp; mchunk = (pp + lane < ec) ? a.ev_meta[base + pp + lane] : 0xFFFFFFFFu; }
+      return (unsigned)__builtin_amdgcn_readlane((int)mchunk, __builtin_amdgcn_readfirstlane(pp - chunk0));
+    };
+    auto pairs_of = [&](int ev_idx, float2 (&dst)[EV_NCMAX]) {
+      const long long e = base + ev_idx;
+      const float2 *o = a.ev_out + (e >> 4) * (long long)n_calls * 64 + 16 * g + (int)(e & 15);
+#pragma unroll
+      for (int kb = 0; kb < EV_NCMAX; ++kb)
+        if (kb < n_calls) dst[kb] = o[kb * 64];
+    };
+    // ---- the chains' pairs at iteration dl0: the last event before it, else what the previous segment left
+    float2 cur[EV_NCMAX];
+#pragma unroll
+    for (int kb = 0; kb < EV_NCMAX; ++kb) cur[kb] = make_float2(0.0f, 0.0f);
+    const float2 *cr = a.carry_in + tile * (long long)n_calls * 64 + lane;
+    {
+      int last = -1;
+      while (p < ec) {
+        const unsigned w = word(p);
+        if ((int)(w >> 4) >= dl0) break;
+        last = ((int)(w & 15u) == j) ? p : last;
+        ++p;
+      }
+      if (last >= 0) pairs_of(last, cur);
+      else if (!a.first) {
+#pragma unroll
+        for (int kb = 0; kb < EV_NCMAX; ++kb)
+          if (kb < n_calls) cur[kb] = cr[kb * 64];
+      }
+    }
+    for (int dl = dl0; dl < dl1; ++dl) {
       const unsigned it = (unsigned)(a.it_begin + dl);
-      const long long d = (long long)it - a.burn_in;
       // ---- events falling due at this iteration: the chain's lanes request their new pairs (consumed behind the noise below)
       int mine = -1;
       while (p < ec) {
-        if (p - chunk0 >= 64) { chunk0 = p; mchunk = (p + lane < ec) ? a.ev_meta[base + p + lane] : 0xFFFFFFFFu; }
-        const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)mchunk, __builtin_amdgcn_readfirstlane(p - chunk0));
+        const unsigned w = word(p);
         if ((int)(w >> 4) != dl) break;
         mine = ((int)(w & 15u) == j) ? p : mine;
         ++p;
@@ -120,13 +170,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_event_spread_kernel(CausalE
       float2 nxt[EV_NCMAX];
 #pragma unroll
       for (int kb = 0; kb < EV_NCMAX; ++kb) nxt[kb] = cur[kb];
-      if (mine >= 0) {
-        const long long e = base + mine;
-        const float2 *o = a.ev_out + (e >> 4) * (long long)n_calls * 64 + 16 * g + (int)(e & 15);
-#pragma unroll
-        for (int kb = 0; kb < EV_NCMAX; ++kb)
-          if (kb < n_calls) nxt[kb] = o[kb * 64];
-      }
+      if (mine >= 0) pairs_of(mine, nxt);
       // ---- outcome noise of (row, iteration): lane group g evaluates call 4c + g of a group of four calls once and uses its word p
       //      in pass 4c + p (dose 16c + 4g + p); a remainder of fewer than four calls is evaluated by every lane group (word g)
       f32x4 nz_own[EV_NCMAX / 4];
@@ -137,7 +181,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_event_spread_kernel(CausalE
       }
 #pragma unroll
       for (int kb = 0; kb < EV_NCMAX; ++kb) cur[kb] = nxt[kb];
-      // ---- the draw's contribution: same expression, reduction and atomics as causal_effects' grouped path
+      // ---- the draw's contribution: same expression and 16-row reduction as causal_effects' grouped path
 #pragma unroll
       for (int kb = 0; kb < EV_NCMAX; ++kb) {
         if (kb < n_calls) {
@@ -151,12 +195,18 @@ __global__ __launch_bounds__(64 * WAVES) void causal_event_spread_kernel(CausalE
           float y = a.sample_y ? fmaf(cur[kb].y, noise, cur[kb].x) : cur[kb].x;
           y = (valid && k < nd) ? y : 0.0f;
           const float tot = sum_over_j_to_lane15(y);
-          if (j == 15 && k < nd) unsafeAtomicAdd(adrf_slot + d * nd + k, tot);
+          if (j == 15 && k < nd) atomicAdd(&acc_lds[dl * nd + k], tot);      // (ds_add_f32: this wave owns the word)
         }
       }
     }
+    if (dl1 == a.n_iters && dl0 < dl1) {      // the wave holding the segment's last iteration leaves the pairs for the next segment
+      float2 *co = a.carry_out + tile * (long long)n_calls * 64 + lane;
 #pragma unroll
-    for (int kb = 0; kb < EV_NCMAX; ++kb)
-      if (kb < n_calls) cr[kb * 64] = cur[kb];
+      for (int kb = 0; kb < EV_NCMAX; ++kb)
+        if (kb < n_calls) co[kb * 64] = cur[kb];
+    }
   }
+  __syncthreads();
+  float *adrf_slot = a.adrf_partial + slot * (long long)nd * a.n_keep + ((long long)a.it_begin - a.burn_in) * nd;
+  for (int i = threadIdx.x; i < a.n_iters * nd; i += 64 * SW) adrf_slot[i] += acc_lds[i];
 }

@@ -1053,11 +1053,20 @@ __global__ __launch_bounds__(64 * WAVES) void causal_effects_kernel(CausalEffKAr
   }
 }
 
-// acc[it_begin + i] += sum over wave slots of scratch[slot][i]
-static __global__ void acc_reduce_kernel(const unsigned *scratch, int n_slots, int n_iters, unsigned *acc) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_iters) return;
+// acc[it_begin + i] += sum over wave slots of scratch[slot][i].  A block of 1024 threads takes 64 consecutive iterations: thread
+// (i & 63, slot group) adds every 16th slot (rows of 256 contiguous bytes), the 16 groups are combined in LDS (integer sums: any order).
+static __global__ __launch_bounds__(1024) void acc_reduce_kernel(const unsigned *scratch, int n_slots, int n_iters, unsigned *acc) {
+  __shared__ unsigned part[16][64];
+  const int ti = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + ti;
   unsigned s = 0;
-  for (int k = 0; k < n_slots; ++k) s += scratch[(long long)k * n_iters + i];
-  acc[i] += s;
+  if (i < n_iters)
+    for (int k = sg; k < n_slots; k += 16) s += scratch[(long long)k * n_iters + i];
+  part[sg][ti] = s;
+  __syncthreads();
+  if (sg == 0 && i < n_iters) {
+#pragma unroll
+    for (int u = 1; u < 16; ++u) s += part[u][ti];
+    acc[i] += s;
+  }
 }

@@ -431,6 +431,10 @@ def test_event_form_of_the_retained_phase_is_bit_identical(case):
     for k in ("adrf_partial", "draws", "acc_count", "state", "logp"):
         assert np.array_equal(got[k].cpu().numpy(), ref[k].cpu().numpy()), k
     assert np.array_equal(got["adrf"].cpu().numpy(), ref["adrf"].cpu().numpy())
+    if case["n"] <= 1000:      # and against the float64 restatement of infer_from_latent_posterior on the same draws (oracle/causal.py)
+        oref = OC.infer_from_latent_posterior(OC.cast_model(m, np.float64), got["draws"].cpu().numpy().astype(np.float64), xs,
+                                              case.get("sample_y", True), 5, burn_in=25)
+        assert np.abs(got["adrf"].cpu().numpy() - oref).max() <= 2e-4
     # several segments: a budget that holds ~9 retained iterations of this panel
     n_slots = eng.mh_slots(case["n"])
     tiles = (case["n"] + 15) // 16
