@@ -349,13 +349,59 @@ def bayesian_leg(params, data, x_values, n_loc, args, device):
     return out
 
 
-def accuracy_leg(params, data, x_values, n_loc, args):
-    """The accuracy half of the metric ("... + ATE abs-error"): the model class of the headline number (deterministic nets)
-    is TRAINED with the reference's default schedule on the tutorial panel (Hirano-Imbens N = 20000, p = 200; 30000 EGM
-    iterations + 100 epochs, causalbgm/base.py:434 defaults), then predicts on the bench panel (N rows of the same generator,
-    other seed) with the bench's MCMC settings, in fp32 and in split precision; errors against the analytic dose-response
-    curve utils.get_ADRF(..., 'Imbens').  `published_configuration`: the reference's default Bayesian-network model on the
-    tutorial's own setting (one run; the distribution over seeds: profiles/r03_accuracy/, tests/test_tutorial_trace.py)."""
+def end_to_end_leg(params, x, y, v, x_values, n_loc, args, use_bnn, epochs=100, tag="det"):
+    """The whole job a user runs on the bench panel, seconds per phase: CausalBGM(params).fit(...) with the
+    reference's defaults (egm_init: 30000 iterations of 5 discriminator + 1 generator step at B = 32; `epochs` epochs of N / 32
+    minibatches, evaluation every 5 epochs; causalbgm/base.py:380-532) followed by predict with the bench's MCMC settings in the
+    product's default configuration.  Returns (object, trained model).  The fit is a latency chain of 32-row minibatches:
+    its time is minibatches x microseconds per minibatch, whatever the GPU's arithmetic rate."""
+    import contextlib
+    import torch
+    from bayesgm_amd.models import CausalBGM
+    from bayesgm_amd.utils import get_ADRF
+    t = {}
+    with contextlib.redirect_stdout(sys.stderr):
+        m = CausalBGM(dict(params, use_bnn=use_bnn), timestamp="bench_e2e_" + tag, random_seed=123)
+        egm = m.egm_init
+
+        def timed_egm(*a_, **k_):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            r = egm(*a_, **k_)
+            torch.cuda.synchronize(); t["egm_init"] = time.perf_counter() - t0
+            return r
+        m.egm_init = timed_egm
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        m.fit((x, y, v), epochs=epochs, epochs_per_eval=5, batch_size=32, use_egm_init=True, egm_n_iter=30000, egm_batches_per_eval=500, verbose=0)
+        torch.cuda.synchronize(); t["fit_total"] = time.perf_counter() - t0
+        m.egm_init = egm
+        m._seed_counter = 0
+        t0 = time.perf_counter()
+        adrf, interval = m.predict((x, y, v), alpha=0.01, n_mcmc=args.n_mcmc, burn_in=args.burn_in, x_values=x_values, q_sd=1.0, sample_y=True,
+                                   verbose=0, **({"bs": 10000} if use_bnn else {}))
+        torch.cuda.synchronize(); t["predict"] = time.perf_counter() - t0
+    truth = get_ADRF(x_values=list(x_values), dataset="Imbens")
+    err = np.asarray(adrf) - truth
+    n_mb = (epochs + 1) * ((n_loc + 31) // 32)
+    fit_loop = t["fit_total"] - t.get("egm_init", 0.0)
+    out = {"model": "CausalBGM(use_bnn=%s)" % use_bnn, "rows": n_loc, "epochs": epochs, "egm_iterations": 30000,
+           "seconds": {"egm_init": t.get("egm_init"), "fit_epochs": fit_loop, "predict": t["predict"], "total": t["fit_total"] + t["predict"]},
+           "minibatches": n_mb, "us_per_minibatch_incl_evaluations": 1e6 * fit_loop / n_mb,
+           "observations_x_epochs_per_s": (epochs + 1) * n_loc / fit_loop,
+           "predict_transitions_per_s": n_loc * (args.burn_in + args.n_mcmc) / t["predict"], "acceptance_rate": m.last_acceptance_rate,
+           "adrf_rmse": float(np.sqrt(np.mean(err ** 2))), "average_effect_abs_error": float(abs(err.mean())), "best_epoch": getattr(m, "best_epoch", None),
+           "sample": "fit((x, y, v), epochs=%d, epochs_per_eval=5, batch_size=32, use_egm_init=True, egm_n_iter=30000) + predict(n_mcmc=%d, burn_in=%d, "
+                     "20 doses) on the bench panel itself (N=%d, p=%d); epochs + 1 passes as the reference loops range(epochs + 1) (base.py:488)"
+                     % (epochs, args.n_mcmc, args.burn_in, n_loc, args.p)}
+    return out, m
+
+
+def accuracy_leg(params, data, x_values, n_loc, args, m=None, with_published=True):
+    """The accuracy half of the metric ("... + ATE abs-error"): the model class of the headline number (deterministic nets) TRAINED with
+    the reference's default schedule (30000 EGM iterations + 100 epochs, causalbgm/base.py:434 defaults) -- `m`, the end-to-end leg's
+    model trained on the bench panel itself, or (m = None) a model trained here on the tutorial panel (Hirano-Imbens N = 20000) --
+    predicts on the bench panel with the bench's MCMC settings, in fp32 and in split precision; errors against the analytic
+    dose-response curve utils.get_ADRF(..., 'Imbens').  `published_configuration`: the reference's default Bayesian-network model on
+    the tutorial's own setting (one run; the distribution over seeds: profiles/r03_accuracy/, tests/test_tutorial_trace.py)."""
     import contextlib
     import torch
     from bayesgm_amd.models import CausalBGM
@@ -364,15 +410,19 @@ def accuracy_leg(params, data, x_values, n_loc, args):
     truth = get_ADRF(x_values=list(x_values), dataset="Imbens")
     x, y, v = Sim_Hirano_Imbens_sampler(N=20000, v_dim=args.p, seed=0).load_all()
     out = {}
+    trained_on = "the bench panel (end_to_end leg)"
     with contextlib.redirect_stdout(sys.stderr):
-        m = CausalBGM(dict(params, use_bnn=False), timestamp="bench_acc", random_seed=123)
-        t0 = time.perf_counter()
-        m.fit((x, y, v), epochs=100, epochs_per_eval=100, use_egm_init=True, egm_n_iter=30000, egm_batches_per_eval=30000, verbose=0)
-        torch.cuda.synchronize()
-        out["fit_seconds"] = time.perf_counter() - t0
+        if m is None:
+            trained_on = "Sim_Hirano_Imbens N=20000 seed 0"
+            m = CausalBGM(dict(params, use_bnn=False), timestamp="bench_acc", random_seed=123)
+            t0 = time.perf_counter()
+            m.fit((x, y, v), epochs=100, epochs_per_eval=100, use_egm_init=True, egm_n_iter=30000, egm_batches_per_eval=30000, verbose=0)
+            torch.cuda.synchronize()
+            out["fit_seconds"] = time.perf_counter() - t0
         for mode in ("fp32", "bf16x3", "f16x3"):
             m.engine.set_precision(mode)
             m._seed_counter = 0
+            m.engine.outcome_cache_stats(reset=True)
             t0 = time.perf_counter()
             adrf, interval = m.predict(data, alpha=0.01, n_mcmc=args.n_mcmc, burn_in=args.burn_in, x_values=x_values, q_sd=1.0,
                                        sample_y=True, verbose=0)
@@ -390,29 +440,30 @@ def accuracy_leg(params, data, x_values, n_loc, args):
         from bayesgm_amd import diagnostics
         with warnings.catch_warnings(record=True) as caught:
             warnings.simplefilter("always")
-            mb = CausalBGM(dict(params, use_bnn=True), timestamp="bench_acc_bnn", random_seed=123)
-            t0 = time.perf_counter()
-            mb.fit((x, y, v), epochs=100, epochs_per_eval=10, use_egm_init=True, egm_n_iter=30000, egm_batches_per_eval=500, verbose=0)
-            torch.cuda.synchronize()
-            fit_s = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            adrf, interval = mb.predict((x, y, v), alpha=0.01, n_mcmc=3000, burn_in=5000, x_values=x_values, q_sd=1.0, sample_y=True, bs=20000)
-            torch.cuda.synchronize()
-            err = adrf - truth
-            out["published_configuration"] = {
-                "adrf_rmse": float(np.sqrt(np.mean(err ** 2))), "adrf_mape": float(np.mean(np.abs(err / truth))),
-                "average_effect_abs_error": float(abs(err.mean())), "acceptance_rate": mb.last_acceptance_rate,
-                "fit_seconds": fit_s, "predict_seconds": time.perf_counter() - t0,
-                "egm_late_l2_loss_z": getattr(mb, "_egm_late_l2z", None),
-                "second_optimum_warning": any(issubclass(w.category, diagnostics.SecondOptimumWarning) for w in caught),
-                "sample": "CausalBGM(use_bnn=True), random_seed 123: fit (30000 EGM iterations + 100 epochs) and predict(n_mcmc=3000, "
-                          "burn_in=5000, q_sd=1.0, bs=20000) on Sim_Hirano_Imbens N=20000 p=%d seed 0 -- the tutorial's setting" % args.p}
+            if with_published:
+                mb = CausalBGM(dict(params, use_bnn=True), timestamp="bench_acc_bnn", random_seed=123)
+                t0 = time.perf_counter()
+                mb.fit((x, y, v), epochs=100, epochs_per_eval=10, use_egm_init=True, egm_n_iter=30000, egm_batches_per_eval=500, verbose=0)
+                torch.cuda.synchronize()
+                fit_s = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                adrf, interval = mb.predict((x, y, v), alpha=0.01, n_mcmc=3000, burn_in=5000, x_values=x_values, q_sd=1.0, sample_y=True, bs=20000)
+                torch.cuda.synchronize()
+                err = adrf - truth
+                out["published_configuration"] = {
+                    "adrf_rmse": float(np.sqrt(np.mean(err ** 2))), "adrf_mape": float(np.mean(np.abs(err / truth))),
+                    "average_effect_abs_error": float(abs(err.mean())), "acceptance_rate": mb.last_acceptance_rate,
+                    "fit_seconds": fit_s, "predict_seconds": time.perf_counter() - t0,
+                    "egm_late_l2_loss_z": getattr(mb, "_egm_late_l2z", None),
+                    "second_optimum_warning": any(issubclass(w.category, diagnostics.SecondOptimumWarning) for w in caught),
+                    "sample": "CausalBGM(use_bnn=True), random_seed 123: fit (30000 EGM iterations + 100 epochs) and predict(n_mcmc=3000, "
+                              "burn_in=5000, q_sd=1.0, bs=20000) on Sim_Hirano_Imbens N=20000 p=%d seed 0 -- the tutorial's setting" % args.p}
     out["interval_coverage_note"] = (f"the interval is the posterior interval of a MEAN over {n_loc} rows (width ~ sd/sqrt(N)): it "
                                      "covers Monte-Carlo error of the chains, not the fit's bias, so coverage of the truth well below "
                                      "1 - alpha is expected and is not a calibration statement")
-    out["sample"] = (f"CausalBGM(use_bnn=False): fit on Sim_Hirano_Imbens N=20000 p={args.p} seed 0 (reference defaults: 30000 EGM "
+    out["sample"] = (f"CausalBGM(use_bnn=False) trained on {trained_on} (reference defaults: 30000 EGM "
                      f"iterations + 100 epochs, batch 32), predict on the bench panel N={n_loc} with burn_in={args.burn_in}, "
-                     f"n_mcmc={args.n_mcmc}, {len(x_values)} doses; truth = x + 2/(1+x)^3")
+                     f"n_mcmc={args.n_mcmc}, {len(x_values)} doses, product defaults (outcome cache on); truth = x + 2/(1+x)^3")
     out["reference_published"] = {"adrf_rmse": 0.0188, "adrf_mape": 0.0103,
                                   "note": "docs/source/causalbgm/tutorial_py.ipynb (use_bnn=True, N=20000 train = test panel)"}
     return out
@@ -421,13 +472,15 @@ def accuracy_leg(params, data, x_values, n_loc, args):
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
 
 
-def outcome_cache_leg(model, data, x_values, n_loc, args, seed_counter, adrf_ref, value_ref):
-    """Secondary measurement: the same predict with the product's default outcome-net cache (bgm_causal_set_outcome_cache(1)): a retained
-    iteration in which none of the 16 chains of a wave moved reuses the (mean, sd) of the previous evaluation of f at the 20 doses and only
-    draws the new outcome noise.  Same Philox streams as the last headline step: the ADRF must be identical to the last bit."""
+def outcome_cache_leg(model, data, x_values, n_loc, args, seed_counter, adrf_ref, value_ref, mode=True):
+    """Secondary measurement: the same predict with the outcome-net cache.  mode True (the product's default, bgm_causal_set_outcome_cache(2)):
+    per CHAIN, the event form of the retained phase (csrc/causal_event_kernels.h: transitions that append an event per accepted move,
+    the outcome net on dense 16-event tiles, a spread pass per (row, draw)); mode 'wave' (round 4): a retained iteration in which none
+    of the 16 chains of a wave moved reuses the previous (mean, sd).  Same Philox streams as the last headline step: the ADRF must be
+    identical to the last bit in both."""
     import torch
     eng = model.engine
-    eng.set_outcome_cache(True)
+    eng.set_outcome_cache(mode)
     try:
         eng.outcome_cache_stats(reset=True)
         eng.timing_enable(True)
@@ -445,12 +498,12 @@ def outcome_cache_leg(model, data, x_values, n_loc, args, seed_counter, adrf_ref
     finally:
         eng.set_outcome_cache(False)
     v = n_loc * (args.burn_in + args.n_mcmc) / dt
-    return {"value": v, "unit": "MH transitions/s", "seconds": dt, "speedup_vs_headline": v / value_ref,
-            "keep_kernel_ms": ms_k / max(1, n_k), "tile_iterations_served_from_cache": served, "retained_tile_iterations": total,
+    unit = "retained chain-iterations" if mode is True else "retained tile-iterations (16 chains)"
+    return {"mode": "per chain (event form)" if mode is True else "per wave of 16 chains", "value": v, "unit": "MH transitions/s", "seconds": dt,
+            "speedup_vs_headline": v / value_ref, "keep_phase_ms": ms_k / max(1, n_k), "served": served, "of": total, "counted_in": unit,
             "served_fraction": served / max(1, total), "acceptance_rate": model.last_acceptance_rate,
             "adrf_max_abs_diff_vs_headline": float(np.abs(np.asarray(adrf) - np.asarray(adrf_ref)).max()),
-            "note": "product default (params['outcome_cache'] = True); the headline `value` and `roofline` are measured with it OFF, "
-                    "every dose evaluated at every retained draw"}
+            "note": "the headline `value` and `roofline` are measured with the cache OFF, every dose evaluated at every retained draw"}
 
 
 def bf16x3_leg(model, data, x_values, n_loc, args, z_dims, flop_row_transition, flop_row_keep, seed_counter, mode="bf16x3"):
@@ -576,6 +629,9 @@ def main():
                     help="weak: --rows per GPU (default); strong: --rows in TOTAL, sharded over the GPUs (BASELINE configs[3]: N=1e6 over 8 GPUs)")
     ap.add_argument("--no-bf16x3", action="store_true", help="skip the secondary split-precision (bf16 x 3) measurement (N=1 only)")
     ap.add_argument("--no-accuracy", action="store_true", help="skip the accuracy leg (fit on the tutorial panel + ADRF error; N=1 only)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the end-to-end leg (egm_init + fit(epochs=100) + predict on the bench panel, deterministic nets; N=1 only)")
+    ap.add_argument("--end-to-end-bnn", type=int, default=0, metavar="EPOCHS",
+                    help="also run the end-to-end job with the reference's default Bayesian nets for EPOCHS epochs (100 = the full default job, ~6 minutes at N=1e6; off by default)")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="launch / rendezvous check without a device: every rank joins the process group over gloo on the CPU, the rank "
                          "count is all-reduced and rank 0 prints {n_gpus, n_ranks_in_collective}; no kernel runs (tests/test_bench_launch.py)")
@@ -775,7 +831,8 @@ def main():
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
             out["parity"] = parity_leg(model, x, y, v, z_dims, p, x_values)
         if world == 1:
-            out["outcome_cache"] = outcome_cache_leg(model, data, x_values, n_loc, args, seed_counter_last, adrf, value)
+            out["outcome_cache"] = outcome_cache_leg(model, data, x_values, n_loc, args, seed_counter_last, adrf, value, mode=True)
+            out["outcome_cache"]["per_wave"] = outcome_cache_leg(model, data, x_values, n_loc, args, seed_counter_last, adrf, value, mode="wave")
         if not args.no_bf16x3 and world == 1:      # before the fit leg, which trains (changes) the weights of `model`
             out["bf16x3"] = bf16x3_leg(model, data, x_values, n_loc, args, z_dims, info.flop_per_row_transition, flop_keep_row, seed_counter_last)
             out["bf16x3"]["speedup_vs_fp32"] = out["bf16x3"]["value"] / value
@@ -785,8 +842,13 @@ def main():
             f16["speedup_vs_fp32"] = f16["value"] / value
             f16["adrf_max_abs_diff_vs_fp32"] = float(np.abs(f16.pop("adrf") - adrf).max())
             out["bf16x3"]["f16x3"] = f16
+        trained = None
+        if not args.no_end_to_end and world == 1:
+            out["end_to_end"], trained = end_to_end_leg(params, x, y, v, x_values, n_loc, args, use_bnn=False)
         if not args.no_accuracy and world == 1:
-            out["accuracy"] = accuracy_leg(params, data, x_values, n_loc, args)
+            out["accuracy"] = accuracy_leg(params, data, x_values, n_loc, args, m=trained)
+        if args.end_to_end_bnn > 0 and world == 1:
+            out["end_to_end_bayesian"], _ = end_to_end_leg(params, x, y, v, x_values, n_loc, args, use_bnn=True, epochs=args.end_to_end_bnn, tag="bnn")
         if not args.no_bayesian and world == 1:
             out["bayesian_nets"] = bayesian_leg(params, data, x_values, n_loc, args, device)
         if not args.no_bgm and world == 1:
