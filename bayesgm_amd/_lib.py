@@ -141,6 +141,13 @@ SYMBOLS = {
                                  C.c_void_p, C.c_float, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bgm_prior_apply": (C.c_int, [C.c_void_p, C.POINTER(PriorConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64,
                                   C.c_void_p]),
+    "bgm_bprior_n_params": (C.c_int, [C.POINTER(PriorConfig), C.POINTER(C.c_int64)]),
+    "bgm_bprior_step": (C.c_int, [C.c_void_p, C.POINTER(PriorConfig), C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_int64, C.c_int64, C.c_uint64,
+                                  C.c_uint32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "bgm_bprior_apply": (C.c_int, [C.c_void_p, C.POINTER(PriorConfig), C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64,
+                                   C.c_void_p]),
+    "bgm_bnn_set_prior": (C.c_int, [C.c_void_p, C.POINTER(PriorConfig), C.c_void_p, C.c_void_p]),
     "bgm_causal_describe": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32]),
     "bgm_causal_fit_z_sync": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p]),
     "bgm_causal_fit_epoch": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

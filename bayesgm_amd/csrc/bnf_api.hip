@@ -225,6 +225,10 @@ int bnf_logpost(bgm_handle *h, BnnState *s, const float *x, const float *y, cons
   a.bs = block_rows; a.n_blocks = n_blocks; a.block0 = block0;
   a.groups_per_block = ((block_rows + 15) / 16 + c.R - 1) / c.R; a.n_items = n_blocks * a.groups_per_block; a.n_states = 1;
   a.mode = 0; a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32); a.out = out; a.queue = st->queue_dev;
+  if (s->bp_on) {      // conditional prior: one noisy call of the prior net for this evaluation (bprior_api.hip)
+    if ((rc = bprior_rows(h, s, n, block_rows, block0, seed, stream_id, 1, stream))) return rc;
+    a.prior = s->bp_rows; a.prior_stride = 0;
+  }
   rc = set_lds(fn, st->lds_mh);
   if (rc) return rc;
   hipLaunchKernelGGL(fn, dim3(grid_for(h)), dim3(64 * c.W), st->lds_mh, stream, a);
@@ -303,6 +307,10 @@ int bnf_mh_run(bgm_handle *h, BnnState *s, const bgm_bnn_mh_args *g, hipStream_t
     launch_noise(st, false, st->dw_dev, P.set_floats, n_blocks, 2, g->seed, 2u * (uint32_t)it, g->block0, stream);
     launch_signs(L, n, bs, g->block0, 2, 7, g->seed, 2u * (uint32_t)it, st->queue_dev, stream);
     a.it = it; a.init = (i == 0 && g->init) ? 1 : 0;
+    if (s->bp_on) {    // conditional prior: the two evaluations' own calls of the prior net (streams 2 it, 2 it + 1)
+      if ((rc = bprior_rows(h, s, n, bs, g->block0, g->seed, 2u * (uint32_t)it, 2, stream))) return rc;
+      a.prior = s->bp_rows; a.prior_stride = n * (long long)(q + 2);
+    }
     a.acc_blocks = g->acc_blocks_dev ? g->acc_blocks_dev + (long long)i * n_blocks : nullptr;
     hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * c.W), st->lds_mh, stream, a);
     const int d = it - g->burn_in;

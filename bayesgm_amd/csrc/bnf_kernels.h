@@ -389,8 +389,28 @@ struct BnfMhArgs {
   float *lp_cache;                     // deterministic nets, MODE 1: [n] log posterior of the current states (in / out)
   double *sums;                        // MODE 2: [3] += sum |v - mu_v|^2, sum (x - x_pred)^2, sum (y - mu_y)^2
   float sig2_v, sig2_x, sig2_y;        // fixed variances params['sigma_*']^2 (<= 0: the networks' variance heads)
+  // conditional latent prior (IdentifiableCausalBGM, bprior_kernels.h): [n_states][n][q + 2] = mu [q], 1 / sigma^2, (q / 2) log sigma^2 of
+  // every row for the state's call of the prior net, or NULL = N(0, I)
+  const float *prior;
+  long long prior_stride;              // floats between the states' tables
   unsigned long long *prof;            // -D BNF_PROF
 };
+
+// The prior term of a row's log posterior through the standard-normal slot of bnf_logpost_rows: it takes zz, the lane's share of
+// |z|^2, and returns  ... - zz / 2  summed over the lane groups; with a conditional prior the share becomes (z - mu)^2 / sigma^2 over the
+// lane's features and (q / 2) log sigma^2 is subtracted afterwards (returned in lc).
+template <int KS>
+__device__ __forceinline__ float bnf_prior_share(const float *pr, int q, int g, const float (&z)[KS], float &lc) {
+  float s = 0.0f;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int f = 16 * (ks >> 2) + 4 * (ks & 3) + g;
+    const float d = z[ks] - pr[min(f, q - 1)];
+    s = f < q ? fmaf(d, d, s) : s;
+  }
+  lc = pr[q + 1];
+  return s * pr[q];
+}
 
 // DET: deterministic nets.  WIDE: g's last layer does not fit the LDS next to the rest (p > 207 at the default widths): its loc
 // fragments stay in the packed blob in HBM / L2 and are requested one output tile ahead, like the perturbations (the workgroups of
@@ -728,11 +748,15 @@ static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_mh_kernel(Bn
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
           if (16 * (ks >> 2) + 4 * (ks & 3) + g == q) zc[rt][ks] = xr[rt];
-      float lp[R], aux[R][3];
+      float lp[R], aux[R][3], lc0[R];
+      if (a.prior) {
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) zzc[rt] = bnf_prior_share<KS>(a.prior + (blk_lo + rib[rt]) * (long long)(q + 2), q, g, zc[rt], lc0[rt]);
+      }
       bnf_logpost_rows<KS, R, DET, WIDE>(a, L, lane, j, g, blk_lo, rib, zc, xr, yr, dwblk, 0, zzc, lp, aux BNF_PROF_ARG);
 #pragma unroll
       for (int rt = 0; rt < R; ++rt)
-        if (valid[rt] && g == 0) a.out[blk_lo + rib[rt]] = lp[rt];
+        if (valid[rt] && g == 0) a.out[blk_lo + rib[rt]] = a.prior ? lp[rt] - lc0[rt] : lp[rt];
       continue;
     }
     if constexpr (MODE == 2) {      // evaluate: reconstruction errors of g, h, f at the given latents
@@ -793,17 +817,23 @@ static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_mh_kernel(Bn
     }
 #pragma nounroll
     for (int st = 0; st < st_hi; ++st) {
-      float zs[R][KS], zzs[R], lp[R], aux[R][3];
+      float zs[R][KS], zzs[R], lp[R], aux[R][3], lcs[R];
 #pragma unroll
       for (int rt = 0; rt < R; ++rt) {
         zzs[rt] = st ? zzc[rt] : zzp[rt];
+        lcs[rt] = 0.0f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) zs[rt][ks] = st ? zc[rt][ks] : zp[rt][ks];
+      }
+      if (a.prior) {      // the state's own call of the prior net (fresh noise per log-posterior evaluation, as for g, h, f)
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt)
+          zzs[rt] = bnf_prior_share<KS>(a.prior + (long long)st * a.prior_stride + (blk_lo + rib[rt]) * (long long)(q + 2), q, g, zs[rt], lcs[rt]);
       }
       bnf_logpost_rows<KS, R, DET, WIDE>(a, L, lane, j, g, blk_lo, rib, zs, xr, yr, DET ? nullptr : dwblk + (long long)st * P.set_floats, st, zzs,
                                          lp, aux BNF_PROF_ARG);
 #pragma unroll
-      for (int rt = 0; rt < R; ++rt) { if (st) lpc[rt] = lp[rt]; else lpp[rt] = lp[rt]; }
+      for (int rt = 0; rt < R; ++rt) { if (st) lpc[rt] = lp[rt] - lcs[rt]; else lpp[rt] = lp[rt] - lcs[rt]; }
     }
     unsigned nacc = 0;
 #pragma unroll

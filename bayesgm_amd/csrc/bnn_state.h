@@ -9,6 +9,7 @@
 #define BNN_ADAM_B2 0.99f
 #define BNN_ADAM_EPS 1e-7f
 
+#include "bprior_types.h"
 struct BnnState {
   bgm_bnn_config cfg{};
   BnnNet net[4];
@@ -30,7 +31,15 @@ struct BnnState {
   void *egm = nullptr;         // BnnEgmState (bnn_egm_api.hip)
   void *chain = nullptr;       // BnnFitChain (bnn_api.hip): tables / workspace of the row-tile-chain step kernels, or NULL
   void *bnw = nullptr;         // BnwState (bnw_api.hip): buffers of the any-width sampling path
+  // conditional latent prior of IdentifiableCausalBGM(use_bnn=True) for the sampling calls (bprior_api.hip, bgm_bnn_set_prior)
+  bool bp_on = false;
+  BPriorNet bp_net{};
+  const float *bp_theta = nullptr;
+  const int *bp_seg = nullptr;
+  float *bp_rows = nullptr;    // [n_states][n][q + 2] of the current call
+  size_t bp_rows_cap = 0;
 };
+int bprior_rows(bgm_handle *h, BnnState *s, long long n, int bs, int block0, uint64_t seed, uint32_t stream0, int n_states, hipStream_t stream);
 
 void bgm_bnn_egm_free(void *egm_state);
 void bnf_free(void *state);
@@ -54,4 +63,6 @@ inline void bnn_free_sampler(BnnState *s) {
   if (s->bnw) bnw_free(s->bnw);
   s->bnw = nullptr;
   s->bnf_valid = false;
+  if (s->bp_rows) hipFree(s->bp_rows);
+  s->bp_rows = nullptr; s->bp_rows_cap = 0;
 }

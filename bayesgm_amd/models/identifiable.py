@@ -9,8 +9,8 @@ and the MH / log-posterior kernels that read it (`bgm_causal_set_prior`, the PRI
 torch holds the arrays and nothing else.
 
 Stated differences.  (i) The reference's `fit` unpacks seven values from `evaluate`, which returns four (:334 vs base.py:555,570),
-so it fails at the first evaluation; the build evaluates as CausalBGM does.  (ii) `use_bnn=True` (a Bayesian prior network on the
-Bayesian-network kernels) is not built: NotImplementedError.  (iii) `fit` and `predict` shard the rows over
+so it fails at the first evaluation; the build evaluates as CausalBGM does.  (ii) `use_bnn=True` constructs the Bayesian form,
+models/identifiable_bnn.py (a Bayesian prior network on the Bayesian-network kernels).  (iii) `fit` and `predict` shard the rows over
 the ranks of torch.distributed (with the adaptive proposal scale the window's acceptance count is all-reduced)."""
 import ctypes as C
 
@@ -36,11 +36,15 @@ def _unflatten(flat, dims):
 
 class IdentifiableCausalBGM(CausalBGM):
     def __new__(cls, params=None, *args, **kwargs):
+        # params['use_bnn'] (indexed without a default by the reference, :56): the Bayesian-network model lives in identifiable_bnn.py
+        if cls is IdentifiableCausalBGM and params is not None and params.get('use_bnn', False):
+            from .identifiable_bnn import IdentifiableCausalBGMBayes
+            inst = object.__new__(IdentifiableCausalBGMBayes)     # (not a subclass of this class: Python will not call __init__ for us)
+            inst.__init__(params, *args, **kwargs)
+            return inst
         return object.__new__(cls)
 
     def __init__(self, params, timestamp=None, random_seed=None, device=None):
-        if params.get('use_bnn', False):
-            raise NotImplementedError("bayesgm_amd: IdentifiableCausalBGM is built for use_bnn=False (deterministic networks) only")
         if 'n_segments' not in params:
             params['n_segments'] = 10                                                         # :50-51
         CausalBGM.__init__(self, params, timestamp=timestamp, random_seed=random_seed, device=device)

@@ -118,6 +118,31 @@ BGM_API int bgm_prior_grad(bgm_handle *h, const bgm_prior_config *cfg, const flo
                    float *grad_dev, float *out_dev, void *stream);
 BGM_API int bgm_prior_apply(bgm_handle *h, const bgm_prior_config *cfg, float *theta_dev, float *m_dev, float *v_dev, const float *grad_dev,
                     float lr_prior, int64_t t_prior, void *stream);
+/* ---- the same with a BAYESIAN prior network, IdentifiableCausalBGM(use_bnn=True): prior_net = BayesianFullyConnectedNet(n_segments ->
+ * prior_units -> q + 1) (identifiable.py:66-67; networks/bnn.py:4-38).  Parameter layout (as the nets of bgm_bnn_begin): gamma [k],
+ * beta [k], then per layer loc [in x out], rho [in x out], bias [out]; bgm_bprior_n_params counts them.  norm_mode: input
+ * BatchNormalization on 0 = the statistics of the batch at hand, 1 = fixed mean 0 / variance 1 (bgm_bnn_config.norm_mode).
+ * Noise: key = seed, call id = stream_id, net id 4 in the streams of oracle/bnn.py; row b of the minibatch draws its sign words as row
+ * row0 + b (row0: this rank's first position in the global minibatch).
+ * bgm_bprior_step replaces the conditional-prior half of update_latent_variable_sgd with use_bnn (identifiable.py:195-226):
+ * dz_dev [batch x q] = gradient of the batch-mean negative log joint with the standard-normal prior (bgm_bnn_z_step with dz_out_dev);
+ * the call exchanges the prior term, takes the latent step with fresh Adam slots (step count t_z) and one Adam step (slots m_dev /
+ * v_dev, step count t_prior, lr_prior) on the prior net with the gradient of  batch-mean prior term + kl_weight * sum KL(N(loc,
+ * sigma^2) || N(0, 1)).  apply = 0 (data parallel): the latent step is taken, the DATA part of the net's gradient goes to grad_dev
+ * -> [caller: RCCL all-reduce(SUM)] -> bgm_bprior_apply adds the KL part and takes the Adam step.  out_dev [3] (or NULL): batch
+ * means of the conditional-prior term and of |z|^2 / 2 (this rank's share), sum of the KL terms. */
+BGM_API int bgm_bprior_n_params(const bgm_prior_config *cfg, int64_t *count);
+BGM_API int bgm_bprior_step(bgm_handle *h, const bgm_prior_config *cfg, int32_t norm_mode, float kl_weight, float *theta_dev, float *m_dev,
+                    float *v_dev, const int32_t *seg_dev, float *data_z_dev, const int32_t *idx_dev, int32_t batch, int32_t batch_global,
+                    int32_t row0, const float *dz_dev, float lr_z, float lr_prior, int64_t t_z, int64_t t_prior, uint64_t seed,
+                    uint32_t stream_id, float *grad_dev, int32_t apply, float *out_dev, void *stream);
+BGM_API int bgm_bprior_apply(bgm_handle *h, const bgm_prior_config *cfg, float kl_weight, float *theta_dev, float *m_dev, float *v_dev,
+                     const float *grad_dev, float lr_prior, int64_t t_prior, void *stream);
+/* Conditional prior of the SAMPLING calls of a Bayesian-network session (bgm_bnn_logpost, bgm_bnn_mh_run) made afterwards:
+ * replaces prior_net(data_u) inside get_log_posterior (identifiable.py:541-551) -- one noisy call of the prior net per log-posterior
+ * evaluation and block of rows (call ids as g, h, f: stream_id; 2 it and 2 it + 1 in the sampler), seg_dev [n] the segments of the
+ * rows of those calls.  theta_dev = NULL clears it.  Built for the inference-mode normalisation, default-shape sampling kernels. */
+BGM_API int bgm_bnn_set_prior(bgm_handle *h, const bgm_prior_config *cfg, const float *theta_dev, const int32_t *seg_dev);
 BGM_API int bgm_destroy(bgm_handle *h);
 
 /* Declare the model shape.  Synchronous.  replaces: CausalBGM.__init__ network
