@@ -257,3 +257,16 @@ def test_other_sampling_configurations_say_so(tmp_path):
         model = IdentifiableCausalBGM(_params(tmp_path, False, bnn_norm="batch"), random_seed=3)
     with pytest.raises(RuntimeError, match="inference-mode normalisation"):
         model.predict((x, y, v), n_mcmc=3, burn_in=3, x_values=[0.5], verbose=0)
+
+
+def test_two_rank_fit_and_predict():
+    """data-parallel fit (theta and prior-net gradients all-reduced: identical networks on both ranks, each holding its half of the rows)
+    and the replicated predict; two ranks on this GPU over gloo (RCCL form: tests/test_gpu_rccl.py)"""
+    import json
+    from conftest import run_two_ranks
+    r = run_two_ranks("dp_ident_bnn_smoke.py", timeout=400)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    objs = [json.loads(l) for l in r.stdout.splitlines() if l.startswith('{"rank"')]
+    assert len(objs) == 2 and all(o["spread"] == 0.0 and o["finite"] for o in objs)
+    assert sorted(o["rows"] for o in objs) == [602, 603] and objs[0]["adrf"] == objs[1]["adrf"]
+    assert all(k > 0 for k in objs[0]["kl_prior"]) and np.all(np.isfinite(objs[0]["loss"]))

@@ -27,7 +27,7 @@ def _lines(r):
 
 @pytest.mark.parametrize("script,key", [("dp_causal_smoke.py", "spread"), ("dp_bnn_smoke.py", "spread"),
                                         ("dp_bgm_fit_smoke.py", "param_spread"), ("dp_bgm_bnn_smoke.py", "param_spread"),
-                                        ("dp_ident_smoke.py", None)])
+                                        ("dp_ident_smoke.py", None), ("dp_ident_bnn_smoke.py", "spread")])
 def test_two_rank_run_over_rccl(script, key):
     """fit + predict with the gradient / ADRF all-reduces on RCCL: replicas stay bit-identical (the scripts assert it too)"""
     _need_two()

@@ -194,3 +194,57 @@ def test_egm_gen_step_matches_autograd(binary):
         ref = [tn[k]["gamma"].grad, tn[k]["beta"].grad] + [a.grad for L in tn[k]["layers"] for a in L]
         for a, b in zip(OB.flat_grads(grads[k]), ref):
             np.testing.assert_allclose(a, b.numpy(), rtol=1e-7, atol=1e-11)
+
+
+@pytest.mark.parametrize("norm", ["batch", "fixed"])
+def test_identifiable_bayesian_prior_step_matches_autograd(norm):
+    """oracle.identifiable.bnn_prior_step_given_dz (identifiable.py:195-226 with use_bnn): the z gradient of the conditional-prior term and
+    the prior net's gradient of  batch-mean prior term + kl_weight * KL  against autograd; the updates are then plain Adam (checked in
+    test_oracle_autograd.py) -- verified here through the first step, where Adam's update is -lr_t * sign-like g / (|g| + eps)."""
+    from oracle import identifiable as OI
+    from oracle.fit import AdamState, adam_lr_t
+    rs = np.random.RandomState(4)
+    k, q, B, klw = 5, 6, 12, 0.3
+    pn = OI.init_prior_bnn(rs, k, q, (7,), dtype=np.float64)
+    pn["gamma"] = 1.0 + 0.3 * rs.standard_normal(k)
+    pn["beta"] = 0.2 * rs.standard_normal(k)
+    if norm == "fixed":
+        pn["norm"] = "fixed"
+    seg = rs.randint(0, k, B)
+    seg[:k] = np.arange(k)                                   # every column has variance under batch statistics
+    z = rs.standard_normal((B, q))
+    dz_std = 0.1 * rs.standard_normal((B, q)) + z / B       # stands for d(NLL + |z|^2 / 2)/dz
+    noise = OB.random_noise(rs, OB.net_dims(pn), B)
+    # autograd
+    tn = _tnet(pn)
+    zt = _t(z).requires_grad_()
+    u = _t(np.eye(k)[seg])
+    if norm == "fixed":
+        h = u / np.sqrt(1.0 + 1e-3) * tn["gamma"] + tn["beta"]
+        L = len(tn["layers"])
+        for l, (loc, rho, bias) in enumerate(tn["layers"]):
+            sg = OB.SCALE_EPS + torch.nn.functional.softplus(rho)
+            pre = h @ loc + ((h * _t(noise["sin"][l])) @ (sg * _t(noise["eps"][l]))) * _t(noise["sout"][l]) + bias
+            h = torch.nn.functional.leaky_relu(pre, 0.2) if l < L - 1 else pre
+        out = h
+    else:
+        out = _tfwd(tn, u, noise)
+    s2 = torch.nn.functional.softplus(out[:, -1]) + 1e-6
+    prior = (((zt - out[:, :-1]) ** 2).sum(1) / (2 * s2) + q * torch.log(s2) / 2).mean()
+    loss = prior + klw * _tkl(tn)
+    params = [tn["gamma"], tn["beta"]] + [a for Lr in tn["layers"] for a in Lr]
+    grads = torch.autograd.grad(loss, [zt] + params)
+    g_z = dz_std - z / B + grads[0].numpy()
+    # oracle step with lr so small that parameters barely move; compare through the first Adam step: delta = -lr_t * m / (sqrt(v) + eps)
+    data_z = z.copy()
+    pn2 = OB.cast_bnn(pn, np.float64)
+    before = [a.copy() for a in OB.flat_params(pn2)]
+    popt = AdamState(OB.flat_params(pn2))
+    lr_z, lr_p = 1e-3, 1e-4
+    lp, lz, klv = OI.bnn_prior_step_given_dz(pn2, popt, data_z, np.arange(B), seg, dz_std, noise, lr_z, 1, lr_p, klw)
+    assert abs(lp - float(prior)) < 1e-10 and abs(klv - float(_tkl(tn))) < 1e-9 and abs(lz - (z ** 2).sum(1).mean() / 2) < 1e-12
+    exp_z = z - adam_lr_t(lr_z, 1) * (0.1 * g_z) / (np.sqrt(0.01 * g_z * g_z) + 1e-7)
+    np.testing.assert_allclose(data_z, exp_z, rtol=0, atol=1e-9)
+    for m_, g in zip(popt.m, grads[1:]):
+        np.testing.assert_allclose(m_ / 0.1, g.numpy(), rtol=1e-8, atol=1e-11)      # first moment after one step = (1 - b1) g
+    assert any(np.abs(a - b).max() > 0 for a, b in zip(before, OB.flat_params(pn2)))
