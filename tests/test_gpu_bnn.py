@@ -760,3 +760,34 @@ def test_wide_bayesian_nets_on_tiny_blocks():
     ref = OB.log_posterior_blocks(m64, x.astype(np.float64), y.astype(np.float64), v.astype(np.float64), z.astype(np.float64), bs, 99, 5)
     assert np.abs(got - ref).max() < 2e-3 * np.abs(ref).max()
     eng.close()
+
+
+@pytest.mark.parametrize("use_bnn", [True, False])
+def test_as_written_semantics_stay_a_supported_mode(tmp_path, use_bnn):
+    """The literal reading of the reference -- input BatchNormalization of the Bayesian nets and the discriminator's BatchNormalization on
+    the statistics of the batch at hand (networks/bnn.py:24-27, base.py:364-379: call(..., training=True) is the call default), Keras'
+    dense-decay Adam on the whole latent table at every minibatch (base.py:296-302) -- is not the build's default but
+    stays selectable: params['bnn_norm'] = params['disc_norm'] = 'batch', fit(z_adam='dense').  The tutorial's workflow through the
+    class in that mode: warm start, fit with evaluations, predict; finite results, falling reconstruction error, and the batch-statistics
+    kernels' acceptance behaviour."""
+    import warnings
+    from bayesgm_amd.models import CausalBGM
+    from bayesgm_amd.datasets import Sim_Hirano_Imbens_sampler
+    x, y, v = Sim_Hirano_Imbens_sampler(N=640, v_dim=20, seed=0).load_all()
+    prm = dict(_params(tmp_path, False), use_bnn=use_bnn, bnn_norm="batch", disc_norm="batch")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = CausalBGM(prm, random_seed=3)
+    _, _, _, mv0 = model.evaluate((x, y, v))
+    model.fit((x, y, v), epochs=3, epochs_per_eval=1, batch_size=32, use_egm_init=True, egm_n_iter=40, egm_batches_per_eval=20, verbose=0,
+              z_adam="dense")
+    _, mx1, my1, mv1 = model.evaluate((x, y, v), data_z=model.data_z.cpu().numpy())
+    assert np.isfinite([mx1, my1, mv1]).all() and mv1 < mv0
+    xs = np.linspace(0, 3, 5)
+    eff, interval = model.predict((x, y, v), alpha=0.05, n_mcmc=30, burn_in=30, x_values=xs, q_sd=0.5, bs=320, verbose=0)
+    assert eff.shape == (5,) and np.isfinite(eff).all() and np.all(interval[:, 0] <= interval[:, 1])
+    assert 0.0 < model.last_acceptance_rate <= 1.0
+    if use_bnn:
+        # batch statistics normalise a constant treatment column away (the reason the build's default differs): the dose-response
+        # estimate does not depend on the dose in this mode
+        assert np.ptp(eff) < 0.2 * (np.abs(eff).mean() + 1.0)
