@@ -61,3 +61,13 @@ def test_library_exports_nothing_of_its_own_besides_the_abi():
     syms = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
     own = [s for s in syms if re.search(r"bgm|gx_|Gx|bnf|Bnf|bnn|Bnn|causal|egm|Egm|fit_", s) and not re.match(r"_Z(N\d+[a-z]+)?\d+[A-Za-z0-9_]*_kernel", s)]      # (N..: stubs inside a namespace, the per-format copies of the split-precision unit)
     assert sorted(own) == _declared_symbols(), sorted(set(own) - set(_declared_symbols()))
+
+
+def test_abi_map_is_current():
+    """ABI_MAP.md (entry point -> translation unit -> kernel headers -> Python wrappers -> tests) is generated from the header, the sources
+    and the test files; it must list every declared entry point and match what scripts/gen_abi_map.py produces now."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "gen_abi_map.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
