@@ -261,6 +261,7 @@ int bgm_causal_bx3_mh_launch(bgm_handle *h, const CausalMhKArgs &a, int effect, 
   ka.bblob = (const unsigned char *)h->bx_blob_dev;
   std::memcpy(&ka.bx, h->bx_meta_store, sizeof(BxMeta));
   const int lds = ka.bx.total_bytes + 64;
+  if (effect == 3) return bx_launch_mh<3>(h, ka, grid, lds, stream);        // event form of the retained phase (causal_event_api.hip)
   if (effect == BGM_EFFECT_ADRF) return bx_launch_mh<1>(h, ka, grid, lds, stream);
   if (effect == BGM_EFFECT_ITE) return bx_launch_mh<2>(h, ka, grid, lds, stream);
   return bx_launch_mh<0>(h, ka, grid, lds, stream);

@@ -561,6 +561,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_bx3_kernel(CausalBxKArgs
       (volatile __attribute__((address_space(3))) int *)((__attribute__((address_space(3))) unsigned char *)bx_lds + m.total_bytes);
   if (lane == 0) prog[wave_u] = 0;
   int tiles_done = 0;
+  [[maybe_unused]] int ev_cnt = 0;          // EFFECT == 3 (event form of the retained phase, causal_event_kernels.h)
   for (long long tile = slot; tile < n_tiles; tile += n_slots) {
     const long long row0 = tile * 16;
     long long row = row0 + j;
@@ -588,6 +589,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_bx3_kernel(CausalBxKArgs
       lp = a.logp[rowc];
     }
     uint4 uacc = make_uint4(0u, 0u, 0u, 0u);
+    [[maybe_unused]] const int ev_tile0 = ev_cnt;
     bool eff_cached = false;      // outcome-net cache of the retained iterations: see causal_mh_kernel
     unsigned n_eff_skipped = 0u;
     for (int it = a.it_begin; it < a.it_begin + a.n_iters; ++it) {
@@ -633,7 +635,11 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_bx3_kernel(CausalBxKArgs
               if (f < m.q) dr[f] = zs[0][t][r];
             }
         }
-        if constexpr (EFFECT == 1) {
+        if constexpr (EFFECT == 3) {
+          // event form: the accepted moves (every chain at a call's first retained iteration) are appended to the slot's region; the
+          // outcome net runs on the dense event tiles afterwards, in fp32 (causal_event_f_kernel on the fp32 sampling blob)
+          causal_event_append<KT1>(a, m.q, slot, ev_cnt, valid && (acc || (a.ev_first && it == a.it_begin)), g, j, zs[0], it);
+        } else if constexpr (EFFECT == 1) {
           float2 *cache = reinterpret_cast<float2 *>(a.eff_cache) + slot * (long long)((a.n_doses + 3) >> 2) * 64;
           float *adrf_slot = a.adrf_partial + slot * (long long)a.n_doses * a.n_keep;
           const bool skip = a.eff_skip && eff_cached && accmask == 0u;                   // wave-uniform: nobody moved
@@ -652,11 +658,17 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_bx3_kernel(CausalBxKArgs
     if constexpr (EFFECT == 1) {
       if (a.eff_stats != nullptr && lane == 0 && n_eff_skipped != 0u) atomicAdd(&a.eff_stats[0], (unsigned long long)n_eff_skipped);
     }
+    if constexpr (EFFECT == 3) {
+      if (lane == 0) { a.tile_ev[2 * tile] = ev_tile0; a.tile_ev[2 * tile + 1] = ev_cnt - ev_tile0; }
+    }
     store_z_rows<KT1, 1>(a.state, n, m.q, row0, j, g, zs);
     if (g == 0 && valid) a.logp[row] = lp;
     ++tiles_done;
   }
   if (lane == 0) prog[wave_u] = 0x7fffffff;
+  if constexpr (EFFECT == 3) {
+    if (lane == 0) a.slot_cnt[slot] = ev_cnt;
+  }
 }
 
 #undef BX_MFMA32

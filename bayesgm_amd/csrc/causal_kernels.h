@@ -670,6 +670,28 @@ __device__ __forceinline__ void causal_ite_cached(int g, int j, unsigned rowid, 
   if (g == 0 && row < n) ite[row * (long long)n_keep + d] = y1 - y0;
 }
 
+// Event form of the retained phase (causal_event_kernels.h): the chains of a wave whose flag `ev` is set append (chain, iteration,
+// state) to the wave slot's region, in lane order; ev_cnt is the slot's running event count (wave-uniform).
+template <int KT1>
+__device__ __forceinline__ void causal_event_append(const CausalMhKArgs &a, int q, long long slot, int &ev_cnt, bool ev, int g, int j,
+                                                    const f32x4 (&z)[KT1], int it) {
+  const unsigned m16 = (unsigned)(__ballot(ev && g == 0) & 0xFFFFull);
+  if (m16 == 0u) return;
+  if (ev) {
+    const long long e = slot * a.ev_cap + ev_cnt + __popc(m16 & ((1u << j) - 1u));
+    float *ez = a.ev_z + e * (long long)q;
+#pragma unroll
+    for (int t = 0; t < KT1; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = 16 * t + 4 * r + g;
+        if (f < q) ez[f] = z[t][r];
+      }
+    if (g == 0) a.ev_meta[e] = ((unsigned)(it - a.it_begin) << 4) | (unsigned)j;
+  }
+  ev_cnt += __popc(m16);
+}
+
 // ---------------------------------------------------------------------------
 // Persistent random-walk Metropolis-Hastings over a segment of iterations.
 // ---------------------------------------------------------------------------
@@ -844,23 +866,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_kernel(CausalMhKArgs a) 
           // event mode: a chain whose proposal was accepted (or every chain at the launch's first iteration, ev_first) appends
           // (chain, iteration, state) to the slot's region, in time order; nothing else happens at a retained iteration
           static_assert(R == 1, "event mode: one row tile per wave");
-          const bool ev = valid[0] && (moved[0] || (a.ev_first && it == a.it_begin));
-          const unsigned m16 = (unsigned)(__ballot(ev && g == 0) & 0xFFFFull);
-          if (m16 != 0u) {
-            if (ev) {
-              const long long e = slot * a.ev_cap + ev_cnt + __popc(m16 & ((1u << j) - 1u));
-              float *ez = a.ev_z + e * (long long)m.q;
-#pragma unroll
-              for (int t = 0; t < KT1; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                  const int f = 16 * t + 4 * r + g;
-                  if (f < m.q) ez[f] = zs[0][t][r];
-                }
-              if (g == 0) a.ev_meta[e] = ((unsigned)(it - a.it_begin) << 4) | (unsigned)j;
-            }
-            ev_cnt += __popc(m16);
-          }
+          causal_event_append<KT1>(a, m.q, slot, ev_cnt, valid[0] && (moved[0] || (a.ev_first && it == a.it_begin)), g, j, zs[0], it);
         } else if constexpr (EFFECT == 1 && R == 1) {
           float2 *cache = reinterpret_cast<float2 *>(a.eff_cache) + slot * (long long)((a.n_doses + 3) >> 2) * 64;
           float *adrf_slot = a.adrf_partial + slot * (long long)a.n_doses * a.n_keep;

