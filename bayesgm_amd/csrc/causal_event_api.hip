@@ -18,11 +18,11 @@
 static constexpr int EV_MH_R = BGM_MH_R, EV_MH_WAVES = BGM_MH_WAVES, EV_SPREAD_WAVES = 4, EV_SPREAD_LDS_FLOATS = 8192;
 #define BGM_CAUSAL_VARIANTS(X) X(1, 3, 13) X(1, 3, 7) X(1, 3, 2) X(2, 1, 10) X(2, 1, 7) X(2, 1, 2)
 
-// served by the event form: dose-response sums on the LDS-resident kernels (fp32 and split precision) with the standard-normal prior,
+// served by the event form: dose-response sums on the LDS-resident kernels (fp32 with either prior, split precision with the standard-normal prior),
 // doses in registers
 bool bgm_causal_event_wanted(const bgm_handle *h, int effect, int n_doses) {
   static const bool off = std::getenv("BGM_NO_EVENT_SPLIT") != nullptr;      // dev A/B
-  return !off && EV_MH_R == 1 && h->outcome_cache == 2 && effect == BGM_EFFECT_ADRF && !h->prior_seg &&
+  return !off && EV_MH_R == 1 && h->outcome_cache == 2 && effect == BGM_EFFECT_ADRF && !(h->prior_seg && h->precision != 0) &&
          n_doses >= 1 && (n_doses + 3) / 4 <= EV_NCMAX;
 }
 
@@ -85,6 +85,8 @@ int bgm_causal_event_mh_launch(bgm_handle *h, CausalMhKArgs &ka, int grid, int l
   ka.ev_z = h->ev_z; ka.ev_meta = h->ev_meta; ka.tile_ev = h->ev_tile; ka.slot_cnt = h->ev_slot_cnt;
   // split precision: the transitions run on the bf16x3 / f16x3 kernel; the events' outcome-net tiles and the spread pass are the fp32 ones
   if (h->precision != 0) return bgm_causal_bx3_mh_launch(h, ka, 3, grid, stream);
+  // conditional latent prior (IdentifiableCausalBGM): the PRIOR = 1 instantiation; the outcome net does not see the prior
+  if (h->prior_seg) return bgm_causal_prior_mh_launch(h, ka, 3, grid, lds, stream);
   int rc;
 #define X(KT1_, KSL1_, NTL_)                                                                   \
   if (h->KT1 == KT1_ && h->KSL1 == KSL1_ && h->NTL == NTL_) {                                  \

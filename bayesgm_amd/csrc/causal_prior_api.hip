@@ -67,6 +67,7 @@ int bgm_causal_prior_mh_launch(bgm_handle *h, const CausalMhKArgs &a, int effect
   CausalMhKArgs ka = a;
   ka.seg = (const int *)h->prior_seg;
   ka.prior_tab = h->prior_tab;
+  if (effect == 3) return pr_launch_mh<3>(h, ka, grid, lds, stream);         // event form of the retained phase (causal_event_api.hip)
   if (effect == BGM_EFFECT_ADRF) return pr_launch_mh<1>(h, ka, grid, lds, stream);
   if (effect == BGM_EFFECT_ITE) return pr_launch_mh<2>(h, ka, grid, lds, stream);
   return pr_launch_mh<0>(h, ka, grid, lds, stream);

@@ -22,6 +22,7 @@ data = tuple(torch.from_numpy(a).cuda() for a in (x, y, v))
 xs = np.linspace(0, 3, 20)
 if budget:
     eng.set_event_budget(budget << 20)
+eng.set_precision(os.environ.get("PREC", "fp32"))       # PREC=bf16x3 | f16x3: split-precision transitions
 res = {}
 for mode in (False, "wave", True, True):
     eng.set_outcome_cache(mode)

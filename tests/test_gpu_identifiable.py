@@ -222,8 +222,8 @@ def test_identifiable_fit_trace_and_predict():
     assert np.all(np.abs(lp - ref) <= 5e-6 * np.abs(ref) + 2e-3), np.abs(lp - ref).max()
     samples, data_u = model.metropolis_hastings_sampler((x, y, v), q_sd=0.5, burn_in=10, n_keep=5)
     assert samples.shape == (5, n, q) and data_u.shape == (n, 6) and np.all(data_u.sum(axis=1) == 1)
-    with pytest.raises(NotImplementedError):
-        IdentifiableCausalBGM(dict(prm, use_bnn=True))
+    # use_bnn=True constructs the Bayesian form (models/identifiable_bnn.py; tests/test_gpu_identifiable_bnn.py)
+    assert type(IdentifiableCausalBGM(dict(prm, use_bnn=True))).__name__ == "IdentifiableCausalBGMBayes"
 
 
 def test_checkpoint_round_trip_restores_the_prior_network(tmp_path):
@@ -340,3 +340,31 @@ def test_general_width_pack_follows_a_fit_on_the_row_tile_chains():
     ref = fresh.logpost(x.ravel(), y.ravel(), v, z).cpu().numpy()
     assert np.abs(lp1 - lp0).max() > 1e-2
     np.testing.assert_allclose(lp1, ref, rtol=1e-6, atol=1e-5)
+
+
+def test_event_form_with_the_conditional_prior_is_bit_identical():
+    """the event form of the retained phase (outcome cache mode 2, csrc/causal_event_kernels.h) on the PRIOR = 1 transition kernel: chains and
+    per-slot ADRF sums equal the fused kernel's with every dose evaluated at every retained draw"""
+    import torch
+    from bayesgm_amd import _lib
+    rs = np.random.RandomState(4)
+    z_dims, p, n, k = [1, 1, 1, 7], 200, 1500, 5
+    q = sum(z_dims)
+    m = _model(5, z_dims, p, False)
+    x, y, v = _data(n, p, 6, False)
+    seg = torch.from_numpy(rs.randint(0, k, n).astype(np.int32)).cuda()
+    tab = torch.from_numpy(OI.prior_table(_prior(rs, k, q), q)).cuda()
+    eng = _engine(m)
+    eng.set_prior(seg, tab)
+    outs = {}
+    for mode in (False, True):
+        eng.set_outcome_cache(mode)
+        eng.outcome_cache_stats(reset=True)
+        outs[mode] = eng.mh_sample(x, y, v, 20, 45, 1.0, 9, want_draws=True, effect=_lib.EFFECT_ADRF, x_values=np.linspace(0, 3, 20))
+        outs[mode]["stats"] = eng.outcome_cache_stats()
+    assert outs[True]["stats"][1] == n * 45                               # chain-iterations: the event form ran
+    for kk in ("adrf_partial", "draws", "acc_count", "state"):
+        assert np.array_equal(outs[True][kk].cpu().numpy(), outs[False][kk].cpu().numpy()), kk
+    eng.set_prior(None, None)
+    plain = eng.mh_sample(x, y, v, 20, 45, 1.0, 9, effect=_lib.EFFECT_ADRF, x_values=np.linspace(0, 3, 20))
+    assert not np.array_equal(plain["state"].cpu().numpy(), outs[True]["state"].cpu().numpy())      # the prior matters here
