@@ -105,6 +105,7 @@ SYMBOLS = {
     "bgm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "bgm_set_disc_norm": (C.c_int, [C.c_void_p, C.c_int32]),
     "bgm_causal_set_precision": (C.c_int, [C.c_void_p, C.c_int32]),
+    "bgm_bnn_set_precision": (C.c_int, [C.c_void_p, C.c_int32]),
     "bgm_causal_set_prior": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "bgm_destroy": (C.c_int, [C.c_void_p]),
     "bgm_causal_configure": (C.c_int, [C.c_void_p, C.POINTER(CausalConfig)]),

@@ -82,6 +82,13 @@ class BnnEngine(object):
         """BatchNormalization mode of the EGM discriminators opened afterwards: "batch" | "fixed" (bgm_set_disc_norm)."""
         _lib.check(self.lib.bgm_set_disc_norm(self.h, {"batch": 0, "fixed": 1}[mode]), "bgm_set_disc_norm")
 
+    def set_precision(self, mode):
+        """Arithmetic of logpost / mh_run / effects launched afterwards: "fp32" (default) | "f16x3" (bgm_bnn_set_precision); needs an open
+        session and is kept across begin()."""
+        self._precision = mode
+        if self.open:
+            _lib.check(self.lib.bgm_bnn_set_precision(self.h, {"fp32": 0, "bf16x3": 1, "f16x3": 2}[mode]), "bgm_bnn_set_precision")
+
     def close(self):
         if getattr(self, "h", None) is not None and self.h:
             self.lib.bgm_destroy(self.h)
@@ -104,6 +111,8 @@ class BnnEngine(object):
         _lib.check(self.lib.bgm_bnn_begin(self.h, C.byref(self.cfg), theta.ctypes.data_as(C.c_void_p), theta.size, self._stream()),
                    "bgm_bnn_begin")
         self.open = True
+        if getattr(self, "_precision", "fp32") != "fp32":
+            self.set_precision(self._precision)
 
     def read(self, what=0):
         out = np.empty(self.n_params, np.float32)

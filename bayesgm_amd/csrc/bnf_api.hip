@@ -13,6 +13,7 @@
 #include "bnf_build.h"
 #include "bnf_kernels.h"
 #include "bnn_state.h"
+#include "bnx_host.h"
 
 namespace {
 
@@ -132,6 +133,10 @@ int bnf_session(bgm_handle *h, BnnState *s, BnfState *&st, hipStream_t stream) {
     if (rc) return rc;
     s->bnf_valid = true;
   }
+  if (s->precision == 2) {      // split precision: the blobs in the fragment encoding of bnx_kernels.h
+    int rc = bnx_prepare(st, stream);
+    if (rc) return rc;
+  }
   (void)h;
   return BGM_OK;
 }
@@ -171,14 +176,15 @@ int set_lds(K kernel, int bytes) {
 
 // effects = true: sets of the outcome net in the effects layout
 void launch_noise(const BnfState *st, bool effects, float *dw, long long set_floats, int n_blocks, int n_states, uint64_t seed, uint32_t stream0,
-                  int block0, hipStream_t stream) {
+                  int block0, hipStream_t stream, bool x3) {
   BnfNoiseArgs na{};
   const int n_lay = effects ? 4 : 14;
   for (int i = 0; i < n_lay; ++i) na.lay[i] = effects ? st->lay_e[i] : st->lay[i];
   na.n_lay = n_lay; na.n_calls = effects ? st->n_calls_e : st->n_calls; na.npos = effects ? st->npos_e_dev : st->npos_dev;
   na.sf = effects ? st->esf_dev : st->sf_dev; na.dw = dw; na.set_floats = set_floats;
   na.n_states = n_states; na.k0 = (uint32_t)seed; na.k1 = (uint32_t)(seed >> 32); na.stream0 = stream0; na.block0 = block0;
-  hipLaunchKernelGGL(bnf_noise_kernel, dim3((na.n_calls + 1023) / 1024, n_blocks * n_states), dim3(256), 0, stream, na);
+  if (x3) bnx_launch_noise(na, effects ? st->posx_e_dev : st->posx_dev, n_blocks * n_states, stream);
+  else hipLaunchKernelGGL(bnf_noise_kernel, dim3((na.n_calls + 1023) / 1024, n_blocks * n_states), dim3(256), 0, stream, na);
 }
 
 void launch_signs(const SgLayout &L, long long n, int bs, int block0, int n_states, int nets, uint64_t seed, uint32_t stream0, unsigned *queue,
@@ -195,6 +201,25 @@ int grid_for(const bgm_handle *h) { return std::max(8, (h->n_cus / 8) * 8); }
 
 void bnf_free(void *state) { bnf_release(static_cast<BnfState *>(state)); }
 
+extern "C" int bgm_bnn_set_precision(bgm_handle *h, int32_t mode) {
+  if (!h || !h->bnn_state) { bgm_set_error("bgm_bnn_set_precision: no Bayesian-network session (bgm_bnn_begin)"); return BGM_E_STATE; }
+  if (mode != 0 && mode != 2) {
+    bgm_set_error("bgm_bnn_set_precision: mode must be 0 (fp32) or 2 (f16x3); the Bayesian sampling kernels have no bf16 form");
+    return mode == 1 ? BGM_E_UNSUPPORTED : BGM_E_INVALID;
+  }
+  BnnState *s = static_cast<BnnState *>(h->bnn_state);
+  if (mode == 2) {      // the split-precision kernels exist for the sessions bnf_kernels.h serves: say so now, not at the first sampling call
+    BnfState probe; BnfTabs tb;
+    if (s->bnf_unsupported || (!s->bnf && !bnf_build_bnn(s, probe, tb))) {
+      bgm_set_error("bgm_bnn_set_precision: split precision exists on the default-shape sampling kernels with inference-mode input normalisation "
+                    "(bnn_norm='fixed', g_units [64]x5, f_units / h_units [64,32,8], sum(z_dims) <= 31, v_dim <= 207)");
+      return BGM_E_UNSUPPORTED;
+    }
+  }
+  s->precision = mode;
+  return BGM_OK;
+}
+
 // returns 1 when the session is outside this path (the caller continues with the batch-statistics kernels), 0 when handled,
 // a negative BGM_E_* code on failure
 int bnf_logpost(bgm_handle *h, BnnState *s, const float *x, const float *y, const float *v, const float *z, int64_t n, int32_t block_rows,
@@ -205,7 +230,8 @@ int bnf_logpost(bgm_handle *h, BnnState *s, const float *x, const float *y, cons
   if (rc) return rc;
   const BnfPlan &P = st->P;
   BnfCfg c;
-  MhFn fn = mh_fn<0>(st->KSc, c);
+  const bool x3 = s->precision == 2;
+  MhFn fn = x3 ? bnx_mh_fn(st->KSc, 0, &c.R, &c.W) : mh_fn<0>(st->KSc, c);
   const int n_blocks = (int)((n + block_rows - 1) / block_rows);
   rc = grow((void **)&st->dw_dev, &st->dw_cap, sizeof(float) * (size_t)n_blocks * P.set_floats, stream, true);
   if (rc) return rc;
@@ -213,10 +239,10 @@ int bnf_logpost(bgm_handle *h, BnnState *s, const float *x, const float *y, cons
   rc = grow(&st->sg_dev, &st->sg_cap, L.bytes, stream, false);
   if (rc) return rc;
   L = sg_layout(st->sg_dev, n, 1, 0);
-  launch_noise(st, false, st->dw_dev, P.set_floats, n_blocks, 1, seed, stream_id, block0, stream);
+  launch_noise(st, false, st->dw_dev, P.set_floats, n_blocks, 1, seed, stream_id, block0, stream, x3);
   launch_signs(L, n, block_rows, block0, 1, 7, seed, stream_id, st->queue_dev, stream);
   BnfMhArgs a{};
-  a.pl = P; a.blob = st->blob_dev; a.dw = st->dw_dev;
+  a.pl = P; a.blob = x3 ? st->blobx_dev : st->blob_dev; a.dw = st->dw_dev;
   a.sig2_v = s->cfg.sigma_v > 0.0f ? s->cfg.sigma_v * s->cfg.sigma_v : 0.0f;      // fixed params['sigma_*'] (0: the variance heads)
   a.sig2_x = s->cfg.sigma_x > 0.0f ? s->cfg.sigma_x * s->cfg.sigma_x : 0.0f;
   a.sig2_y = s->cfg.sigma_y > 0.0f ? s->cfg.sigma_y * s->cfg.sigma_y : 0.0f;
@@ -240,15 +266,15 @@ namespace {
 // effects of ONE draw (state z) -> adrf column / ite column d
 int effects_of(bgm_handle *h, BnfState *st, const float *z, long long n, int bs, int n_blocks, int block0, long long row_base, int n_doses,
                const float *xvals, uint64_t seed, uint32_t stream0, uint32_t it_noise, int sample_y, double *sum_out, long long sum_stride,
-               float *ite_out, long long ite_stride, float *dw_eff, const SgLayout &L, hipStream_t stream) {
+               float *ite_out, long long ite_stride, float *dw_eff, const SgLayout &L, hipStream_t stream, bool x3) {
   const BnfPlan &P = st->P;
   BnfCfg c;
-  EffFn fn = eff_fn(st->KSFc, c);
+  EffFn fn = x3 ? bnx_eff_fn(st->KSFc, &c.R, &c.W) : eff_fn(st->KSFc, c);
   const long long eset = (long long)P.e_frags * 256;
-  launch_noise(st, true, dw_eff, eset, n_blocks, n_doses, seed, stream0, block0, stream);
+  launch_noise(st, true, dw_eff, eset, n_blocks, n_doses, seed, stream0, block0, stream, x3);
   launch_signs(L, n, bs, block0, n_doses, 4, seed, stream0, st->queue_dev + 8, stream);
   BnfEffArgs ea{};
-  ea.pl = P; ea.eblob = st->eblob_dev; ea.dw = dw_eff; ea.sgf = L.f; ea.z = z; ea.n = n; ea.row_base = row_base;
+  ea.pl = P; ea.eblob = x3 ? st->eblobx_dev : st->eblob_dev; ea.dw = dw_eff; ea.sgf = L.f; ea.z = z; ea.n = n; ea.row_base = row_base;
   { const BnnState *bs_ = static_cast<const BnnState *>(h->bnn_state); ea.sig2_y = (bs_ && bs_->cfg.sigma_y > 0.0f) ? bs_->cfg.sigma_y * bs_->cfg.sigma_y : 0.0f; }
   ea.bs = bs; ea.n_blocks = n_blocks; ea.block0 = block0;
   ea.groups_per_block = ((bs + 15) / 16 + c.R - 1) / c.R; ea.n_items = n_blocks * ea.groups_per_block; ea.n_doses = n_doses;
@@ -270,7 +296,8 @@ int bnf_mh_run(bgm_handle *h, BnnState *s, const bgm_bnn_mh_args *g, hipStream_t
   if (rc) return rc;
   const BnfPlan &P = st->P;
   BnfCfg c;
-  MhFn fn = mh_fn<1>(st->KSc, c);
+  const bool x3 = s->precision == 2;
+  MhFn fn = x3 ? bnx_mh_fn(st->KSc, 1, &c.R, &c.W) : mh_fn<1>(st->KSc, c);
   const long long n = g->n;
   const int bs = g->block_rows, n_blocks = (int)((n + bs - 1) / bs), q = s->q;
   const long long eset = (long long)P.e_frags * 256;
@@ -283,7 +310,7 @@ int bnf_mh_run(bgm_handle *h, BnnState *s, const bgm_bnn_mh_args *g, hipStream_t
   L = sg_layout(st->sg_dev, n, 2, n_doses);
   float *dw_eff_dev = st->dw_dev + dw_mh;
   BnfMhArgs a{};
-  a.pl = P; a.blob = st->blob_dev; a.dw = st->dw_dev;
+  a.pl = P; a.blob = x3 ? st->blobx_dev : st->blob_dev; a.dw = st->dw_dev;
   a.sig2_v = s->cfg.sigma_v > 0.0f ? s->cfg.sigma_v * s->cfg.sigma_v : 0.0f;      // fixed params['sigma_*'] (0: the variance heads)
   a.sig2_x = s->cfg.sigma_x > 0.0f ? s->cfg.sigma_x * s->cfg.sigma_x : 0.0f;
   a.sig2_y = s->cfg.sigma_y > 0.0f ? s->cfg.sigma_y * s->cfg.sigma_y : 0.0f;
@@ -304,7 +331,7 @@ int bnf_mh_run(bgm_handle *h, BnnState *s, const bgm_bnn_mh_args *g, hipStream_t
 #endif
   for (int i = 0; i < g->n_iters; ++i) {
     const int it = g->it_begin + i;
-    launch_noise(st, false, st->dw_dev, P.set_floats, n_blocks, 2, g->seed, 2u * (uint32_t)it, g->block0, stream);
+    launch_noise(st, false, st->dw_dev, P.set_floats, n_blocks, 2, g->seed, 2u * (uint32_t)it, g->block0, stream, x3);
     launch_signs(L, n, bs, g->block0, 2, 7, g->seed, 2u * (uint32_t)it, st->queue_dev, stream);
     a.it = it; a.init = (i == 0 && g->init) ? 1 : 0;
     if (s->bp_on) {    // conditional prior: the two evaluations' own calls of the prior net (streams 2 it, 2 it + 1)
@@ -321,7 +348,7 @@ int bnf_mh_run(bgm_handle *h, BnnState *s, const bgm_bnn_mh_args *g, hipStream_t
         rc = effects_of(h, st, g->state_dev, n, bs, n_blocks, g->block0, g->row_base, n_doses, g->effect == 1 ? g->x_values_dev : st->pair_dev,
                         g->seed, 0x40000000u + (uint32_t)d * (uint32_t)n_doses, (uint32_t)it, g->sample_y,
                         g->effect == 1 ? g->adrf_sum_dev + d : nullptr, g->n_keep, g->effect == 2 ? g->ite_dev + d : nullptr, g->n_keep,
-                        dw_eff_dev, L, stream);
+                        dw_eff_dev, L, stream, x3);
         if (rc) return rc;
       }
     }
@@ -365,7 +392,7 @@ int bnf_effects(bgm_handle *h, BnnState *s, const float *draws, int64_t n, int32
   for (int d = 0; d < n_keep; ++d) {
     rc = effects_of(h, st, draws + (long long)d * n * q, n, bs, n_blocks, block0, row_base, nd, effect == 1 ? x_values : st->pair_dev, seed,
                     0x40000000u + (uint32_t)d * (uint32_t)nd, (uint32_t)(it0 + d), sample_y, effect == 1 ? adrf_sum + d : nullptr, n_keep,
-                    effect == 2 ? ite + d : nullptr, n_keep, st->dw_dev, L, stream);
+                    effect == 2 ? ite + d : nullptr, n_keep, st->dw_dev, L, stream, s->precision == 2);
     if (rc) return rc;
   }
   BGM_HIP_CHECK(hipGetLastError());

@@ -27,6 +27,10 @@ struct BnfState {
   int n_w = 0, n_b = 0, n_n = 0, n_we = 0, n_be = 0, n_ne = 0;
   BnfWElem *w_dev = nullptr, *we_dev = nullptr;
   int *npos_dev = nullptr, *npos_e_dev = nullptr;      // noise kernel's position tables
+  // split precision (bnx_kernels.h, bnx_api.hip): second position tables, re-encoded blobs (built at the first call in that mode)
+  int *posx_dev = nullptr, *posx_e_dev = nullptr;
+  float *blobx_dev = nullptr, *eblobx_dev = nullptr;
+  bool x3_valid = false;
   int n_calls = 0, n_calls_e = 0;
   BnfBElem *b_dev = nullptr, *be_dev = nullptr;
   BnfNElem *n_dev = nullptr, *ne_dev = nullptr;
@@ -119,6 +123,11 @@ static inline bool bnf_build(const BnfSrc &S, BnfState &st, BnfTabs &tb) {
         else { t_ = k >> 4; gg = (k & 15) >> 2; r = k & 3; }
         if (head3) j = 4 * (o >> 1) + (o & 1);
         e.pos = (((fb + mt * T + t_) * 64) + gg * 16 + j) * 4 + r;
+        // split layout (bnx_kernels.h), fp16 units: a K = 32 block is the fragment pair (t_ & ~1, + 1), slot 2 r + (t_ & 1) of lane gg * 16 + j;
+        // a layer of one k-tile is a K = 16 block (bit 27), slot r
+        e.posx = T == 1 ? (((fb + mt) * 512 + (gg * 16 + j) * 4 + r) | 0x08000000)
+                        : ((fb + mt * T + (t_ & ~1)) * 512 + (gg * 16 + j) * 8 + 2 * r + (t_ & 1));
+        e.posx |= (e.rep - 1) << 28;
         Wt.push_back(e);
       }
   };
@@ -190,7 +199,8 @@ static inline void bnf_release(BnfState *st) {
   if (!st) return;
   for (void *p : {(void *)st->w_dev, (void *)st->b_dev, (void *)st->n_dev, (void *)st->we_dev, (void *)st->be_dev, (void *)st->ne_dev,
                   (void *)st->esf_dev, (void *)st->npos_dev, (void *)st->npos_e_dev, (void *)st->blob_dev, (void *)st->eblob_dev, (void *)st->sf_dev,
-                  (void *)st->dw_dev, st->sg_dev, (void *)st->pair_dev, (void *)st->queue_dev, (void *)st->theta_dev})
+                  (void *)st->dw_dev, st->sg_dev, (void *)st->pair_dev, (void *)st->queue_dev, (void *)st->theta_dev, (void *)st->posx_dev,
+                  (void *)st->posx_e_dev, (void *)st->blobx_dev, (void *)st->eblobx_dev})
     if (p) hipFree(p);
   delete st;
 }
@@ -204,10 +214,11 @@ static inline bool bnf_upload(BnfState *n, const BnfTabs &tb) {
     return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
   };
   static const float pair_host[2] = {1.0f, 0.0f};
-  std::vector<int> np(tb.W.size()), npe(tb.WE.size());
-  for (size_t i = 0; i < tb.W.size(); ++i) np[i] = tb.W[i].pos | ((tb.W[i].rep - 1) << 28);
-  for (size_t i = 0; i < tb.WE.size(); ++i) npe[i] = tb.WE[i].pos | ((tb.WE[i].rep - 1) << 28);
+  std::vector<int> np(tb.W.size()), npe(tb.WE.size()), px(tb.W.size()), pxe(tb.WE.size());
+  for (size_t i = 0; i < tb.W.size(); ++i) { np[i] = tb.W[i].pos | ((tb.W[i].rep - 1) << 28); px[i] = tb.W[i].posx; }
+  for (size_t i = 0; i < tb.WE.size(); ++i) { npe[i] = tb.WE[i].pos | ((tb.WE[i].rep - 1) << 28); pxe[i] = tb.WE[i].posx; }
   bool ok = up((void **)&n->npos_dev, np.data(), np.size() * sizeof(int)) && up((void **)&n->npos_e_dev, npe.data(), npe.size() * sizeof(int)) &&
+            up((void **)&n->posx_dev, px.data(), px.size() * sizeof(int)) && up((void **)&n->posx_e_dev, pxe.data(), pxe.size() * sizeof(int)) &&
             up((void **)&n->w_dev, tb.W.data(), tb.W.size() * sizeof(BnfWElem)) && up((void **)&n->b_dev, tb.B.data(), tb.B.size() * sizeof(BnfBElem)) &&
             up((void **)&n->n_dev, tb.N.data(), tb.N.size() * sizeof(BnfNElem)) && up((void **)&n->we_dev, tb.WE.data(), tb.WE.size() * sizeof(BnfWElem)) &&
             up((void **)&n->be_dev, tb.BE.data(), tb.BE.size() * sizeof(BnfBElem)) && up((void **)&n->ne_dev, tb.NE.data(), tb.NE.size() * sizeof(BnfNElem)) &&
@@ -235,5 +246,6 @@ static inline int bnf_pack(BnfState *st, const float *theta_dev, hipStream_t str
   pa.blob = st->eblob_dev; pa.sf = st->esf_dev; pa.bias_off = P.e_bias_off;
   hipLaunchKernelGGL(bnf_pack_kernel, dim3(16), dim3(256), 0, stream, pa);
   BGM_HIP_CHECK(hipGetLastError());
+  st->x3_valid = false;
   return BGM_OK;
 }

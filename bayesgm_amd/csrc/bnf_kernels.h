@@ -645,6 +645,16 @@ __device__ __forceinline__ void bnf_logpost_rows(const BnfMhArgs &a, const BnfLd
   BNF_T(5);
 }
 
+// split-precision ("f16 x 3") forms of the network walks, defined in bnx_kernels.h (included behind this file by the translation unit that
+// instantiates the X3 kernels): same arguments, fragment indices and sign-word protocol
+template <int KS, int R>
+__device__ __forceinline__ void bnx_logpost_rows(const BnfMhArgs &a, const BnfLds &L, int lane, int j, int g, long long blk_lo, const int (&rib)[R],
+                                                 const float (&ze)[R][KS], const float (&xr)[R], const float (&yr)[R], const float *dwset, int s,
+                                                 const float (&zz)[R], float (&lp)[R] BNF_PROF_PARAM);
+template <int KS, int R>
+__device__ __forceinline__ void bnx_head(const f32x4 *LF, const f32x4 *__restrict__ DW, const f32x4 *BL, const f32x4 *NORM, const int4 *SHIFT, int lane,
+                                         int g, const float (&ze)[R][KS], const uint4 (&G)[R][BNF_NG_H], float (&mu)[R], float (&raw)[R]);
+
 // ---------------------------------------------------------------------------------------------
 // persistent sampler kernel: grid = a multiple of 8 workgroups (one per CU), WAVES waves each.  Items = groups of R row tiles of
 // one block; the workgroups of XCD x (blockIdx % 8) take the x-th contiguous eighth of the items and walk it in lock step.
@@ -652,8 +662,10 @@ __device__ __forceinline__ void bnf_logpost_rows(const BnfMhArgs &a, const BnfLd
 // MODE 0: log posterior of the given states -> out.  MODE 1: one Metropolis-Hastings iteration; with Bayesian nets both states are
 // evaluated afresh, with deterministic nets (DET) the current state's value is carried in lp_cache like the reference's
 // deterministic result would be (oracle/causal.py mh_transition).  MODE 2 (DET): the sums of CausalBGM.evaluate.
-template <int KS, int R, int WAVES, int MODE, bool DET = false, bool WIDE = false>
+// X3: the networks in split precision (bnx_kernels.h; a.blob / a.dw in its fragment encoding)
+template <int KS, int R, int WAVES, int MODE, bool DET = false, bool WIDE = false, bool X3 = false>
 static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_mh_kernel(BnfMhArgs a) {
+  static_assert(!X3 || (!DET && !WIDE && MODE != 2), "bnf_mh_kernel: split precision serves the Bayesian nets' log posterior and MH modes");
   extern __shared__ __attribute__((aligned(16))) float bnf_lds[];
   const BnfPlan &P = a.pl;
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
@@ -753,7 +765,8 @@ static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_mh_kernel(Bn
 #pragma unroll
         for (int rt = 0; rt < R; ++rt) zzc[rt] = bnf_prior_share<KS>(a.prior + (blk_lo + rib[rt]) * (long long)(q + 2), q, g, zc[rt], lc0[rt]);
       }
-      bnf_logpost_rows<KS, R, DET, WIDE>(a, L, lane, j, g, blk_lo, rib, zc, xr, yr, dwblk, 0, zzc, lp, aux BNF_PROF_ARG);
+      if constexpr (X3) bnx_logpost_rows<KS, R>(a, L, lane, j, g, blk_lo, rib, zc, xr, yr, dwblk, 0, zzc, lp BNF_PROF_ARG);
+      else bnf_logpost_rows<KS, R, DET, WIDE>(a, L, lane, j, g, blk_lo, rib, zc, xr, yr, dwblk, 0, zzc, lp, aux BNF_PROF_ARG);
 #pragma unroll
       for (int rt = 0; rt < R; ++rt)
         if (valid[rt] && g == 0) a.out[blk_lo + rib[rt]] = a.prior ? lp[rt] - lc0[rt] : lp[rt];
@@ -830,8 +843,9 @@ static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_mh_kernel(Bn
         for (int rt = 0; rt < R; ++rt)
           zzs[rt] = bnf_prior_share<KS>(a.prior + (long long)st * a.prior_stride + (blk_lo + rib[rt]) * (long long)(q + 2), q, g, zs[rt], lcs[rt]);
       }
-      bnf_logpost_rows<KS, R, DET, WIDE>(a, L, lane, j, g, blk_lo, rib, zs, xr, yr, DET ? nullptr : dwblk + (long long)st * P.set_floats, st, zzs,
-                                         lp, aux BNF_PROF_ARG);
+      if constexpr (X3) bnx_logpost_rows<KS, R>(a, L, lane, j, g, blk_lo, rib, zs, xr, yr, dwblk + (long long)st * P.set_floats, st, zzs, lp BNF_PROF_ARG);
+      else bnf_logpost_rows<KS, R, DET, WIDE>(a, L, lane, j, g, blk_lo, rib, zs, xr, yr, DET ? nullptr : dwblk + (long long)st * P.set_floats, st, zzs,
+                                              lp, aux BNF_PROF_ARG);
 #pragma unroll
       for (int rt = 0; rt < R; ++rt) { if (st) lpc[rt] = lp[rt] - lcs[rt]; else lpp[rt] = lp[rt] - lcs[rt]; }
     }
@@ -907,8 +921,9 @@ struct BnfEffArgs {
   float sig2_y;                        // fixed params['sigma_y']^2 (<= 0: the variance head)
 };
 
-template <int KS, int R, int WAVES, bool DET = false>      // KS: k-steps of the outcome net's own first layer (BnfPlan::KSF or a larger compiled value)
+template <int KS, int R, int WAVES, bool DET = false, bool X3 = false>      // KS: k-steps of the outcome net's own first layer (BnfPlan::KSF or a larger compiled value)
 static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_effects_kernel(BnfEffArgs a) {
+  static_assert(!X3 || !DET, "bnf_effects_kernel: split precision serves the Bayesian nets");
   extern __shared__ __attribute__((aligned(16))) float bnf_lds[];
   constexpr int T0 = (KS + 3) / 4;
   const BnfPlan &P = a.pl;
@@ -1003,7 +1018,8 @@ static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_effects_kern
           if (16 * (ks >> 2) + 4 * (ks & 3) + g == zz) ze[rt][ks] = xv;
       float mu[R], raw[R];
       BGM_NO_HOIST();
-      bnf_head<KS, R, DET>(LF, (const f32x4 *)(dwblk + (long long)k * eset), BL, NORM, SHIFT, lane, g, ze, G, mu, raw);
+      if constexpr (X3) bnx_head<KS, R>(LF, (const f32x4 *)(dwblk + (long long)k * eset), BL, NORM, SHIFT, lane, g, ze, G, mu, raw);
+      else bnf_head<KS, R, DET>(LF, (const f32x4 *)(dwblk + (long long)k * eset), BL, NORM, SHIFT, lane, g, ze, G, mu, raw);
       const int own = (k >> 2) & 3, e = k & 3;
       float tot = 0.0f;
 #pragma unroll
@@ -1040,7 +1056,7 @@ static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_effects_kern
 // packing, perturbations, sign words
 // ---------------------------------------------------------------------------------------------
 // Element tables (host-built, bnf_api.hip).  A kernel element: theta offsets of loc / rho, position in the set, replication.
-struct BnfWElem { int loc, rho, pos, rep; float scale; };     // rep copies at pos, pos + 16, ...; scale 0.6 behind a LeakyReLU
+struct BnfWElem { int loc, rho, pos, rep; float scale; int posx; };     // rep copies at pos, pos + 16, ...; scale 0.6 behind a LeakyReLU; posx: the split layout's position word (bnx_kernels.h)
 struct BnfBElem { int src, pos, rep; };                       // bias -> bias tiles (float offset from bias_off)
 struct BnfNElem { int gamma, beta, pos_sc, pos_sh, pos_shift, shift; };   // one slot of one net's extended input (gamma < 0: unused)
 

@@ -28,6 +28,7 @@ struct BnnState {
   size_t samp_cap = 0;
   void *bnf = nullptr;         // BnfState (bnf_api.hip): the fixed-normalisation sampling path's tables, packed blob, buffers
   bool bnf_valid = false, bnf_unsupported = false;
+  int precision = 0;           // arithmetic of the sampling calls: 0 fp32, 2 split precision "f16 x 3" (bgm_bnn_set_precision; bnx_kernels.h)
   void *egm = nullptr;         // BnnEgmState (bnn_egm_api.hip)
   void *chain = nullptr;       // BnnFitChain (bnn_api.hip): tables / workspace of the row-tile-chain step kernels, or NULL
   void *bnw = nullptr;         // BnwState (bnw_api.hip): buffers of the any-width sampling path

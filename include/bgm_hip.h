@@ -143,6 +143,17 @@ BGM_API int bgm_bprior_apply(bgm_handle *h, const bgm_prior_config *cfg, float k
  * evaluation and block of rows (call ids as g, h, f: stream_id; 2 it and 2 it + 1 in the sampler), seg_dev [n] the segments of the
  * rows of those calls.  theta_dev = NULL clears it.  Built for the inference-mode normalisation, default-shape sampling kernels. */
 BGM_API int bgm_bnn_set_prior(bgm_handle *h, const bgm_prior_config *cfg, const float *theta_dev, const int32_t *seg_dev);
+/* Arithmetic of the SAMPLING calls of a Bayesian-network session made afterwards (bgm_bnn_logpost, bgm_bnn_mh_run, bgm_bnn_effects --
+ * get_log_posterior / metropolis_hastings_sampler / infer_from_latent_posterior of causalbgm/base.py:671-904 on the Flipout nets of
+ * networks/bnn.py:4-38):
+ *   0 (default)  fp32 MFMA;
+ *   2            split precision "f16 x 3": posterior means, perturbations and activations as sums of two fp16 numbers (22 mantissa
+ *                bits), three fp16 MFMA products per contraction with fp32 accumulation, sign flips as XORs on the packed words
+ *                (csrc/bnx_kernels.h).  Same algorithm, Philox streams, sign words and perturbation draws; the log posterior stays
+ *                within the fp32 kernels' own distance of float64.  fp16 range: a weight beyond 65504 is clamped, an activation beyond it overflows.
+ * Built for the sessions the default-shape kernels serve (inference-mode input normalisation, default widths); BGM_E_UNSUPPORTED otherwise
+ * and for mode 1 (there is no bf16 form of this family).  The minibatch steps and bgm_bnn_evaluate stay fp32. */
+BGM_API int bgm_bnn_set_precision(bgm_handle *h, int32_t mode);
 BGM_API int bgm_destroy(bgm_handle *h);
 
 /* Declare the model shape.  Synchronous.  replaces: CausalBGM.__init__ network

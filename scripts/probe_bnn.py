@@ -15,6 +15,8 @@ q = sum(z_dims)
 m = OB.init_model(0, z_dims, p, False)
 eng = BnnEngine(p, z_dims, False, max_batch=64, norm_mode=1)      # inference-mode input normalisation, the models' default
 eng.begin(m)
+if __import__("os").environ.get("BNN_PRECISION"):      # "f16x3": the split-precision sampling kernels (csrc/bnx_kernels.h)
+    eng.set_precision(__import__("os").environ["BNN_PRECISION"])
 dev = eng.device
 g = torch.Generator(device=dev); g.manual_seed(0)
 v = torch.randn(N, p, device=dev, generator=g)
