@@ -329,6 +329,11 @@ int bnf_mh_run(bgm_handle *h, BnnState *s, const bgm_bnn_mh_args *g, hipStream_t
   hipMemsetAsync(prof_dev, 0, 256, stream);
   a.prof = prof_dev;
 #endif
+  if (x3) {      // proposals [n x q] | the two log posteriors [2][n] of the three-launch iteration
+    rc = grow((void **)&st->mh_dev, &st->mh_cap, sizeof(float) * (size_t)n * (q + 2), stream, false);
+    if (rc) return rc;
+    a.zprop = st->mh_dev; a.out = st->mh_dev + (size_t)n * q; a.mode = 3;
+  }
   for (int i = 0; i < g->n_iters; ++i) {
     const int it = g->it_begin + i;
     launch_noise(st, false, st->dw_dev, P.set_floats, n_blocks, 2, g->seed, 2u * (uint32_t)it, g->block0, stream, x3);
@@ -339,6 +344,14 @@ int bnf_mh_run(bgm_handle *h, BnnState *s, const bgm_bnn_mh_args *g, hipStream_t
       a.prior = s->bp_rows; a.prior_stride = n * (long long)(q + 2);
     }
     a.acc_blocks = g->acc_blocks_dev ? g->acc_blocks_dev + (long long)i * n_blocks : nullptr;
+    if (x3) {      // split precision: proposal, both evaluations as independent (item, state) units, accept step (bnx_kernels.h)
+      BnxMhStep ms{};
+      ms.z = g->state_dev; ms.zprop = st->mh_dev; ms.lp = a.out; ms.n = n; ms.row_base = g->row_base; ms.q = q; ms.bs = bs; ms.it = it; ms.init = a.init;
+      ms.q_sd = g->q_sd; ms.q_sd_blocks = g->q_sd_blocks_dev; ms.k0 = a.k0; ms.k1 = a.k1; ms.acc_count = g->acc_count_dev; ms.acc_blocks = a.acc_blocks;
+      bnx_launch_propose(ms, stream);
+      hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * c.W), st->lds_mh, stream, a);
+      bnx_launch_accept(ms, stream);
+    } else
     hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * c.W), st->lds_mh, stream, a);
     const int d = it - g->burn_in;
     if (d >= 0 && d < g->n_keep) {
@@ -361,6 +374,7 @@ int bnf_mh_run(bgm_handle *h, BnnState *s, const bgm_bnn_mh_args *g, hipStream_t
     const double d = (double)grid * std::max(1, g->n_iters);
     fprintf(stderr, "[BNF_PROF] cycles per workgroup-launch (wave 0, R=%d W=%d): prologue %.0f g-first %.0f g-hidden %.0f g-last %.0f h %.0f f %.0f rest %.0f\n",
             c.R, c.W, hp[0] / d, hp[1] / d, hp[2] / d, hp[3] / d, hp[4] / d, hp[5] / d, hp[6] / d);
+    fprintf(stderr, "[BNF_PROF] extra stamp 7 (split precision: hidden-layer epilogues; 2 = their matrix products): %.0f\n", hp[28] / d);
     const double dw = d * c.W;
     fprintf(stderr, "[BNF_PROF] wave busy cycles per launch: mean %.0f, max (over all launches) %llu; by wave index:", hp[7] / dw, hp[8]);
     for (int w = 0; w < c.W; ++w) fprintf(stderr, " %.0f", hp[9 + w] / d);

@@ -37,6 +37,7 @@ struct BnfState {
   float *blob_dev = nullptr, *eblob_dev = nullptr, *sf_dev = nullptr, *esf_dev = nullptr;
   // per-run buffers, grown on demand
   float *dw_dev = nullptr; size_t dw_cap = 0;          // perturbation sets
+  float *mh_dev = nullptr; size_t mh_cap = 0;          // split precision: proposals [n x q] | log posteriors [2][n] of an iteration
   void *sg_dev = nullptr; size_t sg_cap = 0;           // sign groups
   float *pair_dev = nullptr;                           // (1, 0): the two treatments of a binary model
   unsigned *queue_dev = nullptr;                       // [16] item counters: 0..7 sampler, 8..15 effects
@@ -200,7 +201,7 @@ static inline void bnf_release(BnfState *st) {
   for (void *p : {(void *)st->w_dev, (void *)st->b_dev, (void *)st->n_dev, (void *)st->we_dev, (void *)st->be_dev, (void *)st->ne_dev,
                   (void *)st->esf_dev, (void *)st->npos_dev, (void *)st->npos_e_dev, (void *)st->blob_dev, (void *)st->eblob_dev, (void *)st->sf_dev,
                   (void *)st->dw_dev, st->sg_dev, (void *)st->pair_dev, (void *)st->queue_dev, (void *)st->theta_dev, (void *)st->posx_dev,
-                  (void *)st->posx_e_dev, (void *)st->blobx_dev, (void *)st->eblobx_dev})
+                  (void *)st->posx_e_dev, (void *)st->blobx_dev, (void *)st->eblobx_dev, (void *)st->mh_dev})
     if (p) hipFree(p);
   delete st;
 }

@@ -376,6 +376,7 @@ struct BnfMhArgs {
   BnfSigns sg;
   const float *x, *y, *v;
   float *z;                            // [n x q] state (mode 1: updated in place; mode 0: read)
+  const float *zprop;                  // MODE 3: [n x q] proposals (state slot 0; z is state slot 1)
   long long n, row_base;
   int bs, n_blocks, block0, groups_per_block, n_items, n_states;
   int mode;                            // 0: log posterior of z (state slot 0) -> out; 1: one MH iteration
@@ -659,13 +660,16 @@ __device__ __forceinline__ void bnx_head(const f32x4 *LF, const f32x4 *__restric
 // persistent sampler kernel: grid = a multiple of 8 workgroups (one per CU), WAVES waves each.  Items = groups of R row tiles of
 // one block; the workgroups of XCD x (blockIdx % 8) take the x-th contiguous eighth of the items and walk it in lock step.
 // ---------------------------------------------------------------------------------------------
-// MODE 0: log posterior of the given states -> out.  MODE 1: one Metropolis-Hastings iteration; with Bayesian nets both states are
+// MODE 0: log posterior of the given states -> out.  MODE 3: the two log posteriors of a Metropolis-Hastings iteration (proposals zprop
+// with perturbation set / sign state 0, current states z with set / state 1) -> out [2][n]; proposal and accept step are
+// bnx_propose_kernel / bnx_accept_kernel's.  MODE 1: one Metropolis-Hastings iteration; with Bayesian nets both states are
 // evaluated afresh, with deterministic nets (DET) the current state's value is carried in lp_cache like the reference's
 // deterministic result would be (oracle/causal.py mh_transition).  MODE 2 (DET): the sums of CausalBGM.evaluate.
 // X3: the networks in split precision (bnx_kernels.h; a.blob / a.dw in its fragment encoding)
 template <int KS, int R, int WAVES, int MODE, bool DET = false, bool WIDE = false, bool X3 = false>
 static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_mh_kernel(BnfMhArgs a) {
   static_assert(!X3 || (!DET && !WIDE && MODE != 2), "bnf_mh_kernel: split precision serves the Bayesian nets' log posterior and MH modes");
+  static_assert(MODE != 3 || !DET, "bnf_mh_kernel: MODE 3 evaluates both states afresh (Bayesian nets)");
   extern __shared__ __attribute__((aligned(16))) float bnf_lds[];
   const BnfPlan &P = a.pl;
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
@@ -685,7 +689,9 @@ static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_mh_kernel(Bn
   float ev[3] = {0.0f, 0.0f, 0.0f};
   const int q = P.q;
   const int xcd = blockIdx.x & 7;
-  const int per = (a.n_items + 7) >> 3, lo = xcd * per, hi = min(a.n_items, lo + per);
+  // MODE 3: a unit is (item, state): both log posteriors of a Metropolis-Hastings iteration as independent evaluations in one launch
+  const int n_units = MODE == 3 ? 2 * a.n_items : a.n_items;
+  const int per = (n_units + 7) >> 3, lo = xcd * per, hi = min(n_units, lo + per);
   unsigned nacc_total = 0;
 #ifdef BNF_PROF
   unsigned long long bnf_tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bnf_tl = __builtin_readcyclecounter();
@@ -698,8 +704,9 @@ static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_mh_kernel(Bn
   unsigned *queue = a.queue + xcd;
   unsigned tn = 0;
   if (lane == 0) tn = atomicAdd(queue, 1u);
-  for (int item = lo + (int)__builtin_amdgcn_readfirstlane(tn); item < hi; item = lo + (int)__builtin_amdgcn_readfirstlane(tn)) {
+  for (int unit = lo + (int)__builtin_amdgcn_readfirstlane(tn); unit < hi; unit = lo + (int)__builtin_amdgcn_readfirstlane(tn)) {
     if (lane == 0) tn = atomicAdd(queue, 1u);
+    const int item = MODE == 3 ? unit >> 1 : unit, ust = MODE == 3 ? unit & 1 : 0;
     const int blk = item / a.groups_per_block, grp = item - blk * a.groups_per_block;
     const long long blk_lo = (long long)blk * a.bs;
     const int blk_n = (int)min((long long)a.bs, a.n - blk_lo);
@@ -710,7 +717,7 @@ static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_mh_kernel(Bn
     bool valid[R];
     float xr[R], yr[R];
     const float *xblk = a.x + blk_lo, *yblk = a.y + blk_lo;
-    float *zblk = a.z + blk_lo * q;
+    float *zblk = ((MODE == 3 && ust == 0) ? const_cast<float *>(a.zprop) : a.z) + blk_lo * q;
     const uint32_t rid0 = (uint32_t)(a.row_base + blk_lo);
 #pragma unroll
     for (int rt = 0; rt < R; ++rt) {
@@ -754,7 +761,7 @@ static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_mh_kernel(Bn
       for (int ks = 0; ks < KS; ++ks) s = fmaf(zc[rt][ks], zc[rt][ks], s);
       zzc[rt] = s;
     }
-    if constexpr (MODE == 0) {
+    if constexpr (MODE == 0 || MODE == 3) {
 #pragma unroll
       for (int rt = 0; rt < R; ++rt)
 #pragma unroll
@@ -763,13 +770,15 @@ static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_mh_kernel(Bn
       float lp[R], aux[R][3], lc0[R];
       if (a.prior) {
 #pragma unroll
-        for (int rt = 0; rt < R; ++rt) zzc[rt] = bnf_prior_share<KS>(a.prior + (blk_lo + rib[rt]) * (long long)(q + 2), q, g, zc[rt], lc0[rt]);
+        for (int rt = 0; rt < R; ++rt)
+          zzc[rt] = bnf_prior_share<KS>(a.prior + (long long)ust * a.prior_stride + (blk_lo + rib[rt]) * (long long)(q + 2), q, g, zc[rt], lc0[rt]);
       }
-      if constexpr (X3) bnx_logpost_rows<KS, R>(a, L, lane, j, g, blk_lo, rib, zc, xr, yr, dwblk, 0, zzc, lp BNF_PROF_ARG);
-      else bnf_logpost_rows<KS, R, DET, WIDE>(a, L, lane, j, g, blk_lo, rib, zc, xr, yr, dwblk, 0, zzc, lp, aux BNF_PROF_ARG);
+      const float *dws = dwblk + (long long)ust * P.set_floats;
+      if constexpr (X3) bnx_logpost_rows<KS, R>(a, L, lane, j, g, blk_lo, rib, zc, xr, yr, dws, ust, zzc, lp BNF_PROF_ARG);
+      else bnf_logpost_rows<KS, R, DET, WIDE>(a, L, lane, j, g, blk_lo, rib, zc, xr, yr, dws, ust, zzc, lp, aux BNF_PROF_ARG);
 #pragma unroll
       for (int rt = 0; rt < R; ++rt)
-        if (valid[rt] && g == 0) a.out[blk_lo + rib[rt]] = a.prior ? lp[rt] - lc0[rt] : lp[rt];
+        if (valid[rt] && g == 0) a.out[(long long)ust * a.n + blk_lo + rib[rt]] = a.prior ? lp[rt] - lc0[rt] : lp[rt];
       continue;
     }
     if constexpr (MODE == 2) {      // evaluate: reconstruction errors of g, h, f at the given latents
@@ -889,6 +898,7 @@ static __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bnf_mh_kernel(Bn
   BNF_T(6);
   if (a.prof && tid == 0)
     for (int k = 0; k < 7; ++k) atomicAdd(&a.prof[k], bnf_tp[k]);
+  if (a.prof && tid == 0) atomicAdd(&a.prof[28], bnf_tp[7]);
   if (a.prof && lane == 0) {      // every wave: its busy time (sum and maximum over the waves of the launch), by wave index
     const unsigned long long tot = __builtin_readcyclecounter() - bnf_t0;
     atomicAdd(&a.prof[7], tot);

@@ -17,7 +17,13 @@
 namespace {
 template <int KS>
 BnxMhFn mh_ks(int mode) {
-  return mode == 0 ? bnf_mh_kernel<KS, BNX_R, BNX_W, 0, false, false, true> : bnf_mh_kernel<KS, BNX_R, BNX_W, 1, false, false, true>;
+  return mode == 0 ? bnf_mh_kernel<KS, BNX_R, BNX_W, 0, false, false, true> : bnf_mh_kernel<KS, BNX_R, BNX_W, 3, false, false, true>;
+}
+BnxMhStepArgs step_args(const BnxMhStep &b) {
+  BnxMhStepArgs a{};
+  a.z = b.z; a.zprop = b.zprop; a.lp = b.lp; a.n = b.n; a.row_base = b.row_base; a.q = b.q; a.bs = b.bs; a.it = b.it; a.init = b.init;
+  a.q_sd = b.q_sd; a.q_sd_blocks = b.q_sd_blocks; a.k0 = b.k0; a.k1 = b.k1; a.acc_count = b.acc_count; a.acc_blocks = b.acc_blocks;
+  return a;
 }
 }  // namespace
 
@@ -66,4 +72,12 @@ void bnx_launch_noise(const BnfNoiseArgs &na, const int *posx, int n_sets, hipSt
   BnxNoiseArgs b{};
   b.n = na; b.posx = posx;
   hipLaunchKernelGGL(bnx_noise_kernel, dim3((na.n_calls + 1023) / 1024, n_sets), dim3(256), 0, stream, b);
+}
+
+void bnx_launch_propose(const BnxMhStep &b, hipStream_t stream) {
+  const long long threads = b.n * (4 * ((b.q + 15) >> 4));
+  hipLaunchKernelGGL(bnx_propose_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, step_args(b));
+}
+void bnx_launch_accept(const BnxMhStep &b, hipStream_t stream) {
+  hipLaunchKernelGGL(bnx_accept_kernel, dim3((unsigned)((b.n + 255) / 256)), dim3(256), 0, stream, step_args(b));
 }

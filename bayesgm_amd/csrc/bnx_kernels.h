@@ -43,7 +43,8 @@ struct BnxK16 { bnx_u2 hi, lo; };
 
 // constants of the sign arithmetic in SGPRs (VOP3 takes no literal on gfx9; see bnf_k80)
 __device__ __forceinline__ uint32_t bnx_k8() { uint32_t k; asm("s_mov_b32 %0, 0x80008000" : "=s"(k)); return k; }
-__device__ __forceinline__ uint32_t bnx_k3c() { uint32_t k; asm("s_mov_b32 %0, 0x3c003c00" : "=s"(k)); return k; }
+// (0x3c003c00 sits in a VGPR: a VOP3 instruction reads one SGPR, and (t & k8) | k3c is a single v_bitop3 / v_and_or only then)
+__device__ __forceinline__ uint32_t bnx_k3c() { uint32_t k; asm("v_mov_b32 %0, 0x3c003c00" : "=v"(k)); return k; }
 
 // (a, b) -> packed fp16 (hi pair, lo pair), a = hi_a + lo_a up to 2^-22 |a|: 3 VALU instructions per element
 __device__ __forceinline__ void bnx_split_pair(float a, float b, unsigned &hi, unsigned &lo) {
@@ -53,11 +54,9 @@ __device__ __forceinline__ void bnx_split_pair(float a, float b, unsigned &hi, u
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(bnx_f2{la, lb}, bnx_h2));
 }
 
-// Epilogue of an output tile PAIR (2T, 2T + 1) of a Flipout layer behind a LeakyReLU: y = a1 + s_out a2, v = lrelu_s(y), and v, v o s_in
-// as K block T of the next layer.  wo_sh / wi_sh: the pair's output-sign word and the next layer's input-sign word, both pre-shifted
-// (bnf_preshift: bit 4 g + 3 at position 15, bit 16 + 4 g + 3 at position 31).
-__device__ __forceinline__ void bnx_epi_pair(const f32x4 &a1e, const f32x4 &a2e, const f32x4 &a1o, const f32x4 &a2o, uint32_t wo_sh, uint32_t wi_sh,
-                                             BnxK &h, BnxK &hs) {
+// Epilogue of an output tile PAIR (2T, 2T + 1) of a Flipout layer behind a LeakyReLU: y = a1 + s_out a2, v = lrelu_s(y) as K block T of the
+// next layer.  wo_sh: the pair's output-sign word, pre-shifted (bnf_preshift: bit 4 g + 3 at position 15, bit 16 + 4 g + 3 at position 31).
+__device__ __forceinline__ void bnx_epi_pair(const f32x4 &a1e, const f32x4 &a2e, const f32x4 &a1o, const f32x4 &a2o, uint32_t wo_sh, BnxK &h) {
   const uint32_t k8 = bnx_k8(), k3c = bnx_k3c();
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -66,9 +65,17 @@ __device__ __forceinline__ void bnx_epi_pair(const f32x4 &a1e, const f32x4 &a2e,
     const float ye = fmaf(a2e[r], (float)pm[0], a1e[r]), yo = fmaf(a2o[r], (float)pm[1], a1o[r]);
     unsigned hi, lo;
     bnx_split_pair(lrelu_s(ye), lrelu_s(yo), hi, lo);
-    const uint32_t m = (r == 3 ? wi_sh : wi_sh << (3 - r)) & k8;
     h.hi[r] = hi; h.lo[r] = lo;
-    hs.hi[r] = hi ^ m; hs.lo[r] = lo ^ m;
+  }
+}
+// hs = h o s_in for one K block; wi_sh: the block's input-sign word, pre-shifted.  Formed where the block is consumed (the consuming layer's
+// start), not where it is produced: a layer in flight then holds h, hs of its input and only h of its output.
+__device__ __forceinline__ void bnx_flip(const BnxK &h, uint32_t wi_sh, BnxK &hs) {
+  const uint32_t k8 = bnx_k8();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint32_t m = (r == 3 ? wi_sh : wi_sh << (3 - r)) & k8;
+    hs.hi[r] = h.hi[r] ^ m; hs.lo[r] = h.lo[r] ^ m;
   }
 }
 
@@ -134,12 +141,11 @@ __device__ __forceinline__ void bnx_input(const f32x4 *NORM, const int4 *SHIFT, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// first layer: packed extended input -> 64 units (bnf_first).  wo: output-sign words (pre-shifted); Gn: the next layer's sign group
-// (x: input signs of features 0..31, y: 32..63).
+// first layer: packed extended input -> 64 units (bnf_first).  wo: output-sign words (pre-shifted).
 // ---------------------------------------------------------------------------------------------
 template <int KS, int R>
 __device__ __forceinline__ void bnx_first(const f32x4 *LF, const f32x4 *__restrict__ DW, const f32x4 *BL, int lane, int g, const BnxIn<KS> (&in)[R],
-                                          const uint32_t (&wo)[R][2], const uint4 (&Gn)[R], BnxK (&h)[R][2], BnxK (&hs)[R][2]) {
+                                          const uint32_t (&wo)[R][2], BnxK (&h)[R][2]) {
   constexpr int T0 = (KS + 3) / 4;
   bnx_u4 dh[4], dl[4];            // the four output tiles' perturbation fragments (K = 16: components 0, 1)
 #pragma unroll
@@ -188,49 +194,105 @@ __device__ __forceinline__ void bnx_first(const f32x4 *LF, const f32x4 *__restri
       }
     }
 #pragma unroll
-    for (int rt = 0; rt < R; ++rt)
-      bnx_epi_pair(a1[0][rt], a2[0][rt], a1[1][rt], a2[1][rt], wo[rt][mp], bnf_preshift(mp == 0 ? Gn[rt].x : Gn[rt].y, g), h[rt][mp], hs[rt][mp]);
+    for (int rt = 0; rt < R; ++rt) bnx_epi_pair(a1[0][rt], a2[0][rt], a1[1][rt], a2[1][rt], wo[rt][mp], h[rt][mp]);
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// hidden layer 64 -> 64 of g (bnf_hidden): h, hs -> hn, hsn.  fd: this layer's first output tile's perturbation fragments
-// [K block 0 hi | lo | K block 1 hi | lo] (requested by the caller); on return those at DWnext (the next layer's / section's first tile).
+// The generator's hidden and last layers read their fragments as ONE linear stream (BnfPlan places g's last layer behind its hidden
+// layers): output tile i of the stream (i = 4 (l - 1) + mt in hidden layer l, 16 + mt in the last layer) has its four perturbation
+// fragments [K block 0 hi | lo | K block 1 hi | lo] at DWs + 4 i fragments and its posterior means at LFs + 4 i.  Perturbations come
+// from L2: a tile's are requested TWO tiles ahead (one tile is 12 R matrix instructions, less than an L2 round trip) into a ring of
+// three register sets; the means come from LDS one K block ahead.
 // ---------------------------------------------------------------------------------------------
+struct BnxRing { bnx_u4 cur[4], nxt[4]; bnx_u4 la[2]; };
+// development ablations (never defined in the product build): BNX_ABL_NODW reads the stream's perturbation fragments from LDS (the means)
+// instead of L2; BNX_ABL_NOV reads every data row from the block's first row (cache resident)
+#ifdef BNX_ABL_NODW
+#define BNX_DWSRC(dw, lf) (lf)
+#else
+#define BNX_DWSRC(dw, lf) (dw)
+#endif
+// (i: the stream's first tile behind the ring; n_tiles: its length, requests beyond it are clamped to the last tile)
+__device__ __forceinline__ void bnx_ring_fill(BnxRing &rg, const f32x4 *__restrict__ DWs, const f32x4 *LFs, int lane) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { rg.cur[t] = bnx_ld32(DWs, t, lane); rg.nxt[t] = bnx_ld32(DWs, 4 + t, lane); }
+  rg.la[0] = bnx_ld32(LFs, 0, lane); rg.la[1] = bnx_ld32(LFs, 1, lane);
+}
+// products of stream tile i on a1, a2 (the caller's initial values); advances the ring
 template <int R>
-__device__ __forceinline__ void bnx_hidden(const f32x4 *LF, const f32x4 *__restrict__ DW, const f32x4 *__restrict__ DWnext, const f32x4 *BL, int lane,
-                                           int g, const uint32_t (&wo)[R][2], const uint4 (&Gn)[R], const BnxK (&h)[R][2], const BnxK (&hs)[R][2],
-                                           BnxK (&hn)[R][2], BnxK (&hsn)[R][2], bnx_u4 (&fd)[4]) {
+__device__ __forceinline__ void bnx_stream_tile(BnxRing &rg, const f32x4 *__restrict__ DWs, const f32x4 *LFs, int i, int n_tiles, int lane,
+                                                const BnxK (&h)[R][2], const BnxK (&hs)[R][2], f32x4 (&a1)[R], f32x4 (&a2)[R]) {
+  bnx_u4 fn[4];
+  const int i2 = min(i + 2, n_tiles - 1);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) fn[t] = bnx_ld32(BNX_DWSRC(DWs, LFs) + i2 * 256, t, lane);
+#pragma unroll
+  for (int T = 0; T < 2; ++T) {
+    const bnx_u4 ah = rg.la[0], al = rg.la[1];
+    const int nf = min(4 * i + 2 * T + 2, 4 * n_tiles - 2);
+    rg.la[0] = bnx_ld32(LFs + nf * 64, 0, lane); rg.la[1] = bnx_ld32(LFs + nf * 64, 1, lane);
+    BNF_PIN();
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) { a1[rt] = BNX_MFMA32(al, h[rt][T].hi, a1[rt]); a2[rt] = BNX_MFMA32(rg.cur[2 * T + 1], hs[rt][T].hi, a2[rt]); }
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) { a1[rt] = BNX_MFMA32(ah, h[rt][T].lo, a1[rt]); a2[rt] = BNX_MFMA32(rg.cur[2 * T], hs[rt][T].lo, a2[rt]); }
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) { a1[rt] = BNX_MFMA32(ah, h[rt][T].hi, a1[rt]); a2[rt] = BNX_MFMA32(rg.cur[2 * T], hs[rt][T].hi, a2[rt]); }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { rg.cur[t] = rg.nxt[t]; rg.nxt[t] = fn[t]; }
+}
+
+// the same products with the caller's perturbation fragments fc (no ring); `mid()` runs behind the first K block's products, which it is
+// ordered after (the last layer issues the next pair's requests there: behind the loop top's wait for its own operands, not in front of it)
+template <int R, class Mid>
+__device__ __forceinline__ void bnx_tile_mm(bnx_u4 (&la)[2], const f32x4 *LFs, int i, int n_tiles, int lane, const BnxK (&h)[R][2], const BnxK (&hs)[R][2],
+                                            const bnx_u4 (&fc)[4], f32x4 (&a1)[R], f32x4 (&a2)[R], Mid mid) {
+#pragma unroll
+  for (int T = 0; T < 2; ++T) {
+    const bnx_u4 ah = la[0], al = la[1];
+    const int nf = min(4 * i + 2 * T + 2, 4 * n_tiles - 2);
+    la[0] = bnx_ld32(LFs + nf * 64, 0, lane); la[1] = bnx_ld32(LFs + nf * 64, 1, lane);
+    BNF_PIN();
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) { a1[rt] = BNX_MFMA32(al, h[rt][T].hi, a1[rt]); a2[rt] = BNX_MFMA32(fc[2 * T + 1], hs[rt][T].hi, a2[rt]); }
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) { a1[rt] = BNX_MFMA32(ah, h[rt][T].lo, a1[rt]); a2[rt] = BNX_MFMA32(fc[2 * T], hs[rt][T].lo, a2[rt]); }
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) { a1[rt] = BNX_MFMA32(ah, h[rt][T].hi, a1[rt]); a2[rt] = BNX_MFMA32(fc[2 * T], hs[rt][T].hi, a2[rt]); }
+    if (T == 0) {
+      asm volatile("" : "+v"(a1[0]), "+v"(a2[0]) :: "memory");
+      mid();
+    }
+  }
+}
+
+// hidden layer 64 -> 64 of g (bnf_hidden): stream tiles i0 .. i0 + 3; h -> hn.  wi / wo: the layer's input- / output-sign words
+// (pre-shifted; [0]: features 0..31, [1]: 32..63).
+template <int R>
+__device__ __forceinline__ void bnx_hidden(BnxRing &rg, const f32x4 *__restrict__ DWs, const f32x4 *LFs, int i0, int n_tiles, const f32x4 *BL, int lane,
+                                           int g, const uint32_t (&wi)[R][2], const uint32_t (&wo)[R][2], const BnxK (&h)[R][2], BnxK (&hn)[R][2] BNF_PROF_PARAM) {
+  BnxK hs[R][2];
+#pragma unroll
+  for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+    for (int T = 0; T < 2; ++T) bnx_flip(h[rt][T], wi[rt][T], hs[rt][T]);
 #pragma unroll
   for (int mp = 0; mp < 2; ++mp) {
     f32x4 a1[2][R], a2[2][R];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int mt = 2 * mp + e;
-      bnx_u4 fn[4];
-      const f32x4 *nx = (mt < 3) ? DW + (mt + 1) * 4 * 64 : DWnext;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) fn[t] = bnx_ld32(nx, t, lane);
-      BNF_PIN();
       const f32x4 b = BL[4 * mt + g];
 #pragma unroll
       for (int rt = 0; rt < R; ++rt) { a1[e][rt] = b; a2[e][rt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-      for (int T = 0; T < 2; ++T) {
-        const bnx_u4 ah = bnx_ld32(LF, mt * 4 + 2 * T, lane), al = bnx_ld32(LF, mt * 4 + 2 * T + 1, lane);
-#pragma unroll
-        for (int rt = 0; rt < R; ++rt) { a1[e][rt] = BNX_MFMA32(al, h[rt][T].hi, a1[e][rt]); a2[e][rt] = BNX_MFMA32(fd[2 * T + 1], hs[rt][T].hi, a2[e][rt]); }
-#pragma unroll
-        for (int rt = 0; rt < R; ++rt) { a1[e][rt] = BNX_MFMA32(ah, h[rt][T].lo, a1[e][rt]); a2[e][rt] = BNX_MFMA32(fd[2 * T], hs[rt][T].lo, a2[e][rt]); }
-#pragma unroll
-        for (int rt = 0; rt < R; ++rt) { a1[e][rt] = BNX_MFMA32(ah, h[rt][T].hi, a1[e][rt]); a2[e][rt] = BNX_MFMA32(fd[2 * T], hs[rt][T].hi, a2[e][rt]); }
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) fd[t] = fn[t];
+      bnx_stream_tile<R>(rg, DWs, LFs, i0 + mt, n_tiles, lane, h, hs, a1[e], a2[e]);
     }
+    BNF_T(2);
 #pragma unroll
-    for (int rt = 0; rt < R; ++rt)
-      bnx_epi_pair(a1[0][rt], a2[0][rt], a1[1][rt], a2[1][rt], wo[rt][mp], bnf_preshift(mp == 0 ? Gn[rt].x : Gn[rt].y, g), hn[rt][mp], hsn[rt][mp]);
+    for (int rt = 0; rt < R; ++rt) bnx_epi_pair(a1[0][rt], a2[0][rt], a1[1][rt], a2[1][rt], wo[rt][mp], hn[rt][mp]);
+    BNF_T(7);
   }
 }
 
@@ -249,7 +311,7 @@ __device__ __forceinline__ void bnx_head(const f32x4 *LF, const f32x4 *__restric
 #pragma unroll
     for (int t = 0; t < 4; ++t) fd2[mt][t] = bnx_ld32(D2, mt * 4 + t, lane);
   BNF_PIN();
-  BnxK h1[R][2], hs1[R][2];
+  BnxK h1[R][2], hs1[R][2];      // hs1: formed behind layer 1 from G[.][1].x / .y
   {
     uint32_t w_in[R], wo[R][2];
     uint4 Gn[R];
@@ -261,7 +323,9 @@ __device__ __forceinline__ void bnx_head(const f32x4 *LF, const f32x4 *__restric
     }
     BnxIn<KS> in[R];
     bnx_input<KS, R>(NORM, SHIFT, g, ze, w_in, in);
-    bnx_first<KS, R>(LF, DW, BL, lane, g, in, wo, Gn, h1, hs1);
+    bnx_first<KS, R>(LF, DW, BL, lane, g, in, wo, h1);
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) { bnx_flip(h1[rt][0], bnf_preshift(Gn[rt].x, g), hs1[rt][0]); bnx_flip(h1[rt][1], bnf_preshift(Gn[rt].y, g), hs1[rt][1]); }
   }
   const bnx_u4 fd3h = bnx_ld32(D2, 8, lane), fd3l = bnx_ld32(D2, 9, lane);
   const bnx_u2 fd4h = bnx_ld16(D2, 10, lane, 0), fd4l = bnx_ld16(D2, 10, lane, 1);
@@ -289,7 +353,7 @@ __device__ __forceinline__ void bnx_head(const f32x4 *LF, const f32x4 *__restric
     }
 #pragma unroll
     for (int rt = 0; rt < R; ++rt)
-      bnx_epi_pair(a1[0][rt], a2[0][rt], a1[1][rt], a2[1][rt], bnf_preshift(G[rt][1].z, g), bnf_preshift(G[rt][1].w, g), h2[rt], hs2[rt]);
+    { bnx_epi_pair(a1[0][rt], a2[0][rt], a1[1][rt], a2[1][rt], bnf_preshift(G[rt][1].z, g), h2[rt]); bnx_flip(h2[rt], bnf_preshift(G[rt][1].w, g), hs2[rt]); }
   }
   // layer 3: 32 -> 8, output feature f at lane group f >> 1, register f & 1 (registers 2, 3: zero rows of the packed weights)
   const f32x4 *L3 = L2 + 8 * 64;
@@ -350,13 +414,30 @@ __device__ __forceinline__ void bnx_logpost_rows(const BnfMhArgs &a, const BnfLd
   float ssq[R], rawv[R];
   uint4 GH[R][BNF_NG_H];
   {
-    BnxK h[R][2], hs[R][2];
+    BnxK h[R][2];
     const uint4 *SG = a.sg.g + ((long long)s * BNF_NG_G * a.n + blk_lo);
     uint4 Gc[R], Gn[R];
 #pragma unroll
     for (int rt = 0; rt < R; ++rt) { Gc[rt] = SG[rib[rt]]; Gn[rt] = (SG + a.n)[rib[rt]]; }
+    // the generator's stream behind its first layer: hidden layers 1..4 (16 tiles), last layer (NTL tiles)
+    const int NTL = P.NTL, n_tiles = 16 + NTL;
+    const f32x4 *DWs = DW + P.fgh * 64, *LFs = L.frag + P.fgh * 64;
+    BnxRing rg;
+    bnx_ring_fill(rg, DWs, LFs, lane);
+    // the rows of V of this evaluation's tiles are brought into L2 now (one dword per 128-byte line: lane (j, g) touches lines g and
+    // g + 4 of row j of each tile); the last layer's requests, a pair ahead of their use, then find them there
+    uint32_t touch[2 * R];
+    {
+      const float *vb_ = a.v + blk_lo * p;
+      const int last_w = p - 1;
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+          touch[2 * rt + c] = __builtin_bit_cast(uint32_t, vb_[rib[rt] * p + min(32 * (g + 4 * c), last_w)]);
+    }
     BNF_PIN();
-    uint32_t wo[R][2];
+    uint32_t wo[R][2], wi[R][2];
     {
       uint32_t w_in[R];
 #pragma unroll
@@ -366,62 +447,99 @@ __device__ __forceinline__ void bnx_logpost_rows(const BnfMhArgs &a, const BnfLd
       }
       BnxIn<KS> in[R];
       bnx_input<KS, R>(L.norm, L.shift, g, ze, w_in, in);
-      bnx_first<KS, R>(L.frag + P.fg0 * 64, DW + P.fg0 * 64, L.bias + 4 * P.bg0, lane, g, in, wo, Gn, h, hs);
+      bnx_first<KS, R>(L.frag + P.fg0 * 64, DW + P.fg0 * 64, L.bias + 4 * P.bg0, lane, g, in, wo, h);
     }
     BNF_T(1);
-    bnx_u4 fd[4];
-    {
-      const f32x4 *D = DW + P.fgh * 64;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) fd[t] = bnx_ld32(D, t, lane);
-    }
+    // two layers per trip: h -> hb -> h.  A layer's sign group Gn = [in 0..31 | in 32..63 | out 0..31 | out 32..63] was requested one layer
+    // ago; the next group is requested now and first touched at the next layer's start
 #pragma nounroll
     for (int l = 1; l <= 4; l += 2) {
-      BnxK hb[R][2], hsb[R][2];
+      BnxK hb[R][2];
 #pragma unroll
-      for (int rt = 0; rt < R; ++rt) { wo[rt][0] = bnf_preshift(Gn[rt].z, g); wo[rt][1] = bnf_preshift(Gn[rt].w, g); }
+      for (int rt = 0; rt < R; ++rt) {
+        wi[rt][0] = bnf_preshift(Gn[rt].x, g); wi[rt][1] = bnf_preshift(Gn[rt].y, g);
+        wo[rt][0] = bnf_preshift(Gn[rt].z, g); wo[rt][1] = bnf_preshift(Gn[rt].w, g);
+      }
 #pragma unroll
       for (int rt = 0; rt < R; ++rt) Gn[rt] = (SG + (long long)(l + 1) * a.n)[rib[rt]];
       BNF_PIN();
-      int fo = (P.fgh + 16 * (l - 1)) * 64;
-      bnx_hidden<R>(L.frag + fo, DW + fo, DW + fo + 16 * 64, L.bias + 4 * (P.bgh + 4 * (l - 1)), lane, g, wo, Gn, h, hs, hb, hsb, fd);
+      bnx_hidden<R>(rg, DWs, LFs, 4 * (l - 1), n_tiles, L.bias + 4 * (P.bgh + 4 * (l - 1)), lane, g, wi, wo, h, hb BNF_PROF_ARG);
 #pragma unroll
-      for (int rt = 0; rt < R; ++rt) { wo[rt][0] = bnf_preshift(Gn[rt].z, g); wo[rt][1] = bnf_preshift(Gn[rt].w, g); }
+      for (int rt = 0; rt < R; ++rt) {
+        wi[rt][0] = bnf_preshift(Gn[rt].x, g); wi[rt][1] = bnf_preshift(Gn[rt].y, g);
+        wo[rt][0] = bnf_preshift(Gn[rt].z, g); wo[rt][1] = bnf_preshift(Gn[rt].w, g);
+      }
 #pragma unroll
       for (int rt = 0; rt < R; ++rt) Gn[rt] = (SG + (long long)(l + 2) * a.n)[rib[rt]];
       BNF_PIN();
-      fo += 16 * 64;
-      bnx_hidden<R>(L.frag + fo, DW + fo, (l + 1 < 4) ? DW + fo + 16 * 64 : DW + P.fgl * 64, L.bias + 4 * (P.bgh + 4 * l), lane, g, wo, Gn, hb, hsb, h, hs,
-                    fd);
+      bnx_hidden<R>(rg, DWs, LFs, 4 * l, n_tiles, L.bias + 4 * (P.bgh + 4 * l), lane, g, wi, wo, hb, h BNF_PROF_ARG);
     }
     BNF_T(2);
-    {
-      const uint4 *SH = a.sg.h + ((long long)s * BNF_NG_H * a.n + blk_lo);
 #pragma unroll
-      for (int rt = 0; rt < R; ++rt)
+    for (int c = 0; c < 2 * R; ++c) asm volatile("" :: "v"(touch[c]));
+    BnxK hs[R][2];
 #pragma unroll
-        for (int k = 0; k < BNF_NG_H; ++k) GH[rt][k] = (SH + (long long)k * a.n)[rib[rt]];
-    }
-    // last layer: 64 -> p + 1, tile by tile against the data row; fd holds tile 0's perturbation fragments
-    const int NTL = P.NTL;
-    const f32x4 *LFl = L.frag + P.fgl * 64, *DWl = DW + P.fgl * 64, *BLl = L.bias + 4 * P.bgl;
+    for (int rt = 0; rt < R; ++rt) { bnx_flip(h[rt][0], bnf_preshift(Gn[rt].x, g), hs[rt][0]); bnx_flip(h[rt][1], bnf_preshift(Gn[rt].y, g), hs[rt][1]); }
+    // last layer: 64 -> p + 1 against the data row, in tile PAIRS (the two tiles of a pair share an output-sign word with their bits 16
+    // apart: one packed (+-1, +-1) per register serves both); stream tiles 16 .. 16 + NTL - 1.  Software pipeline over pairs: a pair's
+    // operands (perturbation fragments of both tiles, data rows, sign word) are requested one pair ahead into the other of two register
+    // sets, behind the first products of the pair in flight (the compiler waits for ALL outstanding requests at a loop's head).
+    const f32x4 *BLl = L.bias + 4 * P.bgl;
     const uint32_t *GO = a.sg.gout + ((long long)s * a.n + blk_lo) * BNF_GOUT;
     const float *vblk = a.v + blk_lo * p;
     auto load_v = [&](int rt, int mt) __attribute__((always_inline)) -> f32x4 {
+#ifdef BNX_ABL_NOV
+      const float *vr = vblk + min(16 * mt + 4 * g, p - 4);
+#else
       const float *vr = vblk + rib[rt] * p + min(16 * mt + 4 * g, p - 4);
+#endif
       return *(const f32x4_u *)vr;
     };
-    f32x4 vn[R];
-    uint32_t wn[R];
 #pragma unroll
-    for (int rt = 0; rt < R; ++rt) { vn[rt] = load_v(rt, 0); wn[rt] = GO[rib[rt] * BNF_GOUT]; ssq[rt] = 0.0f; rawv[rt] = 0.0f; }
+    for (int rt = 0; rt < R; ++rt) { ssq[rt] = 0.0f; rawv[rt] = 0.0f; }
+    struct PairSet { bnx_u4 fa[4], fb[4]; };
+    const int NP = (NTL - 1) >> 1;      // full pairs (2k, 2k + 1), k < NP: none of their columns is the variance column or padding
+    // perturbation fragments of pair kp <= NP (kp = NP: the tail's one or two tiles)
+    auto request = [&](int kp, PairSet &S) __attribute__((always_inline)) {
+      const int ta = 2 * kp, tb = min(2 * kp + 1, NTL - 1);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { S.fa[t] = bnx_ld32(BNX_DWSRC(DWs, LFs) + (16 + ta) * 256, t, lane); S.fb[t] = bnx_ld32(BNX_DWSRC(DWs, LFs) + (16 + tb) * 256, t, lane); }
+    };
+    const uint32_t k8 = bnx_k8(), k3c = bnx_k3c();
+    // data rows and sign word of a pair are requested at its start and first touched in its epilogue (the rows were brought into L2 at the
+    // start of the evaluation)
+    auto pair_body = [&](int k, const PairSet &S, auto next) __attribute__((always_inline)) {
+      const int mt = 2 * k;
+      f32x4 a1e[R], a2e[R], a1o[R], a2o[R], va[R], vb[R];
+      uint32_t w[R];
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) { va[rt] = load_v(rt, mt); vb[rt] = load_v(rt, mt + 1); w[rt] = GO[rib[rt] * BNF_GOUT + k]; }
+      const f32x4 be = BLl[4 * mt + g], bo = BLl[4 * (mt + 1) + g];
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) { a1e[rt] = be; a1o[rt] = bo; a2e[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; a2o[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      bnx_tile_mm<R>(rg.la, LFs, 16 + mt, n_tiles, lane, h, hs, S.fa, a1e, a2e, next);
+      bnx_tile_mm<R>(rg.la, LFs, 16 + mt + 1, n_tiles, lane, h, hs, S.fb, a1o, a2o, [] {});
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) {
+        const uint32_t wsh = bnf_preshift(w[rt], g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t to = r == 3 ? wsh : wsh << (3 - r);
+          const bnx_h2 pm = __builtin_bit_cast(bnx_h2, (to & k8) | k3c);
+          const float de = fmaf(a2e[rt][r], (float)pm[0], a1e[rt][r]) - va[rt][r], dq = fmaf(a2o[rt][r], (float)pm[1], a1o[rt][r]) - vb[rt][r];
+          ssq[rt] = fmaf(de, de, ssq[rt]);
+          ssq[rt] = fmaf(dq, dq, ssq[rt]);
+        }
+      }
+    };
+    // single tile of the tail (columns u >= p -- the variance column and the padding -- have no data; a clamped request is shifted back)
     auto tile = [&](int mt, bool last, const f32x4 (&vc)[R], const uint32_t (&wc)[R], const bnx_u4 (&fc)[4]) __attribute__((always_inline)) {
       f32x4 a1[R], a2[R];
       const f32x4 b = BLl[4 * mt + g];
 #pragma unroll
       for (int rt = 0; rt < R; ++rt) {
         a1[rt] = b - vc[rt];
-        if (last) {      // columns u >= p (the variance column and the padding) have no data; a clamped request is shifted back
+        if (last) {
           const int u0 = 16 * mt + 4 * g, sh = u0 - min(u0, p - 4);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -432,16 +550,7 @@ __device__ __forceinline__ void bnx_logpost_rows(const BnfMhArgs &a, const BnfLd
         }
         a2[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-#pragma unroll
-      for (int T = 0; T < 2; ++T) {
-        const bnx_u4 ah = bnx_ld32(LFl, mt * 4 + 2 * T, lane), al = bnx_ld32(LFl, mt * 4 + 2 * T + 1, lane);
-#pragma unroll
-        for (int rt = 0; rt < R; ++rt) { a1[rt] = BNX_MFMA32(al, h[rt][T].hi, a1[rt]); a2[rt] = BNX_MFMA32(fc[2 * T + 1], hs[rt][T].hi, a2[rt]); }
-#pragma unroll
-        for (int rt = 0; rt < R; ++rt) { a1[rt] = BNX_MFMA32(ah, h[rt][T].lo, a1[rt]); a2[rt] = BNX_MFMA32(fc[2 * T], hs[rt][T].lo, a2[rt]); }
-#pragma unroll
-        for (int rt = 0; rt < R; ++rt) { a1[rt] = BNX_MFMA32(ah, h[rt][T].hi, a1[rt]); a2[rt] = BNX_MFMA32(fc[2 * T], hs[rt][T].hi, a2[rt]); }
-      }
+      bnx_tile_mm<R>(rg.la, LFs, 16 + mt, n_tiles, lane, h, hs, fc, a1, a2, [] {});
       const int pos = 16 * (mt & 1);
 #pragma unroll
       for (int rt = 0; rt < R; ++rt) {
@@ -458,23 +567,36 @@ __device__ __forceinline__ void bnx_logpost_rows(const BnfMhArgs &a, const BnfLd
         }
       }
     };
+    auto tail = [&](const PairSet &S) __attribute__((always_inline)) {
+      f32x4 va[R], vb[R];
+      uint32_t w[R];
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) { va[rt] = load_v(rt, 2 * NP); vb[rt] = load_v(rt, NTL - 1); w[rt] = GO[rib[rt] * BNF_GOUT + NP]; }
+      if (NTL & 1) tile(NTL - 1, true, va, w, S.fa);
+      else { tile(NTL - 2, false, va, w, S.fa); tile(NTL - 1, true, vb, w, S.fb); }
+    };
+    PairSet X, Y;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { X.fa[t] = rg.cur[t]; X.fb[t] = rg.nxt[t]; }      // the ring holds stream tiles 16, 17 (an NTL of 1: twice tile 16)
+    int k = 0;
 #pragma nounroll
-    for (int mt = 0; mt < NTL - 1; ++mt) {
-      f32x4 vc[R];
-      bnx_u4 fc[4];
-      uint32_t wc[R];
-#pragma unroll
-      for (int rt = 0; rt < R; ++rt) { vc[rt] = vn[rt]; wc[rt] = wn[rt]; }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) fc[t] = fd[t];
-#pragma unroll
-      for (int rt = 0; rt < R; ++rt) { vn[rt] = load_v(rt, mt + 1); wn[rt] = GO[rib[rt] * BNF_GOUT + ((mt + 1) >> 1)]; }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) fd[t] = bnx_ld32(DWl, (mt + 1) * 4 + t, lane);
-      BNF_PIN();
-      tile(mt, false, vc, wc, fc);
+    for (; k + 2 <= NP; k += 2) {
+      pair_body(k, X, [&] { request(k + 1, Y); });
+      pair_body(k + 1, Y, [&] { request(k + 2, X); });
     }
-    tile(NTL - 1, true, vn, wn, fd);
+    // the treatment net's sign groups: requested here, first touched behind the tail
+    auto request_gh = [&]() __attribute__((always_inline)) {
+      const uint4 *SH = a.sg.h + ((long long)s * BNF_NG_H * a.n + blk_lo);
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+        for (int kk = 0; kk < BNF_NG_H; ++kk) GH[rt][kk] = (SH + (long long)kk * a.n)[rib[rt]];
+    };
+    if (k < NP) {
+      pair_body(k, X, [&] { request(k + 1, Y); });
+      request_gh();
+      tail(Y);
+    } else { request_gh(); tail(X); }
     BNF_T(3);
   }
   float part[R];
@@ -565,6 +687,78 @@ static __global__ __launch_bounds__(256) void bnx_noise_kernel(BnxNoiseArgs b) {
     for (int u = 0; u < 4; ++u) {
       const int idx = 4 * i + u;
       if (idx < L.cnt) bnx_store(dw, b.posx[L.e_base + idx], a.sf[a.npos[L.e_base + idx] & 0x0FFFFFFF] * z[u]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Metropolis-Hastings iteration around the MODE 3 evaluation (bnf_mh_kernel's MODE 1 in three launches): the proposal and the accept
+// step of metropolis_hastings_sampler (causalbgm/base.py:860-871) as row-wise kernels with MODE 1's Philox calls and expressions, so
+// that chains equal the fused kernel's given equal log posteriors.  The evaluation kernel then carries neither the two states nor the
+// accept bookkeeping in registers.
+// ---------------------------------------------------------------------------------------------
+struct BnxMhStepArgs {
+  float *z;                   // [n x q] current states (propose with init: written; accept: updated)
+  float *zprop;               // [n x q]
+  const float *lp;            // accept: [2][n] log posterior of the proposals | of the current states
+  long long n, row_base;
+  int q, bs, it, init;
+  float q_sd;
+  const float *q_sd_blocks;
+  uint32_t k0, k1;
+  unsigned *acc_count, *acc_blocks;
+};
+// one thread per (row, Philox call c = gg + 4 sb): features 16 sb + 4 r + gg, r = 0..3
+static __global__ __launch_bounds__(256) void bnx_propose_kernel(BnxMhStepArgs a) {
+  const int calls = 4 * ((a.q + 15) >> 4);
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long row = t / calls;
+  if (row >= a.n) return;
+  const int c = (int)(t - row * calls), gg = c & 3, sb = c >> 2;
+  const uint32_t rid = (uint32_t)(a.row_base + row);
+  const float sd = a.q_sd_blocks ? a.q_sd_blocks[row / a.bs] : a.q_sd;
+  float *zr = a.z + row * a.q, *zp = a.zprop + row * a.q;
+  f32x4 zc;
+  if (a.init) {
+    zc = box_muller4(philox4x32_10(rid, 0u, (uint32_t)c, TAG_INIT, a.k0, a.k1));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int f = 16 * sb + 4 * r + gg; if (f < a.q) zr[f] = zc[r]; }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int f = 16 * sb + 4 * r + gg; zc[r] = f < a.q ? zr[f] : 0.0f; }
+  }
+  const f32x4 e = box_muller4(philox4x32_10(rid, (uint32_t)a.it, (uint32_t)c, TAG_PROP, a.k0, a.k1));
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { const int f = 16 * sb + 4 * r + gg; if (f < a.q) zp[f] = fmaf(sd, e[r], zc[r]); }
+}
+// one thread per row
+static __global__ __launch_bounds__(256) void bnx_accept_kernel(BnxMhStepArgs a) {
+  const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+  const bool in = row < a.n;
+  bool acc = false;
+  int blk = 0;
+  if (in) {
+    const uint4 w4 = philox4x32_10((uint32_t)(a.row_base + row), (uint32_t)a.it >> 2, 0u, TAG_ACC, a.k0, a.k1);
+    const int it = a.it;
+    const unsigned w = (it & 2) ? ((it & 1) ? w4.w : w4.z) : ((it & 1) ? w4.y : w4.x);
+    acc = u01_open(w) < fast_exp(fminf(a.lp[row] - a.lp[a.n + row], 0.0f));
+    blk = (int)(row / a.bs);
+    if (acc) {
+      const float *zp = a.zprop + row * a.q;
+      float *zr = a.z + row * a.q;
+      for (int f = 0; f < a.q; ++f) zr[f] = zp[f];
+    }
+  }
+  if (a.acc_count || a.acc_blocks) {
+    // one atomic per block of rows the wave's accepted rows lie in (64 consecutive rows: one block, a few when bs is small)
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(acc);
+    if (a.acc_count && lane == 0 && todo) atomicAdd(a.acc_count, (unsigned)__popcll(todo));
+    while (a.acc_blocks && todo) {
+      const int l = __builtin_ctzll(todo), b = __shfl(blk, l);
+      const unsigned long long same = __ballot(acc && blk == b);
+      if (lane == l) atomicAdd(&a.acc_blocks[b], (unsigned)__popcll(same));
+      todo &= ~same;
     }
   }
 }
