@@ -82,6 +82,13 @@ class CausalBGMBayes(CausalBGM):
                                 sigma_v=params.get("sigma_v"), sigma_x=params.get("sigma_x"), sigma_y=params.get("sigma_y"))
         self.engine.set_disc_norm(_disc_norm(p))
         self.engine.begin(self.nets)
+        # params['mh_precision'] (build option): arithmetic of the posterior-sampling kernels of predict / get_log_posterior /
+        # metropolis_hastings_sampler.  'fp32' (default) | 'f16x3' (split precision on the fp16 matrix pipe: csrc/bnx_kernels.h, within the
+        # fp32 kernels' own distance of float64, ~1.9x faster); fit, egm_init and evaluate stay fp32.  There is no bf16 form of this family.
+        if p.get("mh_precision", "fp32") not in ("fp32", "f16x3"):
+            raise ValueError("params['mh_precision'] must be 'fp32' or 'f16x3' for use_bnn=True models")
+        if p.get("mh_precision", "fp32") != "fp32":
+            self.engine.set_precision(p["mh_precision"])
         if self.timestamp is None:
             self.timestamp = datetime.datetime.now().astimezone().strftime('%Y%m%d_%H%M%S')
         self.checkpoint_path = "{}/checkpoints/{}/{}".format(params['output_dir'], params['dataset'], self.timestamp)

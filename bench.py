@@ -304,48 +304,63 @@ def bgm_hmc_leg(device, n=200000, p=500, q=10, L=10, iters=4):
 
 def bayesian_leg(params, data, x_values, n_loc, args, device):
     """Secondary measurement (not `value`): the same predict with the reference's default Bayesian nets (use_bnn=True,
-    DESIGN_HISTORY.md section 7) on a tenth of the iterations -- all blocks advance in lock step, three launches per iteration, so
-    the per-transition rate does not depend on the iteration count."""
+    DESIGN_HISTORY.md section 7) on a tenth of the iterations -- all blocks advance in lock step, a handful of launches per iteration,
+    so the per-transition rate does not depend on the iteration count.  fp32 (the default arithmetic: `value`) and the opt-in split
+    precision of the sampling kernels (params['mh_precision'] = 'f16x3', csrc/bnx_kernels.h: object `f16x3`)."""
     import torch
     from bayesgm_amd.models import CausalBGM
-    m = CausalBGM(dict(params, use_bnn=True), timestamp="bench_bnn", random_seed=0, device=device.index)
     burn, keep, bs = max(1, args.burn_in // 10), max(1, args.n_mcmc // 10), 10000
-    m.predict(data, alpha=0.01, n_mcmc=2, burn_in=2, x_values=x_values, q_sd=1.0, sample_y=True, bs=bs, verbose=0)   # packs, allocates
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    m.predict(data, alpha=0.01, n_mcmc=keep, burn_in=burn, x_values=x_values, q_sd=1.0, sample_y=True, bs=bs, verbose=0)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
     flop_row = 2 * 2 * 2 * 34848 if (args.p == 200) else None      # two states x two GEMMs per Flipout layer x 2 FLOP/MAC
-    out = {"value": n_loc * (burn + keep) / dt, "unit": "MH transitions/s", "seconds": dt,
-           "sample": f"CausalBGM(use_bnn=True).predict, N={n_loc}, bs={bs}, burn_in={burn}, n_mcmc={keep}, 20 doses",
-           "ms_per_iteration": 1e3 * dt / (burn + keep), "acceptance_rate": m.last_acceptance_rate,
-           "flop_per_row_transition": flop_row}
-    # per-iteration cost of the two launch groups (HIP events on the stream the library launches on): a burn-in iteration =
-    # perturbations + sign words + sampler kernel; a kept iteration adds the 20 outcome-net calls.  Fractions are of the fp32-MFMA
-    # peak with the ALGORITHMIC work (2 states x 2 products x 34 848 MAC; 20 doses x 2 products x 2 512 MAC).
-    eng = m.engine
-    xs = torch.as_tensor(np.asarray(x_values, np.float32), device=eng.device)
-    # `data` holds this rank's device tensors behind the Shard wrapper of main()
-    x_, y_, v_ = (a_.t if hasattr(a_, "t") else torch.as_tensor(np.ascontiguousarray(a_, dtype=np.float32), device=eng.device) for a_ in data)
-    x_, y_ = x_.reshape(-1).float().contiguous(), y_.reshape(-1).float().contiguous()
-    v_ = v_.float().contiguous()
-    state = torch.empty((n_loc, eng.q), device=eng.device)
-    its = 20
-    eng.mh_run(x_, y_, v_, state, bs, 0, 2, 0, 1.0, 1, init=True)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    adrf = torch.zeros((len(x_values), its), device=eng.device, dtype=torch.float64)
-    ev[0].record()
-    eng.mh_run(x_, y_, v_, state, bs, 2, its, 10 ** 6, 1.0, 1)
-    ev[1].record()
-    eng.mh_run(x_, y_, v_, state, bs, 100, its, 100, 1.0, 1, n_keep=its, effect=1, x_values=xs, adrf_sum=adrf)
-    ev[2].record()
-    torch.cuda.synchronize()
-    t_mh, t_keep = ev[0].elapsed_time(ev[1]) / its, ev[1].elapsed_time(ev[2]) / its
-    out["burn_in_iteration_ms"], out["kept_iteration_ms"] = t_mh, t_keep
-    if flop_row:
-        out["sampler_frac_of_fp32_mfma_peak"] = flop_row * n_loc / (t_mh * 1e-3) / (PEAK_FP32_MFMA_TFLOPS * 1e12)
-        out["effects_frac_of_fp32_mfma_peak"] = len(x_values) * 2 * 2 * 2512 * n_loc / (max(t_keep - t_mh, 1e-9) * 1e-3) / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+
+    def one(mode):
+        m = CausalBGM(dict(params, use_bnn=True, mh_precision=mode), timestamp="bench_bnn", random_seed=0, device=device.index)
+        m.predict(data, alpha=0.01, n_mcmc=2, burn_in=2, x_values=x_values, q_sd=1.0, sample_y=True, bs=bs, verbose=0)   # packs, allocates
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        adrf, _ = m.predict(data, alpha=0.01, n_mcmc=keep, burn_in=burn, x_values=x_values, q_sd=1.0, sample_y=True, bs=bs, verbose=0)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out = {"value": n_loc * (burn + keep) / dt, "unit": "MH transitions/s", "seconds": dt,
+               "sample": f"CausalBGM(use_bnn=True{'' if mode == 'fp32' else ', mh_precision=' + repr(mode)}).predict, N={n_loc}, bs={bs}, burn_in={burn}, n_mcmc={keep}, 20 doses",
+               "ms_per_iteration": 1e3 * dt / (burn + keep), "acceptance_rate": m.last_acceptance_rate,
+               "adrf_head": [float(t) for t in np.asarray(adrf)[:3]], "flop_per_row_transition": flop_row}
+        # per-iteration cost of the two launch groups (HIP events on the stream the library launches on): a burn-in iteration =
+        # perturbations + sign words + sampler kernel(s); a kept iteration adds the 20 outcome-net calls.  Fractions are of the fp32-MFMA
+        # peak with the ALGORITHMIC work (2 states x 2 products x 34 848 MAC; 20 doses x 2 products x 2 512 MAC) -- for the split-precision
+        # run they say how many fp32-peak-equivalents the fp16 pipe delivers, not a utilisation.
+        eng = m.engine
+        xs = torch.as_tensor(np.asarray(x_values, np.float32), device=eng.device)
+        # `data` holds this rank's device tensors behind the Shard wrapper of main()
+        x_, y_, v_ = (a_.t if hasattr(a_, "t") else torch.as_tensor(np.ascontiguousarray(a_, dtype=np.float32), device=eng.device) for a_ in data)
+        x_, y_ = x_.reshape(-1).float().contiguous(), y_.reshape(-1).float().contiguous()
+        v_ = v_.float().contiguous()
+        state = torch.empty((n_loc, eng.q), device=eng.device)
+        its = 20
+        eng.mh_run(x_, y_, v_, state, bs, 0, 2, 0, 1.0, 1, init=True)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        adrf_s = torch.zeros((len(x_values), its), device=eng.device, dtype=torch.float64)
+        ev[0].record()
+        eng.mh_run(x_, y_, v_, state, bs, 2, its, 10 ** 6, 1.0, 1)
+        ev[1].record()
+        eng.mh_run(x_, y_, v_, state, bs, 100, its, 100, 1.0, 1, n_keep=its, effect=1, x_values=xs, adrf_sum=adrf_s)
+        ev[2].record()
+        torch.cuda.synchronize()
+        t_mh, t_keep = ev[0].elapsed_time(ev[1]) / its, ev[1].elapsed_time(ev[2]) / its
+        out["burn_in_iteration_ms"], out["kept_iteration_ms"] = t_mh, t_keep
+        if flop_row:
+            out["sampler_frac_of_fp32_mfma_peak"] = flop_row * n_loc / (t_mh * 1e-3) / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+            out["effects_frac_of_fp32_mfma_peak"] = len(x_values) * 2 * 2 * 2512 * n_loc / (max(t_keep - t_mh, 1e-9) * 1e-3) / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+        del m
+        torch.cuda.empty_cache()
+        return out
+
+    out = one("fp32")
+    x3 = one("f16x3")
+    if flop_row:      # executed fp16 work: 3 products per contraction
+        x3["sampler_frac_of_f16_mfma_peak"] = 3 * flop_row * n_loc / (x3["burn_in_iteration_ms"] * 1e-3) / 2.5e15
+    x3["speedup_vs_fp32"] = x3["value"] / out["value"]
+    x3["adrf_max_abs_diff_vs_fp32"] = float(np.max(np.abs(np.asarray(x3["adrf_head"]) - np.asarray(out["adrf_head"]))))
+    out["f16x3"] = x3
     return out
 
 

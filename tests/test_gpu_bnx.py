@@ -139,3 +139,27 @@ def test_precision_modes_outside_the_default_shape_kernels_are_refused():
     with pytest.raises(RuntimeError, match="no bf16 form"):
         eng.set_precision("bf16x3")
     eng.close()
+
+
+def test_class_predict_in_split_precision(tmp_path):
+    """CausalBGM(use_bnn=True, mh_precision='f16x3'): same weights, seeds and draws as the fp32 model; the two predicts differ by the
+    chains whose accept decision sat within the arithmetic's distance of the threshold (a few per thousand), the dose-response by less
+    than the posterior spread."""
+    from bayesgm_amd.models import CausalBGM
+    from bayesgm_amd.datasets import Sim_Hirano_Imbens_sampler
+    from test_gpu_bnn import _params
+    x, y, v = Sim_Hirano_Imbens_sampler(N=2000, v_dim=20, seed=0).load_all()
+    xs = np.linspace(0, 3, 7)
+    out = {}
+    for mode in ("fp32", "f16x3"):
+        model = CausalBGM(dict(_params(tmp_path, False), mh_precision=mode, save_res=False), random_seed=3)
+        eff, interval = model.predict((x, y, v), alpha=0.05, n_mcmc=30, burn_in=30, x_values=xs, q_sd=0.5, bs=500, verbose=0)
+        lp = model.get_log_posterior(x[:200], y[:200], v[:200], np.zeros((200, 10), np.float32))
+        out[mode] = (eff, interval, model.last_acceptance_rate, lp)
+        assert np.isfinite(eff).all() and np.all(interval[:, 0] <= interval[:, 1])
+    assert np.abs(out["fp32"][3] - out["f16x3"][3]).max() < 2e-5 * np.abs(out["fp32"][3]).max() + 2e-3
+    assert np.abs(out["fp32"][3] - out["f16x3"][3]).max() > 0.0
+    assert abs(out["fp32"][2] - out["f16x3"][2]) < 5e-3
+    assert np.abs(out["fp32"][0] - out["f16x3"][0]).max() < 0.05
+    with pytest.raises(ValueError, match="mh_precision"):
+        CausalBGM(dict(_params(tmp_path, False), mh_precision="bf16x3", save_res=False), random_seed=3)

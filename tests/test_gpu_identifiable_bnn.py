@@ -85,8 +85,9 @@ def test_bayesian_prior_step_matches_oracle(units, k, B, norm):
     eng.close()
 
 
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
 @pytest.mark.parametrize("binary,p,z_dims,n,bs", [(False, 200, (1, 1, 1, 7), 700, 300), (True, 100, (3, 3, 6, 6), 520, 520), (False, 50, (4, 4, 4, 4), 75, 75)])
-def test_conditional_prior_log_posterior_blocks(binary, p, z_dims, n, bs):
+def test_conditional_prior_log_posterior_blocks(binary, p, z_dims, n, bs, precision):
     from bayesgm_amd import _lib
     from bayesgm_amd.bnn_engine import flatten_bnn
     from tests.test_gpu_bnf import _engine, _panel
@@ -97,6 +98,7 @@ def test_conditional_prior_log_posterior_blocks(binary, p, z_dims, n, bs):
     pn32 = _prior(rs, k, q, (64,), "fixed")
     seg = rs.randint(0, k, n)
     eng = _engine(m)
+    eng.set_precision(precision)          # f16x3: the split-precision kernels (csrc/bnx_kernels.h) read the same per-row prior table
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
     cfg = _cfg([k, 64, q + 1])
     theta, seg_dev = T(flatten_bnn(pn32)), T(seg.astype(np.int32))
@@ -113,7 +115,8 @@ def test_conditional_prior_log_posterior_blocks(binary, p, z_dims, n, bs):
     eng.close()
 
 
-def test_conditional_prior_mh_iterations():
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_conditional_prior_mh_iterations(precision):
     from bayesgm_amd import _lib
     from bayesgm_amd.bnn_engine import flatten_bnn
     from tests.test_gpu_bnf import _engine, _panel
@@ -124,6 +127,7 @@ def test_conditional_prior_mh_iterations():
     pn32 = _prior(rs, k, q, (64,), "fixed")
     seg = rs.randint(0, k, n)
     eng = _engine(m)
+    eng.set_precision(precision)          # f16x3: proposal / evaluation of (item, state) units / accept step as three launches
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
     cfg = _cfg([k, 64, q + 1])
     theta, seg_dev = T(flatten_bnn(pn32)), T(seg.astype(np.int32))
