@@ -109,6 +109,7 @@ int gx_session(bgm_handle *h, GxState *&st, hipStream_t stream, bool need_ghf = 
       delete s; bgm_set_error("general-width engine: a hidden layer is too wide for the 32-row LDS tiles (hidden widths up to ~550)"); return BGM_E_UNSUPPORTED;
     }
     s->occ = std::max(1, std::min(4, (160 * 1024) / std::max(s->lds_bytes, 1)));      // up to 16 waves per CU hide each other's L2 latencies
+    if (const char *o_ = std::getenv("BGM_GX_OCC")) s->occ = std::max(1, std::min(std::atoi(o_), (160 * 1024) / std::max(s->lds_bytes, 1)));      // dev: workgroups per CU
     if (hipMalloc((void **)&s->pack, sizeof(float) * std::max<size_t>(off, 1)) != hipSuccess ||
         hipMalloc((void **)&s->packT, sizeof(float) * std::max<size_t>(offT, 1)) != hipSuccess) {
       if (s->pack) hipFree(s->pack);
@@ -229,6 +230,19 @@ int gx_mh_run(bgm_handle *h, const bgm_mh_args *a, hipStream_t stream) {
   else rc = launch(gx_causal_mh_kernel<0>);
   if (rc) return rc;
   if (h->timing) { BGM_HIP_CHECK(hipEventRecord(e1, stream)); h->events.push_back({e0, e1, a->effect}); }
+#ifdef GX_PHASE_CLOCK
+  {
+    unsigned long long c[16], z[16] = {0};
+    hipStreamSynchronize(stream);
+    hipMemcpyFromSymbol(c, HIP_SYMBOL(gx_phase_clk), sizeof(c));
+    hipMemcpyToSymbol(HIP_SYMBOL(gx_phase_clk), z, sizeof(z));
+    static const char *nm[9] = {"proposal", "stage-g", "g-hidden", "g-last", "f", "h", "assemble", "accept", "effects"};
+    double tot = 0; for (int i = 0; i < 9; ++i) tot += (double)c[i];
+    fprintf(stderr, "[GX_PHASE_CLOCK] cycles per workgroup and iteration (grid %d, %d iterations):", grid, a->n_iters);
+    for (int i = 0; i < 9; ++i) fprintf(stderr, " %s %.0f (%.1f%%)", nm[i], (double)c[i] / grid / std::max(1, a->n_iters), 100.0 * c[i] / std::max(1.0, tot));
+    fprintf(stderr, "\n");
+  }
+#endif
   return BGM_OK;
 }
 

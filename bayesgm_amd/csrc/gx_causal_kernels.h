@@ -17,6 +17,23 @@
 #pragma once
 #include "gx_device.h"
 
+// -D GX_PHASE_CLOCK (development): cycle stamps of thread 0 of every workgroup behind the phases of a transition, summed into
+// gx_phase_clk[] (0 proposal, 1 stage g, 2 g hidden, 3 g last, 4 f, 5 h, 6 assemble, 7 accept / copy, 8 effects); gx_api.hip prints them
+#ifdef GX_PHASE_CLOCK
+__device__ unsigned long long gx_phase_clk[16];
+#define GX_PC_DECL unsigned long long gx_pc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, gx_pl = clock64();
+#define GX_PC(k) { const unsigned long long t__ = clock64(); gx_pc[k] += t__ - gx_pl; gx_pl = t__; }
+#define GX_PC_PARAM , unsigned long long (&gx_pc)[12], unsigned long long &gx_pl
+#define GX_PC_ARG , gx_pc, gx_pl
+#define GX_PC_FLUSH() { if (threadIdx.x == 0) for (int k__ = 0; k__ < 12; ++k__) atomicAdd(&gx_phase_clk[k__], gx_pc[k__]); }
+#else
+#define GX_PC_DECL
+#define GX_PC(k)
+#define GX_PC_PARAM
+#define GX_PC_ARG
+#define GX_PC_FLUSH()
+#endif
+
 struct GxCausalModel {
   GxNet g, f, h, e;
   const float *pack;                 // forward pack of all four networks
@@ -49,20 +66,35 @@ __device__ __forceinline__ GxLds gx_carve(float *lds, int ld, int q, int ncg, in
   return L;
 }
 
-// Likelihood epilogue of g's last layer: (v - mu)^2 summed over the lane's columns < p, the variance column p kept aside.
+// Likelihood epilogue of g's last layer: (v - mu)^2 summed over the lane's columns < p, the variance column p kept aside.  The bias is in
+// the accumulators (gx_dense_ld); the lane's data values of a unit are requested one unit ahead (pre / rotate hooks of the engine): read
+// in the epilogue itself, each unit ended on an exposed L2 / HBM round trip.
 struct GxGLastEpi {
-  const float *bias; const float *v; long long row0, n; int p; float *ssep; float *sraw;
+  const float *v; long long row0, n; int p; float *ssep; float *sraw;
+  float vc[4][2], vn[4][2];
+  __device__ __forceinline__ void pre(int rt, int n0) {
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int c0 = n0 + 2 * j;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      long long gr = row0 + 16 * rt + 4 * g + r; gr = gr < n ? gr : n - 1;
+      const float *vr = v + gr * (long long)p;
+      vn[r][0] = (c0 < p) ? vr[c0] : 0.0f;
+      vn[r][1] = (c0 + 1 < p) ? vr[c0 + 1] : 0.0f;
+    }
+  }
+  __device__ __forceinline__ void rotate() {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { vc[r][0] = vn[r][0]; vc[r][1] = vn[r][1]; }
+  }
   __device__ __forceinline__ void operator()(int rt, int n0, const f32x4 &a0, const f32x4 &a1) const {
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     const int c0 = n0 + 2 * j;
-    const float b0 = bias[c0], b1 = bias[c0 + 1];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = 16 * rt + 4 * g + r;
-      long long gr = row0 + row; gr = gr < n ? gr : n - 1;
-      const float *vr = v + gr * (long long)p;
-      const float m0 = a0[r] + b0, m1 = a1[r] + b1;
-      const float d0 = (c0 < p) ? vr[c0] - m0 : 0.0f, d1 = (c0 + 1 < p) ? vr[c0 + 1] - m1 : 0.0f;
+      const float m0 = a0[r], m1 = a1[r];
+      const float d0 = (c0 < p) ? vc[r][0] - m0 : 0.0f, d1 = (c0 + 1 < p) ? vc[r][1] - m1 : 0.0f;
       if (c0 == p) sraw[row] = m0;
       if (c0 + 1 == p) sraw[row] = m1;
       const float s = gx_sum_j(fmaf(d0, d0, d1 * d1));
@@ -85,45 +117,60 @@ __device__ __forceinline__ void gx_stage(float *buf, int ld, int width_pad, Src 
 template <class XIn>
 __device__ __forceinline__ void gx_f_forward(const GxCausalModel &m, const GxLds &L, const float *z, XIn xin, int nd = 1) {
   const int zf = m.z0 + m.z1, q = m.q, ld = m.ldf, rows = GX_ROWS * nd, nrt = 2 * nd;
+  GxPre pre = gx_prefetch(m.pack + m.f.w[0], m.f.pad[1], m.f.pad[1], m.pack + m.f.b[0], nrt);
   gx_stage(L.bufA, ld, m.f.pad[0], [&](int r, int c) { return c < zf ? z[(r & (GX_ROWS - 1)) * q + c] : (c == zf ? xin(r & (GX_ROWS - 1), r / GX_ROWS) : 0.0f); }, rows);
   __syncthreads();
-  float *cur = gx_hidden(m.f, m.pack, 0, m.f.L - 1, L.bufA, L.bufB, ld, nrt);
+  float *cur = gx_hidden(m.f, m.pack, 0, m.f.L - 1, L.bufA, L.bufB, ld, pre, nrt, nrt);
   float *oth = (cur == L.bufA) ? L.bufB : L.bufA;
   const int l = m.f.L - 1;
-  gx_dense(m.pack + m.f.w[l], m.f.pad[l], m.f.pad[l + 1], cur, ld, GxStore<false>{oth, ld, m.pack + m.f.b[l]}, nrt);
+  gx_dense(m.pack + m.f.w[l], m.f.pad[l], m.f.pad[l + 1], cur, ld, GxStore<false>{oth, ld, nullptr}, nrt, m.pack + m.f.b[l], &pre);
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * rows; i += GX_THREADS) L.fo[i] = oth[(i >> 1) * ld + (i & 1)];
   __syncthreads();
 }
 
 // log p(z | x, y, v) + const for the tile's 32 rows, z in LDS [32][q]; result in L.lpn[row].  base.py:765-817.
+#ifndef GX_PHASE_CLOCK
 __device__ __forceinline__ void gx_causal_logp(const GxCausalModel &m, const GxLds &L, const float *z, const float *x, const float *y,
                                                const float *v, long long row0, long long n) {
+#else
+__device__ __forceinline__ void gx_causal_logp(const GxCausalModel &m, const GxLds &L, const float *z, const float *x, const float *y,
+                                               const float *v, long long row0, long long n, unsigned long long (&gx_pc)[12], unsigned long long &gx_pl) {
+#endif
   const int q = m.q, ld = m.ld;
   // ---- g: z -> (mu_v [p], raw_v)
+  GxPre pre = gx_prefetch(m.pack + m.g.w[0], m.g.pad[1], m.g.pad[1], m.pack + m.g.b[0]);
   gx_stage(L.bufA, ld, m.g.pad[0], [&](int r, int c) { return c < q ? z[r * q + c] : 0.0f; });
   __syncthreads();
+  GX_PC(1);
   {
-    float *cur = gx_hidden(m.g, m.pack, 0, m.g.L - 1, L.bufA, L.bufB, ld);
+    float *cur = gx_hidden(m.g, m.pack, 0, m.g.L - 1, L.bufA, L.bufB, ld, pre);
+    GX_PC(2);
     const int l = m.g.L - 1;
-    gx_dense(m.pack + m.g.w[l], m.g.pad[l], m.g.pad[l + 1], cur, ld, GxGLastEpi{m.pack + m.g.b[l], v, row0, n, m.p, L.ssep, L.sraw});
+    GxGLastEpi ge;
+    ge.v = v; ge.row0 = row0; ge.n = n; ge.p = m.p; ge.ssep = L.ssep; ge.sraw = L.sraw;
+    gx_dense(m.pack + m.g.w[l], m.g.pad[l], m.g.pad[l + 1], cur, ld, ge, 2, m.pack + m.g.b[l], &pre);
     __syncthreads();
+    GX_PC(3);
   }
   // ---- f: (z0, z1, x) -> (mu_y, raw_y)
   gx_f_forward(m, L, z, [&](int r, int) { long long gr = row0 + r; gr = gr < n ? gr : n - 1; return x[gr]; });
+  GX_PC(4);
   // ---- h: (z0, z2) -> (mu_x | logit, raw_x)
   {
     const int z0 = m.z0, z1 = m.z1, z2 = m.z2;
+    GxPre ph = gx_prefetch(m.pack + m.h.w[0], m.h.pad[1], m.h.pad[1], m.pack + m.h.b[0]);
     gx_stage(L.bufA, ld, m.h.pad[0], [&](int r, int c) { return c < z0 ? z[r * q + c] : (c < z0 + z2 ? z[r * q + z1 + c] : 0.0f); });
     __syncthreads();
-    float *cur = gx_hidden(m.h, m.pack, 0, m.h.L - 1, L.bufA, L.bufB, ld);
+    float *cur = gx_hidden(m.h, m.pack, 0, m.h.L - 1, L.bufA, L.bufB, ld, ph);
     float *oth = (cur == L.bufA) ? L.bufB : L.bufA;
     const int l = m.h.L - 1;
-    gx_dense(m.pack + m.h.w[l], m.h.pad[l], m.h.pad[l + 1], cur, ld, GxStore<false>{oth, ld, m.pack + m.h.b[l]});
+    gx_dense(m.pack + m.h.w[l], m.h.pad[l], m.h.pad[l + 1], cur, ld, GxStore<false>{oth, ld, nullptr}, 2, m.pack + m.h.b[l], &ph);
     __syncthreads();
     if (threadIdx.x < 2 * GX_ROWS) L.ho[threadIdx.x] = oth[(threadIdx.x >> 1) * ld + (threadIdx.x & 1)];
     __syncthreads();
   }
+  GX_PC(5);
   // ---- assemble -(loss_v + loss_x + loss_y + prior)   (base.py:800-816)
   if (threadIdx.x < GX_ROWS) {
     const int r = threadIdx.x;
@@ -159,6 +206,7 @@ __device__ __forceinline__ void gx_causal_logp(const GxCausalModel &m, const GxL
     L.lpn[r] = -(0.5f * sse * fast_rcp(s2v) + 0.5f * (float)m.p * fast_log(s2v) + loss_x + loss_y + prior);
   }
   __syncthreads();
+  GX_PC(6);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -174,7 +222,7 @@ __global__ __launch_bounds__(GX_THREADS) void gx_causal_logpost_kernel(GxCausalM
       L.zc[i] = z[gr * m.q + i % m.q];
     }
     __syncthreads();
-    gx_causal_logp(m, L, L.zc, x, y, v, row0, n);
+    { GX_PC_DECL gx_causal_logp(m, L, L.zc, x, y, v, row0, n GX_PC_ARG); }
     if (threadIdx.x < GX_ROWS && row0 + threadIdx.x < n) out[row0 + threadIdx.x] = L.lpn[threadIdx.x];
     __syncthreads();
   }
@@ -269,6 +317,7 @@ __global__ __launch_bounds__(GX_THREADS) void gx_causal_mh_kernel(GxMhArgs a) {
   if (EFFECT == 1) e.adrf_slot = a.adrf_partial + (long long)blockIdx.x * e.n_keep * e.n_doses;
   if (EFFECT != 0 && e.cache) e.cache += (long long)blockIdx.x * ((EFFECT == 2) ? 2 : e.n_doses) * GX_ROWS;
   unsigned n_served = 0u;
+  GX_PC_DECL
   const int ncall = (q + 15) >> 4;            // Philox calls per lane group: features 16 t + 4 e + g  <-  call g + 4 t, output e
   for (long long t = blockIdx.x; t < tiles; t += gridDim.x) {
     const long long row0 = t * GX_ROWS;
@@ -282,7 +331,7 @@ __global__ __launch_bounds__(GX_THREADS) void gx_causal_mh_kernel(GxMhArgs a) {
         for (int w = 0; w < 4; ++w) { const int f = 16 * tt + 4 * w + g; if (f < q) L.zc[r * q + f] = nz[w]; }
       }
       __syncthreads();
-      gx_causal_logp(m, L, L.zc, a.x, a.y, a.v, row0, n);
+      gx_causal_logp(m, L, L.zc, a.x, a.y, a.v, row0, n GX_PC_ARG);
       if (threadIdx.x < GX_ROWS) L.lpc[threadIdx.x] = L.lpn[threadIdx.x];
     } else {
       for (int i = threadIdx.x; i < GX_ROWS * q; i += GX_THREADS) {
@@ -301,7 +350,8 @@ __global__ __launch_bounds__(GX_THREADS) void gx_causal_mh_kernel(GxMhArgs a) {
         for (int w = 0; w < 4; ++w) { const int f = 16 * tt + 4 * w + g; if (f < q) L.zp[r * q + f] = fmaf(a.q_sd, nz[w], L.zc[r * q + f]); }
       }
       __syncthreads();
-      gx_causal_logp(m, L, L.zp, a.x, a.y, a.v, row0, n);
+      GX_PC(0);
+      gx_causal_logp(m, L, L.zp, a.x, a.y, a.v, row0, n GX_PC_ARG);
       // ---- accept / reject   (base.py:868-871).  u(it) = word (it & 3) of Philox(row, it >> 2, 0, TAG_ACC)
       if (threadIdx.x < 64) {
         const int r = threadIdx.x & 31;
@@ -324,6 +374,7 @@ __global__ __launch_bounds__(GX_THREADS) void gx_causal_mh_kernel(GxMhArgs a) {
       for (int i = threadIdx.x; i < GX_ROWS * q; i += GX_THREADS)
         if (L.red[i / q] != 0.0f) L.zc[i] = L.zp[i];
       __syncthreads();
+      GX_PC(7);
       if (it >= a.burn_in) {
         const long long d = it - a.burn_in;
         if (a.draws) {            // samples.append(current_state.copy())  (base.py:896)
@@ -338,6 +389,7 @@ __global__ __launch_bounds__(GX_THREADS) void gx_causal_mh_kernel(GxMhArgs a) {
           eff_cached = true;
           n_served += skip ? 2u : 0u;
         }
+        GX_PC(8);
       }
     }
     // ---- write the chain state back
@@ -349,6 +401,7 @@ __global__ __launch_bounds__(GX_THREADS) void gx_causal_mh_kernel(GxMhArgs a) {
     __syncthreads();
   }
   if (EFFECT != 0 && e.stats != nullptr && threadIdx.x == 0 && n_served != 0u) atomicAdd(&e.stats[0], (unsigned long long)n_served);
+  GX_PC_FLUSH();
 }
 
 // stand-alone effects on a tensor of draws [n_keep][n][q]
@@ -406,7 +459,7 @@ __global__ __launch_bounds__(GX_THREADS) void gx_causal_eval_kernel(GxEvalArgs a
       L.zc[i] = a.z[gr * q + i % q];
     }
     __syncthreads();
-    gx_causal_logp(m, L, L.zc, a.x, a.y, a.v, row0, n);       // leaves sse, f / h outputs in LDS
+    { GX_PC_DECL gx_causal_logp(m, L, L.zc, a.x, a.y, a.v, row0, n GX_PC_ARG); }       // leaves sse, f / h outputs in LDS
     if (threadIdx.x < GX_ROWS && row0 + threadIdx.x < n) {
       const int r = threadIdx.x;
       float sse = 0.0f;
@@ -508,10 +561,12 @@ __global__ __launch_bounds__(GX_THREADS) void gx_encode_kernel(GxEncArgs a) {
     __syncthreads();
     float *cur = bufB, *oth = bufA;
     if (a.e.L > 1) {
-      cur = gx_hidden(a.e, a.pack, 1, a.e.L - 1, bufB, bufA, a.ld);
+      GxPre pe;
+      pe.valid = 0;
+      cur = gx_hidden(a.e, a.pack, 1, a.e.L - 1, bufB, bufA, a.ld, pe);
       oth = (cur == bufA) ? bufB : bufA;
       const int l = a.e.L - 1;
-      gx_dense(a.pack + a.e.w[l], a.e.pad[l], a.e.pad[l + 1], cur, a.ld, GxStore<false>{oth, a.ld, a.pack + a.e.b[l]});
+      gx_dense(a.pack + a.e.w[l], a.e.pad[l], a.e.pad[l + 1], cur, a.ld, GxStore<false>{oth, a.ld, nullptr}, 2, a.pack + a.e.b[l], &pe);
       __syncthreads();
       cur = oth;
     }

@@ -48,9 +48,38 @@ __host__ __device__ inline int gx_ld(int width) { return ((width + 59) / 64) * 6
 // (true: row r of the tile at A + r * lda); gx_dense_ld: the N columns processed are a slice of rows of stride ldw.  epi(rt, n0, acc0, acc1): lane (j, g) holds rows 16 rt + 4g + r (r = 0..3) of columns
 // n0 + 2j (acc0[r]) and n0 + 2j + 1 (acc1[r]).  No barriers inside: the caller separates producers and consumers of A.
 // ---------------------------------------------------------------------------------------------------------------------------
-// nrt: 16-row tiles of A (2 = the workgroup's 32 rows; the effect pass stacks several doses' rows: 2 x doses)
+// First K block of the wave's FIRST unit of a layer (four 8-byte weight pairs) and the unit's bias pair, requested ahead of the barrier
+// that releases the layer's input (weights and biases do not depend on it): the L2 round trip of every layer's first block otherwise
+// sits in front of its first MFMA (measured: ~1.5-3 k cycles per layer of a 64-wide net, more than the layer's own 1 k of matrix work).
+struct GxPre { f32x2 b0, b1, b2, b3, bb; int valid; };
+__device__ __forceinline__ GxPre gx_prefetch(const float *__restrict__ W, int ldw, int N, const float *bias, int nrt = 2) {
+  GxPre p;
+  p.valid = 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  if (wave >= nrt * (N >> 5)) return p;
+  const int n0 = (wave / nrt) << 5;
+  const float *wk = W + (size_t)(4 * g) * ldw + n0 + 2 * j;
+  p.b0 = *reinterpret_cast<const f32x2 *>(wk);
+  p.b1 = *reinterpret_cast<const f32x2 *>(wk + ldw);
+  p.b2 = *reinterpret_cast<const f32x2 *>(wk + 2 * (size_t)ldw);
+  p.b3 = *reinterpret_cast<const f32x2 *>(wk + 3 * (size_t)ldw);
+  p.bb = bias ? *reinterpret_cast<const f32x2 *>(bias + n0 + 2 * j) : f32x2{0.0f, 0.0f};
+  p.valid = 1;
+  return p;
+}
+// optional hooks of an epilogue functor: pre(rt, n0) = requests of unit (rt, n0)'s epilogue operands, issued one unit ahead (with the
+// unit's first weight block); rotate() = behind each epilogue call (next unit's operands become the current ones)
+template <class E> __device__ __forceinline__ auto gx_epi_pre(E &e, int rt, int n0, int) -> decltype(e.pre(rt, n0), void()) { e.pre(rt, n0); }
+template <class E> __device__ __forceinline__ void gx_epi_pre(E &, int, int, long) {}
+template <class E> __device__ __forceinline__ auto gx_epi_rotate(E &e, int) -> decltype(e.rotate(), void()) { e.rotate(); }
+template <class E> __device__ __forceinline__ void gx_epi_rotate(E &, long) {}
+
+// nrt: 16-row tiles of A (2 = the workgroup's 32 rows; the effect pass stacks several doses' rows: 2 x doses).  bias != NULL: the
+// accumulators start from the unit's bias pair (requested with its first weight block; the functor then adds none).  pre: the first
+// unit's first block as requested by gx_prefetch ahead of the barrier in front of this call.
 template <bool A_GLOBAL = false, class Epi>
-__device__ __forceinline__ void gx_dense_ld(const float *__restrict__ W, int ldw, int K, int N, const float *A, int lda, Epi epi, int nrt = 2) {
+__device__ __forceinline__ void gx_dense_ld(const float *__restrict__ W, int ldw, int K, int N, const float *A, int lda, Epi epi, int nrt = 2,
+                                            const float *bias = nullptr, const GxPre *pre = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
   const int units = nrt * (N >> 5);
   int u = wave;
@@ -63,12 +92,19 @@ __device__ __forceinline__ void gx_dense_ld(const float *__restrict__ W, int ldw
   const float *ap = A + (size_t)(16 * rt + j) * lda + 4 * g;
   const float *wk = W + (size_t)(4 * g) * ldw + n0 + 2 * j;
   f32x4 a = *reinterpret_cast<const f32x4 *>(ap);
-  f32x2 b0 = *reinterpret_cast<const f32x2 *>(wk);
-  f32x2 b1 = *reinterpret_cast<const f32x2 *>(wk + ldw);
-  f32x2 b2 = *reinterpret_cast<const f32x2 *>(wk + 2 * (size_t)ldw);
-  f32x2 b3 = *reinterpret_cast<const f32x2 *>(wk + 3 * (size_t)ldw);
+  f32x2 b0, b1, b2, b3, bb = {0.0f, 0.0f};
+  if (pre != nullptr && pre->valid) { b0 = pre->b0; b1 = pre->b1; b2 = pre->b2; b3 = pre->b3; bb = pre->bb; }
+  else {
+    b0 = *reinterpret_cast<const f32x2 *>(wk);
+    b1 = *reinterpret_cast<const f32x2 *>(wk + ldw);
+    b2 = *reinterpret_cast<const f32x2 *>(wk + 2 * (size_t)ldw);
+    b3 = *reinterpret_cast<const f32x2 *>(wk + 3 * (size_t)ldw);
+    if (bias) bb = *reinterpret_cast<const f32x2 *>(bias + n0 + 2 * j);
+  }
+  gx_epi_pre(epi, rt, n0, 0);
+  gx_epi_rotate(epi, 0);
   for (;;) {
-    f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 acc0 = {bb[0], bb[0], bb[0], bb[0]}, acc1 = {bb[1], bb[1], bb[1], bb[1]};
     for (int k0 = 16; k0 < K; k0 += 16) {
       wk += wstep;
       const f32x4 an = *reinterpret_cast<const f32x4 *>(ap + k0);
@@ -88,7 +124,7 @@ __device__ __forceinline__ void gx_dense_ld(const float *__restrict__ W, int ldw
     const bool more = un < units;
     const int rtn = un % nrt, n0n = (un / nrt) << 5;
     f32x4 an = a;
-    f32x2 c0 = b0, c1 = b1, c2 = b2, c3 = b3;
+    f32x2 c0 = b0, c1 = b1, c2 = b2, c3 = b3, bn = bb;
     if (more) {
       ap = A + (size_t)(16 * rtn + j) * lda + 4 * g;
       wk = W + (size_t)(4 * g) * ldw + n0n + 2 * j;
@@ -97,6 +133,8 @@ __device__ __forceinline__ void gx_dense_ld(const float *__restrict__ W, int ldw
       c1 = *reinterpret_cast<const f32x2 *>(wk + ldw);
       c2 = *reinterpret_cast<const f32x2 *>(wk + 2 * (size_t)ldw);
       c3 = *reinterpret_cast<const f32x2 *>(wk + 3 * (size_t)ldw);
+      if (bias) bn = *reinterpret_cast<const f32x2 *>(bias + n0n + 2 * j);
+      gx_epi_pre(epi, rtn, n0n, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     acc0 = BGM_MFMA(a[0], b0[0], acc0); acc1 = BGM_MFMA(a[0], b0[1], acc1);
@@ -105,25 +143,28 @@ __device__ __forceinline__ void gx_dense_ld(const float *__restrict__ W, int ldw
     acc0 = BGM_MFMA(a[3], b3[0], acc0); acc1 = BGM_MFMA(a[3], b3[1], acc1);
     epi(rt, n0, acc0, acc1);
     if (!more) break;
+    gx_epi_rotate(epi, 0);
     u = un; rt = rtn; n0 = n0n;
-    a = an; b0 = c0; b1 = c1; b2 = c2; b3 = c3;
+    a = an; b0 = c0; b1 = c1; b2 = c2; b3 = c3; bb = bn;
   }
 }
 
 // W [K][N] with row stride N
 template <bool A_GLOBAL = false, class Epi>
-__device__ __forceinline__ void gx_dense(const float *__restrict__ W, int K, int N, const float *A, int lda, Epi epi, int nrt = 2) {
-  gx_dense_ld<A_GLOBAL>(W, N, K, N, A, lda, epi, nrt);
+__device__ __forceinline__ void gx_dense(const float *__restrict__ W, int K, int N, const float *A, int lda, Epi epi, int nrt = 2,
+                                         const float *bias = nullptr, const GxPre *pre = nullptr) {
+  gx_dense_ld<A_GLOBAL>(W, N, K, N, A, lda, epi, nrt, bias, pre);
 }
 
 // Epilogue helpers -------------------------------------------------------------------------------------------------------------
 // y = act(acc + b) -> Y (LDS [32][ldy]); LEAKY: LeakyReLU(0.2), else linear
+// (bias == NULL: the engine started the accumulators from the bias)
 template <bool LEAKY>
 struct GxStore {
   float *Y; int ldy; const float *bias;
   __device__ __forceinline__ void operator()(int rt, int n0, const f32x4 &a0, const f32x4 &a1) const {
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
-    const f32x2 bb = *reinterpret_cast<const f32x2 *>(bias + n0 + 2 * j);
+    const f32x2 bb = bias ? *reinterpret_cast<const f32x2 *>(bias + n0 + 2 * j) : f32x2{0.0f, 0.0f};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float y0 = a0[r] + bb[0], y1 = a1[r] + bb[1];
@@ -184,11 +225,18 @@ struct GxRawStore {
 };
 
 // Hidden layers l = l_begin .. l_end - 1 of `net` (LeakyReLU), ping-ponging between two LDS buffers; the input is in `cur`.
-// Returns with the last output in the returned buffer (a barrier has been passed after its last store).
-__device__ __forceinline__ float *gx_hidden(const GxNet &net, const float *pack, int l_begin, int l_end, float *cur, float *oth, int ld, int nrt = 2) {
+// Returns with the last output in the returned buffer (a barrier has been passed after its last store).  pre: in = layer l_begin's first
+// block (gx_prefetch; or valid = 0), out = layer l_end's when the net has one -- every layer's first weights and biases are requested
+// before the previous layer's products and arrive under them and the barrier.
+__device__ __forceinline__ float *gx_hidden(const GxNet &net, const float *pack, int l_begin, int l_end, float *cur, float *oth, int ld, GxPre &pre,
+                                            int nrt = 2, int nrt_after = 2) {
   for (int l = l_begin; l < l_end; ++l) {
-    gx_dense(pack + net.w[l], net.pad[l], net.pad[l + 1], cur, ld, GxStore<true>{oth, ld, pack + net.b[l]}, nrt);
+    GxPre nx;
+    nx.valid = 0;
+    if (l + 1 < net.L) nx = gx_prefetch(pack + net.w[l + 1], net.pad[l + 2], net.pad[l + 2], pack + net.b[l + 1], l + 1 < l_end ? nrt : nrt_after);
+    gx_dense(pack + net.w[l], net.pad[l], net.pad[l + 1], cur, ld, GxStore<true>{oth, ld, nullptr}, nrt, pack + net.b[l], &pre);
     __syncthreads();
+    pre = nx;
     float *t = cur; cur = oth; oth = t;
   }
   return cur;

@@ -18,6 +18,10 @@ if forced:
 only = os.environ.get("GX_ONLY")
 if only == "w256":
     cases = [c for c in cases if c[0].startswith("[256")]
+elif only == "default":
+    cases = cases[:1]
+elif only == "w128":
+    cases = [c for c in cases if c[0].startswith("[128")]
 z_dims, p = [1, 1, 1, 7], 200
 for name, u, n in cases:
     m = OC.init_model(0, z_dims, p, **u)
