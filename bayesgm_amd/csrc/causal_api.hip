@@ -350,11 +350,8 @@ extern "C" int bgm_causal_logpost(bgm_handle *h, const float *x, const float *y,
   int rc = bgm_causal_sampling_blob(h, stream);
   if (rc) return rc;
   const int grid = mh_grid(h, n);
-  if (h->prior_seg) {
-    if (h->precision != 0) { bgm_set_error("bgm_causal_logpost: the conditional prior is built for the fp32 kernels only"); return BGM_E_UNSUPPORTED; }
-    return bgm_causal_prior_logpost(h, x, y, v, z, n, out, grid, stream);
-  }
-  if (h->precision != 0) return bgm_causal_bx3_logpost(h, x, y, v, z, n, out, grid, stream);
+  if (h->precision != 0) return bgm_causal_bx3_logpost(h, x, y, v, z, n, out, grid, stream);      // (carries the conditional prior, if one is set)
+  if (h->prior_seg) return bgm_causal_prior_logpost(h, x, y, v, z, n, out, grid, stream);
   const int lds = h->meta.total * 4;
 #define X(KT1_, KSL1_, NTL_)                                                                   \
   if (h->KT1 == KT1_ && h->KSL1 == KSL1_ && h->NTL == NTL_) {                                  \
@@ -487,10 +484,8 @@ extern "C" int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *a, void *stre
       ka.ev_first = segs[s].ev == 1 ? 1 : 0;
       if ((rc = bgm_causal_event_mh_launch(h, ka, grid, lds, stream))) return rc;
       rc = bgm_causal_event_finish(h, ka, grid, ka.ev_first, stream);
-    } else if (h->prior_seg) {
-      if (h->precision != 0) { bgm_set_error("bgm_causal_mh_run: the conditional prior is built for the fp32 kernels only"); return BGM_E_UNSUPPORTED; }
-      rc = bgm_causal_prior_mh_launch(h, ka, segs[s].effect, grid, lds, stream);
-    } else if (h->precision != 0) rc = bgm_causal_bx3_mh_launch(h, ka, segs[s].effect, grid, stream);
+    } else if (h->precision != 0) rc = bgm_causal_bx3_mh_launch(h, ka, segs[s].effect, grid, stream);      // (carries the conditional prior)
+    else if (h->prior_seg) rc = bgm_causal_prior_mh_launch(h, ka, segs[s].effect, grid, lds, stream);
     else if (segs[s].effect == BGM_EFFECT_ADRF) rc = launch_mh<1>(h, ka, grid, lds, stream);
     else if (segs[s].effect == BGM_EFFECT_ITE) rc = launch_mh<2>(h, ka, grid, lds, stream);
     else rc = launch_mh<0>(h, ka, grid, lds, stream);

@@ -224,7 +224,7 @@ int bgm_causal_bx3_logpost(bgm_handle *h, const float *x, const float *y, const 
     rc = bx_set_lds(k, lds);                                                                                       \
     if (rc) return rc;                                                                                             \
     hipLaunchKernelGGL(k, dim3(grid), dim3(64 * BX_WAVES), lds, stream, (const unsigned char *)h->bx_blob_dev, m, x, y, v, z, \
-                       (long long)n, out);                                                                         \
+                       (long long)n, out, (const int *)h->prior_seg, (const float *)h->prior_tab);                 \
     BGM_HIP_CHECK(hipGetLastError());                                                                              \
     return BGM_OK;                                                                                                 \
   }
@@ -258,6 +258,8 @@ int bgm_causal_bx3_mh_launch(bgm_handle *h, const CausalMhKArgs &a, int effect, 
   if (rc) return rc;
   CausalBxKArgs ka{};
   ka.a = a;
+  ka.a.seg = (const int *)h->prior_seg;            // conditional prior (bgm_causal_set_prior) or NULL
+  ka.a.prior_tab = h->prior_tab;
   ka.bblob = (const unsigned char *)h->bx_blob_dev;
   std::memcpy(&ka.bx, h->bx_meta_store, sizeof(BxMeta));
   const int lds = ka.bx.total_bytes + 64;

@@ -405,7 +405,7 @@ __device__ __forceinline__ void bx_lds_fill(unsigned char *lds, const unsigned c
 template <int KT1, int NTL, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void causal_logpost_bx3_kernel(const unsigned char *blob, BxMeta m, const float *x,
                                                                         const float *y, const float *v, const float *z,
-                                                                        long long n, float *out) {
+                                                                        long long n, float *out, const int *seg, const float *prior_tab) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bx_lds[];
   using L = BxLayout<KT1, NTL>;
   bx_lds_fill(bx_lds, blob, m.total_bytes);
@@ -423,7 +423,12 @@ __global__ __launch_bounds__(64 * WAVES) void causal_logpost_bx3_kernel(const un
     bx_load_v<NTL>(v, ldsf + L::bgl, n, m.p, row0, j, g, vreg);
     f32x4 zin[1][KT1];
     load_z_rows<KT1, 1>(z, n, m.q, row0, j, g, xr, zin);
-    const float lp = causal_logp_bx3<KT1, NTL>(bx_lds, m, lane, g, j, zin[0], vreg, xr[0], yr);
+    float lp = causal_logp_bx3<KT1, NTL>(bx_lds, m, lane, g, j, zin[0], vreg, xr[0], yr);
+    if (seg != nullptr) {      // conditional latent prior (IdentifiableCausalBGM): the row's table entry replaces |z|^2 / 2, in fp32 (PriorRow)
+      PriorRow<KT1> pr;
+      pr.load(seg, prior_tab, row, m.q, g);
+      lp += pr.correction(zin[0], m.q, g);
+    }
     if (g == 0 && row0 + j < n) out[row0 + j] = lp;
   }
 }
@@ -573,6 +578,11 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_bx3_kernel(CausalBxKArgs
     bx_load_v<NTL>(a.v, ldsf + L::bgl, n, m.p, row0, j, g, vreg);
     f32x4 zs[1][KT1];
     float lp;
+    // conditional latent prior (a.seg != NULL, wave-uniform): the row's (mu, 1 / sigma^2, (q / 2) log sigma^2) in registers, the difference to
+    // the standard-normal term added to every log posterior in fp32 (PriorRow of causal_kernels.h, as its PRIOR = 1 instantiations do)
+    const bool has_prior = a.seg != nullptr;
+    PriorRow<KT1> pr;
+    if (has_prior) pr.load(a.seg, a.prior_tab, rowc, m.q, g);
     if (a.init) {
 #pragma unroll
       for (int t = 0; t < KT1; ++t) {
@@ -584,6 +594,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_bx3_kernel(CausalBxKArgs
         }
       }
       lp = causal_logp_bx3<KT1, NTL>(bx_lds, m, lane, g, j, zs[0], vreg, xr[0], yr);
+      if (has_prior) lp += pr.correction(zs[0], m.q, g);
     } else {
       load_z_rows<KT1, 1>(a.state, n, m.q, row0, j, g, xr, zs);
       lp = a.logp[rowc];
@@ -610,7 +621,8 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_bx3_kernel(CausalBxKArgs
           zp[t][r] = (f < m.q) ? fmaf(a.q_sd, e[r], zs[0][t][r]) : zs[0][t][r];
         }
       }
-      const float lpp = causal_logp_bx3<KT1, NTL>(bx_lds, m, lane, g, j, zp, vreg, xr[0], yr);
+      float lpp = causal_logp_bx3<KT1, NTL>(bx_lds, m, lane, g, j, zp, vreg, xr[0], yr);
+      if (has_prior) lpp += pr.correction(zp, m.q, g);
       if ((it & 3) == 0 || it == a.it_begin) uacc = philox4x32_10(rowid, (unsigned)it >> 2, 0u, TAG_ACC, a.k0, a.k1);
       const unsigned w = (it & 2) ? ((it & 1) ? uacc.w : uacc.z) : ((it & 1) ? uacc.y : uacc.x);
       const float u = u01_open(w);

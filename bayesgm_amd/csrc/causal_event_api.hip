@@ -18,11 +18,11 @@
 static constexpr int EV_MH_R = BGM_MH_R, EV_MH_WAVES = BGM_MH_WAVES, EV_SPREAD_WAVES = 4, EV_SPREAD_LDS_FLOATS = 8192;
 #define BGM_CAUSAL_VARIANTS(X) X(1, 3, 13) X(1, 3, 7) X(1, 3, 2) X(2, 1, 10) X(2, 1, 7) X(2, 1, 2)
 
-// served by the event form: dose-response sums on the LDS-resident kernels (fp32 with either prior, split precision with the standard-normal prior),
+// served by the event form: dose-response sums on the LDS-resident kernels (fp32 or split precision, with either prior),
 // doses in registers
 bool bgm_causal_event_wanted(const bgm_handle *h, int effect, int n_doses) {
   static const bool off = std::getenv("BGM_NO_EVENT_SPLIT") != nullptr;      // dev A/B
-  return !off && EV_MH_R == 1 && h->outcome_cache == 2 && effect == BGM_EFFECT_ADRF && !(h->prior_seg && h->precision != 0) &&
+  return !off && EV_MH_R == 1 && h->outcome_cache == 2 && effect == BGM_EFFECT_ADRF &&
          n_doses >= 1 && (n_doses + 3) / 4 <= EV_NCMAX;
 }
 

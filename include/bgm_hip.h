@@ -84,7 +84,7 @@ BGM_API int bgm_set_disc_norm(bgm_handle *h, int32_t mode);
  *                fp32 kernel's own distance of float64; weights beyond 65504 are clamped, an activation beyond 65504 overflows: fp16 range). */
 BGM_API int bgm_causal_set_precision(bgm_handle *h, int32_t mode);
 /* Conditional latent prior Z | U ~ N(mu(U), sigma^2(U) I) of IdentifiableCausalBGM (models/causalbgm/identifiable.py:195-211,
- * 541-551) for the sampling calls made afterwards (bgm_causal_logpost, bgm_causal_mh_run; fp32 kernels): seg_dev [n] = segment of
+ * 541-551) for the sampling calls made afterwards (bgm_causal_logpost, bgm_causal_mh_run; fp32 and split-precision kernels): seg_dev [n] = segment of
  * every LOCAL row of those calls (int32), tab_dev [n_segments x (q + 2)] = per segment mu [q], 1 / sigma^2, (q / 2) log sigma^2.
  * Both NULL: back to the standard-normal prior.  The buffers must stay valid while set. */
 BGM_API int bgm_causal_set_prior(bgm_handle *h, const int32_t *seg_dev, const float *tab_dev, int32_t n_segments);

@@ -91,3 +91,53 @@ def test_bx3_ite_and_class_predict(mode):
     same = (np.abs(ite32 - itebx) <= 1e-3).mean()
     print("ITE rows agreeing with fp32: %.3f, ATE fp32 %.4f %s %.4f" % (same, ite32.mean(), mode, itebx.mean()))
     assert same >= 0.8 and abs(float(ite32.mean()) - float(itebx.mean())) <= 0.01
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x3"])
+def test_bx3_with_the_conditional_prior(mode):
+    """IdentifiableCausalBGM's prior p(z | u) inside the split-precision kernels (the row's table entry in registers, the difference to the
+    standard-normal term added in fp32 as the PRIOR = 1 fp32 instantiations do): log posterior against the float64 oracle, chains against
+    the fp32 kernel's, and the event form of the retained phase bit-identical to the fused split-precision kernel."""
+    import torch
+    from bayesgm_amd import _lib
+    from oracle import identifiable as OI
+    from tests.test_gpu_identifiable import _prior
+    rs = np.random.RandomState(3)
+    z_dims, p, n, k = [1, 1, 1, 7], 200, 700, 7
+    q = sum(z_dims)
+    m = _model(5, z_dims, p, False)
+    x, y, v = _data(n, p, 6, False)
+    z = rs.randn(n, q).astype(np.float32)
+    seg = rs.randint(0, k, n)
+    pn = _prior(rs, k, q)
+    tab = OI.prior_table(pn, q)
+    mu, s2, _ = OI.prior_params([(W.astype(np.float64), b.astype(np.float64)) for W, b in pn], seg)
+    m64 = OC.cast_model(m, np.float64)
+    f64 = lambda a: a.astype(np.float64)
+    ref = OC.log_posterior(m64, f64(x), f64(y), f64(v), f64(z), prior=(mu, s2))
+    std = OC.log_posterior(m64, f64(x), f64(y), f64(v), f64(z))
+    eng = _engine(m)
+    eng.set_prior(torch.from_numpy(seg.astype(np.int32)).cuda(), torch.from_numpy(tab).cuda())
+    lp32 = eng.logpost(x.ravel(), y.ravel(), v, z).cpu().numpy()
+    eng.set_precision(mode)
+    lp = eng.logpost(x.ravel(), y.ravel(), v, z).cpu().numpy()
+    tol = (2e-4 if mode == "bf16x3" else 2e-6) * np.abs(ref) + (2e-2 if mode == "bf16x3" else 5e-4)
+    assert np.all(np.abs(lp - ref) <= tol), np.abs(lp - ref).max()
+    assert np.abs(ref - std).max() > 0.1 and np.abs(lp - lp32).max() > 0.0       # the prior matters; the split kernels ran
+    xs = np.linspace(0, 3, 20)
+    outs = {}
+    for cache in (False, True):
+        eng.set_outcome_cache(cache)
+        eng.outcome_cache_stats(reset=True)
+        outs[cache] = eng.mh_sample(x, y, v, 20, 25, 0.5, 9, want_draws=True, effect=_lib.EFFECT_ADRF, x_values=xs)
+        outs[cache]["stats"] = eng.outcome_cache_stats()
+    assert outs[True]["stats"][1] == n * 25                                      # chain-iterations: the event form ran
+    for kk in ("draws", "acc_count", "state"):
+        assert np.array_equal(outs[True][kk].cpu().numpy(), outs[False][kk].cpu().numpy()), kk
+    eng.set_precision("fp32")
+    eng.set_outcome_cache(False)
+    o32 = eng.mh_sample(x, y, v, 20, 25, 0.5, 9, want_draws=True, effect=_lib.EFFECT_ADRF, x_values=xs)
+    same = np.all(np.abs(o32["draws"].cpu().numpy()[-1] - outs[False]["draws"].cpu().numpy()[-1]) <= 1e-4, axis=1).mean()
+    assert same >= (0.80 if mode == "bf16x3" else 0.97), same
+    eng.set_prior(None, None)
+    eng.close()
