@@ -565,6 +565,7 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_bx3_kernel(CausalBxKArgs
   volatile __attribute__((address_space(3))) int *prog =
       (volatile __attribute__((address_space(3))) int *)((__attribute__((address_space(3))) unsigned char *)bx_lds + m.total_bytes);
   if (lane == 0) prog[wave_u] = 0;
+  const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();
   int tiles_done = 0;
   [[maybe_unused]] int ev_cnt = 0;          // EFFECT == 3 (event form of the retained phase, causal_event_kernels.h)
   for (long long tile = slot; tile < n_tiles; tile += n_slots) {
@@ -680,6 +681,12 @@ __global__ __launch_bounds__(64 * WAVES) void causal_mh_bx3_kernel(CausalBxKArgs
   if (lane == 0) prog[wave_u] = 0x7fffffff;
   if constexpr (EFFECT == 3) {
     if (lane == 0) a.slot_cnt[slot] = ev_cnt;
+  }
+  if (a.clk != nullptr && lane == 0) {   // [n_slots][4]: shader cycles, 100 MHz ticks, start tick, XCC id (as causal_mh_kernel)
+    a.clk[4 * slot + 0] = __builtin_readcyclecounter() - clk_c0;
+    a.clk[4 * slot + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    a.clk[4 * slot + 2] = clk_r0;
+    a.clk[4 * slot + 3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
   }
 }
 

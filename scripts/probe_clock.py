@@ -5,6 +5,7 @@ from oracle import causal as OC
 N, iters = int(float(sys.argv[1])) if len(sys.argv) > 1 else int(1e6), 100
 m = OC.init_model(0, [1,1,1,7], 200)
 eng = CausalEngine(200, [1,1,1,7]); eng.set_model(g=m["g"], f=m["f"], h=m["h"], e=m["e"])
+if len(sys.argv) > 2: eng.set_precision(sys.argv[2])      # "bf16x3" | "f16x3": the split-precision kernel's in-kernel clock
 g = torch.Generator(device="cuda").manual_seed(0)
 v = torch.randn(N, 200, device="cuda", generator=g); x = torch.rand(N, device="cuda", generator=g); y = torch.randn(N, device="cuda", generator=g)
 state = torch.empty(N, 10, device="cuda"); logp = torch.empty(N, device="cuda")
