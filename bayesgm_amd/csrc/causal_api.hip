@@ -647,7 +647,8 @@ extern "C" int bgm_timing_read(bgm_handle *h, int kind, int64_t *n_launches, dou
 extern "C" int bgm_causal_describe(bgm_handle *h, int32_t batch, char *out, int32_t cap) {
   if (!h || !h->configured || !out || cap < 1) { bgm_set_error("bgm_causal_describe: bad argument"); return BGM_E_INVALID; }
   std::string s = "sampler=";
-  s += gx_wanted(h) ? "gx_causal_mh_kernel (general-width engine: 32-row LDS activation tiles, padded weights streamed from L2)" : bnf_det_wanted(h) ? "bnf_mh_kernel<DET> / bnf_effects_kernel<DET> (general shapes: persistent workgroups, weights streamed from L2)"
+  s += gx_wanted(h) ? (gx_row_tile_per_wave(h) ? "gx_causal_mh_kernel -> gw_causal_mh_kernel (general-width engine, one 16-row tile per wave: no barriers inside a transition, padded weights streamed from L2)"
+                                                : "gx_causal_mh_kernel (general-width engine: 32-row LDS activation tiles, padded weights streamed from L2)") : bnf_det_wanted(h) ? "bnf_mh_kernel<DET> / bnf_effects_kernel<DET> (general shapes: persistent workgroups, weights streamed from L2)"
                          : "causal_mh_kernel (weights LDS-resident, one launch per rank shard)";
   if (h->fit_active) {
     s += "; fit=";
@@ -670,7 +671,8 @@ extern "C" int bgm_causal_mh_info(bgm_handle *h, int64_t n, bgm_mh_info *info) {
         pmacs += (double)((nn.dims[l] + 31) / 32 * 32) * ((nn.dims[l + 1] + 31) / 32 * 32);
       }
     }
-    info->rows_per_wave = 8; info->waves_per_block = 4; info->grid_blocks = gx_slots(h, n);
+    info->rows_per_wave = 8; info->waves_per_block = 4; info->grid_blocks = gx_row_tile_per_wave(h) ? gx_slots(h, n) / 4 : gx_slots(h, n);
+    if (gx_row_tile_per_wave(h)) info->rows_per_wave = 16;
     info->mfma_per_transition_per_wave = (int)(pmacs * 32.0 / 1024.0 / 4.0);   // issued 16x16x4 MFMAs per 32-row tile and transition, per wave
     info->lds_bytes = 0;
     info->flop_per_row_transition = 2.0 * macs;

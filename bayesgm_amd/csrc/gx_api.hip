@@ -16,6 +16,7 @@
 
 #include "bgm_host.h"
 #include "gx_fit_kernels.h"
+#include "gw_kernels.h"
 #include "gx_host.h"
 #include "bnf_det_host.h"
 
@@ -28,6 +29,9 @@ struct GxState {
   std::vector<int> fwd_map[4], bwd_map[4];     // canonical parameter of net (G, F, H, E) -> position in pack / packT (-1: none)
   int ld_enc = 0, kc = 0;
   int lds_bytes = 0, lds_enc = 0, lds_fit = 0, occ = 1;
+  // row-tile-per-wave sampling kernels (gw_kernels.h): used when a wave's LDS region stays small enough for >= 8 waves per CU
+  bool gw = false;
+  int gw_db = 1, gw_lds = 0, gw_occ = 1;
   bool fit = false;
   GxFitNet wg{}, wf{}, wh{};
 };
@@ -99,6 +103,22 @@ int gx_session(bgm_handle *h, GxState *&st, hipStream_t stream, bool need_ghf = 
         if (4 * gx_causal_lds_floats(m.ld, m.q, m.ncg, m.ldf, want) <= 160 * 1024) m.db = want;
       }
       s->lds_bytes = 4 * gx_causal_lds_floats(m.ld, m.q, m.ncg, m.ldf, m.db);
+    {   // gw: log posterior / MH / effects with one row tile per wave.  Doses per pass of its effect routine: as many (<= 4) as keep a wave's
+        // region within 20 KB (8 waves per CU); the mapping itself needs the one-dose region within 24 KB (hidden layers up to ~128 wide)
+      static const bool no_gw = std::getenv("BGM_NO_GW") != nullptr;      // dev A/B
+      int wf = 32;
+      for (int l = 0; l <= m.f.L; ++l) wf = std::max(wf, m.f.pad[l]);
+      const int ldf = gx_ld(wf);
+      s->gw = !no_gw && 4 * gw_wave_floats(m.ld, m.q, ldf, 1) <= 24 * 1024;
+      s->gw_db = 1;
+      for (int cand : {4, 3, 2})
+        if (4 * gw_wave_floats(m.ld, m.q, ldf, cand) <= 20 * 1024) { s->gw_db = cand; break; }
+      if (const char *f_ = std::getenv("BGM_GW_DB")) s->gw_db = std::max(1, std::min(GX_MAXDB, std::atoi(f_)));
+      s->gw_lds = 4 * GW_WAVES * gw_wave_floats(m.ld, m.q, ldf, s->gw_db);
+      if (s->gw_lds > 160 * 1024) s->gw = false;
+      s->gw_occ = std::max(1, std::min(4, (160 * 1024) / std::max(s->gw_lds, 1)));
+      if (const char *o_ = std::getenv("BGM_GW_OCC")) s->gw_occ = std::max(1, std::min(std::atoi(o_), (160 * 1024) / std::max(s->gw_lds, 1)));
+    }
     s->lds_fit = 4 * gx_fit_lds_floats(m.ld, m.q);
     int wenc = 32;
     for (int l = 1; l <= m.e.L; ++l) wenc = std::max(wenc, m.e.pad[l]);
@@ -143,6 +163,13 @@ int grid_for(const bgm_handle *h, const GxState *s, int64_t n) {
   return (int)std::max<int64_t>(1, std::min<int64_t>(tiles, (int64_t)h->n_cus * s->occ));
 }
 
+// the model as the row-tile-per-wave kernels read it (their own dose batch) and their launch grid (workgroups of GW_WAVES row tiles)
+GxCausalModel gw_model(const GxState *s) { GxCausalModel w = s->m; w.db = s->gw_db; return w; }
+int gw_grid(const bgm_handle *h, const GxState *s, int64_t n) {
+  const int64_t wgs = ((n + GW_ROWS - 1) / GW_ROWS + GW_WAVES - 1) / GW_WAVES;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(wgs, (int64_t)h->n_cus * s->gw_occ));
+}
+
 bool default_units(const int32_t *u, int n, bool fh) {
   if (fh) return n == 3 && u[0] == 64 && u[1] == 32 && u[2] == 8;
   for (int i = 0; i < n; ++i) if (u[i] != 64) return false;
@@ -165,6 +192,12 @@ bool gx_enc_wanted(const bgm_handle *h) {
   return !default_units(c.e_units, c.n_hidden_e, false) || h->p > 208 || h->q > 32;
 }
 
+bool gx_row_tile_per_wave(bgm_handle *h) {
+  GxState *s = gst(h);
+  if (!s) { gx_slots(h, 16); s = gst(h); }
+  return s && s->gw;
+}
+
 int gx_slots(bgm_handle *h, int64_t n) {
   GxState *s = gst(h);
   if (!s) {      // plan without touching the device contents: the slot count only needs the LDS budget
@@ -172,6 +205,7 @@ int gx_slots(bgm_handle *h, int64_t n) {
     if (gx_session(h, s, st, false) != BGM_OK) return h->n_cus;
     h->gx_valid = false;
   }
+  if (s->gw) return gw_grid(h, s, n) * GW_WAVES;      // one slot per wave
   return grid_for(h, s, n);
 }
 
@@ -179,6 +213,13 @@ int gx_logpost(bgm_handle *h, const float *x, const float *y, const float *v, co
   GxState *s;
   int rc = gx_session(h, s, stream);
   if (rc) return rc;
+  if (s->gw) {
+    rc = set_lds(gw_causal_logpost_kernel, s->gw_lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gw_causal_logpost_kernel, dim3(gw_grid(h, s, n)), dim3(GW_THREADS), s->gw_lds, stream, gw_model(s), x, y, v, z, (long long)n, out);
+    BGM_HIP_CHECK(hipGetLastError());
+    return BGM_OK;
+  }
   rc = set_lds(gx_causal_logpost_kernel, s->lds_bytes);
   if (rc) return rc;
   hipLaunchKernelGGL(gx_causal_logpost_kernel, dim3(grid_for(h, s, n)), dim3(GX_THREADS), s->lds_bytes, stream, s->m, x, y, v, z, (long long)n, out);
@@ -198,10 +239,11 @@ int gx_mh_run(bgm_handle *h, const bgm_mh_args *a, hipStream_t stream) {
   k.e.n_keep = a->n_keep; k.e.sample_y = a->sample_y; k.e.n_doses = a->n_doses; k.e.x_values = a->x_values_dev; k.e.adrf_slot = nullptr;
   k.e.ite = a->ite_dev; k.e.k0 = k.k0; k.e.k1 = k.k1;
   k.adrf_partial = a->adrf_partial_dev;
-  const int grid = grid_for(h, s, a->n);
+  if (s->gw) k.m = gw_model(s);
+  const int grid = s->gw ? gw_grid(h, s, a->n) : grid_for(h, s, a->n);
   const int it_end = a->it_begin + a->n_iters;
   if (a->effect != BGM_EFFECT_NONE && it_end > a->burn_in) {      // outcome-net cache of the retained iterations (bgm_causal_set_outcome_cache)
-    const size_t need = (size_t)grid * (size_t)(a->effect == BGM_EFFECT_ITE ? 2 : a->n_doses) * GX_ROWS * 2;
+    const size_t need = (size_t)grid * (size_t)(a->effect == BGM_EFFECT_ITE ? 2 : a->n_doses) * (s->gw ? GW_WAVES * GW_ROWS : GX_ROWS) * 2;
     if (h->eff_cache_cap < need) {
       if (h->eff_cache) BGM_HIP_CHECK(hipFree(h->eff_cache));
       BGM_HIP_CHECK(hipMalloc(&h->eff_cache, need * sizeof(float)));
@@ -216,16 +258,21 @@ int gx_mh_run(bgm_handle *h, const bgm_mh_args *a, hipStream_t stream) {
     k.e.stats = h->eff_stats_dev;
     h->eff_total += (unsigned long long)((a->n + 15) / 16) * (unsigned long long)(it_end - std::max(a->burn_in, a->it_begin));
   }
+  const int lds_mh = s->gw ? s->gw_lds : s->lds_bytes, threads_mh = s->gw ? GW_THREADS : GX_THREADS;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (h->timing) { BGM_HIP_CHECK(hipEventCreate(&e0)); BGM_HIP_CHECK(hipEventCreate(&e1)); BGM_HIP_CHECK(hipEventRecord(e0, stream)); }
   auto launch = [&](auto kern) {
-    int r = set_lds(kern, s->lds_bytes);
+    int r = set_lds(kern, lds_mh);
     if (r) return r;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(GX_THREADS), s->lds_bytes, stream, k);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads_mh), lds_mh, stream, k);
     BGM_HIP_CHECK(hipGetLastError());
     return (int)BGM_OK;
   };
-  if (a->effect == BGM_EFFECT_ADRF) rc = launch(gx_causal_mh_kernel<1>);
+  if (s->gw) {
+    if (a->effect == BGM_EFFECT_ADRF) rc = launch(gw_causal_mh_kernel<1>);
+    else if (a->effect == BGM_EFFECT_ITE) rc = launch(gw_causal_mh_kernel<2>);
+    else rc = launch(gw_causal_mh_kernel<0>);
+  } else if (a->effect == BGM_EFFECT_ADRF) rc = launch(gx_causal_mh_kernel<1>);
   else if (a->effect == BGM_EFFECT_ITE) rc = launch(gx_causal_mh_kernel<2>);
   else rc = launch(gx_causal_mh_kernel<0>);
   if (rc) return rc;
@@ -271,8 +318,23 @@ int gx_effects(bgm_handle *h, const float *draws, int64_t n, int64_t row_base, i
   k.e.n_keep = n_keep; k.e.sample_y = sample_y; k.e.n_doses = n_doses; k.e.x_values = x_values; k.e.ite = ite;
   k.e.k0 = (unsigned)(seed & 0xFFFFFFFFull); k.e.k1 = (unsigned)(seed >> 32);
   k.adrf_partial = adrf_partial;
-  const int grid = grid_for(h, s, n);
   const bool binary = h->cfg.binary_treatment != 0;
+  if (s->gw) {
+    k.m = gw_model(s);
+    const int gg = gw_grid(h, s, n);
+    if (binary) {
+      rc = set_lds(gw_causal_effects_kernel<2>, s->gw_lds);
+      if (rc) return rc;
+      hipLaunchKernelGGL(gw_causal_effects_kernel<2>, dim3(gg), dim3(GW_THREADS), s->gw_lds, stream, k);
+    } else {
+      rc = set_lds(gw_causal_effects_kernel<1>, s->gw_lds);
+      if (rc) return rc;
+      hipLaunchKernelGGL(gw_causal_effects_kernel<1>, dim3(gg), dim3(GW_THREADS), s->gw_lds, stream, k);
+    }
+    BGM_HIP_CHECK(hipGetLastError());
+    return BGM_OK;
+  }
+  const int grid = grid_for(h, s, n);
   if (binary) {
     rc = set_lds(gx_causal_effects_kernel<2>, s->lds_bytes);
     if (rc) return rc;

@@ -73,7 +73,7 @@ struct GxGLastEpi {
   const float *v; long long row0, n; int p; float *ssep; float *sraw;
   float vc[4][2], vn[4][2];
   __device__ __forceinline__ void pre(int rt, int n0) {
-    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int lane = gx_lane(), j = lane & 15, g = lane >> 4;
     const int c0 = n0 + 2 * j;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -88,7 +88,7 @@ struct GxGLastEpi {
     for (int r = 0; r < 4; ++r) { vc[r][0] = vn[r][0]; vc[r][1] = vn[r][1]; }
   }
   __device__ __forceinline__ void operator()(int rt, int n0, const f32x4 &a0, const f32x4 &a1) const {
-    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int lane = gx_lane(), j = lane & 15, g = lane >> 4;
     const int c0 = n0 + 2 * j;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {

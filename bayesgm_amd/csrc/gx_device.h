@@ -52,10 +52,14 @@ __host__ __device__ inline int gx_ld(int width) { return ((width + 59) / 64) * 6
 // that releases the layer's input (weights and biases do not depend on it): the L2 round trip of every layer's first block otherwise
 // sits in front of its first MFMA (measured: ~1.5-3 k cycles per layer of a 64-wide net, more than the layer's own 1 k of matrix work).
 struct GxPre { f32x2 b0, b1, b2, b3, bb; int valid; };
-__device__ __forceinline__ GxPre gx_prefetch(const float *__restrict__ W, int ldw, int N, const float *bias, int nrt = 2) {
+// the lane index behind a compiler-opaque copy: everything derived from it (fragment offsets of every layer) is then NOT invariant of the
+// surrounding iteration loop -- hoisted out of it, those offsets of all layers stay live across a whole transition and spill
+__device__ __forceinline__ int gx_lane() { int l = threadIdx.x & 63; asm volatile("" : "+v"(l)); return l; }
+// (u0 >= 0: the calling wave's first unit instead of unit `wave` -- the row-tile-per-wave kernels of gw_kernels.h walk all units themselves)
+__device__ __forceinline__ GxPre gx_prefetch(const float *__restrict__ W, int ldw, int N, const float *bias, int nrt = 2, int u0 = -1) {
   GxPre p;
   p.valid = 0;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  const int lane = gx_lane(), wave = u0 >= 0 ? u0 : (int)(threadIdx.x >> 6), j = lane & 15, g = lane >> 4;
   if (wave >= nrt * (N >> 5)) return p;
   const int n0 = (wave / nrt) << 5;
   const float *wk = W + (size_t)(4 * g) * ldw + n0 + 2 * j;
@@ -77,12 +81,14 @@ template <class E> __device__ __forceinline__ void gx_epi_rotate(E &, long) {}
 // nrt: 16-row tiles of A (2 = the workgroup's 32 rows; the effect pass stacks several doses' rows: 2 x doses).  bias != NULL: the
 // accumulators start from the unit's bias pair (requested with its first weight block; the functor then adds none).  pre: the first
 // unit's first block as requested by gx_prefetch ahead of the barrier in front of this call.
+// u0 / ustride: the calling wave's first unit and its stride over the units (default: unit `wave`, stride GX_WAVES -- the workgroup's
+// waves deal the units; 0 / 1: one wave walks them all on ITS rows A, gw_kernels.h).
 template <bool A_GLOBAL = false, class Epi>
 __device__ __forceinline__ void gx_dense_ld(const float *__restrict__ W, int ldw, int K, int N, const float *A, int lda, Epi epi, int nrt = 2,
-                                            const float *bias = nullptr, const GxPre *pre = nullptr) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+                                            const float *bias = nullptr, const GxPre *pre = nullptr, int u0 = -1, int ustride = GX_WAVES) {
+  const int lane = gx_lane(), wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
   const int units = nrt * (N >> 5);
-  int u = wave;
+  int u = u0 >= 0 ? u0 : wave;
   if (u >= units) return;
   const size_t wstep = (size_t)16 * ldw;
   // software pipeline over K blocks AND over the wave's units: the operands of K block k0 + 16 are requested before the MFMAs of
@@ -120,7 +126,7 @@ __device__ __forceinline__ void gx_dense_ld(const float *__restrict__ W, int ldw
       a = an; b0 = c0; b1 = c1; b2 = c2; b3 = c3;
     }
     // last block of this unit; block 0 of the next one is requested first
-    const int un = u + GX_WAVES;
+    const int un = u + ustride;
     const bool more = un < units;
     const int rtn = un % nrt, n0n = (un / nrt) << 5;
     f32x4 an = a;
@@ -152,8 +158,8 @@ __device__ __forceinline__ void gx_dense_ld(const float *__restrict__ W, int ldw
 // W [K][N] with row stride N
 template <bool A_GLOBAL = false, class Epi>
 __device__ __forceinline__ void gx_dense(const float *__restrict__ W, int K, int N, const float *A, int lda, Epi epi, int nrt = 2,
-                                         const float *bias = nullptr, const GxPre *pre = nullptr) {
-  gx_dense_ld<A_GLOBAL>(W, N, K, N, A, lda, epi, nrt, bias, pre);
+                                         const float *bias = nullptr, const GxPre *pre = nullptr, int u0 = -1, int ustride = GX_WAVES) {
+  gx_dense_ld<A_GLOBAL>(W, N, K, N, A, lda, epi, nrt, bias, pre, u0, ustride);
 }
 
 // Epilogue helpers -------------------------------------------------------------------------------------------------------------
@@ -163,7 +169,7 @@ template <bool LEAKY>
 struct GxStore {
   float *Y; int ldy; const float *bias;
   __device__ __forceinline__ void operator()(int rt, int n0, const f32x4 &a0, const f32x4 &a1) const {
-    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int lane = gx_lane(), j = lane & 15, g = lane >> 4;
     const f32x2 bb = bias ? *reinterpret_cast<const f32x2 *>(bias + n0 + 2 * j) : f32x2{0.0f, 0.0f};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {

@@ -10,7 +10,8 @@ struct bgm_handle;
 
 bool gx_wanted(const bgm_handle *h);        // g / f / h are not g [64] x k, f / h [64, 32, 8]  (or BGM_FORCE_GX=1)
 bool gx_enc_wanted(const bgm_handle *h);    // e is not [64] x k with v_dim <= 208 (or BGM_FORCE_GX=1)
-int gx_slots(bgm_handle *h, int64_t n);     // leading dimension of adrf_partial for n rows: one slot per workgroup
+int gx_slots(bgm_handle *h, int64_t n);     // leading dimension of adrf_partial for n rows: one slot per workgroup (per wave: row-tile-per-wave kernels)
+bool gx_row_tile_per_wave(bgm_handle *h);   // the sampling calls of this model run on gw_kernels.h (hidden layers up to ~128 wide)
 int gx_logpost(bgm_handle *h, const float *x, const float *y, const float *v, const float *z, int64_t n, float *out, hipStream_t stream);
 int gx_mh_run(bgm_handle *h, const bgm_mh_args *a, hipStream_t stream);
 int gx_evaluate(bgm_handle *h, const float *x, const float *y, const float *v, const float *z, int64_t n, const float *x_values,
