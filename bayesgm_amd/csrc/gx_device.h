@@ -90,21 +90,22 @@ __device__ __forceinline__ void gx_dense_ld(const float *__restrict__ W, int ldw
   const int units = nrt * (N >> 5);
   int u = u0 >= 0 ? u0 : wave;
   if (u >= units) return;
-  const size_t wstep = (size_t)16 * ldw;
+  // weights are addressed as (uniform base W) + (32-bit byte offset per lane): four row offsets, each advanced by one addition per K
+  // block (64-bit per-lane pointers cost 8 v_lshl_add_u64 + 6 moves per block; the packs stay below 2^30 floats, gx_api.hip)
+  const unsigned wstep = 64u * (unsigned)ldw;                                         // 16 rows of W in bytes
+  auto wld = [&](unsigned boff) { return *reinterpret_cast<const f32x2 *>(reinterpret_cast<const char *>(W) + boff); };
   // software pipeline over K blocks AND over the wave's units: the operands of K block k0 + 16 are requested before the MFMAs of
   // block k0 issue, and block 0 of the wave's NEXT unit before the MFMAs of the current unit's last block -- a unit of a 64-wide
   // layer is 4 blocks (1024 matrix cycles), and starting each one on a cold L2 round trip cost more than the unit itself
   int rt = u % nrt, n0 = (u / nrt) << 5;
   const float *ap = A + (size_t)(16 * rt + j) * lda + 4 * g;
-  const float *wk = W + (size_t)(4 * g) * ldw + n0 + 2 * j;
+  const unsigned ldb = 4u * (unsigned)ldw;
+  unsigned o0 = 4u * ((unsigned)(4 * g) * (unsigned)ldw + (unsigned)(n0 + 2 * j)), o1 = o0 + ldb, o2 = o1 + ldb, o3 = o2 + ldb;
   f32x4 a = *reinterpret_cast<const f32x4 *>(ap);
   f32x2 b0, b1, b2, b3, bb = {0.0f, 0.0f};
   if (pre != nullptr && pre->valid) { b0 = pre->b0; b1 = pre->b1; b2 = pre->b2; b3 = pre->b3; bb = pre->bb; }
   else {
-    b0 = *reinterpret_cast<const f32x2 *>(wk);
-    b1 = *reinterpret_cast<const f32x2 *>(wk + ldw);
-    b2 = *reinterpret_cast<const f32x2 *>(wk + 2 * (size_t)ldw);
-    b3 = *reinterpret_cast<const f32x2 *>(wk + 3 * (size_t)ldw);
+    b0 = wld(o0); b1 = wld(o1); b2 = wld(o2); b3 = wld(o3);
     if (bias) bb = *reinterpret_cast<const f32x2 *>(bias + n0 + 2 * j);
   }
   gx_epi_pre(epi, rt, n0, 0);
@@ -112,12 +113,9 @@ __device__ __forceinline__ void gx_dense_ld(const float *__restrict__ W, int ldw
   for (;;) {
     f32x4 acc0 = {bb[0], bb[0], bb[0], bb[0]}, acc1 = {bb[1], bb[1], bb[1], bb[1]};
     for (int k0 = 16; k0 < K; k0 += 16) {
-      wk += wstep;
+      o0 += wstep; o1 += wstep; o2 += wstep; o3 += wstep;
       const f32x4 an = *reinterpret_cast<const f32x4 *>(ap + k0);
-      const f32x2 c0 = *reinterpret_cast<const f32x2 *>(wk);
-      const f32x2 c1 = *reinterpret_cast<const f32x2 *>(wk + ldw);
-      const f32x2 c2 = *reinterpret_cast<const f32x2 *>(wk + 2 * (size_t)ldw);
-      const f32x2 c3 = *reinterpret_cast<const f32x2 *>(wk + 3 * (size_t)ldw);
+      const f32x2 c0 = wld(o0), c1 = wld(o1), c2 = wld(o2), c3 = wld(o3);
       __builtin_amdgcn_sched_barrier(0);      // keep the requests above the MFMAs of the previous block (hipcc sinks loads to their first use)
       acc0 = BGM_MFMA(a[0], b0[0], acc0); acc1 = BGM_MFMA(a[0], b0[1], acc1);
       acc0 = BGM_MFMA(a[1], b1[0], acc0); acc1 = BGM_MFMA(a[1], b1[1], acc1);
@@ -133,12 +131,9 @@ __device__ __forceinline__ void gx_dense_ld(const float *__restrict__ W, int ldw
     f32x2 c0 = b0, c1 = b1, c2 = b2, c3 = b3, bn = bb;
     if (more) {
       ap = A + (size_t)(16 * rtn + j) * lda + 4 * g;
-      wk = W + (size_t)(4 * g) * ldw + n0n + 2 * j;
+      o0 = 4u * ((unsigned)(4 * g) * (unsigned)ldw + (unsigned)(n0n + 2 * j)); o1 = o0 + ldb; o2 = o1 + ldb; o3 = o2 + ldb;
       an = *reinterpret_cast<const f32x4 *>(ap);
-      c0 = *reinterpret_cast<const f32x2 *>(wk);
-      c1 = *reinterpret_cast<const f32x2 *>(wk + ldw);
-      c2 = *reinterpret_cast<const f32x2 *>(wk + 2 * (size_t)ldw);
-      c3 = *reinterpret_cast<const f32x2 *>(wk + 3 * (size_t)ldw);
+      c0 = wld(o0); c1 = wld(o1); c2 = wld(o2); c3 = wld(o3);
       if (bias) bn = *reinterpret_cast<const f32x2 *>(bias + n0n + 2 * j);
       gx_epi_pre(epi, rtn, n0n, 0);
     }
