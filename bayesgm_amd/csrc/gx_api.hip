@@ -25,6 +25,7 @@ namespace {
 struct GxState {
   GxCausalModel m{};
   float *pack = nullptr, *packT = nullptr;
+  float *packF = nullptr;      // fragment pack of the row-tile-per-wave kernels (gx_device.h, FRAG): pack with every weight matrix in fragment order
   size_t pack_floats = 0, packT_floats = 0;
   std::vector<int> fwd_map[4], bwd_map[4];     // canonical parameter of net (G, F, H, E) -> position in pack / packT (-1: none)
   int ld_enc = 0, kc = 0;
@@ -103,16 +104,13 @@ int gx_session(bgm_handle *h, GxState *&st, hipStream_t stream, bool need_ghf = 
         if (4 * gx_causal_lds_floats(m.ld, m.q, m.ncg, m.ldf, want) <= 160 * 1024) m.db = want;
       }
       s->lds_bytes = 4 * gx_causal_lds_floats(m.ld, m.q, m.ncg, m.ldf, m.db);
-    {   // gw: log posterior / MH / effects with one row tile per wave.  Doses per pass of its effect routine: as many (<= 4) as keep a wave's
-        // region within 20 KB (8 waves per CU); the mapping itself needs the one-dose region within 24 KB (hidden layers up to ~128 wide)
+    {   // gw: log posterior / MH / effects with one row tile per wave; the mapping needs a wave's region within 24 KB (hidden layers up to ~128 wide)
       static const bool no_gw = std::getenv("BGM_NO_GW") != nullptr;      // dev A/B
       int wf = 32;
       for (int l = 0; l <= m.f.L; ++l) wf = std::max(wf, m.f.pad[l]);
       const int ldf = gx_ld(wf);
       s->gw = !no_gw && 4 * gw_wave_floats(m.ld, m.q, ldf, 1) <= 24 * 1024;
-      s->gw_db = 1;
-      for (int cand : {4, 3, 2})
-        if (4 * gw_wave_floats(m.ld, m.q, ldf, cand) <= 20 * 1024) { s->gw_db = cand; break; }
+      s->gw_db = 1;      // doses per pass of the effect routine: one (measured: 2 doses at 8 waves per CU cost 10 % against 1 at 12)
       if (const char *f_ = std::getenv("BGM_GW_DB")) s->gw_db = std::max(1, std::min(GX_MAXDB, std::atoi(f_)));
       s->gw_lds = 4 * GW_WAVES * gw_wave_floats(m.ld, m.q, ldf, s->gw_db);
       if (s->gw_lds > 160 * 1024) s->gw = false;
@@ -131,8 +129,10 @@ int gx_session(bgm_handle *h, GxState *&st, hipStream_t stream, bool need_ghf = 
     s->occ = std::max(1, std::min(4, (160 * 1024) / std::max(s->lds_bytes, 1)));      // up to 16 waves per CU hide each other's L2 latencies
     if (const char *o_ = std::getenv("BGM_GX_OCC")) s->occ = std::max(1, std::min(std::atoi(o_), (160 * 1024) / std::max(s->lds_bytes, 1)));      // dev: workgroups per CU
     if (hipMalloc((void **)&s->pack, sizeof(float) * std::max<size_t>(off, 1)) != hipSuccess ||
-        hipMalloc((void **)&s->packT, sizeof(float) * std::max<size_t>(offT, 1)) != hipSuccess) {
+        hipMalloc((void **)&s->packT, sizeof(float) * std::max<size_t>(offT, 1)) != hipSuccess ||
+        hipMalloc((void **)&s->packF, sizeof(float) * std::max<size_t>(off, 1)) != hipSuccess) {
       if (s->pack) hipFree(s->pack);
+      if (s->packT) hipFree(s->packT);
       delete s; bgm_set_error("general-width engine: device allocation failed"); return BGM_E_HIP;
     }
     m.pack = s->pack;
@@ -153,6 +153,24 @@ int gx_session(bgm_handle *h, GxState *&st, hipStream_t stream, bool need_ghf = 
     BGM_HIP_CHECK(hipStreamSynchronize(stream));
     BGM_HIP_CHECK(hipMemcpy(st->pack, pk.data(), sizeof(float) * pk.size(), hipMemcpyHostToDevice));
     BGM_HIP_CHECK(hipMemcpy(st->packT, pt.data(), sizeof(float) * pt.size(), hipMemcpyHostToDevice));
+    if (st->gw) {      // fragment pack: biases where the padded pack has them, W_l [Kp][Np] re-ordered per (column group, K block, lane)
+      std::vector<float> pf(pk);
+      const GxNet *gn[3] = {&st->m.g, &st->m.f, &st->m.h};
+      for (const GxNet *net : gn)
+        for (int l = 0; l < net->L; ++l) {
+          const int Kp = net->pad[l], Np = net->pad[l + 1], KB = Kp / 16;
+          const float *src = pk.data() + net->w[l];
+          float *dst = pf.data() + net->w[l];
+          for (int cg = 0; cg < Np / 32; ++cg)
+            for (int kb = 0; kb < KB; ++kb)
+              for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 8; ++i) {
+                  const int j = lane & 15, g = lane >> 4, sidx = i >> 1, c = i & 1;
+                  dst[((size_t)(cg * KB + kb) * 64 + lane) * 8 + i] = src[(size_t)(16 * kb + 4 * g + sidx) * Np + 32 * cg + 2 * j + c];
+                }
+        }
+      BGM_HIP_CHECK(hipMemcpy(st->packF, pf.data(), sizeof(float) * pf.size(), hipMemcpyHostToDevice));
+    }
     h->gx_valid = true;
   }
   return BGM_OK;
@@ -164,11 +182,14 @@ int grid_for(const bgm_handle *h, const GxState *s, int64_t n) {
 }
 
 // the model as the row-tile-per-wave kernels read it (their own dose batch) and their launch grid (workgroups of GW_WAVES row tiles)
-GxCausalModel gw_model(const GxState *s) { GxCausalModel w = s->m; w.db = s->gw_db; return w; }
+GxCausalModel gw_model(const GxState *s) { GxCausalModel w = s->m; w.db = s->gw_db; w.pack = s->packF; return w; }
 int gw_grid(const bgm_handle *h, const GxState *s, int64_t n) {
   const int64_t wgs = ((n + GW_ROWS - 1) / GW_ROWS + GW_WAVES - 1) / GW_WAVES;
   return (int)std::max<int64_t>(1, std::min<int64_t>(wgs, (int64_t)h->n_cus * s->gw_occ));
 }
+
+// (inside an open gx fit session the padded pack is kept current on the device by the Adam kernel; the fragment pack is host-built)
+bool use_gw(const GxState *s) { return s->gw && !s->fit; }
 
 bool default_units(const int32_t *u, int n, bool fh) {
   if (fh) return n == 3 && u[0] == 64 && u[1] == 32 && u[2] == 8;
@@ -195,7 +216,7 @@ bool gx_enc_wanted(const bgm_handle *h) {
 bool gx_row_tile_per_wave(bgm_handle *h) {
   GxState *s = gst(h);
   if (!s) { gx_slots(h, 16); s = gst(h); }
-  return s && s->gw;
+  return s && use_gw(s);
 }
 
 int gx_slots(bgm_handle *h, int64_t n) {
@@ -205,7 +226,7 @@ int gx_slots(bgm_handle *h, int64_t n) {
     if (gx_session(h, s, st, false) != BGM_OK) return h->n_cus;
     h->gx_valid = false;
   }
-  if (s->gw) return gw_grid(h, s, n) * GW_WAVES;      // one slot per wave
+  if (use_gw(s)) return gw_grid(h, s, n) * GW_WAVES;      // one slot per wave
   return grid_for(h, s, n);
 }
 
@@ -213,7 +234,7 @@ int gx_logpost(bgm_handle *h, const float *x, const float *y, const float *v, co
   GxState *s;
   int rc = gx_session(h, s, stream);
   if (rc) return rc;
-  if (s->gw) {
+  if (use_gw(s)) {
     rc = set_lds(gw_causal_logpost_kernel, s->gw_lds);
     if (rc) return rc;
     hipLaunchKernelGGL(gw_causal_logpost_kernel, dim3(gw_grid(h, s, n)), dim3(GW_THREADS), s->gw_lds, stream, gw_model(s), x, y, v, z, (long long)n, out);
@@ -239,11 +260,12 @@ int gx_mh_run(bgm_handle *h, const bgm_mh_args *a, hipStream_t stream) {
   k.e.n_keep = a->n_keep; k.e.sample_y = a->sample_y; k.e.n_doses = a->n_doses; k.e.x_values = a->x_values_dev; k.e.adrf_slot = nullptr;
   k.e.ite = a->ite_dev; k.e.k0 = k.k0; k.e.k1 = k.k1;
   k.adrf_partial = a->adrf_partial_dev;
-  if (s->gw) k.m = gw_model(s);
-  const int grid = s->gw ? gw_grid(h, s, a->n) : grid_for(h, s, a->n);
+  const bool gw = use_gw(s);
+  if (gw) k.m = gw_model(s);
+  const int grid = gw ? gw_grid(h, s, a->n) : grid_for(h, s, a->n);
   const int it_end = a->it_begin + a->n_iters;
   if (a->effect != BGM_EFFECT_NONE && it_end > a->burn_in) {      // outcome-net cache of the retained iterations (bgm_causal_set_outcome_cache)
-    const size_t need = (size_t)grid * (size_t)(a->effect == BGM_EFFECT_ITE ? 2 : a->n_doses) * (s->gw ? GW_WAVES * GW_ROWS : GX_ROWS) * 2;
+    const size_t need = (size_t)grid * (size_t)(a->effect == BGM_EFFECT_ITE ? 2 : a->n_doses) * (gw ? GW_WAVES * GW_ROWS : GX_ROWS) * 2;
     if (h->eff_cache_cap < need) {
       if (h->eff_cache) BGM_HIP_CHECK(hipFree(h->eff_cache));
       BGM_HIP_CHECK(hipMalloc(&h->eff_cache, need * sizeof(float)));
@@ -258,7 +280,7 @@ int gx_mh_run(bgm_handle *h, const bgm_mh_args *a, hipStream_t stream) {
     k.e.stats = h->eff_stats_dev;
     h->eff_total += (unsigned long long)((a->n + 15) / 16) * (unsigned long long)(it_end - std::max(a->burn_in, a->it_begin));
   }
-  const int lds_mh = s->gw ? s->gw_lds : s->lds_bytes, threads_mh = s->gw ? GW_THREADS : GX_THREADS;
+  const int lds_mh = gw ? s->gw_lds : s->lds_bytes, threads_mh = gw ? GW_THREADS : GX_THREADS;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (h->timing) { BGM_HIP_CHECK(hipEventCreate(&e0)); BGM_HIP_CHECK(hipEventCreate(&e1)); BGM_HIP_CHECK(hipEventRecord(e0, stream)); }
   auto launch = [&](auto kern) {
@@ -268,7 +290,7 @@ int gx_mh_run(bgm_handle *h, const bgm_mh_args *a, hipStream_t stream) {
     BGM_HIP_CHECK(hipGetLastError());
     return (int)BGM_OK;
   };
-  if (s->gw) {
+  if (gw) {
     if (a->effect == BGM_EFFECT_ADRF) rc = launch(gw_causal_mh_kernel<1>);
     else if (a->effect == BGM_EFFECT_ITE) rc = launch(gw_causal_mh_kernel<2>);
     else rc = launch(gw_causal_mh_kernel<0>);
@@ -319,7 +341,7 @@ int gx_effects(bgm_handle *h, const float *draws, int64_t n, int64_t row_base, i
   k.e.k0 = (unsigned)(seed & 0xFFFFFFFFull); k.e.k1 = (unsigned)(seed >> 32);
   k.adrf_partial = adrf_partial;
   const bool binary = h->cfg.binary_treatment != 0;
-  if (s->gw) {
+  if (use_gw(s)) {
     k.m = gw_model(s);
     const int gg = gw_grid(h, s, n);
     if (binary) {
@@ -457,6 +479,7 @@ void gx_free(bgm_handle *h) {
   if (!s) return;
   if (s->pack) hipFree(s->pack);
   if (s->packT) hipFree(s->packT);
+  if (s->packF) hipFree(s->packF);
   delete s;
   h->gx_state = nullptr; h->gx_valid = false;
 }

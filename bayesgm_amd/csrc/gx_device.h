@@ -56,17 +56,27 @@ struct GxPre { f32x2 b0, b1, b2, b3, bb; int valid; };
 // surrounding iteration loop -- hoisted out of it, those offsets of all layers stay live across a whole transition and spill
 __device__ __forceinline__ int gx_lane() { int l = threadIdx.x & 63; asm volatile("" : "+v"(l)); return l; }
 // (u0 >= 0: the calling wave's first unit instead of unit `wave` -- the row-tile-per-wave kernels of gw_kernels.h walk all units themselves)
-__device__ __forceinline__ GxPre gx_prefetch(const float *__restrict__ W, int ldw, int N, const float *bias, int nrt = 2, int u0 = -1) {
+// FRAG: W is a layer of the FRAGMENT pack (gx_api.hip): per (32-column group cg, 16-row K block kb) the 64 lanes' operands of the block
+// are contiguous -- lane (j, g) owns 8 floats {W[16 kb + 4 g + s][32 cg + 2 j + c]: s = 0..3, c = 0, 1} at ((cg * K / 16 + kb) * 64 + lane) * 8:
+// two 16-byte requests per lane and block (one contiguous 2 KB per wave) instead of four 8-byte ones on four rows, one address step.
+template <bool FRAG = false>
+__device__ __forceinline__ GxPre gx_prefetch(const float *__restrict__ W, int ldw, int N, const float *bias, int nrt = 2, int u0 = -1, int K = 0) {
   GxPre p;
   p.valid = 0;
   const int lane = gx_lane(), wave = u0 >= 0 ? u0 : (int)(threadIdx.x >> 6), j = lane & 15, g = lane >> 4;
   if (wave >= nrt * (N >> 5)) return p;
   const int n0 = (wave / nrt) << 5;
+  if constexpr (FRAG) {
+    const f32x4 *wf = reinterpret_cast<const f32x4 *>(W + ((size_t)(n0 >> 5) * (K >> 4) * 64 + lane) * 8);
+    const f32x4 q0 = wf[0], q1 = wf[1];
+    p.b0 = f32x2{q0[0], q0[1]}; p.b1 = f32x2{q0[2], q0[3]}; p.b2 = f32x2{q1[0], q1[1]}; p.b3 = f32x2{q1[2], q1[3]};
+  } else {
   const float *wk = W + (size_t)(4 * g) * ldw + n0 + 2 * j;
   p.b0 = *reinterpret_cast<const f32x2 *>(wk);
   p.b1 = *reinterpret_cast<const f32x2 *>(wk + ldw);
   p.b2 = *reinterpret_cast<const f32x2 *>(wk + 2 * (size_t)ldw);
   p.b3 = *reinterpret_cast<const f32x2 *>(wk + 3 * (size_t)ldw);
+  }
   p.bb = bias ? *reinterpret_cast<const f32x2 *>(bias + n0 + 2 * j) : f32x2{0.0f, 0.0f};
   p.valid = 1;
   return p;
@@ -83,7 +93,7 @@ template <class E> __device__ __forceinline__ void gx_epi_rotate(E &, long) {}
 // unit's first block as requested by gx_prefetch ahead of the barrier in front of this call.
 // u0 / ustride: the calling wave's first unit and its stride over the units (default: unit `wave`, stride GX_WAVES -- the workgroup's
 // waves deal the units; 0 / 1: one wave walks them all on ITS rows A, gw_kernels.h).
-template <bool A_GLOBAL = false, class Epi>
+template <bool A_GLOBAL = false, bool FRAG = false, class Epi>
 __device__ __forceinline__ void gx_dense_ld(const float *__restrict__ W, int ldw, int K, int N, const float *A, int lda, Epi epi, int nrt = 2,
                                             const float *bias = nullptr, const GxPre *pre = nullptr, int u0 = -1, int ustride = GX_WAVES) {
   const int lane = gx_lane(), wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
@@ -100,12 +110,21 @@ __device__ __forceinline__ void gx_dense_ld(const float *__restrict__ W, int ldw
   int rt = u % nrt, n0 = (u / nrt) << 5;
   const float *ap = A + (size_t)(16 * rt + j) * lda + 4 * g;
   const unsigned ldb = 4u * (unsigned)ldw;
-  unsigned o0 = 4u * ((unsigned)(4 * g) * (unsigned)ldw + (unsigned)(n0 + 2 * j)), o1 = o0 + ldb, o2 = o1 + ldb, o3 = o2 + ldb;
+  // FRAG: one byte offset, 2 KB per K block, two 16-byte requests (see gx_prefetch)
+  const unsigned ubytes = 2048u * (unsigned)(K >> 4);                                 // one column group's blocks in the fragment pack
+  auto fld = [&](unsigned boff, f32x2 &r0, f32x2 &r1, f32x2 &r2, f32x2 &r3) {
+    const f32x4 *wf = reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(W) + boff);
+    const f32x4 q0 = wf[0], q1 = wf[1];
+    r0 = f32x2{q0[0], q0[1]}; r1 = f32x2{q0[2], q0[3]}; r2 = f32x2{q1[0], q1[1]}; r3 = f32x2{q1[2], q1[3]};
+  };
+  unsigned o0 = FRAG ? (unsigned)(n0 >> 5) * ubytes + 32u * (unsigned)lane : 4u * ((unsigned)(4 * g) * (unsigned)ldw + (unsigned)(n0 + 2 * j));
+  unsigned o1 = o0 + ldb, o2 = o1 + ldb, o3 = o2 + ldb;
   f32x4 a = *reinterpret_cast<const f32x4 *>(ap);
   f32x2 b0, b1, b2, b3, bb = {0.0f, 0.0f};
   if (pre != nullptr && pre->valid) { b0 = pre->b0; b1 = pre->b1; b2 = pre->b2; b3 = pre->b3; bb = pre->bb; }
   else {
-    b0 = wld(o0); b1 = wld(o1); b2 = wld(o2); b3 = wld(o3);
+    if constexpr (FRAG) fld(o0, b0, b1, b2, b3);
+    else { b0 = wld(o0); b1 = wld(o1); b2 = wld(o2); b3 = wld(o3); }
     if (bias) bb = *reinterpret_cast<const f32x2 *>(bias + n0 + 2 * j);
   }
   gx_epi_pre(epi, rt, n0, 0);
@@ -113,9 +132,10 @@ __device__ __forceinline__ void gx_dense_ld(const float *__restrict__ W, int ldw
   for (;;) {
     f32x4 acc0 = {bb[0], bb[0], bb[0], bb[0]}, acc1 = {bb[1], bb[1], bb[1], bb[1]};
     for (int k0 = 16; k0 < K; k0 += 16) {
-      o0 += wstep; o1 += wstep; o2 += wstep; o3 += wstep;
+      f32x2 c0, c1, c2, c3;
       const f32x4 an = *reinterpret_cast<const f32x4 *>(ap + k0);
-      const f32x2 c0 = wld(o0), c1 = wld(o1), c2 = wld(o2), c3 = wld(o3);
+      if constexpr (FRAG) { o0 += 2048u; fld(o0, c0, c1, c2, c3); }
+      else { o0 += wstep; o1 += wstep; o2 += wstep; o3 += wstep; c0 = wld(o0); c1 = wld(o1); c2 = wld(o2); c3 = wld(o3); }
       __builtin_amdgcn_sched_barrier(0);      // keep the requests above the MFMAs of the previous block (hipcc sinks loads to their first use)
       acc0 = BGM_MFMA(a[0], b0[0], acc0); acc1 = BGM_MFMA(a[0], b0[1], acc1);
       acc0 = BGM_MFMA(a[1], b1[0], acc0); acc1 = BGM_MFMA(a[1], b1[1], acc1);
@@ -131,9 +151,12 @@ __device__ __forceinline__ void gx_dense_ld(const float *__restrict__ W, int ldw
     f32x2 c0 = b0, c1 = b1, c2 = b2, c3 = b3, bn = bb;
     if (more) {
       ap = A + (size_t)(16 * rtn + j) * lda + 4 * g;
-      o0 = 4u * ((unsigned)(4 * g) * (unsigned)ldw + (unsigned)(n0n + 2 * j)); o1 = o0 + ldb; o2 = o1 + ldb; o3 = o2 + ldb;
       an = *reinterpret_cast<const f32x4 *>(ap);
-      c0 = wld(o0); c1 = wld(o1); c2 = wld(o2); c3 = wld(o3);
+      if constexpr (FRAG) { o0 = (unsigned)(n0n >> 5) * ubytes + 32u * (unsigned)lane; fld(o0, c0, c1, c2, c3); }
+      else {
+        o0 = 4u * ((unsigned)(4 * g) * (unsigned)ldw + (unsigned)(n0n + 2 * j)); o1 = o0 + ldb; o2 = o1 + ldb; o3 = o2 + ldb;
+        c0 = wld(o0); c1 = wld(o1); c2 = wld(o2); c3 = wld(o3);
+      }
       if (bias) bn = *reinterpret_cast<const f32x2 *>(bias + n0n + 2 * j);
       gx_epi_pre(epi, rtn, n0n, 0);
     }
@@ -151,10 +174,10 @@ __device__ __forceinline__ void gx_dense_ld(const float *__restrict__ W, int ldw
 }
 
 // W [K][N] with row stride N
-template <bool A_GLOBAL = false, class Epi>
+template <bool A_GLOBAL = false, bool FRAG = false, class Epi>
 __device__ __forceinline__ void gx_dense(const float *__restrict__ W, int K, int N, const float *A, int lda, Epi epi, int nrt = 2,
                                          const float *bias = nullptr, const GxPre *pre = nullptr, int u0 = -1, int ustride = GX_WAVES) {
-  gx_dense_ld<A_GLOBAL>(W, N, K, N, A, lda, epi, nrt, bias, pre, u0, ustride);
+  gx_dense_ld<A_GLOBAL, FRAG>(W, N, K, N, A, lda, epi, nrt, bias, pre, u0, ustride);
 }
 
 // Epilogue helpers -------------------------------------------------------------------------------------------------------------
