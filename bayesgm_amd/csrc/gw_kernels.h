@@ -22,6 +22,9 @@
 #include "gx_causal_kernels.h"
 
 #define GW_ROWS 16
+// K extent of layer l as the row-tile-per-wave kernels contract it: the true input width rounded up to the 16 of one K block (the padded
+// packs round to 32: a layer of at most 16 inputs -- first layers, the 8 -> 2 heads -- is one block instead of two)
+__host__ __device__ inline int gw_k16(const GxNet &n, int l) { return (n.dim[l] + 15) & ~15; }
 #define GW_WAVES 4
 #define GW_THREADS 256
 
@@ -46,8 +49,8 @@ __device__ __forceinline__ float *gw_hidden(const GxNet &net, const float *pack,
   for (int l = l_begin; l < l_end; ++l) {
     GxPre nx;
     nx.valid = 0;
-    if (l + 1 < net.L) nx = gx_prefetch<true>(pack + net.w[l + 1], net.pad[l + 2], net.pad[l + 2], pack + net.b[l + 1], nrt, 0, net.pad[l + 1]);
-    gx_dense<false, true>(pack + net.w[l], net.pad[l], net.pad[l + 1], cur, ld, GxStore<true>{oth, ld, nullptr}, nrt, pack + net.b[l], &pre, 0, 1);
+    if (l + 1 < net.L) nx = gx_prefetch<true>(pack + net.w[l + 1], net.pad[l + 2], net.pad[l + 2], pack + net.b[l + 1], nrt, 0, gw_k16(net, l + 1));
+    gx_dense<false, true>(pack + net.w[l], gw_k16(net, l), net.pad[l + 1], cur, ld, GxStore<true>{oth, ld, nullptr}, nrt, pack + net.b[l], &pre, 0, 1);
     pre = nx;
     float *t = cur; cur = oth; oth = t;
   }
@@ -93,7 +96,7 @@ struct GwGLastEpi {
 template <class XIn>
 __device__ __forceinline__ const float *gw_f_forward(const GxCausalModel &m, const GwLds &L, const float *z, XIn xin, int nd) {
   const int lane = gx_lane(), zf = m.z0 + m.z1, q = m.q, ld = m.ldf, wp = m.f.pad[0];
-  GxPre pre = gx_prefetch<true>(m.pack + m.f.w[0], m.f.pad[1], m.f.pad[1], m.pack + m.f.b[0], nd, 0, m.f.pad[0]);
+  GxPre pre = gx_prefetch<true>(m.pack + m.f.w[0], m.f.pad[1], m.f.pad[1], m.pack + m.f.b[0], nd, 0, gw_k16(m.f, 0));
   for (int c = lane; c < wp; c += 64)
 #pragma nounroll
     for (int r = 0; r < GW_ROWS * nd; ++r)
@@ -101,7 +104,7 @@ __device__ __forceinline__ const float *gw_f_forward(const GxCausalModel &m, con
   float *cur = gw_hidden(m.f, m.pack, 0, m.f.L - 1, L.bufA, L.bufB, ld, pre, nd);
   float *oth = (cur == L.bufA) ? L.bufB : L.bufA;
   const int l = m.f.L - 1;
-  gx_dense<false, true>(m.pack + m.f.w[l], m.f.pad[l], m.f.pad[l + 1], cur, ld, GxStore<false>{oth, ld, nullptr}, nd, m.pack + m.f.b[l], &pre, 0, 1);
+  gx_dense<false, true>(m.pack + m.f.w[l], gw_k16(m.f, l), m.f.pad[l + 1], cur, ld, GxStore<false>{oth, ld, nullptr}, nd, m.pack + m.f.b[l], &pre, 0, 1);
   return oth;
 }
 
@@ -111,7 +114,7 @@ __device__ __forceinline__ float gw_causal_logp(const GxCausalModel &m, const Gw
   const int lane = gx_lane(), j = lane & 15, g = lane >> 4, q = m.q, ld = m.ld;
   // ---- g: z -> (mu_v [p], raw_v), fused with the Gaussian likelihood of the V rows
   {
-    GxPre pre = gx_prefetch<true>(m.pack + m.g.w[0], m.g.pad[1], m.g.pad[1], m.pack + m.g.b[0], 1, 0, m.g.pad[0]);
+    GxPre pre = gx_prefetch<true>(m.pack + m.g.w[0], m.g.pad[1], m.g.pad[1], m.pack + m.g.b[0], 1, 0, gw_k16(m.g, 0));
     const int wp = m.g.pad[0];
     for (int c = lane; c < wp; c += 64)
 #pragma nounroll
@@ -121,7 +124,7 @@ __device__ __forceinline__ float gw_causal_logp(const GxCausalModel &m, const Gw
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     GwGLastEpi ge;
     ge.v = v; ge.row0 = row0; ge.n = n; ge.p = m.p; ge.sraw = L.sraw; ge.acc = acc;
-    gx_dense<false, true>(m.pack + m.g.w[l], m.g.pad[l], m.g.pad[l + 1], cur, ld, ge, 1, m.pack + m.g.b[l], &pre, 0, 1);
+    gx_dense<false, true>(m.pack + m.g.w[l], gw_k16(m.g, l), m.g.pad[l + 1], cur, ld, ge, 1, m.pack + m.g.b[l], &pre, 0, 1);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float s = gx_sum_j(acc[r]);
@@ -138,14 +141,14 @@ __device__ __forceinline__ float gw_causal_logp(const GxCausalModel &m, const Gw
   float mu_x = 0.0f, raw_x = 0.0f;
   {
     const int z0 = m.z0, z1 = m.z1, z2 = m.z2, wp = m.h.pad[0];
-    GxPre ph = gx_prefetch<true>(m.pack + m.h.w[0], m.h.pad[1], m.h.pad[1], m.pack + m.h.b[0], 1, 0, m.h.pad[0]);
+    GxPre ph = gx_prefetch<true>(m.pack + m.h.w[0], m.h.pad[1], m.h.pad[1], m.pack + m.h.b[0], 1, 0, gw_k16(m.h, 0));
     for (int c = lane; c < wp; c += 64)
 #pragma nounroll
       for (int r = 0; r < GW_ROWS; ++r) L.bufA[r * ld + c] = c < z0 ? z[r * q + c] : (c < z0 + z2 ? z[r * q + z1 + c] : 0.0f);
     float *cur = gw_hidden(m.h, m.pack, 0, m.h.L - 1, L.bufA, L.bufB, ld, ph, 1);
     float *oth = (cur == L.bufA) ? L.bufB : L.bufA;
     const int l = m.h.L - 1;
-    gx_dense<false, true>(m.pack + m.h.w[l], m.h.pad[l], m.h.pad[l + 1], cur, ld, GxStore<false>{oth, ld, nullptr}, 1, m.pack + m.h.b[l], &ph, 0, 1);
+    gx_dense<false, true>(m.pack + m.h.w[l], gw_k16(m.h, l), m.h.pad[l + 1], cur, ld, GxStore<false>{oth, ld, nullptr}, 1, m.pack + m.h.b[l], &ph, 0, 1);
     if (lane < GW_ROWS) { mu_x = oth[lane * ld]; raw_x = oth[lane * ld + 1]; }
   }
   // ---- assemble -(loss_v + loss_x + loss_y + prior)   (base.py:800-816), lane r = row r

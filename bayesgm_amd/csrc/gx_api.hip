@@ -158,7 +158,7 @@ int gx_session(bgm_handle *h, GxState *&st, hipStream_t stream, bool need_ghf = 
       const GxNet *gn[3] = {&st->m.g, &st->m.f, &st->m.h};
       for (const GxNet *net : gn)
         for (int l = 0; l < net->L; ++l) {
-          const int Kp = net->pad[l], Np = net->pad[l + 1], KB = Kp / 16;
+          const int Np = net->pad[l + 1], KB = gw_k16(*net, l) / 16;      // (rows beyond the true input width are zero in the padded pack)
           const float *src = pk.data() + net->w[l];
           float *dst = pf.data() + net->w[l];
           for (int cg = 0; cg < Np / 32; ++cg)
