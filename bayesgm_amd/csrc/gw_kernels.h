@@ -28,18 +28,21 @@ __host__ __device__ inline int gw_k16(const GxNet &n, int l) { return (n.dim[l] 
 #define GW_WAVES 4
 #define GW_THREADS 256
 
-struct GwLds { float *bufA, *bufB, *zc, *zp, *ssq, *sraw, *flag; };
+// LDS row stride of a wave's activation buffers: = 4 (mod 64) floats -- the 16 lanes of a lane group read 16 B at banks 4 j .. 4 j + 3, all
+// distinct, like gx_ld's = 8 (mod 64), and a 64-wide net's region comes to 10 112 B: 16 waves per CU instead of 12
+__host__ __device__ inline int gw_ld(int width) { return ((width + 63) / 64) * 64 + 4; }
+struct GwLds { float *bufA, *bufB, *zc, *zp, *ssq, *sraw; };
 // floats of one wave's LDS region: two activation buffers of GW_ROWS x max(ld, db * ldf), the 16 chains' current / proposed states, sums
 __host__ __device__ inline int gw_buf_floats(int ld, int ldf, int db) { return GW_ROWS * (ld > db * ldf ? ld : db * ldf); }
 __host__ __device__ inline int gw_wave_floats(int ld, int q, int ldf, int db) {
-  return 2 * gw_buf_floats(ld, ldf, db) + 2 * GW_ROWS * q + 3 * GW_ROWS + 16;
+  return 2 * gw_buf_floats(ld, ldf, db) + ((2 * GW_ROWS * q + 3) & ~3) + 2 * GW_ROWS;
 }
 __device__ __forceinline__ GwLds gw_carve(float *w, int ld, int q, int ldf, int db) {
   GwLds L;
   const int bf = gw_buf_floats(ld, ldf, db);
   L.bufA = w; L.bufB = w + bf;
   L.zc = L.bufB + bf; L.zp = L.zc + GW_ROWS * q;
-  L.ssq = L.zp + GW_ROWS * q; L.sraw = L.ssq + GW_ROWS; L.flag = L.sraw + GW_ROWS;
+  L.ssq = L.zp + GW_ROWS * q; L.sraw = L.ssq + GW_ROWS;
   return L;
 }
 

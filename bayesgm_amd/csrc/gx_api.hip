@@ -32,7 +32,7 @@ struct GxState {
   int lds_bytes = 0, lds_enc = 0, lds_fit = 0, occ = 1;
   // row-tile-per-wave sampling kernels (gw_kernels.h): used when a wave's LDS region stays small enough for >= 8 waves per CU
   bool gw = false;
-  int gw_db = 1, gw_lds = 0, gw_occ = 1;
+  int gw_db = 1, gw_lds = 0, gw_occ = 1, gw_ld = 0, gw_ldf = 0;
   bool fit = false;
   GxFitNet wg{}, wf{}, wh{};
 };
@@ -108,11 +108,16 @@ int gx_session(bgm_handle *h, GxState *&st, hipStream_t stream, bool need_ghf = 
       static const bool no_gw = std::getenv("BGM_NO_GW") != nullptr;      // dev A/B
       int wf = 32;
       for (int l = 0; l <= m.f.L; ++l) wf = std::max(wf, m.f.pad[l]);
-      const int ldf = gx_ld(wf);
-      s->gw = !no_gw && 4 * gw_wave_floats(m.ld, m.q, ldf, 1) <= 24 * 1024;
+      int wg_ = 32;
+      for (int l = 0; l < m.g.L; ++l) wg_ = std::max(wg_, m.g.pad[l]);
+      for (int l = 0; l <= m.f.L; ++l) wg_ = std::max(wg_, m.f.pad[l]);
+      for (int l = 0; l <= m.h.L; ++l) wg_ = std::max(wg_, m.h.pad[l]);
+      const int ldf = gw_ld(wf);
+      s->gw_ld = gw_ld(wg_); s->gw_ldf = ldf;
+      s->gw = !no_gw && 4 * gw_wave_floats(s->gw_ld, m.q, ldf, 1) <= 24 * 1024;
       s->gw_db = 1;      // doses per pass of the effect routine: one (measured: 2 doses at 8 waves per CU cost 10 % against 1 at 12)
       if (const char *f_ = std::getenv("BGM_GW_DB")) s->gw_db = std::max(1, std::min(GX_MAXDB, std::atoi(f_)));
-      s->gw_lds = 4 * GW_WAVES * gw_wave_floats(m.ld, m.q, ldf, s->gw_db);
+      s->gw_lds = 4 * GW_WAVES * gw_wave_floats(s->gw_ld, m.q, ldf, s->gw_db);
       if (s->gw_lds > 160 * 1024) s->gw = false;
       s->gw_occ = std::max(1, std::min(4, (160 * 1024) / std::max(s->gw_lds, 1)));
       if (const char *o_ = std::getenv("BGM_GW_OCC")) s->gw_occ = std::max(1, std::min(std::atoi(o_), (160 * 1024) / std::max(s->gw_lds, 1)));
@@ -182,7 +187,7 @@ int grid_for(const bgm_handle *h, const GxState *s, int64_t n) {
 }
 
 // the model as the row-tile-per-wave kernels read it (their own dose batch) and their launch grid (workgroups of GW_WAVES row tiles)
-GxCausalModel gw_model(const GxState *s) { GxCausalModel w = s->m; w.db = s->gw_db; w.pack = s->packF; return w; }
+GxCausalModel gw_model(const GxState *s) { GxCausalModel w = s->m; w.db = s->gw_db; w.pack = s->packF; w.ld = s->gw_ld; w.ldf = s->gw_ldf; return w; }
 int gw_grid(const bgm_handle *h, const GxState *s, int64_t n) {
   const int64_t wgs = ((n + GW_ROWS - 1) / GW_ROWS + GW_WAVES - 1) / GW_WAVES;
   return (int)std::max<int64_t>(1, std::min<int64_t>(wgs, (int64_t)h->n_cus * s->gw_occ));
