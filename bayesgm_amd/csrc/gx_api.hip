@@ -34,6 +34,8 @@ struct GxState {
   bool gw = false;
   int gw_db = 1, gw_lds = 0, gw_occ = 1, gw_ld = 0, gw_ldf = 0;
   bool fit = false;
+  long long fit_dzp = 0, fit_cnt = 0;
+  int fit_dzp_rows = 0;
   GxFitNet wg{}, wf{}, wh{};
 };
 
@@ -442,6 +444,9 @@ int gx_fit_begin(bgm_handle *h, int64_t n_rows, int32_t max_batch, hipStream_t s
   std::memset(&h->fit_ws, 0, sizeof(h->fit_ws));
   h->fit_ws.B = B;
   h->fit_ws.dz = take((long long)B * h->q);
+  s->fit_dzp = take(3LL * B * h->q);                 // the three networks' shares of d loss / dz (gx_causal_fit_kernel)
+  s->fit_cnt = take(B / GX_ROWS + 1);                // arrival counters per 32-row tile (zeroed with the workspace, self-resetting)
+  s->fit_dzp_rows = B;
   h->fit_ws.total = off;
   h->fit_bcap = B;
   h->rows_per_slice = 256;
@@ -469,12 +474,13 @@ int gx_fit_grads(bgm_handle *h, const float *x, const float *y, const float *v, 
   GxFitArgs a{};
   a.m = s->m; a.m.prior_seg = nullptr; a.m.prior_tab = nullptr;
   a.packT = s->packT; a.wg = s->wg; a.wf = s->wf; a.wh = s->wh; a.ws = h->ws_dev; a.dz_off = h->fit_ws.dz;
+  a.dzp_off = s->fit_dzp; a.cnt_off = s->fit_cnt; a.dzp_rows = s->fit_dzp_rows;
   a.x = x; a.y = y; a.v = v; a.data_z = data_z; a.idx = idx; a.row_lo = row_lo; a.B = batch; a.inv_B = 1.0f / (float)batch_global;
   a.z_mode = z_mode; a.loss = loss;
   int rc = set_lds(gx_causal_fit_kernel, s->lds_fit);
   if (rc) return rc;
   const int tiles = (batch + GX_ROWS - 1) / GX_ROWS;
-  hipLaunchKernelGGL(gx_causal_fit_kernel, dim3(std::min(tiles, h->n_cus * 2)), dim3(GX_THREADS), s->lds_fit, stream, a);
+  hipLaunchKernelGGL(gx_causal_fit_kernel, dim3(std::min(tiles, h->n_cus * 2), 3), dim3(GX_THREADS), s->lds_fit, stream, a);      // y: g, f, h
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
 }

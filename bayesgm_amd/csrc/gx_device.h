@@ -204,8 +204,8 @@ template <bool LEAKY>
 struct GxStoreWs {
   float *Y; int ldy; const float *bias; float *G; int ldg;
   __device__ __forceinline__ void operator()(int rt, int n0, const f32x4 &a0, const f32x4 &a1) const {
-    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
-    const f32x2 bb = *reinterpret_cast<const f32x2 *>(bias + n0 + 2 * j);
+    const int lane = gx_lane(), j = lane & 15, g = lane >> 4;
+    const f32x2 bb = bias ? *reinterpret_cast<const f32x2 *>(bias + n0 + 2 * j) : f32x2{0.0f, 0.0f};      // (NULL: already in the accumulators)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float y0 = a0[r] + bb[0], y1 = a1[r] + bb[1];

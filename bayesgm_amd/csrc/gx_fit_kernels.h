@@ -6,11 +6,14 @@
 //   update_latent_variable_sgd :246-302 (gradient half)                   -> gx_causal_fit_kernel (z_mode = 1)
 // Losses and their derivatives are the formulas of fit_kernels.h / oracle/fit.py (accurate log / log1p: reported values).
 //
-// A workgroup owns 32 rows of the minibatch and walks g, f, h one after the other: forward with every layer input copied to the
+// A workgroup owns 32 rows of the minibatch and ONE of the three networks (blockIdx.y: g, f, h run side by side -- a minibatch of 32 rows is a
+// single latency chain, and the chain through g alone is 12 of the 28 layer steps of g, f, h in sequence); it walks its net forward with every layer input copied to the
 // HBM workspace ([B][padded width] row-major -- exactly what the weight-gradient GEMM fit_dw_kernel contracts over rows), the
 // loss derivative written over the last layer's output in place, backward through the transposed pack with the pre-activation
 // gradients stored next to the activations.  g's p-wide last layer never enters LDS: its output goes to the workspace and is the
-// A operand of the first backward product from there.
+// A operand of the first backward product from there.  z_mode = 1: each net's workgroup leaves its share of d loss / dz in a partial buffer and
+// the LAST of a tile's three workgroups to finish (a counter per tile) adds them in the fixed order g + f + h + prior: deterministic sums.
+// Every layer's first weight block (and bias pair) is requested before the products of the layer in front of it (gx_prefetch).
 #pragma once
 #include "gx_causal_kernels.h"
 
@@ -25,6 +28,9 @@ struct GxFitArgs {
   GxFitNet wg, wf, wh;
   float *ws;
   long long dz_off;         // [B][q] latent gradients (z_mode = 1)
+  long long dzp_off;        // [3][Bcap][q] the networks' shares of them; Bcap = dzp_rows
+  long long cnt_off;        // [tiles] arrival counters of the tiles' three workgroups (zero between launches)
+  int dzp_rows;
   const float *x, *y, *v, *data_z;
   const int *idx; long long row_lo;
   int B; float inv_B; int z_mode;
@@ -56,18 +62,25 @@ __device__ __forceinline__ void gx_fit_net(const GxFitArgs &a, const GxNet &net,
       A0[(long long)r * wp + c] = val;
     }
   }
+  GxPre pre = gx_prefetch(m.pack + net.w[0], net.pad[1], net.pad[1], m.pack + net.b[0]);
   __syncthreads();
   // ---- forward
   float *cur = bufA, *oth = bufB;
   for (int l = 0; l < Ln - 1; ++l) {
+    const GxPre nx = gx_prefetch(m.pack + net.w[l + 1], net.pad[l + 2], net.pad[l + 2], m.pack + net.b[l + 1]);
     gx_dense(m.pack + net.w[l], net.pad[l], net.pad[l + 1], cur, ld,
-             GxStoreWs<true>{oth, ld, m.pack + net.b[l], a.ws + w.act[l + 1] + b0 * net.pad[l + 1], net.pad[l + 1]});
+             GxStoreWs<true>{oth, ld, nullptr, a.ws + w.act[l + 1] + b0 * net.pad[l + 1], net.pad[l + 1]}, 2, m.pack + net.b[l], &pre);
     __syncthreads();
+    pre = nx;
     float *t = cur; cur = oth; oth = t;
   }
   const int lo = Ln - 1, NO = net.pad[Ln];
   float *out = a.ws + w.dy[lo] + b0 * NO;
-  gx_dense(m.pack + net.w[lo], net.pad[lo], NO, cur, ld, GxStoreWs<false>{nullptr, 0, m.pack + net.b[lo], out, NO});
+  gx_dense(m.pack + net.w[lo], net.pad[lo], NO, cur, ld, GxStoreWs<false>{nullptr, 0, nullptr, out, NO}, 2, m.pack + net.b[lo], &pre);
+  // the first backward product's first block (transposed pack; no bias)
+  GxPre pb;
+  pb.valid = 0;
+  if (Ln - 1 >= (theta ? 1 : 0)) pb = gx_prefetch(a.packT + net.wt[Ln - 1], net.pad[Ln - 1], net.pad[Ln - 1], nullptr);
   __syncthreads();
   // ---- losses and their derivatives, written over the raw output
   if (NET == 0) {
@@ -122,13 +135,18 @@ __device__ __forceinline__ void gx_fit_net(const GxFitArgs &a, const GxNet &net,
   // ---- backward: d pre-activation of layer l - 1 from layer l
   for (int l = Ln - 1; l >= 1; --l) {
     const GxBackStore epi{oth, ld, a.ws + w.act[l] + b0 * net.pad[l], net.pad[l], theta ? a.ws + w.dy[l - 1] + b0 * net.pad[l] : nullptr, net.pad[l]};
-    if (l == Ln - 1) gx_dense<true>(a.packT + net.wt[l], net.pad[l + 1], net.pad[l], out, NO, epi);
-    else gx_dense(a.packT + net.wt[l], net.pad[l + 1], net.pad[l], cur, ld, epi);
+    GxPre nx;
+    nx.valid = 0;
+    if (l - 1 >= (theta ? 1 : 0)) nx = gx_prefetch(a.packT + net.wt[l - 1], net.pad[l - 1], net.pad[l - 1], nullptr);
+    if (l == Ln - 1) gx_dense<true>(a.packT + net.wt[l], net.pad[l + 1], net.pad[l], out, NO, epi, 2, nullptr, &pb);
+    else gx_dense(a.packT + net.wt[l], net.pad[l + 1], net.pad[l], cur, ld, epi, 2, nullptr, &pb);
     __syncthreads();
+    pb = nx;
     float *t = cur; cur = oth; oth = t;
   }
   if (!theta) {       // gradient with respect to the network input -> the latent columns it was gathered from
-    gx_dense(a.packT + net.wt[0], net.pad[1], net.pad[0], cur, ld, GxRawStore{oth, ld});
+    if (Ln == 1) gx_dense<true>(a.packT + net.wt[0], net.pad[1], net.pad[0], out, NO, GxRawStore{oth, ld}, 2, nullptr, &pb);
+    else gx_dense(a.packT + net.wt[0], net.pad[1], net.pad[0], cur, ld, GxRawStore{oth, ld}, 2, nullptr, &pb);
     __syncthreads();
     const int nin = NET == 0 ? q : (NET == 1 ? zf : m.z0 + m.z2);
     for (int i = threadIdx.x; i < GX_ROWS * nin; i += GX_THREADS) {
@@ -142,8 +160,10 @@ __device__ __forceinline__ void gx_fit_net(const GxFitArgs &a, const GxNet &net,
 
 __global__ __launch_bounds__(GX_THREADS) void gx_causal_fit_kernel(GxFitArgs a) {
   extern __shared__ float lds[];
+  __shared__ int last_s;
   const GxCausalModel &m = a.m;
   const int ld = m.ld, q = m.q;
+  const int net = blockIdx.y;      // 0 g, 1 f, 2 h: the three networks of a tile run as three workgroups
   float *bufA = lds, *bufB = bufA + GX_ROWS * ld, *dzacc = bufB + GX_ROWS * ld, *lossr = dzacc + GX_ROWS * q;
   long long *rowg = reinterpret_cast<long long *>(lossr + 6 * GX_ROWS);        // 32 x 8 bytes = 64 floats
   const int tiles = (a.B + GX_ROWS - 1) / GX_ROWS;
@@ -156,25 +176,53 @@ __global__ __launch_bounds__(GX_THREADS) void gx_causal_fit_kernel(GxFitArgs a) 
       rowg[threadIdx.x] = a.idx ? (long long)a.idx[b] : a.row_lo + b;
     }
     for (int i = threadIdx.x; i < GX_ROWS * q; i += GX_THREADS) dzacc[i] = 0.0f;
+    for (int i = threadIdx.x; i < 6 * GX_ROWS; i += GX_THREADS) lossr[i] = 0.0f;
     __syncthreads();
-    gx_fit_net<0>(a, m.g, a.wg, bufA, bufB, dzacc, lossr, rowg, b0);
-    gx_fit_net<1>(a, m.f, a.wf, bufA, bufB, dzacc, lossr, rowg, b0);
-    gx_fit_net<2>(a, m.h, a.wh, bufA, bufB, dzacc, lossr, rowg, b0);
-    if (a.z_mode) {      // dz = d loss / dz + z / B   (prior term, base.py:292-293)
-      float *dz = a.ws + a.dz_off;
+    if (net == 0) gx_fit_net<0>(a, m.g, a.wg, bufA, bufB, dzacc, lossr, rowg, b0);
+    else if (net == 1) gx_fit_net<1>(a, m.f, a.wf, bufA, bufB, dzacc, lossr, rowg, b0);
+    else gx_fit_net<2>(a, m.h, a.wh, bufA, bufB, dzacc, lossr, rowg, b0);
+    if (a.z_mode) {      // this net's share of d loss / dz; the tile's last workgroup forms dz = g + f + h shares + z / B (prior term, base.py:292-293)
+      float *part = a.ws + a.dzp_off;
+      const long long ps = (long long)a.dzp_rows * q;
       for (int i = threadIdx.x; i < GX_ROWS * q; i += GX_THREADS) {
-        const int r = i / q, c = i - r * q;
-        if (b0 + r < a.B) dz[(b0 + r) * q + c] = dzacc[i] + a.data_z[rowg[r] * q + c] * a.inv_B;
+        const int r = i / q;
+        if (b0 + r < a.B) part[net * ps + b0 * q + i] = dzacc[i];
+      }
+      __threadfence();
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        unsigned *cnt = reinterpret_cast<unsigned *>(a.ws + a.cnt_off) + t;
+        const unsigned old = atomicAdd(cnt, 1u);
+        last_s = old == 2u;
+        if (old == 2u) *cnt = 0u;          // zero again for the next launch
+      }
+      __syncthreads();
+      if (last_s) {
+        __threadfence();
+        float *dz = a.ws + a.dz_off;
+        for (int i = threadIdx.x; i < GX_ROWS * q; i += GX_THREADS) {
+          const int r = i / q, c = i - r * q;
+          if (b0 + r < a.B) {
+            const long long o = b0 * q + i;
+            const float pg = __builtin_nontemporal_load(part + o), pf = __builtin_nontemporal_load(part + ps + o),
+                        ph = __builtin_nontemporal_load(part + 2 * ps + o);
+            dz[o] = ((pg + pf) + ph) + a.data_z[rowg[r] * q + c] * a.inv_B;
+          }
+        }
       }
     }
     if (threadIdx.x < GX_ROWS && b0 + threadIdx.x < a.B) {
       const int r = threadIdx.x;
-      float zsq = 0.0f;
-      const float *zr = a.data_z + rowg[r] * q;
-      for (int c = 0; c < q; ++c) zsq = fmaf(zr[c], zr[c], zsq);
       const float lv = lossr[r], ssq = lossr[GX_ROWS + r], lx = lossr[2 * GX_ROWS + r], ex = lossr[3 * GX_ROWS + r], ly = lossr[4 * GX_ROWS + r],
                   ey = lossr[5 * GX_ROWS + r];
-      acc[0] += lv; acc[1] += ssq; acc[2] += lx; acc[3] += ex; acc[4] += ly; acc[5] += ey; acc[6] += lv + lx + ly + 0.5f * zsq;
+      float tot = lv + lx + ly;          // (the other nets' entries are zero in this workgroup)
+      if (net == 0) {
+        float zsq = 0.0f;
+        const float *zr = a.data_z + rowg[r] * q;
+        for (int c = 0; c < q; ++c) zsq = fmaf(zr[c], zr[c], zsq);
+        tot += 0.5f * zsq;
+      }
+      acc[0] += lv; acc[1] += ssq; acc[2] += lx; acc[3] += ex; acc[4] += ly; acc[5] += ey; acc[6] += tot;
     }
   }
   if (a.loss != nullptr && threadIdx.x < 64) {

@@ -7,8 +7,12 @@ from oracle import causal as OC
 N = int(float(sys.argv[1])); B = int(float(sys.argv[2])); lazy = {"dense": 0, "lazy": 1, "replay": 2}[sys.argv[3]] if len(sys.argv) > 3 else 0
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 200
 z_dims, p = [1, 1, 1, 7], 200
-m = OC.init_model(0, z_dims, p)
-eng = CausalEngine(p, z_dims); eng.set_model(g=m["g"], f=m["f"], h=m["h"], e=m["e"])
+U = {}
+if os.environ.get("FIT_UNITS"):      # e.g. FIT_UNITS=128,128: the same hidden widths for g, e, f, h (general-width engine)
+    u = tuple(int(t) for t in os.environ["FIT_UNITS"].split(","))
+    U = dict(g_units=u, e_units=u, f_units=u, h_units=u)
+m = OC.init_model(0, z_dims, p, **U)
+eng = CausalEngine(p, z_dims, **{k: list(w) for k, w in U.items()}); eng.set_model(g=m["g"], f=m["f"], h=m["h"], e=m["e"])
 g = torch.Generator(device="cuda").manual_seed(0)
 v = torch.randn(N, p, device="cuda", generator=g); x = torch.rand(N, device="cuda", generator=g); y = torch.randn(N, device="cuda", generator=g)
 z = torch.randn(N, 10, device="cuda", generator=g); zm = torch.zeros_like(z); zv = torch.zeros_like(z)
