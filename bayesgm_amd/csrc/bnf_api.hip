@@ -297,7 +297,11 @@ int bnf_mh_run(bgm_handle *h, BnnState *s, const bgm_bnn_mh_args *g, hipStream_t
   const BnfPlan &P = st->P;
   BnfCfg c;
   const bool x3 = s->precision == 2;
-  MhFn fn = x3 ? bnx_mh_fn(st->KSc, 1, &c.R, &c.W) : mh_fn<1>(st->KSc, c);
+  // three-launch iteration (proposal / both evaluations as (item, state) units / accept step): the split-precision path always, fp32 when
+  // BGM_BNF_SPLIT=1 (development A/B)
+  static const bool split32 = std::getenv("BGM_BNF_SPLIT") != nullptr;
+  const bool split = x3 || split32;
+  MhFn fn = x3 ? bnx_mh_fn(st->KSc, 1, &c.R, &c.W) : (split32 ? mh_fn<3>(st->KSc, c) : mh_fn<1>(st->KSc, c));
   const long long n = g->n;
   const int bs = g->block_rows, n_blocks = (int)((n + bs - 1) / bs), q = s->q;
   const long long eset = (long long)P.e_frags * 256;
@@ -329,7 +333,7 @@ int bnf_mh_run(bgm_handle *h, BnnState *s, const bgm_bnn_mh_args *g, hipStream_t
   hipMemsetAsync(prof_dev, 0, 256, stream);
   a.prof = prof_dev;
 #endif
-  if (x3) {      // proposals [n x q] | the two log posteriors [2][n] of the three-launch iteration
+  if (split) {      // proposals [n x q] | the two log posteriors [2][n] of the three-launch iteration
     rc = grow((void **)&st->mh_dev, &st->mh_cap, sizeof(float) * (size_t)n * (q + 2), stream, false);
     if (rc) return rc;
     a.zprop = st->mh_dev; a.out = st->mh_dev + (size_t)n * q; a.mode = 3;
@@ -344,7 +348,7 @@ int bnf_mh_run(bgm_handle *h, BnnState *s, const bgm_bnn_mh_args *g, hipStream_t
       a.prior = s->bp_rows; a.prior_stride = n * (long long)(q + 2);
     }
     a.acc_blocks = g->acc_blocks_dev ? g->acc_blocks_dev + (long long)i * n_blocks : nullptr;
-    if (x3) {      // split precision: proposal, both evaluations as independent (item, state) units, accept step (bnx_kernels.h)
+    if (split) {      // proposal, both evaluations as independent (item, state) units, accept step (bnx_kernels.h)
       BnxMhStep ms{};
       ms.z = g->state_dev; ms.zprop = st->mh_dev; ms.lp = a.out; ms.n = n; ms.row_base = g->row_base; ms.q = q; ms.bs = bs; ms.it = it; ms.init = a.init;
       ms.q_sd = g->q_sd; ms.q_sd_blocks = g->q_sd_blocks_dev; ms.k0 = a.k0; ms.k1 = a.k1; ms.acc_count = g->acc_count_dev; ms.acc_blocks = a.acc_blocks;
