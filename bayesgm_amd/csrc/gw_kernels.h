@@ -94,21 +94,27 @@ struct GwGLastEpi {
   }
 };
 
-// f at treatment values xin(row, dose) for the wave's 16 latents z (LDS [16][q]); nd <= m.db doses stacked as row tiles (row 16 d + r).
-// Returns the buffer whose columns 0, 1 of row 16 d + r hold (mu_y, raw_y).
-template <class XIn>
-__device__ __forceinline__ const float *gw_f_forward(const GxCausalModel &m, const GwLds &L, const float *z, XIn xin, int nd) {
+// f on nd row tiles of the wave: row R (0 .. 16 nd - 1) is the latent of chain src(R) (LDS [16][q]) at treatment value xin(R).  Returns the
+// buffer whose columns 0, 1 of row R hold (mu_y, raw_y).  Lane (r = lane & 15, cq = lane >> 4) stages columns cq, cq + 4, ... of rows r, r + 16, ...
+template <class Src, class XIn>
+__device__ __forceinline__ const float *gw_f_rows(const GxCausalModel &m, const GwLds &L, const float *z, Src src, XIn xin, int nd) {
   const int lane = gx_lane(), zf = m.z0 + m.z1, q = m.q, ld = m.ldf, wp = m.f.pad[0];
   GxPre pre = gx_prefetch<true>(m.pack + m.f.w[0], m.f.pad[1], m.f.pad[1], m.pack + m.f.b[0], nd, 0, gw_k16(m.f, 0));
-  for (int c = lane; c < wp; c += 64)
-#pragma nounroll
-    for (int r = 0; r < GW_ROWS * nd; ++r)
-      L.bufA[r * ld + c] = c < zf ? z[(r & (GW_ROWS - 1)) * q + c] : (c == zf ? xin(r & (GW_ROWS - 1), r >> 4) : 0.0f);
+  for (int R = lane & (GW_ROWS - 1); R < GW_ROWS * nd; R += GW_ROWS) {
+    const int ch = src(R);
+    const float xv = xin(R);
+    for (int c = lane >> 4; c < wp; c += 4) L.bufA[R * ld + c] = c < zf ? z[ch * q + c] : (c == zf ? xv : 0.0f);
+  }
   float *cur = gw_hidden(m.f, m.pack, 0, m.f.L - 1, L.bufA, L.bufB, ld, pre, nd);
   float *oth = (cur == L.bufA) ? L.bufB : L.bufA;
   const int l = m.f.L - 1;
   gx_dense<false, true>(m.pack + m.f.w[l], gw_k16(m.f, l), m.f.pad[l + 1], cur, ld, GxStore<false>{oth, ld, nullptr}, nd, m.pack + m.f.b[l], &pre, 0, 1);
   return oth;
+}
+// the wave's 16 chains at treatment values xin(row, dose), nd <= m.db doses stacked as row tiles (row 16 d + r)
+template <class XIn>
+__device__ __forceinline__ const float *gw_f_forward(const GxCausalModel &m, const GwLds &L, const float *z, XIn xin, int nd) {
+  return gw_f_rows(m, L, z, [](int R) { return R & (GW_ROWS - 1); }, [&](int R) { return xin(R & (GW_ROWS - 1), R >> 4); }, nd);
 }
 
 // log p(z | x, y, v) + const of the wave's 16 rows, z in LDS [16][q]; returned in lane r < 16 for row r.  base.py:765-817.
@@ -209,33 +215,60 @@ __global__ __launch_bounds__(GW_THREADS, 4) void gw_causal_logpost_kernel(GxCaus
 
 // Effects of one retained draw of the wave's 16 chains (latents z in LDS) -- infer_from_latent_posterior, base.py:671-763; EFFECT 1:
 // dose-response sums over the tile's valid rows into the WAVE's slot [n_keep][n_doses]; EFFECT 2: ITE [n][n_keep].  Outcome noise:
-// normals_seq(row, iteration, dose) of oracle/rng.py (tag 3), one Philox call per four doses.  skip (wave-uniform): none of the wave's
-// chains moved since the last evaluation: (mean, sd) of every dose come from e.cache -- same operations in the same order.
+// normals_seq(row, iteration, dose) of oracle/rng.py (tag 3), one Philox call per four doses.
+// Outcome-net cache (e.cache != NULL, e.eff_skip): (mean, sd) of every (dose, chain) of the tile persist in e.cache; `stale` (bits 0..15,
+// wave-uniform) names the chains that moved since their entries were formed (all 16 at a tile's first retained iteration).  Only THEIR
+// (chain, dose) pairs go through f, packed densely as the rows of as few 16-row passes as hold them -- a row of a pass depends on that
+// row's operands only, so the values are the bits a pass over all 16 chains at that dose gives; the sums then run over the cache with the
+// same noise and in the same order as without it.  At the bench's acceptance rate (0.08: 1.3 chains of 16 move per iteration) that is
+// 2-3 passes instead of 20.
 template <int EFFECT>
 __device__ __forceinline__ void gw_causal_effects(const GxCausalModel &m, const GwLds &L, const float *z, long long row0, long long n,
-                                                  long long row_base, unsigned it, long long d, const GxEffArgs &e, bool skip = false) {
-  const int lane = threadIdx.x & 63;
+                                                  long long row_base, unsigned it, long long d, const GxEffArgs &e, unsigned stale = 0xFFFFu,
+                                                  bool cached = false) {
+  const int lane = gx_lane();
   const int nd = (EFFECT == 2) ? 2 : e.n_doses;
   float ykeep = 0.0f;
   f32x4 nz = {0.0f, 0.0f, 0.0f, 0.0f};
   const bool valid = lane < GW_ROWS && row0 + lane < n;
   const unsigned rowid = (unsigned)(row_base + row0 + (lane & (GW_ROWS - 1)));
+  auto xval = [&](int k) { return (EFFECT == 2) ? (k == 0 ? 1.0f : 0.0f) : e.x_values[k]; };
+  if (cached) {
+    const int nmoved = __popc(stale & 0xFFFFu);
+    if (nmoved) {
+      int *list = reinterpret_cast<int *>(L.ssq);          // the moved chains in ascending order (the sums' slots are free outside the log posterior)
+      if (lane < GW_ROWS && ((stale >> lane) & 1u)) list[__popc(stale & ((1u << lane) - 1u))] = lane;
+      const int npairs = nmoved * nd;
+      for (int p0 = 0; p0 < npairs; p0 += GW_ROWS) {
+        const int pi = p0 + (lane & (GW_ROWS - 1));
+        const bool okp = pi < npairs;
+        const int ci = okp ? pi / nd : 0, k = okp ? pi - ci * nd : 0;
+        const int ch = list[ci];
+        const float *fo = gw_f_rows(m, L, z, [&](int) { return ch; }, [&](int) { return xval(k); }, 1);
+        if (lane < GW_ROWS && okp) {
+          const float mean = fo[lane * m.ldf];
+          const float s2y = (m.sig2_y > 0.0f) ? m.sig2_y : softplus_f(fo[lane * m.ldf + 1]) + BGM_EPS;
+          e.cache[k * GW_ROWS + ch] = make_float2(mean, __builtin_sqrtf(s2y));
+        }
+      }
+      __threadfence_block();      // the entries are read back below, by other lanes of this wave
+    }
+  }
   for (int k0 = 0; k0 < nd; k0 += m.db) {
     const int nb = min(m.db, nd - k0);
     const float *fo = nullptr;
-    if (!skip) fo = gw_f_forward(m, L, z, [&](int, int dd) { const int k = k0 + dd; return (EFFECT == 2) ? (k == 0 ? 1.0f : 0.0f) : e.x_values[k]; }, nb);
+    if (!cached) fo = gw_f_forward(m, L, z, [&](int, int dd) { return xval(k0 + dd); }, nb);
     for (int dd = 0; dd < nb; ++dd) {
       const int k = k0 + dd;
       float mean = 0.0f, sd = 0.0f;
       if (lane < GW_ROWS) {
-        if (!skip) {
+        if (!cached) {
           mean = fo[(GW_ROWS * dd + lane) * m.ldf];
           const float s2y = (m.sig2_y > 0.0f) ? m.sig2_y : softplus_f(fo[(GW_ROWS * dd + lane) * m.ldf + 1]) + BGM_EPS;
           sd = __builtin_sqrtf(s2y);
-          if (e.cache) e.cache[k * GW_ROWS + lane] = make_float2(mean, sd);
         } else {
-          const float2 c = e.cache[k * GW_ROWS + lane];
-          mean = c.x; sd = c.y;
+          const float *cp = reinterpret_cast<const float *>(e.cache + k * GW_ROWS + lane);
+          mean = __builtin_nontemporal_load(cp); sd = __builtin_nontemporal_load(cp + 1);
         }
       }
       float yv = mean;
@@ -275,7 +308,7 @@ __global__ __launch_bounds__(GW_THREADS, 4) void gw_causal_mh_kernel(GxMhArgs a)
     const long long row0 = t * GW_ROWS;
     const unsigned rowid = (unsigned)(a.row_base + row0 + r_);
     const bool rvalid = lane < GW_ROWS && row0 + lane < n;
-    bool eff_cached = false;      // e.cache holds the outcome-net values of this tile's current states
+    unsigned stale = 0xFFFFu;     // chains whose entries of e.cache are not those of their current state (all, until the tile's first retained iteration)
     float lpc = 0.0f;             // lane r < 16: log posterior of chain r's current state
     // ---- chain state
     if (a.init) {            // current_state ~ N(0, 1), base.py:842 (tag 0, iteration 0)
@@ -310,7 +343,7 @@ __global__ __launch_bounds__(GW_THREADS, 4) void gw_causal_mh_kernel(GxMhArgs a)
       }
       const unsigned long long bal = __ballot(acc && rvalid), any = __ballot(acc);
       if (a.acc_count && lane == 0 && bal) atomicAdd(&a.acc_count[it], (unsigned)__popcll(bal));
-      const bool moved = bal != 0ull;
+      stale |= (unsigned)(any & 0xFFFFull);
       if ((any >> r_) & 1ull)
         for (int c = c_; c < q; c += 4) L.zc[r_ * q + c] = L.zp[r_ * q + c];
       if (it >= a.burn_in) {
@@ -321,10 +354,10 @@ __global__ __launch_bounds__(GW_THREADS, 4) void gw_causal_mh_kernel(GxMhArgs a)
             for (int c = c_; c < q; c += 4) a.draws[(d * n + gr) * q + c] = L.zc[r_ * q + c];
         }
         if (EFFECT != 0) {
-          const bool skip = e.cache != nullptr && e.eff_skip && eff_cached && !moved;      // wave-uniform
-          gw_causal_effects<EFFECT>(m, L, L.zc, row0, n, a.row_base, (unsigned)it, d, e, skip);
-          eff_cached = true;
-          n_served += skip ? 1u : 0u;
+          const bool cached = e.cache != nullptr && e.eff_skip;
+          n_served += (cached && stale == 0u) ? 1u : 0u;          // retained tile-iterations that needed no pass of the outcome net
+          gw_causal_effects<EFFECT>(m, L, L.zc, row0, n, a.row_base, (unsigned)it, d, e, stale, cached);
+          stale = 0u;
         }
       }
     }

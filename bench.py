@@ -394,8 +394,21 @@ def end_to_end_leg(params, x, y, v, x_values, n_loc, args, use_bnn, epochs=100, 
         adrf, interval = m.predict((x, y, v), alpha=0.01, n_mcmc=args.n_mcmc, burn_in=args.burn_in, x_values=x_values, q_sd=1.0, sample_y=True,
                                    verbose=0, **({"bs": 10000} if use_bnn else {}))
         torch.cuda.synchronize(); t["predict"] = time.perf_counter() - t0
+        x3 = None
+        if use_bnn:      # the same predict (same seeds) with the sampling kernels in split precision (params['mh_precision'] = 'f16x3')
+            m.engine.set_precision("f16x3")
+            m._seed_counter = 0
+            t0 = time.perf_counter()
+            adrf3, _ = m.predict((x, y, v), alpha=0.01, n_mcmc=args.n_mcmc, burn_in=args.burn_in, x_values=x_values, q_sd=1.0, sample_y=True, verbose=0, bs=10000)
+            torch.cuda.synchronize(); dt3 = time.perf_counter() - t0
+            m.engine.set_precision("fp32")
+            x3 = {"predict_seconds": dt3, "predict_transitions_per_s": n_loc * (args.burn_in + args.n_mcmc) / dt3, "acceptance_rate": m.last_acceptance_rate,
+                  "adrf_max_abs_diff_vs_fp32": float(np.max(np.abs(np.asarray(adrf3) - np.asarray(adrf))))}
     truth = get_ADRF(x_values=list(x_values), dataset="Imbens")
     err = np.asarray(adrf) - truth
+    if x3 is not None:
+        e3 = np.asarray(adrf3) - truth
+        x3["adrf_rmse"] = float(np.sqrt(np.mean(e3 ** 2))); x3["average_effect_abs_error"] = float(abs(e3.mean()))
     n_mb = (epochs + 1) * ((n_loc + 31) // 32)
     fit_loop = t["fit_total"] - t.get("egm_init", 0.0)
     out = {"model": "CausalBGM(use_bnn=%s)" % use_bnn, "rows": n_loc, "epochs": epochs, "egm_iterations": 30000,
@@ -407,6 +420,8 @@ def end_to_end_leg(params, x, y, v, x_values, n_loc, args, use_bnn, epochs=100, 
            "sample": "fit((x, y, v), epochs=%d, epochs_per_eval=5, batch_size=32, use_egm_init=True, egm_n_iter=30000) + predict(n_mcmc=%d, burn_in=%d, "
                      "20 doses) on the bench panel itself (N=%d, p=%d); epochs + 1 passes as the reference loops range(epochs + 1) (base.py:488)"
                      % (epochs, args.n_mcmc, args.burn_in, n_loc, args.p)}
+    if x3 is not None:
+        out["predict_f16x3"] = x3
     return out, m
 
 
