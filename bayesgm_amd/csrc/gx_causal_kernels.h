@@ -112,13 +112,13 @@ __device__ __forceinline__ void gx_stage(float *buf, int ld, int width_pad, Src 
   }
 }
 
-// f at treatment values xin(row, dose) for the latents z (LDS [32][q]) -> fo[dose * 64 + 2 * row] = (mu_y, raw_y); nd <= m.db doses per call,
-// their rows stacked in the activation buffers (row 32 d + r, stride m.ldf).  Collective; ends after a barrier.
-template <class XIn>
-__device__ __forceinline__ void gx_f_forward(const GxCausalModel &m, const GxLds &L, const float *z, XIn xin, int nd = 1) {
-  const int zf = m.z0 + m.z1, q = m.q, ld = m.ldf, rows = GX_ROWS * nd, nrt = 2 * nd;
+// f on `rows` rows (a multiple of 16) of the activation buffers: row R is the latent of chain src(R) (LDS [32][q]) at treatment value xv(R)
+// -> fo[2 R] = (mu_y, raw_y).  Collective; ends after a barrier.
+template <class Src, class XV>
+__device__ __forceinline__ void gx_f_rows(const GxCausalModel &m, const GxLds &L, const float *z, Src src, XV xv, int rows) {
+  const int zf = m.z0 + m.z1, q = m.q, ld = m.ldf, nrt = rows >> 4;
   GxPre pre = gx_prefetch(m.pack + m.f.w[0], m.f.pad[1], m.f.pad[1], m.pack + m.f.b[0], nrt);
-  gx_stage(L.bufA, ld, m.f.pad[0], [&](int r, int c) { return c < zf ? z[(r & (GX_ROWS - 1)) * q + c] : (c == zf ? xin(r & (GX_ROWS - 1), r / GX_ROWS) : 0.0f); }, rows);
+  gx_stage(L.bufA, ld, m.f.pad[0], [&](int r, int c) { return c < zf ? z[src(r) * q + c] : (c == zf ? xv(r) : 0.0f); }, rows);
   __syncthreads();
   float *cur = gx_hidden(m.f, m.pack, 0, m.f.L - 1, L.bufA, L.bufB, ld, pre, nrt, nrt);
   float *oth = (cur == L.bufA) ? L.bufB : L.bufA;
@@ -127,6 +127,11 @@ __device__ __forceinline__ void gx_f_forward(const GxCausalModel &m, const GxLds
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * rows; i += GX_THREADS) L.fo[i] = oth[(i >> 1) * ld + (i & 1)];
   __syncthreads();
+}
+// f at treatment values xin(row, dose) for the tile's 32 latents; nd <= m.db doses per call, their rows stacked (row 32 d + r)
+template <class XIn>
+__device__ __forceinline__ void gx_f_forward(const GxCausalModel &m, const GxLds &L, const float *z, XIn xin, int nd = 1) {
+  gx_f_rows(m, L, z, [](int r) { return r & (GX_ROWS - 1); }, [&](int r) { return xin(r & (GX_ROWS - 1), r / GX_ROWS); }, GX_ROWS * nd);
 }
 
 // log p(z | x, y, v) + const for the tile's 32 rows, z in LDS [32][q]; result in L.lpn[row].  base.py:765-817.
@@ -245,30 +250,59 @@ struct GxEffArgs {
   unsigned long long *stats;   // [0] += retained tile-iterations served from the cache (2 row tiles per workgroup), or NULL
 };
 
-// skip (block-uniform): the chains of the workgroup did not move since the last evaluation: (mean, sd) of every dose come from e.cache
-// and only the outcome noise is new -- same operations in the same order, bit-identical sums.
+// Outcome-net cache (cached, block-uniform: e.cache != NULL and e.eff_skip): (mean, sd) of every (dose, chain) persist in e.cache; `stale`
+// (bit r: chain r moved since its entries were formed; all 32 at a tile's first retained iteration) names the chains whose (chain, dose)
+// pairs go through f -- packed densely as the rows of as few passes of 32 m.db rows as hold them.  A row of a pass depends on its own
+// operands only: the entries are the bits a pass over all chains at that dose gives, and the sums below run over the cache with the same
+// noise in the same order as without it (see gw_kernels.h, whose wave-local form this is).
 template <int EFFECT>
 __device__ __forceinline__ void gx_causal_effects(const GxCausalModel &m, const GxLds &L, const float *z, long long row0, long long n,
-                                                  long long row_base, unsigned it, long long d, const GxEffArgs &e, bool skip = false) {
+                                                  long long row_base, unsigned it, long long d, const GxEffArgs &e, unsigned stale = 0xFFFFFFFFu,
+                                                  bool cached = false) {
   const int nd = (EFFECT == 2) ? 2 : e.n_doses;
   float ykeep = 0.0f;        // EFFECT 2: y(x = 1) of thread `row`
+  auto xval = [&](int k) { return (EFFECT == 2) ? (k == 0 ? 1.0f : 0.0f) : e.x_values[k]; };
+  if (cached) {
+    const int nmoved = __popc(stale);
+    if (nmoved) {
+      int *list = reinterpret_cast<int *>(L.ssep);        // the moved chains in ascending order (the likelihood's partial sums are free here)
+      if (threadIdx.x < GX_ROWS && ((stale >> threadIdx.x) & 1u)) list[__popc(stale & ((1u << threadIdx.x) - 1u))] = threadIdx.x;
+      __syncthreads();
+      const int npairs = nmoved * nd, cap = GX_ROWS * m.db;
+      for (int p0 = 0; p0 < npairs; p0 += cap) {
+        const int rows = min(cap, (npairs - p0 + 15) & ~15);
+        gx_f_rows(m, L, z, [&](int r) { const int pi = min(p0 + r, npairs - 1); return list[pi / nd]; },
+                  [&](int r) { const int pi = min(p0 + r, npairs - 1); return xval(pi % nd); }, rows);
+        for (int r = threadIdx.x; r < rows; r += GX_THREADS) {
+          const int pi = p0 + r;
+          if (pi < npairs) {
+            const int ci = pi / nd, k = pi - ci * nd;
+            const float s2y = (m.sig2_y > 0.0f) ? m.sig2_y : softplus_f(L.fo[2 * r + 1]) + BGM_EPS;
+            e.cache[k * GX_ROWS + list[ci]] = make_float2(L.fo[2 * r], __builtin_sqrtf(s2y));
+          }
+        }
+        __syncthreads();
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+  }
   for (int k0 = 0; k0 < nd; k0 += m.db) {
     const int nb = min(m.db, nd - k0);
-    if (!skip) gx_f_forward(m, L, z, [&](int, int dd) { const int k = k0 + dd; return (EFFECT == 2) ? (k == 0 ? 1.0f : 0.0f) : e.x_values[k]; }, nb);
+    if (!cached) gx_f_forward(m, L, z, [&](int, int dd) { return xval(k0 + dd); }, nb);
     if (threadIdx.x < GX_ROWS) {
       const int r = threadIdx.x;
       const bool valid = row0 + r < n;
       for (int dd = 0; dd < nb; ++dd) {
         const int k = k0 + dd;
         float mean, sd;
-        if (!skip) {
+        if (!cached) {
           mean = L.fo[2 * (GX_ROWS * dd + r)];
           const float s2y = (m.sig2_y > 0.0f) ? m.sig2_y : softplus_f(L.fo[2 * (GX_ROWS * dd + r) + 1]) + BGM_EPS;
           sd = __builtin_sqrtf(s2y);
-          if (e.cache) e.cache[k * GX_ROWS + r] = make_float2(mean, sd);
         } else {
-          const float2 c = e.cache[k * GX_ROWS + r];
-          mean = c.x; sd = c.y;
+          const float *cp = reinterpret_cast<const float *>(e.cache + k * GX_ROWS + r);
+          mean = __builtin_nontemporal_load(cp); sd = __builtin_nontemporal_load(cp + 1);
         }
         float yv = mean;
         if (e.sample_y) {
@@ -321,7 +355,7 @@ __global__ __launch_bounds__(GX_THREADS) void gx_causal_mh_kernel(GxMhArgs a) {
   const int ncall = (q + 15) >> 4;            // Philox calls per lane group: features 16 t + 4 e + g  <-  call g + 4 t, output e
   for (long long t = blockIdx.x; t < tiles; t += gridDim.x) {
     const long long row0 = t * GX_ROWS;
-    bool eff_cached = false;      // e.cache holds the outcome-net values of this tile's current states
+    unsigned stale = 0xFFFFFFFFu; // chains whose entries of e.cache are not those of their current state (all, until the tile's first retained iteration)
     // ---- chain state
     if (a.init) {            // current_state ~ N(0, 1), base.py:842 (tag 0, iteration 0)
       for (int i = threadIdx.x; i < GX_ROWS * 4 * ncall; i += GX_THREADS) {
@@ -367,10 +401,11 @@ __global__ __launch_bounds__(GX_THREADS) void gx_causal_mh_kernel(GxMhArgs a) {
         }
         const unsigned long long bal = __ballot(acc && (row0 + r < n) && threadIdx.x < GX_ROWS);
         if (a.acc_count && threadIdx.x == 0) atomicAdd(&a.acc_count[it], (unsigned)__popcll(bal));
-        if (threadIdx.x == 0) L.red[GX_ROWS] = bal != 0ull ? 1.0f : 0.0f;        // did any chain of the workgroup move?
+        const unsigned long long any = __ballot(acc && threadIdx.x < GX_ROWS);
+        if (threadIdx.x == 0) { L.red[GX_ROWS] = bal != 0ull ? 1.0f : 0.0f; reinterpret_cast<unsigned *>(L.red)[GX_ROWS + 1] = (unsigned)any; }      // which chains moved
       }
       __syncthreads();
-      const bool moved = L.red[GX_ROWS] != 0.0f;
+      stale |= reinterpret_cast<const unsigned *>(L.red)[GX_ROWS + 1];
       for (int i = threadIdx.x; i < GX_ROWS * q; i += GX_THREADS)
         if (L.red[i / q] != 0.0f) L.zc[i] = L.zp[i];
       __syncthreads();
@@ -384,10 +419,10 @@ __global__ __launch_bounds__(GX_THREADS) void gx_causal_mh_kernel(GxMhArgs a) {
           }
         }
         if (EFFECT != 0) {
-          const bool skip = e.cache != nullptr && e.eff_skip && eff_cached && !moved;      // block-uniform
-          gx_causal_effects<EFFECT>(m, L, L.zc, row0, n, a.row_base, (unsigned)it, d, e, skip);
-          eff_cached = true;
-          n_served += skip ? 2u : 0u;
+          const bool cached = e.cache != nullptr && e.eff_skip;      // block-uniform
+          n_served += (cached && stale == 0u) ? 2u : 0u;            // retained tile-iterations (2 row tiles) that needed no pass of the outcome net
+          gx_causal_effects<EFFECT>(m, L, L.zc, row0, n, a.row_base, (unsigned)it, d, e, stale, cached);
+          stale = 0u;
         }
         GX_PC(8);
       }

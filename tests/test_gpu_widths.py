@@ -175,10 +175,12 @@ def test_mh_chain_and_effects_match_oracle(case):
     assert np.abs(alone - ref_eff).max() <= 5e-4
 
 
-@pytest.mark.parametrize("shape,binary", [("r_test", False), ("w128", False), ("mixed", True)])
+@pytest.mark.parametrize("shape,binary", [("r_test", False), ("w128", False), ("mixed", True), ("w256", False), ("w256", True)])
 def test_outcome_cache_on_the_general_width_engine_is_bit_identical(shape, binary):
-    """bgm_causal_set_outcome_cache on the general-width engine (gx_causal_mh_kernel: a workgroup of 32 chains reuses the outcome net's
-    (mean, sd) when none of them moved): effects, chains and acceptance counts equal to the last bit with the cache on and off."""
+    """bgm_causal_set_outcome_cache on the general-width engine: only the (chain, dose) pairs of the chains that moved since their cached
+    (mean, sd) were formed go through the outcome net, packed densely into row passes (gw_kernels.h: per wave of 16 chains, hidden widths
+    up to 128; gx_causal_kernels.h: per workgroup of 32 chains, w256): effects, chains and acceptance counts equal to the last bit with
+    the cache on and off."""
     from bayesgm_amd import _lib
     u = SHAPES[shape]
     m = _model(31, [2, 2, 2, 6], 60, binary, **u)
