@@ -72,8 +72,15 @@ struct GwGLastEpi {
     for (int r = 0; r < 4; ++r) {
       long long gr = row0 + 4 * g + r; gr = gr < n ? gr : n - 1;
       const float *vr = v + gr * (long long)p;
-      vn[r][0] = (c0 < p) ? vr[c0] : 0.0f;
-      vn[r][1] = (c0 + 1 < p) ? vr[c0 + 1] : 0.0f;
+      // unconditional requests at clamped columns (a request under a lane condition is an exec-mask branch around it, eight per unit);
+      // the epilogue masks the columns >= p.  p even: the lane's two columns are one aligned 8-byte request
+      if ((p & 1) == 0) {
+        const f32x2 t = *reinterpret_cast<const f32x2 *>(vr + min(c0, p - 2));
+        vn[r][0] = t[0]; vn[r][1] = t[1];
+      } else {
+        vn[r][0] = vr[min(c0, p - 1)];
+        vn[r][1] = vr[min(c0 + 1, p - 1)];
+      }
     }
   }
   __device__ __forceinline__ void rotate() {
@@ -103,7 +110,10 @@ __device__ __forceinline__ const float *gw_f_rows(const GxCausalModel &m, const 
   for (int R = lane & (GW_ROWS - 1); R < GW_ROWS * nd; R += GW_ROWS) {
     const int ch = src(R);
     const float xv = xin(R);
-    for (int c = lane >> 4; c < wp; c += 4) L.bufA[R * ld + c] = c < zf ? z[ch * q + c] : (c == zf ? xv : 0.0f);
+    for (int c = lane >> 4; c < wp; c += 4) {
+      const float zc_ = z[ch * q + min(c, q - 1)];          // unconditional read, then select (no exec-mask branch)
+      L.bufA[R * ld + c] = c < zf ? zc_ : (c == zf ? xv : 0.0f);
+    }
   }
   float *cur = gw_hidden(m.f, m.pack, 0, m.f.L - 1, L.bufA, L.bufB, ld, pre, nd);
   float *oth = (cur == L.bufA) ? L.bufB : L.bufA;
@@ -125,9 +135,11 @@ __device__ __forceinline__ float gw_causal_logp(const GxCausalModel &m, const Gw
   {
     GxPre pre = gx_prefetch<true>(m.pack + m.g.w[0], m.g.pad[1], m.g.pad[1], m.pack + m.g.b[0], 1, 0, gw_k16(m.g, 0));
     const int wp = m.g.pad[0];
-    for (int c = lane; c < wp; c += 64)
-#pragma nounroll
-      for (int r = 0; r < GW_ROWS; ++r) L.bufA[r * ld + c] = c < q ? z[r * q + c] : 0.0f;
+    for (int c = lane >> 4; c < wp; c += 4) {          // lane (r = lane & 15, c = lane >> 4, + 4, ...)
+      const int r = lane & (GW_ROWS - 1);
+      const float zc_ = z[r * q + min(c, q - 1)];
+      L.bufA[r * ld + c] = c < q ? zc_ : 0.0f;
+    }
     float *cur = gw_hidden(m.g, m.pack, 0, m.g.L - 1, L.bufA, L.bufB, ld, pre, 1);
     const int l = m.g.L - 1;
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -151,9 +163,11 @@ __device__ __forceinline__ float gw_causal_logp(const GxCausalModel &m, const Gw
   {
     const int z0 = m.z0, z1 = m.z1, z2 = m.z2, wp = m.h.pad[0];
     GxPre ph = gx_prefetch<true>(m.pack + m.h.w[0], m.h.pad[1], m.h.pad[1], m.pack + m.h.b[0], 1, 0, gw_k16(m.h, 0));
-    for (int c = lane; c < wp; c += 64)
-#pragma nounroll
-      for (int r = 0; r < GW_ROWS; ++r) L.bufA[r * ld + c] = c < z0 ? z[r * q + c] : (c < z0 + z2 ? z[r * q + z1 + c] : 0.0f);
+    for (int c = lane >> 4; c < wp; c += 4) {
+      const int r = lane & (GW_ROWS - 1);
+      const float zc_ = z[r * q + min(c < z0 ? c : z1 + c, q - 1)];
+      L.bufA[r * ld + c] = c < z0 + z2 ? zc_ : 0.0f;
+    }
     float *cur = gw_hidden(m.h, m.pack, 0, m.h.L - 1, L.bufA, L.bufB, ld, ph, 1);
     float *oth = (cur == L.bufA) ? L.bufB : L.bufA;
     const int l = m.h.L - 1;

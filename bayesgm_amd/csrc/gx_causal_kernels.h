@@ -79,8 +79,15 @@ struct GxGLastEpi {
     for (int r = 0; r < 4; ++r) {
       long long gr = row0 + 16 * rt + 4 * g + r; gr = gr < n ? gr : n - 1;
       const float *vr = v + gr * (long long)p;
-      vn[r][0] = (c0 < p) ? vr[c0] : 0.0f;
-      vn[r][1] = (c0 + 1 < p) ? vr[c0 + 1] : 0.0f;
+      // unconditional requests at clamped columns (a request under a lane condition is an exec-mask branch around it, eight per unit);
+      // the epilogue masks the columns >= p.  p even: the lane's two columns are one aligned 8-byte request
+      if ((p & 1) == 0) {
+        const f32x2 t = *reinterpret_cast<const f32x2 *>(vr + min(c0, p - 2));
+        vn[r][0] = t[0]; vn[r][1] = t[1];
+      } else {
+        vn[r][0] = vr[min(c0, p - 1)];
+        vn[r][1] = vr[min(c0 + 1, p - 1)];
+      }
     }
   }
   __device__ __forceinline__ void rotate() {
