@@ -22,6 +22,16 @@ struct BnnFitChain {
   // bgm_bnn_fit_epoch, device-side ordering (fit_sync.h) of the next launches: the gradient-tile kernel (waits for the previous latent
   // phase, counts the Adam step done), the latent phase's noise kernel (waits for the Adam step), its row-update kernel (counts it done)
   FitSync sync_dw{}, sync_zn{}, sync_zr{};
+  // bgm_bnn_fit_epoch, noise off the critical path (EcbRider / EcbAhead, egm_chain_bnn.h): both workspaces exist twice (a phase reads one
+  // while riders fill the other); `rider` / `ahead` are what the next theta launch carries, `theta_prepared` / `z_prepared`: the next
+  // theta / latent phase finds its noise in its workspace (no noise launch)
+  float *ws_ring[2] = {nullptr, nullptr}, *ws_z_ring[2] = {nullptr, nullptr};
+  size_t ws_floats = 0;
+  int kl_cnt_off = 0;
+  int dw_t[4] = {0, 0, 0, 0}, dw_z[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};      // EcbAhead: perturbation offsets of each net's calls
+  EcbRider rider{};
+  EcbAhead ahead{};
+  bool riders_on = false, theta_prepared = false, z_prepared = false;
 };
 template <bool KL>
 static __global__ __launch_bounds__(BNN_THREADS) void bnn_fit_noise_kernel(BnnArgs a, const EcbTab *tab, float *ws, FitSync sy) {
@@ -34,26 +44,34 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_fit_noise_kernel(BnnAr
     ecb_kl_partial(a.theta, a.net[tab->c[c].net], ws + tab->klp + blockIdx.x, part, ECB_NOISE_PARTS, red);
   }
 }
+// rd.kl_cnt != NULL: workgroups blockIdx.y >= 3 are riders (ecb_rider), two per grid row
 template <int NTL, int NB, bool PAD = false, int T0 = 1, bool WS = false>
-static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_chain_kernel(BnnArgs a, const EcbTab *tab, float *ws) {
+static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_chain_kernel(BnnArgs a, const EcbTab *tab, float *ws, EcbRider rd) {
   extern __shared__ __attribute__((aligned(16))) float bnn_chain_lds[];
-  ecb_theta_chain<BnnArgs, 4, NTL, 4, 2, 1, NB, PAD, T0, WS>(a, *tab, ws, bnn_chain_lds);
+  if (blockIdx.y >= 3) {
+    ecb_rider<BnnArgs>(a, *tab, ws, rd, 2 * ((int)blockIdx.y - 3) + (int)blockIdx.x, bnn_chain_lds);
+    return;
+  }
+  ecb_theta_chain<BnnArgs, 4, NTL, 4, 2, 1, NB, PAD, T0, WS>(a, *tab, ws, bnn_chain_lds, rd.kl_cnt);
 }
 template <int NB>
-static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_dw_kernel(BnnArgs a, const EcbTab *tab, const int *tiles, const float *ws, FitSync sy) {
+static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_dw_kernel(BnnArgs a, const EcbTab *tab, const int *tiles, const float *ws, FitSync sy,
+                                                                       EcbAhead ah) {
   fit_sync_wait(sy);
-  ecb_theta_dw<BnnArgs, NB>(a, *tab, tiles, ws);
+  ecb_theta_dw<BnnArgs, NB>(a, *tab, tiles, ws, ah);
   fit_sync_done(sy);
 }
 template <int NTL, int NB, bool PAD = false, int T0 = 1, bool WS = false>
-static __global__ __launch_bounds__(BNN_THREADS) void bnn_z_chain_kernel(BnnArgs a, const EcbTab *tab, float *ws) {
+static __global__ __launch_bounds__(BNN_THREADS) void bnn_z_chain_kernel(BnnArgs a, const EcbTab *tab, float *ws, FitSync sy) {
   extern __shared__ __attribute__((aligned(16))) float bnn_chain_lds[];
+  fit_sync_wait(sy);              // (noise prepared ahead: the wait for the Adam step the noise launch otherwise carries)
   ecb_z_chain<BnnArgs, 4, NTL, 4, 2, 1, NB, PAD, T0, WS>(a, *tab, ws, bnn_chain_lds);
 }
 static void bnn_chain_free(BnnState *s) {
   BnnFitChain *c = static_cast<BnnFitChain *>(s->chain);
   if (!c) return;
-  for (void *p : {(void *)c->tab_theta, (void *)c->tab_z, (void *)c->tiles_theta, (void *)c->ws, (void *)c->ws_z})
+  for (void *p : {(void *)c->tab_theta, (void *)c->tab_z, (void *)c->tiles_theta, (void *)c->ws_ring[0], (void *)c->ws_z_ring[0], (void *)c->ws_ring[1],
+                  (void *)c->ws_z_ring[1]})
     if (p) hipFree(p);
   delete c;
   s->chain = nullptr;
@@ -77,10 +95,19 @@ static int bnn_chain_setup(BnnState *s) {
   const size_t w2 = ecb_build_tab(s->net, znet, zso, 6, B, ntl, tz, none, trained, 0);
   c->n_tiles = tt.n_tiles;
   const size_t wsf = std::max(w1, w2) + 64;
-  BGM_HIP_CHECK(hipMalloc((void **)&c->ws, sizeof(float) * wsf));
-  BGM_HIP_CHECK(hipMemset(c->ws, 0, sizeof(float) * wsf));
-  BGM_HIP_CHECK(hipMalloc((void **)&c->ws_z, sizeof(float) * wsf));
-  BGM_HIP_CHECK(hipMemset(c->ws_z, 0, sizeof(float) * wsf));
+  for (int r = 0; r < 2; ++r) {
+    BGM_HIP_CHECK(hipMalloc((void **)&c->ws_ring[r], sizeof(float) * wsf));
+    BGM_HIP_CHECK(hipMemset(c->ws_ring[r], 0, sizeof(float) * wsf));
+    BGM_HIP_CHECK(hipMalloc((void **)&c->ws_z_ring[r], sizeof(float) * wsf));
+    BGM_HIP_CHECK(hipMemset(c->ws_z_ring[r], 0, sizeof(float) * wsf));
+  }
+  c->ws = c->ws_ring[0]; c->ws_z = c->ws_z_ring[0];
+  c->ws_floats = wsf;
+  for (int k = 0; k < 4; ++k) {
+    if (tt.net_ncalls[k] > 0) c->dw_t[k] = tt.c[tt.net_calls[k][0]].dW;
+    for (int cc = 0; cc < tz.net_ncalls[k] && cc < 2; ++cc) c->dw_z[k][cc] = tz.c[tz.net_calls[k][cc]].dW;
+  }
+  c->kl_cnt_off = tt.klp + 3 * ECB_NOISE_PARTS + 4;          // (a word of the 16 spare ones behind the KL partial sums)
   BGM_HIP_CHECK(hipMalloc((void **)&c->tab_theta, sizeof(EcbTab)));
   BGM_HIP_CHECK(hipMalloc((void **)&c->tab_z, sizeof(EcbTab)));
   BGM_HIP_CHECK(hipMemcpy(c->tab_theta, &tt, sizeof(EcbTab), hipMemcpyHostToDevice));
@@ -262,6 +289,7 @@ static void bnn_theta_launch(BnnState *s, BnnArgs &a, int batch, int parts, hipS
   BnnFitChain *fc = static_cast<BnnFitChain *>(s->chain);
   if (fc && (batch == 32 || (batch == 16 && !fc->pad))) {
     if (parts & 1) {
+    if (!fc->theta_prepared)
     hipLaunchKernelGGL(bnn_fit_noise_kernel<true>, dim3(3 * ECB_NOISE_PARTS), dim3(BNN_THREADS), 0, st, a, fc->tab_theta, fc->ws, FitSync{});
     auto kc = fc->t0 == 2 ? bnn_theta_chain_kernel<13, 2, true, 2> : fc->pad ? bnn_theta_chain_kernel<13, 2, true>
               : batch == 32 ? (fc->ntl == 13 ? bnn_theta_chain_kernel<13, 2> : bnn_theta_chain_kernel<7, 2>)
@@ -271,17 +299,19 @@ static void bnn_theta_launch(BnnState *s, BnnArgs &a, int batch, int parts, hipS
       static const bool no_ws = std::getenv("BGM_FIT_NO_WORKERS") != nullptr;
       if (no_ws) {
         auto ks = fc->ntl == 13 ? bnn_theta_chain_kernel<13, 1> : bnn_theta_chain_kernel<7, 1>;
-        hipLaunchKernelGGL(ks, dim3(2, 3), dim3(BNN_THREADS), 64 * sizeof(float), st, a, fc->tab_theta, fc->ws);
-      } else {      // g's last layer over the idle waves of its workgroup (ecb_theta_chain<WS>)
+        hipLaunchKernelGGL(ks, dim3(2, 3), dim3(BNN_THREADS), 64 * sizeof(float), st, a, fc->tab_theta, fc->ws, EcbRider{});
+      } else {      // g's last layer over the idle waves of its workgroup (ecb_theta_chain<WS>); bgm_bnn_fit_epoch: + the rider workgroups
         auto ks = fc->ntl == 13 ? bnn_theta_chain_kernel<13, 1, false, 1, true> : bnn_theta_chain_kernel<7, 1, false, 1, true>;
-        hipLaunchKernelGGL(ks, dim3(2, 3), dim3(BNN_THREADS), ECB_WS_LDS_FLOATS * sizeof(float), st, a, fc->tab_theta, fc->ws);
+        hipLaunchKernelGGL(ks, dim3(2, fc->riders_on ? 3 + ECB_RIDERS / 2 : 3), dim3(BNN_THREADS), ECB_WS_LDS_FLOATS * sizeof(float), st, a, fc->tab_theta,
+                           fc->ws, fc->riders_on ? fc->rider : EcbRider{});
       }
     } else
-      hipLaunchKernelGGL(kc, dim3(1), dim3(BNN_THREADS), 64 * sizeof(float), st, a, fc->tab_theta, fc->ws);
+      hipLaunchKernelGGL(kc, dim3(1), dim3(BNN_THREADS), 64 * sizeof(float), st, a, fc->tab_theta, fc->ws, EcbRider{});
     }
     if (parts & 2) {
     auto kd = batch == 32 ? bnn_theta_dw_kernel<2> : bnn_theta_dw_kernel<1>;
-    hipLaunchKernelGGL(kd, dim3((fc->n_tiles + ECH_WAVES - 1) / ECH_WAVES + 1), dim3(BNN_THREADS), 0, st, a, fc->tab_theta, fc->tiles_theta, fc->ws, fc->sync_dw);
+    hipLaunchKernelGGL(kd, dim3((fc->n_tiles + ECH_WAVES - 1) / ECH_WAVES + 1), dim3(BNN_THREADS), 0, st, a, fc->tab_theta, fc->tiles_theta, fc->ws, fc->sync_dw,
+                       fc->riders_on ? fc->ahead : EcbAhead{});
     }
   } else if (parts & 2) {          // (the phase machine is one launch: it runs at the point of the parameter write)
     hipLaunchKernelGGL(bnn_theta_step_kernel, dim3(3), dim3(BNN_THREADS), 0, st, a);
@@ -353,6 +383,8 @@ extern "C" int bgm_bnn_z_step(bgm_handle *h, const float *x, const float *y, con
   a.out = out; a.dz = dz_out ? dz_out : s->dz_dev;
   BnnFitChain *fc = static_cast<BnnFitChain *>(s->chain);
   if (fc && (batch == 32 || (batch == 16 && !fc->pad))) {
+    const FitSync zsy = fc->z_prepared ? fc->sync_zn : FitSync{};      // (prepared noise: the chain kernel itself waits for the Adam step)
+    if (!fc->z_prepared)
     hipLaunchKernelGGL(bnn_fit_noise_kernel<false>, dim3(6 * ECB_NOISE_PARTS), dim3(BNN_THREADS), 0, stream, a, fc->tab_z, fc->ws_z, fc->sync_zn);
     auto kc = fc->t0 == 2 ? bnn_z_chain_kernel<13, 2, true, 2> : fc->pad ? bnn_z_chain_kernel<13, 2, true>
               : batch == 32 ? (fc->ntl == 13 ? bnn_z_chain_kernel<13, 2> : bnn_z_chain_kernel<7, 2>)
@@ -363,14 +395,14 @@ extern "C" int bgm_bnn_z_step(bgm_handle *h, const float *x, const float *y, con
       static const bool no_ws = std::getenv("BGM_FIT_NO_WORKERS") != nullptr;
       if (no_ws) {
         auto ks = fc->ntl == 13 ? bnn_z_chain_kernel<13, 1> : bnn_z_chain_kernel<7, 1>;
-        hipLaunchKernelGGL(ks, dim3(2), dim3(BNN_THREADS), lds_z, stream, a, fc->tab_z, fc->ws_z);
+        hipLaunchKernelGGL(ks, dim3(2), dim3(BNN_THREADS), lds_z, stream, a, fc->tab_z, fc->ws_z, zsy);
       } else {      // the mean call's last layer over the idle waves, the variance-head call on its one column (ecb_z_chain<WS>)
         auto ks = fc->ntl == 13 ? bnn_z_chain_kernel<13, 1, false, 1, true> : bnn_z_chain_kernel<7, 1, false, 1, true>;
         const size_t lds_ws = (32 + 2 * 16 + 4 * 16 * 16 + 2 * 1024 + 64 + 4 * 1024 + 8) * sizeof(float);
-        hipLaunchKernelGGL(ks, dim3(2), dim3(BNN_THREADS), std::max(lds_z, lds_ws), stream, a, fc->tab_z, fc->ws_z);
+        hipLaunchKernelGGL(ks, dim3(2), dim3(BNN_THREADS), std::max(lds_z, lds_ws), stream, a, fc->tab_z, fc->ws_z, zsy);
       }
     } else
-      hipLaunchKernelGGL(kc, dim3(1), dim3(BNN_THREADS), lds_z, stream, a, fc->tab_z, fc->ws_z);
+      hipLaunchKernelGGL(kc, dim3(1), dim3(BNN_THREADS), lds_z, stream, a, fc->tab_z, fc->ws_z, zsy);
   } else {
     hipLaunchKernelGGL(bnn_z_grad_kernel, dim3(3), dim3(BNN_THREADS), 0, stream, a);
     hipLaunchKernelGGL(bnn_z_combine_kernel, dim3((batch * s->q + 255) / 256), dim3(256), 0, stream, a.dz_part, a.loss_part, a.dz, out, batch * s->q);
@@ -507,6 +539,10 @@ extern "C" int bgm_bnn_fit_epoch(bgm_handle *h, const float *x, const float *y, 
     if (h->epoch_flags_ok < 0) flags = false;      // (a profiler serialising kernels, one hardware queue): HIP events
   }
   int *err = flags ? (int *)(h->epoch_ctr + 2) : nullptr;
+  static const bool no_ahead = std::getenv("BGM_BNN_NO_AHEAD") != nullptr;
+  static const bool one_wg_env = std::getenv("BGM_FIT_ONE_WG") != nullptr, no_ws_env = std::getenv("BGM_FIT_NO_WORKERS") != nullptr;
+  const bool ahead_ok = flags && !no_ahead && fc && batch == 32 && !fc->pad && fc->t0 == 1 && !one_wg_env && !no_ws_env && lazy != 0;
+  if (fc) { fc->theta_prepared = fc->z_prepared = fc->riders_on = false; }
   const int q = s->q;
   const unsigned dw_blocks = fc ? (unsigned)((fc->n_tiles + ECH_WAVES - 1) / ECH_WAVES + 1) : 0, zr_blocks = (unsigned)((batch * q + 255) / 256);
   auto rows_of = [&](int64_t i) { return (int)std::max<int64_t>(0, std::min<int64_t>(batch, n_use - i)); };
@@ -522,6 +558,7 @@ extern "C" int bgm_bnn_fit_epoch(bgm_handle *h, const float *x, const float *y, 
   // an error exit: nothing stays in flight on the private stream, and the rows replayed ahead without their latent step count as
   // current to the step they were brought to (minibatch j -> tz0 + j), so that the caller's flush does not replay them twice
   auto fail = [&](int rc_) -> int {
+    if (fc) fc->theta_prepared = fc->z_prepared = fc->riders_on = false;
     if (overlap) hipStreamSynchronize(sB);
     if (lazy == 2 && flags && s->tlast_dev)
       for (long long j = k; j < replayed_to; ++j) {
@@ -553,12 +590,30 @@ extern "C" int bgm_bnn_fit_epoch(bgm_handle *h, const float *x, const float *y, 
     a.data_z = data_z; a.idx = idx; a.x_ = x; a.y_ = y; a.v_ = v; a.apply = 1; a.out = out_t;
     s->t_theta += 1;
     a.adam = BnnAdam{adam_lr_t(lr_theta, s->t_theta), BNN_ADAM_B1, BNN_ADAM_B2, BNN_ADAM_EPS};
+    // noise ahead (EcbRider): this minibatch's theta launch prepares the noise of its own latent phase and of the next theta phase
+    const bool ride = ov && ahead_ok;
+    if (ride) {
+      const bool next_full = i + batch < n_use && rows_of(i + batch) == batch;
+      fc->ws = fc->ws_ring[k & 1]; fc->ws_z = fc->ws_z_ring[k & 1];
+      float *ws_next = next_full ? fc->ws_ring[(k + 1) & 1] : nullptr;
+      unsigned *kl_cnt = reinterpret_cast<unsigned *>(fc->ws + fc->kl_cnt_off);
+      fc->rider = EcbRider{ws_next, stream_id0 + (uint32_t)(3 * (k + 1)), fc->tab_z, fc->ws_z, s0 + 1, kl_cnt};
+      fc->ahead = EcbAhead{ws_next, fc->tab_z, fc->ws_z, {0, 0, 0, 0}, {{0, 0}, {0, 0}, {0, 0}, {0, 0}}, next_full ? out_t : nullptr, out_z, kl_cnt};
+      for (int kk = 0; kk < 4; ++kk) { fc->ahead.dw_t[kk] = fc->dw_t[kk]; fc->ahead.dw_z[kk][0] = fc->dw_z[kk][0]; fc->ahead.dw_z[kk][1] = fc->dw_z[kk][1]; }
+      fc->riders_on = true;
+    }
     bnn_theta_launch(s, a, b, 1, sA);
+    if (fc) fc->theta_prepared = false;
     if (ov) fc->sync_dw = FitSync{k > 0 ? h->epoch_ctr + 1 : nullptr, h->epoch_z_done, h->epoch_ctr, err};
     else if (overlap && !flags && k > 0) BGM_HIP_CHECK(hipStreamWaitEvent(sA, h->epoch_ev_z[(k - 1) & 1], 0));
     bnn_theta_launch(s, a, b, 2, sA);
     BGM_HIP_CHECK(hipGetLastError());
     s->packed_valid = false; s->bnf_valid = false;
+    if (ride) {
+      fc->riders_on = false;
+      fc->theta_prepared = fc->ahead.ws_next != nullptr;      // (the next minibatch's theta launch)
+      fc->z_prepared = true;
+    }
     if (ov) {
       fc->sync_dw = FitSync{};
       h->epoch_theta_done += dw_blocks;
@@ -573,6 +628,7 @@ extern "C" int bgm_bnn_fit_epoch(bgm_handle *h, const float *x, const float *y, 
     hipStream_t sz = (flags && !ov) ? sA : sB;
     if (flags && !ov) s->z_synced = s->t_z + 1;
     rc = bgm_bnn_z_step(h, x, y, v, data_z, zm, zv, idx, n_rows, b, 0, lr_z, lazy, seed, s0 + 1, out_z, nullptr, sz);
+    if (fc) fc->z_prepared = false;
     if (ov) { fc->sync_zn = FitSync{}; fc->sync_zr = FitSync{}; if (!rc) h->epoch_z_done += zr_blocks; }
     if (rc) return fail(rc);
     if (overlap && !flags) BGM_HIP_CHECK(hipEventRecord(h->epoch_ev_z[k & 1], sB));

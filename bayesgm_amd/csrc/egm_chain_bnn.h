@@ -123,6 +123,9 @@ struct EcbTab {
 // dW = sigma * eps and the sign words of one call (bnn_noise; eps itself is not stored: the gradient kernel recovers it as dW / sigma).
 // `part` of `parts` workgroup-sized slices: the noise of the nine calls is 40 k Philox blocks -- 110 us on the chain kernel's one CU
 // (integer multiplies at quarter rate, two waves per SIMD), a few microseconds as its own launch over 144 workgroups.
+// RAW: the standard normals themselves (bgm_bnn_fit_epoch prepares a step's noise while the parameters it will be scaled with are still
+// being updated: the gradient-tile kernel multiplies them by sigma of the NEW rho, ecb_theta_dw -- the same single product).
+template <bool RAW = false>
 __device__ __forceinline__ void ecb_noise(const float *theta, const BnnNet &n, const EcbCall &C, float *ws, int B, uint32_t k0, uint32_t k1,
                                           uint32_t stream, int tid, int part, int parts, uint32_t row0 = 0u) {
   for (int l = 0; l < n.n_layers; ++l) {
@@ -134,7 +137,7 @@ __device__ __forceinline__ void ecb_noise(const float *theta, const BnnNet &n, c
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int idx = 4 * i + u;
-        if (idx < cnt) d[idx] = (BNN_SCALE_EPS + softplus_f(rho[idx])) * z[u];      // transcendental-unit softplus: ~2 ulp on the scale of a random perturbation
+        if (idx < cnt) d[idx] = RAW ? z[u] : (BNN_SCALE_EPS + softplus_f(rho[idx])) * z[u];      // transcendental-unit softplus: ~2 ulp on the scale of a random perturbation
       }
     }
   }
@@ -180,6 +183,42 @@ template <class Args>
 __device__ __forceinline__ void ecb_gen_noise(const Args &a, const EcbTab &tab, float *ws_, uint32_t row0 = 0u) {      // grid: n_calls * ECB_NOISE_PARTS workgroups
   const int c = blockIdx.x / ECB_NOISE_PARTS, part = blockIdx.x % ECB_NOISE_PARTS;
   ecb_noise(a.theta, a.net[tab.c[c].net], tab.c[c], ws_, a.B, a.k0, a.k1, a.stream + (uint32_t)tab.c[c].soff, threadIdx.x, part, ECB_NOISE_PARTS, row0);
+}
+
+// bgm_bnn_fit_epoch: the noise of a step off the critical path.  A step's perturbations are sigma(rho) * eps with eps independent of the
+// parameters: RIDER workgroups of the theta-chain launch of minibatch k (the chains occupy six workgroups, the chip is idle beside them)
+// write eps and the sign words of (i) the theta phase of minibatch k + 1 and (ii) the latent phase of minibatch k into the workspaces
+// those phases will read, and the KL partial sums of THIS step (the chain workgroups wait for them on a counter before their last
+// addition); the gradient-tile kernel that follows, in the thread that has just written a weight's new rho, scales the weight's eps in
+// both workspaces.  The noise launches (15-19 us each, in front of the chains of both streams) disappear; values are the same bits.
+struct EcbRider {
+  float *ws_next; uint32_t stream_next;                       // theta phase of the next minibatch (NULL: not prepared)
+  const EcbTab *tab_z; float *ws_z; uint32_t stream_z;        // latent phase of this minibatch (NULL: not prepared)
+  unsigned *kl_cnt;                                           // rider workgroups that have written their KL partial sum
+};
+struct EcbAhead {
+  float *ws_next; const EcbTab *tab_z; float *ws_z;           // workspaces holding raw normals to be scaled (NULL: none)
+  int dw_t[4], dw_z[4][2];                                    // per net: the perturbation offsets (EcbCall::dW) of its theta call / its two latent calls
+  float *zero_t, *zero_z;                                     // loss words the next theta / this latent phase accumulates into
+  unsigned *kl_cnt;                                           // reset for the workspace's next use
+};
+#define ECB_RIDERS (9 * ECB_NOISE_PARTS)
+template <class Args>
+__device__ __forceinline__ void ecb_rider(const Args &a, const EcbTab &tab, float *ws, const EcbRider &rd, int r, float *red) {
+  const int c = r / ECB_NOISE_PARTS, part = r % ECB_NOISE_PARTS;
+  if (r < 3 * ECB_NOISE_PARTS) {
+    ecb_kl_partial(a.theta, a.net[tab.c[c].net], ws + tab.klp + r, part, ECB_NOISE_PARTS, red);
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __hip_atomic_fetch_add(rd.kl_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (rd.ws_next)
+      ecb_noise<true>(a.theta, a.net[tab.c[c].net], tab.c[c], rd.ws_next, a.B, a.k0, a.k1, rd.stream_next + (uint32_t)tab.c[c].soff, threadIdx.x, part,
+                      ECB_NOISE_PARTS);
+  } else if (r < ECB_RIDERS && rd.ws_z) {
+    const EcbCall &C = rd.tab_z->c[c - 3];
+    ecb_noise<true>(a.theta, a.net[C.net], C, rd.ws_z, a.B, a.k0, a.k1, rd.stream_z + (uint32_t)C.soff, threadIdx.x, part, ECB_NOISE_PARTS);
+  }
 }
 
 // v = a W1 + flip(as W2): the Flipout product pair in either direction.  KC: W1, W2 are given K-contiguously (ecg_load_tile): the
@@ -837,7 +876,7 @@ __device__ __forceinline__ void ecb_inputs(const float *zrow, float xv, int q, i
 // h | hs [16 x 64 each] | residual partials [2][4][16] | backward partials [4][16 x 64] | three counters.
 #define ECB_WS_LDS_FLOATS (64 + 2 * 1024 + 128 + 4 * 1024 + 8)
 template <class Args, int HT, int NTL, int T1, int T2, int T3, int NB, bool PAD = false, int T0 = 1, bool WS = false>
-__device__ __forceinline__ void ecb_theta_chain(const Args &a, const EcbTab &tab, float *ws, float *lds) {
+__device__ __forceinline__ void ecb_theta_chain(const Args &a, const EcbTab &tab, float *ws, float *lds, unsigned *kl_cnt = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const int q = a.q, p = a.p;
   // a minibatch may be spread over workgroups: blockIdx.x owns NB row tiles, blockIdx.y (gridDim.y = 3) one network -- on one CU the
@@ -1037,6 +1076,11 @@ __device__ __forceinline__ void ecb_theta_chain(const Args &a, const EcbTab &tab
   __syncthreads();
   if (tid < 3 && a.out) {            // which = 0 g, 1 h, 2 f
     float kl = 0.0f;             // call tid of the theta step is net which = tid; its KL partials come from the noise launch
+    if (kl_cnt) {                // the partials come from rider workgroups of this very launch (ecb_rider)
+      while (__hip_atomic_load(kl_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 3u * ECB_NOISE_PARTS) __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      for (int t = 0; t < ECB_NOISE_PARTS; ++t) kl += __hip_atomic_load(ws + tab.klp + tid * ECB_NOISE_PARTS + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else
     for (int t = 0; t < ECB_NOISE_PARTS; ++t) kl += ws[tab.klp + tid * ECB_NOISE_PARTS + t];
     float l0 = 0.0f, l1 = 0.0f;
     for (int w = 2 * tid; w < 2 * tid + NB; ++w) { l0 += part[w * 4]; l1 += part[w * 4 + 1]; }
@@ -1053,7 +1097,7 @@ __device__ __forceinline__ void ecb_theta_chain(const Args &a, const EcbTab &tab
 
 // gradient tiles of the theta step: ecb_gen_dw with one call per net, plus the KL terms of bnn_kl; Adam when a.apply
 template <class Args, int NB>
-__device__ __forceinline__ void ecb_theta_dw(const Args &a, const EcbTab &tab, const int *tiles, const float *ws) {
+__device__ __forceinline__ void ecb_theta_dw(const Args &a, const EcbTab &tab, const int *tiles, const float *ws, const EcbAhead &ah = EcbAhead{}) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   auto adam = [&](int ei, float gi) {
     a.grad[ei] = gi;
@@ -1066,6 +1110,9 @@ __device__ __forceinline__ void ecb_theta_dw(const Args &a, const EcbTab &tab, c
   };
   const int n_tile_blocks = (tab.n_tiles + ECH_WAVES - 1) / ECH_WAVES;
   if ((int)blockIdx.x == n_tile_blocks) {
+    if (tid == 0 && ah.kl_cnt) *ah.kl_cnt = 0u;
+    if (tid < 6 && ah.zero_t) ah.zero_t[tid] = 0.0f;
+    if (tid == 0 && ah.zero_z) ah.zero_z[0] = 0.0f;
     for (int k = 0; k < 4; ++k) {
       if (tab.net_ncalls[k] == 0) continue;
       const BnnNet &n = a.net[k];
@@ -1110,6 +1157,21 @@ __device__ __forceinline__ void ecb_theta_dw(const Args &a, const EcbTab &tab, c
   }
   bs = sum_over_g(bs);
   const int cnt = n_in * n_out;
+  // prepared steps (EcbAhead): this weight's standard normals in up to three workspaces, requested ahead of the Adam arithmetic
+  const bool sc_t = ah.ws_next != nullptr, sc_z = ah.ws_z != nullptr;
+  const int el = td[12] - ah.dw_t[net];                // the layer's offset inside a call's perturbations
+  float *e_t[4], *e_z0[4], *e_z1[4];
+  float v_t[4] = {0.0f, 0.0f, 0.0f, 0.0f}, v_z0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, v_z1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (sc_t || sc_z) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = 16 * u + 4 * g + r;
+      const int t = min(f, n_in - 1) * n_out + min(o, n_out - 1);
+      e_t[r] = ah.ws_next + td[12] + t; e_z0[r] = ah.ws_z + ah.dw_z[net][0] + el + t; e_z1[r] = ah.ws_z + ah.dw_z[net][1] + el + t;
+      if (sc_t) v_t[r] = *e_t[r];
+      if (sc_z) { v_z0[r] = *e_z0[r]; v_z1[r] = *e_z1[r]; }
+    }
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int f = 16 * u + 4 * g + r;
@@ -1119,6 +1181,11 @@ __device__ __forceinline__ void ecb_theta_dw(const Args &a, const EcbTab &tab, c
       const float sg = BNN_SCALE_EPS + softplus_acc(rho_), sgm = sigmoid_f(rho_);
       adam(woff + t, c1[r] + klw * mu * iv);
       adam(woff + cnt + t, rr[r] / sg * sgm + klw * (-1.0f / sg + sg * iv) * sgm);
+      if (ah.ws_next || ah.ws_z) {            // the prepared steps' perturbations of this weight: sigma(new rho) * eps (ecb_noise)
+        const float sn = BNN_SCALE_EPS + softplus_f(a.theta[woff + cnt + t]);
+        if (sc_t) *e_t[r] = sn * v_t[r];
+        if (sc_z) { *e_z0[r] = sn * v_z0[r]; *e_z1[r] = sn * v_z1[r]; }
+      }
     }
   }
   if (u == 0 && g == 0 && o < n_out) {
