@@ -62,10 +62,11 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_dw_kernel(BnnArg
   fit_sync_done(sy);
 }
 template <int NTL, int NB, bool PAD = false, int T0 = 1, bool WS = false>
-static __global__ __launch_bounds__(BNN_THREADS) void bnn_z_chain_kernel(BnnArgs a, const EcbTab *tab, float *ws, FitSync sy) {
+static __global__ __launch_bounds__(BNN_THREADS) void bnn_z_chain_kernel(BnnArgs a, const EcbTab *tab, float *ws, FitSync sy, EcbZRows zr) {
   extern __shared__ __attribute__((aligned(16))) float bnn_chain_lds[];
   fit_sync_wait(sy);              // (noise prepared ahead: the wait for the Adam step the noise launch otherwise carries)
-  ecb_z_chain<BnnArgs, 4, NTL, 4, 2, 1, NB, PAD, T0, WS>(a, *tab, ws, bnn_chain_lds);
+  ecb_z_chain<BnnArgs, 4, NTL, 4, 2, 1, NB, PAD, T0, WS>(a, *tab, ws, bnn_chain_lds, zr);
+  if (zr.zm) fit_sync_done(sy);   // (rows updated here: the latent phase of this minibatch is complete)
 }
 static void bnn_chain_free(BnnState *s) {
   BnnFitChain *c = static_cast<BnnFitChain *>(s->chain);
@@ -382,8 +383,16 @@ extern "C" int bgm_bnn_z_step(bgm_handle *h, const float *x, const float *y, con
   a.data_z = data_z; a.idx = idx; a.x_ = x; a.y_ = y; a.v_ = v;
   a.out = out; a.dz = dz_out ? dz_out : s->dz_dev;
   BnnFitChain *fc = static_cast<BnnFitChain *>(s->chain);
+  bool fused_rows = false;
   if (fc && (batch == 32 || (batch == 16 && !fc->pad))) {
-    const FitSync zsy = fc->z_prepared ? fc->sync_zn : FitSync{};      // (prepared noise: the chain kernel itself waits for the Adam step)
+    FitSync zsy = fc->z_prepared ? fc->sync_zn : FitSync{};      // (prepared noise: the chain kernel itself waits for the Adam step)
+    // ... and (one row tile per workgroup, batch rows only) applies the rows' Adam step in its epilogue and counts the phase done
+    fused_rows = fc->z_prepared && !dz_out && lazy != 0 && batch == 32 && !fc->pad && fc->t0 == 1;
+    EcbZRows zr{};
+    if (fused_rows) {
+      zr = EcbZRows{data_z, zm, zv, adam_lr_t(lr_z, s->t_z + 1), BNN_ADAM_B1, BNN_ADAM_B2, BNN_ADAM_EPS, lazy == 2 ? s->tlast_dev : nullptr, (int)(s->t_z + 1)};
+      zsy.done_ctr = fc->sync_zr.done_ctr;
+    }
     if (!fc->z_prepared)
     hipLaunchKernelGGL(bnn_fit_noise_kernel<false>, dim3(6 * ECB_NOISE_PARTS), dim3(BNN_THREADS), 0, stream, a, fc->tab_z, fc->ws_z, fc->sync_zn);
     auto kc = fc->t0 == 2 ? bnn_z_chain_kernel<13, 2, true, 2> : fc->pad ? bnn_z_chain_kernel<13, 2, true>
@@ -395,14 +404,14 @@ extern "C" int bgm_bnn_z_step(bgm_handle *h, const float *x, const float *y, con
       static const bool no_ws = std::getenv("BGM_FIT_NO_WORKERS") != nullptr;
       if (no_ws) {
         auto ks = fc->ntl == 13 ? bnn_z_chain_kernel<13, 1> : bnn_z_chain_kernel<7, 1>;
-        hipLaunchKernelGGL(ks, dim3(2), dim3(BNN_THREADS), lds_z, stream, a, fc->tab_z, fc->ws_z, zsy);
+        hipLaunchKernelGGL(ks, dim3(2), dim3(BNN_THREADS), lds_z, stream, a, fc->tab_z, fc->ws_z, zsy, zr);
       } else {      // the mean call's last layer over the idle waves, the variance-head call on its one column (ecb_z_chain<WS>)
         auto ks = fc->ntl == 13 ? bnn_z_chain_kernel<13, 1, false, 1, true> : bnn_z_chain_kernel<7, 1, false, 1, true>;
         const size_t lds_ws = (32 + 2 * 16 + 4 * 16 * 16 + 2 * 1024 + 64 + 4 * 1024 + 8) * sizeof(float);
-        hipLaunchKernelGGL(ks, dim3(2), dim3(BNN_THREADS), std::max(lds_z, lds_ws), stream, a, fc->tab_z, fc->ws_z, zsy);
+        hipLaunchKernelGGL(ks, dim3(2), dim3(BNN_THREADS), std::max(lds_z, lds_ws), stream, a, fc->tab_z, fc->ws_z, zsy, zr);
       }
     } else
-      hipLaunchKernelGGL(kc, dim3(1), dim3(BNN_THREADS), lds_z, stream, a, fc->tab_z, fc->ws_z, zsy);
+      hipLaunchKernelGGL(kc, dim3(1), dim3(BNN_THREADS), lds_z, stream, a, fc->tab_z, fc->ws_z, zsy, EcbZRows{});
   } else {
     hipLaunchKernelGGL(bnn_z_grad_kernel, dim3(3), dim3(BNN_THREADS), 0, stream, a);
     hipLaunchKernelGGL(bnn_z_combine_kernel, dim3((batch * s->q + 255) / 256), dim3(256), 0, stream, a.dz_part, a.loss_part, a.dz, out, batch * s->q);
@@ -414,7 +423,9 @@ extern "C" int bgm_bnn_z_step(bgm_handle *h, const float *x, const float *y, con
   const int q = s->q;
   const long long n = (long long)n_rows * q;
   const int nb = batch * q;
-  if (lazy == 2) {
+  if (fused_rows) {
+    // (the chain kernel has applied the step)
+  } else if (lazy == 2) {
     hipLaunchKernelGGL(bnn_z_rows_kernel, dim3((nb + 255) / 256), dim3(256), 0, stream, data_z, zm, zv, a.dz, idx, batch, q, lr_t,
                        BNN_ADAM_B1, BNN_ADAM_B2, BNN_ADAM_EPS, 1, s->tlast_dev, (int)s->t_z, fc ? fc->sync_zr : FitSync{});
   } else if (lazy) {
@@ -629,7 +640,7 @@ extern "C" int bgm_bnn_fit_epoch(bgm_handle *h, const float *x, const float *y, 
     if (flags && !ov) s->z_synced = s->t_z + 1;
     rc = bgm_bnn_z_step(h, x, y, v, data_z, zm, zv, idx, n_rows, b, 0, lr_z, lazy, seed, s0 + 1, out_z, nullptr, sz);
     if (fc) fc->z_prepared = false;
-    if (ov) { fc->sync_zn = FitSync{}; fc->sync_zr = FitSync{}; if (!rc) h->epoch_z_done += zr_blocks; }
+    if (ov) { fc->sync_zn = FitSync{}; fc->sync_zr = FitSync{}; if (!rc) h->epoch_z_done += ride ? 2u : zr_blocks; }      // (ride: counted by the chain kernel's two workgroups)
     if (rc) return fail(rc);
     if (overlap && !flags) BGM_HIP_CHECK(hipEventRecord(h->epoch_ev_z[k & 1], sB));
     ++k;

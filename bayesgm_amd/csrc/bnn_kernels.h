@@ -694,6 +694,13 @@ static __global__ void bnn_z_decay_kernel(float *zm, float *zv, long long n, flo
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { zm[i] *= b1; zv[i] *= b2; }
 }
+// one element of a batch row (lazy / replay forms), roundings spelled out: the latent chain kernel applies the same step in its epilogue
+// (bgm_bnn_fit_epoch, EcbZRows) and the two must agree to the bit
+__device__ __forceinline__ void bnn_z_row_adam(float *data_z, float *zm, float *zv, long long t, float g, float lr_t, float b1, float b2, float eps) {
+  const float m = fmaf(b1, zm[t], __fmul_rn(1.0f - b1, g)), v = fmaf(b2, zv[t], __fmul_rn(__fmul_rn(1.0f - b2, g), g));
+  zm[t] = m; zv[t] = v;
+  data_z[t] = __fsub_rn(data_z[t], __fdiv_rn(__fmul_rn(lr_t, m), __fadd_rn(sqrtf(v), eps)));
+}
 static __global__ void bnn_z_rows_kernel(float *data_z, float *zm, float *zv, const float *dz, const int *idx, int B, int q,
                                          float lr_t, float b1, float b2, float eps, int lazy, int *t_last = nullptr, int t_now = 0,
                                          FitSync sy = FitSync{}) {
@@ -703,9 +710,7 @@ static __global__ void bnn_z_rows_kernel(float *data_z, float *zm, float *zv, co
     const long long t = (long long)idx[b] * q + j;
     const float g = dz[i];
     if (lazy) {
-      const float m = b1 * zm[t] + (1.0f - b1) * g, v = b2 * zv[t] + (1.0f - b2) * g * g;
-      zm[t] = m; zv[t] = v;
-      data_z[t] -= lr_t * m / (sqrtf(v) + eps);
+      bnn_z_row_adam(data_z, zm, zv, t, g, lr_t, b1, b2, eps);
       if (t_last && j == 0) t_last[idx[b]] = t_now;      // replay mode (z_replay.h): the row is current to this step
     } else {
       zm[t] += (1.0f - b1) * g;

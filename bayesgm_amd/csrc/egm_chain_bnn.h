@@ -202,6 +202,9 @@ struct EcbAhead {
   float *zero_t, *zero_z;                                     // loss words the next theta / this latent phase accumulates into
   unsigned *kl_cnt;                                           // reset for the workspace's next use
 };
+// the latent chain kernel applies the Adam step of its own 16 batch rows in its epilogue (the thread that has assembled an element of
+// dz owns that element of the latent table): no row-update launch behind it.  zm == NULL: dz only.
+struct EcbZRows { float *data_z, *zm, *zv; float lr_t, b1, b2, eps; int *t_last; int t_now; };
 #define ECB_RIDERS (9 * ECB_NOISE_PARTS)
 template <class Args>
 __device__ __forceinline__ void ecb_rider(const Args &a, const EcbTab &tab, float *ws, const EcbRider &rd, int r, float *red) {
@@ -1197,7 +1200,7 @@ __device__ __forceinline__ void ecb_theta_dw(const Args &a, const EcbTab &tab, c
 // latent step: dz [B x q] = d loss / d (batch rows of data_z), out[0] = loss_postrior_z.  Waves 0,1: g mean call; 2,3: g variance-head
 // call (they exchange the row's sum of squares and raw variance through LDS); 4,5: h (both calls); 6,7: f (both calls).
 template <class Args, int HT, int NTL, int T1, int T2, int T3, int NB, bool PAD = false, int T0 = 1, bool WS = false>
-__device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, float *ws, float *lds) {
+__device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, float *ws, float *lds, const EcbZRows &zr = EcbZRows{}) {
   constexpr int B = 16 * NB, ZW = 16 * T0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const int q = a.q, p = a.p, z0 = a.z0, z1 = a.z1, z2 = a.z2;
@@ -1507,6 +1510,11 @@ __device__ __forceinline__ void ecb_z_chain(const Args &a, const EcbTab &tab, fl
     if (col < z0) v += dzc[(2 * B + b) * ZW + col];                                       // h: (z0, z2)
     else if (col >= z0 + z1 && col < z0 + z1 + z2) v += dzc[(2 * B + b) * ZW + col - z1];
     a.dz[i] = v;
+    if (zr.zm) {
+      const long long t = (long long)a.idx[rb + b] * q + col;
+      bnn_z_row_adam(zr.data_z, zr.zm, zr.zv, t, v, zr.lr_t, zr.b1, zr.b2, zr.eps);
+      if (zr.t_last && col == 0) zr.t_last[a.idx[rb + b]] = zr.t_now;
+    }
   }
   if (tid == 0 && a.out) {
     float t = 0.0f;
