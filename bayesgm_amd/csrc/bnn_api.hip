@@ -57,8 +57,7 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_chain_kernel(Bnn
 template <int NB>
 static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_dw_kernel(BnnArgs a, const EcbTab *tab, const int *tiles, const float *ws, FitSync sy,
                                                                        EcbAhead ah) {
-  fit_sync_wait(sy);
-  ecb_theta_dw<BnnArgs, NB>(a, *tab, tiles, ws, ah);
+  ecb_theta_dw<BnnArgs, NB>(a, *tab, tiles, ws, ah, &sy);      // (waits inside, in front of its parameter stores)
   fit_sync_done(sy);
 }
 template <int NTL, int NB, bool PAD = false, int T0 = 1, bool WS = false>

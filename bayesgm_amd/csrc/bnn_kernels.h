@@ -436,13 +436,20 @@ __device__ __forceinline__ float bnn_kl(const BnnCtx &c, const float *theta, flo
   return bnn_block_sum(c, acc);
 }
 
+// one Adam update, roundings spelled out (every site that steps a parameter of the Bayesian nets goes through it: the results of the
+// fused and the split forms of a step must agree to the bit whatever the surrounding code lets the compiler contract)
+struct BnnAdamOut { float m, v, th; };
+__device__ __forceinline__ BnnAdamOut bnn_adam_one(float th, float m, float v, float g, const BnnAdam &a) {
+  BnnAdamOut o;
+  o.m = fmaf(a.b1, m, __fmul_rn(1.0f - a.b1, g));
+  o.v = fmaf(a.b2, v, __fmul_rn(__fmul_rn(1.0f - a.b2, g), g));
+  o.th = __fsub_rn(th, __fdiv_rn(__fmul_rn(a.lr_t, o.m), __fadd_rn(sqrtf(o.v), a.eps)));
+  return o;
+}
 __device__ __forceinline__ void bnn_adam(const BnnCtx &c, float *theta, float *m, float *v, const float *g, int n, const BnnAdam &a) {
   for (int i = c.tid; i < n; i += BNN_THREADS) {
-    const float gi = g[i];
-    const float mi = a.b1 * m[i] + (1.0f - a.b1) * gi;
-    const float vi = a.b2 * v[i] + (1.0f - a.b2) * gi * gi;
-    m[i] = mi; v[i] = vi;
-    theta[i] -= a.lr_t * mi / (sqrtf(vi) + a.eps);
+    const BnnAdamOut o = bnn_adam_one(theta[i], m[i], v[i], g[i], a);
+    m[i] = o.m; v[i] = o.v; theta[i] = o.th;
   }
 }
 
@@ -726,9 +733,7 @@ static __global__ void bnn_z_apply_kernel(float *data_z, const float *zm, const 
 static __global__ void bnn_adam_kernel(float *theta, float *m, float *v, const float *g, int n, BnnAdam a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
-    const float gi = g[i];
-    const float mi = a.b1 * m[i] + (1.0f - a.b1) * gi, vi = a.b2 * v[i] + (1.0f - a.b2) * gi * gi;
-    m[i] = mi; v[i] = vi;
-    theta[i] -= a.lr_t * mi / (sqrtf(vi) + a.eps);
+    const BnnAdamOut o = bnn_adam_one(theta[i], m[i], v[i], g[i], a);
+    m[i] = o.m; v[i] = o.v; theta[i] = o.th;
   }
 }

@@ -1098,21 +1098,22 @@ __device__ __forceinline__ void ecb_theta_chain(const Args &a, const EcbTab &tab
   }
 }
 
-// gradient tiles of the theta step: ecb_gen_dw with one call per net, plus the KL terms of bnn_kl; Adam when a.apply
+// gradient tiles of the theta step: ecb_gen_dw with one call per net, plus the KL terms of bnn_kl; Adam when a.apply.
+// Two phases: everything that only READS (products, the old parameters and Adam slots, the new values) first; then `late` -- the wait
+// for the previous latent phase, which reads the parameters this kernel is about to overwrite (bgm_bnn_fit_epoch; NULL: none) --
+// and behind it the stores alone: the products and the loads run beside the latent chains instead of behind them.
 template <class Args, int NB>
-__device__ __forceinline__ void ecb_theta_dw(const Args &a, const EcbTab &tab, const int *tiles, const float *ws, const EcbAhead &ah = EcbAhead{}) {
+__device__ __forceinline__ void ecb_theta_dw(const Args &a, const EcbTab &tab, const int *tiles, const float *ws, const EcbAhead &ah = EcbAhead{},
+                                             const FitSync *late = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
-  auto adam = [&](int ei, float gi) {
+  auto calc = [&](int ei, float gi) { return a.apply ? bnn_adam_one(a.theta[ei], a.m[ei], a.v[ei], gi, a.adam) : BnnAdamOut{0.0f, 0.0f, 0.0f}; };
+  auto put = [&](int ei, float gi, const BnnAdamOut &o) {
     a.grad[ei] = gi;
-    if (a.apply) {
-      const float mi = a.adam.b1 * a.m[ei] + (1.0f - a.adam.b1) * gi;
-      const float vi = a.adam.b2 * a.v[ei] + (1.0f - a.adam.b2) * gi * gi;
-      a.m[ei] = mi; a.v[ei] = vi;
-      a.theta[ei] -= a.adam.lr_t * mi / (sqrtf(vi) + a.adam.eps);
-    }
+    if (a.apply) { a.m[ei] = o.m; a.v[ei] = o.v; a.theta[ei] = o.th; }
   };
   const int n_tile_blocks = (tab.n_tiles + ECH_WAVES - 1) / ECH_WAVES;
-  if ((int)blockIdx.x == n_tile_blocks) {
+  if ((int)blockIdx.x == n_tile_blocks) {              // input-normalisation parameters (a few hundred), the loss words, the KL counter
+    if (late) fit_sync_wait(*late);
     if (tid == 0 && ah.kl_cnt) *ah.kl_cnt = 0u;
     if (tid < 6 && ah.zero_t) ah.zero_t[tid] = 0.0f;
     if (tid == 0 && ah.zero_z) ah.zero_z[0] = 0.0f;
@@ -1126,14 +1127,15 @@ __device__ __forceinline__ void ecb_theta_dw(const Args &a, const EcbTab &tab, c
           const float *bp = ws + tab.c[tab.net_calls[k][c]].bnp;
           for (int t = 0; t < NB; ++t) { sg += bp[t * 2 * w16 + f]; sb += bp[t * 2 * w16 + w16 + f]; }
         }
-        adam(n.off + f, sg);
-        adam(n.off + in + f, sb);
+        put(n.off + f, sg, calc(n.off + f, sg));
+        put(n.off + in + f, sb, calc(n.off + in + f, sb));
       }
     }
     return;
   }
-  const int tau = blockIdx.x * ECH_WAVES + wave;
-  if (tau >= tab.n_tiles) return;
+  const int tau_ = blockIdx.x * ECH_WAVES + wave;
+  const bool live = tau_ < tab.n_tiles;               // (every wave reaches the wait below)
+  const int tau = live ? tau_ : tab.n_tiles - 1;
   const int *td = tiles + tau * ECB_TILE_INTS;
   const int woff = td[0], n_in = td[1], n_out = td[2], u = td[3], v = td[4], xw = td[5], dw = td[6], ncalls = td[7], net = td[23];
   const float iv = a.net[net].prior_iv, klw = a.kl_weight;
@@ -1160,41 +1162,46 @@ __device__ __forceinline__ void ecb_theta_dw(const Args &a, const EcbTab &tab, c
   }
   bs = sum_over_g(bs);
   const int cnt = n_in * n_out;
-  // prepared steps (EcbAhead): this weight's standard normals in up to three workspaces, requested ahead of the Adam arithmetic
+  // prepared steps (EcbAhead): this weight's standard normals in up to three workspaces times sigma of its NEW rho (ecb_noise's product)
   const bool sc_t = ah.ws_next != nullptr, sc_z = ah.ws_z != nullptr;
   const int el = td[12] - ah.dw_t[net];                // the layer's offset inside a call's perturbations
-  float *e_t[4], *e_z0[4], *e_z1[4];
-  float v_t[4] = {0.0f, 0.0f, 0.0f, 0.0f}, v_z0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, v_z1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  if (sc_t || sc_z) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int f = 16 * u + 4 * g + r;
-      const int t = min(f, n_in - 1) * n_out + min(o, n_out - 1);
-      e_t[r] = ah.ws_next + td[12] + t; e_z0[r] = ah.ws_z + ah.dw_z[net][0] + el + t; e_z1[r] = ah.ws_z + ah.dw_z[net][1] + el + t;
-      if (sc_t) v_t[r] = *e_t[r];
-      if (sc_z) { v_z0[r] = *e_z0[r]; v_z1[r] = *e_z1[r]; }
-    }
-  }
+  float gl[4], gr[4], s_t[4], s_z0[4], s_z1[4];
+  BnnAdamOut ol[4], orh[4];
+  bool ok[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int f = 16 * u + 4 * g + r;
-    if (f < n_in && o < n_out) {
-      const int t = f * n_out + o;
-      const float mu = a.theta[woff + t], rho_ = a.theta[woff + cnt + t];
-      const float sg = BNN_SCALE_EPS + softplus_acc(rho_), sgm = sigmoid_f(rho_);
-      adam(woff + t, c1[r] + klw * mu * iv);
-      adam(woff + cnt + t, rr[r] / sg * sgm + klw * (-1.0f / sg + sg * iv) * sgm);
-      if (ah.ws_next || ah.ws_z) {            // the prepared steps' perturbations of this weight: sigma(new rho) * eps (ecb_noise)
-        const float sn = BNN_SCALE_EPS + softplus_f(a.theta[woff + cnt + t]);
-        if (sc_t) *e_t[r] = sn * v_t[r];
-        if (sc_z) { *e_z0[r] = sn * v_z0[r]; *e_z1[r] = sn * v_z1[r]; }
-      }
+    ok[r] = live && f < n_in && o < n_out;
+    const int t = min(f, n_in - 1) * n_out + min(o, n_out - 1);
+    const float mu = a.theta[woff + t], rho_ = a.theta[woff + cnt + t];
+    const float sg = BNN_SCALE_EPS + softplus_acc(rho_), sgm = sigmoid_f(rho_);
+    gl[r] = c1[r] + klw * mu * iv;
+    gr[r] = rr[r] / sg * sgm + klw * (-1.0f / sg + sg * iv) * sgm;
+    ol[r] = calc(woff + t, gl[r]);
+    orh[r] = calc(woff + cnt + t, gr[r]);
+    s_t[r] = s_z0[r] = s_z1[r] = 0.0f;
+    if (sc_t || sc_z) {
+      const float sn = BNN_SCALE_EPS + softplus_f(a.apply ? orh[r].th : rho_);
+      if (sc_t) s_t[r] = sn * ah.ws_next[td[12] + t];
+      if (sc_z) { s_z0[r] = sn * ah.ws_z[ah.dw_z[net][0] + el + t]; s_z1[r] = sn * ah.ws_z[ah.dw_z[net][1] + el + t]; }
     }
   }
-  if (u == 0 && g == 0 && o < n_out) {
-    const float b = a.theta[woff + 2 * cnt + o];
-    adam(woff + 2 * cnt + o, bs + (bias_prior ? klw * b * iv : 0.0f));
+  const bool bias_here = live && u == 0 && g == 0 && o < n_out;
+  const int eb = woff + 2 * cnt + min(o, n_out - 1);
+  const float gb = bs + (bias_prior ? klw * a.theta[eb] * iv : 0.0f);
+  const BnnAdamOut ob = calc(eb, gb);
+  if (late) fit_sync_wait(*late);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (ok[r]) {
+      const int t = (16 * u + 4 * g + r) * n_out + o;
+      put(woff + t, gl[r], ol[r]);
+      put(woff + cnt + t, gr[r], orh[r]);
+      if (sc_t) ah.ws_next[td[12] + t] = s_t[r];
+      if (sc_z) { ah.ws_z[ah.dw_z[net][0] + el + t] = s_z0[r]; ah.ws_z[ah.dw_z[net][1] + el + t] = s_z1[r]; }
+    }
   }
+  if (bias_here) put(eb, gb, ob);
 }
 
 // latent step: dz [B x q] = d loss / d (batch rows of data_z), out[0] = loss_postrior_z.  Waves 0,1: g mean call; 2,3: g variance-head
