@@ -1141,6 +1141,25 @@ __device__ __forceinline__ void ecb_theta_dw(const Args &a, const EcbTab &tab, c
   const float iv = a.net[net].prior_iv, klw = a.kl_weight;
   const int bias_prior = a.net[net].bias_prior;
   const int o = 16 * v + j;
+  const int cnt = n_in * n_out;
+  // this lane's four weights: old parameters, Adam slots and (prepared steps, EcbAhead) standard normals, requested with the activations
+  const bool sc_t = ah.ws_next != nullptr, sc_z = ah.ws_z != nullptr;
+  const int el = td[12] - ah.dw_t[net];                // the layer's offset inside a call's perturbations
+  float mu[4], rho_[4], ml[4], vl[4], mr[4], vr[4], e_t[4], e_z0[4], e_z1[4];
+  bool ok[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int f = 16 * u + 4 * g + r;
+    ok[r] = live && f < n_in && o < n_out;
+    const int t = min(f, n_in - 1) * n_out + min(o, n_out - 1);
+    mu[r] = a.theta[woff + t]; rho_[r] = a.theta[woff + cnt + t];
+    ml[r] = a.m[woff + t]; vl[r] = a.v[woff + t]; mr[r] = a.m[woff + cnt + t]; vr[r] = a.v[woff + cnt + t];
+    e_t[r] = sc_t ? ah.ws_next[td[12] + t] : 0.0f;
+    e_z0[r] = sc_z ? ah.ws_z[ah.dw_z[net][0] + el + t] : 0.0f;
+    e_z1[r] = sc_z ? ah.ws_z[ah.dw_z[net][1] + el + t] : 0.0f;
+  }
+  const int eb = woff + 2 * cnt + min(o, n_out - 1);
+  const float b_old = a.theta[eb], mb = a.m[eb], vb = a.v[eb];
   f32x4 c1 = {0.0f, 0.0f, 0.0f, 0.0f}, rr = {0.0f, 0.0f, 0.0f, 0.0f};
   float bs = 0.0f;
   for (int c = 0; c < ncalls; ++c) {
@@ -1161,35 +1180,21 @@ __device__ __forceinline__ void ecb_theta_dw(const Args &a, const EcbTab &tab, c
     }
   }
   bs = sum_over_g(bs);
-  const int cnt = n_in * n_out;
-  // prepared steps (EcbAhead): this weight's standard normals in up to three workspaces times sigma of its NEW rho (ecb_noise's product)
-  const bool sc_t = ah.ws_next != nullptr, sc_z = ah.ws_z != nullptr;
-  const int el = td[12] - ah.dw_t[net];                // the layer's offset inside a call's perturbations
   float gl[4], gr[4], s_t[4], s_z0[4], s_z1[4];
   BnnAdamOut ol[4], orh[4];
-  bool ok[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int f = 16 * u + 4 * g + r;
-    ok[r] = live && f < n_in && o < n_out;
-    const int t = min(f, n_in - 1) * n_out + min(o, n_out - 1);
-    const float mu = a.theta[woff + t], rho_ = a.theta[woff + cnt + t];
-    const float sg = BNN_SCALE_EPS + softplus_acc(rho_), sgm = sigmoid_f(rho_);
-    gl[r] = c1[r] + klw * mu * iv;
+    const float sg = BNN_SCALE_EPS + softplus_acc(rho_[r]), sgm = sigmoid_f(rho_[r]);
+    gl[r] = c1[r] + klw * mu[r] * iv;
     gr[r] = rr[r] / sg * sgm + klw * (-1.0f / sg + sg * iv) * sgm;
-    ol[r] = calc(woff + t, gl[r]);
-    orh[r] = calc(woff + cnt + t, gr[r]);
-    s_t[r] = s_z0[r] = s_z1[r] = 0.0f;
-    if (sc_t || sc_z) {
-      const float sn = BNN_SCALE_EPS + softplus_f(a.apply ? orh[r].th : rho_);
-      if (sc_t) s_t[r] = sn * ah.ws_next[td[12] + t];
-      if (sc_z) { s_z0[r] = sn * ah.ws_z[ah.dw_z[net][0] + el + t]; s_z1[r] = sn * ah.ws_z[ah.dw_z[net][1] + el + t]; }
-    }
+    ol[r] = a.apply ? bnn_adam_one(mu[r], ml[r], vl[r], gl[r], a.adam) : BnnAdamOut{0.0f, 0.0f, 0.0f};
+    orh[r] = a.apply ? bnn_adam_one(rho_[r], mr[r], vr[r], gr[r], a.adam) : BnnAdamOut{0.0f, 0.0f, 0.0f};
+    const float sn = BNN_SCALE_EPS + softplus_f(a.apply ? orh[r].th : rho_[r]);      // sigma of the NEW rho (ecb_noise's product)
+    s_t[r] = sn * e_t[r]; s_z0[r] = sn * e_z0[r]; s_z1[r] = sn * e_z1[r];
   }
   const bool bias_here = live && u == 0 && g == 0 && o < n_out;
-  const int eb = woff + 2 * cnt + min(o, n_out - 1);
-  const float gb = bs + (bias_prior ? klw * a.theta[eb] * iv : 0.0f);
-  const BnnAdamOut ob = calc(eb, gb);
+  const float gb = bs + (bias_prior ? klw * b_old * iv : 0.0f);
+  const BnnAdamOut ob = a.apply ? bnn_adam_one(b_old, mb, vb, gb, a.adam) : BnnAdamOut{0.0f, 0.0f, 0.0f};
   if (late) fit_sync_wait(*late);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
