@@ -191,7 +191,7 @@ struct GxStore {
     const f32x2 bb = bias ? *reinterpret_cast<const f32x2 *>(bias + n0 + 2 * j) : f32x2{0.0f, 0.0f};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float y0 = a0[r] + bb[0], y1 = a1[r] + bb[1];
+      float y0 = bias ? a0[r] + bb[0] : a0[r], y1 = bias ? a1[r] + bb[1] : a1[r];      // (x + 0.0f is not folded: -0.0f)
       if (LEAKY) { y0 = lrelu(y0); y1 = lrelu(y1); }
       f32x2 o = {y0, y1};
       *reinterpret_cast<f32x2 *>(Y + (size_t)(16 * rt + 4 * g + r) * ldy + n0 + 2 * j) = o;
@@ -208,7 +208,7 @@ struct GxStoreWs {
     const f32x2 bb = bias ? *reinterpret_cast<const f32x2 *>(bias + n0 + 2 * j) : f32x2{0.0f, 0.0f};      // (NULL: already in the accumulators)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float y0 = a0[r] + bb[0], y1 = a1[r] + bb[1];
+      float y0 = bias ? a0[r] + bb[0] : a0[r], y1 = bias ? a1[r] + bb[1] : a1[r];
       if (LEAKY) { y0 = lrelu(y0); y1 = lrelu(y1); }
       f32x2 o = {y0, y1};
       const int row = 16 * rt + 4 * g + r;
