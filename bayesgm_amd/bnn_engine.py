@@ -114,6 +114,25 @@ class BnnEngine(object):
         if getattr(self, "_precision", "fp32") != "fp32":
             self.set_precision(self._precision)
 
+    MAX_BATCH = 4096      # BNN_MAX_BATCH (csrc/bnn_kernels.h)
+
+    def ensure_max_batch(self, rows):
+        """Minibatches of `rows` rows per rank (causalbgm/base.py:434 takes any batch_size): the session's workspaces are sized at
+        begin(); a larger minibatch re-opens the session around the same parameters -- possible only before its first step (the
+        optimizer clocks start at begin())."""
+        rows = int(rows)
+        if rows <= self.cfg.max_batch:
+            return
+        if rows > self.MAX_BATCH:
+            raise ValueError("bayesgm_amd: minibatches of Bayesian nets hold at most %d rows per rank (got %d)" % (self.MAX_BATCH, rows))
+        if getattr(self, "_stepped", False):
+            raise ValueError("bayesgm_amd: batch_size %d exceeds the session's max_batch %d and optimizer steps have been taken; "
+                             "create the model with params['max_batch'] >= %d" % (rows, self.cfg.max_batch, rows))
+        theta = self.read(0) if self.open else None
+        self.cfg.max_batch = rows
+        if theta is not None:
+            self.begin(theta)
+
     def read(self, what=0):
         out = np.empty(self.n_params, np.float32)
         _lib.check(self.lib.bgm_bnn_read(self.h, what, out.ctypes.data_as(C.c_void_p), out.size, self._stream()), "bgm_bnn_read")
@@ -143,14 +162,17 @@ class BnnEngine(object):
 
     # -- minibatch steps -----------------------------------------------------------------------------
     def theta_step(self, data_z, idx, x, y, v, lr_theta, seed, stream_id, apply=True, batch_global=0, out=None):
+        self._stepped = True
         _lib.check(self.lib.bgm_bnn_theta_step(self.h, _ptr(data_z), _ptr(idx), _ptr(x), _ptr(y), _ptr(v), idx.numel(),
                                                batch_global, float(lr_theta), int(seed), int(stream_id) & 0xFFFFFFFF,
                                                int(apply), _ptr(out), self._stream()), "bgm_bnn_theta_step")
 
     def theta_apply(self, lr_theta):
+        self._stepped = True
         _lib.check(self.lib.bgm_bnn_theta_apply(self.h, float(lr_theta), self._stream()), "bgm_bnn_theta_apply")
 
     def z_step(self, x, y, v, data_z, zm, zv, idx, lr_z, seed, stream_id, lazy=False, batch_global=0, out=None, dz_out=None):
+        self._stepped = True
         _lib.check(self.lib.bgm_bnn_z_step(self.h, _ptr(x), _ptr(y), _ptr(v), _ptr(data_z), _ptr(zm), _ptr(zv), _ptr(idx),
                                            data_z.shape[0], idx.numel(), batch_global, float(lr_z), int(lazy), int(seed),
                                            int(stream_id) & 0xFFFFFFFF, _ptr(out), _ptr(dz_out), self._stream()),
@@ -164,6 +186,7 @@ class BnnEngine(object):
     def fit_epoch(self, x, y, v, data_z, zm, zv, perm, batch, lr_theta, lr_z, lazy, seed, stream_id0, out_t=None, out_z=None):
         """All minibatches perm[0:batch], perm[batch:2 batch], ... of one epoch with the loop inside the library (bgm_bnn_fit_epoch;
         single process).  Returns the number of minibatches run (each consumed three noise streams)."""
+        self._stepped = True
         n_done = C.c_int32(0)
         _lib.check(self.lib.bgm_bnn_fit_epoch(self.h, _ptr(x), _ptr(y), _ptr(v), _ptr(data_z), _ptr(zm), _ptr(zv), _ptr(perm),
                                               data_z.shape[0], int(perm.numel()), int(batch), float(lr_theta), float(lr_z), int(lazy),
@@ -246,6 +269,7 @@ class BnnEngine(object):
         for i, u in enumerate(units):
             cfg.dz_units[i] = u
         self.n_dz = theta.size
+        self._stepped = True          # (the warm start's state lives in the session: no re-begin from here on, ensure_max_batch)
         _lib.check(self.lib.bgm_bnn_egm_begin(self.h, C.byref(cfg), theta.ctypes.data_as(C.c_void_p), theta.size, self._stream()),
                    "bgm_bnn_egm_begin")
 

@@ -169,7 +169,7 @@ extern "C" int bgm_bnn_begin(bgm_handle *h, const bgm_bnn_config *cfg, const flo
   if (!h) { bgm_set_error("bgm_bnn_begin: NULL handle"); return BGM_E_INVALID; }
   if (!cfg || !theta_host) { bgm_set_error("bgm_bnn_begin: NULL argument"); return BGM_E_INVALID; }
   if (cfg->norm_mode != 0 && cfg->norm_mode != 1) { bgm_set_error("bgm_bnn_begin: norm_mode must be 0 or 1"); return BGM_E_INVALID; }
-  if (cfg->max_batch < 2 || cfg->max_batch > BNN_MAX_BATCH) { bgm_set_error("bgm_bnn_begin: max_batch must be in [2, 256]"); return BGM_E_UNSUPPORTED; }
+  if (cfg->max_batch < 2 || cfg->max_batch > BNN_MAX_BATCH) { bgm_set_error("bgm_bnn_begin: max_batch must be in [2, 4096]"); return BGM_E_UNSUPPORTED; }
   BGM_HIP_CHECK(hipSetDevice(h->device));
   bgm_bnn_free_state(h);
   BnnState *s = new BnnState();

@@ -26,7 +26,7 @@
 #define BNN_SCALE_EPS 1.1920928955078125e-07f
 #define BNN_TAG_EPS 8u
 #define BNN_TAG_SIGN 9u
-#define BNN_MAX_BATCH 256          // rows of a minibatch step (one workgroup per net walks them; the row-tile chains serve 16 / 32)
+#define BNN_MAX_BATCH 4096         // rows of a minibatch step (one workgroup per net walks them: a correctness path beyond a few hundred rows; the row-tile chains serve 16 / 32)
 
 // One BayesianFullyConnectedNet.  Parameters (flat, at theta + off): gamma[in], beta[in], then per layer
 // loc[in x out], rho[in x out], bias[out].  All prefix tables are filled on the host (bnn_finish_net).

@@ -13,7 +13,7 @@ which is what Keras 2.10's documented training-mode propagation implies for the 
 treatment column is then normalised away and the ADRF is flat (DESIGN_HISTORY.md section 7).
 
 Stated differences (DESIGN.md "Bayesian nets"): the noise streams are the build's counter-based ones (oracle/bnn.py);
-minibatches are limited to 256 rows (16 and 32 run on the row-tile chains, other sizes on the one-workgroup-per-net kernels); under torch.distributed every rank normalises with the statistics of ITS rows.
+minibatches hold up to 4096 rows per rank (16 and 32 run on the row-tile chains, other sizes on the one-workgroup-per-net kernels; the session is sized for 256 and re-opened for more before its first step, or by params['max_batch']); under torch.distributed every rank normalises with the statistics of ITS rows.
 """
 import datetime
 import os
@@ -77,7 +77,7 @@ class CausalBGMBayes(CausalBGM):
         if device is None:
             device = int(os.environ.get("BGM_DEVICE", os.environ.get("LOCAL_RANK", 0)))
         self.engine = BnnEngine(p["v_dim"], z, binary_treatment=p["binary_treatment"], g_units=p["g_units"], e_units=p["e_units"],
-                                f_units=p["f_units"], h_units=p["h_units"], kl_weight=p["kl_weight"], max_batch=256,
+                                f_units=p["f_units"], h_units=p["h_units"], kl_weight=p["kl_weight"], max_batch=int(params.get("max_batch", 256)),
                                 norm_mode={"batch": 0, "fixed": 1}[self._bnn_norm], device=device,
                                 sigma_v=params.get("sigma_v"), sigma_x=params.get("sigma_x"), sigma_y=params.get("sigma_y"))
         self.engine.set_disc_norm(_disc_norm(p))
@@ -165,6 +165,7 @@ class CausalBGMBayes(CausalBGM):
         emu = int(getattr(self, "_egm_emulate_world", 0)) if world == 1 else 0
         if emu > 1:
             b_loc = (batch_size // emu) * emu
+        eng.ensure_max_batch(b_loc)          # (base.py:380: any batch_size; the session is sized here, before its first step)
         xd, yd, vd = self._dev(data_x[lo_r:hi_r]).reshape(-1), self._dev(data_y[lo_r:hi_r]).reshape(-1), self._dev(data_v[lo_r:hi_r])
         q = sum(p_["z_dims"])
         dims = [q] + list(p_["dz_units"]) + [1]
@@ -254,13 +255,15 @@ class CausalBGMBayes(CausalBGM):
     def fit(self, data, epochs=100, epochs_per_eval=5, batch_size=32, startoff=0, use_egm_init=True,
             egm_n_iter=30000, egm_batches_per_eval=500, save_format='txt', verbose=1, z_adam=None, host_loop=False):
         """Iterative theta / Z updates (base.py:434-532) with the KL terms of the Bayesian nets.  ``batch_size`` is the
-        GLOBAL minibatch (<= 256 per rank); under torch.distributed rows are sharded, the g | h | f gradients all-reduced.
+        GLOBAL minibatch (any size as in base.py:434; up to 4096 rows per rank, 16 / 32 on the row-tile chains, other sizes on the
+        one-workgroup-per-net kernels); under torch.distributed rows are sharded, the g | h | f gradients all-reduced.
         ``host_loop=False`` (single process): one library call per epoch (bgm_bnn_fit_epoch), the latent phase of a minibatch beside
         the chains of the next on a second stream; ``True``: the per-minibatch calls from Python (same results)."""
         if z_adam is None:
             z_adam = "replay"
             diagnostics.notice_once("z_adam", "fit(z_adam=...) not given: the latent Adam runs in its replayed form ('replay': equal to Keras' "
                                     "dense-decay sweep up to fp32 rounding); 'dense' executes the sweep as the reference does (DESIGN_HISTORY.md section 4d)")
+        self.engine.ensure_max_batch(max(2, batch_size // parallel.world_size()))
         if use_egm_init:
             self.egm_init(data, egm_n_iter=egm_n_iter, batch_size=batch_size,
                           egm_batches_per_eval=egm_batches_per_eval, verbose=verbose)

@@ -56,15 +56,16 @@ ACIC = (3, 6, 3, 6)       # Semi_acic.yaml: q = 18, two latent input tiles on th
     (False, 32, {}, 45, ZD),                                                     # ... the 13-tile kernels on a narrower panel (masked columns)
     (True, 32, {}, 177, ACIC), (False, 32, {}, 100, (5, 5, 5, 5)),               # ... with two latent input tiles (Semi_acic, Sim_Colangelo)
     (False, 100, {}, 50, ZD), (True, 160, {}, 200, ZD),                          # minibatches beyond 64 rows (any batch_size, causalbgm/base.py:434): batch statistics / fixed normalisation
+    (False, 300, {}, 50, ZD), (True, 520, {}, 100, ZD),                          # ... and beyond 256
 ])
 def test_theta_step_gradients_match_oracle(binary, B, units, p, zd):
     chain = p >= 100 or p == 45
     m = _model(binary, z_dims=zd, p=p, fixed=chain, **units)
-    z, x, y, v = _panel(m, 200)
+    z, x, y, v = _panel(m, max(200, B + 40))
     eng = _engine(m, max_batch=max(32, B), kl_weight=0.01, **(dict(norm_mode=1) if chain else {}), **units)
     dev = eng.device
     rs = np.random.RandomState(4)
-    idx = rs.choice(200, B, replace=False).astype(np.int32)
+    idx = rs.choice(max(200, B + 40), B, replace=False).astype(np.int32)
     seed, stream = (5 << 32) | 77, 12
     out = torch.zeros(8, device=dev)
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -87,14 +88,15 @@ def test_theta_step_gradients_match_oracle(binary, B, units, p, zd):
 
 @pytest.mark.parametrize("binary,p,B,zd", [(False, 50, 32, ZD), (True, 50, 32, ZD), (False, 200, 32, ZD), (True, 100, 32, ZD), (False, 100, 16, ZD),
                                            (True, 45, 32, ZD), (True, 177, 32, ACIC), (False, 100, 32, (5, 5, 5, 5)),
-                                           (False, 50, 96, ZD), (True, 200, 100, ZD)])          # minibatches beyond 64 rows
+                                           (False, 50, 96, ZD), (True, 200, 100, ZD),           # minibatches beyond 64 rows
+                                           (False, 50, 300, ZD), (True, 100, 520, ZD)])         # ... and beyond 256
 def test_z_step_gradient_matches_oracle(binary, p, B, zd):
     chain = p >= 100 or p == 45
     m = _model(binary, z_dims=zd, p=p, fixed=chain)
-    z, x, y, v = _panel(m, 100)
+    z, x, y, v = _panel(m, max(100, B))
     eng = _engine(m, max_batch=max(32, B), norm_mode=1) if chain else _engine(m, max_batch=max(32, B))
     dev = eng.device
-    idx = np.random.RandomState(9).choice(100, B, replace=False).astype(np.int32)
+    idx = np.random.RandomState(9).choice(max(100, B), B, replace=False).astype(np.int32)
     seed, stream = 123456789, 40
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     out = torch.zeros(4, device=dev)
@@ -590,7 +592,7 @@ def test_epoch_loop_inside_the_library_equals_the_host_loop(tmp_path, z_adam):
 
 
 def test_fit_with_minibatches_beyond_64_rows(tmp_path):
-    """fit(batch_size=...) takes any size in the reference (causalbgm/base.py:434); here up to 256 rows per rank: sizes other than 16 / 32
+    """fit(batch_size=...) takes any size in the reference (causalbgm/base.py:434); here up to 4096 rows per rank: sizes other than 16 / 32
     run the one-workgroup-per-net step kernels, incl. the EGM warm start and the short last minibatch of an epoch (600 = 4 x 128 + 88)."""
     from bayesgm_amd.models import CausalBGM
     from bayesgm_amd.datasets import Sim_Hirano_Imbens_sampler
@@ -600,8 +602,18 @@ def test_fit_with_minibatches_beyond_64_rows(tmp_path):
     model.fit((x, y, v), epochs=3, epochs_per_eval=3, batch_size=128, use_egm_init=True, egm_n_iter=30, egm_batches_per_eval=30, verbose=0)
     _, mx1, my1, mv1 = model.evaluate((x, y, v), data_z=model.data_z.cpu().numpy())
     assert np.isfinite([mx1, my1, mv1]).all() and mv1 < mv0
-    with pytest.raises(Exception):
+    with pytest.raises(ValueError, match="max_batch"):      # the session has been sized for 256 rows and has taken steps
         model.fit((x, y, v), epochs=1, batch_size=300, use_egm_init=False, verbose=0)
+    # beyond 256 rows per rank: the session is re-opened for the larger minibatch before its first step (or sized by params['max_batch'])
+    for extra in ({}, {"max_batch": 512}):
+        prm = _params(tmp_path, False)
+        prm.update(extra)
+        big = CausalBGM(prm, random_seed=3)
+        _, _, _, mv0 = big.evaluate((x, y, v))
+        big.fit((x, y, v), epochs=3, epochs_per_eval=3, batch_size=300, use_egm_init=True, egm_n_iter=30, egm_batches_per_eval=30, verbose=0)
+        _, mx1, my1, mv1 = big.evaluate((x, y, v), data_z=big.data_z.cpu().numpy())
+        assert np.isfinite([mx1, my1, mv1]).all() and mv1 < mv0
+        assert big.engine.cfg.max_batch == (512 if extra else 300)
 
 
 @pytest.mark.parametrize("fixed_norm,p,B", [(True, 100, 32), (True, 100, 16), (False, 50, 19), (True, 50, 40)])
