@@ -172,6 +172,7 @@ struct BnnCache {
   float *H, *HS;      // h_l and h_l * s_in(l) at B * hin[l] / B * hsin[l]
   float *eps, *dW;    // [kernel elements]
   uint32_t *sg;       // [B x swords]
+  const float *ext = nullptr;   // given statistics of the input columns, mean [in] | variance [in] (bnw_kernels.h: the statistics of a BLOCK of rows the call's tile belongs to)
 };
 __device__ __forceinline__ void bnn_cache(const BnnNet &n, int B, float *&p, BnnCache &k, const float *input) {
   auto take = [&](long long cnt) { float *r = p; p += (cnt + 3) & ~3LL; return r; };
@@ -219,7 +220,8 @@ __device__ __forceinline__ void bnn_bn_fwd(const BnnCtx &c, const float *theta, 
   const float *gamma = theta + n.off, *beta = gamma + in, *mvs = beta + in;
   for (int i = c.tid; i < in; i += BNN_THREADS) {
     float mu, var;
-    if (n.bn_fixed == 1) { mu = 0.0f; var = 1.0f; }
+    if (k.ext) { mu = k.ext[i]; var = k.ext[in + i]; }
+    else if (n.bn_fixed == 1) { mu = 0.0f; var = 1.0f; }
     else if (n.bn_fixed == 2) { mu = mvs[i]; var = mvs[in + i]; }
     else {
       float s = 0.0f;

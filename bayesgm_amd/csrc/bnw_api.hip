@@ -11,6 +11,8 @@
 struct BnwState {
   float *dw = nullptr, *ws = nullptr, *pair = nullptr;
   size_t dw_cap = 0, ws_cap = 0;
+  float *st = nullptr;          // batch statistics (params['bnn_norm'] = "batch"), doubles: [2 parities][n_blocks][256] | x [n_blocks][2] | v [2][p]
+  size_t st_cap = 0;
 };
 
 void bnw_free(void *p) {
@@ -19,14 +21,14 @@ void bnw_free(void *p) {
   if (b->dw) hipFree(b->dw);
   if (b->ws) hipFree(b->ws);
   if (b->pair) hipFree(b->pair);
+  if (b->st) hipFree(b->st);
   delete b;
 }
 
 namespace {
 int bnw_need(BnnState *s, const char *who) {
-  if (s->cfg.norm_mode != 1) {
-    bgm_set_error(std::string(who) + ": hidden widths beyond 64 are sampled with params['bnn_norm'] = 'fixed' only (the batch-statistics "
-                  "kernels hold hidden widths <= 64, inputs <= 208)");
+  if (s->cfg.norm_mode != 1 && s->q > 64) {
+    bgm_set_error(std::string(who) + ": batch statistics (params['bnn_norm'] = 'batch') hold at most 64 latent columns");
     return BGM_E_UNSUPPORTED;
   }
   for (int k = 0; k < 4; ++k)
@@ -36,7 +38,7 @@ int bnw_need(BnnState *s, const char *who) {
 // sets of this launch hold the nets listed in ids (order = layout)
 void bnw_nets(const BnnState *s, const int *ids, int n_ids, BnwNets &m) {
   std::memset(&m, 0, sizeof(m));
-  for (int k = 0; k < 4; ++k) { m.net[k] = s->net[k]; m.net[k].bn_fixed = 1; m.noff[k] = -1; }
+  for (int k = 0; k < 4; ++k) { m.net[k] = s->net[k]; m.net[k].bn_fixed = 1; m.noff[k] = -1; }      // ("batch": every call is given its block's statistics, BnwStats)
   long long off = 0;
   for (int i = 0; i < n_ids; ++i) { m.noff[ids[i]] = (int)off; off += (s->net[ids[i]].eoff[s->net[ids[i]].n_layers] + 3) & ~3; }
   m.set_floats = off;
@@ -73,6 +75,35 @@ int bnw_plan(bgm_handle *h, BnnState *s, const BnwNets &m, long long n_sets_tota
   }
   return BGM_OK;
 }
+// batch statistics: zeroed buffers of this call; stats(par) = the parity a launch accumulates into
+struct BnwBatch {
+  bool on = false;
+  double *stats = nullptr, *xstats = nullptr, *vstats = nullptr;
+  int n_blocks = 0;
+  const double *parity(int par) const { return stats + (long long)par * n_blocks * 256; }
+};
+int bnw_batch(BnnState *s, BnwState *b, int n_blocks, BnwBatch &bt, hipStream_t stream) {
+  bt.on = s->cfg.norm_mode != 1;
+  bt.n_blocks = n_blocks;
+  if (!bt.on) return BGM_OK;
+  const size_t doubles = (size_t)2 * n_blocks * 256 + (size_t)2 * n_blocks + (size_t)2 * s->p + 16;
+  int rc = bnw_grow(&b->st, &b->st_cap, 2 * doubles, stream);
+  if (rc) return rc;
+  bt.stats = reinterpret_cast<double *>(b->st);
+  bt.xstats = bt.stats + (size_t)2 * n_blocks * 256;
+  bt.vstats = bt.xstats + (size_t)2 * n_blocks;
+  BGM_HIP_CHECK(hipMemsetAsync(b->st, 0, sizeof(double) * doubles, stream));
+  return BGM_OK;
+}
+// column sums of the states z (slot 1) and of their proposals of iteration `it` (slot 0) into parity `par`; with_x: the treatment column too
+void bnw_stats(const BnwBatch &bt, const float *z, long long n, long long row_base, int q, int bs, int it, int init, float q_sd, const float *q_sd_blocks,
+               uint64_t seed, int par, const float *x, bool with_x, hipStream_t stream) {
+  BnwStatArgs sa{};
+  sa.z = z; sa.n = n; sa.row_base = row_base; sa.q = q; sa.bs = bs; sa.wg_per_block = (bs + 255) / 256; sa.it = it; sa.init = init;
+  sa.q_sd = q_sd; sa.q_sd_blocks = q_sd_blocks; sa.k0 = (uint32_t)seed; sa.k1 = (uint32_t)(seed >> 32);
+  sa.stats = bt.stats; sa.n_blocks = bt.n_blocks; sa.par = par; sa.x = x; sa.xstats = with_x ? bt.xstats : nullptr;
+  hipLaunchKernelGGL(bnw_stats_kernel, dim3((unsigned)(bt.n_blocks * sa.wg_per_block)), dim3(256), 0, stream, sa);
+}
 void bnw_noise(const BnwNets &m, float *dw, int n_blocks, int n_calls, int block0, uint64_t seed, uint32_t stream0, uint32_t stride, hipStream_t stream) {
   BnwNoiseArgs na{};
   na.m = m; na.dw = dw; na.n_calls = n_calls; na.block0 = block0;
@@ -96,6 +127,13 @@ int bnw_logpost(bgm_handle *h, BnnState *s, const float *x, const float *y, cons
   rc = bnw_plan(h, s, a.m, n_blocks, n_blocks * tpb, pl, stream);
   if (rc) return rc;
   bnw_noise(a.m, pl.b->dw, n_blocks, 1, block0, seed, stream_id, 0u, stream);
+  BnwBatch bt;
+  rc = bnw_batch(s, pl.b, n_blocks, bt, stream);
+  if (rc) return rc;
+  if (bt.on) {                          // the call's batch = a block of rows: its statistics (slot 1 = the states themselves)
+    bnw_stats(bt, z, n, 0, s->q, bs, 0, 0, 0.0f, nullptr, seed, 0, x, true, stream);
+    a.stats = bt.parity(0); a.xstats = bt.xstats;
+  }
   a.dw = pl.b->dw; a.n_calls = 1; a.x = x; a.y = y; a.v = v; a.z = const_cast<float *>(z); a.n = n; a.row_base = 0;
   a.bs = bs; a.block0 = block0; a.tiles_per_block = tpb; a.n_items = n_blocks * tpb; a.mode = 0;
   a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32); a.stream0 = stream_id; a.out = out; a.ws = pl.b->ws; a.ws_stride = pl.ws_stride;
@@ -107,9 +145,10 @@ int bnw_logpost(bgm_handle *h, BnnState *s, const float *x, const float *y, cons
 namespace {
 int bnw_effects_of(const BnwNets &mf, const BnwPlan &pl, float *dw_eff, const float *z, long long n, int bs, int n_blocks, int block0, long long row_base,
                    int n_doses, const float *xvals, uint64_t seed, uint32_t stream0, uint32_t it_noise, int sample_y, double *sum_out,
-                   long long sum_stride, float *ite_out, long long ite_stride, hipStream_t stream) {
+                   long long sum_stride, float *ite_out, long long ite_stride, hipStream_t stream, const double *stats = nullptr) {
   bnw_noise(mf, dw_eff, n_blocks, n_doses, block0, seed, stream0, 1u, stream);
   BnwEffArgs e{};
+  e.stats = stats;
   e.m = mf; e.dw = dw_eff; e.z = z; e.n = n; e.row_base = row_base; e.bs = bs; e.block0 = block0;
   e.tiles_per_block = (bs + BNW_RT - 1) / BNW_RT; e.n_items = n_blocks * e.tiles_per_block; e.n_doses = n_doses; e.xvals = xvals;
   e.k0 = (uint32_t)seed; e.k1 = (uint32_t)(seed >> 32); e.stream0 = stream0; e.it_noise = it_noise; e.sample_y = sample_y;
@@ -143,24 +182,42 @@ int bnw_mh_run(bgm_handle *h, BnnState *s, const bgm_bnn_mh_args *g, hipStream_t
   a.q_sd = g->q_sd; a.q_sd_blocks = g->q_sd_blocks_dev;
   a.k0 = (uint32_t)g->seed; a.k1 = (uint32_t)(g->seed >> 32); a.acc_count = g->acc_count_dev;
   a.ws = pl.b->ws; a.ws_stride = pl.ws_stride;
+  BnwBatch bt;
+  rc = bnw_batch(s, pl.b, n_blocks, bt, stream);
+  if (rc) return rc;
+  a.xstats = bt.xstats;
+  // effects of the draw kept by iteration it_kept; batch statistics: those of the states AFTER its accept step = slot 1 of the
+  // statistics pass in front of the next iteration (parity `par`)
+  auto effects = [&](int it_kept, int par) -> int {
+    const int d = it_kept - g->burn_in;
+    return bnw_effects_of(mf, pl, dw_eff, g->state_dev, n, bs, n_blocks, g->block0, g->row_base, n_doses,
+                          g->effect == 1 ? g->x_values_dev : pl.b->pair, g->seed, 0x40000000u + (uint32_t)d * (uint32_t)n_doses, (uint32_t)it_kept,
+                          g->sample_y, g->effect == 1 ? g->adrf_sum_dev + d : nullptr, g->n_keep, g->effect == 2 ? g->ite_dev + d : nullptr,
+                          g->n_keep, stream, bt.on ? bt.parity(par) : nullptr);
+  };
+  auto kept = [&](int it) { return g->effect && it >= g->burn_in && it - g->burn_in < g->n_keep; };
   for (int i = 0; i < g->n_iters; ++i) {
     const int it = g->it_begin + i;
     bnw_noise(a.m, pl.b->dw, n_blocks, 2, g->block0, g->seed, 2u * (uint32_t)it, 1u, stream);
     a.it = it; a.init = (i == 0 && g->init) ? 1 : 0;
+    if (bt.on) {
+      bnw_stats(bt, g->state_dev, n, g->row_base, q, bs, it, a.init, g->q_sd, g->q_sd_blocks_dev, g->seed, i & 1, g->x_dev, i == 0, stream);
+      if (i > 0 && kept(it - 1) && (rc = effects(it - 1, i & 1))) return rc;
+      a.stats = bt.parity(i & 1);
+    }
     a.acc_blocks = g->acc_blocks_dev ? g->acc_blocks_dev + (long long)i * n_blocks : nullptr;
     hipLaunchKernelGGL(bnw_rows_kernel, dim3(pl.grid), dim3(BNN_THREADS), 0, stream, a);
     const int d = it - g->burn_in;
     if (d >= 0 && d < g->n_keep) {
       if (g->draws_dev)
         BGM_HIP_CHECK(hipMemcpyAsync(g->draws_dev + (long long)d * n * q, g->state_dev, sizeof(float) * n * q, hipMemcpyDeviceToDevice, stream));
-      if (g->effect) {
-        rc = bnw_effects_of(mf, pl, dw_eff, g->state_dev, n, bs, n_blocks, g->block0, g->row_base, n_doses,
-                            g->effect == 1 ? g->x_values_dev : pl.b->pair, g->seed, 0x40000000u + (uint32_t)d * (uint32_t)n_doses, (uint32_t)it,
-                            g->sample_y, g->effect == 1 ? g->adrf_sum_dev + d : nullptr, g->n_keep, g->effect == 2 ? g->ite_dev + d : nullptr,
-                            g->n_keep, stream);
-        if (rc) return rc;
-      }
+      if (!bt.on && g->effect && (rc = effects(it, 0))) return rc;
     }
+  }
+  if (bt.on && g->n_iters > 0 && kept(g->it_begin + g->n_iters - 1)) {      // statistics of the final states: one more pass (its proposals are not used)
+    const int i = g->n_iters;
+    bnw_stats(bt, g->state_dev, n, g->row_base, q, bs, g->it_begin + i, 0, g->q_sd, g->q_sd_blocks_dev, g->seed, i & 1, g->x_dev, false, stream);
+    if ((rc = effects(g->it_begin + i - 1, i & 1))) return rc;
   }
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
@@ -178,10 +235,15 @@ int bnw_effects(bgm_handle *h, BnnState *s, const float *draws, int64_t n, int32
   BnwPlan pl;
   rc = bnw_plan(h, s, mf, (long long)n_blocks * nd, n_blocks * tpb, pl, stream);
   if (rc) return rc;
+  BnwBatch bt;
+  rc = bnw_batch(s, pl.b, n_blocks, bt, stream);
+  if (rc) return rc;
   for (int d = 0; d < n_keep; ++d) {
-    rc = bnw_effects_of(mf, pl, pl.b->dw, draws + (long long)d * n * q, n, bs, n_blocks, block0, row_base, nd, effect == 1 ? x_values : pl.b->pair, seed,
+    const float *zd = draws + (long long)d * n * q;
+    if (bt.on) bnw_stats(bt, zd, n, row_base, q, bs, d, 0, 0.0f, nullptr, seed, d & 1, nullptr, false, stream);      // statistics of this draw (slot 1)
+    rc = bnw_effects_of(mf, pl, pl.b->dw, zd, n, bs, n_blocks, block0, row_base, nd, effect == 1 ? x_values : pl.b->pair, seed,
                         0x40000000u + (uint32_t)d * (uint32_t)nd, (uint32_t)(it0 + d), sample_y, effect == 1 ? adrf_sum + d : nullptr, n_keep,
-                        effect == 2 ? ite + d : nullptr, n_keep, stream);
+                        effect == 2 ? ite + d : nullptr, n_keep, stream, bt.on ? bt.parity(d & 1) : nullptr);
     if (rc) return rc;
   }
   return BGM_OK;
@@ -207,9 +269,22 @@ int bnw_evaluate(bgm_handle *h, BnnState *s, const float *x, const float *y, con
   a.dw = pl.b->dw; a.n_calls = 1; a.x = x; a.y = y; a.v = v; a.z = z; a.n = n; a.row_base = 0; a.bs = bs; a.block0 = 0;
   a.tiles_per_block = tpb; a.n_items = tpb; a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32); a.stream0 = stream_id;
   a.ws = pl.b->ws; a.ws_stride = pl.ws_stride;
+  BnwBatch bt;                          // "batch": the whole panel is the batch of every call
+  rc = bnw_batch(s, pl.b, 1, bt, stream);
+  if (rc) return rc;
   if (encode) {
+    if (bt.on) {
+      hipLaunchKernelGGL(bnw_colstats_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 256), (unsigned)std::min(s->p, 1024)), dim3(256), 0, stream,
+                         v, (long long)n, s->p, bt.vstats);
+      a.vstats = bt.vstats;
+    }
     a.mode = 3;
     hipLaunchKernelGGL(bnw_rows_kernel, dim3(pl.grid), dim3(BNN_THREADS), 0, stream, a);
+    a.vstats = nullptr;
+  }
+  if (bt.on && (sums || nd)) {          // statistics of z (slot 1) and of x
+    bnw_stats(bt, z, n, 0, s->q, bs, 0, 0, 0.0f, nullptr, seed, 0, x, x != nullptr, stream);
+    a.stats = bt.parity(0); a.xstats = bt.xstats;
   }
   if (sums) {
     BGM_HIP_CHECK(hipMemsetAsync(sums, 0, 3 * sizeof(double), stream));
@@ -219,7 +294,7 @@ int bnw_evaluate(bgm_handle *h, BnnState *s, const float *x, const float *y, con
   if (nd) {
     if (dose_sums) BGM_HIP_CHECK(hipMemsetAsync(dose_sums, 0, sizeof(double) * nd, stream));
     rc = bnw_effects_of(mf, pl, dw_eff, z, n, bs, 1, 0, 0, nd, dose_sums ? x_values : pl.b->pair, seed, stream_id + 1u, 0u, 0, dose_sums, 1,
-                        dose_sums ? nullptr : ite, 1, stream);
+                        dose_sums ? nullptr : ite, 1, stream, bt.on ? bt.parity(0) : nullptr);
     if (rc) return rc;
   }
   BGM_HIP_CHECK(hipGetLastError());

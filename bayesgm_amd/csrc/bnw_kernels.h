@@ -1,5 +1,7 @@
-// bnw_kernels.h -- posterior sampling, causal effects and evaluation of CausalBGM with Bayesian networks of ANY hidden width
-// (inference-mode input normalisation, params['bnn_norm'] = "fixed") on gfx950.
+// bnw_kernels.h -- posterior sampling, causal effects and evaluation of CausalBGM with Bayesian networks of ANY hidden width on gfx950:
+// inference-mode input normalisation (params['bnn_norm'] = "fixed") or, as the reference is written (networks/bnn.py:25-27), the
+// statistics of the batch a call sees = a block of `bs` rows of predict / the whole panel of evaluate ("batch": bnw_stats_kernel sums
+// the columns of a block's states and proposals in fp64, every tile of the block normalises with them).
 //
 // replaces (src/bayesgm/models/causalbgm/base.py, use_bnn branches; networks/bnn.py:4-38 with any nb_units):
 //   get_log_posterior :765-817, metropolis_hastings_sampler :820-904   -> bnw_noise_kernel + bnw_rows_kernel (modes 0 / 1)
@@ -57,6 +59,101 @@ static __global__ __launch_bounds__(256) void bnw_noise_kernel(BnwNoiseArgs a) {
   }
 }
 
+// ---- batch statistics of a block (params['bnn_norm'] = "batch") ---------------------------------------------------------------
+// stats: double [2 parities][n_blocks][2 (0: proposal, 1: current state)][2 (sum, sum of squares)][64 columns] -- a launch accumulates
+// into parity `par` and clears the other one for the next iteration; xstats: [n_blocks][2] sums of the treatment column (once per run).
+// Same proposals as bnw_rows_kernel forms (bnw_normal), same layout as the narrow family's bns_propose_kernel.
+struct BnwStatArgs {
+  const float *z;
+  long long n, row_base;
+  int q, bs, wg_per_block, it, init;
+  float q_sd;
+  const float *q_sd_blocks;
+  uint32_t k0, k1;
+  double *stats;
+  int n_blocks, par;
+  const float *x; double *xstats;
+};
+__device__ __forceinline__ float bnw_normal(uint32_t row, uint32_t it, int f, uint32_t tag, uint32_t k0, uint32_t k1);
+static __global__ __launch_bounds__(256) void bnw_stats_kernel(BnwStatArgs a) {
+  __shared__ double red[4][4];
+  const int blk = blockIdx.x / a.wg_per_block, wib = blockIdx.x - blk * a.wg_per_block;
+  const long long r_in = (long long)wib * 256 + threadIdx.x, row = (long long)blk * a.bs + r_in;
+  const bool valid = r_in < a.bs && row < a.n;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (blockIdx.x == 0) {
+    double *clr = a.stats + (long long)(a.par ^ 1) * a.n_blocks * 256;
+    for (long long i = threadIdx.x; i < (long long)a.n_blocks * 256; i += 256) clr[i] = 0.0;
+  }
+  const uint32_t rid = (uint32_t)(a.row_base + row);
+  const float sd = a.q_sd_blocks ? a.q_sd_blocks[blk] : a.q_sd;
+  double *st = a.stats + ((long long)a.par * a.n_blocks + blk) * 256;
+  for (int f = 0; f < a.q; ++f) {
+    float zc = 0.0f, zp = 0.0f;
+    if (valid) {
+      zc = a.init ? bnw_normal(rid, 0u, f, TAG_INIT, a.k0, a.k1) : a.z[row * a.q + f];
+      zp = fmaf(sd, bnw_normal(rid, (uint32_t)a.it, f, TAG_PROP, a.k0, a.k1), zc);
+    }
+    double s[4] = {(double)zp, (double)zp * zp, (double)zc, (double)zc * zc};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_xor(s[k], off);
+      if (lane == 0) red[wave][k] = s[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) atomicAdd(&st[threadIdx.x * 64 + f], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    __syncthreads();
+  }
+  if (a.xstats) {
+    const double xv = valid ? (double)a.x[row] : 0.0;
+    double xs = xv, xs2 = xv * xv;
+    for (int off = 32; off > 0; off >>= 1) { xs += __shfl_xor(xs, off); xs2 += __shfl_xor(xs2, off); }
+    if (lane == 0) { atomicAdd(&a.xstats[2 * blk], xs); atomicAdd(&a.xstats[2 * blk + 1], xs2); }
+  }
+}
+// column sums / sums of squares of an [n x d] matrix: st[0 .. d) | st[d .. 2 d)   (evaluate: the encoder's input)
+static __global__ __launch_bounds__(256) void bnw_colstats_kernel(const float *m, long long n, int d, double *st) {
+  __shared__ double red[4][2];
+  for (int col = blockIdx.y; col < d; col += gridDim.y) {
+    double s = 0.0, s2 = 0.0;
+    for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < n; r += (long long)gridDim.x * 256) { const double x = (double)m[r * d + col]; s += x; s2 += x * x; }
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); s2 += __shfl_xor(s2, off); }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = s; red[threadIdx.x >> 6][1] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) { atomicAdd(&st[col], red[0][0] + red[1][0] + red[2][0] + red[3][0]); atomicAdd(&st[d + col], red[0][1] + red[1][1] + red[2][1] + red[3][1]); }
+  }
+}
+// what a tile needs of its block's statistics (all NULL: inference-mode normalisation)
+struct BnwStats {
+  const double *st;      // [2 (sum, sum of squares)][64] of the latent columns of the state the call is made on
+  const double *xst;     // [2] of the treatment column (NULL with `dose`)
+  const double *vst;     // [2][p] of the covariates (encoder call)
+  double cnt;            // rows of the block
+  int dose;              // the treatment column is a constant (infer_from_latent_posterior: mean = the dose, variance 0)
+  float dose_x;
+};
+// mean | variance of net `id`'s input columns -> ext [2 x in]   (column maps as bnw_inputs)
+__device__ __forceinline__ void bnw_ext(const BnnCtx &c, const BnwNets &m, int id, const BnwStats &S, float *ext) {
+  const int in = m.net[id].dims[0];
+  for (int u = c.tid; u < in; u += BNN_THREADS) {
+    double sm, sq;
+    bool konst = false;
+    if (id == BNN_E) { sm = S.vst[u]; sq = S.vst[in + u]; }
+    else {
+      int col = u;
+      if (id == BNN_H) col = u < m.z0 ? u : u + m.z1;
+      if (id == BNN_F && u >= m.z0 + m.z1) {
+        if (S.dose) { konst = true; sm = sq = 0.0; }
+        else { sm = S.xst[0]; sq = S.xst[1]; }
+      } else { sm = S.st[col]; sq = S.st[64 + col]; }
+    }
+    if (konst) { ext[u] = S.dose_x; ext[in + u] = 0.0f; }
+    else { const double mm = sm / S.cnt; ext[u] = (float)mm; ext[in + u] = (float)fmax(sq / S.cnt - mm * mm, 0.0); }
+  }
+  __syncthreads();
+}
+
 // call cache without private perturbation arrays (the call's dW is shared by all tiles of the block)
 __device__ __forceinline__ void bnw_cache(const BnnNet &n, int B, float *p, BnnCache &k, const float *input, const float *dw) {
   auto take = [&](long long cnt) { float *r = p; p += (cnt + 3) & ~3LL; return r; };
@@ -77,13 +174,18 @@ inline size_t bnw_cache_floats(const BnnNet &n, int B) {
 inline size_t bnw_ws_floats(const BnwNets &m) {
   size_t c = 0;
   for (int k = 0; k < 4; ++k) c = std::max(c, bnw_cache_floats(m.net[k], BNW_RT));
-  return (size_t)BNW_RT * (2 * (size_t)m.q + m.net[BNN_F].dims[0] + m.net[BNN_H].dims[0] + 8) + c + 256;
+  int in_max = 0;
+  for (int k = 0; k < 4; ++k) in_max = std::max(in_max, m.net[k].dims[0]);
+  return (size_t)BNW_RT * (2 * (size_t)m.q + m.net[BNN_F].dims[0] + m.net[BNN_H].dims[0] + 8) + 2 * (size_t)in_max + 8 + c + 256;
 }
-struct BnwWs { float *zp, *zc, *fin, *hin, *cache; };
+struct BnwWs { float *zp, *zc, *fin, *hin, *ext, *cache; };
 __device__ __forceinline__ void bnw_take(float *wp, const BnwNets &m, BnwWs &w) {
   auto take = [&](long long cnt) { float *r = wp; wp += (cnt + 3) & ~3LL; return r; };
   w.zp = take((long long)BNW_RT * m.q); w.zc = take((long long)BNW_RT * m.q);
   w.fin = take((long long)BNW_RT * m.net[BNN_F].dims[0]); w.hin = take((long long)BNW_RT * m.net[BNN_H].dims[0]);
+  int in_max = 0;
+  for (int k = 0; k < 4; ++k) in_max = max(in_max, m.net[k].dims[0]);
+  w.ext = take(2LL * in_max);
   w.cache = wp;
 }
 
@@ -96,9 +198,11 @@ __device__ __forceinline__ float bnw_normal(uint32_t row, uint32_t it, int f, ui
 
 // one call of net `id` on the tile's B rows (input [B x in] in the workspace or the panel); returns its output [B x wo]
 __device__ __forceinline__ const float *bnw_call(const BnnCtx &c, const BnwNets &m, int id, const BnwWs &w, const float *input, int B,
-                                                 const float *set, uint32_t k0, uint32_t k1, uint32_t stream, uint32_t row0) {
+                                                 const float *set, uint32_t k0, uint32_t k1, uint32_t stream, uint32_t row0,
+                                                 const BnwStats *S = nullptr) {
   BnnCache k;
   bnw_cache(m.net[id], B, w.cache, k, input, set + m.noff[id]);
+  if (S) { bnw_ext(c, m, id, *S, w.ext); k.ext = w.ext; }
   const float *o = bnn_fwd(c, m.theta, m.net[id], k, B, k0, k1, stream, row0, true);
   __syncthreads();
   return o;
@@ -113,10 +217,10 @@ __device__ __forceinline__ void bnw_inputs(const BnnCtx &c, const BnwNets &m, co
 // log p(z | x, y, v) + const of the tile's rows under the calls (set, stream): lp[b]   (base.py:765-817)
 __device__ __forceinline__ void bnw_logp(const BnnCtx &c, const BnwNets &m, const BnwWs &w, const float *zs, const float *x, const float *y,
                                          const float *v, int B, const float *set, uint32_t k0, uint32_t k1, uint32_t stream, uint32_t row0,
-                                         float *ssq, float *lp) {
+                                         float *ssq, float *lp, const BnwStats *S = nullptr) {
   const int p = m.p, q = m.q;
   {
-    const float *o = bnw_call(c, m, BNN_G, w, zs, B, set, k0, k1, stream, row0);
+    const float *o = bnw_call(c, m, BNN_G, w, zs, B, set, k0, k1, stream, row0, S);
     const int wo = p + 1;
     bnn_row_ssq(c, v, o, B, p, wo, ssq);
     __syncthreads();
@@ -130,7 +234,7 @@ __device__ __forceinline__ void bnw_logp(const BnnCtx &c, const BnwNets &m, cons
   }
   bnw_inputs(c, m, w, zs, x, B);
   {
-    const float *o = bnw_call(c, m, BNN_H, w, w.hin, B, set, k0, k1, stream, row0);
+    const float *o = bnw_call(c, m, BNN_H, w, w.hin, B, set, k0, k1, stream, row0, S);
     for (int b = c.tid; b < B; b += BNN_THREADS) {
       const float l = o[2 * b];
       if (m.binary) lp[b] -= fmaxf(l, 0.0f) - l * x[b] + log1pf(expf(-fabsf(l)));
@@ -139,7 +243,7 @@ __device__ __forceinline__ void bnw_logp(const BnnCtx &c, const BnwNets &m, cons
     __syncthreads();
   }
   {
-    const float *o = bnw_call(c, m, BNN_F, w, w.fin, B, set, k0, k1, stream, row0);
+    const float *o = bnw_call(c, m, BNN_F, w, w.fin, B, set, k0, k1, stream, row0, S);
     for (int b = c.tid; b < B; b += BNN_THREADS) {
       const float s2 = m.sig2[2] > 0.0f ? m.sig2[2] : softplus_acc(o[2 * b + 1]) + BGM_EPS, d = y[b] - o[2 * b];
       lp[b] -= d * d / (2.0f * s2) + logf(s2) * 0.5f;
@@ -166,6 +270,9 @@ struct BnwRowsArgs {
   double *sums;                         // mode 2: [3] += sums over rows of |v - v^|^2, (x - x^)^2, (y - y^)^2
   float *ws;
   long long ws_stride;
+  // batch statistics (NULL: inference-mode normalisation): this launch's parity of bnw_stats_kernel's sums [n_blocks][2][2][64],
+  // the treatment column's [n_blocks][2], the covariates' [2][p] (mode 3)
+  const double *stats, *xstats, *vstats;
 };
 
 static __global__ __launch_bounds__(BNN_THREADS) void bnw_rows_kernel(BnwRowsArgs a) {
@@ -187,8 +294,17 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnw_rows_kernel(BnwRowsArg
     const uint32_t k1b = a.k1 + (uint32_t)(a.block0 + blk);
     const float *xr = a.x ? a.x + r0 : nullptr, *yr = a.y ? a.y + r0 : nullptr, *vr = a.v ? a.v + r0 * p : nullptr;
     const float *set0 = a.dw + (long long)blk * a.n_calls * m.set_floats;
+    const bool batch = a.stats != nullptr || a.vstats != nullptr;
+    BnwStats Sc{}, Sp{};                // statistics of the block's current states / proposals
+    if (batch) {
+      Sc.cnt = Sp.cnt = (double)blk_n;
+      Sc.vst = Sp.vst = a.vstats;
+      Sc.xst = Sp.xst = a.xstats ? a.xstats + 2 * blk : nullptr;
+      if (a.stats) { Sp.st = a.stats + (long long)blk * 256; Sc.st = Sp.st + 128; }
+    }
+    const BnwStats *pSc = batch ? &Sc : nullptr, *pSp = batch ? &Sp : nullptr;
     if (a.mode == 3) {                  // data_z = e_net(data_v)
-      const float *o = bnw_call(c, m, BNN_E, w, vr, B, set0, a.k0, k1b, a.stream0, (uint32_t)rib0);
+      const float *o = bnw_call(c, m, BNN_E, w, vr, B, set0, a.k0, k1b, a.stream0, (uint32_t)rib0, pSc);
       for (int i = c.tid; i < B * q; i += BNN_THREADS) a.z[r0 * q + i] = o[i];
       __syncthreads();
       continue;
@@ -206,12 +322,12 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnw_rows_kernel(BnwRowsArg
     }
     __syncthreads();
     if (a.mode == 0) {
-      bnw_logp(c, m, w, w.zc, xr, yr, vr, B, set0, a.k0, k1b, a.stream0, (uint32_t)rib0, ssq, lpc);
+      bnw_logp(c, m, w, w.zc, xr, yr, vr, B, set0, a.k0, k1b, a.stream0, (uint32_t)rib0, ssq, lpc, pSc);
       for (int b = c.tid; b < B; b += BNN_THREADS) a.out[r0 + b] = lpc[b];
       __syncthreads();
     } else if (a.mode == 1) {
-      bnw_logp(c, m, w, w.zp, xr, yr, vr, B, set0, a.k0, k1b, 2u * (uint32_t)a.it, (uint32_t)rib0, ssq, lpp);
-      bnw_logp(c, m, w, w.zc, xr, yr, vr, B, set0 + m.set_floats, a.k0, k1b, 2u * (uint32_t)a.it + 1u, (uint32_t)rib0, ssq, lpc);
+      bnw_logp(c, m, w, w.zp, xr, yr, vr, B, set0, a.k0, k1b, 2u * (uint32_t)a.it, (uint32_t)rib0, ssq, lpp, pSp);
+      bnw_logp(c, m, w, w.zc, xr, yr, vr, B, set0 + m.set_floats, a.k0, k1b, 2u * (uint32_t)a.it + 1u, (uint32_t)rib0, ssq, lpc, pSc);
       if (c.tid == 0) nacc_s = 0u;
       __syncthreads();
       for (int b = c.tid; b < B; b += BNN_THREADS) {
@@ -232,7 +348,7 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnw_rows_kernel(BnwRowsArg
     } else {                            // mode 2: one call of g, h, f -> squared reconstruction errors (base.py:541-552)
       float sv = 0.0f, sx = 0.0f, sy = 0.0f;
       {
-        const float *o = bnw_call(c, m, BNN_G, w, w.zc, B, set0, a.k0, k1b, a.stream0, (uint32_t)rib0);
+        const float *o = bnw_call(c, m, BNN_G, w, w.zc, B, set0, a.k0, k1b, a.stream0, (uint32_t)rib0, pSc);
         bnn_row_ssq(c, vr, o, B, p, p + 1, ssq);
         __syncthreads();
         for (int b = c.tid; b < B; b += BNN_THREADS) sv += ssq[b];
@@ -240,12 +356,12 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnw_rows_kernel(BnwRowsArg
       }
       bnw_inputs(c, m, w, w.zc, xr, B);
       {
-        const float *o = bnw_call(c, m, BNN_H, w, w.hin, B, set0, a.k0, k1b, a.stream0, (uint32_t)rib0);
+        const float *o = bnw_call(c, m, BNN_H, w, w.hin, B, set0, a.k0, k1b, a.stream0, (uint32_t)rib0, pSc);
         for (int b = c.tid; b < B; b += BNN_THREADS) { const float l = o[2 * b], xp = m.binary ? sigmoid_f(l) : l, d = xr[b] - xp; sx = fmaf(d, d, sx); }
         __syncthreads();
       }
       {
-        const float *o = bnw_call(c, m, BNN_F, w, w.fin, B, set0, a.k0, k1b, a.stream0, (uint32_t)rib0);
+        const float *o = bnw_call(c, m, BNN_F, w, w.fin, B, set0, a.k0, k1b, a.stream0, (uint32_t)rib0, pSc);
         for (int b = c.tid; b < B; b += BNN_THREADS) { const float d = yr[b] - o[2 * b]; sy = fmaf(d, d, sy); }
         __syncthreads();
       }
@@ -271,6 +387,7 @@ struct BnwEffArgs {
   float *ite_out; long long ite_stride;     // binary: ite_out[row * ite_stride] = y(dose 0) - y(dose 1) (or NULL)
   float *ws;
   long long ws_stride;
+  const double *stats;                      // batch statistics of the states: [n_blocks][2][2][64], slot 1 (NULL: inference mode)
 };
 static __global__ __launch_bounds__(BNN_THREADS) void bnw_effects_kernel(BnwEffArgs a) {
   __shared__ float red[32];
@@ -293,7 +410,9 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnw_effects_kernel(BnwEffA
       for (int i = c.tid; i < B * nf; i += BNN_THREADS) { const int b = i / nf, j = i - b * nf; w.fin[i] = j < zf ? a.z[(r0 + b) * q + j] : xv; }
       __syncthreads();
       const float *set = a.dw + ((long long)blk * a.n_doses + k) * m.set_floats;
-      const float *o = bnw_call(c, m, BNN_F, w, w.fin, B, set, a.k0, k1b, a.stream0 + (uint32_t)k, (uint32_t)rib0);
+      BnwStats S{};
+      if (a.stats) { S.st = a.stats + (long long)blk * 256 + 128; S.cnt = (double)blk_n; S.dose = 1; S.dose_x = xv; }
+      const float *o = bnw_call(c, m, BNN_F, w, w.fin, B, set, a.k0, k1b, a.stream0 + (uint32_t)k, (uint32_t)rib0, a.stats ? &S : nullptr);
       float tot = 0.0f;
       for (int b = c.tid; b < B; b += BNN_THREADS) {
         float yk = o[2 * b];

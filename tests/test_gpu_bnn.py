@@ -692,13 +692,16 @@ WIDE = dict(g_units=(128, 96), e_units=(100,), f_units=(80, 40), h_units=(72,))
 WIDE256 = dict(g_units=(256, 256, 256), e_units=(256, 256, 256), f_units=(256, 256, 256), h_units=(256, 256, 256))      # networks/base.py:7 default nb_units
 
 
-@pytest.mark.parametrize("binary,units,p,n,bs", [(False, WIDE, 50, 300, 128), (True, WIDE, 37, 150, 150), (False, WIDE256, 120, 200, 70)])
-def test_wide_bayesian_nets_sampling_and_evaluation_match_oracle(binary, units, p, n, bs):
+@pytest.mark.parametrize("binary,units,p,n,bs,fixed", [(False, WIDE, 50, 300, 128, True), (True, WIDE, 37, 150, 150, True), (False, WIDE256, 120, 200, 70, True),
+                                                        (False, WIDE, 50, 300, 128, False), (True, WIDE, 37, 150, 150, False), (False, WIDE256, 120, 200, 70, False)])
+def test_wide_bayesian_nets_sampling_and_evaluation_match_oracle(binary, units, p, n, bs, fixed):
     """use_bnn=True with hidden widths > 64: log posterior on blocks, two MH iterations, effects of kept draws and evaluate against
-    oracle/bnn.py -- the checks of the narrow-shape tests above (ragged last block, several row tiles per block)."""
-    m = _model(binary, p=p, fixed=True, **units)
+    oracle/bnn.py -- the checks of the narrow-shape tests above (ragged last block, several row tiles per block).  fixed = False: the
+    input BatchNormalization on the statistics of the block / the panel a call sees (networks/bnn.py:25-27 as written,
+    params['bnn_norm'] = 'batch'), any width."""
+    m = _model(binary, p=p, fixed=fixed, **units)
     z, x, y, v = _panel(m, n)
-    eng = _engine(m, norm_mode=1, **units)
+    eng = _engine(m, norm_mode=1 if fixed else 0, **units)
     dev = eng.device
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     m64 = OB.cast_model(m, np.float64)
@@ -744,14 +747,18 @@ def test_wide_bayesian_nets_sampling_and_evaluation_match_oracle(binary, units, 
     eng.close()
 
 
-def test_class_with_wide_bayesian_nets(tmp_path):
+@pytest.mark.parametrize("bnn_norm", ["fixed", "batch"])
+def test_class_with_wide_bayesian_nets(tmp_path, bnn_norm):
     """CausalBGM(use_bnn=True) with g_units = [128, 128] and nb_units-default-sized f / h: EGM warm start, fit (with its evaluations) and
-    predict run through the class."""
+    predict run through the class -- also with the input BatchNormalization on batch statistics (the reference as written)."""
+    import warnings
     from bayesgm_amd.models import CausalBGM
     from bayesgm_amd.datasets import Sim_Hirano_Imbens_sampler
     x, y, v = Sim_Hirano_Imbens_sampler(N=400, v_dim=20, seed=0).load_all()
-    prm = dict(_params(tmp_path, False), g_units=[128, 128], e_units=[128, 128], f_units=[256, 256, 256], h_units=[96, 48])
-    model = CausalBGM(prm, random_seed=3)
+    prm = dict(_params(tmp_path, False), g_units=[128, 128], e_units=[128, 128], f_units=[256, 256, 256], h_units=[96, 48], bnn_norm=bnn_norm)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = CausalBGM(prm, random_seed=3)
     _, _, _, mv0 = model.evaluate((x, y, v))
     model.fit((x, y, v), epochs=2, epochs_per_eval=1, batch_size=32, use_egm_init=True, egm_n_iter=20, egm_batches_per_eval=10, verbose=0)
     _, mx1, my1, mv1 = model.evaluate((x, y, v), data_z=model.data_z.cpu().numpy())
