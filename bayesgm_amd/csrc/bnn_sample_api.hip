@@ -145,8 +145,8 @@ extern "C" int bgm_bnn_logpost(bgm_handle *h, const float *x, const float *y, co
   BGM_HIP_CHECK(hipSetDevice(h->device));
   rc = bnf_logpost(h, s, x, y, v, z, n, block_rows, block0, seed, stream_id, out, stream);     // inference-mode normalisation, default shapes
   if (rc <= 0) return rc;
-  if (s->bp_on) { bgm_set_error("bgm_bnn_logpost: the conditional prior (bgm_bnn_set_prior) exists on the default-shape sampling kernels only"); return BGM_E_UNSUPPORTED; }
-  if (bns_wide) return bnw_logpost(h, s, x, y, v, z, n, block_rows, block0, seed, stream_id, out, stream);
+  // any hidden width -- and the conditional prior (bgm_bnn_set_prior) outside the default shapes: the any-width path reads its row tables
+  if (bns_wide || s->bp_on) return bnw_logpost(h, s, x, y, v, z, n, block_rows, block0, seed, stream_id, out, stream);
   const int n_blocks = (int)((n + block_rows - 1) / block_rows);
   BnsBuf b;
   rc = bns_buffers(h, s, pl, n, n_blocks, (long long)n_blocks * pl.set_ghf, b, stream);
@@ -187,8 +187,7 @@ extern "C" int bgm_bnn_mh_run(bgm_handle *h, const bgm_bnn_mh_args *g, void *str
   BGM_HIP_CHECK(hipSetDevice(h->device));
   rc = bnf_mh_run(h, s, g, stream);
   if (rc <= 0) return rc;
-  if (s->bp_on) { bgm_set_error("bgm_bnn_mh_run: the conditional prior (bgm_bnn_set_prior) exists on the default-shape sampling kernels only"); return BGM_E_UNSUPPORTED; }
-  if (bns_wide) return bnw_mh_run(h, s, g, stream);
+  if (bns_wide || s->bp_on) return bnw_mh_run(h, s, g, stream);
   const long long n = g->n;
   const int bs = g->block_rows, n_blocks = (int)((n + bs - 1) / bs), q = s->q;
   BnsBuf b;

@@ -134,6 +134,10 @@ int bnw_logpost(bgm_handle *h, BnnState *s, const float *x, const float *y, cons
     bnw_stats(bt, z, n, 0, s->q, bs, 0, 0, 0.0f, nullptr, seed, 0, x, true, stream);
     a.stats = bt.parity(0); a.xstats = bt.xstats;
   }
+  if (s->bp_on) {                       // conditional prior: one noisy call of the prior net for this evaluation (bprior_api.hip)
+    if ((rc = bprior_rows(h, s, n, bs, block0, seed, stream_id, 1, stream))) return rc;
+    a.prior = s->bp_rows; a.prior_stride = 0;
+  }
   a.dw = pl.b->dw; a.n_calls = 1; a.x = x; a.y = y; a.v = v; a.z = const_cast<float *>(z); a.n = n; a.row_base = 0;
   a.bs = bs; a.block0 = block0; a.tiles_per_block = tpb; a.n_items = n_blocks * tpb; a.mode = 0;
   a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32); a.stream0 = stream_id; a.out = out; a.ws = pl.b->ws; a.ws_stride = pl.ws_stride;
@@ -204,6 +208,10 @@ int bnw_mh_run(bgm_handle *h, BnnState *s, const bgm_bnn_mh_args *g, hipStream_t
       bnw_stats(bt, g->state_dev, n, g->row_base, q, bs, it, a.init, g->q_sd, g->q_sd_blocks_dev, g->seed, i & 1, g->x_dev, i == 0, stream);
       if (i > 0 && kept(it - 1) && (rc = effects(it - 1, i & 1))) return rc;
       a.stats = bt.parity(i & 1);
+    }
+    if (s->bp_on) {                     // the two evaluations' own calls of the prior net (streams 2 it, 2 it + 1)
+      if ((rc = bprior_rows(h, s, n, bs, g->block0, g->seed, 2u * (uint32_t)it, 2, stream))) return rc;
+      a.prior = s->bp_rows; a.prior_stride = n * (long long)(q + 2);
     }
     a.acc_blocks = g->acc_blocks_dev ? g->acc_blocks_dev + (long long)i * n_blocks : nullptr;
     hipLaunchKernelGGL(bnw_rows_kernel, dim3(pl.grid), dim3(BNN_THREADS), 0, stream, a);

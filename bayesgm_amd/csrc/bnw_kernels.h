@@ -217,7 +217,8 @@ __device__ __forceinline__ void bnw_inputs(const BnnCtx &c, const BnwNets &m, co
 // log p(z | x, y, v) + const of the tile's rows under the calls (set, stream): lp[b]   (base.py:765-817)
 __device__ __forceinline__ void bnw_logp(const BnnCtx &c, const BnwNets &m, const BnwWs &w, const float *zs, const float *x, const float *y,
                                          const float *v, int B, const float *set, uint32_t k0, uint32_t k1, uint32_t stream, uint32_t row0,
-                                         float *ssq, float *lp, const BnwStats *S = nullptr) {
+                                         float *ssq, float *lp, const BnwStats *S = nullptr, const float *prior = nullptr) {
+  // prior: the rows' conditional latent prior [B][q + 2] = mu [q], 1 / sigma^2, (q / 2) log sigma^2 (bprior_api.hip) or NULL = N(0, I)
   const int p = m.p, q = m.q;
   {
     const float *o = bnw_call(c, m, BNN_G, w, zs, B, set, k0, k1, stream, row0, S);
@@ -226,9 +227,14 @@ __device__ __forceinline__ void bnw_logp(const BnnCtx &c, const BnwNets &m, cons
     __syncthreads();
     for (int b = c.tid; b < B; b += BNN_THREADS) {
       const float s2 = m.sig2[0] > 0.0f ? m.sig2[0] : softplus_acc(o[b * wo + p]) + BGM_EPS;
-      float zz = 0.0f;
+      float zz = 0.0f, lc = 0.0f;
+      if (prior) {
+        const float *pr = prior + (long long)b * (q + 2);
+        for (int j = 0; j < q; ++j) { const float d = zs[b * q + j] - pr[j]; zz = fmaf(d, d, zz); }
+        zz *= pr[q]; lc = pr[q + 1];
+      } else
       for (int j = 0; j < q; ++j) zz = fmaf(zs[b * q + j], zs[b * q + j], zz);
-      lp[b] = -(ssq[b] / (2.0f * s2) + (float)p * logf(s2) * 0.5f) - 0.5f * zz;
+      lp[b] = -(ssq[b] / (2.0f * s2) + (float)p * logf(s2) * 0.5f) - 0.5f * zz - lc;
     }
     __syncthreads();
   }
@@ -273,6 +279,10 @@ struct BnwRowsArgs {
   // batch statistics (NULL: inference-mode normalisation): this launch's parity of bnw_stats_kernel's sums [n_blocks][2][2][64],
   // the treatment column's [n_blocks][2], the covariates' [2][p] (mode 3)
   const double *stats, *xstats, *vstats;
+  // conditional latent prior (IdentifiableCausalBGM, bprior_kernels.h): [n_states][n][q + 2] per-row tables of the calls' own noisy
+  // evaluations of the prior net (state 0: the proposal's / mode 0's, state 1: the current state's), or NULL
+  const float *prior;
+  long long prior_stride;
 };
 
 static __global__ __launch_bounds__(BNN_THREADS) void bnw_rows_kernel(BnwRowsArgs a) {
@@ -322,12 +332,14 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnw_rows_kernel(BnwRowsArg
     }
     __syncthreads();
     if (a.mode == 0) {
-      bnw_logp(c, m, w, w.zc, xr, yr, vr, B, set0, a.k0, k1b, a.stream0, (uint32_t)rib0, ssq, lpc, pSc);
+      bnw_logp(c, m, w, w.zc, xr, yr, vr, B, set0, a.k0, k1b, a.stream0, (uint32_t)rib0, ssq, lpc, pSc, a.prior ? a.prior + r0 * (q + 2) : nullptr);
       for (int b = c.tid; b < B; b += BNN_THREADS) a.out[r0 + b] = lpc[b];
       __syncthreads();
     } else if (a.mode == 1) {
-      bnw_logp(c, m, w, w.zp, xr, yr, vr, B, set0, a.k0, k1b, 2u * (uint32_t)a.it, (uint32_t)rib0, ssq, lpp, pSp);
-      bnw_logp(c, m, w, w.zc, xr, yr, vr, B, set0 + m.set_floats, a.k0, k1b, 2u * (uint32_t)a.it + 1u, (uint32_t)rib0, ssq, lpc, pSc);
+      bnw_logp(c, m, w, w.zp, xr, yr, vr, B, set0, a.k0, k1b, 2u * (uint32_t)a.it, (uint32_t)rib0, ssq, lpp, pSp,
+               a.prior ? a.prior + r0 * (q + 2) : nullptr);
+      bnw_logp(c, m, w, w.zc, xr, yr, vr, B, set0 + m.set_floats, a.k0, k1b, 2u * (uint32_t)a.it + 1u, (uint32_t)rib0, ssq, lpc, pSc,
+               a.prior ? a.prior + a.prior_stride + r0 * (q + 2) : nullptr);
       if (c.tid == 0) nacc_s = 0u;
       __syncthreads();
       for (int b = c.tid; b < B; b += BNN_THREADS) {

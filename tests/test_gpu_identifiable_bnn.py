@@ -151,6 +151,47 @@ def test_conditional_prior_mh_iterations(precision):
     eng.close()
 
 
+@pytest.mark.parametrize("units", [dict(g_units=(128, 96), e_units=(100,), f_units=(80, 40), h_units=(72,)),
+                                   dict(g_units=(24, 40), e_units=(16,), f_units=(20, 12), h_units=(9, 5))])
+def test_conditional_prior_outside_the_default_shapes(units):
+    """The conditional prior in the log posterior and the sampler for nets of other widths (wider than 64, or narrower than the default
+    shapes): the any-width path (csrc/bnw_kernels.h) reads the same per-row prior tables (identifiable.py:541-551 with any nb_units)."""
+    from bayesgm_amd import _lib
+    from bayesgm_amd.bnn_engine import flatten_bnn
+    from tests.test_gpu_bnn import _model as model_b, _panel as panel_b, _engine as engine_b
+    m = model_b(False, p=50, fixed=True, **units)
+    n, bs, q, k = 300, 128, 10, 6
+    z, x, y, v = panel_b(m, n)
+    rs = np.random.RandomState(8)
+    pn32 = _prior(rs, k, q, (64,), "fixed")
+    seg = rs.randint(0, k, n)
+    eng = engine_b(m, norm_mode=1, **units)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
+    cfg = _cfg([k, 64, q + 1])
+    theta, seg_dev = T(flatten_bnn(pn32)), T(seg.astype(np.int32))
+    m64, p64 = OB.cast_model(m, np.float64), OB.cast_bnn(pn32, np.float64)
+    seed, stream = (3 << 32) | 1234, 77
+    std = eng.logpost(T(x[:, 0]), T(y[:, 0]), T(v), T(z), bs, seed, stream, block0=2).cpu().numpy()
+    _lib.check(eng.lib.bgm_bnn_set_prior(eng.h, C.byref(cfg), theta.data_ptr(), seg_dev.data_ptr()), "bgm_bnn_set_prior")
+    got = eng.logpost(T(x[:, 0]), T(y[:, 0]), T(v), T(z), bs, seed, stream, block0=2).cpu().numpy()
+    ref = OI.bnn_log_posterior_blocks(m64, p64, seg, f64(x), f64(y), f64(v), f64(z), bs, seed, stream, block0=2)
+    assert np.abs(got - ref).max() < 2e-3 * np.abs(ref).max(), np.abs(got - ref).max()
+    assert np.abs(got - std).max() > 0.1                                # the prior matters here
+    state = T(z)
+    acc = torch.zeros(1, dtype=torch.int32, device=eng.device)
+    eng.mh_run(T(x[:, 0]), T(y[:, 0]), T(v), state, bs, it_begin=5, n_iters=2, burn_in=0, q_sd=0.3, seed=seed, row_base=1000, acc_count=acc)
+    zo, n_acc, fragile = f64(z), 0, np.zeros(n, bool)
+    for it in (5, 6):
+        zo, a, lpp, lpc = OI.bnn_mh_iteration(m64, p64, seg, f64(x), f64(y), f64(v), zo, it, 0.3, seed, bs, row_base=1000)
+        n_acc += int(a.sum())
+        u = OB.R.uniforms(np.arange(1000, 1000 + n), it, OB.R.TAG_ACC, seed)
+        fragile |= np.abs(u - np.exp(np.minimum(lpp - lpc, 0))) < 2e-3
+    ok = ~fragile
+    assert ok.sum() >= 0.97 * n and np.abs(state.cpu().numpy()[ok] - zo[ok]).max() < 1e-5
+    assert abs(int(acc[0]) - n_acc) <= int(fragile.sum())
+    eng.close()
+
+
 def _params(tmp_path, binary, **kw):
     p = dict(dataset="ident_bnn", output_dir=str(tmp_path), save_res=False, save_model=False, binary_treatment=binary, use_bnn=True,
              z_dims=[1, 1, 1, 7], v_dim=20, lr_theta=1e-3, lr_z=1e-2, g_units=[64] * 5, f_units=[64, 32, 8], h_units=[64, 32, 8], e_units=[64] * 5,
@@ -249,6 +290,18 @@ def model_ckpt_prior(model):
         return None
     from bayesgm_amd.bnn_engine import unflatten_bnn
     return unflatten_bnn(np.load(files[-1])["prior_theta"], model._prior_dims)
+
+
+def test_class_with_other_hidden_widths(tmp_path):
+    """IdentifiableCausalBGM(use_bnn=True) with g_units = [128, 128]: fit and predict through the class (the sampler with its prior on the
+    any-width path)."""
+    from bayesgm_amd.models import IdentifiableCausalBGM
+    from bayesgm_amd.datasets import Sim_Hirano_Imbens_sampler
+    x, y, v = Sim_Hirano_Imbens_sampler(N=200, v_dim=20, seed=0).load_all()
+    model = IdentifiableCausalBGM(_params(tmp_path, False, g_units=[128, 128], f_units=[96, 48]), random_seed=3)
+    model.fit((x, y, v), epochs=2, epochs_per_eval=1, batch_size=32, use_egm_init=True, egm_n_iter=20, egm_batches_per_eval=10, verbose=0)
+    eff, interval = model.predict((x, y, v), alpha=0.05, n_mcmc=8, burn_in=8, x_values=np.linspace(0, 3, 4), q_sd=0.5, verbose=0)
+    assert eff.shape == (4,) and np.isfinite(eff).all() and np.isfinite(interval).all()
 
 
 def test_other_sampling_configurations_say_so(tmp_path):
