@@ -52,7 +52,7 @@ extern "C" int bgm_bvn_layout(const bgm_bvn_config *cfg, int64_t *n_params) {
 extern "C" int bgm_bvn_begin(bgm_handle *h, const bgm_bvn_config *cfg, const float *theta_host, int64_t count, void *stream_) {
   (void)stream_;
   if (!h || !cfg || !theta_host) { bgm_set_error("bgm_bvn_begin: NULL argument"); return BGM_E_INVALID; }
-  if (cfg->max_batch < 2 || cfg->max_batch > BGMB_MAX_BATCH) { bgm_set_error("bgm_bvn_begin: max_batch must be in [2, 256]"); return BGM_E_UNSUPPORTED; }
+  if (cfg->max_batch < 2 || cfg->max_batch > BGMB_MAX_BATCH) { bgm_set_error("bgm_bvn_begin: max_batch must be in [2, 4096]"); return BGM_E_UNSUPPORTED; }
   BGM_HIP_CHECK(hipSetDevice(h->device));
   bgm_bvn_free_state(h);
   BgmbState *s = new BgmbState();

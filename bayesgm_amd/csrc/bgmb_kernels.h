@@ -22,7 +22,7 @@
 #include "bnn_kernels.h"
 
 #define BGMB_RT 64
-#define BGMB_MAX_BATCH 256         // rows of a minibatch step (bgmb_theta_step_kernel, bgmb_z_step_kernel)
+#define BGMB_MAX_BATCH 4096        // rows of a minibatch step (bgmb_theta_step_kernel, bgmb_z_step_kernel)
 #define BGMB_STREAM_PREDICT 0x40000000u
 #define BGMB_STREAM_DECODE 0x50000000u
 

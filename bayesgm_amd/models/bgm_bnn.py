@@ -87,7 +87,7 @@ class BGMBayes(BGM):
         self.z_sampler = Gaussian_sampler(mean=np.zeros(q), sd=1.0)
         if device is None:
             device = int(os.environ.get("BGM_DEVICE", os.environ.get("LOCAL_RANK", 0)))
-        self._max_batch = 256
+        self._max_batch = int(params.get("max_batch", 256))      # rows of a minibatch per rank the session is sized for (up to 4096; bgm/base.py:343 takes any batch_size)
         mode = params.get("bnn_mcmc_noise", "frozen")
         if "bnn_mcmc_noise" not in params:
             from .. import diagnostics
@@ -139,7 +139,7 @@ class BGMBayes(BGM):
         p_ = self._p
         q, xd_ = eng.q, eng.p
         if batch_size > self._max_batch:
-            raise ValueError("bayesgm_amd: use_bnn=True supports minibatches of at most %d rows" % self._max_batch)
+            raise ValueError("bayesgm_amd: this session is sized for minibatches of at most %d rows; create the model with params['max_batch'] >= %d (up to 4096)" % (self._max_batch, batch_size))
         self.data_sampler = Base_sampler(x=data, y=data, v=data, batch_size=batch_size, normalize=False)
         xd = self._dev(data)
 
@@ -238,7 +238,7 @@ class BGMBayes(BGM):
         dist_on = parallel.is_dist()
         world = parallel.world_size()
         if batch_size > self._max_batch:
-            raise ValueError("bayesgm_amd: use_bnn=True supports minibatches of at most %d rows" % self._max_batch)
+            raise ValueError("bayesgm_amd: this session is sized for minibatches of at most %d rows; create the model with params['max_batch'] >= %d (up to 4096)" % (self._max_batch, batch_size))
         if use_egm_init:
             self.egm_init(data, egm_n_iter=egm_n_iter, batch_size=batch_size, egm_batches_per_eval=egm_batches_per_eval,
                           verbose=verbose)

@@ -35,11 +35,12 @@ def _flat(parts):
 
 
 @pytest.mark.parametrize("q,units,p,B", [(10, (64,) * 5, 20, 32), (5, (24, 40), 37, 19), (3, (16,), 9, 64),
-                                         (10, (64,) * 5, 20, 160), (4, (32, 32), 12, 200)])      # minibatches beyond 64 rows (any batch_size, bgm/base.py:343)
+                                         (10, (64,) * 5, 20, 160), (4, (32, 32), 12, 200),       # minibatches beyond 64 rows (any batch_size, bgm/base.py:343)
+                                         (10, (64,) * 5, 20, 300)])                              # ... and beyond 256 (params['max_batch'])
 def test_theta_step_gradient_matches_oracle(q, units, p, B):
     net = _net(q, units, p)
     rs = np.random.RandomState(1)
-    N = 200
+    N = max(200, B + 20)
     z = rs.standard_normal((N, q)).astype(np.float32)
     x = rs.standard_normal((N, p)).astype(np.float32)
     idx = rs.choice(N, B, replace=False).astype(np.int32)
