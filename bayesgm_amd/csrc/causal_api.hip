@@ -340,8 +340,7 @@ extern "C" int bgm_causal_logpost(bgm_handle *h, const float *x, const float *y,
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
   if (gx_wanted(h)) {          // hidden widths / depths outside the compiled families: the general-width engine (gx_api.hip)
-    if (h->precision != 0) { bgm_set_error("bgm_causal_logpost: split precision exists for the default hidden widths only"); return BGM_E_UNSUPPORTED; }
-    return gx_logpost(h, x, y, v, z, n, out, stream);
+    return gx_logpost(h, x, y, v, z, n, out, stream);      // (split precision: 'f16x3' on its row-tile-per-wave kernels, else it says so)
   }
   if (bnf_det_wanted(h)) {     // no LDS-resident compiled shape holds the model: the streamed-fragment kernels (bnf_det_api.hip)
     if (h->prior_seg || h->precision != 0) { bgm_set_error("bgm_causal_logpost: the conditional prior / split precision exist for the LDS-resident shapes only"); return BGM_E_UNSUPPORTED; }
@@ -403,7 +402,6 @@ extern "C" int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *a, void *stre
   hipStream_t stream = (hipStream_t)stream_;
   BGM_HIP_CHECK(hipSetDevice(h->device));
   if (gx_wanted(h)) {
-    if (h->precision != 0) { bgm_set_error("bgm_causal_mh_run: split precision exists for the default hidden widths only"); return BGM_E_UNSUPPORTED; }
     return gx_mh_run(h, a, stream);
   }
   if (bnf_det_wanted(h)) {

@@ -200,7 +200,7 @@ int bgm_causal_bx3_blob(bgm_handle *h, hipStream_t stream) {
 
 extern "C" int bgm_causal_set_precision(bgm_handle *h, int32_t mode) {
   if (!h || mode < 0 || mode > 2) { bgm_set_error("bgm_causal_set_precision: mode must be 0 (fp32), 1 (bf16x3) or 2 (f16x3)"); return BGM_E_INVALID; }
-  if (mode != h->precision) h->bx_valid = false;      // the packed blob is per operand format
+  if (mode != h->precision) { h->bx_valid = false; h->gx_valid = false; }      // the packed blob is per operand format; the general-width engine builds its split pack when the mode is on
   h->precision = mode;
   return BGM_OK;
 }

@@ -47,13 +47,29 @@ __device__ __forceinline__ GwLds gw_carve(float *w, int ld, int q, int ldf, int 
 }
 
 // hidden layers l_begin .. l_end - 1 of `net` on the wave's nrt row tiles (no barriers); pre as in gx_hidden
-__device__ __forceinline__ float *gw_hidden(const GxNet &net, const float *pack, int l_begin, int l_end, float *cur, float *oth, int ld, GxPre &pre,
-                                            int nrt) {
+// One dense layer l of `net` on the wave's nrt row tiles, and the request of a layer's first block ahead of it.  X3: split precision
+// (gx_dense_x3 on the split pack; it requests a unit's blocks itself, no first-block prefetch).
+template <bool X3> struct GwPreOf { typedef GxPre T; };
+template <> struct GwPreOf<true> { typedef GxPreX T; };
+template <bool X3, class Epi>
+__device__ __forceinline__ void gw_layer(const GxCausalModel &m, const GxNet &net, int l, const float *cur, int ld, Epi epi, int nrt,
+                                         typename GwPreOf<X3>::T &pre) {
+  if constexpr (X3) gx_dense_x3(m.packx + net.wx[l], net.pad[l], net.pad[l + 1], cur, ld, epi, nrt, m.pack + net.b[l], &pre);
+  else gx_dense<false, true>(m.pack + net.w[l], gw_k16(net, l), net.pad[l + 1], cur, ld, epi, nrt, m.pack + net.b[l], &pre, 0, 1);
+}
+template <bool X3>
+__device__ __forceinline__ typename GwPreOf<X3>::T gw_pre(const GxCausalModel &m, const GxNet &net, int l, int nrt) {
+  if constexpr (X3) return gx_prefetch_x3(m.packx + net.wx[l]);
+  else return gx_prefetch<true>(m.pack + net.w[l], net.pad[l + 1], net.pad[l + 1], m.pack + net.b[l], nrt, 0, gw_k16(net, l));
+}
+template <bool X3 = false>
+__device__ __forceinline__ float *gw_hidden(const GxCausalModel &m, const GxNet &net, int l_begin, int l_end, float *cur, float *oth, int ld,
+                                            typename GwPreOf<X3>::T &pre, int nrt) {
   for (int l = l_begin; l < l_end; ++l) {
-    GxPre nx;
+    typename GwPreOf<X3>::T nx;
     nx.valid = 0;
-    if (l + 1 < net.L) nx = gx_prefetch<true>(pack + net.w[l + 1], net.pad[l + 2], net.pad[l + 2], pack + net.b[l + 1], nrt, 0, gw_k16(net, l + 1));
-    gx_dense<false, true>(pack + net.w[l], gw_k16(net, l), net.pad[l + 1], cur, ld, GxStore<true>{oth, ld, nullptr}, nrt, pack + net.b[l], &pre, 0, 1);
+    if (l + 1 < net.L) nx = gw_pre<X3>(m, net, l + 1, nrt);
+    gw_layer<X3>(m, net, l, cur, ld, GxStore<true>{oth, ld, nullptr}, nrt, pre);
     pre = nx;
     float *t = cur; cur = oth; oth = t;
   }
@@ -103,10 +119,10 @@ struct GwGLastEpi {
 
 // f on nd row tiles of the wave: row R (0 .. 16 nd - 1) is the latent of chain src(R) (LDS [16][q]) at treatment value xin(R).  Returns the
 // buffer whose columns 0, 1 of row R hold (mu_y, raw_y).  Lane (r = lane & 15, cq = lane >> 4) stages columns cq, cq + 4, ... of rows r, r + 16, ...
-template <class Src, class XIn>
+template <bool X3 = false, class Src, class XIn>
 __device__ __forceinline__ const float *gw_f_rows(const GxCausalModel &m, const GwLds &L, const float *z, Src src, XIn xin, int nd) {
   const int lane = gx_lane(), zf = m.z0 + m.z1, q = m.q, ld = m.ldf, wp = m.f.pad[0];
-  GxPre pre = gx_prefetch<true>(m.pack + m.f.w[0], m.f.pad[1], m.f.pad[1], m.pack + m.f.b[0], nd, 0, gw_k16(m.f, 0));
+  auto pre = gw_pre<X3>(m, m.f, 0, nd);
   for (int R = lane & (GW_ROWS - 1); R < GW_ROWS * nd; R += GW_ROWS) {
     const int ch = src(R);
     const float xv = xin(R);
@@ -115,37 +131,36 @@ __device__ __forceinline__ const float *gw_f_rows(const GxCausalModel &m, const 
       L.bufA[R * ld + c] = c < zf ? zc_ : (c == zf ? xv : 0.0f);
     }
   }
-  float *cur = gw_hidden(m.f, m.pack, 0, m.f.L - 1, L.bufA, L.bufB, ld, pre, nd);
+  float *cur = gw_hidden<X3>(m, m.f, 0, m.f.L - 1, L.bufA, L.bufB, ld, pre, nd);
   float *oth = (cur == L.bufA) ? L.bufB : L.bufA;
-  const int l = m.f.L - 1;
-  gx_dense<false, true>(m.pack + m.f.w[l], gw_k16(m.f, l), m.f.pad[l + 1], cur, ld, GxStore<false>{oth, ld, nullptr}, nd, m.pack + m.f.b[l], &pre, 0, 1);
+  gw_layer<X3>(m, m.f, m.f.L - 1, cur, ld, GxStore<false>{oth, ld, nullptr}, nd, pre);
   return oth;
 }
 // the wave's 16 chains at treatment values xin(row, dose), nd <= m.db doses stacked as row tiles (row 16 d + r)
-template <class XIn>
+template <bool X3 = false, class XIn>
 __device__ __forceinline__ const float *gw_f_forward(const GxCausalModel &m, const GwLds &L, const float *z, XIn xin, int nd) {
-  return gw_f_rows(m, L, z, [](int R) { return R & (GW_ROWS - 1); }, [&](int R) { return xin(R & (GW_ROWS - 1), R >> 4); }, nd);
+  return gw_f_rows<X3>(m, L, z, [](int R) { return R & (GW_ROWS - 1); }, [&](int R) { return xin(R & (GW_ROWS - 1), R >> 4); }, nd);
 }
 
 // log p(z | x, y, v) + const of the wave's 16 rows, z in LDS [16][q]; returned in lane r < 16 for row r.  base.py:765-817.
+template <bool X3 = false>
 __device__ __forceinline__ float gw_causal_logp(const GxCausalModel &m, const GwLds &L, const float *z, const float *x, const float *y,
                                                 const float *v, long long row0, long long n) {
   const int lane = gx_lane(), j = lane & 15, g = lane >> 4, q = m.q, ld = m.ld;
   // ---- g: z -> (mu_v [p], raw_v), fused with the Gaussian likelihood of the V rows
   {
-    GxPre pre = gx_prefetch<true>(m.pack + m.g.w[0], m.g.pad[1], m.g.pad[1], m.pack + m.g.b[0], 1, 0, gw_k16(m.g, 0));
+    auto pre = gw_pre<X3>(m, m.g, 0, 1);
     const int wp = m.g.pad[0];
     for (int c = lane >> 4; c < wp; c += 4) {          // lane (r = lane & 15, c = lane >> 4, + 4, ...)
       const int r = lane & (GW_ROWS - 1);
       const float zc_ = z[r * q + min(c, q - 1)];
       L.bufA[r * ld + c] = c < q ? zc_ : 0.0f;
     }
-    float *cur = gw_hidden(m.g, m.pack, 0, m.g.L - 1, L.bufA, L.bufB, ld, pre, 1);
-    const int l = m.g.L - 1;
+    float *cur = gw_hidden<X3>(m, m.g, 0, m.g.L - 1, L.bufA, L.bufB, ld, pre, 1);
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     GwGLastEpi ge;
     ge.v = v; ge.row0 = row0; ge.n = n; ge.p = m.p; ge.sraw = L.sraw; ge.acc = acc;
-    gx_dense<false, true>(m.pack + m.g.w[l], gw_k16(m.g, l), m.g.pad[l + 1], cur, ld, ge, 1, m.pack + m.g.b[l], &pre, 0, 1);
+    gw_layer<X3>(m, m.g, m.g.L - 1, cur, ld, ge, 1, pre);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float s = gx_sum_j(acc[r]);
@@ -155,23 +170,22 @@ __device__ __forceinline__ float gw_causal_logp(const GxCausalModel &m, const Gw
   // ---- f: (z0, z1, x) -> (mu_y, raw_y)
   float mu_y = 0.0f, raw_y = 0.0f;
   {
-    const float *fo = gw_f_forward(m, L, z, [&](int r, int) { long long gr = row0 + r; gr = gr < n ? gr : n - 1; return x[gr]; }, 1);
+    const float *fo = gw_f_forward<X3>(m, L, z, [&](int r, int) { long long gr = row0 + r; gr = gr < n ? gr : n - 1; return x[gr]; }, 1);
     if (lane < GW_ROWS) { mu_y = fo[lane * m.ldf]; raw_y = fo[lane * m.ldf + 1]; }
   }
   // ---- h: (z0, z2) -> (mu_x | logit, raw_x)
   float mu_x = 0.0f, raw_x = 0.0f;
   {
     const int z0 = m.z0, z1 = m.z1, z2 = m.z2, wp = m.h.pad[0];
-    GxPre ph = gx_prefetch<true>(m.pack + m.h.w[0], m.h.pad[1], m.h.pad[1], m.pack + m.h.b[0], 1, 0, gw_k16(m.h, 0));
+    auto ph = gw_pre<X3>(m, m.h, 0, 1);
     for (int c = lane >> 4; c < wp; c += 4) {
       const int r = lane & (GW_ROWS - 1);
       const float zc_ = z[r * q + min(c < z0 ? c : z1 + c, q - 1)];
       L.bufA[r * ld + c] = c < z0 + z2 ? zc_ : 0.0f;
     }
-    float *cur = gw_hidden(m.h, m.pack, 0, m.h.L - 1, L.bufA, L.bufB, ld, ph, 1);
+    float *cur = gw_hidden<X3>(m, m.h, 0, m.h.L - 1, L.bufA, L.bufB, ld, ph, 1);
     float *oth = (cur == L.bufA) ? L.bufB : L.bufA;
-    const int l = m.h.L - 1;
-    gx_dense<false, true>(m.pack + m.h.w[l], gw_k16(m.h, l), m.h.pad[l + 1], cur, ld, GxStore<false>{oth, ld, nullptr}, 1, m.pack + m.h.b[l], &ph, 0, 1);
+    gw_layer<X3>(m, m.h, m.h.L - 1, cur, ld, GxStore<false>{oth, ld, nullptr}, 1, ph);
     if (lane < GW_ROWS) { mu_x = oth[lane * ld]; raw_x = oth[lane * ld + 1]; }
   }
   // ---- assemble -(loss_v + loss_x + loss_y + prior)   (base.py:800-816), lane r = row r
@@ -210,7 +224,8 @@ __device__ __forceinline__ float gw_causal_logp(const GxCausalModel &m, const Gw
   return lp;
 }
 
-__global__ __launch_bounds__(GW_THREADS, 4) void gw_causal_logpost_kernel(GxCausalModel m, const float *x, const float *y, const float *v, const float *z,
+template <bool X3 = false>
+__global__ __launch_bounds__(GW_THREADS, X3 ? 3 : 4) void gw_causal_logpost_kernel(GxCausalModel m, const float *x, const float *y, const float *v, const float *z,
                                                                        long long n, float *out) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), q = m.q;      // (wave: provably uniform, so that the region's pointers and the tile walk live in SGPRs)
@@ -222,7 +237,7 @@ __global__ __launch_bounds__(GW_THREADS, 4) void gw_causal_logpost_kernel(GxCaus
       long long gr = row0 + i / q; gr = gr < n ? gr : n - 1;
       L.zc[i] = z[gr * q + i % q];
     }
-    const float lp = gw_causal_logp(m, L, L.zc, x, y, v, row0, n);
+    const float lp = gw_causal_logp<X3>(m, L, L.zc, x, y, v, row0, n);
     if (lane < GW_ROWS && row0 + lane < n) out[row0 + lane] = lp;
   }
 }
@@ -236,7 +251,7 @@ __global__ __launch_bounds__(GW_THREADS, 4) void gw_causal_logpost_kernel(GxCaus
 // row's operands only, so the values are the bits a pass over all 16 chains at that dose gives; the sums then run over the cache with the
 // same noise and in the same order as without it.  At the bench's acceptance rate (0.08: 1.3 chains of 16 move per iteration) that is
 // 2-3 passes instead of 20.
-template <int EFFECT>
+template <int EFFECT, bool X3 = false>
 __device__ __forceinline__ void gw_causal_effects(const GxCausalModel &m, const GwLds &L, const float *z, long long row0, long long n,
                                                   long long row_base, unsigned it, long long d, const GxEffArgs &e, unsigned stale = 0xFFFFu,
                                                   bool cached = false) {
@@ -258,7 +273,7 @@ __device__ __forceinline__ void gw_causal_effects(const GxCausalModel &m, const 
         const bool okp = pi < npairs;
         const int ci = okp ? pi / nd : 0, k = okp ? pi - ci * nd : 0;
         const int ch = list[ci];
-        const float *fo = gw_f_rows(m, L, z, [&](int) { return ch; }, [&](int) { return xval(k); }, 1);
+        const float *fo = gw_f_rows<X3>(m, L, z, [&](int) { return ch; }, [&](int) { return xval(k); }, 1);
         if (lane < GW_ROWS && okp) {
           const float mean = fo[lane * m.ldf];
           const float s2y = (m.sig2_y > 0.0f) ? m.sig2_y : softplus_f(fo[lane * m.ldf + 1]) + BGM_EPS;
@@ -271,7 +286,7 @@ __device__ __forceinline__ void gw_causal_effects(const GxCausalModel &m, const 
   for (int k0 = 0; k0 < nd; k0 += m.db) {
     const int nb = min(m.db, nd - k0);
     const float *fo = nullptr;
-    if (!cached) fo = gw_f_forward(m, L, z, [&](int, int dd) { return xval(k0 + dd); }, nb);
+    if (!cached) fo = gw_f_forward<X3>(m, L, z, [&](int, int dd) { return xval(k0 + dd); }, nb);
     for (int dd = 0; dd < nb; ++dd) {
       const int k = k0 + dd;
       float mean = 0.0f, sd = 0.0f;
@@ -304,8 +319,8 @@ __device__ __forceinline__ void gw_causal_effects(const GxCausalModel &m, const 
   }
 }
 
-template <int EFFECT>
-__global__ __launch_bounds__(GW_THREADS, 4) void gw_causal_mh_kernel(GxMhArgs a) {
+template <int EFFECT, bool X3 = false>
+__global__ __launch_bounds__(GW_THREADS, X3 ? 3 : 4) void gw_causal_mh_kernel(GxMhArgs a) {      // (X3: the split operands of a layer's input live in 32 more registers)
   extern __shared__ float lds[];
   const GxCausalModel &m = a.m;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), q = m.q;      // (wave: provably uniform, so that the region's pointers and the tile walk live in SGPRs)
@@ -331,7 +346,7 @@ __global__ __launch_bounds__(GW_THREADS, 4) void gw_causal_mh_kernel(GxMhArgs a)
 #pragma unroll
         for (int w = 0; w < 4; ++w) { const int f = 16 * tt + 4 * w + c_; if (f < q) L.zc[r_ * q + f] = nz[w]; }
       }
-      lpc = gw_causal_logp(m, L, L.zc, a.x, a.y, a.v, row0, n);
+      lpc = gw_causal_logp<X3>(m, L, L.zc, a.x, a.y, a.v, row0, n);
     } else {
       for (int c = c_; c < q; c += 4) {
         long long gr = row0 + r_; gr = gr < n ? gr : n - 1;
@@ -346,7 +361,7 @@ __global__ __launch_bounds__(GW_THREADS, 4) void gw_causal_mh_kernel(GxMhArgs a)
 #pragma unroll
         for (int w = 0; w < 4; ++w) { const int f = 16 * tt + 4 * w + c_; if (f < q) L.zp[r_ * q + f] = fmaf(a.q_sd, nz[w], L.zc[r_ * q + f]); }
       }
-      const float lpn = gw_causal_logp(m, L, L.zp, a.x, a.y, a.v, row0, n);
+      const float lpn = gw_causal_logp<X3>(m, L, L.zp, a.x, a.y, a.v, row0, n);
       // ---- accept / reject   (base.py:868-871).  u(it) = word (it & 3) of Philox(row, it >> 2, 0, TAG_ACC)
       bool acc = false;
       if (lane < GW_ROWS) {
@@ -370,7 +385,7 @@ __global__ __launch_bounds__(GW_THREADS, 4) void gw_causal_mh_kernel(GxMhArgs a)
         if (EFFECT != 0) {
           const bool cached = e.cache != nullptr && e.eff_skip;
           n_served += (cached && stale == 0u) ? 1u : 0u;          // retained tile-iterations that needed no pass of the outcome net
-          gw_causal_effects<EFFECT>(m, L, L.zc, row0, n, a.row_base, (unsigned)it, d, e, stale, cached);
+          gw_causal_effects<EFFECT, X3>(m, L, L.zc, row0, n, a.row_base, (unsigned)it, d, e, stale, cached);
           stale = 0u;
         }
       }
@@ -387,7 +402,7 @@ __global__ __launch_bounds__(GW_THREADS, 4) void gw_causal_mh_kernel(GxMhArgs a)
 }
 
 // stand-alone effects on a tensor of draws [n_keep][n][q]
-template <int EFFECT>
+template <int EFFECT, bool X3 = false>
 __global__ __launch_bounds__(GW_THREADS) void gw_causal_effects_kernel(GxEffKArgs a) {
   extern __shared__ float lds[];
   const GxCausalModel &m = a.m;
@@ -403,7 +418,7 @@ __global__ __launch_bounds__(GW_THREADS) void gw_causal_effects_kernel(GxEffKArg
     for (int d = 0; d < e.n_keep; ++d) {
       long long gr = row0 + r_; gr = gr < n ? gr : n - 1;
       for (int c = c_; c < q; c += 4) L.zc[r_ * q + c] = a.draws[((long long)d * n + gr) * q + c];
-      gw_causal_effects<EFFECT>(m, L, L.zc, row0, n, a.row_base, (unsigned)(a.burn_in + d), d, e);
+      gw_causal_effects<EFFECT, X3>(m, L, L.zc, row0, n, a.row_base, (unsigned)(a.burn_in + d), d, e);
     }
   }
 }

@@ -26,6 +26,9 @@ struct GxState {
   GxCausalModel m{};
   float *pack = nullptr, *packT = nullptr;
   float *packF = nullptr;      // fragment pack of the row-tile-per-wave kernels (gx_device.h, FRAG): pack with every weight matrix in fragment order
+  unsigned *packx = nullptr;   // split-precision pack of g, f, h (gx_dense_x3): hi / lo fp16 fragments, GxNet::wx offsets in dwords
+  size_t packx_dwords = 0;
+  bool x3_ok = false;          // every layer input of g, f, h within GX_X3_MAXKB K blocks
   size_t pack_floats = 0, packT_floats = 0;
   std::vector<int> fwd_map[4], bwd_map[4];     // canonical parameter of net (G, F, H, E) -> position in pack / packT (-1: none)
   int ld_enc = 0, kc = 0;
@@ -79,6 +82,18 @@ int gx_session(bgm_handle *h, GxState *&st, hipStream_t stream, bool need_ghf = 
     for (int k = 0; k < 4; ++k) plan_net(*nets[k], *gn[k], off, offT, s->fwd_map[k], s->bwd_map[k]);
     if (off >= (1u << 30) || offT >= (1u << 30)) { delete s; bgm_set_error("general-width engine: networks too large for 32-bit offsets"); return BGM_E_UNSUPPORTED; }
     s->pack_floats = off; s->packT_floats = offT;
+    {   // split-precision pack: per layer of g, f, h (column groups of 32) x (K blocks of 32) x 64 lanes x 16 dwords
+      size_t offx = 0;
+      s->x3_ok = true;
+      for (int k = 0; k < 3; ++k)
+        for (int l = 0; l < gn[k]->L; ++l) {
+          gn[k]->wx[l] = (int)offx;
+          offx += (size_t)(gn[k]->pad[l + 1] / 32) * (size_t)(gn[k]->pad[l] / 32) * 64 * 16;
+          if (gn[k]->pad[l] / 32 > GX_X3_MAXKB) s->x3_ok = false;
+        }
+      s->packx_dwords = offx;
+      if (offx >= (1u << 30)) s->x3_ok = false;
+    }
     m.q = h->q; m.p = h->p; m.z0 = h->cfg.z_dims[0]; m.z1 = h->cfg.z_dims[1]; m.z2 = h->cfg.z_dims[2]; m.binary = h->cfg.binary_treatment ? 1 : 0;
     auto s2 = [](float s_) { return s_ > 0.0f ? s_ * s_ : -1.0f; };
     m.sig2_v = s2(h->cfg.sigma_v); m.sig2_x = s2(h->cfg.sigma_x); m.sig2_y = s2(h->cfg.sigma_y);
@@ -178,6 +193,36 @@ int gx_session(bgm_handle *h, GxState *&st, hipStream_t stream, bool need_ghf = 
         }
       BGM_HIP_CHECK(hipMemcpy(st->packF, pf.data(), sizeof(float) * pf.size(), hipMemcpyHostToDevice));
     }
+    if (st->gw && st->x3_ok && h->precision == 2) {      // split pack (built when the mode is on: bgm_causal_set_precision invalidates the packs)
+      std::vector<unsigned> px(st->packx_dwords, 0u);
+      auto half_bits = [](float x) { const _Float16 hx = (_Float16)x; unsigned short b; std::memcpy(&b, &hx, 2); return b; };
+      const GxNet *gn[3] = {&st->m.g, &st->m.f, &st->m.h};
+      for (const GxNet *net : gn)
+        for (int l = 0; l < net->L; ++l) {
+          const int Np = net->pad[l + 1], KB = net->pad[l] / 32;
+          const float *src = pk.data() + net->w[l];      // [Kp][Np], zeros beyond the true widths
+          unsigned *dst = px.data() + net->wx[l];
+          for (int cg = 0; cg < Np / 32; ++cg)
+            for (int kb = 0; kb < KB; ++kb)
+              for (int lane = 0; lane < 64; ++lane) {
+                const int j = lane & 15, g = lane >> 4;
+                unsigned *d = dst + ((size_t)(cg * KB + kb) * 64 + lane) * 16;
+                for (int c = 0; c < 2; ++c)
+                  for (int i = 0; i < 8; i += 2) {
+                    unsigned hi2 = 0, lo2 = 0;
+                    for (int e = 0; e < 2; ++e) {
+                      const float w = src[(size_t)(32 * kb + 8 * g + i + e) * Np + 32 * cg + 2 * j + c];
+                      const _Float16 hh = (_Float16)w;
+                      hi2 |= (unsigned)half_bits((float)hh) << (16 * e);
+                      lo2 |= (unsigned)half_bits(w - (float)hh) << (16 * e);
+                    }
+                    d[4 * c + i / 2] = hi2; d[8 + 4 * c + i / 2] = lo2;
+                  }
+              }
+        }
+      if (!st->packx) BGM_HIP_CHECK(hipMalloc((void **)&st->packx, sizeof(unsigned) * std::max<size_t>(st->packx_dwords, 1)));
+      BGM_HIP_CHECK(hipMemcpy(st->packx, px.data(), sizeof(unsigned) * px.size(), hipMemcpyHostToDevice));
+    }
     h->gx_valid = true;
   }
   return BGM_OK;
@@ -189,7 +234,15 @@ int grid_for(const bgm_handle *h, const GxState *s, int64_t n) {
 }
 
 // the model as the row-tile-per-wave kernels read it (their own dose batch) and their launch grid (workgroups of GW_WAVES row tiles)
-GxCausalModel gw_model(const GxState *s) { GxCausalModel w = s->m; w.db = s->gw_db; w.pack = s->packF; w.ld = s->gw_ld; w.ldf = s->gw_ldf; return w; }
+GxCausalModel gw_model(const GxState *s) { GxCausalModel w = s->m; w.db = s->gw_db; w.pack = s->packF; w.packx = s->packx; w.ld = s->gw_ld; w.ldf = s->gw_ldf; return w; }
+// Split precision (bgm_causal_set_precision) on this engine: "f16x3" on the row-tile-per-wave kernels.  0: fp32; 1: split; < 0: refused.
+int gx_x3(const bgm_handle *h, const GxState *s, const char *who) {
+  if (h->precision == 0) return 0;
+  if (h->precision == 2 && s->gw && !s->fit && s->x3_ok && s->packx) return 1;
+  bgm_set_error(std::string(who) + ": split precision outside the default shapes exists as 'f16x3' for hidden widths up to 128 (the row-tile-per-wave "
+                "kernels of the general-width engine), outside a fit session");
+  return -1;
+}
 int gw_grid(const bgm_handle *h, const GxState *s, int64_t n) {
   const int64_t wgs = ((n + GW_ROWS - 1) / GW_ROWS + GW_WAVES - 1) / GW_WAVES;
   return (int)std::max<int64_t>(1, std::min<int64_t>(wgs, (int64_t)h->n_cus * s->gw_occ));
@@ -241,10 +294,13 @@ int gx_logpost(bgm_handle *h, const float *x, const float *y, const float *v, co
   GxState *s;
   int rc = gx_session(h, s, stream);
   if (rc) return rc;
+  const int x3 = gx_x3(h, s, "bgm_causal_logpost");
+  if (x3 < 0) return BGM_E_UNSUPPORTED;
   if (use_gw(s)) {
-    rc = set_lds(gw_causal_logpost_kernel, s->gw_lds);
+    auto kern = x3 ? gw_causal_logpost_kernel<true> : gw_causal_logpost_kernel<false>;
+    rc = set_lds(kern, s->gw_lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(gw_causal_logpost_kernel, dim3(gw_grid(h, s, n)), dim3(GW_THREADS), s->gw_lds, stream, gw_model(s), x, y, v, z, (long long)n, out);
+    hipLaunchKernelGGL(kern, dim3(gw_grid(h, s, n)), dim3(GW_THREADS), s->gw_lds, stream, gw_model(s), x, y, v, z, (long long)n, out);
     BGM_HIP_CHECK(hipGetLastError());
     return BGM_OK;
   }
@@ -268,6 +324,8 @@ int gx_mh_run(bgm_handle *h, const bgm_mh_args *a, hipStream_t stream) {
   k.e.ite = a->ite_dev; k.e.k0 = k.k0; k.e.k1 = k.k1;
   k.adrf_partial = a->adrf_partial_dev;
   const bool gw = use_gw(s);
+  const int x3 = gx_x3(h, s, "bgm_causal_mh_run");
+  if (x3 < 0) return BGM_E_UNSUPPORTED;
   if (gw) k.m = gw_model(s);
   const int grid = gw ? gw_grid(h, s, a->n) : grid_for(h, s, a->n);
   const int it_end = a->it_begin + a->n_iters;
@@ -297,7 +355,11 @@ int gx_mh_run(bgm_handle *h, const bgm_mh_args *a, hipStream_t stream) {
     BGM_HIP_CHECK(hipGetLastError());
     return (int)BGM_OK;
   };
-  if (gw) {
+  if (gw && x3) {
+    if (a->effect == BGM_EFFECT_ADRF) rc = launch(gw_causal_mh_kernel<1, true>);
+    else if (a->effect == BGM_EFFECT_ITE) rc = launch(gw_causal_mh_kernel<2, true>);
+    else rc = launch(gw_causal_mh_kernel<0, true>);
+  } else if (gw) {
     if (a->effect == BGM_EFFECT_ADRF) rc = launch(gw_causal_mh_kernel<1>);
     else if (a->effect == BGM_EFFECT_ITE) rc = launch(gw_causal_mh_kernel<2>);
     else rc = launch(gw_causal_mh_kernel<0>);
@@ -348,18 +410,19 @@ int gx_effects(bgm_handle *h, const float *draws, int64_t n, int64_t row_base, i
   k.e.k0 = (unsigned)(seed & 0xFFFFFFFFull); k.e.k1 = (unsigned)(seed >> 32);
   k.adrf_partial = adrf_partial;
   const bool binary = h->cfg.binary_treatment != 0;
+  const int x3 = (h->precision == 2 && s->gw && !s->fit && s->x3_ok && s->packx) ? 1 : 0;      // (stand-alone effects: split precision where it exists, else fp32 as on the resident kernels)
   if (use_gw(s)) {
     k.m = gw_model(s);
     const int gg = gw_grid(h, s, n);
-    if (binary) {
-      rc = set_lds(gw_causal_effects_kernel<2>, s->gw_lds);
-      if (rc) return rc;
-      hipLaunchKernelGGL(gw_causal_effects_kernel<2>, dim3(gg), dim3(GW_THREADS), s->gw_lds, stream, k);
-    } else {
-      rc = set_lds(gw_causal_effects_kernel<1>, s->gw_lds);
-      if (rc) return rc;
-      hipLaunchKernelGGL(gw_causal_effects_kernel<1>, dim3(gg), dim3(GW_THREADS), s->gw_lds, stream, k);
-    }
+    auto go = [&](auto kern) -> int {
+      int r = set_lds(kern, s->gw_lds);
+      if (r) return r;
+      hipLaunchKernelGGL(kern, dim3(gg), dim3(GW_THREADS), s->gw_lds, stream, k);
+      return BGM_OK;
+    };
+    if (binary) rc = x3 ? go(gw_causal_effects_kernel<2, true>) : go(gw_causal_effects_kernel<2>);
+    else rc = x3 ? go(gw_causal_effects_kernel<1, true>) : go(gw_causal_effects_kernel<1>);
+    if (rc) return rc;
     BGM_HIP_CHECK(hipGetLastError());
     return BGM_OK;
   }
@@ -491,6 +554,7 @@ void gx_free(bgm_handle *h) {
   if (s->pack) hipFree(s->pack);
   if (s->packT) hipFree(s->packT);
   if (s->packF) hipFree(s->packF);
+  if (s->packx) hipFree(s->packx);
   delete s;
   h->gx_state = nullptr; h->gx_valid = false;
 }

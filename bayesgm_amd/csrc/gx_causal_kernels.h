@@ -37,6 +37,7 @@ __device__ unsigned long long gx_phase_clk[16];
 struct GxCausalModel {
   GxNet g, f, h, e;
   const float *pack;                 // forward pack of all four networks
+  const unsigned *packx;             // split-precision pack of g, f, h (gx_dense_x3; NULL unless bgm_causal_set_precision(2))
   int q, p, z0, z1, z2, binary;
   float sig2_v, sig2_x, sig2_y;      // fixed variances (params['sigma_*'] ** 2) or < 0: learned heads
   int ld;                            // LDS row stride of the activation buffers

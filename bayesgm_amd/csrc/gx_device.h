@@ -36,6 +36,7 @@ struct GxNet {              // one fully connected network inside the padded pac
   int w[GX_MAXL];           // W_l  [pad[l]][pad[l+1]]   at pack + w[l]
   int b[GX_MAXL];           // b_l  [pad[l+1]]           at pack + b[l]
   int wt[GX_MAXL];          // W_l^T [pad[l+1]][pad[l]]  at packT + wt[l]
+  int wx[GX_MAXL];          // W_l as hi / lo fp16 fragments at packx + wx[l] (dwords; gx_dense_x3)
   int base;                 // first canonical (Keras-order) parameter of the net in the model's flat parameter vector
 };
 
@@ -170,6 +171,92 @@ __device__ __forceinline__ void gx_dense_ld(const float *__restrict__ W, int ldw
     gx_epi_rotate(epi, 0);
     u = un; rt = rtn; n0 = n0n;
     a = an; b0 = c0; b1 = c1; b2 = c2; b3 = c3; bb = bn;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Split precision ("f16 x 3", opt-in: bgm_causal_set_precision(2) on the row-tile-per-wave kernels of gw_kernels.h).  Y = A W for the
+// wave's nrt row tiles with every fp32 operand as hi + lo fp16 and three products W_hi A_hi + W_hi A_lo + W_lo A_hi on
+// v_mfma_f32_16x16x32_f16 (16 cycles for K = 32 against 8 x 32 cycles of the fp32 instruction), fp32 accumulation from the bias.
+// The accumulators come out in gx_dense_ld's layout (lane (j, g): rows 4 g + r of columns n0 + 2 j | n0 + 2 j + 1), so every epilogue
+// functor serves both.  Activations stay fp32 in LDS: a lane reads its row's 8 k-values of a K block (k = 32 kb + 8 g + i) and splits
+// them in registers, ONCE per row tile for all column groups (K <= 128 on these kernels).
+// WX: the layer of the split pack (gx_api.hip): per (32-column group cg, K block kb of 32) and lane 16 dwords =
+// [hi of column 2 j | hi of column 2 j + 1 | lo of 2 j | lo of 2 j + 1], each 8 fp16 (k = 32 kb + 8 g + 0 .. 7): four 16-byte requests.
+typedef _Float16 gx_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 gx_h2 __attribute__((ext_vector_type(2)));
+typedef float gx_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned gx_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gx_split_pair(float a, float b, unsigned &hi, unsigned &lo) {
+  const gx_h2 h = __builtin_convertvector(gx_f2{a, b}, gx_h2);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(gx_f2{a - (float)h[0], b - (float)h[1]}, gx_h2));
+}
+__device__ __forceinline__ void gx_split8(const f32x4 &a, const f32x4 &b, gx_u4 &hi, gx_u4 &lo) {
+  unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+  gx_split_pair(a[0], a[1], h0, l0); gx_split_pair(a[2], a[3], h1, l1);
+  gx_split_pair(b[0], b[1], h2, l2); gx_split_pair(b[2], b[3], h3, l3);
+  hi = gx_u4{h0, h1, h2, h3}; lo = gx_u4{l0, l1, l2, l3};
+}
+#define GX_MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(gx_h8, a), __builtin_bit_cast(gx_h8, b), c, 0, 0, 0)
+#define GX_X3_MAXKB 4      // K <= 128
+// first K block of a layer's first unit, requested ahead of the layer in front of it (as GxPre for the fp32 routine)
+struct GxPreX { gx_u4 w0, w1, w2, w3; int valid; };
+__device__ __forceinline__ GxPreX gx_prefetch_x3(const unsigned *__restrict__ WX) {
+  GxPreX p;
+  const gx_u4 *wp = reinterpret_cast<const gx_u4 *>(WX) + (size_t)gx_lane() * 4;
+  p.w0 = wp[0]; p.w1 = wp[1]; p.w2 = wp[2]; p.w3 = wp[3]; p.valid = 1;
+  return p;
+}
+// The wave's walk is ONE stream of K blocks over the units (block b = unit * KB + kb at WX + b * 4 KB for nrt = 1; with several row
+// tiles a column group's blocks are walked once per tile): block b + 1 is requested before the products of block b, across unit
+// boundaries -- a unit is 6 KB products (a few hundred cycles), an L2 round trip in front of each would cost more than the unit.
+template <class Epi>
+__device__ __forceinline__ void gx_dense_x3(const unsigned *__restrict__ WX, int K, int N, const float *A, int lda, Epi epi, int nrt, const float *bias,
+                                            const GxPreX *pre = nullptr) {
+  const int lane = gx_lane(), j = lane & 15, g = lane >> 4;
+  const int KB = (K + 31) >> 5, units = nrt * (N >> 5);
+  gx_u4 ah[GX_X3_MAXKB], al[GX_X3_MAXKB];
+  int rt_have = -1;
+  gx_epi_pre(epi, 0, 0, 0);
+  gx_epi_rotate(epi, 0);
+  const gx_u4 *wl = reinterpret_cast<const gx_u4 *>(WX) + (size_t)lane * 4;
+  gx_u4 wc0, wc1, wc2, wc3;
+  if (pre != nullptr && pre->valid) { wc0 = pre->w0; wc1 = pre->w1; wc2 = pre->w2; wc3 = pre->w3; }
+  else { wc0 = wl[0]; wc1 = wl[1]; wc2 = wl[2]; wc3 = wl[3]; }
+  gx_u4 wn0 = wc0, wn1 = wc1, wn2 = wc2, wn3 = wc3;
+  f32x2 bb = bias ? *reinterpret_cast<const f32x2 *>(bias + 2 * j) : f32x2{0.0f, 0.0f}, bn = bb;
+  for (int u = 0; u < units; ++u) {
+    const int rt = u % nrt, cg = u / nrt, n0 = cg << 5;
+    if (rt != rt_have) {
+      const float *ap = A + (size_t)(16 * rt + j) * lda + 8 * g;
+#pragma unroll
+      for (int kb = 0; kb < GX_X3_MAXKB; ++kb)
+        if (kb < KB) gx_split8(*reinterpret_cast<const f32x4 *>(ap + 32 * kb), *reinterpret_cast<const f32x4 *>(ap + 32 * kb + 4), ah[kb], al[kb]);
+      rt_have = rt;
+    }
+    const bool more = u + 1 < units;
+    const int cgn = (u + 1) / nrt;
+    if (more) { gx_epi_pre(epi, (u + 1) % nrt, cgn << 5, 0); if (bias) bn = *reinterpret_cast<const f32x2 *>(bias + (cgn << 5) + 2 * j); }
+    f32x4 acc0 = {bb[0], bb[0], bb[0], bb[0]}, acc1 = {bb[1], bb[1], bb[1], bb[1]};
+#pragma unroll
+    for (int kb = 0; kb < GX_X3_MAXKB; ++kb)
+      if (kb < KB) {
+        // the next block of the stream: this unit's kb + 1, or block 0 of the next unit's column group
+        const bool last = kb + 1 == KB;
+        if (!last || more) {
+          const gx_u4 *wq = wl + ((size_t)(last ? cgn : cg) * KB + (last ? 0 : kb + 1)) * 256;
+          wn0 = wq[0]; wn1 = wq[1]; wn2 = wq[2]; wn3 = wq[3];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = GX_MFMA_H(al[kb], wc0, acc0); acc1 = GX_MFMA_H(al[kb], wc1, acc1);      // the small cross terms first
+        acc0 = GX_MFMA_H(ah[kb], wc2, acc0); acc1 = GX_MFMA_H(ah[kb], wc3, acc1);
+        acc0 = GX_MFMA_H(ah[kb], wc0, acc0); acc1 = GX_MFMA_H(ah[kb], wc1, acc1);
+        wc0 = wn0; wc1 = wn1; wc2 = wn2; wc3 = wn3;
+      }
+    epi(rt, n0, acc0, acc1);
+    if (more) gx_epi_rotate(epi, 0);
+    bb = bn;
   }
 }
 

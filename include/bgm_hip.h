@@ -81,7 +81,10 @@ BGM_API int bgm_set_disc_norm(bgm_handle *h, int32_t mode);
  *                contraction with fp32 accumulation (relative error ~6e-6 per layer against 2.4e-7 in fp32).  Same algorithm,
  *                RNG streams and outputs; chains agree with the fp32 ones statistically, not draw for draw (DESIGN_HISTORY.md section 4b);
  *   2            the same kernels on fp16 operands ("f16 x 3": hi + lo carry 22 mantissa bits, the log posterior is within the
- *                fp32 kernel's own distance of float64; weights beyond 65504 are clamped, an activation beyond 65504 overflows: fp16 range). */
+ *                fp32 kernel's own distance of float64; weights beyond 65504 are clamped, an activation beyond 65504 overflows: fp16 range).
+ * Modes 1 and 2 exist for the LDS-resident (default-width) shapes; mode 2 also outside them for hidden widths up to 128 (the general-width
+ * engine's row-tile-per-wave kernels: fp32 activations in LDS split into hi / lo fp16 at the operand load, csrc/gx_device.h gx_dense_x3).
+ * Other shapes answer BGM_E_UNSUPPORTED at the sampling call. */
 BGM_API int bgm_causal_set_precision(bgm_handle *h, int32_t mode);
 /* Conditional latent prior Z | U ~ N(mu(U), sigma^2(U) I) of IdentifiableCausalBGM (models/causalbgm/identifiable.py:195-211,
  * 541-551) for the sampling calls made afterwards (bgm_causal_logpost, bgm_causal_mh_run; fp32 and split-precision kernels): seg_dev [n] = segment of

@@ -27,6 +27,7 @@ for name, u, n in cases:
     m = OC.init_model(0, z_dims, p, **u)
     eng = CausalEngine(p, z_dims, **{k: list(v) for k, v in u.items()})
     eng.set_model(g=m["g"], f=m["f"], h=m["h"], e=m["e"])
+    eng.set_precision(os.environ.get("GX_PRECISION", "fp32"))      # "f16x3": split precision on the row-tile-per-wave kernels (hidden widths <= 128)
     g = torch.Generator(device="cuda").manual_seed(0)
     v = torch.randn(n, p, device="cuda", generator=g); x = torch.rand(n, device="cuda", generator=g); y = torch.randn(n, device="cuda", generator=g)
     xs = np.linspace(0, 3, 20)

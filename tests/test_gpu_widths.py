@@ -113,6 +113,62 @@ def test_logpost_matches_oracle(case):
     assert np.all(err <= 1e-5 * np.abs(ref) + 1e-3), (err.max(), np.abs(ref).max())
 
 
+X3_CASES = [dict(shape="r_test", z_dims=[1, 1, 1, 1], p=4, binary=True, n=64), dict(shape="w128", z_dims=[1, 1, 1, 7], p=200, binary=False, n=300),
+            dict(shape="mixed", z_dims=[2, 3, 2, 3], p=37, binary=False, n=129), dict(shape="mixed", z_dims=[3, 3, 6, 6], p=100, binary=True, n=77)]
+
+
+@pytest.mark.parametrize("case", X3_CASES)
+def test_split_precision_on_the_general_width_engine(case):
+    """bgm_causal_set_precision('f16x3') outside the default shapes (hidden widths up to 128: the row-tile-per-wave kernels,
+    gx_dense_x3): every contraction as three fp16 products of hi / lo splits, fp32 accumulation -- the log posterior within the fp32
+    kernel's own bound of the float64 oracle, chains draw-for-draw equal to the fp32 engine's except where an accept decision lies within
+    the arithmetic's error, fused effects within 2e-3 of the fp32 run's (test_gpu_bx3.py states the same for the default shapes)."""
+    from bayesgm_amd import _lib
+    u = SHAPES[case["shape"]]
+    m = _model(1, case["z_dims"], case["p"], case["binary"], **u)
+    x, y, v = _data(case["n"], case["p"], 2, case["binary"])
+    z = np.random.RandomState(3).randn(case["n"], sum(case["z_dims"])).astype(np.float32)
+    eng = _engine(m, u)
+    m64, (x64, y64, v64, z64) = _as64(m, x, y, v, z)
+    ref = OC.log_posterior(m64, x64, y64, v64, z64)
+    lp32 = eng.logpost(x.ravel(), y.ravel(), v, z).cpu().numpy()
+    eng.set_precision("f16x3")
+    lpx = eng.logpost(x.ravel(), y.ravel(), v, z).cpu().numpy()
+    err32, errx = np.abs(lp32 - ref), np.abs(lpx - ref)
+    print("logpost err: fp32 max %.2e, f16x3 max %.2e (|lp| ~ %.0f)" % (err32.max(), errx.max(), np.abs(ref).mean()))
+    assert np.all(errx <= 1e-5 * np.abs(ref) + 1e-3), errx.max()
+    assert np.abs(lpx - lp32).max() > 0.0                                   # (another arithmetic did run)
+    xs = np.linspace(0, 3, 11)
+    kw = dict(effect=_lib.EFFECT_ITE) if case["binary"] else dict(effect=_lib.EFFECT_ADRF, x_values=xs)
+    outs = {}
+    for mode in ("fp32", "f16x3"):
+        eng.set_precision(mode)
+        out = eng.mh_sample(x, y, v, 30, 20, 0.3, 987654321, want_draws=True, sample_y=True, **kw)
+        outs[mode] = (out["draws"].cpu().numpy(), (out["ite"] if case["binary"] else out["adrf"]).cpu().numpy(), out["acc_count"].cpu().numpy().sum())
+    eng.set_precision("fp32")
+    (d0, e0, a0), (d1, e1, a1) = outs["fp32"], outs["f16x3"]
+    same = np.all(np.abs(d0[-1] - d1[-1]) <= 1e-4, axis=1)
+    assert same.mean() >= 0.97, same.mean()
+    assert abs(int(a0) - int(a1)) <= max(2, 3 * int((~same).sum()))
+    if case["binary"]:
+        assert np.abs(e0 - e1)[same].max() <= 2e-3
+    else:
+        assert np.abs(e0 - e1).max() <= 2e-3 + 3.0 * float((~same).sum()) / case["n"]
+
+
+def test_split_precision_says_where_it_does_not_exist():
+    u = SHAPES["w256"]
+    m = _model(1, [1, 1, 1, 7], 50, False, **u)
+    x, y, v = _data(40, 50, 2)
+    z = np.random.RandomState(3).randn(40, 10).astype(np.float32)
+    eng = _engine(m, u)
+    eng.set_precision("f16x3")
+    with pytest.raises(Exception, match="hidden widths up to 128"):
+        eng.logpost(x.ravel(), y.ravel(), v, z)
+    eng.set_precision("fp32")
+    eng.logpost(x.ravel(), y.ravel(), v, z)
+
+
 def test_logpost_fixed_sigmas():
     u = SHAPES["mixed"]
     m = _model(5, [2, 3, 4, 5], 77, False, sigma_v=0.8, sigma_x=1.3, sigma_y=0.5, **u)
