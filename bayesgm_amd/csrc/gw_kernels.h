@@ -49,20 +49,27 @@ __device__ __forceinline__ GwLds gw_carve(float *w, int ld, int q, int ldf, int 
 // hidden layers l_begin .. l_end - 1 of `net` on the wave's nrt row tiles (no barriers); pre as in gx_hidden
 // One dense layer l of `net` on the wave's nrt row tiles, and the request of a layer's first block ahead of it.  X3: split precision
 // (gx_dense_x3 on the split pack; it requests a unit's blocks itself, no first-block prefetch).
-template <bool X3> struct GwPreOf { typedef GxPre T; };
-template <> struct GwPreOf<true> { typedef GxPreX T; };
-template <bool X3, class Epi>
+// X3: 0 = fp32; split precision: 2 = every layer input within 2 K blocks of 32 (hidden widths <= 64): 16 registers of split input, no
+// cross-layer request -- within 128 VGPRs, four waves per SIMD (the split kernels are wait-bound: 1.14 -> 0.83 ms per iteration at the
+// default widths against the three-wave form); 4 = up to 4 blocks (hidden widths <= 128): 32 registers, ~158 VGPRs, three waves --
+// the LDS of 128-wide rows allows two waves per SIMD anyway, and the once-per-layer split beats re-splitting per column group
+// (0.852 against 0.889 ms at [128,128]; gx_dense_x3<2, RESPLIT>).
+template <int X3> struct GwPreOf { typedef GxPreX T; };
+template <> struct GwPreOf<0> { typedef GxPre T; };
+template <int X3, class Epi>
 __device__ __forceinline__ void gw_layer(const GxCausalModel &m, const GxNet &net, int l, const float *cur, int ld, Epi epi, int nrt,
                                          typename GwPreOf<X3>::T &pre) {
-  if constexpr (X3) gx_dense_x3(m.packx + net.wx[l], net.pad[l], net.pad[l + 1], cur, ld, epi, nrt, m.pack + net.b[l], &pre);
+  if constexpr (X3 == 2) gx_dense_x3<2>(m.packx + net.wx[l], net.pad[l], net.pad[l + 1], cur, ld, epi, nrt, m.pack + net.b[l], nullptr);
+  else if constexpr (X3 == 4) gx_dense_x3<4>(m.packx + net.wx[l], net.pad[l], net.pad[l + 1], cur, ld, epi, nrt, m.pack + net.b[l], &pre);
   else gx_dense<false, true>(m.pack + net.w[l], gw_k16(net, l), net.pad[l + 1], cur, ld, epi, nrt, m.pack + net.b[l], &pre, 0, 1);
 }
-template <bool X3>
+template <int X3>
 __device__ __forceinline__ typename GwPreOf<X3>::T gw_pre(const GxCausalModel &m, const GxNet &net, int l, int nrt) {
-  if constexpr (X3) return gx_prefetch_x3(m.packx + net.wx[l]);
+  if constexpr (X3 == 2) { GxPreX p; p.valid = 0; return p; }      // (no cross-layer request: its 16 registers cost the fourth wave)
+  else if constexpr (X3 == 4) return gx_prefetch_x3(m.packx + net.wx[l]);
   else return gx_prefetch<true>(m.pack + net.w[l], net.pad[l + 1], net.pad[l + 1], m.pack + net.b[l], nrt, 0, gw_k16(net, l));
 }
-template <bool X3 = false>
+template <int X3 = 0>
 __device__ __forceinline__ float *gw_hidden(const GxCausalModel &m, const GxNet &net, int l_begin, int l_end, float *cur, float *oth, int ld,
                                             typename GwPreOf<X3>::T &pre, int nrt) {
   for (int l = l_begin; l < l_end; ++l) {
@@ -119,7 +126,7 @@ struct GwGLastEpi {
 
 // f on nd row tiles of the wave: row R (0 .. 16 nd - 1) is the latent of chain src(R) (LDS [16][q]) at treatment value xin(R).  Returns the
 // buffer whose columns 0, 1 of row R hold (mu_y, raw_y).  Lane (r = lane & 15, cq = lane >> 4) stages columns cq, cq + 4, ... of rows r, r + 16, ...
-template <bool X3 = false, class Src, class XIn>
+template <int X3 = 0, class Src, class XIn>
 __device__ __forceinline__ const float *gw_f_rows(const GxCausalModel &m, const GwLds &L, const float *z, Src src, XIn xin, int nd) {
   const int lane = gx_lane(), zf = m.z0 + m.z1, q = m.q, ld = m.ldf, wp = m.f.pad[0];
   auto pre = gw_pre<X3>(m, m.f, 0, nd);
@@ -137,13 +144,13 @@ __device__ __forceinline__ const float *gw_f_rows(const GxCausalModel &m, const 
   return oth;
 }
 // the wave's 16 chains at treatment values xin(row, dose), nd <= m.db doses stacked as row tiles (row 16 d + r)
-template <bool X3 = false, class XIn>
+template <int X3 = 0, class XIn>
 __device__ __forceinline__ const float *gw_f_forward(const GxCausalModel &m, const GwLds &L, const float *z, XIn xin, int nd) {
   return gw_f_rows<X3>(m, L, z, [](int R) { return R & (GW_ROWS - 1); }, [&](int R) { return xin(R & (GW_ROWS - 1), R >> 4); }, nd);
 }
 
 // log p(z | x, y, v) + const of the wave's 16 rows, z in LDS [16][q]; returned in lane r < 16 for row r.  base.py:765-817.
-template <bool X3 = false>
+template <int X3 = 0>
 __device__ __forceinline__ float gw_causal_logp(const GxCausalModel &m, const GwLds &L, const float *z, const float *x, const float *y,
                                                 const float *v, long long row0, long long n) {
   const int lane = gx_lane(), j = lane & 15, g = lane >> 4, q = m.q, ld = m.ld;
@@ -224,8 +231,8 @@ __device__ __forceinline__ float gw_causal_logp(const GxCausalModel &m, const Gw
   return lp;
 }
 
-template <bool X3 = false>
-__global__ __launch_bounds__(GW_THREADS, X3 ? 3 : 4) void gw_causal_logpost_kernel(GxCausalModel m, const float *x, const float *y, const float *v, const float *z,
+template <int X3 = 0>
+__global__ __launch_bounds__(GW_THREADS, X3 == 4 ? 3 : 4) void gw_causal_logpost_kernel(GxCausalModel m, const float *x, const float *y, const float *v, const float *z,
                                                                        long long n, float *out) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), q = m.q;      // (wave: provably uniform, so that the region's pointers and the tile walk live in SGPRs)
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(GW_THREADS, X3 ? 3 : 4) void gw_causal_logpost_kern
 // row's operands only, so the values are the bits a pass over all 16 chains at that dose gives; the sums then run over the cache with the
 // same noise and in the same order as without it.  At the bench's acceptance rate (0.08: 1.3 chains of 16 move per iteration) that is
 // 2-3 passes instead of 20.
-template <int EFFECT, bool X3 = false>
+template <int EFFECT, int X3 = 0>
 __device__ __forceinline__ void gw_causal_effects(const GxCausalModel &m, const GwLds &L, const float *z, long long row0, long long n,
                                                   long long row_base, unsigned it, long long d, const GxEffArgs &e, unsigned stale = 0xFFFFu,
                                                   bool cached = false) {
@@ -319,8 +326,8 @@ __device__ __forceinline__ void gw_causal_effects(const GxCausalModel &m, const 
   }
 }
 
-template <int EFFECT, bool X3 = false>
-__global__ __launch_bounds__(GW_THREADS, X3 ? 3 : 4) void gw_causal_mh_kernel(GxMhArgs a) {      // (X3: the split operands of a layer's input live in 32 more registers)
+template <int EFFECT, int X3 = 0>
+__global__ __launch_bounds__(GW_THREADS, X3 == 4 ? 3 : 4) void gw_causal_mh_kernel(GxMhArgs a) {      // (X3: the split operands of a layer's input live in 32 more registers)
   extern __shared__ float lds[];
   const GxCausalModel &m = a.m;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), q = m.q;      // (wave: provably uniform, so that the region's pointers and the tile walk live in SGPRs)
@@ -402,7 +409,7 @@ __global__ __launch_bounds__(GW_THREADS, X3 ? 3 : 4) void gw_causal_mh_kernel(Gx
 }
 
 // stand-alone effects on a tensor of draws [n_keep][n][q]
-template <int EFFECT, bool X3 = false>
+template <int EFFECT, int X3 = 0>
 __global__ __launch_bounds__(GW_THREADS) void gw_causal_effects_kernel(GxEffKArgs a) {
   extern __shared__ float lds[];
   const GxCausalModel &m = a.m;

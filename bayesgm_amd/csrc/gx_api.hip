@@ -29,6 +29,7 @@ struct GxState {
   unsigned *packx = nullptr;   // split-precision pack of g, f, h (gx_dense_x3): hi / lo fp16 fragments, GxNet::wx offsets in dwords
   size_t packx_dwords = 0;
   bool x3_ok = false;          // every layer input of g, f, h within GX_X3_MAXKB K blocks
+  bool x3_k64 = false;         // ... within 2 (the kernels with a fourth wave per SIMD)
   size_t pack_floats = 0, packT_floats = 0;
   std::vector<int> fwd_map[4], bwd_map[4];     // canonical parameter of net (G, F, H, E) -> position in pack / packT (-1: none)
   int ld_enc = 0, kc = 0;
@@ -84,14 +85,17 @@ int gx_session(bgm_handle *h, GxState *&st, hipStream_t stream, bool need_ghf = 
     s->pack_floats = off; s->packT_floats = offT;
     {   // split-precision pack: per layer of g, f, h (column groups of 32) x (K blocks of 32) x 64 lanes x 16 dwords
       size_t offx = 0;
+      bool k64 = true;
       s->x3_ok = true;
       for (int k = 0; k < 3; ++k)
         for (int l = 0; l < gn[k]->L; ++l) {
           gn[k]->wx[l] = (int)offx;
           offx += (size_t)(gn[k]->pad[l + 1] / 32) * (size_t)(gn[k]->pad[l] / 32) * 64 * 16;
           if (gn[k]->pad[l] / 32 > GX_X3_MAXKB) s->x3_ok = false;
+          if (gn[k]->pad[l] / 32 > 2) k64 = false;
         }
       s->packx_dwords = offx;
+      s->x3_k64 = k64 && std::getenv("BGM_GW_X3_NO_K64") == nullptr;
       if (offx >= (1u << 30)) s->x3_ok = false;
     }
     m.q = h->q; m.p = h->p; m.z0 = h->cfg.z_dims[0]; m.z1 = h->cfg.z_dims[1]; m.z2 = h->cfg.z_dims[2]; m.binary = h->cfg.binary_treatment ? 1 : 0;
@@ -235,10 +239,10 @@ int grid_for(const bgm_handle *h, const GxState *s, int64_t n) {
 
 // the model as the row-tile-per-wave kernels read it (their own dose batch) and their launch grid (workgroups of GW_WAVES row tiles)
 GxCausalModel gw_model(const GxState *s) { GxCausalModel w = s->m; w.db = s->gw_db; w.pack = s->packF; w.packx = s->packx; w.ld = s->gw_ld; w.ldf = s->gw_ldf; return w; }
-// Split precision (bgm_causal_set_precision) on this engine: "f16x3" on the row-tile-per-wave kernels.  0: fp32; 1: split; < 0: refused.
+// Split precision (bgm_causal_set_precision) on this engine: "f16x3" on the row-tile-per-wave kernels.  0: fp32; 4 / 2: split (kernel variant, gw_kernels.h); < 0: refused.
 int gx_x3(const bgm_handle *h, const GxState *s, const char *who) {
   if (h->precision == 0) return 0;
-  if (h->precision == 2 && s->gw && !s->fit && s->x3_ok && s->packx) return 1;
+  if (h->precision == 2 && s->gw && !s->fit && s->x3_ok && s->packx) return s->x3_k64 ? 2 : 4;
   bgm_set_error(std::string(who) + ": split precision outside the default shapes exists as 'f16x3' for hidden widths up to 128 (the row-tile-per-wave "
                 "kernels of the general-width engine), outside a fit session");
   return -1;
@@ -297,7 +301,7 @@ int gx_logpost(bgm_handle *h, const float *x, const float *y, const float *v, co
   const int x3 = gx_x3(h, s, "bgm_causal_logpost");
   if (x3 < 0) return BGM_E_UNSUPPORTED;
   if (use_gw(s)) {
-    auto kern = x3 ? gw_causal_logpost_kernel<true> : gw_causal_logpost_kernel<false>;
+    auto kern = x3 == 4 ? gw_causal_logpost_kernel<4> : x3 == 2 ? gw_causal_logpost_kernel<2> : gw_causal_logpost_kernel<0>;
     rc = set_lds(kern, s->gw_lds);
     if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3(gw_grid(h, s, n)), dim3(GW_THREADS), s->gw_lds, stream, gw_model(s), x, y, v, z, (long long)n, out);
@@ -355,10 +359,14 @@ int gx_mh_run(bgm_handle *h, const bgm_mh_args *a, hipStream_t stream) {
     BGM_HIP_CHECK(hipGetLastError());
     return (int)BGM_OK;
   };
-  if (gw && x3) {
-    if (a->effect == BGM_EFFECT_ADRF) rc = launch(gw_causal_mh_kernel<1, true>);
-    else if (a->effect == BGM_EFFECT_ITE) rc = launch(gw_causal_mh_kernel<2, true>);
-    else rc = launch(gw_causal_mh_kernel<0, true>);
+  if (gw && x3 == 4) {
+    if (a->effect == BGM_EFFECT_ADRF) rc = launch(gw_causal_mh_kernel<1, 4>);
+    else if (a->effect == BGM_EFFECT_ITE) rc = launch(gw_causal_mh_kernel<2, 4>);
+    else rc = launch(gw_causal_mh_kernel<0, 4>);
+  } else if (gw && x3 == 2) {
+    if (a->effect == BGM_EFFECT_ADRF) rc = launch(gw_causal_mh_kernel<1, 2>);
+    else if (a->effect == BGM_EFFECT_ITE) rc = launch(gw_causal_mh_kernel<2, 2>);
+    else rc = launch(gw_causal_mh_kernel<0, 2>);
   } else if (gw) {
     if (a->effect == BGM_EFFECT_ADRF) rc = launch(gw_causal_mh_kernel<1>);
     else if (a->effect == BGM_EFFECT_ITE) rc = launch(gw_causal_mh_kernel<2>);
@@ -410,7 +418,7 @@ int gx_effects(bgm_handle *h, const float *draws, int64_t n, int64_t row_base, i
   k.e.k0 = (unsigned)(seed & 0xFFFFFFFFull); k.e.k1 = (unsigned)(seed >> 32);
   k.adrf_partial = adrf_partial;
   const bool binary = h->cfg.binary_treatment != 0;
-  const int x3 = (h->precision == 2 && s->gw && !s->fit && s->x3_ok && s->packx) ? 1 : 0;      // (stand-alone effects: split precision where it exists, else fp32 as on the resident kernels)
+  const int x3 = (h->precision == 2 && s->gw && !s->fit && s->x3_ok && s->packx) ? (s->x3_k64 ? 2 : 4) : 0;      // (stand-alone effects: split precision where it exists, else fp32 as on the resident kernels)
   if (use_gw(s)) {
     k.m = gw_model(s);
     const int gg = gw_grid(h, s, n);
@@ -420,8 +428,8 @@ int gx_effects(bgm_handle *h, const float *draws, int64_t n, int64_t row_base, i
       hipLaunchKernelGGL(kern, dim3(gg), dim3(GW_THREADS), s->gw_lds, stream, k);
       return BGM_OK;
     };
-    if (binary) rc = x3 ? go(gw_causal_effects_kernel<2, true>) : go(gw_causal_effects_kernel<2>);
-    else rc = x3 ? go(gw_causal_effects_kernel<1, true>) : go(gw_causal_effects_kernel<1>);
+    if (binary) rc = x3 == 4 ? go(gw_causal_effects_kernel<2, 4>) : x3 == 2 ? go(gw_causal_effects_kernel<2, 2>) : go(gw_causal_effects_kernel<2>);
+    else rc = x3 == 4 ? go(gw_causal_effects_kernel<1, 4>) : x3 == 2 ? go(gw_causal_effects_kernel<1, 2>) : go(gw_causal_effects_kernel<1>);
     if (rc) return rc;
     BGM_HIP_CHECK(hipGetLastError());
     return BGM_OK;

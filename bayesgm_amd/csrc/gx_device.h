@@ -211,12 +211,15 @@ __device__ __forceinline__ GxPreX gx_prefetch_x3(const unsigned *__restrict__ WX
 // The wave's walk is ONE stream of K blocks over the units (block b = unit * KB + kb at WX + b * 4 KB for nrt = 1; with several row
 // tiles a column group's blocks are walked once per tile): block b + 1 is requested before the products of block b, across unit
 // boundaries -- a unit is 6 KB products (a few hundred cycles), an L2 round trip in front of each would cost more than the unit.
-template <class Epi>
+// MAXKB: K blocks whose split operands live in registers at a time (8 registers each).  RESPLIT = false: K <= 32 MAXKB, the input is
+// split once per row tile for all column groups; true: any K up to 128 in chunks of MAXKB blocks, re-split per unit (more conversions,
+// 16 registers instead of 32 at MAXKB = 2: a fourth wave per SIMD).
+template <int MAXKB = GX_X3_MAXKB, bool RESPLIT = false, class Epi>
 __device__ __forceinline__ void gx_dense_x3(const unsigned *__restrict__ WX, int K, int N, const float *A, int lda, Epi epi, int nrt, const float *bias,
                                             const GxPreX *pre = nullptr) {
   const int lane = gx_lane(), j = lane & 15, g = lane >> 4;
   const int KB = (K + 31) >> 5, units = nrt * (N >> 5);
-  gx_u4 ah[GX_X3_MAXKB], al[GX_X3_MAXKB];
+  gx_u4 ah[MAXKB], al[MAXKB];
   int rt_have = -1;
   gx_epi_pre(epi, 0, 0, 0);
   gx_epi_rotate(epi, 0);
@@ -228,32 +231,35 @@ __device__ __forceinline__ void gx_dense_x3(const unsigned *__restrict__ WX, int
   f32x2 bb = bias ? *reinterpret_cast<const f32x2 *>(bias + 2 * j) : f32x2{0.0f, 0.0f}, bn = bb;
   for (int u = 0; u < units; ++u) {
     const int rt = u % nrt, cg = u / nrt, n0 = cg << 5;
-    if (rt != rt_have) {
-      const float *ap = A + (size_t)(16 * rt + j) * lda + 8 * g;
-#pragma unroll
-      for (int kb = 0; kb < GX_X3_MAXKB; ++kb)
-        if (kb < KB) gx_split8(*reinterpret_cast<const f32x4 *>(ap + 32 * kb), *reinterpret_cast<const f32x4 *>(ap + 32 * kb + 4), ah[kb], al[kb]);
-      rt_have = rt;
-    }
+    const float *ap = A + (size_t)(16 * rt + j) * lda + 8 * g;
     const bool more = u + 1 < units;
     const int cgn = (u + 1) / nrt;
     if (more) { gx_epi_pre(epi, (u + 1) % nrt, cgn << 5, 0); if (bias) bn = *reinterpret_cast<const f32x2 *>(bias + (cgn << 5) + 2 * j); }
     f32x4 acc0 = {bb[0], bb[0], bb[0], bb[0]}, acc1 = {bb[1], bb[1], bb[1], bb[1]};
+    for (int kc = 0; kc < KB; kc += MAXKB) {          // (one pass unless RESPLIT)
+      if (RESPLIT || rt != rt_have) {
 #pragma unroll
-    for (int kb = 0; kb < GX_X3_MAXKB; ++kb)
-      if (kb < KB) {
-        // the next block of the stream: this unit's kb + 1, or block 0 of the next unit's column group
-        const bool last = kb + 1 == KB;
-        if (!last || more) {
-          const gx_u4 *wq = wl + ((size_t)(last ? cgn : cg) * KB + (last ? 0 : kb + 1)) * 256;
-          wn0 = wq[0]; wn1 = wq[1]; wn2 = wq[2]; wn3 = wq[3];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        acc0 = GX_MFMA_H(al[kb], wc0, acc0); acc1 = GX_MFMA_H(al[kb], wc1, acc1);      // the small cross terms first
-        acc0 = GX_MFMA_H(ah[kb], wc2, acc0); acc1 = GX_MFMA_H(ah[kb], wc3, acc1);
-        acc0 = GX_MFMA_H(ah[kb], wc0, acc0); acc1 = GX_MFMA_H(ah[kb], wc1, acc1);
-        wc0 = wn0; wc1 = wn1; wc2 = wn2; wc3 = wn3;
+        for (int kb = 0; kb < MAXKB; ++kb)
+          if (kc + kb < KB)
+            gx_split8(*reinterpret_cast<const f32x4 *>(ap + 32 * (kc + kb)), *reinterpret_cast<const f32x4 *>(ap + 32 * (kc + kb) + 4), ah[kb], al[kb]);
+        rt_have = rt;
       }
+#pragma unroll
+      for (int kb = 0; kb < MAXKB; ++kb)
+        if (kc + kb < KB) {
+          // the next block of the stream: this unit's next one, or block 0 of the next unit's column group
+          const bool last = kc + kb + 1 == KB;
+          if (!last || more) {
+            const gx_u4 *wq = wl + ((size_t)(last ? cgn : cg) * KB + (last ? 0 : kc + kb + 1)) * 256;
+            wn0 = wq[0]; wn1 = wq[1]; wn2 = wq[2]; wn3 = wq[3];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          acc0 = GX_MFMA_H(al[kb], wc0, acc0); acc1 = GX_MFMA_H(al[kb], wc1, acc1);      // the small cross terms first
+          acc0 = GX_MFMA_H(ah[kb], wc2, acc0); acc1 = GX_MFMA_H(ah[kb], wc3, acc1);
+          acc0 = GX_MFMA_H(ah[kb], wc0, acc0); acc1 = GX_MFMA_H(ah[kb], wc1, acc1);
+          wc0 = wn0; wc1 = wn1; wc2 = wn2; wc3 = wn3;
+        }
+    }
     epi(rt, n0, acc0, acc1);
     if (more) gx_epi_rotate(epi, 0);
     bb = bn;
