@@ -132,12 +132,34 @@ __device__ __forceinline__ void gx_dense_ld(const float *__restrict__ W, int ldw
   gx_epi_rotate(epi, 0);
   for (;;) {
     f32x4 acc0 = {bb[0], bb[0], bb[0], bb[0]}, acc1 = {bb[1], bb[1], bb[1], bb[1]};
-    for (int k0 = 16; k0 < K; k0 += 16) {
+    // (two K blocks per trip with the two operand sets exchanging roles by NAME: the rotation a = an, b = c of a one-block body is ten
+    // register moves per block that also need the requested data inside the issuing iteration)
+    int k0 = 16;
+    for (; k0 + 16 < K; k0 += 32) {
       f32x2 c0, c1, c2, c3;
       const f32x4 an = *reinterpret_cast<const f32x4 *>(ap + k0);
       if constexpr (FRAG) { o0 += 2048u; fld(o0, c0, c1, c2, c3); }
       else { o0 += wstep; o1 += wstep; o2 += wstep; o3 += wstep; c0 = wld(o0); c1 = wld(o1); c2 = wld(o2); c3 = wld(o3); }
       __builtin_amdgcn_sched_barrier(0);      // keep the requests above the MFMAs of the previous block (hipcc sinks loads to their first use)
+      acc0 = BGM_MFMA(a[0], b0[0], acc0); acc1 = BGM_MFMA(a[0], b0[1], acc1);
+      acc0 = BGM_MFMA(a[1], b1[0], acc0); acc1 = BGM_MFMA(a[1], b1[1], acc1);
+      acc0 = BGM_MFMA(a[2], b2[0], acc0); acc1 = BGM_MFMA(a[2], b2[1], acc1);
+      acc0 = BGM_MFMA(a[3], b3[0], acc0); acc1 = BGM_MFMA(a[3], b3[1], acc1);
+      a = *reinterpret_cast<const f32x4 *>(ap + k0 + 16);
+      if constexpr (FRAG) { o0 += 2048u; fld(o0, b0, b1, b2, b3); }
+      else { o0 += wstep; o1 += wstep; o2 += wstep; o3 += wstep; b0 = wld(o0); b1 = wld(o1); b2 = wld(o2); b3 = wld(o3); }
+      __builtin_amdgcn_sched_barrier(0);
+      acc0 = BGM_MFMA(an[0], c0[0], acc0); acc1 = BGM_MFMA(an[0], c0[1], acc1);
+      acc0 = BGM_MFMA(an[1], c1[0], acc0); acc1 = BGM_MFMA(an[1], c1[1], acc1);
+      acc0 = BGM_MFMA(an[2], c2[0], acc0); acc1 = BGM_MFMA(an[2], c2[1], acc1);
+      acc0 = BGM_MFMA(an[3], c3[0], acc0); acc1 = BGM_MFMA(an[3], c3[1], acc1);
+    }
+    if (k0 < K) {                              // an odd block left
+      f32x2 c0, c1, c2, c3;
+      const f32x4 an = *reinterpret_cast<const f32x4 *>(ap + k0);
+      if constexpr (FRAG) { o0 += 2048u; fld(o0, c0, c1, c2, c3); }
+      else { o0 += wstep; o1 += wstep; o2 += wstep; o3 += wstep; c0 = wld(o0); c1 = wld(o1); c2 = wld(o2); c3 = wld(o3); }
+      __builtin_amdgcn_sched_barrier(0);
       acc0 = BGM_MFMA(a[0], b0[0], acc0); acc1 = BGM_MFMA(a[0], b0[1], acc1);
       acc0 = BGM_MFMA(a[1], b1[0], acc0); acc1 = BGM_MFMA(a[1], b1[1], acc1);
       acc0 = BGM_MFMA(a[2], b2[0], acc0); acc1 = BGM_MFMA(a[2], b2[1], acc1);
