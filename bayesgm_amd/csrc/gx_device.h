@@ -266,22 +266,34 @@ __device__ __forceinline__ void gx_dense_x3(const unsigned *__restrict__ WX, int
             gx_split8(*reinterpret_cast<const f32x4 *>(ap + 32 * (kc + kb)), *reinterpret_cast<const f32x4 *>(ap + 32 * (kc + kb) + 4), ah[kb], al[kb]);
         rt_have = rt;
       }
+      // the two weight sets exchange roles by NAME from block to block (even blocks multiply out of wc and request into wn, odd ones the
+      // other way round): a rotation wc = wn is eight 64-bit moves per block that need the requested data at once -- no block in flight
+      auto next_into = [&](int kabs, gx_u4 &d0, gx_u4 &d1, gx_u4 &d2, gx_u4 &d3) {      // the stream's block behind (this unit, kabs)
+        const bool last = kabs + 1 == KB;
+        if (!last || more) {
+          const gx_u4 *wq = wl + ((size_t)(last ? cgn : cg) * KB + (last ? 0 : kabs + 1)) * 256;
+          d0 = wq[0]; d1 = wq[1]; d2 = wq[2]; d3 = wq[3];
+        }
+      };
 #pragma unroll
-      for (int kb = 0; kb < MAXKB; ++kb)
+      for (int kb = 0; kb < MAXKB; kb += 2) {
         if (kc + kb < KB) {
-          // the next block of the stream: this unit's next one, or block 0 of the next unit's column group
-          const bool last = kc + kb + 1 == KB;
-          if (!last || more) {
-            const gx_u4 *wq = wl + ((size_t)(last ? cgn : cg) * KB + (last ? 0 : kc + kb + 1)) * 256;
-            wn0 = wq[0]; wn1 = wq[1]; wn2 = wq[2]; wn3 = wq[3];
-          }
+          next_into(kc + kb, wn0, wn1, wn2, wn3);
           __builtin_amdgcn_sched_barrier(0);
           acc0 = GX_MFMA_H(al[kb], wc0, acc0); acc1 = GX_MFMA_H(al[kb], wc1, acc1);      // the small cross terms first
           acc0 = GX_MFMA_H(ah[kb], wc2, acc0); acc1 = GX_MFMA_H(ah[kb], wc3, acc1);
           acc0 = GX_MFMA_H(ah[kb], wc0, acc0); acc1 = GX_MFMA_H(ah[kb], wc1, acc1);
-          wc0 = wn0; wc1 = wn1; wc2 = wn2; wc3 = wn3;
         }
+        if (kb + 1 < MAXKB && kc + kb + 1 < KB) {
+          next_into(kc + kb + 1, wc0, wc1, wc2, wc3);
+          __builtin_amdgcn_sched_barrier(0);
+          acc0 = GX_MFMA_H(al[kb + 1], wn0, acc0); acc1 = GX_MFMA_H(al[kb + 1], wn1, acc1);
+          acc0 = GX_MFMA_H(ah[kb + 1], wn2, acc0); acc1 = GX_MFMA_H(ah[kb + 1], wn3, acc1);
+          acc0 = GX_MFMA_H(ah[kb + 1], wn0, acc0); acc1 = GX_MFMA_H(ah[kb + 1], wn1, acc1);
+        }
+      }
     }
+    if (KB & 1) { wc0 = wn0; wc1 = wn1; wc2 = wn2; wc3 = wn3; }      // an odd number of blocks: the next unit's first block sits in the other set
     epi(rt, n0, acc0, acc1);
     if (more) gx_epi_rotate(epi, 0);
     bb = bn;
