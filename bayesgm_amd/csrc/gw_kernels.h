@@ -72,11 +72,12 @@ __device__ __forceinline__ typename GwPreOf<X3>::T gw_pre(const GxCausalModel &m
 template <int X3 = 0>
 __device__ __forceinline__ float *gw_hidden(const GxCausalModel &m, const GxNet &net, int l_begin, int l_end, float *cur, float *oth, int ld,
                                             typename GwPreOf<X3>::T &pre, int nrt) {
+  const int soff = gx_store_off(ld);
   for (int l = l_begin; l < l_end; ++l) {
     typename GwPreOf<X3>::T nx;
     nx.valid = 0;
     if (l + 1 < net.L) nx = gw_pre<X3>(m, net, l + 1, nrt);
-    gw_layer<X3>(m, net, l, cur, ld, GxStore<true>{oth, ld, nullptr}, nrt, pre);
+    gw_layer<X3>(m, net, l, cur, ld, GxStore<true>{oth, ld, nullptr, soff}, nrt, pre);
     pre = nx;
     float *t = cur; cur = oth; oth = t;
   }
@@ -140,7 +141,7 @@ __device__ __forceinline__ const float *gw_f_rows(const GxCausalModel &m, const 
   }
   float *cur = gw_hidden<X3>(m, m.f, 0, m.f.L - 1, L.bufA, L.bufB, ld, pre, nd);
   float *oth = (cur == L.bufA) ? L.bufB : L.bufA;
-  gw_layer<X3>(m, m.f, m.f.L - 1, cur, ld, GxStore<false>{oth, ld, nullptr}, nd, pre);
+  gw_layer<X3>(m, m.f, m.f.L - 1, cur, ld, GxStore<false>{oth, ld, nullptr, gx_store_off(ld)}, nd, pre);
   return oth;
 }
 // the wave's 16 chains at treatment values xin(row, dose), nd <= m.db doses stacked as row tiles (row 16 d + r)
@@ -192,7 +193,7 @@ __device__ __forceinline__ float gw_causal_logp(const GxCausalModel &m, const Gw
     }
     float *cur = gw_hidden<X3>(m, m.h, 0, m.h.L - 1, L.bufA, L.bufB, ld, ph, 1);
     float *oth = (cur == L.bufA) ? L.bufB : L.bufA;
-    gw_layer<X3>(m, m.h, m.h.L - 1, cur, ld, GxStore<false>{oth, ld, nullptr}, 1, ph);
+    gw_layer<X3>(m, m.h, m.h.L - 1, cur, ld, GxStore<false>{oth, ld, nullptr, gx_store_off(ld)}, 1, ph);
     if (lane < GW_ROWS) { mu_x = oth[lane * ld]; raw_x = oth[lane * ld + 1]; }
   }
   // ---- assemble -(loss_v + loss_x + loss_y + prior)   (base.py:800-816), lane r = row r

@@ -310,18 +310,23 @@ __device__ __forceinline__ void gx_dense(const float *__restrict__ W, int K, int
 // Epilogue helpers -------------------------------------------------------------------------------------------------------------
 // y = act(acc + b) -> Y (LDS [32][ldy]); LEAKY: LeakyReLU(0.2), else linear
 // (bias == NULL: the engine started the accumulators from the bias)
+// the lane's own part of a store address, (4 g) ldy + 2 j: formed once per layer walk by the row-tile-per-wave kernels (GxStore::off; the
+// opaque lane copy otherwise makes every epilogue call re-derive it -- two quarter-rate integer multiplies per unit)
+__device__ __forceinline__ int gx_store_off(int ldy) { const int lane = gx_lane(); return (4 * (lane >> 4)) * ldy + 2 * (lane & 15); }
 template <bool LEAKY>
 struct GxStore {
   float *Y; int ldy; const float *bias;
+  int off = -1;               // gx_store_off(ldy), or -1: derive it per call
   __device__ __forceinline__ void operator()(int rt, int n0, const f32x4 &a0, const f32x4 &a1) const {
-    const int lane = gx_lane(), j = lane & 15, g = lane >> 4;
+    const int lane = gx_lane(), j = lane & 15;
     const f32x2 bb = bias ? *reinterpret_cast<const f32x2 *>(bias + n0 + 2 * j) : f32x2{0.0f, 0.0f};
+    float *yp = Y + (off >= 0 ? off : gx_store_off(ldy)) + (16 * rt) * ldy + n0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float y0 = bias ? a0[r] + bb[0] : a0[r], y1 = bias ? a1[r] + bb[1] : a1[r];      // (x + 0.0f is not folded: -0.0f)
       if (LEAKY) { y0 = lrelu(y0); y1 = lrelu(y1); }
       f32x2 o = {y0, y1};
-      *reinterpret_cast<f32x2 *>(Y + (size_t)(16 * rt + 4 * g + r) * ldy + n0 + 2 * j) = o;
+      *reinterpret_cast<f32x2 *>(yp + r * ldy) = o;
     }
   }
 };
