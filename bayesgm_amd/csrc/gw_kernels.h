@@ -89,13 +89,21 @@ __device__ __forceinline__ float *gw_hidden(const GxCausalModel &m, const GxNet 
 struct GwGLastEpi {
   const float *v; long long row0, n; int p; float *sraw; float *acc;
   float vc[4][2], vn[4][2];
+  const float *vb;            // the tile's first data row (uniform)
+  unsigned vo[4];             // the lane's four rows' offsets from it (floats; rows past the panel's end clamped to its last row): formed once
+  __device__ __forceinline__ void init() {
+    const int lane = gx_lane(), g = lane >> 4;
+    vb = v + row0 * (long long)p;
+    const int last = (int)min((long long)(GW_ROWS - 1), n - 1 - row0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) vo[r] = (unsigned)min(4 * g + r, last) * (unsigned)p;
+  }
   __device__ __forceinline__ void pre(int, int n0) {
-    const int lane = gx_lane(), j = lane & 15, g = lane >> 4;
+    const int lane = gx_lane(), j = lane & 15;
     const int c0 = n0 + 2 * j;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      long long gr = row0 + 4 * g + r; gr = gr < n ? gr : n - 1;
-      const float *vr = v + gr * (long long)p;
+      const float *vr = vb + vo[r];
       // unconditional requests at clamped columns (a request under a lane condition is an exec-mask branch around it, eight per unit);
       // the epilogue masks the columns >= p.  p even: the lane's two columns are one aligned 8-byte request
       if ((p & 1) == 0) {
@@ -168,6 +176,7 @@ __device__ __forceinline__ float gw_causal_logp(const GxCausalModel &m, const Gw
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     GwGLastEpi ge;
     ge.v = v; ge.row0 = row0; ge.n = n; ge.p = m.p; ge.sraw = L.sraw; ge.acc = acc;
+    ge.init();
     gw_layer<X3>(m, m.g, m.g.L - 1, cur, ld, ge, 1, pre);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
