@@ -131,7 +131,7 @@ __device__ __forceinline__ void gx_f_rows(const GxCausalModel &m, const GxLds &L
   float *cur = gx_hidden(m.f, m.pack, 0, m.f.L - 1, L.bufA, L.bufB, ld, pre, nrt, nrt);
   float *oth = (cur == L.bufA) ? L.bufB : L.bufA;
   const int l = m.f.L - 1;
-  gx_dense(m.pack + m.f.w[l], m.f.pad[l], m.f.pad[l + 1], cur, ld, GxStore<false>{oth, ld, nullptr}, nrt, m.pack + m.f.b[l], &pre);
+  gx_dense(m.pack + m.f.w[l], m.f.pad[l], m.f.pad[l + 1], cur, ld, GxStore<false>{oth, ld, nullptr, gx_store_off(ld)}, nrt, m.pack + m.f.b[l], &pre);
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * rows; i += GX_THREADS) L.fo[i] = oth[(i >> 1) * ld + (i & 1)];
   __syncthreads();
@@ -178,7 +178,7 @@ __device__ __forceinline__ void gx_causal_logp(const GxCausalModel &m, const GxL
     float *cur = gx_hidden(m.h, m.pack, 0, m.h.L - 1, L.bufA, L.bufB, ld, ph);
     float *oth = (cur == L.bufA) ? L.bufB : L.bufA;
     const int l = m.h.L - 1;
-    gx_dense(m.pack + m.h.w[l], m.h.pad[l], m.h.pad[l + 1], cur, ld, GxStore<false>{oth, ld, nullptr}, 2, m.pack + m.h.b[l], &ph);
+    gx_dense(m.pack + m.h.w[l], m.h.pad[l], m.h.pad[l + 1], cur, ld, GxStore<false>{oth, ld, nullptr, gx_store_off(ld)}, 2, m.pack + m.h.b[l], &ph);
     __syncthreads();
     if (threadIdx.x < 2 * GX_ROWS) L.ho[threadIdx.x] = oth[(threadIdx.x >> 1) * ld + (threadIdx.x & 1)];
     __syncthreads();

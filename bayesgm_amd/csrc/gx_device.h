@@ -386,11 +386,12 @@ struct GxRawStore {
 // before the previous layer's products and arrive under them and the barrier.
 __device__ __forceinline__ float *gx_hidden(const GxNet &net, const float *pack, int l_begin, int l_end, float *cur, float *oth, int ld, GxPre &pre,
                                             int nrt = 2, int nrt_after = 2) {
+  const int soff = gx_store_off(ld);
   for (int l = l_begin; l < l_end; ++l) {
     GxPre nx;
     nx.valid = 0;
     if (l + 1 < net.L) nx = gx_prefetch(pack + net.w[l + 1], net.pad[l + 2], net.pad[l + 2], pack + net.b[l + 1], l + 1 < l_end ? nrt : nrt_after);
-    gx_dense(pack + net.w[l], net.pad[l], net.pad[l + 1], cur, ld, GxStore<true>{oth, ld, nullptr}, nrt, pack + net.b[l], &pre);
+    gx_dense(pack + net.w[l], net.pad[l], net.pad[l + 1], cur, ld, GxStore<true>{oth, ld, nullptr, soff}, nrt, pack + net.b[l], &pre);
     __syncthreads();
     pre = nx;
     float *t = cur; cur = oth; oth = t;
