@@ -62,6 +62,47 @@ def make_panel(n, p, seed, device, lo=0, n_gen=None):
     return (torch.from_numpy(x).to(device), torch.from_numpy(y).to(device), torch.from_numpy(v).to(device))
 
 
+def general_width_leg(p, z_dims, device):
+    """The general-width engine (csrc/gx_api.hip: models whose hidden widths are not the compiled defaults) at two shapes it exists
+    for, glorot weights, 20 burn-in transitions each: `[128, 128]` nets, and the bench's own default widths forced through it
+    (BGM_FORCE_GX) next to the resident kernels' rate -- fp32 and the opt-in split precision ('f16x3', hidden widths <= 128)."""
+    import torch
+    from bayesgm_amd.engine import CausalEngine
+    rs = np.random.RandomState(0)
+
+    def net(dims):
+        return [((rs.uniform(-1, 1, (a, b)) * np.sqrt(6.0 / (a + b))).astype(np.float32), np.zeros(b, np.float32)) for a, b in zip(dims[:-1], dims[1:])]
+    q, (z0, z1, z2, _) = sum(z_dims), z_dims
+    out = {"sample": "CausalEngine.mh_sample, 20 burn-in transitions, p=%d, z_dims %s, glorot weights; TFLOP/s = 2 MACs(g + f + h) per row-transition (algorithmic, also for f16x3: its fraction is a speed relative to the fp32 peak, not a utilisation of the fp16 pipe)" % (p, list(z_dims))}
+    shapes = (("default_widths_forced_through_the_engine", dict(g_units=[64] * 5, e_units=[64] * 5, f_units=[64, 32, 8], h_units=[64, 32, 8]), 1000000, True),
+              ("w128", dict(g_units=[128, 128], e_units=[128, 128], f_units=[128, 128], h_units=[128, 128]), 500000, False))
+    for name, u, n, force in shapes:
+        g = torch.Generator(device=device).manual_seed(0)
+        v = torch.randn(n, p, device=device, generator=g); x = torch.rand(n, device=device, generator=g); y = torch.randn(n, device=device, generator=g)
+        nets = dict(g=net([q] + u["g_units"] + [p + 1]), e=net([p] + u["e_units"] + [q]), f=net([z0 + z1 + 1] + u["f_units"] + [2]),
+                    h=net([z0 + z2] + u["h_units"] + [2]))
+        macs = sum(w.shape[0] * w.shape[1] for k in "gfh" for w, _ in nets[k])
+        rec = {"rows": n, "hidden": {k: u[k] for k in ("g_units", "f_units", "h_units")}}
+        try:
+            if force:
+                os.environ["BGM_FORCE_GX"] = "1"
+            eng = CausalEngine(p, list(z_dims), **u)
+            eng.set_model(**nets)
+            for mode in ("fp32", "f16x3"):
+                eng.set_precision(mode)
+                eng.mh_sample(x, y, v, 2, 0, 1.0, 1)
+                torch.cuda.synchronize(device); t0 = time.time()
+                eng.mh_sample(x, y, v, 20, 0, 1.0, 1)
+                torch.cuda.synchronize(device); dt = (time.time() - t0) / 20
+                rec[mode] = {"ms_per_iteration": 1e3 * dt, "transitions_per_s": n / dt, "tflops_algorithmic": 2 * macs * n / dt / 1e12,
+                             "frac_of_fp32_mfma_peak": 2 * macs * n / dt / 1e12 / 157.3}
+            eng.close()
+        finally:
+            os.environ.pop("BGM_FORCE_GX", None)
+        out[name] = rec
+    return out
+
+
 def cpu_baseline(params, p, z_dims, budget_s=20.0):
     """Reference loop as written, on the host cores (kind = "port")."""
     from oracle import causal as OC
@@ -661,6 +702,7 @@ def main():
     ap.add_argument("--no-bayesian", action="store_true", help="skip the secondary use_bnn=True measurement (N=1 only)")
     ap.add_argument("--no-fit", action="store_true", help="skip the secondary fit-throughput measurement (N=1 only)")
     ap.add_argument("--no-bgm", action="store_true", help="skip the secondary BGM HMC measurement at config C4's shape (N=1 only)")
+    ap.add_argument("--no-general-width", action="store_true", help="skip the secondary measurement of the general-width engine (N=1 only)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --rows per GPU (default); strong: --rows in TOTAL, sharded over the GPUs (BASELINE configs[3]: N=1e6 over 8 GPUs)")
     ap.add_argument("--no-bf16x3", action="store_true", help="skip the secondary split-precision (bf16 x 3) measurement (N=1 only)")
@@ -896,6 +938,8 @@ def main():
             out["bayesian_nets"] = bayesian_leg(params, data, x_values, n_loc, args, device)
         if not args.no_bgm and world == 1:
             out["bgm_hmc"] = bgm_hmc_leg(device)
+        if not args.no_general_width and world == 1:
+            out["general_width_engine"] = general_width_leg(p, z_dims, device)
         if not args.no_fit and world == 1:
             out["fit"] = fit_leg(model, x, y, v, n_loc)
             out["training_steps"] = training_leg(params, x, y, v, device)
