@@ -88,6 +88,10 @@ def test_conditional_prior_on_the_general_width_engine(shape, z_dims, p, binary)
     lp = eng.logpost(x.ravel(), y.ravel(), v, z).cpu().numpy()
     ref = OC.log_posterior(m64, x64, y64, v64, z64, prior=(mu, s2))
     assert np.all(np.abs(lp - ref) <= 2e-6 * np.abs(ref) + 5e-4), np.abs(lp - ref).max()
+    eng.set_precision("f16x3")                                # the split-precision kernels of the engine carry the prior too (fp32 assembly)
+    lpx = eng.logpost(x.ravel(), y.ravel(), v, z).cpu().numpy()
+    eng.set_precision("fp32")
+    assert np.all(np.abs(lpx - ref) <= 1e-5 * np.abs(ref) + 1e-3), np.abs(lpx - ref).max()
     std = OC.log_posterior(m64, x64, y64, v64, z64)
     assert np.abs(ref - std).max() > 0.1                      # the prior matters in this test
     out = eng.mh_sample(x, y, v, 30, 10, 0.4, 77, want_draws=True)
