@@ -128,10 +128,14 @@ class BnnEngine(object):
         if getattr(self, "_stepped", False):
             raise ValueError("bayesgm_amd: batch_size %d exceeds the session's max_batch %d and optimizer steps have been taken; "
                              "create the model with params['max_batch'] >= %d" % (rows, self.cfg.max_batch, rows))
-        theta = self.read(0) if self.open else None
+        # (no step taken in this session, but a checkpoint may have restored the Adam slots: they travel with the parameters)
+        state = [self.read(w) for w in (0, 2, 3)] if self.open else None
         self.cfg.max_batch = rows
-        if theta is not None:
-            self.begin(theta)
+        if state is not None:
+            self.begin(state[0])
+            if np.any(state[1]) or np.any(state[2]):
+                self.write(state[1], 2)
+                self.write(state[2], 3)
 
     def read(self, what=0):
         out = np.empty(self.n_params, np.float32)

@@ -72,7 +72,8 @@ struct bgm_handle {
   float *ev_z = nullptr; unsigned *ev_meta = nullptr; int *ev_tile = nullptr, *ev_slot_cnt = nullptr; float *ev_out = nullptr, *ev_carry = nullptr;
   size_t ev_z_cap = 0, ev_meta_cap = 0, ev_tile_cap = 0, ev_slot_cap = 0, ev_out_cap = 0, ev_carry_cap = 0;
   int ev_carry_flip = 0;
-  long long ev_budget_bytes = 0;                  // bgm_causal_set_event_budget (0: BGM_EVENT_BUDGET_MB or 8 GiB)
+  long long ev_budget_bytes = 0;                  // bgm_causal_set_event_budget (0: BGM_EVENT_BUDGET_MB, else min(8 GiB, half of the free device memory))
+  int ev_fallbacks = 0;                           // retained phases that ran on the per-wave cache because no segment fitted the budget / the device
   bool bx_valid = false;
   alignas(8) unsigned char bx_meta_store[192];
   // per-row conditional latent prior of the sampling kernels (causal_prior_api.hip, bgm_causal_set_prior); NULL = standard normal

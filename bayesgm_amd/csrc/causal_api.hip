@@ -430,11 +430,18 @@ extern "C" int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *a, void *stre
   const int n_slots = grid * MH_WAVES;
   // the retained iterations: the fused sampler + outcome-net kernel, or (outcome cache mode 2, causal_event_api.hip) segments of
   // transitions that append events, each followed by the outcome net on dense event tiles and the spread over the segment's draws
-  const bool ev_form = it_end > split && bgm_causal_event_wanted(h, a->effect, a->n_doses);
+  bool ev_form = it_end > split && bgm_causal_event_wanted(h, a->effect, a->n_doses);
+  int S = 0;
+  long long cap = 0;
+  if (ev_form && (rc = bgm_causal_event_plan(h, a->n, n_slots, a->n_doses, it_end - split, &S, &cap))) {
+    if (rc < 0) return rc;
+    // the event buffers do not fit the budget / the device (rc > 0): release what was reserved and run the retained phase on the
+    // fused kernel with the per-wave cache (mode 1) -- same sums to the last bit, no failure where predict ran before
+    bgm_causal_event_free(h);
+    ev_form = false;
+    ++h->ev_fallbacks;
+  }
   if (ev_form) {
-    int S = 0;
-    long long cap = 0;
-    if ((rc = bgm_causal_event_plan(h, a->n, n_slots, a->n_doses, it_end - split, &S, &cap))) return rc;
     ka.ev_cap = cap;
     for (int b = split; b < it_end; b += S)
       segs.push_back({b, std::min(S, it_end - b), a->effect, (segs.empty() && b == split) ? a->init : 0, b == split ? 1 : 2});

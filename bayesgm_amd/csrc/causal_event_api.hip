@@ -31,15 +31,21 @@ static int ev_reserve(T *&ptr, size_t &cap, size_t need) {
   if (cap >= need) return BGM_OK;
   if (ptr) BGM_HIP_CHECK(hipFree(ptr));
   ptr = nullptr; cap = 0;
-  BGM_HIP_CHECK(hipMalloc((void **)&ptr, need * sizeof(T)));
+  if (hipMalloc((void **)&ptr, need * sizeof(T)) != hipSuccess) {      // out of memory: the caller falls back to the per-wave cache
+    (void)hipGetLastError();
+    ptr = nullptr;
+    return 1;
+  }
   cap = need;
   return BGM_OK;
 }
 
 // Segment length: a slot's region must hold the worst case (every chain of every one of its tiles moves at every iteration), so a
 // segment of S iterations needs  n_slots * tiles_per_slot * 16 * S  events of  4 q + 4 + 32 n_calls  bytes; S is the largest length
-// that fits the budget (bgm_causal_set_event_budget, else BGM_EVENT_BUDGET_MB, else 8 GiB), at least 8.  Typical use touches a
-// fraction `acceptance rate` of it.
+// that fits the budget (bgm_causal_set_event_budget, else BGM_EVENT_BUDGET_MB, else 8 GiB and never more than half of the device
+// memory that is free right now), down to S = 1.  Typical use touches a fraction `acceptance rate` of it.
+// Returns BGM_OK, a negative error, or +1: the buffers of even a one-iteration segment do not fit the budget / the device
+// (the caller then runs the retained phase on the fused kernel with the per-wave cache, mode 1).
 int bgm_causal_event_plan(bgm_handle *h, long long n, int n_slots, int n_doses, int n_iters, int *seg_len, long long *ev_cap) {
   const long long n_tiles = (n + 15) / 16, tps = (n_tiles + n_slots - 1) / n_slots;
   const int n_calls = (n_doses + 3) / 4;
@@ -47,9 +53,20 @@ int bgm_causal_event_plan(bgm_handle *h, long long n, int n_slots, int n_doses, 
   if (budget <= 0) {
     const char *e = std::getenv("BGM_EVENT_BUDGET_MB");
     budget = (e ? std::max(1ll, std::atoll(e)) : 8192ll) << 20;
+    if (!e) {      // the default never asks for more than half of what the device has free (buffers already held count as free)
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const size_t held = (h->ev_z_cap * (size_t)1 + h->ev_meta_cap + h->ev_out_cap) * 4;
+        budget = std::min<long long>(budget, (long long)((free_b + held) / 2));
+      } else (void)hipGetLastError();
+    }
   }
+  // bytes per retained iteration of a segment: state + meta word + (mean, sd) pairs of every event
   const long long per_iter = (long long)n_slots * tps * 16 * (4ll * h->q + 4 + 32ll * n_calls);
-  long long S = std::max(8ll, budget / std::max(1ll, per_iter));
+  // what does not scale with S: the carried pairs (two buffers) and the tile table
+  const long long fixed = 2ll * n_tiles * n_calls * 64 * 2 * 4 + n_tiles * 2 * 4 + (long long)n_slots * 4;
+  long long S = (budget - fixed) / std::max(1ll, per_iter);
+  if (S < 1) return 1;
   S = std::min<long long>(S, n_iters);
   S = std::min<long long>(S, (1ll << 27) / std::max(1ll, tps * 16));      // event indices of a slot stay far inside 32 bits
   S = std::min<long long>(S, std::max(1, EV_SPREAD_LDS_FLOATS / std::max(1, n_doses)));      // the spread pass keeps [S][n_doses] sums in LDS

@@ -359,15 +359,25 @@ class CausalEngine(object):
     def egm_end(self):
         _lib.check(self.lib.bgm_causal_egm_end(self.h, self._stream()), "bgm_causal_egm_end")
 
-    OUTCOME_CACHE_MODES = {False: 0, "off": 0, 0: 0, "wave": 1, 1: 1, True: 2, "chain": 2, 2: 2}
+    OUTCOME_CACHE_NAMES = {"off": 0, "wave": 1, "chain": 2}
+
+    @classmethod
+    def outcome_cache_mode(cls, on):
+        """bool (False = off, True = per chain), a name ('off' / 'wave' / 'chain') or the C ABI's number (0 / 1 / 2, bgm_hip.h) -> mode.
+        (bools are resolved first: True == 1 in Python, but True means 'the default cache' = mode 2, the integer 1 means mode 1.)"""
+        if isinstance(on, (bool, np.bool_)):
+            return 2 if on else 0
+        if isinstance(on, str) and on in cls.OUTCOME_CACHE_NAMES:
+            return cls.OUTCOME_CACHE_NAMES[on]
+        if isinstance(on, (int, np.integer)) and int(on) in (0, 1, 2):
+            return int(on)
+        raise ValueError("outcome cache mode must be False / 'off' / 0, 'wave' / 1 or True / 'chain' / 2; got %r" % (on,))
 
     def set_outcome_cache(self, on=True):
         """Retained phase of the effect samplers: False / 'off' = the outcome net at every retained draw (the reference); 'wave' = reuse
         the (mean, sd) of a 16-chain tile none of whose chains moved; True / 'chain' (default) = per chain, through the event form of the
         retained phase where it exists (csrc/causal_event_kernels.h), else 'wave'.  Bit-identical sums in every mode."""
-        if on not in self.OUTCOME_CACHE_MODES:
-            raise ValueError("outcome cache mode must be False / 'off', 'wave' or True / 'chain'; got %r" % (on,))
-        _lib.check(self.lib.bgm_causal_set_outcome_cache(self.h, self.OUTCOME_CACHE_MODES[on]), "bgm_causal_set_outcome_cache")
+        _lib.check(self.lib.bgm_causal_set_outcome_cache(self.h, self.outcome_cache_mode(on)), "bgm_causal_set_outcome_cache")
 
     def set_event_budget(self, n_bytes):
         """Upper bound on the event buffers of one segment of the retained phase in its event form (0: BGM_EVENT_BUDGET_MB or 8 GiB)."""

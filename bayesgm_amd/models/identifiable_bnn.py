@@ -115,6 +115,10 @@ class IdentifiableCausalBGMBayes(CausalBGMBayes):
         if verbose:
             print(f"Generating auxiliary variable U for {k} segments.")
         self.segments = np.random.randint(0, k, size=n_total)                                               # :283
+        if world > 1:       # one draw for the job: rank 0's (every rank trains on, and rank 0 checkpoints, the same U)
+            seg_all = torch.from_numpy(self.segments.astype(np.int32)).to(dev)
+            parallel.broadcast_(seg_all, 0)
+            self.segments = seg_all.cpu().numpy().astype(np.int64)
         seg_dev = torch.from_numpy(self.segments[lo_r:hi_r].astype(np.int32)).to(dev)
         if self._p['save_res'] and parallel.rank() == 0:
             with open('{}/params.txt'.format(self.save_dir), 'w') as f_params:
@@ -124,6 +128,7 @@ class IdentifiableCausalBGMBayes(CausalBGMBayes):
         x = self._dev(data_x[lo_r:hi_r]).reshape(-1)
         y = self._dev(data_y[lo_r:hi_r]).reshape(-1)
         v = self._dev(data_v[lo_r:hi_r])
+        eng.ensure_max_batch(b_loc)          # (any batch_size, also without the warm start that would have sized the session)
         seed = self._noise_seed(per_rank=True)
         seed_shared = self._noise_seed(per_rank=False)      # the prior net's perturbation is ONE per global minibatch (Flipout), as in the EGM steps
         if use_egm_init:
@@ -179,10 +184,10 @@ class IdentifiableCausalBGMBayes(CausalBGMBayes):
                 acc[0] += out_z[0]; acc[1:] += out_p
                 n_steps += 1
             a = acc.cpu().numpy() / max(1, n_steps)
-            if world > 1:       # the prior outputs are this rank's shares of the global batch means
-                t_ = torch.tensor([a[1], a[2]], device=dev, dtype=torch.float64)
+            if world > 1:       # a[0] (inv_B = 1 / batch_global) and the prior outputs are this rank's shares of the global batch means
+                t_ = torch.tensor([a[0], a[1], a[2]], device=dev, dtype=torch.float64)
                 parallel.all_reduce_sum_(t_)
-                a[1], a[2] = float(t_[0]), float(t_[1])
+                a[0], a[1], a[2] = float(t_[0]), float(t_[1]), float(t_[2])
             post = float(a[0] - a[2] + a[1] + self._prior_klw * a[3])          # exchange the prior term, add the prior net's KL (:213-215)
             lt = out_t.cpu().numpy()
             self.fit_history.append(dict(epoch=epoch, loss_v=float(lt[0]), loss_mse_v=float(lt[1]), loss_x=float(lt[2]), loss_mse_x=float(lt[3]),

@@ -356,8 +356,10 @@ def bayesian_leg(params, data, x_values, n_loc, args, device):
     precision of the sampling kernels (params['mh_precision'] = 'f16x3', csrc/bnx_kernels.h: object `f16x3`)."""
     import torch
     from bayesgm_amd.models import CausalBGM
-    burn, keep, bs = max(1, args.burn_in // 10), max(1, args.n_mcmc // 10), 10000
+    div = max(1, int(args.bayesian_divisor))
+    burn, keep, bs = max(1, args.burn_in // div), max(1, args.n_mcmc // div), 10000
     flop_row = 2 * 2 * 2 * 34848 if (args.p == 200) else None      # two states x two GEMMs per Flipout layer x 2 FLOP/MAC
+    flop_eff_row = len(x_values) * 2 * 2 * 2512                    # per kept iteration: 20 doses x two products x 2 FLOP/MAC x MACs(f)
 
     def one(mode):
         m = CausalBGM(dict(params, use_bnn=True, mh_precision=mode), timestamp="bench_bnn", random_seed=0, device=device.index)
@@ -382,7 +384,7 @@ def bayesian_leg(params, data, x_values, n_loc, args, device):
         x_, y_ = x_.reshape(-1).float().contiguous(), y_.reshape(-1).float().contiguous()
         v_ = v_.float().contiguous()
         state = torch.empty((n_loc, eng.q), device=eng.device)
-        its = 20
+        its = 40
         eng.mh_run(x_, y_, v_, state, bs, 0, 2, 0, 1.0, 1, init=True)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         adrf_s = torch.zeros((len(x_values), its), device=eng.device, dtype=torch.float64)
@@ -396,7 +398,24 @@ def bayesian_leg(params, data, x_values, n_loc, args, device):
         out["burn_in_iteration_ms"], out["kept_iteration_ms"] = t_mh, t_keep
         if flop_row:
             out["sampler_frac_of_fp32_mfma_peak"] = flop_row * n_loc / (t_mh * 1e-3) / (PEAK_FP32_MFMA_TFLOPS * 1e12)
-            out["effects_frac_of_fp32_mfma_peak"] = len(x_values) * 2 * 2 * 2512 * n_loc / (max(t_keep - t_mh, 1e-9) * 1e-3) / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+            out["effects_frac_of_fp32_mfma_peak"] = flop_eff_row * n_loc / (max(t_keep - t_mh, 1e-9) * 1e-3) / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+            # the roofline of THIS model class: the two launch groups of an iteration as instances, HIP-event time
+            # on the library's stream over `its` iterations of the whole panel, algorithmic FLOP as above
+            t_eff = max(t_keep - t_mh, 1e-9)
+            share_mh = t_mh * (burn + keep) / (t_mh * (burn + keep) + t_eff * keep)
+            inst = [{"kernel": "bnf_mh_kernel + perturbation / sign kernels (one MH iteration of every row: two fresh log posteriors on Flipout nets)",
+                     "avg_iteration_ms": t_mh, "iterations_timed": its, "flop_per_row_iteration": flop_row, "flop_per_iteration": flop_row * n_loc,
+                     "achieved": flop_row * n_loc / (t_mh * 1e-3) / 1e12, "frac": out["sampler_frac_of_fp32_mfma_peak"],
+                     "share_of_predict_kernel_time": share_mh},
+                    {"kernel": "bnf_effects_kernel (a kept iteration's %d fresh-noise outcome-net calls)" % len(x_values),
+                     "avg_iteration_ms": t_eff, "iterations_timed": its, "flop_per_row_iteration": flop_eff_row, "flop_per_iteration": flop_eff_row * n_loc,
+                     "achieved": flop_eff_row * n_loc / (t_eff * 1e-3) / 1e12, "frac": out["effects_frac_of_fp32_mfma_peak"],
+                     "share_of_predict_kernel_time": 1.0 - share_mh}]
+            dom = inst[0] if share_mh >= 0.5 else inst[1]
+            out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": dom["frac"], "instances": inst, "traffic": None,
+                               "whole_predict_achieved": (flop_row * (burn + keep) + flop_eff_row * keep) * n_loc / dt / 1e12,
+                               "note": "algorithmic FLOP (for f16x3: fp32-peak equivalents delivered by the fp16 pipe, not a utilisation)"}
         del m
         torch.cuda.empty_cache()
         return out
@@ -409,6 +428,109 @@ def bayesian_leg(params, data, x_values, n_loc, args, device):
     x3["adrf_max_abs_diff_vs_fp32"] = float(np.max(np.abs(np.asarray(x3["adrf_head"]) - np.asarray(out["adrf_head"]))))
     out["f16x3"] = x3
     return out
+
+
+def encoder_leg(model, v, n_loc, p, z_dims, check_against_oracle, reps=20):
+    """north_star's encoder target (">= 40 % MFMA roofline on the encoder GEMM at 1 GPU"): z = e(V) over the whole bench panel
+    (causalbgm/base.py:479, the latent initialisation of fit) on causal_encode_kernel -- six fused layers, V read once.  fp32 MFMA
+    bound (74.6 FLOP per byte of V >> the machine balance); the HBM side is reported next to it."""
+    import torch
+    eng = model.engine
+    q = sum(z_dims)
+    z = eng.encode(v)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        z = eng.encode(v)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    macs = p * 64 + 4 * 64 * 64 + 64 * q
+    flop = 2.0 * macs * n_loc
+    out = {"kernel": "causal_encode_kernel (e_net over the panel: %d -> 64 x 5 -> %d, fused, V read once)" % (p, q), "rows": n_loc,
+           "ms_per_pass": ms, "passes_timed": reps, "rows_per_s": n_loc / (ms * 1e-3), "flop_per_row": 2.0 * macs,
+           "bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+           "frac": flop / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "target_frac": 0.40,
+           "algorithmic_bytes_per_row": 4 * p + 4 * q, "hbm_GBps": n_loc * (4 * p + 4 * q) / (ms * 1e-3) / 1e9,
+           "frac_of_hbm_peak": n_loc * (4 * p + 4 * q) / (ms * 1e-3) / 8e12}
+    if check_against_oracle:       # (the checker, with the cpu_baseline / parity legs only)
+        from oracle.nets import mlp_forward
+        e64 = [(np.asarray(W, np.float64), np.asarray(b, np.float64)) for W, b in model.nets["e"]]
+        ref = mlp_forward(e64, v[:512].cpu().numpy().astype(np.float64))
+        out["max_abs_err_vs_oracle_512_rows"] = float(np.abs(z[:512].cpu().numpy() - ref).max())
+    return out
+
+
+def config_c1_leg(device, n=100000, p=100, burn_in=5000, n_mcmc=3000):
+    """BASELINE configs[1]: CausalBGM binary treatment, N = 1e5, p = 100, z_dims [3,3,6,6] (cli defaults), fp32, one GPU:
+    predict = MH chains + per-row ITE draws + posterior mean and (alpha/2, 1-alpha/2) quantiles per row
+    (causalbgm/base.py:573-668, 686-733), product defaults (outcome cache on); glorot weights, Hirano-Imbens covariates with the
+    treatment binarised at its median (the reference has no binary simulator: SURVEY 8d)."""
+    import torch
+    from bayesgm_amd.models import CausalBGM
+    from bayesgm_amd.datasets import Sim_Hirano_Imbens_sampler, binarize_treatment
+    x, y, v = Sim_Hirano_Imbens_sampler(N=n, v_dim=p, seed=0).load_all()
+    xb = binarize_treatment(x)
+    z_dims = [3, 3, 6, 6]
+    params = dict(dataset="bench_c1", output_dir=".", save_res=False, save_model=False, binary_treatment=True, use_bnn=False,
+                  z_dims=z_dims, v_dim=p, lr_theta=1e-4, lr_z=1e-4, g_units=[64] * 5, f_units=[64, 32, 8], h_units=[64, 32, 8],
+                  e_units=[64] * 5, dz_units=[64, 32, 8], kl_weight=1e-4, lr=2e-4, g_d_freq=5, use_z_rec=True)
+    m = CausalBGM(params, timestamp="bench_c1", random_seed=0, device=device.index)
+    data = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in (xb, y, v))
+    m.predict(data, alpha=0.01, n_mcmc=4, burn_in=4, verbose=0)
+    times = {}
+    res = {}
+    for mode in (True, False):      # product default, then the outcome net at every retained draw (the reference's work)
+        m.engine.set_outcome_cache(mode)
+        m.engine.outcome_cache_stats(reset=True)
+        m._seed_counter = 0
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        ite, interval = m.predict(data, alpha=0.01, n_mcmc=n_mcmc, burn_in=burn_in, verbose=0)
+        torch.cuda.synchronize(); times[mode] = time.perf_counter() - t0
+        res[mode] = (np.asarray(ite), np.asarray(interval), m.engine.outcome_cache_stats(reset=True))
+    m.engine.set_outcome_cache(True)
+    macs = (sum(z_dims) * 64 + 4 * 4096 + 64 * (p + 1)) + ((z_dims[0] + z_dims[1] + 1) * 64 + 2048 + 256 + 16) + ((z_dims[0] + z_dims[2]) * 64 + 2048 + 256 + 16)
+    dt = times[True]
+    served, total = res[True][2]
+    return {"workload": f"CausalBGM.predict binary treatment, N={n}, p={p}, z_dims {z_dims}, burn_in={burn_in}, n_mcmc={n_mcmc}, ITE + per-row intervals, product defaults",
+            "predict_seconds": dt, "value": n * (burn_in + n_mcmc) / dt, "unit": "MH transitions/s", "predict_seconds_cache_off": times[False],
+            "tflops_algorithmic_transitions": 2 * macs * n * (burn_in + n_mcmc) / dt / 1e12,
+            "frac_of_fp32_mfma_peak_transitions_only": 2 * macs * n * (burn_in + n_mcmc) / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "acceptance_rate": m.last_acceptance_rate, "ate": float(res[True][0].mean()), "shapes": [list(res[True][0].shape), list(res[True][1].shape)],
+            "outcome_cache_served_fraction": served / max(1, total), "outcome_cache_counted_in": "retained chain-iterations (event form)" if total == n * n_mcmc else "retained tile-iterations (16 chains)",
+            "ite_identical_with_cache_off": bool(np.array_equal(res[True][0], res[False][0]) and np.array_equal(res[True][1], res[False][1]))}
+
+
+def config_c4_share_leg(device, n=625000, p=500, q=10, burn_in=1000, n_mcmc=1000, use_bnn=False):
+    """BASELINE configs[4], one GPU's share: BGM missing-data imputation, N = 5e6 / 8 = 625 000 rows, p = 500, 10 % of the cells
+    missing (MCAR), 1000 burn-in (800 with the shared step-size adaptation) + 1000 retained HMC transitions of 10 leapfrog steps per
+    row, posterior-predictive imputation + per-cell intervals through BGM.predict (bgm/base.py:527-663, 709-830); glorot weights.
+    FLOP: L = 10 gradient evaluations x 4 MACs(g) per row-transition executed (the gradient at the current state is cached, as TFP does)."""
+    import torch
+    from bayesgm_amd.models import BGM
+    bp = dict(dataset="bench_c4", output_dir=".", save_res=False, save_model=False, use_bnn=use_bnn, z_dim=q, x_dim=p,
+              lr_theta=5e-3, lr_z=5e-3, g_units=[64] * 5, e_units=[64] * 5, dz_units=[64, 32, 8], dx_units=[64, 32, 8],
+              kl_weight=5e-5, lr=1e-3, g_d_freq=1, use_z_rec=True, alpha=0.0, gamma=0.0)
+    bm = BGM(bp, timestamp="bench_c4", random_seed=0)
+    g = torch.Generator(device=device).manual_seed(0)
+    data = torch.randn(n, p, device=device, generator=g)
+    data[torch.rand(n, p, device=device, generator=g) < 0.1] = float("nan")
+    n_missing = int(torch.isnan(data).sum().item())
+    data = data.cpu()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    imp, interval = bm.predict(data, n_mcmc=n_mcmc, burn_in=burn_in)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    macs = q * 64 + 4 * 4096 + 2 * 64 * p
+    prod = 2 if use_bnn else 1
+    return {"workload": f"BGM(use_bnn={use_bnn}).predict imputation, N={n} (one GPU's share of 5e6 over 8), p={p}, z_dim={q}, 10 % cells missing, "
+                        f"burn_in={burn_in}, n_mcmc={n_mcmc}, 10 leapfrog steps, host array in / host arrays out",
+            "predict_seconds": dt, "value": n * (burn_in + n_mcmc) / dt, "unit": "HMC transitions/s", "missing_cells": n_missing,
+            "phases_seconds": {k: v_ for k, v_ in getattr(bm, "last_predict_timing", {}).items() if not k.startswith("_")},
+            "tflops_executed": n * (burn_in + n_mcmc) * 40 * macs * prod / dt / 1e12,
+            "frac_of_fp32_mfma_peak": n * (burn_in + n_mcmc) * 40 * macs * prod / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "acceptance_rate": bm.last_acceptance_rate, "imputed_shape": list(np.asarray(imp).shape),
+            "eight_gpu_job_note": "rows are independent chains; the only exchange is the 8-byte step-size all-reduce per adaptation step (DESIGN 5)"}
 
 
 def end_to_end_leg(params, x, y, v, x_values, n_loc, args, use_bnn, epochs=100, tag="det"):
@@ -710,6 +832,9 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the end-to-end leg (egm_init + fit(epochs=100) + predict on the bench panel, deterministic nets; N=1 only)")
     ap.add_argument("--end-to-end-bnn", type=int, default=0, metavar="EPOCHS",
                     help="also run the end-to-end job with the reference's default Bayesian nets for EPOCHS epochs (100 = the full default job, ~6 minutes at N=1e6; off by default)")
+    ap.add_argument("--bayesian-divisor", type=int, default=1, help="the use_bnn=True leg runs burn_in / n_mcmc divided by this (1 = the BASELINE counts)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the legs of the other BASELINE configurations (C1 binary treatment, C4 one-GPU share) and the encoder leg (N=1 only)")
+    ap.add_argument("--c4-bnn", action="store_true", help="also run the C4 share with the Bayesian generator (use_bnn=True, ~100 s)")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="launch / rendezvous check without a device: every rank joins the process group over gloo on the CPU, the rank "
                          "count is all-reduced and rank 0 prints {n_gpus, n_ranks_in_collective}; no kernel runs (tests/test_bench_launch.py)")
@@ -915,6 +1040,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(params, p, z_dims)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
             out["parity"] = parity_leg(model, x, y, v, z_dims, p, x_values)
+        if not args.no_configs and world == 1:      # (before anything retrains `model`: the encoder of the bench weights)
+            out["encoder"] = encoder_leg(model, v, n_loc, p, z_dims, check_against_oracle=not args.no_cpu_baseline)
         if world == 1:
             out["outcome_cache"] = outcome_cache_leg(model, data, x_values, n_loc, args, seed_counter_last, adrf, value, mode=True)
             out["outcome_cache"]["per_wave"] = outcome_cache_leg(model, data, x_values, n_loc, args, seed_counter_last, adrf, value, mode="wave")
@@ -938,6 +1065,13 @@ def main():
             out["bayesian_nets"] = bayesian_leg(params, data, x_values, n_loc, args, device)
         if not args.no_bgm and world == 1:
             out["bgm_hmc"] = bgm_hmc_leg(device)
+        if not args.no_configs and world == 1:
+            import contextlib
+            with contextlib.redirect_stdout(sys.stderr):      # (the classes print progress lines as the reference does)
+                out["config_c1"] = config_c1_leg(device)
+                out["config_c4_share"] = config_c4_share_leg(device)
+                if args.c4_bnn:
+                    out["config_c4_share"]["use_bnn"] = config_c4_share_leg(device, use_bnn=True)
         if not args.no_general_width and world == 1:
             out["general_width_engine"] = general_width_leg(p, z_dims, device)
         if not args.no_fit and world == 1:

@@ -468,6 +468,42 @@ def test_event_form_falls_back_where_it_does_not_exist():
         eng.set_outcome_cache("sometimes")
 
 
+def test_event_form_honours_its_budget_and_falls_back_when_nothing_fits():
+    """the segment length follows the budget down to ONE retained iteration; when not even that fits (or the allocation
+    fails) the retained phase runs on the fused kernel with the per-wave cache instead of failing -- same sums to the last bit."""
+    from bayesgm_amd import _lib
+    m = _model(25, [1, 1, 1, 7], 200)
+    x, y, v = _data(2000, 200, 26)
+    xs = np.linspace(0, 3, 20)
+    kw = dict(effect=_lib.EFFECT_ADRF, x_values=xs, want_draws=True)
+    eng = _engine(m)
+    eng.set_outcome_cache(False)
+    ref = eng.mh_sample(x, y, v, 10, 24, 1.0, 8, **kw)
+    eng.set_outcome_cache(True)
+    n_slots = eng.mh_slots(2000)
+    tiles = (2000 + 15) // 16
+    per_iter = n_slots * ((tiles + n_slots - 1) // n_slots) * 16 * (4 * 10 + 4 + 32 * 5)
+    fixed = 2 * tiles * 5 * 64 * 2 * 4 + tiles * 8 + n_slots * 4
+    # (i) room for exactly one retained iteration per segment: 24 segments of the event form
+    eng.set_event_budget(fixed + per_iter + 8)
+    eng.outcome_cache_stats(reset=True)
+    one = eng.mh_sample(x, y, v, 10, 24, 1.0, 8, **kw)
+    served, total = eng.outcome_cache_stats()
+    assert total == 2000 * 24                                   # chain-iterations: the event form ran
+    # (ii) not even one iteration fits: per-wave cache on the fused kernel (tile-iterations in the statistics), no error
+    eng.set_event_budget(1024)
+    eng.outcome_cache_stats(reset=True)
+    none = eng.mh_sample(x, y, v, 10, 24, 1.0, 8, **kw)
+    served, total = eng.outcome_cache_stats()
+    assert total == tiles * 24
+    eng.set_event_budget(0)
+    for other in (one, none):
+        for k in ("adrf_partial", "draws", "acc_count", "state", "adrf"):
+            assert np.array_equal(other[k].cpu().numpy(), ref[k].cpu().numpy()), k
+    # the mode argument: bools, names and the C ABI's numbers (True is mode 2, the integer 1 is mode 1)
+    assert [eng.outcome_cache_mode(a) for a in (False, "off", 0, "wave", 1, True, "chain", 2)] == [0, 0, 0, 1, 1, 2, 2, 2]
+
+
 @pytest.mark.parametrize("precision", ["bf16x3", "f16x3"])
 def test_event_form_with_split_precision_transitions(precision):
     """mh_precision = 'bf16x3' / 'f16x3' with outcome cache mode 2: the transitions run on the split-precision kernel and append events,
