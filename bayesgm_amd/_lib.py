@@ -152,6 +152,12 @@ SYMBOLS = {
     "bgm_causal_describe": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32]),
     "bgm_causal_fit_z_sync": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p]),
     "bgm_causal_fit_epoch": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bgm_causal_fit_epoch_dp": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bgm_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "bgm_comm_create": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "bgm_comm_destroy": (C.c_int, [C.c_void_p]),
+    "bgm_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_char_p, C.c_int32]),
+    "bgm_comm_all_reduce_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "bgm_causal_get_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "bgm_causal_fit_z_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bgm_causal_fit_state": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
@@ -231,6 +237,7 @@ SYMBOLS = {
                                  C.c_void_p, C.c_void_p]),
     "bgm_bnn_z_sync": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
     "bgm_bnn_fit_epoch": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bgm_bnn_fit_epoch_dp": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bgm_bnn_logpost": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                   C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]),
     "bgm_bnn_mh_run": (C.c_int, [C.c_void_p, C.POINTER(BnnMhArgs), C.c_void_p]),

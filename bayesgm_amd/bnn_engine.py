@@ -198,6 +198,17 @@ class BnnEngine(object):
                                               self._stream()), "bgm_bnn_fit_epoch")
         return n_done.value
 
+    def fit_epoch_dp(self, comm, x, y, v, data_z, zm, zv, perm, batch, lr_theta, lr_z, lazy, seed, stream_id0, out_t=None, out_z=None):
+        """This rank's share of a data-parallel epoch (bgm_bnn_fit_epoch_dp): the host loop's steps with ONE ncclAllReduce of the
+        session's fused gradient per minibatch, issued from C++.  Returns the number of minibatches run."""
+        self._stepped = True
+        n_done = C.c_int32(0)
+        _lib.check(self.lib.bgm_bnn_fit_epoch_dp(self.h, _ptr(x), _ptr(y), _ptr(v), _ptr(data_z), _ptr(zm), _ptr(zv), _ptr(perm),
+                                                 data_z.shape[0], int(perm.numel()), int(batch), float(lr_theta), float(lr_z), int(lazy),
+                                                 int(seed), int(stream_id0) & 0xFFFFFFFF, _ptr(out_t), _ptr(out_z), C.byref(n_done),
+                                                 comm.handle, self._stream()), "bgm_bnn_fit_epoch_dp")
+        return n_done.value
+
     # -- large-batch side ------------------------------------------------------------------------------
     def logpost(self, x, y, v, z, block_rows, seed, stream_id, block0=0):
         out = torch.empty(z.shape[0], device=self.device, dtype=torch.float32)

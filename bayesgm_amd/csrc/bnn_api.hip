@@ -4,6 +4,7 @@
 #include <vector>
 
 #include "bgm_host.h"
+#include "comm_host.h"
 #include <cstdlib>
 
 #include "bnn_kernels.h"
@@ -651,6 +652,42 @@ extern "C" int bgm_bnn_fit_epoch(bgm_handle *h, const float *x, const float *y, 
   if (n_done) *n_done = (int32_t)k;
   // a device-side wait that gave up voids THIS call: reported now, before the caller evaluates or checkpoints the state
   return flags ? bnn_epoch_check(h, sA) : BGM_OK;
+}
+
+// This rank's share of a data-parallel epoch (models/causalbgm_bnn.py under torch.distributed): per minibatch the steps of the host loop
+// -- replay of the rows' pending latent steps, theta gradient (apply = 0, scaled 1 / (b * world)), the sum of the session's fused
+// g|h|f gradient over the ranks (ncclAllReduce on `stream`, in place in the session's buffer: no exchange copies), the Adam step, the
+// latent step -- issued from C++ on one stream.  replaces: the loop body causalbgm/base.py:490-505 with use_bnn, sharded by rows.
+extern "C" int bgm_bnn_fit_epoch_dp(bgm_handle *h, const float *x, const float *y, const float *v, float *data_z, float *zm, float *zv,
+                                    const int32_t *perm, int64_t n_rows, int64_t n_use, int32_t batch, float lr_theta, float lr_z,
+                                    int32_t lazy, uint64_t seed, uint32_t stream_id0, float *out_t, float *out_z, int32_t *n_done,
+                                    void *comm, void *stream_) {
+  int rc = bnn_need(h, "bgm_bnn_fit_epoch_dp");
+  if (rc) return rc;
+  BnnState *s = bst(h);
+  if (!x || !y || !v || !data_z || !zm || !zv || !perm || n_use < 1 || batch < 2 || batch > s->cfg.max_batch) { bgm_set_error("bgm_bnn_fit_epoch_dp: bad argument"); return BGM_E_INVALID; }
+  if (!comm) { bgm_set_error("bgm_bnn_fit_epoch_dp: NULL communicator (bgm_comm_create)"); return BGM_E_INVALID; }
+  int world = 0, rank = 0;
+  if ((rc = bgm_comm_world(comm, &world, &rank))) return rc;
+  hipStream_t st = (hipStream_t)stream_;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  if (BnnFitChain *fc = static_cast<BnnFitChain *>(s->chain)) fc->theta_prepared = fc->z_prepared = fc->riders_on = false;
+  long long k = 0;
+  for (int64_t i = 0; i < n_use; i += batch) {
+    const int32_t *idx = perm + i;
+    const int b = (int)std::min<int64_t>(batch, n_use - i);
+    if (b < 2) continue;                     // batch statistics need two rows (the same decision on every rank)
+    const int bg = world > 1 ? b * world : 0;
+    const uint32_t s0 = stream_id0 + (uint32_t)(3 * k);
+    if (lazy == 2 && (rc = bgm_bnn_z_sync(h, data_z, zm, zv, idx, n_rows, b, lr_z, st))) break;
+    if ((rc = bgm_bnn_theta_step(h, data_z, idx, x, y, v, b, bg, lr_theta, seed, s0, 0, out_t, st))) break;
+    if ((rc = bgm_comm_enqueue_all_reduce(comm, s->grad_dev, s->n_params, st))) break;
+    if ((rc = bgm_bnn_theta_apply(h, lr_theta, st))) break;
+    if ((rc = bgm_bnn_z_step(h, x, y, v, data_z, zm, zv, idx, n_rows, b, bg, lr_z, lazy, seed, s0 + 1, out_z, nullptr, st))) break;
+    ++k;
+  }
+  if (n_done) *n_done = (int32_t)k;
+  return rc;
 }
 
 extern "C" int bgm_bnn_end(bgm_handle *h, void *stream_) {

@@ -5,6 +5,7 @@
 #include <numeric>
 
 #include "bgm_host.h"
+#include "comm_host.h"
 #include "bnf_det_host.h"
 #include "gx_host.h"
 #include "fit_kernels.h"
@@ -711,9 +712,34 @@ static int fit_epoch_check(bgm_handle *h, hipStream_t stream) {
   return BGM_E_HIP;
 }
 
+// comm != NULL (bgm_causal_fit_epoch_dp): this rank's share of a data-parallel epoch -- every rank calls with its own rows and the
+// same n_use / batch; a minibatch is `batch` local rows of a GLOBAL minibatch of batch * world rows (gradients scaled 1 / (b * world)),
+// and the fused g|f|h gradient is summed over the ranks (ncclAllReduce on the parameter stream) between the gradient tiles and the Adam
+// step, so all ranks take identical steps.  The Adam step is then its own launch (it cannot ride on the tiles: the sum sits between),
+// the streams are ordered by HIP events, the latent phase of minibatch k still runs beside the theta phase of k + 1.
+static int fit_epoch_impl(bgm_handle *h, const float *x, const float *y, const float *v, float *data_z, float *zm, float *zv,
+                          const int32_t *perm, int64_t n_use, int32_t batch, float lr_theta, float lr_z, int32_t lazy,
+                          double *loss, double *loss_z, void *comm, int world, void *stream_);
+
 extern "C" int bgm_causal_fit_epoch(bgm_handle *h, const float *x, const float *y, const float *v, float *data_z, float *zm, float *zv,
                                     const int32_t *perm, int64_t n_use, int32_t batch, float lr_theta, float lr_z, int32_t lazy,
                                     double *loss, double *loss_z, void *stream_) {
+  return fit_epoch_impl(h, x, y, v, data_z, zm, zv, perm, n_use, batch, lr_theta, lr_z, lazy, loss, loss_z, nullptr, 1, stream_);
+}
+
+extern "C" int bgm_causal_fit_epoch_dp(bgm_handle *h, const float *x, const float *y, const float *v, float *data_z, float *zm, float *zv,
+                                       const int32_t *perm, int64_t n_use, int32_t batch, float lr_theta, float lr_z, int32_t lazy,
+                                       double *loss, double *loss_z, void *comm, void *stream_) {
+  if (!comm) { bgm_set_error("bgm_causal_fit_epoch_dp: NULL communicator (bgm_comm_create)"); return BGM_E_INVALID; }
+  int world = 0, rank = 0;
+  int rc = bgm_comm_world(comm, &world, &rank);
+  if (rc) return rc;
+  return fit_epoch_impl(h, x, y, v, data_z, zm, zv, perm, n_use, batch, lr_theta, lr_z, lazy, loss, loss_z, comm, world, stream_);
+}
+
+static int fit_epoch_impl(bgm_handle *h, const float *x, const float *y, const float *v, float *data_z, float *zm, float *zv,
+                          const int32_t *perm, int64_t n_use, int32_t batch, float lr_theta, float lr_z, int32_t lazy,
+                          double *loss, double *loss_z, void *comm, int world, void *stream_) {
   if (!h || !h->fit_active) { bgm_set_error("bgm_causal_fit_epoch: call bgm_causal_fit_begin first"); return BGM_E_STATE; }
   if (!perm || n_use < 1 || batch < 1) { bgm_set_error("bgm_causal_fit_epoch: bad minibatch list"); return BGM_E_INVALID; }
   hipStream_t sA = (hipStream_t)stream_;
@@ -754,7 +780,7 @@ extern "C" int bgm_causal_fit_epoch(bgm_handle *h, const float *x, const float *
   }
   int cur = 0;
   static const bool no_fuse = std::getenv("BGM_FIT_NO_FUSED_ADAM") != nullptr;       // dev A/B: separate Adam launch + explicit row marks
-  const bool fuse = overlap && !no_fuse;
+  const bool fuse = overlap && !no_fuse && !comm;      // (data parallel: the all-reduce sits between the gradient tiles and Adam)
   // Replay mode: the pending zero-gradient steps of minibatch j's rows are replayed D minibatches ahead, on the second stream behind
   // the latent phase j - D -- off the parameter stream's critical path (replay + chains + gradient tiles), and covered by the event the
   // theta phase j waits for anyway.  Legal because the minibatches of one call are disjoint: nothing touches those rows in between,
@@ -822,8 +848,9 @@ extern "C" int bgm_causal_fit_epoch(bgm_handle *h, const float *x, const float *
       ad.fwd_blob = h->blob_dev; ad.bwd_blob = h->bblob_dev; ad.mirror = tTb[(cur + 1) % D];
       ad.fwd_dst = tbl; ad.fwd_dst2 = tbl + np; ad.bwd_dst = tbl + 2 * (size_t)np; ad.mirror_dst = fc->mirror_dst;
     }
-    rc = bgm_causal_fit_theta_grad(h, x, y, v, data_z, idx, 0, b, b, h->epoch_grad, loss, sA);
+    rc = bgm_causal_fit_theta_grad(h, x, y, v, data_z, idx, 0, b, b * world, h->epoch_grad, loss, sA);
     if (fuse) { fc->fused.on = 0; fc->sync_t = FitSync{}; }
+    if (!rc && comm) rc = bgm_comm_enqueue_all_reduce(comm, h->epoch_grad, np, sA);      // C1: the fused g|f|h gradient, summed over the ranks
     if (rc) { hipStreamSynchronize(sB); mark_pending(sA); break; }
     if (flags) h->epoch_theta_done += (unsigned)((fc->base.n_tiles + ECH_WAVES - 1) / ECH_WAVES);      // (the gradient-tile kernel's workgroups)
     if (overlap) {
@@ -852,7 +879,7 @@ extern "C" int bgm_causal_fit_epoch(bgm_handle *h, const float *x, const float *
         replayed = k + D + 1;
       }
     }
-    rc = bgm_causal_fit_z_step(h, x, y, v, data_z, zm, zv, idx, 0, b, b, lr_z, lazy, loss_z, sB);
+    rc = bgm_causal_fit_z_step(h, x, y, v, data_z, zm, zv, idx, 0, b, b * world, lr_z, lazy, loss_z, sB);
     if (flags) {
       fc->sync_z = FitSync{}; fc->rp_n = 0;
       if (!rc) { h->epoch_z_done += (unsigned)fc->last_z_blocks; zt[k % D] = h->epoch_z_done; }

@@ -248,6 +248,13 @@ class CausalEngine(object):
                                                  int(perm.numel()), int(batch), float(lr_theta), float(lr_z), int(lazy), _ptr(loss),
                                                  _ptr(loss_z), self._stream()), "bgm_causal_fit_epoch")
 
+    def fit_epoch_dp(self, comm, x, y, v, data_z, zm, zv, perm, batch, lr_theta, lr_z, lazy, loss=None, loss_z=None):
+        """This rank's share of a data-parallel epoch (bgm_causal_fit_epoch_dp): `batch` local rows per minibatch, the fused g|f|h
+        gradient summed over the ranks of `comm` (parallel.DeviceComm) by one ncclAllReduce per step enqueued inside the library."""
+        _lib.check(self.lib.bgm_causal_fit_epoch_dp(self.h, _ptr(x), _ptr(y), _ptr(v), _ptr(data_z), _ptr(zm), _ptr(zv), _ptr(perm),
+                                                    int(perm.numel()), int(batch), float(lr_theta), float(lr_z), int(lazy), _ptr(loss),
+                                                    _ptr(loss_z), comm.handle, self._stream()), "bgm_causal_fit_epoch_dp")
+
     def describe(self, batch=32):
         """Kernel paths of this handle (sampling; minibatch steps when a fit session is open) as text."""
         buf = C.create_string_buffer(512)

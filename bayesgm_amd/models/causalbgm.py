@@ -286,12 +286,14 @@ class CausalBGM(object):
             print('EGM Initialization Ends.')
 
     def fit(self, data, epochs=100, epochs_per_eval=5, batch_size=32, startoff=0, use_egm_init=True,
-            egm_n_iter=30000, egm_batches_per_eval=500, save_format='txt', verbose=1, z_adam=None, host_loop=False):
+            egm_n_iter=30000, egm_batches_per_eval=500, save_format='txt', verbose=1, z_adam=None, host_loop=False, dp_comm=None):
         """Iterative theta / Z updates (base.py:434-532).
 
         ``host_loop=False`` (single process): the minibatches of an epoch are issued by ONE library call (bgm_causal_fit_epoch), the
         latent phase of a minibatch overlapping the theta phase of the next on a second stream; ``True`` keeps the per-minibatch
-        calls from Python (same results bit for bit; the only form under torch.distributed, where the all-reduce sits between them).
+        calls from Python (same results bit for bit).  Under torch.distributed over RCCL (one GPU per rank) the epoch is ONE library call
+        too (bgm_causal_fit_epoch_dp: the gradient all-reduce is enqueued from C++ between the gradient tiles and the Adam step); other
+        process groups (gloo) keep the host loop, where `parallel.all_reduce_sum_` sits between the calls.
 
         ``batch_size`` is the GLOBAL minibatch; under torch.distributed every rank owns a contiguous row
         shard, draws its share of each minibatch from its own rows, and the g/f/h gradients are
@@ -357,6 +359,13 @@ class CausalBGM(object):
         replay = (lazy == 2)
         lr_z = self._p['lr_z']
         best_loss = np.inf
+        # one process per GPU over RCCL: the epoch stays ONE library call, with an RCCL communicator of the library's own
+        # (parallel.DeviceComm) for the per-step gradient all-reduce; other process groups (gloo) keep the per-minibatch host loop
+        # (``dp_comm``: a parallel.DeviceComm to use instead -- a one-rank communicator runs the data-parallel call in a single process)
+        if dp_comm is None and world > 1 and host_loop is False:
+            dp_comm = parallel.fit_comm(dev)
+        self.last_fit_path = ("library_epoch_dp (RCCL all-reduce inside bgm_causal_fit_epoch_dp, %d ranks)" % dp_comm.world if dp_comm is not None
+                              else "library_epoch" if (world == 1 and host_loop is False) else "host_loop")
         # per-epoch trace (row means over the epoch's minibatches; the reference shows the last minibatch in its progress bar)
         self.fit_history = []
         if verbose:
@@ -368,7 +377,10 @@ class CausalBGM(object):
                 loss.zero_()
                 loss_z.zero_()
                 n_rows = 0
-                if world == 1 and host_loop is False:          # the minibatch loop inside the library (bgm_causal_fit_epoch)
+                if dp_comm is not None:                        # data parallel: the loop AND the all-reduce inside the library
+                    eng.fit_epoch_dp(dp_comm, x, y, v, self.data_z, zm, zv, sample_idx[:n_use], b_loc, self._p['lr_theta'], lr_z, lazy, loss, loss_z)
+                    n_rows = n_use
+                elif world == 1 and host_loop is False:        # the minibatch loop inside the library (bgm_causal_fit_epoch)
                     eng.fit_epoch(x, y, v, self.data_z, zm, zv, sample_idx[:n_use], b_loc, self._p['lr_theta'], lr_z, lazy, loss, loss_z)
                     n_rows = n_use
                 for i in (range(0, n_use, b_loc) if n_rows == 0 else ()):

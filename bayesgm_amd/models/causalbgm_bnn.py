@@ -253,7 +253,7 @@ class CausalBGMBayes(CausalBGM):
 
     # ------------------------------------------------------------------ fit
     def fit(self, data, epochs=100, epochs_per_eval=5, batch_size=32, startoff=0, use_egm_init=True,
-            egm_n_iter=30000, egm_batches_per_eval=500, save_format='txt', verbose=1, z_adam=None, host_loop=False):
+            egm_n_iter=30000, egm_batches_per_eval=500, save_format='txt', verbose=1, z_adam=None, host_loop=False, dp_comm=None):
         """Iterative theta / Z updates (base.py:434-532) with the KL terms of the Bayesian nets.  ``batch_size`` is the
         GLOBAL minibatch (any size as in base.py:434; up to 4096 rows per rank, 16 / 32 on the row-tile chains, other sizes on the
         one-workgroup-per-net kernels); under torch.distributed rows are sharded, the g | h | f gradients all-reduced.
@@ -305,13 +305,21 @@ class CausalBGMBayes(CausalBGM):
         replay = (lazy == 2)
         lr_z = self._p['lr_z']
         best_loss = np.inf
+        if dp_comm is None and world > 1 and not host_loop:      # see CausalBGM.fit
+            dp_comm = parallel.fit_comm(dev)
+        self.last_fit_path = ("library_epoch_dp (RCCL all-reduce inside bgm_bnn_fit_epoch_dp, %d ranks)" % dp_comm.world if dp_comm is not None
+                              else "library_epoch" if (world == 1 and not host_loop) else "host_loop")
         if verbose:
             print('Iterative Updating Starts ...')
         try:
             for epoch in range(epochs + 1):
                 sample_idx = torch.from_numpy(np.random.choice(n_loc, n_loc, replace=False).astype(np.int32)).to(dev)
-                in_library = (world == 1 and not host_loop)      # the minibatch loop inside the library (bgm_bnn_fit_epoch)
-                if in_library:
+                in_library = (world == 1 and not host_loop) or dp_comm is not None      # the minibatch loop inside the library
+                if dp_comm is not None:                          # (bgm_bnn_fit_epoch_dp: one ncclAllReduce per step, enqueued from C++)
+                    done = eng.fit_epoch_dp(dp_comm, x, y, v, self.data_z, zm, zv, sample_idx[:n_use], b_loc, self._p['lr_theta'], lr_z, lazy,
+                                            seed, self._stream, out_t, out_z)
+                    self._streams(3 * done)
+                elif in_library:                                 # (bgm_bnn_fit_epoch)
                     done = eng.fit_epoch(x, y, v, self.data_z, zm, zv, sample_idx[:n_use], b_loc, self._p['lr_theta'], lr_z, lazy, seed,
                                          self._stream, out_t, out_z)
                     self._streams(3 * done)

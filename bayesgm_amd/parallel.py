@@ -109,6 +109,79 @@ def all_gather_rows_var(t):
     return res if host is None else res.cpu()
 
 
+class DeviceComm:
+    """An RCCL communicator owned by the HIP library (csrc/comm_api.hip): what the data-parallel epoch calls
+    (bgm_causal_fit_epoch_dp / bgm_bnn_fit_epoch_dp) enqueue their gradient all-reduce on -- one ncclAllReduce per minibatch between
+    the gradient kernels and the Adam step, issued from C++ on the library's stream, no Python in between.
+
+    ``DeviceComm(device)`` under torch.distributed: rank 0 asks RCCL for a unique id, the 128 bytes are broadcast over the process
+    group, every rank joins with its device.  ``DeviceComm(device, world=1)``: a one-rank communicator (tests, single process)."""
+
+    def __init__(self, device, world=None, rank_=None):
+        import ctypes as C
+        import numpy as np
+        from . import _lib
+        self._lib = _lib
+        lib = _lib.load()
+        dev = torch.device(device) if not isinstance(device, torch.device) else device
+        index = dev.index if dev.index is not None else torch.cuda.current_device()
+        w = world_size() if world is None else int(world)
+        r = rank() if rank_ is None else int(rank_)
+        ident = np.zeros(128, np.uint8)
+        if r == 0:
+            _lib.check(lib.bgm_comm_unique_id(ident.ctypes.data_as(C.c_void_p)), "bgm_comm_unique_id")
+        if w > 1:
+            t = torch.from_numpy(ident).to(torch.device("cuda", index))
+            broadcast_(t, 0)
+            ident = t.cpu().numpy()
+        h = C.c_void_p()
+        with torch.cuda.device(index):
+            _lib.check(lib.bgm_comm_create(index, ident.ctypes.data_as(C.c_void_p), w, r, C.byref(h)), "bgm_comm_create")
+        self.handle, self.world, self.rank, self.device_index = h, w, r, index
+
+    def info(self):
+        import ctypes as C
+        w, r, buf = C.c_int32(), C.c_int32(), C.create_string_buffer(256)
+        self._lib.check(self._lib.load().bgm_comm_info(self.handle, C.byref(w), C.byref(r), buf, 256), "bgm_comm_info")
+        return {"world": w.value, "rank": r.value, "library": buf.value.decode()}
+
+    def all_reduce_sum_(self, t):
+        """In-place sum of a float32 device tensor over the ranks, on torch's current stream."""
+        import ctypes as C
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        self._lib.check(self._lib.load().bgm_comm_all_reduce_f32(self.handle, t.data_ptr(), t.numel(),
+                                                                 C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)), "bgm_comm_all_reduce_f32")
+        return t
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            torch.cuda.synchronize(self.device_index)
+            self._lib.load().bgm_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_fit_comms = {}
+
+
+def fit_comm(device):
+    """The communicator of the data-parallel epoch calls for this process's `device`, or None when the minibatch loop stays in Python:
+    single process, or a process group whose ranks do not each own a GPU (backend gloo: the two-rank runs on ONE device of the test
+    suite -- RCCL refuses two ranks on one device).  BGM_DP_HOST_LOOP=1 forces the host loop (A/B)."""
+    if not is_dist() or dist.get_backend() != "nccl" or os.environ.get("BGM_DP_HOST_LOOP") == "1":
+        return None
+    dev = torch.device(device) if not isinstance(device, torch.device) else device
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _fit_comms:
+        _fit_comms[key] = DeviceComm(torch.device("cuda", key))
+    return _fit_comms[key]
+
+
 def shared_seed(random_seed):
     """Seed every rank derives its host RNG streams and initial weights from.
 

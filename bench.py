@@ -204,6 +204,78 @@ def fit_leg(model, x, y, v, n_loc, steps=2000, batch=32):
             "flop_per_observation": 348480}
 
 
+def fit_dp_leg(model, x, y, v, n_loc, world, device, steps=2000, batch=32):
+    """BASELINE configs[3] ("data-parallel ... RCCL grad all-reduce over xGMI"), the fit side: `steps` minibatches of CausalBGM.fit's
+    data-parallel form on every rank -- `batch` LOCAL rows per rank and step (a global minibatch of batch x world rows: weak scaling),
+    the fused g|f|h gradient summed over the ranks once per step.  Over RCCL (one GPU per rank) that is ONE bgm_causal_fit_epoch_dp
+    call: gradient tiles, ncclAllReduce and Adam enqueued from C++ on the parameter stream, the latent phase beside the next theta
+    phase; with one rank the same call runs on a one-rank communicator (what the N=1 driver run reports next to `fit`); a process
+    group without a GPU per rank (gloo, the one-device development aid) keeps the per-minibatch host loop, as the classes do.
+    Every rank runs it; timing is the max over ranks.  reference: the loop that is sharded, causalbgm/base.py:488-514."""
+    import torch
+    import torch.distributed as dist
+    from bayesgm_amd import parallel
+    eng = model.engine
+    comm = parallel.fit_comm(device) if world > 1 else parallel.DeviceComm(device, world=1, rank_=0)
+    g = torch.Generator(device=device).manual_seed(1)
+    z = torch.randn(n_loc, eng.q, device=device, generator=g)
+    zm, zv = torch.zeros_like(z), torch.zeros_like(z)
+    steps = int(min(steps, n_loc // batch - 20))
+    npar = eng.fit_begin(n_loc, batch)
+    grad = torch.empty(npar, device=device)
+    perm = torch.randperm(n_loc, device=device, generator=g).to(torch.int32)
+
+    def run(k, s0):
+        if comm is not None:
+            eng.fit_epoch_dp(comm, x, y, v, z, zm, zv, perm[s0 * batch:(s0 + k) * batch], batch, 1e-4, 1e-4, 2)
+            return
+        for s_ in range(s0, s0 + k):
+            idx = perm[s_ * batch:(s_ + 1) * batch]
+            eng.fit_z_sync(z, zm, zv, idx, 1e-4)
+            eng.fit_theta_grad(x, y, v, z, idx, batch * world, grad)
+            parallel.all_reduce_sum_(grad)
+            eng.fit_theta_apply(grad, 1e-4)
+            eng.fit_z_step(x, y, v, z, zm, zv, idx, batch * world, 1e-4, lazy=2)
+    try:
+        run(20, 0)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(steps, 20)
+        eng.fit_z_sync(z, zm, zv, None, 1e-4)          # the flush a fit ends with, inside the timed region
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        # the collective alone: the gradient buffer summed over the ranks, back to back on the stream
+        reps = 200
+        red = (lambda: comm.all_reduce_sum_(grad)) if comm is not None else (lambda: parallel.all_reduce_sum_(grad))
+        grad.zero_()
+        red()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            red()
+        torch.cuda.synchronize()
+        ar_us = 1e6 * (time.perf_counter() - t1) / reps
+    finally:
+        eng.fit_end()
+    t = torch.tensor([dt, ar_us], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt, ar_us = float(t[0]), float(t[1])
+    n_in = int(comm.info()["world"]) if comm is not None else world
+    path = ("bgm_causal_fit_epoch_dp (loop + ncclAllReduce inside the library; %s)" % comm.info()["library"]) if comm is not None else \
+           "per-minibatch host loop, torch.distributed all-reduce between the calls (no GPU per rank: backend %s)" % dist.get_backend()
+    if world == 1:
+        comm.close()
+    return {"value": batch * world * steps / dt, "unit": "observations x epochs / s (whole job)", "us_per_minibatch": 1e6 * dt / steps,
+            "minibatches": steps, "rows_per_rank_and_step": batch, "global_minibatch": batch * world, "n_ranks_in_collective": n_in,
+            "gradient_floats": int(npar), "allreduce_us_alone": ar_us, "allreduce_share_of_minibatch": ar_us / (1e6 * dt / steps),
+            "path": path, "scaling": "weak (the global minibatch grows with the ranks; the reference's algorithm at batch_size = 32 x ranks)"}
+
+
 def training_leg(params, x, y, v, device, n=20000, batch=32, reps=200):
     """Secondary measurement: latencies of the training-side steps at the reference batch size on the first `n` rows of the bench
     panel (the tutorial's N) -- EGM discriminator / generator step and the minibatch theta / latent steps, for deterministic and
@@ -955,6 +1027,13 @@ def main():
         for line in paths:
             print(line, file=sys.stderr)
 
+    fit_dp = None
+    if world > 1 and not args.no_fit:      # every rank: the data-parallel minibatch loop with its gradient all-reduce (configs[3], fit side)
+        try:
+            fit_dp = fit_dp_leg(model, x, y, v, n_loc, world, device)
+        except Exception as e:             # the headline line must survive a failure here; the failure is reported in it
+            fit_dp = {"error": "%s: %s" % (type(e).__name__, e)}
+
     if rank == 0:
         iters = args.burn_in + args.n_mcmc
         value = n_total * iters * args.steps / elapsed
@@ -1074,8 +1153,12 @@ def main():
                     out["config_c4_share"]["use_bnn"] = config_c4_share_leg(device, use_bnn=True)
         if not args.no_general_width and world == 1:
             out["general_width_engine"] = general_width_leg(p, z_dims, device)
+        if fit_dp is not None:
+            out["fit_dp"] = fit_dp
         if not args.no_fit and world == 1:
             out["fit"] = fit_leg(model, x, y, v, n_loc)
+            out["fit_dp"] = fit_dp_leg(model, x, y, v, n_loc, 1, device)      # the data-parallel call on a one-rank communicator
+            out["fit_dp"]["vs_single_process_epoch_call"] = out["fit_dp"]["us_per_minibatch"] / out["fit"]["us_per_minibatch"]
             out["training_steps"] = training_leg(params, x, y, v, device)
         print(json.dumps(out))
     if world > 1:

@@ -374,6 +374,19 @@ BGM_API int bgm_causal_fit_epoch(bgm_handle *h, const float *x_dev, const float 
                          float *zv_dev, const int32_t *perm_dev, int64_t n_use, int32_t batch, float lr_theta, float lr_z, int32_t lazy,
                          double *loss_dev, double *loss_z_dev, void *stream);
 
+/* The same loop as this rank's share of a DATA-PARALLEL epoch (BASELINE configs[3]; replaces: causalbgm/base.py:488-514 with
+ * the rows sharded by observation).  Every rank calls it with ITS rows (x, y, v, data_z and slots, perm_dev over local rows) and the
+ * same n_use / batch; a minibatch is `batch` local rows of a global minibatch of batch * world rows (gradients scaled
+ * 1 / (b * world)), and between the gradient tiles and the Adam step the fused g|f|h gradient (n_params floats) is summed over the
+ * ranks: one ncclAllReduce per step enqueued from C++ on the parameter stream -- no Python between the phases.  All ranks take
+ * identical parameter steps; latent rows and their slots stay local.  comm: an ncclComm_t (bgm_comm_create, or the caller's own)
+ * handed through as void *.  The latent phase of minibatch k still runs on the second stream beside the theta phase of k + 1; the
+ * Adam step is its own launch and the streams are ordered by HIP events.  With a one-rank communicator the results equal
+ * bgm_causal_fit_epoch's bit for bit (tests/test_gpu_comm.py). */
+BGM_API int bgm_causal_fit_epoch_dp(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev, float *data_z_dev,
+                            float *zm_dev, float *zv_dev, const int32_t *perm_dev, int64_t n_use, int32_t batch, float lr_theta,
+                            float lr_z, int32_t lazy, double *loss_dev, double *loss_z_dev, void *comm, void *stream);
+
 /* Copy the device parameters of one network back to the host (Keras order) and make them the
  * handle's host copy.  Synchronous. */
 BGM_API int bgm_causal_get_weights(bgm_handle *h, int net_id, float *theta_host, int64_t count, void *stream);
@@ -639,6 +652,13 @@ BGM_API int bgm_bnn_z_sync(bgm_handle *h, float *data_z_dev, float *zm_dev, floa
 BGM_API int bgm_bnn_fit_epoch(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev, float *data_z_dev, float *zm_dev,
                       float *zv_dev, const int32_t *perm_dev, int64_t n_rows, int64_t n_use, int32_t batch, float lr_theta, float lr_z,
                       int32_t lazy, uint64_t seed, uint32_t stream_id0, float *out_t_dev, float *out_z_dev, int32_t *n_done, void *stream);
+/* This rank's share of a data-parallel epoch with Bayesian nets: per minibatch bgm_bnn_z_sync (lazy = 2), bgm_bnn_theta_step(apply = 0,
+ * batch_global = b * world), ONE ncclAllReduce of the session's fused gradient (in place, on `stream`), bgm_bnn_theta_apply,
+ * bgm_bnn_z_step -- the host loop of models/causalbgm_bnn.py issued from C++.  comm as in bgm_causal_fit_epoch_dp. */
+BGM_API int bgm_bnn_fit_epoch_dp(bgm_handle *h, const float *x_dev, const float *y_dev, const float *v_dev, float *data_z_dev, float *zm_dev,
+                         float *zv_dev, const int32_t *perm_dev, int64_t n_rows, int64_t n_use, int32_t batch, float lr_theta,
+                         float lr_z, int32_t lazy, uint64_t seed, uint32_t stream_id0, float *out_t_dev, float *out_z_dev,
+                         int32_t *n_done, void *comm, void *stream);
 BGM_API int bgm_bnn_end(bgm_handle *h, void *stream);
 
 /* ---- EGM warm start with Bayesian nets (train_disc_step :305-330, train_gen_step :332-377 with use_bnn): a sub-session of
@@ -784,6 +804,22 @@ BGM_API int bgm_bvn_egm_encode(bgm_handle *h, const float *x_dev, int64_t n, flo
 BGM_API int bgm_bvn_egm_sync(bgm_handle *h, void *stream);
 BGM_API int bgm_bvn_egm_end(bgm_handle *h, void *stream);
 BGM_API int bgm_bvn_end(bgm_handle *h, void *stream);
+
+/* ---- RCCL communicator for the data-parallel minibatch loops (csrc/comm_api.hip).  The reference has no collective; this is
+ * the exchange north_star names: "the outer loop over observations shards data-parallel across the 8 GPUs of one node with an RCCL
+ * all-reduce of generator / discriminator gradients over xGMI".  RCCL is resolved at run time from the copy the process already maps
+ * (PyTorch-ROCm's librccl.so.1), else the system one (BGM_RCCL_LIB overrides); the calls answer BGM_E_UNSUPPORTED with the reason when
+ * none is found.  Rendezvous: rank 0 calls bgm_comm_unique_id, the BGM_COMM_ID_BYTES bytes travel to the other ranks by any means the
+ * host side has (torch.distributed broadcast in bayesgm_amd/parallel.py), every rank calls bgm_comm_create(its device, id, world, rank). */
+#define BGM_COMM_ID_BYTES 128
+BGM_API int bgm_comm_unique_id(void *id_out);
+BGM_API int bgm_comm_create(int32_t device, const void *id, int32_t world, int32_t rank, void **comm_out);
+BGM_API int bgm_comm_destroy(void *comm);
+/* ranks / this process's rank of a communicator, and which librccl serves it (library: caller's buffer, may be NULL) */
+BGM_API int bgm_comm_info(void *comm, int32_t *world, int32_t *rank, char *library, int32_t library_cap);
+/* in-place sum of `count` floats over the ranks, enqueued on `stream` (what the *_fit_epoch_dp loops issue per minibatch; exported
+ * so that tests and bench.py can time the collective alone) */
+BGM_API int bgm_comm_all_reduce_f32(void *comm, float *buf_dev, int64_t count, void *stream);
 
 #ifdef __cplusplus
 }

@@ -29,7 +29,7 @@ dist.all_reduce(mx, op=dist.ReduceOp.MAX); dist.all_reduce(mn, op=dist.ReduceOp.
 spread = float((mx - mn).abs().max().item())
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from dp_print import print_in_rank_order
-print_in_rank_order(json.dumps(dict(rank=dist.get_rank(), spread=spread, adrf=[float(a) for a in adrf], adrf_untrained=[float(a) for a in adrf0],
+print_in_rank_order(json.dumps(dict(rank=dist.get_rank(), fit_path=getattr(m, 'last_fit_path', None), spread=spread, adrf=[float(a) for a in adrf], adrf_untrained=[float(a) for a in adrf0],
                       interval_untrained=[float(a) for a in interval0.ravel()])))
 assert spread == 0.0 and np.all(np.isfinite(adrf)) and np.all(np.isfinite(theta))
 dist.destroy_process_group()

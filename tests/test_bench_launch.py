@@ -63,3 +63,8 @@ def test_bare_two_rank_bench_on_one_device():
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["n_ranks_in_collective"] == 2 and d["config"]["rows_total"] == 8192
     assert d["value"] > 0 and d["roofline"]["frac"] > 0
+    # the fit side of configs[3]: the data-parallel minibatch loop with its per-step gradient all-reduce, on every rank (over gloo on
+    # one device the per-minibatch host loop; over RCCL bgm_causal_fit_epoch_dp -- tests/test_gpu_rccl.py, tests/test_gpu_comm.py)
+    f = d["fit_dp"]
+    assert "error" not in f, f
+    assert f["n_ranks_in_collective"] == 2 and f["global_minibatch"] == 64 and f["us_per_minibatch"] > 0 and 0 < f["allreduce_share_of_minibatch"] < 1

@@ -38,6 +38,20 @@ def test_two_rank_run_over_rccl(script, key):
         assert all(r_[key] == 0.0 for r_ in rows), rows
 
 
+def test_rccl_fit_runs_inside_the_library_and_equals_the_gloo_host_loop():
+    """Over RCCL the epoch is ONE library call per rank with the gradient all-reduce enqueued from C++ (bgm_causal_fit_epoch_dp /
+    bgm_bnn_fit_epoch_dp on a communicator of the library's own); over gloo (both ranks on one device) the per-minibatch host loop
+    with torch's all-reduce between the calls.  Same minibatches, same sums of two terms: the trained ADRF agrees."""
+    _need_two()
+    from conftest import run_two_ranks
+    for script in ("dp_causal_smoke.py", "dp_bnn_smoke.py"):
+        a = _lines(run_two_ranks(script, timeout=600, backend="nccl"))
+        b = _lines(run_two_ranks(script, timeout=600, backend="gloo"))
+        assert all(r_["fit_path"].startswith("library_epoch_dp") for r_ in a), a[0]["fit_path"]
+        assert all(r_["fit_path"] == "host_loop" for r_ in b), b[0]["fit_path"]
+        np.testing.assert_allclose(a[0]["adrf"], b[0]["adrf"], rtol=0, atol=2e-5)
+
+
 def test_rccl_predict_equals_gloo_predict():
     """the untrained, seeded predict of dp_causal_smoke.py does not depend on the transport: RCCL on two devices = gloo on one"""
     _need_two()
