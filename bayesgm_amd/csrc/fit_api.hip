@@ -780,20 +780,23 @@ static int fit_epoch_impl(bgm_handle *h, const float *x, const float *y, const f
   }
   int cur = 0;
   static const bool no_fuse = std::getenv("BGM_FIT_NO_FUSED_ADAM") != nullptr;       // dev A/B: separate Adam launch + explicit row marks
-  const bool fuse = overlap && !no_fuse && !comm;      // (data parallel: the all-reduce sits between the gradient tiles and Adam)
+  // chained: the machinery of the row-tile chains (replay ahead, device-side ordering, rows stamped by the latent step) is on;
+  // fuse: the Adam step rides on the gradient-tile kernel -- not under data parallelism, where the all-reduce sits between the tiles
+  // and Adam: there the step is its own launch that waits / counts like the tiles would (fit_adam_theta_sync_kernel)
+  const bool chained = overlap && !no_fuse, fuse = chained && !comm;
   // Replay mode: the pending zero-gradient steps of minibatch j's rows are replayed D minibatches ahead, on the second stream behind
   // the latent phase j - D -- off the parameter stream's critical path (replay + chains + gradient tiles), and covered by the event the
   // theta phase j waits for anyway.  Legal because the minibatches of one call are disjoint: nothing touches those rows in between,
   // and the step a replay runs to (the latent step count when minibatch j starts) is known in advance.
   static const bool no_ahead = std::getenv("BGM_FIT_NO_REPLAY_AHEAD") != nullptr;    // dev A/B
-  const bool ahead = fuse && lazy == 2 && !no_ahead;
+  const bool ahead = chained && lazy == 2 && !no_ahead;
   const long long tz0 = h->t_z, n_mb = (n_use + batch - 1) / batch;
   // Ordering between the two streams without events (each record / wait pair costs the stream it sits in 4-6 us of command-processor
   // time: 45.0 us per minibatch with them, 34.7 with the dependencies dropped -- unsafe, measured for the bound): the gradient-tile
   // kernel counts its workgroups into a device counter the latent phase's kernel spins on at entry, and the latent kernel's workgroups
   // (chains + replay riders) count into a second one the theta phase D minibatches later waits for (fit_types.h FitSync).
   static const bool no_flags = std::getenv("BGM_FIT_NO_FLAGS") != nullptr;           // dev A/B: HIP events
-  bool flags = fuse && !no_flags && (lazy != 2 || ahead);
+  bool flags = chained && !no_flags && (lazy != 2 || ahead);
   unsigned zt[4] = {0, 0, 0, 0};   // the latent counter's value once minibatch (slot)'s kernel is done
   if (flags) {
     if (!h->epoch_ctr) {
@@ -817,7 +820,7 @@ static int fit_epoch_impl(bgm_handle *h, const float *x, const float *y, const f
     return fit_z_sync_rows(h, data_z, zm, zv, perm + j * batch, bj, (int)(tz0 + j), lr_z, st, false);
   };
   auto mark_pending = [&](hipStream_t st) {      // a failure: the rows replayed ahead count as current to the step they were brought to
-    if (lazy != 2 || !fuse) return;
+    if (lazy != 2 || !chained) return;
     for (long long j = k; j < std::max(replayed, k + 1) && j < n_mb; ++j)
       fit_mark_rows(h, perm + j * batch, (int)std::min<int64_t>(batch, n_use - j * batch), tz0 + j, st);
   };
@@ -825,7 +828,7 @@ static int fit_epoch_impl(bgm_handle *h, const float *x, const float *y, const f
     const int32_t *idx = perm + i;
     const int b = (int)std::min<int64_t>(batch, n_use - i);
     // (the replayed rows are stamped by the latent step below; only a failure in between needs the explicit mark)
-    if (lazy == 2 && (!ahead || k == 0) && (rc = fit_z_sync_impl(h, data_z, zm, zv, idx, b, lr_z, sA, !fuse))) break;
+    if (lazy == 2 && (!ahead || k == 0) && (rc = fit_z_sync_impl(h, data_z, zm, zv, idx, b, lr_z, sA, !chained))) break;
     if (ahead && k == 0) {
       for (int d = 1; d < D && !rc; ++d) rc = replay(d, sA);
       if (rc) break;
@@ -847,15 +850,27 @@ static int fit_epoch_impl(bgm_handle *h, const float *x, const float *y, const f
       ad.m1 = h->m1_dev; ad.m2 = h->m2_dev; ad.theta_out = tb[(cur + 1) % D];
       ad.fwd_blob = h->blob_dev; ad.bwd_blob = h->bblob_dev; ad.mirror = tTb[(cur + 1) % D];
       ad.fwd_dst = tbl; ad.fwd_dst2 = tbl + np; ad.bwd_dst = tbl + 2 * (size_t)np; ad.mirror_dst = fc->mirror_dst;
-    }
+    } else if (chained && flags) {   // (data parallel) the chains wait as above -- their rows were replayed by the riders of the latent
+      // phase k - D, whose buffer the Adam launch below overwrites -- but nothing of this launch counts the step done: Adam does
+      fc->sync_t = FitSync{k >= D ? h->epoch_ctr + 1 : nullptr, zt[k % D], nullptr, (int *)(h->epoch_ctr + 2)};
+    } else if (chained && k >= D) BGM_HIP_CHECK(hipStreamWaitEvent(sA, h->epoch_ev_z[k % D], 0));      // (the same under HIP events)
     rc = bgm_causal_fit_theta_grad(h, x, y, v, data_z, idx, 0, b, b * world, h->epoch_grad, loss, sA);
-    if (fuse) { fc->fused.on = 0; fc->sync_t = FitSync{}; }
+    if (fuse) fc->fused.on = 0;
+    if (chained) fc->sync_t = FitSync{};
     if (!rc && comm) rc = bgm_comm_enqueue_all_reduce(comm, h->epoch_grad, np, sA);      // C1: the fused g|f|h gradient, summed over the ranks
     if (rc) { hipStreamSynchronize(sB); mark_pending(sA); break; }
-    if (flags) h->epoch_theta_done += (unsigned)((fc->base.n_tiles + ECH_WAVES - 1) / ECH_WAVES);      // (the gradient-tile kernel's workgroups)
+    if (flags && fuse) h->epoch_theta_done += (unsigned)((fc->base.n_tiles + ECH_WAVES - 1) / ECH_WAVES);      // (the gradient-tile kernel's workgroups)
     if (overlap) {
-      if (!fuse) {
-        if (k >= D) BGM_HIP_CHECK(hipStreamWaitEvent(sA, h->epoch_ev_z[k % D], 0));       // latent phase k - D (same slot): it read the buffer written now
+      if (!fuse && flags) {       // (data parallel) the step as its own launch, ordered on the device like the fused tiles
+        const FitSync sy{nullptr, 0u, h->epoch_ctr, (int *)(h->epoch_ctr + 2)};      // (the chains of this minibatch have waited already)
+        const int ab = (np + 1023) / 1024;
+        hipLaunchKernelGGL(fit_adam_theta_sync_kernel, dim3(ab), dim3(1024), 0, sA, tb[cur], h->m1_dev, h->m2_dev, h->epoch_grad, np, lr_t,
+                           ADAM_B1, ADAM_B2, ADAM_EPS, h->blob_dev, h->bblob_dev, tbl, tbl + np, tbl + 2 * (size_t)np, tTb[(cur + 1) % D], fc->mirror_dst,
+                           tb[(cur + 1) % D], sy);
+        BGM_HIP_CHECK(hipGetLastError());
+        h->epoch_theta_done += (unsigned)ab;
+      } else if (!fuse) {
+        if (k >= D && !chained) BGM_HIP_CHECK(hipStreamWaitEvent(sA, h->epoch_ev_z[k % D], 0));       // latent phase k - D (same slot): it read the buffer written now
         hipLaunchKernelGGL(fit_adam_theta_kernel, dim3((np + 255) / 256), dim3(256), 0, sA, tb[cur], h->m1_dev, h->m2_dev, h->epoch_grad, np, lr_t,
                            ADAM_B1, ADAM_B2, ADAM_EPS, h->blob_dev, h->bblob_dev, tbl, tbl + np, tbl + 2 * (size_t)np, tTb[(cur + 1) % D], fc->mirror_dst,
                            tb[(cur + 1) % D]);

@@ -438,6 +438,25 @@ __global__ void fit_adam_theta_kernel(float *theta, float *m1, float *m2, const 
   fit_adam_theta_one(c, grad[c], theta, ad);
 }
 
+// The same step as its own launch BETWEEN two device-ordered phases (bgm_causal_fit_epoch_dp: the gradient was summed over the ranks
+// in front of it): waits at entry for the latent phase that last read the buffer written here, counts the step done at its end.
+__global__ void fit_adam_theta_sync_kernel(float *theta, float *m1, float *m2, const float *grad, int n_params,
+                                           float lr_t, float b1, float b2, float eps, float *fwd_blob,
+                                           float *bwd_blob, const int *fwd_dst, const int *fwd_dst2, const int *bwd_dst,
+                                           float *mirror, const int *mirror_dst, float *theta_out, FitSync sy) {
+  fit_sync_wait(sy);
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < n_params) {
+    FitAdamTheta ad;
+    ad.on = 1; ad.lr_t = lr_t; ad.b1 = b1; ad.b2 = b2; ad.eps = eps;
+    ad.m1 = m1; ad.m2 = m2; ad.theta_out = theta_out ? theta_out : theta;
+    ad.fwd_blob = fwd_blob; ad.bwd_blob = bwd_blob; ad.mirror = mirror;
+    ad.fwd_dst = fwd_dst; ad.fwd_dst2 = fwd_dst2; ad.bwd_dst = bwd_dst; ad.mirror_dst = mirror_dst;
+    fit_adam_theta_one(c, grad[c], theta, ad);
+  }
+  fit_sync_done(sy);
+}
+
 // Adam on the latent matrix.  mode 0 = Keras sparse path (decay + apply on ALL rows, base.py:301),
 // mode 1 = lazy (batch rows only).  `pos[row]` = position of the row in the batch of step `epoch` if pos[n + row] == epoch
 // (fit_set_pos_kernel stamps the rows of a batch; older stamps are simply stale, nothing has to be cleared).

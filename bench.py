@@ -921,6 +921,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.plumbing_only:
         raise SystemExit(plumbing_only(args, world))
+    # stdout carries ONE JSON line.  Native libraries print there too (RCCL writes a version banner through C stdio when a communicator
+    # is created, flushed at exit): from here on descriptor 1 is stderr for everything, and the line is written to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        sys.stdout.flush()
+        os.write(json_fd, (line + "\n").encode())
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
@@ -1160,7 +1170,7 @@ def main():
             out["fit_dp"] = fit_dp_leg(model, x, y, v, n_loc, 1, device)      # the data-parallel call on a one-rank communicator
             out["fit_dp"]["vs_single_process_epoch_call"] = out["fit_dp"]["us_per_minibatch"] / out["fit"]["us_per_minibatch"]
             out["training_steps"] = training_leg(params, x, y, v, device)
-        print(json.dumps(out))
+        emit(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 

@@ -11,7 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
-GOLD = os.path.join(os.path.dirname(__file__), "golden", "hirano_imbens_c0.npz")
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "hirano_imbens_N2000_p20_seed0.npz")
 
 
 def _flat(net):
