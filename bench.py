@@ -605,7 +605,7 @@ def config_c4_share_leg(device, n=625000, p=500, q=10, burn_in=1000, n_mcmc=1000
             "eight_gpu_job_note": "rows are independent chains; the only exchange is the 8-byte step-size all-reduce per adaptation step (DESIGN 5)"}
 
 
-def end_to_end_leg(params, x, y, v, x_values, n_loc, args, use_bnn, epochs=100, tag="det"):
+def end_to_end_leg(params, x, y, v, x_values, n_loc, args, use_bnn, epochs=100, tag="det", seed=123):
     """The whole job a user runs on the bench panel, seconds per phase: CausalBGM(params).fit(...) with the
     reference's defaults (egm_init: 30000 iterations of 5 discriminator + 1 generator step at B = 32; `epochs` epochs of N / 32
     minibatches, evaluation every 5 epochs; causalbgm/base.py:380-532) followed by predict with the bench's MCMC settings in the
@@ -617,7 +617,12 @@ def end_to_end_leg(params, x, y, v, x_values, n_loc, args, use_bnn, epochs=100, 
     from bayesgm_amd.utils import get_ADRF
     t = {}
     with contextlib.redirect_stdout(sys.stderr):
-        m = CausalBGM(dict(params, use_bnn=use_bnn), timestamp="bench_e2e_" + tag, random_seed=123)
+        import warnings
+        from bayesgm_amd import diagnostics
+        caught_cm = warnings.catch_warnings(record=True)
+        caught = caught_cm.__enter__()
+        warnings.simplefilter("always")
+        m = CausalBGM(dict(params, use_bnn=use_bnn), timestamp="bench_e2e_" + tag, random_seed=seed)
         egm = m.egm_init
 
         def timed_egm(*a_, **k_):
@@ -645,6 +650,8 @@ def end_to_end_leg(params, x, y, v, x_values, n_loc, args, use_bnn, epochs=100, 
             m.engine.set_precision("fp32")
             x3 = {"predict_seconds": dt3, "predict_transitions_per_s": n_loc * (args.burn_in + args.n_mcmc) / dt3, "acceptance_rate": m.last_acceptance_rate,
                   "adrf_max_abs_diff_vs_fp32": float(np.max(np.abs(np.asarray(adrf3) - np.asarray(adrf))))}
+        caught_cm.__exit__(None, None, None)
+    second_optimum = any(issubclass(w.category, diagnostics.SecondOptimumWarning) for w in caught)
     truth = get_ADRF(x_values=list(x_values), dataset="Imbens")
     err = np.asarray(adrf) - truth
     if x3 is not None:
@@ -658,6 +665,7 @@ def end_to_end_leg(params, x, y, v, x_values, n_loc, args, use_bnn, epochs=100, 
            "observations_x_epochs_per_s": (epochs + 1) * n_loc / fit_loop,
            "predict_transitions_per_s": n_loc * (args.burn_in + args.n_mcmc) / t["predict"], "acceptance_rate": m.last_acceptance_rate,
            "adrf_rmse": float(np.sqrt(np.mean(err ** 2))), "average_effect_abs_error": float(abs(err.mean())), "best_epoch": getattr(m, "best_epoch", None),
+           "random_seed": seed, "second_optimum_warning": second_optimum, "egm_late_l2_loss_z": getattr(m, "_egm_late_l2z", None),
            "sample": "fit((x, y, v), epochs=%d, epochs_per_eval=5, batch_size=32, use_egm_init=True, egm_n_iter=30000) + predict(n_mcmc=%d, burn_in=%d, "
                      "20 doses) on the bench panel itself (N=%d, p=%d); epochs + 1 passes as the reference loops range(epochs + 1) (base.py:488)"
                      % (epochs, args.n_mcmc, args.burn_in, n_loc, args.p)}
