@@ -13,6 +13,9 @@ static constexpr int BGM_WAVES = 8;
 #ifndef BGM_WAVES_WIDE_HMC
 #define BGM_WAVES_WIDE_HMC 12   // 148 VGPRs -> 3 waves/SIMD; measured 89 vs 86 (8) vs 86 (16) TF at p=500
 #endif
+#ifndef BGM_X3_WAVES_DEFAULT
+#define BGM_X3_WAVES_DEFAULT 8
+#endif
 static constexpr float BN_EPS_F = 1e-3f;   // keras BatchNormalization default epsilon
 
 void bgm_bgm_free_state(bgm_handle *h) {
@@ -21,6 +24,7 @@ void bgm_bgm_free_state(bgm_handle *h) {
   bgm_bgm_fit_free(h);
   gxb_free(s);
   if (s->blob_dev) hipFree(s->blob_dev);
+  if (s->hx3_dev) hipFree(s->hx3_dev);
   delete s;
   h->bgm_state = nullptr;
 }
@@ -71,7 +75,7 @@ static int bgm_build_blob(bgm_handle *h, hipStream_t stream) {
   const int KTQ = (q + 15) / 16;
   BgmMeta &m = s->meta;
   int ntx_variant = 0;
-  const int lds_bytes = bgm_layout(q, p, NH, m, ntx_variant);
+  const int lds_bytes = bgm_layout(q, p, NH, m, ntx_variant, s->precision != 0);      // (split-precision heads: the streamed variant)
   if (lds_bytes < 0) {
     bgm_set_error("BGM generator: trunk + head biases + stage exceed the 160 KiB LDS (x_dim too large)");
     return BGM_E_UNSUPPORTED;
@@ -111,8 +115,61 @@ static int bgm_build_blob(bgm_handle *h, hipStream_t stream) {
     s->blob_cap = blob.size();
   }
   BGM_HIP_CHECK(hipMemcpyAsync(s->blob_dev, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+  std::vector<unsigned short> hx3;
+  if (s->precision != 0) {
+    // split-precision head fragments (bgm_kernels.h): per 16-feature block 16 fragments of 64 lanes x 8 halves --
+    //   forward f = 2 (2 head + b) + (lo): lane (i, gA), slot u <-> W_head[unit 16 (2 b + (u >> 2)) + 4 gA + (u & 3)][column 16 tx + i]
+    //   backward f = 8 + 2 ti + (lo):     lane (i, gA), slot u <-> (u < 4 ? W_mean : W_var)[unit 16 ti + i][column 16 tx + 4 gA + (u & 3)]
+    const float *Wm = th + (o - 2 * ((size_t)64 * p + p)), *Wv = Wm + (size_t)64 * p + p;
+    hx3.assign((size_t)NTX * (BGM_X3_BLOCK_BYTES / 2), 0);
+    auto put = [&](size_t base, float w) {      // hi at base, lo one fragment (512 halves) further
+      const unsigned short hi = bgm_f2h(w);
+      hx3[base] = hi;
+      hx3[base + 512] = bgm_f2h(w - bgm_h2f(hi));
+    };
+    for (int tx = 0; tx < NTX; ++tx) {
+      const size_t blk = (size_t)tx * (BGM_X3_BLOCK_BYTES / 2);
+      for (int lane = 0; lane < 64; ++lane) {
+        const int i = lane & 15, gA = lane >> 4;
+        for (int u = 0; u < 8; ++u) {
+          for (int head = 0; head < 2; ++head)
+            for (int b = 0; b < 2; ++b) {
+              const int unit = 16 * (2 * b + (u >> 2)) + 4 * gA + (u & 3), col = 16 * tx + i;
+              const float w = col < p ? (head ? Wv : Wm)[(size_t)unit * p + col] : 0.0f;
+              put(blk + (size_t)(2 * (2 * head + b)) * 512 + (size_t)lane * 8 + u, w);
+            }
+          for (int ti = 0; ti < 4; ++ti) {
+            const int unit = 16 * ti + i, col = 16 * tx + 4 * gA + (u & 3);
+            const float w = col < p ? (u < 4 ? Wm : Wv)[(size_t)unit * p + col] : 0.0f;
+            put(blk + (size_t)(8 + 2 * ti) * 512 + (size_t)lane * 8 + u, w);
+          }
+        }
+      }
+    }
+    if (s->hx3_cap < hx3.size() * 2) {
+      if (s->hx3_dev) BGM_HIP_CHECK(hipFree(s->hx3_dev));
+      BGM_HIP_CHECK(hipMalloc((void **)&s->hx3_dev, hx3.size() * 2));
+      s->hx3_cap = hx3.size() * 2;
+    }
+    BGM_HIP_CHECK(hipMemcpyAsync(s->hx3_dev, hx3.data(), hx3.size() * 2, hipMemcpyHostToDevice, stream));
+    s->lds_bytes_x3 = (m.stage + 2 * (BGM_X3_BLOCK_BYTES / 4)) * 4;
+    if (s->lds_bytes_x3 > 160 * 1024) { bgm_set_error("BGM generator: trunk + head biases + the split-precision stage exceed the 160 KiB LDS"); return BGM_E_UNSUPPORTED; }
+  }
   BGM_HIP_CHECK(hipStreamSynchronize(stream));
   s->blob_valid = true;
+  return BGM_OK;
+}
+
+// Arithmetic of the posterior kernels' head products (bgm_kernels.h "Split-precision heads"): 0 fp32 (default), 2 f16x3.  Opt-in
+// (models: params['hmc_precision'] = 'f16x3'); serves the dual-access-blob shapes (trunk [64] x {3, 5}, z_dim <= 16) at any x_dim
+// through the streamed-head kernels; log posterior / gradient / HMC.  Predictive draws and the minibatch steps stay fp32.
+extern "C" int bgm_bgm_set_precision(bgm_handle *h, int32_t mode) {
+  if (!h || !h->bgm_state || !bst(h)->configured) { bgm_set_error("bgm_bgm_set_precision: not configured"); return BGM_E_STATE; }
+  if (mode != 0 && mode != 2) { bgm_set_error("bgm_bgm_set_precision: mode must be 0 (fp32) or 2 (f16x3)"); return BGM_E_INVALID; }
+  BgmState *s = bst(h);
+  if (mode != 0 && gxb_wanted(s)) { bgm_set_error("bgm_bgm_set_precision: split precision exists for the default trunk shapes ([64] x 3 / [64] x 5, z_dim <= 16)"); return BGM_E_UNSUPPORTED; }
+  if (mode != 0 && s->fit_active) { bgm_set_error("bgm_bgm_set_precision: not inside a fit session"); return BGM_E_STATE; }
+  if (s->precision != mode) { s->precision = mode; s->blob_valid = false; }
   return BGM_OK;
 }
 
@@ -140,11 +197,27 @@ extern "C" int bgm_bgm_logpost(bgm_handle *h, const float *z, const float *x, in
   if (rc) return rc;
   BgmState *s = bst(h);
   const int grid = bgm_grid(h, (n + 15) / 16), lds = s->lds_bytes;
+  if (s->precision != 0) {      // split-precision heads: the streamed variant with the fp16 fragment stream
+    const int ldx = s->lds_bytes_x3;
+#define X(KTQ_, NH_)                                                                                                \
+    if (s->KTQ == KTQ_ && s->NH == NH_) {                                                                           \
+      auto k = bgm_logpost_kernel<KTQ_, 0, NH_, BGM_WAVES, 1>;                                                      \
+      BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, ldx)); \
+      hipLaunchKernelGGL(k, dim3(grid), dim3(64 * BGM_WAVES), ldx, stream, s->blob_dev, s->meta, z, x, (long long)n, out, grad, \
+                         (const unsigned char *)s->hx3_dev);                                                        \
+      BGM_HIP_CHECK(hipGetLastError());                                                                             \
+      return BGM_OK;                                                                                                \
+    }
+    X(1, 5) X(1, 3)
+#undef X
+    BGM_NO_VARIANT(s)
+  }
 #define X(KTQ_, NTX_, NH_)                                                                                          \
   if (s->KTQ == KTQ_ && s->NTX == NTX_ && s->NH == NH_) {                                                           \
     auto k = bgm_logpost_kernel<KTQ_, NTX_, NH_, BGM_WAVES>;                                                        \
     BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
-    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * BGM_WAVES), lds, stream, s->blob_dev, s->meta, z, x, (long long)n, out, grad); \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * BGM_WAVES), lds, stream, s->blob_dev, s->meta, z, x, (long long)n, out, grad, \
+                       (const unsigned char *)nullptr);                                                             \
     BGM_HIP_CHECK(hipGetLastError());                                                                               \
     return BGM_OK;                                                                                                  \
   }
@@ -172,7 +245,8 @@ extern "C" int bgm_bgm_hmc_run(bgm_handle *h, const bgm_hmc_args *a, void *strea
   ka.it_begin = a->it_begin; ka.n_iters = a->n_iters; ka.burn_in = a->burn_in; ka.n_leapfrog = a->n_leapfrog;
   ka.step = a->step_dev; ka.k0 = (unsigned)(a->seed & 0xFFFFFFFFull); ka.k1 = (unsigned)(a->seed >> 32);
   ka.acc_prob_sum = a->acc_prob_sum_dev; ka.acc_count = a->acc_count_dev; ka.draws = a->draws_dev; ka.m = s->meta;
-  const int lds = s->lds_bytes;
+  ka.hx3 = s->hx3_dev;
+  const int lds = s->precision != 0 ? s->lds_bytes_x3 : s->lds_bytes;
   const long long tiles = (a->n + 15) / 16;
   // The wide variant's unit of work is a block pass (W row tiles x all iterations of the launch) and every block makes the same
   // number of passes.  Tiles are dealt wave-major and tile-less waves skip the matrix work (bgm_hmc_kernel), so a partly filled
@@ -187,6 +261,28 @@ extern "C" int bgm_bgm_hmc_run(bgm_handle *h, const bgm_hmc_args *a, void *strea
     hipLaunchKernelGGL(k, dim3(grid), dim3(64 * W), lds, stream, ka);                                               \
     BGM_HIP_CHECK(hipGetLastError());                                                                               \
     return BGM_OK;                                                                                                  \
+  }
+  if (s->precision != 0) {      // split-precision heads (bgm_kernels.h): waves per block from BGM_X3_WAVES (8, 12 or 16; default 8)
+    static const int xw = std::getenv("BGM_X3_WAVES") ? std::atoi(std::getenv("BGM_X3_WAVES")) : BGM_X3_WAVES_DEFAULT;
+#define LAUNCH_X3(KTQ_, NH_, W)                                                                                     \
+    {                                                                                                               \
+      const int grid = (int)std::max<long long>(1, std::min<long long>((tiles + W - 1) / W, h->n_cus));             \
+      auto k = bgm_hmc_kernel<KTQ_, 0, NH_, W, 1>;                                                                  \
+      BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+      hipLaunchKernelGGL(k, dim3(grid), dim3(64 * W), lds, stream, ka);                                             \
+      BGM_HIP_CHECK(hipGetLastError());                                                                             \
+      return BGM_OK;                                                                                                \
+    }
+#define X(KTQ_, NH_)                                                                                                \
+    if (s->KTQ == KTQ_ && s->NH == NH_) {                                                                           \
+      if (xw == 12) LAUNCH_X3(KTQ_, NH_, 12)                                                                        \
+      if (xw == 16) LAUNCH_X3(KTQ_, NH_, 16)                                                                        \
+      LAUNCH_X3(KTQ_, NH_, 8)                                                                                       \
+    }
+    X(1, 5) X(1, 3)
+#undef X
+#undef LAUNCH_X3
+    BGM_NO_VARIANT(s)
   }
 #define X(KTQ_, NTX_, NH_)                                                                                          \
   if (s->KTQ == KTQ_ && s->NTX == NTX_ && s->NH == NH_) {                                                           \

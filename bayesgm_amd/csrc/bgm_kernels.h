@@ -188,16 +188,140 @@ __device__ __forceinline__ void bgm_head_tile(const float *wl, const float *lds,
   if (WANT_GRAD) heads_bwd17(wl, j, g, dms, dh);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Split-precision heads (opt-in, bgm_bgm_set_precision(h, 2) / params['hmc_precision'] = 'f16x3'): at wide data rows the two
+// p-wide head products are ~80 % of a gradient evaluation's matrix work (BASELINE config C4: 64 000 of 81 024 MACs).  They run on
+// v_mfma_f32_16x16x32_f16 (K = 32 per instruction, half the cycles of the K = 4 fp32 one) with every operand a sum of two fp16
+// numbers, x = x_hi + x_lo, and  W h ~= W_lo h_hi + W_hi h_lo + W_hi h_hi  (fp32 accumulation; the dropped term is 2^-22 of the
+// product): a 16-feature head block is 24 matrix instructions instead of 64.  The trunk (20 % of the work, and the part that needs
+// both orientations of its weights in LDS) stays on the fp32 dual-access layout.
+//   forward   (mean | var)(16 features) = W^T h:  M = output feature, K = 64 hidden units in two blocks of 32; lane group g supplies
+//             k-slot u = 4 s + r  <->  unit 16 (2 b + s) + 4 g + r, i.e. the trunk's accumulators ARE the B operand (split once per evaluation);
+//   backward  dh(64 units) += Wm dmu + Wv ds:  M = hidden unit, K = 32 = the block's 16 mean + 16 variance outputs, lane group g
+//             supplies k-slot u: u < 4 -> mean output 4 g + u, else variance output 4 g + u - 4: again the lane's own registers.
+// Fragments of a block (packed on the host, bgm_api.hip): 16 x 1 KiB = [fwd: (head, K block, hi | lo)][bwd: (hidden tile, hi | lo)],
+// 64 lanes x 8 halves each, streamed through a double-buffered 2 x 16 KiB LDS stage by the whole block like the fp32 pairs.
+// fp16 range: a weight beyond 65504 is clamped by the packer; dlogp/d(mean, s) beyond 6e4 (a variance ~1e-5 under a unit residual) is
+// clamped in the kernel -- the fp32 kernels have no such bound.
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef _Float16 bgm_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 bgm_h2 __attribute__((ext_vector_type(2)));
+typedef float bgm_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned bgm_u4 __attribute__((ext_vector_type(4)));
+#define BGM_X3_BLOCK_BYTES 16384
+#define BGM_MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ void bgm_split_pair(float a, float b, unsigned &hi, unsigned &lo) {
+  const bgm_h2 h = __builtin_convertvector(bgm_f2{a, b}, bgm_h2);
+  hi = __builtin_bit_cast(unsigned, h);
+  const bgm_h2 l = __builtin_convertvector(bgm_f2{a - (float)h[0], b - (float)h[1]}, bgm_h2);      // (exact subtractions)
+  lo = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ void bgm_split8(const f32x4 &a, const f32x4 &b, bgm_h8 &hi, bgm_h8 &lo) {
+  unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+  bgm_split_pair(a[0], a[1], h0, l0);
+  bgm_split_pair(a[2], a[3], h1, l1);
+  bgm_split_pair(b[0], b[1], h2, l2);
+  bgm_split_pair(b[2], b[3], h3, l3);
+  hi = __builtin_bit_cast(bgm_h8, bgm_u4{h0, h1, h2, h3});
+  lo = __builtin_bit_cast(bgm_h8, bgm_u4{l0, l1, l2, l3});
+}
+
+struct BgmHeadStreamX3 {
+  const f32x4 *src;      // global: [ntx][BGM_X3_BLOCK_BYTES]
+  unsigned char *buf;    // LDS:    [2][BGM_X3_BLOCK_BYTES]
+  int cur, tid, nthreads;
+  f32x4 r[2];
+  __device__ __forceinline__ void fetch(int tx) {
+    const f32x4 *s = src + (long long)tx * (BGM_X3_BLOCK_BYTES / 16);
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (tid + k * nthreads < BGM_X3_BLOCK_BYTES / 16) r[k] = s[tid + k * nthreads];
+  }
+  __device__ __forceinline__ void commit() {
+    f32x4 *d = reinterpret_cast<f32x4 *>(buf + (cur ^ 1) * BGM_X3_BLOCK_BYTES);
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (tid + k * nthreads < BGM_X3_BLOCK_BYTES / 16) d[tid + k * nthreads] = r[k];
+    __syncthreads();
+    cur ^= 1;
+  }
+  __device__ __forceinline__ const unsigned char *tile() const { return buf + cur * BGM_X3_BLOCK_BYTES; }
+  __device__ __forceinline__ void begin(const unsigned char *frags, const BgmMeta &m, float *lds) {
+    src = reinterpret_cast<const f32x4 *>(frags); buf = reinterpret_cast<unsigned char *>(lds + m.stage); tid = threadIdx.x; nthreads = blockDim.x;
+    cur = 1;
+    fetch(0);
+    commit();
+  }
+};
+
+// one 16-feature head block in split precision.  hh / hl: the trunk output split into its two K blocks (once per evaluation).
+template <bool WANT_GRAD>
+__device__ __forceinline__ void bgm_head_tile_x3(const unsigned char *tile, const float *lds, const BgmMeta &m, int tx, int lane, int g,
+                                                 const bgm_h8 (&hh)[2], const bgm_h8 (&hl)[2], const f32x4 &xv, bool want_lp, float &nll,
+                                                 f32x4 (&dh)[4]) {
+  const bgm_h8 *fr = reinterpret_cast<const bgm_h8 *>(tile) + lane;      // fragment f at fr[64 f]
+  f32x4 ms[2];
+  ms[0] = *reinterpret_cast<const f32x4 *>(lds + m.bhd + 16 * tx + 4 * g);
+  ms[1] = *reinterpret_cast<const f32x4 *>(lds + m.bhd + 16 * (m.ntx + tx) + 4 * g);
+  {
+    bgm_h8 ah[4], al[4];      // (head, K block) = 0 .. 3
+#pragma unroll
+    for (int f = 0; f < 4; ++f) { ah[f] = fr[64 * (2 * f)]; al[f] = fr[64 * (2 * f + 1)]; }
+#pragma unroll
+    for (int f = 0; f < 4; ++f) ms[f >> 1] = BGM_MFMA_H(al[f], hh[f & 1], ms[f >> 1]);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) ms[f >> 1] = BGM_MFMA_H(ah[f], hl[f & 1], ms[f >> 1]);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) ms[f >> 1] = BGM_MFMA_H(ah[f], hh[f & 1], ms[f >> 1]);
+  }
+  f32x4 dms[2];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float x_ = xv[r], s_ = ms[1][r];
+    const bool obs = (x_ == x_) && (16 * tx + 4 * g + r < m.p);   // NaN = missing
+    // softplus and its derivative from ONE exponential: e = exp(-|s|), softplus = max(s, 0) + log1p(e), sigmoid = (s >= 0 ? 1 : e) / (1 + e)
+    const float e = fast_exp(-fabsf(s_));
+    const float l1p = (e < 2.44140625e-4f) ? e * (1.0f - 0.5f * e) : fast_log(1.0f + e);
+    const float s2 = vmax(s_, 0.0f) + l1p + BGM_EPS;
+    const float inv = fast_rcp(s2);
+    const float d = obs ? x_ - ms[0][r] : 0.0f;
+    if (want_lp) nll += obs ? 0.5f * (d * d * inv + fast_log(s2)) : 0.0f;
+    if (WANT_GRAD) {
+      const float sg = (s_ >= 0.0f ? 1.0f : e) * fast_rcp(1.0f + e);
+      const float di = d * inv;
+      dms[0][r] = __builtin_amdgcn_fmed3f(di, -6.0e4f, 6.0e4f);                                              // dlogp/dmu
+      dms[1][r] = obs ? __builtin_amdgcn_fmed3f((0.5f * di * di - 0.5f * inv) * sg, -6.0e4f, 6.0e4f) : 0.0f;   // dlogp/ds
+    }
+  }
+  if (WANT_GRAD) {
+    bgm_h8 dhi, dlo;
+    bgm_split8(dms[0], dms[1], dhi, dlo);
+    bgm_h8 ah[4], al[4];      // hidden tile ti
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) { ah[ti] = fr[64 * (8 + 2 * ti)]; al[ti] = fr[64 * (9 + 2 * ti)]; }
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) dh[ti] = BGM_MFMA_H(al[ti], dhi, dh[ti]);
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) dh[ti] = BGM_MFMA_H(ah[ti], dlo, dh[ti]);
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) dh[ti] = BGM_MFMA_H(ah[ti], dhi, dh[ti]);
+  }
+}
+
 // log p(z | x_obs) and dlogp/dz for 16 chains held by one wave.
 //   z  : feature 16t + 4r + g in register r of tile t
 //   xs : data row, feature 16t + 4g + r, NaN = missing (ignored), zero padded beyond p
 //   hs : head-weight stream of the block (wide variant only; every wave of the block must call this
 //        function the same number of times)
 // logp is replicated over the lane groups; grad has the layout of z.
-template <int KTQ, int NTX, int NH, bool WANT_GRAD>
+// PREC 1: the heads in split precision (wide variant only, HS = BgmHeadStreamX3); want_lp = false (PREC 1 only): the value of the log
+// posterior is not needed (the inner leapfrog steps of an HMC transition use the gradient alone), logp is then undefined.
+template <int KTQ, int NTX, int NH, bool WANT_GRAD, int PREC = 0, class HS = BgmHeadStream>
 __device__ __forceinline__ void bgm_logp_grad(const float *lds, const BgmMeta &m, int j, int g,
-                                              const f32x4 (&z)[KTQ], const BgmX<NTX> &xs, BgmHeadStream &hs,
-                                              float &logp, f32x4 (&grad)[KTQ]) {
+                                              const f32x4 (&z)[KTQ], const BgmX<NTX> &xs, HS &hs,
+                                              float &logp, f32x4 (&grad)[KTQ], bool want_lp = true) {
+  static_assert(PREC == 0 || NTX == 0, "split-precision heads: the streamed (wide) variant");
   // trunk forward; only the SIGN of every activation is kept for the backward pass (bit 4t+r of sgn[l])
   unsigned sgn[NH];
   f32x4 h[4];
@@ -238,6 +362,24 @@ __device__ __forceinline__ void bgm_logp_grad(const float *lds, const BgmMeta &m
     for (int tx = 0; tx < NTX; ++tx) {
       BGM_NO_HOIST();
       bgm_head_tile<WANT_GRAD>(lds + m.whd + tx * BGM_PAIR, lds, m, tx, j, g, h, xs.r[tx], nll, dh);
+    }
+  } else if constexpr (PREC == 1) {
+    bgm_h8 hh[2], hl[2];
+    bgm_split8(h[0], h[1], hh[0], hl[0]);
+    bgm_split8(h[2], h[3], hh[1], hl[1]);
+    const int lane = 16 * g + j;
+#pragma unroll 1
+    for (int tx = 0; tx < m.ntx; ++tx) {
+      BGM_NO_HOIST();
+      hs.fetch(tx + 1 < m.ntx ? tx + 1 : 0);
+      f32x4 xv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 16 * tx + 4 * g + r;
+        xv[r] = (c < m.p) ? xs.row[c] : 0.0f;
+      }
+      bgm_head_tile_x3<WANT_GRAD>(hs.tile(), lds, m, tx, lane, g, hh, hl, xv, want_lp, nll, dh);
+      hs.commit();
     }
   } else {
 #pragma unroll 1
@@ -330,16 +472,21 @@ __device__ __forceinline__ void bgm_store_z(float *z, int q, long long row, int 
     }
 }
 
+template <int PREC> struct bgm_stream_of { typedef BgmHeadStream type; };
+template <> struct bgm_stream_of<1> { typedef BgmHeadStreamX3 type; };
+
 // get_log_posterior (+ optional gradient) for n rows
-template <int KTQ, int NTX, int NH, int WAVES>
+template <int KTQ, int NTX, int NH, int WAVES, int PREC = 0>
 __global__ __launch_bounds__(64 * WAVES) void bgm_logpost_kernel(const float *blob, BgmMeta m, const float *z,
                                                                  const float *x, long long n, float *out,
-                                                                 float *grad_out) {
+                                                                 float *grad_out, const unsigned char *hx3 = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   lds_fill(lds, blob, m.lds_resident);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
-  BgmHeadStream hs;
-  if constexpr (NTX == 0) hs.begin(blob, m, lds);
+  using HS = typename bgm_stream_of<PREC>::type;
+  HS hs;
+  if constexpr (PREC == 1) hs.begin(hx3, m, lds);
+  else if constexpr (NTX == 0) hs.begin(blob, m, lds);
   const long long n_tiles = (n + 15) / 16, passes = bgm_block_passes(n_tiles, WAVES);
   for (long long ps = 0; ps < passes; ++ps) {
     BGM_NO_HOIST();
@@ -355,8 +502,8 @@ __global__ __launch_bounds__(64 * WAVES) void bgm_logpost_kernel(const float *bl
     bgm_load_x<NTX>(x, n, m.p, row, g, xr);
     bgm_load_z<KTQ>(z, m.q, row, g, zr);
     float lp;
-    if (grad_out != nullptr) bgm_logp_grad<KTQ, NTX, NH, true>(lds, m, j, g, zr, xr, hs, lp, gr);
-    else bgm_logp_grad<KTQ, NTX, NH, false>(lds, m, j, g, zr, xr, hs, lp, gr);
+    if (grad_out != nullptr) bgm_logp_grad<KTQ, NTX, NH, true, PREC, HS>(lds, m, j, g, zr, xr, hs, lp, gr);
+    else bgm_logp_grad<KTQ, NTX, NH, false, PREC, HS>(lds, m, j, g, zr, xr, hs, lp, gr);
     if (ok) {
       if (g == 0) out[row] = lp;
       if (grad_out != nullptr) bgm_store_z<KTQ>(grad_out, m.q, row, g, gr);
@@ -379,16 +526,19 @@ struct BgmHmcKArgs {
   unsigned *acc_count;       // [it]  += accepted chains
   float *draws;              // [n_keep x n x q] or NULL
   BgmMeta m;
+  const unsigned char *hx3;  // PREC 1: the packed fp16 head fragments [ntx][BGM_X3_BLOCK_BYTES]
 };
 
-template <int KTQ, int NTX, int NH, int WAVES>
+template <int KTQ, int NTX, int NH, int WAVES, int PREC = 0>
 __global__ __launch_bounds__(64 * WAVES) void bgm_hmc_kernel(BgmHmcKArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const BgmMeta &m = a.m;
   lds_fill(lds, a.blob, m.lds_resident);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
-  BgmHeadStream hs;
-  if constexpr (NTX == 0) hs.begin(a.blob, m, lds);
+  using HS = typename bgm_stream_of<PREC>::type;
+  HS hs;
+  if constexpr (PREC == 1) hs.begin(a.hx3, m, lds);
+  else if constexpr (NTX == 0) hs.begin(a.blob, m, lds);
   const long long n = a.n, n_tiles = (n + 15) / 16, passes = bgm_block_passes(n_tiles, WAVES);
   const float eps = *a.step;
   for (long long ps = 0; ps < passes; ++ps) {
@@ -422,7 +572,7 @@ __global__ __launch_bounds__(64 * WAVES) void bgm_hmc_kernel(BgmHmcKArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) z[t][r] = (16 * t + 4 * r + g < m.q) ? e[r] : 0.0f;
       }
-      bgm_logp_grad<KTQ, NTX, NH, true>(lds, m, j, g, z, xr, hs, lp, gr);
+      bgm_logp_grad<KTQ, NTX, NH, true, PREC, HS>(lds, m, j, g, z, xr, hs, lp, gr);
     } else {
       bgm_load_z<KTQ>(a.state, m.q, row, g, z);
       bgm_load_z<KTQ>(a.grad, m.q, row, g, gr);
@@ -451,7 +601,7 @@ __global__ __launch_bounds__(64 * WAVES) void bgm_hmc_kernel(BgmHmcKArgs a) {
         for (int t = 0; t < KTQ; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) zc[t][r] = fmaf(eps, mom[t][r], zc[t][r]);
-        bgm_logp_grad<KTQ, NTX, NH, true>(lds, m, j, g, zc, xr, hs, lpc, gc);
+        bgm_logp_grad<KTQ, NTX, NH, true, PREC, HS>(lds, m, j, g, zc, xr, hs, lpc, gc, PREC == 0 || l == a.n_leapfrog - 1);
         const float kick = (l < a.n_leapfrog - 1) ? eps : 0.5f * eps;
 #pragma unroll
         for (int t = 0; t < KTQ; ++t)

@@ -1,6 +1,8 @@
 // bgm_state.h -- host-side state of the BGM path shared by bgm_api.hip and fit_api.hip.
 #pragma once
+#include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "bgm_host.h"
@@ -13,11 +15,18 @@ struct BgmState {
   std::vector<float> theta;
   BgmMeta meta{};
   int KTQ = 0, NTX = 0, NH = 0;   // NTX = 0: wide variant (head weights streamed, any x_dim)
+  int fit_NTX = 0;                // the minibatch kernels' variant (its own field: a split-precision posterior blob is always the streamed variant)
   int lds_bytes = 0;              // dynamic LDS of the posterior kernels
   int fit_lds_bytes = 0;
   float *blob_dev = nullptr;
   size_t blob_cap = 0;
   bool blob_valid = false;
+  // split-precision heads (bgm_bgm_set_precision; bgm_kernels.h "Split-precision heads"): 0 fp32 (default), 2 f16x3 -- the packed fp16
+  // fragments [ntx][16 KiB] next to the blob, the posterior kernels' LDS request with the 2 x 16 KiB stage
+  int precision = 0;
+  unsigned char *hx3_dev = nullptr;
+  size_t hx3_cap = 0;
+  int lds_bytes_x3 = 0;
   // fit session (device)
   bool fit_active = false;
   int fit_bcap = 0, n_params = 0, rows_per_slice = 256, n_slices_cap = 0;
@@ -71,7 +80,7 @@ inline void pack17_heads(std::vector<float> &blob, int off, const float *W, int 
 // Blob layout shared by the inference and the training blob.  Chooses the LDS-resident variant when the
 // whole generator fits the 160 KiB LDS AND a kernel is compiled for ceil(p/16); otherwise the wide variant.
 // Returns the dynamic LDS bytes, or -1 if not even the trunk + stage fits.
-inline int bgm_layout(int q, int p, int NH, BgmMeta &m, int &ntx_variant) {
+inline int bgm_layout(int q, int p, int NH, BgmMeta &m, int &ntx_variant, bool force_wide = false) {
   const int KTQ = (q + 15) / 16, NTX = (p + 15) / 16;
   m = BgmMeta{};
   m.q = q; m.p = p; m.n_hh = NH - 1; m.ntx = NTX;
@@ -83,7 +92,7 @@ inline int bgm_layout(int q, int p, int NH, BgmMeta &m, int &ntx_variant) {
   m.whd = take(NTX * BGM_PAIR);
   m.total = off;
   const char *force = std::getenv("BGM_FORCE_WIDE");   // test hook: run the wide variant on small shapes too
-  const bool resident = (size_t)m.total * 4 <= 160 * 1024 && (NTX == 2 || NTX == 7) && !(force && force[0] == '1');
+  const bool resident = (size_t)m.total * 4 <= 160 * 1024 && (NTX == 2 || NTX == 7) && !(force && force[0] == '1') && !force_wide;
   if (resident) {
     ntx_variant = NTX; m.lds_resident = m.total; m.stage = 0;
     return m.total * 4;
@@ -91,6 +100,37 @@ inline int bgm_layout(int q, int p, int NH, BgmMeta &m, int &ntx_variant) {
   ntx_variant = 0; m.lds_resident = m.whd; m.stage = m.whd;
   const size_t bytes = ((size_t)m.whd + 2 * BGM_PAIR) * 4;
   return bytes <= 160 * 1024 ? (int)bytes : -1;
+}
+
+// fp32 -> fp16 bits, round to nearest even, clamped to the largest finite value (host-side packing of the split-precision fragments)
+inline unsigned short bgm_f2h(float f) {
+  unsigned x;
+  std::memcpy(&x, &f, 4);
+  const unsigned sign = (x >> 16) & 0x8000u;
+  x &= 0x7fffffffu;
+  if (x >= 0x477ff000u) return (unsigned short)(sign | 0x7bffu);          // >= 65520 (or inf / nan): 65504
+  if (x < 0x33000001u) return (unsigned short)sign;                       // < 2^-25: zero
+  if (x < 0x38800000u) {                                                  // subnormal half
+    const int e = (int)(x >> 23);                                         // biased fp32 exponent, 102 .. 112
+    const unsigned m = (x & 0x7fffffu) | 0x800000u;
+    const int sh = 126 - e;                                               // 14 .. 24
+    unsigned r = m >> sh;
+    const unsigned rem = m & ((1u << sh) - 1), half = 1u << (sh - 1);
+    if (rem > half || (rem == half && (r & 1u))) ++r;
+    return (unsigned short)(sign | r);
+  }
+  unsigned r = ((x - 0x38000000u) >> 13);
+  const unsigned rem = x & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) ++r;
+  return (unsigned short)(sign | r);
+}
+inline float bgm_h2f(unsigned short h) {
+  const unsigned sign = (unsigned)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+  float f;
+  if (e == 0) f = std::ldexp((float)m, -24);
+  else { const unsigned x = ((e + 112u) << 23) | (m << 13); std::memcpy(&f, &x, 4); }
+  if (sign) f = -f;
+  return f;
 }
 
 void bgm_bgm_fit_free(bgm_handle *h);

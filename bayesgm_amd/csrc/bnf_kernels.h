@@ -86,7 +86,12 @@ __device__ __forceinline__ float bnf_softplus(float x) {
 // The mask comes out of an (opaque, CSE-able) asm so that it lives in an SGPR: with the literal 0x80000000 the compiler emits
 // v_and_b32 + v_or_b32 (VOP3 takes no literal on gfx9), with a register operand one v_and_or_b32.
 __device__ __forceinline__ uint32_t bnf_k80() { uint32_t k; asm("s_mov_b32 %0, 0x80000000" : "=s"(k)); return k; }
+#ifdef BNF_ABL_NOSIGN      // development ablation (never in the product build): every Rademacher sign = +1, i.e. the sign applications
+// cost nothing at all -- the upper bound of what ANY cheaper form of them (lane masks, packed flips) could gain
+__device__ __forceinline__ float bnf_pm1(uint32_t) { return 1.0f; }
+#else
 __device__ __forceinline__ float bnf_pm1(uint32_t m) { return __builtin_bit_cast(float, (m & bnf_k80()) | 0x3f800000u); }
+#endif
 // sign words are pre-shifted per lane so that bit (4 gg + 19) of the word sits at position 31: feature 16 t + 4 gg + r of a
 // 32-feature word <-> bit B = 16 (t & 1) + r of the lane's view, at position 12 + B
 __device__ __forceinline__ uint32_t bnf_preshift(uint32_t w, int g) { return w << (12 - 4 * g); }

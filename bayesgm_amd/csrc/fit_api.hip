@@ -1070,7 +1070,7 @@ extern "C" int bgm_bgm_fit_begin(bgm_handle *h, int64_t n_rows, int32_t max_batc
   int ntx_variant = 0;
   s->fit_lds_bytes = bgm_layout(q, p, NH, m, ntx_variant);
   if (s->fit_lds_bytes < 0) { bgm_set_error("BGM generator does not fit the LDS layout (x_dim too large)"); return BGM_E_UNSUPPORTED; }
-  s->KTQ = KTQ; s->NTX = ntx_variant; s->NH = NH;
+  s->KTQ = KTQ; s->fit_NTX = ntx_variant; s->NH = NH;      // (fit_NTX: the posterior kernels keep their own variant, bgm_api.hip)
   const int np = (int)s->theta.size();
   if (np >= (1 << 24)) { bgm_set_error("too many parameters"); return BGM_E_UNSUPPORTED; }
   s->n_params = np;
@@ -1170,11 +1170,11 @@ static int bgm_fit_fwd_bwd(bgm_handle *h, BgmState *s, const float *x, const flo
     ka.part = s->split_part_dev;
     ka.part_ctr = reinterpret_cast<unsigned *>(s->split_part_dev + (size_t)BGM_SPLIT_MAX_WG * BGM_FIT_S * 32 * 64);
     ka.bn_w = s->bn_dev; ka.bn_theta = s->theta_dev; ka.bn_moving = s->theta_dev + 2 * q; ka.bn_update = update_moving;
-    grid = std::max(1, std::min(BGM_SPLIT_MAX_WG, s->NTX == 0 ? rounds : (rounds + 1) / 2));
-    if (s->NTX == 0) lds += (BGM_FIT_S - 2) * BGM_PAIR * (int)sizeof(float);      // the stage holds BGM_FIT_S tile pairs
+    grid = std::max(1, std::min(BGM_SPLIT_MAX_WG, s->fit_NTX == 0 ? rounds : (rounds + 1) / 2));
+    if (s->fit_NTX == 0) lds += (BGM_FIT_S - 2) * BGM_PAIR * (int)sizeof(float);      // the stage holds BGM_FIT_S tile pairs
   }
 #define X(KTQ_, NTX_, NH_)                                                                                          \
-  if (s->KTQ == KTQ_ && s->NTX == NTX_ && s->NH == NH_) {                                                           \
+  if (s->KTQ == KTQ_ && s->fit_NTX == NTX_ && s->NH == NH_) {                                                           \
     auto kf = bgm_fit_fwd_kernel<KTQ_, NTX_, NH_, BGM_FIT_WAVES>;                                                   \
     auto kb = bgm_fit_bwd_kernel<KTQ_, NTX_, NH_, BGM_FIT_WAVES>;                                                   \
     BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \

@@ -503,6 +503,15 @@ class BgmEngine(object):
         """BatchNormalization mode of the EGM discriminators opened afterwards: "batch" | "fixed" (bgm_set_disc_norm)."""
         _lib.check(self.lib.bgm_set_disc_norm(self.h, {"batch": 0, "fixed": 1}[mode]), "bgm_set_disc_norm")
 
+    HMC_PRECISIONS = {"fp32": 0, "f16x3": 2}
+
+    def set_precision(self, mode="fp32"):
+        """Arithmetic of the two x_dim-wide head products in logpost / hmc_run: "fp32" (default) or "f16x3" (split precision on the
+        fp16 matrix instruction, opt-in; bgm_bgm_set_precision)."""
+        if mode not in self.HMC_PRECISIONS:
+            raise ValueError("hmc precision must be 'fp32' or 'f16x3'; got %r" % (mode,))
+        _lib.check(self.lib.bgm_bgm_set_precision(self.h, self.HMC_PRECISIONS[mode]), "bgm_bgm_set_precision")
+
     def close(self):
         if getattr(self, "h", None) is not None and self.h:
             self.lib.bgm_destroy(self.h)

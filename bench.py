@@ -407,6 +407,12 @@ def bgm_hmc_leg(device, n=200000, p=500, q=10, L=10, iters=4):
     eng = BgmEngine(p, q, g_units=[64] * 5)
     eng.set_weights(g)
     out["deterministic"] = entry("bgm_hmc_kernel (head weights streamed)", timed(eng), 1)
+    # the same transitions with the head products in split precision (opt-in, params['hmc_precision'] = 'f16x3': csrc/bgm_kernels.h);
+    # frac_of_fp32_mfma_peak is then a speed in fp32-peak equivalents, not a utilisation of the fp16 pipe
+    eng.set_precision("f16x3")
+    out["deterministic_f16x3"] = entry("bgm_hmc_kernel<PREC = 1> (heads on v_mfma_f32_16x16x32_f16, hi / lo fp16 splits, three products; trunk fp32)", timed(eng), 1)
+    out["deterministic_f16x3"]["speedup_vs_fp32"] = out["deterministic"]["ms_per_transition"] / out["deterministic_f16x3"]["ms_per_transition"]
+    eng.set_precision("fp32")
 
     def flip(a, b):
         return ((0.1 * rs.standard_normal((a, b))).astype(np.float32), (-3.0 + 0.1 * rs.standard_normal((a, b))).astype(np.float32),
@@ -574,7 +580,7 @@ def config_c1_leg(device, n=100000, p=100, burn_in=5000, n_mcmc=3000):
             "ite_identical_with_cache_off": bool(np.array_equal(res[True][0], res[False][0]) and np.array_equal(res[True][1], res[False][1]))}
 
 
-def config_c4_share_leg(device, n=625000, p=500, q=10, burn_in=1000, n_mcmc=1000, use_bnn=False):
+def config_c4_share_leg(device, n=625000, p=500, q=10, burn_in=1000, n_mcmc=1000, use_bnn=False, precision="fp32"):
     """BASELINE configs[4], one GPU's share: BGM missing-data imputation, N = 5e6 / 8 = 625 000 rows, p = 500, 10 % of the cells
     missing (MCAR), 1000 burn-in (800 with the shared step-size adaptation) + 1000 retained HMC transitions of 10 leapfrog steps per
     row, posterior-predictive imputation + per-cell intervals through BGM.predict (bgm/base.py:527-663, 709-830); glorot weights.
@@ -584,6 +590,8 @@ def config_c4_share_leg(device, n=625000, p=500, q=10, burn_in=1000, n_mcmc=1000
     bp = dict(dataset="bench_c4", output_dir=".", save_res=False, save_model=False, use_bnn=use_bnn, z_dim=q, x_dim=p,
               lr_theta=5e-3, lr_z=5e-3, g_units=[64] * 5, e_units=[64] * 5, dz_units=[64, 32, 8], dx_units=[64, 32, 8],
               kl_weight=5e-5, lr=1e-3, g_d_freq=1, use_z_rec=True, alpha=0.0, gamma=0.0)
+    if precision != "fp32":
+        bp["hmc_precision"] = precision
     bm = BGM(bp, timestamp="bench_c4", random_seed=0)
     g = torch.Generator(device=device).manual_seed(0)
     data = torch.randn(n, p, device=device, generator=g)
@@ -595,7 +603,8 @@ def config_c4_share_leg(device, n=625000, p=500, q=10, burn_in=1000, n_mcmc=1000
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     macs = q * 64 + 4 * 4096 + 2 * 64 * p
     prod = 2 if use_bnn else 1
-    return {"workload": f"BGM(use_bnn={use_bnn}).predict imputation, N={n} (one GPU's share of 5e6 over 8), p={p}, z_dim={q}, 10 % cells missing, "
+    return {"hmc_precision": precision, "imputed_checksum": float(np.nansum(np.asarray(imp)[:4096].astype(np.float64))),
+            "workload": f"BGM(use_bnn={use_bnn}).predict imputation, N={n} (one GPU's share of 5e6 over 8), p={p}, z_dim={q}, 10 % cells missing, "
                         f"burn_in={burn_in}, n_mcmc={n_mcmc}, 10 leapfrog steps, host array in / host arrays out",
             "predict_seconds": dt, "value": n * (burn_in + n_mcmc) / dt, "unit": "HMC transitions/s", "missing_cells": n_missing,
             "phases_seconds": {k: v_ for k, v_ in getattr(bm, "last_predict_timing", {}).items() if not k.startswith("_")},
@@ -914,6 +923,7 @@ def main():
                     help="also run the end-to-end job with the reference's default Bayesian nets for EPOCHS epochs (100 = the full default job, ~6 minutes at N=1e6; off by default)")
     ap.add_argument("--bayesian-divisor", type=int, default=1, help="the use_bnn=True leg runs burn_in / n_mcmc divided by this (1 = the BASELINE counts)")
     ap.add_argument("--no-configs", action="store_true", help="skip the legs of the other BASELINE configurations (C1 binary treatment, C4 one-GPU share) and the encoder leg (N=1 only)")
+    ap.add_argument("--no-c4-f16x3", action="store_true", help="skip the split-precision run of the C4 share")
     ap.add_argument("--c4-bnn", action="store_true", help="also run the C4 share with the Bayesian generator (use_bnn=True, ~100 s)")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="launch / rendezvous check without a device: every rank joins the process group over gloo on the CPU, the rank "
@@ -1167,6 +1177,10 @@ def main():
             with contextlib.redirect_stdout(sys.stderr):      # (the classes print progress lines as the reference does)
                 out["config_c1"] = config_c1_leg(device)
                 out["config_c4_share"] = config_c4_share_leg(device)
+                if not args.no_c4_f16x3:      # the same job with the opt-in split-precision heads
+                    x3 = config_c4_share_leg(device, precision="f16x3")
+                    x3["speedup_vs_fp32"] = out["config_c4_share"]["predict_seconds"] / x3["predict_seconds"]
+                    out["config_c4_share"]["f16x3"] = x3
                 if args.c4_bnn:
                     out["config_c4_share"]["use_bnn"] = config_c4_share_leg(device, use_bnn=True)
         if not args.no_general_width and world == 1:

@@ -21,6 +21,8 @@ def main():
              "mean": (glorot(rs, 64, p), np.zeros(p, np.float32)), "var": (glorot(rs, 64, p), np.zeros(p, np.float32))}
         eng = BgmEngine(p, q, g_units=[64] * 5)
         eng.set_weights(g)
+        if os.environ.get("BGM_PROBE_PRECISION"):      # "f16x3": split-precision heads (csrc/bgm_kernels.h)
+            eng.set_precision(os.environ["BGM_PROBE_PRECISION"])
         x = torch.randn(n, p, device="cuda")
         x[torch.rand(n, p, device="cuda") < 0.1] = float("nan")
         L = 10

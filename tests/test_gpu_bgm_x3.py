@@ -1,0 +1,114 @@
+"""Split-precision heads of the BGM posterior kernels (opt-in, bgm_bgm_set_precision(2) / params['hmc_precision'] = 'f16x3';
+csrc/bgm_kernels.h "Split-precision heads"): the two x_dim-wide head products -- ~80 % of a gradient evaluation at BASELINE
+config C4 -- on v_mfma_f32_16x16x32_f16 with hi / lo fp16 splits of weights, trunk output and likelihood gradients (three products
+per contraction, fp32 accumulation), everything else fp32.
+
+Tolerances are the fp32 kernels' own (tests/test_gpu_bgm.py): log posterior <= 2e-6 |ref| + 2e-4 and gradient
+<= 2e-5 max|ref| + 2e-5 against the float64 oracle; HMC chains share the Philox stream with the oracle and the fp32 kernels:
+>= 97 % of the rows agree to 2e-3 after a short run, the step-size schedule is the same.
+reference: get_log_posterior bgm/base.py:665-705, tfp_mcmc_sampler :709-830."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import bgm as OB  # noqa: E402
+from test_gpu_bgm import _model, _data, _engine, _bgm_params  # noqa: E402
+
+
+@pytest.mark.parametrize("case", [dict(q=10, p=500, n=300, nh=5), dict(q=10, p=100, n=333, nh=5), dict(q=3, p=20, n=17, nh=3),
+                                  dict(q=10, p=131, n=129, nh=5), dict(q=4, p=50, n=2100, nh=3), dict(q=10, p=7, n=33, nh=5)])
+def test_split_precision_logpost_and_gradient_match_oracle(case):
+    m = _model(1, case["q"], case["p"], case["nh"])
+    x = _data(case["n"], case["p"], 2)
+    z = np.random.RandomState(3).randn(case["n"], case["q"]).astype(np.float32)
+    eng = _engine(m)
+    lp32, gr32 = (t.cpu().numpy() for t in eng.logpost(z, x, want_grad=True))
+    eng.set_precision("f16x3")
+    lp, gr = (t.cpu().numpy() for t in eng.logpost(z, x, want_grad=True))
+    lp0 = eng.logpost(z, x).cpu().numpy()
+    eng.set_precision("fp32")
+    lp32b = eng.logpost(z, x).cpu().numpy()
+    assert np.array_equal(lp32, lp32b)                       # the mode switches back cleanly
+    obs, clean = OB.obs_mask_of(x)
+    m64 = OB.cast_model(m, np.float64)
+    ref_lp, ref_gr = OB.log_posterior_and_grad(m64, z.astype(np.float64), clean.astype(np.float64), obs.astype(np.float64))
+    e32, e3 = np.abs(lp32 - ref_lp).max(), np.abs(lp - ref_lp).max()
+    g32, g3 = np.abs(gr32 - ref_gr).max(), np.abs(gr - ref_gr).max()
+    print("p=%d: log posterior error vs float64 fp32 %.2e / f16x3 %.2e; gradient %.2e / %.2e (max |grad| %.2e)"
+          % (case["p"], e32, e3, g32, g3, np.abs(ref_gr).max()))
+    assert np.array_equal(lp, lp0)
+    assert np.all(np.abs(lp - ref_lp) <= 2e-6 * np.abs(ref_lp) + 2e-4), e3
+    assert g3 <= 2e-5 * np.abs(ref_gr).max() + 2e-5, g3
+    assert abs(lp[0] + 0.5 * (z[0] ** 2).sum()) < 1e-5 and np.allclose(gr[0], -z[0], atol=1e-6)      # nothing observed: the prior
+
+
+@pytest.mark.parametrize("case", [dict(q=10, p=500, n=150), dict(q=10, p=100, n=150), dict(q=10, p=61, n=2100)])
+def test_split_precision_hmc_chain_matches_oracle_and_fp32(case):
+    import torch
+    m = _model(11, case["q"], case["p"])
+    x = _data(case["n"], case["p"], 12)
+    burn, keep, L, seed = 20, 10, 4, 77
+    eng = _engine(m)
+    ref32 = eng.hmc_sample(x, keep, burn, step_size=0.02, n_leapfrog=L, seed=seed)
+    eng.set_precision("f16x3")
+    out = eng.hmc_sample(x, keep, burn, step_size=0.02, n_leapfrog=L, seed=seed)
+    out2 = eng.hmc_sample(x, keep, burn, step_size=0.02, n_leapfrog=L, seed=seed)
+    obs, clean = OB.obs_mask_of(x)
+    ref, info = OB.hmc_sampler(m, clean, obs.astype(np.float32), keep, burn, 0.02, L, seed, return_info=True)
+    draws, d32 = out["draws"].cpu().numpy(), ref32["draws"].cpu().numpy()
+    ok = np.all(np.abs(draws[-1] - ref[-1]) <= 2e-3, axis=1)
+    same = np.all(np.abs(draws[-1] - d32[-1]) <= 2e-3, axis=1)
+    print("p=%d: rows equal to the oracle chain %.3f, to the fp32 kernel's chain %.3f" % (case["p"], ok.mean(), same.mean()))
+    assert ok.mean() >= 0.97 and same.mean() >= 0.97
+    assert abs(float(out["step"].item()) / info["step"] - 1) < 1e-5
+    acc = out["acc_count"].cpu().numpy()[burn:].sum() / (keep * case["n"])
+    assert abs(acc - info["accept_rate"]) < 0.03 and acc > 0.5
+    assert torch.equal(out2["draws"], out["draws"])              # deterministic
+
+
+def test_split_precision_samples_the_prior_when_nothing_is_observed():
+    m = _model(21, 10, 20)
+    x = np.full((512, 20), np.nan, np.float32)
+    eng = _engine(m)
+    eng.set_precision("f16x3")
+    out = eng.hmc_sample(x, 200, 100, step_size=0.1, n_leapfrog=5, seed=5)
+    d = out["draws"].cpu().numpy().reshape(-1, 10)
+    assert np.abs(d.mean(0)).max() < 0.03 and np.abs(d.var(0) - 1).max() < 0.06
+
+
+def test_split_precision_through_the_class_and_where_it_is_refused(tmp_path):
+    """BGM(params['hmc_precision'] = 'f16x3').predict against the fp32 class on the same streams; the general-width engine and the
+    Bayesian generator say that the mode does not exist there."""
+    from bayesgm_amd.models import BGM
+    from bayesgm_amd.engine import BgmEngine
+    p, n = 500, 96
+    m = _model(41, 10, p)
+    rs = np.random.RandomState(42)
+    x = rs.randn(n, p).astype(np.float32)
+    x[rs.rand(n, p) < 0.1] = np.nan
+    res = {}
+    for mode in ("fp32", "f16x3"):
+        model = BGM(dict(_bgm_params(tmp_path, p), hmc_precision=mode), random_seed=0)
+        model.set_weights(m["g"])
+        res[mode] = model.predict(x, alpha=0.1, n_mcmc=40, burn_in=30, step_size=0.05, num_leapfrog_steps=4, seed=5)
+    imp_a, imp_b = res["fp32"][0], res["f16x3"][0]
+    miss = np.isnan(x)
+    assert np.array_equal(imp_b[~miss], x[~miss]) and not np.isnan(imp_b).any()
+    row_d = np.array([np.abs(imp_a[i][miss[i]] - imp_b[i][miss[i]]).max() if miss[i].any() else 0.0 for i in range(n)])
+    print("class predict: rows with imputations within 1e-3 of the fp32 class: %d of %d" % ((row_d < 1e-3).sum(), n))
+    assert (row_d < 1e-3).mean() >= 0.95
+    # a fit still runs (fp32 minibatch kernels); the posterior kernels afterwards follow the trained weights, in split precision
+    g0 = model.engine.get_weights()["mean"][0].copy()
+    model.fit(np.nan_to_num(x), batch_size=32, epochs=1, epochs_per_eval=1, use_egm_init=False, verbose=0)
+    assert not np.array_equal(model.engine.get_weights()["mean"][0], g0)
+    z = rs.randn(n, 10).astype(np.float32)
+    lp3 = model.engine.logpost(z, x).cpu().numpy()
+    model.engine.set_precision("fp32")
+    lp32 = model.engine.logpost(z, x).cpu().numpy()
+    assert np.all(np.abs(lp3 - lp32) <= 2e-6 * np.abs(lp32) + 2e-4)
+    eng = BgmEngine(20, 10, g_units=[128, 128])
+    with pytest.raises(RuntimeError, match="default trunk shapes"):
+        eng.set_precision("f16x3")
+    with pytest.raises(ValueError):
+        eng.set_precision("bf16x3")
