@@ -212,5 +212,5 @@ struct CausalMhKArgs;
 bool bgm_causal_event_wanted(const bgm_handle *h, int effect, int n_doses);
 int bgm_causal_event_plan(bgm_handle *h, long long n, int n_slots, int n_doses, int n_iters, int *seg_len, long long *ev_cap);
 int bgm_causal_event_mh_launch(bgm_handle *h, CausalMhKArgs &ka, int grid, int lds, hipStream_t stream);
-int bgm_causal_event_finish(bgm_handle *h, const CausalMhKArgs &ka, int grid, int first, hipStream_t stream);
+int bgm_causal_event_finish(bgm_handle *h, const CausalMhKArgs &ka, int grid, int first, hipStream_t stream, int effect);
 void bgm_causal_event_free(bgm_handle *h);

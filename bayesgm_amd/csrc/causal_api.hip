@@ -433,7 +433,8 @@ extern "C" int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *a, void *stre
   bool ev_form = it_end > split && bgm_causal_event_wanted(h, a->effect, a->n_doses);
   int S = 0;
   long long cap = 0;
-  if (ev_form && (rc = bgm_causal_event_plan(h, a->n, n_slots, a->n_doses, it_end - split, &S, &cap))) {
+  const int ev_doses = a->effect == BGM_EFFECT_ITE ? 2 : a->n_doses;      // (binary treatment: the two arms)
+  if (ev_form && (rc = bgm_causal_event_plan(h, a->n, n_slots, ev_doses, it_end - split, &S, &cap))) {
     if (rc < 0) return rc;
     // the event buffers do not fit the budget / the device (rc > 0): release what was reserved and run the retained phase on the
     // fused kernel with the per-wave cache (mode 1) -- same sums to the last bit, no failure where predict ran before
@@ -488,7 +489,7 @@ extern "C" int bgm_causal_mh_run(bgm_handle *h, const bgm_mh_args *a, void *stre
     if (segs[s].ev) {
       ka.ev_first = segs[s].ev == 1 ? 1 : 0;
       if ((rc = bgm_causal_event_mh_launch(h, ka, grid, lds, stream))) return rc;
-      rc = bgm_causal_event_finish(h, ka, grid, ka.ev_first, stream);
+      rc = bgm_causal_event_finish(h, ka, grid, ka.ev_first, stream, a->effect);
     } else if (h->precision != 0) rc = bgm_causal_bx3_mh_launch(h, ka, segs[s].effect, grid, stream);      // (carries the conditional prior)
     else if (h->prior_seg) rc = bgm_causal_prior_mh_launch(h, ka, segs[s].effect, grid, lds, stream);
     else if (segs[s].effect == BGM_EFFECT_ADRF) rc = launch_mh<1>(h, ka, grid, lds, stream);

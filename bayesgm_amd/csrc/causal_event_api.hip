@@ -22,8 +22,9 @@ static constexpr int EV_MH_R = BGM_MH_R, EV_MH_WAVES = BGM_MH_WAVES, EV_SPREAD_W
 // doses in registers
 bool bgm_causal_event_wanted(const bgm_handle *h, int effect, int n_doses) {
   static const bool off = std::getenv("BGM_NO_EVENT_SPLIT") != nullptr;      // dev A/B
-  return !off && EV_MH_R == 1 && h->outcome_cache == 2 && effect == BGM_EFFECT_ADRF &&
-         n_doses >= 1 && (n_doses + 3) / 4 <= EV_NCMAX;
+  if (off || EV_MH_R != 1 || h->outcome_cache != 2) return false;
+  if (effect == BGM_EFFECT_ITE) return h->cfg.binary_treatment != 0;         // the two arms of a binary treatment (round 6)
+  return effect == BGM_EFFECT_ADRF && n_doses >= 1 && (n_doses + 3) / 4 <= EV_NCMAX;
 }
 
 template <class T>
@@ -120,13 +121,39 @@ int bgm_causal_event_mh_launch(bgm_handle *h, CausalMhKArgs &ka, int grid, int l
 }
 
 // outcome net on the segment's events, then the spread over its retained iterations
-int bgm_causal_event_finish(bgm_handle *h, const CausalMhKArgs &ka, int grid, int first, hipStream_t stream) {
+int bgm_causal_event_finish(bgm_handle *h, const CausalMhKArgs &ka, int grid, int first, hipStream_t stream, int effect) {
   CausalEventFArgs fa{};
   fa.blob = ka.blob; fa.ev_z = h->ev_z; fa.slot_cnt = h->ev_slot_cnt; fa.ev_cap = ka.ev_cap; fa.n_doses = ka.n_doses;
   fa.x_values = ka.x_values; fa.ev_out = reinterpret_cast<float2 *>(h->ev_out); fa.eff_stats = ka.eff_stats; fa.m = ka.m;
   int rc = BGM_E_UNSUPPORTED;
   bool done = false;
   constexpr int FW = 4, WPS = 2;       // waves per workgroup, waves per sampler slot
+  if (effect == BGM_EFFECT_ITE) {      // binary treatment: the two arms per event, then one thread per chain (causal_event_kernels.h)
+#define X(KT1_, KSL1_)                                                                         \
+    if (!done && h->KT1 == KT1_ && h->KSL1 == KSL1_) {                                         \
+      const int lds = 4 * (16 * KT1_ * 64 + 64 + 64 * 32 + 32 + 32 * 16 + 16 + 16 * 16 + 16 + 64); \
+      auto k = causal_event_f_ite_kernel<KT1_, KSL1_, FW, WPS>;                                \
+      if ((rc = ev_set_lds(k, lds))) return rc;                                                \
+      hipLaunchKernelGGL(k, dim3(grid * EV_MH_WAVES * WPS / FW), dim3(64 * FW), lds, stream, fa); \
+      BGM_HIP_CHECK(hipGetLastError());                                                        \
+      done = true;                                                                             \
+    }
+    X(1, 3) X(2, 1)
+#undef X
+    if (!done) { bgm_set_error("no compiled outcome-net kernel for this shape (event form, binary treatment)"); return BGM_E_UNSUPPORTED; }
+    CausalEventIteArgs ia{};
+    ia.n = ka.n; ia.row_base = ka.row_base; ia.it_begin = ka.it_begin; ia.n_iters = ka.n_iters; ia.burn_in = ka.burn_in; ia.n_keep = ka.n_keep;
+    ia.sample_y = ka.sample_y; ia.n_slots = grid * EV_MH_WAVES; ia.k0 = ka.k0; ia.k1 = ka.k1;
+    ia.ev_meta = h->ev_meta; ia.tile_ev = h->ev_tile; ia.ev_cap = ka.ev_cap; ia.ev_out = reinterpret_cast<const float4 *>(h->ev_out);
+    const size_t carry_floats = (size_t)((ka.n + 15) / 16) * 64 * 2;      // (one Philox call's worth per tile: >= 16 bytes per chain)
+    h->ev_carry_flip = first ? 0 : (h->ev_carry_flip ^ 1);
+    ia.carry_in = reinterpret_cast<const float4 *>(h->ev_carry + (h->ev_carry_flip ^ 1) * carry_floats);
+    ia.carry_out = reinterpret_cast<float4 *>(h->ev_carry + h->ev_carry_flip * carry_floats);
+    ia.first = first; ia.ite = ka.ite;
+    hipLaunchKernelGGL(causal_event_ite_kernel, dim3((unsigned)((ka.n + 255) / 256)), dim3(256), 0, stream, ia);
+    BGM_HIP_CHECK(hipGetLastError());
+    return BGM_OK;
+  }
 #define X(KT1_, KSL1_)                                                                         \
   if (!done && h->KT1 == KT1_ && h->KSL1 == KSL1_) {                                           \
     const int lds = 4 * (16 * KT1_ * 64 + 64 + 64 * 32 + 32 + 32 * 16 + 16 + 16 * 16 + 16 + 64); \

@@ -81,6 +81,100 @@ __global__ __launch_bounds__(64 * WAVES) void causal_event_f_kernel(CausalEventF
   }
 }
 
+// ---- binary treatment: individual treatment effects (round 6).  The same three steps; the outcome net is evaluated at the two arms
+// x = 1, x = 0 of every EVENT (causal_effects<EFFECT = 2> with the noise and the store compiled out: the (mean, sd) pairs the fused
+// kernel forms for that state, bit for bit), 16 bytes per event; the spread is one thread per chain, which walks its tile's events in
+// time order and writes  y(1) - y(0) = fma(sd1, e0, mean1) - fma(sd0, e1, mean0)  of every retained draw with the noise words of
+// Philox(row, iteration, 0, TAG_YNOISE) -- the expression of causal_effects / causal_ite_cached, so the ITE matrix equals the fused
+// kernel's to the last bit.  replaces: infer_from_latent_posterior's binary branch, causalbgm/base.py:686-733.
+template <int KT1, int KSL1, int WAVES, int WPS>
+__global__ __launch_bounds__(64 * WAVES) void causal_event_f_ite_kernel(CausalEventFArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  CausalMeta m = a.m;
+  {
+    int off = 0;
+    auto put = [&](int src, int nfl) {
+      for (int i = threadIdx.x; i < nfl; i += 64 * WAVES) lds[off + i] = a.blob[src + i];
+      const int o = off;
+      off += nfl;
+      return o;
+    };
+    m.w1f = put(a.m.w1f, 16 * KT1 * 64); m.b1f = put(a.m.b1f, 64);
+    m.wf2 = put(a.m.wf2, 64 * 32); m.bf2 = put(a.m.bf2, 32); m.wf3 = put(a.m.wf3, 32 * 16); m.bf3 = put(a.m.bf3, 16);
+    m.wf4 = put(a.m.wf4, 16 * 16); m.bf4 = put(a.m.bf4, 16); m.wxf = put(a.m.wxf, 64);
+    __syncthreads();
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4, lane_off = 64 * g + j;
+  const long long wid = (long long)blockIdx.x * WAVES + wave;
+  const long long slot = wid / WPS;
+  const int sub = (int)(wid % WPS);
+  const int cnt = a.slot_cnt[slot];
+  if (a.eff_stats != nullptr && lane == 0 && sub == 0 && cnt > 0) atomicAdd(&a.eff_stats[1], (unsigned long long)cnt);
+  float4 *out4 = reinterpret_cast<float4 *>(a.ev_out);
+  for (int e0 = 16 * sub; e0 < cnt; e0 += 16 * WPS) {
+    BGM_NO_HOIST();
+    const int el = (e0 + j < cnt) ? e0 + j : cnt - 1;
+    const float *zr = a.ev_z + (slot * a.ev_cap + el) * (long long)m.q;
+    f32x4 zs[1][KT1];
+#pragma unroll
+    for (int t = 0; t < KT1; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = 16 * t + 4 * r + g;
+        zs[0][t][r] = (f < m.q) ? zr[f] : 0.0f;
+      }
+    const unsigned rowid[1] = {0u};
+    const bool valid[1] = {true};
+    float c[4];
+    causal_effects<KT1, KSL1, 1, 2, true, true, true>(lds, m, lane_off, g, j, lane, zs, rowid, valid, 0ll, 16ll, 0u, 0ll, 1, 0, 2,
+                                                      nullptr, nullptr, nullptr, 0u, 0u, nullptr, c);
+    if (g == 0 && e0 + j < cnt) out4[slot * a.ev_cap + e0 + j] = make_float4(c[0], c[1], c[2], c[3]);      // (mean, sd) of arm 1, of arm 0
+  }
+}
+
+struct CausalEventIteArgs {
+  long long n, row_base;
+  int it_begin, n_iters, burn_in, n_keep;
+  int sample_y, n_slots;
+  unsigned k0, k1;
+  const unsigned *ev_meta;
+  const int *tile_ev;
+  long long ev_cap;
+  const float4 *ev_out;              // per event: (mean1, sd1, mean0, sd0)
+  const float4 *carry_in;            // [n]: every chain's pairs at the end of the previous segment of the call
+  float4 *carry_out;
+  int first;
+  float *ite;                        // [n x n_keep]
+};
+
+static __global__ __launch_bounds__(256) void causal_event_ite_kernel(CausalEventIteArgs a) {
+  const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (row >= a.n) return;
+  const long long tile = row >> 4, slot = tile % a.n_slots;      // (the sampler deals tile t to slot t mod n_slots)
+  const int j = (int)(row & 15);
+  const int eb = a.tile_ev[2 * tile], ec = a.tile_ev[2 * tile + 1];
+  const long long base = slot * a.ev_cap + eb;
+  const unsigned rowid = (unsigned)(a.row_base + row);
+  float4 cur = a.first ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : a.carry_in[row];
+  int p = 0;
+  unsigned w = p < ec ? a.ev_meta[base] : 0xFFFFFFFFu;
+  for (int dl = 0; dl < a.n_iters; ++dl) {
+    while (p < ec && (int)(w >> 4) <= dl) {                       // the tile's events up to this iteration, in time order
+      if ((int)(w & 15u) == j) cur = a.ev_out[base + p];
+      ++p;
+      w = p < ec ? a.ev_meta[base + p] : 0xFFFFFFFFu;
+    }
+    const unsigned it = (unsigned)(a.it_begin + dl);
+    f32x4 nz = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (a.sample_y) nz = box_muller4(philox4x32_10(rowid, it, 0u, TAG_YNOISE, a.k0, a.k1));
+    const float y1 = a.sample_y ? fmaf(cur.y, nz[0], cur.x) : cur.x;
+    const float y0 = a.sample_y ? fmaf(cur.w, nz[1], cur.z) : cur.z;
+    a.ite[row * (long long)a.n_keep + ((long long)it - a.burn_in)] = y1 - y0;
+  }
+  a.carry_out[row] = cur;
+}
+
 struct CausalEventSpreadArgs {
   long long n, row_base;
   int it_begin, n_iters, burn_in, n_keep;

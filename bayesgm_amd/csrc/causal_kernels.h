@@ -610,6 +610,7 @@ __device__ __forceinline__ void causal_effects(const float *lds, const CausalMet
         if constexpr (CACHE && EFFECT == 2 && R == 1) { ite_c[2 * e] = mu[e * R + rr]; ite_c[2 * e + 1] = sd; }
         yk[e][rr] = sample_y ? fmaf(sd, nz[rr][e], mu[e * R + rr]) : mu[e * R + rr];
       }
+    if constexpr (EVAL_ONLY) continue;             // (causal_event_f_ite_kernel: the two arms' (mean, sd) in ite_c are all that is wanted)
     if constexpr (EFFECT == 1) {
 #pragma unroll
       for (int e = 0; e < DB; ++e) {

@@ -49,6 +49,9 @@ def _disc_norm(p):
     mode = p.get("disc_norm", DISC_NORM_DEFAULT)
     if mode not in ("batch", "fixed"):
         raise ValueError("params['disc_norm'] must be 'batch' or 'fixed'")
+    if "disc_norm" not in p and mode != "batch":      # a default that is not the reference as written: said once per process
+        diagnostics.notice_once("disc_norm", "params['disc_norm'] not given: the EGM discriminators normalise in inference mode ('fixed'); "
+                                "'batch' runs their BatchNormalization on batch statistics as networks/base.py:364-379 reads (DESIGN_HISTORY.md section 2b)")
     return mode
 
 

@@ -50,6 +50,10 @@ class CausalBGMBayes(CausalBGM):
             if k in params and not float(params[k]) > 0.0:
                 raise ValueError("params['%s'] must be positive" % k)
         self._bnn_norm = p.get("bnn_norm", BNN_NORM_DEFAULT)
+        if "bnn_norm" not in p and self._bnn_norm != "batch":      # a default that is not the reference as written: said once per process
+            diagnostics.notice_once("bnn_norm", "params['bnn_norm'] not given: the Bayesian nets' input BatchNormalization runs in inference mode "
+                                    "('fixed': the mode that reproduces the published tutorial trace); 'batch' = batch statistics, as "
+                                    "networks/bnn.py:25-27 reads (DESIGN_HISTORY.md section 2b)")
         if self._bnn_norm not in ("batch", "fixed"):
             raise ValueError("params['bnn_norm'] must be 'batch' or 'fixed'")
         if self._bnn_norm == "batch":

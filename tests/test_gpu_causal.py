@@ -384,21 +384,66 @@ def test_outcome_cache_is_bit_identical(precision):
 
 
 def test_outcome_cache_binary_treatment_is_bit_identical():
-    """The same for the individual treatment effects of a binary treatment (causal_ite_cached: the two arms' (mean, sd) in registers)."""
+    """The same for the individual treatment effects of a binary treatment: per wave (causal_ite_cached: the two arms' (mean, sd) in
+    registers) and per chain (the event form of the retained phase, below)."""
     from bayesgm_amd import _lib
     m = _model(13, [3, 3, 6, 6], 100, True)
     x, y, v = _data(2000, 100, 14, True)
     eng = _engine(m)
     res = {}
-    for on in (True, False):
+    for on in ("wave", True, False):
         eng.set_outcome_cache(on)
         eng.outcome_cache_stats(reset=True)
         out = eng.mh_sample(x, y, v, 30, 50, 1.0, 9, effect=_lib.EFFECT_ITE)
         res[on] = (out["ite"].cpu().numpy(), eng.outcome_cache_stats())
     eng.set_outcome_cache(True)
-    print("served from cache: %d of %d" % res[True][1])
-    assert res[True][1][1] == 125 * 50 and res[True][1][0] > 0 and res[False][1][0] == 0
-    assert np.array_equal(res[True][0], res[False][0])
+    print("served from cache: per wave %d of %d tile-iterations, per chain %d of %d chain-iterations" % (res["wave"][1] + res[True][1]))
+    assert res["wave"][1][1] == 125 * 50 and res["wave"][1][0] > 0 and res[False][1][0] == 0
+    assert res[True][1][1] == 2000 * 50 and res[True][1][0] > 0.8 * 2000 * 50
+    assert np.array_equal(res["wave"][0], res[False][0]) and np.array_equal(res[True][0], res[False][0])
+
+
+@pytest.mark.parametrize("case", [dict(z_dims=[3, 3, 6, 6], p=100, n=2500), dict(z_dims=[1, 1, 1, 7], p=200, n=1000),
+                                  dict(z_dims=[3, 3, 6, 6], p=100, n=777, sample_y=False), dict(z_dims=[1, 1, 1, 7], p=20, n=40000)])
+def test_event_form_for_binary_treatment_is_bit_identical(case):
+    """Outcome cache mode 2 with a binary treatment (round 6; csrc/causal_event_kernels.h): transitions that append an event per accepted
+    move, the outcome net at the two arms on dense 16-event tiles, one thread per chain writing y(1) - y(0) of every retained draw.
+    Against the fused kernel with both arms evaluated at every retained draw (mode 0), same Philox streams: the ITE matrix, chains,
+    acceptance counts are equal to the last bit -- in one segment, in several (a small event budget), and with the retained phase split
+    over several calls; the ITE draws equal the float64 restatement of infer_from_latent_posterior on the same latent draws.
+    reference: causalbgm/base.py:686-733, 860-899."""
+    from bayesgm_amd import _lib
+    m = _model(31, case["z_dims"], case["p"], True)
+    x, y, v = _data(case["n"], case["p"], 32, True)
+    kw = dict(effect=_lib.EFFECT_ITE, sample_y=case.get("sample_y", True), want_draws=True)
+    eng = _engine(m)
+    eng.set_outcome_cache(False)
+    ref = eng.mh_sample(x, y, v, 25, 70, 1.0, 5, **kw)
+    eng.set_outcome_cache(True)
+    eng.outcome_cache_stats(reset=True)
+    got = eng.mh_sample(x, y, v, 25, 70, 1.0, 5, **kw)
+    served, total = eng.outcome_cache_stats()
+    assert total == case["n"] * 70                                         # chain-iterations: the event form ran
+    events = total - served
+    assert events == int(got["acc_count"].cpu().numpy()[26:].sum()) + case["n"]
+    print("event form, binary: %d of %d retained chain-iterations without an outcome-net evaluation" % (served, total))
+    for k in ("ite", "draws", "acc_count", "state", "logp"):
+        assert np.array_equal(got[k].cpu().numpy(), ref[k].cpu().numpy()), k
+    if case["n"] <= 1000:
+        oref = OC.infer_from_latent_posterior(OC.cast_model(m, np.float64), got["draws"].cpu().numpy().astype(np.float64), None,
+                                              case.get("sample_y", True), 5, burn_in=25)
+        assert np.abs(got["ite"].cpu().numpy() - np.asarray(oref).T).max() <= 5e-4
+    n_slots = eng.mh_slots(case["n"])
+    tiles = (case["n"] + 15) // 16
+    per_iter = n_slots * ((tiles + n_slots - 1) // n_slots) * 16 * (4 * sum(case["z_dims"]) + 4 + 32)
+    fixed = 2 * tiles * 64 * 2 * 4 + tiles * 8 + n_slots * 4
+    eng.set_event_budget(fixed + 9 * per_iter + 100)
+    seg = eng.mh_sample(x, y, v, 25, 70, 1.0, 5, **kw)
+    chunked = eng.mh_sample(x, y, v, 25, 70, 1.0, 5, chunk=30, **kw)
+    eng.set_event_budget(0)
+    for other in (seg, chunked):
+        for k in ("ite", "draws", "acc_count", "state"):
+            assert np.array_equal(other[k].cpu().numpy(), ref[k].cpu().numpy()), k
 
 
 @pytest.mark.parametrize("case", [dict(z_dims=[1, 1, 1, 7], p=200, n=3000, doses=20), dict(z_dims=[1, 1, 1, 7], p=200, n=1000, doses=7),
