@@ -925,6 +925,7 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the legs of the other BASELINE configurations (C1 binary treatment, C4 one-GPU share) and the encoder leg (N=1 only)")
     ap.add_argument("--no-c4-f16x3", action="store_true", help="skip the split-precision run of the C4 share")
     ap.add_argument("--c4-bnn", action="store_true", help="also run the C4 share with the Bayesian generator (use_bnn=True, ~100 s)")
+    ap.add_argument("--fit-dp-timeout", type=int, default=240, help="seconds the N>1 fit_dp leg may take before the line is printed without it")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="launch / rendezvous check without a device: every rank joins the process group over gloo on the CPU, the rank "
                          "count is all-reduced and rank 0 prints {n_gpus, n_ranks_in_collective}; no kernel runs (tests/test_bench_launch.py)")
@@ -1055,13 +1056,7 @@ def main():
         for line in paths:
             print(line, file=sys.stderr)
 
-    fit_dp = None
-    if world > 1 and not args.no_fit:      # every rank: the data-parallel minibatch loop with its gradient all-reduce (configs[3], fit side)
-        try:
-            fit_dp = fit_dp_leg(model, x, y, v, n_loc, world, device)
-        except Exception as e:             # the headline line must survive a failure here; the failure is reported in it
-            fit_dp = {"error": "%s: %s" % (type(e).__name__, e)}
-
+    out = None
     if rank == 0:
         iters = args.burn_in + args.n_mcmc
         value = n_total * iters * args.steps / elapsed
@@ -1185,13 +1180,33 @@ def main():
                     out["config_c4_share"]["use_bnn"] = config_c4_share_leg(device, use_bnn=True)
         if not args.no_general_width and world == 1:
             out["general_width_engine"] = general_width_leg(p, z_dims, device)
-        if fit_dp is not None:
-            out["fit_dp"] = fit_dp
         if not args.no_fit and world == 1:
             out["fit"] = fit_leg(model, x, y, v, n_loc)
             out["fit_dp"] = fit_dp_leg(model, x, y, v, n_loc, 1, device)      # the data-parallel call on a one-rank communicator
             out["fit_dp"]["vs_single_process_epoch_call"] = out["fit_dp"]["us_per_minibatch"] / out["fit"]["us_per_minibatch"]
             out["training_steps"] = training_leg(params, x, y, v, device)
+    if world > 1 and not args.no_fit:
+        # every rank: the data-parallel minibatch loop with its gradient all-reduce (configs[3], fit side) -- AFTER everything of the
+        # headline is measured, and under a watchdog: this is where the library's own RCCL communicator is created, and the headline
+        # line must survive whatever a first multi-GPU run does here (a failure or a stall is reported in the line, not instead of it)
+        import threading
+        finished = threading.Event()
+
+        def watchdog():
+            if not finished.wait(args.fit_dp_timeout):
+                if rank == 0:
+                    out["fit_dp"] = {"error": "no result within %d s (the numbers above were complete before this leg started)" % args.fit_dp_timeout}
+                    emit(json.dumps(out))
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            fit_dp = fit_dp_leg(model, x, y, v, n_loc, world, device)
+        except Exception as e:
+            fit_dp = {"error": "%s: %s" % (type(e).__name__, e)}
+        finished.set()
+        if rank == 0:
+            out["fit_dp"] = fit_dp
+    if rank == 0:
         emit(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -27,9 +27,18 @@ for w in $WHAT; do
     # the Bayesian default model's sampler + effects kernels at N = 1e6 (item 1)
     bnn) passes bnn_sampling_N1e6 env BNN_PROBE_SAMPLING_ONLY=1 python scripts/probe_bnn.py 1000000 200 5 ;;
     # wide Bayesian nets (item 7: a tracked number for bnw_*)
-    bnw) passes bnw_w128 python scripts/probe_bnw.py 1e5 ;;
+    bnw) passes bnw_wide python scripts/probe_bnw.py 1e5 5 ;;
     # BGM HMC at C4's shape, fp32 and split-precision heads
     hmc) passes bgm_hmc_f16x3 env BGM_PROBE_PRECISION=f16x3 python scripts/probe_bgm_wide.py 2e5 4 ;;
+    # configs[1] through the class (event form of the binary-treatment retained phase): kernel trace only
+    c1)
+      timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/c1_kt -o kt -- python scripts/probe_c1.py > $OUT/c1_kt.log 2>&1 < /dev/null
+      { echo "# rocprofv3 --kernel-trace --stats -- python scripts/probe_c1.py"; grep -E "^\{" $OUT/c1_kt.log | sed 's/^/# /'; summ $OUT/c1_kt; } > $OUT/r06_kernel_trace_config_c1.txt
+      rm -rf $OUT/c1_kt ;;
+    # split-precision heads: waves per block
+    hmcw)
+      for w in 8 12 16; do echo "BGM_X3_WAVES=$w"; BGM_X3_WAVES=$w BGM_PROBE_PRECISION=f16x3 python scripts/probe_bgm_wide.py 2e5 4; done > $OUT/r06_bgm_hmc_f16x3_waves.txt 2>&1
+      python scripts/probe_bgm_wide.py 2e5 4 >> $OUT/r06_bgm_hmc_f16x3_waves.txt 2>&1 ;;
     bench)
       timeout 1500 rocprofv3 --kernel-trace --stats -d $OUT/kt_bench -o kt -- python bench.py > $OUT/kt_bench.log 2>&1 < /dev/null
       { echo "# rocprofv3 --kernel-trace --stats -- python bench.py   (the default invocation)"; summ $OUT/kt_bench; } > $OUT/r06_kernel_trace_bench_N1e6.txt
