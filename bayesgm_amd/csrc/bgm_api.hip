@@ -14,7 +14,7 @@ static constexpr int BGM_WAVES = 8;
 #define BGM_WAVES_WIDE_HMC 12   // 148 VGPRs -> 3 waves/SIMD; measured 89 vs 86 (8) vs 86 (16) TF at p=500
 #endif
 #ifndef BGM_X3_WAVES_DEFAULT
-#define BGM_X3_WAVES_DEFAULT 8
+#define BGM_X3_WAVES_DEFAULT 12      // 4.54 / 4.24 / 4.25 ms per transition at 8 / 12 / 16 waves (N = 2e5, p = 500; profiles/r06_bgm_hmc_f16x3_waves.txt)
 #endif
 static constexpr float BN_EPS_F = 1e-3f;   // keras BatchNormalization default epsilon
 
@@ -121,7 +121,7 @@ static int bgm_build_blob(bgm_handle *h, hipStream_t stream) {
     //   forward f = 2 (2 head + b) + (lo): lane (i, gA), slot u <-> W_head[unit 16 (2 b + (u >> 2)) + 4 gA + (u & 3)][column 16 tx + i]
     //   backward f = 8 + 2 ti + (lo):     lane (i, gA), slot u <-> (u < 4 ? W_mean : W_var)[unit 16 ti + i][column 16 tx + 4 gA + (u & 3)]
     const float *Wm = th + (o - 2 * ((size_t)64 * p + p)), *Wv = Wm + (size_t)64 * p + p;
-    hx3.assign((size_t)NTX * (BGM_X3_BLOCK_BYTES / 2), 0);
+    hx3.assign((size_t)((NTX + BGM_X3_STEP - 1) / BGM_X3_STEP * BGM_X3_STEP) * (BGM_X3_BLOCK_BYTES / 2), 0);      // (whole steps of the stream; padding = zero fragments)
     auto put = [&](size_t base, float w) {      // hi at base, lo one fragment (512 halves) further
       const unsigned short hi = bgm_f2h(w);
       hx3[base] = hi;
@@ -152,7 +152,7 @@ static int bgm_build_blob(bgm_handle *h, hipStream_t stream) {
       s->hx3_cap = hx3.size() * 2;
     }
     BGM_HIP_CHECK(hipMemcpyAsync(s->hx3_dev, hx3.data(), hx3.size() * 2, hipMemcpyHostToDevice, stream));
-    s->lds_bytes_x3 = (m.stage + 2 * (BGM_X3_BLOCK_BYTES / 4)) * 4;
+    s->lds_bytes_x3 = (m.stage + 2 * BGM_X3_STEP * (BGM_X3_BLOCK_BYTES / 4)) * 4;
     if (s->lds_bytes_x3 > 160 * 1024) { bgm_set_error("BGM generator: trunk + head biases + the split-precision stage exceed the 160 KiB LDS"); return BGM_E_UNSUPPORTED; }
   }
   BGM_HIP_CHECK(hipStreamSynchronize(stream));

@@ -200,7 +200,8 @@ __device__ __forceinline__ void bgm_head_tile(const float *wl, const float *lds,
 //   backward  dh(64 units) += Wm dmu + Wv ds:  M = hidden unit, K = 32 = the block's 16 mean + 16 variance outputs, lane group g
 //             supplies k-slot u: u < 4 -> mean output 4 g + u, else variance output 4 g + u - 4: again the lane's own registers.
 // Fragments of a block (packed on the host, bgm_api.hip): 16 x 1 KiB = [fwd: (head, K block, hi | lo)][bwd: (hidden tile, hi | lo)],
-// 64 lanes x 8 halves each, streamed through a double-buffered 2 x 16 KiB LDS stage by the whole block like the fp32 pairs.
+// 64 lanes x 8 halves each, streamed through a double-buffered LDS stage (two blocks = 32 KiB per step and buffer) by the whole block
+// like the fp32 pairs.
 // fp16 range: a weight beyond 65504 is clamped by the packer; dlogp/d(mean, s) beyond 6e4 (a variance ~1e-5 under a unit residual) is
 // clamped in the kernel -- the fp32 kernels have no such bound.
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -227,65 +228,104 @@ __device__ __forceinline__ void bgm_split8(const f32x4 &a, const f32x4 &b, bgm_h
   lo = __builtin_bit_cast(bgm_h8, bgm_u4{l0, l1, l2, l3});
 }
 
+// BGM_X3_STEP head blocks per step of the stream (one barrier per step): with the matrix work of a block down to ~400 cycles a
+// barrier and a fetch per 16 features were what the waves waited for (34 % of the wave cycles parked, r06_pmc_sq_bgm_hmc_f16x3.txt)
+#define BGM_X3_STEP 2
+template <int WAVES>
 struct BgmHeadStreamX3 {
-  const f32x4 *src;      // global: [ntx][BGM_X3_BLOCK_BYTES]
-  unsigned char *buf;    // LDS:    [2][BGM_X3_BLOCK_BYTES]
-  int cur, tid, nthreads;
-  f32x4 r[2];
-  __device__ __forceinline__ void fetch(int tx) {
-    const f32x4 *s = src + (long long)tx * (BGM_X3_BLOCK_BYTES / 16);
+  static constexpr int STEP_VEC = BGM_X3_STEP * BGM_X3_BLOCK_BYTES / 16, NT = 64 * WAVES, K = (STEP_VEC + NT - 1) / NT;
+  const f32x4 *src;      // global: [ntx padded to a multiple of BGM_X3_STEP][BGM_X3_BLOCK_BYTES]
+  unsigned char *buf;    // LDS:    [2][BGM_X3_STEP][BGM_X3_BLOCK_BYTES]
+  int cur, tid;
+  f32x4 r[K];
+  __device__ __forceinline__ void fetch(int step) {      // step = first block / BGM_X3_STEP
+#ifdef BGM_X3_ABL_NOSTREAM
+    return;
+#endif
+    const f32x4 *s = src + (long long)step * STEP_VEC;
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
-      if (tid + k * nthreads < BGM_X3_BLOCK_BYTES / 16) r[k] = s[tid + k * nthreads];
+    for (int k = 0; k < K; ++k)
+      if (K * NT == STEP_VEC || tid + k * NT < STEP_VEC) r[k] = s[tid + k * NT];
   }
   __device__ __forceinline__ void commit() {
-    f32x4 *d = reinterpret_cast<f32x4 *>(buf + (cur ^ 1) * BGM_X3_BLOCK_BYTES);
+#ifdef BGM_X3_ABL_NOSTREAM      // development ablation: no refill of the stage, no barrier (wrong results: timing only)
+    return;
+#endif
+    f32x4 *d = reinterpret_cast<f32x4 *>(buf + (cur ^ 1) * (BGM_X3_STEP * BGM_X3_BLOCK_BYTES));
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
-      if (tid + k * nthreads < BGM_X3_BLOCK_BYTES / 16) d[tid + k * nthreads] = r[k];
+    for (int k = 0; k < K; ++k)
+      if (K * NT == STEP_VEC || tid + k * NT < STEP_VEC) d[tid + k * NT] = r[k];
     __syncthreads();
     cur ^= 1;
   }
-  __device__ __forceinline__ const unsigned char *tile() const { return buf + cur * BGM_X3_BLOCK_BYTES; }
+  __device__ __forceinline__ const unsigned char *tile(int b) const { return buf + (cur * BGM_X3_STEP + b) * BGM_X3_BLOCK_BYTES; }
+  // The data values of a step are requested ONE STEP AHEAD (xn; the first step of an evaluation by the last step of the previous
+  // one: the row does not change within a launch's tile): a block's products are ~200 cycles now, the rows come from HBM (1.25 GB at
+  // C4's share, re-read per evaluation) -- requested at the block's start they were what every block waited for.
+  f32x4 xn[BGM_X3_STEP];
+  bool x_valid;
+  __device__ __forceinline__ void load_x(const float *row, int p, int step, int g, f32x4 (&dst)[BGM_X3_STEP]) const {
+#pragma unroll
+    for (int b = 0; b < BGM_X3_STEP; ++b) {
+      const int c = 16 * (BGM_X3_STEP * step + b) + 4 * g;
+      if ((p & 3) == 0) {               // (rows are 16-byte aligned: one request per block and lane)
+        dst[b] = (c < p) ? *reinterpret_cast<const f32x4 *>(row + c) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[b][r] = (c + r < p) ? row[c + r] : 0.0f;
+      }
+    }
+  }
   __device__ __forceinline__ void begin(const unsigned char *frags, const BgmMeta &m, float *lds) {
-    src = reinterpret_cast<const f32x4 *>(frags); buf = reinterpret_cast<unsigned char *>(lds + m.stage); tid = threadIdx.x; nthreads = blockDim.x;
-    cur = 1;
+    src = reinterpret_cast<const f32x4 *>(frags); buf = reinterpret_cast<unsigned char *>(lds + m.stage); tid = threadIdx.x;
+    cur = 1; x_valid = false;
     fetch(0);
     commit();
   }
 };
 
-// one 16-feature head block in split precision.  hh / hl: the trunk output split into its two K blocks (once per evaluation).
-template <bool WANT_GRAD>
-__device__ __forceinline__ void bgm_head_tile_x3(const unsigned char *tile, const float *lds, const BgmMeta &m, int tx, int lane, int g,
-                                                 const bgm_h8 (&hh)[2], const bgm_h8 (&hl)[2], const f32x4 &xv, bool want_lp, float &nll,
-                                                 f32x4 (&dh)[4]) {
+// One 16-feature head block in split precision, in three parts so that a step of the stream (BGM_X3_STEP blocks) can be issued as
+// fwd(0), fwd(1), epilogue(0), bwd(0), epilogue(1), bwd(1): the likelihood arithmetic of one block (~140 VALU instructions, six of
+// them transcendental) then sits under the matrix instructions of the other instead of between its own two products.  All waves of
+// a workgroup are in phase (one barrier per step), so without this every wave of a SIMD wants the matrix pipe, then the VALU, at the same time.
+// hh / hl: the trunk output split into its two K blocks (once per evaluation).
+__device__ __forceinline__ void bgm_x3_fwd(const unsigned char *tile, const float *lds, const BgmMeta &m, int tx, int lane, int g,
+                                           const bgm_h8 (&hh)[2], const bgm_h8 (&hl)[2], f32x4 (&part)[4]) {
   const bgm_h8 *fr = reinterpret_cast<const bgm_h8 *>(tile) + lane;      // fragment f at fr[64 f]
-  f32x4 ms[2];
-  ms[0] = *reinterpret_cast<const f32x4 *>(lds + m.bhd + 16 * tx + 4 * g);
-  ms[1] = *reinterpret_cast<const f32x4 *>(lds + m.bhd + 16 * (m.ntx + tx) + 4 * g);
-  {
-    bgm_h8 ah[4], al[4];      // (head, K block) = 0 .. 3
+  const int tb = tx < m.ntx ? tx : m.ntx - 1;                             // (a padding block behind an odd block count reads the last bias)
+  // (head, K block) = four INDEPENDENT accumulator chains of three products each, issued round-robin: a product never follows
+  // its own accumulator's previous one (the K blocks are summed in the epilogue: 8 additions)
+  bgm_h8 ah[4], al[4];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) { ah[f] = fr[64 * (2 * f)]; al[f] = fr[64 * (2 * f + 1)]; }
+  for (int f = 0; f < 4; ++f) { ah[f] = fr[64 * (2 * f)]; al[f] = fr[64 * (2 * f + 1)]; }
+  part[0] = *reinterpret_cast<const f32x4 *>(lds + m.bhd + 16 * tb + 4 * g);
+  part[2] = *reinterpret_cast<const f32x4 *>(lds + m.bhd + 16 * (m.ntx + tb) + 4 * g);
+  part[1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; part[3] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int f = 0; f < 4; ++f) ms[f >> 1] = BGM_MFMA_H(al[f], hh[f & 1], ms[f >> 1]);
+  for (int f = 0; f < 4; ++f) part[f] = BGM_MFMA_H(al[f], hh[f & 1], part[f]);
 #pragma unroll
-    for (int f = 0; f < 4; ++f) ms[f >> 1] = BGM_MFMA_H(ah[f], hl[f & 1], ms[f >> 1]);
+  for (int f = 0; f < 4; ++f) part[f] = BGM_MFMA_H(ah[f], hl[f & 1], part[f]);
 #pragma unroll
-    for (int f = 0; f < 4; ++f) ms[f >> 1] = BGM_MFMA_H(ah[f], hh[f & 1], ms[f >> 1]);
-  }
+  for (int f = 0; f < 4; ++f) part[f] = BGM_MFMA_H(ah[f], hh[f & 1], part[f]);
+}
+template <bool WANT_GRAD>
+__device__ __forceinline__ void bgm_x3_epilogue(const BgmMeta &m, int tx, int g, const f32x4 (&part)[4], const f32x4 &xv, bool want_lp,
+                                                float &nll, bgm_h8 &dhi, bgm_h8 &dlo) {
   f32x4 dms[2];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const float x_ = xv[r], s_ = ms[1][r];
-    const bool obs = (x_ == x_) && (16 * tx + 4 * g + r < m.p);   // NaN = missing
+    const float x_ = xv[r], mu_ = part[0][r] + part[1][r], s_ = part[2][r] + part[3][r];
+#ifdef BGM_X3_ABL_NOEPI         // development ablation: the likelihood arithmetic replaced by two subtractions (timing only)
+    dms[0][r] = x_ - mu_; dms[1][r] = s_ - x_; nll += mu_;
+    continue;
+#endif
+    const bool obs = (x_ == x_) && (16 * tx + 4 * g + r < m.p);   // NaN = missing; padding columns / blocks are never observed
     // softplus and its derivative from ONE exponential: e = exp(-|s|), softplus = max(s, 0) + log1p(e), sigmoid = (s >= 0 ? 1 : e) / (1 + e)
     const float e = fast_exp(-fabsf(s_));
     const float l1p = (e < 2.44140625e-4f) ? e * (1.0f - 0.5f * e) : fast_log(1.0f + e);
     const float s2 = vmax(s_, 0.0f) + l1p + BGM_EPS;
     const float inv = fast_rcp(s2);
-    const float d = obs ? x_ - ms[0][r] : 0.0f;
+    const float d = obs ? x_ - mu_ : 0.0f;
     if (want_lp) nll += obs ? 0.5f * (d * d * inv + fast_log(s2)) : 0.0f;
     if (WANT_GRAD) {
       const float sg = (s_ >= 0.0f ? 1.0f : e) * fast_rcp(1.0f + e);
@@ -294,19 +334,19 @@ __device__ __forceinline__ void bgm_head_tile_x3(const unsigned char *tile, cons
       dms[1][r] = obs ? __builtin_amdgcn_fmed3f((0.5f * di * di - 0.5f * inv) * sg, -6.0e4f, 6.0e4f) : 0.0f;   // dlogp/ds
     }
   }
-  if (WANT_GRAD) {
-    bgm_h8 dhi, dlo;
-    bgm_split8(dms[0], dms[1], dhi, dlo);
-    bgm_h8 ah[4], al[4];      // hidden tile ti
+  if (WANT_GRAD) bgm_split8(dms[0], dms[1], dhi, dlo);
+}
+__device__ __forceinline__ void bgm_x3_bwd(const unsigned char *tile, int lane, const bgm_h8 &dhi, const bgm_h8 &dlo, f32x4 (&dh)[4]) {
+  const bgm_h8 *fr = reinterpret_cast<const bgm_h8 *>(tile) + lane;
+  bgm_h8 ah[4], al[4];      // hidden tile ti
 #pragma unroll
-    for (int ti = 0; ti < 4; ++ti) { ah[ti] = fr[64 * (8 + 2 * ti)]; al[ti] = fr[64 * (9 + 2 * ti)]; }
+  for (int ti = 0; ti < 4; ++ti) { ah[ti] = fr[64 * (8 + 2 * ti)]; al[ti] = fr[64 * (9 + 2 * ti)]; }
 #pragma unroll
-    for (int ti = 0; ti < 4; ++ti) dh[ti] = BGM_MFMA_H(al[ti], dhi, dh[ti]);
+  for (int ti = 0; ti < 4; ++ti) dh[ti] = BGM_MFMA_H(al[ti], dhi, dh[ti]);
 #pragma unroll
-    for (int ti = 0; ti < 4; ++ti) dh[ti] = BGM_MFMA_H(ah[ti], dlo, dh[ti]);
+  for (int ti = 0; ti < 4; ++ti) dh[ti] = BGM_MFMA_H(ah[ti], dlo, dh[ti]);
 #pragma unroll
-    for (int ti = 0; ti < 4; ++ti) dh[ti] = BGM_MFMA_H(ah[ti], dhi, dh[ti]);
-  }
+  for (int ti = 0; ti < 4; ++ti) dh[ti] = BGM_MFMA_H(ah[ti], dhi, dh[ti]);
 }
 
 // log p(z | x_obs) and dlogp/dz for 16 chains held by one wave.
@@ -368,17 +408,28 @@ __device__ __forceinline__ void bgm_logp_grad(const float *lds, const BgmMeta &m
     bgm_split8(h[0], h[1], hh[0], hl[0]);
     bgm_split8(h[2], h[3], hh[1], hl[1]);
     const int lane = 16 * g + j;
+    const int n_steps = (m.ntx + BGM_X3_STEP - 1) / BGM_X3_STEP;
 #pragma unroll 1
-    for (int tx = 0; tx < m.ntx; ++tx) {
+    for (int st = 0; st < n_steps; ++st) {
       BGM_NO_HOIST();
-      hs.fetch(tx + 1 < m.ntx ? tx + 1 : 0);
-      f32x4 xv;
+      hs.fetch(st + 1 < n_steps ? st + 1 : 0);
+      // the step's blocks as one straight-line region: forward products of every block first, then per block its likelihood
+      // arithmetic (under the products still in flight) and its backward products (an odd block count ends on a padding block of
+      // zero fragments whose columns are never observed: it contributes exact zeros)
+      f32x4 xv[BGM_X3_STEP], part[BGM_X3_STEP][4];
+      if (!hs.x_valid) { hs.load_x(xs.row, m.p, st, g, hs.xn); hs.x_valid = true; }      // (the first evaluation of a tile only)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int c = 16 * tx + 4 * g + r;
-        xv[r] = (c < m.p) ? xs.row[c] : 0.0f;
+      for (int b = 0; b < BGM_X3_STEP; ++b) xv[b] = hs.xn[b];
+      hs.load_x(xs.row, m.p, st + 1 < n_steps ? st + 1 : 0, g, hs.xn);
+      asm volatile("" ::: "memory");      // (hipcc sinks a load to just above its first use: the request stays here, a step ahead)
+#pragma unroll
+      for (int b = 0; b < BGM_X3_STEP; ++b) bgm_x3_fwd(hs.tile(b), lds, m, BGM_X3_STEP * st + b, lane, g, hh, hl, part[b]);
+#pragma unroll
+      for (int b = 0; b < BGM_X3_STEP; ++b) {
+        bgm_h8 dhi, dlo;
+        bgm_x3_epilogue<WANT_GRAD>(m, BGM_X3_STEP * st + b, g, part[b], xv[b], want_lp, nll, dhi, dlo);
+        if (WANT_GRAD) bgm_x3_bwd(hs.tile(b), lane, dhi, dlo, dh);
       }
-      bgm_head_tile_x3<WANT_GRAD>(hs.tile(), lds, m, tx, lane, g, hh, hl, xv, want_lp, nll, dh);
       hs.commit();
     }
   } else {
@@ -472,8 +523,8 @@ __device__ __forceinline__ void bgm_store_z(float *z, int q, long long row, int 
     }
 }
 
-template <int PREC> struct bgm_stream_of { typedef BgmHeadStream type; };
-template <> struct bgm_stream_of<1> { typedef BgmHeadStreamX3 type; };
+template <int PREC, int WAVES> struct bgm_stream_of { typedef BgmHeadStream type; };
+template <int WAVES> struct bgm_stream_of<1, WAVES> { typedef BgmHeadStreamX3<WAVES> type; };
 
 // get_log_posterior (+ optional gradient) for n rows
 template <int KTQ, int NTX, int NH, int WAVES, int PREC = 0>
@@ -483,7 +534,7 @@ __global__ __launch_bounds__(64 * WAVES) void bgm_logpost_kernel(const float *bl
   extern __shared__ __attribute__((aligned(16))) float lds[];
   lds_fill(lds, blob, m.lds_resident);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
-  using HS = typename bgm_stream_of<PREC>::type;
+  using HS = typename bgm_stream_of<PREC, WAVES>::type;
   HS hs;
   if constexpr (PREC == 1) hs.begin(hx3, m, lds);
   else if constexpr (NTX == 0) hs.begin(blob, m, lds);
@@ -500,6 +551,7 @@ __global__ __launch_bounds__(64 * WAVES) void bgm_logpost_kernel(const float *bl
     BgmX<NTX> xr;
     f32x4 zr[KTQ], gr[KTQ];
     bgm_load_x<NTX>(x, n, m.p, row, g, xr);
+    if constexpr (PREC == 1) hs.x_valid = false;       // (a new row: nothing of it has been requested ahead)
     bgm_load_z<KTQ>(z, m.q, row, g, zr);
     float lp;
     if (grad_out != nullptr) bgm_logp_grad<KTQ, NTX, NH, true, PREC, HS>(lds, m, j, g, zr, xr, hs, lp, gr);
@@ -535,7 +587,7 @@ __global__ __launch_bounds__(64 * WAVES) void bgm_hmc_kernel(BgmHmcKArgs a) {
   const BgmMeta &m = a.m;
   lds_fill(lds, a.blob, m.lds_resident);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
-  using HS = typename bgm_stream_of<PREC>::type;
+  using HS = typename bgm_stream_of<PREC, WAVES>::type;
   HS hs;
   if constexpr (PREC == 1) hs.begin(a.hx3, m, lds);
   else if constexpr (NTX == 0) hs.begin(a.blob, m, lds);
@@ -551,8 +603,9 @@ __global__ __launch_bounds__(64 * WAVES) void bgm_hmc_kernel(BgmHmcKArgs a) {
     if constexpr (NTX == 0) {
       if (!tile_ok) {
         const int evals = (a.init ? 1 : 0) + a.n_iters * a.n_leapfrog;
+        const int n_steps = PREC == 1 ? (m.ntx + BGM_X3_STEP - 1) / BGM_X3_STEP : m.ntx;      // (steps of the head stream per evaluation)
         for (int e = 0; e < evals; ++e)
-          for (int tx = 0; tx < m.ntx; ++tx) { hs.fetch(tx + 1 < m.ntx ? tx + 1 : 0); hs.commit(); }
+          for (int tx = 0; tx < n_steps; ++tx) { hs.fetch(tx + 1 < n_steps ? tx + 1 : 0); hs.commit(); }
         continue;
       }
     }
@@ -564,6 +617,7 @@ __global__ __launch_bounds__(64 * WAVES) void bgm_hmc_kernel(BgmHmcKArgs a) {
     BgmX<NTX> xr;
     f32x4 z[KTQ], gr[KTQ];
     bgm_load_x<NTX>(a.x, n, m.p, row, g, xr);
+    if constexpr (PREC == 1) hs.x_valid = false;       // (a new row: nothing of it has been requested ahead)
     float lp;
     if (a.init) {   // initial_state ~ N(0,1)  (bgm/base.py:778), RNG tag 0
 #pragma unroll

@@ -69,6 +69,8 @@ int bgm_causal_event_plan(bgm_handle *h, long long n, int n_slots, int n_doses, 
   long long S = (budget - fixed) / std::max(1ll, per_iter);
   if (S < 1) return 1;
   S = std::min<long long>(S, n_iters);
+  S = std::min<long long>(S, 128);      // (a longer segment saves nothing: three launches and one re-read of the panel per segment are ~1e-4 of its
+                                         //  cost by then -- and a small panel would otherwise reserve the whole 8 GiB: hipMalloc of gigabytes is not free)
   S = std::min<long long>(S, (1ll << 27) / std::max(1ll, tps * 16));      // event indices of a slot stay far inside 32 bits
   S = std::min<long long>(S, std::max(1, EV_SPREAD_LDS_FLOATS / std::max(1, n_doses)));      // the spread pass keeps [S][n_doses] sums in LDS
   S = std::max(1ll, S);

@@ -557,15 +557,18 @@ def config_c1_leg(device, n=100000, p=100, burn_in=5000, n_mcmc=3000):
     m = CausalBGM(params, timestamp="bench_c1", random_seed=0, device=device.index)
     data = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in (xb, y, v))
     m.predict(data, alpha=0.01, n_mcmc=4, burn_in=4, verbose=0)
-    times = {}
+    times, first_call = {}, {}
     res = {}
-    for mode in (True, False):      # product default, then the outcome net at every retained draw (the reference's work)
-        m.engine.set_outcome_cache(mode)
+    for mode in (True, True, False, False):      # product default, then the outcome net at every retained draw (the reference's work);
+        m.engine.set_outcome_cache(mode)         # each twice: the first call of a mode sizes its buffers, the second is what is reported
         m.engine.outcome_cache_stats(reset=True)
         m._seed_counter = 0
         torch.cuda.synchronize(); t0 = time.perf_counter()
         ite, interval = m.predict(data, alpha=0.01, n_mcmc=n_mcmc, burn_in=burn_in, verbose=0)
-        torch.cuda.synchronize(); times[mode] = time.perf_counter() - t0
+        torch.cuda.synchronize(); dt_ = time.perf_counter() - t0
+        if mode in times:
+            first_call[mode] = times[mode]
+        times[mode] = dt_
         res[mode] = (np.asarray(ite), np.asarray(interval), m.engine.outcome_cache_stats(reset=True))
     m.engine.set_outcome_cache(True)
     macs = (sum(z_dims) * 64 + 4 * 4096 + 64 * (p + 1)) + ((z_dims[0] + z_dims[1] + 1) * 64 + 2048 + 256 + 16) + ((z_dims[0] + z_dims[2]) * 64 + 2048 + 256 + 16)
@@ -573,6 +576,7 @@ def config_c1_leg(device, n=100000, p=100, burn_in=5000, n_mcmc=3000):
     served, total = res[True][2]
     return {"workload": f"CausalBGM.predict binary treatment, N={n}, p={p}, z_dims {z_dims}, burn_in={burn_in}, n_mcmc={n_mcmc}, ITE + per-row intervals, product defaults",
             "predict_seconds": dt, "value": n * (burn_in + n_mcmc) / dt, "unit": "MH transitions/s", "predict_seconds_cache_off": times[False],
+            "predict_seconds_first_call": first_call.get(True), "predict_seconds_cache_off_first_call": first_call.get(False),
             "tflops_algorithmic_transitions": 2 * macs * n * (burn_in + n_mcmc) / dt / 1e12,
             "frac_of_fp32_mfma_peak_transitions_only": 2 * macs * n * (burn_in + n_mcmc) / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             "acceptance_rate": m.last_acceptance_rate, "ate": float(res[True][0].mean()), "shapes": [list(res[True][0].shape), list(res[True][1].shape)],
