@@ -13,8 +13,8 @@ static constexpr int BGM_WAVES = 8;
 #ifndef BGM_WAVES_WIDE_HMC
 #define BGM_WAVES_WIDE_HMC 12   // 148 VGPRs -> 3 waves/SIMD; measured 89 vs 86 (8) vs 86 (16) TF at p=500
 #endif
-#ifndef BGM_X3_WAVES_DEFAULT
-#define BGM_X3_WAVES_DEFAULT 12      // 4.54 / 4.24 / 4.25 ms per transition at 8 / 12 / 16 waves (N = 2e5, p = 500; profiles/r06_bgm_hmc_f16x3_waves.txt)
+#ifndef BGM_SX3_WAVES_DEFAULT
+#define BGM_SX3_WAVES_DEFAULT 12      // ms per transition at N = 2e5, p = 500: 3.80 (8 waves, no spill) / 3.62 (12 waves, 168 registers); two 6-wave workgroups per CU: 5.8
 #endif
 static constexpr float BN_EPS_F = 1e-3f;   // keras BatchNormalization default epsilon
 
@@ -24,7 +24,8 @@ void bgm_bgm_free_state(bgm_handle *h) {
   bgm_bgm_fit_free(h);
   gxb_free(s);
   if (s->blob_dev) hipFree(s->blob_dev);
-  if (s->hx3_dev) hipFree(s->hx3_dev);
+  if (s->sx3_dev) hipFree(s->sx3_dev);
+  if (s->sx3_bias_dev) hipFree(s->sx3_bias_dev);
   delete s;
   h->bgm_state = nullptr;
 }
@@ -146,14 +147,79 @@ static int bgm_build_blob(bgm_handle *h, hipStream_t stream) {
         }
       }
     }
-    if (s->hx3_cap < hx3.size() * 2) {
-      if (s->hx3_dev) BGM_HIP_CHECK(hipFree(s->hx3_dev));
-      BGM_HIP_CHECK(hipMalloc((void **)&s->hx3_dev, hx3.size() * 2));
-      s->hx3_cap = hx3.size() * 2;
+    // ---- the stream: steps of BGM_X3_STEP units of 16 KiB, the head blocks above in the middle; unit layouts (64 lanes x 8 halves per fragment, hi at an
+    //      even fragment index, lo behind it):
+    //   L1      f = 2 mt (+1): lane (i, gA), slot u < 4 <-> W1'[latent 4 u + gA][unit 16 mt + i] (BatchNorm folded in, as in the fp32 blob), u >= 4: 0;
+    //           f = 8 + 2 b (+1), the transposed copy: lane (i, gA), slot u <-> W1'[latent 4 (i % 4) + i / 4][unit 16 (2 b + (u >> 2)) + 4 gA + (u & 3)]
+    //   hidden  forward  f = 2 (2 mt + b) (+1): lane (i, gA), slot u <-> W[unit 16 (2 b + (u >> 2)) + 4 gA + (u & 3)][unit 16 mt + i]
+    //           backward f = 2 (2 ti + b) (+1): lane (i, gA), slot u <-> W[unit 16 ti + i][unit 16 (2 b + (u >> 2)) + 4 gA + (u & 3)]
+    //   heads   the 16 KiB blocks above, BGM_X3_STEP per step
+    if (KTQ != 1) { bgm_set_error("BGM generator: split precision serves z_dim <= 16"); return BGM_E_UNSUPPORTED; }
+    {
+      const int S = (NTX + BGM_X3_STEP - 1) / BGM_X3_STEP, n_steps = 2 * NH + S;
+      const size_t step_h = (size_t)BGM_X3_STEP * (BGM_X3_BLOCK_BYTES / 2);      // halves per step
+      std::vector<unsigned short> sx((size_t)n_steps * step_h, 0);
+      auto put2 = [&](size_t step, int frag, int lane, int u, float w) {
+        const size_t base = step * step_h + (size_t)frag * 512 + (size_t)lane * 8 + u;
+        const unsigned short hi = bgm_f2h(w);
+        sx[base] = hi;
+        sx[base + 512] = bgm_f2h(w - bgm_h2f(hi));
+      };
+      const float *Wh = th + 4 * (size_t)q + (size_t)q * 64 + 64;      // hidden layer l (1-based) at Wh + (l - 1) * (4096 + 64)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int i = lane & 15, gA = lane >> 4;
+        for (int u = 0; u < 8; ++u) {
+          const int ku = 4 * gA + (u & 3);      // + 16 (2 b + (u >> 2))
+          for (int first = 0; first < 2; ++first) {      // L1 sits at step 0 (forward use) and at the last step (backward use)
+            const size_t st = first ? 0 : (size_t)n_steps - 1;
+            for (int mt = 0; mt < 4; ++mt) {
+              const int f = 4 * u + gA;
+              put2(st, 2 * mt, lane, u, (u < 4 && f < q) ? W1[(size_t)f * 64 + 16 * mt + i] : 0.0f);
+            }
+            for (int b = 0; b < 2; ++b) {
+              const int f = 4 * (i & 3) + (i >> 2);
+              put2(st, 8 + 2 * b, lane, u, f < q ? W1[(size_t)f * 64 + 16 * (2 * b + (u >> 2)) + ku] : 0.0f);
+            }
+          }
+          for (int l = 1; l < NH; ++l) {
+            const float *W = Wh + (size_t)(l - 1) * (4096 + 64);
+            for (int t = 0; t < 4; ++t)
+              for (int b = 0; b < 2; ++b) {
+                const int k = 16 * (2 * b + (u >> 2)) + ku;
+                put2((size_t)l, 2 * (2 * t + b), lane, u, W[(size_t)k * 64 + 16 * t + i]);                              // forward: out tile t
+                put2((size_t)(NH + S + (NH - 1 - l)), 2 * (2 * t + b), lane, u, W[(size_t)(16 * t + i) * 64 + k]);      // backward: in tile t
+              }
+          }
+        }
+      }
+      for (int tx = 0; tx < NTX; ++tx)      // the head blocks as packed above
+        std::memcpy(&sx[(size_t)(NH + tx / BGM_X3_STEP) * step_h + (size_t)(tx % BGM_X3_STEP) * (BGM_X3_BLOCK_BYTES / 2)],
+                    &hx3[(size_t)tx * (BGM_X3_BLOCK_BYTES / 2)], BGM_X3_BLOCK_BYTES);
+      if (s->sx3_cap < sx.size() * 2) {
+        if (s->sx3_dev) BGM_HIP_CHECK(hipFree(s->sx3_dev));
+        BGM_HIP_CHECK(hipMalloc((void **)&s->sx3_dev, sx.size() * 2));
+        s->sx3_cap = sx.size() * 2;
+      }
+      BGM_HIP_CHECK(hipMemcpy(s->sx3_dev, sx.data(), sx.size() * 2, hipMemcpyHostToDevice));
+      // biases: [b1' (64) | hidden (NH - 1) x 64 | heads 2 x 16 NTX] in the posterior blob's own order, the stage behind them
+      BgmMeta &xm = s->sx3_meta;
+      xm = m;
+      xm.b1 = 0; xm.bh = 64; xm.bhd = 64 + 64 * m.n_hh;
+      const int nb = xm.bhd + 2 * 16 * NTX;
+      xm.w1 = xm.wh = xm.whd = 0;
+      xm.lds_resident = (nb + 3) / 4 * 4; xm.stage = xm.lds_resident; xm.total = xm.lds_resident;
+      std::vector<float> xb(xm.lds_resident, 0.0f);
+      for (int k = 0; k < 64; ++k) xb[xm.b1 + k] = blob[m.b1 + k];
+      for (int k = 0; k < 64 * m.n_hh; ++k) xb[xm.bh + k] = blob[m.bh + k];
+      for (int k = 0; k < 2 * 16 * NTX; ++k) xb[xm.bhd + k] = blob[m.bhd + k];
+      if (s->sx3_bias_cap < xb.size()) {
+        if (s->sx3_bias_dev) BGM_HIP_CHECK(hipFree(s->sx3_bias_dev));
+        BGM_HIP_CHECK(hipMalloc((void **)&s->sx3_bias_dev, xb.size() * sizeof(float)));
+        s->sx3_bias_cap = xb.size();
+      }
+      BGM_HIP_CHECK(hipMemcpy(s->sx3_bias_dev, xb.data(), xb.size() * sizeof(float), hipMemcpyHostToDevice));
+      s->lds_bytes_sx3 = (xm.stage + 2 * BGM_X3_STEP * (BGM_X3_BLOCK_BYTES / 4)) * 4;
     }
-    BGM_HIP_CHECK(hipMemcpyAsync(s->hx3_dev, hx3.data(), hx3.size() * 2, hipMemcpyHostToDevice, stream));
-    s->lds_bytes_x3 = (m.stage + 2 * BGM_X3_STEP * (BGM_X3_BLOCK_BYTES / 4)) * 4;
-    if (s->lds_bytes_x3 > 160 * 1024) { bgm_set_error("BGM generator: trunk + head biases + the split-precision stage exceed the 160 KiB LDS"); return BGM_E_UNSUPPORTED; }
   }
   BGM_HIP_CHECK(hipStreamSynchronize(stream));
   s->blob_valid = true;
@@ -197,14 +263,14 @@ extern "C" int bgm_bgm_logpost(bgm_handle *h, const float *z, const float *x, in
   if (rc) return rc;
   BgmState *s = bst(h);
   const int grid = bgm_grid(h, (n + 15) / 16), lds = s->lds_bytes;
-  if (s->precision != 0) {      // split-precision heads: the streamed variant with the fp16 fragment stream
-    const int ldx = s->lds_bytes_x3;
+  if (s->precision != 0) {      // split precision: the whole generator as one fp16 fragment stream (bgm_kernels.h, PREC 2)
+    const int ldx = s->lds_bytes_sx3;
 #define X(KTQ_, NH_)                                                                                                \
     if (s->KTQ == KTQ_ && s->NH == NH_) {                                                                           \
-      auto k = bgm_logpost_kernel<KTQ_, 0, NH_, BGM_WAVES, 1>;                                                      \
+      auto k = bgm_logpost_kernel<KTQ_, 0, NH_, BGM_WAVES, 2>;                                                      \
       BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, ldx)); \
-      hipLaunchKernelGGL(k, dim3(grid), dim3(64 * BGM_WAVES), ldx, stream, s->blob_dev, s->meta, z, x, (long long)n, out, grad, \
-                         (const unsigned char *)s->hx3_dev);                                                        \
+      hipLaunchKernelGGL(k, dim3(grid), dim3(64 * BGM_WAVES), ldx, stream, s->sx3_bias_dev, s->sx3_meta, z, x, (long long)n, out, grad, \
+                         (const unsigned char *)s->sx3_dev);                                                        \
       BGM_HIP_CHECK(hipGetLastError());                                                                             \
       return BGM_OK;                                                                                                \
     }
@@ -245,8 +311,7 @@ extern "C" int bgm_bgm_hmc_run(bgm_handle *h, const bgm_hmc_args *a, void *strea
   ka.it_begin = a->it_begin; ka.n_iters = a->n_iters; ka.burn_in = a->burn_in; ka.n_leapfrog = a->n_leapfrog;
   ka.step = a->step_dev; ka.k0 = (unsigned)(a->seed & 0xFFFFFFFFull); ka.k1 = (unsigned)(a->seed >> 32);
   ka.acc_prob_sum = a->acc_prob_sum_dev; ka.acc_count = a->acc_count_dev; ka.draws = a->draws_dev; ka.m = s->meta;
-  ka.hx3 = s->hx3_dev;
-  const int lds = s->precision != 0 ? s->lds_bytes_x3 : s->lds_bytes;
+  const int lds = s->lds_bytes;
   const long long tiles = (a->n + 15) / 16;
   // The wide variant's unit of work is a block pass (W row tiles x all iterations of the launch) and every block makes the same
   // number of passes.  Tiles are dealt wave-major and tile-less waves skip the matrix work (bgm_hmc_kernel), so a partly filled
@@ -262,26 +327,27 @@ extern "C" int bgm_bgm_hmc_run(bgm_handle *h, const bgm_hmc_args *a, void *strea
     BGM_HIP_CHECK(hipGetLastError());                                                                               \
     return BGM_OK;                                                                                                  \
   }
-  if (s->precision != 0) {      // split-precision heads (bgm_kernels.h): waves per block from BGM_X3_WAVES (8, 12 or 16; default 8)
-    static const int xw = std::getenv("BGM_X3_WAVES") ? std::atoi(std::getenv("BGM_X3_WAVES")) : BGM_X3_WAVES_DEFAULT;
-#define LAUNCH_X3(KTQ_, NH_, W)                                                                                     \
+  if (s->precision != 0) {      // split precision (bgm_kernels.h, PREC 2): the biases are the only LDS-resident data, everything else streams
+    static const int sw = std::getenv("BGM_SX3_WAVES") ? std::atoi(std::getenv("BGM_SX3_WAVES")) : BGM_SX3_WAVES_DEFAULT;
+    ka.blob = s->sx3_bias_dev; ka.m = s->sx3_meta; ka.hx3 = s->sx3_dev;
+    const int ldx = s->lds_bytes_sx3;
+#define LAUNCH_SX3(KTQ_, NH_, W)                                                                                    \
     {                                                                                                               \
       const int grid = (int)std::max<long long>(1, std::min<long long>((tiles + W - 1) / W, h->n_cus));             \
-      auto k = bgm_hmc_kernel<KTQ_, 0, NH_, W, 1>;                                                                  \
-      BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
-      hipLaunchKernelGGL(k, dim3(grid), dim3(64 * W), lds, stream, ka);                                             \
+      auto k = bgm_hmc_kernel<KTQ_, 0, NH_, W, 2>;                                                                  \
+      BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, ldx)); \
+      hipLaunchKernelGGL(k, dim3(grid), dim3(64 * W), ldx, stream, ka);                                             \
       BGM_HIP_CHECK(hipGetLastError());                                                                             \
       return BGM_OK;                                                                                                \
     }
 #define X(KTQ_, NH_)                                                                                                \
     if (s->KTQ == KTQ_ && s->NH == NH_) {                                                                           \
-      if (xw == 12) LAUNCH_X3(KTQ_, NH_, 12)                                                                        \
-      if (xw == 16) LAUNCH_X3(KTQ_, NH_, 16)                                                                        \
-      LAUNCH_X3(KTQ_, NH_, 8)                                                                                       \
+      if (sw == 8) LAUNCH_SX3(KTQ_, NH_, 8)                                                                         \
+      LAUNCH_SX3(KTQ_, NH_, 12)                                                                                     \
     }
     X(1, 5) X(1, 3)
 #undef X
-#undef LAUNCH_X3
+#undef LAUNCH_SX3
     BGM_NO_VARIANT(s)
   }
 #define X(KTQ_, NTX_, NH_)                                                                                          \

@@ -189,21 +189,27 @@ __device__ __forceinline__ void bgm_head_tile(const float *wl, const float *lds,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Split-precision heads (opt-in, bgm_bgm_set_precision(h, 2) / params['hmc_precision'] = 'f16x3'): at wide data rows the two
-// p-wide head products are ~80 % of a gradient evaluation's matrix work (BASELINE config C4: 64 000 of 81 024 MACs).  They run on
-// v_mfma_f32_16x16x32_f16 (K = 32 per instruction, half the cycles of the K = 4 fp32 one) with every operand a sum of two fp16
-// numbers, x = x_hi + x_lo, and  W h ~= W_lo h_hi + W_hi h_lo + W_hi h_hi  (fp32 accumulation; the dropped term is 2^-22 of the
-// product): a 16-feature head block is 24 matrix instructions instead of 64.  The trunk (20 % of the work, and the part that needs
-// both orientations of its weights in LDS) stays on the fp32 dual-access layout.
-//   forward   (mean | var)(16 features) = W^T h:  M = output feature, K = 64 hidden units in two blocks of 32; lane group g supplies
-//             k-slot u = 4 s + r  <->  unit 16 (2 b + s) + 4 g + r, i.e. the trunk's accumulators ARE the B operand (split once per evaluation);
-//   backward  dh(64 units) += Wm dmu + Wv ds:  M = hidden unit, K = 32 = the block's 16 mean + 16 variance outputs, lane group g
-//             supplies k-slot u: u < 4 -> mean output 4 g + u, else variance output 4 g + u - 4: again the lane's own registers.
-// Fragments of a block (packed on the host, bgm_api.hip): 16 x 1 KiB = [fwd: (head, K block, hi | lo)][bwd: (hidden tile, hi | lo)],
-// 64 lanes x 8 halves each, streamed through a double-buffered LDS stage (two blocks = 32 KiB per step and buffer) by the whole block
-// like the fp32 pairs.
-// fp16 range: a weight beyond 65504 is clamped by the packer; dlogp/d(mean, s) beyond 6e4 (a variance ~1e-5 under a unit residual) is
-// clamped in the kernel -- the fp32 kernels have no such bound.
+// Split precision (opt-in, bgm_bgm_set_precision(h, 2) / params['hmc_precision'] = 'f16x3'; PREC = 2 below).  Every product of the
+// generator -- the two p-wide heads (~80 % of a gradient evaluation's matrix work at BASELINE config C4: 64 000 of 81 024 MACs) and the
+// trunk -- runs on v_mfma_f32_16x16x32_f16 (K = 32 per instruction, half the cycles of the K = 4 fp32 one) with every operand a sum of
+// two fp16 numbers, x = x_hi + x_lo, and  W h ~= W_lo h_hi + W_hi h_lo + W_hi h_hi  (fp32 accumulation; the dropped term is 2^-22 of
+// the product): a 16-feature head block is 24 matrix instructions instead of 64, a 64 -> 64 layer 24 instead of 64.
+//   forward   out(16 features) = W^T h:  M = output feature, K = 64 units in two blocks of 32; lane group g supplies k-slot
+//             u = 4 s + r  <->  unit 16 (2 b + s) + 4 g + r, i.e. a layer's accumulators ARE the next product's B operand (split once per layer);
+//   backward  d_in(64 units) += W d_out: M = input unit, K = the outputs in blocks of 32 (heads: the block's 16 mean + 16 variance
+//             outputs, lane group g supplies slot u: u < 4 -> mean output 4 g + u, else variance output 4 g + u - 4): again the lane's own registers.
+// NO weight lives in LDS.  Forward and backward need both orientations of every matrix; as packed fp16 fragments that is 2 x 16 KiB per
+// hidden layer, which does not fit beside a stage.  So the whole generator is ONE LINEAR STREAM of 32 KiB steps, packed on the host
+// (bgm_api.hip) and walked by the workgroup in lock step through a double-buffered LDS stage filled by global_load_lds_dwordx4 (the
+// fragments are lane-linear: exactly what that instruction writes; no staging registers, no ds_write pass):
+//     [L1 (forward + transposed) | hidden 1 .. NH - 1 forward | head steps (two 16-feature blocks each) | hidden NH - 1 .. 1 transposed | L1]
+// 2 NH + ceil(ntx / 2) steps per gradient evaluation, 0.8 MB at p = 500 (L2 resident); LDS holds the biases and the 64 KiB stage.
+// The likelihood arithmetic, the leapfrog and all accumulations stay fp32.
+// fp16 range: a weight beyond 65504 is clamped by the packer; dlogp/d(mean, s) and the back-propagated d(pre-activation) beyond 6e4 (a
+// variance ~1e-5 under a unit residual) are clamped in the kernel -- the fp32 kernels have no such bound.
+// Measured (N = 2e5, p = 500, 10 leapfrog steps, one MI355X): 7.17 -> 3.62 ms per transition (1.98x); heads only, trunk on the fp32
+// dual-access layout: 4.1 ms.  What bounds it: per wave the heads' likelihood arithmetic (~35 VALU instructions per (row, feature), four
+// of them transcendental) costs as many cycles as their 24 matrix instructions per block (profiles/r06_bgm_hmc_f16x3_*.txt).
 // ---------------------------------------------------------------------------------------------------------------------------
 typedef _Float16 bgm_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 bgm_h2 __attribute__((ext_vector_type(2)));
@@ -231,12 +237,42 @@ __device__ __forceinline__ void bgm_split8(const f32x4 &a, const f32x4 &b, bgm_h
 // BGM_X3_STEP head blocks per step of the stream (one barrier per step): with the matrix work of a block down to ~400 cycles a
 // barrier and a fetch per 16 features were what the waves waited for (34 % of the wave cycles parked, r06_pmc_sq_bgm_hmc_f16x3.txt)
 #define BGM_X3_STEP 2
+#ifndef BGM_X3_INTERLEAVE
+#define BGM_X3_INTERLEAVE 0
+#endif
+#ifndef BGM_X3_DMA
+#define BGM_X3_DMA 1      // 1: the stage is filled by global_load_lds_dwordx4 (no staging registers, no ds_write pass); 0: through registers
+#endif
 template <int WAVES>
 struct BgmHeadStreamX3 {
   static constexpr int STEP_VEC = BGM_X3_STEP * BGM_X3_BLOCK_BYTES / 16, NT = 64 * WAVES, K = (STEP_VEC + NT - 1) / NT;
-  const f32x4 *src;      // global: [ntx padded to a multiple of BGM_X3_STEP][BGM_X3_BLOCK_BYTES]
+  const f32x4 *src;      // global: [steps][BGM_X3_STEP][BGM_X3_BLOCK_BYTES]
   unsigned char *buf;    // LDS:    [2][BGM_X3_STEP][BGM_X3_BLOCK_BYTES]
   int cur, tid;
+#if BGM_X3_DMA
+  // every lane's 16 bytes go straight from L2 to the stage: destination = wave-uniform base + lane x 16 (the fragments are lane-linear,
+  // which is exactly the layout the instruction writes); the other buffer is the one nobody reads during this step
+  __device__ __forceinline__ void fetch(int step) {
+#ifdef BGM_X3_ABL_NOSTREAM
+    return;
+#endif
+    const f32x4 *s = src + (long long)step * STEP_VEC + tid;
+    typedef __attribute__((address_space(3))) unsigned char *lds_ptr;
+    typedef const __attribute__((address_space(1))) f32x4 *glb_ptr;
+    const unsigned dst0 = (unsigned)(unsigned long long)(lds_ptr)(buf + (cur ^ 1) * (BGM_X3_STEP * BGM_X3_BLOCK_BYTES)) + (unsigned)(tid & ~63) * 16u;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (K * NT == STEP_VEC || (tid & ~63) + k * NT < STEP_VEC)
+        __builtin_amdgcn_global_load_lds((glb_ptr)(s + k * NT), (lds_ptr)(unsigned long long)(dst0 + (unsigned)(k * NT) * 16u), 16, 0, 0);
+  }
+  __device__ __forceinline__ void commit() {
+#ifdef BGM_X3_ABL_NOSTREAM
+    return;
+#endif
+    __syncthreads();      // (carries the wait for the loads above: they write LDS)
+    cur ^= 1;
+  }
+#else
   f32x4 r[K];
   __device__ __forceinline__ void fetch(int step) {      // step = first block / BGM_X3_STEP
 #ifdef BGM_X3_ABL_NOSTREAM
@@ -258,6 +294,7 @@ struct BgmHeadStreamX3 {
     __syncthreads();
     cur ^= 1;
   }
+#endif
   __device__ __forceinline__ const unsigned char *tile(int b) const { return buf + (cur * BGM_X3_STEP + b) * BGM_X3_BLOCK_BYTES; }
   // The data values of a step are requested ONE STEP AHEAD (xn; the first step of an evaluation by the last step of the previous
   // one: the row does not change within a launch's tile): a block's products are ~200 cycles now, the rows come from HBM (1.25 GB at
@@ -361,10 +398,77 @@ template <int KTQ, int NTX, int NH, bool WANT_GRAD, int PREC = 0, class HS = Bgm
 __device__ __forceinline__ void bgm_logp_grad(const float *lds, const BgmMeta &m, int j, int g,
                                               const f32x4 (&z)[KTQ], const BgmX<NTX> &xs, HS &hs,
                                               float &logp, f32x4 (&grad)[KTQ], bool want_lp = true) {
-  static_assert(PREC == 0 || NTX == 0, "split-precision heads: the streamed (wide) variant");
+  static_assert(PREC == 0 || NTX == 0, "split precision: the streamed (wide) variant");
   // trunk forward; only the SIGN of every activation is kept for the backward pass (bit 4t+r of sgn[l])
   unsigned sgn[NH];
   f32x4 h[4];
+  if constexpr (PREC == 2) {
+    // PREC 2: the trunk in split precision too, its weights STREAMED like the head blocks (no trunk weight lives in LDS: one unit of
+    // 16 KiB per layer and direction -- forward fragments on the way up, transposed fragments on the way down -- so the workgroup
+    // needs 70 KiB instead of 144 and two of them share a CU, out of phase).  Steps of an evaluation: L1, hidden 1 .. NH - 1, the
+    // head steps, hidden NH - 1 .. 1 backward, L1 backward; step 0 is current on entry, the last step fetches it for the next call.
+    static_assert(KTQ == 1, "split-precision trunk: z_dim <= 16");
+    const int lane2 = 16 * g + j;
+    hs.fetch(1);
+    {
+      bgm_h8 zh, zl;
+      bgm_split8(z[0], f32x4{0.0f, 0.0f, 0.0f, 0.0f}, zh, zl);      // k-slot u < 4 <-> latent feature 4 u + g, the upper half of the K block is zero
+      const bgm_h8 *fr = reinterpret_cast<const bgm_h8 *>(hs.tile(0)) + lane2;
+      bgm_h8 ah[4], al[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) { ah[mt] = fr[64 * (2 * mt)]; al[mt] = fr[64 * (2 * mt + 1)]; h[mt] = *reinterpret_cast<const f32x4 *>(lds + m.b1 + 16 * mt + 4 * g); }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) h[mt] = BGM_MFMA_H(al[mt], zh, h[mt]);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) h[mt] = BGM_MFMA_H(ah[mt], zl, h[mt]);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) h[mt] = BGM_MFMA_H(ah[mt], zh, h[mt]);
+    }
+    sgn[0] = 0u;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sgn[0] |= (h[t][r] > 0.0f) ? (1u << (4 * t + r)) : 0u;
+        h[t][r] = lrelu(h[t][r]);
+      }
+    asm volatile("" : "+v"(sgn[0]));
+    hs.commit();
+#pragma unroll
+    for (int l = 1; l < NH; ++l) {
+      BGM_NO_HOIST();
+      hs.fetch(l + 1);
+      bgm_h8 bh_[2], bl_[2];
+      bgm_split8(h[0], h[1], bh_[0], bl_[0]);
+      bgm_split8(h[2], h[3], bh_[1], bl_[1]);
+      const bgm_h8 *fr = reinterpret_cast<const bgm_h8 *>(hs.tile(0)) + lane2;
+      f32x4 h2[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) h2[mt] = *reinterpret_cast<const f32x4 *>(lds + m.bh + (l - 1) * 64 + 16 * mt + 4 * g);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        bgm_h8 ah[4], al[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) { ah[mt] = fr[64 * (2 * (2 * mt + b))]; al[mt] = fr[64 * (2 * (2 * mt + b) + 1)]; }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) h2[mt] = BGM_MFMA_H(al[mt], bh_[b], h2[mt]);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) h2[mt] = BGM_MFMA_H(ah[mt], bl_[b], h2[mt]);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) h2[mt] = BGM_MFMA_H(ah[mt], bh_[b], h2[mt]);
+      }
+      sgn[l] = 0u;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sgn[l] |= (h2[t][r] > 0.0f) ? (1u << (4 * t + r)) : 0u;
+          h[t][r] = lrelu(h2[t][r]);
+        }
+      asm volatile("" : "+v"(sgn[l]));
+      hs.commit();
+    }
+  } else {
   bias17<4>(lds + m.b1, g, h);
   fwd17<KTQ, 4>(lds + m.w1, j, g, z, h);
   sgn[0] = 0u;
@@ -392,6 +496,7 @@ __device__ __forceinline__ void bgm_logp_grad(const float *lds, const BgmMeta &m
       }
     asm volatile("" : "+v"(sgn[l]));
   }
+  }
   // heads, one 16-feature block at a time
   float nll = 0.0f;
   f32x4 dh[4];
@@ -403,16 +508,19 @@ __device__ __forceinline__ void bgm_logp_grad(const float *lds, const BgmMeta &m
       BGM_NO_HOIST();
       bgm_head_tile<WANT_GRAD>(lds + m.whd + tx * BGM_PAIR, lds, m, tx, j, g, h, xs.r[tx], nll, dh);
     }
-  } else if constexpr (PREC == 1) {
+  } else if constexpr (PREC >= 1) {
     bgm_h8 hh[2], hl[2];
     bgm_split8(h[0], h[1], hh[0], hl[0]);
     bgm_split8(h[2], h[3], hh[1], hl[1]);
     const int lane = 16 * g + j;
     const int n_steps = (m.ntx + BGM_X3_STEP - 1) / BGM_X3_STEP;
+    // (PREC 2: the head steps sit behind the NH forward steps of the trunk; behind the last one comes the first backward step, or
+    // step 0 again when no gradient is wanted)
+    const int s0 = PREC == 2 ? NH : 0, s_after = (PREC == 2 && WANT_GRAD) ? NH + n_steps : 0;
 #pragma unroll 1
     for (int st = 0; st < n_steps; ++st) {
       BGM_NO_HOIST();
-      hs.fetch(st + 1 < n_steps ? st + 1 : 0);
+      const int next_step = st + 1 < n_steps ? s0 + st + 1 : s_after;
       // the step's blocks as one straight-line region: forward products of every block first, then per block its likelihood
       // arithmetic (under the products still in flight) and its backward products (an odd block count ends on a padding block of
       // zero fragments whose columns are never observed: it contributes exact zeros)
@@ -420,8 +528,10 @@ __device__ __forceinline__ void bgm_logp_grad(const float *lds, const BgmMeta &m
       if (!hs.x_valid) { hs.load_x(xs.row, m.p, st, g, hs.xn); hs.x_valid = true; }      // (the first evaluation of a tile only)
 #pragma unroll
       for (int b = 0; b < BGM_X3_STEP; ++b) xv[b] = hs.xn[b];
+      hs.fetch(next_step);      // (behind the use of last step's data values: with a direct-to-LDS load in flight hipcc waits for ALL loads at the next use of one)
       hs.load_x(xs.row, m.p, st + 1 < n_steps ? st + 1 : 0, g, hs.xn);
       asm volatile("" ::: "memory");      // (hipcc sinks a load to just above its first use: the request stays here, a step ahead)
+#if BGM_X3_INTERLEAVE
 #pragma unroll
       for (int b = 0; b < BGM_X3_STEP; ++b) bgm_x3_fwd(hs.tile(b), lds, m, BGM_X3_STEP * st + b, lane, g, hh, hl, part[b]);
 #pragma unroll
@@ -430,6 +540,15 @@ __device__ __forceinline__ void bgm_logp_grad(const float *lds, const BgmMeta &m
         bgm_x3_epilogue<WANT_GRAD>(m, BGM_X3_STEP * st + b, g, part[b], xv[b], want_lp, nll, dhi, dlo);
         if (WANT_GRAD) bgm_x3_bwd(hs.tile(b), lane, dhi, dlo, dh);
       }
+#else
+#pragma unroll
+      for (int b = 0; b < BGM_X3_STEP; ++b) {      // (block after block: 16 accumulator registers fewer in flight; measured equal to the interleaved order)
+        bgm_h8 dhi, dlo;
+        bgm_x3_fwd(hs.tile(b), lds, m, BGM_X3_STEP * st + b, lane, g, hh, hl, part[0]);
+        bgm_x3_epilogue<WANT_GRAD>(m, BGM_X3_STEP * st + b, g, part[0], xv[b], want_lp, nll, dhi, dlo);
+        if (WANT_GRAD) bgm_x3_bwd(hs.tile(b), lane, dhi, dlo, dh);
+      }
+#endif
       hs.commit();
     }
   } else {
@@ -454,6 +573,58 @@ __device__ __forceinline__ void bgm_logp_grad(const float *lds, const BgmMeta &m
     for (int r = 0; r < 4; ++r) zsq = fmaf(z[t][r], z[t][r], zsq);   // padded features are zero
   logp = -sum_over_g(nll + 0.5f * zsq);
   if (WANT_GRAD) {
+    if constexpr (PREC == 2) {
+      const int lane2 = 16 * g + j;
+      const int sb0 = NH + (m.ntx + BGM_X3_STEP - 1) / BGM_X3_STEP;      // first backward step
+#pragma unroll
+      for (int l = NH - 1; l >= 0; --l) {
+        BGM_NO_HOIST();
+        hs.fetch(l > 0 ? sb0 + (NH - 1 - l) + 1 : 0);
+        // d(pre-activation) = dh o LeakyReLU', clamped into the fp16 range like the heads' gradients, split once per layer
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            dh[t][r] = __builtin_amdgcn_fmed3f(dh[t][r] * (((sgn[l] >> (4 * t + r)) & 1u) ? 1.0f : BGM_LEAK), -6.0e4f, 6.0e4f);
+        bgm_h8 dhh[2], dhl[2];
+        bgm_split8(dh[0], dh[1], dhh[0], dhl[0]);
+        bgm_split8(dh[2], dh[3], dhh[1], dhl[1]);
+        const bgm_h8 *fr = reinterpret_cast<const bgm_h8 *>(hs.tile(0)) + lane2;
+        if (l > 0) {
+          f32x4 dn[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) dn[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            bgm_h8 ah[4], al[4];
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) { ah[ti] = fr[64 * (2 * (2 * ti + b))]; al[ti] = fr[64 * (2 * (2 * ti + b) + 1)]; }
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) dn[ti] = BGM_MFMA_H(al[ti], dhh[b], dn[ti]);
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) dn[ti] = BGM_MFMA_H(ah[ti], dhl[b], dn[ti]);
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) dn[ti] = BGM_MFMA_H(ah[ti], dhh[b], dn[ti]);
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t) dh[t] = dn[t];
+        } else {      // first layer: the latent gradient, rows of the fragment in the latent layout (feature 4 r + g in register r)
+          f32x4 ga[2];
+          bgm_h8 ah[2], al[2];
+#pragma unroll
+          for (int b = 0; b < 2; ++b) { ah[b] = fr[64 * (8 + 2 * b)]; al[b] = fr[64 * (9 + 2 * b)]; ga[b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+#pragma unroll
+          for (int b = 0; b < 2; ++b) ga[b] = BGM_MFMA_H(al[b], dhh[b], ga[b]);
+#pragma unroll
+          for (int b = 0; b < 2; ++b) ga[b] = BGM_MFMA_H(ah[b], dhl[b], ga[b]);
+#pragma unroll
+          for (int b = 0; b < 2; ++b) ga[b] = BGM_MFMA_H(ah[b], dhh[b], ga[b]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) grad[0][r] = ga[0][r] + ga[1][r];
+        }
+        hs.commit();
+      }
+    } else {
 #pragma unroll
     for (int l = NH - 1; l >= 0; --l) {
 #pragma unroll
@@ -473,6 +644,7 @@ __device__ __forceinline__ void bgm_logp_grad(const float *lds, const BgmMeta &m
 #pragma unroll
     for (int t = 0; t < KTQ; ++t) grad[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     bwd17<KTQ, 4>(lds + m.w1, j, g, dh, grad);
+    }
 #pragma unroll
     for (int t = 0; t < KTQ; ++t)
 #pragma unroll
@@ -525,6 +697,7 @@ __device__ __forceinline__ void bgm_store_z(float *z, int q, long long row, int 
 
 template <int PREC, int WAVES> struct bgm_stream_of { typedef BgmHeadStream type; };
 template <int WAVES> struct bgm_stream_of<1, WAVES> { typedef BgmHeadStreamX3<WAVES> type; };
+template <int WAVES> struct bgm_stream_of<2, WAVES> { typedef BgmHeadStreamX3<WAVES> type; };
 
 // get_log_posterior (+ optional gradient) for n rows
 template <int KTQ, int NTX, int NH, int WAVES, int PREC = 0>
@@ -536,7 +709,7 @@ __global__ __launch_bounds__(64 * WAVES) void bgm_logpost_kernel(const float *bl
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
   using HS = typename bgm_stream_of<PREC, WAVES>::type;
   HS hs;
-  if constexpr (PREC == 1) hs.begin(hx3, m, lds);
+  if constexpr (PREC >= 1) hs.begin(hx3, m, lds);
   else if constexpr (NTX == 0) hs.begin(blob, m, lds);
   const long long n_tiles = (n + 15) / 16, passes = bgm_block_passes(n_tiles, WAVES);
   for (long long ps = 0; ps < passes; ++ps) {
@@ -551,7 +724,7 @@ __global__ __launch_bounds__(64 * WAVES) void bgm_logpost_kernel(const float *bl
     BgmX<NTX> xr;
     f32x4 zr[KTQ], gr[KTQ];
     bgm_load_x<NTX>(x, n, m.p, row, g, xr);
-    if constexpr (PREC == 1) hs.x_valid = false;       // (a new row: nothing of it has been requested ahead)
+    if constexpr (PREC >= 1) hs.x_valid = false;       // (a new row: nothing of it has been requested ahead)
     bgm_load_z<KTQ>(z, m.q, row, g, zr);
     float lp;
     if (grad_out != nullptr) bgm_logp_grad<KTQ, NTX, NH, true, PREC, HS>(lds, m, j, g, zr, xr, hs, lp, gr);
@@ -589,7 +762,7 @@ __global__ __launch_bounds__(64 * WAVES) void bgm_hmc_kernel(BgmHmcKArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
   using HS = typename bgm_stream_of<PREC, WAVES>::type;
   HS hs;
-  if constexpr (PREC == 1) hs.begin(a.hx3, m, lds);
+  if constexpr (PREC >= 1) hs.begin(a.hx3, m, lds);
   else if constexpr (NTX == 0) hs.begin(a.blob, m, lds);
   const long long n = a.n, n_tiles = (n + 15) / 16, passes = bgm_block_passes(n_tiles, WAVES);
   const float eps = *a.step;
@@ -603,7 +776,7 @@ __global__ __launch_bounds__(64 * WAVES) void bgm_hmc_kernel(BgmHmcKArgs a) {
     if constexpr (NTX == 0) {
       if (!tile_ok) {
         const int evals = (a.init ? 1 : 0) + a.n_iters * a.n_leapfrog;
-        const int n_steps = PREC == 1 ? (m.ntx + BGM_X3_STEP - 1) / BGM_X3_STEP : m.ntx;      // (steps of the head stream per evaluation)
+        const int n_steps = PREC == 0 ? m.ntx : (m.ntx + BGM_X3_STEP - 1) / BGM_X3_STEP + (PREC == 2 ? 2 * NH : 0);      // (steps of the stream per evaluation)
         for (int e = 0; e < evals; ++e)
           for (int tx = 0; tx < n_steps; ++tx) { hs.fetch(tx + 1 < n_steps ? tx + 1 : 0); hs.commit(); }
         continue;
@@ -617,7 +790,7 @@ __global__ __launch_bounds__(64 * WAVES) void bgm_hmc_kernel(BgmHmcKArgs a) {
     BgmX<NTX> xr;
     f32x4 z[KTQ], gr[KTQ];
     bgm_load_x<NTX>(a.x, n, m.p, row, g, xr);
-    if constexpr (PREC == 1) hs.x_valid = false;       // (a new row: nothing of it has been requested ahead)
+    if constexpr (PREC >= 1) hs.x_valid = false;       // (a new row: nothing of it has been requested ahead)
     float lp;
     if (a.init) {   // initial_state ~ N(0,1)  (bgm/base.py:778), RNG tag 0
 #pragma unroll

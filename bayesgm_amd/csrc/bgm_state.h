@@ -21,12 +21,16 @@ struct BgmState {
   float *blob_dev = nullptr;
   size_t blob_cap = 0;
   bool blob_valid = false;
-  // split-precision heads (bgm_bgm_set_precision; bgm_kernels.h "Split-precision heads"): 0 fp32 (default), 2 f16x3 -- the packed fp16
-  // fragments [ntx][16 KiB] next to the blob, the posterior kernels' LDS request with the 2 x 16 KiB stage
+  // split precision (bgm_bgm_set_precision; bgm_kernels.h "Split precision"): 0 fp32 (default), 2 f16x3 -- the whole generator as one
+  // linear stream of 32 KiB steps of fp16 fragments [L1 | hidden forward | head steps | hidden backward | L1], the biases as the only
+  // LDS-resident data
   int precision = 0;
-  unsigned char *hx3_dev = nullptr;
-  size_t hx3_cap = 0;
-  int lds_bytes_x3 = 0;
+  unsigned char *sx3_dev = nullptr;
+  size_t sx3_cap = 0;
+  float *sx3_bias_dev = nullptr;
+  size_t sx3_bias_cap = 0;
+  BgmMeta sx3_meta{};
+  int lds_bytes_sx3 = 0;
   // fit session (device)
   bool fit_active = false;
   int fit_bcap = 0, n_params = 0, rows_per_slice = 256, n_slices_cap = 0;

@@ -506,7 +506,7 @@ class BgmEngine(object):
     HMC_PRECISIONS = {"fp32": 0, "f16x3": 2}
 
     def set_precision(self, mode="fp32"):
-        """Arithmetic of the two x_dim-wide head products in logpost / hmc_run: "fp32" (default) or "f16x3" (split precision on the
+        """Arithmetic of the generator's products in logpost / hmc_run: "fp32" (default) or "f16x3" (split precision on the
         fp16 matrix instruction, opt-in; bgm_bgm_set_precision)."""
         if mode not in self.HMC_PRECISIONS:
             raise ValueError("hmc precision must be 'fp32' or 'f16x3'; got %r" % (mode,))

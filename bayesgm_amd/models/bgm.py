@@ -60,8 +60,8 @@ class BGM(object):
         from .causalbgm import _disc_norm
         self.engine.set_disc_norm(_disc_norm(p))
         self.engine.set_weights(self.g)
-        # params['hmc_precision'] (build option, default "fp32" = the reference's arithmetic): "f16x3" runs the two x_dim-wide head
-        # products of predict's log-posterior / HMC kernels in split precision on the fp16 matrix instruction (csrc/bgm_kernels.h)
+        # params['hmc_precision'] (build option, default "fp32" = the reference's arithmetic): "f16x3" runs the generator's products in
+        # predict's log-posterior / HMC kernels in split precision on the fp16 matrix instruction (csrc/bgm_kernels.h)
         if p.get("hmc_precision", "fp32") != "fp32":
             self.engine.set_precision(p["hmc_precision"])
         if self.timestamp is None:

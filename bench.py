@@ -407,10 +407,10 @@ def bgm_hmc_leg(device, n=200000, p=500, q=10, L=10, iters=4):
     eng = BgmEngine(p, q, g_units=[64] * 5)
     eng.set_weights(g)
     out["deterministic"] = entry("bgm_hmc_kernel (head weights streamed)", timed(eng), 1)
-    # the same transitions with the head products in split precision (opt-in, params['hmc_precision'] = 'f16x3': csrc/bgm_kernels.h);
+    # the same transitions in split precision (opt-in, params['hmc_precision'] = 'f16x3': csrc/bgm_kernels.h);
     # frac_of_fp32_mfma_peak is then a speed in fp32-peak equivalents, not a utilisation of the fp16 pipe
     eng.set_precision("f16x3")
-    out["deterministic_f16x3"] = entry("bgm_hmc_kernel<PREC = 1> (heads on v_mfma_f32_16x16x32_f16, hi / lo fp16 splits, three products; trunk fp32)", timed(eng), 1)
+    out["deterministic_f16x3"] = entry("bgm_hmc_kernel<PREC = 2> (every product on v_mfma_f32_16x16x32_f16 with hi / lo fp16 splits, three products per contraction; the generator streamed through LDS as fp16 fragments)", timed(eng), 1)
     out["deterministic_f16x3"]["speedup_vs_fp32"] = out["deterministic"]["ms_per_transition"] / out["deterministic_f16x3"]["ms_per_transition"]
     eng.set_precision("fp32")
 

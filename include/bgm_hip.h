@@ -495,12 +495,13 @@ typedef struct {
   float *draws_dev;            /* [n_keep x n x q] states after burn_in, or NULL  */
 } bgm_hmc_args;
 BGM_API int bgm_bgm_hmc_run(bgm_handle *h, const bgm_hmc_args *args, void *stream);
-/* Arithmetic of the head products (the two x_dim-wide layers: ~80 % of a gradient evaluation at BASELINE config C4) in
- * bgm_bgm_logpost / bgm_bgm_hmc_run: 0 = fp32 (default, the reference's arithmetic), 2 = "f16x3": v_mfma_f32_16x16x32_f16 on hi / lo
- * fp16 splits of weights, trunk output and likelihood gradients, three products per contraction, fp32 accumulation (22 mantissa
- * bits; csrc/bgm_kernels.h "Split-precision heads").  Opt-in; the trunk, the likelihood and the leapfrog stay fp32.  Served: trunk
- * [64] x 3 / [64] x 5, z_dim <= 16, any x_dim (the streamed-head kernels); BGM_E_UNSUPPORTED for the general-width engine.  fp16 range:
- * weights are clamped to 65504 by the packer, dlogp/d(mean, s) to 6e4 in the kernel.
+/* Arithmetic of the generator's products in bgm_bgm_logpost / bgm_bgm_hmc_run: 0 = fp32 (default, the reference's arithmetic),
+ * 2 = "f16x3": every product (trunk and the two x_dim-wide heads, ~80 % of a gradient evaluation at BASELINE config C4) on
+ * v_mfma_f32_16x16x32_f16 with hi / lo fp16 splits of weights, activations and back-propagated gradients, three products per
+ * contraction, fp32 accumulation (22 mantissa bits); the whole generator is streamed through LDS as packed fp16 fragments
+ * (csrc/bgm_kernels.h "Split precision").  Opt-in; the likelihood, the leapfrog and all sums stay fp32.  Served: trunk
+ * [64] x 3 / [64] x 5, z_dim <= 16, any x_dim; BGM_E_UNSUPPORTED for the general-width engine.  fp16 range: weights are clamped to
+ * 65504 by the packer, gradients to 6e4 in the kernel.
  * same functions as above: get_log_posterior bgm/base.py:665-705, tfp_mcmc_sampler :798-821. */
 BGM_API int bgm_bgm_set_precision(bgm_handle *h, int32_t mode);
 

@@ -1,7 +1,7 @@
-"""Split-precision heads of the BGM posterior kernels (opt-in, bgm_bgm_set_precision(2) / params['hmc_precision'] = 'f16x3';
-csrc/bgm_kernels.h "Split-precision heads"): the two x_dim-wide head products -- ~80 % of a gradient evaluation at BASELINE
-config C4 -- on v_mfma_f32_16x16x32_f16 with hi / lo fp16 splits of weights, trunk output and likelihood gradients (three products
-per contraction, fp32 accumulation), everything else fp32.
+"""Split precision in the BGM posterior kernels (opt-in, bgm_bgm_set_precision(2) / params['hmc_precision'] = 'f16x3';
+csrc/bgm_kernels.h "Split precision"): every product of the generator -- trunk and the two x_dim-wide heads -- on
+v_mfma_f32_16x16x32_f16 with hi / lo fp16 splits of weights, activations and back-propagated gradients (three products per
+contraction, fp32 accumulation), the generator streamed through LDS as packed fp16 fragments; likelihood, leapfrog and sums fp32.
 
 Tolerances are the fp32 kernels' own (tests/test_gpu_bgm.py): log posterior <= 2e-6 |ref| + 2e-4 and gradient
 <= 2e-5 max|ref| + 2e-5 against the float64 oracle; HMC chains share the Philox stream with the oracle and the fp32 kernels:
