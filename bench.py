@@ -24,6 +24,12 @@ The JSON line also carries
                   bounded sample (bs=10000 rows x a few iterations).
   parity       -- (with the cpu_baseline leg) ADRF of the HIP path vs the oracle on 256 rows, same weights and
                   Philox streams: the "matches the reference within a stated fp32 tolerance" number of this run.
+  encoder / config_c1 / config_c4_share / bayesian_nets / fit_dp -- (round 6) one driver-run number per BASELINE config and
+                  north_star target: e(V) over the panel against the fp32-MFMA peak; configs[1] (binary treatment, ITE + intervals)
+                  and one GPU's share of configs[4] (BGM imputation, fp32 and the opt-in split precision) through the classes;
+                  the reference's default Bayesian nets at the BASELINE iteration counts with their own `roofline` instances; and,
+                  at every N, `fit_dp`: the data-parallel minibatch loop with its per-step RCCL gradient all-reduce issued inside the
+                  library (configs[3], fit side) -- at N > 1 after the headline is complete and under a watchdog.
 Weights are glorot-uniform random (seed 0): throughput does not depend on their values.
 """
 import argparse
