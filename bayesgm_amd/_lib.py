@@ -72,7 +72,8 @@ class BnnMhArgs(C.Structure):
                 ("it_begin", C.c_int32), ("n_iters", C.c_int32), ("burn_in", C.c_int32), ("q_sd", C.c_float),
                 ("seed", C.c_uint64), ("acc_count_dev", C.c_void_p), ("draws_dev", C.c_void_p), ("n_keep", C.c_int32),
                 ("effect", C.c_int32), ("sample_y", C.c_int32), ("x_values_dev", C.c_void_p), ("n_doses", C.c_int32),
-                ("adrf_sum_dev", C.c_void_p), ("ite_dev", C.c_void_p), ("q_sd_blocks_dev", C.c_void_p), ("acc_blocks_dev", C.c_void_p)]
+                ("adrf_sum_dev", C.c_void_p), ("ite_dev", C.c_void_p), ("q_sd_blocks_dev", C.c_void_p), ("acc_blocks_dev", C.c_void_p),
+                ("block_row0", C.c_int64)]
 
 
 class EgmConfig(C.Structure):

@@ -209,6 +209,17 @@ class BnnEngine(object):
                                                  comm.handle, self._stream()), "bgm_bnn_fit_epoch_dp")
         return n_done.value
 
+    def serves_block_shares(self):
+        """True when the session samples on the default-shape kernels (csrc/bnf_kernels.h), the family that can run a rank's share of one
+        block (mh_run(block_row0 > 0)) -- probed through the split-precision switch, which exists for exactly those sessions."""
+        prev = getattr(self, "_precision", "fp32")
+        if prev == "f16x3":
+            return True
+        if not self.open or self.lib.bgm_bnn_set_precision(self.h, 2) != 0:
+            return False
+        _lib.check(self.lib.bgm_bnn_set_precision(self.h, {"fp32": 0, "bf16x3": 1}[prev]), "bgm_bnn_set_precision")
+        return True
+
     # -- large-batch side ------------------------------------------------------------------------------
     def logpost(self, x, y, v, z, block_rows, seed, stream_id, block0=0):
         out = torch.empty(z.shape[0], device=self.device, dtype=torch.float32)
@@ -218,8 +229,9 @@ class BnnEngine(object):
 
     def mh_run(self, x, y, v, state, block_rows, it_begin, n_iters, burn_in, q_sd, seed, init=False, row_base=0, block0=0,
                acc_count=None, draws=None, n_keep=0, effect=0, sample_y=True, x_values=None, adrf_sum=None, ite=None,
-               q_sd_blocks=None, acc_blocks=None):
+               q_sd_blocks=None, acc_blocks=None, block_row0=0):
         a = _lib.BnnMhArgs()
+        a.block_row0 = int(block_row0)      # > 0: the rows are a rank's share of ONE block, starting at this position inside it
         a.x_dev, a.y_dev, a.v_dev = x.data_ptr(), y.data_ptr(), v.data_ptr()
         a.n, a.row_base, a.block_rows, a.block0 = state.shape[0], int(row_base), int(block_rows), int(block0)
         a.state_dev, a.init = state.data_ptr(), int(init)

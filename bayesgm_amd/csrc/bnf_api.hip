@@ -188,8 +188,9 @@ void launch_noise(const BnfState *st, bool effects, float *dw, long long set_flo
 }
 
 void launch_signs(const SgLayout &L, long long n, int bs, int block0, int n_states, int nets, uint64_t seed, uint32_t stream0, unsigned *queue,
-                  hipStream_t stream) {
+                  hipStream_t stream, long long rib0 = 0) {
   BnfSignArgs sa{};
+  sa.rib0 = rib0;
   sa.g = L.g; sa.gout = L.gout; sa.h = L.h; sa.f = L.f; sa.n = n; sa.bs = bs; sa.block0 = block0; sa.n_states = n_states; sa.nets = nets;
   sa.k0 = (uint32_t)seed; sa.k1 = (uint32_t)(seed >> 32); sa.stream0 = stream0; sa.queue = queue;
   hipLaunchKernelGGL(bnf_signs_kernel, dim3((unsigned)((n + 255) / 256), n_states), dim3(256), 0, stream, sa);
@@ -266,13 +267,13 @@ namespace {
 // effects of ONE draw (state z) -> adrf column / ite column d
 int effects_of(bgm_handle *h, BnfState *st, const float *z, long long n, int bs, int n_blocks, int block0, long long row_base, int n_doses,
                const float *xvals, uint64_t seed, uint32_t stream0, uint32_t it_noise, int sample_y, double *sum_out, long long sum_stride,
-               float *ite_out, long long ite_stride, float *dw_eff, const SgLayout &L, hipStream_t stream, bool x3) {
+               float *ite_out, long long ite_stride, float *dw_eff, const SgLayout &L, hipStream_t stream, bool x3, long long rib0 = 0) {
   const BnfPlan &P = st->P;
   BnfCfg c;
   EffFn fn = x3 ? bnx_eff_fn(st->KSFc, &c.R, &c.W) : eff_fn(st->KSFc, c);
   const long long eset = (long long)P.e_frags * 256;
   launch_noise(st, true, dw_eff, eset, n_blocks, n_doses, seed, stream0, block0, stream, x3);
-  launch_signs(L, n, bs, block0, n_doses, 4, seed, stream0, st->queue_dev + 8, stream);
+  launch_signs(L, n, bs, block0, n_doses, 4, seed, stream0, st->queue_dev + 8, stream, rib0);
   BnfEffArgs ea{};
   ea.pl = P; ea.eblob = x3 ? st->eblobx_dev : st->eblob_dev; ea.dw = dw_eff; ea.sgf = L.f; ea.z = z; ea.n = n; ea.row_base = row_base;
   { const BnnState *bs_ = static_cast<const BnnState *>(h->bnn_state); ea.sig2_y = (bs_ && bs_->cfg.sigma_y > 0.0f) ? bs_->cfg.sigma_y * bs_->cfg.sigma_y : 0.0f; }
@@ -304,6 +305,11 @@ int bnf_mh_run(bgm_handle *h, BnnState *s, const bgm_bnn_mh_args *g, hipStream_t
   MhFn fn = x3 ? bnx_mh_fn(st->KSc, 1, &c.R, &c.W) : (split32 ? mh_fn<3>(st->KSc, c) : mh_fn<1>(st->KSc, c));
   const long long n = g->n;
   const int bs = g->block_rows, n_blocks = (int)((n + bs - 1) / bs), q = s->q;
+  // A rank's share of ONE block (row_base inside the block block0): the Flipout sign words of the samplers and of the prior net are keyed
+  // by (block, position in the block), so the position of the first row travels with the call -- results do not depend on how the block's
+  // rows are split over ranks (bgm_bnn_mh_args::block_row0; 0 for calls that start a block).
+  const long long rib0 = g->block_row0;
+  if (rib0 < 0 || rib0 >= bs || (rib0 > 0 && rib0 + n > bs)) { bgm_set_error("bgm_bnn_mh_run: block_row0 must lie inside the block, and a call that starts inside a block must end inside it"); return BGM_E_INVALID; }
   const long long eset = (long long)P.e_frags * 256;
   const size_t dw_mh = (size_t)n_blocks * 2 * P.set_floats, dw_eff = (size_t)n_blocks * n_doses * eset;
   rc = grow((void **)&st->dw_dev, &st->dw_cap, sizeof(float) * (dw_mh + dw_eff), stream, true);
@@ -341,10 +347,10 @@ int bnf_mh_run(bgm_handle *h, BnnState *s, const bgm_bnn_mh_args *g, hipStream_t
   for (int i = 0; i < g->n_iters; ++i) {
     const int it = g->it_begin + i;
     launch_noise(st, false, st->dw_dev, P.set_floats, n_blocks, 2, g->seed, 2u * (uint32_t)it, g->block0, stream, x3);
-    launch_signs(L, n, bs, g->block0, 2, 7, g->seed, 2u * (uint32_t)it, st->queue_dev, stream);
+    launch_signs(L, n, bs, g->block0, 2, 7, g->seed, 2u * (uint32_t)it, st->queue_dev, stream, rib0);
     a.it = it; a.init = (i == 0 && g->init) ? 1 : 0;
     if (s->bp_on) {    // conditional prior: the two evaluations' own calls of the prior net (streams 2 it, 2 it + 1)
-      if ((rc = bprior_rows(h, s, n, bs, g->block0, g->seed, 2u * (uint32_t)it, 2, stream))) return rc;
+      if ((rc = bprior_rows(h, s, n, bs, g->block0, g->seed, 2u * (uint32_t)it, 2, stream, rib0))) return rc;
       a.prior = s->bp_rows; a.prior_stride = n * (long long)(q + 2);
     }
     a.acc_blocks = g->acc_blocks_dev ? g->acc_blocks_dev + (long long)i * n_blocks : nullptr;
@@ -365,7 +371,7 @@ int bnf_mh_run(bgm_handle *h, BnnState *s, const bgm_bnn_mh_args *g, hipStream_t
         rc = effects_of(h, st, g->state_dev, n, bs, n_blocks, g->block0, g->row_base, n_doses, g->effect == 1 ? g->x_values_dev : st->pair_dev,
                         g->seed, 0x40000000u + (uint32_t)d * (uint32_t)n_doses, (uint32_t)it, g->sample_y,
                         g->effect == 1 ? g->adrf_sum_dev + d : nullptr, g->n_keep, g->effect == 2 ? g->ite_dev + d : nullptr, g->n_keep,
-                        dw_eff_dev, L, stream, x3);
+                        dw_eff_dev, L, stream, x3, rib0);
         if (rc) return rc;
       }
     }

@@ -1149,14 +1149,15 @@ struct BnfSignArgs {
   int bs, block0, n_states, nets;
   uint32_t k0, k1, stream0;
   unsigned *queue;            // [8] item counters of the sampler / effects launch that follows: cleared here
+  long long rib0;             // position of this call's first row inside its block (a rank's share of ONE block: IdentifiableCausalBGM.predict)
 };
 static __global__ __launch_bounds__(256) void bnf_signs_kernel(BnfSignArgs a) {
   const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
   const int s = blockIdx.y;
   if (blockIdx.x == 0 && s == 0 && threadIdx.x < 8) a.queue[threadIdx.x] = 0u;
   if (row >= a.n) return;
-  const int blk = (int)(row / a.bs);
-  const uint32_t rib = (uint32_t)(row - (long long)blk * a.bs);
+  const int blk = (int)((a.rib0 + row) / a.bs);
+  const uint32_t rib = (uint32_t)(a.rib0 + row - (long long)blk * a.bs);      // the words are keyed by (block, position in the block)
   const uint32_t k1 = a.k1 + (uint32_t)(a.block0 + blk), stream = a.stream0 + (uint32_t)s;
   if (a.nets & 1) {
     uint32_t w[28];

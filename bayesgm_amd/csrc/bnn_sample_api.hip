@@ -187,6 +187,7 @@ extern "C" int bgm_bnn_mh_run(bgm_handle *h, const bgm_bnn_mh_args *g, void *str
   BGM_HIP_CHECK(hipSetDevice(h->device));
   rc = bnf_mh_run(h, s, g, stream);
   if (rc <= 0) return rc;
+  if (g->block_row0 != 0) { bgm_set_error("bgm_bnn_mh_run: a share of one block (block_row0 > 0) is served by the default-shape sampling kernels with inference-mode normalisation only"); return BGM_E_UNSUPPORTED; }
   if (bns_wide || s->bp_on) return bnw_mh_run(h, s, g, stream);
   const long long n = g->n;
   const int bs = g->block_rows, n_blocks = (int)((n + bs - 1) / bs), q = s->q;

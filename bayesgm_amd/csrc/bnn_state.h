@@ -40,7 +40,8 @@ struct BnnState {
   float *bp_rows = nullptr;    // [n_states][n][q + 2] of the current call
   size_t bp_rows_cap = 0;
 };
-int bprior_rows(bgm_handle *h, BnnState *s, long long n, int bs, int block0, uint64_t seed, uint32_t stream0, int n_states, hipStream_t stream);
+int bprior_rows(bgm_handle *h, BnnState *s, long long n, int bs, int block0, uint64_t seed, uint32_t stream0, int n_states, hipStream_t stream,
+                long long rib0 = 0);
 
 void bgm_bnn_egm_free(void *egm_state);
 void bnf_free(void *state);

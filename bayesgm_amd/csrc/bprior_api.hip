@@ -119,7 +119,8 @@ extern "C" int bgm_bnn_set_prior(bgm_handle *h, const bgm_prior_config *cfg, con
 }
 
 // rows_out [n_states][n][q + 2] for the calls stream0 .. stream0 + n_states - 1 of the blocks of this sampling call (bnf_api.hip)
-int bprior_rows(bgm_handle *h, BnnState *s, long long n, int bs, int block0, uint64_t seed, uint32_t stream0, int n_states, hipStream_t stream) {
+int bprior_rows(bgm_handle *h, BnnState *s, long long n, int bs, int block0, uint64_t seed, uint32_t stream0, int n_states, hipStream_t stream,
+                long long rib0) {
   const BPriorNet &net = s->bp_net;
   const int q = s->q, n_blocks = (int)((n + bs - 1) / bs);
   const size_t need = (size_t)n_states * (size_t)n * (size_t)(q + 2);
@@ -138,6 +139,7 @@ int bprior_rows(bgm_handle *h, BnnState *s, long long n, int bs, int block0, uin
   a.net = net; a.theta = s->bp_theta; a.seg = s->bp_seg; a.n = n; a.bs = bs; a.n_blocks = n_blocks; a.block0 = block0; a.q = q;
   a.parts = std::max(1, std::min((bs + BPRIOR_ROWS_CHUNK - 1) / BPRIOR_ROWS_CHUNK, std::max(1, 2048 / std::max(1, n_blocks * n_states))));
   a.k0 = (unsigned)seed; a.k1 = (unsigned)(seed >> 32); a.stream0 = stream0; a.rows_out = s->bp_rows;
+  a.rib0 = (unsigned)rib0;      // (a rank's share of one block: the sign words are keyed by the position in the block)
   hipLaunchKernelGGL(bprior_rows_kernel, dim3(n_blocks * a.parts, n_states), dim3(BPRIOR_THREADS), lds, stream, a);
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;

@@ -270,6 +270,7 @@ struct BPriorRowsArgs {
   int bs, n_blocks, block0, parts, q;
   unsigned k0, k1, stream0;
   float *rows_out;                     // [n_states][n][q + 2]
+  unsigned rib0;                       // position of the call's first row inside its block (0 unless a block's rows are split over ranks)
 };
 
 static __global__ __launch_bounds__(BPRIOR_THREADS) void bprior_rows_kernel(BPriorRowsArgs a) {
@@ -293,7 +294,7 @@ static __global__ __launch_bounds__(BPRIOR_THREADS) void bprior_rows_kernel(BPri
     const int rows = min(R, blk_n - r0);
     __syncthreads();
     for (int b = tid; b < rows; b += blockDim.x) sg[b] = a.seg[blk_lo + r0 + b];
-    bprior_signs(n, sgw, rows, (unsigned)r0, stream, k0, k1);
+    bprior_signs(n, sgw, rows, a.rib0 + (unsigned)r0, stream, k0, k1);
     __syncthreads();
     for (int e = tid; e < rows * k; e += blockDim.x) {
       const int b = e / k, i = e - b * k;

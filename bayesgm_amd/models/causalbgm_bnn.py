@@ -411,7 +411,7 @@ class CausalBGMBayes(CausalBGM):
 
     # ------------------------------------------------------------------ predict
     def _run_chains(self, x, y, v, bs, burn_in, n_keep, q_sd, seed, row_base, block0, adaptive, initial_q_sd=1.0, target=0.25,
-                    tol=0.05, adj_int=50, window=100, **outs):
+                    tol=0.05, adj_int=50, window=100, block_row0=0, block_rows_global=None, **outs):
         """All blocks of the given rows in lock step.  Every block is its own sampler run of the reference
         (metropolis_hastings_sampler is called once per block, base.py:640-645), so an adaptive proposal scale is kept PER
         BLOCK: at counter = 50, 100, ... < burn_in the acceptance rate of the block's last `window` iterations decides
@@ -422,6 +422,11 @@ class CausalBGMBayes(CausalBGM):
         n = x.shape[0]
         n_blocks = (n + bs - 1) // bs
         rows_b = np.minimum(bs, n - bs * np.arange(n_blocks)).astype(np.float64)
+        # ``block_rows_global`` (with ``block_row0``): the rows given are this rank's share of ONE block of that many rows -- the
+        # acceptance counts that steer the block's proposal scale and the final report are then summed over the ranks
+        shared = block_rows_global is not None
+        if shared:
+            rows_b = np.array([float(block_rows_global)])
         state = torch.empty((n, eng.q), device=dev, dtype=torch.float32)
         total = burn_in + n_keep
         tail = min(100, total)
@@ -435,7 +440,9 @@ class CausalBGMBayes(CausalBGM):
             seg = b - it
             acc = torch.zeros((seg, n_blocks), device=dev, dtype=torch.int32)
             eng.mh_run(x, y, v, state, bs, it, seg, burn_in, 1.0, seed, init=(it == 0), row_base=row_base, block0=block0,
-                       n_keep=n_keep, q_sd_blocks=sd, acc_blocks=acc, **outs)
+                       n_keep=n_keep, q_sd_blocks=sd, acc_blocks=acc, block_row0=block_row0, **outs)
+            if shared:
+                parallel.all_reduce_sum_(acc)
             a = acc.cpu().numpy().astype(np.float64)
             if it >= total - tail:
                 acc_tail += int(a.sum())

@@ -258,25 +258,39 @@ class IdentifiableCausalBGMBayes(CausalBGMBayes):
             print('MCMC Latent Variable Sampling ...')
         adaptive = (q_sd is None) or (q_sd <= 0)
         seg_all = parallel.broadcast_(torch.from_numpy(self._segments_for(n).astype(np.int32)).to(dev))      # rank 0's draw is everybody's
-        x, y, v = self._dev(data_x).reshape(-1), self._dev(data_y).reshape(-1), self._dev(data_v)
         seed = self._next_seed()
         block = max(2, n)
-        self._set_prior(seg_all.contiguous())
+        # Under torch.distributed the rows of the ONE block are sharded like every other class's rows (round 6): the perturbations are
+        # keyed by the block, the sign words by the position inside it (mh_run(block_row0 = first local row)), the proposals by the global
+        # row -- the result does not depend on the split.  Sessions outside the default-shape sampling kernels keep the replicated run.
+        world = parallel.world_size()
+        sharded = world > 1 and eng.serves_block_shares()
+        lo_r, hi_r = parallel.shard_range(n) if sharded else (0, n)
+        x, y, v = self._dev(data_x[lo_r:hi_r]).reshape(-1), self._dev(data_y[lo_r:hi_r]).reshape(-1), self._dev(data_v[lo_r:hi_r])
+        n_loc = hi_r - lo_r
+        kw = dict(block_row0=lo_r, block_rows_global=n) if sharded else {}
+        self._set_prior(seg_all[lo_r:hi_r].contiguous())
         try:
             if binary:
-                ite = torch.empty((n, n_mcmc), device=dev, dtype=torch.float32)
-                _, acc_tail, tail = self._run_chains(x, y, v, block, burn_in, n_mcmc, q_sd, seed, 0, 0, adaptive, effect=2, sample_y=sample_y, ite=ite)
+                ite = torch.empty((n_loc, n_mcmc), device=dev, dtype=torch.float32)
+                _, acc_tail, tail = self._run_chains(x, y, v, block, burn_in, n_mcmc, q_sd, seed, lo_r, 0, adaptive, effect=2, sample_y=sample_y, ite=ite, **kw)
             else:
                 xv = self._dev(x_values.astype(np.float32))
                 sums = torch.zeros((len(x_values), n_mcmc), device=dev, dtype=torch.float64)
-                _, acc_tail, tail = self._run_chains(x, y, v, block, burn_in, n_mcmc, q_sd, seed, 0, 0, adaptive, effect=1, sample_y=sample_y,
-                                                     x_values=xv, adrf_sum=sums)
+                _, acc_tail, tail = self._run_chains(x, y, v, block, burn_in, n_mcmc, q_sd, seed, lo_r, 0, adaptive, effect=1, sample_y=sample_y,
+                                                     x_values=xv, adrf_sum=sums, **kw)
         finally:
             self._clear_prior()
         self._report_acceptance(float(acc_tail), tail, n, verbose)
         if binary:
             mean, lo, hi = eng.row_mean_quantiles(ite, alpha / 2, 1 - alpha / 2)
+            if sharded:
+                mean = parallel.all_gather_rows_var(mean.reshape(-1, 1)).reshape(-1)
+                lo = parallel.all_gather_rows_var(lo.reshape(-1, 1)).reshape(-1)
+                hi = parallel.all_gather_rows_var(hi.reshape(-1, 1)).reshape(-1)
             return mean.cpu().numpy(), torch.stack([lo, hi], dim=1).cpu().numpy()
+        if sharded:
+            parallel.all_reduce_sum_(sums)
         eff = (sums / float(n)).float().contiguous()
         mean, lo, hi = eng.row_mean_quantiles(eff, alpha / 2, 1 - alpha / 2)
         return mean.cpu().numpy(), torch.stack([lo, hi], dim=1).cpu().numpy()

@@ -723,6 +723,11 @@ typedef struct {
                                           of the reference is its own sampler run with its own adaptive scale          */
   uint32_t *acc_blocks_dev;            /* optional [n_iters x n_blocks]: accepted proposals per iteration and block
                                           (accumulated; the caller's sliding acceptance window, base.py:873-884)       */
+  int64_t block_row0;                  /* position of this call's first row INSIDE block block0 (0: the call starts a block).  > 0: the call
+                                          is a rank's share of ONE block (it must end inside it): the Flipout sign words are keyed by
+                                          (block, position in the block), so the result does not depend on how a block's rows are split
+                                          over ranks (IdentifiableCausalBGM.predict: the whole panel is one block, identifiable.py:557-614).
+                                          Default-shape sampling kernels only (BGM_E_UNSUPPORTED elsewhere)              */
 } bgm_bnn_mh_args;
 /* replaces: metropolis_hastings_sampler (fixed q_sd) + infer_from_latent_posterior with use_bnn, base.py:820-904,
  * 671-763.  All blocks advance in lock step, three launches per iteration (perturbations, proposal + statistics,

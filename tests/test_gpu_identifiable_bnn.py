@@ -327,3 +327,20 @@ def test_two_rank_fit_and_predict():
     assert len(objs) == 2 and all(o["spread"] == 0.0 and o["finite"] for o in objs)
     assert sorted(o["rows"] for o in objs) == [602, 603] and objs[0]["adrf"] == objs[1]["adrf"]
     assert all(k > 0 for k in objs[0]["kl_prior"]) and np.all(np.isfinite(objs[0]["loss"]))
+    # round 6: predict shards the ONE block of the panel by rows (mh_run(block_row0)): the two-rank result is the single-process result,
+    # with a fixed and with the adaptive proposal scale (the block's acceptance counts are summed over the ranks)
+    assert all(o["predict_sharded"] for o in objs)
+    from bayesgm_amd.models import IdentifiableCausalBGM
+    from bayesgm_amd.datasets import Sim_Hirano_Imbens_sampler
+    prm = dict(dataset="dpib", output_dir="gpurun_out/dpib1", save_res=False, save_model=False, binary_treatment=False, use_bnn=True,
+               z_dims=[1, 1, 1, 7], v_dim=50, lr_theta=1e-3, lr_z=1e-3, g_units=[64] * 5, f_units=[64, 32, 8], h_units=[64, 32, 8],
+               e_units=[64] * 5, dz_units=[64, 32, 8], kl_weight=1e-4, lr=2e-4, g_d_freq=5, use_z_rec=True, n_segments=6)
+    x, y, v = Sim_Hirano_Imbens_sampler(N=1205, v_dim=50, seed=1).load_all()
+    m = IdentifiableCausalBGM(prm, random_seed=4)
+    np.random.seed(5)
+    a1, i1 = m.predict((x, y, v), alpha=0.05, n_mcmc=20, burn_in=20, x_values=np.linspace(0, 3, 5), q_sd=0.5, verbose=0)
+    a2, _ = m.predict((x, y, v), alpha=0.05, n_mcmc=20, burn_in=120, x_values=np.linspace(0, 3, 5), q_sd=-1.0, verbose=0)
+    np.testing.assert_allclose(objs[0]["adrf_untrained"], a1, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(objs[0]["interval_untrained"], i1.ravel(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(objs[0]["q_sd_adapted"], np.asarray(m.last_q_sd).ravel(), rtol=1e-6)
+    np.testing.assert_allclose(objs[0]["adrf_untrained_adaptive"], a2, rtol=0, atol=2e-6)
