@@ -23,6 +23,7 @@ m = IdentifiableCausalBGM(prm, random_seed=4, device=dev)
 np.random.seed(5 + 100 * dist.get_rank())              # the ranks' host generators differ: rank 0's segments must win
 adrf_u, interval_u = m.predict((x, y, v), alpha=0.05, n_mcmc=20, burn_in=20, x_values=np.linspace(0, 3, 5), q_sd=0.5, verbose=0)
 adrf_a, _ = m.predict((x, y, v), alpha=0.05, n_mcmc=20, burn_in=120, x_values=np.linspace(0, 3, 5), q_sd=-1.0, verbose=0)
+q_sd_a = [float(a) for a in np.asarray(m.last_q_sd).ravel()]      # the block's adapted proposal scale (acceptance counts summed over the ranks)
 sharded = bool(m.engine.serves_block_shares())
 np.random.seed(11)                     # fit draws the segments and the permutations from the shared host stream
 m.fit((x, y, v), batch_size=32, epochs=2, epochs_per_eval=2, use_egm_init=True, egm_n_iter=12, egm_batches_per_eval=6, verbose=0)
@@ -35,7 +36,7 @@ mx, mn = t.clone(), t.clone()
 dist.all_reduce(mx, op=dist.ReduceOp.MAX); dist.all_reduce(mn, op=dist.ReduceOp.MIN)
 out = dict(rank=dist.get_rank(), spread=float((mx - mn).abs().max().item()), finite=bool(np.all(np.isfinite(flat))), rows=int(m.data_z.shape[0]),
            adrf=[float(a) for a in adrf], adrf_untrained=[float(a) for a in adrf_u], interval_untrained=[float(a) for a in interval_u.ravel()],
-           adrf_untrained_adaptive=[float(a) for a in adrf_a], q_sd_adapted=[float(a) for a in np.asarray(m.last_q_sd).ravel()], predict_sharded=sharded, loss=[h["loss_postrior_z"] for h in m.fit_history], kl_prior=[h["kl_prior"] for h in m.fit_history])
+           adrf_untrained_adaptive=[float(a) for a in adrf_a], q_sd_adapted=q_sd_a, predict_sharded=sharded, loss=[h["loss_postrior_z"] for h in m.fit_history], kl_prior=[h["kl_prior"] for h in m.fit_history])
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from dp_print import print_in_rank_order
 print_in_rank_order(json.dumps(out))

@@ -340,6 +340,7 @@ def test_two_rank_fit_and_predict():
     np.random.seed(5)
     a1, i1 = m.predict((x, y, v), alpha=0.05, n_mcmc=20, burn_in=20, x_values=np.linspace(0, 3, 5), q_sd=0.5, verbose=0)
     a2, _ = m.predict((x, y, v), alpha=0.05, n_mcmc=20, burn_in=120, x_values=np.linspace(0, 3, 5), q_sd=-1.0, verbose=0)
+    assert float(np.asarray(m.last_q_sd).ravel()[0]) != 1.0          # the scale did adapt
     np.testing.assert_allclose(objs[0]["adrf_untrained"], a1, rtol=0, atol=2e-6)
     np.testing.assert_allclose(objs[0]["interval_untrained"], i1.ravel(), rtol=0, atol=2e-6)
     np.testing.assert_allclose(objs[0]["q_sd_adapted"], np.asarray(m.last_q_sd).ravel(), rtol=1e-6)
