@@ -141,3 +141,30 @@ def test_bx3_with_the_conditional_prior(mode):
     assert same >= (0.80 if mode == "bf16x3" else 0.97), same
     eng.set_prior(None, None)
     eng.close()
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x3"])
+def test_bx3_binary_treatment_in_the_event_form(mode):
+    """Split-precision transitions with the retained phase of a binary-treatment predict in its event form (round 6): the chains are
+    the fused split-precision kernel's draw for draw (the transitions are the same kernel plus the event append); the events' outcome
+    net runs in fp32, so the ITE draws differ from the fused run's by its split-precision outcome-net error only."""
+    from bayesgm_amd import _lib
+    m = _model(51, [3, 3, 6, 6], 100, True)
+    x, y, v = _data(1500, 100, 52, True)
+    eng = _engine(m)
+    eng.set_precision(mode)
+    outs = {}
+    for cache in (False, True):
+        eng.set_outcome_cache(cache)
+        eng.outcome_cache_stats(reset=True)
+        outs[cache] = eng.mh_sample(x, y, v, 20, 40, 1.0, 9, want_draws=True, effect=_lib.EFFECT_ITE)
+        outs[cache]["stats"] = eng.outcome_cache_stats()
+    assert outs[True]["stats"][1] == 1500 * 40                                   # chain-iterations: the event form ran
+    for kk in ("draws", "acc_count", "state"):
+        assert np.array_equal(outs[True][kk].cpu().numpy(), outs[False][kk].cpu().numpy()), kk
+    d = np.abs(outs[True]["ite"].cpu().numpy() - outs[False]["ite"].cpu().numpy()).max()
+    print("%s: max |ITE(event form, fp32 outcome net) - ITE(fused split precision)| = %.2e" % (mode, d))
+    assert d <= (2e-2 if mode == "bf16x3" else 2e-3)
+    eng.set_precision("fp32")
+    eng.set_outcome_cache(True)
+    eng.close()
