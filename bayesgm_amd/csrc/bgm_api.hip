@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <utility>
 
 #include "bgm_host.h"
 #include "bgm_kernels.h"
@@ -156,7 +157,10 @@ static int bgm_build_blob(bgm_handle *h, hipStream_t stream) {
     //   heads   the 16 KiB blocks above, BGM_X3_STEP per step
     if (KTQ != 1) { bgm_set_error("BGM generator: split precision serves z_dim <= 16"); return BGM_E_UNSUPPORTED; }
     {
-      const int S = (NTX + BGM_X3_STEP - 1) / BGM_X3_STEP, n_steps = 2 * NH + S;
+      const int S = (NTX + BGM_X3_STEP - 1) / BGM_X3_STEP, U = BGM_X3_STEP, FT = (NH + U - 1) / U, n_steps = 2 * FT + S;
+      // trunk layer l forward: unit l % U of step l / U; backward unit i = NH - 1 - l (hidden NH - 1 first, L1 last): unit i % U of step FT + S + i / U
+      auto fpos = [&](int l) { return std::pair<size_t, int>((size_t)(l / U), (l % U) * 16); };
+      auto bpos = [&](int l) { const int i = NH - 1 - l; return std::pair<size_t, int>((size_t)(FT + S + i / U), (i % U) * 16); };
       const size_t step_h = (size_t)BGM_X3_STEP * (BGM_X3_BLOCK_BYTES / 2);      // halves per step
       std::vector<unsigned short> sx((size_t)n_steps * step_h, 0);
       auto put2 = [&](size_t step, int frag, int lane, int u, float w) {
@@ -170,30 +174,31 @@ static int bgm_build_blob(bgm_handle *h, hipStream_t stream) {
         const int i = lane & 15, gA = lane >> 4;
         for (int u = 0; u < 8; ++u) {
           const int ku = 4 * gA + (u & 3);      // + 16 (2 b + (u >> 2))
-          for (int first = 0; first < 2; ++first) {      // L1 sits at step 0 (forward use) and at the last step (backward use)
-            const size_t st = first ? 0 : (size_t)n_steps - 1;
+          for (int first = 0; first < 2; ++first) {      // L1 sits at its forward position and at its backward position (the last unit)
+            const auto pos = first ? fpos(0) : bpos(0);
             for (int mt = 0; mt < 4; ++mt) {
               const int f = 4 * u + gA;
-              put2(st, 2 * mt, lane, u, (u < 4 && f < q) ? W1[(size_t)f * 64 + 16 * mt + i] : 0.0f);
+              put2(pos.first, pos.second + 2 * mt, lane, u, (u < 4 && f < q) ? W1[(size_t)f * 64 + 16 * mt + i] : 0.0f);
             }
             for (int b = 0; b < 2; ++b) {
               const int f = 4 * (i & 3) + (i >> 2);
-              put2(st, 8 + 2 * b, lane, u, f < q ? W1[(size_t)f * 64 + 16 * (2 * b + (u >> 2)) + ku] : 0.0f);
+              put2(pos.first, pos.second + 8 + 2 * b, lane, u, f < q ? W1[(size_t)f * 64 + 16 * (2 * b + (u >> 2)) + ku] : 0.0f);
             }
           }
           for (int l = 1; l < NH; ++l) {
             const float *W = Wh + (size_t)(l - 1) * (4096 + 64);
+            const auto pf = fpos(l), pb = bpos(l);
             for (int t = 0; t < 4; ++t)
               for (int b = 0; b < 2; ++b) {
                 const int k = 16 * (2 * b + (u >> 2)) + ku;
-                put2((size_t)l, 2 * (2 * t + b), lane, u, W[(size_t)k * 64 + 16 * t + i]);                              // forward: out tile t
-                put2((size_t)(NH + S + (NH - 1 - l)), 2 * (2 * t + b), lane, u, W[(size_t)(16 * t + i) * 64 + k]);      // backward: in tile t
+                put2(pf.first, pf.second + 2 * (2 * t + b), lane, u, W[(size_t)k * 64 + 16 * t + i]);              // forward: out tile t
+                put2(pb.first, pb.second + 2 * (2 * t + b), lane, u, W[(size_t)(16 * t + i) * 64 + k]);            // backward: in tile t
               }
           }
         }
       }
       for (int tx = 0; tx < NTX; ++tx)      // the head blocks as packed above
-        std::memcpy(&sx[(size_t)(NH + tx / BGM_X3_STEP) * step_h + (size_t)(tx % BGM_X3_STEP) * (BGM_X3_BLOCK_BYTES / 2)],
+        std::memcpy(&sx[(size_t)(FT + tx / BGM_X3_STEP) * step_h + (size_t)(tx % BGM_X3_STEP) * (BGM_X3_BLOCK_BYTES / 2)],
                     &hx3[(size_t)tx * (BGM_X3_BLOCK_BYTES / 2)], BGM_X3_BLOCK_BYTES);
       if (s->sx3_cap < sx.size() * 2) {
         if (s->sx3_dev) BGM_HIP_CHECK(hipFree(s->sx3_dev));

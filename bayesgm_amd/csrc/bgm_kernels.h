@@ -202,8 +202,8 @@ __device__ __forceinline__ void bgm_head_tile(const float *wl, const float *lds,
 // hidden layer, which does not fit beside a stage.  So the whole generator is ONE LINEAR STREAM of 32 KiB steps, packed on the host
 // (bgm_api.hip) and walked by the workgroup in lock step through a double-buffered LDS stage filled by global_load_lds_dwordx4 (the
 // fragments are lane-linear: exactly what that instruction writes; no staging registers, no ds_write pass):
-//     [L1 (forward + transposed) | hidden 1 .. NH - 1 forward | head steps (two 16-feature blocks each) | hidden NH - 1 .. 1 transposed | L1]
-// 2 NH + ceil(ntx / 2) steps per gradient evaluation, 0.8 MB at p = 500 (L2 resident); LDS holds the biases and the 64 KiB stage.
+//     [L1 (forward + transposed), hidden 1 .. NH - 1 forward | head blocks | hidden NH - 1 .. 1 transposed, L1]   two 16 KiB units per step
+// 2 ceil(NH / 2) + ceil(ntx / 2) steps per gradient evaluation (22 at NH = 5, p = 500: 0.7 MB, L2 resident); LDS holds the biases and the 64 KiB stage.
 // The likelihood arithmetic, the leapfrog and all accumulations stay fp32.
 // fp16 range: a weight beyond 65504 is clamped by the packer; dlogp/d(mean, s) and the back-propagated d(pre-activation) beyond 6e4 (a
 // variance ~1e-5 under a unit residual) are clamped in the kernel -- the fp32 kernels have no such bound.
@@ -236,7 +236,9 @@ __device__ __forceinline__ void bgm_split8(const f32x4 &a, const f32x4 &b, bgm_h
 
 // BGM_X3_STEP head blocks per step of the stream (one barrier per step): with the matrix work of a block down to ~400 cycles a
 // barrier and a fetch per 16 features were what the waves waited for (34 % of the wave cycles parked, r06_pmc_sq_bgm_hmc_f16x3.txt)
+#ifndef BGM_X3_STEP
 #define BGM_X3_STEP 2
+#endif
 #ifndef BGM_X3_INTERLEAVE
 #define BGM_X3_INTERLEAVE 0
 #endif
@@ -409,6 +411,7 @@ __device__ __forceinline__ void bgm_logp_grad(const float *lds, const BgmMeta &m
     // head steps, hidden NH - 1 .. 1 backward, L1 backward; step 0 is current on entry, the last step fetches it for the next call.
     static_assert(KTQ == 1, "split-precision trunk: z_dim <= 16");
     const int lane2 = 16 * g + j;
+    constexpr int U = BGM_X3_STEP;      // layer l of the trunk is unit l % U of step l / U: U layers per step, one barrier per U layers
     hs.fetch(1);
     {
       bgm_h8 zh, zl;
@@ -433,15 +436,15 @@ __device__ __forceinline__ void bgm_logp_grad(const float *lds, const BgmMeta &m
         h[t][r] = lrelu(h[t][r]);
       }
     asm volatile("" : "+v"(sgn[0]));
-    hs.commit();
+    if (U == 1 || NH == 1) hs.commit();
 #pragma unroll
     for (int l = 1; l < NH; ++l) {
       BGM_NO_HOIST();
-      hs.fetch(l + 1);
+      if (l % U == 0) hs.fetch(l / U + 1);
       bgm_h8 bh_[2], bl_[2];
       bgm_split8(h[0], h[1], bh_[0], bl_[0]);
       bgm_split8(h[2], h[3], bh_[1], bl_[1]);
-      const bgm_h8 *fr = reinterpret_cast<const bgm_h8 *>(hs.tile(0)) + lane2;
+      const bgm_h8 *fr = reinterpret_cast<const bgm_h8 *>(hs.tile(l % U)) + lane2;
       f32x4 h2[4];
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) h2[mt] = *reinterpret_cast<const f32x4 *>(lds + m.bh + (l - 1) * 64 + 16 * mt + 4 * g);
@@ -466,7 +469,7 @@ __device__ __forceinline__ void bgm_logp_grad(const float *lds, const BgmMeta &m
           h[t][r] = lrelu(h2[t][r]);
         }
       asm volatile("" : "+v"(sgn[l]));
-      hs.commit();
+      if (l % U == U - 1 || l == NH - 1) hs.commit();
     }
   } else {
   bias17<4>(lds + m.b1, g, h);
@@ -516,7 +519,8 @@ __device__ __forceinline__ void bgm_logp_grad(const float *lds, const BgmMeta &m
     const int n_steps = (m.ntx + BGM_X3_STEP - 1) / BGM_X3_STEP;
     // (PREC 2: the head steps sit behind the NH forward steps of the trunk; behind the last one comes the first backward step, or
     // step 0 again when no gradient is wanted)
-    const int s0 = PREC == 2 ? NH : 0, s_after = (PREC == 2 && WANT_GRAD) ? NH + n_steps : 0;
+    constexpr int FT = (NH + BGM_X3_STEP - 1) / BGM_X3_STEP;      // steps of the trunk per direction
+    const int s0 = PREC == 2 ? FT : 0, s_after = (PREC == 2 && WANT_GRAD) ? FT + n_steps : 0;
 #pragma unroll 1
     for (int st = 0; st < n_steps; ++st) {
       BGM_NO_HOIST();
@@ -575,11 +579,13 @@ __device__ __forceinline__ void bgm_logp_grad(const float *lds, const BgmMeta &m
   if (WANT_GRAD) {
     if constexpr (PREC == 2) {
       const int lane2 = 16 * g + j;
-      const int sb0 = NH + (m.ntx + BGM_X3_STEP - 1) / BGM_X3_STEP;      // first backward step
+      constexpr int U = BGM_X3_STEP, FT = (NH + U - 1) / U;
+      const int sb0 = FT + (m.ntx + U - 1) / U;      // first backward step; backward unit i = NH - 1 - l is unit i % U of step sb0 + i / U
 #pragma unroll
       for (int l = NH - 1; l >= 0; --l) {
         BGM_NO_HOIST();
-        hs.fetch(l > 0 ? sb0 + (NH - 1 - l) + 1 : 0);
+        const int bi = NH - 1 - l;
+        if (bi % U == 0) hs.fetch(bi / U + 1 < FT ? sb0 + bi / U + 1 : 0);
         // d(pre-activation) = dh o LeakyReLU', clamped into the fp16 range like the heads' gradients, split once per layer
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -589,7 +595,7 @@ __device__ __forceinline__ void bgm_logp_grad(const float *lds, const BgmMeta &m
         bgm_h8 dhh[2], dhl[2];
         bgm_split8(dh[0], dh[1], dhh[0], dhl[0]);
         bgm_split8(dh[2], dh[3], dhh[1], dhl[1]);
-        const bgm_h8 *fr = reinterpret_cast<const bgm_h8 *>(hs.tile(0)) + lane2;
+        const bgm_h8 *fr = reinterpret_cast<const bgm_h8 *>(hs.tile(bi % U)) + lane2;
         if (l > 0) {
           f32x4 dn[4];
 #pragma unroll
@@ -622,7 +628,7 @@ __device__ __forceinline__ void bgm_logp_grad(const float *lds, const BgmMeta &m
 #pragma unroll
           for (int r = 0; r < 4; ++r) grad[0][r] = ga[0][r] + ga[1][r];
         }
-        hs.commit();
+        if (bi % U == U - 1 || l == 0) hs.commit();
       }
     } else {
 #pragma unroll
@@ -776,7 +782,7 @@ __global__ __launch_bounds__(64 * WAVES) void bgm_hmc_kernel(BgmHmcKArgs a) {
     if constexpr (NTX == 0) {
       if (!tile_ok) {
         const int evals = (a.init ? 1 : 0) + a.n_iters * a.n_leapfrog;
-        const int n_steps = PREC == 0 ? m.ntx : (m.ntx + BGM_X3_STEP - 1) / BGM_X3_STEP + (PREC == 2 ? 2 * NH : 0);      // (steps of the stream per evaluation)
+        const int n_steps = PREC == 0 ? m.ntx : (m.ntx + BGM_X3_STEP - 1) / BGM_X3_STEP + (PREC == 2 ? 2 * ((NH + BGM_X3_STEP - 1) / BGM_X3_STEP) : 0);      // (steps of the stream per evaluation)
         for (int e = 0; e < evals; ++e)
           for (int tx = 0; tx < n_steps; ++tx) { hs.fetch(tx + 1 < n_steps ? tx + 1 : 0); hs.commit(); }
         continue;
