@@ -179,6 +179,7 @@ SYMBOLS = {
     "bgm_bgm_logpost": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bgm_bgm_hmc_run": (C.c_int, [C.c_void_p, C.POINTER(HmcArgs), C.c_void_p]),
     "bgm_bgm_set_precision": (C.c_int, [C.c_void_p, C.c_int32]),
+    "bgm_bvn_set_precision": (C.c_int, [C.c_void_p, C.c_int32]),
     "bgm_bgm_hmc_adapt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_float, C.c_float,
                                     C.c_void_p]),
     "bgm_bgm_predict_draws": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,

@@ -315,12 +315,22 @@ struct BgmHeadStreamX3 {
       }
     }
   }
-  __device__ __forceinline__ void begin(const unsigned char *frags, const BgmMeta &m, float *lds) {
-    src = reinterpret_cast<const f32x4 *>(frags); buf = reinterpret_cast<unsigned char *>(lds + m.stage); tid = threadIdx.x;
+  __device__ __forceinline__ void load_x1(const float *row, int p, int tx, int g) {      // one block's values into xn[0] (bgmfx_kernels.h: one block per step)
+    const int c = 16 * tx + 4 * g;
+    if ((p & 3) == 0) {
+      xn[0] = (c < p) ? *reinterpret_cast<const f32x4 *>(row + c) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xn[0][r] = (c + r < p) ? row[c + r] : 0.0f;
+    }
+  }
+  __device__ __forceinline__ void begin_at(const unsigned char *frags, float *stage) {
+    src = reinterpret_cast<const f32x4 *>(frags); buf = reinterpret_cast<unsigned char *>(stage); tid = threadIdx.x;
     cur = 1; x_valid = false;
     fetch(0);
     commit();
   }
+  __device__ __forceinline__ void begin(const unsigned char *frags, const BgmMeta &m, float *lds) { begin_at(frags, lds + m.stage); }
 };
 
 // One 16-feature head block in split precision, in three parts so that a step of the stream (BGM_X3_STEP blocks) can be issued as
@@ -347,31 +357,38 @@ __device__ __forceinline__ void bgm_x3_fwd(const unsigned char *tile, const floa
 #pragma unroll
   for (int f = 0; f < 4; ++f) part[f] = BGM_MFMA_H(ah[f], hh[f & 1], part[f]);
 }
+// the Gaussian likelihood of one (row, feature) from the heads' raw outputs (mean, s): variance = softplus(s) + eps; dmu / ds clamped
+// into the fp16 range (they are the next products' operands)
+template <bool WANT_GRAD>
+__device__ __forceinline__ void bgm_x3_lik(float x_, float mu_, float s_, bool in_range, bool want_lp, float &nll, float &dmu, float &ds) {
+#ifdef BGM_X3_ABL_NOEPI         // development ablation: the likelihood arithmetic replaced by two subtractions (timing only)
+  dmu = x_ - mu_; ds = s_ - x_; nll += mu_;
+  return;
+#endif
+  const bool obs = (x_ == x_) && in_range;   // NaN = missing; padding columns / blocks are never observed
+  // softplus and its derivative from ONE exponential: e = exp(-|s|), softplus = max(s, 0) + log1p(e), sigmoid = (s >= 0 ? 1 : e) / (1 + e)
+  const float e = fast_exp(-fabsf(s_));
+  const float l1p = (e < 2.44140625e-4f) ? e * (1.0f - 0.5f * e) : fast_log(1.0f + e);
+  const float s2 = vmax(s_, 0.0f) + l1p + BGM_EPS;
+  const float inv = fast_rcp(s2);
+  const float d = obs ? x_ - mu_ : 0.0f;
+  if (want_lp) nll += obs ? 0.5f * (d * d * inv + fast_log(s2)) : 0.0f;
+  if (WANT_GRAD) {
+    const float sg = (s_ >= 0.0f ? 1.0f : e) * fast_rcp(1.0f + e);
+    const float di = d * inv;
+    dmu = __builtin_amdgcn_fmed3f(di, -6.0e4f, 6.0e4f);                                              // dlogp/dmu
+    ds = obs ? __builtin_amdgcn_fmed3f((0.5f * di * di - 0.5f * inv) * sg, -6.0e4f, 6.0e4f) : 0.0f;   // dlogp/ds
+  }
+}
 template <bool WANT_GRAD>
 __device__ __forceinline__ void bgm_x3_epilogue(const BgmMeta &m, int tx, int g, const f32x4 (&part)[4], const f32x4 &xv, bool want_lp,
                                                 float &nll, bgm_h8 &dhi, bgm_h8 &dlo) {
   f32x4 dms[2];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const float x_ = xv[r], mu_ = part[0][r] + part[1][r], s_ = part[2][r] + part[3][r];
-#ifdef BGM_X3_ABL_NOEPI         // development ablation: the likelihood arithmetic replaced by two subtractions (timing only)
-    dms[0][r] = x_ - mu_; dms[1][r] = s_ - x_; nll += mu_;
-    continue;
-#endif
-    const bool obs = (x_ == x_) && (16 * tx + 4 * g + r < m.p);   // NaN = missing; padding columns / blocks are never observed
-    // softplus and its derivative from ONE exponential: e = exp(-|s|), softplus = max(s, 0) + log1p(e), sigmoid = (s >= 0 ? 1 : e) / (1 + e)
-    const float e = fast_exp(-fabsf(s_));
-    const float l1p = (e < 2.44140625e-4f) ? e * (1.0f - 0.5f * e) : fast_log(1.0f + e);
-    const float s2 = vmax(s_, 0.0f) + l1p + BGM_EPS;
-    const float inv = fast_rcp(s2);
-    const float d = obs ? x_ - mu_ : 0.0f;
-    if (want_lp) nll += obs ? 0.5f * (d * d * inv + fast_log(s2)) : 0.0f;
-    if (WANT_GRAD) {
-      const float sg = (s_ >= 0.0f ? 1.0f : e) * fast_rcp(1.0f + e);
-      const float di = d * inv;
-      dms[0][r] = __builtin_amdgcn_fmed3f(di, -6.0e4f, 6.0e4f);                                              // dlogp/dmu
-      dms[1][r] = obs ? __builtin_amdgcn_fmed3f((0.5f * di * di - 0.5f * inv) * sg, -6.0e4f, 6.0e4f) : 0.0f;   // dlogp/ds
-    }
+    float dmu, ds;
+    bgm_x3_lik<WANT_GRAD>(xv[r], part[0][r] + part[1][r], part[2][r] + part[3][r], 16 * tx + 4 * g + r < m.p, want_lp, nll, dmu, ds);
+    dms[0][r] = dmu; dms[1][r] = ds;
   }
   if (WANT_GRAD) bgm_split8(dms[0], dms[1], dhi, dlo);
 }

@@ -426,6 +426,13 @@ extern "C" int bgm_bvn_hmc_run(bgm_handle *h, const bgm_hmc_args *g, void *strea
   return BGM_OK;
 }
 
+extern "C" int bgm_bvn_set_precision(bgm_handle *h, int32_t mode) {
+  int rc = bvn_need(h, "bgm_bvn_set_precision");
+  if (rc) return rc;
+  BGM_HIP_CHECK(hipSetDevice(h->device));
+  return bgmf_set_precision(vst(h), mode);
+}
+
 extern "C" int bgm_bvn_decode(bgm_handle *h, const float *draws_dev, int64_t n, int64_t row_base, int32_t n_draws, int32_t burn_in,
                               uint64_t seed, uint32_t stream_id, uint32_t sign_stride, uint32_t sign_off, const int32_t *slot_dev,
                               int32_t k_slots, float *cells_dev, float *full_dev, float *var_full_dev, int32_t add_noise,

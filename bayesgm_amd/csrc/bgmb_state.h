@@ -24,10 +24,12 @@ struct BgmbState {
   void *egm = nullptr;         // BgmbEgmState (bgmb_egm_api.hip)
   void *gxf = nullptr;         // GxfState (bgmb_api.hip): packs of the LDS-tiled frozen-noise HMC kernel (gx_flipout.h)
   void *bgmf = nullptr;        // BgmfState (bgmf_api.hip): blob of the register-chained frozen-noise HMC kernel (bgmf_kernels.h)
+  int precision = 0;           // 0 fp32 | 2 f16x3 (bgm_bvn_set_precision; frozen-noise HMC on bgmfx_hmc_kernel)
 };
 
 int bgmb_fill(const bgm_bvn_config *cfg, BnnNet &n);
 void bgm_bvn_egm_free(void *egm_state);
 void bgmf_free(BgmbState *s);
+int bgmf_set_precision(BgmbState *s, int mode);
 int bgmf_hmc_try(bgm_handle *h, BgmbState *s, const bgm_hmc_args *g, hipStream_t st);     // 0 launched, 1 not its shape, < 0 error
 int bgmf_hmc_fresh(bgm_handle *h, BgmbState *s, const bgm_hmc_args *g, int it_begin, int n_iters, int init, long long dw_stride, hipStream_t st);

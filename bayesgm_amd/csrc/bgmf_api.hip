@@ -6,7 +6,7 @@
 
 #include "bgm_host.h"
 #include "bgmb_state.h"
-#include "bgmf_kernels.h"
+#include "bgmfx_kernels.h"
 
 struct BgmfState {
   BgmfMeta m{};
@@ -15,6 +15,11 @@ struct BgmfState {
   float *blob_fresh = nullptr; // fresh noise: resident part + fresh_slots slots [dW first layer | dW hidden | head blocks]
   int fresh_slots = 0;
   int lds_bytes = 0, ktq = 1;
+  // split precision (bgmfx_kernels.h): the stream of fp16 fragments, the fp32 resident part, their meta (LDS offsets); 0 bytes = not served
+  BgmfMeta xm{};
+  unsigned char *sx = nullptr;
+  float *xres = nullptr;
+  int lds_bytes_x = 0;
 };
 
 void bgmf_free(BgmbState *s) {
@@ -22,6 +27,8 @@ void bgmf_free(BgmbState *s) {
   if (!f) return;
   if (f->blob) hipFree(f->blob);
   if (f->blob_fresh) hipFree(f->blob_fresh);
+  if (f->sx) hipFree(f->sx);
+  if (f->xres) hipFree(f->xres);
   delete f;
   s->bgmf = nullptr;
 }
@@ -68,11 +75,83 @@ static int bgmf_session(BgmbState *s, BgmfState *&out) {
   return BGM_OK;
 }
 
+// Split precision: meta and buffers of the streamed form, made on first use.  0: ready; 1: not served (z_dim > 16, LDS); < 0: error
+static int bgmfx_session(BgmfState *f) {
+  if (f->sx) return BGM_OK;
+  if (f->ktq != 1) return 1;
+  BgmfMeta &x = f->xm;
+  x = f->m;
+  int off = 0;
+  auto take = [&](int cnt) { const int o = off; off += (cnt + 3) / 4 * 4; return o; };
+  x.w1 = x.d1 = x.wh = 0;
+  x.b1 = take(64); x.bh = take((x.nh - 1) * 64); x.bhd = take(2 * 16 * x.ntx); x.sc = take(16); x.sh = take(16);
+  x.resident = off;
+  x.stage = off; off += 2 * BGM_X3_STEP * (BGM_X3_BLOCK_BYTES / 4);
+  x.sign = off;
+  f->lds_bytes_x = (int)sizeof(float) * (x.sign + 16 * BGMFX_WAVES * x.swp);
+  if (f->lds_bytes_x > 160 * 1024) { f->lds_bytes_x = 0; return 1; }
+  const size_t sx_bytes = (size_t)(2 * x.nh - 1 + x.ntx) * BGM_X3_STEP * BGM_X3_BLOCK_BYTES;
+  if (hipMalloc((void **)&f->sx, sx_bytes) != hipSuccess || hipMemset(f->sx, 0, sx_bytes) != hipSuccess ||
+      hipMalloc((void **)&f->xres, sizeof(float) * (size_t)x.resident) != hipSuccess || hipMemset(f->xres, 0, sizeof(float) * (size_t)x.resident) != hipSuccess) {
+    if (f->sx) hipFree(f->sx);
+    if (f->xres) hipFree(f->xres);
+    f->sx = nullptr; f->xres = nullptr;
+    bgm_set_error("frozen-noise HMC (split precision): device allocation failed");
+    return BGM_E_HIP;
+  }
+  return BGM_OK;
+}
+
+// bgm_bvn_set_precision: 0 fp32 | 2 f16x3 (frozen noise on the reference's generator shape with z_dim <= 16 only)
+int bgmf_set_precision(BgmbState *s, int mode) {
+  if (mode != 0 && mode != 2) { bgm_set_error("bgm_bvn_set_precision: mode 0 (fp32) or 2 (f16x3)"); return BGM_E_INVALID; }
+  if (mode == 2) {
+    BgmfState *f;
+    int rc = s->cfg.hmc_frozen_noise ? bgmf_session(s, f) : 1;
+    if (rc == 0) rc = bgmfx_session(f);
+    if (rc < 0) return rc;
+    if (rc) { bgm_set_error("bgm_bvn_set_precision: f16x3 serves frozen-noise HMC of generators with 3 or 5 hidden layers of 64 units and z_dim <= 16"); return BGM_E_UNSUPPORTED; }
+  }
+  s->precision = mode;
+  return BGM_OK;
+}
+
+static int bgmfx_hmc(bgm_handle *h, BgmbState *s, BgmfState *f, const bgm_hmc_args *g, hipStream_t st) {
+  int rc = bgmfx_session(f);
+  if (rc) return rc < 0 ? rc : BGM_E_UNSUPPORTED;
+  BgmfxPackArgs pk{};
+  pk.m = f->xm;
+  for (int l = 0; l < BGMF_MAXNH + 2; ++l) { pk.woff[l] = f->pk.woff[l]; pk.eoff[l] = f->pk.eoff[l]; }
+  pk.theta = s->theta_dev; pk.dwc = s->dw_dev; pk.bnp = s->theta_dev + s->net.off; pk.sx = f->sx; pk.res = f->xres;
+  const int n_steps = 2 * f->xm.nh - 1 + f->xm.ntx;
+  hipLaunchKernelGGL(bgmfx_pack_kernel, dim3((unsigned)n_steps + 1, 16), dim3(512), 0, st, pk);      // fragments of the CURRENT parameters and of this run's perturbation
+  BGM_HIP_CHECK(hipGetLastError());
+  BgmfxHmcKArgs x{};
+  BgmfHmcKArgs &k = x.k;
+  k.blob = f->xres; k.x = g->x_dev; k.n = g->n; k.row_base = g->row_base; k.state = g->state_dev; k.logp = g->logp_dev; k.grad = g->grad_dev;
+  k.init = g->init; k.it_begin = g->it_begin; k.n_iters = g->n_iters; k.burn_in = g->burn_in; k.n_leapfrog = g->n_leapfrog; k.step = g->step_dev;
+  k.k0 = (uint32_t)(g->seed & 0xFFFFFFFFull); k.k1 = (uint32_t)(g->seed >> 32);
+  k.acc_prob_sum = g->acc_prob_sum_dev; k.acc_count = g->acc_count_dev; k.draws = g->draws_dev;
+  k.m = f->xm;
+  x.sx = f->sx;
+  const long long tiles = (g->n + 15) / 16;
+  const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((tiles + BGMFX_WAVES - 1) / BGMFX_WAVES, h->n_cus));
+  auto launch = [&](auto kern) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, f->lds_bytes_x) != hipSuccess) return BGM_E_HIP;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * BGMFX_WAVES), f->lds_bytes_x, st, x);
+    return hipGetLastError() == hipSuccess ? BGM_OK : BGM_E_HIP;
+  };
+  rc = f->xm.nh == 5 ? launch(bgmfx_hmc_kernel<5, BGMFX_WAVES>) : launch(bgmfx_hmc_kernel<3, BGMFX_WAVES>);
+  if (rc) bgm_set_error("frozen-noise HMC (bgmfx_hmc_kernel): launch failed");
+  return rc;
+}
+
 // 0: launched; 1: not this kernel's shape; < 0: error
 int bgmf_hmc_try(bgm_handle *h, BgmbState *s, const bgm_hmc_args *g, hipStream_t st) {
   BgmfState *f;
   int rc = bgmf_session(s, f);
   if (rc) return rc;
+  if (s->precision == 2) return bgmfx_hmc(h, s, f, g, st);
   BgmfPackArgs pk = f->pk;
   pk.theta = s->theta_dev; pk.dwc = s->dw_dev; pk.bnp = s->theta_dev + s->net.off; pk.fresh = 0; pk.dw_stride = 0;
   hipLaunchKernelGGL(bgmf_pack_kernel, dim3(32, f->m.nh + 1, 1), dim3(256), 0, st, pk);        // blob of the CURRENT parameters and of this run's perturbation

@@ -102,6 +102,10 @@ class BGMBayes(BGM):
         from .causalbgm import _disc_norm
         self.engine.set_disc_norm(_disc_norm(p))
         self.engine.begin(self.g)
+        # params['hmc_precision'] (build option, default "fp32" = the reference's arithmetic): "f16x3" runs the generator's products of
+        # the frozen-noise HMC in split fp16 (bgmfx_kernels.h); raises where that kernel does not serve the model
+        if p.get("hmc_precision", "fp32") != "fp32":
+            self.engine.set_precision(p["hmc_precision"])
         if self.timestamp is None:
             self.timestamp = datetime.datetime.now().astimezone().strftime('%Y%m%d_%H%M%S')
         self.checkpoint_path = "{}/checkpoints/{}/{}".format(params['output_dir'], params['dataset'], self.timestamp)

@@ -794,6 +794,11 @@ BGM_API int bgm_bvn_logpost(bgm_handle *h, const float *z_dev, const float *x_de
  * `leap` of transition `it` is generator call 1 + it * n_leapfrog + leap (call 0 = bootstrap when init = 1); the cached
  * log-prob / gradient of the current state are kept, as TFP does.  Same argument struct as bgm_bgm_hmc_run. */
 BGM_API int bgm_bvn_hmc_run(bgm_handle *h, const bgm_hmc_args *args, void *stream);
+/* Arithmetic of bgm_bvn_hmc_run launched afterwards (no reference counterpart: the reference computes in fp32): 0 fp32 (default) |
+ * 2 f16x3 -- the generator's products (posterior means and perturbation) in split fp16 with fp32 accumulation (bgmfx_kernels.h);
+ * opt-in.  f16x3 serves frozen-noise HMC (cfg.hmc_frozen_noise) of generators with 3 or 5 hidden layers of 64 units and
+ * z_dim <= 16; anything else: BGM_E_UNSUPPORTED and the mode is unchanged. */
+BGM_API int bgm_bvn_set_precision(bgm_handle *h, int32_t mode);
 /* replaces: g_net(z, training=False) + reparameterize in predict_on_posteriors / generate / evaluate (:511-525, :478-509,
  * :444-476): ONE generator call (stream_id) over the flattened [n_draws x n] rows; the Flipout signs of draw d, row r are
  * keyed by d * sign_stride + sign_off + r (predict: sign_stride = bs, sign_off = position of the first row inside its
