@@ -39,6 +39,10 @@ struct BnnState {
   const int *bp_seg = nullptr;
   float *bp_rows = nullptr;    // [n_states][n][q + 2] of the current call
   size_t bp_rows_cap = 0;
+  int *bp_hist = nullptr;      // batch statistics of the prior net's one-hot input: rows per (block, segment) of the panel bp_seg [n_blocks][k]
+  size_t bp_hist_cap = 0;
+  long long bp_hist_n = -1;    // (n, block rows) the counts were made for; -1: none (bgm_bnn_set_prior invalidates)
+  int bp_hist_bs = 0;
 };
 int bprior_rows(bgm_handle *h, BnnState *s, long long n, int bs, int block0, uint64_t seed, uint32_t stream0, int n_states, hipStream_t stream,
                 long long rib0 = 0);
@@ -67,4 +71,6 @@ inline void bnn_free_sampler(BnnState *s) {
   s->bnf_valid = false;
   if (s->bp_rows) hipFree(s->bp_rows);
   s->bp_rows = nullptr; s->bp_rows_cap = 0;
+  if (s->bp_hist) hipFree(s->bp_hist);
+  s->bp_hist = nullptr; s->bp_hist_cap = 0; s->bp_hist_n = -1;
 }

@@ -106,13 +106,13 @@ extern "C" int bgm_bnn_set_prior(bgm_handle *h, const bgm_prior_config *cfg, con
   BnnState *s = static_cast<BnnState *>(h->bnn_state);
   if (!theta_dev) { s->bp_on = false; s->bp_theta = nullptr; s->bp_seg = nullptr; return BGM_OK; }
   if (!seg_dev) { bgm_set_error("bgm_bnn_set_prior: seg_dev == NULL"); return BGM_E_INVALID; }
-  if (s->cfg.norm_mode != 1) {
-    bgm_set_error("bgm_bnn_set_prior: the conditional prior is built for the inference-mode normalisation sampling kernels (bnn_norm='fixed') only");
-    return BGM_E_UNSUPPORTED;
-  }
+  // the prior net's input BatchNormalization follows the session's mode: inference mode (fixed mean 0 / variance 1), or the statistics of
+  // the block of rows of the call (the reference as written; the nets g, h, f then run on the any-width path's statistics passes)
   BPriorNet n;
-  int rc = bprior_net_of(cfg, 1, n, "bgm_bnn_set_prior");
+  int rc = bprior_net_of(cfg, s->cfg.norm_mode == 1 ? 1 : 0, n, "bgm_bnn_set_prior");
   if (rc) return rc;
+  if (n.norm_mode == 0 && n.dims[0] > 64) { bgm_set_error("bgm_bnn_set_prior: batch statistics hold at most 64 segments"); return BGM_E_UNSUPPORTED; }
+  s->bp_hist_n = -1;
   if (n.dims[n.n_layers] != s->q + 1) { bgm_set_error("bgm_bnn_set_prior: the prior net's output width must be sum(z_dims) + 1"); return BGM_E_INVALID; }
   s->bp_net = n; s->bp_theta = theta_dev; s->bp_seg = seg_dev; s->bp_on = true;
   return BGM_OK;
@@ -135,7 +135,23 @@ int bprior_rows(bgm_handle *h, BnnState *s, long long n, int bs, int block0, uin
   const size_t lds = sizeof(float) * ((size_t)tot + (size_t)net.n_kernel + (size_t)BPRIOR_ROWS_CHUNK * net.words + BPRIOR_ROWS_CHUNK);
   if (lds > 150 * 1024) { bgm_set_error("conditional prior: the prior net's widths exceed the LDS budget of the sampling-side kernel"); return BGM_E_UNSUPPORTED; }
   BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(bprior_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (net.norm_mode == 0) {
+    if (rib0 != 0) { bgm_set_error("conditional prior: a share of one block needs the inference-mode normalisation"); return BGM_E_UNSUPPORTED; }
+    if (s->bp_hist_n != n || s->bp_hist_bs != bs) {      // the segments of the panel do not change between the calls of a run
+      const size_t cnt = (size_t)n_blocks * (size_t)net.dims[0];
+      if (s->bp_hist_cap < cnt) {
+        if (s->bp_hist) BGM_HIP_CHECK(hipFree(s->bp_hist));
+        s->bp_hist = nullptr; s->bp_hist_cap = 0;
+        BGM_HIP_CHECK(hipMalloc((void **)&s->bp_hist, cnt * sizeof(int)));
+        s->bp_hist_cap = cnt;
+      }
+      hipLaunchKernelGGL(bprior_hist_kernel, dim3(n_blocks), dim3(256), 0, stream, s->bp_seg, n, bs, net.dims[0], s->bp_hist);
+      BGM_HIP_CHECK(hipGetLastError());
+      s->bp_hist_n = n; s->bp_hist_bs = bs;
+    }
+  }
   BPriorRowsArgs a{};
+  a.hist = s->bp_hist;
   a.net = net; a.theta = s->bp_theta; a.seg = s->bp_seg; a.n = n; a.bs = bs; a.n_blocks = n_blocks; a.block0 = block0; a.q = q;
   a.parts = std::max(1, std::min((bs + BPRIOR_ROWS_CHUNK - 1) / BPRIOR_ROWS_CHUNK, std::max(1, 2048 / std::max(1, n_blocks * n_states))));
   a.k0 = (unsigned)seed; a.k1 = (unsigned)(seed >> 32); a.stream0 = stream0; a.rows_out = s->bp_rows;

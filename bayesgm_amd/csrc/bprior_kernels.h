@@ -271,7 +271,24 @@ struct BPriorRowsArgs {
   unsigned k0, k1, stream0;
   float *rows_out;                     // [n_states][n][q + 2]
   unsigned rib0;                       // position of the call's first row inside its block (0 unless a block's rows are split over ranks)
+  const int *hist;                     // norm_mode 0: rows per (block, segment) [n_blocks][k] (bprior_hist_kernel)
 };
+
+// Batch statistics of the one-hot input (norm_mode 0, the reference as written: bnn.py:26 normalises with the statistics of the rows of
+// the call = of the block): the mean of column i is the share of the block's rows in segment i.  One workgroup per block.
+static __global__ __launch_bounds__(256) void bprior_hist_kernel(const int *seg, long long n, int bs, int k, int *hist) {
+  __shared__ int cnt[64];
+  const int blk = blockIdx.x;
+  for (int i = threadIdx.x; i < k; i += blockDim.x) cnt[i] = 0;
+  __syncthreads();
+  const long long lo = (long long)blk * bs, hi = min(n, lo + bs);
+  for (long long r = lo + threadIdx.x; r < hi; r += blockDim.x) {
+    const int sg = seg[r];
+    if (sg >= 0 && sg < k) atomicAdd(&cnt[sg], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < k; i += blockDim.x) hist[(long long)blk * k + i] = cnt[i];
+}
 
 static __global__ __launch_bounds__(BPRIOR_THREADS) void bprior_rows_kernel(BPriorRowsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -298,7 +315,12 @@ static __global__ __launch_bounds__(BPRIOR_THREADS) void bprior_rows_kernel(BPri
     __syncthreads();
     for (int e = tid; e < rows * k; e += blockDim.x) {
       const int b = e / k, i = e - b * k;
-      act[e] = fmaf((sg[b] == i ? 1.0f : 0.0f) * inv, a.theta[n.gamma_off + i], a.theta[n.beta_off + i]);
+      float xh = (sg[b] == i ? 1.0f : 0.0f) * inv;
+      if (n.norm_mode == 0) {          // batch statistics of the block (bprior_step_kernel's arithmetic)
+        const float mean = (float)a.hist[(long long)blk * k + i] / (float)blk_n;
+        xh = ((sg[b] == i ? 1.0f : 0.0f) - mean) * (1.0f / sqrtf(mean * (1.0f - mean) + BPRIOR_BN_EPS));
+      }
+      act[e] = fmaf(xh, a.theta[n.gamma_off + i], a.theta[n.beta_off + i]);
     }
     __syncthreads();
     bprior_layers(n, a.theta, dw, sgw, act, a_off, rows);

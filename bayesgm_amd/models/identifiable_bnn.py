@@ -10,9 +10,10 @@ latents, prior_optimizer on the prior net; identifiable.py:195-226); one noisy c
 inside the Metropolis-Hastings sampler (`bgm_bnn_set_prior`, :541-551).  oracle: oracle/identifiable.py (bnn_* functions).
 
 Stated differences.  (i) As for the deterministic form, the reference's `fit` fails at its first evaluation (unpacks seven of
-`evaluate`'s four values); the build evaluates as CausalBGM does.  (ii) The sampling side needs the inference-mode normalisation
-(params['bnn_norm'] = 'fixed', the build's default; 'batch' raises at predict time with that message); any hidden widths (outside the
-default shapes the any-width path, csrc/bnw_kernels.h, reads the same per-row prior tables).  (iii) `predict` treats the panel as ONE block, as the reference's sampler call does (:397); under
+`evaluate`'s four values); the build evaluates as CausalBGM does.  (ii) params['bnn_norm'] = 'fixed' (the build's default) or 'batch' (the reference as written: every input BatchNormalization, the prior
+net's on the one-hot segments included, normalises with the statistics of the block of rows of the call; the sampler then runs on the
+any-width path, csrc/bnw_kernels.h, which makes the statistics passes, replicated under torch.distributed); any hidden widths (outside the
+default shapes the any-width path reads the same per-row prior tables).  (iii) `predict` treats the panel as ONE block, as the reference's sampler call does (:397); under
 torch.distributed every rank runs it on the whole panel (same result everywhere), `fit` shards rows and all-reduces the gradients."""
 import ctypes as C
 

@@ -934,7 +934,7 @@ def main():
     ap.add_argument("--bayesian-divisor", type=int, default=1, help="the use_bnn=True leg runs burn_in / n_mcmc divided by this (1 = the BASELINE counts)")
     ap.add_argument("--no-configs", action="store_true", help="skip the legs of the other BASELINE configurations (C1 binary treatment, C4 one-GPU share) and the encoder leg (N=1 only)")
     ap.add_argument("--no-c4-f16x3", action="store_true", help="skip the split-precision run of the C4 share")
-    ap.add_argument("--c4-bnn", action="store_true", help="also run the C4 share with the Bayesian generator (use_bnn=True, ~100 s)")
+    ap.add_argument("--c4-bnn", action="store_true", help="also run the C4 share with the Bayesian generator (use_bnn=True): fp32 (~100 s) and f16x3 (~55 s)")
     ap.add_argument("--fit-dp-timeout", type=int, default=240, help="seconds the N>1 fit_dp leg may take before the line is printed without it")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="launch / rendezvous check without a device: every rank joins the process group over gloo on the CPU, the rank "
@@ -1186,8 +1186,11 @@ def main():
                     x3 = config_c4_share_leg(device, precision="f16x3")
                     x3["speedup_vs_fp32"] = out["config_c4_share"]["predict_seconds"] / x3["predict_seconds"]
                     out["config_c4_share"]["f16x3"] = x3
-                if args.c4_bnn:
+                if args.c4_bnn:      # the Bayesian generator (frozen noise): fp32 and the opt-in split precision (bgmfx_kernels.h)
                     out["config_c4_share"]["use_bnn"] = config_c4_share_leg(device, use_bnn=True)
+                    bx3 = config_c4_share_leg(device, use_bnn=True, precision="f16x3")
+                    bx3["speedup_vs_fp32"] = out["config_c4_share"]["use_bnn"]["predict_seconds"] / bx3["predict_seconds"]
+                    out["config_c4_share"]["use_bnn"]["f16x3"] = bx3
         if not args.no_general_width and world == 1:
             out["general_width_engine"] = general_width_leg(p, z_dims, device)
         if not args.no_fit and world == 1:

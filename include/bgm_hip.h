@@ -144,7 +144,10 @@ BGM_API int bgm_bprior_apply(bgm_handle *h, const bgm_prior_config *cfg, float k
 /* Conditional prior of the SAMPLING calls of a Bayesian-network session (bgm_bnn_logpost, bgm_bnn_mh_run) made afterwards:
  * replaces prior_net(data_u) inside get_log_posterior (identifiable.py:541-551) -- one noisy call of the prior net per log-posterior
  * evaluation and block of rows (call ids as g, h, f: stream_id; 2 it and 2 it + 1 in the sampler), seg_dev [n] the segments of the
- * rows of those calls.  theta_dev = NULL clears it.  Built for the inference-mode normalisation, default-shape sampling kernels. */
+ * rows of those calls.  theta_dev = NULL clears it.  The prior net's input BatchNormalization follows the session's norm_mode:
+ * 1 inference mode; 0 the statistics of the block of rows of the call (shares of the block's rows per segment, counted once per
+ * (n, block_rows) after this call: the contents of seg_dev must not change until the next bgm_bnn_set_prior; at most 64 segments;
+ * no shares of one block, block_row0 = 0). */
 BGM_API int bgm_bnn_set_prior(bgm_handle *h, const bgm_prior_config *cfg, const float *theta_dev, const int32_t *seg_dev);
 /* Arithmetic of the SAMPLING calls of a Bayesian-network session made afterwards (bgm_bnn_logpost, bgm_bnn_mh_run, bgm_bnn_effects --
  * get_log_posterior / metropolis_hastings_sampler / infer_from_latent_posterior of causalbgm/base.py:671-904 on the Flipout nets of

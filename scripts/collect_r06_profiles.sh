@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-6 rocprofv3 evidence, run on the GPU box from the repo root (gpurun).  Counters in their own passes (--kernel-trace only beside
 # --pmc), as MI355X_MICROARCH.md prescribes.  Summaries land in gpurun_out/r06prof/ and are copied to profiles/ by hand.
-# usage: bash scripts/collect_r06_profiles.sh [what ...]   what in: mh bnn bnw hmc bench ablation    (default: mh bnn)
+# usage: bash scripts/collect_r06_profiles.sh [what ...]   what in: mh bnn bnw hmc hmcb c1 hmcw bench ablation    (default: mh bnn)
 set -u
 OUT=gpurun_out/r06prof
 mkdir -p $OUT
@@ -30,6 +30,9 @@ for w in $WHAT; do
     bnw) passes bnw_wide python scripts/probe_bnw.py 1e5 5 ;;
     # BGM HMC at C4's shape, fp32 and split-precision heads
     hmc) passes bgm_hmc_f16x3 env BGM_PROBE_PRECISION=f16x3 python scripts/probe_bgm_wide.py 2e5 4 ;;
+    # the Bayesian generator's frozen-noise HMC at C4's shape in split precision (bgmfx_hmc_kernel)
+    hmcb) passes bgmf_hmc_f16x3 env BGM_PROBE_MODES=f16x3 python scripts/probe_bgmf.py 2e5 4
+          python scripts/probe_bgmf.py 2e5 5 > $OUT/r06_bgmf_hmc_fp32_vs_f16x3.txt 2>/dev/null ;;
     # configs[1] through the class (event form of the binary-treatment retained phase): kernel trace only
     c1)
       timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/c1_kt -o kt -- python scripts/probe_c1.py > $OUT/c1_kt.log 2>&1 < /dev/null

@@ -192,6 +192,57 @@ def test_conditional_prior_outside_the_default_shapes(units):
     eng.close()
 
 
+@pytest.mark.parametrize("units,binary", [(dict(), False), (dict(), True), (dict(g_units=(128, 96), e_units=(100,), f_units=(80, 40), h_units=(72,)), False)])
+def test_conditional_prior_with_batch_statistics(units, binary):
+    """The reference as written (params['bnn_norm'] = 'batch'): every input BatchNormalization -- of g, h, f and of the prior net
+    (bnn.py:26 on the one-hot segments, identifiable.py:541) -- normalises with the statistics of the block of rows of the call.  For
+    the prior net these are the shares of the block's rows per segment (bprior_hist_kernel, once per run); the nets run on the any-width
+    path's statistics passes (csrc/bnw_kernels.h).  Log posterior and two sampler iterations against the float64 oracle, blocks of
+    128 rows with a short last block."""
+    from bayesgm_amd import _lib
+    from bayesgm_amd.bnn_engine import flatten_bnn
+    from tests.test_gpu_bnn import _model as model_b, _panel as panel_b, _engine as engine_b
+    m = model_b(binary, p=50, fixed=False, **units)
+    n, bs, q, k = 300, 128, 10, 6
+    z, x, y, v = panel_b(m, n)
+    rs = np.random.RandomState(8)
+    pn32 = _prior(rs, k, q, (64,), "batch")
+    seg = rs.randint(0, k, n)
+    seg[256:] = rs.randint(0, 3, n - 256)            # the short last block sees only some of the segments (zero-variance columns)
+    eng = engine_b(m, norm_mode=0, **units)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
+    cfg = _cfg([k, 64, q + 1])
+    theta, seg_dev = T(flatten_bnn(pn32)), T(seg.astype(np.int32))
+    m64, p64 = OB.cast_model(m, np.float64), OB.cast_bnn(pn32, np.float64)
+    seed, stream = (3 << 32) | 1234, 77
+    std = eng.logpost(T(x[:, 0]), T(y[:, 0]), T(v), T(z), bs, seed, stream, block0=2).cpu().numpy()
+    _lib.check(eng.lib.bgm_bnn_set_prior(eng.h, C.byref(cfg), theta.data_ptr(), seg_dev.data_ptr()), "bgm_bnn_set_prior")
+    got = eng.logpost(T(x[:, 0]), T(y[:, 0]), T(v), T(z), bs, seed, stream, block0=2).cpu().numpy()
+    ref = OI.bnn_log_posterior_blocks(m64, p64, seg, f64(x), f64(y), f64(v), f64(z), bs, seed, stream, block0=2)
+    assert np.abs(got - ref).max() < 2e-3 * np.abs(ref).max(), np.abs(got - ref).max()
+    assert np.abs(got - std).max() > 0.1                                # the prior matters here
+    state = T(z)
+    acc = torch.zeros(1, dtype=torch.int32, device=eng.device)
+    eng.mh_run(T(x[:, 0]), T(y[:, 0]), T(v), state, bs, it_begin=5, n_iters=2, burn_in=0, q_sd=0.3, seed=seed, row_base=1000, acc_count=acc)
+    zo, n_acc, fragile = f64(z), 0, np.zeros(n, bool)
+    for it in (5, 6):
+        zo, a, lpp, lpc = OI.bnn_mh_iteration(m64, p64, seg, f64(x), f64(y), f64(v), zo, it, 0.3, seed, bs, row_base=1000)
+        n_acc += int(a.sum())
+        u = OB.R.uniforms(np.arange(1000, 1000 + n), it, OB.R.TAG_ACC, seed)
+        fragile |= np.abs(u - np.exp(np.minimum(lpp - lpc, 0))) < 2e-3
+    ok = ~fragile
+    assert ok.sum() >= 0.97 * n and np.abs(state.cpu().numpy()[ok] - zo[ok]).max() < 1e-5
+    assert abs(int(acc[0]) - n_acc) <= int(fragile.sum())
+    # a second panel of the same size on the same session: bgm_bnn_set_prior renews the segment counts
+    seg2 = rs.randint(0, k, n)
+    seg2_dev = T(seg2.astype(np.int32))
+    _lib.check(eng.lib.bgm_bnn_set_prior(eng.h, C.byref(cfg), theta.data_ptr(), seg2_dev.data_ptr()), "bgm_bnn_set_prior")
+    got2 = eng.logpost(T(x[:, 0]), T(y[:, 0]), T(v), T(z), bs, seed, stream, block0=2).cpu().numpy()
+    ref2 = OI.bnn_log_posterior_blocks(m64, p64, seg2, f64(x), f64(y), f64(v), f64(z), bs, seed, stream, block0=2)
+    assert np.abs(got2 - ref2).max() < 2e-3 * np.abs(ref2).max()
+    eng.close()
+
+
 def _params(tmp_path, binary, **kw):
     p = dict(dataset="ident_bnn", output_dir=str(tmp_path), save_res=False, save_model=False, binary_treatment=binary, use_bnn=True,
              z_dims=[1, 1, 1, 7], v_dim=20, lr_theta=1e-3, lr_z=1e-2, g_units=[64] * 5, f_units=[64, 32, 8], h_units=[64, 32, 8], e_units=[64] * 5,
@@ -304,16 +355,27 @@ def test_class_with_other_hidden_widths(tmp_path):
     assert eff.shape == (4,) and np.isfinite(eff).all() and np.isfinite(interval).all()
 
 
-def test_other_sampling_configurations_say_so(tmp_path):
+def test_class_with_batch_statistics(tmp_path):
+    """params['bnn_norm'] = 'batch' through the class: fit (bgm_bprior_step with batch statistics) and predict (the panel is ONE block:
+    the statistics of g, h, f and of the prior net are those of all rows).  The run is deterministic and differs from the 'fixed' run."""
     from bayesgm_amd.models import IdentifiableCausalBGM
     from bayesgm_amd.datasets import Sim_Hirano_Imbens_sampler
-    x, y, v = Sim_Hirano_Imbens_sampler(N=100, v_dim=20, seed=0).load_all()
+    x, y, v = Sim_Hirano_Imbens_sampler(N=300, v_dim=20, seed=0).load_all()
     import warnings
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        model = IdentifiableCausalBGM(_params(tmp_path, False, bnn_norm="batch"), random_seed=3)
-    with pytest.raises(RuntimeError, match="inference-mode normalisation"):
-        model.predict((x, y, v), n_mcmc=3, burn_in=3, x_values=[0.5], verbose=0)
+    out = {}
+    for norm in ("batch", "batch", "fixed"):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            model = IdentifiableCausalBGM(_params(tmp_path, False, bnn_norm=norm), random_seed=3)
+            np.random.seed(5)
+            model.fit((x, y, v), batch_size=32, epochs=1, epochs_per_eval=1, use_egm_init=False, verbose=0)
+            np.random.seed(6)
+            adrf, iv = model.predict((x, y, v), n_mcmc=20, burn_in=30, x_values=[0.5, 1.0], q_sd=0.5, verbose=0)
+        assert adrf.shape == (2,) and iv.shape == (2, 2) and np.isfinite(adrf).all() and np.isfinite(iv).all()
+        assert 0.0 < model.last_acceptance_rate < 1.0
+        out.setdefault(norm, []).append(adrf)
+    np.testing.assert_array_equal(out["batch"][0], out["batch"][1])
+    assert np.abs(out["batch"][0] - out["fixed"][0]).max() > 1e-6
 
 
 def test_two_rank_fit_and_predict():
