@@ -92,12 +92,15 @@ class BvnEngine(object):
         _lib.check(self.lib.bgm_bvn_begin(self.h, C.byref(self.cfg), theta.ctypes.data_as(C.c_void_p), theta.size, self._stream()),
                    "bgm_bvn_begin")
         self.open = True
+        if getattr(self, "_precision", "fp32") != "fp32":      # a new session starts in fp32: the engine's mode travels with the engine
+            self.set_precision(self._precision)
 
     def set_precision(self, mode="fp32"):
         """Arithmetic of hmc_run launched afterwards on this (open) session: "fp32" (default) | "f16x3" (split fp16 products with fp32
         accumulation on the streamed frozen-noise kernel, opt-in; bgm_bvn_set_precision).  "f16x3" raises for sessions it does not serve
         (fresh noise, z_dim > 16, hidden layers other than 3 or 5 of 64 units)."""
         _lib.check(self.lib.bgm_bvn_set_precision(self.h, {"fp32": 0, "f16x3": 2}[mode]), "bgm_bvn_set_precision")
+        self._precision = mode
 
     def read(self, what=0):
         out = np.empty(self.n_params, np.float32)

@@ -272,7 +272,7 @@ extern "C" int bgm_bgm_logpost(bgm_handle *h, const float *z, const float *x, in
     const int ldx = s->lds_bytes_sx3;
 #define X(KTQ_, NH_)                                                                                                \
     if (s->KTQ == KTQ_ && s->NH == NH_) {                                                                           \
-      auto k = bgm_logpost_kernel<KTQ_, 0, NH_, BGM_WAVES, 2>;                                                      \
+      auto k = (s->sx3_meta.p & 3) == 0 ? bgm_logpost_kernel<KTQ_, 0, NH_, BGM_WAVES, 2, true> : bgm_logpost_kernel<KTQ_, 0, NH_, BGM_WAVES, 2, false>; \
       BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, ldx)); \
       hipLaunchKernelGGL(k, dim3(grid), dim3(64 * BGM_WAVES), ldx, stream, s->sx3_bias_dev, s->sx3_meta, z, x, (long long)n, out, grad, \
                          (const unsigned char *)s->sx3_dev);                                                        \
@@ -333,13 +333,13 @@ extern "C" int bgm_bgm_hmc_run(bgm_handle *h, const bgm_hmc_args *a, void *strea
     return BGM_OK;                                                                                                  \
   }
   if (s->precision != 0) {      // split precision (bgm_kernels.h, PREC 2): the biases are the only LDS-resident data, everything else streams
-    static const int sw = std::getenv("BGM_SX3_WAVES") ? std::atoi(std::getenv("BGM_SX3_WAVES")) : BGM_SX3_WAVES_DEFAULT;
     ka.blob = s->sx3_bias_dev; ka.m = s->sx3_meta; ka.hx3 = s->sx3_dev;
     const int ldx = s->lds_bytes_sx3;
-#define LAUNCH_SX3(KTQ_, NH_, W)                                                                                    \
+    constexpr int W = BGM_SX3_WAVES_DEFAULT;      // (12 waves: three per SIMD inside the 168-register line; 8 measured slower, round 6)
+#define LAUNCH_SX3(KTQ_, NH_, X4_)                                                                                  \
     {                                                                                                               \
       const int grid = (int)std::max<long long>(1, std::min<long long>((tiles + W - 1) / W, h->n_cus));             \
-      auto k = bgm_hmc_kernel<KTQ_, 0, NH_, W, 2>;                                                                  \
+      auto k = bgm_hmc_kernel<KTQ_, 0, NH_, W, 2, X4_>;                                                             \
       BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, ldx)); \
       hipLaunchKernelGGL(k, dim3(grid), dim3(64 * W), ldx, stream, ka);                                             \
       BGM_HIP_CHECK(hipGetLastError());                                                                             \
@@ -347,8 +347,8 @@ extern "C" int bgm_bgm_hmc_run(bgm_handle *h, const bgm_hmc_args *a, void *strea
     }
 #define X(KTQ_, NH_)                                                                                                \
     if (s->KTQ == KTQ_ && s->NH == NH_) {                                                                           \
-      if (sw == 8) LAUNCH_SX3(KTQ_, NH_, 8)                                                                         \
-      LAUNCH_SX3(KTQ_, NH_, 12)                                                                                     \
+      if ((s->sx3_meta.p & 3) == 0) LAUNCH_SX3(KTQ_, NH_, true)                                                              \
+      LAUNCH_SX3(KTQ_, NH_, false)                                                                                  \
     }
     X(1, 5) X(1, 3)
 #undef X

@@ -245,7 +245,10 @@ __device__ __forceinline__ void bgm_split8(const f32x4 &a, const f32x4 &b, bgm_h
 #ifndef BGM_X3_DMA
 #define BGM_X3_DMA 1      // 1: the stage is filled by global_load_lds_dwordx4 (no staging registers, no ds_write pass); 0: through registers
 #endif
-template <int WAVES>
+// X4 (compile time): x_dim % 4 == 0, the data rows are 16-byte aligned -- one request per lane and block; else four clamped 4-byte
+// requests.  A run-time branch between the two forms inside the loop made hipcc guard the destination registers of one form against
+// the other's requests with counted waits that, at run time, fall on the direct-to-LDS loads in flight.
+template <int WAVES, bool X4 = false>
 struct BgmHeadStreamX3 {
   static constexpr int STEP_VEC = BGM_X3_STEP * BGM_X3_BLOCK_BYTES / 16, NT = 64 * WAVES, K = (STEP_VEC + NT - 1) / NT;
   const f32x4 *src;      // global: [steps][BGM_X3_STEP][BGM_X3_BLOCK_BYTES]
@@ -253,25 +256,30 @@ struct BgmHeadStreamX3 {
   int cur, tid;
 #if BGM_X3_DMA
   // every lane's 16 bytes go straight from L2 to the stage: destination = wave-uniform base + lane x 16 (the fragments are lane-linear,
-  // which is exactly the layout the instruction writes); the other buffer is the one nobody reads during this step
+  // which is exactly the layout the instruction writes); the other buffer is the one nobody reads during this step.
+  // Issued as inline assembly: behind __builtin_amdgcn_global_load_lds hipcc (7.2) places s_waitcnt vmcnt(0) in front of the NEXT LDS
+  // read of any address (it cannot tell the two buffers of the stage apart), i.e. every step began by waiting out the latency of
+  // the loads it had just issued -- and of the data-row request beside them.  The wait that is needed is the one in commit().
   __device__ __forceinline__ void fetch(int step) {
-#ifdef BGM_X3_ABL_NOSTREAM
+#if defined(BGM_X3_ABL_NOSTREAM) || defined(BGM_X3_ABL_NODMA)      // (NODMA: the barriers stay, the stage is never refilled; timing only)
     return;
 #endif
     const f32x4 *s = src + (long long)step * STEP_VEC + tid;
     typedef __attribute__((address_space(3))) unsigned char *lds_ptr;
-    typedef const __attribute__((address_space(1))) f32x4 *glb_ptr;
     const unsigned dst0 = (unsigned)(unsigned long long)(lds_ptr)(buf + (cur ^ 1) * (BGM_X3_STEP * BGM_X3_BLOCK_BYTES)) + (unsigned)(tid & ~63) * 16u;
 #pragma unroll
     for (int k = 0; k < K; ++k)
-      if (K * NT == STEP_VEC || (tid & ~63) + k * NT < STEP_VEC)
-        __builtin_amdgcn_global_load_lds((glb_ptr)(s + k * NT), (lds_ptr)(unsigned long long)(dst0 + (unsigned)(k * NT) * 16u), 16, 0, 0);
+      if (K * NT == STEP_VEC || (tid & ~63) + k * NT < STEP_VEC) {
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(dst0 + (unsigned)(k * NT) * 16u);
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(m0v), "v"(s + k * NT) : "memory", "m0");
+      }
   }
   __device__ __forceinline__ void commit() {
 #ifdef BGM_X3_ABL_NOSTREAM
     return;
 #endif
-    __syncthreads();      // (carries the wait for the loads above: they write LDS)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the next step have landed ...
+    __syncthreads();                                         // ... and everybody's
     cur ^= 1;
   }
 #else
@@ -303,25 +311,34 @@ struct BgmHeadStreamX3 {
   // C4's share, re-read per evaluation) -- requested at the block's start they were what every block waited for.
   f32x4 xn[BGM_X3_STEP];
   bool x_valid;
+  // (unconditional requests at clamped addresses: a column at or beyond p is masked where the value is used -- bgm_x3_lik's in_range --
+  // so no zero fill, no branch around a request: hipcc counts the requests and places no wait between them)
   __device__ __forceinline__ void load_x(const float *row, int p, int step, int g, f32x4 (&dst)[BGM_X3_STEP]) const {
 #pragma unroll
     for (int b = 0; b < BGM_X3_STEP; ++b) {
       const int c = 16 * (BGM_X3_STEP * step + b) + 4 * g;
-      if ((p & 3) == 0) {               // (rows are 16-byte aligned: one request per block and lane)
-        dst[b] = (c < p) ? *reinterpret_cast<const f32x4 *>(row + c) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (X4) {                         // (rows are 16-byte aligned: one request per block and lane)
+        dst[b] = *reinterpret_cast<const f32x4 *>(row + (c < p ? c : p - 4));
       } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dst[b][r] = (c + r < p) ? row[c + r] : 0.0f;
+        for (int r = 0; r < 4; ++r) dst[b][r] = row[c + r < p ? c + r : p - 1];
       }
     }
   }
+  // last step's request as values: the wait for it is placed HERE, in front of this step's requests (the requests sit in branches, so
+  // hipcc cannot count them and would otherwise wait for ALL outstanding loads -- this step's included -- at the first use of a value)
+  __device__ __forceinline__ f32x4 take_x(int b) const {
+    float x0 = xn[b][0], x1 = xn[b][1], x2 = xn[b][2], x3 = xn[b][3];
+    asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+    return f32x4{x0, x1, x2, x3};
+  }
   __device__ __forceinline__ void load_x1(const float *row, int p, int tx, int g) {      // one block's values into xn[0] (bgmfx_kernels.h: one block per step)
     const int c = 16 * tx + 4 * g;
-    if ((p & 3) == 0) {
-      xn[0] = (c < p) ? *reinterpret_cast<const f32x4 *>(row + c) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (X4) {
+      xn[0] = *reinterpret_cast<const f32x4 *>(row + (c < p ? c : p - 4));
     } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) xn[0][r] = (c + r < p) ? row[c + r] : 0.0f;
+      for (int r = 0; r < 4; ++r) xn[0][r] = row[c + r < p ? c + r : p - 1];
     }
   }
   __device__ __forceinline__ void begin_at(const unsigned char *frags, float *stage) {
@@ -548,7 +565,7 @@ __device__ __forceinline__ void bgm_logp_grad(const float *lds, const BgmMeta &m
       f32x4 xv[BGM_X3_STEP], part[BGM_X3_STEP][4];
       if (!hs.x_valid) { hs.load_x(xs.row, m.p, st, g, hs.xn); hs.x_valid = true; }      // (the first evaluation of a tile only)
 #pragma unroll
-      for (int b = 0; b < BGM_X3_STEP; ++b) xv[b] = hs.xn[b];
+      for (int b = 0; b < BGM_X3_STEP; ++b) xv[b] = hs.take_x(b);
       hs.fetch(next_step);      // (behind the use of last step's data values: with a direct-to-LDS load in flight hipcc waits for ALL loads at the next use of one)
       hs.load_x(xs.row, m.p, st + 1 < n_steps ? st + 1 : 0, g, hs.xn);
       asm volatile("" ::: "memory");      // (hipcc sinks a load to just above its first use: the request stays here, a step ahead)
@@ -718,19 +735,19 @@ __device__ __forceinline__ void bgm_store_z(float *z, int q, long long row, int 
     }
 }
 
-template <int PREC, int WAVES> struct bgm_stream_of { typedef BgmHeadStream type; };
-template <int WAVES> struct bgm_stream_of<1, WAVES> { typedef BgmHeadStreamX3<WAVES> type; };
-template <int WAVES> struct bgm_stream_of<2, WAVES> { typedef BgmHeadStreamX3<WAVES> type; };
+template <int PREC, int WAVES, bool X4> struct bgm_stream_of { typedef BgmHeadStream type; };
+template <int WAVES, bool X4> struct bgm_stream_of<1, WAVES, X4> { typedef BgmHeadStreamX3<WAVES, X4> type; };
+template <int WAVES, bool X4> struct bgm_stream_of<2, WAVES, X4> { typedef BgmHeadStreamX3<WAVES, X4> type; };
 
 // get_log_posterior (+ optional gradient) for n rows
-template <int KTQ, int NTX, int NH, int WAVES, int PREC = 0>
+template <int KTQ, int NTX, int NH, int WAVES, int PREC = 0, bool X4 = false>
 __global__ __launch_bounds__(64 * WAVES) void bgm_logpost_kernel(const float *blob, BgmMeta m, const float *z,
                                                                  const float *x, long long n, float *out,
                                                                  float *grad_out, const unsigned char *hx3 = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   lds_fill(lds, blob, m.lds_resident);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
-  using HS = typename bgm_stream_of<PREC, WAVES>::type;
+  using HS = typename bgm_stream_of<PREC, WAVES, X4>::type;
   HS hs;
   if constexpr (PREC >= 1) hs.begin(hx3, m, lds);
   else if constexpr (NTX == 0) hs.begin(blob, m, lds);
@@ -777,13 +794,13 @@ struct BgmHmcKArgs {
   const unsigned char *hx3;  // PREC 1: the packed fp16 head fragments [ntx][BGM_X3_BLOCK_BYTES]
 };
 
-template <int KTQ, int NTX, int NH, int WAVES, int PREC = 0>
+template <int KTQ, int NTX, int NH, int WAVES, int PREC = 0, bool X4 = false>
 __global__ __launch_bounds__(64 * WAVES) void bgm_hmc_kernel(BgmHmcKArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const BgmMeta &m = a.m;
   lds_fill(lds, a.blob, m.lds_resident);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
-  using HS = typename bgm_stream_of<PREC, WAVES>::type;
+  using HS = typename bgm_stream_of<PREC, WAVES, X4>::type;
   HS hs;
   if constexpr (PREC >= 1) hs.begin(a.hx3, m, lds);
   else if constexpr (NTX == 0) hs.begin(a.blob, m, lds);

@@ -141,7 +141,8 @@ static int bgmfx_hmc(bgm_handle *h, BgmbState *s, BgmfState *f, const bgm_hmc_ar
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * BGMFX_WAVES), f->lds_bytes_x, st, x);
     return hipGetLastError() == hipSuccess ? BGM_OK : BGM_E_HIP;
   };
-  rc = f->xm.nh == 5 ? launch(bgmfx_hmc_kernel<5, BGMFX_WAVES>) : launch(bgmfx_hmc_kernel<3, BGMFX_WAVES>);
+  if ((f->xm.p & 3) == 0) rc = f->xm.nh == 5 ? launch(bgmfx_hmc_kernel<5, BGMFX_WAVES, true>) : launch(bgmfx_hmc_kernel<3, BGMFX_WAVES, true>);
+  else rc = f->xm.nh == 5 ? launch(bgmfx_hmc_kernel<5, BGMFX_WAVES, false>) : launch(bgmfx_hmc_kernel<3, BGMFX_WAVES, false>);
   if (rc) bgm_set_error("frozen-noise HMC (bgmfx_hmc_kernel): launch failed");
   return rc;
 }

@@ -22,6 +22,11 @@ static_assert(BGM_X3_STEP == 2, "a step of the Bayesian stream = [loc unit | dW 
 #ifndef BGMFX_WAVES
 #define BGMFX_WAVES 8
 #endif
+// where in a head block's step the next step's direct-to-LDS loads are issued: 0 top, 1 behind the forward products, 2 before the
+// barrier, 3 / 4 around the transposed loc products; ms per transition at C4's shape: 6.02 / 5.89 / (latency exposed) / ~5.9
+#ifndef BGMFX_FETCH_AT
+#define BGMFX_FETCH_AT 1
+#endif
 
 // XOR masks of the packed halves: element u of K block b <-> bit 8 b + u of `mask` (= bit 4t + r of a register-tile mask, t = 2b + (u >> 2), r = u & 3)
 __device__ __forceinline__ bgm_u4 bgmfx_xmask(unsigned mask, int b) {
@@ -79,9 +84,9 @@ __device__ __forceinline__ void bgmfx_heads_fwd(const unsigned char *unit, int l
 
 // log p(z | x_obs) and dlogp/dz of the wave's 16 chains (z_dim <= 16: one latent tile).  On entry step 0 of the stream (L1) is current;
 // every wave of the workgroup calls this the same number of times.  want_lp = false: the gradient alone (inner leapfrog steps).
-template <int NH, int WAVES>
+template <int NH, int WAVES, bool X4>
 __device__ __forceinline__ void bgmfx_logp_grad(const float *lds, const BgmfMeta &m, int j, int g, const f32x4 &z, const float *xrow,
-                                                BgmHeadStreamX3<WAVES> &hs, const unsigned *sg_row, float &logp, f32x4 &grad, bool want_lp) {
+                                                BgmHeadStreamX3<WAVES, X4> &hs, const unsigned *sg_row, float &logp, f32x4 &grad, bool want_lp) {
   const int lane = 16 * g + j;
   const f32x4 zero4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   // The lane's sign masks are gathered from the wave's sign rows in LDS where they are used (two words and ~10 VALU operations per
@@ -158,8 +163,11 @@ __device__ __forceinline__ void bgmfx_logp_grad(const float *lds, const BgmfMeta
     for (int tx = 0; tx < m.ntx; ++tx) {
       BGM_NO_HOIST();
       if (!hs.x_valid) { hs.load_x1(xrow, m.p, 0, g); hs.x_valid = true; }      // (the first evaluation of a tile only)
-      const f32x4 xv = hs.xn[0];
-      hs.fetch(tx + 1 < m.ntx ? NH + tx + 1 : (NH > 1 ? NH + m.ntx : 0));
+      const f32x4 xv = hs.take_x(0);
+      const int next_step = tx + 1 < m.ntx ? NH + tx + 1 : (NH > 1 ? NH + m.ntx : 0);
+#if BGMFX_FETCH_AT == 0
+      hs.fetch(next_step);
+#endif
       hs.load_x1(xrow, m.p, tx + 1 < m.ntx ? tx + 1 : 0, g);                     // the next block's data values, a step ahead
       asm volatile("" ::: "memory");
       f32x4 part[4], pd[4];
@@ -179,6 +187,9 @@ __device__ __forceinline__ void bgmfx_logp_grad(const float *lds, const BgmfMeta
         bgmfx_heads_fwd(hs.tile(1), lane, mh, ml, vh, vl, pd);
       }
       BGM_NO_HOIST();
+#if BGMFX_FETCH_AT == 1
+      hs.fetch(next_step);
+#endif
       const int sh_ = 16 * (tx & 1) + 4 * g;
       const unsigned bm = (sg_row[m.sout_w[NH] + (tx >> 1)] >> sh_) & 0xFu, bv = (sg_row[m.sout_w[NH + 1] + (tx >> 1)] >> sh_) & 0xFu;
       f32x4 dms[2];
@@ -192,8 +203,14 @@ __device__ __forceinline__ void bgmfx_logp_grad(const float *lds, const BgmfMeta
       }
       bgm_h8 dhi, dlo;
       bgm_split8(dms[0], dms[1], dhi, dlo);
+#if BGMFX_FETCH_AT == 3
+      hs.fetch(next_step);
+#endif
       bgm_x3_bwd(hs.tile(0), lane, dhi, dlo, dh);
       BGM_NO_HOIST();
+#if BGMFX_FETCH_AT == 4
+      hs.fetch(next_step);
+#endif
       {
         // d * s_out in packed halves; the mean part in the lower half of one K block, the variance part in the upper half of another
         const bgm_u4 hi = __builtin_bit_cast(bgm_u4, dhi), lo = __builtin_bit_cast(bgm_u4, dlo);
@@ -212,6 +229,9 @@ __device__ __forceinline__ void bgmfx_logp_grad(const float *lds, const BgmfMeta
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) { dhm[ti] = BGM_MFMA_H(ah[ti], mhi, dhm[ti]); dhv[ti] = BGM_MFMA_H(ah[ti], vhi, dhv[ti]); }
       }
+#if BGMFX_FETCH_AT == 2
+      hs.fetch(next_step);
+#endif
       hs.commit();
     }
   }
@@ -289,8 +309,9 @@ struct BgmfxHmcKArgs {
   const unsigned char *sx;     // the stream: [2 nh - 1 + ntx][2][BGM_X3_BLOCK_BYTES]
 };
 
-// The transition logic of bgmf_hmc_kernel<1, NH, false> on the streamed split-precision target.
-template <int NH, int WAVES>
+// The transition logic of bgmf_hmc_kernel<1, NH, false> on the streamed split-precision target.  X4: x_dim % 4 == 0 (one 16-byte request
+// per lane and block for the data values; else four clamped 4-byte requests).
+template <int NH, int WAVES, bool X4>
 __global__ __launch_bounds__(64 * WAVES) void bgmfx_hmc_kernel(BgmfxHmcKArgs xa) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const BgmfHmcKArgs &a = xa.k;
@@ -298,7 +319,7 @@ __global__ __launch_bounds__(64 * WAVES) void bgmfx_hmc_kernel(BgmfxHmcKArgs xa)
   lds_fill(lds, a.blob, m.resident);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
   const int evals = (a.init ? 1 : 0) + a.n_iters * a.n_leapfrog;
-  BgmHeadStreamX3<WAVES> hs;
+  BgmHeadStreamX3<WAVES, X4> hs;
   hs.begin_at(xa.sx, lds + m.stage);
   unsigned *sg_row = reinterpret_cast<unsigned *>(lds + m.sign) + (16 * wave + j) * m.swp;
   const long long n = a.n, n_tiles = (n + 15) / 16, passes = bgm_block_passes(n_tiles, WAVES);
@@ -331,7 +352,7 @@ __global__ __launch_bounds__(64 * WAVES) void bgmfx_hmc_kernel(BgmfxHmcKArgs xa)
       const f32x4 e = box_muller4(philox4x32_10(rowid, 0u, (unsigned)g, TAG_INIT, a.k0, a.k1));
 #pragma unroll
       for (int r = 0; r < 4; ++r) z[r] = (4 * r + g < m.q) ? e[r] : 0.0f;
-      bgmfx_logp_grad<NH, WAVES>(lds, m, j, g, z, xrow, hs, sg_row, lp, gr, true);
+      bgmfx_logp_grad<NH, WAVES, X4>(lds, m, j, g, z, xrow, hs, sg_row, lp, gr, true);
     } else {
       f32x4 z1[1], g1[1];
       bgm_load_z<1>(a.state, m.q, row, g, z1);
@@ -359,7 +380,7 @@ __global__ __launch_bounds__(64 * WAVES) void bgmfx_hmc_kernel(BgmfxHmcKArgs xa)
         BGM_NO_HOIST();
 #pragma unroll
         for (int r = 0; r < 4; ++r) zc[r] = fmaf(eps, mom[r], zc[r]);
-        bgmfx_logp_grad<NH, WAVES>(lds, m, j, g, zc, xrow, hs, sg_row, lpc, gc, l == a.n_leapfrog - 1);
+        bgmfx_logp_grad<NH, WAVES, X4>(lds, m, j, g, zc, xrow, hs, sg_row, lpc, gc, l == a.n_leapfrog - 1);
         const float kick = (l < a.n_leapfrog - 1) ? eps : 0.5f * eps;
 #pragma unroll
         for (int r = 0; r < 4; ++r) mom[r] = fmaf(kick, gc[r], mom[r]);

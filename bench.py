@@ -429,6 +429,10 @@ def bgm_hmc_leg(device, n=200000, p=500, q=10, L=10, iters=4):
         be = BvnEngine(p, q, g_units=[64] * 5, hmc_frozen_noise=frozen)
         be.begin(vnet)
         out[mode] = entry("bgmf_hmc_kernel (posterior means LDS-resident, perturbation streamed)", timed(be), 2)
+        if frozen:      # the same transitions in split precision (opt-in, params['hmc_precision'] = 'f16x3': csrc/bgmfx_kernels.h)
+            be.set_precision("f16x3")
+            out[mode + "_f16x3"] = entry("bgmfx_hmc_kernel (posterior means and perturbation streamed as fp16 fragments, three fp16 products per contraction)", timed(be), 2)
+            out[mode + "_f16x3"]["speedup_vs_fp32"] = out[mode]["ms_per_transition"] / out[mode + "_f16x3"]["ms_per_transition"]
         be.close()
     return out
 

@@ -39,6 +39,9 @@ def test_split_precision_chains_follow_oracle(q, units, p, n):
     close = np.abs(got - ref).max(axis=(0, 2)) < 1e-3
     print("MEASURED f16x3 frozen chains close to the oracle: %d of %d" % (close.sum(), n))
     assert close.mean() > 0.95
+    eng.begin(net)                                   # a new session of the same engine keeps the mode
+    again = eng.hmc_sample(x, n_mcmc=3, burn_in=5, step_size=0.03, n_leapfrog=4, seed=seed, row_base=9)
+    assert torch.equal(again["draws"], out["draws"])
     eng.close()
 
 
