@@ -207,7 +207,7 @@ __device__ __forceinline__ void bgm_head_tile(const float *wl, const float *lds,
 // The likelihood arithmetic, the leapfrog and all accumulations stay fp32.
 // fp16 range: a weight beyond 65504 is clamped by the packer; dlogp/d(mean, s) and the back-propagated d(pre-activation) beyond 6e4 (a
 // variance ~1e-5 under a unit residual) are clamped in the kernel -- the fp32 kernels have no such bound.
-// Measured (N = 2e5, p = 500, 10 leapfrog steps, one MI355X): 7.17 -> 3.62 ms per transition (1.98x); heads only, trunk on the fp32
+// Measured (N = 2e5, p = 500, 10 leapfrog steps, one MI355X): 7.3 -> 3.2 ms per transition (2.26x); heads only, trunk on the fp32
 // dual-access layout: 4.1 ms.  What bounds it: per wave the heads' likelihood arithmetic (~35 VALU instructions per (row, feature), four
 // of them transcendental) costs as many cycles as their 24 matrix instructions per block (profiles/r06_bgm_hmc_f16x3_*.txt).
 // ---------------------------------------------------------------------------------------------------------------------------
