@@ -566,7 +566,7 @@ __device__ __forceinline__ void bgm_logp_grad(const float *lds, const BgmMeta &m
       if (!hs.x_valid) { hs.load_x(xs.row, m.p, st, g, hs.xn); hs.x_valid = true; }      // (the first evaluation of a tile only)
 #pragma unroll
       for (int b = 0; b < BGM_X3_STEP; ++b) xv[b] = hs.take_x(b);
-      hs.fetch(next_step);      // (behind the use of last step's data values: with a direct-to-LDS load in flight hipcc waits for ALL loads at the next use of one)
+      hs.fetch(next_step);      // (behind take_x: last step's data values are in registers before this step's loads are issued)
       hs.load_x(xs.row, m.p, st + 1 < n_steps ? st + 1 : 0, g, hs.xn);
       asm volatile("" ::: "memory");      // (hipcc sinks a load to just above its first use: the request stays here, a step ahead)
 #if BGM_X3_INTERLEAVE
