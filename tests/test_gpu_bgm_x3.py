@@ -78,8 +78,8 @@ def test_split_precision_samples_the_prior_when_nothing_is_observed():
 
 
 def test_split_precision_through_the_class_and_where_it_is_refused(tmp_path):
-    """BGM(params['hmc_precision'] = 'f16x3').predict against the fp32 class on the same streams; the general-width engine and the
-    Bayesian generator say that the mode does not exist there."""
+    """BGM(params['hmc_precision'] = 'f16x3').predict against the fp32 class on the same streams; the general-width engine says that
+    the mode does not exist there (the Bayesian generator has its own form: tests/test_gpu_bgmf_x3.py)."""
     from bayesgm_amd.models import BGM
     from bayesgm_amd.engine import BgmEngine
     p, n = 500, 96
@@ -112,3 +112,39 @@ def test_split_precision_through_the_class_and_where_it_is_refused(tmp_path):
         eng.set_precision("f16x3")
     with pytest.raises(ValueError):
         eng.set_precision("bf16x3")
+
+
+def test_split_precision_at_one_gpus_share_of_config_c4():
+    """BASELINE configs[4] at the size one GPU of eight holds (625 000 x 500, 10 % of the cells missing, 10 leapfrog steps): three
+    transitions on the fp32 and on the split-precision kernel from the same streams -- the chains agree except where an accept /
+    reject decision sat on the threshold, the acceptance counts agree; rows sampled from the head, the middle and the tail of the
+    panel (a partly filled last pass of the grid included) follow the float64 oracle chain of those rows (row_base keys the streams,
+    so a row's chain does not depend on the panel it rides in)."""
+    import torch
+    q, p, n, L, seed = 10, 500, 625000, 10, 31
+    m = _model(51, q, p)
+    eng = _engine(m)
+    dev = eng.device
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn(n, p, device=dev, generator=g)
+    x[torch.rand(n, p, device=dev, generator=g) < 0.1] = float("nan")
+    res = {}
+    for mode in ("fp32", "f16x3"):
+        eng.set_precision(mode)
+        state, logp, grad = torch.empty((n, q), device=dev), torch.empty(n, device=dev), torch.empty((n, q), device=dev)
+        step = torch.full((1,), 0.02, device=dev)
+        acc = torch.zeros(3, device=dev, dtype=torch.int32)
+        eng.hmc_run(x, state, logp, grad, step, 0, 3, 2 ** 30, L, seed, init=True, acc_count=acc)
+        res[mode] = (state.cpu().numpy(), logp.cpu().numpy(), acc.cpu().numpy())
+    (s0, l0, a0), (s1, l1, a1) = res["fp32"], res["f16x3"]
+    close = np.abs(s0 - s1).max(axis=1) < 1e-3
+    print("C4 share: rows equal between fp32 and f16x3 after three transitions: %.5f, accepted %s vs %s" % (close.mean(), a0.tolist(), a1.tolist()))
+    assert close.mean() > 0.995 and np.abs(a0 - a1).max() <= 2e-3 * n
+    assert np.abs(l0 - l1)[close].max() < 2e-3 * np.abs(l0).max()
+    for lo in (0, 312504, n - 40):
+        hi = min(n, lo + 40)
+        xs = x[lo:hi].cpu().numpy()
+        obs, clean = OB.obs_mask_of(xs)
+        ref = OB.hmc_sampler(OB.cast_model(m, np.float64), clean.astype(np.float64), obs.astype(np.float64), 3, 0, 0.02, L, seed, row0=lo)
+        ok = np.abs(s1[lo:hi] - ref[-1]).max(axis=1) < 1e-3
+        assert ok.mean() >= 0.9, (lo, ok.mean())

@@ -130,3 +130,42 @@ def test_split_precision_through_the_class(tmp_path):
     d = np.abs(out[0] - out[1])
     print("MEASURED imputation f16x3 vs fp32: max %.3e, mean %.3e (scale %.2f)" % (d.max(), d.mean(), np.abs(out[0]).std()))
     assert np.median(d) < 1e-3 and d.mean() < 0.02 * np.abs(out[0]).std() + 1e-3
+
+
+def test_split_precision_at_one_gpus_share_of_config_c4():
+    """BASELINE configs[4] with the Bayesian generator at the size one GPU of eight holds (625 000 x 500, 10 % missing, 10 leapfrog
+    steps, frozen noise): two transitions on bgmf_hmc_kernel (fp32) and bgmfx_hmc_kernel (f16x3) from the same streams agree except
+    at threshold decisions; rows from the head, the middle and the tail of the panel follow the float64 oracle chain of those rows."""
+    q, units, p, n, L, seed = 10, (64,) * 5, 500, 625000, 10, 23
+    net = _net(q, units, p, seed=28)
+    res = {}
+    x = None
+    for mode in ("fp32", "f16x3"):
+        eng = _engine(net, q, units, p, hmc_frozen_noise=True)
+        eng.set_precision(mode)
+        dev = eng.device
+        if x is None:
+            g = torch.Generator(device=dev).manual_seed(5)
+            x = torch.randn(n, p, device=dev, generator=g)
+            x[torch.rand(n, p, device=dev, generator=g) < 0.1] = float("nan")
+        state, logp, grad = torch.empty((n, q), device=dev), torch.empty(n, device=dev), torch.empty((n, q), device=dev)
+        step = torch.full((1,), 0.02, device=dev)
+        acc = torch.zeros(2, device=dev, dtype=torch.int32)
+        eng.hmc_run(x, state, logp, grad, step, 0, 2, 2 ** 30, L, seed, init=True, acc_count=acc)
+        res[mode] = (state.cpu().numpy(), logp.cpu().numpy(), acc.cpu().numpy())
+        eng.close()
+    (s0, l0, a0), (s1, l1, a1) = res["fp32"], res["f16x3"]
+    close = np.abs(s0 - s1).max(axis=1) < 1e-3
+    print("MEASURED C4 share (Bayesian): rows equal between fp32 and f16x3 after two transitions: %.5f, accepted %s vs %s"
+          % (close.mean(), a0.tolist(), a1.tolist()))
+    assert close.mean() > 0.995 and np.abs(a0 - a1).max() <= 2e-3 * n
+    assert np.abs(l0 - l1)[close].max() < 2e-3 * np.abs(l0).max()
+    n64 = OV.cast_vnet(net, np.float64)
+    for lo in (0, 312504, n - 40):
+        hi = min(n, lo + 40)
+        xs = x[lo:hi].cpu().numpy()
+        mask = (~np.isnan(xs)).astype(np.float64)
+        xc = np.where(np.isnan(xs), 0.0, xs).astype(np.float64)
+        ref = OV.hmc_sampler(n64, xc, mask, 2, 0, 0.02, L, seed, row0=lo, frozen=True)
+        ok = np.abs(s1[lo:hi] - ref[-1]).max(axis=1) < 1e-3
+        assert ok.mean() >= 0.9, (lo, ok.mean())
