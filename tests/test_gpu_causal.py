@@ -404,7 +404,8 @@ def test_outcome_cache_binary_treatment_is_bit_identical():
 
 
 @pytest.mark.parametrize("case", [dict(z_dims=[3, 3, 6, 6], p=100, n=2500), dict(z_dims=[1, 1, 1, 7], p=200, n=1000),
-                                  dict(z_dims=[3, 3, 6, 6], p=100, n=777, sample_y=False), dict(z_dims=[1, 1, 1, 7], p=20, n=40000)])
+                                  dict(z_dims=[3, 3, 6, 6], p=100, n=777, sample_y=False), dict(z_dims=[1, 1, 1, 7], p=20, n=40000),
+                                  dict(z_dims=[3, 3, 6, 6], p=100, n=100000)])      # (the last one: BASELINE configs[1] at full size)
 def test_event_form_for_binary_treatment_is_bit_identical(case):
     """Outcome cache mode 2 with a binary treatment (round 6; csrc/causal_event_kernels.h): transitions that append an event per accepted
     move, the outcome net at the two arms on dense 16-event tiles, one thread per chain writing y(1) - y(0) of every retained draw.
