@@ -75,6 +75,44 @@ def test_split_precision_chains_equal_the_fp32_kernel(q, units, p, n):
     assert g_close[close].mean() > 0.99, g_close[close].mean()
 
 
+def test_split_precision_samples_the_prior_when_nothing_is_observed():
+    """Known answer: with every cell missing the target is the latent prior N(0, I), whatever the generator."""
+    q, units, p = 10, (64,) * 5, 20
+    net = _net(q, units, p, seed=21)
+    x = np.full((512, p), np.nan, np.float32)
+    eng = _engine(net, q, units, p, hmc_frozen_noise=True)
+    eng.set_precision("f16x3")
+    out = eng.hmc_sample(x, n_mcmc=200, burn_in=100, step_size=0.1, n_leapfrog=5, seed=5)
+    d = out["draws"].cpu().numpy().reshape(-1, q)
+    assert np.abs(d.mean(0)).max() < 0.03 and np.abs(d.var(0) - 1).max() < 0.06
+    eng.close()
+
+
+@pytest.mark.parametrize("q,units,p,n", [(1, (64,) * 3, 5, 3), (16, (64,) * 3, 1, 17), (2, (64,) * 5, 16, 1)])
+def test_split_precision_at_the_edges_of_the_shapes(q, units, p, n):
+    """One latent dimension / the full latent tile, a single feature, exactly one 16-feature block, fewer rows than a tile, one row:
+    chains against the float64 oracle and against the fp32 kernel."""
+    net = _net(q, units, p, seed=31)
+    rs = np.random.RandomState(32)
+    x = rs.standard_normal((n, p)).astype(np.float32)
+    if p > 1:
+        x[rs.uniform(size=x.shape) < 0.2] = np.nan
+    seed = 9
+    got = {}
+    for mode in ("fp32", "f16x3"):
+        eng = _engine(net, q, units, p, hmc_frozen_noise=True)
+        eng.set_precision(mode)
+        got[mode] = eng.hmc_sample(x, n_mcmc=2, burn_in=4, step_size=0.03, n_leapfrog=3, seed=seed, row_base=100)["draws"].cpu().numpy()
+        eng.close()
+    mask = (~np.isnan(x)).astype(np.float64)
+    xc = np.where(np.isnan(x), 0.0, x).astype(np.float64)
+    ref = OV.hmc_sampler(OV.cast_vnet(net, np.float64), xc, mask, 2, 4, 0.03, 3, seed, row0=100, frozen=True)
+    assert got["f16x3"].shape == ref.shape
+    close = np.abs(got["f16x3"] - ref).max(axis=(0, 2)) < 1e-3
+    same = np.abs(got["f16x3"] - got["fp32"]).max(axis=(0, 2)) < 1e-3
+    assert close.sum() >= n - 1 and same.sum() >= n - 1, (close, same)
+
+
 def test_split_precision_rows_do_not_depend_on_the_launch_they_ride_in():
     """A row's chain is a function of (row_base + row, seed) alone: slices of the panel reproduce the whole run bit for bit."""
     q, units, p, n = 10, (64,) * 5, 100, 5000
