@@ -15,7 +15,7 @@ static constexpr int BGM_WAVES = 8;
 #define BGM_WAVES_WIDE_HMC 12   // 148 VGPRs -> 3 waves/SIMD; measured 89 vs 86 (8) vs 86 (16) TF at p=500
 #endif
 #ifndef BGM_SX3_WAVES_DEFAULT
-#define BGM_SX3_WAVES_DEFAULT 12      // ms per transition at N = 2e5, p = 500: 3.43 (8 waves, no spill) / 3.19 (12 waves, 168 registers); two 6-wave workgroups per CU: 5.8 (before the stream's waits were removed)
+#define BGM_SX3_WAVES_DEFAULT 12      // ms per transition at N = 2e5, p = 500: 3.43 (8 waves, no spill) / 3.19 (12 waves, 168 registers); two 6-wave workgroups per CU: 4.0; two / three / four units per stream step: 3.12 / 3.24 / 3.34
 #endif
 static constexpr float BN_EPS_F = 1e-3f;   // keras BatchNormalization default epsilon
 
