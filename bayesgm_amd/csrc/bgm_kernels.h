@@ -271,7 +271,9 @@ struct BgmHeadStreamX3 {
     for (int k = 0; k < K; ++k)
       if (K * NT == STEP_VEC || (tid & ~63) + k * NT < STEP_VEC) {
         const unsigned m0v = __builtin_amdgcn_readfirstlane(dst0 + (unsigned)(k * NT) * 16u);
-        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(m0v), "v"(s + k * NT) : "memory", "m0");
+        unsigned m0_saved;      // (M0 is handed back as it was found: the compiler does not model a clobber of it)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(m0_saved) : "s"(m0v), "v"(s + k * NT) : "memory");
       }
   }
   __device__ __forceinline__ void commit() {

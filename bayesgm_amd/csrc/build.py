@@ -16,7 +16,7 @@ OUT = os.path.join(PKG, "libbgm_hip.so")
 SOURCES = ["causal_api.hip", "causal_event_api.hip", "causal_bx3_api.hip", "causal_prior_api.hip", "aux_kernels.hip", "fit_api.hip", "bgm_api.hip", "egm_api.hip", "bgm_egm_api.hip", "bnn_api.hip", "bnn_sample_api.hip", "bprior_api.hip", "bnf_api.hip", "bnx_api.hip", "bnf_det_api.hip", "gx_api.hip", "gx_bgm_api.hip", "bnn_egm_api.hip", "bnn_egm_gen_chain_a.hip", "bnn_egm_gen_chain_b.hip", "bnn_egm_gen_chain_c.hip", "bnn_egm_gen_chain_d.hip", "bgmb_api.hip", "bgmb_egm_api.hip", "bgmf_api.hip", "bnw_api.hip", "comm_api.hip"]
 HEADERS = ["bgm_device.h", "causal_kernels.h", "causal_event_kernels.h", "causal_bx3_kernels.h", "fit_kernels.h", "z_replay.h", "prior_kernels.h", "fit_types.h", "fit_sync.h", "bgm_kernels.h", "bgm_fit_kernels.h", "bgm_state.h", "bgm_host.h", "egm_kernels.h", "egm_chain.h", "egm_chain_gen.h", "egm_chain_bnn.h", "bnn_egm_gen_chain.inc", "fit_chain.h", "bgm_egm_kernels.h", "bnn_kernels.h", "bnn_state.h", "bprior_kernels.h", "bprior_types.h", "bnn_sample_kernels.h", "bnf_kernels.h", "bnx_kernels.h", "bnx_host.h", "bnf_host.h", "bnf_build.h", "bnf_det_host.h", "gx_device.h", "gx_causal_kernels.h", "gw_kernels.h", "gx_fit_kernels.h", "gx_host.h", "gx_bgm_kernels.h", "gx_bgm_host.h", "gx_flipout.h", "bgmf_kernels.h", "bgmfx_kernels.h", "bnw_kernels.h", "bnn_egm_kernels.h", "bgmb_kernels.h", "bgmb_state.h", "bgmb_egm_kernels.h", "comm_host.h", os.path.join("..", "..", "include", "bgm_hip.h")]
 FLAGS = os.environ.get("BGM_EXTRA_FLAGS", "").split() + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-munsafe-fp-atomics",
-         "-Wno-unused-value", "-Wno-unused-result", "-Wno-inline-asm"]
+         "-Wno-unused-value", "-Wno-unused-result"]
 
 
 # per-source flags.  bnf_api.hip: hipcc's SLP vectoriser packs the epilogues' scalar fma / mul pairs into v_pk_fma_f32 / v_pk_mul_f32, which
