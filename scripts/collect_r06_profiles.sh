@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-6 rocprofv3 evidence, run on the GPU box from the repo root (gpurun).  Counters in their own passes (--kernel-trace only beside
 # --pmc), as MI355X_MICROARCH.md prescribes.  Summaries land in gpurun_out/r06prof/ and are copied to profiles/ by hand.
-# usage: bash scripts/collect_r06_profiles.sh [what ...]   what in: mh bnn bnw hmc hmcb c1 hmcw bench ablation    (default: mh bnn)
+# usage: bash scripts/collect_r06_profiles.sh [what ...]   what in: mh bnn bnw hmc hmcb hmcmem c1 hmcw bench ablation    (default: mh bnn)
 set -u
 OUT=gpurun_out/r06prof
 mkdir -p $OUT
@@ -20,8 +20,18 @@ passes() {   # tag, command...
   { echo "# rocprofv3 --kernel-trace --pmc $SQ2 -- $*"; summ $OUT/${tag}_sq2; } > $OUT/r06_pmc_sq2_${tag}.txt
   find $OUT -mindepth 1 -maxdepth 1 -type d -name "${tag}_*" -exec rm -rf {} +
 }
+mempasses() {   # tag, command...: HBM bytes (FETCH_SIZE and WRITE_SIZE need a pass each: MI355X_MICROARCH.md, rocprofv3 PMC slots)
+  local tag=$1; shift
+  timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $OUT/${tag}_fetch -o fetch -- "$@" > $OUT/${tag}_fetch.log 2>&1 < /dev/null
+  timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/${tag}_write -o write -- "$@" > $OUT/${tag}_write.log 2>&1 < /dev/null
+  { echo "# --pmc FETCH_SIZE GRBM_GUI_ACTIVE | WRITE_SIZE (one pass each) -- $*"; summ $OUT/${tag}_fetch; summ $OUT/${tag}_write; } > $OUT/r06_pmc_mem_${tag}.txt
+  find $OUT -mindepth 1 -maxdepth 1 -type d -name "${tag}_*" -exec rm -rf {} +
+}
 for w in $WHAT; do
   case $w in
+    # HBM traffic of the split-precision BGM kernels at C4's shape (the data rows are re-read per gradient evaluation: by design, and counted)
+    hmcmem) mempasses bgm_hmc_f16x3 env BGM_PROBE_PRECISION=f16x3 python scripts/probe_bgm_wide.py 2e5 4
+            mempasses bgmf_hmc_f16x3 env BGM_PROBE_MODES=f16x3 python scripts/probe_bgmf.py 2e5 4 ;;
     # the pure-transition kernel that is now 4.5 of the product predict's 4.9 s: 100 burn-in + 40 kept iterations
     mh) passes causal_mh python scripts/probe_mh.py 1e6 100 40 ;;
     # the Bayesian default model's sampler + effects kernels at N = 1e6 (item 1)
