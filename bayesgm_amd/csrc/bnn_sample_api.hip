@@ -145,8 +145,8 @@ extern "C" int bgm_bnn_logpost(bgm_handle *h, const float *x, const float *y, co
   BGM_HIP_CHECK(hipSetDevice(h->device));
   rc = bnf_logpost(h, s, x, y, v, z, n, block_rows, block0, seed, stream_id, out, stream);     // inference-mode normalisation, default shapes
   if (rc <= 0) return rc;
-  // any hidden width -- and the conditional prior (bgm_bnn_set_prior) outside the default shapes: the any-width path reads its row tables
-  if (bns_wide || s->bp_on) return bnw_logpost(h, s, x, y, v, z, n, block_rows, block0, seed, stream_id, out, stream);
+  // any hidden width: the any-width path (it reads the conditional prior's row tables as well)
+  if (bns_wide) return bnw_logpost(h, s, x, y, v, z, n, block_rows, block0, seed, stream_id, out, stream);
   const int n_blocks = (int)((n + block_rows - 1) / block_rows);
   BnsBuf b;
   rc = bns_buffers(h, s, pl, n, n_blocks, (long long)n_blocks * pl.set_ghf, b, stream);
@@ -165,6 +165,10 @@ extern "C" int bgm_bnn_logpost(bgm_handle *h, const float *x, const float *y, co
   a.x = x; a.y = y; a.v = v; a.z = const_cast<float *>(z); a.zprop = b.zprop; a.n = n; a.row_base = 0;
   a.bs = block_rows; a.wg_per_block = (block_rows + BNS_ROWS - 1) / BNS_ROWS; a.block0 = block0; a.mode = 0; a.it = 0;
   a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32); a.stream0 = stream_id; a.out = out;
+  if (s->bp_on) {      // conditional prior under batch statistics: one noisy call of the prior net for this evaluation (bprior_api.hip)
+    if ((rc = bprior_rows(h, s, n, block_rows, block0, seed, stream_id, 1, stream))) return rc;
+    a.prior = s->bp_rows; a.prior_stride = 0;
+  }
   rc = bns_set_lds(bns_mh_kernel, pl.lds_bytes);
   if (rc) return rc;
   a.n_items = n_blocks * a.wg_per_block;
@@ -188,7 +192,7 @@ extern "C" int bgm_bnn_mh_run(bgm_handle *h, const bgm_bnn_mh_args *g, void *str
   rc = bnf_mh_run(h, s, g, stream);
   if (rc <= 0) return rc;
   if (g->block_row0 != 0) { bgm_set_error("bgm_bnn_mh_run: a share of one block (block_row0 > 0) is served by the default-shape sampling kernels with inference-mode normalisation only"); return BGM_E_UNSUPPORTED; }
-  if (bns_wide || s->bp_on) return bnw_mh_run(h, s, g, stream);
+  if (bns_wide) return bnw_mh_run(h, s, g, stream);
   const long long n = g->n;
   const int bs = g->block_rows, n_blocks = (int)((n + bs - 1) / bs), q = s->q;
   BnsBuf b;
@@ -253,6 +257,10 @@ extern "C" int bgm_bnn_mh_run(bgm_handle *h, const bgm_bnn_mh_args *g, void *str
     pa.it = it; pa.par = i & 1; pa.init = (i == 0 && g->init) ? 1 : 0; pa.xstats = (i == 0) ? b.xstats : nullptr;
     hipLaunchKernelGGL(bns_propose_kernel, dim3(n_blocks * pa.wg_per_block), dim3(256), 0, stream, pa);
     if (i > 0 && kept(it - 1)) effects(it - 1, i & 1);
+    if (s->bp_on) {      // the two evaluations' own calls of the prior net (streams 2 it, 2 it + 1)
+      if ((rc = bprior_rows(h, s, n, bs, g->block0, g->seed, 2u * (uint32_t)it, 2, stream))) return rc;
+      a.prior = s->bp_rows; a.prior_stride = n * (long long)(q + 2);
+    }
     a.it = it; a.stats = b.stats + (long long)(i & 1) * n_blocks * 256;
     a.acc_blocks = g->acc_blocks_dev ? g->acc_blocks_dev + (long long)i * n_blocks : nullptr;
     a.n_items = n_blocks * a.wg_per_block;

@@ -473,6 +473,10 @@ struct BnsMhArgs {
   unsigned *acc_count;                 // mode 1 (optional): accepted proposals
   unsigned *acc_blocks;                // mode 1 (optional): accepted proposals of this iteration per block [n_blocks]
   unsigned long long *prof;            // -D BNS_PROF: cycles per phase, summed over workgroups (wave 0)
+  // conditional latent prior (IdentifiableCausalBGM with batch statistics, bprior_api.hip): [n_states][n][q + 2] = mu [q], 1 / sigma^2,
+  // (q / 2) log sigma^2 of every row for the state's own noisy call of the prior net (state 0: proposal / mode 0, state 1: current), or NULL = N(0, I)
+  const float *prior;
+  long long prior_stride;
 };
 
 __device__ __forceinline__ void bns_stat(const double *st, int col, double cnt, float &mean, float &var) {
@@ -557,8 +561,14 @@ __device__ __forceinline__ void bns_logpost_rows(const BnsCtx &c, const BnsMhArg
     const float s2 = a.sig2[2] > 0.0f ? a.sig2[2] : softplus_acc(rw) + BGM_EPS, d = yr[rt] - m_;
     lp[rt] -= d * d / (2.0f * s2) + logf(s2) * 0.5f;
     float zz = 0.0f;
-    for (int u = 0; u < q; ++u) { const float t = zsrc[row[rt] * q + u]; zz = fmaf(t, t, zz); }
-    lp[rt] -= 0.5f * zz;
+    if (a.prior) {      // identifiable.py:541-551: -(|z - mu(u)|^2 / (2 sigma^2(u)) + (q / 2) log sigma^2(u))
+      const float *pr = a.prior + (long long)dw_slot * a.prior_stride + row[rt] * (long long)(q + 2);
+      for (int u = 0; u < q; ++u) { const float t = zsrc[row[rt] * q + u] - pr[u]; zz = fmaf(t, t, zz); }
+      lp[rt] -= 0.5f * zz * pr[q] + pr[q + 1];
+    } else {
+      for (int u = 0; u < q; ++u) { const float t = zsrc[row[rt] * q + u]; zz = fmaf(t, t, zz); }
+      lp[rt] -= 0.5f * zz;
+    }
   }
 }
 

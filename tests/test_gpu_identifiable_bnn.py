@@ -196,8 +196,8 @@ def test_conditional_prior_outside_the_default_shapes(units):
 def test_conditional_prior_with_batch_statistics(units, binary):
     """The reference as written (params['bnn_norm'] = 'batch'): every input BatchNormalization -- of g, h, f and of the prior net
     (bnn.py:26 on the one-hot segments, identifiable.py:541) -- normalises with the statistics of the block of rows of the call.  For
-    the prior net these are the shares of the block's rows per segment (bprior_hist_kernel, once per run); the nets run on the any-width
-    path's statistics passes (csrc/bnw_kernels.h).  Log posterior and two sampler iterations against the float64 oracle, blocks of
+    the prior net these are the shares of the block's rows per segment (bprior_hist_kernel, once per run); the nets run on the batch-statistics
+    kernels (csrc/bnn_sample_kernels.h at the default widths, csrc/bnw_kernels.h otherwise).  Log posterior and two sampler iterations against the float64 oracle, blocks of
     128 rows with a short last block."""
     from bayesgm_amd import _lib
     from bayesgm_amd.bnn_engine import flatten_bnn
