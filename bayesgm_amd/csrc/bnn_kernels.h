@@ -218,6 +218,26 @@ __device__ __forceinline__ void bnn_noise(const BnnCtx &c, const float *theta, c
 __device__ __forceinline__ void bnn_bn_fwd(const BnnCtx &c, const float *theta, const BnnNet &n, const BnnCache &k, int B) {
   const int in = n.dims[0];
   const float *gamma = theta + n.off, *beta = gamma + in, *mvs = beta + in;
+  if (k.ext || n.bn_fixed) {      // statistics known before the call: one thread per element (rows x columns) instead of one per column
+    for (int idx = c.tid; idx < B * in; idx += BNN_THREADS) {
+      const int b = idx / in, i = idx - b * in;
+      float mu, var;
+      if (k.ext) { mu = k.ext[i]; var = k.ext[in + i]; }
+      else if (n.bn_fixed == 1) { mu = 0.0f; var = 1.0f; }
+      else { mu = mvs[i]; var = mvs[in + i]; }
+      const float inv = 1.0f / sqrtf(var + BNN_BN_EPS);
+      if (b == 0) {
+        k.inv[i] = inv;
+        if (k.mu) { k.mu[i] = mu; k.mu[in + i] = var; }
+      }
+      const float xh = (k.x[idx] - mu) * inv;
+      const float h = xh * gamma[i] + beta[i];
+      k.xhat[idx] = xh;
+      k.H[idx] = h;
+      k.HS[idx] = h * bnn_sign(k.sg, n.swords, b, n.sin_w[0], i);
+    }
+    return;
+  }
   for (int i = c.tid; i < in; i += BNN_THREADS) {
     float mu, var;
     if (k.ext) { mu = k.ext[i]; var = k.ext[in + i]; }

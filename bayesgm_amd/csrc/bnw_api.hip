@@ -9,8 +9,9 @@
 #include "bnw_kernels.h"
 
 struct BnwState {
-  float *dw = nullptr, *ws = nullptr, *pair = nullptr;
-  size_t dw_cap = 0, ws_cap = 0;
+  float *dw = nullptr, *ws = nullptr, *pair = nullptr, *loct = nullptr;
+  BnwNets *nets = nullptr;      // [2]: the nets of the call's sets, the outcome net's own
+  size_t dw_cap = 0, ws_cap = 0, loct_cap = 0;
   float *st = nullptr;          // batch statistics (params['bnn_norm'] = "batch"), doubles: [2 parities][n_blocks][256] | x [n_blocks][2] | v [2][p]
   size_t st_cap = 0;
 };
@@ -21,6 +22,8 @@ void bnw_free(void *p) {
   if (b->dw) hipFree(b->dw);
   if (b->ws) hipFree(b->ws);
   if (b->pair) hipFree(b->pair);
+  if (b->loct) hipFree(b->loct);
+  if (b->nets) hipFree(b->nets);
   if (b->st) hipFree(b->st);
   delete b;
 }
@@ -68,11 +71,28 @@ int bnw_plan(bgm_handle *h, BnnState *s, const BnwNets &m, long long n_sets_tota
   if (rc) return rc;
   rc = bnw_grow(&b->dw, &b->dw_cap, (size_t)n_sets_total * (size_t)m.set_floats + 64, stream);
   if (rc) return rc;
+  rc = bnw_grow(&b->loct, &b->loct_cap, 2 * (size_t)m.set_floats + 128, stream);      // the call's sets and the outcome net's own sets
+  if (rc) return rc;
+  if (!b->nets) BGM_HIP_CHECK(hipMalloc((void **)&b->nets, 2 * sizeof(BnwNets)));
   if (!b->pair) {
     BGM_HIP_CHECK(hipMalloc((void **)&b->pair, 2 * sizeof(float)));
     static const float pair_host[2] = {1.0f, 0.0f};
     BGM_HIP_CHECK(hipMemcpy(b->pair, pair_host, sizeof(pair_host), hipMemcpyHostToDevice));
   }
+  return BGM_OK;
+}
+// transposed posterior means of the nets of m's sets at loct + at (the launches of one call read them; theta may change between calls)
+int bnw_pack(BnwState *b, BnwNets &m, size_t at, hipStream_t stream) {
+  float *dst = b->loct + at;
+  long long mx = 0;
+  for (int k = 0; k < 4; ++k) if (m.noff[k] >= 0) mx = std::max<long long>(mx, m.net[k].eoff[m.net[k].n_layers]);
+  hipLaunchKernelGGL(bnw_pack_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(256, (mx + 255) / 256))), dim3(256), 0, stream, m, dst);
+  BGM_HIP_CHECK(hipGetLastError());
+  m.locT = dst;
+  m.dev = b->nets + (at ? 1 : 0);      // the kernels' copy of the nets (device memory: bnw_kernels.h BnwRowsArgs::mp)
+  static_assert(sizeof(BnwNets) % 4 == 0, "BnwNets is copied in words");
+  hipLaunchKernelGGL(bnw_store_nets_kernel, dim3(1), dim3(64), 0, stream, m, b->nets + (at ? 1 : 0));
+  BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
 }
 // batch statistics: zeroed buffers of this call; stats(par) = the parity a launch accumulates into
@@ -126,6 +146,8 @@ int bnw_logpost(bgm_handle *h, BnnState *s, const float *x, const float *y, cons
   BnwPlan pl;
   rc = bnw_plan(h, s, a.m, n_blocks, n_blocks * tpb, pl, stream);
   if (rc) return rc;
+  if ((rc = bnw_pack(pl.b, a.m, 0, stream))) return rc;
+  a.mp = a.m.dev;
   bnw_noise(a.m, pl.b->dw, n_blocks, 1, block0, seed, stream_id, 0u, stream);
   BnwBatch bt;
   rc = bnw_batch(s, pl.b, n_blocks, bt, stream);
@@ -153,7 +175,7 @@ int bnw_effects_of(const BnwNets &mf, const BnwPlan &pl, float *dw_eff, const fl
   bnw_noise(mf, dw_eff, n_blocks, n_doses, block0, seed, stream0, 1u, stream);
   BnwEffArgs e{};
   e.stats = stats;
-  e.m = mf; e.dw = dw_eff; e.z = z; e.n = n; e.row_base = row_base; e.bs = bs; e.block0 = block0;
+  e.m = mf; e.mp = mf.dev; e.dw = dw_eff; e.z = z; e.n = n; e.row_base = row_base; e.bs = bs; e.block0 = block0;
   e.tiles_per_block = (bs + BNW_RT - 1) / BNW_RT; e.n_items = n_blocks * e.tiles_per_block; e.n_doses = n_doses; e.xvals = xvals;
   e.k0 = (uint32_t)seed; e.k1 = (uint32_t)(seed >> 32); e.stream0 = stream0; e.it_noise = it_noise; e.sample_y = sample_y;
   e.sum_out = sum_out; e.sum_stride = sum_stride; e.ite_out = ite_out; e.ite_stride = ite_stride;
@@ -180,6 +202,8 @@ int bnw_mh_run(bgm_handle *h, BnnState *s, const bgm_bnn_mh_args *g, hipStream_t
   const size_t mh_floats = (size_t)2 * n_blocks * a.m.set_floats, eff_floats = (size_t)n_blocks * n_doses * mf.set_floats;
   rc = bnw_plan(h, s, a.m, (long long)((mh_floats + eff_floats) / std::max<long long>(1, a.m.set_floats) + 2), n_blocks * tpb, pl, stream);
   if (rc) return rc;
+  if ((rc = bnw_pack(pl.b, a.m, 0, stream)) || (rc = bnw_pack(pl.b, mf, ((size_t)a.m.set_floats + 63) & ~(size_t)63, stream))) return rc;
+  a.mp = a.m.dev;
   float *dw_eff = pl.b->dw + ((mh_floats + 63) & ~(size_t)63);
   a.dw = pl.b->dw; a.n_calls = 2; a.x = g->x_dev; a.y = g->y_dev; a.v = g->v_dev; a.z = g->state_dev; a.n = n; a.row_base = g->row_base;
   a.bs = bs; a.block0 = g->block0; a.tiles_per_block = tpb; a.n_items = n_blocks * tpb; a.mode = 1;
@@ -228,6 +252,16 @@ int bnw_mh_run(bgm_handle *h, BnnState *s, const bgm_bnn_mh_args *g, hipStream_t
     if ((rc = effects(g->it_begin + i - 1, i & 1))) return rc;
   }
   BGM_HIP_CHECK(hipGetLastError());
+#ifdef BNW_PROF
+  {
+    unsigned long long acc[8], zero[8] = {0};
+    BGM_HIP_CHECK(hipStreamSynchronize(stream));
+    BGM_HIP_CHECK(hipMemcpyFromSymbol(acc, HIP_SYMBOL(bnw_prof_acc), sizeof(acc)));
+    BGM_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(bnw_prof_acc), zero, sizeof(zero)));
+    const double tot = (double)(acc[0] + acc[1] + acc[2]);
+    fprintf(stderr, "BNW_PROF net calls: signs %.3f  input normalisation %.3f  layers %.3f  (of %.3e cycles inside calls)\n", acc[0] / tot, acc[1] / tot, acc[2] / tot, tot);
+  }
+#endif
   return BGM_OK;
 }
 
@@ -243,6 +277,7 @@ int bnw_effects(bgm_handle *h, BnnState *s, const float *draws, int64_t n, int32
   BnwPlan pl;
   rc = bnw_plan(h, s, mf, (long long)n_blocks * nd, n_blocks * tpb, pl, stream);
   if (rc) return rc;
+  if ((rc = bnw_pack(pl.b, mf, 0, stream))) return rc;
   BnwBatch bt;
   rc = bnw_batch(s, pl.b, n_blocks, bt, stream);
   if (rc) return rc;
@@ -272,6 +307,8 @@ int bnw_evaluate(bgm_handle *h, BnnState *s, const float *x, const float *y, con
   const size_t all_floats = (size_t)a.m.set_floats, eff_floats = (size_t)nd * mf.set_floats;
   rc = bnw_plan(h, s, a.m, (long long)((all_floats + eff_floats) / std::max<long long>(1, a.m.set_floats) + 2), tpb, pl, stream);
   if (rc) return rc;
+  if ((rc = bnw_pack(pl.b, a.m, 0, stream)) || (rc = bnw_pack(pl.b, mf, ((size_t)a.m.set_floats + 63) & ~(size_t)63, stream))) return rc;
+  a.mp = a.m.dev;
   float *dw_eff = pl.b->dw + ((all_floats + 63) & ~(size_t)63);
   bnw_noise(a.m, pl.b->dw, 1, 1, 0, seed, stream_id, 0u, stream);
   a.dw = pl.b->dw; a.n_calls = 1; a.x = x; a.y = y; a.v = v; a.z = z; a.n = n; a.row_base = 0; a.bs = bs; a.block0 = 0;

@@ -19,10 +19,29 @@
 #include "bnn_kernels.h"
 
 #define BNW_RT 64                       // rows of a workgroup tile
+#ifndef BNW_GEMM_DB
+#define BNW_GEMM_DB 1                   // operands of the next chunk of 16 K requested before the current chunk's matrix instructions
+#endif
+#ifndef BNW_WAVES_PER_EU
+#define BNW_WAVES_PER_EU 2              // 2: one 512-thread workgroup per CU with 256 registers per lane; 4: two with 128
+#endif
 
+#ifdef BNW_PROF      // development: shader-clock cycles of wave 0 per phase of a net call, summed over workgroups (bnw_api.hip prints them)
+__device__ unsigned long long bnw_prof_acc[8];
+__device__ unsigned long long bnw_prof_last;      // (one value is enough for a relative split: every workgroup overwrites it in the same phase order)
+#define BNW_T0() unsigned long long bnw_t_ = __builtin_amdgcn_s_memtime()
+#define BNW_T(i) do { const unsigned long long t2_ = __builtin_amdgcn_s_memtime(); if (c.tid == 0) atomicAdd(&bnw_prof_acc[i], t2_ - bnw_t_); bnw_t_ = t2_; } while (0)
+#else
+#define BNW_T0() do {} while (0)
+#define BNW_T(i) do {} while (0)
+#endif
+
+struct BnwNets;
 struct BnwNets {
   BnnNet net[4];                        // g, e, f, h (BNN_* ids) with bn_fixed = 1
   const float *theta;
+  const BnwNets *dev;                   // this struct in device memory (bnw_store_nets_kernel), what the row kernels read
+  const float *locT;                    // posterior means of the nets of the sets, transposed, in the layout of one set (bnw_pack_kernel)
   int noff[4];                          // offset of net k's perturbation inside a set (-1: not in the sets of this launch)
   long long set_floats;
   int q, p, z0, z1, z2, binary;
@@ -47,16 +66,38 @@ static __global__ __launch_bounds__(256) void bnw_noise_kernel(BnwNoiseArgs a) {
       const int cnt = n.lin[l] * n.lout[l];
       const float *rho = a.m.theta + n.woff[l] + cnt;
       float *d = base + a.m.noff[k] + n.eoff[l];
+      const int in = n.lin[l], out = n.lout[l];
       for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (cnt + 3) >> 2; i += gridDim.x * blockDim.x) {
         const f32x4 z = box_muller4(philox4x32_10((uint32_t)i, (uint32_t)l | ((uint32_t)n.net_id << 16), stream, BNN_TAG_EPS, a.k0, k1));
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int idx = 4 * i + u;
-          if (idx < cnt) d[idx] = (BNN_SCALE_EPS + softplus_acc(rho[idx])) * z[u];
+          const int idx = 4 * i + u;      // element (row = input unit, column = output unit) of the layer's [in x out] kernel; stored transposed
+          if (idx < cnt) { const int ki = idx / out, no = idx - ki * out; d[no * in + ki] = (BNN_SCALE_EPS + softplus_acc(rho[idx])) * z[u]; }
         }
       }
     }
   }
+}
+
+// posterior means of the nets of a set, transposed ([out x in] per layer), in the set's layout: once per launch sequence (theta is
+// constant inside a sampling run)
+static __global__ __launch_bounds__(256) void bnw_pack_kernel(BnwNets m, float *locT) {
+  for (int k = 0; k < 4; ++k) {
+    if (m.noff[k] < 0) continue;
+    const BnnNet &n = m.net[k];
+    for (int l = 0; l < n.n_layers; ++l) {
+      const int in = n.lin[l], out = n.lout[l], cnt = in * out;
+      const float *loc = m.theta + n.woff[l];
+      float *d = locT + m.noff[k] + n.eoff[l];
+      for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < cnt; idx += gridDim.x * blockDim.x) { const int ki = idx / out, no = idx - ki * out; d[no * in + ki] = loc[idx]; }
+    }
+  }
+}
+
+static __global__ __launch_bounds__(64) void bnw_store_nets_kernel(BnwNets m, BnwNets *dst) {
+  const unsigned *src = reinterpret_cast<const unsigned *>(&m);
+  unsigned *d = reinterpret_cast<unsigned *>(dst);
+  for (int i = threadIdx.x; i < (int)(sizeof(BnwNets) / 4); i += 64) d[i] = src[i];
 }
 
 // ---- batch statistics of a block (params['bnn_norm'] = "batch") ---------------------------------------------------------------
@@ -154,6 +195,123 @@ __device__ __forceinline__ void bnw_ext(const BnnCtx &c, const BnwNets &m, int i
   __syncthreads();
 }
 
+// ---- the layer products of this path ---------------------------------------------------------------------------------------------
+// C1 = A1 W1, C2 = A2 W2 with A [M x K] row-major (the tile's activations and their sign-flipped copy in the workspace) and the weights
+// TRANSPOSED, Wt [N x K] row-major (bnw_pack_kernel: posterior means; bnw_noise_kernel: the call's dW): both operands of a lane are then
+// four consecutive K values = one 16-byte load per operand and chunk of 16 K.  A wave owns a 32 x 32 block of the output = 2 x 2 tiles
+// of v_mfma_f32_16x16x4_f32 for each of the two products (eight independent accumulators); the operands of chunk c + 1 are requested
+// before the 32 matrix instructions of chunk c are issued.  Lane (j = lane & 15, g = lane >> 4) feeds A(m0 + j, k0 + 4 g + u),
+// Wt(n0 + j, k0 + 4 g + u) in step u and receives C(m0 + 4 g + r, n0 + j).  Rows / columns beyond M / N are clamped duplicates whose
+// results are not written; K beyond a multiple of 16 (and any K when an operand is not 16-byte aligned) takes masked scalar loads.
+struct BnwOps { f32x4 a1[2], a2[2], b1[2], b2[2]; };
+template <class Epi>
+__device__ __forceinline__ void bnw_gemm2(int tid, const float *A1, const float *A2, int lda, const float *W1, const float *W2, int M, int N,
+                                          int K, Epi epi) {
+  const int lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6;
+  const int tn = (N + 31) >> 5, blocks = ((M + 31) >> 5) * tn;
+  const bool vec = (lda & 3) == 0 && (K & 3) == 0 &&
+                   ((((unsigned long long)A1 | (unsigned long long)A2 | (unsigned long long)W1 | (unsigned long long)W2) & 15ull) == 0);
+  const int KC = vec ? (K >> 4) : 0;
+  for (int t = wave; t < blocks; t += BNN_THREADS / 64) {
+    const int m0 = (t / tn) << 5, n0 = (t % tn) << 5;
+    int ra[2], cb[2];      // element offsets of the lane's rows / columns from the (wave-uniform) operand bases
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { ra[i] = min(m0 + 16 * i + j, M - 1) * lda; cb[i] = min(n0 + 16 * i + j, N - 1) * K; }
+    f32x4 c1[2][2], c2[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2) { c1[i][i2] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; c2[i][i2] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    auto load = [&](BnwOps &o, int kc) {
+      const int ko = 16 * kc + 4 * g;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        o.a1[i] = *reinterpret_cast<const f32x4 *>(A1 + (ra[i] + ko)); o.a2[i] = *reinterpret_cast<const f32x4 *>(A2 + (ra[i] + ko));
+        o.b1[i] = *reinterpret_cast<const f32x4 *>(W1 + (cb[i] + ko)); o.b2[i] = *reinterpret_cast<const f32x4 *>(W2 + (cb[i] + ko));
+      }
+    };
+    auto mac = [&](const BnwOps &o) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int i2 = 0; i2 < 2; ++i2) {
+            c1[i][i2] = BGM_MFMA(o.a1[i][u], o.b1[i2][u], c1[i][i2]);
+            c2[i][i2] = BGM_MFMA(o.a2[i][u], o.b2[i2][u], c2[i][i2]);
+          }
+    };
+#if BNW_GEMM_DB
+    if (KC > 0) {
+      BnwOps o0, o1;
+      load(o0, 0);
+      int kc = 0;
+      for (; kc + 2 <= KC; kc += 2) {
+        load(o1, kc + 1);
+        BGM_NO_HOIST();
+        mac(o0);
+        if (kc + 2 < KC) load(o0, kc + 2);
+        BGM_NO_HOIST();
+        mac(o1);
+      }
+      if (kc < KC) mac(o0);
+    }
+#else
+    for (int kc = 0; kc < KC; ++kc) {
+      BnwOps o;
+      load(o, kc);
+      BGM_NO_HOIST();
+      mac(o);
+    }
+#endif
+    for (int k0 = 16 * KC; k0 < K; k0 += 16) {
+      BnwOps o;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + 4 * g + u, kq = min(k, K - 1);
+        const float mk = k < K ? 1.0f : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { o.a1[i][u] = A1[ra[i] + kq] * mk; o.a2[i][u] = A2[ra[i] + kq] * mk; o.b1[i][u] = W1[cb[i] + kq]; o.b2[i][u] = W2[cb[i] + kq]; }
+      }
+      BGM_NO_HOIST();
+      mac(o);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + 16 * i + 4 * g + r, n = n0 + 16 * i2 + j;
+          if (m < M && n < N) epi(m, n, c1[i][i2][r], c2[i][i2][r]);
+        }
+  }
+}
+
+// forward of the Flipout stack as bnn_layers_fwd (bnn_kernels.h), on the transposed weights: locT = the posterior means of the net in the
+// layout of a perturbation set (layer l at eoff[l], [out x in]), k.dW = the call's perturbation in the same layout
+__device__ __forceinline__ void bnw_layers_fwd(const BnnCtx &c, const float *theta, const float *locT, const BnnNet &n, const BnnCache &k, int B) {
+  const int L = n.n_layers;
+  for (int l = 0; l < L; ++l) {
+    const int in = n.lin[l], out = n.lout[l];
+    const float *bias = theta + n.woff[l] + 2 * in * out;
+    const float *h = k.H + (long long)B * n.hin[l], *hs = k.HS + (long long)B * n.hsin[l];
+    float *y = k.H + (long long)B * n.hoff[l + 1], *ys = k.HS + (long long)B * n.hoff[l + 1];
+    const bool last = (l == L - 1) || (n.heads && l == L - 2);
+    const bool feeds_heads = n.heads && l == L - 3;
+    float *ys2 = k.HS + (long long)B * n.hsin[L - 1];
+    const int so = n.sout_w[l], si = last ? 0 : n.sin_w[l + 1], si2 = n.sin_w[L - 1];
+    bnw_gemm2(c.tid, h, hs, in, locT + n.eoff[l], k.dW + n.eoff[l], B, out, in, [&](int m, int o, float c1, float c2) {
+      float v = c1 + bias[o] + bnn_sign(k.sg, n.swords, m, so, o) * c2;
+      if (!last) v = fmaxf(v, BNN_LEAK * v);
+      y[(long long)m * out + o] = v;
+      if (!last) ys[(long long)m * out + o] = v * bnn_sign(k.sg, n.swords, m, si, o);
+      if (feeds_heads) ys2[(long long)m * out + o] = v * bnn_sign(k.sg, n.swords, m, si2, o);
+    });
+    if (!(n.heads && l == L - 2)) __syncthreads();
+  }
+}
+
 // call cache without private perturbation arrays (the call's dW is shared by all tiles of the block)
 __device__ __forceinline__ void bnw_cache(const BnnNet &n, int B, float *p, BnnCache &k, const float *input, const float *dw) {
   auto take = [&](long long cnt) { float *r = p; p += (cnt + 3) & ~3LL; return r; };
@@ -202,9 +360,19 @@ __device__ __forceinline__ const float *bnw_call(const BnnCtx &c, const BnwNets 
                                                  const BnwStats *S = nullptr) {
   BnnCache k;
   bnw_cache(m.net[id], B, w.cache, k, input, set + m.noff[id]);
+  BNW_T0();
   if (S) { bnw_ext(c, m, id, *S, w.ext); k.ext = w.ext; }
-  const float *o = bnn_fwd(c, m.theta, m.net[id], k, B, k0, k1, stream, row0, true);
+  const BnnNet &n = m.net[id];
+  bnn_noise(c, m.theta, n, k, B, k0, k1, stream, row0, true);      // (the steps of bnn_fwd)
   __syncthreads();
+  BNW_T(0);
+  bnn_bn_fwd(c, m.theta, n, k, B);
+  __syncthreads();
+  BNW_T(1);
+  bnw_layers_fwd(c, m.theta, m.locT + m.noff[id], n, k, B);
+  const float *o = k.H + (long long)B * n.hoff[n.heads ? n.n_layers - 1 : n.n_layers];
+  __syncthreads();
+  BNW_T(2);
   return o;
 }
 __device__ __forceinline__ void bnw_inputs(const BnnCtx &c, const BnwNets &m, const BnwWs &w, const float *zs, const float *xrow, int B) {
@@ -259,7 +427,8 @@ __device__ __forceinline__ void bnw_logp(const BnnCtx &c, const BnwNets &m, cons
 }
 
 struct BnwRowsArgs {
-  BnwNets m;
+  BnwNets m;                            // host side only: the kernels read the copy at mp (bnw_store_nets_kernel) -- indexing the nets'
+  const BnwNets *mp;                    // layer tables inside a by-value argument makes the compiler copy the whole struct to scratch
   const float *dw;
   int n_calls;                          // sets per block
   const float *x, *y, *v;
@@ -285,12 +454,12 @@ struct BnwRowsArgs {
   long long prior_stride;
 };
 
-static __global__ __launch_bounds__(BNN_THREADS) void bnw_rows_kernel(BnwRowsArgs a) {
+static __global__ __launch_bounds__(BNN_THREADS) __attribute__((amdgpu_waves_per_eu(BNW_WAVES_PER_EU, BNW_WAVES_PER_EU))) void bnw_rows_kernel(BnwRowsArgs a) {
   __shared__ float red[32];
   __shared__ float ssq[BNW_RT], lpp[BNW_RT], lpc[BNW_RT];
   __shared__ unsigned nacc_s;
   BnnCtx c{(int)threadIdx.x, red};
-  const BnwNets &m = a.m;
+  const BnwNets &m = *a.mp;
   const int q = m.q, p = m.p;
   BnwWs w;
   bnw_take(a.ws + (long long)blockIdx.x * a.ws_stride, m, w);
@@ -388,6 +557,7 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnw_rows_kernel(BnwRowsArg
 // dose loops of evaluate).  Set of (block, dose k) = blk * n_doses + k, stream stream0 + k.
 struct BnwEffArgs {
   BnwNets m;
+  const BnwNets *mp;                    // (as BnwRowsArgs)
   const float *dw;
   const float *z;                       // [n x q]
   long long n, row_base;
@@ -401,11 +571,11 @@ struct BnwEffArgs {
   long long ws_stride;
   const double *stats;                      // batch statistics of the states: [n_blocks][2][2][64], slot 1 (NULL: inference mode)
 };
-static __global__ __launch_bounds__(BNN_THREADS) void bnw_effects_kernel(BnwEffArgs a) {
+static __global__ __launch_bounds__(BNN_THREADS) __attribute__((amdgpu_waves_per_eu(BNW_WAVES_PER_EU, BNW_WAVES_PER_EU))) void bnw_effects_kernel(BnwEffArgs a) {
   __shared__ float red[32];
   __shared__ float y0[BNW_RT];
   BnnCtx c{(int)threadIdx.x, red};
-  const BnwNets &m = a.m;
+  const BnwNets &m = *a.mp;
   const int q = m.q, nf = m.net[BNN_F].dims[0], zf = m.z0 + m.z1;
   BnwWs w;
   bnw_take(a.ws + (long long)blockIdx.x * a.ws_stride, m, w);
