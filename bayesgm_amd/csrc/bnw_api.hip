@@ -60,6 +60,7 @@ int bnw_grow(float **p, size_t *cap, size_t floats, hipStream_t stream) {
   *cap = floats;
   return BGM_OK;
 }
+#define BNW_LDS_BYTES (sizeof(float) * 2 * BNW_STAGE_FLOATS)      // the double-buffered stage of bnw_gemm2
 struct BnwPlan { BnwState *b; int grid; long long ws_stride; };
 int bnw_plan(bgm_handle *h, BnnState *s, const BnwNets &m, long long n_sets_total, int n_items, BnwPlan &pl, hipStream_t stream) {
   if (!s->bnw) s->bnw = new BnwState();
@@ -73,7 +74,11 @@ int bnw_plan(bgm_handle *h, BnnState *s, const BnwNets &m, long long n_sets_tota
   if (rc) return rc;
   rc = bnw_grow(&b->loct, &b->loct_cap, 2 * (size_t)m.set_floats + 128, stream);      // the call's sets and the outcome net's own sets
   if (rc) return rc;
-  if (!b->nets) BGM_HIP_CHECK(hipMalloc((void **)&b->nets, 2 * sizeof(BnwNets)));
+  if (!b->nets) {
+    BGM_HIP_CHECK(hipMalloc((void **)&b->nets, 2 * sizeof(BnwNets)));
+    BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(bnw_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BNW_LDS_BYTES));
+    BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(bnw_effects_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BNW_LDS_BYTES));
+  }
   if (!b->pair) {
     BGM_HIP_CHECK(hipMalloc((void **)&b->pair, 2 * sizeof(float)));
     static const float pair_host[2] = {1.0f, 0.0f};
@@ -163,7 +168,7 @@ int bnw_logpost(bgm_handle *h, BnnState *s, const float *x, const float *y, cons
   a.dw = pl.b->dw; a.n_calls = 1; a.x = x; a.y = y; a.v = v; a.z = const_cast<float *>(z); a.n = n; a.row_base = 0;
   a.bs = bs; a.block0 = block0; a.tiles_per_block = tpb; a.n_items = n_blocks * tpb; a.mode = 0;
   a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32); a.stream0 = stream_id; a.out = out; a.ws = pl.b->ws; a.ws_stride = pl.ws_stride;
-  hipLaunchKernelGGL(bnw_rows_kernel, dim3(pl.grid), dim3(BNN_THREADS), 0, stream, a);
+  hipLaunchKernelGGL(bnw_rows_kernel, dim3(pl.grid), dim3(BNN_THREADS), BNW_LDS_BYTES, stream, a);
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
 }
@@ -180,7 +185,7 @@ int bnw_effects_of(const BnwNets &mf, const BnwPlan &pl, float *dw_eff, const fl
   e.k0 = (uint32_t)seed; e.k1 = (uint32_t)(seed >> 32); e.stream0 = stream0; e.it_noise = it_noise; e.sample_y = sample_y;
   e.sum_out = sum_out; e.sum_stride = sum_stride; e.ite_out = ite_out; e.ite_stride = ite_stride;
   e.ws = pl.b->ws; e.ws_stride = pl.ws_stride;
-  hipLaunchKernelGGL(bnw_effects_kernel, dim3(std::max(1, std::min(e.n_items, pl.grid))), dim3(BNN_THREADS), 0, stream, e);
+  hipLaunchKernelGGL(bnw_effects_kernel, dim3(std::max(1, std::min(e.n_items, pl.grid))), dim3(BNN_THREADS), BNW_LDS_BYTES, stream, e);
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
 }
@@ -238,7 +243,7 @@ int bnw_mh_run(bgm_handle *h, BnnState *s, const bgm_bnn_mh_args *g, hipStream_t
       a.prior = s->bp_rows; a.prior_stride = n * (long long)(q + 2);
     }
     a.acc_blocks = g->acc_blocks_dev ? g->acc_blocks_dev + (long long)i * n_blocks : nullptr;
-    hipLaunchKernelGGL(bnw_rows_kernel, dim3(pl.grid), dim3(BNN_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(bnw_rows_kernel, dim3(pl.grid), dim3(BNN_THREADS), BNW_LDS_BYTES, stream, a);
     const int d = it - g->burn_in;
     if (d >= 0 && d < g->n_keep) {
       if (g->draws_dev)
@@ -260,6 +265,8 @@ int bnw_mh_run(bgm_handle *h, BnnState *s, const bgm_bnn_mh_args *g, hipStream_t
     BGM_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(bnw_prof_acc), zero, sizeof(zero)));
     const double tot = (double)(acc[0] + acc[1] + acc[2]);
     fprintf(stderr, "BNW_PROF net calls: signs %.3f  input normalisation %.3f  layers %.3f  (of %.3e cycles inside calls)\n", acc[0] / tot, acc[1] / tot, acc[2] / tot, tot);
+    fprintf(stderr, "BNW_PROF layer products: first fetch %.3f  chunk loops %.3f  epilogues %.3f of the calls' cycles; %.0f cycles per chunk of 16 K, %.0f per epilogue, %.1f chunks per pass\n",
+            acc[3] / tot, acc[4] / tot, acc[5] / tot, (double)acc[4] / (double)acc[6], (double)acc[5] / (double)acc[7], (double)acc[6] / (double)acc[7]);
   }
 #endif
   return BGM_OK;
@@ -324,7 +331,7 @@ int bnw_evaluate(bgm_handle *h, BnnState *s, const float *x, const float *y, con
       a.vstats = bt.vstats;
     }
     a.mode = 3;
-    hipLaunchKernelGGL(bnw_rows_kernel, dim3(pl.grid), dim3(BNN_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(bnw_rows_kernel, dim3(pl.grid), dim3(BNN_THREADS), BNW_LDS_BYTES, stream, a);
     a.vstats = nullptr;
   }
   if (bt.on && (sums || nd)) {          // statistics of z (slot 1) and of x
@@ -334,7 +341,7 @@ int bnw_evaluate(bgm_handle *h, BnnState *s, const float *x, const float *y, con
   if (sums) {
     BGM_HIP_CHECK(hipMemsetAsync(sums, 0, 3 * sizeof(double), stream));
     a.mode = 2; a.sums = sums;
-    hipLaunchKernelGGL(bnw_rows_kernel, dim3(pl.grid), dim3(BNN_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(bnw_rows_kernel, dim3(pl.grid), dim3(BNN_THREADS), BNW_LDS_BYTES, stream, a);
   }
   if (nd) {
     if (dose_sums) BGM_HIP_CHECK(hipMemsetAsync(dose_sums, 0, sizeof(double) * nd, stream));

@@ -19,9 +19,6 @@
 #include "bnn_kernels.h"
 
 #define BNW_RT 64                       // rows of a workgroup tile
-#ifndef BNW_GEMM_DB
-#define BNW_GEMM_DB 1                   // operands of the next chunk of 16 K requested before the current chunk's matrix instructions
-#endif
 #ifndef BNW_WAVES_PER_EU
 #define BNW_WAVES_PER_EU 2              // 2: one 512-thread workgroup per CU with 256 registers per lane; 4: two with 128
 #endif
@@ -31,7 +28,11 @@ __device__ unsigned long long bnw_prof_acc[8];
 __device__ unsigned long long bnw_prof_last;      // (one value is enough for a relative split: every workgroup overwrites it in the same phase order)
 #define BNW_T0() unsigned long long bnw_t_ = __builtin_amdgcn_s_memtime()
 #define BNW_T(i) do { const unsigned long long t2_ = __builtin_amdgcn_s_memtime(); if (c.tid == 0) atomicAdd(&bnw_prof_acc[i], t2_ - bnw_t_); bnw_t_ = t2_; } while (0)
+#define BNW_TG(i) do { const unsigned long long t2_ = __builtin_amdgcn_s_memtime(); if (tid == 0) atomicAdd(&bnw_prof_acc[i], t2_ - bnw_t_); bnw_t_ = t2_; } while (0)
+#define BNW_TN(i, n) atomicAdd(&bnw_prof_acc[i], (unsigned long long)(n))
 #else
+#define BNW_TG(i) do {} while (0)
+#define BNW_TN(i, n) do {} while (0)
 #define BNW_T0() do {} while (0)
 #define BNW_T(i) do {} while (0)
 #endif
@@ -196,101 +197,159 @@ __device__ __forceinline__ void bnw_ext(const BnnCtx &c, const BnwNets &m, int i
 }
 
 // ---- the layer products of this path ---------------------------------------------------------------------------------------------
-// C1 = A1 W1, C2 = A2 W2 with A [M x K] row-major (the tile's activations and their sign-flipped copy in the workspace) and the weights
-// TRANSPOSED, Wt [N x K] row-major (bnw_pack_kernel: posterior means; bnw_noise_kernel: the call's dW): both operands of a lane are then
-// four consecutive K values = one 16-byte load per operand and chunk of 16 K.  A wave owns a 32 x 32 block of the output = 2 x 2 tiles
-// of v_mfma_f32_16x16x4_f32 for each of the two products (eight independent accumulators); the operands of chunk c + 1 are requested
-// before the 32 matrix instructions of chunk c are issued.  Lane (j = lane & 15, g = lane >> 4) feeds A(m0 + j, k0 + 4 g + u),
+// C1 = A1 W1, C2 = A2 W2 with A [M x K] row-major (the tile's activations and their sign-flipped copy in the workspace, M <= 64) and the
+// weights TRANSPOSED, Wt [N x K] row-major (bnw_pack_kernel: posterior means; bnw_noise_kernel: the call's dW).  The workgroup walks K in
+// chunks of 16 through a double-buffered LDS stage: per chunk the 512 threads fetch the chunk of both A operands (64 rows) and of both
+// weight operands for a pass of 128 output columns -- 24 KiB, three 16-byte loads per thread, requested BEFORE the matrix instructions of
+// the current chunk and written to the other half of the stage after them (one barrier per chunk).  Every element is fetched once per
+// workgroup and pass instead of once per wave (the operands come from L2: the weights of all layers do not fit L1).  A wave owns a
+// 32 x 32 block of the pass = 2 x 2 tiles of v_mfma_f32_16x16x4_f32 for each of the two products (eight independent accumulators) and
+// reads its fragments as ds_read_b128 of four consecutive K: lane (j = lane & 15, g = lane >> 4) feeds A(m0 + j, k0 + 4 g + u),
 // Wt(n0 + j, k0 + 4 g + u) in step u and receives C(m0 + 4 g + r, n0 + j).  Rows / columns beyond M / N are clamped duplicates whose
-// results are not written; K beyond a multiple of 16 (and any K when an operand is not 16-byte aligned) takes masked scalar loads.
-struct BnwOps { f32x4 a1[2], a2[2], b1[2], b2[2]; };
-template <class Epi>
-__device__ __forceinline__ void bnw_gemm2(int tid, const float *A1, const float *A2, int lda, const float *W1, const float *W2, int M, int N,
-                                          int K, Epi epi) {
+// results are not written; K beyond the last chunk is zero in the stage.
+#define BNW_KC 16                                           // K of a chunk
+#define BNW_NP 128                                          // output columns of a pass
+#define BNW_STAGE_ROWS (2 * BNW_RT + 2 * BNW_NP)            // rows of one half of the stage: A1 | A2 | W1 | W2 chunks, BNW_KC floats each
+#define BNW_STAGE_FLOATS (BNW_STAGE_ROWS * BNW_KC)
+#define BNW_FETCH (BNW_STAGE_FLOATS / 4 / BNN_THREADS)      // 16-byte fetches per thread and chunk
+// rowinfo(m, n0) -> what the epilogue needs of output row m for the 32 columns from n0 (the sign words), colinfo(n) -> of column n (the
+// bias): requested before the chunk loop -- a load inside the epilogue would wait behind the epilogue's own stores (one vmcnt counter);
+// epi(m N + n, c1, c2, row info, column info, bit): bit = n - n0.
+// Schedule of a chunk (all eight waves meet at one barrier per chunk, so whatever a wave does outside its matrix instructions has to sit
+// BETWEEN them, or the two waves of a SIMD leave the matrix pipe idle together): the fragments of chunk c are in registers when the
+// iteration starts; step 0 of the four K steps -> the staged chunk c + 1 goes to the other half of the stage, the fetch of chunk c + 2 is
+// requested -> step 1 -> barrier -> the fragments of chunk c + 1 are requested from LDS -> steps 2, 3.
+struct BnwFrag { f32x4 a1[2], a2[2], b1[2], b2[2]; };
+template <class RowInfo, class ColInfo, class Epi>
+__device__ __forceinline__ void bnw_gemm2(int tid, float *stage, const float *A1, const float *A2, int lda, const float *W1, const float *W2,
+                                          int M, int N, int K, RowInfo rowinfo, ColInfo colinfo, Epi epi) {
+  static_assert(BNW_KC == 16, "the chunk schedule below is written for chunks of 16 K");
+  constexpr int Q = BNW_KC / 4, RPS = BNN_THREADS / Q;       // 16-byte pieces of a stage row; stage rows per fetch slot
   const int lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6;
-  const int tn = (N + 31) >> 5, blocks = ((M + 31) >> 5) * tn;
+  const int mw = (wave >> 2) << 5, nw = (wave & 3) << 5;      // the wave's block inside the 64 x 128 pass
   const bool vec = (lda & 3) == 0 && (K & 3) == 0 &&
                    ((((unsigned long long)A1 | (unsigned long long)A2 | (unsigned long long)W1 | (unsigned long long)W2) & 15ull) == 0);
-  const int KC = vec ? (K >> 4) : 0;
-  for (int t = wave; t < blocks; t += BNN_THREADS / 64) {
-    const int m0 = (t / tn) << 5, n0 = (t % tn) << 5;
-    int ra[2], cb[2];      // element offsets of the lane's rows / columns from the (wave-uniform) operand bases
+  const int nc = (K + BNW_KC - 1) / BNW_KC;
+  const int fq = 4 * (tid % Q), fr = tid / Q;                 // fetch slot s of this thread: stage row s * RPS + fr, floats fq .. fq + 3
+  auto fetch = [&](const float *p, int k) -> f32x4 {
+    if (vec && k + 3 < K) return *reinterpret_cast<const f32x4 *>(p + k);
+    f32x4 v;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { ra[i] = min(m0 + 16 * i + j, M - 1) * lda; cb[i] = min(n0 + 16 * i + j, N - 1) * K; }
+    for (int e = 0; e < 4; ++e) v[e] = (k + e < K) ? p[min(k + e, K - 1)] : 0.0f;
+    return v;
+  };
+  const int nc_fast = vec ? K / BNW_KC : 0;                   // chunks fetched as whole 16-byte pieces, no tests (wave-uniform)
+  // fragment offsets of the lane inside a half of the stage
+  int ar[2], br[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { ar[i] = (mw + 16 * i + j) * BNW_KC + 4 * g; br[i] = (2 * BNW_RT + nw + 16 * i + j) * BNW_KC + 4 * g; }
+  auto frags = [&](BnwFrag &f, const float *h) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f.a1[i] = *reinterpret_cast<const f32x4 *>(h + ar[i]); f.a2[i] = *reinterpret_cast<const f32x4 *>(h + BNW_RT * BNW_KC + ar[i]);
+      f.b1[i] = *reinterpret_cast<const f32x4 *>(h + br[i]); f.b2[i] = *reinterpret_cast<const f32x4 *>(h + BNW_NP * BNW_KC + br[i]);
+    }
+  };
+  for (int np = 0; np < N; np += BNW_NP) {
+    const float *fp[BNW_FETCH];
+#pragma unroll
+    for (int sl = 0; sl < BNW_FETCH; ++sl) {
+      const int row = sl * RPS + fr;                           // stage row: A1 [0, 64) | A2 [64, 128) | W1 [128, 256) | W2 [256, 384)
+      if (row < BNW_RT) fp[sl] = A1 + min(row, M - 1) * lda;
+      else if (row < 2 * BNW_RT) fp[sl] = A2 + min(row - BNW_RT, M - 1) * lda;
+      else if (row < 2 * BNW_RT + BNW_NP) fp[sl] = W1 + min(np + row - 2 * BNW_RT, N - 1) * K;
+      else fp[sl] = W2 + min(np + row - 2 * BNW_RT - BNW_NP, N - 1) * K;
+    }
+    float *sp = stage + fr * BNW_KC + fq;
     f32x4 c1[2][2], c2[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int i2 = 0; i2 < 2; ++i2) { c1[i][i2] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; c2[i][i2] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
-    auto load = [&](BnwOps &o, int kc) {
-      const int ko = 16 * kc + 4 * g;
+    const bool live = np + nw < N;                               // (wave-uniform) the wave's columns exist
+    BNW_T0();
+    f32x4 rg[BNW_FETCH];
+#pragma unroll
+    for (int sl = 0; sl < BNW_FETCH; ++sl) rg[sl] = fetch(fp[sl], fq);
+    decltype(rowinfo(0, 0)) info[2][4];
+    decltype(colinfo(0)) cinfo[2];
+    if (live) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        o.a1[i] = *reinterpret_cast<const f32x4 *>(A1 + (ra[i] + ko)); o.a2[i] = *reinterpret_cast<const f32x4 *>(A2 + (ra[i] + ko));
-        o.b1[i] = *reinterpret_cast<const f32x4 *>(W1 + (cb[i] + ko)); o.b2[i] = *reinterpret_cast<const f32x4 *>(W2 + (cb[i] + ko));
+        cinfo[i] = colinfo(min(np + nw + 16 * i + j, N - 1));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) info[i][r] = rowinfo(min(mw + 16 * i + 4 * g + r, M - 1), np + nw);
       }
-    };
-    auto mac = [&](const BnwOps &o) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int i2 = 0; i2 < 2; ++i2) {
-            c1[i][i2] = BGM_MFMA(o.a1[i][u], o.b1[i2][u], c1[i][i2]);
-            c2[i][i2] = BGM_MFMA(o.a2[i][u], o.b2[i2][u], c2[i][i2]);
-          }
-    };
-#if BNW_GEMM_DB
-    if (KC > 0) {
-      BnwOps o0, o1;
-      load(o0, 0);
-      int kc = 0;
-      for (; kc + 2 <= KC; kc += 2) {
-        load(o1, kc + 1);
-        BGM_NO_HOIST();
-        mac(o0);
-        if (kc + 2 < KC) load(o0, kc + 2);
-        BGM_NO_HOIST();
-        mac(o1);
-      }
-      if (kc < KC) mac(o0);
-    }
-#else
-    for (int kc = 0; kc < KC; ++kc) {
-      BnwOps o;
-      load(o, kc);
-      BGM_NO_HOIST();
-      mac(o);
-    }
-#endif
-    for (int k0 = 16 * KC; k0 < K; k0 += 16) {
-      BnwOps o;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int k = k0 + 4 * g + u, kq = min(k, K - 1);
-        const float mk = k < K ? 1.0f : 0.0f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { o.a1[i][u] = A1[ra[i] + kq] * mk; o.a2[i][u] = A2[ra[i] + kq] * mk; o.b1[i][u] = W1[cb[i] + kq]; o.b2[i][u] = W2[cb[i] + kq]; }
-      }
-      BGM_NO_HOIST();
-      mac(o);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int sl = 0; sl < BNW_FETCH; ++sl) *reinterpret_cast<f32x4 *>(sp + sl * RPS * BNW_KC) = rg[sl];
+    if (nc > 1) {
 #pragma unroll
-      for (int i2 = 0; i2 < 2; ++i2)
+      for (int sl = 0; sl < BNW_FETCH; ++sl) rg[sl] = fetch(fp[sl], BNW_KC + fq);
+    }
+    __syncthreads();
+    BnwFrag f0, f1;
+    if (live) frags(f0, stage);
+    BNW_TG(3);
+    auto step = [&](const BnwFrag &f, int u) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = m0 + 16 * i + 4 * g + r, n = n0 + 16 * i2 + j;
-          if (m < M && n < N) epi(m, n, c1[i][i2][r], c2[i][i2][r]);
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+          c1[i][i2] = BGM_MFMA(f.a1[i][u], f.b1[i2][u], c1[i][i2]);
+          c2[i][i2] = BGM_MFMA(f.a2[i][u], f.b2[i2][u], c2[i][i2]);
         }
+    };
+    auto chunk = [&](int c, const BnwFrag &cur, BnwFrag &nxt) {
+      float *other = stage + ((c + 1) & 1) * BNW_STAGE_FLOATS;
+      if (live) step(cur, 0);
+      BGM_NO_HOIST();
+      if (c + 1 < nc) {
+#pragma unroll
+        for (int sl = 0; sl < BNW_FETCH; ++sl) *reinterpret_cast<f32x4 *>(other + (sp - stage) + sl * RPS * BNW_KC) = rg[sl];
+        if (c + 2 < nc_fast) {
+          const int k = (c + 2) * BNW_KC + fq;
+#pragma unroll
+          for (int sl = 0; sl < BNW_FETCH; ++sl) rg[sl] = *reinterpret_cast<const f32x4 *>(fp[sl] + k);
+        } else if (c + 2 < nc) {
+          const int k = (c + 2) * BNW_KC + fq;
+#pragma unroll
+          for (int sl = 0; sl < BNW_FETCH; ++sl) rg[sl] = fetch(fp[sl], k);
+        }
+      }
+      BGM_NO_HOIST();
+      if (live) step(cur, 1);
+      __syncthreads();
+      if (live && c + 1 < nc) frags(nxt, other);
+      BGM_NO_HOIST();
+      if (live) { step(cur, 2); step(cur, 3); }
+    };
+    int c = 0;
+    for (; c + 2 <= nc; c += 2) { chunk(c, f0, f1); chunk(c + 1, f1, f0); }
+    if (c < nc) chunk(c, f0, f1);
+    BNW_TG(4);
+    if (tid == 0) { BNW_TN(6, nc); BNW_TN(7, 1); }
+    // every load of this pass has returned long ago; saying so here keeps hipcc from placing s_waitcnt vmcnt(0) in front of each
+    // element of the epilogue (registers of the loop's fetches are reused there), where it waits for the previous element's STORES
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = mw + 16 * i + 4 * g + r, n = np + nw + 16 * i2 + j;
+            if (m < M && n < N) epi((unsigned)(m * N + n), c1[i][i2][r], c2[i][i2][r], info[i][r], cinfo[i2], 16 * i2 + j);
+          }
+    }
+    BNW_TG(5);
   }
 }
 
 // forward of the Flipout stack as bnn_layers_fwd (bnn_kernels.h), on the transposed weights: locT = the posterior means of the net in the
 // layout of a perturbation set (layer l at eoff[l], [out x in]), k.dW = the call's perturbation in the same layout
-__device__ __forceinline__ void bnw_layers_fwd(const BnnCtx &c, const float *theta, const float *locT, const BnnNet &n, const BnnCache &k, int B) {
+__device__ __forceinline__ void bnw_layers_fwd(const BnnCtx &c, float *stage, const float *theta, const float *locT, const BnnNet &n, const BnnCache &k, int B) {
   const int L = n.n_layers;
   for (int l = 0; l < L; ++l) {
     const int in = n.lin[l], out = n.lout[l];
@@ -301,13 +360,24 @@ __device__ __forceinline__ void bnw_layers_fwd(const BnnCtx &c, const float *the
     const bool feeds_heads = n.heads && l == L - 3;
     float *ys2 = k.HS + (long long)B * n.hsin[L - 1];
     const int so = n.sout_w[l], si = last ? 0 : n.sin_w[l + 1], si2 = n.sin_w[L - 1];
-    bnw_gemm2(c.tid, h, hs, in, locT + n.eoff[l], k.dW + n.eoff[l], B, out, in, [&](int m, int o, float c1, float c2) {
-      float v = c1 + bias[o] + bnn_sign(k.sg, n.swords, m, so, o) * c2;
-      if (!last) v = fmaxf(v, BNN_LEAK * v);
-      y[(long long)m * out + o] = v;
-      if (!last) ys[(long long)m * out + o] = v * bnn_sign(k.sg, n.swords, m, si, o);
-      if (feeds_heads) ys2[(long long)m * out + o] = v * bnn_sign(k.sg, n.swords, m, si2, o);
-    });
+    // the wave's 32 columns start at a multiple of 32: one word of the row's s_out string and one of the next layer's s_in string
+    // (and of the variance head's, with heads) hold the bits of all of them
+    struct Words { uint32_t so, si, si2; };
+    bnw_gemm2(c.tid, stage, h, hs, in, locT + n.eoff[l], k.dW + n.eoff[l], B, out, in,
+              [&](int m, int n0) {
+                const uint32_t *sg = k.sg + (long long)m * n.swords + (n0 >> 5);
+                Words w;
+                w.so = sg[so]; w.si = last ? 0u : sg[si]; w.si2 = feeds_heads ? sg[si2] : 0u;
+                return w;
+              },
+              [&](int o) { return bias[o]; },
+              [&](unsigned at, float c1, float c2, const Words &w, float bo, int bit) {      // at = m * out + o
+                float v = c1 + bo + (((w.so >> bit) & 1u) ? -c2 : c2);
+                if (!last) v = fmaxf(v, BNN_LEAK * v);
+                y[at] = v;
+                if (!last) ys[at] = ((w.si >> bit) & 1u) ? -v : v;
+                if (feeds_heads) ys2[at] = ((w.si2 >> bit) & 1u) ? -v : v;
+              });
     if (!(n.heads && l == L - 2)) __syncthreads();
   }
 }
@@ -336,7 +406,7 @@ inline size_t bnw_ws_floats(const BnwNets &m) {
   for (int k = 0; k < 4; ++k) in_max = std::max(in_max, m.net[k].dims[0]);
   return (size_t)BNW_RT * (2 * (size_t)m.q + m.net[BNN_F].dims[0] + m.net[BNN_H].dims[0] + 8) + 2 * (size_t)in_max + 8 + c + 256;
 }
-struct BnwWs { float *zp, *zc, *fin, *hin, *ext, *cache; };
+struct BnwWs { float *zp, *zc, *fin, *hin, *ext, *cache, *stage; };      // (stage: the LDS stage of bnw_gemm2)
 __device__ __forceinline__ void bnw_take(float *wp, const BnwNets &m, BnwWs &w) {
   auto take = [&](long long cnt) { float *r = wp; wp += (cnt + 3) & ~3LL; return r; };
   w.zp = take((long long)BNW_RT * m.q); w.zc = take((long long)BNW_RT * m.q);
@@ -369,7 +439,7 @@ __device__ __forceinline__ const float *bnw_call(const BnnCtx &c, const BnwNets 
   bnn_bn_fwd(c, m.theta, n, k, B);
   __syncthreads();
   BNW_T(1);
-  bnw_layers_fwd(c, m.theta, m.locT + m.noff[id], n, k, B);
+  bnw_layers_fwd(c, w.stage, m.theta, m.locT + m.noff[id], n, k, B);
   const float *o = k.H + (long long)B * n.hoff[n.heads ? n.n_layers - 1 : n.n_layers];
   __syncthreads();
   BNW_T(2);
@@ -456,6 +526,7 @@ struct BnwRowsArgs {
 
 static __global__ __launch_bounds__(BNN_THREADS) __attribute__((amdgpu_waves_per_eu(BNW_WAVES_PER_EU, BNW_WAVES_PER_EU))) void bnw_rows_kernel(BnwRowsArgs a) {
   __shared__ float red[32];
+  extern __shared__ __attribute__((aligned(16))) float bnw_stage[];      // 2 * BNW_STAGE_FLOATS (dynamic: bnw_api.hip)
   __shared__ float ssq[BNW_RT], lpp[BNW_RT], lpc[BNW_RT];
   __shared__ unsigned nacc_s;
   BnnCtx c{(int)threadIdx.x, red};
@@ -463,6 +534,7 @@ static __global__ __launch_bounds__(BNN_THREADS) __attribute__((amdgpu_waves_per
   const int q = m.q, p = m.p;
   BnwWs w;
   bnw_take(a.ws + (long long)blockIdx.x * a.ws_stride, m, w);
+  w.stage = bnw_stage;
   for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
     const int blk = item / a.tiles_per_block, t = item - blk * a.tiles_per_block;
     const long long blk_lo = (long long)blk * a.bs;
@@ -573,12 +645,14 @@ struct BnwEffArgs {
 };
 static __global__ __launch_bounds__(BNN_THREADS) __attribute__((amdgpu_waves_per_eu(BNW_WAVES_PER_EU, BNW_WAVES_PER_EU))) void bnw_effects_kernel(BnwEffArgs a) {
   __shared__ float red[32];
+  extern __shared__ __attribute__((aligned(16))) float bnw_stage[];      // 2 * BNW_STAGE_FLOATS (dynamic: bnw_api.hip)
   __shared__ float y0[BNW_RT];
   BnnCtx c{(int)threadIdx.x, red};
   const BnwNets &m = *a.mp;
   const int q = m.q, nf = m.net[BNN_F].dims[0], zf = m.z0 + m.z1;
   BnwWs w;
   bnw_take(a.ws + (long long)blockIdx.x * a.ws_stride, m, w);
+  w.stage = bnw_stage;
   for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
     const int blk = item / a.tiles_per_block, t = item - blk * a.tiles_per_block;
     const long long blk_lo = (long long)blk * a.bs;
