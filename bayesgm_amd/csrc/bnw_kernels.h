@@ -212,21 +212,113 @@ __device__ __forceinline__ void bnw_ext(const BnnCtx &c, const BnwNets &m, int i
 #define BNW_STAGE_ROWS (2 * BNW_RT + 2 * BNW_NP)            // rows of one half of the stage: A1 | A2 | W1 | W2 chunks, BNW_KC floats each
 #define BNW_STAGE_FLOATS (BNW_STAGE_ROWS * BNW_KC)
 #define BNW_FETCH (BNW_STAGE_FLOATS / 4 / BNN_THREADS)      // 16-byte fetches per thread and chunk
+// N <= 32 (the two-column heads of the outcome / treatment nets): a pass of 128 columns would leave six of the eight waves without a
+// column.  Here the waves split K instead: wave (mb = wave >> 2, kg = wave & 3) takes the chunks kg, kg + 4, ... of the 32-row block mb
+// straight from global memory (no stage, no barrier inside the loop); comb(c1, c2, row info, bit) = the two products joined (linear, so
+// it may be applied to a wave's partial sums), the four partial results of a block meet in the stage and wave kg = 0 runs the epilogue
+// with (sum, 0).
+template <class RowInfo, class ColInfo, class Comb, class Epi>
+__device__ __forceinline__ void bnw_gemm2_narrow(int tid, float *stage, const float *A1, const float *A2, int lda, const float *W1, const float *W2,
+                                                 int M, int N, int K, RowInfo rowinfo, ColInfo colinfo, Comb comb, Epi epi) {
+  const int lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6, mb = wave >> 2, kg = wave & 3;
+  const bool vec = (lda & 3) == 0 && (K & 3) == 0 &&
+                   ((((unsigned long long)A1 | (unsigned long long)A2 | (unsigned long long)W1 | (unsigned long long)W2) & 15ull) == 0);
+  const int nc = (K + 15) >> 4, nt = (N + 15) >> 4;             // chunks of 16 K; column tiles (1 or 2)
+  auto fetch = [&](const float *p, int k) -> f32x4 {
+    if (vec && k + 3 < K) return *reinterpret_cast<const f32x4 *>(p + k);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (k + e < K) ? p[min(k + e, K - 1)] : 0.0f;
+    return v;
+  };
+  int ra[2], cb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { ra[i] = min(32 * mb + 16 * i + j, M - 1) * lda; cb[i] = min(16 * i + j, N - 1) * K; }
+  decltype(rowinfo(0, 0)) info[2][4];
+  decltype(colinfo(0)) cinfo[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    cinfo[i] = colinfo(min(16 * i + j, N - 1));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) info[i][r] = rowinfo(min(32 * mb + 16 * i + 4 * g + r, M - 1), 0);
+  }
+  f32x4 c1[2][2], c2[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2) { c1[i][i2] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; c2[i][i2] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+  for (int c = kg; c < nc; c += 4) {
+    const int k = 16 * c + 4 * g;
+    f32x4 a1[2], a2[2], b1[2], b2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { a1[i] = fetch(A1 + ra[i], k); a2[i] = fetch(A2 + ra[i], k); }
+    b1[0] = fetch(W1 + cb[0], k); b2[0] = fetch(W2 + cb[0], k);
+    if (nt > 1) { b1[1] = fetch(W1 + cb[1], k); b2[1] = fetch(W2 + cb[1], k); }
+    BGM_NO_HOIST();
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        c1[i][0] = BGM_MFMA(a1[i][u], b1[0][u], c1[i][0]);
+        c2[i][0] = BGM_MFMA(a2[i][u], b2[0][u], c2[i][0]);
+        if (nt > 1) { c1[i][1] = BGM_MFMA(a1[i][u], b1[1][u], c1[i][1]); c2[i][1] = BGM_MFMA(a2[i][u], b2[1][u], c2[i][1]); }
+      }
+  }
+  // partial results: stage [wave][i][i2][lane] as float4
+  f32x4 *part = reinterpret_cast<f32x4 *>(stage);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2) {
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = comb(c1[i][i2][r], c2[i][i2][r], info[i][r], 16 * i2 + j);
+      if (i2 < nt) part[((wave * 2 + i) * 2 + i2) * 64 + lane] = v;
+    }
+  __syncthreads();
+  if (kg == 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2) {
+        if (i2 >= nt) continue;
+        f32x4 v = part[((wave * 2 + i) * 2 + i2) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+          const f32x4 t = part[(((wave + w) * 2 + i) * 2 + i2) * 64 + lane];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += t[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = 32 * mb + 16 * i + 4 * g + r, n = 16 * i2 + j;
+          if (m < M && n < N) epi((unsigned)(m * N + n), v[r], 0.0f, info[i][r], cinfo[i2], 16 * i2 + j);
+        }
+      }
+  }
+  __syncthreads();      // the stage is free again
+}
+
 // rowinfo(m, n0) -> what the epilogue needs of output row m for the 32 columns from n0 (the sign words), colinfo(n) -> of column n (the
 // bias): requested before the chunk loop -- a load inside the epilogue would wait behind the epilogue's own stores (one vmcnt counter);
-// epi(m N + n, c1, c2, row info, column info, bit): bit = n - n0.
+// epi(m N + n, c1, c2, row info, column info, bit): bit = n - n0; comb: see bnw_gemm2_narrow.
 // Schedule of a chunk (all eight waves meet at one barrier per chunk, so whatever a wave does outside its matrix instructions has to sit
 // BETWEEN them, or the two waves of a SIMD leave the matrix pipe idle together): the fragments of chunk c are in registers when the
 // iteration starts; step 0 of the four K steps -> the staged chunk c + 1 goes to the other half of the stage, the fetch of chunk c + 2 is
 // requested -> step 1 -> barrier -> the fragments of chunk c + 1 are requested from LDS -> steps 2, 3.
 struct BnwFrag { f32x4 a1[2], a2[2], b1[2], b2[2]; };
-template <class RowInfo, class ColInfo, class Epi>
+template <class RowInfo, class ColInfo, class Comb, class Epi>
 __device__ __forceinline__ void bnw_gemm2(int tid, float *stage, const float *A1, const float *A2, int lda, const float *W1, const float *W2,
-                                          int M, int N, int K, RowInfo rowinfo, ColInfo colinfo, Epi epi) {
+                                          int M, int N, int K, RowInfo rowinfo, ColInfo colinfo, Comb comb, Epi epi) {
+  if (N <= 32) { bnw_gemm2_narrow(tid, stage, A1, A2, lda, W1, W2, M, N, K, rowinfo, colinfo, comb, epi); return; }
   static_assert(BNW_KC == 16, "the chunk schedule below is written for chunks of 16 K");
   constexpr int Q = BNW_KC / 4, RPS = BNN_THREADS / Q;       // 16-byte pieces of a stage row; stage rows per fetch slot
   const int lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6;
   const int mw = (wave >> 2) << 5, nw = (wave & 3) << 5;      // the wave's block inside the 64 x 128 pass
+#ifndef BNW_SKEW
+#define BNW_SKEW 1
+#endif
+  const bool late = BNW_SKEW ? (wave & BNW_SKEW) != 0 : false;
   const bool vec = (lda & 3) == 0 && (K & 3) == 0 &&
                    ((((unsigned long long)A1 | (unsigned long long)A2 | (unsigned long long)W1 | (unsigned long long)W2) & 15ull) == 0);
   const int nc = (K + BNW_KC - 1) / BNW_KC;
@@ -302,8 +394,7 @@ __device__ __forceinline__ void bnw_gemm2(int tid, float *stage, const float *A1
     };
     auto chunk = [&](int c, const BnwFrag &cur, BnwFrag &nxt) {
       float *other = stage + ((c + 1) & 1) * BNW_STAGE_FLOATS;
-      if (live) step(cur, 0);
-      BGM_NO_HOIST();
+      auto put = [&]() {
       if (c + 1 < nc) {
 #pragma unroll
         for (int sl = 0; sl < BNW_FETCH; ++sl) *reinterpret_cast<f32x4 *>(other + (sp - stage) + sl * RPS * BNW_KC) = rg[sl];
@@ -317,12 +408,24 @@ __device__ __forceinline__ void bnw_gemm2(int tid, float *stage, const float *A1
           for (int sl = 0; sl < BNW_FETCH; ++sl) rg[sl] = fetch(fp[sl], k);
         }
       }
+      };
+      // the two waves of a SIMD (w, w + 4) place their stage writes / fragment reads at different K steps, so that one of them has
+      // matrix instructions to issue while the other one is in its memory instructions
+      if (late) put();
+      BGM_NO_HOIST();
+      if (live) step(cur, 0);
+      BGM_NO_HOIST();
+      if (!late) put();
       BGM_NO_HOIST();
       if (live) step(cur, 1);
       __syncthreads();
-      if (live && c + 1 < nc) frags(nxt, other);
+      if (!late && live && c + 1 < nc) frags(nxt, other);
       BGM_NO_HOIST();
-      if (live) { step(cur, 2); step(cur, 3); }
+      if (live) step(cur, 2);
+      BGM_NO_HOIST();
+      if (late && live && c + 1 < nc) frags(nxt, other);
+      BGM_NO_HOIST();
+      if (live) step(cur, 3);
     };
     int c = 0;
     for (; c + 2 <= nc; c += 2) { chunk(c, f0, f1); chunk(c + 1, f1, f0); }
@@ -371,6 +474,7 @@ __device__ __forceinline__ void bnw_layers_fwd(const BnnCtx &c, float *stage, co
                 return w;
               },
               [&](int o) { return bias[o]; },
+              [&](float c1, float c2, const Words &w, int bit) { return c1 + (((w.so >> bit) & 1u) ? -c2 : c2); },
               [&](unsigned at, float c1, float c2, const Words &w, float bo, int bit) {      // at = m * out + o
                 float v = c1 + bo + (((w.so >> bit) & 1u) ? -c2 : c2);
                 if (!last) v = fmaxf(v, BNN_LEAK * v);
