@@ -124,6 +124,7 @@ void bgm_bnn_free_state(bgm_handle *h) {
   if (!h->bnn_state) return;
   BnnState *s = bst(h);
   if (s->dev) hipFree(s->dev);
+  if (s->kl_part_dev) hipFree(s->kl_part_dev);
   if (s->tlast_dev) hipFree(s->tlast_dev);
   bnn_free_sampler(s);
   bgm_bnn_egm_free(s->egm);
@@ -205,6 +206,8 @@ extern "C" int bgm_bnn_begin(bgm_handle *h, const bgm_bnn_config *cfg, const flo
   s->dz_dev = s->out_dev + 64;
   s->dz_part_dev = s->dz_dev + (size_t)B * s->q + 64;      // [3][B x q] + 3 loss partials
   BGM_HIP_CHECK(hipMemcpy(s->theta_dev, theta_host, sizeof(float) * count, hipMemcpyHostToDevice));
+  BGM_HIP_CHECK(hipMalloc((void **)&s->kl_part_dev, sizeof(float) * 3 * BNN_KL_PARTS));
+  BGM_HIP_CHECK(hipMemset(s->kl_part_dev, 0, sizeof(float) * 3 * BNN_KL_PARTS));
   s->t_theta = 0; s->t_z = 0;
   return bnn_chain_setup(s);
 }
@@ -314,8 +317,36 @@ static void bnn_theta_launch(BnnState *s, BnnArgs &a, int batch, int parts, hipS
     hipLaunchKernelGGL(kd, dim3((fc->n_tiles + ECH_WAVES - 1) / ECH_WAVES + 1), dim3(BNN_THREADS), 0, st, a, fc->tab_theta, fc->tiles_theta, fc->ws, fc->sync_dw,
                        fc->riders_on ? fc->ahead : EcbAhead{});
     }
-  } else if (parts & 2) {          // (the phase machine is one launch: it runs at the point of the parameter write)
+  } else if (parts & 2) {          // (the phase machine runs at the point of the parameter write)
+    // general widths: one workgroup per net walks the layer products; the elementwise parts (the call's eps / dW, the KL terms, the Adam
+    // step: half of the step's time at [256] x 3 when the one workgroup did them too) run as their own launches over the chip
+    static const bool one_launch = std::getenv("BGM_BNN_STEP_ONE_LAUNCH") != nullptr;
+    a.wide = (!one_launch && s->kl_part_dev) ? 1 : 0;
+    a.kl_part = s->kl_part_dev;
+    if (a.wide) hipLaunchKernelGGL(bnn_step_noise_kernel, dim3(BNN_NOISE_PARTS, 3, 1), dim3(BNN_THREADS), 0, st, a, 4);
     hipLaunchKernelGGL(bnn_theta_step_kernel, dim3(3), dim3(BNN_THREADS), 0, st, a);
+    if (a.wide) {
+      hipLaunchKernelGGL(bnn_kl_kernel, dim3(BNN_KL_PARTS, 3), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(bnn_kl_finish_kernel, dim3(1), dim3(64), 0, st, a);
+      if (a.apply)
+        for (int k : {BNN_G, BNN_H, BNN_F}) {
+          const BnnNet &n = s->net[k];
+          hipLaunchKernelGGL(bnn_adam_kernel, dim3((n.n_params + 255) / 256), dim3(256), 0, st, s->theta_dev + n.off, s->m_dev + n.off, s->v_dev + n.off,
+                             s->grad_dev + n.off, n.n_params, a.adam);
+        }
+    }
+#ifdef BNN_PROF
+    static int calls = 0;
+    if (++calls % 100 == 0) {
+      unsigned long long acc[8], zero[8] = {0};
+      hipStreamSynchronize(st);
+      hipMemcpyFromSymbol(acc, HIP_SYMBOL(bnn_prof_acc), sizeof(acc));
+      hipMemcpyToSymbol(HIP_SYMBOL(bnn_prof_acc), zero, sizeof(zero));
+      double tot = 0; for (int i = 0; i < 7; ++i) tot += (double)acc[i];
+      fprintf(stderr, "BNN_PROF theta step of g (100 calls, %.0f cycles each): gather %.3f noise %.3f forward %.3f loss %.3f backward %.3f KL %.3f Adam %.3f\n",
+              tot / 100, acc[0] / tot, acc[1] / tot, acc[2] / tot, acc[3] / tot, acc[4] / tot, acc[5] / tot, acc[6] / tot);
+    }
+#endif
   }
 }
 
@@ -413,6 +444,9 @@ extern "C" int bgm_bnn_z_step(bgm_handle *h, const float *x, const float *y, con
     } else
       hipLaunchKernelGGL(kc, dim3(1), dim3(BNN_THREADS), lds_z, stream, a, fc->tab_z, fc->ws_z, zsy, EcbZRows{});
   } else {
+    static const bool one_launch = std::getenv("BGM_BNN_STEP_ONE_LAUNCH") != nullptr;
+    a.wide = one_launch ? 0 : 1;      // the two calls' eps / dW over the chip (bnn_step_noise_kernel), the sign words in the step kernel
+    if (a.wide) hipLaunchKernelGGL(bnn_step_noise_kernel, dim3(BNN_NOISE_PARTS, 3, 2), dim3(BNN_THREADS), 0, stream, a, 6);
     hipLaunchKernelGGL(bnn_z_grad_kernel, dim3(3), dim3(BNN_THREADS), 0, stream, a);
     hipLaunchKernelGGL(bnn_z_combine_kernel, dim3((batch * s->q + 255) / 256), dim3(256), 0, stream, a.dz_part, a.loss_part, a.dz, out, batch * s->q);
   }

@@ -498,14 +498,24 @@ struct BnnArgs {
   float *out;                            // theta: [loss_v, mse_v, loss_x, aux_x, loss_y, mse_y];  z: [loss_posterior]
   float *dz;                             // z step: [B x q] gradient w.r.t. the batch rows of data_z
   float sig2[3];                         // fixed sigma_v^2, sigma_x^2, sigma_y^2 (params['sigma_*']); <= 0: the net's variance head
+  // general (any-width) steps spread over the chip (bnn_api.hip): 1 = eps / dW of the calls were written by bnn_step_noise_kernel (the
+  // step kernels draw the sign words only), the KL terms and the Adam step follow in their own launches (bnn_kl_kernel, bnn_adam_kernel)
+  int wide;
+  float *kl_part;                        // [3][BNN_KL_PARTS] partial sums of the nets' KL terms
 };
+#define BNN_KL_PARTS 32
+#define BNN_NOISE_PARTS 16
 
 // gather the minibatch: zb [B x q], vb [B x p], xb, yb [B], f input [B x nf], h input [B x nh]
 struct BnnBatch { float *zb, *vb, *xb, *yb, *fin, *hin; };
-__device__ __forceinline__ void bnn_gather(const BnnCtx &c, const BnnArgs &a, float *&wp, BnnBatch &bt) {
+__device__ __forceinline__ void bnn_gather_ptrs(const BnnArgs &a, float *&wp, BnnBatch &bt) {
   auto take = [&](int n) { float *r = wp; wp += (n + 3) & ~3; return r; };
   const int B = a.B, q = a.q, p = a.p, nf = a.net[BNN_F].dims[0], nh = a.net[BNN_H].dims[0];
   bt.zb = take(B * q); bt.vb = take(B * p); bt.xb = take(B); bt.yb = take(B); bt.fin = take(B * nf); bt.hin = take(B * nh);
+}
+__device__ __forceinline__ void bnn_gather(const BnnCtx &c, const BnnArgs &a, float *&wp, BnnBatch &bt) {
+  const int B = a.B, q = a.q, p = a.p, nf = a.net[BNN_F].dims[0], nh = a.net[BNN_H].dims[0];
+  bnn_gather_ptrs(a, wp, bt);
   for (int k = c.tid; k < B * p; k += BNN_THREADS) { const int b = k / p; bt.vb[k] = a.v_[(long long)a.idx[b] * p + (k - b * p)]; }
   for (int k = c.tid; k < B * q; k += BNN_THREADS) { const int b = k / q; bt.zb[k] = a.data_z[(long long)a.idx[b] * q + (k - b * q)]; }
   for (int b = c.tid; b < B; b += BNN_THREADS) { bt.xb[b] = a.x_[a.idx[b]]; bt.yb[b] = a.y_[a.idx[b]]; }
@@ -548,6 +558,12 @@ __device__ __forceinline__ float bnn_gauss(float ssq, float raw, float dim, floa
 
 // update_g_net, update_h_net, update_f_net (causalbgm/base.py:156-243) with use_bnn: the three updates are independent
 // given the batch (each reads the latents of BEFORE the step), so one launch does all three, one workgroup per net.
+#ifdef BNN_PROF      // development: shader-clock cycles of wave 0 of g's workgroup per phase of the general theta step (bnn_api.hip prints them)
+__device__ unsigned long long bnn_prof_acc[8];
+#define BNN_T(i) do { const unsigned long long t2_ = __builtin_amdgcn_s_memtime(); if (c.tid == 0 && blockIdx.x == 0) atomicAdd(&bnn_prof_acc[i], t2_ - bnn_t_); bnn_t_ = t2_; } while (0)
+#else
+#define BNN_T(i) do {} while (0)
+#endif
 static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_step_kernel(BnnArgs a) {
   __shared__ float red[32];
   __shared__ float ssq_row[BNN_MAX_BATCH];
@@ -556,7 +572,11 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_step_kernel(BnnA
   float *wp = a.ws + (long long)blockIdx.x * a.ws_stride;
   auto take = [&](int n) { float *r = wp; wp += (n + 3) & ~3; return r; };
   BnnBatch bt;
+#ifdef BNN_PROF
+  unsigned long long bnn_t_ = __builtin_amdgcn_s_memtime();
+#endif
   bnn_gather(c, a, wp, bt);
+  BNN_T(0);
   float *d = take(B * a.wmax), *ds = take(B * a.wmax), *t0 = take(B * a.wmax), *t1 = take(B * a.wmax);
   float *cache_base = wp;
   {   // grid = 3 workgroups: g, h, f are independent given the batch
@@ -566,7 +586,14 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_step_kernel(BnnA
     wp = cache_base;
     BnnCache k;
     bnn_cache(n, B, wp, k, id == BNN_G ? bt.zb : (id == BNN_H ? bt.hin : bt.fin));
-    const float *o = bnn_fwd(c, a.theta, n, k, B, a.k0, a.k1, a.stream);
+    bnn_noise(c, a.theta, n, k, B, a.k0, a.k1, a.stream, 0u, a.wide != 0);      // (the steps of bnn_fwd)
+    __syncthreads();
+    BNN_T(1);
+    bnn_bn_fwd(c, a.theta, n, k, B);
+    __syncthreads();
+    bnn_layers_fwd(c, a.theta, n, k, B);
+    const float *o = k.H + (long long)B * n.hoff[n.heads ? n.n_layers - 1 : n.n_layers];
+    BNN_T(2);
     const int wo = n.dims[n.n_layers];
     float loss = 0.0f, aux = 0.0f;
     if (id == BNN_G) {
@@ -606,10 +633,14 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_step_kernel(BnnA
       aux = bnn_block_sum(c, aux) * a.inv_B;
     }
     __syncthreads();
+    BNN_T(3);
     bnn_bwd(c, a.theta, a.grad, n, k, d, ds, t0, t1, nullptr, B, true, false);
-    const float klv = bnn_kl(c, a.theta, a.grad, n, a.kl_weight);
+    BNN_T(4);
+    const float klv = a.wide ? 0.0f : bnn_kl(c, a.theta, a.grad, n, a.kl_weight);      // (wide: bnn_kl_kernel / bnn_kl_finish_kernel)
     __syncthreads();
-    if (a.apply) bnn_adam(c, a.theta + n.off, a.m + n.off, a.v + n.off, a.grad + n.off, n.n_params, a.adam);
+    BNN_T(5);
+    if (a.apply && !a.wide) bnn_adam(c, a.theta + n.off, a.m + n.off, a.v + n.off, a.grad + n.off, n.n_params, a.adam);
+    BNN_T(6);
     if (c.tid == 0 && a.out) { a.out[2 * which] = loss + a.kl_weight * klv; a.out[2 * which + 1] = aux; }
     __syncthreads();
   }
@@ -648,9 +679,9 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_z_grad_kernel(BnnArgs 
     const bool two = !(id == BNN_H && a.binary);
     BnnCache k1, k2;
     bnn_cache(n, B, wp, k1, input);
-    const float *o1 = bnn_fwd(c, a.theta, n, k1, B, a.k0, a.k1, a.stream);
+    const float *o1 = bnn_fwd(c, a.theta, n, k1, B, a.k0, a.k1, a.stream, 0u, a.wide != 0);
     const float *o2 = o1;
-    if (two) { bnn_cache(n, B, wp, k2, input); o2 = bnn_fwd(c, a.theta, n, k2, B, a.k0, a.k1, a.stream + 1u); }
+    if (two) { bnn_cache(n, B, wp, k2, input); o2 = bnn_fwd(c, a.theta, n, k2, B, a.k0, a.k1, a.stream + 1u, 0u, a.wide != 0); }
     float loss = 0.0f;
     // upstream gradients: d for call 1 (mean), t-buffers reused for call 2 (variance head) after the first backward
     if (id == BNN_G) {
@@ -711,6 +742,78 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_z_grad_kernel(BnnArgs 
 }
 
 // dz = sum of the three per-net partials; loss_postrior_z likewise
+// ---- the elementwise parts of the general steps, spread over the chip (one workgroup per net walks everything else) ----------------
+// eps and dW = sigma * eps of the calls of a step, written where the step kernel's call caches will look for them: the same pointer
+// arithmetic as bnn_theta_step_kernel (scratch = 4 row buffers, one call per net) / bnn_z_grad_kernel (6, two calls unless the
+// treatment is binary).  grid (BNN_NOISE_PARTS, 3 nets, calls); same draws as bnn_noise.
+static __global__ __launch_bounds__(BNN_THREADS) void bnn_step_noise_kernel(BnnArgs a, int n_scratch) {
+  const int which = blockIdx.y, call = blockIdx.z;
+  const int id = which == 0 ? BNN_G : (which == 1 ? BNN_H : BNN_F);
+  if (call == 1 && id == BNN_H && a.binary) return;
+  const BnnNet &n = a.net[id];
+  float *wp = a.ws + (long long)which * a.ws_stride;
+  BnnBatch bt;
+  bnn_gather_ptrs(a, wp, bt);
+  wp += (long long)n_scratch * ((a.B * a.wmax + 3) & ~3);
+  BnnCache k;
+  bnn_cache(n, a.B, wp, k, nullptr);
+  if (call == 1) bnn_cache(n, a.B, wp, k, nullptr);
+  const uint32_t stream = a.stream + (uint32_t)call;
+  for (int l = 0; l < n.n_layers; ++l) {
+    const int cnt = n.lin[l] * n.lout[l];
+    const float *rho = a.theta + n.woff[l] + cnt;
+    float *e = k.eps + n.eoff[l], *d = k.dW + n.eoff[l];
+    for (int i = blockIdx.x * BNN_THREADS + threadIdx.x; i < (cnt + 3) >> 2; i += gridDim.x * BNN_THREADS) {
+      const f32x4 z = box_muller4(philox4x32_10((uint32_t)i, (uint32_t)l | ((uint32_t)n.net_id << 16), stream, BNN_TAG_EPS, a.k0, a.k1));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = 4 * i + u;
+        if (idx < cnt) { e[idx] = z[u]; d[idx] = (BNN_SCALE_EPS + softplus_acc(rho[idx])) * z[u]; }
+      }
+    }
+  }
+}
+// grad += w * dKL/dtheta as bnn_kl, a slice of every layer per workgroup; the slice's share of sum(net.losses) -> kl_part.
+// grid (BNN_KL_PARTS, 3 nets)
+static __global__ __launch_bounds__(256) void bnn_kl_kernel(BnnArgs a) {
+  __shared__ float red[4];
+  const int which = blockIdx.y, id = which == 0 ? BNN_G : (which == 1 ? BNN_H : BNN_F);
+  const BnnNet &n = a.net[id];
+  const float iv = n.prior_iv, ls = n.prior_logs, w = a.kl_weight;
+  float acc = 0.0f;
+  for (int l = 0; l < n.n_layers; ++l) {
+    const int cnt = n.lin[l] * n.lout[l];
+    const float *loc = a.theta + n.woff[l], *rho = loc + cnt;
+    float *gloc = a.grad + n.woff[l], *grho = gloc + cnt;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < cnt; i += gridDim.x * 256) {
+      const float sg = BNN_SCALE_EPS + softplus_acc(rho[i]), mu = loc[i];
+      acc += -logf(sg) + 0.5f * (sg * sg + mu * mu) * iv - 0.5f + ls;
+      gloc[i] += w * mu * iv;
+      grho[i] += w * (-1.0f / sg + sg * iv) * sigmoid_f(rho[i]);
+    }
+    if (n.bias_prior) {
+      const float *b = rho + cnt;
+      float *gb = grho + cnt;
+      for (int i = blockIdx.x * 256 + threadIdx.x; i < n.lout[l]; i += gridDim.x * 256) {
+        acc += 0.5f * b[i] * b[i] * iv + ls + 0.9189385332046727f;
+        gb[i] += w * b[i] * iv;
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) a.kl_part[which * BNN_KL_PARTS + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// out[2 net] += kl_weight * KL(net): the partial sums in a fixed order
+static __global__ void bnn_kl_finish_kernel(BnnArgs a) {
+  const int which = threadIdx.x;
+  if (which >= 3 || !a.out) return;
+  float t = 0.0f;
+  for (int i = 0; i < BNN_KL_PARTS; ++i) t += a.kl_part[which * BNN_KL_PARTS + i];
+  a.out[2 * which] += a.kl_weight * t;
+}
+
 static __global__ void bnn_z_combine_kernel(const float *dz_part, const float *loss_part, float *dz, float *out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dz[i] = dz_part[i] + dz_part[n + i] + dz_part[2 * n + i];
