@@ -195,7 +195,7 @@ extern "C" int bgm_bnn_begin(bgm_handle *h, const bgm_bnn_config *cfg, const flo
   s->wmax = wmax;
   const long long gather = (long long)B * (s->q + s->p + 2 + s->net[BNN_F].dims[0] + s->net[BNN_H].dims[0]) + 64;
   s->ws_stride = (gather + 6LL * B * wmax + 64 + 2 * cache_max + 63) & ~63LL;      // one slice per workgroup (net)
-  s->ws_floats = (size_t)(3 * s->ws_stride);
+  s->ws_floats = (size_t)(6 * s->ws_stride);      // three for the theta step's nets, three for the latent step's (the two overlap in bgm_bnn_fit_epoch)
   const size_t np = ((size_t)s->n_params + 63) & ~(size_t)63;
   const size_t total = 4 * np + s->ws_floats + 64 + 4 * ((size_t)B * s->q + 64);
   BGM_HIP_CHECK(hipMalloc((void **)&s->dev, sizeof(float) * total));
@@ -317,17 +317,25 @@ static void bnn_theta_launch(BnnState *s, BnnArgs &a, int batch, int parts, hipS
     hipLaunchKernelGGL(kd, dim3((fc->n_tiles + ECH_WAVES - 1) / ECH_WAVES + 1), dim3(BNN_THREADS), 0, st, a, fc->tab_theta, fc->tiles_theta, fc->ws, fc->sync_dw,
                        fc->riders_on ? fc->ahead : EcbAhead{});
     }
-  } else if (parts & 2) {          // (the phase machine runs at the point of the parameter write)
+  } else {
     // general widths: one workgroup per net walks the layer products; the elementwise parts (the call's eps / dW, the KL terms, the Adam
-    // step: half of the step's time at [256] x 3 when the one workgroup did them too) run as their own launches over the chip
+    // step: half of the step's time at [256] x 3 when the one workgroup did them too) run as their own launches over the chip.
+    // parts & 1 reads the parameters (noise, step kernel, KL terms -> gradient), parts & 2 writes them (Adam).
+    // BGM_BNN_STEP_ONE_LAUNCH: the one-launch phase machine, at the point of the parameter write.
     static const bool one_launch = std::getenv("BGM_BNN_STEP_ONE_LAUNCH") != nullptr;
     a.wide = (!one_launch && s->kl_part_dev) ? 1 : 0;
     a.kl_part = s->kl_part_dev;
-    if (a.wide) hipLaunchKernelGGL(bnn_step_noise_kernel, dim3(BNN_NOISE_PARTS, 3, 1), dim3(BNN_THREADS), 0, st, a, 4);
-    hipLaunchKernelGGL(bnn_theta_step_kernel, dim3(3), dim3(BNN_THREADS), 0, st, a);
-    if (a.wide) {
+    if (!a.wide) {
+      if (parts & 2) hipLaunchKernelGGL(bnn_theta_step_kernel, dim3(3), dim3(BNN_THREADS), 0, st, a);
+      return;
+    }
+    if (parts & 1) {
+      hipLaunchKernelGGL(bnn_step_noise_kernel, dim3(BNN_NOISE_PARTS, 3, 1), dim3(BNN_THREADS), 0, st, a, 4);
+      hipLaunchKernelGGL(bnn_theta_step_kernel, dim3(3), dim3(BNN_THREADS), 0, st, a);
       hipLaunchKernelGGL(bnn_kl_kernel, dim3(BNN_KL_PARTS, 3), dim3(256), 0, st, a);
       hipLaunchKernelGGL(bnn_kl_finish_kernel, dim3(1), dim3(64), 0, st, a);
+    }
+    if (parts & 2) {
       if (a.apply)
         for (int k : {BNN_G, BNN_H, BNN_F}) {
           const BnnNet &n = s->net[k];
@@ -446,6 +454,7 @@ extern "C" int bgm_bnn_z_step(bgm_handle *h, const float *x, const float *y, con
   } else {
     static const bool one_launch = std::getenv("BGM_BNN_STEP_ONE_LAUNCH") != nullptr;
     a.wide = one_launch ? 0 : 1;      // the two calls' eps / dW over the chip (bnn_step_noise_kernel), the sign words in the step kernel
+    a.ws = s->ws_dev + 3 * s->ws_stride;      // (its own slices: the theta step of the next minibatch may be running beside it)
     if (a.wide) hipLaunchKernelGGL(bnn_step_noise_kernel, dim3(BNN_NOISE_PARTS, 3, 2), dim3(BNN_THREADS), 0, stream, a, 6);
     hipLaunchKernelGGL(bnn_z_grad_kernel, dim3(3), dim3(BNN_THREADS), 0, stream, a);
     hipLaunchKernelGGL(bnn_z_combine_kernel, dim3((batch * s->q + 255) / 256), dim3(256), 0, stream, a.dz_part, a.loss_part, a.dz, out, batch * s->q);
@@ -553,7 +562,11 @@ extern "C" int bgm_bnn_fit_epoch(bgm_handle *h, const float *x, const float *y, 
   BGM_HIP_CHECK(hipSetDevice(h->device));
   BnnFitChain *fc = static_cast<BnnFitChain *>(s->chain);
   static const bool no_overlap = std::getenv("BGM_FIT_NO_OVERLAP") != nullptr;
-  const bool overlap = !no_overlap && lazy != 0 && fc && (batch == 32 || (batch == 16 && !fc->pad));
+  const bool chains = fc && (batch == 32 || (batch == 16 && !fc->pad));
+  // (the general-width step kernels overlap as well -- latent step k beside the reading part of theta step k + 1, own workspace slices --
+  // ordered by HIP events; the device-side counters belong to the row-tile chains)
+  static const bool one_launch = std::getenv("BGM_BNN_STEP_ONE_LAUNCH") != nullptr;
+  const bool overlap = !no_overlap && lazy != 0 && (chains || (!one_launch && s->kl_part_dev));
   if (overlap && !h->epoch_stream) {
     BGM_HIP_CHECK(hipStreamCreateWithFlags(&h->epoch_stream, hipStreamNonBlocking));
     for (int k = 0; k < 4; ++k) {
@@ -568,7 +581,7 @@ extern "C" int bgm_bnn_fit_epoch(bgm_handle *h, const float *x, const float *y, 
   // latent steps runs two minibatches ahead on the second stream (in front of the latent phase k - 2, whose completion the
   // gradient-tile kernel k - 1 waits for), and the latent step itself stamps the rows (no mark launch).  BGM_FIT_NO_FLAGS: events.
   static const bool no_flags = std::getenv("BGM_FIT_NO_FLAGS") != nullptr;
-  bool flags = overlap && !no_flags;
+  bool flags = overlap && !no_flags && chains;
   if (flags) {
     if (!h->epoch_ctr) {
       BGM_HIP_CHECK(hipMalloc((void **)&h->epoch_ctr, sizeof(unsigned) * 8));

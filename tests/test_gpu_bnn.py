@@ -567,11 +567,15 @@ def test_full_size_panel_blocks_are_independent_sampler_runs():
     eng.close()
 
 
-@pytest.mark.parametrize("z_adam", ["replay", "lazy"])
-def test_epoch_loop_inside_the_library_equals_the_host_loop(tmp_path, z_adam):
+@pytest.mark.parametrize("z_adam,units,batch", [("replay", {}, 32), ("lazy", {}, 32),
+                                                 ("replay", dict(g_units=[128, 96], e_units=[100], f_units=[80, 40], h_units=[72]), 32),
+                                                 ("lazy", dict(g_units=[128, 96], e_units=[100], f_units=[80, 40], h_units=[72]), 32),
+                                                 ("replay", {}, 40)])
+def test_epoch_loop_inside_the_library_equals_the_host_loop(tmp_path, z_adam, units, batch):
     """CausalBGM(use_bnn=True).fit(host_loop=False) -- one bgm_bnn_fit_epoch call per epoch, the latent phase of a minibatch on a second
     stream beside the chains of the next -- gives the parameters and the latent table of the per-minibatch calls from Python bit for
-    bit (n = 200 = 6 x 32 + 8: the short last minibatch runs on the phase machine)."""
+    bit (n = 200 = 6 x 32 + 8: the short last minibatch runs on the phase machine).  Other widths / minibatch sizes: the general step
+    kernels, whose latent step runs beside the reading part of the next theta step on its own workspace slices (HIP events)."""
     from bayesgm_amd.models import CausalBGM
     rs = np.random.RandomState(0)
     n, p = 200, 100
@@ -581,10 +585,11 @@ def test_epoch_loop_inside_the_library_equals_the_host_loop(tmp_path, z_adam):
     params = dict(dataset="t", output_dir=str(tmp_path), save_res=False, save_model=False, binary_treatment=False, use_bnn=True,
                   z_dims=[1, 1, 1, 7], v_dim=p, lr_theta=1e-3, lr_z=1e-3, lr=2e-4, g_d_freq=5, use_z_rec=True, kl_weight=1e-4,
                   g_units=[64] * 5, e_units=[64] * 5, f_units=[64, 32, 8], h_units=[64, 32, 8], dz_units=[64, 32, 8])
+    params.update(units)
     res = []
     for host_loop in (True, False):
         m = CausalBGM(dict(params), timestamp="t%d" % host_loop, random_seed=3)
-        m.fit((x, y, v), epochs=2, epochs_per_eval=1, batch_size=32, use_egm_init=False, verbose=0, z_adam=z_adam, host_loop=host_loop)
+        m.fit((x, y, v), epochs=2, epochs_per_eval=1, batch_size=batch, use_egm_init=False, verbose=0, z_adam=z_adam, host_loop=host_loop)
         res.append((m.data_z.cpu().numpy().copy(), m.engine.read(0).copy(), m._stream))
     (za, ta, sa), (zb, tb, sb) = res
     assert sa == sb
