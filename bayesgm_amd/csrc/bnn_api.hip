@@ -332,6 +332,7 @@ static void bnn_theta_launch(BnnState *s, BnnArgs &a, int batch, int parts, hipS
     if (parts & 1) {
       hipLaunchKernelGGL(bnn_step_noise_kernel, dim3(BNN_NOISE_PARTS, 3, 1), dim3(BNN_THREADS), 0, st, a, 4);
       hipLaunchKernelGGL(bnn_theta_step_kernel, dim3(3), dim3(BNN_THREADS), 0, st, a);
+      hipLaunchKernelGGL(bnn_dw_kernel, dim3(BNN_DW_PARTS, 3), dim3(BNN_THREADS), 0, st, a);      // the parameter-gradient tiles of all layers
       hipLaunchKernelGGL(bnn_kl_kernel, dim3(BNN_KL_PARTS, 3), dim3(256), 0, st, a);
       hipLaunchKernelGGL(bnn_kl_finish_kernel, dim3(1), dim3(64), 0, st, a);
     }

@@ -309,9 +309,10 @@ __device__ __forceinline__ float *bnn_fwd(const BnnCtx &c, const float *theta, c
 }
 
 // Parameter gradients of layer l from its input (h, hs) and the upstream gradient (cur, curs = cur * s_out).
+// (wg, n_wg): this workgroup's share when the tiles of a layer are spread over n_wg workgroups (bnn_dw_kernel)
 __device__ __forceinline__ void bnn_bwd_params(const BnnCtx &c, const float *theta, float *grad, const BnnNet &n, const BnnCache &k,
-                                               int l, const float *cur, const float *curs, int B, bool accumulate) {
-  const int in = n.lin[l], out = n.lout[l], nw = BNN_THREADS / 64, wave = c.tid >> 6;
+                                               int l, const float *cur, const float *curs, int B, bool accumulate, int wg = 0, int n_wg = 1) {
+  const int in = n.lin[l], out = n.lout[l], nw = n_wg * (BNN_THREADS / 64), wave = wg * (BNN_THREADS / 64) + (c.tid >> 6);
   const float *rho = theta + n.woff[l] + in * out;
   const float *h = k.H + (long long)B * n.hin[l], *hs = k.HS + (long long)B * n.hsin[l];
   float *gloc = grad + n.woff[l], *grho = gloc + in * out, *gb = grho + in * out;
@@ -323,7 +324,7 @@ __device__ __forceinline__ void bnn_bwd_params(const BnnCtx &c, const float *the
               gloc[t] = accumulate ? gloc[t] + c1 : c1;
               grho[t] = accumulate ? grho[t] + r : r;
             });
-  for (int o = c.tid; o < out; o += BNN_THREADS) {
+  for (int o = wg * BNN_THREADS + c.tid; o < out; o += n_wg * BNN_THREADS) {
     float s = 0.0f;
     for (int b = 0; b < B; ++b) s += cur[(long long)b * out + o];
     gb[o] = accumulate ? gb[o] + s : s;
@@ -336,7 +337,10 @@ __device__ __forceinline__ void bnn_bwd_params(const BnnCtx &c, const float *the
 // receives the gradient w.r.t. the raw input (through the batch statistics).
 __device__ __forceinline__ void bnn_bwd(const BnnCtx &c, const float *theta, float *grad, const BnnNet &n, const BnnCache &k,
                                         float *d, float *ds, float *t0, float *t1, float *dx, int B, bool want_params,
-                                        bool accumulate) {
+                                        bool accumulate, float *G = nullptr, float *GS = nullptr) {
+  // G, GS (nets without heads, want_params): the upstream gradients of EVERY layer are kept -- layer l's at B * hoff[l + 1] of G / GS, where
+  // d / ds must point for the last layer -- and the parameter-gradient tiles are left to bnn_dw_kernel (all layers at once, over the chip)
+  const bool defer = G && !n.heads && want_params;
   const int L = n.n_layers, nw = BNN_THREADS / 64, wave = c.tid >> 6;
   float *cur = d, *curs = ds, *nxt = t0, *nxts = t1;
   int l_top = L - 1;
@@ -387,7 +391,8 @@ __device__ __forceinline__ void bnn_bwd(const BnnCtx &c, const float *theta, flo
     const float *loc = theta + n.woff[l];
     const float *h = k.H + (long long)B * n.hin[l];
     int first = wave;
-    if (want_params) {
+    if (defer) { nxt = G + (long long)B * n.hoff[l]; nxts = GS + (long long)B * n.hoff[l]; }
+    if (want_params && !defer) {
       bnn_bwd_params(c, theta, grad, n, k, l, cur, curs, B, accumulate);
       const int t_w = ((in + 15) >> 4) * ((out + 15) >> 4);
       first = (wave - t_w % nw + nw) % nw;
@@ -586,6 +591,13 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_step_kernel(BnnA
     wp = cache_base;
     BnnCache k;
     bnn_cache(n, B, wp, k, id == BNN_G ? bt.zb : (id == BNN_H ? bt.hin : bt.fin));
+    float *G = nullptr, *GS = nullptr;
+    if (a.wide && !n.heads) {      // the upstream gradients of all layers stay (in the second call cache of the slice) for bnn_dw_kernel
+      BnnCache k2;
+      bnn_cache(n, B, wp, k2, nullptr);
+      G = k2.H; GS = k2.HS;
+      d = G + (long long)B * n.hoff[n.n_layers]; ds = GS + (long long)B * n.hoff[n.n_layers];
+    }
     bnn_noise(c, a.theta, n, k, B, a.k0, a.k1, a.stream, 0u, a.wide != 0);      // (the steps of bnn_fwd)
     __syncthreads();
     BNN_T(1);
@@ -634,7 +646,7 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_step_kernel(BnnA
     }
     __syncthreads();
     BNN_T(3);
-    bnn_bwd(c, a.theta, a.grad, n, k, d, ds, t0, t1, nullptr, B, true, false);
+    bnn_bwd(c, a.theta, a.grad, n, k, d, ds, t0, t1, nullptr, B, true, false, G, GS);
     BNN_T(4);
     const float klv = a.wide ? 0.0f : bnn_kl(c, a.theta, a.grad, n, a.kl_weight);      // (wide: bnn_kl_kernel / bnn_kl_finish_kernel)
     __syncthreads();
@@ -772,6 +784,27 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_step_noise_kernel(BnnA
       }
     }
   }
+}
+// the parameter-gradient tiles of a general theta step (d loc, d rho, d bias of every Flipout layer of g, h, f), left by the step kernel:
+// the layers' inputs are in the call cache, their upstream gradients in G / GS (bnn_bwd).  grid (BNN_DW_PARTS, 3 nets): the tiles of a
+// layer over all waves of the net's workgroups, the same arithmetic per tile as bnn_bwd_params inside the step kernel.
+#define BNN_DW_PARTS 16
+static __global__ __launch_bounds__(BNN_THREADS) void bnn_dw_kernel(BnnArgs a) {
+  __shared__ float red[32];
+  BnnCtx c{(int)threadIdx.x, red};
+  const int which = blockIdx.y, id = which == 0 ? BNN_G : (which == 1 ? BNN_H : BNN_F);
+  const BnnNet &n = a.net[id];
+  if (n.heads) return;
+  float *wp = a.ws + (long long)which * a.ws_stride;
+  BnnBatch bt;
+  bnn_gather_ptrs(a, wp, bt);
+  wp += 4LL * ((a.B * a.wmax + 3) & ~3);
+  BnnCache k, k2;
+  bnn_cache(n, a.B, wp, k, nullptr);
+  bnn_cache(n, a.B, wp, k2, nullptr);
+  for (int l = 0; l < n.n_layers; ++l)
+    bnn_bwd_params(c, a.theta, a.grad, n, k, l, k2.H + (long long)a.B * n.hoff[l + 1], k2.HS + (long long)a.B * n.hoff[l + 1], a.B, false,
+                   (int)blockIdx.x, (int)gridDim.x);
 }
 // grad += w * dKL/dtheta as bnn_kl, a slice of every layer per workgroup; the slice's share of sum(net.losses) -> kl_part.
 // grid (BNN_KL_PARTS, 3 nets)
