@@ -195,16 +195,16 @@ extern "C" int bgm_bnn_begin(bgm_handle *h, const bgm_bnn_config *cfg, const flo
   s->wmax = wmax;
   const long long gather = (long long)B * (s->q + s->p + 2 + s->net[BNN_F].dims[0] + s->net[BNN_H].dims[0]) + 64;
   s->ws_stride = (gather + 6LL * B * wmax + 64 + 2 * cache_max + 63) & ~63LL;      // one slice per workgroup (net)
-  s->ws_floats = (size_t)(6 * s->ws_stride);      // three for the theta step's nets, three for the latent step's (the two overlap in bgm_bnn_fit_epoch)
+  s->ws_floats = (size_t)(9 * s->ws_stride);      // three for the theta step's nets, six for the latent step's (net, call) pairs (the two steps overlap in bgm_bnn_fit_epoch)
   const size_t np = ((size_t)s->n_params + 63) & ~(size_t)63;
-  const size_t total = 4 * np + s->ws_floats + 64 + 4 * ((size_t)B * s->q + 64);
+  const size_t total = 4 * np + s->ws_floats + 64 + 8 * ((size_t)B * s->q + 64);
   BGM_HIP_CHECK(hipMalloc((void **)&s->dev, sizeof(float) * total));
   BGM_HIP_CHECK(hipMemset(s->dev, 0, sizeof(float) * total));
   s->theta_dev = s->dev; s->m_dev = s->dev + np; s->v_dev = s->dev + 2 * np; s->grad_dev = s->dev + 3 * np;
   s->ws_dev = s->dev + 4 * np;
   s->out_dev = s->ws_dev + s->ws_floats;
   s->dz_dev = s->out_dev + 64;
-  s->dz_part_dev = s->dz_dev + (size_t)B * s->q + 64;      // [3][B x q] + 3 loss partials
+  s->dz_part_dev = s->dz_dev + (size_t)B * s->q + 64;      // [6][B x q] + 3 loss partials
   BGM_HIP_CHECK(hipMemcpy(s->theta_dev, theta_host, sizeof(float) * count, hipMemcpyHostToDevice));
   BGM_HIP_CHECK(hipMalloc((void **)&s->kl_part_dev, sizeof(float) * 3 * BNN_KL_PARTS));
   BGM_HIP_CHECK(hipMemset(s->kl_part_dev, 0, sizeof(float) * 3 * BNN_KL_PARTS));
@@ -284,7 +284,7 @@ static void bnn_base_args(BnnState *s, BnnArgs &a, int batch, int batch_global, 
   // data parallel: every rank adds its share of the KL term, the all-reduce (sum) restores kl_weight * KL
   if (batch_global > batch) a.kl_weight = s->cfg.kl_weight * (float)batch / (float)batch_global;
   a.ws = s->ws_dev; a.ws_stride = s->ws_stride;
-  a.dz_part = s->dz_part_dev; a.loss_part = s->dz_part_dev + 3 * (size_t)s->cfg.max_batch * s->q;
+  a.dz_part = s->dz_part_dev; a.loss_part = s->dz_part_dev + 6 * (size_t)s->cfg.max_batch * s->q;
 }
 
 // The launches of one theta step.  parts & 1: noise + forward / backward chains (read the parameters); parts & 2: the gradient tiles
@@ -330,7 +330,7 @@ static void bnn_theta_launch(BnnState *s, BnnArgs &a, int batch, int parts, hipS
       return;
     }
     if (parts & 1) {
-      hipLaunchKernelGGL(bnn_step_noise_kernel, dim3(BNN_NOISE_PARTS, 3, 1), dim3(BNN_THREADS), 0, st, a, 4);
+      hipLaunchKernelGGL(bnn_step_noise_kernel, dim3(BNN_NOISE_PARTS, 3, 1), dim3(BNN_THREADS), 0, st, a, 4, 0);
       hipLaunchKernelGGL(bnn_theta_step_kernel, dim3(3), dim3(BNN_THREADS), 0, st, a);
       hipLaunchKernelGGL(bnn_dw_kernel, dim3(BNN_DW_PARTS, 3), dim3(BNN_THREADS), 0, st, a);      // the parameter-gradient tiles of all layers
       hipLaunchKernelGGL(bnn_kl_kernel, dim3(BNN_KL_PARTS, 3), dim3(256), 0, st, a);
@@ -456,9 +456,16 @@ extern "C" int bgm_bnn_z_step(bgm_handle *h, const float *x, const float *y, con
     static const bool one_launch = std::getenv("BGM_BNN_STEP_ONE_LAUNCH") != nullptr;
     a.wide = one_launch ? 0 : 1;      // the two calls' eps / dW over the chip (bnn_step_noise_kernel), the sign words in the step kernel
     a.ws = s->ws_dev + 3 * s->ws_stride;      // (its own slices: the theta step of the next minibatch may be running beside it)
-    if (a.wide) hipLaunchKernelGGL(bnn_step_noise_kernel, dim3(BNN_NOISE_PARTS, 3, 2), dim3(BNN_THREADS), 0, stream, a, 6);
-    hipLaunchKernelGGL(bnn_z_grad_kernel, dim3(3), dim3(BNN_THREADS), 0, stream, a);
-    hipLaunchKernelGGL(bnn_z_combine_kernel, dim3((batch * s->q + 255) / 256), dim3(256), 0, stream, a.dz_part, a.loss_part, a.dz, out, batch * s->q);
+    if (a.wide) {      // the two noise calls of a net on workgroups of their own, forward and backward as two launches
+      hipLaunchKernelGGL(bnn_step_noise_kernel, dim3(BNN_NOISE_PARTS, 3, 2), dim3(BNN_THREADS), 0, stream, a, 6, 1);
+      hipLaunchKernelGGL(bnn_z_fwd_kernel, dim3(6), dim3(BNN_THREADS), 0, stream, a);
+      hipLaunchKernelGGL(bnn_z_bwd_kernel, dim3(6), dim3(BNN_THREADS), 0, stream, a);
+      hipLaunchKernelGGL(bnn_z_combine6_kernel, dim3((batch * s->q + 255) / 256), dim3(256), 0, stream, a.dz_part, a.loss_part, a.dz, out, batch * s->q,
+                         a.data_z, a.idx, s->q, a.inv_B);
+    } else {
+      hipLaunchKernelGGL(bnn_z_grad_kernel, dim3(3), dim3(BNN_THREADS), 0, stream, a);
+      hipLaunchKernelGGL(bnn_z_combine_kernel, dim3((batch * s->q + 255) / 256), dim3(256), 0, stream, a.dz_part, a.loss_part, a.dz, out, batch * s->q);
+    }
   }
   BGM_HIP_CHECK(hipGetLastError());
   if (dz_out) return BGM_OK;    // gradient only (parity tests)

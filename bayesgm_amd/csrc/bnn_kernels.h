@@ -753,23 +753,149 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_z_grad_kernel(BnnArgs 
   if (c.tid == 0) a.loss_part[which] = total;
 }
 
+// The latent step's gradient with the two noise calls of a net on workgroups of their own (general widths, bgm_bnn_z_step): grid = 6
+// workgroups (net = blockIdx.x >> 1, call = blockIdx.x & 1), each on its own workspace slice.  bnn_z_fwd_kernel: gather + forward of the
+// call (eps / dW from bnn_step_noise_kernel); bnn_z_bwd_kernel: the call's upstream gradient (call 0: the mean, with the other call's
+// variance output; call 1: the variance head, with call 0's residuals recomputed) and its backward; the input gradients land in
+// dz_part [6][B x q] and bnn_z_combine6_kernel adds them up as bnn_z_grad_kernel does: the same sums in the same order.
+struct BnnZSlice { BnnBatch bt; float *d, *ds, *t0, *t1, *dx; BnnCache k; const float *o; };
+__device__ __forceinline__ void bnn_z_slice(const BnnArgs &a, const BnnNet &n, int id, int slice, BnnZSlice &z) {
+  float *wp = a.ws + (long long)slice * a.ws_stride;
+  auto take = [&](int cnt) { float *r = wp; wp += (cnt + 3) & ~3; return r; };
+  bnn_gather_ptrs(a, wp, z.bt);
+  z.d = take(a.B * a.wmax); z.ds = take(a.B * a.wmax); z.t0 = take(a.B * a.wmax); z.t1 = take(a.B * a.wmax);
+  z.dx = take(a.B * a.wmax); take(a.B * a.wmax);
+  bnn_cache(n, a.B, wp, z.k, id == BNN_G ? z.bt.zb : (id == BNN_H ? z.bt.hin : z.bt.fin));
+  z.o = z.k.H + (long long)a.B * n.hoff[n.heads ? n.n_layers - 1 : n.n_layers];
+}
+static __global__ __launch_bounds__(BNN_THREADS) void bnn_z_fwd_kernel(BnnArgs a) {
+  __shared__ float red[32];
+  BnnCtx c{(int)threadIdx.x, red};
+  const int which = blockIdx.x >> 1, call = blockIdx.x & 1;
+  const int id = which == 0 ? BNN_G : (which == 1 ? BNN_H : BNN_F);
+  if (call == 1 && id == BNN_H && a.binary) return;
+  const BnnNet &n = a.net[id];
+  float *wp = a.ws + (long long)blockIdx.x * a.ws_stride;
+  BnnBatch bt;
+  bnn_gather(c, a, wp, bt);
+  BnnZSlice z;
+  bnn_z_slice(a, n, id, blockIdx.x, z);
+  bnn_fwd(c, a.theta, n, z.k, a.B, a.k0, a.k1, a.stream + (uint32_t)call, 0u, true);
+}
+static __global__ __launch_bounds__(BNN_THREADS) void bnn_z_bwd_kernel(BnnArgs a) {
+  __shared__ float red[32];
+  __shared__ float ssq_row[BNN_MAX_BATCH];
+  BnnCtx c{(int)threadIdx.x, red};
+  const int B = a.B, p = a.p, q = a.q;
+  const int which = blockIdx.x >> 1, call = blockIdx.x & 1;
+  const int id = which == 0 ? BNN_G : (which == 1 ? BNN_H : BNN_F);
+  const bool two = !(id == BNN_H && a.binary);
+  if (call == 1 && !two) return;
+  const BnnNet &n = a.net[id];
+  BnnZSlice z, zo;
+  bnn_z_slice(a, n, id, blockIdx.x, z);
+  bnn_z_slice(a, n, id, blockIdx.x ^ 1, zo);
+  const BnnBatch &bt = z.bt;
+  const float *o1 = call ? zo.o : z.o, *o2 = two ? (call ? z.o : zo.o) : o1;
+  const int wo = n.dims[n.n_layers], in = n.dims[0];
+  float *d = z.d;
+  float *dzp = a.dz_part + (long long)blockIdx.x * B * q;
+  for (int i = c.tid; i < B * q; i += BNN_THREADS) {
+    dzp[i] = 0.0f;
+    if (!call && !two) dzp[(long long)B * q + i] = 0.0f;      // (the call that does not exist)
+  }
+  float total = 0.0f;
+  if (!call) {
+    if (which == 0) for (int i = c.tid; i < B * q; i += BNN_THREADS) { const float zz = bt.zb[i]; total += 0.5f * zz * zz; }
+    total = bnn_block_sum(c, total) * a.inv_B;
+    float loss = 0.0f;
+    if (id == BNN_G) {
+      bnn_row_ssq(c, bt.vb, o1, B, p, wo, ssq_row);
+      __syncthreads();
+      for (int i = c.tid; i < B * wo; i += BNN_THREADS) {
+        const int b = i / wo, j = i - b * wo;
+        float lb, s2;
+        bnn_gauss(ssq_row[b], o2[b * wo + wo - 1], (float)p, lb, s2, a.sig2[0]);
+        d[i] = (j < p) ? -(bt.vb[b * p + j] - o1[i]) / s2 * a.inv_B : 0.0f;
+        if (j == wo - 1) loss += lb;
+      }
+    } else {
+      const float *tgt = id == BNN_H ? bt.xb : bt.yb;
+      for (int i = c.tid; i < B * wo; i += BNN_THREADS) d[i] = 0.0f;
+      __syncthreads();
+      for (int b = c.tid; b < B; b += BNN_THREADS) {
+        const float l = o1[b * wo];
+        if (!two) {
+          loss += fmaxf(l, 0.0f) - l * tgt[b] + log1pf(expf(-fabsf(l)));
+          d[b * wo] = (sigmoid_f(l) - tgt[b]) * a.inv_B;
+        } else {
+          const float r = tgt[b] - l;
+          float lb, s2;
+          bnn_gauss(r * r, o2[b * wo + wo - 1], 1.0f, lb, s2, a.sig2[id == BNN_H ? 1 : 2]);
+          loss += lb;
+          d[b * wo] = -r / s2 * a.inv_B;
+        }
+      }
+    }
+    total += bnn_block_sum(c, loss) * a.inv_B;
+  } else {
+    if (id == BNN_G) bnn_row_ssq(c, bt.vb, o1, B, p, wo, ssq_row);
+    else {
+      const float *tgt = id == BNN_H ? bt.xb : bt.yb;
+      for (int b = c.tid; b < B; b += BNN_THREADS) { const float r = tgt[b] - o1[b * wo]; ssq_row[b] = r * r; }
+    }
+    __syncthreads();
+    const float dim = id == BNN_G ? (float)p : 1.0f;
+    for (int i = c.tid; i < B * wo; i += BNN_THREADS) {
+      const int b = i / wo, j = i - b * wo;
+      float lb, s2;
+      d[i] = (j == wo - 1) ? bnn_gauss(ssq_row[b], o2[b * wo + wo - 1], dim, lb, s2, a.sig2[id == BNN_G ? 0 : (id == BNN_H ? 1 : 2)]) * a.inv_B : 0.0f;
+    }
+  }
+  __syncthreads();
+  bnn_bwd(c, a.theta, a.grad, n, z.k, d, z.ds, z.t0, z.t1, z.dx, B, false, false);
+  for (int i = c.tid; i < B * in; i += BNN_THREADS) {
+    const int b = i / in, j = i - b * in;
+    int col = -1;
+    if (id == BNN_G) col = j;
+    else if (id == BNN_F) col = (j < a.z0 + a.z1) ? j : -1;
+    else col = (j < a.z0) ? j : j + a.z1;
+    if (col >= 0) dzp[b * q + col] = z.dx[i];      // one thread per (b, col)
+  }
+  if (!call && c.tid == 0) a.loss_part[which] = total;
+}
+// dz = (z / B + (g call 0 + g call 1)) + (h 0 + h 1) + (f 0 + f 1): the sums of bnn_z_grad_kernel + bnn_z_combine_kernel, term by term
+static __global__ void bnn_z_combine6_kernel(const float *dz_part, const float *loss_part, float *dz, float *out, int n, const float *data_z,
+                                             const int *idx, int q, float inv_B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const int b = i / q, col = i - b * q;
+    const float p0 = __fadd_rn(__fmul_rn(data_z[(long long)idx[b] * q + col], inv_B), __fadd_rn(dz_part[i], dz_part[n + i]));
+    const float p1 = __fadd_rn(0.0f, __fadd_rn(dz_part[2 * n + i], dz_part[3 * n + i]));
+    const float p2 = __fadd_rn(0.0f, __fadd_rn(dz_part[4 * n + i], dz_part[5 * n + i]));
+    dz[i] = __fadd_rn(__fadd_rn(p0, p1), p2);
+  }
+  if (i == 0 && out) out[0] = loss_part[0] + loss_part[1] + loss_part[2];
+}
+
 // dz = sum of the three per-net partials; loss_postrior_z likewise
 // ---- the elementwise parts of the general steps, spread over the chip (one workgroup per net walks everything else) ----------------
 // eps and dW = sigma * eps of the calls of a step, written where the step kernel's call caches will look for them: the same pointer
 // arithmetic as bnn_theta_step_kernel (scratch = 4 row buffers, one call per net) / bnn_z_grad_kernel (6, two calls unless the
 // treatment is binary).  grid (BNN_NOISE_PARTS, 3 nets, calls); same draws as bnn_noise.
-static __global__ __launch_bounds__(BNN_THREADS) void bnn_step_noise_kernel(BnnArgs a, int n_scratch) {
+static __global__ __launch_bounds__(BNN_THREADS) void bnn_step_noise_kernel(BnnArgs a, int n_scratch, int split) {
+  // split: every (net, call) has a workspace slice of its own (bnn_z_fwd_kernel / bnn_z_bwd_kernel), its cache is the slice's first
   const int which = blockIdx.y, call = blockIdx.z;
   const int id = which == 0 ? BNN_G : (which == 1 ? BNN_H : BNN_F);
   if (call == 1 && id == BNN_H && a.binary) return;
   const BnnNet &n = a.net[id];
-  float *wp = a.ws + (long long)which * a.ws_stride;
+  float *wp = a.ws + (long long)(split ? 2 * which + call : which) * a.ws_stride;
   BnnBatch bt;
   bnn_gather_ptrs(a, wp, bt);
   wp += (long long)n_scratch * ((a.B * a.wmax + 3) & ~3);
   BnnCache k;
   bnn_cache(n, a.B, wp, k, nullptr);
-  if (call == 1) bnn_cache(n, a.B, wp, k, nullptr);
+  if (call == 1 && !split) bnn_cache(n, a.B, wp, k, nullptr);
   const uint32_t stream = a.stream + (uint32_t)call;
   for (int l = 0; l < n.n_layers; ++l) {
     const int cnt = n.lin[l] * n.lout[l];
