@@ -375,6 +375,55 @@ def training_leg(params, x, y, v, device, n=20000, batch=32, reps=200):
 
 
 
+def wide_bayesian_leg(device, n=100000, p=200, batch=32):
+    """Secondary measurement: use_bnn=True outside the default widths (csrc/bnw_kernels.h sampling path, the general minibatch step kernels of
+    csrc/bnn_kernels.h): one MH iteration / one kept iteration with 20 doses on n rows in blocks of 1e4, and the microseconds per 32-row
+    minibatch of the epoch call.  Fractions are algorithmic Flipout FLOP (two products per layer, two evaluations per iteration) over the
+    fp32-MFMA peak.  DESIGN.md section 4j."""
+    import torch
+    from bayesgm_amd.models import CausalBGM
+    z_dims, bs, iters = [1, 1, 1, 7], 10000, 5
+    q = sum(z_dims)
+    g = torch.Generator(device=device).manual_seed(0)
+    v = torch.randn(n, p, device=device, generator=g); x = torch.rand(n, device=device, generator=g); y = torch.randn(n, device=device, generator=g)
+    out = {"sample": f"N={n}, p={p}, z_dims {z_dims}, blocks of {bs} rows, {iters} iterations timed; fit: B={batch} on the first 20000 rows"}
+    for name, w in (("[128,128]", [128, 128]), ("[256]x3", [256] * 3)):
+        u = dict(g_units=w, e_units=w, f_units=w, h_units=w)
+        params = dict(dataset="bench_wide", output_dir=".", save_res=False, save_model=False, binary_treatment=False, use_bnn=True, z_dims=z_dims, v_dim=p,
+                      lr_theta=1e-4, lr_z=1e-4, kl_weight=1e-4, lr=2e-4, g_d_freq=5, use_z_rec=True, dz_units=[64, 32, 8], **u)
+        eng = CausalBGM(params, timestamp="bench_wide", random_seed=0, device=device.index).engine      # (random-init weights, inference-mode normalisation)
+        state = torch.empty(n, q, device=device)
+        eng.mh_run(x, y, v, state, bs, 0, 2, 0, 1.0, 1, init=True)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        eng.mh_run(x, y, v, state, bs, 2, iters, 0, 1.0, 1)
+        torch.cuda.synchronize(); t = (time.perf_counter() - t0) / iters
+        dims = {"g": [q] + w + [p + 1], "f": [z_dims[0] + z_dims[1] + 1] + w + [2], "h": [z_dims[0] + z_dims[2]] + w + [2]}
+        macs = sum(a * b for net in ("g", "f", "h") for a, b in zip(dims[net][:-1], dims[net][1:]))
+        macs_f = sum(a * b for a, b in zip(dims["f"][:-1], dims["f"][1:]))
+        xs = torch.linspace(0, 3, 20, device=device)
+        adrf = torch.zeros(20, iters, device=device, dtype=torch.float64)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        eng.mh_run(x, y, v, state, bs, 100, iters, 100, 1.0, 1, n_keep=iters, effect=1, x_values=xs, adrf_sum=adrf)
+        torch.cuda.synchronize(); t2 = (time.perf_counter() - t0) / iters
+        fl, fe = 8 * macs * n, 20 * 4 * macs_f * n
+        ent = {"mh_iteration_ms": 1e3 * t, "transitions_per_s": n / t, "frac_of_fp32_mfma_peak": fl / t / 1e12 / 157.3,
+               "kept_iteration_ms": 1e3 * t2, "outcome_net_frac_of_fp32_mfma_peak": fe / max(t2 - t, 1e-9) / 1e12 / 157.3,
+               "flop_per_row_transition": 8 * macs}
+        # the minibatch loop at these widths (one bgm_bnn_fit_epoch call, 400 minibatches)
+        nf = 20000
+        be = eng
+        z = torch.randn(nf, q, device=device, generator=g); zm, zv = torch.zeros_like(z), torch.zeros_like(z)
+        perm = torch.randperm(nf, device=device, generator=g).to(torch.int32)
+        xs_, ys_, vs_ = x[:nf].contiguous(), y[:nf].contiguous(), v[:nf].contiguous()
+        be.fit_epoch(xs_, ys_, vs_, z, zm, zv, perm[:20 * batch], batch, 1e-4, 1e-4, 2, 1, 0)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        be.fit_epoch(xs_, ys_, vs_, z, zm, zv, perm[:400 * batch], batch, 1e-4, 1e-4, 2, 1, 0)
+        torch.cuda.synchronize()
+        ent["fit_minibatch_us_epoch_call"] = 1e6 * (time.perf_counter() - t0) / 400
+        out[name] = ent
+    return out
+
+
 def bgm_hmc_leg(device, n=200000, p=500, q=10, L=10, iters=4):
     """Secondary measurement (not `value`): the HMC transition kernels of BGM imputation at BASELINE config C4's shape (x_dim 500, z_dim 10,
     g_units [64] x 5, 10 leapfrog steps, 10 % cells missing) -- deterministic generator (bgm_hmc_kernel, head weights streamed) and the
@@ -1197,6 +1246,9 @@ def main():
                     out["config_c4_share"]["use_bnn"]["f16x3"] = bx3
         if not args.no_general_width and world == 1:
             out["general_width_engine"] = general_width_leg(p, z_dims, device)
+            import contextlib
+            with contextlib.redirect_stdout(sys.stderr):
+                out["wide_bayesian_nets"] = wide_bayesian_leg(device)
         if not args.no_fit and world == 1:
             out["fit"] = fit_leg(model, x, y, v, n_loc)
             out["fit_dp"] = fit_dp_leg(model, x, y, v, n_loc, 1, device)      # the data-parallel call on a one-rank communicator
