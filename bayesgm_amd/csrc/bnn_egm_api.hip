@@ -248,9 +248,17 @@ extern "C" int bgm_bnn_egm_gen_step(bgm_handle *h, const float *z_dev, const int
     BGM_HIP_CHECK(hipGetLastError());
     return BGM_OK;
   }
+  // general widths: one workgroup walks the nine calls and their backward passes; the calls' eps / dW and the Adam step (elementwise over
+  // all parameters of g, e, f, h) run as launches over the chip around it.  BGM_BNN_STEP_ONE_LAUNCH: everything inside the one workgroup.
+  static const bool one_launch = std::getenv("BGM_BNN_STEP_ONE_LAUNCH") != nullptr;
+  a.wide = one_launch ? 0 : 1;
   auto k = bnn_egm_gen_step_kernel;
   const int lds = 64 * (int)sizeof(float);
+  if (a.wide) hipLaunchKernelGGL(bnn_egm_gen_noise_wide_kernel, dim3(16, 9), dim3(EGM_THREADS), 0, (hipStream_t)stream_, a);
   hipLaunchKernelGGL(k, dim3(1), dim3(EGM_THREADS), lds, (hipStream_t)stream_, a);
+  if (a.wide && a.apply)
+    hipLaunchKernelGGL(egm_dp_adam_kernel, dim3((unsigned)((a.n_gen + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, a.theta, a.m, a.v, a.grad, a.n_gen,
+                       a.adam, (float *)nullptr, (const int *)nullptr);
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
 }

@@ -29,6 +29,7 @@ struct BnnEgmArgs {
   EgmAdam adam;
   float *ws, *out;
   int apply, disc_lds;
+  int wide;                              // general generator step: eps / dW of the nine calls by bnn_egm_gen_noise_wide_kernel, Adam by its own launch
 };
 
 static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_disc_step_kernel(BnnEgmArgs a) {
@@ -121,39 +122,85 @@ static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_disc_chain_kernel(
   ech_disc_tail<T1, T2, T3, NB, T0>(io, a.dz, P, M, tid);
 }
 
+// The workspace of the general generator step: gathered batch, the call caches of the nine calls (stream + 0 .. 8: g(z), g(z) again, e(v),
+// e(v_), g(z_), f, f again, h, h again), the discriminator cache; `rest` = what follows (the backward's scratch).  One function for the
+// step kernel and for the launch that draws the calls' perturbations ahead of it.
+struct BnnEgmGenLayout { float *vb, *xb, *yb, *v_, *fin, *hin, *z_, *rest; BnnCache k[9]; EgmDiscCache kd; };
+__device__ __forceinline__ void bnn_egm_gen_layout(const BnnEgmArgs &a, BnnEgmGenLayout &L) {
+  const int B = a.B, p = a.p;
+  const BnnNet &G = a.net[BNN_G], &E = a.net[BNN_E], &F = a.net[BNN_F], &H = a.net[BNN_H];
+  float *wp = a.ws;
+  auto take = [&](int n) { float *r = wp; wp += (n + 3) & ~3; return r; };
+  L.vb = take(B * p); L.xb = take(B); L.yb = take(B);
+  bnn_cache(G, B, wp, L.k[0], a.z);
+  bnn_cache(G, B, wp, L.k[1], a.z);
+  bnn_cache(E, B, wp, L.k[2], L.vb);
+  L.z_ = L.k[2].H + (long long)B * E.hoff[E.n_layers];      // the output of e(v) (bnn_fwd)
+  L.v_ = take(B * p);
+  bnn_cache(E, B, wp, L.k[3], L.v_);
+  bnn_cache(G, B, wp, L.k[4], L.z_);
+  egm_disc_cache(a.dz, B, wp, L.kd, L.z_);
+  L.fin = take(B * F.dims[0]); L.hin = take(B * H.dims[0]);
+  bnn_cache(F, B, wp, L.k[5], L.fin);
+  bnn_cache(F, B, wp, L.k[6], L.fin);
+  bnn_cache(H, B, wp, L.k[7], L.hin);
+  bnn_cache(H, B, wp, L.k[8], L.hin);
+  L.rest = wp;
+}
+// eps and dW = sigma * eps of the nine calls, over the chip: grid (parts, 9); same draws as bnn_noise
+static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_gen_noise_wide_kernel(BnnEgmArgs a) {
+  BnnEgmGenLayout L;
+  bnn_egm_gen_layout(a, L);
+  const int call = blockIdx.y;
+  const int id = (call == 2 || call == 3) ? BNN_E : (call == 5 || call == 6) ? BNN_F : (call >= 7) ? BNN_H : BNN_G;
+  const BnnNet &n = a.net[id];
+  const BnnCache &k = L.k[call];
+  const uint32_t stream = a.stream + (uint32_t)call;
+  for (int l = 0; l < n.n_layers; ++l) {
+    const int cnt = n.lin[l] * n.lout[l];
+    const float *rho = a.theta + n.woff[l] + cnt;
+    float *e = k.eps + n.eoff[l], *d = k.dW + n.eoff[l];
+    for (int i = blockIdx.x * EGM_THREADS + threadIdx.x; i < (cnt + 3) >> 2; i += gridDim.x * EGM_THREADS) {
+      const f32x4 z = box_muller4(philox4x32_10((uint32_t)i, (uint32_t)l | ((uint32_t)n.net_id << 16), stream, BNN_TAG_EPS, a.k0, a.k1));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = 4 * i + u;
+        if (idx < cnt) { e[idx] = z[u]; d[idx] = (BNN_SCALE_EPS + softplus_acc(rho[idx])) * z[u]; }
+      }
+    }
+  }
+}
+
 static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_gen_step_kernel(BnnEgmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float egm_lds[];
   EgmCtx c{(int)threadIdx.x, egm_lds};
   BnnCtx cb{(int)threadIdx.x, egm_lds};
   const int B = a.B, q = a.q, p = a.p, z0 = a.z0, z1 = a.z1, z2 = a.z2;
   const float invB = 1.0f / (float)B;
-  float *wp = a.ws;
+  BnnEgmGenLayout L;
+  bnn_egm_gen_layout(a, L);
+  float *wp = L.rest;
   auto take = [&](int n) { float *r = wp; wp += (n + 3) & ~3; return r; };
-  float *vb = take(B * p), *xb = take(B), *yb = take(B);
+  float *vb = L.vb, *xb = L.xb, *yb = L.yb;
   for (int k = c.tid; k < B * p; k += EGM_THREADS) { const int b = k / p; vb[k] = a.v_[(long long)a.idx[b] * p + (k - b * p)]; }
   for (int b = c.tid; b < B; b += EGM_THREADS) { xb[b] = a.x_[a.idx[b]]; yb[b] = a.y_[a.idx[b]]; }
   __syncthreads();
   const BnnNet &G = a.net[BNN_G], &E = a.net[BNN_E], &F = a.net[BNN_F], &H = a.net[BNN_H];
   const int wg = p + 1, nf = F.dims[0], nh = H.dims[0], of = F.dims[F.n_layers], oh = H.dims[H.n_layers];
+  const bool so = a.wide != 0;      // the calls' eps / dW were drawn by bnn_egm_gen_noise_wide_kernel: sign words only
   // ---- forward: nine calls, noise streams stream + 0..8 in the order of oracle/bnn.py EGM_CALLS
-  BnnCache g1, g1s, e1, e2, g2, cf, cfs, ch, chs;
-  bnn_cache(G, B, wp, g1, a.z);
-  const float *gz = bnn_fwd(cb, a.theta, G, g1, B, a.k0, a.k1, a.stream + 0u, a.row0);      // g(z): v_ = [:, :p]
-  bnn_cache(G, B, wp, g1s, a.z);
-  const float *gzs = bnn_fwd(cb, a.theta, G, g1s, B, a.k0, a.k1, a.stream + 1u, a.row0);    // g(z) again: variance head penalty
-  bnn_cache(E, B, wp, e1, vb);
-  float *z_ = bnn_fwd(cb, a.theta, E, e1, B, a.k0, a.k1, a.stream + 2u, a.row0);            // z_ = e(v)
-  float *v_ = take(B * p);
+  BnnCache &g1 = L.k[0], &g1s = L.k[1], &e1 = L.k[2], &e2 = L.k[3], &g2 = L.k[4], &cf = L.k[5], &cfs = L.k[6], &ch = L.k[7], &chs = L.k[8];
+  const float *gz = bnn_fwd(cb, a.theta, G, g1, B, a.k0, a.k1, a.stream + 0u, a.row0, so);      // g(z): v_ = [:, :p]
+  const float *gzs = bnn_fwd(cb, a.theta, G, g1s, B, a.k0, a.k1, a.stream + 1u, a.row0, so);    // g(z) again: variance head penalty
+  float *z_ = bnn_fwd(cb, a.theta, E, e1, B, a.k0, a.k1, a.stream + 2u, a.row0, so);            // z_ = e(v)
+  float *v_ = L.v_;
   for (int k = c.tid; k < B * p; k += EGM_THREADS) { const int b = k / p; v_[k] = gz[b * wg + (k - b * p)]; }
   __syncthreads();
-  bnn_cache(E, B, wp, e2, v_);
-  const float *z__ = bnn_fwd(cb, a.theta, E, e2, B, a.k0, a.k1, a.stream + 3u, a.row0);     // z__ = e(v_)
-  bnn_cache(G, B, wp, g2, z_);
-  const float *gv = bnn_fwd(cb, a.theta, G, g2, B, a.k0, a.k1, a.stream + 4u, a.row0);      // g(z_): v__ = [:, :p]
-  EgmDiscCache kd;
-  egm_disc_cache(a.dz, B, wp, kd, z_);
+  const float *z__ = bnn_fwd(cb, a.theta, E, e2, B, a.k0, a.k1, a.stream + 3u, a.row0, so);     // z__ = e(v_)
+  const float *gv = bnn_fwd(cb, a.theta, G, g2, B, a.k0, a.k1, a.stream + 4u, a.row0, so);      // g(z_): v__ = [:, :p]
+  EgmDiscCache &kd = L.kd;
   egm_disc_fwd(c, a.theta_d, a.dz, kd, B);
-  float *fin = take(B * nf), *hin = take(B * nh);
+  float *fin = L.fin, *hin = L.hin;
   for (int k = c.tid; k < B * nf; k += EGM_THREADS) {
     const int b = k / nf, i = k - b * nf;
     fin[k] = (i < z0 + z1) ? z_[b * q + i] : xb[b];
@@ -163,14 +210,10 @@ static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_gen_step_kernel(Bn
     hin[k] = (i < z0) ? z_[b * q + i] : z_[b * q + z1 + i];
   }
   __syncthreads();
-  bnn_cache(F, B, wp, cf, fin);
-  const float *fo = bnn_fwd(cb, a.theta, F, cf, B, a.k0, a.k1, a.stream + 5u, a.row0);
-  bnn_cache(F, B, wp, cfs, fin);
-  const float *fs = bnn_fwd(cb, a.theta, F, cfs, B, a.k0, a.k1, a.stream + 6u, a.row0);
-  bnn_cache(H, B, wp, ch, hin);
-  const float *ho = bnn_fwd(cb, a.theta, H, ch, B, a.k0, a.k1, a.stream + 7u, a.row0);
-  bnn_cache(H, B, wp, chs, hin);
-  const float *hs = bnn_fwd(cb, a.theta, H, chs, B, a.k0, a.k1, a.stream + 8u, a.row0);
+  const float *fo = bnn_fwd(cb, a.theta, F, cf, B, a.k0, a.k1, a.stream + 5u, a.row0, so);
+  const float *fs = bnn_fwd(cb, a.theta, F, cfs, B, a.k0, a.k1, a.stream + 6u, a.row0, so);
+  const float *ho = bnn_fwd(cb, a.theta, H, ch, B, a.k0, a.k1, a.stream + 7u, a.row0, so);
+  const float *hs = bnn_fwd(cb, a.theta, H, chs, B, a.k0, a.k1, a.stream + 8u, a.row0, so);
   // ---- losses
   float l_v = 0.0f, l_z = 0.0f, l_x = 0.0f, l_y = 0.0f, s_g = 0.0f, s_f = 0.0f, s_h = 0.0f, adv = 0.0f;
   for (int k = c.tid; k < B * p; k += EGM_THREADS) { const int b = k / p; const float t = vb[k] - gv[b * wg + (k - b * p)]; l_v = fmaf(t, t, l_v); }
@@ -248,7 +291,7 @@ static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_gen_step_kernel(Bn
   }
   __syncthreads();
   bnn_bwd(cb, a.theta, a.grad, E, e1, d, ds, t0, t1, nullptr, B, true, true);
-  if (a.apply) egm_adam(c, a.theta, a.m, a.v, a.grad, a.n_gen, a.adam);
+  if (a.apply && !a.wide) egm_adam(c, a.theta, a.m, a.v, a.grad, a.n_gen, a.adam);      // (wide: egm_dp_adam_kernel behind this launch)
   if (c.tid == 0 && a.out) {
     a.out[0] = adv; a.out[1] = l_v; a.out[2] = l_z; a.out[3] = l_x; a.out[4] = l_y;
     a.out[5] = adv + (l_v + zrec * l_z) + (l_x + l_y) + 0.001f * sig;
