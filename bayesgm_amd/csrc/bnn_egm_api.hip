@@ -132,7 +132,9 @@ extern "C" int bgm_bnn_egm_begin(bgm_handle *h, const bgm_egm_config *cfg, const
     e->disc_call.xh = (int)off; off += (size_t)B * EchDims<4, 2, 1, 2>::SW;      // two latent tiles: the tail's fourth stash (EchDiscIo::gstash)
     gen_ws = off;
   }
-  e->ws_floats = gen_ws + 3 * cache_floats(s->net[BNN_G]) + 2 * cache_floats(s->net[BNN_E]) + 2 * cache_floats(s->net[BNN_F]) +
+  size_t keep = 0;      // the kept upstream gradients of the nine calls (wide generator step: G / GS of bnn_bwd)
+  for (int k : {BNN_G, BNN_G, BNN_G, BNN_E, BNN_E, BNN_F, BNN_F, BNN_H, BNN_H}) keep += 2 * ((size_t)B * s->net[k].hoff[s->net[k].n_layers + 1] + 4);
+  e->ws_floats = keep + gen_ws + 3 * cache_floats(s->net[BNN_G]) + 2 * cache_floats(s->net[BNN_E]) + 2 * cache_floats(s->net[BNN_F]) +
                  2 * cache_floats(s->net[BNN_H]) + (size_t)B * (4 * (size_t)s->p + 32 * (size_t)wmax + 256) + 4 * cache + e->n_dz + arena + 8192;
   const size_t np = ((size_t)s->n_params + 63) & ~(size_t)63, nd = (e->n_dz + 63) & ~(size_t)63;
   const size_t total = 2 * np + 4 * nd + e->ws_floats + 64;
@@ -256,6 +258,7 @@ extern "C" int bgm_bnn_egm_gen_step(bgm_handle *h, const float *z_dev, const int
   const int lds = 64 * (int)sizeof(float);
   if (a.wide) hipLaunchKernelGGL(bnn_egm_gen_noise_wide_kernel, dim3(16, 9), dim3(EGM_THREADS), 0, (hipStream_t)stream_, a);
   hipLaunchKernelGGL(k, dim3(1), dim3(EGM_THREADS), lds, (hipStream_t)stream_, a);
+  if (a.wide) hipLaunchKernelGGL(bnn_egm_gen_dw_wide_kernel, dim3(16, 4), dim3(EGM_THREADS), 0, (hipStream_t)stream_, a);      // the gradient tiles of all layers
   if (a.wide && a.apply)
     hipLaunchKernelGGL(egm_dp_adam_kernel, dim3((unsigned)((a.n_gen + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, a.theta, a.m, a.v, a.grad, a.n_gen,
                        a.adam, (float *)nullptr, (const int *)nullptr);

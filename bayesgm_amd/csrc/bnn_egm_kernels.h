@@ -125,7 +125,9 @@ static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_disc_chain_kernel(
 // The workspace of the general generator step: gathered batch, the call caches of the nine calls (stream + 0 .. 8: g(z), g(z) again, e(v),
 // e(v_), g(z_), f, f again, h, h again), the discriminator cache; `rest` = what follows (the backward's scratch).  One function for the
 // step kernel and for the launch that draws the calls' perturbations ahead of it.
-struct BnnEgmGenLayout { float *vb, *xb, *yb, *v_, *fin, *hin, *z_, *rest; BnnCache k[9]; EgmDiscCache kd; };
+struct BnnEgmGenLayout { float *vb, *xb, *yb, *v_, *fin, *hin, *z_, *rest; BnnCache k[9]; EgmDiscCache kd; float *G[9], *GS[9]; };
+// net of call c (oracle/bnn.py EGM_CALLS)
+__device__ __forceinline__ int bnn_egm_call_net(int call) { return (call == 2 || call == 3) ? BNN_E : (call == 5 || call == 6) ? BNN_F : (call >= 7) ? BNN_H : BNN_G; }
 __device__ __forceinline__ void bnn_egm_gen_layout(const BnnEgmArgs &a, BnnEgmGenLayout &L) {
   const int B = a.B, p = a.p;
   const BnnNet &G = a.net[BNN_G], &E = a.net[BNN_E], &F = a.net[BNN_F], &H = a.net[BNN_H];
@@ -145,6 +147,11 @@ __device__ __forceinline__ void bnn_egm_gen_layout(const BnnEgmArgs &a, BnnEgmGe
   bnn_cache(F, B, wp, L.k[6], L.fin);
   bnn_cache(H, B, wp, L.k[7], L.hin);
   bnn_cache(H, B, wp, L.k[8], L.hin);
+  // the upstream gradients of every layer of every call (bnn_bwd's G / GS), kept for the gradient-tile launch (wide steps)
+  for (int cidx = 0; cidx < 9; ++cidx) {
+    const BnnNet &n = a.net[bnn_egm_call_net(cidx)];
+    L.G[cidx] = take(B * n.hoff[n.n_layers + 1]); L.GS[cidx] = take(B * n.hoff[n.n_layers + 1]);
+  }
   L.rest = wp;
 }
 // eps and dW = sigma * eps of the nine calls, over the chip: grid (parts, 9); same draws as bnn_noise
@@ -152,8 +159,7 @@ static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_gen_noise_wide_ker
   BnnEgmGenLayout L;
   bnn_egm_gen_layout(a, L);
   const int call = blockIdx.y;
-  const int id = (call == 2 || call == 3) ? BNN_E : (call == 5 || call == 6) ? BNN_F : (call >= 7) ? BNN_H : BNN_G;
-  const BnnNet &n = a.net[id];
+  const BnnNet &n = a.net[bnn_egm_call_net(call)];
   const BnnCache &k = L.k[call];
   const uint32_t stream = a.stream + (uint32_t)call;
   for (int l = 0; l < n.n_layers; ++l) {
@@ -241,61 +247,93 @@ static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_gen_step_kernel(Bn
   float *d = take(B * wmax), *ds = take(B * wmax), *t0 = take(B * wmax), *t1 = take(B * wmax);
   float *dv_ = take(B * wmax), *dzsum = take(B * wmax), *dtmp = take(B * wmax), *da = take(B * wmax), *du = take(B * wmax);
   float *dfin = take(B * wmax), *dfin2 = take(B * wmax), *dhin = take(B * wmax), *dhin2 = take(B * wmax);
+  // (wide steps: the upstream gradient of a call is written where bnn_bwd keeps the gradients of all its layers, L.G / L.GS)
+  float *dd, *dds;
+  auto up = [&](int ci, const BnnNet &N, float *dflt) { return a.wide ? L.G[ci] + (long long)B * N.hoff[N.n_layers] : dflt; };
+  auto up2 = [&](int ci, const BnnNet &N, float *dflt) { return a.wide ? L.GS[ci] + (long long)B * N.hoff[N.n_layers] : dflt; };
   // z__ branch: e (call 2, input v_) -> g (call 1)
-  for (int k = c.tid; k < B * q; k += EGM_THREADS) d[k] = zrec * (-2.0f / (float)(B * q)) * (a.z[k] - z__[k]);
+  dd = up(3, E, d); dds = up2(3, E, ds);
+  for (int k = c.tid; k < B * q; k += EGM_THREADS) dd[k] = zrec * (-2.0f / (float)(B * q)) * (a.z[k] - z__[k]);
   __syncthreads();
-  bnn_bwd(cb, a.theta, a.grad, E, e2, d, ds, t0, t1, dv_, B, true, false);
-  for (int k = c.tid; k < B * wg; k += EGM_THREADS) { const int b = k / wg, i = k - b * wg; d[k] = (i < p) ? dv_[b * p + i] : 0.0f; }
+  bnn_bwd(cb, a.theta, a.grad, E, e2, dd, dds, t0, t1, dv_, B, true, false, a.wide ? L.G[3] : nullptr, a.wide ? L.GS[3] : nullptr);
+  dd = up(0, G, d); dds = up2(0, G, ds);
+  for (int k = c.tid; k < B * wg; k += EGM_THREADS) { const int b = k / wg, i = k - b * wg; dd[k] = (i < p) ? dv_[b * p + i] : 0.0f; }
   __syncthreads();
-  bnn_bwd(cb, a.theta, a.grad, G, g1, d, ds, t0, t1, nullptr, B, true, false);
+  bnn_bwd(cb, a.theta, a.grad, G, g1, dd, dds, t0, t1, nullptr, B, true, false, a.wide ? L.G[0] : nullptr, a.wide ? L.GS[0] : nullptr);
   // variance-head penalty of the second g(z) call
-  for (int k = c.tid; k < B * wg; k += EGM_THREADS) { const int i = k % wg; d[k] = (i == p) ? 0.001f * 2.0f * gzs[k] * invB : 0.0f; }
+  dd = up(1, G, d); dds = up2(1, G, ds);
+  for (int k = c.tid; k < B * wg; k += EGM_THREADS) { const int i = k % wg; dd[k] = (i == p) ? 0.001f * 2.0f * gzs[k] * invB : 0.0f; }
   __syncthreads();
-  bnn_bwd(cb, a.theta, a.grad, G, g1s, d, ds, t0, t1, nullptr, B, true, true);
+  bnn_bwd(cb, a.theta, a.grad, G, g1s, dd, dds, t0, t1, nullptr, B, true, true, a.wide ? L.G[1] : nullptr, a.wide ? L.GS[1] : nullptr);
   // v__ branch: g (call 3, input z_)
+  dd = up(4, G, d); dds = up2(4, G, ds);
   for (int k = c.tid; k < B * wg; k += EGM_THREADS) {
     const int b = k / wg, i = k - b * wg;
-    d[k] = (i < p) ? (-2.0f / (float)(B * p)) * (vb[b * p + i] - gv[k]) : 0.0f;
+    dd[k] = (i < p) ? (-2.0f / (float)(B * p)) * (vb[b * p + i] - gv[k]) : 0.0f;
   }
   __syncthreads();
-  bnn_bwd(cb, a.theta, a.grad, G, g2, d, ds, t0, t1, dzsum, B, true, true);
+  bnn_bwd(cb, a.theta, a.grad, G, g2, dd, dds, t0, t1, dzsum, B, true, true, a.wide ? L.G[4] : nullptr, a.wide ? L.GS[4] : nullptr);
   // adversarial branch through the fixed discriminator
   float *gd_scratch = take(a.dz.n_params);
   egm_disc_bwd(c, a.theta_d, gd_scratch, a.dz, kd, true, -invB, nullptr, da, du, dtmp, B, false, 1.0f);
   for (int k = c.tid; k < B * q; k += EGM_THREADS) dzsum[k] += dtmp[k];
   __syncthreads();
   // f: mean call, variance call
-  for (int k = c.tid; k < B * of; k += EGM_THREADS) { const int b = k / of, i = k - b * of; d[k] = (i == 0) ? 2.0f * (fo[k] - yb[b]) * invB : 0.0f; }
+  dd = up(5, F, d); dds = up2(5, F, ds);
+  for (int k = c.tid; k < B * of; k += EGM_THREADS) { const int b = k / of, i = k - b * of; dd[k] = (i == 0) ? 2.0f * (fo[k] - yb[b]) * invB : 0.0f; }
   __syncthreads();
-  bnn_bwd(cb, a.theta, a.grad, F, cf, d, ds, t0, t1, dfin, B, true, false);
-  for (int k = c.tid; k < B * of; k += EGM_THREADS) { const int i = k % of; d[k] = (i == of - 1) ? 0.001f * 2.0f * fs[k] * invB : 0.0f; }
+  bnn_bwd(cb, a.theta, a.grad, F, cf, dd, dds, t0, t1, dfin, B, true, false, a.wide ? L.G[5] : nullptr, a.wide ? L.GS[5] : nullptr);
+  dd = up(6, F, d); dds = up2(6, F, ds);
+  for (int k = c.tid; k < B * of; k += EGM_THREADS) { const int i = k % of; dd[k] = (i == of - 1) ? 0.001f * 2.0f * fs[k] * invB : 0.0f; }
   __syncthreads();
-  bnn_bwd(cb, a.theta, a.grad, F, cfs, d, ds, t0, t1, dfin2, B, true, true);
+  bnn_bwd(cb, a.theta, a.grad, F, cfs, dd, dds, t0, t1, dfin2, B, true, true, a.wide ? L.G[6] : nullptr, a.wide ? L.GS[6] : nullptr);
   // h: mean call, variance call
+  dd = up(7, H, d); dds = up2(7, H, ds);
   for (int k = c.tid; k < B * oh; k += EGM_THREADS) {
     const int b = k / oh, i = k - b * oh;
-    d[k] = (i == 0) ? (a.binary ? (1.0f / (1.0f + expf(-ho[k])) - xb[b]) * invB : 2.0f * (ho[k] - xb[b]) * invB) : 0.0f;
+    dd[k] = (i == 0) ? (a.binary ? (1.0f / (1.0f + expf(-ho[k])) - xb[b]) * invB : 2.0f * (ho[k] - xb[b]) * invB) : 0.0f;
   }
   __syncthreads();
-  bnn_bwd(cb, a.theta, a.grad, H, ch, d, ds, t0, t1, dhin, B, true, false);
-  for (int k = c.tid; k < B * oh; k += EGM_THREADS) { const int i = k % oh; d[k] = (i == oh - 1) ? 0.001f * 2.0f * hs[k] * invB : 0.0f; }
+  bnn_bwd(cb, a.theta, a.grad, H, ch, dd, dds, t0, t1, dhin, B, true, false, a.wide ? L.G[7] : nullptr, a.wide ? L.GS[7] : nullptr);
+  dd = up(8, H, d); dds = up2(8, H, ds);
+  for (int k = c.tid; k < B * oh; k += EGM_THREADS) { const int i = k % oh; dd[k] = (i == oh - 1) ? 0.001f * 2.0f * hs[k] * invB : 0.0f; }
   __syncthreads();
-  bnn_bwd(cb, a.theta, a.grad, H, chs, d, ds, t0, t1, dhin2, B, true, true);
+  bnn_bwd(cb, a.theta, a.grad, H, chs, dd, dds, t0, t1, dhin2, B, true, true, a.wide ? L.G[8] : nullptr, a.wide ? L.GS[8] : nullptr);
+  dd = up(2, E, d); dds = up2(2, E, ds);
   for (int k = c.tid; k < B * q; k += EGM_THREADS) {
     const int b = k / q, i = k - b * q;
     float t = dzsum[k];
     if (i < z0) t += dfin[b * nf + i] + dfin2[b * nf + i] + dhin[b * nh + i] + dhin2[b * nh + i];
     else if (i < z0 + z1) t += dfin[b * nf + i] + dfin2[b * nf + i];
     else if (i < z0 + z1 + z2) t += dhin[b * nh + (i - z1)] + dhin2[b * nh + (i - z1)];
-    d[k] = t;
+    dd[k] = t;
   }
   __syncthreads();
-  bnn_bwd(cb, a.theta, a.grad, E, e1, d, ds, t0, t1, nullptr, B, true, true);
+  bnn_bwd(cb, a.theta, a.grad, E, e1, dd, dds, t0, t1, nullptr, B, true, true, a.wide ? L.G[2] : nullptr, a.wide ? L.GS[2] : nullptr);
   if (a.apply && !a.wide) egm_adam(c, a.theta, a.m, a.v, a.grad, a.n_gen, a.adam);      // (wide: egm_dp_adam_kernel behind this launch)
   if (c.tid == 0 && a.out) {
     a.out[0] = adv; a.out[1] = l_v; a.out[2] = l_z; a.out[3] = l_x; a.out[4] = l_y;
     a.out[5] = adv + (l_v + zrec * l_z) + (l_x + l_y) + 0.001f * sig;
   }
+}
+
+// The parameter-gradient tiles of a wide generator step: every layer of g, e, f, h, the calls of a net in the order the step kernel
+// accumulated them (first call assigns, the others add: a tile is always the same wave's, so the sums keep their order).  grid (parts, 4 nets)
+static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_gen_dw_wide_kernel(BnnEgmArgs a) {
+  __shared__ float red[32];
+  BnnCtx c{(int)threadIdx.x, red};
+  BnnEgmGenLayout L;
+  bnn_egm_gen_layout(a, L);
+  const int id = blockIdx.y;      // BNN_G, BNN_E, BNN_F, BNN_H
+  const BnnNet &n = a.net[id];
+  const int order[4][3] = {{0, 1, 4}, {3, 2, -1}, {5, 6, -1}, {7, 8, -1}};      // [net id][position]: g1, g1s, g2 | e2, e1 | cf, cfs | ch, chs
+  for (int l = 0; l < n.n_layers; ++l)
+    for (int j = 0; j < 3; ++j) {
+      const int ci = order[id][j];
+      if (ci < 0) continue;
+      bnn_bwd_params(c, a.theta, a.grad, n, L.k[ci], l, L.G[ci] + (long long)a.B * n.hoff[l + 1], L.GS[ci] + (long long)a.B * n.hoff[l + 1], a.B, j > 0,
+                     (int)blockIdx.x, (int)gridDim.x);
+    }
 }
 
 // train_gen_step as row-tile chains (egm_chain_bnn.h) + its gradient / Adam launch
