@@ -204,6 +204,9 @@ extern "C" int bgm_bnn_egm_disc_step(bgm_handle *h, const float *z_dev, const in
       if (ntl == 13 || ntl == 7) {
         hipLaunchKernelGGL(bnn_egm_disc_noise_kernel, dim3(ECB_NOISE_PARTS), dim3(EGM_THREADS), 0, (hipStream_t)stream_, a, e->disc_call);
         BGM_HIP_CHECK(hipGetLastError());
+      } else if (!std::getenv("BGM_BNN_STEP_ONE_LAUNCH")) {      // general encoder: its call's eps / dW over the chip
+        a.wide = 1;
+        hipLaunchKernelGGL(bnn_egm_disc_noise_wide_kernel, dim3(16), dim3(EGM_THREADS), 0, (hipStream_t)stream_, a, 0);
       }
       hipLaunchKernelGGL(kc, dim3(1), dim3(EGM_THREADS), bytes, (hipStream_t)stream_, a, e->disc_call);
       BGM_HIP_CHECK(hipGetLastError());
@@ -211,6 +214,10 @@ extern "C" int bgm_bnn_egm_disc_step(bgm_handle *h, const float *z_dev, const in
     }
   }
   auto k = bnn_egm_disc_step_kernel;
+  if (!std::getenv("BGM_BNN_STEP_ONE_LAUNCH")) {
+    a.wide = 1;
+    hipLaunchKernelGGL(bnn_egm_disc_noise_wide_kernel, dim3(16), dim3(EGM_THREADS), 0, (hipStream_t)stream_, a, 1);
+  }
   BGM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
   hipLaunchKernelGGL(k, dim3(1), dim3(EGM_THREADS), e->lds_bytes, (hipStream_t)stream_, a);
   BGM_HIP_CHECK(hipGetLastError());

@@ -32,6 +32,31 @@ struct BnnEgmArgs {
   int wide;                              // general generator step: eps / dW of the nine calls by bnn_egm_gen_noise_wide_kernel, Adam by its own launch
 };
 
+// eps and dW = sigma * eps of the discriminator step's one noisy encoder call, over the chip (general encoder widths): the call cache
+// sits behind the gathered covariates (and, in bnn_egm_disc_step_kernel's workspace, behind zhat); same draws as bnn_noise
+static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_disc_noise_wide_kernel(BnnEgmArgs a, int with_zhat) {
+  const BnnNet &n = a.net[BNN_E];
+  float *wp = a.ws;
+  auto take = [&](int cnt) { float *r = wp; wp += (cnt + 3) & ~3; return r; };
+  float *vb = take(a.B * a.p);
+  if (with_zhat) take(a.B * a.q);
+  BnnCache k;
+  bnn_cache(n, a.B, wp, k, vb);
+  for (int l = 0; l < n.n_layers; ++l) {
+    const int cnt = n.lin[l] * n.lout[l];
+    const float *rho = a.theta + n.woff[l] + cnt;
+    float *e = k.eps + n.eoff[l], *d = k.dW + n.eoff[l];
+    for (int i = blockIdx.x * EGM_THREADS + threadIdx.x; i < (cnt + 3) >> 2; i += gridDim.x * EGM_THREADS) {
+      const f32x4 z = box_muller4(philox4x32_10((uint32_t)i, (uint32_t)l | ((uint32_t)n.net_id << 16), a.stream, BNN_TAG_EPS, a.k0, a.k1));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = 4 * i + u;
+        if (idx < cnt) { e[idx] = z[u]; d[idx] = (BNN_SCALE_EPS + softplus_acc(rho[idx])) * z[u]; }
+      }
+    }
+  }
+}
+
 static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_disc_step_kernel(BnnEgmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float egm_lds[];
   EgmCtx c{(int)threadIdx.x, egm_lds};
@@ -44,7 +69,7 @@ static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_disc_step_kernel(B
   __syncthreads();
   BnnCache ke;
   bnn_cache(a.net[BNN_E], B, wp, ke, vb);
-  float *z_ = bnn_fwd(cb, a.theta, a.net[BNN_E], ke, B, a.k0, a.k1, a.stream, a.row0);     // noisy encoder call (fixed in this step)
+  float *z_ = bnn_fwd(cb, a.theta, a.net[BNN_E], ke, B, a.k0, a.k1, a.stream, a.row0, a.wide != 0);     // noisy encoder call (fixed in this step)
   for (int k = c.tid; k < B * q; k += EGM_THREADS) zhat[k] = a.z[k] * a.eps + z_[k] * (1.0f - a.eps);
   __syncthreads();
   float *arena = a.disc_lds ? (egm_lds + 64) : wp;
@@ -113,7 +138,7 @@ static __global__ __launch_bounds__(EGM_THREADS) void bnn_egm_disc_chain_kernel(
     __syncthreads();
     BnnCache ke;
     bnn_cache(a.net[BNN_E], B, wp, ke, vb);
-    const float *z_ = bnn_fwd(cb, a.theta, a.net[BNN_E], ke, B, a.k0, a.k1, a.stream, a.row0);     // noisy encoder call (fixed in this step)
+    const float *z_ = bnn_fwd(cb, a.theta, a.net[BNN_E], ke, B, a.k0, a.k1, a.stream, a.row0, a.wide != 0);     // noisy encoder call (fixed in this step)
     for (int k = tid; k < ZW * B; k += EGM_THREADS) { const int b = k / ZW, i = k - b * ZW; const float t = z_[b * q + min(i, q - 1)]; M.zt[k] = i < q ? t : 0.0f; }
     ech_fill_params<T1, T2, T3, T0>(M.par, P, a.theta_d, a.dz, tid, EGM_THREADS);
     __syncthreads();
