@@ -66,9 +66,9 @@ extern "C" int bgm_bvn_begin(bgm_handle *h, const bgm_bvn_config *cfg, const flo
   for (int i = 0; i <= s->net.n_layers; ++i) wmax = std::max(wmax, s->net.dims[i]);
   s->wmax = wmax;
   const int B = cfg->max_batch;
-  s->ws_floats = bgmb_ws_floats(B, s->q, s->p, wmax) + bnn_cache_floats(s->net, B) + 256;
+  s->ws_floats = bgmb_ws_floats(B, s->q, s->p, wmax) + 2 * bnn_cache_floats(s->net, B) + 256;      // (the second cache: the kept upstream gradients of a wide theta step)
   const size_t np = ((size_t)s->n_params + 63) & ~(size_t)63;
-  const size_t total = 4 * np + s->ws_floats + 64;
+  const size_t total = 4 * np + s->ws_floats + 64 + 64;      // (+ 64: out, + 64: the KL partial sums of a wide theta step)
   BGM_HIP_CHECK(hipMalloc((void **)&s->dev, sizeof(float) * total));
   BGM_HIP_CHECK(hipMemset(s->dev, 0, sizeof(float) * total));
   s->theta_dev = s->dev; s->m_dev = s->dev + np; s->v_dev = s->dev + 2 * np; s->grad_dev = s->dev + 3 * np;
@@ -147,7 +147,21 @@ extern "C" int bgm_bvn_theta_step(bgm_handle *h, const float *x_dev, float *data
   a.apply = apply ? 1 : 0;
   a.kl_weight *= (float)batch / (float)batch_global;      // data parallel: the ranks' gradients are summed, the KL term counts once
   if (apply) { s->t_theta += 1; a.adam = BnnAdam{bvn_lr_t(lr, s->t_theta), BGMB_ADAM_B1, BGMB_ADAM_B2, BGMB_ADAM_EPS}; }
-  hipLaunchKernelGGL(bgmb_theta_step_kernel, dim3(1), dim3(BNN_THREADS), 0, (hipStream_t)stream_, a);
+  // one workgroup walks the call; the elementwise parts (eps / dW, KL terms, Adam) and the parameter-gradient tiles run over the chip
+  // around it -- same arithmetic per element / tile.  BGM_BNN_STEP_ONE_LAUNCH: everything inside the one workgroup.
+  static const bool one_launch = std::getenv("BGM_BNN_STEP_ONE_LAUNCH") != nullptr;
+  a.wide = one_launch ? 0 : 1;
+  a.kl_part = s->out_dev + 64;
+  hipStream_t st = (hipStream_t)stream_;
+  if (a.wide) hipLaunchKernelGGL(bgmb_noise_kernel, dim3(16), dim3(BNN_THREADS), 0, st, a);
+  hipLaunchKernelGGL(bgmb_theta_step_kernel, dim3(1), dim3(BNN_THREADS), 0, st, a);
+  if (a.wide) {
+    hipLaunchKernelGGL(bgmb_dw_kernel, dim3(16), dim3(BNN_THREADS), 0, st, a);
+    hipLaunchKernelGGL(bgmb_kl_kernel, dim3(BNN_KL_PARTS), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(bgmb_kl_finish_kernel, dim3(1), dim3(64), 0, st, a);
+    if (a.apply)
+      hipLaunchKernelGGL(bnn_adam_kernel, dim3((s->n_params + 255) / 256), dim3(256), 0, st, s->theta_dev, s->m_dev, s->v_dev, s->grad_dev, s->n_params, a.adam);
+  }
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;
 }
@@ -185,6 +199,8 @@ extern "C" int bgm_bvn_z_step(bgm_handle *h, const float *x_dev, float *data_z_d
   BGM_HIP_CHECK(hipSetDevice(h->device));
   s->t_z += 1;
   a.z_lr_t = bvn_lr_t(lr_z, s->t_z); a.z_b1 = BGMB_ADAM_B1; a.z_b2 = BGMB_ADAM_B2; a.z_eps = BGMB_ADAM_EPS;
+  a.wide = std::getenv("BGM_BNN_STEP_ONE_LAUNCH") ? 0 : 1;
+  if (a.wide) hipLaunchKernelGGL(bgmb_noise_kernel, dim3(16), dim3(BNN_THREADS), 0, (hipStream_t)stream_, a);
   hipLaunchKernelGGL(bgmb_z_step_kernel, dim3(1), dim3(BNN_THREADS), 0, (hipStream_t)stream_, a);
   BGM_HIP_CHECK(hipGetLastError());
   return BGM_OK;

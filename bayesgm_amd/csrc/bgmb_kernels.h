@@ -83,6 +83,10 @@ struct BgmbArgs {
   float z_lr_t, z_b1, z_b2, z_eps;       // fresh-slot Adam of the batch latents (bgm/base.py:402)
   float *ws;
   float *out;                            // theta: [loss_x + kl_weight KL, loss_mse];  z: [loss_postrior_z]
+  // steps spread over the chip (bgmb_api.hip): the call's eps / dW by bgmb_noise_kernel, and for the theta step the parameter-gradient
+  // tiles (bgmb_dw_kernel), the KL terms (bgmb_kl_kernel / bgmb_kl_finish_kernel) and Adam (bnn_adam_kernel) behind the step kernel
+  int wide;
+  float *kl_part;                        // [BNN_KL_PARTS]
 };
 
 struct BgmbWs { float *zb, *xb, *d, *ds, *t0, *t1, *ll, *dx; };
@@ -111,20 +115,102 @@ static __global__ __launch_bounds__(BNN_THREADS) void bgmb_theta_step_kernel(Bgm
   __syncthreads();
   BnnCache k;
   bnn_cache(n, B, wp, k, w.zb);
-  const float *o = bnn_fwd(c, a.theta, n, k, B, a.k0, a.k1, a.stream);
-  float sq = bgmb_cells(c, o, w.xb, B, p, a.inv_B, w.d, w.ll);
+  float *G = nullptr, *GS = nullptr, *d = w.d, *ds = w.ds;
+  if (a.wide) {      // every layer's upstream gradient stays (in a second call cache) for bgmb_dw_kernel
+    BnnCache k2;
+    bnn_cache(n, B, wp, k2, nullptr);
+    G = k2.H; GS = k2.HS;
+    d = G + (long long)B * n.hoff[n.n_layers - 1]; ds = GS + (long long)B * n.hoff[n.n_layers - 1];
+  }
+  const float *o = bnn_fwd(c, a.theta, n, k, B, a.k0, a.k1, a.stream, 0u, a.wide != 0);
+  float sq = bgmb_cells(c, o, w.xb, B, p, a.inv_B, d, w.ll);
   sq = bnn_block_sum(c, sq);
   bgmb_row_sums(c, w.ll, B, p, nullptr, 0, rowv);
   __syncthreads();
   float loss = 0.0f;
   for (int b = 0; b < B; ++b) loss += rowv[b];
-  bnn_bwd(c, a.theta, a.grad, n, k, w.d, w.ds, w.t0, w.t1, nullptr, B, true, false);
-  const float klv = bnn_kl(c, a.theta, a.grad, n, a.kl_weight);
+  bnn_bwd(c, a.theta, a.grad, n, k, d, ds, w.t0, w.t1, nullptr, B, true, false, G, GS);
+  const float klv = a.wide ? 0.0f : bnn_kl(c, a.theta, a.grad, n, a.kl_weight);
   __syncthreads();
   bnn_bn_move(c, a.theta, n, k);
   __syncthreads();
-  if (a.apply) bnn_adam(c, a.theta + n.off, a.m + n.off, a.v + n.off, a.grad + n.off, n.n_params, a.adam);
+  if (a.apply && !a.wide) bnn_adam(c, a.theta + n.off, a.m + n.off, a.v + n.off, a.grad + n.off, n.n_params, a.adam);
   if (c.tid == 0 && a.out) { a.out[0] = loss * a.inv_B + a.kl_weight * klv; a.out[1] = sq / (float)(B * p); }
+}
+
+// ---- the elementwise parts and the gradient tiles of a step, over the chip (the step kernels are one workgroup) ----------------------
+// eps and dW = sigma * eps of the step's call, written into the call cache of the step kernel (same pointer arithmetic); grid (parts)
+static __global__ __launch_bounds__(BNN_THREADS) void bgmb_noise_kernel(BgmbArgs a) {
+  const BnnNet &n = a.net;
+  float *wp = a.ws;
+  BgmbWs w;
+  bgmb_take(wp, w, a.B, a.q, a.p, a.wmax);
+  BnnCache k;
+  bnn_cache(n, a.B, wp, k, w.zb);
+  for (int l = 0; l < n.n_layers; ++l) {
+    const int cnt = n.lin[l] * n.lout[l];
+    const float *rho = a.theta + n.woff[l] + cnt;
+    float *e = k.eps + n.eoff[l], *d = k.dW + n.eoff[l];
+    for (int i = blockIdx.x * BNN_THREADS + threadIdx.x; i < (cnt + 3) >> 2; i += gridDim.x * BNN_THREADS) {
+      const f32x4 z = box_muller4(philox4x32_10((uint32_t)i, (uint32_t)l | ((uint32_t)n.net_id << 16), a.stream, BNN_TAG_EPS, a.k0, a.k1));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = 4 * i + u;
+        if (idx < cnt) { e[idx] = z[u]; d[idx] = (BNN_SCALE_EPS + softplus_acc(rho[idx])) * z[u]; }
+      }
+    }
+  }
+}
+// the parameter-gradient tiles of all layers (trunk and both heads) behind bgmb_theta_step_kernel; grid (parts)
+static __global__ __launch_bounds__(BNN_THREADS) void bgmb_dw_kernel(BgmbArgs a) {
+  __shared__ float red[32];
+  BnnCtx c{(int)threadIdx.x, red};
+  const BnnNet &n = a.net;
+  float *wp = a.ws;
+  BgmbWs w;
+  bgmb_take(wp, w, a.B, a.q, a.p, a.wmax);
+  BnnCache k, k2;
+  bnn_cache(n, a.B, wp, k, w.zb);
+  bnn_cache(n, a.B, wp, k2, nullptr);
+  for (int l = 0; l < n.n_layers; ++l)
+    bnn_bwd_params(c, a.theta, a.grad, n, k, l, k2.H + (long long)a.B * n.hoff[l + 1], k2.HS + (long long)a.B * n.hoff[l + 1], a.B, false,
+                   (int)blockIdx.x, (int)gridDim.x);
+}
+// grad += w * dKL/dtheta as bnn_kl; the workgroup's share of sum(net.losses) -> kl_part.  grid (BNN_KL_PARTS)
+static __global__ __launch_bounds__(256) void bgmb_kl_kernel(BgmbArgs a) {
+  __shared__ float red[4];
+  const BnnNet &n = a.net;
+  const float iv = n.prior_iv, ls = n.prior_logs, w = a.kl_weight;
+  float acc = 0.0f;
+  for (int l = 0; l < n.n_layers; ++l) {
+    const int cnt = n.lin[l] * n.lout[l];
+    const float *loc = a.theta + n.woff[l], *rho = loc + cnt;
+    float *gloc = a.grad + n.woff[l], *grho = gloc + cnt;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < cnt; i += gridDim.x * 256) {
+      const float sg = BNN_SCALE_EPS + softplus_acc(rho[i]), mu = loc[i];
+      acc += -logf(sg) + 0.5f * (sg * sg + mu * mu) * iv - 0.5f + ls;
+      gloc[i] += w * mu * iv;
+      grho[i] += w * (-1.0f / sg + sg * iv) * sigmoid_f(rho[i]);
+    }
+    if (n.bias_prior) {
+      const float *b = rho + cnt;
+      float *gb = grho + cnt;
+      for (int i = blockIdx.x * 256 + threadIdx.x; i < n.lout[l]; i += gridDim.x * 256) {
+        acc += 0.5f * b[i] * b[i] * iv + ls + 0.9189385332046727f;
+        gb[i] += w * b[i] * iv;
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) a.kl_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+static __global__ void bgmb_kl_finish_kernel(BgmbArgs a) {
+  if (threadIdx.x != 0 || !a.out) return;
+  float t = 0.0f;
+  for (int i = 0; i < BNN_KL_PARTS; ++i) t += a.kl_part[i];
+  a.out[0] += a.kl_weight * t;
 }
 
 // update_latent_variable_sgd (bgm/base.py:167-187) + the fresh-slot Adam step on the batch rows (:402)
@@ -142,7 +228,7 @@ static __global__ __launch_bounds__(BNN_THREADS) void bgmb_z_step_kernel(BgmbArg
   __syncthreads();
   BnnCache k;
   bnn_cache(n, B, wp, k, w.zb);
-  const float *o = bnn_fwd(c, a.theta, n, k, B, a.k0, a.k1, a.stream);
+  const float *o = bnn_fwd(c, a.theta, n, k, B, a.k0, a.k1, a.stream, 0u, a.wide != 0);
   bgmb_cells(c, o, w.xb, B, p, a.inv_B, w.d, w.ll);
   __syncthreads();
   bgmb_row_sums(c, w.ll, B, p, w.zb, q, rowv);

@@ -338,9 +338,9 @@ __device__ __forceinline__ void bnn_bwd_params(const BnnCtx &c, const float *the
 __device__ __forceinline__ void bnn_bwd(const BnnCtx &c, const float *theta, float *grad, const BnnNet &n, const BnnCache &k,
                                         float *d, float *ds, float *t0, float *t1, float *dx, int B, bool want_params,
                                         bool accumulate, float *G = nullptr, float *GS = nullptr) {
-  // G, GS (nets without heads, want_params): the upstream gradients of EVERY layer are kept -- layer l's at B * hoff[l + 1] of G / GS, where
+  // G, GS (want_params): the upstream gradients of EVERY layer are kept -- layer l's at B * hoff[l + 1] of G / GS, where
   // d / ds must point for the last layer -- and the parameter-gradient tiles are left to bnn_dw_kernel (all layers at once, over the chip)
-  const bool defer = G && !n.heads && want_params;
+  const bool defer = G && want_params;      // (with heads: d / ds at B * hoff[L - 1] of G / GS -- mean head's rows, then the variance head's)
   const int L = n.n_layers, nw = BNN_THREADS / 64, wave = c.tid >> 6;
   float *cur = d, *curs = ds, *nxt = t0, *nxts = t1;
   int l_top = L - 1;
@@ -352,10 +352,11 @@ __device__ __forceinline__ void bnn_bwd(const BnnCtx &c, const float *theta, flo
       dvs[i] = dv[i] * bnn_sign(k.sg, n.swords, i / p, n.sout_w[L - 1], i % p);
     }
     __syncthreads();
-    if (want_params) {
+    if (want_params && !defer) {
       bnn_bwd_params(c, theta, grad, n, k, L - 2, d, ds, B, accumulate);
       bnn_bwd_params(c, theta, grad, n, k, L - 1, dv, dvs, B, accumulate);
     }
+    if (defer) { t0 = G + (long long)B * n.hoff[L - 2]; t1 = GS + (long long)B * n.hoff[L - 2]; }      // the trunk output's gradient stays as well
     const float *h = k.H + (long long)B * n.hin[L - 1];
     {   // variance head -> t1 (raw), then mean head adds its share, applies the activation mask of the trunk output
       const float *loc = theta + n.woff[L - 1];
