@@ -815,3 +815,27 @@ def test_as_written_semantics_stay_a_supported_mode(tmp_path, use_bnn):
         # batch statistics normalise a constant treatment column away (the reason the build's default differs): the dose-response
         # estimate does not depend on the dose in this mode
         assert np.ptp(eff) < 0.2 * (np.abs(eff).mean() + 1.0)
+
+
+def test_general_steps_over_the_chip_equal_the_one_launch_form(tmp_path):
+    """The general (any-width / any-minibatch) Bayesian training steps run their elementwise parts (the calls' eps / dW, KL terms, Adam) and
+    their parameter-gradient tiles as launches over the chip around the one-workgroup step kernels, the latent step's two noise calls on
+    workgroups of their own.  Same arithmetic per element and per tile, same order of every sum: parameters and latents of a
+    short job -- CausalBGM(use_bnn=True) at [128, 96]-type nets with the EGM warm start, BGM(use_bnn=True) -- equal those of the
+    one-launch form (BGM_BNN_STEP_ONE_LAUNCH=1, read once per process: two subprocesses) up to the last bits (hipcc is free to contract
+    a multiply-add of the same source expression differently in two kernels: 3e-7 on parameters of order one after the job)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for tag, extra in (("chip", {}), ("one", {"BGM_BNN_STEP_ONE_LAUNCH": "1"})):
+        out = str(tmp_path / ("steps_%s.npz" % tag))
+        env = dict(os.environ)
+        env.pop("BGM_BNN_STEP_ONE_LAUNCH", None)
+        env.update(extra)
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "_wide_steps_helper.py"), out], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    a, b = outs
+    for key in ("causal_theta", "causal_z", "bgm_theta", "bgm_z"):
+        assert np.isfinite(a[key]).all()
+        assert np.abs(a[key] - b[key]).max() < 5e-6, (key, float(np.abs(a[key] - b[key]).max()))
