@@ -320,7 +320,7 @@ static void bnn_theta_launch(BnnState *s, BnnArgs &a, int batch, int parts, hipS
   } else {
     // general widths: one workgroup per net walks the layer products; the elementwise parts (the call's eps / dW, the KL terms, the Adam
     // step: half of the step's time at [256] x 3 when the one workgroup did them too) run as their own launches over the chip.
-    // parts & 1 reads the parameters (noise, step kernel, KL terms -> gradient), parts & 2 writes them (Adam).
+    // parts & 1 reads the parameters (noise, step kernel, gradient tiles), parts & 2 writes them (KL gradients + Adam in one launch).
     // BGM_BNN_STEP_ONE_LAUNCH: the one-launch phase machine, at the point of the parameter write.
     static const bool one_launch = std::getenv("BGM_BNN_STEP_ONE_LAUNCH") != nullptr;
     a.wide = (!one_launch && s->kl_part_dev) ? 1 : 0;
@@ -333,16 +333,10 @@ static void bnn_theta_launch(BnnState *s, BnnArgs &a, int batch, int parts, hipS
       hipLaunchKernelGGL(bnn_step_noise_kernel, dim3(BNN_NOISE_PARTS, 3, 1), dim3(BNN_THREADS), 0, st, a, 4, 0);
       hipLaunchKernelGGL(bnn_theta_step_kernel, dim3(3), dim3(BNN_THREADS), 0, st, a);
       hipLaunchKernelGGL(bnn_dw_kernel, dim3(BNN_DW_PARTS, 3), dim3(BNN_THREADS), 0, st, a);      // the parameter-gradient tiles of all layers
-      hipLaunchKernelGGL(bnn_kl_kernel, dim3(BNN_KL_PARTS, 3), dim3(256), 0, st, a);
-      hipLaunchKernelGGL(bnn_kl_finish_kernel, dim3(1), dim3(64), 0, st, a);
     }
-    if (parts & 2) {
-      if (a.apply)
-        for (int k : {BNN_G, BNN_H, BNN_F}) {
-          const BnnNet &n = s->net[k];
-          hipLaunchKernelGGL(bnn_adam_kernel, dim3((n.n_params + 255) / 256), dim3(256), 0, st, s->theta_dev + n.off, s->m_dev + n.off, s->v_dev + n.off,
-                             s->grad_dev + n.off, n.n_params, a.adam);
-        }
+    if (parts & 2) {      // KL gradients and (apply) Adam of every parameter: one launch; the KL terms join the reported losses
+      hipLaunchKernelGGL(bnn_kl_adam_kernel, dim3(BNN_KL_PARTS, 3), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(bnn_kl_finish_kernel, dim3(1), dim3(64), 0, st, a);
     }
 #ifdef BNN_PROF
     static int calls = 0;
@@ -352,6 +346,12 @@ static void bnn_theta_launch(BnnState *s, BnnArgs &a, int batch, int parts, hipS
       hipMemcpyFromSymbol(acc, HIP_SYMBOL(bnn_prof_acc), sizeof(acc));
       hipMemcpyToSymbol(HIP_SYMBOL(bnn_prof_acc), zero, sizeof(zero));
       double tot = 0; for (int i = 0; i < 7; ++i) tot += (double)acc[i];
+      unsigned long long sp[8];
+      hipMemcpyFromSymbol(sp, HIP_SYMBOL(bnn_prof_span), sizeof(sp));
+      fprintf(stderr, "BNN_PROF last call, workgroups g / h / f on the 100 MHz counter: start +%.1f +%.1f +%.1f us, end +%.1f +%.1f +%.1f us after g's start\n",
+              0.0, ((double)sp[2] - (double)sp[0]) / 100.0, ((double)sp[4] - (double)sp[0]) / 100.0, ((double)sp[1] - (double)sp[0]) / 100.0,
+              ((double)sp[3] - (double)sp[0]) / 100.0, ((double)sp[5] - (double)sp[0]) / 100.0);
+      fprintf(stderr, "BNN_PROF shader clock during the kernel: %.2f GHz (%.1f us per call on the 100 MHz counter)\n", tot / ((double)acc[7] * 10.0), (double)acc[7] / 100.0 / 100.0);
       fprintf(stderr, "BNN_PROF theta step of g (100 calls, %.0f cycles each): gather %.3f noise %.3f forward %.3f loss %.3f backward %.3f KL %.3f Adam %.3f\n",
               tot / 100, acc[0] / tot, acc[1] / tot, acc[2] / tot, acc[3] / tot, acc[4] / tot, acc[5] / tot, acc[6] / tot);
     }

@@ -505,12 +505,12 @@ struct BnnArgs {
   float *dz;                             // z step: [B x q] gradient w.r.t. the batch rows of data_z
   float sig2[3];                         // fixed sigma_v^2, sigma_x^2, sigma_y^2 (params['sigma_*']); <= 0: the net's variance head
   // general (any-width) steps spread over the chip (bnn_api.hip): 1 = eps / dW of the calls were written by bnn_step_noise_kernel (the
-  // step kernels draw the sign words only), the KL terms and the Adam step follow in their own launches (bnn_kl_kernel, bnn_adam_kernel)
+  // step kernels draw the sign words only), the KL terms and the Adam step follow in their own launches (bnn_kl_adam_kernel)
   int wide;
   float *kl_part;                        // [3][BNN_KL_PARTS] partial sums of the nets' KL terms
 };
 #define BNN_KL_PARTS 32
-#define BNN_NOISE_PARTS 16
+#define BNN_NOISE_PARTS 48
 
 // gather the minibatch: zb [B x q], vb [B x p], xb, yb [B], f input [B x nf], h input [B x nh]
 struct BnnBatch { float *zb, *vb, *xb, *yb, *fin, *hin; };
@@ -564,9 +564,13 @@ __device__ __forceinline__ float bnn_gauss(float ssq, float raw, float dim, floa
 
 // update_g_net, update_h_net, update_f_net (causalbgm/base.py:156-243) with use_bnn: the three updates are independent
 // given the batch (each reads the latents of BEFORE the step), so one launch does all three, one workgroup per net.
-#ifdef BNN_PROF      // development: shader-clock cycles of wave 0 of g's workgroup per phase of the general theta step (bnn_api.hip prints them)
+#ifdef BNN_PROF      // development: shader-clock cycles of wave 0 of one net's workgroup (BNN_PROF_WG: 0 g, 1 h, 2 f) per phase of the general theta step (bnn_api.hip prints them)
+#ifndef BNN_PROF_WG
+#define BNN_PROF_WG 0
+#endif
 __device__ unsigned long long bnn_prof_acc[8];
-#define BNN_T(i) do { const unsigned long long t2_ = __builtin_amdgcn_s_memtime(); if (c.tid == 0 && blockIdx.x == 0) atomicAdd(&bnn_prof_acc[i], t2_ - bnn_t_); bnn_t_ = t2_; } while (0)
+__device__ unsigned long long bnn_prof_span[8];
+#define BNN_T(i) do { const unsigned long long t2_ = __builtin_amdgcn_s_memtime(); if (c.tid == 0 && blockIdx.x == BNN_PROF_WG) atomicAdd(&bnn_prof_acc[i], t2_ - bnn_t_); bnn_t_ = t2_; } while (0)
 #else
 #define BNN_T(i) do {} while (0)
 #endif
@@ -580,6 +584,7 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_step_kernel(BnnA
   BnnBatch bt;
 #ifdef BNN_PROF
   unsigned long long bnn_t_ = __builtin_amdgcn_s_memtime();
+  const unsigned long long bnn_rt0_ = wall_clock64();      // (the constant 100 MHz counter: what the shader clock was during the kernel)
 #endif
   bnn_gather(c, a, wp, bt);
   BNN_T(0);
@@ -649,11 +654,15 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_step_kernel(BnnA
     BNN_T(3);
     bnn_bwd(c, a.theta, a.grad, n, k, d, ds, t0, t1, nullptr, B, true, false, G, GS);
     BNN_T(4);
-    const float klv = a.wide ? 0.0f : bnn_kl(c, a.theta, a.grad, n, a.kl_weight);      // (wide: bnn_kl_kernel / bnn_kl_finish_kernel)
+    const float klv = a.wide ? 0.0f : bnn_kl(c, a.theta, a.grad, n, a.kl_weight);      // (wide: bnn_kl_adam_kernel / bnn_kl_finish_kernel)
     __syncthreads();
     BNN_T(5);
     if (a.apply && !a.wide) bnn_adam(c, a.theta + n.off, a.m + n.off, a.v + n.off, a.grad + n.off, n.n_params, a.adam);
     BNN_T(6);
+#ifdef BNN_PROF
+    if (c.tid == 0 && blockIdx.x == BNN_PROF_WG) atomicAdd(&bnn_prof_acc[7], wall_clock64() - bnn_rt0_);
+    if (c.tid == 0) { bnn_prof_span[2 * blockIdx.x] = bnn_rt0_; bnn_prof_span[2 * blockIdx.x + 1] = wall_clock64(); }      // (last call's start / end of each workgroup)
+#endif
     if (c.tid == 0 && a.out) { a.out[2 * which] = loss + a.kl_weight * klv; a.out[2 * which + 1] = aux; }
     __syncthreads();
   }
@@ -915,7 +924,7 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_step_noise_kernel(BnnA
 // the parameter-gradient tiles of a general theta step (d loc, d rho, d bias of every Flipout layer of g, h, f), left by the step kernel:
 // the layers' inputs are in the call cache, their upstream gradients in G / GS (bnn_bwd).  grid (BNN_DW_PARTS, 3 nets): the tiles of a
 // layer over all waves of the net's workgroups, the same arithmetic per tile as bnn_bwd_params inside the step kernel.
-#define BNN_DW_PARTS 16
+#define BNN_DW_PARTS 48
 static __global__ __launch_bounds__(BNN_THREADS) void bnn_dw_kernel(BnnArgs a) {
   __shared__ float red[32];
   BnnCtx c{(int)threadIdx.x, red};
@@ -933,33 +942,41 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_dw_kernel(BnnArgs a) {
     bnn_bwd_params(c, a.theta, a.grad, n, k, l, k2.H + (long long)a.B * n.hoff[l + 1], k2.HS + (long long)a.B * n.hoff[l + 1], a.B, false,
                    (int)blockIdx.x, (int)gridDim.x);
 }
-// grad += w * dKL/dtheta as bnn_kl, a slice of every layer per workgroup; the slice's share of sum(net.losses) -> kl_part.
-// grid (BNN_KL_PARTS, 3 nets)
-static __global__ __launch_bounds__(256) void bnn_kl_kernel(BnnArgs a) {
+// grad += w * dKL/dtheta as bnn_kl (a slice of every layer per workgroup, the slice's share of sum(net.losses) -> kl_part) and, with
+// a.apply, the Adam step of every parameter of g, h, f in the same launch: an element's KL gradient and its
+// Adam step are the same thread's (no ordering between workgroups needed); the parameters the KL terms do not touch (gamma, beta, the
+// moving statistics, the biases without a prior) take their step in a second loop.  grid (BNN_KL_PARTS, 3 nets)
+static __global__ __launch_bounds__(256) void bnn_kl_adam_kernel(BnnArgs a) {
   __shared__ float red[4];
   const int which = blockIdx.y, id = which == 0 ? BNN_G : (which == 1 ? BNN_H : BNN_F);
   const BnnNet &n = a.net[id];
   const float iv = n.prior_iv, ls = n.prior_logs, w = a.kl_weight;
+  const int gt = blockIdx.x * 256 + threadIdx.x, gs = gridDim.x * 256;
+  auto adam = [&](int j) {      // parameter j of the flat vector
+    const BnnAdamOut o = bnn_adam_one(a.theta[j], a.m[j], a.v[j], a.grad[j], a.adam);
+    a.m[j] = o.m; a.v[j] = o.v; a.theta[j] = o.th;
+  };
   float acc = 0.0f;
   for (int l = 0; l < n.n_layers; ++l) {
-    const int cnt = n.lin[l] * n.lout[l];
-    const float *loc = a.theta + n.woff[l], *rho = loc + cnt;
-    float *gloc = a.grad + n.woff[l], *grho = gloc + cnt;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < cnt; i += gridDim.x * 256) {
-      const float sg = BNN_SCALE_EPS + softplus_acc(rho[i]), mu = loc[i];
+    const int cnt = n.lin[l] * n.lout[l], o_loc = n.woff[l], o_rho = o_loc + cnt, o_b = o_rho + cnt;
+    for (int i = gt; i < cnt; i += gs) {
+      const float rho = a.theta[o_rho + i], mu = a.theta[o_loc + i];
+      const float sg = BNN_SCALE_EPS + softplus_acc(rho);
       acc += -logf(sg) + 0.5f * (sg * sg + mu * mu) * iv - 0.5f + ls;
-      gloc[i] += w * mu * iv;
-      grho[i] += w * (-1.0f / sg + sg * iv) * sigmoid_f(rho[i]);
+      a.grad[o_loc + i] += w * mu * iv;
+      a.grad[o_rho + i] += w * (-1.0f / sg + sg * iv) * sigmoid_f(rho);
+      if (a.apply) { adam(o_loc + i); adam(o_rho + i); }
     }
-    if (n.bias_prior) {
-      const float *b = rho + cnt;
-      float *gb = grho + cnt;
-      for (int i = blockIdx.x * 256 + threadIdx.x; i < n.lout[l]; i += gridDim.x * 256) {
-        acc += 0.5f * b[i] * b[i] * iv + ls + 0.9189385332046727f;
-        gb[i] += w * b[i] * iv;
+    for (int i = gt; i < n.lout[l]; i += gs) {
+      if (n.bias_prior) {
+        const float b = a.theta[o_b + i];
+        acc += 0.5f * b * b * iv + ls + 0.9189385332046727f;
+        a.grad[o_b + i] += w * b * iv;
       }
+      if (a.apply) adam(o_b + i);
     }
   }
+  if (a.apply) for (int i = gt; i < (n.mv ? 4 : 2) * n.dims[0]; i += gs) adam(n.off + i);      // gamma, beta (, moving mean, moving variance)
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();

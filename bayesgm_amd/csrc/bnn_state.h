@@ -19,7 +19,7 @@ struct BnnState {
         *dz_dev = nullptr, *dz_part_dev = nullptr;
   long long ws_stride = 0;
   size_t ws_floats = 0;
-  float *kl_part_dev = nullptr;      // partial KL sums of the general theta step (bnn_kl_kernel)
+  float *kl_part_dev = nullptr;      // partial KL sums of the general theta step (bnn_kl_adam_kernel)
   long long t_theta = 0, t_z = 0;
   int *tlast_dev = nullptr;    // replay mode of the latent Adam (bgm_bnn_z_sync): step each row's (z, m, v) are current to
   long long tlast_rows = 0, z_synced = -1;
