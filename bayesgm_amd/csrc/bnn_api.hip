@@ -287,6 +287,28 @@ static void bnn_base_args(BnnState *s, BnnArgs &a, int batch, int batch_global, 
   a.dz_part = s->dz_part_dev; a.loss_part = s->dz_part_dev + 6 * (size_t)s->cfg.max_batch * s->q;
 }
 
+#ifdef BNN_PROF
+// development: every 100 launches of bnn_theta_step_kernel, where the profiled workgroup's cycles went (bnn_kernels.h BNN_T)
+static void bnn_prof_report(hipStream_t st) {
+  static int calls = 0;
+  if (++calls % 100) return;
+  unsigned long long acc[8], zero[8] = {0}, sp[8];
+  hipStreamSynchronize(st);
+  hipMemcpyFromSymbol(acc, HIP_SYMBOL(bnn_prof_acc), sizeof(acc));
+  hipMemcpyToSymbol(HIP_SYMBOL(bnn_prof_acc), zero, sizeof(zero));
+  hipMemcpyFromSymbol(sp, HIP_SYMBOL(bnn_prof_span), sizeof(sp));
+  double tot = 0; for (int i = 0; i < 7; ++i) tot += (double)acc[i];
+  fprintf(stderr, "BNN_PROF last call, workgroups g / h / f on the 100 MHz counter: start +%.1f +%.1f +%.1f us, end +%.1f +%.1f +%.1f us after g's start\n",
+          0.0, ((double)sp[2] - (double)sp[0]) / 100.0, ((double)sp[4] - (double)sp[0]) / 100.0, ((double)sp[1] - (double)sp[0]) / 100.0,
+          ((double)sp[3] - (double)sp[0]) / 100.0, ((double)sp[5] - (double)sp[0]) / 100.0);
+  fprintf(stderr, "BNN_PROF shader clock during the kernel: %.2f GHz (%.1f us per call on the 100 MHz counter)\n", tot / ((double)acc[7] * 10.0), (double)acc[7] / 100.0 / 100.0);
+  fprintf(stderr, "BNN_PROF theta step, workgroup %d (100 calls, %.0f cycles each): gather %.3f noise %.3f forward %.3f loss %.3f backward %.3f KL %.3f Adam %.3f\n",
+          BNN_PROF_WG, tot / 100, acc[0] / tot, acc[1] / tot, acc[2] / tot, acc[3] / tot, acc[4] / tot, acc[5] / tot, acc[6] / tot);
+}
+#else
+static void bnn_prof_report(hipStream_t) {}
+#endif
+
 // The launches of one theta step.  parts & 1: noise + forward / backward chains (read the parameters); parts & 2: the gradient tiles
 // and, with a.apply, the Adam step on them (write the parameters).  bgm_bnn_fit_epoch puts a stream dependency between the two.
 static void bnn_theta_launch(BnnState *s, BnnArgs &a, int batch, int parts, hipStream_t st) {
@@ -326,7 +348,7 @@ static void bnn_theta_launch(BnnState *s, BnnArgs &a, int batch, int parts, hipS
     a.wide = (!one_launch && s->kl_part_dev) ? 1 : 0;
     a.kl_part = s->kl_part_dev;
     if (!a.wide) {
-      if (parts & 2) hipLaunchKernelGGL(bnn_theta_step_kernel, dim3(3), dim3(BNN_THREADS), 0, st, a);
+      if (parts & 2) { hipLaunchKernelGGL(bnn_theta_step_kernel, dim3(3), dim3(BNN_THREADS), 0, st, a); bnn_prof_report(st); }
       return;
     }
     if (parts & 1) {
@@ -338,24 +360,7 @@ static void bnn_theta_launch(BnnState *s, BnnArgs &a, int batch, int parts, hipS
       hipLaunchKernelGGL(bnn_kl_adam_kernel, dim3(BNN_KL_PARTS, 3), dim3(256), 0, st, a);
       hipLaunchKernelGGL(bnn_kl_finish_kernel, dim3(1), dim3(64), 0, st, a);
     }
-#ifdef BNN_PROF
-    static int calls = 0;
-    if (++calls % 100 == 0) {
-      unsigned long long acc[8], zero[8] = {0};
-      hipStreamSynchronize(st);
-      hipMemcpyFromSymbol(acc, HIP_SYMBOL(bnn_prof_acc), sizeof(acc));
-      hipMemcpyToSymbol(HIP_SYMBOL(bnn_prof_acc), zero, sizeof(zero));
-      double tot = 0; for (int i = 0; i < 7; ++i) tot += (double)acc[i];
-      unsigned long long sp[8];
-      hipMemcpyFromSymbol(sp, HIP_SYMBOL(bnn_prof_span), sizeof(sp));
-      fprintf(stderr, "BNN_PROF last call, workgroups g / h / f on the 100 MHz counter: start +%.1f +%.1f +%.1f us, end +%.1f +%.1f +%.1f us after g's start\n",
-              0.0, ((double)sp[2] - (double)sp[0]) / 100.0, ((double)sp[4] - (double)sp[0]) / 100.0, ((double)sp[1] - (double)sp[0]) / 100.0,
-              ((double)sp[3] - (double)sp[0]) / 100.0, ((double)sp[5] - (double)sp[0]) / 100.0);
-      fprintf(stderr, "BNN_PROF shader clock during the kernel: %.2f GHz (%.1f us per call on the 100 MHz counter)\n", tot / ((double)acc[7] * 10.0), (double)acc[7] / 100.0 / 100.0);
-      fprintf(stderr, "BNN_PROF theta step of g (100 calls, %.0f cycles each): gather %.3f noise %.3f forward %.3f loss %.3f backward %.3f KL %.3f Adam %.3f\n",
-              tot / 100, acc[0] / tot, acc[1] / tot, acc[2] / tot, acc[3] / tot, acc[4] / tot, acc[5] / tot, acc[6] / tot);
-    }
-#endif
+    if (parts & 1) bnn_prof_report(st);
   }
 }
 
