@@ -353,7 +353,10 @@ static void bnn_theta_launch(BnnState *s, BnnArgs &a, int batch, int parts, hipS
     }
     if (parts & 1) {
       hipLaunchKernelGGL(bnn_step_noise_kernel, dim3(BNN_NOISE_PARTS, 3, 1), dim3(BNN_THREADS), 0, st, a, 4, 0);
-      hipLaunchKernelGGL(bnn_theta_step_kernel, dim3(3), dim3(BNN_THREADS), 0, st, a);
+      static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(bnn_theta_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)BNN_R32_LDS_BYTES) == hipSuccess;
+      (void)lds_ok;
+      hipLaunchKernelGGL(bnn_theta_step_kernel, dim3(3), dim3(BNN_THREADS), BNN_R32_LDS_BYTES, st, a);
       hipLaunchKernelGGL(bnn_dw_kernel, dim3(BNN_DW_PARTS, 3), dim3(BNN_THREADS), 0, st, a);      // the parameter-gradient tiles of all layers
     }
     if (parts & 2) {      // KL gradients and (apply) Adam of every parameter: one launch; the KL terms join the reported losses
@@ -464,7 +467,10 @@ extern "C" int bgm_bnn_z_step(bgm_handle *h, const float *x, const float *y, con
     if (a.wide) {      // the two noise calls of a net on workgroups of their own, forward and backward as two launches
       hipLaunchKernelGGL(bnn_step_noise_kernel, dim3(BNN_NOISE_PARTS, 3, 2), dim3(BNN_THREADS), 0, stream, a, 6, 1);
       hipLaunchKernelGGL(bnn_z_fwd_kernel, dim3(6), dim3(BNN_THREADS), 0, stream, a);
-      hipLaunchKernelGGL(bnn_z_bwd_kernel, dim3(6), dim3(BNN_THREADS), 0, stream, a);
+      static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(bnn_z_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)BNN_R32_LDS_BYTES) == hipSuccess;
+      (void)lds_ok;
+      hipLaunchKernelGGL(bnn_z_bwd_kernel, dim3(6), dim3(BNN_THREADS), BNN_R32_LDS_BYTES, stream, a);
       hipLaunchKernelGGL(bnn_z_combine6_kernel, dim3((batch * s->q + 255) / 256), dim3(256), 0, stream, a.dz_part, a.loss_part, a.dz, out, batch * s->q,
                          a.data_z, a.idx, s->q, a.inv_B);
     } else {

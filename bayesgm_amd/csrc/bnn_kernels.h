@@ -163,6 +163,149 @@ __device__ __forceinline__ void bnn_gemm2(int tid, BnnMat A1, BnnMat A2, BnnMat 
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same pair of products for minibatches of up to 32 rows when BOTH operands run along K in memory -- A [M x K] row-major and the
+// weights as Wt [N x K] row-major (the input-gradient products of the backward pass: A = the upstream gradient, Wt = loc / dW as stored,
+// [in][out]) -- with all eight waves on ONE tile row: the workgroup walks K in chunks of 16 through a double-buffered LDS stage
+// (A1 | A2: 32 rows, W1 | W2: 256 columns of a pass, 36 KiB per half; every element fetched once per workgroup and pass), a wave owns a
+// 32 x 32 block of the pass = 2 x 2 tiles for each product, fragments as ds_read_b128, the schedule of a chunk as in bnw_kernels.h
+// (stage writes, fetches and fragment reads between the K steps, odd waves shifted).  16 chunks of a 256 x 256 layer instead of 4 tiles x 8
+// chunks of a lone wave each.  rowinfo(m, n0) / eleminfo(m, n): what the epilogue loads, requested before the chunk loop;
+// epi(m, n, c1, c2, row info, element info, bit = n - n0).
+// ---------------------------------------------------------------------------------------------
+#define BNN_R32_KC 16
+#define BNN_R32_NP 256
+#define BNN_R32_ROWS (2 * 32 + 2 * BNN_R32_NP)
+#define BNN_R32_STAGE_FLOATS (BNN_R32_ROWS * BNN_R32_KC)      // one half of the stage
+#define BNN_R32_LDS_BYTES (2 * BNN_R32_STAGE_FLOATS * sizeof(float))
+struct BnnR32Frag { f32x4 a1[2], a2[2], b1[2], b2[2]; };
+template <class RowInfo, class ElemInfo, class Epi>
+__device__ __forceinline__ void bnn_gemm2_rows32(int tid, float *stage, const float *A1, const float *A2, int lda, const float *W1, const float *W2,
+                                                 int ldw, int M, int N, int K, RowInfo rowinfo, ElemInfo eleminfo, Epi epi) {
+  constexpr int KC = BNN_R32_KC, SLOTS = (BNN_R32_ROWS * 4 + BNN_THREADS - 1) / BNN_THREADS;
+  const int lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6, nw = wave << 5;
+  const bool late = (wave & 1) != 0;
+  const bool vec = (lda & 3) == 0 && (ldw & 3) == 0 &&
+                   ((((unsigned long long)A1 | (unsigned long long)A2 | (unsigned long long)W1 | (unsigned long long)W2) & 15ull) == 0);
+  const int nc = (K + KC - 1) / KC;
+  auto fetch = [&](const float *p, int k) -> f32x4 {
+    if (vec && k + 3 < K) return *reinterpret_cast<const f32x4 *>(p + k);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (k + e < K) ? p[min(k + e, K - 1)] : 0.0f;
+    return v;
+  };
+  int ar[2], br[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { ar[i] = (16 * i + j) * KC + 4 * g; br[i] = (64 + nw + 16 * i + j) * KC + 4 * g; }
+  auto frags = [&](BnnR32Frag &f, const float *h) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f.a1[i] = *reinterpret_cast<const f32x4 *>(h + ar[i]); f.a2[i] = *reinterpret_cast<const f32x4 *>(h + 32 * KC + ar[i]);
+      f.b1[i] = *reinterpret_cast<const f32x4 *>(h + br[i]); f.b2[i] = *reinterpret_cast<const f32x4 *>(h + BNN_R32_NP * KC + br[i]);
+    }
+  };
+  const int fq = 4 * (tid & 3);
+  for (int np = 0; np < N; np += BNN_R32_NP) {
+    const float *fp[SLOTS];
+    int so[SLOTS];      // stage offset of the slot (-1: none)
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+      const int row = (tid + BNN_THREADS * sl) >> 2;           // stage row: A1 [0, 32) | A2 [32, 64) | W1 [64, 320) | W2 [320, 576)
+      so[sl] = row < BNN_R32_ROWS ? row * KC + fq : -1;
+      if (row < 32) fp[sl] = A1 + (long long)min(row, M - 1) * lda;
+      else if (row < 64) fp[sl] = A2 + (long long)min(row - 32, M - 1) * lda;
+      else if (row < 64 + BNN_R32_NP) fp[sl] = W1 + (long long)min(np + row - 64, N - 1) * ldw;
+      else fp[sl] = W2 + (long long)min(np + min(row, BNN_R32_ROWS - 1) - 64 - BNN_R32_NP, N - 1) * ldw;
+    }
+    f32x4 c1[2][2], c2[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2) { c1[i][i2] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; c2[i][i2] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    const bool live = np + nw < N;
+    f32x4 rg[SLOTS];
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) if (so[sl] >= 0) rg[sl] = fetch(fp[sl], fq);
+    decltype(rowinfo(0, 0)) rinfo[2][4];
+    decltype(eleminfo(0, 0)) einfo[2][2][4];
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = min(16 * i + 4 * g + r, M - 1);
+          rinfo[i][r] = rowinfo(m, np + nw);
+#pragma unroll
+          for (int i2 = 0; i2 < 2; ++i2) einfo[i][i2][r] = eleminfo(m, min(np + nw + 16 * i2 + j, N - 1));
+        }
+    }
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) if (so[sl] >= 0) *reinterpret_cast<f32x4 *>(stage + so[sl]) = rg[sl];
+    if (nc > 1) {
+#pragma unroll
+      for (int sl = 0; sl < SLOTS; ++sl) if (so[sl] >= 0) rg[sl] = fetch(fp[sl], KC + fq);
+    }
+    __syncthreads();
+    BnnR32Frag f0, f1;
+    if (live) frags(f0, stage);
+    auto step = [&](const BnnR32Frag &f, int u) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+          c1[i][i2] = BGM_MFMA(f.a1[i][u], f.b1[i2][u], c1[i][i2]);
+          c2[i][i2] = BGM_MFMA(f.a2[i][u], f.b2[i2][u], c2[i][i2]);
+        }
+    };
+    auto chunk = [&](int c, const BnnR32Frag &cur, BnnR32Frag &nxt) {
+      float *other = stage + ((c + 1) & 1) * BNN_R32_STAGE_FLOATS;
+      auto put = [&]() {
+        if (c + 1 < nc) {
+#pragma unroll
+          for (int sl = 0; sl < SLOTS; ++sl) if (so[sl] >= 0) *reinterpret_cast<f32x4 *>(other + so[sl]) = rg[sl];
+          if (c + 2 < nc) {
+            const int k = (c + 2) * KC + fq;
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl) if (so[sl] >= 0) rg[sl] = fetch(fp[sl], k);
+          }
+        }
+      };
+      if (late) put();
+      BGM_NO_HOIST();
+      if (live) step(cur, 0);
+      BGM_NO_HOIST();
+      if (!late) put();
+      BGM_NO_HOIST();
+      if (live) step(cur, 1);
+      __syncthreads();
+      if (!late && live && c + 1 < nc) frags(nxt, other);
+      BGM_NO_HOIST();
+      if (live) step(cur, 2);
+      BGM_NO_HOIST();
+      if (late && live && c + 1 < nc) frags(nxt, other);
+      BGM_NO_HOIST();
+      if (live) step(cur, 3);
+    };
+    int c = 0;
+    for (; c + 2 <= nc; c += 2) { chunk(c, f0, f1); chunk(c + 1, f1, f0); }
+    if (c < nc) chunk(c, f0, f1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): no load is outstanding (keeps per-element waits out of the epilogue)
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = 16 * i + 4 * g + r, n = np + nw + 16 * i2 + j;
+            if (m < M && n < N) epi(m, n, c1[i][i2][r], c2[i][i2][r], rinfo[i][r], einfo[i][i2][r], 16 * i2 + j);
+          }
+    }
+    __syncthreads();      // (the stage is reused by the next pass / the next product)
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // One call of a net on a batch of B rows: cache, noise, forward, backward
 // ---------------------------------------------------------------------------------------------
 struct BnnCache {
@@ -337,7 +480,8 @@ __device__ __forceinline__ void bnn_bwd_params(const BnnCtx &c, const float *the
 // receives the gradient w.r.t. the raw input (through the batch statistics).
 __device__ __forceinline__ void bnn_bwd(const BnnCtx &c, const float *theta, float *grad, const BnnNet &n, const BnnCache &k,
                                         float *d, float *ds, float *t0, float *t1, float *dx, int B, bool want_params,
-                                        bool accumulate, float *G = nullptr, float *GS = nullptr) {
+                                        bool accumulate, float *G = nullptr, float *GS = nullptr, float *stage = nullptr) {
+  // stage: LDS of BNN_R32_LDS_BYTES -- minibatches of up to 32 rows run the trunk's input-gradient products on bnn_gemm2_rows32
   // G, GS (want_params): the upstream gradients of EVERY layer are kept -- layer l's at B * hoff[l + 1] of G / GS, where
   // d / ds must point for the last layer -- and the parameter-gradient tiles are left to bnn_dw_kernel (all layers at once, over the chip)
   const bool defer = G && want_params;      // (with heads: d / ds at B * hoff[L - 1] of G / GS -- mean head's rows, then the variance head's)
@@ -398,7 +542,26 @@ __device__ __forceinline__ void bnn_bwd(const BnnCtx &c, const float *theta, flo
       const int t_w = ((in + 15) >> 4) * ((out + 15) >> 4);
       first = (wave - t_w % nw + nw) % nw;
     }
-    if (l > 0 || dx || want_params) {
+    if (stage && B <= 32 && (l > 0 || dx || want_params)) {
+      const int si = n.sin_w[l], sop = l > 0 ? n.sout_w[l - 1] : 0;
+      struct Rw { uint32_t si, sop; };
+      bnn_gemm2_rows32(c.tid, stage, cur, curs, out, loc, k.dW + n.eoff[l], out, B, in, out,
+                       [&](int m, int n0) {
+                         const uint32_t *sg = k.sg + (long long)m * n.swords + (n0 >> 5);
+                         Rw w; w.si = sg[si]; w.sop = l > 0 ? sg[sop] : 0u;
+                         return w;
+                       },
+                       [&](int m, int i) { return l > 0 ? h[(long long)m * in + i] : 1.0f; },
+                       [&](int m, int i, float c1, float c2, const Rw &w, float hv, int bit) {
+                         const long long t = (long long)m * in + i;
+                         float v = c1 + (((w.si >> bit) & 1u) ? -c2 : c2);
+                         if (l > 0) {
+                           v *= (hv > 0.0f) ? 1.0f : BNN_LEAK;
+                           nxts[t] = ((w.sop >> bit) & 1u) ? -v : v;
+                         }
+                         nxt[t] = v;
+                       });
+    } else if (l > 0 || dx || want_params) {
       const int si = n.sin_w[l], sop = l > 0 ? n.sout_w[l - 1] : 0;
       bnn_gemm2(c.tid, BnnMat{cur, out, 1}, BnnMat{curs, out, 1}, BnnMat{loc, 1, out}, BnnMat{k.dW + n.eoff[l], 1, out}, B, in, out,
                 first, nw, [&](int m, int i, float c1, float c2) {
@@ -575,6 +738,7 @@ __device__ unsigned long long bnn_prof_span[8];
 #define BNN_T(i) do {} while (0)
 #endif
 static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_step_kernel(BnnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float bnn_r32_stage[];      // BNN_R32_LDS_BYTES when a.wide (bnn_api.hip), else none
   __shared__ float red[32];
   __shared__ float ssq_row[BNN_MAX_BATCH];
   BnnCtx c{(int)threadIdx.x, red};
@@ -652,7 +816,7 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_step_kernel(BnnA
     }
     __syncthreads();
     BNN_T(3);
-    bnn_bwd(c, a.theta, a.grad, n, k, d, ds, t0, t1, nullptr, B, true, false, G, GS);
+    bnn_bwd(c, a.theta, a.grad, n, k, d, ds, t0, t1, nullptr, B, true, false, G, GS, a.wide ? bnn_r32_stage : nullptr);
     BNN_T(4);
     const float klv = a.wide ? 0.0f : bnn_kl(c, a.theta, a.grad, n, a.kl_weight);      // (wide: bnn_kl_adam_kernel / bnn_kl_finish_kernel)
     __syncthreads();
@@ -793,6 +957,7 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_z_fwd_kernel(BnnArgs a
   bnn_fwd(c, a.theta, n, z.k, a.B, a.k0, a.k1, a.stream + (uint32_t)call, 0u, true);
 }
 static __global__ __launch_bounds__(BNN_THREADS) void bnn_z_bwd_kernel(BnnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float bnn_r32_stage[];      // BNN_R32_LDS_BYTES
   __shared__ float red[32];
   __shared__ float ssq_row[BNN_MAX_BATCH];
   BnnCtx c{(int)threadIdx.x, red};
@@ -863,7 +1028,7 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_z_bwd_kernel(BnnArgs a
     }
   }
   __syncthreads();
-  bnn_bwd(c, a.theta, a.grad, n, z.k, d, z.ds, z.t0, z.t1, z.dx, B, false, false);
+  bnn_bwd(c, a.theta, a.grad, n, z.k, d, z.ds, z.t0, z.t1, z.dx, B, false, false, nullptr, nullptr, bnn_r32_stage);
   for (int i = c.tid; i < B * in; i += BNN_THREADS) {
     const int b = i / in, j = i - b * in;
     int col = -1;
