@@ -466,7 +466,10 @@ extern "C" int bgm_bnn_z_step(bgm_handle *h, const float *x, const float *y, con
     a.ws = s->ws_dev + 3 * s->ws_stride;      // (its own slices: the theta step of the next minibatch may be running beside it)
     if (a.wide) {      // the two noise calls of a net on workgroups of their own, forward and backward as two launches
       hipLaunchKernelGGL(bnn_step_noise_kernel, dim3(BNN_NOISE_PARTS, 3, 2), dim3(BNN_THREADS), 0, stream, a, 6, 1);
-      hipLaunchKernelGGL(bnn_z_fwd_kernel, dim3(6), dim3(BNN_THREADS), 0, stream, a);
+      static const bool lds_ok_f = hipFuncSetAttribute(reinterpret_cast<const void *>(bnn_z_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       (int)BNN_R32_LDS_BYTES) == hipSuccess;
+      (void)lds_ok_f;
+      hipLaunchKernelGGL(bnn_z_fwd_kernel, dim3(6), dim3(BNN_THREADS), BNN_R32_LDS_BYTES, stream, a);
       static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(bnn_z_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                      (int)BNN_R32_LDS_BYTES) == hipSuccess;
       (void)lds_ok;

@@ -418,7 +418,10 @@ __device__ __forceinline__ void bnn_bn_move(const BnnCtx &c, float *theta, const
 }
 
 // forward of the Flipout stack (after bnn_noise + barrier + bnn_bn_fwd + barrier)
-__device__ __forceinline__ void bnn_layers_fwd(const BnnCtx &c, const float *theta, const BnnNet &n, const BnnCache &k, int B) {
+// stage, locT, dWT (nets without heads, up to 32 rows): the LDS stage of bnn_gemm2_rows32 and the call's weights TRANSPOSED -- posterior means
+// and perturbation, layer l at eoff[l] as [out][in] (bnn_step_noise_kernel writes both) -- so that both operands of the forward products run along K
+__device__ __forceinline__ void bnn_layers_fwd(const BnnCtx &c, const float *theta, const BnnNet &n, const BnnCache &k, int B, float *stage = nullptr,
+                                               const float *locT = nullptr, const float *dWT = nullptr) {
   const int L = n.n_layers;
   for (int l = 0; l < L; ++l) {
     const int in = n.lin[l], out = n.lout[l];
@@ -429,6 +432,23 @@ __device__ __forceinline__ void bnn_layers_fwd(const BnnCtx &c, const float *the
     const bool feeds_heads = n.heads && l == L - 3;
     float *ys2 = k.HS + (long long)B * n.hsin[L - 1];
     const int so = n.sout_w[l], si = last ? 0 : n.sin_w[l + 1], si2 = n.sin_w[L - 1];
+    if (stage && locT && !n.heads && B <= 32) {
+      struct Rw { uint32_t so, si; };
+      bnn_gemm2_rows32(c.tid, stage, h, hs, in, locT + n.eoff[l], dWT + n.eoff[l], in, B, out, in,
+                       [&](int m, int n0) {
+                         const uint32_t *sg = k.sg + (long long)m * n.swords + (n0 >> 5);
+                         Rw w; w.so = sg[so]; w.si = last ? 0u : sg[si];
+                         return w;
+                       },
+                       [&](int, int o) { return bias[o]; },
+                       [&](int m, int o, float c1, float c2, const Rw &w, float bo, int bit) {
+                         float v = c1 + bo + (((w.so >> bit) & 1u) ? -c2 : c2);
+                         if (!last) v = fmaxf(v, BNN_LEAK * v);
+                         y[(long long)m * out + o] = v;
+                         if (!last) ys[(long long)m * out + o] = ((w.si >> bit) & 1u) ? -v : v;
+                       });
+      continue;      // (bnn_gemm2_rows32 ends with a barrier)
+    }
     bnn_gemm2(c.tid, BnnMat{h, in, 1}, BnnMat{hs, in, 1}, BnnMat{loc, out, 1}, BnnMat{k.dW + n.eoff[l], out, 1}, B, out, in,
               c.tid >> 6, BNN_THREADS / 64, [&](int m, int o, float c1, float c2) {
                 float v = c1 + bias[o] + bnn_sign(k.sg, n.swords, m, so, o) * c2;
@@ -442,12 +462,13 @@ __device__ __forceinline__ void bnn_layers_fwd(const BnnCtx &c, const float *the
 }
 
 __device__ __forceinline__ float *bnn_fwd(const BnnCtx &c, const float *theta, const BnnNet &n, const BnnCache &k, int B,
-                                          uint32_t k0, uint32_t k1, uint32_t stream, uint32_t row0 = 0u, bool signs_only = false) {
+                                          uint32_t k0, uint32_t k1, uint32_t stream, uint32_t row0 = 0u, bool signs_only = false, float *stage = nullptr,
+                                          const float *locT = nullptr, const float *dWT = nullptr) {
   bnn_noise(c, theta, n, k, B, k0, k1, stream, row0, signs_only);
   __syncthreads();
   bnn_bn_fwd(c, theta, n, k, B);
   __syncthreads();
-  bnn_layers_fwd(c, theta, n, k, B);
+  bnn_layers_fwd(c, theta, n, k, B, stage, locT, dWT);
   return k.H + (long long)B * n.hoff[n.heads ? n.n_layers - 1 : n.n_layers];     // heads: mean [B x p], then var-raw [B x p]
 }
 
@@ -762,10 +783,12 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_step_kernel(BnnA
     BnnCache k;
     bnn_cache(n, B, wp, k, id == BNN_G ? bt.zb : (id == BNN_H ? bt.hin : bt.fin));
     float *G = nullptr, *GS = nullptr;
+    const float *locT = nullptr, *dWT = nullptr;
     if (a.wide && !n.heads) {      // the upstream gradients of all layers stay (in the second call cache of the slice) for bnn_dw_kernel
       BnnCache k2;
       bnn_cache(n, B, wp, k2, nullptr);
       G = k2.H; GS = k2.HS;
+      locT = k2.eps; dWT = k2.dW;      // (and its noise arrays hold the transposed weights of the call: bnn_step_noise_kernel)
       d = G + (long long)B * n.hoff[n.n_layers]; ds = GS + (long long)B * n.hoff[n.n_layers];
     }
     bnn_noise(c, a.theta, n, k, B, a.k0, a.k1, a.stream, 0u, a.wide != 0);      // (the steps of bnn_fwd)
@@ -773,7 +796,7 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_theta_step_kernel(BnnA
     BNN_T(1);
     bnn_bn_fwd(c, a.theta, n, k, B);
     __syncthreads();
-    bnn_layers_fwd(c, a.theta, n, k, B);
+    bnn_layers_fwd(c, a.theta, n, k, B, a.wide ? bnn_r32_stage : nullptr, locT, dWT);
     const float *o = k.H + (long long)B * n.hoff[n.heads ? n.n_layers - 1 : n.n_layers];
     BNN_T(2);
     const int wo = n.dims[n.n_layers];
@@ -932,7 +955,7 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_z_grad_kernel(BnnArgs 
 // call (eps / dW from bnn_step_noise_kernel); bnn_z_bwd_kernel: the call's upstream gradient (call 0: the mean, with the other call's
 // variance output; call 1: the variance head, with call 0's residuals recomputed) and its backward; the input gradients land in
 // dz_part [6][B x q] and bnn_z_combine6_kernel adds them up as bnn_z_grad_kernel does: the same sums in the same order.
-struct BnnZSlice { BnnBatch bt; float *d, *ds, *t0, *t1, *dx; BnnCache k; const float *o; };
+struct BnnZSlice { BnnBatch bt; float *d, *ds, *t0, *t1, *dx; BnnCache k; const float *o; const float *locT, *dWT; };
 __device__ __forceinline__ void bnn_z_slice(const BnnArgs &a, const BnnNet &n, int id, int slice, BnnZSlice &z) {
   float *wp = a.ws + (long long)slice * a.ws_stride;
   auto take = [&](int cnt) { float *r = wp; wp += (cnt + 3) & ~3; return r; };
@@ -941,8 +964,12 @@ __device__ __forceinline__ void bnn_z_slice(const BnnArgs &a, const BnnNet &n, i
   z.dx = take(a.B * a.wmax); take(a.B * a.wmax);
   bnn_cache(n, a.B, wp, z.k, id == BNN_G ? z.bt.zb : (id == BNN_H ? z.bt.hin : z.bt.fin));
   z.o = z.k.H + (long long)a.B * n.hoff[n.heads ? n.n_layers - 1 : n.n_layers];
+  BnnCache k2;      // the slice's second cache: its noise arrays hold the call's transposed weights (bnn_step_noise_kernel)
+  bnn_cache(n, a.B, wp, k2, nullptr);
+  z.locT = k2.eps; z.dWT = k2.dW;
 }
 static __global__ __launch_bounds__(BNN_THREADS) void bnn_z_fwd_kernel(BnnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float bnn_r32_stage[];      // BNN_R32_LDS_BYTES
   __shared__ float red[32];
   BnnCtx c{(int)threadIdx.x, red};
   const int which = blockIdx.x >> 1, call = blockIdx.x & 1;
@@ -954,7 +981,7 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_z_fwd_kernel(BnnArgs a
   bnn_gather(c, a, wp, bt);
   BnnZSlice z;
   bnn_z_slice(a, n, id, blockIdx.x, z);
-  bnn_fwd(c, a.theta, n, z.k, a.B, a.k0, a.k1, a.stream + (uint32_t)call, 0u, true);
+  bnn_fwd(c, a.theta, n, z.k, a.B, a.k0, a.k1, a.stream + (uint32_t)call, 0u, true, bnn_r32_stage, n.heads ? nullptr : z.locT, z.dWT);
 }
 static __global__ __launch_bounds__(BNN_THREADS) void bnn_z_bwd_kernel(BnnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float bnn_r32_stage[];      // BNN_R32_LDS_BYTES
@@ -1068,20 +1095,26 @@ static __global__ __launch_bounds__(BNN_THREADS) void bnn_step_noise_kernel(BnnA
   BnnBatch bt;
   bnn_gather_ptrs(a, wp, bt);
   wp += (long long)n_scratch * ((a.B * a.wmax + 3) & ~3);
-  BnnCache k;
+  BnnCache k, k2;
   bnn_cache(n, a.B, wp, k, nullptr);
   if (call == 1 && !split) bnn_cache(n, a.B, wp, k, nullptr);
+  bnn_cache(n, a.B, wp, k2, nullptr);      // the cache behind the call's: its noise arrays take the call's weights transposed ([out][in] per layer:
+  const bool tr = !n.heads;                //   posterior means -> k2.eps, dW -> k2.dW) for the forward products of bnn_gemm2_rows32
   const uint32_t stream = a.stream + (uint32_t)call;
   for (int l = 0; l < n.n_layers; ++l) {
-    const int cnt = n.lin[l] * n.lout[l];
-    const float *rho = a.theta + n.woff[l] + cnt;
-    float *e = k.eps + n.eoff[l], *d = k.dW + n.eoff[l];
+    const int in = n.lin[l], out = n.lout[l], cnt = in * out;
+    const float *loc = a.theta + n.woff[l], *rho = loc + cnt;
+    float *e = k.eps + n.eoff[l], *d = k.dW + n.eoff[l], *lt = k2.eps + n.eoff[l], *dt = k2.dW + n.eoff[l];
     for (int i = blockIdx.x * BNN_THREADS + threadIdx.x; i < (cnt + 3) >> 2; i += gridDim.x * BNN_THREADS) {
       const f32x4 z = box_muller4(philox4x32_10((uint32_t)i, (uint32_t)l | ((uint32_t)n.net_id << 16), stream, BNN_TAG_EPS, a.k0, a.k1));
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int idx = 4 * i + u;
-        if (idx < cnt) { e[idx] = z[u]; d[idx] = (BNN_SCALE_EPS + softplus_acc(rho[idx])) * z[u]; }
+        if (idx < cnt) {
+          const float dw = (BNN_SCALE_EPS + softplus_acc(rho[idx])) * z[u];
+          e[idx] = z[u]; d[idx] = dw;
+          if (tr) { const int ki = idx / out, no = idx - ki * out; lt[no * in + ki] = loc[idx]; dt[no * in + ki] = dw; }
+        }
       }
     }
   }
